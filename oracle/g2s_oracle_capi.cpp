@@ -1,0 +1,121 @@
+// oracle/g2s_oracle_capi.cpp — extern "C" face of the CPU oracle for ctypes.
+// TEST INFRASTRUCTURE ONLY (see g2s_oracle.hpp).  Parity unpinned by the reference.
+#include <cstdlib>
+#include <cstring>
+#include <sstream>
+
+#include "g2s_oracle.hpp"
+
+using namespace orc;
+
+extern "C" {
+
+struct orc_info {
+  uint64_t sub[6];      // vertices, edges, nontrivial, size_nontrivial, vertices_final, edges_final
+  uint64_t ctr[6];      // xA sA xB sB xD sD
+  int32_t phaseC_count, n_lengths, lengths[2], reached_fuz, draws, q7, backtrace_failed, mem_exceeded;
+};
+
+struct orc_params {
+  int32_t k, solid, d_err, max_fuz;
+  double max_mem_gb;
+  int32_t skip_confident, unique_paths, all_paths, randseed, nb_cores;
+};
+
+struct orc_summary {
+  int32_t gaps, filled, q7_gaps, pad;
+  uint64_t ctr[6];
+  double fill_seconds;
+};
+
+static std::vector<std::string> split_csv(const char* s) {
+  std::vector<std::string> v;
+  std::stringstream ss(s);
+  std::string f;
+  while (std::getline(ss, f, ',')) v.push_back(f);
+  return v;
+}
+
+void* orc_graph_from_files(const char* reads_csv, int k, int solid) {
+  return graph_from_files(split_csv(reads_csv), k, solid);
+}
+void* orc_graph_from_seqs(const char** seqs, int n, int k, int solid) {
+  std::vector<std::string> v;
+  for (int i = 0; i < n; i++) v.push_back(seqs[i]);
+  return graph_from_seqs(v, k, solid);
+}
+void orc_graph_free(void* g) { graph_free((GraphBase*)g); }
+uint64_t orc_graph_num_kmers(void* g) { return graph_num_kmers((GraphBase*)g); }
+
+void* orc_rng_new(unsigned seed) { GlibcRand* r = new GlibcRand(); r->seed(seed); return r; }
+void orc_rng_free(void* r) { delete (GlibcRand*)r; }
+int orc_rng_next(void* r) { return ((GlibcRand*)r)->next(); }
+
+static void pack_info(const FillInfo& fi, orc_info* o) {
+  o->sub[0] = fi.sub.vertices; o->sub[1] = fi.sub.edges; o->sub[2] = fi.sub.nontrivial_components;
+  o->sub[3] = fi.sub.size_nontrivial_components; o->sub[4] = fi.sub.vertices_final; o->sub[5] = fi.sub.edges_final;
+  o->ctr[0] = fi.ctr.xA; o->ctr[1] = fi.ctr.sA; o->ctr[2] = fi.ctr.xB; o->ctr[3] = fi.ctr.sB;
+  o->ctr[4] = fi.ctr.xD; o->ctr[5] = fi.ctr.sD;
+  o->phaseC_count = fi.phaseC_count; o->n_lengths = fi.n_lengths;
+  o->lengths[0] = fi.lengths[0]; o->lengths[1] = fi.lengths[1];
+  o->reached_fuz = fi.reached_fuz; o->draws = fi.draws; o->q7 = fi.q7;
+  o->backtrace_failed = fi.backtrace_failed; o->mem_exceeded = fi.mem_exceeded;
+}
+
+// One fill_gap call.  `fill` must hold gap_len + k + gap_err + lmf + rmf + 3 bytes (Gap2Seq.cpp:374).
+int orc_fill_gap(void* g, void* rng, const char* left, const char* right, int gap_len, int gap_err, int lmf, int rmf,
+                 long long max_mem, int skip_confident, int all_paths, char* fill, int* left_fuz, int* right_fuz,
+                 orc_info* out) {
+  GraphBase* G = (GraphBase*)g;
+  FillInfo fi;
+  SubgraphStats st;
+  *left_fuz = 0;
+  *right_fuz = 0;
+  int r = fill_gap(G, *(GlibcRand*)rng, left, right, gap_len, graph_k(G), gap_err, lmf, rmf, left_fuz, right_fuz,
+                   max_mem, fill, skip_confident != 0, all_paths != 0, &st, &fi);
+  if (out) pack_info(fi, out);
+  return r;
+}
+
+static Params to_params(const orc_params* p) {
+  Params q;
+  q.k = p->k; q.solid = p->solid; q.d_err = p->d_err; q.max_fuz = p->max_fuz; q.max_mem_gb = p->max_mem_gb;
+  q.skip_confident = p->skip_confident != 0; q.unique_paths = p->unique_paths != 0; q.all_paths = p->all_paths != 0;
+  q.randseed = p->randseed; q.nb_cores = p->nb_cores;
+  return q;
+}
+
+static char* dup_str(const std::string& s) {
+  char* p = (char*)malloc(s.size() + 1);
+  memcpy(p, s.c_str(), s.size() + 1);
+  return p;
+}
+void orc_free_str(char* p) { free(p); }
+
+// Scaffold mode on in-memory FASTA text; returns malloc'ed FASTA and log texts.
+int orc_execute_scaffolds(void* g, const orc_params* p, const char* reads_label, const char* filled_label,
+                          const char* scaffolds_text, char** fasta, char** log, orc_summary* sum) {
+  std::string fa, lg;
+  ExecSummary es;
+  int r = execute_scaffolds((GraphBase*)g, to_params(p), reads_label, filled_label, scaffolds_text, &fa, &lg, &es);
+  if (fasta) *fasta = dup_str(fa);
+  if (log) *log = dup_str(lg);
+  if (sum) {
+    sum->gaps = es.gaps; sum->filled = es.filled; sum->q7_gaps = es.q7_gaps; sum->pad = 0;
+    sum->ctr[0] = es.ctr.xA; sum->ctr[1] = es.ctr.sA; sum->ctr[2] = es.ctr.xB; sum->ctr[3] = es.ctr.sB;
+    sum->ctr[4] = es.ctr.xD; sum->ctr[5] = es.ctr.sD;
+    sum->fill_seconds = es.fill_seconds;
+  }
+  return r;
+}
+
+int orc_execute_single(void* g, const orc_params* p, const char* reads_label, const char* filled_label,
+                       const char* left, const char* right, int length, char** fasta, char** log) {
+  std::string fa, lg;
+  int r = execute_single((GraphBase*)g, to_params(p), reads_label, filled_label, left, right, length, &fa, &lg);
+  if (fasta) *fasta = dup_str(fa);
+  if (log) *log = dup_str(lg);
+  return r;
+}
+
+}  // extern "C"
