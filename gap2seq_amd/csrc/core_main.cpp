@@ -1,0 +1,121 @@
+// gap2seq_amd/csrc/core_main.cpp — `Gap2Seq-core` command line, drop-in for the
+// reference binary's options (/root/reference/src/Gap2Seq.cpp:51-67,75-90 and
+// GATB Tool's -nb-cores/-verbose; main: /root/reference/src/main.cpp:25-35).
+// It accepts exactly the argv the reference wrapper builds
+// (/root/reference/src/Gap2Seq.py:178-188,230-241).  Everything below the option
+// parsing goes through the C ABI in include/g2s.h.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <iostream>
+#include <string>
+
+#include "../../include/g2s.h"
+
+static bool readable(const std::string& path) {
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) return false;
+  fclose(f);
+  return true;
+}
+
+int main(int argc, char** argv) {
+  g2s_run_opts o;
+  o.k = 31; o.solid = 2; o.max_fuz = 10; o.nb_cores = 0; o.max_mem_gb = 20.0;
+  g2s_params p;
+  memset(&p, 0, sizeof p);
+  p.d_err = 500; p.all_paths = 1;
+  int randseed = 0, device = 0;
+  std::string reads, scaffolds, filled, left, right;
+  int length = 0;
+  bool saw_left = false, saw_right = false, saw_len = false;
+  if (const char* e = getenv("G2S_DEVICE")) device = atoi(e);
+  for (int i = 1; i < argc; i++) {
+    const std::string a = argv[i];
+    auto val = [&]() -> const char* { return (i + 1 < argc) ? argv[++i] : ""; };
+    if (a == "-k") o.k = atoi(val());
+    else if (a == "-solid") o.solid = atoi(val());
+    else if (a == "-reads") reads = val();
+    else if (a == "-scaffolds") scaffolds = val();
+    else if (a == "-filled") filled = val();
+    else if (a == "-dist-error") p.d_err = atoi(val());
+    else if (a == "-fuz") o.max_fuz = atoi(val());
+    else if (a == "-max-mem") o.max_mem_gb = atof(val());
+    else if (a == "-all-upper") p.skip_confident = 1;
+    else if (a == "-best-only") p.all_paths = 0;
+    else if (a == "-unique") p.unique_paths = 1;
+    else if (a == "-randseed") randseed = atoi(val());
+    else if (a == "-nb-cores") o.nb_cores = atoi(val());
+    else if (a == "-left") { left = val(); saw_left = true; }
+    else if (a == "-right") { right = val(); saw_right = true; }
+    else if (a == "-length") { length = atoi(val()); saw_len = true; }
+    else if (a == "-verbose") (void)val();
+    else if (a == "-device") device = atoi(val());
+    else if (a == "-help" || a == "-h") {
+      std::cout << "Gap2Seq-core (MI355X) -reads a.fq[,b.fq] -filled out.fa (-scaffolds in.fa | -left S -right S -length N)\n"
+                   "  [-k 31] [-solid 2] [-dist-error 500] [-fuz 10] [-max-mem 20] [-randseed 0]\n"
+                   "  [-all-upper] [-best-only] [-unique] [-nb-cores N] [-device D]\n";
+      return EXIT_SUCCESS;
+    }
+    // unknown options are ignored, never errors
+  }
+  if (reads.empty() || filled.empty()) {
+    std::cout << "EXCEPTION: missing mandatory option (-reads, -filled)" << std::endl;  // main.cpp:29-31
+    return EXIT_FAILURE;
+  }
+  if (o.nb_cores <= 0) o.nb_cores = 1;
+  // GATB's Tool divides -max-mem by the dispatcher's thread count (:302); one GPU stream = one unit here
+  p.max_mem = (int64_t)(o.max_mem_gb * 1024 * 1024 * 1024) / o.nb_cores;
+  p.randseed = randseed > 0 ? (uint32_t)randseed : (uint32_t)time(NULL);  // :178
+  p.host_threads = 0;
+
+  g2s_graph* g = nullptr;
+  const std::string cache = reads + ".g2s";  // the reference reuses "<reads>.h5" (:171,195-197)
+  int rc;
+  if (readable(cache)) {
+    std::cout << "Loading from " << cache << std::endl;
+    rc = g2s_graph_load(cache.c_str(), &g);
+  } else {
+    rc = g2s_graph_build_files(reads.c_str(), o.k, o.solid, 0, &g);
+  }
+  if (rc != G2S_OK) {
+    std::cout << "DBG building failed: " << g2s_last_error() << std::endl;  // :215-218
+    return EXIT_FAILURE;
+  }
+  g2s_session* s = nullptr;
+  rc = g2s_session_create(g, device, &p, &s);
+  if (rc != G2S_OK) {
+    std::cout << "EXCEPTION: " << g2s_last_error() << std::endl;
+    return EXIT_FAILURE;
+  }
+  char *fasta = nullptr, *log = nullptr;
+  if (saw_left && saw_right && saw_len) {
+    rc = g2s_execute_single(s, &o, reads.c_str(), filled.c_str(), left.c_str(), right.c_str(), length, &fasta, &log);
+  } else {
+    FILE* f = fopen(scaffolds.c_str(), "rb");
+    if (!f) { std::cout << "EXCEPTION: cannot open " << scaffolds << std::endl; return EXIT_FAILURE; }
+    std::string text;
+    char buf[1 << 16];
+    size_t got;
+    while ((got = fread(buf, 1, sizeof buf, f)) > 0) text.append(buf, got);
+    fclose(f);
+    int32_t gaps = 0, nfilled = 0;
+    rc = g2s_execute_scaffolds(s, &o, reads.c_str(), filled.c_str(), text.c_str(), &fasta, &log, &gaps, &nfilled);
+  }
+  if (rc != G2S_OK) {
+    std::cout << "EXCEPTION: " << g2s_last_error() << std::endl;
+    return EXIT_FAILURE;
+  }
+  // the parameter echo prints the user's -randseed, not the time-derived one
+  std::cout << log;
+  FILE* out = fopen(filled.c_str(), "wb");
+  if (!out) { std::cout << "EXCEPTION: cannot write " << filled << std::endl; return EXIT_FAILURE; }
+  fputs(fasta, out);
+  fclose(out);
+  g2s_free(fasta);
+  g2s_free(log);
+  g2s_session_destroy(s);
+  g2s_graph_free(g);
+  return EXIT_SUCCESS;
+}

@@ -1,0 +1,66 @@
+// gap2seq_amd/csrc/dbg.hpp — host-side de Bruijn graph: exact solid k-mer set,
+// unitig-ordered node numbering and the 4-slot oriented successor table that is
+// uploaded to HBM.
+//
+// Replaces gatb Graph::create / Graph::load as used at
+// /root/reference/src/Gap2Seq.cpp:193-219 and the neighbour primitives
+// Graph::successors / predecessors / contains / buildNode / toString whose call
+// sites are Gap2Seq.cpp:879,884,924,955,957,995,1000,1043,1084,1086,1114,1199,
+// 1203,1204,1263,1271,1452,1456,1476.  Membership is exact (no Bloom filter).
+#pragma once
+#include <cstdint>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "kmer.hpp"
+
+namespace g2s {
+
+static const uint32_t kInvalidNode = 0xFFFFFFFFu;
+
+struct DeviceGraph {
+  uint32_t* succ = nullptr;  // [2n*4]
+  uint32_t* pred = nullptr;  // [2n*4], only when k is even (palindromic k-mers exist)
+  uint64_t bytes = 0;
+};
+
+struct Graph {
+  int k = 0;
+  bool wide = false;  // 128-bit k-mers (k >= 32)
+  uint64_t n = 0;     // canonical solid k-mers
+  uint64_t n_unitigs = 0;
+  // sorted canonical k-mers; exactly one of the two is used
+  std::vector<uint64_t> kmers64;
+  std::vector<u128> kmers128;
+  std::vector<uint32_t> bucket;   // prefix index over the sorted array
+  int bucket_bits = 0;
+  std::vector<uint32_t> rank2id;  // sorted rank -> node index (unitig order)
+  std::vector<uint32_t> id2rank;
+  // oriented node = 2*index + strand.  succ[v*4 + nt] = oriented successor
+  // obtained by appending nt (A,C,T,G) or kInvalidNode.
+  std::vector<uint32_t> succ;
+  std::vector<uint32_t> pred;     // explicit predecessor table, even k only
+  std::vector<uint8_t> lastnt;    // [2n] code of the last base of the oriented sequence
+  std::map<int, DeviceGraph> dev; // per device copies
+
+  // buildNode + contains
+  uint32_t node_of(const char* s) const;
+  inline uint32_t succ_of(uint32_t v, int nt) const { return succ[(size_t)v * 4 + nt]; }
+  // predecessor i in GATB order (prepend T,G,A,C)
+  inline uint32_t pred_of(uint32_t v, int nt) const {
+    if (!pred.empty()) return pred[(size_t)v * 4 + nt];
+    uint32_t w = succ[(size_t)(v ^ 1u) * 4 + nt];
+    return w == kInvalidNode ? w : (w ^ 1u);
+  }
+  std::string node_string(uint32_t v) const;
+  inline char last_char(uint32_t v) const { return kNtChar[lastnt[v]]; }
+};
+
+// seqs may contain any bytes; k-mers containing N/n are skipped (GATB model).
+Graph* graph_build(const std::vector<std::pair<const char*, uint64_t>>& seqs, int k, int solid, int nthreads,
+                   std::string* err);
+bool graph_save(const Graph& g, const std::string& path, std::string* err);
+Graph* graph_load(const std::string& path, std::string* err);
+
+}  // namespace g2s

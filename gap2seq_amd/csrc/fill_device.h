@@ -1,0 +1,53 @@
+// gap2seq_amd/csrc/fill_device.h — structures shared by the HIP kernels and the
+// host orchestration of the fill path (layout of the per-gap work areas in HBM).
+//
+// The path is /root/reference/src/Gap2Seq.cpp:858-1167 (fill_gap phases A-C);
+// the per-gap quantities below are the locals of that function.
+#pragma once
+#include <stdint.h>
+
+#define G2S_DEV_INVALID 0xFFFFFFFFu
+#define G2S_DEV_EMPTY64 0xFFFFFFFFFFFFFFFFull
+#define G2S_DEV_MAX_PATHS 1073741822u /* Gap2Seq.cpp:38 */
+
+/* GapOut.flags */
+#define G2S_DEV_Q7_A 0x1u        /* both strands of a k-mer in the right set       */
+#define G2S_DEV_Q7_B 0x2u        /* both strands of a k-mer at one DP level        */
+#define G2S_DEV_OVERFLOW_A 0x4u  /* right-set tables too small for this gap        */
+#define G2S_DEV_OVERFLOW_B 0x8u  /* state tables too small for this gap            */
+
+struct GapDev {
+  int32_t g;           // gap_len
+  int32_t e;           // gap_err
+  int32_t lmf, rmf;    // left/right_max_fuz
+  int32_t D;           // left_half + right_half = lmf + rmf + g + e   (:862-863,1029)
+  int32_t right_half;  // rmf + ceil((g+e)/2)                          (:862)
+  int32_t prune_from;  // g/2 + e/2 + lmf                              (:1050)
+  int32_t all_paths;
+  uint32_t flank_off;  // flank_nodes: [left seeds lmf+1][right seeds rmf+1][targets rmf+1]
+  uint32_t rs_mask;    // right-set hash: capacity-1 (u32 slots)
+  uint32_t rlog_cap;   // right BFS visit log capacity
+  uint32_t st_mask;    // state hash: capacity-1
+  uint32_t slog_cap;   // state log capacity (<= (st_mask+1)/2)
+  uint32_t pad0;
+  uint64_t rs_off;     // element offsets into the session arrays
+  uint64_t rlog_off;
+  uint64_t st_off;
+  uint64_t slog_off;
+  uint64_t lvl_off;    // D+2 entries
+};
+
+struct GapOut {
+  uint32_t flags;
+  uint32_t n_right;    // visited oriented nodes in the right set
+  uint32_t x_right;    // expansions done by the right BFS
+  uint32_t n_states;   // states set by the left DP (= S_B)
+  uint32_t x_left;     // expansions done by the left DP (= X_B)
+  int32_t final_d;     // currentD when the DP loop ended (D+1, or the -best-only break level)
+  int32_t c_count;     // phase C count (:1131-1150)
+  int32_t n_len;       // pathLengths.size()
+  int32_t len[2];
+  int32_t reached_j;   // reachedFuz
+  uint32_t pad;
+  uint64_t out_off;    // offset of this gap's packed (node<<32|count) log in out_states
+};

@@ -1,0 +1,390 @@
+// gap2seq_amd/csrc/fill_kernels.hip — HIP kernels (gfx950 / CDNA4) for phases
+// A-C of Gap2Seq-core's fill_gap (/root/reference/src/Gap2Seq.cpp:858-1167).
+//
+// Mapping: one 64-lane wavefront per gap, the depth loop runs inside the kernel
+// (no per-level launches).  A frontier entry is expanded by 4 adjacent lanes,
+// one per nucleotide slot, so the 16-byte successor record of a node is read by
+// one coalesced 4-lane access; duplicate targets inside a level are merged by
+// a per-gap open-addressing table keyed by (oriented node, depth), the new
+// states of a level are compacted into the next frontier with a wave ballot +
+// popcount prefix.  All tables of a gap live in a work area in HBM (they are
+// L2 resident in practice: a C2 gap touches ~100 KB).
+//
+// Integer/bitset work only: no MFMA on this path (HBM/latency bound).
+//
+// Memory-model note (MI355X_MICROARCH.md, "Inter-workgroup visibility"): a work
+// area is only ever touched by the one wave that owns the gap, but it is
+// mutated by L2 atomics, so every re-read of mutated words uses an agent-scope
+// relaxed atomic load (sc1, served by L2) rather than a plain load that could
+// hit a stale line in the CU's vector L1.
+#include <hip/hip_runtime.h>
+
+#include "fill_device.h"
+#include "fill_launch.h"
+
+namespace {
+
+__device__ __forceinline__ uint32_t ld32(const uint32_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint64_t ld64(const uint64_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Everything this wave has stored or issued atomically is complete before any
+// later load is issued.
+__device__ __forceinline__ void wave_mem_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ uint32_t mix64(uint64_t k) {
+  k ^= k >> 33; k *= 0xff51afd7ed558ccdULL; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ULL; k ^= k >> 33;
+  return (uint32_t)k;
+}
+__device__ __forceinline__ uint64_t lanes_below(int lane) { return (1ull << lane) - 1ull; }
+__device__ __forceinline__ uint32_t flip(uint32_t v) { return v == G2S_DEV_INVALID ? v : (v ^ 1u); }
+
+// ---- right set: open addressing over oriented node ids ----------------------
+// 1 = inserted, 0 = already present, 2 = table full
+__device__ int rs_insert(uint32_t* tab, uint32_t mask, uint32_t v) {
+  uint32_t h = mix32(v) & mask;
+  for (uint32_t i = 0; i <= mask; i++) {
+    uint32_t old = atomicCAS(&tab[h], G2S_DEV_INVALID, v);
+    if (old == G2S_DEV_INVALID) return 1;
+    if (old == v) return 0;
+    h = (h + 1) & mask;
+  }
+  return 2;
+}
+template <bool COHERENT>
+__device__ bool rs_contains(const uint32_t* tab, uint32_t mask, uint32_t v) {
+  uint32_t h = mix32(v) & mask;
+  for (uint32_t i = 0; i <= mask; i++) {
+    uint32_t cur = COHERENT ? ld32(&tab[h]) : tab[h];
+    if (cur == v) return true;
+    if (cur == G2S_DEV_INVALID) return false;
+    h = (h + 1) & mask;
+  }
+  return false;
+}
+
+// ---- DP states: open addressing over (node << 32 | depth) ------------------
+__device__ __forceinline__ uint64_t state_key(uint32_t v, int d) { return ((uint64_t)v << 32) | (uint32_t)d; }
+
+__device__ uint32_t st_insert(uint64_t* keys, uint32_t mask, uint64_t key, uint32_t* isnew) {
+  uint32_t h = mix64(key) & mask;
+  for (uint32_t i = 0; i <= mask; i++) {
+    unsigned long long old =
+        atomicCAS((unsigned long long*)&keys[h], (unsigned long long)G2S_DEV_EMPTY64, (unsigned long long)key);
+    if (old == G2S_DEV_EMPTY64) { *isnew = 1; return h; }
+    if (old == key) { *isnew = 0; return h; }
+    h = (h + 1) & mask;
+  }
+  *isnew = 0;
+  return G2S_DEV_INVALID;
+}
+__device__ uint32_t st_find(const uint64_t* keys, uint32_t mask, uint64_t key) {
+  uint32_t h = mix64(key) & mask;
+  for (uint32_t i = 0; i <= mask; i++) {
+    uint64_t cur = ld64(&keys[h]);
+    if (cur == key) return h;
+    if (cur == G2S_DEV_EMPTY64) return G2S_DEV_INVALID;
+    h = (h + 1) & mask;
+  }
+  return G2S_DEV_INVALID;
+}
+
+}  // namespace
+
+// ============================================================================
+// Phase A — right BFS (Gap2Seq.cpp:871-982).
+// The reference re-expands the whole border level by level and keeps per-depth
+// rows, but the only consumer is a k-mer membership test (Gap2Seq.cpp:1050), so
+// a visited-set BFS with the staggered right-flank seeds yields the same set.
+// ============================================================================
+__global__ __launch_bounds__(64) void g2s_right_bfs(const uint32_t* __restrict__ succ,
+                                                     const uint32_t* __restrict__ predtab,
+                                                     const GapDev* __restrict__ gaps,
+                                                     const uint32_t* __restrict__ gap_ids,
+                                                     const uint32_t* __restrict__ flank_nodes, uint32_t* rs_all,
+                                                     uint32_t* rlog_all, GapOut* outs) {
+  const uint32_t gi = __builtin_amdgcn_readfirstlane(gap_ids[blockIdx.x]);
+  const GapDev gd = gaps[gi];
+  const int lane = threadIdx.x;
+  uint32_t* tab = rs_all + gd.rs_off;
+  uint32_t* log = rlog_all + gd.rlog_off;
+  const uint32_t mask = gd.rs_mask, cap = gd.rlog_cap;
+  const uint32_t* rseeds = flank_nodes + gd.flank_off + (uint32_t)(gd.lmf + 1);
+
+  uint32_t nlog = 0, flags = 0, xcount = 0;
+  {
+    const uint32_t s0 = rseeds[0];  // rightmost k-mer of the right flank (:878-899)
+    if (s0 != G2S_DEV_INVALID) {
+      if (lane == 0) { rs_insert(tab, mask, s0); log[0] = s0; }
+      nlog = 1;
+    }
+  }
+  wave_mem_fence();
+  uint32_t bstart = 0, bend = nlog;
+  bool overflow = false;
+  for (int d = 1; d <= gd.right_half && !overflow; d++) {
+    const uint32_t nb = bend - bstart;
+    xcount += nb;
+    for (uint32_t i0 = 0; i0 < nb * 4u; i0 += 64u) {
+      const uint32_t i = i0 + (uint32_t)lane;
+      uint32_t isnew = 0, p = G2S_DEV_INVALID;
+      if (i < nb * 4u) {
+        const uint32_t n = ld32(&log[bstart + (i >> 2)]);
+        const uint32_t nt = i & 3u;
+        if (nt == 0 && rs_contains<true>(tab, mask, n ^ 1u)) flags |= G2S_DEV_Q7_A;
+        // graph.predecessors(n) in GATB order: pred(v)[i] = succ(v^1)[i]^1
+        p = predtab ? predtab[(size_t)n * 4 + nt] : flip(succ[(size_t)(n ^ 1u) * 4 + nt]);
+        if (p != G2S_DEV_INVALID) {
+          const int r = rs_insert(tab, mask, p);
+          isnew = (r == 1);
+          if (r == 2) flags |= G2S_DEV_OVERFLOW_A;
+        }
+      }
+      const uint64_t m = __ballot(isnew);
+      if (isnew) {
+        const uint32_t off = nlog + (uint32_t)__popcll(m & lanes_below(lane));
+        if (off < cap) log[off] = p;
+      }
+      nlog += (uint32_t)__popcll(m);
+      if (nlog > cap) { overflow = true; break; }
+    }
+    wave_mem_fence();
+    bstart = bend;
+    bend = nlog;
+    if (!overflow && d <= gd.rmf) {  // next right-flank seed (:953-976)
+      const uint32_t s = rseeds[d];
+      if (s != G2S_DEV_INVALID) {
+        int r = 0;
+        if (lane == 0) r = rs_insert(tab, mask, s);
+        r = __shfl(r, 0);
+        if (r == 1) {
+          if (nlog < cap) { if (lane == 0) log[nlog] = s; } else overflow = true;
+          nlog++;
+          bend = nlog;
+        }
+        wave_mem_fence();
+      }
+    }
+    if (bend == bstart && d >= gd.rmf) break;  // empty border and no seed left
+  }
+  // lanes carry partial flags
+  for (int o = 32; o > 0; o >>= 1) flags |= __shfl_xor(flags, o);
+  if (overflow) flags |= G2S_DEV_OVERFLOW_A;
+  if (lane == 0) {
+    GapOut* go = &outs[gi];
+    go->flags = flags;
+    go->n_right = nlog;
+    go->x_right = xcount;
+  }
+}
+
+// ============================================================================
+// Phases B + C — left DP with pruning, flank seeds and target check
+// (Gap2Seq.cpp:984-1167).  The frontier kernel.
+// ============================================================================
+__global__ __launch_bounds__(64) void g2s_left_dp(const uint32_t* __restrict__ succ,
+                                                   const GapDev* __restrict__ gaps,
+                                                   const uint32_t* __restrict__ gap_ids,
+                                                   const uint32_t* __restrict__ flank_nodes,
+                                                   const uint32_t* __restrict__ rs_all, uint64_t* st_keys_all,
+                                                   uint32_t* st_cnt_all, uint32_t* slog_all, uint32_t* lvl_all,
+                                                   uint64_t* out_states, unsigned long long* out_counter,
+                                                   GapOut* outs) {
+  const uint32_t gi = __builtin_amdgcn_readfirstlane(gap_ids[blockIdx.x]);
+  const GapDev gd = gaps[gi];
+  const int lane = threadIdx.x;
+  GapOut* go = &outs[gi];
+  uint32_t flags = go->flags;  // phase A flags (uniform)
+  if (flags & G2S_DEV_OVERFLOW_A) return;
+
+  const uint32_t* rs = rs_all + gd.rs_off;
+  const uint32_t rmask = gd.rs_mask;
+  uint64_t* keys = st_keys_all + gd.st_off;
+  uint32_t* cnt = st_cnt_all + gd.st_off;
+  uint32_t* log = slog_all + gd.slog_off;
+  uint32_t* lvl = lvl_all + gd.lvl_off;
+  const uint32_t smask = gd.st_mask, cap = gd.slog_cap;
+  const uint32_t* lseeds = flank_nodes + gd.flank_off;
+  const uint32_t* targets = lseeds + (uint32_t)(gd.lmf + 1) + (uint32_t)(gd.rmf + 1);
+
+  uint32_t nlog = 0, xcount = 0, lflags = 0;
+  {
+    const uint32_t s0 = lseeds[0];  // leftmost k-mer, count 1 at depth 0 (:995-1015)
+    if (s0 != G2S_DEV_INVALID) {
+      if (lane == 0) {
+        uint32_t isnew;
+        const uint32_t pos = st_insert(keys, smask, state_key(s0, 0), &isnew);
+        atomicExch(&cnt[pos], 1u);
+        log[0] = pos;
+      }
+      nlog = 1;
+    }
+  }
+  if (lane == 0) { lvl[0] = 0; lvl[1] = nlog; }
+  wave_mem_fence();
+
+  uint32_t bstart = 0, bend = nlog;
+  bool overflow = false, found = false;
+  int c_count = 0, n_len = 0, len0 = 0, len1 = 0, reached_j = 0;
+  int d = 1;
+  for (; d <= gd.D; d++) {
+    const uint32_t nb = bend - bstart;
+    xcount += nb;
+    const bool unpruned = d < gd.prune_from;  // :1050 first disjunct
+    for (uint32_t i0 = 0; i0 < nb * 4u; i0 += 64u) {
+      const uint32_t i = i0 + (uint32_t)lane;
+      uint32_t isnew = 0, pos2 = G2S_DEV_INVALID;
+      if (i < nb * 4u) {
+        const uint32_t pos = ld32(&log[bstart + (i >> 2)]);
+        const uint32_t n = (uint32_t)(ld64(&keys[pos]) >> 32);
+        const uint32_t nt = i & 3u;
+        uint32_t np = ld32(&cnt[pos]);  // num_paths of the parent, saturated (:1047)
+        if (np > G2S_DEV_MAX_PATHS) np = G2S_DEV_MAX_PATHS;
+        if (nt == 0 && st_find(keys, smask, state_key(n ^ 1u, d - 1)) != G2S_DEV_INVALID) lflags |= G2S_DEV_Q7_B;
+        const uint32_t v = succ[(size_t)n * 4 + nt];  // graph.successors(n), GATB order
+        if (v != G2S_DEV_INVALID &&
+            (unpruned || rs_contains<false>(rs, rmask, v) || rs_contains<false>(rs, rmask, v ^ 1u))) {
+          pos2 = st_insert(keys, smask, state_key(v, d), &isnew);
+          // <= 4 predecessors, each <= MAX_PATHS < 2^30: the u32 sum cannot wrap;
+          // min(MAX, .) on read equals the reference's saturating adds (:1058-1060)
+          if (pos2 != G2S_DEV_INVALID) atomicAdd(&cnt[pos2], np); else lflags |= G2S_DEV_OVERFLOW_B;
+        }
+      }
+      const uint64_t m = __ballot(isnew);
+      if (isnew) {
+        const uint32_t off = nlog + (uint32_t)__popcll(m & lanes_below(lane));
+        if (off < cap) log[off] = pos2;
+      }
+      nlog += (uint32_t)__popcll(m);
+      if (nlog > cap) { overflow = true; break; }
+    }
+    if (overflow) break;
+    wave_mem_fence();
+    bstart = bend;
+    bend = nlog;
+    if (d <= gd.lmf) {  // next left-flank seed, row value ASSIGNED 1 (:1082-1105)
+      const uint32_t s = lseeds[d];
+      if (s != G2S_DEV_INVALID) {
+        uint32_t isnew = 0, pos = G2S_DEV_INVALID;
+        if (lane == 0) {
+          pos = st_insert(keys, smask, state_key(s, d), &isnew);
+          if (pos != G2S_DEV_INVALID) atomicExch(&cnt[pos], 1u);
+        }
+        isnew = __shfl(isnew, 0);
+        pos = __shfl(pos, 0);
+        if (pos == G2S_DEV_INVALID) { overflow = true; break; }
+        if (isnew) {
+          if (nlog >= cap) { overflow = true; break; }
+          if (lane == 0) log[nlog] = pos;
+          nlog++;
+          bend = nlog;
+        }
+        wave_mem_fence();
+      }
+    }
+    if (lane == 0) lvl[d + 1] = nlog;
+
+    // ---- phase C: target check (:1107-1159) --------------------------------
+    if (!found && d >= gd.g + gd.lmf + gd.rmf) {
+      const int err = d - gd.g - (gd.lmf + gd.rmf);
+      for (int jbase = 0; jbase <= gd.rmf && !found; jbase += 32) {
+        const int j = jbase + (lane >> 1);
+        const int which = lane & 1;
+        const int L = which == 0 ? gd.g + gd.lmf + j + err : gd.g + gd.lmf + j - err;
+        uint32_t c = 0;
+        if (j <= gd.rmf && (which == 0 || (err != 0 && L >= 0))) {
+          const uint32_t t = targets[j];
+          if (t != G2S_DEV_INVALID) {
+            const uint32_t pos = st_find(keys, smask, state_key(t, L));
+            if (pos != G2S_DEV_INVALID) {
+              c = ld32(&cnt[pos]);
+              if (c > G2S_DEV_MAX_PATHS) c = G2S_DEV_MAX_PATHS;
+            }
+          }
+        }
+        const uint64_t hits = __ballot(c > 0);
+        if (hits) {
+          const int first = __builtin_ctzll(hits) >> 1;  // lowest j with a hit
+          const uint32_t c1 = __shfl(c, first * 2), c2 = __shfl(c, first * 2 + 1);
+          const uint32_t sum = c1 + c2;
+          c_count = (int)(sum > G2S_DEV_MAX_PATHS ? G2S_DEV_MAX_PATHS : sum);
+          reached_j = jbase + first;
+          const int l1 = gd.g + gd.lmf + reached_j + err, l2 = gd.g + gd.lmf + reached_j - err;
+          if (c1 > 0) { len0 = l1; n_len = 1; if (c2 > 0) { len1 = l2; n_len = 2; } }
+          else { len0 = l2; n_len = 1; }
+          found = true;
+        }
+      }
+      if (found && !gd.all_paths) break;  // -best-only (:1156-1158)
+    }
+  }
+  const int final_d = d;  // currentD when the reference's while loop ends (D+1 unless -best-only broke out)
+  int last_level = d > gd.D ? gd.D : d;
+  if (overflow) { lflags |= G2S_DEV_OVERFLOW_B; last_level = d - 1; }
+  for (int o = 32; o > 0; o >>= 1) lflags |= __shfl_xor(lflags, o);
+  flags |= lflags;
+  if (flags & G2S_DEV_OVERFLOW_B) {
+    if (lane == 0) { go->flags = flags; go->n_states = nlog; go->x_left = xcount; go->final_d = final_d; }
+    return;
+  }
+  // levels that were never reached (-best-only break) are empty
+  for (int dd = last_level + 2 + lane; dd <= gd.D + 1; dd += 64) lvl[dd] = nlog;
+
+  // ---- pack this gap's state log: (node << 32 | count) in log order ---------
+  unsigned long long base = 0;
+  if (lane == 0) base = atomicAdd(out_counter, (unsigned long long)nlog);
+  base = __shfl(base, 0);
+  for (uint32_t i = (uint32_t)lane; i < nlog; i += 64u) {
+    const uint32_t pos = ld32(&log[i]);
+    uint32_t c = ld32(&cnt[pos]);
+    if (c > G2S_DEV_MAX_PATHS) c = G2S_DEV_MAX_PATHS;
+    out_states[base + i] = (ld64(&keys[pos]) & 0xFFFFFFFF00000000ull) | (uint64_t)c;
+  }
+  if (lane == 0) {
+    go->flags = flags;
+    go->n_states = nlog;
+    go->x_left = xcount;
+    go->final_d = final_d;
+    go->c_count = c_count;
+    go->n_len = n_len;
+    go->len[0] = len0;
+    go->len[1] = len1;
+    go->reached_j = reached_j;
+    go->out_off = base;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// launchers (host)
+// ---------------------------------------------------------------------------
+namespace g2s {
+
+hipError_t launch_right_bfs(hipStream_t st, uint32_t ngaps, const uint32_t* succ, const uint32_t* predtab,
+                            const GapDev* gaps, const uint32_t* gap_ids, const uint32_t* flank_nodes, uint32_t* rs_all,
+                            uint32_t* rlog_all, GapOut* outs) {
+  if (ngaps == 0) return hipSuccess;
+  hipLaunchKernelGGL(g2s_right_bfs, dim3(ngaps), dim3(64), 0, st, succ, predtab, gaps, gap_ids, flank_nodes, rs_all,
+                     rlog_all, outs);
+  return hipGetLastError();
+}
+
+hipError_t launch_left_dp(hipStream_t st, uint32_t ngaps, const uint32_t* succ, const GapDev* gaps,
+                          const uint32_t* gap_ids, const uint32_t* flank_nodes, const uint32_t* rs_all,
+                          uint64_t* st_keys_all, uint32_t* st_cnt_all, uint32_t* slog_all, uint32_t* lvl_all,
+                          uint64_t* out_states, unsigned long long* out_counter, GapOut* outs) {
+  if (ngaps == 0) return hipSuccess;
+  hipLaunchKernelGGL(g2s_left_dp, dim3(ngaps), dim3(64), 0, st, succ, gaps, gap_ids, flank_nodes, rs_all, st_keys_all,
+                     st_cnt_all, slog_all, lvl_all, out_states, out_counter, outs);
+  return hipGetLastError();
+}
+
+}  // namespace g2s

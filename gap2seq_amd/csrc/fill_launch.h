@@ -1,0 +1,20 @@
+// gap2seq_amd/csrc/fill_launch.h — host-callable launchers of the HIP kernels
+// in fill_kernels.hip (phases A-C of /root/reference/src/Gap2Seq.cpp:858-1167).
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+#include "fill_device.h"
+
+namespace g2s {
+
+hipError_t launch_right_bfs(hipStream_t st, uint32_t ngaps, const uint32_t* succ, const uint32_t* predtab,
+                            const GapDev* gaps, const uint32_t* gap_ids, const uint32_t* flank_nodes, uint32_t* rs_all,
+                            uint32_t* rlog_all, GapOut* outs);
+
+hipError_t launch_left_dp(hipStream_t st, uint32_t ngaps, const uint32_t* succ, const GapDev* gaps,
+                          const uint32_t* gap_ids, const uint32_t* flank_nodes, const uint32_t* rs_all,
+                          uint64_t* st_keys_all, uint32_t* st_cnt_all, uint32_t* slog_all, uint32_t* lvl_all,
+                          uint64_t* out_states, unsigned long long* out_counter, GapOut* outs);
+
+}  // namespace g2s

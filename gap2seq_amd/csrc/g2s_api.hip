@@ -1,0 +1,679 @@
+// gap2seq_amd/csrc/g2s_api.hip — implementation of the C ABI in include/g2s.h:
+// graph handles, sessions, batches, and the orchestration of the fill path
+// (kernels on one HIP stream -> device-to-host of the state logs -> host phase D).
+//
+// Replaces the call edge Gap2Seq::execute() -> Gap2Seq::fill_gap()
+// (/root/reference/src/Gap2Seq.cpp:252,380 -> :858).  No CPU fallback: without a
+// usable gfx950 device every fill entry point fails with G2S_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/g2s.h"
+#include "dbg.hpp"
+#include "fastx.hpp"
+#include "fill_device.h"
+#include "fill_launch.h"
+#include "glibc_rand.hpp"
+#include "post.hpp"
+
+using namespace g2s;
+
+// ---------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------
+static thread_local std::string tl_error;
+static int fail(int code, const std::string& msg) { tl_error = msg; return code; }
+#define HIP_TRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess)                                                                     \
+      return fail(G2S_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));            \
+  } while (0)
+
+extern "C" int g2s_abi_version(void) { return G2S_ABI_VERSION; }
+extern "C" const char* g2s_last_error(void) { return tl_error.c_str(); }
+extern "C" void g2s_free(void* p) { free(p); }
+
+extern "C" int g2s_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  int ok = 0;
+  for (int d = 0; d < n; d++) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, d) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) == 0) ok++;
+  }
+  return ok;
+}
+
+// ---------------------------------------------------------------------------
+// graph
+// ---------------------------------------------------------------------------
+struct g2s_graph {
+  Graph* g = nullptr;
+};
+
+extern "C" int g2s_graph_build_seqs(const char* const* seqs, const uint64_t* lens, int nseqs, int k, int solid,
+                                    int nthreads, g2s_graph** out) {
+  if (!seqs || !out || nseqs < 0) return fail(G2S_ERR_ARG, "g2s_graph_build_seqs: bad argument");
+  std::vector<std::pair<const char*, uint64_t>> v;
+  for (int i = 0; i < nseqs; i++) v.emplace_back(seqs[i], lens ? lens[i] : (uint64_t)strlen(seqs[i]));
+  std::string err;
+  Graph* g = graph_build(v, k, solid, nthreads, &err);
+  if (!g) return fail(G2S_ERR_ARG, err);
+  *out = new g2s_graph();
+  (*out)->g = g;
+  return G2S_OK;
+}
+
+extern "C" int g2s_graph_build_files(const char* reads_csv, int k, int solid, int nthreads, g2s_graph** out) {
+  if (!reads_csv || !out) return fail(G2S_ERR_ARG, "g2s_graph_build_files: bad argument");
+  std::vector<FastxRecord> recs;
+  std::string csv(reads_csv);
+  size_t pos = 0;
+  while (pos <= csv.size()) {  // comma separated list (Gap2Seq.cpp:199-210)
+    size_t e = csv.find(',', pos);
+    if (e == std::string::npos) e = csv.size();
+    std::string file = csv.substr(pos, e - pos);
+    pos = e + 1;
+    if (file.empty()) continue;
+    std::string text;
+    if (!read_text_file(file, &text)) return fail(G2S_ERR_IO, "cannot read " + file);
+    parse_fastx(text, &recs);
+  }
+  std::vector<std::pair<const char*, uint64_t>> v;
+  for (auto& r : recs) v.emplace_back(r.seq.data(), (uint64_t)r.seq.size());
+  std::string err;
+  Graph* g = graph_build(v, k, solid, nthreads, &err);
+  if (!g) return fail(G2S_ERR_ARG, err);
+  *out = new g2s_graph();
+  (*out)->g = g;
+  return G2S_OK;
+}
+
+extern "C" int g2s_graph_save(const g2s_graph* g, const char* path) {
+  std::string err;
+  if (!g || !path) return fail(G2S_ERR_ARG, "g2s_graph_save: bad argument");
+  return graph_save(*g->g, path, &err) ? G2S_OK : fail(G2S_ERR_IO, err);
+}
+extern "C" int g2s_graph_load(const char* path, g2s_graph** out) {
+  std::string err;
+  if (!path || !out) return fail(G2S_ERR_ARG, "g2s_graph_load: bad argument");
+  Graph* g = graph_load(path, &err);
+  if (!g) return fail(G2S_ERR_IO, err);
+  *out = new g2s_graph();
+  (*out)->g = g;
+  return G2S_OK;
+}
+extern "C" void g2s_graph_free(g2s_graph* g) {
+  if (!g) return;
+  if (g->g) {
+    for (auto& kv : g->g->dev) {
+      if (hipSetDevice(kv.first) == hipSuccess) {
+        if (kv.second.succ) (void)hipFree(kv.second.succ);
+        if (kv.second.pred) (void)hipFree(kv.second.pred);
+      }
+    }
+    delete g->g;
+  }
+  delete g;
+}
+extern "C" int g2s_graph_k(const g2s_graph* g) { return g ? g->g->k : 0; }
+extern "C" uint64_t g2s_graph_num_kmers(const g2s_graph* g) { return g ? g->g->n : 0; }
+extern "C" uint64_t g2s_graph_num_unitigs(const g2s_graph* g) { return g ? g->g->n_unitigs : 0; }
+extern "C" uint32_t g2s_graph_node(const g2s_graph* g, const char* kmer) {
+  if (!g || !kmer || (int)strnlen(kmer, (size_t)g->g->k) < g->g->k) return G2S_INVALID_NODE;
+  return g->g->node_of(kmer);
+}
+extern "C" int g2s_graph_successors(const g2s_graph* g, uint32_t node, uint32_t out[4]) {
+  if (!g || (uint64_t)node >= 2 * g->g->n) return 0;
+  int c = 0;
+  for (int nt = 0; nt < 4; nt++) {
+    uint32_t w = g->g->succ_of(node, nt);
+    if (w != kInvalidNode) out[c++] = w;
+  }
+  return c;
+}
+extern "C" int g2s_graph_predecessors(const g2s_graph* g, uint32_t node, uint32_t out[4]) {
+  if (!g || (uint64_t)node >= 2 * g->g->n) return 0;
+  int c = 0;
+  for (int nt = 0; nt < 4; nt++) {
+    uint32_t w = g->g->pred_of(node, nt);
+    if (w != kInvalidNode) out[c++] = w;
+  }
+  return c;
+}
+extern "C" int g2s_graph_node_string(const g2s_graph* g, uint32_t node, char* out) {
+  if (!g || !out || (uint64_t)node >= 2 * g->g->n) return fail(G2S_ERR_ARG, "g2s_graph_node_string: bad node");
+  std::string s = g->g->node_string(node);
+  memcpy(out, s.c_str(), s.size() + 1);
+  return G2S_OK;
+}
+
+extern "C" int g2s_graph_upload(g2s_graph* gh, int device) {
+  if (!gh) return fail(G2S_ERR_ARG, "g2s_graph_upload: null graph");
+  Graph& g = *gh->g;
+  if (g.dev.count(device)) return G2S_OK;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev)
+    return fail(G2S_ERR_NO_DEVICE, "no HIP device " + std::to_string(device) + " (this library has no CPU fallback)");
+  HIP_TRY(hipSetDevice(device));
+  DeviceGraph dg;
+  const size_t bytes = g.succ.size() * sizeof(uint32_t);
+  HIP_TRY(hipMalloc((void**)&dg.succ, std::max<size_t>(bytes, 16)));
+  HIP_TRY(hipMemcpy(dg.succ, g.succ.data(), bytes, hipMemcpyHostToDevice));
+  dg.bytes = bytes;
+  if (!g.pred.empty()) {
+    HIP_TRY(hipMalloc((void**)&dg.pred, bytes));
+    HIP_TRY(hipMemcpy(dg.pred, g.pred.data(), bytes, hipMemcpyHostToDevice));
+    dg.bytes += bytes;
+  }
+  g.dev[device] = dg;
+  return G2S_OK;
+}
+extern "C" uint64_t g2s_graph_device_bytes(const g2s_graph* g, int device) {
+  if (!g) return 0;
+  auto it = g->g->dev.find(device);
+  return it == g->g->dev.end() ? 0 : it->second.bytes;
+}
+
+// ---------------------------------------------------------------------------
+// session
+// ---------------------------------------------------------------------------
+namespace {
+
+struct DevBuf {  // grow-only device allocation
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+    size_t want = bytes + bytes / 4 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) { e = hipMalloc(&p, bytes); want = bytes; }
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+struct PinBuf {  // grow-only pinned host allocation
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+    size_t want = bytes + bytes / 4 + 256;
+    hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
+inline uint32_t pow2ceil(uint64_t x) {
+  uint64_t p = 1;
+  while (p < x) p <<= 1;
+  return (uint32_t)std::min<uint64_t>(p, 1u << 30);
+}
+
+}  // namespace
+
+struct g2s_session {
+  g2s_graph* graph = nullptr;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  g2s_params params;
+  GlibcRand rng;
+  size_t mem_budget = 0;  // bytes of HBM this session may use for work areas
+  DevBuf d_gaps, d_ids, d_flank, d_outs, d_rs, d_rlog, d_keys, d_cnt, d_slog, d_lvl, d_states, d_counter;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+};
+
+extern "C" int g2s_session_create(g2s_graph* g, int device, const g2s_params* p, g2s_session** out) {
+  if (!g || !p || !out) return fail(G2S_ERR_ARG, "g2s_session_create: bad argument");
+  int rc = g2s_graph_upload(g, device);
+  if (rc != G2S_OK) return rc;
+  HIP_TRY(hipSetDevice(device));
+  g2s_session* s = new g2s_session();
+  s->graph = g;
+  s->device = device;
+  s->params = *p;
+  s->rng.seed(p->randseed);
+  hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
+  for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipEventCreate(&s->ev[i]);
+  size_t free_b = 0, total_b = 0;
+  if (e == hipSuccess) e = hipMemGetInfo(&free_b, &total_b);
+  if (e != hipSuccess) { delete s; return fail(G2S_ERR_HIP, std::string("session setup: ") + hipGetErrorString(e)); }
+  s->mem_budget = (size_t)((double)free_b * 0.6);
+  *out = s;
+  return G2S_OK;
+}
+
+extern "C" void g2s_session_destroy(g2s_session* s) {
+  if (!s) return;
+  (void)hipSetDevice(s->device);
+  DevBuf* bufs[] = {&s->d_gaps, &s->d_ids, &s->d_flank, &s->d_outs, &s->d_rs, &s->d_rlog,
+                    &s->d_keys, &s->d_cnt, &s->d_slog, &s->d_lvl, &s->d_states, &s->d_counter};
+  for (DevBuf* b : bufs) b->release();
+  for (int i = 0; i < 4; i++) if (s->ev[i]) (void)hipEventDestroy(s->ev[i]);
+  if (s->stream) (void)hipStreamDestroy(s->stream);
+  delete s;
+}
+
+extern "C" void g2s_session_srand(g2s_session* s, uint32_t seed) { if (s) s->rng.seed(seed); }
+
+// ---------------------------------------------------------------------------
+// batch
+// ---------------------------------------------------------------------------
+namespace {
+struct TierData {  // what came back from one launch group
+  PinBuf outs, lvl, states;
+  std::vector<uint32_t> gap_ids;
+  std::vector<uint64_t> lvl_off;  // per listed gap, into lvl
+};
+}  // namespace
+
+struct g2s_batch {
+  g2s_session* s = nullptr;
+  std::vector<GapJob> jobs;
+  std::vector<uint32_t> flank_off;
+  size_t arena_bytes = 0;
+  g2s_timing timing;
+  std::vector<TierData*> tiers;
+  ~g2s_batch() {
+    for (TierData* t : tiers) { t->outs.release(); t->lvl.release(); t->states.release(); delete t; }
+  }
+};
+
+extern "C" int g2s_batch_prepare(g2s_session* s, const g2s_gap* gaps, size_t n, g2s_batch** out) {
+  if (!s || (!gaps && n) || !out) return fail(G2S_ERR_ARG, "g2s_batch_prepare: bad argument");
+  const Graph& g = *s->graph->g;
+  const int k = g.k;
+  g2s_batch* b = new g2s_batch();
+  b->s = s;
+  memset(&b->timing, 0, sizeof b->timing);
+  b->jobs.resize(n);
+  b->flank_off.resize(n);
+  std::vector<uint32_t> flank_all;
+  for (size_t i = 0; i < n; i++) {
+    GapJob& j = b->jobs[i];
+    const g2s_gap& in = gaps[i];
+    j.g = in.gap_len;
+    j.lmf = in.lmf;
+    j.rmf = in.rmf;
+    j.skip_if_prev_right_fuz_gt = in.skip_if_prev_right_fuz_gt;
+    // D2: flanks too short would make the reference throw from substr
+    j.bad_flank = !in.left || !in.right || in.lmf < 0 || in.rmf < 0 || in.gap_len < 0 || in.left_len < k + in.lmf ||
+                  in.right_len < k + in.rmf;
+    if (!j.bad_flank) {
+      j.left.assign(in.left, (size_t)in.left_len);
+      j.right.assign(in.right, (size_t)in.right_len);
+      j.flank_nodes.resize((size_t)(j.lmf + 1) + 2 * (size_t)(j.rmf + 1));
+      uint32_t* fn = j.flank_nodes.data();
+      for (int d = 0; d <= j.lmf; d++) *fn++ = g.node_of(j.left.c_str() + d);                       // :995,1083
+      for (int d = 0; d <= j.rmf; d++) *fn++ = g.node_of(j.right.c_str() + (j.right.size() - k - d));  // :878,954
+      for (int d = 0; d <= j.rmf; d++) *fn++ = g.node_of(j.right.c_str() + d);                      // :1113
+      b->timing.flank_bytes += (uint64_t)(j.left.size() + j.right.size());
+    } else {
+      j.lmf = std::max(0, j.lmf);
+      j.rmf = std::max(0, j.rmf);
+      j.g = std::max(0, j.g);
+    }
+    b->flank_off[i] = (uint32_t)flank_all.size();
+    flank_all.insert(flank_all.end(), j.flank_nodes.begin(), j.flank_nodes.end());
+    b->arena_bytes += j.buf_bytes(k, s->params.d_err);
+  }
+  if (hipSetDevice(s->device) != hipSuccess) { delete b; return fail(G2S_ERR_NO_DEVICE, "cannot select device"); }
+  hipError_t e = s->d_flank.ensure(std::max<size_t>(flank_all.size() * 4, 16));
+  if (e == hipSuccess && !flank_all.empty())
+    e = hipMemcpyAsync(s->d_flank.p, flank_all.data(), flank_all.size() * 4, hipMemcpyHostToDevice, s->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+  if (e != hipSuccess) { delete b; return fail(G2S_ERR_HIP, std::string("batch upload: ") + hipGetErrorString(e)); }
+  *out = b;
+  return G2S_OK;
+}
+
+extern "C" size_t g2s_batch_arena_bytes(const g2s_batch* b) { return b ? b->arena_bytes : 0; }
+extern "C" int g2s_batch_timing(const g2s_batch* b, g2s_timing* out) {
+  if (!b || !out) return fail(G2S_ERR_ARG, "g2s_batch_timing: bad argument");
+  *out = b->timing;
+  return G2S_OK;
+}
+extern "C" void g2s_batch_free(g2s_batch* b) { delete b; }
+
+namespace {
+
+struct Plan {  // per-gap capacities at one scale
+  uint32_t rlog_cap, slog_cap;
+  uint64_t bytes;
+};
+
+Plan plan_gap(const GapJob& j, int d_err, uint64_t scale, uint64_t max_states) {
+  const int right_half = j.rmf + (j.g + d_err + 1) / 2;
+  const int D = j.lmf + j.rmf + j.g + d_err;
+  uint64_t r = (uint64_t)pow2ceil(std::max<uint64_t>(256, 2ull * (uint64_t)(right_half + j.rmf + 2))) * scale;
+  uint64_t st = (uint64_t)pow2ceil(std::max<uint64_t>(512, 2ull * (uint64_t)(D + 2))) * scale;
+  const uint64_t lim = std::max<uint64_t>(1024, std::min<uint64_t>(max_states, 1u << 28));
+  uint64_t limp = 1;
+  while (limp * 2 <= lim) limp <<= 1;
+  Plan p;
+  p.rlog_cap = (uint32_t)std::min(r, limp);
+  p.slog_cap = (uint32_t)std::min(st, limp);
+  p.bytes = (uint64_t)p.rlog_cap * (8 + 4) + (uint64_t)p.slog_cap * (2 * 12 + 4 + 8) + (uint64_t)(D + 2) * 4;
+  return p;
+}
+
+// Launch phases A-C for the listed gaps at one table scale and bring the results back.
+int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uint64_t max_states, TierData* td) {
+  g2s_session* s = b->s;
+  const Graph& g = *s->graph->g;
+  const DeviceGraph& dg = s->graph->g->dev.at(s->device);
+  const size_t n = b->jobs.size();
+  const int d_err = s->params.d_err;
+  std::vector<GapDev> gd(n);
+  memset(gd.data(), 0, n * sizeof(GapDev));
+  uint64_t rs_total = 0, rlog_total = 0, st_total = 0, slog_total = 0, lvl_total = 0;
+  td->gap_ids = ids;
+  td->lvl_off.resize(ids.size());
+  for (size_t x = 0; x < ids.size(); x++) {
+    const uint32_t i = ids[x];
+    const GapJob& j = b->jobs[i];
+    const Plan p = plan_gap(j, d_err, scale, max_states);
+    GapDev& d = gd[i];
+    d.g = j.g; d.e = d_err; d.lmf = j.lmf; d.rmf = j.rmf;
+    d.D = j.lmf + j.rmf + j.g + d_err;
+    d.right_half = j.rmf + (j.g + d_err + 1) / 2;
+    d.prune_from = j.g / 2 + d_err / 2 + j.lmf;
+    d.all_paths = s->params.all_paths ? 1 : 0;
+    d.flank_off = b->flank_off[i];
+    d.rlog_cap = p.rlog_cap; d.rs_mask = 2 * p.rlog_cap - 1;
+    d.slog_cap = p.slog_cap; d.st_mask = 2 * p.slog_cap - 1;
+    d.rs_off = rs_total; rs_total += 2ull * p.rlog_cap;
+    d.rlog_off = rlog_total; rlog_total += p.rlog_cap;
+    d.st_off = st_total; st_total += 2ull * p.slog_cap;
+    d.slog_off = slog_total; slog_total += p.slog_cap;
+    d.lvl_off = lvl_total; td->lvl_off[x] = lvl_total; lvl_total += (uint64_t)(d.D + 2);
+  }
+  (void)g;
+  HIP_TRY(s->d_gaps.ensure(n * sizeof(GapDev)));
+  HIP_TRY(s->d_ids.ensure(std::max<size_t>(ids.size() * 4, 16)));
+  HIP_TRY(s->d_outs.ensure(n * sizeof(GapOut)));
+  HIP_TRY(s->d_rs.ensure(rs_total * 4));
+  HIP_TRY(s->d_rlog.ensure(rlog_total * 4));
+  HIP_TRY(s->d_keys.ensure(st_total * 8));
+  HIP_TRY(s->d_cnt.ensure(st_total * 4));
+  HIP_TRY(s->d_slog.ensure(slog_total * 4));
+  HIP_TRY(s->d_lvl.ensure(lvl_total * 4));
+  HIP_TRY(s->d_states.ensure(slog_total * 8));
+  HIP_TRY(s->d_counter.ensure(16));
+  hipStream_t st = s->stream;
+  HIP_TRY(hipMemcpyAsync(s->d_gaps.p, gd.data(), n * sizeof(GapDev), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(s->d_ids.p, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemsetAsync(s->d_outs.p, 0, n * sizeof(GapOut), st));
+  HIP_TRY(hipMemsetAsync(s->d_rs.p, 0xFF, rs_total * 4, st));
+  HIP_TRY(hipMemsetAsync(s->d_keys.p, 0xFF, st_total * 8, st));
+  HIP_TRY(hipMemsetAsync(s->d_cnt.p, 0, st_total * 4, st));
+  HIP_TRY(hipMemsetAsync(s->d_counter.p, 0, 16, st));
+
+  HIP_TRY(hipEventRecord(s->ev[0], st));
+  HIP_TRY(launch_right_bfs(st, (uint32_t)ids.size(), dg.succ, dg.pred, (const GapDev*)s->d_gaps.p,
+                           (const uint32_t*)s->d_ids.p, (const uint32_t*)s->d_flank.p, (uint32_t*)s->d_rs.p,
+                           (uint32_t*)s->d_rlog.p, (GapOut*)s->d_outs.p));
+  HIP_TRY(hipEventRecord(s->ev[1], st));
+  HIP_TRY(launch_left_dp(st, (uint32_t)ids.size(), dg.succ, (const GapDev*)s->d_gaps.p, (const uint32_t*)s->d_ids.p,
+                         (const uint32_t*)s->d_flank.p, (const uint32_t*)s->d_rs.p, (uint64_t*)s->d_keys.p,
+                         (uint32_t*)s->d_cnt.p, (uint32_t*)s->d_slog.p, (uint32_t*)s->d_lvl.p,
+                         (uint64_t*)s->d_states.p, (unsigned long long*)s->d_counter.p, (GapOut*)s->d_outs.p));
+  HIP_TRY(hipEventRecord(s->ev[2], st));
+
+  // device -> host: per-gap results, level offsets, then the packed state logs
+  auto t0 = std::chrono::steady_clock::now();
+  HIP_TRY(td->outs.ensure(n * sizeof(GapOut)));
+  HIP_TRY(td->lvl.ensure(std::max<uint64_t>(lvl_total * 4, 16)));
+  unsigned long long total_states = 0;
+  HIP_TRY(hipMemcpyAsync(td->outs.p, s->d_outs.p, n * sizeof(GapOut), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(td->lvl.p, s->d_lvl.p, lvl_total * 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(&total_states, s->d_counter.p, 8, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(td->states.ensure(std::max<uint64_t>(total_states * 8, 16)));
+  if (total_states)
+    HIP_TRY(hipMemcpyAsync(td->states.p, s->d_states.p, total_states * 8, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  b->timing.ms_d2h += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  float ms = 0;
+  HIP_TRY(hipEventElapsedTime(&ms, s->ev[0], s->ev[1]));
+  b->timing.ms_right_bfs += ms;
+  HIP_TRY(hipEventElapsedTime(&ms, s->ev[1], s->ev[2]));
+  b->timing.ms_left_dp += ms;
+  b->timing.launches_left_dp++;
+  return G2S_OK;
+}
+
+}  // namespace
+
+extern "C" int g2s_batch_run(g2s_batch* b, g2s_result* results, char* arena, size_t arena_cap) {
+  if (!b || !results || (!arena && b->arena_bytes)) return fail(G2S_ERR_ARG, "g2s_batch_run: bad argument");
+  if (arena_cap < b->arena_bytes) return fail(G2S_ERR_ARG, "g2s_batch_run: fill arena too small");
+  g2s_session* s = b->s;
+  if (hipSetDevice(s->device) != hipSuccess) return fail(G2S_ERR_NO_DEVICE, "cannot select device");
+  const Graph& g = *s->graph->g;
+  const size_t n = b->jobs.size();
+  auto t_begin = std::chrono::steady_clock::now();
+  for (TierData* t : b->tiers) { t->outs.release(); t->lvl.release(); t->states.release(); delete t; }
+  b->tiers.clear();
+  g2s_timing keep = b->timing;
+  memset(&b->timing, 0, sizeof b->timing);
+  b->timing.flank_bytes = keep.flank_bytes;
+
+  FillParams fp;
+  fp.k = g.k;
+  fp.d_err = s->params.d_err;
+  fp.skip_confident = s->params.skip_confident != 0;
+  fp.all_paths = s->params.all_paths != 0;
+  fp.unique_paths = s->params.unique_paths != 0;
+  // device-budget analogue of -max-mem: states a gap may hold
+  const uint64_t max_states = (uint64_t)std::max<int64_t>(s->params.max_mem, 1 << 16) / 64;
+
+  memset(results, 0, n * sizeof(g2s_result));
+  memset(arena, 0, b->arena_bytes);
+  std::vector<DpView> views(n);
+  std::vector<char> mem_exceeded(n, 0);
+
+  // ---- GPU: phases A-C, retrying gaps whose tables overflowed with 8x larger ones
+  std::vector<uint32_t> todo;
+  for (size_t i = 0; i < n; i++) if (!b->jobs[i].bad_flank) todo.push_back((uint32_t)i);
+  uint64_t scale = 1;
+  while (!todo.empty()) {
+    // split into groups that fit the session's HBM budget
+    std::vector<uint32_t> next_todo;
+    size_t pos = 0;
+    while (pos < todo.size()) {
+      std::vector<uint32_t> group;
+      uint64_t bytes = 0;
+      while (pos < todo.size()) {
+        const Plan p = plan_gap(b->jobs[todo[pos]], fp.d_err, scale, max_states);
+        if (!group.empty() && bytes + p.bytes > s->mem_budget) break;
+        bytes += p.bytes;
+        group.push_back(todo[pos++]);
+      }
+      TierData* td = new TierData();
+      b->tiers.push_back(td);
+      int rc = run_tier(b, group, scale, max_states, td);
+      if (rc != G2S_OK) return rc;
+      const GapOut* outs = (const GapOut*)td->outs.p;
+      for (size_t x = 0; x < group.size(); x++) {
+        const uint32_t i = group[x];
+        const GapOut& go = outs[i];
+        if (go.flags & (G2S_DEV_OVERFLOW_A | G2S_DEV_OVERFLOW_B)) {
+          const Plan p = plan_gap(b->jobs[i], fp.d_err, scale, max_states);
+          const Plan p8 = plan_gap(b->jobs[i], fp.d_err, scale * 8, max_states);
+          if (p8.bytes > s->mem_budget || (p8.rlog_cap == p.rlog_cap && p8.slog_cap == p.slog_cap))
+            mem_exceeded[i] = 1;  // cannot grow further: -max-mem verdict
+          else
+            next_todo.push_back(i);
+          continue;
+        }
+        DpView& v = views[i];
+        v.out = &go;
+        v.D = b->jobs[i].lmf + b->jobs[i].rmf + b->jobs[i].g + fp.d_err;
+        v.lvl = (const uint32_t*)td->lvl.p + td->lvl_off[x];
+        v.states = (uint64_t*)td->states.p + go.out_off;
+        b->timing.xA += go.x_right; b->timing.sA += go.n_right;
+        b->timing.xB += go.x_left; b->timing.sB += go.n_states;
+      }
+    }
+    b->timing.retried_gaps += (uint32_t)next_todo.size();
+    todo.swap(next_todo);
+    scale *= 8;
+  }
+
+  // ---- host: D1/D2 per gap on a thread pool ---------------------------------
+  auto t_post = std::chrono::steady_clock::now();
+  std::vector<PostPrep> prep(n);
+  {
+    int nth = s->params.host_threads > 0 ? s->params.host_threads : (int)std::thread::hardware_concurrency();
+    nth = std::max(1, std::min<int>(nth, (int)std::max<size_t>(1, n / 8)));
+    std::atomic<size_t> next(0);
+    auto work = [&]() {
+      while (true) {
+        const size_t i = next.fetch_add(1);
+        if (i >= n) break;
+        if (!views[i].out) continue;
+        dp_sort_levels(&views[i]);
+        post_extract(g, fp, b->jobs[i], views[i], &prep[i]);
+      }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nth; t++) th.emplace_back(work);
+    work();
+    for (auto& x : th) x.join();
+  }
+
+  // ---- host: D3 traceback in gap order (one rand() stream) -------------------
+  size_t arena_pos = 0;
+  bool prev_filled = false;
+  int prev_right_fuz = 0;
+  for (size_t i = 0; i < n; i++) {
+    const GapJob& j = b->jobs[i];
+    g2s_result& r = results[i];
+    char* buf = arena + arena_pos;
+    arena_pos += j.buf_bytes(g.k, fp.d_err);
+    r.fill_off = (uint64_t)(buf - arena) + (uint64_t)j.lmf;
+    if (j.skip_if_prev_right_fuz_gt >= 0 && prev_filled && prev_right_fuz > j.skip_if_prev_right_fuz_gt) {
+      r.flags |= G2S_GAP_SKIPPED;
+      prev_filled = false;
+      continue;
+    }
+    if (j.bad_flank) { r.flags |= G2S_GAP_BAD_FLANK; prev_filled = false; continue; }
+    if (mem_exceeded[i]) { r.count = -1; r.flags |= G2S_GAP_MEM_EXCEEDED; prev_filled = false; continue; }
+    const DpView& v = views[i];
+    const PostPrep& pp = prep[i];
+    r.phaseC_count = v.out->c_count;
+    r.n_lengths = v.out->n_len;
+    r.lengths[0] = v.out->len[0];
+    r.lengths[1] = v.out->len[1];
+    if (v.out->flags & (G2S_DEV_Q7_A | G2S_DEV_Q7_B)) r.flags |= G2S_GAP_Q7;
+    r.flags |= pp.flags;
+    r.count = pp.count;
+    b->timing.xD += pp.xD;
+    b->timing.sD += pp.sD;
+    if (pp.phase_d) {
+      post_traceback(g, fp, j, v, pp, s->rng, buf, &r);
+      r.vertices = pp.sub[0]; r.edges = pp.sub[1]; r.nontrivial_components = pp.sub[2];
+      r.size_nontrivial_components = pp.sub[3]; r.vertices_final = pp.sub[4]; r.edges_final = pp.sub[5];
+      r.fill_off = (uint64_t)(buf - arena) + (uint64_t)(j.lmf - r.left_fuz);
+      r.fill_len = (int32_t)strlen(arena + r.fill_off);
+      b->timing.fill_bytes += (uint64_t)r.fill_len;
+    }
+    prev_filled = r.count > 0 && (!fp.unique_paths || r.count == 1);
+    prev_right_fuz = r.right_fuz;
+  }
+  auto t_end = std::chrono::steady_clock::now();
+  b->timing.ms_host_post = std::chrono::duration<double, std::milli>(t_end - t_post).count();
+  b->timing.ms_total = std::chrono::duration<double, std::milli>(t_end - t_begin).count();
+  return G2S_OK;
+}
+
+extern "C" int g2s_fill_batch(g2s_session* s, const g2s_gap* gaps, size_t n, g2s_result* results, char* fill_arena,
+                              size_t arena_cap) {
+  g2s_batch* b = nullptr;
+  int rc = g2s_batch_prepare(s, gaps, n, &b);
+  if (rc != G2S_OK) return rc;
+  rc = g2s_batch_run(b, results, fill_arena, arena_cap);
+  g2s_batch_free(b);
+  return rc;
+}
+
+// accessors used by the host driver (g2s_execute.cpp)
+extern "C" const g2s_graph* g2s_session_graph(const g2s_session* s) { return s ? s->graph : nullptr; }
+extern "C" int g2s_session_get_params(const g2s_session* s, g2s_params* out) {
+  if (!s || !out) return fail(G2S_ERR_ARG, "g2s_session_get_params: bad argument");
+  *out = s->params;
+  return G2S_OK;
+}
+
+// TEST HOOK, see include/g2s.h: host half of phase D on a caller-supplied DP table.
+extern "C" int g2s_test_post_gap(const g2s_graph* gh, const g2s_params* p, const g2s_gap* gap, int32_t n_states,
+                                 const uint32_t* nodes, const int32_t* depths, const uint32_t* counts,
+                                 int32_t c_count, int32_t n_lengths, const int32_t* lengths, int32_t reached_j,
+                                 int32_t final_d, uint32_t seed, uint32_t skip, g2s_result* res, char* buf) {
+  if (!gh || !p || !gap || !res || !buf || n_states < 0) return fail(G2S_ERR_ARG, "g2s_test_post_gap: bad argument");
+  const Graph& g = *gh->g;
+  const int k = g.k;
+  GapJob j;
+  j.g = gap->gap_len; j.lmf = gap->lmf; j.rmf = gap->rmf;
+  if (gap->left_len < k + j.lmf || gap->right_len < k + j.rmf) return fail(G2S_ERR_ARG, "flank too short");
+  j.left.assign(gap->left, (size_t)gap->left_len);
+  j.right.assign(gap->right, (size_t)gap->right_len);
+  for (int d = 0; d <= j.lmf; d++) j.flank_nodes.push_back(g.node_of(j.left.c_str() + d));
+  for (int d = 0; d <= j.rmf; d++) j.flank_nodes.push_back(g.node_of(j.right.c_str() + (j.right.size() - k - d)));
+  for (int d = 0; d <= j.rmf; d++) j.flank_nodes.push_back(g.node_of(j.right.c_str() + d));
+  const int D = j.lmf + j.rmf + j.g + p->d_err;
+  std::vector<uint32_t> lvl((size_t)D + 2, 0);
+  for (int i = 0; i < n_states; i++) if (depths[i] >= 0 && depths[i] <= D) lvl[(size_t)depths[i] + 1]++;
+  for (int d = 0; d <= D; d++) lvl[(size_t)d + 1] += lvl[(size_t)d];
+  std::vector<uint64_t> states((size_t)n_states + 1);
+  {
+    std::vector<uint32_t> pos(lvl.begin(), lvl.end() - 1);
+    for (int i = 0; i < n_states; i++)
+      if (depths[i] >= 0 && depths[i] <= D)
+        states[pos[(size_t)depths[i]]++] = ((uint64_t)nodes[i] << 32) | std::min<uint32_t>(counts[i], G2S_MAX_PATHS);
+  }
+  GapOut go;
+  memset(&go, 0, sizeof go);
+  go.c_count = c_count; go.n_len = n_lengths; go.reached_j = reached_j; go.final_d = final_d;
+  for (int i = 0; i < n_lengths && i < 2; i++) go.len[i] = lengths[i];
+  DpView v;
+  v.out = &go; v.lvl = lvl.data(); v.states = states.data(); v.D = D;
+  dp_sort_levels(&v);
+  FillParams fp;
+  fp.k = k; fp.d_err = p->d_err; fp.skip_confident = p->skip_confident != 0; fp.all_paths = p->all_paths != 0;
+  fp.unique_paths = p->unique_paths != 0;
+  PostPrep prep;
+  post_extract(g, fp, j, v, &prep);
+  memset(res, 0, sizeof *res);
+  memset(buf, 0, j.buf_bytes(k, fp.d_err));
+  res->phaseC_count = c_count;
+  res->count = prep.count;
+  res->flags |= prep.flags;
+  res->fill_off = (uint64_t)j.lmf;
+  if (prep.phase_d) {
+    GlibcRand rng;
+    rng.seed(seed);
+    for (uint32_t i = 0; i < skip; i++) rng.next();
+    post_traceback(g, fp, j, v, prep, rng, buf, res);
+    res->vertices = prep.sub[0]; res->edges = prep.sub[1]; res->nontrivial_components = prep.sub[2];
+    res->size_nontrivial_components = prep.sub[3]; res->vertices_final = prep.sub[4]; res->edges_final = prep.sub[5];
+    res->fill_off = (uint64_t)(j.lmf - res->left_fuz);
+    res->fill_len = (int32_t)strlen(buf + res->fill_off);
+  }
+  return G2S_OK;
+}

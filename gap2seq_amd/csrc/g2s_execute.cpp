@@ -1,0 +1,321 @@
+// gap2seq_amd/csrc/g2s_execute.cpp — host driver around the C ABI that mirrors
+// Gap2Seq::execute() after the graph exists
+// (/root/reference/src/Gap2Seq.cpp:224-438) and print_statistics (:100-156):
+// scaffold scanner, per-gap statistics text, splice, FASTA text.
+//
+// The reference calls fill_gap gap by gap; here the scanner first collects the
+// gaps of ALL records into one batch for the GPU (g2s_fill_batch), then replays
+// the reference's splice logic over the results in input order.  Two couplings
+// between consecutive gaps of one record survive batching and are kept exact:
+//  * `i += right_fuz` after a filled gap (:402,415) can make the next gap
+//    ineligible -> g2s_gap.skip_if_prev_right_fuz_gt;
+//  * when k < max_fuz the next gap's left_max_fuz (:349) can depend on it ->
+//    the batch is cut there and the scan resumes from the exact state.
+// Only this file's callers' view of fill_gap is the C ABI: it proves the ABI is
+// sufficient for the reference's own driver.
+#include <algorithm>
+#include <cctype>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/g2s.h"
+#include "fastx.hpp"
+
+using namespace g2s;
+
+namespace {
+
+char* dup_text(const std::string& s) {
+  char* p = (char*)malloc(s.size() + 1);
+  if (p) memcpy(p, s.c_str(), s.size() + 1);
+  return p;
+}
+
+inline bool is_n(char c) { return c == 'N' || c == 'n'; }
+
+// print_statistics (Gap2Seq.cpp:100-156); `tail` = &buf[left_max_fuz - left_fuz]
+void stats_line(std::ostringstream& os, int filledStart, int gapStart, int gapEnd, int paths, const char* tail, int k,
+                int lmf, int rmf, int left_fuz, int right_fuz, bool skip_confident, bool unique_paths,
+                const g2s_result& r, int gap, const std::string& comment) {
+  if (paths > 0 && (!unique_paths || paths == 1)) {
+    const int filledLen = (int)strlen(tail) - k;
+    if (!skip_confident) {
+      int lower = 0, upper = 0;
+      for (int j = 0; j < filledLen; j++) {
+        if (isupper((unsigned char)tail[j])) upper++; else lower++;
+      }
+      os << "Scaffold: " << comment << " GapStart: " << gapStart << " GapEnd: " << gapEnd << " GapLength: " << gap
+         << " PathsFound: " << paths << " FilledStart: " << filledStart << " FilledEnd: " << filledStart + filledLen
+         << " FilledGapLength: " << filledLen << " LeftMaxFuz: " << lmf << " LeftFuz: " << left_fuz
+         << " RightMaxFuz: " << rmf << " RightFuz: " << right_fuz << " ConfidentBases: " << upper
+         << " TotalBases: " << (upper + lower) << "\n";
+      os << "SubgraphStats: Vertices: " << r.vertices << " Edges: " << r.edges
+         << " NontrivialStrongComponents: " << r.nontrivial_components
+         << " SizeNontrivialStrongComponents: " << r.size_nontrivial_components
+         << " VerticesFinal: " << r.vertices_final << " EdgesFinal: " << r.edges_final << "\n";
+    } else {
+      os << "Scaffold: " << comment << " GapStart: " << gapStart << " GapEnd: " << gapEnd << " GapLength: " << gap
+         << " PathsFound: " << paths << " FilledStart: " << filledStart << " FilledEnd: " << filledStart + filledLen
+         << " FilledGapLength: " << filledLen << " LeftFuz: " << left_fuz << " RightFuz: " << right_fuz << "\n";
+    }
+  } else {
+    os << "Scaffold: " << comment << " GapStart: " << gapStart << " GapEnd: " << gapEnd << " GapLength: " << gap
+       << " PathsFound: 0 FilledStart: 0 FilledEnd: 0 FilledGapLength: 0"
+       << " LeftMaxFuz: " << lmf << " LeftFuz: " << left_fuz << " RightMaxFuz: " << rmf << " RightFuz: " << right_fuz;
+    if (paths == -1) os << " Memory limit exceeded";
+    os << "\n";
+  }
+}
+
+void echo_params(std::ostringstream& os, const g2s_run_opts& o, const g2s_params& p, const char* reads,
+                 const char* filled, long long max_mem) {
+  // Gap2Seq.cpp:180-191
+  os << "k-mer size: " << o.k << "\n";
+  os << "Solidity threshold: " << o.solid << "\n";
+  os << "Reads file: " << (reads ? reads : "") << "\n";
+  os << "Filled scaffolds file: " << (filled ? filled : "") << "\n";
+  os << "Distance error: " << p.d_err << "\n";
+  os << "Max Fuz: " << o.max_fuz << "\n";
+  os << "Max memory: " << max_mem << "\n";
+  os << "Skip confident: " << (p.skip_confident ? 1 : 0) << "\n";
+  os << "Unique: " << (p.unique_paths ? 1 : 0) << "\n";
+  os << "All paths: " << (p.all_paths ? 1 : 0) << "\n";
+  os << "Random seed: " << p.randseed << "\n";
+}
+
+struct GapEvent {
+  size_t rec;
+  size_t istart, iend;  // N-run [istart, iend)
+  int gap, lmf, rmf, kmer_start;
+  bool ok;
+  int job;  // index into the batch or -1
+};
+
+}  // namespace
+
+// Internal accessors implemented in g2s_api.hip
+extern "C" const g2s_graph* g2s_session_graph(const g2s_session* s);
+extern "C" int g2s_session_get_params(const g2s_session* s, g2s_params* out);
+
+extern "C" int g2s_execute_scaffolds(g2s_session* s, const g2s_run_opts* o, const char* reads_label,
+                                     const char* filled_label, const char* scaffolds_text, char** fasta_out,
+                                     char** log_out, int32_t* gaps_out, int32_t* filled_out) {
+  if (!s || !o || !scaffolds_text) return G2S_ERR_ARG;
+  g2s_params p;
+  g2s_session_get_params(s, &p);
+  const int k = g2s_graph_k(g2s_session_graph(s));
+  const int max_fuz = o->max_fuz;
+  std::ostringstream os;
+  std::string fasta;
+  const long long max_mem_total = (long long)(o->max_mem_gb * 1024 * 1024 * 1024);  // :170
+  echo_params(os, *o, p, reads_label, filled_label, max_mem_total);
+  os << "Max mem: " << max_mem_total / std::max(1, o->nb_cores) << "\n";  // :302-303
+
+  std::vector<FastxRecord> recs;
+  parse_fastx(std::string(scaffolds_text), &recs);
+  int gapcount = 0, filledgapcount = 0;
+
+  // exact scanner state (the reference's locals, Gap2Seq.cpp:330-337)
+  size_t cur_rec = 0;
+  size_t i_exact = 0;
+  int prevGapEnd = 0;
+  std::string filledSeq;
+  bool done = recs.empty();
+
+  while (!done) {
+    // ---- static scan: collect gaps until the input ends or a barrier is hit ----
+    std::vector<GapEvent> events;
+    std::vector<g2s_gap> jobs;
+    std::vector<std::string> flanks;  // keeps left/right strings alive
+    size_t sr = cur_rec, si = i_exact;
+    int sprev = prevGapEnd;
+    bool prev_attempted = false;  // previous gap of this record is in this batch and eligible
+    int prev_rmf = 0;
+    bool barrier = false;
+    flanks.reserve(2 * 1024);
+    std::vector<std::pair<size_t, size_t>> flank_idx;  // per job: indices into flanks
+    while (sr < recs.size() && !barrier) {
+      const std::string& seq = recs[sr].seq;
+      while (si < seq.size()) {
+        if (!is_n(seq[si])) { si++; continue; }
+        const size_t istart = si;
+        if (prev_attempted) {
+          const int hi = std::min((int)istart + k - sprev, max_fuz);
+          const int lo = std::min((int)istart + k - (sprev + prev_rmf), max_fuz);
+          if (lo != hi) { barrier = true; break; }  // left_max_fuz would depend on the previous right_fuz
+        }
+        GapEvent ev;
+        ev.rec = sr;
+        ev.istart = istart;
+        ev.lmf = std::min(((int)istart + k) - sprev, max_fuz);  // :349 (Q9)
+        ev.kmer_start = (int)istart - k - ev.lmf;
+        ev.gap = 0;
+        while (si < seq.size() && is_n(seq[si])) { si++; ev.gap++; }
+        ev.iend = si;
+        ev.rmf = std::min((int)seq.size() - ((int)si + k), max_fuz);  // :360
+        ev.ok = si + k + ev.rmf <= seq.size();
+        if (ev.rmf < 0) ev.ok = false;  // D2 (Q10): the reference would throw from substr
+        for (int j = 0; j < k + ev.rmf && ev.ok; j++)
+          if (is_n(seq[si + j])) ev.ok = false;
+        ev.job = -1;
+        const bool eligible = ev.kmer_start >= sprev && ev.ok;
+        if (eligible) {
+          ev.job = (int)jobs.size();
+          g2s_gap gj;
+          memset(&gj, 0, sizeof gj);
+          flanks.push_back(seq.substr((size_t)ev.kmer_start, (size_t)(k + ev.lmf)));
+          flanks.push_back(seq.substr(si, (size_t)(k + ev.rmf)));
+          flank_idx.emplace_back(flanks.size() - 2, flanks.size() - 1);
+          gj.left_len = k + ev.lmf;
+          gj.right_len = k + ev.rmf;
+          gj.gap_len = ev.gap;
+          gj.lmf = ev.lmf;
+          gj.rmf = ev.rmf;
+          gj.skip_if_prev_right_fuz_gt = -1;
+          if (prev_attempted && ev.kmer_start - sprev < prev_rmf) gj.skip_if_prev_right_fuz_gt = ev.kmer_start - sprev;
+          jobs.push_back(gj);
+        }
+        events.push_back(ev);
+        sprev = (int)si;
+        prev_attempted = eligible;
+        prev_rmf = std::max(0, ev.rmf);
+      }
+      if (barrier) break;
+      sr++;
+      si = 0;
+      sprev = 0;
+      prev_attempted = false;
+    }
+    for (size_t j = 0; j < jobs.size(); j++) {
+      jobs[j].left = flanks[flank_idx[j].first].c_str();
+      jobs[j].right = flanks[flank_idx[j].second].c_str();
+    }
+
+    // ---- the hot path: one batch on the GPU -----------------------------------
+    std::vector<g2s_result> results(jobs.size());
+    std::vector<char> arena;
+    if (!jobs.empty()) {
+      g2s_batch* b = nullptr;
+      int rc = g2s_batch_prepare(s, jobs.data(), jobs.size(), &b);
+      if (rc != G2S_OK) return rc;
+      arena.resize(g2s_batch_arena_bytes(b));
+      rc = g2s_batch_run(b, results.data(), arena.data(), arena.size());
+      g2s_batch_free(b);
+      if (rc != G2S_OK) return rc;
+    }
+
+    // ---- exact replay of the reference's splice logic (:340-423) ---------------
+    auto finish_record = [&]() {
+      const std::string& seq = recs[cur_rec].seq;
+      filledSeq += seq.substr((size_t)prevGapEnd);  // :423
+      append_fasta(&fasta, recs[cur_rec].comment, filledSeq);  // :426-431
+      filledSeq.clear();
+      prevGapEnd = 0;
+      i_exact = 0;
+      cur_rec++;
+    };
+    for (const GapEvent& ev : events) {
+      while (cur_rec < ev.rec) finish_record();
+      const std::string& seq = recs[cur_rec].seq;
+      const std::string& comment = recs[cur_rec].comment;
+      gapcount++;
+      size_t i = ev.iend;
+      const int lmf = ev.lmf, rmf = ev.rmf, kmer_start = ev.kmer_start, gap = ev.gap;
+      const bool eligible = kmer_start >= prevGapEnd && ev.ok;
+      if (eligible) {
+        const g2s_result& r = results[(size_t)ev.job];
+        const int sres = r.count;
+        const char* tail = arena.data() + r.fill_off;
+        if (r.flags & G2S_GAP_BACKTRACE_FAIL) os << r.backtrace_msg << "\n";
+        const int filledStart = (int)filledSeq.length() + kmer_start + k + lmf - r.left_fuz - prevGapEnd;
+        const int gapStart = kmer_start + k + lmf;
+        stats_line(os, filledStart, gapStart, (int)i, sres, tail, k, lmf, rmf, r.left_fuz, r.right_fuz,
+                   p.skip_confident != 0, p.unique_paths != 0, r, gap, comment);
+        if (sres > 0 && (!p.unique_paths || sres == 1)) {
+          filledgapcount++;
+          // :396 assignment, not append (Q8); :399 drop the right k-mer
+          filledSeq = seq.substr((size_t)prevGapEnd, (size_t)(kmer_start + k + lmf - r.left_fuz - prevGapEnd)) +
+                      std::string(tail);
+          filledSeq.resize(filledSeq.size() - (size_t)k);
+          i += (size_t)r.right_fuz;  // :402
+        } else {
+          filledSeq += seq.substr((size_t)prevGapEnd, (size_t)(kmer_start + k + lmf + gap - prevGapEnd));  // :406
+        }
+      } else {
+        filledSeq += seq.substr((size_t)prevGapEnd, (size_t)(kmer_start + k + lmf + gap - prevGapEnd));  // :412
+      }
+      prevGapEnd = (int)i;  // :415
+      i_exact = i;
+    }
+    if (barrier) {
+      while (cur_rec < sr) finish_record();
+      // resume exactly at the barrier gap of record sr: N-run boundaries do not move,
+      // only prevGapEnd (already exact) matters
+      i_exact = si;
+    } else {
+      while (cur_rec < recs.size()) finish_record();
+      done = true;
+    }
+  }
+  os << "Filled " << filledgapcount << " gaps out of " << gapcount << "\n";  // :437
+  if (fasta_out) *fasta_out = dup_text(fasta);
+  if (log_out) *log_out = dup_text(os.str());
+  if (gaps_out) *gaps_out = gapcount;
+  if (filled_out) *filled_out = filledgapcount;
+  return G2S_OK;
+}
+
+// Single-gap mode (Gap2Seq.cpp:227-283)
+extern "C" int g2s_execute_single(g2s_session* s, const g2s_run_opts* o, const char* reads_label,
+                                  const char* filled_label, const char* left, const char* right, int32_t length,
+                                  char** fasta_out, char** log_out) {
+  if (!s || !o || !left || !right) return G2S_ERR_ARG;
+  g2s_params p;
+  g2s_session_get_params(s, &p);
+  const int k = g2s_graph_k(g2s_session_graph(s));
+  std::ostringstream os;
+  std::string fasta;
+  echo_params(os, *o, p, reads_label, filled_label, (long long)(o->max_mem_gb * 1024 * 1024 * 1024));
+  const std::string left_flank(left), right_flank(right);
+  if ((int)left_flank.length() < k || (int)right_flank.length() < k) {
+    fprintf(stderr, "Flanks need to be at least k length\n");  // :233-236
+    if (fasta_out) *fasta_out = dup_text("");
+    if (log_out) *log_out = dup_text(os.str());
+    return G2S_OK;
+  }
+  const int lmf = std::min((int)left_flank.length() - k, o->max_fuz);
+  const int rmf = std::min((int)right_flank.length() - k, o->max_fuz);
+  g2s_gap gj;
+  memset(&gj, 0, sizeof gj);
+  gj.left = left_flank.c_str();
+  gj.right = right_flank.c_str();
+  gj.left_len = (int)left_flank.size();
+  gj.right_len = (int)right_flank.size();
+  gj.gap_len = length;
+  gj.lmf = lmf;
+  gj.rmf = rmf;
+  gj.skip_if_prev_right_fuz_gt = -1;
+  g2s_result r;
+  std::vector<char> arena((size_t)(length + k + p.d_err + lmf + rmf + 3));
+  int rc = g2s_fill_batch(s, &gj, 1, &r, arena.data(), arena.size());
+  if (rc != G2S_OK) return rc;
+  if (r.flags & G2S_GAP_BACKTRACE_FAIL) os << r.backtrace_msg << "\n";
+  const char* tail = arena.data() + r.fill_off;
+  const int filledStart = (int)left_flank.length() - lmf - r.left_fuz;  // :257
+  stats_line(os, filledStart, (int)left_flank.length(), (int)left_flank.length() + length, r.count, tail, k, lmf, rmf,
+             r.left_fuz, r.right_fuz, p.skip_confident != 0, p.unique_paths != 0, r, length, "");
+  std::string filledSeq;
+  if (r.count > 0 && (!p.unique_paths || r.count == 1)) {
+    filledSeq = left_flank.substr(0, left_flank.length() - (size_t)r.left_fuz) + std::string(tail);  // :268
+  } else {
+    filledSeq = left_flank + std::string((size_t)length, 'N') + right_flank;  // :270-272
+  }
+  append_fasta(&fasta, "", filledSeq);
+  if (fasta_out) *fasta_out = dup_text(fasta);
+  if (log_out) *log_out = dup_text(os.str());
+  return G2S_OK;
+}

@@ -1,0 +1,387 @@
+"""ctypes binding of include/g2s.h (the drop-in boundary for
+/root/reference/src/Gap2Seq.cpp:858 ``Gap2Seq::fill_gap`` and its caller
+``Gap2Seq::execute`` :161-438).  Names follow the C ABI one to one.
+
+No compute lives here.  If ``libg2s_hip.so`` is missing the import of the library
+raises; if no gfx950 device is usable every fill call raises G2SError
+(G2S_ERR_NO_DEVICE) — there is no CPU path to fall back to.
+"""
+import ctypes as C
+import os
+
+G2S_OK = 0
+G2S_ERR_NO_DEVICE = -3
+G2S_INVALID_NODE = 0xFFFFFFFF
+G2S_MAX_PATHS = 2147483647 // 2 - 1
+G2S_GAP_SKIPPED = 0x1
+G2S_GAP_Q7 = 0x2
+G2S_GAP_MEM_EXCEEDED = 0x4
+G2S_GAP_BACKTRACE_FAIL = 0x8
+G2S_GAP_BAD_FLANK = 0x10
+G2S_GAP_PHASE_D = 0x20
+
+
+class G2SError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("g2s error %d: %s" % (code, msg))
+        self.code = code
+
+
+class g2s_params(C.Structure):
+    _fields_ = [("d_err", C.c_int32), ("skip_confident", C.c_int32), ("all_paths", C.c_int32),
+                ("unique_paths", C.c_int32), ("max_mem", C.c_int64), ("randseed", C.c_uint32),
+                ("host_threads", C.c_int32)]
+
+
+class g2s_gap(C.Structure):
+    _fields_ = [("left", C.c_char_p), ("right", C.c_char_p), ("left_len", C.c_int32), ("right_len", C.c_int32),
+                ("gap_len", C.c_int32), ("lmf", C.c_int32), ("rmf", C.c_int32),
+                ("skip_if_prev_right_fuz_gt", C.c_int32)]
+
+
+class g2s_result(C.Structure):
+    _fields_ = [("count", C.c_int32), ("left_fuz", C.c_int32), ("right_fuz", C.c_int32), ("flags", C.c_uint32),
+                ("fill_off", C.c_uint64), ("fill_len", C.c_int32), ("draws", C.c_int32),
+                ("vertices", C.c_uint64), ("edges", C.c_uint64), ("nontrivial_components", C.c_uint64),
+                ("size_nontrivial_components", C.c_uint64), ("vertices_final", C.c_uint64),
+                ("edges_final", C.c_uint64), ("phaseC_count", C.c_int32), ("n_lengths", C.c_int32),
+                ("lengths", C.c_int32 * 2), ("backtrace_msg", C.c_char * 96)]
+
+
+class g2s_timing(C.Structure):
+    _fields_ = [("ms_right_bfs", C.c_double), ("ms_left_dp", C.c_double), ("ms_extract", C.c_double),
+                ("ms_d2h", C.c_double), ("ms_host_post", C.c_double), ("ms_total", C.c_double),
+                ("xA", C.c_uint64), ("sA", C.c_uint64), ("xB", C.c_uint64), ("sB", C.c_uint64),
+                ("xD", C.c_uint64), ("sD", C.c_uint64), ("flank_bytes", C.c_uint64), ("fill_bytes", C.c_uint64),
+                ("launches_left_dp", C.c_uint32), ("retried_gaps", C.c_uint32)]
+
+
+class g2s_run_opts(C.Structure):
+    _fields_ = [("k", C.c_int32), ("solid", C.c_int32), ("max_fuz", C.c_int32), ("nb_cores", C.c_int32),
+                ("max_mem_gb", C.c_double)]
+
+
+# every symbol include/g2s.h declares: name -> (restype, argtypes)
+_VP = C.c_void_p
+_SIGS = {
+    "g2s_abi_version": (C.c_int, []),
+    "g2s_last_error": (C.c_char_p, []),
+    "g2s_graph_build_files": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(_VP)]),
+    "g2s_graph_build_seqs": (C.c_int, [C.POINTER(C.c_char_p), C.POINTER(C.c_uint64), C.c_int, C.c_int, C.c_int,
+                                       C.c_int, C.POINTER(_VP)]),
+    "g2s_graph_save": (C.c_int, [_VP, C.c_char_p]),
+    "g2s_graph_load": (C.c_int, [C.c_char_p, C.POINTER(_VP)]),
+    "g2s_graph_free": (None, [_VP]),
+    "g2s_graph_k": (C.c_int, [_VP]),
+    "g2s_graph_num_kmers": (C.c_uint64, [_VP]),
+    "g2s_graph_num_unitigs": (C.c_uint64, [_VP]),
+    "g2s_graph_node": (C.c_uint32, [_VP, C.c_char_p]),
+    "g2s_graph_successors": (C.c_int, [_VP, C.c_uint32, C.POINTER(C.c_uint32)]),
+    "g2s_graph_predecessors": (C.c_int, [_VP, C.c_uint32, C.POINTER(C.c_uint32)]),
+    "g2s_graph_node_string": (C.c_int, [_VP, C.c_uint32, C.c_char_p]),
+    "g2s_graph_upload": (C.c_int, [_VP, C.c_int]),
+    "g2s_graph_device_bytes": (C.c_uint64, [_VP, C.c_int]),
+    "g2s_session_create": (C.c_int, [_VP, C.c_int, C.POINTER(g2s_params), C.POINTER(_VP)]),
+    "g2s_session_destroy": (None, [_VP]),
+    "g2s_session_srand": (None, [_VP, C.c_uint32]),
+    "g2s_session_graph": (_VP, [_VP]),
+    "g2s_session_get_params": (C.c_int, [_VP, C.POINTER(g2s_params)]),
+    "g2s_batch_prepare": (C.c_int, [_VP, C.POINTER(g2s_gap), C.c_size_t, C.POINTER(_VP)]),
+    "g2s_batch_run": (C.c_int, [_VP, C.POINTER(g2s_result), C.c_char_p, C.c_size_t]),
+    "g2s_batch_arena_bytes": (C.c_size_t, [_VP]),
+    "g2s_batch_timing": (C.c_int, [_VP, C.POINTER(g2s_timing)]),
+    "g2s_batch_free": (None, [_VP]),
+    "g2s_fill_batch": (C.c_int, [_VP, C.POINTER(g2s_gap), C.c_size_t, C.POINTER(g2s_result), C.c_char_p,
+                                 C.c_size_t]),
+    "g2s_execute_scaffolds": (C.c_int, [_VP, C.POINTER(g2s_run_opts), C.c_char_p, C.c_char_p, C.c_char_p,
+                                        C.POINTER(_VP), C.POINTER(_VP), C.POINTER(C.c_int32),
+                                        C.POINTER(C.c_int32)]),
+    "g2s_execute_single": (C.c_int, [_VP, C.POINTER(g2s_run_opts), C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p,
+                                     C.c_int32, C.POINTER(_VP), C.POINTER(_VP)]),
+    "g2s_free": (None, [_VP]),
+    "g2s_device_count": (C.c_int, []),
+    "g2s_synth_genome": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint64, C.POINTER(_VP)]),
+    "g2s_synth_gaps": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64,
+                                 C.POINTER(_VP)]),
+    "g2s_test_post_gap": (C.c_int, [_VP, C.POINTER(g2s_params), C.POINTER(g2s_gap), C.c_int32,
+                                    C.POINTER(C.c_uint32), C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.c_int32,
+                                    C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_uint32, C.c_uint32,
+                                    C.POINTER(g2s_result), C.c_char_p]),
+}
+
+
+def library_path():
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "libg2s_hip.so")
+
+
+_LIB = None
+
+
+def load_library():
+    """Load the in-tree HIP extension; raises OSError when it has not been built."""
+    global _LIB
+    if _LIB is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise OSError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc, gfx950). There is no CPU fallback." % path)
+        lib = C.CDLL(path)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(lib, name)  # AttributeError = ABI symbol missing
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = lib
+    return _LIB
+
+
+def _check(rc):
+    if rc != G2S_OK:
+        raise G2SError(rc, (load_library().g2s_last_error() or b"").decode("utf-8", "replace"))
+
+
+def _take_text(ptr):
+    lib = load_library()
+    if not ptr:
+        return ""
+    s = C.string_at(ptr).decode("ascii")
+    lib.g2s_free(ptr)
+    return s
+
+
+class G2S:
+    """Namespace for the free functions of the ABI."""
+
+    @staticmethod
+    def device_count():
+        return load_library().g2s_device_count()
+
+    @staticmethod
+    def synth_genome(length, variant, seed):
+        out = _VP()
+        _check(load_library().g2s_synth_genome(length, variant, seed, C.byref(out)))
+        return _take_text(out)
+
+    @staticmethod
+    def synth_gaps(reads_fasta, k, fuz, ngaps, min_len, max_len, seed):
+        out = _VP()
+        _check(load_library().g2s_synth_gaps(reads_fasta.encode("ascii"), k, fuz, ngaps, min_len, max_len, seed,
+                                             C.byref(out)))
+        return _take_text(out)
+
+
+class Graph:
+    """g2s_graph: replaces gatb Graph::create / Graph::load (Gap2Seq.cpp:193-219)."""
+
+    def __init__(self, handle):
+        self.h = handle
+
+    @classmethod
+    def from_seqs(cls, seqs, k, solid, nthreads=0):
+        lib = load_library()
+        enc = [s.encode("ascii") if isinstance(s, str) else s for s in seqs]
+        arr = (C.c_char_p * len(enc))(*enc)
+        lens = (C.c_uint64 * len(enc))(*[len(e) for e in enc])
+        h = _VP()
+        _check(lib.g2s_graph_build_seqs(arr, lens, len(enc), k, solid, nthreads, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_files(cls, reads_csv, k, solid, nthreads=0):
+        h = _VP()
+        _check(load_library().g2s_graph_build_files(reads_csv.encode(), k, solid, nthreads, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def load(cls, path):
+        h = _VP()
+        _check(load_library().g2s_graph_load(path.encode(), C.byref(h)))
+        return cls(h)
+
+    def save(self, path):
+        _check(load_library().g2s_graph_save(self.h, path.encode()))
+
+    @property
+    def k(self):
+        return load_library().g2s_graph_k(self.h)
+
+    @property
+    def num_kmers(self):
+        return load_library().g2s_graph_num_kmers(self.h)
+
+    @property
+    def num_unitigs(self):
+        return load_library().g2s_graph_num_unitigs(self.h)
+
+    def node(self, kmer):
+        return load_library().g2s_graph_node(self.h, kmer.encode("ascii"))
+
+    def node_string(self, v):
+        buf = C.create_string_buffer(self.k + 1)
+        _check(load_library().g2s_graph_node_string(self.h, v, buf))
+        return buf.value.decode()
+
+    def successors(self, v):
+        out = (C.c_uint32 * 4)()
+        n = load_library().g2s_graph_successors(self.h, v, out)
+        return [out[i] for i in range(n)]
+
+    def predecessors(self, v):
+        out = (C.c_uint32 * 4)()
+        n = load_library().g2s_graph_predecessors(self.h, v, out)
+        return [out[i] for i in range(n)]
+
+    def upload(self, device=0):
+        _check(load_library().g2s_graph_upload(self.h, device))
+
+    def device_bytes(self, device=0):
+        return load_library().g2s_graph_device_bytes(self.h, device)
+
+    def free(self):
+        if self.h:
+            load_library().g2s_graph_free(self.h)
+            self.h = None
+
+
+class Gap:
+    """Arguments of one fill_gap call (Gap2Seq.cpp:380-383)."""
+
+    def __init__(self, left, right, gap_len, lmf, rmf, skip_if_prev_right_fuz_gt=-1):
+        self.left, self.right, self.gap_len, self.lmf, self.rmf = left, right, gap_len, lmf, rmf
+        self.skip_dep = skip_if_prev_right_fuz_gt
+
+
+def make_params(d_err=500, skip_confident=False, all_paths=True, unique_paths=False, max_mem=20 << 30, randseed=1,
+                host_threads=0):
+    return g2s_params(d_err, int(skip_confident), int(all_paths), int(unique_paths), max_mem, randseed, host_threads)
+
+
+def _gap_array(gaps):
+    keep = []
+    arr = (g2s_gap * max(1, len(gaps)))()
+    for i, g in enumerate(gaps):
+        l, r = g.left.encode("ascii"), g.right.encode("ascii")
+        keep.append((l, r))
+        arr[i] = g2s_gap(l, r, len(l), len(r), g.gap_len, g.lmf, g.rmf, g.skip_dep)
+    return arr, keep
+
+
+class FillResult:
+    """g2s_result with the fill text resolved."""
+
+    def __init__(self, r, arena):
+        for name, _ in g2s_result._fields_:
+            if name not in ("lengths", "backtrace_msg"):
+                setattr(self, name, getattr(r, name))
+        self.lengths = [r.lengths[i] for i in range(r.n_lengths)]
+        self.backtrace_msg = r.backtrace_msg.decode("ascii", "replace")
+        self.fill = arena[r.fill_off:r.fill_off + r.fill_len].decode("ascii") if r.fill_len > 0 else ""
+        self.substats = [r.vertices, r.edges, r.nontrivial_components, r.size_nontrivial_components,
+                         r.vertices_final, r.edges_final]
+
+
+class Session:
+    """g2s_session: one GPU, one rand() stream."""
+
+    def __init__(self, graph, device=0, **kw):
+        self.graph = graph
+        self.params = make_params(**kw)
+        h = _VP()
+        _check(load_library().g2s_session_create(graph.h, device, C.byref(self.params), C.byref(h)))
+        self.h = h
+
+    def srand(self, seed):
+        load_library().g2s_session_srand(self.h, seed)
+
+    def fill_batch(self, gaps, want_timing=False):
+        """prepare + run; returns list of FillResult (and g2s_timing)."""
+        lib = load_library()
+        arr, keep = _gap_array(gaps)
+        b = _VP()
+        _check(lib.g2s_batch_prepare(self.h, arr, len(gaps), C.byref(b)))
+        try:
+            nbytes = lib.g2s_batch_arena_bytes(b)
+            arena = C.create_string_buffer(max(1, nbytes))
+            res = (g2s_result * max(1, len(gaps)))()
+            _check(lib.g2s_batch_run(b, res, arena, nbytes))
+            t = g2s_timing()
+            _check(lib.g2s_batch_timing(b, C.byref(t)))
+        finally:
+            lib.g2s_batch_free(b)
+        raw = arena.raw
+        out = [FillResult(res[i], raw) for i in range(len(gaps))]
+        return (out, t) if want_timing else out
+
+    def prepare(self, gaps):
+        """g2s_batch_prepare; returns an opaque PreparedBatch to run repeatedly."""
+        return PreparedBatch(self, gaps)
+
+    def execute_scaffolds(self, scaffolds_text, k, solid=2, max_fuz=10, nb_cores=1, max_mem_gb=20.0,
+                          reads_label="reads.fa", filled_label="filled.fa"):
+        lib = load_library()
+        o = g2s_run_opts(k, solid, max_fuz, nb_cores, max_mem_gb)
+        fa, lg = _VP(), _VP()
+        gaps, filled = C.c_int32(0), C.c_int32(0)
+        _check(lib.g2s_execute_scaffolds(self.h, C.byref(o), reads_label.encode(), filled_label.encode(),
+                                         scaffolds_text.encode("ascii"), C.byref(fa), C.byref(lg), C.byref(gaps),
+                                         C.byref(filled)))
+        return _take_text(fa), _take_text(lg), gaps.value, filled.value
+
+    def execute_single(self, left, right, length, k, solid=2, max_fuz=10, max_mem_gb=20.0,
+                       reads_label="reads.fa", filled_label="filled.fa"):
+        lib = load_library()
+        o = g2s_run_opts(k, solid, max_fuz, 1, max_mem_gb)
+        fa, lg = _VP(), _VP()
+        _check(lib.g2s_execute_single(self.h, C.byref(o), reads_label.encode(), filled_label.encode(),
+                                      left.encode("ascii"), right.encode("ascii"), length, C.byref(fa), C.byref(lg)))
+        return _take_text(fa), _take_text(lg)
+
+    def destroy(self):
+        if self.h:
+            load_library().g2s_session_destroy(self.h)
+            self.h = None
+
+
+class PreparedBatch:
+    def __init__(self, session, gaps):
+        lib = load_library()
+        self.session = session
+        self.n = len(gaps)
+        self._arr, self._keep = _gap_array(gaps)
+        self.h = _VP()
+        _check(lib.g2s_batch_prepare(session.h, self._arr, self.n, C.byref(self.h)))
+        self.nbytes = lib.g2s_batch_arena_bytes(self.h)
+        self.arena = C.create_string_buffer(max(1, self.nbytes))
+        self.res = (g2s_result * max(1, self.n))()
+
+    def run(self):
+        _check(load_library().g2s_batch_run(self.h, self.res, self.arena, self.nbytes))
+
+    def timing(self):
+        t = g2s_timing()
+        _check(load_library().g2s_batch_timing(self.h, C.byref(t)))
+        return t
+
+    def results(self):
+        raw = self.arena.raw
+        return [FillResult(self.res[i], raw) for i in range(self.n)]
+
+    def free(self):
+        if self.h:
+            load_library().g2s_batch_free(self.h)
+            self.h = None
+
+
+def test_post_gap(graph, params, gap, states, c_count, lengths, reached_j, final_d, seed, skip):
+    """TEST HOOK binding (host half of phase D on a supplied DP table)."""
+    lib = load_library()
+    arr, keep = _gap_array([gap])
+    n = len(states)
+    nodes = (C.c_uint32 * max(1, n))(*[s[0] for s in states])
+    depths = (C.c_int32 * max(1, n))(*[s[1] for s in states])
+    counts = (C.c_uint32 * max(1, n))(*[s[2] for s in states])
+    lens = (C.c_int32 * 2)(*(list(lengths) + [0, 0])[:2])
+    res = g2s_result()
+    buf = C.create_string_buffer(gap.gap_len + graph.k + params.d_err + gap.lmf + gap.rmf + 3)
+    _check(lib.g2s_test_post_gap(graph.h, C.byref(params), arr, n, nodes, depths, counts, c_count, len(lengths), lens,
+                                 reached_j, final_d, seed, skip, C.byref(res), buf))
+    return FillResult(res, buf.raw)

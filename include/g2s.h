@@ -1,0 +1,238 @@
+/* ===========================================================================
+ *  include/g2s.h — C ABI of the MI355X-native Gap2Seq-core fill path.
+ *
+ *  This is the drop-in boundary.  The reference has no FFI of its own: the hot
+ *  path is the in-process C++ member
+ *      int Gap2Seq::fill_gap(const Graph&, const std::string& kmer_left,
+ *                            const std::string& kmer_right, int gap_len, int k,
+ *                            int gap_err, int left_max_fuz, int right_max_fuz,
+ *                            int* left_fuz, int* right_fuz, long long max_mem,
+ *                            char* fill, bool skip_confident, bool all_paths,
+ *                            subgraph_stats*)
+ *  (/root/reference/src/Gap2Seq.hpp:74-76, Gap2Seq.cpp:858-1556), called once
+ *  per gap from Gap2Seq::execute() (Gap2Seq.cpp:252 and :380) on a GATB Graph
+ *  built once (Gap2Seq.cpp:193-219).  Each entry point below names the piece of
+ *  that interface it replaces.  INTEGRATION.md shows the stub a maintainer of
+ *  the reference would add to call it.
+ *
+ *  Plain C: opaque handles, caller-owned buffers, integer status codes, no
+ *  exceptions cross this boundary.  One g2s_session drives one GPU; sessions
+ *  on different devices may run on different host threads.
+ *  There is NO CPU fallback: every fill entry point returns G2S_ERR_NO_DEVICE
+ *  when no gfx950 device is usable.
+ * ======================================================================== */
+#ifndef G2S_H_
+#define G2S_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define G2S_ABI_VERSION 1
+
+/* status codes */
+#define G2S_OK 0
+#define G2S_ERR_ARG (-1)
+#define G2S_ERR_IO (-2)
+#define G2S_ERR_NO_DEVICE (-3)
+#define G2S_ERR_HIP (-4)
+#define G2S_ERR_NOMEM (-5)
+#define G2S_ERR_STATE (-6)
+
+/* Gap2Seq.cpp:38 */
+#define G2S_MAX_PATHS (2147483647 / 2 - 1)
+#define G2S_INVALID_NODE 0xFFFFFFFFu
+
+typedef struct g2s_graph g2s_graph;     /* replaces gatb Graph (host + device copies) */
+typedef struct g2s_session g2s_session; /* one device, one rand() stream, reusable workspaces */
+typedef struct g2s_batch g2s_batch;     /* a prepared list of gaps resident in HBM */
+
+int g2s_abi_version(void);
+/* Thread-local text of the last error returned on this thread. */
+const char* g2s_last_error(void);
+
+/* ---------------------------------------------------------------------------
+ *  Graph: replaces Graph::create(BankAlbum, "-kmer-size k -abundance-min solid
+ *  ...") / Graph::load (Gap2Seq.cpp:193-219).  Exact solid canonical k-mer set
+ *  (GATB codec A0 C1 T2 G3, canonical = min(fwd, revcomp), k-mers containing
+ *  N/n skipped), numbered in unitig order, with a 4-slot successor table per
+ *  oriented node in GATB enumeration order (A,C,T,G).  Predecessors are read
+ *  from the same table: pred(v)[i] = succ(v^1)[i]^1.
+ * ------------------------------------------------------------------------ */
+int g2s_graph_build_files(const char* reads_csv, int k, int solid, int nthreads, g2s_graph** out);
+int g2s_graph_build_seqs(const char* const* seqs, const uint64_t* lens, int nseqs, int k, int solid,
+                         int nthreads, g2s_graph** out);
+/* Own binary cache (the reference reuses "<reads>.h5", Gap2Seq.cpp:171,195-197). */
+int g2s_graph_save(const g2s_graph* g, const char* path);
+int g2s_graph_load(const char* path, g2s_graph** out);
+void g2s_graph_free(g2s_graph* g);
+int g2s_graph_k(const g2s_graph* g);
+uint64_t g2s_graph_num_kmers(const g2s_graph* g);
+uint64_t g2s_graph_num_unitigs(const g2s_graph* g);
+/* graph.buildNode + graph.contains: oriented node id (2*index + strand) of the
+ * first k characters of `kmer`, or G2S_INVALID_NODE when it is not solid. */
+uint32_t g2s_graph_node(const g2s_graph* g, const char* kmer);
+/* graph.successors / graph.predecessors in GATB order; returns the count. */
+int g2s_graph_successors(const g2s_graph* g, uint32_t node, uint32_t out[4]);
+int g2s_graph_predecessors(const g2s_graph* g, uint32_t node, uint32_t out[4]);
+/* graph.toString(node): writes k chars + NUL. */
+int g2s_graph_node_string(const g2s_graph* g, uint32_t node, char* out);
+/* Copy the successor table into the HBM of `device` (idempotent per device). */
+int g2s_graph_upload(g2s_graph* g, int device);
+/* Bytes resident in HBM for this graph on `device` (0 when not uploaded). */
+uint64_t g2s_graph_device_bytes(const g2s_graph* g, int device);
+
+/* ---------------------------------------------------------------------------
+ *  Parameters: the Gap2Seq-core options that reach fill_gap
+ *  (Gap2Seq.cpp:164-175).
+ * ------------------------------------------------------------------------ */
+typedef struct g2s_params {
+  int32_t d_err;          /* -dist-error (gap_err)                       */
+  int32_t skip_confident; /* -all-upper                                  */
+  int32_t all_paths;      /* !-best-only                                 */
+  int32_t unique_paths;   /* -unique (applied by the caller of fill_gap) */
+  int64_t max_mem;        /* bytes per gap, already divided by threads
+                             (Gap2Seq.cpp:170,302); device-budget analogue */
+  uint32_t randseed;      /* srand() argument (Gap2Seq.cpp:178)          */
+  int32_t host_threads;   /* threads for the per-gap host post-process; 0 = all */
+} g2s_params;
+
+/* One fill_gap call's inputs (Gap2Seq.cpp:380-383 / :252-254). */
+typedef struct g2s_gap {
+  const char* left;   /* kmer_left : k+lmf chars (longer allowed, as in -left)  */
+  const char* right;  /* kmer_right: k+rmf chars                                */
+  int32_t left_len;
+  int32_t right_len;
+  int32_t gap_len;
+  int32_t lmf;        /* left_max_fuz  */
+  int32_t rmf;        /* right_max_fuz */
+  /* Scaffold scanning continues at i += right_fuz after a filled gap
+   * (Gap2Seq.cpp:402,415), which can make the NEXT gap of the same record
+   * ineligible.  If >= 0: skip this gap (status G2S_GAP_SKIPPED, no rand()
+   * draws) when the previous gap of the batch was filled with right_fuz
+   * greater than this value.  -1: independent. */
+  int32_t skip_if_prev_right_fuz_gt;
+} g2s_gap;
+
+/* g2s_result.flags */
+#define G2S_GAP_SKIPPED 0x1        /* see skip_if_prev_right_fuz_gt                     */
+#define G2S_GAP_Q7 0x2             /* both strands of one k-mer met: result is
+                                      well defined but outside the bit-exact claim        */
+#define G2S_GAP_MEM_EXCEEDED 0x4   /* count == -1                                         */
+#define G2S_GAP_BACKTRACE_FAIL 0x8 /* "Unable to backtrace!" (Gap2Seq.cpp:1493-1510)      */
+#define G2S_GAP_BAD_FLANK 0x10     /* flank shorter than k+fuz (reference would throw)    */
+#define G2S_GAP_PHASE_D 0x20       /* phase D ran: fill / left_fuz / right_fuz written    */
+
+typedef struct g2s_result {
+  int32_t count;      /* fill_gap return value: >0 paths (saturating), 0, or -1 */
+  int32_t left_fuz;
+  int32_t right_fuz;
+  uint32_t flags;
+  /* `fill` as the reference leaves it: the useful text starts at
+   * buf[lmf - left_fuz]; here fill_off points at exactly that position inside
+   * the caller's arena and fill_len = strlen(&buf[lmf-left_fuz]) (it INCLUDES
+   * the right k-mer, Gap2Seq.cpp:856-857).  NUL terminated. */
+  uint64_t fill_off;
+  int32_t fill_len;
+  int32_t draws;      /* rand() calls consumed */
+  /* subgraph_stats (Gap2Seq.hpp:50-58); valid when count > 0 and !skip_confident */
+  uint64_t vertices, edges, nontrivial_components, size_nontrivial_components, vertices_final, edges_final;
+  /* phase C result before the D1 recount */
+  int32_t phaseC_count;
+  int32_t n_lengths;
+  int32_t lengths[2];
+  char backtrace_msg[96]; /* text of the "Unable to backtrace!" line, else "" */
+} g2s_result;
+
+/* Per-batch measurements (bench.py). */
+typedef struct g2s_timing {
+  double ms_right_bfs;    /* kernel g2s_right_bfs, HIP events on the session stream */
+  double ms_left_dp;      /* kernel g2s_left_dp  (the frontier kernel)              */
+  double ms_extract;      /* kernel g2s_extract                                     */
+  double ms_d2h;
+  double ms_host_post;    /* SCC / branch rule / traceback on the host              */
+  double ms_total;        /* wall time of g2s_batch_run                             */
+  uint64_t xA, sA, xB, sB, xD, sD; /* expansions / newly set states per phase, counted on device */
+  uint64_t flank_bytes;   /* sum over gaps of (k+lmf)+(k+rmf)                       */
+  uint64_t fill_bytes;    /* sum over gaps of fill_len                              */
+  uint32_t launches_left_dp; /* >1 when overflowing gaps were retried with larger tables */
+  uint32_t retried_gaps;
+} g2s_timing;
+
+/* ---------------------------------------------------------------------------
+ *  Session: owns the device, the stream, the reusable workspaces and the
+ *  glibc-compatible rand() stream that the traceback consumes in gap order.
+ * ------------------------------------------------------------------------ */
+int g2s_session_create(g2s_graph* g, int device, const g2s_params* p, g2s_session** out);
+void g2s_session_destroy(g2s_session* s);
+/* srand(seed) (Gap2Seq.cpp:178). */
+void g2s_session_srand(g2s_session* s, uint32_t seed);
+
+/* Resolve flank k-mers to node ids on the host and upload the gap descriptors
+ * to HBM.  Replaces the argument marshalling of Gap2Seq.cpp:380-383. */
+int g2s_batch_prepare(g2s_session* s, const g2s_gap* gaps, size_t n, g2s_batch** out);
+/* The hot path: phases A-D of fill_gap for every gap of the batch (kernels on
+ * the session stream, device->host of the state logs, host SCC/branch rule and
+ * the in-order traceback).  `fill_arena` receives the NUL-terminated fills;
+ * it needs sum(gap_len + k + d_err + lmf + rmf + 3) bytes (g2s_batch_arena_bytes). */
+int g2s_batch_run(g2s_batch* b, g2s_result* results, char* fill_arena, size_t arena_cap);
+size_t g2s_batch_arena_bytes(const g2s_batch* b);
+int g2s_batch_timing(const g2s_batch* b, g2s_timing* out);
+void g2s_batch_free(g2s_batch* b);
+/* prepare + run + free. */
+int g2s_fill_batch(g2s_session* s, const g2s_gap* gaps, size_t n, g2s_result* results, char* fill_arena,
+                   size_t arena_cap);
+
+/* ---------------------------------------------------------------------------
+ *  Gap2Seq::execute() after the graph exists (Gap2Seq.cpp:224-438): scaffold
+ *  scanner, per-gap statistics text, splice, FASTA text.  Outputs are malloc'ed
+ *  strings released with g2s_free.  `reads_label`/`filled_label` only feed the
+ *  parameter echo (Gap2Seq.cpp:180-191).
+ * ------------------------------------------------------------------------ */
+typedef struct g2s_run_opts {
+  int32_t k, solid, max_fuz, nb_cores;
+  double max_mem_gb;
+} g2s_run_opts;
+int g2s_execute_scaffolds(g2s_session* s, const g2s_run_opts* o, const char* reads_label,
+                          const char* filled_label, const char* scaffolds_text, char** fasta, char** log,
+                          int32_t* gaps, int32_t* filled);
+int g2s_execute_single(g2s_session* s, const g2s_run_opts* o, const char* reads_label, const char* filled_label,
+                       const char* left, const char* right, int32_t length, char** fasta, char** log);
+void g2s_free(void* p);
+
+/* Accessors. */
+const g2s_graph* g2s_session_graph(const g2s_session* s);
+int g2s_session_get_params(const g2s_session* s, g2s_params* out);
+
+/* ---------------------------------------------------------------------------
+ *  TEST HOOK (CPU unit tests of the host half of phase D only; not a fill
+ *  path: it cannot compute the DP).  Runs D1/D2/D3 for ONE gap on a DP table
+ *  supplied by the caller: n_states states (oriented node, depth, count) plus
+ *  the phase C outcome.  The rand() stream is srand(seed) advanced by `skip`
+ *  draws.  `buf` needs gap_len + k + d_err + lmf + rmf + 3 bytes.
+ * ------------------------------------------------------------------------ */
+int g2s_test_post_gap(const g2s_graph* g, const g2s_params* p, const g2s_gap* gap, int32_t n_states,
+                      const uint32_t* nodes, const int32_t* depths, const uint32_t* counts, int32_t c_count,
+                      int32_t n_lengths, const int32_t* lengths, int32_t reached_j, int32_t final_d, uint32_t seed,
+                      uint32_t skip, g2s_result* res, char* buf);
+
+/* Number of usable gfx950 devices (0 when none / no driver). */
+int g2s_device_count(void);
+
+/* ---------------------------------------------------------------------------
+ *  Synthetic workloads of BASELINE.md / SURVEY.md §8(d) (seeded, generator
+ *  lives here so that bench.py, the tests and the CLI agree byte for byte).
+ *  variant bit 0: plant repeats (V1), bit 1: second haplotype with one
+ *  substitution every ~500 bp (V2).  Returns malloc'ed FASTA texts.
+ * ------------------------------------------------------------------------ */
+int g2s_synth_genome(uint64_t length, uint32_t variant, uint64_t seed, char** reads_fasta);
+int g2s_synth_gaps(const char* reads_fasta, int k, int fuz, int ngaps, int min_len, int max_len, uint64_t seed,
+                   char** scaffolds_fasta);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* G2S_H_ */

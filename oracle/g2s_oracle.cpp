@@ -581,6 +581,16 @@ static int fill_gap_t(const OGraph<KT>& G, GlibcRand& rng, const std::string& km
     mymemuse = mm.bytes;
   }
   info->phaseC_count = count;
+  info->final_d = currentD;
+  if (info->dump_states) {
+    std::ostringstream ds;
+    for (auto& kv : reachLeft)
+      for (int st = 0; st < 2; st++) {
+        Node nn; nn.kmer = kv.first; nn.strand = (uint8_t)st;
+        for (auto& pr : kv.second->s[st]) ds << G.toString(nn) << " " << pr.first << " " << pr.second << "\n";
+      }
+    *info->dump_states = ds.str();
+  }
   info->n_lengths = (int)pathLengths.size();
   for (size_t i = 0; i < pathLengths.size() && i < 2; i++) info->lengths[i] = pathLengths[i];
   info->reached_fuz = reachedFuz;

@@ -14,6 +14,7 @@ struct orc_info {
   uint64_t sub[6];      // vertices, edges, nontrivial, size_nontrivial, vertices_final, edges_final
   uint64_t ctr[6];      // xA sA xB sB xD sD
   int32_t phaseC_count, n_lengths, lengths[2], reached_fuz, draws, q7, backtrace_failed, mem_exceeded;
+  int32_t final_d, pad;
 };
 
 struct orc_params {
@@ -60,6 +61,7 @@ static void pack_info(const FillInfo& fi, orc_info* o) {
   o->lengths[0] = fi.lengths[0]; o->lengths[1] = fi.lengths[1];
   o->reached_fuz = fi.reached_fuz; o->draws = fi.draws; o->q7 = fi.q7;
   o->backtrace_failed = fi.backtrace_failed; o->mem_exceeded = fi.mem_exceeded;
+  o->final_d = fi.final_d; o->pad = 0;
 }
 
 // One fill_gap call.  `fill` must hold gap_len + k + gap_err + lmf + rmf + 3 bytes (Gap2Seq.cpp:374).
@@ -74,6 +76,25 @@ int orc_fill_gap(void* g, void* rng, const char* left, const char* right, int ga
   int r = fill_gap(G, *(GlibcRand*)rng, left, right, gap_len, graph_k(G), gap_err, lmf, rmf, left_fuz, right_fuz,
                    max_mem, fill, skip_confident != 0, all_paths != 0, &st, &fi);
   if (out) pack_info(fi, out);
+  return r;
+}
+
+// Same as orc_fill_gap, plus a malloc'ed text dump of the left DP table
+// ("ORIENTED_KMER depth count" per line) for unit tests of host post-processing.
+int orc_fill_gap_dump(void* g, void* rng, const char* left, const char* right, int gap_len, int gap_err, int lmf,
+                      int rmf, long long max_mem, int skip_confident, int all_paths, char* fill, int* left_fuz,
+                      int* right_fuz, orc_info* out, char** states) {
+  GraphBase* G = (GraphBase*)g;
+  FillInfo fi;
+  std::string dump;
+  fi.dump_states = &dump;
+  SubgraphStats st;
+  *left_fuz = 0;
+  *right_fuz = 0;
+  int r = fill_gap(G, *(GlibcRand*)rng, left, right, gap_len, graph_k(G), gap_err, lmf, rmf, left_fuz, right_fuz,
+                   max_mem, fill, skip_confident != 0, all_paths != 0, &st, &fi);
+  if (out) pack_info(fi, out);
+  if (states) { *states = (char*)malloc(dump.size() + 1); memcpy(*states, dump.c_str(), dump.size() + 1); }
   return r;
 }
 
