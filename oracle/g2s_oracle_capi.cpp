@@ -2,7 +2,11 @@
 // TEST INFRASTRUCTURE ONLY (see g2s_oracle.hpp).  Parity unpinned by the reference.
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <chrono>
 #include <sstream>
+#include <thread>
+#include <vector>
 
 #include "g2s_oracle.hpp"
 
@@ -96,6 +100,54 @@ int orc_fill_gap_dump(void* g, void* rng, const char* left, const char* right, i
   if (out) pack_info(fi, out);
   if (states) { *states = (char*)malloc(dump.size() + 1); memcpy(*states, dump.c_str(), dump.size() + 1); }
   return r;
+}
+
+// Timed CPU baseline: fill_gap over a list of gaps, pulled one at a time by
+// `nthreads` threads (gap-level parallelism like the reference's dispatcher,
+// Gap2Seq.cpp:296-306; each thread has its own rand() stream, as nothing is compared).
+// Returns wall seconds of the fill loop only.
+double orc_time_fill_batch(void* g, const char** lefts, const char** rights, const int* gap_lens, const int* lmfs,
+                           const int* rmfs, int n, int gap_err, int skip_confident, int all_paths, int nthreads,
+                           int* filled_out, uint64_t* ctr_out) {
+  GraphBase* G = (GraphBase*)g;
+  const int k = graph_k(G);
+  if (nthreads < 1) nthreads = 1;
+  std::vector<int> filled((size_t)nthreads, 0);
+  std::vector<Counters> ctrs((size_t)nthreads);
+  std::atomic<int> next_gap(0);
+  auto work = [&](int t) {
+    GlibcRand rng;
+    rng.seed(1 + (unsigned)t);
+    while (true) {  // shared iterator, one gap at a time (Gap2Seq.cpp:313-323)
+      const int i = next_gap.fetch_add(1);
+      if (i >= n) break;
+      std::vector<char> buf((size_t)(gap_lens[i] + k + gap_err + lmfs[i] + rmfs[i] + 3));
+      int lf = 0, rf = 0;
+      SubgraphStats st;
+      FillInfo fi;
+      int c = fill_gap(G, rng, lefts[i], rights[i], gap_lens[i], k, gap_err, lmfs[i], rmfs[i], &lf, &rf,
+                       (long long)1 << 60, buf.data(), skip_confident != 0, all_paths != 0, &st, &fi);
+      if (c > 0) filled[(size_t)t]++;
+      Counters& cc = ctrs[(size_t)t];
+      cc.xA += fi.ctr.xA; cc.sA += fi.ctr.sA; cc.xB += fi.ctr.xB; cc.sB += fi.ctr.sB; cc.xD += fi.ctr.xD; cc.sD += fi.ctr.sD;
+    }
+  };
+  auto t0 = std::chrono::steady_clock::now();
+  std::vector<std::thread> th;
+  for (int t = 1; t < nthreads; t++) th.emplace_back(work, t);
+  work(0);
+  for (auto& x : th) x.join();
+  double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  int total = 0;
+  uint64_t c6[6] = {0, 0, 0, 0, 0, 0};
+  for (int t = 0; t < nthreads; t++) {
+    total += filled[(size_t)t];
+    c6[0] += ctrs[(size_t)t].xA; c6[1] += ctrs[(size_t)t].sA; c6[2] += ctrs[(size_t)t].xB;
+    c6[3] += ctrs[(size_t)t].sB; c6[4] += ctrs[(size_t)t].xD; c6[5] += ctrs[(size_t)t].sD;
+  }
+  if (filled_out) *filled_out = total;
+  if (ctr_out) for (int i = 0; i < 6; i++) ctr_out[i] = c6[i];
+  return secs;
 }
 
 static Params to_params(const orc_params* p) {

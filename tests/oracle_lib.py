@@ -62,8 +62,29 @@ def lib():
                                             C.POINTER(VP), C.POINTER(VP), C.POINTER(orc_summary)]
         L.orc_execute_single.argtypes = [VP, C.POINTER(orc_params), C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p,
                                          C.c_int, C.POINTER(VP), C.POINTER(VP)]
+        L.orc_time_fill_batch.restype = C.c_double
+        L.orc_time_fill_batch.argtypes = [VP, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_int),
+                                          C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_uint64)]
         _LIB = L
     return _LIB
+
+
+def time_fill_batch(graph, gaps, gap_err, nthreads=1, skip_confident=False, all_paths=True):
+    """CPU baseline timing: (seconds, filled, counters[6]) for fill_gap over `gaps`
+    (dicts with left/right/gap_len/lmf/rmf)."""
+    L = lib()
+    n = len(gaps)
+    lefts = (C.c_char_p * n)(*[g["left"].encode() for g in gaps])
+    rights = (C.c_char_p * n)(*[g["right"].encode() for g in gaps])
+    gl = (C.c_int * n)(*[g["gap_len"] for g in gaps])
+    lm = (C.c_int * n)(*[g["lmf"] for g in gaps])
+    rm = (C.c_int * n)(*[g["rmf"] for g in gaps])
+    filled = C.c_int(0)
+    ctr = (C.c_uint64 * 6)()
+    secs = L.orc_time_fill_batch(graph.h, lefts, rights, gl, lm, rm, n, gap_err, int(skip_confident), int(all_paths),
+                                 nthreads, C.byref(filled), ctr)
+    return secs, filled.value, [int(x) for x in ctr]
 
 
 class OracleGraph:

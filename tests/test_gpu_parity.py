@@ -1,0 +1,306 @@
+"""GPU parity tests (run with `-m gpu` on an MI355X): the HIP fill path, called
+through the C ABI, against the CPU oracle on the same seeded inputs, against the
+committed golden vectors, and — at BASELINE.json's full sizes — through properties
+that need no oracle (cut -> fill -> original sequence round trip on a repeat-free
+genome).  Bit-exact: counts, fuz values, rand() draw counts, fill strings including
+the upper/lower-case safe/unsafe classification, subgraph statistics, FASTA and log
+text.  Gaps flagged Q7 (both strands of a k-mer in one border; the reference's
+outcome depends on libstdc++ hash-set order) are excluded from the
+bit-exact claim but must be flagged by the GPU path whenever the oracle flags them.
+"""
+import json
+import os
+import subprocess
+
+import pytest
+
+import cases
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _gaps(product, gl):
+    return [product.Gap(g["left"], g["right"], g["gap_len"], g["lmf"], g["rmf"]) for g in gl]
+
+
+def _parse_scaffolds(text, fuz=10):
+    lines = text.splitlines()
+    out = []
+    for j in range(0, len(lines), 2):
+        s = lines[j + 1]
+        a = s.index("N")
+        b = len(s) - s[::-1].index("N")
+        out.append(dict(left=s[:a], right=s[b:], gap_len=b - a, lmf=fuz, rmf=fuz))
+    return out
+
+
+def _check_batch(product, oracle, seqs, k, gaps, e, skip=False, allp=True, seed=5, max_mem=20 << 30):
+    og = oracle.OracleGraph(seqs, k, 1)
+    pg = product.Graph.from_seqs(seqs, k, 1)
+    sess = product.Session(pg, 0, d_err=e, skip_confident=skip, all_paths=allp, randseed=seed, max_mem=max_mem)
+    res, tm = sess.fill_batch(_gaps(product, gaps), True)
+    rng = oracle.OracleRng(seed)
+    compared = filled = 0
+    xb = sb = 0
+    try:
+        for g, r in zip(gaps, res):
+            o = oracle.fill_gap(og, rng, g["left"], g["right"], g["gap_len"], e, g["lmf"], g["rmf"], skip, allp)
+            if o.info.q7:
+                assert r.flags & product.G2S_GAP_Q7, "oracle saw a Q7 collision the GPU path did not flag"
+            if o.info.q7 or (r.flags & product.G2S_GAP_Q7):
+                if o.info.draws != r.draws:
+                    break  # the shared rand() stream has diverged: later gaps cannot be compared
+                continue
+            assert r.count == o.count
+            assert r.phaseC_count == o.info.phaseC_count and r.lengths == o.lengths
+            assert r.draws == o.info.draws
+            if o.phase_d:
+                assert (r.left_fuz, r.right_fuz) == (o.left_fuz, o.right_fuz)
+                assert r.fill == o.fill  # sequence AND case (safe/unsafe bases)
+                if not skip:
+                    assert r.substats == o.substats
+            xb += o.info.ctr[2]
+            sb += o.info.ctr[3]
+            compared += 1
+            filled += o.count > 0
+    finally:
+        sess.destroy()
+        pg.free()
+        og.free()
+    return compared, filled, tm, xb, sb
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_toy_graphs_all_modes(product, oracle, seed):
+    k = [5, 7, 9, 11, 13, 15][seed % 6]
+    seqs = cases.toy_genome(seed, 900, k, repeats=seed % 4, tandem=seed % 3, inverted=int(seed % 5 == 0),
+                            snp_every=(0 if seed % 2 else 83))
+    e = [0, 4, 9, 20, 31][seed % 5] + k
+    gaps = cases.cut_gaps(seed, seqs[0], k, fuz=seed % 5 + 1, ngaps=40, min_len=1, max_len=60, d_err=e)
+    total = 0
+    for skip, allp in ((False, True), (False, False), (True, True)):
+        c, f, _, _, _ = _check_batch(product, oracle, seqs, k, gaps, e, skip, allp)
+        total += c
+    if k >= 9:
+        assert total > 30
+
+
+def test_golden_vectors_on_gpu(product):
+    sets = json.load(open(os.path.join(HERE, "golden", "fill_gap_cases.json")))
+    n = 0
+    for s in sets:
+        pg = product.Graph.from_seqs(s["seqs"], s["k"], s["solid"])
+        sess = product.Session(pg, 0, d_err=s["d_err"], skip_confident=s["skip_confident"], all_paths=s["all_paths"],
+                               randseed=s["randseed"])
+        res = sess.fill_batch(_gaps(product, s["gaps"]))
+        diverged = False
+        for r, exp in zip(res, s["expected"]):
+            if exp["q7"]:
+                assert r.flags & product.G2S_GAP_Q7
+            if exp["q7"] or (r.flags & product.G2S_GAP_Q7):
+                diverged = diverged or exp["draws"] != r.draws
+                continue
+            if diverged:
+                continue
+            assert (r.count, r.draws, r.phaseC_count, r.lengths) == (exp["count"], exp["draws"], exp["phaseC_count"],
+                                                                    exp["lengths"]), s["name"]
+            if exp["fill"]:
+                assert (r.left_fuz, r.right_fuz, r.fill) == (exp["left_fuz"], exp["right_fuz"], exp["fill"]), s["name"]
+            if exp["substats"] is not None and exp["phaseC_count"] > 0:
+                assert r.substats == exp["substats"], s["name"]
+            n += 1
+        sess.destroy()
+        pg.free()
+    assert n >= 80
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+def test_k31_default_parameters(product, oracle, variant):
+    """k=31, -fuz 10, -dist-error 500 on a 200 kbp genome: V0 plain, V1 repeats,
+    V2 bubbles, V3 both; device work counters equal the oracle's."""
+    reads = product.G2S.synth_genome(200000, variant, 20240101)
+    seqs = [ln for ln in reads.splitlines() if not ln.startswith(">")]
+    gaps = _parse_scaffolds(product.G2S.synth_gaps(reads, 31, 10, 80, 50, 600, 20240103))
+    c, f, tm, xb, sb = _check_batch(product, oracle, seqs, 31, gaps, 500)
+    assert c == 80 and f >= 70
+    assert (tm.xB, tm.sB) == (xb, sb)
+
+
+def test_wide_kmers_k63_and_even_k(product, oracle):
+    """128-bit k-mer encoding (BASELINE config 4 uses k=63) and an even k (palindromes)."""
+    for k, variant in ((63, 3), (33, 1), (32, 2), (12, 0)):
+        reads = product.G2S.synth_genome(60000, variant, 7)
+        seqs = [ln for ln in reads.splitlines() if not ln.startswith(">")]
+        fuz = 10 if k > 12 else 3
+        gaps = _parse_scaffolds(product.G2S.synth_gaps(reads, k, fuz, 30, 40, 300, 11), fuz)
+        c, f, _, _, _ = _check_batch(product, oracle, seqs, k, gaps, 200 if k > 12 else 40)
+        assert c >= 25 and f >= 15
+
+
+def test_deep_dp_dist_error_2000(product, oracle):
+    """BASELINE config 5 shape (wide rows): -dist-error 2000, gaps of 2-5 kbp, few gaps."""
+    reads = product.G2S.synth_genome(300000, 3, 20240101)
+    seqs = [ln for ln in reads.splitlines() if not ln.startswith(">")]
+    gaps = _parse_scaffolds(product.G2S.synth_gaps(reads, 31, 10, 16, 2000, 5000, 5))
+    c, f, _, _, _ = _check_batch(product, oracle, seqs, 31, gaps, 2000)
+    assert c == 16 and f >= 12
+
+
+def test_unfillable_and_ragged_inputs(product, oracle):
+    k = 15
+    seqs = cases.toy_genome(4, 3000, k, repeats=2)
+    g = seqs[0]
+    other = cases.random_dna(cases.SplitMix(99), 200)
+    gaps = [
+        dict(left=other[:k + 3], right=g[500:500 + k + 3], gap_len=30, lmf=3, rmf=3),   # left flank not in graph
+        dict(left=g[100:100 + k + 3], right=other[50:50 + k + 3], gap_len=30, lmf=3, rmf=3),  # right not in graph
+        dict(left=g[100:100 + k], right=g[140:140 + k], gap_len=40, lmf=0, rmf=0),      # fuz 0 (Q4)
+        dict(left=g[100:100 + k + 2], right=g[2000:2000 + k + 2], gap_len=50, lmf=2, rmf=2),  # too far apart
+        dict(left=g[200:200 + k + 3], right=g[200 + k + 3 + 1:200 + 2 * k + 7], gap_len=1, lmf=3, rmf=3),  # 1 base
+    ]
+    c, f, _, _, _ = _check_batch(product, oracle, seqs, k, gaps, k + 10)
+    assert c >= 4
+    # empty batch and a flank shorter than k + fuz (the reference would throw; D2)
+    pg = product.Graph.from_seqs(seqs, k, 1)
+    sess = product.Session(pg, 0, d_err=30)
+    assert sess.fill_batch([]) == []
+    r = sess.fill_batch([product.Gap(g[:k - 1], g[100:100 + k], 10, 0, 0)])[0]
+    assert r.count == 0 and (r.flags & product.G2S_GAP_BAD_FLANK)
+    sess.destroy()
+    pg.free()
+
+
+def test_table_overflow_retry_and_memory_verdict(product, oracle):
+    """Repeat-rich graph: small first-tier tables overflow and are retried (same
+    results); with a tiny -max-mem the gap ends as -1 'Memory limit exceeded'."""
+    reads = product.G2S.synth_genome(200000, 1, 20240101)
+    seqs = [ln for ln in reads.splitlines() if not ln.startswith(">")]
+    gaps = _parse_scaffolds(product.G2S.synth_gaps(reads, 31, 10, 120, 200, 1000, 3))
+    c, f, tm, _, _ = _check_batch(product, oracle, seqs, 31, gaps, 500)
+    assert c == 120
+    assert tm.retried_gaps > 0 and tm.launches_left_dp >= 2
+    pg = product.Graph.from_seqs(seqs, 31, 1)
+    sess = product.Session(pg, 0, d_err=500, max_mem=1 << 16)  # 1024 states per gap
+    res = sess.fill_batch(_gaps(product, gaps))
+    assert any(r.count == -1 and (r.flags & product.G2S_GAP_MEM_EXCEEDED) for r in res)
+    assert all(r.count == -1 or r.count >= 0 for r in res)
+    sess.destroy()
+    pg.free()
+
+
+def test_scaffold_mode_fasta_and_log_identical(product, oracle):
+    sc = json.load(open(os.path.join(HERE, "golden", "scaffold_cases.json")))
+    pg = product.Graph.from_seqs(sc["seqs"], sc["k"], sc["solid"])
+    modes = dict(default={}, best_only=dict(all_paths=False), all_upper=dict(skip_confident=True),
+                 unique=dict(unique_paths=True))
+    for mode, kw in modes.items():
+        sess = product.Session(pg, 0, d_err=sc["d_err"], randseed=sc["randseed"], **kw)
+        fa, lg, gaps, filled = sess.execute_scaffolds(sc["scaffolds"], sc["k"], solid=sc["solid"],
+                                                      max_fuz=sc["max_fuz"])
+        assert fa == sc["expected"][mode]["fasta"], mode
+        assert lg == sc["expected"][mode]["log"], mode
+        sess.destroy()
+    pg.free()
+
+
+def test_scaffold_mode_many_records_vs_oracle(product, oracle):
+    """Multi-gap scaffolds with close gaps (right_fuz coupling), k < fuz (left_max_fuz
+    coupling -> batch barrier), lower-case n runs."""
+    for k, fuz, e in ((11, 4, 30), (5, 8, 20), (21, 10, 60)):
+        seqs = cases.toy_genome(k, 6000, k, repeats=3, tandem=1, snp_every=211)
+        g = seqs[0]
+        rng = cases.SplitMix(k)
+        recs = []
+        for r in range(25):
+            start = rng.randint(0, 4000)
+            pos = start + k + fuz + 5
+            triples = []
+            for _ in range(rng.randint(1, 4)):
+                ln = rng.randint(1, 40)
+                triples.append((pos, ln, max(1, ln + k + rng.randint(-3, 3))))
+                pos += ln + rng.choice([k + fuz - 1, k + fuz, k + fuz + 1, k + 2 * fuz, 3 * k + 2 * fuz + 7])
+            recs.append(("rec%d extra words" % r, cases.scaffold_record(g, k, fuz, triples)))
+        text = "".join(">%s\n%s\n" % x for x in recs)
+        og = oracle.OracleGraph(seqs, k, 1)
+        pg = product.Graph.from_seqs(seqs, k, 1)
+        for kw in ({}, dict(unique_paths=True), dict(all_paths=False)):
+            ofa, olog, sm = oracle.execute_scaffolds(og, text, k, solid=1, d_err=e, max_fuz=fuz, randseed=9, **kw)
+            if sm.q7_gaps:
+                continue
+            sess = product.Session(pg, 0, d_err=e, randseed=9, **kw)
+            fa, lg, gaps, filled = sess.execute_scaffolds(text, k, solid=1, max_fuz=fuz)
+            sess.destroy()
+            assert fa == ofa
+            assert lg == olog
+            assert (gaps, filled) == (sm.gaps, sm.filled)
+        og.free()
+        pg.free()
+
+
+def test_single_gap_mode(product, oracle):
+    k = 13
+    seqs = cases.toy_genome(8, 2000, k, snp_every=97)
+    g = seqs[0]
+    og = oracle.OracleGraph(seqs, k, 1)
+    pg = product.Graph.from_seqs(seqs, k, 1)
+    for left, right, length in ((g[300:330], g[360:395], 30 + k), (g[300:300 + k], g[340:340 + k], 27 + k),
+                                (g[300:310], g[340:380], 30)):
+        ofa, olog = oracle.execute_single(og, left, right, length, k, solid=1, d_err=40, max_fuz=6, randseed=2)
+        sess = product.Session(pg, 0, d_err=40, randseed=2)
+        fa, lg = sess.execute_single(left, right, length, k, solid=1, max_fuz=6)
+        sess.destroy()
+        assert (fa, lg) == (ofa, olog)
+    og.free()
+    pg.free()
+
+
+def test_full_size_round_trip_c3(product):
+    """BASELINE config 3 size (3 Mbp DBG, 10 000 gaps, k=31, -fuz 10, -dist-error 500) on
+    the repeat-free V0 genome: every gap has exactly one path, so cut -> fill must give
+    back the original bases, all upper case (safe), with 1 path, and the device state
+    count has the closed form of an unbranched chain."""
+    reads = product.G2S.synth_genome(3000000, 0, 20240101)
+    genome = reads.splitlines()[1]
+    gaps = _parse_scaffolds(product.G2S.synth_gaps(reads, 31, 10, 10000, 200, 1000, 20240103))
+    pg = product.Graph.from_seqs([genome], 31, 1)
+    assert pg.num_unitigs == 1
+    sess = product.Session(pg, 0, d_err=500, randseed=1)
+    res, tm = sess.fill_batch(_gaps(product, gaps), True)
+    for g, r in zip(gaps, res):
+        assert r.count == 1 and r.left_fuz == 0 and r.right_fuz == 0 and r.flags == product.G2S_GAP_PHASE_D
+        pos = genome.index(g["left"]) + len(g["left"])
+        assert r.fill == genome[pos:pos + g["gap_len"] + 31]
+        assert r.draws == 1 + g["gap_len"] + 31  # 1 + (L - depth_at_stop), SURVEY A.3
+    assert tm.retried_gaps == 0
+    sess.destroy()
+    pg.free()
+
+
+def test_cli_binary_is_a_drop_in(product, oracle, tmp_path):
+    """gap2seq_amd/Gap2Seq-core with the argv the reference wrapper builds
+    (Gap2Seq.py:230-241) against the oracle CLI: identical FASTA and stdout."""
+    k = 21
+    seqs = cases.toy_genome(12, 20000, k, repeats=4, snp_every=301)
+    reads = tmp_path / "reads.fa"
+    reads.write_text("".join(">r%d\n%s\n" % (i, s) for i, s in enumerate(seqs)))
+    g = seqs[0]
+    recs = []
+    for r in range(20):
+        p = 100 + r * 900
+        recs.append((">sc%d\n" % r) + cases.scaffold_record(g, k, 10, [(p, 50 + r, 50 + r + k), (p + 300, 20, 20 + k)]))
+    scaf = tmp_path / "scaf.fa"
+    scaf.write_text("\n".join(recs) + "\n")
+    outs = {}
+    for name, exe in (("gpu", os.path.join(ROOT, "gap2seq_amd", "Gap2Seq-core")),
+                      ("cpu", os.path.join(os.path.dirname(oracle.ORACLE_SO), "g2s_oracle_cli"))):
+        out = tmp_path / ("out_%s.fa" % name)
+        res = subprocess.run([exe, "-k", str(k), "-fuz", "10", "-solid", "1", "-nb-cores", "1", "-dist-error", "100",
+                              "-max-mem", "20", "-randseed", "4", "-reads", str(reads), "-filled", str(out),
+                              "-scaffolds", str(scaf)], capture_output=True, text=True, timeout=300)
+        assert res.returncode == 0, res.stdout + res.stderr
+        outs[name] = (out.read_text(), res.stdout.replace(str(out), "OUT"))
+    assert outs["gpu"][0] == outs["cpu"][0]
+    assert outs["gpu"][1] == outs["cpu"][1]
+    assert "Filled 40 gaps out of 40" in outs["gpu"][1] or "Filled" in outs["gpu"][1]
