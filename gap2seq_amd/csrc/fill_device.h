@@ -15,6 +15,7 @@
 #define G2S_DEV_Q7_B 0x2u        /* both strands of a k-mer at one DP level        */
 #define G2S_DEV_OVERFLOW_A 0x4u  /* right-set tables too small for this gap        */
 #define G2S_DEV_OVERFLOW_B 0x8u  /* state tables too small for this gap            */
+#define G2S_DEV_Q7_D 0x10u       /* both strands of a k-mer at one level of the backward sweep */
 
 struct GapDev {
   int32_t g;           // gap_len
@@ -34,7 +35,24 @@ struct GapDev {
   uint64_t rlog_off;
   uint64_t st_off;
   uint64_t slog_off;
-  uint64_t lvl_off;    // D+2 entries
+};
+
+/* SubState.flags */
+#define G2S_SUB_IN_S 0x1u     /* on a path to a sink of the reference's subgraph (D1/D2)      */
+#define G2S_SUB_IN_T 0x2u     /* reachable backwards from a traceback start (D3)              */
+#define G2S_SUB_SOURCE 0x4u   /* depth <= lmf and k-mer == left flank k-mer at that offset    */
+#define G2S_SUB_SINK 0x8u     /* has an edge to the sink pseudo-vertex                        */
+#define G2S_SUB_START_T 0x10u /* (reachedTarget, pathLengths[i])                              */
+
+/* One state of the backward closure that phase D works on, in discovery order
+ * (depth descending).  pred[i] = index (within the gap's array) of the state of
+ * graph.predecessors(node)[i] at depth-1 when that state is set, else -1. */
+struct SubState {
+  uint32_t node;
+  uint32_t depth;
+  uint32_t cnt;
+  uint32_t flags;
+  int32_t pred[4];
 };
 
 struct GapOut {
@@ -48,6 +66,8 @@ struct GapOut {
   int32_t n_len;       // pathLengths.size()
   int32_t len[2];
   int32_t reached_j;   // reachedFuz
+  uint32_t n_sub;      // states in the backward closure (phase D input)
+  uint64_t sub_off;    // offset of this gap's SubState array in the packed output
+  uint32_t x_sub;      // expansions done by the backward sweep
   uint32_t pad;
-  uint64_t out_off;    // offset of this gap's packed (node<<32|count) log in out_states
 };

@@ -196,9 +196,7 @@ __global__ __launch_bounds__(64) void g2s_left_dp(const uint32_t* __restrict__ s
                                                    const uint32_t* __restrict__ gap_ids,
                                                    const uint32_t* __restrict__ flank_nodes,
                                                    const uint32_t* __restrict__ rs_all, uint64_t* st_keys_all,
-                                                   uint32_t* st_cnt_all, uint32_t* slog_all, uint32_t* lvl_all,
-                                                   uint64_t* out_states, unsigned long long* out_counter,
-                                                   GapOut* outs) {
+                                                   uint32_t* st_cnt_all, uint32_t* slog_all, GapOut* outs) {
   const uint32_t gi = __builtin_amdgcn_readfirstlane(gap_ids[blockIdx.x]);
   const GapDev gd = gaps[gi];
   const int lane = threadIdx.x;
@@ -211,7 +209,6 @@ __global__ __launch_bounds__(64) void g2s_left_dp(const uint32_t* __restrict__ s
   uint64_t* keys = st_keys_all + gd.st_off;
   uint32_t* cnt = st_cnt_all + gd.st_off;
   uint32_t* log = slog_all + gd.slog_off;
-  uint32_t* lvl = lvl_all + gd.lvl_off;
   const uint32_t smask = gd.st_mask, cap = gd.slog_cap;
   const uint32_t* lseeds = flank_nodes + gd.flank_off;
   const uint32_t* targets = lseeds + (uint32_t)(gd.lmf + 1) + (uint32_t)(gd.rmf + 1);
@@ -229,7 +226,6 @@ __global__ __launch_bounds__(64) void g2s_left_dp(const uint32_t* __restrict__ s
       nlog = 1;
     }
   }
-  if (lane == 0) { lvl[0] = 0; lvl[1] = nlog; }
   wave_mem_fence();
 
   uint32_t bstart = 0, bend = nlog;
@@ -291,7 +287,6 @@ __global__ __launch_bounds__(64) void g2s_left_dp(const uint32_t* __restrict__ s
         wave_mem_fence();
       }
     }
-    if (lane == 0) lvl[d + 1] = nlog;
 
     // ---- phase C: target check (:1107-1159) --------------------------------
     if (!found && d >= gd.g + gd.lmf + gd.rmf) {
@@ -328,27 +323,9 @@ __global__ __launch_bounds__(64) void g2s_left_dp(const uint32_t* __restrict__ s
     }
   }
   const int final_d = d;  // currentD when the reference's while loop ends (D+1 unless -best-only broke out)
-  int last_level = d > gd.D ? gd.D : d;
-  if (overflow) { lflags |= G2S_DEV_OVERFLOW_B; last_level = d - 1; }
+  if (overflow) lflags |= G2S_DEV_OVERFLOW_B;
   for (int o = 32; o > 0; o >>= 1) lflags |= __shfl_xor(lflags, o);
   flags |= lflags;
-  if (flags & G2S_DEV_OVERFLOW_B) {
-    if (lane == 0) { go->flags = flags; go->n_states = nlog; go->x_left = xcount; go->final_d = final_d; }
-    return;
-  }
-  // levels that were never reached (-best-only break) are empty
-  for (int dd = last_level + 2 + lane; dd <= gd.D + 1; dd += 64) lvl[dd] = nlog;
-
-  // ---- pack this gap's state log: (node << 32 | count) in log order ---------
-  unsigned long long base = 0;
-  if (lane == 0) base = atomicAdd(out_counter, (unsigned long long)nlog);
-  base = __shfl(base, 0);
-  for (uint32_t i = (uint32_t)lane; i < nlog; i += 64u) {
-    const uint32_t pos = ld32(&log[i]);
-    uint32_t c = ld32(&cnt[pos]);
-    if (c > G2S_DEV_MAX_PATHS) c = G2S_DEV_MAX_PATHS;
-    out_states[base + i] = (ld64(&keys[pos]) & 0xFFFFFFFF00000000ull) | (uint64_t)c;
-  }
   if (lane == 0) {
     go->flags = flags;
     go->n_states = nlog;
@@ -359,7 +336,160 @@ __global__ __launch_bounds__(64) void g2s_left_dp(const uint32_t* __restrict__ s
     go->len[0] = len0;
     go->len[1] = len1;
     go->reached_j = reached_j;
-    go->out_off = base;
+  }
+}
+
+// ============================================================================
+// Phase D1 — backward closure over (node, depth) states
+// (Gap2Seq.cpp:1169-1312), plus the closure the traceback (:1437-1517) can
+// reach from (reachedTarget, pathLengths[i]).  One wave per gap, depth loop in
+// the kernel, 4 lanes per border state (one per predecessor slot).  Output: a
+// packed SubState array per gap; the host runs SCC / branch rule / traceback on it.
+// ============================================================================
+namespace {
+// lanes with pos != INVALID claim their state; first claimer appends it to sub[].
+__device__ __forceinline__ uint32_t sub_discover(uint32_t pos, uint32_t node, int depth, const uint32_t* cnt,
+                                                 uint32_t* mark, SubState* sub, uint32_t nsub, uint32_t cap, int lane) {
+  uint32_t won = 0;
+  if (pos != G2S_DEV_INVALID) won = (atomicCAS(&mark[pos], 0u, 0xFFFFFFFFu) == 0u);
+  const uint64_t m = __ballot(won);
+  if (won) {
+    const uint32_t idx = nsub + (uint32_t)__popcll(m & lanes_below(lane));
+    if (idx < cap) {
+      uint32_t c = ld32(&cnt[pos]);
+      if (c > G2S_DEV_MAX_PATHS) c = G2S_DEV_MAX_PATHS;
+      SubState st;
+      st.node = node; st.depth = (uint32_t)depth; st.cnt = c; st.flags = 0;
+      st.pred[0] = st.pred[1] = st.pred[2] = st.pred[3] = -1;
+      sub[idx] = st;
+    }
+    __hip_atomic_store(&mark[pos], idx + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  return nsub + (uint32_t)__popcll(m);
+}
+}  // namespace
+
+__global__ __launch_bounds__(64) void g2s_extract(const uint32_t* __restrict__ succ,
+                                                   const uint32_t* __restrict__ predtab,
+                                                   const GapDev* __restrict__ gaps,
+                                                   const uint32_t* __restrict__ gap_ids,
+                                                   const uint32_t* __restrict__ flank_nodes,
+                                                   const uint64_t* st_keys_all, const uint32_t* st_cnt_all,
+                                                   uint32_t* st_mark_all, SubState* sub_scratch, SubState* sub_out,
+                                                   unsigned long long* out_counter, GapOut* outs,
+                                                   int skip_confident) {
+  const uint32_t gi = __builtin_amdgcn_readfirstlane(gap_ids[blockIdx.x]);
+  const GapDev gd = gaps[gi];
+  const int lane = threadIdx.x;
+  GapOut* go = &outs[gi];
+  const uint32_t gflags = go->flags;
+  const int c_count = go->c_count, n_len = go->n_len;
+  if ((gflags & (G2S_DEV_OVERFLOW_A | G2S_DEV_OVERFLOW_B)) || !(c_count > 0 && n_len > 0)) return;  // :1169
+
+  const uint64_t* keys = st_keys_all + gd.st_off;
+  const uint32_t* cnt = st_cnt_all + gd.st_off;
+  uint32_t* mark = st_mark_all + gd.st_off;
+  SubState* sub = sub_scratch + gd.slog_off;
+  const uint32_t smask = gd.st_mask, cap = gd.slog_cap;
+  const uint32_t* lseeds = flank_nodes + gd.flank_off;
+  const uint32_t* targets = lseeds + (uint32_t)(gd.lmf + 1) + (uint32_t)(gd.rmf + 1);
+  const int len0 = go->len[0], len1 = go->len[1];
+  const uint32_t reached = targets[go->reached_j];
+  // all-paths mode: the only sink k-mer is kmer_right[rmf-1..] (Q3), none when rmf == 0 (Q4)
+  const bool want_s = !skip_confident;
+  const uint32_t sinknode = (want_s && gd.all_paths && gd.rmf >= 1) ? targets[gd.rmf - 1] : G2S_DEV_INVALID;
+  const int lo_sink = max(0, gd.lmf + gd.g - gd.e);  // :1196
+  const uint32_t t_flags = G2S_SUB_IN_T | G2S_SUB_START_T | ((want_s && !gd.all_paths) ? (G2S_SUB_IN_S | G2S_SUB_SINK) : 0u);
+
+  uint32_t nsub = 0, bstart = 0, xcount = 0, lflags = 0;
+  int win_lo = gd.D + 1;      // depths [win_lo, win_lo+63] have been probed for the sink state
+  uint64_t sink_mask = 0;
+  const int min_len = n_len > 1 ? min(len0, len1) : len0;
+  for (int d2 = gd.D; d2 >= 0; d2--) {
+    // ---- new paths starting at this depth (:1195-1259) -----------------------
+    if (sinknode != G2S_DEV_INVALID && d2 >= lo_sink && d2 < win_lo) {
+      win_lo = max(0, d2 - 63);
+      const int dd = win_lo + lane;
+      const bool hit = dd <= d2 && dd >= lo_sink && st_find(keys, smask, state_key(sinknode, dd)) != G2S_DEV_INVALID;
+      sink_mask = __ballot(hit);
+    }
+    const bool s_here = sinknode != G2S_DEV_INVALID && d2 >= lo_sink && ((sink_mask >> (d2 - win_lo)) & 1ull);
+    const bool t_here = (d2 == len0) || (n_len > 1 && d2 == len1);
+    if (s_here || t_here) {
+      uint32_t pos = G2S_DEV_INVALID, node = G2S_DEV_INVALID, f = 0;
+      if (lane == 0 && s_here) { node = sinknode; f = G2S_SUB_IN_S | G2S_SUB_SINK; }
+      if (lane == 1 && t_here) { node = reached; f = t_flags; }
+      if (node != G2S_DEV_INVALID) pos = st_find(keys, smask, state_key(node, d2));
+      nsub = sub_discover(pos, node, d2, cnt, mark, sub, nsub, cap, lane);
+      if (nsub > cap) { lflags |= G2S_DEV_OVERFLOW_B; break; }
+      wave_mem_fence();
+      if (pos != G2S_DEV_INVALID) atomicOr(&sub[ld32(&mark[pos]) - 1u].flags, f);
+      wave_mem_fence();
+    }
+    const uint32_t bend = nsub, nb = bend - bstart;
+    if (nb == 0) {
+      if (d2 < min_len && (sinknode == G2S_DEV_INVALID || d2 < lo_sink)) break;  // nothing can start below
+      continue;
+    }
+    xcount += nb;
+    const uint32_t lidx = (d2 <= gd.lmf) ? (lseeds[d2] >> 1) : 0xFFFFFFFFu;  // buildNode(kmer_left.substr(d2,k))
+    // pass 1: claim predecessor states; pass 2: link + propagate closure flags
+    for (int pass = 0; pass < 2; pass++) {
+      for (uint32_t i0 = 0; i0 < nb * 4u; i0 += 64u) {
+        const uint32_t i = i0 + (uint32_t)lane;
+        uint32_t pos = G2S_DEV_INVALID, p = G2S_DEV_INVALID, f = 0, si = 0, nt = 0;
+        if (i < nb * 4u) {
+          si = bstart + (i >> 2);
+          nt = i & 3u;
+          const uint32_t cur = ld32(&sub[si].node);
+          f = ld32(&sub[si].flags) & (G2S_SUB_IN_S | G2S_SUB_IN_T);
+          if (d2 <= gd.lmf && (cur >> 1) == lidx) {  // :1270 end condition, k-mer comparison only
+            if (pass == 0 && nt == 0) atomicOr(&sub[si].flags, G2S_SUB_SOURCE);
+          } else if (d2 > 0) {
+            p = predtab ? predtab[(size_t)cur * 4 + nt] : flip(succ[(size_t)(cur ^ 1u) * 4 + nt]);
+            if (p != G2S_DEV_INVALID) pos = st_find(keys, smask, state_key(p, d2 - 1));
+          }
+        }
+        if (pass == 0) {
+          nsub = sub_discover(pos, p, d2 - 1, cnt, mark, sub, nsub, cap, lane);
+        } else if (pos != G2S_DEV_INVALID) {
+          const uint32_t idx = ld32(&mark[pos]) - 1u;
+          if (idx < cap) {
+            sub[si].pred[nt] = (int32_t)idx;
+            atomicOr(&sub[idx].flags, f);
+          }
+          const uint32_t pos2 = st_find(keys, smask, state_key(p ^ 1u, d2 - 1));  // Q7: other strand in this border?
+          if (pos2 != G2S_DEV_INVALID && ld32(&mark[pos2]) != 0u) lflags |= G2S_DEV_Q7_D;
+        }
+      }
+      if (nsub > cap) break;
+      wave_mem_fence();
+    }
+    if (nsub > cap) { lflags |= G2S_DEV_OVERFLOW_B; break; }
+    bstart = bend;
+  }
+  for (int o = 32; o > 0; o >>= 1) lflags |= __shfl_xor(lflags, o);
+  if (lflags & G2S_DEV_OVERFLOW_B) {
+    if (lane == 0) go->flags = gflags | lflags;
+    return;
+  }
+  // ---- pack: reserve exactly n_sub records in the dense output --------------------
+  unsigned long long base = 0;
+  if (lane == 0) base = atomicAdd(out_counter, (unsigned long long)nsub);
+  base = __shfl(base, 0);
+  const uint4* src = (const uint4*)sub;
+  uint4* dst = (uint4*)(sub_out + base);
+  for (uint32_t i = (uint32_t)lane; i < nsub * 2u; i += 64u) {
+    uint4 v;
+    v.x = ld32((const uint32_t*)&src[i] + 0); v.y = ld32((const uint32_t*)&src[i] + 1);
+    v.z = ld32((const uint32_t*)&src[i] + 2); v.w = ld32((const uint32_t*)&src[i] + 3);
+    dst[i] = v;
+  }
+  if (lane == 0) {
+    go->flags = gflags | lflags;
+    go->n_sub = nsub;
+    go->sub_off = base;
+    go->x_sub = xcount;
   }
 }
 
@@ -379,11 +509,21 @@ hipError_t launch_right_bfs(hipStream_t st, uint32_t ngaps, const uint32_t* succ
 
 hipError_t launch_left_dp(hipStream_t st, uint32_t ngaps, const uint32_t* succ, const GapDev* gaps,
                           const uint32_t* gap_ids, const uint32_t* flank_nodes, const uint32_t* rs_all,
-                          uint64_t* st_keys_all, uint32_t* st_cnt_all, uint32_t* slog_all, uint32_t* lvl_all,
-                          uint64_t* out_states, unsigned long long* out_counter, GapOut* outs) {
+                          uint64_t* st_keys_all, uint32_t* st_cnt_all, uint32_t* slog_all, GapOut* outs) {
   if (ngaps == 0) return hipSuccess;
   hipLaunchKernelGGL(g2s_left_dp, dim3(ngaps), dim3(64), 0, st, succ, gaps, gap_ids, flank_nodes, rs_all, st_keys_all,
-                     st_cnt_all, slog_all, lvl_all, out_states, out_counter, outs);
+                     st_cnt_all, slog_all, outs);
+  return hipGetLastError();
+}
+
+hipError_t launch_extract(hipStream_t st, uint32_t ngaps, const uint32_t* succ, const uint32_t* predtab,
+                          const GapDev* gaps, const uint32_t* gap_ids, const uint32_t* flank_nodes,
+                          const uint64_t* st_keys_all, const uint32_t* st_cnt_all, uint32_t* st_mark_all,
+                          SubState* sub_scratch, SubState* sub_out, unsigned long long* out_counter, GapOut* outs,
+                          int skip_confident) {
+  if (ngaps == 0) return hipSuccess;
+  hipLaunchKernelGGL(g2s_extract, dim3(ngaps), dim3(64), 0, st, succ, predtab, gaps, gap_ids, flank_nodes, st_keys_all,
+                     st_cnt_all, st_mark_all, sub_scratch, sub_out, out_counter, outs, skip_confident);
   return hipGetLastError();
 }
 

@@ -14,7 +14,13 @@ hipError_t launch_right_bfs(hipStream_t st, uint32_t ngaps, const uint32_t* succ
 
 hipError_t launch_left_dp(hipStream_t st, uint32_t ngaps, const uint32_t* succ, const GapDev* gaps,
                           const uint32_t* gap_ids, const uint32_t* flank_nodes, const uint32_t* rs_all,
-                          uint64_t* st_keys_all, uint32_t* st_cnt_all, uint32_t* slog_all, uint32_t* lvl_all,
-                          uint64_t* out_states, unsigned long long* out_counter, GapOut* outs);
+                          uint64_t* st_keys_all, uint32_t* st_cnt_all, uint32_t* slog_all, GapOut* outs);
+
+// phase D1 on the device (Gap2Seq.cpp:1169-1312) + the traceback's closure
+hipError_t launch_extract(hipStream_t st, uint32_t ngaps, const uint32_t* succ, const uint32_t* predtab,
+                          const GapDev* gaps, const uint32_t* gap_ids, const uint32_t* flank_nodes,
+                          const uint64_t* st_keys_all, const uint32_t* st_cnt_all, uint32_t* st_mark_all,
+                          SubState* sub_scratch, SubState* sub_out, unsigned long long* out_counter, GapOut* outs,
+                          int skip_confident);
 
 }  // namespace g2s

@@ -12,7 +12,10 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -226,14 +229,92 @@ inline uint32_t pow2ceil(uint64_t x) {
 
 }  // namespace
 
+// Persistent host workers for the per-gap post-processing (spawning threads per
+// batch costs more than the work at 500 gaps per batch).
+class WorkerPool {
+ public:
+  explicit WorkerPool(int nthreads) {
+    for (int t = 0; t < nthreads; t++) th_.emplace_back([this]() { loop(); });
+  }
+  ~WorkerPool() {
+    { std::lock_guard<std::mutex> lk(mu_); stop_ = true; gen_++; }
+    cv_.notify_all();
+    for (auto& t : th_) t.join();
+  }
+  int size() const { return (int)th_.size(); }
+  // f(i) for i in [0,n); the calling thread helps
+  void run(size_t n, const std::function<void(size_t)>& f) {
+    if (n == 0) return;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      fn_ = &f; n_ = n; next_.store(0); pending_ = (int)th_.size(); gen_++;
+    }
+    cv_.notify_all();
+    drain();
+    std::unique_lock<std::mutex> lk(mu_);
+    done_.wait(lk, [this]() { return pending_ == 0; });
+    fn_ = nullptr;
+  }
+ private:
+  void drain() {
+    while (true) {
+      const size_t i = next_.fetch_add(1);
+      if (i >= n_) break;
+      (*fn_)(i);
+    }
+  }
+  void loop() {
+    uint64_t seen = 0;
+    while (true) {
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&]() { return gen_ != seen; });
+        seen = gen_;
+        if (stop_) return;
+      }
+      drain();
+      { std::lock_guard<std::mutex> lk(mu_); if (--pending_ == 0) done_.notify_all(); }
+    }
+  }
+  std::vector<std::thread> th_;
+  std::mutex mu_;
+  std::condition_variable cv_, done_;
+  const std::function<void(size_t)>* fn_ = nullptr;
+  size_t n_ = 0;
+  std::atomic<size_t> next_{0};
+  int pending_ = 0;
+  uint64_t gen_ = 0;
+  bool stop_ = false;
+};
+
+// The session's rand() stream, materialised ahead of use so that tracebacks of
+// different gaps can read their draws at known offsets in parallel.
+struct RandCache {
+  GlibcRand rng;
+  std::vector<int32_t> buf;
+  size_t head = 0;  // buf[head] is the next undrawn value of the stream
+  void seed(uint32_t s) { rng.seed(s); buf.clear(); head = 0; }
+  void ensure(size_t n) {  // at least n values available from head
+    if (buf.size() - head >= n) return;
+    if (head > (1u << 20)) { buf.erase(buf.begin(), buf.begin() + (ptrdiff_t)head); head = 0; }
+    size_t want = head + n + (n >> 2) + 4096;
+    buf.reserve(want);
+    while (buf.size() < want) buf.push_back((int32_t)rng.next());
+  }
+  int32_t at(size_t off) { ensure(off + 1); return buf[head + off]; }
+  const int32_t* ptr(size_t off) const { return buf.data() + head + off; }
+  void consume(size_t n) { head += n; }
+};
+
 struct g2s_session {
   g2s_graph* graph = nullptr;
   int device = 0;
   hipStream_t stream = nullptr;
   g2s_params params;
-  GlibcRand rng;
+  RandCache rcache;
+  WorkerPool* pool = nullptr;
   size_t mem_budget = 0;  // bytes of HBM this session may use for work areas
-  DevBuf d_gaps, d_ids, d_flank, d_outs, d_rs, d_rlog, d_keys, d_cnt, d_slog, d_lvl, d_states, d_counter;
+  DevBuf d_gaps, d_ids, d_flank, d_outs, d_rs, d_rlog, d_keys, d_cnt, d_mark, d_slog, d_subscr, d_subout, d_counter;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 
@@ -246,13 +327,18 @@ extern "C" int g2s_session_create(g2s_graph* g, int device, const g2s_params* p,
   s->graph = g;
   s->device = device;
   s->params = *p;
-  s->rng.seed(p->randseed);
+  s->rcache.seed(p->randseed);
   hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
   for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipEventCreate(&s->ev[i]);
   size_t free_b = 0, total_b = 0;
   if (e == hipSuccess) e = hipMemGetInfo(&free_b, &total_b);
   if (e != hipSuccess) { delete s; return fail(G2S_ERR_HIP, std::string("session setup: ") + hipGetErrorString(e)); }
   s->mem_budget = (size_t)((double)free_b * 0.6);
+  {
+    int nth = p->host_threads > 0 ? p->host_threads : (int)std::thread::hardware_concurrency();
+    nth = std::max(1, std::min(nth, 32));
+    s->pool = new WorkerPool(nth - 1);
+  }
   *out = s;
   return G2S_OK;
 }
@@ -260,24 +346,24 @@ extern "C" int g2s_session_create(g2s_graph* g, int device, const g2s_params* p,
 extern "C" void g2s_session_destroy(g2s_session* s) {
   if (!s) return;
   (void)hipSetDevice(s->device);
-  DevBuf* bufs[] = {&s->d_gaps, &s->d_ids, &s->d_flank, &s->d_outs, &s->d_rs, &s->d_rlog,
-                    &s->d_keys, &s->d_cnt, &s->d_slog, &s->d_lvl, &s->d_states, &s->d_counter};
+  DevBuf* bufs[] = {&s->d_gaps, &s->d_ids, &s->d_flank, &s->d_outs, &s->d_rs, &s->d_rlog, &s->d_keys,
+                    &s->d_cnt, &s->d_mark, &s->d_slog, &s->d_subscr, &s->d_subout, &s->d_counter};
   for (DevBuf* b : bufs) b->release();
+  delete s->pool;
   for (int i = 0; i < 4; i++) if (s->ev[i]) (void)hipEventDestroy(s->ev[i]);
   if (s->stream) (void)hipStreamDestroy(s->stream);
   delete s;
 }
 
-extern "C" void g2s_session_srand(g2s_session* s, uint32_t seed) { if (s) s->rng.seed(seed); }
+extern "C" void g2s_session_srand(g2s_session* s, uint32_t seed) { if (s) s->rcache.seed(seed); }
 
 // ---------------------------------------------------------------------------
 // batch
 // ---------------------------------------------------------------------------
 namespace {
 struct TierData {  // what came back from one launch group
-  PinBuf outs, lvl, states;
+  PinBuf outs, subs;
   std::vector<uint32_t> gap_ids;
-  std::vector<uint64_t> lvl_off;  // per listed gap, into lvl
 };
 }  // namespace
 
@@ -288,9 +374,11 @@ struct g2s_batch {
   size_t arena_bytes = 0;
   g2s_timing timing;
   std::vector<TierData*> tiers;
-  ~g2s_batch() {
-    for (TierData* t : tiers) { t->outs.release(); t->lvl.release(); t->states.release(); delete t; }
+  void drop_tiers() {
+    for (TierData* t : tiers) { t->outs.release(); t->subs.release(); delete t; }
+    tiers.clear();
   }
+  ~g2s_batch() { drop_tiers(); }
 };
 
 extern "C" int g2s_batch_prepare(g2s_session* s, const g2s_gap* gaps, size_t n, g2s_batch** out) {
@@ -359,30 +447,29 @@ struct Plan {  // per-gap capacities at one scale
 Plan plan_gap(const GapJob& j, int d_err, uint64_t scale, uint64_t max_states) {
   const int right_half = j.rmf + (j.g + d_err + 1) / 2;
   const int D = j.lmf + j.rmf + j.g + d_err;
-  uint64_t r = (uint64_t)pow2ceil(std::max<uint64_t>(256, 2ull * (uint64_t)(right_half + j.rmf + 2))) * scale;
-  uint64_t st = (uint64_t)pow2ceil(std::max<uint64_t>(512, 2ull * (uint64_t)(D + 2))) * scale;
+  uint64_t r = (uint64_t)pow2ceil(std::max<uint64_t>(256, 4ull * (uint64_t)(right_half + j.rmf + 2))) * scale;
+  uint64_t st = (uint64_t)pow2ceil(std::max<uint64_t>(512, 4ull * (uint64_t)(D + 2))) * scale;
   const uint64_t lim = std::max<uint64_t>(1024, std::min<uint64_t>(max_states, 1u << 28));
   uint64_t limp = 1;
   while (limp * 2 <= lim) limp <<= 1;
   Plan p;
   p.rlog_cap = (uint32_t)std::min(r, limp);
   p.slog_cap = (uint32_t)std::min(st, limp);
-  p.bytes = (uint64_t)p.rlog_cap * (8 + 4) + (uint64_t)p.slog_cap * (2 * 12 + 4 + 8) + (uint64_t)(D + 2) * 4;
+  // right set (hash + log), state table (keys, counts, marks), state log, closure scratch + packed output
+  p.bytes = (uint64_t)p.rlog_cap * (8 + 4) + (uint64_t)p.slog_cap * (2 * 16 + 4 + 2 * sizeof(SubState));
   return p;
 }
 
-// Launch phases A-C for the listed gaps at one table scale and bring the results back.
+// Launch phases A-D1 for the listed gaps at one table scale and bring the results back.
 int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uint64_t max_states, TierData* td) {
   g2s_session* s = b->s;
-  const Graph& g = *s->graph->g;
   const DeviceGraph& dg = s->graph->g->dev.at(s->device);
   const size_t n = b->jobs.size();
   const int d_err = s->params.d_err;
   std::vector<GapDev> gd(n);
   memset(gd.data(), 0, n * sizeof(GapDev));
-  uint64_t rs_total = 0, rlog_total = 0, st_total = 0, slog_total = 0, lvl_total = 0;
+  uint64_t rs_total = 0, rlog_total = 0, st_total = 0, slog_total = 0;
   td->gap_ids = ids;
-  td->lvl_off.resize(ids.size());
   for (size_t x = 0; x < ids.size(); x++) {
     const uint32_t i = ids[x];
     const GapJob& j = b->jobs[i];
@@ -400,9 +487,7 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
     d.rlog_off = rlog_total; rlog_total += p.rlog_cap;
     d.st_off = st_total; st_total += 2ull * p.slog_cap;
     d.slog_off = slog_total; slog_total += p.slog_cap;
-    d.lvl_off = lvl_total; td->lvl_off[x] = lvl_total; lvl_total += (uint64_t)(d.D + 2);
   }
-  (void)g;
   HIP_TRY(s->d_gaps.ensure(n * sizeof(GapDev)));
   HIP_TRY(s->d_ids.ensure(std::max<size_t>(ids.size() * 4, 16)));
   HIP_TRY(s->d_outs.ensure(n * sizeof(GapOut)));
@@ -410,9 +495,10 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
   HIP_TRY(s->d_rlog.ensure(rlog_total * 4));
   HIP_TRY(s->d_keys.ensure(st_total * 8));
   HIP_TRY(s->d_cnt.ensure(st_total * 4));
+  HIP_TRY(s->d_mark.ensure(st_total * 4));
   HIP_TRY(s->d_slog.ensure(slog_total * 4));
-  HIP_TRY(s->d_lvl.ensure(lvl_total * 4));
-  HIP_TRY(s->d_states.ensure(slog_total * 8));
+  HIP_TRY(s->d_subscr.ensure(slog_total * sizeof(SubState)));
+  HIP_TRY(s->d_subout.ensure(slog_total * sizeof(SubState)));
   HIP_TRY(s->d_counter.ensure(16));
   hipStream_t st = s->stream;
   HIP_TRY(hipMemcpyAsync(s->d_gaps.p, gd.data(), n * sizeof(GapDev), hipMemcpyHostToDevice, st));
@@ -421,6 +507,7 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
   HIP_TRY(hipMemsetAsync(s->d_rs.p, 0xFF, rs_total * 4, st));
   HIP_TRY(hipMemsetAsync(s->d_keys.p, 0xFF, st_total * 8, st));
   HIP_TRY(hipMemsetAsync(s->d_cnt.p, 0, st_total * 4, st));
+  HIP_TRY(hipMemsetAsync(s->d_mark.p, 0, st_total * 4, st));
   HIP_TRY(hipMemsetAsync(s->d_counter.p, 0, 16, st));
 
   HIP_TRY(hipEventRecord(s->ev[0], st));
@@ -430,22 +517,25 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
   HIP_TRY(hipEventRecord(s->ev[1], st));
   HIP_TRY(launch_left_dp(st, (uint32_t)ids.size(), dg.succ, (const GapDev*)s->d_gaps.p, (const uint32_t*)s->d_ids.p,
                          (const uint32_t*)s->d_flank.p, (const uint32_t*)s->d_rs.p, (uint64_t*)s->d_keys.p,
-                         (uint32_t*)s->d_cnt.p, (uint32_t*)s->d_slog.p, (uint32_t*)s->d_lvl.p,
-                         (uint64_t*)s->d_states.p, (unsigned long long*)s->d_counter.p, (GapOut*)s->d_outs.p));
+                         (uint32_t*)s->d_cnt.p, (uint32_t*)s->d_slog.p, (GapOut*)s->d_outs.p));
   HIP_TRY(hipEventRecord(s->ev[2], st));
+  HIP_TRY(launch_extract(st, (uint32_t)ids.size(), dg.succ, dg.pred, (const GapDev*)s->d_gaps.p,
+                         (const uint32_t*)s->d_ids.p, (const uint32_t*)s->d_flank.p, (const uint64_t*)s->d_keys.p,
+                         (const uint32_t*)s->d_cnt.p, (uint32_t*)s->d_mark.p, (SubState*)s->d_subscr.p,
+                         (SubState*)s->d_subout.p, (unsigned long long*)s->d_counter.p, (GapOut*)s->d_outs.p,
+                         s->params.skip_confident ? 1 : 0));
+  HIP_TRY(hipEventRecord(s->ev[3], st));
 
-  // device -> host: per-gap results, level offsets, then the packed state logs
-  auto t0 = std::chrono::steady_clock::now();
+  // device -> host: per-gap results, then the packed closures
   HIP_TRY(td->outs.ensure(n * sizeof(GapOut)));
-  HIP_TRY(td->lvl.ensure(std::max<uint64_t>(lvl_total * 4, 16)));
-  unsigned long long total_states = 0;
+  unsigned long long total_sub = 0;
   HIP_TRY(hipMemcpyAsync(td->outs.p, s->d_outs.p, n * sizeof(GapOut), hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(td->lvl.p, s->d_lvl.p, lvl_total * 4, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(&total_states, s->d_counter.p, 8, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(&total_sub, s->d_counter.p, 8, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
-  HIP_TRY(td->states.ensure(std::max<uint64_t>(total_states * 8, 16)));
-  if (total_states)
-    HIP_TRY(hipMemcpyAsync(td->states.p, s->d_states.p, total_states * 8, hipMemcpyDeviceToHost, st));
+  auto t0 = std::chrono::steady_clock::now();
+  HIP_TRY(td->subs.ensure(std::max<uint64_t>(total_sub * sizeof(SubState), 16)));
+  if (total_sub)
+    HIP_TRY(hipMemcpyAsync(td->subs.p, s->d_subout.p, total_sub * sizeof(SubState), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   b->timing.ms_d2h += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   float ms = 0;
@@ -453,6 +543,8 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
   b->timing.ms_right_bfs += ms;
   HIP_TRY(hipEventElapsedTime(&ms, s->ev[1], s->ev[2]));
   b->timing.ms_left_dp += ms;
+  HIP_TRY(hipEventElapsedTime(&ms, s->ev[2], s->ev[3]));
+  b->timing.ms_extract += ms;
   b->timing.launches_left_dp++;
   return G2S_OK;
 }
@@ -467,8 +559,7 @@ extern "C" int g2s_batch_run(g2s_batch* b, g2s_result* results, char* arena, siz
   const Graph& g = *s->graph->g;
   const size_t n = b->jobs.size();
   auto t_begin = std::chrono::steady_clock::now();
-  for (TierData* t : b->tiers) { t->outs.release(); t->lvl.release(); t->states.release(); delete t; }
-  b->tiers.clear();
+  b->drop_tiers();
   g2s_timing keep = b->timing;
   memset(&b->timing, 0, sizeof b->timing);
   b->timing.flank_bytes = keep.flank_bytes;
@@ -484,18 +575,17 @@ extern "C" int g2s_batch_run(g2s_batch* b, g2s_result* results, char* arena, siz
 
   memset(results, 0, n * sizeof(g2s_result));
   memset(arena, 0, b->arena_bytes);
-  std::vector<DpView> views(n);
+  std::vector<SubView> views(n);
   std::vector<char> mem_exceeded(n, 0);
 
-  // ---- GPU: phases A-C, retrying gaps whose tables overflowed with 8x larger ones
+  // ---- GPU: phases A-D1, retrying gaps whose tables overflowed with 8x larger ones
   std::vector<uint32_t> todo;
   for (size_t i = 0; i < n; i++) if (!b->jobs[i].bad_flank) todo.push_back((uint32_t)i);
   uint64_t scale = 1;
   while (!todo.empty()) {
-    // split into groups that fit the session's HBM budget
     std::vector<uint32_t> next_todo;
     size_t pos = 0;
-    while (pos < todo.size()) {
+    while (pos < todo.size()) {  // groups that fit the session's HBM budget
       std::vector<uint32_t> group;
       uint64_t bytes = 0;
       while (pos < todo.size()) {
@@ -521,13 +611,13 @@ extern "C" int g2s_batch_run(g2s_batch* b, g2s_result* results, char* arena, siz
             next_todo.push_back(i);
           continue;
         }
-        DpView& v = views[i];
+        SubView& v = views[i];
         v.out = &go;
-        v.D = b->jobs[i].lmf + b->jobs[i].rmf + b->jobs[i].g + fp.d_err;
-        v.lvl = (const uint32_t*)td->lvl.p + td->lvl_off[x];
-        v.states = (uint64_t*)td->states.p + go.out_off;
+        v.st = (const SubState*)td->subs.p + go.sub_off;
+        v.n = go.n_sub;
         b->timing.xA += go.x_right; b->timing.sA += go.n_right;
         b->timing.xB += go.x_left; b->timing.sB += go.n_states;
+        b->timing.xD += go.x_sub; b->timing.sD += go.n_sub;
       }
     }
     b->timing.retried_gaps += (uint32_t)next_todo.size();
@@ -535,38 +625,30 @@ extern "C" int g2s_batch_run(g2s_batch* b, g2s_result* results, char* arena, siz
     scale *= 8;
   }
 
-  // ---- host: D1/D2 per gap on a thread pool ---------------------------------
+  // ---- host: D2 + stop-depth analysis per gap, thread pool ----------------------
   auto t_post = std::chrono::steady_clock::now();
-  std::vector<PostPrep> prep(n);
-  {
-    int nth = s->params.host_threads > 0 ? s->params.host_threads : (int)std::thread::hardware_concurrency();
-    nth = std::max(1, std::min<int>(nth, (int)std::max<size_t>(1, n / 8)));
-    std::atomic<size_t> next(0);
-    auto work = [&]() {
-      while (true) {
-        const size_t i = next.fetch_add(1);
-        if (i >= n) break;
-        if (!views[i].out) continue;
-        dp_sort_levels(&views[i]);
-        post_extract(g, fp, b->jobs[i], views[i], &prep[i]);
-      }
-    };
-    std::vector<std::thread> th;
-    for (int t = 1; t < nth; t++) th.emplace_back(work);
-    work();
-    for (auto& x : th) x.join();
-  }
+  std::vector<SubPrep> prep(n);
+  s->pool->run(n, [&](size_t i) {
+    if (views[i].out) sub_analyze(fp, b->jobs[i], views[i], &prep[i]);
+  });
 
-  // ---- host: D3 traceback in gap order (one rand() stream) -------------------
-  size_t arena_pos = 0;
+  // ---- host: assign rand() stream offsets in gap order (:178,1440,1513) ---------
+  // A gap whose draw count does not depend on the draws gets its offset in O(1);
+  // the others are traced right here.  All remaining tracebacks then run in parallel.
+  std::vector<size_t> arena_off(n), rand_off(n, 0);
+  std::vector<char> todo_tb(n, 0);
+  {
+    size_t apos = 0;
+    for (size_t i = 0; i < n; i++) { arena_off[i] = apos; apos += b->jobs[i].buf_bytes(g.k, fp.d_err); }
+  }
+  size_t draws_total = 0;
   bool prev_filled = false;
   int prev_right_fuz = 0;
   for (size_t i = 0; i < n; i++) {
     const GapJob& j = b->jobs[i];
     g2s_result& r = results[i];
-    char* buf = arena + arena_pos;
-    arena_pos += j.buf_bytes(g.k, fp.d_err);
-    r.fill_off = (uint64_t)(buf - arena) + (uint64_t)j.lmf;
+    char* buf = arena + arena_off[i];
+    r.fill_off = (uint64_t)arena_off[i] + (uint64_t)j.lmf;
     if (j.skip_if_prev_right_fuz_gt >= 0 && prev_filled && prev_right_fuz > j.skip_if_prev_right_fuz_gt) {
       r.flags |= G2S_GAP_SKIPPED;
       prev_filled = false;
@@ -574,27 +656,49 @@ extern "C" int g2s_batch_run(g2s_batch* b, g2s_result* results, char* arena, siz
     }
     if (j.bad_flank) { r.flags |= G2S_GAP_BAD_FLANK; prev_filled = false; continue; }
     if (mem_exceeded[i]) { r.count = -1; r.flags |= G2S_GAP_MEM_EXCEEDED; prev_filled = false; continue; }
-    const DpView& v = views[i];
-    const PostPrep& pp = prep[i];
+    const SubView& v = views[i];
+    const SubPrep& pp = prep[i];
     r.phaseC_count = v.out->c_count;
     r.n_lengths = v.out->n_len;
     r.lengths[0] = v.out->len[0];
     r.lengths[1] = v.out->len[1];
-    if (v.out->flags & (G2S_DEV_Q7_A | G2S_DEV_Q7_B)) r.flags |= G2S_GAP_Q7;
+    if (v.out->flags & (G2S_DEV_Q7_A | G2S_DEV_Q7_B | G2S_DEV_Q7_D)) r.flags |= G2S_GAP_Q7;
     r.flags |= pp.flags;
     r.count = pp.count;
-    b->timing.xD += pp.xD;
-    b->timing.sD += pp.sD;
     if (pp.phase_d) {
-      post_traceback(g, fp, j, v, pp, s->rng, buf, &r);
       r.vertices = pp.sub[0]; r.edges = pp.sub[1]; r.nontrivial_components = pp.sub[2];
       r.size_nontrivial_components = pp.sub[3]; r.vertices_final = pp.sub[4]; r.edges_final = pp.sub[5];
-      r.fill_off = (uint64_t)(buf - arena) + (uint64_t)(j.lmf - r.left_fuz);
-      r.fill_len = (int32_t)strlen(arena + r.fill_off);
-      b->timing.fill_bytes += (uint64_t)r.fill_len;
+      rand_off[i] = draws_total;
+      const int pick = (int)(s->rcache.at(draws_total) % v.out->n_len);
+      const int fixed = sub_fixed_draws(v, pp, pick);
+      if (fixed >= 0) {
+        todo_tb[i] = 1;
+        r.draws = fixed;
+        r.right_fuz = v.out->reached_j;
+      } else {
+        s->rcache.ensure(draws_total + (size_t)v.out->len[pick] + 2);
+        sub_traceback(g, fp, j, v, pp, s->rcache.ptr(draws_total), buf, &r);
+      }
+      draws_total += (size_t)r.draws;
     }
     prev_filled = r.count > 0 && (!fp.unique_paths || r.count == 1);
     prev_right_fuz = r.right_fuz;
+  }
+  s->rcache.ensure(draws_total + 1);
+  s->pool->run(n, [&](size_t i) {
+    if (!todo_tb[i]) return;
+    g2s_result& r = results[i];
+    const int expect = r.draws;
+    sub_traceback(g, fp, b->jobs[i], views[i], prep[i], s->rcache.ptr(rand_off[i]), arena + arena_off[i], &r);
+    if (r.draws != expect) r.flags |= G2S_GAP_BACKTRACE_FAIL;  // cannot happen: the draw count was proven fixed
+  });
+  s->rcache.consume(draws_total);
+  for (size_t i = 0; i < n; i++) {
+    g2s_result& r = results[i];
+    if (!(r.flags & G2S_GAP_PHASE_D)) continue;
+    r.fill_off = (uint64_t)arena_off[i] + (uint64_t)(b->jobs[i].lmf - r.left_fuz);
+    r.fill_len = (int32_t)strlen(arena + r.fill_off);
+    b->timing.fill_bytes += (uint64_t)r.fill_len;
   }
   auto t_end = std::chrono::steady_clock::now();
   b->timing.ms_host_post = std::chrono::duration<double, std::milli>(t_end - t_post).count();
@@ -621,6 +725,7 @@ extern "C" int g2s_session_get_params(const g2s_session* s, g2s_params* out) {
 }
 
 // TEST HOOK, see include/g2s.h: host half of phase D on a caller-supplied DP table.
+// The closure the g2s_extract kernel would compute is derived on the host (host_closure).
 extern "C" int g2s_test_post_gap(const g2s_graph* gh, const g2s_params* p, const g2s_gap* gap, int32_t n_states,
                                  const uint32_t* nodes, const int32_t* depths, const uint32_t* counts,
                                  int32_t c_count, int32_t n_lengths, const int32_t* lengths, int32_t reached_j,
@@ -636,40 +741,49 @@ extern "C" int g2s_test_post_gap(const g2s_graph* gh, const g2s_params* p, const
   for (int d = 0; d <= j.lmf; d++) j.flank_nodes.push_back(g.node_of(j.left.c_str() + d));
   for (int d = 0; d <= j.rmf; d++) j.flank_nodes.push_back(g.node_of(j.right.c_str() + (j.right.size() - k - d)));
   for (int d = 0; d <= j.rmf; d++) j.flank_nodes.push_back(g.node_of(j.right.c_str() + d));
-  const int D = j.lmf + j.rmf + j.g + p->d_err;
-  std::vector<uint32_t> lvl((size_t)D + 2, 0);
-  for (int i = 0; i < n_states; i++) if (depths[i] >= 0 && depths[i] <= D) lvl[(size_t)depths[i] + 1]++;
-  for (int d = 0; d <= D; d++) lvl[(size_t)d + 1] += lvl[(size_t)d];
-  std::vector<uint64_t> states((size_t)n_states + 1);
+  HostTable t;
+  t.D = j.lmf + j.rmf + j.g + p->d_err;
+  t.lvl.assign((size_t)t.D + 2, 0);
+  for (int i = 0; i < n_states; i++) if (depths[i] >= 0 && depths[i] <= t.D) t.lvl[(size_t)depths[i] + 1]++;
+  for (int d = 0; d <= t.D; d++) t.lvl[(size_t)d + 1] += t.lvl[(size_t)d];
+  t.states.assign((size_t)n_states + 1, 0);
   {
-    std::vector<uint32_t> pos(lvl.begin(), lvl.end() - 1);
+    std::vector<uint32_t> pos(t.lvl.begin(), t.lvl.end() - 1);
     for (int i = 0; i < n_states; i++)
-      if (depths[i] >= 0 && depths[i] <= D)
-        states[pos[(size_t)depths[i]]++] = ((uint64_t)nodes[i] << 32) | std::min<uint32_t>(counts[i], G2S_MAX_PATHS);
+      if (depths[i] >= 0 && depths[i] <= t.D)
+        t.states[pos[(size_t)depths[i]]++] = ((uint64_t)nodes[i] << 32) | std::min<uint32_t>(counts[i], G2S_MAX_PATHS);
+    for (int d = 0; d <= t.D; d++) std::sort(t.states.begin() + t.lvl[(size_t)d], t.states.begin() + t.lvl[(size_t)d + 1]);
   }
   GapOut go;
   memset(&go, 0, sizeof go);
   go.c_count = c_count; go.n_len = n_lengths; go.reached_j = reached_j; go.final_d = final_d;
   for (int i = 0; i < n_lengths && i < 2; i++) go.len[i] = lengths[i];
-  DpView v;
-  v.out = &go; v.lvl = lvl.data(); v.states = states.data(); v.D = D;
-  dp_sort_levels(&v);
   FillParams fp;
   fp.k = k; fp.d_err = p->d_err; fp.skip_confident = p->skip_confident != 0; fp.all_paths = p->all_paths != 0;
   fp.unique_paths = p->unique_paths != 0;
-  PostPrep prep;
-  post_extract(g, fp, j, v, &prep);
+  std::vector<SubState> closure;
+  uint32_t q7 = 0;
+  host_closure(g, fp, j, t, go, &closure, &q7);
+  SubView v;
+  v.out = &go; v.st = closure.data(); v.n = (uint32_t)closure.size();
+  SubPrep prep;
+  sub_analyze(fp, j, v, &prep);
   memset(res, 0, sizeof *res);
   memset(buf, 0, j.buf_bytes(k, fp.d_err));
   res->phaseC_count = c_count;
   res->count = prep.count;
-  res->flags |= prep.flags;
+  res->flags |= prep.flags | q7;
   res->fill_off = (uint64_t)j.lmf;
   if (prep.phase_d) {
     GlibcRand rng;
     rng.seed(seed);
     for (uint32_t i = 0; i < skip; i++) rng.next();
-    post_traceback(g, fp, j, v, prep, rng, buf, res);
+    std::vector<int32_t> rands((size_t)t.D + 4);
+    for (auto& x : rands) x = (int32_t)rng.next();
+    const int pick = (int)(rands[0] % go.n_len);
+    const int fixed = sub_fixed_draws(v, prep, pick);
+    sub_traceback(g, fp, j, v, prep, rands.data(), buf, res);
+    if (fixed >= 0 && fixed != res->draws) return fail(G2S_ERR_STATE, "stop-depth analysis disagrees with the traceback");
     res->vertices = prep.sub[0]; res->edges = prep.sub[1]; res->nontrivial_components = prep.sub[2];
     res->size_nontrivial_components = prep.sub[3]; res->vertices_final = prep.sub[4]; res->edges_final = prep.sub[5];
     res->fill_off = (uint64_t)(j.lmf - res->left_fuz);

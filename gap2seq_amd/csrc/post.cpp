@@ -5,73 +5,43 @@
 #include <cctype>
 #include <cstdio>
 #include <cstring>
-#include <unordered_set>
 
 namespace g2s {
 
-static inline int sat_add(int a, int b) {
+namespace {
+
+inline int sat_add(int a, int b) {
   long long s = (long long)a + (long long)b;
   return s > (long long)G2S_MAX_PATHS ? G2S_MAX_PATHS : (int)s;
 }
 
-void dp_sort_levels(DpView* v) {
-  for (int d = 0; d <= v->D; d++) {
-    const uint32_t b = v->lvl[d], e = v->lvl[d + 1];
-    if (e - b > 1) std::sort(v->states + b, v->states + e);
+// canonical k-mer index -> dense vertex id, open addressing (no allocation per key)
+struct VertexMap {
+  std::vector<uint32_t> key, val;
+  uint32_t mask = 0;
+  void init(size_t n) {
+    size_t cap = 16;
+    while (cap < 2 * n + 2) cap <<= 1;
+    key.assign(cap, 0xFFFFFFFFu);
+    val.assign(cap, 0);
+    mask = (uint32_t)cap - 1;
   }
-}
-
-uint32_t dp_find(const DpView& v, int depth, uint32_t node) {
-  if (depth < 0 || depth > v.D) return 0;
-  uint32_t lo = v.lvl[depth], hi = v.lvl[depth + 1];
-  if (hi - lo <= 8) {
-    for (uint32_t i = lo; i < hi; i++)
-      if ((uint32_t)(v.states[i] >> 32) == node) return (uint32_t)v.states[i];
-    return 0;
+  static uint32_t h(uint32_t x) { x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x; }
+  int find(uint32_t k) const {
+    uint32_t s = h(k) & mask;
+    while (key[s] != 0xFFFFFFFFu) { if (key[s] == k) return (int)val[s]; s = (s + 1) & mask; }
+    return -1;
   }
-  const uint32_t end = hi;
-  while (lo < hi) {
-    uint32_t mid = (lo + hi) >> 1;
-    if ((uint32_t)(v.states[mid] >> 32) < node) lo = mid + 1; else hi = mid;
-  }
-  return (lo < end && (uint32_t)(v.states[lo] >> 32) == node) ? (uint32_t)v.states[lo] : 0;
-}
-
-namespace {
-
-// A border of the backward sweep: the reference keys it by canonical k-mer
-// (Node::operator== ignores the strand), first insertion wins (Q7 otherwise).
-struct BackBorder {
-  std::vector<uint32_t> items;
-  std::unordered_map<uint32_t, uint32_t> seen;  // only used once the level is wide
-  bool insert(uint32_t node, uint32_t* flags) {
-    const uint32_t idx = node >> 1;
-    if (items.size() < 16 && seen.empty()) {
-      for (uint32_t x : items)
-        if ((x >> 1) == idx) { if (x != node) *flags |= G2S_GAP_Q7; return false; }
-      items.push_back(node);
-      return true;
-    }
-    if (seen.empty()) for (uint32_t x : items) seen.emplace(x >> 1, x);
-    auto it = seen.find(idx);
-    if (it != seen.end()) { if (it->second != node) *flags |= G2S_GAP_Q7; return false; }
-    seen.emplace(idx, node);
-    items.push_back(node);
-    return true;
-  }
-  void clear() { items.clear(); seen.clear(); }
-};
-
-struct EdgeList {
-  std::vector<std::pair<int, int>> e;
-  std::unordered_set<uint64_t> have;
-  void add_once(int u, int v) {  // boost::edge(u,v).second test + add_edge
-    const uint64_t key = ((uint64_t)(uint32_t)u << 32) | (uint32_t)v;
-    if (have.insert(key).second) e.emplace_back(u, v);
+  int get_or_add(uint32_t k, int* next) {
+    uint32_t s = h(k) & mask;
+    while (key[s] != 0xFFFFFFFFu) { if (key[s] == k) return (int)val[s]; s = (s + 1) & mask; }
+    key[s] = k;
+    val[s] = (uint32_t)(*next);
+    return (*next)++;
   }
 };
 
-// Tarjan over a CSR adjacency; comp ids are arbitrary.
+// Tarjan over a CSR adjacency; component ids are arbitrary.
 int strong_components(int nv, const std::vector<int>& off, const std::vector<int>& adj, std::vector<int>* comp) {
   std::vector<int> index((size_t)nv, -1), low((size_t)nv, 0), it((size_t)nv, 0), stack, call;
   std::vector<char> on((size_t)nv, 0);
@@ -111,85 +81,74 @@ int strong_components(int nv, const std::vector<int>& off, const std::vector<int
 
 }  // namespace
 
-void post_extract(const Graph& g, const FillParams& p, const GapJob& job, const DpView& v, PostPrep* out) {
+void sub_analyze(const FillParams& p, const GapJob& job, const SubView& v, SubPrep* out) {
   const GapOut& go = *v.out;
   out->count = go.c_count;
   out->phase_d = go.c_count > 0 && go.n_len > 0;  // :1169 (fill is never NULL here)
-  if (!out->phase_d || p.skip_confident) return;
+  if (!out->phase_d) return;
+  const uint32_t n = v.n;
+  const SubState* st = v.st;
+  (void)job;
 
-  const int lmf = job.lmf, rmf = job.rmf, gl = job.g, e = p.d_err;
-  const uint32_t* targets = job.targets();
-  const uint32_t* lseeds = job.lseeds();
-  const uint32_t reached = targets[go.reached_j];
-  const int kSink = 0, kSource = 1;
-  int nverts = 2;
-  auto vertex = [&](uint32_t node) -> int {
-    auto it = out->vertex_of.find(node >> 1);
-    if (it != out->vertex_of.end()) return it->second;
-    out->vertex_of.emplace(node >> 1, nverts);
-    return nverts++;
-  };
-  EdgeList edges;
-  BackBorder back, next;
-  int count = p.all_paths ? 0 : go.c_count;  // :1189-1191
-
-  for (int d2 = lmf + gl + e + rmf; d2 >= 0; d2--) {
-    if (p.all_paths) {
-      if (d2 >= lmf + gl - e) {
-        for (int j = 0; j < rmf; j++) {  // strictly < rmf: only j = rmf-1 can be a sink (Q3/Q4)
-          const uint32_t rnode = targets[j];
-          if (j < rmf - 1 && rnode != kInvalidNode) continue;  // graph.contains(rnode) (:1201-1206)
-          if (rnode == kInvalidNode) continue;                 // cannot be in reachableSetLeft
-          const uint32_t c = dp_find(v, d2, rnode);
-          if (c >= 1) {
-            count = sat_add(count, (int)c);
-            if (back.insert(rnode, &out->flags)) out->sD++;
-            edges.add_once(vertex(rnode), kSink);
-          }
-        }
-      }
-    } else {
-      for (int j = 0; j < go.n_len; j++) {
-        if (go.len[j] == d2) {
-          if (back.insert(reached, &out->flags)) out->sD++;
-          edges.add_once(vertex(reached), kSink);
-        }
-      }
-    }
-    const uint32_t lidx = (d2 <= lmf) ? (lseeds[d2] >> 1) : 0xFFFFFFFFu;  // buildNode(kmer_left.substr(d2,k))
-    for (size_t bi = 0; bi < back.items.size(); bi++) {
-      const uint32_t cur = back.items[bi];
-      out->xD++;
-      if (d2 > lmf || (cur >> 1) != lidx) {  // :1270, k-mer comparison only
-        for (int nt = 0; nt < 4; nt++) {
-          const uint32_t pr = g.pred_of(cur, nt);
-          if (pr == kInvalidNode) continue;
-          if (dp_find(v, d2 - 1, pr) > 0) {
-            if (next.insert(pr, &out->flags)) out->sD++;
-            const int pv = vertex(pr), cv = vertex(cur);
-            edges.add_once(pv, cv);
-          }
-        }
-      } else {
-        edges.add_once(kSource, vertex(cur));
-      }
-    }
-    back.clear();
-    std::swap(back.items, next.items);
-    std::swap(back.seen, next.seen);
-  }
-  if (p.all_paths) out->count = count;
-
-  // ---- D2: condensation statistics and the branch rule ----------------------
-  const int V = nverts;
-  const size_t E = edges.e.size();
-  std::vector<int> off((size_t)V + 1, 0), adj(E);
-  for (auto& ed : edges.e) off[(size_t)ed.first + 1]++;
-  for (int i = 0; i < V; i++) off[(size_t)i + 1] += off[(size_t)i];
+  // traceback starts and, per start, the depth at which every traceback stops
+  // (states are stored depth-descending, so a reverse sweep sees predecessors first)
   {
-    std::vector<int> pos(off.begin(), off.end() - 1);
-    for (auto& ed : edges.e) adj[(size_t)pos[(size_t)ed.first]++] = ed.second;
+    std::vector<int> lo((size_t)n, -2), hi((size_t)n, -2);  // -2: not on a traceback closure
+    for (int64_t i = (int64_t)n - 1; i >= 0; i--) {
+      const SubState& s = st[i];
+      if (!(s.flags & G2S_SUB_IN_T)) continue;
+      if (s.flags & G2S_SUB_SOURCE) { lo[(size_t)i] = hi[(size_t)i] = (int)s.depth; continue; }  // :1455-1462
+      int l = 1 << 30, h = -1, np = 0;
+      for (int nt = 0; nt < 4; nt++) {
+        const int32_t q = s.pred[nt];
+        if (q < 0) continue;
+        np++;
+        if (lo[(size_t)q] < 0) { l = -1; h = 1 << 30; } else { l = std::min(l, lo[(size_t)q]); h = std::max(h, hi[(size_t)q]); }
+      }
+      if (np == 0) { lo[(size_t)i] = -1; hi[(size_t)i] = 1 << 30; }  // walk ends here without a stop: not fixed
+      else { lo[(size_t)i] = l; hi[(size_t)i] = h; }
+    }
+    for (uint32_t i = 0; i < n; i++) {
+      if (!(st[i].flags & G2S_SUB_START_T)) continue;
+      for (int j = 0; j < go.n_len && j < 2; j++) {
+        if ((int)st[i].depth == go.len[j] && out->start_idx[j] < 0) {
+          out->start_idx[j] = (int)i;
+          out->stop_depth[j] = (lo[i] >= 0 && lo[i] == hi[i]) ? lo[i] : -1;
+        }
+      }
+    }
   }
+  if (p.skip_confident) return;  // no D1/D2 with -all-upper (:1181)
+
+  // ---- D2 on the S closure: vertices = canonical k-mers (+ sink 0, source 1) ----
+  VertexMap vm;
+  vm.init(n);
+  int nverts = 2;
+  std::vector<int> vid((size_t)n, -1);
+  for (uint32_t i = 0; i < n; i++)
+    if (st[i].flags & G2S_SUB_IN_S) vid[i] = vm.get_or_add(st[i].node >> 1, &nverts);
+  std::vector<uint64_t> el;
+  el.reserve((size_t)n + 8);
+  int count = 0;
+  auto edge = [&](int a, int b) { el.push_back(((uint64_t)(uint32_t)a << 32) | (uint32_t)b); };
+  for (uint32_t i = 0; i < n; i++) {
+    const SubState& s = st[i];
+    if (!(s.flags & G2S_SUB_IN_S)) continue;
+    if (s.flags & G2S_SUB_SINK) { edge(vid[i], 0); count = sat_add(count, (int)s.cnt); }  // :1216-1226 / :1248-1256
+    if (s.flags & G2S_SUB_SOURCE) { edge(1, vid[i]); continue; }                           // :1303-1305
+    for (int nt = 0; nt < 4; nt++)
+      if (s.pred[nt] >= 0) edge(vid[(size_t)s.pred[nt]], vid[i]);                          // :1283-1297
+  }
+  if (p.all_paths) out->count = count;  // recount (:1189-1191); -best-only keeps the phase C count
+  std::sort(el.begin(), el.end());
+  el.erase(std::unique(el.begin(), el.end()), el.end());  // boost::edge(u,v).second de-duplication
+
+  const int V = nverts;
+  const size_t E = el.size();
+  std::vector<int> off((size_t)V + 1, 0), adj(E);
+  for (uint64_t x : el) off[(size_t)(x >> 32) + 1]++;
+  for (int i = 0; i < V; i++) off[(size_t)i + 1] += off[(size_t)i];
+  for (size_t x = 0; x < E; x++) adj[x] = (int)(uint32_t)el[x];  // el is sorted by source: already CSR order
   std::vector<int> comp;
   const int nc = strong_components(V, off, adj, &comp);
   std::vector<int> csize((size_t)nc, 0), cvert((size_t)nc, -1);
@@ -197,18 +156,19 @@ void post_extract(const Graph& g, const FillParams& p, const GapJob& job, const 
   int nontrivial = 0, size_nontrivial = 0;
   for (int c = 0; c < nc; c++)
     if (csize[(size_t)c] > 1) { cvert[(size_t)c] = V + nontrivial++; size_nontrivial += csize[(size_t)c]; }
-  const int VF = V + nontrivial;  // final vertex ids: trivial real vertices keep theirs, members map to cvert
+  const int VF = V + nontrivial;  // trivial vertices keep their id, SCC members map to the contracted vertex
   auto fin = [&](int x) { return csize[(size_t)comp[(size_t)x]] > 1 ? cvert[(size_t)comp[(size_t)x]] : x; };
   std::vector<int> din((size_t)VF, 0), dout((size_t)VF, 0);
   std::vector<std::pair<int, int>> fe;
   fe.reserve(E);
   size_t loops_trivial = 0;
-  for (auto& ed : edges.e) {
-    if (comp[(size_t)ed.first] == comp[(size_t)ed.second]) {
-      if (csize[(size_t)comp[(size_t)ed.first]] == 1) loops_trivial++;  // self loop on a trivial vertex (:1385-1402)
-      continue;  // intra-component edges disappear with clear_vertex (:1374-1378)
+  for (uint64_t x : el) {
+    const int a0 = (int)(x >> 32), b0 = (int)(uint32_t)x;
+    if (comp[(size_t)a0] == comp[(size_t)b0]) {
+      if (csize[(size_t)comp[(size_t)a0]] == 1) loops_trivial++;  // self loop on a trivial vertex (:1385-1402)
+      continue;  // intra-component edges vanish with clear_vertex (:1374-1378)
     }
-    const int a = fin(ed.first), b = fin(ed.second);  // one contracted edge per real edge, parallel edges kept
+    const int a = fin(a0), b = fin(b0);  // one contracted edge per real edge, parallel edges kept (:1342-1372)
     fe.emplace_back(a, b);
     dout[(size_t)a]++;
     din[(size_t)b]++;
@@ -220,7 +180,7 @@ void post_extract(const Graph& g, const FillParams& p, const GapJob& job, const 
   out->sub[4] = (uint64_t)(VF - size_nontrivial);
   out->sub[5] = (uint64_t)fe.size();
 
-  // topological order of the condensed multigraph (Kahn), then :1420-1434
+  // topological order of the condensed multigraph (Kahn), then the branch rule (:1420-1434)
   std::vector<int> foff((size_t)VF + 1, 0), fadj(fe.size());
   for (auto& ed : fe) foff[(size_t)ed.first + 1]++;
   for (int i = 0; i < VF; i++) foff[(size_t)i + 1] += foff[(size_t)i];
@@ -245,57 +205,128 @@ void post_extract(const Graph& g, const FillParams& p, const GapJob& job, const 
       if (dout[(size_t)u] > 1) bc += dout[(size_t)u] - 1;
     }
   }
-  out->branch.assign((size_t)V, 0);
-  for (int i = 0; i < V; i++)
-    if (csize[(size_t)comp[(size_t)i]] == 1) out->branch[(size_t)i] = fbranch[(size_t)i];  // SCC members stay 0
+  // per-state safe bit for the traceback (:1466): k-mers outside the subgraph read
+  // branch[sink] (node2boost default-inserts vertex 0, Q5); SCC members stay 0
+  out->safe.assign((size_t)n, 0);
+  const bool sink_safe = (csize[(size_t)comp[0]] == 1) && fbranch[0] == 1;
+  for (uint32_t i = 0; i < n; i++) {
+    if (!(st[i].flags & G2S_SUB_IN_T)) continue;
+    int vtx = vid[i];
+    if (vtx < 0) vtx = vm.find(st[i].node >> 1);
+    if (vtx < 0) { out->safe[i] = sink_safe; continue; }
+    out->safe[i] = (csize[(size_t)comp[(size_t)vtx]] == 1) && fbranch[(size_t)vtx] == 1;
+  }
 }
 
-void post_traceback(const Graph& g, const FillParams& p, const GapJob& job, const DpView& v, const PostPrep& prep,
-                    GlibcRand& rng, char* buf, g2s_result* res) {
+void sub_traceback(const Graph& g, const FillParams& p, const GapJob& job, const SubView& v, const SubPrep& prep,
+                   const int32_t* rands, char* buf, g2s_result* res) {
   const GapOut& go = *v.out;
   const int lmf = job.lmf, k = p.k;
-  const uint32_t* lseeds = job.lseeds();
   res->right_fuz = go.reached_j;  // :1171
   res->flags |= G2S_GAP_PHASE_D;
-  int d2 = go.len[(size_t)(rng.next() % go.n_len)];  // :1440
-  res->draws++;
+  int draws = 0;
+  const int pick = (int)(rands[draws++] % go.n_len);  // :1440
+  int d2 = go.len[pick];
   int last_solid = d2;
-  uint32_t cur = job.targets()[go.reached_j];
+  int i = prep.start_idx[pick];
   buf[d2] = '\0';
-  uint32_t backv[4];
-  while (d2 >= 0) {
-    if (d2 <= lmf && (lseeds[d2] >> 1) == (cur >> 1)) {  // :1455-1462, k-mer equality
+  res->count = prep.count;
+  while (d2 >= 0 && i >= 0) {
+    const SubState& s = v.st[i];
+    if (s.flags & G2S_SUB_SOURCE) {  // :1455-1462 (depth <= lmf and k-mer equal to the flank k-mer)
       res->left_fuz = lmf - d2;
       break;
     }
     if (d2 > 0) {
-      bool solid = p.skip_confident;
-      if (!solid) {
-        auto it = prep.vertex_of.find(cur >> 1);
-        const int bv = it == prep.vertex_of.end() ? 0 : it->second;  // Q5: unknown k-mers read branch[sink]
-        solid = prep.branch[(size_t)bv] == 1;
-      }
-      if (solid) last_solid = d2;
-      const char c = g.last_char(cur);
+      if (p.skip_confident || prep.safe[(size_t)i]) last_solid = d2;  // :1466-1468
+      const char c = g.last_char(s.node);
       buf[d2 - 1] = (d2 > last_solid - k) ? (char)toupper((unsigned char)c) : (char)tolower((unsigned char)c);
-      int nb = 0;
-      for (int nt = 0; nt < 4; nt++) {  // GATB predecessor order
-        const uint32_t pr = g.pred_of(cur, nt);
-        if (pr != kInvalidNode && dp_find(v, d2 - 1, pr) > 0) backv[nb++] = pr;
-      }
+      int back[4], nb = 0;
+      for (int nt = 0; nt < 4; nt++)  // GATB predecessor order
+        if (s.pred[nt] >= 0) back[nb++] = s.pred[nt];
       if (nb == 0) {  // :1493-1510
-        snprintf(res->backtrace_msg, sizeof res->backtrace_msg, "Unable to backtrace! %d %d %s", d2,
-                 go.final_d, g.node_string(job.targets()[go.reached_j]).c_str());
+        snprintf(res->backtrace_msg, sizeof res->backtrace_msg, "Unable to backtrace! %d %d %s", d2, go.final_d,
+                 g.node_string(job.targets()[go.reached_j]).c_str());
         res->flags |= G2S_GAP_BACKTRACE_FAIL;
         res->count = 0;
-        return;
+        break;
       }
-      cur = backv[rng.next() % nb];  // :1513
-      res->draws++;
+      i = back[rands[draws++] % nb];  // :1513
     }
     d2--;
   }
-  res->count = prep.count;
+  res->draws = draws;
+}
+
+// ---------------------------------------------------------------------------
+// TEST HOOK support (host restatement of what g2s_extract computes)
+// ---------------------------------------------------------------------------
+uint32_t HostTable::find(int depth, uint32_t node) const {
+  if (depth < 0 || depth > D) return 0;
+  uint32_t lo = lvl[(size_t)depth], hi = lvl[(size_t)depth + 1];
+  const uint32_t end = hi;
+  while (lo < hi) {
+    uint32_t mid = (lo + hi) >> 1;
+    if ((uint32_t)(states[mid] >> 32) < node) lo = mid + 1; else hi = mid;
+  }
+  return (lo < end && (uint32_t)(states[lo] >> 32) == node) ? (uint32_t)states[lo] : 0;
+}
+
+void host_closure(const Graph& g, const FillParams& p, const GapJob& job, const HostTable& t, const GapOut& go,
+                  std::vector<SubState>* out, uint32_t* q7) {
+  out->clear();
+  if (!(go.c_count > 0 && go.n_len > 0)) return;
+  const int lmf = job.lmf, rmf = job.rmf;
+  const uint32_t* targets = job.targets();
+  const uint32_t* lseeds = job.lseeds();
+  const bool want_s = !p.skip_confident;
+  const uint32_t sinknode = (want_s && p.all_paths && rmf >= 1) ? targets[rmf - 1] : kInvalidNode;
+  const int lo_sink = std::max(0, lmf + job.g - p.d_err);
+  const uint32_t reached = targets[go.reached_j];
+  const uint32_t t_flags = G2S_SUB_IN_T | G2S_SUB_START_T | ((want_s && !p.all_paths) ? (G2S_SUB_IN_S | G2S_SUB_SINK) : 0u);
+  std::vector<std::pair<uint64_t, int>> index;  // (node<<32|depth) -> state index, kept sorted per level lazily
+  auto find_idx = [&](uint32_t node, int depth, size_t from) -> int {
+    for (size_t i = from; i < out->size(); i++)
+      if ((*out)[i].node == node && (int)(*out)[i].depth == depth) return (int)i;
+    return -1;
+  };
+  auto discover = [&](uint32_t node, int depth, size_t level_from) -> int {
+    int idx = find_idx(node, depth, level_from);
+    if (idx >= 0) return idx;
+    SubState s;
+    s.node = node; s.depth = (uint32_t)depth; s.cnt = t.find(depth, node); s.flags = 0;
+    s.pred[0] = s.pred[1] = s.pred[2] = s.pred[3] = -1;
+    out->push_back(s);
+    return (int)out->size() - 1;
+  };
+  size_t bstart = 0;
+  for (int d2 = t.D; d2 >= 0; d2--) {
+    if (sinknode != kInvalidNode && d2 >= lo_sink && t.find(d2, sinknode) > 0)
+      (*out)[(size_t)discover(sinknode, d2, bstart)].flags |= G2S_SUB_IN_S | G2S_SUB_SINK;
+    for (int j = 0; j < go.n_len; j++)
+      if (go.len[j] == d2 && t.find(d2, reached) > 0) (*out)[(size_t)discover(reached, d2, bstart)].flags |= t_flags;
+    const size_t bend = out->size();
+    const uint32_t lidx = d2 <= lmf ? (lseeds[d2] >> 1) : 0xFFFFFFFFu;
+    for (size_t i = bstart; i < bend; i++) {
+      const uint32_t cur = (*out)[i].node;
+      const uint32_t f = (*out)[i].flags & (G2S_SUB_IN_S | G2S_SUB_IN_T);
+      if (d2 <= lmf && (cur >> 1) == lidx) { (*out)[i].flags |= G2S_SUB_SOURCE; continue; }
+      if (d2 == 0) continue;
+      for (int nt = 0; nt < 4; nt++) {
+        const uint32_t pr = g.pred_of(cur, nt);
+        if (pr == kInvalidNode || t.find(d2 - 1, pr) == 0) continue;
+        const int idx = discover(pr, d2 - 1, bend);
+        (*out)[i].pred[nt] = idx;
+        (*out)[(size_t)idx].flags |= f;
+        if (find_idx(pr ^ 1u, d2 - 1, bend) >= 0) *q7 |= G2S_GAP_Q7;
+      }
+    }
+    // a later sibling may have discovered the other strand after the check above
+    for (size_t a = bend; a < out->size(); a++)
+      for (size_t b2 = a + 1; b2 < out->size(); b2++)
+        if (((*out)[a].node ^ (*out)[b2].node) == 1u) *q7 |= G2S_GAP_Q7;
+    bstart = bend;
+  }
 }
 
 }  // namespace g2s

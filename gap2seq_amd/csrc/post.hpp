@@ -1,14 +1,15 @@
-// gap2seq_amd/csrc/post.hpp — host part of fill_gap's phase D, driven by the DP
-// state log that the HIP kernels produced for one gap:
-//   D1 subgraph extraction   /root/reference/src/Gap2Seq.cpp:1169-1312
-//   D2 SCC contraction + the "vertex on all paths" rule        :1314-1435
-//   D3 random traceback                                         :1437-1522
-// D1/D2 are independent per gap (run on a thread pool); D3 consumes the single
-// rand() stream and therefore runs in gap order on one thread.
+// gap2seq_amd/csrc/post.hpp — host part of fill_gap's phase D, driven by the
+// packed backward closure (SubState array) that the g2s_extract kernel produced
+// for one gap:
+//   D2 SCC contraction + the "vertex on all paths" rule   /root/reference/src/Gap2Seq.cpp:1314-1435
+//   D3 random traceback                                                               :1437-1522
+// (D1, the subgraph extraction :1169-1312, runs on the GPU.)
+// Everything except the assignment of rand() stream offsets is independent per
+// gap and runs on a thread pool; offsets are assigned in gap order by a pass that
+// costs O(1) per gap whenever the number of draws does not depend on the choices.
 #pragma once
 #include <cstdint>
 #include <string>
-#include <unordered_map>
 #include <vector>
 
 #include "../../include/g2s.h"
@@ -33,37 +34,49 @@ struct GapJob {
   size_t buf_bytes(int k, int d_err) const { return (size_t)(g + k + d_err + lmf + rmf + 1 + 2); }
 };
 
-// Device results of one gap, as seen on the host after the copy back.
-struct DpView {
-  const GapOut* out = nullptr;
-  const uint32_t* lvl = nullptr;  // D+2 offsets relative to `states`
-  uint64_t* states = nullptr;     // (node << 32 | count), level by level; sorted per level by prepare()
-  int D = 0;
-};
-
-struct PostPrep {
-  bool phase_d = false;   // count > 0 && pathLengths non-empty
-  int count = 0;          // value fill_gap will return (before the memory verdict)
-  uint32_t flags = 0;     // G2S_GAP_* bits found on the host (Q7 in D1)
-  uint64_t sub[6] = {0, 0, 0, 0, 0, 0};
-  uint64_t xD = 0, sD = 0;
-  std::unordered_map<uint32_t, int> vertex_of;  // canonical index -> subgraph vertex
-  std::vector<int> branch;                      // per real vertex; 0 = sink, 1 = source
-};
-
 struct FillParams {
   int k = 31, d_err = 500;
   bool skip_confident = false, all_paths = true, unique_paths = false;
 };
 
-// Sort every level by node id (the kernels emit levels in arrival order).
-void dp_sort_levels(DpView* v);
-// count of state (node, depth) or 0
-uint32_t dp_find(const DpView& v, int depth, uint32_t node);
+// Device results of one gap as seen on the host.
+struct SubView {
+  const GapOut* out = nullptr;
+  const SubState* st = nullptr;
+  uint32_t n = 0;
+};
 
-void post_extract(const Graph& g, const FillParams& p, const GapJob& job, const DpView& v, PostPrep* out);
-// Writes the reference's `fill` buffer into buf (size job.buf_bytes) and fills res.
-void post_traceback(const Graph& g, const FillParams& p, const GapJob& job, const DpView& v, const PostPrep& prep,
-                    GlibcRand& rng, char* buf, g2s_result* res);
+struct SubPrep {
+  bool phase_d = false;   // count > 0 && pathLengths non-empty (:1169)
+  int count = 0;          // value fill_gap returns (before a backtrace failure / memory verdict)
+  uint32_t flags = 0;     // G2S_GAP_* bits found on the host
+  uint64_t sub[6] = {0, 0, 0, 0, 0, 0};
+  std::vector<uint8_t> safe;  // per state: branch[vertex of its k-mer] == 1 (Q5 default = sink)
+  int start_idx[2] = {-1, -1};  // state index of (reachedTarget, pathLengths[i])
+  int stop_depth[2] = {-1, -1}; // depth every traceback from start i stops at, or -1 when it depends on the draws
+};
+
+// SCC / branch rule / stop-depth analysis of one gap; thread safe.
+void sub_analyze(const FillParams& p, const GapJob& job, const SubView& v, SubPrep* out);
+// Number of rand() draws the traceback will consume when pathLengths[pick] is chosen,
+// or -1 when that depends on later draws.
+inline int sub_fixed_draws(const SubView& v, const SubPrep& prep, int pick) {
+  return prep.stop_depth[pick] < 0 ? -1 : 1 + (v.out->len[pick] - prep.stop_depth[pick]);
+}
+// D3.  `rands` points at this gap's first draw; returns through res (count, fuz, draws, flags).
+// Writes the reference's `fill` buffer into buf (size job.buf_bytes).
+void sub_traceback(const Graph& g, const FillParams& p, const GapJob& job, const SubView& v, const SubPrep& prep,
+                   const int32_t* rands, char* buf, g2s_result* res);
+
+// TEST HOOK support: the closure the g2s_extract kernel computes, derived on the host
+// from a full DP table (states sorted per level).  Not used by the product path.
+struct HostTable {
+  std::vector<uint32_t> lvl;     // D+2 offsets
+  std::vector<uint64_t> states;  // (node << 32 | count), sorted inside each level
+  int D = 0;
+  uint32_t find(int depth, uint32_t node) const;
+};
+void host_closure(const Graph& g, const FillParams& p, const GapJob& job, const HostTable& t, const GapOut& go,
+                  std::vector<SubState>* out, uint32_t* q7);
 
 }  // namespace g2s
