@@ -134,7 +134,10 @@ def main():
         steps = max(1, args.steps)
         # ---- roofline of the dominant kernel (g2s_left_dp), measured live with HIP events
         io_bytes = tm.flank_bytes + tm.fill_bytes
-        alg_bytes = algorithmic_bytes(tm.xB, tm.sB, io_bytes)  # per step (all launches of the kernel in a step)
+        fused = acc["ms_right_bfs"] == 0.0  # LDS tier: phases A-C are one kernel (g2s_fill_lds)
+        x_units = tm.xB + (tm.xA if fused else 0)
+        s_units = tm.sB + (tm.sA if fused else 0)
+        alg_bytes = algorithmic_bytes(x_units, s_units, io_bytes)  # per step (all launches of the kernel in a step)
         kern_s = (acc["ms_left_dp"] / steps) / 1e3
         achieved = alg_bytes / kern_s / 1e9 if kern_s > 0 else 0.0
         traffic = None
@@ -144,9 +147,10 @@ def main():
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_step")
             except Exception:
                 traffic = None
-        roofline = dict(bound="hbm", kernel="g2s_left_dp", achieved=round(achieved, 3), peak=HBM_PEAK_GBS, unit="GB/s",
+        roofline = dict(bound="hbm", kernel="g2s_fill_lds" if fused else "g2s_left_dp", achieved=round(achieved, 3),
+                        peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(achieved / HBM_PEAK_GBS, 6), traffic=traffic,
-                        algorithmic_bytes_per_step=alg_bytes, expansions=tm.xB, states=tm.sB,
+                        algorithmic_bytes_per_step=alg_bytes, expansions=x_units, states=s_units,
                         kernel_ms_per_step=round(acc["ms_left_dp"] / steps, 4),
                         launches_per_step=acc["launches"] / steps)
         # ---- CPU baseline: the oracle (faithful port of the reference algorithm), same gaps

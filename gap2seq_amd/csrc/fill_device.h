@@ -34,7 +34,8 @@ struct GapDev {
   uint64_t rs_off;     // element offsets into the session arrays
   uint64_t rlog_off;
   uint64_t st_off;
-  uint64_t slog_off;
+  uint64_t slog_off;   // also: offset of the gap's state log / closure scratch in the LDS tier
+  uint64_t lvl_off;    // LDS tier: D+2 level offsets into the state log
 };
 
 /* SubState.flags */

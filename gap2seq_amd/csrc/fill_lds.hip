@@ -1,0 +1,619 @@
+// gap2seq_amd/csrc/fill_lds.hip — LDS-resident fast tier of the fill path for
+// gfx950 (CDNA4): phases A-C (g2s_fill_lds) and D1 (g2s_extract_lds) of
+// /root/reference/src/Gap2Seq.cpp:858-1312.
+//
+// Why a second tier: the first correct kernels (fill_kernels.hip) keep every
+// per-gap table in HBM and pay 5-6 dependent L2/HBM round trips per DP level
+// (~1.9 us/level measured, profiles/r01_v1_*).  A gap's working set is tiny —
+// frontier width 1-4 on real graphs — so here everything a level touches lives in
+// the CU's LDS (160 KB/CU on MI355X):
+//   * frontier (node, count) ping-pong buffers, 64 entries;
+//   * the right set (phase A's visited k-mers) as an LDS open-addressing table;
+//   * a per-level merge table keyed (depth, node) so that duplicate targets of one
+//     level are combined (64-bit LDS compare-and-swap + wave ballot compaction);
+//   * a direct-mapped cache of 512-byte successor blocks (16 consecutive nodes x
+//     2 strands x 4 slots).  Nodes are numbered in unitig order, so a walk along a
+//     unitig misses once per 16 levels and the miss is ONE coalesced 512 B load by
+//     the whole wave;
+//   * the target k-mers and the list of (target, depth, count) hits for phase C.
+// HBM sees only the block loads and append-only, fire-and-forget stores of the
+// state log.  One wavefront (64 lanes) per gap, the depth loop inside the kernel,
+// 4 lanes per frontier entry (one per nucleotide slot).  A level whose frontier
+// has a single entry — the common case — skips the merge table altogether.
+// Anything that does not fit (frontier > 64, right set too large, explicit
+// predecessor table for even k) is flagged and re-run by the general HBM tier.
+#include <hip/hip_runtime.h>
+
+#include "fill_device.h"
+#include "fill_launch.h"
+
+#define LDS_NB 8u         /* cached successor blocks          */
+#define LDS_BLK_WORDS 128u /* 16 nodes x 2 strands x 4 slots   */
+#define LDS_F 64u         /* frontier capacity                 */
+#define LDS_LH (2u * LDS_F)
+#define LDS_TH 128u       /* target hits kept for phase C      */
+#define LDS_TG 32u        /* right_max_fuz + 1 must fit        */
+#define LDS_W 256u        /* log / level-offset window (D1)    */
+
+namespace {
+
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ uint64_t lanes_below(int lane) { return (1ull << lane) - 1ull; }
+// One wavefront per workgroup: LDS operations of a wave execute in issue order, so
+// ordering LDS writes before later LDS reads of other lanes needs no s_barrier and,
+// unlike __syncthreads(), must NOT wait for the outstanding global stores of the
+// state log (vmcnt) — that wait alone costs an HBM round trip per level.
+__device__ __forceinline__ void lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ uint32_t flip(uint32_t v) { return v == G2S_DEV_INVALID ? v : (v ^ 1u); }
+
+// succ4[v*4+nt] through the LDS block cache.  Wave-uniform call; lanes with !want get INVALID.
+__device__ uint32_t cached_succ(const uint32_t* __restrict__ succ, uint32_t* tag, uint32_t* data, bool want, uint32_t v,
+                                uint32_t nt, int lane) {
+  uint32_t res = G2S_DEV_INVALID;
+  const uint32_t blk = v >> 5;
+  bool pending = want;
+  if (pending) {
+    const uint32_t sl = blk & (LDS_NB - 1u);
+    if (tag[sl] == blk) { res = data[sl * LDS_BLK_WORDS + (v & 31u) * 4u + nt]; pending = false; }
+  }
+  uint64_t m = __ballot(pending);
+  while (m) {
+    const uint32_t b = (uint32_t)__shfl((int)blk, __builtin_ctzll(m));
+    const uint32_t sl = b & (LDS_NB - 1u);
+    lds_sync();  // every earlier read of this slot has completed
+    const uint2 w = ((const uint2*)succ)[(size_t)b * 64u + (uint32_t)lane];  // one coalesced 512 B block
+    ((uint2*)data)[sl * 64u + (uint32_t)lane] = w;
+    if (lane == 0) tag[sl] = b;
+    lds_sync();
+    if (pending && blk == b) { res = data[sl * LDS_BLK_WORDS + (v & 31u) * 4u + nt]; pending = false; }
+    m = __ballot(pending);
+  }
+  return res;
+}
+
+// LDS right set.  1 inserted, 0 present, 2 full.
+__device__ int lrs_insert(uint32_t* tab, uint32_t mask, uint32_t v) {
+  uint32_t h = mix32(v) & mask;
+  for (uint32_t i = 0; i <= mask; i++) {
+    const uint32_t old = atomicCAS(&tab[h], G2S_DEV_INVALID, v);
+    if (old == G2S_DEV_INVALID) return 1;
+    if (old == v) return 0;
+    h = (h + 1) & mask;
+  }
+  return 2;
+}
+__device__ bool lrs_has(const uint32_t* tab, uint32_t mask, uint32_t v) {
+  uint32_t h = mix32(v) & mask;
+  for (uint32_t i = 0; i <= mask; i++) {
+    const uint32_t cur = tab[h];
+    if (cur == v) return true;
+    if (cur == G2S_DEV_INVALID) return false;
+    h = (h + 1) & mask;
+  }
+  return false;
+}
+
+}  // namespace
+
+// ============================================================================
+// Phases A + B + C, LDS tier.
+// dynamic LDS: [tag NB][data NB*128][fa 2F][fn 2F][fc 2F][lh 2F x u64][lhslot 2F]
+//              [tgt TG][th 3*TH][misc 4][rs rs_cap]
+// ============================================================================
+__global__ __launch_bounds__(64) void g2s_fill_lds(const uint32_t* __restrict__ succ,
+                                                    const GapDev* __restrict__ gaps,
+                                                    const uint32_t* __restrict__ gap_ids,
+                                                    const uint32_t* __restrict__ flank_nodes, uint64_t* log_all,
+                                                    uint32_t* lvl_all, GapOut* outs, uint32_t rs_cap_max) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  const uint32_t gi = __builtin_amdgcn_readfirstlane(gap_ids[blockIdx.x]);
+  const GapDev gd = gaps[gi];
+  const int lane = threadIdx.x;
+  GapOut* go = &outs[gi];
+
+  uint32_t* tag = lds;
+  uint32_t* data = tag + LDS_NB;
+  uint32_t* fa = data + LDS_NB * LDS_BLK_WORDS;   // phase A frontiers [2][F]
+  uint32_t* fn = fa + 2 * LDS_F;                  // phase B frontier nodes [2][F]
+  uint32_t* fc = fn + 2 * LDS_F;                  // phase B frontier counts [2][F]
+  uint64_t* lh = (uint64_t*)(fc + 2 * LDS_F);     // level merge table keys
+  uint32_t* lhslot = (uint32_t*)(lh + LDS_LH);
+  uint32_t* tgt = lhslot + LDS_LH;
+  uint32_t* th_j = tgt + LDS_TG;
+  uint32_t* th_d = th_j + LDS_TH;
+  uint32_t* th_c = th_d + LDS_TH;
+  uint32_t* misc = th_c + LDS_TH;                 // [0] = number of target hits
+  uint32_t* rs = misc + 4;
+
+  const uint32_t rs_cap = gd.rs_mask + 1u;  // LDS capacity chosen by the host for this gap (<= rs_cap_max)
+  const uint32_t rmask = gd.rs_mask;
+  const uint32_t* lseeds = flank_nodes + gd.flank_off;
+  const uint32_t* rseeds = lseeds + (uint32_t)(gd.lmf + 1);
+  const uint32_t* targets = rseeds + (uint32_t)(gd.rmf + 1);
+  uint64_t* log = log_all + gd.slog_off;
+  uint32_t* lvl = lvl_all + gd.lvl_off;
+  const uint32_t cap = gd.slog_cap;
+
+  for (uint32_t i = (uint32_t)lane; i < LDS_NB; i += 64u) tag[i] = G2S_DEV_INVALID;
+  for (uint32_t i = (uint32_t)lane; i < rs_cap; i += 64u) rs[i] = G2S_DEV_INVALID;
+  for (uint32_t i = (uint32_t)lane; i < LDS_LH; i += 64u) lh[i] = G2S_DEV_EMPTY64;
+  if (lane <= gd.rmf && lane < (int)LDS_TG) tgt[lane] = targets[lane];
+  if (lane == 0) misc[0] = 0;
+  uint64_t tbloom = 0;  // which hash bits any target k-mer sets
+  for (int j = 0; j <= gd.rmf; j++) {
+    const uint32_t t = targets[j];
+    if (t != G2S_DEV_INVALID) tbloom |= 1ull << (mix32(t) & 63u);
+  }
+  lds_sync();
+  (void)rs_cap_max;
+
+  uint32_t flags = 0;
+  bool overflow = (gd.rmf + 1 > (int)LDS_TG);
+
+  // ---------------- phase A: right BFS (Gap2Seq.cpp:871-982) -------------------
+  uint32_t nvis = 0, xa = 0;
+  {
+    uint32_t cur = 0, nb = 0;
+    const uint32_t s0 = rseeds[0];
+    if (s0 != G2S_DEV_INVALID) {
+      if (lane == 0) { lrs_insert(rs, rmask, s0); fa[0] = s0; }
+      nb = 1;
+      nvis = 1;
+    }
+    lds_sync();
+    for (int d = 1; d <= gd.right_half && !overflow; d++) {
+      uint32_t* fcur = fa + cur * LDS_F;
+      uint32_t* fnxt = fa + (cur ^ 1u) * LDS_F;
+      uint32_t nnew = 0;
+      xa += nb;
+      for (uint32_t i0 = 0; i0 < nb * 4u; i0 += 64u) {
+        const uint32_t i = i0 + (uint32_t)lane;
+        const bool valid = i < nb * 4u;
+        const uint32_t n = valid ? fcur[i >> 2] : 0u;
+        const uint32_t nt = i & 3u;
+        if (valid && nt == 0 && lrs_has(rs, rmask, n ^ 1u)) flags |= G2S_DEV_Q7_A;
+        // graph.predecessors(n)[nt] = graph.successors(n^1)[nt] ^ 1
+        const uint32_t p = flip(cached_succ(succ, tag, data, valid, n ^ 1u, nt, lane));
+        uint32_t isnew = 0;
+        if (p != G2S_DEV_INVALID) {
+          const int r = lrs_insert(rs, rmask, p);
+          isnew = (r == 1);
+          if (r == 2) flags |= G2S_DEV_OVERFLOW_A;
+        }
+        const uint64_t m = __ballot(isnew);
+        if (isnew) {
+          const uint32_t off = nnew + (uint32_t)__popcll(m & lanes_below(lane));
+          if (off < LDS_F) fnxt[off] = p;
+        }
+        nnew += (uint32_t)__popcll(m);
+      }
+      nvis += nnew;
+      if (nnew > LDS_F || nvis > rs_cap / 4u * 3u) { overflow = true; break; }
+      lds_sync();
+      if (d <= gd.rmf) {  // next right-flank seed (:953-976)
+        const uint32_t s = rseeds[d];
+        if (s != G2S_DEV_INVALID) {
+          int r = 0;
+          if (lane == 0) r = lrs_insert(rs, rmask, s);
+          r = __shfl(r, 0);
+          if (r == 1) {
+            if (nnew < LDS_F) { if (lane == 0) fnxt[nnew] = s; } else overflow = true;
+            nnew++;
+            nvis++;
+          }
+          lds_sync();
+        }
+      }
+      cur ^= 1u;
+      nb = nnew;
+      if (nb == 0 && d >= gd.rmf) break;
+    }
+    if (overflow) flags |= G2S_DEV_OVERFLOW_A;
+  }
+  lds_sync();
+
+  // ---------------- phase B + C: left DP (Gap2Seq.cpp:984-1167) -----------------
+  uint32_t nlog = 0, xb = 0;
+  bool found = false;
+  int c_count = 0, n_len = 0, len0 = 0, len1 = 0, reached_j = 0, final_d = 0;
+  if (!overflow) {
+    uint32_t cur = 0, nb = 0;
+    {
+      const uint32_t s0 = lseeds[0];  // leftmost k-mer: count 1 at depth 0 (:995-1015)
+      if (s0 != G2S_DEV_INVALID) {
+        if (lane == 0) { fn[0] = s0; fc[0] = 1; log[0] = ((uint64_t)s0 << 32) | 1ull; }
+        nb = 1;
+        nlog = 1;
+      }
+      if (lane == 0) { lvl[0] = 0; lvl[1] = nlog; }
+    }
+    // the leftmost seed can itself be a target k-mer (tandem flanks): depth 0 hit
+    if (lane == 0 && nb == 1) {
+      for (int j = 0; j <= gd.rmf; j++)
+        if (tgt[j] == fn[0]) { const uint32_t idx = misc[0]++; th_j[idx] = (uint32_t)j; th_d[idx] = 0; th_c[idx] = 1; }
+    }
+    lds_sync();
+    int d = 1, lvl_written = 1;  // lvl[0..lvl_written] hold valid offsets
+    for (; d <= gd.D; d++) {
+      uint32_t* ncur = fn + cur * LDS_F;
+      uint32_t* ccur = fc + cur * LDS_F;
+      uint32_t* nnxt = fn + (cur ^ 1u) * LDS_F;
+      uint32_t* cnxt = fc + (cur ^ 1u) * LDS_F;
+      const bool unpruned = d < gd.prune_from;  // :1050 first disjunct
+      uint32_t nnew = 0;
+      xb += nb;
+      if (nb == 1) {
+        // single-entry frontier: its <=4 successors are distinct, no merging needed
+        const uint32_t n = ncur[0];
+        uint32_t np = ccur[0];
+        if (np > G2S_DEV_MAX_PATHS) np = G2S_DEV_MAX_PATHS;
+        const bool valid = lane < 4;
+        const uint32_t v = cached_succ(succ, tag, data, valid, n, (uint32_t)lane & 3u, lane);
+        const bool pass = v != G2S_DEV_INVALID && (unpruned || lrs_has(rs, rmask, v) || lrs_has(rs, rmask, v ^ 1u));
+        const uint64_t m = __ballot(pass);
+        if (pass) {
+          const uint32_t off = (uint32_t)__popcll(m & lanes_below(lane));
+          nnxt[off] = v;
+          cnxt[off] = np;
+        }
+        nnew = (uint32_t)__popcll(m);
+      } else if (nb > 1) {
+        // Q7: both strands of one k-mer in this border (the reference keeps only one)
+        if (lane < (int)nb) {
+          const uint32_t mine = ncur[lane];
+          for (uint32_t e = 0; e < nb; e++) if (ncur[e] == (mine ^ 1u)) flags |= G2S_DEV_Q7_B;
+        }
+        for (uint32_t i0 = 0; i0 < nb * 4u; i0 += 64u) {
+          const uint32_t i = i0 + (uint32_t)lane;
+          const bool valid = i < nb * 4u;
+          const uint32_t n = valid ? ncur[i >> 2] : 0u;
+          uint32_t np = valid ? ccur[i >> 2] : 0u;
+          if (np > G2S_DEV_MAX_PATHS) np = G2S_DEV_MAX_PATHS;
+          const uint32_t v = cached_succ(succ, tag, data, valid, n, i & 3u, lane);
+          const bool pass = v != G2S_DEV_INVALID && (unpruned || lrs_has(rs, rmask, v) || lrs_has(rs, rmask, v ^ 1u));
+          // pass 1: claim (depth, node) in the merge table; stale entries of older levels count as free
+          uint32_t h = 0, won = 0;
+          if (pass) {
+            const uint64_t key = ((uint64_t)(uint32_t)d << 32) | v;
+            h = mix32(v) & (LDS_LH - 1u);
+            while (true) {
+              const uint64_t c = lh[h];
+              if ((uint32_t)(c >> 32) == (uint32_t)d) {
+                if ((uint32_t)c == v) break;          // already claimed at this level
+                h = (h + 1) & (LDS_LH - 1u);          // other node of this level: probe on
+                continue;
+              }
+              const unsigned long long old =
+                  atomicCAS((unsigned long long*)&lh[h], (unsigned long long)c, (unsigned long long)key);
+              if (old == c) { won = 1; break; }       // else somebody changed the slot: look again
+            }
+          }
+          const uint64_t m = __ballot(won);
+          if (won) {
+            const uint32_t off = nnew + (uint32_t)__popcll(m & lanes_below(lane));
+            lhslot[h] = off;
+            if (off < LDS_F) { nnxt[off] = v; cnxt[off] = 0; }
+          }
+          nnew += (uint32_t)__popcll(m);
+          lds_sync();
+          // pass 2: <=4 predecessors x <=MAX_PATHS each: the u32 sum cannot wrap (:1058-1060)
+          if (pass && nnew <= LDS_F) atomicAdd(&cnxt[lhslot[h]], np);
+          lds_sync();
+          if (nnew > LDS_F) break;
+        }
+      }
+      if (nnew > LDS_F) { overflow = true; break; }
+      lds_sync();
+      if (d <= gd.lmf) {  // next left-flank seed, row value ASSIGNED 1 (:1082-1105)
+        const uint32_t s = lseeds[d];
+        if (s != G2S_DEV_INVALID) {
+          const uint64_t m = __ballot(lane < (int)nnew && nnxt[lane] == s);
+          if (m) {
+            if (lane == 0) cnxt[__builtin_ctzll(m)] = 1;
+          } else if (nnew < LDS_F) {
+            if (lane == 0) { nnxt[nnew] = s; cnxt[nnew] = 1; }
+            nnew++;
+          } else { overflow = true; break; }
+          lds_sync();
+        }
+      }
+      // append the level to the state log (fire and forget) and note target k-mers
+      if (nlog + nnew > cap) { overflow = true; break; }
+      if (lane < (int)nnew) {
+        const uint32_t node = nnxt[lane];
+        uint32_t c = cnxt[lane];
+        if (c > G2S_DEV_MAX_PATHS) c = G2S_DEV_MAX_PATHS;
+        log[nlog + (uint32_t)lane] = ((uint64_t)node << 32) | c;
+        if ((tbloom >> (mix32(node) & 63u)) & 1ull) {
+          for (int j = 0; j <= gd.rmf; j++) {
+            if (tgt[j] == node) {
+              const uint32_t idx = atomicAdd(&misc[0], 1u);
+              if (idx < LDS_TH) { th_j[idx] = (uint32_t)j; th_d[idx] = (uint32_t)d; th_c[idx] = c; }
+            }
+          }
+        }
+      }
+      nlog += nnew;
+      if (lane == 0) lvl[d + 1] = nlog;
+      lvl_written = d + 1;
+      lds_sync();
+      if (misc[0] > LDS_TH) { overflow = true; break; }
+      cur ^= 1u;
+      nb = nnew;
+
+      // ---- phase C: target check (:1107-1159) over the recorded hits ---------------
+      if (!found && d >= gd.g + gd.lmf + gd.rmf) {
+        const int err = d - gd.g - (gd.lmf + gd.rmf);
+        const uint32_t nth = misc[0];
+        int bestj = 1 << 30;
+        uint32_t c1 = 0, c2 = 0;
+        for (uint32_t t0 = 0; t0 < nth; t0 += 64u) {
+          const uint32_t t = t0 + (uint32_t)lane;
+          int j = 1 << 30;
+          uint32_t h1 = 0, h2 = 0;
+          if (t < nth) {
+            const int tj = (int)th_j[t], td = (int)th_d[t];
+            const int l1 = gd.g + gd.lmf + tj + err, l2 = gd.g + gd.lmf + tj - err;
+            if (td == l1) h1 = th_c[t];
+            if (err != 0 && l2 >= 0 && td == l2) h2 = th_c[t];
+            if (h1 | h2) j = tj;
+          }
+          int jm = j;
+          for (int o = 32; o > 0; o >>= 1) jm = min(jm, __shfl_xor(jm, o));
+          if (jm < bestj) { bestj = jm; c1 = 0; c2 = 0; }
+          if (jm == bestj && jm < (1 << 30)) {
+            // (node, depth) states are unique: at most one lane holds each of the two lengths
+            const uint64_t m1 = __ballot(j == bestj && h1), m2 = __ballot(j == bestj && h2);
+            if (m1) c1 = (uint32_t)__shfl((int)h1, __builtin_ctzll(m1));
+            if (m2) c2 = (uint32_t)__shfl((int)h2, __builtin_ctzll(m2));
+          }
+        }
+        if (bestj < (1 << 30)) {
+          const uint32_t sum = c1 + c2;
+          c_count = (int)(sum > G2S_DEV_MAX_PATHS ? G2S_DEV_MAX_PATHS : sum);
+          reached_j = bestj;
+          const int l1 = gd.g + gd.lmf + bestj + err, l2 = gd.g + gd.lmf + bestj - err;
+          if (c1 > 0) { len0 = l1; n_len = 1; if (c2 > 0) { len1 = l2; n_len = 2; } }
+          else { len0 = l2; n_len = 1; }
+          found = true;
+        }
+        if (found && !gd.all_paths) break;  // -best-only (:1156-1158)
+      }
+      // nothing left to expand, no seed to come and nothing more to find: the remaining
+      // levels of the reference's loop are empty
+      if (nb == 0 && d > gd.lmf && found) { d = gd.D + 1; break; }
+    }
+    final_d = d;
+    // levels that were never reached are empty
+    for (int dd = lvl_written + 1 + lane; dd <= gd.D + 1; dd += 64) lvl[dd] = nlog;
+    if (overflow) flags |= G2S_DEV_OVERFLOW_B;
+  }
+  for (int o = 32; o > 0; o >>= 1) flags |= __shfl_xor(flags, o);
+  if (lane == 0) {
+    go->flags = flags;
+    go->n_right = nvis;
+    go->x_right = xa;
+    go->n_states = nlog;
+    go->x_left = xb;
+    go->final_d = final_d;
+    go->c_count = c_count;
+    go->n_len = n_len;
+    go->len[0] = len0;
+    go->len[1] = len1;
+    go->reached_j = reached_j;
+  }
+}
+
+// ============================================================================
+// Phase D1 from the level-ordered state log, LDS tier (Gap2Seq.cpp:1169-1312)
+// plus the traceback's closure.  Walks the log backwards, one level per step; the
+// level's entries sit in lane registers, the border of the level above in LDS.
+// dynamic LDS: [tag NB][data NB*128][wl W+1][we_node W][we_cnt W][bn F][be F][bf F]
+//              [cfl F][cem F][lm 4F]
+// ============================================================================
+__global__ __launch_bounds__(64) void g2s_extract_lds(const uint32_t* __restrict__ succ,
+                                                       const GapDev* __restrict__ gaps,
+                                                       const uint32_t* __restrict__ gap_ids,
+                                                       const uint32_t* __restrict__ flank_nodes,
+                                                       const uint64_t* __restrict__ log_all,
+                                                       const uint32_t* __restrict__ lvl_all, SubState* sub_scratch,
+                                                       SubState* sub_out, unsigned long long* out_counter,
+                                                       GapOut* outs, int skip_confident) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  const uint32_t gi = __builtin_amdgcn_readfirstlane(gap_ids[blockIdx.x]);
+  const GapDev gd = gaps[gi];
+  const int lane = threadIdx.x;
+  GapOut* go = &outs[gi];
+  const uint32_t gflags = go->flags;
+  const int c_count = go->c_count, n_len = go->n_len;
+  if ((gflags & (G2S_DEV_OVERFLOW_A | G2S_DEV_OVERFLOW_B)) || !(c_count > 0 && n_len > 0)) return;  // :1169
+
+  uint32_t* tag = lds;
+  uint32_t* data = tag + LDS_NB;
+  uint32_t* wl = data + LDS_NB * LDS_BLK_WORDS;  // level offsets window [W+1]
+  uint32_t* wen = wl + (LDS_W + 1u);             // log window: nodes
+  uint32_t* wec = wen + LDS_W;                   // log window: counts
+  uint32_t* bn = wec + LDS_W;                    // border (depth d2+1): node, emit index, flags
+  uint32_t* be = bn + LDS_F;
+  uint32_t* bf = be + LDS_F;
+  uint32_t* cfl = bf + LDS_F;                    // candidates (depth d2): accumulated flags, emit index
+  uint32_t* cem = cfl + LDS_F;
+  uint32_t* lm = cem + LDS_F;                    // match of each (border entry, nt) among the candidates
+
+  const uint64_t* log = log_all + gd.slog_off;
+  const uint32_t* lvl = lvl_all + gd.lvl_off;
+  SubState* sub = sub_scratch + gd.slog_off;
+  const uint32_t* lseeds = flank_nodes + gd.flank_off;
+  const uint32_t* targets = lseeds + (uint32_t)(gd.lmf + 1) + (uint32_t)(gd.rmf + 1);
+  const int len0 = go->len[0], len1 = go->len[1];
+  const uint32_t reached = targets[go->reached_j];
+  const bool want_s = !skip_confident;
+  const uint32_t sinknode = (want_s && gd.all_paths && gd.rmf >= 1) ? targets[gd.rmf - 1] : G2S_DEV_INVALID;
+  const int lo_sink = max(0, gd.lmf + gd.g - gd.e);  // :1196
+  const uint32_t t_flags = G2S_SUB_IN_T | G2S_SUB_START_T | ((want_s && !gd.all_paths) ? (G2S_SUB_IN_S | G2S_SUB_SINK) : 0u);
+  const int min_len = n_len > 1 ? min(len0, len1) : len0;
+
+  for (uint32_t i = (uint32_t)lane; i < LDS_NB; i += 64u) tag[i] = G2S_DEV_INVALID;
+  lds_sync();
+
+  int wl_lo = gd.D + 2;          // wl[i] = lvl[wl_lo + i], i in [0, W]
+  uint32_t we_lo = 0, we_hi = 0; // log positions [we_lo, we_hi) are in the entry window
+  uint32_t nsub = 0, nbord = 0, xcount = 0, lflags = 0;
+  const uint32_t cap = gd.slog_cap;
+
+  for (int d2 = gd.D; d2 >= 0; d2--) {
+    if (nbord == 0 && d2 < min_len && (sinknode == G2S_DEV_INVALID || d2 < lo_sink)) break;  // nothing can start below
+    // ---- level offsets and entries of depth d2 through the LDS windows ---------------
+    if (d2 < wl_lo) {
+      lds_sync();
+      wl_lo = max(0, d2 + 1 - (int)LDS_W);
+      for (uint32_t i = (uint32_t)lane; i <= LDS_W; i += 64u) {
+        const int dd = wl_lo + (int)i;
+        wl[i] = dd <= gd.D + 1 ? lvl[dd] : 0xFFFFFFFFu;
+      }
+      lds_sync();
+    }
+    const uint32_t lo = wl[d2 - wl_lo], hi = wl[d2 + 1 - wl_lo];
+    const uint32_t w = hi - lo;  // <= LDS_F by construction of the log
+    if (w == 0 && nbord == 0) continue;
+    if (w > 0 && (lo < we_lo || hi > we_hi)) {
+      lds_sync();
+      we_hi = hi;
+      we_lo = hi > LDS_W ? hi - LDS_W : 0u;
+      for (uint32_t i = (uint32_t)lane; i < we_hi - we_lo; i += 64u) {
+        const uint64_t e = log[we_lo + i];
+        wen[i] = (uint32_t)(e >> 32);
+        wec[i] = (uint32_t)e;
+      }
+      lds_sync();
+    }
+    // candidates of this level live in lane registers
+    const bool is_c = (uint32_t)lane < w;
+    const uint32_t cn = is_c ? wen[lo - we_lo + (uint32_t)lane] : G2S_DEV_INVALID;
+    const uint32_t cc = is_c ? wec[lo - we_lo + (uint32_t)lane] : 0u;
+    uint32_t cf = 0;
+    // new paths starting at this depth (:1195-1259)
+    if (is_c && cn == sinknode && d2 >= lo_sink) cf |= G2S_SUB_IN_S | G2S_SUB_SINK;
+    if (is_c && cn == reached && (d2 == len0 || (n_len > 1 && d2 == len1))) cf |= t_flags;
+    if (is_c) cfl[lane] = 0;
+    lds_sync();
+    // ---- expand the border of depth d2+1 towards this level (:1266-1301) ---------------
+    xcount += nbord;
+    for (uint32_t i0 = 0; i0 < nbord * 4u; i0 += 64u) {
+      const uint32_t i = i0 + (uint32_t)lane;
+      const bool valid = i < nbord * 4u;
+      const uint32_t e = i >> 2, nt = i & 3u;
+      const uint32_t cur = valid ? bn[e] : 0u;
+      const uint32_t f = valid ? bf[e] : 0u;
+      const bool expand = valid && !(f & G2S_SUB_SOURCE);
+      const uint32_t p = flip(cached_succ(succ, tag, data, expand, cur ^ 1u, nt, lane));
+      uint32_t match = 0xFFFFFFFFu;
+      for (uint32_t c = 0; c < w; c++) {
+        const uint32_t cand = (uint32_t)__shfl((int)cn, (int)c);
+        if (p != G2S_DEV_INVALID && p == cand) match = c;
+      }
+      if (match != 0xFFFFFFFFu) atomicOr(&cfl[match], f & (G2S_SUB_IN_S | G2S_SUB_IN_T));
+      if (valid) lm[i] = match;
+    }
+    lds_sync();
+    // ---- reached candidates join the closure ------------------------------------------
+    if (is_c) cf |= cfl[lane];
+    lds_sync();
+    if (is_c) cfl[lane] = cf;  // final flags, visible to the other candidates (Q7 check)
+    lds_sync();
+    const bool in = is_c && cf != 0;
+    const uint64_t m = __ballot(in);
+    const uint32_t nin = (uint32_t)__popcll(m);
+    if (nsub + nin > cap) { lflags |= G2S_DEV_OVERFLOW_B; break; }
+    const uint32_t lidx = (d2 <= gd.lmf) ? (lseeds[d2] >> 1) : 0xFFFFFFFFu;  // buildNode(kmer_left.substr(d2,k))
+    const uint32_t slot = (uint32_t)__popcll(m & lanes_below(lane));
+    if (in) {
+      if (d2 <= gd.lmf && (cn >> 1) == lidx) cf |= G2S_SUB_SOURCE;  // :1270 end condition, k-mer comparison only
+      SubState st;
+      st.node = cn; st.depth = (uint32_t)d2; st.cnt = cc; st.flags = cf;
+      st.pred[0] = st.pred[1] = st.pred[2] = st.pred[3] = -1;
+      sub[nsub + slot] = st;
+      cem[lane] = nsub + slot;
+      // Q7: both strands of one k-mer in this border
+      for (uint32_t c = 0; c < w; c++) {
+        const uint32_t other = wen[lo - we_lo + c];
+        if (other == (cn ^ 1u) && cfl[c] != 0u) lflags |= G2S_DEV_Q7_D;
+      }
+    }
+    lds_sync();
+    // ---- links from the border above to this level -------------------------------------
+    for (uint32_t i0 = 0; i0 < nbord * 4u; i0 += 64u) {
+      const uint32_t i = i0 + (uint32_t)lane;
+      if (i < nbord * 4u) {
+        const uint32_t match = lm[i];
+        if (match != 0xFFFFFFFFu) sub[be[i >> 2]].pred[i & 3u] = (int32_t)cem[match];
+      }
+    }
+    lds_sync();
+    if (in) { bn[slot] = cn; be[slot] = nsub + slot; bf[slot] = cf; }
+    nsub += nin;
+    nbord = nin;
+    lds_sync();
+  }
+  for (int o = 32; o > 0; o >>= 1) lflags |= __shfl_xor(lflags, o);
+  if (lflags & G2S_DEV_OVERFLOW_B) {
+    if (lane == 0) go->flags = gflags | lflags;
+    return;
+  }
+  // ---- pack: reserve exactly n_sub records in the dense output --------------------------
+  __threadfence_block();
+  unsigned long long base = 0;
+  if (lane == 0) base = atomicAdd(out_counter, (unsigned long long)nsub);
+  base = __shfl(base, 0);
+  const uint32_t* src = (const uint32_t*)sub;
+  uint32_t* dst = (uint32_t*)(sub_out + base);
+  for (uint32_t i = (uint32_t)lane; i < nsub * 8u; i += 64u)
+    dst[i] = __hip_atomic_load(&src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (lane == 0) {
+    go->flags = gflags | lflags;
+    go->n_sub = nsub;
+    go->sub_off = base;
+    go->x_sub = xcount;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// launchers (host)
+// ---------------------------------------------------------------------------
+namespace g2s {
+
+size_t fill_lds_bytes(uint32_t rs_cap) {
+  return 4u * (LDS_NB + LDS_NB * LDS_BLK_WORDS + 2 * LDS_F * 3 + LDS_LH * 2 + LDS_LH + LDS_TG + 3 * LDS_TH + 4 + rs_cap);
+}
+size_t extract_lds_bytes() {
+  return 4u * (LDS_NB + LDS_NB * LDS_BLK_WORDS + (LDS_W + 1) + 2 * LDS_W + 5 * LDS_F + 4 * LDS_F);
+}
+uint32_t fill_lds_frontier_cap() { return LDS_F; }
+uint32_t fill_lds_max_fuz() { return LDS_TG - 1; }
+
+hipError_t launch_fill_lds(hipStream_t st, uint32_t ngaps, uint32_t rs_cap_max, const uint32_t* succ, const GapDev* gaps,
+                           const uint32_t* gap_ids, const uint32_t* flank_nodes, uint64_t* log_all, uint32_t* lvl_all,
+                           GapOut* outs) {
+  if (ngaps == 0) return hipSuccess;
+  const size_t bytes = fill_lds_bytes(rs_cap_max);
+  hipError_t e = hipFuncSetAttribute((const void*)g2s_fill_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(g2s_fill_lds, dim3(ngaps), dim3(64), bytes, st, succ, gaps, gap_ids, flank_nodes, log_all, lvl_all,
+                     outs, rs_cap_max);
+  return hipGetLastError();
+}
+
+hipError_t launch_extract_lds(hipStream_t st, uint32_t ngaps, const uint32_t* succ, const GapDev* gaps,
+                              const uint32_t* gap_ids, const uint32_t* flank_nodes, const uint64_t* log_all,
+                              const uint32_t* lvl_all, SubState* sub_scratch, SubState* sub_out,
+                              unsigned long long* out_counter, GapOut* outs, int skip_confident) {
+  if (ngaps == 0) return hipSuccess;
+  hipLaunchKernelGGL(g2s_extract_lds, dim3(ngaps), dim3(64), extract_lds_bytes(), st, succ, gaps, gap_ids, flank_nodes,
+                     log_all, lvl_all, sub_scratch, sub_out, out_counter, outs, skip_confident);
+  return hipGetLastError();
+}
+
+}  // namespace g2s

@@ -171,7 +171,9 @@ extern "C" int g2s_graph_upload(g2s_graph* gh, int device) {
   HIP_TRY(hipSetDevice(device));
   DeviceGraph dg;
   const size_t bytes = g.succ.size() * sizeof(uint32_t);
-  HIP_TRY(hipMalloc((void**)&dg.succ, std::max<size_t>(bytes, 16)));
+  // the LDS tier reads whole 512 B blocks: pad the table with INVALID entries
+  HIP_TRY(hipMalloc((void**)&dg.succ, bytes + 1024));
+  HIP_TRY(hipMemset(dg.succ, 0xFF, bytes + 1024));
   HIP_TRY(hipMemcpy(dg.succ, g.succ.data(), bytes, hipMemcpyHostToDevice));
   dg.bytes = bytes;
   if (!g.pred.empty()) {
@@ -313,8 +315,10 @@ struct g2s_session {
   g2s_params params;
   RandCache rcache;
   WorkerPool* pool = nullptr;
+  bool no_lds_tier = false;  // G2S_NO_LDS_TIER=1: force the general HBM tier (tests, A/B timing)
   size_t mem_budget = 0;  // bytes of HBM this session may use for work areas
   DevBuf d_gaps, d_ids, d_flank, d_outs, d_rs, d_rlog, d_keys, d_cnt, d_mark, d_slog, d_subscr, d_subout, d_counter;
+  DevBuf d_log, d_lvl;  // LDS tier: level-ordered state log + level offsets
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 
@@ -328,6 +332,7 @@ extern "C" int g2s_session_create(g2s_graph* g, int device, const g2s_params* p,
   s->device = device;
   s->params = *p;
   s->rcache.seed(p->randseed);
+  if (const char* env = getenv("G2S_NO_LDS_TIER")) s->no_lds_tier = atoi(env) != 0;
   hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
   for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipEventCreate(&s->ev[i]);
   size_t free_b = 0, total_b = 0;
@@ -347,7 +352,8 @@ extern "C" void g2s_session_destroy(g2s_session* s) {
   if (!s) return;
   (void)hipSetDevice(s->device);
   DevBuf* bufs[] = {&s->d_gaps, &s->d_ids, &s->d_flank, &s->d_outs, &s->d_rs, &s->d_rlog, &s->d_keys,
-                    &s->d_cnt, &s->d_mark, &s->d_slog, &s->d_subscr, &s->d_subout, &s->d_counter};
+                    &s->d_cnt, &s->d_mark, &s->d_slog, &s->d_subscr, &s->d_subout, &s->d_counter,
+                    &s->d_log, &s->d_lvl};
   for (DevBuf* b : bufs) b->release();
   delete s->pool;
   for (int i = 0; i < 4; i++) if (s->ev[i]) (void)hipEventDestroy(s->ev[i]);
@@ -444,6 +450,25 @@ struct Plan {  // per-gap capacities at one scale
   uint64_t bytes;
 };
 
+// LDS tier: capacity of the in-LDS right set for one gap, 0 when the gap is not eligible
+// `room` = entries the launch can afford per gap (LDS per CU / gaps per CU).
+uint32_t lds_rs_cap(const GapJob& j, int d_err, uint32_t room) {
+  const int right_half = j.rmf + (j.g + d_err + 1) / 2;
+  if (j.rmf > (int)fill_lds_max_fuz()) return 0;
+  const uint64_t need = (uint64_t)pow2ceil(std::max<uint64_t>(512, 2ull * (uint64_t)(right_half + j.rmf + 2)));
+  if (need > room) return 0;
+  // small batches leave most of the 160 KB/CU unused: take it, branching right sets then stay in LDS
+  return (uint32_t)std::max<uint64_t>(need, room);
+}
+// entries of right set each gap may have in LDS when `ngaps` gaps share the chip
+uint32_t lds_room(size_t ngaps) {
+  const size_t per_cu = std::max<size_t>(1, (ngaps + 255) / 256);
+  const size_t bytes = (160u * 1024u) / std::min<size_t>(per_cu, 6) - fill_lds_bytes(0) - 512;
+  uint32_t cap = 512;
+  while ((size_t)cap * 2 * 4 <= bytes && cap < 16384) cap <<= 1;
+  return cap;
+}
+
 Plan plan_gap(const GapJob& j, int d_err, uint64_t scale, uint64_t max_states) {
   const int right_half = j.rmf + (j.g + d_err + 1) / 2;
   const int D = j.lmf + j.rmf + j.g + d_err;
@@ -460,15 +485,19 @@ Plan plan_gap(const GapJob& j, int d_err, uint64_t scale, uint64_t max_states) {
   return p;
 }
 
-// Launch phases A-D1 for the listed gaps at one table scale and bring the results back.
-int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uint64_t max_states, TierData* td) {
+// Launch phases A-D1 for the listed gaps and bring the results back.  lds = true: the
+// LDS-resident kernels (fill_lds.hip); false: the general tier with per-gap tables in
+// HBM (fill_kernels.hip) at the given table scale.
+int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uint64_t max_states, TierData* td,
+             bool lds) {
   g2s_session* s = b->s;
   const DeviceGraph& dg = s->graph->g->dev.at(s->device);
   const size_t n = b->jobs.size();
   const int d_err = s->params.d_err;
   std::vector<GapDev> gd(n);
   memset(gd.data(), 0, n * sizeof(GapDev));
-  uint64_t rs_total = 0, rlog_total = 0, st_total = 0, slog_total = 0;
+  uint64_t rs_total = 0, rlog_total = 0, st_total = 0, slog_total = 0, lvl_total = 0;
+  uint32_t lds_cap_max = 0;
   td->gap_ids = ids;
   for (size_t x = 0; x < ids.size(); x++) {
     const uint32_t i = ids[x];
@@ -487,16 +516,16 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
     d.rlog_off = rlog_total; rlog_total += p.rlog_cap;
     d.st_off = st_total; st_total += 2ull * p.slog_cap;
     d.slog_off = slog_total; slog_total += p.slog_cap;
+    d.lvl_off = lvl_total; lvl_total += (uint64_t)(d.D + 2);
+    if (lds) {
+      const uint32_t c = lds_rs_cap(j, d_err, lds_room(ids.size()));
+      d.rs_mask = c - 1;
+      lds_cap_max = std::max(lds_cap_max, c);
+    }
   }
   HIP_TRY(s->d_gaps.ensure(n * sizeof(GapDev)));
   HIP_TRY(s->d_ids.ensure(std::max<size_t>(ids.size() * 4, 16)));
   HIP_TRY(s->d_outs.ensure(n * sizeof(GapOut)));
-  HIP_TRY(s->d_rs.ensure(rs_total * 4));
-  HIP_TRY(s->d_rlog.ensure(rlog_total * 4));
-  HIP_TRY(s->d_keys.ensure(st_total * 8));
-  HIP_TRY(s->d_cnt.ensure(st_total * 4));
-  HIP_TRY(s->d_mark.ensure(st_total * 4));
-  HIP_TRY(s->d_slog.ensure(slog_total * 4));
   HIP_TRY(s->d_subscr.ensure(slog_total * sizeof(SubState)));
   HIP_TRY(s->d_subout.ensure(slog_total * sizeof(SubState)));
   HIP_TRY(s->d_counter.ensure(16));
@@ -504,27 +533,50 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
   HIP_TRY(hipMemcpyAsync(s->d_gaps.p, gd.data(), n * sizeof(GapDev), hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemcpyAsync(s->d_ids.p, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemsetAsync(s->d_outs.p, 0, n * sizeof(GapOut), st));
-  HIP_TRY(hipMemsetAsync(s->d_rs.p, 0xFF, rs_total * 4, st));
-  HIP_TRY(hipMemsetAsync(s->d_keys.p, 0xFF, st_total * 8, st));
-  HIP_TRY(hipMemsetAsync(s->d_cnt.p, 0, st_total * 4, st));
-  HIP_TRY(hipMemsetAsync(s->d_mark.p, 0, st_total * 4, st));
   HIP_TRY(hipMemsetAsync(s->d_counter.p, 0, 16, st));
-
-  HIP_TRY(hipEventRecord(s->ev[0], st));
-  HIP_TRY(launch_right_bfs(st, (uint32_t)ids.size(), dg.succ, dg.pred, (const GapDev*)s->d_gaps.p,
-                           (const uint32_t*)s->d_ids.p, (const uint32_t*)s->d_flank.p, (uint32_t*)s->d_rs.p,
-                           (uint32_t*)s->d_rlog.p, (GapOut*)s->d_outs.p));
-  HIP_TRY(hipEventRecord(s->ev[1], st));
-  HIP_TRY(launch_left_dp(st, (uint32_t)ids.size(), dg.succ, (const GapDev*)s->d_gaps.p, (const uint32_t*)s->d_ids.p,
-                         (const uint32_t*)s->d_flank.p, (const uint32_t*)s->d_rs.p, (uint64_t*)s->d_keys.p,
-                         (uint32_t*)s->d_cnt.p, (uint32_t*)s->d_slog.p, (GapOut*)s->d_outs.p));
-  HIP_TRY(hipEventRecord(s->ev[2], st));
-  HIP_TRY(launch_extract(st, (uint32_t)ids.size(), dg.succ, dg.pred, (const GapDev*)s->d_gaps.p,
-                         (const uint32_t*)s->d_ids.p, (const uint32_t*)s->d_flank.p, (const uint64_t*)s->d_keys.p,
-                         (const uint32_t*)s->d_cnt.p, (uint32_t*)s->d_mark.p, (SubState*)s->d_subscr.p,
-                         (SubState*)s->d_subout.p, (unsigned long long*)s->d_counter.p, (GapOut*)s->d_outs.p,
-                         s->params.skip_confident ? 1 : 0));
-  HIP_TRY(hipEventRecord(s->ev[3], st));
+  if (lds) {
+    HIP_TRY(s->d_log.ensure(slog_total * 8));
+    HIP_TRY(s->d_lvl.ensure(lvl_total * 4));
+    HIP_TRY(hipEventRecord(s->ev[0], st));
+    HIP_TRY(hipEventRecord(s->ev[1], st));  // phases A-C are one kernel in this tier
+    HIP_TRY(launch_fill_lds(st, (uint32_t)ids.size(), lds_cap_max, dg.succ, (const GapDev*)s->d_gaps.p,
+                            (const uint32_t*)s->d_ids.p, (const uint32_t*)s->d_flank.p, (uint64_t*)s->d_log.p,
+                            (uint32_t*)s->d_lvl.p, (GapOut*)s->d_outs.p));
+    HIP_TRY(hipEventRecord(s->ev[2], st));
+    HIP_TRY(launch_extract_lds(st, (uint32_t)ids.size(), dg.succ, (const GapDev*)s->d_gaps.p,
+                               (const uint32_t*)s->d_ids.p, (const uint32_t*)s->d_flank.p, (const uint64_t*)s->d_log.p,
+                               (const uint32_t*)s->d_lvl.p, (SubState*)s->d_subscr.p, (SubState*)s->d_subout.p,
+                               (unsigned long long*)s->d_counter.p, (GapOut*)s->d_outs.p,
+                               s->params.skip_confident ? 1 : 0));
+    HIP_TRY(hipEventRecord(s->ev[3], st));
+  } else {
+    HIP_TRY(s->d_rs.ensure(rs_total * 4));
+    HIP_TRY(s->d_rlog.ensure(rlog_total * 4));
+    HIP_TRY(s->d_keys.ensure(st_total * 8));
+    HIP_TRY(s->d_cnt.ensure(st_total * 4));
+    HIP_TRY(s->d_mark.ensure(st_total * 4));
+    HIP_TRY(s->d_slog.ensure(slog_total * 4));
+    HIP_TRY(hipMemsetAsync(s->d_rs.p, 0xFF, rs_total * 4, st));
+    HIP_TRY(hipMemsetAsync(s->d_keys.p, 0xFF, st_total * 8, st));
+    HIP_TRY(hipMemsetAsync(s->d_cnt.p, 0, st_total * 4, st));
+    HIP_TRY(hipMemsetAsync(s->d_mark.p, 0, st_total * 4, st));
+    HIP_TRY(hipEventRecord(s->ev[0], st));
+    HIP_TRY(launch_right_bfs(st, (uint32_t)ids.size(), dg.succ, dg.pred, (const GapDev*)s->d_gaps.p,
+                             (const uint32_t*)s->d_ids.p, (const uint32_t*)s->d_flank.p, (uint32_t*)s->d_rs.p,
+                             (uint32_t*)s->d_rlog.p, (GapOut*)s->d_outs.p));
+    HIP_TRY(hipEventRecord(s->ev[1], st));
+    HIP_TRY(launch_left_dp(st, (uint32_t)ids.size(), dg.succ, (const GapDev*)s->d_gaps.p,
+                           (const uint32_t*)s->d_ids.p, (const uint32_t*)s->d_flank.p, (const uint32_t*)s->d_rs.p,
+                           (uint64_t*)s->d_keys.p, (uint32_t*)s->d_cnt.p, (uint32_t*)s->d_slog.p,
+                           (GapOut*)s->d_outs.p));
+    HIP_TRY(hipEventRecord(s->ev[2], st));
+    HIP_TRY(launch_extract(st, (uint32_t)ids.size(), dg.succ, dg.pred, (const GapDev*)s->d_gaps.p,
+                           (const uint32_t*)s->d_ids.p, (const uint32_t*)s->d_flank.p, (const uint64_t*)s->d_keys.p,
+                           (const uint32_t*)s->d_cnt.p, (uint32_t*)s->d_mark.p, (SubState*)s->d_subscr.p,
+                           (SubState*)s->d_subout.p, (unsigned long long*)s->d_counter.p, (GapOut*)s->d_outs.p,
+                           s->params.skip_confident ? 1 : 0));
+    HIP_TRY(hipEventRecord(s->ev[3], st));
+  }
 
   // device -> host: per-gap results, then the packed closures
   HIP_TRY(td->outs.ensure(n * sizeof(GapOut)));
@@ -579,9 +631,45 @@ extern "C" int g2s_batch_run(g2s_batch* b, g2s_result* results, char* arena, siz
   std::vector<char> mem_exceeded(n, 0);
 
   // ---- GPU: phases A-D1, retrying gaps whose tables overflowed with 8x larger ones
-  std::vector<uint32_t> todo;
-  for (size_t i = 0; i < n; i++) if (!b->jobs[i].bad_flank) todo.push_back((uint32_t)i);
-  uint64_t scale = 1;
+  std::vector<uint32_t> todo, lds_ids;
+  const bool lds_ok = s->graph->g->dev.at(s->device).pred == nullptr && !s->no_lds_tier;
+  {
+    size_t nvalid = 0;
+    for (size_t i = 0; i < n; i++) nvalid += !b->jobs[i].bad_flank;
+    const uint32_t room = lds_room(nvalid);
+    for (size_t i = 0; i < n; i++) {
+      if (b->jobs[i].bad_flank) continue;
+      if (lds_ok && lds_rs_cap(b->jobs[i], fp.d_err, room) != 0) lds_ids.push_back((uint32_t)i);
+      else todo.push_back((uint32_t)i);
+    }
+  }
+  // ---- tier 0: LDS-resident kernels; whatever does not fit falls through to the HBM tier
+  if (!lds_ids.empty()) {
+    TierData* td = new TierData();
+    b->tiers.push_back(td);
+    int rc = run_tier(b, lds_ids, 1, max_states, td, true);
+    if (rc != G2S_OK) return rc;
+    const GapOut* outs = (const GapOut*)td->outs.p;
+    for (uint32_t i : lds_ids) {
+      const GapOut& go = outs[i];
+      if (go.flags & (G2S_DEV_OVERFLOW_A | G2S_DEV_OVERFLOW_B)) { todo.push_back(i); continue; }
+      SubView& v = views[i];
+      v.out = &go;
+      v.st = (const SubState*)td->subs.p + go.sub_off;
+      v.n = go.n_sub;
+      b->timing.xA += go.x_right; b->timing.sA += go.n_right;
+      b->timing.xB += go.x_left; b->timing.sB += go.n_states;
+      b->timing.xD += go.x_sub; b->timing.sD += go.n_sub;
+    }
+    size_t before = todo.size();
+    (void)before;
+    uint32_t fell = 0;
+    for (uint32_t i : lds_ids) if (!views[i].out) fell++;
+    std::sort(todo.begin(), todo.end());
+    b->timing.retried_gaps += fell;
+  }
+  // gaps that outgrew the LDS tier are known to branch: start them with 8x tables
+  uint64_t scale = lds_ids.empty() ? 1 : 8;
   while (!todo.empty()) {
     std::vector<uint32_t> next_todo;
     size_t pos = 0;
@@ -596,7 +684,7 @@ extern "C" int g2s_batch_run(g2s_batch* b, g2s_result* results, char* arena, siz
       }
       TierData* td = new TierData();
       b->tiers.push_back(td);
-      int rc = run_tier(b, group, scale, max_states, td);
+      int rc = run_tier(b, group, scale, max_states, td, false);
       if (rc != G2S_OK) return rc;
       const GapOut* outs = (const GapOut*)td->outs.p;
       for (size_t x = 0; x < group.size(); x++) {

