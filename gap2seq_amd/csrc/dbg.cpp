@@ -179,8 +179,9 @@ inline int out_degree(const std::vector<uint32_t>& succ, uint32_t v, uint32_t* o
 // New node indices in unitig order: k-mers of one maximal non-branching path are
 // consecutive, in path order.  rank-space tables in, permutation out.
 void unitig_order(const std::vector<uint32_t>& succ, uint64_t n, bool even_k, std::vector<uint32_t>* rank2id,
-                  uint64_t* n_unitigs) {
+                  std::vector<uint8_t>* flip, uint64_t* n_unitigs) {
   rank2id->assign((size_t)n, kInvalidNode);
+  flip->assign((size_t)n, 0);
   uint32_t next_id = 0;
   uint64_t unitigs = 0;
   // the unique continuation v -> w when the edge is unitig-internal
@@ -213,6 +214,7 @@ void unitig_order(const std::vector<uint32_t>& succ, uint64_t n, bool even_k, st
     unitigs++;
     while (true) {
       (*rank2id)[v >> 1] = next_id++;
+      (*flip)[v >> 1] = (uint8_t)(v & 1u);  // GATB strand of the numbering direction
       uint32_t w = step(v);
       if (w == kInvalidNode || (*rank2id)[w >> 1] != kInvalidNode) break;
       v = w;
@@ -226,7 +228,7 @@ void finish_graph(Graph& g, int nthreads) {
   build_bucket_index<KT>(g);
   std::vector<uint32_t> succ_r, pred_r;
   build_tables_rank<KT>(g, nthreads, &succ_r, &pred_r);
-  unitig_order(succ_r, g.n, (g.k % 2) == 0, &g.rank2id, &g.n_unitigs);
+  unitig_order(succ_r, g.n, (g.k % 2) == 0, &g.rank2id, &g.flip, &g.n_unitigs);
   g.id2rank.assign((size_t)g.n, 0);
   for (uint64_t r = 0; r < g.n; r++) g.id2rank[g.rank2id[(size_t)r]] = (uint32_t)r;
   // permute tables into id space
@@ -236,21 +238,26 @@ void finish_graph(Graph& g, int nthreads) {
   g.lastnt.assign((size_t)g.n * 2, 0);
   const int k = g.k;
   parallel_for(g.n, nthreads, [&](uint64_t b, uint64_t e, int) {
+    auto remap = [&](uint32_t w) -> uint32_t {  // rank-space (GATB strand) -> id-space (unitig orientation)
+      return 2 * g.rank2id[w >> 1] + ((w & 1u) ^ (uint32_t)g.flip[w >> 1]);
+    };
     for (uint64_t r = b; r < e; r++) {
       const uint32_t id = g.rank2id[(size_t)r];
       for (int s = 0; s < 2; s++) {
+        const size_t row = ((size_t)id * 2 + (size_t)(s ^ g.flip[(size_t)r])) * 4;
         for (int nt = 0; nt < 4; nt++) {
           uint32_t w = succ_r[((size_t)r * 2 + s) * 4 + nt];
-          if (w != kInvalidNode) g.succ[((size_t)id * 2 + s) * 4 + nt] = 2 * g.rank2id[w >> 1] + (w & 1u);
+          if (w != kInvalidNode) g.succ[row + nt] = remap(w);
           if (!pred_r.empty()) {
             uint32_t p = pred_r[((size_t)r * 2 + s) * 4 + nt];
-            if (p != kInvalidNode) g.pred[((size_t)id * 2 + s) * 4 + nt] = 2 * g.rank2id[p >> 1] + (p & 1u);
+            if (p != kInvalidNode) g.pred[row + nt] = remap(p);
           }
         }
       }
       const KT c = v[(size_t)r];
-      g.lastnt[(size_t)id * 2 + 0] = (uint8_t)(c & 3);
-      g.lastnt[(size_t)id * 2 + 1] = (uint8_t)(((c >> (2 * (k - 1))) & 3) ^ 2);
+      const uint8_t last_fwd = (uint8_t)(c & 3), last_rev = (uint8_t)(((c >> (2 * (k - 1))) & 3) ^ 2);
+      g.lastnt[(size_t)id * 2 + (size_t)(0 ^ g.flip[(size_t)r])] = last_fwd;
+      g.lastnt[(size_t)id * 2 + (size_t)(1 ^ g.flip[(size_t)r])] = last_rev;
     }
   });
 }
@@ -271,13 +278,14 @@ uint32_t Graph::node_of(const char* s) const {
     r = rank_of<u128>(*this, c);
   }
   if (r < 0) return kInvalidNode;
-  return 2 * rank2id[(size_t)r] + (uint32_t)strand;
+  return 2 * rank2id[(size_t)r] + ((uint32_t)strand ^ (uint32_t)flip[(size_t)r]);
 }
 
 std::string Graph::node_string(uint32_t v) const {
   const uint32_t r = id2rank[v >> 1];
-  if (!wide) return decode_kmer<uint64_t>(kmers64[r], (int)(v & 1u), k);
-  return decode_kmer<u128>(kmers128[r], (int)(v & 1u), k);
+  const int strand = (int)((v & 1u) ^ (uint32_t)flip[r]);
+  if (!wide) return decode_kmer<uint64_t>(kmers64[r], strand, k);
+  return decode_kmer<u128>(kmers128[r], strand, k);
 }
 
 Graph* graph_build(const std::vector<std::pair<const char*, uint64_t>>& seqs, int k, int solid, int nthreads,
@@ -294,7 +302,7 @@ Graph* graph_build(const std::vector<std::pair<const char*, uint64_t>>& seqs, in
 }
 
 // ---- own cache format ------------------------------------------------------
-static const char kMagic[8] = {'G', '2', 'S', 'D', 'B', 'G', '0', '1'};
+static const char kMagic[8] = {'G', '2', 'S', 'D', 'B', 'G', '0', '2'};
 
 bool graph_save(const Graph& g, const std::string& path, std::string* err) {
   FILE* f = fopen(path.c_str(), "wb");
@@ -304,6 +312,7 @@ bool graph_save(const Graph& g, const std::string& path, std::string* err) {
   auto put = [&](const void* p, size_t bytes) { if (ok && bytes) ok = fwrite(p, 1, bytes, f) == bytes; };
   if (!g.wide) put(g.kmers64.data(), g.kmers64.size() * 8); else put(g.kmers128.data(), g.kmers128.size() * 16);
   put(g.rank2id.data(), g.rank2id.size() * 4);
+  put(g.flip.data(), g.flip.size());
   put(g.succ.data(), g.succ.size() * 4);
   put(g.pred.data(), g.pred.size() * 4);
   put(g.lastnt.data(), g.lastnt.size());
@@ -332,6 +341,7 @@ Graph* graph_load(const std::string& path, std::string* err) {
   if (!g->wide) { g->kmers64.resize((size_t)g->n); get(g->kmers64.data(), (size_t)g->n * 8); }
   else { g->kmers128.resize((size_t)g->n); get(g->kmers128.data(), (size_t)g->n * 16); }
   g->rank2id.resize((size_t)g->n); get(g->rank2id.data(), (size_t)g->n * 4);
+  g->flip.resize((size_t)g->n); get(g->flip.data(), (size_t)g->n);
   g->succ.resize((size_t)g->n * 8); get(g->succ.data(), (size_t)g->n * 32);
   if (hdr[3]) { g->pred.resize((size_t)g->n * 8); get(g->pred.data(), (size_t)g->n * 32); }
   g->lastnt.resize((size_t)g->n * 2); get(g->lastnt.data(), (size_t)g->n * 2);

@@ -37,7 +37,15 @@ struct Graph {
   int bucket_bits = 0;
   std::vector<uint32_t> rank2id;  // sorted rank -> node index (unitig order)
   std::vector<uint32_t> id2rank;
-  // oriented node = 2*index + strand.  succ[v*4 + nt] = oriented successor
+  // Orientation bit of an oriented node id is RELATIVE TO ITS UNITIG: bit 0 = the
+  // direction in which the unitig was numbered.  flip[rank] = GATB strand
+  // (0 = canonical) of that direction, so GATB strand = orientation ^ flip.  Inside a
+  // unitig the only successor of an even id v is v+2 and of an odd id v is v-2, which
+  // lets the kernels walk unitigs by arithmetic and verify in bulk.  GATB's strand is
+  // only a label separating the two DP rows of a k-mer (Node::operator== ignores it),
+  // so any consistent labelling gives identical results.
+  std::vector<uint8_t> flip;
+  // oriented node = 2*index + orientation.  succ[v*4 + nt] = oriented successor
   // obtained by appending nt (A,C,T,G) or kInvalidNode.
   std::vector<uint32_t> succ;
   std::vector<uint32_t> pred;     // explicit predecessor table, even k only

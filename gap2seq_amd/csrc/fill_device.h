@@ -71,4 +71,7 @@ struct GapOut {
   uint64_t sub_off;    // offset of this gap's SubState array in the packed output
   uint32_t x_sub;      // expansions done by the backward sweep
   uint32_t pad;
+  // LDS tier statistics: per-level iterations / bulk iterations of phases A, B, D1 and
+  // shader cycles (in units of 256) spent in A, B+C, D1
+  uint32_t stat[8];
 };

@@ -28,12 +28,12 @@ size_t fill_lds_bytes(uint32_t rs_cap);
 size_t extract_lds_bytes();
 uint32_t fill_lds_frontier_cap();
 uint32_t fill_lds_max_fuz();
-hipError_t launch_fill_lds(hipStream_t st, uint32_t ngaps, uint32_t rs_cap_max, const uint32_t* succ, const GapDev* gaps,
-                           const uint32_t* gap_ids, const uint32_t* flank_nodes, uint64_t* log_all, uint32_t* lvl_all,
-                           GapOut* outs);
-hipError_t launch_extract_lds(hipStream_t st, uint32_t ngaps, const uint32_t* succ, const GapDev* gaps,
-                              const uint32_t* gap_ids, const uint32_t* flank_nodes, const uint64_t* log_all,
-                              const uint32_t* lvl_all, SubState* sub_scratch, SubState* sub_out,
-                              unsigned long long* out_counter, GapOut* outs, int skip_confident);
+hipError_t launch_fill_lds(hipStream_t st, uint32_t ngaps, uint32_t rs_cap_max, uint32_t num_oriented,
+                           const uint32_t* succ, const GapDev* gaps, const uint32_t* gap_ids,
+                           const uint32_t* flank_nodes, uint64_t* log_all, uint32_t* lvl_all, GapOut* outs);
+hipError_t launch_extract_lds(hipStream_t st, uint32_t ngaps, uint32_t num_oriented, const uint32_t* succ,
+                              const GapDev* gaps, const uint32_t* gap_ids, const uint32_t* flank_nodes,
+                              const uint64_t* log_all, const uint32_t* lvl_all, SubState* sub_scratch,
+                              SubState* sub_out, unsigned long long* out_counter, GapOut* outs, int skip_confident);
 
 }  // namespace g2s

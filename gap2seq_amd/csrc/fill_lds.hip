@@ -74,6 +74,34 @@ __device__ uint32_t cached_succ(const uint32_t* __restrict__ succ, uint32_t* tag
   return res;
 }
 
+// If exactly one slot of the record is valid return it (and its index), else INVALID.
+__device__ __forceinline__ uint32_t only_slot(const uint4 r, uint32_t* nt) {
+  const uint32_t v0 = r.x != G2S_DEV_INVALID, v1 = r.y != G2S_DEV_INVALID, v2 = r.z != G2S_DEV_INVALID,
+                 v3 = r.w != G2S_DEV_INVALID;
+  if (v0 + v1 + v2 + v3 != 1u) return G2S_DEV_INVALID;
+  *nt = v1 * 1u + v2 * 2u + v3 * 3u;
+  return v0 ? r.x : v1 ? r.y : v2 ? r.z : r.w;
+}
+// number of leading lanes (from lane 0) whose predicate holds
+__device__ __forceinline__ uint32_t leading_true(bool p) {
+  const uint64_t m = ~__ballot(p);
+  return m ? (uint32_t)__builtin_ctzll(m) : 64u;
+}
+
+// Lanes are arranged level-major for a bulk step over R parallel runs: lane = i*Rp + r
+// with Rp = R rounded up to a power of two.  Given the per-lane predicate (idle lanes
+// r >= R must pass true) return how many leading levels have ALL runs true.
+__device__ __forceinline__ uint32_t leading_levels(bool p, uint32_t lg) {
+  uint64_t m = __ballot(p);
+  const uint32_t rp = 1u << lg;
+  for (uint32_t sh = 1; sh < rp; sh <<= 1) m &= (m >> sh);
+  const uint64_t gmask = lg == 0 ? ~0ull : lg == 1 ? 0x5555555555555555ull : lg == 2 ? 0x1111111111111111ull
+                         : lg == 3 ? 0x0101010101010101ull : 0x0001000100010001ull;
+  const uint64_t bad = ~m & gmask;
+  return bad ? ((uint32_t)__builtin_ctzll(bad) >> lg) : (64u >> lg);
+}
+__device__ __forceinline__ uint32_t log2ceil16(uint32_t r) { return r <= 1 ? 0u : r <= 2 ? 1u : r <= 4 ? 2u : r <= 8 ? 3u : 4u; }
+
 // LDS right set.  1 inserted, 0 present, 2 full.
 __device__ int lrs_insert(uint32_t* tab, uint32_t mask, uint32_t v) {
   uint32_t h = mix32(v) & mask;
@@ -107,7 +135,7 @@ __global__ __launch_bounds__(64) void g2s_fill_lds(const uint32_t* __restrict__ 
                                                     const GapDev* __restrict__ gaps,
                                                     const uint32_t* __restrict__ gap_ids,
                                                     const uint32_t* __restrict__ flank_nodes, uint64_t* log_all,
-                                                    uint32_t* lvl_all, GapOut* outs, uint32_t rs_cap_max) {
+                                                    uint32_t* lvl_all, GapOut* outs, uint32_t num_oriented) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   const uint32_t gi = __builtin_amdgcn_readfirstlane(gap_ids[blockIdx.x]);
   const GapDev gd = gaps[gi];
@@ -148,13 +176,14 @@ __global__ __launch_bounds__(64) void g2s_fill_lds(const uint32_t* __restrict__ 
     if (t != G2S_DEV_INVALID) tbloom |= 1ull << (mix32(t) & 63u);
   }
   lds_sync();
-  (void)rs_cap_max;
 
   uint32_t flags = 0;
   bool overflow = (gd.rmf + 1 > (int)LDS_TG);
 
   // ---------------- phase A: right BFS (Gap2Seq.cpp:871-982) -------------------
   uint32_t nvis = 0, xa = 0;
+  uint32_t st_slowA = 0, st_bulkA = 0, st_slowB = 0, st_bulkB = 0;
+  const unsigned long long cyc0 = __builtin_amdgcn_s_memtime();
   {
     uint32_t cur = 0, nb = 0;
     const uint32_t s0 = rseeds[0];
@@ -168,6 +197,77 @@ __global__ __launch_bounds__(64) void g2s_fill_lds(const uint32_t* __restrict__ 
       uint32_t* fcur = fa + cur * LDS_F;
       uint32_t* fnxt = fa + (cur ^ 1u) * LDS_F;
       uint32_t nnew = 0;
+      // ---- bulk step: every border node (<= 16) sits inside a unitig, where the only
+      // predecessor of id v is v-2 (even orientation) or v+2 (odd), see dbg.hpp.  Lanes are
+      // level-major (lane = i*Rp + r: run r, level d+i); each lane speculates its node and
+      // verifies it with one 16 B record load (coalesced over the wave).  The leading
+      // levels on which all runs hold are inserted into the right set at once.
+      if (nb >= 1 && nb <= 16 && d > gd.rmf) {
+        const uint32_t R = nb, lg = log2ceil16(R), Rp = 1u << lg;
+        const uint32_t r = (uint32_t)lane & (Rp - 1u), i = (uint32_t)lane >> lg;
+        const bool mine = r < R;
+        const uint32_t n = mine ? fcur[r] : 0u;
+        const uint32_t L = (uint32_t)min((int)(64u >> lg), gd.right_half - d + 1);
+        const uint32_t step = 2u * (i + 1u);
+        const bool up = (n & 1u) != 0;  // odd orientation: predecessors have larger ids
+        const bool inrange = mine && i < L && (up ? (n + step < num_oriented) : (n >= step));
+        const uint32_t x = up ? n + step - 2u : n - (step - 2u);  // border node of level d+i
+        const uint32_t p = up ? n + step : n - step;               // its speculated predecessor
+        bool ok = !mine;
+        if (inrange) {
+          uint32_t nt;
+          const uint4 rec = *(const uint4*)(succ + (size_t)(x ^ 1u) * 4);
+          ok = only_slot(rec, &nt) == (p ^ 1u);
+          // two runs walking over the same ids would race for "who visited first": leave
+          // such levels to the per-level code, where arrival order is the depth order
+          for (uint32_t q = 0; q < R && ok; q++) {
+            if (q == r) continue;
+            const uint32_t o = fcur[q];
+            if ((o & 1u) != (n & 1u)) continue;
+            const uint32_t span = 2u * (64u >> lg);
+            const bool oup = (o & 1u) != 0;
+            if (oup ? (p > o && p <= o + span) : (p < o && p + span >= o)) ok = false;
+          }
+        }
+        const uint32_t lok = leading_levels(ok, lg);
+        if (lok >= 2) {
+          const bool act = mine && i < lok;
+          uint32_t isnew = 0;
+          if (act) {
+            if (lrs_has(rs, rmask, x ^ 1u)) flags |= G2S_DEV_Q7_A;
+            const int rr = lrs_insert(rs, rmask, p);
+            isnew = (rr == 1);
+            if (rr == 2) flags |= G2S_DEV_OVERFLOW_A;
+          }
+          nvis += (uint32_t)__popcll(__ballot(isnew));
+          if (nvis > rs_cap / 4u * 3u) { overflow = true; break; }
+          // per run: an already visited node ends that walk (visited-set BFS); what lies beyond
+          // it was reached earlier with a larger depth budget, so those inserts were no-ops
+          const uint64_t dupm = __ballot(act && !isnew);
+          uint32_t first_dup = lok;  // level index of this run's first duplicate
+          {
+            uint64_t mm = dupm >> r;  // bits of run r sit at r, r+Rp, ...
+            for (uint32_t q = 0; q < lok; q++) { if ((mm >> (q << lg)) & 1ull) { first_dup = q; break; } }
+          }
+          const bool alive = mine && first_dup == lok;
+          // expansions: a run that dies at level q was still expanded at levels 0..q
+          const uint32_t myexp = (mine && i == 0) ? (first_dup == lok ? lok : first_dup + 1u) : 0u;
+          uint32_t sumexp = myexp;
+          for (int o = 32; o > 0; o >>= 1) sumexp += (uint32_t)__shfl_xor((int)sumexp, o);
+          xa += sumexp;
+          const uint32_t last = (uint32_t)__shfl((int)p, (int)(((lok - 1u) << lg) + r));
+          const uint64_t am = __ballot(alive && i == 0);
+          lds_sync();
+          if (alive && i == 0) fcur[(uint32_t)__popcll(am & lanes_below(lane))] = last;
+          nb = (uint32_t)__popcll(am);
+          lds_sync();
+          d += (int)lok - 1;
+          st_bulkA++;
+          if (nb == 0) break;  // border empty and no seed left (d > rmf)
+          continue;
+        }
+      }
+      st_slowA++;
       xa += nb;
       for (uint32_t i0 = 0; i0 < nb * 4u; i0 += 64u) {
         const uint32_t i = i0 + (uint32_t)lane;
@@ -176,7 +276,7 @@ __global__ __launch_bounds__(64) void g2s_fill_lds(const uint32_t* __restrict__ 
         const uint32_t nt = i & 3u;
         if (valid && nt == 0 && lrs_has(rs, rmask, n ^ 1u)) flags |= G2S_DEV_Q7_A;
         // graph.predecessors(n)[nt] = graph.successors(n^1)[nt] ^ 1
-        const uint32_t p = flip(cached_succ(succ, tag, data, valid, n ^ 1u, nt, lane));
+        const uint32_t p = valid ? flip(succ[(size_t)(n ^ 1u) * 4 + nt]) : G2S_DEV_INVALID;
         uint32_t isnew = 0;
         if (p != G2S_DEV_INVALID) {
           const int r = lrs_insert(rs, rmask, p);
@@ -215,6 +315,7 @@ __global__ __launch_bounds__(64) void g2s_fill_lds(const uint32_t* __restrict__ 
   }
   lds_sync();
 
+  const unsigned long long cyc1 = __builtin_amdgcn_s_memtime();
   // ---------------- phase B + C: left DP (Gap2Seq.cpp:984-1167) -----------------
   uint32_t nlog = 0, xb = 0;
   bool found = false;
@@ -244,6 +345,111 @@ __global__ __launch_bounds__(64) void g2s_fill_lds(const uint32_t* __restrict__ 
       uint32_t* cnxt = fc + (cur ^ 1u) * LDS_F;
       const bool unpruned = d < gd.prune_from;  // :1050 first disjunct
       uint32_t nnew = 0;
+      // ---- bulk step: every border state (<= 16 of them) sits inside a unitig, where the
+      // only successor of id v is v+2 (even orientation) or v-2 (odd), see dbg.hpp.
+      // Lanes are level-major: lane = i*Rp + r handles run r at level d+i.  Each lane
+      // speculates its state, verifies it against the graph (one coalesced load of 16 B
+      // records for the whole wave), applies the pruning rule; the leading levels on
+      // which ALL runs hold are appended to the state log at once, and each level's
+      // target check is evaluated by one lane.  Runs stay on distinct (node, depth)
+      // diagonals inside unitigs, so no merging is needed; anything else (branching,
+      // dead end, pruned state, unitig end) stops the bulk and the per-level code below
+      // handles that level.
+      if (nb >= 1 && nb <= 16 && d > gd.lmf) {
+        const uint32_t R = nb, lg = log2ceil16(R), Rp = 1u << lg;
+        const uint32_t r = (uint32_t)lane & (Rp - 1u), i = (uint32_t)lane >> lg;
+        const bool mine = r < R;
+        const uint32_t n = mine ? ncur[r] : 0u;
+        uint32_t np = mine ? ccur[r] : 0u;
+        if (np > G2S_DEV_MAX_PATHS) np = G2S_DEV_MAX_PATHS;
+        const uint32_t L = (uint32_t)min((int)(64u >> lg), gd.D - d + 1);
+        const uint32_t step = 2u * (i + 1u);
+        const bool up = (n & 1u) == 0;  // even orientation: successors have larger ids
+        const bool inrange = mine && i < L && (up ? (n + step < num_oriented) : (n >= step));
+        const uint32_t x = up ? n + step - 2u : n - (step - 2u);  // border node of level d+i
+        const uint32_t v = up ? n + step : n - step;               // its speculated successor
+        bool ok = !mine;
+        if (inrange) {
+          uint32_t nt;
+          const uint4 rec = *(const uint4*)(succ + (size_t)x * 4);
+          ok = only_slot(rec, &nt) == v;
+          if (ok && d + (int)i >= gd.prune_from) ok = lrs_has(rs, rmask, v) || lrs_has(rs, rmask, v ^ 1u);  // :1050
+        }
+        uint32_t lrun = leading_levels(ok, lg);
+        if (lrun > L) lrun = L;
+        if (lrun >= 2 && nlog + lrun * R <= cap && misc[0] + 64u <= LDS_TH) {
+          const bool act = mine && i < lrun;
+          if (act && R > 1) {  // Q7: the other strand of my k-mer on another run at this level
+            for (uint32_t q = 0; q < R; q++) {
+              const uint32_t o = ncur[q];
+              const uint32_t ov = (o & 1u) == 0 ? o + step : o - step;
+              if (q != r && ov == (v ^ 1u)) flags |= G2S_DEV_Q7_B;
+            }
+          }
+          if (act && ((tbloom >> (mix32(v) & 63u)) & 1ull)) {
+            for (int j = 0; j <= gd.rmf; j++) {
+              if (tgt[j] == v) {
+                const uint32_t idx = atomicAdd(&misc[0], 1u);
+                if (idx < LDS_TH) { th_j[idx] = (uint32_t)j; th_d[idx] = (uint32_t)d + i; th_c[idx] = np; }
+              }
+            }
+          }
+          lds_sync();
+          if (misc[0] > LDS_TH) { overflow = true; break; }
+          // phase C for the levels of the run, one lane (r == 0) per level (:1107-1159)
+          if (!found) {
+            const int dl = d + (int)i;
+            int bj = 1 << 30;
+            uint32_t c1 = 0, c2 = 0;
+            if (r == 0 && i < lrun && dl >= gd.g + gd.lmf + gd.rmf) {
+              const int err = dl - gd.g - (gd.lmf + gd.rmf);
+              const uint32_t nth = min(misc[0], LDS_TH);
+              for (uint32_t t = 0; t < nth; t++) {
+                const int tj = (int)th_j[t], td = (int)th_d[t];
+                const int l1 = gd.g + gd.lmf + tj + err, l2 = gd.g + gd.lmf + tj - err;
+                const bool h1 = td == l1, h2 = err != 0 && l2 >= 0 && td == l2;
+                if (!(h1 || h2) || tj > bj) continue;
+                if (tj < bj) { bj = tj; c1 = 0; c2 = 0; }
+                if (h1) c1 = th_c[t];
+                if (h2) c2 = th_c[t];
+              }
+            }
+            const uint64_t hm = __ballot(bj < (1 << 30));
+            if (hm) {
+              const int l0 = __builtin_ctzll(hm);  // lane of the first level with a hit
+              const int i0 = l0 >> lg;
+              bj = __shfl(bj, l0);
+              c1 = (uint32_t)__shfl((int)c1, l0);
+              c2 = (uint32_t)__shfl((int)c2, l0);
+              const int err = d + i0 - gd.g - (gd.lmf + gd.rmf);
+              const uint32_t sum = c1 + c2;
+              c_count = (int)(sum > G2S_DEV_MAX_PATHS ? G2S_DEV_MAX_PATHS : sum);
+              reached_j = bj;
+              const int l1 = gd.g + gd.lmf + bj + err, l2 = gd.g + gd.lmf + bj - err;
+              if (c1 > 0) { len0 = l1; n_len = 1; if (c2 > 0) { len1 = l2; n_len = 2; } }
+              else { len0 = l2; n_len = 1; }
+              found = true;
+              if (!gd.all_paths) lrun = (uint32_t)i0 + 1u;  // -best-only: the DP stops after this level
+            }
+          }
+          if (mine && i < lrun) {
+            log[nlog + i * R + r] = ((uint64_t)v << 32) | np;
+            if (r == 0) lvl[d + (int)i + 1] = nlog + (i + 1u) * R;
+          }
+          nlog += lrun * R;
+          xb += lrun * R;
+          lvl_written = d + (int)lrun;
+          const uint32_t last = (uint32_t)__shfl((int)v, (int)(((lrun - 1u) << lg) + r));
+          lds_sync();
+          if (mine && i == 0) ncur[r] = last;  // counts are unchanged along a run
+          lds_sync();
+          d += (int)lrun - 1;
+          st_bulkB++;
+          if (found && !gd.all_paths) break;  // (:1156-1158)
+          continue;
+        }
+      }
+      st_slowB++;
       xb += nb;
       if (nb == 1) {
         // single-entry frontier: its <=4 successors are distinct, no merging needed
@@ -251,7 +457,7 @@ __global__ __launch_bounds__(64) void g2s_fill_lds(const uint32_t* __restrict__ 
         uint32_t np = ccur[0];
         if (np > G2S_DEV_MAX_PATHS) np = G2S_DEV_MAX_PATHS;
         const bool valid = lane < 4;
-        const uint32_t v = cached_succ(succ, tag, data, valid, n, (uint32_t)lane & 3u, lane);
+        const uint32_t v = valid ? succ[(size_t)n * 4 + ((uint32_t)lane & 3u)] : G2S_DEV_INVALID;
         const bool pass = v != G2S_DEV_INVALID && (unpruned || lrs_has(rs, rmask, v) || lrs_has(rs, rmask, v ^ 1u));
         const uint64_t m = __ballot(pass);
         if (pass) {
@@ -272,7 +478,7 @@ __global__ __launch_bounds__(64) void g2s_fill_lds(const uint32_t* __restrict__ 
           const uint32_t n = valid ? ncur[i >> 2] : 0u;
           uint32_t np = valid ? ccur[i >> 2] : 0u;
           if (np > G2S_DEV_MAX_PATHS) np = G2S_DEV_MAX_PATHS;
-          const uint32_t v = cached_succ(succ, tag, data, valid, n, i & 3u, lane);
+          const uint32_t v = valid ? succ[(size_t)n * 4 + (i & 3u)] : G2S_DEV_INVALID;
           const bool pass = v != G2S_DEV_INVALID && (unpruned || lrs_has(rs, rmask, v) || lrs_has(rs, rmask, v ^ 1u));
           // pass 1: claim (depth, node) in the merge table; stale entries of older levels count as free
           uint32_t h = 0, won = 0;
@@ -393,6 +599,9 @@ __global__ __launch_bounds__(64) void g2s_fill_lds(const uint32_t* __restrict__ 
   }
   for (int o = 32; o > 0; o >>= 1) flags |= __shfl_xor(flags, o);
   if (lane == 0) {
+    const unsigned long long cyc2 = __builtin_amdgcn_s_memtime();
+    go->stat[0] = st_slowA; go->stat[1] = st_bulkA; go->stat[2] = st_slowB; go->stat[3] = st_bulkB;
+    go->stat[4] = (uint32_t)((cyc1 - cyc0) >> 8); go->stat[5] = (uint32_t)((cyc2 - cyc1) >> 8);
     go->flags = flags;
     go->n_right = nvis;
     go->x_right = xa;
@@ -421,7 +630,7 @@ __global__ __launch_bounds__(64) void g2s_extract_lds(const uint32_t* __restrict
                                                        const uint64_t* __restrict__ log_all,
                                                        const uint32_t* __restrict__ lvl_all, SubState* sub_scratch,
                                                        SubState* sub_out, unsigned long long* out_counter,
-                                                       GapOut* outs, int skip_confident) {
+                                                       GapOut* outs, int skip_confident, uint32_t num_oriented) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   const uint32_t gi = __builtin_amdgcn_readfirstlane(gap_ids[blockIdx.x]);
   const GapDev gd = gaps[gi];
@@ -459,6 +668,8 @@ __global__ __launch_bounds__(64) void g2s_extract_lds(const uint32_t* __restrict
   for (uint32_t i = (uint32_t)lane; i < LDS_NB; i += 64u) tag[i] = G2S_DEV_INVALID;
   lds_sync();
 
+  uint32_t st_slowD = 0, st_bulkD = 0;
+  const unsigned long long cyc0 = __builtin_amdgcn_s_memtime();
   int wl_lo = gd.D + 2;          // wl[i] = lvl[wl_lo + i], i in [0, W]
   uint32_t we_lo = 0, we_hi = 0; // log positions [we_lo, we_hi) are in the entry window
   uint32_t nsub = 0, nbord = 0, xcount = 0, lflags = 0;
@@ -466,6 +677,125 @@ __global__ __launch_bounds__(64) void g2s_extract_lds(const uint32_t* __restrict
 
   for (int d2 = gd.D; d2 >= 0; d2--) {
     if (nbord == 0 && d2 < min_len && (sinknode == G2S_DEV_INVALID || d2 < lo_sink)) break;  // nothing can start below
+    // ---- bulk step: every border state (<= 8) continues down a unitig.  Lanes are
+    // level-major (lane = i*Rp + r: run r, level d2-i).  A lane looks for the speculated
+    // predecessor (id -/+ 2) among the states of its level, and the graph must confirm
+    // the edge.  A level that holds a path start which is not on one of the runs ends
+    // the bulk (the per-level code below then adds it to the border).
+    {
+      bool any_source = false;
+      for (uint32_t q = 0; q < nbord && q < 8u; q++) any_source |= (bf[q] & G2S_SUB_SOURCE) != 0;
+      if (nbord >= 1 && nbord <= 8 && !any_source && d2 > gd.lmf + 1) {
+        const uint32_t R = nbord, lg = log2ceil16(R), Rp = 1u << lg;
+        const uint32_t r = (uint32_t)lane & (Rp - 1u), i = (uint32_t)lane >> lg;
+        const bool mine = r < R;
+        const uint32_t cur = mine ? bn[r] : 0u;
+        const uint32_t curf = mine ? (bf[r] & (G2S_SUB_IN_S | G2S_SUB_IN_T)) : 0u;
+        const uint32_t L = (uint32_t)min((int)(64u >> lg), d2 - gd.lmf);  // stay above the left flank: no sources
+        const uint32_t step = 2u * (i + 1u);
+        const bool up = (cur & 1u) != 0;  // odd orientation: predecessors have larger ids
+        const int li = d2 - (int)i;
+        const bool inrange = mine && i < L && (up ? (cur + step < num_oriented) : (cur >= step));
+        const uint32_t x = up ? cur + step - 2u : cur - (step - 2u);  // state of level li+1
+        const uint32_t p = up ? cur + step : cur - step;               // speculated state of level li
+        bool ok = !mine;
+        uint32_t nt = 0, ccnt = 0;
+        if (i < L && li >= 0) {
+          const uint32_t lo = lvl[li], hi = lvl[li + 1];
+          bool found_p = false, stray_start = false;
+          uint32_t ents[16];
+          const uint32_t w = hi - lo;
+          if (w <= 16u) {
+            uint64_t raw[16];
+#pragma unroll
+            for (uint32_t c = 0; c < 16u; c++) raw[c] = c < w ? log[lo + c] : G2S_DEV_EMPTY64;  // independent loads
+#pragma unroll
+            for (uint32_t c = 0; c < 16u; c++) {
+              const uint32_t en = (uint32_t)(raw[c] >> 32);
+              ents[c] = en;
+              if (c >= w) continue;
+              if (mine && en == p) { found_p = true; ccnt = (uint32_t)raw[c]; }
+              // a start of this level must be one of the runs' states, else it is a new border entry
+              if ((en == sinknode && li >= lo_sink) || (en == reached && (li == len0 || (n_len > 1 && li == len1)))) {
+                bool on_run = false;
+                for (uint32_t q = 0; q < R; q++) {
+                  const uint32_t o = bn[q];
+                  const uint32_t op = (o & 1u) != 0 ? o + step : o - step;
+                  on_run |= op == en;
+                }
+                stray_start |= !on_run;
+              }
+            }
+          } else {
+            stray_start = true;  // wide level: leave it to the per-level code
+          }
+          if (inrange && found_p && !stray_start) {
+            const uint4 rec = *(const uint4*)(succ + (size_t)(x ^ 1u) * 4);
+            const uint32_t qv = p ^ 1u;
+            nt = rec.x == qv ? 0u : rec.y == qv ? 1u : rec.z == qv ? 2u : rec.w == qv ? 3u : 4u;
+            // every set predecessor of x must be the speculated one: any other valid slot
+            // whose state is set at this level would be a second closure entry
+            bool other = false;
+            const uint32_t o0 = (nt == 0u || rec.x == G2S_DEV_INVALID) ? 0xFFFFFFFEu : (rec.x ^ 1u);
+            const uint32_t o1 = (nt == 1u || rec.y == G2S_DEV_INVALID) ? 0xFFFFFFFEu : (rec.y ^ 1u);
+            const uint32_t o2 = (nt == 2u || rec.z == G2S_DEV_INVALID) ? 0xFFFFFFFEu : (rec.z ^ 1u);
+            const uint32_t o3 = (nt == 3u || rec.w == G2S_DEV_INVALID) ? 0xFFFFFFFEu : (rec.w ^ 1u);
+#pragma unroll
+            for (uint32_t c = 0; c < 16u; c++) other |= ents[c] == o0 || ents[c] == o1 || ents[c] == o2 || ents[c] == o3;
+            ok = nt < 4u && !other;
+          } else if (mine) {
+            ok = false;
+          }
+          if (!mine && stray_start) ok = false;
+        } else if (mine) {
+          ok = false;
+        }
+        const uint32_t lok = leading_levels(ok, lg);
+        if (lok >= 2 && nsub + lok * R <= cap) {
+          const bool act = mine && i < lok;
+          uint32_t own = 0;  // attributes of this state itself
+          if (act && p == sinknode && li >= lo_sink) own |= G2S_SUB_IN_S | G2S_SUB_SINK;       // :1195-1244
+          if (act && p == reached && (li == len0 || (n_len > 1 && li == len1))) own |= t_flags;  // :1245-1259
+          uint32_t prop = (own | (i == 0 ? curf : 0u)) & (G2S_SUB_IN_S | G2S_SUB_IN_T);
+          for (uint32_t o = Rp; o < 64u; o <<= 1) {  // closure membership flows down each run: prefix OR over i
+            const uint32_t t = (uint32_t)__shfl_up((int)prop, (int)o);
+            if ((uint32_t)lane >= o) prop |= t;
+          }
+          const uint32_t f = own | prop;
+          const uint32_t nt_next = (uint32_t)__shfl_down((int)nt, (int)Rp);  // slot of state (i+1,r) among preds of (i,r)
+          if (act) {
+            SubState st;
+            st.node = p; st.depth = (uint32_t)li; st.cnt = ccnt; st.flags = f;
+            const int32_t nxt = (i + 1u < lok) ? (int32_t)(nsub + (i + 1u) * R + r) : -1;
+            st.pred[0] = nt_next == 0u ? nxt : -1;
+            st.pred[1] = nt_next == 1u ? nxt : -1;
+            st.pred[2] = nt_next == 2u ? nxt : -1;
+            st.pred[3] = nt_next == 3u ? nxt : -1;
+            sub[nsub + i * R + r] = st;
+            if (R > 1) {  // Q7: the other strand of my k-mer on another run at this level
+              for (uint32_t q = 0; q < R; q++) {
+                const uint32_t o = bn[q];
+                const uint32_t op = (o & 1u) != 0 ? o + step : o - step;
+                if (q != r && op == (p ^ 1u)) lflags |= G2S_DEV_Q7_D;
+              }
+            }
+          }
+          if (mine && i == 0) sub[be[r]].pred[nt] = (int32_t)(nsub + r);
+          const int src = (int)(((lok - 1u) << lg) + r);
+          const uint32_t lastp = (uint32_t)__shfl((int)p, src);
+          const uint32_t lastf = (uint32_t)__shfl((int)f, src);
+          lds_sync();
+          if (mine && i == 0) { bn[r] = lastp; be[r] = nsub + (lok - 1u) * R + r; bf[r] = lastf; }
+          lds_sync();
+          xcount += lok * R;
+          nsub += lok * R;
+          d2 -= (int)lok - 1;
+          st_bulkD++;
+          continue;
+        }
+      }
+    }
+    st_slowD++;
     // ---- level offsets and entries of depth d2 through the LDS windows ---------------
     if (d2 < wl_lo) {
       lds_sync();
@@ -509,7 +839,7 @@ __global__ __launch_bounds__(64) void g2s_extract_lds(const uint32_t* __restrict
       const uint32_t cur = valid ? bn[e] : 0u;
       const uint32_t f = valid ? bf[e] : 0u;
       const bool expand = valid && !(f & G2S_SUB_SOURCE);
-      const uint32_t p = flip(cached_succ(succ, tag, data, expand, cur ^ 1u, nt, lane));
+      const uint32_t p = expand ? flip(succ[(size_t)(cur ^ 1u) * 4 + nt]) : G2S_DEV_INVALID;
       uint32_t match = 0xFFFFFFFFu;
       for (uint32_t c = 0; c < w; c++) {
         const uint32_t cand = (uint32_t)__shfl((int)cn, (int)c);
@@ -577,6 +907,8 @@ __global__ __launch_bounds__(64) void g2s_extract_lds(const uint32_t* __restrict
     go->n_sub = nsub;
     go->sub_off = base;
     go->x_sub = xcount;
+    go->stat[6] = st_slowD | (st_bulkD << 16);
+    go->stat[7] = (uint32_t)((__builtin_amdgcn_s_memtime() - cyc0) >> 8);
   }
 }
 
@@ -594,25 +926,25 @@ size_t extract_lds_bytes() {
 uint32_t fill_lds_frontier_cap() { return LDS_F; }
 uint32_t fill_lds_max_fuz() { return LDS_TG - 1; }
 
-hipError_t launch_fill_lds(hipStream_t st, uint32_t ngaps, uint32_t rs_cap_max, const uint32_t* succ, const GapDev* gaps,
-                           const uint32_t* gap_ids, const uint32_t* flank_nodes, uint64_t* log_all, uint32_t* lvl_all,
-                           GapOut* outs) {
+hipError_t launch_fill_lds(hipStream_t st, uint32_t ngaps, uint32_t rs_cap_max, uint32_t num_oriented,
+                           const uint32_t* succ, const GapDev* gaps, const uint32_t* gap_ids,
+                           const uint32_t* flank_nodes, uint64_t* log_all, uint32_t* lvl_all, GapOut* outs) {
   if (ngaps == 0) return hipSuccess;
   const size_t bytes = fill_lds_bytes(rs_cap_max);
   hipError_t e = hipFuncSetAttribute((const void*)g2s_fill_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(g2s_fill_lds, dim3(ngaps), dim3(64), bytes, st, succ, gaps, gap_ids, flank_nodes, log_all, lvl_all,
-                     outs, rs_cap_max);
+                     outs, num_oriented);
   return hipGetLastError();
 }
 
-hipError_t launch_extract_lds(hipStream_t st, uint32_t ngaps, const uint32_t* succ, const GapDev* gaps,
-                              const uint32_t* gap_ids, const uint32_t* flank_nodes, const uint64_t* log_all,
-                              const uint32_t* lvl_all, SubState* sub_scratch, SubState* sub_out,
-                              unsigned long long* out_counter, GapOut* outs, int skip_confident) {
+hipError_t launch_extract_lds(hipStream_t st, uint32_t ngaps, uint32_t num_oriented, const uint32_t* succ,
+                              const GapDev* gaps, const uint32_t* gap_ids, const uint32_t* flank_nodes,
+                              const uint64_t* log_all, const uint32_t* lvl_all, SubState* sub_scratch,
+                              SubState* sub_out, unsigned long long* out_counter, GapOut* outs, int skip_confident) {
   if (ngaps == 0) return hipSuccess;
   hipLaunchKernelGGL(g2s_extract_lds, dim3(ngaps), dim3(64), extract_lds_bytes(), st, succ, gaps, gap_ids, flank_nodes,
-                     log_all, lvl_all, sub_scratch, sub_out, out_counter, outs, skip_confident);
+                     log_all, lvl_all, sub_scratch, sub_out, out_counter, outs, skip_confident, num_oriented);
   return hipGetLastError();
 }
 

@@ -473,7 +473,7 @@ Plan plan_gap(const GapJob& j, int d_err, uint64_t scale, uint64_t max_states) {
   const int right_half = j.rmf + (j.g + d_err + 1) / 2;
   const int D = j.lmf + j.rmf + j.g + d_err;
   uint64_t r = (uint64_t)pow2ceil(std::max<uint64_t>(256, 4ull * (uint64_t)(right_half + j.rmf + 2))) * scale;
-  uint64_t st = (uint64_t)pow2ceil(std::max<uint64_t>(512, 4ull * (uint64_t)(D + 2))) * scale;
+  uint64_t st = (uint64_t)pow2ceil(std::max<uint64_t>(2048, 8ull * (uint64_t)(D + 2))) * scale;
   const uint64_t lim = std::max<uint64_t>(1024, std::min<uint64_t>(max_states, 1u << 28));
   uint64_t limp = 1;
   while (limp * 2 <= lim) limp <<= 1;
@@ -539,11 +539,12 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
     HIP_TRY(s->d_lvl.ensure(lvl_total * 4));
     HIP_TRY(hipEventRecord(s->ev[0], st));
     HIP_TRY(hipEventRecord(s->ev[1], st));  // phases A-C are one kernel in this tier
-    HIP_TRY(launch_fill_lds(st, (uint32_t)ids.size(), lds_cap_max, dg.succ, (const GapDev*)s->d_gaps.p,
+    const uint32_t num_oriented = (uint32_t)(2 * s->graph->g->n);
+    HIP_TRY(launch_fill_lds(st, (uint32_t)ids.size(), lds_cap_max, num_oriented, dg.succ, (const GapDev*)s->d_gaps.p,
                             (const uint32_t*)s->d_ids.p, (const uint32_t*)s->d_flank.p, (uint64_t*)s->d_log.p,
                             (uint32_t*)s->d_lvl.p, (GapOut*)s->d_outs.p));
     HIP_TRY(hipEventRecord(s->ev[2], st));
-    HIP_TRY(launch_extract_lds(st, (uint32_t)ids.size(), dg.succ, (const GapDev*)s->d_gaps.p,
+    HIP_TRY(launch_extract_lds(st, (uint32_t)ids.size(), num_oriented, dg.succ, (const GapDev*)s->d_gaps.p,
                                (const uint32_t*)s->d_ids.p, (const uint32_t*)s->d_flank.p, (const uint64_t*)s->d_log.p,
                                (const uint32_t*)s->d_lvl.p, (SubState*)s->d_subscr.p, (SubState*)s->d_subout.p,
                                (unsigned long long*)s->d_counter.p, (GapOut*)s->d_outs.p,
@@ -652,7 +653,13 @@ extern "C" int g2s_batch_run(g2s_batch* b, g2s_result* results, char* arena, siz
     const GapOut* outs = (const GapOut*)td->outs.p;
     for (uint32_t i : lds_ids) {
       const GapOut& go = outs[i];
-      if (go.flags & (G2S_DEV_OVERFLOW_A | G2S_DEV_OVERFLOW_B)) { todo.push_back(i); continue; }
+      if (go.flags & (G2S_DEV_OVERFLOW_A | G2S_DEV_OVERFLOW_B)) {
+        if (getenv("G2S_DEBUG"))
+          fprintf(stderr, "[g2s] gap %u left the LDS tier: flags 0x%x n_right %u x_right %u n_states %u x_left %u final_d %d g %d\n",
+                  i, go.flags, go.n_right, go.x_right, go.n_states, go.x_left, go.final_d, b->jobs[i].g);
+        todo.push_back(i);
+        continue;
+      }
       SubView& v = views[i];
       v.out = &go;
       v.st = (const SubState*)td->subs.p + go.sub_off;
@@ -660,6 +667,17 @@ extern "C" int g2s_batch_run(g2s_batch* b, g2s_result* results, char* arena, siz
       b->timing.xA += go.x_right; b->timing.sA += go.n_right;
       b->timing.xB += go.x_left; b->timing.sB += go.n_states;
       b->timing.xD += go.x_sub; b->timing.sD += go.n_sub;
+    }
+    if (getenv("G2S_DEBUG")) {  // the slowest gaps of the LDS tier and why
+      std::vector<uint32_t> ord(lds_ids);
+      std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t c) {
+        return outs[a].stat[4] + outs[a].stat[5] + outs[a].stat[7] > outs[c].stat[4] + outs[c].stat[5] + outs[c].stat[7]; });
+      for (size_t q = 0; q < ord.size() && q < 6; q++) {
+        const GapOut& o = outs[ord[q]];
+        fprintf(stderr, "[g2s] slow gap %u: g %d | A per-level %u bulk %u kcyc %u | B per-level %u bulk %u kcyc %u | D1 per-level %u bulk %u kcyc %u | xA %u xB %u xD %u\n",
+                ord[q], b->jobs[ord[q]].g, o.stat[0], o.stat[1], o.stat[4] >> 2, o.stat[2], o.stat[3], o.stat[5] >> 2,
+                o.stat[6] & 0xFFFF, o.stat[6] >> 16, o.stat[7] >> 2, o.x_right, o.x_left, o.x_sub);
+      }
     }
     size_t before = todo.size();
     (void)before;

@@ -53,7 +53,9 @@ def test_graph_builder_matches_python_restatement(product, k):
                 if not p.contains(x):
                     assert v == product.G2S_INVALID_NODE
                     continue
-                assert g.node_string(v) == x and (v & 1) == pyref.canon(x)[1]
+                assert g.node_string(v) == x
+                if pyref.revcomp(x) != x:  # orientation bit is unitig-relative: only v^1 == revcomp is promised
+                    assert g.node(pyref.revcomp(x)) == v ^ 1
                 for y in (x, pyref.revcomp(x)):
                     w = g.node(y)
                     assert [g.node_string(t) for t in g.successors(w)] == p.succ(y)
@@ -65,9 +67,11 @@ def test_unitig_order_numbers_a_chain_consecutively(product):
     g = cases.random_dna(cases.SplitMix(3), 5000)
     gr = product.Graph.from_seqs([g], 21, 1)
     assert gr.num_unitigs == 1
-    ids = [gr.node(g[i:i + 21]) >> 1 for i in range(len(g) - 20)]
+    ids = [gr.node(g[i:i + 21]) for i in range(len(g) - 20)]
     step = ids[1] - ids[0]
-    assert step in (1, -1) and all(b - a == step for a, b in zip(ids, ids[1:]))
+    # oriented ids advance by +2 (even orientation) or -2 (odd) along the whole unitig
+    assert step in (2, -2) and all(b - a == step for a, b in zip(ids, ids[1:]))
+    assert (ids[0] & 1) == (0 if step == 2 else 1)
     gr.free()
 
 
