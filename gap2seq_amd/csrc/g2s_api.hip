@@ -231,6 +231,13 @@ inline uint32_t pow2ceil(uint64_t x) {
 
 }  // namespace
 
+namespace {
+struct TierData {  // what came back from one launch group (pinned buffers live in the session)
+  PinBuf outs, subs;
+  std::vector<uint32_t> gap_ids;
+};
+}  // namespace
+
 // Persistent host workers for the per-gap post-processing (spawning threads per
 // batch costs more than the work at 500 gaps per batch).
 class WorkerPool {
@@ -319,6 +326,8 @@ struct g2s_session {
   size_t mem_budget = 0;  // bytes of HBM this session may use for work areas
   DevBuf d_gaps, d_ids, d_flank, d_outs, d_rs, d_rlog, d_keys, d_cnt, d_mark, d_slog, d_subscr, d_subout, d_counter;
   DevBuf d_log, d_lvl;  // LDS tier: level-ordered state log + level offsets
+  std::vector<void*> tier_pool;  // recycled TierData (pinned host buffers)
+  PinBuf h_gaps;                 // staging for the GapDev upload
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 
@@ -356,6 +365,8 @@ extern "C" void g2s_session_destroy(g2s_session* s) {
                     &s->d_log, &s->d_lvl};
   for (DevBuf* b : bufs) b->release();
   delete s->pool;
+  for (void* v : s->tier_pool) { TierData* t = (TierData*)v; t->outs.release(); t->subs.release(); delete t; }
+  s->h_gaps.release();
   for (int i = 0; i < 4; i++) if (s->ev[i]) (void)hipEventDestroy(s->ev[i]);
   if (s->stream) (void)hipStreamDestroy(s->stream);
   delete s;
@@ -366,12 +377,6 @@ extern "C" void g2s_session_srand(g2s_session* s, uint32_t seed) { if (s) s->rca
 // ---------------------------------------------------------------------------
 // batch
 // ---------------------------------------------------------------------------
-namespace {
-struct TierData {  // what came back from one launch group
-  PinBuf outs, subs;
-  std::vector<uint32_t> gap_ids;
-};
-}  // namespace
 
 struct g2s_batch {
   g2s_session* s = nullptr;
@@ -380,12 +385,20 @@ struct g2s_batch {
   size_t arena_bytes = 0;
   g2s_timing timing;
   std::vector<TierData*> tiers;
-  void drop_tiers() {
-    for (TierData* t : tiers) { t->outs.release(); t->subs.release(); delete t; }
-    tiers.clear();
-  }
-  ~g2s_batch() { drop_tiers(); }
+  void drop_tiers();
+  ~g2s_batch() { if (s) drop_tiers(); }
 };
+
+// pinned result buffers are recycled through the session: allocating page-locked memory
+// costs more than a whole 500-gap batch
+void g2s_batch::drop_tiers() {
+  for (TierData* t : tiers) { t->gap_ids.clear(); s->tier_pool.push_back(t); }
+  tiers.clear();
+}
+static TierData* take_tier(g2s_session* s) {
+  if (!s->tier_pool.empty()) { TierData* t = (TierData*)s->tier_pool.back(); s->tier_pool.pop_back(); return t; }
+  return new TierData();
+}
 
 extern "C" int g2s_batch_prepare(g2s_session* s, const g2s_gap* gaps, size_t n, g2s_batch** out) {
   if (!s || (!gaps && n) || !out) return fail(G2S_ERR_ARG, "g2s_batch_prepare: bad argument");
@@ -494,8 +507,9 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
   const DeviceGraph& dg = s->graph->g->dev.at(s->device);
   const size_t n = b->jobs.size();
   const int d_err = s->params.d_err;
-  std::vector<GapDev> gd(n);
-  memset(gd.data(), 0, n * sizeof(GapDev));
+  HIP_TRY(s->h_gaps.ensure(std::max<size_t>(n * sizeof(GapDev), 16)));
+  GapDev* gd = (GapDev*)s->h_gaps.p;
+  memset(gd, 0, n * sizeof(GapDev));
   uint64_t rs_total = 0, rlog_total = 0, st_total = 0, slog_total = 0, lvl_total = 0;
   uint32_t lds_cap_max = 0;
   td->gap_ids = ids;
@@ -530,7 +544,7 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
   HIP_TRY(s->d_subout.ensure(slog_total * sizeof(SubState)));
   HIP_TRY(s->d_counter.ensure(16));
   hipStream_t st = s->stream;
-  HIP_TRY(hipMemcpyAsync(s->d_gaps.p, gd.data(), n * sizeof(GapDev), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(s->d_gaps.p, gd, n * sizeof(GapDev), hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemcpyAsync(s->d_ids.p, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemsetAsync(s->d_outs.p, 0, n * sizeof(GapOut), st));
   HIP_TRY(hipMemsetAsync(s->d_counter.p, 0, 16, st));
@@ -628,6 +642,12 @@ extern "C" int g2s_batch_run(g2s_batch* b, g2s_result* results, char* arena, siz
 
   memset(results, 0, n * sizeof(g2s_result));
   memset(arena, 0, b->arena_bytes);
+  // rand() values are input independent: materialise what this batch will need while the
+  // GPU runs (one draw per traced base plus one per gap, Gap2Seq.cpp:1440,1513)
+  size_t rand_need = 0;
+  for (size_t i = 0; i < n; i++) rand_need += (size_t)(b->jobs[i].g + g.k + b->jobs[i].lmf + b->jobs[i].rmf + 2);
+  std::thread rand_fill([s, rand_need]() { s->rcache.ensure(rand_need); });
+  struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } rand_join{rand_fill};
   std::vector<SubView> views(n);
   std::vector<char> mem_exceeded(n, 0);
 
@@ -646,7 +666,7 @@ extern "C" int g2s_batch_run(g2s_batch* b, g2s_result* results, char* arena, siz
   }
   // ---- tier 0: LDS-resident kernels; whatever does not fit falls through to the HBM tier
   if (!lds_ids.empty()) {
-    TierData* td = new TierData();
+    TierData* td = take_tier(s);
     b->tiers.push_back(td);
     int rc = run_tier(b, lds_ids, 1, max_states, td, true);
     if (rc != G2S_OK) return rc;
@@ -700,7 +720,7 @@ extern "C" int g2s_batch_run(g2s_batch* b, g2s_result* results, char* arena, siz
         bytes += p.bytes;
         group.push_back(todo[pos++]);
       }
-      TierData* td = new TierData();
+      TierData* td = take_tier(s);
       b->tiers.push_back(td);
       int rc = run_tier(b, group, scale, max_states, td, false);
       if (rc != G2S_OK) return rc;
@@ -732,12 +752,14 @@ extern "C" int g2s_batch_run(g2s_batch* b, g2s_result* results, char* arena, siz
   }
 
   // ---- host: D2 + stop-depth analysis per gap, thread pool ----------------------
+  rand_fill.join();
   auto t_post = std::chrono::steady_clock::now();
   std::vector<SubPrep> prep(n);
   s->pool->run(n, [&](size_t i) {
     if (views[i].out) sub_analyze(fp, b->jobs[i], views[i], &prep[i]);
   });
 
+  auto t_ana = std::chrono::steady_clock::now();
   // ---- host: assign rand() stream offsets in gap order (:178,1440,1513) ---------
   // A gap whose draw count does not depend on the draws gets its offset in O(1);
   // the others are traced right here.  All remaining tracebacks then run in parallel.
@@ -790,6 +812,7 @@ extern "C" int g2s_batch_run(g2s_batch* b, g2s_result* results, char* arena, siz
     prev_filled = r.count > 0 && (!fp.unique_paths || r.count == 1);
     prev_right_fuz = r.right_fuz;
   }
+  auto t_off = std::chrono::steady_clock::now();
   s->rcache.ensure(draws_total + 1);
   s->pool->run(n, [&](size_t i) {
     if (!todo_tb[i]) return;
@@ -807,6 +830,11 @@ extern "C" int g2s_batch_run(g2s_batch* b, g2s_result* results, char* arena, siz
     b->timing.fill_bytes += (uint64_t)r.fill_len;
   }
   auto t_end = std::chrono::steady_clock::now();
+  if (getenv("G2S_DEBUG"))
+    fprintf(stderr, "[g2s] host phase D: analyze %.3f ms, offsets+inline tracebacks %.3f ms, parallel tracebacks %.3f ms (draws %zu)\n",
+            std::chrono::duration<double, std::milli>(t_ana - t_post).count(),
+            std::chrono::duration<double, std::milli>(t_off - t_ana).count(),
+            std::chrono::duration<double, std::milli>(t_end - t_off).count(), draws_total);
   b->timing.ms_host_post = std::chrono::duration<double, std::milli>(t_end - t_post).count();
   b->timing.ms_total = std::chrono::duration<double, std::milli>(t_end - t_begin).count();
   return G2S_OK;
