@@ -606,13 +606,20 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
   HIP_TRY(hipStreamSynchronize(st));
   b->timing.ms_d2h += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   float ms = 0;
-  HIP_TRY(hipEventElapsedTime(&ms, s->ev[0], s->ev[1]));
-  b->timing.ms_right_bfs += ms;
-  HIP_TRY(hipEventElapsedTime(&ms, s->ev[1], s->ev[2]));
-  b->timing.ms_left_dp += ms;
-  HIP_TRY(hipEventElapsedTime(&ms, s->ev[2], s->ev[3]));
-  b->timing.ms_extract += ms;
-  b->timing.launches_left_dp++;
+  if (lds) {
+    HIP_TRY(hipEventElapsedTime(&ms, s->ev[1], s->ev[2]));
+    b->timing.ms_fill_lds += ms;
+    HIP_TRY(hipEventElapsedTime(&ms, s->ev[2], s->ev[3]));
+    b->timing.ms_extract_lds += ms;
+  } else {
+    HIP_TRY(hipEventElapsedTime(&ms, s->ev[0], s->ev[1]));
+    b->timing.ms_right_bfs += ms;
+    HIP_TRY(hipEventElapsedTime(&ms, s->ev[1], s->ev[2]));
+    b->timing.ms_left_dp += ms;
+    HIP_TRY(hipEventElapsedTime(&ms, s->ev[2], s->ev[3]));
+    b->timing.ms_extract += ms;
+    b->timing.launches_left_dp++;
+  }
   return G2S_OK;
 }
 
@@ -687,6 +694,9 @@ extern "C" int g2s_batch_run(g2s_batch* b, g2s_result* results, char* arena, siz
       b->timing.xA += go.x_right; b->timing.sA += go.n_right;
       b->timing.xB += go.x_left; b->timing.sB += go.n_states;
       b->timing.xD += go.x_sub; b->timing.sD += go.n_sub;
+      b->timing.x_fill_lds += (uint64_t)go.x_right + go.x_left;
+      b->timing.s_fill_lds += (uint64_t)go.n_right + go.n_states;
+      b->timing.lds_tier_gaps++;
     }
     if (getenv("G2S_DEBUG")) {  // the slowest gaps of the LDS tier and why
       std::vector<uint32_t> ord(lds_ids);

@@ -53,7 +53,9 @@ class g2s_timing(C.Structure):
                 ("ms_d2h", C.c_double), ("ms_host_post", C.c_double), ("ms_total", C.c_double),
                 ("xA", C.c_uint64), ("sA", C.c_uint64), ("xB", C.c_uint64), ("sB", C.c_uint64),
                 ("xD", C.c_uint64), ("sD", C.c_uint64), ("flank_bytes", C.c_uint64), ("fill_bytes", C.c_uint64),
-                ("launches_left_dp", C.c_uint32), ("retried_gaps", C.c_uint32)]
+                ("launches_left_dp", C.c_uint32), ("retried_gaps", C.c_uint32),
+                ("ms_fill_lds", C.c_double), ("ms_extract_lds", C.c_double), ("x_fill_lds", C.c_uint64),
+                ("s_fill_lds", C.c_uint64), ("lds_tier_gaps", C.c_uint32), ("pad", C.c_uint32)]
 
 
 class g2s_run_opts(C.Structure):

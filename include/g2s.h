@@ -149,9 +149,9 @@ typedef struct g2s_result {
 
 /* Per-batch measurements (bench.py). */
 typedef struct g2s_timing {
-  double ms_right_bfs;    /* kernel g2s_right_bfs, HIP events on the session stream */
-  double ms_left_dp;      /* kernel g2s_left_dp  (the frontier kernel)              */
-  double ms_extract;      /* kernel g2s_extract                                     */
+  double ms_right_bfs;    /* kernel g2s_right_bfs (HBM tier), HIP events on the session stream */
+  double ms_left_dp;      /* kernel g2s_left_dp  (HBM tier frontier kernel)         */
+  double ms_extract;      /* kernel g2s_extract  (HBM tier)                         */
   double ms_d2h;
   double ms_host_post;    /* SCC / branch rule / traceback on the host              */
   double ms_total;        /* wall time of g2s_batch_run                             */
@@ -160,6 +160,13 @@ typedef struct g2s_timing {
   uint64_t fill_bytes;    /* sum over gaps of fill_len                              */
   uint32_t launches_left_dp; /* >1 when overflowing gaps were retried with larger tables */
   uint32_t retried_gaps;
+  /* LDS tier (kernels g2s_fill_lds = phases A-C fused, g2s_extract_lds = D1) */
+  double ms_fill_lds;
+  double ms_extract_lds;
+  uint64_t x_fill_lds;       /* expansions (A+B) of the gaps that completed in the LDS tier */
+  uint64_t s_fill_lds;       /* states set (A+B) by those gaps */
+  uint32_t lds_tier_gaps;    /* gaps that completed in the LDS tier */
+  uint32_t pad;
 } g2s_timing;
 
 /* ---------------------------------------------------------------------------
