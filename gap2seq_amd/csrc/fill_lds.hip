@@ -11,24 +11,27 @@
 //   * the right set (phase A's visited k-mers) as an LDS open-addressing table;
 //   * a per-level merge table keyed (depth, node) so that duplicate targets of one
 //     level are combined (64-bit LDS compare-and-swap + wave ballot compaction);
-//   * a direct-mapped cache of 512-byte successor blocks (16 consecutive nodes x
-//     2 strands x 4 slots).  Nodes are numbered in unitig order, so a walk along a
-//     unitig misses once per 16 levels and the miss is ONE coalesced 512 B load by
-//     the whole wave;
 //   * the target k-mers and the list of (target, depth, count) hits for phase C.
-// HBM sees only the block loads and append-only, fire-and-forget stores of the
-// state log.  One wavefront (64 lanes) per gap, the depth loop inside the kernel,
-// 4 lanes per frontier entry (one per nucleotide slot).  A level whose frontier
-// has a single entry — the common case — skips the merge table altogether.
-// Anything that does not fit (frontier > 64, right set too large, explicit
-// predecessor table for even k) is flagged and re-run by the general HBM tier.
+// HBM sees only successor-record loads (16 B per expansion, coalesced 4 lanes per
+// record) and append-only, fire-and-forget stores of the state log.
+//
+// One wavefront (64 lanes) per gap, the depth loop inside the kernel.  With a single
+// wave per SIMD the loop is bound by instruction issue (~2 000 cycles per level
+// measured with s_memtime), so the common case is not stepped level by level at all:
+// node ids are numbered along unitigs with a unitig-relative orientation bit
+// (dbg.hpp), inside a unitig the successor of v is v+2 / v-2, and a BULK STEP lets
+// lane i speculate the state of level d+i, verify it against the graph with one
+// coalesced record load for the whole wave, and commit up to 64 levels per iteration
+// (several parallel runs share the lanes level-major).  Levels that branch, merge,
+// die or leave a unitig fail verification and take the per-level step (4 lanes per
+// frontier entry, one per nucleotide slot).
+// Anything that does not fit (frontier > 64, right set too large, > 128 target hits,
+// explicit predecessor table for even k) is flagged and re-run by the HBM tier.
 #include <hip/hip_runtime.h>
 
 #include "fill_device.h"
 #include "fill_launch.h"
 
-#define LDS_NB 8u         /* cached successor blocks          */
-#define LDS_BLK_WORDS 128u /* 16 nodes x 2 strands x 4 slots   */
 #define LDS_F 64u         /* frontier capacity                 */
 #define LDS_LH (2u * LDS_F)
 #define LDS_TH 128u       /* target hits kept for phase C      */
@@ -48,31 +51,6 @@ __device__ __forceinline__ uint64_t lanes_below(int lane) { return (1ull << lane
 // state log (vmcnt) — that wait alone costs an HBM round trip per level.
 __device__ __forceinline__ void lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ uint32_t flip(uint32_t v) { return v == G2S_DEV_INVALID ? v : (v ^ 1u); }
-
-// succ4[v*4+nt] through the LDS block cache.  Wave-uniform call; lanes with !want get INVALID.
-__device__ uint32_t cached_succ(const uint32_t* __restrict__ succ, uint32_t* tag, uint32_t* data, bool want, uint32_t v,
-                                uint32_t nt, int lane) {
-  uint32_t res = G2S_DEV_INVALID;
-  const uint32_t blk = v >> 5;
-  bool pending = want;
-  if (pending) {
-    const uint32_t sl = blk & (LDS_NB - 1u);
-    if (tag[sl] == blk) { res = data[sl * LDS_BLK_WORDS + (v & 31u) * 4u + nt]; pending = false; }
-  }
-  uint64_t m = __ballot(pending);
-  while (m) {
-    const uint32_t b = (uint32_t)__shfl((int)blk, __builtin_ctzll(m));
-    const uint32_t sl = b & (LDS_NB - 1u);
-    lds_sync();  // every earlier read of this slot has completed
-    const uint2 w = ((const uint2*)succ)[(size_t)b * 64u + (uint32_t)lane];  // one coalesced 512 B block
-    ((uint2*)data)[sl * 64u + (uint32_t)lane] = w;
-    if (lane == 0) tag[sl] = b;
-    lds_sync();
-    if (pending && blk == b) { res = data[sl * LDS_BLK_WORDS + (v & 31u) * 4u + nt]; pending = false; }
-    m = __ballot(pending);
-  }
-  return res;
-}
 
 // If exactly one slot of the record is valid return it (and its index), else INVALID.
 __device__ __forceinline__ uint32_t only_slot(const uint4 r, uint32_t* nt) {
@@ -128,8 +106,7 @@ __device__ bool lrs_has(const uint32_t* tab, uint32_t mask, uint32_t v) {
 
 // ============================================================================
 // Phases A + B + C, LDS tier.
-// dynamic LDS: [tag NB][data NB*128][fa 2F][fn 2F][fc 2F][lh 2F x u64][lhslot 2F]
-//              [tgt TG][th 3*TH][misc 4][rs rs_cap]
+// dynamic LDS: [fa 2F][fn 2F][fc 2F][lh 2F x u64][lhslot 2F][tgt TG][th 3*TH][misc 4][rs rs_cap]
 // ============================================================================
 __global__ __launch_bounds__(64) void g2s_fill_lds(const uint32_t* __restrict__ succ,
                                                     const GapDev* __restrict__ gaps,
@@ -142,9 +119,7 @@ __global__ __launch_bounds__(64) void g2s_fill_lds(const uint32_t* __restrict__ 
   const int lane = threadIdx.x;
   GapOut* go = &outs[gi];
 
-  uint32_t* tag = lds;
-  uint32_t* data = tag + LDS_NB;
-  uint32_t* fa = data + LDS_NB * LDS_BLK_WORDS;   // phase A frontiers [2][F]
+  uint32_t* fa = lds;                             // phase A frontiers [2][F]
   uint32_t* fn = fa + 2 * LDS_F;                  // phase B frontier nodes [2][F]
   uint32_t* fc = fn + 2 * LDS_F;                  // phase B frontier counts [2][F]
   uint64_t* lh = (uint64_t*)(fc + 2 * LDS_F);     // level merge table keys
@@ -165,7 +140,6 @@ __global__ __launch_bounds__(64) void g2s_fill_lds(const uint32_t* __restrict__ 
   uint32_t* lvl = lvl_all + gd.lvl_off;
   const uint32_t cap = gd.slog_cap;
 
-  for (uint32_t i = (uint32_t)lane; i < LDS_NB; i += 64u) tag[i] = G2S_DEV_INVALID;
   for (uint32_t i = (uint32_t)lane; i < rs_cap; i += 64u) rs[i] = G2S_DEV_INVALID;
   for (uint32_t i = (uint32_t)lane; i < LDS_LH; i += 64u) lh[i] = G2S_DEV_EMPTY64;
   if (lane <= gd.rmf && lane < (int)LDS_TG) tgt[lane] = targets[lane];
@@ -620,8 +594,7 @@ __global__ __launch_bounds__(64) void g2s_fill_lds(const uint32_t* __restrict__ 
 // Phase D1 from the level-ordered state log, LDS tier (Gap2Seq.cpp:1169-1312)
 // plus the traceback's closure.  Walks the log backwards, one level per step; the
 // level's entries sit in lane registers, the border of the level above in LDS.
-// dynamic LDS: [tag NB][data NB*128][wl W+1][we_node W][we_cnt W][bn F][be F][bf F]
-//              [cfl F][cem F][lm 4F]
+// dynamic LDS: [wl W+1][we_node W][we_cnt W][bn F][be F][bf F][cfl F][cem F][lm 4F]
 // ============================================================================
 __global__ __launch_bounds__(64) void g2s_extract_lds(const uint32_t* __restrict__ succ,
                                                        const GapDev* __restrict__ gaps,
@@ -640,9 +613,7 @@ __global__ __launch_bounds__(64) void g2s_extract_lds(const uint32_t* __restrict
   const int c_count = go->c_count, n_len = go->n_len;
   if ((gflags & (G2S_DEV_OVERFLOW_A | G2S_DEV_OVERFLOW_B)) || !(c_count > 0 && n_len > 0)) return;  // :1169
 
-  uint32_t* tag = lds;
-  uint32_t* data = tag + LDS_NB;
-  uint32_t* wl = data + LDS_NB * LDS_BLK_WORDS;  // level offsets window [W+1]
+  uint32_t* wl = lds;                            // level offsets window [W+1]
   uint32_t* wen = wl + (LDS_W + 1u);             // log window: nodes
   uint32_t* wec = wen + LDS_W;                   // log window: counts
   uint32_t* bn = wec + LDS_W;                    // border (depth d2+1): node, emit index, flags
@@ -664,9 +635,6 @@ __global__ __launch_bounds__(64) void g2s_extract_lds(const uint32_t* __restrict
   const int lo_sink = max(0, gd.lmf + gd.g - gd.e);  // :1196
   const uint32_t t_flags = G2S_SUB_IN_T | G2S_SUB_START_T | ((want_s && !gd.all_paths) ? (G2S_SUB_IN_S | G2S_SUB_SINK) : 0u);
   const int min_len = n_len > 1 ? min(len0, len1) : len0;
-
-  for (uint32_t i = (uint32_t)lane; i < LDS_NB; i += 64u) tag[i] = G2S_DEV_INVALID;
-  lds_sync();
 
   uint32_t st_slowD = 0, st_bulkD = 0;
   const unsigned long long cyc0 = __builtin_amdgcn_s_memtime();
@@ -918,10 +886,10 @@ __global__ __launch_bounds__(64) void g2s_extract_lds(const uint32_t* __restrict
 namespace g2s {
 
 size_t fill_lds_bytes(uint32_t rs_cap) {
-  return 4u * (LDS_NB + LDS_NB * LDS_BLK_WORDS + 2 * LDS_F * 3 + LDS_LH * 2 + LDS_LH + LDS_TG + 3 * LDS_TH + 4 + rs_cap);
+  return 4u * (2 * LDS_F * 3 + LDS_LH * 2 + LDS_LH + LDS_TG + 3 * LDS_TH + 4 + rs_cap);
 }
 size_t extract_lds_bytes() {
-  return 4u * (LDS_NB + LDS_NB * LDS_BLK_WORDS + (LDS_W + 1) + 2 * LDS_W + 5 * LDS_F + 4 * LDS_F);
+  return 4u * ((LDS_W + 1) + 2 * LDS_W + 5 * LDS_F + 4 * LDS_F);
 }
 uint32_t fill_lds_frontier_cap() { return LDS_F; }
 uint32_t fill_lds_max_fuz() { return LDS_TG - 1; }
