@@ -149,13 +149,13 @@ def main():
         io_bytes = tm.flank_bytes + tm.fill_bytes
         if tm.lds_tier_gaps > 0:
             kname, x_units, s_units = "g2s_fill_lds", tm.x_fill_lds, tm.s_fill_lds
-            kern_ms = acc["ms_fill_lds"] / steps
-            launches = 1.0
+            launches = float(max(1, tm.lds_launches))
+            kern_ms = acc["ms_fill_lds"] / steps / launches  # average launch duration
         else:
             kname, x_units, s_units = "g2s_left_dp", tm.xB, tm.sB
             kern_ms = acc["ms_left_dp"] / steps
             launches = acc["launches"] / steps
-        alg_bytes = algorithmic_bytes(x_units, s_units, io_bytes)  # per launch
+        alg_bytes = algorithmic_bytes(x_units, s_units, io_bytes) / launches  # per launch
         achieved = alg_bytes / (kern_ms / 1e3) / 1e9 if kern_ms > 0 else 0.0
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_fill_lds.json")

@@ -296,7 +296,7 @@ Graph* graph_build(const std::vector<std::pair<const char*, uint64_t>>& seqs, in
   g->k = k;
   g->wide = k >= 32;
   if (!g->wide) count_solid<uint64_t>(*g, seqs, solid, nthreads); else count_solid<u128>(*g, seqs, solid, nthreads);
-  if (g->n >= 0x7FFFFFFFull) { if (err) *err = "too many k-mers for 32-bit oriented node ids"; delete g; return nullptr; }
+  if (g->n >= (1ull << 30)) { if (err) *err = "too many k-mers for 32-bit oriented node ids"; delete g; return nullptr; }
   if (!g->wide) finish_graph<uint64_t>(*g, nthreads); else finish_graph<u128>(*g, nthreads);
   return g;
 }

@@ -30,7 +30,8 @@ uint32_t fill_lds_frontier_cap();
 uint32_t fill_lds_max_fuz();
 hipError_t launch_fill_lds(hipStream_t st, uint32_t ngaps, uint32_t rs_cap_max, uint32_t num_oriented,
                            const uint32_t* succ, const GapDev* gaps, const uint32_t* gap_ids,
-                           const uint32_t* flank_nodes, uint64_t* log_all, uint32_t* lvl_all, GapOut* outs);
+                           const uint32_t* flank_nodes, uint64_t* log_all, uint32_t* lvl_all, GapOut* outs,
+                           uint32_t* rs_global /* nullptr: right set in LDS */);
 hipError_t launch_extract_lds(hipStream_t st, uint32_t ngaps, uint32_t num_oriented, const uint32_t* succ,
                               const GapDev* gaps, const uint32_t* gap_ids, const uint32_t* flank_nodes,
                               const uint64_t* log_all, const uint32_t* lvl_all, SubState* sub_scratch,

@@ -74,29 +74,52 @@ __device__ __forceinline__ uint32_t leading_levels(bool p, uint32_t lg) {
   const uint32_t rp = 1u << lg;
   for (uint32_t sh = 1; sh < rp; sh <<= 1) m &= (m >> sh);
   const uint64_t gmask = lg == 0 ? ~0ull : lg == 1 ? 0x5555555555555555ull : lg == 2 ? 0x1111111111111111ull
-                         : lg == 3 ? 0x0101010101010101ull : 0x0001000100010001ull;
+                         : lg == 3 ? 0x0101010101010101ull : lg == 4 ? 0x0001000100010001ull
+                         : lg == 5 ? 0x0000000100000001ull : 1ull;
   const uint64_t bad = ~m & gmask;
   return bad ? ((uint32_t)__builtin_ctzll(bad) >> lg) : (64u >> lg);
 }
+// up to 16 runs share the lanes level-major.  (Wider borders are faster in the per-level
+// step: measured 2.4 k cycles per level against 6.8 k for a one-level bulk step.)
 __device__ __forceinline__ uint32_t log2ceil16(uint32_t r) { return r <= 1 ? 0u : r <= 2 ? 1u : r <= 4 ? 2u : r <= 8 ? 3u : 4u; }
 
-// LDS right set.  1 inserted, 0 present, 2 full.
-__device__ int lrs_insert(uint32_t* tab, uint32_t mask, uint32_t v) {
-  uint32_t h = mix32(v) & mask;
+// Right set keyed by k-mer index: entry = index << 2 | strand bits.  The reference's set
+// is keyed by k-mer as well (membership at :1050 ignores the strand), so one probe answers
+// "is either strand of this k-mer in the right set" and, on insert, whether the other
+// strand is already there (Q7).  G = false: table in LDS; G = true: table in HBM (gaps
+// whose right set outgrows the LDS), re-read with agent-scope loads because it is
+// mutated by L2 atomics.  Returns bit0 = newly inserted orientation, bit1 = both strands
+// now present, bit2 = table full.
+template <bool G>
+__device__ __forceinline__ uint32_t rs_load(const uint32_t* p) {
+  return G ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+}
+template <bool G>
+__device__ uint32_t lrs_insert(uint32_t* tab, uint32_t mask, uint32_t v) {
+  const uint32_t idx = v >> 1, bit = 1u << (v & 1u);
+  uint32_t h = mix32(idx) & mask;
   for (uint32_t i = 0; i <= mask; i++) {
-    const uint32_t old = atomicCAS(&tab[h], G2S_DEV_INVALID, v);
-    if (old == G2S_DEV_INVALID) return 1;
-    if (old == v) return 0;
+    uint32_t cur = rs_load<G>(&tab[h]);
+    if (cur == G2S_DEV_INVALID) {
+      cur = atomicCAS(&tab[h], G2S_DEV_INVALID, (idx << 2) | bit);
+      if (cur == G2S_DEV_INVALID) return 1u;
+    }
+    if ((cur >> 2) == idx) {
+      const uint32_t old = atomicOr(&tab[h], bit);
+      return ((old & bit) ? 0u : 1u) | ((((old | bit) & 3u) == 3u) ? 2u : 0u);
+    }
     h = (h + 1) & mask;
   }
-  return 2;
+  return 4u;
 }
-__device__ bool lrs_has(const uint32_t* tab, uint32_t mask, uint32_t v) {
-  uint32_t h = mix32(v) & mask;
+template <bool G>
+__device__ bool lrs_has_kmer(const uint32_t* tab, uint32_t mask, uint32_t v) {
+  const uint32_t idx = v >> 1;
+  uint32_t h = mix32(idx) & mask;
   for (uint32_t i = 0; i <= mask; i++) {
-    const uint32_t cur = tab[h];
-    if (cur == v) return true;
+    const uint32_t cur = rs_load<G>(&tab[h]);
     if (cur == G2S_DEV_INVALID) return false;
+    if ((cur >> 2) == idx) return true;
     h = (h + 1) & mask;
   }
   return false;
@@ -108,11 +131,12 @@ __device__ bool lrs_has(const uint32_t* tab, uint32_t mask, uint32_t v) {
 // Phases A + B + C, LDS tier.
 // dynamic LDS: [fa 2F][fn 2F][fc 2F][lh 2F x u64][lhslot 2F][tgt TG][th 3*TH][misc 4][rs rs_cap]
 // ============================================================================
-__global__ __launch_bounds__(64) void g2s_fill_lds(const uint32_t* __restrict__ succ,
-                                                    const GapDev* __restrict__ gaps,
-                                                    const uint32_t* __restrict__ gap_ids,
-                                                    const uint32_t* __restrict__ flank_nodes, uint64_t* log_all,
-                                                    uint32_t* lvl_all, GapOut* outs, uint32_t num_oriented) {
+template <bool RSG>
+__device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ, const GapDev* __restrict__ gaps,
+                                              const uint32_t* __restrict__ gap_ids,
+                                              const uint32_t* __restrict__ flank_nodes, uint64_t* log_all,
+                                              uint32_t* lvl_all, GapOut* outs, uint32_t num_oriented,
+                                              uint32_t* rs_global) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   const uint32_t gi = __builtin_amdgcn_readfirstlane(gap_ids[blockIdx.x]);
   const GapDev gd = gaps[gi];
@@ -129,7 +153,7 @@ __global__ __launch_bounds__(64) void g2s_fill_lds(const uint32_t* __restrict__ 
   uint32_t* th_d = th_j + LDS_TH;
   uint32_t* th_c = th_d + LDS_TH;
   uint32_t* misc = th_c + LDS_TH;                 // [0] = number of target hits
-  uint32_t* rs = misc + 4;
+  uint32_t* rs = RSG ? rs_global + gd.rs_off : misc + 4;  // right set: HBM (host pre-filled 0xFF) or LDS
 
   const uint32_t rs_cap = gd.rs_mask + 1u;  // LDS capacity chosen by the host for this gap (<= rs_cap_max)
   const uint32_t rmask = gd.rs_mask;
@@ -140,7 +164,7 @@ __global__ __launch_bounds__(64) void g2s_fill_lds(const uint32_t* __restrict__ 
   uint32_t* lvl = lvl_all + gd.lvl_off;
   const uint32_t cap = gd.slog_cap;
 
-  for (uint32_t i = (uint32_t)lane; i < rs_cap; i += 64u) rs[i] = G2S_DEV_INVALID;
+  if (!RSG) for (uint32_t i = (uint32_t)lane; i < rs_cap; i += 64u) rs[i] = G2S_DEV_INVALID;
   for (uint32_t i = (uint32_t)lane; i < LDS_LH; i += 64u) lh[i] = G2S_DEV_EMPTY64;
   if (lane <= gd.rmf && lane < (int)LDS_TG) tgt[lane] = targets[lane];
   if (lane == 0) misc[0] = 0;
@@ -162,7 +186,7 @@ __global__ __launch_bounds__(64) void g2s_fill_lds(const uint32_t* __restrict__ 
     uint32_t cur = 0, nb = 0;
     const uint32_t s0 = rseeds[0];
     if (s0 != G2S_DEV_INVALID) {
-      if (lane == 0) { lrs_insert(rs, rmask, s0); fa[0] = s0; }
+      if (lane == 0) { (void)lrs_insert<RSG>(rs, rmask, s0); fa[0] = s0; }
       nb = 1;
       nvis = 1;
     }
@@ -194,7 +218,8 @@ __global__ __launch_bounds__(64) void g2s_fill_lds(const uint32_t* __restrict__ 
           ok = only_slot(rec, &nt) == (p ^ 1u);
           // two runs walking over the same ids would race for "who visited first": leave
           // such levels to the per-level code, where arrival order is the depth order
-          for (uint32_t q = 0; q < R && ok; q++) {
+          // (with one level per step, lg == 6, all inserts belong to the same depth: no race)
+          for (uint32_t q = 0; q < R && ok && lg < 6u; q++) {
             if (q == r) continue;
             const uint32_t o = fcur[q];
             if ((o & 1u) != (n & 1u)) continue;
@@ -204,14 +229,14 @@ __global__ __launch_bounds__(64) void g2s_fill_lds(const uint32_t* __restrict__ 
           }
         }
         const uint32_t lok = leading_levels(ok, lg);
-        if (lok >= 2) {
+        if (lok >= (lg == 6u ? 1u : 2u)) {
           const bool act = mine && i < lok;
           uint32_t isnew = 0;
           if (act) {
-            if (lrs_has(rs, rmask, x ^ 1u)) flags |= G2S_DEV_Q7_A;
-            const int rr = lrs_insert(rs, rmask, p);
-            isnew = (rr == 1);
-            if (rr == 2) flags |= G2S_DEV_OVERFLOW_A;
+            const uint32_t rr = lrs_insert<RSG>(rs, rmask, p);
+            isnew = rr & 1u;
+            if (rr & 2u) flags |= G2S_DEV_Q7_A;
+            if (rr & 4u) flags |= G2S_DEV_OVERFLOW_A;
           }
           nvis += (uint32_t)__popcll(__ballot(isnew));
           if (nvis > rs_cap / 4u * 3u) { overflow = true; break; }
@@ -248,14 +273,14 @@ __global__ __launch_bounds__(64) void g2s_fill_lds(const uint32_t* __restrict__ 
         const bool valid = i < nb * 4u;
         const uint32_t n = valid ? fcur[i >> 2] : 0u;
         const uint32_t nt = i & 3u;
-        if (valid && nt == 0 && lrs_has(rs, rmask, n ^ 1u)) flags |= G2S_DEV_Q7_A;
         // graph.predecessors(n)[nt] = graph.successors(n^1)[nt] ^ 1
         const uint32_t p = valid ? flip(succ[(size_t)(n ^ 1u) * 4 + nt]) : G2S_DEV_INVALID;
         uint32_t isnew = 0;
         if (p != G2S_DEV_INVALID) {
-          const int r = lrs_insert(rs, rmask, p);
-          isnew = (r == 1);
-          if (r == 2) flags |= G2S_DEV_OVERFLOW_A;
+          const uint32_t r = lrs_insert<RSG>(rs, rmask, p);
+          isnew = r & 1u;
+          if (r & 2u) flags |= G2S_DEV_Q7_A;
+          if (r & 4u) flags |= G2S_DEV_OVERFLOW_A;
         }
         const uint64_t m = __ballot(isnew);
         if (isnew) {
@@ -271,9 +296,10 @@ __global__ __launch_bounds__(64) void g2s_fill_lds(const uint32_t* __restrict__ 
         const uint32_t s = rseeds[d];
         if (s != G2S_DEV_INVALID) {
           int r = 0;
-          if (lane == 0) r = lrs_insert(rs, rmask, s);
+          if (lane == 0) r = (int)lrs_insert<RSG>(rs, rmask, s);
           r = __shfl(r, 0);
-          if (r == 1) {
+          if (r & 2) flags |= G2S_DEV_Q7_A;
+          if (r & 1) {
             if (nnew < LDS_F) { if (lane == 0) fnxt[nnew] = s; } else overflow = true;
             nnew++;
             nvis++;
@@ -312,6 +338,7 @@ __global__ __launch_bounds__(64) void g2s_fill_lds(const uint32_t* __restrict__ 
     }
     lds_sync();
     int d = 1, lvl_written = 1;  // lvl[0..lvl_written] hold valid offsets
+    uint32_t bulk_epoch = 0x80000000u;  // tags merge-table entries of bulk steps; never equals a depth
     for (; d <= gd.D; d++) {
       uint32_t* ncur = fn + cur * LDS_F;
       uint32_t* ccur = fc + cur * LDS_F;
@@ -347,19 +374,30 @@ __global__ __launch_bounds__(64) void g2s_fill_lds(const uint32_t* __restrict__ 
           uint32_t nt;
           const uint4 rec = *(const uint4*)(succ + (size_t)x * 4);
           ok = only_slot(rec, &nt) == v;
-          if (ok && d + (int)i >= gd.prune_from) ok = lrs_has(rs, rmask, v) || lrs_has(rs, rmask, v ^ 1u);  // :1050
+          if (ok && d + (int)i >= gd.prune_from) ok = lrs_has_kmer<RSG>(rs, rmask, v);  // :1050
         }
         uint32_t lrun = leading_levels(ok, lg);
         if (lrun > L) lrun = L;
-        if (lrun >= 2 && nlog + lrun * R <= cap && misc[0] + 64u <= LDS_TH) {
+        if (lrun >= (lg == 6u ? 1u : 2u) && nlog + lrun * R <= cap && misc[0] + 64u <= LDS_TH) {
           const bool act = mine && i < lrun;
-          if (act && R > 1) {  // Q7: the other strand of my k-mer on another run at this level
-            for (uint32_t q = 0; q < R; q++) {
-              const uint32_t o = ncur[q];
-              const uint32_t ov = (o & 1u) == 0 ? o + step : o - step;
-              if (q != r && ov == (v ^ 1u)) flags |= G2S_DEV_Q7_B;
+          if (act && R > 1) {
+            // Q7: the other strand of my k-mer on another run at this level.  All states of the
+            // bulk are distinct, so claiming (epoch | k-mer index, level) in the merge table can
+            // only collide with the other strand.  (Index truncated above 2^26 k-mers: the flag
+            // is conservative, a false positive only narrows the bit-exact claim.)
+            const uint64_t key = ((uint64_t)bulk_epoch << 32) | (uint32_t)(((v >> 1) << 6) | i);
+            uint32_t h = mix32((uint32_t)key) & (LDS_LH - 1u);
+            while (true) {
+              const uint64_t c = lh[h];
+              if ((uint32_t)(c >> 32) == bulk_epoch) {
+                if (c == key) { flags |= G2S_DEV_Q7_B; break; }
+                h = (h + 1) & (LDS_LH - 1u);
+                continue;
+              }
+              if (atomicCAS((unsigned long long*)&lh[h], (unsigned long long)c, (unsigned long long)key) == c) break;
             }
           }
+          bulk_epoch++;
           if (act && ((tbloom >> (mix32(v) & 63u)) & 1ull)) {
             for (int j = 0; j <= gd.rmf; j++) {
               if (tgt[j] == v) {
@@ -432,7 +470,7 @@ __global__ __launch_bounds__(64) void g2s_fill_lds(const uint32_t* __restrict__ 
         if (np > G2S_DEV_MAX_PATHS) np = G2S_DEV_MAX_PATHS;
         const bool valid = lane < 4;
         const uint32_t v = valid ? succ[(size_t)n * 4 + ((uint32_t)lane & 3u)] : G2S_DEV_INVALID;
-        const bool pass = v != G2S_DEV_INVALID && (unpruned || lrs_has(rs, rmask, v) || lrs_has(rs, rmask, v ^ 1u));
+        const bool pass = v != G2S_DEV_INVALID && (unpruned || lrs_has_kmer<RSG>(rs, rmask, v));
         const uint64_t m = __ballot(pass);
         if (pass) {
           const uint32_t off = (uint32_t)__popcll(m & lanes_below(lane));
@@ -453,7 +491,7 @@ __global__ __launch_bounds__(64) void g2s_fill_lds(const uint32_t* __restrict__ 
           uint32_t np = valid ? ccur[i >> 2] : 0u;
           if (np > G2S_DEV_MAX_PATHS) np = G2S_DEV_MAX_PATHS;
           const uint32_t v = valid ? succ[(size_t)n * 4 + (i & 3u)] : G2S_DEV_INVALID;
-          const bool pass = v != G2S_DEV_INVALID && (unpruned || lrs_has(rs, rmask, v) || lrs_has(rs, rmask, v ^ 1u));
+          const bool pass = v != G2S_DEV_INVALID && (unpruned || lrs_has_kmer<RSG>(rs, rmask, v));
           // pass 1: claim (depth, node) in the merge table; stale entries of older levels count as free
           uint32_t h = 0, won = 0;
           if (pass) {
@@ -588,6 +626,24 @@ __global__ __launch_bounds__(64) void g2s_fill_lds(const uint32_t* __restrict__ 
     go->len[1] = len1;
     go->reached_j = reached_j;
   }
+}
+
+__global__ __launch_bounds__(64) void g2s_fill_lds(const uint32_t* __restrict__ succ,
+                                                    const GapDev* __restrict__ gaps,
+                                                    const uint32_t* __restrict__ gap_ids,
+                                                    const uint32_t* __restrict__ flank_nodes, uint64_t* log_all,
+                                                    uint32_t* lvl_all, GapOut* outs, uint32_t num_oriented) {
+  fill_lds_body<false>(succ, gaps, gap_ids, flank_nodes, log_all, lvl_all, outs, num_oriented, nullptr);
+}
+// Same kernel with the right set in HBM: for gaps whose right set outgrows the LDS (deep
+// DP, -dist-error in the thousands); everything else of the gap stays in LDS.
+__global__ __launch_bounds__(64) void g2s_fill_lds_rsg(const uint32_t* __restrict__ succ,
+                                                        const GapDev* __restrict__ gaps,
+                                                        const uint32_t* __restrict__ gap_ids,
+                                                        const uint32_t* __restrict__ flank_nodes, uint64_t* log_all,
+                                                        uint32_t* lvl_all, GapOut* outs, uint32_t num_oriented,
+                                                        uint32_t* rs_global) {
+  fill_lds_body<true>(succ, gaps, gap_ids, flank_nodes, log_all, lvl_all, outs, num_oriented, rs_global);
 }
 
 // ============================================================================
@@ -896,8 +952,15 @@ uint32_t fill_lds_max_fuz() { return LDS_TG - 1; }
 
 hipError_t launch_fill_lds(hipStream_t st, uint32_t ngaps, uint32_t rs_cap_max, uint32_t num_oriented,
                            const uint32_t* succ, const GapDev* gaps, const uint32_t* gap_ids,
-                           const uint32_t* flank_nodes, uint64_t* log_all, uint32_t* lvl_all, GapOut* outs) {
+                           const uint32_t* flank_nodes, uint64_t* log_all, uint32_t* lvl_all, GapOut* outs,
+                           uint32_t* rs_global) {
   if (ngaps == 0) return hipSuccess;
+  if (rs_global) {  // right set in HBM: no LDS for it
+    const size_t bytes = fill_lds_bytes(0);
+    hipLaunchKernelGGL(g2s_fill_lds_rsg, dim3(ngaps), dim3(64), bytes, st, succ, gaps, gap_ids, flank_nodes, log_all,
+                       lvl_all, outs, num_oriented, rs_global);
+    return hipGetLastError();
+  }
   const size_t bytes = fill_lds_bytes(rs_cap_max);
   hipError_t e = hipFuncSetAttribute((const void*)g2s_fill_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   if (e != hipSuccess) return e;

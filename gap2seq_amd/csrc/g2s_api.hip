@@ -297,22 +297,14 @@ class WorkerPool {
 };
 
 // The session's rand() stream, materialised ahead of use so that tracebacks of
-// different gaps can read their draws at known offsets in parallel.
+// different gaps can read their draws at known offsets in parallel (value = word >> 1).
 struct RandCache {
-  GlibcRand rng;
-  std::vector<int32_t> buf;
-  size_t head = 0;  // buf[head] is the next undrawn value of the stream
-  void seed(uint32_t s) { rng.seed(s); buf.clear(); head = 0; }
-  void ensure(size_t n) {  // at least n values available from head
-    if (buf.size() - head >= n) return;
-    if (head > (1u << 20)) { buf.erase(buf.begin(), buf.begin() + (ptrdiff_t)head); head = 0; }
-    size_t want = head + n + (n >> 2) + 4096;
-    buf.reserve(want);
-    while (buf.size() < want) buf.push_back((int32_t)rng.next());
-  }
-  int32_t at(size_t off) { ensure(off + 1); return buf[head + off]; }
-  const int32_t* ptr(size_t off) const { return buf.data() + head + off; }
-  void consume(size_t n) { head += n; }
+  GlibcRandStream st;
+  void seed(uint32_t s) { st.seed(s); }
+  void ensure(size_t n) { st.ensure(n); }  // at least n upcoming values materialised
+  int32_t at(size_t off) { st.ensure(off + 1); return st.value(off); }
+  const uint32_t* ptr(size_t off) const { return st.raw() + off; }
+  void consume(size_t n) { st.consume(n); }
 };
 
 struct g2s_session {
@@ -390,14 +382,14 @@ struct g2s_batch {
 };
 
 // pinned result buffers are recycled through the session: allocating page-locked memory
-// costs more than a whole 500-gap batch
-void g2s_batch::drop_tiers() {
-  for (TierData* t : tiers) { t->gap_ids.clear(); s->tier_pool.push_back(t); }
-  tiers.clear();
-}
-static TierData* take_tier(g2s_session* s) {
-  if (!s->tier_pool.empty()) { TierData* t = (TierData*)s->tier_pool.back(); s->tier_pool.pop_back(); return t; }
-  return new TierData();
+// costs more than a whole 500-gap batch.  The k-th launch group of a run always uses the
+// session's k-th slot, so buffer sizes settle after the first run.
+void g2s_batch::drop_tiers() { tiers.clear(); }
+static TierData* take_tier(g2s_session* s, size_t slot) {
+  while (s->tier_pool.size() <= slot) s->tier_pool.push_back(new TierData());
+  TierData* t = (TierData*)s->tier_pool[slot];
+  t->gap_ids.clear();
+  return t;
 }
 
 extern "C" int g2s_batch_prepare(g2s_session* s, const g2s_gap* gaps, size_t n, g2s_batch** out) {
@@ -502,7 +494,7 @@ Plan plan_gap(const GapJob& j, int d_err, uint64_t scale, uint64_t max_states) {
 // LDS-resident kernels (fill_lds.hip); false: the general tier with per-gap tables in
 // HBM (fill_kernels.hip) at the given table scale.
 int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uint64_t max_states, TierData* td,
-             bool lds) {
+             bool lds, uint32_t lds_room_override = 0, bool rs_in_hbm = false) {
   g2s_session* s = b->s;
   const DeviceGraph& dg = s->graph->g->dev.at(s->device);
   const size_t n = b->jobs.size();
@@ -531,8 +523,8 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
     d.st_off = st_total; st_total += 2ull * p.slog_cap;
     d.slog_off = slog_total; slog_total += p.slog_cap;
     d.lvl_off = lvl_total; lvl_total += (uint64_t)(d.D + 2);
-    if (lds) {
-      const uint32_t c = lds_rs_cap(j, d_err, lds_room(ids.size()));
+    if (lds && !rs_in_hbm) {
+      const uint32_t c = lds_rs_cap(j, d_err, lds_room_override ? lds_room_override : lds_room(ids.size()));
       d.rs_mask = c - 1;
       lds_cap_max = std::max(lds_cap_max, c);
     }
@@ -551,12 +543,16 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
   if (lds) {
     HIP_TRY(s->d_log.ensure(slog_total * 8));
     HIP_TRY(s->d_lvl.ensure(lvl_total * 4));
+    if (rs_in_hbm) {
+      HIP_TRY(s->d_rs.ensure(rs_total * 4));
+      HIP_TRY(hipMemsetAsync(s->d_rs.p, 0xFF, rs_total * 4, st));
+    }
     HIP_TRY(hipEventRecord(s->ev[0], st));
     HIP_TRY(hipEventRecord(s->ev[1], st));  // phases A-C are one kernel in this tier
     const uint32_t num_oriented = (uint32_t)(2 * s->graph->g->n);
     HIP_TRY(launch_fill_lds(st, (uint32_t)ids.size(), lds_cap_max, num_oriented, dg.succ, (const GapDev*)s->d_gaps.p,
                             (const uint32_t*)s->d_ids.p, (const uint32_t*)s->d_flank.p, (uint64_t*)s->d_log.p,
-                            (uint32_t*)s->d_lvl.p, (GapOut*)s->d_outs.p));
+                            (uint32_t*)s->d_lvl.p, (GapOut*)s->d_outs.p, rs_in_hbm ? (uint32_t*)s->d_rs.p : nullptr));
     HIP_TRY(hipEventRecord(s->ev[2], st));
     HIP_TRY(launch_extract_lds(st, (uint32_t)ids.size(), num_oriented, dg.succ, (const GapDev*)s->d_gaps.p,
                                (const uint32_t*)s->d_ids.p, (const uint32_t*)s->d_flank.p, (const uint64_t*)s->d_log.p,
@@ -609,6 +605,7 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
   if (lds) {
     HIP_TRY(hipEventElapsedTime(&ms, s->ev[1], s->ev[2]));
     b->timing.ms_fill_lds += ms;
+    b->timing.lds_launches++;
     HIP_TRY(hipEventElapsedTime(&ms, s->ev[2], s->ev[3]));
     b->timing.ms_extract_lds += ms;
   } else {
@@ -671,20 +668,40 @@ extern "C" int g2s_batch_run(g2s_batch* b, g2s_result* results, char* arena, siz
       else todo.push_back((uint32_t)i);
     }
   }
-  // ---- tier 0: LDS-resident kernels; whatever does not fit falls through to the HBM tier
-  if (!lds_ids.empty()) {
-    TierData* td = take_tier(s);
+  // ---- tier 0: LDS-resident kernels.  Pass 1 shares the CU's LDS among as many gaps as
+  // the batch needs resident; gaps whose right set outgrows that share are run again with
+  // the largest LDS tables (pass 2, few gaps per CU); what still does not fit (frontier
+  // > 64, > 128 target hits, state log) falls through to the HBM tier.
+  //   pass 0: LDS shared among all gaps of the batch, state log 8 (D+2)
+  //   pass 1: largest LDS right set (16 K entries), state log 64 (D+2)
+  //   pass 2: right set in HBM (any size up to -max-mem), the rest still in LDS
+  std::vector<uint32_t> cand[3];
+  cand[0] = lds_ids;
+  const bool room0_is_max = lds_room(n) >= 16384u;
+  for (int pass = 0; pass < 3; pass++) {
+    if (cand[pass].empty()) continue;
+    const std::vector<uint32_t>& ids = cand[pass];
+    const uint32_t room = pass == 0 ? 0u : 16384u;
+    TierData* td = take_tier(s, b->tiers.size());
     b->tiers.push_back(td);
-    int rc = run_tier(b, lds_ids, 1, max_states, td, true);
+    int rc = run_tier(b, ids, pass == 0 ? 1 : 8, max_states, td, true, room, pass == 2);
     if (rc != G2S_OK) return rc;
     const GapOut* outs = (const GapOut*)td->outs.p;
-    for (uint32_t i : lds_ids) {
+    for (uint32_t i : ids) {
       const GapOut& go = outs[i];
       if (go.flags & (G2S_DEV_OVERFLOW_A | G2S_DEV_OVERFLOW_B)) {
         if (getenv("G2S_DEBUG"))
-          fprintf(stderr, "[g2s] gap %u left the LDS tier: flags 0x%x n_right %u x_right %u n_states %u x_left %u final_d %d g %d\n",
-                  i, go.flags, go.n_right, go.x_right, go.n_states, go.x_left, go.final_d, b->jobs[i].g);
-        todo.push_back(i);
+          fprintf(stderr, "[g2s] gap %u left LDS pass %d: flags 0x%x n_right %u x_right %u n_states %u x_left %u final_d %d g %d\n",
+                  i, pass, go.flags, go.n_right, go.x_right, go.n_states, go.x_left, go.final_d, b->jobs[i].g);
+        // a right-set overflow is cured by a larger right set (pass 1 unless pass 0 already
+        // had the largest LDS table, else pass 2); a state-log overflow may be cured by pass
+        // 1's larger log; a frontier wider than the LDS buffers needs the HBM tier
+        const bool only_a = (go.flags & G2S_DEV_OVERFLOW_A) && !(go.flags & G2S_DEV_OVERFLOW_B);
+        int target = 3;
+        if (pass == 0) target = (only_a && room0_is_max) ? 2 : 1;
+        else if (pass == 1 && only_a) target = 2;
+        if (target < 3) cand[target].push_back(i);
+        else { todo.push_back(i); b->timing.retried_gaps++; }
         continue;
       }
       SubView& v = views[i];
@@ -699,23 +716,18 @@ extern "C" int g2s_batch_run(g2s_batch* b, g2s_result* results, char* arena, siz
       b->timing.lds_tier_gaps++;
     }
     if (getenv("G2S_DEBUG")) {  // the slowest gaps of the LDS tier and why
-      std::vector<uint32_t> ord(lds_ids);
+      std::vector<uint32_t> ord(ids);
       std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t c) {
         return outs[a].stat[4] + outs[a].stat[5] + outs[a].stat[7] > outs[c].stat[4] + outs[c].stat[5] + outs[c].stat[7]; });
-      for (size_t q = 0; q < ord.size() && q < 6; q++) {
+      for (size_t q = 0; q < ord.size() && q < 4; q++) {
         const GapOut& o = outs[ord[q]];
-        fprintf(stderr, "[g2s] slow gap %u: g %d | A per-level %u bulk %u kcyc %u | B per-level %u bulk %u kcyc %u | D1 per-level %u bulk %u kcyc %u | xA %u xB %u xD %u\n",
-                ord[q], b->jobs[ord[q]].g, o.stat[0], o.stat[1], o.stat[4] >> 2, o.stat[2], o.stat[3], o.stat[5] >> 2,
+        fprintf(stderr, "[g2s] pass %d slow gap %u: g %d | A per-level %u bulk %u kcyc %u | B per-level %u bulk %u kcyc %u | D1 per-level %u bulk %u kcyc %u | xA %u xB %u xD %u\n",
+                pass, ord[q], b->jobs[ord[q]].g, o.stat[0], o.stat[1], o.stat[4] >> 2, o.stat[2], o.stat[3], o.stat[5] >> 2,
                 o.stat[6] & 0xFFFF, o.stat[6] >> 16, o.stat[7] >> 2, o.x_right, o.x_left, o.x_sub);
       }
     }
-    size_t before = todo.size();
-    (void)before;
-    uint32_t fell = 0;
-    for (uint32_t i : lds_ids) if (!views[i].out) fell++;
-    std::sort(todo.begin(), todo.end());
-    b->timing.retried_gaps += fell;
   }
+  std::sort(todo.begin(), todo.end());
   // gaps that outgrew the LDS tier are known to branch: start them with 8x tables
   uint64_t scale = lds_ids.empty() ? 1 : 8;
   while (!todo.empty()) {
@@ -730,7 +742,7 @@ extern "C" int g2s_batch_run(g2s_batch* b, g2s_result* results, char* arena, siz
         bytes += p.bytes;
         group.push_back(todo[pos++]);
       }
-      TierData* td = take_tier(s);
+      TierData* td = take_tier(s, b->tiers.size());
       b->tiers.push_back(td);
       int rc = run_tier(b, group, scale, max_states, td, false);
       if (rc != G2S_OK) return rc;
@@ -922,9 +934,9 @@ extern "C" int g2s_test_post_gap(const g2s_graph* gh, const g2s_params* p, const
     GlibcRand rng;
     rng.seed(seed);
     for (uint32_t i = 0; i < skip; i++) rng.next();
-    std::vector<int32_t> rands((size_t)t.D + 4);
-    for (auto& x : rands) x = (int32_t)rng.next();
-    const int pick = (int)(rands[0] % go.n_len);
+    std::vector<uint32_t> rands((size_t)t.D + 4);
+    for (auto& x : rands) x = (uint32_t)rng.next() << 1;  // raw words: value = word >> 1
+    const int pick = (int)((rands[0] >> 1) % (uint32_t)go.n_len);
     const int fixed = sub_fixed_draws(v, prep, pick);
     sub_traceback(g, fp, j, v, prep, rands.data(), buf, res);
     if (fixed >= 0 && fixed != res->draws) return fail(G2S_ERR_STATE, "stop-depth analysis disagrees with the traceback");
@@ -933,5 +945,18 @@ extern "C" int g2s_test_post_gap(const g2s_graph* gh, const g2s_params* p, const
     res->fill_off = (uint64_t)(j.lmf - res->left_fuz);
     res->fill_len = (int32_t)strlen(buf + res->fill_off);
   }
+  return G2S_OK;
+}
+
+extern "C" int g2s_test_rand_stream(uint32_t seed, uint32_t skip, uint32_t n, int32_t* out) {
+  if (!out) return fail(G2S_ERR_ARG, "g2s_test_rand_stream: bad argument");
+  GlibcRandStream st;
+  st.seed(seed);
+  // consume in two pieces so that the compaction path is exercised too
+  st.ensure(skip / 2 + 1);
+  st.consume(skip / 2);
+  st.ensure(skip - skip / 2 + n);
+  st.consume(skip - skip / 2);
+  for (uint32_t i = 0; i < n; i++) out[i] = st.value(i);
   return G2S_OK;
 }

@@ -4,7 +4,10 @@
 // Algorithm: glibc stdlib/random_r.c, TYPE_3 (x^31 + x^3 + 1 additive feedback),
 // seeded by a 16807 Lehmer sequence, first 310 outputs discarded.
 #pragma once
+#include <cstddef>
 #include <cstdint>
+#include <cstdlib>
+#include <cstring>
 
 namespace g2s {
 
@@ -35,6 +38,74 @@ class GlibcRand {
  private:
   uint32_t state_[31];
   int front_, rear_;
+};
+
+// The same stream materialised into a flat array, many values at a time.  glibc's ring
+// update r[f] += r[f-3] is the lagged Fibonacci recurrence x[n] = x[n-31] + x[n-3]; laid
+// out flat (e[0..30] = seeded state rotated by 3, e[n] = e[n-31] + e[n-3]) three values per
+// step are independent, so this runs several times faster than calling next() in a loop.
+class GlibcRandStream {
+ public:
+  GlibcRandStream() {}
+  ~GlibcRandStream() { free(e_); }
+  GlibcRandStream(const GlibcRandStream&) = delete;
+  GlibcRandStream& operator=(const GlibcRandStream&) = delete;
+  void seed(uint32_t s) {
+    if (s == 0) s = 1;
+    uint32_t r[31];
+    int64_t w = (int32_t)s;
+    r[0] = (uint32_t)w;
+    for (int i = 1; i < 31; i++) {
+      w = (16807 * w) % 2147483647;
+      if (w < 0) w += 2147483647;
+      r[i] = (uint32_t)w;
+    }
+    reserve(31 + 310 + 4096);
+    size_ = 31;
+    for (int i = 0; i < 31; i++) e_[i] = r[(i + 3) % 31];
+    extend(310);          // srand() discards the first 310 outputs
+    first_ = 31 + 310;    // e_[first_ + k] >> 1 is the k-th value rand() returns
+  }
+  // make the next `upto` values of the stream available
+  void ensure(size_t upto) { if (first_ + upto > size_) extend(first_ + upto - size_ + 4096); }
+  int32_t value(size_t k) const { return (int32_t)(e_[first_ + k] >> 1); }
+  // raw words of the upcoming values: value k = raw()[k] >> 1
+  const uint32_t* raw() const { return e_ + first_; }
+  // drop the first n values (they were consumed)
+  void consume(size_t n) {
+    first_ += n;
+    if (first_ > (1u << 22) && first_ <= size_) {  // keep the array from growing without bound
+      const size_t keep_from = first_ - 31;
+      memmove(e_, e_ + keep_from, (size_ - keep_from) * sizeof(uint32_t));
+      size_ -= keep_from;
+      first_ = 31;
+    }
+  }
+ private:
+  void reserve(size_t n) {
+    if (n <= cap_) return;
+    size_t want = n + n / 2;
+    e_ = (uint32_t*)realloc(e_, want * sizeof(uint32_t));  // no zero fill: every word is written below
+    cap_ = want;
+  }
+  void extend(size_t n) {
+    const size_t old = size_;
+    reserve(old + n);
+    size_ = old + n;
+    uint32_t* e = e_;
+    // the three most recent values stay in registers: every load is 31 elements behind the
+    // stores, so the loop runs at load/store throughput instead of store-forwarding latency
+    uint32_t a = e[old - 3], b = e[old - 2], c = e[old - 1];
+    size_t i = old;
+    for (; i + 3 <= old + n; i += 3) {
+      a += e[i - 31]; e[i] = a;
+      b += e[i - 30]; e[i + 1] = b;
+      c += e[i - 29]; e[i + 2] = c;
+    }
+    for (; i < old + n; i++) e[i] = e[i - 31] + e[i - 3];
+  }
+  uint32_t* e_ = nullptr;
+  size_t size_ = 0, cap_ = 0, first_ = 31;
 };
 
 }  // namespace g2s

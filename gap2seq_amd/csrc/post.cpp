@@ -43,8 +43,14 @@ struct VertexMap {
 
 // Tarjan over a CSR adjacency; component ids are arbitrary.
 int strong_components(int nv, const std::vector<int>& off, const std::vector<int>& adj, std::vector<int>* comp) {
-  std::vector<int> index((size_t)nv, -1), low((size_t)nv, 0), it((size_t)nv, 0), stack, call;
-  std::vector<char> on((size_t)nv, 0);
+  static thread_local std::vector<int> index, low, it, stack, call;
+  static thread_local std::vector<char> on;
+  index.assign((size_t)nv, -1);
+  low.assign((size_t)nv, 0);
+  it.assign((size_t)nv, 0);
+  on.assign((size_t)nv, 0);
+  stack.clear();
+  call.clear();
   comp->assign((size_t)nv, -1);
   int counter = 0, nc = 0;
   for (int r = 0; r < nv; r++) {
@@ -92,8 +98,14 @@ void sub_analyze(const FillParams& p, const GapJob& job, const SubView& v, SubPr
 
   // traceback starts and, per start, the depth at which every traceback stops
   // (states are stored depth-descending, so a reverse sweep sees predecessors first)
+  // per-thread scratch: these vectors are reused across gaps (no allocation in steady state)
+  static thread_local std::vector<int> lo, hi, vid, off, adj, comp, csize, cvert, din, dout, foff, fadj, indeg, order, fbranch;
+  static thread_local std::vector<uint64_t> el;
+  static thread_local std::vector<std::pair<int, int>> fe;
+  static thread_local VertexMap vm;
   {
-    std::vector<int> lo((size_t)n, -2), hi((size_t)n, -2);  // -2: not on a traceback closure
+    lo.assign((size_t)n, -2);  // -2: not on a traceback closure
+    hi.assign((size_t)n, -2);
     for (int64_t i = (int64_t)n - 1; i >= 0; i--) {
       const SubState& s = st[i];
       if (!(s.flags & G2S_SUB_IN_T)) continue;
@@ -121,13 +133,12 @@ void sub_analyze(const FillParams& p, const GapJob& job, const SubView& v, SubPr
   if (p.skip_confident) return;  // no D1/D2 with -all-upper (:1181)
 
   // ---- D2 on the S closure: vertices = canonical k-mers (+ sink 0, source 1) ----
-  VertexMap vm;
   vm.init(n);
   int nverts = 2;
-  std::vector<int> vid((size_t)n, -1);
+  vid.assign((size_t)n, -1);
   for (uint32_t i = 0; i < n; i++)
     if (st[i].flags & G2S_SUB_IN_S) vid[i] = vm.get_or_add(st[i].node >> 1, &nverts);
-  std::vector<uint64_t> el;
+  el.clear();
   el.reserve((size_t)n + 8);
   int count = 0;
   auto edge = [&](int a, int b) { el.push_back(((uint64_t)(uint32_t)a << 32) | (uint32_t)b); };
@@ -145,21 +156,23 @@ void sub_analyze(const FillParams& p, const GapJob& job, const SubView& v, SubPr
 
   const int V = nverts;
   const size_t E = el.size();
-  std::vector<int> off((size_t)V + 1, 0), adj(E);
+  off.assign((size_t)V + 1, 0);
+  adj.resize(E);
   for (uint64_t x : el) off[(size_t)(x >> 32) + 1]++;
   for (int i = 0; i < V; i++) off[(size_t)i + 1] += off[(size_t)i];
   for (size_t x = 0; x < E; x++) adj[x] = (int)(uint32_t)el[x];  // el is sorted by source: already CSR order
-  std::vector<int> comp;
   const int nc = strong_components(V, off, adj, &comp);
-  std::vector<int> csize((size_t)nc, 0), cvert((size_t)nc, -1);
+  csize.assign((size_t)nc, 0);
+  cvert.assign((size_t)nc, -1);
   for (int i = 0; i < V; i++) csize[(size_t)comp[(size_t)i]]++;
   int nontrivial = 0, size_nontrivial = 0;
   for (int c = 0; c < nc; c++)
     if (csize[(size_t)c] > 1) { cvert[(size_t)c] = V + nontrivial++; size_nontrivial += csize[(size_t)c]; }
   const int VF = V + nontrivial;  // trivial vertices keep their id, SCC members map to the contracted vertex
   auto fin = [&](int x) { return csize[(size_t)comp[(size_t)x]] > 1 ? cvert[(size_t)comp[(size_t)x]] : x; };
-  std::vector<int> din((size_t)VF, 0), dout((size_t)VF, 0);
-  std::vector<std::pair<int, int>> fe;
+  din.assign((size_t)VF, 0);
+  dout.assign((size_t)VF, 0);
+  fe.clear();
   fe.reserve(E);
   size_t loops_trivial = 0;
   for (uint64_t x : el) {
@@ -181,14 +194,16 @@ void sub_analyze(const FillParams& p, const GapJob& job, const SubView& v, SubPr
   out->sub[5] = (uint64_t)fe.size();
 
   // topological order of the condensed multigraph (Kahn), then the branch rule (:1420-1434)
-  std::vector<int> foff((size_t)VF + 1, 0), fadj(fe.size());
+  foff.assign((size_t)VF + 1, 0);
+  fadj.resize(fe.size());
   for (auto& ed : fe) foff[(size_t)ed.first + 1]++;
   for (int i = 0; i < VF; i++) foff[(size_t)i + 1] += foff[(size_t)i];
   {
     std::vector<int> pos(foff.begin(), foff.end() - 1);
     for (auto& ed : fe) fadj[(size_t)pos[(size_t)ed.first]++] = ed.second;
   }
-  std::vector<int> indeg(din), order;
+  indeg = din;
+  order.clear();
   order.reserve((size_t)VF);
   for (int i = 0; i < VF; i++) if (indeg[(size_t)i] == 0) order.push_back(i);
   for (size_t qi = 0; qi < order.size(); qi++) {
@@ -196,7 +211,7 @@ void sub_analyze(const FillParams& p, const GapJob& job, const SubView& v, SubPr
     for (int x = foff[(size_t)u]; x < foff[(size_t)u + 1]; x++)
       if (--indeg[(size_t)fadj[(size_t)x]] == 0) order.push_back(fadj[(size_t)x]);
   }
-  std::vector<int> fbranch((size_t)VF, 0);
+  fbranch.assign((size_t)VF, 0);
   int bc = 1;
   for (int u : order) {
     if (din[(size_t)u] >= 1 || dout[(size_t)u] >= 1) {
@@ -219,13 +234,13 @@ void sub_analyze(const FillParams& p, const GapJob& job, const SubView& v, SubPr
 }
 
 void sub_traceback(const Graph& g, const FillParams& p, const GapJob& job, const SubView& v, const SubPrep& prep,
-                   const int32_t* rands, char* buf, g2s_result* res) {
+                   const uint32_t* rands, char* buf, g2s_result* res) {
   const GapOut& go = *v.out;
   const int lmf = job.lmf, k = p.k;
   res->right_fuz = go.reached_j;  // :1171
   res->flags |= G2S_GAP_PHASE_D;
   int draws = 0;
-  const int pick = (int)(rands[draws++] % go.n_len);  // :1440
+  const int pick = (int)((rands[draws++] >> 1) % (uint32_t)go.n_len);  // :1440
   int d2 = go.len[pick];
   int last_solid = d2;
   int i = prep.start_idx[pick];
@@ -251,7 +266,7 @@ void sub_traceback(const Graph& g, const FillParams& p, const GapJob& job, const
         res->count = 0;
         break;
       }
-      i = back[rands[draws++] % nb];  // :1513
+      i = back[(rands[draws++] >> 1) % (uint32_t)nb];  // :1513
     }
     d2--;
   }

@@ -63,10 +63,11 @@ void sub_analyze(const FillParams& p, const GapJob& job, const SubView& v, SubPr
 inline int sub_fixed_draws(const SubView& v, const SubPrep& prep, int pick) {
   return prep.stop_depth[pick] < 0 ? -1 : 1 + (v.out->len[pick] - prep.stop_depth[pick]);
 }
-// D3.  `rands` points at this gap's first draw; returns through res (count, fuz, draws, flags).
+// D3.  `rands` points at the raw word of this gap's first draw (rand() value = word >> 1);
+// returns through res (count, fuz, draws, flags).
 // Writes the reference's `fill` buffer into buf (size job.buf_bytes).
 void sub_traceback(const Graph& g, const FillParams& p, const GapJob& job, const SubView& v, const SubPrep& prep,
-                   const int32_t* rands, char* buf, g2s_result* res);
+                   const uint32_t* rands, char* buf, g2s_result* res);
 
 // TEST HOOK support: the closure the g2s_extract kernel computes, derived on the host
 // from a full DP table (states sorted per level).  Not used by the product path.

@@ -55,7 +55,7 @@ class g2s_timing(C.Structure):
                 ("xD", C.c_uint64), ("sD", C.c_uint64), ("flank_bytes", C.c_uint64), ("fill_bytes", C.c_uint64),
                 ("launches_left_dp", C.c_uint32), ("retried_gaps", C.c_uint32),
                 ("ms_fill_lds", C.c_double), ("ms_extract_lds", C.c_double), ("x_fill_lds", C.c_uint64),
-                ("s_fill_lds", C.c_uint64), ("lds_tier_gaps", C.c_uint32), ("pad", C.c_uint32)]
+                ("s_fill_lds", C.c_uint64), ("lds_tier_gaps", C.c_uint32), ("lds_launches", C.c_uint32)]
 
 
 class g2s_run_opts(C.Structure):
@@ -105,6 +105,7 @@ _SIGS = {
     "g2s_synth_genome": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint64, C.POINTER(_VP)]),
     "g2s_synth_gaps": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64,
                                  C.POINTER(_VP)]),
+    "g2s_test_rand_stream": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_int32)]),
     "g2s_test_post_gap": (C.c_int, [_VP, C.POINTER(g2s_params), C.POINTER(g2s_gap), C.c_int32,
                                     C.POINTER(C.c_uint32), C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.c_int32,
                                     C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_uint32, C.c_uint32,
@@ -387,3 +388,10 @@ def test_post_gap(graph, params, gap, states, c_count, lengths, reached_j, final
     _check(lib.g2s_test_post_gap(graph.h, C.byref(params), arr, n, nodes, depths, counts, c_count, len(lengths), lens,
                                  reached_j, final_d, seed, skip, C.byref(res), buf))
     return FillResult(res, buf.raw)
+
+
+def test_rand_stream(seed, skip, n):
+    """TEST HOOK binding: n values of the product's rand() stream after srand(seed), skipping `skip`."""
+    out = (C.c_int32 * max(1, n))()
+    _check(load_library().g2s_test_rand_stream(seed, skip, n, out))
+    return [out[i] for i in range(n)]

@@ -166,7 +166,7 @@ typedef struct g2s_timing {
   uint64_t x_fill_lds;       /* expansions (A+B) of the gaps that completed in the LDS tier */
   uint64_t s_fill_lds;       /* states set (A+B) by those gaps */
   uint32_t lds_tier_gaps;    /* gaps that completed in the LDS tier */
-  uint32_t pad;
+  uint32_t lds_launches;     /* launches of g2s_fill_lds (2 when a second pass with larger LDS tables ran) */
 } g2s_timing;
 
 /* ---------------------------------------------------------------------------
@@ -225,6 +225,10 @@ int g2s_test_post_gap(const g2s_graph* g, const g2s_params* p, const g2s_gap* ga
                       const uint32_t* nodes, const int32_t* depths, const uint32_t* counts, int32_t c_count,
                       int32_t n_lengths, const int32_t* lengths, int32_t reached_j, int32_t final_d, uint32_t seed,
                       uint32_t skip, g2s_result* res, char* buf);
+
+/* TEST HOOK: values [skip, skip+n) of the session-style rand() stream after srand(seed)
+ * (the flat glibc TYPE_3 generator the tracebacks read), for comparison with libc. */
+int g2s_test_rand_stream(uint32_t seed, uint32_t skip, uint32_t n, int32_t* out);
 
 /* Number of usable gfx950 devices (0 when none / no driver). */
 int g2s_device_count(void);

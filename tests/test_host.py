@@ -142,6 +142,19 @@ def test_host_phase_d_matches_oracle_on_oracle_tables(product, oracle, seed):
     assert compared > 10
 
 
+def test_product_rand_stream_matches_libc(product):
+    """The flat glibc TYPE_3 stream the tracebacks read at precomputed offsets
+    (Gap2Seq.cpp:178,1440,1513 use libc rand()), incl. the buffer compaction path."""
+    libc = ctypes.CDLL("libc.so.6")
+    for seed, skip in ((1, 0), (42, 1000), (20240101, 5000000)):
+        libc.srand(seed)
+        for _ in range(skip):
+            libc.rand()
+        got = product.test_rand_stream(seed, skip, 3000)
+        assert got == [libc.rand() for _ in range(3000)]
+    assert product.test_rand_stream(1, 0, 3) == [1804289383, 846930886, 1681692777]
+
+
 def test_fill_path_fails_loudly_without_a_gpu(product):
     if product.G2S.device_count() > 0:
         pytest.skip("a GPU is present")
