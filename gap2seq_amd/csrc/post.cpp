@@ -136,8 +136,66 @@ void sub_analyze(const FillParams& p, const GapJob& job, const SubView& v, SubPr
   vm.init(n);
   int nverts = 2;
   vid.assign((size_t)n, -1);
+  uint32_t n_s = 0;
   for (uint32_t i = 0; i < n; i++)
-    if (st[i].flags & G2S_SUB_IN_S) vid[i] = vm.get_or_add(st[i].node >> 1, &nverts);
+    if (st[i].flags & G2S_SUB_IN_S) { vid[i] = vm.get_or_add(st[i].node >> 1, &nverts); n_s++; }
+
+  if ((uint32_t)nverts == n_s + 2) {
+    // ---- fast path: every k-mer occurs at exactly one depth of the S closure.  An edge goes
+    // from depth d-1 to depth d, so the subgraph is a DAG (a cycle would need a k-mer at two
+    // depths), vertices are the states themselves, nothing is contracted, no self loops, and
+    // ascending depth (reverse emission order) is a topological order.
+    static thread_local std::vector<int> outdeg;
+    outdeg.assign((size_t)n, 0);
+    int count = 0;
+    uint64_t edges = 0;
+    int src_out = 0, sink_in = 0;
+    for (uint32_t i = 0; i < n; i++) {
+      const SubState& s = st[i];
+      if (!(s.flags & G2S_SUB_IN_S)) continue;
+      if (s.flags & G2S_SUB_SINK) { sink_in++; edges++; count = sat_add(count, (int)s.cnt); }
+      if (s.flags & G2S_SUB_SOURCE) { src_out++; edges++; continue; }
+      for (int nt = 0; nt < 4; nt++)
+        if (s.pred[nt] >= 0) { outdeg[(size_t)s.pred[nt]]++; edges++; }
+    }
+    if (p.all_paths) out->count = count;
+    out->sub[0] = (uint64_t)nverts;
+    out->sub[1] = edges;
+    out->sub[2] = 0;
+    out->sub[3] = 0;
+    out->sub[4] = (uint64_t)nverts;
+    out->sub[5] = edges;
+    out->safe.assign((size_t)n, 0);
+    int bc = 1;
+    // source (vertex 1) comes first in topological order: in-degree 0
+    if (src_out >= 1) { if (src_out > 1) bc += src_out - 1; }
+    for (int64_t i = (int64_t)n - 1; i >= 0; i--) {
+      const SubState& s = st[i];
+      if (!(s.flags & G2S_SUB_IN_S)) continue;
+      int din = 0;
+      if (s.flags & G2S_SUB_SOURCE) din = 1;
+      else for (int nt = 0; nt < 4; nt++) din += s.pred[nt] >= 0;
+      const int dout = outdeg[(size_t)i] + ((s.flags & G2S_SUB_SINK) ? 1 : 0);
+      if (din >= 1 || dout >= 1) {
+        if (din > 1) bc -= din - 1;
+        out->safe[(size_t)i] = bc == 1;
+        if (dout > 1) bc += dout - 1;
+      }
+    }
+    // sink (vertex 0) is last
+    bool sink_safe = false;
+    if (sink_in >= 1) { if (sink_in > 1) bc -= sink_in - 1; sink_safe = bc == 1; }
+    for (uint32_t i = 0; i < n; i++) {  // traceback states outside the subgraph (Q5)
+      if (!(st[i].flags & G2S_SUB_IN_T) || (st[i].flags & G2S_SUB_IN_S)) continue;
+      const int vtx = vm.find(st[i].node >> 1);
+      if (vtx < 0) { out->safe[i] = sink_safe; continue; }
+      // its k-mer is in the subgraph at another depth: that vertex's value
+      for (uint32_t q = 0; q < n; q++)
+        if ((st[q].flags & G2S_SUB_IN_S) && vid[q] == vtx) { out->safe[i] = out->safe[q]; break; }
+    }
+    return;
+  }
+
   el.clear();
   el.reserve((size_t)n + 8);
   int count = 0;
