@@ -64,6 +64,9 @@ def main():
     ap.add_argument("--fuz", type=int, default=10)
     ap.add_argument("--dist-error", type=int, default=500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the barrier/timing reduction")
+    ap.add_argument("--share-device", action="store_true",
+                    help="testing only: every rank uses HIP device 0 (needs --backend gloo)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -73,8 +76,10 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist
+        if args.share_device:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
     from gap2seq_amd import lib as P
     from gap2seq_amd import shard
 

@@ -94,9 +94,40 @@ template <bool G>
 __device__ __forceinline__ uint32_t rs_load(const uint32_t* p) {
   return G ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
 }
+// LDS flavour: buckets of 4 consecutive slots read with one ds_read_b128.  With linear
+// probing one slot at a time the slowest of 64 lanes needed ~8 probes at load factor 0.5
+// (measured: 1.4 k cycles per insert round); a 4-slot bucket is almost never full, so
+// nearly every lane finishes with a single LDS read.
 template <bool G>
 __device__ uint32_t lrs_insert(uint32_t* tab, uint32_t mask, uint32_t v) {
   const uint32_t idx = v >> 1, bit = 1u << (v & 1u);
+  if (!G) {
+    const uint32_t bmask = mask >> 2;
+    uint32_t b = mix32(idx) & bmask;
+    for (uint32_t i = 0; i <= bmask; i++) {
+      uint32_t* slot = tab + b * 4u;
+      const uint4 c = *(const uint4*)slot;
+      const uint32_t cs[4] = {c.x, c.y, c.z, c.w};
+      int hit = -1, free_ = -1;
+#pragma unroll
+      for (int q = 3; q >= 0; q--) {
+        if (cs[q] != G2S_DEV_INVALID && (cs[q] >> 2) == idx) hit = q;
+        if (cs[q] == G2S_DEV_INVALID) free_ = q;
+      }
+      if (hit < 0 && free_ >= 0) {
+        const uint32_t prev = atomicCAS(&slot[free_], G2S_DEV_INVALID, (idx << 2) | bit);
+        if (prev == G2S_DEV_INVALID) return 1u;
+        if ((prev >> 2) == idx) hit = free_;
+        else continue;  // somebody else took the slot: look at this bucket again
+      }
+      if (hit >= 0) {
+        const uint32_t old = atomicOr(&slot[hit], bit);
+        return ((old & bit) ? 0u : 1u) | ((((old | bit) & 3u) == 3u) ? 2u : 0u);
+      }
+      b = (b + 1) & bmask;  // bucket full of other k-mers
+    }
+    return 4u;
+  }
   uint32_t h = mix32(idx) & mask;
   for (uint32_t i = 0; i <= mask; i++) {
     uint32_t cur = rs_load<G>(&tab[h]);
@@ -115,6 +146,21 @@ __device__ uint32_t lrs_insert(uint32_t* tab, uint32_t mask, uint32_t v) {
 template <bool G>
 __device__ bool lrs_has_kmer(const uint32_t* tab, uint32_t mask, uint32_t v) {
   const uint32_t idx = v >> 1;
+  if (!G) {
+    const uint32_t bmask = mask >> 2;
+    uint32_t b = mix32(idx) & bmask;
+    for (uint32_t i = 0; i <= bmask; i++) {
+      const uint4 c = *(const uint4*)(tab + b * 4u);
+      const uint32_t key = idx;
+      if ((c.x != G2S_DEV_INVALID && (c.x >> 2) == key) || (c.y != G2S_DEV_INVALID && (c.y >> 2) == key) ||
+          (c.z != G2S_DEV_INVALID && (c.z >> 2) == key) || (c.w != G2S_DEV_INVALID && (c.w >> 2) == key))
+        return true;
+      if (c.x == G2S_DEV_INVALID || c.y == G2S_DEV_INVALID || c.z == G2S_DEV_INVALID || c.w == G2S_DEV_INVALID)
+        return false;  // inserts fill the first bucket with room along the probe sequence
+      b = (b + 1) & bmask;
+    }
+    return false;
+  }
   uint32_t h = mix32(idx) & mask;
   for (uint32_t i = 0; i <= mask; i++) {
     const uint32_t cur = rs_load<G>(&tab[h]);
@@ -268,6 +314,30 @@ __device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ,
       }
       st_slowA++;
       xa += nb;
+      if (nb > 16) {
+        // wide border: one border node per lane, its whole 16 B record in one load (a single
+        // HBM round trip for the level), then the four predecessor slots in turn
+        const bool valid = (uint32_t)lane < nb;
+        uint4 rec = make_uint4(G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID);
+        if (valid) rec = *(const uint4*)(succ + (size_t)(fcur[lane] ^ 1u) * 4);
+#pragma unroll
+        for (uint32_t nt = 0; nt < 4; nt++) {
+          const uint32_t p = flip(nt == 0 ? rec.x : nt == 1 ? rec.y : nt == 2 ? rec.z : rec.w);
+          uint32_t isnew = 0;
+          if (p != G2S_DEV_INVALID) {
+            const uint32_t r = lrs_insert<RSG>(rs, rmask, p);
+            isnew = r & 1u;
+            if (r & 2u) flags |= G2S_DEV_Q7_A;
+            if (r & 4u) flags |= G2S_DEV_OVERFLOW_A;
+          }
+          const uint64_t m = __ballot(isnew);
+          if (isnew) {
+            const uint32_t off = nnew + (uint32_t)__popcll(m & lanes_below(lane));
+            if (off < LDS_F) fnxt[off] = p;
+          }
+          nnew += (uint32_t)__popcll(m);
+        }
+      } else
       for (uint32_t i0 = 0; i0 < nb * 4u; i0 += 64u) {
         const uint32_t i = i0 + (uint32_t)lane;
         const bool valid = i < nb * 4u;
@@ -478,23 +548,41 @@ __device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ,
           cnxt[off] = np;
         }
         nnew = (uint32_t)__popcll(m);
-      } else if (nb > 1) {
-        // Q7: both strands of one k-mer in this border (the reference keeps only one)
-        if (lane < (int)nb) {
-          const uint32_t mine = ncur[lane];
-          for (uint32_t e = 0; e < nb; e++) if (ncur[e] == (mine ^ 1u)) flags |= G2S_DEV_Q7_B;
+        for (int q = 0; q < 4; q++) {  // Q7: two successors that are each other's reverse complement
+          const uint32_t o = (uint32_t)__shfl((int)v, q);
+          const bool op = (m >> q) & 1ull;
+          if (pass && op && o == (v ^ 1u)) flags |= G2S_DEV_Q7_B;
         }
-        for (uint32_t i0 = 0; i0 < nb * 4u; i0 += 64u) {
-          const uint32_t i = i0 + (uint32_t)lane;
-          const bool valid = i < nb * 4u;
-          const uint32_t n = valid ? ncur[i >> 2] : 0u;
-          uint32_t np = valid ? ccur[i >> 2] : 0u;
-          if (np > G2S_DEV_MAX_PATHS) np = G2S_DEV_MAX_PATHS;
-          const uint32_t v = valid ? succ[(size_t)n * 4 + (i & 3u)] : G2S_DEV_INVALID;
+      } else if (nb > 1) {
+        // Per-level step with merging.  Narrow borders use 4 lanes per entry (one 16 B record
+        // = one coalesced 4-lane access); wide borders use one entry per lane with the whole
+        // record in one load, so a level costs one HBM round trip whatever its width.
+        const bool wide = nb > 16;
+        const uint32_t rounds = wide ? 4u : 1u;
+        uint32_t hh[4] = {0, 0, 0, 0}, vv[4];
+        uint32_t np = 0;
+        uint4 rec = make_uint4(G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID);
+        if (wide) {
+          if ((uint32_t)lane < nb) { rec = *(const uint4*)(succ + (size_t)ncur[lane] * 4); np = ccur[lane]; }
+        } else {
+          const uint32_t i = (uint32_t)lane;
+          if (i < nb * 4u) {
+            const uint32_t v1 = succ[(size_t)ncur[i >> 2] * 4 + (i & 3u)];
+            rec.x = v1;
+            np = ccur[i >> 2];
+          }
+        }
+        if (np > G2S_DEV_MAX_PATHS) np = G2S_DEV_MAX_PATHS;
+        // pass 1: claim (depth, node) in the merge table; stale entries of older levels count as free
+#pragma unroll
+        for (uint32_t q = 0; q < 4; q++) {
+          if (q >= rounds) break;
+          const uint32_t v = q == 0 ? rec.x : q == 1 ? rec.y : q == 2 ? rec.z : rec.w;
+          vv[q] = G2S_DEV_INVALID;
           const bool pass = v != G2S_DEV_INVALID && (unpruned || lrs_has_kmer<RSG>(rs, rmask, v));
-          // pass 1: claim (depth, node) in the merge table; stale entries of older levels count as free
           uint32_t h = 0, won = 0;
           if (pass) {
+            vv[q] = v;
             const uint64_t key = ((uint64_t)(uint32_t)d << 32) | v;
             h = mix32(v) & (LDS_LH - 1u);
             while (true) {
@@ -509,6 +597,7 @@ __device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ,
               if (old == c) { won = 1; break; }       // else somebody changed the slot: look again
             }
           }
+          hh[q] = h;
           const uint64_t m = __ballot(won);
           if (won) {
             const uint32_t off = nnew + (uint32_t)__popcll(m & lanes_below(lane));
@@ -516,18 +605,33 @@ __device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ,
             if (off < LDS_F) { nnxt[off] = v; cnxt[off] = 0; }
           }
           nnew += (uint32_t)__popcll(m);
-          lds_sync();
-          // pass 2: <=4 predecessors x <=MAX_PATHS each: the u32 sum cannot wrap (:1058-1060)
-          if (pass && nnew <= LDS_F) atomicAdd(&cnxt[lhslot[h]], np);
-          lds_sync();
-          if (nnew > LDS_F) break;
         }
+        lds_sync();
+        // pass 2: <=4 predecessors x <=MAX_PATHS each: the u32 sum cannot wrap (:1058-1060).
+        // Q7: is the other strand of my k-mer a state of this level too?
+        if (nnew <= LDS_F) {
+#pragma unroll
+          for (uint32_t q = 0; q < 4; q++) {
+            if (q >= rounds || vv[q] == G2S_DEV_INVALID) continue;
+            atomicAdd(&cnxt[lhslot[hh[q]]], np);
+            const uint32_t o = vv[q] ^ 1u;
+            uint32_t h = mix32(o) & (LDS_LH - 1u);
+            while (true) {
+              const uint64_t c = lh[h];
+              if ((uint32_t)(c >> 32) != (uint32_t)d) break;
+              if ((uint32_t)c == o) { flags |= G2S_DEV_Q7_B; break; }
+              h = (h + 1) & (LDS_LH - 1u);
+            }
+          }
+        }
+        lds_sync();
       }
       if (nnew > LDS_F) { overflow = true; break; }
       lds_sync();
       if (d <= gd.lmf) {  // next left-flank seed, row value ASSIGNED 1 (:1082-1105)
         const uint32_t s = lseeds[d];
         if (s != G2S_DEV_INVALID) {
+          if (__ballot(lane < (int)nnew && nnxt[lane] == (s ^ 1u))) flags |= G2S_DEV_Q7_B;
           const uint64_t m = __ballot(lane < (int)nnew && nnxt[lane] == s);
           if (m) {
             if (lane == 0) cnxt[__builtin_ctzll(m)] = 1;

@@ -272,6 +272,51 @@ def test_single_gap_mode(product, oracle):
     pg.free()
 
 
+def test_bench_workload_c2_vs_oracle(product, oracle):
+    """The exact bench.py workload (BASELINE config 2: 3 Mbp genome V3 = repeats + bubbles,
+    k=31, 500 gaps of 200-1000 bp, -fuz 10 -dist-error 500): every gap bit-exact against
+    the oracle, FASTA and log of the scaffold run identical, device work counters equal."""
+    reads = product.G2S.synth_genome(3000000, 3, 20240101)
+    seqs = [ln for ln in reads.splitlines() if not ln.startswith(">")]
+    scaf = product.G2S.synth_gaps(reads, 31, 10, 500, 200, 1000, 20240103)
+    gaps = _parse_scaffolds(scaf)
+    c, f, tm, xb, sb = _check_batch(product, oracle, seqs, 31, gaps, 500, seed=1)
+    assert (c, f) == (500, 500)
+    assert (tm.xB, tm.sB) == (xb, sb)
+    assert tm.lds_tier_gaps == 500 and tm.retried_gaps == 0
+    og = oracle.OracleGraph(seqs, 31, 1)
+    pg = product.Graph.from_seqs(seqs, 31, 1)
+    ofa, olog, sm = oracle.execute_scaffolds(og, scaf, 31, solid=1, d_err=500, max_fuz=10, randseed=1)
+    sess = product.Session(pg, 0, d_err=500, randseed=1)
+    fa, lg, ngaps, nfilled = sess.execute_scaffolds(scaf, 31, solid=1, max_fuz=10)
+    sess.destroy()
+    assert fa == ofa and lg == olog and (ngaps, nfilled) == (500, 500)
+    assert any(ch.islower() for ch in fa.replace(">", "")), "expected some unsafe (lower-case) bases in V3"
+    og.free()
+    pg.free()
+
+
+def test_multi_rank_bench_path(product, tmp_path):
+    """bench.py under torch.distributed.run with 2 ranks (gloo, both on device 0): the
+    one-process-per-GPU code path, rank-specific gap sets, max/sum reduction, one JSON line."""
+    import socket
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+           "--warmup", "1", "--genome", "300000", "--gaps", "100", "--backend", "gloo", "--share-device"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["cpu_baseline"] is None and out["roofline"]["kernel"] == "g2s_fill_lds"
+
+
 def test_full_size_round_trip_c3(product):
     """BASELINE config 3 size (3 Mbp DBG, 10 000 gaps, k=31, -fuz 10, -dist-error 500) on
     the repeat-free V0 genome: every gap has exactly one path, so cut -> fill must give
