@@ -16,6 +16,10 @@
 #define G2S_DEV_OVERFLOW_A 0x4u  /* right-set tables too small for this gap        */
 #define G2S_DEV_OVERFLOW_B 0x8u  /* state tables too small for this gap            */
 #define G2S_DEV_Q7_D 0x10u       /* both strands of a k-mer at one level of the backward sweep */
+/* why a gap left the LDS tier (diagnostics, set together with OVERFLOW_B) */
+#define G2S_DEV_WHY_FRONTIER 0x100u /* a DP level wider than the LDS frontier buffers */
+#define G2S_DEV_WHY_HITS 0x200u     /* more target hits than the LDS list holds       */
+#define G2S_DEV_WHY_LOG 0x400u      /* state log full                                 */
 
 struct GapDev {
   int32_t g;           // gap_len

@@ -477,7 +477,7 @@ __device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ,
             }
           }
           lds_sync();
-          if (misc[0] > LDS_TH) { overflow = true; break; }
+          if (misc[0] > LDS_TH) { overflow = true; flags |= G2S_DEV_WHY_HITS; break; }
           // phase C for the levels of the run, one lane (r == 0) per level (:1107-1159)
           if (!found) {
             const int dl = d + (int)i;
@@ -626,7 +626,7 @@ __device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ,
         }
         lds_sync();
       }
-      if (nnew > LDS_F) { overflow = true; break; }
+      if (nnew > LDS_F) { overflow = true; flags |= G2S_DEV_WHY_FRONTIER; break; }
       lds_sync();
       if (d <= gd.lmf) {  // next left-flank seed, row value ASSIGNED 1 (:1082-1105)
         const uint32_t s = lseeds[d];
@@ -638,12 +638,12 @@ __device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ,
           } else if (nnew < LDS_F) {
             if (lane == 0) { nnxt[nnew] = s; cnxt[nnew] = 1; }
             nnew++;
-          } else { overflow = true; break; }
+          } else { overflow = true; flags |= G2S_DEV_WHY_FRONTIER; break; }
           lds_sync();
         }
       }
       // append the level to the state log (fire and forget) and note target k-mers
-      if (nlog + nnew > cap) { overflow = true; break; }
+      if (nlog + nnew > cap) { overflow = true; flags |= G2S_DEV_WHY_LOG; break; }
       if (lane < (int)nnew) {
         const uint32_t node = nnxt[lane];
         uint32_t c = cnxt[lane];
@@ -662,7 +662,7 @@ __device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ,
       if (lane == 0) lvl[d + 1] = nlog;
       lvl_written = d + 1;
       lds_sync();
-      if (misc[0] > LDS_TH) { overflow = true; break; }
+      if (misc[0] > LDS_TH) { overflow = true; flags |= G2S_DEV_WHY_HITS; break; }
       cur ^= 1u;
       nb = nnew;
 

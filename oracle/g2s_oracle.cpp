@@ -473,6 +473,7 @@ static int fill_gap_t(const OGraph<KT>& G, GlibcRand& rng, const std::string& km
   long long mymemuse = mm.bytes;
   while (currentD < right_half && mymemuse < max_mem) {
     currentD++;
+    info->max_border_a = std::max(info->max_border_a, (int)border.items.size());
     for (size_t bi = 0; bi < border.items.size(); bi++) {
       mymemuse = mm.bytes;
       if (mymemuse >= max_mem) break;
@@ -526,6 +527,7 @@ static int fill_gap_t(const OGraph<KT>& G, GlibcRand& rng, const std::string& km
   const int prune_from = gap_len / 2 + gap_err / 2 + lmf;  // :1050 (Q1: two int divisions)
 
   while (currentD <= right_half + left_half && mymemuse < max_mem) {
+    info->max_border_b = std::max(info->max_border_b, (int)border.items.size());
     for (size_t bi = 0; bi < border.items.size(); bi++) {
       mymemuse = mm.bytes;
       if (mymemuse >= max_mem) break;

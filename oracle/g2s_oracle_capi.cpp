@@ -19,6 +19,7 @@ struct orc_info {
   uint64_t ctr[6];      // xA sA xB sB xD sD
   int32_t phaseC_count, n_lengths, lengths[2], reached_fuz, draws, q7, backtrace_failed, mem_exceeded;
   int32_t final_d, pad;
+  int32_t max_border_a, max_border_b;
 };
 
 struct orc_params {
@@ -66,6 +67,7 @@ static void pack_info(const FillInfo& fi, orc_info* o) {
   o->reached_fuz = fi.reached_fuz; o->draws = fi.draws; o->q7 = fi.q7;
   o->backtrace_failed = fi.backtrace_failed; o->mem_exceeded = fi.mem_exceeded;
   o->final_d = fi.final_d; o->pad = 0;
+  o->max_border_a = fi.max_border_a; o->max_border_b = fi.max_border_b;
 }
 
 // One fill_gap call.  `fill` must hold gap_len + k + gap_err + lmf + rmf + 3 bytes (Gap2Seq.cpp:374).

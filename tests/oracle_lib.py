@@ -14,7 +14,8 @@ class orc_info(C.Structure):
     _fields_ = [("sub", C.c_uint64 * 6), ("ctr", C.c_uint64 * 6), ("phaseC_count", C.c_int32),
                 ("n_lengths", C.c_int32), ("lengths", C.c_int32 * 2), ("reached_fuz", C.c_int32),
                 ("draws", C.c_int32), ("q7", C.c_int32), ("backtrace_failed", C.c_int32),
-                ("mem_exceeded", C.c_int32), ("final_d", C.c_int32), ("pad", C.c_int32)]
+                ("mem_exceeded", C.c_int32), ("final_d", C.c_int32), ("pad", C.c_int32),
+                ("max_border_a", C.c_int32), ("max_border_b", C.c_int32)]
 
 
 class orc_params(C.Structure):
