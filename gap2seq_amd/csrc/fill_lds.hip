@@ -34,7 +34,6 @@
 
 #define LDS_F 64u         /* frontier capacity                 */
 #define LDS_LH (2u * LDS_F)
-#define LDS_TH 128u       /* target hits kept for phase C      */
 #define LDS_TG 32u        /* right_max_fuz + 1 must fit        */
 #define LDS_W 256u        /* log / level-offset window (D1)    */
 
@@ -182,7 +181,9 @@ __device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ,
                                               const uint32_t* __restrict__ gap_ids,
                                               const uint32_t* __restrict__ flank_nodes, uint64_t* log_all,
                                               uint32_t* lvl_all, GapOut* outs, uint32_t num_oriented,
-                                              uint32_t* rs_global) {
+                                              uint32_t* rs_global, const uint32_t F) {
+  const uint32_t LH = 2u * F;  // merge table slots (F = frontier capacity of this launch, a power of two)
+  const uint32_t TH = 2u * F;  // target hits kept for phase C (128 in the first pass, 2048 later)
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   const uint32_t gi = __builtin_amdgcn_readfirstlane(gap_ids[blockIdx.x]);
   const GapDev gd = gaps[gi];
@@ -190,15 +191,15 @@ __device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ,
   GapOut* go = &outs[gi];
 
   uint32_t* fa = lds;                             // phase A frontiers [2][F]
-  uint32_t* fn = fa + 2 * LDS_F;                  // phase B frontier nodes [2][F]
-  uint32_t* fc = fn + 2 * LDS_F;                  // phase B frontier counts [2][F]
-  uint64_t* lh = (uint64_t*)(fc + 2 * LDS_F);     // level merge table keys
-  uint32_t* lhslot = (uint32_t*)(lh + LDS_LH);
-  uint32_t* tgt = lhslot + LDS_LH;
+  uint32_t* fn = fa + 2 * F;                  // phase B frontier nodes [2][F]
+  uint32_t* fc = fn + 2 * F;                  // phase B frontier counts [2][F]
+  uint64_t* lh = (uint64_t*)(fc + 2 * F);     // level merge table keys
+  uint32_t* lhslot = (uint32_t*)(lh + LH);
+  uint32_t* tgt = lhslot + LH;
   uint32_t* th_j = tgt + LDS_TG;
-  uint32_t* th_d = th_j + LDS_TH;
-  uint32_t* th_c = th_d + LDS_TH;
-  uint32_t* misc = th_c + LDS_TH;                 // [0] = number of target hits
+  uint32_t* th_d = th_j + TH;
+  uint32_t* th_c = th_d + TH;
+  uint32_t* misc = th_c + TH;                 // [0] = number of target hits
   uint32_t* rs = RSG ? rs_global + gd.rs_off : misc + 4;  // right set: HBM (host pre-filled 0xFF) or LDS
 
   const uint32_t rs_cap = gd.rs_mask + 1u;  // LDS capacity chosen by the host for this gap (<= rs_cap_max)
@@ -211,7 +212,7 @@ __device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ,
   const uint32_t cap = gd.slog_cap;
 
   if (!RSG) for (uint32_t i = (uint32_t)lane; i < rs_cap; i += 64u) rs[i] = G2S_DEV_INVALID;
-  for (uint32_t i = (uint32_t)lane; i < LDS_LH; i += 64u) lh[i] = G2S_DEV_EMPTY64;
+  for (uint32_t i = (uint32_t)lane; i < LH; i += 64u) lh[i] = G2S_DEV_EMPTY64;
   if (lane <= gd.rmf && lane < (int)LDS_TG) tgt[lane] = targets[lane];
   if (lane == 0) misc[0] = 0;
   uint64_t tbloom = 0;  // which hash bits any target k-mer sets
@@ -238,8 +239,8 @@ __device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ,
     }
     lds_sync();
     for (int d = 1; d <= gd.right_half && !overflow; d++) {
-      uint32_t* fcur = fa + cur * LDS_F;
-      uint32_t* fnxt = fa + (cur ^ 1u) * LDS_F;
+      uint32_t* fcur = fa + cur * F;
+      uint32_t* fnxt = fa + (cur ^ 1u) * F;
       uint32_t nnew = 0;
       // ---- bulk step: every border node (<= 16) sits inside a unitig, where the only
       // predecessor of id v is v-2 (even orientation) or v+2 (odd), see dbg.hpp.  Lanes are
@@ -317,25 +318,27 @@ __device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ,
       if (nb > 16) {
         // wide border: one border node per lane, its whole 16 B record in one load (a single
         // HBM round trip for the level), then the four predecessor slots in turn
-        const bool valid = (uint32_t)lane < nb;
-        uint4 rec = make_uint4(G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID);
-        if (valid) rec = *(const uint4*)(succ + (size_t)(fcur[lane] ^ 1u) * 4);
+        for (uint32_t e0 = 0; e0 < nb; e0 += 64u) {
+          const bool valid = e0 + (uint32_t)lane < nb;
+          uint4 rec = make_uint4(G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID);
+          if (valid) rec = *(const uint4*)(succ + (size_t)(fcur[e0 + (uint32_t)lane] ^ 1u) * 4);
 #pragma unroll
-        for (uint32_t nt = 0; nt < 4; nt++) {
-          const uint32_t p = flip(nt == 0 ? rec.x : nt == 1 ? rec.y : nt == 2 ? rec.z : rec.w);
-          uint32_t isnew = 0;
-          if (p != G2S_DEV_INVALID) {
-            const uint32_t r = lrs_insert<RSG>(rs, rmask, p);
-            isnew = r & 1u;
-            if (r & 2u) flags |= G2S_DEV_Q7_A;
-            if (r & 4u) flags |= G2S_DEV_OVERFLOW_A;
+          for (uint32_t nt = 0; nt < 4; nt++) {
+            const uint32_t p = flip(nt == 0 ? rec.x : nt == 1 ? rec.y : nt == 2 ? rec.z : rec.w);
+            uint32_t isnew = 0;
+            if (p != G2S_DEV_INVALID) {
+              const uint32_t r = lrs_insert<RSG>(rs, rmask, p);
+              isnew = r & 1u;
+              if (r & 2u) flags |= G2S_DEV_Q7_A;
+              if (r & 4u) flags |= G2S_DEV_OVERFLOW_A;
+            }
+            const uint64_t m = __ballot(isnew);
+            if (isnew) {
+              const uint32_t off = nnew + (uint32_t)__popcll(m & lanes_below(lane));
+              if (off < F) fnxt[off] = p;
+            }
+            nnew += (uint32_t)__popcll(m);
           }
-          const uint64_t m = __ballot(isnew);
-          if (isnew) {
-            const uint32_t off = nnew + (uint32_t)__popcll(m & lanes_below(lane));
-            if (off < LDS_F) fnxt[off] = p;
-          }
-          nnew += (uint32_t)__popcll(m);
         }
       } else
       for (uint32_t i0 = 0; i0 < nb * 4u; i0 += 64u) {
@@ -355,12 +358,13 @@ __device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ,
         const uint64_t m = __ballot(isnew);
         if (isnew) {
           const uint32_t off = nnew + (uint32_t)__popcll(m & lanes_below(lane));
-          if (off < LDS_F) fnxt[off] = p;
+          if (off < F) fnxt[off] = p;
         }
         nnew += (uint32_t)__popcll(m);
       }
       nvis += nnew;
-      if (nnew > LDS_F || nvis > rs_cap / 4u * 3u) { overflow = true; break; }
+      if (nnew > F) { overflow = true; flags |= G2S_DEV_WHY_FRONTIER; break; }
+      if (nvis > rs_cap / 4u * 3u) { overflow = true; break; }
       lds_sync();
       if (d <= gd.rmf) {  // next right-flank seed (:953-976)
         const uint32_t s = rseeds[d];
@@ -370,7 +374,7 @@ __device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ,
           r = __shfl(r, 0);
           if (r & 2) flags |= G2S_DEV_Q7_A;
           if (r & 1) {
-            if (nnew < LDS_F) { if (lane == 0) fnxt[nnew] = s; } else overflow = true;
+            if (nnew < F) { if (lane == 0) fnxt[nnew] = s; } else overflow = true;
             nnew++;
             nvis++;
           }
@@ -410,10 +414,10 @@ __device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ,
     int d = 1, lvl_written = 1;  // lvl[0..lvl_written] hold valid offsets
     uint32_t bulk_epoch = 0x80000000u;  // tags merge-table entries of bulk steps; never equals a depth
     for (; d <= gd.D; d++) {
-      uint32_t* ncur = fn + cur * LDS_F;
-      uint32_t* ccur = fc + cur * LDS_F;
-      uint32_t* nnxt = fn + (cur ^ 1u) * LDS_F;
-      uint32_t* cnxt = fc + (cur ^ 1u) * LDS_F;
+      uint32_t* ncur = fn + cur * F;
+      uint32_t* ccur = fc + cur * F;
+      uint32_t* nnxt = fn + (cur ^ 1u) * F;
+      uint32_t* cnxt = fc + (cur ^ 1u) * F;
       const bool unpruned = d < gd.prune_from;  // :1050 first disjunct
       uint32_t nnew = 0;
       // ---- bulk step: every border state (<= 16 of them) sits inside a unitig, where the
@@ -448,7 +452,7 @@ __device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ,
         }
         uint32_t lrun = leading_levels(ok, lg);
         if (lrun > L) lrun = L;
-        if (lrun >= (lg == 6u ? 1u : 2u) && nlog + lrun * R <= cap && misc[0] + 64u <= LDS_TH) {
+        if (lrun >= (lg == 6u ? 1u : 2u) && nlog + lrun * R <= cap && misc[0] + 64u <= TH) {
           const bool act = mine && i < lrun;
           if (act && R > 1) {
             // Q7: the other strand of my k-mer on another run at this level.  All states of the
@@ -456,12 +460,12 @@ __device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ,
             // only collide with the other strand.  (Index truncated above 2^26 k-mers: the flag
             // is conservative, a false positive only narrows the bit-exact claim.)
             const uint64_t key = ((uint64_t)bulk_epoch << 32) | (uint32_t)(((v >> 1) << 6) | i);
-            uint32_t h = mix32((uint32_t)key) & (LDS_LH - 1u);
+            uint32_t h = mix32((uint32_t)key) & (LH - 1u);
             while (true) {
               const uint64_t c = lh[h];
               if ((uint32_t)(c >> 32) == bulk_epoch) {
                 if (c == key) { flags |= G2S_DEV_Q7_B; break; }
-                h = (h + 1) & (LDS_LH - 1u);
+                h = (h + 1) & (LH - 1u);
                 continue;
               }
               if (atomicCAS((unsigned long long*)&lh[h], (unsigned long long)c, (unsigned long long)key) == c) break;
@@ -472,12 +476,12 @@ __device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ,
             for (int j = 0; j <= gd.rmf; j++) {
               if (tgt[j] == v) {
                 const uint32_t idx = atomicAdd(&misc[0], 1u);
-                if (idx < LDS_TH) { th_j[idx] = (uint32_t)j; th_d[idx] = (uint32_t)d + i; th_c[idx] = np; }
+                if (idx < TH) { th_j[idx] = (uint32_t)j; th_d[idx] = (uint32_t)d + i; th_c[idx] = np; }
               }
             }
           }
           lds_sync();
-          if (misc[0] > LDS_TH) { overflow = true; flags |= G2S_DEV_WHY_HITS; break; }
+          if (misc[0] > TH) { overflow = true; flags |= G2S_DEV_WHY_HITS; break; }
           // phase C for the levels of the run, one lane (r == 0) per level (:1107-1159)
           if (!found) {
             const int dl = d + (int)i;
@@ -485,7 +489,7 @@ __device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ,
             uint32_t c1 = 0, c2 = 0;
             if (r == 0 && i < lrun && dl >= gd.g + gd.lmf + gd.rmf) {
               const int err = dl - gd.g - (gd.lmf + gd.rmf);
-              const uint32_t nth = min(misc[0], LDS_TH);
+              const uint32_t nth = min(misc[0], TH);
               for (uint32_t t = 0; t < nth; t++) {
                 const int tj = (int)th_j[t], td = (int)th_d[t];
                 const int l1 = gd.g + gd.lmf + tj + err, l2 = gd.g + gd.lmf + tj - err;
@@ -559,83 +563,90 @@ __device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ,
         // record in one load, so a level costs one HBM round trip whatever its width.
         const bool wide = nb > 16;
         const uint32_t rounds = wide ? 4u : 1u;
-        uint32_t hh[4] = {0, 0, 0, 0}, vv[4];
-        uint32_t np = 0;
-        uint4 rec = make_uint4(G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID);
-        if (wide) {
-          if ((uint32_t)lane < nb) { rec = *(const uint4*)(succ + (size_t)ncur[lane] * 4); np = ccur[lane]; }
-        } else {
-          const uint32_t i = (uint32_t)lane;
-          if (i < nb * 4u) {
-            const uint32_t v1 = succ[(size_t)ncur[i >> 2] * 4 + (i & 3u)];
-            rec.x = v1;
-            np = ccur[i >> 2];
-          }
-        }
-        if (np > G2S_DEV_MAX_PATHS) np = G2S_DEV_MAX_PATHS;
-        // pass 1: claim (depth, node) in the merge table; stale entries of older levels count as free
-#pragma unroll
-        for (uint32_t q = 0; q < 4; q++) {
-          if (q >= rounds) break;
-          const uint32_t v = q == 0 ? rec.x : q == 1 ? rec.y : q == 2 ? rec.z : rec.w;
-          vv[q] = G2S_DEV_INVALID;
-          const bool pass = v != G2S_DEV_INVALID && (unpruned || lrs_has_kmer<RSG>(rs, rmask, v));
-          uint32_t h = 0, won = 0;
-          if (pass) {
-            vv[q] = v;
-            const uint64_t key = ((uint64_t)(uint32_t)d << 32) | v;
-            h = mix32(v) & (LDS_LH - 1u);
-            while (true) {
-              const uint64_t c = lh[h];
-              if ((uint32_t)(c >> 32) == (uint32_t)d) {
-                if ((uint32_t)c == v) break;          // already claimed at this level
-                h = (h + 1) & (LDS_LH - 1u);          // other node of this level: probe on
-                continue;
-              }
-              const unsigned long long old =
-                  atomicCAS((unsigned long long*)&lh[h], (unsigned long long)c, (unsigned long long)key);
-              if (old == c) { won = 1; break; }       // else somebody changed the slot: look again
+        for (uint32_t e0 = 0; e0 < (wide ? nb : 1u); e0 += 64u) {  // chunks of 64 border entries (wide) / one pass
+          uint32_t hh[4] = {0, 0, 0, 0}, vv[4];
+          uint32_t np = 0;
+          uint4 rec = make_uint4(G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID);
+          if (wide) {
+            const uint32_t e = e0 + (uint32_t)lane;
+            if (e < nb) { rec = *(const uint4*)(succ + (size_t)ncur[e] * 4); np = ccur[e]; }
+          } else {
+            const uint32_t i = (uint32_t)lane;
+            if (i < nb * 4u) {
+              rec.x = succ[(size_t)ncur[i >> 2] * 4 + (i & 3u)];
+              np = ccur[i >> 2];
             }
           }
-          hh[q] = h;
-          const uint64_t m = __ballot(won);
-          if (won) {
-            const uint32_t off = nnew + (uint32_t)__popcll(m & lanes_below(lane));
-            lhslot[h] = off;
-            if (off < LDS_F) { nnxt[off] = v; cnxt[off] = 0; }
+          if (np > G2S_DEV_MAX_PATHS) np = G2S_DEV_MAX_PATHS;
+          // pass 1: claim (depth, node) in the merge table; stale entries of older levels count as free
+#pragma unroll
+          for (uint32_t q = 0; q < 4; q++) {
+            if (q >= rounds) break;
+            const uint32_t v = q == 0 ? rec.x : q == 1 ? rec.y : q == 2 ? rec.z : rec.w;
+            vv[q] = G2S_DEV_INVALID;
+            const bool pass = v != G2S_DEV_INVALID && (unpruned || lrs_has_kmer<RSG>(rs, rmask, v));
+            uint32_t h = 0, won = 0;
+            if (pass) {
+              vv[q] = v;
+              const uint64_t key = ((uint64_t)(uint32_t)d << 32) | v;
+              h = mix32(v) & (LH - 1u);
+              while (true) {
+                const uint64_t c = lh[h];
+                if ((uint32_t)(c >> 32) == (uint32_t)d) {
+                  if ((uint32_t)c == v) break;          // already claimed at this level
+                  h = (h + 1) & (LH - 1u);              // other node of this level: probe on
+                  continue;
+                }
+                const unsigned long long old =
+                    atomicCAS((unsigned long long*)&lh[h], (unsigned long long)c, (unsigned long long)key);
+                if (old == c) { won = 1; break; }       // else somebody changed the slot: look again
+              }
+            }
+            hh[q] = h;
+            const uint64_t m = __ballot(won);
+            if (won) {
+              const uint32_t off = nnew + (uint32_t)__popcll(m & lanes_below(lane));
+              lhslot[h] = off < F ? off : 0u;
+              if (off < F) { nnxt[off] = v; cnxt[off] = 0; }
+            }
+            nnew += (uint32_t)__popcll(m);
+            if (nnew > F) break;  // keeps the merge table (2F slots) from filling up: at most F + 64 claims
           }
-          nnew += (uint32_t)__popcll(m);
-        }
-        lds_sync();
-        // pass 2: <=4 predecessors x <=MAX_PATHS each: the u32 sum cannot wrap (:1058-1060).
-        // Q7: is the other strand of my k-mer a state of this level too?
-        if (nnew <= LDS_F) {
+          lds_sync();
+          if (nnew > F) break;
+          // pass 2: <=4 predecessors x <=MAX_PATHS each: the u32 sum cannot wrap (:1058-1060).
+          // Q7: is the other strand of my k-mer a state of this level too?
 #pragma unroll
           for (uint32_t q = 0; q < 4; q++) {
             if (q >= rounds || vv[q] == G2S_DEV_INVALID) continue;
             atomicAdd(&cnxt[lhslot[hh[q]]], np);
             const uint32_t o = vv[q] ^ 1u;
-            uint32_t h = mix32(o) & (LDS_LH - 1u);
+            uint32_t h = mix32(o) & (LH - 1u);
             while (true) {
               const uint64_t c = lh[h];
               if ((uint32_t)(c >> 32) != (uint32_t)d) break;
               if ((uint32_t)c == o) { flags |= G2S_DEV_Q7_B; break; }
-              h = (h + 1) & (LDS_LH - 1u);
+              h = (h + 1) & (LH - 1u);
             }
           }
+          lds_sync();
         }
-        lds_sync();
       }
-      if (nnew > LDS_F) { overflow = true; flags |= G2S_DEV_WHY_FRONTIER; break; }
+      if (nnew > F) { overflow = true; flags |= G2S_DEV_WHY_FRONTIER; break; }
       lds_sync();
       if (d <= gd.lmf) {  // next left-flank seed, row value ASSIGNED 1 (:1082-1105)
         const uint32_t s = lseeds[d];
         if (s != G2S_DEV_INVALID) {
-          if (__ballot(lane < (int)nnew && nnxt[lane] == (s ^ 1u))) flags |= G2S_DEV_Q7_B;
-          const uint64_t m = __ballot(lane < (int)nnew && nnxt[lane] == s);
-          if (m) {
-            if (lane == 0) cnxt[__builtin_ctzll(m)] = 1;
-          } else if (nnew < LDS_F) {
+          int at = -1;
+          for (uint32_t e0 = 0; e0 < nnew; e0 += 64u) {
+            const uint32_t e = e0 + (uint32_t)lane;
+            if (__ballot(e < nnew && nnxt[e] == (s ^ 1u))) flags |= G2S_DEV_Q7_B;
+            const uint64_t m = __ballot(e < nnew && nnxt[e] == s);
+            if (m && at < 0) at = (int)e0 + __builtin_ctzll(m);
+          }
+          if (at >= 0) {
+            if (lane == 0) cnxt[at] = 1;
+          } else if (nnew < F) {
             if (lane == 0) { nnxt[nnew] = s; cnxt[nnew] = 1; }
             nnew++;
           } else { overflow = true; flags |= G2S_DEV_WHY_FRONTIER; break; }
@@ -644,16 +655,16 @@ __device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ,
       }
       // append the level to the state log (fire and forget) and note target k-mers
       if (nlog + nnew > cap) { overflow = true; flags |= G2S_DEV_WHY_LOG; break; }
-      if (lane < (int)nnew) {
-        const uint32_t node = nnxt[lane];
-        uint32_t c = cnxt[lane];
+      for (uint32_t e = (uint32_t)lane; e < nnew; e += 64u) {
+        const uint32_t node = nnxt[e];
+        uint32_t c = cnxt[e];
         if (c > G2S_DEV_MAX_PATHS) c = G2S_DEV_MAX_PATHS;
-        log[nlog + (uint32_t)lane] = ((uint64_t)node << 32) | c;
+        log[nlog + e] = ((uint64_t)node << 32) | c;
         if ((tbloom >> (mix32(node) & 63u)) & 1ull) {
           for (int j = 0; j <= gd.rmf; j++) {
             if (tgt[j] == node) {
               const uint32_t idx = atomicAdd(&misc[0], 1u);
-              if (idx < LDS_TH) { th_j[idx] = (uint32_t)j; th_d[idx] = (uint32_t)d; th_c[idx] = c; }
+              if (idx < TH) { th_j[idx] = (uint32_t)j; th_d[idx] = (uint32_t)d; th_c[idx] = c; }
             }
           }
         }
@@ -662,7 +673,7 @@ __device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ,
       if (lane == 0) lvl[d + 1] = nlog;
       lvl_written = d + 1;
       lds_sync();
-      if (misc[0] > LDS_TH) { overflow = true; flags |= G2S_DEV_WHY_HITS; break; }
+      if (misc[0] > TH) { overflow = true; flags |= G2S_DEV_WHY_HITS; break; }
       cur ^= 1u;
       nb = nnew;
 
@@ -736,8 +747,9 @@ __global__ __launch_bounds__(64) void g2s_fill_lds(const uint32_t* __restrict__ 
                                                     const GapDev* __restrict__ gaps,
                                                     const uint32_t* __restrict__ gap_ids,
                                                     const uint32_t* __restrict__ flank_nodes, uint64_t* log_all,
-                                                    uint32_t* lvl_all, GapOut* outs, uint32_t num_oriented) {
-  fill_lds_body<false>(succ, gaps, gap_ids, flank_nodes, log_all, lvl_all, outs, num_oriented, nullptr);
+                                                    uint32_t* lvl_all, GapOut* outs, uint32_t num_oriented,
+                                                    uint32_t fcap) {
+  fill_lds_body<false>(succ, gaps, gap_ids, flank_nodes, log_all, lvl_all, outs, num_oriented, nullptr, fcap);
 }
 // Same kernel with the right set in HBM: for gaps whose right set outgrows the LDS (deep
 // DP, -dist-error in the thousands); everything else of the gap stays in LDS.
@@ -746,15 +758,15 @@ __global__ __launch_bounds__(64) void g2s_fill_lds_rsg(const uint32_t* __restric
                                                         const uint32_t* __restrict__ gap_ids,
                                                         const uint32_t* __restrict__ flank_nodes, uint64_t* log_all,
                                                         uint32_t* lvl_all, GapOut* outs, uint32_t num_oriented,
-                                                        uint32_t* rs_global) {
-  fill_lds_body<true>(succ, gaps, gap_ids, flank_nodes, log_all, lvl_all, outs, num_oriented, rs_global);
+                                                        uint32_t* rs_global, uint32_t fcap) {
+  fill_lds_body<true>(succ, gaps, gap_ids, flank_nodes, log_all, lvl_all, outs, num_oriented, rs_global, fcap);
 }
 
 // ============================================================================
 // Phase D1 from the level-ordered state log, LDS tier (Gap2Seq.cpp:1169-1312)
 // plus the traceback's closure.  Walks the log backwards, one level per step; the
 // level's entries sit in lane registers, the border of the level above in LDS.
-// dynamic LDS: [wl W+1][we_node W][we_cnt W][bn F][be F][bf F][cfl F][cem F][lm 4F]
+// dynamic LDS: [chk 2F x u64][chs 2F][wl W+1][we_node W][we_cnt W][border 2x3F][cfl F][cem F][lm 4F]
 // ============================================================================
 __global__ __launch_bounds__(64) void g2s_extract_lds(const uint32_t* __restrict__ succ,
                                                        const GapDev* __restrict__ gaps,
@@ -763,7 +775,9 @@ __global__ __launch_bounds__(64) void g2s_extract_lds(const uint32_t* __restrict
                                                        const uint64_t* __restrict__ log_all,
                                                        const uint32_t* __restrict__ lvl_all, SubState* sub_scratch,
                                                        SubState* sub_out, unsigned long long* out_counter,
-                                                       GapOut* outs, int skip_confident, uint32_t num_oriented) {
+                                                       GapOut* outs, int skip_confident, uint32_t num_oriented,
+                                                       const uint32_t F) {
+  const uint32_t W = F > 256u ? F : 256u;  // log / level-offset window: holds at least one whole level
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   const uint32_t gi = __builtin_amdgcn_readfirstlane(gap_ids[blockIdx.x]);
   const GapDev gd = gaps[gi];
@@ -773,15 +787,17 @@ __global__ __launch_bounds__(64) void g2s_extract_lds(const uint32_t* __restrict
   const int c_count = go->c_count, n_len = go->n_len;
   if ((gflags & (G2S_DEV_OVERFLOW_A | G2S_DEV_OVERFLOW_B)) || !(c_count > 0 && n_len > 0)) return;  // :1169
 
-  uint32_t* wl = lds;                            // level offsets window [W+1]
-  uint32_t* wen = wl + (LDS_W + 1u);             // log window: nodes
-  uint32_t* wec = wen + LDS_W;                   // log window: counts
-  uint32_t* bn = wec + LDS_W;                    // border (depth d2+1): node, emit index, flags
-  uint32_t* be = bn + LDS_F;
-  uint32_t* bf = be + LDS_F;
-  uint32_t* cfl = bf + LDS_F;                    // candidates (depth d2): accumulated flags, emit index
-  uint32_t* cem = cfl + LDS_F;
-  uint32_t* lm = cem + LDS_F;                    // match of each (border entry, nt) among the candidates
+  uint64_t* chk = (uint64_t*)lds;                // candidate hash keys (tag << 32 | node) [2F], 8-byte aligned
+  uint32_t* chs = lds + 4u * F;                  // candidate hash: slot -> candidate index [2F]
+  uint32_t* wl = chs + 2u * F;                   // level offsets window [W+1]
+  uint32_t* wen = wl + (W + 1u);                 // log window: nodes
+  uint32_t* wec = wen + W;                       // log window: counts
+  uint32_t* bbuf = wec + W;                      // border (depth d2+1), ping-pong: node, emit index, flags
+  uint32_t* cfl = bbuf + 6u * F;                 // candidates (depth d2): accumulated flags, emit index
+  uint32_t* cem = cfl + F;
+  uint32_t* lm = cem + F;                        // match of each (border entry, nt) among the candidates [4F]
+  uint32_t bsel = 0;                             // which border buffer is current
+  uint32_t *bn = bbuf, *be = bbuf + F, *bf = bbuf + 2u * F;
 
   const uint64_t* log = log_all + gd.slog_off;
   const uint32_t* lvl = lvl_all + gd.lvl_off;
@@ -796,6 +812,8 @@ __global__ __launch_bounds__(64) void g2s_extract_lds(const uint32_t* __restrict
   const uint32_t t_flags = G2S_SUB_IN_T | G2S_SUB_START_T | ((want_s && !gd.all_paths) ? (G2S_SUB_IN_S | G2S_SUB_SINK) : 0u);
   const int min_len = n_len > 1 ? min(len0, len1) : len0;
 
+  for (uint32_t i = (uint32_t)lane; i < 2u * F; i += 64u) chk[i] = G2S_DEV_EMPTY64;
+  lds_sync();
   uint32_t st_slowD = 0, st_bulkD = 0;
   const unsigned long long cyc0 = __builtin_amdgcn_s_memtime();
   int wl_lo = gd.D + 2;          // wl[i] = lvl[wl_lo + i], i in [0, W]
@@ -927,20 +945,20 @@ __global__ __launch_bounds__(64) void g2s_extract_lds(const uint32_t* __restrict
     // ---- level offsets and entries of depth d2 through the LDS windows ---------------
     if (d2 < wl_lo) {
       lds_sync();
-      wl_lo = max(0, d2 + 1 - (int)LDS_W);
-      for (uint32_t i = (uint32_t)lane; i <= LDS_W; i += 64u) {
+      wl_lo = max(0, d2 + 1 - (int)W);
+      for (uint32_t i = (uint32_t)lane; i <= W; i += 64u) {
         const int dd = wl_lo + (int)i;
         wl[i] = dd <= gd.D + 1 ? lvl[dd] : 0xFFFFFFFFu;
       }
       lds_sync();
     }
     const uint32_t lo = wl[d2 - wl_lo], hi = wl[d2 + 1 - wl_lo];
-    const uint32_t w = hi - lo;  // <= LDS_F by construction of the log
+    const uint32_t w = hi - lo;  // <= F by construction of the log
     if (w == 0 && nbord == 0) continue;
     if (w > 0 && (lo < we_lo || hi > we_hi)) {
       lds_sync();
       we_hi = hi;
-      we_lo = hi > LDS_W ? hi - LDS_W : 0u;
+      we_lo = hi > W ? hi - W : 0u;
       for (uint32_t i = (uint32_t)lane; i < we_hi - we_lo; i += 64u) {
         const uint64_t e = log[we_lo + i];
         wen[i] = (uint32_t)(e >> 32);
@@ -948,59 +966,83 @@ __global__ __launch_bounds__(64) void g2s_extract_lds(const uint32_t* __restrict
       }
       lds_sync();
     }
-    // candidates of this level live in lane registers
-    const bool is_c = (uint32_t)lane < w;
-    const uint32_t cn = is_c ? wen[lo - we_lo + (uint32_t)lane] : G2S_DEV_INVALID;
-    const uint32_t cc = is_c ? wec[lo - we_lo + (uint32_t)lane] : 0u;
-    uint32_t cf = 0;
-    // new paths starting at this depth (:1195-1259)
-    if (is_c && cn == sinknode && d2 >= lo_sink) cf |= G2S_SUB_IN_S | G2S_SUB_SINK;
-    if (is_c && cn == reached && (d2 == len0 || (n_len > 1 && d2 == len1))) cf |= t_flags;
-    if (is_c) cfl[lane] = 0;
+    // ---- per-level step: any width up to F.  The level's states (candidates) are indexed
+    // c = 0..w-1 in the log window; a depth-tagged LDS hash maps node -> c.
+    const uint32_t wbase = lo - we_lo;
+    const uint32_t tag = (uint32_t)d2 | 0x80000000u;
+    for (uint32_t c = (uint32_t)lane; c < w; c += 64u) {
+      const uint32_t cn = wen[wbase + c];
+      uint32_t f = 0;
+      if (cn == sinknode && d2 >= lo_sink) f |= G2S_SUB_IN_S | G2S_SUB_SINK;                // :1195-1244
+      if (cn == reached && (d2 == len0 || (n_len > 1 && d2 == len1))) f |= t_flags;         // :1245-1259
+      cfl[c] = f;
+      const uint64_t key = ((uint64_t)tag << 32) | cn;
+      uint32_t h = mix32(cn) & (2u * F - 1u);
+      while (true) {  // states of one level are distinct: plain claim, stale tags are free
+        const uint64_t cur = chk[h];
+        if ((uint32_t)(cur >> 32) == tag) { h = (h + 1) & (2u * F - 1u); continue; }
+        if (atomicCAS((unsigned long long*)&chk[h], (unsigned long long)cur, (unsigned long long)key) == cur) break;
+      }
+      chs[h] = c;
+    }
     lds_sync();
+    auto find_cand = [&](uint32_t node) -> uint32_t {
+      uint32_t h = mix32(node) & (2u * F - 1u);
+      while (true) {
+        const uint64_t cur = chk[h];
+        if ((uint32_t)(cur >> 32) != tag) return 0xFFFFFFFFu;
+        if ((uint32_t)cur == node) return chs[h];
+        h = (h + 1) & (2u * F - 1u);
+      }
+    };
     // ---- expand the border of depth d2+1 towards this level (:1266-1301) ---------------
     xcount += nbord;
     for (uint32_t i0 = 0; i0 < nbord * 4u; i0 += 64u) {
       const uint32_t i = i0 + (uint32_t)lane;
-      const bool valid = i < nbord * 4u;
-      const uint32_t e = i >> 2, nt = i & 3u;
-      const uint32_t cur = valid ? bn[e] : 0u;
-      const uint32_t f = valid ? bf[e] : 0u;
-      const bool expand = valid && !(f & G2S_SUB_SOURCE);
-      const uint32_t p = expand ? flip(succ[(size_t)(cur ^ 1u) * 4 + nt]) : G2S_DEV_INVALID;
-      uint32_t match = 0xFFFFFFFFu;
-      for (uint32_t c = 0; c < w; c++) {
-        const uint32_t cand = (uint32_t)__shfl((int)cn, (int)c);
-        if (p != G2S_DEV_INVALID && p == cand) match = c;
+      if (i < nbord * 4u) {
+        const uint32_t e = i >> 2, nt = i & 3u;
+        const uint32_t cur = bn[e], f = bf[e];
+        uint32_t match = 0xFFFFFFFFu;
+        if (!(f & G2S_SUB_SOURCE)) {
+          const uint32_t p = flip(succ[(size_t)(cur ^ 1u) * 4 + nt]);
+          if (p != G2S_DEV_INVALID) match = find_cand(p);
+          if (match != 0xFFFFFFFFu) atomicOr(&cfl[match], f & (G2S_SUB_IN_S | G2S_SUB_IN_T));
+        }
+        lm[i] = match;
       }
-      if (match != 0xFFFFFFFFu) atomicOr(&cfl[match], f & (G2S_SUB_IN_S | G2S_SUB_IN_T));
-      if (valid) lm[i] = match;
     }
     lds_sync();
     // ---- reached candidates join the closure ------------------------------------------
-    if (is_c) cf |= cfl[lane];
-    lds_sync();
-    if (is_c) cfl[lane] = cf;  // final flags, visible to the other candidates (Q7 check)
-    lds_sync();
-    const bool in = is_c && cf != 0;
-    const uint64_t m = __ballot(in);
-    const uint32_t nin = (uint32_t)__popcll(m);
-    if (nsub + nin > cap) { lflags |= G2S_DEV_OVERFLOW_B; break; }
     const uint32_t lidx = (d2 <= gd.lmf) ? (lseeds[d2] >> 1) : 0xFFFFFFFFu;  // buildNode(kmer_left.substr(d2,k))
-    const uint32_t slot = (uint32_t)__popcll(m & lanes_below(lane));
-    if (in) {
-      if (d2 <= gd.lmf && (cn >> 1) == lidx) cf |= G2S_SUB_SOURCE;  // :1270 end condition, k-mer comparison only
-      SubState st;
-      st.node = cn; st.depth = (uint32_t)d2; st.cnt = cc; st.flags = cf;
-      st.pred[0] = st.pred[1] = st.pred[2] = st.pred[3] = -1;
-      sub[nsub + slot] = st;
-      cem[lane] = nsub + slot;
-      // Q7: both strands of one k-mer in this border
-      for (uint32_t c = 0; c < w; c++) {
-        const uint32_t other = wen[lo - we_lo + c];
-        if (other == (cn ^ 1u) && cfl[c] != 0u) lflags |= G2S_DEV_Q7_D;
+    uint32_t* nbn = bbuf + (bsel ^ 1u) * 3u * F;
+    uint32_t* nbe = nbn + F;
+    uint32_t* nbf = nbn + 2u * F;
+    uint32_t nin_total = 0;
+    bool over = false;
+    for (uint32_t c0 = 0; c0 < w; c0 += 64u) {
+      const uint32_t c = c0 + (uint32_t)lane;
+      uint32_t cf = c < w ? cfl[c] : 0u;
+      const bool in = cf != 0;
+      const uint64_t m = __ballot(in);
+      const uint32_t nin = (uint32_t)__popcll(m);
+      if (nsub + nin_total + nin > cap) { over = true; break; }
+      if (in) {
+        const uint32_t cn = wen[wbase + c];
+        const uint32_t slot = nin_total + (uint32_t)__popcll(m & lanes_below(lane));
+        if (d2 <= gd.lmf && (cn >> 1) == lidx) cf |= G2S_SUB_SOURCE;  // :1270 end condition, k-mer comparison only
+        SubState st;
+        st.node = cn; st.depth = (uint32_t)d2; st.cnt = wec[wbase + c]; st.flags = cf;
+        st.pred[0] = st.pred[1] = st.pred[2] = st.pred[3] = -1;
+        sub[nsub + slot] = st;
+        cem[c] = nsub + slot;
+        nbn[slot] = cn; nbe[slot] = nsub + slot; nbf[slot] = cf;
+        // Q7: both strands of one k-mer in this border
+        const uint32_t oc = find_cand(cn ^ 1u);
+        if (oc != 0xFFFFFFFFu && cfl[oc] != 0u) lflags |= G2S_DEV_Q7_D;
       }
+      nin_total += nin;
     }
+    if (over) { lflags |= G2S_DEV_OVERFLOW_B; break; }
     lds_sync();
     // ---- links from the border above to this level -------------------------------------
     for (uint32_t i0 = 0; i0 < nbord * 4u; i0 += 64u) {
@@ -1011,10 +1053,10 @@ __global__ __launch_bounds__(64) void g2s_extract_lds(const uint32_t* __restrict
       }
     }
     lds_sync();
-    if (in) { bn[slot] = cn; be[slot] = nsub + slot; bf[slot] = cf; }
-    nsub += nin;
-    nbord = nin;
-    lds_sync();
+    bsel ^= 1u;
+    bn = nbn; be = nbe; bf = nbf;
+    nsub += nin_total;
+    nbord = nin_total;
   }
   for (int o = 32; o > 0; o >>= 1) lflags |= __shfl_xor(lflags, o);
   if (lflags & G2S_DEV_OVERFLOW_B) {
@@ -1045,41 +1087,48 @@ __global__ __launch_bounds__(64) void g2s_extract_lds(const uint32_t* __restrict
 // ---------------------------------------------------------------------------
 namespace g2s {
 
-size_t fill_lds_bytes(uint32_t rs_cap) {
-  return 4u * (2 * LDS_F * 3 + LDS_LH * 2 + LDS_LH + LDS_TG + 3 * LDS_TH + 4 + rs_cap);
+size_t fill_lds_bytes(uint32_t rs_cap, uint32_t fcap) {
+  return 4u * (2 * fcap * 3 + (2 * fcap) * 2 + (2 * fcap) + LDS_TG + 3 * (2 * fcap) + 4 + rs_cap);
 }
-size_t extract_lds_bytes() {
-  return 4u * ((LDS_W + 1) + 2 * LDS_W + 5 * LDS_F + 4 * LDS_F);
+size_t extract_lds_bytes(uint32_t fcap) {
+  const uint32_t w = fcap > 256u ? fcap : 256u;
+  return 4u * ((w + 1) + 2 * w + 6 * fcap + 2 * fcap + 4 * fcap + 2 * fcap + 1 + 4 * fcap);
 }
-uint32_t fill_lds_frontier_cap() { return LDS_F; }
+uint32_t fill_lds_frontier_cap() { return LDS_F; }  // pass 0; later passes use LDS_F_WIDE
 uint32_t fill_lds_max_fuz() { return LDS_TG - 1; }
 
 hipError_t launch_fill_lds(hipStream_t st, uint32_t ngaps, uint32_t rs_cap_max, uint32_t num_oriented,
                            const uint32_t* succ, const GapDev* gaps, const uint32_t* gap_ids,
                            const uint32_t* flank_nodes, uint64_t* log_all, uint32_t* lvl_all, GapOut* outs,
-                           uint32_t* rs_global) {
+                           uint32_t* rs_global, uint32_t fcap) {
   if (ngaps == 0) return hipSuccess;
   if (rs_global) {  // right set in HBM: no LDS for it
-    const size_t bytes = fill_lds_bytes(0);
+    const size_t bytes = fill_lds_bytes(0, fcap);
+    hipError_t e = hipFuncSetAttribute((const void*)g2s_fill_lds_rsg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(g2s_fill_lds_rsg, dim3(ngaps), dim3(64), bytes, st, succ, gaps, gap_ids, flank_nodes, log_all,
-                       lvl_all, outs, num_oriented, rs_global);
+                       lvl_all, outs, num_oriented, rs_global, fcap);
     return hipGetLastError();
   }
-  const size_t bytes = fill_lds_bytes(rs_cap_max);
+  const size_t bytes = fill_lds_bytes(rs_cap_max, fcap);
   hipError_t e = hipFuncSetAttribute((const void*)g2s_fill_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(g2s_fill_lds, dim3(ngaps), dim3(64), bytes, st, succ, gaps, gap_ids, flank_nodes, log_all, lvl_all,
-                     outs, num_oriented);
+                     outs, num_oriented, fcap);
   return hipGetLastError();
 }
 
 hipError_t launch_extract_lds(hipStream_t st, uint32_t ngaps, uint32_t num_oriented, const uint32_t* succ,
                               const GapDev* gaps, const uint32_t* gap_ids, const uint32_t* flank_nodes,
                               const uint64_t* log_all, const uint32_t* lvl_all, SubState* sub_scratch,
-                              SubState* sub_out, unsigned long long* out_counter, GapOut* outs, int skip_confident) {
+                              SubState* sub_out, unsigned long long* out_counter, GapOut* outs, int skip_confident,
+                              uint32_t fcap) {
   if (ngaps == 0) return hipSuccess;
-  hipLaunchKernelGGL(g2s_extract_lds, dim3(ngaps), dim3(64), extract_lds_bytes(), st, succ, gaps, gap_ids, flank_nodes,
-                     log_all, lvl_all, sub_scratch, sub_out, out_counter, outs, skip_confident, num_oriented);
+  const size_t bytes = extract_lds_bytes(fcap);
+  hipError_t e = hipFuncSetAttribute((const void*)g2s_extract_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(g2s_extract_lds, dim3(ngaps), dim3(64), bytes, st, succ, gaps, gap_ids, flank_nodes, log_all,
+                     lvl_all, sub_scratch, sub_out, out_counter, outs, skip_confident, num_oriented, fcap);
   return hipGetLastError();
 }
 

@@ -468,7 +468,7 @@ uint32_t lds_rs_cap(const GapJob& j, int d_err, uint32_t room) {
 // entries of right set each gap may have in LDS when `ngaps` gaps share the chip
 uint32_t lds_room(size_t ngaps) {
   const size_t per_cu = std::max<size_t>(1, (ngaps + 255) / 256);
-  const size_t bytes = (160u * 1024u) / std::min<size_t>(per_cu, 6) - fill_lds_bytes(0) - 512;
+  const size_t bytes = (160u * 1024u) / std::min<size_t>(per_cu, 6) - fill_lds_bytes(0, 64) - 512;
   uint32_t cap = 512;
   while ((size_t)cap * 2 * 4 <= bytes && cap < 16384) cap <<= 1;
   return cap;
@@ -494,7 +494,7 @@ Plan plan_gap(const GapJob& j, int d_err, uint64_t scale, uint64_t max_states) {
 // LDS-resident kernels (fill_lds.hip); false: the general tier with per-gap tables in
 // HBM (fill_kernels.hip) at the given table scale.
 int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uint64_t max_states, TierData* td,
-             bool lds, uint32_t lds_room_override = 0, bool rs_in_hbm = false) {
+             bool lds, uint32_t lds_room_override = 0, bool rs_in_hbm = false, uint32_t fcap = 64) {
   g2s_session* s = b->s;
   const DeviceGraph& dg = s->graph->g->dev.at(s->device);
   const size_t n = b->jobs.size();
@@ -552,13 +552,14 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
     const uint32_t num_oriented = (uint32_t)(2 * s->graph->g->n);
     HIP_TRY(launch_fill_lds(st, (uint32_t)ids.size(), lds_cap_max, num_oriented, dg.succ, (const GapDev*)s->d_gaps.p,
                             (const uint32_t*)s->d_ids.p, (const uint32_t*)s->d_flank.p, (uint64_t*)s->d_log.p,
-                            (uint32_t*)s->d_lvl.p, (GapOut*)s->d_outs.p, rs_in_hbm ? (uint32_t*)s->d_rs.p : nullptr));
+                            (uint32_t*)s->d_lvl.p, (GapOut*)s->d_outs.p, rs_in_hbm ? (uint32_t*)s->d_rs.p : nullptr,
+                            fcap));
     HIP_TRY(hipEventRecord(s->ev[2], st));
     HIP_TRY(launch_extract_lds(st, (uint32_t)ids.size(), num_oriented, dg.succ, (const GapDev*)s->d_gaps.p,
                                (const uint32_t*)s->d_ids.p, (const uint32_t*)s->d_flank.p, (const uint64_t*)s->d_log.p,
                                (const uint32_t*)s->d_lvl.p, (SubState*)s->d_subscr.p, (SubState*)s->d_subout.p,
                                (unsigned long long*)s->d_counter.p, (GapOut*)s->d_outs.p,
-                               s->params.skip_confident ? 1 : 0));
+                               s->params.skip_confident ? 1 : 0, fcap));
     HIP_TRY(hipEventRecord(s->ev[3], st));
   } else {
     HIP_TRY(s->d_rs.ensure(rs_total * 4));
@@ -684,7 +685,9 @@ extern "C" int g2s_batch_run(g2s_batch* b, g2s_result* results, char* arena, siz
     const uint32_t room = pass == 0 ? 0u : 16384u;
     TierData* td = take_tier(s, b->tiers.size());
     b->tiers.push_back(td);
-    int rc = run_tier(b, ids, pass == 0 ? 1 : 8, max_states, td, true, room, pass == 2);
+    // pass 0 keeps the LDS footprint small (frontier 64); later passes run few gaps per CU and
+    // take wide frontiers (1024 entries) so that repeat-rich gaps stay out of the HBM tier
+    int rc = run_tier(b, ids, pass == 0 ? 1 : 8, max_states, td, true, room, pass == 2, pass == 0 ? 64u : 1024u);
     if (rc != G2S_OK) return rc;
     const GapOut* outs = (const GapOut*)td->outs.p;
     for (uint32_t i : ids) {
@@ -694,11 +697,13 @@ extern "C" int g2s_batch_run(g2s_batch* b, g2s_result* results, char* arena, siz
           fprintf(stderr, "[g2s] gap %u left LDS pass %d: flags 0x%x n_right %u x_right %u n_states %u x_left %u final_d %d g %d\n",
                   i, pass, go.flags, go.n_right, go.x_right, go.n_states, go.x_left, go.final_d, b->jobs[i].g);
         // a right-set overflow is cured by a larger right set (pass 1 unless pass 0 already
-        // had the largest LDS table, else pass 2); a state-log overflow may be cured by pass
-        // 1's larger log; a frontier wider than the LDS buffers needs the HBM tier
+        // had the largest LDS table, else pass 2); state-log and frontier overflows by pass 1's
+        // larger log and 1024-entry frontier; what still overflows goes to the HBM tier
         const bool only_a = (go.flags & G2S_DEV_OVERFLOW_A) && !(go.flags & G2S_DEV_OVERFLOW_B);
         int target = 3;
-        if (pass == 0) target = (only_a && room0_is_max) ? 2 : 1;
+        // deep searches (-dist-error in the thousands) overflow the largest LDS right set too
+        const bool deep = b->jobs[i].rmf + (b->jobs[i].g + fp.d_err + 1) / 2 > 2048;
+        if (pass == 0) target = (only_a && (room0_is_max || deep)) ? 2 : 1;
         else if (pass == 1 && only_a) target = 2;
         if (target < 3) cand[target].push_back(i);
         else { todo.push_back(i); b->timing.retried_gaps++; }
