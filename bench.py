@@ -63,6 +63,10 @@ def main():
     ap.add_argument("--k", type=int, default=31)
     ap.add_argument("--fuz", type=int, default=10)
     ap.add_argument("--dist-error", type=int, default=500)
+    ap.add_argument("--sessions", type=int, default=1,
+                    help="sessions per GPU; >1 (or --group) times g2s_team_fill: groups of gaps pipelined over the "
+                         "sessions, host flank lookup + upload INSIDE the timed region")
+    ap.add_argument("--group", type=int, default=0, help="gaps per group for --sessions (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the barrier/timing reduction")
     ap.add_argument("--share-device", action="store_true",
@@ -109,17 +113,28 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    team = None
+    if args.sessions > 1 or args.group > 0:
+        team = [sess] + [P.Session(graph, local_rank, d_err=args.dist_error, randseed=1)
+                         for _ in range(args.sessions - 1)]
+        team_gaps = [P.Gap(g["left"], g["right"], g["gap_len"], g["lmf"], g["rmf"]) for g in gaps]
+        team_prep, _ = P.team_fill(team, team_gaps, args.group, "raw")
+
+    def one_step():
         sess.srand(1)
-        batch.run()
+        if team is None:
+            batch.run()  # synchronous: returns after kernels, copies and host phase D
+            return batch.timing()
+        return P.team_fill(team, team_gaps, args.group, "raw", team_prep)[1]
+
+    for _ in range(args.warmup):
+        one_step()
     acc = dict(ms_right_bfs=0.0, ms_left_dp=0.0, ms_extract=0.0, ms_fill_lds=0.0, ms_extract_lds=0.0, ms_d2h=0.0,
                ms_host_post=0.0, ms_total=0.0, launches=0)
     sync_all()
     t_begin = time.perf_counter()
     for _ in range(args.steps):
-        sess.srand(1)
-        batch.run()  # synchronous: returns after kernels, copies and host phase D
-        tm = batch.timing()
+        tm = one_step()
         acc["ms_right_bfs"] += tm.ms_right_bfs
         acc["ms_left_dp"] += tm.ms_left_dp
         acc["ms_extract"] += tm.ms_extract
@@ -138,10 +153,15 @@ def main():
     sess.srand(1)
     sess.fill_batch([P.Gap(g["left"], g["right"], g["gap_len"], g["lmf"], g["rmf"]) for g in gaps])
     t_pcie = time.perf_counter() - t_pcie
+    tm_team = one_step() if team is not None else None
     sess.srand(1)
     batch.run()
     tm = batch.timing()
     res = batch.results()
+    if tm_team is not None:
+        tm_team.fill_bytes = tm.fill_bytes
+        tm_team.flank_bytes = tm.flank_bytes
+        tm = tm_team
     filled = sum(1 for r in res if r.count > 0)
     q7 = sum(1 for r in res if r.flags & P.G2S_GAP_Q7)
 
@@ -209,7 +229,8 @@ def main():
                                    "dist-error %d" % (args.genome, args.variant, args.k, args.gaps, args.min_len,
                                                       args.max_len, args.fuz, args.dist_error),
                        "gaps_per_gpu": args.gaps, "genome_bp": args.genome, "variant": args.variant, "k": args.k,
-                       "parallelism": "gap-sharded x%d, graph replicated, no collective" % world},
+                       "parallelism": "gap-sharded x%d, graph replicated, no collective" % world,
+                       "sessions_per_gpu": args.sessions, "group": args.group},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "filled": filled,
@@ -230,6 +251,8 @@ def main():
         }
         print(json.dumps(out))
     batch.free()
+    for t in (team or [])[1:]:
+        t.destroy()
     sess.destroy()
     graph.free()
     if dist is not None:

@@ -6,8 +6,8 @@ graph builder in C++, HIP kernels for gfx950, host phase D) and the drop-in
 ctypes binding over that ABI for tests and ``bench.py``; it contains no compute
 and no CPU fallback.
 """
-from .lib import (G2S, G2SError, Graph, Session, Gap, load_library, library_path,  # noqa: F401
+from .lib import (G2S, G2SError, Graph, Session, Gap, load_library, library_path, team_fill,  # noqa: F401
                   G2S_GAP_SKIPPED, G2S_GAP_Q7, G2S_GAP_MEM_EXCEEDED, G2S_GAP_BACKTRACE_FAIL,
                   G2S_GAP_BAD_FLANK, G2S_GAP_PHASE_D)
 
-__all__ = ["G2S", "G2SError", "Graph", "Session", "Gap", "load_library", "library_path"]
+__all__ = ["G2S", "G2SError", "Graph", "Session", "Gap", "load_library", "library_path", "team_fill"]

@@ -9,7 +9,9 @@
 #include <cstring>
 #include <ctime>
 #include <iostream>
+#include <algorithm>
 #include <string>
+#include <vector>
 
 #include "../../include/g2s.h"
 
@@ -26,11 +28,13 @@ int main(int argc, char** argv) {
   g2s_params p;
   memset(&p, 0, sizeof p);
   p.d_err = 500; p.all_paths = 1;
-  int randseed = 0, device = 0;
+  int randseed = 0, device = 0, streams = 2;
+  std::string devices;  // "0,1,2": GPUs sharing the gap list (the graph is replicated)
   std::string reads, scaffolds, filled, left, right;
   int length = 0;
   bool saw_left = false, saw_right = false, saw_len = false;
   if (const char* e = getenv("G2S_DEVICE")) device = atoi(e);
+  if (const char* e = getenv("G2S_DEVICES")) devices = e;
   for (int i = 1; i < argc; i++) {
     const std::string a = argv[i];
     auto val = [&]() -> const char* { return (i + 1 < argc) ? argv[++i] : ""; };
@@ -52,10 +56,12 @@ int main(int argc, char** argv) {
     else if (a == "-length") { length = atoi(val()); saw_len = true; }
     else if (a == "-verbose") (void)val();
     else if (a == "-device") device = atoi(val());
+    else if (a == "-devices") devices = val();
+    else if (a == "-streams") streams = atoi(val());
     else if (a == "-help" || a == "-h") {
       std::cout << "Gap2Seq-core (MI355X) -reads a.fq[,b.fq] -filled out.fa (-scaffolds in.fa | -left S -right S -length N)\n"
                    "  [-k 31] [-solid 2] [-dist-error 500] [-fuz 10] [-max-mem 20] [-randseed 0]\n"
-                   "  [-all-upper] [-best-only] [-unique] [-nb-cores N] [-device D]\n";
+                   "  [-all-upper] [-best-only] [-unique] [-nb-cores N] [-device D | -devices D0,D1,...] [-streams 2]\n";
       return EXIT_SUCCESS;
     }
     // unknown options are ignored, never errors
@@ -89,6 +95,31 @@ int main(int argc, char** argv) {
     std::cout << "EXCEPTION: " << g2s_last_error() << std::endl;
     return EXIT_FAILURE;
   }
+  // the dispatcher: `streams` sessions on every listed device pull groups of gaps from one
+  // list (g2s_team_fill); the first session of the first device owns the rand() stream
+  std::vector<int> devs;
+  for (size_t pos = 0; pos < devices.size();) {
+    size_t e = devices.find(',', pos);
+    if (e == std::string::npos) e = devices.size();
+    if (e > pos) devs.push_back(atoi(devices.substr(pos, e - pos).c_str()));
+    pos = e + 1;
+  }
+  if (devs.empty()) devs.push_back(device);
+  else if (devs[0] != device) {  // the lead session sits on the first listed device
+    g2s_session_destroy(s);
+    s = nullptr;
+    rc = g2s_session_create(g, devs[0], &p, &s);
+    if (rc != G2S_OK) { std::cout << "EXCEPTION: " << g2s_last_error() << std::endl; return EXIT_FAILURE; }
+  }
+  std::vector<g2s_session*> helpers;
+  for (size_t d = 0; d < devs.size(); d++)
+    for (int t = (d == 0 ? 1 : 0); t < std::max(1, streams); t++) {
+      g2s_session* h = nullptr;
+      rc = g2s_session_create(g, devs[d], &p, &h);
+      if (rc != G2S_OK) { std::cout << "EXCEPTION: " << g2s_last_error() << std::endl; return EXIT_FAILURE; }
+      helpers.push_back(h);
+    }
+  if (!helpers.empty()) g2s_session_set_team(s, helpers.data(), (int)helpers.size(), 0);
   char *fasta = nullptr, *log = nullptr;
   if (saw_left && saw_right && saw_len) {
     rc = g2s_execute_single(s, &o, reads.c_str(), filled.c_str(), left.c_str(), right.c_str(), length, &fasta, &log);
@@ -116,6 +147,7 @@ int main(int argc, char** argv) {
   g2s_free(fasta);
   g2s_free(log);
   g2s_session_destroy(s);
+  for (g2s_session* h : helpers) g2s_session_destroy(h);
   g2s_graph_free(g);
   return EXIT_SUCCESS;
 }

@@ -319,6 +319,10 @@ struct g2s_session {
   DevBuf d_gaps, d_ids, d_flank, d_outs, d_rs, d_rlog, d_keys, d_cnt, d_mark, d_slog, d_subscr, d_subout, d_counter;
   DevBuf d_log, d_lvl;  // LDS tier: level-ordered state log + level offsets
   std::vector<void*> tier_pool;  // recycled TierData (pinned host buffers)
+  size_t tier_cursor = 0;        // next free slot of tier_pool in the current run
+  const void* flank_owner = nullptr;  // batch whose flank nodes d_flank holds
+  std::vector<g2s_session*> helpers;  // g2s_session_set_team
+  size_t team_group = 0;
   PinBuf h_gaps;                 // staging for the GapDev upload
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 };
@@ -374,18 +378,25 @@ struct g2s_batch {
   g2s_session* s = nullptr;
   std::vector<GapJob> jobs;
   std::vector<uint32_t> flank_off;
+  std::vector<uint32_t> flank_all;  // oriented flank nodes of every gap, as uploaded to d_flank
+  int upload_flanks();
   size_t arena_bytes = 0;
   g2s_timing timing;
   std::vector<TierData*> tiers;
+  // stage 1 results (GPU passes + per-gap analysis), consumed by stage 2 (offsets + tracebacks)
+  std::vector<SubView> views;
+  std::vector<SubPrep> prep;
+  std::vector<char> mem_exceeded;
   void drop_tiers();
-  ~g2s_batch() { if (s) drop_tiers(); }
+  ~g2s_batch() { if (s) { drop_tiers(); if (s->flank_owner == this) s->flank_owner = nullptr; } }
 };
 
 // pinned result buffers are recycled through the session: allocating page-locked memory
 // costs more than a whole 500-gap batch.  The k-th launch group of a run always uses the
 // session's k-th slot, so buffer sizes settle after the first run.
 void g2s_batch::drop_tiers() { tiers.clear(); }
-static TierData* take_tier(g2s_session* s, size_t slot) {
+static TierData* take_tier(g2s_session* s, size_t /*unused*/) {
+  const size_t slot = s->tier_cursor++;
   while (s->tier_pool.size() <= slot) s->tier_pool.push_back(new TierData());
   TierData* t = (TierData*)s->tier_pool[slot];
   t->gap_ids.clear();
@@ -401,42 +412,66 @@ extern "C" int g2s_batch_prepare(g2s_session* s, const g2s_gap* gaps, size_t n, 
   memset(&b->timing, 0, sizeof b->timing);
   b->jobs.resize(n);
   b->flank_off.resize(n);
-  std::vector<uint32_t> flank_all;
-  for (size_t i = 0; i < n; i++) {
-    GapJob& j = b->jobs[i];
-    const g2s_gap& in = gaps[i];
-    j.g = in.gap_len;
-    j.lmf = in.lmf;
-    j.rmf = in.rmf;
-    j.skip_if_prev_right_fuz_gt = in.skip_if_prev_right_fuz_gt;
-    // D2: flanks too short would make the reference throw from substr
-    j.bad_flank = !in.left || !in.right || in.lmf < 0 || in.rmf < 0 || in.gap_len < 0 || in.left_len < k + in.lmf ||
-                  in.right_len < k + in.rmf;
-    if (!j.bad_flank) {
-      j.left.assign(in.left, (size_t)in.left_len);
-      j.right.assign(in.right, (size_t)in.right_len);
-      j.flank_nodes.resize((size_t)(j.lmf + 1) + 2 * (size_t)(j.rmf + 1));
-      uint32_t* fn = j.flank_nodes.data();
-      for (int d = 0; d <= j.lmf; d++) *fn++ = g.node_of(j.left.c_str() + d);                       // :995,1083
-      for (int d = 0; d <= j.rmf; d++) *fn++ = g.node_of(j.right.c_str() + (j.right.size() - k - d));  // :878,954
-      for (int d = 0; d <= j.rmf; d++) *fn++ = g.node_of(j.right.c_str() + d);                      // :1113
-      b->timing.flank_bytes += (uint64_t)(j.left.size() + j.right.size());
-    } else {
-      j.lmf = std::max(0, j.lmf);
-      j.rmf = std::max(0, j.rmf);
-      j.g = std::max(0, j.g);
+  std::vector<uint32_t>& flank_all = b->flank_all;
+  // flank k-mer -> node lookups (33 per gap at -fuz 10) are independent: pool, 64 gaps a task
+  const size_t per_task = 64;
+  const int d_err = s->params.d_err;
+  auto do_range = [&](size_t t) {
+    const size_t lo = t * per_task, hi = std::min(n, lo + per_task);
+    for (size_t i = lo; i < hi; i++) {
+      GapJob& j = b->jobs[i];
+      const g2s_gap& in = gaps[i];
+      j.g = in.gap_len;
+      j.lmf = in.lmf;
+      j.rmf = in.rmf;
+      j.skip_if_prev_right_fuz_gt = in.skip_if_prev_right_fuz_gt;
+      // D2: flanks too short would make the reference throw from substr
+      j.bad_flank = !in.left || !in.right || in.lmf < 0 || in.rmf < 0 || in.gap_len < 0 ||
+                    in.left_len < k + in.lmf || in.right_len < k + in.rmf;
+      if (!j.bad_flank) {
+        j.left.assign(in.left, (size_t)in.left_len);
+        j.right.assign(in.right, (size_t)in.right_len);
+        j.flank_nodes.resize((size_t)(j.lmf + 1) + 2 * (size_t)(j.rmf + 1));
+        uint32_t* fn = j.flank_nodes.data();
+        for (int d = 0; d <= j.lmf; d++) *fn++ = g.node_of(j.left.c_str() + d);                       // :995,1083
+        for (int d = 0; d <= j.rmf; d++) *fn++ = g.node_of(j.right.c_str() + (j.right.size() - k - d));  // :878,954
+        for (int d = 0; d <= j.rmf; d++) *fn++ = g.node_of(j.right.c_str() + d);                      // :1113
+      } else {
+        j.lmf = std::max(0, j.lmf);
+        j.rmf = std::max(0, j.rmf);
+        j.g = std::max(0, j.g);
+      }
     }
+  };
+  const size_t ntasks = (n + per_task - 1) / per_task;
+  if (ntasks > 1) s->pool->run(ntasks, do_range);
+  else if (ntasks == 1) do_range(0);
+  size_t nflank = 0;
+  for (size_t i = 0; i < n; i++) nflank += b->jobs[i].flank_nodes.size();
+  flank_all.reserve(nflank);
+  for (size_t i = 0; i < n; i++) {
+    const GapJob& j = b->jobs[i];
+    if (!j.bad_flank) b->timing.flank_bytes += (uint64_t)(j.left.size() + j.right.size());
     b->flank_off[i] = (uint32_t)flank_all.size();
     flank_all.insert(flank_all.end(), j.flank_nodes.begin(), j.flank_nodes.end());
-    b->arena_bytes += j.buf_bytes(k, s->params.d_err);
+    b->arena_bytes += j.buf_bytes(k, d_err);
   }
-  if (hipSetDevice(s->device) != hipSuccess) { delete b; return fail(G2S_ERR_NO_DEVICE, "cannot select device"); }
+  const int rc = b->upload_flanks();
+  if (rc != G2S_OK) { delete b; return rc; }
+  *out = b;
+  return G2S_OK;
+}
+
+// d_flank belongs to the session; the batch that ran last owns its contents.
+int g2s_batch::upload_flanks() {
+  if (s->flank_owner == this) return G2S_OK;
+  if (hipSetDevice(s->device) != hipSuccess) return fail(G2S_ERR_NO_DEVICE, "cannot select device");
   hipError_t e = s->d_flank.ensure(std::max<size_t>(flank_all.size() * 4, 16));
   if (e == hipSuccess && !flank_all.empty())
     e = hipMemcpyAsync(s->d_flank.p, flank_all.data(), flank_all.size() * 4, hipMemcpyHostToDevice, s->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
-  if (e != hipSuccess) { delete b; return fail(G2S_ERR_HIP, std::string("batch upload: ") + hipGetErrorString(e)); }
-  *out = b;
+  if (e != hipSuccess) return fail(G2S_ERR_HIP, std::string("batch upload: ") + hipGetErrorString(e));
+  s->flank_owner = this;
   return G2S_OK;
 }
 
@@ -623,38 +658,40 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
 
 }  // namespace
 
-extern "C" int g2s_batch_run(g2s_batch* b, g2s_result* results, char* arena, size_t arena_cap) {
-  if (!b || !results || (!arena && b->arena_bytes)) return fail(G2S_ERR_ARG, "g2s_batch_run: bad argument");
-  if (arena_cap < b->arena_bytes) return fail(G2S_ERR_ARG, "g2s_batch_run: fill arena too small");
+namespace {
+
+FillParams fill_params_of(const g2s_session* s) {
+  FillParams fp;
+  fp.k = s->graph->g->k;
+  fp.d_err = s->params.d_err;
+  fp.skip_confident = s->params.skip_confident != 0;
+  fp.all_paths = s->params.all_paths != 0;
+  fp.unique_paths = s->params.unique_paths != 0;
+  return fp;
+}
+
+// Stage 1 of a batch: phases A-D1 on the GPU (all passes/tiers) and the per-gap host
+// analysis (D2, stop depths).  Independent of every other batch.
+int batch_stage1(g2s_batch* b) {
   g2s_session* s = b->s;
   if (hipSetDevice(s->device) != hipSuccess) return fail(G2S_ERR_NO_DEVICE, "cannot select device");
   const Graph& g = *s->graph->g;
   const size_t n = b->jobs.size();
   auto t_begin = std::chrono::steady_clock::now();
+  { const int rc = b->upload_flanks(); if (rc != G2S_OK) return rc; }
   b->drop_tiers();
   g2s_timing keep = b->timing;
   memset(&b->timing, 0, sizeof b->timing);
   b->timing.flank_bytes = keep.flank_bytes;
 
-  FillParams fp;
-  fp.k = g.k;
-  fp.d_err = s->params.d_err;
-  fp.skip_confident = s->params.skip_confident != 0;
-  fp.all_paths = s->params.all_paths != 0;
-  fp.unique_paths = s->params.unique_paths != 0;
+  const FillParams fp = fill_params_of(s);
   // device-budget analogue of -max-mem: states a gap may hold
   const uint64_t max_states = (uint64_t)std::max<int64_t>(s->params.max_mem, 1 << 16) / 64;
 
-  memset(results, 0, n * sizeof(g2s_result));
-  memset(arena, 0, b->arena_bytes);
-  // rand() values are input independent: materialise what this batch will need while the
-  // GPU runs (one draw per traced base plus one per gap, Gap2Seq.cpp:1440,1513)
-  size_t rand_need = 0;
-  for (size_t i = 0; i < n; i++) rand_need += (size_t)(b->jobs[i].g + g.k + b->jobs[i].lmf + b->jobs[i].rmf + 2);
-  std::thread rand_fill([s, rand_need]() { s->rcache.ensure(rand_need); });
-  struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } rand_join{rand_fill};
-  std::vector<SubView> views(n);
-  std::vector<char> mem_exceeded(n, 0);
+  std::vector<SubView>& views = b->views;
+  std::vector<char>& mem_exceeded = b->mem_exceeded;
+  views.assign(n, SubView());
+  mem_exceeded.assign(n, 0);
 
   // ---- GPU: phases A-D1, retrying gaps whose tables overflowed with 8x larger ones
   std::vector<uint32_t> todo, lds_ids;
@@ -779,40 +816,63 @@ extern "C" int g2s_batch_run(g2s_batch* b, g2s_result* results, char* arena, siz
   }
 
   // ---- host: D2 + stop-depth analysis per gap, thread pool ----------------------
-  rand_fill.join();
   auto t_post = std::chrono::steady_clock::now();
-  std::vector<SubPrep> prep(n);
+  std::vector<SubPrep>& prep = b->prep;
+  prep.assign(n, SubPrep());
   s->pool->run(n, [&](size_t i) {
     if (views[i].out) sub_analyze(fp, b->jobs[i], views[i], &prep[i]);
   });
+  b->timing.ms_host_post = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_post).count();
+  b->timing.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+  (void)g;
+  return G2S_OK;
+}
 
+
+// Stage 2 over batches in gap order: assign rand() stream offsets (:178,1440,1513) and run
+// the tracebacks.  A gap whose draw count does not depend on the draws gets its offset in
+// O(1); the others are traced inline.  All remaining tracebacks then run in parallel.
+// results/arena are laid out batch after batch.
+int batches_stage2(const std::vector<g2s_batch*>& bs, g2s_session* lead, g2s_result* results, char* arena,
+                   g2s_timing* timing) {
+  const Graph& g = *lead->graph->g;
+  const FillParams fp = fill_params_of(lead);
   auto t_ana = std::chrono::steady_clock::now();
-  // ---- host: assign rand() stream offsets in gap order (:178,1440,1513) ---------
-  // A gap whose draw count does not depend on the draws gets its offset in O(1);
-  // the others are traced right here.  All remaining tracebacks then run in parallel.
+  size_t n = 0;
+  for (g2s_batch* b : bs) n += b->jobs.size();
   std::vector<size_t> arena_off(n), rand_off(n, 0);
   std::vector<char> todo_tb(n, 0);
+  std::vector<g2s_batch*> owner(n);
+  std::vector<uint32_t> local(n);
   {
-    size_t apos = 0;
-    for (size_t i = 0; i < n; i++) { arena_off[i] = apos; apos += b->jobs[i].buf_bytes(g.k, fp.d_err); }
+    size_t apos = 0, gi = 0;
+    for (g2s_batch* b : bs)
+      for (size_t i = 0; i < b->jobs.size(); i++, gi++) {
+        arena_off[gi] = apos;
+        apos += b->jobs[i].buf_bytes(g.k, fp.d_err);
+        owner[gi] = b;
+        local[gi] = (uint32_t)i;
+      }
   }
   size_t draws_total = 0;
   bool prev_filled = false;
   int prev_right_fuz = 0;
-  for (size_t i = 0; i < n; i++) {
+  for (size_t gi = 0; gi < n; gi++) {
+    g2s_batch* b = owner[gi];
+    const size_t i = local[gi];
     const GapJob& j = b->jobs[i];
-    g2s_result& r = results[i];
-    char* buf = arena + arena_off[i];
-    r.fill_off = (uint64_t)arena_off[i] + (uint64_t)j.lmf;
+    g2s_result& r = results[gi];
+    char* buf = arena + arena_off[gi];
+    r.fill_off = (uint64_t)arena_off[gi] + (uint64_t)j.lmf;
     if (j.skip_if_prev_right_fuz_gt >= 0 && prev_filled && prev_right_fuz > j.skip_if_prev_right_fuz_gt) {
       r.flags |= G2S_GAP_SKIPPED;
       prev_filled = false;
       continue;
     }
     if (j.bad_flank) { r.flags |= G2S_GAP_BAD_FLANK; prev_filled = false; continue; }
-    if (mem_exceeded[i]) { r.count = -1; r.flags |= G2S_GAP_MEM_EXCEEDED; prev_filled = false; continue; }
-    const SubView& v = views[i];
-    const SubPrep& pp = prep[i];
+    if (b->mem_exceeded[i]) { r.count = -1; r.flags |= G2S_GAP_MEM_EXCEEDED; prev_filled = false; continue; }
+    const SubView& v = b->views[i];
+    const SubPrep& pp = b->prep[i];
     r.phaseC_count = v.out->c_count;
     r.n_lengths = v.out->n_len;
     r.lengths[0] = v.out->len[0];
@@ -823,16 +883,16 @@ extern "C" int g2s_batch_run(g2s_batch* b, g2s_result* results, char* arena, siz
     if (pp.phase_d) {
       r.vertices = pp.sub[0]; r.edges = pp.sub[1]; r.nontrivial_components = pp.sub[2];
       r.size_nontrivial_components = pp.sub[3]; r.vertices_final = pp.sub[4]; r.edges_final = pp.sub[5];
-      rand_off[i] = draws_total;
-      const int pick = (int)(s->rcache.at(draws_total) % v.out->n_len);
+      rand_off[gi] = draws_total;
+      const int pick = (int)(lead->rcache.at(draws_total) % v.out->n_len);
       const int fixed = sub_fixed_draws(v, pp, pick);
       if (fixed >= 0) {
-        todo_tb[i] = 1;
+        todo_tb[gi] = 1;
         r.draws = fixed;
         r.right_fuz = v.out->reached_j;
       } else {
-        s->rcache.ensure(draws_total + (size_t)v.out->len[pick] + 2);
-        sub_traceback(g, fp, j, v, pp, s->rcache.ptr(draws_total), buf, &r);
+        lead->rcache.ensure(draws_total + (size_t)v.out->len[pick] + 2);
+        sub_traceback(g, fp, j, v, pp, lead->rcache.ptr(draws_total), buf, &r);
       }
       draws_total += (size_t)r.draws;
     }
@@ -840,41 +900,180 @@ extern "C" int g2s_batch_run(g2s_batch* b, g2s_result* results, char* arena, siz
     prev_right_fuz = r.right_fuz;
   }
   auto t_off = std::chrono::steady_clock::now();
-  s->rcache.ensure(draws_total + 1);
-  s->pool->run(n, [&](size_t i) {
-    if (!todo_tb[i]) return;
-    g2s_result& r = results[i];
+  lead->rcache.ensure(draws_total + 1);
+  lead->pool->run(n, [&](size_t gi) {
+    if (!todo_tb[gi]) return;
+    g2s_result& r = results[gi];
+    g2s_batch* b = owner[gi];
+    const size_t i = local[gi];
     const int expect = r.draws;
-    sub_traceback(g, fp, b->jobs[i], views[i], prep[i], s->rcache.ptr(rand_off[i]), arena + arena_off[i], &r);
+    sub_traceback(g, fp, b->jobs[i], b->views[i], b->prep[i], lead->rcache.ptr(rand_off[gi]), arena + arena_off[gi], &r);
     if (r.draws != expect) r.flags |= G2S_GAP_BACKTRACE_FAIL;  // cannot happen: the draw count was proven fixed
   });
-  s->rcache.consume(draws_total);
-  for (size_t i = 0; i < n; i++) {
-    g2s_result& r = results[i];
+  lead->rcache.consume(draws_total);
+  uint64_t fill_bytes = 0;
+  for (size_t gi = 0; gi < n; gi++) {
+    g2s_result& r = results[gi];
     if (!(r.flags & G2S_GAP_PHASE_D)) continue;
-    r.fill_off = (uint64_t)arena_off[i] + (uint64_t)(b->jobs[i].lmf - r.left_fuz);
+    r.fill_off = (uint64_t)arena_off[gi] + (uint64_t)(owner[gi]->jobs[local[gi]].lmf - r.left_fuz);
     r.fill_len = (int32_t)strlen(arena + r.fill_off);
-    b->timing.fill_bytes += (uint64_t)r.fill_len;
+    fill_bytes += (uint64_t)r.fill_len;
   }
   auto t_end = std::chrono::steady_clock::now();
   if (getenv("G2S_DEBUG"))
-    fprintf(stderr, "[g2s] host phase D: analyze %.3f ms, offsets+inline tracebacks %.3f ms, parallel tracebacks %.3f ms (draws %zu)\n",
-            std::chrono::duration<double, std::milli>(t_ana - t_post).count(),
+    fprintf(stderr, "[g2s] host stage 2: offsets+inline tracebacks %.3f ms, parallel tracebacks %.3f ms (draws %zu)\n",
             std::chrono::duration<double, std::milli>(t_off - t_ana).count(),
             std::chrono::duration<double, std::milli>(t_end - t_off).count(), draws_total);
-  b->timing.ms_host_post = std::chrono::duration<double, std::milli>(t_end - t_post).count();
-  b->timing.ms_total = std::chrono::duration<double, std::milli>(t_end - t_begin).count();
+  if (timing) {
+    timing->fill_bytes += fill_bytes;
+    timing->ms_host_post += std::chrono::duration<double, std::milli>(t_end - t_ana).count();
+    timing->ms_total += std::chrono::duration<double, std::milli>(t_end - t_ana).count();
+  }
   return G2S_OK;
+}
+
+size_t rand_need_of(const g2s_gap* gaps, size_t n, int k) {
+  size_t need = 0;
+  for (size_t i = 0; i < n; i++) need += (size_t)(std::max(0, gaps[i].gap_len) + k + std::max(0, gaps[i].lmf) + std::max(0, gaps[i].rmf) + 2);
+  return need;
+}
+
+}  // namespace
+
+extern "C" int g2s_batch_run(g2s_batch* b, g2s_result* results, char* arena, size_t arena_cap) {
+  if (!b || !results || (!arena && b->arena_bytes)) return fail(G2S_ERR_ARG, "g2s_batch_run: bad argument");
+  if (arena_cap < b->arena_bytes) return fail(G2S_ERR_ARG, "g2s_batch_run: fill arena too small");
+  g2s_session* s = b->s;
+  const size_t n = b->jobs.size();
+  memset(results, 0, n * sizeof(g2s_result));
+  memset(arena, 0, b->arena_bytes);
+  // rand() values are input independent: materialise what this batch will need while the
+  // GPU runs (one draw per traced base plus one per gap, Gap2Seq.cpp:1440,1513)
+  size_t rand_need = 0;
+  for (size_t i = 0; i < n; i++)
+    rand_need += (size_t)(b->jobs[i].g + s->graph->g->k + b->jobs[i].lmf + b->jobs[i].rmf + 2);
+  std::thread rand_fill([s, rand_need]() { s->rcache.ensure(rand_need); });
+  s->tier_cursor = 0;
+  const int rc = batch_stage1(b);
+  rand_fill.join();
+  if (rc != G2S_OK) return rc;
+  return batches_stage2(std::vector<g2s_batch*>{b}, s, results, arena, &b->timing);
+}
+
+// A team of sessions (any mix of devices, several per device allowed) fills one gap list:
+// the list is cut into groups, every session's host thread pulls the next group from a
+// shared counter (static start, work stealing by construction), runs stage 1 on its GPU,
+// and stage 2 runs once over all groups in gap order on the first session's rand() stream.
+// Two sessions on one device overlap one group's host analysis with the next group's
+// kernels.  No collective: the graph is replicated, gaps are independent.
+extern "C" int g2s_team_fill(g2s_session* const* sessions, int nsessions, const g2s_gap* gaps, size_t n,
+                             size_t group_size, g2s_result* results, char* arena, size_t arena_cap,
+                             g2s_timing* timing_out) {
+  if (!sessions || nsessions < 1 || (!gaps && n) || !results) return fail(G2S_ERR_ARG, "g2s_team_fill: bad argument");
+  for (int t = 0; t < nsessions; t++)
+    if (!sessions[t] || sessions[t]->graph != sessions[0]->graph)
+      return fail(G2S_ERR_ARG, "g2s_team_fill: sessions must share one graph");
+  if (group_size == 0) group_size = 2048;
+  auto t_begin = std::chrono::steady_clock::now();
+  g2s_session* lead = sessions[0];
+  const size_t ngroups = (n + group_size - 1) / group_size;
+  std::vector<g2s_batch*> subs(ngroups, nullptr);
+  std::vector<int> rcs((size_t)nsessions, G2S_OK);
+  std::vector<std::string> errs((size_t)nsessions);
+  std::atomic<size_t> next(0);
+  std::thread rand_fill([lead, gaps, n]() { lead->rcache.ensure(rand_need_of(gaps, n, lead->graph->g->k)); });
+  auto worker = [&](int t) {
+    g2s_session* s = sessions[t];
+    s->tier_cursor = 0;
+    while (true) {
+      const size_t gi = next.fetch_add(1);
+      if (gi >= ngroups) break;
+      const size_t off = gi * group_size, cnt = std::min(group_size, n - off);
+      g2s_batch* b = nullptr;
+      auto t0 = std::chrono::steady_clock::now();
+      int rc = g2s_batch_prepare(s, gaps + off, cnt, &b);
+      auto t1 = std::chrono::steady_clock::now();
+      if (rc == G2S_OK) { subs[gi] = b; rc = batch_stage1(b); }
+      if (getenv("G2S_DEBUG"))
+        fprintf(stderr, "[g2s] team session %d group %zu (%zu gaps): prepare %.3f ms, stage 1 %.3f ms\n", t, gi, cnt,
+                std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
+      if (rc != G2S_OK) { rcs[(size_t)t] = rc; errs[(size_t)t] = tl_error; next.store(ngroups); break; }
+    }
+  };
+  {
+    std::vector<std::thread> th;
+    for (int t = 1; t < nsessions; t++) th.emplace_back(worker, t);
+    worker(0);
+    for (auto& x : th) x.join();
+  }
+  rand_fill.join();
+  int rc = G2S_OK;
+  for (int t = 0; t < nsessions; t++) if (rcs[(size_t)t] != G2S_OK) { rc = rcs[(size_t)t]; tl_error = errs[(size_t)t]; }
+  g2s_timing total;
+  memset(&total, 0, sizeof total);
+  if (rc == G2S_OK) {
+    size_t need = 0;
+    for (g2s_batch* b : subs) need += b->arena_bytes;
+    if (arena_cap < need || (!arena && need)) rc = fail(G2S_ERR_ARG, "g2s_team_fill: fill arena too small");
+    if (rc == G2S_OK) {
+      memset(results, 0, n * sizeof(g2s_result));
+      memset(arena, 0, need);
+      for (g2s_batch* b : subs) {
+        const g2s_timing& t = b->timing;
+        total.ms_right_bfs += t.ms_right_bfs; total.ms_left_dp += t.ms_left_dp; total.ms_extract += t.ms_extract;
+        total.ms_fill_lds += t.ms_fill_lds; total.ms_extract_lds += t.ms_extract_lds; total.ms_d2h += t.ms_d2h;
+        total.ms_host_post += t.ms_host_post;
+        total.xA += t.xA; total.sA += t.sA; total.xB += t.xB; total.sB += t.sB; total.xD += t.xD; total.sD += t.sD;
+        total.flank_bytes += t.flank_bytes; total.launches_left_dp += t.launches_left_dp;
+        total.retried_gaps += t.retried_gaps; total.x_fill_lds += t.x_fill_lds; total.s_fill_lds += t.s_fill_lds;
+        total.lds_tier_gaps += t.lds_tier_gaps; total.lds_launches += t.lds_launches;
+      }
+      rc = batches_stage2(subs, lead, results, arena, &total);
+    }
+  }
+  for (g2s_batch* b : subs) g2s_batch_free(b);
+  total.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+  if (timing_out) *timing_out = total;
+  return rc;
+}
+
+extern "C" size_t g2s_team_arena_bytes(const g2s_session* s, const g2s_gap* gaps, size_t n) {
+  if (!s || (!gaps && n)) return 0;
+  size_t need = 0;
+  for (size_t i = 0; i < n; i++)
+    need += (size_t)(std::max(0, gaps[i].gap_len) + s->graph->g->k + s->params.d_err + std::max(0, gaps[i].lmf) +
+                     std::max(0, gaps[i].rmf) + 1 + 2);
+  return need;
 }
 
 extern "C" int g2s_fill_batch(g2s_session* s, const g2s_gap* gaps, size_t n, g2s_result* results, char* fill_arena,
                               size_t arena_cap) {
+  if (!s) return fail(G2S_ERR_ARG, "g2s_fill_batch: bad argument");
+  // long lists go through the group pipeline: with helpers to use every session, without
+  // them to bound the HBM the state logs of one launch take
+  const size_t group = s->team_group ? s->team_group : (s->helpers.empty() ? (size_t)16384 : (size_t)2048);
+  if (n > group) {
+    std::vector<g2s_session*> team{s};
+    team.insert(team.end(), s->helpers.begin(), s->helpers.end());
+    return g2s_team_fill(team.data(), (int)team.size(), gaps, n, group, results, fill_arena, arena_cap, nullptr);
+  }
   g2s_batch* b = nullptr;
   int rc = g2s_batch_prepare(s, gaps, n, &b);
   if (rc != G2S_OK) return rc;
   rc = g2s_batch_run(b, results, fill_arena, arena_cap);
   g2s_batch_free(b);
   return rc;
+}
+
+extern "C" int g2s_session_set_team(g2s_session* lead, g2s_session* const* helpers, int nhelpers, size_t group_size) {
+  if (!lead || nhelpers < 0 || (nhelpers && !helpers)) return fail(G2S_ERR_ARG, "g2s_session_set_team: bad argument");
+  for (int i = 0; i < nhelpers; i++)
+    if (!helpers[i] || helpers[i] == lead || helpers[i]->graph != lead->graph)
+      return fail(G2S_ERR_ARG, "g2s_session_set_team: helpers must be other sessions on the same graph");
+  lead->helpers.assign(helpers, helpers + nhelpers);
+  lead->team_group = group_size;
+  return G2S_OK;
 }
 
 // accessors used by the host driver (g2s_execute.cpp)

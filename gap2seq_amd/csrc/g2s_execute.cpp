@@ -199,12 +199,9 @@ extern "C" int g2s_execute_scaffolds(g2s_session* s, const g2s_run_opts* o, cons
     std::vector<g2s_result> results(jobs.size());
     std::vector<char> arena;
     if (!jobs.empty()) {
-      g2s_batch* b = nullptr;
-      int rc = g2s_batch_prepare(s, jobs.data(), jobs.size(), &b);
-      if (rc != G2S_OK) return rc;
-      arena.resize(g2s_batch_arena_bytes(b));
-      rc = g2s_batch_run(b, results.data(), arena.data(), arena.size());
-      g2s_batch_free(b);
+      // g2s_fill_batch spreads long lists over the session's team (g2s_session_set_team)
+      arena.resize(g2s_team_arena_bytes(s, jobs.data(), jobs.size()));
+      int rc = g2s_fill_batch(s, jobs.data(), jobs.size(), results.data(), arena.data(), arena.size());
       if (rc != G2S_OK) return rc;
     }
 

@@ -95,6 +95,10 @@ _SIGS = {
     "g2s_batch_free": (None, [_VP]),
     "g2s_fill_batch": (C.c_int, [_VP, C.POINTER(g2s_gap), C.c_size_t, C.POINTER(g2s_result), C.c_char_p,
                                  C.c_size_t]),
+    "g2s_team_fill": (C.c_int, [C.POINTER(_VP), C.c_int, C.POINTER(g2s_gap), C.c_size_t, C.c_size_t,
+                                C.POINTER(g2s_result), C.c_char_p, C.c_size_t, C.POINTER(g2s_timing)]),
+    "g2s_team_arena_bytes": (C.c_size_t, [_VP, C.POINTER(g2s_gap), C.c_size_t]),
+    "g2s_session_set_team": (C.c_int, [_VP, C.POINTER(_VP), C.c_int, C.c_size_t]),
     "g2s_execute_scaffolds": (C.c_int, [_VP, C.POINTER(g2s_run_opts), C.c_char_p, C.c_char_p, C.c_char_p,
                                         C.POINTER(_VP), C.POINTER(_VP), C.POINTER(C.c_int32),
                                         C.POINTER(C.c_int32)]),
@@ -314,6 +318,12 @@ class Session:
         out = [FillResult(res[i], raw) for i in range(len(gaps))]
         return (out, t) if want_timing else out
 
+    def set_team(self, helpers, group_size=0):
+        """g2s_session_set_team: fill_batch / execute_* on this session use self + helpers."""
+        arr = (_VP * max(1, len(helpers)))(*[h.h for h in helpers])
+        _check(load_library().g2s_session_set_team(self.h, arr, len(helpers), group_size))
+        self._helpers = list(helpers)
+
     def prepare(self, gaps):
         """g2s_batch_prepare; returns an opaque PreparedBatch to run repeatedly."""
         return PreparedBatch(self, gaps)
@@ -342,6 +352,28 @@ class Session:
         if self.h:
             load_library().g2s_session_destroy(self.h)
             self.h = None
+
+
+def team_fill(sessions, gaps, group_size=0, want_timing=False, prepared=None):
+    """g2s_team_fill: the sessions (one or more per device) share one gap list; results equal
+    sessions[0].fill_batch(gaps).  `prepared` = (arr, keep, arena, res) from a previous call to
+    skip the marshalling (bench)."""
+    lib = load_library()
+    if prepared is None:
+        arr, keep = _gap_array(gaps)
+        nbytes = lib.g2s_team_arena_bytes(sessions[0].h, arr, len(gaps))
+        arena = C.create_string_buffer(max(1, nbytes))
+        res = (g2s_result * max(1, len(gaps)))()
+        prepared = (arr, keep, arena, res, nbytes)
+    arr, keep, arena, res, nbytes = prepared
+    hs = (_VP * len(sessions))(*[s.h for s in sessions])
+    t = g2s_timing()
+    _check(lib.g2s_team_fill(hs, len(sessions), arr, len(gaps), group_size, res, arena, nbytes, C.byref(t)))
+    if want_timing == "raw":
+        return prepared, t
+    raw = arena.raw
+    out = [FillResult(res[i], raw) for i in range(len(gaps))]
+    return (out, t) if want_timing else out
 
 
 class PreparedBatch:

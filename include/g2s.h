@@ -194,6 +194,27 @@ int g2s_fill_batch(g2s_session* s, const g2s_gap* gaps, size_t n, g2s_result* re
                    size_t arena_cap);
 
 /* ---------------------------------------------------------------------------
+ *  Several sessions on one gap list = the reference's dispatcher
+ *  (`-nb-cores`, Gap2Seq.cpp:300-304: threads pulling scaffolds from a shared
+ *  iterator), with GPUs in place of threads.  The list is cut into groups of
+ *  `group_size` gaps (0 = default); each session's host thread pulls the next
+ *  group from a shared counter and runs phases A-D2 for it; the rand()
+ *  dependent part (D3) then runs once, in gap order, on sessions[0]'s stream,
+ *  so results equal g2s_fill_batch(sessions[0], ...) bit for bit.  Sessions
+ *  must share one graph; they may sit on different devices (graph replicated,
+ *  no exchange step) or on the same device (one session's host analysis then
+ *  overlaps the other's kernels).  `timing` (optional) receives the sums over
+ *  groups with ms_total = wall time of the call.
+ *  g2s_session_set_team makes g2s_fill_batch / g2s_execute_* on `lead` use
+ *  lead + helpers this way for lists longer than group_size; helpers must
+ *  outlive the lead or be detached with nhelpers = 0.
+ * ------------------------------------------------------------------------ */
+int g2s_team_fill(g2s_session* const* sessions, int nsessions, const g2s_gap* gaps, size_t n, size_t group_size,
+                  g2s_result* results, char* fill_arena, size_t arena_cap, g2s_timing* timing);
+size_t g2s_team_arena_bytes(const g2s_session* s, const g2s_gap* gaps, size_t n);
+int g2s_session_set_team(g2s_session* lead, g2s_session* const* helpers, int nhelpers, size_t group_size);
+
+/* ---------------------------------------------------------------------------
  *  Gap2Seq::execute() after the graph exists (Gap2Seq.cpp:224-438): scaffold
  *  scanner, per-gap statistics text, splice, FASTA text.  Outputs are malloc'ed
  *  strings released with g2s_free.  `reads_label`/`filled_label` only feed the

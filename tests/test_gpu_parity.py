@@ -317,6 +317,90 @@ def test_multi_rank_bench_path(product, tmp_path):
     assert out["cpu_baseline"] is None and out["roofline"]["kernel"] == "g2s_fill_lds"
 
 
+def _result_tuple(r):
+    return (r.count, r.left_fuz, r.right_fuz, r.flags, r.draws, r.fill, tuple(r.substats), r.phaseC_count,
+            tuple(r.lengths))
+
+
+@pytest.mark.parametrize("nsess,group", [(1, 37), (2, 64), (3, 50)])
+def test_team_of_sessions_equals_one_session(product, oracle, nsess, group):
+    """g2s_team_fill (the dispatcher: sessions pulling groups of gaps from one list, D3 in
+    gap order on the lead's rand() stream) must reproduce a single session's batch bit for
+    bit, and therefore the oracle: V3 genome (repeats + bubbles), 300 gaps."""
+    reads = product.G2S.synth_genome(300000, 3, 20240101)
+    seqs = [ln for ln in reads.splitlines() if not ln.startswith(">")]
+    gl = _parse_scaffolds(product.G2S.synth_gaps(reads, 31, 10, 300, 50, 700, 99))
+    gaps = _gaps(product, gl)
+    pg = product.Graph.from_seqs(seqs, 31, 1)
+    og = oracle.OracleGraph(seqs, 31, 1)
+    single = product.Session(pg, 0, d_err=500, randseed=17)
+    team = [product.Session(pg, 0, d_err=500, randseed=17) for _ in range(nsess)]
+    try:
+        want = [_result_tuple(r) for r in single.fill_batch(gaps)]
+        got, tm = product.team_fill(team, gaps, group_size=group, want_timing=True)
+        assert [_result_tuple(r) for r in got] == want
+        assert tm.lds_launches >= (300 + group - 1) // group
+        # and a second list on the same team continues the lead's rand() stream like the single session
+        want2 = [_result_tuple(r) for r in single.fill_batch(gaps[:120])]
+        got2 = product.team_fill(team, gaps[:120], group_size=group)
+        assert [_result_tuple(r) for r in got2] == want2
+        rng = oracle.OracleRng(17)
+        n = 0
+        for g, r in zip(gl, got):
+            o = oracle.fill_gap(og, rng, g["left"], g["right"], g["gap_len"], 500, g["lmf"], g["rmf"], False, True)
+            if o.info.q7 or (r.flags & product.G2S_GAP_Q7):
+                if o.info.draws != r.draws:
+                    break
+                continue
+            assert (r.count, r.draws) == (o.count, o.info.draws)
+            if o.phase_d:
+                assert r.fill == o.fill
+            n += 1
+        assert n > 250
+    finally:
+        for t in team:
+            t.destroy()
+        single.destroy()
+        pg.free()
+        og.free()
+
+
+def test_session_team_drives_execute_scaffolds(product, oracle):
+    """g2s_session_set_team: execute() on the lead spreads the record list's gaps over the
+    helpers; FASTA and log equal the oracle's execute()."""
+    k = 21
+    seqs = cases.toy_genome(5, 30000, k, repeats=3, snp_every=401)
+    g = seqs[0]
+    recs = []
+    for r in range(60):
+        p = 100 + r * 450
+        recs.append((">sc%d\n" % r) + cases.scaffold_record(g, k, 10, [(p, 30 + r % 40, 30 + r % 40 + k), (p + 200, 20, 20 + k)]))
+    text = "\n".join(recs) + "\n"
+    pg = product.Graph.from_seqs(seqs, k, 1)
+    og = oracle.OracleGraph(seqs, k, 1)
+    lead = product.Session(pg, 0, d_err=100, randseed=4)
+    helpers = [product.Session(pg, 0, d_err=100, randseed=4) for _ in range(2)]
+    try:
+        lead.set_team(helpers, group_size=16)
+        fa, lg, ngaps, nfilled = lead.execute_scaffolds(text, k, solid=1)
+        ofa, olg, sm = oracle.execute_scaffolds(og, text, k, solid=1, d_err=100, max_fuz=10, randseed=4)
+        assert ngaps == 120
+        if not sm.q7_gaps:
+            assert (ngaps, nfilled) == (sm.gaps, sm.filled)
+            assert fa == ofa
+            assert lg == olg
+        lead.set_team([])
+        lead.srand(4)
+        fa1, lg1, _, _ = lead.execute_scaffolds(text, k, solid=1)
+        assert (fa1, lg1) == (fa, lg)
+    finally:
+        lead.destroy()
+        for h in helpers:
+            h.destroy()
+        pg.free()
+        og.free()
+
+
 def test_full_size_round_trip_c3(product):
     """BASELINE config 3 size (3 Mbp DBG, 10 000 gaps, k=31, -fuz 10, -dist-error 500) on
     the repeat-free V0 genome: every gap has exactly one path, so cut -> fill must give
