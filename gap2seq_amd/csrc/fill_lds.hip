@@ -36,6 +36,9 @@
 #define LDS_LH (2u * LDS_F)
 #define LDS_TG 32u        /* right_max_fuz + 1 must fit        */
 #define LDS_W 256u        /* log / level-offset window (D1)    */
+#define LDS_TF 128u       /* target filter slots               */
+#define LDS_TF_COLLIDE 0xFFFFFFFEu
+#define LDS_CW 256u       /* candidates of 64 border entries   */
 
 namespace {
 
@@ -174,7 +177,7 @@ __device__ bool lrs_has_kmer(const uint32_t* tab, uint32_t mask, uint32_t v) {
 
 // ============================================================================
 // Phases A + B + C, LDS tier.
-// dynamic LDS: [fa 2F][fn 2F][fc 2F][lh 2F x u64][lhslot 2F][tgt TG][th 3*TH][misc 4][rs rs_cap]
+// dynamic LDS: [fa 2F][fn 2F][fc 2F][lh 2F x u64][lhslot 2F][tgt TG][th 3*TH][misc 4][tflt 128][cw 2x256][rs rs_cap]
 // ============================================================================
 template <bool RSG>
 __device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ, const GapDev* __restrict__ gaps,
@@ -200,7 +203,10 @@ __device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ,
   uint32_t* th_d = th_j + TH;
   uint32_t* th_c = th_d + TH;
   uint32_t* misc = th_c + TH;                 // [0] = number of target hits
-  uint32_t* rs = RSG ? rs_global + gd.rs_off : misc + 4;  // right set: HBM (host pre-filled 0xFF) or LDS
+  uint32_t* tflt = misc + 4;                  // exact target filter: 128 direct-mapped slots
+  uint32_t* cw_v = tflt + LDS_TF;             // wide levels: compacted candidate nodes / counts
+  uint32_t* cw_c = cw_v + LDS_CW;
+  uint32_t* rs = RSG ? rs_global + gd.rs_off : cw_c + LDS_CW;  // right set: HBM (host pre-filled 0xFF) or LDS
 
   const uint32_t rs_cap = gd.rs_mask + 1u;  // LDS capacity chosen by the host for this gap (<= rs_cap_max)
   const uint32_t rmask = gd.rs_mask;
@@ -212,15 +218,49 @@ __device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ,
   const uint32_t cap = gd.slog_cap;
 
   if (!RSG) for (uint32_t i = (uint32_t)lane; i < rs_cap; i += 64u) rs[i] = G2S_DEV_INVALID;
-  for (uint32_t i = (uint32_t)lane; i < LH; i += 64u) lh[i] = G2S_DEV_EMPTY64;
   if (lane <= gd.rmf && lane < (int)LDS_TG) tgt[lane] = targets[lane];
   if (lane == 0) misc[0] = 0;
+  // Is a state's node one of the <= 32 target k-mers?  Two filters in front of the exact scan
+  // of tgt[]: a 64-bit Bloom word in registers, then a direct-mapped LDS table that is exact
+  // except for slots two targets share.  (The scan used to run on most levels: with 11
+  // targets the Bloom word alone passes 1 state in 6.)
   uint64_t tbloom = 0;  // which hash bits any target k-mer sets
   for (int j = 0; j <= gd.rmf; j++) {
     const uint32_t t = targets[j];
     if (t != G2S_DEV_INVALID) tbloom |= 1ull << (mix32(t) & 63u);
   }
+  for (uint32_t i = (uint32_t)lane; i < LDS_TF; i += 64u) tflt[i] = G2S_DEV_INVALID;
   lds_sync();
+  if (lane <= gd.rmf && lane < (int)LDS_TG) {
+    const uint32_t t = targets[lane];
+    if (t != G2S_DEV_INVALID) {
+      uint32_t* slot = &tflt[(mix32(t) >> 6) & (LDS_TF - 1u)];
+      const uint32_t prev = atomicCAS(slot, G2S_DEV_INVALID, t);
+      if (prev != G2S_DEV_INVALID && prev != t) *slot = LDS_TF_COLLIDE;
+    }
+  }
+  lds_sync();
+  uint32_t nhit = 0;  // == misc[0], kept in a register
+  // record (target index, depth, count) for every target k-mer equal to `node`
+  auto note_targets = [&](bool active, uint32_t node, uint32_t depth, uint32_t c) {
+    bool maybe = active && ((tbloom >> (mix32(node) & 63u)) & 1ull);
+    if (__ballot(maybe) == 0) return;
+    if (maybe) {
+      const uint32_t x = tflt[(mix32(node) >> 6) & (LDS_TF - 1u)];
+      maybe = x == node || x == LDS_TF_COLLIDE;
+    }
+    if (__ballot(maybe) == 0) return;
+    if (maybe) {
+      for (int j = 0; j <= gd.rmf; j++) {
+        if (tgt[j] == node) {
+          const uint32_t idx = atomicAdd(&misc[0], 1u);
+          if (idx < TH) { th_j[idx] = (uint32_t)j; th_d[idx] = depth; th_c[idx] = c; }
+        }
+      }
+    }
+    lds_sync();
+    nhit = misc[0];
+  };
 
   uint32_t flags = 0;
   bool overflow = (gd.rmf + 1 > (int)LDS_TG);
@@ -228,6 +268,11 @@ __device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ,
   // ---------------- phase A: right BFS (Gap2Seq.cpp:871-982) -------------------
   uint32_t nvis = 0, xa = 0;
   uint32_t st_slowA = 0, st_bulkA = 0, st_slowB = 0, st_bulkB = 0;
+#ifdef G2S_PROF_A
+  unsigned long long pa[4] = {0, 0, 0, 0}, pb[2] = {0, 0}, pc[5] = {0, 0, 0, 0, 0}, pd[5] = {0, 0, 0, 0, 0};
+  uint32_t pnB[5] = {0, 0, 0, 0, 0};
+  uint32_t pn_fail = 0, pn_wide = 0;
+#endif
   const unsigned long long cyc0 = __builtin_amdgcn_s_memtime();
   {
     uint32_t cur = 0, nb = 0;
@@ -247,34 +292,55 @@ __device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ,
       // level-major (lane = i*Rp + r: run r, level d+i); each lane speculates its node and
       // verifies it with one 16 B record load (coalesced over the wave).  The leading
       // levels on which all runs hold are inserted into the right set at once.
+#ifdef G2S_PROF_A
+      unsigned long long pt0 = __builtin_amdgcn_s_memtime();
+#endif
       if (nb >= 1 && nb <= 16 && d > gd.rmf) {
         const uint32_t R = nb, lg = log2ceil16(R), Rp = 1u << lg;
         const uint32_t r = (uint32_t)lane & (Rp - 1u), i = (uint32_t)lane >> lg;
         const bool mine = r < R;
         const uint32_t n = mine ? fcur[r] : 0u;
         const uint32_t L = (uint32_t)min((int)(64u >> lg), gd.right_half - d + 1);
+#ifdef G2S_PROF_A
+        unsigned long long ptl = pt0;
+#endif
         const uint32_t step = 2u * (i + 1u);
         const bool up = (n & 1u) != 0;  // odd orientation: predecessors have larger ids
         const bool inrange = mine && i < L && (up ? (n + step < num_oriented) : (n >= step));
         const uint32_t x = up ? n + step - 2u : n - (step - 2u);  // border node of level d+i
         const uint32_t p = up ? n + step : n - step;               // its speculated predecessor
+        // the verification load goes out first; the checks below run while it is in flight
+        uint4 rec = make_uint4(G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID);
+        if (inrange) rec = *(const uint4*)(succ + (size_t)(x ^ 1u) * 4);
+        // A run that follows another one over the same ids (same orientation, fewer than
+        // `levels` steps behind) would race with it for "who visited first": it may only
+        // advance up to the other run's border node, which is already in the right set.
+        // (Run q's node sits in lane q; readlane keeps this loop free of LDS traffic.)
+        uint32_t lim = 64u;
+        if (R > 1) {
+          for (uint32_t q = 0; q < R; q++) {
+            const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)n, (int)q);
+            const int ahead = up ? (int)(o - n) : (int)(n - o);  // ids the other run is in front of mine
+            const bool same = ((o ^ n) & 1u) == 0u && ahead > 0;
+            const uint32_t cand = same ? (uint32_t)ahead >> 1 : 64u;
+            lim = min(lim, cand);
+          }
+        }
         bool ok = !mine;
         if (inrange) {
           uint32_t nt;
-          const uint4 rec = *(const uint4*)(succ + (size_t)(x ^ 1u) * 4);
-          ok = only_slot(rec, &nt) == (p ^ 1u);
-          // two runs walking over the same ids would race for "who visited first": leave
-          // such levels to the per-level code, where arrival order is the depth order
-          // (with one level per step, lg == 6, all inserts belong to the same depth: no race)
-          for (uint32_t q = 0; q < R && ok && lg < 6u; q++) {
-            if (q == r) continue;
-            const uint32_t o = fcur[q];
-            if ((o & 1u) != (n & 1u)) continue;
-            const uint32_t span = 2u * (64u >> lg);
-            const bool oup = (o & 1u) != 0;
-            if (oup ? (p > o && p <= o + span) : (p < o && p + span >= o)) ok = false;
-          }
+          ok = only_slot(rec, &nt) == (p ^ 1u) && i < lim;
+#ifdef G2S_PROF_A
+          { int okk = ok; asm volatile("" :: "v"(okk)); }
+          ptl = __builtin_amdgcn_s_memtime();
+#endif
         }
+#ifdef G2S_PROF_A
+        { uint64_t bm = __ballot(ok); asm volatile("" :: "s"(bm)); }
+        unsigned long long pt2 = __builtin_amdgcn_s_memtime();
+        ptl = __shfl((int)(ptl - pt0), 0);  // lane 0 always loads (run 0, level 0)
+        pb[0] += ptl; pb[1] += pt2 - pt0 - ptl;
+#endif
         const uint32_t lok = leading_levels(ok, lg);
         if (lok >= (lg == 6u ? 1u : 2u)) {
           const bool act = mine && i < lok;
@@ -292,15 +358,15 @@ __device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ,
           const uint64_t dupm = __ballot(act && !isnew);
           uint32_t first_dup = lok;  // level index of this run's first duplicate
           {
-            uint64_t mm = dupm >> r;  // bits of run r sit at r, r+Rp, ...
-            for (uint32_t q = 0; q < lok; q++) { if ((mm >> (q << lg)) & 1ull) { first_dup = q; break; } }
+            // bits of run r sit at r, r+Rp, ...: keep those, the lowest one is the first duplicate
+            const uint64_t gm = lg == 0 ? ~0ull : lg == 1 ? 0x5555555555555555ull : lg == 2 ? 0x1111111111111111ull
+                                : lg == 3 ? 0x0101010101010101ull : 0x0001000100010001ull;
+            const uint64_t mm = (dupm >> r) & gm;
+            if (mm) first_dup = min(lok, (uint32_t)__builtin_ctzll(mm) >> lg);
           }
           const bool alive = mine && first_dup == lok;
           // expansions: a run that dies at level q was still expanded at levels 0..q
-          const uint32_t myexp = (mine && i == 0) ? (first_dup == lok ? lok : first_dup + 1u) : 0u;
-          uint32_t sumexp = myexp;
-          for (int o = 32; o > 0; o >>= 1) sumexp += (uint32_t)__shfl_xor((int)sumexp, o);
-          xa += sumexp;
+          xa += (uint32_t)__popcll(__ballot(act && i <= first_dup));
           const uint32_t last = (uint32_t)__shfl((int)p, (int)(((lok - 1u) << lg) + r));
           const uint64_t am = __ballot(alive && i == 0);
           lds_sync();
@@ -309,15 +375,28 @@ __device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ,
           lds_sync();
           d += (int)lok - 1;
           st_bulkA++;
+#ifdef G2S_PROF_A
+          pa[0] += __builtin_amdgcn_s_memtime() - pt0;
+#endif
           if (nb == 0) break;  // border empty and no seed left (d > rmf)
           continue;
         }
+#ifdef G2S_PROF_A
+        { unsigned long long t = __builtin_amdgcn_s_memtime(); pa[1] += t - pt0; pt0 = t; pn_fail++; }
+#endif
       }
       st_slowA++;
+#ifdef G2S_PROF_A
+      const bool was_wide = nb > 16;
+#endif
       xa += nb;
       if (nb > 16) {
         // wide border: one border node per lane, its whole 16 B record in one load (a single
-        // HBM round trip for the level), then the four predecessor slots in turn
+        // HBM round trip for the level).  Most slots are empty, so the valid predecessors are
+        // first compacted into an LDS list (the merge table of phase B is idle during phase A)
+        // and then inserted 64 at a time: about one insert round per 64 border nodes, not four.
+        uint32_t* cand = (uint32_t*)lh;  // 4F words
+        uint32_t ncand = 0;
         for (uint32_t e0 = 0; e0 < nb; e0 += 64u) {
           const bool valid = e0 + (uint32_t)lane < nb;
           uint4 rec = make_uint4(G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID);
@@ -325,20 +404,27 @@ __device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ,
 #pragma unroll
           for (uint32_t nt = 0; nt < 4; nt++) {
             const uint32_t p = flip(nt == 0 ? rec.x : nt == 1 ? rec.y : nt == 2 ? rec.z : rec.w);
-            uint32_t isnew = 0;
-            if (p != G2S_DEV_INVALID) {
-              const uint32_t r = lrs_insert<RSG>(rs, rmask, p);
-              isnew = r & 1u;
-              if (r & 2u) flags |= G2S_DEV_Q7_A;
-              if (r & 4u) flags |= G2S_DEV_OVERFLOW_A;
-            }
-            const uint64_t m = __ballot(isnew);
-            if (isnew) {
-              const uint32_t off = nnew + (uint32_t)__popcll(m & lanes_below(lane));
-              if (off < F) fnxt[off] = p;
-            }
-            nnew += (uint32_t)__popcll(m);
+            const uint64_t m = __ballot(p != G2S_DEV_INVALID);
+            if (p != G2S_DEV_INVALID) cand[ncand + (uint32_t)__popcll(m & lanes_below(lane))] = p;
+            ncand += (uint32_t)__popcll(m);
           }
+        }
+        lds_sync();
+        for (uint32_t c0 = 0; c0 < ncand; c0 += 64u) {
+          const uint32_t p = c0 + (uint32_t)lane < ncand ? cand[c0 + (uint32_t)lane] : G2S_DEV_INVALID;
+          uint32_t isnew = 0;
+          if (p != G2S_DEV_INVALID) {
+            const uint32_t r = lrs_insert<RSG>(rs, rmask, p);
+            isnew = r & 1u;
+            if (r & 2u) flags |= G2S_DEV_Q7_A;
+            if (r & 4u) flags |= G2S_DEV_OVERFLOW_A;
+          }
+          const uint64_t m = __ballot(isnew);
+          if (isnew) {
+            const uint32_t off = nnew + (uint32_t)__popcll(m & lanes_below(lane));
+            if (off < F) fnxt[off] = p;
+          }
+          nnew += (uint32_t)__popcll(m);
         }
       } else
       for (uint32_t i0 = 0; i0 < nb * 4u; i0 += 64u) {
@@ -383,10 +469,15 @@ __device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ,
       }
       cur ^= 1u;
       nb = nnew;
+#ifdef G2S_PROF_A
+      { unsigned long long t = __builtin_amdgcn_s_memtime(); pa[was_wide ? 3 : 2] += t - pt0; pn_wide += was_wide; }
+#endif
       if (nb == 0 && d >= gd.rmf) break;
     }
     if (overflow) flags |= G2S_DEV_OVERFLOW_A;
   }
+  lds_sync();
+  for (uint32_t i = (uint32_t)lane; i < LH; i += 64u) lh[i] = G2S_DEV_EMPTY64;  // phase A used it as scratch
   lds_sync();
 
   const unsigned long long cyc1 = __builtin_amdgcn_s_memtime();
@@ -411,6 +502,7 @@ __device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ,
         if (tgt[j] == fn[0]) { const uint32_t idx = misc[0]++; th_j[idx] = (uint32_t)j; th_d[idx] = 0; th_c[idx] = 1; }
     }
     lds_sync();
+    nhit = misc[0];
     int d = 1, lvl_written = 1;  // lvl[0..lvl_written] hold valid offsets
     uint32_t bulk_epoch = 0x80000000u;  // tags merge-table entries of bulk steps; never equals a depth
     for (; d <= gd.D; d++) {
@@ -420,6 +512,10 @@ __device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ,
       uint32_t* cnxt = fc + (cur ^ 1u) * F;
       const bool unpruned = d < gd.prune_from;  // :1050 first disjunct
       uint32_t nnew = 0;
+#ifdef G2S_PROF_A
+      unsigned long long qt0 = __builtin_amdgcn_s_memtime();
+      int qcat = 0;
+#endif
       // ---- bulk step: every border state (<= 16 of them) sits inside a unitig, where the
       // only successor of id v is v+2 (even orientation) or v-2 (odd), see dbg.hpp.
       // Lanes are level-major: lane = i*Rp + r handles run r at level d+i.  Each lane
@@ -452,7 +548,7 @@ __device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ,
         }
         uint32_t lrun = leading_levels(ok, lg);
         if (lrun > L) lrun = L;
-        if (lrun >= (lg == 6u ? 1u : 2u) && nlog + lrun * R <= cap && misc[0] + 64u <= TH) {
+        if (lrun >= (lg == 6u ? 1u : 2u) && nlog + lrun * R <= cap && nhit + 64u <= TH) {
           const bool act = mine && i < lrun;
           if (act && R > 1) {
             // Q7: the other strand of my k-mer on another run at this level.  All states of the
@@ -472,16 +568,8 @@ __device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ,
             }
           }
           bulk_epoch++;
-          if (act && ((tbloom >> (mix32(v) & 63u)) & 1ull)) {
-            for (int j = 0; j <= gd.rmf; j++) {
-              if (tgt[j] == v) {
-                const uint32_t idx = atomicAdd(&misc[0], 1u);
-                if (idx < TH) { th_j[idx] = (uint32_t)j; th_d[idx] = (uint32_t)d + i; th_c[idx] = np; }
-              }
-            }
-          }
-          lds_sync();
-          if (misc[0] > TH) { overflow = true; flags |= G2S_DEV_WHY_HITS; break; }
+          note_targets(act, v, (uint32_t)d + i, np);
+          if (nhit > TH) { overflow = true; flags |= G2S_DEV_WHY_HITS; break; }
           // phase C for the levels of the run, one lane (r == 0) per level (:1107-1159)
           if (!found) {
             const int dl = d + (int)i;
@@ -489,7 +577,7 @@ __device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ,
             uint32_t c1 = 0, c2 = 0;
             if (r == 0 && i < lrun && dl >= gd.g + gd.lmf + gd.rmf) {
               const int err = dl - gd.g - (gd.lmf + gd.rmf);
-              const uint32_t nth = min(misc[0], TH);
+              const uint32_t nth = min(nhit, TH);
               for (uint32_t t = 0; t < nth; t++) {
                 const int tj = (int)th_j[t], td = (int)th_d[t];
                 const int l1 = gd.g + gd.lmf + tj + err, l2 = gd.g + gd.lmf + tj - err;
@@ -531,12 +619,22 @@ __device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ,
           lds_sync();
           d += (int)lrun - 1;
           st_bulkB++;
+#ifdef G2S_PROF_A
+          pc[0] += __builtin_amdgcn_s_memtime() - qt0; pnB[0]++;
+#endif
           if (found && !gd.all_paths) break;  // (:1156-1158)
           continue;
         }
+#ifdef G2S_PROF_A
+        { unsigned long long t = __builtin_amdgcn_s_memtime(); pc[1] += t - qt0; qt0 = t; pnB[1]++; }
+#endif
       }
       st_slowB++;
       xb += nb;
+#ifdef G2S_PROF_A
+      qcat = nb == 1 ? 2 : nb <= 16 ? 3 : 4;
+      unsigned long long qt1 = __builtin_amdgcn_s_memtime();
+#endif
       if (nb == 1) {
         // single-entry frontier: its <=4 successors are distinct, no merging needed
         const uint32_t n = ncur[0];
@@ -558,82 +656,96 @@ __device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ,
           if (pass && op && o == (v ^ 1u)) flags |= G2S_DEV_Q7_B;
         }
       } else if (nb > 1) {
-        // Per-level step with merging.  Narrow borders use 4 lanes per entry (one 16 B record
-        // = one coalesced 4-lane access); wide borders use one entry per lane with the whole
-        // record in one load, so a level costs one HBM round trip whatever its width.
-        const bool wide = nb > 16;
-        const uint32_t rounds = wide ? 4u : 1u;
-        for (uint32_t e0 = 0; e0 < (wide ? nb : 1u); e0 += 64u) {  // chunks of 64 border entries (wide) / one pass
-          uint32_t hh[4] = {0, 0, 0, 0}, vv[4];
-          uint32_t np = 0;
-          uint4 rec = make_uint4(G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID);
-          if (wide) {
-            const uint32_t e = e0 + (uint32_t)lane;
-            if (e < nb) { rec = *(const uint4*)(succ + (size_t)ncur[e] * 4); np = ccur[e]; }
-          } else {
-            const uint32_t i = (uint32_t)lane;
-            if (i < nb * 4u) {
-              rec.x = succ[(size_t)ncur[i >> 2] * 4 + (i & 3u)];
-              np = ccur[i >> 2];
-            }
-          }
-          if (np > G2S_DEV_MAX_PATHS) np = G2S_DEV_MAX_PATHS;
-          // pass 1: claim (depth, node) in the merge table; stale entries of older levels count as free
-#pragma unroll
-          for (uint32_t q = 0; q < 4; q++) {
-            if (q >= rounds) break;
-            const uint32_t v = q == 0 ? rec.x : q == 1 ? rec.y : q == 2 ? rec.z : rec.w;
-            vv[q] = G2S_DEV_INVALID;
-            const bool pass = v != G2S_DEV_INVALID && (unpruned || lrs_has_kmer<RSG>(rs, rmask, v));
-            uint32_t h = 0, won = 0;
-            if (pass) {
-              vv[q] = v;
-              const uint64_t key = ((uint64_t)(uint32_t)d << 32) | v;
-              h = mix32(v) & (LH - 1u);
-              while (true) {
-                const uint64_t c = lh[h];
-                if ((uint32_t)(c >> 32) == (uint32_t)d) {
-                  if ((uint32_t)c == v) break;          // already claimed at this level
-                  h = (h + 1) & (LH - 1u);              // other node of this level: probe on
-                  continue;
-                }
-                const unsigned long long old =
-                    atomicCAS((unsigned long long*)&lh[h], (unsigned long long)c, (unsigned long long)key);
-                if (old == c) { won = 1; break; }       // else somebody changed the slot: look again
-              }
-            }
-            hh[q] = h;
-            const uint64_t m = __ballot(won);
-            if (won) {
-              const uint32_t off = nnew + (uint32_t)__popcll(m & lanes_below(lane));
-              lhslot[h] = off < F ? off : 0u;
-              if (off < F) { nnxt[off] = v; cnxt[off] = 0; }
-            }
-            nnew += (uint32_t)__popcll(m);
-            if (nnew > F) break;  // keeps the merge table (2F slots) from filling up: at most F + 64 claims
-          }
-          lds_sync();
-          if (nnew > F) break;
-          // pass 2: <=4 predecessors x <=MAX_PATHS each: the u32 sum cannot wrap (:1058-1060).
-          // Q7: is the other strand of my k-mer a state of this level too?
-#pragma unroll
-          for (uint32_t q = 0; q < 4; q++) {
-            if (q >= rounds || vv[q] == G2S_DEV_INVALID) continue;
-            atomicAdd(&cnxt[lhslot[hh[q]]], np);
-            const uint32_t o = vv[q] ^ 1u;
-            uint32_t h = mix32(o) & (LH - 1u);
+        // Per-level step with merging.  One round takes up to 64 candidate states (node, count
+        // of the expanded border state), one per lane:
+        //   * claim (depth, node) in the merge table — stale entries of older levels count as
+        //     free, so the table is never cleared; the hash is taken over the k-mer index, so
+        //     both strands of a k-mer probe the same slots and Q7 is seen on the way;
+        //   * the winner of a claim appends the node to the next border, every claimant adds
+        //     its count (<= 4 predecessors x <= MAX_PATHS: the u32 sum cannot wrap, :1058-1060).
+        auto merge_round = [&](uint32_t v, uint32_t np) {
+          const bool pass = v != G2S_DEV_INVALID && (unpruned || lrs_has_kmer<RSG>(rs, rmask, v));  // :1050
+          uint32_t h = 0, won = 0;
+          if (pass) {
+            const uint64_t key = ((uint64_t)(uint32_t)d << 32) | v;
+            h = mix32(v >> 1) & (LH - 1u);
             while (true) {
               const uint64_t c = lh[h];
-              if ((uint32_t)(c >> 32) != (uint32_t)d) break;
-              if ((uint32_t)c == o) { flags |= G2S_DEV_Q7_B; break; }
-              h = (h + 1) & (LH - 1u);
+              if ((uint32_t)(c >> 32) == (uint32_t)d) {
+                const uint32_t cv = (uint32_t)c;
+                if (cv == v) break;                         // already claimed at this level
+                if ((cv ^ v) == 1u) flags |= G2S_DEV_Q7_B;  // the other strand is a state of this level
+                h = (h + 1) & (LH - 1u);
+                continue;
+              }
+              const unsigned long long old =
+                  atomicCAS((unsigned long long*)&lh[h], (unsigned long long)c, (unsigned long long)key);
+              if (old == c) { won = 1; break; }             // else somebody changed the slot: look again
             }
           }
+          const uint64_t m = __ballot(won);
+          if (won) {
+            const uint32_t off = nnew + (uint32_t)__popcll(m & lanes_below(lane));
+            lhslot[h] = off < F ? off : 0u;
+            if (off < F) { nnxt[off] = v; cnxt[off] = 0; }
+          }
+          nnew += (uint32_t)__popcll(m);
           lds_sync();
+          if (nnew > F) return;  // keeps the merge table (2F slots) from filling up: at most F + 64 claims
+          if (pass) atomicAdd(&cnxt[lhslot[h]], np);
+        };
+        if (nb <= 16) {
+          // narrow border: 4 lanes per entry, one per successor slot (one coalesced 16 B access)
+          uint32_t v = G2S_DEV_INVALID, np = 0;
+          if ((uint32_t)lane < nb * 4u) {
+            v = succ[(size_t)ncur[(uint32_t)lane >> 2] * 4 + ((uint32_t)lane & 3u)];
+            np = ccur[(uint32_t)lane >> 2];
+          }
+          if (np > G2S_DEV_MAX_PATHS) np = G2S_DEV_MAX_PATHS;
+#ifdef G2S_PROF_A
+          { uint32_t t = v + np; asm volatile("" :: "v"(t)); }
+          { unsigned long long t = __builtin_amdgcn_s_memtime(); pd[0] += t - qt1; qt1 = t; }
+#endif
+          merge_round(v, np);
+        } else {
+          // wide border: one entry per lane with its whole record in one load (a level costs
+          // one HBM round trip whatever its width); most slots are empty, so the valid
+          // successors of 64 entries are compacted through LDS and merged 64 per round.
+          for (uint32_t e0 = 0; e0 < nb && nnew <= F; e0 += 64u) {
+            const uint32_t e = e0 + (uint32_t)lane;
+            uint4 rec = make_uint4(G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID);
+            uint32_t np = 0;
+            if (e < nb) { rec = *(const uint4*)(succ + (size_t)ncur[e] * 4); np = ccur[e]; }
+            if (np > G2S_DEV_MAX_PATHS) np = G2S_DEV_MAX_PATHS;
+            uint32_t ncand = 0;
+#pragma unroll
+            for (uint32_t q = 0; q < 4; q++) {
+              const uint32_t v = q == 0 ? rec.x : q == 1 ? rec.y : q == 2 ? rec.z : rec.w;
+              const uint64_t m = __ballot(v != G2S_DEV_INVALID);
+              if (v != G2S_DEV_INVALID) {
+                const uint32_t at = ncand + (uint32_t)__popcll(m & lanes_below(lane));
+                cw_v[at] = v;
+                cw_c[at] = np;
+              }
+              ncand += (uint32_t)__popcll(m);
+            }
+            lds_sync();
+            for (uint32_t c0 = 0; c0 < ncand && nnew <= F; c0 += 64u) {
+              const uint32_t c = c0 + (uint32_t)lane;
+              merge_round(c < ncand ? cw_v[c] : G2S_DEV_INVALID, c < ncand ? cw_c[c] : 0u);
+            }
+            lds_sync();
+          }
         }
+#ifdef G2S_PROF_A
+        if (qcat == 3) { unsigned long long t = __builtin_amdgcn_s_memtime(); pd[1] += t - qt1; qt1 = t; }
+#endif
       }
       if (nnew > F) { overflow = true; flags |= G2S_DEV_WHY_FRONTIER; break; }
       lds_sync();
+#ifdef G2S_PROF_A
+      if (qcat == 3) { unsigned long long t = __builtin_amdgcn_s_memtime(); pd[2] += t - qt1; qt1 = t; }
+#endif
       if (d <= gd.lmf) {  // next left-flank seed, row value ASSIGNED 1 (:1082-1105)
         const uint32_t s = lseeds[d];
         if (s != G2S_DEV_INVALID) {
@@ -655,32 +767,30 @@ __device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ,
       }
       // append the level to the state log (fire and forget) and note target k-mers
       if (nlog + nnew > cap) { overflow = true; flags |= G2S_DEV_WHY_LOG; break; }
-      for (uint32_t e = (uint32_t)lane; e < nnew; e += 64u) {
-        const uint32_t node = nnxt[e];
-        uint32_t c = cnxt[e];
+      for (uint32_t e0 = 0; e0 < nnew; e0 += 64u) {
+        const uint32_t e = e0 + (uint32_t)lane;
+        const bool have = e < nnew;
+        const uint32_t node = have ? nnxt[e] : 0u;
+        uint32_t c = have ? cnxt[e] : 0u;
         if (c > G2S_DEV_MAX_PATHS) c = G2S_DEV_MAX_PATHS;
-        log[nlog + e] = ((uint64_t)node << 32) | c;
-        if ((tbloom >> (mix32(node) & 63u)) & 1ull) {
-          for (int j = 0; j <= gd.rmf; j++) {
-            if (tgt[j] == node) {
-              const uint32_t idx = atomicAdd(&misc[0], 1u);
-              if (idx < TH) { th_j[idx] = (uint32_t)j; th_d[idx] = (uint32_t)d; th_c[idx] = c; }
-            }
-          }
-        }
+        if (have) log[nlog + e] = ((uint64_t)node << 32) | c;
+        note_targets(have, node, (uint32_t)d, c);
       }
       nlog += nnew;
       if (lane == 0) lvl[d + 1] = nlog;
       lvl_written = d + 1;
       lds_sync();
-      if (misc[0] > TH) { overflow = true; flags |= G2S_DEV_WHY_HITS; break; }
+      if (nhit > TH) { overflow = true; flags |= G2S_DEV_WHY_HITS; break; }
       cur ^= 1u;
       nb = nnew;
+#ifdef G2S_PROF_A
+      if (qcat == 3) { unsigned long long t = __builtin_amdgcn_s_memtime(); pd[3] += t - qt1; qt1 = t; }
+#endif
 
       // ---- phase C: target check (:1107-1159) over the recorded hits ---------------
       if (!found && d >= gd.g + gd.lmf + gd.rmf) {
         const int err = d - gd.g - (gd.lmf + gd.rmf);
-        const uint32_t nth = misc[0];
+        const uint32_t nth = nhit;
         int bestj = 1 << 30;
         uint32_t c1 = 0, c2 = 0;
         for (uint32_t t0 = 0; t0 < nth; t0 += 64u) {
@@ -715,6 +825,9 @@ __device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ,
         }
         if (found && !gd.all_paths) break;  // -best-only (:1156-1158)
       }
+#ifdef G2S_PROF_A
+      { unsigned long long t = __builtin_amdgcn_s_memtime(); pc[qcat] += t - qt0; pnB[qcat]++; if (qcat == 3) pd[4] += t - qt1; }
+#endif
       // nothing left to expand, no seed to come and nothing more to find: the remaining
       // levels of the reference's loop are empty
       if (nb == 0 && d > gd.lmf && found) { d = gd.D + 1; break; }
@@ -729,6 +842,16 @@ __device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ,
     const unsigned long long cyc2 = __builtin_amdgcn_s_memtime();
     go->stat[0] = st_slowA; go->stat[1] = st_bulkA; go->stat[2] = st_slowB; go->stat[3] = st_bulkB;
     go->stat[4] = (uint32_t)((cyc1 - cyc0) >> 8); go->stat[5] = (uint32_t)((cyc2 - cyc1) >> 8);
+#ifdef G2S_PROF_A
+    for (int q = 0; q < 4; q++) go->prof[q] = (uint32_t)(pa[q] >> 8);
+    go->prof[4] = (uint32_t)(pb[0] >> 8); go->prof[5] = (uint32_t)(pb[1] >> 8);
+    go->prof[6] = pn_fail | (pn_wide << 16);
+    for (int q = 0; q < 5; q++) go->prof[8 + q] = (uint32_t)(pc[q] >> 8);
+    go->prof[13] = pnB[1] | (pnB[4] << 16); go->prof[14] = pnB[2] | (pnB[3] << 16);
+    go->prof[7] = (uint32_t)(pd[0] >> 8); go->prof[15] = (uint32_t)(pd[1] >> 8);
+    go->stat[0] = (uint32_t)(pd[2] >> 8); go->stat[1] = (uint32_t)(pd[3] >> 8); go->stat[2] = (uint32_t)(pd[4] >> 8);
+
+#endif
     go->flags = flags;
     go->n_right = nvis;
     go->x_right = xa;
@@ -1088,7 +1211,7 @@ __global__ __launch_bounds__(64) void g2s_extract_lds(const uint32_t* __restrict
 namespace g2s {
 
 size_t fill_lds_bytes(uint32_t rs_cap, uint32_t fcap) {
-  return 4u * (2 * fcap * 3 + (2 * fcap) * 2 + (2 * fcap) + LDS_TG + 3 * (2 * fcap) + 4 + rs_cap);
+  return 4u * (2 * fcap * 3 + (2 * fcap) * 2 + (2 * fcap) + LDS_TG + 3 * (2 * fcap) + 4 + LDS_TF + 2 * LDS_CW + rs_cap);
 }
 size_t extract_lds_bytes(uint32_t fcap) {
   const uint32_t w = fcap > 256u ? fcap : 256u;

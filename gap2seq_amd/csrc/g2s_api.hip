@@ -766,6 +766,16 @@ int batch_stage1(g2s_batch* b) {
         fprintf(stderr, "[g2s] pass %d slow gap %u: g %d | A per-level %u bulk %u kcyc %u | B per-level %u bulk %u kcyc %u | D1 per-level %u bulk %u kcyc %u | xA %u xB %u xD %u\n",
                 pass, ord[q], b->jobs[ord[q]].g, o.stat[0], o.stat[1], o.stat[4] >> 2, o.stat[2], o.stat[3], o.stat[5] >> 2,
                 o.stat[6] & 0xFFFF, o.stat[6] >> 16, o.stat[7] >> 2, o.x_right, o.x_left, o.x_sub);
+#ifdef G2S_PROF_A
+        fprintf(stderr, "[g2s]   prof A (kcyc): bulk ok %u | bulk fail %u (n %u) | narrow %u | wide %u (n %u) || bulk attempts: load wait %u, checks %u\n",
+                o.prof[0] >> 2, o.prof[1] >> 2, o.prof[6] & 0xFFFF, o.prof[2] >> 2, o.prof[3] >> 2, o.prof[6] >> 16,
+                o.prof[4] >> 2, o.prof[5] >> 2);
+        fprintf(stderr, "[g2s]   prof B (kcyc): bulk ok %u | bulk fail %u (n %u) | single %u (n %u) | narrow %u (n %u) | wide %u (n %u)\n",
+                o.prof[8] >> 2, o.prof[9] >> 2, o.prof[13] & 0xFFFF, o.prof[10] >> 2, o.prof[14] & 0xFFFF, o.prof[11] >> 2,
+                o.prof[14] >> 16, o.prof[12] >> 2, o.prof[13] >> 16);
+        fprintf(stderr, "[g2s]   prof B narrow (kcyc): load+prune %u | claim %u | pass2 %u | seed+append+hits %u | phase C %u\n",
+                o.prof[7] >> 2, o.prof[15] >> 2, o.stat[0] >> 2, o.stat[1] >> 2, o.stat[2] >> 2);
+#endif
       }
     }
   }
