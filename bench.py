@@ -67,6 +67,7 @@ def main():
                     help="sessions per GPU; >1 (or --group) times g2s_team_fill: groups of gaps pipelined over the "
                          "sessions, host flank lookup + upload INSIDE the timed region")
     ap.add_argument("--group", type=int, default=0, help="gaps per group for --sessions (0 = library default)")
+    ap.add_argument("--host-threads", type=int, default=0, help="host worker threads per session (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the barrier/timing reduction")
     ap.add_argument("--share-device", action="store_true",
@@ -103,7 +104,7 @@ def main():
     t0 = time.time()
     graph.upload(local_rank)
     t_upload = time.time() - t0
-    sess = P.Session(graph, local_rank, d_err=args.dist_error, randseed=1)
+    sess = P.Session(graph, local_rank, d_err=args.dist_error, randseed=1, host_threads=args.host_threads)
     batch = sess.prepare([P.Gap(g["left"], g["right"], g["gap_len"], g["lmf"], g["rmf"]) for g in gaps])
 
     def sync_all():

@@ -6,6 +6,8 @@
 // (/root/reference/src/Gap2Seq.cpp:252,380 -> :858).  No CPU fallback: without a
 // usable gfx950 device every fill entry point fails with G2S_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
+#include <pthread.h>
+#include <sched.h>
 
 #include <algorithm>
 #include <atomic>
@@ -238,61 +240,138 @@ struct TierData {  // what came back from one launch group (pinned buffers live 
 };
 }  // namespace
 
+// CPUs this process may actually use: the affinity mask, capped by the cgroup CPU quota
+// (cpu.max) when there is one — a 256-thread host often hands a container 16 CPUs' worth.
+static int usable_cpus() {
+  int n = (int)std::thread::hardware_concurrency();
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::min(n, CPU_COUNT(&set));
+  if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char q[32];
+    long long period = 0;
+    if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0)
+      n = std::min(n, (int)std::max(1ll, (atoll(q) + period - 1) / period));
+    fclose(f);
+  } else {
+    long long quota = -1, period = 0;
+    if (FILE* fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(fq, "%lld", &quota) != 1) quota = -1; fclose(fq); }
+    if (FILE* fp2 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(fp2, "%lld", &period) != 1) period = 0; fclose(fp2); }
+    if (quota > 0 && period > 0) n = std::min(n, (int)std::max(1ll, (quota + period - 1) / period));
+  }
+  return std::max(1, n);
+}
+
+// CPUs of the NUMA node the calling thread runs on, intersected with its affinity mask.
+static bool local_node_cpus(cpu_set_t* out) {
+  const int cpu = sched_getcpu();
+  cpu_set_t allowed;
+  if (cpu < 0 || sched_getaffinity(0, sizeof allowed, &allowed) != 0) return false;
+  for (int node = 0; node < 64; node++) {
+    char path[96];
+    snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+    FILE* f = fopen(path, "r");
+    if (!f) return false;  // no more nodes: not found
+    char buf[4096];
+    const bool got = fgets(buf, sizeof buf, f) != nullptr;
+    fclose(f);
+    if (!got) continue;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    bool mine = false;
+    for (char* tok = strtok(buf, ",\n"); tok; tok = strtok(nullptr, ",\n")) {
+      int a = 0, b = 0;
+      if (sscanf(tok, "%d-%d", &a, &b) == 2) {}
+      else if (sscanf(tok, "%d", &a) == 1) b = a;
+      else continue;
+      for (int c = a; c <= b && c < CPU_SETSIZE; c++) {
+        if (CPU_ISSET(c, &allowed)) CPU_SET(c, &set);
+        if (c == cpu) mine = true;
+      }
+    }
+    if (mine) {
+      if (CPU_COUNT(&set) < 2) return false;
+      *out = set;
+      return true;
+    }
+  }
+  return false;
+}
+
 // Persistent host workers for the per-gap post-processing (spawning threads per
 // batch costs more than the work at 500 gaps per batch).
 class WorkerPool {
  public:
   explicit WorkerPool(int nthreads) {
     for (int t = 0; t < nthreads; t++) th_.emplace_back([this]() { loop(); });
+    // keep the workers on the NUMA node of the thread that owns the session: the closures
+    // they read were copied into pinned memory of that node, and what they write is read
+    // back by that thread
+    cpu_set_t node;
+    if (!getenv("G2S_NO_NUMA_BIND") && local_node_cpus(&node))
+      for (auto& t : th_) pthread_setaffinity_np(t.native_handle(), sizeof node, &node);
   }
   ~WorkerPool() {
-    { std::lock_guard<std::mutex> lk(mu_); stop_ = true; gen_++; }
+    { std::lock_guard<std::mutex> lk(mu_); stop_ = true; gen_.fetch_add(1); }
     cv_.notify_all();
     for (auto& t : th_) t.join();
   }
   int size() const { return (int)th_.size(); }
-  // f(i) for i in [0,n); the calling thread helps
+  // f(i) for i in [0,n); the calling thread helps.  Completion is counted in tasks, not in
+  // workers: a worker that wakes up late finds nothing to do and nobody waits for it.
   void run(size_t n, const std::function<void(size_t)>& f) {
     if (n == 0) return;
+    uint64_t g;
     {
       std::lock_guard<std::mutex> lk(mu_);
-      fn_ = &f; n_ = n; next_.store(0); pending_ = (int)th_.size(); gen_++;
+      fn_ = &f; n_ = n; done_.store(0);
+      g = gen_.load() + 1;
+      next_.store(g << 32);  // the generation tags every ticket: stale workers cannot take one
+      gen_.store(g);
     }
     cv_.notify_all();
-    drain();
-    std::unique_lock<std::mutex> lk(mu_);
-    done_.wait(lk, [this]() { return pending_ == 0; });
-    fn_ = nullptr;
+    drain(g, n, &f);
+    // tail of the last tasks (a few microseconds): the only place a thread waits without sleeping
+    while (done_.load(std::memory_order_acquire) != n) __builtin_ia32_pause();
   }
  private:
-  void drain() {
+  void drain(uint64_t g, size_t n, const std::function<void(size_t)>* f) {
+    size_t mine = 0;
+    uint64_t t = next_.load(std::memory_order_acquire);
     while (true) {
-      const size_t i = next_.fetch_add(1);
-      if (i >= n_) break;
-      (*fn_)(i);
+      // a ticket is only taken when it belongs to this generation (a plain fetch_add by a
+      // late worker would swallow a ticket of the next run)
+      if ((t >> 32) != (g & 0xFFFFFFFFull) || (t & 0xFFFFFFFFull) >= n) break;
+      if (!next_.compare_exchange_weak(t, t + 1, std::memory_order_acq_rel)) continue;
+      (*f)((size_t)(t & 0xFFFFFFFFull));
+      mine++;
+      t = next_.load(std::memory_order_acquire);
     }
+    if (mine) done_.fetch_add(mine, std::memory_order_acq_rel);
   }
   void loop() {
     uint64_t seen = 0;
     while (true) {
+      uint64_t g;
+      size_t n;
+      const std::function<void(size_t)>* f;
       {
         std::unique_lock<std::mutex> lk(mu_);
-        cv_.wait(lk, [&]() { return gen_ != seen; });
-        seen = gen_;
+        cv_.wait(lk, [&]() { return gen_.load() != seen; });
         if (stop_) return;
+        g = gen_.load(); n = n_; f = fn_;
       }
-      drain();
-      { std::lock_guard<std::mutex> lk(mu_); if (--pending_ == 0) done_.notify_all(); }
+      seen = g;
+      drain(g, n, f);
     }
   }
   std::vector<std::thread> th_;
   std::mutex mu_;
-  std::condition_variable cv_, done_;
+  std::condition_variable cv_;
   const std::function<void(size_t)>* fn_ = nullptr;
   size_t n_ = 0;
-  std::atomic<size_t> next_{0};
-  int pending_ = 0;
-  uint64_t gen_ = 0;
+  std::atomic<uint64_t> next_{0};
+  std::atomic<size_t> done_{0};
+  std::atomic<uint64_t> gen_{0};
   bool stop_ = false;
 };
 
@@ -304,6 +383,7 @@ struct RandCache {
   void ensure(size_t n) { st.ensure(n); }  // at least n upcoming values materialised
   int32_t at(size_t off) { st.ensure(off + 1); return st.value(off); }
   const uint32_t* ptr(size_t off) const { return st.raw() + off; }
+  int32_t at_const(size_t off) const { return st.value(off); }  // already materialised
   void consume(size_t n) { st.consume(n); }
 };
 
@@ -345,8 +425,11 @@ extern "C" int g2s_session_create(g2s_graph* g, int device, const g2s_params* p,
   if (e != hipSuccess) { delete s; return fail(G2S_ERR_HIP, std::string("session setup: ") + hipGetErrorString(e)); }
   s->mem_budget = (size_t)((double)free_b * 0.6);
   {
-    int nth = p->host_threads > 0 ? p->host_threads : (int)std::thread::hardware_concurrency();
-    nth = std::max(1, std::min(nth, 32));
+    int nth = p->host_threads > 0 ? p->host_threads : usable_cpus();
+    // default cap 32: beyond that the wake-up of the pool costs more than it saves at 500 gaps
+    // per batch; an explicit host_threads is honoured up to 256
+    nth = std::max(1, std::min(nth, p->host_threads > 0 ? 256 : 32));
+    if (p->host_threads <= 0) nth = std::max(nth, std::min(32, 2 * nth));  // short bursts: a CPU quota is an average
     s->pool = new WorkerPool(nth - 1);
   }
   *out = s;
@@ -387,6 +470,17 @@ struct g2s_batch {
   std::vector<SubView> views;
   std::vector<SubPrep> prep;
   std::vector<char> mem_exceeded;
+  // per gap, written by the parallel analysis and read by the in-order offset pass (16 B per
+  // gap, contiguous: the sequential part of a batch touches nothing else)
+  struct GapInfo {
+    int32_t fixed[2];   // draws when pathLengths[pick] is chosen, or -1 when that depends on the draws
+    int16_t n_len;      // 0: no phase D
+    int16_t reached_j;
+    uint8_t kind;       // 0 normal, 1 bad flank, 2 -max-mem verdict
+    uint8_t filled;     // count > 0 (&& == 1 with -unique)
+    int16_t skip_thr;   // skip_if_prev_right_fuz_gt clamped to int16 (-1: never skip)
+  };
+  std::vector<GapInfo> info;
   void drop_tiers();
   ~g2s_batch() { if (s) { drop_tiers(); if (s->flank_owner == this) s->flank_owner = nullptr; } }
 };
@@ -670,9 +764,40 @@ FillParams fill_params_of(const g2s_session* s) {
   return fp;
 }
 
-// Stage 1 of a batch: phases A-D1 on the GPU (all passes/tiers) and the per-gap host
-// analysis (D2, stop depths).  Independent of every other batch.
-int batch_stage1(g2s_batch* b) {
+// Everything about gap i that does not depend on the gaps before it: D2 + stop-depth
+// analysis, the order-independent result fields, and the summary the offset pass reads.
+// *r must be zeroed.
+void analyze_gap(g2s_batch* b, size_t i, const FillParams& fp, g2s_result* r) {
+  g2s_batch::GapInfo& gi = b->info[i];
+  gi.fixed[0] = gi.fixed[1] = -1;
+  gi.n_len = 0; gi.reached_j = 0; gi.kind = 0; gi.filled = 0;
+  const GapJob& j = b->jobs[i];
+  gi.skip_thr = (int16_t)std::max(-1, std::min(j.skip_if_prev_right_fuz_gt, 32767));
+  if (j.bad_flank) { gi.kind = 1; r->flags |= G2S_GAP_BAD_FLANK; return; }
+  if (b->mem_exceeded[i]) { gi.kind = 2; r->count = -1; r->flags |= G2S_GAP_MEM_EXCEEDED; return; }
+  const SubView& v = b->views[i];
+  SubPrep& pp = b->prep[i];
+  sub_analyze(fp, j, v, &pp);
+  r->phaseC_count = v.out->c_count;
+  r->n_lengths = v.out->n_len;
+  r->lengths[0] = v.out->len[0];
+  r->lengths[1] = v.out->len[1];
+  if (v.out->flags & (G2S_DEV_Q7_A | G2S_DEV_Q7_B | G2S_DEV_Q7_D)) r->flags |= G2S_GAP_Q7;
+  r->flags |= pp.flags;
+  r->count = pp.count;
+  gi.filled = pp.count > 0 && (!fp.unique_paths || pp.count == 1);
+  if (pp.phase_d) {
+    r->vertices = pp.sub[0]; r->edges = pp.sub[1]; r->nontrivial_components = pp.sub[2];
+    r->size_nontrivial_components = pp.sub[3]; r->vertices_final = pp.sub[4]; r->edges_final = pp.sub[5];
+    gi.n_len = (int16_t)v.out->n_len;
+    gi.reached_j = (int16_t)v.out->reached_j;
+    for (int q = 0; q < v.out->n_len && q < 2; q++) gi.fixed[q] = sub_fixed_draws(v, pp, q);
+  }
+}
+
+// Stage 1 of a batch: phases A-D1 on the GPU (all passes/tiers) and, on request, the per-gap
+// host analysis (D2, stop depths).  Independent of every other batch.
+int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
   g2s_session* s = b->s;
   if (hipSetDevice(s->device) != hipSuccess) return fail(G2S_ERR_NO_DEVICE, "cannot select device");
   const Graph& g = *s->graph->g;
@@ -825,119 +950,152 @@ int batch_stage1(g2s_batch* b) {
     scale *= 8;
   }
 
-  // ---- host: D2 + stop-depth analysis per gap, thread pool ----------------------
-  auto t_post = std::chrono::steady_clock::now();
-  std::vector<SubPrep>& prep = b->prep;
-  prep.assign(n, SubPrep());
-  s->pool->run(n, [&](size_t i) {
-    if (views[i].out) sub_analyze(fp, b->jobs[i], views[i], &prep[i]);
-  });
-  b->timing.ms_host_post = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_post).count();
   b->timing.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+  if (analyze) {
+    // ---- host: D2 + stop-depth analysis per gap, thread pool (teams: per group, so that it
+    // overlaps the other sessions' kernels)
+    auto t_post = std::chrono::steady_clock::now();
+    b->prep.assign(n, SubPrep());
+    b->info.assign(n, g2s_batch::GapInfo());
+    const size_t per = 8, nt = (n + per - 1) / per;
+    s->pool->run(nt, [&](size_t t) {
+      for (size_t i = t * per; i < std::min(n, (t + 1) * per); i++) analyze_gap(b, i, fp, &results[i]);
+    });
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_post).count();
+    b->timing.ms_host_post = ms;
+    b->timing.ms_total += ms;
+  }
   (void)g;
+  (void)views;
   return G2S_OK;
 }
 
-
 // Stage 2 over batches in gap order: assign rand() stream offsets (:178,1440,1513) and run
-// the tracebacks.  A gap whose draw count does not depend on the draws gets its offset in
-// O(1); the others are traced inline.  All remaining tracebacks then run in parallel.
-// results/arena are laid out batch after batch.
+// the tracebacks.  results/arena are laid out batch after batch.
+//   1. (only when `analyze`) per-gap analysis on the pool, chunks of gaps claimed dynamically;
+//   2. the in-order pass on the calling thread: O(1) per gap from the 16-byte GapInfo records
+//      when the number of draws does not depend on the draws (the others are traced inline),
+//      honouring skip_if_prev_right_fuz_gt;
+//   3. tracebacks + fill offsets on the pool.
 int batches_stage2(const std::vector<g2s_batch*>& bs, g2s_session* lead, g2s_result* results, char* arena,
-                   g2s_timing* timing) {
+                   g2s_timing* timing, bool analyze) {
   const Graph& g = *lead->graph->g;
   const FillParams fp = fill_params_of(lead);
-  auto t_ana = std::chrono::steady_clock::now();
+  auto t_begin = std::chrono::steady_clock::now();
   size_t n = 0;
   for (g2s_batch* b : bs) n += b->jobs.size();
+  if (n == 0) return G2S_OK;
   std::vector<size_t> arena_off(n), rand_off(n, 0);
   std::vector<char> todo_tb(n, 0);
   std::vector<g2s_batch*> owner(n);
   std::vector<uint32_t> local(n);
   {
     size_t apos = 0, gi = 0;
-    for (g2s_batch* b : bs)
+    for (g2s_batch* b : bs) {
+      if (analyze) { b->prep.assign(b->jobs.size(), SubPrep()); b->info.assign(b->jobs.size(), g2s_batch::GapInfo()); }
       for (size_t i = 0; i < b->jobs.size(); i++, gi++) {
         arena_off[gi] = apos;
         apos += b->jobs[i].buf_bytes(g.k, fp.d_err);
         owner[gi] = b;
         local[gi] = (uint32_t)i;
       }
-  }
-  size_t draws_total = 0;
-  bool prev_filled = false;
-  int prev_right_fuz = 0;
-  for (size_t gi = 0; gi < n; gi++) {
-    g2s_batch* b = owner[gi];
-    const size_t i = local[gi];
-    const GapJob& j = b->jobs[i];
-    g2s_result& r = results[gi];
-    char* buf = arena + arena_off[gi];
-    r.fill_off = (uint64_t)arena_off[gi] + (uint64_t)j.lmf;
-    if (j.skip_if_prev_right_fuz_gt >= 0 && prev_filled && prev_right_fuz > j.skip_if_prev_right_fuz_gt) {
-      r.flags |= G2S_GAP_SKIPPED;
-      prev_filled = false;
-      continue;
     }
-    if (j.bad_flank) { r.flags |= G2S_GAP_BAD_FLANK; prev_filled = false; continue; }
-    if (b->mem_exceeded[i]) { r.count = -1; r.flags |= G2S_GAP_MEM_EXCEEDED; prev_filled = false; continue; }
-    const SubView& v = b->views[i];
-    const SubPrep& pp = b->prep[i];
-    r.phaseC_count = v.out->c_count;
-    r.n_lengths = v.out->n_len;
-    r.lengths[0] = v.out->len[0];
-    r.lengths[1] = v.out->len[1];
-    if (v.out->flags & (G2S_DEV_Q7_A | G2S_DEV_Q7_B | G2S_DEV_Q7_D)) r.flags |= G2S_GAP_Q7;
-    r.flags |= pp.flags;
-    r.count = pp.count;
-    if (pp.phase_d) {
-      r.vertices = pp.sub[0]; r.edges = pp.sub[1]; r.nontrivial_components = pp.sub[2];
-      r.size_nontrivial_components = pp.sub[3]; r.vertices_final = pp.sub[4]; r.edges_final = pp.sub[5];
-      rand_off[gi] = draws_total;
-      const int pick = (int)(lead->rcache.at(draws_total) % v.out->n_len);
-      const int fixed = sub_fixed_draws(v, pp, pick);
-      if (fixed >= 0) {
-        todo_tb[gi] = 1;
-        r.draws = fixed;
-        r.right_fuz = v.out->reached_j;
-      } else {
-        lead->rcache.ensure(draws_total + (size_t)v.out->len[pick] + 2);
-        sub_traceback(g, fp, j, v, pp, lead->rcache.ptr(draws_total), buf, &r);
+  }
+  const size_t per = 8, nchunks = (n + per - 1) / per;
+  std::atomic<uint64_t> fill_bytes(0);
+  double ms_order = 0, ms_order_loop = 0, ms_ana = 0;
+  size_t n_inline = 0, n_two = 0;
+  size_t draws_used = 0;
+
+  auto in_order_pass = [&]() {
+    auto t0 = std::chrono::steady_clock::now();
+    size_t draws_total = 0;
+    bool prev_filled = false;
+    int prev_right_fuz = 0;
+    for (size_t gi = 0; gi < n; gi++) {
+      g2s_batch* b = owner[gi];
+      const size_t i = local[gi];
+      const g2s_batch::GapInfo& in = b->info[i];
+      if (i + 32 < b->info.size()) __builtin_prefetch(&b->info[i + 32]);  // written by other cores
+      const int skip_thr = in.skip_thr;
+      if (skip_thr >= 0 && prev_filled && prev_right_fuz > skip_thr) {
+        g2s_result& r = results[gi];  // the gap is not attempted at all (:369)
+        memset(&r, 0, sizeof r);
+        r.flags = G2S_GAP_SKIPPED;
+        prev_filled = false;
+        continue;
       }
-      draws_total += (size_t)r.draws;
+      if (in.kind != 0) { prev_filled = false; continue; }
+      int right_fuz = 0;
+      if (in.n_len > 0) {
+        rand_off[gi] = draws_total;
+        const int pick = in.n_len > 1 ? (int)(lead->rcache.at(draws_total) % in.n_len) : 0;
+        int draws = in.fixed[pick];
+        n_two += in.n_len > 1;
+        if (draws >= 0) {
+          todo_tb[gi] = 1;
+          right_fuz = in.reached_j;
+        } else {
+          n_inline++;
+          g2s_result& r = results[gi];
+          const SubView& v = b->views[i];
+          lead->rcache.ensure(draws_total + (size_t)v.out->len[pick] + 2);
+          sub_traceback(g, fp, b->jobs[i], v, b->prep[i], lead->rcache.ptr(draws_total), arena + arena_off[gi], &r);
+          draws = r.draws;
+          right_fuz = r.right_fuz;
+        }
+        draws_total += (size_t)draws;
+      }
+      prev_filled = in.filled != 0;
+      prev_right_fuz = right_fuz;
     }
-    prev_filled = r.count > 0 && (!fp.unique_paths || r.count == 1);
-    prev_right_fuz = r.right_fuz;
-  }
-  auto t_off = std::chrono::steady_clock::now();
-  lead->rcache.ensure(draws_total + 1);
-  lead->pool->run(n, [&](size_t gi) {
-    if (!todo_tb[gi]) return;
-    g2s_result& r = results[gi];
-    g2s_batch* b = owner[gi];
-    const size_t i = local[gi];
-    const int expect = r.draws;
-    sub_traceback(g, fp, b->jobs[i], b->views[i], b->prep[i], lead->rcache.ptr(rand_off[gi]), arena + arena_off[gi], &r);
-    if (r.draws != expect) r.flags |= G2S_GAP_BACKTRACE_FAIL;  // cannot happen: the draw count was proven fixed
+    ms_order_loop = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    lead->rcache.ensure(draws_total + 1);
+    draws_used = draws_total;
+    ms_order = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  };
+
+  // Threads never busy-wait for one another: GPU nodes are usually shared and the process
+  // may run under a CPU quota, where spinning workers get the whole process throttled.
+  if (analyze)
+    lead->pool->run(nchunks, [&](size_t c) {
+      for (size_t gi = c * per; gi < std::min(n, (c + 1) * per); gi++) analyze_gap(owner[gi], local[gi], fp, &results[gi]);
+    });
+  ms_ana = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+  in_order_pass();
+  lead->pool->run(nchunks, [&](size_t c) {
+    uint64_t bytes = 0;
+    for (size_t gi = c * per; gi < std::min(n, (c + 1) * per); gi++) {
+      g2s_result& r = results[gi];
+      const GapJob& j = owner[gi]->jobs[local[gi]];
+      r.fill_off = (uint64_t)arena_off[gi] + (uint64_t)j.lmf;
+      if (todo_tb[gi]) {
+        const g2s_batch* b = owner[gi];
+        const size_t i = local[gi];
+        const g2s_batch::GapInfo& in = b->info[i];
+        const int pick = in.n_len > 1 ? (int)(lead->rcache.at_const(rand_off[gi]) % in.n_len) : 0;
+        const int expect = in.fixed[pick];
+        sub_traceback(g, fp, j, b->views[i], b->prep[i], lead->rcache.ptr(rand_off[gi]), arena + arena_off[gi], &r);
+        if (r.draws != expect) r.flags |= G2S_GAP_BACKTRACE_FAIL;  // cannot happen: the draw count was proven fixed
+      }
+      if (r.flags & G2S_GAP_PHASE_D) {
+        r.fill_off = (uint64_t)arena_off[gi] + (uint64_t)(j.lmf - r.left_fuz);
+        r.fill_len = (int32_t)strlen(arena + r.fill_off);
+        bytes += (uint64_t)r.fill_len;
+      }
+    }
+    if (bytes) fill_bytes.fetch_add(bytes);
   });
-  lead->rcache.consume(draws_total);
-  uint64_t fill_bytes = 0;
-  for (size_t gi = 0; gi < n; gi++) {
-    g2s_result& r = results[gi];
-    if (!(r.flags & G2S_GAP_PHASE_D)) continue;
-    r.fill_off = (uint64_t)arena_off[gi] + (uint64_t)(owner[gi]->jobs[local[gi]].lmf - r.left_fuz);
-    r.fill_len = (int32_t)strlen(arena + r.fill_off);
-    fill_bytes += (uint64_t)r.fill_len;
-  }
+  lead->rcache.consume(draws_used);
   auto t_end = std::chrono::steady_clock::now();
   if (getenv("G2S_DEBUG"))
-    fprintf(stderr, "[g2s] host stage 2: offsets+inline tracebacks %.3f ms, parallel tracebacks %.3f ms (draws %zu)\n",
-            std::chrono::duration<double, std::milli>(t_off - t_ana).count(),
-            std::chrono::duration<double, std::milli>(t_end - t_off).count(), draws_total);
+    fprintf(stderr, "[g2s] host stage 2 (%s analysis): %.3f ms = setup+analysis %.3f + in-order pass %.3f (loop %.3f; %zu gaps traced inline, %zu with two lengths) + tracebacks\n",
+            analyze ? "with" : "after", std::chrono::duration<double, std::milli>(t_end - t_begin).count(), ms_ana, ms_order,
+            ms_order_loop, n_inline, n_two);
   if (timing) {
-    timing->fill_bytes += fill_bytes;
-    timing->ms_host_post += std::chrono::duration<double, std::milli>(t_end - t_ana).count();
-    timing->ms_total += std::chrono::duration<double, std::milli>(t_end - t_ana).count();
+    timing->fill_bytes += fill_bytes.load();
+    timing->ms_host_post += std::chrono::duration<double, std::milli>(t_end - t_begin).count();
+    timing->ms_total += std::chrono::duration<double, std::milli>(t_end - t_begin).count();
   }
   return G2S_OK;
 }
@@ -964,10 +1122,10 @@ extern "C" int g2s_batch_run(g2s_batch* b, g2s_result* results, char* arena, siz
     rand_need += (size_t)(b->jobs[i].g + s->graph->g->k + b->jobs[i].lmf + b->jobs[i].rmf + 2);
   std::thread rand_fill([s, rand_need]() { s->rcache.ensure(rand_need); });
   s->tier_cursor = 0;
-  const int rc = batch_stage1(b);
+  int rc = batch_stage1(b, false, results);
   rand_fill.join();
-  if (rc != G2S_OK) return rc;
-  return batches_stage2(std::vector<g2s_batch*>{b}, s, results, arena, &b->timing);
+  if (rc == G2S_OK) rc = batches_stage2(std::vector<g2s_batch*>{b}, s, results, arena, &b->timing, true);
+  return rc;
 }
 
 // A team of sessions (any mix of devices, several per device allowed) fills one gap list:
@@ -991,6 +1149,12 @@ extern "C" int g2s_team_fill(g2s_session* const* sessions, int nsessions, const 
   std::vector<int> rcs((size_t)nsessions, G2S_OK);
   std::vector<std::string> errs((size_t)nsessions);
   std::atomic<size_t> next(0);
+  {
+    const size_t need = g2s_team_arena_bytes(lead, gaps, n);
+    if (arena_cap < need || (!arena && need)) return fail(G2S_ERR_ARG, "g2s_team_fill: fill arena too small");
+    memset(results, 0, n * sizeof(g2s_result));
+    memset(arena, 0, need);
+  }
   std::thread rand_fill([lead, gaps, n]() { lead->rcache.ensure(rand_need_of(gaps, n, lead->graph->g->k)); });
   auto worker = [&](int t) {
     g2s_session* s = sessions[t];
@@ -1003,7 +1167,7 @@ extern "C" int g2s_team_fill(g2s_session* const* sessions, int nsessions, const 
       auto t0 = std::chrono::steady_clock::now();
       int rc = g2s_batch_prepare(s, gaps + off, cnt, &b);
       auto t1 = std::chrono::steady_clock::now();
-      if (rc == G2S_OK) { subs[gi] = b; rc = batch_stage1(b); }
+      if (rc == G2S_OK) { subs[gi] = b; rc = batch_stage1(b, true, results + off); }
       if (getenv("G2S_DEBUG"))
         fprintf(stderr, "[g2s] team session %d group %zu (%zu gaps): prepare %.3f ms, stage 1 %.3f ms\n", t, gi, cnt,
                 std::chrono::duration<double, std::milli>(t1 - t0).count(),
@@ -1023,12 +1187,7 @@ extern "C" int g2s_team_fill(g2s_session* const* sessions, int nsessions, const 
   g2s_timing total;
   memset(&total, 0, sizeof total);
   if (rc == G2S_OK) {
-    size_t need = 0;
-    for (g2s_batch* b : subs) need += b->arena_bytes;
-    if (arena_cap < need || (!arena && need)) rc = fail(G2S_ERR_ARG, "g2s_team_fill: fill arena too small");
-    if (rc == G2S_OK) {
-      memset(results, 0, n * sizeof(g2s_result));
-      memset(arena, 0, need);
+    {
       for (g2s_batch* b : subs) {
         const g2s_timing& t = b->timing;
         total.ms_right_bfs += t.ms_right_bfs; total.ms_left_dp += t.ms_left_dp; total.ms_extract += t.ms_extract;
@@ -1039,7 +1198,7 @@ extern "C" int g2s_team_fill(g2s_session* const* sessions, int nsessions, const 
         total.retried_gaps += t.retried_gaps; total.x_fill_lds += t.x_fill_lds; total.s_fill_lds += t.s_fill_lds;
         total.lds_tier_gaps += t.lds_tier_gaps; total.lds_launches += t.lds_launches;
       }
-      rc = batches_stage2(subs, lead, results, arena, &total);
+      rc = batches_stage2(subs, lead, results, arena, &total, false);
     }
   }
   for (g2s_batch* b : subs) g2s_batch_free(b);
@@ -1158,6 +1317,22 @@ extern "C" int g2s_test_post_gap(const g2s_graph* gh, const g2s_params* p, const
     res->size_nontrivial_components = prep.sub[3]; res->vertices_final = prep.sub[4]; res->edges_final = prep.sub[5];
     res->fill_off = (uint64_t)(j.lmf - res->left_fuz);
     res->fill_len = (int32_t)strlen(buf + res->fill_off);
+  }
+  return G2S_OK;
+}
+
+extern "C" int g2s_test_worker_pool(int32_t threads, int32_t rounds, int32_t n) {
+  if (threads < 1 || rounds < 0 || n < 0) return fail(G2S_ERR_ARG, "g2s_test_worker_pool: bad argument");
+  WorkerPool pool(threads - 1);
+  std::vector<std::atomic<int>> hits((size_t)n);
+  for (int r = 0; r < rounds; r++) {
+    for (auto& h : hits) h.store(0);
+    std::atomic<long long> sum(0);
+    const int nn = (r % 7 == 0) ? std::min(n, 3) : n;  // rounds shorter than the pool: idle workers arrive late
+    pool.run((size_t)nn, [&](size_t i) { hits[i].fetch_add(1); sum.fetch_add((long long)i + 1); });
+    if (sum.load() != (long long)nn * (nn + 1) / 2) return fail(G2S_ERR_STATE, "worker pool: wrong task sum");
+    for (int i = 0; i < nn; i++)
+      if (hits[(size_t)i].load() != 1) return fail(G2S_ERR_STATE, "worker pool: task not run exactly once");
   }
   return G2S_OK;
 }

@@ -110,6 +110,7 @@ _SIGS = {
     "g2s_synth_gaps": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64,
                                  C.POINTER(_VP)]),
     "g2s_test_rand_stream": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_int32)]),
+    "g2s_test_worker_pool": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
     "g2s_test_post_gap": (C.c_int, [_VP, C.POINTER(g2s_params), C.POINTER(g2s_gap), C.c_int32,
                                     C.POINTER(C.c_uint32), C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.c_int32,
                                     C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_uint32, C.c_uint32,
@@ -420,6 +421,11 @@ def test_post_gap(graph, params, gap, states, c_count, lengths, reached_j, final
     _check(lib.g2s_test_post_gap(graph.h, C.byref(params), arr, n, nodes, depths, counts, c_count, len(lengths), lens,
                                  reached_j, final_d, seed, skip, C.byref(res), buf))
     return FillResult(res, buf.raw)
+
+
+def test_worker_pool(threads, rounds, n):
+    """TEST HOOK binding: stress the host worker pool; raises G2SError on a lost or repeated task."""
+    _check(load_library().g2s_test_worker_pool(threads, rounds, n))
 
 
 def test_rand_stream(seed, skip, n):

@@ -251,6 +251,11 @@ int g2s_test_post_gap(const g2s_graph* g, const g2s_params* p, const g2s_gap* ga
  * (the flat glibc TYPE_3 generator the tracebacks read), for comparison with libc. */
 int g2s_test_rand_stream(uint32_t seed, uint32_t skip, uint32_t n, int32_t* out);
 
+/* TEST HOOK: the host worker pool that runs the per-gap analysis and tracebacks: `rounds`
+ * parallel-for rounds of `n` tasks on `threads` threads (task i adds i+1 to a per-round
+ * sum); returns G2S_OK when every task of every round ran exactly once. */
+int g2s_test_worker_pool(int32_t threads, int32_t rounds, int32_t n);
+
 /* Number of usable gfx950 devices (0 when none / no driver). */
 int g2s_device_count(void);
 

@@ -142,6 +142,15 @@ def test_host_phase_d_matches_oracle_on_oracle_tables(product, oracle, seed):
     assert compared > 10
 
 
+def test_worker_pool_runs_every_task_once(product):
+    """The host pool behind the per-gap analysis/tracebacks: thousands of short parallel-for
+    rounds (some with fewer tasks than threads, so idle workers arrive after the round is
+    over) must run every task exactly once and never stall."""
+    product.test_worker_pool(8, 3000, 40)
+    product.test_worker_pool(16, 500, 1000)
+    product.test_worker_pool(1, 10, 100)
+
+
 def test_product_rand_stream_matches_libc(product):
     """The flat glibc TYPE_3 stream the tracebacks read at precomputed offsets
     (Gap2Seq.cpp:178,1440,1513 use libc rand()), incl. the buffer compaction path."""
