@@ -20,6 +20,12 @@
 #define G2S_DEV_WHY_FRONTIER 0x100u /* a DP level wider than the LDS frontier buffers */
 #define G2S_DEV_WHY_HITS 0x200u     /* more target hits than the LDS list holds       */
 #define G2S_DEV_WHY_LOG 0x400u      /* state log full                                 */
+/* closure from the LDS tier: pred[] of a SubState holds the parents from slot 0 in arrival
+ * order, not in GATB predecessor order (the host orders the few multi-parent states) */
+#define G2S_DEV_PRED_UNORDERED 0x1000u
+/* LDS tier, lvl[]: bit 31 of the END offset of level L = L was produced by a bulk step
+ * (same width as level L-1, state r has the single parent r of level L-1) */
+#define G2S_LVL_UNIFORM 0x80000000u
 
 struct GapDev {
   int32_t g;           // gap_len
@@ -34,10 +40,10 @@ struct GapDev {
   uint32_t rlog_cap;   // right BFS visit log capacity
   uint32_t st_mask;    // state hash: capacity-1
   uint32_t slog_cap;   // state log capacity (<= (st_mask+1)/2)
-  uint32_t pad0;
+  uint32_t pad0;       // LDS tier: capacity of the gap's extra-parent list
   uint64_t rs_off;     // element offsets into the session arrays
   uint64_t rlog_off;
-  uint64_t st_off;
+  uint64_t st_off;     // LDS tier: offset of the gap's extra-parent list
   uint64_t slog_off;   // also: offset of the gap's state log / closure scratch in the LDS tier
   uint64_t lvl_off;    // LDS tier: D+2 level offsets into the state log
 };
@@ -74,7 +80,9 @@ struct GapOut {
   uint32_t n_sub;      // states in the backward closure (phase D input)
   uint64_t sub_off;    // offset of this gap's SubState array in the packed output
   uint32_t x_sub;      // expansions done by the backward sweep
-  uint32_t pad;
+  uint32_t n_xl;       // LDS tier: entries in the gap's extra-parent list
+  uint32_t top_level;  // LDS tier: last DP level that holds a state
+  uint32_t pad1;
   // LDS tier statistics: per-level iterations / bulk iterations of phases A, B, D1 and
   // shader cycles (in units of 256) spent in A, B+C, D1
   uint32_t stat[8];

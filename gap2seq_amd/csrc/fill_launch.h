@@ -30,12 +30,12 @@ uint32_t fill_lds_frontier_cap();
 uint32_t fill_lds_max_fuz();
 hipError_t launch_fill_lds(hipStream_t st, uint32_t ngaps, uint32_t rs_cap_max, uint32_t num_oriented,
                            const uint32_t* succ, const GapDev* gaps, const uint32_t* gap_ids,
-                           const uint32_t* flank_nodes, uint64_t* log_all, uint32_t* lvl_all, GapOut* outs,
-                           uint32_t* rs_global /* nullptr: right set in LDS */, uint32_t fcap /* frontier capacity */);
-hipError_t launch_extract_lds(hipStream_t st, uint32_t ngaps, uint32_t num_oriented, const uint32_t* succ,
-                              const GapDev* gaps, const uint32_t* gap_ids, const uint32_t* flank_nodes,
-                              const uint64_t* log_all, const uint32_t* lvl_all, SubState* sub_scratch,
-                              SubState* sub_out, unsigned long long* out_counter, GapOut* outs, int skip_confident,
-                              uint32_t fcap);
+                           const uint32_t* flank_nodes, uint64_t* log_all, uint32_t* lvl_all, uint32_t* plk_all,
+                           uint64_t* xl_all, GapOut* outs, uint32_t* rs_global /* nullptr: right set in LDS */,
+                           uint32_t fcap /* frontier capacity */);
+hipError_t launch_extract_lds(hipStream_t st, uint32_t ngaps, const GapDev* gaps, const uint32_t* gap_ids,
+                              const uint32_t* flank_nodes, const uint64_t* log_all, const uint32_t* lvl_all,
+                              const uint32_t* plk_all, const uint64_t* xl_all, SubState* sub_scratch, SubState* sub_out,
+                              unsigned long long* out_counter, GapOut* outs, int skip_confident, uint32_t fcap);
 
 }  // namespace g2s

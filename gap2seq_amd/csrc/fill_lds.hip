@@ -177,14 +177,14 @@ __device__ bool lrs_has_kmer(const uint32_t* tab, uint32_t mask, uint32_t v) {
 
 // ============================================================================
 // Phases A + B + C, LDS tier.
-// dynamic LDS: [fa 2F][fn 2F][fc 2F][lh 2F x u64][lhslot 2F][tgt TG][th 3*TH][misc 4][tflt 128][cw 2x256][rs rs_cap]
+// dynamic LDS: [fa 2F][fn 2F][fc 2F][lh 2F x u64][lhslot 2F][tgt TG][th 3*TH][misc 4][tflt 128][cw 3x256][rs rs_cap]
 // ============================================================================
 template <bool RSG>
 __device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ, const GapDev* __restrict__ gaps,
                                               const uint32_t* __restrict__ gap_ids,
                                               const uint32_t* __restrict__ flank_nodes, uint64_t* log_all,
-                                              uint32_t* lvl_all, GapOut* outs, uint32_t num_oriented,
-                                              uint32_t* rs_global, const uint32_t F) {
+                                              uint32_t* lvl_all, uint32_t* plk_all, uint64_t* xl_all, GapOut* outs,
+                                              uint32_t num_oriented, uint32_t* rs_global, const uint32_t F) {
   const uint32_t LH = 2u * F;  // merge table slots (F = frontier capacity of this launch, a power of two)
   const uint32_t TH = 2u * F;  // target hits kept for phase C (128 in the first pass, 2048 later)
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -206,7 +206,8 @@ __device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ,
   uint32_t* tflt = misc + 4;                  // exact target filter: 128 direct-mapped slots
   uint32_t* cw_v = tflt + LDS_TF;             // wide levels: compacted candidate nodes / counts
   uint32_t* cw_c = cw_v + LDS_CW;
-  uint32_t* rs = RSG ? rs_global + gd.rs_off : cw_c + LDS_CW;  // right set: HBM (host pre-filled 0xFF) or LDS
+  uint32_t* cw_e = cw_c + LDS_CW;
+  uint32_t* rs = RSG ? rs_global + gd.rs_off : cw_e + LDS_CW;  // right set: HBM (host pre-filled 0xFF) or LDS
 
   const uint32_t rs_cap = gd.rs_mask + 1u;  // LDS capacity chosen by the host for this gap (<= rs_cap_max)
   const uint32_t rmask = gd.rs_mask;
@@ -216,6 +217,13 @@ __device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ,
   uint64_t* log = log_all + gd.slog_off;
   uint32_t* lvl = lvl_all + gd.lvl_off;
   const uint32_t cap = gd.slog_cap;
+  // Parent links for phase D1 (g2s_extract_lds walks them instead of the graph): plk[s] = the
+  // position, within the previous level, of the state that first produced state s; the
+  // other parents of merged states go to the list xl as (state << 32 | position).
+  uint32_t* plk = plk_all + gd.slog_off;
+  uint64_t* xl = xl_all + gd.st_off;  // LDS tier: st_off / pad0 carry the extra-link list's offset / capacity
+  const uint32_t xcap = gd.pad0;
+  uint32_t nxl = 0;
 
   if (!RSG) for (uint32_t i = (uint32_t)lane; i < rs_cap; i += 64u) rs[i] = G2S_DEV_INVALID;
   if (lane <= gd.rmf && lane < (int)LDS_TG) tgt[lane] = targets[lane];
@@ -483,6 +491,7 @@ __device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ,
   const unsigned long long cyc1 = __builtin_amdgcn_s_memtime();
   // ---------------- phase B + C: left DP (Gap2Seq.cpp:984-1167) -----------------
   uint32_t nlog = 0, xb = 0;
+  int lvl_top = -1;
   bool found = false;
   int c_count = 0, n_len = 0, len0 = 0, len1 = 0, reached_j = 0, final_d = 0;
   if (!overflow) {
@@ -490,7 +499,7 @@ __device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ,
     {
       const uint32_t s0 = lseeds[0];  // leftmost k-mer: count 1 at depth 0 (:995-1015)
       if (s0 != G2S_DEV_INVALID) {
-        if (lane == 0) { fn[0] = s0; fc[0] = 1; log[0] = ((uint64_t)s0 << 32) | 1ull; }
+        if (lane == 0) { fn[0] = s0; fc[0] = 1; log[0] = ((uint64_t)s0 << 32) | 1ull; plk[0] = G2S_DEV_INVALID; }
         nb = 1;
         nlog = 1;
       }
@@ -504,6 +513,7 @@ __device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ,
     lds_sync();
     nhit = misc[0];
     int d = 1, lvl_written = 1;  // lvl[0..lvl_written] hold valid offsets
+    lvl_top = nb ? 0 : -1;
     uint32_t bulk_epoch = 0x80000000u;  // tags merge-table entries of bulk steps; never equals a depth
     for (; d <= gd.D; d++) {
       uint32_t* ncur = fn + cur * F;
@@ -608,11 +618,13 @@ __device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ,
           }
           if (mine && i < lrun) {
             log[nlog + i * R + r] = ((uint64_t)v << 32) | np;
-            if (r == 0) lvl[d + (int)i + 1] = nlog + (i + 1u) * R;
+            plk[nlog + i * R + r] = r;  // run r of the level above, no other parent
+            if (r == 0) lvl[d + (int)i + 1] = (nlog + (i + 1u) * R) | G2S_LVL_UNIFORM;
           }
           nlog += lrun * R;
           xb += lrun * R;
           lvl_written = d + (int)lrun;
+          lvl_top = d + (int)lrun - 1;
           const uint32_t last = (uint32_t)__shfl((int)v, (int)(((lrun - 1u) << lg) + r));
           lds_sync();
           if (mine && i == 0) ncur[r] = last;  // counts are unchanged along a run
@@ -648,6 +660,7 @@ __device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ,
           const uint32_t off = (uint32_t)__popcll(m & lanes_below(lane));
           nnxt[off] = v;
           cnxt[off] = np;
+          if (nlog + off < cap) plk[nlog + off] = 0u;
         }
         nnew = (uint32_t)__popcll(m);
         for (int q = 0; q < 4; q++) {  // Q7: two successors that are each other's reverse complement
@@ -663,7 +676,7 @@ __device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ,
         //     both strands of a k-mer probe the same slots and Q7 is seen on the way;
         //   * the winner of a claim appends the node to the next border, every claimant adds
         //     its count (<= 4 predecessors x <= MAX_PATHS: the u32 sum cannot wrap, :1058-1060).
-        auto merge_round = [&](uint32_t v, uint32_t np) {
+        auto merge_round = [&](uint32_t v, uint32_t np, uint32_t e) {  // e = position of the expanded border state
           const bool pass = v != G2S_DEV_INVALID && (unpruned || lrs_has_kmer<RSG>(rs, rmask, v));  // :1050
           uint32_t h = 0, won = 0;
           if (pass) {
@@ -687,12 +700,25 @@ __device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ,
           if (won) {
             const uint32_t off = nnew + (uint32_t)__popcll(m & lanes_below(lane));
             lhslot[h] = off < F ? off : 0u;
-            if (off < F) { nnxt[off] = v; cnxt[off] = 0; }
+            if (off < F) {
+              nnxt[off] = v;
+              cnxt[off] = 0;
+              if (nlog + off < cap) plk[nlog + off] = e;
+            }
           }
           nnew += (uint32_t)__popcll(m);
           lds_sync();
           if (nnew > F) return;  // keeps the merge table (2F slots) from filling up: at most F + 64 claims
-          if (pass) atomicAdd(&cnxt[lhslot[h]], np);
+          uint32_t slot = 0;
+          if (pass) { slot = lhslot[h]; atomicAdd(&cnxt[slot], np); }
+          const uint64_t xm = __ballot(pass && !won);  // further parents of a merged state
+          if (xm) {
+            if (pass && !won) {
+              const uint32_t at = nxl + (uint32_t)__popcll(xm & lanes_below(lane));
+              if (at < xcap) xl[at] = ((uint64_t)(nlog + slot) << 32) | e;
+            }
+            nxl += (uint32_t)__popcll(xm);
+          }
         };
         if (nb <= 16) {
           // narrow border: 4 lanes per entry, one per successor slot (one coalesced 16 B access)
@@ -706,7 +732,7 @@ __device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ,
           { uint32_t t = v + np; asm volatile("" :: "v"(t)); }
           { unsigned long long t = __builtin_amdgcn_s_memtime(); pd[0] += t - qt1; qt1 = t; }
 #endif
-          merge_round(v, np);
+          merge_round(v, np, (uint32_t)lane >> 2);
         } else {
           // wide border: one entry per lane with its whole record in one load (a level costs
           // one HBM round trip whatever its width); most slots are empty, so the valid
@@ -726,13 +752,14 @@ __device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ,
                 const uint32_t at = ncand + (uint32_t)__popcll(m & lanes_below(lane));
                 cw_v[at] = v;
                 cw_c[at] = np;
+                cw_e[at] = e;
               }
               ncand += (uint32_t)__popcll(m);
             }
             lds_sync();
             for (uint32_t c0 = 0; c0 < ncand && nnew <= F; c0 += 64u) {
               const uint32_t c = c0 + (uint32_t)lane;
-              merge_round(c < ncand ? cw_v[c] : G2S_DEV_INVALID, c < ncand ? cw_c[c] : 0u);
+              merge_round(c < ncand ? cw_v[c] : G2S_DEV_INVALID, c < ncand ? cw_c[c] : 0u, c < ncand ? cw_e[c] : 0u);
             }
             lds_sync();
           }
@@ -759,14 +786,14 @@ __device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ,
           if (at >= 0) {
             if (lane == 0) cnxt[at] = 1;
           } else if (nnew < F) {
-            if (lane == 0) { nnxt[nnew] = s; cnxt[nnew] = 1; }
+            if (lane == 0) { nnxt[nnew] = s; cnxt[nnew] = 1; if (nlog + nnew < cap) plk[nlog + nnew] = G2S_DEV_INVALID; }
             nnew++;
           } else { overflow = true; flags |= G2S_DEV_WHY_FRONTIER; break; }
           lds_sync();
         }
       }
       // append the level to the state log (fire and forget) and note target k-mers
-      if (nlog + nnew > cap) { overflow = true; flags |= G2S_DEV_WHY_LOG; break; }
+      if (nlog + nnew > cap || nxl > xcap) { overflow = true; flags |= G2S_DEV_WHY_LOG; break; }
       for (uint32_t e0 = 0; e0 < nnew; e0 += 64u) {
         const uint32_t e = e0 + (uint32_t)lane;
         const bool have = e < nnew;
@@ -779,6 +806,7 @@ __device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ,
       nlog += nnew;
       if (lane == 0) lvl[d + 1] = nlog;
       lvl_written = d + 1;
+      if (nnew) lvl_top = d;
       lds_sync();
       if (nhit > TH) { overflow = true; flags |= G2S_DEV_WHY_HITS; break; }
       cur ^= 1u;
@@ -863,6 +891,8 @@ __device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ,
     go->len[0] = len0;
     go->len[1] = len1;
     go->reached_j = reached_j;
+    go->n_xl = nxl;
+    go->top_level = (uint32_t)max(0, min(lvl_top, gd.D));
   }
 }
 
@@ -870,9 +900,10 @@ __global__ __launch_bounds__(64) void g2s_fill_lds(const uint32_t* __restrict__ 
                                                     const GapDev* __restrict__ gaps,
                                                     const uint32_t* __restrict__ gap_ids,
                                                     const uint32_t* __restrict__ flank_nodes, uint64_t* log_all,
-                                                    uint32_t* lvl_all, GapOut* outs, uint32_t num_oriented,
-                                                    uint32_t fcap) {
-  fill_lds_body<false>(succ, gaps, gap_ids, flank_nodes, log_all, lvl_all, outs, num_oriented, nullptr, fcap);
+                                                    uint32_t* lvl_all, uint32_t* plk_all, uint64_t* xl_all,
+                                                    GapOut* outs, uint32_t num_oriented, uint32_t fcap) {
+  fill_lds_body<false>(succ, gaps, gap_ids, flank_nodes, log_all, lvl_all, plk_all, xl_all, outs, num_oriented, nullptr,
+                       fcap);
 }
 // Same kernel with the right set in HBM: for gaps whose right set outgrows the LDS (deep
 // DP, -dist-error in the thousands); everything else of the gap stays in LDS.
@@ -880,26 +911,39 @@ __global__ __launch_bounds__(64) void g2s_fill_lds_rsg(const uint32_t* __restric
                                                         const GapDev* __restrict__ gaps,
                                                         const uint32_t* __restrict__ gap_ids,
                                                         const uint32_t* __restrict__ flank_nodes, uint64_t* log_all,
-                                                        uint32_t* lvl_all, GapOut* outs, uint32_t num_oriented,
-                                                        uint32_t* rs_global, uint32_t fcap) {
-  fill_lds_body<true>(succ, gaps, gap_ids, flank_nodes, log_all, lvl_all, outs, num_oriented, rs_global, fcap);
+                                                        uint32_t* lvl_all, uint32_t* plk_all, uint64_t* xl_all,
+                                                        GapOut* outs, uint32_t num_oriented, uint32_t* rs_global,
+                                                        uint32_t fcap) {
+  fill_lds_body<true>(succ, gaps, gap_ids, flank_nodes, log_all, lvl_all, plk_all, xl_all, outs, num_oriented, rs_global,
+                      fcap);
 }
 
 // ============================================================================
-// Phase D1 from the level-ordered state log, LDS tier (Gap2Seq.cpp:1169-1312)
-// plus the traceback's closure.  Walks the log backwards, one level per step; the
-// level's entries sit in lane registers, the border of the level above in LDS.
-// dynamic LDS: [chk 2F x u64][chs 2F][wl W+1][we_node W][we_cnt W][border 2x3F][cfl F][cem F][lm 4F]
+// Phase D1 (Gap2Seq.cpp:1169-1312) plus the traceback's closure, LDS tier.
+//
+// The reference discovers the subgraph by walking graph predecessors backwards from
+// the targets and looking every one of them up in the DP table.  Here phase B has
+// already written, next to every state of the level-ordered log, the position of its
+// parent in the level above (plk) and the list of further parents of merged states
+// (xl); the backward sweep therefore touches neither the graph nor a hash table: one
+// wave per gap walks the levels from D to 0, the closure marks of a level live in LDS,
+// and every marked state is emitted once (depth descending) with the emit indices of
+// its parents.  Runs of levels that phase B produced with a bulk step (flagged in
+// lvl[]: same width, parent = same position, no merges) are swept up to 64 levels per
+// iteration.  Parents are emitted in pred[0..] in arrival order, not GATB order; the
+// host puts the few multi-parent states in order (G2S_DEV_PRED_UNORDERED).
+// dynamic LDS: [wl W+1][wen W][wec W][wpl W][mk 2F][em F][ch 2x2F][pc F][xc 3x64]
 // ============================================================================
-__global__ __launch_bounds__(64) void g2s_extract_lds(const uint32_t* __restrict__ succ,
-                                                       const GapDev* __restrict__ gaps,
+#define LDS_XC 64u /* extra links handled per level */
+__global__ __launch_bounds__(64) void g2s_extract_lds(const GapDev* __restrict__ gaps,
                                                        const uint32_t* __restrict__ gap_ids,
                                                        const uint32_t* __restrict__ flank_nodes,
                                                        const uint64_t* __restrict__ log_all,
-                                                       const uint32_t* __restrict__ lvl_all, SubState* sub_scratch,
+                                                       const uint32_t* __restrict__ lvl_all,
+                                                       const uint32_t* __restrict__ plk_all,
+                                                       const uint64_t* __restrict__ xl_all, SubState* sub_scratch,
                                                        SubState* sub_out, unsigned long long* out_counter,
-                                                       GapOut* outs, int skip_confident, uint32_t num_oriented,
-                                                       const uint32_t F) {
+                                                       GapOut* outs, int skip_confident, const uint32_t F) {
   const uint32_t W = F > 256u ? F : 256u;  // log / level-offset window: holds at least one whole level
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   const uint32_t gi = __builtin_amdgcn_readfirstlane(gap_ids[blockIdx.x]);
@@ -910,20 +954,21 @@ __global__ __launch_bounds__(64) void g2s_extract_lds(const uint32_t* __restrict
   const int c_count = go->c_count, n_len = go->n_len;
   if ((gflags & (G2S_DEV_OVERFLOW_A | G2S_DEV_OVERFLOW_B)) || !(c_count > 0 && n_len > 0)) return;  // :1169
 
-  uint64_t* chk = (uint64_t*)lds;                // candidate hash keys (tag << 32 | node) [2F], 8-byte aligned
-  uint32_t* chs = lds + 4u * F;                  // candidate hash: slot -> candidate index [2F]
-  uint32_t* wl = chs + 2u * F;                   // level offsets window [W+1]
-  uint32_t* wen = wl + (W + 1u);                 // log window: nodes
-  uint32_t* wec = wen + W;                       // log window: counts
-  uint32_t* bbuf = wec + W;                      // border (depth d2+1), ping-pong: node, emit index, flags
-  uint32_t* cfl = bbuf + 6u * F;                 // candidates (depth d2): accumulated flags, emit index
-  uint32_t* cem = cfl + F;
-  uint32_t* lm = cem + F;                        // match of each (border entry, nt) among the candidates [4F]
-  uint32_t bsel = 0;                             // which border buffer is current
-  uint32_t *bn = bbuf, *be = bbuf + F, *bf = bbuf + 2u * F;
+  uint32_t* wl = lds;                  // level offsets window [W+1] (bit 31: G2S_LVL_UNIFORM)
+  uint32_t* wen = wl + (W + 1u);       // log window: nodes, counts, parent positions
+  uint32_t* wec = wen + W;
+  uint32_t* wpl = wec + W;
+  uint32_t* mk = wpl + W;              // closure marks (IN_S | IN_T) by position: [0,F) this level, [F,2F) the one below
+  uint32_t* em = mk + 2u * F;          // emit index by position, this level
+  uint32_t* ch = em + F;               // closure states of a level: emit index [F], parent position [F]; ping-pong
+  uint32_t* pc = ch + 4u * F;          // parents already linked, by position (levels with merged states only)
+  uint32_t* xc = pc + F;               // merged states of the level above: emit index, parent position, slot [3][XC]
+  uint32_t msel = 0, csel = 0;
 
   const uint64_t* log = log_all + gd.slog_off;
   const uint32_t* lvl = lvl_all + gd.lvl_off;
+  const uint32_t* plk = plk_all + gd.slog_off;
+  const uint64_t* xl = xl_all + gd.st_off;
   SubState* sub = sub_scratch + gd.slog_off;
   const uint32_t* lseeds = flank_nodes + gd.flank_off;
   const uint32_t* targets = lseeds + (uint32_t)(gd.lmf + 1) + (uint32_t)(gd.rmf + 1);
@@ -934,151 +979,150 @@ __global__ __launch_bounds__(64) void g2s_extract_lds(const uint32_t* __restrict
   const int lo_sink = max(0, gd.lmf + gd.g - gd.e);  // :1196
   const uint32_t t_flags = G2S_SUB_IN_T | G2S_SUB_START_T | ((want_s && !gd.all_paths) ? (G2S_SUB_IN_S | G2S_SUB_SINK) : 0u);
   const int min_len = n_len > 1 ? min(len0, len1) : len0;
+  const uint32_t FL = G2S_SUB_IN_S | G2S_SUB_IN_T;
+  auto own_flags = [&](uint32_t node, int depth) -> uint32_t {
+    uint32_t f = 0;
+    if (node == sinknode && depth >= lo_sink) f |= G2S_SUB_IN_S | G2S_SUB_SINK;              // :1195-1244
+    if (node == reached && (depth == len0 || (n_len > 1 && depth == len1))) f |= t_flags;    // :1245-1259
+    return f;
+  };
 
-  for (uint32_t i = (uint32_t)lane; i < 2u * F; i += 64u) chk[i] = G2S_DEV_EMPTY64;
+  for (uint32_t i = (uint32_t)lane; i < 2u * F; i += 64u) mk[i] = 0;
   lds_sync();
   uint32_t st_slowD = 0, st_bulkD = 0;
   const unsigned long long cyc0 = __builtin_amdgcn_s_memtime();
   int wl_lo = gd.D + 2;          // wl[i] = lvl[wl_lo + i], i in [0, W]
   uint32_t we_lo = 0, we_hi = 0; // log positions [we_lo, we_hi) are in the entry window
-  uint32_t nsub = 0, nbord = 0, xcount = 0, lflags = 0;
+  uint32_t nsub = 0, nch = 0, nxc = 0, xcount = 0, lflags = 0;
+  uint32_t xpos = go->n_xl;      // extra links [0, xpos) not yet consumed (sorted by state, ascending)
+  uint32_t xtop = xpos ? (uint32_t)(xl[xpos - 1u] >> 32) : 0u;
   const uint32_t cap = gd.slog_cap;
+  bool over = false;
 
-  for (int d2 = gd.D; d2 >= 0; d2--) {
-    if (nbord == 0 && d2 < min_len && (sinknode == G2S_DEV_INVALID || d2 < lo_sink)) break;  // nothing can start below
-    // ---- bulk step: every border state (<= 8) continues down a unitig.  Lanes are
-    // level-major (lane = i*Rp + r: run r, level d2-i).  A lane looks for the speculated
-    // predecessor (id -/+ 2) among the states of its level, and the graph must confirm
-    // the edge.  A level that holds a path start which is not on one of the runs ends
-    // the bulk (the per-level code below then adds it to the border).
-    {
-      bool any_source = false;
-      for (uint32_t q = 0; q < nbord && q < 8u; q++) any_source |= (bf[q] & G2S_SUB_SOURCE) != 0;
-      if (nbord >= 1 && nbord <= 8 && !any_source && d2 > gd.lmf + 1) {
-        const uint32_t R = nbord, lg = log2ceil16(R), Rp = 1u << lg;
-        const uint32_t r = (uint32_t)lane & (Rp - 1u), i = (uint32_t)lane >> lg;
-        const bool mine = r < R;
-        const uint32_t cur = mine ? bn[r] : 0u;
-        const uint32_t curf = mine ? (bf[r] & (G2S_SUB_IN_S | G2S_SUB_IN_T)) : 0u;
-        const uint32_t L = (uint32_t)min((int)(64u >> lg), d2 - gd.lmf);  // stay above the left flank: no sources
-        const uint32_t step = 2u * (i + 1u);
-        const bool up = (cur & 1u) != 0;  // odd orientation: predecessors have larger ids
-        const int li = d2 - (int)i;
-        const bool inrange = mine && i < L && (up ? (cur + step < num_oriented) : (cur >= step));
-        const uint32_t x = up ? cur + step - 2u : cur - (step - 2u);  // state of level li+1
-        const uint32_t p = up ? cur + step : cur - step;               // speculated state of level li
-        bool ok = !mine;
-        uint32_t nt = 0, ccnt = 0;
-        if (i < L && li >= 0) {
-          const uint32_t lo = lvl[li], hi = lvl[li + 1];
-          bool found_p = false, stray_start = false;
-          uint32_t ents[16];
-          const uint32_t w = hi - lo;
-          if (w <= 16u) {
-            uint64_t raw[16];
-#pragma unroll
-            for (uint32_t c = 0; c < 16u; c++) raw[c] = c < w ? log[lo + c] : G2S_DEV_EMPTY64;  // independent loads
-#pragma unroll
-            for (uint32_t c = 0; c < 16u; c++) {
-              const uint32_t en = (uint32_t)(raw[c] >> 32);
-              ents[c] = en;
-              if (c >= w) continue;
-              if (mine && en == p) { found_p = true; ccnt = (uint32_t)raw[c]; }
-              // a start of this level must be one of the runs' states, else it is a new border entry
-              if ((en == sinknode && li >= lo_sink) || (en == reached && (li == len0 || (n_len > 1 && li == len1)))) {
-                bool on_run = false;
-                for (uint32_t q = 0; q < R; q++) {
-                  const uint32_t o = bn[q];
-                  const uint32_t op = (o & 1u) != 0 ? o + step : o - step;
-                  on_run |= op == en;
-                }
-                stray_start |= !on_run;
-              }
-            }
-          } else {
-            stray_start = true;  // wide level: leave it to the per-level code
-          }
-          if (inrange && found_p && !stray_start) {
-            const uint4 rec = *(const uint4*)(succ + (size_t)(x ^ 1u) * 4);
-            const uint32_t qv = p ^ 1u;
-            nt = rec.x == qv ? 0u : rec.y == qv ? 1u : rec.z == qv ? 2u : rec.w == qv ? 3u : 4u;
-            // every set predecessor of x must be the speculated one: any other valid slot
-            // whose state is set at this level would be a second closure entry
-            bool other = false;
-            const uint32_t o0 = (nt == 0u || rec.x == G2S_DEV_INVALID) ? 0xFFFFFFFEu : (rec.x ^ 1u);
-            const uint32_t o1 = (nt == 1u || rec.y == G2S_DEV_INVALID) ? 0xFFFFFFFEu : (rec.y ^ 1u);
-            const uint32_t o2 = (nt == 2u || rec.z == G2S_DEV_INVALID) ? 0xFFFFFFFEu : (rec.z ^ 1u);
-            const uint32_t o3 = (nt == 3u || rec.w == G2S_DEV_INVALID) ? 0xFFFFFFFEu : (rec.w ^ 1u);
-#pragma unroll
-            for (uint32_t c = 0; c < 16u; c++) other |= ents[c] == o0 || ents[c] == o1 || ents[c] == o2 || ents[c] == o3;
-            ok = nt < 4u && !other;
-          } else if (mine) {
-            ok = false;
-          }
-          if (!mine && stray_start) ok = false;
-        } else if (mine) {
-          ok = false;
-        }
-        const uint32_t lok = leading_levels(ok, lg);
-        if (lok >= 2 && nsub + lok * R <= cap) {
-          const bool act = mine && i < lok;
-          uint32_t own = 0;  // attributes of this state itself
-          if (act && p == sinknode && li >= lo_sink) own |= G2S_SUB_IN_S | G2S_SUB_SINK;       // :1195-1244
-          if (act && p == reached && (li == len0 || (n_len > 1 && li == len1))) own |= t_flags;  // :1245-1259
-          uint32_t prop = (own | (i == 0 ? curf : 0u)) & (G2S_SUB_IN_S | G2S_SUB_IN_T);
-          for (uint32_t o = Rp; o < 64u; o <<= 1) {  // closure membership flows down each run: prefix OR over i
-            const uint32_t t = (uint32_t)__shfl_up((int)prop, (int)o);
-            if ((uint32_t)lane >= o) prop |= t;
-          }
-          const uint32_t f = own | prop;
-          const uint32_t nt_next = (uint32_t)__shfl_down((int)nt, (int)Rp);  // slot of state (i+1,r) among preds of (i,r)
-          if (act) {
-            SubState st;
-            st.node = p; st.depth = (uint32_t)li; st.cnt = ccnt; st.flags = f;
-            const int32_t nxt = (i + 1u < lok) ? (int32_t)(nsub + (i + 1u) * R + r) : -1;
-            st.pred[0] = nt_next == 0u ? nxt : -1;
-            st.pred[1] = nt_next == 1u ? nxt : -1;
-            st.pred[2] = nt_next == 2u ? nxt : -1;
-            st.pred[3] = nt_next == 3u ? nxt : -1;
-            sub[nsub + i * R + r] = st;
-            if (R > 1) {  // Q7: the other strand of my k-mer on another run at this level
-              for (uint32_t q = 0; q < R; q++) {
-                const uint32_t o = bn[q];
-                const uint32_t op = (o & 1u) != 0 ? o + step : o - step;
-                if (q != r && op == (p ^ 1u)) lflags |= G2S_DEV_Q7_D;
-              }
-            }
-          }
-          if (mine && i == 0) sub[be[r]].pred[nt] = (int32_t)(nsub + r);
-          const int src = (int)(((lok - 1u) << lg) + r);
-          const uint32_t lastp = (uint32_t)__shfl((int)p, src);
-          const uint32_t lastf = (uint32_t)__shfl((int)f, src);
-          lds_sync();
-          if (mine && i == 0) { bn[r] = lastp; be[r] = nsub + (lok - 1u) * R + r; bf[r] = lastf; }
-          lds_sync();
-          xcount += lok * R;
-          nsub += lok * R;
-          d2 -= (int)lok - 1;
-          st_bulkD++;
-          continue;
-        }
-      }
+#ifdef G2S_PROF_A
+  unsigned long long pe[4] = {0, 0, 0, 0};
+  pe[3] = __builtin_amdgcn_s_memtime() - cyc0;
+#endif
+  // nothing can start above the last level that holds a state, nor (without a sink k-mer)
+  // above the longest path length
+  int d_top = min(gd.D, (int)go->top_level);
+  if (sinknode == G2S_DEV_INVALID) d_top = min(d_top, n_len > 1 ? max(len0, len1) : len0);
+  if (xpos > 0) {  // extra links of the levels that are skipped
+    const uint32_t hi_top = lvl[d_top + 1] & ~G2S_LVL_UNIFORM;
+    while (xpos > 0) {
+      const bool above = (uint32_t)lane < xpos && (uint32_t)(xl[xpos - 1u - (uint32_t)lane] >> 32) >= hi_top;
+      const uint32_t cnt = leading_true(above);
+      xpos -= cnt;
+      if (cnt < 64u) break;
     }
-    st_slowD++;
-    // ---- level offsets and entries of depth d2 through the LDS windows ---------------
+    xtop = xpos ? (uint32_t)(xl[xpos - 1u] >> 32) : 0u;
+  }
+  for (int d2 = d_top; d2 >= 0; d2--) {
+#ifdef G2S_PROF_A
+    const unsigned long long et0 = __builtin_amdgcn_s_memtime();
+#endif
+    if (nch == 0 && nxc == 0 && d2 < min_len && (sinknode == G2S_DEV_INVALID || d2 < lo_sink)) break;  // nothing can start below
+    uint32_t* mcur = mk + msel * F;
+    uint32_t* mnxt = mk + (msel ^ 1u) * F;
+    // ---- level offsets through the LDS window -----------------------------------------
     if (d2 < wl_lo) {
       lds_sync();
       wl_lo = max(0, d2 + 1 - (int)W);
       for (uint32_t i = (uint32_t)lane; i <= W; i += 64u) {
         const int dd = wl_lo + (int)i;
-        wl[i] = dd <= gd.D + 1 ? lvl[dd] : 0xFFFFFFFFu;
+        wl[i] = dd <= gd.D + 1 ? lvl[dd] : 0x7FFFFFFFu;
       }
       lds_sync();
     }
-    const uint32_t lo = wl[d2 - wl_lo], hi = wl[d2 + 1 - wl_lo];
+    const uint32_t lo = wl[d2 - wl_lo] & ~G2S_LVL_UNIFORM, hi_raw = wl[d2 + 1 - wl_lo];
+    const uint32_t hi = hi_raw & ~G2S_LVL_UNIFORM;
     const uint32_t w = hi - lo;  // <= F by construction of the log
-    if (w == 0 && nbord == 0) continue;
-    if (w > 0 && (lo < we_lo || hi > we_hi)) {
+    if (w == 0) {                // empty level: nothing above can have a parent here
+      nch = 0; nxc = 0;
+      continue;
+    }
+    // ---- bulk step: this level and the K-1 below it were produced by bulk steps of phase B
+    // (lvl flag): same width R, state (level, r) has the single parent (level-1, r).  Lane
+    // i*Rp + r takes state r of level d2-i; closure membership flows down each run.
+    if ((hi_raw & G2S_LVL_UNIFORM) && w <= 16u && d2 > gd.lmf + 1 && nxc == 0) {
+      const uint32_t R = w, lg = log2ceil16(R), Rp = 1u << lg;
+      const uint32_t r = (uint32_t)lane & (Rp - 1u), i = (uint32_t)lane >> lg;
+      const bool mine = r < R;
+      const int li = d2 - (int)i;
+      // levels d2-i for i < K must all carry the flag and stay above the left flank and inside the window
+      const bool lvl_ok = li > gd.lmf + 1 && li >= wl_lo && (wl[li + 1 - wl_lo] & G2S_LVL_UNIFORM) != 0;
+      uint32_t K = leading_levels(lvl_ok || !mine, lg);
+      K = min(K, 64u >> lg);
+      if (K >= 2 && nsub + K * R <= cap) {
+        const bool act = mine && i < K;
+        // the K levels are contiguous in the log (uniform levels of one width): [hi - K*R, hi)
+        if (hi - K * R < we_lo || hi > we_hi) {
+          lds_sync();
+          we_hi = hi;
+          we_lo = hi > W ? hi - W : 0u;
+          for (uint32_t q = (uint32_t)lane; q < we_hi - we_lo; q += 64u) {
+            const uint64_t e = log[we_lo + q];
+            wen[q] = (uint32_t)(e >> 32);
+            wec[q] = (uint32_t)e;
+            wpl[q] = plk[we_lo + q];
+          }
+          lds_sync();
+        }
+        const uint32_t wi = act ? (lo - i * R + r) - we_lo : 0u;
+        const uint32_t node = act ? wen[wi] : 0u;
+        const uint32_t own = act ? own_flags(node, li) : 0u;
+        const uint32_t seed = own | ((act && i == 0) ? mcur[r] : 0u);
+        // closure membership flows down each run: lane (i, r) has a flag when any lane (i' <= i, r) seeds it
+        const uint64_t runmask = (lg == 0 ? ~0ull : lg == 1 ? 0x5555555555555555ull : lg == 2 ? 0x1111111111111111ull
+                                  : lg == 3 ? 0x0101010101010101ull : 0x0001000100010001ull) << r;
+        const uint64_t upto = lanes_below(lane) | (1ull << lane);
+        const uint64_t ms = __ballot((seed & G2S_SUB_IN_S) != 0), mt = __ballot((seed & G2S_SUB_IN_T) != 0);
+        const uint32_t prop = ((ms & runmask & upto) ? G2S_SUB_IN_S : 0u) | ((mt & runmask & upto) ? G2S_SUB_IN_T : 0u);
+        const uint32_t f = act ? (own | prop) : 0u;
+        const bool in = f != 0;
+        const uint64_t m = __ballot(in);
+        const uint32_t slot = nsub + (uint32_t)__popcll(m & lanes_below(lane));
+        // the parent (i+1, r) is marked whenever (i, r) is; it is emitted by lane + Rp
+        const uint32_t pslot = lane + (int)Rp < 64 ? nsub + (uint32_t)__popcll(m & lanes_below(lane + (int)Rp)) : 0u;
+        if (in) {
+          SubState st;
+          st.node = node; st.depth = (uint32_t)li; st.cnt = wec[wi]; st.flags = f;
+          st.pred[0] = (i + 1u < K) ? (int32_t)pslot : -1;
+          st.pred[1] = st.pred[2] = st.pred[3] = -1;
+          sub[slot] = st;
+        }
+        if (mine && i == 0) em[r] = slot;  // for the links from the level above
+        lds_sync();
+        uint32_t* chc = ch + csel * 2u * F;
+        for (uint32_t j = (uint32_t)lane; j < nch; j += 64u) sub[chc[j]].pred[0] = (int32_t)em[chc[F + j]];
+        lds_sync();
+        // the last level of the stretch becomes "the level above" of the next iteration
+        const uint64_t lm = __ballot(in && i == K - 1u);
+        if (in && i == K - 1u) {
+          const uint32_t at = (uint32_t)__popcll(lm & lanes_below(lane));
+          chc[at] = slot;
+          chc[F + at] = r;
+        }
+        nch = (uint32_t)__popcll(lm);
+        // the same buffer takes the marks of the level below the stretch (msel does not move)
+        if (mine && i == 0) mcur[r] = 0;
+        lds_sync();
+        if (in && i == K - 1u) mcur[r] = f & FL;
+        lds_sync();
+        const uint32_t nin = (uint32_t)__popcll(m);
+        xcount += nin;
+        nsub += nin;
+        d2 -= (int)K - 1;
+        st_bulkD++;
+#ifdef G2S_PROF_A
+        pe[0] += __builtin_amdgcn_s_memtime() - et0;
+#endif
+        continue;
+      }
+    }
+    st_slowD++;
+    // ---- entries of the level through the LDS window ----------------------------------
+    if (lo < we_lo || hi > we_hi) {
       lds_sync();
       we_hi = hi;
       we_lo = hi > W ? hi - W : 0u;
@@ -1086,122 +1130,144 @@ __global__ __launch_bounds__(64) void g2s_extract_lds(const uint32_t* __restrict
         const uint64_t e = log[we_lo + i];
         wen[i] = (uint32_t)(e >> 32);
         wec[i] = (uint32_t)e;
+        wpl[i] = plk[we_lo + i];
       }
       lds_sync();
     }
-    // ---- per-level step: any width up to F.  The level's states (candidates) are indexed
-    // c = 0..w-1 in the log window; a depth-tagged LDS hash maps node -> c.
     const uint32_t wbase = lo - we_lo;
-    const uint32_t tag = (uint32_t)d2 | 0x80000000u;
-    for (uint32_t c = (uint32_t)lane; c < w; c += 64u) {
-      const uint32_t cn = wen[wbase + c];
-      uint32_t f = 0;
-      if (cn == sinknode && d2 >= lo_sink) f |= G2S_SUB_IN_S | G2S_SUB_SINK;                // :1195-1244
-      if (cn == reached && (d2 == len0 || (n_len > 1 && d2 == len1))) f |= t_flags;         // :1245-1259
-      cfl[c] = f;
-      const uint64_t key = ((uint64_t)tag << 32) | cn;
-      uint32_t h = mix32(cn) & (2u * F - 1u);
-      while (true) {  // states of one level are distinct: plain claim, stale tags are free
-        const uint64_t cur = chk[h];
-        if ((uint32_t)(cur >> 32) == tag) { h = (h + 1) & (2u * F - 1u); continue; }
-        if (atomicCAS((unsigned long long*)&chk[h], (unsigned long long)cur, (unsigned long long)key) == cur) break;
-      }
-      chs[h] = c;
+    // ---- merged states of this level: their further parents (rare) ----------------------
+    uint32_t xfirst = xpos;
+    if (xtop >= lo && xpos > 0) {  // xtop = state of the last unconsumed extra link
+      while (xfirst > 0 && (uint32_t)(xl[xfirst - 1u] >> 32) >= lo) xfirst--;
+      xtop = xfirst > 0 ? (uint32_t)(xl[xfirst - 1u] >> 32) : 0u;
     }
-    lds_sync();
-    auto find_cand = [&](uint32_t node) -> uint32_t {
-      uint32_t h = mix32(node) & (2u * F - 1u);
-      while (true) {
-        const uint64_t cur = chk[h];
-        if ((uint32_t)(cur >> 32) != tag) return 0xFFFFFFFFu;
-        if ((uint32_t)cur == node) return chs[h];
-        h = (h + 1) & (2u * F - 1u);
-      }
-    };
-    // ---- expand the border of depth d2+1 towards this level (:1266-1301) ---------------
-    xcount += nbord;
-    for (uint32_t i0 = 0; i0 < nbord * 4u; i0 += 64u) {
-      const uint32_t i = i0 + (uint32_t)lane;
-      if (i < nbord * 4u) {
-        const uint32_t e = i >> 2, nt = i & 3u;
-        const uint32_t cur = bn[e], f = bf[e];
-        uint32_t match = 0xFFFFFFFFu;
-        if (!(f & G2S_SUB_SOURCE)) {
-          const uint32_t p = flip(succ[(size_t)(cur ^ 1u) * 4 + nt]);
-          if (p != G2S_DEV_INVALID) match = find_cand(p);
-          if (match != 0xFFFFFFFFu) atomicOr(&cfl[match], f & (G2S_SUB_IN_S | G2S_SUB_IN_T));
-        }
-        lm[i] = match;
-      }
-    }
-    lds_sync();
-    // ---- reached candidates join the closure ------------------------------------------
+    const uint32_t nx = xpos - xfirst;  // extra links of states in [lo, hi)
+    if (nx > LDS_XC) { over = true; break; }
+    if (nx) { for (uint32_t c = (uint32_t)lane; c < w; c += 64u) pc[c] = 1u; lds_sync(); }
+    // ---- per-level step: emit the marked states, pass the marks on to their parents -------
     const uint32_t lidx = (d2 <= gd.lmf) ? (lseeds[d2] >> 1) : 0xFFFFFFFFu;  // buildNode(kmer_left.substr(d2,k))
-    uint32_t* nbn = bbuf + (bsel ^ 1u) * 3u * F;
-    uint32_t* nbe = nbn + F;
-    uint32_t* nbf = nbn + 2u * F;
-    uint32_t nin_total = 0;
-    bool over = false;
+    uint32_t* chc = ch + csel * 2u * F;           // closure states of the level above (emit index, parent position)
+    uint32_t* chn = ch + (csel ^ 1u) * 2u * F;    // the same for this level, built here
+    uint32_t nin_total = 0, nlink = 0;
     for (uint32_t c0 = 0; c0 < w; c0 += 64u) {
       const uint32_t c = c0 + (uint32_t)lane;
-      uint32_t cf = c < w ? cfl[c] : 0u;
+      const uint32_t cn = c < w ? wen[wbase + c] : 0u;
+      uint32_t cf = c < w ? (mcur[c] | own_flags(cn, d2)) : 0u;
       const bool in = cf != 0;
       const uint64_t m = __ballot(in);
       const uint32_t nin = (uint32_t)__popcll(m);
       if (nsub + nin_total + nin > cap) { over = true; break; }
+      if (in && d2 <= gd.lmf && (cn >> 1) == lidx) cf |= G2S_SUB_SOURCE;  // :1270 end condition, k-mer comparison only
+      const uint32_t slot = nsub + nin_total + (uint32_t)__popcll(m & lanes_below(lane));
+      const uint32_t pp = in ? wpl[wbase + c] : G2S_DEV_INVALID;
+      // the parent joins the closure (:1266-1301); sources are not expanded
+      const bool expand = in && !(cf & G2S_SUB_SOURCE) && d2 > 0 && pp != G2S_DEV_INVALID;
+      const uint64_t lm = __ballot(expand);
       if (in) {
-        const uint32_t cn = wen[wbase + c];
-        const uint32_t slot = nin_total + (uint32_t)__popcll(m & lanes_below(lane));
-        if (d2 <= gd.lmf && (cn >> 1) == lidx) cf |= G2S_SUB_SOURCE;  // :1270 end condition, k-mer comparison only
         SubState st;
         st.node = cn; st.depth = (uint32_t)d2; st.cnt = wec[wbase + c]; st.flags = cf;
         st.pred[0] = st.pred[1] = st.pred[2] = st.pred[3] = -1;
-        sub[nsub + slot] = st;
-        cem[c] = nsub + slot;
-        nbn[slot] = cn; nbe[slot] = nsub + slot; nbf[slot] = cf;
-        // Q7: both strands of one k-mer in this border
-        const uint32_t oc = find_cand(cn ^ 1u);
-        if (oc != 0xFFFFFFFFu && cfl[oc] != 0u) lflags |= G2S_DEV_Q7_D;
+        sub[slot] = st;
+        em[c] = slot;
+      }
+      if (expand) {
+        atomicOr(&mnxt[pp], cf & FL);
+        const uint32_t at = nlink + (uint32_t)__popcll(lm & lanes_below(lane));
+        chn[at] = slot;
+        chn[F + at] = pp;
       }
       nin_total += nin;
+      nlink += (uint32_t)__popcll(lm);
     }
-    if (over) { lflags |= G2S_DEV_OVERFLOW_B; break; }
+    if (over) break;
     lds_sync();
-    // ---- links from the border above to this level -------------------------------------
-    for (uint32_t i0 = 0; i0 < nbord * 4u; i0 += 64u) {
-      const uint32_t i = i0 + (uint32_t)lane;
-      if (i < nbord * 4u) {
-        const uint32_t match = lm[i];
-        if (match != 0xFFFFFFFFu) sub[be[i >> 2]].pred[i & 3u] = (int32_t)cem[match];
+    // ---- links from the level above to this level ----------------------------------------
+    for (uint32_t j = (uint32_t)lane; j < nch; j += 64u) sub[chc[j]].pred[0] = (int32_t)em[chc[F + j]];
+    for (uint32_t j = (uint32_t)lane; j < nxc; j += 64u) sub[xc[j]].pred[xc[2u * LDS_XC + j]] = (int32_t)em[xc[LDS_XC + j]];
+    lds_sync();
+    nch = nlink;
+    csel ^= 1u;
+    // ---- further parents of merged states of this level -----------------------------------
+    nxc = 0;
+    if (nx) {
+      const uint32_t j = (uint32_t)lane;
+      bool link = false;
+      uint32_t c = 0, pp = 0;
+      if (j < nx) {
+        const uint64_t e = xl[xfirst + j];
+        c = (uint32_t)(e >> 32) - lo;
+        pp = (uint32_t)e;
+        const uint32_t cn = wen[wbase + c];
+        const uint32_t f = mcur[c] | own_flags(cn, d2);
+        const bool src = d2 <= gd.lmf && (cn >> 1) == lidx;
+        link = f != 0 && !src && d2 > 0;
+        if (link) atomicOr(&mnxt[pp], f & FL);
       }
+      const uint64_t m = __ballot(link);
+      if (link) {
+        const uint32_t at = (uint32_t)__popcll(m & lanes_below(lane));
+        xc[at] = em[c];
+        xc[LDS_XC + at] = pp;
+        xc[2u * LDS_XC + at] = atomicAdd(&pc[c], 1u);  // slots 1..3 in arrival order
+      }
+      nxc = (uint32_t)__popcll(m);
+      xpos = xfirst;
     }
     lds_sync();
-    bsel ^= 1u;
-    bn = nbn; be = nbe; bf = nbf;
+    for (uint32_t c = (uint32_t)lane; c < w; c += 64u) mcur[c] = 0;  // recycled for the level after next
+    lds_sync();
+    msel ^= 1u;
+    xcount += nin_total;
     nsub += nin_total;
-    nbord = nin_total;
+#ifdef G2S_PROF_A
+    pe[1] += __builtin_amdgcn_s_memtime() - et0;
+#endif
   }
+#ifdef G2S_PROF_A
+  const unsigned long long et_pack = __builtin_amdgcn_s_memtime();
+#endif
+  if (over) lflags |= G2S_DEV_OVERFLOW_B;
   for (int o = 32; o > 0; o >>= 1) lflags |= __shfl_xor(lflags, o);
   if (lflags & G2S_DEV_OVERFLOW_B) {
     if (lane == 0) go->flags = gflags | lflags;
     return;
   }
   // ---- pack: reserve exactly n_sub records in the dense output --------------------------
-  __threadfence_block();
+  // (the fence makes this wave's own stores, including the 4-byte link patches, visible to
+  // its loads: they were written through to L2, the L1 copies are dropped)
+  __threadfence();
   unsigned long long base = 0;
   if (lane == 0) base = atomicAdd(out_counter, (unsigned long long)nsub);
   base = __shfl(base, 0);
-  const uint32_t* src = (const uint32_t*)sub;
-  uint32_t* dst = (uint32_t*)(sub_out + base);
-  for (uint32_t i = (uint32_t)lane; i < nsub * 8u; i += 64u)
-    dst[i] = __hip_atomic_load(&src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  {
+    const uint4* src = (const uint4*)sub;
+    uint4* dst = (uint4*)(sub_out + base);
+    const uint32_t nq = nsub * 2u;  // 16-byte halves of the 32-byte records
+    for (uint32_t i0 = 0; i0 < nq; i0 += 256u) {
+      uint4 v[4];
+#pragma unroll
+      for (uint32_t q = 0; q < 4; q++) {  // four independent loads in flight per lane
+        const uint32_t i = i0 + q * 64u + (uint32_t)lane;
+        if (i < nq) v[q] = src[i];
+      }
+#pragma unroll
+      for (uint32_t q = 0; q < 4; q++) {
+        const uint32_t i = i0 + q * 64u + (uint32_t)lane;
+        if (i < nq) dst[i] = v[q];
+      }
+    }
+  }
   if (lane == 0) {
-    go->flags = gflags | lflags;
+    go->flags = gflags | lflags | G2S_DEV_PRED_UNORDERED;
     go->n_sub = nsub;
     go->sub_off = base;
     go->x_sub = xcount;
     go->stat[6] = st_slowD | (st_bulkD << 16);
     go->stat[7] = (uint32_t)((__builtin_amdgcn_s_memtime() - cyc0) >> 8);
+#ifdef G2S_PROF_A
+    go->stat[0] = (uint32_t)(pe[0] >> 8); go->stat[1] = (uint32_t)(pe[1] >> 8);
+    go->stat[2] = (uint32_t)((__builtin_amdgcn_s_memtime() - et_pack) >> 8); go->stat[3] = (uint32_t)(pe[3] >> 8);
+#endif
   }
 }
 
@@ -1211,47 +1277,46 @@ __global__ __launch_bounds__(64) void g2s_extract_lds(const uint32_t* __restrict
 namespace g2s {
 
 size_t fill_lds_bytes(uint32_t rs_cap, uint32_t fcap) {
-  return 4u * (2 * fcap * 3 + (2 * fcap) * 2 + (2 * fcap) + LDS_TG + 3 * (2 * fcap) + 4 + LDS_TF + 2 * LDS_CW + rs_cap);
+  return 4u * (2 * fcap * 3 + (2 * fcap) * 2 + (2 * fcap) + LDS_TG + 3 * (2 * fcap) + 4 + LDS_TF + 3 * LDS_CW + rs_cap);
 }
 size_t extract_lds_bytes(uint32_t fcap) {
   const uint32_t w = fcap > 256u ? fcap : 256u;
-  return 4u * ((w + 1) + 2 * w + 6 * fcap + 2 * fcap + 4 * fcap + 2 * fcap + 1 + 4 * fcap);
+  return 4u * ((w + 1) + 3 * w + 2 * fcap + fcap + 4 * fcap + fcap + 3 * LDS_XC + 4);
 }
 uint32_t fill_lds_frontier_cap() { return LDS_F; }  // pass 0; later passes use LDS_F_WIDE
 uint32_t fill_lds_max_fuz() { return LDS_TG - 1; }
 
 hipError_t launch_fill_lds(hipStream_t st, uint32_t ngaps, uint32_t rs_cap_max, uint32_t num_oriented,
                            const uint32_t* succ, const GapDev* gaps, const uint32_t* gap_ids,
-                           const uint32_t* flank_nodes, uint64_t* log_all, uint32_t* lvl_all, GapOut* outs,
-                           uint32_t* rs_global, uint32_t fcap) {
+                           const uint32_t* flank_nodes, uint64_t* log_all, uint32_t* lvl_all, uint32_t* plk_all,
+                           uint64_t* xl_all, GapOut* outs, uint32_t* rs_global, uint32_t fcap) {
   if (ngaps == 0) return hipSuccess;
   if (rs_global) {  // right set in HBM: no LDS for it
     const size_t bytes = fill_lds_bytes(0, fcap);
     hipError_t e = hipFuncSetAttribute((const void*)g2s_fill_lds_rsg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(g2s_fill_lds_rsg, dim3(ngaps), dim3(64), bytes, st, succ, gaps, gap_ids, flank_nodes, log_all,
-                       lvl_all, outs, num_oriented, rs_global, fcap);
+                       lvl_all, plk_all, xl_all, outs, num_oriented, rs_global, fcap);
     return hipGetLastError();
   }
   const size_t bytes = fill_lds_bytes(rs_cap_max, fcap);
   hipError_t e = hipFuncSetAttribute((const void*)g2s_fill_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(g2s_fill_lds, dim3(ngaps), dim3(64), bytes, st, succ, gaps, gap_ids, flank_nodes, log_all, lvl_all,
-                     outs, num_oriented, fcap);
+                     plk_all, xl_all, outs, num_oriented, fcap);
   return hipGetLastError();
 }
 
-hipError_t launch_extract_lds(hipStream_t st, uint32_t ngaps, uint32_t num_oriented, const uint32_t* succ,
-                              const GapDev* gaps, const uint32_t* gap_ids, const uint32_t* flank_nodes,
-                              const uint64_t* log_all, const uint32_t* lvl_all, SubState* sub_scratch,
-                              SubState* sub_out, unsigned long long* out_counter, GapOut* outs, int skip_confident,
-                              uint32_t fcap) {
+hipError_t launch_extract_lds(hipStream_t st, uint32_t ngaps, const GapDev* gaps, const uint32_t* gap_ids,
+                              const uint32_t* flank_nodes, const uint64_t* log_all, const uint32_t* lvl_all,
+                              const uint32_t* plk_all, const uint64_t* xl_all, SubState* sub_scratch, SubState* sub_out,
+                              unsigned long long* out_counter, GapOut* outs, int skip_confident, uint32_t fcap) {
   if (ngaps == 0) return hipSuccess;
   const size_t bytes = extract_lds_bytes(fcap);
   hipError_t e = hipFuncSetAttribute((const void*)g2s_extract_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(g2s_extract_lds, dim3(ngaps), dim3(64), bytes, st, succ, gaps, gap_ids, flank_nodes, log_all,
-                     lvl_all, sub_scratch, sub_out, out_counter, outs, skip_confident, num_oriented, fcap);
+  hipLaunchKernelGGL(g2s_extract_lds, dim3(ngaps), dim3(64), bytes, st, gaps, gap_ids, flank_nodes, log_all, lvl_all,
+                     plk_all, xl_all, sub_scratch, sub_out, out_counter, outs, skip_confident, fcap);
   return hipGetLastError();
 }
 

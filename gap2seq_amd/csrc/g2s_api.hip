@@ -397,7 +397,7 @@ struct g2s_session {
   bool no_lds_tier = false;  // G2S_NO_LDS_TIER=1: force the general HBM tier (tests, A/B timing)
   size_t mem_budget = 0;  // bytes of HBM this session may use for work areas
   DevBuf d_gaps, d_ids, d_flank, d_outs, d_rs, d_rlog, d_keys, d_cnt, d_mark, d_slog, d_subscr, d_subout, d_counter;
-  DevBuf d_log, d_lvl;  // LDS tier: level-ordered state log + level offsets
+  DevBuf d_log, d_lvl, d_plk, d_xl;  // LDS tier: level-ordered state log, level offsets, parent links
   std::vector<void*> tier_pool;  // recycled TierData (pinned host buffers)
   size_t tier_cursor = 0;        // next free slot of tier_pool in the current run
   const void* flank_owner = nullptr;  // batch whose flank nodes d_flank holds
@@ -441,7 +441,7 @@ extern "C" void g2s_session_destroy(g2s_session* s) {
   (void)hipSetDevice(s->device);
   DevBuf* bufs[] = {&s->d_gaps, &s->d_ids, &s->d_flank, &s->d_outs, &s->d_rs, &s->d_rlog, &s->d_keys,
                     &s->d_cnt, &s->d_mark, &s->d_slog, &s->d_subscr, &s->d_subout, &s->d_counter,
-                    &s->d_log, &s->d_lvl};
+                    &s->d_log, &s->d_lvl, &s->d_plk, &s->d_xl};
   for (DevBuf* b : bufs) b->release();
   delete s->pool;
   for (void* v : s->tier_pool) { TierData* t = (TierData*)v; t->outs.release(); t->subs.release(); delete t; }
@@ -631,7 +631,7 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
   HIP_TRY(s->h_gaps.ensure(std::max<size_t>(n * sizeof(GapDev), 16)));
   GapDev* gd = (GapDev*)s->h_gaps.p;
   memset(gd, 0, n * sizeof(GapDev));
-  uint64_t rs_total = 0, rlog_total = 0, st_total = 0, slog_total = 0, lvl_total = 0;
+  uint64_t rs_total = 0, rlog_total = 0, st_total = 0, slog_total = 0, lvl_total = 0, xl_total = 0;
   uint32_t lds_cap_max = 0;
   td->gap_ids = ids;
   for (size_t x = 0; x < ids.size(); x++) {
@@ -652,6 +652,11 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
     d.st_off = st_total; st_total += 2ull * p.slog_cap;
     d.slog_off = slog_total; slog_total += p.slog_cap;
     d.lvl_off = lvl_total; lvl_total += (uint64_t)(d.D + 2);
+    if (lds) {  // extra-parent list of merged states: a quarter of the log's capacity
+      d.pad0 = std::max(64u, p.slog_cap / 4);
+      d.st_off = xl_total;
+      xl_total += d.pad0;
+    }
     if (lds && !rs_in_hbm) {
       const uint32_t c = lds_rs_cap(j, d_err, lds_room_override ? lds_room_override : lds_room(ids.size()));
       d.rs_mask = c - 1;
@@ -672,6 +677,8 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
   if (lds) {
     HIP_TRY(s->d_log.ensure(slog_total * 8));
     HIP_TRY(s->d_lvl.ensure(lvl_total * 4));
+    HIP_TRY(s->d_plk.ensure(slog_total * 4));
+    HIP_TRY(s->d_xl.ensure(std::max<uint64_t>(xl_total * 8, 16)));
     if (rs_in_hbm) {
       HIP_TRY(s->d_rs.ensure(rs_total * 4));
       HIP_TRY(hipMemsetAsync(s->d_rs.p, 0xFF, rs_total * 4, st));
@@ -681,13 +688,13 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
     const uint32_t num_oriented = (uint32_t)(2 * s->graph->g->n);
     HIP_TRY(launch_fill_lds(st, (uint32_t)ids.size(), lds_cap_max, num_oriented, dg.succ, (const GapDev*)s->d_gaps.p,
                             (const uint32_t*)s->d_ids.p, (const uint32_t*)s->d_flank.p, (uint64_t*)s->d_log.p,
-                            (uint32_t*)s->d_lvl.p, (GapOut*)s->d_outs.p, rs_in_hbm ? (uint32_t*)s->d_rs.p : nullptr,
-                            fcap));
+                            (uint32_t*)s->d_lvl.p, (uint32_t*)s->d_plk.p, (uint64_t*)s->d_xl.p, (GapOut*)s->d_outs.p,
+                            rs_in_hbm ? (uint32_t*)s->d_rs.p : nullptr, fcap));
     HIP_TRY(hipEventRecord(s->ev[2], st));
-    HIP_TRY(launch_extract_lds(st, (uint32_t)ids.size(), num_oriented, dg.succ, (const GapDev*)s->d_gaps.p,
-                               (const uint32_t*)s->d_ids.p, (const uint32_t*)s->d_flank.p, (const uint64_t*)s->d_log.p,
-                               (const uint32_t*)s->d_lvl.p, (SubState*)s->d_subscr.p, (SubState*)s->d_subout.p,
-                               (unsigned long long*)s->d_counter.p, (GapOut*)s->d_outs.p,
+    HIP_TRY(launch_extract_lds(st, (uint32_t)ids.size(), (const GapDev*)s->d_gaps.p, (const uint32_t*)s->d_ids.p,
+                               (const uint32_t*)s->d_flank.p, (const uint64_t*)s->d_log.p, (const uint32_t*)s->d_lvl.p,
+                               (const uint32_t*)s->d_plk.p, (const uint64_t*)s->d_xl.p, (SubState*)s->d_subscr.p,
+                               (SubState*)s->d_subout.p, (unsigned long long*)s->d_counter.p, (GapOut*)s->d_outs.p,
                                s->params.skip_confident ? 1 : 0, fcap));
     HIP_TRY(hipEventRecord(s->ev[3], st));
   } else {
@@ -777,6 +784,7 @@ void analyze_gap(g2s_batch* b, size_t i, const FillParams& fp, g2s_result* r) {
   if (b->mem_exceeded[i]) { gi.kind = 2; r->count = -1; r->flags |= G2S_GAP_MEM_EXCEEDED; return; }
   const SubView& v = b->views[i];
   SubPrep& pp = b->prep[i];
+  if (v.out->flags & G2S_DEV_PRED_UNORDERED) sub_order_preds(*b->s->graph->g, const_cast<SubState*>(v.st), v.n);
   sub_analyze(fp, j, v, &pp);
   r->phaseC_count = v.out->c_count;
   r->n_lengths = v.out->n_len;
@@ -898,7 +906,9 @@ int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
         fprintf(stderr, "[g2s]   prof B (kcyc): bulk ok %u | bulk fail %u (n %u) | single %u (n %u) | narrow %u (n %u) | wide %u (n %u)\n",
                 o.prof[8] >> 2, o.prof[9] >> 2, o.prof[13] & 0xFFFF, o.prof[10] >> 2, o.prof[14] & 0xFFFF, o.prof[11] >> 2,
                 o.prof[14] >> 16, o.prof[12] >> 2, o.prof[13] >> 16);
-        fprintf(stderr, "[g2s]   prof B narrow (kcyc): load+prune %u | claim %u | pass2 %u | seed+append+hits %u | phase C %u\n",
+        fprintf(stderr, "[g2s]   prof D1 (kcyc): bulk %u | per-level %u | pack %u | startup %u\n", o.stat[0] >> 2, o.stat[1] >> 2,
+                o.stat[2] >> 2, o.stat[3] >> 2);
+        if (0) fprintf(stderr, "[g2s]   prof B narrow (kcyc): load+prune %u | claim %u | pass2 %u | seed+append+hits %u | phase C %u\n",
                 o.prof[7] >> 2, o.prof[15] >> 2, o.stat[0] >> 2, o.stat[1] >> 2, o.stat[2] >> 2);
 #endif
       }

@@ -87,6 +87,17 @@ int strong_components(int nv, const std::vector<int>& off, const std::vector<int
 
 }  // namespace
 
+void sub_order_preds(const Graph& g, SubState* st, uint32_t n) {
+  for (uint32_t i = 0; i < n; i++) {
+    SubState& s = st[i];
+    if (s.pred[1] < 0 && s.pred[2] < 0 && s.pred[3] < 0) continue;  // at most one parent: any slot will do
+    int32_t in[4] = {s.pred[0], s.pred[1], s.pred[2], s.pred[3]};
+    s.pred[0] = s.pred[1] = s.pred[2] = s.pred[3] = -1;
+    for (int q = 0; q < 4; q++)
+      if (in[q] >= 0) s.pred[g.lastnt[st[(size_t)in[q]].node ^ 1u]] = in[q];
+  }
+}
+
 void sub_analyze(const FillParams& p, const GapJob& job, const SubView& v, SubPrep* out) {
   const GapOut& go = *v.out;
   out->count = go.c_count;

@@ -56,6 +56,11 @@ struct SubPrep {
   int stop_depth[2] = {-1, -1}; // depth every traceback from start i stops at, or -1 when it depends on the draws
 };
 
+// Closures from the LDS tier list a state's parents from slot 0 in arrival order
+// (G2S_DEV_PRED_UNORDERED); the traceback draws among them in GATB predecessor order
+// (:1476-1513), so states with several parents are put in order here: the slot of parent p
+// is the base that p^1 ends with (pred(v)[i] = succ(v^1)[i]^1).  In place, idempotent.
+void sub_order_preds(const Graph& g, SubState* st, uint32_t n);
 // SCC / branch rule / stop-depth analysis of one gap; thread safe.
 void sub_analyze(const FillParams& p, const GapJob& job, const SubView& v, SubPrep* out);
 // Number of rand() draws the traceback will consume when pathLengths[pick] is chosen,
