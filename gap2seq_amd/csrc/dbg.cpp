@@ -223,6 +223,30 @@ void unitig_order(const std::vector<uint32_t>& succ, uint64_t n, bool even_k, st
   *n_unitigs = unitigs;
 }
 
+// unitig-start bitmap from the id-space successor table (same predicate as unitig_order's step)
+void build_ustart(Graph& g) {
+  const uint64_t n = g.n;
+  g.ustart.assign((size_t)((n + 63) / 64 + 1), 0);
+  auto only_out = [&](uint32_t v, uint32_t* w) -> int {
+    int c = 0;
+    for (int nt = 0; nt < 4; nt++) {
+      const uint32_t x = g.succ[(size_t)v * 4 + nt];
+      if (x != kInvalidNode) { c++; *w = x; }
+    }
+    return c;
+  };
+  for (uint64_t i = 0; i < n; i++) {
+    bool internal = false;
+    if (i > 0) {
+      const uint32_t v = (uint32_t)(2 * (i - 1)), want = (uint32_t)(2 * i);
+      uint32_t w = kInvalidNode, back = kInvalidNode;
+      internal = only_out(v, &w) == 1 && w == want && only_out(want ^ 1u, &back) == 1 && back == (v ^ 1u);
+    }
+    if (!internal) g.ustart[(size_t)(i >> 6)] |= 1ull << (i & 63);
+  }
+  for (uint64_t i = n; i < (uint64_t)g.ustart.size() * 64; i++) g.ustart[(size_t)(i >> 6)] |= 1ull << (i & 63);
+}
+
 template <class KT>
 void finish_graph(Graph& g, int nthreads) {
   build_bucket_index<KT>(g);
@@ -260,6 +284,7 @@ void finish_graph(Graph& g, int nthreads) {
       g.lastnt[(size_t)id * 2 + (size_t)(1 ^ g.flip[(size_t)r])] = last_rev;
     }
   });
+  build_ustart(g);
 }
 
 }  // namespace
@@ -350,6 +375,7 @@ Graph* graph_load(const std::string& path, std::string* err) {
   g->id2rank.assign((size_t)g->n, 0);
   for (uint64_t r = 0; r < g->n; r++) g->id2rank[g->rank2id[(size_t)r]] = (uint32_t)r;
   if (!g->wide) build_bucket_index<uint64_t>(*g); else build_bucket_index<u128>(*g);
+  build_ustart(*g);
   return g;
 }
 

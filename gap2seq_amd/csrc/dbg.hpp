@@ -18,10 +18,12 @@
 namespace g2s {
 
 static const uint32_t kInvalidNode = 0xFFFFFFFFu;
+static const uint32_t kUstartPad = 64;  // 64-bit words of all-ones padding on either side of the device bitmap
 
 struct DeviceGraph {
   uint32_t* succ = nullptr;  // [2n*4]
   uint32_t* pred = nullptr;  // [2n*4], only when k is even (palindromic k-mers exist)
+  uint64_t* ustart = nullptr;  // unitig-start bitmap, offset by kUstartPad words of all-ones padding
   uint64_t bytes = 0;
 };
 
@@ -50,6 +52,10 @@ struct Graph {
   std::vector<uint32_t> succ;
   std::vector<uint32_t> pred;     // explicit predecessor table, even k only
   std::vector<uint8_t> lastnt;    // [2n] code of the last base of the oriented sequence
+  // bit i set: k-mer index i is the first of its unitig in numbering order, i.e. the edge
+  // 2(i-1) -> 2i is NOT unitig-internal.  Between two set bits the walk arithmetic
+  // (v +/- 2) is exact: every node there has exactly one predecessor and one successor.
+  std::vector<uint64_t> ustart;
   std::map<int, DeviceGraph> dev; // per device copies
 
   // buildNode + contains

@@ -29,7 +29,7 @@ size_t extract_lds_bytes(uint32_t fcap);
 uint32_t fill_lds_frontier_cap();
 uint32_t fill_lds_max_fuz();
 hipError_t launch_fill_lds(hipStream_t st, uint32_t ngaps, uint32_t rs_cap_max, uint32_t num_oriented,
-                           const uint32_t* succ, const GapDev* gaps, const uint32_t* gap_ids,
+                           const uint32_t* succ, const uint64_t* ustart, const GapDev* gaps, const uint32_t* gap_ids,
                            const uint32_t* flank_nodes, uint64_t* log_all, uint32_t* lvl_all, uint32_t* plk_all,
                            uint64_t* xl_all, GapOut* outs, uint32_t* rs_global /* nullptr: right set in LDS */,
                            uint32_t fcap /* frontier capacity */);

@@ -85,24 +85,32 @@ __device__ __forceinline__ uint32_t leading_levels(bool p, uint32_t lg) {
 // step: measured 2.4 k cycles per level against 6.8 k for a one-level bulk step.)
 __device__ __forceinline__ uint32_t log2ceil16(uint32_t r) { return r <= 1 ? 0u : r <= 2 ? 1u : r <= 4 ? 2u : r <= 8 ? 3u : 4u; }
 
-// Right set keyed by k-mer index: entry = index << 2 | strand bits.  The reference's set
-// is keyed by k-mer as well (membership at :1050 ignores the strand), so one probe answers
-// "is either strand of this k-mer in the right set" and, on insert, whether the other
-// strand is already there (Q7).  G = false: table in LDS; G = true: table in HBM (gaps
-// whose right set outgrows the LDS), re-read with agent-scope loads because it is
-// mutated by L2 atomics.  Returns bit0 = newly inserted orientation, bit1 = both strands
-// now present, bit2 = table full.
+// Right set keyed by k-mer index: entry = index << 4 | expanded bits (3..2) | visited bits (1..0),
+// one bit per strand.  The reference's set is keyed by k-mer as well (membership at :1050
+// ignores the strand), so one probe answers "is either strand of this k-mer in the right
+// set" and, on insert, whether the other strand is already there (Q7).  The expanded bit
+// marks nodes reached with depth budget left (they were expanded by the reference's BFS):
+// it only feeds the expansion counter.  G = false: table in LDS; G = true: table in HBM
+// (gaps whose right set outgrows the LDS), re-read with agent-scope loads because it is
+// mutated by L2 atomics.  Returns bit0 = orientation newly visited, bit1 = both strands now
+// present, bit2 = table full, bit3 = orientation newly expanded.
+#define RS_SHIFT 4u
 template <bool G>
 __device__ __forceinline__ uint32_t rs_load(const uint32_t* p) {
   return G ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+}
+__device__ __forceinline__ uint32_t rs_result(uint32_t old, uint32_t bits) {
+  const uint32_t now = old | bits;
+  return ((bits & 3u & ~old) ? 1u : 0u) | (((now & 3u) == 3u) ? 2u : 0u) | ((bits & 12u & ~old) ? 8u : 0u);
 }
 // LDS flavour: buckets of 4 consecutive slots read with one ds_read_b128.  With linear
 // probing one slot at a time the slowest of 64 lanes needed ~8 probes at load factor 0.5
 // (measured: 1.4 k cycles per insert round); a 4-slot bucket is almost never full, so
 // nearly every lane finishes with a single LDS read.
 template <bool G>
-__device__ uint32_t lrs_insert(uint32_t* tab, uint32_t mask, uint32_t v) {
-  const uint32_t idx = v >> 1, bit = 1u << (v & 1u);
+__device__ uint32_t lrs_insert(uint32_t* tab, uint32_t mask, uint32_t v, bool expanded) {
+  const uint32_t idx = v >> 1;
+  const uint32_t bits = (1u << (v & 1u)) | (expanded ? (4u << (v & 1u)) : 0u);
   if (!G) {
     const uint32_t bmask = mask >> 2;
     uint32_t b = mix32(idx) & bmask;
@@ -113,19 +121,16 @@ __device__ uint32_t lrs_insert(uint32_t* tab, uint32_t mask, uint32_t v) {
       int hit = -1, free_ = -1;
 #pragma unroll
       for (int q = 3; q >= 0; q--) {
-        if (cs[q] != G2S_DEV_INVALID && (cs[q] >> 2) == idx) hit = q;
+        if (cs[q] != G2S_DEV_INVALID && (cs[q] >> RS_SHIFT) == idx) hit = q;
         if (cs[q] == G2S_DEV_INVALID) free_ = q;
       }
       if (hit < 0 && free_ >= 0) {
-        const uint32_t prev = atomicCAS(&slot[free_], G2S_DEV_INVALID, (idx << 2) | bit);
-        if (prev == G2S_DEV_INVALID) return 1u;
-        if ((prev >> 2) == idx) hit = free_;
+        const uint32_t prev = atomicCAS(&slot[free_], G2S_DEV_INVALID, (idx << RS_SHIFT) | bits);
+        if (prev == G2S_DEV_INVALID) return rs_result(0u, bits);
+        if ((prev >> RS_SHIFT) == idx) hit = free_;
         else continue;  // somebody else took the slot: look at this bucket again
       }
-      if (hit >= 0) {
-        const uint32_t old = atomicOr(&slot[hit], bit);
-        return ((old & bit) ? 0u : 1u) | ((((old | bit) & 3u) == 3u) ? 2u : 0u);
-      }
+      if (hit >= 0) return rs_result(atomicOr(&slot[hit], bits), bits);
       b = (b + 1) & bmask;  // bucket full of other k-mers
     }
     return 4u;
@@ -134,13 +139,10 @@ __device__ uint32_t lrs_insert(uint32_t* tab, uint32_t mask, uint32_t v) {
   for (uint32_t i = 0; i <= mask; i++) {
     uint32_t cur = rs_load<G>(&tab[h]);
     if (cur == G2S_DEV_INVALID) {
-      cur = atomicCAS(&tab[h], G2S_DEV_INVALID, (idx << 2) | bit);
-      if (cur == G2S_DEV_INVALID) return 1u;
+      cur = atomicCAS(&tab[h], G2S_DEV_INVALID, (idx << RS_SHIFT) | bits);
+      if (cur == G2S_DEV_INVALID) return rs_result(0u, bits);
     }
-    if ((cur >> 2) == idx) {
-      const uint32_t old = atomicOr(&tab[h], bit);
-      return ((old & bit) ? 0u : 1u) | ((((old | bit) & 3u) == 3u) ? 2u : 0u);
-    }
+    if ((cur >> RS_SHIFT) == idx) return rs_result(atomicOr(&tab[h], bits), bits);
     h = (h + 1) & mask;
   }
   return 4u;
@@ -154,8 +156,8 @@ __device__ bool lrs_has_kmer(const uint32_t* tab, uint32_t mask, uint32_t v) {
     for (uint32_t i = 0; i <= bmask; i++) {
       const uint4 c = *(const uint4*)(tab + b * 4u);
       const uint32_t key = idx;
-      if ((c.x != G2S_DEV_INVALID && (c.x >> 2) == key) || (c.y != G2S_DEV_INVALID && (c.y >> 2) == key) ||
-          (c.z != G2S_DEV_INVALID && (c.z >> 2) == key) || (c.w != G2S_DEV_INVALID && (c.w >> 2) == key))
+      if ((c.x != G2S_DEV_INVALID && (c.x >> RS_SHIFT) == key) || (c.y != G2S_DEV_INVALID && (c.y >> RS_SHIFT) == key) ||
+          (c.z != G2S_DEV_INVALID && (c.z >> RS_SHIFT) == key) || (c.w != G2S_DEV_INVALID && (c.w >> RS_SHIFT) == key))
         return true;
       if (c.x == G2S_DEV_INVALID || c.y == G2S_DEV_INVALID || c.z == G2S_DEV_INVALID || c.w == G2S_DEV_INVALID)
         return false;  // inserts fill the first bucket with room along the probe sequence
@@ -167,7 +169,7 @@ __device__ bool lrs_has_kmer(const uint32_t* tab, uint32_t mask, uint32_t v) {
   for (uint32_t i = 0; i <= mask; i++) {
     const uint32_t cur = rs_load<G>(&tab[h]);
     if (cur == G2S_DEV_INVALID) return false;
-    if ((cur >> 2) == idx) return true;
+    if ((cur >> RS_SHIFT) == idx) return true;
     h = (h + 1) & mask;
   }
   return false;
@@ -177,10 +179,11 @@ __device__ bool lrs_has_kmer(const uint32_t* tab, uint32_t mask, uint32_t v) {
 
 // ============================================================================
 // Phases A + B + C, LDS tier.
-// dynamic LDS: [fa 2F][fn 2F][fc 2F][lh 2F x u64][lhslot 2F][tgt TG][th 3*TH][misc 4][tflt 128][cw 3x256][rs rs_cap]
+// dynamic LDS: [fa 2F][fn 2F][fc 2F][lh 2F x u64][lhslot 2F][th 3*TH][tgt TG][misc 4][tflt 128][cw 3x256][rs rs_cap]
 // ============================================================================
 template <bool RSG>
-__device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ, const GapDev* __restrict__ gaps,
+__device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ,
+                                              const uint64_t* __restrict__ ustart, const GapDev* __restrict__ gaps,
                                               const uint32_t* __restrict__ gap_ids,
                                               const uint32_t* __restrict__ flank_nodes, uint64_t* log_all,
                                               uint32_t* lvl_all, uint32_t* plk_all, uint64_t* xl_all, GapOut* outs,
@@ -198,11 +201,11 @@ __device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ,
   uint32_t* fc = fn + 2 * F;                  // phase B frontier counts [2][F]
   uint64_t* lh = (uint64_t*)(fc + 2 * F);     // level merge table keys
   uint32_t* lhslot = (uint32_t*)(lh + LH);
-  uint32_t* tgt = lhslot + LH;
-  uint32_t* th_j = tgt + LDS_TG;
+  uint32_t* th_j = lhslot + LH;               // (fn .. th_c are contiguous: phase A keeps its labels there)
   uint32_t* th_d = th_j + TH;
   uint32_t* th_c = th_d + TH;
-  uint32_t* misc = th_c + TH;                 // [0] = number of target hits
+  uint32_t* tgt = th_c + TH;
+  uint32_t* misc = tgt + LDS_TG;              // [0] = number of target hits
   uint32_t* tflt = misc + 4;                  // exact target filter: 128 direct-mapped slots
   uint32_t* cw_v = tflt + LDS_TF;             // wide levels: compacted candidate nodes / counts
   uint32_t* cw_c = cw_v + LDS_CW;
@@ -274,219 +277,176 @@ __device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ,
   bool overflow = (gd.rmf + 1 > (int)LDS_TG);
 
   // ---------------- phase A: right BFS (Gap2Seq.cpp:871-982) -------------------
+  // The reference's visited-set BFS computes {v : depth(v) <= right_half}, depth = fewest
+  // predecessor steps from a right-flank seed (seed j starts at depth j); only membership is
+  // consumed later (:1050).  A level-synchronous sweep would need right_half dependent
+  // steps; instead the search runs over UNITIGS: an event (entry node, depth) covers the
+  // entry's unitig backwards by arithmetic (ids -/+ 2, the unitig-start bitmap says how
+  // far), inserts that run into the right set 64 nodes per instruction, and, where the
+  // unitig ends with budget left, reads one successor record to propose the predecessor
+  // unitigs.  Depth labels per entry node (LDS table, 64-bit atomic min) make this a
+  // label-correcting search: an entry is processed again only if it was reached with a
+  // smaller depth, so the final set is exactly the reference's.  The number of dependent
+  // steps is the number of unitig hops (tens), not the number of levels (hundreds).
   uint32_t nvis = 0, xa = 0;
   uint32_t st_slowA = 0, st_bulkA = 0, st_slowB = 0, st_bulkB = 0;
 #ifdef G2S_PROF_A
-  unsigned long long pa[4] = {0, 0, 0, 0}, pb[2] = {0, 0}, pc[5] = {0, 0, 0, 0, 0}, pd[5] = {0, 0, 0, 0, 0};
+  unsigned long long pc[5] = {0, 0, 0, 0, 0}, pd[5] = {0, 0, 0, 0, 0};
   uint32_t pnB[5] = {0, 0, 0, 0, 0};
-  uint32_t pn_fail = 0, pn_wide = 0;
 #endif
   const unsigned long long cyc0 = __builtin_amdgcn_s_memtime();
-  {
-    uint32_t cur = 0, nb = 0;
-    const uint32_t s0 = rseeds[0];
-    if (s0 != G2S_DEV_INVALID) {
-      if (lane == 0) { (void)lrs_insert<RSG>(rs, rmask, s0); fa[0] = s0; }
-      nb = 1;
-      nvis = 1;
-    }
+  if (!overflow) {
+    uint64_t* lab = (uint64_t*)fn;        // labels (entry node << 32 | depth): the arrays of phase B are idle
+    const uint32_t LAB = 8u * F;          // [fn 2F][fc 2F][lh 4F][lhslot 2F][th 6F] = 16F words
+    for (uint32_t i = (uint32_t)lane; i < LAB; i += 64u) lab[i] = G2S_DEV_EMPTY64;
     lds_sync();
-    for (int d = 1; d <= gd.right_half && !overflow; d++) {
+    uint32_t nlab = 0;
+    // propose depth dp for entry node p; true when the label improved (the caller queues p)
+    auto relabel = [&](bool active, uint32_t p, uint32_t dp) -> bool {
+      bool improved = false, fresh = false;
+      if (active) {
+        const uint64_t key = ((uint64_t)p << 32) | dp;
+        uint32_t h = mix32(p) & (LAB - 1u);
+        while (true) {
+          const uint64_t c = lab[h];
+          if ((uint32_t)(c >> 32) == p) {
+            improved = atomicMin((unsigned long long*)&lab[h], (unsigned long long)key) > key;
+            break;
+          }
+          if (c == G2S_DEV_EMPTY64) {
+            const unsigned long long prev =
+                atomicCAS((unsigned long long*)&lab[h], (unsigned long long)G2S_DEV_EMPTY64, (unsigned long long)key);
+            if (prev == G2S_DEV_EMPTY64) { improved = true; fresh = true; break; }
+            continue;  // somebody took the slot: look at it again
+          }
+          h = (h + 1) & (LAB - 1u);
+        }
+      }
+      nlab += (uint32_t)__popcll(__ballot(fresh));
+      return improved;
+    };
+    auto label_of = [&](uint32_t p) -> uint32_t {
+      uint32_t h = mix32(p) & (LAB - 1u);
+      while (true) {
+        const uint64_t c = lab[h];
+        if ((uint32_t)(c >> 32) == p) return (uint32_t)c;
+        h = (h + 1) & (LAB - 1u);
+      }
+    };
+    uint32_t cur = 0, ne = 0;
+    {  // seeds: right.substr(len-k-j, k) enters at depth j (:878-884, :953-976)
+      const bool have = lane <= gd.rmf && lane < (int)LDS_TG;
+      const uint32_t sd = have ? rseeds[lane] : G2S_DEV_INVALID;
+      const bool imp = relabel(sd != G2S_DEV_INVALID && lane <= gd.right_half, sd, (uint32_t)lane);
+      const uint64_t m = __ballot(imp);
+      if (imp) fa[(uint32_t)__popcll(m & lanes_below(lane))] = sd;
+      ne = (uint32_t)__popcll(m);
+      lds_sync();
+    }
+    while (ne > 0 && !overflow) {
       uint32_t* fcur = fa + cur * F;
       uint32_t* fnxt = fa + (cur ^ 1u) * F;
-      uint32_t nnew = 0;
-      // ---- bulk step: every border node (<= 16) sits inside a unitig, where the only
-      // predecessor of id v is v-2 (even orientation) or v+2 (odd), see dbg.hpp.  Lanes are
-      // level-major (lane = i*Rp + r: run r, level d+i); each lane speculates its node and
-      // verifies it with one 16 B record load (coalesced over the wave).  The leading
-      // levels on which all runs hold are inserted into the right set at once.
-#ifdef G2S_PROF_A
-      unsigned long long pt0 = __builtin_amdgcn_s_memtime();
-#endif
-      if (nb >= 1 && nb <= 16 && d > gd.rmf) {
-        const uint32_t R = nb, lg = log2ceil16(R), Rp = 1u << lg;
-        const uint32_t r = (uint32_t)lane & (Rp - 1u), i = (uint32_t)lane >> lg;
-        const bool mine = r < R;
-        const uint32_t n = mine ? fcur[r] : 0u;
-        const uint32_t L = (uint32_t)min((int)(64u >> lg), gd.right_half - d + 1);
-#ifdef G2S_PROF_A
-        unsigned long long ptl = pt0;
-#endif
-        const uint32_t step = 2u * (i + 1u);
-        const bool up = (n & 1u) != 0;  // odd orientation: predecessors have larger ids
-        const bool inrange = mine && i < L && (up ? (n + step < num_oriented) : (n >= step));
-        const uint32_t x = up ? n + step - 2u : n - (step - 2u);  // border node of level d+i
-        const uint32_t p = up ? n + step : n - step;               // its speculated predecessor
-        // the verification load goes out first; the checks below run while it is in flight
-        uint4 rec = make_uint4(G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID);
-        if (inrange) rec = *(const uint4*)(succ + (size_t)(x ^ 1u) * 4);
-        // A run that follows another one over the same ids (same orientation, fewer than
-        // `levels` steps behind) would race with it for "who visited first": it may only
-        // advance up to the other run's border node, which is already in the right set.
-        // (Run q's node sits in lane q; readlane keeps this loop free of LDS traffic.)
-        uint32_t lim = 64u;
-        if (R > 1) {
-          for (uint32_t q = 0; q < R; q++) {
-            const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)n, (int)q);
-            const int ahead = up ? (int)(o - n) : (int)(n - o);  // ids the other run is in front of mine
-            const bool same = ((o ^ n) & 1u) == 0u && ahead > 0;
-            const uint32_t cand = same ? (uint32_t)ahead >> 1 : 64u;
-            lim = min(lim, cand);
+      uint32_t nn = 0;
+      st_bulkA++;
+      for (uint32_t e0 = 0; e0 < ne && !overflow; e0 += 16u) {
+        st_slowA++;
+        const uint32_t G = min(16u, ne - e0), lg = log2ceil16(G), Rp = 1u << lg, LP = 64u >> lg;
+        const uint32_t r = (uint32_t)lane & (Rp - 1u), jl = (uint32_t)lane >> lg;  // event r of the group, lane jl of it
+        const bool mine = r < G;
+        const uint32_t v = mine ? fcur[e0 + r] : 0u;
+        const uint32_t d = mine ? label_of(v) : 0u;
+        const uint32_t B = (uint32_t)gd.right_half - d;  // nodes at offsets t <= B have depth <= right_half
+        const bool up = (v & 1u) != 0;                    // odd orientation: predecessors have larger ids
+        const uint32_t idx = v >> 1;
+        // ---- how far does the unitig go?  each of the event's LP lanes reads one bitmap word
+        uint32_t dist = 0xFFFFFFFFu;  // offset of the unitig's last node in walking direction, if seen
+        if (mine) {
+          const int64_t w0 = (int64_t)(idx >> 6);
+          if (!up) {
+            uint64_t word = ustart[w0 - (int64_t)jl];
+            if (jl == 0) word &= ~0ull >> (63u - (idx & 63u));
+            if (word) dist = idx - (uint32_t)((w0 - (int64_t)jl) * 64 + (63 - __builtin_clzll(word)));
+          } else {
+            uint64_t word = ustart[w0 + (int64_t)jl];
+            if (jl == 0) word = (idx & 63u) == 63u ? 0ull : word & (~0ull << ((idx & 63u) + 1u));
+            if (word) dist = (uint32_t)((w0 + (int64_t)jl) * 64 + __builtin_ctzll(word)) - 1u - idx;
           }
         }
-        bool ok = !mine;
-        if (inrange) {
-          uint32_t nt;
-          ok = only_slot(rec, &nt) == (p ^ 1u) && i < lim;
-#ifdef G2S_PROF_A
-          { int okk = ok; asm volatile("" :: "v"(okk)); }
-          ptl = __builtin_amdgcn_s_memtime();
-#endif
+        const uint64_t runmask = (lg == 0 ? ~0ull : lg == 1 ? 0x5555555555555555ull : lg == 2 ? 0x1111111111111111ull
+                                  : lg == 3 ? 0x0101010101010101ull : 0x0001000100010001ull) << r;
+        const uint64_t fm = __ballot(dist != 0xFFFFFFFFu) & runmask;
+        // the nearest boundary is the one seen by the event's lowest lane; else the window's edge
+        uint32_t tmax;
+        bool bounded = fm != 0;
+        if (bounded) tmax = (uint32_t)__shfl((int)dist, __builtin_ctzll(fm));
+        else tmax = !up ? (idx & 63u) + 64u * (LP - 1u) : (63u - (idx & 63u)) + 64u * (LP - 1u);
+        const uint32_t L = mine ? min(tmax, B) + 1u : 0u;  // nodes of the run: offsets 0 .. L-1
+        // ---- insert the runs of the group, 64 nodes per round, balanced over the lanes
+        uint32_t incl = (jl == 0 && mine) ? L : 0u;  // inclusive prefix of L over the events, in lanes 0..Rp-1
+        for (uint32_t o = 1; o < Rp; o <<= 1) {
+          const uint32_t t = (uint32_t)__shfl_up((int)incl, (int)o);
+          if ((uint32_t)lane >= o && (uint32_t)lane < Rp) incl += t;
         }
-#ifdef G2S_PROF_A
-        { uint64_t bm = __ballot(ok); asm volatile("" :: "s"(bm)); }
-        unsigned long long pt2 = __builtin_amdgcn_s_memtime();
-        ptl = __shfl((int)(ptl - pt0), 0);  // lane 0 always loads (run 0, level 0)
-        pb[0] += ptl; pb[1] += pt2 - pt0 - ptl;
-#endif
-        const uint32_t lok = leading_levels(ok, lg);
-        if (lok >= (lg == 6u ? 1u : 2u)) {
-          const bool act = mine && i < lok;
-          uint32_t isnew = 0;
-          if (act) {
-            const uint32_t rr = lrs_insert<RSG>(rs, rmask, p);
+        const uint32_t total = (uint32_t)__shfl((int)incl, (int)(Rp - 1u));
+        for (uint32_t k0 = 0; k0 < total; k0 += 64u) {
+          const uint32_t k = k0 + (uint32_t)lane;
+          uint32_t ev = 0;  // event whose run holds item k: the first with inclusive prefix > k
+          for (uint32_t q = 0; q < G; q++) {
+            const uint32_t iq = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)q);
+            ev += (k >= iq) ? 1u : 0u;
+          }
+          if (ev >= G) ev = G - 1u;  // lanes past the end: any valid source lane
+          // (cross-lane reads happen with every lane active: a disabled source lane reads as 0)
+          const uint32_t startq = (uint32_t)__shfl((int)incl, (int)(ev ? ev - 1u : 0u));
+          const uint32_t ve = (uint32_t)__shfl((int)v, (int)ev), de = (uint32_t)__shfl((int)d, (int)ev);
+          uint32_t isnew = 0, isexp = 0;
+          if (k < total) {
+            const uint32_t t = k - (ev ? startq : 0u);
+            const uint32_t node = (ve & 1u) ? ve + 2u * t : ve - 2u * t;
+            const uint32_t rr = lrs_insert<RSG>(rs, rmask, node, de + t < (uint32_t)gd.right_half);
             isnew = rr & 1u;
+            isexp = (rr >> 3) & 1u;
             if (rr & 2u) flags |= G2S_DEV_Q7_A;
             if (rr & 4u) flags |= G2S_DEV_OVERFLOW_A;
           }
           nvis += (uint32_t)__popcll(__ballot(isnew));
-          if (nvis > rs_cap / 4u * 3u) { overflow = true; break; }
-          // per run: an already visited node ends that walk (visited-set BFS); what lies beyond
-          // it was reached earlier with a larger depth budget, so those inserts were no-ops
-          const uint64_t dupm = __ballot(act && !isnew);
-          uint32_t first_dup = lok;  // level index of this run's first duplicate
-          {
-            // bits of run r sit at r, r+Rp, ...: keep those, the lowest one is the first duplicate
-            const uint64_t gm = lg == 0 ? ~0ull : lg == 1 ? 0x5555555555555555ull : lg == 2 ? 0x1111111111111111ull
-                                : lg == 3 ? 0x0101010101010101ull : 0x0001000100010001ull;
-            const uint64_t mm = (dupm >> r) & gm;
-            if (mm) first_dup = min(lok, (uint32_t)__builtin_ctzll(mm) >> lg);
-          }
-          const bool alive = mine && first_dup == lok;
-          // expansions: a run that dies at level q was still expanded at levels 0..q
-          xa += (uint32_t)__popcll(__ballot(act && i <= first_dup));
-          const uint32_t last = (uint32_t)__shfl((int)p, (int)(((lok - 1u) << lg) + r));
-          const uint64_t am = __ballot(alive && i == 0);
-          lds_sync();
-          if (alive && i == 0) fcur[(uint32_t)__popcll(am & lanes_below(lane))] = last;
-          nb = (uint32_t)__popcll(am);
-          lds_sync();
-          d += (int)lok - 1;
-          st_bulkA++;
-#ifdef G2S_PROF_A
-          pa[0] += __builtin_amdgcn_s_memtime() - pt0;
-#endif
-          if (nb == 0) break;  // border empty and no seed left (d > rmf)
-          continue;
+          xa += (uint32_t)__popcll(__ballot(isexp));
         }
-#ifdef G2S_PROF_A
-        { unsigned long long t = __builtin_amdgcn_s_memtime(); pa[1] += t - pt0; pt0 = t; pn_fail++; }
-#endif
+        if (nvis > rs_cap / 4u * 3u) { overflow = true; break; }
+        // ---- where a run stopped with budget left: the predecessors of its last node
+        // (unitig boundary: one record, 4 lanes), or the next node of the same unitig when
+        // the bitmap window was too short to see the boundary
+        {
+          const uint32_t er = (uint32_t)lane >> 2, nt = (uint32_t)lane & 3u;  // event, slot
+          const uint32_t ve = (uint32_t)__shfl((int)v, (int)er), de = (uint32_t)__shfl((int)d, (int)er);
+          const uint32_t te = (uint32_t)__shfl((int)tmax, (int)er);
+          const bool be = __shfl((int)bounded, (int)er) != 0;
+          const bool live = er < G && de + te < (uint32_t)gd.right_half;  // the run's last node is expanded
+          const uint32_t last = (ve & 1u) ? ve + 2u * te : ve - 2u * te;
+          uint32_t p = G2S_DEV_INVALID;
+          if (live && be) p = flip(succ[(size_t)(last ^ 1u) * 4 + nt]);       // graph.predecessors(last)[nt]
+          else if (live && nt == 0) p = (ve & 1u) ? last + 2u : last - 2u;     // still inside the unitig
+          const bool imp = relabel(p != G2S_DEV_INVALID, p, de + te + 1u);
+          const uint64_t m = __ballot(imp);
+          if (imp) {
+            const uint32_t at = nn + (uint32_t)__popcll(m & lanes_below(lane));
+            if (at < F) fnxt[at] = p;
+          }
+          nn += (uint32_t)__popcll(m);
+        }
+        if (nn > F) { overflow = true; flags |= G2S_DEV_WHY_FRONTIER; break; }
+        if (nlab > LAB / 2u) { overflow = true; break; }
       }
-      st_slowA++;
-#ifdef G2S_PROF_A
-      const bool was_wide = nb > 16;
-#endif
-      xa += nb;
-      if (nb > 16) {
-        // wide border: one border node per lane, its whole 16 B record in one load (a single
-        // HBM round trip for the level).  Most slots are empty, so the valid predecessors are
-        // first compacted into an LDS list (the merge table of phase B is idle during phase A)
-        // and then inserted 64 at a time: about one insert round per 64 border nodes, not four.
-        uint32_t* cand = (uint32_t*)lh;  // 4F words
-        uint32_t ncand = 0;
-        for (uint32_t e0 = 0; e0 < nb; e0 += 64u) {
-          const bool valid = e0 + (uint32_t)lane < nb;
-          uint4 rec = make_uint4(G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID);
-          if (valid) rec = *(const uint4*)(succ + (size_t)(fcur[e0 + (uint32_t)lane] ^ 1u) * 4);
-#pragma unroll
-          for (uint32_t nt = 0; nt < 4; nt++) {
-            const uint32_t p = flip(nt == 0 ? rec.x : nt == 1 ? rec.y : nt == 2 ? rec.z : rec.w);
-            const uint64_t m = __ballot(p != G2S_DEV_INVALID);
-            if (p != G2S_DEV_INVALID) cand[ncand + (uint32_t)__popcll(m & lanes_below(lane))] = p;
-            ncand += (uint32_t)__popcll(m);
-          }
-        }
-        lds_sync();
-        for (uint32_t c0 = 0; c0 < ncand; c0 += 64u) {
-          const uint32_t p = c0 + (uint32_t)lane < ncand ? cand[c0 + (uint32_t)lane] : G2S_DEV_INVALID;
-          uint32_t isnew = 0;
-          if (p != G2S_DEV_INVALID) {
-            const uint32_t r = lrs_insert<RSG>(rs, rmask, p);
-            isnew = r & 1u;
-            if (r & 2u) flags |= G2S_DEV_Q7_A;
-            if (r & 4u) flags |= G2S_DEV_OVERFLOW_A;
-          }
-          const uint64_t m = __ballot(isnew);
-          if (isnew) {
-            const uint32_t off = nnew + (uint32_t)__popcll(m & lanes_below(lane));
-            if (off < F) fnxt[off] = p;
-          }
-          nnew += (uint32_t)__popcll(m);
-        }
-      } else
-      for (uint32_t i0 = 0; i0 < nb * 4u; i0 += 64u) {
-        const uint32_t i = i0 + (uint32_t)lane;
-        const bool valid = i < nb * 4u;
-        const uint32_t n = valid ? fcur[i >> 2] : 0u;
-        const uint32_t nt = i & 3u;
-        // graph.predecessors(n)[nt] = graph.successors(n^1)[nt] ^ 1
-        const uint32_t p = valid ? flip(succ[(size_t)(n ^ 1u) * 4 + nt]) : G2S_DEV_INVALID;
-        uint32_t isnew = 0;
-        if (p != G2S_DEV_INVALID) {
-          const uint32_t r = lrs_insert<RSG>(rs, rmask, p);
-          isnew = r & 1u;
-          if (r & 2u) flags |= G2S_DEV_Q7_A;
-          if (r & 4u) flags |= G2S_DEV_OVERFLOW_A;
-        }
-        const uint64_t m = __ballot(isnew);
-        if (isnew) {
-          const uint32_t off = nnew + (uint32_t)__popcll(m & lanes_below(lane));
-          if (off < F) fnxt[off] = p;
-        }
-        nnew += (uint32_t)__popcll(m);
-      }
-      nvis += nnew;
-      if (nnew > F) { overflow = true; flags |= G2S_DEV_WHY_FRONTIER; break; }
-      if (nvis > rs_cap / 4u * 3u) { overflow = true; break; }
       lds_sync();
-      if (d <= gd.rmf) {  // next right-flank seed (:953-976)
-        const uint32_t s = rseeds[d];
-        if (s != G2S_DEV_INVALID) {
-          int r = 0;
-          if (lane == 0) r = (int)lrs_insert<RSG>(rs, rmask, s);
-          r = __shfl(r, 0);
-          if (r & 2) flags |= G2S_DEV_Q7_A;
-          if (r & 1) {
-            if (nnew < F) { if (lane == 0) fnxt[nnew] = s; } else overflow = true;
-            nnew++;
-            nvis++;
-          }
-          lds_sync();
-        }
-      }
       cur ^= 1u;
-      nb = nnew;
-#ifdef G2S_PROF_A
-      { unsigned long long t = __builtin_amdgcn_s_memtime(); pa[was_wide ? 3 : 2] += t - pt0; pn_wide += was_wide; }
-#endif
-      if (nb == 0 && d >= gd.rmf) break;
+      ne = nn;
     }
-    if (overflow) flags |= G2S_DEV_OVERFLOW_A;
+    lds_sync();
+    // hand the arrays back to phase B
+    for (uint32_t i = (uint32_t)lane; i < LH; i += 64u) lh[i] = G2S_DEV_EMPTY64;
+    lds_sync();
   }
-  lds_sync();
-  for (uint32_t i = (uint32_t)lane; i < LH; i += 64u) lh[i] = G2S_DEV_EMPTY64;  // phase A used it as scratch
-  lds_sync();
+  if (overflow) flags |= G2S_DEV_OVERFLOW_A;
 
   const unsigned long long cyc1 = __builtin_amdgcn_s_memtime();
   // ---------------- phase B + C: left DP (Gap2Seq.cpp:984-1167) -----------------
@@ -871,9 +831,6 @@ __device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ,
     go->stat[0] = st_slowA; go->stat[1] = st_bulkA; go->stat[2] = st_slowB; go->stat[3] = st_bulkB;
     go->stat[4] = (uint32_t)((cyc1 - cyc0) >> 8); go->stat[5] = (uint32_t)((cyc2 - cyc1) >> 8);
 #ifdef G2S_PROF_A
-    for (int q = 0; q < 4; q++) go->prof[q] = (uint32_t)(pa[q] >> 8);
-    go->prof[4] = (uint32_t)(pb[0] >> 8); go->prof[5] = (uint32_t)(pb[1] >> 8);
-    go->prof[6] = pn_fail | (pn_wide << 16);
     for (int q = 0; q < 5; q++) go->prof[8 + q] = (uint32_t)(pc[q] >> 8);
     go->prof[13] = pnB[1] | (pnB[4] << 16); go->prof[14] = pnB[2] | (pnB[3] << 16);
     go->prof[7] = (uint32_t)(pd[0] >> 8); go->prof[15] = (uint32_t)(pd[1] >> 8);
@@ -897,24 +854,26 @@ __device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ,
 }
 
 __global__ __launch_bounds__(64) void g2s_fill_lds(const uint32_t* __restrict__ succ,
+                                                    const uint64_t* __restrict__ ustart,
                                                     const GapDev* __restrict__ gaps,
                                                     const uint32_t* __restrict__ gap_ids,
                                                     const uint32_t* __restrict__ flank_nodes, uint64_t* log_all,
                                                     uint32_t* lvl_all, uint32_t* plk_all, uint64_t* xl_all,
                                                     GapOut* outs, uint32_t num_oriented, uint32_t fcap) {
-  fill_lds_body<false>(succ, gaps, gap_ids, flank_nodes, log_all, lvl_all, plk_all, xl_all, outs, num_oriented, nullptr,
+  fill_lds_body<false>(succ, ustart, gaps, gap_ids, flank_nodes, log_all, lvl_all, plk_all, xl_all, outs, num_oriented, nullptr,
                        fcap);
 }
 // Same kernel with the right set in HBM: for gaps whose right set outgrows the LDS (deep
 // DP, -dist-error in the thousands); everything else of the gap stays in LDS.
 __global__ __launch_bounds__(64) void g2s_fill_lds_rsg(const uint32_t* __restrict__ succ,
+                                                        const uint64_t* __restrict__ ustart,
                                                         const GapDev* __restrict__ gaps,
                                                         const uint32_t* __restrict__ gap_ids,
                                                         const uint32_t* __restrict__ flank_nodes, uint64_t* log_all,
                                                         uint32_t* lvl_all, uint32_t* plk_all, uint64_t* xl_all,
                                                         GapOut* outs, uint32_t num_oriented, uint32_t* rs_global,
                                                         uint32_t fcap) {
-  fill_lds_body<true>(succ, gaps, gap_ids, flank_nodes, log_all, lvl_all, plk_all, xl_all, outs, num_oriented, rs_global,
+  fill_lds_body<true>(succ, ustart, gaps, gap_ids, flank_nodes, log_all, lvl_all, plk_all, xl_all, outs, num_oriented, rs_global,
                       fcap);
 }
 
@@ -1287,7 +1246,7 @@ uint32_t fill_lds_frontier_cap() { return LDS_F; }  // pass 0; later passes use 
 uint32_t fill_lds_max_fuz() { return LDS_TG - 1; }
 
 hipError_t launch_fill_lds(hipStream_t st, uint32_t ngaps, uint32_t rs_cap_max, uint32_t num_oriented,
-                           const uint32_t* succ, const GapDev* gaps, const uint32_t* gap_ids,
+                           const uint32_t* succ, const uint64_t* ustart, const GapDev* gaps, const uint32_t* gap_ids,
                            const uint32_t* flank_nodes, uint64_t* log_all, uint32_t* lvl_all, uint32_t* plk_all,
                            uint64_t* xl_all, GapOut* outs, uint32_t* rs_global, uint32_t fcap) {
   if (ngaps == 0) return hipSuccess;
@@ -1295,15 +1254,15 @@ hipError_t launch_fill_lds(hipStream_t st, uint32_t ngaps, uint32_t rs_cap_max, 
     const size_t bytes = fill_lds_bytes(0, fcap);
     hipError_t e = hipFuncSetAttribute((const void*)g2s_fill_lds_rsg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(g2s_fill_lds_rsg, dim3(ngaps), dim3(64), bytes, st, succ, gaps, gap_ids, flank_nodes, log_all,
-                       lvl_all, plk_all, xl_all, outs, num_oriented, rs_global, fcap);
+    hipLaunchKernelGGL(g2s_fill_lds_rsg, dim3(ngaps), dim3(64), bytes, st, succ, ustart, gaps, gap_ids, flank_nodes,
+                       log_all, lvl_all, plk_all, xl_all, outs, num_oriented, rs_global, fcap);
     return hipGetLastError();
   }
   const size_t bytes = fill_lds_bytes(rs_cap_max, fcap);
   hipError_t e = hipFuncSetAttribute((const void*)g2s_fill_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(g2s_fill_lds, dim3(ngaps), dim3(64), bytes, st, succ, gaps, gap_ids, flank_nodes, log_all, lvl_all,
-                     plk_all, xl_all, outs, num_oriented, fcap);
+  hipLaunchKernelGGL(g2s_fill_lds, dim3(ngaps), dim3(64), bytes, st, succ, ustart, gaps, gap_ids, flank_nodes, log_all,
+                     lvl_all, plk_all, xl_all, outs, num_oriented, fcap);
   return hipGetLastError();
 }
 

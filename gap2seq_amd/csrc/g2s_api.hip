@@ -125,6 +125,7 @@ extern "C" void g2s_graph_free(g2s_graph* g) {
       if (hipSetDevice(kv.first) == hipSuccess) {
         if (kv.second.succ) (void)hipFree(kv.second.succ);
         if (kv.second.pred) (void)hipFree(kv.second.pred);
+        if (kv.second.ustart) (void)hipFree(kv.second.ustart - kUstartPad);
       }
     }
     delete g->g;
@@ -182,6 +183,15 @@ extern "C" int g2s_graph_upload(g2s_graph* gh, int device) {
     HIP_TRY(hipMalloc((void**)&dg.pred, bytes));
     HIP_TRY(hipMemcpy(dg.pred, g.pred.data(), bytes, hipMemcpyHostToDevice));
     dg.bytes += bytes;
+  }
+  {  // unitig-start bitmap between two pads of all-ones words (scans past either end stop there)
+    const size_t words = g.ustart.size();
+    uint64_t* base = nullptr;
+    HIP_TRY(hipMalloc((void**)&base, (words + 2 * kUstartPad) * 8));
+    HIP_TRY(hipMemset(base, 0xFF, (words + 2 * kUstartPad) * 8));
+    HIP_TRY(hipMemcpy(base + kUstartPad, g.ustart.data(), words * 8, hipMemcpyHostToDevice));
+    dg.ustart = base + kUstartPad;
+    dg.bytes += (words + 2 * kUstartPad) * 8;
   }
   g.dev[device] = dg;
   return G2S_OK;
@@ -686,7 +696,8 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
     HIP_TRY(hipEventRecord(s->ev[0], st));
     HIP_TRY(hipEventRecord(s->ev[1], st));  // phases A-C are one kernel in this tier
     const uint32_t num_oriented = (uint32_t)(2 * s->graph->g->n);
-    HIP_TRY(launch_fill_lds(st, (uint32_t)ids.size(), lds_cap_max, num_oriented, dg.succ, (const GapDev*)s->d_gaps.p,
+    HIP_TRY(launch_fill_lds(st, (uint32_t)ids.size(), lds_cap_max, num_oriented, dg.succ, dg.ustart,
+                            (const GapDev*)s->d_gaps.p,
                             (const uint32_t*)s->d_ids.p, (const uint32_t*)s->d_flank.p, (uint64_t*)s->d_log.p,
                             (uint32_t*)s->d_lvl.p, (uint32_t*)s->d_plk.p, (uint64_t*)s->d_xl.p, (GapOut*)s->d_outs.p,
                             rs_in_hbm ? (uint32_t*)s->d_rs.p : nullptr, fcap));
@@ -828,7 +839,9 @@ int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
 
   // ---- GPU: phases A-D1, retrying gaps whose tables overflowed with 8x larger ones
   std::vector<uint32_t> todo, lds_ids;
-  const bool lds_ok = s->graph->g->dev.at(s->device).pred == nullptr && !s->no_lds_tier;
+  // (the LDS right set keeps 28-bit k-mer indices)
+  const bool lds_ok = s->graph->g->dev.at(s->device).pred == nullptr && !s->no_lds_tier &&
+                      s->graph->g->n < (1ull << 28) - 1;
   {
     size_t nvalid = 0;
     for (size_t i = 0; i < n; i++) nvalid += !b->jobs[i].bad_flank;
