@@ -35,7 +35,9 @@ hipError_t launch_fill_lds(hipStream_t st, uint32_t ngaps, uint32_t rs_cap_max, 
                            uint32_t fcap /* frontier capacity */);
 hipError_t launch_extract_lds(hipStream_t st, uint32_t ngaps, const GapDev* gaps, const uint32_t* gap_ids,
                               const uint32_t* flank_nodes, const uint64_t* log_all, const uint32_t* lvl_all,
-                              const uint32_t* plk_all, const uint64_t* xl_all, SubState* sub_scratch, SubState* sub_out,
-                              unsigned long long* out_counter, GapOut* outs, int skip_confident, uint32_t fcap);
+                              const uint32_t* plk_all, const uint64_t* xl_all, SubState* sub_scratch,
+                              SubState* sub_out /* pinned host */, unsigned long long out_cap /* records */,
+                              unsigned long long* out_counter, GapOut* outs, GapOut* outs_host /* pinned host */,
+                              int skip_confident, uint32_t fcap);
 
 }  // namespace g2s

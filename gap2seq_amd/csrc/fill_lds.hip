@@ -901,8 +901,9 @@ __global__ __launch_bounds__(64) void g2s_extract_lds(const GapDev* __restrict__
                                                        const uint32_t* __restrict__ lvl_all,
                                                        const uint32_t* __restrict__ plk_all,
                                                        const uint64_t* __restrict__ xl_all, SubState* sub_scratch,
-                                                       SubState* sub_out, unsigned long long* out_counter,
-                                                       GapOut* outs, int skip_confident, const uint32_t F) {
+                                                       SubState* sub_out, unsigned long long out_cap,
+                                                       unsigned long long* out_counter, GapOut* outs,
+                                                       GapOut* outs_host, int skip_confident, const uint32_t F) {
   const uint32_t W = F > 256u ? F : 256u;  // log / level-offset window: holds at least one whole level
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   const uint32_t gi = __builtin_amdgcn_readfirstlane(gap_ids[blockIdx.x]);
@@ -911,7 +912,16 @@ __global__ __launch_bounds__(64) void g2s_extract_lds(const GapDev* __restrict__
   GapOut* go = &outs[gi];
   const uint32_t gflags = go->flags;
   const int c_count = go->c_count, n_len = go->n_len;
-  if ((gflags & (G2S_DEV_OVERFLOW_A | G2S_DEV_OVERFLOW_B)) || !(c_count > 0 && n_len > 0)) return;  // :1169
+  // sub_out and outs_host are pinned host memory: the closure and the per-gap record go
+  // straight over the link as each gap finishes, there is no device-to-host copy afterwards
+  auto publish = [&]() {
+    if ((uint32_t)lane < sizeof(GapOut) / 4u)
+      ((uint32_t*)&outs_host[gi])[lane] = __hip_atomic_load(&((const uint32_t*)go)[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  if ((gflags & (G2S_DEV_OVERFLOW_A | G2S_DEV_OVERFLOW_B)) || !(c_count > 0 && n_len > 0)) {  // :1169
+    publish();
+    return;
+  }
 
   uint32_t* wl = lds;                  // level offsets window [W+1] (bit 31: G2S_LVL_UNIFORM)
   uint32_t* wen = wl + (W + 1u);       // log window: nodes, counts, parent positions
@@ -1189,6 +1199,8 @@ __global__ __launch_bounds__(64) void g2s_extract_lds(const GapDev* __restrict__
   for (int o = 32; o > 0; o >>= 1) lflags |= __shfl_xor(lflags, o);
   if (lflags & G2S_DEV_OVERFLOW_B) {
     if (lane == 0) go->flags = gflags | lflags;
+    __threadfence();
+    publish();
     return;
   }
   // ---- pack: reserve exactly n_sub records in the dense output --------------------------
@@ -1198,6 +1210,12 @@ __global__ __launch_bounds__(64) void g2s_extract_lds(const GapDev* __restrict__
   unsigned long long base = 0;
   if (lane == 0) base = atomicAdd(out_counter, (unsigned long long)nsub);
   base = __shfl(base, 0);
+  if (base + nsub > out_cap) {  // the host buffer is full: the gap is run again with the next pass
+    if (lane == 0) go->flags = gflags | lflags | G2S_DEV_OVERFLOW_B | G2S_DEV_WHY_LOG;
+    __threadfence();
+    publish();
+    return;
+  }
   {
     const uint4* src = (const uint4*)sub;
     uint4* dst = (uint4*)(sub_out + base);
@@ -1228,6 +1246,8 @@ __global__ __launch_bounds__(64) void g2s_extract_lds(const GapDev* __restrict__
     go->stat[2] = (uint32_t)((__builtin_amdgcn_s_memtime() - et_pack) >> 8); go->stat[3] = (uint32_t)(pe[3] >> 8);
 #endif
   }
+  __threadfence();
+  publish();
 }
 
 // ---------------------------------------------------------------------------
@@ -1269,13 +1289,14 @@ hipError_t launch_fill_lds(hipStream_t st, uint32_t ngaps, uint32_t rs_cap_max, 
 hipError_t launch_extract_lds(hipStream_t st, uint32_t ngaps, const GapDev* gaps, const uint32_t* gap_ids,
                               const uint32_t* flank_nodes, const uint64_t* log_all, const uint32_t* lvl_all,
                               const uint32_t* plk_all, const uint64_t* xl_all, SubState* sub_scratch, SubState* sub_out,
-                              unsigned long long* out_counter, GapOut* outs, int skip_confident, uint32_t fcap) {
+                              unsigned long long out_cap, unsigned long long* out_counter, GapOut* outs,
+                              GapOut* outs_host, int skip_confident, uint32_t fcap) {
   if (ngaps == 0) return hipSuccess;
   const size_t bytes = extract_lds_bytes(fcap);
   hipError_t e = hipFuncSetAttribute((const void*)g2s_extract_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(g2s_extract_lds, dim3(ngaps), dim3(64), bytes, st, gaps, gap_ids, flank_nodes, log_all, lvl_all,
-                     plk_all, xl_all, sub_scratch, sub_out, out_counter, outs, skip_confident, fcap);
+                     plk_all, xl_all, sub_scratch, sub_out, out_cap, out_counter, outs, outs_host, skip_confident, fcap);
   return hipGetLastError();
 }
 

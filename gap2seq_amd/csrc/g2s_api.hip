@@ -228,7 +228,8 @@ struct PinBuf {  // grow-only pinned host allocation
     if (bytes <= cap) return hipSuccess;
     if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
     size_t want = bytes + bytes / 4 + 256;
-    hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+    // mapped + coherent: the LDS tier's kernels write their results here directly
+    hipError_t e = hipHostMalloc(&p, want, hipHostMallocMapped | hipHostMallocCoherent);
     if (e == hipSuccess) cap = want;
     return e;
   }
@@ -641,7 +642,7 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
   HIP_TRY(s->h_gaps.ensure(std::max<size_t>(n * sizeof(GapDev), 16)));
   GapDev* gd = (GapDev*)s->h_gaps.p;
   memset(gd, 0, n * sizeof(GapDev));
-  uint64_t rs_total = 0, rlog_total = 0, st_total = 0, slog_total = 0, lvl_total = 0, xl_total = 0;
+  uint64_t rs_total = 0, rlog_total = 0, st_total = 0, slog_total = 0, lvl_total = 0, xl_total = 0, out_states = 0, out_max = 0;
   uint32_t lds_cap_max = 0;
   td->gap_ids = ids;
   for (size_t x = 0; x < ids.size(); x++) {
@@ -662,6 +663,10 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
     d.st_off = st_total; st_total += 2ull * p.slog_cap;
     d.slog_off = slog_total; slog_total += p.slog_cap;
     d.lvl_off = lvl_total; lvl_total += (uint64_t)(d.D + 2);
+    // pinned output pool of the LDS tier: 4 states per DP level and gap, plus room for one
+    // gap's worst case (what does not fit is run again by the next pass)
+    out_states += std::min<uint64_t>(p.slog_cap, 4ull * (uint64_t)(d.D + 2));
+    out_max = std::max<uint64_t>(out_max, p.slog_cap);
     if (lds) {  // extra-parent list of merged states: a quarter of the log's capacity
       d.pad0 = std::max(64u, p.slog_cap / 4);
       d.st_off = xl_total;
@@ -677,7 +682,7 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
   HIP_TRY(s->d_ids.ensure(std::max<size_t>(ids.size() * 4, 16)));
   HIP_TRY(s->d_outs.ensure(n * sizeof(GapOut)));
   HIP_TRY(s->d_subscr.ensure(slog_total * sizeof(SubState)));
-  HIP_TRY(s->d_subout.ensure(slog_total * sizeof(SubState)));
+  if (!lds) HIP_TRY(s->d_subout.ensure(slog_total * sizeof(SubState)));
   HIP_TRY(s->d_counter.ensure(16));
   hipStream_t st = s->stream;
   HIP_TRY(hipMemcpyAsync(s->d_gaps.p, gd, n * sizeof(GapDev), hipMemcpyHostToDevice, st));
@@ -702,10 +707,18 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
                             (uint32_t*)s->d_lvl.p, (uint32_t*)s->d_plk.p, (uint64_t*)s->d_xl.p, (GapOut*)s->d_outs.p,
                             rs_in_hbm ? (uint32_t*)s->d_rs.p : nullptr, fcap));
     HIP_TRY(hipEventRecord(s->ev[2], st));
+    // results go straight to pinned host memory (closures packed by an atomic cursor)
+    HIP_TRY(td->outs.ensure(n * sizeof(GapOut)));
+    out_states += out_max;
+    HIP_TRY(td->subs.ensure(std::max<uint64_t>(out_states * sizeof(SubState), 16)));
+    void *d_outs_host = nullptr, *d_subs_host = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(&d_outs_host, td->outs.p, 0));
+    HIP_TRY(hipHostGetDevicePointer(&d_subs_host, td->subs.p, 0));
     HIP_TRY(launch_extract_lds(st, (uint32_t)ids.size(), (const GapDev*)s->d_gaps.p, (const uint32_t*)s->d_ids.p,
                                (const uint32_t*)s->d_flank.p, (const uint64_t*)s->d_log.p, (const uint32_t*)s->d_lvl.p,
                                (const uint32_t*)s->d_plk.p, (const uint64_t*)s->d_xl.p, (SubState*)s->d_subscr.p,
-                               (SubState*)s->d_subout.p, (unsigned long long*)s->d_counter.p, (GapOut*)s->d_outs.p,
+                               (SubState*)d_subs_host, (unsigned long long)out_states,
+                               (unsigned long long*)s->d_counter.p, (GapOut*)s->d_outs.p, (GapOut*)d_outs_host,
                                s->params.skip_confident ? 1 : 0, fcap));
     HIP_TRY(hipEventRecord(s->ev[3], st));
   } else {
@@ -737,18 +750,22 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
     HIP_TRY(hipEventRecord(s->ev[3], st));
   }
 
-  // device -> host: per-gap results, then the packed closures
-  HIP_TRY(td->outs.ensure(n * sizeof(GapOut)));
-  unsigned long long total_sub = 0;
-  HIP_TRY(hipMemcpyAsync(td->outs.p, s->d_outs.p, n * sizeof(GapOut), hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(&total_sub, s->d_counter.p, 8, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
-  auto t0 = std::chrono::steady_clock::now();
-  HIP_TRY(td->subs.ensure(std::max<uint64_t>(total_sub * sizeof(SubState), 16)));
-  if (total_sub)
-    HIP_TRY(hipMemcpyAsync(td->subs.p, s->d_subout.p, total_sub * sizeof(SubState), hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
-  b->timing.ms_d2h += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  if (lds) {
+    HIP_TRY(hipStreamSynchronize(st));  // the kernels wrote td->outs / td->subs themselves
+  } else {
+    // device -> host: per-gap results, then the packed closures
+    HIP_TRY(td->outs.ensure(n * sizeof(GapOut)));
+    unsigned long long total_sub = 0;
+    HIP_TRY(hipMemcpyAsync(td->outs.p, s->d_outs.p, n * sizeof(GapOut), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&total_sub, s->d_counter.p, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    auto t0 = std::chrono::steady_clock::now();
+    HIP_TRY(td->subs.ensure(std::max<uint64_t>(total_sub * sizeof(SubState), 16)));
+    if (total_sub)
+      HIP_TRY(hipMemcpyAsync(td->subs.p, s->d_subout.p, total_sub * sizeof(SubState), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    b->timing.ms_d2h += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  }
   float ms = 0;
   if (lds) {
     HIP_TRY(hipEventElapsedTime(&ms, s->ev[1], s->ev[2]));
