@@ -28,16 +28,13 @@ size_t fill_lds_bytes(uint32_t rs_cap, uint32_t fcap);
 size_t extract_lds_bytes(uint32_t fcap);
 uint32_t fill_lds_frontier_cap();
 uint32_t fill_lds_max_fuz();
+// phases A-D1 of every listed gap in one launch; results land in pinned host memory
 hipError_t launch_fill_lds(hipStream_t st, uint32_t ngaps, uint32_t rs_cap_max, uint32_t num_oriented,
                            const uint32_t* succ, const uint64_t* ustart, const GapDev* gaps, const uint32_t* gap_ids,
                            const uint32_t* flank_nodes, uint64_t* log_all, uint32_t* lvl_all, uint32_t* plk_all,
-                           uint64_t* xl_all, GapOut* outs, uint32_t* rs_global /* nullptr: right set in LDS */,
-                           uint32_t fcap /* frontier capacity */);
-hipError_t launch_extract_lds(hipStream_t st, uint32_t ngaps, const GapDev* gaps, const uint32_t* gap_ids,
-                              const uint32_t* flank_nodes, const uint64_t* log_all, const uint32_t* lvl_all,
-                              const uint32_t* plk_all, const uint64_t* xl_all, SubState* sub_scratch,
-                              SubState* sub_out /* pinned host */, unsigned long long out_cap /* records */,
-                              unsigned long long* out_counter, GapOut* outs, GapOut* outs_host /* pinned host */,
-                              int skip_confident, uint32_t fcap);
+                           uint64_t* xl_all, SubState* sub_scratch, SubState* sub_out /* pinned host */,
+                           unsigned long long out_cap /* records */, unsigned long long* out_counter, GapOut* outs,
+                           GapOut* outs_host /* pinned host */, int skip_confident,
+                           uint32_t* rs_global /* nullptr: right set in LDS */, uint32_t fcap /* frontier capacity */);
 
 }  // namespace g2s

@@ -29,6 +29,8 @@
 // explicit predecessor table for even k) is flagged and re-run by the HBM tier.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "fill_device.h"
 #include "fill_launch.h"
 
@@ -181,8 +183,14 @@ __device__ bool lrs_has_kmer(const uint32_t* tab, uint32_t mask, uint32_t v) {
 // Phases A + B + C, LDS tier.
 // dynamic LDS: [fa 2F][fn 2F][fc 2F][lh 2F x u64][lhslot 2F][th 3*TH][tgt TG][misc 4][tflt 128][cw 3x256][rs rs_cap]
 // ============================================================================
+// what phase D1 needs from phases A-C of the same gap (wave-uniform values)
+struct FillOut {
+  uint32_t flags, n_xl, top_level;
+  int c_count, n_len, len0, len1, reached_j;
+};
+
 template <bool RSG>
-__device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ,
+__device__ __forceinline__ FillOut fill_lds_body(const uint32_t* __restrict__ succ,
                                               const uint64_t* __restrict__ ustart, const GapDev* __restrict__ gaps,
                                               const uint32_t* __restrict__ gap_ids,
                                               const uint32_t* __restrict__ flank_nodes, uint64_t* log_all,
@@ -851,30 +859,10 @@ __device__ __forceinline__ void fill_lds_body(const uint32_t* __restrict__ succ,
     go->n_xl = nxl;
     go->top_level = (uint32_t)max(0, min(lvl_top, gd.D));
   }
-}
-
-__global__ __launch_bounds__(64) void g2s_fill_lds(const uint32_t* __restrict__ succ,
-                                                    const uint64_t* __restrict__ ustart,
-                                                    const GapDev* __restrict__ gaps,
-                                                    const uint32_t* __restrict__ gap_ids,
-                                                    const uint32_t* __restrict__ flank_nodes, uint64_t* log_all,
-                                                    uint32_t* lvl_all, uint32_t* plk_all, uint64_t* xl_all,
-                                                    GapOut* outs, uint32_t num_oriented, uint32_t fcap) {
-  fill_lds_body<false>(succ, ustart, gaps, gap_ids, flank_nodes, log_all, lvl_all, plk_all, xl_all, outs, num_oriented, nullptr,
-                       fcap);
-}
-// Same kernel with the right set in HBM: for gaps whose right set outgrows the LDS (deep
-// DP, -dist-error in the thousands); everything else of the gap stays in LDS.
-__global__ __launch_bounds__(64) void g2s_fill_lds_rsg(const uint32_t* __restrict__ succ,
-                                                        const uint64_t* __restrict__ ustart,
-                                                        const GapDev* __restrict__ gaps,
-                                                        const uint32_t* __restrict__ gap_ids,
-                                                        const uint32_t* __restrict__ flank_nodes, uint64_t* log_all,
-                                                        uint32_t* lvl_all, uint32_t* plk_all, uint64_t* xl_all,
-                                                        GapOut* outs, uint32_t num_oriented, uint32_t* rs_global,
-                                                        uint32_t fcap) {
-  fill_lds_body<true>(succ, ustart, gaps, gap_ids, flank_nodes, log_all, lvl_all, plk_all, xl_all, outs, num_oriented, rs_global,
-                      fcap);
+  FillOut fo;
+  fo.flags = flags; fo.n_xl = nxl; fo.top_level = (uint32_t)max(0, min(lvl_top, gd.D));
+  fo.c_count = c_count; fo.n_len = n_len; fo.len0 = len0; fo.len1 = len1; fo.reached_j = reached_j;
+  return fo;
 }
 
 // ============================================================================
@@ -894,24 +882,24 @@ __global__ __launch_bounds__(64) void g2s_fill_lds_rsg(const uint32_t* __restric
 // dynamic LDS: [wl W+1][wen W][wec W][wpl W][mk 2F][em F][ch 2x2F][pc F][xc 3x64]
 // ============================================================================
 #define LDS_XC 64u /* extra links handled per level */
-__global__ __launch_bounds__(64) void g2s_extract_lds(const GapDev* __restrict__ gaps,
-                                                       const uint32_t* __restrict__ gap_ids,
-                                                       const uint32_t* __restrict__ flank_nodes,
-                                                       const uint64_t* __restrict__ log_all,
-                                                       const uint32_t* __restrict__ lvl_all,
-                                                       const uint32_t* __restrict__ plk_all,
-                                                       const uint64_t* __restrict__ xl_all, SubState* sub_scratch,
-                                                       SubState* sub_out, unsigned long long out_cap,
-                                                       unsigned long long* out_counter, GapOut* outs,
-                                                       GapOut* outs_host, int skip_confident, const uint32_t F) {
+__device__ __forceinline__ void extract_lds_body(const FillOut fo, const GapDev* __restrict__ gaps,
+                                                 const uint32_t* __restrict__ gap_ids,
+                                                 const uint32_t* __restrict__ flank_nodes,
+                                                 const uint64_t* __restrict__ log_all,
+                                                 const uint32_t* __restrict__ lvl_all,
+                                                 const uint32_t* __restrict__ plk_all,
+                                                 const uint64_t* __restrict__ xl_all, SubState* sub_scratch,
+                                                 SubState* sub_out, unsigned long long out_cap,
+                                                 unsigned long long* out_counter, GapOut* outs, GapOut* outs_host,
+                                                 int skip_confident, const uint32_t F) {
   const uint32_t W = F > 256u ? F : 256u;  // log / level-offset window: holds at least one whole level
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   const uint32_t gi = __builtin_amdgcn_readfirstlane(gap_ids[blockIdx.x]);
   const GapDev gd = gaps[gi];
   const int lane = threadIdx.x;
   GapOut* go = &outs[gi];
-  const uint32_t gflags = go->flags;
-  const int c_count = go->c_count, n_len = go->n_len;
+  const uint32_t gflags = fo.flags;
+  const int c_count = fo.c_count, n_len = fo.n_len;
   // sub_out and outs_host are pinned host memory: the closure and the per-gap record go
   // straight over the link as each gap finishes, there is no device-to-host copy afterwards
   auto publish = [&]() {
@@ -941,8 +929,8 @@ __global__ __launch_bounds__(64) void g2s_extract_lds(const GapDev* __restrict__
   SubState* sub = sub_scratch + gd.slog_off;
   const uint32_t* lseeds = flank_nodes + gd.flank_off;
   const uint32_t* targets = lseeds + (uint32_t)(gd.lmf + 1) + (uint32_t)(gd.rmf + 1);
-  const int len0 = go->len[0], len1 = go->len[1];
-  const uint32_t reached = targets[go->reached_j];
+  const int len0 = fo.len0, len1 = fo.len1;
+  const uint32_t reached = targets[fo.reached_j];
   const bool want_s = !skip_confident;
   const uint32_t sinknode = (want_s && gd.all_paths && gd.rmf >= 1) ? targets[gd.rmf - 1] : G2S_DEV_INVALID;
   const int lo_sink = max(0, gd.lmf + gd.g - gd.e);  // :1196
@@ -963,7 +951,7 @@ __global__ __launch_bounds__(64) void g2s_extract_lds(const GapDev* __restrict__
   int wl_lo = gd.D + 2;          // wl[i] = lvl[wl_lo + i], i in [0, W]
   uint32_t we_lo = 0, we_hi = 0; // log positions [we_lo, we_hi) are in the entry window
   uint32_t nsub = 0, nch = 0, nxc = 0, xcount = 0, lflags = 0;
-  uint32_t xpos = go->n_xl;      // extra links [0, xpos) not yet consumed (sorted by state, ascending)
+  uint32_t xpos = fo.n_xl;       // extra links [0, xpos) not yet consumed (sorted by state, ascending)
   uint32_t xtop = xpos ? (uint32_t)(xl[xpos - 1u] >> 32) : 0u;
   const uint32_t cap = gd.slog_cap;
   bool over = false;
@@ -974,7 +962,7 @@ __global__ __launch_bounds__(64) void g2s_extract_lds(const GapDev* __restrict__
 #endif
   // nothing can start above the last level that holds a state, nor (without a sink k-mer)
   // above the longest path length
-  int d_top = min(gd.D, (int)go->top_level);
+  int d_top = min(gd.D, (int)fo.top_level);
   if (sinknode == G2S_DEV_INVALID) d_top = min(d_top, n_len > 1 ? max(len0, len1) : len0);
   if (xpos > 0) {  // extra links of the levels that are skipped
     const uint32_t hi_top = lvl[d_top + 1] & ~G2S_LVL_UNIFORM;
@@ -1250,6 +1238,33 @@ __global__ __launch_bounds__(64) void g2s_extract_lds(const GapDev* __restrict__
   publish();
 }
 
+// ============================================================================
+// One wave per gap, phases A-D1 back to back: a gap's closure leaves for the host as soon
+// as that gap is done, whatever the other gaps of the launch are doing.
+// ============================================================================
+#define G2S_FUSED_PARAMS                                                                                              \
+  const uint32_t *__restrict__ succ, const uint64_t *__restrict__ ustart, const GapDev *__restrict__ gaps,            \
+      const uint32_t *__restrict__ gap_ids, const uint32_t *__restrict__ flank_nodes, uint64_t *log_all,              \
+      uint32_t *lvl_all, uint32_t *plk_all, uint64_t *xl_all, SubState *sub_scratch, SubState *sub_out,               \
+      unsigned long long out_cap, unsigned long long *out_counter, GapOut *outs, GapOut *outs_host,                   \
+      int skip_confident, uint32_t num_oriented
+__global__ __launch_bounds__(64) void g2s_fill_lds(G2S_FUSED_PARAMS, uint32_t fcap) {
+  const FillOut fo = fill_lds_body<false>(succ, ustart, gaps, gap_ids, flank_nodes, log_all, lvl_all, plk_all, xl_all, outs,
+                                          num_oriented, nullptr, fcap);
+  __threadfence();  // the log, level offsets and links of this gap were written through: read them back from L2
+  extract_lds_body(fo, gaps, gap_ids, flank_nodes, log_all, lvl_all, plk_all, xl_all, sub_scratch, sub_out, out_cap,
+                   out_counter, outs, outs_host, skip_confident, fcap);
+}
+// Same kernel with the right set in HBM: for gaps whose right set outgrows the LDS (deep
+// DP, -dist-error in the thousands); everything else of the gap stays in LDS.
+__global__ __launch_bounds__(64) void g2s_fill_lds_rsg(G2S_FUSED_PARAMS, uint32_t* rs_global, uint32_t fcap) {
+  const FillOut fo = fill_lds_body<true>(succ, ustart, gaps, gap_ids, flank_nodes, log_all, lvl_all, plk_all, xl_all, outs,
+                                         num_oriented, rs_global, fcap);
+  __threadfence();
+  extract_lds_body(fo, gaps, gap_ids, flank_nodes, log_all, lvl_all, plk_all, xl_all, sub_scratch, sub_out, out_cap,
+                   out_counter, outs, outs_host, skip_confident, fcap);
+}
+
 // ---------------------------------------------------------------------------
 // launchers (host)
 // ---------------------------------------------------------------------------
@@ -1268,35 +1283,24 @@ uint32_t fill_lds_max_fuz() { return LDS_TG - 1; }
 hipError_t launch_fill_lds(hipStream_t st, uint32_t ngaps, uint32_t rs_cap_max, uint32_t num_oriented,
                            const uint32_t* succ, const uint64_t* ustart, const GapDev* gaps, const uint32_t* gap_ids,
                            const uint32_t* flank_nodes, uint64_t* log_all, uint32_t* lvl_all, uint32_t* plk_all,
-                           uint64_t* xl_all, GapOut* outs, uint32_t* rs_global, uint32_t fcap) {
+                           uint64_t* xl_all, SubState* sub_scratch, SubState* sub_out, unsigned long long out_cap,
+                           unsigned long long* out_counter, GapOut* outs, GapOut* outs_host, int skip_confident,
+                           uint32_t* rs_global, uint32_t fcap) {
   if (ngaps == 0) return hipSuccess;
+  const size_t bytes = std::max(fill_lds_bytes(rs_global ? 0 : rs_cap_max, fcap), extract_lds_bytes(fcap));
   if (rs_global) {  // right set in HBM: no LDS for it
-    const size_t bytes = fill_lds_bytes(0, fcap);
     hipError_t e = hipFuncSetAttribute((const void*)g2s_fill_lds_rsg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(g2s_fill_lds_rsg, dim3(ngaps), dim3(64), bytes, st, succ, ustart, gaps, gap_ids, flank_nodes,
-                       log_all, lvl_all, plk_all, xl_all, outs, num_oriented, rs_global, fcap);
+                       log_all, lvl_all, plk_all, xl_all, sub_scratch, sub_out, out_cap, out_counter, outs, outs_host,
+                       skip_confident, num_oriented, rs_global, fcap);
     return hipGetLastError();
   }
-  const size_t bytes = fill_lds_bytes(rs_cap_max, fcap);
   hipError_t e = hipFuncSetAttribute((const void*)g2s_fill_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(g2s_fill_lds, dim3(ngaps), dim3(64), bytes, st, succ, ustart, gaps, gap_ids, flank_nodes, log_all,
-                     lvl_all, plk_all, xl_all, outs, num_oriented, fcap);
-  return hipGetLastError();
-}
-
-hipError_t launch_extract_lds(hipStream_t st, uint32_t ngaps, const GapDev* gaps, const uint32_t* gap_ids,
-                              const uint32_t* flank_nodes, const uint64_t* log_all, const uint32_t* lvl_all,
-                              const uint32_t* plk_all, const uint64_t* xl_all, SubState* sub_scratch, SubState* sub_out,
-                              unsigned long long out_cap, unsigned long long* out_counter, GapOut* outs,
-                              GapOut* outs_host, int skip_confident, uint32_t fcap) {
-  if (ngaps == 0) return hipSuccess;
-  const size_t bytes = extract_lds_bytes(fcap);
-  hipError_t e = hipFuncSetAttribute((const void*)g2s_extract_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(g2s_extract_lds, dim3(ngaps), dim3(64), bytes, st, gaps, gap_ids, flank_nodes, log_all, lvl_all,
-                     plk_all, xl_all, sub_scratch, sub_out, out_cap, out_counter, outs, outs_host, skip_confident, fcap);
+                     lvl_all, plk_all, xl_all, sub_scratch, sub_out, out_cap, out_counter, outs, outs_host, skip_confident,
+                     num_oriented, fcap);
   return hipGetLastError();
 }
 

@@ -701,12 +701,6 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
     HIP_TRY(hipEventRecord(s->ev[0], st));
     HIP_TRY(hipEventRecord(s->ev[1], st));  // phases A-C are one kernel in this tier
     const uint32_t num_oriented = (uint32_t)(2 * s->graph->g->n);
-    HIP_TRY(launch_fill_lds(st, (uint32_t)ids.size(), lds_cap_max, num_oriented, dg.succ, dg.ustart,
-                            (const GapDev*)s->d_gaps.p,
-                            (const uint32_t*)s->d_ids.p, (const uint32_t*)s->d_flank.p, (uint64_t*)s->d_log.p,
-                            (uint32_t*)s->d_lvl.p, (uint32_t*)s->d_plk.p, (uint64_t*)s->d_xl.p, (GapOut*)s->d_outs.p,
-                            rs_in_hbm ? (uint32_t*)s->d_rs.p : nullptr, fcap));
-    HIP_TRY(hipEventRecord(s->ev[2], st));
     // results go straight to pinned host memory (closures packed by an atomic cursor)
     HIP_TRY(td->outs.ensure(n * sizeof(GapOut)));
     out_states += out_max;
@@ -714,12 +708,13 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
     void *d_outs_host = nullptr, *d_subs_host = nullptr;
     HIP_TRY(hipHostGetDevicePointer(&d_outs_host, td->outs.p, 0));
     HIP_TRY(hipHostGetDevicePointer(&d_subs_host, td->subs.p, 0));
-    HIP_TRY(launch_extract_lds(st, (uint32_t)ids.size(), (const GapDev*)s->d_gaps.p, (const uint32_t*)s->d_ids.p,
-                               (const uint32_t*)s->d_flank.p, (const uint64_t*)s->d_log.p, (const uint32_t*)s->d_lvl.p,
-                               (const uint32_t*)s->d_plk.p, (const uint64_t*)s->d_xl.p, (SubState*)s->d_subscr.p,
-                               (SubState*)d_subs_host, (unsigned long long)out_states,
-                               (unsigned long long*)s->d_counter.p, (GapOut*)s->d_outs.p, (GapOut*)d_outs_host,
-                               s->params.skip_confident ? 1 : 0, fcap));
+    HIP_TRY(launch_fill_lds(st, (uint32_t)ids.size(), lds_cap_max, num_oriented, dg.succ, dg.ustart,
+                            (const GapDev*)s->d_gaps.p, (const uint32_t*)s->d_ids.p, (const uint32_t*)s->d_flank.p,
+                            (uint64_t*)s->d_log.p, (uint32_t*)s->d_lvl.p, (uint32_t*)s->d_plk.p, (uint64_t*)s->d_xl.p,
+                            (SubState*)s->d_subscr.p, (SubState*)d_subs_host, (unsigned long long)out_states,
+                            (unsigned long long*)s->d_counter.p, (GapOut*)s->d_outs.p, (GapOut*)d_outs_host,
+                            s->params.skip_confident ? 1 : 0, rs_in_hbm ? (uint32_t*)s->d_rs.p : nullptr, fcap));
+    HIP_TRY(hipEventRecord(s->ev[2], st));
     HIP_TRY(hipEventRecord(s->ev[3], st));
   } else {
     HIP_TRY(s->d_rs.ensure(rs_total * 4));
