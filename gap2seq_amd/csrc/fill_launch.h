@@ -34,7 +34,8 @@ hipError_t launch_fill_lds(hipStream_t st, uint32_t ngaps, uint32_t rs_cap_max, 
                            const uint32_t* flank_nodes, uint64_t* log_all, uint32_t* lvl_all, uint32_t* plk_all,
                            uint64_t* xl_all, SubState* sub_scratch, SubState* sub_out /* pinned host */,
                            unsigned long long out_cap /* records */, unsigned long long* out_counter, GapOut* outs,
-                           GapOut* outs_host /* pinned host */, int skip_confident,
+                           GapOut* outs_host /* pinned host */, uint32_t* done_list /* pinned host, ngaps entries */,
+                           int skip_confident,
                            uint32_t* rs_global /* nullptr: right set in LDS */, uint32_t fcap /* frontier capacity */);
 
 }  // namespace g2s

@@ -891,7 +891,7 @@ __device__ __forceinline__ void extract_lds_body(const FillOut fo, const GapDev*
                                                  const uint64_t* __restrict__ xl_all, SubState* sub_scratch,
                                                  SubState* sub_out, unsigned long long out_cap,
                                                  unsigned long long* out_counter, GapOut* outs, GapOut* outs_host,
-                                                 int skip_confident, const uint32_t F) {
+                                                 uint32_t* done_list, int skip_confident, const uint32_t F) {
   const uint32_t W = F > 256u ? F : 256u;  // log / level-offset window: holds at least one whole level
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   const uint32_t gi = __builtin_amdgcn_readfirstlane(gap_ids[blockIdx.x]);
@@ -902,9 +902,17 @@ __device__ __forceinline__ void extract_lds_body(const FillOut fo, const GapDev*
   const int c_count = fo.c_count, n_len = fo.n_len;
   // sub_out and outs_host are pinned host memory: the closure and the per-gap record go
   // straight over the link as each gap finishes, there is no device-to-host copy afterwards
+  // ... and the gap's index is appended to done_list (pinned host memory too) once all of
+  // that is on its way: the host analyses finished gaps while the others are still running.
+  // (The cursor of the list lives in device memory next to the output cursor.)
   auto publish = [&]() {
     if ((uint32_t)lane < sizeof(GapOut) / 4u)
       ((uint32_t*)&outs_host[gi])[lane] = __hip_atomic_load(&((const uint32_t*)go)[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence_system();  // every lane's stores to host memory are out before the list entry
+    if (lane == 0) {
+      const unsigned long long at = atomicAdd(out_counter + 1, 1ull);
+      __hip_atomic_store(&done_list[at], gi, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   };
   if ((gflags & (G2S_DEV_OVERFLOW_A | G2S_DEV_OVERFLOW_B)) || !(c_count > 0 && n_len > 0)) {  // :1169
     publish();
@@ -1247,13 +1255,13 @@ __device__ __forceinline__ void extract_lds_body(const FillOut fo, const GapDev*
       const uint32_t *__restrict__ gap_ids, const uint32_t *__restrict__ flank_nodes, uint64_t *log_all,              \
       uint32_t *lvl_all, uint32_t *plk_all, uint64_t *xl_all, SubState *sub_scratch, SubState *sub_out,               \
       unsigned long long out_cap, unsigned long long *out_counter, GapOut *outs, GapOut *outs_host,                   \
-      int skip_confident, uint32_t num_oriented
+      uint32_t *done_list, int skip_confident, uint32_t num_oriented
 __global__ __launch_bounds__(64) void g2s_fill_lds(G2S_FUSED_PARAMS, uint32_t fcap) {
   const FillOut fo = fill_lds_body<false>(succ, ustart, gaps, gap_ids, flank_nodes, log_all, lvl_all, plk_all, xl_all, outs,
                                           num_oriented, nullptr, fcap);
   __threadfence();  // the log, level offsets and links of this gap were written through: read them back from L2
   extract_lds_body(fo, gaps, gap_ids, flank_nodes, log_all, lvl_all, plk_all, xl_all, sub_scratch, sub_out, out_cap,
-                   out_counter, outs, outs_host, skip_confident, fcap);
+                   out_counter, outs, outs_host, done_list, skip_confident, fcap);
 }
 // Same kernel with the right set in HBM: for gaps whose right set outgrows the LDS (deep
 // DP, -dist-error in the thousands); everything else of the gap stays in LDS.
@@ -1262,7 +1270,7 @@ __global__ __launch_bounds__(64) void g2s_fill_lds_rsg(G2S_FUSED_PARAMS, uint32_
                                          num_oriented, rs_global, fcap);
   __threadfence();
   extract_lds_body(fo, gaps, gap_ids, flank_nodes, log_all, lvl_all, plk_all, xl_all, sub_scratch, sub_out, out_cap,
-                   out_counter, outs, outs_host, skip_confident, fcap);
+                   out_counter, outs, outs_host, done_list, skip_confident, fcap);
 }
 
 // ---------------------------------------------------------------------------
@@ -1284,8 +1292,8 @@ hipError_t launch_fill_lds(hipStream_t st, uint32_t ngaps, uint32_t rs_cap_max, 
                            const uint32_t* succ, const uint64_t* ustart, const GapDev* gaps, const uint32_t* gap_ids,
                            const uint32_t* flank_nodes, uint64_t* log_all, uint32_t* lvl_all, uint32_t* plk_all,
                            uint64_t* xl_all, SubState* sub_scratch, SubState* sub_out, unsigned long long out_cap,
-                           unsigned long long* out_counter, GapOut* outs, GapOut* outs_host, int skip_confident,
-                           uint32_t* rs_global, uint32_t fcap) {
+                           unsigned long long* out_counter, GapOut* outs, GapOut* outs_host, uint32_t* done_list,
+                           int skip_confident, uint32_t* rs_global, uint32_t fcap) {
   if (ngaps == 0) return hipSuccess;
   const size_t bytes = std::max(fill_lds_bytes(rs_global ? 0 : rs_cap_max, fcap), extract_lds_bytes(fcap));
   if (rs_global) {  // right set in HBM: no LDS for it
@@ -1293,14 +1301,14 @@ hipError_t launch_fill_lds(hipStream_t st, uint32_t ngaps, uint32_t rs_cap_max, 
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(g2s_fill_lds_rsg, dim3(ngaps), dim3(64), bytes, st, succ, ustart, gaps, gap_ids, flank_nodes,
                        log_all, lvl_all, plk_all, xl_all, sub_scratch, sub_out, out_cap, out_counter, outs, outs_host,
-                       skip_confident, num_oriented, rs_global, fcap);
+                       done_list, skip_confident, num_oriented, rs_global, fcap);
     return hipGetLastError();
   }
   hipError_t e = hipFuncSetAttribute((const void*)g2s_fill_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(g2s_fill_lds, dim3(ngaps), dim3(64), bytes, st, succ, ustart, gaps, gap_ids, flank_nodes, log_all,
-                     lvl_all, plk_all, xl_all, sub_scratch, sub_out, out_cap, out_counter, outs, outs_host, skip_confident,
-                     num_oriented, fcap);
+                     lvl_all, plk_all, xl_all, sub_scratch, sub_out, out_cap, out_counter, outs, outs_host, done_list,
+                     skip_confident, num_oriented, fcap);
   return hipGetLastError();
 }
 

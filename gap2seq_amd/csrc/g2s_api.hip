@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <pthread.h>
 #include <sched.h>
+#include <time.h>
 
 #include <algorithm>
 #include <atomic>
@@ -247,6 +248,7 @@ inline uint32_t pow2ceil(uint64_t x) {
 namespace {
 struct TierData {  // what came back from one launch group (pinned buffers live in the session)
   PinBuf outs, subs;
+  PinBuf done;  // LDS tier: gap indices in completion order, written by the kernel as gaps finish
   std::vector<uint32_t> gap_ids;
 };
 }  // namespace
@@ -455,7 +457,7 @@ extern "C" void g2s_session_destroy(g2s_session* s) {
                     &s->d_log, &s->d_lvl, &s->d_plk, &s->d_xl};
   for (DevBuf* b : bufs) b->release();
   delete s->pool;
-  for (void* v : s->tier_pool) { TierData* t = (TierData*)v; t->outs.release(); t->subs.release(); delete t; }
+  for (void* v : s->tier_pool) { TierData* t = (TierData*)v; t->outs.release(); t->subs.release(); t->done.release(); delete t; }
   s->h_gaps.release();
   for (int i = 0; i < 4; i++) if (s->ev[i]) (void)hipEventDestroy(s->ev[i]);
   if (s->stream) (void)hipStreamDestroy(s->stream);
@@ -633,8 +635,13 @@ Plan plan_gap(const GapJob& j, int d_err, uint64_t scale, uint64_t max_states) {
 // Launch phases A-D1 for the listed gaps and bring the results back.  lds = true: the
 // LDS-resident kernels (fill_lds.hip); false: the general tier with per-gap tables in
 // HBM (fill_kernels.hip) at the given table scale.
+// on_done (LDS tier): called on the calling thread while the kernel runs, with the indices of
+// gaps whose results have arrived in td->outs / td->subs since the last call.
+using DoneFn = std::function<void(const uint32_t* gaps_done, size_t count)>;
 int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uint64_t max_states, TierData* td,
-             bool lds, uint32_t lds_room_override = 0, bool rs_in_hbm = false, uint32_t fcap = 64) {
+             bool lds, uint32_t lds_room_override = 0, bool rs_in_hbm = false, uint32_t fcap = 64,
+             const DoneFn* on_done = nullptr) {
+  const auto t_enter = std::chrono::steady_clock::now();
   g2s_session* s = b->s;
   const DeviceGraph& dg = s->graph->g->dev.at(s->device);
   const size_t n = b->jobs.size();
@@ -688,7 +695,7 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
   HIP_TRY(hipMemcpyAsync(s->d_gaps.p, gd, n * sizeof(GapDev), hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemcpyAsync(s->d_ids.p, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemsetAsync(s->d_outs.p, 0, n * sizeof(GapOut), st));
-  HIP_TRY(hipMemsetAsync(s->d_counter.p, 0, 16, st));
+  HIP_TRY(hipMemsetAsync(s->d_counter.p, 0, 16, st));  // [0] output cursor, [1] completion-list cursor
   if (lds) {
     HIP_TRY(s->d_log.ensure(slog_total * 8));
     HIP_TRY(s->d_lvl.ensure(lvl_total * 4));
@@ -705,15 +712,19 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
     HIP_TRY(td->outs.ensure(n * sizeof(GapOut)));
     out_states += out_max;
     HIP_TRY(td->subs.ensure(std::max<uint64_t>(out_states * sizeof(SubState), 16)));
-    void *d_outs_host = nullptr, *d_subs_host = nullptr;
+    HIP_TRY(td->done.ensure(std::max<size_t>(ids.size() * 4, 16)));
+    memset(td->done.p, 0xFF, ids.size() * 4);
+    void *d_outs_host = nullptr, *d_subs_host = nullptr, *d_done_host = nullptr;
     HIP_TRY(hipHostGetDevicePointer(&d_outs_host, td->outs.p, 0));
     HIP_TRY(hipHostGetDevicePointer(&d_subs_host, td->subs.p, 0));
+    HIP_TRY(hipHostGetDevicePointer(&d_done_host, td->done.p, 0));
     HIP_TRY(launch_fill_lds(st, (uint32_t)ids.size(), lds_cap_max, num_oriented, dg.succ, dg.ustart,
                             (const GapDev*)s->d_gaps.p, (const uint32_t*)s->d_ids.p, (const uint32_t*)s->d_flank.p,
                             (uint64_t*)s->d_log.p, (uint32_t*)s->d_lvl.p, (uint32_t*)s->d_plk.p, (uint64_t*)s->d_xl.p,
                             (SubState*)s->d_subscr.p, (SubState*)d_subs_host, (unsigned long long)out_states,
                             (unsigned long long*)s->d_counter.p, (GapOut*)s->d_outs.p, (GapOut*)d_outs_host,
-                            s->params.skip_confident ? 1 : 0, rs_in_hbm ? (uint32_t*)s->d_rs.p : nullptr, fcap));
+                            (uint32_t*)d_done_host, s->params.skip_confident ? 1 : 0,
+                            rs_in_hbm ? (uint32_t*)s->d_rs.p : nullptr, fcap));
     HIP_TRY(hipEventRecord(s->ev[2], st));
     HIP_TRY(hipEventRecord(s->ev[3], st));
   } else {
@@ -745,8 +756,40 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
     HIP_TRY(hipEventRecord(s->ev[3], st));
   }
 
+  const auto t_launched = std::chrono::steady_clock::now();
   if (lds) {
+    if (on_done) {
+      // gaps finish at very different times (the longest take 10x the median): hand the
+      // finished ones to the caller while the kernel is still running.  Only this thread
+      // polls, and it naps between looks: a busy host must not starve the HIP runtime.
+      const volatile uint32_t* done = (const volatile uint32_t*)td->done.p;
+      size_t seen = 0, given = 0;
+      const size_t total = ids.size();
+      while (given < total) {
+        while (seen < total && done[seen] != 0xFFFFFFFFu) seen++;
+        std::atomic_thread_fence(std::memory_order_acquire);
+        const bool finished = hipEventQuery(s->ev[2]) != hipErrorNotReady;
+        // (a few large hand-overs: every one of them wakes the worker pool)
+        const size_t chunk = std::max<size_t>(32, total / 8);
+        if (seen - given >= chunk || (finished && seen > given) || seen == total) {
+          (*on_done)((const uint32_t*)td->done.p + given, seen - given);
+          given = seen;
+        } else if (finished) {
+          while (seen < total && done[seen] != 0xFFFFFFFFu) seen++;
+          if (seen == given) break;  // kernel over and nothing new: an error, reported by the sync below
+        } else {
+          struct timespec ts = {0, 20000};
+          nanosleep(&ts, nullptr);
+        }
+      }
+    }
+    const auto t_polled = std::chrono::steady_clock::now();
     HIP_TRY(hipStreamSynchronize(st));  // the kernels wrote td->outs / td->subs themselves
+    if (getenv("G2S_DEBUG"))
+      fprintf(stderr, "[g2s] run_tier: plan+upload+launch %.3f ms, polling/analysis %.3f ms, final sync %.3f ms\n",
+              std::chrono::duration<double, std::milli>(t_launched - t_enter).count(),
+              std::chrono::duration<double, std::milli>(t_polled - t_launched).count(),
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_polled).count());
   } else {
     // device -> host: per-gap results, then the packed closures
     HIP_TRY(td->outs.ensure(n * sizeof(GapOut)));
@@ -848,6 +891,37 @@ int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
   std::vector<char>& mem_exceeded = b->mem_exceeded;
   views.assign(n, SubView());
   mem_exceeded.assign(n, 0);
+  // analysis of finished gaps runs on the pool while the kernel is still busy with the rest
+  std::vector<char> analyzed(n, 0);
+  std::vector<uint32_t> fresh;
+  double ms_stream = 0;
+  if (analyze) {
+    b->prep.assign(n, SubPrep());
+    b->info.assign(n, g2s_batch::GapInfo());
+  }
+  TierData* td_live = nullptr;
+  const DoneFn on_done = [&](const uint32_t* done_ids, size_t cnt) {
+    auto t0 = std::chrono::steady_clock::now();
+    const GapOut* outs = (const GapOut*)td_live->outs.p;
+    fresh.clear();
+    for (size_t x = 0; x < cnt; x++) {
+      const uint32_t i = done_ids[x];
+      if (i >= n || analyzed[i]) continue;
+      const GapOut& go = outs[i];
+      if (go.flags & (G2S_DEV_OVERFLOW_A | G2S_DEV_OVERFLOW_B)) continue;  // runs again in a later pass
+      SubView& v = views[i];
+      v.out = &go;
+      v.st = (const SubState*)td_live->subs.p + go.sub_off;
+      v.n = go.n_sub;
+      analyzed[i] = 1;
+      fresh.push_back(i);
+    }
+    const size_t per = 8, nt = (fresh.size() + per - 1) / per;
+    s->pool->run(nt, [&](size_t t) {
+      for (size_t x = t * per; x < std::min(fresh.size(), (t + 1) * per); x++) analyze_gap(b, fresh[x], fp, &results[fresh[x]]);
+    });
+    ms_stream += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  };
 
   // ---- GPU: phases A-D1, retrying gaps whose tables overflowed with 8x larger ones
   std::vector<uint32_t> todo, lds_ids;
@@ -882,7 +956,9 @@ int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
     b->tiers.push_back(td);
     // pass 0 keeps the LDS footprint small (frontier 64); later passes run few gaps per CU and
     // take wide frontiers (1024 entries) so that repeat-rich gaps stay out of the HBM tier
-    int rc = run_tier(b, ids, pass == 0 ? 1 : 8, max_states, td, true, room, pass == 2, pass == 0 ? 64u : 1024u);
+    td_live = td;
+    int rc = run_tier(b, ids, pass == 0 ? 1 : 8, max_states, td, true, room, pass == 2, pass == 0 ? 64u : 1024u,
+                      analyze ? &on_done : nullptr);
     if (rc != G2S_OK) return rc;
     const GapOut* outs = (const GapOut*)td->outs.p;
     for (uint32_t i : ids) {
@@ -989,16 +1065,19 @@ int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
   if (analyze) {
     // ---- host: D2 + stop-depth analysis per gap, thread pool (teams: per group, so that it
     // overlaps the other sessions' kernels)
+    // what was not analysed while the kernels ran: bad flanks, verdicts, gaps of the HBM tier
     auto t_post = std::chrono::steady_clock::now();
-    b->prep.assign(n, SubPrep());
-    b->info.assign(n, g2s_batch::GapInfo());
-    const size_t per = 8, nt = (n + per - 1) / per;
+    fresh.clear();
+    for (size_t i = 0; i < n; i++) if (!analyzed[i]) fresh.push_back((uint32_t)i);
+    const size_t per = 8, nt = (fresh.size() + per - 1) / per;
     s->pool->run(nt, [&](size_t t) {
-      for (size_t i = t * per; i < std::min(n, (t + 1) * per); i++) analyze_gap(b, i, fp, &results[i]);
+      for (size_t x = t * per; x < std::min(fresh.size(), (t + 1) * per); x++) analyze_gap(b, fresh[x], fp, &results[fresh[x]]);
     });
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_post).count();
-    b->timing.ms_host_post = ms;
+    b->timing.ms_host_post = ms + ms_stream;  // ms_stream overlapped the kernels
     b->timing.ms_total += ms;
+    if (getenv("G2S_DEBUG"))
+      fprintf(stderr, "[g2s] analysis: %.3f ms while the kernels ran, %.3f ms after (%zu gaps)\n", ms_stream, ms, fresh.size());
   }
   (void)g;
   (void)views;
@@ -1157,9 +1236,9 @@ extern "C" int g2s_batch_run(g2s_batch* b, g2s_result* results, char* arena, siz
     rand_need += (size_t)(b->jobs[i].g + s->graph->g->k + b->jobs[i].lmf + b->jobs[i].rmf + 2);
   std::thread rand_fill([s, rand_need]() { s->rcache.ensure(rand_need); });
   s->tier_cursor = 0;
-  int rc = batch_stage1(b, false, results);
+  int rc = batch_stage1(b, true, results);
   rand_fill.join();
-  if (rc == G2S_OK) rc = batches_stage2(std::vector<g2s_batch*>{b}, s, results, arena, &b->timing, true);
+  if (rc == G2S_OK) rc = batches_stage2(std::vector<g2s_batch*>{b}, s, results, arena, &b->timing, false);
   return rc;
 }
 
