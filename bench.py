@@ -3,11 +3,12 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path (g2s_batch_run: kernels g2s_fill_lds +
-g2s_extract_lds [+ the HBM-tier kernels for gaps that outgrow the LDS], device->host
-of the packed closures, host phase D incl. the traceback at in-order rand() offsets) over one batch of synthetic gaps whose descriptors are already
-resident in HBM (g2s_batch_prepare is outside the timed region, as is the one-off
-graph build + upload, reported separately).
+A "step" is one pass of the hot path (g2s_batch_run: the fused kernel g2s_fill_lds =
+phases A-D1 of every gap, writing its results into pinned host memory [+ the HBM-tier
+kernels for gaps that outgrow the LDS], host phase D2 overlapping the kernel, the
+in-order rand() offset pass and the tracebacks) over one batch of synthetic gaps whose
+descriptors are already resident in HBM (g2s_batch_prepare is outside the timed region,
+as is the one-off graph build + upload, reported separately).
 
 Workload at N=1: BASELINE config 2 — synthetic 3 Mbp genome (seed 20240101),
 k=31, -fuz 10, -dist-error 500, 500 gaps of 200-1000 bp (seed 20240103), one gap
@@ -168,35 +169,9 @@ def main():
 
     if rank == 0:
         steps = max(1, args.steps)
-        # ---- roofline of the dominant kernel, measured live with HIP events on the session stream.
-        # g2s_fill_lds fuses phases A (right BFS), B (left DP) and C (target check) for every gap
-        # that fits the LDS tier; algorithmic bytes = 24 B per expansion + 8 B per state set
-        #  over phases A+B of those gaps + their flank/fill I/O.
-        io_bytes = tm.flank_bytes + tm.fill_bytes
-        if tm.lds_tier_gaps > 0:
-            kname, x_units, s_units = "g2s_fill_lds", tm.x_fill_lds, tm.s_fill_lds
-            launches = float(max(1, tm.lds_launches))
-            kern_ms = acc["ms_fill_lds"] / steps / launches  # average launch duration
-        else:
-            kname, x_units, s_units = "g2s_left_dp", tm.xB, tm.sB
-            kern_ms = acc["ms_left_dp"] / steps
-            launches = acc["launches"] / steps
-        alg_bytes = algorithmic_bytes(x_units, s_units, io_bytes) / launches  # per launch
-        achieved = alg_bytes / (kern_ms / 1e3) / 1e9 if kern_ms > 0 else 0.0
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_fill_lds.json")
-        if os.path.exists(pmc) and kname == "g2s_fill_lds" and args.gaps == 500 and args.variant == 3:
-            try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        roofline = dict(bound="hbm", kernel=kname, achieved=round(achieved, 3), peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(achieved / HBM_PEAK_GBS, 6), traffic=traffic,
-                        algorithmic_bytes_per_launch=alg_bytes, expansions=x_units, states=s_units,
-                        kernel_ms_per_launch=round(kern_ms, 4), launches_per_step=launches,
-                        lds_tier_gaps=tm.lds_tier_gaps)
         # ---- CPU baseline: the oracle (faithful port of the reference algorithm), same gaps
         cpu = None
+        octr = None
         if world == 1 and not args.no_cpu_baseline:
             import oracle_lib as O
             og = O.OracleGraph(seqs, args.k, 1)
@@ -211,8 +186,44 @@ def main():
                        sample="all %d gaps of the bench workload, %d passes, oracle fill_gap only (graph build excluded)"
                               % (len(gaps), passes),
                        value_all_cores=round(len(gaps) / sN, 2), cores_all=ncpu, filled=ofilled,
-                       oracle_expansions_B=octr[2], oracle_states_B=octr[3])
+                       oracle_expansions_A_B_D1=[octr[0], octr[2], octr[4]],
+                       oracle_states_A_B_D1=[octr[1], octr[3], octr[5]])
             og.free()
+        # ---- roofline of the dominant kernel, measured live with HIP events on the session stream.
+        # g2s_fill_lds runs phases A (right search), B (left DP), C (target check) and D1 (closure)
+        # of every gap that fits the LDS tier, one wave per gap.  Algorithmic bytes
+        # = 24 B per expansion + 8 B per newly set state over phases A, B and D1 + per-gap
+        # flank/fill I/O, with the expansion/state counts of the REFERENCE algorithm as counted by
+        # the CPU oracle on the same gaps (the product's own counters are lower for phase A: it
+        # visits every node once, the reference re-expands nodes reached by walks of several
+        # lengths); without the CPU leg the product's counters are used and labelled so.
+        io_bytes = tm.flank_bytes + tm.fill_bytes
+        if tm.lds_tier_gaps > 0:
+            kname = "g2s_fill_lds"
+            if octr is not None and tm.lds_tier_gaps == len(gaps):
+                x_units, s_units, counted_by = octr[0] + octr[2] + octr[4], octr[1] + octr[3] + octr[5], "oracle"
+            else:
+                x_units, s_units, counted_by = tm.xA + tm.xB + tm.xD, tm.sA + tm.sB + tm.sD, "product"
+            launches = float(max(1, tm.lds_launches))
+            kern_ms = acc["ms_fill_lds"] / steps / launches  # average launch duration
+        else:
+            kname, x_units, s_units, counted_by = "g2s_left_dp", tm.xB, tm.sB, "product"
+            kern_ms = acc["ms_left_dp"] / steps
+            launches = acc["launches"] / steps
+        alg_bytes = algorithmic_bytes(x_units, s_units, io_bytes) / launches  # per launch
+        achieved = alg_bytes / (kern_ms / 1e3) / 1e9 if kern_ms > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_v5_pmc_fill_lds.json")
+        if os.path.exists(pmc) and kname == "g2s_fill_lds" and args.gaps == 500 and args.variant == 3:
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = dict(bound="hbm", kernel=kname, achieved=round(achieved, 3), peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=round(achieved / HBM_PEAK_GBS, 6), traffic=traffic,
+                        algorithmic_bytes_per_launch=alg_bytes, expansions=x_units, states=s_units,
+                        units_counted_by=counted_by, kernel_ms_per_launch=round(kern_ms, 4),
+                        launches_per_step=launches, lds_tier_gaps=tm.lds_tier_gaps)
         out = {
             "metric": "gaps filled/sec (whole node), k=31 synthetic 3 Mbp DBG",
             "value": round(units / elapsed, 2),
