@@ -86,7 +86,4 @@ struct GapOut {
   // LDS tier statistics: per-level iterations / bulk iterations of phases A, B, D1 and
   // shader cycles (in units of 256) spent in A, B+C, D1
   uint32_t stat[8];
-#ifdef G2S_PROF_A
-  uint32_t prof[16];  // profiling build only: cycles/256 per code path of phases A and B
-#endif
 };

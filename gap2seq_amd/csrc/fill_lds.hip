@@ -298,10 +298,6 @@ __device__ __forceinline__ FillOut fill_lds_body(const uint32_t* __restrict__ su
   // steps is the number of unitig hops (tens), not the number of levels (hundreds).
   uint32_t nvis = 0, xa = 0;
   uint32_t st_slowA = 0, st_bulkA = 0, st_slowB = 0, st_bulkB = 0;
-#ifdef G2S_PROF_A
-  unsigned long long pc[5] = {0, 0, 0, 0, 0}, pd[5] = {0, 0, 0, 0, 0};
-  uint32_t pnB[5] = {0, 0, 0, 0, 0};
-#endif
   const unsigned long long cyc0 = __builtin_amdgcn_s_memtime();
   if (!overflow) {
     uint64_t* lab = (uint64_t*)fn;        // labels (entry node << 32 | depth): the arrays of phase B are idle
@@ -490,10 +486,6 @@ __device__ __forceinline__ FillOut fill_lds_body(const uint32_t* __restrict__ su
       uint32_t* cnxt = fc + (cur ^ 1u) * F;
       const bool unpruned = d < gd.prune_from;  // :1050 first disjunct
       uint32_t nnew = 0;
-#ifdef G2S_PROF_A
-      unsigned long long qt0 = __builtin_amdgcn_s_memtime();
-      int qcat = 0;
-#endif
       // ---- bulk step: every border state (<= 16 of them) sits inside a unitig, where the
       // only successor of id v is v+2 (even orientation) or v-2 (odd), see dbg.hpp.
       // Lanes are level-major: lane = i*Rp + r handles run r at level d+i.  Each lane
@@ -599,22 +591,12 @@ __device__ __forceinline__ FillOut fill_lds_body(const uint32_t* __restrict__ su
           lds_sync();
           d += (int)lrun - 1;
           st_bulkB++;
-#ifdef G2S_PROF_A
-          pc[0] += __builtin_amdgcn_s_memtime() - qt0; pnB[0]++;
-#endif
           if (found && !gd.all_paths) break;  // (:1156-1158)
           continue;
         }
-#ifdef G2S_PROF_A
-        { unsigned long long t = __builtin_amdgcn_s_memtime(); pc[1] += t - qt0; qt0 = t; pnB[1]++; }
-#endif
       }
       st_slowB++;
       xb += nb;
-#ifdef G2S_PROF_A
-      qcat = nb == 1 ? 2 : nb <= 16 ? 3 : 4;
-      unsigned long long qt1 = __builtin_amdgcn_s_memtime();
-#endif
       if (nb == 1) {
         // single-entry frontier: its <=4 successors are distinct, no merging needed
         const uint32_t n = ncur[0];
@@ -696,10 +678,6 @@ __device__ __forceinline__ FillOut fill_lds_body(const uint32_t* __restrict__ su
             np = ccur[(uint32_t)lane >> 2];
           }
           if (np > G2S_DEV_MAX_PATHS) np = G2S_DEV_MAX_PATHS;
-#ifdef G2S_PROF_A
-          { uint32_t t = v + np; asm volatile("" :: "v"(t)); }
-          { unsigned long long t = __builtin_amdgcn_s_memtime(); pd[0] += t - qt1; qt1 = t; }
-#endif
           merge_round(v, np, (uint32_t)lane >> 2);
         } else {
           // wide border: one entry per lane with its whole record in one load (a level costs
@@ -732,15 +710,9 @@ __device__ __forceinline__ FillOut fill_lds_body(const uint32_t* __restrict__ su
             lds_sync();
           }
         }
-#ifdef G2S_PROF_A
-        if (qcat == 3) { unsigned long long t = __builtin_amdgcn_s_memtime(); pd[1] += t - qt1; qt1 = t; }
-#endif
       }
       if (nnew > F) { overflow = true; flags |= G2S_DEV_WHY_FRONTIER; break; }
       lds_sync();
-#ifdef G2S_PROF_A
-      if (qcat == 3) { unsigned long long t = __builtin_amdgcn_s_memtime(); pd[2] += t - qt1; qt1 = t; }
-#endif
       if (d <= gd.lmf) {  // next left-flank seed, row value ASSIGNED 1 (:1082-1105)
         const uint32_t s = lseeds[d];
         if (s != G2S_DEV_INVALID) {
@@ -779,9 +751,6 @@ __device__ __forceinline__ FillOut fill_lds_body(const uint32_t* __restrict__ su
       if (nhit > TH) { overflow = true; flags |= G2S_DEV_WHY_HITS; break; }
       cur ^= 1u;
       nb = nnew;
-#ifdef G2S_PROF_A
-      if (qcat == 3) { unsigned long long t = __builtin_amdgcn_s_memtime(); pd[3] += t - qt1; qt1 = t; }
-#endif
 
       // ---- phase C: target check (:1107-1159) over the recorded hits ---------------
       if (!found && d >= gd.g + gd.lmf + gd.rmf) {
@@ -821,9 +790,6 @@ __device__ __forceinline__ FillOut fill_lds_body(const uint32_t* __restrict__ su
         }
         if (found && !gd.all_paths) break;  // -best-only (:1156-1158)
       }
-#ifdef G2S_PROF_A
-      { unsigned long long t = __builtin_amdgcn_s_memtime(); pc[qcat] += t - qt0; pnB[qcat]++; if (qcat == 3) pd[4] += t - qt1; }
-#endif
       // nothing left to expand, no seed to come and nothing more to find: the remaining
       // levels of the reference's loop are empty
       if (nb == 0 && d > gd.lmf && found) { d = gd.D + 1; break; }
@@ -838,13 +804,6 @@ __device__ __forceinline__ FillOut fill_lds_body(const uint32_t* __restrict__ su
     const unsigned long long cyc2 = __builtin_amdgcn_s_memtime();
     go->stat[0] = st_slowA; go->stat[1] = st_bulkA; go->stat[2] = st_slowB; go->stat[3] = st_bulkB;
     go->stat[4] = (uint32_t)((cyc1 - cyc0) >> 8); go->stat[5] = (uint32_t)((cyc2 - cyc1) >> 8);
-#ifdef G2S_PROF_A
-    for (int q = 0; q < 5; q++) go->prof[8 + q] = (uint32_t)(pc[q] >> 8);
-    go->prof[13] = pnB[1] | (pnB[4] << 16); go->prof[14] = pnB[2] | (pnB[3] << 16);
-    go->prof[7] = (uint32_t)(pd[0] >> 8); go->prof[15] = (uint32_t)(pd[1] >> 8);
-    go->stat[0] = (uint32_t)(pd[2] >> 8); go->stat[1] = (uint32_t)(pd[3] >> 8); go->stat[2] = (uint32_t)(pd[4] >> 8);
-
-#endif
     go->flags = flags;
     go->n_right = nvis;
     go->x_right = xa;
@@ -964,10 +923,6 @@ __device__ __forceinline__ void extract_lds_body(const FillOut fo, const GapDev*
   const uint32_t cap = gd.slog_cap;
   bool over = false;
 
-#ifdef G2S_PROF_A
-  unsigned long long pe[4] = {0, 0, 0, 0};
-  pe[3] = __builtin_amdgcn_s_memtime() - cyc0;
-#endif
   // nothing can start above the last level that holds a state, nor (without a sink k-mer)
   // above the longest path length
   int d_top = min(gd.D, (int)fo.top_level);
@@ -983,9 +938,6 @@ __device__ __forceinline__ void extract_lds_body(const FillOut fo, const GapDev*
     xtop = xpos ? (uint32_t)(xl[xpos - 1u] >> 32) : 0u;
   }
   for (int d2 = d_top; d2 >= 0; d2--) {
-#ifdef G2S_PROF_A
-    const unsigned long long et0 = __builtin_amdgcn_s_memtime();
-#endif
     if (nch == 0 && nxc == 0 && d2 < min_len && (sinknode == G2S_DEV_INVALID || d2 < lo_sink)) break;  // nothing can start below
     uint32_t* mcur = mk + msel * F;
     uint32_t* mnxt = mk + (msel ^ 1u) * F;
@@ -1079,9 +1031,6 @@ __device__ __forceinline__ void extract_lds_body(const FillOut fo, const GapDev*
         nsub += nin;
         d2 -= (int)K - 1;
         st_bulkD++;
-#ifdef G2S_PROF_A
-        pe[0] += __builtin_amdgcn_s_memtime() - et0;
-#endif
         continue;
       }
     }
@@ -1184,13 +1133,7 @@ __device__ __forceinline__ void extract_lds_body(const FillOut fo, const GapDev*
     msel ^= 1u;
     xcount += nin_total;
     nsub += nin_total;
-#ifdef G2S_PROF_A
-    pe[1] += __builtin_amdgcn_s_memtime() - et0;
-#endif
   }
-#ifdef G2S_PROF_A
-  const unsigned long long et_pack = __builtin_amdgcn_s_memtime();
-#endif
   if (over) lflags |= G2S_DEV_OVERFLOW_B;
   for (int o = 32; o > 0; o >>= 1) lflags |= __shfl_xor(lflags, o);
   if (lflags & G2S_DEV_OVERFLOW_B) {
@@ -1237,10 +1180,6 @@ __device__ __forceinline__ void extract_lds_body(const FillOut fo, const GapDev*
     go->x_sub = xcount;
     go->stat[6] = st_slowD | (st_bulkD << 16);
     go->stat[7] = (uint32_t)((__builtin_amdgcn_s_memtime() - cyc0) >> 8);
-#ifdef G2S_PROF_A
-    go->stat[0] = (uint32_t)(pe[0] >> 8); go->stat[1] = (uint32_t)(pe[1] >> 8);
-    go->stat[2] = (uint32_t)((__builtin_amdgcn_s_memtime() - et_pack) >> 8); go->stat[3] = (uint32_t)(pe[3] >> 8);
-#endif
   }
   __threadfence();
   publish();

@@ -765,13 +765,20 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
       const volatile uint32_t* done = (const volatile uint32_t*)td->done.p;
       size_t seen = 0, given = 0;
       const size_t total = ids.size();
+      // a few large hand-overs (every one of them wakes the worker pool) while gaps arrive in
+      // numbers; once arrivals dry up — the stragglers — whatever is there goes out at once,
+      // so that next to nothing is left when the last gap finishes
+      const size_t chunk = std::max<size_t>(32, total / 8);
+      auto last_arrival = std::chrono::steady_clock::now();
       while (given < total) {
+        const size_t before = seen;
         while (seen < total && done[seen] != 0xFFFFFFFFu) seen++;
         std::atomic_thread_fence(std::memory_order_acquire);
+        const auto now = std::chrono::steady_clock::now();
+        if (seen != before) last_arrival = now;
         const bool finished = hipEventQuery(s->ev[2]) != hipErrorNotReady;
-        // (a few large hand-overs: every one of them wakes the worker pool)
-        const size_t chunk = std::max<size_t>(32, total / 8);
-        if (seen - given >= chunk || (finished && seen > given) || seen == total) {
+        const bool lull = seen > given && std::chrono::duration<double, std::micro>(now - last_arrival).count() > 60.0;
+        if (seen - given >= chunk || lull || (finished && seen > given) || seen == total) {
           (*on_done)((const uint32_t*)td->done.p + given, seen - given);
           given = seen;
         } else if (finished) {
@@ -916,15 +923,19 @@ int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
       analyzed[i] = 1;
       fresh.push_back(i);
     }
-    const size_t per = 8, nt = (fresh.size() + per - 1) / per;
-    s->pool->run(nt, [&](size_t t) {
-      for (size_t x = t * per; x < std::min(fresh.size(), (t + 1) * per); x++) analyze_gap(b, fresh[x], fp, &results[fresh[x]]);
-    });
+    if (fresh.size() <= 6) {  // not worth waking the pool
+      for (uint32_t i : fresh) analyze_gap(b, i, fp, &results[i]);
+    } else {
+      const size_t per = 8, nt = (fresh.size() + per - 1) / per;
+      s->pool->run(nt, [&](size_t t) {
+        for (size_t x = t * per; x < std::min(fresh.size(), (t + 1) * per); x++) analyze_gap(b, fresh[x], fp, &results[fresh[x]]);
+      });
+    }
     ms_stream += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   };
 
   // ---- GPU: phases A-D1, retrying gaps whose tables overflowed with 8x larger ones
-  std::vector<uint32_t> todo, lds_ids;
+  std::vector<uint32_t> todo, lds_ids, late1, late2;  // late1/late2: gaps that start in pass 1 / pass 2
   // (the LDS right set keeps 28-bit k-mer indices)
   const bool lds_ok = s->graph->g->dev.at(s->device).pred == nullptr && !s->no_lds_tier &&
                       s->graph->g->n < (1ull << 28) - 1;
@@ -935,6 +946,8 @@ int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
     for (size_t i = 0; i < n; i++) {
       if (b->jobs[i].bad_flank) continue;
       if (lds_ok && lds_rs_cap(b->jobs[i], fp.d_err, room) != 0) lds_ids.push_back((uint32_t)i);
+      else if (lds_ok && lds_rs_cap(b->jobs[i], fp.d_err, 16384u) != 0) late1.push_back((uint32_t)i);   // pass 1's table
+      else if (lds_ok && b->jobs[i].rmf <= (int)fill_lds_max_fuz()) late2.push_back((uint32_t)i);        // right set in HBM
       else todo.push_back((uint32_t)i);
     }
   }
@@ -947,6 +960,8 @@ int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
   //   pass 2: right set in HBM (any size up to -max-mem), the rest still in LDS
   std::vector<uint32_t> cand[3];
   cand[0] = lds_ids;
+  cand[1] = late1;
+  cand[2] = late2;
   const bool room0_is_max = lds_room(n) >= 16384u;
   for (int pass = 0; pass < 3; pass++) {
     if (cand[pass].empty()) continue;
@@ -1000,24 +1015,12 @@ int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
         fprintf(stderr, "[g2s] pass %d slow gap %u: g %d | A per-level %u bulk %u kcyc %u | B per-level %u bulk %u kcyc %u | D1 per-level %u bulk %u kcyc %u | xA %u xB %u xD %u\n",
                 pass, ord[q], b->jobs[ord[q]].g, o.stat[0], o.stat[1], o.stat[4] >> 2, o.stat[2], o.stat[3], o.stat[5] >> 2,
                 o.stat[6] & 0xFFFF, o.stat[6] >> 16, o.stat[7] >> 2, o.x_right, o.x_left, o.x_sub);
-#ifdef G2S_PROF_A
-        fprintf(stderr, "[g2s]   prof A (kcyc): bulk ok %u | bulk fail %u (n %u) | narrow %u | wide %u (n %u) || bulk attempts: load wait %u, checks %u\n",
-                o.prof[0] >> 2, o.prof[1] >> 2, o.prof[6] & 0xFFFF, o.prof[2] >> 2, o.prof[3] >> 2, o.prof[6] >> 16,
-                o.prof[4] >> 2, o.prof[5] >> 2);
-        fprintf(stderr, "[g2s]   prof B (kcyc): bulk ok %u | bulk fail %u (n %u) | single %u (n %u) | narrow %u (n %u) | wide %u (n %u)\n",
-                o.prof[8] >> 2, o.prof[9] >> 2, o.prof[13] & 0xFFFF, o.prof[10] >> 2, o.prof[14] & 0xFFFF, o.prof[11] >> 2,
-                o.prof[14] >> 16, o.prof[12] >> 2, o.prof[13] >> 16);
-        fprintf(stderr, "[g2s]   prof D1 (kcyc): bulk %u | per-level %u | pack %u | startup %u\n", o.stat[0] >> 2, o.stat[1] >> 2,
-                o.stat[2] >> 2, o.stat[3] >> 2);
-        if (0) fprintf(stderr, "[g2s]   prof B narrow (kcyc): load+prune %u | claim %u | pass2 %u | seed+append+hits %u | phase C %u\n",
-                o.prof[7] >> 2, o.prof[15] >> 2, o.stat[0] >> 2, o.stat[1] >> 2, o.stat[2] >> 2);
-#endif
       }
     }
   }
   std::sort(todo.begin(), todo.end());
   // gaps that outgrew the LDS tier are known to branch: start them with 8x tables
-  uint64_t scale = lds_ids.empty() ? 1 : 8;
+  uint64_t scale = (lds_ids.empty() && late1.empty() && late2.empty()) ? 1 : 8;
   while (!todo.empty()) {
     std::vector<uint32_t> next_todo;
     size_t pos = 0;

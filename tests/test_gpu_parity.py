@@ -449,3 +449,13 @@ def test_cli_binary_is_a_drop_in(product, oracle, tmp_path):
     assert outs["gpu"][0] == outs["cpu"][0]
     assert outs["gpu"][1] == outs["cpu"][1]
     assert "Filled 40 gaps out of 40" in outs["gpu"][1] or "Filled" in outs["gpu"][1]
+    # the dispatcher: several sessions (here three on device 0, as -devices 0,0 -streams 2 minus
+    # the lead) share the gap list; FASTA and stdout must not change
+    out = tmp_path / "out_team.fa"
+    res = subprocess.run([os.path.join(ROOT, "gap2seq_amd", "Gap2Seq-core"), "-k", str(k), "-fuz", "10", "-solid", "1",
+                          "-nb-cores", "1", "-dist-error", "100", "-max-mem", "20", "-randseed", "4", "-reads", str(reads),
+                          "-filled", str(out), "-scaffolds", str(scaf), "-devices", "0,0", "-streams", "2"],
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert out.read_text() == outs["cpu"][0]
+    assert res.stdout.replace(str(out), "OUT") == outs["cpu"][1]
