@@ -20,9 +20,6 @@
 #define G2S_DEV_WHY_FRONTIER 0x100u /* a DP level wider than the LDS frontier buffers */
 #define G2S_DEV_WHY_HITS 0x200u     /* more target hits than the LDS list holds       */
 #define G2S_DEV_WHY_LOG 0x400u      /* state log full                                 */
-/* closure from the LDS tier: pred[] of a SubState holds the parents from slot 0 in arrival
- * order, not in GATB predecessor order (the host orders the few multi-parent states) */
-#define G2S_DEV_PRED_UNORDERED 0x1000u
 /* LDS tier, lvl[]: bit 31 of the END offset of level L = L was produced by a bulk step
  * (same width as level L-1, state r has the single parent r of level L-1) */
 #define G2S_LVL_UNIFORM 0x80000000u
@@ -55,15 +52,32 @@ struct GapDev {
 #define G2S_SUB_SINK 0x8u     /* has an edge to the sink pseudo-vertex                        */
 #define G2S_SUB_START_T 0x10u /* (reachedTarget, pathLengths[i])                              */
 
-/* One state of the backward closure that phase D works on, in discovery order
- * (depth descending).  pred[i] = index (within the gap's array) of the state of
- * graph.predecessors(node)[i] at depth-1 when that state is set, else -1. */
+/* One state of the backward closure that phase D works on, in discovery order (depth
+ * descending), as the HBM tier's kernel emits it: pred[i] = index (within the gap's array) of
+ * the state of graph.predecessors(node)[i] at depth-1 when that state is set, else -1.  The
+ * host converts these to SubRec. */
 struct SubState {
   uint32_t node;
   uint32_t depth;
   uint32_t cnt;
   uint32_t flags;
   int32_t pred[4];
+};
+
+/* The closure as the host works on it and as the LDS tier emits it: 16 bytes per state.
+ * Almost every state has one parent; the others set G2S_SUB_MORE in `pred` and list their
+ * further parents in the gap's side list xp[] = (state << 32 | parent), sorted by state.
+ * Parents are a set here; where their GATB order matters (the traceback, :1476-1513) it
+ * is recovered from the graph: predecessors(v)[i] is the parent p whose p^1 ends with base i. */
+#define G2S_SUB_META_FLAG_SHIFT 27u         /* meta = depth | flags << 27 */
+#define G2S_SUB_META_DEPTH_MASK 0x07FFFFFFu
+#define G2S_SUB_MORE 0x40000000             /* in pred: further parents in xp[] */
+#define G2S_SUB_PRED_MASK 0x3FFFFFFF
+struct SubRec {
+  uint32_t node;
+  uint32_t cnt;
+  uint32_t meta;
+  int32_t pred;  /* -1: none */
 };
 
 struct GapOut {
@@ -78,11 +92,11 @@ struct GapOut {
   int32_t len[2];
   int32_t reached_j;   // reachedFuz
   uint32_t n_sub;      // states in the backward closure (phase D input)
-  uint64_t sub_off;    // offset of this gap's SubState array in the packed output
+  uint64_t sub_off;    // offset of this gap's closure in the packed output (SubRec / SubState units)
   uint32_t x_sub;      // expansions done by the backward sweep
   uint32_t n_xl;       // LDS tier: entries in the gap's extra-parent list
   uint32_t top_level;  // LDS tier: last DP level that holds a state
-  uint32_t pad1;
+  uint32_t n_xp;       // LDS tier: entries of the closure's side list (parents beyond the first)
   // LDS tier statistics: per-level iterations / bulk iterations of phases A, B, D1 and
   // shader cycles (in units of 256) spent in A, B+C, D1
   uint32_t stat[8];

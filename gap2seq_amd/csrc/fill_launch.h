@@ -32,7 +32,7 @@ uint32_t fill_lds_max_fuz();
 hipError_t launch_fill_lds(hipStream_t st, uint32_t ngaps, uint32_t rs_cap_max, uint32_t num_oriented,
                            const uint32_t* succ, const uint64_t* ustart, const GapDev* gaps, const uint32_t* gap_ids,
                            const uint32_t* flank_nodes, uint64_t* log_all, uint32_t* lvl_all, uint32_t* plk_all,
-                           uint64_t* xl_all, SubState* sub_scratch, SubState* sub_out /* pinned host */,
+                           uint64_t* xl_all, uint64_t* xo_all, SubRec* sub_scratch, SubRec* sub_out /* pinned host */,
                            unsigned long long out_cap /* records */, unsigned long long* out_counter, GapOut* outs,
                            GapOut* outs_host /* pinned host */, uint32_t* done_list /* pinned host, ngaps entries */,
                            int skip_confident,

@@ -837,8 +837,8 @@ __device__ __forceinline__ FillOut fill_lds_body(const uint32_t* __restrict__ su
 // its parents.  Runs of levels that phase B produced with a bulk step (flagged in
 // lvl[]: same width, parent = same position, no merges) are swept up to 64 levels per
 // iteration.  Parents are emitted in pred[0..] in arrival order, not GATB order; the
-// host puts the few multi-parent states in order (G2S_DEV_PRED_UNORDERED).
-// dynamic LDS: [wl W+1][wen W][wec W][wpl W][mk 2F][em F][ch 2x2F][pc F][xc 3x64]
+// traceback recovers the GATB order of a multi-parent state's parents from the graph.
+// dynamic LDS: [wl W+1][wen W][wec W][wpl W][mk 2F][em F][ch 2x3F][pc F][xc 3x64]
 // ============================================================================
 #define LDS_XC 64u /* extra links handled per level */
 __device__ __forceinline__ void extract_lds_body(const FillOut fo, const GapDev* __restrict__ gaps,
@@ -847,8 +847,8 @@ __device__ __forceinline__ void extract_lds_body(const FillOut fo, const GapDev*
                                                  const uint64_t* __restrict__ log_all,
                                                  const uint32_t* __restrict__ lvl_all,
                                                  const uint32_t* __restrict__ plk_all,
-                                                 const uint64_t* __restrict__ xl_all, SubState* sub_scratch,
-                                                 SubState* sub_out, unsigned long long out_cap,
+                                                 const uint64_t* __restrict__ xl_all, uint64_t* xo_all,
+                                                 SubRec* sub_scratch, SubRec* sub_out, unsigned long long out_cap,
                                                  unsigned long long* out_counter, GapOut* outs, GapOut* outs_host,
                                                  uint32_t* done_list, int skip_confident, const uint32_t F) {
   const uint32_t W = F > 256u ? F : 256u;  // log / level-offset window: holds at least one whole level
@@ -884,8 +884,8 @@ __device__ __forceinline__ void extract_lds_body(const FillOut fo, const GapDev*
   uint32_t* wpl = wec + W;
   uint32_t* mk = wpl + W;              // closure marks (IN_S | IN_T) by position: [0,F) this level, [F,2F) the one below
   uint32_t* em = mk + 2u * F;          // emit index by position, this level
-  uint32_t* ch = em + F;               // closure states of a level: emit index [F], parent position [F]; ping-pong
-  uint32_t* pc = ch + 4u * F;          // parents already linked, by position (levels with merged states only)
+  uint32_t* ch = em + F;               // closure states of a level: emit index, parent position, "more parents" [3][F]; ping-pong
+  uint32_t* pc = ch + 6u * F;          // has further parents, by position (levels with merged states only)
   uint32_t* xc = pc + F;               // merged states of the level above: emit index, parent position, slot [3][XC]
   uint32_t msel = 0, csel = 0;
 
@@ -893,7 +893,9 @@ __device__ __forceinline__ void extract_lds_body(const FillOut fo, const GapDev*
   const uint32_t* lvl = lvl_all + gd.lvl_off;
   const uint32_t* plk = plk_all + gd.slog_off;
   const uint64_t* xl = xl_all + gd.st_off;
-  SubState* sub = sub_scratch + gd.slog_off;
+  SubRec* sub = sub_scratch + gd.slog_off;
+  uint64_t* xo = xo_all + gd.st_off;  // the closure's side list: parents beyond the first, (state << 32 | parent)
+  uint32_t nxo = 0;
   const uint32_t* lseeds = flank_nodes + gd.flank_off;
   const uint32_t* targets = lseeds + (uint32_t)(gd.lmf + 1) + (uint32_t)(gd.rmf + 1);
   const int len0 = fo.len0, len1 = fo.len1;
@@ -1002,16 +1004,15 @@ __device__ __forceinline__ void extract_lds_body(const FillOut fo, const GapDev*
         // the parent (i+1, r) is marked whenever (i, r) is; it is emitted by lane + Rp
         const uint32_t pslot = lane + (int)Rp < 64 ? nsub + (uint32_t)__popcll(m & lanes_below(lane + (int)Rp)) : 0u;
         if (in) {
-          SubState st;
-          st.node = node; st.depth = (uint32_t)li; st.cnt = wec[wi]; st.flags = f;
-          st.pred[0] = (i + 1u < K) ? (int32_t)pslot : -1;
-          st.pred[1] = st.pred[2] = st.pred[3] = -1;
+          SubRec st;
+          st.node = node; st.cnt = wec[wi]; st.meta = (uint32_t)li | (f << G2S_SUB_META_FLAG_SHIFT);
+          st.pred = (i + 1u < K) ? (int32_t)pslot : -1;
           sub[slot] = st;
         }
         if (mine && i == 0) em[r] = slot;  // for the links from the level above
         lds_sync();
-        uint32_t* chc = ch + csel * 2u * F;
-        for (uint32_t j = (uint32_t)lane; j < nch; j += 64u) sub[chc[j]].pred[0] = (int32_t)em[chc[F + j]];
+        uint32_t* chc = ch + csel * 3u * F;
+        for (uint32_t j = (uint32_t)lane; j < nch; j += 64u) sub[chc[j]].pred = (int32_t)em[chc[F + j]];
         lds_sync();
         // the last level of the stretch becomes "the level above" of the next iteration
         const uint64_t lm = __ballot(in && i == K - 1u);
@@ -1019,6 +1020,7 @@ __device__ __forceinline__ void extract_lds_body(const FillOut fo, const GapDev*
           const uint32_t at = (uint32_t)__popcll(lm & lanes_below(lane));
           chc[at] = slot;
           chc[F + at] = r;
+          chc[2u * F + at] = 0u;
         }
         nch = (uint32_t)__popcll(lm);
         // the same buffer takes the marks of the level below the stretch (msel does not move)
@@ -1057,11 +1059,16 @@ __device__ __forceinline__ void extract_lds_body(const FillOut fo, const GapDev*
     }
     const uint32_t nx = xpos - xfirst;  // extra links of states in [lo, hi)
     if (nx > LDS_XC) { over = true; break; }
-    if (nx) { for (uint32_t c = (uint32_t)lane; c < w; c += 64u) pc[c] = 1u; lds_sync(); }
+    if (nx) {  // which positions of this level have further parents
+      for (uint32_t c = (uint32_t)lane; c < w; c += 64u) pc[c] = 0u;
+      lds_sync();
+      if ((uint32_t)lane < nx) pc[(uint32_t)(xl[xfirst + (uint32_t)lane] >> 32) - lo] = 1u;
+      lds_sync();
+    }
     // ---- per-level step: emit the marked states, pass the marks on to their parents -------
     const uint32_t lidx = (d2 <= gd.lmf) ? (lseeds[d2] >> 1) : 0xFFFFFFFFu;  // buildNode(kmer_left.substr(d2,k))
-    uint32_t* chc = ch + csel * 2u * F;           // closure states of the level above (emit index, parent position)
-    uint32_t* chn = ch + (csel ^ 1u) * 2u * F;    // the same for this level, built here
+    uint32_t* chc = ch + csel * 3u * F;           // closure states of the level above (emit index, parent position, more)
+    uint32_t* chn = ch + (csel ^ 1u) * 3u * F;    // the same for this level, built here
     uint32_t nin_total = 0, nlink = 0;
     for (uint32_t c0 = 0; c0 < w; c0 += 64u) {
       const uint32_t c = c0 + (uint32_t)lane;
@@ -1078,9 +1085,9 @@ __device__ __forceinline__ void extract_lds_body(const FillOut fo, const GapDev*
       const bool expand = in && !(cf & G2S_SUB_SOURCE) && d2 > 0 && pp != G2S_DEV_INVALID;
       const uint64_t lm = __ballot(expand);
       if (in) {
-        SubState st;
-        st.node = cn; st.depth = (uint32_t)d2; st.cnt = wec[wbase + c]; st.flags = cf;
-        st.pred[0] = st.pred[1] = st.pred[2] = st.pred[3] = -1;
+        SubRec st;
+        st.node = cn; st.cnt = wec[wbase + c]; st.meta = (uint32_t)d2 | (cf << G2S_SUB_META_FLAG_SHIFT);
+        st.pred = -1;
         sub[slot] = st;
         em[c] = slot;
       }
@@ -1089,6 +1096,7 @@ __device__ __forceinline__ void extract_lds_body(const FillOut fo, const GapDev*
         const uint32_t at = nlink + (uint32_t)__popcll(lm & lanes_below(lane));
         chn[at] = slot;
         chn[F + at] = pp;
+        chn[2u * F + at] = nx ? pc[c] : 0u;
       }
       nin_total += nin;
       nlink += (uint32_t)__popcll(lm);
@@ -1096,8 +1104,13 @@ __device__ __forceinline__ void extract_lds_body(const FillOut fo, const GapDev*
     if (over) break;
     lds_sync();
     // ---- links from the level above to this level ----------------------------------------
-    for (uint32_t j = (uint32_t)lane; j < nch; j += 64u) sub[chc[j]].pred[0] = (int32_t)em[chc[F + j]];
-    for (uint32_t j = (uint32_t)lane; j < nxc; j += 64u) sub[xc[j]].pred[xc[2u * LDS_XC + j]] = (int32_t)em[xc[LDS_XC + j]];
+    // (a state with a side-list entry always has a first parent: its plk link is in chc too)
+    for (uint32_t j = (uint32_t)lane; j < nch; j += 64u) {
+      const uint32_t more = chc[2u * F + j] ? (uint32_t)G2S_SUB_MORE : 0u;
+      sub[chc[j]].pred = (int32_t)(em[chc[F + j]] | more);
+    }
+    for (uint32_t j = (uint32_t)lane; j < nxc; j += 64u) xo[nxo + j] = ((uint64_t)xc[j] << 32) | em[xc[LDS_XC + j]];
+    nxo += nxc;
     lds_sync();
     nch = nlink;
     csel ^= 1u;
@@ -1122,7 +1135,6 @@ __device__ __forceinline__ void extract_lds_body(const FillOut fo, const GapDev*
         const uint32_t at = (uint32_t)__popcll(m & lanes_below(lane));
         xc[at] = em[c];
         xc[LDS_XC + at] = pp;
-        xc[2u * LDS_XC + at] = atomicAdd(&pc[c], 1u);  // slots 1..3 in arrival order
       }
       nxc = (uint32_t)__popcll(m);
       xpos = xfirst;
@@ -1142,14 +1154,16 @@ __device__ __forceinline__ void extract_lds_body(const FillOut fo, const GapDev*
     publish();
     return;
   }
-  // ---- pack: reserve exactly n_sub records in the dense output --------------------------
-  // (the fence makes this wave's own stores, including the 4-byte link patches, visible to
-  // its loads: they were written through to L2, the L1 copies are dropped)
+  // ---- pack: reserve exactly what the closure takes in the host buffer: n_sub records, then
+  // the side list (two 8-byte entries per record slot).  The fence makes this wave's own
+  // stores, including the 4-byte link patches, visible to its loads: they were written
+  // through to L2, the L1 copies are dropped.
   __threadfence();
+  const uint32_t nres = nsub + (nxo + 1u) / 2u;
   unsigned long long base = 0;
-  if (lane == 0) base = atomicAdd(out_counter, (unsigned long long)nsub);
+  if (lane == 0) base = atomicAdd(out_counter, (unsigned long long)nres);
   base = __shfl(base, 0);
-  if (base + nsub > out_cap) {  // the host buffer is full: the gap is run again with the next pass
+  if (base + nres > out_cap) {  // the host buffer is full: the gap is run again with the next pass
     if (lane == 0) go->flags = gflags | lflags | G2S_DEV_OVERFLOW_B | G2S_DEV_WHY_LOG;
     __threadfence();
     publish();
@@ -1158,24 +1172,26 @@ __device__ __forceinline__ void extract_lds_body(const FillOut fo, const GapDev*
   {
     const uint4* src = (const uint4*)sub;
     uint4* dst = (uint4*)(sub_out + base);
-    const uint32_t nq = nsub * 2u;  // 16-byte halves of the 32-byte records
-    for (uint32_t i0 = 0; i0 < nq; i0 += 256u) {
+    for (uint32_t i0 = 0; i0 < nsub; i0 += 256u) {
       uint4 v[4];
 #pragma unroll
       for (uint32_t q = 0; q < 4; q++) {  // four independent loads in flight per lane
         const uint32_t i = i0 + q * 64u + (uint32_t)lane;
-        if (i < nq) v[q] = src[i];
+        if (i < nsub) v[q] = src[i];
       }
 #pragma unroll
       for (uint32_t q = 0; q < 4; q++) {
         const uint32_t i = i0 + q * 64u + (uint32_t)lane;
-        if (i < nq) dst[i] = v[q];
+        if (i < nsub) dst[i] = v[q];
       }
     }
+    uint64_t* xdst = (uint64_t*)(sub_out + base + nsub);
+    for (uint32_t i = (uint32_t)lane; i < nxo; i += 64u) xdst[i] = xo[i];
   }
   if (lane == 0) {
-    go->flags = gflags | lflags | G2S_DEV_PRED_UNORDERED;
+    go->flags = gflags | lflags;
     go->n_sub = nsub;
+    go->n_xp = nxo;
     go->sub_off = base;
     go->x_sub = xcount;
     go->stat[6] = st_slowD | (st_bulkD << 16);
@@ -1192,15 +1208,15 @@ __device__ __forceinline__ void extract_lds_body(const FillOut fo, const GapDev*
 #define G2S_FUSED_PARAMS                                                                                              \
   const uint32_t *__restrict__ succ, const uint64_t *__restrict__ ustart, const GapDev *__restrict__ gaps,            \
       const uint32_t *__restrict__ gap_ids, const uint32_t *__restrict__ flank_nodes, uint64_t *log_all,              \
-      uint32_t *lvl_all, uint32_t *plk_all, uint64_t *xl_all, SubState *sub_scratch, SubState *sub_out,               \
+      uint32_t *lvl_all, uint32_t *plk_all, uint64_t *xl_all, uint64_t *xo_all, SubRec *sub_scratch, SubRec *sub_out, \
       unsigned long long out_cap, unsigned long long *out_counter, GapOut *outs, GapOut *outs_host,                   \
       uint32_t *done_list, int skip_confident, uint32_t num_oriented
 __global__ __launch_bounds__(64) void g2s_fill_lds(G2S_FUSED_PARAMS, uint32_t fcap) {
   const FillOut fo = fill_lds_body<false>(succ, ustart, gaps, gap_ids, flank_nodes, log_all, lvl_all, plk_all, xl_all, outs,
                                           num_oriented, nullptr, fcap);
   __threadfence();  // the log, level offsets and links of this gap were written through: read them back from L2
-  extract_lds_body(fo, gaps, gap_ids, flank_nodes, log_all, lvl_all, plk_all, xl_all, sub_scratch, sub_out, out_cap,
-                   out_counter, outs, outs_host, done_list, skip_confident, fcap);
+  extract_lds_body(fo, gaps, gap_ids, flank_nodes, log_all, lvl_all, plk_all, xl_all, xo_all, sub_scratch, sub_out,
+                   out_cap, out_counter, outs, outs_host, done_list, skip_confident, fcap);
 }
 // Same kernel with the right set in HBM: for gaps whose right set outgrows the LDS (deep
 // DP, -dist-error in the thousands); everything else of the gap stays in LDS.
@@ -1208,8 +1224,8 @@ __global__ __launch_bounds__(64) void g2s_fill_lds_rsg(G2S_FUSED_PARAMS, uint32_
   const FillOut fo = fill_lds_body<true>(succ, ustart, gaps, gap_ids, flank_nodes, log_all, lvl_all, plk_all, xl_all, outs,
                                          num_oriented, rs_global, fcap);
   __threadfence();
-  extract_lds_body(fo, gaps, gap_ids, flank_nodes, log_all, lvl_all, plk_all, xl_all, sub_scratch, sub_out, out_cap,
-                   out_counter, outs, outs_host, done_list, skip_confident, fcap);
+  extract_lds_body(fo, gaps, gap_ids, flank_nodes, log_all, lvl_all, plk_all, xl_all, xo_all, sub_scratch, sub_out,
+                   out_cap, out_counter, outs, outs_host, done_list, skip_confident, fcap);
 }
 
 // ---------------------------------------------------------------------------
@@ -1222,7 +1238,7 @@ size_t fill_lds_bytes(uint32_t rs_cap, uint32_t fcap) {
 }
 size_t extract_lds_bytes(uint32_t fcap) {
   const uint32_t w = fcap > 256u ? fcap : 256u;
-  return 4u * ((w + 1) + 3 * w + 2 * fcap + fcap + 4 * fcap + fcap + 3 * LDS_XC + 4);
+  return 4u * ((w + 1) + 3 * w + 2 * fcap + fcap + 6 * fcap + fcap + 3 * LDS_XC + 4);
 }
 uint32_t fill_lds_frontier_cap() { return LDS_F; }  // pass 0; later passes use LDS_F_WIDE
 uint32_t fill_lds_max_fuz() { return LDS_TG - 1; }
@@ -1230,7 +1246,8 @@ uint32_t fill_lds_max_fuz() { return LDS_TG - 1; }
 hipError_t launch_fill_lds(hipStream_t st, uint32_t ngaps, uint32_t rs_cap_max, uint32_t num_oriented,
                            const uint32_t* succ, const uint64_t* ustart, const GapDev* gaps, const uint32_t* gap_ids,
                            const uint32_t* flank_nodes, uint64_t* log_all, uint32_t* lvl_all, uint32_t* plk_all,
-                           uint64_t* xl_all, SubState* sub_scratch, SubState* sub_out, unsigned long long out_cap,
+                           uint64_t* xl_all, uint64_t* xo_all, SubRec* sub_scratch, SubRec* sub_out,
+                           unsigned long long out_cap,
                            unsigned long long* out_counter, GapOut* outs, GapOut* outs_host, uint32_t* done_list,
                            int skip_confident, uint32_t* rs_global, uint32_t fcap) {
   if (ngaps == 0) return hipSuccess;
@@ -1239,14 +1256,15 @@ hipError_t launch_fill_lds(hipStream_t st, uint32_t ngaps, uint32_t rs_cap_max, 
     hipError_t e = hipFuncSetAttribute((const void*)g2s_fill_lds_rsg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(g2s_fill_lds_rsg, dim3(ngaps), dim3(64), bytes, st, succ, ustart, gaps, gap_ids, flank_nodes,
-                       log_all, lvl_all, plk_all, xl_all, sub_scratch, sub_out, out_cap, out_counter, outs, outs_host,
-                       done_list, skip_confident, num_oriented, rs_global, fcap);
+                       log_all, lvl_all, plk_all, xl_all, xo_all, sub_scratch, sub_out, out_cap, out_counter, outs,
+                       outs_host, done_list, skip_confident, num_oriented, rs_global, fcap);
     return hipGetLastError();
   }
   hipError_t e = hipFuncSetAttribute((const void*)g2s_fill_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(g2s_fill_lds, dim3(ngaps), dim3(64), bytes, st, succ, ustart, gaps, gap_ids, flank_nodes, log_all,
-                     lvl_all, plk_all, xl_all, sub_scratch, sub_out, out_cap, out_counter, outs, outs_host, done_list,
+                     lvl_all, plk_all, xl_all, xo_all, sub_scratch, sub_out, out_cap, out_counter, outs, outs_host,
+                     done_list,
                      skip_confident, num_oriented, fcap);
   return hipGetLastError();
 }

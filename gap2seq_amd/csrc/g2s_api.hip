@@ -249,6 +249,8 @@ namespace {
 struct TierData {  // what came back from one launch group (pinned buffers live in the session)
   PinBuf outs, subs;
   PinBuf done;  // LDS tier: gap indices in completion order, written by the kernel as gaps finish
+  std::vector<SubRec> conv;        // HBM tier: closures converted to the host's 16-byte records
+  std::vector<uint64_t> conv_xp;
   std::vector<uint32_t> gap_ids;
 };
 }  // namespace
@@ -410,7 +412,7 @@ struct g2s_session {
   bool no_lds_tier = false;  // G2S_NO_LDS_TIER=1: force the general HBM tier (tests, A/B timing)
   size_t mem_budget = 0;  // bytes of HBM this session may use for work areas
   DevBuf d_gaps, d_ids, d_flank, d_outs, d_rs, d_rlog, d_keys, d_cnt, d_mark, d_slog, d_subscr, d_subout, d_counter;
-  DevBuf d_log, d_lvl, d_plk, d_xl;  // LDS tier: level-ordered state log, level offsets, parent links
+  DevBuf d_log, d_lvl, d_plk, d_xl, d_xo;  // LDS tier: state log, level offsets, parent links, closure side lists
   std::vector<void*> tier_pool;  // recycled TierData (pinned host buffers)
   size_t tier_cursor = 0;        // next free slot of tier_pool in the current run
   const void* flank_owner = nullptr;  // batch whose flank nodes d_flank holds
@@ -454,7 +456,7 @@ extern "C" void g2s_session_destroy(g2s_session* s) {
   (void)hipSetDevice(s->device);
   DevBuf* bufs[] = {&s->d_gaps, &s->d_ids, &s->d_flank, &s->d_outs, &s->d_rs, &s->d_rlog, &s->d_keys,
                     &s->d_cnt, &s->d_mark, &s->d_slog, &s->d_subscr, &s->d_subout, &s->d_counter,
-                    &s->d_log, &s->d_lvl, &s->d_plk, &s->d_xl};
+                    &s->d_log, &s->d_lvl, &s->d_plk, &s->d_xl, &s->d_xo};
   for (DevBuf* b : bufs) b->release();
   delete s->pool;
   for (void* v : s->tier_pool) { TierData* t = (TierData*)v; t->outs.release(); t->subs.release(); t->done.release(); delete t; }
@@ -688,7 +690,7 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
   HIP_TRY(s->d_gaps.ensure(n * sizeof(GapDev)));
   HIP_TRY(s->d_ids.ensure(std::max<size_t>(ids.size() * 4, 16)));
   HIP_TRY(s->d_outs.ensure(n * sizeof(GapOut)));
-  HIP_TRY(s->d_subscr.ensure(slog_total * sizeof(SubState)));
+  HIP_TRY(s->d_subscr.ensure(slog_total * (lds ? sizeof(SubRec) : sizeof(SubState))));
   if (!lds) HIP_TRY(s->d_subout.ensure(slog_total * sizeof(SubState)));
   HIP_TRY(s->d_counter.ensure(16));
   hipStream_t st = s->stream;
@@ -701,6 +703,7 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
     HIP_TRY(s->d_lvl.ensure(lvl_total * 4));
     HIP_TRY(s->d_plk.ensure(slog_total * 4));
     HIP_TRY(s->d_xl.ensure(std::max<uint64_t>(xl_total * 8, 16)));
+    HIP_TRY(s->d_xo.ensure(std::max<uint64_t>(xl_total * 8, 16)));
     if (rs_in_hbm) {
       HIP_TRY(s->d_rs.ensure(rs_total * 4));
       HIP_TRY(hipMemsetAsync(s->d_rs.p, 0xFF, rs_total * 4, st));
@@ -711,7 +714,7 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
     // results go straight to pinned host memory (closures packed by an atomic cursor)
     HIP_TRY(td->outs.ensure(n * sizeof(GapOut)));
     out_states += out_max;
-    HIP_TRY(td->subs.ensure(std::max<uint64_t>(out_states * sizeof(SubState), 16)));
+    HIP_TRY(td->subs.ensure(std::max<uint64_t>(out_states * sizeof(SubRec), 16)));
     HIP_TRY(td->done.ensure(std::max<size_t>(ids.size() * 4, 16)));
     memset(td->done.p, 0xFF, ids.size() * 4);
     void *d_outs_host = nullptr, *d_subs_host = nullptr, *d_done_host = nullptr;
@@ -721,7 +724,8 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
     HIP_TRY(launch_fill_lds(st, (uint32_t)ids.size(), lds_cap_max, num_oriented, dg.succ, dg.ustart,
                             (const GapDev*)s->d_gaps.p, (const uint32_t*)s->d_ids.p, (const uint32_t*)s->d_flank.p,
                             (uint64_t*)s->d_log.p, (uint32_t*)s->d_lvl.p, (uint32_t*)s->d_plk.p, (uint64_t*)s->d_xl.p,
-                            (SubState*)s->d_subscr.p, (SubState*)d_subs_host, (unsigned long long)out_states,
+                            (uint64_t*)s->d_xo.p, (SubRec*)s->d_subscr.p, (SubRec*)d_subs_host,
+                            (unsigned long long)out_states,
                             (unsigned long long*)s->d_counter.p, (GapOut*)s->d_outs.p, (GapOut*)d_outs_host,
                             (uint32_t*)d_done_host, s->params.skip_confident ? 1 : 0,
                             rs_in_hbm ? (uint32_t*)s->d_rs.p : nullptr, fcap));
@@ -857,7 +861,7 @@ void analyze_gap(g2s_batch* b, size_t i, const FillParams& fp, g2s_result* r) {
   if (b->mem_exceeded[i]) { gi.kind = 2; r->count = -1; r->flags |= G2S_GAP_MEM_EXCEEDED; return; }
   const SubView& v = b->views[i];
   SubPrep& pp = b->prep[i];
-  if (v.out->flags & G2S_DEV_PRED_UNORDERED) sub_order_preds(*b->s->graph->g, const_cast<SubState*>(v.st), v.n);
+  if (v.n_xp > 1) std::sort(const_cast<uint64_t*>(v.xp), const_cast<uint64_t*>(v.xp) + v.n_xp);  // by state (the kernel appends per level)
   sub_analyze(fp, j, v, &pp);
   r->phaseC_count = v.out->c_count;
   r->n_lengths = v.out->n_len;
@@ -918,8 +922,10 @@ int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
       if (go.flags & (G2S_DEV_OVERFLOW_A | G2S_DEV_OVERFLOW_B)) continue;  // runs again in a later pass
       SubView& v = views[i];
       v.out = &go;
-      v.st = (const SubState*)td_live->subs.p + go.sub_off;
+      v.st = (const SubRec*)td_live->subs.p + go.sub_off;
       v.n = go.n_sub;
+      v.xp = (const uint64_t*)(v.st + go.n_sub);
+      v.n_xp = go.n_xp;
       analyzed[i] = 1;
       fresh.push_back(i);
     }
@@ -997,8 +1003,10 @@ int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
       }
       SubView& v = views[i];
       v.out = &go;
-      v.st = (const SubState*)td->subs.p + go.sub_off;
+      v.st = (const SubRec*)td->subs.p + go.sub_off;
       v.n = go.n_sub;
+      v.xp = (const uint64_t*)(v.st + go.n_sub);
+      v.n_xp = go.n_xp;
       b->timing.xA += go.x_right; b->timing.sA += go.n_right;
       b->timing.xB += go.x_left; b->timing.sB += go.n_states;
       b->timing.xD += go.x_sub; b->timing.sD += go.n_sub;
@@ -1038,6 +1046,24 @@ int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
       int rc = run_tier(b, group, scale, max_states, td, false);
       if (rc != G2S_OK) return rc;
       const GapOut* outs = (const GapOut*)td->outs.p;
+      // this tier's kernel emits 32-byte records with the parents by GATB slot: convert them
+      // to the host's 16-byte records + side lists (sizes first: the views point into the vectors)
+      {
+        size_t nrec = 0, nxp = 0;
+        for (uint32_t i : group) {
+          const GapOut& go = outs[i];
+          if (go.flags & (G2S_DEV_OVERFLOW_A | G2S_DEV_OVERFLOW_B)) continue;
+          const SubState* in = (const SubState*)td->subs.p + go.sub_off;
+          nrec += go.n_sub;
+          for (uint32_t q = 0; q < go.n_sub; q++) {
+            int np = 0;
+            for (int nt = 0; nt < 4; nt++) np += in[q].pred[nt] >= 0;
+            if (np > 1) nxp += (size_t)np - 1;
+          }
+        }
+        td->conv.clear(); td->conv.reserve(nrec);
+        td->conv_xp.clear(); td->conv_xp.reserve(nxp);
+      }
       for (size_t x = 0; x < group.size(); x++) {
         const uint32_t i = group[x];
         const GapOut& go = outs[i];
@@ -1052,8 +1078,14 @@ int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
         }
         SubView& v = views[i];
         v.out = &go;
-        v.st = (const SubState*)td->subs.p + go.sub_off;
-        v.n = go.n_sub;
+        {
+          const size_t r0 = td->conv.size(), x0 = td->conv_xp.size();
+          sub_convert((const SubState*)td->subs.p + go.sub_off, go.n_sub, &td->conv, &td->conv_xp);
+          v.st = td->conv.data() + r0;
+          v.n = go.n_sub;
+          v.xp = td->conv_xp.data() + x0;
+          v.n_xp = (uint32_t)(td->conv_xp.size() - x0);
+        }
         b->timing.xA += go.x_right; b->timing.sA += go.n_right;
         b->timing.xB += go.x_left; b->timing.sB += go.n_states;
         b->timing.xD += go.x_sub; b->timing.sD += go.n_sub;
@@ -1410,8 +1442,11 @@ extern "C" int g2s_test_post_gap(const g2s_graph* gh, const g2s_params* p, const
   std::vector<SubState> closure;
   uint32_t q7 = 0;
   host_closure(g, fp, j, t, go, &closure, &q7);
+  std::vector<SubRec> recs;
+  std::vector<uint64_t> xps;
+  sub_convert(closure.data(), (uint32_t)closure.size(), &recs, &xps);
   SubView v;
-  v.out = &go; v.st = closure.data(); v.n = (uint32_t)closure.size();
+  v.out = &go; v.st = recs.data(); v.n = (uint32_t)recs.size(); v.xp = xps.data(); v.n_xp = (uint32_t)xps.size();
   SubPrep prep;
   sub_analyze(fp, j, v, &prep);
   memset(res, 0, sizeof *res);

@@ -87,14 +87,20 @@ int strong_components(int nv, const std::vector<int>& off, const std::vector<int
 
 }  // namespace
 
-void sub_order_preds(const Graph& g, SubState* st, uint32_t n) {
+void sub_convert(const SubState* in, uint32_t n, std::vector<SubRec>* recs, std::vector<uint64_t>* xp) {
   for (uint32_t i = 0; i < n; i++) {
-    SubState& s = st[i];
-    if (s.pred[1] < 0 && s.pred[2] < 0 && s.pred[3] < 0) continue;  // at most one parent: any slot will do
-    int32_t in[4] = {s.pred[0], s.pred[1], s.pred[2], s.pred[3]};
-    s.pred[0] = s.pred[1] = s.pred[2] = s.pred[3] = -1;
-    for (int q = 0; q < 4; q++)
-      if (in[q] >= 0) s.pred[g.lastnt[st[(size_t)in[q]].node ^ 1u]] = in[q];
+    const SubState& s = in[i];
+    SubRec r;
+    r.node = s.node;
+    r.cnt = s.cnt;
+    r.meta = (s.depth & G2S_SUB_META_DEPTH_MASK) | (s.flags << G2S_SUB_META_FLAG_SHIFT);
+    r.pred = -1;
+    for (int nt = 0; nt < 4; nt++) {
+      if (s.pred[nt] < 0) continue;
+      if (r.pred < 0) r.pred = s.pred[nt];
+      else { r.pred |= G2S_SUB_MORE; xp->push_back(((uint64_t)i << 32) | (uint32_t)s.pred[nt]); }
+    }
+    recs->push_back(r);
   }
 }
 
@@ -104,8 +110,9 @@ void sub_analyze(const FillParams& p, const GapJob& job, const SubView& v, SubPr
   out->phase_d = go.c_count > 0 && go.n_len > 0;  // :1169 (fill is never NULL here)
   if (!out->phase_d) return;
   const uint32_t n = v.n;
-  const SubState* st = v.st;
+  const SubRec* st = v.st;
   (void)job;
+  auto FL = [&](uint32_t i) -> uint32_t { return sub_flags(st[i]); };
 
   // traceback starts and, per start, the depth at which every traceback stops
   // (states are stored depth-descending, so a reverse sweep sees predecessors first)
@@ -118,23 +125,23 @@ void sub_analyze(const FillParams& p, const GapJob& job, const SubView& v, SubPr
     lo.assign((size_t)n, -2);  // -2: not on a traceback closure
     hi.assign((size_t)n, -2);
     for (int64_t i = (int64_t)n - 1; i >= 0; i--) {
-      const SubState& s = st[i];
-      if (!(s.flags & G2S_SUB_IN_T)) continue;
-      if (s.flags & G2S_SUB_SOURCE) { lo[(size_t)i] = hi[(size_t)i] = (int)s.depth; continue; }  // :1455-1462
-      int l = 1 << 30, h = -1, np = 0;
-      for (int nt = 0; nt < 4; nt++) {
-        const int32_t q = s.pred[nt];
-        if (q < 0) continue;
-        np++;
+      const uint32_t sf = FL((uint32_t)i);
+      if (!(sf & G2S_SUB_IN_T)) continue;
+      if (sf & G2S_SUB_SOURCE) { lo[(size_t)i] = hi[(size_t)i] = (int)sub_depth(st[i]); continue; }  // :1455-1462
+      int l = 1 << 30, h = -1;
+      int32_t pr[4];
+      const int np = sub_preds(v, (uint32_t)i, pr);
+      for (int x = 0; x < np; x++) {
+        const int32_t q = pr[x];
         if (lo[(size_t)q] < 0) { l = -1; h = 1 << 30; } else { l = std::min(l, lo[(size_t)q]); h = std::max(h, hi[(size_t)q]); }
       }
       if (np == 0) { lo[(size_t)i] = -1; hi[(size_t)i] = 1 << 30; }  // walk ends here without a stop: not fixed
       else { lo[(size_t)i] = l; hi[(size_t)i] = h; }
     }
     for (uint32_t i = 0; i < n; i++) {
-      if (!(st[i].flags & G2S_SUB_START_T)) continue;
+      if (!(FL(i) & G2S_SUB_START_T)) continue;
       for (int j = 0; j < go.n_len && j < 2; j++) {
-        if ((int)st[i].depth == go.len[j] && out->start_idx[j] < 0) {
+        if ((int)sub_depth(st[i]) == go.len[j] && out->start_idx[j] < 0) {
           out->start_idx[j] = (int)i;
           out->stop_depth[j] = (lo[i] >= 0 && lo[i] == hi[i]) ? lo[i] : -1;
         }
@@ -149,7 +156,7 @@ void sub_analyze(const FillParams& p, const GapJob& job, const SubView& v, SubPr
   vid.assign((size_t)n, -1);
   uint32_t n_s = 0;
   for (uint32_t i = 0; i < n; i++)
-    if (st[i].flags & G2S_SUB_IN_S) { vid[i] = vm.get_or_add(st[i].node >> 1, &nverts); n_s++; }
+    if (FL(i) & G2S_SUB_IN_S) { vid[i] = vm.get_or_add(st[i].node >> 1, &nverts); n_s++; }
 
   if ((uint32_t)nverts == n_s + 2) {
     // ---- fast path: every k-mer occurs at exactly one depth of the S closure.  An edge goes
@@ -162,12 +169,14 @@ void sub_analyze(const FillParams& p, const GapJob& job, const SubView& v, SubPr
     uint64_t edges = 0;
     int src_out = 0, sink_in = 0;
     for (uint32_t i = 0; i < n; i++) {
-      const SubState& s = st[i];
-      if (!(s.flags & G2S_SUB_IN_S)) continue;
-      if (s.flags & G2S_SUB_SINK) { sink_in++; edges++; count = sat_add(count, (int)s.cnt); }
-      if (s.flags & G2S_SUB_SOURCE) { src_out++; edges++; continue; }
-      for (int nt = 0; nt < 4; nt++)
-        if (s.pred[nt] >= 0) { outdeg[(size_t)s.pred[nt]]++; edges++; }
+      const SubRec& s = st[i];
+      const uint32_t sf = FL(i);
+      if (!(sf & G2S_SUB_IN_S)) continue;
+      if (sf & G2S_SUB_SINK) { sink_in++; edges++; count = sat_add(count, (int)s.cnt); }
+      if (sf & G2S_SUB_SOURCE) { src_out++; edges++; continue; }
+      int32_t pr[4];
+      const int np = sub_preds(v, i, pr);
+      for (int x = 0; x < np; x++) { outdeg[(size_t)pr[x]]++; edges++; }
     }
     if (p.all_paths) out->count = count;
     out->sub[0] = (uint64_t)nverts;
@@ -181,12 +190,13 @@ void sub_analyze(const FillParams& p, const GapJob& job, const SubView& v, SubPr
     // source (vertex 1) comes first in topological order: in-degree 0
     if (src_out >= 1) { if (src_out > 1) bc += src_out - 1; }
     for (int64_t i = (int64_t)n - 1; i >= 0; i--) {
-      const SubState& s = st[i];
-      if (!(s.flags & G2S_SUB_IN_S)) continue;
+      const uint32_t sf = FL((uint32_t)i);
+      if (!(sf & G2S_SUB_IN_S)) continue;
       int din = 0;
-      if (s.flags & G2S_SUB_SOURCE) din = 1;
-      else for (int nt = 0; nt < 4; nt++) din += s.pred[nt] >= 0;
-      const int dout = outdeg[(size_t)i] + ((s.flags & G2S_SUB_SINK) ? 1 : 0);
+      int32_t pr[4];
+      if (sf & G2S_SUB_SOURCE) din = 1;
+      else din = sub_preds(v, (uint32_t)i, pr);
+      const int dout = outdeg[(size_t)i] + ((sf & G2S_SUB_SINK) ? 1 : 0);
       if (din >= 1 || dout >= 1) {
         if (din > 1) bc -= din - 1;
         out->safe[(size_t)i] = bc == 1;
@@ -197,12 +207,12 @@ void sub_analyze(const FillParams& p, const GapJob& job, const SubView& v, SubPr
     bool sink_safe = false;
     if (sink_in >= 1) { if (sink_in > 1) bc -= sink_in - 1; sink_safe = bc == 1; }
     for (uint32_t i = 0; i < n; i++) {  // traceback states outside the subgraph (Q5)
-      if (!(st[i].flags & G2S_SUB_IN_T) || (st[i].flags & G2S_SUB_IN_S)) continue;
+      if (!(FL(i) & G2S_SUB_IN_T) || (FL(i) & G2S_SUB_IN_S)) continue;
       const int vtx = vm.find(st[i].node >> 1);
       if (vtx < 0) { out->safe[i] = sink_safe; continue; }
       // its k-mer is in the subgraph at another depth: that vertex's value
       for (uint32_t q = 0; q < n; q++)
-        if ((st[q].flags & G2S_SUB_IN_S) && vid[q] == vtx) { out->safe[i] = out->safe[q]; break; }
+        if ((FL(q) & G2S_SUB_IN_S) && vid[q] == vtx) { out->safe[i] = out->safe[q]; break; }
     }
     return;
   }
@@ -212,12 +222,14 @@ void sub_analyze(const FillParams& p, const GapJob& job, const SubView& v, SubPr
   int count = 0;
   auto edge = [&](int a, int b) { el.push_back(((uint64_t)(uint32_t)a << 32) | (uint32_t)b); };
   for (uint32_t i = 0; i < n; i++) {
-    const SubState& s = st[i];
-    if (!(s.flags & G2S_SUB_IN_S)) continue;
-    if (s.flags & G2S_SUB_SINK) { edge(vid[i], 0); count = sat_add(count, (int)s.cnt); }  // :1216-1226 / :1248-1256
-    if (s.flags & G2S_SUB_SOURCE) { edge(1, vid[i]); continue; }                           // :1303-1305
-    for (int nt = 0; nt < 4; nt++)
-      if (s.pred[nt] >= 0) edge(vid[(size_t)s.pred[nt]], vid[i]);                          // :1283-1297
+    const SubRec& s = st[i];
+    const uint32_t sf = FL(i);
+    if (!(sf & G2S_SUB_IN_S)) continue;
+    if (sf & G2S_SUB_SINK) { edge(vid[i], 0); count = sat_add(count, (int)s.cnt); }  // :1216-1226 / :1248-1256
+    if (sf & G2S_SUB_SOURCE) { edge(1, vid[i]); continue; }                          // :1303-1305
+    int32_t pr[4];
+    const int np = sub_preds(v, i, pr);
+    for (int x = 0; x < np; x++) edge(vid[(size_t)pr[x]], vid[i]);                     // :1283-1297
   }
   if (p.all_paths) out->count = count;  // recount (:1189-1191); -best-only keeps the phase C count
   std::sort(el.begin(), el.end());
@@ -294,7 +306,7 @@ void sub_analyze(const FillParams& p, const GapJob& job, const SubView& v, SubPr
   out->safe.assign((size_t)n, 0);
   const bool sink_safe = (csize[(size_t)comp[0]] == 1) && fbranch[0] == 1;
   for (uint32_t i = 0; i < n; i++) {
-    if (!(st[i].flags & G2S_SUB_IN_T)) continue;
+    if (!(FL(i) & G2S_SUB_IN_T)) continue;
     int vtx = vid[i];
     if (vtx < 0) vtx = vm.find(st[i].node >> 1);
     if (vtx < 0) { out->safe[i] = sink_safe; continue; }
@@ -316,8 +328,8 @@ void sub_traceback(const Graph& g, const FillParams& p, const GapJob& job, const
   buf[d2] = '\0';
   res->count = prep.count;
   while (d2 >= 0 && i >= 0) {
-    const SubState& s = v.st[i];
-    if (s.flags & G2S_SUB_SOURCE) {  // :1455-1462 (depth <= lmf and k-mer equal to the flank k-mer)
+    const SubRec& s = v.st[i];
+    if (sub_flags(s) & G2S_SUB_SOURCE) {  // :1455-1462 (depth <= lmf and k-mer equal to the flank k-mer)
       res->left_fuz = lmf - d2;
       break;
     }
@@ -325,9 +337,14 @@ void sub_traceback(const Graph& g, const FillParams& p, const GapJob& job, const
       if (p.skip_confident || prep.safe[(size_t)i]) last_solid = d2;  // :1466-1468
       const char c = g.last_char(s.node);
       buf[d2 - 1] = (d2 > last_solid - k) ? (char)toupper((unsigned char)c) : (char)tolower((unsigned char)c);
-      int back[4], nb = 0;
-      for (int nt = 0; nt < 4; nt++)  // GATB predecessor order
-        if (s.pred[nt] >= 0) back[nb++] = s.pred[nt];
+      int32_t back[4];
+      const int nb = sub_preds(v, (uint32_t)i, back);
+      if (nb > 1) {  // GATB predecessor order: predecessors(v)[slot] is the parent p whose p^1 ends with base `slot`
+        int32_t by_slot[4] = {-1, -1, -1, -1};
+        for (int x = 0; x < nb; x++) by_slot[g.lastnt[v.st[(size_t)back[x]].node ^ 1u]] = back[x];
+        int w = 0;
+        for (int nt = 0; nt < 4; nt++) if (by_slot[nt] >= 0) back[w++] = by_slot[nt];
+      }
       if (nb == 0) {  // :1493-1510
         snprintf(res->backtrace_msg, sizeof res->backtrace_msg, "Unable to backtrace! %d %d %s", d2, go.final_d,
                  g.node_string(job.targets()[go.reached_j]).c_str());

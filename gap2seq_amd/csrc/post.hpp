@@ -42,9 +42,31 @@ struct FillParams {
 // Device results of one gap as seen on the host.
 struct SubView {
   const GapOut* out = nullptr;
-  const SubState* st = nullptr;
+  const SubRec* st = nullptr;
   uint32_t n = 0;
+  const uint64_t* xp = nullptr;  // parents beyond the first: (state << 32 | parent), sorted by state
+  uint32_t n_xp = 0;
 };
+inline uint32_t sub_depth(const SubRec& s) { return s.meta & G2S_SUB_META_DEPTH_MASK; }
+inline uint32_t sub_flags(const SubRec& s) { return s.meta >> G2S_SUB_META_FLAG_SHIFT; }
+// the parents of state i (a set, at most 4); returns how many
+inline int sub_preds(const SubView& v, uint32_t i, int32_t out[4]) {
+  const int32_t p = v.st[i].pred;
+  if (p < 0) return 0;
+  out[0] = p & G2S_SUB_PRED_MASK;
+  int n = 1;
+  if (p & G2S_SUB_MORE) {
+    uint32_t lo = 0, hi = v.n_xp;
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if ((uint32_t)(v.xp[mid] >> 32) < i) lo = mid + 1; else hi = mid;
+    }
+    for (; lo < v.n_xp && (uint32_t)(v.xp[lo] >> 32) == i && n < 4; lo++) out[n++] = (int32_t)(uint32_t)v.xp[lo];
+  }
+  return n;
+}
+// HBM-tier closure (SubState, parents by GATB slot) -> SubRec + side list, appended to the vectors
+void sub_convert(const SubState* in, uint32_t n, std::vector<SubRec>* recs, std::vector<uint64_t>* xp);
 
 struct SubPrep {
   bool phase_d = false;   // count > 0 && pathLengths non-empty (:1169)
@@ -56,11 +78,6 @@ struct SubPrep {
   int stop_depth[2] = {-1, -1}; // depth every traceback from start i stops at, or -1 when it depends on the draws
 };
 
-// Closures from the LDS tier list a state's parents from slot 0 in arrival order
-// (G2S_DEV_PRED_UNORDERED); the traceback draws among them in GATB predecessor order
-// (:1476-1513), so states with several parents are put in order here: the slot of parent p
-// is the base that p^1 ends with (pred(v)[i] = succ(v^1)[i]^1).  In place, idempotent.
-void sub_order_preds(const Graph& g, SubState* st, uint32_t n);
 // SCC / branch rule / stop-depth analysis of one gap; thread safe.
 void sub_analyze(const FillParams& p, const GapJob& job, const SubView& v, SubPrep* out);
 // Number of rand() draws the traceback will consume when pathLengths[pick] is chosen,
