@@ -2,12 +2,17 @@
 #include "dbg.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <atomic>
 #include <cstdio>
 #include <cstring>
 #include <thread>
 
 namespace g2s {
+
+// dbg_gpu.hip
+bool unitig_order_gpu(const std::vector<uint32_t>& succ_r, uint64_t n, int device, std::vector<uint32_t>* rank2id,
+                      std::vector<uint8_t>* flip, uint64_t* n_unitigs, uint32_t* next_id, std::string* why);
 
 namespace {
 
@@ -178,12 +183,16 @@ inline int out_degree(const std::vector<uint32_t>& succ, uint32_t v, uint32_t* o
 
 // New node indices in unitig order: k-mers of one maximal non-branching path are
 // consecutive, in path order.  rank-space tables in, permutation out.
+// With `resume` the k-mers already numbered (by unitig_order_gpu) are kept and the walk
+// numbers the rest from first_id on.
 void unitig_order(const std::vector<uint32_t>& succ, uint64_t n, bool even_k, std::vector<uint32_t>* rank2id,
-                  std::vector<uint8_t>* flip, uint64_t* n_unitigs) {
-  rank2id->assign((size_t)n, kInvalidNode);
-  flip->assign((size_t)n, 0);
-  uint32_t next_id = 0;
-  uint64_t unitigs = 0;
+                  std::vector<uint8_t>* flip, uint64_t* n_unitigs, bool resume = false, uint32_t first_id = 0) {
+  if (!resume) {
+    rank2id->assign((size_t)n, kInvalidNode);
+    flip->assign((size_t)n, 0);
+  }
+  uint32_t next_id = resume ? first_id : 0;
+  uint64_t unitigs = resume ? *n_unitigs : 0;
   // the unique continuation v -> w when the edge is unitig-internal
   auto step = [&](uint32_t v) -> uint32_t {
     uint32_t w = kInvalidNode, back = kInvalidNode;
@@ -249,10 +258,26 @@ void build_ustart(Graph& g) {
 
 template <class KT>
 void finish_graph(Graph& g, int nthreads) {
+  const auto f0 = std::chrono::steady_clock::now();
   build_bucket_index<KT>(g);
   std::vector<uint32_t> succ_r, pred_r;
   build_tables_rank<KT>(g, nthreads, &succ_r, &pred_r);
-  unitig_order(succ_r, g.n, (g.k % 2) == 0, &g.rank2id, &g.flip, &g.n_unitigs);
+  const auto f1 = std::chrono::steady_clock::now();
+  // numbering along unitigs: list ranking on the GPU when there is one (odd k), the
+  // sequential walk otherwise and for what the GPU leaves unnumbered (circular unitigs)
+  bool on_gpu = false;
+  if ((g.k % 2) == 1 && !getenv("G2S_HOST_UNITIG")) {
+    uint32_t next_id = 0;
+    std::string why;
+    const int dev = getenv("G2S_DEVICE") ? atoi(getenv("G2S_DEVICE")) : 0;
+    on_gpu = unitig_order_gpu(succ_r, g.n, dev, &g.rank2id, &g.flip, &g.n_unitigs, &next_id, &why);
+    if (on_gpu && next_id < g.n) unitig_order(succ_r, g.n, false, &g.rank2id, &g.flip, &g.n_unitigs, true, next_id);
+    if (!on_gpu && getenv("G2S_DEBUG")) fprintf(stderr, "[g2s]   unitig order on the host (%s)\n", why.c_str());
+  }
+  if (!on_gpu) unitig_order(succ_r, g.n, (g.k % 2) == 0, &g.rank2id, &g.flip, &g.n_unitigs);
+  if (getenv("G2S_DEBUG"))
+    fprintf(stderr, "[g2s]   index + successor table %.3f s, unitig order %.3f s (%s)\n", std::chrono::duration<double>(f1 - f0).count(),
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - f1).count(), on_gpu ? "GPU list ranking" : "host walk");
   g.id2rank.assign((size_t)g.n, 0);
   for (uint64_t r = 0; r < g.n; r++) g.id2rank[g.rank2id[(size_t)r]] = (uint32_t)r;
   // permute tables into id space
@@ -320,9 +345,15 @@ Graph* graph_build(const std::vector<std::pair<const char*, uint64_t>>& seqs, in
   Graph* g = new Graph();
   g->k = k;
   g->wide = k >= 32;
+  const auto t0 = std::chrono::steady_clock::now();
   if (!g->wide) count_solid<uint64_t>(*g, seqs, solid, nthreads); else count_solid<u128>(*g, seqs, solid, nthreads);
+  const auto t1 = std::chrono::steady_clock::now();
   if (g->n >= (1ull << 30)) { if (err) *err = "too many k-mers for 32-bit oriented node ids"; delete g; return nullptr; }
   if (!g->wide) finish_graph<uint64_t>(*g, nthreads); else finish_graph<u128>(*g, nthreads);
+  if (getenv("G2S_DEBUG"))
+    fprintf(stderr, "[g2s] graph build: %llu k-mers; solid k-mer set %.3f s, tables + unitig order %.3f s (%d threads)\n",
+            (unsigned long long)g->n, std::chrono::duration<double>(t1 - t0).count(),
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count(), nthreads);
   return g;
 }
 

@@ -401,6 +401,49 @@ def test_session_team_drives_execute_scaffolds(product, oracle):
         og.free()
 
 
+def test_gpu_unitig_numbering_equals_host_walk(product, monkeypatch):
+    """The graph build numbers k-mers along unitigs by list ranking on the GPU (dbg_gpu.hip);
+    G2S_HOST_UNITIG=1 keeps the sequential host walk.  Same unitigs, same adjacency (compared
+    through k-mer strings, node ids differ), same fills.  V3 genome + a circular sequence
+    (a unitig without a head, which the GPU leaves to the host walk)."""
+    reads = product.G2S.synth_genome(200000, 3, 20240101)
+    seqs = [ln for ln in reads.splitlines() if not ln.startswith(">")]
+    import random
+    rr = random.Random(11)
+    ring = "".join(rr.choice("ACGT") for _ in range(400))  # not in the genome: an isolated circular unitig
+    seqs.append(ring + ring[:40])  # k-1 = 30 bases of overlap close the circle (and 10 more)
+    gl = _parse_scaffolds(product.G2S.synth_gaps(reads, 31, 10, 60, 50, 500, 5))
+    monkeypatch.setenv("G2S_HOST_UNITIG", "1")
+    gh = product.Graph.from_seqs(seqs, 31, 1)
+    monkeypatch.delenv("G2S_HOST_UNITIG")
+    gg = product.Graph.from_seqs(seqs, 31, 1)
+    try:
+        assert (gg.num_kmers, gg.num_unitigs) == (gh.num_kmers, gh.num_unitigs)
+        rnd = random.Random(3)
+        for s in (seqs[0], seqs[1], seqs[-1]):
+            for _ in range(300):
+                p = rnd.randrange(0, len(s) - 31)
+                km = s[p:p + 31]
+                a, b = gg.node(km), gh.node(km)
+                assert a != 0xFFFFFFFF and b != 0xFFFFFFFF
+                assert gg.node_string(a) == km and gh.node_string(b) == km
+                # same neighbours, in the same (GATB) order
+                assert [gg.node_string(x) for x in gg.successors(a)] == [gh.node_string(x) for x in gh.successors(b)]
+                assert [gg.node_string(x) for x in gg.predecessors(a)] == [gh.node_string(x) for x in gh.predecessors(b)]
+        sg = product.Session(gg, 0, d_err=500, randseed=3)
+        sh = product.Session(gh, 0, d_err=500, randseed=3)
+        try:
+            rg = [_result_tuple(r) for r in sg.fill_batch(_gaps(product, gl))]
+            rh = [_result_tuple(r) for r in sh.fill_batch(_gaps(product, gl))]
+            assert rg == rh
+        finally:
+            sg.destroy()
+            sh.destroy()
+    finally:
+        gg.free()
+        gh.free()
+
+
 def test_full_size_round_trip_c3(product):
     """BASELINE config 3 size (3 Mbp DBG, 10 000 gaps, k=31, -fuz 10, -dist-error 500) on
     the repeat-free V0 genome: every gap has exactly one path, so cut -> fill must give
