@@ -6,13 +6,14 @@
 #include <atomic>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <thread>
 
 namespace g2s {
 
 // dbg_gpu.hip
-bool unitig_order_gpu(const std::vector<uint32_t>& succ_r, uint64_t n, int device, std::vector<uint32_t>* rank2id,
-                      std::vector<uint8_t>* flip, uint64_t* n_unitigs, uint32_t* next_id, std::string* why);
+bool graph_finish_gpu(Graph& g, int device, const std::function<void(const std::vector<uint32_t>&, uint32_t)>& host_walk,
+                      std::string* why);
 
 namespace {
 
@@ -260,24 +261,29 @@ template <class KT>
 void finish_graph(Graph& g, int nthreads) {
   const auto f0 = std::chrono::steady_clock::now();
   build_bucket_index<KT>(g);
+  // With a GPU (odd k): successor table by binary search, numbering along unitigs by list
+  // ranking, tables in id space and the unitig-start bitmap all on the device (dbg_gpu.hip);
+  // the host only numbers circular unitigs.  Otherwise, and for even k, the host build below.
+  if (!getenv("G2S_HOST_BUILD")) {
+    std::string why;
+    const int dev = getenv("G2S_DEVICE") ? atoi(getenv("G2S_DEVICE")) : 0;
+    const bool ok = graph_finish_gpu(g, dev, [&](const std::vector<uint32_t>& succ_r, uint32_t first_id) {
+      unitig_order(succ_r, g.n, false, &g.rank2id, &g.flip, &g.n_unitigs, true, first_id);
+    }, &why);
+    if (getenv("G2S_DEBUG"))
+      fprintf(stderr, "[g2s]   tables, unitig order, id space: %.3f s on the %s%s%s\n",
+              std::chrono::duration<double>(std::chrono::steady_clock::now() - f0).count(), ok ? "GPU" : "host next (",
+              ok ? "" : why.c_str(), ok ? "" : ")");
+    if (ok) return;
+  }
   std::vector<uint32_t> succ_r, pred_r;
   build_tables_rank<KT>(g, nthreads, &succ_r, &pred_r);
   const auto f1 = std::chrono::steady_clock::now();
-  // numbering along unitigs: list ranking on the GPU when there is one (odd k), the
-  // sequential walk otherwise and for what the GPU leaves unnumbered (circular unitigs)
-  bool on_gpu = false;
-  if ((g.k % 2) == 1 && !getenv("G2S_HOST_UNITIG")) {
-    uint32_t next_id = 0;
-    std::string why;
-    const int dev = getenv("G2S_DEVICE") ? atoi(getenv("G2S_DEVICE")) : 0;
-    on_gpu = unitig_order_gpu(succ_r, g.n, dev, &g.rank2id, &g.flip, &g.n_unitigs, &next_id, &why);
-    if (on_gpu && next_id < g.n) unitig_order(succ_r, g.n, false, &g.rank2id, &g.flip, &g.n_unitigs, true, next_id);
-    if (!on_gpu && getenv("G2S_DEBUG")) fprintf(stderr, "[g2s]   unitig order on the host (%s)\n", why.c_str());
-  }
-  if (!on_gpu) unitig_order(succ_r, g.n, (g.k % 2) == 0, &g.rank2id, &g.flip, &g.n_unitigs);
+  unitig_order(succ_r, g.n, (g.k % 2) == 0, &g.rank2id, &g.flip, &g.n_unitigs);
   if (getenv("G2S_DEBUG"))
-    fprintf(stderr, "[g2s]   index + successor table %.3f s, unitig order %.3f s (%s)\n", std::chrono::duration<double>(f1 - f0).count(),
-            std::chrono::duration<double>(std::chrono::steady_clock::now() - f1).count(), on_gpu ? "GPU list ranking" : "host walk");
+    fprintf(stderr, "[g2s]   index + successor table %.3f s, unitig order %.3f s (host walk)\n",
+            std::chrono::duration<double>(f1 - f0).count(),
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - f1).count());
   g.id2rank.assign((size_t)g.n, 0);
   for (uint64_t r = 0; r < g.n; r++) g.id2rank[g.rank2id[(size_t)r]] = (uint32_t)r;
   // permute tables into id space

@@ -1,24 +1,32 @@
-// gap2seq_amd/csrc/dbg_gpu.hip — unitig-ordered node numbering on the GPU.
+// gap2seq_amd/csrc/dbg_gpu.hip — the graph build after the solid k-mer set, on the GPU.
 //
-// The graph build (replaces gatb Graph::create, /root/reference/src/Gap2Seq.cpp:193-219)
-// ends with numbering the k-mers along maximal non-branching paths (dbg.cpp:unitig_order).
-// On the host that walk is one dependent, cache-missing load per k-mer: 0.35 s of the 0.49 s
-// build at 3 Mbp, 11.7 s of 16.6 s at 60 Mbp.  Here it is list ranking by pointer jumping:
-//   nxt[v]   the successor of oriented node v when the edge is unitig-internal (same
-//            predicate as the host's `step`), else INVALID;
-//   chains   every unitig is two mirrored chains (v -> w  <=>  w^1 -> v^1); a chain's head is
-//            the node without an internal predecessor;
-//   ranking  pd[v] = (predecessor, distance) is squared log2(longest unitig) times until it
-//            holds (head, distance from head);
-//   ids      of the two mirrored chains the one with the smaller head is kept; kept heads take
-//            consecutive id ranges in head order (exclusive scan of the chain lengths), node
-//            id = base[head] + distance, orientation bit = the node's strand on that chain.
-// Circular unitigs have no head; their nodes come back unnumbered and the host walk numbers
-// them after the rest.  HBM-bound random access: ~10 ms at 3 Mbp.
+// The build (replaces gatb Graph::create, /root/reference/src/Gap2Seq.cpp:193-219) has four
+// steps after the sorted set of solid canonical k-mers exists (dbg.cpp: count_solid):
+//   1. successor table in sorted-rank space: 8 neighbour k-mers per k-mer, each a binary
+//      search inside its prefix bucket (k_succ; 64- and 128-bit k-mers);
+//   2. numbering along maximal non-branching paths.  On the host this is one dependent,
+//      cache-missing load per k-mer (0.35 s of a 0.49 s build at 3 Mbp, 11.7 s of 16.6 s at
+//      60 Mbp); here it is list ranking by pointer jumping:
+//        nxt[v]   the successor of oriented node v when the edge is unitig-internal (same
+//                 predicate as the host's `step`), else INVALID;
+//        chains   every unitig is two mirrored chains (v -> w  <=>  w^1 -> v^1); a chain's
+//                 head is the node without an internal predecessor;
+//        ranking  pd[v] = (predecessor, distance) is squared log2(longest unitig) times
+//                 until it holds (head, distance from head);
+//        ids      of the two mirrored chains the one with the smaller head is kept; kept
+//                 heads take consecutive id ranges in head order (exclusive scan of the
+//                 chain lengths), node id = base[head] + distance, orientation bit = the
+//                 node's strand on that chain.
+//      Circular unitigs have no head; the host walk numbers them after the rest.
+//   3. the tables permuted into id space + the last base of every oriented node (k_remap);
+//   4. the unitig-start bitmap (k_ustart).
+// The id-space table and the bitmap stay on the device: they are the graph's copy for the
+// fill path.  All of it is HBM-bound random access: 0.05 s at 3 Mbp.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -106,21 +114,106 @@ __global__ void k_assign(const uint64_t* __restrict__ pd, const uint32_t* __rest
   flip[v >> 1] = (uint8_t)(v & 1u);
 }
 
+// ---- successor table in sorted-rank space (dbg.cpp: build_tables_rank, odd k) -------------
+typedef unsigned __int128 u128;
+
+__device__ __forceinline__ uint64_t d_revcomp32(uint64_t x) {  // all 32 bases of a word (kmer.hpp)
+  x = ((x >> 2) & 0x3333333333333333ULL) | ((x & 0x3333333333333333ULL) << 2);
+  x = ((x >> 4) & 0x0F0F0F0F0F0F0F0FULL) | ((x & 0x0F0F0F0F0F0F0F0FULL) << 4);
+  x = __builtin_bswap64(x);
+  return x ^ 0xAAAAAAAAAAAAAAAAULL;
+}
+__device__ __forceinline__ uint64_t d_revcomp(uint64_t x, int k) { return d_revcomp32(x) >> (64 - 2 * k); }
+__device__ __forceinline__ u128 d_revcomp(u128 x, int k) {
+  const u128 y = ((u128)d_revcomp32((uint64_t)x) << 64) | (u128)d_revcomp32((uint64_t)(x >> 64));
+  return y >> (128 - 2 * k);
+}
+
+template <class KT>
+__device__ __forceinline__ uint32_t d_rank_of(const KT* __restrict__ v, const uint32_t* __restrict__ bucket, int shift,
+                                              KT x) {
+  const uint32_t b = (uint32_t)(x >> shift);
+  uint32_t lo = bucket[b], hi = bucket[b + 1];
+  const uint32_t end = hi;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (v[mid] < x) lo = mid + 1; else hi = mid;
+  }
+  return (lo < end && v[lo] == x) ? lo : INV;
+}
+
+template <class KT>
+__global__ void k_succ(const KT* __restrict__ v, const uint32_t* __restrict__ bucket, int shift, uint32_t n2, int k,
+                       uint32_t* __restrict__ succ) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;  // oriented node in rank space: 2*rank + strand
+  if (t >= n2) return;
+  const KT mask = (2 * k >= (int)(8 * sizeof(KT))) ? ~(KT)0 : ((((KT)1) << (2 * k)) - 1);
+  const KT c = v[t >> 1], rc = d_revcomp(c, k);
+  const KT seq = (t & 1u) ? rc : c, rseq = (t & 1u) ? c : rc;
+  uint32_t out[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; nt++) {
+    const KT y = ((seq << 2) | (KT)nt) & mask;
+    const KT ry = (rseq >> 2) | ((KT)(nt ^ 2) << (2 * (k - 1)));
+    const uint32_t r = d_rank_of<KT>(v, bucket, shift, y < ry ? y : ry);
+    out[nt] = r == INV ? INV : 2u * r + (y < ry ? 0u : 1u);
+  }
+  *(uint4*)(succ + (size_t)t * 4) = make_uint4(out[0], out[1], out[2], out[3]);
+}
+
+// ---- tables in id space (dbg.cpp: finish_graph) ----------------------------------------------
+template <class KT>
+__global__ void k_remap(const KT* __restrict__ v, const uint32_t* __restrict__ succ_r, const uint32_t* __restrict__ rank2id,
+                        const uint8_t* __restrict__ flip, uint32_t n2, int k, uint32_t* __restrict__ succ_id,
+                        uint8_t* __restrict__ lastnt, uint32_t* __restrict__ id2rank) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n2) return;
+  const uint32_t r = t >> 1, s = t & 1u;
+  const uint32_t row = 2u * rank2id[r] + (s ^ (uint32_t)flip[r]);
+  const uint4 in = *(const uint4*)(succ_r + (size_t)t * 4);
+  auto remap = [&](uint32_t w) -> uint32_t { return w == INV ? INV : 2u * rank2id[w >> 1] + ((w & 1u) ^ (uint32_t)flip[w >> 1]); };
+  *(uint4*)(succ_id + (size_t)row * 4) = make_uint4(remap(in.x), remap(in.y), remap(in.z), remap(in.w));
+  const KT c = v[r];
+  lastnt[row] = s == 0 ? (uint8_t)(c & 3) : (uint8_t)(((c >> (2 * (k - 1))) & 3) ^ 2);
+  if (s == 0) id2rank[rank2id[r]] = r;
+}
+
+// unitig-start bitmap from the id-space table (dbg.cpp: build_ustart); one wave per 64-bit word
+__global__ void k_ustart(const uint32_t* __restrict__ succ, uint32_t n, uint32_t nbits, uint64_t* __restrict__ words) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool start = true;
+  if (i < n && i > 0) {
+    const uint32_t v = 2u * (i - 1u), want = 2u * i;
+    uint32_t deg, w = only_succ(succ, v, &deg);
+    if (deg == 1 && w == want) {
+      uint32_t dback, back = only_succ(succ, want ^ 1u, &dback);
+      start = !(dback == 1 && back == (v ^ 1u));
+    }
+  }
+  const uint64_t m = __ballot(i < nbits && start);
+  if ((threadIdx.x & 63u) == 0 && i < nbits) words[i >> 6] = m;
+}
+
 struct Dev {
   void* p = nullptr;
   ~Dev() { if (p) (void)hipFree(p); }
   hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+  void* release() { void* q = p; p = nullptr; return q; }
 };
 
 }  // namespace
 
 namespace g2s {
 
-// rank-space successor table in, numbering out.  Entries of rank2id left at kInvalidNode
-// (circular unitigs) are numbered by the caller from *next_id on.  Returns false (with a
-// reason) when the device cannot be used; the caller then runs the host walk.
-bool unitig_order_gpu(const std::vector<uint32_t>& succ_r, uint64_t n, int device, std::vector<uint32_t>* rank2id,
-                      std::vector<uint8_t>* flip, uint64_t* n_unitigs, uint32_t* next_id, std::string* why) {
+// Everything of the graph build after the sorted solid k-mer set (and its prefix index):
+// successor table, unitig-ordered numbering, tables in id space, last-base table, unitig-start
+// bitmap.  The id-space table and the bitmap stay on the device as the graph's copy for the
+// fill path (g2s_graph_upload finds them).  `host_walk` numbers what list ranking leaves
+// unnumbered (circular unitigs).  Returns false (with a reason) when the device cannot be
+// used; nothing of g is touched then and the caller runs the host build.
+template <class KT>
+static bool finish_gpu_t(Graph& g, const std::vector<KT>& kmers, int device,
+                         const std::function<void(const std::vector<uint32_t>&, uint32_t)>& host_walk, std::string* why) {
 #define G2S_GPU_TRY(expr)                                                                 \
   do {                                                                                    \
     hipError_t e_ = (expr);                                                               \
@@ -128,11 +221,22 @@ bool unitig_order_gpu(const std::vector<uint32_t>& succ_r, uint64_t n, int devic
   } while (0)
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { if (why) *why = "no device"; return false; }
+  const uint64_t n = g.n;
   if (n == 0 || 2 * n >= (1ull << 31)) { if (why) *why = "size"; return false; }
   G2S_GPU_TRY(hipSetDevice(device));
   const uint32_t n2 = (uint32_t)(2 * n);
-  Dev d_succ, d_nxt, d_pd0, d_pd1, d_len, d_tail, d_cnt, d_base, d_id, d_flip, d_flag, d_tmp;
-  G2S_GPU_TRY(d_succ.alloc(succ_r.size() * 4));
+  const int k = g.k;
+  const dim3 blk(256), grd((n2 + 255) / 256);
+  Dev d_km, d_bucket, d_succ, d_nxt, d_pd0, d_pd1, d_len, d_tail, d_cnt, d_base, d_id, d_flip, d_flag, d_tmp;
+  // ---- successor table, rank space
+  G2S_GPU_TRY(d_km.alloc(kmers.size() * sizeof(KT)));
+  G2S_GPU_TRY(d_bucket.alloc(g.bucket.size() * 4));
+  G2S_GPU_TRY(d_succ.alloc((size_t)n2 * 16));
+  G2S_GPU_TRY(hipMemcpy(d_km.p, kmers.data(), kmers.size() * sizeof(KT), hipMemcpyHostToDevice));
+  G2S_GPU_TRY(hipMemcpy(d_bucket.p, g.bucket.data(), g.bucket.size() * 4, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_succ<KT>, grd, blk, 0, 0, (const KT*)d_km.p, (const uint32_t*)d_bucket.p, 2 * k - g.bucket_bits, n2, k,
+                     (uint32_t*)d_succ.p);
+  // ---- numbering along unitigs: list ranking
   G2S_GPU_TRY(d_nxt.alloc((size_t)n2 * 4));
   G2S_GPU_TRY(d_pd0.alloc((size_t)n2 * 8));
   G2S_GPU_TRY(d_pd1.alloc((size_t)n2 * 8));
@@ -143,12 +247,10 @@ bool unitig_order_gpu(const std::vector<uint32_t>& succ_r, uint64_t n, int devic
   G2S_GPU_TRY(d_id.alloc((size_t)n * 4));
   G2S_GPU_TRY(d_flip.alloc((size_t)n));
   G2S_GPU_TRY(d_flag.alloc(16));
-  G2S_GPU_TRY(hipMemcpy(d_succ.p, succ_r.data(), succ_r.size() * 4, hipMemcpyHostToDevice));
   G2S_GPU_TRY(hipMemset(d_len.p, 0, (size_t)n2 * 4));
   G2S_GPU_TRY(hipMemset(d_tail.p, 0, (size_t)n2 * 4));
   G2S_GPU_TRY(hipMemset(d_id.p, 0xFF, (size_t)n * 4));
   G2S_GPU_TRY(hipMemset(d_flip.p, 0, (size_t)n));
-  const dim3 blk(256), grd((n2 + 255) / 256);
   hipLaunchKernelGGL(k_next, grd, blk, 0, 0, (const uint32_t*)d_succ.p, n2, (uint32_t*)d_nxt.p);
   hipLaunchKernelGGL(k_init, grd, blk, 0, 0, (const uint32_t*)d_nxt.p, n2, (uint64_t*)d_pd0.p);
   uint64_t *cur = (uint64_t*)d_pd0.p, *oth = (uint64_t*)d_pd1.p;
@@ -174,18 +276,70 @@ bool unitig_order_gpu(const std::vector<uint32_t>& succ_r, uint64_t n, int devic
   hipLaunchKernelGGL(k_assign, grd, blk, 0, 0, (const uint64_t*)cur, (const uint32_t*)d_cnt.p, (const uint32_t*)d_base.p, n2,
                      (uint32_t*)d_id.p, (uint8_t*)d_flip.p);
   G2S_GPU_TRY(hipGetLastError());
-  rank2id->assign((size_t)n, kInvalidNode);
-  flip->assign((size_t)n, 0);
-  G2S_GPU_TRY(hipMemcpy(rank2id->data(), d_id.p, (size_t)n * 4, hipMemcpyDeviceToHost));
-  G2S_GPU_TRY(hipMemcpy(flip->data(), d_flip.p, (size_t)n, hipMemcpyDeviceToHost));
   uint32_t kept = 0, last_base = 0, last_cnt = 0;
   G2S_GPU_TRY(hipMemcpy(&kept, d_flag.p, 4, hipMemcpyDeviceToHost));
   G2S_GPU_TRY(hipMemcpy(&last_base, (const uint32_t*)d_base.p + (n2 - 1), 4, hipMemcpyDeviceToHost));
   G2S_GPU_TRY(hipMemcpy(&last_cnt, (const uint32_t*)d_cnt.p + (n2 - 1), 4, hipMemcpyDeviceToHost));
-  *n_unitigs = kept;
-  *next_id = last_base + last_cnt;  // ids handed out so far
+  const uint32_t next_id = last_base + last_cnt;  // ids handed out so far
+  // free the ranking scratch before the id-space tables are allocated
+  for (Dev* d : {&d_nxt, &d_pd0, &d_pd1, &d_len, &d_tail, &d_cnt, &d_base, &d_tmp}) { if (d->p) (void)hipFree(d->release()); }
+  // ---- everything that can still fail is done: from here on g is written
+  g.rank2id.assign((size_t)n, kInvalidNode);
+  g.flip.assign((size_t)n, 0);
+  g.n_unitigs = kept;
+  if (next_id < n) {  // circular unitigs: the host walk numbers them after the rest
+    std::vector<uint32_t> succ_r((size_t)n2 * 4);
+    G2S_GPU_TRY(hipMemcpy(succ_r.data(), d_succ.p, (size_t)n2 * 16, hipMemcpyDeviceToHost));
+    G2S_GPU_TRY(hipMemcpy(g.rank2id.data(), d_id.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    G2S_GPU_TRY(hipMemcpy(g.flip.data(), d_flip.p, (size_t)n, hipMemcpyDeviceToHost));
+    host_walk(succ_r, next_id);
+    G2S_GPU_TRY(hipMemcpy(d_id.p, g.rank2id.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    G2S_GPU_TRY(hipMemcpy(d_flip.p, g.flip.data(), (size_t)n, hipMemcpyHostToDevice));
+  }
+  // ---- tables in id space
+  Dev d_sid, d_last, d_i2r, d_us;
+  const size_t sbytes = (size_t)n2 * 16;
+  const size_t words = (size_t)((n + 63) / 64 + 1);
+  G2S_GPU_TRY(d_sid.alloc(sbytes + 1024));  // the LDS tier may read past the end: INVALID padding
+  G2S_GPU_TRY(hipMemset(d_sid.p, 0xFF, sbytes + 1024));
+  G2S_GPU_TRY(d_last.alloc((size_t)n2));
+  G2S_GPU_TRY(d_i2r.alloc((size_t)n * 4));
+  G2S_GPU_TRY(d_us.alloc((words + 2 * kUstartPad) * 8));
+  G2S_GPU_TRY(hipMemset(d_us.p, 0xFF, (words + 2 * kUstartPad) * 8));
+  hipLaunchKernelGGL(k_remap<KT>, grd, blk, 0, 0, (const KT*)d_km.p, (const uint32_t*)d_succ.p, (const uint32_t*)d_id.p,
+                     (const uint8_t*)d_flip.p, n2, k, (uint32_t*)d_sid.p, (uint8_t*)d_last.p, (uint32_t*)d_i2r.p);
+  const uint32_t nbits = (uint32_t)(words * 64);
+  hipLaunchKernelGGL(k_ustart, dim3((nbits + 255) / 256), blk, 0, 0, (const uint32_t*)d_sid.p, (uint32_t)n, nbits,
+                     (uint64_t*)d_us.p + kUstartPad);
+  G2S_GPU_TRY(hipGetLastError());
+  g.succ.resize((size_t)n2 * 4);
+  g.pred.clear();
+  g.lastnt.resize((size_t)n2);
+  g.id2rank.resize((size_t)n);
+  g.ustart.resize(words);
+  G2S_GPU_TRY(hipMemcpy(g.succ.data(), d_sid.p, sbytes, hipMemcpyDeviceToHost));
+  G2S_GPU_TRY(hipMemcpy(g.lastnt.data(), d_last.p, (size_t)n2, hipMemcpyDeviceToHost));
+  G2S_GPU_TRY(hipMemcpy(g.id2rank.data(), d_i2r.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+  G2S_GPU_TRY(hipMemcpy(g.ustart.data(), (uint64_t*)d_us.p + kUstartPad, words * 8, hipMemcpyDeviceToHost));
+  if (next_id >= n) {
+    G2S_GPU_TRY(hipMemcpy(g.rank2id.data(), d_id.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    G2S_GPU_TRY(hipMemcpy(g.flip.data(), d_flip.p, (size_t)n, hipMemcpyDeviceToHost));
+  }
+  // the device copy of the graph for the fill path
+  DeviceGraph dg;
+  dg.succ = (uint32_t*)d_sid.release();
+  dg.ustart = (uint64_t*)d_us.release() + kUstartPad;
+  dg.bytes = sbytes + (words + 2 * kUstartPad) * 8;
+  g.dev[device] = dg;
   return true;
 #undef G2S_GPU_TRY
+}
+
+bool graph_finish_gpu(Graph& g, int device, const std::function<void(const std::vector<uint32_t>&, uint32_t)>& host_walk,
+                      std::string* why) {
+  if ((g.k % 2) == 0) { if (why) *why = "even k"; return false; }
+  return g.wide ? finish_gpu_t<u128>(g, g.kmers128, device, host_walk, why)
+                : finish_gpu_t<uint64_t>(g, g.kmers64, device, host_walk, why);
 }
 
 }  // namespace g2s

@@ -403,7 +403,7 @@ def test_session_team_drives_execute_scaffolds(product, oracle):
 
 def test_gpu_unitig_numbering_equals_host_walk(product, monkeypatch):
     """The graph build numbers k-mers along unitigs by list ranking on the GPU (dbg_gpu.hip);
-    G2S_HOST_UNITIG=1 keeps the sequential host walk.  Same unitigs, same adjacency (compared
+    G2S_HOST_BUILD=1 keeps the sequential host walk.  Same unitigs, same adjacency (compared
     through k-mer strings, node ids differ), same fills.  V3 genome + a circular sequence
     (a unitig without a head, which the GPU leaves to the host walk)."""
     reads = product.G2S.synth_genome(200000, 3, 20240101)
@@ -413,9 +413,9 @@ def test_gpu_unitig_numbering_equals_host_walk(product, monkeypatch):
     ring = "".join(rr.choice("ACGT") for _ in range(400))  # not in the genome: an isolated circular unitig
     seqs.append(ring + ring[:40])  # k-1 = 30 bases of overlap close the circle (and 10 more)
     gl = _parse_scaffolds(product.G2S.synth_gaps(reads, 31, 10, 60, 50, 500, 5))
-    monkeypatch.setenv("G2S_HOST_UNITIG", "1")
+    monkeypatch.setenv("G2S_HOST_BUILD", "1")
     gh = product.Graph.from_seqs(seqs, 31, 1)
-    monkeypatch.delenv("G2S_HOST_UNITIG")
+    monkeypatch.delenv("G2S_HOST_BUILD")
     gg = product.Graph.from_seqs(seqs, 31, 1)
     try:
         assert (gg.num_kmers, gg.num_unitigs) == (gh.num_kmers, gh.num_unitigs)
