@@ -256,7 +256,7 @@ def main():
                                       "d2h_closures": round(acc["ms_d2h"] / steps, 4),
                                       "host_phase_d": round(acc["ms_host_post"] / steps, 4),
                                       "batch_run_total": round(acc["ms_total"] / steps, 4)},
-            "setup_s": {"synth": round(t_synth, 3), "graph_build_host": round(t_build, 3),
+            "setup_s": {"synth": round(t_synth, 3), "graph_build": round(t_build, 3),
                         "graph_upload": round(t_upload, 3)},
             "graph": {"kmers": graph.num_kmers, "unitigs": graph.num_unitigs,
                       "hbm_bytes": graph.device_bytes(local_rank)},

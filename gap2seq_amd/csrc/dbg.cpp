@@ -12,6 +12,8 @@
 namespace g2s {
 
 // dbg_gpu.hip
+bool count_solid_gpu(Graph& g, const std::vector<std::pair<const char*, uint64_t>>& seqs, int solid, int device,
+                     std::string* why);
 bool graph_finish_gpu(Graph& g, int device, const std::function<void(const std::vector<uint32_t>&, uint32_t)>& host_walk,
                       std::string* why);
 
@@ -260,7 +262,7 @@ void build_ustart(Graph& g) {
 template <class KT>
 void finish_graph(Graph& g, int nthreads) {
   const auto f0 = std::chrono::steady_clock::now();
-  build_bucket_index<KT>(g);
+  if (g.bucket.empty()) build_bucket_index<KT>(g);  // (the GPU k-mer set brings its index along)
   // With a GPU (odd k): successor table by binary search, numbering along unitigs by list
   // ranking, tables in id space and the unitig-start bitmap all on the device (dbg_gpu.hip);
   // the host only numbers circular unitigs.  Otherwise, and for even k, the host build below.
@@ -352,13 +354,20 @@ Graph* graph_build(const std::vector<std::pair<const char*, uint64_t>>& seqs, in
   g->k = k;
   g->wide = k >= 32;
   const auto t0 = std::chrono::steady_clock::now();
-  if (!g->wide) count_solid<uint64_t>(*g, seqs, solid, nthreads); else count_solid<u128>(*g, seqs, solid, nthreads);
+  // the solid k-mer set: sort on the GPU when there is one (dbg_gpu.hip), host threads otherwise
+  bool set_on_gpu = false;
+  if (!getenv("G2S_HOST_BUILD")) {
+    std::string why;
+    set_on_gpu = count_solid_gpu(*g, seqs, solid, getenv("G2S_DEVICE") ? atoi(getenv("G2S_DEVICE")) : 0, &why);
+    if (!set_on_gpu && getenv("G2S_DEBUG")) fprintf(stderr, "[g2s]   k-mer set on the host (%s)\n", why.c_str());
+  }
+  if (!set_on_gpu) { if (!g->wide) count_solid<uint64_t>(*g, seqs, solid, nthreads); else count_solid<u128>(*g, seqs, solid, nthreads); }
   const auto t1 = std::chrono::steady_clock::now();
   if (g->n >= (1ull << 30)) { if (err) *err = "too many k-mers for 32-bit oriented node ids"; delete g; return nullptr; }
   if (!g->wide) finish_graph<uint64_t>(*g, nthreads); else finish_graph<u128>(*g, nthreads);
   if (getenv("G2S_DEBUG"))
-    fprintf(stderr, "[g2s] graph build: %llu k-mers; solid k-mer set %.3f s, tables + unitig order %.3f s (%d threads)\n",
-            (unsigned long long)g->n, std::chrono::duration<double>(t1 - t0).count(),
+    fprintf(stderr, "[g2s] graph build: %llu k-mers; solid k-mer set %.3f s (%s), tables + unitig order %.3f s (%d threads)\n",
+            (unsigned long long)g->n, std::chrono::duration<double>(t1 - t0).count(), set_on_gpu ? "GPU sort" : "host",
             std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count(), nthreads);
   return g;
 }

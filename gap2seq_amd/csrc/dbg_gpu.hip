@@ -194,6 +194,82 @@ __global__ void k_ustart(const uint32_t* __restrict__ succ, uint32_t n, uint32_t
   if ((threadIdx.x & 63u) == 0 && i < nbits) words[i >> 6] = m;
 }
 
+// ---- solid k-mer set (dbg.cpp: count_solid) ----------------------------------------------
+// one thread per text position: the canonical k-mer starting there, or all-ones when the
+// window holds an N/n (GATB: k-mers with an invalid character are skipped) or runs off the end
+template <class KT>
+__global__ void k_extract(const uint8_t* __restrict__ text, uint64_t len, int k, KT* __restrict__ keys) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= len) return;
+  KT f = 0;
+  bool ok = i + (uint64_t)k <= len;
+  if (ok) {
+    for (int j = 0; j < k; j++) {
+      const uint8_t c = text[i + (uint64_t)j];
+      ok = ok && ((c >> 3) & 1u) == 0u;
+      f = (f << 2) | (KT)((c >> 1) & 3u);
+    }
+  }
+  const KT r = d_revcomp(f, k);
+  keys[i] = ok ? (f < r ? f : r) : ~(KT)0;
+}
+template <class KT>
+__global__ void k_split(const KT* __restrict__ keys, uint64_t n, uint64_t* __restrict__ lo, uint64_t* __restrict__ hi) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  lo[i] = (uint64_t)keys[i];
+  hi[i] = (uint64_t)(keys[i] >> 64);
+}
+__global__ void k_join(const uint64_t* __restrict__ lo, const uint64_t* __restrict__ hi, uint64_t n, u128* __restrict__ keys) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  keys[i] = ((u128)hi[i] << 64) | (u128)lo[i];
+}
+// heads of runs of equal keys in the sorted array (the all-ones filler is no k-mer)
+template <class KT>
+__global__ void k_heads(const KT* __restrict__ keys, uint64_t n, uint32_t* __restrict__ flag) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const KT x = keys[i];
+  flag[i] = (x != ~(KT)0 && (i == 0 || keys[i - 1] != x)) ? 1u : 0u;
+}
+template <class KT>
+__global__ void k_head_index(const KT* __restrict__ keys, const uint32_t* __restrict__ flag,
+                             const uint32_t* __restrict__ pos, uint64_t n, uint32_t* __restrict__ hidx,
+                             uint32_t* n_valid) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (flag[i]) hidx[pos[i]] = (uint32_t)i;
+  // the first filler (or the end) closes the last run
+  if (keys[i] != ~(KT)0 && (i + 1 == n || keys[i + 1] == ~(KT)0)) *n_valid = (uint32_t)(i + 1);
+}
+__global__ void k_solid_flag(const uint32_t* __restrict__ hidx, uint32_t nheads, uint32_t n_valid, uint32_t solid,
+                             uint32_t* __restrict__ keep) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nheads) return;
+  const uint32_t end = j + 1 < nheads ? hidx[j + 1] : n_valid;
+  keep[j] = (end - hidx[j] >= solid) ? 1u : 0u;
+}
+template <class KT>
+__global__ void k_compact(const KT* __restrict__ keys, const uint32_t* __restrict__ hidx, const uint32_t* __restrict__ keep,
+                          const uint32_t* __restrict__ kpos, uint32_t nheads, KT* __restrict__ out) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nheads || !keep[j]) return;
+  out[kpos[j]] = keys[hidx[j]];
+}
+// prefix index over the sorted set: bucket[b] = first rank whose top bits are >= b
+template <class KT>
+__global__ void k_bucket(const KT* __restrict__ v, uint32_t n, int shift, uint32_t nb, uint32_t* __restrict__ bucket) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b > nb) return;
+  uint32_t lo = 0, hi = n;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if ((uint64_t)(v[mid] >> shift) < (uint64_t)b) lo = mid + 1; else hi = mid;
+  }
+  bucket[b] = lo;
+}
+
 struct Dev {
   void* p = nullptr;
   ~Dev() { if (p) (void)hipFree(p); }
@@ -333,6 +409,142 @@ static bool finish_gpu_t(Graph& g, const std::vector<KT>& kmers, int device,
   g.dev[device] = dg;
   return true;
 #undef G2S_GPU_TRY
+}
+
+// The sorted set of solid canonical k-mers and its prefix index, from the reads.  One key per
+// text position, radix sort (rocPRIM; 128-bit keys as two stable 64-bit passes), run heads,
+// runs of at least `solid` copies compacted.  Returns false (g untouched) when the device
+// cannot be used or the text does not fit comfortably.
+template <class KT>
+static bool count_solid_gpu_t(Graph& g, std::vector<KT>& out, const std::vector<std::pair<const char*, uint64_t>>& seqs,
+                              int solid, int device, std::string* why) {
+#define G2S_GPU_TRY(expr)                                                                 \
+  do {                                                                                    \
+    hipError_t e_ = (expr);                                                               \
+    if (e_ != hipSuccess) { if (why) *why = std::string(#expr) + ": " + hipGetErrorString(e_); return false; } \
+  } while (0)
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { if (why) *why = "no device"; return false; }
+  G2S_GPU_TRY(hipSetDevice(device));
+  const int k = g.k;
+  uint64_t T = 0;
+  for (auto& sq : seqs) T += sq.second + 1;  // one separator after every sequence
+  if (T == 0 || T >= (1ull << 32)) { if (why) *why = "text size"; return false; }
+  size_t free_b = 0, total_b = 0;
+  G2S_GPU_TRY(hipMemGetInfo(&free_b, &total_b));
+  if ((double)T * (double)(4 * sizeof(KT) + 24) > 0.5 * (double)free_b) { if (why) *why = "text too large for the device"; return false; }
+  std::vector<uint8_t> text((size_t)T);
+  {
+    size_t pos = 0;
+    for (auto& sq : seqs) { memcpy(text.data() + pos, sq.first, (size_t)sq.second); pos += (size_t)sq.second; text[pos++] = 'N'; }
+  }
+  Dev d_text, d_keys, d_alt, d_lo, d_hi, d_lo2, d_hi2, d_flag, d_pos, d_hidx, d_keep, d_kpos, d_out, d_tmp, d_misc;
+  G2S_GPU_TRY(d_text.alloc((size_t)T));
+  G2S_GPU_TRY(d_keys.alloc((size_t)T * sizeof(KT)));
+  G2S_GPU_TRY(d_misc.alloc(16));
+  G2S_GPU_TRY(hipMemcpy(d_text.p, text.data(), (size_t)T, hipMemcpyHostToDevice));
+  const dim3 blk(256), grdT((unsigned)((T + 255) / 256));
+  hipLaunchKernelGGL(k_extract<KT>, grdT, blk, 0, 0, (const uint8_t*)d_text.p, T, k, (KT*)d_keys.p);
+  (void)hipFree(d_text.release());
+  KT* sorted = nullptr;
+  if constexpr (sizeof(KT) == 8) {
+    G2S_GPU_TRY(d_alt.alloc((size_t)T * 8));
+    size_t tb = 0;
+    G2S_GPU_TRY(rocprim::radix_sort_keys(nullptr, tb, (uint64_t*)d_keys.p, (uint64_t*)d_alt.p, (size_t)T, 0, 64));
+    G2S_GPU_TRY(d_tmp.alloc(tb));
+    // (the filler is all-ones: sort on all 64 bits so that it ends up last)
+    G2S_GPU_TRY(rocprim::radix_sort_keys(d_tmp.p, tb, (uint64_t*)d_keys.p, (uint64_t*)d_alt.p, (size_t)T, 0, 64));
+    sorted = (KT*)d_alt.p;
+  } else {
+    G2S_GPU_TRY(d_lo.alloc((size_t)T * 8));
+    G2S_GPU_TRY(d_hi.alloc((size_t)T * 8));
+    G2S_GPU_TRY(d_lo2.alloc((size_t)T * 8));
+    G2S_GPU_TRY(d_hi2.alloc((size_t)T * 8));
+    hipLaunchKernelGGL(k_split<KT>, grdT, blk, 0, 0, (const KT*)d_keys.p, T, (uint64_t*)d_lo.p, (uint64_t*)d_hi.p);
+    size_t tb = 0;
+    G2S_GPU_TRY(rocprim::radix_sort_pairs(nullptr, tb, (uint64_t*)d_lo.p, (uint64_t*)d_lo2.p, (uint64_t*)d_hi.p,
+                                          (uint64_t*)d_hi2.p, (size_t)T, 0, 64));
+    G2S_GPU_TRY(d_tmp.alloc(tb));
+    // least significant word first, then a stable pass on the most significant word
+    G2S_GPU_TRY(rocprim::radix_sort_pairs(d_tmp.p, tb, (uint64_t*)d_lo.p, (uint64_t*)d_lo2.p, (uint64_t*)d_hi.p,
+                                          (uint64_t*)d_hi2.p, (size_t)T, 0, 64));
+    G2S_GPU_TRY(rocprim::radix_sort_pairs(d_tmp.p, tb, (uint64_t*)d_hi2.p, (uint64_t*)d_hi.p, (uint64_t*)d_lo2.p,
+                                          (uint64_t*)d_lo.p, (size_t)T, 0, 64));
+    hipLaunchKernelGGL(k_join, grdT, blk, 0, 0, (const uint64_t*)d_lo.p, (const uint64_t*)d_hi.p, T, (u128*)d_keys.p);
+    sorted = (KT*)d_keys.p;
+    for (Dev* d : {&d_lo2, &d_hi2}) (void)hipFree(d->release());
+  }
+  // ---- runs of equal keys -> the k-mers seen at least `solid` times
+  G2S_GPU_TRY(d_flag.alloc((size_t)T * 4));
+  G2S_GPU_TRY(d_pos.alloc((size_t)T * 4));
+  hipLaunchKernelGGL(k_heads<KT>, grdT, blk, 0, 0, (const KT*)sorted, T, (uint32_t*)d_flag.p);
+  size_t tb2 = 0;
+  G2S_GPU_TRY(rocprim::exclusive_scan(nullptr, tb2, (const uint32_t*)d_flag.p, (uint32_t*)d_pos.p, 0u, (size_t)T,
+                                      rocprim::plus<uint32_t>()));
+  Dev d_tmp2;
+  G2S_GPU_TRY(d_tmp2.alloc(tb2));
+  G2S_GPU_TRY(rocprim::exclusive_scan(d_tmp2.p, tb2, (const uint32_t*)d_flag.p, (uint32_t*)d_pos.p, 0u, (size_t)T,
+                                      rocprim::plus<uint32_t>()));
+  uint32_t lastf = 0, lastp = 0;
+  G2S_GPU_TRY(hipMemcpy(&lastf, (const uint32_t*)d_flag.p + (T - 1), 4, hipMemcpyDeviceToHost));
+  G2S_GPU_TRY(hipMemcpy(&lastp, (const uint32_t*)d_pos.p + (T - 1), 4, hipMemcpyDeviceToHost));
+  const uint32_t nheads = lastp + lastf;
+  uint32_t n_solid = 0;
+  if (nheads) {
+    G2S_GPU_TRY(d_hidx.alloc((size_t)nheads * 4));
+    G2S_GPU_TRY(d_keep.alloc((size_t)nheads * 4));
+    G2S_GPU_TRY(d_kpos.alloc((size_t)nheads * 4));
+    G2S_GPU_TRY(hipMemset(d_misc.p, 0, 16));
+    hipLaunchKernelGGL(k_head_index<KT>, grdT, blk, 0, 0, (const KT*)sorted, (const uint32_t*)d_flag.p,
+                       (const uint32_t*)d_pos.p, T, (uint32_t*)d_hidx.p, (uint32_t*)d_misc.p);
+    uint32_t n_valid = 0;
+    G2S_GPU_TRY(hipMemcpy(&n_valid, d_misc.p, 4, hipMemcpyDeviceToHost));
+    const dim3 grdH((nheads + 255) / 256);
+    hipLaunchKernelGGL(k_solid_flag, grdH, blk, 0, 0, (const uint32_t*)d_hidx.p, nheads, n_valid, (uint32_t)std::max(1, solid),
+                       (uint32_t*)d_keep.p);
+    size_t tb3 = 0;
+    G2S_GPU_TRY(rocprim::exclusive_scan(nullptr, tb3, (const uint32_t*)d_keep.p, (uint32_t*)d_kpos.p, 0u, (size_t)nheads,
+                                        rocprim::plus<uint32_t>()));
+    Dev d_tmp3;
+    G2S_GPU_TRY(d_tmp3.alloc(tb3));
+    G2S_GPU_TRY(rocprim::exclusive_scan(d_tmp3.p, tb3, (const uint32_t*)d_keep.p, (uint32_t*)d_kpos.p, 0u, (size_t)nheads,
+                                        rocprim::plus<uint32_t>()));
+    uint32_t lk = 0, lkp = 0;
+    G2S_GPU_TRY(hipMemcpy(&lk, (const uint32_t*)d_keep.p + (nheads - 1), 4, hipMemcpyDeviceToHost));
+    G2S_GPU_TRY(hipMemcpy(&lkp, (const uint32_t*)d_kpos.p + (nheads - 1), 4, hipMemcpyDeviceToHost));
+    n_solid = lk + lkp;
+    if (n_solid) {
+      G2S_GPU_TRY(d_out.alloc((size_t)n_solid * sizeof(KT)));
+      hipLaunchKernelGGL(k_compact<KT>, grdH, blk, 0, 0, (const KT*)sorted, (const uint32_t*)d_hidx.p,
+                         (const uint32_t*)d_keep.p, (const uint32_t*)d_kpos.p, nheads, (KT*)d_out.p);
+    }
+  }
+  G2S_GPU_TRY(hipGetLastError());
+  // ---- prefix index and the copies the host keeps (node look-ups, node strings)
+  const int bits = std::min(2 * k, 22);
+  const uint32_t nb = 1u << bits;
+  std::vector<uint32_t> bucket((size_t)nb + 1, 0);
+  std::vector<KT> host((size_t)n_solid);
+  if (n_solid) {
+    Dev d_bucket;
+    G2S_GPU_TRY(d_bucket.alloc(((size_t)nb + 1) * 4));
+    hipLaunchKernelGGL(k_bucket<KT>, dim3((nb + 1 + 255) / 256), blk, 0, 0, (const KT*)d_out.p, n_solid, 2 * k - bits, nb,
+                       (uint32_t*)d_bucket.p);
+    G2S_GPU_TRY(hipMemcpy(bucket.data(), d_bucket.p, ((size_t)nb + 1) * 4, hipMemcpyDeviceToHost));
+    G2S_GPU_TRY(hipMemcpy(host.data(), d_out.p, (size_t)n_solid * sizeof(KT), hipMemcpyDeviceToHost));
+  }
+  out.swap(host);
+  g.n = n_solid;
+  g.bucket.swap(bucket);
+  g.bucket_bits = bits;
+  return true;
+#undef G2S_GPU_TRY
+}
+
+bool count_solid_gpu(Graph& g, const std::vector<std::pair<const char*, uint64_t>>& seqs, int solid, int device,
+                     std::string* why) {
+  return g.wide ? count_solid_gpu_t<u128>(g, g.kmers128, seqs, solid, device, why)
+                : count_solid_gpu_t<uint64_t>(g, g.kmers64, seqs, solid, device, why);
 }
 
 bool graph_finish_gpu(Graph& g, int device, const std::function<void(const std::vector<uint32_t>&, uint32_t)>& host_walk,

@@ -444,6 +444,46 @@ def test_gpu_unitig_numbering_equals_host_walk(product, monkeypatch):
         gh.free()
 
 
+@pytest.mark.parametrize("k", [15, 31, 47, 63])
+def test_gpu_graph_build_solid_threshold_and_wide_kmers(product, monkeypatch, k):
+    """GPU graph build (k-mer extraction + radix sort + run lengths, dbg_gpu.hip) against the
+    host build: reads with N's, lower case, overlaps and `-solid 2`; 64- and 128-bit k-mers."""
+    import random
+    rr = random.Random(k)
+    genome = "".join(rr.choice("ACGT") for _ in range(30000))
+    reads = []
+    for i in range(0, len(genome) - 400, 150):  # 400 bp reads every 150 bp: coverage 2-3
+        r = genome[i:i + 400]
+        if i % 900 == 0:
+            r = r[:200] + "N" + r[201:]
+        if i % 1350 == 0:
+            r = r.lower()
+        reads.append(r)
+    reads.append(genome[:k - 1])  # shorter than k: contributes nothing
+    graphs = {}
+    for mode in ("host", "gpu"):
+        if mode == "host":
+            monkeypatch.setenv("G2S_HOST_BUILD", "1")
+        else:
+            monkeypatch.delenv("G2S_HOST_BUILD", raising=False)
+        graphs[mode] = product.Graph.from_seqs(reads, k, 2)
+    gh, gg = graphs["host"], graphs["gpu"]
+    try:
+        assert gg.num_kmers == gh.num_kmers and gg.num_kmers > 20000
+        assert gg.num_unitigs == gh.num_unitigs
+        for _ in range(500):
+            p = rr.randrange(0, len(genome) - k)
+            km = genome[p:p + k]
+            a, b = gg.node(km), gh.node(km)
+            assert (a == 0xFFFFFFFF) == (b == 0xFFFFFFFF)
+            if a != 0xFFFFFFFF:
+                assert gg.node_string(a) == km
+                assert [gg.node_string(x) for x in gg.successors(a)] == [gh.node_string(x) for x in gh.successors(b)]
+    finally:
+        gg.free()
+        gh.free()
+
+
 def test_full_size_round_trip_c3(product):
     """BASELINE config 3 size (3 Mbp DBG, 10 000 gaps, k=31, -fuz 10, -dist-error 500) on
     the repeat-free V0 genome: every gap has exactly one path, so cut -> fill must give
