@@ -15,7 +15,8 @@
 #define G2S_DEV_Q7_B 0x2u        /* both strands of a k-mer at one DP level        */
 #define G2S_DEV_OVERFLOW_A 0x4u  /* right-set tables too small for this gap        */
 #define G2S_DEV_OVERFLOW_B 0x8u  /* state tables too small for this gap            */
-#define G2S_DEV_Q7_D 0x10u       /* both strands of a k-mer at one level of the backward sweep */
+#define G2S_DEV_Q7_D 0x10u       /* both strands of a k-mer at one level of the backward sweep (HBM tier; the LDS
+                                    tier's closure is a subset of the DP states, covered by Q7_B) */
 /* why a gap left the LDS tier (diagnostics, set together with OVERFLOW_B) */
 #define G2S_DEV_WHY_FRONTIER 0x100u /* a DP level wider than the LDS frontier buffers */
 #define G2S_DEV_WHY_HITS 0x200u     /* more target hits than the LDS list holds       */

@@ -1,32 +1,38 @@
 // gap2seq_amd/csrc/fill_lds.hip — LDS-resident fast tier of the fill path for
-// gfx950 (CDNA4): phases A-C (g2s_fill_lds) and D1 (g2s_extract_lds) of
-// /root/reference/src/Gap2Seq.cpp:858-1312.
+// gfx950 (CDNA4): phases A, B, C and D1 of /root/reference/src/Gap2Seq.cpp:858-1312 in
+// one kernel (g2s_fill_lds), one 64-lane wavefront per gap.
 //
 // Why a second tier: the first correct kernels (fill_kernels.hip) keep every
 // per-gap table in HBM and pay 5-6 dependent L2/HBM round trips per DP level
 // (~1.9 us/level measured, profiles/r01_v1_*).  A gap's working set is tiny —
 // frontier width 1-4 on real graphs — so here everything a level touches lives in
 // the CU's LDS (160 KB/CU on MI355X):
-//   * frontier (node, count) ping-pong buffers, 64 entries;
-//   * the right set (phase A's visited k-mers) as an LDS open-addressing table;
+//   * frontier (node, count) ping-pong buffers;
+//   * the right set (phase A's visited k-mers) as a bucketized LDS table;
 //   * a per-level merge table keyed (depth, node) so that duplicate targets of one
 //     level are combined (64-bit LDS compare-and-swap + wave ballot compaction);
-//   * the target k-mers and the list of (target, depth, count) hits for phase C.
-// HBM sees only successor-record loads (16 B per expansion, coalesced 4 lanes per
-// record) and append-only, fire-and-forget stores of the state log.
+//   * the target k-mers and the list of (target, depth, count) hits for phase C;
+//   * phase D1's closure marks and log windows (the same LDS, after phase B).
+// HBM sees successor-record loads (16 B per expansion), unitig-bitmap words and
+// append-only, fire-and-forget stores of the state log and parent links; a gap's
+// results go straight into pinned host memory when the gap is done.
 //
-// One wavefront (64 lanes) per gap, the depth loop inside the kernel.  With a single
-// wave per SIMD the loop is bound by instruction issue (~2 000 cycles per level
-// measured with s_memtime), so the common case is not stepped level by level at all:
-// node ids are numbered along unitigs with a unitig-relative orientation bit
-// (dbg.hpp), inside a unitig the successor of v is v+2 / v-2, and a BULK STEP lets
-// lane i speculate the state of level d+i, verify it against the graph with one
-// coalesced record load for the whole wave, and commit up to 64 levels per iteration
-// (several parallel runs share the lanes level-major).  Levels that branch, merge,
-// die or leave a unitig fail verification and take the per-level step (4 lanes per
-// frontier entry, one per nucleotide slot).
-// Anything that does not fit (frontier > 64, right set too large, > 128 target hits,
-// explicit predecessor table for even k) is flagged and re-run by the HBM tier.
+// With a single wave per SIMD the depth loop is bound by instruction issue (~2 000
+// cycles per level measured with s_memtime), so dependent steps are what every phase
+// avoids.  Node ids are numbered along unitigs with a unitig-relative orientation bit
+// (dbg.hpp): inside a unitig the successor of v is v+2 / v-2.
+//   phase A  searches over unitigs, not levels: an event covers a whole unitig by
+//            arithmetic and inserts it into the right set 64 nodes per instruction;
+//   phase B  takes BULK STEPS: lane i speculates the state of level d+i, verifies it
+//            with one coalesced record load for the whole wave, and up to 64 levels are
+//            committed per iteration (several parallel runs share the lanes
+//            level-major); levels that branch, merge, die or leave a unitig take the
+//            per-level step;
+//   phase D1 walks the parent links phase B recorded instead of the graph and sweeps
+//            the bulk-produced levels 64 at a time.
+// A gap that does not fit a pass (frontier, right set, label table, target hits, state
+// log, host buffer) is flagged and run again by the next pass; the last resort is the
+// HBM tier (also used for even k: explicit predecessor table).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -34,10 +40,8 @@
 #include "fill_device.h"
 #include "fill_launch.h"
 
-#define LDS_F 64u         /* frontier capacity                 */
-#define LDS_LH (2u * LDS_F)
+#define LDS_F 64u         /* frontier capacity of the first pass */
 #define LDS_TG 32u        /* right_max_fuz + 1 must fit        */
-#define LDS_W 256u        /* log / level-offset window (D1)    */
 #define LDS_TF 128u       /* target filter slots               */
 #define LDS_TF_COLLIDE 0xFFFFFFFEu
 #define LDS_CW 256u       /* candidates of 64 border entries   */
@@ -1240,7 +1244,7 @@ size_t extract_lds_bytes(uint32_t fcap) {
   const uint32_t w = fcap > 256u ? fcap : 256u;
   return 4u * ((w + 1) + 3 * w + 2 * fcap + fcap + 6 * fcap + fcap + 3 * LDS_XC + 4);
 }
-uint32_t fill_lds_frontier_cap() { return LDS_F; }  // pass 0; later passes use LDS_F_WIDE
+uint32_t fill_lds_frontier_cap() { return LDS_F; }
 uint32_t fill_lds_max_fuz() { return LDS_TG - 1; }
 
 hipError_t launch_fill_lds(hipStream_t st, uint32_t ngaps, uint32_t rs_cap_max, uint32_t num_oriented,
