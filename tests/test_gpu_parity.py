@@ -159,6 +159,24 @@ def test_deep_dp_dist_error_2000(product, oracle, tier):
     assert c == 16 and f >= 12
 
 
+@pytest.mark.parametrize("lmf,rmf", [(31, 31), (40, 40), (3, 25), (25, 0)])
+def test_fuz_extremes(product, oracle, lmf, rmf):
+    """Flank fuzz at and beyond what the LDS tier holds (32 target k-mers): -fuz 31 stays in the
+    LDS tier, -fuz 40 takes the HBM tier; asymmetric values as `execute` produces them near
+    record ends (:349,360)."""
+    reads = product.G2S.synth_genome(120000, 3, 20240101)
+    seqs = [ln for ln in reads.splitlines() if not ln.startswith(">")]
+    g = seqs[0]
+    k = 31
+    gaps = []
+    for i in range(40):
+        p = 500 + i * 2500
+        ln = 60 + 13 * i
+        gaps.append(dict(left=g[p - k - lmf:p], right=g[p + ln:p + ln + k + rmf], gap_len=ln, lmf=lmf, rmf=rmf))
+    c, f, _, _, _ = _check_batch(product, oracle, seqs, k, gaps, 200)
+    assert c >= 35 and (f >= 30 or rmf == 0)
+
+
 def test_unfillable_and_ragged_inputs(product, oracle):
     k = 15
     seqs = cases.toy_genome(4, 3000, k, repeats=2)
