@@ -319,6 +319,18 @@ class Session:
         out = [FillResult(res[i], raw) for i in range(len(gaps))]
         return (out, t) if want_timing else out
 
+    def fill_batch_onecall(self, gaps):
+        """g2s_fill_batch (prepare + run + free in one ABI call; lists longer than the group size
+        go through the group pipeline, with the session's team when it has one)."""
+        lib = load_library()
+        arr, keep = _gap_array(gaps)
+        nbytes = lib.g2s_team_arena_bytes(self.h, arr, len(gaps))
+        arena = C.create_string_buffer(max(1, nbytes))
+        res = (g2s_result * max(1, len(gaps)))()
+        _check(lib.g2s_fill_batch(self.h, arr, len(gaps), res, arena, nbytes))
+        raw = arena.raw
+        return [FillResult(res[i], raw) for i in range(len(gaps))]
+
     def set_team(self, helpers, group_size=0):
         """g2s_session_set_team: fill_batch / execute_* on this session use self + helpers."""
         arr = (_VP * max(1, len(helpers)))(*[h.h for h in helpers])

@@ -383,6 +383,27 @@ def test_team_of_sessions_equals_one_session(product, oracle, nsess, group):
         og.free()
 
 
+def test_long_list_goes_through_the_group_pipeline(product):
+    """g2s_fill_batch cuts lists of more than 16 384 gaps into groups (bounded HBM for the
+    state logs) even on a single session; same results as one prepared batch."""
+    reads = product.G2S.synth_genome(400000, 3, 20240101)
+    seqs = [ln for ln in reads.splitlines() if not ln.startswith(">")]
+    gl = _parse_scaffolds(product.G2S.synth_gaps(reads, 31, 10, 17000, 30, 120, 77))
+    gaps = _gaps(product, gl)
+    pg = product.Graph.from_seqs(seqs, 31, 1)
+    a = product.Session(pg, 0, d_err=100, randseed=21)
+    b = product.Session(pg, 0, d_err=100, randseed=21)
+    try:
+        one = [_result_tuple(r) for r in a.fill_batch(gaps)]
+        grouped = [_result_tuple(r) for r in b.fill_batch_onecall(gaps)]
+        assert grouped == one
+        assert sum(1 for r in one if r[0] > 0) > 16000
+    finally:
+        a.destroy()
+        b.destroy()
+        pg.free()
+
+
 def test_session_team_drives_execute_scaffolds(product, oracle):
     """g2s_session_set_team: execute() on the lead spreads the record list's gaps over the
     helpers; FASTA and log equal the oracle's execute()."""
