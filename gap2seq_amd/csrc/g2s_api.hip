@@ -334,19 +334,30 @@ class WorkerPool {
   // f(i) for i in [0,n); the calling thread helps.  Completion is counted in tasks, not in
   // workers: a worker that wakes up late finds nothing to do and nobody waits for it.
   void run(size_t n, const std::function<void(size_t)>& f) {
+    post(n, f);
+    finish();
+  }
+  // post: hand the tasks to the workers and return (f must stay alive until finish());
+  // finish: help with what is left and wait for the last task.  One job at a time.
+  void post(size_t n, const std::function<void(size_t)>& f) {
+    posted_n_ = n;
+    posted_f_ = &f;
     if (n == 0) return;
-    uint64_t g;
     {
       std::lock_guard<std::mutex> lk(mu_);
       fn_ = &f; n_ = n; done_.store(0);
-      g = gen_.load() + 1;
-      next_.store(g << 32);  // the generation tags every ticket: stale workers cannot take one
-      gen_.store(g);
+      posted_g_ = gen_.load() + 1;
+      next_.store(posted_g_ << 32);  // the generation tags every ticket: stale workers cannot take one
+      gen_.store(posted_g_);
     }
     cv_.notify_all();
-    drain(g, n, &f);
+  }
+  void finish() {
+    if (posted_n_ == 0) return;
+    drain(posted_g_, posted_n_, posted_f_);
     // tail of the last tasks (a few microseconds): the only place a thread waits without sleeping
-    while (done_.load(std::memory_order_acquire) != n) __builtin_ia32_pause();
+    while (done_.load(std::memory_order_acquire) != posted_n_) __builtin_ia32_pause();
+    posted_n_ = 0;
   }
  private:
   void drain(uint64_t g, size_t n, const std::function<void(size_t)>* f) {
@@ -388,6 +399,9 @@ class WorkerPool {
   std::atomic<size_t> done_{0};
   std::atomic<uint64_t> gen_{0};
   bool stop_ = false;
+  size_t posted_n_ = 0;
+  uint64_t posted_g_ = 0;
+  const std::function<void(size_t)>* posted_f_ = nullptr;
 };
 
 // The session's rand() stream, materialised ahead of use so that tracebacks of
@@ -399,6 +413,7 @@ struct RandCache {
   int32_t at(size_t off) { st.ensure(off + 1); return st.value(off); }
   const uint32_t* ptr(size_t off) const { return st.raw() + off; }
   int32_t at_const(size_t off) const { return st.value(off); }  // already materialised
+  bool would_grow(size_t n) const { return st.would_grow(n); }  // ensure(n) would move the buffer
   void consume(size_t n) { st.consume(n); }
 };
 
@@ -1156,12 +1171,18 @@ int batches_stage2(const std::vector<g2s_batch*>& bs, g2s_session* lead, g2s_res
   size_t n_inline = 0, n_two = 0;
   size_t draws_used = 0;
 
-  auto in_order_pass = [&]() {
+  size_t draws_total = 0;
+  bool prev_filled = false;
+  int prev_right_fuz = 0;
+  bool jobs_in_flight = false;  // tracebacks of an earlier segment are reading the rand() buffer
+  auto grow_rands = [&](size_t upto) {  // materialise more values; the buffer may move, so nobody may be reading it
+    if (!lead->rcache.would_grow(upto)) return;
+    if (jobs_in_flight) { lead->pool->finish(); jobs_in_flight = false; }
+    lead->rcache.ensure(upto + (1u << 16));
+  };
+  auto in_order_pass = [&](size_t g_lo, size_t g_hi) {
     auto t0 = std::chrono::steady_clock::now();
-    size_t draws_total = 0;
-    bool prev_filled = false;
-    int prev_right_fuz = 0;
-    for (size_t gi = 0; gi < n; gi++) {
+    for (size_t gi = g_lo; gi < g_hi; gi++) {
       g2s_batch* b = owner[gi];
       const size_t i = local[gi];
       const g2s_batch::GapInfo& in = b->info[i];
@@ -1178,7 +1199,8 @@ int batches_stage2(const std::vector<g2s_batch*>& bs, g2s_session* lead, g2s_res
       int right_fuz = 0;
       if (in.n_len > 0) {
         rand_off[gi] = draws_total;
-        const int pick = in.n_len > 1 ? (int)(lead->rcache.at(draws_total) % in.n_len) : 0;
+        if (in.n_len > 1) grow_rands(draws_total + 1);
+        const int pick = in.n_len > 1 ? (int)(lead->rcache.at_const(draws_total) % in.n_len) : 0;
         int draws = in.fixed[pick];
         n_two += in.n_len > 1;
         if (draws >= 0) {
@@ -1188,7 +1210,7 @@ int batches_stage2(const std::vector<g2s_batch*>& bs, g2s_session* lead, g2s_res
           n_inline++;
           g2s_result& r = results[gi];
           const SubView& v = b->views[i];
-          lead->rcache.ensure(draws_total + (size_t)v.out->len[pick] + 2);
+          grow_rands(draws_total + (size_t)v.out->len[pick] + 2);
           sub_traceback(g, fp, b->jobs[i], v, b->prep[i], lead->rcache.ptr(draws_total), arena + arena_off[gi], &r);
           draws = r.draws;
           right_fuz = r.right_fuz;
@@ -1198,10 +1220,10 @@ int batches_stage2(const std::vector<g2s_batch*>& bs, g2s_session* lead, g2s_res
       prev_filled = in.filled != 0;
       prev_right_fuz = right_fuz;
     }
-    ms_order_loop = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    lead->rcache.ensure(draws_total + 1);
+    grow_rands(draws_total + 1);
     draws_used = draws_total;
-    ms_order = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    ms_order += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    ms_order_loop = ms_order;
   };
 
   // Threads never busy-wait for one another: GPU nodes are usually shared and the process
@@ -1211,30 +1233,41 @@ int batches_stage2(const std::vector<g2s_batch*>& bs, g2s_session* lead, g2s_res
       for (size_t gi = c * per; gi < std::min(n, (c + 1) * per); gi++) analyze_gap(owner[gi], local[gi], fp, &results[gi]);
     });
   ms_ana = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
-  in_order_pass();
-  lead->pool->run(nchunks, [&](size_t c) {
-    uint64_t bytes = 0;
-    for (size_t gi = c * per; gi < std::min(n, (c + 1) * per); gi++) {
-      g2s_result& r = results[gi];
-      const GapJob& j = owner[gi]->jobs[local[gi]];
-      r.fill_off = (uint64_t)arena_off[gi] + (uint64_t)j.lmf;
-      if (todo_tb[gi]) {
-        const g2s_batch* b = owner[gi];
-        const size_t i = local[gi];
-        const g2s_batch::GapInfo& in = b->info[i];
-        const int pick = in.n_len > 1 ? (int)(lead->rcache.at_const(rand_off[gi]) % in.n_len) : 0;
-        const int expect = in.fixed[pick];
-        sub_traceback(g, fp, j, b->views[i], b->prep[i], lead->rcache.ptr(rand_off[gi]), arena + arena_off[gi], &r);
-        if (r.draws != expect) r.flags |= G2S_GAP_BACKTRACE_FAIL;  // cannot happen: the draw count was proven fixed
+  // The in-order pass and the tracebacks are pipelined over segments of the gap list: while
+  // the pool traces segment s, this thread assigns the offsets of segment s+1.
+  const size_t nseg = n >= 256 ? std::min<size_t>(8, n / 128) : 1;
+  std::vector<std::function<void(size_t)>> jobs(nseg);
+  for (size_t sg = 0; sg < nseg; sg++) {
+    const size_t g_lo = n * sg / nseg, g_hi = n * (sg + 1) / nseg;
+    in_order_pass(g_lo, g_hi);
+    if (jobs_in_flight) { lead->pool->finish(); jobs_in_flight = false; }
+    jobs[sg] = [&, g_lo, g_hi](size_t c) {
+      uint64_t bytes = 0;
+      for (size_t gi = g_lo + c * per; gi < std::min(g_hi, g_lo + (c + 1) * per); gi++) {
+        g2s_result& r = results[gi];
+        const GapJob& j = owner[gi]->jobs[local[gi]];
+        r.fill_off = (uint64_t)arena_off[gi] + (uint64_t)j.lmf;
+        if (todo_tb[gi]) {
+          const g2s_batch* b = owner[gi];
+          const size_t i = local[gi];
+          const g2s_batch::GapInfo& in = b->info[i];
+          const int pick = in.n_len > 1 ? (int)(lead->rcache.at_const(rand_off[gi]) % in.n_len) : 0;
+          const int expect = in.fixed[pick];
+          sub_traceback(g, fp, j, b->views[i], b->prep[i], lead->rcache.ptr(rand_off[gi]), arena + arena_off[gi], &r);
+          if (r.draws != expect) r.flags |= G2S_GAP_BACKTRACE_FAIL;  // cannot happen: the draw count was proven fixed
+        }
+        if (r.flags & G2S_GAP_PHASE_D) {
+          r.fill_off = (uint64_t)arena_off[gi] + (uint64_t)(j.lmf - r.left_fuz);
+          r.fill_len = (int32_t)strlen(arena + r.fill_off);
+          bytes += (uint64_t)r.fill_len;
+        }
       }
-      if (r.flags & G2S_GAP_PHASE_D) {
-        r.fill_off = (uint64_t)arena_off[gi] + (uint64_t)(j.lmf - r.left_fuz);
-        r.fill_len = (int32_t)strlen(arena + r.fill_off);
-        bytes += (uint64_t)r.fill_len;
-      }
-    }
-    if (bytes) fill_bytes.fetch_add(bytes);
-  });
+      if (bytes) fill_bytes.fetch_add(bytes);
+    };
+    lead->pool->post((g_hi - g_lo + per - 1) / per, jobs[sg]);
+    jobs_in_flight = true;
+  }
+  if (jobs_in_flight) lead->pool->finish();
   lead->rcache.consume(draws_used);
   auto t_end = std::chrono::steady_clock::now();
   if (getenv("G2S_DEBUG"))

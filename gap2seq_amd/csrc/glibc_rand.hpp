@@ -68,6 +68,7 @@ class GlibcRandStream {
   }
   // make the next `upto` values of the stream available
   void ensure(size_t upto) { if (first_ + upto > size_) extend(first_ + upto - size_ + 4096); }
+  bool would_grow(size_t upto) const { return first_ + upto > size_; }
   int32_t value(size_t k) const { return (int32_t)(e_[first_ + k] >> 1); }
   // raw words of the upcoming values: value k = raw()[k] >> 1
   const uint32_t* raw() const { return e_ + first_; }
