@@ -789,6 +789,7 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
       // so that next to nothing is left when the last gap finishes
       const size_t chunk = std::max<size_t>(32, total / 8);
       auto last_arrival = std::chrono::steady_clock::now();
+      double dbg_first = -1, dbg_fin = -1;
       while (given < total) {
         const size_t before = seen;
         while (seen < total && done[seen] != 0xFFFFFFFFu) seen++;
@@ -796,6 +797,8 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
         const auto now = std::chrono::steady_clock::now();
         if (seen != before) last_arrival = now;
         const bool finished = hipEventQuery(s->ev[2]) != hipErrorNotReady;
+        if (dbg_first < 0 && seen > 0) dbg_first = std::chrono::duration<double, std::milli>(now - t_launched).count();
+        if (dbg_fin < 0 && finished) dbg_fin = std::chrono::duration<double, std::milli>(now - t_launched).count();
         const bool lull = seen > given && std::chrono::duration<double, std::micro>(now - last_arrival).count() > 60.0;
         if (seen - given >= chunk || lull || (finished && seen > given) || seen == total) {
           (*on_done)((const uint32_t*)td->done.p + given, seen - given);
@@ -804,10 +807,13 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
           while (seen < total && done[seen] != 0xFFFFFFFFu) seen++;
           if (seen == given) break;  // kernel over and nothing new: an error, reported by the sync below
         } else {
-          struct timespec ts = {0, 20000};
+          // (short naps once only the stragglers are left: their arrival ends the launch)
+          struct timespec ts = {0, seen * 10 > total * 9 ? 4000 : 20000};
           nanosleep(&ts, nullptr);
         }
       }
+      if (getenv("G2S_DEBUG"))
+        fprintf(stderr, "[g2s] run_tier: first gap seen %.3f ms after the launch call, kernel seen finished at %.3f ms\n", dbg_first, dbg_fin);
     }
     const auto t_polled = std::chrono::steady_clock::now();
     HIP_TRY(hipStreamSynchronize(st));  // the kernels wrote td->outs / td->subs themselves
@@ -944,10 +950,13 @@ int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
       analyzed[i] = 1;
       fresh.push_back(i);
     }
-    if (fresh.size() <= 6) {  // not worth waking the pool
+    size_t work = 0;
+    for (uint32_t i : fresh) work += views[i].n;
+    if (fresh.size() <= 1 || work < 1500) {  // not worth waking the pool (~20 ns per closure state)
       for (uint32_t i : fresh) analyze_gap(b, i, fp, &results[i]);
     } else {
-      const size_t per = 8, nt = (fresh.size() + per - 1) / per;
+      // the last gaps of a launch are few and large: one task per gap then
+      const size_t per = fresh.size() >= 64 ? 8 : 1, nt = (fresh.size() + per - 1) / per;
       s->pool->run(nt, [&](size_t t) {
         for (size_t x = t * per; x < std::min(fresh.size(), (t + 1) * per); x++) analyze_gap(b, fresh[x], fp, &results[fresh[x]]);
       });
