@@ -1041,6 +1041,51 @@ __device__ __forceinline__ void extract_lds_body(const FillOut fo, const GapDev*
       }
     }
     st_slowD++;
+    // ---- the common per-level step, straight-line: the level fits one pass of the wave, is
+    // in the LDS window, lies above the left flank (no sources) and neither it nor the level
+    // above has merged states.  Same work as the general code below, a third of the
+    // instructions (a lone wave pays ~5 cycles per instruction and ~64 per LDS round trip).
+    if (w <= 64u && nxc == 0 && d2 > gd.lmf && lo >= we_lo && hi <= we_hi && !(xtop >= lo && xpos > 0)) {
+      const uint32_t c = (uint32_t)lane;
+      const bool have = c < w;
+      const uint32_t wi = lo - we_lo + c;
+      const uint32_t cn = have ? wen[wi] : 0u, cc = have ? wec[wi] : 0u;
+      const uint32_t pp = have ? wpl[wi] : G2S_DEV_INVALID;
+      const uint32_t cf = have ? (mcur[c] | own_flags(cn, d2)) : 0u;
+      const bool in = cf != 0;
+      const uint64_t m = __ballot(in);
+      const uint32_t nin = (uint32_t)__popcll(m);
+      if (nsub + nin > cap) { over = true; break; }
+      const uint32_t slot = nsub + (uint32_t)__popcll(m & lanes_below(lane));
+      const bool expand = in && pp != G2S_DEV_INVALID;  // d2 > lmf >= 0: neither a source nor depth 0
+      const uint64_t lm = __ballot(expand);
+      uint32_t* chc = ch + csel * 3u * F;
+      uint32_t* chn = ch + (csel ^ 1u) * 3u * F;
+      if (in) {
+        SubRec st;
+        st.node = cn; st.cnt = cc; st.meta = (uint32_t)d2 | (cf << G2S_SUB_META_FLAG_SHIFT);
+        st.pred = -1;
+        sub[slot] = st;
+        em[c] = slot;
+      }
+      if (expand) {
+        atomicOr(&mnxt[pp], cf & FL);
+        const uint32_t at = (uint32_t)__popcll(lm & lanes_below(lane));
+        chn[at] = slot;
+        chn[F + at] = pp;
+        chn[2u * F + at] = 0u;
+      }
+      if (have) mcur[c] = 0;  // recycled for the level after next
+      lds_sync();
+      for (uint32_t j = (uint32_t)lane; j < nch; j += 64u) sub[chc[j]].pred = (int32_t)em[chc[F + j]];
+      lds_sync();
+      nch = (uint32_t)__popcll(lm);
+      csel ^= 1u;
+      msel ^= 1u;
+      xcount += nin;
+      nsub += nin;
+      continue;
+    }
     // ---- entries of the level through the LDS window ----------------------------------
     if (lo < we_lo || hi > we_hi) {
       lds_sync();
