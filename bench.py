@@ -100,6 +100,7 @@ def main():
     gaps = parse_gaps(scaf, args.fuz)
     t_synth = time.time() - t0
     t0 = time.time()
+    os.environ["G2S_DEVICE"] = str(local_rank)  # the graph is built on (and stays on) this rank's GPU
     graph = P.Graph.from_seqs(seqs, args.k, 1)
     t_build = time.time() - t0
     t0 = time.time()

@@ -76,6 +76,11 @@ int main(int argc, char** argv) {
   p.randseed = randseed > 0 ? (uint32_t)randseed : (uint32_t)time(NULL);  // :178
   p.host_threads = 0;
 
+  {  // the graph is built on the first GPU this run uses
+    int build_dev = device;
+    if (!devices.empty()) build_dev = atoi(devices.c_str());
+    setenv("G2S_DEVICE", std::to_string(build_dev).c_str(), 1);
+  }
   g2s_graph* g = nullptr;
   const std::string cache = reads + ".g2s";  // the reference reuses "<reads>.h5" (:171,195-197)
   int rc;

@@ -61,6 +61,11 @@ const char* g2s_last_error(void);
  *  N/n skipped), numbered in unitig order, with a 4-slot successor table per
  *  oriented node in GATB enumeration order (A,C,T,G).  Predecessors are read
  *  from the same table: pred(v)[i] = succ(v^1)[i]^1.
+ *  The build itself (k-mer sort, successor table, unitig numbering) runs on
+ *  the GPU named by the environment variable G2S_DEVICE (default 0) when there
+ *  is one, and the graph then already resides on that device; without a
+ *  device, for even k, or with G2S_HOST_BUILD=1 it runs on `nthreads` host
+ *  threads.  Either way the same graph results, up to the numbering of nodes.
  * ------------------------------------------------------------------------ */
 int g2s_graph_build_files(const char* reads_csv, int k, int solid, int nthreads, g2s_graph** out);
 int g2s_graph_build_seqs(const char* const* seqs, const uint64_t* lens, int nseqs, int k, int solid,
