@@ -54,8 +54,8 @@ def algorithmic_bytes(x, s, io_bytes):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200, help="timed steps (a step takes ~1.3 ms: 200 of them ride out host noise)")
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--variant", type=int, default=3, help="graph variant: bit0 repeats (V1), bit1 bubbles (V2)")
     ap.add_argument("--genome", type=int, default=3000000)
     ap.add_argument("--gaps", type=int, default=500, help="gaps per GPU")
