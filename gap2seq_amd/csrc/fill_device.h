@@ -21,6 +21,7 @@
 #define G2S_DEV_WHY_FRONTIER 0x100u /* a DP level wider than the LDS frontier buffers */
 #define G2S_DEV_WHY_HITS 0x200u     /* more target hits than the LDS list holds       */
 #define G2S_DEV_WHY_LOG 0x400u      /* state log full                                 */
+#define G2S_DEV_WHY_RS 0x800u       /* (with OVERFLOW_A) the right-set table was full */
 /* LDS tier, lvl[]: bit 31 of the END offset of level L = L was produced by a bulk step
  * (same width as level L-1, state r has the single parent r of level L-1) */
 #define G2S_LVL_UNIFORM 0x80000000u

@@ -36,6 +36,8 @@ hipError_t launch_fill_lds(hipStream_t st, uint32_t ngaps, uint32_t rs_cap_max, 
                            unsigned long long out_cap /* records */, unsigned long long* out_counter, GapOut* outs,
                            GapOut* outs_host /* pinned host */, uint32_t* done_list /* pinned host, ngaps entries */,
                            int skip_confident,
-                           uint32_t* rs_global /* nullptr: right set in LDS */, uint32_t fcap /* frontier capacity */);
+                           uint32_t* rs_global /* nullptr: right set in LDS */, uint32_t fcap /* frontier capacity */,
+                           uint32_t* rs_pool /* spill pool for LDS right sets, 0xFF filled */, uint32_t pool_chunks,
+                           uint32_t chunk_entries /* power of two */);
 
 }  // namespace g2s

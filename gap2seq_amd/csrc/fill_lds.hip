@@ -101,8 +101,7 @@ __device__ __forceinline__ uint32_t log2ceil16(uint32_t r) { return r <= 1 ? 0u 
 // mutated by L2 atomics.  Returns bit0 = orientation newly visited, bit1 = both strands now
 // present, bit2 = table full, bit3 = orientation newly expanded.
 #define RS_SHIFT 4u
-template <bool G>
-__device__ __forceinline__ uint32_t rs_load(const uint32_t* p) {
+__device__ __forceinline__ uint32_t rs_load(const bool G, const uint32_t* p) {
   return G ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
 }
 __device__ __forceinline__ uint32_t rs_result(uint32_t old, uint32_t bits) {
@@ -113,8 +112,7 @@ __device__ __forceinline__ uint32_t rs_result(uint32_t old, uint32_t bits) {
 // probing one slot at a time the slowest of 64 lanes needed ~8 probes at load factor 0.5
 // (measured: 1.4 k cycles per insert round); a 4-slot bucket is almost never full, so
 // nearly every lane finishes with a single LDS read.
-template <bool G>
-__device__ uint32_t lrs_insert(uint32_t* tab, uint32_t mask, uint32_t v, bool expanded) {
+__device__ __forceinline__ uint32_t lrs_insert(const bool G, uint32_t* tab, uint32_t mask, uint32_t v, bool expanded) {
   const uint32_t idx = v >> 1;
   const uint32_t bits = (1u << (v & 1u)) | (expanded ? (4u << (v & 1u)) : 0u);
   if (!G) {
@@ -143,7 +141,7 @@ __device__ uint32_t lrs_insert(uint32_t* tab, uint32_t mask, uint32_t v, bool ex
   }
   uint32_t h = mix32(idx) & mask;
   for (uint32_t i = 0; i <= mask; i++) {
-    uint32_t cur = rs_load<G>(&tab[h]);
+    uint32_t cur = rs_load(G, &tab[h]);
     if (cur == G2S_DEV_INVALID) {
       cur = atomicCAS(&tab[h], G2S_DEV_INVALID, (idx << RS_SHIFT) | bits);
       if (cur == G2S_DEV_INVALID) return rs_result(0u, bits);
@@ -153,8 +151,7 @@ __device__ uint32_t lrs_insert(uint32_t* tab, uint32_t mask, uint32_t v, bool ex
   }
   return 4u;
 }
-template <bool G>
-__device__ bool lrs_has_kmer(const uint32_t* tab, uint32_t mask, uint32_t v) {
+__device__ __forceinline__ bool lrs_has_kmer(const bool G, const uint32_t* tab, uint32_t mask, uint32_t v) {
   const uint32_t idx = v >> 1;
   if (!G) {
     const uint32_t bmask = mask >> 2;
@@ -173,7 +170,7 @@ __device__ bool lrs_has_kmer(const uint32_t* tab, uint32_t mask, uint32_t v) {
   }
   uint32_t h = mix32(idx) & mask;
   for (uint32_t i = 0; i <= mask; i++) {
-    const uint32_t cur = rs_load<G>(&tab[h]);
+    const uint32_t cur = rs_load(G, &tab[h]);
     if (cur == G2S_DEV_INVALID) return false;
     if ((cur >> RS_SHIFT) == idx) return true;
     h = (h + 1) & mask;
@@ -193,13 +190,14 @@ struct FillOut {
   int c_count, n_len, len0, len1, reached_j;
 };
 
-template <bool RSG>
 __device__ __forceinline__ FillOut fill_lds_body(const uint32_t* __restrict__ succ,
                                               const uint64_t* __restrict__ ustart, const GapDev* __restrict__ gaps,
                                               const uint32_t* __restrict__ gap_ids,
                                               const uint32_t* __restrict__ flank_nodes, uint64_t* log_all,
                                               uint32_t* lvl_all, uint32_t* plk_all, uint64_t* xl_all, GapOut* outs,
-                                              uint32_t num_oriented, uint32_t* rs_global, const uint32_t F) {
+                                              uint32_t num_oriented, uint32_t* rs_global, const uint32_t F,
+                                              unsigned long long* pool_cursor, uint32_t* rs_pool, uint32_t pool_chunks,
+                                              uint32_t chunk_entries) {
   const uint32_t LH = 2u * F;  // merge table slots (F = frontier capacity of this launch, a power of two)
   const uint32_t TH = 2u * F;  // target hits kept for phase C (128 in the first pass, 2048 later)
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -222,10 +220,12 @@ __device__ __forceinline__ FillOut fill_lds_body(const uint32_t* __restrict__ su
   uint32_t* cw_v = tflt + LDS_TF;             // wide levels: compacted candidate nodes / counts
   uint32_t* cw_c = cw_v + LDS_CW;
   uint32_t* cw_e = cw_c + LDS_CW;
-  uint32_t* rs = RSG ? rs_global + gd.rs_off : cw_e + LDS_CW;  // right set: HBM (host pre-filled 0xFF) or LDS
-
-  const uint32_t rs_cap = gd.rs_mask + 1u;  // LDS capacity chosen by the host for this gap (<= rs_cap_max)
-  const uint32_t rmask = gd.rs_mask;
+  // right set: in LDS, or in HBM (host pre-filled 0xFF) — the gap's own table when the launch
+  // keeps right sets in HBM, or a chunk of the launch's spill pool once the LDS share is outgrown
+  bool rsg = rs_global != nullptr;
+  uint32_t* rs = rsg ? rs_global + gd.rs_off : cw_e + LDS_CW;
+  uint32_t rmask = gd.rs_mask;
+  uint32_t rs_cap = rmask + 1u;  // capacity chosen by the host for this gap (LDS: <= rs_cap_max)
   const uint32_t* lseeds = flank_nodes + gd.flank_off;
   const uint32_t* rseeds = lseeds + (uint32_t)(gd.lmf + 1);
   const uint32_t* targets = rseeds + (uint32_t)(gd.rmf + 1);
@@ -240,7 +240,7 @@ __device__ __forceinline__ FillOut fill_lds_body(const uint32_t* __restrict__ su
   const uint32_t xcap = gd.pad0;
   uint32_t nxl = 0;
 
-  if (!RSG) for (uint32_t i = (uint32_t)lane; i < rs_cap; i += 64u) rs[i] = G2S_DEV_INVALID;
+  if (!rsg) for (uint32_t i = (uint32_t)lane; i < rs_cap; i += 64u) rs[i] = G2S_DEV_INVALID;
   if (lane <= gd.rmf && lane < (int)LDS_TG) tgt[lane] = targets[lane];
   if (lane == 0) misc[0] = 0;
   // Is a state's node one of the <= 32 target k-mers?  Two filters in front of the exact scan
@@ -303,7 +303,7 @@ __device__ __forceinline__ FillOut fill_lds_body(const uint32_t* __restrict__ su
   uint32_t nvis = 0, xa = 0;
   uint32_t st_slowA = 0, st_bulkA = 0, st_slowB = 0, st_bulkB = 0;
   const unsigned long long cyc0 = __builtin_amdgcn_s_memtime();
-  if (!overflow) {
+  for (int attempt = 0; attempt < 2 && !overflow; attempt++) {
     uint64_t* lab = (uint64_t*)fn;        // labels (entry node << 32 | depth): the arrays of phase B are idle
     const uint32_t LAB = 8u * F;          // [fn 2F][fc 2F][lh 4F][lhslot 2F][th 6F] = 16F words
     for (uint32_t i = (uint32_t)lane; i < LAB; i += 64u) lab[i] = G2S_DEV_EMPTY64;
@@ -411,16 +411,16 @@ __device__ __forceinline__ FillOut fill_lds_body(const uint32_t* __restrict__ su
           if (k < total) {
             const uint32_t t = k - (ev ? startq : 0u);
             const uint32_t node = (ve & 1u) ? ve + 2u * t : ve - 2u * t;
-            const uint32_t rr = lrs_insert<RSG>(rs, rmask, node, de + t < (uint32_t)gd.right_half);
+            const uint32_t rr = lrs_insert(rsg, rs, rmask, node, de + t < (uint32_t)gd.right_half);
             isnew = rr & 1u;
             isexp = (rr >> 3) & 1u;
             if (rr & 2u) flags |= G2S_DEV_Q7_A;
-            if (rr & 4u) flags |= G2S_DEV_OVERFLOW_A;
+            if (rr & 4u) flags |= G2S_DEV_OVERFLOW_A | G2S_DEV_WHY_RS;
           }
           nvis += (uint32_t)__popcll(__ballot(isnew));
           xa += (uint32_t)__popcll(__ballot(isexp));
         }
-        if (nvis > rs_cap / 4u * 3u) { overflow = true; break; }
+        if (nvis > rs_cap / 4u * 3u) { overflow = true; flags |= G2S_DEV_WHY_RS; break; }
         // ---- where a run stopped with budget left: the predecessors of its last node
         // (unitig boundary: one record, 4 lanes), or the next node of the same unitig when
         // the bitmap window was too short to see the boundary
@@ -450,9 +450,28 @@ __device__ __forceinline__ FillOut fill_lds_body(const uint32_t* __restrict__ su
       ne = nn;
     }
     lds_sync();
+    // A right set that outgrew its share of the LDS (8 % of C3's gaps at 1250+ gaps per GPU)
+    // moves to a chunk of the launch's spill pool in HBM and the search starts over right
+    // here, instead of in a second launch after every other gap is done.
+    if (overflow && !rsg && pool_chunks && (flags & G2S_DEV_WHY_RS) && !(flags & G2S_DEV_WHY_FRONTIER) && nlab <= LAB / 2u) {
+      unsigned long long chunk = 0;
+      if (lane == 0) chunk = atomicAdd(pool_cursor, 1ull);
+      chunk = __shfl(chunk, 0);
+      if (chunk < pool_chunks) {
+        rsg = true;
+        rs = rs_pool + (size_t)chunk * chunk_entries;
+        rmask = chunk_entries - 1u;
+        rs_cap = chunk_entries;
+        overflow = false;
+        flags &= ~(G2S_DEV_OVERFLOW_A | G2S_DEV_WHY_RS | G2S_DEV_Q7_A);
+        nvis = 0; xa = 0;
+        continue;
+      }
+    }
     // hand the arrays back to phase B
     for (uint32_t i = (uint32_t)lane; i < LH; i += 64u) lh[i] = G2S_DEV_EMPTY64;
     lds_sync();
+    break;
   }
   if (overflow) flags |= G2S_DEV_OVERFLOW_A;
 
@@ -518,7 +537,7 @@ __device__ __forceinline__ FillOut fill_lds_body(const uint32_t* __restrict__ su
           uint32_t nt;
           const uint4 rec = *(const uint4*)(succ + (size_t)x * 4);
           ok = only_slot(rec, &nt) == v;
-          if (ok && d + (int)i >= gd.prune_from) ok = lrs_has_kmer<RSG>(rs, rmask, v);  // :1050
+          if (ok && d + (int)i >= gd.prune_from) ok = lrs_has_kmer(rsg, rs, rmask, v);  // :1050
         }
         uint32_t lrun = leading_levels(ok, lg);
         if (lrun > L) lrun = L;
@@ -608,7 +627,7 @@ __device__ __forceinline__ FillOut fill_lds_body(const uint32_t* __restrict__ su
         if (np > G2S_DEV_MAX_PATHS) np = G2S_DEV_MAX_PATHS;
         const bool valid = lane < 4;
         const uint32_t v = valid ? succ[(size_t)n * 4 + ((uint32_t)lane & 3u)] : G2S_DEV_INVALID;
-        const bool pass = v != G2S_DEV_INVALID && (unpruned || lrs_has_kmer<RSG>(rs, rmask, v));
+        const bool pass = v != G2S_DEV_INVALID && (unpruned || lrs_has_kmer(rsg, rs, rmask, v));
         const uint64_t m = __ballot(pass);
         if (pass) {
           const uint32_t off = (uint32_t)__popcll(m & lanes_below(lane));
@@ -631,7 +650,7 @@ __device__ __forceinline__ FillOut fill_lds_body(const uint32_t* __restrict__ su
         //   * the winner of a claim appends the node to the next border, every claimant adds
         //     its count (<= 4 predecessors x <= MAX_PATHS: the u32 sum cannot wrap, :1058-1060).
         auto merge_round = [&](uint32_t v, uint32_t np, uint32_t e) {  // e = position of the expanded border state
-          const bool pass = v != G2S_DEV_INVALID && (unpruned || lrs_has_kmer<RSG>(rs, rmask, v));  // :1050
+          const bool pass = v != G2S_DEV_INVALID && (unpruned || lrs_has_kmer(rsg, rs, rmask, v));  // :1050
           uint32_t h = 0, won = 0;
           if (pass) {
             const uint64_t key = ((uint64_t)(uint32_t)d << 32) | v;
@@ -1260,18 +1279,19 @@ __device__ __forceinline__ void extract_lds_body(const FillOut fo, const GapDev*
       uint32_t *lvl_all, uint32_t *plk_all, uint64_t *xl_all, uint64_t *xo_all, SubRec *sub_scratch, SubRec *sub_out, \
       unsigned long long out_cap, unsigned long long *out_counter, GapOut *outs, GapOut *outs_host,                   \
       uint32_t *done_list, int skip_confident, uint32_t num_oriented
-__global__ __launch_bounds__(64) void g2s_fill_lds(G2S_FUSED_PARAMS, uint32_t fcap) {
-  const FillOut fo = fill_lds_body<false>(succ, ustart, gaps, gap_ids, flank_nodes, log_all, lvl_all, plk_all, xl_all, outs,
-                                          num_oriented, nullptr, fcap);
+__global__ __launch_bounds__(64) void g2s_fill_lds(G2S_FUSED_PARAMS, uint32_t fcap, uint32_t* rs_pool,
+                                                    uint32_t pool_chunks, uint32_t chunk_entries) {
+  const FillOut fo = fill_lds_body(succ, ustart, gaps, gap_ids, flank_nodes, log_all, lvl_all, plk_all, xl_all, outs,
+                                   num_oriented, nullptr, fcap, out_counter + 2, rs_pool, pool_chunks, chunk_entries);
   __threadfence();  // the log, level offsets and links of this gap were written through: read them back from L2
   extract_lds_body(fo, gaps, gap_ids, flank_nodes, log_all, lvl_all, plk_all, xl_all, xo_all, sub_scratch, sub_out,
                    out_cap, out_counter, outs, outs_host, done_list, skip_confident, fcap);
 }
-// Same kernel with the right set in HBM: for gaps whose right set outgrows the LDS (deep
-// DP, -dist-error in the thousands); everything else of the gap stays in LDS.
+// Same kernel with every right set in HBM from the start: for gaps known to outgrow the
+// LDS (deep DP, -dist-error in the thousands); everything else of the gap stays in LDS.
 __global__ __launch_bounds__(64) void g2s_fill_lds_rsg(G2S_FUSED_PARAMS, uint32_t* rs_global, uint32_t fcap) {
-  const FillOut fo = fill_lds_body<true>(succ, ustart, gaps, gap_ids, flank_nodes, log_all, lvl_all, plk_all, xl_all, outs,
-                                         num_oriented, rs_global, fcap);
+  const FillOut fo = fill_lds_body(succ, ustart, gaps, gap_ids, flank_nodes, log_all, lvl_all, plk_all, xl_all, outs,
+                                   num_oriented, rs_global, fcap, out_counter + 2, nullptr, 0u, 0u);
   __threadfence();
   extract_lds_body(fo, gaps, gap_ids, flank_nodes, log_all, lvl_all, plk_all, xl_all, xo_all, sub_scratch, sub_out,
                    out_cap, out_counter, outs, outs_host, done_list, skip_confident, fcap);
@@ -1298,7 +1318,8 @@ hipError_t launch_fill_lds(hipStream_t st, uint32_t ngaps, uint32_t rs_cap_max, 
                            uint64_t* xl_all, uint64_t* xo_all, SubRec* sub_scratch, SubRec* sub_out,
                            unsigned long long out_cap,
                            unsigned long long* out_counter, GapOut* outs, GapOut* outs_host, uint32_t* done_list,
-                           int skip_confident, uint32_t* rs_global, uint32_t fcap) {
+                           int skip_confident, uint32_t* rs_global, uint32_t fcap, uint32_t* rs_pool,
+                           uint32_t pool_chunks, uint32_t chunk_entries) {
   if (ngaps == 0) return hipSuccess;
   const size_t bytes = std::max(fill_lds_bytes(rs_global ? 0 : rs_cap_max, fcap), extract_lds_bytes(fcap));
   if (rs_global) {  // right set in HBM: no LDS for it
@@ -1313,8 +1334,7 @@ hipError_t launch_fill_lds(hipStream_t st, uint32_t ngaps, uint32_t rs_cap_max, 
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(g2s_fill_lds, dim3(ngaps), dim3(64), bytes, st, succ, ustart, gaps, gap_ids, flank_nodes, log_all,
                      lvl_all, plk_all, xl_all, xo_all, sub_scratch, sub_out, out_cap, out_counter, outs, outs_host,
-                     done_list,
-                     skip_confident, num_oriented, fcap);
+                     done_list, skip_confident, num_oriented, fcap, rs_pool, pool_chunks, chunk_entries);
   return hipGetLastError();
 }
 

@@ -428,6 +428,7 @@ struct g2s_session {
   size_t mem_budget = 0;  // bytes of HBM this session may use for work areas
   DevBuf d_gaps, d_ids, d_flank, d_outs, d_rs, d_rlog, d_keys, d_cnt, d_mark, d_slog, d_subscr, d_subout, d_counter;
   DevBuf d_log, d_lvl, d_plk, d_xl, d_xo;  // LDS tier: state log, level offsets, parent links, closure side lists
+  DevBuf d_rspool;                          // LDS tier: spill pool for right sets
   std::vector<void*> tier_pool;  // recycled TierData (pinned host buffers)
   size_t tier_cursor = 0;        // next free slot of tier_pool in the current run
   const void* flank_owner = nullptr;  // batch whose flank nodes d_flank holds
@@ -471,7 +472,7 @@ extern "C" void g2s_session_destroy(g2s_session* s) {
   (void)hipSetDevice(s->device);
   DevBuf* bufs[] = {&s->d_gaps, &s->d_ids, &s->d_flank, &s->d_outs, &s->d_rs, &s->d_rlog, &s->d_keys,
                     &s->d_cnt, &s->d_mark, &s->d_slog, &s->d_subscr, &s->d_subout, &s->d_counter,
-                    &s->d_log, &s->d_lvl, &s->d_plk, &s->d_xl, &s->d_xo};
+                    &s->d_log, &s->d_lvl, &s->d_plk, &s->d_xl, &s->d_xo, &s->d_rspool};
   for (DevBuf* b : bufs) b->release();
   delete s->pool;
   for (void* v : s->tier_pool) { TierData* t = (TierData*)v; t->outs.release(); t->subs.release(); t->done.release(); delete t; }
@@ -707,12 +708,12 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
   HIP_TRY(s->d_outs.ensure(n * sizeof(GapOut)));
   HIP_TRY(s->d_subscr.ensure(slog_total * (lds ? sizeof(SubRec) : sizeof(SubState))));
   if (!lds) HIP_TRY(s->d_subout.ensure(slog_total * sizeof(SubState)));
-  HIP_TRY(s->d_counter.ensure(16));
+  HIP_TRY(s->d_counter.ensure(32));
   hipStream_t st = s->stream;
   HIP_TRY(hipMemcpyAsync(s->d_gaps.p, gd, n * sizeof(GapDev), hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemcpyAsync(s->d_ids.p, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemsetAsync(s->d_outs.p, 0, n * sizeof(GapOut), st));
-  HIP_TRY(hipMemsetAsync(s->d_counter.p, 0, 16, st));  // [0] output cursor, [1] completion-list cursor
+  HIP_TRY(hipMemsetAsync(s->d_counter.p, 0, 32, st));  // [0] output cursor, [1] completion-list cursor, [2] spill-pool cursor
   if (lds) {
     HIP_TRY(s->d_log.ensure(slog_total * 8));
     HIP_TRY(s->d_lvl.ensure(lvl_total * 4));
@@ -736,6 +737,15 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
     HIP_TRY(hipHostGetDevicePointer(&d_outs_host, td->outs.p, 0));
     HIP_TRY(hipHostGetDevicePointer(&d_subs_host, td->subs.p, 0));
     HIP_TRY(hipHostGetDevicePointer(&d_done_host, td->done.p, 0));
+    // spill pool for right sets that outgrow their LDS share (launches with the right set in LDS):
+    // chunks of 32 K entries for an eighth of the gaps
+    const uint32_t chunk_entries = 32768u;
+    uint32_t pool_chunks = 0;
+    if (!rs_in_hbm && lds_cap_max < chunk_entries) {
+      pool_chunks = (uint32_t)std::min<size_t>(ids.size() / 8 + 16, (s->mem_budget / 8) / ((size_t)chunk_entries * 4));
+      HIP_TRY(s->d_rspool.ensure((size_t)pool_chunks * chunk_entries * 4));
+      HIP_TRY(hipMemsetAsync(s->d_rspool.p, 0xFF, (size_t)pool_chunks * chunk_entries * 4, st));
+    }
     HIP_TRY(launch_fill_lds(st, (uint32_t)ids.size(), lds_cap_max, num_oriented, dg.succ, dg.ustart,
                             (const GapDev*)s->d_gaps.p, (const uint32_t*)s->d_ids.p, (const uint32_t*)s->d_flank.p,
                             (uint64_t*)s->d_log.p, (uint32_t*)s->d_lvl.p, (uint32_t*)s->d_plk.p, (uint64_t*)s->d_xl.p,
@@ -743,7 +753,8 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
                             (unsigned long long)out_states,
                             (unsigned long long*)s->d_counter.p, (GapOut*)s->d_outs.p, (GapOut*)d_outs_host,
                             (uint32_t*)d_done_host, s->params.skip_confident ? 1 : 0,
-                            rs_in_hbm ? (uint32_t*)s->d_rs.p : nullptr, fcap));
+                            rs_in_hbm ? (uint32_t*)s->d_rs.p : nullptr, fcap, (uint32_t*)s->d_rspool.p, pool_chunks,
+                            chunk_entries));
     HIP_TRY(hipEventRecord(s->ev[2], st));
     HIP_TRY(hipEventRecord(s->ev[3], st));
   } else {
