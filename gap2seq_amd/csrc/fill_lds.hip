@@ -704,33 +704,44 @@ __device__ __forceinline__ FillOut fill_lds_body(const uint32_t* __restrict__ su
           merge_round(v, np, (uint32_t)lane >> 2);
         } else {
           // wide border: one entry per lane with its whole record in one load (a level costs
-          // one HBM round trip whatever its width); most slots are empty, so the valid
-          // successors of 64 entries are compacted through LDS and merged 64 per round.
+          // one HBM round trip whatever its width).  Nearly every entry has exactly one
+          // successor: the first valid slot of every lane goes through a merge round straight
+          // from the register; only the further slots (branching entries) are compacted
+          // through LDS and merged 64 per round.
           for (uint32_t e0 = 0; e0 < nb && nnew <= F; e0 += 64u) {
             const uint32_t e = e0 + (uint32_t)lane;
             uint4 rec = make_uint4(G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID);
             uint32_t np = 0;
             if (e < nb) { rec = *(const uint4*)(succ + (size_t)ncur[e] * 4); np = ccur[e]; }
             if (np > G2S_DEV_MAX_PATHS) np = G2S_DEV_MAX_PATHS;
+            const uint32_t fq = rec.x != G2S_DEV_INVALID ? 0u : rec.y != G2S_DEV_INVALID ? 1u : rec.z != G2S_DEV_INVALID ? 2u : 3u;
+            const uint32_t first = fq == 0u ? rec.x : fq == 1u ? rec.y : fq == 2u ? rec.z : rec.w;
+            merge_round(first, np, e);
+            if (nnew > F) break;
             uint32_t ncand = 0;
 #pragma unroll
-            for (uint32_t q = 0; q < 4; q++) {
-              const uint32_t v = q == 0 ? rec.x : q == 1 ? rec.y : q == 2 ? rec.z : rec.w;
-              const uint64_t m = __ballot(v != G2S_DEV_INVALID);
-              if (v != G2S_DEV_INVALID) {
-                const uint32_t at = ncand + (uint32_t)__popcll(m & lanes_below(lane));
-                cw_v[at] = v;
-                cw_c[at] = np;
-                cw_e[at] = e;
+            for (uint32_t q = 1; q < 4; q++) {
+              const uint32_t v = q == 1 ? rec.y : q == 2 ? rec.z : rec.w;
+              const bool more = v != G2S_DEV_INVALID && q > fq;
+              const uint64_t m = __ballot(more);
+              if (m) {
+                if (more) {
+                  const uint32_t at = ncand + (uint32_t)__popcll(m & lanes_below(lane));
+                  cw_v[at] = v;
+                  cw_c[at] = np;
+                  cw_e[at] = e;
+                }
+                ncand += (uint32_t)__popcll(m);
               }
-              ncand += (uint32_t)__popcll(m);
             }
-            lds_sync();
-            for (uint32_t c0 = 0; c0 < ncand && nnew <= F; c0 += 64u) {
-              const uint32_t c = c0 + (uint32_t)lane;
-              merge_round(c < ncand ? cw_v[c] : G2S_DEV_INVALID, c < ncand ? cw_c[c] : 0u, c < ncand ? cw_e[c] : 0u);
+            if (ncand) {
+              lds_sync();
+              for (uint32_t c0 = 0; c0 < ncand && nnew <= F; c0 += 64u) {
+                const uint32_t c = c0 + (uint32_t)lane;
+                merge_round(c < ncand ? cw_v[c] : G2S_DEV_INVALID, c < ncand ? cw_c[c] : 0u, c < ncand ? cw_e[c] : 0u);
+              }
+              lds_sync();
             }
-            lds_sync();
           }
         }
       }
