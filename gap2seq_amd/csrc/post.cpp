@@ -121,64 +121,64 @@ void sub_analyze(const FillParams& p, const GapJob& job, const SubView& v, SubPr
   static thread_local std::vector<uint64_t> el;
   static thread_local std::vector<std::pair<int, int>> fe;
   static thread_local VertexMap vm;
-  {
-    lo.assign((size_t)n, -2);  // -2: not on a traceback closure
-    hi.assign((size_t)n, -2);
-    for (int64_t i = (int64_t)n - 1; i >= 0; i--) {
-      const uint32_t sf = FL((uint32_t)i);
-      if (!(sf & G2S_SUB_IN_T)) continue;
-      if (sf & G2S_SUB_SOURCE) { lo[(size_t)i] = hi[(size_t)i] = (int)sub_depth(st[i]); continue; }  // :1455-1462
-      int l = 1 << 30, h = -1;
-      int32_t pr[4];
-      const int np = sub_preds(v, (uint32_t)i, pr);
-      for (int x = 0; x < np; x++) {
-        const int32_t q = pr[x];
-        if (lo[(size_t)q] < 0) { l = -1; h = 1 << 30; } else { l = std::min(l, lo[(size_t)q]); h = std::max(h, hi[(size_t)q]); }
-      }
-      if (np == 0) { lo[(size_t)i] = -1; hi[(size_t)i] = 1 << 30; }  // walk ends here without a stop: not fixed
-      else { lo[(size_t)i] = l; hi[(size_t)i] = h; }
-    }
-    for (uint32_t i = 0; i < n; i++) {
-      if (!(FL(i) & G2S_SUB_START_T)) continue;
-      for (int j = 0; j < go.n_len && j < 2; j++) {
-        if ((int)sub_depth(st[i]) == go.len[j] && out->start_idx[j] < 0) {
-          out->start_idx[j] = (int)i;
-          out->stop_depth[j] = (lo[i] >= 0 && lo[i] == hi[i]) ? lo[i] : -1;
+  // One reverse sweep (states are stored depth-descending, so it sees predecessors first)
+  // collects everything that is per state: stop depths of the traceback closure, vertex ids
+  // of the S closure, out-degrees, edge and sink/source counts.
+  static thread_local std::vector<int> outdeg;
+  const bool want_s = !p.skip_confident;  // no D1/D2 with -all-upper (:1181)
+  lo.assign((size_t)n, -2);  // -2: not on a traceback closure
+  hi.assign((size_t)n, -2);
+  int nverts = 2;
+  uint32_t n_s = 0, n_t_only = 0;
+  int count_s = 0, src_out = 0, sink_in = 0;
+  uint64_t edges = 0;
+  if (want_s) {
+    vm.init(n);
+    vid.assign((size_t)n, -1);
+    outdeg.assign((size_t)n, 0);
+  }
+  for (int64_t i = (int64_t)n - 1; i >= 0; i--) {
+    const SubRec& s = st[i];
+    const uint32_t sf = sub_flags(s);
+    int32_t pr[4];
+    const bool src = (sf & G2S_SUB_SOURCE) != 0;
+    const int np = src ? 0 : sub_preds(v, (uint32_t)i, pr);
+    if (sf & G2S_SUB_IN_T) {
+      if (src) { lo[(size_t)i] = hi[(size_t)i] = (int)sub_depth(s); }  // :1455-1462
+      else if (np == 0) { lo[(size_t)i] = -1; hi[(size_t)i] = 1 << 30; }  // walk ends here without a stop: not fixed
+      else {
+        int l = 1 << 30, h = -1;
+        for (int x = 0; x < np; x++) {
+          const int32_t q = pr[x];
+          if (lo[(size_t)q] < 0) { l = -1; h = 1 << 30; } else { l = std::min(l, lo[(size_t)q]); h = std::max(h, hi[(size_t)q]); }
         }
+        lo[(size_t)i] = l; hi[(size_t)i] = h;
       }
+      if (sf & G2S_SUB_START_T) {
+        for (int j = 0; j < go.n_len && j < 2; j++)
+          if ((int)sub_depth(s) == go.len[j]) {  // the lowest index wins, as in a forward scan
+            out->start_idx[j] = (int)i;
+            out->stop_depth[j] = (lo[(size_t)i] >= 0 && lo[(size_t)i] == hi[(size_t)i]) ? lo[(size_t)i] : -1;
+          }
+      }
+      if (!(sf & G2S_SUB_IN_S)) n_t_only++;
+    }
+    if (want_s && (sf & G2S_SUB_IN_S)) {
+      vid[(size_t)i] = vm.get_or_add(s.node >> 1, &nverts);
+      n_s++;
+      if (sf & G2S_SUB_SINK) { sink_in++; edges++; count_s = sat_add(count_s, (int)s.cnt); }
+      if (src) { src_out++; edges++; }
+      else for (int x = 0; x < np; x++) { outdeg[(size_t)pr[x]]++; edges++; }
     }
   }
-  if (p.skip_confident) return;  // no D1/D2 with -all-upper (:1181)
-
-  // ---- D2 on the S closure: vertices = canonical k-mers (+ sink 0, source 1) ----
-  vm.init(n);
-  int nverts = 2;
-  vid.assign((size_t)n, -1);
-  uint32_t n_s = 0;
-  for (uint32_t i = 0; i < n; i++)
-    if (FL(i) & G2S_SUB_IN_S) { vid[i] = vm.get_or_add(st[i].node >> 1, &nverts); n_s++; }
+  if (!want_s) return;
 
   if ((uint32_t)nverts == n_s + 2) {
     // ---- fast path: every k-mer occurs at exactly one depth of the S closure.  An edge goes
     // from depth d-1 to depth d, so the subgraph is a DAG (a cycle would need a k-mer at two
     // depths), vertices are the states themselves, nothing is contracted, no self loops, and
     // ascending depth (reverse emission order) is a topological order.
-    static thread_local std::vector<int> outdeg;
-    outdeg.assign((size_t)n, 0);
-    int count = 0;
-    uint64_t edges = 0;
-    int src_out = 0, sink_in = 0;
-    for (uint32_t i = 0; i < n; i++) {
-      const SubRec& s = st[i];
-      const uint32_t sf = FL(i);
-      if (!(sf & G2S_SUB_IN_S)) continue;
-      if (sf & G2S_SUB_SINK) { sink_in++; edges++; count = sat_add(count, (int)s.cnt); }
-      if (sf & G2S_SUB_SOURCE) { src_out++; edges++; continue; }
-      int32_t pr[4];
-      const int np = sub_preds(v, i, pr);
-      for (int x = 0; x < np; x++) { outdeg[(size_t)pr[x]]++; edges++; }
-    }
-    if (p.all_paths) out->count = count;
+    if (p.all_paths) out->count = count_s;
     out->sub[0] = (uint64_t)nverts;
     out->sub[1] = edges;
     out->sub[2] = 0;
@@ -192,10 +192,12 @@ void sub_analyze(const FillParams& p, const GapJob& job, const SubView& v, SubPr
     for (int64_t i = (int64_t)n - 1; i >= 0; i--) {
       const uint32_t sf = FL((uint32_t)i);
       if (!(sf & G2S_SUB_IN_S)) continue;
-      int din = 0;
-      int32_t pr[4];
-      if (sf & G2S_SUB_SOURCE) din = 1;
-      else din = sub_preds(v, (uint32_t)i, pr);
+      int din = 1;
+      if (!(sf & G2S_SUB_SOURCE)) {
+        const int32_t pw = st[i].pred;
+        din = pw < 0 ? 0 : 1;
+        if (pw >= 0 && (pw & G2S_SUB_MORE)) { int32_t pr[4]; din = sub_preds(v, (uint32_t)i, pr); }
+      }
       const int dout = outdeg[(size_t)i] + ((sf & G2S_SUB_SINK) ? 1 : 0);
       if (din >= 1 || dout >= 1) {
         if (din > 1) bc -= din - 1;
@@ -206,13 +208,15 @@ void sub_analyze(const FillParams& p, const GapJob& job, const SubView& v, SubPr
     // sink (vertex 0) is last
     bool sink_safe = false;
     if (sink_in >= 1) { if (sink_in > 1) bc -= sink_in - 1; sink_safe = bc == 1; }
-    for (uint32_t i = 0; i < n; i++) {  // traceback states outside the subgraph (Q5)
-      if (!(FL(i) & G2S_SUB_IN_T) || (FL(i) & G2S_SUB_IN_S)) continue;
-      const int vtx = vm.find(st[i].node >> 1);
-      if (vtx < 0) { out->safe[i] = sink_safe; continue; }
-      // its k-mer is in the subgraph at another depth: that vertex's value
-      for (uint32_t q = 0; q < n; q++)
-        if ((FL(q) & G2S_SUB_IN_S) && vid[q] == vtx) { out->safe[i] = out->safe[q]; break; }
+    if (n_t_only) {
+      for (uint32_t i = 0; i < n; i++) {  // traceback states outside the subgraph (Q5)
+        if (!(FL(i) & G2S_SUB_IN_T) || (FL(i) & G2S_SUB_IN_S)) continue;
+        const int vtx = vm.find(st[i].node >> 1);
+        if (vtx < 0) { out->safe[i] = sink_safe; continue; }
+        // its k-mer is in the subgraph at another depth: that vertex's value
+        for (uint32_t q = 0; q < n; q++)
+          if ((FL(q) & G2S_SUB_IN_S) && vid[q] == vtx) { out->safe[i] = out->safe[q]; break; }
+      }
     }
     return;
   }
