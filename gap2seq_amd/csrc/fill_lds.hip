@@ -526,22 +526,36 @@ __device__ __forceinline__ FillOut fill_lds_body(const uint32_t* __restrict__ su
         const uint32_t n = mine ? ncur[r] : 0u;
         uint32_t np = mine ? ccur[r] : 0u;
         if (np > G2S_DEV_MAX_PATHS) np = G2S_DEV_MAX_PATHS;
-        const uint32_t L = (uint32_t)min((int)(64u >> lg), gd.D - d + 1);
         const uint32_t step = 2u * (i + 1u);
         const bool up = (n & 1u) == 0;  // even orientation: successors have larger ids
-        const bool inrange = mine && i < L && (up ? (n + step < num_oriented) : (n >= step));
-        const uint32_t x = up ? n + step - 2u : n - (step - 2u);  // border node of level d+i
-        const uint32_t v = up ? n + step : n - step;               // its speculated successor
-        bool ok = !mine;
-        if (inrange) {
-          uint32_t nt;
-          const uint4 rec = *(const uint4*)(succ + (size_t)x * 4);
-          ok = only_slot(rec, &nt) == v;
-          if (ok && d + (int)i >= gd.prune_from) ok = lrs_has_kmer(rsg, rs, rmask, v);  // :1050
+        const uint32_t v = up ? n + step : n - step;  // state of run r at level d+i
+        // How many more steps does every run stay inside its unitig?  Two words of the
+        // unitig-start bitmap per run (lanes i = 0 and 1; the bitmap lives in L2) instead of
+        // 64/Rp successor records from HBM, and nothing to verify afterwards: inside a
+        // unitig the only successor of v is v +/- 2 and v is its only predecessor.
+        uint32_t rem = 128u;
+        if (mine && i < 2u) {
+          const uint32_t idx = n >> 1, b = idx & 63u;
+          const int64_t w0 = (int64_t)(idx >> 6);
+          if (up) {  // steps until the position before the next unitig start
+            const uint64_t word = ustart[w0 + (int64_t)i];
+            const uint64_t m = i == 1u ? word : (b == 63u ? 0ull : word & (~0ull << (b + 1u)));
+            if (m) rem = (i == 1u ? 64u : 0u) + (uint32_t)__builtin_ctzll(m) - 1u - b;
+          } else {   // steps down to the unitig's own start
+            const uint64_t word = ustart[w0 - (int64_t)i];
+            const uint64_t m = i == 1u ? word : word & (~0ull >> (63u - b));
+            if (m) rem = i == 1u ? b + 1u + (uint32_t)__builtin_clzll(m) : b - (63u - (uint32_t)__builtin_clzll(m));
+          }
         }
-        uint32_t lrun = leading_levels(ok, lg);
+        rem = min(rem, (uint32_t)__shfl_xor((int)rem, (int)Rp));  // the two words of a run (Rp <= 16: lanes < 32)
+        for (uint32_t o = 1; o < Rp; o <<= 1) rem = min(rem, (uint32_t)__shfl_xor((int)rem, (int)o));  // over the runs
+        rem = (uint32_t)__builtin_amdgcn_readfirstlane((int)rem);
+        const uint32_t L = min(min(rem, 64u >> lg), (uint32_t)(gd.D - d + 1));
+        bool ok = !mine;
+        if (mine && i < L) ok = d + (int)i < gd.prune_from || lrs_has_kmer(rsg, rs, rmask, v);  // :1050
+        uint32_t lrun = L ? leading_levels(ok, lg) : 0u;
         if (lrun > L) lrun = L;
-        if (lrun >= (lg == 6u ? 1u : 2u) && nlog + lrun * R <= cap && nhit + 64u <= TH) {
+        if (lrun >= 1u && nlog + lrun * R <= cap && nhit + 64u <= TH) {
           const bool act = mine && i < lrun;
           if (act && R > 1) {
             // Q7: the other strand of my k-mer on another run at this level.  All states of the
