@@ -23,11 +23,11 @@
 // (dbg.hpp): inside a unitig the successor of v is v+2 / v-2.
 //   phase A  searches over unitigs, not levels: an event covers a whole unitig by
 //            arithmetic and inserts it into the right set 64 nodes per instruction;
-//   phase B  takes BULK STEPS: lane i speculates the state of level d+i, verifies it
-//            with one coalesced record load for the whole wave, and up to 64 levels are
-//            committed per iteration (several parallel runs share the lanes
-//            level-major); levels that branch, merge, die or leave a unitig take the
-//            per-level step;
+//   phase B  takes BULK STEPS: the unitig-start bitmap says for how many levels every
+//            border state stays inside its unitig; lane i then holds the state of level
+//            d+i by arithmetic and up to 64 levels are committed per iteration without
+//            touching the graph (several parallel runs share the lanes level-major);
+//            levels that branch, merge, die or leave a unitig take the per-level step;
 //   phase D1 walks the parent links phase B recorded instead of the graph and sweeps
 //            the bulk-produced levels 64 at a time.
 // A gap that does not fit a pass (frontier, right set, label table, target hits, state
@@ -60,14 +60,6 @@ __device__ __forceinline__ uint64_t lanes_below(int lane) { return (1ull << lane
 __device__ __forceinline__ void lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ uint32_t flip(uint32_t v) { return v == G2S_DEV_INVALID ? v : (v ^ 1u); }
 
-// If exactly one slot of the record is valid return it (and its index), else INVALID.
-__device__ __forceinline__ uint32_t only_slot(const uint4 r, uint32_t* nt) {
-  const uint32_t v0 = r.x != G2S_DEV_INVALID, v1 = r.y != G2S_DEV_INVALID, v2 = r.z != G2S_DEV_INVALID,
-                 v3 = r.w != G2S_DEV_INVALID;
-  if (v0 + v1 + v2 + v3 != 1u) return G2S_DEV_INVALID;
-  *nt = v1 * 1u + v2 * 2u + v3 * 3u;
-  return v0 ? r.x : v1 ? r.y : v2 ? r.z : r.w;
-}
 // number of leading lanes (from lane 0) whose predicate holds
 __device__ __forceinline__ uint32_t leading_true(bool p) {
   const uint64_t m = ~__ballot(p);
@@ -511,14 +503,13 @@ __device__ __forceinline__ FillOut fill_lds_body(const uint32_t* __restrict__ su
       uint32_t nnew = 0;
       // ---- bulk step: every border state (<= 16 of them) sits inside a unitig, where the
       // only successor of id v is v+2 (even orientation) or v-2 (odd), see dbg.hpp.
-      // Lanes are level-major: lane = i*Rp + r handles run r at level d+i.  Each lane
-      // speculates its state, verifies it against the graph (one coalesced load of 16 B
-      // records for the whole wave), applies the pruning rule; the leading levels on
-      // which ALL runs hold are appended to the state log at once, and each level's
-      // target check is evaluated by one lane.  Runs stay on distinct (node, depth)
-      // diagonals inside unitigs, so no merging is needed; anything else (branching,
-      // dead end, pruned state, unitig end) stops the bulk and the per-level code below
-      // handles that level.
+      // Lanes are level-major: lane = i*Rp + r holds run r at level d+i, by arithmetic; the
+      // unitig-start bitmap bounds i; the pruning rule is checked per lane; the leading
+      // levels on which ALL runs hold are appended to the state log at once, and each
+      // level's target check is evaluated by one lane.  Runs stay on distinct (node, depth)
+      // diagonals inside unitigs, so no merging is needed; a run at the end of its unitig
+      // (branching, dead end, merge) or a pruned state ends the bulk and the per-level code
+      // below handles that level.
       if (nb >= 1 && nb <= 16 && d > gd.lmf) {
         const uint32_t R = nb, lg = log2ceil16(R), Rp = 1u << lg;
         const uint32_t r = (uint32_t)lane & (Rp - 1u), i = (uint32_t)lane >> lg;
