@@ -379,7 +379,9 @@ __device__ __forceinline__ FillOut fill_lds_body(const uint32_t* __restrict__ su
         uint32_t tmax;
         bool bounded = fm != 0;
         if (bounded) tmax = (uint32_t)__shfl((int)dist, __builtin_ctzll(fm));
-        else tmax = !up ? (idx & 63u) + 64u * (LP - 1u) : (63u - (idx & 63u)) + 64u * (LP - 1u);
+        // (walking up, the bit that ends the unitig is the one AFTER its last node: stop one
+        // short of the window's edge, so that the continuation node's own bit has been seen)
+        else tmax = !up ? (idx & 63u) + 64u * (LP - 1u) : (63u - (idx & 63u)) + 64u * (LP - 1u) - 1u;
         const uint32_t L = mine ? min(tmax, B) + 1u : 0u;  // nodes of the run: offsets 0 .. L-1
         // ---- insert the runs of the group, 64 nodes per round, balanced over the lanes
         uint32_t incl = (jl == 0 && mine) ? L : 0u;  // inclusive prefix of L over the events, in lanes 0..Rp-1

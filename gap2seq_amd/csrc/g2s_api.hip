@@ -6,6 +6,7 @@
 // (/root/reference/src/Gap2Seq.cpp:252,380 -> :858).  No CPU fallback: without a
 // usable gfx950 device every fill entry point fails with G2S_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
+#include <sys/prctl.h>
 #include <pthread.h>
 #include <sched.h>
 #include <time.h>
@@ -495,6 +496,9 @@ struct g2s_batch {
   std::vector<uint32_t> flank_all;  // oriented flank nodes of every gap, as uploaded to d_flank
   int upload_flanks();
   size_t arena_bytes = 0;
+  std::vector<size_t> arena_off;  // of each gap's fill buffer within the batch's share of the arena
+  char* arena = nullptr;          // the batch's share of the caller's fill arena (stage 1 writes the
+  size_t arena_base = 0;          // fills that do not depend on rand() values); base = its offset there
   g2s_timing timing;
   std::vector<TierData*> tiers;
   // stage 1 results (GPU passes + per-gap analysis), consumed by stage 2 (offsets + tracebacks)
@@ -508,7 +512,7 @@ struct g2s_batch {
     int16_t n_len;      // 0: no phase D
     int16_t reached_j;
     uint8_t kind;       // 0 normal, 1 bad flank, 2 -max-mem verdict
-    uint8_t filled;     // count > 0 (&& == 1 with -unique)
+    uint8_t filled;     // bit 0: count > 0 (&& == 1 with -unique); bit 1: fill already written by the analysis
     int16_t skip_thr;   // skip_if_prev_right_fuz_gt clamped to int16 (-1: never skip)
   };
   std::vector<GapInfo> info;
@@ -579,6 +583,7 @@ extern "C" int g2s_batch_prepare(g2s_session* s, const g2s_gap* gaps, size_t n, 
     if (!j.bad_flank) b->timing.flank_bytes += (uint64_t)(j.left.size() + j.right.size());
     b->flank_off[i] = (uint32_t)flank_all.size();
     flank_all.insert(flank_all.end(), j.flank_nodes.begin(), j.flank_nodes.end());
+    b->arena_off.push_back(b->arena_bytes);
     b->arena_bytes += j.buf_bytes(k, d_err);
   }
   const int rc = b->upload_flanks();
@@ -799,6 +804,9 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
       // numbers; once arrivals dry up — the stragglers — whatever is there goes out at once,
       // so that next to nothing is left when the last gap finishes
       const size_t chunk = std::max<size_t>(32, total / 8);
+      // the naps below are a few microseconds; the default timer slack (50 us) would stretch them
+      const int old_slack = prctl(PR_GET_TIMERSLACK, 0, 0, 0, 0);
+      prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0);
       auto last_arrival = std::chrono::steady_clock::now();
       double dbg_first = -1, dbg_fin = -1;
       while (given < total) {
@@ -823,6 +831,7 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
           nanosleep(&ts, nullptr);
         }
       }
+      prctl(PR_SET_TIMERSLACK, old_slack > 0 ? (unsigned long)old_slack : 50000UL, 0, 0, 0);
       if (getenv("G2S_DEBUG"))
         fprintf(stderr, "[g2s] run_tier: first gap seen %.3f ms after the launch call, kernel seen finished at %.3f ms\n", dbg_first, dbg_fin);
     }
@@ -909,6 +918,16 @@ void analyze_gap(g2s_batch* b, size_t i, const FillParams& fp, g2s_result* r) {
     gi.n_len = (int16_t)v.out->n_len;
     gi.reached_j = (int16_t)v.out->reached_j;
     for (int q = 0; q < v.out->n_len && q < 2; q++) gi.fixed[q] = sub_fixed_draws(v, pp, q);
+    // One path length and no state with a second parent: every rand() % 1 of the traceback is
+    // 0, so the fill does not depend on where the gap's draws start in the stream.  Write it
+    // now (under the kernels); the in-order pass only adds up the draw count.
+    if (b->arena && v.out->n_len == 1 && v.n_xp == 0 && gi.fixed[0] >= 0) {
+      sub_traceback(*b->s->graph->g, fp, j, v, pp, nullptr, b->arena + b->arena_off[i], r);
+      if (r->draws != gi.fixed[0]) r->flags |= G2S_GAP_BACKTRACE_FAIL;  // cannot happen: the draw count was proven fixed
+      r->fill_off = (uint64_t)(b->arena_base + b->arena_off[i]) + (uint64_t)(j.lmf - r->left_fuz);
+      r->fill_len = (int32_t)strlen(b->arena + b->arena_off[i] + (j.lmf - r->left_fuz));
+      gi.filled |= 2;
+    }
   }
 }
 
@@ -1055,9 +1074,10 @@ int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
         return outs[a].stat[4] + outs[a].stat[5] + outs[a].stat[7] > outs[c].stat[4] + outs[c].stat[5] + outs[c].stat[7]; });
       for (size_t q = 0; q < ord.size() && q < 4; q++) {
         const GapOut& o = outs[ord[q]];
-        fprintf(stderr, "[g2s] pass %d slow gap %u: g %d | A per-level %u bulk %u kcyc %u | B per-level %u bulk %u kcyc %u | D1 per-level %u bulk %u kcyc %u | xA %u xB %u xD %u\n",
+        fprintf(stderr, "[g2s] pass %d slow gap %u: g %d | A per-level %u bulk %u kcyc %u | B per-level %u bulk %u kcyc %u | D1 per-level %u bulk %u kcyc %u | xA %u xB %u xD %u | right set %u states %u final_d %d top level %u flags %#x count %d\n",
                 pass, ord[q], b->jobs[ord[q]].g, o.stat[0], o.stat[1], o.stat[4] >> 2, o.stat[2], o.stat[3], o.stat[5] >> 2,
-                o.stat[6] & 0xFFFF, o.stat[6] >> 16, o.stat[7] >> 2, o.x_right, o.x_left, o.x_sub);
+                o.stat[6] & 0xFFFF, o.stat[6] >> 16, o.stat[7] >> 2, o.x_right, o.x_left, o.x_sub, o.n_right, o.n_states,
+                o.final_d, o.top_level, o.flags, o.c_count);
       }
     }
   }
@@ -1188,7 +1208,8 @@ int batches_stage2(const std::vector<g2s_batch*>& bs, g2s_session* lead, g2s_res
   const size_t per = 8, nchunks = (n + per - 1) / per;
   std::atomic<uint64_t> fill_bytes(0);
   double ms_order = 0, ms_order_loop = 0, ms_ana = 0;
-  size_t n_inline = 0, n_two = 0;
+  size_t n_inline = 0, n_two = 0, n_rest = 0;
+  bool serial = false;
   size_t draws_used = 0;
 
   size_t draws_total = 0;
@@ -1212,6 +1233,7 @@ int batches_stage2(const std::vector<g2s_batch*>& bs, g2s_session* lead, g2s_res
         g2s_result& r = results[gi];  // the gap is not attempted at all (:369)
         memset(&r, 0, sizeof r);
         r.flags = G2S_GAP_SKIPPED;
+        if (in.filled & 2) memset(arena + arena_off[gi], 0, b->jobs[i].buf_bytes(g.k, fp.d_err));
         prev_filled = false;
         continue;
       }
@@ -1223,8 +1245,9 @@ int batches_stage2(const std::vector<g2s_batch*>& bs, g2s_session* lead, g2s_res
         const int pick = in.n_len > 1 ? (int)(lead->rcache.at_const(draws_total) % in.n_len) : 0;
         int draws = in.fixed[pick];
         n_two += in.n_len > 1;
+        if (draws >= 0 && !(in.filled & 2) && serial) draws = -1;  // few gaps left to trace: no pool round for them
         if (draws >= 0) {
-          todo_tb[gi] = 1;
+          todo_tb[gi] = !(in.filled & 2);
           right_fuz = in.reached_j;
         } else {
           n_inline++;
@@ -1237,7 +1260,7 @@ int batches_stage2(const std::vector<g2s_batch*>& bs, g2s_session* lead, g2s_res
         }
         draws_total += (size_t)draws;
       }
-      prev_filled = in.filled != 0;
+      prev_filled = (in.filled & 1) != 0;
       prev_right_fuz = right_fuz;
     }
     grow_rands(draws_total + 1);
@@ -1254,8 +1277,15 @@ int batches_stage2(const std::vector<g2s_batch*>& bs, g2s_session* lead, g2s_res
     });
   ms_ana = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
   // The in-order pass and the tracebacks are pipelined over segments of the gap list: while
-  // the pool traces segment s, this thread assigns the offsets of segment s+1.
-  const size_t nseg = n >= 256 ? std::min<size_t>(8, n / 128) : 1;
+  // the pool traces segment s, this thread assigns the offsets of segment s+1.  When the
+  // analysis has already written most fills, the few that are left are traced by the
+  // in-order pass itself: waking the pool costs more than they do.
+  for (size_t gi = 0; gi < n; gi++) {
+    const g2s_batch::GapInfo& in = owner[gi]->info[local[gi]];
+    n_rest += in.kind == 0 && in.n_len > 0 && !(in.filled & 2);
+  }
+  serial = n_rest <= 64;
+  const size_t nseg = serial ? 1 : (n >= 256 ? std::min<size_t>(8, n / 128) : 1);
   std::vector<std::function<void(size_t)>> jobs(nseg);
   for (size_t sg = 0; sg < nseg; sg++) {
     const size_t g_lo = n * sg / nseg, g_hi = n * (sg + 1) / nseg;
@@ -1266,6 +1296,10 @@ int batches_stage2(const std::vector<g2s_batch*>& bs, g2s_session* lead, g2s_res
       for (size_t gi = g_lo + c * per; gi < std::min(g_hi, g_lo + (c + 1) * per); gi++) {
         g2s_result& r = results[gi];
         const GapJob& j = owner[gi]->jobs[local[gi]];
+        if ((owner[gi]->info[local[gi]].filled & 2) && (r.flags & G2S_GAP_PHASE_D)) {  // written by the analysis
+          bytes += (uint64_t)r.fill_len;
+          continue;
+        }
         r.fill_off = (uint64_t)arena_off[gi] + (uint64_t)j.lmf;
         if (todo_tb[gi]) {
           const g2s_batch* b = owner[gi];
@@ -1284,16 +1318,20 @@ int batches_stage2(const std::vector<g2s_batch*>& bs, g2s_session* lead, g2s_res
       }
       if (bytes) fill_bytes.fetch_add(bytes);
     };
-    lead->pool->post((g_hi - g_lo + per - 1) / per, jobs[sg]);
-    jobs_in_flight = true;
+    if (serial) {
+      for (size_t c = 0; c < (g_hi - g_lo + per - 1) / per; c++) jobs[sg](c);
+    } else {
+      lead->pool->post((g_hi - g_lo + per - 1) / per, jobs[sg]);
+      jobs_in_flight = true;
+    }
   }
   if (jobs_in_flight) lead->pool->finish();
   lead->rcache.consume(draws_used);
   auto t_end = std::chrono::steady_clock::now();
   if (getenv("G2S_DEBUG"))
-    fprintf(stderr, "[g2s] host stage 2 (%s analysis): %.3f ms = setup+analysis %.3f + in-order pass %.3f (loop %.3f; %zu gaps traced inline, %zu with two lengths) + tracebacks\n",
+    fprintf(stderr, "[g2s] host stage 2 (%s analysis): %.3f ms = setup+analysis %.3f + in-order pass %.3f (loop %.3f; %zu gaps traced inline, %zu with two lengths, %zu not traced by the analysis) + tracebacks\n",
             analyze ? "with" : "after", std::chrono::duration<double, std::milli>(t_end - t_begin).count(), ms_ana, ms_order,
-            ms_order_loop, n_inline, n_two);
+            ms_order_loop, n_inline, n_two, n_rest);
   if (timing) {
     timing->fill_bytes += fill_bytes.load();
     timing->ms_host_post += std::chrono::duration<double, std::milli>(t_end - t_begin).count();
@@ -1324,6 +1362,8 @@ extern "C" int g2s_batch_run(g2s_batch* b, g2s_result* results, char* arena, siz
     rand_need += (size_t)(b->jobs[i].g + s->graph->g->k + b->jobs[i].lmf + b->jobs[i].rmf + 2);
   std::thread rand_fill([s, rand_need]() { s->rcache.ensure(rand_need); });
   s->tier_cursor = 0;
+  b->arena = arena;
+  b->arena_base = 0;
   int rc = batch_stage1(b, true, results);
   rand_fill.join();
   if (rc == G2S_OK) rc = batches_stage2(std::vector<g2s_batch*>{b}, s, results, arena, &b->timing, false);
@@ -1358,6 +1398,11 @@ extern "C" int g2s_team_fill(g2s_session* const* sessions, int nsessions, const 
     memset(arena, 0, need);
   }
   std::thread rand_fill([lead, gaps, n]() { lead->rcache.ensure(rand_need_of(gaps, n, lead->graph->g->k)); });
+  std::vector<size_t> group_arena(ngroups + 1, 0);  // where each group's fill buffers start
+  for (size_t gi = 0; gi < ngroups; gi++) {
+    const size_t off = gi * group_size, cnt = std::min(group_size, n - off);
+    group_arena[gi + 1] = group_arena[gi] + g2s_team_arena_bytes(lead, gaps + off, cnt);
+  }
   auto worker = [&](int t) {
     g2s_session* s = sessions[t];
     s->tier_cursor = 0;
@@ -1369,7 +1414,12 @@ extern "C" int g2s_team_fill(g2s_session* const* sessions, int nsessions, const 
       auto t0 = std::chrono::steady_clock::now();
       int rc = g2s_batch_prepare(s, gaps + off, cnt, &b);
       auto t1 = std::chrono::steady_clock::now();
-      if (rc == G2S_OK) { subs[gi] = b; rc = batch_stage1(b, true, results + off); }
+      if (rc == G2S_OK) {
+        subs[gi] = b;
+        b->arena = arena + group_arena[gi];
+        b->arena_base = group_arena[gi];
+        rc = batch_stage1(b, true, results + off);
+      }
       if (getenv("G2S_DEBUG"))
         fprintf(stderr, "[g2s] team session %d group %zu (%zu gaps): prepare %.3f ms, stage 1 %.3f ms\n", t, gi, cnt,
                 std::chrono::duration<double, std::milli>(t1 - t0).count(),
@@ -1524,6 +1574,51 @@ extern "C" int g2s_test_post_gap(const g2s_graph* gh, const g2s_params* p, const
     res->fill_len = (int32_t)strlen(buf + res->fill_off);
   }
   return G2S_OK;
+}
+
+extern "C" int64_t g2s_graph_validate(const g2s_graph* gr, char* msg, size_t msg_cap) {
+  if (!gr || !gr->g) return -1;
+  const Graph& g = *gr->g;
+  std::string text;
+  int64_t bad = 0;
+  auto note = [&](const char* what, uint64_t i) {
+    if (bad++ < 8) text += std::string(what) + " at k-mer " + std::to_string(i) + "; ";
+  };
+  auto only = [&](uint32_t v, uint32_t want) {  // the single valid successor of v is `want`
+    int cnt = 0;
+    bool hit = false;
+    for (int nt = 0; nt < 4; nt++) {
+      const uint32_t w = g.succ_of(v, nt);
+      if (w == kInvalidNode) continue;
+      cnt++;
+      hit = hit || w == want;
+    }
+    return cnt == 1 && hit;
+  };
+  uint64_t starts = 0;
+  for (uint64_t i = 0; i < g.n; i++) {
+    const bool start = (g.ustart[i >> 6] >> (i & 63)) & 1;
+    starts += start;
+    if (i == 0) { if (!start) note("first k-mer is not a unitig start", i); continue; }
+    if (start) continue;
+    const uint32_t a = (uint32_t)(2 * (i - 1)), b = (uint32_t)(2 * i);
+    if (!only(a, b)) note("internal edge is not the only successor (even orientation)", i);
+    if (!only(b ^ 1u, a ^ 1u)) note("internal edge is not the only successor (odd orientation)", i);
+  }
+  if (starts != g.n_unitigs) note("bitmap population differs from the unitig count", starts);
+  for (uint64_t v = 0; v < 2 * g.n; v++)
+    for (int nt = 0; nt < 4; nt++) {
+      const uint32_t w = g.succ_of((uint32_t)v, nt);
+      if (w == kInvalidNode) continue;
+      if (w >= 2 * g.n) { note("successor out of range", v >> 1); continue; }
+      if (g.lastnt[w] != nt) note("last base of a successor differs from its slot", v >> 1);
+    }
+  if (msg && msg_cap) {
+    const size_t c = std::min(text.size(), msg_cap - 1);
+    memcpy(msg, text.data(), c);
+    msg[c] = 0;
+  }
+  return bad;
 }
 
 extern "C" int g2s_test_worker_pool(int32_t threads, int32_t rounds, int32_t n) {

@@ -325,7 +325,9 @@ void sub_traceback(const Graph& g, const FillParams& p, const GapJob& job, const
   res->right_fuz = go.reached_j;  // :1171
   res->flags |= G2S_GAP_PHASE_D;
   int draws = 0;
-  const int pick = (int)((rands[draws++] >> 1) % (uint32_t)go.n_len);  // :1440
+  // rands == nullptr: the caller knows that every draw is taken modulo 1
+  auto draw = [&]() -> uint32_t { const uint32_t r = rands ? rands[draws] : 0u; draws++; return r; };
+  const int pick = (int)((draw() >> 1) % (uint32_t)go.n_len);  // :1440
   int d2 = go.len[pick];
   int last_solid = d2;
   int i = prep.start_idx[pick];
@@ -356,7 +358,7 @@ void sub_traceback(const Graph& g, const FillParams& p, const GapJob& job, const
         res->count = 0;
         break;
       }
-      i = back[(rands[draws++] >> 1) % (uint32_t)nb];  // :1513
+      i = back[(draw() >> 1) % (uint32_t)nb];  // :1513
     }
     d2--;
   }

@@ -111,6 +111,7 @@ _SIGS = {
                                  C.POINTER(_VP)]),
     "g2s_test_rand_stream": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_int32)]),
     "g2s_test_worker_pool": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
+    "g2s_graph_validate": (C.c_int64, [C.c_void_p, C.c_char_p, C.c_size_t]),
     "g2s_test_post_gap": (C.c_int, [_VP, C.POINTER(g2s_params), C.POINTER(g2s_gap), C.c_int32,
                                     C.POINTER(C.c_uint32), C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.c_int32,
                                     C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_uint32, C.c_uint32,
@@ -219,6 +220,12 @@ class Graph:
     @property
     def num_unitigs(self):
         return load_library().g2s_graph_num_unitigs(self.h)
+
+    def validate(self):
+        """(violations, text): bitmap / successor table / last-base table consistency (test hook)."""
+        buf = C.create_string_buffer(2048)
+        n = load_library().g2s_graph_validate(self.h, buf, 2048)
+        return n, buf.value.decode()
 
     def node(self, kmer):
         return load_library().g2s_graph_node(self.h, kmer.encode("ascii"))

@@ -261,6 +261,13 @@ int g2s_test_rand_stream(uint32_t seed, uint32_t skip, uint32_t n, int32_t* out)
  * sum); returns G2S_OK when every task of every round ran exactly once. */
 int g2s_test_worker_pool(int32_t threads, int32_t rounds, int32_t n);
 
+/* TEST HOOK: checks the invariants the kernels rely on between the unitig-start bitmap and
+ * the successor table (every edge the bitmap calls unitig-internal is the only edge out of
+ * its source and the only edge into its target, in both orientations; the last-base table
+ * agrees with the successor slots).  Returns the number of violations found (0 = consistent)
+ * and describes the first few in msg (NUL-terminated, at most msg_cap bytes). */
+int64_t g2s_graph_validate(const g2s_graph* g, char* msg, size_t msg_cap);
+
 /* Number of usable gfx950 devices (0 when none / no driver). */
 int g2s_device_count(void);
 

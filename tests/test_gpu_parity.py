@@ -581,3 +581,24 @@ def test_cli_binary_is_a_drop_in(product, oracle, tmp_path):
     assert res.returncode == 0, res.stdout + res.stderr
     assert out.read_text() == outs["cpu"][0]
     assert res.stdout.replace(str(out), "OUT") == outs["cpu"][1]
+
+
+def _fuzz_regressions():
+    return json.load(open(os.path.join(HERE, "golden", "fuzz_regressions.json")))
+
+
+@pytest.mark.parametrize("idx", range(len(_fuzz_regressions())))
+def test_fuzz_regressions(product, oracle, idx, monkeypatch):
+    """Configurations on which tools/fuzz_parity.py (random graphs and parameters, GPU path
+    against the oracle) once found a difference; `why` in the fixture names the cause."""
+    cfg = _fuzz_regressions()[idx]
+    k = cfg["k"]
+    seqs = cases.toy_genome(cfg["gseed"], cfg["length"], k, repeats=cfg["repeats"], tandem=cfg["tandem"],
+                            inverted=cfg["inverted"], snp_every=cfg["snp_every"])
+    gaps = cases.cut_gaps(cfg["cseed"], seqs[0], k, fuz=cfg["fuz"], ngaps=cfg["ngaps"], min_len=cfg["min_len"],
+                          max_len=cfg["max_len"], d_err=cfg["d_err"])
+    if cfg["hbm_tier"]:
+        monkeypatch.setenv("G2S_NO_LDS_TIER", "1")
+    c, f, _, _, _ = _check_batch(product, oracle, seqs, k, gaps, cfg["d_err"], cfg["skip"], cfg["allp"],
+                                 seed=cfg["randseed"])
+    assert c > 0.8 * len(gaps) and f > 0

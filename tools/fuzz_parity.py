@@ -1,0 +1,152 @@
+#!/usr/bin/env python3
+"""Differential campaign on an MI355X: random graphs, gap lists and parameters, the HIP
+fill path (through the C ABI) against the CPU oracle, gap by gap and bit-exact (the same
+comparison as tests/test_gpu_parity.py::_check_batch).  Not part of the test suite: run
+it on the GPU box for as long as the budget allows,
+
+    python tools/fuzz_parity.py --seconds 600 --seed 1 > gpurun_out/fuzz.log
+
+Every failing configuration is printed as one JSON line that reproduces it
+(`--replay "$(cat cfg.json)"`); the exit code is the number of failing configurations (max 100).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import traceback
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import cases  # noqa: E402
+import oracle_lib  # noqa: E402
+import test_gpu_parity as tp  # noqa: E402
+from gap2seq_amd import lib as product  # noqa: E402
+
+
+def draw(rng):
+    k = rng.choice([9, 11, 13, 15, 21, 25, 31, 31, 31, 33, 41, 55, 63, 16, 32])
+    length = rng.choice([2000, 5000, 20000, 60000, 200000])
+    dens = rng.choice([0, 1, 1, 3, 8])  # structures per 10 kbp
+    units = max(1, length // 10000)
+    cfg = dict(
+        k=k, length=length,
+        repeats=dens * units * rng.randint(0, 2), tandem=dens * units * rng.randint(0, 1) // 2,
+        inverted=rng.choice([0, 0, 0, 1, 2]) * (1 if dens else 0),
+        snp_every=rng.choice([0, 0, 37, 83, 211, 500, 1000]),
+        fuz=rng.choice([0, 1, 3, 10, 10, 10, 15, 20]),
+        d_err=rng.choice([k, 50, 200, 500, 500, 1000]),
+        ngaps=rng.choice([20, 100, 300, 600]),
+        min_len=rng.choice([1, 20, 200]), max_len=rng.choice([60, 300, 1000, 1500]),
+        skip=rng.random() < 0.15, allp=rng.random() < 0.75, randseed=rng.randint(1, 1 << 20),
+        hbm_tier=rng.random() < 0.15, gseed=rng.randint(0, 1 << 30), cseed=rng.randint(0, 1 << 30),
+    )
+    if k <= 13:  # 4^k is small: the graph of a long genome is a tangle, every gap costs the oracle seconds
+        cfg["length"] = min(length, 2000 if k == 9 else 5000)
+        cfg["d_err"] = min(cfg["d_err"], 200)
+        cfg["ngaps"] = min(cfg["ngaps"], 60)
+        cfg["max_len"] = min(cfg["max_len"], 300)
+        cfg["repeats"] = min(cfg["repeats"], 4)
+        cfg["tandem"] = min(cfg["tandem"], 2)
+        length = cfg["length"]
+    cfg["max_len"] = max(cfg["max_len"], cfg["min_len"] + 1)
+    cfg["max_len"] = min(cfg["max_len"], length // 4)
+    cfg["min_len"] = min(cfg["min_len"], cfg["max_len"] - 1)
+    return cfg
+
+
+def run(cfg):
+    k = cfg["k"]
+    seqs = cases.toy_genome(cfg["gseed"], cfg["length"], k, repeats=cfg["repeats"], tandem=cfg["tandem"],
+                            inverted=cfg["inverted"], snp_every=cfg["snp_every"])
+    gaps = cases.cut_gaps(cfg["cseed"], seqs[0], k, fuz=cfg["fuz"], ngaps=cfg["ngaps"], min_len=cfg["min_len"],
+                          max_len=cfg["max_len"], d_err=cfg["d_err"])
+    if cfg["hbm_tier"]:
+        os.environ["G2S_NO_LDS_TIER"] = "1"
+    else:
+        os.environ.pop("G2S_NO_LDS_TIER", None)
+    return tp._check_batch(product, oracle_lib, seqs, k, gaps, cfg["d_err"], cfg["skip"], cfg["allp"],
+                           seed=cfg["randseed"])
+
+
+def explain(cfg):
+    """The comparison of _check_batch again, printing every field that differs."""
+    k = cfg["k"]
+    seqs = cases.toy_genome(cfg["gseed"], cfg["length"], k, repeats=cfg["repeats"], tandem=cfg["tandem"],
+                            inverted=cfg["inverted"], snp_every=cfg["snp_every"])
+    gaps = cases.cut_gaps(cfg["cseed"], seqs[0], k, fuz=cfg["fuz"], ngaps=cfg["ngaps"], min_len=cfg["min_len"],
+                          max_len=cfg["max_len"], d_err=cfg["d_err"])
+    if cfg["hbm_tier"]:
+        os.environ["G2S_NO_LDS_TIER"] = "1"
+    if os.environ.get("G2S_FUZZ_ONLY"):  # indices of the gaps to keep (the rand() stream then differs, counts do not)
+        gaps = [gaps[int(x)] for x in os.environ["G2S_FUZZ_ONLY"].split(",")]
+    og = oracle_lib.OracleGraph(seqs, k, 1)
+    pg = product.Graph.from_seqs(seqs, k, 1)
+    sess = product.Session(pg, 0, d_err=cfg["d_err"], skip_confident=cfg["skip"], all_paths=cfg["allp"],
+                           randseed=cfg["randseed"])
+    res, _ = sess.fill_batch(tp._gaps(product, gaps), True)
+    rng = oracle_lib.OracleRng(cfg["randseed"])
+    for i, (g, r) in enumerate(zip(gaps, res)):
+        o = oracle_lib.fill_gap(og, rng, g["left"], g["right"], g["gap_len"], cfg["d_err"], g["lmf"], g["rmf"],
+                                cfg["skip"], cfg["allp"])
+        q7 = bool(o.info.q7), bool(r.flags & product.G2S_GAP_Q7)
+        diffs = []
+        if q7[0] and not q7[1]:
+            diffs.append("oracle q7, gpu not")
+        if not (q7[0] or q7[1]):
+            for name, a, b in (("count", r.count, o.count), ("phaseC", r.phaseC_count, o.info.phaseC_count),
+                               ("lengths", r.lengths, o.lengths), ("draws", r.draws, o.info.draws)):
+                if a != b:
+                    diffs.append(f"{name}: gpu {a} oracle {b}")
+            if o.phase_d:
+                if (r.left_fuz, r.right_fuz) != (o.left_fuz, o.right_fuz):
+                    diffs.append(f"fuz: gpu {(r.left_fuz, r.right_fuz)} oracle {(o.left_fuz, o.right_fuz)}")
+                if r.fill != o.fill:
+                    pos = next((x for x in range(min(len(r.fill), len(o.fill))) if r.fill[x] != o.fill[x]), -1)
+                    diffs.append(f"fill differs at {pos} (len gpu {len(r.fill)} oracle {len(o.fill)}): "
+                                 f"gpu ..{r.fill[max(0, pos - 5):pos + 10]} oracle ..{o.fill[max(0, pos - 5):pos + 10]}")
+                if not cfg["skip"] and r.substats != o.substats:
+                    diffs.append(f"substats: gpu {r.substats} oracle {o.substats}")
+        elif o.info.draws != r.draws:
+            print(f"gap {i}: q7 {q7}, draws differ (gpu {r.draws} oracle {o.info.draws}): stream diverged, stop")
+            break
+        if diffs:
+            print(f"gap {i} (g {g['gap_len']} lmf {g['lmf']} rmf {g['rmf']} flags {r.flags:#x}): " + "; ".join(diffs))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=300)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--replay", default=None)
+    a = ap.parse_args()
+    oracle_lib.lib()
+    product.load_library()
+    if a.replay:
+        explain(json.loads(a.replay))
+        return 0
+    rng = cases.SplitMix(a.seed * 1000003 + 17)
+    t_end = time.time() + a.seconds
+    n = bad = compared = filled = 0
+    while time.time() < t_end and bad < 100:
+        cfg = draw(rng)
+        n += 1
+        try:
+            c, f = run(cfg)[:2]
+            compared += c
+            filled += f
+        except Exception as ex:  # noqa: BLE001 (report and go on)
+            bad += 1
+            print("FAIL " + json.dumps(cfg), flush=True)
+            print("     " + "".join(traceback.format_exception_only(type(ex), ex)).strip()[:600], flush=True)
+        if n % 50 == 0:
+            print(f"# {n} configurations, {compared} gaps compared ({filled} filled), {bad} failing", flush=True)
+    print(f"# done: {n} configurations, {compared} gaps compared ({filled} filled), {bad} failing", flush=True)
+    return bad
+
+
+if __name__ == "__main__":
+    sys.exit(main())
