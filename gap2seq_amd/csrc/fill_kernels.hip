@@ -140,13 +140,16 @@ __global__ __launch_bounds__(64) void g2s_right_bfs(const uint32_t* __restrict__
       if (i < nb * 4u) {
         const uint32_t n = ld32(&log[bstart + (i >> 2)]);
         const uint32_t nt = i & 3u;
-        if (nt == 0 && rs_contains<true>(tab, mask, n ^ 1u)) flags |= G2S_DEV_Q7_A;
         // graph.predecessors(n) in GATB order: pred(v)[i] = succ(v^1)[i]^1
         p = predtab ? predtab[(size_t)n * 4 + nt] : flip(succ[(size_t)(n ^ 1u) * 4 + nt]);
         if (p != G2S_DEV_INVALID) {
           const int r = rs_insert(tab, mask, p);
           isnew = (r == 1);
           if (r == 2) flags |= G2S_DEV_OVERFLOW_A;
+          // Q7: both strands of a k-mer in the set (a superset of "in one border").  Checked
+          // by whoever comes second; two lanes inserting the pair in one instruction both look
+          // after both inserts.
+          if (isnew && rs_contains<true>(tab, mask, p ^ 1u)) flags |= G2S_DEV_Q7_A;
         }
       }
       const uint64_t m = __ballot(isnew);
@@ -164,7 +167,10 @@ __global__ __launch_bounds__(64) void g2s_right_bfs(const uint32_t* __restrict__
       const uint32_t s = rseeds[d];
       if (s != G2S_DEV_INVALID) {
         int r = 0;
-        if (lane == 0) r = rs_insert(tab, mask, s);
+        if (lane == 0) {
+          r = rs_insert(tab, mask, s);
+          if (r == 1 && rs_contains<true>(tab, mask, s ^ 1u)) flags |= G2S_DEV_Q7_A;
+        }
         r = __shfl(r, 0);
         if (r == 1) {
           if (nlog < cap) { if (lane == 0) log[nlog] = s; } else overflow = true;
@@ -245,7 +251,6 @@ __global__ __launch_bounds__(64) void g2s_left_dp(const uint32_t* __restrict__ s
         const uint32_t nt = i & 3u;
         uint32_t np = ld32(&cnt[pos]);  // num_paths of the parent, saturated (:1047)
         if (np > G2S_DEV_MAX_PATHS) np = G2S_DEV_MAX_PATHS;
-        if (nt == 0 && st_find(keys, smask, state_key(n ^ 1u, d - 1)) != G2S_DEV_INVALID) lflags |= G2S_DEV_Q7_B;
         const uint32_t v = succ[(size_t)n * 4 + nt];  // graph.successors(n), GATB order
         if (v != G2S_DEV_INVALID &&
             (unpruned || rs_contains<false>(rs, rmask, v) || rs_contains<false>(rs, rmask, v ^ 1u))) {
@@ -253,6 +258,9 @@ __global__ __launch_bounds__(64) void g2s_left_dp(const uint32_t* __restrict__ s
           // <= 4 predecessors, each <= MAX_PATHS < 2^30: the u32 sum cannot wrap;
           // min(MAX, .) on read equals the reference's saturating adds (:1058-1060)
           if (pos2 != G2S_DEV_INVALID) atomicAdd(&cnt[pos2], np); else lflags |= G2S_DEV_OVERFLOW_B;
+          // Q7: the other strand of this k-mer at the same level, the last level included
+          // (seen by whichever of the two states is set second, or by both)
+          if (isnew && st_find(keys, smask, state_key(v ^ 1u, d)) != G2S_DEV_INVALID) lflags |= G2S_DEV_Q7_B;
         }
       }
       const uint64_t m = __ballot(isnew);
@@ -274,6 +282,7 @@ __global__ __launch_bounds__(64) void g2s_left_dp(const uint32_t* __restrict__ s
         if (lane == 0) {
           pos = st_insert(keys, smask, state_key(s, d), &isnew);
           if (pos != G2S_DEV_INVALID) atomicExch(&cnt[pos], 1u);
+          if (isnew && st_find(keys, smask, state_key(s ^ 1u, d)) != G2S_DEV_INVALID) lflags |= G2S_DEV_Q7_B;
         }
         isnew = __shfl(isnew, 0);
         pos = __shfl(pos, 0);
