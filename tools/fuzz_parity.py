@@ -27,7 +27,27 @@ import test_gpu_parity as tp  # noqa: E402
 from gap2seq_amd import lib as product  # noqa: E402
 
 
-def draw(rng):
+def draw_big(rng):
+    """Long gap lists and deep gaps: small LDS shares, the right-set spill pool, passes 1 and 2,
+    gaps that start in a later pass, the HBM tier as the last resort."""
+    length = rng.choice([300000, 1000000])
+    units = length // 10000
+    deep = rng.random() < 0.4
+    return dict(
+        k=rng.choice([31, 31, 21, 41]), length=length, repeats=units * rng.randint(0, 3), tandem=units * rng.randint(0, 1),
+        inverted=0, snp_every=rng.choice([0, 211, 500, 1000]), fuz=rng.choice([10, 10, 20]),
+        d_err=rng.choice([1000, 2000]) if deep else rng.choice([200, 500, 1000]),
+        ngaps=rng.choice([200, 600]) if deep else rng.choice([1500, 4000]),
+        min_len=rng.choice([1, 200, 1000]) if deep else rng.choice([1, 200]),
+        max_len=rng.choice([2000, 5000]) if deep else rng.choice([300, 1000]),
+        skip=rng.random() < 0.1, allp=rng.random() < 0.8, randseed=rng.randint(1, 1 << 20),
+        hbm_tier=False, gseed=rng.randint(0, 1 << 30), cseed=rng.randint(0, 1 << 30),
+    )
+
+
+def draw(rng, big_share=0.08):
+    if rng.random() < big_share:
+        return draw_big(rng)
     k = rng.choice([9, 11, 13, 15, 21, 25, 31, 31, 31, 33, 41, 55, 63, 16, 32])
     length = rng.choice([2000, 5000, 20000, 60000, 200000])
     dens = rng.choice([0, 1, 1, 3, 8])  # structures per 10 kbp
@@ -121,6 +141,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=300)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--big", type=float, default=0.08, help="share of long-list / deep-gap configurations")
     ap.add_argument("--replay", default=None)
     a = ap.parse_args()
     oracle_lib.lib()
@@ -132,7 +153,7 @@ def main():
     t_end = time.time() + a.seconds
     n = bad = compared = filled = 0
     while time.time() < t_end and bad < 100:
-        cfg = draw(rng)
+        cfg = draw(rng, a.big)
         n += 1
         try:
             c, f = run(cfg)[:2]
