@@ -1233,7 +1233,7 @@ int batches_stage2(const std::vector<g2s_batch*>& bs, g2s_session* lead, g2s_res
         g2s_result& r = results[gi];  // the gap is not attempted at all (:369)
         memset(&r, 0, sizeof r);
         r.flags = G2S_GAP_SKIPPED;
-        if (in.filled & 2) memset(arena + arena_off[gi], 0, b->jobs[i].buf_bytes(g.k, fp.d_err));
+        if (in.filled & 2) arena[arena_off[gi] + (size_t)b->jobs[i].lmf] = '\0';
         prev_filled = false;
         continue;
       }
@@ -1354,7 +1354,8 @@ extern "C" int g2s_batch_run(g2s_batch* b, g2s_result* results, char* arena, siz
   g2s_session* s = b->s;
   const size_t n = b->jobs.size();
   memset(results, 0, n * sizeof(g2s_result));
-  memset(arena, 0, b->arena_bytes);
+  // an unfilled gap reads as the empty string; filled ones are written in full by the traceback
+  for (size_t i = 0; i < n; i++) arena[b->arena_off[i] + (size_t)b->jobs[i].lmf] = '\0';
   // rand() values are input independent: materialise what this batch will need while the
   // GPU runs (one draw per traced base plus one per gap, Gap2Seq.cpp:1440,1513)
   size_t rand_need = 0;
@@ -1395,7 +1396,11 @@ extern "C" int g2s_team_fill(g2s_session* const* sessions, int nsessions, const 
     const size_t need = g2s_team_arena_bytes(lead, gaps, n);
     if (arena_cap < need || (!arena && need)) return fail(G2S_ERR_ARG, "g2s_team_fill: fill arena too small");
     memset(results, 0, n * sizeof(g2s_result));
-    memset(arena, 0, need);
+    size_t pos = 0;  // an unfilled gap reads as the empty string
+    for (size_t i = 0; i < n; i++) {
+      arena[pos + (size_t)std::max(0, gaps[i].lmf)] = '\0';
+      pos += g2s_team_arena_bytes(lead, gaps + i, 1);
+    }
   }
   std::thread rand_fill([lead, gaps, n]() { lead->rcache.ensure(rand_need_of(gaps, n, lead->graph->g->k)); });
   std::vector<size_t> group_arena(ngroups + 1, 0);  // where each group's fill buffers start

@@ -356,6 +356,7 @@ void sub_traceback(const Graph& g, const FillParams& p, const GapJob& job, const
                  g.node_string(job.targets()[go.reached_j]).c_str());
         res->flags |= G2S_GAP_BACKTRACE_FAIL;
         res->count = 0;
+        buf[lmf] = '\0';  // no fill: the caller's view of the buffer starts here (left_fuz stays 0)
         break;
       }
       i = back[(draw() >> 1) % (uint32_t)nb];  // :1513
