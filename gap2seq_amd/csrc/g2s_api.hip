@@ -1191,6 +1191,7 @@ int batches_stage2(const std::vector<g2s_batch*>& bs, g2s_session* lead, g2s_res
   if (n == 0) return G2S_OK;
   std::vector<size_t> arena_off(n), rand_off(n, 0);
   std::vector<char> todo_tb(n, 0);
+  std::vector<int> expect_draws(n, 0);
   std::vector<g2s_batch*> owner(n);
   std::vector<uint32_t> local(n);
   {
@@ -1207,7 +1208,7 @@ int batches_stage2(const std::vector<g2s_batch*>& bs, g2s_session* lead, g2s_res
   }
   const size_t per = 8, nchunks = (n + per - 1) / per;
   std::atomic<uint64_t> fill_bytes(0);
-  double ms_order = 0, ms_order_loop = 0, ms_ana = 0;
+  double ms_order = 0, ms_order_loop = 0, ms_ana = 0, ms_walks = 0;
   size_t n_inline = 0, n_two = 0, n_rest = 0;
   bool serial = false;
   size_t draws_used = 0;
@@ -1249,7 +1250,7 @@ int batches_stage2(const std::vector<g2s_batch*>& bs, g2s_session* lead, g2s_res
         if (draws >= 0) {
           todo_tb[gi] = !(in.filled & 2);
           right_fuz = in.reached_j;
-        } else {
+        } else if (serial) {
           n_inline++;
           g2s_result& r = results[gi];
           const SubView& v = b->views[i];
@@ -1257,7 +1258,19 @@ int batches_stage2(const std::vector<g2s_batch*>& bs, g2s_session* lead, g2s_res
           sub_traceback(g, fp, b->jobs[i], v, b->prep[i], lead->rcache.ptr(draws_total), arena + arena_off[gi], &r);
           draws = r.draws;
           right_fuz = r.right_fuz;
+        } else {
+          // the draw count depends on the draws: walk the parent links once for the count,
+          // the fill itself is written by the pool with the others
+          n_inline++;
+          const auto tw0 = std::chrono::steady_clock::now();
+          const SubView& v = b->views[i];
+          grow_rands(draws_total + (size_t)v.out->len[pick] + 2);
+          draws = sub_count_draws(g, v, b->prep[i], lead->rcache.ptr(draws_total));
+          ms_walks += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count();
+          todo_tb[gi] = 1;
+          right_fuz = in.reached_j;
         }
+        expect_draws[gi] = draws;
         draws_total += (size_t)draws;
       }
       prev_filled = (in.filled & 1) != 0;
@@ -1306,7 +1319,8 @@ int batches_stage2(const std::vector<g2s_batch*>& bs, g2s_session* lead, g2s_res
           const size_t i = local[gi];
           const g2s_batch::GapInfo& in = b->info[i];
           const int pick = in.n_len > 1 ? (int)(lead->rcache.at_const(rand_off[gi]) % in.n_len) : 0;
-          const int expect = in.fixed[pick];
+          (void)pick;
+          const int expect = expect_draws[gi];
           sub_traceback(g, fp, j, b->views[i], b->prep[i], lead->rcache.ptr(rand_off[gi]), arena + arena_off[gi], &r);
           if (r.draws != expect) r.flags |= G2S_GAP_BACKTRACE_FAIL;  // cannot happen: the draw count was proven fixed
         }
@@ -1329,9 +1343,9 @@ int batches_stage2(const std::vector<g2s_batch*>& bs, g2s_session* lead, g2s_res
   lead->rcache.consume(draws_used);
   auto t_end = std::chrono::steady_clock::now();
   if (getenv("G2S_DEBUG"))
-    fprintf(stderr, "[g2s] host stage 2 (%s analysis): %.3f ms = setup+analysis %.3f + in-order pass %.3f (loop %.3f; %zu gaps traced inline, %zu with two lengths, %zu not traced by the analysis) + tracebacks\n",
+    fprintf(stderr, "[g2s] host stage 2 (%s analysis): %.3f ms = setup+analysis %.3f + in-order pass %.3f (draw-count walks %.3f; %zu gaps traced inline, %zu with two lengths, %zu not traced by the analysis) + tracebacks\n",
             analyze ? "with" : "after", std::chrono::duration<double, std::milli>(t_end - t_begin).count(), ms_ana, ms_order,
-            ms_order_loop, n_inline, n_two, n_rest);
+            ms_walks, n_inline, n_two, n_rest);
   if (timing) {
     timing->fill_bytes += fill_bytes.load();
     timing->ms_host_post += std::chrono::duration<double, std::milli>(t_end - t_begin).count();

@@ -359,11 +359,41 @@ void sub_traceback(const Graph& g, const FillParams& p, const GapJob& job, const
         buf[lmf] = '\0';  // no fill: the caller's view of the buffer starts here (left_fuz stays 0)
         break;
       }
-      i = back[(draw() >> 1) % (uint32_t)nb];  // :1513
+      const uint32_t rv = draw() >> 1;  // :1513 (drawn even when there is one choice)
+      i = nb == 1 ? back[0] : back[rv % (uint32_t)nb];
     }
     d2--;
   }
   res->draws = draws;
+}
+
+// The number of rand() values sub_traceback will consume from `rands` on, without writing
+// the fill: the in-order offset pass needs only this of a gap whose draw count depends on
+// the draws themselves; the traceback proper then runs on the pool like every other.
+int sub_count_draws(const Graph& g, const SubView& v, const SubPrep& prep, const uint32_t* rands) {
+  const GapOut& go = *v.out;
+  int draws = 0;
+  const int pick = (int)((rands[draws++] >> 1) % (uint32_t)go.n_len);
+  int d2 = go.len[pick];
+  int i = prep.start_idx[pick];
+  while (d2 >= 0 && i >= 0) {
+    if (sub_flags(v.st[i]) & G2S_SUB_SOURCE) break;
+    if (d2 > 0) {
+      int32_t back[4];
+      const int nb = sub_preds(v, (uint32_t)i, back);
+      if (nb == 0) break;
+      if (nb > 1) {
+        int32_t by_slot[4] = {-1, -1, -1, -1};
+        for (int x = 0; x < nb; x++) by_slot[g.lastnt[v.st[(size_t)back[x]].node ^ 1u]] = back[x];
+        int w = 0;
+        for (int nt = 0; nt < 4; nt++) if (by_slot[nt] >= 0) back[w++] = by_slot[nt];
+      }
+      const uint32_t rv = rands[draws++] >> 1;
+      i = nb == 1 ? back[0] : back[rv % (uint32_t)nb];  // (a division per base is most of this walk's time)
+    }
+    d2--;
+  }
+  return draws;
 }
 
 // ---------------------------------------------------------------------------

@@ -93,6 +93,8 @@ void sub_traceback(const Graph& g, const FillParams& p, const GapJob& job, const
 
 // TEST HOOK support: the closure the g2s_extract kernel computes, derived on the host
 // from a full DP table (states sorted per level).  Not used by the product path.
+int sub_count_draws(const Graph& g, const SubView& v, const SubPrep& prep, const uint32_t* rands);
+
 struct HostTable {
   std::vector<uint32_t> lvl;     // D+2 offsets
   std::vector<uint64_t> states;  // (node << 32 | count), sorted inside each level
