@@ -22,6 +22,9 @@
 #define G2S_DEV_WHY_HITS 0x200u     /* more target hits than the LDS list holds       */
 #define G2S_DEV_WHY_LOG 0x400u      /* state log full                                 */
 #define G2S_DEV_WHY_RS 0x800u       /* (with OVERFLOW_A) the right-set table was full */
+/* diagnostics of the LDS tier's pools (no effect on results) */
+#define G2S_DEV_LOG_POOL 0x1000u    /* the state log moved to a chunk of the log pool        */
+#define G2S_DEV_RS_POOL 0x2000u     /* the right set moved from LDS to a chunk of the spill pool */
 /* LDS tier, lvl[]: bit 31 of the END offset of level L = L was produced by a bulk step
  * (same width as level L-1, state r has the single parent r of level L-1) */
 #define G2S_LVL_UNIFORM 0x80000000u

@@ -38,6 +38,9 @@ hipError_t launch_fill_lds(hipStream_t st, uint32_t ngaps, uint32_t rs_cap_max, 
                            int skip_confident,
                            uint32_t* rs_global /* nullptr: right set in LDS */, uint32_t fcap /* frontier capacity */,
                            uint32_t* rs_pool /* spill pool for LDS right sets, 0xFF filled */, uint32_t pool_chunks,
-                           uint32_t chunk_entries /* power of two */);
+                           uint32_t chunk_entries /* power of two */,
+                           void* log_pool /* chunks for state logs that outgrow their slice, or nullptr */,
+                           uint32_t log_chunks, uint32_t log_chunk_states);
+size_t fill_lds_log_chunk_bytes(uint32_t states);
 
 }  // namespace g2s

@@ -180,7 +180,24 @@ __device__ __forceinline__ bool lrs_has_kmer(const bool G, const uint32_t* tab, 
 struct FillOut {
   uint32_t flags, n_xl, top_level;
   int c_count, n_len, len0, len1, reached_j;
+  // where the gap's state log, parent links and extra links ended up (its own slice of the
+  // launch's arrays, or a chunk of the log pool) and where D1 keeps its scratch
+  uint64_t* log;
+  uint32_t* plk;
+  uint64_t* xl;
+  SubRec* sub;
+  uint64_t* xo;
+  uint32_t cap;
 };
+
+// A gap whose state log outgrows its slice (8 (D+2) states in the first pass) moves to a chunk
+// of this pool and goes on, instead of running again in a later launch after every other gap
+// is done.  Chunk layout: [log 8C][sub 16C][plk 4C][xl 8C/4][xo 8C/4] bytes, C = states.
+struct LogPool {
+  uint8_t* base;
+  uint32_t chunks, states;
+};
+__device__ __forceinline__ size_t log_chunk_bytes(uint32_t c) { return (size_t)c * 32u; }
 
 __device__ __forceinline__ FillOut fill_lds_body(const uint32_t* __restrict__ succ,
                                               const uint64_t* __restrict__ ustart, const GapDev* __restrict__ gaps,
@@ -189,7 +206,8 @@ __device__ __forceinline__ FillOut fill_lds_body(const uint32_t* __restrict__ su
                                               uint32_t* lvl_all, uint32_t* plk_all, uint64_t* xl_all, GapOut* outs,
                                               uint32_t num_oriented, uint32_t* rs_global, const uint32_t F,
                                               unsigned long long* pool_cursor, uint32_t* rs_pool, uint32_t pool_chunks,
-                                              uint32_t chunk_entries) {
+                                              uint32_t chunk_entries, const LogPool lp, SubRec* sub_scratch,
+                                              uint64_t* xo_all) {
   const uint32_t LH = 2u * F;  // merge table slots (F = frontier capacity of this launch, a power of two)
   const uint32_t TH = 2u * F;  // target hits kept for phase C (128 in the first pass, 2048 later)
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -223,13 +241,16 @@ __device__ __forceinline__ FillOut fill_lds_body(const uint32_t* __restrict__ su
   const uint32_t* targets = rseeds + (uint32_t)(gd.rmf + 1);
   uint64_t* log = log_all + gd.slog_off;
   uint32_t* lvl = lvl_all + gd.lvl_off;
-  const uint32_t cap = gd.slog_cap;
+  uint32_t cap = gd.slog_cap;
+  SubRec* sub = sub_scratch + gd.slog_off;
+  uint64_t* xo = xo_all + gd.st_off;
+  bool grown = false;
   // Parent links for phase D1 (g2s_extract_lds walks them instead of the graph): plk[s] = the
   // position, within the previous level, of the state that first produced state s; the
   // other parents of merged states go to the list xl as (state << 32 | position).
   uint32_t* plk = plk_all + gd.slog_off;
   uint64_t* xl = xl_all + gd.st_off;  // LDS tier: st_off / pad0 carry the extra-link list's offset / capacity
-  const uint32_t xcap = gd.pad0;
+  uint32_t xcap = gd.pad0;
   uint32_t nxl = 0;
 
   if (!rsg) for (uint32_t i = (uint32_t)lane; i < rs_cap; i += 64u) rs[i] = G2S_DEV_INVALID;
@@ -458,6 +479,7 @@ __device__ __forceinline__ FillOut fill_lds_body(const uint32_t* __restrict__ su
         rs_cap = chunk_entries;
         overflow = false;
         flags &= ~(G2S_DEV_OVERFLOW_A | G2S_DEV_WHY_RS | G2S_DEV_Q7_A);
+        flags |= G2S_DEV_RS_POOL;
         nvis = 0; xa = 0;
         continue;
       }
@@ -497,6 +519,33 @@ __device__ __forceinline__ FillOut fill_lds_body(const uint32_t* __restrict__ su
     lvl_top = nb ? 0 : -1;
     uint32_t bulk_epoch = 0x80000000u;  // tags merge-table entries of bulk steps; never equals a depth
     for (; d <= gd.D; d++) {
+      // a level adds at most F states (and 64 from a bulk step): with less room than that left,
+      // move the log, its links and the extra links to a chunk of the pool, once
+      if ((nlog + max(F, 64u) > cap || nxl + max(F, 64u) > xcap) && !grown && lp.chunks && lp.states > cap) {
+        unsigned long long chunk = 0;
+        if (lane == 0) chunk = atomicAdd(pool_cursor + 1, 1ull);
+        chunk = __shfl(chunk, 0);
+        grown = true;  // (also when the pool is used up: do not ask again)
+        if (chunk < lp.chunks) {
+          uint8_t* cb = lp.base + chunk * log_chunk_bytes(lp.states);
+          uint64_t* nlogp = (uint64_t*)cb;
+          SubRec* nsubp = (SubRec*)(cb + (size_t)lp.states * 8u);
+          uint32_t* nplk = (uint32_t*)(cb + (size_t)lp.states * 24u);
+          uint64_t* nxlp = (uint64_t*)(cb + (size_t)lp.states * 28u);
+          uint64_t* nxop = nxlp + lp.states / 4u;
+          __threadfence();  // this wave's earlier stores are in L2 before they are read back
+          for (uint32_t i = (uint32_t)lane; i < nlog; i += 64u) {
+            nlogp[i] = __hip_atomic_load(&log[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            nplk[i] = __hip_atomic_load(&plk[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          for (uint32_t i = (uint32_t)lane; i < nxl; i += 64u)
+            nxlp[i] = __hip_atomic_load(&xl[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          log = nlogp; plk = nplk; xl = nxlp; sub = nsubp; xo = nxop;
+          cap = lp.states;
+          xcap = lp.states / 4u;
+          flags |= G2S_DEV_LOG_POOL;
+        }
+      }
       uint32_t* ncur = fn + cur * F;
       uint32_t* ccur = fc + cur * F;
       uint32_t* nnxt = fn + (cur ^ 1u) * F;
@@ -862,6 +911,7 @@ __device__ __forceinline__ FillOut fill_lds_body(const uint32_t* __restrict__ su
   FillOut fo;
   fo.flags = flags; fo.n_xl = nxl; fo.top_level = (uint32_t)max(0, min(lvl_top, gd.D));
   fo.c_count = c_count; fo.n_len = n_len; fo.len0 = len0; fo.len1 = len1; fo.reached_j = reached_j;
+  fo.log = log; fo.plk = plk; fo.xl = xl; fo.sub = sub; fo.xo = xo; fo.cap = cap;
   return fo;
 }
 
@@ -930,12 +980,13 @@ __device__ __forceinline__ void extract_lds_body(const FillOut fo, const GapDev*
   uint32_t* xc = pc + F;               // merged states of the level above: emit index, parent position, slot [3][XC]
   uint32_t msel = 0, csel = 0;
 
-  const uint64_t* log = log_all + gd.slog_off;
+  (void)log_all; (void)plk_all; (void)xl_all; (void)xo_all; (void)sub_scratch;
+  const uint64_t* log = fo.log;
   const uint32_t* lvl = lvl_all + gd.lvl_off;
-  const uint32_t* plk = plk_all + gd.slog_off;
-  const uint64_t* xl = xl_all + gd.st_off;
-  SubRec* sub = sub_scratch + gd.slog_off;
-  uint64_t* xo = xo_all + gd.st_off;  // the closure's side list: parents beyond the first, (state << 32 | parent)
+  const uint32_t* plk = fo.plk;
+  const uint64_t* xl = fo.xl;
+  SubRec* sub = fo.sub;
+  uint64_t* xo = fo.xo;  // the closure's side list: parents beyond the first, (state << 32 | parent)
   uint32_t nxo = 0;
   const uint32_t* lseeds = flank_nodes + gd.flank_off;
   const uint32_t* targets = lseeds + (uint32_t)(gd.lmf + 1) + (uint32_t)(gd.rmf + 1);
@@ -963,7 +1014,7 @@ __device__ __forceinline__ void extract_lds_body(const FillOut fo, const GapDev*
   uint32_t nsub = 0, nch = 0, nxc = 0, xcount = 0, lflags = 0;
   uint32_t xpos = fo.n_xl;       // extra links [0, xpos) not yet consumed (sorted by state, ascending)
   uint32_t xtop = xpos ? (uint32_t)(xl[xpos - 1u] >> 32) : 0u;
-  const uint32_t cap = gd.slog_cap;
+  const uint32_t cap = fo.cap;
   bool over = false;
 
   // nothing can start above the last level that holds a state, nor (without a sink k-mer)
@@ -1296,11 +1347,12 @@ __device__ __forceinline__ void extract_lds_body(const FillOut fo, const GapDev*
       const uint32_t *__restrict__ gap_ids, const uint32_t *__restrict__ flank_nodes, uint64_t *log_all,              \
       uint32_t *lvl_all, uint32_t *plk_all, uint64_t *xl_all, uint64_t *xo_all, SubRec *sub_scratch, SubRec *sub_out, \
       unsigned long long out_cap, unsigned long long *out_counter, GapOut *outs, GapOut *outs_host,                   \
-      uint32_t *done_list, int skip_confident, uint32_t num_oriented
+      uint32_t *done_list, int skip_confident, uint32_t num_oriented, LogPool lp
 __global__ __launch_bounds__(64) void g2s_fill_lds(G2S_FUSED_PARAMS, uint32_t fcap, uint32_t* rs_pool,
                                                     uint32_t pool_chunks, uint32_t chunk_entries) {
   const FillOut fo = fill_lds_body(succ, ustart, gaps, gap_ids, flank_nodes, log_all, lvl_all, plk_all, xl_all, outs,
-                                   num_oriented, nullptr, fcap, out_counter + 2, rs_pool, pool_chunks, chunk_entries);
+                                   num_oriented, nullptr, fcap, out_counter + 2, rs_pool, pool_chunks, chunk_entries, lp,
+                                   sub_scratch, xo_all);
   __threadfence();  // the log, level offsets and links of this gap were written through: read them back from L2
   extract_lds_body(fo, gaps, gap_ids, flank_nodes, log_all, lvl_all, plk_all, xl_all, xo_all, sub_scratch, sub_out,
                    out_cap, out_counter, outs, outs_host, done_list, skip_confident, fcap);
@@ -1309,7 +1361,8 @@ __global__ __launch_bounds__(64) void g2s_fill_lds(G2S_FUSED_PARAMS, uint32_t fc
 // LDS (deep DP, -dist-error in the thousands); everything else of the gap stays in LDS.
 __global__ __launch_bounds__(64) void g2s_fill_lds_rsg(G2S_FUSED_PARAMS, uint32_t* rs_global, uint32_t fcap) {
   const FillOut fo = fill_lds_body(succ, ustart, gaps, gap_ids, flank_nodes, log_all, lvl_all, plk_all, xl_all, outs,
-                                   num_oriented, rs_global, fcap, out_counter + 2, nullptr, 0u, 0u);
+                                   num_oriented, rs_global, fcap, out_counter + 2, nullptr, 0u, 0u, lp, sub_scratch,
+                                   xo_all);
   __threadfence();
   extract_lds_body(fo, gaps, gap_ids, flank_nodes, log_all, lvl_all, plk_all, xl_all, xo_all, sub_scratch, sub_out,
                    out_cap, out_counter, outs, outs_host, done_list, skip_confident, fcap);
@@ -1329,6 +1382,7 @@ size_t extract_lds_bytes(uint32_t fcap) {
 }
 uint32_t fill_lds_frontier_cap() { return LDS_F; }
 uint32_t fill_lds_max_fuz() { return LDS_TG - 1; }
+size_t fill_lds_log_chunk_bytes(uint32_t states) { return (size_t)states * 32u; }
 
 hipError_t launch_fill_lds(hipStream_t st, uint32_t ngaps, uint32_t rs_cap_max, uint32_t num_oriented,
                            const uint32_t* succ, const uint64_t* ustart, const GapDev* gaps, const uint32_t* gap_ids,
@@ -1337,22 +1391,27 @@ hipError_t launch_fill_lds(hipStream_t st, uint32_t ngaps, uint32_t rs_cap_max, 
                            unsigned long long out_cap,
                            unsigned long long* out_counter, GapOut* outs, GapOut* outs_host, uint32_t* done_list,
                            int skip_confident, uint32_t* rs_global, uint32_t fcap, uint32_t* rs_pool,
-                           uint32_t pool_chunks, uint32_t chunk_entries) {
+                           uint32_t pool_chunks, uint32_t chunk_entries, void* log_pool, uint32_t log_chunks,
+                           uint32_t log_chunk_states) {
   if (ngaps == 0) return hipSuccess;
+  LogPool lp;
+  lp.base = (uint8_t*)log_pool;
+  lp.chunks = log_pool ? log_chunks : 0u;
+  lp.states = log_chunk_states;
   const size_t bytes = std::max(fill_lds_bytes(rs_global ? 0 : rs_cap_max, fcap), extract_lds_bytes(fcap));
   if (rs_global) {  // right set in HBM: no LDS for it
     hipError_t e = hipFuncSetAttribute((const void*)g2s_fill_lds_rsg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(g2s_fill_lds_rsg, dim3(ngaps), dim3(64), bytes, st, succ, ustart, gaps, gap_ids, flank_nodes,
                        log_all, lvl_all, plk_all, xl_all, xo_all, sub_scratch, sub_out, out_cap, out_counter, outs,
-                       outs_host, done_list, skip_confident, num_oriented, rs_global, fcap);
+                       outs_host, done_list, skip_confident, num_oriented, lp, rs_global, fcap);
     return hipGetLastError();
   }
   hipError_t e = hipFuncSetAttribute((const void*)g2s_fill_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(g2s_fill_lds, dim3(ngaps), dim3(64), bytes, st, succ, ustart, gaps, gap_ids, flank_nodes, log_all,
                      lvl_all, plk_all, xl_all, xo_all, sub_scratch, sub_out, out_cap, out_counter, outs, outs_host,
-                     done_list, skip_confident, num_oriented, fcap, rs_pool, pool_chunks, chunk_entries);
+                     done_list, skip_confident, num_oriented, lp, fcap, rs_pool, pool_chunks, chunk_entries);
   return hipGetLastError();
 }
 

@@ -429,7 +429,8 @@ struct g2s_session {
   size_t mem_budget = 0;  // bytes of HBM this session may use for work areas
   DevBuf d_gaps, d_ids, d_flank, d_outs, d_rs, d_rlog, d_keys, d_cnt, d_mark, d_slog, d_subscr, d_subout, d_counter;
   DevBuf d_log, d_lvl, d_plk, d_xl, d_xo;  // LDS tier: state log, level offsets, parent links, closure side lists
-  DevBuf d_rspool;                          // LDS tier: spill pool for right sets
+  DevBuf d_rspool;
+  DevBuf d_logpool;  // chunks for state logs that outgrow their slice of d_log (LDS tier)                          // LDS tier: spill pool for right sets
   std::vector<void*> tier_pool;  // recycled TierData (pinned host buffers)
   size_t tier_cursor = 0;        // next free slot of tier_pool in the current run
   const void* flank_owner = nullptr;  // batch whose flank nodes d_flank holds
@@ -473,7 +474,7 @@ extern "C" void g2s_session_destroy(g2s_session* s) {
   (void)hipSetDevice(s->device);
   DevBuf* bufs[] = {&s->d_gaps, &s->d_ids, &s->d_flank, &s->d_outs, &s->d_rs, &s->d_rlog, &s->d_keys,
                     &s->d_cnt, &s->d_mark, &s->d_slog, &s->d_subscr, &s->d_subout, &s->d_counter,
-                    &s->d_log, &s->d_lvl, &s->d_plk, &s->d_xl, &s->d_xo, &s->d_rspool};
+                    &s->d_log, &s->d_lvl, &s->d_plk, &s->d_xl, &s->d_xo, &s->d_rspool, &s->d_logpool};
   for (DevBuf* b : bufs) b->release();
   delete s->pool;
   for (void* v : s->tier_pool) { TierData* t = (TierData*)v; t->outs.release(); t->subs.release(); t->done.release(); delete t; }
@@ -751,6 +752,11 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
       HIP_TRY(s->d_rspool.ensure((size_t)pool_chunks * chunk_entries * 4));
       HIP_TRY(hipMemsetAsync(s->d_rspool.p, 0xFF, (size_t)pool_chunks * chunk_entries * 4, st));
     }
+    // log pool: a gap whose state log outgrows its slice takes a chunk and goes on (a handful
+    // of repeat-rich gaps per ten thousand; without it they would run again after the launch)
+    const uint32_t log_chunk_states = 131072u;
+    const uint32_t log_chunks = (uint32_t)std::min<size_t>(ids.size() / 64 + 4, 256);
+    HIP_TRY(s->d_logpool.ensure((size_t)log_chunks * fill_lds_log_chunk_bytes(log_chunk_states)));
     HIP_TRY(launch_fill_lds(st, (uint32_t)ids.size(), lds_cap_max, num_oriented, dg.succ, dg.ustart,
                             (const GapDev*)s->d_gaps.p, (const uint32_t*)s->d_ids.p, (const uint32_t*)s->d_flank.p,
                             (uint64_t*)s->d_log.p, (uint32_t*)s->d_lvl.p, (uint32_t*)s->d_plk.p, (uint64_t*)s->d_xl.p,
@@ -759,7 +765,7 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
                             (unsigned long long*)s->d_counter.p, (GapOut*)s->d_outs.p, (GapOut*)d_outs_host,
                             (uint32_t*)d_done_host, s->params.skip_confident ? 1 : 0,
                             rs_in_hbm ? (uint32_t*)s->d_rs.p : nullptr, fcap, (uint32_t*)s->d_rspool.p, pool_chunks,
-                            chunk_entries));
+                            chunk_entries, s->d_logpool.p, log_chunks, log_chunk_states));
     HIP_TRY(hipEventRecord(s->ev[2], st));
     HIP_TRY(hipEventRecord(s->ev[3], st));
   } else {
@@ -1067,6 +1073,8 @@ int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
       b->timing.x_fill_lds += (uint64_t)go.x_right + go.x_left;
       b->timing.s_fill_lds += (uint64_t)go.n_right + go.n_states;
       b->timing.lds_tier_gaps++;
+      b->timing.log_pool_gaps += (go.flags & G2S_DEV_LOG_POOL) != 0;
+      b->timing.rs_pool_gaps += (go.flags & G2S_DEV_RS_POOL) != 0;
     }
     if (getenv("G2S_DEBUG")) {  // the slowest gaps of the LDS tier and why
       std::vector<uint32_t> ord(ids);
@@ -1380,7 +1388,11 @@ extern "C" int g2s_batch_run(g2s_batch* b, g2s_result* results, char* arena, siz
   b->arena = arena;
   b->arena_base = 0;
   int rc = batch_stage1(b, true, results);
+  const auto t_join = std::chrono::steady_clock::now();
   rand_fill.join();
+  if (getenv("G2S_DEBUG"))
+    fprintf(stderr, "[g2s] waited %.3f ms for the rand() values after stage 1\n",
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_join).count());
   if (rc == G2S_OK) rc = batches_stage2(std::vector<g2s_batch*>{b}, s, results, arena, &b->timing, false);
   return rc;
 }
@@ -1468,6 +1480,7 @@ extern "C" int g2s_team_fill(g2s_session* const* sessions, int nsessions, const 
         total.flank_bytes += t.flank_bytes; total.launches_left_dp += t.launches_left_dp;
         total.retried_gaps += t.retried_gaps; total.x_fill_lds += t.x_fill_lds; total.s_fill_lds += t.s_fill_lds;
         total.lds_tier_gaps += t.lds_tier_gaps; total.lds_launches += t.lds_launches;
+        total.log_pool_gaps += t.log_pool_gaps; total.rs_pool_gaps += t.rs_pool_gaps;
       }
       rc = batches_stage2(subs, lead, results, arena, &total, false);
     }

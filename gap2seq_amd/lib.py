@@ -55,7 +55,8 @@ class g2s_timing(C.Structure):
                 ("xD", C.c_uint64), ("sD", C.c_uint64), ("flank_bytes", C.c_uint64), ("fill_bytes", C.c_uint64),
                 ("launches_left_dp", C.c_uint32), ("retried_gaps", C.c_uint32),
                 ("ms_fill_lds", C.c_double), ("ms_extract_lds", C.c_double), ("x_fill_lds", C.c_uint64),
-                ("s_fill_lds", C.c_uint64), ("lds_tier_gaps", C.c_uint32), ("lds_launches", C.c_uint32)]
+                ("s_fill_lds", C.c_uint64), ("lds_tier_gaps", C.c_uint32), ("lds_launches", C.c_uint32),
+                ("log_pool_gaps", C.c_uint32), ("rs_pool_gaps", C.c_uint32)]
 
 
 class g2s_run_opts(C.Structure):

@@ -172,6 +172,8 @@ typedef struct g2s_timing {
   uint64_t s_fill_lds;       /* states set (A+B) by those gaps */
   uint32_t lds_tier_gaps;    /* gaps that completed in the LDS tier */
   uint32_t lds_launches;     /* launches of g2s_fill_lds (2 when a second pass with larger LDS tables ran) */
+  uint32_t log_pool_gaps;    /* gaps whose state log moved to a chunk of the launch's log pool */
+  uint32_t rs_pool_gaps;     /* gaps whose right set moved from LDS to a chunk of the launch's spill pool */
 } g2s_timing;
 
 /* ---------------------------------------------------------------------------

@@ -314,6 +314,23 @@ def test_bench_workload_c2_vs_oracle(product, oracle):
     pg.free()
 
 
+def test_c3_gap_list_on_the_branching_genome_vs_oracle(product, oracle):
+    """BASELINE config 3's list length (10 000 gaps, 3 Mbp, k=31, -fuz 10, -dist-error 500) on
+    the V3 genome (repeats + bubbles), gap by gap against the oracle.  At this list length the
+    LDS share per gap is at its smallest: right sets spill to the launch's pool in HBM, and the
+    few repeat-rich gaps whose state log outgrows its slice move to the log pool; both must
+    have happened here, and nothing may need a second launch."""
+    reads = product.G2S.synth_genome(3000000, 3, 20240101)
+    scaff = product.G2S.synth_gaps(reads, 31, 10, 10000, 200, 1000, 20240103)
+    seqs = [ln for ln in reads.splitlines() if not ln.startswith(">")]
+    gaps = _parse_scaffolds(scaff)
+    assert len(gaps) == 10000
+    c, f, tm, _, _ = _check_batch(product, oracle, seqs, 31, gaps, 500, seed=1)
+    assert c > 9900 and f > 9900
+    assert tm.lds_tier_gaps == 10000 and tm.lds_launches == 1
+    assert tm.rs_pool_gaps > 0 and tm.log_pool_gaps > 0
+
+
 def test_multi_rank_bench_path(product, tmp_path):
     """bench.py under torch.distributed.run with 2 ranks (gloo, both on device 0): the
     one-process-per-GPU code path, rank-specific gap sets, max/sum reduction, one JSON line."""
