@@ -475,6 +475,7 @@ def test_gpu_unitig_numbering_equals_host_walk(product, monkeypatch):
     gg = product.Graph.from_seqs(seqs, 31, 1)
     try:
         assert (gg.num_kmers, gg.num_unitigs) == (gh.num_kmers, gh.num_unitigs)
+        assert gg.validate() == (0, "") and gh.validate() == (0, "")
         rnd = random.Random(3)
         for s in (seqs[0], seqs[1], seqs[-1]):
             for _ in range(300):
@@ -527,6 +528,7 @@ def test_gpu_graph_build_solid_threshold_and_wide_kmers(product, monkeypatch, k)
     try:
         assert gg.num_kmers == gh.num_kmers and gg.num_kmers > 20000
         assert gg.num_unitigs == gh.num_unitigs
+        assert gg.validate() == (0, "")
         for _ in range(500):
             p = rr.randrange(0, len(genome) - k)
             km = genome[p:p + k]

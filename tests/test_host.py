@@ -75,6 +75,19 @@ def test_unitig_order_numbers_a_chain_consecutively(product):
     gr.free()
 
 
+@pytest.mark.parametrize("k", [9, 15, 31, 33, 63])
+def test_graph_tables_are_consistent(product, k):
+    """g2s_graph_validate: the unitig-start bitmap, the successor table and the last-base table
+    agree on tangled graphs (dispersed, tandem and inverted repeats, a second haplotype) — the
+    invariants the kernels walk unitigs by — and the check survives the cache round trip."""
+    for seed in range(6):
+        seqs = cases.toy_genome(seed * 5 + k, 4000, k, repeats=seed, tandem=seed % 3, inverted=seed % 2,
+                                snp_every=(0 if seed % 2 else 97))
+        g = product.Graph.from_seqs(seqs, k, 1)
+        assert g.validate() == (0, ""), (k, seed)
+        g.free()
+
+
 def test_graph_cache_roundtrip(product, tmp_path):
     seqs = cases.toy_genome(3, 2000, 15, repeats=3, snp_every=101)
     a = product.Graph.from_seqs(seqs, 15, 1)
