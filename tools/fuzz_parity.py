@@ -79,6 +79,8 @@ def draw(rng, big_share=0.08):
 
 
 def run(cfg):
+    if cfg.get("scaffold"):
+        return run_scaffold(cfg)
     k = cfg["k"]
     seqs = cases.toy_genome(cfg["gseed"], cfg["length"], k, repeats=cfg["repeats"], tandem=cfg["tandem"],
                             inverted=cfg["inverted"], snp_every=cfg["snp_every"])
@@ -90,6 +92,71 @@ def run(cfg):
         os.environ.pop("G2S_NO_LDS_TIER", None)
     return tp._check_batch(product, oracle_lib, seqs, k, gaps, cfg["d_err"], cfg["skip"], cfg["allp"],
                            seed=cfg["randseed"])
+
+
+def draw_scaffold(rng):
+    k = rng.choice([5, 7, 11, 15, 21, 31])
+    cfg = dict(
+        scaffold=True, k=k, length=rng.choice([3000, 8000, 30000]), repeats=rng.randint(0, 6), tandem=rng.randint(0, 2),
+        inverted=rng.choice([0, 0, 1]), snp_every=rng.choice([0, 97, 211]), fuz=rng.choice([1, 4, 8, 10, 12]),
+        d_err=rng.choice([k, 20, 60, 200]), records=rng.choice([5, 25, 60]), max_gaps=rng.randint(1, 6),
+        max_len=rng.choice([10, 40, 200]), mode=rng.choice(["default", "default", "unique", "best_only", "all_upper"]),
+        randseed=rng.randint(1, 1 << 20), gseed=rng.randint(0, 1 << 30), cseed=rng.randint(0, 1 << 30),
+    )
+    if k <= 11:  # tangled graphs: keep the searches shallow (cf. draw)
+        cfg["length"] = min(cfg["length"], 8000)
+        cfg["d_err"] = min(cfg["d_err"], 30 if k <= 7 else 60)
+        cfg["max_len"] = min(cfg["max_len"], 40)
+    if k <= 7:
+        cfg["length"] = min(cfg["length"], 600 if k == 5 else 2000)
+        cfg["records"] = min(cfg["records"], 25)
+    return cfg
+
+
+def run_scaffold(cfg):
+    """Whole-scaffold runs (the gap scan, the couplings between consecutive gaps of a record,
+    the splice and the log text): FASTA, log and counters against the oracle's execute."""
+    k, fuz, e = cfg["k"], cfg["fuz"], cfg["d_err"]
+    seqs = cases.toy_genome(cfg["gseed"], cfg["length"], k, repeats=cfg["repeats"], tandem=cfg["tandem"],
+                            inverted=cfg["inverted"], snp_every=cfg["snp_every"])
+    g = seqs[0]
+    rng = cases.SplitMix(cfg["cseed"])
+    recs = []
+    for r in range(cfg["records"]):
+        span = cfg["max_gaps"] * (cfg["max_len"] + 3 * k + 2 * fuz + 10) + 2 * (k + fuz + 10)
+        start = rng.randint(0, max(1, len(g) - span - 1))
+        pos = start + k + fuz + 5
+        triples = []
+        for _ in range(rng.randint(1, cfg["max_gaps"])):
+            ln = rng.randint(1, cfg["max_len"])
+            triples.append((pos, ln, max(1, ln + k + rng.randint(-3, 3))))
+            pos += ln + rng.choice([k + fuz - 1, k + fuz, k + fuz + 1, k + 2 * fuz, 3 * k + 2 * fuz + 7])
+        rec = cases.scaffold_record(g, k, fuz, triples)
+        if rng.random() < 0.2:
+            rec = rec.replace("N", "n")
+        recs.append(("rec%d extra words" % r, rec))
+    text = "".join(">%s\n%s\n" % x for x in recs)
+    kw = dict(default={}, unique=dict(unique_paths=True), best_only=dict(all_paths=False),
+              all_upper=dict(skip_confident=True))[cfg["mode"]]
+    og = oracle_lib.OracleGraph(seqs, k, 1)
+    pg = product.Graph.from_seqs(seqs, k, 1)
+    try:
+        ofa, olog, sm = oracle_lib.execute_scaffolds(og, text, k, solid=1, d_err=e, max_fuz=fuz,
+                                                     randseed=cfg["randseed"], **kw)
+        if sm.q7_gaps:
+            return 0, 0
+        sess = product.Session(pg, 0, d_err=e, randseed=cfg["randseed"], **kw)
+        try:
+            fa, lg, gaps, filled = sess.execute_scaffolds(text, k, solid=1, max_fuz=fuz)
+        finally:
+            sess.destroy()
+        assert fa == ofa, "FASTA differs"
+        assert lg == olog, "log differs"
+        assert (gaps, filled) == (sm.gaps, sm.filled), "counters differ"
+        return sm.gaps, sm.filled
+    finally:
+        og.free()
+        pg.free()
 
 
 def explain(cfg):
@@ -142,18 +209,23 @@ def main():
     ap.add_argument("--seconds", type=float, default=300)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--big", type=float, default=0.08, help="share of long-list / deep-gap configurations")
+    ap.add_argument("--scaffold", type=float, default=0.1, help="share of whole-scaffold (execute) configurations")
     ap.add_argument("--replay", default=None)
     a = ap.parse_args()
     oracle_lib.lib()
     product.load_library()
     if a.replay:
-        explain(json.loads(a.replay))
+        cfg = json.loads(a.replay)
+        if cfg.get("scaffold"):
+            print(run_scaffold(cfg))
+        else:
+            explain(cfg)
         return 0
     rng = cases.SplitMix(a.seed * 1000003 + 17)
     t_end = time.time() + a.seconds
     n = bad = compared = filled = 0
     while time.time() < t_end and bad < 100:
-        cfg = draw(rng, a.big)
+        cfg = draw_scaffold(rng) if rng.random() < a.scaffold else draw(rng, a.big)
         n += 1
         try:
             c, f = run(cfg)[:2]
