@@ -672,8 +672,10 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
   const DeviceGraph& dg = s->graph->g->dev.at(s->device);
   const size_t n = b->jobs.size();
   const int d_err = s->params.d_err;
-  HIP_TRY(s->h_gaps.ensure(std::max<size_t>(n * sizeof(GapDev), 16)));
+  HIP_TRY(s->h_gaps.ensure(n * sizeof(GapDev) + ids.size() * 4 + 16));
   GapDev* gd = (GapDev*)s->h_gaps.p;
+  uint32_t* ids_pinned = (uint32_t*)(gd + n);  // the LDS tier reads descriptors and ids from here (no upload)
+  if (!ids.empty()) memcpy(ids_pinned, ids.data(), ids.size() * 4);
   memset(gd, 0, n * sizeof(GapDev));
   uint64_t rs_total = 0, rlog_total = 0, st_total = 0, slog_total = 0, lvl_total = 0, xl_total = 0, out_states = 0, out_max = 0;
   uint32_t lds_cap_max = 0;
@@ -718,8 +720,10 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
   if (!lds) HIP_TRY(s->d_subout.ensure(slog_total * sizeof(SubState)));
   HIP_TRY(s->d_counter.ensure(32));
   hipStream_t st = s->stream;
-  HIP_TRY(hipMemcpyAsync(s->d_gaps.p, gd, n * sizeof(GapDev), hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(s->d_ids.p, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, st));
+  if (!lds) {
+    HIP_TRY(hipMemcpyAsync(s->d_gaps.p, gd, n * sizeof(GapDev), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(s->d_ids.p, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, st));
+  }
   // d_outs, the cursors and the spill pool are reset right after an LDS-tier launch has
   // finished, while the host works on its results: the next launch then starts behind one
   // copy instead of behind three fill kernels (~25 us on the stream)
@@ -768,8 +772,22 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
     const uint32_t log_chunk_states = 131072u;
     const uint32_t log_chunks = (uint32_t)std::min<size_t>(ids.size() / 64 + 4, 256);
     HIP_TRY(s->d_logpool.ensure((size_t)log_chunks * fill_lds_log_chunk_bytes(log_chunk_states)));
+    // short lists: gap descriptors and the id list are read once per gap, straight from pinned
+    // host memory — with no upload in front of it the kernel starts ~13 us earlier (2-3 % of a
+    // 500-gap step); at 10 000 gaps the reads over the link cost more (kernel +4 %) than the
+    // upload, so long lists keep it
+    void* d_gaps_host = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(&d_gaps_host, s->h_gaps.p, 0));
+    const GapDev* gaps_dev = (const GapDev*)d_gaps_host;
+    const uint32_t* ids_dev = (const uint32_t*)(gaps_dev + n);
+    if (ids.size() > 2048) {
+      HIP_TRY(hipMemcpyAsync(s->d_gaps.p, gd, n * sizeof(GapDev), hipMemcpyHostToDevice, st));
+      HIP_TRY(hipMemcpyAsync(s->d_ids.p, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, st));
+      gaps_dev = (const GapDev*)s->d_gaps.p;
+      ids_dev = (const uint32_t*)s->d_ids.p;
+    }
     HIP_TRY(launch_fill_lds(st, (uint32_t)ids.size(), lds_cap_max, num_oriented, dg.succ, dg.ustart,
-                            (const GapDev*)s->d_gaps.p, (const uint32_t*)s->d_ids.p, (const uint32_t*)s->d_flank.p,
+                            gaps_dev, ids_dev, (const uint32_t*)s->d_flank.p,
                             (uint64_t*)s->d_log.p, (uint32_t*)s->d_lvl.p, (uint32_t*)s->d_plk.p, (uint64_t*)s->d_xl.p,
                             (uint64_t*)s->d_xo.p, (SubRec*)s->d_subscr.p, (SubRec*)d_subs_host,
                             (unsigned long long)out_states,
