@@ -353,7 +353,10 @@ class WorkerPool {
       next_.store(posted_g_ << 32);  // the generation tags every ticket: stale workers cannot take one
       gen_.store(posted_g_);
     }
-    cv_.notify_all();
+    // wake no more workers than there are tasks besides the caller's share (every wake-up of a
+    // sleeping thread costs microseconds of CPU on a host that is usually shared)
+    if (n > th_.size()) cv_.notify_all();
+    else for (size_t i = 0; i + 1 < n; i++) cv_.notify_one();
   }
   void finish() {
     if (posted_n_ == 0) return;
