@@ -45,6 +45,9 @@
 #define LDS_TF 128u       /* target filter slots               */
 #define LDS_TF_COLLIDE 0xFFFFFFFEu
 #define LDS_CW 256u       /* candidates of 64 border entries   */
+#ifndef G2S_BULK_MAX
+#define G2S_BULK_MAX 64u  /* widest border the bulk step takes (runs share the 64 lanes level-major) */
+#endif
 
 namespace {
 
@@ -79,9 +82,11 @@ __device__ __forceinline__ uint32_t leading_levels(bool p, uint32_t lg) {
   const uint64_t bad = ~m & gmask;
   return bad ? ((uint32_t)__builtin_ctzll(bad) >> lg) : (64u >> lg);
 }
-// up to 16 runs share the lanes level-major.  (Wider borders are faster in the per-level
-// step: measured 2.4 k cycles per level against 6.8 k for a one-level bulk step.)
+// up to 64 runs share the lanes level-major.  (With verification loads a one-level bulk step
+// on a wide border cost 6.8 k cycles against 2.4-5.5 k for the per-level step, so bulk steps
+// stopped at 16 runs; driven by the bitmap they are the cheaper ones at any width.)
 __device__ __forceinline__ uint32_t log2ceil16(uint32_t r) { return r <= 1 ? 0u : r <= 2 ? 1u : r <= 4 ? 2u : r <= 8 ? 3u : 4u; }
+__device__ __forceinline__ uint32_t log2ceil64(uint32_t r) { return r <= 16 ? log2ceil16(r) : r <= 32 ? 5u : 6u; }
 
 // Right set keyed by k-mer index: entry = index << 4 | expanded bits (3..2) | visited bits (1..0),
 // one bit per strand.  The reference's set is keyed by k-mer as well (membership at :1050
@@ -552,7 +557,7 @@ __device__ __forceinline__ FillOut fill_lds_body(const uint32_t* __restrict__ su
       uint32_t* cnxt = fc + (cur ^ 1u) * F;
       const bool unpruned = d < gd.prune_from;  // :1050 first disjunct
       uint32_t nnew = 0;
-      // ---- bulk step: every border state (<= 16 of them) sits inside a unitig, where the
+      // ---- bulk step: every border state (<= 64 of them) sits inside a unitig, where the
       // only successor of id v is v+2 (even orientation) or v-2 (odd), see dbg.hpp.
       // Lanes are level-major: lane = i*Rp + r holds run r at level d+i, by arithmetic; the
       // unitig-start bitmap bounds i; the pruning rule is checked per lane; the leading
@@ -561,8 +566,8 @@ __device__ __forceinline__ FillOut fill_lds_body(const uint32_t* __restrict__ su
       // diagonals inside unitigs, so no merging is needed; a run at the end of its unitig
       // (branching, dead end, merge) or a pruned state ends the bulk and the per-level code
       // below handles that level.
-      if (nb >= 1 && nb <= 16 && d > gd.lmf) {
-        const uint32_t R = nb, lg = log2ceil16(R), Rp = 1u << lg;
+      if (nb >= 1 && nb <= G2S_BULK_MAX && d > gd.lmf) {
+        const uint32_t R = nb, lg = log2ceil64(R), Rp = 1u << lg;
         const uint32_t r = (uint32_t)lane & (Rp - 1u), i = (uint32_t)lane >> lg;
         const bool mine = r < R;
         const uint32_t n = mine ? ncur[r] : 0u;
@@ -576,20 +581,25 @@ __device__ __forceinline__ FillOut fill_lds_body(const uint32_t* __restrict__ su
         // 64/Rp successor records from HBM, and nothing to verify afterwards: inside a
         // unitig the only successor of v is v +/- 2 and v is its only predecessor.
         uint32_t rem = 128u;
-        if (mine && i < 2u) {
+        auto rem_from = [&](uint32_t wi) -> uint32_t {  // from word wi (0: the run's own, 1: the next in walking direction)
           const uint32_t idx = n >> 1, b = idx & 63u;
           const int64_t w0 = (int64_t)(idx >> 6);
           if (up) {  // steps until the position before the next unitig start
-            const uint64_t word = ustart[w0 + (int64_t)i];
-            const uint64_t m = i == 1u ? word : (b == 63u ? 0ull : word & (~0ull << (b + 1u)));
-            if (m) rem = (i == 1u ? 64u : 0u) + (uint32_t)__builtin_ctzll(m) - 1u - b;
-          } else {   // steps down to the unitig's own start
-            const uint64_t word = ustart[w0 - (int64_t)i];
-            const uint64_t m = i == 1u ? word : word & (~0ull >> (63u - b));
-            if (m) rem = i == 1u ? b + 1u + (uint32_t)__builtin_clzll(m) : b - (63u - (uint32_t)__builtin_clzll(m));
+            const uint64_t word = ustart[w0 + (int64_t)wi];
+            const uint64_t m = wi == 1u ? word : (b == 63u ? 0ull : word & (~0ull << (b + 1u)));
+            return m ? (wi == 1u ? 64u : 0u) + (uint32_t)__builtin_ctzll(m) - 1u - b : 128u;
           }
+          // steps down to the unitig's own start
+          const uint64_t word = ustart[w0 - (int64_t)wi];
+          const uint64_t m = wi == 1u ? word : word & (~0ull >> (63u - b));
+          return m ? (wi == 1u ? b + 1u + (uint32_t)__builtin_clzll(m) : b - (63u - (uint32_t)__builtin_clzll(m))) : 128u;
+        };
+        if (Rp <= 32u) {
+          if (mine && i < 2u) rem = rem_from(i);
+          rem = min(rem, (uint32_t)__shfl_xor((int)rem, (int)Rp));  // the two words of a run (lanes i = 0 and 1)
+        } else if (mine) {
+          rem = min(rem_from(0u), rem_from(1u));  // 33..64 runs: one lane per run reads both words
         }
-        rem = min(rem, (uint32_t)__shfl_xor((int)rem, (int)Rp));  // the two words of a run (Rp <= 16: lanes < 32)
         for (uint32_t o = 1; o < Rp; o <<= 1) rem = min(rem, (uint32_t)__shfl_xor((int)rem, (int)o));  // over the runs
         rem = (uint32_t)__builtin_amdgcn_readfirstlane((int)rem);
         const uint32_t L = min(min(rem, 64u >> lg), (uint32_t)(gd.D - d + 1));
