@@ -1065,8 +1065,8 @@ __device__ __forceinline__ void extract_lds_body(const FillOut fo, const GapDev*
     // ---- bulk step: this level and the K-1 below it were produced by bulk steps of phase B
     // (lvl flag): same width R, state (level, r) has the single parent (level-1, r).  Lane
     // i*Rp + r takes state r of level d2-i; closure membership flows down each run.
-    if ((hi_raw & G2S_LVL_UNIFORM) && w <= 16u && d2 > gd.lmf + 1 && nxc == 0) {
-      const uint32_t R = w, lg = log2ceil16(R), Rp = 1u << lg;
+    if ((hi_raw & G2S_LVL_UNIFORM) && w <= 32u && d2 > gd.lmf + 1 && nxc == 0) {  // (33+ wide: one level per iteration, no gain)
+      const uint32_t R = w, lg = log2ceil64(R), Rp = 1u << lg;
       const uint32_t r = (uint32_t)lane & (Rp - 1u), i = (uint32_t)lane >> lg;
       const bool mine = r < R;
       const int li = d2 - (int)i;
@@ -1095,7 +1095,8 @@ __device__ __forceinline__ void extract_lds_body(const FillOut fo, const GapDev*
         const uint32_t seed = own | ((act && i == 0) ? mcur[r] : 0u);
         // closure membership flows down each run: lane (i, r) has a flag when any lane (i' <= i, r) seeds it
         const uint64_t runmask = (lg == 0 ? ~0ull : lg == 1 ? 0x5555555555555555ull : lg == 2 ? 0x1111111111111111ull
-                                  : lg == 3 ? 0x0101010101010101ull : 0x0001000100010001ull) << r;
+                                  : lg == 3 ? 0x0101010101010101ull : lg == 4 ? 0x0001000100010001ull
+                                  : 0x0000000100000001ull) << r;
         const uint64_t upto = lanes_below(lane) | (1ull << lane);
         const uint64_t ms = __ballot((seed & G2S_SUB_IN_S) != 0), mt = __ballot((seed & G2S_SUB_IN_T) != 0);
         const uint32_t prop = ((ms & runmask & upto) ? G2S_SUB_IN_S : 0u) | ((mt & runmask & upto) ? G2S_SUB_IN_T : 0u);
