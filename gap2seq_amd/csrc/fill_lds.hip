@@ -232,7 +232,8 @@ __device__ __forceinline__ FillOut fill_lds_body(const uint32_t* __restrict__ su
   uint32_t* tgt = th_c + TH;
   uint32_t* misc = tgt + LDS_TG;              // [0] = number of target hits
   uint32_t* tflt = misc + 4;                  // exact target filter: 128 direct-mapped slots
-  uint32_t* cw_v = tflt + LDS_TF;             // wide levels: compacted candidate nodes / counts
+  uint32_t* prem = tflt + LDS_TF;             // bulk steps: a lower bound of the levels each run still has inside its unitig
+  uint32_t* cw_v = prem + G2S_BULK_MAX;       // wide levels: compacted candidate nodes / counts
   uint32_t* cw_c = cw_v + LDS_CW;
   uint32_t* cw_e = cw_c + LDS_CW;
   // right set: in LDS, or in HBM (host pre-filled 0xFF) — the gap's own table when the launch
@@ -523,6 +524,7 @@ __device__ __forceinline__ FillOut fill_lds_body(const uint32_t* __restrict__ su
     int d = 1, lvl_written = 1;  // lvl[0..lvl_written] hold valid offsets
     lvl_top = nb ? 0 : -1;
     uint32_t bulk_epoch = 0x80000000u;  // tags merge-table entries of bulk steps; never equals a depth
+    bool rem_kept = false;              // prem[] is valid for the border as it stands (set by a bulk step)
     for (; d <= gd.D; d++) {
       // a level adds at most F states (and 64 from a bulk step): with less room than that left,
       // move the log, its links and the extra links to a chunk of the pool, once
@@ -580,28 +582,54 @@ __device__ __forceinline__ FillOut fill_lds_body(const uint32_t* __restrict__ su
         // unitig-start bitmap per run (lanes i = 0 and 1; the bitmap lives in L2) instead of
         // 64/Rp successor records from HBM, and nothing to verify afterwards: inside a
         // unitig the only successor of v is v +/- 2 and v is its only predecessor.
-        uint32_t rem = 128u;
+        // (64 = "no unitig start within the two words": at least 64 levels are left)
+        uint32_t rem = 64u;
         auto rem_from = [&](uint32_t wi) -> uint32_t {  // from word wi (0: the run's own, 1: the next in walking direction)
           const uint32_t idx = n >> 1, b = idx & 63u;
           const int64_t w0 = (int64_t)(idx >> 6);
           if (up) {  // steps until the position before the next unitig start
             const uint64_t word = ustart[w0 + (int64_t)wi];
             const uint64_t m = wi == 1u ? word : (b == 63u ? 0ull : word & (~0ull << (b + 1u)));
-            return m ? (wi == 1u ? 64u : 0u) + (uint32_t)__builtin_ctzll(m) - 1u - b : 128u;
+            return m ? min(64u, (wi == 1u ? 64u : 0u) + (uint32_t)__builtin_ctzll(m) - 1u - b) : 64u;
           }
           // steps down to the unitig's own start
           const uint64_t word = ustart[w0 - (int64_t)wi];
           const uint64_t m = wi == 1u ? word : word & (~0ull >> (63u - b));
-          return m ? (wi == 1u ? b + 1u + (uint32_t)__builtin_clzll(m) : b - (63u - (uint32_t)__builtin_clzll(m))) : 128u;
+          return m ? min(64u, wi == 1u ? b + 1u + (uint32_t)__builtin_clzll(m) : b - (63u - (uint32_t)__builtin_clzll(m))) : 64u;
         };
-        if (Rp <= 32u) {
-          if (mine && i < 2u) rem = rem_from(i);
-          rem = min(rem, (uint32_t)__shfl_xor((int)rem, (int)Rp));  // the two words of a run (lanes i = 0 and 1)
-        } else if (mine) {
-          rem = min(rem_from(0u), rem_from(1u));  // 33..64 runs: one lane per run reads both words
+        // The previous bulk step left a lower bound per run in LDS (what the bitmap said, minus
+        // the levels taken since): no trip to the bitmap while every bound is positive.
+        // min(smallest bound over the runs, cap_l) by bisection with ballots: a handful of
+        // scalar steps where a shuffle reduction over 64 lanes is six LDS-crossbar round trips
+        const uint32_t cap_l = min(64u >> lg, (uint32_t)(gd.D - d + 1));
+        auto least = [&](uint32_t x) -> uint32_t {  // lanes without a run pass 64
+          if (lg < 4u) {  // few runs: the shuffle reduction is the shorter one (lg steps against log2(cap_l) + 1)
+            for (uint32_t o = 1; o < Rp; o <<= 1) x = min(x, (uint32_t)__shfl_xor((int)x, (int)o));
+            return min((uint32_t)__builtin_amdgcn_readfirstlane((int)x), cap_l);
+          }
+          uint32_t lo_ = 0, hi_ = cap_l;
+          while (lo_ < hi_) {
+            const uint32_t mid = (lo_ + hi_ + 1u) >> 1;
+            if (__ballot(x < mid)) hi_ = mid - 1u; else lo_ = mid;
+          }
+          return lo_;
+        };
+        uint32_t rem_own = 0, rem_all = 0;
+        if (rem_kept) {
+          rem_own = (mine && i == 0u) ? prem[r] : 64u;
+          rem_all = least(rem_own);
         }
-        for (uint32_t o = 1; o < Rp; o <<= 1) rem = min(rem, (uint32_t)__shfl_xor((int)rem, (int)o));  // over the runs
-        rem = (uint32_t)__builtin_amdgcn_readfirstlane((int)rem);
+        if (rem_all == 0u) {
+          if (Rp <= 32u) {
+            if (mine && i < 2u) rem = rem_from(i);
+            rem = min(rem, (uint32_t)__shfl_xor((int)rem, (int)Rp));  // the two words of a run (lanes i = 0 and 1)
+          } else if (mine) {
+            rem = min(rem_from(0u), rem_from(1u));  // 33..64 runs: one lane per run reads both words
+          }
+          rem_own = rem;
+          rem_all = least(rem_own);
+        }
+        rem = rem_all;
         const uint32_t L = min(min(rem, 64u >> lg), (uint32_t)(gd.D - d + 1));
         bool ok = !mine;
         if (mine && i < L) ok = d + (int)i < gd.prune_from || lrs_has_kmer(rsg, rs, rmask, v);  // :1050
@@ -676,7 +704,11 @@ __device__ __forceinline__ FillOut fill_lds_body(const uint32_t* __restrict__ su
           lvl_top = d + (int)lrun - 1;
           const uint32_t last = (uint32_t)__shfl((int)v, (int)(((lrun - 1u) << lg) + r));
           lds_sync();
-          if (mine && i == 0) ncur[r] = last;  // counts are unchanged along a run
+          if (mine && i == 0) {
+            ncur[r] = last;  // counts are unchanged along a run
+            prem[r] = rem_own - lrun;
+          }
+          rem_kept = true;
           lds_sync();
           d += (int)lrun - 1;
           st_bulkB++;
@@ -685,6 +717,7 @@ __device__ __forceinline__ FillOut fill_lds_body(const uint32_t* __restrict__ su
         }
       }
       st_slowB++;
+      rem_kept = false;  // the per-level step rebuilds the border
       xb += nb;
       if (nb == 1) {
         // single-entry frontier: its <=4 successors are distinct, no merging needed
@@ -1385,7 +1418,7 @@ __global__ __launch_bounds__(64) void g2s_fill_lds_rsg(G2S_FUSED_PARAMS, uint32_
 namespace g2s {
 
 size_t fill_lds_bytes(uint32_t rs_cap, uint32_t fcap) {
-  return 4u * (2 * fcap * 3 + (2 * fcap) * 2 + (2 * fcap) + LDS_TG + 3 * (2 * fcap) + 4 + LDS_TF + 3 * LDS_CW + rs_cap);
+  return 4u * (2 * fcap * 3 + (2 * fcap) * 2 + (2 * fcap) + LDS_TG + 3 * (2 * fcap) + 4 + LDS_TF + G2S_BULK_MAX + 3 * LDS_CW + rs_cap);
 }
 size_t extract_lds_bytes(uint32_t fcap) {
   const uint32_t w = fcap > 256u ? fcap : 256u;
