@@ -637,7 +637,10 @@ __device__ __forceinline__ FillOut fill_lds_body(const uint32_t* __restrict__ su
         if (lrun > L) lrun = L;
         if (lrun >= 1u && nlog + lrun * R <= cap && nhit + 64u <= TH) {
           const bool act = mine && i < lrun;
-          if (act && R > 1) {
+          // (both strands of a k-mer are an even-orientation and an odd-orientation run of one
+          // unitig walking towards each other: nothing to look for when all runs walk one way)
+          const bool mixed = __ballot(mine && i == 0u && up) != 0ull && __ballot(mine && i == 0u && !up) != 0ull;
+          if (act && R > 1 && mixed) {
             // Q7: the other strand of my k-mer on another run at this level.  All states of the
             // bulk are distinct, so claiming (epoch | k-mer index, level) in the merge table can
             // only collide with the other strand.  (Index truncated above 2^26 k-mers: the flag
