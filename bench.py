@@ -214,7 +214,7 @@ def main():
         alg_bytes = algorithmic_bytes(x_units, s_units, io_bytes) / launches  # per launch
         achieved = alg_bytes / (kern_ms / 1e3) / 1e9 if kern_ms > 0 else 0.0
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_v9_pmc_fill_lds.json")
+        pmc = os.path.join(ROOT, "profiles", "r01_v10_pmc_fill_lds.json")
         if os.path.exists(pmc) and kname == "g2s_fill_lds" and args.gaps == 500 and args.variant == 3:
             try:
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
