@@ -905,6 +905,7 @@ __device__ __forceinline__ FillOut fill_lds_body(const uint32_t* __restrict__ su
             if (err != 0 && l2 >= 0 && td == l2) h2 = th_c[t];
             if (h1 | h2) j = tj;
           }
+          if (__ballot(j < (1 << 30)) == 0ull) continue;  // no hit of an accepted length among these 64
           int jm = j;
           for (int o = 32; o > 0; o >>= 1) jm = min(jm, __shfl_xor(jm, o));
           if (jm < bestj) { bestj = jm; c1 = 0; c2 = 0; }
