@@ -30,9 +30,11 @@
 //            levels that branch, merge, die or leave a unitig take the per-level step;
 //   phase D1 walks the parent links phase B recorded instead of the graph and sweeps
 //            the bulk-produced levels 64 at a time.
-// A gap that does not fit a pass (frontier, right set, label table, target hits, state
-// log, host buffer) is flagged and run again by the next pass; the last resort is the
-// HBM tier (also used for even k: explicit predecessor table).
+// A right set or a state log that outgrows its share moves, inside the kernel, to a chunk
+// of a per-launch pool in HBM (spill pool / log pool) and the gap goes on.  A gap that does
+// not fit a pass otherwise (frontier, label table, target hits, host buffer) is flagged and
+// run again by the next pass; the last resort is the HBM tier (also used for even k:
+// explicit predecessor table).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
