@@ -1367,12 +1367,9 @@ int batches_stage2(const std::vector<g2s_batch*>& bs, g2s_session* lead, g2s_res
         if (todo_tb[gi]) {
           const g2s_batch* b = owner[gi];
           const size_t i = local[gi];
-          const g2s_batch::GapInfo& in = b->info[i];
-          const int pick = in.n_len > 1 ? (int)(lead->rcache.at_const(rand_off[gi]) % in.n_len) : 0;
-          (void)pick;
-          const int expect = expect_draws[gi];
           sub_traceback(g, fp, j, b->views[i], b->prep[i], lead->rcache.ptr(rand_off[gi]), arena + arena_off[gi], &r);
-          if (r.draws != expect) r.flags |= G2S_GAP_BACKTRACE_FAIL;  // cannot happen: the draw count was proven fixed
+          // cannot happen: the draw count was proven fixed, or counted over the same draws
+          if (r.draws != expect_draws[gi]) r.flags |= G2S_GAP_BACKTRACE_FAIL;
         }
         if (r.flags & G2S_GAP_PHASE_D) {
           r.fill_off = (uint64_t)arena_off[gi] + (uint64_t)(j.lmf - r.left_fuz);
