@@ -1639,6 +1639,18 @@ extern "C" int g2s_test_post_gap(const g2s_graph* gh, const g2s_params* p, const
     const int fixed = sub_fixed_draws(v, prep, pick);
     sub_traceback(g, fp, j, v, prep, rands.data(), buf, res);
     if (fixed >= 0 && fixed != res->draws) return fail(G2S_ERR_STATE, "stop-depth analysis disagrees with the traceback");
+    // the two shortcuts of the batch path, checked here on the CPU: the draw-count walk, and
+    // the fill written without rand() values when no state has a second parent
+    if (sub_count_draws(g, v, prep, rands.data()) != res->draws)
+      return fail(G2S_ERR_STATE, "draw-count walk disagrees with the traceback");
+    if (go.n_len == 1 && v.n_xp == 0 && fixed >= 0) {
+      std::vector<char> buf2(j.buf_bytes(k, fp.d_err), 0);
+      g2s_result r2;
+      memset(&r2, 0, sizeof r2);
+      sub_traceback(g, fp, j, v, prep, nullptr, buf2.data(), &r2);
+      if (r2.draws != res->draws || r2.left_fuz != res->left_fuz || memcmp(buf2.data(), buf, buf2.size()) != 0)
+        return fail(G2S_ERR_STATE, "rand()-free traceback disagrees with the traceback");
+    }
     res->vertices = prep.sub[0]; res->edges = prep.sub[1]; res->nontrivial_components = prep.sub[2];
     res->size_nontrivial_components = prep.sub[3]; res->vertices_final = prep.sub[4]; res->edges_final = prep.sub[5];
     res->fill_off = (uint64_t)(j.lmf - res->left_fuz);
