@@ -162,6 +162,7 @@ def test_worker_pool_runs_every_task_once(product):
     product.test_worker_pool(8, 3000, 40)
     product.test_worker_pool(16, 500, 1000)
     product.test_worker_pool(1, 10, 100)
+    product.test_worker_pool(16, 2000, 10)  # fewer tasks than workers: only as many workers are woken as there are tasks
 
 
 def test_product_rand_stream_matches_libc(product):
