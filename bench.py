@@ -1,27 +1,38 @@
 #!/usr/bin/env python3
-"""bench.py — gaps filled/sec of the MI355X fill path on BASELINE.json's workload.
+"""bench.py — gaps filled/sec of the MI355X fill path on BASELINE.json's workloads.
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path (g2s_batch_run: the fused kernel g2s_fill_lds =
-phases A-D1 of every gap, writing its results into pinned host memory [+ the HBM-tier
-kernels for gaps that outgrow the LDS], host phase D2 overlapping the kernel, the
-in-order rand() offset pass and the tracebacks) over one batch of synthetic gaps whose
-descriptors are already resident in HBM (g2s_batch_prepare is outside the timed region,
-as is the one-off graph build + upload, reported separately).
+A "step" is ONE call of the boundary's hot-path entry point on one list of synthetic gaps
+handed over as host C structs (g2s_gap[]): g2s_fill_batch at N=1, g2s_team_fill at N>1.
+The timed region is that call and nothing else, so it contains what SURVEY.md 8(d)
+defines as the metric: flank k-mer -> node resolution and the upload of the gap
+descriptors (g2s_batch_prepare), the kernels (g2s_fill_lds = phases A-D1 of every gap,
+results written into pinned host memory; the HBM-tier kernels for what outgrows the LDS),
+the host part of phase D (D2 under the kernel, in-order rand() offsets, tracebacks) and
+the results in the caller's buffers.  The one-off graph build + upload is outside and
+reported separately.  Python builds the g2s_gap array once, before the timed region.
 
-Workload at N=1: BASELINE config 2 — synthetic 3 Mbp genome (seed 20240101),
-k=31, -fuz 10, -dist-error 500, 500 gaps of 200-1000 bp (seed 20240103), one gap
-per record with (k+fuz)-base flanks.  Default graph variant V3 = planted repeats
-(V1) + second haplotype with a SNP every ~500 bp (V2); --variant 0/1/2 select the
-others.  N>1: one process per GPU (torchrun), the graph replicated per GPU, every
-rank fills its own 500-gap set (seed + rank) -> weak scaling, no data-path
-collective; torch.distributed is used only for the barrier and the max/sum
-reduction of the timing.
+Workloads (synthetic, seeded): --config C2 (default at N=1: 3 Mbp genome
+V3 = planted repeats + second haplotype, k=31, -fuz 10, -dist-error 500, 500 gaps of
+200-1000 bp), C3 (default at N>1: the same graph, ONE list of 10 000 gaps whatever N is:
+strong scaling), C4 (60 Mbp, k=63, 2 000 gaps), C5 (-dist-error 2000, 1 000 gaps of 2-5
+kbp); individual parameters can be overridden.
 
-Rank 0 prints ONE JSON line (see README/DESIGN.md §Measurement for the fields).
+N>1: one process drives N GPUs — the reference's dispatcher (Gap2Seq.cpp:296-306: threads
+pulling scaffolds from a shared iterator) with one session (host thread + stream) per GPU:
+the graph is replicated in every GPU's HBM, the gap list is cut into contiguous groups,
+every session pulls the next group from a shared counter (static start, stealing by
+construction), there is no collective; the rand()-dependent part runs once in gap order,
+so the results equal the one-GPU results bit for bit (checked in the run).  Under
+torch.distributed.run the other ranks only join the barriers around the timed region
+(their GPUs are driven by rank 0's sessions); exit status is non-zero when fewer than N
+devices are usable.
+
+Rank 0 prints ONE JSON line (README / DESIGN.md §5 describe the fields).
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -32,6 +43,14 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+CONFIGS = {
+    #      genome    k  gaps  min   max  d_err  BASELINE.json configs[] text
+    "C2": (3000000, 31, 500, 200, 1000, 500, "configs[1]: synthetic 3 Mbp genome, 500 gaps len 200-1000 bp, k=31, 1xMI355X"),
+    "C3": (3000000, 31, 10000, 200, 1000, 500, "configs[2]: same 3 Mbp DBG, 10 000 gaps, static shard across the GPUs of one node"),
+    "C4": (60000000, 63, 2000, 200, 1000, 500, "configs[3]: k=63 (128-bit k-mers), ~60 Mbp DBG, 2 000 gaps, 1xMI355X"),
+    "C5": (3000000, 31, 1000, 2000, 5000, 2000, "configs[4]: --dist-error 2000 deep-DP stress, 1 000 gaps len 2-5 kbp"),
+}
 
 
 def parse_gaps(scaffolds_text, fuz):
@@ -51,226 +70,343 @@ def algorithmic_bytes(x, s, io_bytes):
     return 24 * x + 8 * s + io_bytes
 
 
+class Runner:
+    """The boundary call of one step, with every buffer allocated once."""
+
+    def __init__(self, P, sessions, gaps, group):
+        self.P, self.lib = P, P.load_library()
+        self.sessions = sessions
+        self.n = len(gaps)
+        self.group = group
+        self.arr, self._keep = P._gap_array([P.Gap(g["left"], g["right"], g["gap_len"], g["lmf"], g["rmf"]) for g in gaps])
+        self.nbytes = self.lib.g2s_team_arena_bytes(sessions[0].h, self.arr, self.n)
+        self.arena = C.create_string_buffer(max(1, self.nbytes))
+        self.res = (P.g2s_result * max(1, self.n))()
+        self.hs = (C.c_void_p * len(sessions))(*[s.h for s in sessions])
+        self.tm = P.g2s_timing()
+
+    def step(self):
+        """srand(1) + ONE ABI call; returns its wall time in seconds (the timed region of a step)."""
+        self.sessions[0].srand(1)
+        t0 = time.perf_counter()
+        if len(self.sessions) == 1 and self.group == 0:
+            rc = self.lib.g2s_fill_batch(self.sessions[0].h, self.arr, self.n, self.res, self.arena, self.nbytes)
+        else:
+            rc = self.lib.g2s_team_fill(self.hs, len(self.sessions), self.arr, self.n, self.group, self.res, self.arena,
+                                        self.nbytes, C.byref(self.tm))
+        dt = time.perf_counter() - t0
+        self.P._check(rc)
+        return dt
+
+    def timing(self):
+        if len(self.sessions) == 1 and self.group == 0:
+            self.P._check(self.lib.g2s_session_last_timing(self.sessions[0].h, C.byref(self.tm)))
+        return self.tm
+
+    def results(self):
+        raw = self.arena.raw
+        return [self.P.FillResult(self.res[i], raw) for i in range(self.n)]
+
+
+def result_key(r):
+    return (r.count, r.left_fuz, r.right_fuz, r.flags, r.draws, r.fill, tuple(r.substats), r.phaseC_count, tuple(r.lengths))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200, help="timed steps (a step takes ~1.3 ms: 200 of them ride out host noise)")
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=0, help="timed steps (0 = 200 for C2, fewer for the larger configs)")
+    ap.add_argument("--warmup", type=int, default=-1)
+    ap.add_argument("--config", default="", help="C2 | C3 | C4 | C5 (default: C2 at --gpus 1, C3 beyond)")
     ap.add_argument("--variant", type=int, default=3, help="graph variant: bit0 repeats (V1), bit1 bubbles (V2)")
-    ap.add_argument("--genome", type=int, default=3000000)
-    ap.add_argument("--gaps", type=int, default=500, help="gaps per GPU")
-    ap.add_argument("--min-len", type=int, default=200)
-    ap.add_argument("--max-len", type=int, default=1000)
-    ap.add_argument("--k", type=int, default=31)
+    ap.add_argument("--genome", type=int, default=0)
+    ap.add_argument("--gaps", type=int, default=0, help="gaps in the list (whole job)")
+    ap.add_argument("--min-len", type=int, default=0)
+    ap.add_argument("--max-len", type=int, default=0)
+    ap.add_argument("--k", type=int, default=0)
     ap.add_argument("--fuz", type=int, default=10)
-    ap.add_argument("--dist-error", type=int, default=500)
-    ap.add_argument("--sessions", type=int, default=1,
-                    help="sessions per GPU; >1 (or --group) times g2s_team_fill: groups of gaps pipelined over the "
-                         "sessions, host flank lookup + upload INSIDE the timed region")
-    ap.add_argument("--group", type=int, default=0, help="gaps per group for --sessions (0 = library default)")
+    ap.add_argument("--dist-error", type=int, default=0)
+    ap.add_argument("--sessions", type=int, default=1, help="sessions (host thread + stream) per GPU")
+    ap.add_argument("--group", type=int, default=-1,
+                    help="gaps per group of the dispatcher (-1 = one group per session at N>1, one batch at N=1)")
     ap.add_argument("--host-threads", type=int, default=0, help="host worker threads per session (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the barrier/timing reduction")
-    ap.add_argument("--share-device", action="store_true",
-                    help="testing only: every rank uses HIP device 0 (needs --backend gloo)")
+    ap.add_argument("--no-c3-beside", action="store_true", help="N=1/C2: skip the C3-on-one-GPU measurement beside it")
+    ap.add_argument("--backend", default="gloo", help="torch.distributed backend for the barriers under torchrun")
+    ap.add_argument("--share-device", action="store_true", help="testing only: all N sessions on HIP device 0")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="testing only (CPU): the launch protocol — rendezvous, barriers, timing reduction, one JSON "
+                         "line from rank 0 — without touching a device or measuring anything")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    if world > 1:
-        import torch
+    if world > 1:  # launched by torch.distributed.run: barriers only, no data-path collective exists
         import torch.distributed as dist
-        if args.share_device:
-            local_rank = 0
-        torch.cuda.set_device(local_rank)
         dist.init_process_group(args.backend, rank=rank, world_size=world)
-    from gap2seq_amd import lib as P
-    from gap2seq_amd import shard
+    ngpu = max(1, args.gpus)
 
-    if P.G2S.device_count() < 1:
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    from gap2seq_amd import shard
+    if rank != 0:
+        # this rank's GPU is driven by a session of rank 0's process (one process, N devices)
+        barrier()  # timed region begins
+        t_begin = time.perf_counter()
+        barrier()  # timed region ends
+        shard.reduce_timing(time.perf_counter() - t_begin, 0.0, dist)
+        dist.destroy_process_group()
+        return 0
+    if args.dry_run:
+        barrier()
+        t_begin = time.perf_counter()
+        time.sleep(0.01)
+        elapsed = time.perf_counter() - t_begin
+        barrier()
+        elapsed, units = shard.reduce_timing(elapsed, 1.0, dist)
+        print(json.dumps({"dry_run": True, "n_gpus": ngpu, "ranks_under_torchrun": world, "value": None,
+                          "elapsed_max_over_ranks_s": round(elapsed, 4), "units": units,
+                          "group": shard.group_size(10000, ngpu), "groups": len(shard.group_bounds(10000, shard.group_size(10000, ngpu)))}))
+        if dist is not None:
+            dist.destroy_process_group()
+        return 0
+
+    from gap2seq_amd import lib as P
+
+    ndev = P.G2S.device_count()
+    if ndev < 1:
         raise SystemExit("bench.py: no gfx950 device; the fill path has no CPU fallback")
+    if ndev < ngpu and not args.share_device:
+        raise SystemExit("bench.py: --gpus %d but only %d gfx950 device(s) are usable" % (ngpu, ndev))
+    devices = [0] * ngpu if args.share_device else list(range(ngpu))
+
+    cfg_name = args.config or ("C2" if ngpu == 1 else "C3")
+    genome_bp, k, ngaps, min_len, max_len, d_err, cfg_text = CONFIGS[cfg_name]
+    genome_bp = args.genome or genome_bp
+    k = args.k or k
+    ngaps = args.gaps or ngaps
+    min_len = args.min_len or min_len
+    max_len = args.max_len or max_len
+    d_err = args.dist_error or d_err
+    custom = any([args.genome, args.k, args.gaps, args.min_len, args.max_len, args.dist_error, args.variant != 3,
+                  args.fuz != 10])
+    steps = args.steps or {"C2": 200, "C3": 30, "C4": 30, "C5": 3}[cfg_name]
+    warmup = args.warmup if args.warmup >= 0 else (10 if steps >= 100 else 3 if steps >= 10 else 1)
 
     # ---- workload (untimed) -------------------------------------------------------
     t0 = time.time()
-    reads = P.G2S.synth_genome(args.genome, args.variant, 20240101)
+    reads = P.G2S.synth_genome(genome_bp, args.variant, 20240101)
     seqs = [ln for ln in reads.splitlines() if not ln.startswith(">")]
-    scaf = P.G2S.synth_gaps(reads, args.k, args.fuz, args.gaps, args.min_len, args.max_len, 20240103 + rank)
-    gaps = parse_gaps(scaf, args.fuz)
+    gaps = parse_gaps(P.G2S.synth_gaps(reads, k, args.fuz, ngaps, min_len, max_len, 20240103), args.fuz)
     t_synth = time.time() - t0
     t0 = time.time()
-    os.environ["G2S_DEVICE"] = str(local_rank)  # the graph is built on (and stays on) this rank's GPU
-    graph = P.Graph.from_seqs(seqs, args.k, 1)
+    os.environ["G2S_DEVICE"] = str(devices[0])  # the graph is built on (and stays on) the first GPU
+    graph = P.Graph.from_seqs(seqs, k, 1)
     t_build = time.time() - t0
     t0 = time.time()
-    graph.upload(local_rank)
+    for d in sorted(set(devices)):
+        graph.upload(d)  # replicas for the other GPUs
     t_upload = time.time() - t0
-    sess = P.Session(graph, local_rank, d_err=args.dist_error, randseed=1, host_threads=args.host_threads)
-    batch = sess.prepare([P.Gap(g["left"], g["right"], g["gap_len"], g["lmf"], g["rmf"]) for g in gaps])
 
-    def sync_all():
-        if dist is not None:
-            import torch
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
+    def make_sessions(devs, per_dev):
+        return [P.Session(graph, d, d_err=d_err, randseed=1, host_threads=args.host_threads)
+                for d in devs for _ in range(per_dev)]
 
-    team = None
-    if args.sessions > 1 or args.group > 0:
-        team = [sess] + [P.Session(graph, local_rank, d_err=args.dist_error, randseed=1)
-                         for _ in range(args.sessions - 1)]
-        team_gaps = [P.Gap(g["left"], g["right"], g["gap_len"], g["lmf"], g["rmf"]) for g in gaps]
-        team_prep, _ = P.team_fill(team, team_gaps, args.group, "raw")
+    sessions = make_sessions(devices, max(1, args.sessions))
+    group = args.group
+    if group < 0:
+        group = 0 if len(sessions) == 1 else shard.group_size(len(gaps), len(sessions))
+    run = Runner(P, sessions, gaps, group)
 
-    def one_step():
-        sess.srand(1)
-        if team is None:
-            batch.run()  # synchronous: returns after kernels, copies and host phase D
-            return batch.timing()
-        return P.team_fill(team, team_gaps, args.group, "raw", team_prep)[1]
-
-    for _ in range(args.warmup):
-        one_step()
+    for _ in range(warmup):
+        run.step()
     acc = dict(ms_right_bfs=0.0, ms_left_dp=0.0, ms_extract=0.0, ms_fill_lds=0.0, ms_extract_lds=0.0, ms_d2h=0.0,
-               ms_host_post=0.0, ms_total=0.0, launches=0)
-    sync_all()
+               ms_host_post=0.0, ms_prepare=0.0, ms_total=0.0, launches=0, lds_launches=0)
+    in_call = 0.0
+    barrier()
     t_begin = time.perf_counter()
-    for _ in range(args.steps):
-        tm = one_step()
-        acc["ms_right_bfs"] += tm.ms_right_bfs
-        acc["ms_left_dp"] += tm.ms_left_dp
-        acc["ms_extract"] += tm.ms_extract
-        acc["ms_fill_lds"] += tm.ms_fill_lds
-        acc["ms_extract_lds"] += tm.ms_extract_lds
-        acc["ms_d2h"] += tm.ms_d2h
-        acc["ms_host_post"] += tm.ms_host_post
-        acc["ms_total"] += tm.ms_total
+    for _ in range(steps):
+        in_call += run.step()
+        tm = run.timing()
+        for key in ("ms_right_bfs", "ms_left_dp", "ms_extract", "ms_fill_lds", "ms_extract_lds", "ms_d2h",
+                    "ms_host_post", "ms_prepare", "ms_total"):
+            acc[key] += getattr(tm, key)
         acc["launches"] += tm.launches_left_dp
-    sync_all()
+        acc["lds_launches"] += tm.lds_launches
     elapsed = time.perf_counter() - t_begin
-    elapsed, units = shard.reduce_timing(elapsed, float(len(gaps) * args.steps), dist)
+    barrier()
+    elapsed, units = shard.reduce_timing(elapsed, float(len(gaps) * steps), dist)
 
-    # host-buffers-in / host-buffers-out rate (prepare + run), reported beside `value`, never as `value`
-    t_pcie = time.perf_counter()
-    sess.srand(1)
-    sess.fill_batch([P.Gap(g["left"], g["right"], g["gap_len"], g["lmf"], g["rmf"]) for g in gaps])
-    t_pcie = time.perf_counter() - t_pcie
-    tm_team = one_step() if team is not None else None
-    sess.srand(1)
-    batch.run()
-    tm = batch.timing()
-    res = batch.results()
-    if tm_team is not None:
-        tm_team.fill_bytes = tm.fill_bytes
-        tm_team.flank_bytes = tm.flank_bytes
-        tm = tm_team
+    tm = run.timing()
+    res = run.results()
     filled = sum(1 for r in res if r.count > 0)
     q7 = sum(1 for r in res if r.flags & P.G2S_GAP_Q7)
 
-    if rank == 0:
-        steps = max(1, args.steps)
-        # ---- CPU baseline: the oracle (faithful port of the reference algorithm), same gaps
-        cpu = None
-        octr = None
-        if world == 1 and not args.no_cpu_baseline:
-            import oracle_lib as O
-            og = O.OracleGraph(seqs, args.k, 1)
-            passes = 3
-            secs1 = 0.0
-            for _ in range(passes):
-                s1, ofilled, octr = O.time_fill_batch(og, gaps, args.dist_error, 1)
-                secs1 += s1
-            ncpu = os.cpu_count() or 1
-            sN, _, _ = O.time_fill_batch(og, gaps, args.dist_error, ncpu)
-            cpu = dict(value=round(len(gaps) * passes / secs1, 2), unit="gaps/s", cores=1, kind="port",
-                       sample="all %d gaps of the bench workload, %d passes, oracle fill_gap only (graph build excluded)"
-                              % (len(gaps), passes),
-                       value_all_cores=round(len(gaps) / sN, 2), cores_all=ncpu, filled=ofilled,
-                       oracle_expansions_A_B_D1=[octr[0], octr[2], octr[4]],
-                       oracle_states_A_B_D1=[octr[1], octr[3], octr[5]])
-            og.free()
-        # ---- roofline of the dominant kernel, measured live with HIP events on the session stream.
-        # g2s_fill_lds runs phases A (right search), B (left DP), C (target check) and D1 (closure)
-        # of every gap that fits the LDS tier, one wave per gap.  Algorithmic bytes
-        # = 24 B per expansion + 8 B per newly set state over phases A, B and D1 + per-gap
-        # flank/fill I/O, with the expansion/state counts of the REFERENCE algorithm as counted by
-        # the CPU oracle on the same gaps (the product's own counters are lower for phase A: it
-        # visits every node once, the reference re-expands nodes reached by walks of several
-        # lengths); without the CPU leg the product's counters are used and labelled so.
-        io_bytes = tm.flank_bytes + tm.fill_bytes
-        if tm.lds_tier_gaps > 0:
-            kname = "g2s_fill_lds"
-            if octr is not None and tm.lds_tier_gaps == len(gaps):
-                x_units, s_units, counted_by = octr[0] + octr[2] + octr[4], octr[1] + octr[3] + octr[5], "oracle"
-            else:
-                x_units, s_units, counted_by = tm.xA + tm.xB + tm.xD, tm.sA + tm.sB + tm.sD, "product"
-            launches = float(max(1, tm.lds_launches))
-            kern_ms = acc["ms_fill_lds"] / steps / launches  # average launch duration
+    # ---- N>1: the list sharded over N GPUs must give the one-GPU result, bit for bit ----------
+    one_gpu = None
+    if len(sessions) > 1:
+        solo = make_sessions(devices[:1], 1)
+        r1 = Runner(P, solo, gaps, 0)
+        r1.step()
+        same = [result_key(a) for a in r1.results()] == [result_key(b) for b in res]
+        if not same:
+            raise SystemExit("bench.py: results on %d sessions differ from the one-session results" % len(sessions))
+        n1 = max(3, min(steps, 10))
+        t1 = 0.0
+        for _ in range(n1):
+            t1 += r1.step()
+        one_gpu = dict(value=round(len(gaps) * n1 / t1, 2), unit="gaps/s", steps=n1, ms_per_step=round(t1 / n1 * 1e3, 4),
+                       note="the same list through g2s_fill_batch on device %d alone, same run" % devices[0])
+        for s in solo:
+            s.destroy()
+
+    # ---- N=1 on C2: config 3's list on this one GPU, beside the headline ----------------------
+    c3_beside = None
+    if ngpu == 1 and cfg_name == "C2" and not custom and not args.no_c3_beside:
+        g3 = parse_gaps(P.G2S.synth_gaps(reads, k, args.fuz, 10000, min_len, max_len, 20240103), args.fuz)
+        r3 = Runner(P, sessions[:1], g3, 0)
+        for _ in range(2):
+            r3.step()
+        n3, t3, k3 = 10, 0.0, 0.0
+        for _ in range(n3):
+            t3 += r3.step()
+            k3 += r3.timing().ms_fill_lds
+        tm3 = r3.timing()
+        x3, s3 = tm3.xA + tm3.xB + tm3.xD, tm3.sA + tm3.sB + tm3.sD
+        ab3 = algorithmic_bytes(x3, s3, tm3.flank_bytes + tm3.fill_bytes) / max(1, tm3.lds_launches)
+        kms3 = k3 / n3 / max(1, tm3.lds_launches)
+        c3_beside = dict(workload=CONFIGS["C3"][6], value=round(10000 * n3 / t3, 2), unit="gaps/s", steps=n3,
+                         ms_per_step=round(t3 / n3 * 1e3, 4), kernel_ms_per_launch=round(kms3, 4),
+                         launches_per_step=tm3.lds_launches, algorithmic_bytes_per_launch=ab3,
+                         units_counted_by="product", roofline_frac=round(ab3 / (kms3 / 1e3) / 1e9 / HBM_PEAK_GBS, 6),
+                         filled=sum(1 for r in r3.results() if r.count > 0))
+
+    # ---- CPU baseline: the oracle (port of the reference algorithm) on the GPU box's host cores,
+    # N=1 only, on a bounded sample of the same gaps
+    cpu = None
+    octr = None
+    if ngpu == 1 and not args.no_cpu_baseline:
+        import oracle_lib as O
+        og = O.OracleGraph(seqs, k, 1)
+        sample = gaps
+        # ~1 k gaps/s on one core for C2-shaped gaps; deep gaps (C5) take ~25 ms each
+        budget = 1500 if d_err <= 500 else 300
+        if len(sample) > budget:
+            sample = gaps[:budget]
+        passes = 3 if len(sample) <= 500 else 1
+        secs1 = 0.0
+        for _ in range(passes):
+            s1, ofilled, octr = O.time_fill_batch(og, sample, d_err, 1)
+            secs1 += s1
+        ncpu = os.cpu_count() or 1
+        sN, _, _ = O.time_fill_batch(og, sample, d_err, ncpu)
+        cpu = dict(value=round(len(sample) * passes / secs1, 2), unit="gaps/s", cores=1, kind="port",
+                   sample="%s %d gaps of the bench list, %d pass(es), oracle fill_gap only (graph build excluded)"
+                          % ("all" if len(sample) == len(gaps) else "the first", len(sample), passes),
+                   value_all_cores=round(len(sample) / sN, 2), cores_all=ncpu, filled=ofilled,
+                   oracle_expansions_A_B_D1=[octr[0], octr[2], octr[4]],
+                   oracle_states_A_B_D1=[octr[1], octr[3], octr[5]])
+        if len(sample) != len(gaps):
+            octr = None  # the oracle's unit counts cover the sample only
+        og.free()
+
+    # ---- roofline of the dominant kernel, its duration measured with HIP events on the session
+    # streams inside the timed steps (g2s_timing.ms_fill_lds, summed over launches).  g2s_fill_lds
+    # runs phases A (right search), B (left DP), C (target check) and D1 (closure) of every gap that
+    # fits the LDS tier.  Algorithmic bytes (SURVEY.md 8d) = 24 B per expansion + 8 B per newly set
+    # state over phases A, B and D1 + per-gap flank/fill I/O, with the unit counts of the REFERENCE
+    # algorithm as counted by the CPU oracle on the same gaps when the CPU leg covered the whole
+    # list (the product's own counters are lower for phase A: it visits every node once, the
+    # reference re-expands nodes reached by walks of several lengths); otherwise the product's
+    # counters, labelled so.
+    io_bytes = tm.flank_bytes + tm.fill_bytes
+    if tm.lds_tier_gaps > 0:
+        kname = "g2s_fill_lds"
+        if octr is not None and tm.lds_tier_gaps == len(gaps):
+            x_units, s_units, counted_by = octr[0] + octr[2] + octr[4], octr[1] + octr[3] + octr[5], "oracle"
         else:
-            kname, x_units, s_units, counted_by = "g2s_left_dp", tm.xB, tm.sB, "product"
-            kern_ms = acc["ms_left_dp"] / steps
-            launches = acc["launches"] / steps
-        alg_bytes = algorithmic_bytes(x_units, s_units, io_bytes) / launches  # per launch
-        achieved = alg_bytes / (kern_ms / 1e3) / 1e9 if kern_ms > 0 else 0.0
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_v10_pmc_fill_lds.json")
-        if os.path.exists(pmc) and kname == "g2s_fill_lds" and args.gaps == 500 and args.variant == 3:
-            try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        roofline = dict(bound="hbm", kernel=kname, achieved=round(achieved, 3), peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(achieved / HBM_PEAK_GBS, 6), traffic=traffic,
-                        algorithmic_bytes_per_launch=alg_bytes, expansions=x_units, states=s_units,
-                        units_counted_by=counted_by, kernel_ms_per_launch=round(kern_ms, 4),
-                        launches_per_step=launches, lds_tier_gaps=tm.lds_tier_gaps)
-        out = {
-            "metric": "gaps filled/sec (whole node), k=31 synthetic 3 Mbp DBG",
-            "value": round(units / elapsed, 2),
-            "unit": "gaps/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(elapsed / steps * 1e3, 4),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "u32",
-            "data": "synthetic",
-            "config": {"workload": "BASELINE config 2 (C2): %d bp genome V%d, k=%d, %d gaps/GPU len %d-%d, fuz %d, "
-                                   "dist-error %d" % (args.genome, args.variant, args.k, args.gaps, args.min_len,
-                                                      args.max_len, args.fuz, args.dist_error),
-                       "gaps_per_gpu": args.gaps, "genome_bp": args.genome, "variant": args.variant, "k": args.k,
-                       "parallelism": "gap-sharded x%d, graph replicated, no collective" % world,
-                       "sessions_per_gpu": args.sessions, "group": args.group},
-            "roofline": roofline,
-            "cpu_baseline": cpu,
-            "filled": filled,
-            "fill_batch_ms_incl_prepare_and_python_marshalling": round(t_pcie * 1e3, 3),
-            "q7_gaps": q7,
-            "retried_gaps": tm.retried_gaps,
-            "breakdown_ms_per_step": {"fill_lds_kernel": round(acc["ms_fill_lds"] / steps, 4),
-                                      "extract_lds_kernel": round(acc["ms_extract_lds"] / steps, 4),
-                                      "hbm_tier_kernels": round((acc["ms_right_bfs"] + acc["ms_left_dp"] +
-                                                                 acc["ms_extract"]) / steps, 4),
-                                      "d2h_closures": round(acc["ms_d2h"] / steps, 4),
-                                      "host_phase_d": round(acc["ms_host_post"] / steps, 4),
-                                      "batch_run_total": round(acc["ms_total"] / steps, 4)},
-            "setup_s": {"synth": round(t_synth, 3), "graph_build": round(t_build, 3),
-                        "graph_upload": round(t_upload, 3)},
-            "graph": {"kmers": graph.num_kmers, "unitigs": graph.num_unitigs,
-                      "hbm_bytes": graph.device_bytes(local_rank)},
-        }
-        print(json.dumps(out))
-    batch.free()
-    for t in (team or [])[1:]:
-        t.destroy()
-    sess.destroy()
+            x_units, s_units, counted_by = tm.xA + tm.xB + tm.xD, tm.sA + tm.sB + tm.sD, "product"
+        launches = acc["lds_launches"] / float(steps)
+        kern_ms = acc["ms_fill_lds"] / max(1, acc["lds_launches"])  # average launch duration
+    else:
+        kname, x_units, s_units, counted_by = "g2s_left_dp", tm.xB, tm.sB, "product"
+        launches = max(1.0, acc["launches"] / float(steps))
+        kern_ms = acc["ms_left_dp"] / max(1, acc["launches"])
+    alg_bytes = algorithmic_bytes(x_units, s_units, io_bytes) / max(1.0, launches)  # per launch
+    achieved = alg_bytes / (kern_ms / 1e3) / 1e9 if kern_ms > 0 else 0.0
+    traffic, traffic_src = None, None
+    pmc = os.path.join(ROOT, "profiles", "r02_pmc_fill_lds.json")
+    if os.path.exists(pmc) and kname == "g2s_fill_lds" and cfg_name == "C2" and not custom and ngpu == 1:
+        try:
+            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            traffic_src = "from_profile: profiles/r02_pmc_fill_lds.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, " \
+                          "separate passes of this command; not measured in this run)"
+        except Exception:
+            traffic = None
+    roofline = dict(bound="hbm", kernel=kname, achieved=round(achieved, 3), peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(achieved / HBM_PEAK_GBS, 6), traffic=traffic, traffic_source=traffic_src,
+                    algorithmic_bytes_per_launch=alg_bytes, expansions=x_units, states=s_units,
+                    units_counted_by=counted_by, kernel_ms_per_launch=round(kern_ms, 4),
+                    launches_per_step=round(launches, 3), lds_tier_gaps=tm.lds_tier_gaps)
+    workload = "BASELINE %s%s: %d bp genome V%d, k=%d, %d gaps len %d-%d, fuz %d, dist-error %d" % (
+        cfg_text if not custom else "custom (based on %s)" % cfg_name, "", genome_bp, args.variant, k, len(gaps), min_len,
+        max_len, args.fuz, d_err)
+    per_step = lambda key: round(acc[key] / steps, 4)  # noqa: E731
+    out = {
+        "metric": "gaps filled/sec (whole node), k=%d synthetic %s DBG" % (k, "3 Mbp" if genome_bp == 3000000 else "%d bp" % genome_bp),
+        "value": round(units / elapsed, 2),
+        "unit": "gaps/s",
+        "n_gpus": len(set(devices)) if not args.share_device else ngpu,
+        "steps": steps,
+        "warmup": warmup,
+        "ms_per_step": round(elapsed / steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "strong" if ngpu > 1 else "weak",
+        "vs_baseline": None,
+        "dtype": "u32",
+        "data": "synthetic",
+        "config": {"workload": workload, "config": cfg_name if not custom else cfg_name + "-custom",
+                   "gaps": len(gaps), "genome_bp": genome_bp, "variant": args.variant, "k": k,
+                   "timed_region": "one %s call per step: flank lookup + descriptor upload + kernels + host phase D"
+                                   % ("g2s_fill_batch" if (len(sessions) == 1 and group == 0) else "g2s_team_fill"),
+                   "parallelism": "one process, %d GPU(s) x %d session(s), graph replicated, list cut into groups of %s "
+                                  "pulled from a shared counter, no collective"
+                                  % (ngpu, max(1, args.sessions), group if group else "all"),
+                   "devices": devices, "group": group, "ranks_under_torchrun": world},
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+        "filled": filled,
+        "q7_gaps": q7,
+        "retried_gaps": tm.retried_gaps,
+        "breakdown_ms_per_step": {"wall_inside_the_abi_call": round(in_call / steps * 1e3, 4),
+                                  "prepare_flank_lookup_and_upload": per_step("ms_prepare"),
+                                  "fill_lds_kernel": per_step("ms_fill_lds"),
+                                  "extract_lds_kernel": per_step("ms_extract_lds"),
+                                  "hbm_tier_kernels": round((acc["ms_right_bfs"] + acc["ms_left_dp"] +
+                                                             acc["ms_extract"]) / steps, 4),
+                                  "d2h_closures": per_step("ms_d2h"),
+                                  "host_phase_d": per_step("ms_host_post"),
+                                  "library_total": per_step("ms_total"),
+                                  "note": "kernel and host figures are sums over sessions and overlap at N>1"},
+        "setup_s": {"synth": round(t_synth, 3), "graph_build": round(t_build, 3), "graph_upload": round(t_upload, 3)},
+        "graph": {"kmers": graph.num_kmers, "unitigs": graph.num_unitigs, "hbm_bytes": graph.device_bytes(devices[0])},
+    }
+    if one_gpu is not None:
+        out["one_gpu_same_list"] = one_gpu
+        out["equals_one_gpu_result"] = True
+    if c3_beside is not None:
+        out["c3_on_one_gpu"] = c3_beside
+    print(json.dumps(out))
+    for s in sessions:
+        s.destroy()
     graph.free()
     if dist is not None:
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

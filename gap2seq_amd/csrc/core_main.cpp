@@ -11,6 +11,7 @@
 #include <iostream>
 #include <algorithm>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/g2s.h"
@@ -55,6 +56,7 @@ int main(int argc, char** argv) {
     else if (a == "-right") { right = val(); saw_right = true; }
     else if (a == "-length") { length = atoi(val()); saw_len = true; }
     else if (a == "-verbose") (void)val();
+    else if (a == "-version") { std::cout << "Gap2Seq-core (MI355X) ABI " << G2S_ABI_VERSION << std::endl; return EXIT_SUCCESS; }
     else if (a == "-device") device = atoi(val());
     else if (a == "-devices") devices = val();
     else if (a == "-streams") streams = atoi(val());
@@ -64,16 +66,20 @@ int main(int argc, char** argv) {
                    "  [-all-upper] [-best-only] [-unique] [-nb-cores N] [-device D | -devices D0,D1,...] [-streams 2]\n";
       return EXIT_SUCCESS;
     }
-    // unknown options are ignored, never errors
+    else {  // GATB's OptionsParser rejects what it does not know; main.cpp:29-31 prints the message
+      std::cout << "EXCEPTION: Unknown parameter '" << a << "'" << std::endl;
+      return EXIT_FAILURE;
+    }
   }
   if (reads.empty() || filled.empty()) {
     std::cout << "EXCEPTION: missing mandatory option (-reads, -filled)" << std::endl;  // main.cpp:29-31
     return EXIT_FAILURE;
   }
-  if (o.nb_cores <= 0) o.nb_cores = 1;
-  // GATB's Tool divides -max-mem by the dispatcher's thread count (:302); one GPU stream = one unit here
+  // -nb-cores 0 = all cores (GATB Tool); -max-mem is divided by that number (:302)
+  if (o.nb_cores <= 0) o.nb_cores = (int)std::max(1u, std::thread::hardware_concurrency());
   p.max_mem = (int64_t)(o.max_mem_gb * 1024 * 1024 * 1024) / o.nb_cores;
-  p.randseed = randseed > 0 ? (uint32_t)randseed : (uint32_t)time(NULL);  // :178
+  // the session seeds with time(NULL) when this is 0 (:178); the echo prints the user's value (:191)
+  p.randseed = randseed > 0 ? (uint32_t)randseed : 0u;
   p.host_threads = 0;
 
   {  // the graph is built on the first GPU this run uses
@@ -87,8 +93,16 @@ int main(int argc, char** argv) {
   if (readable(cache)) {
     std::cout << "Loading from " << cache << std::endl;
     rc = g2s_graph_load(cache.c_str(), &g);
+    if (rc == G2S_OK && g2s_graph_k(g) != o.k) {  // a cache of another -k is not this run's graph
+      g2s_graph_free(g);
+      g = nullptr;
+      rc = g2s_graph_build_files(reads.c_str(), o.k, o.solid, 0, &g);
+    }
   } else {
     rc = g2s_graph_build_files(reads.c_str(), o.k, o.solid, 0, &g);
+    // like Graph::create leaving "<reads>.h5" behind for the next run (:195-197); opt-in here
+    // because the file is as large as the graph (32 B per k-mer)
+    if (rc == G2S_OK && getenv("G2S_SAVE_GRAPH")) (void)g2s_graph_save(g, cache.c_str());
   }
   if (rc != G2S_OK) {
     std::cout << "DBG building failed: " << g2s_last_error() << std::endl;  // :215-218
@@ -143,7 +157,6 @@ int main(int argc, char** argv) {
     std::cout << "EXCEPTION: " << g2s_last_error() << std::endl;
     return EXIT_FAILURE;
   }
-  // the parameter echo prints the user's -randseed, not the time-derived one
   std::cout << log;
   FILE* out = fopen(filled.c_str(), "wb");
   if (!out) { std::cout << "EXCEPTION: cannot write " << filled << std::endl; return EXIT_FAILURE; }

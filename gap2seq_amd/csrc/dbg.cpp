@@ -402,6 +402,24 @@ Graph* graph_load(const std::string& path, std::string* err) {
     if (err) *err = "not a g2s graph cache: " + path;
     return nullptr;
   }
+  // the file is not trusted: every size and index is checked before it is used
+  if (hdr[0] < 1 || hdr[0] > 63 || hdr[1] >= (1ull << 30) || hdr[2] > hdr[1] || hdr[3] > 1) {
+    fclose(f);
+    if (err) *err = "corrupt graph cache header: " + path;
+    return nullptr;
+  }
+  {
+    const uint64_t per = (hdr[0] >= 32 ? 16u : 8u) + 4u + 1u + 32u + (hdr[3] ? 32u : 0u) + 2u;
+    const long here = ftell(f);
+    fseek(f, 0, SEEK_END);
+    const long end = ftell(f);
+    fseek(f, here, SEEK_SET);
+    if (here < 0 || end < 0 || (uint64_t)(end - here) != per * hdr[1]) {
+      fclose(f);
+      if (err) *err = "graph cache has the wrong size for its header: " + path;
+      return nullptr;
+    }
+  }
   Graph* g = new Graph();
   g->k = (int)hdr[0];
   g->n = hdr[1];
@@ -418,8 +436,27 @@ Graph* graph_load(const std::string& path, std::string* err) {
   g->lastnt.resize((size_t)g->n * 2); get(g->lastnt.data(), (size_t)g->n * 2);
   fclose(f);
   if (!ok) { if (err) *err = "truncated graph cache: " + path; delete g; return nullptr; }
-  g->id2rank.assign((size_t)g->n, 0);
-  for (uint64_t r = 0; r < g->n; r++) g->id2rank[g->rank2id[(size_t)r]] = (uint32_t)r;
+  auto corrupt = [&](const char* what) -> Graph* {
+    if (err) *err = std::string("corrupt graph cache (") + what + "): " + path;
+    delete g;
+    return nullptr;
+  };
+  // sorted k-mer set, rank2id a permutation, neighbour ids in range, codes 0..3
+  for (uint64_t r = 1; r < g->n; r++) {
+    const bool ascending = g->wide ? g->kmers128[(size_t)r - 1] < g->kmers128[(size_t)r]
+                                   : g->kmers64[(size_t)r - 1] < g->kmers64[(size_t)r];
+    if (!ascending) return corrupt("k-mers not strictly ascending");
+  }
+  g->id2rank.assign((size_t)g->n, kInvalidNode);
+  for (uint64_t r = 0; r < g->n; r++) {
+    const uint32_t id = g->rank2id[(size_t)r];
+    if (id >= g->n || g->id2rank[id] != kInvalidNode) return corrupt("rank2id is not a permutation");
+    g->id2rank[id] = (uint32_t)r;
+  }
+  for (uint32_t w : g->succ) if (w != kInvalidNode && w >= 2 * g->n) return corrupt("successor out of range");
+  for (uint32_t w : g->pred) if (w != kInvalidNode && w >= 2 * g->n) return corrupt("predecessor out of range");
+  for (uint8_t c : g->lastnt) if (c > 3) return corrupt("base code out of range");
+  for (uint8_t c : g->flip) if (c > 1) return corrupt("strand flag out of range");
   if (!g->wide) build_bucket_index<uint64_t>(*g); else build_bucket_index<u128>(*g);
   build_ustart(*g);
   return g;

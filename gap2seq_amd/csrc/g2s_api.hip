@@ -443,6 +443,7 @@ struct g2s_session {
   size_t team_group = 0;
   PinBuf h_gaps;                 // staging for the GapDev upload
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  g2s_timing last_timing;        // of the last g2s_fill_batch / g2s_batch_run (g2s_session_last_timing)
 };
 
 extern "C" int g2s_session_create(g2s_graph* g, int device, const g2s_params* p, g2s_session** out) {
@@ -454,7 +455,9 @@ extern "C" int g2s_session_create(g2s_graph* g, int device, const g2s_params* p,
   s->graph = g;
   s->device = device;
   s->params = *p;
-  s->rcache.seed(p->randseed);
+  memset(&s->last_timing, 0, sizeof s->last_timing);
+  // srand((randseed > 0) ? randseed : time(NULL)) (Gap2Seq.cpp:178); params keep the user's value for the echo (:191)
+  s->rcache.seed(p->randseed > 0 ? p->randseed : (uint32_t)time(nullptr));
   if (const char* env = getenv("G2S_NO_LDS_TIER")) s->no_lds_tier = atoi(env) != 0;
   hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
   for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipEventCreate(&s->ev[i]);
@@ -490,6 +493,15 @@ extern "C" void g2s_session_destroy(g2s_session* s) {
 }
 
 extern "C" void g2s_session_srand(g2s_session* s, uint32_t seed) { if (s) s->rcache.seed(seed); }
+extern "C" void g2s_session_skip_draws(g2s_session* s, uint64_t n) {
+  if (!s) return;
+  while (n) {  // in pieces: the stream is materialised before it is consumed
+    const size_t c = (size_t)std::min<uint64_t>(n, 1u << 20);
+    s->rcache.ensure(c);
+    s->rcache.consume(c);
+    n -= c;
+  }
+}
 
 // ---------------------------------------------------------------------------
 // batch
@@ -992,6 +1004,7 @@ int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
   g2s_timing keep = b->timing;
   memset(&b->timing, 0, sizeof b->timing);
   b->timing.flank_bytes = keep.flank_bytes;
+  b->timing.ms_prepare = keep.ms_prepare;
 
   const FillParams fp = fill_params_of(s);
   // device-budget analogue of -max-mem: states a gap may hold
@@ -1433,8 +1446,36 @@ extern "C" int g2s_batch_run(g2s_batch* b, g2s_result* results, char* arena, siz
     fprintf(stderr, "[g2s] waited %.3f ms for the rand() values after stage 1\n",
             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_join).count());
   if (rc == G2S_OK) rc = batches_stage2(std::vector<g2s_batch*>{b}, s, results, arena, &b->timing, false);
+  s->last_timing = b->timing;
   return rc;
 }
+extern "C" int g2s_session_last_timing(const g2s_session* s, g2s_timing* out) {
+  if (!s || !out) return fail(G2S_ERR_ARG, "g2s_session_last_timing: bad argument");
+  *out = s->last_timing;
+  return G2S_OK;
+}
+
+// The dispatcher's shared iterator (Gap2Seq.cpp:313-323: threads pull the next scaffold under
+// a lock): the list is cut into contiguous groups and every session's host thread pulls the
+// next group from one counter — a static start (session t begins with group t) with work
+// stealing by construction (whoever is free takes what is left).
+namespace {
+struct GroupQueue {
+  size_t n = 0, group = 1, ngroups = 0;
+  std::atomic<size_t> next{0};
+  GroupQueue(size_t n_, size_t group_) : n(n_), group(std::max<size_t>(1, group_)) { ngroups = (n + group - 1) / group; }
+  // the next group [off, off+cnt) and its index, or false when the list is used up (or aborted)
+  bool pull(size_t* gi, size_t* off, size_t* cnt) {
+    const size_t g = next.fetch_add(1);
+    if (g >= ngroups) return false;
+    *gi = g;
+    *off = g * group;
+    *cnt = std::min(group, n - *off);
+    return true;
+  }
+  void abort() { next.store(ngroups); }
+};
+}  // namespace
 
 // A team of sessions (any mix of devices, several per device allowed) fills one gap list:
 // the list is cut into groups, every session's host thread pulls the next group from a
@@ -1452,11 +1493,11 @@ extern "C" int g2s_team_fill(g2s_session* const* sessions, int nsessions, const 
   if (group_size == 0) group_size = 2048;
   auto t_begin = std::chrono::steady_clock::now();
   g2s_session* lead = sessions[0];
-  const size_t ngroups = (n + group_size - 1) / group_size;
+  GroupQueue queue(n, group_size);
+  const size_t ngroups = queue.ngroups;
   std::vector<g2s_batch*> subs(ngroups, nullptr);
   std::vector<int> rcs((size_t)nsessions, G2S_OK);
   std::vector<std::string> errs((size_t)nsessions);
-  std::atomic<size_t> next(0);
   {
     const size_t need = g2s_team_arena_bytes(lead, gaps, n);
     if (arena_cap < need || (!arena && need)) return fail(G2S_ERR_ARG, "g2s_team_fill: fill arena too small");
@@ -1476,16 +1517,15 @@ extern "C" int g2s_team_fill(g2s_session* const* sessions, int nsessions, const 
   auto worker = [&](int t) {
     g2s_session* s = sessions[t];
     s->tier_cursor = 0;
-    while (true) {
-      const size_t gi = next.fetch_add(1);
-      if (gi >= ngroups) break;
-      const size_t off = gi * group_size, cnt = std::min(group_size, n - off);
+    size_t gi = 0, off = 0, cnt = 0;
+    while (queue.pull(&gi, &off, &cnt)) {
       g2s_batch* b = nullptr;
       auto t0 = std::chrono::steady_clock::now();
       int rc = g2s_batch_prepare(s, gaps + off, cnt, &b);
       auto t1 = std::chrono::steady_clock::now();
       if (rc == G2S_OK) {
         subs[gi] = b;
+        b->timing.ms_prepare = std::chrono::duration<double, std::milli>(t1 - t0).count();
         b->arena = arena + group_arena[gi];
         b->arena_base = group_arena[gi];
         rc = batch_stage1(b, true, results + off);
@@ -1494,7 +1534,7 @@ extern "C" int g2s_team_fill(g2s_session* const* sessions, int nsessions, const 
         fprintf(stderr, "[g2s] team session %d group %zu (%zu gaps): prepare %.3f ms, stage 1 %.3f ms\n", t, gi, cnt,
                 std::chrono::duration<double, std::milli>(t1 - t0).count(),
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
-      if (rc != G2S_OK) { rcs[(size_t)t] = rc; errs[(size_t)t] = tl_error; next.store(ngroups); break; }
+      if (rc != G2S_OK) { rcs[(size_t)t] = rc; errs[(size_t)t] = tl_error; queue.abort(); break; }
     }
   };
   {
@@ -1520,6 +1560,7 @@ extern "C" int g2s_team_fill(g2s_session* const* sessions, int nsessions, const 
         total.retried_gaps += t.retried_gaps; total.x_fill_lds += t.x_fill_lds; total.s_fill_lds += t.s_fill_lds;
         total.lds_tier_gaps += t.lds_tier_gaps; total.lds_launches += t.lds_launches;
         total.log_pool_gaps += t.log_pool_gaps; total.rs_pool_gaps += t.rs_pool_gaps;
+        total.ms_prepare += t.ms_prepare;
       }
       rc = batches_stage2(subs, lead, results, arena, &total, false);
     }
@@ -1550,11 +1591,15 @@ extern "C" int g2s_fill_batch(g2s_session* s, const g2s_gap* gaps, size_t n, g2s
     team.insert(team.end(), s->helpers.begin(), s->helpers.end());
     return g2s_team_fill(team.data(), (int)team.size(), gaps, n, group, results, fill_arena, arena_cap, nullptr);
   }
+  const auto t_begin = std::chrono::steady_clock::now();
   g2s_batch* b = nullptr;
   int rc = g2s_batch_prepare(s, gaps, n, &b);
   if (rc != G2S_OK) return rc;
+  const double ms_prep = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
   rc = g2s_batch_run(b, results, fill_arena, arena_cap);
   g2s_batch_free(b);
+  s->last_timing.ms_prepare = ms_prep;
+  s->last_timing.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
   return rc;
 }
 
@@ -1717,6 +1762,27 @@ extern "C" int g2s_test_worker_pool(int32_t threads, int32_t rounds, int32_t n) 
     for (int i = 0; i < nn; i++)
       if (hits[(size_t)i].load() != 1) return fail(G2S_ERR_STATE, "worker pool: task not run exactly once");
   }
+  return G2S_OK;
+}
+
+extern "C" int g2s_test_group_queue(int32_t nworkers, uint64_t n, uint64_t group_size, int32_t* owner) {
+  if (nworkers < 1 || !owner) return fail(G2S_ERR_ARG, "g2s_test_group_queue: bad argument");
+  for (uint64_t i = 0; i < n; i++) owner[i] = -1;
+  GroupQueue queue((size_t)n, (size_t)group_size);
+  std::atomic<int> clash(0);
+  auto worker = [&](int t) {
+    size_t gi = 0, off = 0, cnt = 0;
+    while (queue.pull(&gi, &off, &cnt)) {
+      for (size_t i = off; i < off + cnt; i++) { if (owner[i] != -1) clash.fetch_add(1); owner[i] = t; }
+      std::this_thread::yield();
+    }
+  };
+  std::vector<std::thread> th;
+  for (int t = 1; t < nworkers; t++) th.emplace_back(worker, t);
+  worker(0);
+  for (auto& x : th) x.join();
+  if (clash.load()) return fail(G2S_ERR_STATE, "group queue: a gap was handed out twice");
+  for (uint64_t i = 0; i < n; i++) if (owner[i] < 0) return fail(G2S_ERR_STATE, "group queue: a gap was never handed out");
   return G2S_OK;
 }
 

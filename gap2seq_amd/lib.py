@@ -56,7 +56,7 @@ class g2s_timing(C.Structure):
                 ("launches_left_dp", C.c_uint32), ("retried_gaps", C.c_uint32),
                 ("ms_fill_lds", C.c_double), ("ms_extract_lds", C.c_double), ("x_fill_lds", C.c_uint64),
                 ("s_fill_lds", C.c_uint64), ("lds_tier_gaps", C.c_uint32), ("lds_launches", C.c_uint32),
-                ("log_pool_gaps", C.c_uint32), ("rs_pool_gaps", C.c_uint32)]
+                ("log_pool_gaps", C.c_uint32), ("rs_pool_gaps", C.c_uint32), ("ms_prepare", C.c_double)]
 
 
 class g2s_run_opts(C.Structure):
@@ -87,6 +87,7 @@ _SIGS = {
     "g2s_session_create": (C.c_int, [_VP, C.c_int, C.POINTER(g2s_params), C.POINTER(_VP)]),
     "g2s_session_destroy": (None, [_VP]),
     "g2s_session_srand": (None, [_VP, C.c_uint32]),
+    "g2s_session_skip_draws": (None, [_VP, C.c_uint64]),
     "g2s_session_graph": (_VP, [_VP]),
     "g2s_session_get_params": (C.c_int, [_VP, C.POINTER(g2s_params)]),
     "g2s_batch_prepare": (C.c_int, [_VP, C.POINTER(g2s_gap), C.c_size_t, C.POINTER(_VP)]),
@@ -94,6 +95,7 @@ _SIGS = {
     "g2s_batch_arena_bytes": (C.c_size_t, [_VP]),
     "g2s_batch_timing": (C.c_int, [_VP, C.POINTER(g2s_timing)]),
     "g2s_batch_free": (None, [_VP]),
+    "g2s_session_last_timing": (C.c_int, [_VP, C.POINTER(g2s_timing)]),
     "g2s_fill_batch": (C.c_int, [_VP, C.POINTER(g2s_gap), C.c_size_t, C.POINTER(g2s_result), C.c_char_p,
                                  C.c_size_t]),
     "g2s_team_fill": (C.c_int, [C.POINTER(_VP), C.c_int, C.POINTER(g2s_gap), C.c_size_t, C.c_size_t,
@@ -112,6 +114,7 @@ _SIGS = {
                                  C.POINTER(_VP)]),
     "g2s_test_rand_stream": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_int32)]),
     "g2s_test_worker_pool": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
+    "g2s_test_group_queue": (C.c_int, [C.c_int32, C.c_uint64, C.c_uint64, C.POINTER(C.c_int32)]),
     "g2s_graph_validate": (C.c_int64, [C.c_void_p, C.c_char_p, C.c_size_t]),
     "g2s_test_post_gap": (C.c_int, [_VP, C.POINTER(g2s_params), C.POINTER(g2s_gap), C.c_int32,
                                     C.POINTER(C.c_uint32), C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.c_int32,
@@ -305,8 +308,10 @@ class Session:
         _check(load_library().g2s_session_create(graph.h, device, C.byref(self.params), C.byref(h)))
         self.h = h
 
-    def srand(self, seed):
+    def srand(self, seed, skip=0):
         load_library().g2s_session_srand(self.h, seed)
+        if skip:
+            load_library().g2s_session_skip_draws(self.h, skip)
 
     def fill_batch(self, gaps, want_timing=False):
         """prepare + run; returns list of FillResult (and g2s_timing)."""
@@ -446,6 +451,14 @@ def test_post_gap(graph, params, gap, states, c_count, lengths, reached_j, final
 def test_worker_pool(threads, rounds, n):
     """TEST HOOK binding: stress the host worker pool; raises G2SError on a lost or repeated task."""
     _check(load_library().g2s_test_worker_pool(threads, rounds, n))
+
+
+def test_group_queue(nworkers, n, group_size):
+    """TEST HOOK binding: the dispatcher's shared group counter with host threads in place of
+    sessions; returns the worker each gap was handed to (raises G2SError on a lost or doubled gap)."""
+    owner = (C.c_int32 * max(1, n))()
+    _check(load_library().g2s_test_group_queue(nworkers, n, group_size, owner))
+    return [owner[i] for i in range(n)]
 
 
 def test_rand_stream(seed, skip, n):

@@ -1,66 +1,31 @@
-"""gap2seq_amd/shard.py — how a gap list is spread over the GPUs of one node.
+"""gap2seq_amd/shard.py — how bench.py spreads one gap list over the GPUs of a node.
 
 Gaps are independent given the read-only graph (fill_gap takes `const Graph&`,
 /root/reference/src/Gap2Seq.cpp:858; the reference itself parallelises per gap,
 :296-306), so there is NO data-path collective: the graph is replicated in every
-GPU's HBM, the gap list is cut into contiguous chunks, chunk c belongs to rank
-c mod world (static), and ranks that finish early take chunks from the tail of
-the most loaded rank's share (host-side stealing; in one-process-per-GPU mode the
-steal order is decided up front from the per-chunk cost estimate, so no
-communication is needed).  torch.distributed is only used by bench.py for the
-barrier and the max-over-ranks timing.
+GPU's HBM and the list is cut into contiguous groups that the sessions of
+g2s_team_fill (one host thread + stream per GPU, in ONE process) pull from a shared
+counter: a static start with stealing by construction.  This module only chooses
+the group size and reduces the timing; torch.distributed is used for nothing but
+the barriers when bench.py is started by torch.distributed.run.
 """
 
 
-def chunk_bounds(n_items, chunk):
-    """Contiguous chunks [(begin, end), ...] of at most `chunk` items."""
-    if chunk <= 0:
-        raise ValueError("chunk must be positive")
-    return [(b, min(n_items, b + chunk)) for b in range(0, n_items, chunk)]
+def group_size(n_gaps, n_sessions, min_group=256):
+    """Gaps per group for g2s_team_fill.  A launch is bound by its slowest gap (a dependent
+    chain of ~D levels), not by the number of gaps, so splitting a GPU's share into many
+    small launches costs more than it balances: one group per session, but never fewer than
+    `min_group` gaps (then some sessions may stay idle on very short lists)."""
+    if n_gaps <= 0 or n_sessions <= 0:
+        raise ValueError("n_gaps and n_sessions must be positive")
+    return max(min(min_group, n_gaps), -(-n_gaps // n_sessions))
 
 
-def gap_cost(gap_len, d_err, lmf, rmf):
-    """Levels the DP runs for one gap: D = lmf + rmf + g + e (Gap2Seq.cpp:862-863,1029)."""
-    return lmf + rmf + gap_len + d_err
-
-
-def assign_chunks(costs, world):
-    """Static round-robin start, then greedy stealing: repeatedly move the last chunk
-    of the most loaded rank to the least loaded rank while that lowers the maximum.
-    costs: per-chunk cost estimates.  Returns a list of chunk-index lists per rank;
-    every rank keeps its chunks in increasing order so results merge by index."""
-    if world <= 0:
-        raise ValueError("world must be positive")
-    owner = [[] for _ in range(world)]
-    for c in range(len(costs)):
-        owner[c % world].append(c)
-    load = [sum(costs[c] for c in o) for o in owner]
-    while True:
-        hi = max(range(world), key=lambda r: load[r])
-        lo = min(range(world), key=lambda r: load[r])
-        if hi == lo or not owner[hi]:
-            break
-        c = owner[hi][-1]
-        if max(load[hi] - costs[c], load[lo] + costs[c]) >= load[hi]:
-            break
-        owner[hi].pop()
-        owner[lo].append(c)
-        load[hi] -= costs[c]
-        load[lo] += costs[c]
-    for o in owner:
-        o.sort()
-    return owner
-
-
-def shard_for_rank(n_items, costs_per_item, rank, world, chunk=64):
-    """Item indices (sorted) that `rank` processes."""
-    bounds = chunk_bounds(n_items, chunk)
-    costs = [sum(costs_per_item[b:e]) for b, e in bounds]
-    mine = assign_chunks(costs, world)[rank]
-    idx = []
-    for c in mine:
-        idx.extend(range(*bounds[c]))
-    return idx
+def group_bounds(n_gaps, group):
+    """The contiguous groups [(begin, end), ...] g2s_team_fill cuts a list into."""
+    if group <= 0:
+        raise ValueError("group must be positive")
+    return [(b, min(n_gaps, b + group)) for b in range(0, n_gaps, group)]
 
 
 def reduce_timing(seconds, units, dist=None):

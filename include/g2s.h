@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define G2S_ABI_VERSION 1
+#define G2S_ABI_VERSION 2
 
 /* status codes */
 #define G2S_OK 0
@@ -101,7 +101,7 @@ typedef struct g2s_params {
   int32_t unique_paths;   /* -unique (applied by the caller of fill_gap) */
   int64_t max_mem;        /* bytes per gap, already divided by threads
                              (Gap2Seq.cpp:170,302); device-budget analogue */
-  uint32_t randseed;      /* srand() argument (Gap2Seq.cpp:178)          */
+  uint32_t randseed;      /* -randseed: srand() argument; 0 = time(NULL) (Gap2Seq.cpp:178) */
   int32_t host_threads;   /* threads for the per-gap host post-process; 0 = all */
 } g2s_params;
 
@@ -174,6 +174,8 @@ typedef struct g2s_timing {
   uint32_t lds_launches;     /* launches of g2s_fill_lds (2 when a second pass with larger LDS tables ran) */
   uint32_t log_pool_gaps;    /* gaps whose state log moved to a chunk of the launch's log pool */
   uint32_t rs_pool_gaps;     /* gaps whose right set moved from LDS to a chunk of the launch's spill pool */
+  double ms_prepare;         /* g2s_fill_batch / g2s_team_fill: flank k-mer -> node resolution + descriptor upload
+                                (g2s_batch_prepare), inside ms_total; summed over sessions for a team */
 } g2s_timing;
 
 /* ---------------------------------------------------------------------------
@@ -184,6 +186,9 @@ int g2s_session_create(g2s_graph* g, int device, const g2s_params* p, g2s_sessio
 void g2s_session_destroy(g2s_session* s);
 /* srand(seed) (Gap2Seq.cpp:178). */
 void g2s_session_srand(g2s_session* s, uint32_t seed);
+/* Discard the next n values of the session's rand() stream: what n calls of rand() by the
+ * caller between two fill_gap calls would do to the reference's libc stream. */
+void g2s_session_skip_draws(g2s_session* s, uint64_t n);
 
 /* Resolve flank k-mers to node ids on the host and upload the gap descriptors
  * to HBM.  Replaces the argument marshalling of Gap2Seq.cpp:380-383. */
@@ -196,6 +201,9 @@ int g2s_batch_run(g2s_batch* b, g2s_result* results, char* fill_arena, size_t ar
 size_t g2s_batch_arena_bytes(const g2s_batch* b);
 int g2s_batch_timing(const g2s_batch* b, g2s_timing* out);
 void g2s_batch_free(g2s_batch* b);
+/* Measurements of the last g2s_fill_batch / g2s_batch_run on this session (ms_total = wall
+ * time of that call, preparation included for g2s_fill_batch). */
+int g2s_session_last_timing(const g2s_session* s, g2s_timing* out);
 /* prepare + run + free. */
 int g2s_fill_batch(g2s_session* s, const g2s_gap* gaps, size_t n, g2s_result* results, char* fill_arena,
                    size_t arena_cap);
@@ -262,6 +270,11 @@ int g2s_test_rand_stream(uint32_t seed, uint32_t skip, uint32_t n, int32_t* out)
  * parallel-for rounds of `n` tasks on `threads` threads (task i adds i+1 to a per-round
  * sum); returns G2S_OK when every task of every round ran exactly once. */
 int g2s_test_worker_pool(int32_t threads, int32_t rounds, int32_t n);
+
+/* TEST HOOK: the shared group counter g2s_team_fill's sessions pull from, with `nworkers`
+ * host threads in place of sessions: owner[i] receives the worker that was handed gap i.
+ * G2S_OK when every gap of [0, n) was handed out exactly once, in contiguous groups. */
+int g2s_test_group_queue(int32_t nworkers, uint64_t n, uint64_t group_size, int32_t* owner);
 
 /* TEST HOOK: checks the invariants the kernels rely on between the unitig-start bitmap and
  * the successor table (every edge the bitmap calls unitig-internal is the only edge out of

@@ -56,6 +56,9 @@ uint64_t orc_graph_num_kmers(void* g) { return graph_num_kmers((GraphBase*)g); }
 void* orc_rng_new(unsigned seed) { GlibcRand* r = new GlibcRand(); r->seed(seed); return r; }
 void orc_rng_free(void* r) { delete (GlibcRand*)r; }
 int orc_rng_next(void* r) { return ((GlibcRand*)r)->next(); }
+// discard n draws (tests re-synchronise the oracle's stream with the product's after a gap
+// whose draw count legitimately differs: SURVEY Q7)
+void orc_rng_skip(void* r, unsigned long long n) { for (unsigned long long i = 0; i < n; i++) ((GlibcRand*)r)->next(); }
 
 static void pack_info(const FillInfo& fi, orc_info* o) {
   o->sub[0] = fi.sub.vertices; o->sub[1] = fi.sub.edges; o->sub[2] = fi.sub.nontrivial_components;

@@ -7,6 +7,7 @@
 #include <fstream>
 #include <iostream>
 #include <sstream>
+#include <thread>
 
 #include "g2s_oracle.hpp"
 
@@ -32,7 +33,10 @@ int main(int argc, char** argv) {
     else if (a == "-best-only") p.all_paths = false;
     else if (a == "-unique") p.unique_paths = true;
     else if (a == "-randseed") p.randseed = atoi(val());
-    else if (a == "-nb-cores") p.nb_cores = std::max(1, atoi(val()));
+    else if (a == "-nb-cores") {  // 0 = all cores (GATB Tool); only divides -max-mem (Gap2Seq.cpp:302)
+      p.nb_cores = atoi(val());
+      if (p.nb_cores <= 0) p.nb_cores = (int)std::max(1u, std::thread::hardware_concurrency());
+    }
     else if (a == "-left") { left = val(); saw_left = true; }
     else if (a == "-right") { right = val(); saw_right = true; }
     else if (a == "-length") { length = atoi(val()); saw_len = true; }
@@ -47,14 +51,18 @@ int main(int argc, char** argv) {
   GraphBase* g = graph_from_files(files, p.k, p.solid);
   if (!g) { std::cout << "DBG building failed: cannot read " << reads << std::endl; return EXIT_FAILURE; }
   std::string fasta, log;
+  int q7_gaps = 0;  // gaps whose outcome depends on libstdc++'s hash-set order, reported on stderr
   if (saw_left && saw_right && saw_len) {
     execute_single(g, p, reads, filled, left, right, length, &fasta, &log);
   } else {
     std::string text;
     if (!read_file(scaffolds, &text)) { std::cout << "EXCEPTION: cannot open " << scaffolds << std::endl; return EXIT_FAILURE; }
-    execute_scaffolds(g, p, reads, filled, text, &fasta, &log, NULL);
+    ExecSummary es;
+    execute_scaffolds(g, p, reads, filled, text, &fasta, &log, &es);
+    q7_gaps = es.q7_gaps;
   }
   std::cout << log;
+  std::cerr << "# oracle: q7_gaps " << q7_gaps << std::endl;
   std::ofstream out(filled.c_str());
   out << fasta;
   graph_free(g);

@@ -54,6 +54,7 @@ def lib():
         L.orc_rng_new.argtypes = [C.c_uint]
         L.orc_rng_free.argtypes = [VP]
         L.orc_rng_next.argtypes = [VP]
+        L.orc_rng_skip.argtypes = [VP, C.c_ulonglong]
         fill_args = [VP, VP, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_longlong, C.c_int,
                      C.c_int, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(orc_info)]
         L.orc_fill_gap.argtypes = fill_args
@@ -108,11 +109,23 @@ class OracleGraph:
 
 
 class OracleRng:
-    def __init__(self, seed):
+    """srand(seed), optionally advanced by `skip` draws."""
+
+    def __init__(self, seed, skip=0):
         self.h = lib().orc_rng_new(seed)
+        if skip:
+            lib().orc_rng_skip(self.h, skip)
 
     def next(self):
         return lib().orc_rng_next(self.h)
+
+    def skip(self, n):
+        lib().orc_rng_skip(self.h, n)
+
+    def free(self):
+        if self.h:
+            lib().orc_rng_free(self.h)
+            self.h = None
 
 
 class OracleFill:

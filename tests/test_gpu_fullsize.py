@@ -1,0 +1,155 @@
+"""GPU parity at BASELINE.json's STATED sizes (run with `-m gpu` on an MI355X): every config
+of BASELINE.json that test_gpu_parity.py only covers on a smaller graph or list is run here
+at full size — C1's stand-in (2.9 Mbp, multi-gap simulated scaffolds through the two command
+lines), C4 (60 Mbp, k=63, 2 000 gaps) and C5 (3 Mbp, -dist-error 2000, 1 000 gaps of 2-5 kbp).
+Bit-exact against the CPU oracle wherever the oracle finishes in about a minute, and through
+size-independent properties (cut -> fill -> original bases on a repeat-free genome) beyond.
+"""
+import os
+import subprocess
+
+import pytest
+
+import cases
+from test_gpu_parity import _assert_gap_equal, _check_batch, _gaps, _parse_scaffolds
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _seqs(reads):
+    return [ln for ln in reads.splitlines() if not ln.startswith(">")]
+
+
+def test_c4_full_size_round_trip_k63_60mbp(product):
+    """BASELINE config 4 at its stated size on the repeat-free V0 genome: 60 Mbp, k=63 (128-bit
+    k-mers, the 110 M oriented-id space, the two-pass radix sort of the graph build), 2 000 gaps
+    of 200-1000 bp.  Every gap has exactly one path: the fill is the genome slice, all upper
+    case, 1 path, draws = 1 + g + k."""
+    k = 63
+    reads = product.G2S.synth_genome(60000000, 0, 20240101)
+    genome = reads.splitlines()[1]
+    gaps = _parse_scaffolds(product.G2S.synth_gaps(reads, k, 10, 2000, 200, 1000, 20240103))
+    assert len(gaps) == 2000
+    pg = product.Graph.from_seqs([genome], k, 1)
+    try:
+        assert pg.num_kmers == 60000000 - k + 1 and pg.num_unitigs == 1
+        sess = product.Session(pg, 0, d_err=500, randseed=1)
+        res, tm = sess.fill_batch(_gaps(product, gaps), True)
+        sess.destroy()
+        for g, r in zip(gaps, res):
+            assert r.count == 1 and r.left_fuz == 0 and r.right_fuz == 0 and r.flags == product.G2S_GAP_PHASE_D
+            pos = genome.find(g["left"]) + len(g["left"])
+            assert r.fill == genome[pos:pos + g["gap_len"] + k]
+            assert r.draws == 1 + g["gap_len"] + k
+        assert tm.retried_gaps == 0 and tm.lds_tier_gaps == 2000
+    finally:
+        pg.free()
+
+
+def test_c4_full_size_vs_oracle_k63_60mbp(product, oracle):
+    """BASELINE config 4 at its stated size on the branching V3 genome (planted repeats + second
+    haplotype: 54.8 M k-mers, 1.75 GB of successor table): the GPU path fills all 2 000 gaps;
+    the first 250 are compared with the oracle gap by gap, every field (the oracle's own graph
+    of 55 M 128-bit k-mers takes most of this test's minute)."""
+    k = 63
+    reads = product.G2S.synth_genome(60000000, 3, 20240101)
+    seqs = _seqs(reads)
+    gaps = _parse_scaffolds(product.G2S.synth_gaps(reads, k, 10, 2000, 200, 1000, 20240103))
+    pg = product.Graph.from_seqs(seqs, k, 1)
+    og = None
+    try:
+        assert pg.num_kmers > 54000000
+        sess = product.Session(pg, 0, d_err=500, randseed=1)
+        res, tm = sess.fill_batch(_gaps(product, gaps), True)
+        sess.destroy()
+        assert tm.lds_tier_gaps + tm.retried_gaps >= 2000 and sum(1 for r in res if r.count > 0) >= 1990
+        og = oracle.OracleGraph(seqs, k, 1)
+        assert og.num_kmers == pg.num_kmers
+        rng = oracle.OracleRng(1)
+        used = nq7 = n = 0
+        for g, r in list(zip(gaps, res))[:250]:
+            o = oracle.fill_gap(og, rng, g["left"], g["right"], g["gap_len"], 500, g["lmf"], g["rmf"], False, True)
+            used += r.draws
+            if o.info.q7:
+                assert r.flags & product.G2S_GAP_Q7
+                nq7 += 1
+                if o.info.draws != r.draws:
+                    rng = oracle.OracleRng(1, used)
+                continue
+            _assert_gap_equal(product, r, o, False)
+            n += 1
+        assert n == 250 - nq7 and n >= 245
+    finally:
+        pg.free()
+        if og is not None:
+            og.free()
+
+
+def test_c5_full_size_vs_oracle(product, oracle):
+    """BASELINE config 5 at its stated size: the 3 Mbp V3 graph, -dist-error 2000, 1 000 gaps of
+    2-5 kbp (D = 4-7 k levels), every gap against the oracle.  This list holds the gaps whose
+    frontiers outgrow the LDS tier's 1 024 entries (they finish in the HBM tier) as well as
+    right sets and state logs that move to the launch's pools."""
+    reads = product.G2S.synth_genome(3000000, 3, 20240101)
+    seqs = _seqs(reads)
+    gaps = _parse_scaffolds(product.G2S.synth_gaps(reads, 31, 10, 1000, 2000, 5000, 20240103))
+    assert len(gaps) == 1000
+    c, f, tm, xb, sb = _check_batch(product, oracle, seqs, 31, gaps, 2000, seed=1)
+    assert c >= 995 and f >= 990
+    assert (tm.xB, tm.sB) == (xb, sb)
+
+
+def _simulated_scaffolds(genome, k, fuz, seed, nrec, rec_len):
+    """Scaffold records as an assembler leaves them: consecutive slices of the genome, each with
+    1-6 N runs whose lengths are the true gap lengths plus an estimate error, some runs closer
+    together than k+fuz (the couplings between consecutive gaps, Gap2Seq.cpp:349,402), some in
+    lower case, one next to a record end."""
+    rng = cases.SplitMix(seed)
+    recs = []
+    for r in range(nrec):
+        lo = r * rec_len
+        s = genome[lo:lo + rec_len]
+        pos = rng.randint(k + fuz, 400)
+        out, cur = [], 0
+        for _ in range(rng.randint(1, 6)):
+            true_len = rng.choice([rng.randint(1, 60), rng.randint(100, 700), rng.randint(700, 1500)])
+            if pos + true_len + k + fuz + 5 >= len(s):
+                break
+            est = max(1, true_len + rng.choice([0, 0, 0, 0, -3, 7, -40, 60, -150, 200]))
+            out.append(s[cur:pos])
+            out.append(("n" if rng.random() < 0.1 else "N") * est)
+            cur = pos + true_len
+            pos = cur + rng.choice([k + fuz - 1, k + fuz, k + fuz + 1, k + 2 * fuz, rng.randint(200, 3000)])
+        out.append(s[cur:] if r % 37 else s[cur:cur + k + 3])  # now and then the record ends right behind a gap
+        recs.append(">scaffold%d simulated\n%s\n" % (r, "".join(out)))
+    return "".join(recs)
+
+
+def test_c1_stand_in_multi_gap_scaffolds_through_the_cli(product, oracle, tmp_path):
+    """BASELINE config 1's plumbing on the stand-in SURVEY 8(d) names (GAGE S. aureus cannot be
+    downloaded): a 2.9 Mbp synthetic genome (V3), ~300 simulated multi-gap scaffolds, reads = the
+    two haplotypes, run through gap2seq_amd/Gap2Seq-core and through the oracle's command line
+    with the argv the reference wrapper builds (Gap2Seq.py:230-241): FASTA and stdout identical."""
+    k, fuz = 31, 10
+    reads_text = product.G2S.synth_genome(2900000, 3, 20240105)
+    genome = _seqs(reads_text)[0]
+    reads = tmp_path / "reads.fa"
+    reads.write_text(reads_text)
+    scaf = tmp_path / "scaffolds.fa"
+    scaf.write_text(_simulated_scaffolds(genome, k, fuz, 7, 300, 9600))
+    outs = {}
+    for name, exe in (("gpu", os.path.join(ROOT, "gap2seq_amd", "Gap2Seq-core")),
+                      ("cpu", os.path.join(os.path.dirname(oracle.ORACLE_SO), "g2s_oracle_cli"))):
+        out = tmp_path / ("filled_%s.fa" % name)
+        res = subprocess.run([exe, "-k", str(k), "-fuz", str(fuz), "-solid", "1", "-nb-cores", "1", "-dist-error", "500",
+                              "-max-mem", "20", "-randseed", "1", "-reads", str(reads), "-filled", str(out),
+                              "-scaffolds", str(scaf)], capture_output=True, text=True, timeout=900)
+        assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+        outs[name] = (out.read_text(), res.stdout.replace(str(out), "OUT"), res.stderr)
+    assert "# oracle: q7_gaps 0" in outs["cpu"][2], outs["cpu"][2][-300:]
+    assert outs["gpu"][1] == outs["cpu"][1]
+    assert outs["gpu"][0] == outs["cpu"][0]
+    last = outs["gpu"][1].strip().splitlines()[-1].split()  # "Filled X gaps out of Y"
+    assert last[0] == "Filled" and int(last[5]) >= 600 and int(last[1]) >= int(last[5]) // 2

@@ -1,77 +1,64 @@
-"""Multi-GPU path on CPU: the gap list is sharded with no data-path collective
-(gloo, world_size 2, covers bench.py's rendezvous + max/sum reduction and the
-static-chunk + stealing assignment)."""
+"""The N>1 path on CPU: one gap list spread over the sessions of the dispatcher with no
+data-path collective.  Covered here without a GPU: the choice of the group size, the shared
+group counter g2s_team_fill's sessions pull from (C++ test hook, host threads in place of
+sessions), and bench.py's launch protocol under torch.distributed.run with 2 ranks (gloo):
+rendezvous on 127.0.0.1, barriers around the timed region, max/sum reduction, one JSON line."""
+import json
 import os
 import socket
+import subprocess
 import sys
-
-import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from gap2seq_amd import shard  # noqa: E402
 
 
-def test_chunks_partition_the_list():
-    b = shard.chunk_bounds(1000, 64)
-    assert b[0] == (0, 64) and b[-1] == (960, 1000)
-    assert sum(e - s for s, e in b) == 1000
+def test_group_size_and_bounds_partition_the_list():
+    for n, sessions in ((10000, 1), (10000, 2), (10000, 4), (10000, 8), (10000, 16), (500, 8), (7, 3)):
+        g = shard.group_size(n, sessions)
+        b = shard.group_bounds(n, g)
+        assert b[0][0] == 0 and b[-1][1] == n and all(x[1] == y[0] for x, y in zip(b, b[1:]))
+        assert len(b) <= sessions  # one launch per session at most: a launch costs its slowest gap
+    assert shard.group_size(10000, 8) == 1250 and shard.group_size(500, 8) == 256
 
 
-def test_assignment_is_a_partition_and_balanced():
-    costs = [100] * 7 + [1000, 10, 10, 5000, 3, 3, 3, 3, 3]
-    for world in (1, 2, 3, 4, 8):
-        owner = shard.assign_chunks(costs, world)
-        flat = sorted(c for o in owner for c in o)
-        assert flat == list(range(len(costs)))
-        load = [sum(costs[c] for c in o) for o in owner]
-        # never worse than plain round robin
-        rr = [sum(costs[c] for c in range(r, len(costs), world)) for r in range(world)]
-        assert max(load) <= max(rr)
+def test_group_queue_hands_every_gap_out_once(product):
+    for workers, n, group in ((1, 1000, 64), (2, 10000, 1250), (8, 10000, 1250), (8, 10000, 100), (3, 17, 5), (4, 5, 100)):
+        owner = product.test_group_queue(workers, n, group)
+        assert len(owner) == n and all(0 <= o < workers for o in owner)
+        for b, e in shard.group_bounds(n, group):  # a group goes to one worker as a whole
+            assert len(set(owner[b:e])) == 1
+    assert product.test_group_queue(4, 0, 16) == []
 
 
-def test_shards_cover_all_gaps_for_every_world_size():
-    n = 10000
-    costs = [shard.gap_cost(200 + (i * 37) % 800, 500, 10, 10) for i in range(n)]
-    for world in (1, 2, 4, 8):
-        seen = []
-        for r in range(world):
-            idx = shard.shard_for_rank(n, costs, r, world, chunk=64)
-            assert idx == sorted(idx)
-            seen.extend(idx)
-        assert sorted(seen) == list(range(n))
-
-
-def _worker(rank, world, port, q):
-    import torch.distributed as dist
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    n = 1000
-    costs = [shard.gap_cost(200 + (i * 37) % 800, 500, 10, 10) for i in range(n)]
-    mine = shard.shard_for_rank(n, costs, rank, world, chunk=16)
-    dist.barrier()
-    secs, units = shard.reduce_timing(0.5 + rank, float(len(mine)), dist)
-    q.put((rank, secs, units, len(mine)))
-    dist.destroy_process_group()
-
-
-def test_gloo_two_ranks_no_data_collective():
-    import torch.multiprocessing as mp
+def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    out = [q.get(timeout=120) for _ in procs]
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
-    out.sort()
-    assert out[0][1] == out[1][1] == 1.5          # max over ranks
-    assert out[0][2] == out[1][2] == 1000.0       # whole-job units
-    assert out[0][3] + out[1][3] == 1000
+    return port
+
+
+def test_bench_launch_protocol_two_ranks_gloo():
+    """What the driver does for N>1: torch.distributed.run starts one rank per GPU; rank 0's
+    process drives the N devices, the other ranks only join the barriers; exactly one JSON line."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--dry-run"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["dry_run"] and out["n_gpus"] == 2 and out["ranks_under_torchrun"] == 2
+    assert out["units"] == 1.0 and out["elapsed_max_over_ranks_s"] >= 0.01
+    assert (out["group"], out["groups"]) == (5000, 2)
+
+
+def test_bench_refuses_more_gpus_than_there_are():
+    """`--gpus N` is never silently reduced: without N usable devices the run fails."""
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode != 0
+    assert "device" in (res.stdout + res.stderr)

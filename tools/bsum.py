@@ -8,5 +8,9 @@ for ln in sys.stdin:
         continue
     d = json.loads(ln)
     b = d["breakdown_ms_per_step"]
-    print(tag, d["value"], "ms/step", d["ms_per_step"], "fill", b["fill_lds_kernel"], "extract", b["extract_lds_kernel"],
-          "hbm", b["hbm_tier_kernels"], "d2h", b["d2h_closures"], "host", b["host_phase_d"], "frac", d["roofline"]["frac"])
+    r = d["roofline"]
+    print(tag, d["value"], "gaps/s | ms/step", d["ms_per_step"], "prepare", b["prepare_flank_lookup_and_upload"], "kernel",
+          b["fill_lds_kernel"], "(per launch", r["kernel_ms_per_launch"], "x", r["launches_per_step"], ") hbm-tier",
+          b["hbm_tier_kernels"], "host", b["host_phase_d"], "| frac", r["frac"], "| filled", d["filled"],
+          "| c3:", (d.get("c3_on_one_gpu") or {}).get("value"), (d.get("c3_on_one_gpu") or {}).get("kernel_ms_per_launch"),
+          (d.get("c3_on_one_gpu") or {}).get("roofline_frac"))

@@ -176,14 +176,16 @@ def explain(cfg):
                            randseed=cfg["randseed"])
     res, _ = sess.fill_batch(tp._gaps(product, gaps), True)
     rng = oracle_lib.OracleRng(cfg["randseed"])
+    used = 0
     for i, (g, r) in enumerate(zip(gaps, res)):
         o = oracle_lib.fill_gap(og, rng, g["left"], g["right"], g["gap_len"], cfg["d_err"], g["lmf"], g["rmf"],
                                 cfg["skip"], cfg["allp"])
+        used += r.draws
         q7 = bool(o.info.q7), bool(r.flags & product.G2S_GAP_Q7)
         diffs = []
         if q7[0] and not q7[1]:
             diffs.append("oracle q7, gpu not")
-        if not (q7[0] or q7[1]):
+        if not q7[0] and r.count != -1:
             for name, a, b in (("count", r.count, o.count), ("phaseC", r.phaseC_count, o.info.phaseC_count),
                                ("lengths", r.lengths, o.lengths), ("draws", r.draws, o.info.draws)):
                 if a != b:
@@ -197,9 +199,8 @@ def explain(cfg):
                                  f"gpu ..{r.fill[max(0, pos - 5):pos + 10]} oracle ..{o.fill[max(0, pos - 5):pos + 10]}")
                 if not cfg["skip"] and r.substats != o.substats:
                     diffs.append(f"substats: gpu {r.substats} oracle {o.substats}")
-        elif o.info.draws != r.draws:
-            print(f"gap {i}: q7 {q7}, draws differ (gpu {r.draws} oracle {o.info.draws}): stream diverged, stop")
-            break
+        if o.info.draws != r.draws:  # put the oracle's stream where the product's is
+            rng = oracle_lib.OracleRng(cfg["randseed"], used)
         if diffs:
             print(f"gap {i} (g {g['gap_len']} lmf {g['lmf']} rmf {g['rmf']} flags {r.flags:#x}): " + "; ".join(diffs))
 
