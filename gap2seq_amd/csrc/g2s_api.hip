@@ -1086,6 +1086,12 @@ int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
   const bool room0_is_max = lds_room(n) >= 16384u;
   for (int pass = 0; pass < 3; pass++) {
     if (cand[pass].empty()) continue;
+    // Workgroups are dispatched in id order and a launch ends with its slowest gap: start the
+    // gaps with the most DP levels first, so that the long ones are not the last to begin
+    // (lists longer than the chip holds at once; G2S_NO_LPT=1 keeps the input order).
+    if (cand[pass].size() > 1024 && !getenv("G2S_NO_LPT"))
+      std::stable_sort(cand[pass].begin(), cand[pass].end(),
+                       [&](uint32_t a, uint32_t c) { return b->jobs[a].g > b->jobs[c].g; });
     const std::vector<uint32_t>& ids = cand[pass];
     const uint32_t room = pass == 0 ? 0u : 16384u;
     TierData* td = take_tier(s, b->tiers.size());
@@ -1130,6 +1136,18 @@ int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
       b->timing.lds_tier_gaps++;
       b->timing.log_pool_gaps += (go.flags & G2S_DEV_LOG_POOL) != 0;
       b->timing.rs_pool_gaps += (go.flags & G2S_DEV_RS_POOL) != 0;
+    }
+    if (const char* dump = getenv("G2S_DUMP_STATS")) {  // diagnostics: one line per gap of this pass (appended)
+      if (FILE* f = fopen(dump, "a")) {
+        fprintf(f, "# pass %d: gap g flags A_steps A_rounds B_slow B_bulk cycA cycB D_slow D_bulk cycD n_right x_right n_states x_left n_sub top_level\n", pass);
+        for (uint32_t i : ids) {
+          const GapOut& o = outs[i];
+          fprintf(f, "%u %d %#x %u %u %u %u %llu %llu %u %u %llu %u %u %u %u %u %u\n", i, b->jobs[i].g, o.flags, o.stat[0], o.stat[1],
+                  o.stat[2], o.stat[3], (unsigned long long)o.stat[4] << 8, (unsigned long long)o.stat[5] << 8, o.stat[6] & 0xFFFF,
+                  o.stat[6] >> 16, (unsigned long long)o.stat[7] << 8, o.n_right, o.x_right, o.n_states, o.x_left, o.n_sub, o.top_level);
+        }
+        fclose(f);
+      }
     }
     if (getenv("G2S_DEBUG")) {  // the slowest gaps of the LDS tier and why
       std::vector<uint32_t> ord(ids);
