@@ -224,7 +224,8 @@ def main():
     for _ in range(warmup):
         run.step()
     acc = dict(ms_right_bfs=0.0, ms_left_dp=0.0, ms_extract=0.0, ms_fill_lds=0.0, ms_extract_lds=0.0, ms_d2h=0.0,
-               ms_host_post=0.0, ms_prepare=0.0, ms_total=0.0, launches=0, lds_launches=0)
+               ms_host_post=0.0, ms_prepare=0.0, ms_total=0.0, ms_fill_seg=0.0, launches=0, lds_launches=0,
+               seg_launches=0)
     in_call = 0.0
     barrier()
     t_begin = time.perf_counter()
@@ -232,10 +233,11 @@ def main():
         in_call += run.step()
         tm = run.timing()
         for key in ("ms_right_bfs", "ms_left_dp", "ms_extract", "ms_fill_lds", "ms_extract_lds", "ms_d2h",
-                    "ms_host_post", "ms_prepare", "ms_total"):
+                    "ms_host_post", "ms_prepare", "ms_total", "ms_fill_seg"):
             acc[key] += getattr(tm, key)
         acc["launches"] += tm.launches_left_dp
         acc["lds_launches"] += tm.lds_launches
+        acc["seg_launches"] += tm.seg_launches
     elapsed = time.perf_counter() - t_begin
     barrier()
     elapsed, units = shard.reduce_timing(elapsed, float(len(gaps) * steps), dist)
@@ -273,14 +275,16 @@ def main():
         n3, t3, k3 = 10, 0.0, 0.0
         for _ in range(n3):
             t3 += r3.step()
-            k3 += r3.timing().ms_fill_lds
+            k3 += r3.timing().ms_fill_seg if r3.timing().seg_tier_gaps else r3.timing().ms_fill_lds
         tm3 = r3.timing()
+        nl3 = max(1, tm3.seg_launches if tm3.seg_tier_gaps else tm3.lds_launches)
         x3, s3 = tm3.xA + tm3.xB + tm3.xD, tm3.sA + tm3.sB + tm3.sD
-        ab3 = algorithmic_bytes(x3, s3, tm3.flank_bytes + tm3.fill_bytes) / max(1, tm3.lds_launches)
-        kms3 = k3 / n3 / max(1, tm3.lds_launches)
+        ab3 = algorithmic_bytes(x3, s3, tm3.flank_bytes + tm3.fill_bytes) / nl3
+        kms3 = k3 / n3 / nl3
         c3_beside = dict(workload=CONFIGS["C3"][6], value=round(10000 * n3 / t3, 2), unit="gaps/s", steps=n3,
-                         ms_per_step=round(t3 / n3 * 1e3, 4), kernel_ms_per_launch=round(kms3, 4),
-                         launches_per_step=tm3.lds_launches, algorithmic_bytes_per_launch=ab3,
+                         ms_per_step=round(t3 / n3 * 1e3, 4), kernel="g2s_fill_seg" if tm3.seg_tier_gaps else "g2s_fill_lds",
+                         kernel_ms_per_launch=round(kms3, 4), gaps_left_to_other_kernels=10000 - max(tm3.seg_tier_gaps, tm3.lds_tier_gaps),
+                         launches_per_step=nl3, algorithmic_bytes_per_launch=ab3,
                          units_counted_by="product", roofline_frac=round(ab3 / (kms3 / 1e3) / 1e9 / HBM_PEAK_GBS, 6),
                          filled=sum(1 for r in r3.results() if r.count > 0))
 
@@ -323,7 +327,16 @@ def main():
     # reference re-expands nodes reached by walks of several lengths); otherwise the product's
     # counters, labelled so.
     io_bytes = tm.flank_bytes + tm.fill_bytes
-    if tm.lds_tier_gaps > 0:
+    if tm.seg_tier_gaps > 0 and tm.seg_tier_gaps >= tm.lds_tier_gaps:
+        # the segment tier took (most of) the list: phases A-D1 over unitig segments, one wave per gap
+        kname = "g2s_fill_seg"
+        if octr is not None and tm.seg_tier_gaps == len(gaps):
+            x_units, s_units, counted_by = octr[0] + octr[2] + octr[4], octr[1] + octr[3] + octr[5], "oracle"
+        else:
+            x_units, s_units, counted_by = tm.xA + tm.xB + tm.xD, tm.sA + tm.sB + tm.sD, "product"
+        launches = acc["seg_launches"] / float(steps)
+        kern_ms = acc["ms_fill_seg"] / max(1, acc["seg_launches"])  # average launch duration
+    elif tm.lds_tier_gaps > 0:
         kname = "g2s_fill_lds"
         if octr is not None and tm.lds_tier_gaps == len(gaps):
             x_units, s_units, counted_by = octr[0] + octr[2] + octr[4], octr[1] + octr[3] + octr[5], "oracle"
@@ -338,11 +351,11 @@ def main():
     alg_bytes = algorithmic_bytes(x_units, s_units, io_bytes) / max(1.0, launches)  # per launch
     achieved = alg_bytes / (kern_ms / 1e3) / 1e9 if kern_ms > 0 else 0.0
     traffic, traffic_src = None, None
-    pmc = os.path.join(ROOT, "profiles", "r02_pmc_fill_lds.json")
-    if os.path.exists(pmc) and kname == "g2s_fill_lds" and cfg_name == "C2" and not custom and ngpu == 1:
+    pmc = os.path.join(ROOT, "profiles", "r02_pmc_fill_seg.json")
+    if os.path.exists(pmc) and kname == "g2s_fill_seg" and cfg_name == "C2" and not custom and ngpu == 1:
         try:
             traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            traffic_src = "from_profile: profiles/r02_pmc_fill_lds.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, " \
+            traffic_src = "from_profile: profiles/r02_pmc_fill_seg.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, " \
                           "separate passes of this command; not measured in this run)"
         except Exception:
             traffic = None
@@ -350,7 +363,8 @@ def main():
                     frac=round(achieved / HBM_PEAK_GBS, 6), traffic=traffic, traffic_source=traffic_src,
                     algorithmic_bytes_per_launch=alg_bytes, expansions=x_units, states=s_units,
                     units_counted_by=counted_by, kernel_ms_per_launch=round(kern_ms, 4),
-                    launches_per_step=round(launches, 3), lds_tier_gaps=tm.lds_tier_gaps)
+                    launches_per_step=round(launches, 3), seg_tier_gaps=tm.seg_tier_gaps, lds_tier_gaps=tm.lds_tier_gaps,
+                    segments=tm.seg_segments)
     workload = "BASELINE %s%s: %d bp genome V%d, k=%d, %d gaps len %d-%d, fuz %d, dist-error %d" % (
         cfg_text if not custom else "custom (based on %s)" % cfg_name, "", genome_bp, args.variant, k, len(gaps), min_len,
         max_len, args.fuz, d_err)
@@ -383,6 +397,7 @@ def main():
         "retried_gaps": tm.retried_gaps,
         "breakdown_ms_per_step": {"wall_inside_the_abi_call": round(in_call / steps * 1e3, 4),
                                   "prepare_flank_lookup_and_upload": per_step("ms_prepare"),
+                                  "fill_seg_kernel": per_step("ms_fill_seg"),
                                   "fill_lds_kernel": per_step("ms_fill_lds"),
                                   "extract_lds_kernel": per_step("ms_extract_lds"),
                                   "hbm_tier_kernels": round((acc["ms_right_bfs"] + acc["ms_left_dp"] +

@@ -1,0 +1,24 @@
+// gap2seq_amd/csrc/fill_seg.h — launcher of the segment tier (fill_seg.hip): phases A-D1 of
+// /root/reference/src/Gap2Seq.cpp:858-1312 as a search over unitig segments.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+#include "fill_device.h"
+
+#define G2S_SEG_CAP 512u  /* segments per gap kept in LDS */
+#define G2S_SEG_ASETS 4   /* right-set entries per gap: 64 per set, in registers */
+
+namespace g2s {
+
+size_t fill_seg_lds_bytes();
+uint32_t fill_seg_dbg_words();  // words per gap of the optional diagnostics buffer
+// phases A-D1 of every listed gap in one launch; results land in pinned host memory exactly as
+// the LDS tier leaves them (GapOut per gap, closures packed by an atomic cursor, completion list)
+hipError_t launch_fill_seg(hipStream_t st, uint32_t ngaps, const uint32_t* succ, const uint32_t* rem, const GapDev* gaps,
+                           const uint32_t* gap_ids, const uint32_t* flank_nodes, SubRec* sub_out /* pinned host */,
+                           unsigned long long out_cap /* records */, unsigned long long* out_counter, GapOut* outs,
+                           GapOut* outs_host /* pinned host */, uint32_t* done_list /* pinned host */, int skip_confident,
+                           uint32_t* dbg /* nullptr, or ngaps * fill_seg_dbg_words() words */);
+
+}  // namespace g2s

@@ -1,0 +1,665 @@
+// gap2seq_amd/csrc/fill_seg.hip — SEGMENT TIER of the fill path for gfx950 (CDNA4): phases
+// A, B, C and D1 of /root/reference/src/Gap2Seq.cpp:858-1312 in one kernel (g2s_fill_seg),
+// one 64-lane wavefront per gap, as a search over UNITIG SEGMENTS instead of DP levels.
+// tests/seg_model.py is the executable restatement of this algorithm that the CPU suite checks
+// without a GPU; read the two side by side.
+//
+// Why: one wave per SIMD is bound by instruction issue and by dependent LDS / memory round
+// trips (rocprofv3, profiles/r02_pmc_sq_*.json: 39 % of the wave cycles issue instructions,
+// 58 % wait), so what a gap costs is the number of dependent steps it takes.  The LDS tier
+// (fill_lds.hip) takes one step per DP level that is not unitig-internal for EVERY border
+// state (~190 + ~190 steps for the slowest gaps of BASELINE config 2).  Here the unit of work
+// is the segment: node ids are numbered along unitigs (dbg.hpp: inside a unitig the only
+// successor of an even id v is v+2, of an odd id v-2, and v is that node's only predecessor),
+// so a DP state (v, d, count) that enters a unitig determines the whole diagonal
+// (v +- 2t, d + t, count) up to the unitig's end (one load of rem[v], seg_tables.hip), the
+// last level D, or the first state the pruning rule (:1050) rejects.  A gap of config 2 has
+// ~1 000 states but only ~25 segments, found in ~18 steps.
+//
+//   phase A  (:871-982) label-correcting search over unitigs as in the LDS tier, but the right
+//            set is never materialised node by node: it IS the table of (entry node, depth
+//            label) pairs, i.e. a union of k-mer index intervals kept in registers (lane =
+//            entry).  Membership of a k-mer (:1050 ignores strand and depth) is one compare +
+//            ballot; "how far does this run stay inside the right set" is interval arithmetic.
+//   phase B  (:984-1105) ENTRY EVENTS (node, depth, count, <= 4 parents) live in registers
+//            (lane = pending event; merging = compare + ballot, no hash table).  An event is
+//            final once its depth is below the HORIZON = min over pending events of (depth +
+//            states to the end of its unitig): no pending event can still create a child at or
+//            above it.  All final events are expanded in one step: their lengths under the
+//            pruning rule, one successor record per segment that reaches its unitig's end, the
+//            children merged into the pending set.  Left-flank seeds (:1082-1105, value
+//            ASSIGNED 1, Q6) are pre-inserted events with a fixed count; events above the flank
+//            (depth < lmf) are cut after one state so that no segment runs across a seed state.
+//   phase C  (:1107-1159) in closed form from the target hits of the segments: a hit (j, depth)
+//            is found at level |depth - (g+lmf+j)| + g+lmf+rmf; smallest level, then smallest j.
+//   Q7       both strands of a k-mer at one depth: among pending events (compare + ballot) and
+//            where an upward and a downward segment of one unitig cross (arithmetic).
+//   phase D1 (:1169-1312) backward closure over the segments, generation by generation in
+//            reverse (children were created after their parent was expanded), then expanded
+//            into the 16-byte per-state records of the host half of phase D, children before
+//            parents, written straight into pinned host memory.
+// Segments (<= G2S_SEG_CAP) live in LDS; there is no state log in HBM at all.  A gap that
+// outgrows a capacity (segments, 64 pending events, 256 right-set entries, host buffer) is
+// flagged and runs in the LDS tier instead.  Integer work only: no MFMA on this path.
+#include <hip/hip_runtime.h>
+
+#include "fill_device.h"
+#include "fill_seg.h"
+
+#define SEG_INF 0x7FFFFFFFu
+#define SEG_NOPAR 0xFFFFu
+
+namespace {
+
+__device__ __forceinline__ void lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ uint32_t rl(uint32_t x, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)x, l); }
+__device__ __forceinline__ uint32_t uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+__device__ __forceinline__ uint64_t below(int lane) { return (1ull << lane) - 1ull; }
+// state t of the segment that starts at v0
+__device__ __forceinline__ uint32_t seg_node(uint32_t v0, uint32_t t) { return (v0 & 1u) ? v0 - 2u * t : v0 + 2u * t; }
+// t with seg_node(v0, t) == node and t < len, else -1
+__device__ __forceinline__ int seg_pos(uint32_t v0, uint32_t len, uint32_t node) {
+  if (node == G2S_DEV_INVALID || ((node ^ v0) & 1u)) return -1;
+  const int dt = (int)(node - v0) >> 1;  // node ids are below 2^31
+  const int t = (v0 & 1u) ? -dt : dt;
+  return (t >= 0 && (uint32_t)t < len) ? t : -1;
+}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t x) {
+  for (int o = 32; o > 0; o >>= 1) x += (uint32_t)__shfl_xor((int)x, o);
+  return uni(x);
+}
+// inclusive prefix sum over the lanes
+__device__ __forceinline__ uint32_t wave_scan(uint32_t x, int lane) {
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t y = (uint32_t)__shfl_up((int)x, o);
+    if (lane >= o) x += y;
+  }
+  return x;
+}
+
+}  // namespace
+
+// dynamic LDS: 7 arrays of G2S_SEG_CAP words + left seeds
+__global__ __launch_bounds__(64) void g2s_fill_seg(const uint32_t* __restrict__ succ, const uint32_t* __restrict__ rem,
+                                                    const GapDev* __restrict__ gaps, const uint32_t* __restrict__ gap_ids,
+                                                    const uint32_t* __restrict__ flank_nodes, SubRec* sub_out,
+                                                    unsigned long long out_cap, unsigned long long* out_counter,
+                                                    GapOut* outs, GapOut* outs_host, uint32_t* done_list,
+                                                    int skip_confident, uint32_t* dbg, uint32_t dbg_words) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  uint32_t* s_node = lds;                       // entry node of the segment
+  uint32_t* s_dl = s_node + G2S_SEG_CAP;        // entry depth | length << 16
+  uint32_t* s_cnt = s_dl + G2S_SEG_CAP;         // path count of every state of the segment
+  uint32_t* s_p01 = s_cnt + G2S_SEG_CAP;        // parents (segment ids, 16 bits each, 0xFFFF = none)
+  uint32_t* s_p23 = s_p01 + G2S_SEG_CAP;
+  uint32_t* s_aux = s_p23 + G2S_SEG_CAP;        // generation | closure marks of the children << 16; later: emit offset
+  uint32_t* s_t = s_aux + G2S_SEG_CAP;          // last closure state: towards a sink | from a traceback start << 16 (0xFFFF none)
+  uint32_t* l_seed = s_t + G2S_SEG_CAP;         // left-flank seeds by depth [32]
+
+  const int lane = threadIdx.x;
+  const uint32_t gi = uni(gap_ids[blockIdx.x]);
+  const GapDev gd = gaps[gi];
+  GapOut* go = &outs[gi];
+  const uint32_t* lseeds = flank_nodes + gd.flank_off;
+  const uint32_t* rseeds = lseeds + (uint32_t)(gd.lmf + 1);
+  const uint32_t* targets = rseeds + (uint32_t)(gd.rmf + 1);
+  const int D = gd.D, lmf = gd.lmf, rmf = gd.rmf;
+  const unsigned long long cyc0 = __builtin_amdgcn_s_memtime();
+
+  uint32_t flags = 0;
+  bool overflow = D >= 32767 || rmf + 1 > 32 || lmf + 1 > 32;  // (16-bit depths and lengths, 32 seeds / targets)
+
+  // results go to pinned host memory as each gap finishes (as in the LDS tier)
+  auto publish = [&]() {
+    if ((uint32_t)lane < sizeof(GapOut) / 4u)
+      ((uint32_t*)&outs_host[gi])[lane] = __hip_atomic_load(&((const uint32_t*)go)[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence_system();
+    if (lane == 0) {
+      const unsigned long long at = atomicAdd(out_counter + 1, 1ull);
+      __hip_atomic_store(&done_list[at], gi, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  };
+
+  const uint32_t tg = (lane <= rmf && lane < 32) ? targets[lane] : G2S_DEV_INVALID;  // lane j: target k-mer j
+  if (lane < 32) l_seed[lane] = lane <= lmf ? lseeds[lane] : G2S_DEV_INVALID;
+
+  // ---------------- phase A: the right set as (entry node, depth label) pairs ----------------
+  // lane l of set s holds entry 64 s + l: node, label = fewest predecessor steps from a right
+  // seed (seed j enters at depth j), and the unitig-internal steps left when walking back from it.
+  uint32_t an[G2S_SEG_ASETS], al[G2S_SEG_ASETS], ar[G2S_SEG_ASETS];
+  uint64_t aq[G2S_SEG_ASETS];  // entries to be (re)expanded
+#pragma unroll
+  for (int s = 0; s < G2S_SEG_ASETS; s++) { an[s] = G2S_DEV_INVALID; al[s] = 0; ar[s] = 0; aq[s] = 0; }
+  uint32_t nA = 0, roundsA = 0;
+  // propose label dp for entry node p (both wave-uniform)
+  auto propose = [&](uint32_t p, uint32_t dp) {
+    bool found = false;
+#pragma unroll
+    for (int s = 0; s < G2S_SEG_ASETS; s++) {
+      if ((uint32_t)s * 64u < nA) {
+        const uint64_t m = __ballot(an[s] == p);
+        if (m) {
+          const int l = __builtin_ctzll(m);
+          if (dp < rl(al[s], l)) {
+            if (lane == l) al[s] = dp;
+            aq[s] |= 1ull << l;
+          }
+          found = true;
+        }
+      }
+    }
+    if (found) return;
+    if (nA >= 64u * G2S_SEG_ASETS) { overflow = true; flags |= G2S_DEV_OVERFLOW_A | G2S_DEV_WHY_RS; return; }
+    const uint32_t sA = nA >> 6;
+    const int lA = (int)(nA & 63u);
+#pragma unroll
+    for (int s = 0; s < G2S_SEG_ASETS; s++) {
+      if (sA == (uint32_t)s) {
+        if (lane == lA) { an[s] = p; al[s] = dp; ar[s] = rem[p ^ 1u]; }
+        aq[s] |= 1ull << lA;
+      }
+    }
+    nA++;
+  };
+  if (!overflow) {
+    for (int j = 0; j <= rmf && j <= gd.right_half; j++) {  // right.substr(len-k-j, k) enters at depth j (:878-884, :953-976)
+      const uint32_t sd = uni(rseeds[j]);
+      if (sd != G2S_DEV_INVALID) propose(sd, (uint32_t)j);
+    }
+    while (!overflow) {
+      uint64_t any = 0;
+#pragma unroll
+      for (int s = 0; s < G2S_SEG_ASETS; s++) any |= aq[s];
+      if (!any) break;
+      roundsA++;
+#pragma unroll
+      for (int s = 0; s < G2S_SEG_ASETS; s++) {
+        const uint64_t q = aq[s];
+        if (!q) continue;
+        aq[s] = 0;
+        const bool mine = (q >> lane) & 1ull;
+        const uint32_t d = al[s];
+        const uint32_t steps = min(ar[s], (uint32_t)gd.right_half - d);
+        const uint32_t last = seg_node(an[s] ^ 1u, steps) ^ 1u;  // walking back from v = walking on from v^1
+        const bool live = mine && d + steps < (uint32_t)gd.right_half;
+        uint4 rec = make_uint4(G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID);
+        if (live) rec = *(const uint4*)(succ + (size_t)(last ^ 1u) * 4);  // graph.predecessors(last)[i] = succ(last^1)[i] ^ 1
+        const uint32_t dchild = d + steps + 1u;
+        for (uint64_t m = __ballot(live); m && !overflow; m &= m - 1) {
+          const int l = __builtin_ctzll(m);
+          const uint32_t dl = rl(dchild, l);
+#pragma unroll 1
+          for (int q = 0; q < 4; q++) {
+            const uint32_t w = rl(q == 0 ? rec.x : q == 1 ? rec.y : q == 2 ? rec.z : rec.w, l);
+            if (w != G2S_DEV_INVALID) propose(w ^ 1u, dl);
+          }
+        }
+      }
+    }
+  }
+  // the entries as k-mer index intervals [alo, ahi]; lanes without an entry hold an empty interval
+  uint32_t alo[G2S_SEG_ASETS], ahi[G2S_SEG_ASETS];
+  uint32_t nvis = 0, xa = 0;
+#pragma unroll
+  for (int s = 0; s < G2S_SEG_ASETS; s++) {
+    const bool have = (uint32_t)s * 64u + (uint32_t)lane < nA;
+    const uint32_t steps = have ? min(ar[s], (uint32_t)gd.right_half - al[s]) : 0u;
+    const uint32_t w0 = an[s] ^ 1u, idx = w0 >> 1;
+    alo[s] = have ? ((w0 & 1u) ? idx - steps : idx) : 1u;
+    ahi[s] = have ? ((w0 & 1u) ? idx : idx + steps) : 0u;
+    if ((uint32_t)s * 64u < nA) {
+      nvis += wave_sum(have ? steps + 1u : 0u);  // (intervals of one unitig may overlap: an upper bound of the set's size)
+      xa += wave_sum(have ? min(steps + 1u, (uint32_t)gd.right_half - al[s]) : 0u);
+    }
+  }
+  // Q7 in the right set, conservatively as in the LDS tier: both strands of some k-mer are in
+  // it = an entry of each orientation with overlapping intervals
+  if (!overflow) {
+    bool both = false;
+    {
+      uint64_t odd = 0, even = 0;
+#pragma unroll
+      for (int s = 0; s < G2S_SEG_ASETS; s++) {
+        const bool have = (uint32_t)s * 64u + (uint32_t)lane < nA;
+        odd |= __ballot(have && (an[s] & 1u));
+        even |= __ballot(have && !(an[s] & 1u));
+      }
+      both = odd != 0 && even != 0;
+    }
+    if (both) {
+      for (uint32_t e = 0; e < nA && !(flags & G2S_DEV_Q7_A); e++) {
+        uint32_t lo_e = 0, hi_e = 0, or_e = 0;
+#pragma unroll
+        for (int s = 0; s < G2S_SEG_ASETS; s++)
+          if ((e >> 6) == (uint32_t)s) { lo_e = rl(alo[s], (int)(e & 63u)); hi_e = rl(ahi[s], (int)(e & 63u)); or_e = rl(an[s], (int)(e & 63u)) & 1u; }
+#pragma unroll
+        for (int s = 0; s < G2S_SEG_ASETS; s++)
+          if ((uint32_t)s * 64u < nA && __ballot(alo[s] <= hi_e && lo_e <= ahi[s] && ((an[s] & 1u) != or_e) && alo[s] <= ahi[s]))
+            flags |= G2S_DEV_Q7_A;
+      }
+    }
+  }
+  // k-mer index x in the right set?  (wave-uniform)
+  auto contains = [&](uint32_t x) -> bool {
+    uint64_t m = 0;
+#pragma unroll
+    for (int s = 0; s < G2S_SEG_ASETS; s++)
+      if ((uint32_t)s * 64u < nA) m |= __ballot(alo[s] <= x && x <= ahi[s]);
+    return m != 0;
+  };
+  // largest y <= xmax with [x0, y] inside the right set (x0 - 1 when x0 is not in it)
+  auto covered_up = [&](uint32_t x0, uint32_t xmax) -> uint32_t {
+    uint32_t cur = x0;
+    while (cur <= xmax) {
+      uint32_t best = 0;
+      bool hit = false;
+#pragma unroll
+      for (int s = 0; s < G2S_SEG_ASETS; s++) {
+        if ((uint32_t)s * 64u < nA) {
+          for (uint64_t m = __ballot(alo[s] <= cur && cur <= ahi[s]); m; m &= m - 1) {
+            const uint32_t h = rl(ahi[s], __builtin_ctzll(m));
+            best = hit ? max(best, h) : h;
+            hit = true;
+          }
+        }
+      }
+      if (!hit) break;
+      cur = best + 1u;
+    }
+    return min(cur - 1u, xmax);
+  };
+  // smallest y >= xmin with [y, x0] inside the right set (x0 + 1 when x0 is not in it)
+  auto covered_down = [&](uint32_t x0, uint32_t xmin) -> uint32_t {
+    uint32_t cur = x0;
+    while (true) {
+      uint32_t best = 0;
+      bool hit = false;
+#pragma unroll
+      for (int s = 0; s < G2S_SEG_ASETS; s++) {
+        if ((uint32_t)s * 64u < nA) {
+          for (uint64_t m = __ballot(alo[s] <= cur && cur <= ahi[s]); m; m &= m - 1) {
+            const uint32_t lo_ = rl(alo[s], __builtin_ctzll(m));
+            best = hit ? min(best, lo_) : lo_;
+            hit = true;
+          }
+        }
+      }
+      if (!hit) return cur + 1u;
+      if (best <= xmin) return xmin;
+      cur = best - 1u;
+    }
+  };
+  const unsigned long long cyc1 = __builtin_amdgcn_s_memtime();
+
+  // ---------------- phase B: entry events in registers, segments into LDS ----------------------
+  uint32_t en = G2S_DEV_INVALID, ec = 0, es = 1, ep01 = 0xFFFFFFFFu, ep23 = 0xFFFFFFFFu;
+  int ed = 0;
+  uint64_t ev = 0, efx = 0;  // pending events, and which of them have an assigned count (left seeds)
+  uint32_t nseg = 0, gen = 0, xb = 0, sb = 0;
+  uint32_t best = SEG_INF, c1 = 0, c2 = 0;  // phase C: (found level << 6 | j) and the counts of its two lengths
+  auto add_event = [&](uint32_t w, int dw, uint32_t c, uint32_t par) {
+    const bool valid = (ev >> lane) & 1ull;
+    const uint64_t m = __ballot(valid && en == w && ed == dw);
+    if (m) {
+      const int l = __builtin_ctzll(m);
+      if (lane == l) {
+        ec = min(ec + c, (uint32_t)G2S_DEV_MAX_PATHS);  // saturating add is associative (:1058-1060)
+        if ((ep01 >> 16) == SEG_NOPAR) ep01 = (ep01 & 0xFFFFu) | (par << 16);
+        else if ((ep23 & 0xFFFFu) == SEG_NOPAR) ep23 = (ep23 & 0xFFFF0000u) | par;
+        else ep23 = (ep23 & 0xFFFFu) | (par << 16);
+      }
+      return;
+    }
+    if (__ballot(valid && en == (w ^ 1u) && ed == dw)) flags |= G2S_DEV_Q7_B;  // the other strand at this depth
+    const uint64_t fr = ~ev;
+    if (!fr) { overflow = true; flags |= G2S_DEV_OVERFLOW_B | G2S_DEV_WHY_FRONTIER; return; }
+    const int l = __builtin_ctzll(fr);
+    if (lane == l) {
+      en = w; ed = dw; ec = c; ep01 = 0xFFFF0000u | par; ep23 = 0xFFFFFFFFu;
+      es = dw < lmf ? 1u : rem[w] + 1u;  // states up to the end of the unitig
+    }
+    ev |= 1ull << l;
+  };
+  if (!overflow) {
+    // left seeds: left.substr(d, k) enters at depth d with the value 1 ASSIGNED (:995-1015, :1082-1105)
+    const uint32_t sd = lane <= lmf ? lseeds[lane] : G2S_DEV_INVALID;
+    ev = efx = __ballot(sd != G2S_DEV_INVALID && lane <= D);
+    if ((ev >> lane) & 1ull) {
+      en = sd; ed = lane; ec = 1; ep01 = ep23 = 0xFFFFFFFFu;
+      es = lane < lmf ? 1u : rem[sd] + 1u;
+    }
+  }
+  while (ev && !overflow) {
+    // ---- which events are final: depth below the horizon
+    uint32_t H = SEG_INF;
+    for (uint64_t m = ev; m; m &= m - 1) {
+      const int l = __builtin_ctzll(m);
+      H = min(H, (uint32_t)rl((uint32_t)ed, l) + rl(es, l));
+    }
+    const bool valid = (ev >> lane) & 1ull;
+    const uint64_t sel = __ballot(valid && (uint32_t)ed < H);
+    const uint32_t nsel = (uint32_t)__popcll(sel);
+    if (nseg + nsel > G2S_SEG_CAP) { overflow = true; flags |= G2S_DEV_OVERFLOW_B | G2S_DEV_WHY_LOG; break; }
+    const bool mine = (sel >> lane) & 1ull;
+    const uint32_t cnt = ((efx >> lane) & 1ull) ? 1u : ec;
+    const uint32_t lcap = min(es, (uint32_t)(D - ed + 1));
+    uint32_t elen = lcap;
+    const uint32_t esid = nseg + (uint32_t)__popcll(sel & below(lane));
+    // ---- their lengths under the pruning rule, their target hits (one segment at a time, wave-uniform)
+    for (uint64_t m = sel; m; m &= m - 1) {
+      const int l = __builtin_ctzll(m);
+      const uint32_t node = rl(en, l), lc = rl(lcap, l), c = rl(cnt, l);
+      const int depth = (int)rl((uint32_t)ed, l);
+      uint32_t L = lc;
+      if (lc > 1u && depth + (int)lc - 1 >= gd.prune_from) {  // interior states are entered under :1050
+        const uint32_t t1 = (uint32_t)max(1, gd.prune_from - depth);
+        const uint32_t idx0 = node >> 1;
+        if (!(node & 1u)) L = covered_up(idx0 + t1, idx0 + lc - 1u) - idx0 + 1u;
+        else L = idx0 - covered_down(idx0 - t1, idx0 - (lc - 1u)) + 1u;
+        if (lane == l) elen = L;
+      }
+      sb += L;
+      xb += min(L, (uint32_t)(D - depth));
+      // phase C: target k-mer j at position t of the segment is a hit at depth + t
+      const int t = seg_pos(node, L, tg);
+      for (uint64_t hm = __ballot(t >= 0); hm; hm &= hm - 1) {
+        const int j = __builtin_ctzll(hm);
+        const int td = depth + (int)rl((uint32_t)t, j), base = gd.g + lmf + j;
+        const int err = td >= base ? td - base : base - td;
+        if (err > gd.e) continue;
+        const uint32_t key = ((uint32_t)(err + gd.g + lmf + rmf) << 6) | (uint32_t)j;
+        if (key < best) { best = key; c1 = 0; c2 = 0; }
+        if (key == best) { if (td >= base) c1 = c; else c2 = c; }
+      }
+    }
+    if (mine) {
+      s_node[esid] = en;
+      s_dl[esid] = (uint32_t)ed | (elen << 16);
+      s_cnt[esid] = cnt;
+      s_p01[esid] = ep01;
+      s_p23[esid] = ep23;
+      s_aux[esid] = gen;
+    }
+    nseg += nsel;
+    // ---- segments that reached the end of their stretch leave through the successor table
+    const bool exits = mine && elen == lcap && ed + (int)elen - 1 < D;
+    uint4 rec = make_uint4(G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID);
+    if (exits) rec = *(const uint4*)(succ + (size_t)seg_node(en, elen - 1u) * 4);
+    const uint32_t xd = (uint32_t)ed + elen;  // depth of the children
+    ev &= ~sel;
+    efx &= ~sel;
+    for (uint64_t m = __ballot(exits); m && !overflow; m &= m - 1) {
+      const int l = __builtin_ctzll(m);
+      const int dw = (int)rl(xd, l);
+      const uint32_t c = rl(cnt, l), par = rl(esid, l);
+#pragma unroll 1
+      for (int q = 0; q < 4; q++) {
+        const uint32_t w = rl(q == 0 ? rec.x : q == 1 ? rec.y : q == 2 ? rec.z : rec.w, l);
+        if (w != G2S_DEV_INVALID && (dw < gd.prune_from || contains(w >> 1))) add_event(w, dw, c, par);  // :1050
+      }
+    }
+    gen++;
+  }
+  if (overflow && !(flags & G2S_DEV_OVERFLOW_A)) flags |= G2S_DEV_OVERFLOW_B;
+  lds_sync();
+  const unsigned long long cyc2 = __builtin_amdgcn_s_memtime();
+
+  // ---------------- Q7: an upward and a downward segment of one unitig meeting on a k-mer ------
+  if (!overflow && !(flags & G2S_DEV_Q7_B) && nseg > 1) {
+    uint64_t anyup = 0, anydn = 0;
+    for (uint32_t b0 = 0; b0 < nseg; b0 += 64u) {
+      const uint32_t b = b0 + (uint32_t)lane;
+      anyup |= __ballot(b < nseg && !(s_node[b < nseg ? b : 0] & 1u));
+      anydn |= __ballot(b < nseg && (s_node[b < nseg ? b : 0] & 1u));
+    }
+    if (anyup && anydn) {
+      for (uint32_t b0 = 0; b0 < nseg && !(flags & G2S_DEV_Q7_B); b0 += 64u) {
+        const uint32_t b = b0 + (uint32_t)lane;
+        const bool hb = b < nseg;
+        const uint32_t nb_ = hb ? s_node[b] : 0u, dlb = hb ? s_dl[b] : 0u;
+        const int ib = (int)(nb_ >> 1), db = (int)(dlb & 0xFFFFu), lb = (int)(dlb >> 16);
+        const bool down = hb && (nb_ & 1u);
+        if (!__ballot(down)) continue;
+        for (uint32_t a = 0; a < nseg; a++) {
+          const uint32_t na = uni(s_node[a]);
+          if (na & 1u) continue;
+          const uint32_t dla = uni(s_dl[a]);
+          const int ia = (int)(na >> 1), da = (int)(dla & 0xFFFFu), la = (int)(dla >> 16);
+          const int sdiff = ib - ia, ddiff = db - da;
+          const int t1 = (sdiff + ddiff) >> 1, t2 = (sdiff - ddiff) >> 1;
+          if (__ballot(down && !((sdiff + ddiff) & 1) && t1 >= 0 && t1 < la && t2 >= 0 && t2 < lb)) { flags |= G2S_DEV_Q7_B; break; }
+        }
+      }
+    }
+  }
+
+  // ---------------- phase C in closed form (:1107-1159) ------------------------------------------
+  const bool found = best != SEG_INF;
+  int c_count = 0, n_len = 0, len0 = 0, len1 = 0, reached_j = 0;
+  int d_last = D, final_d = D + 1;
+  if (found && !overflow) {
+    const int dfound = (int)(best >> 6);
+    reached_j = (int)(best & 63u);
+    const int err = dfound - (gd.g + lmf + rmf);
+    const int l1 = gd.g + lmf + reached_j + err, l2 = gd.g + lmf + reached_j - err;
+    c_count = (int)min(c1 + c2, (uint32_t)G2S_DEV_MAX_PATHS);
+    if (c1 > 0) { len0 = l1; n_len = 1; if (c2 > 0) { len1 = l2; n_len = 2; } }
+    else { len0 = l2; n_len = 1; }
+    if (!gd.all_paths) {  // -best-only: the DP stops after the level of the find (:1156-1158)
+      d_last = dfound;
+      final_d = dfound;
+      xb = 0; sb = 0;
+      for (uint32_t b0 = 0; b0 < nseg; b0 += 64u) {
+        const uint32_t b = b0 + (uint32_t)lane;
+        const uint32_t dl = b < nseg ? s_dl[b] : 0u;
+        const int d0 = (int)(dl & 0xFFFFu), len = (int)(dl >> 16);
+        sb += wave_sum(b < nseg ? (uint32_t)max(0, min(len, d_last - d0 + 1)) : 0u);
+        xb += wave_sum(b < nseg ? (uint32_t)max(0, min(len, d_last - d0)) : 0u);
+      }
+    }
+  }
+  if (dbg) {  // diagnostics (tests): the entries of phase A and the segments of phase B
+    uint32_t* o = dbg + (size_t)blockIdx.x * dbg_words;
+    if (lane == 0) { o[0] = gi; o[1] = nA; o[2] = nseg; o[3] = flags; o[4] = roundsA; o[5] = gen; o[6] = (uint32_t)c_count; o[7] = best; }
+#pragma unroll
+    for (int s = 0; s < G2S_SEG_ASETS; s++) {
+      const uint32_t e = (uint32_t)s * 64u + (uint32_t)lane;
+      if (e < nA && 8u + 2u * e + 1u < dbg_words) { o[8u + 2u * e] = an[s]; o[9u + 2u * e] = al[s]; }
+    }
+    const uint32_t sb0 = 8u + 2u * 64u * G2S_SEG_ASETS;
+    for (uint32_t b = (uint32_t)lane; b < nseg; b += 64u)
+      if (sb0 + 6u * b + 5u < dbg_words) {
+        o[sb0 + 6u * b] = s_node[b]; o[sb0 + 6u * b + 1] = s_dl[b]; o[sb0 + 6u * b + 2] = s_cnt[b];
+        o[sb0 + 6u * b + 3] = s_p01[b]; o[sb0 + 6u * b + 4] = s_p23[b]; o[sb0 + 6u * b + 5] = s_aux[b];
+      }
+  }
+  if (lane == 0) {
+    go->flags = flags;
+    go->n_right = nvis;
+    go->x_right = xa;
+    go->n_states = sb;
+    go->x_left = xb;
+    go->final_d = final_d;
+    go->c_count = c_count;
+    go->n_len = n_len;
+    go->len[0] = len0;
+    go->len[1] = len1;
+    go->reached_j = reached_j;
+    go->n_xl = 0;
+    go->top_level = 0;
+    go->stat[0] = roundsA; go->stat[1] = nA; go->stat[2] = gen; go->stat[3] = nseg;
+    go->stat[4] = (uint32_t)((cyc1 - cyc0) >> 8); go->stat[5] = (uint32_t)((cyc2 - cyc1) >> 8);
+  }
+  if (overflow || !(c_count > 0 && n_len > 0)) {  // :1169
+    __threadfence();
+    publish();
+    return;
+  }
+
+  // ---------------- phase D1: backward closure over the segments ---------------------------------
+  const bool want_s = !skip_confident;
+  const uint32_t sinknode = (want_s && gd.all_paths && rmf >= 1) ? uni(targets[rmf - 1]) : G2S_DEV_INVALID;  // Q3/Q4
+  const int lo_sink = max(0, lmf + gd.g - gd.e);  // :1196
+  const uint32_t reached = uni(targets[reached_j]);
+  const bool t_is_s = want_s && !gd.all_paths;  // -best-only: the traceback starts are the sinks (:1245-1259)
+  {
+    uint32_t hi = nseg;
+    while (hi > 0) {
+      const uint32_t lo = hi > 64u ? hi - 64u : 0u;
+      const uint32_t b = lo + (uint32_t)lane;
+      const bool hb = b < hi;
+      const uint32_t aux = hb ? s_aux[b] : 0u;
+      const uint32_t gtop = rl(aux & 0xFFFFu, (int)(hi - 1u - lo));
+      const uint64_t gm = __ballot(hb && (aux & 0xFFFFu) == gtop);  // segments of one generation are contiguous
+      const int first = __builtin_ctzll(gm);
+      const bool act = hb && lane >= first;
+      if (act) {
+        const uint32_t v0 = s_node[b], dl = s_dl[b];
+        const int d0 = (int)(dl & 0xFFFFu);
+        const int len = max(0, min((int)(dl >> 16), d_last - d0 + 1));
+        int ts = -1, tt = -1;
+        if (len > 0) {
+          const int ps = seg_pos(v0, (uint32_t)len, sinknode);
+          if (ps >= 0 && d0 + ps >= lo_sink) ts = ps;
+          const int pt = seg_pos(v0, (uint32_t)len, reached);
+          if (pt >= 0 && (d0 + pt == len0 || (n_len > 1 && d0 + pt == len1))) { tt = pt; if (t_is_s) ts = max(ts, pt); }
+          if (aux & (G2S_SUB_IN_S << 16)) ts = len - 1;
+          if (aux & (G2S_SUB_IN_T << 16)) tt = len - 1;
+        }
+        s_t[b] = (uint32_t)(ts & 0xFFFF) | ((uint32_t)(tt & 0xFFFF) << 16);
+        const uint32_t mk = ((ts >= 0 ? G2S_SUB_IN_S : 0u) | (tt >= 0 ? G2S_SUB_IN_T : 0u)) << 16;
+        if (mk && d0 > 0) {
+          const uint32_t ls = d0 <= lmf ? l_seed[d0] : G2S_DEV_INVALID;
+          const bool source = ls != G2S_DEV_INVALID && (v0 >> 1) == (ls >> 1);  // :1270, k-mer comparison only
+          if (!source) {
+            const uint32_t p01 = s_p01[b], p23 = s_p23[b];
+            if ((p01 & 0xFFFFu) != SEG_NOPAR) atomicOr(&s_aux[p01 & 0xFFFFu], mk);
+            if ((p01 >> 16) != SEG_NOPAR) atomicOr(&s_aux[p01 >> 16], mk);
+            if ((p23 & 0xFFFFu) != SEG_NOPAR) atomicOr(&s_aux[p23 & 0xFFFFu], mk);
+            if ((p23 >> 16) != SEG_NOPAR) atomicOr(&s_aux[p23 >> 16], mk);
+          }
+        }
+      }
+      lds_sync();
+      hi = lo + (uint32_t)first;
+    }
+  }
+  // ---- emit offsets: children before parents = descending segment id; inside a segment from its
+  // last closure state down.  s_aux becomes the offset of the segment's first record.
+  uint32_t nsub = 0, nxp = 0;
+  for (uint32_t top = nseg; top > 0; top = top > 64u ? top - 64u : 0u) {
+    const bool hb = (uint32_t)lane < top;
+    const uint32_t b = hb ? top - 1u - (uint32_t)lane : 0u;
+    const uint32_t st = hb ? s_t[b] : 0xFFFFFFFFu;
+    const int ts = (int)(int16_t)(st & 0xFFFFu), tt = (int)(int16_t)(st >> 16);
+    const uint32_t cntv = (uint32_t)(max(ts, tt) + 1);
+    const uint32_t incl = wave_scan(cntv, lane);
+    if (hb) s_aux[b] = nsub + incl - cntv;
+    // further parents of closure entries (not sources, not depth 0) go to the side list
+    uint32_t extra = 0;
+    if (hb && cntv > 0) {
+      const uint32_t v0 = s_node[b];
+      const int d0 = (int)(s_dl[b] & 0xFFFFu);
+      const uint32_t ls = d0 <= lmf ? l_seed[d0] : G2S_DEV_INVALID;
+      const bool source = ls != G2S_DEV_INVALID && (v0 >> 1) == (ls >> 1);
+      if (d0 > 0 && !source) {
+        const uint32_t p01 = s_p01[b], p23 = s_p23[b];
+        extra = ((p01 >> 16) != SEG_NOPAR) + ((p23 & 0xFFFFu) != SEG_NOPAR) + ((p23 >> 16) != SEG_NOPAR);
+      }
+    }
+    nsub += rl(incl, 63);
+    nxp += wave_sum(extra);
+  }
+  lds_sync();
+  const uint32_t nres = nsub + (nxp + 1u) / 2u;
+  unsigned long long hbase = 0;
+  if (lane == 0) hbase = atomicAdd(out_counter, (unsigned long long)nres);
+  hbase = __shfl(hbase, 0);
+  if (hbase + nres > out_cap) {  // the host buffer is full: the gap runs again in the LDS tier
+    if (lane == 0) go->flags = flags | G2S_DEV_OVERFLOW_B | G2S_DEV_WHY_LOG;
+    __threadfence();
+    publish();
+    return;
+  }
+  {
+    SubRec* dst = sub_out + hbase;
+    uint64_t* xdst = (uint64_t*)(sub_out + hbase + nsub);
+    uint32_t xi = 0;
+    const uint32_t t_flags = G2S_SUB_IN_T | G2S_SUB_START_T | (t_is_s ? (G2S_SUB_IN_S | G2S_SUB_SINK) : 0u);
+    for (uint32_t b = 0; b < nseg; b++) {
+      const uint32_t st = uni(s_t[b]);
+      const int ts = (int)(int16_t)(st & 0xFFFFu), tt = (int)(int16_t)(st >> 16);
+      const int tmax = max(ts, tt);
+      if (tmax < 0) continue;
+      const uint32_t v0 = uni(s_node[b]), cntb = uni(s_cnt[b]), off = uni(s_aux[b]);
+      const int d0 = (int)(uni(s_dl[b]) & 0xFFFFu);
+      for (int t = tmax - lane; t >= 0; t -= 64) {
+        const uint32_t node = seg_node(v0, (uint32_t)t);
+        const int depth = d0 + t;
+        uint32_t f = (t <= ts ? G2S_SUB_IN_S : 0u) | (t <= tt ? G2S_SUB_IN_T : 0u);
+        if (node == sinknode && depth >= lo_sink) f |= G2S_SUB_IN_S | G2S_SUB_SINK;               // :1195-1244
+        if (node == reached && (depth == len0 || (n_len > 1 && depth == len1))) f |= t_flags;      // :1245-1259
+        int32_t pred = t > 0 ? (int32_t)(off + (uint32_t)(tmax - t) + 1u) : -1;
+        if (t == 0) {
+          const uint32_t ls = d0 <= lmf ? l_seed[d0] : G2S_DEV_INVALID;
+          if (ls != G2S_DEV_INVALID && (v0 >> 1) == (ls >> 1)) f |= G2S_SUB_SOURCE;               // :1270
+          else if (d0 > 0) {
+            const uint32_t p01 = s_p01[b], p23 = s_p23[b];
+            const uint32_t ps[4] = {p01 & 0xFFFFu, p01 >> 16, p23 & 0xFFFFu, p23 >> 16};
+            uint32_t k = 0;
+            for (int q = 0; q < 4; q++) {
+              if (ps[q] == SEG_NOPAR) continue;
+              const uint32_t pb = s_aux[ps[q]];  // the parent's last state: a child in the closure puts all of the parent there
+              if (k == 0) pred = (int32_t)pb;
+              else { pred |= G2S_SUB_MORE; xdst[xi + k - 1u] = ((uint64_t)(off + (uint32_t)tmax) << 32) | pb; }
+              k++;
+            }
+          }
+        }
+        SubRec r;
+        r.node = node; r.cnt = cntb; r.meta = (uint32_t)depth | (f << G2S_SUB_META_FLAG_SHIFT); r.pred = pred;
+        dst[off + (uint32_t)(tmax - t)] = r;
+      }
+      {  // (wave-uniform) side-list entries this segment wrote
+        const int d0u = d0;
+        const uint32_t ls = d0u <= lmf ? uni(l_seed[d0u]) : G2S_DEV_INVALID;
+        const bool source = ls != G2S_DEV_INVALID && (v0 >> 1) == (ls >> 1);
+        if (d0u > 0 && !source) {
+          const uint32_t p01 = uni(s_p01[b]), p23 = uni(s_p23[b]);
+          xi += ((p01 >> 16) != SEG_NOPAR) + ((p23 & 0xFFFFu) != SEG_NOPAR) + ((p23 >> 16) != SEG_NOPAR);
+        }
+      }
+    }
+  }
+  if (lane == 0) {
+    go->flags = flags;
+    go->n_sub = nsub;
+    go->n_xp = nxp;
+    go->sub_off = hbase;
+    go->x_sub = nsub;
+    go->stat[6] = gen;
+    go->stat[7] = (uint32_t)((__builtin_amdgcn_s_memtime() - cyc2) >> 8);
+  }
+  __threadfence();
+  publish();
+}
+
+namespace g2s {
+
+size_t fill_seg_lds_bytes() { return 4u * (7u * G2S_SEG_CAP + 32u); }
+uint32_t fill_seg_dbg_words() { return 8u + 2u * 64u * G2S_SEG_ASETS + 6u * G2S_SEG_CAP; }
+
+hipError_t launch_fill_seg(hipStream_t st, uint32_t ngaps, const uint32_t* succ, const uint32_t* rem, const GapDev* gaps,
+                           const uint32_t* gap_ids, const uint32_t* flank_nodes, SubRec* sub_out,
+                           unsigned long long out_cap, unsigned long long* out_counter, GapOut* outs, GapOut* outs_host,
+                           uint32_t* done_list, int skip_confident, uint32_t* dbg) {
+  if (ngaps == 0) return hipSuccess;
+  const size_t bytes = fill_seg_lds_bytes();
+  hipError_t e = hipFuncSetAttribute((const void*)g2s_fill_seg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(g2s_fill_seg, dim3(ngaps), dim3(64), bytes, st, succ, rem, gaps, gap_ids, flank_nodes, sub_out, out_cap,
+                     out_counter, outs, outs_host, done_list, skip_confident, dbg, fill_seg_dbg_words());
+  return hipGetLastError();
+}
+
+}  // namespace g2s

@@ -29,8 +29,10 @@
 #include "fastx.hpp"
 #include "fill_device.h"
 #include "fill_launch.h"
+#include "fill_seg.h"
 #include "glibc_rand.hpp"
 #include "post.hpp"
+#include "seg_tables.h"
 
 using namespace g2s;
 
@@ -128,6 +130,7 @@ extern "C" void g2s_graph_free(g2s_graph* g) {
         if (kv.second.succ) (void)hipFree(kv.second.succ);
         if (kv.second.pred) (void)hipFree(kv.second.pred);
         if (kv.second.ustart) (void)hipFree(kv.second.ustart - kUstartPad);
+        if (kv.second.rem) (void)hipFree(kv.second.rem);
       }
     }
     delete g->g;
@@ -451,6 +454,13 @@ extern "C" int g2s_session_create(g2s_graph* g, int device, const g2s_params* p,
   int rc = g2s_graph_upload(g, device);
   if (rc != G2S_OK) return rc;
   HIP_TRY(hipSetDevice(device));
+  {  // the segment tier's table, derived on the device from the bitmap that is already there
+    DeviceGraph& dg = g->g->dev.at(device);
+    if (!dg.rem && !dg.pred && g->g->n > 0) {
+      HIP_TRY(build_rem_table(dg.ustart, g->g->n, &dg.rem));
+      dg.bytes += g->g->n * 8;
+    }
+  }
   g2s_session* s = new g2s_session();
   s->graph = g;
   s->device = device;
@@ -681,9 +691,10 @@ Plan plan_gap(const GapJob& j, int d_err, uint64_t scale, uint64_t max_states) {
 using DoneFn = std::function<void(const uint32_t* gaps_done, size_t count)>;
 int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uint64_t max_states, TierData* td,
              bool lds, uint32_t lds_room_override = 0, bool rs_in_hbm = false, uint32_t fcap = 64,
-             const DoneFn* on_done = nullptr) {
+             const DoneFn* on_done = nullptr, bool seg = false /* segment tier (fill_seg.hip); needs lds = true */) {
   const auto t_enter = std::chrono::steady_clock::now();
   g2s_session* s = b->s;
+  uint32_t* seg_dbg = nullptr;
   const DeviceGraph& dg = s->graph->g->dev.at(s->device);
   const size_t n = b->jobs.size();
   const int d_err = s->params.d_err;
@@ -717,12 +728,12 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
     // gap's worst case (what does not fit is run again by the next pass)
     out_states += std::min<uint64_t>(p.slog_cap, 4ull * (uint64_t)(d.D + 2));
     out_max = std::max<uint64_t>(out_max, p.slog_cap);
-    if (lds) {  // extra-parent list of merged states: a quarter of the log's capacity
+    if (lds && !seg) {  // extra-parent list of merged states: a quarter of the log's capacity
       d.pad0 = std::max(64u, p.slog_cap / 4);
       d.st_off = xl_total;
       xl_total += d.pad0;
     }
-    if (lds && !rs_in_hbm) {
+    if (lds && !rs_in_hbm && !seg) {
       const uint32_t c = lds_rs_cap(j, d_err, lds_room_override ? lds_room_override : lds_room(ids.size()));
       d.rs_mask = c - 1;
       lds_cap_max = std::max(lds_cap_max, c);
@@ -731,7 +742,7 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
   HIP_TRY(s->d_gaps.ensure(n * sizeof(GapDev)));
   HIP_TRY(s->d_ids.ensure(std::max<size_t>(ids.size() * 4, 16)));
   HIP_TRY(s->d_outs.ensure(n * sizeof(GapOut)));
-  HIP_TRY(s->d_subscr.ensure(slog_total * (lds ? sizeof(SubRec) : sizeof(SubState))));
+  if (!seg) HIP_TRY(s->d_subscr.ensure(slog_total * (lds ? sizeof(SubRec) : sizeof(SubState))));
   if (!lds) HIP_TRY(s->d_subout.ensure(slog_total * sizeof(SubState)));
   HIP_TRY(s->d_counter.ensure(32));
   hipStream_t st = s->stream;
@@ -748,11 +759,13 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
   s->d_outs.clean = 0;
   s->d_counter.clean = 0;
   if (lds) {
-    HIP_TRY(s->d_log.ensure(slog_total * 8));
-    HIP_TRY(s->d_lvl.ensure(lvl_total * 4));
-    HIP_TRY(s->d_plk.ensure(slog_total * 4));
-    HIP_TRY(s->d_xl.ensure(std::max<uint64_t>(xl_total * 8, 16)));
-    HIP_TRY(s->d_xo.ensure(std::max<uint64_t>(xl_total * 8, 16)));
+    if (!seg) {
+      HIP_TRY(s->d_log.ensure(slog_total * 8));
+      HIP_TRY(s->d_lvl.ensure(lvl_total * 4));
+      HIP_TRY(s->d_plk.ensure(slog_total * 4));
+      HIP_TRY(s->d_xl.ensure(std::max<uint64_t>(xl_total * 8, 16)));
+      HIP_TRY(s->d_xo.ensure(std::max<uint64_t>(xl_total * 8, 16)));
+    }
     if (rs_in_hbm) {
       HIP_TRY(s->d_rs.ensure(rs_total * 4));
       HIP_TRY(hipMemsetAsync(s->d_rs.p, 0xFF, rs_total * 4, st));
@@ -774,7 +787,7 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
     // chunks of 32 K entries for an eighth of the gaps
     const uint32_t chunk_entries = 32768u;
     uint32_t pool_chunks = 0;
-    if (!rs_in_hbm && lds_cap_max < chunk_entries) {
+    if (!rs_in_hbm && lds_cap_max < chunk_entries && !seg) {
       pool_chunks = (uint32_t)std::min<size_t>(ids.size() / 8 + 16, (s->mem_budget / 8) / ((size_t)chunk_entries * 4));
       HIP_TRY(s->d_rspool.ensure((size_t)pool_chunks * chunk_entries * 4));
       if (s->d_rspool.clean < (size_t)pool_chunks * chunk_entries * 4)
@@ -786,7 +799,7 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
     // of repeat-rich gaps per ten thousand; without it they would run again after the launch)
     const uint32_t log_chunk_states = 131072u;
     const uint32_t log_chunks = (uint32_t)std::min<size_t>(ids.size() / 64 + 4, 256);
-    HIP_TRY(s->d_logpool.ensure((size_t)log_chunks * fill_lds_log_chunk_bytes(log_chunk_states)));
+    if (!seg) HIP_TRY(s->d_logpool.ensure((size_t)log_chunks * fill_lds_log_chunk_bytes(log_chunk_states)));
     // short lists: gap descriptors and the id list are read once per gap, straight from pinned
     // host memory — with no upload in front of it the kernel starts ~13 us earlier (2-3 % of a
     // 500-gap step); at 10 000 gaps the reads over the link cost more (kernel +4 %) than the
@@ -801,6 +814,18 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
       gaps_dev = (const GapDev*)s->d_gaps.p;
       ids_dev = (const uint32_t*)s->d_ids.p;
     }
+    const char* seg_dump = seg ? getenv("G2S_SEG_DUMP") : nullptr;  // diagnostics: phase A entries + segments of every gap
+    if (seg_dump) {
+      HIP_TRY(s->d_slog.ensure((size_t)ids.size() * fill_seg_dbg_words() * 4));
+      HIP_TRY(hipMemsetAsync(s->d_slog.p, 0, (size_t)ids.size() * fill_seg_dbg_words() * 4, st));
+      seg_dbg = (uint32_t*)s->d_slog.p;
+    }
+    if (seg)
+      HIP_TRY(launch_fill_seg(st, (uint32_t)ids.size(), dg.succ, dg.rem, gaps_dev, ids_dev, (const uint32_t*)s->d_flank.p,
+                              (SubRec*)d_subs_host, (unsigned long long)out_states, (unsigned long long*)s->d_counter.p,
+                              (GapOut*)s->d_outs.p, (GapOut*)d_outs_host, (uint32_t*)d_done_host,
+                              s->params.skip_confident ? 1 : 0, seg_dbg));
+    else
     HIP_TRY(launch_fill_lds(st, (uint32_t)ids.size(), lds_cap_max, num_oriented, dg.succ, dg.ustart,
                             gaps_dev, ids_dev, (const uint32_t*)s->d_flank.p,
                             (uint64_t*)s->d_log.p, (uint32_t*)s->d_lvl.p, (uint32_t*)s->d_plk.p, (uint64_t*)s->d_xl.p,
@@ -887,6 +912,22 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
     }
     const auto t_polled = std::chrono::steady_clock::now();
     HIP_TRY(hipStreamSynchronize(st));  // the kernels wrote td->outs / td->subs themselves
+    if (seg_dbg) {
+      std::vector<uint32_t> h((size_t)ids.size() * fill_seg_dbg_words());
+      HIP_TRY(hipMemcpy(h.data(), seg_dbg, h.size() * 4, hipMemcpyDeviceToHost));
+      if (FILE* f = fopen(getenv("G2S_SEG_DUMP"), "a")) {
+        const uint32_t W = fill_seg_dbg_words(), sb0 = 8u + 2u * 64u * G2S_SEG_ASETS;
+        for (size_t x = 0; x < ids.size(); x++) {
+          const uint32_t* o = h.data() + x * W;
+          fprintf(f, "gap %u nA %u nseg %u flags %#x roundsA %u roundsB %u c_count %u best %u\n", o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7]);
+          for (uint32_t e = 0; e < o[1] && e < 64u * G2S_SEG_ASETS; e++) fprintf(f, "A %u %u\n", o[8 + 2 * e], o[9 + 2 * e]);
+          for (uint32_t q = 0; q < o[2] && q < G2S_SEG_CAP; q++)
+            fprintf(f, "S %u %u %u %u %#x %#x %u\n", o[sb0 + 6 * q], o[sb0 + 6 * q + 1] & 0xFFFF, o[sb0 + 6 * q + 1] >> 16,
+                    o[sb0 + 6 * q + 2], o[sb0 + 6 * q + 3], o[sb0 + 6 * q + 4], o[sb0 + 6 * q + 5]);
+        }
+        fclose(f);
+      }
+    }
     {  // resets for the next launch, off its critical path (nobody waits for them here)
       HIP_TRY(hipMemsetAsync(s->d_outs.p, 0, n * sizeof(GapOut), st));
       s->d_outs.clean = n * sizeof(GapOut);
@@ -917,7 +958,11 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
     b->timing.ms_d2h += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   }
   float ms = 0;
-  if (lds) {
+  if (seg) {
+    HIP_TRY(hipEventElapsedTime(&ms, s->ev[1], s->ev[2]));
+    b->timing.ms_fill_seg += ms;
+    b->timing.seg_launches++;
+  } else if (lds) {
     HIP_TRY(hipEventElapsedTime(&ms, s->ev[1], s->ev[2]));
     b->timing.ms_fill_lds += ms;
     b->timing.lds_launches++;
@@ -1060,12 +1105,78 @@ int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
   // (the LDS right set keeps 28-bit k-mer indices)
   const bool lds_ok = s->graph->g->dev.at(s->device).pred == nullptr && !s->no_lds_tier &&
                       s->graph->g->n < (1ull << 28) - 1;
+  // ---- segment tier first (fill_seg.hip): every gap it can hold (odd k, -fuz <= 31, D < 2^15);
+  // a gap that outgrows one of its capacities comes back flagged and takes the passes below
+  std::vector<char> seg_done(n, 0);
+  const bool seg_ok = lds_ok && s->graph->g->dev.at(s->device).rem != nullptr && !getenv("G2S_NO_SEG_TIER");
+  if (seg_ok) {
+    std::vector<uint32_t> seg_ids;
+    for (size_t i = 0; i < n; i++) {
+      const GapJob& j = b->jobs[i];
+      if (j.bad_flank || j.rmf > 31 || j.lmf > 31 || j.lmf + j.rmf + j.g + fp.d_err >= 32767) continue;
+      seg_ids.push_back((uint32_t)i);
+    }
+    if (seg_ids.size() > 1024 && !getenv("G2S_NO_LPT"))  // longest searches first (see below)
+      std::stable_sort(seg_ids.begin(), seg_ids.end(), [&](uint32_t a, uint32_t c) { return b->jobs[a].g > b->jobs[c].g; });
+    if (!seg_ids.empty()) {
+      TierData* td = take_tier(s, b->tiers.size());
+      b->tiers.push_back(td);
+      td_live = td;
+      int rc = run_tier(b, seg_ids, 1, max_states, td, true, 0, false, 64u, analyze ? &on_done : nullptr, true);
+      if (rc != G2S_OK) return rc;
+      const GapOut* outs = (const GapOut*)td->outs.p;
+      for (uint32_t i : seg_ids) {
+        const GapOut& go = outs[i];
+        if (go.flags & (G2S_DEV_OVERFLOW_A | G2S_DEV_OVERFLOW_B)) {
+          if (getenv("G2S_DEBUG"))
+            fprintf(stderr, "[g2s] gap %u left the segment tier: flags 0x%x entries %u segments %u g %d\n", i, go.flags,
+                    go.stat[1], go.stat[3], b->jobs[i].g);
+          continue;
+        }
+        seg_done[i] = 1;
+        SubView& v = views[i];
+        v.out = &go;
+        v.st = (const SubRec*)td->subs.p + go.sub_off;
+        v.n = go.n_sub;
+        v.xp = (const uint64_t*)(v.st + go.n_sub);
+        v.n_xp = go.n_xp;
+        b->timing.xA += go.x_right; b->timing.sA += go.n_right;
+        b->timing.xB += go.x_left; b->timing.sB += go.n_states;
+        b->timing.xD += go.x_sub; b->timing.sD += go.n_sub;
+        b->timing.seg_tier_gaps++;
+        b->timing.seg_segments += go.stat[3];
+      }
+      if (const char* dump = getenv("G2S_DUMP_STATS")) {
+        if (FILE* f = fopen(dump, "a")) {
+          fprintf(f, "# segment tier: gap g flags A_rounds A_entries B_rounds segments cycA cycB 0 0 cycD n_right x_right n_states x_left n_sub 0\n");
+          for (uint32_t i : seg_ids) {
+            const GapOut& o = outs[i];
+            fprintf(f, "%u %d %#x %u %u %u %u %llu %llu %u %u %llu %u %u %u %u %u %u\n", i, b->jobs[i].g, o.flags, o.stat[0], o.stat[1],
+                    o.stat[2], o.stat[3], (unsigned long long)o.stat[4] << 8, (unsigned long long)o.stat[5] << 8, 0u, 0u,
+                    (unsigned long long)o.stat[7] << 8, o.n_right, o.x_right, o.n_states, o.x_left, o.n_sub, 0u);
+          }
+          fclose(f);
+        }
+      }
+      if (getenv("G2S_DEBUG")) {
+        std::vector<uint32_t> ord(seg_ids);
+        std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t c) {
+          return outs[a].stat[4] + outs[a].stat[5] + outs[a].stat[7] > outs[c].stat[4] + outs[c].stat[5] + outs[c].stat[7]; });
+        for (size_t q = 0; q < ord.size() && q < 4; q++) {
+          const GapOut& o = outs[ord[q]];
+          fprintf(stderr, "[g2s] segment tier slow gap %u: g %d | A rounds %u entries %u kcyc %u | B rounds %u segments %u kcyc %u | D1+emit kcyc %u | states %u closure %u flags %#x count %d\n",
+                  ord[q], b->jobs[ord[q]].g, o.stat[0], o.stat[1], o.stat[4] >> 2, o.stat[2], o.stat[3], o.stat[5] >> 2, o.stat[7] >> 2,
+                  o.n_states, o.n_sub, o.flags, o.c_count);
+        }
+      }
+    }
+  }
   {
     size_t nvalid = 0;
-    for (size_t i = 0; i < n; i++) nvalid += !b->jobs[i].bad_flank;
-    const uint32_t room = lds_room(nvalid);
+    for (size_t i = 0; i < n; i++) nvalid += !b->jobs[i].bad_flank && !seg_done[i];
+    const uint32_t room = lds_room(std::max<size_t>(1, nvalid));
     for (size_t i = 0; i < n; i++) {
-      if (b->jobs[i].bad_flank) continue;
+      if (b->jobs[i].bad_flank || seg_done[i]) continue;
       if (lds_ok && lds_rs_cap(b->jobs[i], fp.d_err, room) != 0) lds_ids.push_back((uint32_t)i);
       else if (lds_ok && lds_rs_cap(b->jobs[i], fp.d_err, 16384u) != 0) late1.push_back((uint32_t)i);   // pass 1's table
       else if (lds_ok && b->jobs[i].rmf <= (int)fill_lds_max_fuz()) late2.push_back((uint32_t)i);        // right set in HBM
@@ -1579,6 +1690,8 @@ extern "C" int g2s_team_fill(g2s_session* const* sessions, int nsessions, const 
         total.lds_tier_gaps += t.lds_tier_gaps; total.lds_launches += t.lds_launches;
         total.log_pool_gaps += t.log_pool_gaps; total.rs_pool_gaps += t.rs_pool_gaps;
         total.ms_prepare += t.ms_prepare;
+        total.ms_fill_seg += t.ms_fill_seg; total.seg_tier_gaps += t.seg_tier_gaps; total.seg_launches += t.seg_launches;
+        total.seg_segments += t.seg_segments;
       }
       rc = batches_stage2(subs, lead, results, arena, &total, false);
     }
@@ -1719,6 +1832,69 @@ extern "C" int g2s_test_post_gap(const g2s_graph* gh, const g2s_params* p, const
     res->fill_off = (uint64_t)(j.lmf - res->left_fuz);
     res->fill_len = (int32_t)strlen(buf + res->fill_off);
   }
+  return G2S_OK;
+}
+
+extern "C" int g2s_test_post_closure(const g2s_graph* gh, const g2s_params* p, const g2s_gap* gap, uint32_t n_records,
+                                     const uint32_t* records, uint32_t n_xp, const uint64_t* xp, int32_t c_count,
+                                     int32_t n_lengths, const int32_t* lengths, int32_t reached_j, int32_t final_d,
+                                     uint32_t seed, uint64_t skip, g2s_result* res, char* buf) {
+  if (!gh || !p || !gap || !res || !buf || (n_records && !records) || (n_xp && !xp))
+    return fail(G2S_ERR_ARG, "g2s_test_post_closure: bad argument");
+  const Graph& g = *gh->g;
+  const int k = g.k;
+  GapJob j;
+  j.g = gap->gap_len; j.lmf = gap->lmf; j.rmf = gap->rmf;
+  if (gap->left_len < k + j.lmf || gap->right_len < k + j.rmf) return fail(G2S_ERR_ARG, "flank too short");
+  j.left.assign(gap->left, (size_t)gap->left_len);
+  j.right.assign(gap->right, (size_t)gap->right_len);
+  for (int d = 0; d <= j.lmf; d++) j.flank_nodes.push_back(g.node_of(j.left.c_str() + d));
+  for (int d = 0; d <= j.rmf; d++) j.flank_nodes.push_back(g.node_of(j.right.c_str() + (j.right.size() - k - d)));
+  for (int d = 0; d <= j.rmf; d++) j.flank_nodes.push_back(g.node_of(j.right.c_str() + d));
+  GapOut go;
+  memset(&go, 0, sizeof go);
+  go.c_count = c_count; go.n_len = n_lengths; go.reached_j = reached_j; go.final_d = final_d;
+  for (int i = 0; i < n_lengths && i < 2; i++) go.len[i] = lengths[i];
+  FillParams fp;
+  fp.k = k; fp.d_err = p->d_err; fp.skip_confident = p->skip_confident != 0; fp.all_paths = p->all_paths != 0;
+  fp.unique_paths = p->unique_paths != 0;
+  std::vector<SubRec> recs(n_records);
+  if (n_records) memcpy(recs.data(), records, (size_t)n_records * sizeof(SubRec));
+  std::vector<uint64_t> xps(xp, xp + n_xp);
+  std::sort(xps.begin(), xps.end());
+  SubView v;
+  v.out = &go; v.st = recs.data(); v.n = n_records; v.xp = xps.data(); v.n_xp = n_xp;
+  SubPrep prep;
+  sub_analyze(fp, j, v, &prep);
+  memset(res, 0, sizeof *res);
+  memset(buf, 0, j.buf_bytes(k, fp.d_err));
+  res->phaseC_count = c_count;
+  res->n_lengths = n_lengths;
+  for (int i = 0; i < n_lengths && i < 2; i++) res->lengths[i] = lengths[i];
+  res->count = prep.count;
+  res->flags |= prep.flags;
+  res->fill_off = (uint64_t)j.lmf;
+  if (prep.phase_d) {
+    GlibcRand rng;
+    rng.seed(seed);
+    for (uint64_t i = 0; i < skip; i++) rng.next();
+    const int D = j.lmf + j.rmf + j.g + p->d_err;
+    std::vector<uint32_t> rands((size_t)D + 4);
+    for (auto& x : rands) x = (uint32_t)rng.next() << 1;  // raw words: value = word >> 1
+    sub_traceback(g, fp, j, v, prep, rands.data(), buf, res);
+    res->vertices = prep.sub[0]; res->edges = prep.sub[1]; res->nontrivial_components = prep.sub[2];
+    res->size_nontrivial_components = prep.sub[3]; res->vertices_final = prep.sub[4]; res->edges_final = prep.sub[5];
+    res->fill_off = (uint64_t)(j.lmf - res->left_fuz);
+    res->fill_len = (int32_t)strlen(buf + res->fill_off);
+  }
+  return G2S_OK;
+}
+
+extern "C" int g2s_test_graph_tables(const g2s_graph* gh, uint32_t* succ_out, uint64_t* ustart_out) {
+  if (!gh || !gh->g) return fail(G2S_ERR_ARG, "g2s_test_graph_tables: bad argument");
+  const Graph& g = *gh->g;
+  if (succ_out) memcpy(succ_out, g.succ.data(), (size_t)g.n * 8 * sizeof(uint32_t));
+  if (ustart_out) memcpy(ustart_out, g.ustart.data(), (size_t)((g.n + 63) / 64) * 8);
   return G2S_OK;
 }
 

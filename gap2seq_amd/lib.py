@@ -56,7 +56,9 @@ class g2s_timing(C.Structure):
                 ("launches_left_dp", C.c_uint32), ("retried_gaps", C.c_uint32),
                 ("ms_fill_lds", C.c_double), ("ms_extract_lds", C.c_double), ("x_fill_lds", C.c_uint64),
                 ("s_fill_lds", C.c_uint64), ("lds_tier_gaps", C.c_uint32), ("lds_launches", C.c_uint32),
-                ("log_pool_gaps", C.c_uint32), ("rs_pool_gaps", C.c_uint32), ("ms_prepare", C.c_double)]
+                ("log_pool_gaps", C.c_uint32), ("rs_pool_gaps", C.c_uint32), ("ms_prepare", C.c_double),
+                ("ms_fill_seg", C.c_double), ("seg_tier_gaps", C.c_uint32), ("seg_launches", C.c_uint32),
+                ("seg_segments", C.c_uint64)]
 
 
 class g2s_run_opts(C.Structure):
@@ -113,6 +115,11 @@ _SIGS = {
     "g2s_synth_gaps": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64,
                                  C.POINTER(_VP)]),
     "g2s_test_rand_stream": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_int32)]),
+    "g2s_test_post_closure": (C.c_int, [_VP, C.POINTER(g2s_params), C.POINTER(g2s_gap), C.c_uint32,
+                                        C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_uint64), C.c_int32, C.c_int32,
+                                        C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_uint32, C.c_uint64,
+                                        C.POINTER(g2s_result), C.c_char_p]),
+    "g2s_test_graph_tables": (C.c_int, [_VP, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
     "g2s_test_worker_pool": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
     "g2s_test_group_queue": (C.c_int, [C.c_int32, C.c_uint64, C.c_uint64, C.POINTER(C.c_int32)]),
     "g2s_graph_validate": (C.c_int64, [C.c_void_p, C.c_char_p, C.c_size_t]),
@@ -446,6 +453,33 @@ def test_post_gap(graph, params, gap, states, c_count, lengths, reached_j, final
     _check(lib.g2s_test_post_gap(graph.h, C.byref(params), arr, n, nodes, depths, counts, c_count, len(lengths), lens,
                                  reached_j, final_d, seed, skip, C.byref(res), buf))
     return FillResult(res, buf.raw)
+
+
+def test_post_closure(graph, params, gap, records, xp, c_count, lengths, reached_j, final_d, seed, skip):
+    """TEST HOOK binding: host D2 + D3 on a closure in the kernels' output layout.
+    records: list of (node, count, meta, pred) with pred as a signed int."""
+    lib = load_library()
+    arr, keep = _gap_array([gap])
+    n = len(records)
+    flat = (C.c_uint32 * max(1, 4 * n))()
+    for i, (node, cnt, meta, pred) in enumerate(records):
+        flat[4 * i], flat[4 * i + 1], flat[4 * i + 2], flat[4 * i + 3] = node, cnt, meta, pred & 0xFFFFFFFF
+    xs = (C.c_uint64 * max(1, len(xp)))(*xp)
+    lens = (C.c_int32 * 2)(*(list(lengths) + [0, 0])[:2])
+    res = g2s_result()
+    buf = C.create_string_buffer(gap.gap_len + graph.k + params.d_err + gap.lmf + gap.rmf + 3)
+    _check(lib.g2s_test_post_closure(graph.h, C.byref(params), arr, n, flat, len(xp), xs, c_count, len(lengths), lens,
+                                     reached_j, final_d, seed, skip, C.byref(res), buf))
+    return FillResult(res, buf.raw)
+
+
+def test_graph_tables(graph):
+    """TEST HOOK binding: (succ, ustart) as flat lists of ints: successor table (2n x 4) and bitmap words."""
+    n = graph.num_kmers
+    succ = (C.c_uint32 * max(1, 8 * n))()
+    words = (C.c_uint64 * max(1, (n + 63) // 64))()
+    _check(load_library().g2s_test_graph_tables(graph.h, succ, words))
+    return succ, words
 
 
 def test_worker_pool(threads, rounds, n):

@@ -176,6 +176,11 @@ typedef struct g2s_timing {
   uint32_t rs_pool_gaps;     /* gaps whose right set moved from LDS to a chunk of the launch's spill pool */
   double ms_prepare;         /* g2s_fill_batch / g2s_team_fill: flank k-mer -> node resolution + descriptor upload
                                 (g2s_batch_prepare), inside ms_total; summed over sessions for a team */
+  /* segment tier (kernel g2s_fill_seg = phases A-D1 over unitig segments, fill_seg.hip) */
+  double ms_fill_seg;        /* HIP events on the session stream, summed over launches */
+  uint32_t seg_tier_gaps;    /* gaps that completed in the segment tier */
+  uint32_t seg_launches;
+  uint64_t seg_segments;     /* segments those gaps took (a config-2 gap: ~25 for ~1000 DP states) */
 } g2s_timing;
 
 /* ---------------------------------------------------------------------------
@@ -261,6 +266,21 @@ int g2s_test_post_gap(const g2s_graph* g, const g2s_params* p, const g2s_gap* ga
                       const uint32_t* nodes, const int32_t* depths, const uint32_t* counts, int32_t c_count,
                       int32_t n_lengths, const int32_t* lengths, int32_t reached_j, int32_t final_d, uint32_t seed,
                       uint32_t skip, g2s_result* res, char* buf);
+
+/* TEST HOOK: the host half of phase D (D2 + D3) on a backward closure supplied by the caller in
+ * the layout the kernels emit: n records of 16 bytes {node, count, depth | flags << 27, first
+ * parent index | G2S more-parents bit, or -1} in an order in which every parent comes AFTER its
+ * children, plus the side list of further parents (state << 32 | parent).  Used by the CPU
+ * tests of the kernel's algorithm model (tests/seg_model.py); cannot compute the DP. */
+int g2s_test_post_closure(const g2s_graph* g, const g2s_params* p, const g2s_gap* gap, uint32_t n_records,
+                          const uint32_t* records /* 4 words each */, uint32_t n_xp, const uint64_t* xp, int32_t c_count,
+                          int32_t n_lengths, const int32_t* lengths, int32_t reached_j, int32_t final_d, uint32_t seed,
+                          uint64_t skip, g2s_result* res, char* buf);
+
+/* TEST HOOK: copies of the tables the kernels walk: the successor table (2 * kmers * 4 words,
+ * G2S_INVALID_NODE = none) and the unitig-start bitmap ((kmers + 63) / 64 words; bit i set = the
+ * edge 2(i-1) -> 2i is not unitig-internal). */
+int g2s_test_graph_tables(const g2s_graph* g, uint32_t* succ_out, uint64_t* ustart_out);
 
 /* TEST HOOK: values [skip, skip+n) of the session-style rand() stream after srand(seed)
  * (the flat glibc TYPE_3 generator the tracebacks read), for comparison with libc. */
