@@ -25,6 +25,8 @@
 /* diagnostics of the LDS tier's pools (no effect on results) */
 #define G2S_DEV_LOG_POOL 0x1000u    /* the state log moved to a chunk of the log pool        */
 #define G2S_DEV_RS_POOL 0x2000u     /* the right set moved from LDS to a chunk of the spill pool */
+/* the closure of this gap was emitted as segments (SegRec, segment tier), not as per-state records */
+#define G2S_DEV_COMPACT 0x4000u
 /* LDS tier, lvl[]: bit 31 of the END offset of level L = L was produced by a bulk step
  * (same width as level L-1, state r has the single parent r of level L-1) */
 #define G2S_LVL_UNIFORM 0x80000000u
@@ -85,6 +87,22 @@ struct SubRec {
   int32_t pred;  /* -1: none */
 };
 
+/* The closure as the segment tier emits it: one record per unitig segment that holds closure
+ * states, children before parents.  The states of a segment are (node +- 2t, depth + t) for
+ * t = 0 .. len-1 (even node ids walk up, odd down), all with the same path count; t <= ts are on a
+ * path to a sink, t <= tt reachable backwards from a traceback start (0xFFFF = none); the parents
+ * of state 0 are the LAST states of the parent segments (indices into this array, 0xFFFF = none).
+ * post.cpp: seg_expand turns this into SubRec + side list for the host half of phase D. */
+struct SegRec {
+  uint32_t node;
+  uint32_t depth_len;  /* depth | len << 16 */
+  uint32_t cnt;
+  uint32_t ts_tt;      /* ts | tt << 16 */
+  uint32_t par01, par23;
+  uint32_t flags;      /* G2S_SUB_SOURCE: state 0 is a left-flank k-mer at its offset (not expanded) */
+  uint32_t pad;
+};
+
 struct GapOut {
   uint32_t flags;
   uint32_t n_right;    // visited oriented nodes in the right set
@@ -99,7 +117,7 @@ struct GapOut {
   uint32_t n_sub;      // states in the backward closure (phase D input)
   uint64_t sub_off;    // offset of this gap's closure in the packed output (SubRec / SubState units)
   uint32_t x_sub;      // expansions done by the backward sweep
-  uint32_t n_xl;       // LDS tier: entries in the gap's extra-parent list
+  uint32_t n_xl;       // LDS tier: entries in the gap's extra-parent list; segment tier: SegRec records emitted
   uint32_t top_level;  // LDS tier: last DP level that holds a state
   uint32_t n_xp;       // LDS tier: entries of the closure's side list (parents beyond the first)
   // LDS tier statistics: per-level iterations / bulk iterations of phases A, B, D1 and

@@ -155,7 +155,7 @@ __global__ __launch_bounds__(64) void g2s_fill_seg(const uint32_t* __restrict__ 
 #pragma unroll
     for (int s = 0; s < G2S_SEG_ASETS; s++) {
       if (sA == (uint32_t)s) {
-        if (lane == lA) { an[s] = p; al[s] = dp; ar[s] = rem[p ^ 1u]; }
+        if (lane == lA) { an[s] = p; al[s] = dp; ar[s] = G2S_DEV_INVALID; }  // (steps left: loaded for all new entries at once)
         aq[s] |= 1ull << lA;
       }
     }
@@ -178,6 +178,7 @@ __global__ __launch_bounds__(64) void g2s_fill_seg(const uint32_t* __restrict__ 
         if (!q) continue;
         aq[s] = 0;
         const bool mine = (q >> lane) & 1ull;
+        if (mine && ar[s] == G2S_DEV_INVALID) ar[s] = rem[an[s] ^ 1u];  // one round trip for all new entries of the set
         const uint32_t d = al[s];
         const uint32_t steps = min(ar[s], (uint32_t)gd.right_half - d);
         const uint32_t last = seg_node(an[s] ^ 1u, steps) ^ 1u;  // walking back from v = walking on from v^1
@@ -316,7 +317,7 @@ __global__ __launch_bounds__(64) void g2s_fill_seg(const uint32_t* __restrict__ 
     const int l = __builtin_ctzll(fr);
     if (lane == l) {
       en = w; ed = dw; ec = c; ep01 = 0xFFFF0000u | par; ep23 = 0xFFFFFFFFu;
-      es = dw < lmf ? 1u : rem[w] + 1u;  // states up to the end of the unitig
+      es = dw < lmf ? 1u : 0u;  // states up to the end of the unitig (0: loaded for all new events at once)
     }
     ev |= 1ull << l;
   };
@@ -330,6 +331,7 @@ __global__ __launch_bounds__(64) void g2s_fill_seg(const uint32_t* __restrict__ 
     }
   }
   while (ev && !overflow) {
+    if (((ev >> lane) & 1ull) && es == 0u) es = rem[en] + 1u;  // one round trip for all events created last round
     // ---- which events are final: depth below the horizon
     uint32_t H = SEG_INF;
     for (uint64_t m = ev; m; m &= m - 1) {
@@ -544,34 +546,25 @@ __global__ __launch_bounds__(64) void g2s_fill_seg(const uint32_t* __restrict__ 
       hi = lo + (uint32_t)first;
     }
   }
-  // ---- emit offsets: children before parents = descending segment id; inside a segment from its
-  // last closure state down.  s_aux becomes the offset of the segment's first record.
-  uint32_t nsub = 0, nxp = 0;
+  // ---- the closure leaves as SEGMENTS (32 bytes each, SegRec), children before parents = descending
+  // segment id; the host expands them into per-state records (post.cpp: seg_expand).  Writing the
+  // ~730 16-byte state records of a gap over the link instead made the launch PCIe-bound: 5.8 MB per
+  // 500 gaps, 117 MB per 10 000 (measured: config 3's kernel 2.6 ms = the time the link takes).
+  // s_aux becomes the segment's index among the emitted ones.
+  uint32_t nrec = 0, nsub = 0, nxp = 0;
   for (uint32_t top = nseg; top > 0; top = top > 64u ? top - 64u : 0u) {
     const bool hb = (uint32_t)lane < top;
     const uint32_t b = hb ? top - 1u - (uint32_t)lane : 0u;
     const uint32_t st = hb ? s_t[b] : 0xFFFFFFFFu;
     const int ts = (int)(int16_t)(st & 0xFFFFu), tt = (int)(int16_t)(st >> 16);
-    const uint32_t cntv = (uint32_t)(max(ts, tt) + 1);
-    const uint32_t incl = wave_scan(cntv, lane);
-    if (hb) s_aux[b] = nsub + incl - cntv;
-    // further parents of closure entries (not sources, not depth 0) go to the side list
-    uint32_t extra = 0;
-    if (hb && cntv > 0) {
-      const uint32_t v0 = s_node[b];
-      const int d0 = (int)(s_dl[b] & 0xFFFFu);
-      const uint32_t ls = d0 <= lmf ? l_seed[d0] : G2S_DEV_INVALID;
-      const bool source = ls != G2S_DEV_INVALID && (v0 >> 1) == (ls >> 1);
-      if (d0 > 0 && !source) {
-        const uint32_t p01 = s_p01[b], p23 = s_p23[b];
-        extra = ((p01 >> 16) != SEG_NOPAR) + ((p23 & 0xFFFFu) != SEG_NOPAR) + ((p23 >> 16) != SEG_NOPAR);
-      }
-    }
-    nsub += rl(incl, 63);
-    nxp += wave_sum(extra);
+    const bool in = max(ts, tt) >= 0;
+    const uint64_t m = __ballot(in);
+    if (in) s_aux[b] = nrec + (uint32_t)__popcll(m & below(lane));
+    nrec += (uint32_t)__popcll(m);
+    nsub += wave_sum(in ? (uint32_t)(max(ts, tt) + 1) : 0u);
   }
   lds_sync();
-  const uint32_t nres = nsub + (nxp + 1u) / 2u;
+  const uint32_t nres = 2u * nrec;  // in 16-byte units of the output buffer
   unsigned long long hbase = 0;
   if (lane == 0) hbase = atomicAdd(out_counter, (unsigned long long)nres);
   hbase = __shfl(hbase, 0);
@@ -582,59 +575,47 @@ __global__ __launch_bounds__(64) void g2s_fill_seg(const uint32_t* __restrict__ 
     return;
   }
   {
-    SubRec* dst = sub_out + hbase;
-    uint64_t* xdst = (uint64_t*)(sub_out + hbase + nsub);
-    uint32_t xi = 0;
-    const uint32_t t_flags = G2S_SUB_IN_T | G2S_SUB_START_T | (t_is_s ? (G2S_SUB_IN_S | G2S_SUB_SINK) : 0u);
-    for (uint32_t b = 0; b < nseg; b++) {
-      const uint32_t st = uni(s_t[b]);
+    SegRec* dst = (SegRec*)(sub_out + hbase);
+    for (uint32_t b0 = 0; b0 < nseg; b0 += 64u) {
+      const uint32_t b = b0 + (uint32_t)lane;
+      if (b >= nseg) continue;
+      const uint32_t st = s_t[b];
       const int ts = (int)(int16_t)(st & 0xFFFFu), tt = (int)(int16_t)(st >> 16);
-      const int tmax = max(ts, tt);
-      if (tmax < 0) continue;
-      const uint32_t v0 = uni(s_node[b]), cntb = uni(s_cnt[b]), off = uni(s_aux[b]);
-      const int d0 = (int)(uni(s_dl[b]) & 0xFFFFu);
-      for (int t = tmax - lane; t >= 0; t -= 64) {
-        const uint32_t node = seg_node(v0, (uint32_t)t);
-        const int depth = d0 + t;
-        uint32_t f = (t <= ts ? G2S_SUB_IN_S : 0u) | (t <= tt ? G2S_SUB_IN_T : 0u);
-        if (node == sinknode && depth >= lo_sink) f |= G2S_SUB_IN_S | G2S_SUB_SINK;               // :1195-1244
-        if (node == reached && (depth == len0 || (n_len > 1 && depth == len1))) f |= t_flags;      // :1245-1259
-        int32_t pred = t > 0 ? (int32_t)(off + (uint32_t)(tmax - t) + 1u) : -1;
-        if (t == 0) {
-          const uint32_t ls = d0 <= lmf ? l_seed[d0] : G2S_DEV_INVALID;
-          if (ls != G2S_DEV_INVALID && (v0 >> 1) == (ls >> 1)) f |= G2S_SUB_SOURCE;               // :1270
-          else if (d0 > 0) {
-            const uint32_t p01 = s_p01[b], p23 = s_p23[b];
-            const uint32_t ps[4] = {p01 & 0xFFFFu, p01 >> 16, p23 & 0xFFFFu, p23 >> 16};
-            uint32_t k = 0;
-            for (int q = 0; q < 4; q++) {
-              if (ps[q] == SEG_NOPAR) continue;
-              const uint32_t pb = s_aux[ps[q]];  // the parent's last state: a child in the closure puts all of the parent there
-              if (k == 0) pred = (int32_t)pb;
-              else { pred |= G2S_SUB_MORE; xdst[xi + k - 1u] = ((uint64_t)(off + (uint32_t)tmax) << 32) | pb; }
-              k++;
-            }
-          }
-        }
-        SubRec r;
-        r.node = node; r.cnt = cntb; r.meta = (uint32_t)depth | (f << G2S_SUB_META_FLAG_SHIFT); r.pred = pred;
-        dst[off + (uint32_t)(tmax - t)] = r;
+      if (max(ts, tt) < 0) continue;
+      const uint32_t dl = s_dl[b];
+      const int d0 = (int)(dl & 0xFFFFu);
+      const uint32_t v0 = s_node[b];
+      const uint32_t ls = d0 <= lmf ? l_seed[d0] : G2S_DEV_INVALID;
+      const bool source = ls != G2S_DEV_INVALID && (v0 >> 1) == (ls >> 1);  // :1270, k-mer comparison only
+      SegRec r;
+      r.node = v0;
+      r.depth_len = (uint32_t)d0 | ((uint32_t)(max(ts, tt) + 1) << 16);
+      r.cnt = s_cnt[b];
+      r.ts_tt = st;
+      r.par01 = r.par23 = 0xFFFFFFFFu;
+      r.flags = source ? G2S_SUB_SOURCE : 0u;
+      r.pad = 0;
+      if (!source && d0 > 0) {  // parents as indices among the emitted segments (they are all in the closure)
+        const uint32_t p01 = s_p01[b], p23 = s_p23[b];
+        const uint32_t ps[4] = {p01 & 0xFFFFu, p01 >> 16, p23 & 0xFFFFu, p23 >> 16};
+        uint32_t out[4] = {SEG_NOPAR, SEG_NOPAR, SEG_NOPAR, SEG_NOPAR};
+        uint32_t k = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+          if (ps[q] != SEG_NOPAR) out[k++] = s_aux[ps[q]];
+        r.par01 = out[0] | (out[1] << 16);
+        r.par23 = out[2] | (out[3] << 16);
+        nxp += k > 1u ? k - 1u : 0u;
       }
-      {  // (wave-uniform) side-list entries this segment wrote
-        const int d0u = d0;
-        const uint32_t ls = d0u <= lmf ? uni(l_seed[d0u]) : G2S_DEV_INVALID;
-        const bool source = ls != G2S_DEV_INVALID && (v0 >> 1) == (ls >> 1);
-        if (d0u > 0 && !source) {
-          const uint32_t p01 = uni(s_p01[b]), p23 = uni(s_p23[b]);
-          xi += ((p01 >> 16) != SEG_NOPAR) + ((p23 & 0xFFFFu) != SEG_NOPAR) + ((p23 >> 16) != SEG_NOPAR);
-        }
-      }
+      dst[s_aux[b]] = r;
     }
+    nxp = wave_sum(nxp);
   }
   if (lane == 0) {
-    go->flags = flags;
+    go->flags = flags | G2S_DEV_COMPACT;
     go->n_sub = nsub;
     go->n_xp = nxp;
+    go->n_xl = nrec;
     go->sub_off = hbase;
     go->x_sub = nsub;
     go->stat[6] = gen;

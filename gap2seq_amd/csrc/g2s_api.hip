@@ -258,6 +258,10 @@ struct TierData {  // what came back from one launch group (pinned buffers live 
   std::vector<SubRec> conv;        // HBM tier: closures converted to the host's 16-byte records
   std::vector<uint64_t> conv_xp;
   std::vector<uint32_t> gap_ids;
+  // segment tier: the closures arrive as segments and are expanded into per-state records here,
+  // each gap taking its share with one atomic add (analysis threads work on different gaps)
+  std::vector<SubRec> exp;
+  std::atomic<size_t> exp_cursor{0};
 };
 }  // namespace
 
@@ -529,6 +533,7 @@ struct g2s_batch {
   size_t arena_base = 0;          // fills that do not depend on rand() values); base = its offset there
   g2s_timing timing;
   std::vector<TierData*> tiers;
+  TierData* seg_td = nullptr;  // the segment tier's launch of this run (closures expanded into its buffer)
   // stage 1 results (GPU passes + per-gap analysis), consumed by stage 2 (offsets + tracebacks)
   std::vector<SubView> views;
   std::vector<SubPrep> prep;
@@ -776,6 +781,8 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
     // results go straight to pinned host memory (closures packed by an atomic cursor)
     HIP_TRY(td->outs.ensure(n * sizeof(GapOut)));
     out_states += out_max;
+    // (segment tier: two 16-byte units per closure segment; ~15 segments per gap, at most G2S_SEG_CAP)
+    if (seg) out_states = (uint64_t)ids.size() * 128u + 2u * G2S_SEG_CAP;
     HIP_TRY(td->subs.ensure(std::max<uint64_t>(out_states * sizeof(SubRec), 16)));
     HIP_TRY(td->done.ensure(std::max<size_t>(ids.size() * 4, 16)));
     memset(td->done.p, 0xFF, ids.size() * 4);
@@ -1005,8 +1012,22 @@ void analyze_gap(g2s_batch* b, size_t i, const FillParams& fp, g2s_result* r) {
   gi.skip_thr = (int16_t)std::max(-1, std::min(j.skip_if_prev_right_fuz_gt, 32767));
   if (j.bad_flank) { gi.kind = 1; r->flags |= G2S_GAP_BAD_FLANK; return; }
   if (b->mem_exceeded[i]) { gi.kind = 2; r->count = -1; r->flags |= G2S_GAP_MEM_EXCEEDED; return; }
-  const SubView& v = b->views[i];
+  SubView& v = b->views[i];
   SubPrep& pp = b->prep[i];
+  if (v.segs) {  // segment tier: expand the closure segments into per-state records first
+    const GapOut& go = *v.out;
+    const size_t need = (size_t)go.n_sub + ((size_t)go.n_xp + 1) / 2;
+    SubRec* dst = nullptr;
+    if (b->seg_td) {
+      const size_t at = b->seg_td->exp_cursor.fetch_add(need);
+      if (at + need <= b->seg_td->exp.size()) dst = b->seg_td->exp.data() + at;
+    }
+    if (!dst) { pp.own.resize(need); dst = pp.own.data(); }  // (the shared buffer is sized for 4 states per DP level and gap)
+    uint64_t* xp = (uint64_t*)(dst + go.n_sub);
+    seg_expand(fp, j, go, v.segs, v.n_segs, dst, xp);
+    v.st = dst; v.n = go.n_sub; v.xp = xp; v.n_xp = go.n_xp;
+    v.segs = nullptr;
+  }
   if (v.n_xp > 1) std::sort(const_cast<uint64_t*>(v.xp), const_cast<uint64_t*>(v.xp) + v.n_xp);  // by state (the kernel appends per level)
   sub_analyze(fp, j, v, &pp);
   r->phaseC_count = v.out->c_count;
@@ -1079,15 +1100,21 @@ int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
       if (go.flags & (G2S_DEV_OVERFLOW_A | G2S_DEV_OVERFLOW_B)) continue;  // runs again in a later pass
       SubView& v = views[i];
       v.out = &go;
-      v.st = (const SubRec*)td_live->subs.p + go.sub_off;
-      v.n = go.n_sub;
-      v.xp = (const uint64_t*)(v.st + go.n_sub);
-      v.n_xp = go.n_xp;
+      if (go.flags & G2S_DEV_COMPACT) {
+        v.segs = (const SegRec*)((const SubRec*)td_live->subs.p + go.sub_off);
+        v.n_segs = go.n_xl;
+        v.st = nullptr; v.n = 0; v.xp = nullptr; v.n_xp = 0;
+      } else {
+        v.st = (const SubRec*)td_live->subs.p + go.sub_off;
+        v.n = go.n_sub;
+        v.xp = (const uint64_t*)(v.st + go.n_sub);
+        v.n_xp = go.n_xp;
+      }
       analyzed[i] = 1;
       fresh.push_back(i);
     }
     size_t work = 0;
-    for (uint32_t i : fresh) work += views[i].n;
+    for (uint32_t i : fresh) work += views[i].segs ? views[i].out->n_sub : views[i].n;
     if (fresh.size() <= 1 || work < 1500) {  // not worth waking the pool (~20 ns per closure state)
       for (uint32_t i : fresh) analyze_gap(b, i, fp, &results[i]);
     } else {
@@ -1122,6 +1149,13 @@ int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
       TierData* td = take_tier(s, b->tiers.size());
       b->tiers.push_back(td);
       td_live = td;
+      b->seg_td = td;
+      {  // room for the expanded closures: 4 states per DP level and gap (more falls back to per-gap buffers)
+        size_t want = 0;
+        for (uint32_t i : seg_ids) want += 4u * (size_t)(b->jobs[i].lmf + b->jobs[i].rmf + b->jobs[i].g + fp.d_err + 2);
+        if (td->exp.size() < want) td->exp.resize(want);
+        td->exp_cursor.store(0);
+      }
       int rc = run_tier(b, seg_ids, 1, max_states, td, true, 0, false, 64u, analyze ? &on_done : nullptr, true);
       if (rc != G2S_OK) return rc;
       const GapOut* outs = (const GapOut*)td->outs.p;
@@ -1134,12 +1168,13 @@ int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
           continue;
         }
         seg_done[i] = 1;
-        SubView& v = views[i];
-        v.out = &go;
-        v.st = (const SubRec*)td->subs.p + go.sub_off;
-        v.n = go.n_sub;
-        v.xp = (const uint64_t*)(v.st + go.n_sub);
-        v.n_xp = go.n_xp;
+        if (!analyzed[i]) {  // (gaps analysed while the kernel ran already have their view, expanded)
+          SubView& v = views[i];
+          v.out = &go;
+          v.segs = (const SegRec*)((const SubRec*)td->subs.p + go.sub_off);
+          v.n_segs = go.n_xl;
+          v.st = nullptr; v.n = 0; v.xp = nullptr; v.n_xp = 0;
+        }
         b->timing.xA += go.x_right; b->timing.sA += go.n_right;
         b->timing.xB += go.x_left; b->timing.sB += go.n_states;
         b->timing.xD += go.x_sub; b->timing.sD += go.n_sub;
@@ -1887,6 +1922,43 @@ extern "C" int g2s_test_post_closure(const g2s_graph* gh, const g2s_params* p, c
     res->fill_off = (uint64_t)(j.lmf - res->left_fuz);
     res->fill_len = (int32_t)strlen(buf + res->fill_off);
   }
+  return G2S_OK;
+}
+
+extern "C" int g2s_test_seg_expand(const g2s_graph* gh, const g2s_params* p, const g2s_gap* gap, uint32_t n_segs,
+                                   const uint32_t* segs, int32_t n_lengths, const int32_t* lengths, int32_t reached_j,
+                                   uint32_t n_records, uint32_t* records, uint32_t n_xp, uint64_t* xp) {
+  if (!gh || !p || !gap || (n_segs && !segs) || (n_records && !records) || (n_xp && !xp))
+    return fail(G2S_ERR_ARG, "g2s_test_seg_expand: bad argument");
+  const Graph& g = *gh->g;
+  const int k = g.k;
+  GapJob j;
+  j.g = gap->gap_len; j.lmf = gap->lmf; j.rmf = gap->rmf;
+  if (gap->left_len < k + j.lmf || gap->right_len < k + j.rmf) return fail(G2S_ERR_ARG, "flank too short");
+  j.left.assign(gap->left, (size_t)gap->left_len);
+  j.right.assign(gap->right, (size_t)gap->right_len);
+  for (int d = 0; d <= j.lmf; d++) j.flank_nodes.push_back(g.node_of(j.left.c_str() + d));
+  for (int d = 0; d <= j.rmf; d++) j.flank_nodes.push_back(g.node_of(j.right.c_str() + (j.right.size() - k - d)));
+  for (int d = 0; d <= j.rmf; d++) j.flank_nodes.push_back(g.node_of(j.right.c_str() + d));
+  GapOut go;
+  memset(&go, 0, sizeof go);
+  go.n_len = n_lengths; go.reached_j = reached_j;
+  for (int i = 0; i < n_lengths && i < 2; i++) go.len[i] = lengths[i];
+  FillParams fp;
+  fp.k = k; fp.d_err = p->d_err; fp.skip_confident = p->skip_confident != 0; fp.all_paths = p->all_paths != 0;
+  fp.unique_paths = p->unique_paths != 0;
+  const SegRec* sr = (const SegRec*)segs;
+  size_t total = 0, nx = 0;
+  for (uint32_t i = 0; i < n_segs; i++) {
+    total += sr[i].depth_len >> 16;
+    if (!(sr[i].flags & G2S_SUB_SOURCE)) {
+      int np = ((sr[i].par01 & 0xFFFFu) != 0xFFFFu) + ((sr[i].par01 >> 16) != 0xFFFFu) + ((sr[i].par23 & 0xFFFFu) != 0xFFFFu) +
+               ((sr[i].par23 >> 16) != 0xFFFFu);
+      if (np > 1) nx += (size_t)np - 1;
+    }
+  }
+  if (total != n_records || nx != n_xp) return fail(G2S_ERR_ARG, "g2s_test_seg_expand: output sizes do not match the segments");
+  seg_expand(fp, j, go, sr, n_segs, (SubRec*)records, xp);
   return G2S_OK;
 }
 

@@ -104,6 +104,53 @@ void sub_convert(const SubState* in, uint32_t n, std::vector<SubRec>* recs, std:
   }
 }
 
+void seg_expand(const FillParams& p, const GapJob& job, const GapOut& go, const SegRec* segs, uint32_t n_segs,
+                SubRec* out, uint64_t* xp) {
+  const int lmf = job.lmf, rmf = job.rmf;
+  const uint32_t* targets = job.targets();
+  const bool want_s = !p.skip_confident;
+  const uint32_t sinknode = (want_s && p.all_paths && rmf >= 1) ? targets[rmf - 1] : kInvalidNode;  // Q3/Q4 (:1195-1244)
+  const int lo_sink = std::max(0, lmf + job.g - p.d_err);                                          // :1196
+  const uint32_t reached = targets[go.reached_j];
+  const uint32_t t_flags = G2S_SUB_IN_T | G2S_SUB_START_T | ((want_s && !p.all_paths) ? (G2S_SUB_IN_S | G2S_SUB_SINK) : 0u);
+  static thread_local std::vector<uint32_t> base;
+  base.resize(n_segs);
+  uint32_t total = 0;
+  for (uint32_t i = 0; i < n_segs; i++) { base[i] = total; total += segs[i].depth_len >> 16; }
+  uint32_t nx = 0;
+  for (uint32_t i = 0; i < n_segs; i++) {
+    const SegRec& s = segs[i];
+    const int d0 = (int)(s.depth_len & 0xFFFFu), len = (int)(s.depth_len >> 16);
+    const int ts = (int)(int16_t)(s.ts_tt & 0xFFFFu), tt = (int)(int16_t)(s.ts_tt >> 16);
+    const bool up = (s.node & 1u) == 0;
+    SubRec* o = out + base[i];
+    for (int t = len - 1; t >= 0; t--, o++) {
+      const uint32_t node = up ? s.node + 2u * (uint32_t)t : s.node - 2u * (uint32_t)t;
+      const int depth = d0 + t;
+      uint32_t f = (t <= ts ? G2S_SUB_IN_S : 0u) | (t <= tt ? G2S_SUB_IN_T : 0u);
+      if (node == sinknode && depth >= lo_sink) f |= G2S_SUB_IN_S | G2S_SUB_SINK;
+      if (node == reached && (depth == go.len[0] || (go.n_len > 1 && depth == go.len[1]))) f |= t_flags;  // :1245-1259
+      int32_t pred = t > 0 ? (int32_t)(base[i] + (uint32_t)(len - t)) : -1;
+      if (t == 0) {
+        if (s.flags & G2S_SUB_SOURCE) f |= G2S_SUB_SOURCE;  // :1270
+        else {
+          const uint32_t ps[4] = {s.par01 & 0xFFFFu, s.par01 >> 16, s.par23 & 0xFFFFu, s.par23 >> 16};
+          for (int q = 0; q < 4; q++) {
+            if (ps[q] == 0xFFFFu) continue;
+            const uint32_t pb = base[ps[q]];  // the parent's last state is its first record
+            if (pred < 0) pred = (int32_t)pb;
+            else { pred |= G2S_SUB_MORE; xp[nx++] = ((uint64_t)(base[i] + (uint32_t)(len - 1)) << 32) | pb; }
+          }
+        }
+      }
+      o->node = node;
+      o->cnt = s.cnt;
+      o->meta = (uint32_t)depth | (f << G2S_SUB_META_FLAG_SHIFT);
+      o->pred = pred;
+    }
+  }
+}
+
 void sub_analyze(const FillParams& p, const GapJob& job, const SubView& v, SubPrep* out) {
   const GapOut& go = *v.out;
   out->count = go.c_count;

@@ -46,7 +46,15 @@ struct SubView {
   uint32_t n = 0;
   const uint64_t* xp = nullptr;  // parents beyond the first: (state << 32 | parent), sorted by state
   uint32_t n_xp = 0;
+  // segment tier: the closure as it came from the device (SegRec); st / xp are filled by seg_expand
+  const SegRec* segs = nullptr;
+  uint32_t n_segs = 0;
 };
+// Closure segments (segment tier) -> per-state records + side list, in the order the other tiers
+// emit them: children before parents, inside a segment from its last closure state down to its
+// entry.  out needs go.n_sub records, xp go.n_xp entries.
+void seg_expand(const FillParams& p, const GapJob& job, const GapOut& go, const SegRec* segs, uint32_t n_segs,
+                SubRec* out, uint64_t* xp);
 inline uint32_t sub_depth(const SubRec& s) { return s.meta & G2S_SUB_META_DEPTH_MASK; }
 inline uint32_t sub_flags(const SubRec& s) { return s.meta >> G2S_SUB_META_FLAG_SHIFT; }
 // the parents of state i (a set, at most 4); returns how many
@@ -74,6 +82,7 @@ struct SubPrep {
   uint32_t flags = 0;     // G2S_GAP_* bits found on the host
   uint64_t sub[6] = {0, 0, 0, 0, 0, 0};
   std::vector<uint8_t> safe;  // per state: branch[vertex of its k-mer] == 1 (Q5 default = sink)
+  std::vector<SubRec> own;    // segment tier: this gap's expanded closure when the launch's shared buffer is full
   int start_idx[2] = {-1, -1};  // state index of (reachedTarget, pathLengths[i])
   int stop_depth[2] = {-1, -1}; // depth every traceback from start i stops at, or -1 when it depends on the draws
 };

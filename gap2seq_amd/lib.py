@@ -120,6 +120,9 @@ _SIGS = {
                                         C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_uint32, C.c_uint64,
                                         C.POINTER(g2s_result), C.c_char_p]),
     "g2s_test_graph_tables": (C.c_int, [_VP, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
+    "g2s_test_seg_expand": (C.c_int, [_VP, C.POINTER(g2s_params), C.POINTER(g2s_gap), C.c_uint32, C.POINTER(C.c_uint32),
+                                      C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_uint32, C.POINTER(C.c_uint32),
+                                      C.c_uint32, C.POINTER(C.c_uint64)]),
     "g2s_test_worker_pool": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
     "g2s_test_group_queue": (C.c_int, [C.c_int32, C.c_uint64, C.c_uint64, C.POINTER(C.c_int32)]),
     "g2s_graph_validate": (C.c_int64, [C.c_void_p, C.c_char_p, C.c_size_t]),
@@ -471,6 +474,24 @@ def test_post_closure(graph, params, gap, records, xp, c_count, lengths, reached
     _check(lib.g2s_test_post_closure(graph.h, C.byref(params), arr, n, flat, len(xp), xs, c_count, len(lengths), lens,
                                      reached_j, final_d, seed, skip, C.byref(res), buf))
     return FillResult(res, buf.raw)
+
+
+def test_seg_expand(graph, params, gap, segs, lengths, reached_j, n_records, n_xp):
+    """TEST HOOK binding: closure segments (8 words each) -> ([(node, cnt, meta, pred)], sorted xp)."""
+    lib = load_library()
+    arr, keep = _gap_array([gap])
+    flat = (C.c_uint32 * max(1, 8 * len(segs)))()
+    for i, rec in enumerate(segs):
+        for q in range(8):
+            flat[8 * i + q] = rec[q] & 0xFFFFFFFF
+    lens = (C.c_int32 * 2)(*(list(lengths) + [0, 0])[:2])
+    out = (C.c_uint32 * max(1, 4 * n_records))()
+    xs = (C.c_uint64 * max(1, n_xp))()
+    _check(lib.g2s_test_seg_expand(graph.h, C.byref(params), arr, len(segs), flat, len(lengths), lens, reached_j,
+                                   n_records, out, n_xp, xs))
+    recs = [(out[4 * i], out[4 * i + 1], out[4 * i + 2], out[4 * i + 3] - (1 << 32) if out[4 * i + 3] >> 31 else out[4 * i + 3])
+            for i in range(n_records)]
+    return recs, sorted(xs[i] for i in range(n_xp))
 
 
 def test_graph_tables(graph):

@@ -277,6 +277,14 @@ int g2s_test_post_closure(const g2s_graph* g, const g2s_params* p, const g2s_gap
                           int32_t n_lengths, const int32_t* lengths, int32_t reached_j, int32_t final_d, uint32_t seed,
                           uint64_t skip, g2s_result* res, char* buf);
 
+/* TEST HOOK: the host's expansion of a closure given as unitig segments (what the segment tier's
+ * kernel emits: 8 words per segment {node, depth | len << 16, count, ts | tt << 16, parents 0-1,
+ * parents 2-3, flags, 0}, children before parents) into the per-state records and side list of
+ * g2s_test_post_closure.  n_records / n_xp must be the exact output sizes. */
+int g2s_test_seg_expand(const g2s_graph* g, const g2s_params* p, const g2s_gap* gap, uint32_t n_segs,
+                        const uint32_t* segs, int32_t n_lengths, const int32_t* lengths, int32_t reached_j,
+                        uint32_t n_records, uint32_t* records, uint32_t n_xp, uint64_t* xp);
+
 /* TEST HOOK: copies of the tables the kernels walk: the successor table (2 * kmers * 4 words,
  * G2S_INVALID_NODE = none) and the unitig-start bitmap ((kmers + 63) / 64 words; bit i set = the
  * edge 2(i-1) -> 2i is not unitig-internal). */

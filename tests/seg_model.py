@@ -314,6 +314,21 @@ def fill_model(tb, gap, rs=None, stats=None):
                         res.xp.append(((base[sid] + tmax) << 32) | base[p])
             res.records.append((node, min(cnt, MAX_PATHS), depth | (f << META_FLAG_SHIFT), pred))
     assert len(res.records) == n_rec
+    # the same closure as the kernel emits it: one 8-word record per segment with closure states,
+    # children before parents (descending segment id), parents as indices among the emitted segments
+    emitted = [sid for sid in range(ns - 1, -1, -1) if max(t_s[sid], t_t[sid]) >= 0]
+    index = {sid: i for i, sid in enumerate(emitted)}
+    res.compact = []
+    for sid in emitted:
+        v0, d0, cnt, length, parents, _ = segs[sid]
+        src = is_source(v0, d0)
+        ps = [0xFFFF] * 4
+        if not src and d0 > 0:
+            for q, pp in enumerate(sorted(set(parents))):
+                ps[q] = index[pp]
+        res.compact.append((v0, d0 | ((max(t_s[sid], t_t[sid]) + 1) << 16), min(cnt, MAX_PATHS),
+                            (t_s[sid] & 0xFFFF) | ((t_t[sid] & 0xFFFF) << 16), ps[0] | (ps[1] << 16), ps[2] | (ps[3] << 16),
+                            SUB_SOURCE if src else 0, 0))
     if stats is not None:
         stats.append((rounds, len(segs), n_gen))
     return res

@@ -96,14 +96,17 @@ def _check_batch(product, oracle, seqs, k, gaps, e, skip=False, allp=True, seed=
     return compared, filled, tm, xb, sb
 
 
-@pytest.fixture(params=["lds", "hbm"])
+@pytest.fixture(params=["seg", "lds", "hbm"])
 def tier(request, monkeypatch):
-    """Both kernel tiers: the LDS-resident fast tier (default) and the general tier
-    with per-gap tables in HBM (what gaps fall back to when they outgrow the LDS)."""
+    """All three kernel tiers: the segment tier (default: the search over unitig segments),
+    the LDS tier (level by level, what a gap takes when it outgrows the segment tier's
+    capacities) and the general tier with per-gap tables in HBM (the last resort)."""
+    monkeypatch.delenv("G2S_NO_LDS_TIER", raising=False)
+    monkeypatch.delenv("G2S_NO_SEG_TIER", raising=False)
     if request.param == "hbm":
         monkeypatch.setenv("G2S_NO_LDS_TIER", "1")
-    else:
-        monkeypatch.delenv("G2S_NO_LDS_TIER", raising=False)
+    elif request.param == "lds":
+        monkeypatch.setenv("G2S_NO_SEG_TIER", "1")
     return request.param
 
 
@@ -334,7 +337,7 @@ def test_bench_workload_c2_vs_oracle(product, oracle):
     c, f, tm, xb, sb = _check_batch(product, oracle, seqs, 31, gaps, 500, seed=1)
     assert (c, f) == (500, 500)
     assert (tm.xB, tm.sB) == (xb, sb)
-    assert tm.lds_tier_gaps == 500 and tm.retried_gaps == 0
+    assert tm.seg_tier_gaps == 500 and tm.lds_tier_gaps == 0 and tm.retried_gaps == 0
     og = oracle.OracleGraph(seqs, 31, 1)
     pg = product.Graph.from_seqs(seqs, 31, 1)
     ofa, olog, sm = oracle.execute_scaffolds(og, scaf, 31, solid=1, d_err=500, max_fuz=10, randseed=1)
@@ -347,12 +350,16 @@ def test_bench_workload_c2_vs_oracle(product, oracle):
     pg.free()
 
 
-def test_c3_gap_list_on_the_branching_genome_vs_oracle(product, oracle):
+@pytest.mark.parametrize("which", ["seg", "lds"])
+def test_c3_gap_list_on_the_branching_genome_vs_oracle(product, oracle, which, monkeypatch):
     """BASELINE config 3's list length (10 000 gaps, 3 Mbp, k=31, -fuz 10, -dist-error 500) on
-    the V3 genome (repeats + bubbles), gap by gap against the oracle.  At this list length the
-    LDS share per gap is at its smallest: right sets spill to the launch's pool in HBM, and the
-    few repeat-rich gaps whose state log outgrows its slice move to the log pool; both must
-    have happened here, and nothing may need a second launch."""
+    the V3 genome (repeats + bubbles), gap by gap against the oracle.  Segment tier: every gap
+    of this list fits its capacities (one launch, nothing left for the other tiers).  LDS tier
+    alone (G2S_NO_SEG_TIER): at this list length the LDS share per gap is at its smallest,
+    right sets spill to the launch's pool in HBM and the few repeat-rich gaps whose state log
+    outgrows its slice move to the log pool; both must have happened, in a single launch."""
+    if which == "lds":
+        monkeypatch.setenv("G2S_NO_SEG_TIER", "1")
     reads = product.G2S.synth_genome(3000000, 3, 20240101)
     scaff = product.G2S.synth_gaps(reads, 31, 10, 10000, 200, 1000, 20240103)
     seqs = [ln for ln in reads.splitlines() if not ln.startswith(">")]
@@ -360,8 +367,12 @@ def test_c3_gap_list_on_the_branching_genome_vs_oracle(product, oracle):
     assert len(gaps) == 10000
     c, f, tm, _, _ = _check_batch(product, oracle, seqs, 31, gaps, 500, seed=1)
     assert c > 9900 and f > 9900
-    assert tm.lds_tier_gaps == 10000 and tm.lds_launches == 1
-    assert tm.rs_pool_gaps > 0 and tm.log_pool_gaps > 0
+    if which == "seg":
+        assert tm.seg_tier_gaps == 10000 and tm.seg_launches == 1 and tm.lds_launches == 0
+        assert 200000 < tm.seg_segments < 300000  # ~25 segments per gap for ~1000 DP states
+    else:
+        assert tm.lds_tier_gaps == 10000 and tm.lds_launches == 1
+        assert tm.rs_pool_gaps > 0 and tm.log_pool_gaps > 0
 
 
 def test_multi_rank_bench_path(product, tmp_path):
@@ -386,7 +397,7 @@ def test_multi_rank_bench_path(product, tmp_path):
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["value"] > 0
     assert out["equals_one_gpu_result"] is True and out["one_gpu_same_list"]["value"] > 0
     assert out["config"]["gaps"] == 600 and out["config"]["group"] == 300
-    assert out["cpu_baseline"] is None and out["roofline"]["kernel"] == "g2s_fill_lds"
+    assert out["cpu_baseline"] is None and out["roofline"]["kernel"] == "g2s_fill_seg"
     assert out["roofline"]["launches_per_step"] == 2.0
 
 
@@ -429,7 +440,7 @@ def test_team_of_sessions_equals_one_session(product, oracle, nsess, group):
         want = [_result_tuple(r) for r in single.fill_batch(gaps)]
         got, tm = product.team_fill(team, gaps, group_size=group, want_timing=True)
         assert [_result_tuple(r) for r in got] == want
-        assert tm.lds_launches >= (300 + group - 1) // group
+        assert tm.seg_launches >= (300 + group - 1) // group
         # and a second list on the same team continues the lead's rand() stream like the single session
         want2 = [_result_tuple(r) for r in single.fill_batch(gaps[:120])]
         got2 = product.team_fill(team, gaps[:120], group_size=group)

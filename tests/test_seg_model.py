@@ -16,6 +16,16 @@ def _model_gap(pg, k, g, e, allp=True, skip=False):
     return M.Gap(g["gap_len"], e, lmf, rmf, lseeds, rseeds, targets, all_paths=allp, skip_confident=skip)
 
 
+def _parent_sets(records, xp):
+    extra = {}
+    for x in xp:
+        extra.setdefault(x >> 32, set()).add(x & 0xFFFFFFFF)
+    out = []
+    for i, (_, _, _, pred) in enumerate(records):
+        out.append(set() if pred < 0 else ({pred & M.SUB_MORE - 1} | extra.get(i, set())))
+    return out
+
+
 def check_config(product, oracle, seqs, k, gaps, e, allp=True, skip=False, seed=5, stats=None):
     pg = product.Graph.from_seqs(seqs, k, 1)
     og = oracle.OracleGraph(seqs, k, 1)
@@ -41,8 +51,15 @@ def check_config(product, oracle, seqs, k, gaps, e, allp=True, skip=False, seed=
             assert m.c_count == o.info.phaseC_count and m.lengths == o.lengths, what
             if o.phase_d:
                 assert m.reached_j == o.info.reached_fuz and m.final_d == o.info.final_d, what
-                r = product.test_post_closure(pg, params, product.Gap(g["left"], g["right"], g["gap_len"], g["lmf"], g["rmf"]),
-                                              m.records, m.xp, m.c_count, m.lengths, m.reached_j, m.final_d, seed, 0)
+                pgap = product.Gap(g["left"], g["right"], g["gap_len"], g["lmf"], g["rmf"])
+                # the host's expansion of the closure segments = the model's per-state records (the side
+                # list as a set per state: the kernel lists a state's parents in arrival order)
+                recs, xps = product.test_seg_expand(pg, params, pgap, m.compact, m.lengths, m.reached_j, len(m.records),
+                                                    len(m.xp))
+                assert [x[:3] for x in recs] == [x[:3] for x in m.records], what
+                assert _parent_sets(recs, xps) == _parent_sets(m.records, sorted(m.xp)), what
+                r = product.test_post_closure(pg, params, pgap, recs, xps, m.c_count, m.lengths, m.reached_j, m.final_d,
+                                              seed, 0)
                 assert r.count == o.count, what
                 assert (r.left_fuz, r.right_fuz, r.draws) == (o.left_fuz, o.right_fuz, o.info.draws), what
                 assert r.fill == o.fill, what
