@@ -124,79 +124,129 @@ __global__ __launch_bounds__(64) void g2s_fill_seg(const uint32_t* __restrict__ 
   if (lane < 32) l_seed[lane] = lane <= lmf ? lseeds[lane] : G2S_DEV_INVALID;
 
   // ---------------- phase A: the right set as (entry node, depth label) pairs ----------------
-  // lane l of set s holds entry 64 s + l: node, label = fewest predecessor steps from a right
-  // seed (seed j enters at depth j), and the unitig-internal steps left when walking back from it.
-  uint32_t an[G2S_SEG_ASETS], al[G2S_SEG_ASETS], ar[G2S_SEG_ASETS];
-  uint64_t aq[G2S_SEG_ASETS];  // entries to be (re)expanded
-#pragma unroll
-  for (int s = 0; s < G2S_SEG_ASETS; s++) { an[s] = G2S_DEV_INVALID; al[s] = 0; ar[s] = 0; aq[s] = 0; }
+  // Label-correcting search over unitigs (:871-982 computes {v : fewest predecessor steps from a
+  // right seed <= right_half}, seed j entering at depth j; only membership is consumed, :1050).
+  // An entry (node, label) covers its unitig backwards for min(rem, right_half - label) steps;
+  // where the unitig ends with budget left, the predecessors of its last node are proposed with
+  // label + steps + 1.  All entries of a round are expanded at once (lane = entry): one load of
+  // rem[], one successor record, and the proposals of the whole wave go through one LDS table
+  // keyed by node with 64-bit atomic min on (node << 32 | label) — a per-proposal compare against
+  // register-resident entries costs ~1.5 k cycles of scalar/vector ping-pong each (measured).
+  // LDS (aliasing the segment arrays, which phase B fills later):
+  //   lab[ALAB] u64 | labrem[ALAB] u32 | q[2][ACAP] u32
+  const uint32_t ACAP = 64u * G2S_SEG_ASETS, ALAB = 2u * ACAP;
+  uint64_t* lab = (uint64_t*)lds;
+  uint32_t* labrem = (uint32_t*)(lab + ALAB);
+  uint32_t* aq0 = labrem + ALAB;
   uint32_t nA = 0, roundsA = 0;
-  // propose label dp for entry node p (both wave-uniform)
-  auto propose = [&](uint32_t p, uint32_t dp) {
-    bool found = false;
-#pragma unroll
-    for (int s = 0; s < G2S_SEG_ASETS; s++) {
-      if ((uint32_t)s * 64u < nA) {
-        const uint64_t m = __ballot(an[s] == p);
-        if (m) {
-          const int l = __builtin_ctzll(m);
-          if (dp < rl(al[s], l)) {
-            if (lane == l) al[s] = dp;
-            aq[s] |= 1ull << l;
-          }
-          found = true;
+  for (uint32_t i = (uint32_t)lane; i < ALAB; i += 64u) lab[i] = G2S_DEV_EMPTY64;
+  lds_sync();
+  auto a_hash = [&](uint32_t p) -> uint32_t { uint32_t x = p; x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x & (ALAB - 1u); };
+  // propose label dp for node p (per lane); true when the label improved (the caller queues p)
+  auto relabel = [&](bool active, uint32_t p, uint32_t dp) -> bool {
+    bool improved = false, fresh = false;
+    if (active) {
+      const uint64_t key = ((uint64_t)p << 32) | dp;
+      uint32_t h = a_hash(p);
+      while (true) {
+        const uint64_t c = lab[h];
+        if ((uint32_t)(c >> 32) == p) {
+          improved = atomicMin((unsigned long long*)&lab[h], (unsigned long long)key) > key;
+          break;
         }
+        if (c == G2S_DEV_EMPTY64) {
+          const unsigned long long prev =
+              atomicCAS((unsigned long long*)&lab[h], (unsigned long long)G2S_DEV_EMPTY64, (unsigned long long)key);
+          if (prev == G2S_DEV_EMPTY64) { improved = true; fresh = true; break; }
+          continue;  // somebody took the slot: look at it again
+        }
+        h = (h + 1u) & (ALAB - 1u);
       }
     }
-    if (found) return;
-    if (nA >= 64u * G2S_SEG_ASETS) { overflow = true; flags |= G2S_DEV_OVERFLOW_A | G2S_DEV_WHY_RS; return; }
-    const uint32_t sA = nA >> 6;
-    const int lA = (int)(nA & 63u);
-#pragma unroll
-    for (int s = 0; s < G2S_SEG_ASETS; s++) {
-      if (sA == (uint32_t)s) {
-        if (lane == lA) { an[s] = p; al[s] = dp; ar[s] = G2S_DEV_INVALID; }  // (steps left: loaded for all new entries at once)
-        aq[s] |= 1ull << lA;
-      }
-    }
-    nA++;
+    nA += (uint32_t)__popcll(__ballot(fresh));
+    return improved;
   };
   if (!overflow) {
-    for (int j = 0; j <= rmf && j <= gd.right_half; j++) {  // right.substr(len-k-j, k) enters at depth j (:878-884, :953-976)
-      const uint32_t sd = uni(rseeds[j]);
-      if (sd != G2S_DEV_INVALID) propose(sd, (uint32_t)j);
+    uint32_t cur = 0, ne = 0;
+    {  // seeds: right.substr(len-k-j, k) enters at depth j (:878-884, :953-976)
+      const uint32_t sd = (lane <= rmf && lane < 32) ? rseeds[lane] : G2S_DEV_INVALID;
+      const bool imp = relabel(sd != G2S_DEV_INVALID && lane <= gd.right_half, sd, (uint32_t)lane);
+      const uint64_t m = __ballot(imp);
+      if (imp) aq0[(uint32_t)__popcll(m & below(lane))] = sd;
+      ne = (uint32_t)__popcll(m);
+      lds_sync();
     }
-    while (!overflow) {
-      uint64_t any = 0;
-#pragma unroll
-      for (int s = 0; s < G2S_SEG_ASETS; s++) any |= aq[s];
-      if (!any) break;
+    while (ne > 0 && !overflow) {
       roundsA++;
-#pragma unroll
-      for (int s = 0; s < G2S_SEG_ASETS; s++) {
-        const uint64_t q = aq[s];
-        if (!q) continue;
-        aq[s] = 0;
-        const bool mine = (q >> lane) & 1ull;
-        if (mine && ar[s] == G2S_DEV_INVALID) ar[s] = rem[an[s] ^ 1u];  // one round trip for all new entries of the set
-        const uint32_t d = al[s];
-        const uint32_t steps = min(ar[s], (uint32_t)gd.right_half - d);
-        const uint32_t last = seg_node(an[s] ^ 1u, steps) ^ 1u;  // walking back from v = walking on from v^1
+      uint32_t* qc = aq0 + cur * ACAP;
+      uint32_t* qn = aq0 + (cur ^ 1u) * ACAP;
+      uint32_t nn = 0;
+      for (uint32_t e0 = 0; e0 < ne && !overflow; e0 += 64u) {
+        const bool mine = e0 + (uint32_t)lane < ne;
+        const uint32_t v = mine ? qc[e0 + (uint32_t)lane] : 0u;
+        uint32_t d = 0, slot = 0;
+        if (mine) {  // the entry's current label
+          slot = a_hash(v);
+          while ((uint32_t)(lab[slot] >> 32) != v) slot = (slot + 1u) & (ALAB - 1u);
+          d = (uint32_t)lab[slot];
+        }
+        const uint32_t r = mine ? rem[v ^ 1u] : 0u;  // walking back from v = walking on from v^1
+        if (mine) labrem[slot] = r;
+        const uint32_t steps = min(r, (uint32_t)gd.right_half - d);
+        const uint32_t last = seg_node(v ^ 1u, steps) ^ 1u;
         const bool live = mine && d + steps < (uint32_t)gd.right_half;
         uint4 rec = make_uint4(G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID);
         if (live) rec = *(const uint4*)(succ + (size_t)(last ^ 1u) * 4);  // graph.predecessors(last)[i] = succ(last^1)[i] ^ 1
         const uint32_t dchild = d + steps + 1u;
-        for (uint64_t m = __ballot(live); m && !overflow; m &= m - 1) {
-          const int l = __builtin_ctzll(m);
-          const uint32_t dl = rl(dchild, l);
-#pragma unroll 1
-          for (int q = 0; q < 4; q++) {
-            const uint32_t w = rl(q == 0 ? rec.x : q == 1 ? rec.y : q == 2 ? rec.z : rec.w, l);
-            if (w != G2S_DEV_INVALID) propose(w ^ 1u, dl);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const uint32_t w = q == 0 ? rec.x : q == 1 ? rec.y : q == 2 ? rec.z : rec.w;
+          const bool imp = relabel(w != G2S_DEV_INVALID && !overflow, w ^ 1u, dchild);
+          const uint64_t m = __ballot(imp);
+          if (imp) {
+            const uint32_t at = nn + (uint32_t)__popcll(m & below(lane));
+            if (at < ACAP) qn[at] = w ^ 1u;
           }
+          nn += (uint32_t)__popcll(m);
+          // (the table has 2 ACAP slots: at most ACAP + 64 are ever taken, so every probe ends)
+          if (nn > ACAP || nA > ACAP) { overflow = true; flags |= G2S_DEV_OVERFLOW_A | G2S_DEV_WHY_RS; }
         }
       }
+      lds_sync();
+      cur ^= 1u;
+      ne = nn;
     }
+  }
+  // the table's entries into registers: lane l of set s holds entry 64 s + l
+  uint32_t an[G2S_SEG_ASETS], al[G2S_SEG_ASETS], ar[G2S_SEG_ASETS];
+#pragma unroll
+  for (int s = 0; s < G2S_SEG_ASETS; s++) { an[s] = G2S_DEV_INVALID; al[s] = 0; ar[s] = 0; }
+  if (!overflow) {
+    uint32_t* cnode = aq0;                 // compact list (the queues are idle now)
+    uint32_t* clab = aq0 + ACAP;
+    uint32_t* crem = (uint32_t*)lab;       // written only after the whole table was read: see the two loops
+    uint32_t got = 0;
+    uint32_t keep_n[ALAB / 64u], keep_l[ALAB / 64u], keep_r[ALAB / 64u], keep_at[ALAB / 64u];
+#pragma unroll
+    for (uint32_t c = 0; c < ALAB / 64u; c++) {
+      const uint64_t e = lab[c * 64u + (uint32_t)lane];
+      const bool have = e != G2S_DEV_EMPTY64;
+      const uint64_t m = __ballot(have);
+      keep_n[c] = (uint32_t)(e >> 32); keep_l[c] = (uint32_t)e; keep_r[c] = labrem[c * 64u + (uint32_t)lane];
+      keep_at[c] = have ? got + (uint32_t)__popcll(m & below(lane)) : G2S_DEV_INVALID;
+      got += (uint32_t)__popcll(m);
+    }
+    lds_sync();
+#pragma unroll
+    for (uint32_t c = 0; c < ALAB / 64u; c++)
+      if (keep_at[c] != G2S_DEV_INVALID) { cnode[keep_at[c]] = keep_n[c]; clab[keep_at[c]] = keep_l[c]; crem[keep_at[c]] = keep_r[c]; }
+    lds_sync();
+#pragma unroll
+    for (int s = 0; s < G2S_SEG_ASETS; s++) {
+      const uint32_t e = (uint32_t)s * 64u + (uint32_t)lane;
+      if (e < nA) { an[s] = cnode[e]; al[s] = clab[e]; ar[s] = crem[e]; }
+    }
+    lds_sync();
   }
   // the entries as k-mer index intervals [alo, ahi]; lanes without an entry hold an empty interval
   uint32_t alo[G2S_SEG_ASETS], ahi[G2S_SEG_ASETS];

@@ -1098,6 +1098,8 @@ int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
       if (i >= n || analyzed[i]) continue;
       const GapOut& go = outs[i];
       if (go.flags & (G2S_DEV_OVERFLOW_A | G2S_DEV_OVERFLOW_B)) continue;  // runs again in a later pass
+      if ((go.flags & G2S_DEV_COMPACT) && ((uint64_t)go.n_states > max_states || (uint64_t)go.n_right > max_states))
+        mem_exceeded[i] = 1;  // segment tier: the -max-mem analogue is applied to the state count
       SubView& v = views[i];
       v.out = &go;
       if (go.flags & G2S_DEV_COMPACT) {
@@ -1168,6 +1170,8 @@ int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
           continue;
         }
         seg_done[i] = 1;
+        // device-budget analogue of -max-mem: the states a gap may hold
+        if ((uint64_t)go.n_states > max_states || (uint64_t)go.n_right > max_states) { mem_exceeded[i] = 1; continue; }
         if (!analyzed[i]) {  // (gaps analysed while the kernel ran already have their view, expanded)
           SubView& v = views[i];
           v.out = &go;
