@@ -1014,7 +1014,12 @@ void analyze_gap(g2s_batch* b, size_t i, const FillParams& fp, g2s_result* r) {
   if (b->mem_exceeded[i]) { gi.kind = 2; r->count = -1; r->flags |= G2S_GAP_MEM_EXCEEDED; return; }
   SubView& v = b->views[i];
   SubPrep& pp = b->prep[i];
-  if (v.segs) {  // segment tier: expand the closure segments into per-state records first
+  bool analysed = false;
+  if (v.segs) {  // segment tier: the analysis runs on the closure segments themselves, O(segments) ...
+    analysed = seg_analyze(fp, j, v, &pp);
+    if (!analysed) pp = SubPrep();
+  }
+  if (v.segs && !analysed) {  // ... unless a k-mer occurs at two depths of the closure: per-state records then
     const GapOut& go = *v.out;
     const size_t need = (size_t)go.n_sub + ((size_t)go.n_xp + 1) / 2;
     SubRec* dst = nullptr;
@@ -1028,8 +1033,10 @@ void analyze_gap(g2s_batch* b, size_t i, const FillParams& fp, g2s_result* r) {
     v.st = dst; v.n = go.n_sub; v.xp = xp; v.n_xp = go.n_xp;
     v.segs = nullptr;
   }
-  if (v.n_xp > 1) std::sort(const_cast<uint64_t*>(v.xp), const_cast<uint64_t*>(v.xp) + v.n_xp);  // by state (the kernel appends per level)
-  sub_analyze(fp, j, v, &pp);
+  if (!analysed) {
+    if (v.n_xp > 1) std::sort(const_cast<uint64_t*>(v.xp), const_cast<uint64_t*>(v.xp) + v.n_xp);  // by state (the kernel appends per level)
+    sub_analyze(fp, j, v, &pp);
+  }
   r->phaseC_count = v.out->c_count;
   r->n_lengths = v.out->n_len;
   r->lengths[0] = v.out->len[0];
@@ -1047,8 +1054,9 @@ void analyze_gap(g2s_batch* b, size_t i, const FillParams& fp, g2s_result* r) {
     // One path length and no state with a second parent: every rand() % 1 of the traceback is
     // 0, so the fill does not depend on where the gap's draws start in the stream.  Write it
     // now (under the kernels); the in-order pass only adds up the draw count.
-    if (b->arena && v.out->n_len == 1 && v.n_xp == 0 && gi.fixed[0] >= 0) {
-      sub_traceback(*b->s->graph->g, fp, j, v, pp, nullptr, b->arena + b->arena_off[i], r);
+    if (b->arena && v.out->n_len == 1 && (pp.seg_mode ? !pp.has_choice : v.n_xp == 0) && gi.fixed[0] >= 0) {
+      if (pp.seg_mode) seg_traceback(*b->s->graph->g, fp, j, v, pp, nullptr, b->arena + b->arena_off[i], r);
+      else sub_traceback(*b->s->graph->g, fp, j, v, pp, nullptr, b->arena + b->arena_off[i], r);
       if (r->draws != gi.fixed[0]) r->flags |= G2S_GAP_BACKTRACE_FAIL;  // cannot happen: the draw count was proven fixed
       r->fill_off = (uint64_t)(b->arena_base + b->arena_off[i]) + (uint64_t)(j.lmf - r->left_fuz);
       r->fill_len = (int32_t)strlen(b->arena + b->arena_off[i] + (j.lmf - r->left_fuz));
@@ -1486,7 +1494,8 @@ int batches_stage2(const std::vector<g2s_batch*>& bs, g2s_session* lead, g2s_res
           g2s_result& r = results[gi];
           const SubView& v = b->views[i];
           grow_rands(draws_total + (size_t)v.out->len[pick] + 2);
-          sub_traceback(g, fp, b->jobs[i], v, b->prep[i], lead->rcache.ptr(draws_total), arena + arena_off[gi], &r);
+          if (b->prep[i].seg_mode) seg_traceback(g, fp, b->jobs[i], v, b->prep[i], lead->rcache.ptr(draws_total), arena + arena_off[gi], &r);
+          else sub_traceback(g, fp, b->jobs[i], v, b->prep[i], lead->rcache.ptr(draws_total), arena + arena_off[gi], &r);
           draws = r.draws;
           right_fuz = r.right_fuz;
         } else {
@@ -1496,7 +1505,8 @@ int batches_stage2(const std::vector<g2s_batch*>& bs, g2s_session* lead, g2s_res
           const auto tw0 = std::chrono::steady_clock::now();
           const SubView& v = b->views[i];
           grow_rands(draws_total + (size_t)v.out->len[pick] + 2);
-          draws = sub_count_draws(g, v, b->prep[i], lead->rcache.ptr(draws_total));
+          draws = b->prep[i].seg_mode ? seg_count_draws(g, v, b->prep[i], lead->rcache.ptr(draws_total))
+                                      : sub_count_draws(g, v, b->prep[i], lead->rcache.ptr(draws_total));
           ms_walks += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count();
           todo_tb[gi] = 1;
           right_fuz = in.reached_j;
@@ -1548,7 +1558,8 @@ int batches_stage2(const std::vector<g2s_batch*>& bs, g2s_session* lead, g2s_res
         if (todo_tb[gi]) {
           const g2s_batch* b = owner[gi];
           const size_t i = local[gi];
-          sub_traceback(g, fp, j, b->views[i], b->prep[i], lead->rcache.ptr(rand_off[gi]), arena + arena_off[gi], &r);
+          if (b->prep[i].seg_mode) seg_traceback(g, fp, j, b->views[i], b->prep[i], lead->rcache.ptr(rand_off[gi]), arena + arena_off[gi], &r);
+          else sub_traceback(g, fp, j, b->views[i], b->prep[i], lead->rcache.ptr(rand_off[gi]), arena + arena_off[gi], &r);
           // cannot happen: the draw count was proven fixed, or counted over the same draws
           if (r.draws != expect_draws[gi]) r.flags |= G2S_GAP_BACKTRACE_FAIL;
         }
@@ -1921,6 +1932,71 @@ extern "C" int g2s_test_post_closure(const g2s_graph* gh, const g2s_params* p, c
     std::vector<uint32_t> rands((size_t)D + 4);
     for (auto& x : rands) x = (uint32_t)rng.next() << 1;  // raw words: value = word >> 1
     sub_traceback(g, fp, j, v, prep, rands.data(), buf, res);
+    res->vertices = prep.sub[0]; res->edges = prep.sub[1]; res->nontrivial_components = prep.sub[2];
+    res->size_nontrivial_components = prep.sub[3]; res->vertices_final = prep.sub[4]; res->edges_final = prep.sub[5];
+    res->fill_off = (uint64_t)(j.lmf - res->left_fuz);
+    res->fill_len = (int32_t)strlen(buf + res->fill_off);
+  }
+  return G2S_OK;
+}
+
+extern "C" int g2s_test_post_segments(const g2s_graph* gh, const g2s_params* p, const g2s_gap* gap, uint32_t n_segs,
+                                      const uint32_t* segs, int32_t c_count, int32_t n_lengths, const int32_t* lengths,
+                                      int32_t reached_j, int32_t final_d, uint32_t seed, uint64_t skip, g2s_result* res,
+                                      char* buf, int32_t* on_segments) {
+  if (!gh || !p || !gap || !res || !buf || (n_segs && !segs)) return fail(G2S_ERR_ARG, "g2s_test_post_segments: bad argument");
+  const Graph& g = *gh->g;
+  const int k = g.k;
+  GapJob j;
+  j.g = gap->gap_len; j.lmf = gap->lmf; j.rmf = gap->rmf;
+  if (gap->left_len < k + j.lmf || gap->right_len < k + j.rmf) return fail(G2S_ERR_ARG, "flank too short");
+  j.left.assign(gap->left, (size_t)gap->left_len);
+  j.right.assign(gap->right, (size_t)gap->right_len);
+  for (int d = 0; d <= j.lmf; d++) j.flank_nodes.push_back(g.node_of(j.left.c_str() + d));
+  for (int d = 0; d <= j.rmf; d++) j.flank_nodes.push_back(g.node_of(j.right.c_str() + (j.right.size() - k - d)));
+  for (int d = 0; d <= j.rmf; d++) j.flank_nodes.push_back(g.node_of(j.right.c_str() + d));
+  GapOut go;
+  memset(&go, 0, sizeof go);
+  go.c_count = c_count; go.n_len = n_lengths; go.reached_j = reached_j; go.final_d = final_d;
+  for (int i = 0; i < n_lengths && i < 2; i++) go.len[i] = lengths[i];
+  FillParams fp;
+  fp.k = k; fp.d_err = p->d_err; fp.skip_confident = p->skip_confident != 0; fp.all_paths = p->all_paths != 0;
+  fp.unique_paths = p->unique_paths != 0;
+  SubView v;
+  v.out = &go; v.segs = (const SegRec*)segs; v.n_segs = n_segs;
+  SubPrep prep;
+  const bool ok = seg_analyze(fp, j, v, &prep);
+  if (on_segments) *on_segments = ok ? 1 : 0;
+  memset(res, 0, sizeof *res);
+  memset(buf, 0, j.buf_bytes(k, fp.d_err));
+  if (!ok) return G2S_OK;  // a k-mer at two depths: the caller takes g2s_test_seg_expand + g2s_test_post_closure
+  res->phaseC_count = c_count;
+  res->n_lengths = n_lengths;
+  for (int i = 0; i < n_lengths && i < 2; i++) res->lengths[i] = lengths[i];
+  res->count = prep.count;
+  res->flags |= prep.flags;
+  res->fill_off = (uint64_t)j.lmf;
+  if (prep.phase_d) {
+    GlibcRand rng;
+    rng.seed(seed);
+    for (uint64_t i = 0; i < skip; i++) rng.next();
+    const int D = j.lmf + j.rmf + j.g + p->d_err;
+    std::vector<uint32_t> rands((size_t)D + 4);
+    for (auto& x : rands) x = (uint32_t)rng.next() << 1;
+    const int pick = (int)((rands[0] >> 1) % (uint32_t)go.n_len);
+    const int fixed = sub_fixed_draws(v, prep, pick);
+    seg_traceback(g, fp, j, v, prep, rands.data(), buf, res);
+    if (fixed >= 0 && fixed != res->draws) return fail(G2S_ERR_STATE, "stop-depth analysis disagrees with the traceback (segments)");
+    if (seg_count_draws(g, v, prep, rands.data()) != res->draws)
+      return fail(G2S_ERR_STATE, "draw-count walk disagrees with the traceback (segments)");
+    if (go.n_len == 1 && !prep.has_choice && fixed >= 0) {
+      std::vector<char> buf2(j.buf_bytes(k, fp.d_err), 0);
+      g2s_result r2;
+      memset(&r2, 0, sizeof r2);
+      seg_traceback(g, fp, j, v, prep, nullptr, buf2.data(), &r2);
+      if (r2.draws != res->draws || r2.left_fuz != res->left_fuz || memcmp(buf2.data(), buf, buf2.size()) != 0)
+        return fail(G2S_ERR_STATE, "rand()-free traceback disagrees with the traceback (segments)");
+    }
     res->vertices = prep.sub[0]; res->edges = prep.sub[1]; res->nontrivial_components = prep.sub[2];
     res->size_nontrivial_components = prep.sub[3]; res->vertices_final = prep.sub[4]; res->edges_final = prep.sub[5];
     res->fill_off = (uint64_t)(j.lmf - res->left_fuz);

@@ -515,3 +515,263 @@ void host_closure(const Graph& g, const FillParams& p, const GapJob& job, const 
 }
 
 }  // namespace g2s
+
+// ---------------------------------------------------------------------------
+// Phase D2/D3 on closure segments (segment tier).
+// ---------------------------------------------------------------------------
+namespace g2s {
+
+namespace {
+
+inline int seg_find(uint32_t v0, int len, uint32_t node) {  // t with state t == node, else -1
+  if (node == kInvalidNode || ((node ^ v0) & 1u)) return -1;
+  const int dt = (int)(node - v0) >> 1;
+  const int t = (v0 & 1u) ? -dt : dt;
+  return (t >= 0 && t < len) ? t : -1;
+}
+inline uint32_t seg_state(const SegRec& s, int t) { return (s.node & 1u) ? s.node - 2u * (uint32_t)t : s.node + 2u * (uint32_t)t; }
+inline int seg_parents(const SegRec& s, uint32_t out[4]) {
+  if (s.flags & G2S_SUB_SOURCE) return 0;
+  int n = 0;
+  const uint32_t ps[4] = {s.par01 & 0xFFFFu, s.par01 >> 16, s.par23 & 0xFFFFu, s.par23 >> 16};
+  for (int q = 0; q < 4; q++) if (ps[q] != 0xFFFFu) out[n++] = ps[q];
+  return n;
+}
+
+// safe bit of state t of segment i (:1466; k-mers outside the subgraph read branch[sink], Q5)
+inline bool seg_safe(const SubView& v, const SubPrep& prep, uint32_t i, int t) {
+  const SegRec& s = v.segs[i];
+  const int ts = (int)(int16_t)(s.ts_tt & 0xFFFFu);
+  const SegInfo& in = prep.seg[i];
+  if (t <= ts) return t <= in.split ? in.safe_a : in.safe_b;
+  // a traceback state outside the subgraph: its k-mer may be in the subgraph at another depth
+  const uint32_t x = seg_state(s, t) >> 1;
+  const auto& iv = prep.s_iv;
+  size_t lo = 0, hi = iv.size();
+  while (lo < hi) { const size_t mid = (lo + hi) >> 1; if (iv[mid].first <= x) lo = mid + 1; else hi = mid; }
+  if (lo > 0) {
+    const uint32_t q = iv[lo - 1].second;
+    const SegRec& o = v.segs[q];
+    const int ots = (int)(int16_t)(o.ts_tt & 0xFFFFu);
+    const uint32_t oidx = o.node >> 1;
+    const int tq = (o.node & 1u) ? (int)oidx - (int)x : (int)x - (int)oidx;
+    if (tq >= 0 && tq <= ots) return tq <= prep.seg[q].split ? prep.seg[q].safe_a : prep.seg[q].safe_b;
+  }
+  return prep.sink_safe;
+}
+
+}  // namespace
+
+bool seg_analyze(const FillParams& p, const GapJob& job, const SubView& v, SubPrep* out) {
+  const GapOut& go = *v.out;
+  out->count = go.c_count;
+  out->phase_d = go.c_count > 0 && go.n_len > 0;  // :1169
+  out->seg_mode = true;
+  if (!out->phase_d) return true;
+  const uint32_t n = v.n_segs;
+  const SegRec* sg = v.segs;
+  const int lmf = job.lmf, rmf = job.rmf;
+  const uint32_t* targets = job.targets();
+  const bool want_s = !p.skip_confident;
+  const uint32_t sinknode = (want_s && p.all_paths && rmf >= 1) ? targets[rmf - 1] : kInvalidNode;  // Q3/Q4
+  const int lo_sink = std::max(0, lmf + job.g - p.d_err);
+  const uint32_t reached = targets[go.reached_j];
+  const bool t_is_s = want_s && !p.all_paths;  // -best-only: the traceback starts are the sinks
+  std::vector<SegInfo>& si = out->seg;
+  si.assign(n, SegInfo{-2, -2, 0, 0, 0, 0});
+  static thread_local std::vector<int> sinkpos, outs;
+  sinkpos.assign(n, -1);
+  // ---- own positions: sinks and traceback starts
+  for (uint32_t i = 0; i < n; i++) {
+    const SegRec& s = sg[i];
+    const int d0 = (int)(s.depth_len & 0xFFFFu), len = (int)(s.depth_len >> 16);
+    uint32_t ps[4];
+    si[i].npar = (uint8_t)seg_parents(s, ps);
+    const int pk = seg_find(s.node, len, sinknode);
+    if (pk >= 0 && d0 + pk >= lo_sink) sinkpos[i] = pk;
+    const int pt = seg_find(s.node, len, reached);
+    if (pt >= 0) {
+      for (int j = 0; j < go.n_len && j < 2; j++)
+        if (d0 + pt == go.len[j]) {
+          if (out->start_seg[j] < 0) { out->start_seg[j] = (int)i; out->start_t[j] = pt; }
+          if (t_is_s) sinkpos[i] = pt;
+        }
+    }
+  }
+  // ---- stop depths of the traceback closure, parents first (= descending index)
+  for (int64_t i = (int64_t)n - 1; i >= 0; i--) {
+    const SegRec& s = sg[i];
+    const int tt = (int)(int16_t)(s.ts_tt >> 16);
+    if (tt < 0) continue;
+    const int d0 = (int)(s.depth_len & 0xFFFFu);
+    if (s.flags & G2S_SUB_SOURCE) { si[i].lo = si[i].hi = d0; continue; }  // :1455-1462
+    uint32_t ps[4];
+    const int np = seg_parents(s, ps);
+    if (np == 0) { si[i].lo = -1; si[i].hi = 1 << 30; continue; }
+    if (np > 1) out->has_choice = true;
+    int l = 1 << 30, h = -1;
+    for (int x = 0; x < np; x++) {
+      const SegInfo& q = si[ps[x]];
+      if (q.lo < 0) { l = -1; h = 1 << 30; } else { l = std::min(l, q.lo); h = std::max(h, q.hi); }
+    }
+    si[i].lo = l; si[i].hi = h;
+  }
+  for (int j = 0; j < go.n_len && j < 2; j++) {
+    const int i = out->start_seg[j];
+    out->stop_depth[j] = (i >= 0 && si[(size_t)i].lo >= 0 && si[(size_t)i].lo == si[(size_t)i].hi) ? si[(size_t)i].lo : -1;
+  }
+  if (!want_s) return true;  // no D1/D2 with -all-upper (:1181)
+
+  // ---- the S closure: every k-mer at one depth only?  (index intervals must not overlap)
+  auto& iv = out->s_iv;
+  iv.clear();
+  uint64_t n_s = 0, edges = 0;
+  int count_s = 0, src_out = 0, sink_in = 0;
+  outs.assign(n, 0);
+  static thread_local std::vector<std::pair<uint32_t, uint32_t>> hi_of;
+  hi_of.clear();
+  for (uint32_t i = 0; i < n; i++) {
+    const SegRec& s = sg[i];
+    const int ts = (int)(int16_t)(s.ts_tt & 0xFFFFu);
+    if (ts < 0) continue;
+    const uint32_t idx = s.node >> 1;
+    const uint32_t lo = (s.node & 1u) ? idx - (uint32_t)ts : idx;
+    iv.emplace_back(lo, i);
+    n_s += (uint64_t)ts + 1;
+    edges += (uint64_t)ts;  // interior edges
+    if (s.flags & G2S_SUB_SOURCE) { src_out++; edges++; }
+    else {
+      uint32_t ps[4];
+      const int np = seg_parents(s, ps);
+      edges += (uint64_t)np;
+      for (int x = 0; x < np; x++) outs[ps[x]]++;
+    }
+    if (sinkpos[i] >= 0 && sinkpos[i] <= ts) { sink_in++; edges++; count_s = sat_add(count_s, (int)s.cnt); }
+  }
+  std::sort(iv.begin(), iv.end());
+  for (size_t x = 1; x < iv.size(); x++) {
+    const SegRec& a = sg[iv[x - 1].second];
+    const uint32_t a_hi = iv[x - 1].first + (uint32_t)(int)(int16_t)(a.ts_tt & 0xFFFFu);
+    if (iv[x].first <= a_hi) { out->seg_mode = false; return false; }  // a k-mer at two depths: general path
+  }
+  if (p.all_paths) out->count = count_s;
+  out->sub[0] = n_s + 2; out->sub[1] = edges; out->sub[2] = 0; out->sub[3] = 0; out->sub[4] = n_s + 2; out->sub[5] = edges;
+  // ---- branch rule (:1411-1434) over a topological order: parents first, a segment's states in order.
+  // Interior states have one edge in and one out, so the running count only moves at a segment's
+  // entry (in-degree), at a sink inside it, and at its last S state (out-degree).
+  int bc = 1;
+  if (src_out > 1) bc += src_out - 1;  // the source pseudo-vertex comes first
+  for (int64_t i = (int64_t)n - 1; i >= 0; i--) {
+    const SegRec& s = sg[i];
+    const int ts = (int)(int16_t)(s.ts_tt & 0xFFFFu);
+    if (ts < 0) continue;
+    const int len = (int)(s.depth_len >> 16);
+    const int din = (s.flags & G2S_SUB_SOURCE) ? 1 : (int)si[i].npar;
+    if (din > 1) bc -= din - 1;
+    si[i].safe_a = bc == 1;
+    si[i].split = (int16_t)ts;
+    si[i].safe_b = si[i].safe_a;
+    const int sp = (sinkpos[i] >= 0 && sinkpos[i] <= ts) ? sinkpos[i] : -1;
+    if (sp >= 0 && sp < ts) { bc += 1; si[i].split = (int16_t)sp; si[i].safe_b = bc == 1; }  // out-degree 2: next state + sink
+    const int dout = (ts == len - 1 ? outs[(size_t)i] : 0) + (sp == ts ? 1 : 0);
+    if (dout > 1) bc += dout - 1;
+  }
+  out->sink_safe = false;
+  if (sink_in >= 1) { if (sink_in > 1) bc -= sink_in - 1; out->sink_safe = bc == 1; }
+  return true;
+}
+
+void seg_traceback(const Graph& g, const FillParams& p, const GapJob& job, const SubView& v, const SubPrep& prep,
+                   const uint32_t* rands, char* buf, g2s_result* res) {
+  const GapOut& go = *v.out;
+  const int lmf = job.lmf, k = p.k;
+  res->right_fuz = go.reached_j;  // :1171
+  res->flags |= G2S_GAP_PHASE_D;
+  int draws = 0;
+  auto draw = [&]() -> uint32_t { const uint32_t r = rands ? rands[draws] : 0u; draws++; return r; };
+  const int pick = (int)((draw() >> 1) % (uint32_t)go.n_len);  // :1440
+  int d2 = go.len[pick];
+  int last_solid = d2;
+  int i = prep.start_seg[pick], t = prep.start_t[pick];
+  buf[d2] = '\0';
+  res->count = prep.count;
+  while (d2 >= 0 && i >= 0) {
+    const SegRec& s = v.segs[i];
+    if (t == 0 && (s.flags & G2S_SUB_SOURCE)) {  // :1455-1462
+      res->left_fuz = lmf - d2;
+      break;
+    }
+    if (d2 > 0) {
+      if (p.skip_confident || seg_safe(v, prep, (uint32_t)i, t)) last_solid = d2;  // :1466-1468
+      const char c = g.last_char(seg_state(s, t));
+      buf[d2 - 1] = (d2 > last_solid - k) ? (char)toupper((unsigned char)c) : (char)tolower((unsigned char)c);
+      if (t > 0) {
+        (void)draw();  // one choice, still drawn (:1513)
+        t--;
+      } else {
+        uint32_t back[4];
+        const int nb = seg_parents(s, back);
+        if (nb > 1) {  // GATB predecessor order: predecessors(v)[slot] is the parent p whose p^1 ends with base `slot`
+          int64_t by_slot[4] = {-1, -1, -1, -1};
+          for (int x = 0; x < nb; x++) {
+            const SegRec& q = v.segs[back[x]];
+            by_slot[g.lastnt[seg_state(q, (int)(q.depth_len >> 16) - 1) ^ 1u]] = (int64_t)back[x];
+          }
+          int w = 0;
+          for (int nt = 0; nt < 4; nt++) if (by_slot[nt] >= 0) back[w++] = (uint32_t)by_slot[nt];
+        }
+        if (nb == 0) {  // :1493-1510
+          snprintf(res->backtrace_msg, sizeof res->backtrace_msg, "Unable to backtrace! %d %d %s", d2, go.final_d,
+                   g.node_string(job.targets()[go.reached_j]).c_str());
+          res->flags |= G2S_GAP_BACKTRACE_FAIL;
+          res->count = 0;
+          buf[lmf] = '\0';
+          break;
+        }
+        const uint32_t rv = draw() >> 1;
+        i = (int)(nb == 1 ? back[0] : back[rv % (uint32_t)nb]);
+        t = (int)(v.segs[i].depth_len >> 16) - 1;  // a child in the closure puts the whole parent there
+      }
+    }
+    d2--;
+  }
+  res->draws = draws;
+}
+
+int seg_count_draws(const Graph& g, const SubView& v, const SubPrep& prep, const uint32_t* rands) {
+  const GapOut& go = *v.out;
+  int draws = 0;
+  const int pick = (int)((rands[draws++] >> 1) % (uint32_t)go.n_len);
+  int d2 = go.len[pick];
+  int i = prep.start_seg[pick], t = prep.start_t[pick];
+  while (d2 >= 0 && i >= 0) {
+    const SegRec& s = v.segs[i];
+    if (t == 0 && (s.flags & G2S_SUB_SOURCE)) break;
+    if (d2 > 0) {
+      if (t > 0) {  // the rest of the segment is drawn base by base with one choice each
+        const int run = std::min(t, d2);
+        draws += run; d2 -= run; t -= run;
+        continue;
+      }
+      uint32_t back[4];
+      const int nb = seg_parents(s, back);
+      if (nb == 0) break;
+      if (nb > 1) {
+        int64_t by_slot[4] = {-1, -1, -1, -1};
+        for (int x = 0; x < nb; x++) {
+          const SegRec& q = v.segs[back[x]];
+          by_slot[g.lastnt[seg_state(q, (int)(q.depth_len >> 16) - 1) ^ 1u]] = (int64_t)back[x];
+        }
+        int w = 0;
+        for (int nt = 0; nt < 4; nt++) if (by_slot[nt] >= 0) back[w++] = (uint32_t)by_slot[nt];
+      }
+      const uint32_t rv = rands[draws++] >> 1;
+      i = (int)(nb == 1 ? back[0] : back[rv % (uint32_t)nb]);
+      t = (int)(v.segs[i].depth_len >> 16) - 1;
+    }
+    d2--;
+  }
+  return draws;
+}
+
+}  // namespace g2s

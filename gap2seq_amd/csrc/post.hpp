@@ -76,7 +76,20 @@ inline int sub_preds(const SubView& v, uint32_t i, int32_t out[4]) {
 // HBM-tier closure (SubState, parents by GATB slot) -> SubRec + side list, appended to the vectors
 void sub_convert(const SubState* in, uint32_t n, std::vector<SubRec>* recs, std::vector<uint64_t>* xp);
 
+// Per-segment results of seg_analyze (segment tier, closures without a repeated k-mer).
+struct SegInfo {
+  int32_t lo, hi;      // depths at which tracebacks through this segment's entry stop (-1 / 1<<30: not fixed)
+  int16_t split;       // S part: states t <= split carry safe_a, the others safe_b (a sink inside the segment)
+  uint8_t safe_a, safe_b;
+  uint8_t npar;
+};
+
 struct SubPrep {
+  bool seg_mode = false;  // analysed on the closure SEGMENTS (seg_analyze); st / safe are not used then
+  std::vector<SegInfo> seg;                              // per closure segment
+  std::vector<std::pair<uint32_t, uint32_t>> s_iv;       // S closure as k-mer index intervals (lo, segment), sorted
+  bool sink_safe = false, has_choice = false;
+  int start_seg[2] = {-1, -1}, start_t[2] = {0, 0};
   bool phase_d = false;   // count > 0 && pathLengths non-empty (:1169)
   int count = 0;          // value fill_gap returns (before a backtrace failure / memory verdict)
   uint32_t flags = 0;     // G2S_GAP_* bits found on the host
@@ -94,6 +107,16 @@ void sub_analyze(const FillParams& p, const GapJob& job, const SubView& v, SubPr
 inline int sub_fixed_draws(const SubView& v, const SubPrep& prep, int pick) {
   return prep.stop_depth[pick] < 0 ? -1 : 1 + (v.out->len[pick] - prep.stop_depth[pick]);
 }
+// The same analysis on the closure SEGMENTS of the segment tier, in O(segments): applies when no
+// k-mer occurs at two depths of the S closure (then the subgraph is a DAG whose vertices are the
+// states: nothing to contract, :1314-1435 reduces to the branch rule, which is constant along a
+// segment).  Returns false otherwise: the caller expands the segments (seg_expand) and takes
+// sub_analyze.  seg_traceback / seg_count_draws are sub_traceback / sub_count_draws on segments.
+bool seg_analyze(const FillParams& p, const GapJob& job, const SubView& v, SubPrep* out);
+void seg_traceback(const Graph& g, const FillParams& p, const GapJob& job, const SubView& v, const SubPrep& prep,
+                   const uint32_t* rands, char* buf, g2s_result* res);
+int seg_count_draws(const Graph& g, const SubView& v, const SubPrep& prep, const uint32_t* rands);
+
 // D3.  `rands` points at the raw word of this gap's first draw (rand() value = word >> 1);
 // returns through res (count, fuz, draws, flags).
 // Writes the reference's `fill` buffer into buf (size job.buf_bytes).

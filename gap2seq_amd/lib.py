@@ -120,6 +120,10 @@ _SIGS = {
                                         C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_uint32, C.c_uint64,
                                         C.POINTER(g2s_result), C.c_char_p]),
     "g2s_test_graph_tables": (C.c_int, [_VP, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
+    "g2s_test_post_segments": (C.c_int, [_VP, C.POINTER(g2s_params), C.POINTER(g2s_gap), C.c_uint32,
+                                         C.POINTER(C.c_uint32), C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int32,
+                                         C.c_int32, C.c_uint32, C.c_uint64, C.POINTER(g2s_result), C.c_char_p,
+                                         C.POINTER(C.c_int32)]),
     "g2s_test_seg_expand": (C.c_int, [_VP, C.POINTER(g2s_params), C.POINTER(g2s_gap), C.c_uint32, C.POINTER(C.c_uint32),
                                       C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_uint32, C.POINTER(C.c_uint32),
                                       C.c_uint32, C.POINTER(C.c_uint64)]),
@@ -474,6 +478,23 @@ def test_post_closure(graph, params, gap, records, xp, c_count, lengths, reached
     _check(lib.g2s_test_post_closure(graph.h, C.byref(params), arr, n, flat, len(xp), xs, c_count, len(lengths), lens,
                                      reached_j, final_d, seed, skip, C.byref(res), buf))
     return FillResult(res, buf.raw)
+
+
+def test_post_segments(graph, params, gap, segs, c_count, lengths, reached_j, final_d, seed, skip):
+    """TEST HOOK binding: host D2 + D3 directly on closure segments; returns (FillResult, on_segments)."""
+    lib = load_library()
+    arr, keep = _gap_array([gap])
+    flat = (C.c_uint32 * max(1, 8 * len(segs)))()
+    for i, rec in enumerate(segs):
+        for q in range(8):
+            flat[8 * i + q] = rec[q] & 0xFFFFFFFF
+    lens = (C.c_int32 * 2)(*(list(lengths) + [0, 0])[:2])
+    res = g2s_result()
+    on = C.c_int32(0)
+    buf = C.create_string_buffer(gap.gap_len + graph.k + params.d_err + gap.lmf + gap.rmf + 3)
+    _check(lib.g2s_test_post_segments(graph.h, C.byref(params), arr, len(segs), flat, c_count, len(lengths), lens,
+                                      reached_j, final_d, seed, skip, C.byref(res), buf, C.byref(on)))
+    return FillResult(res, buf.raw), bool(on.value)
 
 
 def test_seg_expand(graph, params, gap, segs, lengths, reached_j, n_records, n_xp):

@@ -277,6 +277,15 @@ int g2s_test_post_closure(const g2s_graph* g, const g2s_params* p, const g2s_gap
                           int32_t n_lengths, const int32_t* lengths, int32_t reached_j, int32_t final_d, uint32_t seed,
                           uint64_t skip, g2s_result* res, char* buf);
 
+/* TEST HOOK: the host half of phase D run directly on closure segments (the segment tier's output,
+ * layout as for g2s_test_seg_expand), as the batch path does when no k-mer occurs at two depths of
+ * the closure; *on_segments = 0 when that does not hold (nothing is computed then: take
+ * g2s_test_seg_expand + g2s_test_post_closure, as the batch path does). */
+int g2s_test_post_segments(const g2s_graph* g, const g2s_params* p, const g2s_gap* gap, uint32_t n_segs,
+                           const uint32_t* segs, int32_t c_count, int32_t n_lengths, const int32_t* lengths,
+                           int32_t reached_j, int32_t final_d, uint32_t seed, uint64_t skip, g2s_result* res, char* buf,
+                           int32_t* on_segments);
+
 /* TEST HOOK: the host's expansion of a closure given as unitig segments (what the segment tier's
  * kernel emits: 8 words per segment {node, depth | len << 16, count, ts | tt << 16, parents 0-1,
  * parents 2-3, flags, 0}, children before parents) into the per-state records and side list of

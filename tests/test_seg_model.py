@@ -16,6 +16,9 @@ def _model_gap(pg, k, g, e, allp=True, skip=False):
     return M.Gap(g["gap_len"], e, lmf, rmf, lseeds, rseeds, targets, all_paths=allp, skip_confident=skip)
 
 
+STATS = {}
+
+
 def _parent_sets(records, xp):
     extra = {}
     for x in xp:
@@ -32,6 +35,7 @@ def check_config(product, oracle, seqs, k, gaps, e, allp=True, skip=False, seed=
     tb = M.Tables(product, pg)
     params = product.make_params(d_err=e, skip_confident=skip, all_paths=allp, randseed=seed)
     compared = nq7 = 0
+    nseg_path = STATS.setdefault("on_segments", [0])
     try:
         for gi, g in enumerate(gaps):
             rng = oracle.OracleRng(seed)
@@ -60,6 +64,16 @@ def check_config(product, oracle, seqs, k, gaps, e, allp=True, skip=False, seed=
                 assert _parent_sets(recs, xps) == _parent_sets(m.records, sorted(m.xp)), what
                 r = product.test_post_closure(pg, params, pgap, recs, xps, m.c_count, m.lengths, m.reached_j, m.final_d,
                                               seed, 0)
+                # and the analysis + traceback run on the segments themselves (what the batch path does
+                # whenever no k-mer occurs at two depths of the closure)
+                r2, on_segments = product.test_post_segments(pg, params, pgap, m.compact, m.c_count, m.lengths, m.reached_j,
+                                                             m.final_d, seed, 0)
+                if on_segments:
+                    nseg_path[0] += 1
+                    assert (r2.count, r2.left_fuz, r2.right_fuz, r2.draws, r2.fill, r2.flags) == \
+                        (r.count, r.left_fuz, r.right_fuz, r.draws, r.fill, r.flags), what
+                    if not skip:
+                        assert r2.substats == r.substats, what
                 assert r.count == o.count, what
                 assert (r.left_fuz, r.right_fuz, r.draws) == (o.left_fuz, o.right_fuz, o.info.draws), what
                 assert r.fill == o.fill, what
@@ -92,10 +106,12 @@ def test_model_k31_default_parameters(product, oracle, variant):
     reads = product.G2S.synth_genome(200000, variant, 20240101)
     seqs = [ln for ln in reads.splitlines() if not ln.startswith(">")]
     from test_gpu_parity import _parse_scaffolds
-    gaps = _parse_scaffolds(product.G2S.synth_gaps(reads, 31, 10, 40, 50, 600, 20240103))
+    gaps = _parse_scaffolds(product.G2S.synth_gaps(reads, 31, 10, 40, 50, 400, 20240103))
     stats = []
+    before = STATS.setdefault("on_segments", [0])[0]
     c, q = check_config(product, oracle, seqs, 31, gaps, 500, stats=stats)
     assert c == 40
+    assert STATS["on_segments"][0] - before >= 36  # nearly every closure has each k-mer at one depth only
 
 
 def test_model_tandem_flanks_and_fuz_extremes(product, oracle):
