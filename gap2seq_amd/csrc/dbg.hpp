@@ -25,6 +25,7 @@ struct DeviceGraph {
   uint32_t* pred = nullptr;  // [2n*4], only when k is even (palindromic k-mers exist)
   uint64_t* ustart = nullptr;  // unitig-start bitmap, offset by kUstartPad words of all-ones padding
   uint32_t* rem = nullptr;     // [2n] unitig-internal steps left from an oriented node (seg_tables.hip), odd k only
+  uint32_t* urec = nullptr;    // [2n][8] successor record of the end of the node's unitig walk + rem (seg_tables.hip)
   uint64_t bytes = 0;
 };
 

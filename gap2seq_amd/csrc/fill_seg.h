@@ -15,7 +15,8 @@ size_t fill_seg_lds_bytes();
 uint32_t fill_seg_dbg_words();  // words per gap of the optional diagnostics buffer
 // phases A-D1 of every listed gap in one launch; results land in pinned host memory exactly as
 // the LDS tier leaves them (GapOut per gap, closures packed by an atomic cursor, completion list)
-hipError_t launch_fill_seg(hipStream_t st, uint32_t ngaps, const uint32_t* succ, const uint32_t* rem, const GapDev* gaps,
+hipError_t launch_fill_seg(hipStream_t st, uint32_t ngaps, const uint32_t* succ, const uint32_t* urec /* seg_tables.hip */,
+                           const GapDev* gaps,
                            const uint32_t* gap_ids, const uint32_t* flank_nodes, SubRec* sub_out /* pinned host */,
                            unsigned long long out_cap /* records */, unsigned long long* out_counter, GapOut* outs,
                            GapOut* outs_host /* pinned host */, uint32_t* done_list /* pinned host */, int skip_confident,

@@ -80,7 +80,7 @@ __device__ __forceinline__ uint32_t wave_scan(uint32_t x, int lane) {
 }  // namespace
 
 // dynamic LDS: 7 arrays of G2S_SEG_CAP words + left seeds
-__global__ __launch_bounds__(64) void g2s_fill_seg(const uint32_t* __restrict__ succ, const uint32_t* __restrict__ rem,
+__global__ __launch_bounds__(64) void g2s_fill_seg(const uint32_t* __restrict__ succ, const uint32_t* __restrict__ urec,
                                                     const GapDev* __restrict__ gaps, const uint32_t* __restrict__ gap_ids,
                                                     const uint32_t* __restrict__ flank_nodes, SubRec* sub_out,
                                                     unsigned long long out_cap, unsigned long long* out_counter,
@@ -190,13 +190,19 @@ __global__ __launch_bounds__(64) void g2s_fill_seg(const uint32_t* __restrict__ 
           while ((uint32_t)(lab[slot] >> 32) != v) slot = (slot + 1u) & (ALAB - 1u);
           d = (uint32_t)lab[slot];
         }
-        const uint32_t r = mine ? rem[v ^ 1u] : 0u;  // walking back from v = walking on from v^1
-        if (mine) labrem[slot] = r;
-        const uint32_t steps = min(r, (uint32_t)gd.right_half - d);
-        const uint32_t last = seg_node(v ^ 1u, steps) ^ 1u;
-        const bool live = mine && d + steps < (uint32_t)gd.right_half;
+        // walking back from v = walking on from v^1: steps left in the unitig and the successor record
+        // of the walk's last node (graph.predecessors(last)[i] = succ(last^1)[i] ^ 1) in one record
         uint4 rec = make_uint4(G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID);
-        if (live) rec = *(const uint4*)(succ + (size_t)(last ^ 1u) * 4);  // graph.predecessors(last)[i] = succ(last^1)[i] ^ 1
+        uint32_t r = 0;
+        if (mine) {
+          const uint4* u = (const uint4*)(urec + (size_t)(v ^ 1u) * 8);
+          rec = u[0];
+          r = u[1].x;
+          labrem[slot] = r;
+        }
+        const uint32_t steps = min(r, (uint32_t)gd.right_half - d);
+        const bool live = mine && d + steps < (uint32_t)gd.right_half;  // (then steps == r: the record is the last node's)
+        if (!live) rec = make_uint4(G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID);
         const uint32_t dchild = d + steps + 1u;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -344,6 +350,7 @@ __global__ __launch_bounds__(64) void g2s_fill_seg(const uint32_t* __restrict__ 
 
   // ---------------- phase B: entry events in registers, segments into LDS ----------------------
   uint32_t en = G2S_DEV_INVALID, ec = 0, es = 1, ep01 = 0xFFFFFFFFu, ep23 = 0xFFFFFFFFu;
+  uint4 erec = make_uint4(G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID);  // where the event's segment leaves
   int ed = 0;
   uint64_t ev = 0, efx = 0;  // pending events, and which of them have an assigned count (left seeds)
   uint32_t nseg = 0, gen = 0, xb = 0, sb = 0;
@@ -367,21 +374,53 @@ __global__ __launch_bounds__(64) void g2s_fill_seg(const uint32_t* __restrict__ 
     const int l = __builtin_ctzll(fr);
     if (lane == l) {
       en = w; ed = dw; ec = c; ep01 = 0xFFFF0000u | par; ep23 = 0xFFFFFFFFu;
-      es = dw < lmf ? 1u : 0u;  // states up to the end of the unitig (0: loaded for all new events at once)
+      es = 0u;  // states up to the end of the unitig: loaded with the exit record for all new events at once
     }
     ev |= 1ull << l;
+  };
+  // phase C: target k-mer j at position t of a segment is a hit at depth + t (lane j holds target j)
+  auto note_hits = [&](uint32_t node, uint32_t L, int depth, uint32_t c) {
+    const int t = seg_pos(node, L, tg);
+    for (uint64_t hm = __ballot(t >= 0); hm; hm &= hm - 1) {
+      const int j = __builtin_ctzll(hm);
+      const int td = depth + (int)rl((uint32_t)t, j), base = gd.g + lmf + j;
+      const int err = td >= base ? td - base : base - td;
+      if (err > gd.e) continue;
+      const uint32_t key = ((uint32_t)(err + gd.g + lmf + rmf) << 6) | (uint32_t)j;
+      if (key < best) { best = key; c1 = 0; c2 = 0; }
+      if (key == best) { if (td >= base) c1 = c; else c2 = c; }
+    }
   };
   if (!overflow) {
     // left seeds: left.substr(d, k) enters at depth d with the value 1 ASSIGNED (:995-1015, :1082-1105)
     const uint32_t sd = lane <= lmf ? lseeds[lane] : G2S_DEV_INVALID;
-    ev = efx = __ballot(sd != G2S_DEV_INVALID && lane <= D);
-    if ((ev >> lane) & 1ull) {
-      en = sd; ed = lane; ec = 1; ep01 = ep23 = 0xFFFFFFFFu;
-      es = lane < lmf ? 1u : rem[sd] + 1u;
+    const uint32_t s0 = rl(sd, 0);
+    // The usual flank is a stretch of ONE unitig: seed d is the d-th node after seed 0 and the walk
+    // from seed 0 stays unitig-internal for lmf steps.  Levels 0 .. lmf-1 are then that chain with
+    // count 1 (every state has the next seed as its only successor, and a seed's value is 1 anyway):
+    // one segment, and the seed at depth lmf as the only pending event, instead of lmf rounds.
+    bool chain = lmf >= 1 && s0 != G2S_DEV_INVALID && __ballot(lane <= lmf && sd != seg_node(s0, (uint32_t)lane)) == 0ull;
+    if (chain) chain = uni(urec[(size_t)s0 * 8 + 4]) >= (uint32_t)lmf;
+    if (chain) {
+      if (lane == 0) {
+        s_node[0] = s0; s_dl[0] = (uint32_t)lmf << 16; s_cnt[0] = 1u; s_p01[0] = s_p23[0] = 0xFFFFFFFFu; s_aux[0] = 0u;
+      }
+      nseg = 1; gen = 1;
+      sb += (uint32_t)lmf;
+      xb += (uint32_t)lmf;
+      note_hits(s0, (uint32_t)lmf, 0, 1u);
+      ev = efx = 1ull << lmf;
+      if (lane == lmf) { en = sd; ed = lmf; ec = 1; ep01 = 0xFFFF0000u; ep23 = 0xFFFFFFFFu; es = 0u; }
+    } else {
+      ev = efx = __ballot(sd != G2S_DEV_INVALID && lane <= D);
+      if ((ev >> lane) & 1ull) { en = sd; ed = lane; ec = 1; ep01 = ep23 = 0xFFFFFFFFu; es = 0u; }
     }
   }
   while (ev && !overflow) {
-    if (((ev >> lane) & 1ull) && es == 0u) es = rem[en] + 1u;  // one round trip for all events created last round
+    if (((ev >> lane) & 1ull) && es == 0u) {  // one round trip for all events created last round
+      if (ed < lmf) { es = 1u; erec = *(const uint4*)(succ + (size_t)en * 4); }  // above the flank: one state, leaves at once
+      else { const uint4* u = (const uint4*)(urec + (size_t)en * 8); erec = u[0]; es = u[1].x + 1u; }
+    }
     // ---- which events are final: depth below the horizon
     uint32_t H = SEG_INF;
     for (uint64_t m = ev; m; m &= m - 1) {
@@ -412,17 +451,7 @@ __global__ __launch_bounds__(64) void g2s_fill_seg(const uint32_t* __restrict__ 
       }
       sb += L;
       xb += min(L, (uint32_t)(D - depth));
-      // phase C: target k-mer j at position t of the segment is a hit at depth + t
-      const int t = seg_pos(node, L, tg);
-      for (uint64_t hm = __ballot(t >= 0); hm; hm &= hm - 1) {
-        const int j = __builtin_ctzll(hm);
-        const int td = depth + (int)rl((uint32_t)t, j), base = gd.g + lmf + j;
-        const int err = td >= base ? td - base : base - td;
-        if (err > gd.e) continue;
-        const uint32_t key = ((uint32_t)(err + gd.g + lmf + rmf) << 6) | (uint32_t)j;
-        if (key < best) { best = key; c1 = 0; c2 = 0; }
-        if (key == best) { if (td >= base) c1 = c; else c2 = c; }
-      }
+      note_hits(node, L, depth, c);
     }
     if (mine) {
       s_node[esid] = en;
@@ -434,9 +463,8 @@ __global__ __launch_bounds__(64) void g2s_fill_seg(const uint32_t* __restrict__ 
     }
     nseg += nsel;
     // ---- segments that reached the end of their stretch leave through the successor table
-    const bool exits = mine && elen == lcap && ed + (int)elen - 1 < D;
-    uint4 rec = make_uint4(G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID);
-    if (exits) rec = *(const uint4*)(succ + (size_t)seg_node(en, elen - 1u) * 4);
+    const bool exits = mine && elen == es && ed + (int)elen - 1 < D;
+    const uint4 rec = erec;  // elen == lcap == es: the walk reached the node the record belongs to
     const uint32_t xd = (uint32_t)ed + elen;  // depth of the children
     ev &= ~sel;
     efx &= ~sel;
@@ -680,7 +708,7 @@ namespace g2s {
 size_t fill_seg_lds_bytes() { return 4u * (7u * G2S_SEG_CAP + 32u); }
 uint32_t fill_seg_dbg_words() { return 8u + 2u * 64u * G2S_SEG_ASETS + 6u * G2S_SEG_CAP; }
 
-hipError_t launch_fill_seg(hipStream_t st, uint32_t ngaps, const uint32_t* succ, const uint32_t* rem, const GapDev* gaps,
+hipError_t launch_fill_seg(hipStream_t st, uint32_t ngaps, const uint32_t* succ, const uint32_t* urec, const GapDev* gaps,
                            const uint32_t* gap_ids, const uint32_t* flank_nodes, SubRec* sub_out,
                            unsigned long long out_cap, unsigned long long* out_counter, GapOut* outs, GapOut* outs_host,
                            uint32_t* done_list, int skip_confident, uint32_t* dbg) {
@@ -688,7 +716,7 @@ hipError_t launch_fill_seg(hipStream_t st, uint32_t ngaps, const uint32_t* succ,
   const size_t bytes = fill_seg_lds_bytes();
   hipError_t e = hipFuncSetAttribute((const void*)g2s_fill_seg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(g2s_fill_seg, dim3(ngaps), dim3(64), bytes, st, succ, rem, gaps, gap_ids, flank_nodes, sub_out, out_cap,
+  hipLaunchKernelGGL(g2s_fill_seg, dim3(ngaps), dim3(64), bytes, st, succ, urec, gaps, gap_ids, flank_nodes, sub_out, out_cap,
                      out_counter, outs, outs_host, done_list, skip_confident, dbg, fill_seg_dbg_words());
   return hipGetLastError();
 }

@@ -131,6 +131,7 @@ extern "C" void g2s_graph_free(g2s_graph* g) {
         if (kv.second.pred) (void)hipFree(kv.second.pred);
         if (kv.second.ustart) (void)hipFree(kv.second.ustart - kUstartPad);
         if (kv.second.rem) (void)hipFree(kv.second.rem);
+        if (kv.second.urec) (void)hipFree(kv.second.urec);
       }
     }
     delete g->g;
@@ -462,7 +463,8 @@ extern "C" int g2s_session_create(g2s_graph* g, int device, const g2s_params* p,
     DeviceGraph& dg = g->g->dev.at(device);
     if (!dg.rem && !dg.pred && g->g->n > 0) {
       HIP_TRY(build_rem_table(dg.ustart, g->g->n, &dg.rem));
-      dg.bytes += g->g->n * 8;
+      HIP_TRY(build_urec_table(dg.succ, dg.rem, g->g->n, &dg.urec));
+      dg.bytes += g->g->n * (8 + 64);
     }
   }
   g2s_session* s = new g2s_session();
@@ -828,7 +830,7 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
       seg_dbg = (uint32_t*)s->d_slog.p;
     }
     if (seg)
-      HIP_TRY(launch_fill_seg(st, (uint32_t)ids.size(), dg.succ, dg.rem, gaps_dev, ids_dev, (const uint32_t*)s->d_flank.p,
+      HIP_TRY(launch_fill_seg(st, (uint32_t)ids.size(), dg.succ, dg.urec, gaps_dev, ids_dev, (const uint32_t*)s->d_flank.p,
                               (SubRec*)d_subs_host, (unsigned long long)out_states, (unsigned long long*)s->d_counter.p,
                               (GapOut*)s->d_outs.p, (GapOut*)d_outs_host, (uint32_t*)d_done_host,
                               s->params.skip_confident ? 1 : 0, seg_dbg));
@@ -875,7 +877,33 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
 
   const auto t_launched = std::chrono::steady_clock::now();
   if (lds) {
-    if (on_done) {
+   if (seg && on_done) {
+    // Segment tier: the analysis of a gap costs about a microsecond (it runs on the closure
+    // segments), so two hand-overs are enough: the gaps that have arrived by the time half of the
+    // list is done (their analysis runs under the rest of the kernel), then the others.  Each
+    // hand-over wakes the pool once; only this thread polls, napping between looks.
+    const volatile uint32_t* done = (const volatile uint32_t*)td->done.p;
+    const size_t total = ids.size();
+    size_t seen = 0, given = 0;
+    const int old_slack = prctl(PR_GET_TIMERSLACK, 0, 0, 0, 0);
+    prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0);
+    while (given < total) {
+      while (seen < total && done[seen] != 0xFFFFFFFFu) seen++;
+      std::atomic_thread_fence(std::memory_order_acquire);
+      const bool finished = hipEventQuery(s->ev[2]) != hipErrorNotReady;
+      if (finished) { while (seen < total && done[seen] != 0xFFFFFFFFu) seen++; }
+      if ((given == 0 && total >= 128 && seen * 2 >= total && seen < total) || seen == total || (finished && seen > given)) {
+        (*on_done)((const uint32_t*)td->done.p + given, seen - given);
+        given = seen;
+      } else if (finished) {
+        break;  // kernel over and nothing new: an error, reported by the sync below
+      } else {
+        struct timespec ts = {0, 5000};
+        nanosleep(&ts, nullptr);
+      }
+    }
+    prctl(PR_SET_TIMERSLACK, old_slack > 0 ? (unsigned long)old_slack : 50000UL, 0, 0, 0);
+   } else if (on_done) {
       // gaps finish at very different times (the longest take 10x the median): hand the
       // finished ones to the caller while the kernel is still running.  Only this thread
       // polls, and it naps between looks: a busy host must not starve the HIP runtime.

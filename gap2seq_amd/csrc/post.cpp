@@ -683,6 +683,7 @@ bool seg_analyze(const FillParams& p, const GapJob& job, const SubView& v, SubPr
 
 void seg_traceback(const Graph& g, const FillParams& p, const GapJob& job, const SubView& v, const SubPrep& prep,
                    const uint32_t* rands, char* buf, g2s_result* res) {
+  static const char kUp[4] = {'A', 'C', 'T', 'G'}, kLow[4] = {'a', 'c', 't', 'g'};  // GATB codes (kmer.hpp)
   const GapOut& go = *v.out;
   const int lmf = job.lmf, k = p.k;
   res->right_fuz = go.reached_j;  // :1171
@@ -695,43 +696,69 @@ void seg_traceback(const Graph& g, const FillParams& p, const GapJob& job, const
   int i = prep.start_seg[pick], t = prep.start_t[pick];
   buf[d2] = '\0';
   res->count = prep.count;
+  const uint8_t* lastnt = g.lastnt.data();
   while (d2 >= 0 && i >= 0) {
     const SegRec& s = v.segs[i];
-    if (t == 0 && (s.flags & G2S_SUB_SOURCE)) {  // :1455-1462
+    const int d0 = (int)(s.depth_len & 0xFFFFu);
+    // ---- the states t, t-1, ..., 1 of this segment: one choice each (still drawn, :1513), written
+    // in runs that share their safe bit (:1466-1468); state 0 is left for the parent choice below
+    if (t > 0) {
+      const int ts = (int)(int16_t)(s.ts_tt & 0xFFFFu);
+      const int split = p.skip_confident ? t : (int)prep.seg[(size_t)i].split;
+      int pos = t;
+      while (pos > 0) {
+        int lo_run;  // the run is [lo_run, pos]
+        bool sf;
+        if (p.skip_confident) { lo_run = 1; sf = true; }
+        else if (pos > ts) { lo_run = pos; sf = seg_safe(v, prep, (uint32_t)i, pos); }  // outside the subgraph (Q5): state by state
+        else if (pos > split) { lo_run = std::max(1, split + 1); sf = prep.seg[(size_t)i].safe_b; }
+        else { lo_run = 1; sf = prep.seg[(size_t)i].safe_a; }
+        const bool up = (s.node & 1u) == 0;
+        uint32_t node = up ? s.node + 2u * (uint32_t)pos : s.node - 2u * (uint32_t)pos;
+        char* o = buf + (d0 + pos - 1);
+        if (sf) {
+          for (int q = pos; q >= lo_run; q--, o--, node = up ? node - 2u : node + 2u) *o = kUp[lastnt[node]];
+          last_solid = d0 + lo_run;
+        } else {
+          for (int q = pos; q >= lo_run; q--, o--, node = up ? node - 2u : node + 2u)
+            *o = (d0 + q > last_solid - k) ? kUp[lastnt[node]] : kLow[lastnt[node]];
+        }
+        pos = lo_run - 1;
+      }
+      draws += t;
+      d2 -= t;
+      t = 0;
+    }
+    if (s.flags & G2S_SUB_SOURCE) {  // :1455-1462
       res->left_fuz = lmf - d2;
       break;
     }
     if (d2 > 0) {
-      if (p.skip_confident || seg_safe(v, prep, (uint32_t)i, t)) last_solid = d2;  // :1466-1468
-      const char c = g.last_char(seg_state(s, t));
-      buf[d2 - 1] = (d2 > last_solid - k) ? (char)toupper((unsigned char)c) : (char)tolower((unsigned char)c);
-      if (t > 0) {
-        (void)draw();  // one choice, still drawn (:1513)
-        t--;
-      } else {
-        uint32_t back[4];
-        const int nb = seg_parents(s, back);
-        if (nb > 1) {  // GATB predecessor order: predecessors(v)[slot] is the parent p whose p^1 ends with base `slot`
-          int64_t by_slot[4] = {-1, -1, -1, -1};
-          for (int x = 0; x < nb; x++) {
-            const SegRec& q = v.segs[back[x]];
-            by_slot[g.lastnt[seg_state(q, (int)(q.depth_len >> 16) - 1) ^ 1u]] = (int64_t)back[x];
-          }
-          int w = 0;
-          for (int nt = 0; nt < 4; nt++) if (by_slot[nt] >= 0) back[w++] = (uint32_t)by_slot[nt];
+      if (p.skip_confident || seg_safe(v, prep, (uint32_t)i, 0)) last_solid = d2;
+      const uint8_t c = lastnt[s.node];
+      buf[d2 - 1] = (d2 > last_solid - k) ? kUp[c] : kLow[c];
+      uint32_t back[4];
+      const int nb = seg_parents(s, back);
+      if (nb > 1) {  // GATB predecessor order: predecessors(v)[slot] is the parent p whose p^1 ends with base `slot`
+        int64_t by_slot[4] = {-1, -1, -1, -1};
+        for (int x = 0; x < nb; x++) {
+          const SegRec& q = v.segs[back[x]];
+          by_slot[lastnt[seg_state(q, (int)(q.depth_len >> 16) - 1) ^ 1u]] = (int64_t)back[x];
         }
-        if (nb == 0) {  // :1493-1510
-          snprintf(res->backtrace_msg, sizeof res->backtrace_msg, "Unable to backtrace! %d %d %s", d2, go.final_d,
-                   g.node_string(job.targets()[go.reached_j]).c_str());
-          res->flags |= G2S_GAP_BACKTRACE_FAIL;
-          res->count = 0;
-          buf[lmf] = '\0';
-          break;
-        }
-        const uint32_t rv = draw() >> 1;
-        i = (int)(nb == 1 ? back[0] : back[rv % (uint32_t)nb]);
-        t = (int)(v.segs[i].depth_len >> 16) - 1;  // a child in the closure puts the whole parent there
+        int w = 0;
+        for (int nt = 0; nt < 4; nt++) if (by_slot[nt] >= 0) back[w++] = (uint32_t)by_slot[nt];
       }
+      if (nb == 0) {  // :1493-1510
+        snprintf(res->backtrace_msg, sizeof res->backtrace_msg, "Unable to backtrace! %d %d %s", d2, go.final_d,
+                 g.node_string(job.targets()[go.reached_j]).c_str());
+        res->flags |= G2S_GAP_BACKTRACE_FAIL;
+        res->count = 0;
+        buf[lmf] = '\0';
+        break;
+      }
+      const uint32_t rv = draw() >> 1;
+      i = (int)(nb == 1 ? back[0] : back[rv % (uint32_t)nb]);
+      t = (int)(v.segs[i].depth_len >> 16) - 1;  // a child in the closure puts the whole parent there
     }
     d2--;
   }

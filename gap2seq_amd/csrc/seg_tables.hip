@@ -70,9 +70,36 @@ __global__ __launch_bounds__(256) void k_rem(const uint64_t* __restrict__ words,
   ((uint2*)rem)[idx] = out;
 }
 
+// urec[v] = {successor record of the LAST node of v's unitig walk (4 words), rem[v], 0, 0, 0}: what
+// a segment that enters at v needs to know — how far it can go and where it leaves — in one
+// 32-byte record, one memory round trip instead of two dependent ones (rem[v], then succ[end]).
+__global__ __launch_bounds__(256) void k_urec(const uint32_t* __restrict__ succ, const uint32_t* __restrict__ rem,
+                                              uint64_t n2, uint4* __restrict__ urec) {
+  const uint64_t v = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  if (v >= n2) return;
+  const uint32_t r = rem[v];
+  const uint32_t e = (v & 1u) ? (uint32_t)v - 2u * r : (uint32_t)v + 2u * r;
+  urec[2 * v] = *(const uint4*)(succ + (size_t)e * 4);
+  urec[2 * v + 1] = make_uint4(r, 0u, 0u, 0u);
+}
+
 }  // namespace
 
 namespace g2s {
+
+hipError_t build_urec_table(const uint32_t* succ_dev, const uint32_t* rem_dev, uint64_t n, uint32_t** urec_out) {
+  *urec_out = nullptr;
+  if (n == 0) return hipSuccess;
+  uint32_t* urec = nullptr;
+  hipError_t e = hipMalloc((void**)&urec, (size_t)n * 64 + 64);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_urec, dim3((unsigned)((2 * n + 255) / 256)), dim3(256), 0, 0, succ_dev, rem_dev, 2 * n, (uint4*)urec);
+  e = hipGetLastError();
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e != hipSuccess) { (void)hipFree(urec); return e; }
+  *urec_out = urec;
+  return hipSuccess;
+}
 
 hipError_t build_rem_table(const uint64_t* ustart_dev, uint64_t n, uint32_t** rem_out) {
   *rem_out = nullptr;

@@ -144,11 +144,22 @@ def fill_model(tb, gap, rs=None, stats=None):
             ev[0] = min(MAX_PATHS, ev[0] + count)  # saturating add is associative: the order does not matter
             ev[2].append(parent)
 
-    for d in range(lmf + 1):
-        if gap.lseeds[d] != INVALID and d <= D:
-            add_event(gap.lseeds[d], d, 0, None, fixed=True)
     segs = []     # [v0, d0, count, length, parents, generation]
     gen = 0
+    s0 = gap.lseeds[0]
+    chain = (lmf >= 1 and s0 != INVALID and all(gap.lseeds[d] == seg_node(s0, d) for d in range(lmf + 1))
+             and int(tb.rem[s0]) >= lmf)
+    if chain:
+        # the usual flank: seed d is the d-th node after seed 0 inside one unitig.  Levels 0 .. lmf-1 are
+        # that chain with count 1: one segment, and the seed at depth lmf as the only pending event
+        segs.append([s0, 0, 1, lmf, [], 0])
+        gen = 1
+        add_event(gap.lseeds[lmf], lmf, 0, None, fixed=True)
+        events[(gap.lseeds[lmf], lmf)][2].append(0)
+    else:
+        for d in range(lmf + 1):
+            if gap.lseeds[d] != INVALID and d <= D:
+                add_event(gap.lseeds[d], d, 0, None, fixed=True)
     rounds = 0
     max_pending = max_batch = 0
     while pending:
