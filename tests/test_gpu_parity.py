@@ -369,7 +369,7 @@ def test_c3_gap_list_on_the_branching_genome_vs_oracle(product, oracle, which, m
     assert c > 9900 and f > 9900
     if which == "seg":
         assert tm.seg_tier_gaps == 10000 and tm.seg_launches == 1 and tm.lds_launches == 0
-        assert 200000 < tm.seg_segments < 300000  # ~25 segments per gap for ~1000 DP states
+        assert 100000 < tm.seg_segments < 300000  # ~17 segments per gap for ~1000 DP states
     else:
         assert tm.lds_tier_gaps == 10000 and tm.lds_launches == 1
         assert tm.rs_pool_gaps > 0 and tm.log_pool_gaps > 0
