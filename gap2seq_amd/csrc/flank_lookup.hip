@@ -1,0 +1,91 @@
+// gap2seq_amd/csrc/flank_lookup.hip — flank k-mers -> oriented node ids on the device.
+//
+// Every gap needs graph.buildNode + graph.contains for the k-mers of its flanks: the lmf+1 left
+// seeds kmer_left.substr(d, k), the rmf+1 right-search seeds kmer_right.substr(len-k-j, k) and the
+// rmf+1 targets kmer_right.substr(j, k) (/root/reference/src/Gap2Seq.cpp:878-884, 953-957,
+// 995-1000, 1083-1086, 1113-1114): 33 look-ups per gap at -fuz 10.  On the host they were a third
+// of a 500-gap step (binary searches over the sorted k-mer set, cache-missing); here one wave per
+// gap does them in parallel in front of the fill kernel, on the same stream: lane i encodes its
+// k-mer from the flank text (GATB codec, kmer.hpp), takes the canonical form and finds it in the
+// device copy of the sorted k-mer set through the 22-bit prefix index.  The flank text and the
+// per-gap descriptors are read straight from pinned host memory; the node ids go to HBM (for the
+// fill kernels) and to pinned host memory (for the host half of phase D).
+#include <hip/hip_runtime.h>
+
+#include "fill_device.h"
+#include "flank_lookup.h"
+#include "kmer.hpp"
+
+namespace {
+
+using g2s::u128;
+
+__device__ __forceinline__ uint64_t d_revcomp32(uint64_t x) {
+  x = ((x >> 2) & 0x3333333333333333ULL) | ((x & 0x3333333333333333ULL) << 2);
+  x = ((x >> 4) & 0x0F0F0F0F0F0F0F0FULL) | ((x & 0x0F0F0F0F0F0F0F0FULL) << 4);
+  x = __builtin_bswap64(x);
+  return x ^ 0xAAAAAAAAAAAAAAAAULL;
+}
+__device__ __forceinline__ uint64_t d_revcomp(uint64_t x, int k) { return d_revcomp32(x) >> (64 - 2 * k); }
+__device__ __forceinline__ u128 d_revcomp(u128 x, int k) {
+  const u128 y = ((u128)d_revcomp32((uint64_t)x) << 64) | (u128)d_revcomp32((uint64_t)(x >> 64));
+  return y >> (128 - 2 * k);
+}
+
+template <class KT>
+__global__ __launch_bounds__(64) void g2s_resolve_flanks(g2s::FlankLookup lk, const g2s::FlankDesc* __restrict__ desc,
+                                                         const char* __restrict__ text, uint32_t* __restrict__ nodes_dev,
+                                                         uint32_t* __restrict__ nodes_host) {
+  // the gap's flank text: [left: first k+lmf chars][right: first k+rmf chars][right: last k+rmf chars]
+  __shared__ __attribute__((aligned(16))) uint32_t tw[G2S_FLANK_TEXT_MAX / 4];
+  const g2s::FlankDesc d = desc[blockIdx.x];
+  const int lane = threadIdx.x;
+  const int k = lk.k;
+  const int nl = (int)d.lmf + 1, nr = (int)d.rmf + 1;
+  const int llen = k + (int)d.lmf, rlen = k + (int)d.rmf;
+  const uint32_t words = (uint32_t)(llen + 2 * rlen + 3) / 4u;
+  for (uint32_t w = (uint32_t)lane; w < words; w += 64u) tw[w] = ((const uint32_t*)(text + d.text_off))[w];  // (4-byte aligned, padded)
+  __syncthreads();
+  const char* t = (const char*)tw;
+  const KT* v = (const KT*)lk.kmers;
+  const int shift = 2 * k - lk.bucket_bits;
+  for (int i = lane; i < nl + 2 * nr; i += 64) {
+    int off;
+    if (i < nl) off = i;                                     // left.substr(d, k)          :995,1083
+    else if (i < nl + nr) off = llen + rlen + (rlen - k - (i - nl));  // right.substr(len-k-j, k)    :878,954
+    else off = llen + (i - nl - nr);                        // right.substr(j, k)         :1113
+    KT f = 0;
+    for (int c = 0; c < k; c++) f = (f << 2) | (KT)((t[off + c] >> 1) & 3);  // GATB codec: A0 C1 T2 G3, any byte maps to a base
+    const KT r = d_revcomp(f, k);
+    const bool fwd = f < r;
+    const KT canon = fwd ? f : r;
+    // sorted rank through the prefix index (dbg.cpp: rank_of)
+    const size_t b = (size_t)(canon >> shift);
+    uint32_t lo = lk.bucket[b], hi = lk.bucket[b + 1];
+    const uint32_t end = hi;
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (v[mid] < canon) lo = mid + 1; else hi = mid;
+    }
+    uint32_t node = G2S_DEV_INVALID;
+    if (lo < end && v[lo] == canon) node = 2u * lk.rank2id[lo] + ((fwd ? 0u : 1u) ^ (uint32_t)lk.flip[lo]);
+    nodes_dev[d.flank_off + (uint32_t)i] = node;
+    nodes_host[d.flank_off + (uint32_t)i] = node;
+  }
+}
+
+}  // namespace
+
+namespace g2s {
+
+hipError_t launch_resolve_flanks(hipStream_t st, const FlankLookup& lk, uint32_t ngaps, const FlankDesc* desc, const char* text,
+                                 uint32_t* nodes_dev, uint32_t* nodes_host) {
+  if (ngaps == 0) return hipSuccess;
+  if (lk.wide)
+    hipLaunchKernelGGL(g2s_resolve_flanks<u128>, dim3(ngaps), dim3(64), 0, st, lk, desc, text, nodes_dev, nodes_host);
+  else
+    hipLaunchKernelGGL(g2s_resolve_flanks<uint64_t>, dim3(ngaps), dim3(64), 0, st, lk, desc, text, nodes_dev, nodes_host);
+  return hipGetLastError();
+}
+
+}  // namespace g2s

@@ -30,6 +30,7 @@
 #include "fill_device.h"
 #include "fill_launch.h"
 #include "fill_seg.h"
+#include "flank_lookup.h"
 #include "glibc_rand.hpp"
 #include "post.hpp"
 #include "seg_tables.h"
@@ -450,6 +451,9 @@ struct g2s_session {
   std::vector<g2s_session*> helpers;  // g2s_session_set_team
   size_t team_group = 0;
   PinBuf h_gaps;                 // staging for the GapDev upload
+  std::vector<PinBuf*> pin_free; // pinned buffers of finished batches (flank text in, node ids out), reused
+  FlankLookup lookup;            // device copy of the sorted k-mer set for the flank look-up kernel
+  DevBuf d_lk_kmers, d_lk_bucket, d_lk_rank2id, d_lk_flip;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   g2s_timing last_timing;        // of the last g2s_fill_batch / g2s_batch_run (g2s_session_last_timing)
 };
@@ -468,6 +472,22 @@ extern "C" int g2s_session_create(g2s_graph* g, int device, const g2s_params* p,
     }
   }
   g2s_session* s = new g2s_session();
+  {  // what the flank look-up kernel searches: the sorted k-mer set, its prefix index, rank -> node
+    const Graph& gr = *g->g;
+    const size_t kb = gr.wide ? gr.kmers128.size() * 16 : gr.kmers64.size() * 8;
+    hipError_t e = s->d_lk_kmers.ensure(std::max<size_t>(kb, 16));
+    if (e == hipSuccess && kb) e = hipMemcpy(s->d_lk_kmers.p, gr.wide ? (const void*)gr.kmers128.data() : (const void*)gr.kmers64.data(), kb, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = s->d_lk_bucket.ensure(std::max<size_t>(gr.bucket.size() * 4, 16));
+    if (e == hipSuccess && !gr.bucket.empty()) e = hipMemcpy(s->d_lk_bucket.p, gr.bucket.data(), gr.bucket.size() * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = s->d_lk_rank2id.ensure(std::max<size_t>(gr.rank2id.size() * 4, 16));
+    if (e == hipSuccess && !gr.rank2id.empty()) e = hipMemcpy(s->d_lk_rank2id.p, gr.rank2id.data(), gr.rank2id.size() * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = s->d_lk_flip.ensure(std::max<size_t>(gr.flip.size(), 16));
+    if (e == hipSuccess && !gr.flip.empty()) e = hipMemcpy(s->d_lk_flip.p, gr.flip.data(), gr.flip.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { delete s; return fail(G2S_ERR_HIP, std::string("session setup (look-up tables): ") + hipGetErrorString(e)); }
+    s->lookup.kmers = s->d_lk_kmers.p; s->lookup.bucket = (const uint32_t*)s->d_lk_bucket.p;
+    s->lookup.rank2id = (const uint32_t*)s->d_lk_rank2id.p; s->lookup.flip = (const uint8_t*)s->d_lk_flip.p;
+    s->lookup.k = gr.k; s->lookup.bucket_bits = gr.bucket_bits; s->lookup.wide = gr.wide ? 1 : 0;
+  }
   s->graph = g;
   s->device = device;
   s->params = *p;
@@ -501,6 +521,8 @@ extern "C" void g2s_session_destroy(g2s_session* s) {
                     &s->d_log, &s->d_lvl, &s->d_plk, &s->d_xl, &s->d_xo, &s->d_rspool, &s->d_logpool};
   for (DevBuf* b : bufs) b->release();
   delete s->pool;
+  for (PinBuf* pb : s->pin_free) { pb->release(); delete pb; }
+  s->d_lk_kmers.release(); s->d_lk_bucket.release(); s->d_lk_rank2id.release(); s->d_lk_flip.release();
   for (void* v : s->tier_pool) { TierData* t = (TierData*)v; t->outs.release(); t->subs.release(); t->done.release(); delete t; }
   s->h_gaps.release();
   for (int i = 0; i < 4; i++) if (s->ev[i]) (void)hipEventDestroy(s->ev[i]);
@@ -527,7 +549,13 @@ struct g2s_batch {
   g2s_session* s = nullptr;
   std::vector<GapJob> jobs;
   std::vector<uint32_t> flank_off;
-  std::vector<uint32_t> flank_all;  // oriented flank nodes of every gap, as uploaded to d_flank
+  // pinned, from the session's pool: [FlankDesc per valid gap][flank text][node ids of every gap]
+  PinBuf* pin = nullptr;
+  FlankDesc* desc = nullptr;
+  char* text = nullptr;
+  uint32_t* nodes = nullptr;   // oriented flank nodes of every gap (written by the look-up kernel)
+  size_t n_desc = 0, n_nodes = 0;
+  bool host_lookup = false;    // flanks too long for the kernel's staging buffer: resolved on the host
   int upload_flanks();
   size_t arena_bytes = 0;
   std::vector<size_t> arena_off;  // of each gap's fill buffer within the batch's share of the arena
@@ -552,7 +580,13 @@ struct g2s_batch {
   };
   std::vector<GapInfo> info;
   void drop_tiers();
-  ~g2s_batch() { if (s) { drop_tiers(); if (s->flank_owner == this) s->flank_owner = nullptr; } }
+  ~g2s_batch() {
+    if (s) {
+      drop_tiers();
+      if (s->flank_owner == this) s->flank_owner = nullptr;
+      if (pin) s->pin_free.push_back(pin);
+    }
+  }
 };
 
 // pinned result buffers are recycled through the session: allocating page-locked memory
@@ -576,50 +610,84 @@ extern "C" int g2s_batch_prepare(g2s_session* s, const g2s_gap* gaps, size_t n, 
   memset(&b->timing, 0, sizeof b->timing);
   b->jobs.resize(n);
   b->flank_off.resize(n);
-  std::vector<uint32_t>& flank_all = b->flank_all;
-  // flank k-mer -> node lookups (33 per gap at -fuz 10) are independent: pool, 64 gaps a task
-  const size_t per_task = 64;
+  b->arena_off.resize(n);
   const int d_err = s->params.d_err;
-  auto do_range = [&](size_t t) {
-    const size_t lo = t * per_task, hi = std::min(n, lo + per_task);
-    for (size_t i = lo; i < hi; i++) {
-      GapJob& j = b->jobs[i];
-      const g2s_gap& in = gaps[i];
-      j.g = in.gap_len;
-      j.lmf = in.lmf;
-      j.rmf = in.rmf;
-      j.skip_if_prev_right_fuz_gt = in.skip_if_prev_right_fuz_gt;
-      // D2: flanks too short would make the reference throw from substr
-      j.bad_flank = !in.left || !in.right || in.lmf < 0 || in.rmf < 0 || in.gap_len < 0 ||
-                    in.left_len < k + in.lmf || in.right_len < k + in.rmf;
-      if (!j.bad_flank) {
-        j.left.assign(in.left, (size_t)in.left_len);
-        j.right.assign(in.right, (size_t)in.right_len);
-        j.flank_nodes.resize((size_t)(j.lmf + 1) + 2 * (size_t)(j.rmf + 1));
-        uint32_t* fn = j.flank_nodes.data();
-        for (int d = 0; d <= j.lmf; d++) *fn++ = g.node_of(j.left.c_str() + d);                       // :995,1083
-        for (int d = 0; d <= j.rmf; d++) *fn++ = g.node_of(j.right.c_str() + (j.right.size() - k - d));  // :878,954
-        for (int d = 0; d <= j.rmf; d++) *fn++ = g.node_of(j.right.c_str() + d);                      // :1113
-      } else {
-        j.lmf = std::max(0, j.lmf);
-        j.rmf = std::max(0, j.rmf);
-        j.g = std::max(0, j.g);
-      }
-    }
-  };
-  const size_t ntasks = (n + per_task - 1) / per_task;
-  if (ntasks > 1) s->pool->run(ntasks, do_range);
-  else if (ntasks == 1) do_range(0);
-  size_t nflank = 0;
-  for (size_t i = 0; i < n; i++) nflank += b->jobs[i].flank_nodes.size();
-  flank_all.reserve(nflank);
+  // ---- sizes: what fill_gap reads of the flanks is the first k+lmf characters of the left one and the
+  // first and last k+rmf of the right one; the k-mer -> node look-ups run on the device (flank_lookup.hip)
+  size_t text_bytes = 0, n_nodes = 0, n_desc = 0;
+  std::vector<uint32_t> text_off(n);
   for (size_t i = 0; i < n; i++) {
-    const GapJob& j = b->jobs[i];
-    if (!j.bad_flank) b->timing.flank_bytes += (uint64_t)(j.left.size() + j.right.size());
-    b->flank_off[i] = (uint32_t)flank_all.size();
-    flank_all.insert(flank_all.end(), j.flank_nodes.begin(), j.flank_nodes.end());
-    b->arena_off.push_back(b->arena_bytes);
+    GapJob& j = b->jobs[i];
+    const g2s_gap& in = gaps[i];
+    j.g = in.gap_len;
+    j.lmf = in.lmf;
+    j.rmf = in.rmf;
+    j.skip_if_prev_right_fuz_gt = in.skip_if_prev_right_fuz_gt;
+    // D2: flanks too short would make the reference throw from substr
+    j.bad_flank = !in.left || !in.right || in.lmf < 0 || in.rmf < 0 || in.gap_len < 0 ||
+                  in.left_len < k + in.lmf || in.right_len < k + in.rmf;
+    b->flank_off[i] = (uint32_t)n_nodes;
+    if (!j.bad_flank) {
+      const size_t tb = (size_t)(k + j.lmf) + 2 * (size_t)(k + j.rmf);
+      if (tb > G2S_FLANK_TEXT_MAX || j.lmf > 65535 || j.rmf > 65535) b->host_lookup = true;
+      text_off[i] = (uint32_t)text_bytes;
+      text_bytes += (tb + 3) & ~(size_t)3;
+      n_nodes += (size_t)(j.lmf + 1) + 2 * (size_t)(j.rmf + 1);
+      n_desc++;
+      b->timing.flank_bytes += (uint64_t)in.left_len + (uint64_t)in.right_len;
+    } else {
+      j.lmf = std::max(0, j.lmf);
+      j.rmf = std::max(0, j.rmf);
+      j.g = std::max(0, j.g);
+    }
+    b->arena_off[i] = b->arena_bytes;
     b->arena_bytes += j.buf_bytes(k, d_err);
+  }
+  if (hipSetDevice(s->device) != hipSuccess) { delete b; return fail(G2S_ERR_NO_DEVICE, "cannot select device"); }
+  if (!s->pin_free.empty()) { b->pin = s->pin_free.back(); s->pin_free.pop_back(); }
+  else b->pin = new PinBuf();
+  const size_t desc_bytes = (n_desc * sizeof(FlankDesc) + 15) & ~(size_t)15;
+  const size_t text_pad = (text_bytes + 16 + 15) & ~(size_t)15;
+  if (b->pin->ensure(desc_bytes + text_pad + n_nodes * 4 + 16) != hipSuccess) { delete b; return fail(G2S_ERR_NOMEM, "pinned flank buffer"); }
+  b->desc = (FlankDesc*)b->pin->p;
+  b->text = (char*)b->pin->p + desc_bytes;
+  b->nodes = (uint32_t*)((char*)b->pin->p + desc_bytes + text_pad);
+  b->n_desc = n_desc;
+  b->n_nodes = n_nodes;
+  // ---- flank text and descriptors into the pinned buffer (long lists: on the pool)
+  {
+    std::vector<uint32_t> didx(n);  // descriptor index of every valid gap
+    uint32_t q = 0;
+    for (size_t i = 0; i < n; i++) didx[i] = b->jobs[i].bad_flank ? 0xFFFFFFFFu : q++;
+    const size_t per_task = 256;
+    auto do_range = [&](size_t t) {
+      const size_t lo = t * per_task, hi = std::min(n, lo + per_task);
+      for (size_t i = lo; i < hi; i++) {
+        GapJob& j = b->jobs[i];
+        j.nodes = b->nodes + b->flank_off[i];
+        if (j.bad_flank) continue;
+        const g2s_gap& in = gaps[i];
+        char* t = b->text + text_off[i];
+        const size_t ll = (size_t)(k + j.lmf), rl2 = (size_t)(k + j.rmf);
+        memcpy(t, in.left, ll);
+        memcpy(t + ll, in.right, rl2);
+        memcpy(t + ll + rl2, in.right + ((size_t)in.right_len - rl2), rl2);
+        FlankDesc& d = b->desc[didx[i]];
+        d.text_off = text_off[i];
+        d.flank_off = b->flank_off[i];
+        d.lmf = (uint16_t)j.lmf;
+        d.rmf = (uint16_t)j.rmf;
+        if (b->host_lookup) {  // node ids on the host (Graph::node_of), uploaded by upload_flanks
+          uint32_t* fn = b->nodes + b->flank_off[i];
+          for (int x = 0; x <= j.lmf; x++) *fn++ = g.node_of(t + x);                          // :995,1083
+          for (int x = 0; x <= j.rmf; x++) *fn++ = g.node_of(t + ll + rl2 + (rl2 - k - x));   // :878,954
+          for (int x = 0; x <= j.rmf; x++) *fn++ = g.node_of(t + ll + x);                     // :1113
+        }
+      }
+    };
+    const size_t ntasks = (n + per_task - 1) / per_task;
+    if (ntasks > 4) s->pool->run(ntasks, do_range);
+    else for (size_t t = 0; t < ntasks; t++) do_range(t);
   }
   const int rc = b->upload_flanks();
   if (rc != G2S_OK) { delete b; return rc; }
@@ -627,15 +695,28 @@ extern "C" int g2s_batch_prepare(g2s_session* s, const g2s_gap* gaps, size_t n, 
   return G2S_OK;
 }
 
-// d_flank belongs to the session; the batch that ran last owns its contents.
+// d_flank belongs to the session; the batch that ran last owns its contents.  The node ids are
+// computed on the session's stream by the look-up kernel (no host synchronisation: the fill
+// kernels follow on the same stream; the host reads them from pinned memory only after a fill
+// kernel has reported gaps as done).
 int g2s_batch::upload_flanks() {
   if (s->flank_owner == this) return G2S_OK;
   if (hipSetDevice(s->device) != hipSuccess) return fail(G2S_ERR_NO_DEVICE, "cannot select device");
-  hipError_t e = s->d_flank.ensure(std::max<size_t>(flank_all.size() * 4, 16));
-  if (e == hipSuccess && !flank_all.empty())
-    e = hipMemcpyAsync(s->d_flank.p, flank_all.data(), flank_all.size() * 4, hipMemcpyHostToDevice, s->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
-  if (e != hipSuccess) return fail(G2S_ERR_HIP, std::string("batch upload: ") + hipGetErrorString(e));
+  hipError_t e = s->d_flank.ensure(std::max<size_t>(n_nodes * 4, 16));
+  if (e == hipSuccess && n_nodes) {
+    if (host_lookup) {
+      e = hipMemcpyAsync(s->d_flank.p, nodes, n_nodes * 4, hipMemcpyHostToDevice, s->stream);
+    } else {
+      void *d_desc = nullptr, *d_text = nullptr, *d_nodes = nullptr;
+      e = hipHostGetDevicePointer(&d_desc, desc, 0);
+      if (e == hipSuccess) e = hipHostGetDevicePointer(&d_text, text, 0);
+      if (e == hipSuccess) e = hipHostGetDevicePointer(&d_nodes, nodes, 0);
+      if (e == hipSuccess)
+        e = launch_resolve_flanks(s->stream, s->lookup, (uint32_t)n_desc, (const FlankDesc*)d_desc, (const char*)d_text,
+                                  (uint32_t*)s->d_flank.p, (uint32_t*)d_nodes);
+    }
+  }
+  if (e != hipSuccess) return fail(G2S_ERR_HIP, std::string("batch flank look-up: ") + hipGetErrorString(e));
   s->flank_owner = this;
   return G2S_OK;
 }
@@ -1044,7 +1125,13 @@ void analyze_gap(g2s_batch* b, size_t i, const FillParams& fp, g2s_result* r) {
   SubPrep& pp = b->prep[i];
   bool analysed = false;
   if (v.segs) {  // segment tier: the analysis runs on the closure segments themselves, O(segments) ...
-    analysed = seg_analyze(fp, j, v, &pp);
+    void* scratch = nullptr;
+    if (b->seg_td) {  // 24 bytes per segment from the launch's shared buffer (no allocation per gap)
+      const size_t need = ((size_t)v.n_segs * 24 + 15) / 16 + 1;
+      const size_t at = b->seg_td->exp_cursor.fetch_add(need);
+      if (at + need <= b->seg_td->exp.size()) scratch = b->seg_td->exp.data() + at;
+    }
+    analysed = seg_analyze(fp, j, v, &pp, scratch);
     if (!analysed) pp = SubPrep();
   }
   if (v.segs && !analysed) {  // ... unless a k-mer occurs at two depths of the closure: per-state records then
@@ -1188,9 +1275,9 @@ int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
       b->tiers.push_back(td);
       td_live = td;
       b->seg_td = td;
-      {  // room for the expanded closures: 4 states per DP level and gap (more falls back to per-gap buffers)
-        size_t want = 0;
-        for (uint32_t i : seg_ids) want += 4u * (size_t)(b->jobs[i].lmf + b->jobs[i].rmf + b->jobs[i].g + fp.d_err + 2);
+      {  // scratch of the per-gap analysis (24 bytes per closure segment; the rare closure with a k-mer at
+         // two depths is expanded into per-state records here too): 1 KB per gap, per-gap buffers beyond
+        const size_t want = seg_ids.size() * 64u + 4096u;
         if (td->exp.size() < want) td->exp.resize(want);
         td->exp_cursor.store(0);
       }
@@ -1842,11 +1929,7 @@ extern "C" int g2s_test_post_gap(const g2s_graph* gh, const g2s_params* p, const
   GapJob j;
   j.g = gap->gap_len; j.lmf = gap->lmf; j.rmf = gap->rmf;
   if (gap->left_len < k + j.lmf || gap->right_len < k + j.rmf) return fail(G2S_ERR_ARG, "flank too short");
-  j.left.assign(gap->left, (size_t)gap->left_len);
-  j.right.assign(gap->right, (size_t)gap->right_len);
-  for (int d = 0; d <= j.lmf; d++) j.flank_nodes.push_back(g.node_of(j.left.c_str() + d));
-  for (int d = 0; d <= j.rmf; d++) j.flank_nodes.push_back(g.node_of(j.right.c_str() + (j.right.size() - k - d)));
-  for (int d = 0; d <= j.rmf; d++) j.flank_nodes.push_back(g.node_of(j.right.c_str() + d));
+  j.resolve_on_host(g, gap->left, (size_t)gap->left_len, gap->right, (size_t)gap->right_len);
   HostTable t;
   t.D = j.lmf + j.rmf + j.g + p->d_err;
   t.lvl.assign((size_t)t.D + 2, 0);
@@ -1924,11 +2007,7 @@ extern "C" int g2s_test_post_closure(const g2s_graph* gh, const g2s_params* p, c
   GapJob j;
   j.g = gap->gap_len; j.lmf = gap->lmf; j.rmf = gap->rmf;
   if (gap->left_len < k + j.lmf || gap->right_len < k + j.rmf) return fail(G2S_ERR_ARG, "flank too short");
-  j.left.assign(gap->left, (size_t)gap->left_len);
-  j.right.assign(gap->right, (size_t)gap->right_len);
-  for (int d = 0; d <= j.lmf; d++) j.flank_nodes.push_back(g.node_of(j.left.c_str() + d));
-  for (int d = 0; d <= j.rmf; d++) j.flank_nodes.push_back(g.node_of(j.right.c_str() + (j.right.size() - k - d)));
-  for (int d = 0; d <= j.rmf; d++) j.flank_nodes.push_back(g.node_of(j.right.c_str() + d));
+  j.resolve_on_host(g, gap->left, (size_t)gap->left_len, gap->right, (size_t)gap->right_len);
   GapOut go;
   memset(&go, 0, sizeof go);
   go.c_count = c_count; go.n_len = n_lengths; go.reached_j = reached_j; go.final_d = final_d;
@@ -1978,11 +2057,7 @@ extern "C" int g2s_test_post_segments(const g2s_graph* gh, const g2s_params* p, 
   GapJob j;
   j.g = gap->gap_len; j.lmf = gap->lmf; j.rmf = gap->rmf;
   if (gap->left_len < k + j.lmf || gap->right_len < k + j.rmf) return fail(G2S_ERR_ARG, "flank too short");
-  j.left.assign(gap->left, (size_t)gap->left_len);
-  j.right.assign(gap->right, (size_t)gap->right_len);
-  for (int d = 0; d <= j.lmf; d++) j.flank_nodes.push_back(g.node_of(j.left.c_str() + d));
-  for (int d = 0; d <= j.rmf; d++) j.flank_nodes.push_back(g.node_of(j.right.c_str() + (j.right.size() - k - d)));
-  for (int d = 0; d <= j.rmf; d++) j.flank_nodes.push_back(g.node_of(j.right.c_str() + d));
+  j.resolve_on_host(g, gap->left, (size_t)gap->left_len, gap->right, (size_t)gap->right_len);
   GapOut go;
   memset(&go, 0, sizeof go);
   go.c_count = c_count; go.n_len = n_lengths; go.reached_j = reached_j; go.final_d = final_d;
@@ -2043,11 +2118,7 @@ extern "C" int g2s_test_seg_expand(const g2s_graph* gh, const g2s_params* p, con
   GapJob j;
   j.g = gap->gap_len; j.lmf = gap->lmf; j.rmf = gap->rmf;
   if (gap->left_len < k + j.lmf || gap->right_len < k + j.rmf) return fail(G2S_ERR_ARG, "flank too short");
-  j.left.assign(gap->left, (size_t)gap->left_len);
-  j.right.assign(gap->right, (size_t)gap->right_len);
-  for (int d = 0; d <= j.lmf; d++) j.flank_nodes.push_back(g.node_of(j.left.c_str() + d));
-  for (int d = 0; d <= j.rmf; d++) j.flank_nodes.push_back(g.node_of(j.right.c_str() + (j.right.size() - k - d)));
-  for (int d = 0; d <= j.rmf; d++) j.flank_nodes.push_back(g.node_of(j.right.c_str() + d));
+  j.resolve_on_host(g, gap->left, (size_t)gap->left_len, gap->right, (size_t)gap->right_len);
   GapOut go;
   memset(&go, 0, sizeof go);
   go.n_len = n_lengths; go.reached_j = reached_j;

@@ -546,8 +546,8 @@ inline bool seg_safe(const SubView& v, const SubPrep& prep, uint32_t i, int t) {
   if (t <= ts) return t <= in.split ? in.safe_a : in.safe_b;
   // a traceback state outside the subgraph: its k-mer may be in the subgraph at another depth
   const uint32_t x = seg_state(s, t) >> 1;
-  const auto& iv = prep.s_iv;
-  size_t lo = 0, hi = iv.size();
+  const std::pair<uint32_t, uint32_t>* iv = prep.s_iv;
+  size_t lo = 0, hi = prep.n_iv;
   while (lo < hi) { const size_t mid = (lo + hi) >> 1; if (iv[mid].first <= x) lo = mid + 1; else hi = mid; }
   if (lo > 0) {
     const uint32_t q = iv[lo - 1].second;
@@ -562,7 +562,7 @@ inline bool seg_safe(const SubView& v, const SubPrep& prep, uint32_t i, int t) {
 
 }  // namespace
 
-bool seg_analyze(const FillParams& p, const GapJob& job, const SubView& v, SubPrep* out) {
+bool seg_analyze(const FillParams& p, const GapJob& job, const SubView& v, SubPrep* out, void* scratch) {
   const GapOut& go = *v.out;
   out->count = go.c_count;
   out->phase_d = go.c_count > 0 && go.n_len > 0;  // :1169
@@ -577,8 +577,12 @@ bool seg_analyze(const FillParams& p, const GapJob& job, const SubView& v, SubPr
   const int lo_sink = std::max(0, lmf + job.g - p.d_err);
   const uint32_t reached = targets[go.reached_j];
   const bool t_is_s = want_s && !p.all_paths;  // -best-only: the traceback starts are the sinks
-  std::vector<SegInfo>& si = out->seg;
-  si.assign(n, SegInfo{-2, -2, 0, 0, 0, 0});
+  if (!scratch) { out->own_seg.resize(3 * (size_t)n + 1); scratch = out->own_seg.data(); }
+  static_assert(sizeof(SegInfo) == 16, "SegInfo layout");
+  SegInfo* si = out->seg = (SegInfo*)scratch;
+  out->s_iv = (std::pair<uint32_t, uint32_t>*)(si + n);
+  out->n_iv = 0;
+  for (uint32_t i = 0; i < n; i++) si[i] = SegInfo{-2, -2, 0, 0, 0, 0};
   static thread_local std::vector<int> sinkpos, outs;
   sinkpos.assign(n, -1);
   // ---- own positions: sinks and traceback starts
@@ -623,8 +627,8 @@ bool seg_analyze(const FillParams& p, const GapJob& job, const SubView& v, SubPr
   if (!want_s) return true;  // no D1/D2 with -all-upper (:1181)
 
   // ---- the S closure: every k-mer at one depth only?  (index intervals must not overlap)
-  auto& iv = out->s_iv;
-  iv.clear();
+  std::pair<uint32_t, uint32_t>* iv = out->s_iv;
+  uint32_t niv = 0;
   uint64_t n_s = 0, edges = 0;
   int count_s = 0, src_out = 0, sink_in = 0;
   outs.assign(n, 0);
@@ -636,7 +640,7 @@ bool seg_analyze(const FillParams& p, const GapJob& job, const SubView& v, SubPr
     if (ts < 0) continue;
     const uint32_t idx = s.node >> 1;
     const uint32_t lo = (s.node & 1u) ? idx - (uint32_t)ts : idx;
-    iv.emplace_back(lo, i);
+    iv[niv++] = std::make_pair(lo, i);
     n_s += (uint64_t)ts + 1;
     edges += (uint64_t)ts;  // interior edges
     if (s.flags & G2S_SUB_SOURCE) { src_out++; edges++; }
@@ -648,8 +652,9 @@ bool seg_analyze(const FillParams& p, const GapJob& job, const SubView& v, SubPr
     }
     if (sinkpos[i] >= 0 && sinkpos[i] <= ts) { sink_in++; edges++; count_s = sat_add(count_s, (int)s.cnt); }
   }
-  std::sort(iv.begin(), iv.end());
-  for (size_t x = 1; x < iv.size(); x++) {
+  out->n_iv = niv;
+  std::sort(iv, iv + niv);
+  for (size_t x = 1; x < niv; x++) {
     const SegRec& a = sg[iv[x - 1].second];
     const uint32_t a_hi = iv[x - 1].first + (uint32_t)(int)(int16_t)(a.ts_tt & 0xFFFFu);
     if (iv[x].first <= a_hi) { out->seg_mode = false; return false; }  // a k-mer at two depths: general path

@@ -21,16 +21,28 @@ namespace g2s {
 
 // One gap as the host keeps it.
 struct GapJob {
-  std::string left, right;
   int g = 0, lmf = 0, rmf = 0;
   int skip_if_prev_right_fuz_gt = -1;
   bool bad_flank = false;
   // oriented node (or kInvalidNode) of: left.substr(d,k) d=0..lmf | right-BFS
-  // seeds right.substr(len-k-j,k) j=0..rmf | targets right.substr(j,k) j=0..rmf
-  std::vector<uint32_t> flank_nodes;
-  const uint32_t* lseeds() const { return flank_nodes.data(); }
-  const uint32_t* rseeds() const { return flank_nodes.data() + (lmf + 1); }
-  const uint32_t* targets() const { return flank_nodes.data() + (lmf + 1) + (rmf + 1); }
+  // seeds right.substr(len-k-j,k) j=0..rmf | targets right.substr(j,k) j=0..rmf.
+  // Not owned: the batch's pinned buffer (written by the flank look-up kernel, flank_lookup.hip)
+  // or, in the test hooks, own_nodes.
+  const uint32_t* nodes = nullptr;
+  std::vector<uint32_t> own_nodes;  // test hooks only
+  const uint32_t* lseeds() const { return nodes; }
+  const uint32_t* rseeds() const { return nodes + (lmf + 1); }
+  const uint32_t* targets() const { return nodes + (lmf + 1) + (rmf + 1); }
+  // (hooks) resolve the flank k-mers of left / right on the host
+  void resolve_on_host(const Graph& gr, const char* left, size_t left_len, const char* right, size_t right_len) {
+    const int k = gr.k;
+    (void)left_len;
+    own_nodes.clear();
+    for (int d = 0; d <= lmf; d++) own_nodes.push_back(gr.node_of(left + d));                        // :995,1083
+    for (int d = 0; d <= rmf; d++) own_nodes.push_back(gr.node_of(right + (right_len - k - d)));     // :878,954
+    for (int d = 0; d <= rmf; d++) own_nodes.push_back(gr.node_of(right + d));                       // :1113
+    nodes = own_nodes.data();
+  }
   size_t buf_bytes(int k, int d_err) const { return (size_t)(g + k + d_err + lmf + rmf + 1 + 2); }
 };
 
@@ -86,8 +98,10 @@ struct SegInfo {
 
 struct SubPrep {
   bool seg_mode = false;  // analysed on the closure SEGMENTS (seg_analyze); st / safe are not used then
-  std::vector<SegInfo> seg;                              // per closure segment
-  std::vector<std::pair<uint32_t, uint32_t>> s_iv;       // S closure as k-mer index intervals (lo, segment), sorted
+  SegInfo* seg = nullptr;                                // per closure segment
+  std::pair<uint32_t, uint32_t>* s_iv = nullptr;         // S closure as k-mer index intervals (lo, segment), sorted
+  uint32_t n_iv = 0;
+  std::vector<uint64_t> own_seg;                         // backing store of the two when the caller gives no scratch
   bool sink_safe = false, has_choice = false;
   int start_seg[2] = {-1, -1}, start_t[2] = {0, 0};
   bool phase_d = false;   // count > 0 && pathLengths non-empty (:1169)
@@ -112,7 +126,8 @@ inline int sub_fixed_draws(const SubView& v, const SubPrep& prep, int pick) {
 // states: nothing to contract, :1314-1435 reduces to the branch rule, which is constant along a
 // segment).  Returns false otherwise: the caller expands the segments (seg_expand) and takes
 // sub_analyze.  seg_traceback / seg_count_draws are sub_traceback / sub_count_draws on segments.
-bool seg_analyze(const FillParams& p, const GapJob& job, const SubView& v, SubPrep* out);
+// `scratch`: 24 bytes per segment, 8-byte aligned, alive as long as *out is used (nullptr: *out allocates).
+bool seg_analyze(const FillParams& p, const GapJob& job, const SubView& v, SubPrep* out, void* scratch = nullptr);
 void seg_traceback(const Graph& g, const FillParams& p, const GapJob& job, const SubView& v, const SubPrep& prep,
                    const uint32_t* rands, char* buf, g2s_result* res);
 int seg_count_draws(const Graph& g, const SubView& v, const SubPrep& prep, const uint32_t* rands);
