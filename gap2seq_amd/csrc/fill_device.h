@@ -97,10 +97,10 @@ struct SegRec {
   uint32_t node;
   uint32_t depth_len;  /* depth | len << 16 */
   uint32_t cnt;
-  uint32_t ts_tt;      /* ts | tt << 16 */
+  uint32_t ts_tt;      /* ts (bits 0-14) | safe_a << 15 | tt << 16 (bits 16-30) | safe_b << 31; 0x7FFF = none */
   uint32_t par01, par23;
   uint32_t flags;      /* G2S_SUB_SOURCE: state 0 is a left-flank k-mer at its offset (not expanded) */
-  uint32_t pad;
+  uint32_t pad;        /* split: states t <= split carry safe_a, the others safe_b (device analysis only) */
 };
 
 struct GapOut {
@@ -123,4 +123,14 @@ struct GapOut {
   // LDS tier statistics: per-level iterations / bulk iterations of phases A, B, D1 and
   // shader cycles (in units of 256) spent in A, B+C, D1
   uint32_t stat[8];
+  // segment tier: phase D2 and the stop-depth analysis done on the device (valid with G2S_DEVA_ANALYSED)
+  int32_t fixed_draws[2];  // rand() draws a traceback from start j consumes, or -1 when that depends on the draws
+  uint32_t start_seg;      // emitted segment of traceback start 0 | start 1 << 16 (0xFFFF none)
+  uint32_t start_t;        // its position inside the segment, same packing
+  uint32_t sub_vertices, sub_edges;  // SubgraphStats of a closure without a repeated k-mer (nothing contracted)
+  int32_t count_s;         // all-paths recount: sum of the counts of the sink states (:1189-1226)
+  uint32_t dflags;
 };
+#define G2S_DEVA_ANALYSED 0x1u   /* D2 (branch rule) done on the device: safe bits in SegRec.ts_tt, split in SegRec.pad */
+#define G2S_DEVA_CHOICE 0x2u     /* some entry of the traceback closure has more than one parent */
+#define G2S_DEVA_SINK_SAFE 0x4u  /* branch[sink] == 1 (Q5: what k-mers outside the subgraph read) */

@@ -64,6 +64,9 @@ __device__ __forceinline__ int seg_pos(uint32_t v0, uint32_t len, uint32_t node)
   const int t = (v0 & 1u) ? -dt : dt;
   return (t >= 0 && (uint32_t)t < len) ? t : -1;
 }
+// ts / tt of a segment are kept in 15 bits each (0x7FFF = none); bits 15 and 31 carry the safe bits
+__device__ __forceinline__ int dec15(uint32_t x) { return (x & 0x7FFFu) == 0x7FFFu ? -1 : (int)(x & 0x7FFFu); }
+__device__ __forceinline__ uint32_t enc15(int t) { return t < 0 ? 0x7FFFu : (uint32_t)t; }
 __device__ __forceinline__ uint32_t wave_sum(uint32_t x) {
   for (int o = 32; o > 0; o >>= 1) x += (uint32_t)__shfl_xor((int)x, o);
   return uni(x);
@@ -355,12 +358,26 @@ __global__ __launch_bounds__(64) void g2s_fill_seg(const uint32_t* __restrict__ 
   uint64_t ev = 0, efx = 0;  // pending events, and which of them have an assigned count (left seeds)
   uint32_t nseg = 0, gen = 0, xb = 0, sb = 0;
   uint32_t best = SEG_INF, c1 = 0, c2 = 0;  // phase C: (found level << 6 | j) and the counts of its two lengths
-  auto add_event = [&](uint32_t w, int dw, uint32_t c, uint32_t par) {
+  // Stop depths of the traceback (:1455-1462): a traceback that passes through an entry stops at one of
+  // the depths of the left-flank k-mers reachable backwards from it.  est = lowest | highest << 16 of
+  // them per pending event: a source entry (depth <= lmf, the left-flank k-mer of that offset) has its
+  // own depth, any other the union over its parents.  (0x7FFF, 0) = no parent yet, (0, 0x7FFF) = unknown;
+  // both never read as "one depth".  s1 / s2 keep the values of the entries behind c1 / c2.
+  uint32_t est = 0x7FFFu, s1 = 0x7FFFu, s2 = 0x7FFFu;
+  auto stop_join = [](uint32_t a, uint32_t b) -> uint32_t { return min(a & 0xFFFFu, b & 0xFFFFu) | (max(a >> 16, b >> 16) << 16); };
+  auto is_source = [&](uint32_t w, int dw) -> bool {  // (wave-uniform) :1270, k-mer comparison only
+    if (dw > lmf) return false;
+    const uint32_t ls = uni(l_seed[dw]);
+    return ls != G2S_DEV_INVALID && (w >> 1) == (ls >> 1);
+  };
+  auto add_event = [&](uint32_t w, int dw, uint32_t c, uint32_t par, uint32_t pstop) {
     const bool valid = (ev >> lane) & 1ull;
     const uint64_t m = __ballot(valid && en == w && ed == dw);
+    const bool src = is_source(w, dw);
     if (m) {
       const int l = __builtin_ctzll(m);
       if (lane == l) {
+        if (!src) est = stop_join(est, pstop);
         ec = min(ec + c, (uint32_t)G2S_DEV_MAX_PATHS);  // saturating add is associative (:1058-1060)
         if ((ep01 >> 16) == SEG_NOPAR) ep01 = (ep01 & 0xFFFFu) | (par << 16);
         else if ((ep23 & 0xFFFFu) == SEG_NOPAR) ep23 = (ep23 & 0xFFFF0000u) | par;
@@ -375,11 +392,12 @@ __global__ __launch_bounds__(64) void g2s_fill_seg(const uint32_t* __restrict__ 
     if (lane == l) {
       en = w; ed = dw; ec = c; ep01 = 0xFFFF0000u | par; ep23 = 0xFFFFFFFFu;
       es = 0u;  // states up to the end of the unitig: loaded with the exit record for all new events at once
+      est = src ? ((uint32_t)dw | ((uint32_t)dw << 16)) : pstop;
     }
     ev |= 1ull << l;
   };
   // phase C: target k-mer j at position t of a segment is a hit at depth + t (lane j holds target j)
-  auto note_hits = [&](uint32_t node, uint32_t L, int depth, uint32_t c) {
+  auto note_hits = [&](uint32_t node, uint32_t L, int depth, uint32_t c, uint32_t st) {
     const int t = seg_pos(node, L, tg);
     for (uint64_t hm = __ballot(t >= 0); hm; hm &= hm - 1) {
       const int j = __builtin_ctzll(hm);
@@ -388,7 +406,7 @@ __global__ __launch_bounds__(64) void g2s_fill_seg(const uint32_t* __restrict__ 
       if (err > gd.e) continue;
       const uint32_t key = ((uint32_t)(err + gd.g + lmf + rmf) << 6) | (uint32_t)j;
       if (key < best) { best = key; c1 = 0; c2 = 0; }
-      if (key == best) { if (td >= base) c1 = c; else c2 = c; }
+      if (key == best) { if (td >= base) { c1 = c; s1 = st; } else { c2 = c; s2 = st; } }
     }
   };
   if (!overflow) {
@@ -401,6 +419,9 @@ __global__ __launch_bounds__(64) void g2s_fill_seg(const uint32_t* __restrict__ 
     // one segment, and the seed at depth lmf as the only pending event, instead of lmf rounds.
     bool chain = lmf >= 1 && s0 != G2S_DEV_INVALID && __ballot(lane <= lmf && sd != seg_node(s0, (uint32_t)lane)) == 0ull;
     if (chain) chain = uni(urec[(size_t)s0 * 8 + 4]) >= (uint32_t)lmf;
+    // (a target k-mer inside the chain could make one of its states a sink or a traceback start: every
+    // state there is a source of its own, which only single-state segments express: the general path then)
+    if (chain) chain = __ballot(seg_pos(s0, (uint32_t)lmf, tg) >= 0) == 0ull;
     if (chain) {
       if (lane == 0) {
         s_node[0] = s0; s_dl[0] = (uint32_t)lmf << 16; s_cnt[0] = 1u; s_p01[0] = s_p23[0] = 0xFFFFFFFFu; s_aux[0] = 0u;
@@ -408,12 +429,11 @@ __global__ __launch_bounds__(64) void g2s_fill_seg(const uint32_t* __restrict__ 
       nseg = 1; gen = 1;
       sb += (uint32_t)lmf;
       xb += (uint32_t)lmf;
-      note_hits(s0, (uint32_t)lmf, 0, 1u);
       ev = efx = 1ull << lmf;
-      if (lane == lmf) { en = sd; ed = lmf; ec = 1; ep01 = 0xFFFF0000u; ep23 = 0xFFFFFFFFu; es = 0u; }
+      if (lane == lmf) { en = sd; ed = lmf; ec = 1; ep01 = 0xFFFF0000u; ep23 = 0xFFFFFFFFu; es = 0u; est = (uint32_t)lmf | ((uint32_t)lmf << 16); }
     } else {
       ev = efx = __ballot(sd != G2S_DEV_INVALID && lane <= D);
-      if ((ev >> lane) & 1ull) { en = sd; ed = lane; ec = 1; ep01 = ep23 = 0xFFFFFFFFu; es = 0u; }
+      if ((ev >> lane) & 1ull) { en = sd; ed = lane; ec = 1; ep01 = ep23 = 0xFFFFFFFFu; es = 0u; est = (uint32_t)lane | ((uint32_t)lane << 16); }
     }
   }
   while (ev && !overflow) {
@@ -439,7 +459,7 @@ __global__ __launch_bounds__(64) void g2s_fill_seg(const uint32_t* __restrict__ 
     // ---- their lengths under the pruning rule, their target hits (one segment at a time, wave-uniform)
     for (uint64_t m = sel; m; m &= m - 1) {
       const int l = __builtin_ctzll(m);
-      const uint32_t node = rl(en, l), lc = rl(lcap, l), c = rl(cnt, l);
+      const uint32_t node = rl(en, l), lc = rl(lcap, l), c = rl(cnt, l), stl = rl(est, l);
       const int depth = (int)rl((uint32_t)ed, l);
       uint32_t L = lc;
       if (lc > 1u && depth + (int)lc - 1 >= gd.prune_from) {  // interior states are entered under :1050
@@ -451,7 +471,7 @@ __global__ __launch_bounds__(64) void g2s_fill_seg(const uint32_t* __restrict__ 
       }
       sb += L;
       xb += min(L, (uint32_t)(D - depth));
-      note_hits(node, L, depth, c);
+      note_hits(node, L, depth, c, stl);
     }
     if (mine) {
       s_node[esid] = en;
@@ -466,16 +486,17 @@ __global__ __launch_bounds__(64) void g2s_fill_seg(const uint32_t* __restrict__ 
     const bool exits = mine && elen == es && ed + (int)elen - 1 < D;
     const uint4 rec = erec;  // elen == lcap == es: the walk reached the node the record belongs to
     const uint32_t xd = (uint32_t)ed + elen;  // depth of the children
+    const uint32_t est_sel = est;             // (add_event below may reuse a selected lane for a new event)
     ev &= ~sel;
     efx &= ~sel;
     for (uint64_t m = __ballot(exits); m && !overflow; m &= m - 1) {
       const int l = __builtin_ctzll(m);
       const int dw = (int)rl(xd, l);
-      const uint32_t c = rl(cnt, l), par = rl(esid, l);
+      const uint32_t c = rl(cnt, l), par = rl(esid, l), pst = rl(est_sel, l);
 #pragma unroll 1
       for (int q = 0; q < 4; q++) {
         const uint32_t w = rl(q == 0 ? rec.x : q == 1 ? rec.y : q == 2 ? rec.z : rec.w, l);
-        if (w != G2S_DEV_INVALID && (dw < gd.prune_from || contains(w >> 1))) add_event(w, dw, c, par);  // :1050
+        if (w != G2S_DEV_INVALID && (dw < gd.prune_from || contains(w >> 1))) add_event(w, dw, c, par, pst);  // :1050
       }
     }
     gen++;
@@ -582,6 +603,8 @@ __global__ __launch_bounds__(64) void g2s_fill_seg(const uint32_t* __restrict__ 
   const int lo_sink = max(0, lmf + gd.g - gd.e);  // :1196
   const uint32_t reached = uni(targets[reached_j]);
   const bool t_is_s = want_s && !gd.all_paths;  // -best-only: the traceback starts are the sinks (:1245-1259)
+  uint32_t start_b0 = SEG_NOPAR, start_b1 = SEG_NOPAR, start_t0 = 0, start_t1 = 0;  // segments and positions of the traceback starts
+  bool choice = false;  // some entry of the traceback closure has more than one parent
   {
     uint32_t hi = nseg;
     while (hi > 0) {
@@ -593,6 +616,8 @@ __global__ __launch_bounds__(64) void g2s_fill_seg(const uint32_t* __restrict__ 
       const uint64_t gm = __ballot(hb && (aux & 0xFFFFu) == gtop);  // segments of one generation are contiguous
       const int first = __builtin_ctzll(gm);
       const bool act = hb && lane >= first;
+      int pstart = -1, jstart = 0;
+      bool multi = false;
       if (act) {
         const uint32_t v0 = s_node[b], dl = s_dl[b];
         const int d0 = (int)(dl & 0xFFFFu);
@@ -602,26 +627,132 @@ __global__ __launch_bounds__(64) void g2s_fill_seg(const uint32_t* __restrict__ 
           const int ps = seg_pos(v0, (uint32_t)len, sinknode);
           if (ps >= 0 && d0 + ps >= lo_sink) ts = ps;
           const int pt = seg_pos(v0, (uint32_t)len, reached);
-          if (pt >= 0 && (d0 + pt == len0 || (n_len > 1 && d0 + pt == len1))) { tt = pt; if (t_is_s) ts = max(ts, pt); }
+          if (pt >= 0 && (d0 + pt == len0 || (n_len > 1 && d0 + pt == len1))) {
+            tt = pt;
+            if (t_is_s) ts = max(ts, pt);
+            pstart = pt;
+            jstart = d0 + pt == len0 ? 0 : 1;
+          }
           if (aux & (G2S_SUB_IN_S << 16)) ts = len - 1;
           if (aux & (G2S_SUB_IN_T << 16)) tt = len - 1;
         }
-        s_t[b] = (uint32_t)(ts & 0xFFFF) | ((uint32_t)(tt & 0xFFFF) << 16);
-        const uint32_t mk = ((ts >= 0 ? G2S_SUB_IN_S : 0u) | (tt >= 0 ? G2S_SUB_IN_T : 0u)) << 16;
-        if (mk && d0 > 0) {
+        s_t[b] = enc15(ts) | (enc15(tt) << 16);
+        // marks for the parents; a parent also counts its children on paths to a sink (bits 20..22: the
+        // out-degree of its last state in the subgraph, for the branch rule below)
+        const uint32_t mk = (((ts >= 0 ? G2S_SUB_IN_S : 0u) | (tt >= 0 ? G2S_SUB_IN_T : 0u)) << 16) | (ts >= 0 ? (1u << 20) : 0u);
+        if ((mk & 0x30000u) && d0 > 0) {
           const uint32_t ls = d0 <= lmf ? l_seed[d0] : G2S_DEV_INVALID;
           const bool source = ls != G2S_DEV_INVALID && (v0 >> 1) == (ls >> 1);  // :1270, k-mer comparison only
           if (!source) {
             const uint32_t p01 = s_p01[b], p23 = s_p23[b];
-            if ((p01 & 0xFFFFu) != SEG_NOPAR) atomicOr(&s_aux[p01 & 0xFFFFu], mk);
-            if ((p01 >> 16) != SEG_NOPAR) atomicOr(&s_aux[p01 >> 16], mk);
-            if ((p23 & 0xFFFFu) != SEG_NOPAR) atomicOr(&s_aux[p23 & 0xFFFFu], mk);
-            if ((p23 >> 16) != SEG_NOPAR) atomicOr(&s_aux[p23 >> 16], mk);
+            if ((p01 & 0xFFFFu) != SEG_NOPAR) atomicAdd(&s_aux[p01 & 0xFFFFu], mk & ~0x30000u), atomicOr(&s_aux[p01 & 0xFFFFu], mk & 0x30000u);
+            if ((p01 >> 16) != SEG_NOPAR) atomicAdd(&s_aux[p01 >> 16], mk & ~0x30000u), atomicOr(&s_aux[p01 >> 16], mk & 0x30000u);
+            if ((p23 & 0xFFFFu) != SEG_NOPAR) atomicAdd(&s_aux[p23 & 0xFFFFu], mk & ~0x30000u), atomicOr(&s_aux[p23 & 0xFFFFu], mk & 0x30000u);
+            if ((p23 >> 16) != SEG_NOPAR) atomicAdd(&s_aux[p23 >> 16], mk & ~0x30000u), atomicOr(&s_aux[p23 >> 16], mk & 0x30000u);
+            multi = tt >= 0 && (p01 >> 16) != SEG_NOPAR;
           }
         }
       }
+      if (__ballot(multi)) choice = true;
+      for (uint64_t sm = __ballot(pstart >= 0); sm; sm &= sm - 1) {  // (state (reached, len_j) is unique)
+        const int l = __builtin_ctzll(sm);
+        if (rl((uint32_t)jstart, l) == 0u) { start_b0 = lo + (uint32_t)l; start_t0 = rl((uint32_t)pstart, l); }
+        else { start_b1 = lo + (uint32_t)l; start_t1 = rl((uint32_t)pstart, l); }
+      }
       lds_sync();
       hi = lo + (uint32_t)first;
+    }
+  }
+  // ---------------- phase D2 for closures without a repeated k-mer (:1314-1435) -----------------
+  // When every k-mer occurs at one depth of the S closure the subgraph is a DAG whose vertices are
+  // the states: nothing to contract, and the branch rule (:1411-1434: walk the vertices in
+  // topological order with a running count, -(in-1) before a vertex, +(out-1) after it; safe <=> the
+  // count is 1 at the vertex) only moves at a segment's entry, at a sink inside it and at its last
+  // state.  Ascending segment id is a topological order (parents were created first), so the count
+  // in front of every segment is a prefix sum.  Otherwise (overlapping index intervals, or more
+  // segments than the pairwise check is worth) the host analyses the gap (post.cpp).
+  bool analysed = false, sink_safe = false;
+  uint32_t sub_vertices = 0, sub_edges = 0;
+  int count_s = 0;
+  if (want_s && nseg <= 192u) {
+    uint32_t n_s = 0, edges = 0, src_out = 0, sink_in = 0;
+    bool dag = true;
+    for (uint32_t b0 = 0; b0 < nseg; b0 += 64u) {  // totals, and no two S intervals may overlap
+      const uint32_t b = b0 + (uint32_t)lane;
+      const bool hb = b < nseg;
+      const uint32_t st = hb ? s_t[b] : 0x7FFF7FFFu;
+      const int ts = dec15(st);
+      const bool in_s = ts >= 0;
+      const uint32_t v0 = hb ? s_node[b] : 0u, dl = hb ? s_dl[b] : 0u;
+      const int d0 = (int)(dl & 0xFFFFu);
+      const int len = max(0, min((int)(dl >> 16), d_last - d0 + 1));
+      const uint32_t ls = (hb && d0 <= lmf) ? l_seed[d0] : G2S_DEV_INVALID;
+      const bool source = ls != G2S_DEV_INVALID && (v0 >> 1) == (ls >> 1);
+      const uint32_t p01 = hb ? s_p01[b] : 0xFFFFFFFFu, p23 = hb ? s_p23[b] : 0xFFFFFFFFu;
+      const uint32_t npar = ((p01 & 0xFFFFu) != SEG_NOPAR) + ((p01 >> 16) != SEG_NOPAR) + ((p23 & 0xFFFFu) != SEG_NOPAR) + ((p23 >> 16) != SEG_NOPAR);
+      int sp = -1;
+      if (in_s) {
+        const int pk = seg_pos(v0, (uint32_t)len, sinknode);
+        if (pk >= 0 && d0 + pk >= lo_sink) sp = pk;
+        if (t_is_s) { const int pt = seg_pos(v0, (uint32_t)len, reached); if (pt >= 0 && (d0 + pt == len0 || (n_len > 1 && d0 + pt == len1))) sp = pt; }
+        if (sp > ts) sp = -1;
+      }
+      n_s += wave_sum(in_s ? (uint32_t)ts + 1u : 0u);
+      edges += wave_sum(in_s ? (uint32_t)ts + (source ? 1u : (d0 > 0 ? npar : 0u)) + (sp >= 0 ? 1u : 0u) : 0u);
+      src_out += (uint32_t)__popcll(__ballot(in_s && source));
+      sink_in += (uint32_t)__popcll(__ballot(sp >= 0));
+      for (uint64_t m = __ballot(sp >= 0); m; m &= m - 1)
+        count_s = (int)min((uint32_t)count_s + rl(hb ? s_cnt[b] : 0u, __builtin_ctzll(m)), (uint32_t)G2S_DEV_MAX_PATHS);
+      const uint32_t idx = v0 >> 1;
+      const uint32_t ilo = (v0 & 1u) ? idx - (uint32_t)max(ts, 0) : idx, ihi = (v0 & 1u) ? idx : idx + (uint32_t)max(ts, 0);
+      for (uint32_t a = 0; a < nseg && dag; a++) {
+        const uint32_t sta = uni(s_t[a]);
+        const int tsa = dec15(sta);
+        if (tsa < 0) continue;
+        const uint32_t va = uni(s_node[a]), ia = va >> 1;
+        const uint32_t alo_ = (va & 1u) ? ia - (uint32_t)tsa : ia, ahi_ = (va & 1u) ? ia : ia + (uint32_t)tsa;
+        if (__ballot(in_s && b > a && ilo <= ahi_ && alo_ <= ihi)) dag = false;
+      }
+    }
+    if (dag) {
+      int bc = 1 + (src_out > 1u ? (int)src_out - 1 : 0);  // the source pseudo-vertex comes first
+      for (uint32_t b0 = 0; b0 < nseg; b0 += 64u) {
+        const uint32_t b = b0 + (uint32_t)lane;
+        const bool hb = b < nseg;
+        const uint32_t st = hb ? s_t[b] : 0x7FFF7FFFu;
+        const int ts = dec15(st);
+        const bool in_s = ts >= 0;
+        const uint32_t v0 = hb ? s_node[b] : 0u, dl = hb ? s_dl[b] : 0u;
+        const int d0 = (int)(dl & 0xFFFFu);
+        const int len = max(0, min((int)(dl >> 16), d_last - d0 + 1));
+        const uint32_t ls = (hb && d0 <= lmf) ? l_seed[d0] : G2S_DEV_INVALID;
+        const bool source = ls != G2S_DEV_INVALID && (v0 >> 1) == (ls >> 1);
+        const uint32_t p01 = hb ? s_p01[b] : 0xFFFFFFFFu, p23 = hb ? s_p23[b] : 0xFFFFFFFFu;
+        const int npar = ((p01 & 0xFFFFu) != SEG_NOPAR) + ((p01 >> 16) != SEG_NOPAR) + ((p23 & 0xFFFFu) != SEG_NOPAR) + ((p23 >> 16) != SEG_NOPAR);
+        int sp = -1;
+        if (in_s) {
+          const int pk = seg_pos(v0, (uint32_t)len, sinknode);
+          if (pk >= 0 && d0 + pk >= lo_sink) sp = pk;
+          if (t_is_s) { const int pt = seg_pos(v0, (uint32_t)len, reached); if (pt >= 0 && (d0 + pt == len0 || (n_len > 1 && d0 + pt == len1))) sp = pt; }
+          if (sp > ts) sp = -1;
+        }
+        const int din = source ? 1 : npar;
+        const int outs = hb ? (int)((s_aux[b] >> 20) & 7u) : 0;
+        const int d_in = (in_s && din > 1) ? -(din - 1) : 0;
+        const int d_mid = (in_s && sp >= 0 && sp < ts) ? 1 : 0;  // out-degree 2: the next state and the sink
+        const int dout = in_s ? (ts == len - 1 ? outs : 0) + (sp == ts ? 1 : 0) : 0;
+        const int d_out = dout > 1 ? dout - 1 : 0;
+        const int total = d_in + d_mid + d_out;
+        const int incl = (int)wave_scan((uint32_t)total, lane);
+        const int at_entry = bc + incl - total + d_in;
+        if (in_s) s_t[b] = st | (at_entry == 1 ? 0x8000u : 0u) | ((at_entry + d_mid == 1) ? 0x80000000u : 0u);
+        bc += (int)rl((uint32_t)incl, 63);
+      }
+      if (sink_in >= 1u) { if (sink_in > 1u) bc -= (int)sink_in - 1; sink_safe = bc == 1; }
+      analysed = true;
+      sub_vertices = n_s + 2u;
+      sub_edges = edges;
+      lds_sync();
     }
   }
   // ---- the closure leaves as SEGMENTS (32 bytes each, SegRec), children before parents = descending
@@ -633,8 +764,8 @@ __global__ __launch_bounds__(64) void g2s_fill_seg(const uint32_t* __restrict__ 
   for (uint32_t top = nseg; top > 0; top = top > 64u ? top - 64u : 0u) {
     const bool hb = (uint32_t)lane < top;
     const uint32_t b = hb ? top - 1u - (uint32_t)lane : 0u;
-    const uint32_t st = hb ? s_t[b] : 0xFFFFFFFFu;
-    const int ts = (int)(int16_t)(st & 0xFFFFu), tt = (int)(int16_t)(st >> 16);
+    const uint32_t st = hb ? s_t[b] : 0x7FFF7FFFu;
+    const int ts = dec15(st), tt = dec15(st >> 16);
     const bool in = max(ts, tt) >= 0;
     const uint64_t m = __ballot(in);
     if (in) s_aux[b] = nrec + (uint32_t)__popcll(m & below(lane));
@@ -658,11 +789,20 @@ __global__ __launch_bounds__(64) void g2s_fill_seg(const uint32_t* __restrict__ 
       const uint32_t b = b0 + (uint32_t)lane;
       if (b >= nseg) continue;
       const uint32_t st = s_t[b];
-      const int ts = (int)(int16_t)(st & 0xFFFFu), tt = (int)(int16_t)(st >> 16);
+      const int ts = dec15(st), tt = dec15(st >> 16);
       if (max(ts, tt) < 0) continue;
       const uint32_t dl = s_dl[b];
       const int d0 = (int)(dl & 0xFFFFu);
       const uint32_t v0 = s_node[b];
+      int split = ts;  // states t <= split carry safe bit a, the others b: a sink inside the S part
+      if (analysed && ts >= 0) {
+        const int len = max(0, min((int)(dl >> 16), d_last - d0 + 1));
+        int sp = -1;
+        const int pk = seg_pos(v0, (uint32_t)len, sinknode);
+        if (pk >= 0 && d0 + pk >= lo_sink) sp = pk;
+        if (t_is_s) { const int pt = seg_pos(v0, (uint32_t)len, reached); if (pt >= 0 && (d0 + pt == len0 || (n_len > 1 && d0 + pt == len1))) sp = pt; }
+        if (sp >= 0 && sp < ts) split = sp;
+      }
       const uint32_t ls = d0 <= lmf ? l_seed[d0] : G2S_DEV_INVALID;
       const bool source = ls != G2S_DEV_INVALID && (v0 >> 1) == (ls >> 1);  // :1270, k-mer comparison only
       SegRec r;
@@ -672,7 +812,7 @@ __global__ __launch_bounds__(64) void g2s_fill_seg(const uint32_t* __restrict__ 
       r.ts_tt = st;
       r.par01 = r.par23 = 0xFFFFFFFFu;
       r.flags = source ? G2S_SUB_SOURCE : 0u;
-      r.pad = 0;
+      r.pad = (uint32_t)max(split, 0);
       if (!source && d0 > 0) {  // parents as indices among the emitted segments (they are all in the closure)
         const uint32_t p01 = s_p01[b], p23 = s_p23[b];
         const uint32_t ps[4] = {p01 & 0xFFFFu, p01 >> 16, p23 & 0xFFFFu, p23 >> 16};
@@ -690,6 +830,17 @@ __global__ __launch_bounds__(64) void g2s_fill_seg(const uint32_t* __restrict__ 
     nxp = wave_sum(nxp);
   }
   if (lane == 0) {
+    // a traceback from start j consumes 1 + (length - stop depth) draws whenever every path back from it
+    // stops at one depth (s1 / s2: lowest | highest << 16 stop depth behind the hits of phase C)
+    const uint32_t sa = c1 > 0 ? s1 : s2, sb2 = s2;
+    go->fixed_draws[0] = ((sa & 0xFFFFu) == (sa >> 16)) ? 1 + len0 - (int)(sa & 0xFFFFu) : -1;
+    go->fixed_draws[1] = (n_len > 1 && (sb2 & 0xFFFFu) == (sb2 >> 16)) ? 1 + len1 - (int)(sb2 & 0xFFFFu) : -1;
+    go->start_seg = (start_b0 != SEG_NOPAR ? s_aux[start_b0] : 0xFFFFu) | ((start_b1 != SEG_NOPAR ? s_aux[start_b1] : 0xFFFFu) << 16);
+    go->start_t = start_t0 | (start_t1 << 16);
+    go->sub_vertices = sub_vertices;
+    go->sub_edges = sub_edges;
+    go->count_s = count_s;
+    go->dflags = (analysed || !want_s ? G2S_DEVA_ANALYSED : 0u) | (choice ? G2S_DEVA_CHOICE : 0u) | (sink_safe ? G2S_DEVA_SINK_SAFE : 0u);
     go->flags = flags | G2S_DEV_COMPACT;
     go->n_sub = nsub;
     go->n_xp = nxp;

@@ -629,7 +629,7 @@ extern "C" int g2s_batch_prepare(g2s_session* s, const g2s_gap* gaps, size_t n, 
     b->flank_off[i] = (uint32_t)n_nodes;
     if (!j.bad_flank) {
       const size_t tb = (size_t)(k + j.lmf) + 2 * (size_t)(k + j.rmf);
-      if (tb > G2S_FLANK_TEXT_MAX || j.lmf > 65535 || j.rmf > 65535) b->host_lookup = true;
+      if (tb > G2S_FLANK_TEXT_MAX || j.lmf > 65535 || j.rmf > 65535 || getenv("G2S_HOST_LOOKUP")) b->host_lookup = true;
       text_off[i] = (uint32_t)text_bytes;
       text_bytes += (tb + 3) & ~(size_t)3;
       n_nodes += (size_t)(j.lmf + 1) + 2 * (size_t)(j.rmf + 1);
@@ -1124,7 +1124,30 @@ void analyze_gap(g2s_batch* b, size_t i, const FillParams& fp, g2s_result* r) {
   SubView& v = b->views[i];
   SubPrep& pp = b->prep[i];
   bool analysed = false;
-  if (v.segs) {  // segment tier: the analysis runs on the closure segments themselves, O(segments) ...
+  if (v.segs && (v.out->dflags & G2S_DEVA_ANALYSED) && !getenv("G2S_HOST_D2")) {
+    // segment tier, phase D2 and the stop depths done on the device: nothing per segment is left to do
+    const GapOut& go = *v.out;
+    pp.seg_mode = true;
+    pp.count = go.c_count;
+    pp.phase_d = go.c_count > 0 && go.n_len > 0;  // :1169
+    if (pp.phase_d) {
+      if (!fp.skip_confident) {
+        if (fp.all_paths) pp.count = go.count_s;  // the recount (:1189-1191)
+        pp.sub[0] = go.sub_vertices; pp.sub[1] = go.sub_edges; pp.sub[2] = 0; pp.sub[3] = 0;
+        pp.sub[4] = go.sub_vertices; pp.sub[5] = go.sub_edges;
+      }
+      pp.sink_safe = (go.dflags & G2S_DEVA_SINK_SAFE) != 0;
+      pp.has_choice = (go.dflags & G2S_DEVA_CHOICE) != 0;
+      for (int q = 0; q < 2; q++) {
+        const uint32_t sg = (go.start_seg >> (16 * q)) & 0xFFFFu;
+        pp.start_seg[q] = sg == 0xFFFFu ? -1 : (int)sg;
+        pp.start_t[q] = (int)((go.start_t >> (16 * q)) & 0xFFFFu);
+        const int fd = go.fixed_draws[q];
+        pp.stop_depth[q] = (q < go.n_len && fd >= 0) ? go.len[q] + 1 - fd : -1;
+      }
+    }
+    analysed = true;
+  } else if (v.segs) {  // segment tier: the analysis runs on the closure segments themselves, O(segments) ...
     void* scratch = nullptr;
     if (b->seg_td) {  // 24 bytes per segment from the launch's shared buffer (no allocation per gap)
       const size_t need = ((size_t)v.n_segs * 24 + 15) / 16 + 1;

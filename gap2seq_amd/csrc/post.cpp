@@ -121,7 +121,7 @@ void seg_expand(const FillParams& p, const GapJob& job, const GapOut& go, const 
   for (uint32_t i = 0; i < n_segs; i++) {
     const SegRec& s = segs[i];
     const int d0 = (int)(s.depth_len & 0xFFFFu), len = (int)(s.depth_len >> 16);
-    const int ts = (int)(int16_t)(s.ts_tt & 0xFFFFu), tt = (int)(int16_t)(s.ts_tt >> 16);
+    const int ts = seg_ts(s), tt = seg_tt(s);
     const bool up = (s.node & 1u) == 0;
     SubRec* o = out + base[i];
     for (int t = len - 1; t >= 0; t--, o++) {
@@ -541,21 +541,35 @@ inline int seg_parents(const SegRec& s, uint32_t out[4]) {
 // safe bit of state t of segment i (:1466; k-mers outside the subgraph read branch[sink], Q5)
 inline bool seg_safe(const SubView& v, const SubPrep& prep, uint32_t i, int t) {
   const SegRec& s = v.segs[i];
-  const int ts = (int)(int16_t)(s.ts_tt & 0xFFFFu);
-  const SegInfo& in = prep.seg[i];
-  if (t <= ts) return t <= in.split ? in.safe_a : in.safe_b;
+  const int ts = seg_ts(s);
+  // the branch rule's verdict for state tq of segment q: from the host analysis (prep.seg) or, when
+  // phase D2 ran on the device, from the bits it left in the record
+  auto verdict = [&](uint32_t q, int tq) -> bool {
+    if (prep.seg) return tq <= prep.seg[q].split ? prep.seg[q].safe_a : prep.seg[q].safe_b;
+    const SegRec& o = v.segs[q];
+    return tq <= (int)o.pad ? (o.ts_tt & 0x8000u) != 0 : (o.ts_tt & 0x80000000u) != 0;
+  };
+  if (t <= ts) return verdict(i, t);
   // a traceback state outside the subgraph: its k-mer may be in the subgraph at another depth
   const uint32_t x = seg_state(s, t) >> 1;
-  const std::pair<uint32_t, uint32_t>* iv = prep.s_iv;
-  size_t lo = 0, hi = prep.n_iv;
-  while (lo < hi) { const size_t mid = (lo + hi) >> 1; if (iv[mid].first <= x) lo = mid + 1; else hi = mid; }
-  if (lo > 0) {
-    const uint32_t q = iv[lo - 1].second;
-    const SegRec& o = v.segs[q];
-    const int ots = (int)(int16_t)(o.ts_tt & 0xFFFFu);
-    const uint32_t oidx = o.node >> 1;
-    const int tq = (o.node & 1u) ? (int)oidx - (int)x : (int)x - (int)oidx;
-    if (tq >= 0 && tq <= ots) return tq <= prep.seg[q].split ? prep.seg[q].safe_a : prep.seg[q].safe_b;
+  if (prep.s_iv) {
+    const std::pair<uint32_t, uint32_t>* iv = prep.s_iv;
+    size_t lo = 0, hi = prep.n_iv;
+    while (lo < hi) { const size_t mid = (lo + hi) >> 1; if (iv[mid].first <= x) lo = mid + 1; else hi = mid; }
+    if (lo > 0) {
+      const uint32_t q = iv[lo - 1].second;
+      const SegRec& o = v.segs[q];
+      const uint32_t oidx = o.node >> 1;
+      const int tq = (o.node & 1u) ? (int)oidx - (int)x : (int)x - (int)oidx;
+      if (tq >= 0 && tq <= seg_ts(o)) return verdict(q, tq);
+    }
+  } else {  // (device analysis keeps no index of the intervals: such states are rare, scan)
+    for (uint32_t q = 0; q < v.n_segs; q++) {
+      const SegRec& o = v.segs[q];
+      const uint32_t oidx = o.node >> 1;
+      const int tq = (o.node & 1u) ? (int)oidx - (int)x : (int)x - (int)oidx;
+      if (tq >= 0 && tq <= seg_ts(o)) return verdict(q, tq);
+    }
   }
   return prep.sink_safe;
 }
@@ -605,7 +619,7 @@ bool seg_analyze(const FillParams& p, const GapJob& job, const SubView& v, SubPr
   // ---- stop depths of the traceback closure, parents first (= descending index)
   for (int64_t i = (int64_t)n - 1; i >= 0; i--) {
     const SegRec& s = sg[i];
-    const int tt = (int)(int16_t)(s.ts_tt >> 16);
+    const int tt = seg_tt(s);
     if (tt < 0) continue;
     const int d0 = (int)(s.depth_len & 0xFFFFu);
     if (s.flags & G2S_SUB_SOURCE) { si[i].lo = si[i].hi = d0; continue; }  // :1455-1462
@@ -636,7 +650,7 @@ bool seg_analyze(const FillParams& p, const GapJob& job, const SubView& v, SubPr
   hi_of.clear();
   for (uint32_t i = 0; i < n; i++) {
     const SegRec& s = sg[i];
-    const int ts = (int)(int16_t)(s.ts_tt & 0xFFFFu);
+    const int ts = seg_ts(s);
     if (ts < 0) continue;
     const uint32_t idx = s.node >> 1;
     const uint32_t lo = (s.node & 1u) ? idx - (uint32_t)ts : idx;
@@ -656,7 +670,7 @@ bool seg_analyze(const FillParams& p, const GapJob& job, const SubView& v, SubPr
   std::sort(iv, iv + niv);
   for (size_t x = 1; x < niv; x++) {
     const SegRec& a = sg[iv[x - 1].second];
-    const uint32_t a_hi = iv[x - 1].first + (uint32_t)(int)(int16_t)(a.ts_tt & 0xFFFFu);
+    const uint32_t a_hi = iv[x - 1].first + (uint32_t)seg_ts(a);
     if (iv[x].first <= a_hi) { out->seg_mode = false; return false; }  // a k-mer at two depths: general path
   }
   if (p.all_paths) out->count = count_s;
@@ -668,7 +682,7 @@ bool seg_analyze(const FillParams& p, const GapJob& job, const SubView& v, SubPr
   if (src_out > 1) bc += src_out - 1;  // the source pseudo-vertex comes first
   for (int64_t i = (int64_t)n - 1; i >= 0; i--) {
     const SegRec& s = sg[i];
-    const int ts = (int)(int16_t)(s.ts_tt & 0xFFFFu);
+    const int ts = seg_ts(s);
     if (ts < 0) continue;
     const int len = (int)(s.depth_len >> 16);
     const int din = (s.flags & G2S_SUB_SOURCE) ? 1 : (int)si[i].npar;
@@ -708,16 +722,18 @@ void seg_traceback(const Graph& g, const FillParams& p, const GapJob& job, const
     // ---- the states t, t-1, ..., 1 of this segment: one choice each (still drawn, :1513), written
     // in runs that share their safe bit (:1466-1468); state 0 is left for the parent choice below
     if (t > 0) {
-      const int ts = (int)(int16_t)(s.ts_tt & 0xFFFFu);
-      const int split = p.skip_confident ? t : (int)prep.seg[(size_t)i].split;
+      const int ts = seg_ts(s);
+      const int split = p.skip_confident ? t : (prep.seg ? (int)prep.seg[(size_t)i].split : (int)s.pad);
+      const bool sfa = prep.seg ? prep.seg[(size_t)i].safe_a != 0 : (s.ts_tt & 0x8000u) != 0;
+      const bool sfb = prep.seg ? prep.seg[(size_t)i].safe_b != 0 : (s.ts_tt & 0x80000000u) != 0;
       int pos = t;
       while (pos > 0) {
         int lo_run;  // the run is [lo_run, pos]
         bool sf;
         if (p.skip_confident) { lo_run = 1; sf = true; }
         else if (pos > ts) { lo_run = pos; sf = seg_safe(v, prep, (uint32_t)i, pos); }  // outside the subgraph (Q5): state by state
-        else if (pos > split) { lo_run = std::max(1, split + 1); sf = prep.seg[(size_t)i].safe_b; }
-        else { lo_run = 1; sf = prep.seg[(size_t)i].safe_a; }
+        else if (pos > split) { lo_run = std::max(1, split + 1); sf = sfb; }
+        else { lo_run = 1; sf = sfa; }
         const bool up = (s.node & 1u) == 0;
         uint32_t node = up ? s.node + 2u * (uint32_t)pos : s.node - 2u * (uint32_t)pos;
         char* o = buf + (d0 + pos - 1);

@@ -67,6 +67,9 @@ struct SubView {
 // entry.  out needs go.n_sub records, xp go.n_xp entries.
 void seg_expand(const FillParams& p, const GapJob& job, const GapOut& go, const SegRec* segs, uint32_t n_segs,
                 SubRec* out, uint64_t* xp);
+// ts / tt of a closure segment: 15 bits each, 0x7FFF = none (bits 15 / 31 are the device's safe bits)
+inline int seg_ts(const SegRec& s) { return (s.ts_tt & 0x7FFFu) == 0x7FFFu ? -1 : (int)(s.ts_tt & 0x7FFFu); }
+inline int seg_tt(const SegRec& s) { return ((s.ts_tt >> 16) & 0x7FFFu) == 0x7FFFu ? -1 : (int)((s.ts_tt >> 16) & 0x7FFFu); }
 inline uint32_t sub_depth(const SubRec& s) { return s.meta & G2S_SUB_META_DEPTH_MASK; }
 inline uint32_t sub_flags(const SubRec& s) { return s.meta >> G2S_SUB_META_FLAG_SHIFT; }
 // the parents of state i (a set, at most 4); returns how many

@@ -148,7 +148,8 @@ def fill_model(tb, gap, rs=None, stats=None):
     gen = 0
     s0 = gap.lseeds[0]
     chain = (lmf >= 1 and s0 != INVALID and all(gap.lseeds[d] == seg_node(s0, d) for d in range(lmf + 1))
-             and int(tb.rem[s0]) >= lmf)
+             and int(tb.rem[s0]) >= lmf
+             and all(seg_pos(s0, lmf, t) < 0 for t in gap.targets))  # (no sink / traceback start inside the chain)
     if chain:
         # the usual flank: seed d is the d-th node after seed 0 inside one unitig.  Levels 0 .. lmf-1 are
         # that chain with count 1: one segment, and the seed at depth lmf as the only pending event
@@ -338,7 +339,8 @@ def fill_model(tb, gap, rs=None, stats=None):
             for q, pp in enumerate(sorted(set(parents))):
                 ps[q] = index[pp]
         res.compact.append((v0, d0 | ((max(t_s[sid], t_t[sid]) + 1) << 16), min(cnt, MAX_PATHS),
-                            (t_s[sid] & 0xFFFF) | ((t_t[sid] & 0xFFFF) << 16), ps[0] | (ps[1] << 16), ps[2] | (ps[3] << 16),
+                            (t_s[sid] if t_s[sid] >= 0 else 0x7FFF) | ((t_t[sid] if t_t[sid] >= 0 else 0x7FFF) << 16),
+                            ps[0] | (ps[1] << 16), ps[2] | (ps[3] << 16),
                             SUB_SOURCE if src else 0, 0))
     if stats is not None:
         stats.append((rounds, len(segs), n_gen))
