@@ -703,15 +703,26 @@ __global__ __launch_bounds__(64) void g2s_fill_seg(const uint32_t* __restrict__ 
       sink_in += (uint32_t)__popcll(__ballot(sp >= 0));
       for (uint64_t m = __ballot(sp >= 0); m; m &= m - 1)
         count_s = (int)min((uint32_t)count_s + rl(hb ? s_cnt[b] : 0u, __builtin_ctzll(m)), (uint32_t)G2S_DEV_MAX_PATHS);
+      // no two S intervals may overlap: this chunk against itself and the chunks before it, both sides
+      // in registers (a pass over LDS per pair of segments was 15 % of the kernel)
       const uint32_t idx = v0 >> 1;
       const uint32_t ilo = (v0 & 1u) ? idx - (uint32_t)max(ts, 0) : idx, ihi = (v0 & 1u) ? idx : idx + (uint32_t)max(ts, 0);
-      for (uint32_t a = 0; a < nseg && dag; a++) {
-        const uint32_t sta = uni(s_t[a]);
-        const int tsa = dec15(sta);
-        if (tsa < 0) continue;
-        const uint32_t va = uni(s_node[a]), ia = va >> 1;
-        const uint32_t alo_ = (va & 1u) ? ia - (uint32_t)tsa : ia, ahi_ = (va & 1u) ? ia : ia + (uint32_t)tsa;
-        if (__ballot(in_s && b > a && ilo <= ahi_ && alo_ <= ihi)) dag = false;
+      for (uint32_t a0 = 0; a0 <= b0 && dag; a0 += 64u) {
+        uint32_t alo_ = ilo, ahi_ = ihi;
+        bool a_in = in_s;
+        if (a0 != b0) {
+          const uint32_t a = a0 + (uint32_t)lane;  // (a < nseg: an earlier chunk is full)
+          const int tsa = dec15(s_t[a]);
+          const uint32_t va = s_node[a], ia = va >> 1;
+          a_in = tsa >= 0;
+          alo_ = (va & 1u) ? ia - (uint32_t)max(tsa, 0) : ia;
+          ahi_ = (va & 1u) ? ia : ia + (uint32_t)max(tsa, 0);
+        }
+        for (uint64_t am = __ballot(a_in); am && dag; am &= am - 1) {
+          const int al = __builtin_ctzll(am);
+          const uint32_t lo_a = rl(alo_, al), hi_a = rl(ahi_, al);
+          if (__ballot(in_s && b > a0 + (uint32_t)al && ilo <= hi_a && lo_a <= ihi)) dag = false;
+        }
       }
     }
     if (dag) {

@@ -973,7 +973,11 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
       std::atomic_thread_fence(std::memory_order_acquire);
       const bool finished = hipEventQuery(s->ev[2]) != hipErrorNotReady;
       if (finished) { while (seen < total && done[seen] != 0xFFFFFFFFu) seen++; }
-      if ((given == 0 && total >= 128 && seen * 2 >= total && seen < total) || seen == total || (finished && seen > given)) {
+      // short lists: whatever has arrived is analysed at once on this thread (a gap whose phase D2 ran on
+      // the device costs a fraction of a microsecond here), so that only the last gaps are left
+      // when the kernel ends; long lists: two hand-overs to the pool
+      if ((total <= 2048 && seen > given) ||
+          (given == 0 && total >= 128 && seen * 2 >= total && seen < total) || seen == total || (finished && seen > given)) {
         (*on_done)((const uint32_t*)td->done.p + given, seen - given);
         given = seen;
       } else if (finished) {
@@ -1213,6 +1217,7 @@ int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
   auto t_begin = std::chrono::steady_clock::now();
   { const int rc = b->upload_flanks(); if (rc != G2S_OK) return rc; }
   b->drop_tiers();
+  if (getenv("G2S_DEBUG")) fprintf(stderr, "[g2s] stage 1 begins\n");
   g2s_timing keep = b->timing;
   memset(&b->timing, 0, sizeof b->timing);
   b->timing.flank_bytes = keep.flank_bytes;
@@ -1262,7 +1267,8 @@ int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
       fresh.push_back(i);
     }
     size_t work = 0;
-    for (uint32_t i : fresh) work += views[i].segs ? views[i].out->n_sub : views[i].n;
+    for (uint32_t i : fresh)  // (closure states to look at; 2 for a gap analysed on the device)
+      work += views[i].segs ? ((views[i].out->dflags & G2S_DEVA_ANALYSED) ? 2u : views[i].out->n_sub) : views[i].n;
     if (fresh.size() <= 1 || work < 1500) {  // not worth waking the pool (~20 ns per closure state)
       for (uint32_t i : fresh) analyze_gap(b, i, fp, &results[i]);
     } else {
@@ -1744,6 +1750,7 @@ extern "C" int g2s_batch_run(g2s_batch* b, g2s_result* results, char* arena, siz
   if (arena_cap < b->arena_bytes) return fail(G2S_ERR_ARG, "g2s_batch_run: fill arena too small");
   g2s_session* s = b->s;
   const size_t n = b->jobs.size();
+  const auto t_run0 = std::chrono::steady_clock::now();
   memset(results, 0, n * sizeof(g2s_result));
   // an unfilled gap reads as the empty string; filled ones are written in full by the traceback
   for (size_t i = 0; i < n; i++) arena[b->arena_off[i] + (size_t)b->jobs[i].lmf] = '\0';
@@ -1756,13 +1763,17 @@ extern "C" int g2s_batch_run(g2s_batch* b, g2s_result* results, char* arena, siz
   s->tier_cursor = 0;
   b->arena = arena;
   b->arena_base = 0;
+  const auto t_run1 = std::chrono::steady_clock::now();
   int rc = batch_stage1(b, true, results);
   const auto t_join = std::chrono::steady_clock::now();
   rand_fill.join();
-  if (getenv("G2S_DEBUG"))
-    fprintf(stderr, "[g2s] waited %.3f ms for the rand() values after stage 1\n",
-            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_join).count());
+  const auto t_run2 = std::chrono::steady_clock::now();
   if (rc == G2S_OK) rc = batches_stage2(std::vector<g2s_batch*>{b}, s, results, arena, &b->timing, false);
+  if (getenv("G2S_DEBUG")) {
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point c) { return std::chrono::duration<double, std::milli>(c - a).count(); };
+    fprintf(stderr, "[g2s] batch_run: init %.3f ms, stage 1 %.3f ms, wait for rand() values %.3f ms, stage 2 %.3f ms\n",
+            ms(t_run0, t_run1), ms(t_run1, t_join), ms(t_join, t_run2), ms(t_run2, std::chrono::steady_clock::now()));
+  }
   s->last_timing = b->timing;
   return rc;
 }
@@ -1916,7 +1927,11 @@ extern "C" int g2s_fill_batch(g2s_session* s, const g2s_gap* gaps, size_t n, g2s
   if (rc != G2S_OK) return rc;
   const double ms_prep = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
   rc = g2s_batch_run(b, results, fill_arena, arena_cap);
+  const auto t_free = std::chrono::steady_clock::now();
   g2s_batch_free(b);
+  if (getenv("G2S_DEBUG"))
+    fprintf(stderr, "[g2s] fill_batch: prepare %.3f ms, free %.3f ms\n", ms_prep,
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_free).count());
   s->last_timing.ms_prepare = ms_prep;
   s->last_timing.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
   return rc;
