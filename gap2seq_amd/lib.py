@@ -110,6 +110,10 @@ _SIGS = {
     "g2s_execute_single": (C.c_int, [_VP, C.POINTER(g2s_run_opts), C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p,
                                      C.c_int32, C.POINTER(_VP), C.POINTER(_VP)]),
     "g2s_free": (None, [_VP]),
+    "g2s_cut_scaffolds": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p,
+                                    C.c_char_p, C.POINTER(_VP), C.POINTER(_VP), C.POINTER(_VP), C.POINTER(_VP)]),
+    "g2s_merge_scaffolds": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(_VP),
+                                      C.POINTER(_VP)]),
     "g2s_device_count": (C.c_int, []),
     "g2s_synth_genome": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint64, C.POINTER(_VP)]),
     "g2s_synth_gaps": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64,
@@ -194,6 +198,22 @@ class G2S:
         _check(load_library().g2s_synth_gaps(reads_fasta.encode("ascii"), k, fuz, ngaps, min_len, max_len, seed,
                                              C.byref(out)))
         return _take_text(out)
+
+
+def cut_scaffolds(scaffolds_text, k=31, fuz=10, mask=False, no_split=False, labels=("scaffolds.fa", "contigs.fa", "gaps.fa", "gaps.bed")):
+    """g2s_cut_scaffolds (GapCutter): returns (contigs_fasta, gaps_fasta, bed, log)."""
+    outs = [_VP(), _VP(), _VP(), _VP()]
+    _check(load_library().g2s_cut_scaffolds(scaffolds_text.encode("ascii"), k, fuz, int(mask), int(no_split),
+                                            *[x.encode() for x in labels], *[C.byref(o) for o in outs]))
+    return tuple(_take_text(o) for o in outs)
+
+
+def merge_scaffolds(contigs_text, gaps_text, labels=("merged.fa", "contigs.fa", "filled.fa")):
+    """g2s_merge_scaffolds (GapMerger): returns (scaffolds_fasta, log)."""
+    out, log = _VP(), _VP()
+    _check(load_library().g2s_merge_scaffolds(contigs_text.encode("ascii"), gaps_text.encode("ascii"),
+                                              *[x.encode() for x in labels], C.byref(out), C.byref(log)))
+    return _take_text(out), _take_text(log)
 
 
 class Graph:

@@ -251,6 +251,23 @@ int g2s_execute_single(g2s_session* s, const g2s_run_opts* o, const char* reads_
                        const char* left, const char* right, int32_t length, char** fasta, char** log);
 void g2s_free(void* p);
 
+/* ---------------------------------------------------------------------------
+ *  The formats either side of Gap2Seq-core in the reference's pipeline
+ *  (Gap2Seq.py:294-326: GapCutter -> Gap2Seq-core -> GapMerger), host string work.
+ *  g2s_cut_scaffolds: GapCutter.cpp:119-321 — scaffolds FASTA/Q text -> contigs FASTA,
+ *  one-gap records FASTA (comment "<name> scaffold S contig C gap G[ split 1| split 2 k]",
+ *  flanks of at most k+fuz bases), BED lines, and the tool's stdout text.
+ *  g2s_merge_scaffolds: GapMerger.cpp:142-235 — contigs + (filled) gap records -> scaffolds
+ *  FASTA with the markers stripped, and the tool's stdout text.
+ *  The *_label arguments only feed the echoed file names.  Outputs are malloc'ed
+ *  strings released with g2s_free.
+ * ------------------------------------------------------------------------ */
+int g2s_cut_scaffolds(const char* scaffolds_text, int k, int fuz, int mask, int no_split, const char* scaffolds_label,
+                      const char* contigs_label, const char* gaps_label, const char* bed_label, char** contigs_out,
+                      char** gaps_out, char** bed_out, char** log_out);
+int g2s_merge_scaffolds(const char* contigs_text, const char* gaps_text, const char* scaffolds_label,
+                        const char* contigs_label, const char* gaps_label, char** scaffolds_out, char** log_out);
+
 /* Accessors. */
 const g2s_graph* g2s_session_graph(const g2s_session* s);
 int g2s_session_get_params(const g2s_session* s, g2s_params* out);

@@ -153,3 +153,64 @@ def test_c1_stand_in_multi_gap_scaffolds_through_the_cli(product, oracle, tmp_pa
     assert outs["gpu"][0] == outs["cpu"][0]
     last = outs["gpu"][1].strip().splitlines()[-1].split()  # "Filled X gaps out of Y"
     assert last[0] == "Filled" and int(last[5]) >= 600 and int(last[1]) >= int(last[5]) // 2
+
+
+def test_c1_wrapper_flow_cut_fill_merge(product, oracle, tmp_path):
+    """The reference wrapper's flow without read filtering (Gap2Seq.py:448-454: GapCutter ->
+    Gap2Seq-core on the one-gap records -> GapMerger) on the C1 stand-in, with this repository's
+    three command lines: (a) multi-gap scaffolds: the merged scaffolds equal those of the same flow
+    with the oracle's core in the middle; (b) one gap per scaffold: they also equal what
+    `Gap2Seq-core -scaffolds` makes of the uncut scaffolds (with several gaps per record the direct
+    run drops the sequence in front of a later filled gap; the cut records do not)."""
+    k, fuz = 31, 10
+    reads_text = product.G2S.synth_genome(2900000, 3, 20240105)
+    genome = _seqs(reads_text)[0]
+    reads = tmp_path / "reads.fa"
+    reads.write_text(reads_text)
+    bins = os.path.join(ROOT, "gap2seq_amd")
+    core = {"gpu": os.path.join(bins, "Gap2Seq-core"), "cpu": os.path.join(os.path.dirname(oracle.ORACLE_SO), "g2s_oracle_cli")}
+
+    def run(cmd):
+        res = subprocess.run([str(c) for c in cmd], capture_output=True, text=True, timeout=900)
+        assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+        return res
+
+    def flow(which, scaf, tag):
+        gaps, contigs, bed = (tmp_path / (tag + n) for n in (".gaps", ".contigs", ".bed"))
+        run([os.path.join(bins, "GapCutter"), "-k", k, "-fuz", fuz, "-scaffolds", scaf, "-gaps", gaps, "-contigs", contigs, "-bed", bed])
+        filled = tmp_path / (tag + "." + which + ".filled")
+        res = run([core[which], "-k", k, "-fuz", fuz, "-solid", 1, "-nb-cores", 1, "-dist-error", 500, "-max-mem", 20,
+                   "-randseed", 1, "-reads", reads, "-filled", filled, "-scaffolds", gaps])
+        if which == "cpu":
+            assert "# oracle: q7_gaps 0" in res.stderr
+        merged = tmp_path / (tag + "." + which + ".merged")
+        run([os.path.join(bins, "GapMerger"), "-scaffolds", merged, "-gaps", filled, "-contigs", contigs])
+        return merged.read_text(), filled.read_text()
+
+    multi = tmp_path / "multi.fa"
+    multi.write_text(_simulated_scaffolds(genome, k, fuz, 7, 300, 9600))
+    m_gpu, f_gpu = flow("gpu", multi, "multi")
+    m_cpu, f_cpu = flow("cpu", multi, "multi")
+    assert f_gpu == f_cpu and m_gpu == m_cpu
+    assert m_gpu.count(">") == 300 and f_gpu.count(">") >= 600
+    # (b) one gap per scaffold, true gap lengths 1-1500 with an estimate error
+    rng = cases.SplitMix(99)
+    recs = []
+    for r in range(200):
+        lo = r * 14000
+        s = genome[lo:lo + 6000]
+        pos = rng.randint(200, 3000)
+        true_len = rng.choice([rng.randint(1, 60), rng.randint(100, 700), rng.randint(700, 1500)])
+        est = max(1, true_len + rng.choice([0, 0, 0, -3, 7, -40, 60]))
+        recs.append(">one%d sim\n%s%s%s\n" % (r, s[:pos], "N" * est, s[pos + true_len:]))
+    single = tmp_path / "single.fa"
+    single.write_text("".join(recs))
+    m_gpu, _ = flow("gpu", single, "single")
+    direct = tmp_path / "direct.fa"
+    run([core["gpu"], "-k", k, "-fuz", fuz, "-solid", 1, "-nb-cores", 1, "-dist-error", 500, "-max-mem", 20, "-randseed", 1,
+         "-reads", reads, "-filled", direct, "-scaffolds", single])
+    want = direct.read_text()
+    assert m_gpu.replace(">one", ">ONE").count(">ONE") == 200
+    # the merged records carry the comment up to the first marker, the direct run the whole comment: same here
+    assert m_gpu == want
+    assert sum(1 for ln in want.splitlines() if not ln.startswith(">") and "N" not in ln) >= 150
