@@ -18,7 +18,7 @@ python tools/pmc_summary.py $O/fetch $O/write g2s_fill_seg $O/pmc.json
 timeout 200 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS --output-format csv -d $O/sq1 -- $B > /dev/null 2> $O/rp4.err
 timeout 200 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU --output-format csv -d $O/sq2 -- $B > /dev/null 2> $O/rp5.err
 python tools/pmc_sq_summary.py $O/pmc_sq.json g2s_fill_seg $O/sq1 $O/sq2
-tail -3 $O/rp4.err $O/rp5.err | cut -c1-300
+for f in $O/rp4.err $O/rp5.err; do tail -n 2 $f | cut -c1-300; done
 [ "$WHAT" = "c2" ] && exit 0
 for v in 0 1 2; do timeout 100 python bench.py --no-cpu-baseline --no-c3-beside --variant $v | tee -a $O/variants.json | python tools/bsum.py V$v; done
 timeout 100 python bench.py --no-cpu-baseline --config C3 --gaps 1250 --steps 100 | tee -a $O/c3.json | python tools/bsum.py C3-1250
