@@ -224,8 +224,8 @@ def main():
     for _ in range(warmup):
         run.step()
     acc = dict(ms_right_bfs=0.0, ms_left_dp=0.0, ms_extract=0.0, ms_fill_lds=0.0, ms_extract_lds=0.0, ms_d2h=0.0,
-               ms_host_post=0.0, ms_prepare=0.0, ms_total=0.0, ms_fill_seg=0.0, launches=0, lds_launches=0,
-               seg_launches=0)
+               ms_host_post=0.0, ms_prepare=0.0, ms_total=0.0, ms_fill_seg=0.0, ms_fill_segx=0.0, launches=0,
+               lds_launches=0, seg_launches=0, segx_launches=0)
     in_call = 0.0
     barrier()
     t_begin = time.perf_counter()
@@ -233,11 +233,12 @@ def main():
         in_call += run.step()
         tm = run.timing()
         for key in ("ms_right_bfs", "ms_left_dp", "ms_extract", "ms_fill_lds", "ms_extract_lds", "ms_d2h",
-                    "ms_host_post", "ms_prepare", "ms_total", "ms_fill_seg"):
+                    "ms_host_post", "ms_prepare", "ms_total", "ms_fill_seg", "ms_fill_segx"):
             acc[key] += getattr(tm, key)
         acc["launches"] += tm.launches_left_dp
         acc["lds_launches"] += tm.lds_launches
         acc["seg_launches"] += tm.seg_launches
+        acc["segx_launches"] += tm.segx_launches
     elapsed = time.perf_counter() - t_begin
     barrier()
     elapsed, units = shard.reduce_timing(elapsed, float(len(gaps) * steps), dist)
@@ -327,7 +328,8 @@ def main():
     # reference re-expands nodes reached by walks of several lengths); otherwise the product's
     # counters, labelled so.
     io_bytes = tm.flank_bytes + tm.fill_bytes
-    if tm.seg_tier_gaps > 0 and tm.seg_tier_gaps >= tm.lds_tier_gaps:
+    seg_gaps = tm.seg_tier_gaps + tm.segx_tier_gaps
+    if seg_gaps > 0 and seg_gaps >= tm.lds_tier_gaps:
         # the segment tier took (most of) the list: phases A-D1 over unitig segments, one wave per gap
         kname = "g2s_fill_seg"
         if octr is not None and tm.seg_tier_gaps == len(gaps):
@@ -336,6 +338,10 @@ def main():
             x_units, s_units, counted_by = tm.xA + tm.xB + tm.xD, tm.sA + tm.sB + tm.sD, "product"
         launches = acc["seg_launches"] / float(steps)
         kern_ms = acc["ms_fill_seg"] / max(1, acc["seg_launches"])  # average launch duration
+        if tm.segx_tier_gaps > 0:
+            # deep gaps took the tier's large variant as well: the two kernels' launches of a step as one unit
+            kname = "g2s_fill_seg + g2s_fill_segx"
+            kern_ms = (acc["ms_fill_seg"] + acc["ms_fill_segx"]) / max(1, acc["seg_launches"])
     elif tm.lds_tier_gaps > 0:
         kname = "g2s_fill_lds"
         if octr is not None and tm.lds_tier_gaps == len(gaps):
@@ -363,7 +369,7 @@ def main():
                     frac=round(achieved / HBM_PEAK_GBS, 6), traffic=traffic, traffic_source=traffic_src,
                     algorithmic_bytes_per_launch=alg_bytes, expansions=x_units, states=s_units,
                     units_counted_by=counted_by, kernel_ms_per_launch=round(kern_ms, 4),
-                    launches_per_step=round(launches, 3), seg_tier_gaps=tm.seg_tier_gaps, lds_tier_gaps=tm.lds_tier_gaps,
+                    launches_per_step=round(launches, 3), seg_tier_gaps=tm.seg_tier_gaps, segx_tier_gaps=tm.segx_tier_gaps, lds_tier_gaps=tm.lds_tier_gaps,
                     segments=tm.seg_segments)
     workload = "BASELINE %s%s: %d bp genome V%d, k=%d, %d gaps len %d-%d, fuz %d, dist-error %d" % (
         cfg_text if not custom else "custom (based on %s)" % cfg_name, "", genome_bp, args.variant, k, len(gaps), min_len,
@@ -398,6 +404,7 @@ def main():
         "breakdown_ms_per_step": {"wall_inside_the_abi_call": round(in_call / steps * 1e3, 4),
                                   "prepare_flank_lookup_and_upload": per_step("ms_prepare"),
                                   "fill_seg_kernel": per_step("ms_fill_seg"),
+                                  "fill_segx_kernel": per_step("ms_fill_segx"),
                                   "fill_lds_kernel": per_step("ms_fill_lds"),
                                   "extract_lds_kernel": per_step("ms_extract_lds"),
                                   "hbm_tier_kernels": round((acc["ms_right_bfs"] + acc["ms_left_dp"] +

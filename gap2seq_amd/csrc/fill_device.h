@@ -27,6 +27,9 @@
 #define G2S_DEV_RS_POOL 0x2000u     /* the right set moved from LDS to a chunk of the spill pool */
 /* the closure of this gap was emitted as segments (SegRec, segment tier), not as per-state records */
 #define G2S_DEV_COMPACT 0x4000u
+/* (with an OVERFLOW bit) a probe loop of the segment tier's large variant ran past its bound: a defect, never
+   expected; the gap runs again in the LDS tier instead of holding the GPU */
+#define G2S_DEV_WATCHDOG 0x8000u
 /* LDS tier, lvl[]: bit 31 of the END offset of level L = L was produced by a bulk step
  * (same width as level L-1, state r has the single parent r of level L-1) */
 #define G2S_LVL_UNIFORM 0x80000000u

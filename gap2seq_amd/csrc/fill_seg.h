@@ -8,6 +8,13 @@
 
 #define G2S_SEG_CAP 512u  /* segments per gap kept in LDS */
 #define G2S_SEG_ASETS 4   /* right-set entries per gap: 64 per set, in registers */
+/* the large variant (g2s_fill_segx): gaps that outgrow the capacities above */
+#define G2S_SEGX_CAP 16384u  /* segments per gap, in the workgroup's global scratch */
+#define G2S_SEGX_EA 6144u    /* right-set entries */
+#define G2S_SEGX_AS 16384u   /* slots of the label table of phase A (LDS) */
+#define G2S_SEGX_QCAP 16384u /* entries one round of phase A may queue */
+#define G2S_SEGX_PE 1024u    /* pending events (LDS slots) */
+#define G2S_SEGX_HS 4096u    /* slots of the event table */
 
 namespace g2s {
 
@@ -21,5 +28,16 @@ hipError_t launch_fill_seg(hipStream_t st, uint32_t ngaps, const uint32_t* succ,
                            unsigned long long out_cap /* records */, unsigned long long* out_counter, GapOut* outs,
                            GapOut* outs_host /* pinned host */, uint32_t* done_list /* pinned host */, int skip_confident,
                            uint32_t* dbg /* nullptr, or ngaps * fill_seg_dbg_words() words */);
+
+// The large variant: `workgroups` persistent workgroups (one per compute unit) take the listed gaps
+// in order from the counter *next_gap (zero before the launch); scratch: fill_segx_scratch_bytes().
+size_t fill_segx_lds_bytes();
+size_t fill_segx_scratch_bytes(uint32_t workgroups);
+uint32_t fill_segx_dbg_words();
+hipError_t launch_fill_segx(hipStream_t st, uint32_t ngaps, uint32_t workgroups, const uint32_t* succ, const uint32_t* urec,
+                            const GapDev* gaps, const uint32_t* gap_ids, const uint32_t* flank_nodes, SubRec* sub_out,
+                            unsigned long long out_cap, unsigned long long* out_counter, GapOut* outs, GapOut* outs_host,
+                            uint32_t* done_list, int skip_confident, uint32_t* dbg, uint32_t* scratch,
+                            unsigned long long* next_gap);
 
 }  // namespace g2s

@@ -80,27 +80,122 @@ __device__ __forceinline__ uint32_t wave_scan(uint32_t x, int lane) {
   return x;
 }
 
+// ascending bitonic sort of n2 (a power of two >= 2) 64-bit keys in LDS by one wave
+__device__ __forceinline__ void lds_sort64(uint64_t* a, uint32_t n2, int lane) {
+  for (uint32_t k = 2; k <= n2; k <<= 1)
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      for (uint32_t t = (uint32_t)lane; t < (n2 >> 1); t += 64u) {
+        const uint32_t i = ((t & ~(j - 1u)) << 1) | (t & (j - 1u));  // the t-th index with bit j clear
+        const uint32_t l = i | j;
+        const bool up = (i & k) == 0u;
+        const uint64_t p = a[i], q = a[l];
+        if ((p > q) == up) { a[i] = q; a[l] = p; }
+      }
+      lds_sync();
+    }
+}
+// a[0 .. n): keys (first index << 32 | orientation << 31 | last index), sorted.  Merges overlapping and
+// adjacent intervals in place: a[g] = first << 32 | last for g < M (returned), sorted and disjoint with a
+// hole between any two.  *cross: an interval of each orientation overlap.
+__device__ __forceinline__ uint32_t lds_merge_intervals(uint64_t* a, uint32_t n, int lane, bool* cross) {
+  uint32_t* w = (uint32_t*)a;
+  uint32_t M = 0, pm = 0, pm_e = 0, pm_o = 0;  // highest (last index + 1) so far: all, even, odd entries
+  bool cr = false;
+  for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
+    const uint32_t i = i0 + (uint32_t)lane;
+    const bool h = i < n;
+    const uint64_t key = h ? a[i] : 0ull;
+    const uint32_t lo = (uint32_t)(key >> 32), hi = (uint32_t)key & 0x7FFFFFFFu, odd = ((uint32_t)key >> 31) & 1u;
+    uint32_t sa = h ? hi + 1u : 0u, se = (h && !odd) ? hi + 1u : 0u, so = (h && odd) ? hi + 1u : 0u;
+    for (int o = 1; o < 64; o <<= 1) {  // inclusive prefix maxima
+      const uint32_t ya = (uint32_t)__shfl_up((int)sa, o), ye = (uint32_t)__shfl_up((int)se, o), yo = (uint32_t)__shfl_up((int)so, o);
+      if (lane >= o) { sa = max(sa, ya); se = max(se, ye); so = max(so, yo); }
+    }
+    uint32_t xa = (uint32_t)__shfl_up((int)sa, 1), xe = (uint32_t)__shfl_up((int)se, 1), xo = (uint32_t)__shfl_up((int)so, 1);
+    if (lane == 0) { xa = 0u; xe = 0u; xo = 0u; }
+    xa = max(xa, pm); xe = max(xe, pm_e); xo = max(xo, pm_o);   // over everything before element i
+    if (__ballot(h && (odd ? xe : xo) > lo)) cr = true;          // an earlier interval of the other orientation ends at or after lo
+    const bool start = h && (xa == 0u || lo > xa);               // a hole in front of this element
+    const uint64_t sm = __ballot(start);
+    const uint32_t g = M + (uint32_t)__popcll(sm & below(lane));
+    lds_sync();  // (every lane has read its element: the writes below land at or in front of this chunk)
+    if (start) {
+      w[2u * g + 1u] = lo;
+      if (g > 0u) w[2u * (g - 1u)] = xa - 1u;
+    }
+    M += (uint32_t)__popcll(sm);
+    pm = max(pm, rl(sa, 63)); pm_e = max(pm_e, rl(se, 63)); pm_o = max(pm_o, rl(so, 63));
+    lds_sync();
+  }
+  if (M > 0u && lane == 0) w[2u * (M - 1u)] = pm - 1u;
+  lds_sync();
+  *cross = cr;
+  return M;
+}
+
 }  // namespace
 
-// dynamic LDS: 7 arrays of G2S_SEG_CAP words + left seeds
-__global__ __launch_bounds__(64) void g2s_fill_seg(const uint32_t* __restrict__ succ, const uint32_t* __restrict__ urec,
-                                                    const GapDev* __restrict__ gaps, const uint32_t* __restrict__ gap_ids,
-                                                    const uint32_t* __restrict__ flank_nodes, SubRec* sub_out,
-                                                    unsigned long long out_cap, unsigned long long* out_counter,
-                                                    GapOut* outs, GapOut* outs_host, uint32_t* done_list,
-                                                    int skip_confident, uint32_t* dbg, uint32_t dbg_words) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-  uint32_t* s_node = lds;                       // entry node of the segment
-  uint32_t* s_dl = s_node + G2S_SEG_CAP;        // entry depth | length << 16
-  uint32_t* s_cnt = s_dl + G2S_SEG_CAP;         // path count of every state of the segment
-  uint32_t* s_p01 = s_cnt + G2S_SEG_CAP;        // parents (segment ids, 16 bits each, 0xFFFF = none)
-  uint32_t* s_p23 = s_p01 + G2S_SEG_CAP;
-  uint32_t* s_aux = s_p23 + G2S_SEG_CAP;        // generation | closure marks of the children << 16; later: emit offset
-  uint32_t* s_t = s_aux + G2S_SEG_CAP;          // last closure state: towards a sink | from a traceback start << 16 (0xFFFF none)
-  uint32_t* l_seed = s_t + G2S_SEG_CAP;         // left-flank seeds by depth [32]
+// What one launch works with (both kernels).
+struct SegArgs {
+  const uint32_t* succ;
+  const uint32_t* urec;
+  const GapDev* gaps;
+  const uint32_t* gap_ids;
+  const uint32_t* flank_nodes;
+  SubRec* sub_out;
+  unsigned long long out_cap;
+  unsigned long long* out_counter;
+  GapOut* outs;
+  GapOut* outs_host;
+  uint32_t* done_list;
+  int skip_confident;
+  uint32_t* dbg;
+  uint32_t dbg_words;
+};
+
+// LDS of the large variant (words): see the layout notes at each phase
+#define SEGX_LDS_WORDS 39936u
+// global scratch of one workgroup of the large variant (words): six segment arrays + two queues
+#define SEGX_SCR_WORDS (6u * G2S_SEGX_CAP + 2u * G2S_SEGX_QCAP)
+#define SEGX_EMPTY64 0xFFFFFFFFFFFFFFFFull
+#define SEGX_TOMB64 0xFFFFFFFFFFFFFFFEull
+
+// One gap, one wave.  BIG = false: the tier proper (segments in LDS, pending events and the right set in
+// registers).  BIG = true: the same search for the gaps that outgrow those capacities (-dist-error 2000:
+// thousands of segments, hundreds of pending events, thousands of right-set entries): segments in the
+// workgroup's global scratch `scr`, pending events in an LDS hash table, the right set as a sorted array
+// of disjoint index intervals in LDS that every lane searches on its own.
+template <bool BIG>
+__device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, const uint32_t x /* position in the launch */,
+                                             uint32_t* scr) {
+  const uint32_t* __restrict__ succ = A.succ;
+  const uint32_t* __restrict__ urec = A.urec;
+  const GapDev* __restrict__ gaps = A.gaps;
+  const uint32_t* __restrict__ gap_ids = A.gap_ids;
+  const uint32_t* __restrict__ flank_nodes = A.flank_nodes;
+  SubRec* sub_out = A.sub_out;
+  const unsigned long long out_cap = A.out_cap;
+  unsigned long long* out_counter = A.out_counter;
+  GapOut* outs = A.outs;
+  GapOut* outs_host = A.outs_host;
+  uint32_t* done_list = A.done_list;
+  const int skip_confident = A.skip_confident;
+  uint32_t* dbg = A.dbg;
+  const uint32_t dbg_words = A.dbg_words;
+  constexpr uint32_t CAP = BIG ? G2S_SEGX_CAP : G2S_SEG_CAP;
+  // segment arrays: LDS (7 arrays of G2S_SEG_CAP words + left seeds), or the scratch; s_aux / s_t always in LDS
+  uint32_t* s_node = BIG ? scr : lds;           // entry node of the segment
+  uint32_t* s_dl = s_node + CAP;                // entry depth | length << 16
+  uint32_t* s_cnt = s_dl + CAP;                 // path count of every state of the segment
+  uint32_t* s_p01 = s_cnt + CAP;                // parents (segment ids, 16 bits each, 0xFFFF = none)
+  uint32_t* s_p23 = s_p01 + CAP;
+  uint32_t* s_gen = s_p23 + CAP;                // (BIG) generation, copied into s_aux before phase D1
+  uint32_t* s_aux = BIG ? lds : s_p23 + CAP;    // generation | closure marks of the children << 16; later: emit offset
+  uint32_t* s_t = s_aux + CAP;                  // last closure state: towards a sink | from a traceback start << 16 (0xFFFF none)
+  uint32_t* l_seed = BIG ? lds + (SEGX_LDS_WORDS - 32u) : s_t + CAP;  // left-flank seeds by depth [32]
 
   const int lane = threadIdx.x;
-  const uint32_t gi = uni(gap_ids[blockIdx.x]);
+  const uint32_t gi = uni(gap_ids[x]);
   const GapDev gd = gaps[gi];
   GapOut* go = &outs[gi];
   const uint32_t* lseeds = flank_nodes + gd.flank_off;
@@ -126,177 +221,322 @@ __global__ __launch_bounds__(64) void g2s_fill_seg(const uint32_t* __restrict__ 
   const uint32_t tg = (lane <= rmf && lane < 32) ? targets[lane] : G2S_DEV_INVALID;  // lane j: target k-mer j
   if (lane < 32) l_seed[lane] = lane <= lmf ? lseeds[lane] : G2S_DEV_INVALID;
 
-  // ---------------- phase A: the right set as (entry node, depth label) pairs ----------------
-  // Label-correcting search over unitigs (:871-982 computes {v : fewest predecessor steps from a
-  // right seed <= right_half}, seed j entering at depth j; only membership is consumed, :1050).
-  // An entry (node, label) covers its unitig backwards for min(rem, right_half - label) steps;
-  // where the unitig ends with budget left, the predecessors of its last node are proposed with
-  // label + steps + 1.  All entries of a round are expanded at once (lane = entry): one load of
-  // rem[], one successor record, and the proposals of the whole wave go through one LDS table
-  // keyed by node with 64-bit atomic min on (node << 32 | label) — a per-proposal compare against
-  // register-resident entries costs ~1.5 k cycles of scalar/vector ping-pong each (measured).
-  // LDS (aliasing the segment arrays, which phase B fills later):
-  //   lab[ALAB] u64 | labrem[ALAB] u32 | q[2][ACAP] u32
-  const uint32_t ACAP = 64u * G2S_SEG_ASETS, ALAB = 2u * ACAP;
-  uint64_t* lab = (uint64_t*)lds;
-  uint32_t* labrem = (uint32_t*)(lab + ALAB);
-  uint32_t* aq0 = labrem + ALAB;
-  uint32_t nA = 0, roundsA = 0;
-  for (uint32_t i = (uint32_t)lane; i < ALAB; i += 64u) lab[i] = G2S_DEV_EMPTY64;
-  lds_sync();
-  auto a_hash = [&](uint32_t p) -> uint32_t { uint32_t x = p; x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x & (ALAB - 1u); };
-  // propose label dp for node p (per lane); true when the label improved (the caller queues p)
-  auto relabel = [&](bool active, uint32_t p, uint32_t dp) -> bool {
-    bool improved = false, fresh = false;
-    if (active) {
-      const uint64_t key = ((uint64_t)p << 32) | dp;
-      uint32_t h = a_hash(p);
-      while (true) {
-        const uint64_t c = lab[h];
-        if ((uint32_t)(c >> 32) == p) {
-          improved = atomicMin((unsigned long long*)&lab[h], (unsigned long long)key) > key;
-          break;
-        }
-        if (c == G2S_DEV_EMPTY64) {
-          const unsigned long long prev =
-              atomicCAS((unsigned long long*)&lab[h], (unsigned long long)G2S_DEV_EMPTY64, (unsigned long long)key);
-          if (prev == G2S_DEV_EMPTY64) { improved = true; fresh = true; break; }
-          continue;  // somebody took the slot: look at it again
-        }
-        h = (h + 1u) & (ALAB - 1u);
-      }
-    }
-    nA += (uint32_t)__popcll(__ballot(fresh));
-    return improved;
-  };
-  if (!overflow) {
-    uint32_t cur = 0, ne = 0;
-    {  // seeds: right.substr(len-k-j, k) enters at depth j (:878-884, :953-976)
-      const uint32_t sd = (lane <= rmf && lane < 32) ? rseeds[lane] : G2S_DEV_INVALID;
-      const bool imp = relabel(sd != G2S_DEV_INVALID && lane <= gd.right_half, sd, (uint32_t)lane);
-      const uint64_t m = __ballot(imp);
-      if (imp) aq0[(uint32_t)__popcll(m & below(lane))] = sd;
-      ne = (uint32_t)__popcll(m);
-      lds_sync();
-    }
-    while (ne > 0 && !overflow) {
-      roundsA++;
-      uint32_t* qc = aq0 + cur * ACAP;
-      uint32_t* qn = aq0 + (cur ^ 1u) * ACAP;
-      uint32_t nn = 0;
-      for (uint32_t e0 = 0; e0 < ne && !overflow; e0 += 64u) {
-        const bool mine = e0 + (uint32_t)lane < ne;
-        const uint32_t v = mine ? qc[e0 + (uint32_t)lane] : 0u;
-        uint32_t d = 0, slot = 0;
-        if (mine) {  // the entry's current label
-          slot = a_hash(v);
-          while ((uint32_t)(lab[slot] >> 32) != v) slot = (slot + 1u) & (ALAB - 1u);
-          d = (uint32_t)lab[slot];
-        }
-        // walking back from v = walking on from v^1: steps left in the unitig and the successor record
-        // of the walk's last node (graph.predecessors(last)[i] = succ(last^1)[i] ^ 1) in one record
-        uint4 rec = make_uint4(G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID);
-        uint32_t r = 0;
-        if (mine) {
-          const uint4* u = (const uint4*)(urec + (size_t)(v ^ 1u) * 8);
-          rec = u[0];
-          r = u[1].x;
-          labrem[slot] = r;
-        }
-        const uint32_t steps = min(r, (uint32_t)gd.right_half - d);
-        const bool live = mine && d + steps < (uint32_t)gd.right_half;  // (then steps == r: the record is the last node's)
-        if (!live) rec = make_uint4(G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID);
-        const uint32_t dchild = d + steps + 1u;
+  uint32_t nA = 0, roundsA = 0, nvis = 0, xa = 0;
+  // (!BIG) the right-set entries in registers: lane l of set s holds entry 64 s + l, as a k-mer index interval
+  uint32_t an[G2S_SEG_ASETS], al[G2S_SEG_ASETS], ar[G2S_SEG_ASETS], alo[G2S_SEG_ASETS], ahi[G2S_SEG_ASETS];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const uint32_t w = q == 0 ? rec.x : q == 1 ? rec.y : q == 2 ? rec.z : rec.w;
-          const bool imp = relabel(w != G2S_DEV_INVALID && !overflow, w ^ 1u, dchild);
-          const uint64_t m = __ballot(imp);
-          if (imp) {
-            const uint32_t at = nn + (uint32_t)__popcll(m & below(lane));
-            if (at < ACAP) qn[at] = w ^ 1u;
+  for (int s = 0; s < G2S_SEG_ASETS; s++) { an[s] = G2S_DEV_INVALID; al[s] = 0; ar[s] = 0; alo[s] = 1u; ahi[s] = 0u; }
+  // (BIG) the right set as M disjoint, sorted index intervals in LDS: ivw[2 i] = last index, ivw[2 i + 1] = first
+  uint32_t* ivw = lds;
+  uint32_t M = 0, ivP = 0;  // ivP: largest power of two <= M
+  if constexpr (!BIG) {
+    // ---------------- phase A: the right set as (entry node, depth label) pairs ----------------
+    // Label-correcting search over unitigs (:871-982 computes {v : fewest predecessor steps from a
+    // right seed <= right_half}, seed j entering at depth j; only membership is consumed, :1050).
+    // An entry (node, label) covers its unitig backwards for min(rem, right_half - label) steps;
+    // where the unitig ends with budget left, the predecessors of its last node are proposed with
+    // label + steps + 1.  All entries of a round are expanded at once (lane = entry): one load of
+    // rem[], one successor record, and the proposals of the whole wave go through one LDS table
+    // keyed by node with 64-bit atomic min on (node << 32 | label) — a per-proposal compare against
+    // register-resident entries costs ~1.5 k cycles of scalar/vector ping-pong each (measured).
+    // LDS (aliasing the segment arrays, which phase B fills later):
+    //   lab[ALAB] u64 | labrem[ALAB] u32 | q[2][ACAP] u32
+    const uint32_t ACAP = 64u * G2S_SEG_ASETS, ALAB = 2u * ACAP;
+    uint64_t* lab = (uint64_t*)lds;
+    uint32_t* labrem = (uint32_t*)(lab + ALAB);
+    uint32_t* aq0 = labrem + ALAB;
+    for (uint32_t i = (uint32_t)lane; i < ALAB; i += 64u) lab[i] = G2S_DEV_EMPTY64;
+    lds_sync();
+    auto a_hash = [&](uint32_t p) -> uint32_t { uint32_t x = p; x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x & (ALAB - 1u); };
+    // propose label dp for node p (per lane); true when the label improved (the caller queues p)
+    auto relabel = [&](bool active, uint32_t p, uint32_t dp) -> bool {
+      bool improved = false, fresh = false;
+      if (active) {
+        const uint64_t key = ((uint64_t)p << 32) | dp;
+        uint32_t h = a_hash(p);
+        while (true) {
+          const uint64_t c = lab[h];
+          if ((uint32_t)(c >> 32) == p) {
+            improved = atomicMin((unsigned long long*)&lab[h], (unsigned long long)key) > key;
+            break;
           }
-          nn += (uint32_t)__popcll(m);
-          // (the table has 2 ACAP slots: at most ACAP + 64 are ever taken, so every probe ends)
-          if (nn > ACAP || nA > ACAP) { overflow = true; flags |= G2S_DEV_OVERFLOW_A | G2S_DEV_WHY_RS; }
+          if (c == G2S_DEV_EMPTY64) {
+            const unsigned long long prev =
+                atomicCAS((unsigned long long*)&lab[h], (unsigned long long)G2S_DEV_EMPTY64, (unsigned long long)key);
+            if (prev == G2S_DEV_EMPTY64) { improved = true; fresh = true; break; }
+            continue;  // somebody took the slot: look at it again
+          }
+          h = (h + 1u) & (ALAB - 1u);
         }
       }
+      nA += (uint32_t)__popcll(__ballot(fresh));
+      return improved;
+    };
+    if (!overflow) {
+      uint32_t cur = 0, ne = 0;
+      {  // seeds: right.substr(len-k-j, k) enters at depth j (:878-884, :953-976)
+        const uint32_t sd = (lane <= rmf && lane < 32) ? rseeds[lane] : G2S_DEV_INVALID;
+        const bool imp = relabel(sd != G2S_DEV_INVALID && lane <= gd.right_half, sd, (uint32_t)lane);
+        const uint64_t m = __ballot(imp);
+        if (imp) aq0[(uint32_t)__popcll(m & below(lane))] = sd;
+        ne = (uint32_t)__popcll(m);
+        lds_sync();
+      }
+      while (ne > 0 && !overflow) {
+        roundsA++;
+        uint32_t* qc = aq0 + cur * ACAP;
+        uint32_t* qn = aq0 + (cur ^ 1u) * ACAP;
+        uint32_t nn = 0;
+        for (uint32_t e0 = 0; e0 < ne && !overflow; e0 += 64u) {
+          const bool mine = e0 + (uint32_t)lane < ne;
+          const uint32_t v = mine ? qc[e0 + (uint32_t)lane] : 0u;
+          uint32_t d = 0, slot = 0;
+          if (mine) {  // the entry's current label
+            slot = a_hash(v);
+            while ((uint32_t)(lab[slot] >> 32) != v) slot = (slot + 1u) & (ALAB - 1u);
+            d = (uint32_t)lab[slot];
+          }
+          // walking back from v = walking on from v^1: steps left in the unitig and the successor record
+          // of the walk's last node (graph.predecessors(last)[i] = succ(last^1)[i] ^ 1) in one record
+          uint4 rec = make_uint4(G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID);
+          uint32_t r = 0;
+          if (mine) {
+            const uint4* u = (const uint4*)(urec + (size_t)(v ^ 1u) * 8);
+            rec = u[0];
+            r = u[1].x;
+            labrem[slot] = r;
+          }
+          const uint32_t steps = min(r, (uint32_t)gd.right_half - d);
+          const bool live = mine && d + steps < (uint32_t)gd.right_half;  // (then steps == r: the record is the last node's)
+          if (!live) rec = make_uint4(G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID);
+          const uint32_t dchild = d + steps + 1u;
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const uint32_t w = q == 0 ? rec.x : q == 1 ? rec.y : q == 2 ? rec.z : rec.w;
+            const bool imp = relabel(w != G2S_DEV_INVALID && !overflow, w ^ 1u, dchild);
+            const uint64_t m = __ballot(imp);
+            if (imp) {
+              const uint32_t at = nn + (uint32_t)__popcll(m & below(lane));
+              if (at < ACAP) qn[at] = w ^ 1u;
+            }
+            nn += (uint32_t)__popcll(m);
+            // (the table has 2 ACAP slots: at most ACAP + 64 are ever taken, so every probe ends)
+            if (nn > ACAP || nA > ACAP) { overflow = true; flags |= G2S_DEV_OVERFLOW_A | G2S_DEV_WHY_RS; }
+          }
+        }
+        lds_sync();
+        cur ^= 1u;
+        ne = nn;
+      }
+    }
+    // the table's entries into registers: lane l of set s holds entry 64 s + l
+    if (!overflow) {
+      uint32_t* cnode = aq0;                 // compact list (the queues are idle now)
+      uint32_t* clab = aq0 + ACAP;
+      uint32_t* crem = (uint32_t*)lab;       // written only after the whole table was read: see the two loops
+      uint32_t got = 0;
+      uint32_t keep_n[ALAB / 64u], keep_l[ALAB / 64u], keep_r[ALAB / 64u], keep_at[ALAB / 64u];
+#pragma unroll
+      for (uint32_t c = 0; c < ALAB / 64u; c++) {
+        const uint64_t e = lab[c * 64u + (uint32_t)lane];
+        const bool have = e != G2S_DEV_EMPTY64;
+        const uint64_t m = __ballot(have);
+        keep_n[c] = (uint32_t)(e >> 32); keep_l[c] = (uint32_t)e; keep_r[c] = labrem[c * 64u + (uint32_t)lane];
+        keep_at[c] = have ? got + (uint32_t)__popcll(m & below(lane)) : G2S_DEV_INVALID;
+        got += (uint32_t)__popcll(m);
+      }
       lds_sync();
-      cur ^= 1u;
-      ne = nn;
-    }
-  }
-  // the table's entries into registers: lane l of set s holds entry 64 s + l
-  uint32_t an[G2S_SEG_ASETS], al[G2S_SEG_ASETS], ar[G2S_SEG_ASETS];
 #pragma unroll
-  for (int s = 0; s < G2S_SEG_ASETS; s++) { an[s] = G2S_DEV_INVALID; al[s] = 0; ar[s] = 0; }
-  if (!overflow) {
-    uint32_t* cnode = aq0;                 // compact list (the queues are idle now)
-    uint32_t* clab = aq0 + ACAP;
-    uint32_t* crem = (uint32_t*)lab;       // written only after the whole table was read: see the two loops
-    uint32_t got = 0;
-    uint32_t keep_n[ALAB / 64u], keep_l[ALAB / 64u], keep_r[ALAB / 64u], keep_at[ALAB / 64u];
-#pragma unroll
-    for (uint32_t c = 0; c < ALAB / 64u; c++) {
-      const uint64_t e = lab[c * 64u + (uint32_t)lane];
-      const bool have = e != G2S_DEV_EMPTY64;
-      const uint64_t m = __ballot(have);
-      keep_n[c] = (uint32_t)(e >> 32); keep_l[c] = (uint32_t)e; keep_r[c] = labrem[c * 64u + (uint32_t)lane];
-      keep_at[c] = have ? got + (uint32_t)__popcll(m & below(lane)) : G2S_DEV_INVALID;
-      got += (uint32_t)__popcll(m);
-    }
-    lds_sync();
-#pragma unroll
-    for (uint32_t c = 0; c < ALAB / 64u; c++)
-      if (keep_at[c] != G2S_DEV_INVALID) { cnode[keep_at[c]] = keep_n[c]; clab[keep_at[c]] = keep_l[c]; crem[keep_at[c]] = keep_r[c]; }
-    lds_sync();
-#pragma unroll
-    for (int s = 0; s < G2S_SEG_ASETS; s++) {
-      const uint32_t e = (uint32_t)s * 64u + (uint32_t)lane;
-      if (e < nA) { an[s] = cnode[e]; al[s] = clab[e]; ar[s] = crem[e]; }
-    }
-    lds_sync();
-  }
-  // the entries as k-mer index intervals [alo, ahi]; lanes without an entry hold an empty interval
-  uint32_t alo[G2S_SEG_ASETS], ahi[G2S_SEG_ASETS];
-  uint32_t nvis = 0, xa = 0;
-#pragma unroll
-  for (int s = 0; s < G2S_SEG_ASETS; s++) {
-    const bool have = (uint32_t)s * 64u + (uint32_t)lane < nA;
-    const uint32_t steps = have ? min(ar[s], (uint32_t)gd.right_half - al[s]) : 0u;
-    const uint32_t w0 = an[s] ^ 1u, idx = w0 >> 1;
-    alo[s] = have ? ((w0 & 1u) ? idx - steps : idx) : 1u;
-    ahi[s] = have ? ((w0 & 1u) ? idx : idx + steps) : 0u;
-    if ((uint32_t)s * 64u < nA) {
-      nvis += wave_sum(have ? steps + 1u : 0u);  // (intervals of one unitig may overlap: an upper bound of the set's size)
-      xa += wave_sum(have ? min(steps + 1u, (uint32_t)gd.right_half - al[s]) : 0u);
-    }
-  }
-  // Q7 in the right set, conservatively as in the LDS tier: both strands of some k-mer are in
-  // it = an entry of each orientation with overlapping intervals
-  if (!overflow) {
-    bool both = false;
-    {
-      uint64_t odd = 0, even = 0;
+      for (uint32_t c = 0; c < ALAB / 64u; c++)
+        if (keep_at[c] != G2S_DEV_INVALID) { cnode[keep_at[c]] = keep_n[c]; clab[keep_at[c]] = keep_l[c]; crem[keep_at[c]] = keep_r[c]; }
+      lds_sync();
 #pragma unroll
       for (int s = 0; s < G2S_SEG_ASETS; s++) {
-        const bool have = (uint32_t)s * 64u + (uint32_t)lane < nA;
-        odd |= __ballot(have && (an[s] & 1u));
-        even |= __ballot(have && !(an[s] & 1u));
+        const uint32_t e = (uint32_t)s * 64u + (uint32_t)lane;
+        if (e < nA) { an[s] = cnode[e]; al[s] = clab[e]; ar[s] = crem[e]; }
       }
-      both = odd != 0 && even != 0;
+      lds_sync();
     }
-    if (both) {
-      for (uint32_t e = 0; e < nA && !(flags & G2S_DEV_Q7_A); e++) {
-        uint32_t lo_e = 0, hi_e = 0, or_e = 0;
+    // the entries as k-mer index intervals [alo, ahi]; lanes without an entry hold an empty interval
 #pragma unroll
-        for (int s = 0; s < G2S_SEG_ASETS; s++)
-          if ((e >> 6) == (uint32_t)s) { lo_e = rl(alo[s], (int)(e & 63u)); hi_e = rl(ahi[s], (int)(e & 63u)); or_e = rl(an[s], (int)(e & 63u)) & 1u; }
-#pragma unroll
-        for (int s = 0; s < G2S_SEG_ASETS; s++)
-          if ((uint32_t)s * 64u < nA && __ballot(alo[s] <= hi_e && lo_e <= ahi[s] && ((an[s] & 1u) != or_e) && alo[s] <= ahi[s]))
-            flags |= G2S_DEV_Q7_A;
+    for (int s = 0; s < G2S_SEG_ASETS; s++) {
+      const bool have = (uint32_t)s * 64u + (uint32_t)lane < nA;
+      const uint32_t steps = have ? min(ar[s], (uint32_t)gd.right_half - al[s]) : 0u;
+      const uint32_t w0 = an[s] ^ 1u, idx = w0 >> 1;
+      alo[s] = have ? ((w0 & 1u) ? idx - steps : idx) : 1u;
+      ahi[s] = have ? ((w0 & 1u) ? idx : idx + steps) : 0u;
+      if ((uint32_t)s * 64u < nA) {
+        nvis += wave_sum(have ? steps + 1u : 0u);  // (intervals of one unitig may overlap: an upper bound of the set's size)
+        xa += wave_sum(have ? min(steps + 1u, (uint32_t)gd.right_half - al[s]) : 0u);
       }
+    }
+    // Q7 in the right set, conservatively as in the LDS tier: both strands of some k-mer are in
+    // it = an entry of each orientation with overlapping intervals
+    if (!overflow) {
+      bool both = false;
+      {
+        uint64_t odd = 0, even = 0;
+#pragma unroll
+        for (int s = 0; s < G2S_SEG_ASETS; s++) {
+          const bool have = (uint32_t)s * 64u + (uint32_t)lane < nA;
+          odd |= __ballot(have && (an[s] & 1u));
+          even |= __ballot(have && !(an[s] & 1u));
+        }
+        both = odd != 0 && even != 0;
+      }
+      if (both) {
+        for (uint32_t e = 0; e < nA && !(flags & G2S_DEV_Q7_A); e++) {
+          uint32_t lo_e = 0, hi_e = 0, or_e = 0;
+#pragma unroll
+          for (int s = 0; s < G2S_SEG_ASETS; s++)
+            if ((e >> 6) == (uint32_t)s) { lo_e = rl(alo[s], (int)(e & 63u)); hi_e = rl(ahi[s], (int)(e & 63u)); or_e = rl(an[s], (int)(e & 63u)) & 1u; }
+#pragma unroll
+          for (int s = 0; s < G2S_SEG_ASETS; s++)
+            if ((uint32_t)s * 64u < nA && __ballot(alo[s] <= hi_e && lo_e <= ahi[s] && ((an[s] & 1u) != or_e) && alo[s] <= ahi[s]))
+              flags |= G2S_DEV_Q7_A;
+        }
+      }
+    }
+  } else {
+    // ---- (BIG) the same label-correcting search with room for G2S_SEGX_EA entries.
+    // LDS: tab[AS] u64 (node << 32 | label); the two queues live in the workgroup's scratch.
+    constexpr uint32_t AS = G2S_SEGX_AS, EA = G2S_SEGX_EA, QCAP = G2S_SEGX_QCAP;
+    uint64_t* tab = (uint64_t*)lds;
+    uint32_t* gq = scr + 6u * G2S_SEGX_CAP;
+    bool stuck = false;  // (per lane) a probe ran past its bound
+    for (uint32_t i = (uint32_t)lane; i < AS; i += 64u) tab[i] = SEGX_EMPTY64;
+    lds_sync();
+    auto a_hash = [&](uint32_t p) -> uint32_t { uint32_t x = p; x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x & (AS - 1u); };
+    auto relabel = [&](bool active, uint32_t p, uint32_t dp) -> bool {
+      bool improved = false, fresh = false;
+      if (active) {
+        const uint64_t key = ((uint64_t)p << 32) | dp;
+        uint32_t h = a_hash(p);
+        uint32_t guard = 0;
+        while (true) {
+          if (++guard > 4u * AS) { stuck = true; break; }
+          const uint64_t c = tab[h];
+          if ((uint32_t)(c >> 32) == p) {
+            improved = atomicMin((unsigned long long*)&tab[h], (unsigned long long)key) > key;
+            break;
+          }
+          if (c == SEGX_EMPTY64) {
+            const unsigned long long prev =
+                atomicCAS((unsigned long long*)&tab[h], (unsigned long long)SEGX_EMPTY64, (unsigned long long)key);
+            if (prev == SEGX_EMPTY64) { improved = true; fresh = true; break; }
+            continue;
+          }
+          h = (h + 1u) & (AS - 1u);
+        }
+      }
+      nA += (uint32_t)__popcll(__ballot(fresh));
+      return improved;
+    };
+    if (!overflow) {
+      uint32_t cur = 0, ne = 0;
+      {
+        const uint32_t sd = (lane <= rmf && lane < 32) ? rseeds[lane] : G2S_DEV_INVALID;
+        const bool imp = relabel(sd != G2S_DEV_INVALID && lane <= gd.right_half, sd, (uint32_t)lane);
+        const uint64_t m = __ballot(imp);
+        if (imp) gq[(uint32_t)__popcll(m & below(lane))] = sd;
+        ne = (uint32_t)__popcll(m);
+      }
+      while (ne > 0 && !overflow) {
+        roundsA++;
+        if (roundsA > 65535u) { overflow = true; flags |= G2S_DEV_OVERFLOW_A | G2S_DEV_WATCHDOG; break; }
+        // (the queue was written by this wave; lines of it this compute unit read for an earlier gap go)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const uint32_t* qc = gq + cur * QCAP;
+        uint32_t* qn = gq + (cur ^ 1u) * QCAP;
+        uint32_t nn = 0;
+        for (uint32_t e0 = 0; e0 < ne && !overflow; e0 += 64u) {
+          const bool mine = e0 + (uint32_t)lane < ne;
+          const uint32_t v = mine ? qc[e0 + (uint32_t)lane] : 0u;
+          uint32_t d = 0;
+          if (mine) {
+            uint32_t slot = a_hash(v), guard = 0;
+            while ((uint32_t)(tab[slot] >> 32) != v) {
+              if (++guard > AS) { stuck = true; break; }
+              slot = (slot + 1u) & (AS - 1u);
+            }
+            d = (uint32_t)tab[slot];
+          }
+          if (__ballot(stuck)) { overflow = true; flags |= G2S_DEV_OVERFLOW_A | G2S_DEV_WATCHDOG; break; }
+          uint4 rec = make_uint4(G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID);
+          uint32_t r = 0;
+          if (mine) {
+            const uint4* u = (const uint4*)(urec + (size_t)(v ^ 1u) * 8);
+            rec = u[0];
+            r = u[1].x;
+          }
+          const uint32_t steps = min(r, (uint32_t)gd.right_half - d);
+          const bool live = mine && d + steps < (uint32_t)gd.right_half;
+          if (!live) rec = make_uint4(G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID);
+          const uint32_t dchild = d + steps + 1u;
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const uint32_t w = q == 0 ? rec.x : q == 1 ? rec.y : q == 2 ? rec.z : rec.w;
+            const bool imp = relabel(w != G2S_DEV_INVALID && !overflow, w ^ 1u, dchild);
+            const uint64_t m = __ballot(imp);
+            if (imp) {
+              const uint32_t at = nn + (uint32_t)__popcll(m & below(lane));
+              if (at < QCAP) qn[at] = w ^ 1u;
+            }
+            nn += (uint32_t)__popcll(m);
+            // (at most EA + 64 of the AS slots are ever taken, so every probe ends)
+            if (nn > QCAP || nA > EA) { overflow = true; flags |= G2S_DEV_OVERFLOW_A | G2S_DEV_WHY_RS; }
+            if (__ballot(stuck)) { overflow = true; flags |= G2S_DEV_OVERFLOW_A | G2S_DEV_WATCHDOG; }
+          }
+        }
+        lds_sync();
+        cur ^= 1u;
+        ne = nn;
+      }
+    }
+    if (!overflow) {
+      // the entries, packed to the front of the table (in place: the write cursor never passes the read cursor)
+      uint32_t got = 0;
+      for (uint32_t c = 0; c < AS; c += 64u) {
+        const uint64_t e = tab[c + (uint32_t)lane];
+        const bool have = e != SEGX_EMPTY64;
+        const uint64_t m = __ballot(have);
+        if (have) tab[got + (uint32_t)__popcll(m & below(lane))] = e;
+        got += (uint32_t)__popcll(m);
+      }
+      lds_sync();
+      // entry -> k-mer index interval (lo << 32 | orientation << 31 | hi): one record load each
+      uint32_t acc_vis = 0, acc_xa = 0;
+      uint32_t* o = dbg ? dbg + (size_t)x * dbg_words : nullptr;
+#pragma unroll 2
+      for (uint32_t e0 = 0; e0 < nA; e0 += 64u) {
+        const uint32_t e = e0 + (uint32_t)lane;
+        const bool have = e < nA;
+        const uint64_t ent = have ? tab[e] : 0ull;
+        const uint32_t v = (uint32_t)(ent >> 32), label = (uint32_t)ent;
+        const uint32_t r = have ? urec[(size_t)(v ^ 1u) * 8 + 4] : 0u;
+        const uint32_t steps = have ? min(r, (uint32_t)gd.right_half - label) : 0u;
+        const uint32_t w0 = v ^ 1u, idx = w0 >> 1;
+        const uint32_t lo = (w0 & 1u) ? idx - steps : idx, hi = (w0 & 1u) ? idx : idx + steps;
+        if (have) {
+          tab[e] = ((uint64_t)lo << 32) | ((uint64_t)(v & 1u) << 31) | hi;
+          acc_vis += steps + 1u;
+          acc_xa += min(steps + 1u, (uint32_t)gd.right_half - label);
+          if (o && 9u + 2u * e < dbg_words) { o[8u + 2u * e] = v; o[9u + 2u * e] = label; }
+        }
+      }
+      nvis = wave_sum(acc_vis);
+      xa = wave_sum(acc_xa);
+      uint32_t n2 = 2;
+      while (n2 < nA) n2 <<= 1;
+      for (uint32_t i = nA + (uint32_t)lane; i < n2; i += 64u) tab[i] = SEGX_EMPTY64;
+      lds_sync();
+      lds_sort64(tab, n2, lane);
+      // Q7 in the right set, conservatively as above: an entry of each orientation with overlapping intervals
+      bool cross = false;
+      M = lds_merge_intervals(tab, nA, lane, &cross);
+      if (cross) flags |= G2S_DEV_Q7_A;
+      ivP = M ? 1u << (31 - __builtin_clz(M)) : 0u;
     }
   }
   // k-mer index x in the right set?  (wave-uniform)
@@ -409,126 +649,495 @@ __global__ __launch_bounds__(64) void g2s_fill_seg(const uint32_t* __restrict__ 
       if (key == best) { if (td >= base) { c1 = c; s1 = st; } else { c2 = c; s2 = st; } }
     }
   };
-  if (!overflow) {
-    // left seeds: left.substr(d, k) enters at depth d with the value 1 ASSIGNED (:995-1015, :1082-1105)
-    const uint32_t sd = lane <= lmf ? lseeds[lane] : G2S_DEV_INVALID;
-    const uint32_t s0 = rl(sd, 0);
-    // The usual flank is a stretch of ONE unitig: seed d is the d-th node after seed 0 and the walk
-    // from seed 0 stays unitig-internal for lmf steps.  Levels 0 .. lmf-1 are then that chain with
-    // count 1 (every state has the next seed as its only successor, and a seed's value is 1 anyway):
-    // one segment, and the seed at depth lmf as the only pending event, instead of lmf rounds.
-    bool chain = lmf >= 1 && s0 != G2S_DEV_INVALID && __ballot(lane <= lmf && sd != seg_node(s0, (uint32_t)lane)) == 0ull;
-    if (chain) chain = uni(urec[(size_t)s0 * 8 + 4]) >= (uint32_t)lmf;
-    // (a target k-mer inside the chain could make one of its states a sink or a traceback start: every
-    // state there is a source of its own, which only single-state segments express: the general path then)
-    if (chain) chain = __ballot(seg_pos(s0, (uint32_t)lmf, tg) >= 0) == 0ull;
-    if (chain) {
-      if (lane == 0) {
-        s_node[0] = s0; s_dl[0] = (uint32_t)lmf << 16; s_cnt[0] = 1u; s_p01[0] = s_p23[0] = 0xFFFFFFFFu; s_aux[0] = 0u;
+  if constexpr (!BIG) {
+    if (!overflow) {
+      // left seeds: left.substr(d, k) enters at depth d with the value 1 ASSIGNED (:995-1015, :1082-1105)
+      const uint32_t sd = lane <= lmf ? lseeds[lane] : G2S_DEV_INVALID;
+      const uint32_t s0 = rl(sd, 0);
+      // The usual flank is a stretch of ONE unitig: seed d is the d-th node after seed 0 and the walk
+      // from seed 0 stays unitig-internal for lmf steps.  Levels 0 .. lmf-1 are then that chain with
+      // count 1 (every state has the next seed as its only successor, and a seed's value is 1 anyway):
+      // one segment, and the seed at depth lmf as the only pending event, instead of lmf rounds.
+      bool chain = lmf >= 1 && s0 != G2S_DEV_INVALID && __ballot(lane <= lmf && sd != seg_node(s0, (uint32_t)lane)) == 0ull;
+      if (chain) chain = uni(urec[(size_t)s0 * 8 + 4]) >= (uint32_t)lmf;
+      // (a target k-mer inside the chain could make one of its states a sink or a traceback start: every
+      // state there is a source of its own, which only single-state segments express: the general path then)
+      if (chain) chain = __ballot(seg_pos(s0, (uint32_t)lmf, tg) >= 0) == 0ull;
+      if (chain) {
+        if (lane == 0) {
+          s_node[0] = s0; s_dl[0] = (uint32_t)lmf << 16; s_cnt[0] = 1u; s_p01[0] = s_p23[0] = 0xFFFFFFFFu; s_aux[0] = 0u;
+        }
+        nseg = 1; gen = 1;
+        sb += (uint32_t)lmf;
+        xb += (uint32_t)lmf;
+        ev = efx = 1ull << lmf;
+        if (lane == lmf) { en = sd; ed = lmf; ec = 1; ep01 = 0xFFFF0000u; ep23 = 0xFFFFFFFFu; es = 0u; est = (uint32_t)lmf | ((uint32_t)lmf << 16); }
+      } else {
+        ev = efx = __ballot(sd != G2S_DEV_INVALID && lane <= D);
+        if ((ev >> lane) & 1ull) { en = sd; ed = lane; ec = 1; ep01 = ep23 = 0xFFFFFFFFu; es = 0u; est = (uint32_t)lane | ((uint32_t)lane << 16); }
       }
-      nseg = 1; gen = 1;
-      sb += (uint32_t)lmf;
-      xb += (uint32_t)lmf;
-      ev = efx = 1ull << lmf;
-      if (lane == lmf) { en = sd; ed = lmf; ec = 1; ep01 = 0xFFFF0000u; ep23 = 0xFFFFFFFFu; es = 0u; est = (uint32_t)lmf | ((uint32_t)lmf << 16); }
-    } else {
-      ev = efx = __ballot(sd != G2S_DEV_INVALID && lane <= D);
-      if ((ev >> lane) & 1ull) { en = sd; ed = lane; ec = 1; ep01 = ep23 = 0xFFFFFFFFu; es = 0u; est = (uint32_t)lane | ((uint32_t)lane << 16); }
     }
-  }
-  while (ev && !overflow) {
-    if (((ev >> lane) & 1ull) && es == 0u) {  // one round trip for all events created last round
-      if (ed < lmf) { es = 1u; erec = *(const uint4*)(succ + (size_t)en * 4); }  // above the flank: one state, leaves at once
-      else { const uint4* u = (const uint4*)(urec + (size_t)en * 8); erec = u[0]; es = u[1].x + 1u; }
-    }
-    // ---- which events are final: depth below the horizon
-    uint32_t H = SEG_INF;
-    for (uint64_t m = ev; m; m &= m - 1) {
-      const int l = __builtin_ctzll(m);
-      H = min(H, (uint32_t)rl((uint32_t)ed, l) + rl(es, l));
-    }
-    const bool valid = (ev >> lane) & 1ull;
-    const uint64_t sel = __ballot(valid && (uint32_t)ed < H);
-    const uint32_t nsel = (uint32_t)__popcll(sel);
-    if (nseg + nsel > G2S_SEG_CAP) { overflow = true; flags |= G2S_DEV_OVERFLOW_B | G2S_DEV_WHY_LOG; break; }
-    const bool mine = (sel >> lane) & 1ull;
-    const uint32_t cnt = ((efx >> lane) & 1ull) ? 1u : ec;
-    const uint32_t lcap = min(es, (uint32_t)(D - ed + 1));
-    uint32_t elen = lcap;
-    const uint32_t esid = nseg + (uint32_t)__popcll(sel & below(lane));
-    // ---- their lengths under the pruning rule, their target hits (one segment at a time, wave-uniform)
-    for (uint64_t m = sel; m; m &= m - 1) {
-      const int l = __builtin_ctzll(m);
-      const uint32_t node = rl(en, l), lc = rl(lcap, l), c = rl(cnt, l), stl = rl(est, l);
-      const int depth = (int)rl((uint32_t)ed, l);
-      uint32_t L = lc;
-      if (lc > 1u && depth + (int)lc - 1 >= gd.prune_from) {  // interior states are entered under :1050
-        const uint32_t t1 = (uint32_t)max(1, gd.prune_from - depth);
-        const uint32_t idx0 = node >> 1;
-        if (!(node & 1u)) L = covered_up(idx0 + t1, idx0 + lc - 1u) - idx0 + 1u;
-        else L = idx0 - covered_down(idx0 - t1, idx0 - (lc - 1u)) + 1u;
-        if (lane == l) elen = L;
+    while (ev && !overflow) {
+      if (((ev >> lane) & 1ull) && es == 0u) {  // one round trip for all events created last round
+        if (ed < lmf) { es = 1u; erec = *(const uint4*)(succ + (size_t)en * 4); }  // above the flank: one state, leaves at once
+        else { const uint4* u = (const uint4*)(urec + (size_t)en * 8); erec = u[0]; es = u[1].x + 1u; }
       }
-      sb += L;
-      xb += min(L, (uint32_t)(D - depth));
-      note_hits(node, L, depth, c, stl);
-    }
-    if (mine) {
-      s_node[esid] = en;
-      s_dl[esid] = (uint32_t)ed | (elen << 16);
-      s_cnt[esid] = cnt;
-      s_p01[esid] = ep01;
-      s_p23[esid] = ep23;
-      s_aux[esid] = gen;
-    }
-    nseg += nsel;
-    // ---- segments that reached the end of their stretch leave through the successor table
-    const bool exits = mine && elen == es && ed + (int)elen - 1 < D;
-    const uint4 rec = erec;  // elen == lcap == es: the walk reached the node the record belongs to
-    const uint32_t xd = (uint32_t)ed + elen;  // depth of the children
-    const uint32_t est_sel = est;             // (add_event below may reuse a selected lane for a new event)
-    ev &= ~sel;
-    efx &= ~sel;
-    for (uint64_t m = __ballot(exits); m && !overflow; m &= m - 1) {
-      const int l = __builtin_ctzll(m);
-      const int dw = (int)rl(xd, l);
-      const uint32_t c = rl(cnt, l), par = rl(esid, l), pst = rl(est_sel, l);
+      // ---- which events are final: depth below the horizon
+      uint32_t H = SEG_INF;
+      for (uint64_t m = ev; m; m &= m - 1) {
+        const int l = __builtin_ctzll(m);
+        H = min(H, (uint32_t)rl((uint32_t)ed, l) + rl(es, l));
+      }
+      const bool valid = (ev >> lane) & 1ull;
+      const uint64_t sel = __ballot(valid && (uint32_t)ed < H);
+      const uint32_t nsel = (uint32_t)__popcll(sel);
+      if (nseg + nsel > G2S_SEG_CAP) { overflow = true; flags |= G2S_DEV_OVERFLOW_B | G2S_DEV_WHY_LOG; break; }
+      const bool mine = (sel >> lane) & 1ull;
+      const uint32_t cnt = ((efx >> lane) & 1ull) ? 1u : ec;
+      const uint32_t lcap = min(es, (uint32_t)(D - ed + 1));
+      uint32_t elen = lcap;
+      const uint32_t esid = nseg + (uint32_t)__popcll(sel & below(lane));
+      // ---- their lengths under the pruning rule, their target hits (one segment at a time, wave-uniform)
+      for (uint64_t m = sel; m; m &= m - 1) {
+        const int l = __builtin_ctzll(m);
+        const uint32_t node = rl(en, l), lc = rl(lcap, l), c = rl(cnt, l), stl = rl(est, l);
+        const int depth = (int)rl((uint32_t)ed, l);
+        uint32_t L = lc;
+        if (lc > 1u && depth + (int)lc - 1 >= gd.prune_from) {  // interior states are entered under :1050
+          const uint32_t t1 = (uint32_t)max(1, gd.prune_from - depth);
+          const uint32_t idx0 = node >> 1;
+          if (!(node & 1u)) L = covered_up(idx0 + t1, idx0 + lc - 1u) - idx0 + 1u;
+          else L = idx0 - covered_down(idx0 - t1, idx0 - (lc - 1u)) + 1u;
+          if (lane == l) elen = L;
+        }
+        sb += L;
+        xb += min(L, (uint32_t)(D - depth));
+        note_hits(node, L, depth, c, stl);
+      }
+      if (mine) {
+        s_node[esid] = en;
+        s_dl[esid] = (uint32_t)ed | (elen << 16);
+        s_cnt[esid] = cnt;
+        s_p01[esid] = ep01;
+        s_p23[esid] = ep23;
+        s_aux[esid] = gen;
+      }
+      nseg += nsel;
+      // ---- segments that reached the end of their stretch leave through the successor table
+      const bool exits = mine && elen == es && ed + (int)elen - 1 < D;
+      const uint4 rec = erec;  // elen == lcap == es: the walk reached the node the record belongs to
+      const uint32_t xd = (uint32_t)ed + elen;  // depth of the children
+      const uint32_t est_sel = est;             // (add_event below may reuse a selected lane for a new event)
+      ev &= ~sel;
+      efx &= ~sel;
+      for (uint64_t m = __ballot(exits); m && !overflow; m &= m - 1) {
+        const int l = __builtin_ctzll(m);
+        const int dw = (int)rl(xd, l);
+        const uint32_t c = rl(cnt, l), par = rl(esid, l), pst = rl(est_sel, l);
 #pragma unroll 1
-      for (int q = 0; q < 4; q++) {
-        const uint32_t w = rl(q == 0 ? rec.x : q == 1 ? rec.y : q == 2 ? rec.z : rec.w, l);
-        if (w != G2S_DEV_INVALID && (dw < gd.prune_from || contains(w >> 1))) add_event(w, dw, c, par, pst);  // :1050
+        for (int q = 0; q < 4; q++) {
+          const uint32_t w = rl(q == 0 ? rec.x : q == 1 ? rec.y : q == 2 ? rec.z : rec.w, l);
+          if (w != G2S_DEV_INVALID && (dw < gd.prune_from || contains(w >> 1))) add_event(w, dw, c, par, pst);  // :1050
+        }
+      }
+      gen++;
+    }
+  } else {
+    // ---- (BIG) the same search with the pending events in LDS.  Lane = event only while a chunk of them is
+    // looked at; an event lives in a SLOT (fields below), found by (node, depth) through an open-addressing
+    // table ht (node << 32 | depth << 16 | slot).  Children of a whole chunk of final events are inserted
+    // by all lanes at once: claim by compare-and-swap, counts merged with atomic adds (at most four
+    // parents of at most 2^30 - 1 each: no wrap; clamped when read), stop depths with atomic min / max.
+    // A selected event leaves a tombstone behind (no later proposal can carry its key: all have depths
+    // at or above the horizon); the table is rebuilt from the pending list when tombstones pile up.
+    // LDS (words): iv 2 EA | slots: node, depth|fixed<<15|parents<<16, count, p01, p23, stop lo, stop hi,
+    //   states to the unitig's end, table position [PE each], exit record [4 PE] | ht [2 HS] |
+    //   pending list x 2, free slots, new slots, final events of the round [PE each]
+    constexpr uint32_t PE = G2S_SEGX_PE, HS = G2S_SEGX_HS;
+    uint32_t* e_node = lds + 2u * G2S_SEGX_EA;
+    uint32_t* e_dp = e_node + PE;
+    uint32_t* e_cnt = e_dp + PE;
+    uint32_t* e_p01 = e_cnt + PE;
+    uint32_t* e_p23 = e_p01 + PE;
+    uint32_t* e_slo = e_p23 + PE;
+    uint32_t* e_shi = e_slo + PE;
+    uint32_t* e_es = e_shi + PE;
+    uint32_t* e_hpos = e_es + PE;
+    uint4* e_rec = (uint4*)(e_hpos + PE);
+    uint64_t* ht = (uint64_t*)(e_rec + PE);
+    uint32_t* plist = (uint32_t*)(ht + HS);
+    uint32_t* fstack = plist + 2u * PE;
+    uint32_t* newl = fstack + PE;
+    uint32_t* sell = newl + PE;
+    static_assert(2u * G2S_SEGX_EA + 9u * PE + 4u * PE + 2u * HS + 5u * PE + 64u <= SEGX_LDS_WORDS, "LDS layout of the large variant");
+    uint32_t np = 0, npn = 0, nnew = 0, nfree = PE, ntomb = 0, pcur = 0;
+    uint32_t acc_sb = 0, acc_xb = 0;
+    bool stuckb = false;  // (per lane) a probe ran past its bound
+    for (uint32_t i = (uint32_t)lane; i < HS; i += 64u) ht[i] = SEGX_EMPTY64;
+    for (uint32_t i = (uint32_t)lane; i < PE; i += 64u) fstack[i] = PE - 1u - i;  // slot 0 on top
+    lds_sync();
+    auto e_hash = [&](uint32_t w, uint32_t dw) -> uint32_t {
+      uint32_t h = w * 0x9E3779B1u ^ dw * 0x85EBCA6Bu;
+      h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
+      return h & (HS - 1u);
+    };
+    // index of the last interval that begins at or before k-mer index q (-1: none), per lane
+    auto iv_find = [&](uint32_t q) -> int {
+      uint32_t pos = 0;
+      for (uint32_t st = ivP; st; st >>= 1) {
+        const uint32_t pp = pos + st;
+        if (pp <= M && ivw[2u * (pp - 1u) + 1u] <= q) pos = pp;
+      }
+      return (int)pos - 1;
+    };
+    // proposals of all lanes: event (w, dw) gains count c from segment par (0xFFFF: a seed, no parent)
+    auto ev_insert = [&](bool act, uint32_t w, uint32_t dw, uint32_t c, uint32_t par, uint32_t pslo, uint32_t pshi, bool fixed) {
+      const uint64_t am = __ballot(act);
+      const uint32_t na = (uint32_t)__popcll(am);
+      if (na == 0u) return;
+      if (nfree < na) { overflow = true; flags |= G2S_DEV_OVERFLOW_B | G2S_DEV_WHY_FRONTIER; return; }
+      uint32_t slot = 0;
+      if (act) slot = fstack[nfree - 1u - (uint32_t)__popcll(am & below(lane))];
+      nfree -= na;
+      bool src = false;
+      if (act && dw <= (uint32_t)lmf) { const uint32_t ls = l_seed[dw]; src = ls != G2S_DEV_INVALID && (w >> 1) == (ls >> 1); }  // :1270
+      const uint64_t kpart = ((uint64_t)w << 32) | ((uint64_t)dw << 16);
+      if (act) {  // the candidate slot is complete before it can be seen through the table
+        e_node[slot] = w;
+        e_dp[slot] = dw | (fixed ? 0x8000u : 0u) | (par != SEG_NOPAR ? 0x10000u : 0u);
+        e_cnt[slot] = c;
+        e_p01[slot] = 0xFFFF0000u | par;
+        e_p23[slot] = 0xFFFFFFFFu;
+        e_slo[slot] = src ? dw : pslo;
+        e_shi[slot] = src ? dw : pshi;
+        e_es[slot] = 0u;
+      }
+      bool fresh = false, merged = false;
+      uint32_t mslot = 0;
+      uint32_t pos = act ? e_hash(w, dw) : 0u;
+      int freepos = -1;
+      uint32_t guard = 0;
+      if (act) {  // among what was there before this call; the first free position of the probe sequence
+        while (true) {
+          if (++guard > 2u * HS) { stuckb = true; break; }
+          const uint64_t cc = ht[pos];
+          if (cc == SEGX_EMPTY64) break;
+          if (cc == SEGX_TOMB64) { if (freepos < 0) freepos = (int)pos; }
+          else if ((cc & ~0xFFFFull) == kpart) { merged = true; mslot = (uint32_t)cc & 0xFFFFu; break; }
+          pos = (pos + 1u) & (HS - 1u);
+        }
+        if (freepos >= 0) pos = (uint32_t)freepos;
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (act && !merged && !stuckb) {  // claim it, or meet the lane that did with the same key
+        while (true) {
+          if (++guard > 8u * HS) { stuckb = true; break; }
+          const uint64_t cc = ht[pos];
+          if (cc == SEGX_EMPTY64 || cc == SEGX_TOMB64) {
+            const unsigned long long prev = atomicCAS((unsigned long long*)&ht[pos], (unsigned long long)cc, (unsigned long long)(kpart | slot));
+            if (prev == cc) { fresh = true; e_hpos[slot] = pos; break; }
+            continue;
+          }
+          if ((cc & ~0xFFFFull) == kpart) { merged = true; mslot = (uint32_t)cc & 0xFFFFu; break; }
+          pos = (pos + 1u) & (HS - 1u);
+        }
+      }
+      if (merged) {
+        atomicAdd(&e_cnt[mslot], c);
+        if (par != SEG_NOPAR) {
+          const uint32_t kk = (atomicAdd(&e_dp[mslot], 0x10000u) >> 16) & 0xFu;
+          if (kk == 0u) atomicAnd(&e_p01[mslot], 0xFFFF0000u | par);
+          else if (kk == 1u) atomicAnd(&e_p01[mslot], 0x0000FFFFu | (par << 16));
+          else if (kk == 2u) atomicAnd(&e_p23[mslot], 0xFFFF0000u | par);
+          else if (kk == 3u) atomicAnd(&e_p23[mslot], 0x0000FFFFu | (par << 16));
+        }
+        if (!src) { atomicMin(&e_slo[mslot], pslo); atomicMax(&e_shi[mslot], pshi); }
+      }
+      const uint64_t mm = __ballot(merged);
+      if (merged) fstack[nfree + (uint32_t)__popcll(mm & below(lane))] = slot;  // the candidate slot was not needed
+      nfree += (uint32_t)__popcll(mm);
+      const uint64_t fm = __ballot(fresh);
+      if (fresh) {
+        const uint32_t at = (uint32_t)__popcll(fm & below(lane));
+        plist[(pcur ^ 1u) * PE + npn + at] = slot;
+        newl[nnew + at] = slot;
+      }
+      npn += (uint32_t)__popcll(fm);
+      nnew += (uint32_t)__popcll(fm);
+      lds_sync();
+      // Q7: the other strand pending at this depth (looked up after the insertions of this call)
+      bool other = false;
+      if (fresh) {
+        const uint64_t okey = ((uint64_t)(w ^ 1u) << 32) | ((uint64_t)dw << 16);
+        uint32_t p2 = e_hash(w ^ 1u, dw), g2 = 0;
+        while (true) {
+          if (++g2 > 2u * HS) { stuckb = true; break; }
+          const uint64_t cc = ht[p2];
+          if (cc == SEGX_EMPTY64) break;
+          if (cc != SEGX_TOMB64 && (cc & ~0xFFFFull) == okey) { other = true; break; }
+          p2 = (p2 + 1u) & (HS - 1u);
+        }
+      }
+      if (__ballot(other)) flags |= G2S_DEV_Q7_B;
+      if (__ballot(stuckb)) { overflow = true; flags |= G2S_DEV_OVERFLOW_B | G2S_DEV_WATCHDOG; }
+    };
+    if (!overflow) {
+      // left seeds: left.substr(d, k) enters at depth d with the value 1 ASSIGNED (:995-1015, :1082-1105)
+      const uint32_t sd = lane <= lmf ? lseeds[lane] : G2S_DEV_INVALID;
+      const uint32_t s0 = rl(sd, 0);
+      bool chain = lmf >= 1 && s0 != G2S_DEV_INVALID && __ballot(lane <= lmf && sd != seg_node(s0, (uint32_t)lane)) == 0ull;
+      if (chain) chain = uni(urec[(size_t)s0 * 8 + 4]) >= (uint32_t)lmf;
+      if (chain) chain = __ballot(seg_pos(s0, (uint32_t)lmf, tg) >= 0) == 0ull;
+      if (chain) {  // (see above: the flank as one segment, the seed at depth lmf the only pending event)
+        if (lane == 0) {
+          s_node[0] = s0; s_dl[0] = (uint32_t)lmf << 16; s_cnt[0] = 1u; s_p01[0] = s_p23[0] = 0xFFFFFFFFu; s_gen[0] = 0u;
+        }
+        nseg = 1; gen = 1;
+        sb += (uint32_t)lmf;
+        xb += (uint32_t)lmf;
+        ev_insert(lane == lmf, sd, (uint32_t)lmf, 1u, 0u, (uint32_t)lmf, (uint32_t)lmf, true);
+      } else {
+        ev_insert(sd != G2S_DEV_INVALID && lane <= D, sd, (uint32_t)lane, 1u, SEG_NOPAR, (uint32_t)lane, (uint32_t)lane, true);
+      }
+      pcur ^= 1u; np = npn; npn = 0;
+    }
+    while (np > 0 && !overflow) {
+      // ---- one round trip for all events created last round: states to the end of the unitig, exit record
+      for (uint32_t i0 = 0; i0 < nnew; i0 += 64u) {
+        if (i0 + (uint32_t)lane < nnew) {
+          const uint32_t slot = newl[i0 + (uint32_t)lane];
+          const uint32_t node = e_node[slot], dd = e_dp[slot] & 0x7FFFu;
+          if ((int)dd < lmf) { e_rec[slot] = *(const uint4*)(succ + (size_t)node * 4); e_es[slot] = 1u; }  // above the flank: one state
+          else { const uint4* u = (const uint4*)(urec + (size_t)node * 8); e_rec[slot] = u[0]; e_es[slot] = u[1].x + 1u; }
+        }
+      }
+      nnew = 0;
+      lds_sync();
+      // ---- the horizon
+      const uint32_t* pl = plist + pcur * PE;
+      uint32_t hmin = SEG_INF;
+      for (uint32_t i0 = 0; i0 < np; i0 += 64u)
+        if (i0 + (uint32_t)lane < np) { const uint32_t slot = pl[i0 + (uint32_t)lane]; hmin = min(hmin, (e_dp[slot] & 0x7FFFu) + e_es[slot]); }
+      for (int o = 32; o > 0; o >>= 1) hmin = min(hmin, (uint32_t)__shfl_xor((int)hmin, o));
+      const uint32_t H = uni(hmin);
+      // ---- final events: gathered first (they are scattered over the pending list), then worked on in
+      // full chunks — every chunk below costs a few thousand cycles whatever the number of its events
+      uint32_t nsl = 0;
+      for (uint32_t i0 = 0; i0 < np; i0 += 64u) {
+        const bool have = i0 + (uint32_t)lane < np;
+        const uint32_t slot = have ? pl[i0 + (uint32_t)lane] : 0u;
+        const bool fin = have && (e_dp[slot] & 0x7FFFu) < H;
+        const uint64_t fm = __ballot(fin), km = __ballot(have && !fin);
+        if (fin) sell[nsl + (uint32_t)__popcll(fm & below(lane))] = slot;
+        if (have && !fin) plist[(pcur ^ 1u) * PE + npn + (uint32_t)__popcll(km & below(lane))] = slot;  // the others stay pending
+        nsl += (uint32_t)__popcll(fm);
+        npn += (uint32_t)__popcll(km);
+      }
+      lds_sync();
+      for (uint32_t i0 = 0; i0 < nsl && !overflow; i0 += 64u) {
+        const bool mine = i0 + (uint32_t)lane < nsl;
+        const uint32_t slot = mine ? sell[i0 + (uint32_t)lane] : 0u;
+        const uint32_t dp = mine ? e_dp[slot] : 0u;
+        const int ed = (int)(dp & 0x7FFFu);
+        const uint64_t sel = __ballot(mine);
+        const uint32_t nsel = (uint32_t)__popcll(sel);
+        if (nseg + nsel > G2S_SEGX_CAP) { overflow = true; flags |= G2S_DEV_OVERFLOW_B | G2S_DEV_WHY_LOG; break; }
+        const uint32_t esid = nseg + (uint32_t)__popcll(sel & below(lane));
+        const uint32_t en = mine ? e_node[slot] : 0u, es = mine ? e_es[slot] : 1u;
+        const uint4 rec = mine ? e_rec[slot] : make_uint4(G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID);
+        const uint32_t cnt = (dp & 0x8000u) ? 1u : min(mine ? e_cnt[slot] : 0u, (uint32_t)G2S_DEV_MAX_PATHS);
+        const uint32_t slo = mine ? e_slo[slot] : 0x7FFFu, shi = mine ? e_shi[slot] : 0u;
+        const uint32_t p01 = mine ? e_p01[slot] : 0xFFFFFFFFu, p23 = mine ? e_p23[slot] : 0xFFFFFFFFu;
+        // the slots and table positions of the selected events are free again
+        if (mine) { ht[e_hpos[slot]] = SEGX_TOMB64; fstack[nfree + (uint32_t)__popcll(sel & below(lane))] = slot; }
+        nfree += nsel;
+        ntomb += nsel;
+        // ---- lengths under the pruning rule (:1050): every lane searches the intervals for its own event
+        const uint32_t lcap = min(es, (uint32_t)(D - ed + 1));
+        uint32_t L = lcap;
+        {
+          const bool pr = mine && lcap > 1u && ed + (int)lcap - 1 >= gd.prune_from;
+          const uint32_t t1 = (uint32_t)max(1, gd.prune_from - ed);
+          const uint32_t idx0 = en >> 1;
+          const uint32_t q0 = (en & 1u) ? idx0 - t1 : idx0 + t1;  // first state entered under the rule
+          const int f = iv_find(pr ? q0 : 0u);
+          if (pr) {
+            const bool in = f >= 0 && q0 <= ivw[2u * (uint32_t)f];
+            if (!(en & 1u)) {
+              const uint32_t y = in ? min(ivw[2u * (uint32_t)f], idx0 + lcap - 1u) : q0 - 1u;   // last covered index
+              L = y - idx0 + 1u;
+            } else {
+              const uint32_t y = in ? max(ivw[2u * (uint32_t)f + 1u], idx0 - (lcap - 1u)) : q0 + 1u;  // first covered index
+              L = idx0 - y + 1u;
+            }
+          }
+        }
+        if (mine) { acc_sb += L; acc_xb += min(L, (uint32_t)(D - ed)); }
+        // ---- phase C: target k-mer j at position t of a segment is a hit at depth + t
+        for (int j = 0; j <= rmf; j++) {
+          const uint32_t tj = rl(tg, j);
+          const int t = mine ? seg_pos(en, L, tj) : -1;
+          for (uint64_t hm = __ballot(t >= 0); hm; hm &= hm - 1) {
+            const int l = __builtin_ctzll(hm);
+            const int td = (int)rl((uint32_t)ed, l) + (int)rl((uint32_t)t, l), base = gd.g + lmf + j;
+            const int err = td >= base ? td - base : base - td;
+            if (err > gd.e) continue;
+            const uint32_t key = ((uint32_t)(err + gd.g + lmf + rmf) << 6) | (uint32_t)j;
+            const uint32_t c = rl(cnt, l), st = rl(slo, l) | (rl(shi, l) << 16);
+            if (key < best) { best = key; c1 = 0; c2 = 0; }
+            if (key == best) { if (td >= base) { c1 = c; s1 = st; } else { c2 = c; s2 = st; } }
+          }
+        }
+        if (mine) {
+          s_node[esid] = en;
+          s_dl[esid] = (uint32_t)ed | (L << 16);
+          s_cnt[esid] = cnt;
+          s_p01[esid] = p01;
+          s_p23[esid] = p23;
+          s_gen[esid] = gen;
+        }
+        nseg += nsel;
+        // ---- segments that reached the end of their stretch leave through the successor table
+        const bool exits = mine && L == es && ed + (int)L - 1 < D;
+        const uint32_t xd = (uint32_t)ed + L;  // depth of the children
+        // lane = (segment, successor slot): sixteen segments' children per pass, one search and one insertion each
+        for (uint32_t g0 = 0; g0 < nsel && !overflow; g0 += 16u) {
+          const int from = (int)(g0 + ((uint32_t)lane >> 2));
+          const uint32_t q = (uint32_t)lane & 3u;
+          const uint32_t wx = (uint32_t)__shfl((int)rec.x, from), wy = (uint32_t)__shfl((int)rec.y, from);
+          const uint32_t wz = (uint32_t)__shfl((int)rec.z, from), ww = (uint32_t)__shfl((int)rec.w, from);
+          const uint32_t w = q == 0u ? wx : q == 1u ? wy : q == 2u ? wz : ww;
+          const bool ex = __shfl((int)exits, from) != 0;
+          const uint32_t xdl = (uint32_t)__shfl((int)xd, from), cl = (uint32_t)__shfl((int)cnt, from);
+          const uint32_t parl = (uint32_t)__shfl((int)esid, from);
+          const uint32_t slol = (uint32_t)__shfl((int)slo, from), shil = (uint32_t)__shfl((int)shi, from);
+          const int f = iv_find(w >> 1);
+          const bool inset = f >= 0 && (w >> 1) <= ivw[2u * (uint32_t)f];
+          const bool ok = ex && w != G2S_DEV_INVALID && ((int)xdl < gd.prune_from || inset);  // :1050
+          ev_insert(ok, w, xdl, cl, parl, slol, shil, false);
+        }
+      }
+      pcur ^= 1u;
+      np = npn;
+      npn = 0;
+      gen++;
+      // ---- tombstones pile up: rebuild the table from the pending list
+      if (ntomb > HS / 4u && !overflow) {
+        for (uint32_t i = (uint32_t)lane; i < HS; i += 64u) ht[i] = SEGX_EMPTY64;
+        lds_sync();
+        const uint32_t* pn = plist + pcur * PE;
+        for (uint32_t i0 = 0; i0 < np; i0 += 64u) {
+          if (i0 + (uint32_t)lane < np) {
+            const uint32_t slot = pn[i0 + (uint32_t)lane];
+            const uint32_t w = e_node[slot], dw = e_dp[slot] & 0x7FFFu;
+            const uint64_t ent = ((uint64_t)w << 32) | ((uint64_t)dw << 16) | slot;
+            uint32_t pos = e_hash(w, dw), g3 = 0;
+            while (atomicCAS((unsigned long long*)&ht[pos], (unsigned long long)SEGX_EMPTY64, (unsigned long long)ent) != SEGX_EMPTY64) {
+              if (++g3 > 2u * HS) { stuckb = true; break; }
+              pos = (pos + 1u) & (HS - 1u);
+            }
+            e_hpos[slot] = pos;
+          }
+        }
+        ntomb = 0;
+        lds_sync();
+        if (__ballot(stuckb)) { overflow = true; flags |= G2S_DEV_OVERFLOW_B | G2S_DEV_WATCHDOG; }
       }
     }
-    gen++;
+    sb += wave_sum(acc_sb);
+    xb += wave_sum(acc_xb);
+    // (the segment arrays in the scratch are read back below; lines this compute unit read for an earlier gap go)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   if (overflow && !(flags & G2S_DEV_OVERFLOW_A)) flags |= G2S_DEV_OVERFLOW_B;
   lds_sync();
   const unsigned long long cyc2 = __builtin_amdgcn_s_memtime();
 
   // ---------------- Q7: an upward and a downward segment of one unitig meeting on a k-mer ------
-  if (!overflow && !(flags & G2S_DEV_Q7_B) && nseg > 1) {
-    uint64_t anyup = 0, anydn = 0;
-    for (uint32_t b0 = 0; b0 < nseg; b0 += 64u) {
-      const uint32_t b = b0 + (uint32_t)lane;
-      anyup |= __ballot(b < nseg && !(s_node[b < nseg ? b : 0] & 1u));
-      anydn |= __ballot(b < nseg && (s_node[b < nseg ? b : 0] & 1u));
-    }
-    if (anyup && anydn) {
-      for (uint32_t b0 = 0; b0 < nseg && !(flags & G2S_DEV_Q7_B); b0 += 64u) {
+  if constexpr (BIG) {
+    // Thousands of segments: all pairs are too many.  The upward segments' index intervals are sorted and
+    // merged (LDS); a downward segment that touches none of them (the usual case) is done after one
+    // search; the few others are checked against every upward segment as above.
+    if (!overflow && !(flags & G2S_DEV_Q7_B) && nseg > 1) {
+      uint64_t* sbuf = (uint64_t*)lds;
+      uint32_t nu = 0;
+      bool anydn = false;
+      for (uint32_t b0 = 0; b0 < nseg; b0 += 64u) {
         const uint32_t b = b0 + (uint32_t)lane;
         const bool hb = b < nseg;
-        const uint32_t nb_ = hb ? s_node[b] : 0u, dlb = hb ? s_dl[b] : 0u;
-        const int ib = (int)(nb_ >> 1), db = (int)(dlb & 0xFFFFu), lb = (int)(dlb >> 16);
-        const bool down = hb && (nb_ & 1u);
-        if (!__ballot(down)) continue;
-        for (uint32_t a = 0; a < nseg; a++) {
-          const uint32_t na = uni(s_node[a]);
-          if (na & 1u) continue;
-          const uint32_t dla = uni(s_dl[a]);
-          const int ia = (int)(na >> 1), da = (int)(dla & 0xFFFFu), la = (int)(dla >> 16);
-          const int sdiff = ib - ia, ddiff = db - da;
-          const int t1 = (sdiff + ddiff) >> 1, t2 = (sdiff - ddiff) >> 1;
-          if (__ballot(down && !((sdiff + ddiff) & 1) && t1 >= 0 && t1 < la && t2 >= 0 && t2 < lb)) { flags |= G2S_DEV_Q7_B; break; }
+        const uint32_t nb_ = hb ? s_node[b] : 0u, lb = hb ? s_dl[b] >> 16 : 0u;
+        const bool up = hb && !(nb_ & 1u) && lb > 0u;
+        const uint64_t m = __ballot(up);
+        if (up) sbuf[nu + (uint32_t)__popcll(m & below(lane))] = ((uint64_t)(nb_ >> 1) << 32) | (uint64_t)((nb_ >> 1) + lb - 1u);
+        nu += (uint32_t)__popcll(m);
+        if (__ballot(hb && (nb_ & 1u) && lb > 0u)) anydn = true;
+      }
+      lds_sync();
+      if (nu > 0u && anydn) {
+        uint32_t n2 = 2;
+        while (n2 < nu) n2 <<= 1;
+        for (uint32_t i = nu + (uint32_t)lane; i < n2; i += 64u) sbuf[i] = SEGX_EMPTY64;
+        lds_sync();
+        lds_sort64(sbuf, n2, lane);
+        bool unused = false;
+        const uint32_t Mu = lds_merge_intervals(sbuf, nu, lane, &unused);
+        const uint32_t Pu = 1u << (31 - __builtin_clz(Mu));
+        const uint32_t* uw = (const uint32_t*)sbuf;
+        for (uint32_t b0 = 0; b0 < nseg && !(flags & G2S_DEV_Q7_B); b0 += 64u) {
+          const uint32_t b = b0 + (uint32_t)lane;
+          const bool hb = b < nseg;
+          const uint32_t nb_ = hb ? s_node[b] : 0u, dlb = hb ? s_dl[b] : 0u;
+          const int ib = (int)(nb_ >> 1), db = (int)(dlb & 0xFFFFu), lb = (int)(dlb >> 16);
+          const bool down = hb && (nb_ & 1u) && lb > 0;
+          uint32_t pos = 0;
+          for (uint32_t st = Pu; st; st >>= 1) {
+            const uint32_t pp = pos + st;
+            if (pp <= Mu && uw[2u * (pp - 1u) + 1u] <= (uint32_t)ib) pos = pp;
+          }
+          const bool cand = down && pos > 0u && (int)uw[2u * (pos - 1u)] >= ib - lb + 1;
+          for (uint64_t cm = __ballot(cand); cm && !(flags & G2S_DEV_Q7_B); cm &= cm - 1) {
+            const int l = __builtin_ctzll(cm);
+            const int ibl = (int)rl((uint32_t)ib, l), dbl = (int)rl((uint32_t)db, l), lbl = (int)rl((uint32_t)lb, l);
+            for (uint32_t a0 = 0; a0 < nseg; a0 += 64u) {
+              const uint32_t a = a0 + (uint32_t)lane;
+              const bool ha = a < nseg;
+              const uint32_t na = ha ? s_node[a] : 1u, dla = ha ? s_dl[a] : 0u;
+              const int ia = (int)(na >> 1), da = (int)(dla & 0xFFFFu), la = (int)(dla >> 16);
+              const int sdiff = ibl - ia, ddiff = dbl - da;
+              const int t1 = (sdiff + ddiff) >> 1, t2 = (sdiff - ddiff) >> 1;
+              if (__ballot(ha && !(na & 1u) && !((sdiff + ddiff) & 1) && t1 >= 0 && t1 < la && t2 >= 0 && t2 < lbl)) { flags |= G2S_DEV_Q7_B; break; }
+            }
+          }
+        }
+      }
+      lds_sync();
+    }
+  } else {
+    if (!overflow && !(flags & G2S_DEV_Q7_B) && nseg > 1) {
+      uint64_t anyup = 0, anydn = 0;
+      for (uint32_t b0 = 0; b0 < nseg; b0 += 64u) {
+        const uint32_t b = b0 + (uint32_t)lane;
+        anyup |= __ballot(b < nseg && !(s_node[b < nseg ? b : 0] & 1u));
+        anydn |= __ballot(b < nseg && (s_node[b < nseg ? b : 0] & 1u));
+      }
+      if (anyup && anydn) {
+        for (uint32_t b0 = 0; b0 < nseg && !(flags & G2S_DEV_Q7_B); b0 += 64u) {
+          const uint32_t b = b0 + (uint32_t)lane;
+          const bool hb = b < nseg;
+          const uint32_t nb_ = hb ? s_node[b] : 0u, dlb = hb ? s_dl[b] : 0u;
+          const int ib = (int)(nb_ >> 1), db = (int)(dlb & 0xFFFFu), lb = (int)(dlb >> 16);
+          const bool down = hb && (nb_ & 1u);
+          if (!__ballot(down)) continue;
+          for (uint32_t a = 0; a < nseg; a++) {
+            const uint32_t na = uni(s_node[a]);
+            if (na & 1u) continue;
+            const uint32_t dla = uni(s_dl[a]);
+            const int ia = (int)(na >> 1), da = (int)(dla & 0xFFFFu), la = (int)(dla >> 16);
+            const int sdiff = ib - ia, ddiff = db - da;
+            const int t1 = (sdiff + ddiff) >> 1, t2 = (sdiff - ddiff) >> 1;
+            if (__ballot(down && !((sdiff + ddiff) & 1) && t1 >= 0 && t1 < la && t2 >= 0 && t2 < lb)) { flags |= G2S_DEV_Q7_B; break; }
+          }
         }
       }
     }
@@ -560,18 +1169,20 @@ __global__ __launch_bounds__(64) void g2s_fill_seg(const uint32_t* __restrict__ 
     }
   }
   if (dbg) {  // diagnostics (tests): the entries of phase A and the segments of phase B
-    uint32_t* o = dbg + (size_t)blockIdx.x * dbg_words;
+    uint32_t* o = dbg + (size_t)x * dbg_words;
     if (lane == 0) { o[0] = gi; o[1] = nA; o[2] = nseg; o[3] = flags; o[4] = roundsA; o[5] = gen; o[6] = (uint32_t)c_count; o[7] = best; }
+    if constexpr (!BIG) {  // (BIG: written while the entries were turned into intervals)
 #pragma unroll
-    for (int s = 0; s < G2S_SEG_ASETS; s++) {
-      const uint32_t e = (uint32_t)s * 64u + (uint32_t)lane;
-      if (e < nA && 8u + 2u * e + 1u < dbg_words) { o[8u + 2u * e] = an[s]; o[9u + 2u * e] = al[s]; }
+      for (int s = 0; s < G2S_SEG_ASETS; s++) {
+        const uint32_t e = (uint32_t)s * 64u + (uint32_t)lane;
+        if (e < nA && 8u + 2u * e + 1u < dbg_words) { o[8u + 2u * e] = an[s]; o[9u + 2u * e] = al[s]; }
+      }
     }
-    const uint32_t sb0 = 8u + 2u * 64u * G2S_SEG_ASETS;
+    const uint32_t sb0 = 8u + 2u * (BIG ? G2S_SEGX_EA : 64u * G2S_SEG_ASETS);
     for (uint32_t b = (uint32_t)lane; b < nseg; b += 64u)
       if (sb0 + 6u * b + 5u < dbg_words) {
         o[sb0 + 6u * b] = s_node[b]; o[sb0 + 6u * b + 1] = s_dl[b]; o[sb0 + 6u * b + 2] = s_cnt[b];
-        o[sb0 + 6u * b + 3] = s_p01[b]; o[sb0 + 6u * b + 4] = s_p23[b]; o[sb0 + 6u * b + 5] = s_aux[b];
+        o[sb0 + 6u * b + 3] = s_p01[b]; o[sb0 + 6u * b + 4] = s_p23[b]; o[sb0 + 6u * b + 5] = BIG ? s_gen[b] : s_aux[b];
       }
   }
   if (lane == 0) {
@@ -598,6 +1209,10 @@ __global__ __launch_bounds__(64) void g2s_fill_seg(const uint32_t* __restrict__ 
   }
 
   // ---------------- phase D1: backward closure over the segments ---------------------------------
+  if constexpr (BIG) {  // generations into LDS: s_aux collects the closure marks there
+    for (uint32_t b = (uint32_t)lane; b < nseg; b += 64u) s_aux[b] = s_gen[b];
+    lds_sync();
+  }
   const bool want_s = !skip_confident;
   const uint32_t sinknode = (want_s && gd.all_paths && rmf >= 1) ? uni(targets[rmf - 1]) : G2S_DEV_INVALID;  // Q3/Q4
   const int lo_sink = max(0, lmf + gd.g - gd.e);  // :1196
@@ -865,10 +1480,36 @@ __global__ __launch_bounds__(64) void g2s_fill_seg(const uint32_t* __restrict__ 
   publish();
 }
 
+// dynamic LDS: 7 arrays of G2S_SEG_CAP words + left seeds
+__global__ __launch_bounds__(64) void g2s_fill_seg(const SegArgs A) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  seg_fill_one<false>(lds, A, blockIdx.x, nullptr);
+}
+
+// The large variant: one workgroup per compute unit (it takes nearly all of the LDS), each working
+// through the list by an atomic counter so that the longest searches (the list is sorted) start first.
+__global__ __launch_bounds__(64) void g2s_fill_segx(const SegArgs A, uint32_t* scratch, uint32_t ngaps,
+                                                     unsigned long long* next_gap) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  uint32_t* scr = scratch + (size_t)blockIdx.x * SEGX_SCR_WORDS;
+  while (true) {
+    unsigned long long x = 0;
+    if (threadIdx.x == 0) x = atomicAdd(next_gap, 1ull);
+    x = __shfl(x, 0);
+    if (x >= (unsigned long long)ngaps) break;
+    seg_fill_one<true>(lds, A, (uint32_t)x, scr);
+    lds_sync();
+    __threadfence_block();
+  }
+}
+
 namespace g2s {
 
 size_t fill_seg_lds_bytes() { return 4u * (7u * G2S_SEG_CAP + 32u); }
 uint32_t fill_seg_dbg_words() { return 8u + 2u * 64u * G2S_SEG_ASETS + 6u * G2S_SEG_CAP; }
+size_t fill_segx_lds_bytes() { return 4u * SEGX_LDS_WORDS; }
+size_t fill_segx_scratch_bytes(uint32_t workgroups) { return (size_t)workgroups * SEGX_SCR_WORDS * 4u; }
+uint32_t fill_segx_dbg_words() { return 8u + 2u * G2S_SEGX_EA + 6u * G2S_SEGX_CAP; }
 
 hipError_t launch_fill_seg(hipStream_t st, uint32_t ngaps, const uint32_t* succ, const uint32_t* urec, const GapDev* gaps,
                            const uint32_t* gap_ids, const uint32_t* flank_nodes, SubRec* sub_out,
@@ -878,8 +1519,24 @@ hipError_t launch_fill_seg(hipStream_t st, uint32_t ngaps, const uint32_t* succ,
   const size_t bytes = fill_seg_lds_bytes();
   hipError_t e = hipFuncSetAttribute((const void*)g2s_fill_seg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(g2s_fill_seg, dim3(ngaps), dim3(64), bytes, st, succ, urec, gaps, gap_ids, flank_nodes, sub_out, out_cap,
-                     out_counter, outs, outs_host, done_list, skip_confident, dbg, fill_seg_dbg_words());
+  const SegArgs A = {succ, urec, gaps, gap_ids, flank_nodes, sub_out, out_cap, out_counter, outs, outs_host, done_list,
+                     skip_confident, dbg, fill_seg_dbg_words()};
+  hipLaunchKernelGGL(g2s_fill_seg, dim3(ngaps), dim3(64), bytes, st, A);
+  return hipGetLastError();
+}
+
+hipError_t launch_fill_segx(hipStream_t st, uint32_t ngaps, uint32_t workgroups, const uint32_t* succ, const uint32_t* urec,
+                            const GapDev* gaps, const uint32_t* gap_ids, const uint32_t* flank_nodes, SubRec* sub_out,
+                            unsigned long long out_cap, unsigned long long* out_counter, GapOut* outs, GapOut* outs_host,
+                            uint32_t* done_list, int skip_confident, uint32_t* dbg, uint32_t* scratch,
+                            unsigned long long* next_gap) {
+  if (ngaps == 0) return hipSuccess;
+  const size_t bytes = fill_segx_lds_bytes();
+  hipError_t e = hipFuncSetAttribute((const void*)g2s_fill_segx, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) return e;
+  const SegArgs A = {succ, urec, gaps, gap_ids, flank_nodes, sub_out, out_cap, out_counter, outs, outs_host, done_list,
+                     skip_confident, dbg, fill_segx_dbg_words()};
+  hipLaunchKernelGGL(g2s_fill_segx, dim3(workgroups), dim3(64), bytes, st, A, scratch, ngaps, next_gap);
   return hipGetLastError();
 }
 

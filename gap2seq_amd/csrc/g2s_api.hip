@@ -6,6 +6,7 @@
 // (/root/reference/src/Gap2Seq.cpp:252,380 -> :858).  No CPU fallback: without a
 // usable gfx950 device every fill entry point fails with G2S_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
+#include <cstdarg>
 #include <sys/prctl.h>
 #include <pthread.h>
 #include <sched.h>
@@ -253,6 +254,21 @@ inline uint32_t pow2ceil(uint64_t x) {
 
 }  // namespace
 
+// diagnostics: G2S_PROGRESS_FILE=path appends one line per kernel launch / completion (opened and closed per
+// line, so that the file is complete even when the process has to be abandoned)
+static void progress_note(const char* fmt, ...) {
+  const char* path = getenv("G2S_PROGRESS_FILE");
+  if (!path) return;
+  if (FILE* f = fopen(path, "a")) {
+    va_list ap;
+    va_start(ap, fmt);
+    vfprintf(f, fmt, ap);
+    va_end(ap);
+    fputc('\n', f);
+    fclose(f);
+  }
+}
+
 namespace {
 struct TierData {  // what came back from one launch group (pinned buffers live in the session)
   PinBuf outs, subs;
@@ -443,6 +459,8 @@ struct g2s_session {
   size_t mem_budget = 0;  // bytes of HBM this session may use for work areas
   DevBuf d_gaps, d_ids, d_flank, d_outs, d_rs, d_rlog, d_keys, d_cnt, d_mark, d_slog, d_subscr, d_subout, d_counter;
   DevBuf d_log, d_lvl, d_plk, d_xl, d_xo;  // LDS tier: state log, level offsets, parent links, closure side lists
+  DevBuf d_segx;  // large variant of the segment tier: segment arrays and queues of its persistent workgroups
+  int num_cus = 256;
   DevBuf d_rspool;
   DevBuf d_logpool;  // chunks for state logs that outgrow their slice of d_log (LDS tier)                          // LDS tier: spill pool for right sets
   std::vector<void*> tier_pool;  // recycled TierData (pinned host buffers)
@@ -472,6 +490,10 @@ extern "C" int g2s_session_create(g2s_graph* g, int device, const g2s_params* p,
     }
   }
   g2s_session* s = new g2s_session();
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) s->num_cus = cus;
+  }
   {  // what the flank look-up kernel searches: the sorted k-mer set, its prefix index, rank -> node
     const Graph& gr = *g->g;
     const size_t kb = gr.wide ? gr.kmers128.size() * 16 : gr.kmers64.size() * 8;
@@ -518,7 +540,7 @@ extern "C" void g2s_session_destroy(g2s_session* s) {
   (void)hipSetDevice(s->device);
   DevBuf* bufs[] = {&s->d_gaps, &s->d_ids, &s->d_flank, &s->d_outs, &s->d_rs, &s->d_rlog, &s->d_keys,
                     &s->d_cnt, &s->d_mark, &s->d_slog, &s->d_subscr, &s->d_subout, &s->d_counter,
-                    &s->d_log, &s->d_lvl, &s->d_plk, &s->d_xl, &s->d_xo, &s->d_rspool, &s->d_logpool};
+                    &s->d_log, &s->d_lvl, &s->d_plk, &s->d_xl, &s->d_xo, &s->d_rspool, &s->d_logpool, &s->d_segx};
   for (DevBuf* b : bufs) b->release();
   delete s->pool;
   for (PinBuf* pb : s->pin_free) { pb->release(); delete pb; }
@@ -779,7 +801,8 @@ Plan plan_gap(const GapJob& j, int d_err, uint64_t scale, uint64_t max_states) {
 using DoneFn = std::function<void(const uint32_t* gaps_done, size_t count)>;
 int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uint64_t max_states, TierData* td,
              bool lds, uint32_t lds_room_override = 0, bool rs_in_hbm = false, uint32_t fcap = 64,
-             const DoneFn* on_done = nullptr, bool seg = false /* segment tier (fill_seg.hip); needs lds = true */) {
+             const DoneFn* on_done = nullptr,
+             int seg = 0 /* segment tier (fill_seg.hip): 1 the tier proper, 2 its large variant; needs lds = true */) {
   const auto t_enter = std::chrono::steady_clock::now();
   g2s_session* s = b->s;
   uint32_t* seg_dbg = nullptr;
@@ -865,7 +888,9 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
     HIP_TRY(td->outs.ensure(n * sizeof(GapOut)));
     out_states += out_max;
     // (segment tier: two 16-byte units per closure segment; ~15 segments per gap, at most G2S_SEG_CAP)
-    if (seg) out_states = (uint64_t)ids.size() * 128u + 2u * G2S_SEG_CAP;
+    if (seg == 1) out_states = (uint64_t)ids.size() * 128u + 2u * G2S_SEG_CAP;
+    // (large variant: closures of a few thousand segments; what does not fit runs in the LDS tier)
+    if (seg == 2) out_states = (uint64_t)ids.size() * 4096u + 2u * G2S_SEGX_CAP;
     HIP_TRY(td->subs.ensure(std::max<uint64_t>(out_states * sizeof(SubRec), 16)));
     HIP_TRY(td->done.ensure(std::max<size_t>(ids.size() * 4, 16)));
     memset(td->done.p, 0xFF, ids.size() * 4);
@@ -905,12 +930,22 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
       ids_dev = (const uint32_t*)s->d_ids.p;
     }
     const char* seg_dump = seg ? getenv("G2S_SEG_DUMP") : nullptr;  // diagnostics: phase A entries + segments of every gap
+    const uint32_t seg_dbg_w = seg == 2 ? fill_segx_dbg_words() : fill_seg_dbg_words();
     if (seg_dump) {
-      HIP_TRY(s->d_slog.ensure((size_t)ids.size() * fill_seg_dbg_words() * 4));
-      HIP_TRY(hipMemsetAsync(s->d_slog.p, 0, (size_t)ids.size() * fill_seg_dbg_words() * 4, st));
+      HIP_TRY(s->d_slog.ensure((size_t)ids.size() * seg_dbg_w * 4));
+      HIP_TRY(hipMemsetAsync(s->d_slog.p, 0, (size_t)ids.size() * seg_dbg_w * 4, st));
       seg_dbg = (uint32_t*)s->d_slog.p;
     }
-    if (seg)
+    if (seg == 2) {
+      // one persistent workgroup per compute unit (the variant takes nearly all of a CU's LDS)
+      const uint32_t wgs = (uint32_t)std::min<size_t>(ids.size(), (size_t)std::max(1, s->num_cus));
+      HIP_TRY(s->d_segx.ensure(fill_segx_scratch_bytes(wgs)));
+      HIP_TRY(launch_fill_segx(st, (uint32_t)ids.size(), wgs, dg.succ, dg.urec, gaps_dev, ids_dev, (const uint32_t*)s->d_flank.p,
+                               (SubRec*)d_subs_host, (unsigned long long)out_states, (unsigned long long*)s->d_counter.p,
+                               (GapOut*)s->d_outs.p, (GapOut*)d_outs_host, (uint32_t*)d_done_host,
+                               s->params.skip_confident ? 1 : 0, seg_dbg, (uint32_t*)s->d_segx.p,
+                               (unsigned long long*)s->d_counter.p + 2));
+    } else if (seg)
       HIP_TRY(launch_fill_seg(st, (uint32_t)ids.size(), dg.succ, dg.urec, gaps_dev, ids_dev, (const uint32_t*)s->d_flank.p,
                               (SubRec*)d_subs_host, (unsigned long long)out_states, (unsigned long long*)s->d_counter.p,
                               (GapOut*)s->d_outs.p, (GapOut*)d_outs_host, (uint32_t*)d_done_host,
@@ -957,6 +992,7 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
   }
 
   const auto t_launched = std::chrono::steady_clock::now();
+  progress_note("launched: %zu gaps, lds %d seg %d scale %llu", ids.size(), (int)lds, seg, (unsigned long long)scale);
   if (lds) {
    if (seg && on_done) {
     // Segment tier: the analysis of a gap costs about a microsecond (it runs on the closure
@@ -1033,15 +1069,17 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
     const auto t_polled = std::chrono::steady_clock::now();
     HIP_TRY(hipStreamSynchronize(st));  // the kernels wrote td->outs / td->subs themselves
     if (seg_dbg) {
-      std::vector<uint32_t> h((size_t)ids.size() * fill_seg_dbg_words());
+      const uint32_t W = seg == 2 ? fill_segx_dbg_words() : fill_seg_dbg_words();
+      const uint32_t ecap = seg == 2 ? G2S_SEGX_EA : 64u * G2S_SEG_ASETS, scap = seg == 2 ? G2S_SEGX_CAP : G2S_SEG_CAP;
+      std::vector<uint32_t> h((size_t)ids.size() * W);
       HIP_TRY(hipMemcpy(h.data(), seg_dbg, h.size() * 4, hipMemcpyDeviceToHost));
       if (FILE* f = fopen(getenv("G2S_SEG_DUMP"), "a")) {
-        const uint32_t W = fill_seg_dbg_words(), sb0 = 8u + 2u * 64u * G2S_SEG_ASETS;
+        const uint32_t sb0 = 8u + 2u * ecap;
         for (size_t x = 0; x < ids.size(); x++) {
           const uint32_t* o = h.data() + x * W;
           fprintf(f, "gap %u nA %u nseg %u flags %#x roundsA %u roundsB %u c_count %u best %u\n", o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7]);
-          for (uint32_t e = 0; e < o[1] && e < 64u * G2S_SEG_ASETS; e++) fprintf(f, "A %u %u\n", o[8 + 2 * e], o[9 + 2 * e]);
-          for (uint32_t q = 0; q < o[2] && q < G2S_SEG_CAP; q++)
+          for (uint32_t e = 0; e < o[1] && e < ecap; e++) fprintf(f, "A %u %u\n", o[8 + 2 * e], o[9 + 2 * e]);
+          for (uint32_t q = 0; q < o[2] && q < scap; q++)
             fprintf(f, "S %u %u %u %u %#x %#x %u\n", o[sb0 + 6 * q], o[sb0 + 6 * q + 1] & 0xFFFF, o[sb0 + 6 * q + 1] >> 16,
                     o[sb0 + 6 * q + 2], o[sb0 + 6 * q + 3], o[sb0 + 6 * q + 4], o[sb0 + 6 * q + 5]);
         }
@@ -1077,8 +1115,13 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
     HIP_TRY(hipStreamSynchronize(st));
     b->timing.ms_d2h += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   }
+  progress_note("finished: %zu gaps, lds %d seg %d", ids.size(), (int)lds, seg);
   float ms = 0;
-  if (seg) {
+  if (seg == 2) {
+    HIP_TRY(hipEventElapsedTime(&ms, s->ev[1], s->ev[2]));
+    b->timing.ms_fill_segx += ms;
+    b->timing.segx_launches++;
+  } else if (seg) {
     HIP_TRY(hipEventElapsedTime(&ms, s->ev[1], s->ev[2]));
     b->timing.ms_fill_seg += ms;
     b->timing.seg_launches++;
@@ -1297,28 +1340,41 @@ int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
       if (j.bad_flank || j.rmf > 31 || j.lmf > 31 || j.lmf + j.rmf + j.g + fp.d_err >= 32767) continue;
       seg_ids.push_back((uint32_t)i);
     }
-    if (seg_ids.size() > 1024 && !getenv("G2S_NO_LPT"))  // longest searches first (see below)
-      std::stable_sort(seg_ids.begin(), seg_ids.end(), [&](uint32_t a, uint32_t c) { return b->jobs[a].g > b->jobs[c].g; });
-    if (!seg_ids.empty()) {
+    // mode 1: the tier proper; mode 2: its large variant (g2s_fill_segx) for the gaps that outgrew a capacity of
+    // mode 1 (-dist-error 2000: thousands of segments and right-set entries); what outgrows that too takes
+    // the passes below
+    // (tests: G2S_FORCE_SEGX=1 sends every gap to the large variant, G2S_NO_SEGX_TIER=1 none)
+    for (int mode = getenv("G2S_FORCE_SEGX") ? 2 : 1; mode <= 2 && !seg_ids.empty(); mode++) {
+      if (mode == 2 && getenv("G2S_NO_SEGX_TIER")) break;
+      // longest searches first (see below): always for the large variant, whose workgroups take the list in order
+      if ((seg_ids.size() > 1024 || mode == 2) && !getenv("G2S_NO_LPT"))
+        std::stable_sort(seg_ids.begin(), seg_ids.end(), [&](uint32_t a, uint32_t c) { return b->jobs[a].g > b->jobs[c].g; });
       TierData* td = take_tier(s, b->tiers.size());
       b->tiers.push_back(td);
       td_live = td;
       b->seg_td = td;
       {  // scratch of the per-gap analysis (24 bytes per closure segment; the rare closure with a k-mer at
          // two depths is expanded into per-state records here too): 1 KB per gap, per-gap buffers beyond
-        const size_t want = seg_ids.size() * 64u + 4096u;
+        const size_t want = seg_ids.size() * (mode == 2 ? 8192u : 64u) + 4096u;
         if (td->exp.size() < want) td->exp.resize(want);
         td->exp_cursor.store(0);
       }
-      int rc = run_tier(b, seg_ids, 1, max_states, td, true, 0, false, 64u, analyze ? &on_done : nullptr, true);
+      int rc = run_tier(b, seg_ids, 1, max_states, td, true, 0, false, 64u, analyze ? &on_done : nullptr, mode);
       if (rc != G2S_OK) return rc;
       const GapOut* outs = (const GapOut*)td->outs.p;
+      std::vector<uint32_t> left;
       for (uint32_t i : seg_ids) {
         const GapOut& go = outs[i];
         if (go.flags & (G2S_DEV_OVERFLOW_A | G2S_DEV_OVERFLOW_B)) {
           if (getenv("G2S_DEBUG"))
-            fprintf(stderr, "[g2s] gap %u left the segment tier: flags 0x%x entries %u segments %u g %d\n", i, go.flags,
-                    go.stat[1], go.stat[3], b->jobs[i].g);
+            fprintf(stderr, "[g2s] gap %u left the segment tier (mode %d): flags 0x%x entries %u segments %u g %d\n", i, mode,
+                    go.flags, go.stat[1], go.stat[3], b->jobs[i].g);
+          if (go.flags & G2S_DEV_WATCHDOG) {  // a defect, never expected: say so, the gap is filled by the LDS tier
+            b->timing.watchdog_gaps++;
+            fprintf(stderr, "[g2s] segment tier (mode %d): a probe loop ran past its bound on gap %u (flags 0x%x); the gap runs in the LDS tier\n",
+                    mode, i, go.flags);
+          }
+          left.push_back(i);
           continue;
         }
         seg_done[i] = 1;
@@ -1334,12 +1390,13 @@ int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
         b->timing.xA += go.x_right; b->timing.sA += go.n_right;
         b->timing.xB += go.x_left; b->timing.sB += go.n_states;
         b->timing.xD += go.x_sub; b->timing.sD += go.n_sub;
-        b->timing.seg_tier_gaps++;
+        if (mode == 2) b->timing.segx_tier_gaps++; else b->timing.seg_tier_gaps++;
         b->timing.seg_segments += go.stat[3];
       }
       if (const char* dump = getenv("G2S_DUMP_STATS")) {
         if (FILE* f = fopen(dump, "a")) {
-          fprintf(f, "# segment tier: gap g flags A_rounds A_entries B_rounds segments cycA cycB 0 0 cycD n_right x_right n_states x_left n_sub 0\n");
+          fprintf(f, "# segment tier%s: gap g flags A_rounds A_entries B_rounds segments cycA cycB 0 0 cycD n_right x_right n_states x_left n_sub 0\n",
+                  mode == 2 ? " (large variant)" : "");
           for (uint32_t i : seg_ids) {
             const GapOut& o = outs[i];
             fprintf(f, "%u %d %#x %u %u %u %u %llu %llu %u %u %llu %u %u %u %u %u %u\n", i, b->jobs[i].g, o.flags, o.stat[0], o.stat[1],
@@ -1355,11 +1412,12 @@ int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
           return outs[a].stat[4] + outs[a].stat[5] + outs[a].stat[7] > outs[c].stat[4] + outs[c].stat[5] + outs[c].stat[7]; });
         for (size_t q = 0; q < ord.size() && q < 4; q++) {
           const GapOut& o = outs[ord[q]];
-          fprintf(stderr, "[g2s] segment tier slow gap %u: g %d | A rounds %u entries %u kcyc %u | B rounds %u segments %u kcyc %u | D1+emit kcyc %u | states %u closure %u flags %#x count %d\n",
-                  ord[q], b->jobs[ord[q]].g, o.stat[0], o.stat[1], o.stat[4] >> 2, o.stat[2], o.stat[3], o.stat[5] >> 2, o.stat[7] >> 2,
+          fprintf(stderr, "[g2s] segment tier (mode %d) slow gap %u: g %d | A rounds %u entries %u kcyc %u | B rounds %u segments %u kcyc %u | D1+emit kcyc %u | states %u closure %u flags %#x count %d\n",
+                  mode, ord[q], b->jobs[ord[q]].g, o.stat[0], o.stat[1], o.stat[4] >> 2, o.stat[2], o.stat[3], o.stat[5] >> 2, o.stat[7] >> 2,
                   o.n_states, o.n_sub, o.flags, o.c_count);
         }
       }
+      seg_ids.swap(left);
     }
   }
   {
@@ -1891,6 +1949,8 @@ extern "C" int g2s_team_fill(g2s_session* const* sessions, int nsessions, const 
         total.ms_prepare += t.ms_prepare;
         total.ms_fill_seg += t.ms_fill_seg; total.seg_tier_gaps += t.seg_tier_gaps; total.seg_launches += t.seg_launches;
         total.seg_segments += t.seg_segments;
+        total.ms_fill_segx += t.ms_fill_segx; total.segx_tier_gaps += t.segx_tier_gaps; total.segx_launches += t.segx_launches;
+        total.watchdog_gaps += t.watchdog_gaps;
       }
       rc = batches_stage2(subs, lead, results, arena, &total, false);
     }

@@ -181,6 +181,11 @@ typedef struct g2s_timing {
   uint32_t seg_tier_gaps;    /* gaps that completed in the segment tier */
   uint32_t seg_launches;
   uint64_t seg_segments;     /* segments those gaps took (a config-2 gap: ~25 for ~1000 DP states) */
+  double ms_fill_segx;       /* the tier's large variant (g2s_fill_segx): gaps that outgrow the LDS-resident capacities */
+  uint32_t segx_tier_gaps;
+  uint32_t segx_launches;
+  uint32_t watchdog_gaps;    /* gaps on which a probe loop of the large variant ran past its bound (a defect; expected 0) */
+  uint32_t reserved0;
 } g2s_timing;
 
 /* ---------------------------------------------------------------------------

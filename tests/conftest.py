@@ -31,3 +31,12 @@ def product():
     from gap2seq_amd import lib
     lib.load_library()
     return lib
+
+
+def pytest_runtest_logstart(nodeid, location):
+    """G2S_TEST_PROGRESS=path: append the id of every test as it starts (diagnostics on the GPU box:
+    the file is closed after every line, so it survives a run that has to be abandoned)."""
+    path = os.environ.get("G2S_TEST_PROGRESS")
+    if path:
+        with open(path, "a") as f:
+            f.write(nodeid + "\n")

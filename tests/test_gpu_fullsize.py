@@ -91,8 +91,8 @@ def test_c4_full_size_vs_oracle_k63_60mbp(product, oracle):
 def test_c5_full_size_vs_oracle(product, oracle):
     """BASELINE config 5 at its stated size: the 3 Mbp V3 graph, -dist-error 2000, 1 000 gaps of
     2-5 kbp (D = 4-7 k levels), every gap against the oracle.  This list holds the gaps whose
-    frontiers outgrow the LDS tier's 1 024 entries (they finish in the HBM tier) as well as
-    right sets and state logs that move to the launch's pools."""
+    segments, pending events and right-set entries outgrow the segment tier's LDS-resident
+    capacities: they run in its large variant (g2s_fill_segx)."""
     reads = product.G2S.synth_genome(3000000, 3, 20240101)
     seqs = _seqs(reads)
     gaps = _parse_scaffolds(product.G2S.synth_gaps(reads, 31, 10, 1000, 2000, 5000, 20240103))
@@ -100,6 +100,9 @@ def test_c5_full_size_vs_oracle(product, oracle):
     c, f, tm, xb, sb = _check_batch(product, oracle, seqs, 31, gaps, 2000, seed=1)
     assert c >= 995 and f >= 990
     assert (tm.xB, tm.sB) == (xb, sb)
+    # the segment tier holds the whole list: ~58 % in the tier proper, the deep ones in its large variant
+    assert tm.seg_tier_gaps >= 500 and tm.seg_tier_gaps + tm.segx_tier_gaps == 1000
+    assert tm.lds_tier_gaps == 0 and tm.retried_gaps == 0 and tm.watchdog_gaps == 0
 
 
 def _simulated_scaffolds(genome, k, fuz, seed, nrec, rec_len):

@@ -61,6 +61,7 @@ def _check_batch(product, oracle, seqs, k, gaps, e, skip=False, allp=True, seed=
     pg = product.Graph.from_seqs(seqs, k, 1)
     sess = product.Session(pg, 0, d_err=e, skip_confident=skip, all_paths=allp, randseed=seed, max_mem=max_mem)
     res, tm = sess.fill_batch(_gaps(product, gaps), True)
+    assert tm.watchdog_gaps == 0  # (a probe loop of the large variant ran past its bound: a defect)
     rng = oracle.OracleRng(seed)
     compared = filled = oracle_q7 = 0
     xb = sb = 0
@@ -96,14 +97,18 @@ def _check_batch(product, oracle, seqs, k, gaps, e, skip=False, allp=True, seed=
     return compared, filled, tm, xb, sb
 
 
-@pytest.fixture(params=["seg", "lds", "hbm"])
+@pytest.fixture(params=["seg", "segx", "lds", "hbm"])
 def tier(request, monkeypatch):
-    """All three kernel tiers: the segment tier (default: the search over unitig segments),
-    the LDS tier (level by level, what a gap takes when it outgrows the segment tier's
-    capacities) and the general tier with per-gap tables in HBM (the last resort)."""
+    """All kernel tiers: the segment tier (default: the search over unitig segments), its large
+    variant (what a gap takes when it outgrows the LDS-resident capacities), the LDS tier (level by
+    level, round 1's kernel: the fallback behind both) and the general tier with per-gap tables in
+    HBM (the last resort)."""
     monkeypatch.delenv("G2S_NO_LDS_TIER", raising=False)
     monkeypatch.delenv("G2S_NO_SEG_TIER", raising=False)
-    if request.param == "hbm":
+    monkeypatch.delenv("G2S_FORCE_SEGX", raising=False)
+    if request.param == "segx":
+        monkeypatch.setenv("G2S_FORCE_SEGX", "1")
+    elif request.param == "hbm":
         monkeypatch.setenv("G2S_NO_LDS_TIER", "1")
     elif request.param == "lds":
         monkeypatch.setenv("G2S_NO_SEG_TIER", "1")
