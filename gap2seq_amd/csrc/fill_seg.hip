@@ -47,6 +47,17 @@
 #include "fill_seg.h"
 
 #define SEG_INF 0x7FFFFFFFu
+// -DG2S_SEG_PROFILE: cycles of the sections of a phase B round, summed per gap into the last words of the
+// gap's diagnostics row (G2S_SEG_DUMP; tools only)
+#ifdef G2S_SEG_PROFILE
+#define SEG_PROF_T(i) prof_t[i] = __builtin_amdgcn_s_memtime()
+#define SEG_PROF_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define SEG_PROF_ACC() do { for (int pi = 0; pi < 4; pi++) prof_acc[pi] += (uint32_t)(prof_t[pi + 1] - prof_t[pi]); } while (0)
+#else
+#define SEG_PROF_T(i) do {} while (0)
+#define SEG_PROF_WAIT() do {} while (0)
+#define SEG_PROF_ACC() do {} while (0)
+#endif
 #define SEG_NOPAR 0xFFFFu
 
 namespace {
@@ -597,6 +608,10 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
   int ed = 0;
   uint64_t ev = 0, efx = 0;  // pending events, and which of them have an assigned count (left seeds)
   uint32_t nseg = 0, gen = 0, xb = 0, sb = 0;
+#ifdef G2S_SEG_PROFILE
+  unsigned long long prof_t[5] = {0, 0, 0, 0, 0};
+  uint32_t prof_acc[4] = {0, 0, 0, 0};
+#endif
   uint32_t best = SEG_INF, c1 = 0, c2 = 0;  // phase C: (found level << 6 | j) and the counts of its two lengths
   // Stop depths of the traceback (:1455-1462): a traceback that passes through an entry stops at one of
   // the depths of the left-flank k-mers reachable backwards from it.  est = lowest | highest << 16 of
@@ -678,10 +693,13 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
       }
     }
     while (ev && !overflow) {
+      SEG_PROF_T(0);
       if (((ev >> lane) & 1ull) && es == 0u) {  // one round trip for all events created last round
         if (ed < lmf) { es = 1u; erec = *(const uint4*)(succ + (size_t)en * 4); }  // above the flank: one state, leaves at once
         else { const uint4* u = (const uint4*)(urec + (size_t)en * 8); erec = u[0]; es = u[1].x + 1u; }
       }
+      SEG_PROF_WAIT();
+      SEG_PROF_T(1);
       // ---- which events are final: depth below the horizon
       uint32_t H = SEG_INF;
       for (uint64_t m = ev; m; m &= m - 1) {
@@ -697,6 +715,7 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
       const uint32_t lcap = min(es, (uint32_t)(D - ed + 1));
       uint32_t elen = lcap;
       const uint32_t esid = nseg + (uint32_t)__popcll(sel & below(lane));
+      SEG_PROF_T(2);
       // ---- their lengths under the pruning rule, their target hits (one segment at a time, wave-uniform)
       for (uint64_t m = sel; m; m &= m - 1) {
         const int l = __builtin_ctzll(m);
@@ -723,6 +742,7 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
         s_aux[esid] = gen;
       }
       nseg += nsel;
+      SEG_PROF_T(3);
       // ---- segments that reached the end of their stretch leave through the successor table
       const bool exits = mine && elen == es && ed + (int)elen - 1 < D;
       const uint4 rec = erec;  // elen == lcap == es: the walk reached the node the record belongs to
@@ -740,6 +760,8 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
           if (w != G2S_DEV_INVALID && (dw < gd.prune_from || contains(w >> 1))) add_event(w, dw, c, par, pst);  // :1050
         }
       }
+      SEG_PROF_T(4);
+      SEG_PROF_ACC();
       gen++;
     }
   } else {
@@ -1171,6 +1193,9 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
   if (dbg) {  // diagnostics (tests): the entries of phase A and the segments of phase B
     uint32_t* o = dbg + (size_t)x * dbg_words;
     if (lane == 0) { o[0] = gi; o[1] = nA; o[2] = nseg; o[3] = flags; o[4] = roundsA; o[5] = gen; o[6] = (uint32_t)c_count; o[7] = best; }
+#ifdef G2S_SEG_PROFILE
+    if (lane == 0) for (int pi = 0; pi < 4; pi++) o[dbg_words - 4u + pi] = prof_acc[pi];
+#endif
     if constexpr (!BIG) {  // (BIG: written while the entries were turned into intervals)
 #pragma unroll
       for (int s = 0; s < G2S_SEG_ASETS; s++) {
@@ -1506,10 +1531,10 @@ __global__ __launch_bounds__(64) void g2s_fill_segx(const SegArgs A, uint32_t* s
 namespace g2s {
 
 size_t fill_seg_lds_bytes() { return 4u * (7u * G2S_SEG_CAP + 32u); }
-uint32_t fill_seg_dbg_words() { return 8u + 2u * 64u * G2S_SEG_ASETS + 6u * G2S_SEG_CAP; }
+uint32_t fill_seg_dbg_words() { return 8u + 2u * 64u * G2S_SEG_ASETS + 6u * G2S_SEG_CAP + 4u; }  // (+4: profile words)
 size_t fill_segx_lds_bytes() { return 4u * SEGX_LDS_WORDS; }
 size_t fill_segx_scratch_bytes(uint32_t workgroups) { return (size_t)workgroups * SEGX_SCR_WORDS * 4u; }
-uint32_t fill_segx_dbg_words() { return 8u + 2u * G2S_SEGX_EA + 6u * G2S_SEGX_CAP; }
+uint32_t fill_segx_dbg_words() { return 8u + 2u * G2S_SEGX_EA + 6u * G2S_SEGX_CAP + 4u; }
 
 hipError_t launch_fill_seg(hipStream_t st, uint32_t ngaps, const uint32_t* succ, const uint32_t* urec, const GapDev* gaps,
                            const uint32_t* gap_ids, const uint32_t* flank_nodes, SubRec* sub_out,

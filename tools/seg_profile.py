@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""GPU box, library built with -DG2S_SEG_PROFILE: where a phase B round of the segment tier spends its cycles
+(records wait | horizon | lengths + hits | children), summed over the gaps of a bench configuration and for the
+slowest gaps.  usage: python tools/seg_profile.py [C2|C3]"""
+import os
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from gap2seq_amd import lib as P  # noqa: E402
+
+cfg = sys.argv[1] if len(sys.argv) > 1 else "C2"
+genome_bp, k, ngaps, min_len, max_len, d_err, _ = bench.CONFIGS[cfg]
+reads = P.G2S.synth_genome(genome_bp, 3, 20240101)
+seqs = [ln for ln in reads.splitlines() if not ln.startswith(">")]
+gaps = bench.parse_gaps(P.G2S.synth_gaps(reads, k, 10, ngaps, min_len, max_len, 20240103), 10)
+dump = tempfile.mktemp()
+os.environ["G2S_SEG_DUMP"] = dump
+pg = P.Graph.from_seqs(seqs, k, 1)
+sess = P.Session(pg, 0, d_err=d_err, randseed=1)
+res, tm = sess.fill_batch([P.Gap(g["left"], g["right"], g["gap_len"], g["lmf"], g["rmf"]) for g in gaps], True)
+rows = []
+cur = None
+for ln in open(dump):
+    p = ln.split()
+    if p[0] == "gap":
+        cur = dict(gap=int(p[1]), nseg=int(p[5]), rounds=int(p[11]), prof=None)
+        rows.append(cur)
+    elif p[0] == "P":
+        cur["prof"] = [int(x) for x in p[1:5]]
+rows = [r for r in rows if r["prof"]]
+tot = [sum(r["prof"][i] for r in rows) for i in range(4)]
+allc = sum(tot)
+print("gaps %d rounds %d segments %d | cycles per round %.0f: wait %.1f%% horizon %.1f%% lengths+hits %.1f%% children %.1f%%" % (
+    len(rows), sum(r["rounds"] for r in rows), sum(r["nseg"] for r in rows), allc / max(1, sum(r["rounds"] for r in rows)),
+    100.0 * tot[0] / allc, 100.0 * tot[1] / allc, 100.0 * tot[2] / allc, 100.0 * tot[3] / allc))
+for r in sorted(rows, key=lambda r: -sum(r["prof"]))[:6]:
+    t = sum(r["prof"])
+    print("gap %d: rounds %d segments %d cycles %d (%.0f per round): wait %d horizon %d lengths+hits %d children %d" % (
+        r["gap"], r["rounds"], r["nseg"], t, t / max(1, r["rounds"]), *r["prof"]))
