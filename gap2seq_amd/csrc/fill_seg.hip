@@ -53,7 +53,9 @@
 #define SEG_PROF_T(i) prof_t[i] = __builtin_amdgcn_s_memtime()
 #define SEG_PROF_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #define SEG_PROF_ACC() do { for (int pi = 0; pi < 4; pi++) prof_acc[pi] += (uint32_t)(prof_t[pi + 1] - prof_t[pi]); } while (0)
+#define SEG_PROF_TAIL(i) prof_tail[i] = __builtin_amdgcn_s_memtime()
 #else
+#define SEG_PROF_TAIL(i) do {} while (0)
 #define SEG_PROF_T(i) do {} while (0)
 #define SEG_PROF_WAIT() do {} while (0)
 #define SEG_PROF_ACC() do {} while (0)
@@ -251,7 +253,7 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
     // keyed by node with 64-bit atomic min on (node << 32 | label) — a per-proposal compare against
     // register-resident entries costs ~1.5 k cycles of scalar/vector ping-pong each (measured).
     // LDS (aliasing the segment arrays, which phase B fills later):
-    //   lab[ALAB] u64 | labrem[ALAB] u32 | q[2][ACAP] u32
+    //   lab[ALAB] u64 | labrem[ALAB] u32 | q[2][ACAP] u32 nodes | q[2][ACAP] u32 table positions
     const uint32_t ACAP = 64u * G2S_SEG_ASETS, ALAB = 2u * ACAP;
     uint64_t* lab = (uint64_t*)lds;
     uint32_t* labrem = (uint32_t*)(lab + ALAB);
@@ -259,12 +261,12 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
     for (uint32_t i = (uint32_t)lane; i < ALAB; i += 64u) lab[i] = G2S_DEV_EMPTY64;
     lds_sync();
     auto a_hash = [&](uint32_t p) -> uint32_t { uint32_t x = p; x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x & (ALAB - 1u); };
-    // propose label dp for node p (per lane); true when the label improved (the caller queues p)
-    auto relabel = [&](bool active, uint32_t p, uint32_t dp) -> bool {
+    // propose label dp for node p (per lane) from table position h on; true when the label improved (the
+    // caller queues p); *at = where p sits in the table
+    auto relabel = [&](bool active, uint32_t p, uint32_t dp, uint32_t h, uint32_t* at) -> bool {
       bool improved = false, fresh = false;
       if (active) {
         const uint64_t key = ((uint64_t)p << 32) | dp;
-        uint32_t h = a_hash(p);
         while (true) {
           const uint64_t c = lab[h];
           if ((uint32_t)(c >> 32) == p) {
@@ -279,56 +281,94 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
           }
           h = (h + 1u) & (ALAB - 1u);
         }
+        *at = h;
       }
       nA += (uint32_t)__popcll(__ballot(fresh));
       return improved;
     };
+    // the queues hold (node, table position) pairs: q[2][ACAP] nodes, then q[2][ACAP] positions
+    uint32_t* aqs = aq0 + 2u * ACAP;
     if (!overflow) {
       uint32_t cur = 0, ne = 0;
       {  // seeds: right.substr(len-k-j, k) enters at depth j (:878-884, :953-976)
         const uint32_t sd = (lane <= rmf && lane < 32) ? rseeds[lane] : G2S_DEV_INVALID;
-        const bool imp = relabel(sd != G2S_DEV_INVALID && lane <= gd.right_half, sd, (uint32_t)lane);
+        uint32_t at = 0;
+        const bool imp = relabel(sd != G2S_DEV_INVALID && lane <= gd.right_half, sd, (uint32_t)lane, a_hash(sd), &at);
         const uint64_t m = __ballot(imp);
-        if (imp) aq0[(uint32_t)__popcll(m & below(lane))] = sd;
+        if (imp) { aq0[(uint32_t)__popcll(m & below(lane))] = sd; aqs[(uint32_t)__popcll(m & below(lane))] = at; }
         ne = (uint32_t)__popcll(m);
         lds_sync();
       }
       while (ne > 0 && !overflow) {
         roundsA++;
-        uint32_t* qc = aq0 + cur * ACAP;
+        const uint32_t* qc = aq0 + cur * ACAP;
+        const uint32_t* qcs = aqs + cur * ACAP;
         uint32_t* qn = aq0 + (cur ^ 1u) * ACAP;
+        uint32_t* qns = aqs + (cur ^ 1u) * ACAP;
         uint32_t nn = 0;
         for (uint32_t e0 = 0; e0 < ne && !overflow; e0 += 64u) {
           const bool mine = e0 + (uint32_t)lane < ne;
           const uint32_t v = mine ? qc[e0 + (uint32_t)lane] : 0u;
-          uint32_t d = 0, slot = 0;
-          if (mine) {  // the entry's current label
-            slot = a_hash(v);
-            while ((uint32_t)(lab[slot] >> 32) != v) slot = (slot + 1u) & (ALAB - 1u);
-            d = (uint32_t)lab[slot];
-          }
+          const uint32_t slot = mine ? qcs[e0 + (uint32_t)lane] : 0u;
           // walking back from v = walking on from v^1: steps left in the unitig and the successor record
-          // of the walk's last node (graph.predecessors(last)[i] = succ(last^1)[i] ^ 1) in one record
+          // of the walk's last node (graph.predecessors(last)[i] = succ(last^1)[i] ^ 1) in one record,
+          // asked for before the entry's label is read (the label comes from LDS while the record travels)
           uint4 rec = make_uint4(G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID);
           uint32_t r = 0;
           if (mine) {
             const uint4* u = (const uint4*)(urec + (size_t)(v ^ 1u) * 8);
             rec = u[0];
             r = u[1].x;
-            labrem[slot] = r;
           }
+          const uint32_t d = mine ? (uint32_t)lab[slot] : 0u;  // the entry's current label
+          if (mine) labrem[slot] = r;
           const uint32_t steps = min(r, (uint32_t)gd.right_half - d);
           const bool live = mine && d + steps < (uint32_t)gd.right_half;  // (then steps == r: the record is the last node's)
-          if (!live) rec = make_uint4(G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID);
           const uint32_t dchild = d + steps + 1u;
+          // the four proposals of every entry: first probes side by side (four reads, then four atomics in
+          // flight: one after the other they were eight dependent LDS round trips per round), the rare
+          // collision takes the general loop
+          const uint32_t wq[4] = {rec.x, rec.y, rec.z, rec.w};
+          uint32_t hq[4];
+          uint64_t cq[4], oldmin[4], oldcas[4];  // (one result register pair per atomic: none waits for another)
+          bool aq[4];
 #pragma unroll
           for (int q = 0; q < 4; q++) {
-            const uint32_t w = q == 0 ? rec.x : q == 1 ? rec.y : q == 2 ? rec.z : rec.w;
-            const bool imp = relabel(w != G2S_DEV_INVALID && !overflow, w ^ 1u, dchild);
+            aq[q] = live && wq[q] != G2S_DEV_INVALID;
+            hq[q] = a_hash(wq[q] ^ 1u);
+          }
+#pragma unroll
+          for (int q = 0; q < 4; q++) cq[q] = aq[q] ? lab[hq[q]] : 0ull;
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const uint32_t pnode = wq[q] ^ 1u;
+            const uint64_t key = ((uint64_t)pnode << 32) | dchild;
+            oldmin[q] = 0ull;
+            oldcas[q] = 0ull;
+            if (aq[q] && (uint32_t)(cq[q] >> 32) == pnode) oldmin[q] = atomicMin((unsigned long long*)&lab[hq[q]], (unsigned long long)key);
+            if (aq[q] && cq[q] == G2S_DEV_EMPTY64)
+              oldcas[q] = atomicCAS((unsigned long long*)&lab[hq[q]], (unsigned long long)G2S_DEV_EMPTY64, (unsigned long long)key);
+          }
+          // (all eight in flight before the first result is looked at: the empty statements keep the compiler
+          // from moving the tests of the results up into the branches above)
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int q = 0; q < 4; q++) asm volatile("" : "+v"(oldmin[q]), "+v"(oldcas[q]));
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const uint32_t pnode = wq[q] ^ 1u;
+            const uint64_t key = ((uint64_t)pnode << 32) | dchild;
+            const bool hit = aq[q] && (uint32_t)(cq[q] >> 32) == pnode;
+            const bool claimed = aq[q] && cq[q] == G2S_DEV_EMPTY64 && oldcas[q] == G2S_DEV_EMPTY64;
+            bool imp = (hit && oldmin[q] > key) || claimed;
+            nA += (uint32_t)__popcll(__ballot(claimed));
+            uint32_t at = hq[q];
+            const bool slow = aq[q] && !hit && !claimed;  // another node there, or the slot was taken meanwhile
+            if (__ballot(slow)) { if (relabel(slow, pnode, dchild, hq[q], &at)) imp = true; }
             const uint64_t m = __ballot(imp);
             if (imp) {
-              const uint32_t at = nn + (uint32_t)__popcll(m & below(lane));
-              if (at < ACAP) qn[at] = w ^ 1u;
+              const uint32_t pos = nn + (uint32_t)__popcll(m & below(lane));
+              if (pos < ACAP) { qn[pos] = pnode; qns[pos] = at; }
             }
             nn += (uint32_t)__popcll(m);
             // (the table has 2 ACAP slots: at most ACAP + 64 are ever taken, so every probe ends)
@@ -609,7 +649,7 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
   uint64_t ev = 0, efx = 0;  // pending events, and which of them have an assigned count (left seeds)
   uint32_t nseg = 0, gen = 0, xb = 0, sb = 0;
 #ifdef G2S_SEG_PROFILE
-  unsigned long long prof_t[5] = {0, 0, 0, 0, 0};
+  unsigned long long prof_t[5] = {0, 0, 0, 0, 0}, prof_tail[5] = {0, 0, 0, 0, 0};
   uint32_t prof_acc[4] = {0, 0, 0, 0};
 #endif
   uint32_t best = SEG_INF, c1 = 0, c2 = 0;  // phase C: (found level << 6 | j) and the counts of its two lengths
@@ -1075,6 +1115,7 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
   if (overflow && !(flags & G2S_DEV_OVERFLOW_A)) flags |= G2S_DEV_OVERFLOW_B;
   lds_sync();
   const unsigned long long cyc2 = __builtin_amdgcn_s_memtime();
+  SEG_PROF_TAIL(0);
 
   // ---------------- Q7: an upward and a downward segment of one unitig meeting on a k-mer ------
   if constexpr (BIG) {
@@ -1144,21 +1185,28 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
         anydn |= __ballot(b < nseg && (s_node[b < nseg ? b : 0] & 1u));
       }
       if (anyup && anydn) {
+        // every downward segment against every upward one, both sides a chunk at a time in registers (a pass
+        // over LDS per pair cost 350 cycles: 73 k of the 550 k cycles of config 2's slowest gap)
         for (uint32_t b0 = 0; b0 < nseg && !(flags & G2S_DEV_Q7_B); b0 += 64u) {
           const uint32_t b = b0 + (uint32_t)lane;
           const bool hb = b < nseg;
           const uint32_t nb_ = hb ? s_node[b] : 0u, dlb = hb ? s_dl[b] : 0u;
           const int ib = (int)(nb_ >> 1), db = (int)(dlb & 0xFFFFu), lb = (int)(dlb >> 16);
-          const bool down = hb && (nb_ & 1u);
-          if (!__ballot(down)) continue;
-          for (uint32_t a = 0; a < nseg; a++) {
-            const uint32_t na = uni(s_node[a]);
-            if (na & 1u) continue;
-            const uint32_t dla = uni(s_dl[a]);
+          const uint64_t dm0 = __ballot(hb && (nb_ & 1u));
+          if (!dm0) continue;
+          for (uint32_t a0 = 0; a0 < nseg && !(flags & G2S_DEV_Q7_B); a0 += 64u) {
+            const uint32_t a = a0 + (uint32_t)lane;
+            const bool ha = a < nseg;
+            const uint32_t na = ha ? s_node[a] : 1u, dla = ha ? s_dl[a] : 0u;
+            const bool upa = ha && !(na & 1u);
+            if (!__ballot(upa)) continue;
             const int ia = (int)(na >> 1), da = (int)(dla & 0xFFFFu), la = (int)(dla >> 16);
-            const int sdiff = ib - ia, ddiff = db - da;
-            const int t1 = (sdiff + ddiff) >> 1, t2 = (sdiff - ddiff) >> 1;
-            if (__ballot(down && !((sdiff + ddiff) & 1) && t1 >= 0 && t1 < la && t2 >= 0 && t2 < lb)) { flags |= G2S_DEV_Q7_B; break; }
+            for (uint64_t dm = dm0; dm; dm &= dm - 1) {
+              const int l = __builtin_ctzll(dm);
+              const int sdiff = (int)rl((uint32_t)ib, l) - ia, ddiff = (int)rl((uint32_t)db, l) - da;
+              const int t1 = (sdiff + ddiff) >> 1, t2 = (sdiff - ddiff) >> 1;
+              if (__ballot(upa && !((sdiff + ddiff) & 1) && t1 >= 0 && t1 < la && t2 >= 0 && t2 < (int)rl((uint32_t)lb, l))) { flags |= G2S_DEV_Q7_B; break; }
+            }
           }
         }
       }
@@ -1234,6 +1282,7 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
   }
 
   // ---------------- phase D1: backward closure over the segments ---------------------------------
+  SEG_PROF_TAIL(1);
   if constexpr (BIG) {  // generations into LDS: s_aux collects the closure marks there
     for (uint32_t b = (uint32_t)lane; b < nseg; b += 64u) s_aux[b] = s_gen[b];
     lds_sync();
@@ -1251,7 +1300,10 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
       const uint32_t lo = hi > 64u ? hi - 64u : 0u;
       const uint32_t b = lo + (uint32_t)lane;
       const bool hb = b < hi;
+      // (everything a segment's step reads is asked for at once: one LDS round trip instead of three)
       const uint32_t aux = hb ? s_aux[b] : 0u;
+      const uint32_t v0 = hb ? s_node[b] : 0u, dl = hb ? s_dl[b] : 0u;
+      const uint32_t p01 = hb ? s_p01[b] : 0xFFFFFFFFu, p23 = hb ? s_p23[b] : 0xFFFFFFFFu;
       const uint32_t gtop = rl(aux & 0xFFFFu, (int)(hi - 1u - lo));
       const uint64_t gm = __ballot(hb && (aux & 0xFFFFu) == gtop);  // segments of one generation are contiguous
       const int first = __builtin_ctzll(gm);
@@ -1259,7 +1311,6 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
       int pstart = -1, jstart = 0;
       bool multi = false;
       if (act) {
-        const uint32_t v0 = s_node[b], dl = s_dl[b];
         const int d0 = (int)(dl & 0xFFFFu);
         const int len = max(0, min((int)(dl >> 16), d_last - d0 + 1));
         int ts = -1, tt = -1;
@@ -1284,7 +1335,8 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
           const uint32_t ls = d0 <= lmf ? l_seed[d0] : G2S_DEV_INVALID;
           const bool source = ls != G2S_DEV_INVALID && (v0 >> 1) == (ls >> 1);  // :1270, k-mer comparison only
           if (!source) {
-            const uint32_t p01 = s_p01[b], p23 = s_p23[b];
+            // (the S-children count sits above the two mark bits and those are only ever set: one add of
+            // mark bits that are still clear would do, but two children may carry the same mark: add, then or)
             if ((p01 & 0xFFFFu) != SEG_NOPAR) atomicAdd(&s_aux[p01 & 0xFFFFu], mk & ~0x30000u), atomicOr(&s_aux[p01 & 0xFFFFu], mk & 0x30000u);
             if ((p01 >> 16) != SEG_NOPAR) atomicAdd(&s_aux[p01 >> 16], mk & ~0x30000u), atomicOr(&s_aux[p01 >> 16], mk & 0x30000u);
             if ((p23 & 0xFFFFu) != SEG_NOPAR) atomicAdd(&s_aux[p23 & 0xFFFFu], mk & ~0x30000u), atomicOr(&s_aux[p23 & 0xFFFFu], mk & 0x30000u);
@@ -1303,6 +1355,7 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
       hi = lo + (uint32_t)first;
     }
   }
+  SEG_PROF_TAIL(2);
   // ---------------- phase D2 for closures without a repeated k-mer (:1314-1435) -----------------
   // When every k-mer occurs at one depth of the S closure the subgraph is a DAG whose vertices are
   // the states: nothing to contract, and the branch rule (:1411-1434: walk the vertices in
@@ -1406,6 +1459,7 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
       lds_sync();
     }
   }
+  SEG_PROF_TAIL(3);
   // ---- the closure leaves as SEGMENTS (32 bytes each, SegRec), children before parents = descending
   // segment id; the host expands them into per-state records (post.cpp: seg_expand).  Writing the
   // ~730 16-byte state records of a gap over the link instead made the launch PCIe-bound: 5.8 MB per
@@ -1501,6 +1555,13 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
     go->stat[6] = gen;
     go->stat[7] = (uint32_t)((__builtin_amdgcn_s_memtime() - cyc2) >> 8);
   }
+#ifdef G2S_SEG_PROFILE
+  SEG_PROF_TAIL(4);
+  if (dbg && lane == 0) {
+    uint32_t* o = dbg + (size_t)x * dbg_words;
+    for (int pi = 0; pi < 4; pi++) o[dbg_words - 8u + pi] = (uint32_t)(prof_tail[pi + 1] - prof_tail[pi]);
+  }
+#endif
   __threadfence();
   publish();
 }
@@ -1531,10 +1592,10 @@ __global__ __launch_bounds__(64) void g2s_fill_segx(const SegArgs A, uint32_t* s
 namespace g2s {
 
 size_t fill_seg_lds_bytes() { return 4u * (7u * G2S_SEG_CAP + 32u); }
-uint32_t fill_seg_dbg_words() { return 8u + 2u * 64u * G2S_SEG_ASETS + 6u * G2S_SEG_CAP + 4u; }  // (+4: profile words)
+uint32_t fill_seg_dbg_words() { return 8u + 2u * 64u * G2S_SEG_ASETS + 6u * G2S_SEG_CAP + 8u; }  // (+8: profile words)
 size_t fill_segx_lds_bytes() { return 4u * SEGX_LDS_WORDS; }
 size_t fill_segx_scratch_bytes(uint32_t workgroups) { return (size_t)workgroups * SEGX_SCR_WORDS * 4u; }
-uint32_t fill_segx_dbg_words() { return 8u + 2u * G2S_SEGX_EA + 6u * G2S_SEGX_CAP + 4u; }
+uint32_t fill_segx_dbg_words() { return 8u + 2u * G2S_SEGX_EA + 6u * G2S_SEGX_CAP + 8u; }
 
 hipError_t launch_fill_seg(hipStream_t st, uint32_t ngaps, const uint32_t* succ, const uint32_t* urec, const GapDev* gaps,
                            const uint32_t* gap_ids, const uint32_t* flank_nodes, SubRec* sub_out,

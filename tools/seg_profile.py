@@ -30,6 +30,7 @@ for ln in open(dump):
         rows.append(cur)
     elif p[0] == "P":
         cur["prof"] = [int(x) for x in p[1:5]]
+        cur["tail"] = [int(x) for x in p[5:9]]
 rows = [r for r in rows if r["prof"]]
 tot = [sum(r["prof"][i] for r in rows) for i in range(4)]
 allc = sum(tot)
@@ -40,3 +41,8 @@ for r in sorted(rows, key=lambda r: -sum(r["prof"]))[:6]:
     t = sum(r["prof"])
     print("gap %d: rounds %d segments %d cycles %d (%.0f per round): wait %d horizon %d lengths+hits %d children %d" % (
         r["gap"], r["rounds"], r["nseg"], t, t / max(1, r["rounds"]), *r["prof"]))
+tt = [sum(r["tail"][i] for r in rows) for i in range(4)]
+print("tail (Q7 between segments + phase C | D1 | D2 | emission), all gaps: %s; share of tail %s" % (
+    tt, ["%.1f%%" % (100.0 * x / max(1, sum(tt))) for x in tt]))
+for r in sorted(rows, key=lambda r: -sum(r["tail"]))[:6]:
+    print("gap %d: segments %d tail cycles %d: q7+C %d D1 %d D2 %d emission %d" % (r["gap"], r["nseg"], sum(r["tail"]), *r["tail"]))
