@@ -84,6 +84,18 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t x) {
   for (int o = 32; o > 0; o >>= 1) x += (uint32_t)__shfl_xor((int)x, o);
   return uni(x);
 }
+// minimum over the lanes, wave-uniform: row shifts and row broadcasts inside the vector ALU (a shuffle
+// through the LDS crossbar per step costs ten times as much)
+__device__ __forceinline__ uint32_t wave_min(uint32_t x) {
+  const int inf = (int)0xFFFFFFFFu;
+  x = min(x, (uint32_t)__builtin_amdgcn_update_dpp(inf, (int)x, 0x111, 0xF, 0xF, false));  // row_shr:1
+  x = min(x, (uint32_t)__builtin_amdgcn_update_dpp(inf, (int)x, 0x112, 0xF, 0xF, false));  // row_shr:2
+  x = min(x, (uint32_t)__builtin_amdgcn_update_dpp(inf, (int)x, 0x114, 0xF, 0xF, false));  // row_shr:4
+  x = min(x, (uint32_t)__builtin_amdgcn_update_dpp(inf, (int)x, 0x118, 0xF, 0xF, false));  // row_shr:8
+  x = min(x, (uint32_t)__builtin_amdgcn_update_dpp(inf, (int)x, 0x142, 0xA, 0xF, false));  // row_bcast:15
+  x = min(x, (uint32_t)__builtin_amdgcn_update_dpp(inf, (int)x, 0x143, 0xC, 0xF, false));  // row_bcast:31
+  return rl(x, 63);
+}
 // inclusive prefix sum over the lanes
 __device__ __forceinline__ uint32_t wave_scan(uint32_t x, int lane) {
   for (int o = 1; o < 64; o <<= 1) {
@@ -741,12 +753,8 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
       SEG_PROF_WAIT();
       SEG_PROF_T(1);
       // ---- which events are final: depth below the horizon
-      uint32_t H = SEG_INF;
-      for (uint64_t m = ev; m; m &= m - 1) {
-        const int l = __builtin_ctzll(m);
-        H = min(H, (uint32_t)rl((uint32_t)ed, l) + rl(es, l));
-      }
       const bool valid = (ev >> lane) & 1ull;
+      const uint32_t H = wave_min(valid ? (uint32_t)ed + es : SEG_INF);
       const uint64_t sel = __ballot(valid && (uint32_t)ed < H);
       const uint32_t nsel = (uint32_t)__popcll(sel);
       if (nseg + nsel > G2S_SEG_CAP) { overflow = true; flags |= G2S_DEV_OVERFLOW_B | G2S_DEV_WHY_LOG; break; }
@@ -790,14 +798,16 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
       const uint32_t est_sel = est;             // (add_event below may reuse a selected lane for a new event)
       ev &= ~sel;
       efx &= ~sel;
-      for (uint64_t m = __ballot(exits); m && !overflow; m &= m - 1) {
-        const int l = __builtin_ctzll(m);
-        const int dw = (int)rl(xd, l);
-        const uint32_t c = rl(cnt, l), par = rl(esid, l), pst = rl(est_sel, l);
-#pragma unroll 1
-        for (int q = 0; q < 4; q++) {
-          const uint32_t w = rl(q == 0 ? rec.x : q == 1 ? rec.y : q == 2 ? rec.z : rec.w, l);
-          if (w != G2S_DEV_INVALID && (dw < gd.prune_from || contains(w >> 1))) add_event(w, dw, c, par, pst);  // :1050
+      // (successor slot by successor slot, only the lanes whose slot holds a node: the order in which the
+      // children arrive does not matter — counts add up, the host puts parents into GATB order)
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const uint32_t wv = q == 0 ? rec.x : q == 1 ? rec.y : q == 2 ? rec.z : rec.w;
+        for (uint64_t m = __ballot(exits && wv != G2S_DEV_INVALID); m && !overflow; m &= m - 1) {
+          const int l = __builtin_ctzll(m);
+          const uint32_t w = rl(wv, l);
+          const int dw = (int)rl(xd, l);
+          if (dw < gd.prune_from || contains(w >> 1)) add_event(w, dw, rl(cnt, l), rl(esid, l), rl(est_sel, l));  // :1050
         }
       }
       SEG_PROF_T(4);
