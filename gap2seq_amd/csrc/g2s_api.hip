@@ -448,12 +448,59 @@ struct RandCache {
   void consume(size_t n) { st.consume(n); }
 };
 
+// One helper thread per session for the work that runs beside a batch (materialising rand() values):
+// started once, handed a job per batch — creating a thread per call cost ~20 us of a 500 us step.
+struct BgWorker {
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::function<void()> job;
+  bool has_job = false, busy = false, quit = false;
+  void loop() {
+    std::unique_lock<std::mutex> lk(mu);
+    while (true) {
+      cv.wait(lk, [&] { return has_job || quit; });
+      if (quit) return;
+      std::function<void()> j = std::move(job);
+      has_job = false;
+      lk.unlock();
+      j();
+      lk.lock();
+      busy = false;
+      cv.notify_all();
+    }
+  }
+  void submit(std::function<void()> j) {
+    std::unique_lock<std::mutex> lk(mu);
+    if (!th.joinable()) th = std::thread([this] { loop(); });
+    cv.wait(lk, [&] { return !busy; });
+    job = std::move(j);
+    has_job = true;
+    busy = true;
+    cv.notify_all();
+  }
+  void wait() {
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [&] { return !busy; });
+  }
+  ~BgWorker() {
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [&] { return !busy; });
+      quit = true;
+      cv.notify_all();
+    }
+    if (th.joinable()) th.join();
+  }
+};
+
 struct g2s_session {
   g2s_graph* graph = nullptr;
   int device = 0;
   hipStream_t stream = nullptr;
   g2s_params params;
   RandCache rcache;
+  BgWorker bg;
   WorkerPool* pool = nullptr;
   bool no_lds_tier = false;  // G2S_NO_LDS_TIER=1: force the general HBM tier (tests, A/B timing)
   size_t mem_budget = 0;  // bytes of HBM this session may use for work areas
@@ -1067,6 +1114,8 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
         fprintf(stderr, "[g2s] run_tier: first gap seen %.3f ms after the launch call, kernel seen finished at %.3f ms\n", dbg_first, dbg_fin);
     }
     const auto t_polled = std::chrono::steady_clock::now();
+    // (measured: leaving this wait to the end of the run makes the step slower, not faster — the runtime's
+    // completion handling then competes with the tracebacks for the host's CPUs)
     HIP_TRY(hipStreamSynchronize(st));  // the kernels wrote td->outs / td->subs themselves
     if (seg_dbg) {
       const uint32_t W = seg == 2 ? fill_segx_dbg_words() : fill_seg_dbg_words();
@@ -1260,9 +1309,18 @@ int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
   const Graph& g = *s->graph->g;
   const size_t n = b->jobs.size();
   auto t_begin = std::chrono::steady_clock::now();
+  const bool dbg_laps = getenv("G2S_DEBUG") != nullptr;
+  auto t_lap = t_begin;
+  auto lap = [&](const char* what) {  // (diagnostics) where stage 1 spends its time outside the launches
+    if (!dbg_laps) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[g2s] stage 1 lap %s: %.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_lap).count());
+    t_lap = now;
+  };
   { const int rc = b->upload_flanks(); if (rc != G2S_OK) return rc; }
   b->drop_tiers();
   if (getenv("G2S_DEBUG")) fprintf(stderr, "[g2s] stage 1 begins\n");
+  lap("flank upload");
   g2s_timing keep = b->timing;
   memset(&b->timing, 0, sizeof b->timing);
   b->timing.flank_bytes = keep.flank_bytes;
@@ -1284,6 +1342,7 @@ int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
     b->prep.assign(n, SubPrep());
     b->info.assign(n, g2s_batch::GapInfo());
   }
+  lap("per-gap arrays");
   TierData* td_live = nullptr;
   const DoneFn on_done = [&](const uint32_t* done_ids, size_t cnt) {
     auto t0 = std::chrono::steady_clock::now();
@@ -1361,8 +1420,10 @@ int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
         if (td->exp.size() < want) td->exp.resize(want);
         td->exp_cursor.store(0);
       }
+      lap("segment pass set-up");
       int rc = run_tier(b, seg_ids, 1, max_states, td, true, 0, false, 64u, analyze ? &on_done : nullptr, mode);
       if (rc != G2S_OK) return rc;
+      lap("segment pass run_tier");
       const GapOut* outs = (const GapOut*)td->outs.p;
       std::vector<uint32_t> left;
       for (uint32_t i : seg_ids) {
@@ -1598,6 +1659,7 @@ int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
   if (analyze) {
     // ---- host: D2 + stop-depth analysis per gap, thread pool (teams: per group, so that it
     // overlaps the other sessions' kernels)
+    lap("passes, bookkeeping");
     // what was not analysed while the kernels ran: bad flanks, verdicts, gaps of the HBM tier
     auto t_post = std::chrono::steady_clock::now();
     fresh.clear();
@@ -1819,14 +1881,14 @@ extern "C" int g2s_batch_run(g2s_batch* b, g2s_result* results, char* arena, siz
   size_t rand_need = 0;
   for (size_t i = 0; i < n; i++)
     rand_need += (size_t)(b->jobs[i].g + s->graph->g->k + b->jobs[i].lmf + b->jobs[i].rmf + 2);
-  std::thread rand_fill([s, rand_need]() { s->rcache.ensure(rand_need); });
+  s->bg.submit([s, rand_need]() { s->rcache.ensure(rand_need); });
   s->tier_cursor = 0;
   b->arena = arena;
   b->arena_base = 0;
   const auto t_run1 = std::chrono::steady_clock::now();
   int rc = batch_stage1(b, true, results);
   const auto t_join = std::chrono::steady_clock::now();
-  rand_fill.join();
+  s->bg.wait();
   const auto t_run2 = std::chrono::steady_clock::now();
   if (rc == G2S_OK) rc = batches_stage2(std::vector<g2s_batch*>{b}, s, results, arena, &b->timing, false);
   if (getenv("G2S_DEBUG")) {
@@ -1896,7 +1958,7 @@ extern "C" int g2s_team_fill(g2s_session* const* sessions, int nsessions, const 
       pos += g2s_team_arena_bytes(lead, gaps + i, 1);
     }
   }
-  std::thread rand_fill([lead, gaps, n]() { lead->rcache.ensure(rand_need_of(gaps, n, lead->graph->g->k)); });
+  lead->bg.submit([lead, gaps, n]() { lead->rcache.ensure(rand_need_of(gaps, n, lead->graph->g->k)); });
   std::vector<size_t> group_arena(ngroups + 1, 0);  // where each group's fill buffers start
   for (size_t gi = 0; gi < ngroups; gi++) {
     const size_t off = gi * group_size, cnt = std::min(group_size, n - off);
@@ -1931,7 +1993,7 @@ extern "C" int g2s_team_fill(g2s_session* const* sessions, int nsessions, const 
     worker(0);
     for (auto& x : th) x.join();
   }
-  rand_fill.join();
+  lead->bg.wait();
   int rc = G2S_OK;
   for (int t = 0; t < nsessions; t++) if (rcs[(size_t)t] != G2S_OK) { rc = rcs[(size_t)t]; tl_error = errs[(size_t)t]; }
   g2s_timing total;
