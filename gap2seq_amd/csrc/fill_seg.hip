@@ -80,9 +80,15 @@ __device__ __forceinline__ int seg_pos(uint32_t v0, uint32_t len, uint32_t node)
 // ts / tt of a segment are kept in 15 bits each (0x7FFF = none); bits 15 and 31 carry the safe bits
 __device__ __forceinline__ int dec15(uint32_t x) { return (x & 0x7FFFu) == 0x7FFFu ? -1 : (int)(x & 0x7FFFu); }
 __device__ __forceinline__ uint32_t enc15(int t) { return t < 0 ? 0x7FFFu : (uint32_t)t; }
+// sum over the lanes, wave-uniform (row shifts and row broadcasts inside the vector ALU, see wave_min)
 __device__ __forceinline__ uint32_t wave_sum(uint32_t x) {
-  for (int o = 32; o > 0; o >>= 1) x += (uint32_t)__shfl_xor((int)x, o);
-  return uni(x);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, false);  // row_shr:1
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, false);  // row_shr:2
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, false);  // row_shr:4
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, false);  // row_shr:8: lane 15 of a row = its sum
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1 and 3
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);  // row_bcast:31 into rows 2 and 3
+  return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
 }
 // minimum over the lanes, wave-uniform: row shifts and row broadcasts inside the vector ALU (a shuffle
 // through the LDS crossbar per step costs ten times as much)
@@ -96,12 +102,15 @@ __device__ __forceinline__ uint32_t wave_min(uint32_t x) {
   x = min(x, (uint32_t)__builtin_amdgcn_update_dpp(inf, (int)x, 0x143, 0xC, 0xF, false));  // row_bcast:31
   return rl(x, 63);
 }
-// inclusive prefix sum over the lanes
+// inclusive prefix sum over the lanes (the same six steps: a scan inside every row of 16, then the row totals)
 __device__ __forceinline__ uint32_t wave_scan(uint32_t x, int lane) {
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t y = (uint32_t)__shfl_up((int)x, o);
-    if (lane >= o) x += y;
-  }
+  (void)lane;
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, false);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, false);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, false);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, false);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);
   return x;
 }
 
