@@ -61,6 +61,8 @@ struct GapDev {
 #define G2S_SUB_SOURCE 0x4u   /* depth <= lmf and k-mer == left flank k-mer at that offset    */
 #define G2S_SUB_SINK 0x8u     /* has an edge to the sink pseudo-vertex                        */
 #define G2S_SUB_START_T 0x10u /* (reachedTarget, pathLengths[i])                              */
+/* SegRec.flags only: the parents are listed in GATB's predecessor order (sorted on the device) */
+#define G2S_SEG_ORDERED 0x100u
 
 /* One state of the backward closure that phase D works on, in discovery order (depth
  * descending), as the HBM tier's kernel emits it: pred[i] = index (within the gap's array) of

@@ -1540,13 +1540,33 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
       if (!source && d0 > 0) {  // parents as indices among the emitted segments (they are all in the closure)
         const uint32_t p01 = s_p01[b], p23 = s_p23[b];
         const uint32_t ps[4] = {p01 & 0xFFFFu, p01 >> 16, p23 & 0xFFFFu, p23 >> 16};
-        uint32_t out[4] = {SEG_NOPAR, SEG_NOPAR, SEG_NOPAR, SEG_NOPAR};
-        uint32_t k = 0;
+        const uint32_t k = (ps[0] != SEG_NOPAR) + (ps[1] != SEG_NOPAR) + (ps[2] != SEG_NOPAR) + (ps[3] != SEG_NOPAR);
+        // Several parents: the traceback picks predecessors(v)[rand() % n] (:1476-1513), i.e. in GATB's
+        // neighbour order.  predecessors(v)[i] = succ(v^1)[i] ^ 1, so the slot of a parent is where its last
+        // node shows up in v's record of the table; sorted here, the host's sequential in-order pass and
+        // the tracebacks do not have to look the order up per segment (G2S_SEG_ORDERED).
+        uint32_t key[4] = {0u, 1u, 2u, 3u}, id[4];
+        bool ordered = true;
+        uint4 sr = make_uint4(G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID);
+        if (k > 1u) sr = *(const uint4*)(succ + (size_t)(v0 ^ 1u) * 4);
 #pragma unroll
-        for (int q = 0; q < 4; q++)
-          if (ps[q] != SEG_NOPAR) out[k++] = s_aux[ps[q]];
-        r.par01 = out[0] | (out[1] << 16);
-        r.par23 = out[2] | (out[3] << 16);
+        for (int q = 0; q < 4; q++) {
+          id[q] = SEG_NOPAR;
+          if (ps[q] == SEG_NOPAR) { key[q] = 8u + (uint32_t)q; continue; }
+          id[q] = s_aux[ps[q]];
+          if (k > 1u) {
+            const uint32_t pn = s_node[ps[q]];
+            const uint32_t pl = seg_node(pn, (s_dl[ps[q]] >> 16) - 1u) ^ 1u;  // the parent's last node, flipped
+            key[q] = sr.x == pl ? 0u : sr.y == pl ? 1u : sr.z == pl ? 2u : sr.w == pl ? 3u : 4u;
+            if (key[q] == 4u) ordered = false;  // (cannot happen on a consistent table: the host sorts then)
+          }
+        }
+#define SEG_CSWAP(a, c) do { if (key[a] > key[c]) { const uint32_t tk = key[a], ti = id[a]; key[a] = key[c]; id[a] = id[c]; key[c] = tk; id[c] = ti; } } while (0)
+        SEG_CSWAP(0, 1); SEG_CSWAP(2, 3); SEG_CSWAP(0, 2); SEG_CSWAP(1, 3); SEG_CSWAP(1, 2);
+#undef SEG_CSWAP
+        r.par01 = id[0] | (id[1] << 16);
+        r.par23 = id[2] | (id[3] << 16);
+        if (ordered) r.flags |= G2S_SEG_ORDERED;
         nxp += k > 1u ? k - 1u : 0u;
       }
       dst[s_aux[b]] = r;

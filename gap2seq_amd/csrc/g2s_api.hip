@@ -1243,6 +1243,17 @@ void analyze_gap(g2s_batch* b, size_t i, const FillParams& fp, g2s_result* r) {
         const int fd = go.fixed_draws[q];
         pp.stop_depth[q] = (q < go.n_len && fd >= 0) ? go.len[q] + 1 - fd : -1;
       }
+      // the draw count depends on the draws (~4 % of the gaps): the in-order pass will walk the parent links;
+      // the stop depths behind every segment, computed here in parallel, let that walk end early
+      if (b->seg_td && ((go.n_len > 0 && go.fixed_draws[0] < 0) || (go.n_len > 1 && go.fixed_draws[1] < 0))) {
+        const size_t need = ((size_t)v.n_segs * 8 + 15) / 16 + 1;
+        const size_t at = b->seg_td->exp_cursor.fetch_add(need);
+        if (at + need <= b->seg_td->exp.size()) {
+          int32_t* st = (int32_t*)(b->seg_td->exp.data() + at);
+          seg_stop_depths(v, st);
+          pp.stop = st;
+        }
+      }
     }
     analysed = true;
   } else if (v.segs) {  // segment tier: the analysis runs on the closure segments themselves, O(segments) ...

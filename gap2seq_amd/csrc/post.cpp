@@ -760,7 +760,7 @@ void seg_traceback(const Graph& g, const FillParams& p, const GapJob& job, const
       buf[d2 - 1] = (d2 > last_solid - k) ? kUp[c] : kLow[c];
       uint32_t back[4];
       const int nb = seg_parents(s, back);
-      if (nb > 1) {  // GATB predecessor order: predecessors(v)[slot] is the parent p whose p^1 ends with base `slot`
+      if (nb > 1 && !(s.flags & G2S_SEG_ORDERED)) {  // GATB predecessor order: predecessors(v)[slot] is the parent p whose p^1 ends with base `slot`
         int64_t by_slot[4] = {-1, -1, -1, -1};
         for (int x = 0; x < nb; x++) {
           const SegRec& q = v.segs[back[x]];
@@ -786,6 +786,27 @@ void seg_traceback(const Graph& g, const FillParams& p, const GapJob& job, const
   res->draws = draws;
 }
 
+void seg_stop_depths(const SubView& v, int32_t* out) {
+  const uint32_t n = v.n_segs;
+  for (int64_t i = (int64_t)n - 1; i >= 0; i--) {  // parents first (= descending index)
+    const SegRec& s = v.segs[i];
+    int32_t& lo = out[2 * i];
+    int32_t& hi = out[2 * i + 1];
+    lo = -2; hi = -2;
+    if (seg_tt(s) < 0) continue;
+    if (s.flags & G2S_SUB_SOURCE) { lo = hi = (int32_t)(s.depth_len & 0xFFFFu); continue; }
+    uint32_t ps[4];
+    const int np = seg_parents(s, ps);
+    if (np == 0) { lo = -1; hi = 1 << 30; continue; }
+    int l = 1 << 30, h = -1;
+    for (int x = 0; x < np; x++) {
+      const int32_t ql = out[2 * ps[x]], qh = out[2 * ps[x] + 1];
+      if (ql < 0) { l = -1; h = 1 << 30; } else { l = std::min(l, (int)ql); h = std::max(h, (int)qh); }
+    }
+    lo = l; hi = h;
+  }
+}
+
 int seg_count_draws(const Graph& g, const SubView& v, const SubPrep& prep, const uint32_t* rands) {
   const GapOut& go = *v.out;
   int draws = 0;
@@ -795,6 +816,12 @@ int seg_count_draws(const Graph& g, const SubView& v, const SubPrep& prep, const
   while (d2 >= 0 && i >= 0) {
     const SegRec& s = v.segs[i];
     if (t == 0 && (s.flags & G2S_SUB_SOURCE)) break;
+    {  // every traceback through this segment's entry stops at one depth: one draw per level down to it
+      int lo = -1, hi = -2;
+      if (prep.seg) { lo = prep.seg[i].lo; hi = prep.seg[i].hi; }
+      else if (prep.stop) { lo = prep.stop[2 * i]; hi = prep.stop[2 * i + 1]; }
+      if (lo >= 0 && lo == hi && d2 >= lo) { draws += d2 - lo; break; }
+    }
     if (d2 > 0) {
       if (t > 0) {  // the rest of the segment is drawn base by base with one choice each
         const int run = std::min(t, d2);
@@ -804,7 +831,7 @@ int seg_count_draws(const Graph& g, const SubView& v, const SubPrep& prep, const
       uint32_t back[4];
       const int nb = seg_parents(s, back);
       if (nb == 0) break;
-      if (nb > 1) {
+      if (nb > 1 && !(s.flags & G2S_SEG_ORDERED)) {
         int64_t by_slot[4] = {-1, -1, -1, -1};
         for (int x = 0; x < nb; x++) {
           const SegRec& q = v.segs[back[x]];

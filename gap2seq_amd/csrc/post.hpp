@@ -106,6 +106,9 @@ struct SubPrep {
   uint32_t n_iv = 0;
   std::vector<uint64_t> own_seg;                         // backing store of the two when the caller gives no scratch
   bool sink_safe = false, has_choice = false;
+  // closures analysed on the device whose draw count depends on the draws: (lowest, highest) stop depth
+  // behind every segment's entry (seg_stop_depths), so that the draw-count walk ends where the two meet
+  const int32_t* stop = nullptr;
   int start_seg[2] = {-1, -1}, start_t[2] = {0, 0};
   bool phase_d = false;   // count > 0 && pathLengths non-empty (:1169)
   int count = 0;          // value fill_gap returns (before a backtrace failure / memory verdict)
@@ -134,6 +137,9 @@ bool seg_analyze(const FillParams& p, const GapJob& job, const SubView& v, SubPr
 void seg_traceback(const Graph& g, const FillParams& p, const GapJob& job, const SubView& v, const SubPrep& prep,
                    const uint32_t* rands, char* buf, g2s_result* res);
 int seg_count_draws(const Graph& g, const SubView& v, const SubPrep& prep, const uint32_t* rands);
+// (lowest, highest) depth at which a traceback that passes through the entry of each closure segment stops
+// (:1455-1462), (-1, 1 << 30) where that is not fixed by the subgraph; out: two values per segment
+void seg_stop_depths(const SubView& v, int32_t* out);
 
 // D3.  `rands` points at the raw word of this gap's first draw (rand() value = word >> 1);
 // returns through res (count, fuz, draws, flags).
