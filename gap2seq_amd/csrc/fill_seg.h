@@ -27,7 +27,8 @@ hipError_t launch_fill_seg(hipStream_t st, uint32_t ngaps, const uint32_t* succ,
                            const uint32_t* gap_ids, const uint32_t* flank_nodes, SubRec* sub_out /* pinned host */,
                            unsigned long long out_cap /* records */, unsigned long long* out_counter, GapOut* outs,
                            GapOut* outs_host /* pinned host */, uint32_t* done_list /* pinned host */, int skip_confident,
-                           uint32_t* dbg /* nullptr, or ngaps * fill_seg_dbg_words() words */);
+                           uint32_t* dbg /* nullptr, or ngaps * fill_seg_dbg_words() words */,
+                           bool two_waves /* g2s_fill_seg2: phase A on a second wave beside the first half of phase B */);
 
 // The large variant: `workgroups` persistent workgroups (one per compute unit) take the listed gaps
 // in order from the counter *next_gap (zero before the launch); scratch: fill_segx_scratch_bytes().

@@ -199,9 +199,13 @@ struct SegArgs {
 // thousands of segments, hundreds of pending events, thousands of right-set entries): segments in the
 // workgroup's global scratch `scr`, pending events in an LDS hash table, the right set as a sorted array
 // of disjoint index intervals in LDS that every lane searches on its own.
-template <bool BIG>
+// TWO (with BIG = false): the workgroup has two waves — wave 1 runs phase A while wave 0 runs the part of
+// phase B that does not look at the right set yet (:1050 first consults it at depth g/2 + e/2 + lmf), so
+// that phase A leaves the critical path of the slowest gaps; they meet at one barrier.
+template <bool BIG, bool TWO>
 __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, const uint32_t x /* position in the launch */,
                                              uint32_t* scr) {
+  static_assert(!(BIG && TWO), "the large variant is one wave per gap");
   const uint32_t* __restrict__ succ = A.succ;
   const uint32_t* __restrict__ urec = A.urec;
   const GapDev* __restrict__ gaps = A.gaps;
@@ -228,7 +232,8 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
   uint32_t* s_t = s_aux + CAP;                  // last closure state: towards a sink | from a traceback start << 16 (0xFFFF none)
   uint32_t* l_seed = BIG ? lds + (SEGX_LDS_WORDS - 32u) : s_t + CAP;  // left-flank seeds by depth [32]
 
-  const int lane = threadIdx.x;
+  const int lane = (int)(threadIdx.x & 63u);
+  const int wave = TWO ? (int)(threadIdx.x >> 6) : 0;
   const uint32_t gi = uni(gap_ids[x]);
   const GapDev gd = gaps[gi];
   GapOut* go = &outs[gi];
@@ -253,7 +258,7 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
   };
 
   const uint32_t tg = (lane <= rmf && lane < 32) ? targets[lane] : G2S_DEV_INVALID;  // lane j: target k-mer j
-  if (lane < 32) l_seed[lane] = lane <= lmf ? lseeds[lane] : G2S_DEV_INVALID;
+  if (lane < 32 && wave == 0) l_seed[lane] = lane <= lmf ? lseeds[lane] : G2S_DEV_INVALID;
 
   uint32_t nA = 0, roundsA = 0, nvis = 0, xa = 0;
   // (!BIG) the right-set entries in registers: lane l of set s holds entry 64 s + l, as a k-mer index interval
@@ -263,22 +268,82 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
   // (BIG) the right set as M disjoint, sorted index intervals in LDS: ivw[2 i] = last index, ivw[2 i + 1] = first
   uint32_t* ivw = lds;
   uint32_t M = 0, ivP = 0;  // ivP: largest power of two <= M
+  // ---------------- phase A: the right set as (entry node, depth label) pairs ----------------
+  // Label-correcting search over unitigs (:871-982 computes {v : fewest predecessor steps from a
+  // right seed <= right_half}, seed j entering at depth j; only membership is consumed, :1050).
+  // An entry (node, label) covers its unitig backwards for min(rem, right_half - label) steps;
+  // where the unitig ends with budget left, the predecessors of its last node are proposed with
+  // label + steps + 1.  All entries of a round are expanded at once (lane = entry): one load of
+  // rem[], one successor record, and the proposals of the whole wave go through one LDS table
+  // keyed by node with 64-bit atomic min on (node << 32 | label) — a per-proposal compare against
+  // register-resident entries costs ~1.5 k cycles of scalar/vector ping-pong each (measured).
+  // LDS (one wave: aliasing the segment arrays, which phase B fills later; two waves: behind them):
+  //   lab[ALAB] u64 | labrem[ALAB] u32 | q[2][ACAP] u32 nodes | q[2][ACAP] u32 table positions | 8 words
+  constexpr uint32_t ACAP = 64u * G2S_SEG_ASETS, ALAB = 2u * ACAP;
+  uint64_t* lab = (uint64_t*)(TWO ? lds + (7u * G2S_SEG_CAP + 32u) : lds);
+  uint32_t* labrem = (uint32_t*)(lab + ALAB);
+  uint32_t* aq0 = labrem + ALAB;
+  uint32_t* ash = aq0 + 4u * ACAP;  // (two waves) what wave 1 hands over: entries, rounds, flags, overflow, cycles
+  // the table's entries, packed (the queues are idle by then), and from there into registers: lane l of set s
+  // holds entry 64 s + l as a k-mer index interval; then Q7 in the right set
+  auto load_right_set = [&]() {
+    if constexpr (!BIG) {
+      const uint32_t* cnode = aq0;
+      const uint32_t* clab = aq0 + ACAP;
+      const uint32_t* crem = (const uint32_t*)lab;
+      if (!overflow) {
+#pragma unroll
+        for (int s = 0; s < G2S_SEG_ASETS; s++) {
+          const uint32_t e = (uint32_t)s * 64u + (uint32_t)lane;
+          if (e < nA) { an[s] = cnode[e]; al[s] = clab[e]; ar[s] = crem[e]; }
+        }
+        lds_sync();
+      }
+      // the entries as k-mer index intervals [alo, ahi]; lanes without an entry hold an empty interval
+#pragma unroll
+      for (int s = 0; s < G2S_SEG_ASETS; s++) {
+        const bool have = (uint32_t)s * 64u + (uint32_t)lane < nA;
+        const uint32_t steps = have ? min(ar[s], (uint32_t)gd.right_half - al[s]) : 0u;
+        const uint32_t w0 = an[s] ^ 1u, idx = w0 >> 1;
+        alo[s] = have ? ((w0 & 1u) ? idx - steps : idx) : 1u;
+        ahi[s] = have ? ((w0 & 1u) ? idx : idx + steps) : 0u;
+        if ((uint32_t)s * 64u < nA) {
+          nvis += wave_sum(have ? steps + 1u : 0u);  // (intervals of one unitig may overlap: an upper bound of the set's size)
+          xa += wave_sum(have ? min(steps + 1u, (uint32_t)gd.right_half - al[s]) : 0u);
+        }
+      }
+      // Q7 in the right set, conservatively as in the LDS tier: both strands of some k-mer are in
+      // it = an entry of each orientation with overlapping intervals
+      if (!overflow) {
+        bool both = false;
+        {
+          uint64_t odd = 0, even = 0;
+#pragma unroll
+          for (int s = 0; s < G2S_SEG_ASETS; s++) {
+            const bool have = (uint32_t)s * 64u + (uint32_t)lane < nA;
+            odd |= __ballot(have && (an[s] & 1u));
+            even |= __ballot(have && !(an[s] & 1u));
+          }
+          both = odd != 0 && even != 0;
+        }
+        if (both) {
+          for (uint32_t e = 0; e < nA && !(flags & G2S_DEV_Q7_A); e++) {
+            uint32_t lo_e = 0, hi_e = 0, or_e = 0;
+#pragma unroll
+            for (int s = 0; s < G2S_SEG_ASETS; s++)
+              if ((e >> 6) == (uint32_t)s) { lo_e = rl(alo[s], (int)(e & 63u)); hi_e = rl(ahi[s], (int)(e & 63u)); or_e = rl(an[s], (int)(e & 63u)) & 1u; }
+#pragma unroll
+            for (int s = 0; s < G2S_SEG_ASETS; s++)
+              if ((uint32_t)s * 64u < nA && __ballot(alo[s] <= hi_e && lo_e <= ahi[s] && ((an[s] & 1u) != or_e) && alo[s] <= ahi[s]))
+                flags |= G2S_DEV_Q7_A;
+          }
+        }
+      }
+    }
+  };
+  unsigned long long cyc_a_end = cyc0;
   if constexpr (!BIG) {
-    // ---------------- phase A: the right set as (entry node, depth label) pairs ----------------
-    // Label-correcting search over unitigs (:871-982 computes {v : fewest predecessor steps from a
-    // right seed <= right_half}, seed j entering at depth j; only membership is consumed, :1050).
-    // An entry (node, label) covers its unitig backwards for min(rem, right_half - label) steps;
-    // where the unitig ends with budget left, the predecessors of its last node are proposed with
-    // label + steps + 1.  All entries of a round are expanded at once (lane = entry): one load of
-    // rem[], one successor record, and the proposals of the whole wave go through one LDS table
-    // keyed by node with 64-bit atomic min on (node << 32 | label) — a per-proposal compare against
-    // register-resident entries costs ~1.5 k cycles of scalar/vector ping-pong each (measured).
-    // LDS (aliasing the segment arrays, which phase B fills later):
-    //   lab[ALAB] u64 | labrem[ALAB] u32 | q[2][ACAP] u32 nodes | q[2][ACAP] u32 table positions
-    const uint32_t ACAP = 64u * G2S_SEG_ASETS, ALAB = 2u * ACAP;
-    uint64_t* lab = (uint64_t*)lds;
-    uint32_t* labrem = (uint32_t*)(lab + ALAB);
-    uint32_t* aq0 = labrem + ALAB;
+   if (!TWO || wave == 1) {
     for (uint32_t i = (uint32_t)lane; i < ALAB; i += 64u) lab[i] = G2S_DEV_EMPTY64;
     lds_sync();
     auto a_hash = [&](uint32_t p) -> uint32_t { uint32_t x = p; x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x & (ALAB - 1u); };
@@ -401,9 +466,9 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
         ne = nn;
       }
     }
-    // the table's entries into registers: lane l of set s holds entry 64 s + l
+    // the table's entries, packed into the (idle) queues
     if (!overflow) {
-      uint32_t* cnode = aq0;                 // compact list (the queues are idle now)
+      uint32_t* cnode = aq0;
       uint32_t* clab = aq0 + ACAP;
       uint32_t* crem = (uint32_t*)lab;       // written only after the whole table was read: see the two loops
       uint32_t got = 0;
@@ -422,53 +487,18 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
       for (uint32_t c = 0; c < ALAB / 64u; c++)
         if (keep_at[c] != G2S_DEV_INVALID) { cnode[keep_at[c]] = keep_n[c]; clab[keep_at[c]] = keep_l[c]; crem[keep_at[c]] = keep_r[c]; }
       lds_sync();
-#pragma unroll
-      for (int s = 0; s < G2S_SEG_ASETS; s++) {
-        const uint32_t e = (uint32_t)s * 64u + (uint32_t)lane;
-        if (e < nA) { an[s] = cnode[e]; al[s] = clab[e]; ar[s] = crem[e]; }
-      }
-      lds_sync();
     }
-    // the entries as k-mer index intervals [alo, ahi]; lanes without an entry hold an empty interval
-#pragma unroll
-    for (int s = 0; s < G2S_SEG_ASETS; s++) {
-      const bool have = (uint32_t)s * 64u + (uint32_t)lane < nA;
-      const uint32_t steps = have ? min(ar[s], (uint32_t)gd.right_half - al[s]) : 0u;
-      const uint32_t w0 = an[s] ^ 1u, idx = w0 >> 1;
-      alo[s] = have ? ((w0 & 1u) ? idx - steps : idx) : 1u;
-      ahi[s] = have ? ((w0 & 1u) ? idx : idx + steps) : 0u;
-      if ((uint32_t)s * 64u < nA) {
-        nvis += wave_sum(have ? steps + 1u : 0u);  // (intervals of one unitig may overlap: an upper bound of the set's size)
-        xa += wave_sum(have ? min(steps + 1u, (uint32_t)gd.right_half - al[s]) : 0u);
+    cyc_a_end = __builtin_amdgcn_s_memtime();
+    if constexpr (TWO) {  // wave 1 is done: what wave 0 needs to know, then the barrier it waits at
+      if (lane == 0) {
+        ash[0] = nA; ash[1] = roundsA; ash[2] = flags; ash[3] = overflow ? 1u : 0u;
+        ash[4] = (uint32_t)((cyc_a_end - cyc0) >> 8);
       }
+      __syncthreads();
+      return;
     }
-    // Q7 in the right set, conservatively as in the LDS tier: both strands of some k-mer are in
-    // it = an entry of each orientation with overlapping intervals
-    if (!overflow) {
-      bool both = false;
-      {
-        uint64_t odd = 0, even = 0;
-#pragma unroll
-        for (int s = 0; s < G2S_SEG_ASETS; s++) {
-          const bool have = (uint32_t)s * 64u + (uint32_t)lane < nA;
-          odd |= __ballot(have && (an[s] & 1u));
-          even |= __ballot(have && !(an[s] & 1u));
-        }
-        both = odd != 0 && even != 0;
-      }
-      if (both) {
-        for (uint32_t e = 0; e < nA && !(flags & G2S_DEV_Q7_A); e++) {
-          uint32_t lo_e = 0, hi_e = 0, or_e = 0;
-#pragma unroll
-          for (int s = 0; s < G2S_SEG_ASETS; s++)
-            if ((e >> 6) == (uint32_t)s) { lo_e = rl(alo[s], (int)(e & 63u)); hi_e = rl(ahi[s], (int)(e & 63u)); or_e = rl(an[s], (int)(e & 63u)) & 1u; }
-#pragma unroll
-          for (int s = 0; s < G2S_SEG_ASETS; s++)
-            if ((uint32_t)s * 64u < nA && __ballot(alo[s] <= hi_e && lo_e <= ahi[s] && ((an[s] & 1u) != or_e) && alo[s] <= ahi[s]))
-              flags |= G2S_DEV_Q7_A;
-        }
-      }
-    }
+   }
+   if constexpr (!TWO) load_right_set();
   } else {
     // ---- (BIG) the same label-correcting search with room for G2S_SEGX_EA entries.
     // LDS: tab[AS] u64 (node << 32 | label); the two queues live in the workgroup's scratch.
@@ -661,7 +691,20 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
       cur = best - 1u;
     }
   };
-  const unsigned long long cyc1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long cyc1 = TWO ? cyc0 : __builtin_amdgcn_s_memtime();
+  uint32_t cyc_a_kc = (uint32_t)((cyc_a_end - cyc0) >> 8);
+  // (two waves) phase B starts without the right set; the first round that needs it waits for wave 1
+  bool have_rs = !TWO;
+  auto take_right_set = [&]() {
+    if constexpr (TWO) {
+      __syncthreads();
+      nA = ash[0]; roundsA = ash[1]; flags |= ash[2];
+      if (ash[3]) overflow = true;
+      cyc_a_kc = ash[4];
+      load_right_set();
+      have_rs = true;
+    }
+  };
 
   // ---------------- phase B: entry events in registers, segments into LDS ----------------------
   uint32_t en = G2S_DEV_INVALID, ec = 0, es = 1, ep01 = 0xFFFFFFFFu, ep23 = 0xFFFFFFFFu;
@@ -772,6 +815,12 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
       const uint32_t lcap = min(es, (uint32_t)(D - ed + 1));
       uint32_t elen = lcap;
       const uint32_t esid = nseg + (uint32_t)__popcll(sel & below(lane));
+      if constexpr (TWO) {  // a state or a child at or beyond the depth the pruning rule starts at: the right set now
+        if (!have_rs && __ballot(mine && ed + (int)lcap >= gd.prune_from)) {
+          take_right_set();
+          if (overflow) break;
+        }
+      }
       SEG_PROF_T(2);
       // ---- their lengths under the pruning rule, their target hits (one segment at a time, wave-uniform)
       for (uint64_t m = sel; m; m &= m - 1) {
@@ -1131,6 +1180,7 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
+  if (!have_rs) take_right_set();  // (the search ended before the pruning depth: wave 1 is met here)
   if (overflow && !(flags & G2S_DEV_OVERFLOW_A)) flags |= G2S_DEV_OVERFLOW_B;
   lds_sync();
   const unsigned long long cyc2 = __builtin_amdgcn_s_memtime();
@@ -1292,7 +1342,7 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
     go->n_xl = 0;
     go->top_level = 0;
     go->stat[0] = roundsA; go->stat[1] = nA; go->stat[2] = gen; go->stat[3] = nseg;
-    go->stat[4] = (uint32_t)((cyc1 - cyc0) >> 8); go->stat[5] = (uint32_t)((cyc2 - cyc1) >> 8);
+    go->stat[4] = cyc_a_kc; go->stat[5] = (uint32_t)((cyc2 - cyc1) >> 8);
   }
   if (overflow || !(c_count > 0 && n_len > 0)) {  // :1169
     __threadfence();
@@ -1608,7 +1658,15 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
 // dynamic LDS: 7 arrays of G2S_SEG_CAP words + left seeds
 __global__ __launch_bounds__(64) void g2s_fill_seg(const SegArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-  seg_fill_one<false>(lds, A, blockIdx.x, nullptr);
+  seg_fill_one<false, false>(lds, A, blockIdx.x, nullptr);
+}
+
+// Two waves per gap (see seg_fill_one): for lists short enough to be latency-bound — the launch ends with its
+// slowest gap, and that gap's phase A (a quarter of its cycles) runs beside the first half of its phase B.
+// dynamic LDS: the segment arrays and seeds, then phase A's table, queues and hand-over words
+__global__ __launch_bounds__(128) void g2s_fill_seg2(const SegArgs A) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  seg_fill_one<false, true>(lds, A, blockIdx.x, nullptr);
 }
 
 // The large variant: one workgroup per compute unit (it takes nearly all of the LDS), each working
@@ -1622,7 +1680,7 @@ __global__ __launch_bounds__(64) void g2s_fill_segx(const SegArgs A, uint32_t* s
     if (threadIdx.x == 0) x = atomicAdd(next_gap, 1ull);
     x = __shfl(x, 0);
     if (x >= (unsigned long long)ngaps) break;
-    seg_fill_one<true>(lds, A, (uint32_t)x, scr);
+    seg_fill_one<true, false>(lds, A, (uint32_t)x, scr);
     lds_sync();
     __threadfence_block();
   }
@@ -1631,6 +1689,7 @@ __global__ __launch_bounds__(64) void g2s_fill_segx(const SegArgs A, uint32_t* s
 namespace g2s {
 
 size_t fill_seg_lds_bytes() { return 4u * (7u * G2S_SEG_CAP + 32u); }
+size_t fill_seg2_lds_bytes() { return 4u * (7u * G2S_SEG_CAP + 32u + 2u * 128u * G2S_SEG_ASETS + 128u * G2S_SEG_ASETS + 4u * 64u * G2S_SEG_ASETS + 8u); }
 uint32_t fill_seg_dbg_words() { return 8u + 2u * 64u * G2S_SEG_ASETS + 6u * G2S_SEG_CAP + 8u; }  // (+8: profile words)
 size_t fill_segx_lds_bytes() { return 4u * SEGX_LDS_WORDS; }
 size_t fill_segx_scratch_bytes(uint32_t workgroups) { return (size_t)workgroups * SEGX_SCR_WORDS * 4u; }
@@ -1639,14 +1698,16 @@ uint32_t fill_segx_dbg_words() { return 8u + 2u * G2S_SEGX_EA + 6u * G2S_SEGX_CA
 hipError_t launch_fill_seg(hipStream_t st, uint32_t ngaps, const uint32_t* succ, const uint32_t* urec, const GapDev* gaps,
                            const uint32_t* gap_ids, const uint32_t* flank_nodes, SubRec* sub_out,
                            unsigned long long out_cap, unsigned long long* out_counter, GapOut* outs, GapOut* outs_host,
-                           uint32_t* done_list, int skip_confident, uint32_t* dbg) {
+                           uint32_t* done_list, int skip_confident, uint32_t* dbg, bool two_waves) {
   if (ngaps == 0) return hipSuccess;
-  const size_t bytes = fill_seg_lds_bytes();
-  hipError_t e = hipFuncSetAttribute((const void*)g2s_fill_seg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  const size_t bytes = two_waves ? fill_seg2_lds_bytes() : fill_seg_lds_bytes();
+  hipError_t e = hipFuncSetAttribute(two_waves ? (const void*)g2s_fill_seg2 : (const void*)g2s_fill_seg,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   if (e != hipSuccess) return e;
   const SegArgs A = {succ, urec, gaps, gap_ids, flank_nodes, sub_out, out_cap, out_counter, outs, outs_host, done_list,
                      skip_confident, dbg, fill_seg_dbg_words()};
-  hipLaunchKernelGGL(g2s_fill_seg, dim3(ngaps), dim3(64), bytes, st, A);
+  if (two_waves) hipLaunchKernelGGL(g2s_fill_seg2, dim3(ngaps), dim3(128), bytes, st, A);
+  else hipLaunchKernelGGL(g2s_fill_seg, dim3(ngaps), dim3(64), bytes, st, A);
   return hipGetLastError();
 }
 

@@ -996,7 +996,10 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
       HIP_TRY(launch_fill_seg(st, (uint32_t)ids.size(), dg.succ, dg.urec, gaps_dev, ids_dev, (const uint32_t*)s->d_flank.p,
                               (SubRec*)d_subs_host, (unsigned long long)out_states, (unsigned long long*)s->d_counter.p,
                               (GapOut*)s->d_outs.p, (GapOut*)d_outs_host, (uint32_t*)d_done_host,
-                              s->params.skip_confident ? 1 : 0, seg_dbg));
+                              s->params.skip_confident ? 1 : 0, seg_dbg,
+                              // short lists are latency-bound (the launch ends with its slowest gap): two waves per
+                              // gap; long lists fill the chip and are throughput-bound: one (G2S_SEG_WAVES=1|2 forces)
+                              getenv("G2S_SEG_WAVES") ? atoi(getenv("G2S_SEG_WAVES")) == 2 : ids.size() <= 2048));
     else
     HIP_TRY(launch_fill_lds(st, (uint32_t)ids.size(), lds_cap_max, num_oriented, dg.succ, dg.ustart,
                             gaps_dev, ids_dev, (const uint32_t*)s->d_flank.p,
