@@ -283,7 +283,8 @@ def main():
         ab3 = algorithmic_bytes(x3, s3, tm3.flank_bytes + tm3.fill_bytes) / nl3
         kms3 = k3 / n3 / nl3
         c3_beside = dict(workload=CONFIGS["C3"][6], value=round(10000 * n3 / t3, 2), unit="gaps/s", steps=n3,
-                         ms_per_step=round(t3 / n3 * 1e3, 4), kernel="g2s_fill_seg" if tm3.seg_tier_gaps else "g2s_fill_lds",
+                         ms_per_step=round(t3 / n3 * 1e3, 4),
+                         kernel=("g2s_fill_seg2" if tm3.seg2_launches else "g2s_fill_seg") if tm3.seg_tier_gaps else "g2s_fill_lds",
                          kernel_ms_per_launch=round(kms3, 4), gaps_left_to_other_kernels=10000 - max(tm3.seg_tier_gaps, tm3.lds_tier_gaps),
                          launches_per_step=nl3, algorithmic_bytes_per_launch=ab3,
                          units_counted_by="product", roofline_frac=round(ab3 / (kms3 / 1e3) / 1e9 / HBM_PEAK_GBS, 6),
@@ -331,7 +332,8 @@ def main():
     seg_gaps = tm.seg_tier_gaps + tm.segx_tier_gaps
     if seg_gaps > 0 and seg_gaps >= tm.lds_tier_gaps:
         # the segment tier took (most of) the list: phases A-D1 over unitig segments, one wave per gap
-        kname = "g2s_fill_seg"
+        # (short lists run two waves per gap: the same code as g2s_fill_seg, phase A on the second wave)
+        kname = "g2s_fill_seg2" if tm.seg2_launches else "g2s_fill_seg"
         if octr is not None and tm.seg_tier_gaps == len(gaps):
             x_units, s_units, counted_by = octr[0] + octr[2] + octr[4], octr[1] + octr[3] + octr[5], "oracle"
         else:
@@ -340,7 +342,7 @@ def main():
         kern_ms = acc["ms_fill_seg"] / max(1, acc["seg_launches"])  # average launch duration
         if tm.segx_tier_gaps > 0:
             # deep gaps took the tier's large variant as well: the two kernels' launches of a step as one unit
-            kname = "g2s_fill_seg + g2s_fill_segx"
+            kname = kname + " + g2s_fill_segx"
             kern_ms = (acc["ms_fill_seg"] + acc["ms_fill_segx"]) / max(1, acc["seg_launches"])
     elif tm.lds_tier_gaps > 0:
         kname = "g2s_fill_lds"
@@ -358,11 +360,13 @@ def main():
     achieved = alg_bytes / (kern_ms / 1e3) / 1e9 if kern_ms > 0 else 0.0
     traffic, traffic_src = None, None
     pmc = os.path.join(ROOT, "profiles", "r02_pmc_fill_seg.json")
-    if os.path.exists(pmc) and kname == "g2s_fill_seg" and cfg_name == "C2" and not custom and ngpu == 1:
+    if os.path.exists(pmc) and kname == "g2s_fill_seg2" and cfg_name == "C2" and not custom and ngpu == 1:
         try:
-            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            traffic_src = "from_profile: profiles/r02_pmc_fill_seg.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, " \
-                          "separate passes of this command; not measured in this run)"
+            pj = json.load(open(pmc))
+            traffic = pj.get("hbm_bytes_per_launch") if pj.get("kernel", "").startswith(kname) else None
+            if traffic is not None:
+                traffic_src = "from_profile: profiles/r02_pmc_fill_seg.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, " \
+                              "separate passes of this command; not measured in this run)"
         except Exception:
             traffic = None
     roofline = dict(bound="hbm", kernel=kname, achieved=round(achieved, 3), peak=HBM_PEAK_GBS, unit="GB/s",

@@ -978,6 +978,8 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
     }
     const char* seg_dump = seg ? getenv("G2S_SEG_DUMP") : nullptr;  // diagnostics: phase A entries + segments of every gap
     const uint32_t seg_dbg_w = seg == 2 ? fill_segx_dbg_words() : fill_seg_dbg_words();
+    const bool seg_two_waves = getenv("G2S_SEG_WAVES") ? atoi(getenv("G2S_SEG_WAVES")) == 2 : ids.size() <= 2048;
+    if (seg == 1 && seg_two_waves) b->timing.seg2_launches++;
     if (seg_dump) {
       HIP_TRY(s->d_slog.ensure((size_t)ids.size() * seg_dbg_w * 4));
       HIP_TRY(hipMemsetAsync(s->d_slog.p, 0, (size_t)ids.size() * seg_dbg_w * 4, st));
@@ -999,7 +1001,7 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
                               s->params.skip_confident ? 1 : 0, seg_dbg,
                               // short lists are latency-bound (the launch ends with its slowest gap): two waves per
                               // gap; long lists fill the chip and are throughput-bound: one (G2S_SEG_WAVES=1|2 forces)
-                              getenv("G2S_SEG_WAVES") ? atoi(getenv("G2S_SEG_WAVES")) == 2 : ids.size() <= 2048));
+                              seg_two_waves));
     else
     HIP_TRY(launch_fill_lds(st, (uint32_t)ids.size(), lds_cap_max, num_oriented, dg.succ, dg.ustart,
                             gaps_dev, ids_dev, (const uint32_t*)s->d_flank.p,
@@ -2028,7 +2030,7 @@ extern "C" int g2s_team_fill(g2s_session* const* sessions, int nsessions, const 
         total.ms_fill_seg += t.ms_fill_seg; total.seg_tier_gaps += t.seg_tier_gaps; total.seg_launches += t.seg_launches;
         total.seg_segments += t.seg_segments;
         total.ms_fill_segx += t.ms_fill_segx; total.segx_tier_gaps += t.segx_tier_gaps; total.segx_launches += t.segx_launches;
-        total.watchdog_gaps += t.watchdog_gaps;
+        total.watchdog_gaps += t.watchdog_gaps; total.seg2_launches += t.seg2_launches;
       }
       rc = batches_stage2(subs, lead, results, arena, &total, false);
     }

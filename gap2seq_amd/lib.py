@@ -59,7 +59,7 @@ class g2s_timing(C.Structure):
                 ("log_pool_gaps", C.c_uint32), ("rs_pool_gaps", C.c_uint32), ("ms_prepare", C.c_double),
                 ("ms_fill_seg", C.c_double), ("seg_tier_gaps", C.c_uint32), ("seg_launches", C.c_uint32),
                 ("seg_segments", C.c_uint64), ("ms_fill_segx", C.c_double), ("segx_tier_gaps", C.c_uint32),
-                ("segx_launches", C.c_uint32), ("watchdog_gaps", C.c_uint32), ("reserved0", C.c_uint32)]
+                ("segx_launches", C.c_uint32), ("watchdog_gaps", C.c_uint32), ("seg2_launches", C.c_uint32)]
 
 
 class g2s_run_opts(C.Structure):

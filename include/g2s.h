@@ -185,7 +185,7 @@ typedef struct g2s_timing {
   uint32_t segx_tier_gaps;
   uint32_t segx_launches;
   uint32_t watchdog_gaps;    /* gaps on which a probe loop of the large variant ran past its bound (a defect; expected 0) */
-  uint32_t reserved0;
+  uint32_t seg2_launches;    /* segment-tier launches that ran two waves per gap (g2s_fill_seg2: short lists) */
 } g2s_timing;
 
 /* ---------------------------------------------------------------------------
