@@ -1,46 +1,50 @@
-// gap2seq_amd/csrc/fill_seg.hip — SEGMENT TIER of the fill path for gfx950 (CDNA4): phases
-// A, B, C and D1 of /root/reference/src/Gap2Seq.cpp:858-1312 in one kernel (g2s_fill_seg),
-// one 64-lane wavefront per gap, as a search over UNITIG SEGMENTS instead of DP levels.
-// tests/seg_model.py is the executable restatement of this algorithm that the CPU suite checks
-// without a GPU; read the two side by side.
+// gap2seq_amd/csrc/fill_seg.hip — SEGMENT TIER of the fill path for gfx950 (CDNA4): phases A, B, C, D1 and
+// (for closures without a repeated k-mer) D2 of /root/reference/src/Gap2Seq.cpp:858-1435 in one kernel, as a
+// search over UNITIG SEGMENTS instead of DP levels.  tests/seg_model.py is the executable restatement of this
+// algorithm that the CPU suite checks without a GPU; read the two side by side.
 //
-// Why: one wave per SIMD is bound by instruction issue and by dependent LDS / memory round
-// trips (rocprofv3, profiles/r02_pmc_sq_*.json: 39 % of the wave cycles issue instructions,
-// 58 % wait), so what a gap costs is the number of dependent steps it takes.  The LDS tier
-// (fill_lds.hip) takes one step per DP level that is not unitig-internal for EVERY border
-// state (~190 + ~190 steps for the slowest gaps of BASELINE config 2).  Here the unit of work
-// is the segment: node ids are numbered along unitigs (dbg.hpp: inside a unitig the only
-// successor of an even id v is v+2, of an odd id v-2, and v is that node's only predecessor),
-// so a DP state (v, d, count) that enters a unitig determines the whole diagonal
-// (v +- 2t, d + t, count) up to the unitig's end (one load of rem[v], seg_tables.hip), the
-// last level D, or the first state the pruning rule (:1050) rejects.  A gap of config 2 has
-// ~1 000 states but only ~25 segments, found in ~18 steps.
+// Three kernels from one template (seg_fill_one):
+//   g2s_fill_seg    one wave per gap, everything in LDS and registers: lists that fill the chip
+//   g2s_fill_seg2   the same with two waves per gap (phase A beside the first half of phase B): short lists,
+//                   whose launch ends with its slowest gap
+//   g2s_fill_segx   the large variant for gaps that outgrow the LDS-resident capacities (-dist-error 2000):
+//                   segments in global scratch, pending events in an LDS hash table, the right set as sorted
+//                   index intervals searched per lane; persistent workgroups, one per compute unit
 //
-//   phase A  (:871-982) label-correcting search over unitigs as in the LDS tier, but the right
-//            set is never materialised node by node: it IS the table of (entry node, depth
-//            label) pairs, i.e. a union of k-mer index intervals kept in registers (lane =
-//            entry).  Membership of a k-mer (:1050 ignores strand and depth) is one compare +
-//            ballot; "how far does this run stay inside the right set" is interval arithmetic.
-//   phase B  (:984-1105) ENTRY EVENTS (node, depth, count, <= 4 parents) live in registers
-//            (lane = pending event; merging = compare + ballot, no hash table).  An event is
-//            final once its depth is below the HORIZON = min over pending events of (depth +
-//            states to the end of its unitig): no pending event can still create a child at or
-//            above it.  All final events are expanded in one step: their lengths under the
-//            pruning rule, one successor record per segment that reaches its unitig's end, the
-//            children merged into the pending set.  Left-flank seeds (:1082-1105, value
-//            ASSIGNED 1, Q6) are pre-inserted events with a fixed count; events above the flank
-//            (depth < lmf) are cut after one state so that no segment runs across a seed state.
-//   phase C  (:1107-1159) in closed form from the target hits of the segments: a hit (j, depth)
-//            is found at level |depth - (g+lmf+j)| + g+lmf+rmf; smallest level, then smallest j.
-//   Q7       both strands of a k-mer at one depth: among pending events (compare + ballot) and
-//            where an upward and a downward segment of one unitig cross (arithmetic).
-//   phase D1 (:1169-1312) backward closure over the segments, generation by generation in
-//            reverse (children were created after their parent was expanded), then expanded
-//            into the 16-byte per-state records of the host half of phase D, children before
-//            parents, written straight into pinned host memory.
-// Segments (<= G2S_SEG_CAP) live in LDS; there is no state log in HBM at all.  A gap that
-// outgrows a capacity (segments, 64 pending events, 256 right-set entries, host buffer) is
-// flagged and runs in the LDS tier instead.  Integer work only: no MFMA on this path.
+// Why segments: one wave per SIMD is bound by instruction issue and by dependent LDS / memory round trips
+// (rocprofv3, profiles/r02_pmc_sq_*.json: a third of the wave cycles issue instructions, two thirds wait),
+// so what a gap costs is the number of dependent steps it takes.  The LDS tier (fill_lds.hip) takes one
+// step per DP level that is not unitig-internal for EVERY border state (~190 + ~190 steps for the slowest
+// gaps of BASELINE config 2).  Here the unit of work is the segment: node ids are numbered along unitigs
+// (dbg.hpp: inside a unitig the only successor of an even id v is v+2, of an odd id v-2, and v is that node's
+// only predecessor), so a DP state (v, d, count) that enters a unitig determines the whole diagonal
+// (v +- 2t, d + t, count) up to the unitig's end (one 32-byte record of urec[], seg_tables.hip), the last
+// level D, or the first state the pruning rule (:1050) rejects.  A gap of config 2 has ~1 000 states but
+// only ~17 segments, found in ~10 steps.
+//
+//   phase A  (:871-982) label-correcting search over unitigs; the right set is never materialised node by
+//            node: it IS the table of (entry node, depth label) pairs, i.e. a union of k-mer index intervals
+//            kept in registers (lane = entry).  Membership of a k-mer (:1050 ignores strand and depth) is one
+//            compare + ballot; "how far does this run stay inside the right set" is interval arithmetic.
+//   phase B  (:984-1105) ENTRY EVENTS (node, depth, count, <= 4 parents, stop depths) live in registers
+//            (lane = pending event; merging = compare + ballot, no hash table).  An event is final once its
+//            depth is below the HORIZON = min over pending events of (depth + states to the end of its
+//            unitig): no pending event can still create a child at or above it.  All final events are
+//            expanded in one step: their lengths under the pruning rule, one record per segment that
+//            reaches its unitig's end, the children merged into the pending set.  Left-flank seeds
+//            (:1082-1105, value ASSIGNED 1, Q6) are pre-inserted events with a fixed count; events above the
+//            flank (depth < lmf) are cut after one state so that no segment runs across a seed state.
+//   phase C  (:1107-1159) in closed form from the target hits of the segments: a hit (j, depth) is found at
+//            level |depth - (g+lmf+j)| + g+lmf+rmf; smallest level, then smallest j.
+//   Q7       both strands of a k-mer at one depth: among pending events (compare + ballot) and where an
+//            upward and a downward segment of one unitig cross (arithmetic).
+//   phase D1 (:1169-1312) backward closure over the segments, generation by generation in reverse (children
+//            were created after their parent was expanded).
+//   phase D2 (:1314-1435) when no k-mer repeats in the closure: the branch rule as a prefix sum over segments.
+//   output   the closure as 32-byte segment records (SegRec), children before parents, parents in GATB's
+//            predecessor order, written straight into pinned host memory; the host walks them (post.cpp).
+// A gap that outgrows a capacity (segments, pending events, right-set entries, host buffer) is flagged and
+// runs again in the next kernel of the chain (g2s_fill_segx, then the LDS tier).  Integer work only: no MFMA.
 #include <hip/hip_runtime.h>
 
 #include "fill_device.h"

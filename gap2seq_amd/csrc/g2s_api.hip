@@ -383,6 +383,8 @@ class WorkerPool {
     if (n > th_.size()) cv_.notify_all();
     else for (size_t i = 0; i + 1 < n; i++) cv_.notify_one();
   }
+  // nothing posted, or every task of the posted job done (finish() will not wait)
+  bool idle() const { return posted_n_ == 0 || done_.load(std::memory_order_acquire) == posted_n_; }
   void finish() {
     if (posted_n_ == 0) return;
     drain(posted_g_, posted_n_, posted_f_);
@@ -633,6 +635,7 @@ struct g2s_batch {
   g2s_timing timing;
   std::vector<TierData*> tiers;
   TierData* seg_td = nullptr;  // the segment tier's launch of this run (closures expanded into its buffer)
+  bool force_host_d2 = false;  // G2S_HOST_D2=1 (tests): phase D2 on the host even where the device did it
   // stage 1 results (GPU passes + per-gap analysis), consumed by stage 2 (offsets + tracebacks)
   std::vector<SubView> views;
   std::vector<SubPrep> prep;
@@ -685,6 +688,7 @@ extern "C" int g2s_batch_prepare(g2s_session* s, const g2s_gap* gaps, size_t n, 
   // first and last k+rmf of the right one; the k-mer -> node look-ups run on the device (flank_lookup.hip)
   size_t text_bytes = 0, n_nodes = 0, n_desc = 0;
   std::vector<uint32_t> text_off(n);
+  const bool force_host_lookup = getenv("G2S_HOST_LOOKUP") != nullptr;
   for (size_t i = 0; i < n; i++) {
     GapJob& j = b->jobs[i];
     const g2s_gap& in = gaps[i];
@@ -698,7 +702,7 @@ extern "C" int g2s_batch_prepare(g2s_session* s, const g2s_gap* gaps, size_t n, 
     b->flank_off[i] = (uint32_t)n_nodes;
     if (!j.bad_flank) {
       const size_t tb = (size_t)(k + j.lmf) + 2 * (size_t)(k + j.rmf);
-      if (tb > G2S_FLANK_TEXT_MAX || j.lmf > 65535 || j.rmf > 65535 || getenv("G2S_HOST_LOOKUP")) b->host_lookup = true;
+      if (tb > G2S_FLANK_TEXT_MAX || j.lmf > 65535 || j.rmf > 65535 || force_host_lookup) b->host_lookup = true;
       text_off[i] = (uint32_t)text_bytes;
       text_bytes += (tb + 3) & ~(size_t)3;
       n_nodes += (size_t)(j.lmf + 1) + 2 * (size_t)(j.rmf + 1);
@@ -1071,6 +1075,7 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
       } else if (finished) {
         break;  // kernel over and nothing new: an error, reported by the sync below
       } else {
+        (*on_done)(nullptr, 0);  // (lets closures that wait for the pool go as soon as it is free)
         struct timespec ts = {0, 5000};
         nanosleep(&ts, nullptr);
       }
@@ -1216,6 +1221,10 @@ FillParams fill_params_of(const g2s_session* s) {
 // Everything about gap i that does not depend on the gaps before it: D2 + stop-depth
 // analysis, the order-independent result fields, and the summary the offset pass reads.
 // *r must be zeroed.
+// (G2S_DEBUG) what the host analysis of a run was made of
+static const bool dbg_analysis_stats = getenv("G2S_DEBUG") != nullptr;
+static std::atomic<uint64_t> dbg_ns_seg{0}, dbg_n_seg{0}, dbg_ns_state{0}, dbg_n_state{0}, dbg_states{0};
+
 void analyze_gap(g2s_batch* b, size_t i, const FillParams& fp, g2s_result* r) {
   g2s_batch::GapInfo& gi = b->info[i];
   gi.fixed[0] = gi.fixed[1] = -1;
@@ -1227,7 +1236,7 @@ void analyze_gap(g2s_batch* b, size_t i, const FillParams& fp, g2s_result* r) {
   SubView& v = b->views[i];
   SubPrep& pp = b->prep[i];
   bool analysed = false;
-  if (v.segs && (v.out->dflags & G2S_DEVA_ANALYSED) && !getenv("G2S_HOST_D2")) {
+  if (v.segs && (v.out->dflags & G2S_DEVA_ANALYSED) && !b->force_host_d2) {
     // segment tier, phase D2 and the stop depths done on the device: nothing per segment is left to do
     const GapOut& go = *v.out;
     pp.seg_mode = true;
@@ -1268,8 +1277,13 @@ void analyze_gap(g2s_batch* b, size_t i, const FillParams& fp, g2s_result* r) {
       const size_t at = b->seg_td->exp_cursor.fetch_add(need);
       if (at + need <= b->seg_td->exp.size()) scratch = b->seg_td->exp.data() + at;
     }
+    const auto ta0 = std::chrono::steady_clock::now();
     analysed = seg_analyze(fp, j, v, &pp, scratch);
     if (!analysed) pp = SubPrep();
+    if (dbg_analysis_stats) {
+      dbg_ns_seg.fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - ta0).count());
+      dbg_n_seg.fetch_add(1);
+    }
   }
   if (v.segs && !analysed) {  // ... unless a k-mer occurs at two depths of the closure: per-state records then
     const GapOut& go = *v.out;
@@ -1286,8 +1300,14 @@ void analyze_gap(g2s_batch* b, size_t i, const FillParams& fp, g2s_result* r) {
     v.segs = nullptr;
   }
   if (!analysed) {
+    const auto ta0 = std::chrono::steady_clock::now();
     if (v.n_xp > 1) std::sort(const_cast<uint64_t*>(v.xp), const_cast<uint64_t*>(v.xp) + v.n_xp);  // by state (the kernel appends per level)
     sub_analyze(fp, j, v, &pp);
+    if (dbg_analysis_stats) {
+      dbg_ns_state.fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - ta0).count());
+      dbg_n_state.fetch_add(1);
+      dbg_states.fetch_add(v.n);
+    }
   }
   r->phaseC_count = v.out->c_count;
   r->n_lengths = v.out->n_len;
@@ -1335,6 +1355,7 @@ int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
   };
   { const int rc = b->upload_flanks(); if (rc != G2S_OK) return rc; }
   b->drop_tiers();
+  b->force_host_d2 = getenv("G2S_HOST_D2") != nullptr;
   if (getenv("G2S_DEBUG")) fprintf(stderr, "[g2s] stage 1 begins\n");
   lap("flank upload");
   g2s_timing keep = b->timing;
@@ -1360,6 +1381,22 @@ int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
   }
   lap("per-gap arrays");
   TierData* td_live = nullptr;
+  std::vector<uint32_t> heavy_wait, heavy_job;
+  std::function<void(size_t)> heavy_fn = [&](size_t t) { analyze_gap(b, heavy_job[t], fp, &results[heavy_job[t]]); };
+  auto post_heavy = [&]() {  // the pool is free: what has piled up becomes its next job (largest closures first)
+    s->pool->finish();
+    heavy_job.swap(heavy_wait);
+    heavy_wait.clear();
+    std::sort(heavy_job.begin(), heavy_job.end(), [&](uint32_t a, uint32_t c) { return views[a].out->n_sub > views[c].out->n_sub; });
+    s->pool->post(heavy_job.size(), heavy_fn);
+  };
+  auto flush_heavy = [&]() {  // before anything else uses the pool, and before the views of a launch are consumed
+    while (true) {
+      s->pool->finish();
+      if (heavy_wait.empty()) break;
+      post_heavy();
+    }
+  };
   const DoneFn on_done = [&](const uint32_t* done_ids, size_t cnt) {
     auto t0 = std::chrono::steady_clock::now();
     const GapOut* outs = (const GapOut*)td_live->outs.p;
@@ -1386,6 +1423,17 @@ int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
       analyzed[i] = 1;
       fresh.push_back(i);
     }
+    // Closures of many thousand states that the host has to analyse (the large variant's gaps, a k-mer at two
+    // depths: milliseconds each) go to the pool WITHOUT waiting for them: this thread keeps polling, and
+    // whatever has arrived by the time the pool is free again forms the next job.
+    {
+      size_t w = 0;
+      for (uint32_t i : fresh) {
+        const bool heavy = views[i].segs && !(views[i].out->dflags & G2S_DEVA_ANALYSED) && views[i].out->n_sub >= 4000;
+        if (heavy) heavy_wait.push_back(i); else fresh[w++] = i;
+      }
+      fresh.resize(w);
+    }
     size_t work = 0;
     for (uint32_t i : fresh)  // (closure states to look at; 2 for a gap analysed on the device)
       work += views[i].segs ? ((views[i].out->dflags & G2S_DEVA_ANALYSED) ? 2u : views[i].out->n_sub) : views[i].n;
@@ -1393,11 +1441,13 @@ int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
       for (uint32_t i : fresh) analyze_gap(b, i, fp, &results[i]);
     } else {
       // the last gaps of a launch are few and large: one task per gap then
+      s->pool->finish();  // (a job of heavy closures may still be open)
       const size_t per = fresh.size() >= 64 ? 8 : 1, nt = (fresh.size() + per - 1) / per;
       s->pool->run(nt, [&](size_t t) {
         for (size_t x = t * per; x < std::min(fresh.size(), (t + 1) * per); x++) analyze_gap(b, fresh[x], fp, &results[fresh[x]]);
       });
     }
+    if (!heavy_wait.empty() && s->pool->idle()) post_heavy();
     ms_stream += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   };
 
@@ -1438,6 +1488,7 @@ int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
       }
       lap("segment pass set-up");
       int rc = run_tier(b, seg_ids, 1, max_states, td, true, 0, false, 64u, analyze ? &on_done : nullptr, mode);
+      flush_heavy();
       if (rc != G2S_OK) return rc;
       lap("segment pass run_tier");
       const GapOut* outs = (const GapOut*)td->outs.p;
@@ -1687,8 +1738,12 @@ int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_post).count();
     b->timing.ms_host_post = ms + ms_stream;  // ms_stream overlapped the kernels
     b->timing.ms_total += ms;
-    if (getenv("G2S_DEBUG"))
+    if (getenv("G2S_DEBUG")) {
       fprintf(stderr, "[g2s] analysis: %.3f ms while the kernels ran, %.3f ms after (%zu gaps)\n", ms_stream, ms, fresh.size());
+      fprintf(stderr, "[g2s] analysis on the host: %llu closures on segments %.3f ms; %llu on per-state records (a k-mer at two depths) %.3f ms, %llu states\n",
+              (unsigned long long)dbg_n_seg.exchange(0), dbg_ns_seg.exchange(0) / 1e6, (unsigned long long)dbg_n_state.exchange(0),
+              dbg_ns_state.exchange(0) / 1e6, (unsigned long long)dbg_states.exchange(0));
+    }
   }
   (void)g;
   (void)views;
