@@ -29,7 +29,7 @@ int main(int argc, char** argv) {
   g2s_params p;
   memset(&p, 0, sizeof p);
   p.d_err = 500; p.all_paths = 1;
-  int randseed = 0, device = 0, streams = 2;
+  int randseed = 0, device = 0, streams = 2, stream_gaps = 8192;
   std::string devices;  // "0,1,2": GPUs sharing the gap list (the graph is replicated)
   std::string reads, scaffolds, filled, left, right;
   int length = 0;
@@ -60,10 +60,12 @@ int main(int argc, char** argv) {
     else if (a == "-device") device = atoi(val());
     else if (a == "-devices") devices = val();
     else if (a == "-streams") streams = atoi(val());
+    else if (a == "-stream-gaps") stream_gaps = atoi(val());
     else if (a == "-help" || a == "-h") {
       std::cout << "Gap2Seq-core (MI355X) -reads a.fq[,b.fq] -filled out.fa (-scaffolds in.fa | -left S -right S -length N)\n"
                    "  [-k 31] [-solid 2] [-dist-error 500] [-fuz 10] [-max-mem 20] [-randseed 0]\n"
-                   "  [-all-upper] [-best-only] [-unique] [-nb-cores N] [-device D | -devices D0,D1,...] [-streams 2]\n";
+                   "  [-all-upper] [-best-only] [-unique] [-nb-cores N] [-device D | -devices D0,D1,...] [-streams 2]\n"
+                   "  [-stream-gaps 8192]\n";
       return EXIT_SUCCESS;
     }
     else {  // GATB's OptionsParser rejects what it does not know; main.cpp:29-31 prints the message
@@ -151,7 +153,22 @@ int main(int argc, char** argv) {
     while ((got = fread(buf, 1, sizeof buf, f)) > 0) text.append(buf, got);
     fclose(f);
     int32_t gaps = 0, nfilled = 0;
-    rc = g2s_execute_scaffolds(s, &o, reads.c_str(), filled.c_str(), text.c_str(), &fasta, &log, &gaps, &nfilled);
+    // the log is printed and the records are written as the batches finish (-stream-gaps N per batch)
+    FILE* out = fopen(filled.c_str(), "wb");
+    if (!out) { std::cout << "EXCEPTION: cannot write " << filled << std::endl; return EXIT_FAILURE; }
+    rc = g2s_execute_scaffolds_stream(
+        s, &o, reads.c_str(), filled.c_str(), text.c_str(), (size_t)std::max(0, stream_gaps),
+        [](const char* t, size_t n, void* u) { fwrite(t, 1, n, (FILE*)u); },
+        [](const char* t, size_t n, void*) { fwrite(t, 1, n, stdout); fflush(stdout); }, out, &gaps, &nfilled);
+    fclose(out);
+    if (rc != G2S_OK) {
+      std::cout << "EXCEPTION: " << g2s_last_error() << std::endl;
+      return EXIT_FAILURE;
+    }
+    g2s_session_destroy(s);
+    for (g2s_session* h : helpers) g2s_session_destroy(h);
+    g2s_graph_free(g);
+    return EXIT_SUCCESS;
   }
   if (rc != G2S_OK) {
     std::cout << "EXCEPTION: " << g2s_last_error() << std::endl;

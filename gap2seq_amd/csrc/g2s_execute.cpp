@@ -101,9 +101,15 @@ struct GapEvent {
 extern "C" const g2s_graph* g2s_session_graph(const g2s_session* s);
 extern "C" int g2s_session_get_params(const g2s_session* s, g2s_params* out);
 
-extern "C" int g2s_execute_scaffolds(g2s_session* s, const g2s_run_opts* o, const char* reads_label,
-                                     const char* filled_label, const char* scaffolds_text, char** fasta_out,
-                                     char** log_out, int32_t* gaps_out, int32_t* filled_out) {
+// The log and the FASTA leave as the records are done: after every batch of about `chunk_gaps` gaps (cut at
+// record boundaries; 0 = one batch) what has been decided so far is handed to the two callbacks, in input
+// order — the reference prints a gap's statistics when the gap is done (:385), not at the end of the run.
+// The rand() stream runs on across the batches and the couplings between gaps stay inside a record, so the
+// text is the same for every chunk size.
+extern "C" int g2s_execute_scaffolds_stream(g2s_session* s, const g2s_run_opts* o, const char* reads_label,
+                                            const char* filled_label, const char* scaffolds_text, size_t chunk_gaps,
+                                            g2s_text_fn on_fasta, g2s_text_fn on_log, void* user, int32_t* gaps_out,
+                                            int32_t* filled_out) {
   if (!s || !o || !scaffolds_text) return G2S_ERR_ARG;
   g2s_params p;
   g2s_session_get_params(s, &p);
@@ -135,7 +141,7 @@ extern "C" int g2s_execute_scaffolds(g2s_session* s, const g2s_run_opts* o, cons
     int sprev = prevGapEnd;
     bool prev_attempted = false;  // previous gap of this record is in this batch and eligible
     int prev_rmf = 0;
-    bool barrier = false;
+    bool barrier = false, soft = false;
     flanks.reserve(2 * 1024);
     std::vector<std::pair<size_t, size_t>> flank_idx;  // per job: indices into flanks
     while (sr < recs.size() && !barrier) {
@@ -189,6 +195,7 @@ extern "C" int g2s_execute_scaffolds(g2s_session* s, const g2s_run_opts* o, cons
       si = 0;
       sprev = 0;
       prev_attempted = false;
+      if (chunk_gaps && jobs.size() >= chunk_gaps && sr < recs.size()) { soft = true; break; }  // enough for one batch
     }
     for (size_t j = 0; j < jobs.size(); j++) {
       jobs[j].left = flanks[flank_idx[j].first].c_str();
@@ -253,16 +260,46 @@ extern "C" int g2s_execute_scaffolds(g2s_session* s, const g2s_run_opts* o, cons
       // resume exactly at the barrier gap of record sr: N-run boundaries do not move,
       // only prevGapEnd (already exact) matters
       i_exact = si;
+    } else if (soft) {
+      while (cur_rec < sr) finish_record();  // (record sr starts the next batch)
     } else {
       while (cur_rec < recs.size()) finish_record();
       done = true;
     }
+    if (done) os << "Filled " << filledgapcount << " gaps out of " << gapcount << "\n";  // :437
+    {  // what is decided so far leaves now
+      const std::string lg = os.str();
+      if (on_log && !lg.empty()) on_log(lg.data(), lg.size(), user);
+      os.str(std::string());
+      if (on_fasta && !fasta.empty()) on_fasta(fasta.data(), fasta.size(), user);
+      fasta.clear();
+    }
   }
-  os << "Filled " << filledgapcount << " gaps out of " << gapcount << "\n";  // :437
-  if (fasta_out) *fasta_out = dup_text(fasta);
-  if (log_out) *log_out = dup_text(os.str());
+  if (recs.empty()) {
+    os << "Filled " << filledgapcount << " gaps out of " << gapcount << "\n";
+    const std::string lg = os.str();
+    if (on_log) on_log(lg.data(), lg.size(), user);
+  }
   if (gaps_out) *gaps_out = gapcount;
   if (filled_out) *filled_out = filledgapcount;
+  return G2S_OK;
+}
+
+namespace {
+struct TwoTexts { std::string fasta, log; };
+void collect_fasta(const char* t, size_t n, void* u) { ((TwoTexts*)u)->fasta.append(t, n); }
+void collect_log(const char* t, size_t n, void* u) { ((TwoTexts*)u)->log.append(t, n); }
+}  // namespace
+
+extern "C" int g2s_execute_scaffolds(g2s_session* s, const g2s_run_opts* o, const char* reads_label,
+                                     const char* filled_label, const char* scaffolds_text, char** fasta_out,
+                                     char** log_out, int32_t* gaps_out, int32_t* filled_out) {
+  TwoTexts tt;
+  const int rc = g2s_execute_scaffolds_stream(s, o, reads_label, filled_label, scaffolds_text, 0, collect_fasta, collect_log,
+                                              &tt, gaps_out, filled_out);
+  if (rc != G2S_OK) return rc;
+  if (fasta_out) *fasta_out = dup_text(tt.fasta);
+  if (log_out) *log_out = dup_text(tt.log);
   return G2S_OK;
 }
 

@@ -69,6 +69,7 @@ class g2s_run_opts(C.Structure):
 
 # every symbol include/g2s.h declares: name -> (restype, argtypes)
 _VP = C.c_void_p
+TEXT_FN = C.CFUNCTYPE(None, C.POINTER(C.c_char), C.c_size_t, C.c_void_p)  # g2s_text_fn
 _SIGS = {
     "g2s_abi_version": (C.c_int, []),
     "g2s_last_error": (C.c_char_p, []),
@@ -105,6 +106,8 @@ _SIGS = {
                                 C.POINTER(g2s_result), C.c_char_p, C.c_size_t, C.POINTER(g2s_timing)]),
     "g2s_team_arena_bytes": (C.c_size_t, [_VP, C.POINTER(g2s_gap), C.c_size_t]),
     "g2s_session_set_team": (C.c_int, [_VP, C.POINTER(_VP), C.c_int, C.c_size_t]),
+    "g2s_execute_scaffolds_stream": (C.c_int, [_VP, C.POINTER(g2s_run_opts), C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t,
+                                             TEXT_FN, TEXT_FN, _VP, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "g2s_execute_scaffolds": (C.c_int, [_VP, C.POINTER(g2s_run_opts), C.c_char_p, C.c_char_p, C.c_char_p,
                                         C.POINTER(_VP), C.POINTER(_VP), C.POINTER(C.c_int32),
                                         C.POINTER(C.c_int32)]),
@@ -399,6 +402,20 @@ class Session:
                                          scaffolds_text.encode("ascii"), C.byref(fa), C.byref(lg), C.byref(gaps),
                                          C.byref(filled)))
         return _take_text(fa), _take_text(lg), gaps.value, filled.value
+
+    def execute_scaffolds_stream(self, scaffolds_text, k, chunk_gaps, solid=2, max_fuz=10, nb_cores=1, max_mem_gb=20.0,
+                                 reads_label="reads.fa", filled_label="filled.fa"):
+        """g2s_execute_scaffolds_stream; returns (fasta pieces, log pieces, gaps, filled): one piece per batch."""
+        lib = load_library()
+        o = g2s_run_opts(k, solid, max_fuz, nb_cores, max_mem_gb)
+        fa, lg = [], []
+        on_fa = TEXT_FN(lambda t, n, u: fa.append(C.string_at(t, n).decode("ascii")))
+        on_lg = TEXT_FN(lambda t, n, u: lg.append(C.string_at(t, n).decode("ascii")))
+        gaps, filled = C.c_int32(0), C.c_int32(0)
+        _check(lib.g2s_execute_scaffolds_stream(self.h, C.byref(o), reads_label.encode(), filled_label.encode(),
+                                                scaffolds_text.encode("ascii"), chunk_gaps, on_fa, on_lg, None,
+                                                C.byref(gaps), C.byref(filled)))
+        return fa, lg, gaps.value, filled.value
 
     def execute_single(self, left, right, length, k, solid=2, max_fuz=10, max_mem_gb=20.0,
                        reads_label="reads.fa", filled_label="filled.fa"):

@@ -252,6 +252,15 @@ typedef struct g2s_run_opts {
 int g2s_execute_scaffolds(g2s_session* s, const g2s_run_opts* o, const char* reads_label,
                           const char* filled_label, const char* scaffolds_text, char** fasta, char** log,
                           int32_t* gaps, int32_t* filled);
+/* The same run with the text handed over as the records are done (the reference prints a gap's statistics when
+ * the gap is done, Gap2Seq.cpp:385, and appends a record to the output bank when the record is, :426-431):
+ * the gaps are filled in batches of about chunk_gaps (cut at record boundaries; 0 = one batch) and after every
+ * batch on_log / on_fasta receive, in input order, what that batch decided.  The concatenated text does not
+ * depend on chunk_gaps. */
+typedef void (*g2s_text_fn)(const char* text, size_t len, void* user);
+int g2s_execute_scaffolds_stream(g2s_session* s, const g2s_run_opts* o, const char* reads_label,
+                                 const char* filled_label, const char* scaffolds_text, size_t chunk_gaps,
+                                 g2s_text_fn on_fasta, g2s_text_fn on_log, void* user, int32_t* gaps, int32_t* filled);
 int g2s_execute_single(g2s_session* s, const g2s_run_opts* o, const char* reads_label, const char* filled_label,
                        const char* left, const char* right, int32_t length, char** fasta, char** log);
 void g2s_free(void* p);

@@ -493,6 +493,40 @@ def test_long_list_goes_through_the_group_pipeline(product):
         pg.free()
 
 
+def test_execute_stream_is_the_one_batch_text_for_every_chunk_size(product):
+    """g2s_execute_scaffolds_stream hands the log and the records over batch by batch; the concatenation is the
+    text of the one-batch run whatever the batch size (the rand() stream runs on across batches, the couplings
+    between consecutive gaps never cross a record boundary)."""
+    k = 21
+    seqs = cases.toy_genome(11, 60000, k, repeats=6, snp_every=400)
+    text = _stream_scaffolds(seqs[0], k)
+    pg = product.Graph.from_seqs(seqs, k, 1)
+    try:
+        want = None
+        for chunk in (0, 1, 7, 40, 100000):
+            sess = product.Session(pg, 0, d_err=100, randseed=4)
+            try:
+                if chunk == 0:
+                    fa, lg, ngaps, nfilled = sess.execute_scaffolds(text, k, solid=1)
+                    want = (fa, lg, ngaps, nfilled)
+                    assert ngaps >= 60 and nfilled >= 20
+                else:
+                    fas, lgs, ngaps, nfilled = sess.execute_scaffolds_stream(text, k, chunk, solid=1)
+                    assert ("".join(fas), "".join(lgs), ngaps, nfilled) == want, chunk
+                    if chunk == 1:
+                        assert len(lgs) >= 20  # really handed over in pieces: a batch per record
+            finally:
+                sess.destroy()
+    finally:
+        pg.free()
+
+
+def _stream_scaffolds(genome, k):
+    """multi-gap scaffold records over a toy genome (the generator of the full-size C1 stand-in)"""
+    import test_gpu_fullsize
+    return test_gpu_fullsize._simulated_scaffolds(genome, k, 10, 77, 40, 1500)
+
+
 def test_session_team_drives_execute_scaffolds(product, oracle):
     """g2s_session_set_team: execute() on the lead spreads the record list's gaps over the
     helpers; FASTA and log equal the oracle's execute()."""
