@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cctype>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace g2s {
@@ -538,9 +539,20 @@ inline int seg_parents(const SegRec& s, uint32_t out[4]) {
   return n;
 }
 
+// the run (SubPrep::runs, run_mode) that holds k-mer index x, or nullptr
+inline const SegRun* run_of(const SubPrep& prep, uint32_t x) {
+  size_t lo = 0, hi = prep.runs.size();
+  while (lo < hi) { const size_t mid = (lo + hi) >> 1; if (prep.runs[mid].lo <= x) lo = mid + 1; else hi = mid; }
+  return (lo > 0 && x <= prep.runs[lo - 1].hi) ? &prep.runs[lo - 1] : nullptr;
+}
+
 // safe bit of state t of segment i (:1466; k-mers outside the subgraph read branch[sink], Q5)
 inline bool seg_safe(const SubView& v, const SubPrep& prep, uint32_t i, int t) {
   const SegRec& s = v.segs[i];
+  if (prep.run_mode) {  // the verdict belongs to the k-mer, whatever the depth (k-mers outside the subgraph: Q5)
+    const SegRun* r = run_of(prep, seg_state(s, t) >> 1);
+    return r ? r->safe != 0 : prep.sink_safe;
+  }
   const int ts = seg_ts(s);
   // the branch rule's verdict for state tq of segment q: from the host analysis (prep.seg) or, when
   // phase D2 ran on the device, from the bits it left in the record
@@ -572,6 +584,239 @@ inline bool seg_safe(const SubView& v, const SubPrep& prep, uint32_t i, int t) {
     }
   }
   return prep.sink_safe;
+}
+
+}  // namespace
+
+namespace {
+
+// sorted, disjoint intervals from a list of (first, last) pairs; overlapping and adjacent ones merge
+void merge_intervals(std::vector<std::pair<uint32_t, uint32_t>>* a) {
+  std::sort(a->begin(), a->end());
+  size_t w = 0;
+  for (size_t i = 0; i < a->size(); i++) {
+    if (w > 0 && (*a)[i].first <= (*a)[w - 1].second + 1u) (*a)[w - 1].second = std::max((*a)[w - 1].second, (*a)[i].second);
+    else (*a)[w++] = (*a)[i];
+  }
+  a->resize(w);
+}
+inline bool in_intervals(const std::vector<std::pair<uint32_t, uint32_t>>& a, uint32_t x) {
+  size_t lo = 0, hi = a.size();
+  while (lo < hi) { const size_t mid = (lo + hi) >> 1; if (a[mid].first <= x) lo = mid + 1; else hi = mid; }
+  return lo > 0 && x <= a[lo - 1].second;
+}
+
+// :1314-1435 on a closure in which k-mers occur at several depths.  The reference's vertices are k-mers
+// (node2boost), its edges the deduplicated (boost::edge(u, v).second) state transitions.  Inside a unitig the
+// transitions are index +-1 steps, so the k-mer graph is made of CHAINS: cut the closure's index intervals at
+// every segment end and at every k-mer that carries another edge (a parent's last k-mer, an entry, a sink
+// position); what lies between two cuts is a run of k-mers whose only edges are the chain's own (one
+// direction, or both when an upward and a downward segment cover it).  Strong components (Tarjan), the
+// contraction and the branch rule run on runs; a run that is not in a component of several vertices stands
+// for a row of trivial vertices with one edge in and one out each, along which the running count of the
+// branch rule cannot change.  sinkpos: position of the sink state inside each segment or -1.
+void seg_analyze_runs(const FillParams& p, const SubView& v, SubPrep* out, const std::vector<int>& sinkpos) {
+  typedef std::pair<uint32_t, uint32_t> IV;
+  const uint32_t n = v.n_segs;
+  const SegRec* sg = v.segs;
+  constexpr uint32_t VSINK = 0xFFFFFFFEu, VSRC = 0xFFFFFFFFu;
+  static thread_local std::vector<IV> viv, uiv, div;
+  static thread_local std::vector<uint64_t> sp;
+  static thread_local std::vector<uint32_t> bp;
+  static thread_local std::vector<std::pair<int, int>> ce;
+  static thread_local std::vector<int> off, adj, comp, cnodes, cweight, din, dout, foff, fadj, indeg, order, fbranch, internal, loops;
+  static thread_local std::vector<char> cyc, nontriv;
+  viv.clear(); uiv.clear(); div.clear(); sp.clear(); bp.clear(); ce.clear(); loops.clear();
+  int count = 0;
+  for (uint32_t i = 0; i < n; i++) {
+    const SegRec& s = sg[i];
+    const int ts = seg_ts(s);
+    if (ts < 0) continue;
+    const uint32_t idx = s.node >> 1;
+    const bool up = (s.node & 1u) == 0;
+    const uint32_t lo = up ? idx : idx - (uint32_t)ts, hi = up ? idx + (uint32_t)ts : idx;
+    viv.emplace_back(lo, hi);
+    bp.push_back(lo);
+    bp.push_back(hi);
+    if (ts > 0) (up ? uiv : div).emplace_back(lo, hi - 1u);  // chain edges by the lower index of their two k-mers
+    if (s.flags & G2S_SUB_SOURCE) sp.push_back(((uint64_t)VSRC << 32) | idx);                    // :1303-1305
+    else {
+      uint32_t ps[4];
+      const int np = seg_parents(s, ps);
+      for (int x = 0; x < np; x++) {                                                              // :1283-1297
+        const SegRec& q = sg[ps[x]];
+        const uint32_t last = seg_state(q, (int)(q.depth_len >> 16) - 1) >> 1;
+        sp.push_back(((uint64_t)last << 32) | idx);
+        bp.push_back(last);
+      }
+    }
+    if (sinkpos[i] >= 0 && sinkpos[i] <= ts) {                                                    // :1216-1226 / :1248-1256
+      const uint32_t x = seg_state(s, sinkpos[i]) >> 1;
+      sp.push_back(((uint64_t)x << 32) | VSINK);
+      bp.push_back(x);
+      count = sat_add(count, (int)s.cnt);
+    }
+  }
+  if (p.all_paths) out->count = count;  // recount (:1189-1191); -best-only keeps the phase C count
+  merge_intervals(&uiv);
+  merge_intervals(&div);
+  {  // vertices: overlapping intervals merge (adjacent ones may: whether an edge joins them is looked up)
+    std::sort(viv.begin(), viv.end());
+    size_t w = 0;
+    for (size_t i = 0; i < viv.size(); i++) {
+      if (w > 0 && viv[i].first <= viv[w - 1].second) viv[w - 1].second = std::max(viv[w - 1].second, viv[i].second);
+      else viv[w++] = viv[i];
+    }
+    viv.resize(w);
+  }
+  uint64_t V = 2;
+  for (const IV& a : viv) V += (uint64_t)(a.second - a.first) + 1u;
+  std::sort(bp.begin(), bp.end());
+  bp.erase(std::unique(bp.begin(), bp.end()), bp.end());
+  std::sort(sp.begin(), sp.end());
+  sp.erase(std::unique(sp.begin(), sp.end()), sp.end());  // boost::edge(u, v).second de-duplication ...
+  {                                                       // ... also against the chains' own edges
+    size_t w = 0;
+    for (uint64_t e : sp) {
+      const uint32_t a = (uint32_t)(e >> 32), b = (uint32_t)e;
+      if (a < VSINK && b < VSINK) {
+        if (b == a + 1u && in_intervals(uiv, a)) continue;
+        if (a == b + 1u && in_intervals(div, b)) continue;
+      }
+      sp[w++] = e;
+    }
+    sp.resize(w);
+  }
+  // ---- runs: every cut k-mer alone, and what lies between two cuts
+  std::vector<SegRun>& runs = out->runs;
+  runs.clear();
+  {
+    size_t b = 0;
+    for (const IV& a : viv) {
+      uint32_t next = a.first;  // first k-mer not yet in a run
+      while (b < bp.size() && bp[b] < a.first) b++;
+      for (; b < bp.size() && bp[b] <= a.second; b++) {
+        if (bp[b] > next) runs.push_back(SegRun{next, bp[b] - 1u, 0});
+        runs.push_back(SegRun{bp[b], bp[b], 0});
+        next = bp[b] + 1u;
+      }
+      if (next <= a.second) runs.push_back(SegRun{next, a.second, 0});  // (cannot happen: interval ends are cuts)
+    }
+  }
+  const int R = (int)runs.size(), NV = R + 2;  // node 0 = sink, 1 = source, 2 + r = run r
+  auto node_of = [&](uint32_t x) -> int {
+    if (x == VSINK) return 0;
+    if (x == VSRC) return 1;
+    size_t lo = 0, hi = runs.size();
+    while (lo < hi) { const size_t mid = (lo + hi) >> 1; if (runs[mid].lo <= x) lo = mid + 1; else hi = mid; }
+    return 2 + (int)(lo - 1);
+  };
+  // ---- edges between nodes, one per distinct edge of the reference's graph; edges inside a run are counted
+  internal.assign((size_t)NV, 0);
+  cyc.assign((size_t)NV, 0);
+  uint64_t e_all = 0;
+  for (int r = 0; r < R; r++) {
+    const uint32_t L = runs[(size_t)r].hi - runs[(size_t)r].lo + 1u;
+    if (L > 1u) {
+      const bool u = in_intervals(uiv, runs[(size_t)r].lo), d = in_intervals(div, runs[(size_t)r].lo);
+      internal[(size_t)(2 + r)] = (int)((u ? L - 1u : 0u) + (d ? L - 1u : 0u));
+      cyc[(size_t)(2 + r)] = u && d;  // covered in both directions: its k-mers are one strong component
+      e_all += (uint64_t)internal[(size_t)(2 + r)];
+    }
+    if (r + 1 < R && runs[(size_t)r].hi + 1u == runs[(size_t)r + 1].lo) {  // the chain edge(s) into the next run
+      const uint32_t x = runs[(size_t)r].hi;
+      if (in_intervals(uiv, x)) ce.emplace_back(2 + r, 2 + r + 1);
+      if (in_intervals(div, x)) ce.emplace_back(2 + r + 1, 2 + r);
+    }
+  }
+  for (uint64_t e : sp) {
+    const uint32_t a = (uint32_t)(e >> 32), b = (uint32_t)e;
+    if (a == b) { loops.push_back(node_of(a)); continue; }  // self loop (a homopolymer k-mer): never between components
+    ce.emplace_back(node_of(a), node_of(b));
+  }
+  e_all += (uint64_t)ce.size() + (uint64_t)loops.size();
+  // ---- strong components of the node graph
+  off.assign((size_t)NV + 1, 0);
+  adj.resize(ce.size());
+  for (auto& ed : ce) off[(size_t)ed.first + 1]++;
+  for (int i = 0; i < NV; i++) off[(size_t)i + 1] += off[(size_t)i];
+  {
+    std::vector<int> pos(off.begin(), off.end() - 1);
+    for (auto& ed : ce) adj[(size_t)pos[(size_t)ed.first]++] = ed.second;
+  }
+  const int nc = strong_components(NV, off, adj, &comp);
+  cnodes.assign((size_t)nc, 0);
+  cweight.assign((size_t)nc, 0);
+  nontriv.assign((size_t)nc, 0);
+  for (int x = 0; x < NV; x++) {
+    const int c = comp[(size_t)x];
+    cnodes[(size_t)c]++;
+    cweight[(size_t)c] += x < 2 ? 1 : (int)(runs[(size_t)(x - 2)].hi - runs[(size_t)(x - 2)].lo + 1u);
+    if (cyc[(size_t)x]) nontriv[(size_t)c] = 1;
+  }
+  int nontrivial = 0;
+  uint64_t size_nontrivial = 0;
+  for (int c = 0; c < nc; c++) {
+    if (cnodes[(size_t)c] > 1) nontriv[(size_t)c] = 1;  // (a cycle through a chain takes all of the chain)
+    if (nontriv[(size_t)c]) { nontrivial++; size_nontrivial += (uint64_t)cweight[(size_t)c]; }
+  }
+  uint64_t loops_trivial = 0;
+  for (int x : loops) if (!nontriv[(size_t)comp[(size_t)x]]) loops_trivial++;  // :1385-1402
+  // ---- the contracted multigraph: one edge per edge between components (:1342-1378)
+  din.assign((size_t)nc, 0);
+  dout.assign((size_t)nc, 0);
+  uint64_t fe = 0;
+  for (int x = 2; x < NV; x++) if (!nontriv[(size_t)comp[(size_t)x]]) fe += (uint64_t)internal[(size_t)x];
+  foff.assign((size_t)nc + 1, 0);
+  for (auto& ed : ce) {
+    const int a = comp[(size_t)ed.first], b = comp[(size_t)ed.second];
+    if (a == b) continue;
+    fe++;
+    dout[(size_t)a]++;
+    din[(size_t)b]++;
+    foff[(size_t)a + 1]++;
+  }
+  out->sub[0] = V;
+  out->sub[1] = e_all - loops_trivial;
+  out->sub[2] = (uint64_t)nontrivial;
+  out->sub[3] = size_nontrivial;
+  out->sub[4] = V + (uint64_t)nontrivial - size_nontrivial;
+  out->sub[5] = fe;
+  // ---- topological order of the components (Kahn), then the branch rule (:1420-1434).  A run outside the
+  // components of several vertices is a row of vertices with one edge in and one out each: the count is the
+  // same in front of every one of them.
+  for (int c = 0; c < nc; c++) foff[(size_t)c + 1] += foff[(size_t)c];
+  fadj.resize(foff[(size_t)nc]);
+  {
+    std::vector<int> pos(foff.begin(), foff.end() - 1);
+    for (auto& ed : ce) {
+      const int a = comp[(size_t)ed.first], b = comp[(size_t)ed.second];
+      if (a != b) fadj[(size_t)pos[(size_t)a]++] = b;
+    }
+  }
+  indeg = din;
+  order.clear();
+  for (int c = 0; c < nc; c++) if (indeg[(size_t)c] == 0) order.push_back(c);
+  for (size_t qi = 0; qi < order.size(); qi++) {
+    const int u = order[qi];
+    for (int x = foff[(size_t)u]; x < foff[(size_t)u + 1]; x++)
+      if (--indeg[(size_t)fadj[(size_t)x]] == 0) order.push_back(fadj[(size_t)x]);
+  }
+  fbranch.assign((size_t)nc, 0);
+  int bc = 1;
+  for (int u : order) {
+    if (din[(size_t)u] >= 1 || dout[(size_t)u] >= 1) {
+      if (din[(size_t)u] > 1) bc -= din[(size_t)u] - 1;
+      fbranch[(size_t)u] = bc;
+      if (dout[(size_t)u] > 1) bc += dout[(size_t)u] - 1;
+    }
+  }
+  for (int r = 0; r < R; r++) {
+    const int c = comp[(size_t)(2 + r)];
+    runs[(size_t)r].safe = !nontriv[(size_t)c] && fbranch[(size_t)c] == 1;
+  }
+  out->sink_safe = !nontriv[(size_t)comp[0]] && fbranch[(size_t)comp[0]] == 1;
+  out->run_mode = true;
 }
 
 }  // namespace
@@ -671,7 +916,12 @@ bool seg_analyze(const FillParams& p, const GapJob& job, const SubView& v, SubPr
   for (size_t x = 1; x < niv; x++) {
     const SegRec& a = sg[iv[x - 1].second];
     const uint32_t a_hi = iv[x - 1].first + (uint32_t)seg_ts(a);
-    if (iv[x].first <= a_hi) { out->seg_mode = false; return false; }  // a k-mer at two depths: general path
+    if (iv[x].first <= a_hi) {  // a k-mer at two depths: the vertices are k-mers, not states
+      static const bool state_d2 = getenv("G2S_STATE_D2") != nullptr;  // (tests: the per-state analysis instead)
+      if (state_d2) { out->seg_mode = false; return false; }
+      seg_analyze_runs(p, v, out, sinkpos);
+      return true;
+    }
   }
   if (p.all_paths) out->count = count_s;
   out->sub[0] = n_s + 2; out->sub[1] = edges; out->sub[2] = 0; out->sub[3] = 0; out->sub[4] = n_s + 2; out->sub[5] = edges;
@@ -731,6 +981,16 @@ void seg_traceback(const Graph& g, const FillParams& p, const GapJob& job, const
         int lo_run;  // the run is [lo_run, pos]
         bool sf;
         if (p.skip_confident) { lo_run = 1; sf = true; }
+        else if (prep.run_mode) {  // the states whose k-mers lie in the run of this one share its verdict
+          const uint32_t idx0 = s.node >> 1;
+          const uint32_t x = (s.node & 1u) ? idx0 - (uint32_t)pos : idx0 + (uint32_t)pos;
+          const SegRun* r = run_of(prep, x);
+          if (!r) { lo_run = pos; sf = prep.sink_safe; }
+          else {
+            sf = r->safe != 0;
+            lo_run = (s.node & 1u) ? std::max(1, (int)idx0 - (int)r->hi) : std::max(1, (int)r->lo - (int)idx0);
+          }
+        }
         else if (pos > ts) { lo_run = pos; sf = seg_safe(v, prep, (uint32_t)i, pos); }  // outside the subgraph (Q5): state by state
         else if (pos > split) { lo_run = std::max(1, split + 1); sf = sfb; }
         else { lo_run = 1; sf = sfa; }

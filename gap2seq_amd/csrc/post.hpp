@@ -99,6 +99,13 @@ struct SegInfo {
   uint8_t npar;
 };
 
+// A stretch of consecutive k-mer indices of the S closure whose vertices share the verdict of the branch rule
+// (seg_analyze on closures in which a k-mer occurs at several depths): sorted by first index, disjoint.
+struct SegRun {
+  uint32_t lo, hi;
+  uint8_t safe;
+};
+
 struct SubPrep {
   bool seg_mode = false;  // analysed on the closure SEGMENTS (seg_analyze); st / safe are not used then
   SegInfo* seg = nullptr;                                // per closure segment
@@ -106,6 +113,10 @@ struct SubPrep {
   uint32_t n_iv = 0;
   std::vector<uint64_t> own_seg;                         // backing store of the two when the caller gives no scratch
   bool sink_safe = false, has_choice = false;
+  // a k-mer at several depths of the closure: the vertices of :1314-1435 are k-mers, not states, and the safe
+  // bit of a state is that of its k-mer's run (run_mode; seg[].split / safe_a / safe_b are unused then)
+  bool run_mode = false;
+  std::vector<SegRun> runs;
   // closures analysed on the device whose draw count depends on the draws: (lowest, highest) stop depth
   // behind every segment's entry (seg_stop_depths), so that the draw-count walk ends where the two meet
   const int32_t* stop = nullptr;
@@ -127,11 +138,15 @@ void sub_analyze(const FillParams& p, const GapJob& job, const SubView& v, SubPr
 inline int sub_fixed_draws(const SubView& v, const SubPrep& prep, int pick) {
   return prep.stop_depth[pick] < 0 ? -1 : 1 + (v.out->len[pick] - prep.stop_depth[pick]);
 }
-// The same analysis on the closure SEGMENTS of the segment tier, in O(segments): applies when no
-// k-mer occurs at two depths of the S closure (then the subgraph is a DAG whose vertices are the
-// states: nothing to contract, :1314-1435 reduces to the branch rule, which is constant along a
-// segment).  Returns false otherwise: the caller expands the segments (seg_expand) and takes
-// sub_analyze.  seg_traceback / seg_count_draws are sub_traceback / sub_count_draws on segments.
+// The same analysis on the closure SEGMENTS of the segment tier.  When no k-mer occurs at two depths of the S
+// closure the subgraph is a DAG whose vertices are the states: nothing to contract, :1314-1435 reduces to the
+// branch rule, which is constant along a segment: O(segments).  Otherwise the vertices are k-mers: the closure's
+// index intervals are cut at every segment end and every edge that is not unitig-internal, which leaves RUNS of
+// k-mers that are chains; strong components, contraction and the branch rule then work on runs, not on states
+// (a deep gap of config 5: ~10 k runs for ~150 k states).  Always returns true (the closure has been analysed);
+// G2S_STATE_D2=1 makes it return false where a k-mer repeats, and the caller then expands the segments
+// (seg_expand) and takes sub_analyze.  seg_traceback / seg_count_draws are sub_traceback / sub_count_draws on
+// segments.
 // `scratch`: 24 bytes per segment, 8-byte aligned, alive as long as *out is used (nullptr: *out allocates).
 bool seg_analyze(const FillParams& p, const GapJob& job, const SubView& v, SubPrep* out, void* scratch = nullptr);
 void seg_traceback(const Graph& g, const FillParams& p, const GapJob& job, const SubView& v, const SubPrep& prep,

@@ -402,7 +402,7 @@ def test_multi_rank_bench_path(product, tmp_path):
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["value"] > 0
     assert out["equals_one_gpu_result"] is True and out["one_gpu_same_list"]["value"] > 0
     assert out["config"]["gaps"] == 600 and out["config"]["group"] == 300
-    assert out["cpu_baseline"] is None and out["roofline"]["kernel"] == "g2s_fill_seg"
+    assert out["cpu_baseline"] is None and out["roofline"]["kernel"] == "g2s_fill_seg2"  # (groups of 300: two waves per gap)
     assert out["roofline"]["launches_per_step"] == 2.0
 
 

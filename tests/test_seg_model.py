@@ -115,6 +115,21 @@ def test_model_k31_default_parameters(product, oracle, variant):
     assert STATS["on_segments"][0] - before >= 36  # nearly every closure has each k-mer at one depth only
 
 
+def test_model_repeated_kmers_are_analysed_on_runs(product, oracle):
+    """Closures in which a k-mer occurs at several depths (tandem repeats, bubbles of unequal length): the
+    host analyses them on runs of k-mers (post.cpp: seg_analyze_runs).  check_config compares fill, flags,
+    draws and the subgraph statistics of that analysis with the per-state one for every closure; here nearly
+    every gap's closure stays on segments (with the run analysis switched off, G2S_STATE_D2=1, a third of
+    this set falls back to per-state records)."""
+    k = 11
+    seqs = cases.toy_genome(21, 3000, k, repeats=4, tandem=6, snp_every=97)
+    gaps = cases.cut_gaps(10, seqs[0], k, fuz=7, ngaps=40, min_len=1, max_len=80, d_err=30)
+    before = STATS.setdefault("on_segments", [0])[0]
+    c, q = check_config(product, oracle, seqs, k, gaps, 30)
+    assert c + q == 40
+    assert STATS["on_segments"][0] - before >= 25
+
+
 def test_model_tandem_flanks_and_fuz_extremes(product, oracle):
     """Q6 territory (seed states reached by the DP as well) and fuz 0 / large fuz."""
     k = 11
