@@ -1051,10 +1051,10 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
   progress_note("launched: %zu gaps, lds %d seg %d scale %llu", ids.size(), (int)lds, seg, (unsigned long long)scale);
   if (lds) {
    if (seg && on_done) {
-    // Segment tier: the analysis of a gap costs about a microsecond (it runs on the closure
-    // segments), so two hand-overs are enough: the gaps that have arrived by the time half of the
-    // list is done (their analysis runs under the rest of the kernel), then the others.  Each
-    // hand-over wakes the pool once; only this thread polls, napping between looks.
+    // Segment tier: the analysis of a gap costs a fraction of a microsecond (it runs on the closure
+    // segments, or only copies what the device found).  Short lists: whatever has arrived is analysed
+    // at once on this thread.  Long lists: a hand-over to the pool for every eighth of the list, so that
+    // an eighth at most is left when the kernel ends.  Only this thread polls, napping between looks.
     const volatile uint32_t* done = (const volatile uint32_t*)td->done.p;
     const size_t total = ids.size();
     size_t seen = 0, given = 0;
@@ -1068,8 +1068,8 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
       // short lists: whatever has arrived is analysed at once on this thread (a gap whose phase D2 ran on
       // the device costs a fraction of a microsecond here), so that only the last gaps are left
       // when the kernel ends; long lists: two hand-overs to the pool
-      if ((total <= 2048 && seen > given) ||
-          (given == 0 && total >= 128 && seen * 2 >= total && seen < total) || seen == total || (finished && seen > given)) {
+      if ((total <= 2048 && seen > given) || (total > 2048 && seen - given >= std::max<size_t>(1024, total / 8)) ||
+          seen == total || (finished && seen > given)) {
         (*on_done)((const uint32_t*)td->done.p + given, seen - given);
         given = seen;
       } else if (finished) {
@@ -1474,8 +1474,20 @@ int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
     for (int mode = getenv("G2S_FORCE_SEGX") ? 2 : 1; mode <= 2 && !seg_ids.empty(); mode++) {
       if (mode == 2 && getenv("G2S_NO_SEGX_TIER")) break;
       // longest searches first (see below): always for the large variant, whose workgroups take the list in order
-      if ((seg_ids.size() > 1024 || mode == 2) && !getenv("G2S_NO_LPT"))
-        std::stable_sort(seg_ids.begin(), seg_ids.end(), [&](uint32_t a, uint32_t c) { return b->jobs[a].g > b->jobs[c].g; });
+      if ((seg_ids.size() > 1024 || mode == 2) && !getenv("G2S_NO_LPT")) {
+        // (a stable counting sort by gap length, longest first: a comparison sort of 10 000 ids cost 0.3 ms)
+        int gmax = 0;
+        for (uint32_t i : seg_ids) gmax = std::max(gmax, b->jobs[i].g);
+        if ((size_t)gmax <= 8 * seg_ids.size() + 65536) {
+          std::vector<uint32_t> at((size_t)gmax + 2, 0), sorted(seg_ids.size());
+          for (uint32_t i : seg_ids) at[(size_t)(gmax - b->jobs[i].g) + 1]++;
+          for (size_t x = 1; x < at.size(); x++) at[x] += at[x - 1];
+          for (uint32_t i : seg_ids) sorted[at[(size_t)(gmax - b->jobs[i].g)]++] = i;
+          seg_ids.swap(sorted);
+        } else {
+          std::stable_sort(seg_ids.begin(), seg_ids.end(), [&](uint32_t a, uint32_t c) { return b->jobs[a].g > b->jobs[c].g; });
+        }
+      }
       TierData* td = take_tier(s, b->tiers.size());
       b->tiers.push_back(td);
       td_live = td;
