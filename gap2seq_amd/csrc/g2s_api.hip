@@ -1810,8 +1810,29 @@ int batches_stage2(const std::vector<g2s_batch*>& bs, g2s_session* lead, g2s_res
     if (jobs_in_flight) { lead->pool->finish(); jobs_in_flight = false; }
     lead->rcache.ensure(upto + (1u << 16));
   };
+  std::vector<uint32_t> walk_ids;  // gaps of the current segment whose draw count needs a walk
   auto in_order_pass = [&](size_t g_lo, size_t g_hi) {
     auto t0 = std::chrono::steady_clock::now();
+    // The walks are the serial part of a run (one depends on the other through the stream offset), and the
+    // closure records they chase were written by the GPU: nobody on the host has read them yet.  The records
+    // of the gaps a few walks ahead are fetched while the current walk runs.
+    walk_ids.clear();
+    for (size_t gi = g_lo; gi < g_hi; gi++) {
+      const g2s_batch::GapInfo& in = owner[gi]->info[local[gi]];
+      if (in.kind == 0 && in.n_len > 0 && (in.fixed[0] < 0 || (in.n_len > 1 && in.fixed[1] < 0))) walk_ids.push_back((uint32_t)(gi - g_lo));
+    }
+    size_t walk_next = 0;
+    auto fetch_ahead = [&](size_t gi) {
+      while (walk_next < walk_ids.size() && g_lo + walk_ids[walk_next] <= gi) walk_next++;
+      const size_t k = walk_next + 5;
+      if (k >= walk_ids.size()) return;
+      const size_t gj = g_lo + walk_ids[k];
+      const SubView& pv = owner[gj]->views[local[gj]];
+      if (!pv.segs) return;
+      const char* p0 = (const char*)pv.segs;
+      const size_t bytes = std::min<size_t>((size_t)pv.n_segs * sizeof(SegRec), 4096);
+      for (size_t o = 0; o < bytes; o += 64) __builtin_prefetch(p0 + o);
+    };
     for (size_t gi = g_lo; gi < g_hi; gi++) {
       g2s_batch* b = owner[gi];
       const size_t i = local[gi];
@@ -1852,8 +1873,13 @@ int batches_stage2(const std::vector<g2s_batch*>& bs, g2s_session* lead, g2s_res
           // the fill itself is written by the pool with the others
           n_inline++;
           const auto tw0 = std::chrono::steady_clock::now();
+          fetch_ahead(gi);
           const SubView& v = b->views[i];
           grow_rands(draws_total + (size_t)v.out->len[pick] + 2);
+          {  // the values this walk will draw were written by other threads a moment ago: all their lines at once
+            const char* r0 = (const char*)lead->rcache.ptr(draws_total);
+            for (size_t o = 0; o < ((size_t)v.out->len[pick] + 2) * 4; o += 64) __builtin_prefetch(r0 + o);
+          }
           draws = b->prep[i].seg_mode ? seg_count_draws(g, v, b->prep[i], lead->rcache.ptr(draws_total))
                                       : sub_count_draws(g, v, b->prep[i], lead->rcache.ptr(draws_total));
           ms_walks += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count();
