@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../include/g2s.h"
+#include "fastx.hpp"
 
 static bool readable(const std::string& path) {
   FILE* f = fopen(path.c_str(), "rb");
@@ -30,6 +31,7 @@ int main(int argc, char** argv) {
   memset(&p, 0, sizeof p);
   p.d_err = 500; p.all_paths = 1;
   int randseed = 0, device = 0, streams = 2, stream_gaps = 8192;
+  static int fasta_width = 0;  // (static: read by the output callback)
   std::string devices;  // "0,1,2": GPUs sharing the gap list (the graph is replicated)
   std::string reads, scaffolds, filled, left, right;
   int length = 0;
@@ -61,11 +63,12 @@ int main(int argc, char** argv) {
     else if (a == "-devices") devices = val();
     else if (a == "-streams") streams = atoi(val());
     else if (a == "-stream-gaps") stream_gaps = atoi(val());
+    else if (a == "-fasta-width") fasta_width = atoi(val());
     else if (a == "-help" || a == "-h") {
       std::cout << "Gap2Seq-core (MI355X) -reads a.fq[,b.fq] -filled out.fa (-scaffolds in.fa | -left S -right S -length N)\n"
                    "  [-k 31] [-solid 2] [-dist-error 500] [-fuz 10] [-max-mem 20] [-randseed 0]\n"
                    "  [-all-upper] [-best-only] [-unique] [-nb-cores N] [-device D | -devices D0,D1,...] [-streams 2]\n"
-                   "  [-stream-gaps 8192]\n";
+                   "  [-stream-gaps 8192] [-fasta-width 0]\n";
       return EXIT_SUCCESS;
     }
     else {  // GATB's OptionsParser rejects what it does not know; main.cpp:29-31 prints the message
@@ -158,7 +161,10 @@ int main(int argc, char** argv) {
     if (!out) { std::cout << "EXCEPTION: cannot write " << filled << std::endl; return EXIT_FAILURE; }
     rc = g2s_execute_scaffolds_stream(
         s, &o, reads.c_str(), filled.c_str(), text.c_str(), (size_t)std::max(0, stream_gaps),
-        [](const char* t, size_t n, void* u) { fwrite(t, 1, n, (FILE*)u); },
+        [](const char* t, size_t n, void* u) {
+          const std::string w = g2s::wrap_fasta(t, n, fasta_width);
+          fwrite(w.data(), 1, w.size(), (FILE*)u);
+        },
         [](const char* t, size_t n, void*) { fwrite(t, 1, n, stdout); fflush(stdout); }, out, &gaps, &nfilled);
     fclose(out);
     if (rc != G2S_OK) {
@@ -177,7 +183,10 @@ int main(int argc, char** argv) {
   std::cout << log;
   FILE* out = fopen(filled.c_str(), "wb");
   if (!out) { std::cout << "EXCEPTION: cannot write " << filled << std::endl; return EXIT_FAILURE; }
-  fputs(fasta, out);
+  {
+    const std::string w = g2s::wrap_fasta(fasta, strlen(fasta), fasta_width);
+    fwrite(w.data(), 1, w.size(), out);
+  }
   fclose(out);
   g2s_free(fasta);
   g2s_free(log);

@@ -5,6 +5,7 @@
 // kept, the comment is the header line without '>', output is one line per
 // sequence.
 #pragma once
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -23,6 +24,32 @@ inline void append_fasta(std::string* out, const std::string& comment, const std
   out->push_back('\n');
   out->append(seq);
   out->push_back('\n');
+}
+
+// FASTA text whose records are ">comment\nSEQ\n" -> the same records with SEQ broken into lines of `width`
+// characters (width <= 0: unchanged).  GATB's BankFasta, which the reference writes its output through
+// (Gap2Seq.cpp:224,426-431), is recalled to break data lines at 70 columns unless told otherwise; that cannot
+// be checked here (gatb-core is not part of the reference tree), so the command lines keep one line per
+// record by default and offer -fasta-width 70.  Every FASTA reader of the pipeline accepts both.
+inline std::string wrap_fasta(const char* text, size_t n, int width) {
+  if (width <= 0) return std::string(text, n);
+  std::string out;
+  out.reserve(n + n / (size_t)width + 16);
+  size_t i = 0;
+  while (i < n) {
+    size_t e = i;
+    while (e < n && text[e] != '\n') e++;
+    if (text[i] == '>') out.append(text + i, e - i);
+    else {
+      for (size_t p = i; p < e; p += (size_t)width) {
+        if (p > i) out.push_back('\n');
+        out.append(text + p, std::min<size_t>((size_t)width, e - p));
+      }
+    }
+    out.push_back('\n');
+    i = e + 1;
+  }
+  return out;
 }
 
 }  // namespace g2s

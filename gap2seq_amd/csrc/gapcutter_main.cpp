@@ -9,6 +9,7 @@
 #include <string>
 
 #include "../../include/g2s.h"
+#include "fastx.hpp"
 
 static bool slurp(const std::string& path, std::string* out) {
   FILE* f = fopen(path.c_str(), "rb");
@@ -19,16 +20,21 @@ static bool slurp(const std::string& path, std::string* out) {
   fclose(f);
   return true;
 }
-static bool spill(const std::string& path, const char* text) {
+static bool spill(const std::string& path, const char* text, int fasta_width = 0) {
   FILE* f = fopen(path.c_str(), "wb");
   if (!f) return false;
-  fputs(text, f);
+  if (fasta_width > 0) {  // (see fastx.hpp: GATB's BankFasta is recalled to break data lines at 70 columns)
+    const std::string w = g2s::wrap_fasta(text, strlen(text), fasta_width);
+    fwrite(w.data(), 1, w.size(), f);
+  } else {
+    fputs(text, f);
+  }
   fclose(f);
   return true;
 }
 
 int main(int argc, char** argv) {
-  int k = 31, fuz = 10, mask = 0, no_split = 0;
+  int k = 31, fuz = 10, mask = 0, no_split = 0, fasta_width = 0;
   std::string scaffolds, contigs, gaps, bed;
   for (int i = 1; i < argc; i++) {
     const std::string a = argv[i];
@@ -41,6 +47,7 @@ int main(int argc, char** argv) {
     else if (a == "-bed") bed = val();
     else if (a == "-mask") mask = 1;
     else if (a == "-no-split") no_split = 1;
+    else if (a == "-fasta-width") fasta_width = atoi(val());
     else if (a == "-nb-cores" || a == "-verbose") (void)val();
     else { std::cout << "EXCEPTION: Unknown parameter '" << a << "'" << std::endl; return EXIT_FAILURE; }
   }
@@ -57,7 +64,7 @@ int main(int argc, char** argv) {
     return EXIT_FAILURE;
   }
   std::cout << log;
-  const bool ok = spill(contigs, c) && spill(gaps, g) && spill(bed, b);
+  const bool ok = spill(contigs, c, fasta_width) && spill(gaps, g, fasta_width) && spill(bed, b);
   g2s_free(c); g2s_free(g); g2s_free(b); g2s_free(log);
   if (!ok) { std::cout << "EXCEPTION: cannot write the output files" << std::endl; return EXIT_FAILURE; }
   return EXIT_SUCCESS;

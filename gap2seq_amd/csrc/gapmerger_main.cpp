@@ -3,10 +3,12 @@
 // GapMerger -scaffolds OUT -gaps FILLED -contigs C).  The work is g2s_merge_scaffolds (gapio.cpp).
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <iostream>
 #include <string>
 
 #include "../../include/g2s.h"
+#include "fastx.hpp"
 
 static bool slurp(const std::string& path, std::string* out) {
   FILE* f = fopen(path.c_str(), "rb");
@@ -20,12 +22,14 @@ static bool slurp(const std::string& path, std::string* out) {
 
 int main(int argc, char** argv) {
   std::string scaffolds, contigs, gaps;
+  int fasta_width = 0;
   for (int i = 1; i < argc; i++) {
     const std::string a = argv[i];
     auto val = [&]() -> const char* { return (i + 1 < argc) ? argv[++i] : ""; };
     if (a == "-scaffolds") scaffolds = val();
     else if (a == "-contigs") contigs = val();
     else if (a == "-gaps") gaps = val();
+    else if (a == "-fasta-width") fasta_width = atoi(val());
     else if (a == "-nb-cores" || a == "-verbose") (void)val();
     else { std::cout << "EXCEPTION: Unknown parameter '" << a << "'" << std::endl; return EXIT_FAILURE; }
   }
@@ -44,7 +48,10 @@ int main(int argc, char** argv) {
   std::cout << log;
   FILE* f = fopen(scaffolds.c_str(), "wb");
   if (!f) { std::cout << "EXCEPTION: cannot write " << scaffolds << std::endl; return EXIT_FAILURE; }
-  fputs(out, f);
+  {
+    const std::string w = g2s::wrap_fasta(out, strlen(out), fasta_width);  // (see fastx.hpp)
+    fwrite(w.data(), 1, w.size(), f);
+  }
   fclose(f);
   g2s_free(out); g2s_free(log);
   return EXIT_SUCCESS;

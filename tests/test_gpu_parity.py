@@ -706,6 +706,28 @@ def test_cli_binary_is_a_drop_in(product, oracle, tmp_path):
     assert res.returncode == 0, res.stdout + res.stderr
     assert out.read_text() == outs["cpu"][0]
     assert res.stdout.replace(str(out), "OUT") == outs["cpu"][1]
+    # -fasta-width 70 (GATB's BankFasta line length, as recalled) and small batches (-stream-gaps): the same
+    # records, data lines of at most 70 characters; the log is the same text
+    out = tmp_path / "out_wrapped.fa"
+    res = subprocess.run([os.path.join(ROOT, "gap2seq_amd", "Gap2Seq-core"), "-k", str(k), "-fuz", "10", "-solid", "1",
+                          "-nb-cores", "1", "-dist-error", "100", "-max-mem", "20", "-randseed", "4", "-reads", str(reads),
+                          "-filled", str(out), "-scaffolds", str(scaf), "-fasta-width", "70", "-stream-gaps", "6"],
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert res.stdout.replace(str(out), "OUT") == outs["cpu"][1]
+    wrapped = out.read_text()
+    assert all(len(ln) <= 70 for ln in wrapped.splitlines() if not ln.startswith(">"))
+    unwrapped, cur = [], []
+    for ln in wrapped.splitlines():
+        if ln.startswith(">"):
+            if cur:
+                unwrapped.append("".join(cur))
+            unwrapped.append(ln)
+            cur = []
+        else:
+            cur.append(ln)
+    unwrapped.append("".join(cur))
+    assert "\n".join(unwrapped) + "\n" == outs["cpu"][0]
 
 
 def _fuzz_regressions():
