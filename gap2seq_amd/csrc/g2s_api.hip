@@ -1381,6 +1381,8 @@ int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
   }
   lap("per-gap arrays");
   TierData* td_live = nullptr;
+  int seg_mode_live = 0;               // 1 / 2 while a launch of the segment tier (its large variant) is polled
+  std::vector<char> seg_accounted(n, 0);  // 1: counted by on_done, 2: counted, over the -max-mem analogue
   std::vector<uint32_t> heavy_wait, heavy_job;
   std::function<void(size_t)> heavy_fn = [&](size_t t) { analyze_gap(b, heavy_job[t], fp, &results[heavy_job[t]]); };
   auto post_heavy = [&]() {  // the pool is free: what has piled up becomes its next job (largest closures first)
@@ -1422,6 +1424,17 @@ int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
       }
       analyzed[i] = 1;
       fresh.push_back(i);
+      if (seg_mode_live) {  // the launch's bookkeeping while the gap's record is in this core's cache
+        const bool mx = (uint64_t)go.n_states > max_states || (uint64_t)go.n_right > max_states;
+        seg_accounted[i] = mx ? 2 : 1;
+        if (!mx) {
+          b->timing.xA += go.x_right; b->timing.sA += go.n_right;
+          b->timing.xB += go.x_left; b->timing.sB += go.n_states;
+          b->timing.xD += go.x_sub; b->timing.sD += go.n_sub;
+          if (seg_mode_live == 2) b->timing.segx_tier_gaps++; else b->timing.seg_tier_gaps++;
+          b->timing.seg_segments += go.stat[3];
+        }
+      }
     }
     // Closures of many thousand states that the host has to analyse (the large variant's gaps, a k-mer at two
     // depths: milliseconds each) go to the pool WITHOUT waiting for them: this thread keeps polling, and
@@ -1499,13 +1512,21 @@ int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
         td->exp_cursor.store(0);
       }
       lap("segment pass set-up");
+      seg_mode_live = mode;
       int rc = run_tier(b, seg_ids, 1, max_states, td, true, 0, false, 64u, analyze ? &on_done : nullptr, mode);
+      seg_mode_live = 0;
       flush_heavy();
       if (rc != G2S_OK) return rc;
       lap("segment pass run_tier");
       const GapOut* outs = (const GapOut*)td->outs.p;
       std::vector<uint32_t> left;
       for (uint32_t i : seg_ids) {
+        if (seg_accounted[i]) {  // (on_done saw the gap done and did the sums: its record is not read again here)
+          seg_done[i] = 1;
+          if (seg_accounted[i] == 2) mem_exceeded[i] = 1;
+          seg_accounted[i] = 0;
+          continue;
+        }
         const GapOut& go = outs[i];
         if (go.flags & (G2S_DEV_OVERFLOW_A | G2S_DEV_OVERFLOW_B)) {
           if (getenv("G2S_DEBUG"))
