@@ -109,3 +109,28 @@ def test_command_lines_take_the_wrappers_argv(product, tmp_path):
     assert res.stdout.endswith("Merged %d contigs and %d gaps into %d scaffolds\n" % (counts[1], counts[2], counts[0]))
     bad = subprocess.run([cutter, "-k", "9", "-bogus"], capture_output=True, text=True, timeout=60)
     assert bad.returncode != 0 and "EXCEPTION" in bad.stdout
+
+
+def test_fasta_width_breaks_data_lines_and_the_pipeline_reads_them_back(product, tmp_path):
+    """-fasta-width 70 (GATB BankFasta's layout, as recalled): GapCutter writes wrapped gap / contig files, GapMerger
+    reads them and writes a wrapped scaffold file; unwrapped, everything equals the one-line-per-record run."""
+    recs = _random_scaffolds(13, 12)
+    scaf = tmp_path / "scaffolds.fa"
+    scaf.write_text(_fasta(recs))
+    cutter = os.path.join(ROOT, "gap2seq_amd", "GapCutter")
+    merger = os.path.join(ROOT, "gap2seq_amd", "GapMerger")
+    outs = {}
+    for width in (0, 70):
+        gaps, contigs, bed, merged = (tmp_path / ("%s.%d" % (n, width)) for n in ("gaps", "contigs", "bed", "merged"))
+        extra = ["-fasta-width", str(width)] if width else []
+        res = subprocess.run([cutter, "-k", "9", "-fuz", "3", "-scaffolds", str(scaf), "-gaps", str(gaps), "-contigs", str(contigs),
+                              "-bed", str(bed)] + extra, capture_output=True, text=True, timeout=120)
+        assert res.returncode == 0, res.stdout + res.stderr
+        res = subprocess.run([merger, "-scaffolds", str(merged), "-gaps", str(gaps), "-contigs", str(contigs)] + extra,
+                             capture_output=True, text=True, timeout=120)
+        assert res.returncode == 0, res.stdout + res.stderr
+        outs[width] = [f.read_text() for f in (gaps, contigs, merged)]
+    for wrapped, plain in zip(outs[70], outs[0]):
+        assert all(len(ln) <= 70 for ln in wrapped.splitlines() if not ln.startswith(">"))
+        assert R.parse_fasta(wrapped) == R.parse_fasta(plain)
+    assert any(len(ln) == 70 for ln in outs[70][2].splitlines())  # (the scaffolds are longer than a line)
