@@ -1036,6 +1036,7 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
       pcur ^= 1u; np = npn; npn = 0;
     }
     while (np > 0 && !overflow) {
+      SEG_PROF_T(0);
       // ---- one round trip for all events created last round: states to the end of the unitig, exit record
       for (uint32_t i0 = 0; i0 < nnew; i0 += 64u) {
         if (i0 + (uint32_t)lane < nnew) {
@@ -1047,6 +1048,8 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
       }
       nnew = 0;
       lds_sync();
+      SEG_PROF_WAIT();
+      SEG_PROF_T(1);
       // ---- the horizon
       const uint32_t* pl = plist + pcur * PE;
       uint32_t hmin = SEG_INF;
@@ -1068,6 +1071,10 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
         npn += (uint32_t)__popcll(km);
       }
       lds_sync();
+      SEG_PROF_T(2);
+#ifdef G2S_SEG_PROFILE
+      unsigned long long prof_children = 0;
+#endif
       for (uint32_t i0 = 0; i0 < nsl && !overflow; i0 += 64u) {
         const bool mine = i0 + (uint32_t)lane < nsl;
         const uint32_t slot = mine ? sell[i0 + (uint32_t)lane] : 0u;
@@ -1135,6 +1142,9 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
         const bool exits = mine && L == es && ed + (int)L - 1 < D;
         const uint32_t xd = (uint32_t)ed + L;  // depth of the children
         // lane = (segment, successor slot): sixteen segments' children per pass, one search and one insertion each
+#ifdef G2S_SEG_PROFILE
+        const unsigned long long prof_c0 = __builtin_amdgcn_s_memtime();
+#endif
         for (uint32_t g0 = 0; g0 < nsel && !overflow; g0 += 16u) {
           const int from = (int)(g0 + ((uint32_t)lane >> 2));
           const uint32_t q = (uint32_t)lane & 3u;
@@ -1150,7 +1160,16 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
           const bool ok = ex && w != G2S_DEV_INVALID && ((int)xdl < gd.prune_from || inset);  // :1050
           ev_insert(ok, w, xdl, cl, parl, slol, shil, false);
         }
+#ifdef G2S_SEG_PROFILE
+        prof_children += __builtin_amdgcn_s_memtime() - prof_c0;
+#endif
       }
+#ifdef G2S_SEG_PROFILE
+      // (sections: records wait | horizon + gather | lengths, hits, segment records | children)
+      prof_t[3] = __builtin_amdgcn_s_memtime() - prof_children;
+      prof_t[4] = prof_t[3] + prof_children;
+      SEG_PROF_ACC();
+#endif
       pcur ^= 1u;
       np = npn;
       npn = 0;

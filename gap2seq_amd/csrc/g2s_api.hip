@@ -941,7 +941,7 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
     // (segment tier: two 16-byte units per closure segment; ~15 segments per gap, at most G2S_SEG_CAP)
     if (seg == 1) out_states = (uint64_t)ids.size() * 128u + 2u * G2S_SEG_CAP;
     // (large variant: closures of a few thousand segments; what does not fit runs in the LDS tier)
-    if (seg == 2) out_states = (uint64_t)ids.size() * 4096u + 2u * G2S_SEGX_CAP;
+    if (seg == 2) out_states = std::min<uint64_t>((uint64_t)ids.size() * 4096u, 8ull << 20) + 2u * G2S_SEGX_CAP;  // (<= 128 MB pinned)
     HIP_TRY(td->subs.ensure(std::max<uint64_t>(out_states * sizeof(SubRec), 16)));
     HIP_TRY(td->done.ensure(std::max<size_t>(ids.size() * 4, 16)));
     memset(td->done.p, 0xFF, ids.size() * 4);
@@ -1507,7 +1507,8 @@ int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
       b->seg_td = td;
       {  // scratch of the per-gap analysis (24 bytes per closure segment; the rare closure with a k-mer at
          // two depths is expanded into per-state records here too): 1 KB per gap, per-gap buffers beyond
-        const size_t want = seg_ids.size() * (mode == 2 ? 8192u : 64u) + 4096u;
+        // (the large variant's closures: a few thousand segments; a gap that finds the buffer used up allocates its own)
+        const size_t want = std::min<size_t>(seg_ids.size() * (mode == 2 ? 2048u : 64u), (size_t)16 << 20) + 4096u;
         if (td->exp.size() < want) td->exp.resize(want);
         td->exp_cursor.store(0);
       }

@@ -12,10 +12,13 @@ import bench  # noqa: E402
 from gap2seq_amd import lib as P  # noqa: E402
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else "C2"
+ngaps_override = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 genome_bp, k, ngaps, min_len, max_len, d_err, _ = bench.CONFIGS[cfg]
 reads = P.G2S.synth_genome(genome_bp, 3, 20240101)
 seqs = [ln for ln in reads.splitlines() if not ln.startswith(">")]
 gaps = bench.parse_gaps(P.G2S.synth_gaps(reads, k, 10, ngaps, min_len, max_len, 20240103), 10)
+if ngaps_override:
+    gaps = gaps[:ngaps_override]
 dump = tempfile.mktemp()
 os.environ["G2S_SEG_DUMP"] = dump
 pg = P.Graph.from_seqs(seqs, k, 1)
