@@ -316,33 +316,6 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
           xa += wave_sum(have ? min(steps + 1u, (uint32_t)gd.right_half - al[s]) : 0u);
         }
       }
-      // Q7 in the right set, conservatively as in the LDS tier: both strands of some k-mer are in
-      // it = an entry of each orientation with overlapping intervals
-      if (!overflow) {
-        bool both = false;
-        {
-          uint64_t odd = 0, even = 0;
-#pragma unroll
-          for (int s = 0; s < G2S_SEG_ASETS; s++) {
-            const bool have = (uint32_t)s * 64u + (uint32_t)lane < nA;
-            odd |= __ballot(have && (an[s] & 1u));
-            even |= __ballot(have && !(an[s] & 1u));
-          }
-          both = odd != 0 && even != 0;
-        }
-        if (both) {
-          for (uint32_t e = 0; e < nA && !(flags & G2S_DEV_Q7_A); e++) {
-            uint32_t lo_e = 0, hi_e = 0, or_e = 0;
-#pragma unroll
-            for (int s = 0; s < G2S_SEG_ASETS; s++)
-              if ((e >> 6) == (uint32_t)s) { lo_e = rl(alo[s], (int)(e & 63u)); hi_e = rl(ahi[s], (int)(e & 63u)); or_e = rl(an[s], (int)(e & 63u)) & 1u; }
-#pragma unroll
-            for (int s = 0; s < G2S_SEG_ASETS; s++)
-              if ((uint32_t)s * 64u < nA && __ballot(alo[s] <= hi_e && lo_e <= ahi[s] && ((an[s] & 1u) != or_e) && alo[s] <= ahi[s]))
-                flags |= G2S_DEV_Q7_A;
-          }
-        }
-      }
     }
   };
   unsigned long long cyc_a_end = cyc0;
@@ -490,6 +463,47 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
 #pragma unroll
       for (uint32_t c = 0; c < ALAB / 64u; c++)
         if (keep_at[c] != G2S_DEV_INVALID) { cnode[keep_at[c]] = keep_n[c]; clab[keep_at[c]] = keep_l[c]; crem[keep_at[c]] = keep_r[c]; }
+      lds_sync();
+    }
+    // Q7 in the right set, conservatively as in the LDS tier: both strands of some k-mer are in it = an entry of
+    // each orientation with overlapping intervals.  Every lane keeps its (up to four) entries in registers and
+    // all lanes walk the list of intervals together (uniform LDS reads): a loop over the entries with a
+    // broadcast per entry from registers cost 350 cycles per entry, up to 50 k cycles of a 450 k-cycle gap.
+    if (!overflow && nA > 1u) {
+      const uint32_t* cnode = aq0;
+      const uint32_t* clab = aq0 + ACAP;
+      const uint32_t* crem = (const uint32_t*)lab;
+      uint64_t* ivl = (uint64_t*)(aq0 + 2u * ACAP);  // (the table-position queues are idle): first | (last | orientation << 31) << 32
+      uint32_t mlo[G2S_SEG_ASETS], mhi[G2S_SEG_ASETS];
+      uint64_t odd = 0, even = 0;
+#pragma unroll
+      for (int q = 0; q < G2S_SEG_ASETS; q++) {
+        const uint32_t e = (uint32_t)q * 64u + (uint32_t)lane;
+        mlo[q] = 0xFFFFFFFFu; mhi[q] = 0u;  // (no entry: starts behind every interval)
+        if (e < nA) {
+          const uint32_t v = cnode[e];
+          const uint32_t steps = min(crem[e], (uint32_t)gd.right_half - clab[e]);
+          const uint32_t w0 = v ^ 1u, idx = w0 >> 1;
+          mlo[q] = (w0 & 1u) ? idx - steps : idx;
+          mhi[q] = ((w0 & 1u) ? idx : idx + steps) | ((v & 1u) << 31);
+          ivl[e] = (uint64_t)mlo[q] | ((uint64_t)mhi[q] << 32);
+        }
+        odd |= __ballot(e < nA && (mhi[q] >> 31));
+        even |= __ballot(e < nA && !(mhi[q] >> 31));
+      }
+      lds_sync();
+      if (odd && even) {
+        bool hit = false;
+#pragma unroll 4
+        for (uint32_t e = 0; e < nA; e++) {
+          const uint64_t x = ivl[e];
+          const uint32_t lo_e = (uint32_t)x, hi_e = (uint32_t)(x >> 32) & 0x7FFFFFFFu, or_e = (uint32_t)(x >> 63);
+#pragma unroll
+          for (int q = 0; q < G2S_SEG_ASETS; q++)
+            hit |= (mhi[q] >> 31) != or_e && mlo[q] <= hi_e && lo_e <= (mhi[q] & 0x7FFFFFFFu);
+        }
+        if (__ballot(hit)) flags |= G2S_DEV_Q7_A;
+      }
       lds_sync();
     }
     cyc_a_end = __builtin_amdgcn_s_memtime();
