@@ -473,9 +473,9 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
       const uint32_t* cnode = aq0;
       const uint32_t* clab = aq0 + ACAP;
       const uint32_t* crem = (const uint32_t*)lab;
-      uint64_t* ivl = (uint64_t*)(aq0 + 2u * ACAP);  // (the table-position queues are idle): first | (last | orientation << 31) << 32
+      uint64_t* ivl = (uint64_t*)(aq0 + 2u * ACAP);  // (the table-position queues are idle): first | last << 32
       uint32_t mlo[G2S_SEG_ASETS], mhi[G2S_SEG_ASETS];
-      uint64_t odd = 0, even = 0;
+      uint32_t n_odd = 0, n_even = 0;
 #pragma unroll
       for (int q = 0; q < G2S_SEG_ASETS; q++) {
         const uint32_t e = (uint32_t)q * 64u + (uint32_t)lane;
@@ -486,21 +486,33 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
           const uint32_t w0 = v ^ 1u, idx = w0 >> 1;
           mlo[q] = (w0 & 1u) ? idx - steps : idx;
           mhi[q] = ((w0 & 1u) ? idx : idx + steps) | ((v & 1u) << 31);
-          ivl[e] = (uint64_t)mlo[q] | ((uint64_t)mhi[q] << 32);
         }
-        odd |= __ballot(e < nA && (mhi[q] >> 31));
-        even |= __ballot(e < nA && !(mhi[q] >> 31));
+        n_odd += (uint32_t)__popcll(__ballot(e < nA && (mhi[q] >> 31)));
+        n_even += (uint32_t)__popcll(__ballot(e < nA && !(mhi[q] >> 31)));
       }
-      lds_sync();
-      if (odd && even) {
+      if (n_odd && n_even) {
+        // the intervals of the rarer orientation as a list; every lane tests its entries of the other one
+        const uint32_t minor = n_odd <= n_even ? 1u : 0u;
+        uint32_t m = 0;
+#pragma unroll
+        for (int q = 0; q < G2S_SEG_ASETS; q++) {
+          const uint32_t e = (uint32_t)q * 64u + (uint32_t)lane;
+          const bool put = e < nA && (mhi[q] >> 31) == minor;
+          const uint64_t pm = __ballot(put);
+          if (put) ivl[m + (uint32_t)__popcll(pm & below(lane))] = (uint64_t)mlo[q] | ((uint64_t)(mhi[q] & 0x7FFFFFFFu) << 32);
+          m += (uint32_t)__popcll(pm);
+          if (put || e >= nA) mlo[q] = 0xFFFFFFFFu;  // (only entries of the other orientation are tested below)
+          mhi[q] &= 0x7FFFFFFFu;
+        }
+        lds_sync();
         bool hit = false;
 #pragma unroll 4
-        for (uint32_t e = 0; e < nA; e++) {
+        for (uint32_t e = 0; e < m; e++) {
           const uint64_t x = ivl[e];
-          const uint32_t lo_e = (uint32_t)x, hi_e = (uint32_t)(x >> 32) & 0x7FFFFFFFu, or_e = (uint32_t)(x >> 63);
+          const uint32_t lo_e = (uint32_t)x, hi_e = (uint32_t)(x >> 32);
 #pragma unroll
           for (int q = 0; q < G2S_SEG_ASETS; q++)
-            hit |= (mhi[q] >> 31) != or_e && mlo[q] <= hi_e && lo_e <= (mhi[q] & 0x7FFFFFFFu);
+            if ((uint32_t)q * 64u < nA) hit |= mlo[q] <= hi_e && lo_e <= mhi[q];
         }
         if (__ballot(hit)) flags |= G2S_DEV_Q7_A;
       }
