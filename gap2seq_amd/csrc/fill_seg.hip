@@ -725,14 +725,27 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
   uint32_t cyc_a_kc = (uint32_t)((cyc_a_end - cyc0) >> 8);
   // (two waves) phase B starts without the right set; the first round that needs it waits for wave 1
   bool have_rs = !TWO;
+#ifdef G2S_SEG_PROFILE
+  uint32_t prof_wait = 0, prof_load = 0;  // (two waves) cycles at the barrier, and loading the right set behind it
+#endif
   auto take_right_set = [&]() {
     if constexpr (TWO) {
+#ifdef G2S_SEG_PROFILE
+      const unsigned long long tw0 = __builtin_amdgcn_s_memtime();
+#endif
       __syncthreads();
+#ifdef G2S_SEG_PROFILE
+      const unsigned long long tw1 = __builtin_amdgcn_s_memtime();
+#endif
       nA = ash[0]; roundsA = ash[1]; flags |= ash[2];
       if (ash[3]) overflow = true;
       cyc_a_kc = ash[4];
       load_right_set();
       have_rs = true;
+#ifdef G2S_SEG_PROFILE
+      prof_wait = (uint32_t)(tw1 - tw0);
+      prof_load = (uint32_t)(__builtin_amdgcn_s_memtime() - tw1);
+#endif
     }
   };
 
@@ -1698,6 +1711,8 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
   if (dbg && lane == 0) {
     uint32_t* o = dbg + (size_t)x * dbg_words;
     for (int pi = 0; pi < 4; pi++) o[dbg_words - 8u + pi] = (uint32_t)(prof_tail[pi + 1] - prof_tail[pi]);
+    o[dbg_words - 10u] = prof_wait;
+    o[dbg_words - 9u] = prof_load;
   }
 #endif
   __threadfence();
@@ -1739,10 +1754,10 @@ namespace g2s {
 
 size_t fill_seg_lds_bytes() { return 4u * (7u * G2S_SEG_CAP + 32u); }
 size_t fill_seg2_lds_bytes() { return 4u * (7u * G2S_SEG_CAP + 32u + 2u * 128u * G2S_SEG_ASETS + 128u * G2S_SEG_ASETS + 4u * 64u * G2S_SEG_ASETS + 8u); }
-uint32_t fill_seg_dbg_words() { return 8u + 2u * 64u * G2S_SEG_ASETS + 6u * G2S_SEG_CAP + 8u; }  // (+8: profile words)
+uint32_t fill_seg_dbg_words() { return 8u + 2u * 64u * G2S_SEG_ASETS + 6u * G2S_SEG_CAP + 10u; }  // (+10: profile words)
 size_t fill_segx_lds_bytes() { return 4u * SEGX_LDS_WORDS; }
 size_t fill_segx_scratch_bytes(uint32_t workgroups) { return (size_t)workgroups * SEGX_SCR_WORDS * 4u; }
-uint32_t fill_segx_dbg_words() { return 8u + 2u * G2S_SEGX_EA + 6u * G2S_SEGX_CAP + 8u; }
+uint32_t fill_segx_dbg_words() { return 8u + 2u * G2S_SEGX_EA + 6u * G2S_SEGX_CAP + 10u; }
 
 hipError_t launch_fill_seg(hipStream_t st, uint32_t ngaps, const uint32_t* succ, const uint32_t* urec, const GapDev* gaps,
                            const uint32_t* gap_ids, const uint32_t* flank_nodes, SubRec* sub_out,

@@ -1138,7 +1138,8 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
           const uint32_t* o = h.data() + x * W;
           fprintf(f, "gap %u nA %u nseg %u flags %#x roundsA %u roundsB %u c_count %u best %u\n", o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7]);
           if (o[W - 4] | o[W - 3] | o[W - 2] | o[W - 1])  // (-DG2S_SEG_PROFILE builds) cycles of phase B's sections
-            fprintf(f, "P %u %u %u %u %u %u %u %u\n", o[W - 4], o[W - 3], o[W - 2], o[W - 1], o[W - 8], o[W - 7], o[W - 6], o[W - 5]);
+            fprintf(f, "P %u %u %u %u %u %u %u %u %u %u\n", o[W - 4], o[W - 3], o[W - 2], o[W - 1], o[W - 8], o[W - 7], o[W - 6], o[W - 5],
+                    o[W - 10], o[W - 9]);
           for (uint32_t e = 0; e < o[1] && e < ecap; e++) fprintf(f, "A %u %u\n", o[8 + 2 * e], o[9 + 2 * e]);
           for (uint32_t q = 0; q < o[2] && q < scap; q++)
             fprintf(f, "S %u %u %u %u %#x %#x %u\n", o[sb0 + 6 * q], o[sb0 + 6 * q + 1] & 0xFFFF, o[sb0 + 6 * q + 1] >> 16,

@@ -34,6 +34,7 @@ for ln in open(dump):
     elif p[0] == "P":
         cur["prof"] = [int(x) for x in p[1:5]]
         cur["tail"] = [int(x) for x in p[5:9]]
+        cur["sync"] = [int(x) for x in p[9:11]] if len(p) >= 11 else [0, 0]
 rows = [r for r in rows if r["prof"]]
 tot = [sum(r["prof"][i] for r in rows) for i in range(4)]
 allc = sum(tot)
@@ -49,3 +50,7 @@ print("tail (Q7 between segments + phase C | D1 | D2 | emission), all gaps: %s; 
     tt, ["%.1f%%" % (100.0 * x / max(1, sum(tt))) for x in tt]))
 for r in sorted(rows, key=lambda r: -sum(r["tail"]))[:6]:
     print("gap %d: segments %d tail cycles %d: q7+C %d D1 %d D2 %d emission %d" % (r["gap"], r["nseg"], sum(r["tail"]), *r["tail"]))
+ws = sum(r["sync"][0] for r in rows); ls = sum(r["sync"][1] for r in rows)
+print("two waves: cycles waiting at the barrier for phase A %d, loading the right set behind it %d (all gaps)" % (ws, ls))
+for r in sorted(rows, key=lambda r: -(sum(r["prof"]) + sum(r["tail"]) + sum(r["sync"])))[:6]:
+    print("gap %d: B rounds %d, wait for A %d, load %d, tail %d" % (r["gap"], sum(r["prof"]), r["sync"][0], r["sync"][1], sum(r["tail"])))
