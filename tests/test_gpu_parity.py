@@ -406,6 +406,17 @@ def test_multi_rank_bench_path(product, tmp_path):
     assert out["roofline"]["launches_per_step"] == 2.0
 
 
+def test_bench_refuses_more_gpus_than_there_are(product):
+    """`bench.py --gpus N` drives N devices itself; with fewer usable devices it must fail, not fall back to one."""
+    import sys
+    n = product.G2S.device_count()
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n + 1), "--steps", "1", "--warmup", "0",
+                          "--genome", "100000", "--gaps", "50", "--no-cpu-baseline"], capture_output=True, text=True, timeout=300)
+    assert res.returncode != 0
+    assert "--gpus %d but only %d" % (n + 1, n) in (res.stdout + res.stderr)
+    assert not [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+
+
 def test_bench_one_gpu_line(product):
     """bench.py's default shape on a small graph: the timed region is the whole ABI call, the
     JSON line carries roofline and cpu_baseline, and the workload label names what ran."""
