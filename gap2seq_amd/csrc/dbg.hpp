@@ -8,6 +8,7 @@
 // sites are Gap2Seq.cpp:879,884,924,955,957,995,1000,1043,1084,1086,1114,1199,
 // 1203,1204,1263,1271,1452,1456,1476.  Membership is exact (no Bloom filter).
 #pragma once
+#include <mutex>
 #include <cstdint>
 #include <map>
 #include <string>
@@ -54,6 +55,19 @@ struct Graph {
   std::vector<uint32_t> succ;
   std::vector<uint32_t> pred;     // explicit predecessor table, even k only
   std::vector<uint8_t> lastnt;    // [2n] code of the last base of the oriented sequence
+  // The same as upper-case characters, one array per orientation ([n] each, by k-mer index): the bases along a
+  // unitig are then consecutive bytes, and the traceback copies a run of states instead of looking every base
+  // up (ensure_lastch builds them once, from lastnt).
+  mutable std::vector<char> lastch_up, lastch_dn;
+  mutable std::once_flag lastch_once;
+  void ensure_lastch() const {
+    std::call_once(lastch_once, [this]() {
+      static const char kUpChar[4] = {'A', 'C', 'T', 'G'};  // GATB codes (kmer.hpp)
+      lastch_up.resize((size_t)n);
+      lastch_dn.resize((size_t)n);
+      for (size_t i = 0; i < (size_t)n; i++) { lastch_up[i] = kUpChar[lastnt[2 * i] & 3]; lastch_dn[i] = kUpChar[lastnt[2 * i + 1] & 3]; }
+    });
+  }
   // bit i set: k-mer index i is the first of its unitig in numbering order, i.e. the edge
   // 2(i-1) -> 2i is NOT unitig-internal.  Between two set bits the walk arithmetic
   // (v +/- 2) is exact: every node there has exactly one predecessor and one successor.

@@ -1932,16 +1932,144 @@ int batches_stage2(const std::vector<g2s_batch*>& bs, g2s_session* lead, g2s_res
   // the pool traces segment s, this thread assigns the offsets of segment s+1.  When the
   // analysis has already written most fills, the few that are left are traced by the
   // in-order pass itself: waking the pool costs more than they do.
-  for (size_t gi = 0; gi < n; gi++) {
-    const g2s_batch::GapInfo& in = owner[gi]->info[local[gi]];
-    n_rest += in.kind == 0 && in.n_len > 0 && !(in.filled & 2);
+  // Long lists: what does not depend on the stream offset is done per block of the list on the pool — which gaps
+  // are skipped (:369; that rule reads the previous gap of the record only), the draws of the gaps whose count is
+  // fixed, their running sums inside the block — so that the sequential part only visits the gaps whose draw
+  // count depends on the draws themselves (~4 %).  Offsets are then sums of three terms, put together where
+  // they are needed: fixed draws of earlier blocks + of earlier gaps of the block + draws of the earlier
+  // variable gaps.
+  // (tests: G2S_STAGE2_BLOCK=<gaps per block> makes short lists take this path too, two blocks and up)
+  static const size_t fb_env = getenv("G2S_STAGE2_BLOCK") ? (size_t)std::max(1, atoi(getenv("G2S_STAGE2_BLOCK"))) : 0;
+  const size_t FB = fb_env ? fb_env : 1024;
+  const bool blocks = n >= 2 * FB;
+  const size_t nblk = blocks ? (n + FB - 1) / FB : 0;
+  std::vector<size_t> blk_fix(nblk, 0), blk_fixbase(nblk + 1, 0), blk_rest(nblk, 0);
+  std::vector<uint32_t> blk_varbase(nblk + 1, 0), vrank(blocks ? n : 0), vars_flat;
+  std::vector<std::vector<uint32_t>> blk_vars(nblk);
+  std::vector<size_t> var_cum;
+  double ms_blocks = 0;
+  if (blocks) {
+    const auto tb0 = std::chrono::steady_clock::now();
+    lead->pool->run(nblk, [&](size_t t) {
+      const size_t s0 = t * FB, e0 = std::min(n, s0 + FB);
+      auto info_of = [&](size_t gi) -> const g2s_batch::GapInfo& { return owner[gi]->info[local[gi]]; };
+      // what the gap in front of the block left behind: walk back to a gap the rule cannot skip, then forward
+      bool pf = false;
+      int prf = 0;
+      auto step = [&](size_t gi, bool act) {  // the rule for one gap; act: this block's own gaps
+        const g2s_batch::GapInfo& in = info_of(gi);
+        if (in.skip_thr >= 0 && pf && prf > in.skip_thr) {  // not attempted at all (:369)
+          if (act) {
+            g2s_result& r = results[gi];
+            memset(&r, 0, sizeof r);
+            r.flags = G2S_GAP_SKIPPED;
+            if (in.filled & 2) arena[arena_off[gi] + (size_t)owner[gi]->jobs[local[gi]].lmf] = '\0';
+          }
+          pf = false;
+          return 0;
+        }
+        if (in.kind != 0) { pf = false; return 0; }
+        pf = (in.filled & 1) != 0;
+        prf = in.n_len > 0 ? in.reached_j : 0;
+        return in.n_len > 0 ? (in.n_len == 1 && in.fixed[0] >= 0 ? 1 : 2) : 0;  // 1: fixed draw count, 2: depends on the stream
+      };
+      if (s0 > 0) {
+        size_t c = s0 - 1;
+        while (c > 0 && info_of(c).skip_thr >= 0) c--;
+        for (size_t gi = c; gi < s0; gi++) (void)step(gi, false);
+      }
+      size_t fsum = 0, rest = 0;
+      uint32_t nv = 0;
+      for (size_t gi = s0; gi < e0; gi++) {
+        const g2s_batch::GapInfo& in = info_of(gi);
+        rand_off[gi] = fsum;  // (inside the block, fixed draws only)
+        vrank[gi] = nv;
+        const int cls = step(gi, true);
+        if (cls == 1) {
+          fsum += (size_t)in.fixed[0];
+          todo_tb[gi] = !(in.filled & 2);
+          expect_draws[gi] = in.fixed[0];
+        } else if (cls == 2) {
+          blk_vars[t].push_back((uint32_t)gi);
+          nv++;
+        }
+        rest += in.kind == 0 && in.n_len > 0 && !(in.filled & 2);
+      }
+      blk_fix[t] = fsum;
+      blk_rest[t] = rest;
+    });
+    for (size_t t = 0; t < nblk; t++) {
+      blk_fixbase[t + 1] = blk_fixbase[t] + blk_fix[t];
+      blk_varbase[t + 1] = blk_varbase[t] + (uint32_t)blk_vars[t].size();
+      vars_flat.insert(vars_flat.end(), blk_vars[t].begin(), blk_vars[t].end());
+      n_rest += blk_rest[t];
+    }
+    var_cum.assign(vars_flat.size() + 1, 0);
+    ms_blocks = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb0).count();
+  } else {
+    for (size_t gi = 0; gi < n; gi++) {
+      const g2s_batch::GapInfo& in = owner[gi]->info[local[gi]];
+      n_rest += in.kind == 0 && in.n_len > 0 && !(in.filled & 2);
+    }
   }
   serial = n_rest <= 64;
+  const bool fast = blocks && !serial;
+  // where gap gi's draws start in the stream
+  auto offset_of = [&](size_t gi) -> size_t {
+    return fast ? blk_fixbase[gi / FB] + rand_off[gi] + var_cum[(size_t)blk_varbase[gi / FB] + vrank[gi]] : rand_off[gi];
+  };
+  size_t vk = 0;  // variable gaps done so far
+  auto in_order_fast = [&](size_t g_lo, size_t g_hi) {
+    (void)g_lo;
+    auto t0 = std::chrono::steady_clock::now();
+    while (vk < vars_flat.size() && vars_flat[vk] < g_hi) {
+      const size_t gi = vars_flat[vk];
+      g2s_batch* b = owner[gi];
+      const size_t i = local[gi];
+      const g2s_batch::GapInfo& in = b->info[i];
+      const size_t off = blk_fixbase[gi / FB] + rand_off[gi] + var_cum[vk];
+      if (in.n_len > 1) grow_rands(off + 1);
+      const int pick = in.n_len > 1 ? (int)(lead->rcache.at_const(off) % in.n_len) : 0;
+      n_two += in.n_len > 1;
+      int draws = in.fixed[pick];
+      if (draws >= 0) {
+        todo_tb[gi] = !(in.filled & 2);
+      } else {  // the draw count depends on the draws: walk the parent links once for the count
+        n_inline++;
+        const auto tw0 = std::chrono::steady_clock::now();
+        if (vk + 5 < vars_flat.size()) {  // (the closure records of a walk a few walks ahead: written by the GPU, not read yet)
+          const size_t gj = vars_flat[vk + 5];
+          const SubView& pv = owner[gj]->views[local[gj]];
+          if (pv.segs)
+            for (size_t o = 0; o < std::min<size_t>((size_t)pv.n_segs * sizeof(SegRec), 4096); o += 64) __builtin_prefetch((const char*)pv.segs + o);
+        }
+        const SubView& v = b->views[i];
+        grow_rands(off + (size_t)v.out->len[pick] + 2);
+        {
+          const char* r0 = (const char*)lead->rcache.ptr(off);
+          for (size_t o = 0; o < ((size_t)v.out->len[pick] + 2) * 4; o += 64) __builtin_prefetch(r0 + o);
+        }
+        draws = b->prep[i].seg_mode ? seg_count_draws(g, v, b->prep[i], lead->rcache.ptr(off))
+                                    : sub_count_draws(g, v, b->prep[i], lead->rcache.ptr(off));
+        ms_walks += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count();
+        todo_tb[gi] = 1;
+      }
+      expect_draws[gi] = draws;
+      var_cum[vk + 1] = var_cum[vk] + (size_t)draws;
+      vk++;
+    }
+    if (g_hi >= n) {  // the whole list is done: what the run consumed
+      draws_total = blk_fixbase[nblk] + var_cum[vars_flat.size()];
+      grow_rands(draws_total + 1);
+      draws_used = draws_total;
+    }
+    ms_order += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  };
   const size_t nseg = serial ? 1 : (n >= 256 ? std::min<size_t>(8, n / 128) : 1);
   std::vector<std::function<void(size_t)>> jobs(nseg);
   for (size_t sg = 0; sg < nseg; sg++) {
     const size_t g_lo = n * sg / nseg, g_hi = n * (sg + 1) / nseg;
-    in_order_pass(g_lo, g_hi);
+    if (fast) in_order_fast(g_lo, g_hi); else in_order_pass(g_lo, g_hi);
     if (jobs_in_flight) { lead->pool->finish(); jobs_in_flight = false; }
     jobs[sg] = [&, g_lo, g_hi](size_t c) {
       uint64_t bytes = 0;
@@ -1956,8 +2084,9 @@ int batches_stage2(const std::vector<g2s_batch*>& bs, g2s_session* lead, g2s_res
         if (todo_tb[gi]) {
           const g2s_batch* b = owner[gi];
           const size_t i = local[gi];
-          if (b->prep[i].seg_mode) seg_traceback(g, fp, j, b->views[i], b->prep[i], lead->rcache.ptr(rand_off[gi]), arena + arena_off[gi], &r);
-          else sub_traceback(g, fp, j, b->views[i], b->prep[i], lead->rcache.ptr(rand_off[gi]), arena + arena_off[gi], &r);
+          const uint32_t* rp = lead->rcache.ptr(offset_of(gi));
+          if (b->prep[i].seg_mode) seg_traceback(g, fp, j, b->views[i], b->prep[i], rp, arena + arena_off[gi], &r);
+          else sub_traceback(g, fp, j, b->views[i], b->prep[i], rp, arena + arena_off[gi], &r);
           // cannot happen: the draw count was proven fixed, or counted over the same draws
           if (r.draws != expect_draws[gi]) r.flags |= G2S_GAP_BACKTRACE_FAIL;
         }
@@ -1980,8 +2109,8 @@ int batches_stage2(const std::vector<g2s_batch*>& bs, g2s_session* lead, g2s_res
   lead->rcache.consume(draws_used);
   auto t_end = std::chrono::steady_clock::now();
   if (getenv("G2S_DEBUG"))
-    fprintf(stderr, "[g2s] host stage 2 (%s analysis): %.3f ms = setup+analysis %.3f + in-order pass %.3f (draw-count walks %.3f; %zu gaps traced inline, %zu with two lengths, %zu not traced by the analysis) + tracebacks\n",
-            analyze ? "with" : "after", std::chrono::duration<double, std::milli>(t_end - t_begin).count(), ms_ana, ms_order,
+    fprintf(stderr, "[g2s] host stage 2 (%s analysis): %.3f ms = setup+analysis %.3f + block pass %.3f + in-order pass %.3f (draw-count walks %.3f; %zu gaps traced inline, %zu with two lengths, %zu not traced by the analysis) + tracebacks\n",
+            analyze ? "with" : "after", std::chrono::duration<double, std::milli>(t_end - t_begin).count(), ms_ana, ms_blocks, ms_order,
             ms_walks, n_inline, n_two, n_rest);
   if (timing) {
     timing->fill_bytes += fill_bytes.load();

@@ -966,6 +966,9 @@ void seg_traceback(const Graph& g, const FillParams& p, const GapJob& job, const
   buf[d2] = '\0';
   res->count = prep.count;
   const uint8_t* lastnt = g.lastnt.data();
+  g.ensure_lastch();
+  const char* chu = g.lastch_up.data();
+  const char* chd = g.lastch_dn.data();
   while (d2 >= 0 && i >= 0) {
     const SegRec& s = v.segs[i];
     const int d0 = (int)(s.depth_len & 0xFFFFu);
@@ -994,15 +997,21 @@ void seg_traceback(const Graph& g, const FillParams& p, const GapJob& job, const
         else if (pos > ts) { lo_run = pos; sf = seg_safe(v, prep, (uint32_t)i, pos); }  // outside the subgraph (Q5): state by state
         else if (pos > split) { lo_run = std::max(1, split + 1); sf = sfb; }
         else { lo_run = 1; sf = sfa; }
+        // the bases of states lo_run .. pos are consecutive bytes of the unitig's last-base string (ascending
+        // for an upward segment, descending for a downward one): copied, then lower-cased where the rule says so
         const bool up = (s.node & 1u) == 0;
-        uint32_t node = up ? s.node + 2u * (uint32_t)pos : s.node - 2u * (uint32_t)pos;
-        char* o = buf + (d0 + pos - 1);
-        if (sf) {
-          for (int q = pos; q >= lo_run; q--, o--, node = up ? node - 2u : node + 2u) *o = kUp[lastnt[node]];
-          last_solid = d0 + lo_run;
-        } else {
-          for (int q = pos; q >= lo_run; q--, o--, node = up ? node - 2u : node + 2u)
-            *o = (d0 + q > last_solid - k) ? kUp[lastnt[node]] : kLow[lastnt[node]];
+        const uint32_t idx0 = s.node >> 1;
+        const int cnt = pos - lo_run + 1;
+        char* dst = buf + (d0 + lo_run - 1);
+        if (up) memcpy(dst, chu + ((size_t)idx0 + (size_t)lo_run), (size_t)cnt);
+        else {
+          const char* src = chd + ((size_t)idx0 - (size_t)pos);  // k-mer idx0 - q for q = pos down to lo_run
+          for (int x = 0; x < cnt; x++) dst[cnt - 1 - x] = src[x];
+        }
+        if (sf) last_solid = d0 + lo_run;
+        else {  // (:1466-1468) lower case unless within k of the last safe base: d0 + q > last_solid - k
+          const int qmax = std::min(pos, last_solid - k - d0);
+          for (int q = lo_run; q <= qmax; q++) dst[q - lo_run] |= 0x20;
         }
         pos = lo_run - 1;
       }
