@@ -132,6 +132,10 @@ def main():
     ap.add_argument("--host-threads", type=int, default=0, help="host worker threads per session (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-c3-beside", action="store_true", help="N=1/C2: skip the C3-on-one-GPU measurement beside it")
+    ap.add_argument("--prime-seconds", type=float, default=0.3,
+                    help="untimed steps run for this long before the W warm-up steps (a fresh box starts with idle CPU "
+                         "clocks, sleeping worker threads and unallocated pinned buffers: the first ~0.1 s of steps run "
+                         "up to 40 %% slower); reported as priming_steps")
     ap.add_argument("--backend", default="gloo", help="torch.distributed backend for the barriers under torchrun")
     ap.add_argument("--share-device", action="store_true", help="testing only: all N sessions on HIP device 0")
     ap.add_argument("--dry-run", action="store_true",
@@ -221,6 +225,11 @@ def main():
         group = 0 if len(sessions) == 1 else shard.group_size(len(gaps), len(sessions))
     run = Runner(P, sessions, gaps, group)
 
+    priming_steps = 0
+    t_prime = time.perf_counter()
+    while time.perf_counter() - t_prime < args.prime_seconds:
+        run.step()
+        priming_steps += 1
     for _ in range(warmup):
         run.step()
     acc = dict(ms_right_bfs=0.0, ms_left_dp=0.0, ms_extract=0.0, ms_fill_lds=0.0, ms_extract_lds=0.0, ms_d2h=0.0,
@@ -404,6 +413,7 @@ def main():
         "cpu_baseline": cpu,
         "filled": filled,
         "q7_gaps": q7,
+        "priming_steps": priming_steps,
         "retried_gaps": tm.retried_gaps,
         "breakdown_ms_per_step": {"wall_inside_the_abi_call": round(in_call / steps * 1e3, 4),
                                   "prepare_flank_lookup_and_upload": per_step("ms_prepare"),
