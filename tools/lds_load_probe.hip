@@ -1,3 +1,7 @@
+// tools/lds_load_probe.hip — where __builtin_amdgcn_global_load_lds puts its data on gfx950: lane L of the wave
+// writes at the LDS base + L * size (16-byte and 4-byte forms), whatever lanes are active.  Measured on an MI355X:
+//   hipcc --offload-arch=gfx950 tools/lds_load_probe.hip -o /tmp/probe && /tmp/probe
+// (the record prefetch DESIGN.md §8 lists as a next step would use it)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
