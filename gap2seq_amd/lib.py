@@ -10,6 +10,7 @@ import ctypes as C
 import os
 
 G2S_OK = 0
+G2S_ERR_IO = -2
 G2S_ERR_NO_DEVICE = -3
 G2S_INVALID_NODE = 0xFFFFFFFF
 G2S_MAX_PATHS = 2147483647 // 2 - 1
@@ -67,6 +68,12 @@ class g2s_run_opts(C.Structure):
                 ("max_mem_gb", C.c_double)]
 
 
+class g2s_filter_opts(C.Structure):
+    _fields_ = [("mean_insert", C.c_int32), ("std_dev", C.c_int32), ("breakpoint", C.c_int32), ("gap_length", C.c_int32),
+                ("flank_length", C.c_int32), ("unmapped_only", C.c_int32), ("threads", C.c_int32),
+                ("scaffold", C.c_char_p)]
+
+
 # every symbol include/g2s.h declares: name -> (restype, argtypes)
 _VP = C.c_void_p
 TEXT_FN = C.CFUNCTYPE(None, C.POINTER(C.c_char), C.c_size_t, C.c_void_p)  # g2s_text_fn
@@ -118,6 +125,11 @@ _SIGS = {
                                     C.c_char_p, C.POINTER(_VP), C.POINTER(_VP), C.POINTER(_VP), C.POINTER(_VP)]),
     "g2s_merge_scaffolds": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(_VP),
                                       C.POINTER(_VP)]),
+    "g2s_filter_reads": (C.c_int, [C.c_char_p, C.POINTER(g2s_filter_opts), C.POINTER(_VP), C.POINTER(_VP),
+                                   C.POINTER(_VP), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "g2s_filter_reads_mem": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(g2s_filter_opts), C.POINTER(_VP),
+                                       C.POINTER(_VP), C.POINTER(_VP), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "g2s_filter_last_error": (C.c_char_p, []),
     "g2s_device_count": (C.c_int, []),
     "g2s_synth_genome": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint64, C.POINTER(_VP)]),
     "g2s_synth_gaps": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64,
@@ -218,6 +230,25 @@ def merge_scaffolds(contigs_text, gaps_text, labels=("merged.fa", "contigs.fa", 
     _check(load_library().g2s_merge_scaffolds(contigs_text.encode("ascii"), gaps_text.encode("ascii"),
                                               *[x.encode() for x in labels], C.byref(out), C.byref(log)))
     return _take_text(out), _take_text(log)
+
+
+def filter_reads(bam, mean, std_dev, scaffold, breakpoint, gap_length=-1, flank_length=-1, unmapped_only=False,
+                 threads=0):
+    """g2s_filter_reads / g2s_filter_reads_mem (ReadFilter): `bam` is a path (str) or the file's bytes.
+    Returns (fasta, stdout_text, stderr_text, extracted, total)."""
+    lib = load_library()
+    o = g2s_filter_opts(mean, std_dev, breakpoint, gap_length, flank_length, int(unmapped_only), threads,
+                        scaffold.encode())
+    outs = [_VP(), _VP(), _VP()]
+    ext, tot = C.c_int64(0), C.c_int64(0)
+    tail = [C.byref(o)] + [C.byref(x) for x in outs] + [C.byref(ext), C.byref(tot)]
+    if isinstance(bam, (bytes, bytearray)):
+        rc = lib.g2s_filter_reads_mem(bytes(bam), len(bam), *tail)
+    else:
+        rc = lib.g2s_filter_reads(str(bam).encode(), *tail)
+    if rc != G2S_OK:
+        raise G2SError(rc, (lib.g2s_filter_last_error() or b"").decode("utf-8", "replace"))
+    return tuple(_take_text(x) for x in outs) + (ext.value, tot.value)
 
 
 class Graph:

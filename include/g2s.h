@@ -282,6 +282,30 @@ int g2s_cut_scaffolds(const char* scaffolds_text, int k, int fuz, int mask, int 
 int g2s_merge_scaffolds(const char* contigs_text, const char* gaps_text, const char* scaffolds_label,
                         const char* contigs_label, const char* gaps_label, char** scaffolds_out, char** log_out);
 
+/* ---------------------------------------------------------------------------
+ *  The reference's ReadFilter (ReadFilter.cpp:344-415; called once per gap and library by Gap2Seq.py:145-149,
+ *  once per library with unmapped_only by Gap2Seq.py:64-72): from a BAM file of aligned read pairs, the reads
+ *  that can belong to one gap, as FASTA text (">name/1" or ">name/2", the read as sequenced).  Host work beside
+ *  the fill path: BGZF/BAM are read with zlib, no index file is needed (the reference wants "<bam>.bai").
+ *  fasta_out is "" when nothing was extracted (the reference then leaves no output file, Gap2Seq.py:151-153);
+ *  log_out is the tool's stdout line (:406), warn_out what it writes to stderr (:188-190).  The strings are
+ *  malloc'ed, released with g2s_free.  g2s_filter_last_error() describes a G2S_ERR_IO.
+ * ------------------------------------------------------------------------ */
+typedef struct g2s_filter_opts {
+  int32_t mean_insert, std_dev;      /* -mean, -std-dev */
+  int32_t breakpoint;                /* -breakpoint: 0-based position of the gap in the scaffold */
+  int32_t gap_length;                /* -gap-length (default -1, as the reference's parser has it) */
+  int32_t flank_length;              /* -flank-length; -1 = do not add the reads overlapping the flanks */
+  int32_t unmapped_only;             /* -unmapped-only */
+  int32_t threads;                   /* inflating threads; 0 = up to 8 */
+  const char* scaffold;              /* -scaffold: reference sequence name in the BAM header */
+} g2s_filter_opts;
+int g2s_filter_reads(const char* bam_path, const g2s_filter_opts* o, char** fasta_out, char** log_out, char** warn_out,
+                     int64_t* extracted, int64_t* total);
+int g2s_filter_reads_mem(const void* bam_bytes, size_t n, const g2s_filter_opts* o, char** fasta_out, char** log_out,
+                         char** warn_out, int64_t* extracted, int64_t* total);
+const char* g2s_filter_last_error(void);
+
 /* Accessors. */
 const g2s_graph* g2s_session_graph(const g2s_session* s);
 int g2s_session_get_params(const g2s_session* s, g2s_params* out);
