@@ -248,7 +248,11 @@ def filter_reads(bam, mean, std_dev, scaffold, breakpoint, gap_length=-1, flank_
         rc = lib.g2s_filter_reads(str(bam).encode(), *tail)
     if rc != G2S_OK:
         raise G2SError(rc, (lib.g2s_filter_last_error() or b"").decode("utf-8", "replace"))
-    return tuple(_take_text(x) for x in outs) + (ext.value, tot.value)
+    texts = []
+    for x in outs:  # (read names are bytes of the BAM file: not necessarily ASCII)
+        texts.append(C.string_at(x).decode("latin-1") if x else "")
+        lib.g2s_free(x)
+    return tuple(texts) + (ext.value, tot.value)
 
 
 class Graph:

@@ -11,6 +11,7 @@ bit-exact claim but must be flagged by the GPU path whenever the oracle flags th
 import json
 import os
 import subprocess
+import sys
 
 import pytest
 
@@ -739,6 +740,74 @@ def test_cli_binary_is_a_drop_in(product, oracle, tmp_path):
             cur.append(ln)
     unwrapped.append("".join(cur))
     assert "\n".join(unwrapped) + "\n" == outs["cpu"][0]
+
+
+def test_per_gap_flow_with_filtered_reads(product, oracle, tmp_path):
+    """The wrapper's per-gap flow (Gap2Seq.py:133-218): ReadFilter on the library's BAM for ONE gap, then
+    Gap2Seq-core -left/-right/-length on the reads it extracted.  The filter's output is checked against its
+    restatement, the fill against the oracle CLI on the same reads, and the filled bases against the genome
+    the reads were simulated from."""
+    import random
+    import bamwriter as BW
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import readfilter_ref as RF
+    rng = random.Random(77)
+    # (-mean is the distance BETWEEN the two reads of a pair: the windows of ReadFilter.cpp:384-385 put the mate
+    # on the breakpoint for that reading.  Only the left-hand window works in the reference (:388-389), so the gap
+    # must be short enough for the left-hand mates and the flank reads to cover it.)
+    k, rl, frag, sd = 31, 100, 400, 20
+    mean = frag - 2 * rl
+    glen, gap_at, gap_len, flank = 8000, 4000, 60, 41  # (flanks of k + fuz bases, as GapCutter cuts them)
+    genome = "".join(rng.choice("ACGT") for _ in range(glen))
+    recs, uid = [], 0
+    for _ in range(2400):  # 60x
+        ins = max(2 * rl, int(rng.gauss(frag, sd)))
+        a = rng.randrange(0, glen - ins)
+        ends = [(a, False), (a + ins - rl, True)]
+        mapped = [not (st + rl > gap_at and st < gap_at + gap_len) for st, _ in ends]
+        name = "p%05d" % uid
+        uid += 1
+        for i, (st, rev) in enumerate(ends):
+            o = 1 - i
+            flag = 1 | (64 if i == 0 else 128) | (0 if mapped[i] else 4) | (0 if mapped[o] else 8)
+            if mapped[i] and rev:
+                flag |= 16
+            seq = genome[st:st + rl]
+            if mapped[i]:
+                pos, cig = st, "%dM" % rl
+                stored = BW.revcomp(seq) if rev else seq
+            elif mapped[o]:
+                pos, cig, stored = ends[o][0], "", seq
+            else:
+                pos, cig, stored = -1, "", seq
+            tid = 0 if pos >= 0 else -1
+            recs.append(((tid if tid >= 0 else 1 << 30, pos, len(recs)), BW.record(name, flag, tid, pos, cig, stored, tid, ends[o][0] if mapped[o] else pos)))
+    recs.sort(key=lambda r: r[0])
+    bam = BW.bam_bytes([("scaffold1", glen)], [r[1] for r in recs], block=20000)
+    bam_path = tmp_path / "lib.bam"
+    bam_path.write_bytes(bam)
+    filt = tmp_path / "tmp.reads.1.0"
+    res = subprocess.run([os.path.join(ROOT, "gap2seq_amd", "ReadFilter"), "-reads", str(filt), "-scaffold", "scaffold1",
+                          "-breakpoint", str(gap_at), "-flank-length", str(flank), "-gap-length", str(gap_len), "-bam", str(bam_path),
+                          "-mean", str(mean), "-std-dev", str(sd)], capture_output=True, text=True, timeout=120)
+    want = RF.read_filter(bam, mean, sd, "scaffold1", gap_at, gap_len, flank)
+    assert res.returncode == 0 and res.stdout == want[1] and filt.read_text() == want[0]
+    n_reads = filt.read_text().count(">")
+    assert 20 < n_reads < len(recs) // 4  # a small part of the library
+    left, right = genome[gap_at - flank:gap_at], genome[gap_at + gap_len:gap_at + gap_len + flank]
+    outs = {}
+    for name, exe in (("gpu", os.path.join(ROOT, "gap2seq_amd", "Gap2Seq-core")),
+                      ("cpu", os.path.join(os.path.dirname(oracle.ORACLE_SO), "g2s_oracle_cli"))):
+        out = tmp_path / ("tmp.filled.%s" % name)
+        r = subprocess.run([exe, "-k", str(k), "-fuz", "10", "-solid", "2", "-nb-cores", "1", "-dist-error", "500", "-max-mem", "20",
+                            "-randseed", "3", "-reads", str(filt), "-filled", str(out), "-left", left, "-right", right,
+                            "-length", str(gap_len)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs[name] = (out.read_text(), r.stdout.replace(str(out), "OUT"))
+    assert outs["gpu"] == outs["cpu"]
+    fill = "".join(ln for ln in outs["gpu"][0].splitlines() if not ln.startswith(">"))
+    # single-gap mode writes the left flank, the fill and the right k-mer (Gap2Seq.cpp:262-266)
+    assert fill.upper() == genome[gap_at - flank:gap_at + gap_len + k]
 
 
 def _fuzz_regressions():

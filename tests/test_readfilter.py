@@ -163,6 +163,40 @@ def test_broken_files_are_reported():
     P.filter_reads(BW.bgzf(raw, eof=False), **kw)  # a missing end-of-file marker is tolerated (htslib warns only)
 
 
+def test_garbled_records_never_crash():
+    """Bytes of the inflated stream changed at random and compressed again (so every block checksum is right and the
+    record parser sees the damage): the filter either reports G2S_ERR_IO or returns text; whenever the checker
+    can read the same bytes the two agree."""
+    import random
+    refs, recs, _ = BW.simulate_library(8, pairs=40, unmapped_pairs=3)
+    raw = bytearray(REF.bgzf_inflate(BW.bam_bytes(refs, recs)))
+    rng = random.Random(99)
+    kw = dict(mean=300, std_dev=20, scaffold="scaf0", breakpoint=1400, gap_length=200, flank_length=100)
+    errors = agreed = 0
+    for it in range(300):
+        b = bytearray(raw)
+        for _ in range(rng.randrange(1, 4)):
+            i = rng.randrange(len(b))
+            b[i] = rng.randrange(256) if rng.random() < 0.7 else (b[i] ^ (1 << rng.randrange(8)))
+        if rng.random() < 0.2:
+            del b[rng.randrange(len(b)):]
+        bam = BW.bgzf(bytes(b), block=rng.choice([65280, 333]))
+        try:
+            got = P.filter_reads(bam, **kw)
+        except P.G2SError as e:
+            assert e.code == P.G2S_ERR_IO
+            errors += 1
+            continue
+        try:
+            want = REF.read_filter(bam, 300, 20, "scaf0", 1400, 200, 100)
+        except Exception:
+            continue  # (the checker is less careful about broken layouts than the product)
+        if all(32 <= ord(c) < 127 or c == "\n" for c in want[0]):
+            assert got[:3] == want
+            agreed += 1
+    assert errors > 10 and agreed > 50
+
+
 def test_binary_is_a_drop_in(tmp_path):
     """The wrapper's two calls (Gap2Seq.py:64-72 and :145-149): same argv, output file only when reads came out."""
     refs, recs, _ = BW.simulate_library(7, pairs=300)
