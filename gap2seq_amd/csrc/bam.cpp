@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cstdlib>
 #include <thread>
 
 namespace g2s {
@@ -16,7 +17,15 @@ namespace g2s {
 namespace {
 inline uint16_t rd16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
 inline uint32_t rd32(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }  // (little-endian host)
-const size_t kChunkBytes = (size_t)32 << 20;  // inflated bytes per refill
+// inflated bytes per refill (G2S_BAM_CHUNK: the tests make it small so that records span refills)
+size_t chunk_bytes() {
+  static const size_t v = [] {
+    const char* e = getenv("G2S_BAM_CHUNK");
+    const long long n = e ? atoll(e) : 0;
+    return n > 0 ? (size_t)n : (size_t)32 << 20;
+  }();
+  return v;
+}
 }  // namespace
 
 BamFile::~BamFile() {
@@ -100,7 +109,7 @@ struct BamFile::Stream {
     if (next_blk >= nb || !err.empty()) return false;
     if (lo) { memmove(buf.data(), buf.data() + lo, hi - lo); hi -= lo; lo = 0; }
     size_t e = next_blk, bytes = 0;
-    while (e < nb && (e == next_blk || bytes + f.blk_isize_[e] <= kChunkBytes)) bytes += f.blk_isize_[e++];
+    while (e < nb && (e == next_blk || bytes + f.blk_isize_[e] <= chunk_bytes())) bytes += f.blk_isize_[e++];
     if (buf.size() < hi + bytes) buf.resize(hi + bytes);
     std::vector<size_t> at(e - next_blk);
     for (size_t b = next_blk, o = hi; b < e; b++) { at[b - next_blk] = o; o += f.blk_isize_[b]; }

@@ -148,6 +148,23 @@ def test_empty_and_unknown_scaffold_and_threads():
     assert one == many and one[3] > 0
 
 
+def test_records_spanning_refills(tmp_path):
+    """The reader inflates a window of blocks at a time and carries a cut record over to the next window; with
+    G2S_BAM_CHUNK=1500 (normally 32 MB) every few records are cut."""
+    refs, recs, _ = BW.simulate_library(9, pairs=400)
+    bam = BW.bam_bytes(refs, recs, block=400)
+    path = tmp_path / "lib.bam"
+    path.write_bytes(bam)
+    out = tmp_path / "r.fa"
+    want = REF.read_filter(bam, 300, 20, "scaf1", 1400, 200, 100)
+    for chunk in ("1500", "401", "70000"):
+        r = subprocess.run([BIN, "-reads", str(out), "-scaffold", "scaf1", "-breakpoint", "1400", "-flank-length", "100",
+                            "-gap-length", "200", "-bam", str(path), "-mean", "300", "-std-dev", "20"], capture_output=True,
+                           text=True, env=dict(os.environ, G2S_BAM_CHUNK=chunk))
+        assert r.returncode == 0 and r.stdout == want[1] and out.read_text() == want[0], chunk
+        out.unlink()
+
+
 def test_broken_files_are_reported():
     refs, recs, _ = BW.simulate_library(6, pairs=50)
     bam = BW.bam_bytes(refs, recs, block=500)
