@@ -250,14 +250,32 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
   uint32_t flags = 0;
   bool overflow = D >= 32767 || rmf + 1 > 32 || lmf + 1 > 32;  // (16-bit depths and lengths, 32 seeds / targets)
 
-  // results go to pinned host memory as each gap finishes (as in the LDS tier)
+  // Results go to pinned host memory as each gap finishes (as in the LDS tier).  One wave publishes what it stored
+  // itself: the record it wrote to device memory went through the L1 into this XCD's L2, where the copy below reads
+  // it back (agent-scope loads bypass the L1) once "s_waitcnt vmcnt(0)" says the stores were acknowledged — no
+  // fence is needed for that.  ONE system-scope release then puts everything (closure segments and record in host
+  // memory) in front of the flag in done_list.  (This used to be __threadfence() + __threadfence_system() + a
+  // release store: three write-backs of the XCD's L2 and two invalidations per gap, which every other wave of the
+  // XCD pays for.  The last write-back has to stay.  Tried on the GPU: "vmcnt(0)" alone in its place — the host
+  // saw flags before records, plain stores to this memory do stay in the L2; and write-through (sc0 sc1) stores with
+  // "vmcnt(0)" — correct, but every 16-byte store is then a write over the link of its own: config 3's launch
+  // took 10-16 ms instead of 0.8.)  The large variant's workgroups publish what several waves stored: it keeps
+  // the fences.
   auto publish = [&]() {
+    if constexpr (BIG) __threadfence();
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if ((uint32_t)lane < sizeof(GapOut) / 4u)
       ((uint32_t*)&outs_host[gi])[lane] = __hip_atomic_load(&((const uint32_t*)go)[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __threadfence_system();
+    if constexpr (BIG) {
+      __threadfence_system();
+    } else {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope: buffer_wbl2 sc0 sc1
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the compiler leaves no wait between the write-back and a following store)
+    }
     if (lane == 0) {
       const unsigned long long at = atomicAdd(out_counter + 1, 1ull);
-      __hip_atomic_store(&done_list[at], gi, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      if constexpr (BIG) __hip_atomic_store(&done_list[at], gi, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      else __hip_atomic_store(&done_list[at], gi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   };
 
@@ -1407,7 +1425,6 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
     go->stat[4] = cyc_a_kc; go->stat[5] = (uint32_t)((cyc2 - cyc1) >> 8);
   }
   if (overflow || !(c_count > 0 && n_len > 0)) {  // :1169
-    __threadfence();
     publish();
     return;
   }
@@ -1615,7 +1632,6 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
   hbase = __shfl(hbase, 0);
   if (hbase + nres > out_cap) {  // the host buffer is full: the gap runs again in the LDS tier
     if (lane == 0) go->flags = flags | G2S_DEV_OVERFLOW_B | G2S_DEV_WHY_LOG;
-    __threadfence();
     publish();
     return;
   }
@@ -1715,7 +1731,6 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
     o[dbg_words - 9u] = prof_load;
   }
 #endif
-  __threadfence();
   publish();
 }
 
