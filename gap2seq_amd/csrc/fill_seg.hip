@@ -189,6 +189,12 @@ struct SegArgs {
   int skip_confident;
   uint32_t* dbg;
   uint32_t dbg_words;
+  // batched announcements (g2s_fill_seg / g2s_fill_seg2; see `publish`): per XCD a ticket counter and a list of the
+  // gaps finished there; pub_batch 1 = every gap announces itself
+  unsigned long long* xcd_tickets;  // 8 counters, zero before the launch
+  uint32_t* xcd_list;               // 8 lists of xcd_stride entries, 0xFFFFFFFF before the launch
+  uint32_t xcd_stride;
+  uint32_t pub_batch;               // a power of two <= 64
 };
 
 // LDS of the large variant (words): see the layout notes at each phase
@@ -253,14 +259,21 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
   // Results go to pinned host memory as each gap finishes (as in the LDS tier).  One wave publishes what it stored
   // itself: the record it wrote to device memory went through the L1 into this XCD's L2, where the copy below reads
   // it back (agent-scope loads bypass the L1) once "s_waitcnt vmcnt(0)" says the stores were acknowledged — no
-  // fence is needed for that.  ONE system-scope release then puts everything (closure segments and record in host
-  // memory) in front of the flag in done_list.  (This used to be __threadfence() + __threadfence_system() + a
-  // release store: three write-backs of the XCD's L2 and two invalidations per gap, which every other wave of the
-  // XCD pays for.  The last write-back has to stay.  Tried on the GPU: "vmcnt(0)" alone in its place — the host
-  // saw flags before records, plain stores to this memory do stay in the L2; and write-through (sc0 sc1) stores with
-  // "vmcnt(0)" — correct, but every 16-byte store is then a write over the link of its own: config 3's launch
-  // took 10-16 ms instead of 0.8.)  The large variant's workgroups publish what several waves stored: it keeps
-  // the fences.
+  // fence is needed for that.  A system-scope release (a write-back of this XCD's L2) then puts closure segments
+  // and record in host memory, in front of the gap's entry in done_list.  (This used to be __threadfence() +
+  // __threadfence_system() + a release store: three write-backs of the XCD's L2 and two invalidations per gap,
+  // which every other wave of the XCD pays for.  A write-back has to stay.  Tried on the GPU: "vmcnt(0)" alone in
+  // its place — the host saw flags before records, plain stores to this memory do stay in the L2; and
+  // write-through (sc0 sc1) stores with "vmcnt(0)" — correct, but every 16-byte store is then a write over the
+  // link of its own: config 3's launch took 10-16 ms instead of 0.8.)
+  // Batches (pub_batch > 1): one write-back announces pub_batch gaps.  A finished wave — its stores acknowledged,
+  // i.e. in the L2 of ITS XCD — takes a ticket from that XCD's counter and leaves its gap in that XCD's list;
+  // the wave whose ticket completes a batch waits for the batch's entries (their waves hold tickets, so they are
+  // running and about to store them), writes this XCD's L2 back — which holds everything those waves stored
+  // before they took their tickets — and enters the whole batch in done_list.  The XCD is read from the hardware
+  // register, not inferred from the block index.  Gaps of a batch that never completes are not announced: the
+  // host takes them at the end of the launch, which flushes everything.
+  // The large variant's workgroups publish what several waves stored: it keeps the fences.
   auto publish = [&]() {
     if constexpr (BIG) __threadfence();
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -268,14 +281,48 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
       ((uint32_t*)&outs_host[gi])[lane] = __hip_atomic_load(&((const uint32_t*)go)[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if constexpr (BIG) {
       __threadfence_system();
+      if (lane == 0) {
+        const unsigned long long at = atomicAdd(out_counter + 1, 1ull);
+        __hip_atomic_store(&done_list[at], gi, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
     } else {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope: buffer_wbl2 sc0 sc1
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the compiler leaves no wait between the write-back and a following store)
-    }
-    if (lane == 0) {
-      const unsigned long long at = atomicAdd(out_counter + 1, 1ull);
-      if constexpr (BIG) __hip_atomic_store(&done_list[at], gi, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-      else __hip_atomic_store(&done_list[at], gi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      const uint32_t B = A.pub_batch;
+      if (B <= 1u) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope: buffer_wbl2 sc0 sc1
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the compiler leaves no wait between the write-back and a following store)
+        if (lane == 0) {
+          const unsigned long long at = atomicAdd(out_counter + 1, 1ull);
+          __hip_atomic_store(&done_list[at], gi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the copy of the record too
+      const uint32_t xcd = (uint32_t)__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u;  // HW_REG_XCC_ID, bits 0-3
+      uint32_t* list = A.xcd_list + (size_t)xcd * A.xcd_stride;
+      uint32_t t = 0;
+      if (lane == 0) {
+        t = (uint32_t)atomicAdd(A.xcd_tickets + xcd, 1ull);
+        __hip_atomic_store(&list[t], gi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      t = uni((uint32_t)__shfl((int)t, 0));
+      if (((t + 1u) & (B - 1u)) != 0u) return;
+      const uint32_t first = t + 1u - B;
+      uint32_t e = G2S_DEV_INVALID;
+      bool all = true;
+      if ((uint32_t)lane < B) {
+        uint32_t spins = 0;
+        do {
+          e = __hip_atomic_load(&list[first + (uint32_t)lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } while (e == G2S_DEV_INVALID && ++spins < (1u << 18));
+        all = e != G2S_DEV_INVALID;
+      }
+      if (__ballot(!all)) return;  // (never expected; the batch is then taken at the end of the launch)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      unsigned long long base = 0;
+      if (lane == 0) base = atomicAdd(out_counter + 1, (unsigned long long)B);
+      base = (unsigned long long)(uint32_t)__shfl((int)(uint32_t)base, 0);
+      if ((uint32_t)lane < B) __hip_atomic_store(&done_list[base + (uint32_t)lane], e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   };
 
@@ -1777,14 +1824,16 @@ uint32_t fill_segx_dbg_words() { return 8u + 2u * G2S_SEGX_EA + 6u * G2S_SEGX_CA
 hipError_t launch_fill_seg(hipStream_t st, uint32_t ngaps, const uint32_t* succ, const uint32_t* urec, const GapDev* gaps,
                            const uint32_t* gap_ids, const uint32_t* flank_nodes, SubRec* sub_out,
                            unsigned long long out_cap, unsigned long long* out_counter, GapOut* outs, GapOut* outs_host,
-                           uint32_t* done_list, int skip_confident, uint32_t* dbg, bool two_waves) {
+                           uint32_t* done_list, int skip_confident, uint32_t* dbg, bool two_waves, unsigned long long* xcd_tickets,
+                           uint32_t* xcd_list, uint32_t xcd_stride, uint32_t pub_batch) {
   if (ngaps == 0) return hipSuccess;
   const size_t bytes = two_waves ? fill_seg2_lds_bytes() : fill_seg_lds_bytes();
   hipError_t e = hipFuncSetAttribute(two_waves ? (const void*)g2s_fill_seg2 : (const void*)g2s_fill_seg,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   if (e != hipSuccess) return e;
+  if (!xcd_tickets || !xcd_list || pub_batch < 2u || pub_batch > 64u || (pub_batch & (pub_batch - 1u))) pub_batch = 1u;
   const SegArgs A = {succ, urec, gaps, gap_ids, flank_nodes, sub_out, out_cap, out_counter, outs, outs_host, done_list,
-                     skip_confident, dbg, fill_seg_dbg_words()};
+                     skip_confident, dbg, fill_seg_dbg_words(), xcd_tickets, xcd_list, xcd_stride, pub_batch};
   if (two_waves) hipLaunchKernelGGL(g2s_fill_seg2, dim3(ngaps), dim3(128), bytes, st, A);
   else hipLaunchKernelGGL(g2s_fill_seg, dim3(ngaps), dim3(64), bytes, st, A);
   return hipGetLastError();
@@ -1800,7 +1849,7 @@ hipError_t launch_fill_segx(hipStream_t st, uint32_t ngaps, uint32_t workgroups,
   hipError_t e = hipFuncSetAttribute((const void*)g2s_fill_segx, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   if (e != hipSuccess) return e;
   const SegArgs A = {succ, urec, gaps, gap_ids, flank_nodes, sub_out, out_cap, out_counter, outs, outs_host, done_list,
-                     skip_confident, dbg, fill_segx_dbg_words()};
+                     skip_confident, dbg, fill_segx_dbg_words(), nullptr, nullptr, 0u, 1u};
   hipLaunchKernelGGL(g2s_fill_segx, dim3(workgroups), dim3(64), bytes, st, A, scratch, ngaps, next_gap);
   return hipGetLastError();
 }

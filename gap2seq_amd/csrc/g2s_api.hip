@@ -507,6 +507,7 @@ struct g2s_session {
   bool no_lds_tier = false;  // G2S_NO_LDS_TIER=1: force the general HBM tier (tests, A/B timing)
   size_t mem_budget = 0;  // bytes of HBM this session may use for work areas
   DevBuf d_gaps, d_ids, d_flank, d_outs, d_rs, d_rlog, d_keys, d_cnt, d_mark, d_slog, d_subscr, d_subout, d_counter;
+  DevBuf d_xcd;  // segment tier, batched announcements: 8 ticket counters (64 bytes), then 8 lists of finished gaps
   DevBuf d_log, d_lvl, d_plk, d_xl, d_xo;  // LDS tier: state log, level offsets, parent links, closure side lists
   DevBuf d_segx;  // large variant of the segment tier: segment arrays and queues of its persistent workgroups
   int num_cus = 256;
@@ -588,7 +589,7 @@ extern "C" void g2s_session_destroy(g2s_session* s) {
   if (!s) return;
   (void)hipSetDevice(s->device);
   DevBuf* bufs[] = {&s->d_gaps, &s->d_ids, &s->d_flank, &s->d_outs, &s->d_rs, &s->d_rlog, &s->d_keys,
-                    &s->d_cnt, &s->d_mark, &s->d_slog, &s->d_subscr, &s->d_subout, &s->d_counter,
+                    &s->d_cnt, &s->d_mark, &s->d_slog, &s->d_subscr, &s->d_subout, &s->d_counter, &s->d_xcd,
                     &s->d_log, &s->d_lvl, &s->d_plk, &s->d_xl, &s->d_xo, &s->d_rspool, &s->d_logpool, &s->d_segx};
   for (DevBuf* b : bufs) b->release();
   delete s->pool;
@@ -915,7 +916,7 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
   // d_outs, the cursors and the spill pool are reset right after an LDS-tier launch has
   // finished, while the host works on its results: the next launch then starts behind one
   // copy instead of behind three fill kernels (~25 us on the stream)
-  size_t pool_bytes_used = 0;
+  size_t pool_bytes_used = 0, xcd_bytes_used = 0;
   if (s->d_outs.clean < n * sizeof(GapOut)) HIP_TRY(hipMemsetAsync(s->d_outs.p, 0, n * sizeof(GapOut), st));
   if (s->d_counter.clean < 32) HIP_TRY(hipMemsetAsync(s->d_counter.p, 0, 32, st));  // [0] output cursor, [1] completion-list cursor, [2] spill-pool cursor, [3] log-pool cursor
   s->d_outs.clean = 0;
@@ -984,6 +985,21 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
     const uint32_t seg_dbg_w = seg == 2 ? fill_segx_dbg_words() : fill_seg_dbg_words();
     const bool seg_two_waves = getenv("G2S_SEG_WAVES") ? atoi(getenv("G2S_SEG_WAVES")) == 2 : ids.size() <= 2048;
     if (seg == 1 && seg_two_waves) b->timing.seg2_launches++;
+    // finished gaps are announced in batches per XCD (one L2 write-back per batch instead of per gap; fill_seg.hip,
+    // `publish`): 4 on short lists, whose last few gaps this thread then takes when the launch ends, 16 on long
+    // ones.  G2S_PUBLISH_BATCH=1 announces every gap by itself.
+    uint32_t pub_batch = getenv("G2S_PUBLISH_BATCH") ? (uint32_t)atoi(getenv("G2S_PUBLISH_BATCH")) : (ids.size() <= 2048 ? 4u : 16u);
+    size_t xcd_bytes = 0;
+    if (seg == 1 && pub_batch > 1) {
+      xcd_bytes = 64 + 8 * ids.size() * 4;
+      HIP_TRY(s->d_xcd.ensure(xcd_bytes));
+      if (s->d_xcd.clean < xcd_bytes) {
+        HIP_TRY(hipMemsetAsync(s->d_xcd.p, 0, 64, st));
+        HIP_TRY(hipMemsetAsync((char*)s->d_xcd.p + 64, 0xFF, xcd_bytes - 64, st));
+      }
+      s->d_xcd.clean = 0;
+      xcd_bytes_used = xcd_bytes;
+    }
     if (seg_dump) {
       HIP_TRY(s->d_slog.ensure((size_t)ids.size() * seg_dbg_w * 4));
       HIP_TRY(hipMemsetAsync(s->d_slog.p, 0, (size_t)ids.size() * seg_dbg_w * 4, st));
@@ -1005,7 +1021,8 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
                               s->params.skip_confident ? 1 : 0, seg_dbg,
                               // short lists are latency-bound (the launch ends with its slowest gap): two waves per
                               // gap; long lists fill the chip and are throughput-bound: one (G2S_SEG_WAVES=1|2 forces)
-                              seg_two_waves));
+                              seg_two_waves, (unsigned long long*)s->d_xcd.p, (uint32_t*)((char*)s->d_xcd.p + 64),
+                              (uint32_t)ids.size(), pub_batch));
     else
     HIP_TRY(launch_fill_lds(st, (uint32_t)ids.size(), lds_cap_max, num_oriented, dg.succ, dg.ustart,
                             gaps_dev, ids_dev, (const uint32_t*)s->d_flank.p,
@@ -1153,6 +1170,11 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
       s->d_outs.clean = n * sizeof(GapOut);
       HIP_TRY(hipMemsetAsync(s->d_counter.p, 0, 32, st));
       s->d_counter.clean = 32;
+      if (xcd_bytes_used) {
+        HIP_TRY(hipMemsetAsync(s->d_xcd.p, 0, 64, st));
+        HIP_TRY(hipMemsetAsync((char*)s->d_xcd.p + 64, 0xFF, xcd_bytes_used - 64, st));
+        s->d_xcd.clean = xcd_bytes_used;
+      }
       if (pool_bytes_used) {
         HIP_TRY(hipMemsetAsync(s->d_rspool.p, 0xFF, pool_bytes_used, st));
         s->d_rspool.clean = pool_bytes_used;
