@@ -985,10 +985,12 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
     const uint32_t seg_dbg_w = seg == 2 ? fill_segx_dbg_words() : fill_seg_dbg_words();
     const bool seg_two_waves = getenv("G2S_SEG_WAVES") ? atoi(getenv("G2S_SEG_WAVES")) == 2 : ids.size() <= 2048;
     if (seg == 1 && seg_two_waves) b->timing.seg2_launches++;
-    // finished gaps are announced in batches per XCD (one L2 write-back per batch instead of per gap; fill_seg.hip,
-    // `publish`): 4 on short lists, whose last few gaps this thread then takes when the launch ends, 16 on long
-    // ones.  G2S_PUBLISH_BATCH=1 announces every gap by itself.
-    uint32_t pub_batch = getenv("G2S_PUBLISH_BATCH") ? (uint32_t)atoi(getenv("G2S_PUBLISH_BATCH")) : (ids.size() <= 2048 ? 4u : 16u);
+    // long lists: finished gaps are announced in batches of 16 per XCD (one L2 write-back per batch instead of per
+    // gap; fill_seg.hip, `publish`): config 3's launch 0.8 -> 0.48 ms.  Short lists announce every gap by itself:
+    // their launch ends with its slowest gap either way (config 2: 0.152 ms with batches of 4, 0.153 without), and
+    // the gaps of unfinished batches would be analysed behind the launch's end instead of under it (config 2's
+    // step 0.39 ms against 0.37).  G2S_PUBLISH_BATCH=N forces (1 = every gap by itself).
+    uint32_t pub_batch = getenv("G2S_PUBLISH_BATCH") ? (uint32_t)atoi(getenv("G2S_PUBLISH_BATCH")) : (ids.size() <= 2048 ? 1u : 16u);
     size_t xcd_bytes = 0;
     if (seg == 1 && pub_batch > 1) {
       xcd_bytes = 64 + 8 * ids.size() * 4;
