@@ -508,6 +508,10 @@ struct g2s_session {
   size_t mem_budget = 0;  // bytes of HBM this session may use for work areas
   DevBuf d_gaps, d_ids, d_flank, d_outs, d_rs, d_rlog, d_keys, d_cnt, d_mark, d_slog, d_subscr, d_subout, d_counter;
   DevBuf d_xcd;  // segment tier, batched announcements: 8 ticket counters (64 bytes), then 8 lists of finished gaps
+  // the two largest per-gap arrays of a batch, kept from one batch to the next: allocated afresh they are new
+  // pages every time (3 MB per 10 000 gaps: 0.2-0.3 ms of page faults per call)
+  std::vector<SubView> spare_views;
+  std::vector<SubPrep> spare_prep;
   DevBuf d_log, d_lvl, d_plk, d_xl, d_xo;  // LDS tier: state log, level offsets, parent links, closure side lists
   DevBuf d_segx;  // large variant of the segment tier: segment arrays and queues of its persistent workgroups
   int num_cus = 256;
@@ -658,6 +662,8 @@ struct g2s_batch {
       drop_tiers();
       if (s->flank_owner == this) s->flank_owner = nullptr;
       if (pin) s->pin_free.push_back(pin);
+      if (views.capacity() > s->spare_views.capacity()) { views.clear(); s->spare_views.swap(views); }
+      if (prep.capacity() > s->spare_prep.capacity()) s->spare_prep.swap(prep);  // (elements kept: analyze_gap resets what it uses)
     }
   }
 };
@@ -1251,6 +1257,7 @@ static const bool dbg_analysis_stats = getenv("G2S_DEBUG") != nullptr;
 static std::atomic<uint64_t> dbg_ns_seg{0}, dbg_n_seg{0}, dbg_ns_state{0}, dbg_n_state{0}, dbg_states{0};
 
 void analyze_gap(g2s_batch* b, size_t i, const FillParams& fp, g2s_result* r) {
+  b->prep[i].reset();  // (the array is recycled from batch to batch and not wiped in between: 10 000 of these are 0.4 ms)
   g2s_batch::GapInfo& gi = b->info[i];
   gi.fixed[0] = gi.fixed[1] = -1;
   gi.n_len = 0; gi.reached_j = 0; gi.kind = 0; gi.filled = 0;
@@ -1394,6 +1401,8 @@ int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
 
   std::vector<SubView>& views = b->views;
   std::vector<char>& mem_exceeded = b->mem_exceeded;
+  if (views.capacity() < n && s->spare_views.capacity() >= n) views.swap(s->spare_views);
+  if (b->prep.capacity() < n && s->spare_prep.capacity() >= n) b->prep.swap(s->spare_prep);
   views.assign(n, SubView());
   mem_exceeded.assign(n, 0);
   // analysis of finished gaps runs on the pool while the kernel is still busy with the rest
@@ -1401,7 +1410,7 @@ int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
   std::vector<uint32_t> fresh;
   double ms_stream = 0;
   if (analyze) {
-    b->prep.assign(n, SubPrep());
+    b->prep.resize(n);  // (every gap passes through analyze_gap once, which resets its element)
     b->info.assign(n, g2s_batch::GapInfo());
   }
   lap("per-gap arrays");
@@ -1424,53 +1433,94 @@ int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
       post_heavy();
     }
   };
-  const DoneFn on_done = [&](const uint32_t* done_ids, size_t cnt) {
-    auto t0 = std::chrono::steady_clock::now();
+  struct DoneSums { uint64_t xA = 0, sA = 0, xB = 0, sB = 0, xD = 0, sD = 0, segs = 0; uint32_t seg_gaps = 0, segx_gaps = 0; };
+  // a finished gap's view of the launch's buffers and its share of the launch's sums; 0: nothing to analyse (seen
+  // before, or it runs again in a later pass), 1: analyse now, 2: a large closure for the host, analysed without waiting
+  auto admit = [&](uint32_t i, DoneSums& acc) -> int {
+    if (i >= n || analyzed[i]) return 0;
     const GapOut* outs = (const GapOut*)td_live->outs.p;
-    fresh.clear();
-    for (size_t x = 0; x < cnt; x++) {
-      const uint32_t i = done_ids[x];
-      if (i >= n || analyzed[i]) continue;
-      const GapOut& go = outs[i];
-      if (go.flags & (G2S_DEV_OVERFLOW_A | G2S_DEV_OVERFLOW_B)) continue;  // runs again in a later pass
-      if ((go.flags & G2S_DEV_COMPACT) && ((uint64_t)go.n_states > max_states || (uint64_t)go.n_right > max_states))
-        mem_exceeded[i] = 1;  // segment tier: the -max-mem analogue is applied to the state count
-      SubView& v = views[i];
-      v.out = &go;
-      if (go.flags & G2S_DEV_COMPACT) {
-        v.segs = (const SegRec*)((const SubRec*)td_live->subs.p + go.sub_off);
-        v.n_segs = go.n_xl;
-        v.st = nullptr; v.n = 0; v.xp = nullptr; v.n_xp = 0;
-      } else {
-        v.st = (const SubRec*)td_live->subs.p + go.sub_off;
-        v.n = go.n_sub;
-        v.xp = (const uint64_t*)(v.st + go.n_sub);
-        v.n_xp = go.n_xp;
-      }
-      analyzed[i] = 1;
-      fresh.push_back(i);
-      if (seg_mode_live) {  // the launch's bookkeeping while the gap's record is in this core's cache
-        const bool mx = (uint64_t)go.n_states > max_states || (uint64_t)go.n_right > max_states;
-        seg_accounted[i] = mx ? 2 : 1;
-        if (!mx) {
-          b->timing.xA += go.x_right; b->timing.sA += go.n_right;
-          b->timing.xB += go.x_left; b->timing.sB += go.n_states;
-          b->timing.xD += go.x_sub; b->timing.sD += go.n_sub;
-          if (seg_mode_live == 2) b->timing.segx_tier_gaps++; else b->timing.seg_tier_gaps++;
-          b->timing.seg_segments += go.stat[3];
-        }
+    const GapOut& go = outs[i];
+    if (go.flags & (G2S_DEV_OVERFLOW_A | G2S_DEV_OVERFLOW_B)) return 0;  // runs again in a later pass
+    if ((go.flags & G2S_DEV_COMPACT) && ((uint64_t)go.n_states > max_states || (uint64_t)go.n_right > max_states))
+      mem_exceeded[i] = 1;  // segment tier: the -max-mem analogue is applied to the state count
+    SubView& v = views[i];
+    v.out = &go;
+    if (go.flags & G2S_DEV_COMPACT) {
+      v.segs = (const SegRec*)((const SubRec*)td_live->subs.p + go.sub_off);
+      v.n_segs = go.n_xl;
+      v.st = nullptr; v.n = 0; v.xp = nullptr; v.n_xp = 0;
+    } else {
+      v.st = (const SubRec*)td_live->subs.p + go.sub_off;
+      v.n = go.n_sub;
+      v.xp = (const uint64_t*)(v.st + go.n_sub);
+      v.n_xp = go.n_xp;
+    }
+    analyzed[i] = 1;
+    if (seg_mode_live) {  // the launch's bookkeeping while the gap's record is in this core's cache
+      const bool mx = (uint64_t)go.n_states > max_states || (uint64_t)go.n_right > max_states;
+      seg_accounted[i] = mx ? 2 : 1;
+      if (!mx) {
+        acc.xA += go.x_right; acc.sA += go.n_right;
+        acc.xB += go.x_left; acc.sB += go.n_states;
+        acc.xD += go.x_sub; acc.sD += go.n_sub;
+        if (seg_mode_live == 2) acc.segx_gaps++; else acc.seg_gaps++;
+        acc.segs += go.stat[3];
       }
     }
     // Closures of many thousand states that the host has to analyse (the large variant's gaps, a k-mer at two
     // depths: milliseconds each) go to the pool WITHOUT waiting for them: this thread keeps polling, and
     // whatever has arrived by the time the pool is free again forms the next job.
+    const bool heavy = v.segs && !(go.dflags & G2S_DEVA_ANALYSED) && go.n_sub >= 4000;
+    return heavy ? 2 : 1;
+  };
+  auto add_sums = [&](const DoneSums& acc) {
+    b->timing.xA += acc.xA; b->timing.sA += acc.sA;
+    b->timing.xB += acc.xB; b->timing.sB += acc.sB;
+    b->timing.xD += acc.xD; b->timing.sD += acc.sD;
+    b->timing.seg_tier_gaps += acc.seg_gaps; b->timing.segx_tier_gaps += acc.segx_gaps;
+    b->timing.seg_segments += acc.segs;
+  };
+  std::mutex done_mu;
+  const DoneFn on_done = [&](const uint32_t* done_ids, size_t cnt) {
+    auto t0 = std::chrono::steady_clock::now();
+    if (cnt >= 512) {
+      // A hand-over of a long list: the finished gaps' records were written by the GPU and are in no core's cache,
+      // so even the set-up above is a memory round trip or two per gap (10 000 gaps: 1 ms on this thread, twice the
+      // kernel's time) — all of it goes to the pool, a few gaps per task.
+      s->pool->finish();  // (a job of heavy closures may still be open)
+      const size_t per = 16, nt = (cnt + per - 1) / per;
+      s->pool->run(nt, [&](size_t t) {
+        DoneSums acc;
+        uint32_t heavy_here[16];
+        size_t nh = 0;
+        const size_t lo = t * per, hi = std::min(cnt, lo + per);
+        const GapOut* outs = (const GapOut*)td_live->outs.p;
+        for (size_t x = lo; x < hi; x++)
+          if (done_ids[x] < n) __builtin_prefetch(&outs[done_ids[x]]);
+        for (size_t x = lo; x < hi; x++) {
+          const uint32_t i = done_ids[x];
+          const int c = admit(i, acc);
+          if (c == 1) analyze_gap(b, i, fp, &results[i]);
+          else if (c == 2) heavy_here[nh++] = i;
+        }
+        std::lock_guard<std::mutex> lk(done_mu);
+        add_sums(acc);
+        for (size_t h = 0; h < nh; h++) heavy_wait.push_back(heavy_here[h]);
+      });
+      if (!heavy_wait.empty() && s->pool->idle()) post_heavy();
+      ms_stream += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      return;
+    }
+    fresh.clear();
     {
-      size_t w = 0;
-      for (uint32_t i : fresh) {
-        const bool heavy = views[i].segs && !(views[i].out->dflags & G2S_DEVA_ANALYSED) && views[i].out->n_sub >= 4000;
-        if (heavy) heavy_wait.push_back(i); else fresh[w++] = i;
+      DoneSums acc;
+      for (size_t x = 0; x < cnt; x++) {
+        const uint32_t i = done_ids[x];
+        const int c = admit(i, acc);
+        if (c == 1) fresh.push_back(i);
+        else if (c == 2) heavy_wait.push_back(i);
       }
-      fresh.resize(w);
+      add_sums(acc);
     }
     size_t work = 0;
     for (uint32_t i : fresh)  // (closure states to look at; 2 for a gap analysed on the device)
@@ -1832,7 +1882,7 @@ int batches_stage2(const std::vector<g2s_batch*>& bs, g2s_session* lead, g2s_res
   {
     size_t apos = 0, gi = 0;
     for (g2s_batch* b : bs) {
-      if (analyze) { b->prep.assign(b->jobs.size(), SubPrep()); b->info.assign(b->jobs.size(), g2s_batch::GapInfo()); }
+      if (analyze) { b->prep.resize(b->jobs.size()); b->info.assign(b->jobs.size(), g2s_batch::GapInfo()); }
       for (size_t i = 0; i < b->jobs.size(); i++, gi++) {
         arena_off[gi] = apos;
         apos += b->jobs[i].buf_bytes(g.k, fp.d_err);

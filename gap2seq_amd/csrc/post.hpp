@@ -129,6 +129,16 @@ struct SubPrep {
   std::vector<SubRec> own;    // segment tier: this gap's expanded closure when the launch's shared buffer is full
   int start_idx[2] = {-1, -1};  // state index of (reachedTarget, pathLengths[i])
   int stop_depth[2] = {-1, -1}; // depth every traceback from start i stops at, or -1 when it depends on the draws
+  // back to the state of a new object, keeping the vectors' storage (the per-gap array of a batch is recycled)
+  void reset() {
+    seg_mode = false; seg = nullptr; s_iv = nullptr; n_iv = 0; own_seg.clear();
+    sink_safe = has_choice = run_mode = false; runs.clear(); stop = nullptr;
+    start_seg[0] = start_seg[1] = -1; start_t[0] = start_t[1] = 0;
+    phase_d = false; count = 0; flags = 0;
+    for (int q = 0; q < 6; q++) sub[q] = 0;
+    safe.clear(); own.clear();
+    start_idx[0] = start_idx[1] = -1; stop_depth[0] = stop_depth[1] = -1;
+  }
 };
 
 // SCC / branch rule / stop-depth analysis of one gap; thread safe.
