@@ -1500,7 +1500,9 @@ int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
         for (size_t x = lo; x < hi; x++) {
           const uint32_t i = done_ids[x];
           const int c = admit(i, acc);
-          if (c == 1) analyze_gap(b, i, fp, &results[i]);
+          // (a closure of a few thousand states takes 20-40 us on the host: nothing to set aside when the whole
+          // pool is at work on this hand-over; the closures of the large variant's gaps still are)
+          if (c == 1 || (c == 2 && views[i].out->n_sub < 50000u)) analyze_gap(b, i, fp, &results[i]);
           else if (c == 2) heavy_here[nh++] = i;
         }
         std::lock_guard<std::mutex> lk(done_mu);
@@ -1840,7 +1842,7 @@ int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
     auto t_post = std::chrono::steady_clock::now();
     fresh.clear();
     for (size_t i = 0; i < n; i++) if (!analyzed[i]) fresh.push_back((uint32_t)i);
-    const size_t per = 8, nt = (fresh.size() + per - 1) / per;
+    const size_t per = fresh.size() >= 64 ? 8 : 1, nt = (fresh.size() + per - 1) / per;
     s->pool->run(nt, [&](size_t t) {
       for (size_t x = t * per; x < std::min(fresh.size(), (t + 1) * per); x++) analyze_gap(b, fresh[x], fp, &results[fresh[x]]);
     });

@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU box: two builds of the library (gap2seq_amd/_ab/old.so, new.so) against each other, interleaved, on one box.
-for rep in 1 2 3 4; do
+for rep in 1 2 3 4 5 6; do
   for v in old new; do
     cp gap2seq_amd/_ab/$v.so gap2seq_amd/libg2s_hip.so
     timeout 200 python bench.py --no-cpu-baseline "$@" < /dev/null | python tools/bsum.py $v | cut -c1-330
