@@ -3,7 +3,8 @@
 // aligned an insert size away from the breakpoint, the reads overlapping the flanks — or every unmapped read.
 // Host string work on the wrapper's side of Gap2Seq-core (Gap2Seq.py:64-72,145-149); BAM input through bam.hpp
 // (zlib) instead of htslib, no GATB.  Output order, names ("/1", "/2"), reverse-complementing and the name filter
-// follow the reference line by line in MEANING; the passes over the file are arranged differently (see below).
+// follow the reference line by line in MEANING; the passes over the file are arranged differently (two instead
+// of five, see below).
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -103,34 +104,53 @@ int run_filter(g2s::BamFile& bam, const g2s_filter_opts* o, char** fasta_out, ch
                int64_t* extracted_out, int64_t* total_out) {
   std::string err, warn, fasta, region_fasta;
   bam.set_threads(o->threads > 0 ? o->threads : (int)std::min(8u, std::max(1u, std::thread::hardware_concurrency())));
-  // pass 1 (:225-241): the number of records and the longest read
+  // pass 1 (:225-241): the number of records and the longest read.  The windows of pass 2 depend on that length, so
+  // they cannot be applied yet — but only reads of the gap's scaffold whose mate is unmapped can ever be in them:
+  // those are remembered (position, end, name), which saves the reference's pass over the file for them unless
+  // there are millions.
   uint64_t total = 0;
   int32_t read_length = 0;
-  if (!bam.for_each([&](const g2s::BamRec& r) { total++; read_length = std::max(read_length, r.l_seq); return true; }, &err)) {
+  const int tid = o->unmapped_only ? -1 : bam.ref_id(o->scaffold ? o->scaffold : "");  // :381
+  struct Cand { int64_t pos, end; std::string name; };
+  std::vector<Cand> cands;
+  // (G2S_FILTER_MAX_CANDS: the tests make it small to take the pass over the file instead)
+  const size_t kMaxCands = getenv("G2S_FILTER_MAX_CANDS") ? (size_t)atoll(getenv("G2S_FILTER_MAX_CANDS")) : (size_t)2 << 20;
+  bool cands_complete = true;
+  if (!bam.for_each([&](const g2s::BamRec& r) {
+        total++;
+        read_length = std::max(read_length, r.l_seq);
+        if (tid >= 0 && r.ref_id == tid && (r.flag & g2s::BAM_MATE_UNMAPPED)) {
+          if (cands.size() < kMaxCands) cands.push_back({(int64_t)r.pos, r.end_pos(), own_name(r)});
+          else cands_complete = false;
+        }
+        return true;
+      }, &err)) {
     rf_error = err;
     return G2S_ERR_IO;
   }
   NameFilter names(5 * total);  // :371
   int64_t extracted = 0;
   if (!o->unmapped_only) {
-    const int tid = bam.ref_id(o->scaffold ? o->scaffold : "");  // :381
     // :383-390: where a read must align for its mate to fall in the gap (the right-hand window as written there)
     const int64_t bp = o->breakpoint, mu = o->mean_insert, sd = o->std_dev, gl = o->gap_length, rl = read_length;
     const Region left = make_region(tid, bp - (mu + 3 * sd + 2 * rl), bp - (mu - 3 * sd + rl), &warn);
     const Region right = make_region(tid, bp + (mu + 3 * sd + rl) + gl, bp + (mu - 3 * sd + rl) + gl, &warn);
     // pass 2 (:300-310): names of reads in the windows whose mate is unmapped
-    if (left.valid || right.valid) {
-      std::vector<std::string> lnames, rnames;  // (the left window's before the right's; order does not matter to a set)
+    auto in_window = [](int64_t pos, int64_t end, const Region& q) { return q.valid && pos < q.end && end > q.beg; };
+    if ((left.valid || right.valid) && cands_complete) {
+      for (const Cand& c : cands)
+        if (in_window(c.pos, c.end, left) || in_window(c.pos, c.end, right)) names.insert(c.name);
+    } else if (left.valid || right.valid) {
       if (!bam.for_each([&](const g2s::BamRec& r) {
             if (!(r.flag & g2s::BAM_MATE_UNMAPPED)) return true;
-            if (overlaps(r, left)) names.insert(own_name(r));
-            if (overlaps(r, right)) names.insert(own_name(r));
+            if (overlaps(r, left) || overlaps(r, right)) names.insert(own_name(r));
             return true;
           }, &err)) {
         rf_error = err;
         return G2S_ERR_IO;
       }
     }
+    std::vector<Cand>().swap(cands);
     // pass 3: (:313-323) every record whose MATE's name is in the filter, then (:395-399, :283-297) the reads
     // overlapping the flanks whose own name is not — the reference makes two passes and writes as it goes;
     // here the second list is collected beside the first and appended

@@ -157,11 +157,14 @@ def test_records_spanning_refills(tmp_path):
     path.write_bytes(bam)
     out = tmp_path / "r.fa"
     want = REF.read_filter(bam, 300, 20, "scaf1", 1400, 200, 100)
-    for chunk in ("1500", "401", "70000"):
+    for chunk, cands in (("1500", None), ("401", None), ("70000", None), ("70000", "3"), ("1500", "0")):
+        env = dict(os.environ, G2S_BAM_CHUNK=chunk)
+        if cands is not None:  # more window candidates than the filter remembers in its first pass: it reads the file again
+            env["G2S_FILTER_MAX_CANDS"] = cands
         r = subprocess.run([BIN, "-reads", str(out), "-scaffold", "scaf1", "-breakpoint", "1400", "-flank-length", "100",
                             "-gap-length", "200", "-bam", str(path), "-mean", "300", "-std-dev", "20"], capture_output=True,
-                           text=True, env=dict(os.environ, G2S_BAM_CHUNK=chunk))
-        assert r.returncode == 0 and r.stdout == want[1] and out.read_text() == want[0], chunk
+                           text=True, env=env)
+        assert r.returncode == 0 and r.stdout == want[1] and out.read_text() == want[0], (chunk, cands)
         out.unlink()
 
 
