@@ -29,6 +29,26 @@ def _both(bam, **kw):
     return got
 
 
+def test_golden_cases():
+    """tests/golden/readfilter_cases.json (make_readfilter_golden.py): a committed BAM file and the committed
+    answers, against the product AND against the restatement."""
+    import base64
+    import json
+    g = json.load(open(os.path.join(HERE, "golden", "readfilter_cases.json")))
+    bam = base64.b64decode(g["bam_base64"])
+    assert len(g["calls"]) >= 6
+    n = 0
+    for c in g["calls"]:
+        kw = c["args"]
+        got = P.filter_reads(bam, **kw)
+        assert got[:3] == (c["fasta"], c["stdout"], c["stderr"]) and got[4] == g["records"]
+        want = REF.read_filter(bam, kw["mean"], kw["std_dev"], kw["scaffold"], kw["breakpoint"], kw.get("gap_length", -1),
+                               kw.get("flank_length", -1), kw.get("unmapped_only", False))
+        assert want == (c["fasta"], c["stdout"], c["stderr"])
+        n += got[3]
+    assert n > 10
+
+
 def test_std_hash_restatement_is_libstdcxx(tmp_path):
     """The checker's std::hash<std::string> against the compiler's own."""
     names = ["", "a", "r00001/1", "r00001/2", "abcdefgh", "abcdefghi", "x" * 31, "read:with:colons/2", "0123456789abcdef"]
