@@ -64,6 +64,42 @@ def parse_gaps(scaffolds_text, fuz):
     return out
 
 
+UNITS_FILE = os.path.join(ROOT, "profiles", "oracle_units.json")
+GENOME_SEED, GAP_SEED = 20240101, 20240103
+
+
+def units_key(genome_bp, variant, k, ngaps, min_len, max_len, fuz, d_err):
+    """Key of a synthetic workload in profiles/oracle_units.json (written by tools/oracle_units.py)."""
+    return "genome%d.V%d.seed%d|k%d|gaps%d.len%d-%d.seed%d|fuz%d|e%d" % (
+        genome_bp, variant, GENOME_SEED, k, ngaps, min_len, max_len, GAP_SEED, fuz, d_err)
+
+
+def load_oracle_units():
+    try:
+        with open(UNITS_FILE) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return {}
+
+
+def oracle_units(key, count_now=None):
+    """(X, S, source) of SURVEY.md 8(d) for one workload, ALWAYS the CPU oracle's counts of the reference
+    algorithm's expansions and newly set states over phases A, B and D1 (Gap2Seq.cpp:912,930,1031,1049-1065,
+    1266-1301): from the committed table (tools/oracle_units.py ran the oracle over the whole list), else counted
+    in this run by count_now() (the cpu_baseline leg, all host cores), else (None, None, why) — and then no
+    roofline fraction is printed.  The kernels' own counters are never used for this: the segment tier does not
+    perform those expansions one by one, its phase A counter is an upper bound (1.64x on config 3)."""
+    u = load_oracle_units().get(key)
+    if u:
+        return (u["xA"] + u["xB"] + u["xD"], u["sA"] + u["sB"] + u["sD"],
+                "oracle (profiles/oracle_units.json: %s threads over all %d gaps)" % (u.get("threads", "?"), u["gaps"]))
+    if count_now is not None:
+        c = count_now()
+        if c is not None:
+            return c[0] + c[2] + c[4], c[1] + c[3] + c[5], "oracle (counted in this run over the whole list)"
+    return None, None, "unavailable: workload not in profiles/oracle_units.json and the oracle did not cover the whole list"
+
+
 def algorithmic_bytes(x, s, io_bytes):
     """24 B per expansion (4 B frontier id + 16 B successor record +
     4 B next-frontier write) + 8 B per newly set state + per-gap flank/fill I/O."""
@@ -202,9 +238,9 @@ def main():
 
     # ---- workload (untimed) -------------------------------------------------------
     t0 = time.time()
-    reads = P.G2S.synth_genome(genome_bp, args.variant, 20240101)
+    reads = P.G2S.synth_genome(genome_bp, args.variant, GENOME_SEED)
     seqs = [ln for ln in reads.splitlines() if not ln.startswith(">")]
-    gaps = parse_gaps(P.G2S.synth_gaps(reads, k, args.fuz, ngaps, min_len, max_len, 20240103), args.fuz)
+    gaps = parse_gaps(P.G2S.synth_gaps(reads, k, args.fuz, ngaps, min_len, max_len, GAP_SEED), args.fuz)
     t_synth = time.time() - t0
     t0 = time.time()
     os.environ["G2S_DEVICE"] = str(devices[0])  # the graph is built on (and stays on) the first GPU
@@ -278,7 +314,7 @@ def main():
     # ---- N=1 on C2: config 3's list on this one GPU, beside the headline ----------------------
     c3_beside = None
     if ngpu == 1 and cfg_name == "C2" and not custom and not args.no_c3_beside:
-        g3 = parse_gaps(P.G2S.synth_gaps(reads, k, args.fuz, 10000, min_len, max_len, 20240103), args.fuz)
+        g3 = parse_gaps(P.G2S.synth_gaps(reads, k, args.fuz, 10000, min_len, max_len, GAP_SEED), args.fuz)
         r3 = Runner(P, sessions[:1], g3, 0)
         for _ in range(2):
             r3.step()
@@ -288,15 +324,16 @@ def main():
             k3 += r3.timing().ms_fill_seg if r3.timing().seg_tier_gaps else r3.timing().ms_fill_lds
         tm3 = r3.timing()
         nl3 = max(1, tm3.seg_launches if tm3.seg_tier_gaps else tm3.lds_launches)
-        x3, s3 = tm3.xA + tm3.xB + tm3.xD, tm3.sA + tm3.sB + tm3.sD
-        ab3 = algorithmic_bytes(x3, s3, tm3.flank_bytes + tm3.fill_bytes) / nl3
+        x3, s3, by3 = oracle_units(units_key(genome_bp, args.variant, k, 10000, min_len, max_len, args.fuz, d_err))
         kms3 = k3 / n3 / nl3
+        ab3 = algorithmic_bytes(x3, s3, tm3.flank_bytes + tm3.fill_bytes) / nl3 if x3 is not None else None
         c3_beside = dict(workload=CONFIGS["C3"][6], value=round(10000 * n3 / t3, 2), unit="gaps/s", steps=n3,
                          ms_per_step=round(t3 / n3 * 1e3, 4),
                          kernel=("g2s_fill_seg2" if tm3.seg2_launches else "g2s_fill_seg") if tm3.seg_tier_gaps else "g2s_fill_lds",
                          kernel_ms_per_launch=round(kms3, 4), gaps_left_to_other_kernels=10000 - max(tm3.seg_tier_gaps, tm3.lds_tier_gaps),
-                         launches_per_step=nl3, algorithmic_bytes_per_launch=ab3,
-                         units_counted_by="product", roofline_frac=round(ab3 / (kms3 / 1e3) / 1e9 / HBM_PEAK_GBS, 6),
+                         launches_per_step=nl3, algorithmic_bytes_per_launch=ab3, expansions=x3, states=s3,
+                         units_counted_by=by3,
+                         roofline_frac=round(ab3 / (kms3 / 1e3) / 1e9 / HBM_PEAK_GBS, 6) if ab3 is not None else None,
                          filled=sum(1 for r in r3.results() if r.count > 0))
 
     # ---- CPU baseline: the oracle (port of the reference algorithm) on the GPU box's host cores,
@@ -326,6 +363,11 @@ def main():
                    oracle_states_A_B_D1=[octr[1], octr[3], octr[5]])
         if len(sample) != len(gaps):
             octr = None  # the oracle's unit counts cover the sample only
+            key = units_key(genome_bp, args.variant, k, len(gaps), min_len, max_len, args.fuz, d_err)
+            if key not in load_oracle_units() and len(gaps) / (len(sample) / sN) < 90.0:
+                # a list the committed table does not hold: the units of the WHOLE list, all cores, untimed
+                _, _, octr = O.time_fill_batch(og, gaps, d_err, ncpu)
+                cpu["oracle_units_counted_over"] = "the whole list of %d gaps, %d threads" % (len(gaps), ncpu)
         og.free()
 
     # ---- roofline of the dominant kernel, its duration measured with HIP events on the session
@@ -333,20 +375,18 @@ def main():
     # runs phases A (right search), B (left DP), C (target check) and D1 (closure) of every gap that
     # fits the LDS tier.  Algorithmic bytes = 24 B per expansion + 8 B per newly set
     # state over phases A, B and D1 + per-gap flank/fill I/O, with the unit counts of the REFERENCE
-    # algorithm as counted by the CPU oracle on the same gaps when the CPU leg covered the whole
-    # list (the product's own counters are lower for phase A: it visits every node once, the
-    # reference re-expands nodes reached by walks of several lengths); otherwise the product's
-    # counters, labelled so.
+    # algorithm as counted by the CPU ORACLE over the whole list (oracle_units above: the committed
+    # table profiles/oracle_units.json, or counted by the cpu_baseline leg of this run).  Without an
+    # oracle count no fraction is printed; the kernels' own counters never price a roofline.
     io_bytes = tm.flank_bytes + tm.fill_bytes
     seg_gaps = tm.seg_tier_gaps + tm.segx_tier_gaps
+    x_units, s_units, counted_by = oracle_units(
+        units_key(genome_bp, args.variant, k, len(gaps), min_len, max_len, args.fuz, d_err),
+        (lambda: octr) if octr is not None else None)
     if seg_gaps > 0 and seg_gaps >= tm.lds_tier_gaps:
-        # the segment tier took (most of) the list: phases A-D1 over unitig segments, one wave per gap
+        # the segment tier took (most of) the list: phases A-D2 over unitig segments, one wave per gap
         # (short lists run two waves per gap: the same code as g2s_fill_seg, phase A on the second wave)
         kname = "g2s_fill_seg2" if tm.seg2_launches else "g2s_fill_seg"
-        if octr is not None and tm.seg_tier_gaps == len(gaps):
-            x_units, s_units, counted_by = octr[0] + octr[2] + octr[4], octr[1] + octr[3] + octr[5], "oracle"
-        else:
-            x_units, s_units, counted_by = tm.xA + tm.xB + tm.xD, tm.sA + tm.sB + tm.sD, "product"
         launches = acc["seg_launches"] / float(steps)
         kern_ms = acc["ms_fill_seg"] / max(1, acc["seg_launches"])  # average launch duration
         if tm.segx_tier_gaps > 0:
@@ -355,18 +395,17 @@ def main():
             kern_ms = (acc["ms_fill_seg"] + acc["ms_fill_segx"]) / max(1, acc["seg_launches"])
     elif tm.lds_tier_gaps > 0:
         kname = "g2s_fill_lds"
-        if octr is not None and tm.lds_tier_gaps == len(gaps):
-            x_units, s_units, counted_by = octr[0] + octr[2] + octr[4], octr[1] + octr[3] + octr[5], "oracle"
-        else:
-            x_units, s_units, counted_by = tm.xA + tm.xB + tm.xD, tm.sA + tm.sB + tm.sD, "product"
         launches = acc["lds_launches"] / float(steps)
         kern_ms = acc["ms_fill_lds"] / max(1, acc["lds_launches"])  # average launch duration
     else:
-        kname, x_units, s_units, counted_by = "g2s_left_dp", tm.xB, tm.sB, "product"
+        kname = "g2s_left_dp"
         launches = max(1.0, acc["launches"] / float(steps))
         kern_ms = acc["ms_left_dp"] / max(1, acc["launches"])
-    alg_bytes = algorithmic_bytes(x_units, s_units, io_bytes) / max(1.0, launches)  # per launch
-    achieved = alg_bytes / (kern_ms / 1e3) / 1e9 if kern_ms > 0 else 0.0
+    if x_units is not None:
+        alg_bytes = algorithmic_bytes(x_units, s_units, io_bytes) / max(1.0, launches)  # per launch
+        achieved = alg_bytes / (kern_ms / 1e3) / 1e9 if kern_ms > 0 else 0.0
+    else:
+        alg_bytes, achieved = None, None  # no oracle count for this list: no fraction is quoted
     traffic, traffic_src = None, None
     pmc = os.path.join(ROOT, "profiles", "r02_pmc_fill_seg.json")
     if os.path.exists(pmc) and kname == "g2s_fill_seg2" and cfg_name == "C2" and not custom and ngpu == 1:
@@ -378,8 +417,10 @@ def main():
                               "separate passes of this command; not measured in this run)"
         except Exception:
             traffic = None
-    roofline = dict(bound="hbm", kernel=kname, achieved=round(achieved, 3), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(achieved / HBM_PEAK_GBS, 6), traffic=traffic, traffic_source=traffic_src,
+    roofline = dict(bound="hbm", kernel=kname, achieved=round(achieved, 3) if achieved is not None else None,
+                    peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(achieved / HBM_PEAK_GBS, 6) if achieved is not None else None,
+                    traffic=traffic, traffic_source=traffic_src,
                     algorithmic_bytes_per_launch=alg_bytes, expansions=x_units, states=s_units,
                     units_counted_by=counted_by, kernel_ms_per_launch=round(kern_ms, 4),
                     launches_per_step=round(launches, 3), seg_tier_gaps=tm.seg_tier_gaps, segx_tier_gaps=tm.segx_tier_gaps, lds_tier_gaps=tm.lds_tier_gaps,

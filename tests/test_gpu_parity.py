@@ -431,7 +431,7 @@ def test_bench_one_gpu_line(product):
     b = out["breakdown_ms_per_step"]
     assert 0 < b["prepare_flank_lookup_and_upload"] < b["wall_inside_the_abi_call"] <= out["ms_per_step"] * 1.05
     assert out["cpu_baseline"]["kind"] == "port" and out["cpu_baseline"]["cores"] == 1
-    assert out["roofline"]["units_counted_by"] == "oracle" and 0 < out["roofline"]["frac"] < 1
+    assert out["roofline"]["units_counted_by"].startswith("oracle (counted in this run") and 0 < out["roofline"]["frac"] < 1
     assert out["filled"] >= 190
 
 

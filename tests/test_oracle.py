@@ -248,3 +248,25 @@ def test_oracle_cli_accepts_wrapper_argv(oracle, tmp_path):
     assert res.returncode == 0
     assert "Filled 1 gaps out of 1" in res.stdout
     assert out.read_text().splitlines()[1].upper() == seqs[0][200 - k - 4 - 5:200 + 20 + k + 4 + 5].upper()
+
+
+def test_committed_oracle_units_are_the_oracles(oracle, product):
+    """profiles/oracle_units.json prices bench.py's rooflines (X and S are "counted by the CPU
+    oracle"): the table's entry for the headline workload (BASELINE config 2) and for config 3's share of one
+    GPU at 8 GPUs must be what the oracle counts on those lists now, and an unknown workload has no entry."""
+    import bench
+    for ngaps in (500, 1250):
+        key = bench.units_key(3000000, 3, 31, ngaps, 200, 1000, 10, 500)
+        u = bench.load_oracle_units()[key]
+        reads = product.G2S.synth_genome(3000000, 3, bench.GENOME_SEED)
+        seqs = [ln for ln in reads.splitlines() if not ln.startswith(">")]
+        gaps = bench.parse_gaps(product.G2S.synth_gaps(reads, 31, 10, ngaps, 200, 1000, bench.GAP_SEED), 10)
+        og = oracle.OracleGraph(seqs, 31, 1)
+        _, filled, c = oracle.time_fill_batch(og, gaps, 500, 4)
+        og.free()
+        assert [u["xA"], u["sA"], u["xB"], u["sB"], u["xD"], u["sD"]] == c and u["filled"] == filled == ngaps
+        x, s, by = bench.oracle_units(key)
+        assert (x, s) == (c[0] + c[2] + c[4], c[1] + c[3] + c[5]) and by.startswith("oracle")
+    x, s, by = bench.oracle_units(bench.units_key(3000000, 3, 31, 499, 200, 1000, 10, 500))
+    assert x is None and s is None and by.startswith("unavailable")
+    assert bench.oracle_units("no such workload", lambda: [1, 2, 3, 4, 5, 6]) == (9, 12, "oracle (counted in this run over the whole list)")
