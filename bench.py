@@ -109,15 +109,23 @@ def algorithmic_bytes(x, s, io_bytes):
 class Runner:
     """The boundary call of one step, with every buffer allocated once."""
 
-    def __init__(self, P, sessions, gaps, group):
+    def __init__(self, P, sessions, gaps, group, pinned=True):
         self.P, self.lib = P, P.load_library()
         self.sessions = sessions
         self.n = len(gaps)
         self.group = group
         self.arr, self._keep = P._gap_array([P.Gap(g["left"], g["right"], g["gap_len"], g["lmf"], g["rmf"]) for g in gaps])
         self.nbytes = self.lib.g2s_team_arena_bytes(sessions[0].h, self.arr, self.n)
-        self.arena = C.create_string_buffer(max(1, self.nbytes))
-        self.res = (P.g2s_result * max(1, self.n))()
+        # the caller's buffers, allocated once: page-locked through the ABI (g2s_host_alloc) so that a list finished on
+        # the device is written there by the kernels themselves; --pageable-buffers takes ordinary memory (staged copy)
+        if pinned:
+            self._bufs = [P.HostBuffer(max(1, self.nbytes)), P.HostBuffer(C.sizeof(P.g2s_result) * max(1, self.n))]
+            self.arena = C.cast(self._bufs[0].p, C.c_char_p)
+            self.res = self._bufs[1].array(P.g2s_result, max(1, self.n))
+        else:
+            self._bufs = []
+            self.arena = C.create_string_buffer(max(1, self.nbytes))
+            self.res = (P.g2s_result * max(1, self.n))()
         self.hs = (C.c_void_p * len(sessions))(*[s.h for s in sessions])
         self.tm = P.g2s_timing()
 
@@ -140,8 +148,13 @@ class Runner:
         return self.tm
 
     def results(self):
-        raw = self.arena.raw
+        raw = self._bufs[0].raw if self._bufs else self.arena.raw
         return [self.P.FillResult(self.res[i], raw) for i in range(self.n)]
+
+    def free(self):
+        for hb in self._bufs:
+            hb.free()
+        self._bufs = []
 
 
 def result_key(r):
@@ -172,6 +185,8 @@ def main():
                     help="untimed steps run for this long before the W warm-up steps (a fresh box starts with idle CPU "
                          "clocks, sleeping worker threads and unallocated pinned buffers: the first ~0.1 s of steps run "
                          "up to 40 %% slower); reported as priming_steps")
+    ap.add_argument("--pageable-buffers", action="store_true",
+                    help="results and fill arena in ordinary memory instead of g2s_host_alloc's page-locked memory")
     ap.add_argument("--backend", default="gloo", help="torch.distributed backend for the barriers under torchrun")
     ap.add_argument("--share-device", action="store_true", help="testing only: all N sessions on HIP device 0")
     ap.add_argument("--dry-run", action="store_true",
@@ -259,7 +274,7 @@ def main():
     group = args.group
     if group < 0:
         group = 0 if len(sessions) == 1 else shard.group_size(len(gaps), len(sessions))
-    run = Runner(P, sessions, gaps, group)
+    run = Runner(P, sessions, gaps, group, not args.pageable_buffers)
 
     priming_steps = 0
     t_prime = time.perf_counter()
@@ -269,7 +284,7 @@ def main():
     for _ in range(warmup):
         run.step()
     acc = dict(ms_right_bfs=0.0, ms_left_dp=0.0, ms_extract=0.0, ms_fill_lds=0.0, ms_extract_lds=0.0, ms_d2h=0.0,
-               ms_host_post=0.0, ms_prepare=0.0, ms_total=0.0, ms_fill_seg=0.0, ms_fill_segx=0.0, launches=0,
+               ms_host_post=0.0, ms_prepare=0.0, ms_total=0.0, ms_fill_seg=0.0, ms_fill_segx=0.0, ms_d3=0.0, launches=0,
                lds_launches=0, seg_launches=0, segx_launches=0)
     in_call = 0.0
     barrier()
@@ -278,7 +293,7 @@ def main():
         in_call += run.step()
         tm = run.timing()
         for key in ("ms_right_bfs", "ms_left_dp", "ms_extract", "ms_fill_lds", "ms_extract_lds", "ms_d2h",
-                    "ms_host_post", "ms_prepare", "ms_total", "ms_fill_seg", "ms_fill_segx"):
+                    "ms_host_post", "ms_prepare", "ms_total", "ms_fill_seg", "ms_fill_segx", "ms_d3"):
             acc[key] += getattr(tm, key)
         acc["launches"] += tm.launches_left_dp
         acc["lds_launches"] += tm.lds_launches
@@ -297,7 +312,7 @@ def main():
     one_gpu = None
     if len(sessions) > 1:
         solo = make_sessions(devices[:1], 1)
-        r1 = Runner(P, solo, gaps, 0)
+        r1 = Runner(P, solo, gaps, 0, not args.pageable_buffers)
         r1.step()
         same = [result_key(a) for a in r1.results()] == [result_key(b) for b in res]
         if not same:
@@ -315,7 +330,7 @@ def main():
     c3_beside = None
     if ngpu == 1 and cfg_name == "C2" and not custom and not args.no_c3_beside:
         g3 = parse_gaps(P.G2S.synth_gaps(reads, k, args.fuz, 10000, min_len, max_len, GAP_SEED), args.fuz)
-        r3 = Runner(P, sessions[:1], g3, 0)
+        r3 = Runner(P, sessions[:1], g3, 0, not args.pageable_buffers)
         for _ in range(2):
             r3.step()
         n3, t3, k3 = 10, 0.0, 0.0
@@ -456,10 +471,15 @@ def main():
         "q7_gaps": q7,
         "priming_steps": priming_steps,
         "retried_gaps": tm.retried_gaps,
+        "resident": {"lists_finished_on_the_device": tm.resident_launches, "lists_given_back_to_the_host_path": tm.resident_fallbacks,
+                     "draw_dependent_gaps": tm.draw_dependent_gaps, "draw_count_table_entries": tm.d3_table_entries,
+                     "gaps_finished_by_the_host": tm.host_finished_gaps,
+                     "buffers": "pageable" if args.pageable_buffers else "page-locked (g2s_host_alloc)"},
         "breakdown_ms_per_step": {"wall_inside_the_abi_call": round(in_call / steps * 1e3, 4),
                                   "prepare_flank_lookup_and_upload": per_step("ms_prepare"),
                                   "fill_seg_kernel": per_step("ms_fill_seg"),
                                   "fill_segx_kernel": per_step("ms_fill_segx"),
+                                  "phase_d3_kernels": per_step("ms_d3"),
                                   "fill_lds_kernel": per_step("ms_fill_lds"),
                                   "extract_lds_kernel": per_step("ms_extract_lds"),
                                   "hbm_tier_kernels": round((acc["ms_right_bfs"] + acc["ms_left_dp"] +

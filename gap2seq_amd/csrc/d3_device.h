@@ -1,0 +1,119 @@
+// gap2seq_amd/csrc/d3_device.h — phase D3 of fill_gap on the device (d3_device.hip): the rand() stream,
+// the stream offsets of every gap of a list and the tracebacks (/root/reference/src/Gap2Seq.cpp:178,
+// 1437-1522), for lists whose gaps all finished in the segment tier with phase D2 done by the kernel.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+#include "fill_device.h"
+
+#define G2S_D3_BLOCK_VARS 16u            /* draw-dependent gaps per block of the offset chain */
+#define G2S_RAND_BLOCK 4096u             /* values one wave of g2s_rand_fill generates (64 per lane) */
+#define G2S_RAND_WINDOW 160u             /* words of the stream the host hands over (31 of state + what the jumps read) */
+#define G2S_D3_TABLE_BUDGET (8u << 20)   /* entries of the draw-count tables a list may need */
+
+/* D3Summary.status */
+#define G2S_D3_UNHANDLED 0x1u  /* a gap overflowed the segment tier, or its closure was left to the host's analysis */
+#define G2S_D3_BUDGET 0x2u     /* the draw-count tables would not fit */
+#define G2S_D3_ANOMALY 0x4u    /* a walk met something the host path has to look at (never expected) */
+
+namespace g2s {
+
+// one gap of the list, host -> device
+struct D3Gap {
+  uint64_t arena_off;  // of the gap's fill buffer in the arena
+  int32_t skip_thr;    // skip_if_prev_right_fuz_gt (-1: never skipped)
+  uint16_t lmf;
+  uint8_t kind;        // 0 launched, 1 bad flank
+  uint8_t pad;
+};
+
+// A gap whose closure the device did not analyse (a k-mer at two depths, or more segments than the kernel's
+// pairwise check takes: post.cpp analyses those on segments or runs): its draws are counted here like everybody's —
+// the number of draws does not depend on the safe/unsafe verdicts — and the trace kernel hands the host what it
+// needs to finish the gap: the gap's record, its closure segments and the rand() values of its traceback.
+struct D3HostItem {
+  uint32_t gap, n_segs;
+  uint64_t seg_off;   // into D3Side.segs
+  uint64_t rnd_off;   // into D3Side.rnd: the raw words of the gap's draws
+  uint32_t draws;     // it will consume
+  uint32_t pad;
+};
+struct D3Side {  // pinned host memory, written by g2s_d3_trace
+  D3HostItem* items = nullptr;
+  GapOut* outs = nullptr;  // by item
+  SegRec* segs = nullptr;
+  uint32_t* rnd = nullptr;
+  uint64_t cap_items = 0, cap_segs = 0, cap_rnd = 0;
+};
+
+// what the host reads back after the last kernel
+struct D3Summary {
+  uint32_t status, unhandled, n_var, anomalies;
+  unsigned long long host_items, host_segs, host_rnd;  // cursors of D3Side
+  uint64_t table_entries, block_entries;
+  uint64_t draws_min, draws_spread, draws_total;
+  uint64_t xA, sA, xB, sB, xD, sD, segs, fill_bytes;
+  uint32_t seg_gaps, filled;
+  uint32_t rand_state[31];  // the 31 words in front of the first value the list did not consume
+  uint32_t pad;
+};
+
+// the jump tables of the generator (seed independent): x^(2^20 a), x^(4096 b), x^(64 l) modulo the
+// recurrence's polynomial, 31 coefficients each
+struct RandTables {
+  const uint32_t* hi = nullptr;   // [128][31]
+  const uint32_t* mid = nullptr;  // [256][31]
+  const uint32_t* lane = nullptr; // [64][31]
+};
+void rand_tables_host(uint32_t* hi /* 128*31 */, uint32_t* mid /* 256*31 */, uint32_t* lane /* 64*31 */);
+
+// work areas of one list (all device memory, sized by d3_work_bytes and carved by d3_work_carve)
+struct D3Work {
+  uint32_t* ginfo = nullptr;    // [n] class | filled << 2 | skipped << 3 | right_fuz << 8
+  uint32_t* dmin = nullptr;     // [n] draws of the gap (fewest, when they depend on the draws)
+  uint32_t* dspread = nullptr;  // [n] most - fewest
+  uint32_t* base = nullptr;     // [n] sum of dmin over the gaps in front
+  uint32_t* vrank = nullptr;    // [n] draw-dependent gaps in front
+  uint32_t* var_gap = nullptr;  // [n] the draw-dependent gaps in list order
+  uint32_t* var_R = nullptr;    // [n + 1] sum of dspread over the draw-dependent gaps in front
+  uint32_t* var_toff = nullptr; // [n + 1] where the gap's table starts
+  uint32_t* var_tile = nullptr; // [n + 1] tiles of 256 table entries in front of the gap's
+  uint32_t* blk_toff = nullptr; // [n / BLOCK_VARS + 2]
+  uint32_t* blk_in = nullptr;   // [n / BLOCK_VARS + 2] deviation in front of the block
+  uint32_t* dvar = nullptr;     // [n + 1] deviation in front of the i-th draw-dependent gap (last: of the whole list)
+  uint16_t* tab = nullptr;      // [G2S_D3_TABLE_BUDGET] draws - dmin by (gap, deviation)
+  uint32_t* btab = nullptr;     // [G2S_D3_TABLE_BUDGET / 4] deviation behind a block by deviation in front of it
+  D3Summary* sum = nullptr;
+  unsigned long long* fill_bytes = nullptr;  // 64 counters, 16 words apart, right behind the summary's 1024 bytes
+};
+size_t d3_work_bytes(uint32_t n);
+void d3_work_carve(void* p, uint32_t n, D3Work* w);
+
+struct D3Params {
+  int32_t k, skip_confident, all_paths, unique_paths;
+  uint64_t max_states;
+  uint32_t n;          // gaps of the list
+  uint32_t has_skip;   // some gap carries a skip rule
+  uint32_t seg_cap;    // closure segments the trace kernel stages in LDS
+  uint32_t map_cap;    // fill-buffer positions it can map there: the longest path of the list + 2
+};
+
+// the stream: values [0, capacity) into rnd_all[31 ..] (sum_dev = nullptr; independent of the list's kernels, so
+// it runs beside the fill kernel on a stream of its own), or only as far as the summary at sum_dev says the list
+// can draw.  rnd_all[0 .. G2S_RAND_WINDOW) come from the host.
+hipError_t launch_rand_fill(hipStream_t st, uint32_t* rnd_all, const RandTables& rt, const D3Summary* sum_dev, uint64_t capacity);
+
+// all of phase D3 behind the fill kernel, on its stream, without a host round trip:
+//   g2s_d3_classify / g2s_d3_scan   classes, draw counts, the skip rule (:369), prefix sums, table layout
+//   (g2s_rand_fill has filled rnd_all by then: launch_rand_fill, on another stream)
+//   g2s_d3_tables  draws of every draw-dependent gap for every offset it can start at
+//   g2s_d3_blocks / g2s_d3_chain  the chain of deviations through those tables, block-wise
+//   g2s_d3_trace   one wave per gap: the traceback, fill text and result record
+hipError_t launch_d3(hipStream_t st, const D3Params& P, const D3Work& W, const GapDev* gaps, const GapOut* outs,
+                     const D3Gap* dgaps, const SubRec* sub, const char* lastch_up, const char* lastch_dn,
+                     const RandTables& rt, uint32_t* rnd_all /* [31 + capacity]: first G2S_RAND_WINDOW words set */,
+                     uint64_t rnd_capacity, void* results /* g2s_result[n], device-writable */,
+                     char* arena /* device-writable */, const D3Side& side);
+
+}  // namespace g2s

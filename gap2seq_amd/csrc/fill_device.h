@@ -135,6 +135,9 @@ struct GapOut {
   uint32_t sub_vertices, sub_edges;  // SubgraphStats of a closure without a repeated k-mer (nothing contracted)
   int32_t count_s;         // all-paths recount: sum of the counts of the sink states (:1189-1226)
   uint32_t dflags;
+  // stop depths behind traceback start j (:1455-1462): lowest | highest << 16 of the depths at which a traceback
+  // from it can meet its left-flank k-mer; equal = fixed_draws[j] is known (d3_device.hip prices the others)
+  uint32_t stop[2];
 };
 #define G2S_DEVA_ANALYSED 0x1u   /* D2 (branch rule) done on the device: safe bits in SegRec.ts_tt, split in SegRec.pad */
 #define G2S_DEVA_CHOICE 0x2u     /* some entry of the traceback closure has more than one parent */

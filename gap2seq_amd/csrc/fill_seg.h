@@ -31,7 +31,10 @@ hipError_t launch_fill_seg(hipStream_t st, uint32_t ngaps, const uint32_t* succ,
                            bool two_waves /* g2s_fill_seg2: phase A on a second wave beside the first half of phase B */,
                            // announcements in batches of pub_batch gaps per XCD (fill_seg.hip, `publish`): 8 zeroed
                            // counters, 8 lists of xcd_stride >= ngaps entries set to 0xFFFFFFFF; pub_batch 1 = per gap
-                           unsigned long long* xcd_tickets, uint32_t* xcd_list, uint32_t xcd_stride, uint32_t pub_batch);
+                           unsigned long long* xcd_tickets, uint32_t* xcd_list, uint32_t xcd_stride, uint32_t pub_batch,
+                           // results stay on the device (sub_out, outs: device memory; outs_host, done_list unused):
+                           // phase D3 follows on the stream (d3_device.hip)
+                           bool resident = false);
 
 // The large variant: `workgroups` persistent workgroups (one per compute unit) take the listed gaps
 // in order from the counter *next_gap (zero before the launch); scratch: fill_segx_scratch_bytes().

@@ -195,6 +195,9 @@ struct SegArgs {
   uint32_t* xcd_list;               // 8 lists of xcd_stride entries, 0xFFFFFFFF before the launch
   uint32_t xcd_stride;
   uint32_t pub_batch;               // a power of two <= 64
+  // the results stay on the device (sub_out and outs are device memory, phase D3 follows on the stream:
+  // d3_device.hip): nothing is announced to the host, no write-back of the L2 per gap
+  uint32_t resident;
 };
 
 // LDS of the large variant (words): see the layout notes at each phase
@@ -275,6 +278,7 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
   // host takes them at the end of the launch, which flushes everything.
   // The large variant's workgroups publish what several waves stored: it keeps the fences.
   auto publish = [&]() {
+    if (A.resident) return;
     if constexpr (BIG) __threadfence();
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if ((uint32_t)lane < sizeof(GapOut) / 4u)
@@ -1754,6 +1758,8 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
     const uint32_t sa = c1 > 0 ? s1 : s2, sb2 = s2;
     go->fixed_draws[0] = ((sa & 0xFFFFu) == (sa >> 16)) ? 1 + len0 - (int)(sa & 0xFFFFu) : -1;
     go->fixed_draws[1] = (n_len > 1 && (sb2 & 0xFFFFu) == (sb2 >> 16)) ? 1 + len1 - (int)(sb2 & 0xFFFFu) : -1;
+    go->stop[0] = sa;
+    go->stop[1] = sb2;
     go->start_seg = (start_b0 != SEG_NOPAR ? s_aux[start_b0] : 0xFFFFu) | ((start_b1 != SEG_NOPAR ? s_aux[start_b1] : 0xFFFFu) << 16);
     go->start_t = start_t0 | (start_t1 << 16);
     go->sub_vertices = sub_vertices;
@@ -1825,7 +1831,7 @@ hipError_t launch_fill_seg(hipStream_t st, uint32_t ngaps, const uint32_t* succ,
                            const uint32_t* gap_ids, const uint32_t* flank_nodes, SubRec* sub_out,
                            unsigned long long out_cap, unsigned long long* out_counter, GapOut* outs, GapOut* outs_host,
                            uint32_t* done_list, int skip_confident, uint32_t* dbg, bool two_waves, unsigned long long* xcd_tickets,
-                           uint32_t* xcd_list, uint32_t xcd_stride, uint32_t pub_batch) {
+                           uint32_t* xcd_list, uint32_t xcd_stride, uint32_t pub_batch, bool resident) {
   if (ngaps == 0) return hipSuccess;
   const size_t bytes = two_waves ? fill_seg2_lds_bytes() : fill_seg_lds_bytes();
   hipError_t e = hipFuncSetAttribute(two_waves ? (const void*)g2s_fill_seg2 : (const void*)g2s_fill_seg,
@@ -1833,7 +1839,7 @@ hipError_t launch_fill_seg(hipStream_t st, uint32_t ngaps, const uint32_t* succ,
   if (e != hipSuccess) return e;
   if (!xcd_tickets || !xcd_list || pub_batch < 2u || pub_batch > 64u || (pub_batch & (pub_batch - 1u))) pub_batch = 1u;
   const SegArgs A = {succ, urec, gaps, gap_ids, flank_nodes, sub_out, out_cap, out_counter, outs, outs_host, done_list,
-                     skip_confident, dbg, fill_seg_dbg_words(), xcd_tickets, xcd_list, xcd_stride, pub_batch};
+                     skip_confident, dbg, fill_seg_dbg_words(), xcd_tickets, xcd_list, xcd_stride, pub_batch, resident ? 1u : 0u};
   if (two_waves) hipLaunchKernelGGL(g2s_fill_seg2, dim3(ngaps), dim3(128), bytes, st, A);
   else hipLaunchKernelGGL(g2s_fill_seg, dim3(ngaps), dim3(64), bytes, st, A);
   return hipGetLastError();
@@ -1849,7 +1855,7 @@ hipError_t launch_fill_segx(hipStream_t st, uint32_t ngaps, uint32_t workgroups,
   hipError_t e = hipFuncSetAttribute((const void*)g2s_fill_segx, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   if (e != hipSuccess) return e;
   const SegArgs A = {succ, urec, gaps, gap_ids, flank_nodes, sub_out, out_cap, out_counter, outs, outs_host, done_list,
-                     skip_confident, dbg, fill_segx_dbg_words(), nullptr, nullptr, 0u, 1u};
+                     skip_confident, dbg, fill_segx_dbg_words(), nullptr, nullptr, 0u, 1u, 0u};
   hipLaunchKernelGGL(g2s_fill_segx, dim3(workgroups), dim3(64), bytes, st, A, scratch, ngaps, next_gap);
   return hipGetLastError();
 }

@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "../../include/g2s.h"
+#include "d3_device.h"
 #include "dbg.hpp"
 #include "fastx.hpp"
 #include "fill_device.h"
@@ -53,6 +54,13 @@ static int fail(int code, const std::string& msg) { tl_error = msg; return code;
 extern "C" int g2s_abi_version(void) { return G2S_ABI_VERSION; }
 extern "C" const char* g2s_last_error(void) { return tl_error.c_str(); }
 extern "C" void g2s_free(void* p) { free(p); }
+extern "C" void* g2s_host_alloc(size_t bytes) {
+  void* p = nullptr;
+  // portable: every device of the process may write it (one session per GPU fills its share of one arena)
+  if (hipHostMalloc(&p, std::max<size_t>(bytes, 16), hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  return p;
+}
+extern "C" void g2s_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
 extern "C" int g2s_device_count(void) {
   int n = 0;
@@ -441,6 +449,9 @@ class WorkerPool {
 // different gaps can read their draws at known offsets in parallel (value = word >> 1).
 struct RandCache {
   GlibcRandStream st;
+  // the generator's state and the next values as one window of the flat stream (resident mode hands it to the device)
+  const uint32_t* window(size_t words) { return st.window(words); }
+  void jump(size_t n, const uint32_t state31[31]) { st.jump(n, state31); }
   void seed(uint32_t s) { st.seed(s); }
   void ensure(size_t n) { st.ensure(n); }  // at least n upcoming values materialised
   int32_t at(size_t off) { st.ensure(off + 1); return st.value(off); }
@@ -500,6 +511,8 @@ struct g2s_session {
   g2s_graph* graph = nullptr;
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;  // resident mode: the rand() stream is generated beside the fill kernel
+  hipEvent_t ev_rand = nullptr;
   g2s_params params;
   RandCache rcache;
   BgWorker bg;
@@ -526,8 +539,15 @@ struct g2s_session {
   std::vector<PinBuf*> pin_free; // pinned buffers of finished batches (flank text in, node ids out), reused
   FlankLookup lookup;            // device copy of the sorted k-mer set for the flank look-up kernel
   DevBuf d_lk_kmers, d_lk_bucket, d_lk_rank2id, d_lk_flip;
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   g2s_timing last_timing;        // of the last g2s_fill_batch / g2s_batch_run (g2s_session_last_timing)
+  // resident mode (run_resident): closures, phase D3 work areas and the rand() stream stay on the device
+  DevBuf d_sub, d_d3, d_rnd, d_lastch, d_rtab, d_resout, d_textout;
+  PinBuf h_d3;                   // D3Gap per gap | summary | stream window; staging of results / text when the caller's are not pinned
+  PinBuf h_res, h_text, h_side;
+  RandTables rtab;
+  int resident_strikes = 0;      // lists that had to be run again on the host path; three in a row switch the mode off
+  bool resident_off = false;
 };
 
 extern "C" int g2s_session_create(g2s_graph* g, int device, const g2s_params* p, g2s_session** out) {
@@ -564,6 +584,23 @@ extern "C" int g2s_session_create(g2s_graph* g, int device, const g2s_params* p,
     s->lookup.rank2id = (const uint32_t*)s->d_lk_rank2id.p; s->lookup.flip = (const uint8_t*)s->d_lk_flip.p;
     s->lookup.k = gr.k; s->lookup.bucket_bits = gr.bucket_bits; s->lookup.wide = gr.wide ? 1 : 0;
   }
+  {  // phase D3 on the device (d3_device.hip): the last base of every oriented k-mer as text, the generator's jump tables
+    const Graph& gr = *g->g;
+    gr.ensure_lastch();
+    hipError_t e = s->d_lastch.ensure(std::max<size_t>(2 * (size_t)gr.n, 16));
+    if (e == hipSuccess && gr.n) e = hipMemcpy(s->d_lastch.p, gr.lastch_up.data(), (size_t)gr.n, hipMemcpyHostToDevice);
+    if (e == hipSuccess && gr.n) e = hipMemcpy((char*)s->d_lastch.p + gr.n, gr.lastch_dn.data(), (size_t)gr.n, hipMemcpyHostToDevice);
+    static std::vector<uint32_t> tables;  // seed independent: once per process
+    static std::once_flag tables_once;
+    std::call_once(tables_once, []() { tables.resize((128 + 256 + 64) * 31); rand_tables_host(tables.data(), tables.data() + 128 * 31, tables.data() + (128 + 256) * 31); });
+    if (e == hipSuccess) e = s->d_rtab.ensure(tables.size() * 4);
+    if (e == hipSuccess) e = hipMemcpy(s->d_rtab.p, tables.data(), tables.size() * 4, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { delete s; return fail(G2S_ERR_HIP, std::string("session setup (phase D3 tables): ") + hipGetErrorString(e)); }
+    s->rtab.hi = (const uint32_t*)s->d_rtab.p;
+    s->rtab.mid = s->rtab.hi + 128 * 31;
+    s->rtab.lane = s->rtab.mid + 256 * 31;
+    if (const char* env = getenv("G2S_RESIDENT")) s->resident_off = atoi(env) == 0;
+  }
   s->graph = g;
   s->device = device;
   s->params = *p;
@@ -572,7 +609,9 @@ extern "C" int g2s_session_create(g2s_graph* g, int device, const g2s_params* p,
   s->rcache.seed(p->randseed > 0 ? p->randseed : (uint32_t)time(nullptr));
   if (const char* env = getenv("G2S_NO_LDS_TIER")) s->no_lds_tier = atoi(env) != 0;
   hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
-  for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipEventCreate(&s->ev[i]);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_rand, hipEventDisableTiming);
+  for (int i = 0; i < 5 && e == hipSuccess; i++) e = hipEventCreate(&s->ev[i]);
   size_t free_b = 0, total_b = 0;
   if (e == hipSuccess) e = hipMemGetInfo(&free_b, &total_b);
   if (e != hipSuccess) { delete s; return fail(G2S_ERR_HIP, std::string("session setup: ") + hipGetErrorString(e)); }
@@ -601,7 +640,11 @@ extern "C" void g2s_session_destroy(g2s_session* s) {
   s->d_lk_kmers.release(); s->d_lk_bucket.release(); s->d_lk_rank2id.release(); s->d_lk_flip.release();
   for (void* v : s->tier_pool) { TierData* t = (TierData*)v; t->outs.release(); t->subs.release(); t->done.release(); delete t; }
   s->h_gaps.release();
-  for (int i = 0; i < 4; i++) if (s->ev[i]) (void)hipEventDestroy(s->ev[i]);
+  for (int i = 0; i < 5; i++) if (s->ev[i]) (void)hipEventDestroy(s->ev[i]);
+  s->d_resout.release(); s->d_textout.release(); s->d_sub.release(); s->d_d3.release(); s->d_rnd.release(); s->d_lastch.release(); s->d_rtab.release();
+  s->h_d3.release(); s->h_res.release(); s->h_text.release(); s->h_side.release();
+  if (s->ev_rand) (void)hipEventDestroy(s->ev_rand);
+  if (s->stream2) (void)hipStreamDestroy(s->stream2);
   if (s->stream) (void)hipStreamDestroy(s->stream);
   delete s;
 }
@@ -1394,6 +1437,7 @@ int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
   memset(&b->timing, 0, sizeof b->timing);
   b->timing.flank_bytes = keep.flank_bytes;
   b->timing.ms_prepare = keep.ms_prepare;
+  b->timing.resident_fallbacks = keep.resident_fallbacks;
 
   const FillParams fp = fill_params_of(s);
   // device-budget analogue of -max-mem: states a gap may hold
@@ -2202,6 +2246,324 @@ size_t rand_need_of(const g2s_gap* gaps, size_t n, int k) {
   return need;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// RESIDENT MODE: the whole of fill_gap on the device.  The segment tier's kernel leaves closures and per-gap
+// records in device memory, phase D3 (rand() stream, offsets, tracebacks: d3_device.hip) follows on the same
+// stream, and the kernels write the result records and the fill text where the caller wants them — directly
+// when those buffers are pinned (g2s_host_alloc), through pinned staging otherwise.  The host prepares the
+// descriptors, launches, waits once and reads one summary.  Lists this cannot finish (a gap that outgrows the
+// segment tier or whose closure needs the host's analysis, draw-count tables beyond the budget, anything a
+// walk did not expect) are counted by the kernels and run again through the host path below, which stays
+// the authority; three such lists in a row switch the mode off for the session.
+// Returns G2S_OK (done), 1 (not applicable / fall back to the host path), or an error.
+// ---------------------------------------------------------------------------------------------------------
+static bool device_pointer_of(void* host, void** dev) {
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, host) != hipSuccess) { (void)hipGetLastError(); return false; }
+  if (attr.type != hipMemoryTypeHost || !attr.devicePointer) return false;
+  *dev = attr.devicePointer;
+  return true;
+}
+
+// One gap the device left to the host (D3HostItem): phase D2 on its closure segments (post.cpp), then its traceback
+// over the rand() values the device copied out for it.  False when the traceback did not draw what the device's
+// walk over the same closure counted (never expected: the list then takes the host path).
+static bool finish_gap_on_host(const Graph& g, const FillParams& fp, const GapJob& j, const GapOut& go, const SegRec* segs,
+                               uint32_t n_segs, const uint32_t* rands, uint32_t expect_draws, uint64_t arena_off, char* arena,
+                               g2s_result* r) {
+  memset(r, 0, sizeof *r);
+  SubView v;
+  v.out = &go; v.segs = segs; v.n_segs = n_segs;
+  SubPrep pp;
+  std::vector<SubRec> own;
+  if (!seg_analyze(fp, j, v, &pp, nullptr)) {  // (G2S_STATE_D2: per-state records)
+    pp = SubPrep();
+    own.resize((size_t)go.n_sub + ((size_t)go.n_xp + 1) / 2 + 1);
+    uint64_t* xp = (uint64_t*)(own.data() + go.n_sub);
+    seg_expand(fp, j, go, segs, n_segs, own.data(), xp);
+    v.st = own.data(); v.n = go.n_sub; v.xp = xp; v.n_xp = go.n_xp; v.segs = nullptr;
+    if (v.n_xp > 1) std::sort(xp, xp + v.n_xp);
+    sub_analyze(fp, j, v, &pp);
+  }
+  r->phaseC_count = go.c_count;
+  r->n_lengths = go.n_len;
+  r->lengths[0] = go.len[0];
+  r->lengths[1] = go.len[1];
+  if (go.flags & (G2S_DEV_Q7_A | G2S_DEV_Q7_B | G2S_DEV_Q7_D)) r->flags |= G2S_GAP_Q7;
+  r->flags |= pp.flags;
+  r->count = pp.count;
+  r->fill_off = arena_off + (uint64_t)j.lmf;
+  if (!pp.phase_d) return false;
+  r->vertices = pp.sub[0]; r->edges = pp.sub[1]; r->nontrivial_components = pp.sub[2];
+  r->size_nontrivial_components = pp.sub[3]; r->vertices_final = pp.sub[4]; r->edges_final = pp.sub[5];
+  if (pp.seg_mode) seg_traceback(g, fp, j, v, pp, rands, arena + arena_off, r);
+  else sub_traceback(g, fp, j, v, pp, rands, arena + arena_off, r);
+  if ((uint32_t)r->draws != expect_draws || (r->flags & G2S_GAP_BACKTRACE_FAIL)) return false;
+  r->fill_off = arena_off + (uint64_t)(j.lmf - r->left_fuz);
+  r->fill_len = (int32_t)strlen(arena + r->fill_off);
+  return true;
+}
+
+int run_resident(g2s_batch* b, g2s_result* results, char* arena) {
+  g2s_session* s = b->s;
+  const size_t n = b->jobs.size();
+  if (s->resident_off || n == 0) return 1;
+  const int forced = getenv("G2S_RESIDENT") ? atoi(getenv("G2S_RESIDENT")) : -1;  // (1: lists of any length; 0: never)
+  if (forced == 0 || (forced != 1 && n < 1024)) return 1;  // (short lists: the host analyses gaps while the launch's stragglers run)
+  if (getenv("G2S_NO_SEG_TIER") || getenv("G2S_FORCE_SEGX") || getenv("G2S_HOST_D2") || getenv("G2S_SEG_DUMP") ||
+      getenv("G2S_DUMP_STATS") || getenv("G2S_NO_LDS_TIER") || getenv("G2S_STATE_D2"))
+    return 1;
+  const Graph& g = *s->graph->g;
+  const DeviceGraph& dg = g.dev.at(s->device);
+  if (dg.pred != nullptr || !dg.rem || s->no_lds_tier || g.n >= (1ull << 28) - 1) return 1;
+  const FillParams fp = fill_params_of(s);
+  const int d_err = fp.d_err;
+  const auto t_enter = std::chrono::steady_clock::now();
+  if (hipSetDevice(s->device) != hipSuccess) return fail(G2S_ERR_NO_DEVICE, "cannot select device");
+  { const int rc = b->upload_flanks(); if (rc != G2S_OK) return rc; }
+  // ---- descriptors: GapDev for the fill kernel, D3Gap for phase D3, the launch order (longest gaps first)
+  std::vector<uint32_t> ids;
+  ids.reserve(n);
+  bool has_skip = false;
+  size_t rnd_cap = 0;
+  int gmax = 0, dmax = 0;
+  for (size_t i = 0; i < n; i++) {
+    const GapJob& j = b->jobs[i];
+    if (j.bad_flank) continue;
+    if (j.rmf > 31 || j.lmf > 31 || j.lmf + j.rmf + j.g + d_err >= 32767) return 1;  // (not a gap of the segment tier)
+    ids.push_back((uint32_t)i);
+    gmax = std::max(gmax, j.g);
+    dmax = std::max(dmax, j.g + j.lmf + j.rmf + d_err);
+    rnd_cap += (size_t)(j.g + j.lmf + j.rmf + d_err + 2);
+  }
+  if (rnd_cap >= (1ull << 31) || dmax > 12000) return 1;  // (the trace kernel maps a whole fill in LDS)
+  if (ids.size() > 1024 && !getenv("G2S_NO_LPT") && (size_t)gmax <= 8 * ids.size() + 65536) {
+    std::vector<uint32_t> at((size_t)gmax + 2, 0), sorted(ids.size());
+    for (uint32_t i : ids) at[(size_t)(gmax - b->jobs[i].g) + 1]++;
+    for (size_t x = 1; x < at.size(); x++) at[x] += at[x - 1];
+    for (uint32_t i : ids) sorted[at[(size_t)(gmax - b->jobs[i].g)]++] = i;
+    ids.swap(sorted);
+  }
+  HIP_TRY(s->h_gaps.ensure(n * sizeof(GapDev) + ids.size() * 4 + 16));
+  HIP_TRY(s->h_d3.ensure(n * sizeof(D3Gap) + 2048 + 64 * 128 + G2S_RAND_WINDOW * 4));
+  GapDev* gd = (GapDev*)s->h_gaps.p;
+  uint32_t* ids_pinned = (uint32_t*)(gd + n);
+  if (!ids.empty()) memcpy(ids_pinned, ids.data(), ids.size() * 4);
+  D3Gap* dgaps = (D3Gap*)s->h_d3.p;
+  D3Summary* hsum = (D3Summary*)((char*)s->h_d3.p + n * sizeof(D3Gap) + 16 - (n * sizeof(D3Gap)) % 16);
+  uint32_t* hwin = (uint32_t*)((char*)hsum + 1024 + 64 * 128);  // (summary, the trace kernel's 64 fill-byte counters, the window)
+  {
+    auto fill_range = [&](size_t lo, size_t hi) {
+      for (size_t i = lo; i < hi; i++) {
+        const GapJob& j = b->jobs[i];
+        GapDev& d = gd[i];
+        memset(&d, 0, sizeof d);
+        D3Gap& q = dgaps[i];
+        q.arena_off = (uint64_t)(b->arena_base + b->arena_off[i]);
+        q.skip_thr = std::max(-1, std::min(j.skip_if_prev_right_fuz_gt, 32767));
+        q.lmf = (uint16_t)j.lmf;
+        q.kind = j.bad_flank ? 1 : 0;
+        q.pad = 0;
+        if (j.bad_flank) continue;
+        d.g = j.g; d.e = d_err; d.lmf = j.lmf; d.rmf = j.rmf;
+        d.D = j.lmf + j.rmf + j.g + d_err;
+        d.right_half = j.rmf + (j.g + d_err + 1) / 2;
+        d.prune_from = j.g / 2 + d_err / 2 + j.lmf;
+        d.all_paths = s->params.all_paths ? 1 : 0;
+        d.flank_off = b->flank_off[i];
+      }
+    };
+    const size_t per_task = 512, ntasks = (n + per_task - 1) / per_task;
+    if (ntasks > 4) s->pool->run(ntasks, [&](size_t t) { fill_range(t * per_task, std::min(n, (t + 1) * per_task)); });
+    else fill_range(0, n);
+    for (size_t i = 0; i < n && !has_skip; i++) has_skip = dgaps[i].skip_thr >= 0;
+  }
+  // ---- device buffers
+  const uint64_t out_states = (uint64_t)ids.size() * 128u + 2u * G2S_SEG_CAP;  // 16-byte units: two per closure segment
+  rnd_cap = (rnd_cap + 2 * G2S_RAND_BLOCK) & ~(size_t)(G2S_RAND_BLOCK - 1);
+  HIP_TRY(s->d_gaps.ensure(n * sizeof(GapDev)));
+  HIP_TRY(s->d_ids.ensure(std::max<size_t>(ids.size() * 4, 16)));
+  HIP_TRY(s->d_outs.ensure(n * sizeof(GapOut)));
+  HIP_TRY(s->d_counter.ensure(32));
+  HIP_TRY(s->d_sub.ensure(out_states * sizeof(SubRec)));
+  HIP_TRY(s->d_d3.ensure(d3_work_bytes((uint32_t)n)));
+  HIP_TRY(s->d_rnd.ensure((31 + rnd_cap + 64) * 4));
+  // what the trace kernel hands back for the gaps whose closure the host analyses (a fraction of a per cent of a list)
+  D3Side side, side_h;
+  {
+    side_h.cap_items = n;
+    side_h.cap_segs = std::max<uint64_t>((uint64_t)ids.size() * 16u, 65536u);
+    side_h.cap_rnd = rnd_cap / 8 + 65536u;
+    const size_t b_items = (n * sizeof(D3HostItem) + 63) & ~(size_t)63, b_outs = (n * sizeof(GapOut) + 63) & ~(size_t)63;
+    const size_t b_segs = side_h.cap_segs * sizeof(SegRec);
+    HIP_TRY(s->h_side.ensure(b_items + b_outs + b_segs + side_h.cap_rnd * 4 + 64));
+    char* hp = (char*)s->h_side.p;
+    side_h.items = (D3HostItem*)hp; side_h.outs = (GapOut*)(hp + b_items); side_h.segs = (SegRec*)(hp + b_items + b_outs);
+    side_h.rnd = (uint32_t*)(hp + b_items + b_outs + b_segs);
+    void* dp = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(&dp, s->h_side.p, 0));
+    side = side_h;
+    side.items = (D3HostItem*)dp; side.outs = (GapOut*)((char*)dp + b_items); side.segs = (SegRec*)((char*)dp + b_items + b_outs);
+    side.rnd = (uint32_t*)((char*)dp + b_items + b_outs + b_segs);
+  }
+  D3Work W;
+  d3_work_carve(s->d_d3.p, (uint32_t)n, &W);
+  // where the kernels write results and text: the caller's buffers when those are pinned, staging otherwise
+  void *res_dev = nullptr, *arena_dev = nullptr;
+  // (G2S_D3_STAGE=device, measurements only: the kernels write device memory, two copies bring it to the caller)
+  const bool stage_dev = getenv("G2S_D3_STAGE") && !strcmp(getenv("G2S_D3_STAGE"), "device");
+  bool res_direct = !stage_dev && device_pointer_of(results, &res_dev);
+  bool arena_direct = !stage_dev && (b->arena_bytes == 0 || device_pointer_of(arena, &arena_dev));
+  if (stage_dev) {
+    HIP_TRY(s->d_resout.ensure(n * sizeof(g2s_result)));
+    HIP_TRY(s->d_textout.ensure(b->arena_bytes + 16));
+    res_dev = s->d_resout.p;
+    arena_dev = (char*)s->d_textout.p - b->arena_base;
+    res_direct = arena_direct = true;
+  }
+  if (!res_direct && !stage_dev) {
+    HIP_TRY(s->h_res.ensure(n * sizeof(g2s_result)));
+    HIP_TRY(hipHostGetDevicePointer(&res_dev, s->h_res.p, 0));
+  }
+  if (!arena_direct && !stage_dev) {
+    HIP_TRY(s->h_text.ensure(b->arena_bytes + 16));
+    HIP_TRY(hipHostGetDevicePointer(&arena_dev, s->h_text.p, 0));
+    arena_dev = (char*)arena_dev - b->arena_base;  // (the kernels index with the arena offsets of the whole list)
+  }
+  hipStream_t st = s->stream;
+  void *d_gaps_host = nullptr, *d_dgaps = nullptr;
+  HIP_TRY(hipHostGetDevicePointer(&d_gaps_host, s->h_gaps.p, 0));
+  HIP_TRY(hipHostGetDevicePointer(&d_dgaps, s->h_d3.p, 0));
+  const GapDev* gaps_dev = (const GapDev*)d_gaps_host;
+  const uint32_t* ids_dev = (const uint32_t*)(gaps_dev + n);
+  if (ids.size() > 2048) {  // (long lists: the descriptors are read by several kernels; short ones read them once, over the link)
+    HIP_TRY(hipMemcpyAsync(s->d_gaps.p, gd, n * sizeof(GapDev), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(s->d_ids.p, ids_pinned, ids.size() * 4, hipMemcpyHostToDevice, st));
+    gaps_dev = (const GapDev*)s->d_gaps.p;
+    ids_dev = (const uint32_t*)s->d_ids.p;
+  }
+  if (s->d_outs.clean < n * sizeof(GapOut)) HIP_TRY(hipMemsetAsync(s->d_outs.p, 0, n * sizeof(GapOut), st));
+  if (s->d_counter.clean < 32) HIP_TRY(hipMemsetAsync(s->d_counter.p, 0, 32, st));
+  s->d_outs.clean = 0;
+  s->d_counter.clean = 0;
+  // the rand() values the list can draw, generated beside the look-up and fill kernels on a stream of their own
+  memcpy(hwin, s->rcache.window(G2S_RAND_WINDOW), G2S_RAND_WINDOW * 4);
+  HIP_TRY(hipMemcpyAsync(s->d_rnd.p, hwin, G2S_RAND_WINDOW * 4, hipMemcpyHostToDevice, s->stream2));
+  HIP_TRY(launch_rand_fill(s->stream2, (uint32_t*)s->d_rnd.p, s->rtab, nullptr, (uint64_t)rnd_cap));
+  HIP_TRY(hipEventRecord(s->ev_rand, s->stream2));
+  // ---- the launches: fill kernel, then phase D3, nothing in between comes back to the host
+  const bool two_waves = getenv("G2S_SEG_WAVES") ? atoi(getenv("G2S_SEG_WAVES")) == 2 : ids.size() <= 2048;
+  HIP_TRY(hipEventRecord(s->ev[1], st));
+  HIP_TRY(launch_fill_seg(st, (uint32_t)ids.size(), dg.succ, dg.urec, gaps_dev, ids_dev, (const uint32_t*)s->d_flank.p,
+                          (SubRec*)s->d_sub.p, (unsigned long long)out_states, (unsigned long long*)s->d_counter.p,
+                          (GapOut*)s->d_outs.p, nullptr, nullptr, s->params.skip_confident ? 1 : 0, nullptr, two_waves,
+                          nullptr, nullptr, 0u, 1u, true));
+  HIP_TRY(hipEventRecord(s->ev[2], st));
+  HIP_TRY(hipStreamWaitEvent(st, s->ev_rand, 0));
+  D3Params P;
+  P.k = fp.k; P.skip_confident = fp.skip_confident ? 1 : 0; P.all_paths = fp.all_paths ? 1 : 0; P.unique_paths = fp.unique_paths ? 1 : 0;
+  P.max_states = (uint64_t)std::max<int64_t>(s->params.max_mem, 1 << 16) / 64;
+  P.n = (uint32_t)n;
+  P.has_skip = has_skip ? 1u : 0u;
+  P.seg_cap = fp.skip_confident ? G2S_SEG_CAP : 192u;
+  P.map_cap = ((uint32_t)dmax + 2u + 3u) & ~3u;
+  HIP_TRY(launch_d3(st, P, W, gaps_dev, (const GapOut*)s->d_outs.p, (const D3Gap*)d_dgaps, (const SubRec*)s->d_sub.p,
+                    (const char*)s->d_lastch.p, (const char*)s->d_lastch.p + g.n, s->rtab, (uint32_t*)s->d_rnd.p,
+                    (uint64_t)rnd_cap, res_dev, (char*)arena_dev, side));
+  HIP_TRY(hipEventRecord(s->ev[3], st));
+  if (stage_dev) {
+    HIP_TRY(hipMemcpyAsync(results, s->d_resout.p, n * sizeof(g2s_result), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(arena + b->arena_base, s->d_textout.p, b->arena_bytes, hipMemcpyDeviceToHost, st));
+  }
+  HIP_TRY(hipMemcpyAsync(hsum, W.sum, 1024 + 64 * 128, hipMemcpyDeviceToHost, st));
+  const auto t_launched = std::chrono::steady_clock::now();
+  HIP_TRY(hipStreamSynchronize(st));
+  const auto t_synced = std::chrono::steady_clock::now();
+  {  // resets for the next launch, off its critical path
+    HIP_TRY(hipMemsetAsync(s->d_outs.p, 0, n * sizeof(GapOut), st));
+    s->d_outs.clean = n * sizeof(GapOut);
+    HIP_TRY(hipMemsetAsync(s->d_counter.p, 0, 32, st));
+    s->d_counter.clean = 32;
+  }
+  float ms_fill = 0, ms_d3 = 0;
+  HIP_TRY(hipEventElapsedTime(&ms_fill, s->ev[1], s->ev[2]));
+  HIP_TRY(hipEventElapsedTime(&ms_d3, s->ev[2], s->ev[3]));
+  for (int q = 0; q < 64; q++) hsum->fill_bytes += ((const unsigned long long*)((const char*)hsum + 1024))[q * 16];
+  const bool test_fallback = getenv("G2S_RESIDENT_TEST_FALLBACK") != nullptr;  // (tests: the attempt is discarded)
+  if (hsum->status != 0 || hsum->anomalies != 0 || test_fallback) {
+    if (getenv("G2S_DEBUG"))
+      fprintf(stderr, "[g2s] resident mode: list of %zu gaps goes to the host path (status %#x, %u gaps not finished on the device, %u anomalies, %llu table entries)\n",
+              n, hsum->status, hsum->unhandled, hsum->anomalies, (unsigned long long)hsum->table_entries);
+    b->timing.resident_fallbacks++;
+    if (!test_fallback && ++s->resident_strikes >= 3) s->resident_off = true;
+    return 1;
+  }
+  // ---- gaps the device left to the host: analysis of the closure, traceback, record (written where the kernels
+  // wrote the others': the caller's buffers or the staging)
+  if (hsum->host_items) {
+    g2s_result* rs = res_direct ? results : (g2s_result*)s->h_res.p;
+    char* text = arena_direct ? arena : (char*)s->h_text.p - b->arena_base;
+    std::atomic<int> bad(0);
+    const size_t ni = (size_t)hsum->host_items;
+    auto one = [&](size_t x) {
+      const D3HostItem& h = side_h.items[x];
+      const GapJob& j = b->jobs[h.gap];
+      if (!finish_gap_on_host(g, fp, j, side_h.outs[x], side_h.segs + h.seg_off, h.n_segs, side_h.rnd + h.rnd_off, h.draws,
+                              (uint64_t)(b->arena_base + b->arena_off[h.gap]), text, &rs[h.gap]))
+        bad.fetch_add(1);
+    };
+    if (ni > 2) s->pool->run(ni, one);
+    else for (size_t x = 0; x < ni; x++) one(x);
+    if (bad.load()) {
+      if (getenv("G2S_DEBUG")) fprintf(stderr, "[g2s] resident mode: %d host-finished gaps disagree with the device's draw counts; the list goes to the host path\n", bad.load());
+      b->timing.resident_fallbacks++;
+      if (++s->resident_strikes >= 3) s->resident_off = true;
+      return 1;
+    }
+    for (size_t x = 0; x < ni; x++) hsum->fill_bytes += (uint64_t)rs[side_h.items[x].gap].fill_len;
+  }
+  s->resident_strikes = 0;
+  // ---- results that went through staging
+  if (!res_direct || !arena_direct) {
+    const g2s_result* rs = res_direct ? results : (const g2s_result*)s->h_res.p;
+    const char* text = (const char*)s->h_text.p - b->arena_base;
+    const size_t per_task = 256, ntasks = (n + per_task - 1) / per_task;
+    auto copy_range = [&](size_t t) {
+      const size_t lo = t * per_task, hi = std::min(n, lo + per_task);
+      if (!res_direct) memcpy(results + lo, rs + lo, (hi - lo) * sizeof(g2s_result));
+      if (!arena_direct)
+        for (size_t i = lo; i < hi; i++) memcpy(arena + rs[i].fill_off, text + rs[i].fill_off, (size_t)rs[i].fill_len + 1);
+    };
+    if (ntasks > 2) s->pool->run(ntasks, copy_range);
+    else for (size_t t = 0; t < ntasks; t++) copy_range(t);
+  }
+  s->rcache.jump((size_t)hsum->draws_total, hsum->rand_state);
+  g2s_timing& tm = b->timing;
+  tm.xA += hsum->xA; tm.sA += hsum->sA; tm.xB += hsum->xB; tm.sB += hsum->sB; tm.xD += hsum->xD; tm.sD += hsum->sD;
+  tm.seg_segments += hsum->segs;
+  tm.seg_tier_gaps += hsum->seg_gaps;
+  tm.fill_bytes += hsum->fill_bytes;
+  tm.ms_fill_seg += ms_fill;
+  tm.ms_d3 += ms_d3;
+  tm.seg_launches++;
+  tm.resident_launches++;
+  if (two_waves) tm.seg2_launches++;
+  tm.draw_dependent_gaps += hsum->n_var;
+  tm.host_finished_gaps += (uint32_t)hsum->host_items;
+  tm.d3_table_entries += hsum->table_entries;
+  const auto t_end = std::chrono::steady_clock::now();
+  tm.ms_total = std::chrono::duration<double, std::milli>(t_end - t_enter).count();
+  if (getenv("G2S_DEBUG"))
+    fprintf(stderr, "[g2s] resident mode: %zu gaps: descriptors + launches %.3f ms, wait %.3f ms (fill kernel %.3f ms, phase D3 kernels %.3f ms), results %.3f ms; %u draw-dependent gaps, %llu table entries, %llu draws; results %s, text %s\n",
+            n, std::chrono::duration<double, std::milli>(t_launched - t_enter).count(),
+            std::chrono::duration<double, std::milli>(t_synced - t_launched).count(), ms_fill, ms_d3,
+            std::chrono::duration<double, std::milli>(t_end - t_synced).count(), hsum->n_var,
+            (unsigned long long)hsum->table_entries, (unsigned long long)hsum->draws_total, res_direct ? "direct" : "staged",
+            arena_direct ? "direct" : "staged");
+  return G2S_OK;
+}
+
 }  // namespace
 
 extern "C" int g2s_batch_run(g2s_batch* b, g2s_result* results, char* arena, size_t arena_cap) {
@@ -2210,6 +2572,13 @@ extern "C" int g2s_batch_run(g2s_batch* b, g2s_result* results, char* arena, siz
   g2s_session* s = b->s;
   const size_t n = b->jobs.size();
   const auto t_run0 = std::chrono::steady_clock::now();
+  {  // the whole list on the device when that applies (run_resident); otherwise, or when it gives up, the host path
+    b->arena = arena;
+    b->arena_base = 0;
+    const int rr = run_resident(b, results, arena);
+    if (rr == G2S_OK) { s->last_timing = b->timing; return G2S_OK; }
+    if (rr < 0) return rr;
+  }
   memset(results, 0, n * sizeof(g2s_result));
   // an unfilled gap reads as the empty string; filled ones are written in full by the traceback
   for (size_t i = 0; i < n; i++) arena[b->arena_off[i] + (size_t)b->jobs[i].lmf] = '\0';
@@ -2727,6 +3096,44 @@ extern "C" int g2s_test_group_queue(int32_t nworkers, uint64_t n, uint64_t group
   for (auto& x : th) x.join();
   if (clash.load()) return fail(G2S_ERR_STATE, "group queue: a gap was handed out twice");
   for (uint64_t i = 0; i < n; i++) if (owner[i] < 0) return fail(G2S_ERR_STATE, "group queue: a gap was never handed out");
+  return G2S_OK;
+}
+
+extern "C" int g2s_test_device_rand(int device, uint32_t seed, uint64_t skip, uint32_t n, int32_t* out) {
+  if (!out) return fail(G2S_ERR_ARG, "g2s_test_device_rand: bad argument");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return fail(G2S_ERR_NO_DEVICE, "no such device");
+  HIP_TRY(hipSetDevice(device));
+  GlibcRandStream st;
+  st.seed(seed);
+  for (uint64_t left = skip; left;) {  // the host's generator up to the position, as a session would have consumed it
+    const size_t c = (size_t)std::min<uint64_t>(left, 1u << 20);
+    st.ensure(c);
+    st.consume(c);
+    left -= c;
+  }
+  std::vector<uint32_t> tables((128 + 256 + 64) * 31);
+  rand_tables_host(tables.data(), tables.data() + 128 * 31, tables.data() + (128 + 256) * 31);
+  const uint64_t cap = ((uint64_t)n + 2 * G2S_RAND_BLOCK) & ~(uint64_t)(G2S_RAND_BLOCK - 1);
+  uint32_t *d_tab = nullptr, *d_rnd = nullptr;
+  D3Summary* d_sum = nullptr;
+  HIP_TRY(hipMalloc((void**)&d_tab, tables.size() * 4));
+  HIP_TRY(hipMalloc((void**)&d_rnd, (31 + cap + 64) * 4));
+  HIP_TRY(hipMalloc((void**)&d_sum, sizeof(D3Summary)));
+  D3Summary sum;
+  memset(&sum, 0, sizeof sum);
+  sum.draws_min = n;
+  HIP_TRY(hipMemcpy(d_tab, tables.data(), tables.size() * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_sum, &sum, sizeof sum, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_rnd, st.window(G2S_RAND_WINDOW), G2S_RAND_WINDOW * 4, hipMemcpyHostToDevice));
+  RandTables rt;
+  rt.hi = d_tab; rt.mid = d_tab + 128 * 31; rt.lane = d_tab + (128 + 256) * 31;
+  HIP_TRY(launch_rand_fill(nullptr, d_rnd, rt, d_sum, cap));
+  HIP_TRY(hipDeviceSynchronize());
+  std::vector<uint32_t> h(n);
+  HIP_TRY(hipMemcpy(h.data(), d_rnd + 31, (size_t)n * 4, hipMemcpyDeviceToHost));
+  for (uint32_t i = 0; i < n; i++) out[i] = (int32_t)(h[i] >> 1);
+  (void)hipFree(d_tab); (void)hipFree(d_rnd); (void)hipFree(d_sum);
   return G2S_OK;
 }
 

@@ -75,6 +75,19 @@ class GlibcRandStream {
   int32_t value(size_t k) const { return (int32_t)(e_[first_ + k] >> 1); }
   // raw words of the upcoming values: value k = raw()[k] >> 1
   const uint32_t* raw() const { return e_ + first_; }
+  // words [first value - 31, first value - 31 + words) of the flat stream: the generator's state, then the next values
+  const uint32_t* window(size_t words) {
+    if (words > 31) ensure(words - 31);
+    return e_ + first_ - 31;
+  }
+  // n values were consumed elsewhere (on the device); state31 = the 31 words in front of the next value
+  void jump(size_t n, const uint32_t state31[31]) {
+    if (first_ + n <= size_) { consume(n); return; }
+    reserve(31 + 4096);
+    memcpy(e_, state31, 31 * sizeof(uint32_t));
+    size_ = 31;
+    first_ = 31;
+  }
   // drop the first n values (they were consumed)
   void consume(size_t n) {
     first_ += n;

@@ -60,7 +60,10 @@ class g2s_timing(C.Structure):
                 ("log_pool_gaps", C.c_uint32), ("rs_pool_gaps", C.c_uint32), ("ms_prepare", C.c_double),
                 ("ms_fill_seg", C.c_double), ("seg_tier_gaps", C.c_uint32), ("seg_launches", C.c_uint32),
                 ("seg_segments", C.c_uint64), ("ms_fill_segx", C.c_double), ("segx_tier_gaps", C.c_uint32),
-                ("segx_launches", C.c_uint32), ("watchdog_gaps", C.c_uint32), ("seg2_launches", C.c_uint32)]
+                ("segx_launches", C.c_uint32), ("watchdog_gaps", C.c_uint32), ("seg2_launches", C.c_uint32),
+                ("ms_d3", C.c_double), ("resident_launches", C.c_uint32), ("resident_fallbacks", C.c_uint32),
+                ("draw_dependent_gaps", C.c_uint64), ("d3_table_entries", C.c_uint64),
+                ("host_finished_gaps", C.c_uint32), ("pad_", C.c_uint32)]
 
 
 class g2s_run_opts(C.Structure):
@@ -121,6 +124,8 @@ _SIGS = {
     "g2s_execute_single": (C.c_int, [_VP, C.POINTER(g2s_run_opts), C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p,
                                      C.c_int32, C.POINTER(_VP), C.POINTER(_VP)]),
     "g2s_free": (None, [_VP]),
+    "g2s_host_alloc": (_VP, [C.c_size_t]),
+    "g2s_host_free": (None, [_VP]),
     "g2s_cut_scaffolds": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p,
                                     C.c_char_p, C.POINTER(_VP), C.POINTER(_VP), C.POINTER(_VP), C.POINTER(_VP)]),
     "g2s_merge_scaffolds": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(_VP),
@@ -135,6 +140,7 @@ _SIGS = {
     "g2s_synth_gaps": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64,
                                  C.POINTER(_VP)]),
     "g2s_test_rand_stream": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_int32)]),
+    "g2s_test_device_rand": (C.c_int, [C.c_int, C.c_uint32, C.c_uint64, C.c_uint32, C.POINTER(C.c_int32)]),
     "g2s_test_post_closure": (C.c_int, [_VP, C.POINTER(g2s_params), C.POINTER(g2s_gap), C.c_uint32,
                                         C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_uint64), C.c_int32, C.c_int32,
                                         C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_uint32, C.c_uint64,
@@ -371,6 +377,28 @@ class FillResult:
                          r.vertices_final, r.edges_final]
 
 
+class HostBuffer:
+    """g2s_host_alloc: page-locked memory the kernels write directly (results, fill arena)."""
+
+    def __init__(self, nbytes):
+        self.nbytes = max(16, int(nbytes))
+        self.p = load_library().g2s_host_alloc(self.nbytes)
+        if not self.p:
+            raise MemoryError("g2s_host_alloc(%d) failed" % self.nbytes)
+
+    def array(self, ctype, count):
+        return (ctype * count).from_address(self.p)
+
+    @property
+    def raw(self):
+        return C.string_at(self.p, self.nbytes)
+
+    def free(self):
+        if self.p:
+            load_library().g2s_host_free(self.p)
+            self.p = None
+
+
 class Session:
     """g2s_session: one GPU, one rand() stream."""
 
@@ -386,23 +414,33 @@ class Session:
         if skip:
             load_library().g2s_session_skip_draws(self.h, skip)
 
-    def fill_batch(self, gaps, want_timing=False):
-        """prepare + run; returns list of FillResult (and g2s_timing)."""
+    def fill_batch(self, gaps, want_timing=False, pinned=False):
+        """prepare + run; returns list of FillResult (and g2s_timing).  pinned: results and arena in
+        g2s_host_alloc memory (the kernels then write them directly when the list is finished on the device)."""
         lib = load_library()
         arr, keep = _gap_array(gaps)
         b = _VP()
         _check(lib.g2s_batch_prepare(self.h, arr, len(gaps), C.byref(b)))
+        bufs = []
         try:
             nbytes = lib.g2s_batch_arena_bytes(b)
-            arena = C.create_string_buffer(max(1, nbytes))
-            res = (g2s_result * max(1, len(gaps)))()
-            _check(lib.g2s_batch_run(b, res, arena, nbytes))
+            if pinned:
+                bufs = [HostBuffer(max(1, nbytes)), HostBuffer(C.sizeof(g2s_result) * max(1, len(gaps)))]
+                arena = bufs[0]
+                res = bufs[1].array(g2s_result, max(1, len(gaps)))
+                _check(lib.g2s_batch_run(b, res, C.cast(arena.p, C.c_char_p), nbytes))
+            else:
+                arena = C.create_string_buffer(max(1, nbytes))
+                res = (g2s_result * max(1, len(gaps)))()
+                _check(lib.g2s_batch_run(b, res, arena, nbytes))
             t = g2s_timing()
             _check(lib.g2s_batch_timing(b, C.byref(t)))
+            raw = arena.raw
+            out = [FillResult(res[i], raw) for i in range(len(gaps))]
         finally:
             lib.g2s_batch_free(b)
-        raw = arena.raw
-        out = [FillResult(res[i], raw) for i in range(len(gaps))]
+            for hb in bufs:
+                hb.free()
         return (out, t) if want_timing else out
 
     def fill_batch_onecall(self, gaps):
@@ -608,6 +646,13 @@ def test_group_queue(nworkers, n, group_size):
     owner = (C.c_int32 * max(1, n))()
     _check(load_library().g2s_test_group_queue(nworkers, n, group_size, owner))
     return [owner[i] for i in range(n)]
+
+
+def test_device_rand(device, seed, skip, n):
+    """TEST HOOK binding: the same n values from the device's generator (g2s_rand_fill)."""
+    out = (C.c_int32 * max(1, n))()
+    _check(load_library().g2s_test_device_rand(device, seed, skip, n, out))
+    return [out[i] for i in range(n)]
 
 
 def test_rand_stream(seed, skip, n):

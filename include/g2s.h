@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define G2S_ABI_VERSION 2
+#define G2S_ABI_VERSION 3
 
 /* status codes */
 #define G2S_OK 0
@@ -186,6 +186,14 @@ typedef struct g2s_timing {
   uint32_t segx_launches;
   uint32_t watchdog_gaps;    /* gaps on which a probe loop of the large variant ran past its bound (a defect; expected 0) */
   uint32_t seg2_launches;    /* segment-tier launches that ran two waves per gap (g2s_fill_seg2: short lists) */
+  /* resident mode: the whole list on the device, phase D3 included (d3_device.hip) */
+  double ms_d3;              /* kernels of phase D3 behind the fill kernel (scan, rand() stream, tables, chain, tracebacks) */
+  uint32_t resident_launches;   /* lists (groups) finished on the device */
+  uint32_t resident_fallbacks;  /* lists the device gave back to the host path */
+  uint64_t draw_dependent_gaps; /* gaps whose number of rand() draws depends on the values drawn */
+  uint64_t d3_table_entries;    /* entries of the draw-count tables that resolved their offsets */
+  uint32_t host_finished_gaps;  /* gaps of resident lists whose closure the host analysed and traced (a k-mer at two depths) */
+  uint32_t pad_;
 } g2s_timing;
 
 /* ---------------------------------------------------------------------------
@@ -306,6 +314,15 @@ int g2s_filter_reads_mem(const void* bam_bytes, size_t n, const g2s_filter_opts*
                          char** warn_out, int64_t* extracted, int64_t* total);
 const char* g2s_filter_last_error(void);
 
+/* ---------------------------------------------------------------------------
+ *  Page-locked host memory the GPUs can write: a `results` array or fill arena
+ *  allocated here is written by the kernels directly (no staging copy) when a
+ *  list is finished on the device.  Any other memory works too.  The reference's
+ *  caller allocates `fill` with new[] (Gap2Seq.cpp:374).
+ * ------------------------------------------------------------------------ */
+void* g2s_host_alloc(size_t bytes);
+void g2s_host_free(void* p);
+
 /* Accessors. */
 const g2s_graph* g2s_session_graph(const g2s_session* s);
 int g2s_session_get_params(const g2s_session* s, g2s_params* out);
@@ -357,6 +374,10 @@ int g2s_test_graph_tables(const g2s_graph* g, uint32_t* succ_out, uint64_t* usta
 /* TEST HOOK: values [skip, skip+n) of the session-style rand() stream after srand(seed)
  * (the flat glibc TYPE_3 generator the tracebacks read), for comparison with libc. */
 int g2s_test_rand_stream(uint32_t seed, uint32_t skip, uint32_t n, int32_t* out);
+
+/* TEST HOOK: the same values from the DEVICE's generator (d3_device.hip: g2s_rand_fill — the state behind `skip`
+ * values handed over by the host, every block of 4096 values reached with three jump polynomials). */
+int g2s_test_device_rand(int device, uint32_t seed, uint64_t skip, uint32_t n, int32_t* out);
 
 /* TEST HOOK: the host worker pool that runs the per-gap analysis and tracebacks: `rounds`
  * parallel-for rounds of `n` tasks on `threads` threads (task i adds i+1 to a per-round

@@ -98,15 +98,17 @@ def _check_batch(product, oracle, seqs, k, gaps, e, skip=False, allp=True, seed=
     return compared, filled, tm, xb, sb
 
 
-@pytest.fixture(params=["seg", "segx", "lds", "hbm"])
+@pytest.fixture(params=["seg", "res", "segx", "lds", "hbm"])
 def tier(request, monkeypatch):
-    """All kernel tiers: the segment tier (default: the search over unitig segments), its large
+    """All kernel tiers: the segment tier (default: the search over unitig segments) with phase D on the host
+    ("seg") and with the whole list finished on the device ("res": resident mode, d3_device.hip), its large
     variant (what a gap takes when it outgrows the LDS-resident capacities), the LDS tier (level by
     level, round 1's kernel: the fallback behind both) and the general tier with per-gap tables in
     HBM (the last resort)."""
     monkeypatch.delenv("G2S_NO_LDS_TIER", raising=False)
     monkeypatch.delenv("G2S_NO_SEG_TIER", raising=False)
     monkeypatch.delenv("G2S_FORCE_SEGX", raising=False)
+    monkeypatch.setenv("G2S_RESIDENT", "1" if request.param == "res" else "0")
     if request.param == "segx":
         monkeypatch.setenv("G2S_FORCE_SEGX", "1")
     elif request.param == "hbm":
@@ -356,7 +358,7 @@ def test_bench_workload_c2_vs_oracle(product, oracle):
     pg.free()
 
 
-@pytest.mark.parametrize("which", ["seg", "lds"])
+@pytest.mark.parametrize("which", ["res", "seg", "lds"])
 def test_c3_gap_list_on_the_branching_genome_vs_oracle(product, oracle, which, monkeypatch):
     """BASELINE config 3's list length (10 000 gaps, 3 Mbp, k=31, -fuz 10, -dist-error 500) on
     the V3 genome (repeats + bubbles), gap by gap against the oracle.  Segment tier: every gap
@@ -366,6 +368,7 @@ def test_c3_gap_list_on_the_branching_genome_vs_oracle(product, oracle, which, m
     outgrows its slice move to the log pool; both must have happened, in a single launch."""
     if which == "lds":
         monkeypatch.setenv("G2S_NO_SEG_TIER", "1")
+    monkeypatch.setenv("G2S_RESIDENT", "1" if which == "res" else "0")
     reads = product.G2S.synth_genome(3000000, 3, 20240101)
     scaff = product.G2S.synth_gaps(reads, 31, 10, 10000, 200, 1000, 20240103)
     seqs = [ln for ln in reads.splitlines() if not ln.startswith(">")]
@@ -373,7 +376,10 @@ def test_c3_gap_list_on_the_branching_genome_vs_oracle(product, oracle, which, m
     assert len(gaps) == 10000
     c, f, tm, _, _ = _check_batch(product, oracle, seqs, 31, gaps, 500, seed=1)
     assert c > 9900 and f > 9900
-    if which == "seg":
+    if which == "res":  # the whole list on the device: fill kernel + phase D3, nothing left for the host path
+        assert tm.resident_launches == 1 and tm.resident_fallbacks == 0 and tm.seg_tier_gaps == 10000
+        assert tm.draw_dependent_gaps > 100
+    if which in ("seg", "res"):
         assert tm.seg_tier_gaps == 10000 and tm.seg_launches == 1 and tm.lds_launches == 0
         assert 100000 < tm.seg_segments < 300000  # ~17 segments per gap for ~1000 DP states
     else:

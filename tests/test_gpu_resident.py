@@ -1,0 +1,130 @@
+"""GPU tests of RESIDENT MODE (run with `-m gpu` on an MI355X): lists finished entirely on the device — the
+segment tier's kernel, then phase D3 (rand() stream, stream offsets, tracebacks: gap2seq_amd/csrc/d3_device.hip)
+on the same stream — against the CPU oracle and, field by field, against the host path of the same library
+(g2s_api.hip: batch_stage1 + batches_stage2), which the reference parity suite has pinned since round 1.
+Everything goes through the C ABI."""
+import pytest
+
+import cases
+from test_gpu_parity import _check_batch, _gaps, _parse_scaffolds
+
+pytestmark = pytest.mark.gpu
+
+
+def _key(r):
+    return (r.count, r.left_fuz, r.right_fuz, r.flags, r.draws, r.fill, r.fill_len, tuple(r.substats), r.phaseC_count,
+            tuple(r.lengths), r.backtrace_msg)
+
+
+@pytest.mark.parametrize("seed,skip", [(1, 0), (42, 5), (20240101, 4095), (7, 4096 * 300 + 17), (1, 3000000)])
+def test_device_rand_stream_is_glibcs(product, seed, skip):
+    """g2s_rand_fill (every block of 4096 values reached from the host's state with three jump polynomials,
+    then the recurrence per lane) against the host's generator, which the CPU suite pins to libc's rand():
+    70 000 values behind `skip` consumed ones, i.e. blocks in the first and, for the last case, the third 2^20."""
+    n = 70000
+    dev = product.test_device_rand(0, seed, skip, n)
+    host = product.test_rand_stream(seed, skip, n)
+    assert dev == host
+
+
+def _run(product, monkeypatch, resident, seqs, k, gaps, e, pinned=False, seed=3, **kw):
+    monkeypatch.setenv("G2S_RESIDENT", "1" if resident else "0")
+    pg = product.Graph.from_seqs(seqs, k, 1)
+    sess = product.Session(pg, 0, d_err=e, randseed=seed, **kw)
+    try:
+        # two lists in a row on one session: the second starts where the first left the rand() stream
+        r1, t1 = sess.fill_batch(_gaps(product, gaps), True, pinned=pinned)
+        r2, t2 = sess.fill_batch(_gaps(product, gaps[: max(1, len(gaps) // 3)]), True, pinned=pinned)
+    finally:
+        sess.destroy()
+        pg.free()
+    return [_key(r) for r in r1], [_key(r) for r in r2], t1, t2
+
+
+@pytest.mark.parametrize("mode", ["default", "best_only", "all_upper", "unique"])
+@pytest.mark.parametrize("pinned", [False, True])
+def test_resident_mode_equals_the_host_path(product, monkeypatch, mode, pinned):
+    """A branching genome (repeats + second haplotype): every field of every result, the fill text included, and
+    the position the rand() stream is left at, with the caller's buffers pinned (written by the kernels) and
+    not (staged)."""
+    kw = dict(default={}, best_only=dict(all_paths=False), all_upper=dict(skip_confident=True), unique=dict(unique_paths=True))[mode]
+    reads = product.G2S.synth_genome(200000, 3, 20240101)
+    seqs = [ln for ln in reads.splitlines() if not ln.startswith(">")]
+    gaps = _parse_scaffolds(product.G2S.synth_gaps(reads, 31, 10, 700, 100, 900, 20240103))
+    h1, h2, th, _ = _run(product, monkeypatch, False, seqs, 31, gaps, 500, **kw)
+    d1, d2, td, td2 = _run(product, monkeypatch, True, seqs, 31, gaps, 500, pinned=pinned, **kw)
+    assert th.resident_launches == 0 and td.resident_launches == 1 and td.resident_fallbacks == 0 and td2.resident_launches == 1
+    assert d1 == h1
+    assert d2 == h2  # (the second list began at the right place in the stream)
+    assert (td.xB, td.sB, td.seg_tier_gaps, td.seg_segments, td.fill_bytes) == (th.xB, th.sB, th.seg_tier_gaps, th.seg_segments, th.fill_bytes)
+    assert td.draw_dependent_gaps > 0 and td.d3_table_entries >= td.draw_dependent_gaps
+    # a few closures per thousand hold a k-mer at two depths: the host analyses and traces those (with -all-upper
+    # nothing is analysed at all)
+    assert (td.host_finished_gaps > 0) == (mode != "all_upper")
+    assert sum(1 for r in d1 if r[0] > 0) > 600
+
+
+def test_resident_mode_vs_oracle_on_the_bench_workload(product, oracle, monkeypatch):
+    """BASELINE config 2's list (500 gaps) forced through resident mode, gap by gap against the oracle."""
+    monkeypatch.setenv("G2S_RESIDENT", "1")
+    reads = product.G2S.synth_genome(3000000, 3, 20240101)
+    seqs = [ln for ln in reads.splitlines() if not ln.startswith(">")]
+    gaps = _parse_scaffolds(product.G2S.synth_gaps(reads, 31, 10, 500, 200, 1000, 20240103))
+    c, f, tm, xb, sb = _check_batch(product, oracle, seqs, 31, gaps, 500, seed=1)
+    assert (c, f) == (500, 500) and (tm.xB, tm.sB) == (xb, sb)
+    assert tm.resident_launches == 1 and tm.resident_fallbacks == 0 and tm.seg_tier_gaps == 500
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_resident_mode_on_toy_graphs(product, oracle, monkeypatch, seed):
+    """Small k, tandem repeats, inverted repeats: most lists hold a closure the device leaves to the host's
+    analysis (a k-mer at two depths) or a gap with both strands of a k-mer — the attempt is then discarded and
+    the host path runs; either way the results are the oracle's."""
+    monkeypatch.setenv("G2S_RESIDENT", "1")
+    k = [9, 11, 13, 15, 17, 21][seed % 6]
+    seqs = cases.toy_genome(seed, 1500, k, repeats=seed % 3, tandem=seed % 2, inverted=int(seed % 4 == 0), snp_every=(0 if seed % 2 else 97))
+    e = [0, 9, 20, 31][seed % 4] + k
+    gaps = cases.cut_gaps(seed, seqs[0], k, fuz=seed % 5 + 1, ngaps=60, min_len=1, max_len=80, d_err=e)
+    for skip, allp in ((False, True), (False, False), (True, True)):
+        c, f, tm, _, _ = _check_batch(product, oracle, seqs, k, gaps, e, skip, allp)
+        assert tm.resident_launches + tm.resident_fallbacks == 1
+
+
+def test_resident_mode_gives_a_list_back(product, monkeypatch):
+    """G2S_RESIDENT_TEST_FALLBACK: the device's attempt is discarded after it ran; the host path must then
+    produce the same results from the same stream position (nothing of the attempt may have stuck)."""
+    reads = product.G2S.synth_genome(150000, 3, 20240101)
+    seqs = [ln for ln in reads.splitlines() if not ln.startswith(">")]
+    gaps = _parse_scaffolds(product.G2S.synth_gaps(reads, 31, 10, 300, 100, 700, 20240103))
+    h1, h2, _, _ = _run(product, monkeypatch, False, seqs, 31, gaps, 500)
+    monkeypatch.setenv("G2S_RESIDENT_TEST_FALLBACK", "1")
+    d1, d2, td, _ = _run(product, monkeypatch, True, seqs, 31, gaps, 500)
+    assert td.resident_launches == 0 and td.resident_fallbacks == 1
+    assert d1 == h1 and d2 == h2
+
+
+def test_resident_mode_scaffold_records_and_the_skip_rule(product, oracle, monkeypatch):
+    """Multi-gap records through g2s_execute_scaffolds: consecutive gaps of a record are coupled (a gap is not
+    attempted when the previous one was filled past it, Gap2Seq.cpp:369,402) — the device's scan applies the rule;
+    FASTA and log text against the oracle's execute()."""
+    k = 21
+    seqs = cases.toy_genome(11, 60000, k, repeats=4, tandem=0, inverted=0, snp_every=0)
+    recs = []
+    for r in range(40):
+        start = 200 + r * 1400
+        holes = [(300, 10, 40), (420, 15, 8), (460, 30, 3), (700, 80, 25)]
+        recs.append(">rec%d\n%s" % (r, cases.scaffold_record(seqs[0][start:start + 1300], k, 6, holes)))
+    scaf = "\n".join(recs) + "\n"
+    og = oracle.OracleGraph(seqs, k, 1)
+    ofa, olog, sm = oracle.execute_scaffolds(og, scaf, k, solid=1, d_err=60, max_fuz=6, randseed=1)
+    og.free()
+    out = {}
+    for resident in ("0", "1"):
+        monkeypatch.setenv("G2S_RESIDENT", resident)
+        pg = product.Graph.from_seqs(seqs, k, 1)
+        sess = product.Session(pg, 0, d_err=60, randseed=1)
+        out[resident] = sess.execute_scaffolds(scaf, k, solid=1, max_fuz=6)
+        sess.destroy()
+        pg.free()
+    assert out["1"] == out["0"]
+    assert out["1"][0] == ofa and out["1"][1] == olog
