@@ -21,7 +21,7 @@ namespace g2s {
 
 // one gap of the list, host -> device
 struct D3Gap {
-  uint64_t arena_off;  // of the gap's fill buffer in the arena
+  uint64_t arena_off;  // of the gap's fill buffer in its list's share of the arena (D3Params.arena_base in front)
   int32_t skip_thr;    // skip_if_prev_right_fuz_gt (-1: never skipped)
   uint16_t lmf;
   uint8_t kind;        // 0 launched, 1 bad flank
@@ -45,12 +45,14 @@ struct D3Side {  // pinned host memory, written by g2s_d3_trace
   SegRec* segs = nullptr;
   uint32_t* rnd = nullptr;
   uint64_t cap_items = 0, cap_segs = 0, cap_rnd = 0;
+  unsigned long long* count = nullptr;  // items handed over (bit 63: something did not fit), written by g2s_d3_handoff's last wave
 };
 
 // what the host reads back after the last kernel
 struct D3Summary {
   uint32_t status, unhandled, n_var, anomalies;
   unsigned long long host_items, host_segs, host_rnd;  // cursors of D3Side
+  uint32_t handoff_waves, pad2;
   uint64_t table_entries, block_entries;
   uint64_t draws_min, draws_spread, draws_total;
   uint64_t xA, sA, xB, sB, xD, sD, segs, fill_bytes;
@@ -93,6 +95,7 @@ void d3_work_carve(void* p, uint32_t n, D3Work* w);
 struct D3Params {
   int32_t k, skip_confident, all_paths, unique_paths;
   uint64_t max_states;
+  uint64_t arena_base; // where the list's share of the arena begins
   uint32_t n;          // gaps of the list
   uint32_t has_skip;   // some gap carries a skip rule
   uint32_t seg_cap;    // closure segments the trace kernel stages in LDS
@@ -109,11 +112,13 @@ hipError_t launch_rand_fill(hipStream_t st, uint32_t* rnd_all, const RandTables&
 //   (g2s_rand_fill has filled rnd_all by then: launch_rand_fill, on another stream)
 //   g2s_d3_tables  draws of every draw-dependent gap for every offset it can start at
 //   g2s_d3_blocks / g2s_d3_chain  the chain of deviations through those tables, block-wise
+//   g2s_d3_handoff what the host needs to finish the gaps whose closure it analyses, into pinned memory
 //   g2s_d3_trace   one wave per gap: the traceback, fill text and result record
 hipError_t launch_d3(hipStream_t st, const D3Params& P, const D3Work& W, const GapDev* gaps, const GapOut* outs,
                      const D3Gap* dgaps, const SubRec* sub, const char* lastch_up, const char* lastch_dn,
                      const RandTables& rt, uint32_t* rnd_all /* [31 + capacity]: first G2S_RAND_WINDOW words set */,
                      uint64_t rnd_capacity, void* results /* g2s_result[n], device-writable */,
-                     char* arena /* device-writable */, const D3Side& side);
+                     char* arena /* device-writable */, const D3Side& side,
+                     hipEvent_t handed_over /* recorded behind g2s_d3_handoff, in front of g2s_d3_trace; may be null */);
 
 }  // namespace g2s

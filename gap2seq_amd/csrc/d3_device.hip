@@ -487,6 +487,61 @@ __global__ __launch_bounds__(1024) void g2s_d3_chain(const D3Work W, const uint3
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// hand-off: the gaps whose closure the host analyses (GI_HOST) get their record, closure segments and the rand()
+// values of their traceback copied into pinned memory — in front of the trace kernel, so that the host
+// finishes them while that kernel runs.  One wave per 64 gaps of the list.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void g2s_d3_handoff(const D3Params P, const D3Work W, const GapOut* __restrict__ outs,
+                                                     const SubRec* __restrict__ sub, const uint32_t* __restrict__ rnd,
+                                                     uint64_t capacity, const g2s::D3Side side) {
+  D3Summary* S = W.sum;
+  if (S->status) return;
+  const int lane = (int)threadIdx.x;
+  const uint32_t i0 = blockIdx.x * 64u;
+  const uint32_t mine = i0 + (uint32_t)lane;
+  const bool host = mine < P.n && (W.ginfo[mine] & GI_HOST) != 0u;
+  for (uint64_t m = __ballot(host); m; m &= m - 1) {
+    const uint32_t i = i0 + (uint32_t)__builtin_ctzll(m);
+    const uint32_t gi = W.ginfo[i];
+    const GapOut& go = outs[i];
+    const uint32_t vr = W.vrank[i];
+    const uint32_t off = W.base[i] + W.dvar[vr];
+    const uint32_t want = W.dmin[i] + (GI_CLASS(gi) == 2u ? (uint32_t)W.tab[(uint64_t)W.var_toff[vr] + W.dvar[vr]] : 0u);
+    const uint32_t ns = go.n_xl;
+    unsigned long long it = 0, so = 0, ro = 0;
+    if (lane == 0) {
+      it = atomicAdd(&S->host_items, 1ull);
+      so = atomicAdd(&S->host_segs, (unsigned long long)ns);
+      ro = atomicAdd(&S->host_rnd, (unsigned long long)want + 1ull);
+    }
+    it = __shfl(it, 0); so = __shfl(so, 0); ro = __shfl(ro, 0);
+    if (it >= side.cap_items || so + ns > side.cap_segs || ro + want + 1ull > side.cap_rnd || (uint64_t)off + want + 1ull > capacity) {
+      if (lane == 0) atomicAdd(&S->anomalies, 1u);
+      continue;
+    }
+    if ((uint32_t)lane < sizeof(GapOut) / 4u) ((uint32_t*)&side.outs[it])[lane] = ((const uint32_t*)&go)[lane];
+    const uint4* src = (const uint4*)(sub + go.sub_off);
+    uint4* dst = (uint4*)(side.segs + so);
+    for (uint32_t w = (uint32_t)lane; w < 2u * ns; w += 64u) dst[w] = src[w];
+    for (uint32_t w = (uint32_t)lane; w < want + 1u; w += 64u) side.rnd[ro + w] = rnd[off + w];
+    if (lane == 0) {
+      g2s::D3HostItem h;
+      h.gap = i; h.n_segs = ns; h.seg_off = so; h.rnd_off = ro; h.draws = want; h.pad = 0;
+      side.items[it] = h;
+    }
+  }
+  // the number of items, where the host reads it once this kernel's event has fired
+  __threadfence_system();
+  if (lane == 0) {
+    const unsigned int done = atomicAdd(&S->handoff_waves, 1u) + 1u;
+    if (done == gridDim.x) {
+      __threadfence_system();
+      *side.count = (unsigned long long)S->host_items | ((unsigned long long)(S->anomalies ? 1u : 0u) << 63);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // the tracebacks: one wave per gap.  Writes g2s_result[i] in full and the gap's fill text.
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void g2s_d3_trace(const D3Params P, const D3Work W, const GapDev* __restrict__ gaps,
@@ -494,7 +549,7 @@ __global__ __launch_bounds__(64) void g2s_d3_trace(const D3Params P, const D3Wor
                                                    const SubRec* __restrict__ sub, const char* __restrict__ chu,
                                                    const char* __restrict__ chd, const uint32_t* __restrict__ rnd,
                                                    uint64_t capacity, g2s_result* __restrict__ results,
-                                                   char* __restrict__ arena, const g2s::D3Side side) {
+                                                   char* __restrict__ arena) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   D3Summary* S = W.sum;
   if (S->status) return;
@@ -504,7 +559,8 @@ __global__ __launch_bounds__(64) void g2s_d3_trace(const D3Params P, const D3Wor
   static_assert(sizeof(g2s_result) == 192, "g2s_result layout");
   const D3Gap dg = dgaps[i];
   const uint32_t gi = W.ginfo[i];
-  char* buf = arena + dg.arena_off;
+  const uint64_t abs_off = P.arena_base + dg.arena_off;
+  char* buf = arena + abs_off;
   const int k = P.k;
   (void)gaps;
   // the record, words 0-23 of g2s_result (count, left_fuz, right_fuz, flags, fill_off, fill_len, draws, six 64-bit
@@ -515,7 +571,7 @@ __global__ __launch_bounds__(64) void g2s_d3_trace(const D3Params P, const D3Wor
   int left_fuz = 0;
   auto finish = [&](uint32_t fill_len) {
     if (lane == 0) {
-      const uint64_t fo = dg.arena_off + (uint64_t)((int)dg.lmf - left_fuz);
+      const uint64_t fo = abs_off + (uint64_t)((int)dg.lmf - left_fuz);
       rw[1] = (uint32_t)left_fuz;
       rw[4] = (uint32_t)fo; rw[5] = (uint32_t)(fo >> 32);
       rw[6] = fill_len;
@@ -549,35 +605,7 @@ __global__ __launch_bounds__(64) void g2s_d3_trace(const D3Params P, const D3Wor
     finish(0u);
     return;
   }
-  if (gi & GI_HOST) {
-    // the host finishes this gap (analysis of its closure, traceback, record): what it needs, into pinned memory
-    const uint32_t vr = W.vrank[i];
-    const uint32_t off = W.base[i] + W.dvar[vr];
-    const uint32_t want = W.dmin[i] + (GI_CLASS(gi) == 2u ? (uint32_t)W.tab[(uint64_t)W.var_toff[vr] + W.dvar[vr]] : 0u);
-    const uint32_t ns = go.n_xl;
-    unsigned long long it = 0, so = 0, ro = 0;
-    if (lane == 0) {
-      it = atomicAdd(&S->host_items, 1ull);
-      so = atomicAdd(&S->host_segs, (unsigned long long)ns);
-      ro = atomicAdd(&S->host_rnd, (unsigned long long)want + 1ull);
-    }
-    it = __shfl(it, 0); so = __shfl(so, 0); ro = __shfl(ro, 0);
-    if (it >= side.cap_items || so + ns > side.cap_segs || ro + want + 1ull > side.cap_rnd || (uint64_t)off + want + 1ull > capacity) {
-      if (lane == 0) atomicAdd(&S->anomalies, 1u);
-      return;
-    }
-    if ((uint32_t)lane < sizeof(GapOut) / 4u) ((uint32_t*)&side.outs[it])[lane] = ((const uint32_t*)&go)[lane];
-    const uint4* src = (const uint4*)(sub + go.sub_off);
-    uint4* dst = (uint4*)(side.segs + so);
-    for (uint32_t w = (uint32_t)lane; w < 2u * ns; w += 64u) dst[w] = src[w];
-    for (uint32_t w = (uint32_t)lane; w < want + 1u; w += 64u) side.rnd[ro + w] = rnd[off + w];
-    if (lane == 0) {
-      g2s::D3HostItem h;
-      h.gap = i; h.n_segs = ns; h.seg_off = so; h.rnd_off = ro; h.draws = want; h.pad = 0;
-      side.items[it] = h;
-    }
-    return;
-  }
+  if (gi & GI_HOST) return;  // (g2s_d3_handoff gave it to the host, which writes its record and text)
   // ---- the closure into LDS
   const uint32_t nsegs = go.n_xl;
   const bool in_lds = nsegs <= P.seg_cap;
@@ -797,7 +825,7 @@ hipError_t launch_rand_fill(hipStream_t st, uint32_t* rnd_all, const RandTables&
 hipError_t launch_d3(hipStream_t st, const D3Params& P, const D3Work& W, const GapDev* gaps, const GapOut* outs,
                      const D3Gap* dgaps, const SubRec* sub, const char* lastch_up, const char* lastch_dn,
                      const RandTables& rt, uint32_t* rnd_all, uint64_t rnd_capacity, void* results, char* arena,
-                     const D3Side& side) {
+                     const D3Side& side, hipEvent_t handed_over) {
   if (P.n == 0) return hipSuccess;
   static_assert(sizeof(D3Summary) <= 1024, "summary slot");
   // (the summary and, behind it, the 64 fill-byte counters of the trace kernel)
@@ -808,11 +836,16 @@ hipError_t launch_d3(hipStream_t st, const D3Params& P, const D3Work& W, const G
   hipLaunchKernelGGL(g2s_d3_tables, dim3(8192), dim3(256), 0, st, W, outs, sub, rnd_all + 31, rnd_capacity);
   hipLaunchKernelGGL(g2s_d3_blocks, dim3(256), dim3(256), 0, st, W);
   hipLaunchKernelGGL(g2s_d3_chain, dim3(1), dim3(1024), 0, st, W, rnd_all);
+  hipLaunchKernelGGL(g2s_d3_handoff, dim3((P.n + 63u) / 64u), dim3(64), 0, st, P, W, outs, sub, rnd_all + 31, rnd_capacity, side);
+  if (handed_over) {
+    e = hipEventRecord(handed_over, st);
+    if (e != hipSuccess) return e;
+  }
   const size_t lds = (size_t)P.seg_cap * sizeof(SegRec) + (size_t)P.map_cap * 4 + 16;
   e = hipFuncSetAttribute((const void*)g2s_d3_trace, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(g2s_d3_trace, dim3(P.n), dim3(64), lds, st, P, W, gaps, outs, dgaps, sub, lastch_up, lastch_dn,
-                     rnd_all + 31, rnd_capacity, (g2s_result*)results, arena, side);
+                     rnd_all + 31, rnd_capacity, (g2s_result*)results, arena);
   return hipGetLastError();
 }
 

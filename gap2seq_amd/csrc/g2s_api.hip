@@ -527,12 +527,14 @@ struct g2s_session {
   std::vector<SubPrep> spare_prep;
   DevBuf d_log, d_lvl, d_plk, d_xl, d_xo;  // LDS tier: state log, level offsets, parent links, closure side lists
   DevBuf d_segx;  // large variant of the segment tier: segment arrays and queues of its persistent workgroups
+  DevBuf d_segscr;  // segment tier: the segments phase B appends, a chunk per gap of the launch
   int num_cus = 256;
   DevBuf d_rspool;
   DevBuf d_logpool;  // chunks for state logs that outgrow their slice of d_log (LDS tier)                          // LDS tier: spill pool for right sets
   std::vector<void*> tier_pool;  // recycled TierData (pinned host buffers)
   size_t tier_cursor = 0;        // next free slot of tier_pool in the current run
   const void* flank_owner = nullptr;  // batch whose flank nodes d_flank holds
+  const void* desc_owner = nullptr;   // batch whose resident-mode descriptors h_gaps / h_d3 hold
   std::vector<g2s_session*> helpers;  // g2s_session_set_team
   size_t team_group = 0;
   PinBuf h_gaps;                 // staging for the GapDev upload
@@ -546,6 +548,7 @@ struct g2s_session {
   PinBuf h_d3;                   // D3Gap per gap | summary | stream window; staging of results / text when the caller's are not pinned
   PinBuf h_res, h_text, h_side;
   RandTables rtab;
+  std::vector<uint32_t> res_ids, res_at;  // launch order of a resident list and its counting sort, kept between lists
   int resident_strikes = 0;      // lists that had to be run again on the host path; three in a row switch the mode off
   bool resident_off = false;
 };
@@ -633,7 +636,7 @@ extern "C" void g2s_session_destroy(g2s_session* s) {
   (void)hipSetDevice(s->device);
   DevBuf* bufs[] = {&s->d_gaps, &s->d_ids, &s->d_flank, &s->d_outs, &s->d_rs, &s->d_rlog, &s->d_keys,
                     &s->d_cnt, &s->d_mark, &s->d_slog, &s->d_subscr, &s->d_subout, &s->d_counter, &s->d_xcd,
-                    &s->d_log, &s->d_lvl, &s->d_plk, &s->d_xl, &s->d_xo, &s->d_rspool, &s->d_logpool, &s->d_segx};
+                    &s->d_log, &s->d_lvl, &s->d_plk, &s->d_xl, &s->d_xo, &s->d_rspool, &s->d_logpool, &s->d_segx, &s->d_segscr};
   for (DevBuf* b : bufs) b->release();
   delete s->pool;
   for (PinBuf* pb : s->pin_free) { pb->release(); delete pb; }
@@ -675,6 +678,11 @@ struct g2s_batch {
   uint32_t* nodes = nullptr;   // oriented flank nodes of every gap (written by the look-up kernel)
   size_t n_desc = 0, n_nodes = 0;
   bool host_lookup = false;    // flanks too long for the kernel's staging buffer: resolved on the host
+  // what resident mode needs of the list, gathered by the preparation's own passes
+  bool has_skip = false, seg_tier_all = true;  // a gap carries a skip rule; every gap with flanks fits the segment tier
+  int gmax = 0, dmax = 0;                       // longest gap, deepest search
+  size_t rnd_cap = 0, n_valid = 0;              // rand() values the list can draw at most; gaps with complete flanks
+  bool fast_desc = false;                       // GapDev / D3Gap of every gap are in the session's pinned buffers (desc_owner)
   int upload_flanks();
   size_t arena_bytes = 0;
   std::vector<size_t> arena_off;  // of each gap's fill buffer within the batch's share of the arena
@@ -704,6 +712,7 @@ struct g2s_batch {
     if (s) {
       drop_tiers();
       if (s->flank_owner == this) s->flank_owner = nullptr;
+      if (s->desc_owner == this) s->desc_owner = nullptr;
       if (pin) s->pin_free.push_back(pin);
       if (views.capacity() > s->spare_views.capacity()) { views.clear(); s->spare_views.swap(views); }
       if (prep.capacity() > s->spare_prep.capacity()) s->spare_prep.swap(prep);  // (elements kept: analyze_gap resets what it uses)
@@ -721,6 +730,21 @@ static TierData* take_tier(g2s_session* s, size_t /*unused*/) {
   TierData* t = (TierData*)s->tier_pool[slot];
   t->gap_ids.clear();
   return t;
+}
+
+// Can a list of n gaps be finished on the device (run_resident)?  The checks that do not look at the gaps.
+static bool resident_applicable(const g2s_session* s, size_t n) {
+  if (s->resident_off || n == 0) return false;
+  const int forced = getenv("G2S_RESIDENT") ? atoi(getenv("G2S_RESIDENT")) : -1;  // (1: lists of any length; 0: never)
+  if (forced == 0 || (forced != 1 && n < 1024)) return false;  // (short lists: the host analyses gaps while the launch's stragglers run)
+  if (getenv("G2S_NO_SEG_TIER") || getenv("G2S_FORCE_SEGX") || getenv("G2S_HOST_D2") || getenv("G2S_SEG_DUMP") ||
+      getenv("G2S_DUMP_STATS") || getenv("G2S_NO_LDS_TIER") || getenv("G2S_STATE_D2"))
+    return false;
+  const Graph& g = *s->graph->g;
+  auto it = g.dev.find(s->device);
+  if (it == g.dev.end()) return false;
+  const DeviceGraph& dg = it->second;
+  return dg.pred == nullptr && dg.rem != nullptr && !s->no_lds_tier && g.n < (1ull << 28) - 1;
 }
 
 extern "C" int g2s_batch_prepare(g2s_session* s, const g2s_gap* gaps, size_t n, g2s_batch** out) {
@@ -758,15 +782,35 @@ extern "C" int g2s_batch_prepare(g2s_session* s, const g2s_gap* gaps, size_t n, 
       n_nodes += (size_t)(j.lmf + 1) + 2 * (size_t)(j.rmf + 1);
       n_desc++;
       b->timing.flank_bytes += (uint64_t)in.left_len + (uint64_t)in.right_len;
+      const int dd = j.lmf + j.rmf + j.g + d_err;
+      if (j.rmf > 31 || j.lmf > 31 || dd >= 32767) b->seg_tier_all = false;
+      b->gmax = std::max(b->gmax, j.g);
+      b->dmax = std::max(b->dmax, dd);
+      b->rnd_cap += (size_t)(dd + 2);
     } else {
       j.lmf = std::max(0, j.lmf);
       j.rmf = std::max(0, j.rmf);
       j.g = std::max(0, j.g);
     }
+    if (j.skip_if_prev_right_fuz_gt >= 0) b->has_skip = true;
     b->arena_off[i] = b->arena_bytes;
     b->arena_bytes += j.buf_bytes(k, d_err);
   }
+  b->n_valid = n_desc;
   if (hipSetDevice(s->device) != hipSuccess) { delete b; return fail(G2S_ERR_NO_DEVICE, "cannot select device"); }
+  // resident mode is likely to take this list: its descriptors are filled by the pass below as well
+  GapDev* fast_gd = nullptr;
+  D3Gap* fast_dg = nullptr;
+  if (resident_applicable(s, n) && b->seg_tier_all && !b->host_lookup) {
+    if (s->h_gaps.ensure(n * sizeof(GapDev) + n * 4 + 16) == hipSuccess &&
+        s->h_d3.ensure(n * sizeof(D3Gap) + 2048 + 64 * 128 + G2S_RAND_WINDOW * 4) == hipSuccess) {
+      fast_gd = (GapDev*)s->h_gaps.p;
+      fast_dg = (D3Gap*)s->h_d3.p;
+      s->desc_owner = b;
+      b->fast_desc = true;
+    }
+  }
+  const int all_paths = s->params.all_paths ? 1 : 0;
   if (!s->pin_free.empty()) { b->pin = s->pin_free.back(); s->pin_free.pop_back(); }
   else b->pin = new PinBuf();
   const size_t desc_bytes = (n_desc * sizeof(FlankDesc) + 15) & ~(size_t)15;
@@ -782,12 +826,30 @@ extern "C" int g2s_batch_prepare(g2s_session* s, const g2s_gap* gaps, size_t n, 
     std::vector<uint32_t> didx(n);  // descriptor index of every valid gap
     uint32_t q = 0;
     for (size_t i = 0; i < n; i++) didx[i] = b->jobs[i].bad_flank ? 0xFFFFFFFFu : q++;
-    const size_t per_task = 256;
+    const size_t per_task = std::max<size_t>(256, (n + 15) / 16);  // (at most 16 tasks: every task wakes a thread)
     auto do_range = [&](size_t t) {
       const size_t lo = t * per_task, hi = std::min(n, lo + per_task);
       for (size_t i = lo; i < hi; i++) {
         GapJob& j = b->jobs[i];
         j.nodes = b->nodes + b->flank_off[i];
+        if (fast_gd) {
+          GapDev& d = fast_gd[i];
+          memset(&d, 0, sizeof d);
+          D3Gap& q = fast_dg[i];
+          q.arena_off = (uint64_t)b->arena_off[i];  // (within the batch's share of the arena: D3Params.arena_base is added on the device)
+          q.skip_thr = std::max(-1, std::min(j.skip_if_prev_right_fuz_gt, 32767));
+          q.lmf = (uint16_t)j.lmf;
+          q.kind = j.bad_flank ? 1 : 0;
+          q.pad = 0;
+          if (!j.bad_flank) {
+            d.g = j.g; d.e = d_err; d.lmf = j.lmf; d.rmf = j.rmf;
+            d.D = j.lmf + j.rmf + j.g + d_err;
+            d.right_half = j.rmf + (j.g + d_err + 1) / 2;
+            d.prune_from = j.g / 2 + d_err / 2 + j.lmf;
+            d.all_paths = all_paths;
+            d.flank_off = b->flank_off[i];
+          }
+        }
         if (j.bad_flank) continue;
         const g2s_gap& in = gaps[i];
         char* t = b->text + text_off[i];
@@ -1056,6 +1118,7 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
       HIP_TRY(hipMemsetAsync(s->d_slog.p, 0, (size_t)ids.size() * seg_dbg_w * 4, st));
       seg_dbg = (uint32_t*)s->d_slog.p;
     }
+    if (seg == 1) HIP_TRY(s->d_segscr.ensure(fill_seg_scratch_bytes((uint32_t)ids.size())));
     if (seg == 2) {
       // one persistent workgroup per compute unit (the variant takes nearly all of a CU's LDS)
       const uint32_t wgs = (uint32_t)std::min<size_t>(ids.size(), (size_t)std::max(1, s->num_cus));
@@ -1073,7 +1136,7 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
                               // short lists are latency-bound (the launch ends with its slowest gap): two waves per
                               // gap; long lists fill the chip and are throughput-bound: one (G2S_SEG_WAVES=1|2 forces)
                               seg_two_waves, (unsigned long long*)s->d_xcd.p, (uint32_t*)((char*)s->d_xcd.p + 64),
-                              (uint32_t)ids.size(), pub_batch));
+                              (uint32_t)ids.size(), pub_batch, false, (uint32_t*)s->d_segscr.p));
     else
     HIP_TRY(launch_fill_lds(st, (uint32_t)ids.size(), lds_cap_max, num_oriented, dg.succ, dg.ustart,
                             gaps_dev, ids_dev, (const uint32_t*)s->d_flank.p,
@@ -2308,44 +2371,33 @@ static bool finish_gap_on_host(const Graph& g, const FillParams& fp, const GapJo
 int run_resident(g2s_batch* b, g2s_result* results, char* arena) {
   g2s_session* s = b->s;
   const size_t n = b->jobs.size();
-  if (s->resident_off || n == 0) return 1;
-  const int forced = getenv("G2S_RESIDENT") ? atoi(getenv("G2S_RESIDENT")) : -1;  // (1: lists of any length; 0: never)
-  if (forced == 0 || (forced != 1 && n < 1024)) return 1;  // (short lists: the host analyses gaps while the launch's stragglers run)
-  if (getenv("G2S_NO_SEG_TIER") || getenv("G2S_FORCE_SEGX") || getenv("G2S_HOST_D2") || getenv("G2S_SEG_DUMP") ||
-      getenv("G2S_DUMP_STATS") || getenv("G2S_NO_LDS_TIER") || getenv("G2S_STATE_D2"))
-    return 1;
+  if (!resident_applicable(s, n) || !b->seg_tier_all || b->host_lookup) return 1;
   const Graph& g = *s->graph->g;
   const DeviceGraph& dg = g.dev.at(s->device);
-  if (dg.pred != nullptr || !dg.rem || s->no_lds_tier || g.n >= (1ull << 28) - 1) return 1;
   const FillParams fp = fill_params_of(s);
   const int d_err = fp.d_err;
   const auto t_enter = std::chrono::steady_clock::now();
   if (hipSetDevice(s->device) != hipSuccess) return fail(G2S_ERR_NO_DEVICE, "cannot select device");
   { const int rc = b->upload_flanks(); if (rc != G2S_OK) return rc; }
-  // ---- descriptors: GapDev for the fill kernel, D3Gap for phase D3, the launch order (longest gaps first)
-  std::vector<uint32_t> ids;
-  ids.reserve(n);
-  bool has_skip = false;
-  size_t rnd_cap = 0;
-  int gmax = 0, dmax = 0;
-  for (size_t i = 0; i < n; i++) {
-    const GapJob& j = b->jobs[i];
-    if (j.bad_flank) continue;
-    if (j.rmf > 31 || j.lmf > 31 || j.lmf + j.rmf + j.g + d_err >= 32767) return 1;  // (not a gap of the segment tier)
-    ids.push_back((uint32_t)i);
-    gmax = std::max(gmax, j.g);
-    dmax = std::max(dmax, j.g + j.lmf + j.rmf + d_err);
-    rnd_cap += (size_t)(j.g + j.lmf + j.rmf + d_err + 2);
-  }
+  size_t rnd_cap = b->rnd_cap;
+  const int gmax = b->gmax, dmax = b->dmax;
+  const bool has_skip = b->has_skip;
   if (rnd_cap >= (1ull << 31) || dmax > 12000) return 1;  // (the trace kernel maps a whole fill in LDS)
-  if (ids.size() > 1024 && !getenv("G2S_NO_LPT") && (size_t)gmax <= 8 * ids.size() + 65536) {
-    std::vector<uint32_t> at((size_t)gmax + 2, 0), sorted(ids.size());
-    for (uint32_t i : ids) at[(size_t)(gmax - b->jobs[i].g) + 1]++;
+  // ---- the launch order: longest gaps first (a stable counting sort; the session keeps the vectors)
+  std::vector<uint32_t>& ids = s->res_ids;
+  ids.clear();
+  ids.reserve(n);
+  if (b->n_valid > 1024 && !getenv("G2S_NO_LPT") && (size_t)gmax <= 8 * b->n_valid + 65536) {
+    std::vector<uint32_t>& at = s->res_at;
+    at.assign((size_t)gmax + 2, 0);
+    for (size_t i = 0; i < n; i++) if (!b->jobs[i].bad_flank) at[(size_t)(gmax - b->jobs[i].g) + 1]++;
     for (size_t x = 1; x < at.size(); x++) at[x] += at[x - 1];
-    for (uint32_t i : ids) sorted[at[(size_t)(gmax - b->jobs[i].g)]++] = i;
-    ids.swap(sorted);
+    ids.resize(b->n_valid);
+    for (size_t i = 0; i < n; i++) if (!b->jobs[i].bad_flank) ids[at[(size_t)(gmax - b->jobs[i].g)]++] = (uint32_t)i;
+  } else {
+    for (size_t i = 0; i < n; i++) if (!b->jobs[i].bad_flank) ids.push_back((uint32_t)i);
   }
-  HIP_TRY(s->h_gaps.ensure(n * sizeof(GapDev) + ids.size() * 4 + 16));
+  HIP_TRY(s->h_gaps.ensure(n * sizeof(GapDev) + n * 4 + 16));
   HIP_TRY(s->h_d3.ensure(n * sizeof(D3Gap) + 2048 + 64 * 128 + G2S_RAND_WINDOW * 4));
   GapDev* gd = (GapDev*)s->h_gaps.p;
   uint32_t* ids_pinned = (uint32_t*)(gd + n);
@@ -2353,14 +2405,17 @@ int run_resident(g2s_batch* b, g2s_result* results, char* arena) {
   D3Gap* dgaps = (D3Gap*)s->h_d3.p;
   D3Summary* hsum = (D3Summary*)((char*)s->h_d3.p + n * sizeof(D3Gap) + 16 - (n * sizeof(D3Gap)) % 16);
   uint32_t* hwin = (uint32_t*)((char*)hsum + 1024 + 64 * 128);  // (summary, the trace kernel's 64 fill-byte counters, the window)
-  {
+  if (!(b->fast_desc && s->desc_owner == b)) {
+    // ---- descriptors (the preparation fills them itself when it expects this mode; a batch that is run again
+    // after another one was prepared on the session finds them overwritten): GapDev for the fill kernel, D3Gap
+    // for phase D3
     auto fill_range = [&](size_t lo, size_t hi) {
       for (size_t i = lo; i < hi; i++) {
         const GapJob& j = b->jobs[i];
         GapDev& d = gd[i];
         memset(&d, 0, sizeof d);
         D3Gap& q = dgaps[i];
-        q.arena_off = (uint64_t)(b->arena_base + b->arena_off[i]);
+        q.arena_off = (uint64_t)b->arena_off[i];
         q.skip_thr = std::max(-1, std::min(j.skip_if_prev_right_fuz_gt, 32767));
         q.lmf = (uint16_t)j.lmf;
         q.kind = j.bad_flank ? 1 : 0;
@@ -2374,11 +2429,13 @@ int run_resident(g2s_batch* b, g2s_result* results, char* arena) {
         d.flank_off = b->flank_off[i];
       }
     };
-    const size_t per_task = 512, ntasks = (n + per_task - 1) / per_task;
+    const size_t per_task = std::max<size_t>(512, (n + 15) / 16), ntasks = (n + per_task - 1) / per_task;
     if (ntasks > 4) s->pool->run(ntasks, [&](size_t t) { fill_range(t * per_task, std::min(n, (t + 1) * per_task)); });
     else fill_range(0, n);
-    for (size_t i = 0; i < n && !has_skip; i++) has_skip = dgaps[i].skip_thr >= 0;
+    s->desc_owner = b;
+    b->fast_desc = true;
   }
+  const auto t_desc = std::chrono::steady_clock::now();
   // ---- device buffers
   const uint64_t out_states = (uint64_t)ids.size() * 128u + 2u * G2S_SEG_CAP;  // 16-byte units: two per closure segment
   rnd_cap = (rnd_cap + 2 * G2S_RAND_BLOCK) & ~(size_t)(G2S_RAND_BLOCK - 1);
@@ -2387,6 +2444,7 @@ int run_resident(g2s_batch* b, g2s_result* results, char* arena) {
   HIP_TRY(s->d_outs.ensure(n * sizeof(GapOut)));
   HIP_TRY(s->d_counter.ensure(32));
   HIP_TRY(s->d_sub.ensure(out_states * sizeof(SubRec)));
+  HIP_TRY(s->d_segscr.ensure(fill_seg_scratch_bytes((uint32_t)ids.size())));
   HIP_TRY(s->d_d3.ensure(d3_work_bytes((uint32_t)n)));
   HIP_TRY(s->d_rnd.ensure((31 + rnd_cap + 64) * 4));
   // what the trace kernel hands back for the gaps whose closure the host analyses (a fraction of a per cent of a list)
@@ -2397,15 +2455,18 @@ int run_resident(g2s_batch* b, g2s_result* results, char* arena) {
     side_h.cap_rnd = rnd_cap / 8 + 65536u;
     const size_t b_items = (n * sizeof(D3HostItem) + 63) & ~(size_t)63, b_outs = (n * sizeof(GapOut) + 63) & ~(size_t)63;
     const size_t b_segs = side_h.cap_segs * sizeof(SegRec);
-    HIP_TRY(s->h_side.ensure(b_items + b_outs + b_segs + side_h.cap_rnd * 4 + 64));
+    HIP_TRY(s->h_side.ensure(b_items + b_outs + b_segs + side_h.cap_rnd * 4 + 128));
     char* hp = (char*)s->h_side.p;
     side_h.items = (D3HostItem*)hp; side_h.outs = (GapOut*)(hp + b_items); side_h.segs = (SegRec*)(hp + b_items + b_outs);
     side_h.rnd = (uint32_t*)(hp + b_items + b_outs + b_segs);
+    side_h.count = (unsigned long long*)(hp + b_items + b_outs + b_segs + ((side_h.cap_rnd * 4 + 63) & ~(size_t)63));
+    *side_h.count = 0;
     void* dp = nullptr;
     HIP_TRY(hipHostGetDevicePointer(&dp, s->h_side.p, 0));
     side = side_h;
     side.items = (D3HostItem*)dp; side.outs = (GapOut*)((char*)dp + b_items); side.segs = (SegRec*)((char*)dp + b_items + b_outs);
     side.rnd = (uint32_t*)((char*)dp + b_items + b_outs + b_segs);
+    side.count = (unsigned long long*)((char*)dp + ((char*)side_h.count - hp));
   }
   D3Work W;
   d3_work_carve(s->d_d3.p, (uint32_t)n, &W);
@@ -2419,7 +2480,7 @@ int run_resident(g2s_batch* b, g2s_result* results, char* arena) {
     HIP_TRY(s->d_resout.ensure(n * sizeof(g2s_result)));
     HIP_TRY(s->d_textout.ensure(b->arena_bytes + 16));
     res_dev = s->d_resout.p;
-    arena_dev = (char*)s->d_textout.p - b->arena_base;
+    arena_dev = (char*)s->d_textout.p - b->arena_base;  // (the kernels index with arena_base + the gap's offset)
     res_direct = arena_direct = true;
   }
   if (!res_direct && !stage_dev) {
@@ -2431,6 +2492,7 @@ int run_resident(g2s_batch* b, g2s_result* results, char* arena) {
     HIP_TRY(hipHostGetDevicePointer(&arena_dev, s->h_text.p, 0));
     arena_dev = (char*)arena_dev - b->arena_base;  // (the kernels index with the arena offsets of the whole list)
   }
+  const auto t_bufs = std::chrono::steady_clock::now();
   hipStream_t st = s->stream;
   void *d_gaps_host = nullptr, *d_dgaps = nullptr;
   HIP_TRY(hipHostGetDevicePointer(&d_gaps_host, s->h_gaps.p, 0));
@@ -2458,7 +2520,7 @@ int run_resident(g2s_batch* b, g2s_result* results, char* arena) {
   HIP_TRY(launch_fill_seg(st, (uint32_t)ids.size(), dg.succ, dg.urec, gaps_dev, ids_dev, (const uint32_t*)s->d_flank.p,
                           (SubRec*)s->d_sub.p, (unsigned long long)out_states, (unsigned long long*)s->d_counter.p,
                           (GapOut*)s->d_outs.p, nullptr, nullptr, s->params.skip_confident ? 1 : 0, nullptr, two_waves,
-                          nullptr, nullptr, 0u, 1u, true));
+                          nullptr, nullptr, 0u, 1u, true, (uint32_t*)s->d_segscr.p));
   HIP_TRY(hipEventRecord(s->ev[2], st));
   HIP_TRY(hipStreamWaitEvent(st, s->ev_rand, 0));
   D3Params P;
@@ -2466,11 +2528,12 @@ int run_resident(g2s_batch* b, g2s_result* results, char* arena) {
   P.max_states = (uint64_t)std::max<int64_t>(s->params.max_mem, 1 << 16) / 64;
   P.n = (uint32_t)n;
   P.has_skip = has_skip ? 1u : 0u;
+  P.arena_base = (uint64_t)b->arena_base;
   P.seg_cap = fp.skip_confident ? G2S_SEG_CAP : 192u;
   P.map_cap = ((uint32_t)dmax + 2u + 3u) & ~3u;
   HIP_TRY(launch_d3(st, P, W, gaps_dev, (const GapOut*)s->d_outs.p, (const D3Gap*)d_dgaps, (const SubRec*)s->d_sub.p,
                     (const char*)s->d_lastch.p, (const char*)s->d_lastch.p + g.n, s->rtab, (uint32_t*)s->d_rnd.p,
-                    (uint64_t)rnd_cap, res_dev, (char*)arena_dev, side));
+                    (uint64_t)rnd_cap, res_dev, (char*)arena_dev, side, s->ev[4]));
   HIP_TRY(hipEventRecord(s->ev[3], st));
   if (stage_dev) {
     HIP_TRY(hipMemcpyAsync(results, s->d_resout.p, n * sizeof(g2s_result), hipMemcpyDeviceToHost, st));
@@ -2478,6 +2541,29 @@ int run_resident(g2s_batch* b, g2s_result* results, char* arena) {
   }
   HIP_TRY(hipMemcpyAsync(hsum, W.sum, 1024 + 64 * 128, hipMemcpyDeviceToHost, st));
   const auto t_launched = std::chrono::steady_clock::now();
+  // ---- gaps the device leaves to the host (their closure holds a k-mer at two depths: post.cpp analyses those):
+  // handed over in front of the trace kernel, finished here while it runs — analysis of the closure, traceback,
+  // record, written where the kernels write the others' (the caller's buffers or the staging)
+  HIP_TRY(hipEventSynchronize(s->ev[4]));
+  const auto t_handed = std::chrono::steady_clock::now();
+  std::atomic<int> host_bad(0);
+  const size_t ni = (size_t)(*side_h.count & 0x7FFFFFFFFFFFFFFFull);
+  g2s_result* rs_host = res_direct && !stage_dev ? results : (g2s_result*)s->h_res.p;
+  uint64_t host_fill_bytes = 0;
+  if (ni && !(*side_h.count >> 63) && !stage_dev) {
+    char* text = arena_direct ? arena : (char*)s->h_text.p - b->arena_base;
+    auto one = [&](size_t x) {
+      const D3HostItem& h = side_h.items[x];
+      const GapJob& j = b->jobs[h.gap];
+      if (!finish_gap_on_host(g, fp, j, side_h.outs[x], side_h.segs + h.seg_off, h.n_segs, side_h.rnd + h.rnd_off, h.draws,
+                              (uint64_t)(b->arena_base + b->arena_off[h.gap]), text, &rs_host[h.gap]))
+        host_bad.fetch_add(1);
+    };
+    if (ni > 2) s->pool->run(ni, one);
+    else for (size_t x = 0; x < ni; x++) one(x);
+    for (size_t x = 0; x < ni; x++) host_fill_bytes += (uint64_t)rs_host[side_h.items[x].gap].fill_len;
+  }
+  const auto t_finished = std::chrono::steady_clock::now();
   HIP_TRY(hipStreamSynchronize(st));
   const auto t_synced = std::chrono::steady_clock::now();
   {  // resets for the next launch, off its critical path
@@ -2490,38 +2576,16 @@ int run_resident(g2s_batch* b, g2s_result* results, char* arena) {
   HIP_TRY(hipEventElapsedTime(&ms_fill, s->ev[1], s->ev[2]));
   HIP_TRY(hipEventElapsedTime(&ms_d3, s->ev[2], s->ev[3]));
   for (int q = 0; q < 64; q++) hsum->fill_bytes += ((const unsigned long long*)((const char*)hsum + 1024))[q * 16];
+  hsum->fill_bytes += host_fill_bytes;
   const bool test_fallback = getenv("G2S_RESIDENT_TEST_FALLBACK") != nullptr;  // (tests: the attempt is discarded)
-  if (hsum->status != 0 || hsum->anomalies != 0 || test_fallback) {
+  if (stage_dev && hsum->host_items) hsum->anomalies++;  // (the measurement switch has no path for host-finished gaps)
+  if (hsum->status != 0 || hsum->anomalies != 0 || test_fallback || host_bad.load() || hsum->host_items != ni) {
     if (getenv("G2S_DEBUG"))
-      fprintf(stderr, "[g2s] resident mode: list of %zu gaps goes to the host path (status %#x, %u gaps not finished on the device, %u anomalies, %llu table entries)\n",
-              n, hsum->status, hsum->unhandled, hsum->anomalies, (unsigned long long)hsum->table_entries);
+      fprintf(stderr, "[g2s] resident mode: list of %zu gaps goes to the host path (status %#x, %u gaps not finished on the device, %u anomalies, %llu table entries, %d host-finished gaps disagree)\n",
+              n, hsum->status, hsum->unhandled, hsum->anomalies, (unsigned long long)hsum->table_entries, host_bad.load());
     b->timing.resident_fallbacks++;
     if (!test_fallback && ++s->resident_strikes >= 3) s->resident_off = true;
     return 1;
-  }
-  // ---- gaps the device left to the host: analysis of the closure, traceback, record (written where the kernels
-  // wrote the others': the caller's buffers or the staging)
-  if (hsum->host_items) {
-    g2s_result* rs = res_direct ? results : (g2s_result*)s->h_res.p;
-    char* text = arena_direct ? arena : (char*)s->h_text.p - b->arena_base;
-    std::atomic<int> bad(0);
-    const size_t ni = (size_t)hsum->host_items;
-    auto one = [&](size_t x) {
-      const D3HostItem& h = side_h.items[x];
-      const GapJob& j = b->jobs[h.gap];
-      if (!finish_gap_on_host(g, fp, j, side_h.outs[x], side_h.segs + h.seg_off, h.n_segs, side_h.rnd + h.rnd_off, h.draws,
-                              (uint64_t)(b->arena_base + b->arena_off[h.gap]), text, &rs[h.gap]))
-        bad.fetch_add(1);
-    };
-    if (ni > 2) s->pool->run(ni, one);
-    else for (size_t x = 0; x < ni; x++) one(x);
-    if (bad.load()) {
-      if (getenv("G2S_DEBUG")) fprintf(stderr, "[g2s] resident mode: %d host-finished gaps disagree with the device's draw counts; the list goes to the host path\n", bad.load());
-      b->timing.resident_fallbacks++;
-      if (++s->resident_strikes >= 3) s->resident_off = true;
-      return 1;
-    }
-    for (size_t x = 0; x < ni; x++) hsum->fill_bytes += (uint64_t)rs[side_h.items[x].gap].fill_len;
   }
   s->resident_strikes = 0;
   // ---- results that went through staging
@@ -2554,6 +2618,11 @@ int run_resident(g2s_batch* b, g2s_result* results, char* arena) {
   tm.d3_table_entries += hsum->table_entries;
   const auto t_end = std::chrono::steady_clock::now();
   tm.ms_total = std::chrono::duration<double, std::milli>(t_end - t_enter).count();
+  if (getenv("G2S_DEBUG"))
+    fprintf(stderr, "[g2s] resident mode: host: descriptors %.3f ms, buffers %.3f ms, launches %.3f ms, wait for the hand-over %.3f ms, %zu gaps finished by the host in %.3f ms, wait for the trace kernel %.3f ms\n",
+            std::chrono::duration<double, std::milli>(t_desc - t_enter).count(), std::chrono::duration<double, std::milli>(t_bufs - t_desc).count(),
+            std::chrono::duration<double, std::milli>(t_launched - t_bufs).count(), std::chrono::duration<double, std::milli>(t_handed - t_launched).count(),
+            ni, std::chrono::duration<double, std::milli>(t_finished - t_handed).count(), std::chrono::duration<double, std::milli>(t_synced - t_finished).count());
   if (getenv("G2S_DEBUG"))
     fprintf(stderr, "[g2s] resident mode: %zu gaps: descriptors + launches %.3f ms, wait %.3f ms (fill kernel %.3f ms, phase D3 kernels %.3f ms), results %.3f ms; %u draw-dependent gaps, %llu table entries, %llu draws; results %s, text %s\n",
             n, std::chrono::duration<double, std::milli>(t_launched - t_enter).count(),
@@ -2797,7 +2866,8 @@ extern "C" int g2s_test_post_gap(const g2s_graph* gh, const g2s_params* p, const
   GapJob j;
   j.g = gap->gap_len; j.lmf = gap->lmf; j.rmf = gap->rmf;
   if (gap->left_len < k + j.lmf || gap->right_len < k + j.rmf) return fail(G2S_ERR_ARG, "flank too short");
-  j.resolve_on_host(g, gap->left, (size_t)gap->left_len, gap->right, (size_t)gap->right_len);
+  std::vector<uint32_t> flank_store;
+  j.resolve_on_host(g, gap->left, (size_t)gap->left_len, gap->right, (size_t)gap->right_len, &flank_store);
   HostTable t;
   t.D = j.lmf + j.rmf + j.g + p->d_err;
   t.lvl.assign((size_t)t.D + 2, 0);
@@ -2875,7 +2945,8 @@ extern "C" int g2s_test_post_closure(const g2s_graph* gh, const g2s_params* p, c
   GapJob j;
   j.g = gap->gap_len; j.lmf = gap->lmf; j.rmf = gap->rmf;
   if (gap->left_len < k + j.lmf || gap->right_len < k + j.rmf) return fail(G2S_ERR_ARG, "flank too short");
-  j.resolve_on_host(g, gap->left, (size_t)gap->left_len, gap->right, (size_t)gap->right_len);
+  std::vector<uint32_t> flank_store;
+  j.resolve_on_host(g, gap->left, (size_t)gap->left_len, gap->right, (size_t)gap->right_len, &flank_store);
   GapOut go;
   memset(&go, 0, sizeof go);
   go.c_count = c_count; go.n_len = n_lengths; go.reached_j = reached_j; go.final_d = final_d;
@@ -2925,7 +2996,8 @@ extern "C" int g2s_test_post_segments(const g2s_graph* gh, const g2s_params* p, 
   GapJob j;
   j.g = gap->gap_len; j.lmf = gap->lmf; j.rmf = gap->rmf;
   if (gap->left_len < k + j.lmf || gap->right_len < k + j.rmf) return fail(G2S_ERR_ARG, "flank too short");
-  j.resolve_on_host(g, gap->left, (size_t)gap->left_len, gap->right, (size_t)gap->right_len);
+  std::vector<uint32_t> flank_store;
+  j.resolve_on_host(g, gap->left, (size_t)gap->left_len, gap->right, (size_t)gap->right_len, &flank_store);
   GapOut go;
   memset(&go, 0, sizeof go);
   go.c_count = c_count; go.n_len = n_lengths; go.reached_j = reached_j; go.final_d = final_d;
@@ -2986,7 +3058,8 @@ extern "C" int g2s_test_seg_expand(const g2s_graph* gh, const g2s_params* p, con
   GapJob j;
   j.g = gap->gap_len; j.lmf = gap->lmf; j.rmf = gap->rmf;
   if (gap->left_len < k + j.lmf || gap->right_len < k + j.rmf) return fail(G2S_ERR_ARG, "flank too short");
-  j.resolve_on_host(g, gap->left, (size_t)gap->left_len, gap->right, (size_t)gap->right_len);
+  std::vector<uint32_t> flank_store;
+  j.resolve_on_host(g, gap->left, (size_t)gap->left_len, gap->right, (size_t)gap->right_len, &flank_store);
   GapOut go;
   memset(&go, 0, sizeof go);
   go.n_len = n_lengths; go.reached_j = reached_j;

@@ -27,21 +27,22 @@ struct GapJob {
   // oriented node (or kInvalidNode) of: left.substr(d,k) d=0..lmf | right-BFS
   // seeds right.substr(len-k-j,k) j=0..rmf | targets right.substr(j,k) j=0..rmf.
   // Not owned: the batch's pinned buffer (written by the flank look-up kernel, flank_lookup.hip)
-  // or, in the test hooks, own_nodes.
+  // or, in the test hooks, the caller's vector (resolve_on_host).
+  // (No member with a destructor: a batch holds one GapJob per gap, built and dropped with every list.)
   const uint32_t* nodes = nullptr;
-  std::vector<uint32_t> own_nodes;  // test hooks only
   const uint32_t* lseeds() const { return nodes; }
   const uint32_t* rseeds() const { return nodes + (lmf + 1); }
   const uint32_t* targets() const { return nodes + (lmf + 1) + (rmf + 1); }
-  // (hooks) resolve the flank k-mers of left / right on the host
-  void resolve_on_host(const Graph& gr, const char* left, size_t left_len, const char* right, size_t right_len) {
+  // (hooks) resolve the flank k-mers of left / right on the host, into *store (which must outlive the job)
+  void resolve_on_host(const Graph& gr, const char* left, size_t left_len, const char* right, size_t right_len,
+                       std::vector<uint32_t>* store) {
     const int k = gr.k;
     (void)left_len;
-    own_nodes.clear();
-    for (int d = 0; d <= lmf; d++) own_nodes.push_back(gr.node_of(left + d));                        // :995,1083
-    for (int d = 0; d <= rmf; d++) own_nodes.push_back(gr.node_of(right + (right_len - k - d)));     // :878,954
-    for (int d = 0; d <= rmf; d++) own_nodes.push_back(gr.node_of(right + d));                       // :1113
-    nodes = own_nodes.data();
+    store->clear();
+    for (int d = 0; d <= lmf; d++) store->push_back(gr.node_of(left + d));                        // :995,1083
+    for (int d = 0; d <= rmf; d++) store->push_back(gr.node_of(right + (right_len - k - d)));     // :878,954
+    for (int d = 0; d <= rmf; d++) store->push_back(gr.node_of(right + d));                       // :1113
+    nodes = store->data();
   }
   size_t buf_bytes(int k, int d_err) const { return (size_t)(g + k + d_err + lmf + rmf + 1 + 2); }
 };
