@@ -474,6 +474,8 @@ def main():
         "resident": {"lists_finished_on_the_device": tm.resident_launches, "lists_given_back_to_the_host_path": tm.resident_fallbacks,
                      "draw_dependent_gaps": tm.draw_dependent_gaps, "draw_count_table_entries": tm.d3_table_entries,
                      "gaps_finished_by_the_host": tm.host_finished_gaps,
+                     "team_groups": tm.team_groups,
+                     "team_groups_by_session": [tm.team_groups_by_session[i] for i in range(min(16, max(1, len(sessions))))],
                      "buffers": "pageable" if args.pageable_buffers else "page-locked (g2s_host_alloc)"},
         "breakdown_ms_per_step": {"wall_inside_the_abi_call": round(in_call / steps * 1e3, 4),
                                   "prepare_flank_lookup_and_upload": per_step("ms_prepare"),

@@ -100,6 +100,8 @@ struct D3Params {
   uint32_t has_skip;   // some gap carries a skip rule
   uint32_t seg_cap;    // closure segments the trace kernel stages in LDS
   uint32_t map_cap;    // fill-buffer positions it can map there: the longest path of the list + 2
+  uint32_t group_size; // gaps per group of the list (a list filled by several sessions: one region of closure records
+  uint64_t sub_region; // per group, sub_region 16-byte units apart); one group: group_size >= n
 };
 
 // the stream: values [0, capacity) into rnd_all[31 ..] (sum_dev = nullptr; independent of the list's kernels, so

@@ -54,6 +54,11 @@ __device__ __forceinline__ uint32_t uni(uint32_t x) { return (uint32_t)__builtin
 #define D3_TILE 256u   /* deviations of one gap a workgroup of g2s_d3_tables takes */
 #define GI_HOST 0x80u  /* the host finishes this gap: its closure was not analysed by the fill kernel */
 
+// the closure records of gap i's group (a list filled by several sessions arrives as one region per group)
+__device__ __forceinline__ const SubRec* sub_of(const D3Params& P, const SubRec* sub, uint32_t i) {
+  return sub + (uint64_t)(i / P.group_size) * P.sub_region;
+}
+
 // the value pp.count of the host analysis (g2s_api.hip: analyze_gap)
 __device__ __forceinline__ int gap_count(const GapOut& go, const D3Params& P, bool phase_d) {
   if (phase_d && !P.skip_confident && P.all_paths) return go.count_s;
@@ -69,12 +74,12 @@ __device__ __forceinline__ unsigned long long wave_add64(unsigned long long v) {
   return v;
 }
 
-__global__ __launch_bounds__(256) void g2s_d3_classify(const D3Params P, const D3Work W, const GapOut* __restrict__ outs,
-                                                       const D3Gap* __restrict__ dgaps) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, n = P.n;
+__device__ __forceinline__ void d3_classify_body(const D3Params& P, const D3Work& W, const GapOut* __restrict__ outs,
+                                                 const D3Gap* __restrict__ dgaps, uint32_t first, uint32_t stride) {
+  const uint32_t n = P.n;
   unsigned long long xA = 0, sA = 0, xB = 0, sB = 0, xD = 0, sD = 0, segs = 0;
   uint32_t unhandled = 0, seg_gaps = 0;
-  if (i < n) {
+  for (uint32_t i = first; i < n; i += stride) {
     const D3Gap dg = dgaps[i];
     uint32_t gi = 0, dmin = 0, spread = 0;
     if (dg.kind != 0) gi = GI_BAD;
@@ -135,6 +140,10 @@ __global__ __launch_bounds__(256) void g2s_d3_classify(const D3Params P, const D
     if (cnts & 0xFFFFFFFFull) atomicAdd(&S->seg_gaps, (uint32_t)cnts);
   }
 }
+__global__ __launch_bounds__(256) void g2s_d3_classify(const D3Params P, const D3Work W, const GapOut* __restrict__ outs,
+                                                       const D3Gap* __restrict__ dgaps) {
+  d3_classify_body(P, W, outs, dgaps, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // scan: the skip rule, prefix sums in list order, table layout.  One workgroup of 1024 threads over the compact
@@ -172,10 +181,8 @@ __device__ __forceinline__ void block_scan3(uint64_t& a, uint64_t& b, uint32_t& 
   __syncthreads();
 }
 
-__global__ __launch_bounds__(1024) void g2s_d3_scan(const D3Params P, const D3Work W, const D3Gap* __restrict__ dgaps) {
-  __shared__ uint64_t sh64[34];
-  __shared__ uint32_t sh32[17];
-  __shared__ uint32_t sh_f[1024];
+__device__ __forceinline__ void d3_scan_body(const D3Params& P, const D3Work& W, const D3Gap* __restrict__ dgaps, uint64_t* sh64 /* [34] */,
+                                             uint32_t* sh32 /* [17] */, uint32_t* sh_f /* [1024] */) {
   const uint32_t t = threadIdx.x, n = P.n;
   const uint32_t per = (n + 1023u) / 1024u;
   const uint32_t lo = min(n, t * per), hi = min(n, lo + per);
@@ -283,6 +290,12 @@ __global__ __launch_bounds__(1024) void g2s_d3_scan(const D3Params P, const D3Wo
     S->draws_min = tot_d;
     S->draws_spread = tot_s;
   }
+}
+__global__ __launch_bounds__(1024) void g2s_d3_scan(const D3Params P, const D3Work W, const D3Gap* __restrict__ dgaps) {
+  __shared__ uint64_t sh64[34];
+  __shared__ uint32_t sh32[17];
+  __shared__ uint32_t sh_f[1024];
+  d3_scan_body(P, W, dgaps, sh64, sh32, sh_f);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -404,31 +417,40 @@ __device__ int d3_walk_count(int n_len, int len0, int len1, uint32_t start_seg, 
 // draws of draw-dependent gap v when its draws start at base + d, for every d it can meet: a workgroup takes 256
 // consecutive deviations of one gap: the closure's links in LDS, one walk per thread
 #define D3_TAB_SEGS 512u
-__global__ __launch_bounds__(256) void g2s_d3_tables(const D3Work W, const GapOut* __restrict__ outs, const SubRec* __restrict__ sub,
-                                                     const uint32_t* __restrict__ rnd /* first upcoming value */, uint64_t capacity) {
-  __shared__ SegLite lseg[D3_TAB_SEGS];
+// (the body: sub-block `sb` of `nsb` sub-blocks of 256 threads takes tiles sb, sb + nsb, ...; every thread of the
+// workgroup passes the same number of barriers)
+__device__ __forceinline__ void d3_tables_body(const D3Params& P, const D3Work& W, const GapOut* __restrict__ outs,
+                                               const SubRec* __restrict__ sub, const uint32_t* __restrict__ rnd, uint64_t capacity,
+                                               SegLite* lseg /* this sub-block's [D3_TAB_SEGS] */, uint32_t sb, uint32_t nsb, uint32_t tid /* 0 .. 255 */) {
   const D3Summary* S = W.sum;
-  if (S->status) return;
   const uint32_t V = S->n_var;
   const uint32_t tiles = V ? W.var_tile[V] : 0u;
   bool bad_any = false;
-  for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-    uint32_t lo = 0, hi = V;  // last v with var_tile[v] <= tile
-    while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (W.var_tile[mid] <= tile) lo = mid; else hi = mid; }
-    const uint32_t v = lo;
-    const uint32_t i = W.var_gap[v];
-    const GapOut& go = outs[i];
-    const uint32_t ns = go.n_xl;
-    const SegW* gs = (const SegW*)(sub + go.sub_off);
-    __syncthreads();
-    for (uint32_t q = threadIdx.x; q < ns && q < D3_TAB_SEGS; q += blockDim.x) {
-      SegLite l;
-      l.depth_len = gs[q].depth_len; l.par01 = gs[q].par01; l.par23 = gs[q].par23; l.flags = gs[q].flags;
-      lseg[q] = l;
+  for (uint32_t t0 = 0; t0 < tiles; t0 += nsb) {
+    const uint32_t tile = t0 + sb;
+    const bool have = tile < tiles;
+    uint32_t v = 0, i = 0, ns = 0;
+    if (have) {
+      uint32_t lo = 0, hi = V;  // last v with var_tile[v] <= tile
+      while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (W.var_tile[mid] <= tile) lo = mid; else hi = mid; }
+      v = lo;
+      i = W.var_gap[v];
+      ns = outs[i].n_xl;
     }
     __syncthreads();
+    if (have) {
+      const SegW* gs = (const SegW*)(sub_of(P, sub, i) + outs[i].sub_off);
+      for (uint32_t q = tid; q < ns && q < D3_TAB_SEGS; q += 256u) {
+        SegLite l;
+        l.depth_len = gs[q].depth_len; l.par01 = gs[q].par01; l.par23 = gs[q].par23; l.flags = gs[q].flags;
+        lseg[q] = l;
+      }
+    }
+    __syncthreads();
+    if (!have) continue;
+    const GapOut& go = outs[i];
     const uint32_t R = W.var_R[v];
-    const uint32_t d = (tile - W.var_tile[v]) * D3_TILE + threadIdx.x;
+    const uint32_t d = (tile - W.var_tile[v]) * D3_TILE + tid;
     if (d <= R) {
       bool bad = ns > D3_TAB_SEGS;
       const uint64_t at = (uint64_t)W.base[i] + d;
@@ -442,15 +464,21 @@ __global__ __launch_bounds__(256) void g2s_d3_tables(const D3Work W, const GapOu
   }
   if (bad_any) atomicAdd(&W.sum->anomalies, 1u);
 }
+__global__ __launch_bounds__(256) void g2s_d3_tables(const D3Params P, const D3Work W, const GapOut* __restrict__ outs,
+                                                     const SubRec* __restrict__ sub,
+                                                     const uint32_t* __restrict__ rnd /* first upcoming value */, uint64_t capacity) {
+  __shared__ SegLite lseg[D3_TAB_SEGS];
+  if (W.sum->status) return;
+  d3_tables_body(P, W, outs, sub, rnd, capacity, lseg, blockIdx.x, gridDim.x, threadIdx.x);
+}
 
 // deviation behind block b for every deviation in front of it
-__global__ __launch_bounds__(256) void g2s_d3_blocks(const D3Work W) {
+__device__ __forceinline__ void d3_blocks_body(const D3Work& W, uint64_t first, uint64_t stride) {
   const D3Summary* S = W.sum;
-  if (S->status) return;
   const uint32_t V = S->n_var;
   const uint32_t NB = (V + G2S_D3_BLOCK_VARS - 1u) / G2S_D3_BLOCK_VARS;
   const uint64_t TB = S->block_entries;
-  for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < TB; e += (uint64_t)gridDim.x * blockDim.x) {
+  for (uint64_t e = first; e < TB; e += stride) {
     uint32_t lo = 0, hi = NB;
     while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if ((uint64_t)W.blk_toff[mid] <= e) lo = mid; else hi = mid; }
     const uint32_t b = lo;
@@ -460,19 +488,21 @@ __global__ __launch_bounds__(256) void g2s_d3_blocks(const D3Work W) {
     W.btab[e] = d;
   }
 }
+__global__ __launch_bounds__(256) void g2s_d3_blocks(const D3Work W) {
+  if (W.sum->status) return;
+  d3_blocks_body(W, (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, (uint64_t)gridDim.x * blockDim.x);
+}
 
 // the chain over blocks, then inside every block; the list's total and the generator's state behind it
-__global__ __launch_bounds__(1024) void g2s_d3_chain(const D3Work W, const uint32_t* __restrict__ Wd) {
+__device__ __forceinline__ void d3_chain_body(const D3Work& W, const uint32_t* __restrict__ Wd, uint32_t* total_dev /* shared */) {
   D3Summary* S = W.sum;
-  if (S->status) return;
   const uint32_t V = S->n_var;
   const uint32_t NB = (V + G2S_D3_BLOCK_VARS - 1u) / G2S_D3_BLOCK_VARS;
-  __shared__ uint32_t total_dev;
   if (threadIdx.x == 0) {
     uint32_t d = 0;
     for (uint32_t b = 0; b < NB; b++) { W.blk_in[b] = d; d = W.btab[(uint64_t)W.blk_toff[b] + d]; }
     W.dvar[V] = d;
-    total_dev = d;
+    *total_dev = d;
   }
   __threadfence_block();
   __syncthreads();
@@ -481,9 +511,35 @@ __global__ __launch_bounds__(1024) void g2s_d3_chain(const D3Work W, const uint3
     const uint32_t v1 = min(V, (b + 1u) * G2S_D3_BLOCK_VARS);
     for (uint32_t v = b * G2S_D3_BLOCK_VARS; v < v1; v++) { W.dvar[v] = d; d += W.tab[(uint64_t)W.var_toff[v] + d]; }
   }
-  const uint64_t total = S->draws_min + total_dev;
+  const uint64_t total = S->draws_min + *total_dev;
   if (threadIdx.x == 0) S->draws_total = total;
   if (threadIdx.x < 31u) S->rand_state[threadIdx.x] = Wd[total + threadIdx.x];
+}
+__global__ __launch_bounds__(1024) void g2s_d3_chain(const D3Work W, const uint32_t* __restrict__ Wd) {
+  __shared__ uint32_t total_dev;
+  if (W.sum->status) return;
+  d3_chain_body(W, Wd, &total_dev);
+}
+
+// Short lists: five launches cost a 2 000-gap list more than the work in them — classes and scan in one launch
+// of one workgroup, blocks and chain in another; the tables keep their own (they want the whole chip).
+__global__ __launch_bounds__(1024) void g2s_d3_front(const D3Params P, const D3Work W, const GapOut* __restrict__ outs,
+                                                     const D3Gap* __restrict__ dgaps) {
+  __shared__ uint64_t sh64[34];
+  __shared__ uint32_t sh32[17];
+  __shared__ uint32_t sh_f[1024];
+  d3_classify_body(P, W, outs, dgaps, threadIdx.x, 1024u);
+  __threadfence();
+  __syncthreads();
+  d3_scan_body(P, W, dgaps, sh64, sh32, sh_f);
+}
+__global__ __launch_bounds__(1024) void g2s_d3_back(const D3Work W, const uint32_t* __restrict__ Wd) {
+  __shared__ uint32_t total_dev;
+  if (W.sum->status) return;
+  d3_blocks_body(W, threadIdx.x, 1024u);
+  __threadfence();
+  __syncthreads();
+  d3_chain_body(W, Wd, &total_dev);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -520,7 +576,7 @@ __global__ __launch_bounds__(64) void g2s_d3_handoff(const D3Params P, const D3W
       continue;
     }
     if ((uint32_t)lane < sizeof(GapOut) / 4u) ((uint32_t*)&side.outs[it])[lane] = ((const uint32_t*)&go)[lane];
-    const uint4* src = (const uint4*)(sub + go.sub_off);
+    const uint4* src = (const uint4*)(sub_of(P, sub, i) + go.sub_off);
     uint4* dst = (uint4*)(side.segs + so);
     for (uint32_t w = (uint32_t)lane; w < 2u * ns; w += 64u) dst[w] = src[w];
     for (uint32_t w = (uint32_t)lane; w < want + 1u; w += 64u) side.rnd[ro + w] = rnd[off + w];
@@ -531,7 +587,7 @@ __global__ __launch_bounds__(64) void g2s_d3_handoff(const D3Params P, const D3W
     }
   }
   // the number of items, where the host reads it once this kernel's event has fired
-  __threadfence_system();
+  if (__ballot(host)) __threadfence_system();
   if (lane == 0) {
     const unsigned int done = atomicAdd(&S->handoff_waves, 1u) + 1u;
     if (done == gridDim.x) {
@@ -609,7 +665,7 @@ __global__ __launch_bounds__(64) void g2s_d3_trace(const D3Params P, const D3Wor
   // ---- the closure into LDS
   const uint32_t nsegs = go.n_xl;
   const bool in_lds = nsegs <= P.seg_cap;
-  const SegW* gsegs = (const SegW*)(sub + go.sub_off);
+  const SegW* gsegs = (const SegW*)(sub_of(P, sub, i) + go.sub_off);
   uint32_t* cmap = lds + (size_t)P.seg_cap * 8u;  // by fill-buffer index: k-mer index | orientation << 30 | lower case << 31
   if (in_lds) {
     const uint4* src = (const uint4*)gsegs;
@@ -831,11 +887,18 @@ hipError_t launch_d3(hipStream_t st, const D3Params& P, const D3Work& W, const G
   // (the summary and, behind it, the 64 fill-byte counters of the trace kernel)
   hipError_t e = hipMemsetAsync(W.sum, 0, 1024 + 64 * 128, st);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(g2s_d3_classify, dim3((P.n + 255u) / 256u), dim3(256), 0, st, P, W, outs, dgaps);
-  hipLaunchKernelGGL(g2s_d3_scan, dim3(1), dim3(1024), 0, st, P, W, dgaps);
-  hipLaunchKernelGGL(g2s_d3_tables, dim3(8192), dim3(256), 0, st, W, outs, sub, rnd_all + 31, rnd_capacity);
-  hipLaunchKernelGGL(g2s_d3_blocks, dim3(256), dim3(256), 0, st, W);
-  hipLaunchKernelGGL(g2s_d3_chain, dim3(1), dim3(1024), 0, st, W, rnd_all);
+  const bool short_list = P.n <= 3072u;
+  if (short_list) hipLaunchKernelGGL(g2s_d3_front, dim3(1), dim3(1024), 0, st, P, W, outs, dgaps);
+  else {
+    hipLaunchKernelGGL(g2s_d3_classify, dim3((P.n + 255u) / 256u), dim3(256), 0, st, P, W, outs, dgaps);
+    hipLaunchKernelGGL(g2s_d3_scan, dim3(1), dim3(1024), 0, st, P, W, dgaps);
+  }
+  hipLaunchKernelGGL(g2s_d3_tables, dim3(8192), dim3(256), 0, st, P, W, outs, sub, rnd_all + 31, rnd_capacity);
+  if (short_list) hipLaunchKernelGGL(g2s_d3_back, dim3(1), dim3(1024), 0, st, W, rnd_all);
+  else {
+    hipLaunchKernelGGL(g2s_d3_blocks, dim3(256), dim3(256), 0, st, W);
+    hipLaunchKernelGGL(g2s_d3_chain, dim3(1), dim3(1024), 0, st, W, rnd_all);
+  }
   hipLaunchKernelGGL(g2s_d3_handoff, dim3((P.n + 63u) / 64u), dim3(64), 0, st, P, W, outs, sub, rnd_all + 31, rnd_capacity, side);
   if (handed_over) {
     e = hipEventRecord(handed_over, st);

@@ -19,7 +19,6 @@
 namespace g2s {
 
 size_t fill_seg_lds_bytes();
-size_t fill_seg_scratch_bytes(uint32_t ngaps);
 uint32_t fill_seg_dbg_words();  // words per gap of the optional diagnostics buffer
 // phases A-D1 of every listed gap in one launch; results land in pinned host memory exactly as
 // the LDS tier leaves them (GapOut per gap, closures packed by an atomic cursor, completion list)
@@ -35,9 +34,7 @@ hipError_t launch_fill_seg(hipStream_t st, uint32_t ngaps, const uint32_t* succ,
                            unsigned long long* xcd_tickets, uint32_t* xcd_list, uint32_t xcd_stride, uint32_t pub_batch,
                            // results stay on the device (sub_out, outs: device memory; outs_host, done_list unused):
                            // phase D3 follows on the stream (d3_device.hip)
-                           bool resident = false,
-                           // fill_seg_scratch_bytes(ngaps) of device memory: the segments phase B appends
-                           uint32_t* seg_scratch = nullptr);
+                           bool resident = false);
 
 // The large variant: `workgroups` persistent workgroups (one per compute unit) take the listed gaps
 // in order from the counter *next_gap (zero before the launch); scratch: fill_segx_scratch_bytes().

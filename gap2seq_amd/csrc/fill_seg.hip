@@ -72,14 +72,6 @@ __device__ __forceinline__ void lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)"
 __device__ __forceinline__ uint32_t rl(uint32_t x, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)x, l); }
 __device__ __forceinline__ uint32_t uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
 __device__ __forceinline__ uint64_t below(int lane) { return (1ull << lane) - 1ull; }
-// A launch ends with its slowest gap, and on a full chip every gap runs at half the speed it has alone: a gap that
-// has been searching for many rounds is one of the few that decide the launch — its wave asks for issue priority
-// over the waves of the gaps that have only just begun (s_setprio: 0 lowest .. 3).
-__device__ __forceinline__ void age_priority(uint32_t rounds) {
-  if (rounds == 12u) __builtin_amdgcn_s_setprio(1);
-  else if (rounds == 28u) __builtin_amdgcn_s_setprio(2);
-  else if (rounds == 56u) __builtin_amdgcn_s_setprio(3);
-}
 // state t of the segment that starts at v0
 __device__ __forceinline__ uint32_t seg_node(uint32_t v0, uint32_t t) { return (v0 & 1u) ? v0 - 2u * t : v0 + 2u * t; }
 // t with seg_node(v0, t) == node and t < len, else -1
@@ -206,15 +198,12 @@ struct SegArgs {
   // the results stay on the device (sub_out and outs are device memory, phase D3 follows on the stream:
   // d3_device.hip): nothing is announced to the host, no write-back of the L2 per gap
   uint32_t resident;
-  uint32_t* seg_scratch;            // regular tier: SEG_SCR_WORDS words of global scratch per gap of the launch
 };
 
 // LDS of the large variant (words): see the layout notes at each phase
 #define SEGX_LDS_WORDS 39936u
 // global scratch of one workgroup of the large variant (words): six segment arrays + two queues
 #define SEGX_SCR_WORDS (6u * G2S_SEGX_CAP + 2u * G2S_SEGX_QCAP)
-// global scratch of one gap of the regular tier (words): node, depth | length, count, parents x 2
-#define SEG_SCR_WORDS (5u * G2S_SEG_CAP)
 #define SEGX_EMPTY64 0xFFFFFFFFFFFFFFFFull
 #define SEGX_TOMB64 0xFFFFFFFFFFFFFFFEull
 
@@ -245,22 +234,16 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
   uint32_t* dbg = A.dbg;
   const uint32_t dbg_words = A.dbg_words;
   constexpr uint32_t CAP = BIG ? G2S_SEGX_CAP : G2S_SEG_CAP;
-  // Segment arrays.  What phase B appends per segment (entry node, depth | length, count, parents) is WRITE-ONLY until
-  // the search has ended: it goes to the gap's chunk of global scratch — stores nobody waits for — and is read back by
-  // the tail (Q7 between segments, phases C, D1, D2, emission) through the L2.  Only the two words per segment that
-  // phase D1 updates (s_aux, s_t) live in LDS.  (Until round 2 all seven arrays of the regular tier were in LDS:
-  // 14.5 KB per gap, 11 gaps per compute unit; the LDS a gap needs is now phase A's table, SEG_A_BYTES.)
-  uint32_t* s_node = scr;                       // entry node of the segment
+  // segment arrays: LDS (7 arrays of G2S_SEG_CAP words + left seeds), or the scratch; s_aux / s_t always in LDS
+  uint32_t* s_node = BIG ? scr : lds;           // entry node of the segment
   uint32_t* s_dl = s_node + CAP;                // entry depth | length << 16
   uint32_t* s_cnt = s_dl + CAP;                 // path count of every state of the segment
   uint32_t* s_p01 = s_cnt + CAP;                // parents (segment ids, 16 bits each, 0xFFFF = none)
   uint32_t* s_p23 = s_p01 + CAP;
   uint32_t* s_gen = s_p23 + CAP;                // (BIG) generation, copied into s_aux before phase D1
-  // LDS of the regular tier: left seeds [32] | s_aux, s_t [CAP each], aliased by phase A's region when one wave does
-  // both (two waves: phase A's region behind them)
-  uint32_t* s_aux = BIG ? lds : lds + 32u;      // generation | closure marks of the children << 16; later: emit offset
+  uint32_t* s_aux = BIG ? lds : s_p23 + CAP;    // generation | closure marks of the children << 16; later: emit offset
   uint32_t* s_t = s_aux + CAP;                  // last closure state: towards a sink | from a traceback start << 16 (0xFFFF none)
-  uint32_t* l_seed = BIG ? lds + (SEGX_LDS_WORDS - 32u) : lds;  // left-flank seeds by depth [32]
+  uint32_t* l_seed = BIG ? lds + (SEGX_LDS_WORDS - 32u) : s_t + CAP;  // left-flank seeds by depth [32]
 
   const int lane = (int)(threadIdx.x & 63u);
   const int wave = TWO ? (int)(threadIdx.x >> 6) : 0;
@@ -367,10 +350,10 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
   // rem[], one successor record, and the proposals of the whole wave go through one LDS table
   // keyed by node with 64-bit atomic min on (node << 32 | label) — a per-proposal compare against
   // register-resident entries costs ~1.5 k cycles of scalar/vector ping-pong each (measured).
-  // LDS (one wave: aliasing s_aux / s_t, which phase B fills later; two waves: behind them):
+  // LDS (one wave: aliasing the segment arrays, which phase B fills later; two waves: behind them):
   //   lab[ALAB] u64 | labrem[ALAB] u32 | q[2][ACAP] u32 nodes | q[2][ACAP] u32 table positions | 8 words
   constexpr uint32_t ACAP = 64u * G2S_SEG_ASETS, ALAB = 2u * ACAP;
-  uint64_t* lab = (uint64_t*)(TWO ? lds + (2u * G2S_SEG_CAP + 32u) : lds + 32u);
+  uint64_t* lab = (uint64_t*)(TWO ? lds + (7u * G2S_SEG_CAP + 32u) : lds);
   uint32_t* labrem = (uint32_t*)(lab + ALAB);
   uint32_t* aq0 = labrem + ALAB;
   uint32_t* ash = aq0 + 4u * ACAP;  // (two waves) what wave 1 hands over: entries, rounds, flags, overflow, cycles
@@ -450,7 +433,6 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
       }
       while (ne > 0 && !overflow) {
         roundsA++;
-        age_priority(roundsA);
         const uint32_t* qc = aq0 + cur * ACAP;
         const uint32_t* qcs = aqs + cur * ACAP;
         uint32_t* qn = aq0 + (cur ^ 1u) * ACAP;
@@ -927,7 +909,6 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
       }
     }
     while (ev && !overflow) {
-      age_priority((TWO ? 0u : roundsA) + gen);
       SEG_PROF_T(0);
       if (((ev >> lane) & 1ull) && es == 0u) {  // one round trip for all events created last round
         if (ed < lmf) { es = 1u; erec = *(const uint4*)(succ + (size_t)en * 4); }  // above the flank: one state, leaves at once
@@ -1332,11 +1313,6 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
   }
   if (!have_rs) take_right_set();  // (the search ended before the pruning depth: wave 1 is met here)
   if (overflow && !(flags & G2S_DEV_OVERFLOW_A)) flags |= G2S_DEV_OVERFLOW_B;
-  if constexpr (!BIG) {
-    // (the segment arrays in the scratch are read back below; lines this compute unit cached for another gap go)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  }
   lds_sync();
   const unsigned long long cyc2 = __builtin_amdgcn_s_memtime();
   SEG_PROF_TAIL(0);
@@ -1811,10 +1787,10 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
   publish();
 }
 
-// dynamic LDS: left seeds, then phase A's region over s_aux / s_t
+// dynamic LDS: 7 arrays of G2S_SEG_CAP words + left seeds
 __global__ __launch_bounds__(64) void g2s_fill_seg(const SegArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-  seg_fill_one<false, false>(lds, A, blockIdx.x, A.seg_scratch + (size_t)blockIdx.x * SEG_SCR_WORDS);
+  seg_fill_one<false, false>(lds, A, blockIdx.x, nullptr);
 }
 
 // Two waves per gap (see seg_fill_one): for lists short enough to be latency-bound — the launch ends with its
@@ -1822,7 +1798,7 @@ __global__ __launch_bounds__(64) void g2s_fill_seg(const SegArgs A) {
 // dynamic LDS: the segment arrays and seeds, then phase A's table, queues and hand-over words
 __global__ __launch_bounds__(128) void g2s_fill_seg2(const SegArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-  seg_fill_one<false, true>(lds, A, blockIdx.x, A.seg_scratch + (size_t)blockIdx.x * SEG_SCR_WORDS);
+  seg_fill_one<false, true>(lds, A, blockIdx.x, nullptr);
 }
 
 // The large variant: one workgroup per compute unit (it takes nearly all of the LDS), each working
@@ -1844,11 +1820,8 @@ __global__ __launch_bounds__(64) void g2s_fill_segx(const SegArgs A, uint32_t* s
 
 namespace g2s {
 
-// phase A's region (words): label table (64-bit) | steps left | two queues of nodes and of table positions | hand-over words
-#define SEG_A_WORDS (2u * 128u * G2S_SEG_ASETS + 128u * G2S_SEG_ASETS + 4u * 64u * G2S_SEG_ASETS + 8u)
-size_t fill_seg_lds_bytes() { return 4u * (32u + (SEG_A_WORDS > 2u * G2S_SEG_CAP ? SEG_A_WORDS : 2u * G2S_SEG_CAP)); }
-size_t fill_seg2_lds_bytes() { return 4u * (32u + 2u * G2S_SEG_CAP + SEG_A_WORDS); }
-size_t fill_seg_scratch_bytes(uint32_t ngaps) { return (size_t)ngaps * SEG_SCR_WORDS * 4u; }
+size_t fill_seg_lds_bytes() { return 4u * (7u * G2S_SEG_CAP + 32u); }
+size_t fill_seg2_lds_bytes() { return 4u * (7u * G2S_SEG_CAP + 32u + 2u * 128u * G2S_SEG_ASETS + 128u * G2S_SEG_ASETS + 4u * 64u * G2S_SEG_ASETS + 8u); }
 uint32_t fill_seg_dbg_words() { return 8u + 2u * 64u * G2S_SEG_ASETS + 6u * G2S_SEG_CAP + 10u; }  // (+10: profile words)
 size_t fill_segx_lds_bytes() { return 4u * SEGX_LDS_WORDS; }
 size_t fill_segx_scratch_bytes(uint32_t workgroups) { return (size_t)workgroups * SEGX_SCR_WORDS * 4u; }
@@ -1858,16 +1831,15 @@ hipError_t launch_fill_seg(hipStream_t st, uint32_t ngaps, const uint32_t* succ,
                            const uint32_t* gap_ids, const uint32_t* flank_nodes, SubRec* sub_out,
                            unsigned long long out_cap, unsigned long long* out_counter, GapOut* outs, GapOut* outs_host,
                            uint32_t* done_list, int skip_confident, uint32_t* dbg, bool two_waves, unsigned long long* xcd_tickets,
-                           uint32_t* xcd_list, uint32_t xcd_stride, uint32_t pub_batch, bool resident, uint32_t* seg_scratch) {
+                           uint32_t* xcd_list, uint32_t xcd_stride, uint32_t pub_batch, bool resident) {
   if (ngaps == 0) return hipSuccess;
-  if (!seg_scratch) return hipErrorInvalidValue;
   const size_t bytes = two_waves ? fill_seg2_lds_bytes() : fill_seg_lds_bytes();
   hipError_t e = hipFuncSetAttribute(two_waves ? (const void*)g2s_fill_seg2 : (const void*)g2s_fill_seg,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   if (e != hipSuccess) return e;
   if (!xcd_tickets || !xcd_list || pub_batch < 2u || pub_batch > 64u || (pub_batch & (pub_batch - 1u))) pub_batch = 1u;
   const SegArgs A = {succ, urec, gaps, gap_ids, flank_nodes, sub_out, out_cap, out_counter, outs, outs_host, done_list,
-                     skip_confident, dbg, fill_seg_dbg_words(), xcd_tickets, xcd_list, xcd_stride, pub_batch, resident ? 1u : 0u, seg_scratch};
+                     skip_confident, dbg, fill_seg_dbg_words(), xcd_tickets, xcd_list, xcd_stride, pub_batch, resident ? 1u : 0u};
   if (two_waves) hipLaunchKernelGGL(g2s_fill_seg2, dim3(ngaps), dim3(128), bytes, st, A);
   else hipLaunchKernelGGL(g2s_fill_seg, dim3(ngaps), dim3(64), bytes, st, A);
   return hipGetLastError();
@@ -1883,7 +1855,7 @@ hipError_t launch_fill_segx(hipStream_t st, uint32_t ngaps, uint32_t workgroups,
   hipError_t e = hipFuncSetAttribute((const void*)g2s_fill_segx, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   if (e != hipSuccess) return e;
   const SegArgs A = {succ, urec, gaps, gap_ids, flank_nodes, sub_out, out_cap, out_counter, outs, outs_host, done_list,
-                     skip_confident, dbg, fill_segx_dbg_words(), nullptr, nullptr, 0u, 1u, 0u, nullptr};
+                     skip_confident, dbg, fill_segx_dbg_words(), nullptr, nullptr, 0u, 1u, 0u};
   hipLaunchKernelGGL(g2s_fill_segx, dim3(workgroups), dim3(64), bytes, st, A, scratch, ngaps, next_gap);
   return hipGetLastError();
 }

@@ -527,7 +527,6 @@ struct g2s_session {
   std::vector<SubPrep> spare_prep;
   DevBuf d_log, d_lvl, d_plk, d_xl, d_xo;  // LDS tier: state log, level offsets, parent links, closure side lists
   DevBuf d_segx;  // large variant of the segment tier: segment arrays and queues of its persistent workgroups
-  DevBuf d_segscr;  // segment tier: the segments phase B appends, a chunk per gap of the launch
   int num_cus = 256;
   DevBuf d_rspool;
   DevBuf d_logpool;  // chunks for state logs that outgrow their slice of d_log (LDS tier)                          // LDS tier: spill pool for right sets
@@ -545,10 +544,14 @@ struct g2s_session {
   g2s_timing last_timing;        // of the last g2s_fill_batch / g2s_batch_run (g2s_session_last_timing)
   // resident mode (run_resident): closures, phase D3 work areas and the rand() stream stay on the device
   DevBuf d_sub, d_d3, d_rnd, d_lastch, d_rtab, d_resout, d_textout;
+  DevBuf d_outs_all, d_sub_all;  // lead of a team: the groups' records and closure records, gathered for phase D3
+  PinBuf h_d3all;                // and the list's D3Gap array, summary and stream window
   PinBuf h_d3;                   // D3Gap per gap | summary | stream window; staging of results / text when the caller's are not pinned
   PinBuf h_res, h_text, h_side;
   RandTables rtab;
   std::vector<uint32_t> res_ids, res_at;  // launch order of a resident list and its counting sort, kept between lists
+  bool in_team_list = false;     // the session is filling a group of a team's list (team_resident)
+  bool team_shares_device = false;  // ... and another session of the team sits on the same device
   int resident_strikes = 0;      // lists that had to be run again on the host path; three in a row switch the mode off
   bool resident_off = false;
 };
@@ -636,7 +639,7 @@ extern "C" void g2s_session_destroy(g2s_session* s) {
   (void)hipSetDevice(s->device);
   DevBuf* bufs[] = {&s->d_gaps, &s->d_ids, &s->d_flank, &s->d_outs, &s->d_rs, &s->d_rlog, &s->d_keys,
                     &s->d_cnt, &s->d_mark, &s->d_slog, &s->d_subscr, &s->d_subout, &s->d_counter, &s->d_xcd,
-                    &s->d_log, &s->d_lvl, &s->d_plk, &s->d_xl, &s->d_xo, &s->d_rspool, &s->d_logpool, &s->d_segx, &s->d_segscr};
+                    &s->d_log, &s->d_lvl, &s->d_plk, &s->d_xl, &s->d_xo, &s->d_rspool, &s->d_logpool, &s->d_segx};
   for (DevBuf* b : bufs) b->release();
   delete s->pool;
   for (PinBuf* pb : s->pin_free) { pb->release(); delete pb; }
@@ -644,6 +647,7 @@ extern "C" void g2s_session_destroy(g2s_session* s) {
   for (void* v : s->tier_pool) { TierData* t = (TierData*)v; t->outs.release(); t->subs.release(); t->done.release(); delete t; }
   s->h_gaps.release();
   for (int i = 0; i < 5; i++) if (s->ev[i]) (void)hipEventDestroy(s->ev[i]);
+  s->d_outs_all.release(); s->d_sub_all.release(); s->h_d3all.release();
   s->d_resout.release(); s->d_textout.release(); s->d_sub.release(); s->d_d3.release(); s->d_rnd.release(); s->d_lastch.release(); s->d_rtab.release();
   s->h_d3.release(); s->h_res.release(); s->h_text.release(); s->h_side.release();
   if (s->ev_rand) (void)hipEventDestroy(s->ev_rand);
@@ -736,7 +740,9 @@ static TierData* take_tier(g2s_session* s, size_t /*unused*/) {
 static bool resident_applicable(const g2s_session* s, size_t n) {
   if (s->resident_off || n == 0) return false;
   const int forced = getenv("G2S_RESIDENT") ? atoi(getenv("G2S_RESIDENT")) : -1;  // (1: lists of any length; 0: never)
-  if (forced == 0 || (forced != 1 && n < 1024)) return false;  // (short lists: the host analyses gaps while the launch's stragglers run)
+  // (short lists: the host analyses gaps while the launch's stragglers run; the groups of a team's list are short
+  // on purpose)
+  if (forced == 0 || (forced != 1 && !s->in_team_list && n < 1024)) return false;
   if (getenv("G2S_NO_SEG_TIER") || getenv("G2S_FORCE_SEGX") || getenv("G2S_HOST_D2") || getenv("G2S_SEG_DUMP") ||
       getenv("G2S_DUMP_STATS") || getenv("G2S_NO_LDS_TIER") || getenv("G2S_STATE_D2"))
     return false;
@@ -1118,7 +1124,6 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
       HIP_TRY(hipMemsetAsync(s->d_slog.p, 0, (size_t)ids.size() * seg_dbg_w * 4, st));
       seg_dbg = (uint32_t*)s->d_slog.p;
     }
-    if (seg == 1) HIP_TRY(s->d_segscr.ensure(fill_seg_scratch_bytes((uint32_t)ids.size())));
     if (seg == 2) {
       // one persistent workgroup per compute unit (the variant takes nearly all of a CU's LDS)
       const uint32_t wgs = (uint32_t)std::min<size_t>(ids.size(), (size_t)std::max(1, s->num_cus));
@@ -1136,7 +1141,7 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
                               // short lists are latency-bound (the launch ends with its slowest gap): two waves per
                               // gap; long lists fill the chip and are throughput-bound: one (G2S_SEG_WAVES=1|2 forces)
                               seg_two_waves, (unsigned long long*)s->d_xcd.p, (uint32_t*)((char*)s->d_xcd.p + 64),
-                              (uint32_t)ids.size(), pub_batch, false, (uint32_t*)s->d_segscr.p));
+                              (uint32_t)ids.size(), pub_batch));
     else
     HIP_TRY(launch_fill_lds(st, (uint32_t)ids.size(), lds_cap_max, num_oriented, dg.succ, dg.ustart,
                             gaps_dev, ids_dev, (const uint32_t*)s->d_flank.p,
@@ -2368,21 +2373,25 @@ static bool finish_gap_on_host(const Graph& g, const FillParams& fp, const GapJo
   return true;
 }
 
-int run_resident(g2s_batch* b, g2s_result* results, char* arena) {
+// ---- resident mode, first half: one batch's fill kernel on its session's stream, records and closures into the
+// session's own device buffers (d_outs, d_sub).  *units: 16-byte units of closure records the launch may write.
+// Returns G2S_OK, 1 (the batch is not one for this mode) or an error.
+struct ResidentLaunch {
+  uint64_t units = 0;
+  bool two_waves = false;
+  size_t launched = 0;
+};
+static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl) {
   g2s_session* s = b->s;
   const size_t n = b->jobs.size();
   if (!resident_applicable(s, n) || !b->seg_tier_all || b->host_lookup) return 1;
   const Graph& g = *s->graph->g;
   const DeviceGraph& dg = g.dev.at(s->device);
-  const FillParams fp = fill_params_of(s);
-  const int d_err = fp.d_err;
-  const auto t_enter = std::chrono::steady_clock::now();
+  const int d_err = s->params.d_err;
   if (hipSetDevice(s->device) != hipSuccess) return fail(G2S_ERR_NO_DEVICE, "cannot select device");
   { const int rc = b->upload_flanks(); if (rc != G2S_OK) return rc; }
-  size_t rnd_cap = b->rnd_cap;
-  const int gmax = b->gmax, dmax = b->dmax;
-  const bool has_skip = b->has_skip;
-  if (rnd_cap >= (1ull << 31) || dmax > 12000) return 1;  // (the trace kernel maps a whole fill in LDS)
+  const int gmax = b->gmax;
+  if (b->rnd_cap >= (1ull << 31) || b->dmax > 12000) return 1;  // (the trace kernel maps a whole fill in LDS)
   // ---- the launch order: longest gaps first (a stable counting sort; the session keeps the vectors)
   std::vector<uint32_t>& ids = s->res_ids;
   ids.clear();
@@ -2403,8 +2412,6 @@ int run_resident(g2s_batch* b, g2s_result* results, char* arena) {
   uint32_t* ids_pinned = (uint32_t*)(gd + n);
   if (!ids.empty()) memcpy(ids_pinned, ids.data(), ids.size() * 4);
   D3Gap* dgaps = (D3Gap*)s->h_d3.p;
-  D3Summary* hsum = (D3Summary*)((char*)s->h_d3.p + n * sizeof(D3Gap) + 16 - (n * sizeof(D3Gap)) % 16);
-  uint32_t* hwin = (uint32_t*)((char*)hsum + 1024 + 64 * 128);  // (summary, the trace kernel's 64 fill-byte counters, the window)
   if (!(b->fast_desc && s->desc_owner == b)) {
     // ---- descriptors (the preparation fills them itself when it expects this mode; a batch that is run again
     // after another one was prepared on the session finds them overwritten): GapDev for the fill kernel, D3Gap
@@ -2435,23 +2442,87 @@ int run_resident(g2s_batch* b, g2s_result* results, char* arena) {
     s->desc_owner = b;
     b->fast_desc = true;
   }
-  const auto t_desc = std::chrono::steady_clock::now();
   // ---- device buffers
   const uint64_t out_states = (uint64_t)ids.size() * 128u + 2u * G2S_SEG_CAP;  // 16-byte units: two per closure segment
-  rnd_cap = (rnd_cap + 2 * G2S_RAND_BLOCK) & ~(size_t)(G2S_RAND_BLOCK - 1);
   HIP_TRY(s->d_gaps.ensure(n * sizeof(GapDev)));
   HIP_TRY(s->d_ids.ensure(std::max<size_t>(ids.size() * 4, 16)));
   HIP_TRY(s->d_outs.ensure(n * sizeof(GapOut)));
   HIP_TRY(s->d_counter.ensure(32));
   HIP_TRY(s->d_sub.ensure(out_states * sizeof(SubRec)));
-  HIP_TRY(s->d_segscr.ensure(fill_seg_scratch_bytes((uint32_t)ids.size())));
+  hipStream_t st = s->stream;
+  void* d_gaps_host = nullptr;
+  HIP_TRY(hipHostGetDevicePointer(&d_gaps_host, s->h_gaps.p, 0));
+  const GapDev* gaps_dev = (const GapDev*)d_gaps_host;
+  const uint32_t* ids_dev = (const uint32_t*)(gaps_dev + n);
+  if (ids.size() > 2048) {  // (long lists: the descriptors are read by several kernels; short ones read them once, over the link)
+    HIP_TRY(hipMemcpyAsync(s->d_gaps.p, gd, n * sizeof(GapDev), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(s->d_ids.p, ids_pinned, ids.size() * 4, hipMemcpyHostToDevice, st));
+    gaps_dev = (const GapDev*)s->d_gaps.p;
+    ids_dev = (const uint32_t*)s->d_ids.p;
+  }
+  if (s->d_outs.clean < n * sizeof(GapOut)) HIP_TRY(hipMemsetAsync(s->d_outs.p, 0, n * sizeof(GapOut), st));
+  if (s->d_counter.clean < 32) HIP_TRY(hipMemsetAsync(s->d_counter.p, 0, 32, st));
+  s->d_outs.clean = 0;
+  s->d_counter.clean = 0;
+  // (two waves per gap when the launch is short enough to end with its slowest gap — unless the sessions of a team
+  // share this device: the chip is then as full as one long launch makes it)
+  const bool two_waves = getenv("G2S_SEG_WAVES") ? atoi(getenv("G2S_SEG_WAVES")) == 2 : (ids.size() <= 2048 && !s->team_shares_device);
+  HIP_TRY(hipEventRecord(s->ev[1], st));
+  HIP_TRY(launch_fill_seg(st, (uint32_t)ids.size(), dg.succ, dg.urec, gaps_dev, ids_dev, (const uint32_t*)s->d_flank.p,
+                          (SubRec*)s->d_sub.p, (unsigned long long)out_states, (unsigned long long*)s->d_counter.p,
+                          (GapOut*)s->d_outs.p, nullptr, nullptr, s->params.skip_confident ? 1 : 0, nullptr, two_waves,
+                          nullptr, nullptr, 0u, 1u, true));
+  HIP_TRY(hipEventRecord(s->ev[2], st));
+  rl->units = out_states;
+  rl->two_waves = two_waves;
+  rl->launched = ids.size();
+  return G2S_OK;
+}
+// the buffers a fill launch used are reset for the next one, off its critical path
+static int resident_reset_fill(g2s_session* s, size_t n) {
+  HIP_TRY(hipMemsetAsync(s->d_outs.p, 0, n * sizeof(GapOut), s->stream));
+  s->d_outs.clean = n * sizeof(GapOut);
+  HIP_TRY(hipMemsetAsync(s->d_counter.p, 0, 32, s->stream));
+  s->d_counter.clean = 32;
+  return G2S_OK;
+}
+
+// ---- resident mode, second half: phase D3 for a whole list on the lead session's device.  The list is one batch
+// (run_resident) or the groups of a team (team_resident), whose records and closures have been gathered on the lead's
+// device: outs_dev [n], the closure records of group q at sub_dev + q * sub_region.
+struct ResidentList {
+  std::vector<g2s_batch*> groups;      // in list order
+  size_t n = 0, group_size = 0;        // gaps of the list; gaps per group (all but the last)
+  std::vector<size_t> group_arena;     // where each group's share of the arena begins
+  size_t arena_bytes = 0;
+  const GapOut* outs_dev = nullptr;
+  const SubRec* sub_dev = nullptr;
+  uint64_t sub_region = 0;
+  PinBuf* pin = nullptr;               // [D3Gap x n | summary | fill-byte counters | stream window], D3Gap filled by the caller
+  size_t rnd_cap = 0;
+  int dmax = 0;
+  bool has_skip = false;
+  const GapDev* gaps_dev = nullptr;
+  hipEvent_t ready = nullptr;          // (optional) the lead's stream waits for it in front of phase D3
+};
+static int resident_d3(g2s_session* s, const ResidentList& L, g2s_result* results, char* arena, g2s_timing* tm_out,
+                       double* ms_d3_out, bool* fell_back) {
+  const size_t n = L.n;
+  const Graph& g = *s->graph->g;
+  const FillParams fp = fill_params_of(s);
+  const auto t_enter = std::chrono::steady_clock::now();
+  *fell_back = false;
+  if (hipSetDevice(s->device) != hipSuccess) return fail(G2S_ERR_NO_DEVICE, "cannot select device");
+  D3Summary* hsum = (D3Summary*)((char*)L.pin->p + n * sizeof(D3Gap) + 16 - (n * sizeof(D3Gap)) % 16);
+  uint32_t* hwin = (uint32_t*)((char*)hsum + 1024 + 64 * 128);  // (summary, the trace kernel's 64 fill-byte counters, the window)
+  size_t rnd_cap = (L.rnd_cap + 2 * G2S_RAND_BLOCK) & ~(size_t)(G2S_RAND_BLOCK - 1);
   HIP_TRY(s->d_d3.ensure(d3_work_bytes((uint32_t)n)));
   HIP_TRY(s->d_rnd.ensure((31 + rnd_cap + 64) * 4));
-  // what the trace kernel hands back for the gaps whose closure the host analyses (a fraction of a per cent of a list)
+  // what the hand-off kernel gives the host for the gaps whose closure the host analyses (a fraction of a per cent of a list)
   D3Side side, side_h;
   {
     side_h.cap_items = n;
-    side_h.cap_segs = std::max<uint64_t>((uint64_t)ids.size() * 16u, 65536u);
+    side_h.cap_segs = std::max<uint64_t>((uint64_t)n * 16u, 65536u);
     side_h.cap_rnd = rnd_cap / 8 + 65536u;
     const size_t b_items = (n * sizeof(D3HostItem) + 63) & ~(size_t)63, b_outs = (n * sizeof(GapOut) + 63) & ~(size_t)63;
     const size_t b_segs = side_h.cap_segs * sizeof(SegRec);
@@ -2475,12 +2546,12 @@ int run_resident(g2s_batch* b, g2s_result* results, char* arena) {
   // (G2S_D3_STAGE=device, measurements only: the kernels write device memory, two copies bring it to the caller)
   const bool stage_dev = getenv("G2S_D3_STAGE") && !strcmp(getenv("G2S_D3_STAGE"), "device");
   bool res_direct = !stage_dev && device_pointer_of(results, &res_dev);
-  bool arena_direct = !stage_dev && (b->arena_bytes == 0 || device_pointer_of(arena, &arena_dev));
+  bool arena_direct = !stage_dev && (L.arena_bytes == 0 || device_pointer_of(arena, &arena_dev));
   if (stage_dev) {
     HIP_TRY(s->d_resout.ensure(n * sizeof(g2s_result)));
-    HIP_TRY(s->d_textout.ensure(b->arena_bytes + 16));
+    HIP_TRY(s->d_textout.ensure(L.arena_bytes + 16));
     res_dev = s->d_resout.p;
-    arena_dev = (char*)s->d_textout.p - b->arena_base;  // (the kernels index with arena_base + the gap's offset)
+    arena_dev = s->d_textout.p;
     res_direct = arena_direct = true;
   }
   if (!res_direct && !stage_dev) {
@@ -2488,56 +2559,37 @@ int run_resident(g2s_batch* b, g2s_result* results, char* arena) {
     HIP_TRY(hipHostGetDevicePointer(&res_dev, s->h_res.p, 0));
   }
   if (!arena_direct && !stage_dev) {
-    HIP_TRY(s->h_text.ensure(b->arena_bytes + 16));
+    HIP_TRY(s->h_text.ensure(L.arena_bytes + 16));
     HIP_TRY(hipHostGetDevicePointer(&arena_dev, s->h_text.p, 0));
-    arena_dev = (char*)arena_dev - b->arena_base;  // (the kernels index with the arena offsets of the whole list)
   }
-  const auto t_bufs = std::chrono::steady_clock::now();
   hipStream_t st = s->stream;
-  void *d_gaps_host = nullptr, *d_dgaps = nullptr;
-  HIP_TRY(hipHostGetDevicePointer(&d_gaps_host, s->h_gaps.p, 0));
-  HIP_TRY(hipHostGetDevicePointer(&d_dgaps, s->h_d3.p, 0));
-  const GapDev* gaps_dev = (const GapDev*)d_gaps_host;
-  const uint32_t* ids_dev = (const uint32_t*)(gaps_dev + n);
-  if (ids.size() > 2048) {  // (long lists: the descriptors are read by several kernels; short ones read them once, over the link)
-    HIP_TRY(hipMemcpyAsync(s->d_gaps.p, gd, n * sizeof(GapDev), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(s->d_ids.p, ids_pinned, ids.size() * 4, hipMemcpyHostToDevice, st));
-    gaps_dev = (const GapDev*)s->d_gaps.p;
-    ids_dev = (const uint32_t*)s->d_ids.p;
-  }
-  if (s->d_outs.clean < n * sizeof(GapOut)) HIP_TRY(hipMemsetAsync(s->d_outs.p, 0, n * sizeof(GapOut), st));
-  if (s->d_counter.clean < 32) HIP_TRY(hipMemsetAsync(s->d_counter.p, 0, 32, st));
-  s->d_outs.clean = 0;
-  s->d_counter.clean = 0;
+  void* d_dgaps = nullptr;
+  HIP_TRY(hipHostGetDevicePointer(&d_dgaps, L.pin->p, 0));
   // the rand() values the list can draw, generated beside the look-up and fill kernels on a stream of their own
   memcpy(hwin, s->rcache.window(G2S_RAND_WINDOW), G2S_RAND_WINDOW * 4);
   HIP_TRY(hipMemcpyAsync(s->d_rnd.p, hwin, G2S_RAND_WINDOW * 4, hipMemcpyHostToDevice, s->stream2));
   HIP_TRY(launch_rand_fill(s->stream2, (uint32_t*)s->d_rnd.p, s->rtab, nullptr, (uint64_t)rnd_cap));
   HIP_TRY(hipEventRecord(s->ev_rand, s->stream2));
-  // ---- the launches: fill kernel, then phase D3, nothing in between comes back to the host
-  const bool two_waves = getenv("G2S_SEG_WAVES") ? atoi(getenv("G2S_SEG_WAVES")) == 2 : ids.size() <= 2048;
-  HIP_TRY(hipEventRecord(s->ev[1], st));
-  HIP_TRY(launch_fill_seg(st, (uint32_t)ids.size(), dg.succ, dg.urec, gaps_dev, ids_dev, (const uint32_t*)s->d_flank.p,
-                          (SubRec*)s->d_sub.p, (unsigned long long)out_states, (unsigned long long*)s->d_counter.p,
-                          (GapOut*)s->d_outs.p, nullptr, nullptr, s->params.skip_confident ? 1 : 0, nullptr, two_waves,
-                          nullptr, nullptr, 0u, 1u, true, (uint32_t*)s->d_segscr.p));
-  HIP_TRY(hipEventRecord(s->ev[2], st));
   HIP_TRY(hipStreamWaitEvent(st, s->ev_rand, 0));
+  if (L.ready) HIP_TRY(hipStreamWaitEvent(st, L.ready, 0));
+  HIP_TRY(hipEventRecord(s->ev[0], st));
   D3Params P;
   P.k = fp.k; P.skip_confident = fp.skip_confident ? 1 : 0; P.all_paths = fp.all_paths ? 1 : 0; P.unique_paths = fp.unique_paths ? 1 : 0;
   P.max_states = (uint64_t)std::max<int64_t>(s->params.max_mem, 1 << 16) / 64;
   P.n = (uint32_t)n;
-  P.has_skip = has_skip ? 1u : 0u;
-  P.arena_base = (uint64_t)b->arena_base;
+  P.has_skip = L.has_skip ? 1u : 0u;
+  P.arena_base = 0;
+  P.group_size = (uint32_t)std::max<size_t>(L.group_size, 1);
+  P.sub_region = L.sub_region;
   P.seg_cap = fp.skip_confident ? G2S_SEG_CAP : 192u;
-  P.map_cap = ((uint32_t)dmax + 2u + 3u) & ~3u;
-  HIP_TRY(launch_d3(st, P, W, gaps_dev, (const GapOut*)s->d_outs.p, (const D3Gap*)d_dgaps, (const SubRec*)s->d_sub.p,
+  P.map_cap = ((uint32_t)L.dmax + 2u + 3u) & ~3u;
+  HIP_TRY(launch_d3(st, P, W, L.gaps_dev, L.outs_dev, (const D3Gap*)d_dgaps, L.sub_dev,
                     (const char*)s->d_lastch.p, (const char*)s->d_lastch.p + g.n, s->rtab, (uint32_t*)s->d_rnd.p,
                     (uint64_t)rnd_cap, res_dev, (char*)arena_dev, side, s->ev[4]));
   HIP_TRY(hipEventRecord(s->ev[3], st));
   if (stage_dev) {
     HIP_TRY(hipMemcpyAsync(results, s->d_resout.p, n * sizeof(g2s_result), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(arena + b->arena_base, s->d_textout.p, b->arena_bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(arena, s->d_textout.p, L.arena_bytes, hipMemcpyDeviceToHost, st));
   }
   HIP_TRY(hipMemcpyAsync(hsum, W.sum, 1024 + 64 * 128, hipMemcpyDeviceToHost, st));
   const auto t_launched = std::chrono::steady_clock::now();
@@ -2551,12 +2603,13 @@ int run_resident(g2s_batch* b, g2s_result* results, char* arena) {
   g2s_result* rs_host = res_direct && !stage_dev ? results : (g2s_result*)s->h_res.p;
   uint64_t host_fill_bytes = 0;
   if (ni && !(*side_h.count >> 63) && !stage_dev) {
-    char* text = arena_direct ? arena : (char*)s->h_text.p - b->arena_base;
+    char* text = arena_direct ? arena : (char*)s->h_text.p;
     auto one = [&](size_t x) {
       const D3HostItem& h = side_h.items[x];
-      const GapJob& j = b->jobs[h.gap];
-      if (!finish_gap_on_host(g, fp, j, side_h.outs[x], side_h.segs + h.seg_off, h.n_segs, side_h.rnd + h.rnd_off, h.draws,
-                              (uint64_t)(b->arena_base + b->arena_off[h.gap]), text, &rs_host[h.gap]))
+      const size_t q = h.gap / L.group_size, loc = h.gap % L.group_size;
+      const g2s_batch* gb = L.groups[q];
+      if (!finish_gap_on_host(g, fp, gb->jobs[loc], side_h.outs[x], side_h.segs + h.seg_off, h.n_segs, side_h.rnd + h.rnd_off, h.draws,
+                              (uint64_t)(L.group_arena[q] + gb->arena_off[loc]), text, &rs_host[h.gap]))
         host_bad.fetch_add(1);
     };
     if (ni > 2) s->pool->run(ni, one);
@@ -2566,15 +2619,9 @@ int run_resident(g2s_batch* b, g2s_result* results, char* arena) {
   const auto t_finished = std::chrono::steady_clock::now();
   HIP_TRY(hipStreamSynchronize(st));
   const auto t_synced = std::chrono::steady_clock::now();
-  {  // resets for the next launch, off its critical path
-    HIP_TRY(hipMemsetAsync(s->d_outs.p, 0, n * sizeof(GapOut), st));
-    s->d_outs.clean = n * sizeof(GapOut);
-    HIP_TRY(hipMemsetAsync(s->d_counter.p, 0, 32, st));
-    s->d_counter.clean = 32;
-  }
-  float ms_fill = 0, ms_d3 = 0;
-  HIP_TRY(hipEventElapsedTime(&ms_fill, s->ev[1], s->ev[2]));
-  HIP_TRY(hipEventElapsedTime(&ms_d3, s->ev[2], s->ev[3]));
+  float ms_d3 = 0;
+  HIP_TRY(hipEventElapsedTime(&ms_d3, s->ev[0], s->ev[3]));
+  *ms_d3_out = ms_d3;
   for (int q = 0; q < 64; q++) hsum->fill_bytes += ((const unsigned long long*)((const char*)hsum + 1024))[q * 16];
   hsum->fill_bytes += host_fill_bytes;
   const bool test_fallback = getenv("G2S_RESIDENT_TEST_FALLBACK") != nullptr;  // (tests: the attempt is discarded)
@@ -2583,15 +2630,15 @@ int run_resident(g2s_batch* b, g2s_result* results, char* arena) {
     if (getenv("G2S_DEBUG"))
       fprintf(stderr, "[g2s] resident mode: list of %zu gaps goes to the host path (status %#x, %u gaps not finished on the device, %u anomalies, %llu table entries, %d host-finished gaps disagree)\n",
               n, hsum->status, hsum->unhandled, hsum->anomalies, (unsigned long long)hsum->table_entries, host_bad.load());
-    b->timing.resident_fallbacks++;
     if (!test_fallback && ++s->resident_strikes >= 3) s->resident_off = true;
-    return 1;
+    *fell_back = true;
+    return G2S_OK;
   }
   s->resident_strikes = 0;
   // ---- results that went through staging
   if (!res_direct || !arena_direct) {
     const g2s_result* rs = res_direct ? results : (const g2s_result*)s->h_res.p;
-    const char* text = (const char*)s->h_text.p - b->arena_base;
+    const char* text = (const char*)s->h_text.p;
     const size_t per_task = 256, ntasks = (n + per_task - 1) / per_task;
     auto copy_range = [&](size_t t) {
       const size_t lo = t * per_task, hi = std::min(n, lo + per_task);
@@ -2603,33 +2650,64 @@ int run_resident(g2s_batch* b, g2s_result* results, char* arena) {
     else for (size_t t = 0; t < ntasks; t++) copy_range(t);
   }
   s->rcache.jump((size_t)hsum->draws_total, hsum->rand_state);
-  g2s_timing& tm = b->timing;
+  g2s_timing& tm = *tm_out;
   tm.xA += hsum->xA; tm.sA += hsum->sA; tm.xB += hsum->xB; tm.sB += hsum->sB; tm.xD += hsum->xD; tm.sD += hsum->sD;
   tm.seg_segments += hsum->segs;
   tm.seg_tier_gaps += hsum->seg_gaps;
   tm.fill_bytes += hsum->fill_bytes;
-  tm.ms_fill_seg += ms_fill;
   tm.ms_d3 += ms_d3;
-  tm.seg_launches++;
   tm.resident_launches++;
-  if (two_waves) tm.seg2_launches++;
   tm.draw_dependent_gaps += hsum->n_var;
   tm.host_finished_gaps += (uint32_t)hsum->host_items;
   tm.d3_table_entries += hsum->table_entries;
   const auto t_end = std::chrono::steady_clock::now();
-  tm.ms_total = std::chrono::duration<double, std::milli>(t_end - t_enter).count();
   if (getenv("G2S_DEBUG"))
-    fprintf(stderr, "[g2s] resident mode: host: descriptors %.3f ms, buffers %.3f ms, launches %.3f ms, wait for the hand-over %.3f ms, %zu gaps finished by the host in %.3f ms, wait for the trace kernel %.3f ms\n",
-            std::chrono::duration<double, std::milli>(t_desc - t_enter).count(), std::chrono::duration<double, std::milli>(t_bufs - t_desc).count(),
-            std::chrono::duration<double, std::milli>(t_launched - t_bufs).count(), std::chrono::duration<double, std::milli>(t_handed - t_launched).count(),
-            ni, std::chrono::duration<double, std::milli>(t_finished - t_handed).count(), std::chrono::duration<double, std::milli>(t_synced - t_finished).count());
-  if (getenv("G2S_DEBUG"))
-    fprintf(stderr, "[g2s] resident mode: %zu gaps: descriptors + launches %.3f ms, wait %.3f ms (fill kernel %.3f ms, phase D3 kernels %.3f ms), results %.3f ms; %u draw-dependent gaps, %llu table entries, %llu draws; results %s, text %s\n",
-            n, std::chrono::duration<double, std::milli>(t_launched - t_enter).count(),
-            std::chrono::duration<double, std::milli>(t_synced - t_launched).count(), ms_fill, ms_d3,
-            std::chrono::duration<double, std::milli>(t_end - t_synced).count(), hsum->n_var,
+    fprintf(stderr, "[g2s] resident mode, phase D3 of %zu gaps: set-up + launches %.3f ms, wait for the hand-over %.3f ms, %zu gaps finished by the host in %.3f ms, wait for the trace kernel %.3f ms, results %.3f ms (kernels %.3f ms); %u draw-dependent gaps, %llu table entries, %llu draws; results %s, text %s\n",
+            n, std::chrono::duration<double, std::milli>(t_launched - t_enter).count(), std::chrono::duration<double, std::milli>(t_handed - t_launched).count(),
+            ni, std::chrono::duration<double, std::milli>(t_finished - t_handed).count(), std::chrono::duration<double, std::milli>(t_synced - t_finished).count(),
+            std::chrono::duration<double, std::milli>(t_end - t_synced).count(), ms_d3, hsum->n_var,
             (unsigned long long)hsum->table_entries, (unsigned long long)hsum->draws_total, res_direct ? "direct" : "staged",
             arena_direct ? "direct" : "staged");
+  return G2S_OK;
+}
+
+// One batch on one session.  Returns G2S_OK (done), 1 (not applicable / fall back to the host path), or an error.
+int run_resident(g2s_batch* b, g2s_result* results, char* arena) {
+  g2s_session* s = b->s;
+  const size_t n = b->jobs.size();
+  const auto t_enter = std::chrono::steady_clock::now();
+  ResidentLaunch rl;
+  { const int rc = resident_launch_fill(b, &rl); if (rc != G2S_OK) return rc; }
+  ResidentList L;
+  L.groups.push_back(b);
+  L.n = n; L.group_size = std::max<size_t>(n, 1);
+  L.group_arena.push_back(b->arena_base);
+  L.arena_bytes = b->arena_base + b->arena_bytes;
+  L.outs_dev = (const GapOut*)s->d_outs.p;
+  L.sub_dev = (const SubRec*)s->d_sub.p;
+  L.sub_region = 0;
+  L.pin = &s->h_d3;
+  L.rnd_cap = b->rnd_cap; L.dmax = b->dmax; L.has_skip = b->has_skip;
+  L.gaps_dev = (const GapDev*)s->d_gaps.p;
+  if (b->arena_base) {  // (the D3Gap offsets are within the batch's share: make them offsets into the arena)
+    D3Gap* dq = (D3Gap*)s->h_d3.p;
+    for (size_t i = 0; i < n; i++) dq[i].arena_off += (uint64_t)b->arena_base;
+    s->desc_owner = nullptr;
+  }
+  double ms_d3 = 0;
+  bool fell_back = false;
+  const int rc = resident_d3(s, L, results, arena, &b->timing, &ms_d3, &fell_back);
+  if (rc != G2S_OK) return rc;
+  { const int r2 = resident_reset_fill(s, n); if (r2 != G2S_OK) return r2; }
+  if (fell_back) { b->timing.resident_fallbacks++; return 1; }
+  float ms_fill = 0;
+  HIP_TRY(hipEventElapsedTime(&ms_fill, s->ev[1], s->ev[2]));
+  g2s_timing& tm = b->timing;
+  tm.ms_fill_seg += ms_fill;
+  tm.seg_launches++;
+  if (rl.two_waves) tm.seg2_launches++;
+  tm.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enter).count();
+  if (getenv("G2S_DEBUG")) fprintf(stderr, "[g2s] resident mode: %zu gaps in %.3f ms (fill kernel %.3f ms)\n", n, tm.ms_total, ms_fill);
   return G2S_OK;
 }
 
@@ -2702,6 +2780,143 @@ struct GroupQueue {
 };
 }  // namespace
 
+
+// A team of sessions finishes one list on the devices: every session's thread pulls groups from the shared counter
+// (GroupQueue: whoever is free takes the next one), runs the look-ups and the fill kernel of its group on its GPU and
+// sends the group's records and closures to the lead session's device (a peer copy over xGMI; a device-to-device
+// copy when both sit on one GPU); phase D3 then runs once, for the whole list in gap order, on the lead's device
+// (resident_d3) — the stream offsets chain through all groups, and the kernels write results and text straight into
+// the caller's buffers.  No collective; the graph is replicated.  Returns G2S_OK (done), 1 (the host path takes the
+// list) or an error.
+static int team_resident(g2s_session* const* sessions, int nsessions, const g2s_gap* gaps, size_t n, size_t group_size,
+                         g2s_result* results, char* arena, g2s_timing* timing_out) {
+  g2s_session* lead = sessions[0];
+  if (!resident_applicable(lead, n)) return 1;
+  for (int t = 1; t < nsessions; t++) if (!resident_applicable(sessions[t], n)) return 1;
+  struct InTeam {  // (the size threshold of resident mode is the list's, not the groups')
+    g2s_session* const* ss; int ns;
+    InTeam(g2s_session* const* a, int b_) : ss(a), ns(b_) {
+      for (int t = 0; t < ns; t++) {
+        ss[t]->in_team_list = true;
+        for (int u = 0; u < ns; u++) if (u != t && ss[u]->device == ss[t]->device) ss[t]->team_shares_device = true;
+      }
+    }
+    ~InTeam() { for (int t = 0; t < ns; t++) { ss[t]->in_team_list = false; ss[t]->team_shares_device = false; } }
+  } in_team(sessions, nsessions);
+  const auto t_begin = std::chrono::steady_clock::now();
+  GroupQueue queue(n, group_size);
+  const size_t ngroups = queue.ngroups;
+  std::vector<g2s_batch*> subs(ngroups, nullptr);
+  std::vector<int> owner(ngroups, -1);
+  std::vector<float> fill_ms(ngroups, 0.f);
+  std::vector<char> two(ngroups, 0);
+  std::vector<size_t> group_arena(ngroups + 1, 0);
+  for (size_t gi = 0; gi < ngroups; gi++) {
+    const size_t off = gi * group_size, cnt = std::min(group_size, n - off);
+    group_arena[gi + 1] = group_arena[gi] + g2s_team_arena_bytes(lead, gaps + off, cnt);
+  }
+  // the lead's device gathers every group's records and closure records (a region per group)
+  const uint64_t region = (uint64_t)group_size * 128u + 2u * G2S_SEG_CAP;  // 16-byte units, what one launch may write
+  if (hipSetDevice(lead->device) != hipSuccess) return fail(G2S_ERR_NO_DEVICE, "cannot select device");
+  HIP_TRY(lead->d_outs_all.ensure(n * sizeof(GapOut)));
+  HIP_TRY(lead->d_sub_all.ensure(ngroups * region * sizeof(SubRec)));
+  HIP_TRY(lead->h_d3all.ensure(n * sizeof(D3Gap) + 2048 + 64 * 128 + G2S_RAND_WINDOW * 4));
+  D3Gap* dg_all = (D3Gap*)lead->h_d3all.p;
+  std::vector<int> rcs((size_t)nsessions, G2S_OK);
+  std::vector<std::string> errs((size_t)nsessions);
+  std::atomic<int> not_for_us(0);
+  auto worker = [&](int t) {
+    g2s_session* s = sessions[t];
+    size_t gi = 0, off = 0, cnt = 0;
+    while (queue.pull(&gi, &off, &cnt)) {
+      owner[gi] = t;
+      g2s_batch* b = nullptr;
+      auto t0 = std::chrono::steady_clock::now();
+      int rc = g2s_batch_prepare(s, gaps + off, cnt, &b);
+      if (rc == G2S_OK) {
+        subs[gi] = b;
+        b->timing.ms_prepare = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        b->arena = arena + group_arena[gi];
+        b->arena_base = group_arena[gi];
+        ResidentLaunch rl;
+        rc = resident_launch_fill(b, &rl);
+        if (rc == 1) { not_for_us.fetch_add(1); queue.abort(); break; }
+        if (rc == G2S_OK) {
+          two[gi] = rl.two_waves ? 1 : 0;
+          // the group's share of the list's D3Gap array (offsets into the whole arena)
+          const D3Gap* mine = (const D3Gap*)s->h_d3.p;
+          for (size_t i = 0; i < cnt; i++) { dg_all[off + i] = mine[i]; dg_all[off + i].arena_off += (uint64_t)group_arena[gi]; }
+          // records and closure records to the lead's device
+          hipError_t e;
+          char* dst_o = (char*)lead->d_outs_all.p + off * sizeof(GapOut);
+          char* dst_s = (char*)lead->d_sub_all.p + gi * region * sizeof(SubRec);
+          const size_t sub_bytes = (size_t)std::min<uint64_t>(rl.units, region) * sizeof(SubRec);
+          if (s->device == lead->device) {
+            e = hipMemcpyAsync(dst_o, s->d_outs.p, cnt * sizeof(GapOut), hipMemcpyDeviceToDevice, s->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(dst_s, s->d_sub.p, sub_bytes, hipMemcpyDeviceToDevice, s->stream);
+          } else {
+            e = hipMemcpyPeerAsync(dst_o, lead->device, s->d_outs.p, s->device, cnt * sizeof(GapOut), s->stream);
+            if (e == hipSuccess) e = hipMemcpyPeerAsync(dst_s, lead->device, s->d_sub.p, s->device, sub_bytes, s->stream);
+          }
+          if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+          if (e == hipSuccess) e = hipEventElapsedTime(&fill_ms[gi], s->ev[1], s->ev[2]);
+          if (e != hipSuccess) rc = fail(G2S_ERR_HIP, std::string("team, group to the lead's device: ") + hipGetErrorString(e));
+          else rc = resident_reset_fill(s, cnt);
+          s->desc_owner = nullptr;  // (h_d3 of this session is rewritten by its next group)
+        }
+      }
+      if (rc != G2S_OK) { rcs[(size_t)t] = rc; errs[(size_t)t] = tl_error; queue.abort(); break; }
+    }
+  };
+  {
+    std::vector<std::thread> th;
+    for (int t = 1; t < nsessions; t++) th.emplace_back(worker, t);
+    worker(0);
+    for (auto& x : th) x.join();
+  }
+  int rc = G2S_OK;
+  for (int t = 0; t < nsessions; t++) if (rcs[(size_t)t] != G2S_OK) { rc = rcs[(size_t)t]; tl_error = errs[(size_t)t]; }
+  bool fell_back = not_for_us.load() != 0;
+  for (g2s_batch* b : subs) if (!b) fell_back = fell_back || rc == G2S_OK;  // (aborted before every group ran)
+  g2s_timing total;
+  memset(&total, 0, sizeof total);
+  if (rc == G2S_OK && !fell_back) {
+    ResidentList L;
+    L.groups = subs;
+    L.n = n; L.group_size = group_size;
+    L.group_arena = group_arena;
+    L.arena_bytes = group_arena[ngroups];
+    L.outs_dev = (const GapOut*)lead->d_outs_all.p;
+    L.sub_dev = (const SubRec*)lead->d_sub_all.p;
+    L.sub_region = region;
+    L.pin = &lead->h_d3all;
+    L.gaps_dev = nullptr;
+    for (g2s_batch* b : subs) { L.rnd_cap += b->rnd_cap; L.dmax = std::max(L.dmax, b->dmax); L.has_skip = L.has_skip || b->has_skip; }
+    double ms_d3 = 0;
+    rc = resident_d3(lead, L, results, arena, &total, &ms_d3, &fell_back);
+  }
+  if (rc == G2S_OK && !fell_back) {
+    total.team_groups = (uint32_t)ngroups;
+    total.team_sessions = (uint32_t)nsessions;
+    for (size_t gi = 0; gi < ngroups; gi++) {
+      const g2s_timing& t = subs[gi]->timing;
+      total.flank_bytes += t.flank_bytes;
+      total.ms_prepare += t.ms_prepare;
+      total.ms_fill_seg += fill_ms[gi];
+      total.seg_launches++;
+      total.seg2_launches += two[gi];
+      if (owner[gi] >= 0 && owner[gi] < 16) total.team_groups_by_session[owner[gi]]++;
+    }
+  }
+  for (g2s_batch* b : subs) g2s_batch_free(b);
+  if (rc != G2S_OK) return rc;
+  if (fell_back) return 1;
+  total.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+  if (timing_out) *timing_out = total;
+  lead->last_timing = total;
+  return G2S_OK;
+}
+
 // A team of sessions (any mix of devices, several per device allowed) fills one gap list:
 // the list is cut into groups, every session's host thread pulls the next group from a
 // shared counter (static start, work stealing by construction), runs stage 1 on its GPU,
@@ -2716,6 +2931,13 @@ extern "C" int g2s_team_fill(g2s_session* const* sessions, int nsessions, const 
     if (!sessions[t] || sessions[t]->graph != sessions[0]->graph)
       return fail(G2S_ERR_ARG, "g2s_team_fill: sessions must share one graph");
   if (group_size == 0) group_size = 2048;
+  {
+    const size_t need = g2s_team_arena_bytes(sessions[0], gaps, n);
+    if (arena_cap < need || (!arena && need)) return fail(G2S_ERR_ARG, "g2s_team_fill: fill arena too small");
+    const int rr = team_resident(sessions, nsessions, gaps, n, group_size, results, arena, timing_out);  // (the host path below when it declines)
+    if (rr == G2S_OK) return G2S_OK;
+    if (rr < 0) return rr;
+  }
   auto t_begin = std::chrono::steady_clock::now();
   g2s_session* lead = sessions[0];
   GroupQueue queue(n, group_size);

@@ -193,6 +193,9 @@ typedef struct g2s_timing {
   uint64_t draw_dependent_gaps; /* gaps whose number of rand() draws depends on the values drawn */
   uint64_t d3_table_entries;    /* entries of the draw-count tables that resolved their offsets */
   uint32_t host_finished_gaps;  /* gaps of resident lists whose closure the host analysed and traced (a k-mer at two depths) */
+  /* g2s_team_fill: the dispatcher's groups and which session took how many (sessions beyond the 16th are not listed) */
+  uint32_t team_groups, team_sessions;
+  uint32_t team_groups_by_session[16];
   uint32_t pad_;
 } g2s_timing;
 

@@ -128,3 +128,37 @@ def test_resident_mode_scaffold_records_and_the_skip_rule(product, oracle, monke
         pg.free()
     assert out["1"] == out["0"]
     assert out["1"][0] == ofa and out["1"][1] == olog
+
+
+@pytest.mark.parametrize("nsess,group", [(1, 400), (2, 700), (3, 300), (4, 97)])
+def test_team_on_the_devices_equals_one_session(product, monkeypatch, nsess, group):
+    """g2s_team_fill with the list finished on the devices: every session runs the fill kernel of the groups it
+    pulls, the groups' records and closures are gathered on the lead's device and phase D3 runs once over the
+    whole list (the stream offsets chain through the groups).  Same results as one session on the host path,
+    same stream position afterwards; every group was handed out, in the list's order."""
+    reads = product.G2S.synth_genome(200000, 3, 20240101)
+    seqs = [ln for ln in reads.splitlines() if not ln.startswith(">")]
+    gl = _parse_scaffolds(product.G2S.synth_gaps(reads, 31, 10, 1400, 100, 900, 20240103))
+    gaps = _gaps(product, gl)
+    monkeypatch.setenv("G2S_RESIDENT", "0")
+    pg = product.Graph.from_seqs(seqs, 31, 1)
+    solo = product.Session(pg, 0, d_err=500, randseed=9)
+    want = [_key(r) for r in solo.fill_batch(gaps)]
+    want2 = [_key(r) for r in solo.fill_batch(gaps[:200])]
+    solo.destroy()
+    monkeypatch.delenv("G2S_RESIDENT")
+    team = [product.Session(pg, 0, d_err=500, randseed=9) for _ in range(nsess)]
+    try:
+        got, tm = product.team_fill(team, gaps, group_size=group, want_timing=True)
+        assert [_key(r) for r in got] == want
+        assert tm.resident_launches == 1 and tm.resident_fallbacks == 0
+        ngroups = -(-len(gaps) // group)
+        assert tm.team_groups == ngroups and tm.team_sessions == nsess and tm.seg_launches == ngroups
+        assert sum(tm.team_groups_by_session[i] for i in range(16)) == ngroups
+        assert tm.seg_tier_gaps == len(gaps)
+        got2 = product.team_fill(team, gaps[:200], group_size=group)  # (short list: the host path; the stream goes on)
+        assert [_key(r) for r in got2] == want2
+    finally:
+        for s in team:
+            s.destroy()
+        pg.free()
