@@ -178,6 +178,8 @@ def main():
     ap.add_argument("--sessions", type=int, default=1, help="sessions (host thread + stream) per GPU")
     ap.add_argument("--group", type=int, default=-1,
                     help="gaps per group of the dispatcher (-1 = one group per session at N>1, one batch at N=1)")
+    ap.add_argument("--groups-per-session", type=int, default=1,
+                    help="N>1: groups of the list per session (pulled from a shared counter: whoever is free takes the next)")
     ap.add_argument("--host-threads", type=int, default=0, help="host worker threads per session (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-c3-beside", action="store_true", help="N=1/C2: skip the C3-on-one-GPU measurement beside it")
@@ -273,7 +275,7 @@ def main():
     sessions = make_sessions(devices, max(1, args.sessions))
     group = args.group
     if group < 0:
-        group = 0 if len(sessions) == 1 else shard.group_size(len(gaps), len(sessions))
+        group = 0 if len(sessions) == 1 else shard.group_size(len(gaps), len(sessions), per_session=args.groups_per_session)
     run = Runner(P, sessions, gaps, group, not args.pageable_buffers)
 
     priming_steps = 0

@@ -2961,11 +2961,13 @@ extern "C" int g2s_team_fill(g2s_session* const* sessions, int nsessions, const 
     const size_t off = gi * group_size, cnt = std::min(group_size, n - off);
     group_arena[gi + 1] = group_arena[gi] + g2s_team_arena_bytes(lead, gaps + off, cnt);
   }
+  std::vector<int> group_owner(ngroups, -1);
   auto worker = [&](int t) {
     g2s_session* s = sessions[t];
     s->tier_cursor = 0;
     size_t gi = 0, off = 0, cnt = 0;
     while (queue.pull(&gi, &off, &cnt)) {
+      group_owner[gi] = t;
       g2s_batch* b = nullptr;
       auto t0 = std::chrono::steady_clock::now();
       int rc = g2s_batch_prepare(s, gaps + off, cnt, &b);
@@ -3014,6 +3016,9 @@ extern "C" int g2s_team_fill(g2s_session* const* sessions, int nsessions, const 
         total.watchdog_gaps += t.watchdog_gaps; total.seg2_launches += t.seg2_launches;
       }
       rc = batches_stage2(subs, lead, results, arena, &total, false);
+      total.team_groups = (uint32_t)ngroups;
+      total.team_sessions = (uint32_t)nsessions;
+      for (size_t q = 0; q < ngroups; q++) if (group_owner[q] >= 0 && group_owner[q] < 16) total.team_groups_by_session[group_owner[q]]++;
     }
   }
   for (g2s_batch* b : subs) g2s_batch_free(b);
@@ -3374,6 +3379,10 @@ extern "C" int g2s_test_worker_pool(int32_t threads, int32_t rounds, int32_t n) 
 }
 
 extern "C" int g2s_test_group_queue(int32_t nworkers, uint64_t n, uint64_t group_size, int32_t* owner) {
+  return g2s_test_group_queue_slow(nworkers, n, group_size, -1, 0, owner);
+}
+extern "C" int g2s_test_group_queue_slow(int32_t nworkers, uint64_t n, uint64_t group_size, int32_t slow_worker,
+                                         uint32_t slow_us, int32_t* owner) {
   if (nworkers < 1 || !owner) return fail(G2S_ERR_ARG, "g2s_test_group_queue: bad argument");
   for (uint64_t i = 0; i < n; i++) owner[i] = -1;
   GroupQueue queue((size_t)n, (size_t)group_size);
@@ -3382,7 +3391,8 @@ extern "C" int g2s_test_group_queue(int32_t nworkers, uint64_t n, uint64_t group
     size_t gi = 0, off = 0, cnt = 0;
     while (queue.pull(&gi, &off, &cnt)) {
       for (size_t i = off; i < off + cnt; i++) { if (owner[i] != -1) clash.fetch_add(1); owner[i] = t; }
-      std::this_thread::yield();
+      // a group takes every worker 20 us (its "launch"); the slow one slow_us on top
+      std::this_thread::sleep_for(std::chrono::microseconds(20 + (t == slow_worker ? slow_us : 0u)));
     }
   };
   std::vector<std::thread> th;

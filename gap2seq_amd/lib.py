@@ -156,6 +156,7 @@ _SIGS = {
                                       C.c_uint32, C.POINTER(C.c_uint64)]),
     "g2s_test_worker_pool": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
     "g2s_test_group_queue": (C.c_int, [C.c_int32, C.c_uint64, C.c_uint64, C.POINTER(C.c_int32)]),
+    "g2s_test_group_queue_slow": (C.c_int, [C.c_int32, C.c_uint64, C.c_uint64, C.c_int32, C.c_uint32, C.POINTER(C.c_int32)]),
     "g2s_graph_validate": (C.c_int64, [C.c_void_p, C.c_char_p, C.c_size_t]),
     "g2s_test_post_gap": (C.c_int, [_VP, C.POINTER(g2s_params), C.POINTER(g2s_gap), C.c_int32,
                                     C.POINTER(C.c_uint32), C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.c_int32,
@@ -654,6 +655,13 @@ def test_device_rand(device, seed, skip, n):
     out = (C.c_int32 * max(1, n))()
     _check(load_library().g2s_test_device_rand(device, seed, skip, n, out))
     return [out[i] for i in range(n)]
+
+
+def test_group_queue_slow(nworkers, n, group_size, slow_worker, slow_us):
+    """TEST HOOK binding: the group counter with one worker that is slow_us microseconds slower per group."""
+    owner = (C.c_int32 * max(1, n))()
+    _check(load_library().g2s_test_group_queue_slow(nworkers, n, group_size, slow_worker, slow_us, owner))
+    return [owner[i] for i in range(n)]
 
 
 def test_rand_stream(seed, skip, n):

@@ -11,14 +11,18 @@ the barriers when bench.py is started by torch.distributed.run.
 """
 
 
-def group_size(n_gaps, n_sessions, min_group=256):
-    """Gaps per group for g2s_team_fill.  A launch is bound by its slowest gap (a dependent
-    chain of ~D levels), not by the number of gaps, so splitting a GPU's share into many
-    small launches costs more than it balances: one group per session, but never fewer than
-    `min_group` gaps (then some sessions may stay idle on very short lists)."""
-    if n_gaps <= 0 or n_sessions <= 0:
-        raise ValueError("n_gaps and n_sessions must be positive")
-    return max(min(min_group, n_gaps), -(-n_gaps // n_sessions))
+def group_size(n_gaps, n_sessions, min_group=256, per_session=1):
+    """Gaps per group for g2s_team_fill.  The sessions pull groups from one counter — whoever is
+    free takes the next one (tests/test_shard.py shows a slow worker's share being taken over) —
+    so `per_session` > 1 groups per session balance devices of unequal speed.  The default is ONE
+    group per session: a launch of the fill kernel is bound by its slowest gap (a dependent chain
+    of search rounds), not by the number of gaps, and a session runs its groups one after the
+    other — measured on config 3's list with the sessions sharing one MI355X
+    (profiles/r03_shared_device_sessions.txt): four groups per session take 2-3x as long as one.
+    Never fewer than `min_group` gaps per group (some sessions may then stay idle on short lists)."""
+    if n_gaps <= 0 or n_sessions <= 0 or per_session <= 0:
+        raise ValueError("n_gaps, n_sessions and per_session must be positive")
+    return max(min(min_group, n_gaps), -(-n_gaps // (n_sessions * per_session)))
 
 
 def group_bounds(n_gaps, group):

@@ -391,6 +391,10 @@ int g2s_test_worker_pool(int32_t threads, int32_t rounds, int32_t n);
  * host threads in place of sessions: owner[i] receives the worker that was handed gap i.
  * G2S_OK when every gap of [0, n) was handed out exactly once, in contiguous groups. */
 int g2s_test_group_queue(int32_t nworkers, uint64_t n, uint64_t group_size, int32_t* owner);
+/* The same with one worker that needs slow_us microseconds more for every group it takes than the others (a busy
+ * or slower device): what it does not get to is taken by the others — the queue hands a group to whoever asks. */
+int g2s_test_group_queue_slow(int32_t nworkers, uint64_t n, uint64_t group_size, int32_t slow_worker, uint32_t slow_us,
+                              int32_t* owner);
 
 /* TEST HOOK: checks the invariants the kernels rely on between the unitig-start bitmap and
  * the successor table (every edge the bitmap calls unitig-internal is the only edge out of

@@ -32,6 +32,23 @@ def test_group_queue_hands_every_gap_out_once(product):
     assert product.test_group_queue(4, 0, 16) == []
 
 
+def test_a_slow_sessions_groups_are_taken_by_the_others(product):
+    """The dispatcher's counter hands a group to whoever asks (the reference's threads pull scaffolds from a
+    shared iterator the same way, Gap2Seq.cpp:313-323): with more groups than workers, a worker that needs 3 ms
+    more per group than the others (a busy device) ends up with a handful of the 80 groups, the other three share
+    the rest, and every gap is still handed out exactly once."""
+    n, group, workers = 4000, 50, 4
+    assert shard.group_size(n, workers, min_group=1, per_session=20) == group
+    owner = product.test_group_queue_slow(workers, n, group, 0, 3000)
+    per_worker = [sum(1 for b, _ in shard.group_bounds(n, group) if owner[b] == w) for w in range(workers)]
+    assert sum(per_worker) == 80 and len(owner) == n and all(0 <= o < workers for o in owner)
+    assert per_worker[0] <= 4, per_worker                      # (a static split would have left it 20)
+    assert min(per_worker[1:]) >= 15, per_worker               # the others took what it did not get to
+    even = product.test_group_queue_slow(workers, n, group, -1, 0)
+    counts = [sum(1 for b, _ in shard.group_bounds(n, group) if even[b] == w) for w in range(workers)]
+    assert sum(counts) == 80 and min(counts) >= 8, counts      # nobody slow: everybody gets a fair share
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
