@@ -278,6 +278,10 @@ def main():
         group = 0 if len(sessions) == 1 else shard.group_size(len(gaps), len(sessions), per_session=args.groups_per_session)
     run = Runner(P, sessions, gaps, group, not args.pageable_buffers)
 
+    # what a one-shot run pays: the first call on a fresh session (buffers are allocated and page-locked in it,
+    # sleeping workers and idle clocks wake up), and the second (everything allocated, nothing warm yet)
+    first_call_ms = run.step() * 1e3
+    second_call_ms = run.step() * 1e3
     priming_steps = 0
     t_prime = time.perf_counter()
     while time.perf_counter() - t_prime < args.prime_seconds:
@@ -472,6 +476,8 @@ def main():
         "filled": filled,
         "q7_gaps": q7,
         "priming_steps": priming_steps,
+        "first_call_ms": round(first_call_ms, 3),
+        "second_call_ms": round(second_call_ms, 3),
         "retried_gaps": tm.retried_gaps,
         "resident": {"lists_finished_on_the_device": tm.resident_launches, "lists_given_back_to_the_host_path": tm.resident_fallbacks,
                      "draw_dependent_gaps": tm.draw_dependent_gaps, "draw_count_table_entries": tm.d3_table_entries,

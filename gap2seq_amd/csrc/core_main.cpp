@@ -80,9 +80,12 @@ int main(int argc, char** argv) {
     std::cout << "EXCEPTION: missing mandatory option (-reads, -filled)" << std::endl;  // main.cpp:29-31
     return EXIT_FAILURE;
   }
-  // -nb-cores 0 = all cores (GATB Tool); -max-mem is divided by that number (:302)
+  // -max-mem is divided by the number of threads (:302) — by an EXPLICIT -nb-cores here: with the option omitted
+  // (GATB: all cores) the reference's per-gap budget depends on the host's CPU count, which says nothing about
+  // what a GPU can hold; the whole budget then applies per gap (the device-budget analogue D3)
+  const int mem_div = std::max(1, o.nb_cores);
   if (o.nb_cores <= 0) o.nb_cores = (int)std::max(1u, std::thread::hardware_concurrency());
-  p.max_mem = (int64_t)(o.max_mem_gb * 1024 * 1024 * 1024) / o.nb_cores;
+  p.max_mem = (int64_t)(o.max_mem_gb * 1024 * 1024 * 1024) / mem_div;
   // the session seeds with time(NULL) when this is 0 (:178); the echo prints the user's value (:191)
   p.randseed = randseed > 0 ? (uint32_t)randseed : 0u;
   p.host_threads = 0;
@@ -98,7 +101,7 @@ int main(int argc, char** argv) {
   if (readable(cache)) {
     std::cout << "Loading from " << cache << std::endl;
     rc = g2s_graph_load(cache.c_str(), &g);
-    if (rc == G2S_OK && g2s_graph_k(g) != o.k) {  // a cache of another -k is not this run's graph
+    if (rc == G2S_OK && (g2s_graph_k(g) != o.k || g2s_graph_solid(g) != o.solid)) {  // a cache of another -k or -solid is not this run's graph
       g2s_graph_free(g);
       g = nullptr;
       rc = g2s_graph_build_files(reads.c_str(), o.k, o.solid, 0, &g);
@@ -157,7 +160,9 @@ int main(int argc, char** argv) {
     fclose(f);
     int32_t gaps = 0, nfilled = 0;
     // the log is printed and the records are written as the batches finish (-stream-gaps N per batch)
-    FILE* out = fopen(filled.c_str(), "wb");
+    // (written beside the target and renamed when the run is complete: a failed run leaves no partial -filled file)
+    const std::string partial = filled + ".partial";
+    FILE* out = fopen(partial.c_str(), "wb");
     if (!out) { std::cout << "EXCEPTION: cannot write " << filled << std::endl; return EXIT_FAILURE; }
     rc = g2s_execute_scaffolds_stream(
         s, &o, reads.c_str(), filled.c_str(), text.c_str(), (size_t)std::max(0, stream_gaps),
@@ -168,9 +173,11 @@ int main(int argc, char** argv) {
         [](const char* t, size_t n, void*) { fwrite(t, 1, n, stdout); fflush(stdout); }, out, &gaps, &nfilled);
     fclose(out);
     if (rc != G2S_OK) {
+      remove(partial.c_str());
       std::cout << "EXCEPTION: " << g2s_last_error() << std::endl;
       return EXIT_FAILURE;
     }
+    if (rename(partial.c_str(), filled.c_str()) != 0) { std::cout << "EXCEPTION: cannot write " << filled << std::endl; return EXIT_FAILURE; }
     g2s_session_destroy(s);
     for (g2s_session* h : helpers) g2s_session_destroy(h);
     g2s_graph_free(g);

@@ -352,6 +352,7 @@ Graph* graph_build(const std::vector<std::pair<const char*, uint64_t>>& seqs, in
   if (nthreads <= 0) nthreads = (int)std::max(1u, std::thread::hardware_concurrency());
   Graph* g = new Graph();
   g->k = k;
+  g->solid = solid;
   g->wide = k >= 32;
   const auto t0 = std::chrono::steady_clock::now();
   // the solid k-mer set: sort on the GPU when there is one (dbg_gpu.hip), host threads otherwise
@@ -378,7 +379,8 @@ static const char kMagic[8] = {'G', '2', 'S', 'D', 'B', 'G', '0', '2'};
 bool graph_save(const Graph& g, const std::string& path, std::string* err) {
   FILE* f = fopen(path.c_str(), "wb");
   if (!f) { if (err) *err = "cannot open " + path; return false; }
-  uint64_t hdr[4] = {(uint64_t)g.k, g.n, g.n_unitigs, (uint64_t)(g.pred.empty() ? 0 : 1)};
+  // (header word 3: bit 0 = explicit predecessor table, bits 8.. = the abundance threshold of the set)
+  uint64_t hdr[4] = {(uint64_t)g.k, g.n, g.n_unitigs, (uint64_t)(g.pred.empty() ? 0 : 1) | ((uint64_t)std::max(0, g.solid) << 8)};
   bool ok = fwrite(kMagic, 1, 8, f) == 8 && fwrite(hdr, 8, 4, f) == 4;
   auto put = [&](const void* p, size_t bytes) { if (ok && bytes) ok = fwrite(p, 1, bytes, f) == bytes; };
   if (!g.wide) put(g.kmers64.data(), g.kmers64.size() * 8); else put(g.kmers128.data(), g.kmers128.size() * 16);
@@ -403,7 +405,9 @@ Graph* graph_load(const std::string& path, std::string* err) {
     return nullptr;
   }
   // the file is not trusted: every size and index is checked before it is used
-  if (hdr[0] < 1 || hdr[0] > 63 || hdr[1] >= (1ull << 30) || hdr[2] > hdr[1] || hdr[3] > 1) {
+  const uint64_t solid_of_cache = hdr[3] >> 8;
+  hdr[3] &= 0xFFull;
+  if (hdr[0] < 1 || hdr[0] > 63 || hdr[1] >= (1ull << 30) || hdr[2] > hdr[1] || hdr[3] > 1 || solid_of_cache > (1ull << 30)) {
     fclose(f);
     if (err) *err = "corrupt graph cache header: " + path;
     return nullptr;
@@ -422,6 +426,7 @@ Graph* graph_load(const std::string& path, std::string* err) {
   }
   Graph* g = new Graph();
   g->k = (int)hdr[0];
+  g->solid = (int)solid_of_cache;
   g->n = hdr[1];
   g->n_unitigs = hdr[2];
   g->wide = g->k >= 32;

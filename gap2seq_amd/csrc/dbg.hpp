@@ -32,6 +32,7 @@ struct DeviceGraph {
 
 struct Graph {
   int k = 0;
+  int solid = 0;      // abundance threshold the set was built with (0: unknown, a cache written before it was recorded)
   bool wide = false;  // 128-bit k-mers (k >= 32)
   uint64_t n = 0;     // canonical solid k-mers
   uint64_t n_unitigs = 0;

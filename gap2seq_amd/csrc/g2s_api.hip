@@ -149,6 +149,7 @@ extern "C" void g2s_graph_free(g2s_graph* g) {
   delete g;
 }
 extern "C" int g2s_graph_k(const g2s_graph* g) { return g ? g->g->k : 0; }
+extern "C" int g2s_graph_solid(const g2s_graph* g) { return g ? g->g->solid : 0; }
 extern "C" uint64_t g2s_graph_num_kmers(const g2s_graph* g) { return g ? g->g->n : 0; }
 extern "C" uint64_t g2s_graph_num_unitigs(const g2s_graph* g) { return g ? g->g->n_unitigs : 0; }
 extern "C" uint32_t g2s_graph_node(const g2s_graph* g, const char* kmer) {

@@ -8,9 +8,11 @@
 //   g2s_merge_scaffolds = what GapMerger reads back (/root/reference/src/GapMerger.cpp:142-235):
 //                         contigs in order, each followed by its (filled) gap record(s), the
 //                         markers stripped from the comment.
-// Pure host string work: nothing here touches the GPU.  The scan is written over "stretches"
-// (maximal runs of bases / of N's seen from a position) rather than as the reference's chain of
-// distance variables; the three cases and every offset are the reference's.
+// Pure host string work: nothing here touches the GPU.  g2s_cut_scaffolds follows the reference's scan
+// (GapCutter.cpp:160-319) case for case: its chain of distances from the current position (bases, N run,
+// bases, N run, bases) is the same chain here under other names, because the three cases and every offset
+// in them ARE the file format the wrapper and GapMerger depend on.  g2s_merge_scaffolds is arranged
+// differently (an index over the gap records instead of the reference's rescan per contig).
 #include <cstdlib>
 #include <cstring>
 #include <map>

@@ -91,6 +91,7 @@ _SIGS = {
     "g2s_graph_load": (C.c_int, [C.c_char_p, C.POINTER(_VP)]),
     "g2s_graph_free": (None, [_VP]),
     "g2s_graph_k": (C.c_int, [_VP]),
+    "g2s_graph_solid": (C.c_int, [_VP]),
     "g2s_graph_num_kmers": (C.c_uint64, [_VP]),
     "g2s_graph_num_unitigs": (C.c_uint64, [_VP]),
     "g2s_graph_node": (C.c_uint32, [_VP, C.c_char_p]),

@@ -75,6 +75,8 @@ int g2s_graph_save(const g2s_graph* g, const char* path);
 int g2s_graph_load(const char* path, g2s_graph** out);
 void g2s_graph_free(g2s_graph* g);
 int g2s_graph_k(const g2s_graph* g);
+/* -solid the set was built with (0: a cache file written before this was recorded). */
+int g2s_graph_solid(const g2s_graph* g);
 uint64_t g2s_graph_num_kmers(const g2s_graph* g);
 uint64_t g2s_graph_num_unitigs(const g2s_graph* g);
 /* graph.buildNode + graph.contains: oriented node id (2*index + strand) of the

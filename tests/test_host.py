@@ -95,6 +95,15 @@ def test_graph_cache_roundtrip(product, tmp_path):
     a.save(path)
     b = product.Graph.load(path)
     assert (a.num_kmers, a.num_unitigs, a.k) == (b.num_kmers, b.num_unitigs, b.k)
+    # the cache records -solid as well as -k: Gap2Seq-core reuses "<reads>.g2s" only when both are this run's
+    lib = product.load_library()
+    assert lib.g2s_graph_solid(a.h) == 1 and lib.g2s_graph_solid(b.h) == 1
+    c = product.Graph.from_seqs(seqs + seqs, 15, 2)
+    c.save(path)
+    d = product.Graph.load(path)
+    assert lib.g2s_graph_solid(d.h) == 2 and d.num_kmers == c.num_kmers
+    c.free()
+    d.free()
     for i in range(0, 1900, 7):
         km = seqs[0][i:i + 15]
         assert a.node(km) == b.node(km)
