@@ -275,7 +275,9 @@ def main():
     sessions = make_sessions(devices, max(1, args.sessions))
     group = args.group
     if group < 0:
-        group = 0 if len(sessions) == 1 else shard.group_size(len(gaps), len(sessions), per_session=args.groups_per_session)
+        # groups are cut for DEVICES: sessions that share a device (--share-device, --sessions) pull from the same
+        # counter, and a device gains nothing from two launches where one would do
+        group = 0 if len(sessions) == 1 else shard.group_size(len(gaps), len(set(devices)), per_session=args.groups_per_session)
     run = Runner(P, sessions, gaps, group, not args.pageable_buffers)
 
     # what a one-shot run pays: the first call on a fresh session (buffers are allocated and page-locked in it,
@@ -428,20 +430,25 @@ def main():
     else:
         alg_bytes, achieved = None, None  # no oracle count for this list: no fraction is quoted
     traffic, traffic_src = None, None
-    pmc = os.path.join(ROOT, "profiles", "r02_pmc_fill_seg.json")
-    if os.path.exists(pmc) and kname == "g2s_fill_seg2" and cfg_name == "C2" and not custom and ngpu == 1:
+    # HBM bytes per launch of that kernel from the committed counter passes of this workload (rocprofv3 --pmc
+    # FETCH_SIZE / WRITE_SIZE in passes of their own, gfx950 read-side correction: tools/pmc_summary.py)
+    pmc = os.path.join(ROOT, "profiles", "r03_pmc_%s.json" % cfg_name.lower())
+    if os.path.exists(pmc) and not custom and ngpu == 1:
         try:
             pj = json.load(open(pmc))
-            traffic = pj.get("hbm_bytes_per_launch") if pj.get("kernel", "").startswith(kname) else None
-            if traffic is not None:
-                traffic_src = "from_profile: profiles/r02_pmc_fill_seg.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, " \
-                              "separate passes of this command; not measured in this run)"
+            if pj.get("kernel", "") == kname.split(" ")[0]:
+                traffic = pj.get("hbm_bytes_per_launch")
+                traffic_src = "from_profile: profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of " \
+                              "this command; not measured in this run)" % os.path.basename(pmc)
         except Exception:
             traffic = None
     roofline = dict(bound="hbm", kernel=kname, achieved=round(achieved, 3) if achieved is not None else None,
                     peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBS, 6) if achieved is not None else None,
                     traffic=traffic, traffic_source=traffic_src,
+                    achieved_is="algorithmic bytes of the REFERENCE algorithm (SURVEY 8d: 24 B per expansion + 8 B per state, "
+                                "oracle counts) per second of the kernel — not bytes moved: the segment search touches a fraction of them",
+                    measured_traffic_GBps=round(traffic / (kern_ms / 1e3) / 1e9, 3) if traffic and kern_ms > 0 else None,
                     algorithmic_bytes_per_launch=alg_bytes, expansions=x_units, states=s_units,
                     units_counted_by=counted_by, kernel_ms_per_launch=round(kern_ms, 4),
                     launches_per_step=round(launches, 3), seg_tier_gaps=tm.seg_tier_gaps, segx_tier_gaps=tm.segx_tier_gaps, lds_tier_gaps=tm.lds_tier_gaps,

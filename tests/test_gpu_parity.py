@@ -400,7 +400,7 @@ def test_multi_rank_bench_path(product, tmp_path):
     s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
-           "--warmup", "1", "--genome", "300000", "--gaps", "600", "--share-device"]
+           "--warmup", "1", "--genome", "300000", "--gaps", "600", "--share-device", "--group", "300"]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
