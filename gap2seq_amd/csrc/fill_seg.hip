@@ -1318,94 +1318,101 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
   SEG_PROF_TAIL(0);
 
   // ---------------- Q7: an upward and a downward segment of one unitig meeting on a k-mer ------
-  if constexpr (BIG) {
-    // Thousands of segments: all pairs are too many.  The upward segments' index intervals are sorted and
-    // merged (LDS); a downward segment that touches none of them (the usual case) is done after one
-    // search; the few others are checked against every upward segment as above.
-    if (!overflow && !(flags & G2S_DEV_Q7_B) && nseg > 1) {
-      uint64_t* sbuf = (uint64_t*)lds;
-      uint32_t nu = 0;
-      bool anydn = false;
-      for (uint32_t b0 = 0; b0 < nseg; b0 += 64u) {
+  // All pairs (every downward segment against every upward one) cost the slowest gaps of a 10 000-gap list a third
+  // of their tail — 130-265 k cycles at 230-310 segments, measured with the instrumented build
+  // (profiles/r03_segprof_*.txt).  Almost no pair can meet: the two must share k-mers, i.e. overlap as index
+  // intervals.  So the upward segments' index intervals are sorted and merged in LDS (the space of s_t, which
+  // phase D1 fills later; the large variant: the start of its LDS), a downward segment that touches none of them
+  // (the usual case) is done after one binary search, and only the few others are checked against every upward
+  // segment.  Lists of a few dozen segments keep the direct all-pairs pass.
+  auto q7_sorted = [&](uint64_t* sbuf, uint32_t cap) -> bool {  // false: more upward segments than sbuf holds
+    uint32_t nu = 0;
+    bool anydn = false;
+    for (uint32_t b0 = 0; b0 < nseg; b0 += 64u) {
+      const uint32_t b = b0 + (uint32_t)lane;
+      const bool hb = b < nseg;
+      const uint32_t nb_ = hb ? s_node[b] : 0u, lb = hb ? s_dl[b] >> 16 : 0u;
+      const bool up = hb && !(nb_ & 1u) && lb > 0u;
+      const uint64_t m = __ballot(up);
+      if (nu + (uint32_t)__popcll(m) > cap) return false;
+      if (up) sbuf[nu + (uint32_t)__popcll(m & below(lane))] = ((uint64_t)(nb_ >> 1) << 32) | (uint64_t)((nb_ >> 1) + lb - 1u);
+      nu += (uint32_t)__popcll(m);
+      if (__ballot(hb && (nb_ & 1u) && lb > 0u)) anydn = true;
+    }
+    lds_sync();
+    if (nu > 0u && anydn) {
+      uint32_t n2 = 2;
+      while (n2 < nu) n2 <<= 1;
+      for (uint32_t i = nu + (uint32_t)lane; i < n2; i += 64u) sbuf[i] = SEGX_EMPTY64;
+      lds_sync();
+      lds_sort64(sbuf, n2, lane);
+      bool unused = false;
+      const uint32_t Mu = lds_merge_intervals(sbuf, nu, lane, &unused);
+      const uint32_t Pu = 1u << (31 - __builtin_clz(Mu));
+      const uint32_t* uw = (const uint32_t*)sbuf;
+      for (uint32_t b0 = 0; b0 < nseg && !(flags & G2S_DEV_Q7_B); b0 += 64u) {
         const uint32_t b = b0 + (uint32_t)lane;
         const bool hb = b < nseg;
-        const uint32_t nb_ = hb ? s_node[b] : 0u, lb = hb ? s_dl[b] >> 16 : 0u;
-        const bool up = hb && !(nb_ & 1u) && lb > 0u;
-        const uint64_t m = __ballot(up);
-        if (up) sbuf[nu + (uint32_t)__popcll(m & below(lane))] = ((uint64_t)(nb_ >> 1) << 32) | (uint64_t)((nb_ >> 1) + lb - 1u);
-        nu += (uint32_t)__popcll(m);
-        if (__ballot(hb && (nb_ & 1u) && lb > 0u)) anydn = true;
-      }
-      lds_sync();
-      if (nu > 0u && anydn) {
-        uint32_t n2 = 2;
-        while (n2 < nu) n2 <<= 1;
-        for (uint32_t i = nu + (uint32_t)lane; i < n2; i += 64u) sbuf[i] = SEGX_EMPTY64;
-        lds_sync();
-        lds_sort64(sbuf, n2, lane);
-        bool unused = false;
-        const uint32_t Mu = lds_merge_intervals(sbuf, nu, lane, &unused);
-        const uint32_t Pu = 1u << (31 - __builtin_clz(Mu));
-        const uint32_t* uw = (const uint32_t*)sbuf;
-        for (uint32_t b0 = 0; b0 < nseg && !(flags & G2S_DEV_Q7_B); b0 += 64u) {
-          const uint32_t b = b0 + (uint32_t)lane;
-          const bool hb = b < nseg;
-          const uint32_t nb_ = hb ? s_node[b] : 0u, dlb = hb ? s_dl[b] : 0u;
-          const int ib = (int)(nb_ >> 1), db = (int)(dlb & 0xFFFFu), lb = (int)(dlb >> 16);
-          const bool down = hb && (nb_ & 1u) && lb > 0;
-          uint32_t pos = 0;
-          for (uint32_t st = Pu; st; st >>= 1) {
-            const uint32_t pp = pos + st;
-            if (pp <= Mu && uw[2u * (pp - 1u) + 1u] <= (uint32_t)ib) pos = pp;
-          }
-          const bool cand = down && pos > 0u && (int)uw[2u * (pos - 1u)] >= ib - lb + 1;
-          for (uint64_t cm = __ballot(cand); cm && !(flags & G2S_DEV_Q7_B); cm &= cm - 1) {
-            const int l = __builtin_ctzll(cm);
-            const int ibl = (int)rl((uint32_t)ib, l), dbl = (int)rl((uint32_t)db, l), lbl = (int)rl((uint32_t)lb, l);
-            for (uint32_t a0 = 0; a0 < nseg; a0 += 64u) {
-              const uint32_t a = a0 + (uint32_t)lane;
-              const bool ha = a < nseg;
-              const uint32_t na = ha ? s_node[a] : 1u, dla = ha ? s_dl[a] : 0u;
-              const int ia = (int)(na >> 1), da = (int)(dla & 0xFFFFu), la = (int)(dla >> 16);
-              const int sdiff = ibl - ia, ddiff = dbl - da;
-              const int t1 = (sdiff + ddiff) >> 1, t2 = (sdiff - ddiff) >> 1;
-              if (__ballot(ha && !(na & 1u) && !((sdiff + ddiff) & 1) && t1 >= 0 && t1 < la && t2 >= 0 && t2 < lbl)) { flags |= G2S_DEV_Q7_B; break; }
-            }
-          }
+        const uint32_t nb_ = hb ? s_node[b] : 0u, dlb = hb ? s_dl[b] : 0u;
+        const int ib = (int)(nb_ >> 1), db = (int)(dlb & 0xFFFFu), lb = (int)(dlb >> 16);
+        const bool down = hb && (nb_ & 1u) && lb > 0;
+        uint32_t pos = 0;
+        for (uint32_t st = Pu; st; st >>= 1) {
+          const uint32_t pp = pos + st;
+          if (pp <= Mu && uw[2u * (pp - 1u) + 1u] <= (uint32_t)ib) pos = pp;
         }
-      }
-      lds_sync();
-    }
-  } else {
-    if (!overflow && !(flags & G2S_DEV_Q7_B) && nseg > 1) {
-      uint64_t anyup = 0, anydn = 0;
-      for (uint32_t b0 = 0; b0 < nseg; b0 += 64u) {
-        const uint32_t b = b0 + (uint32_t)lane;
-        anyup |= __ballot(b < nseg && !(s_node[b < nseg ? b : 0] & 1u));
-        anydn |= __ballot(b < nseg && (s_node[b < nseg ? b : 0] & 1u));
-      }
-      if (anyup && anydn) {
-        // every downward segment against every upward one, both sides a chunk at a time in registers (a pass
-        // over LDS per pair cost 350 cycles: 73 k of the 550 k cycles of config 2's slowest gap)
-        for (uint32_t b0 = 0; b0 < nseg && !(flags & G2S_DEV_Q7_B); b0 += 64u) {
-          const uint32_t b = b0 + (uint32_t)lane;
-          const bool hb = b < nseg;
-          const uint32_t nb_ = hb ? s_node[b] : 0u, dlb = hb ? s_dl[b] : 0u;
-          const int ib = (int)(nb_ >> 1), db = (int)(dlb & 0xFFFFu), lb = (int)(dlb >> 16);
-          const uint64_t dm0 = __ballot(hb && (nb_ & 1u));
-          if (!dm0) continue;
-          for (uint32_t a0 = 0; a0 < nseg && !(flags & G2S_DEV_Q7_B); a0 += 64u) {
+        const bool cand = down && pos > 0u && (int)uw[2u * (pos - 1u)] >= ib - lb + 1;
+        for (uint64_t cm = __ballot(cand); cm && !(flags & G2S_DEV_Q7_B); cm &= cm - 1) {
+          const int l = __builtin_ctzll(cm);
+          const int ibl = (int)rl((uint32_t)ib, l), dbl = (int)rl((uint32_t)db, l), lbl = (int)rl((uint32_t)lb, l);
+          for (uint32_t a0 = 0; a0 < nseg; a0 += 64u) {
             const uint32_t a = a0 + (uint32_t)lane;
             const bool ha = a < nseg;
             const uint32_t na = ha ? s_node[a] : 1u, dla = ha ? s_dl[a] : 0u;
-            const bool upa = ha && !(na & 1u);
-            if (!__ballot(upa)) continue;
             const int ia = (int)(na >> 1), da = (int)(dla & 0xFFFFu), la = (int)(dla >> 16);
-            for (uint64_t dm = dm0; dm; dm &= dm - 1) {
-              const int l = __builtin_ctzll(dm);
-              const int sdiff = (int)rl((uint32_t)ib, l) - ia, ddiff = (int)rl((uint32_t)db, l) - da;
-              const int t1 = (sdiff + ddiff) >> 1, t2 = (sdiff - ddiff) >> 1;
-              if (__ballot(upa && !((sdiff + ddiff) & 1) && t1 >= 0 && t1 < la && t2 >= 0 && t2 < (int)rl((uint32_t)lb, l))) { flags |= G2S_DEV_Q7_B; break; }
+            const int sdiff = ibl - ia, ddiff = dbl - da;
+            const int t1 = (sdiff + ddiff) >> 1, t2 = (sdiff - ddiff) >> 1;
+            if (__ballot(ha && !(na & 1u) && !((sdiff + ddiff) & 1) && t1 >= 0 && t1 < la && t2 >= 0 && t2 < lbl)) { flags |= G2S_DEV_Q7_B; break; }
+          }
+        }
+      }
+    }
+    lds_sync();
+    return true;
+  };
+  if constexpr (BIG) {
+    if (!overflow && !(flags & G2S_DEV_Q7_B) && nseg > 1) (void)q7_sorted((uint64_t*)lds, G2S_SEGX_CAP);
+  } else {
+    if (!overflow && !(flags & G2S_DEV_Q7_B) && nseg > 1) {
+      if (nseg <= 64u || !q7_sorted((uint64_t*)s_t, CAP / 2u)) {
+        uint64_t anyup = 0, anydn = 0;
+        for (uint32_t b0 = 0; b0 < nseg; b0 += 64u) {
+          const uint32_t b = b0 + (uint32_t)lane;
+          anyup |= __ballot(b < nseg && !(s_node[b < nseg ? b : 0] & 1u));
+          anydn |= __ballot(b < nseg && (s_node[b < nseg ? b : 0] & 1u));
+        }
+        if (anyup && anydn) {
+          // every downward segment against every upward one, both sides a chunk at a time in registers
+          for (uint32_t b0 = 0; b0 < nseg && !(flags & G2S_DEV_Q7_B); b0 += 64u) {
+            const uint32_t b = b0 + (uint32_t)lane;
+            const bool hb = b < nseg;
+            const uint32_t nb_ = hb ? s_node[b] : 0u, dlb = hb ? s_dl[b] : 0u;
+            const int ib = (int)(nb_ >> 1), db = (int)(dlb & 0xFFFFu), lb = (int)(dlb >> 16);
+            const uint64_t dm0 = __ballot(hb && (nb_ & 1u));
+            if (!dm0) continue;
+            for (uint32_t a0 = 0; a0 < nseg && !(flags & G2S_DEV_Q7_B); a0 += 64u) {
+              const uint32_t a = a0 + (uint32_t)lane;
+              const bool ha = a < nseg;
+              const uint32_t na = ha ? s_node[a] : 1u, dla = ha ? s_dl[a] : 0u;
+              const bool upa = ha && !(na & 1u);
+              if (!__ballot(upa)) continue;
+              const int ia = (int)(na >> 1), da = (int)(dla & 0xFFFFu), la = (int)(dla >> 16);
+              for (uint64_t dm = dm0; dm; dm &= dm - 1) {
+                const int l = __builtin_ctzll(dm);
+                const int sdiff = (int)rl((uint32_t)ib, l) - ia, ddiff = (int)rl((uint32_t)db, l) - da;
+                const int t1 = (sdiff + ddiff) >> 1, t2 = (sdiff - ddiff) >> 1;
+                if (__ballot(upa && !((sdiff + ddiff) & 1) && t1 >= 0 && t1 < la && t2 >= 0 && t2 < (int)rl((uint32_t)lb, l))) { flags |= G2S_DEV_Q7_B; break; }
+              }
             }
           }
         }
