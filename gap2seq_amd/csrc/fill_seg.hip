@@ -46,6 +46,7 @@
 // A gap that outgrows a capacity (segments, pending events, right-set entries, host buffer) is flagged and
 // runs again in the next kernel of the chain (g2s_fill_segx, then the LDS tier).  Integer work only: no MFMA.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include "fill_device.h"
 #include "fill_seg.h"
@@ -1840,7 +1841,9 @@ hipError_t launch_fill_seg(hipStream_t st, uint32_t ngaps, const uint32_t* succ,
                            uint32_t* done_list, int skip_confident, uint32_t* dbg, bool two_waves, unsigned long long* xcd_tickets,
                            uint32_t* xcd_list, uint32_t xcd_stride, uint32_t pub_batch, bool resident) {
   if (ngaps == 0) return hipSuccess;
-  const size_t bytes = two_waves ? fill_seg2_lds_bytes() : fill_seg_lds_bytes();
+  size_t bytes = two_waves ? fill_seg2_lds_bytes() : fill_seg_lds_bytes();
+  // (G2S_SEG_LDS_PAD=BYTES, measurements only: a larger LDS request per gap = fewer gaps resident per compute unit)
+  if (const char* pad = getenv("G2S_SEG_LDS_PAD")) bytes += (size_t)atoi(pad);
   hipError_t e = hipFuncSetAttribute(two_waves ? (const void*)g2s_fill_seg2 : (const void*)g2s_fill_seg,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   if (e != hipSuccess) return e;
