@@ -93,10 +93,9 @@ __device__ __forceinline__ void d3_classify_body(const D3Params& P, const D3Work
         seg_gaps++;
         const bool phase_d = go.c_count > 0 && go.n_len > 0;  // :1169
         const bool by_host = phase_d && !(go.dflags & G2S_DEVA_ANALYSED);
-        // (the all-paths recount of a closure the host analyses is the host's; whether the gap counts as filled
-        // only matters to the skip rule: lists that carry one wait for the host then)
-        const int cnt = gap_count(go, P, phase_d && !by_host);
-        if (by_host && P.has_skip) unhandled++;
+        // (the all-paths recount — the sum of the counts of the sink states — is the kernel's for every closure,
+        // also for those the host analyses: whether a gap counts as filled decides the skip rule of the next)
+        const int cnt = gap_count(go, P, phase_d);
         if (cnt > 0 && (!P.unique_paths || cnt == 1)) gi |= GI_FILLED;
         if (go.n_len > 0) gi |= ((uint32_t)go.reached_j & 0xFFu) << 8;
         if (phase_d) {

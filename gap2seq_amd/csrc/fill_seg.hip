@@ -1666,6 +1666,27 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
       lds_sync();
     }
   }
+  if (want_s && nseg > 192u) {
+    // (closures the host analyses: the all-paths recount alone — the sum of the counts of the sink states,
+    // :1189-1226 — so that phase D3 on the device knows whether the gap counts as filled, :369)
+    for (uint32_t b0 = 0; b0 < nseg; b0 += 64u) {
+      const uint32_t b = b0 + (uint32_t)lane;
+      const bool hb = b < nseg;
+      const int ts = dec15(hb ? s_t[b] : 0x7FFF7FFFu);
+      const uint32_t v0 = hb ? s_node[b] : 0u, dl = hb ? s_dl[b] : 0u;
+      const int d0 = (int)(dl & 0xFFFFu);
+      const int len = max(0, min((int)(dl >> 16), d_last - d0 + 1));
+      int sp = -1;
+      if (ts >= 0) {
+        const int pk = seg_pos(v0, (uint32_t)len, sinknode);
+        if (pk >= 0 && d0 + pk >= lo_sink) sp = pk;
+        if (t_is_s) { const int pt = seg_pos(v0, (uint32_t)len, reached); if (pt >= 0 && (d0 + pt == len0 || (n_len > 1 && d0 + pt == len1))) sp = pt; }
+        if (sp > ts) sp = -1;
+      }
+      for (uint64_t m = __ballot(sp >= 0); m; m &= m - 1)
+        count_s = (int)min((uint32_t)count_s + rl(hb ? s_cnt[b] : 0u, __builtin_ctzll(m)), (uint32_t)G2S_DEV_MAX_PATHS);
+    }
+  }
   SEG_PROF_TAIL(3);
   // ---- the closure leaves as SEGMENTS (32 bytes each, SegRec), children before parents = descending
   // segment id; the host expands them into per-state records (post.cpp: seg_expand).  Writing the

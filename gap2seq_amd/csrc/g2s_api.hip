@@ -2935,6 +2935,57 @@ extern "C" int g2s_team_fill(g2s_session* const* sessions, int nsessions, const 
   {
     const size_t need = g2s_team_arena_bytes(sessions[0], gaps, n);
     if (arena_cap < need || (!arena && need)) return fail(G2S_ERR_ARG, "g2s_team_fill: fill arena too small");
+  }
+  // Long lists go slice by slice.  The draw-count tables of phase D3 grow with the SQUARE of the draw-dependent gaps
+  // they chain through (d3_device.hip): 16 384 gaps need about a million entries, 100 000 would need forty.  A slice
+  // ends where a record ends (no skip rule reaches across), is spread over all the sessions, and the lead's rand()
+  // stream runs on from slice to slice.
+  constexpr size_t kSlice = 16384;
+  auto slice_end = [&](size_t lo) {
+    size_t hi = std::min(n, lo + kSlice);
+    if (n - hi < kSlice / 4) hi = n;                                   // (no sliver at the end)
+    while (hi < n && gaps[hi].skip_if_prev_right_fuz_gt >= 0) hi++;  // the record goes on: take it whole
+    return hi;
+  };
+  if (n > kSlice + kSlice / 4 && slice_end(0) < n) {
+    const auto t_begin = std::chrono::steady_clock::now();
+    g2s_timing total;
+    memset(&total, 0, sizeof total);
+    size_t lo = 0, abase = 0;
+    while (lo < n) {
+      const size_t hi = slice_end(lo);
+      const size_t cnt = hi - lo;
+      const size_t per = std::max<size_t>(256, (cnt + (size_t)nsessions - 1) / (size_t)nsessions);
+      const size_t abytes = g2s_team_arena_bytes(sessions[0], gaps + lo, cnt);
+      g2s_timing tm;
+      memset(&tm, 0, sizeof tm);
+      const int rc = g2s_team_fill(sessions, nsessions, gaps + lo, cnt, std::min(group_size, per), results + lo, arena + abase, abytes, &tm);
+      if (rc != G2S_OK) return rc;
+      for (size_t i = lo; i < hi; i++) results[i].fill_off += (uint64_t)abase;  // (offsets into the whole arena)
+      total.ms_right_bfs += tm.ms_right_bfs; total.ms_left_dp += tm.ms_left_dp; total.ms_extract += tm.ms_extract;
+      total.ms_fill_lds += tm.ms_fill_lds; total.ms_extract_lds += tm.ms_extract_lds; total.ms_d2h += tm.ms_d2h;
+      total.ms_host_post += tm.ms_host_post; total.ms_prepare += tm.ms_prepare; total.ms_d3 += tm.ms_d3;
+      total.xA += tm.xA; total.sA += tm.sA; total.xB += tm.xB; total.sB += tm.sB; total.xD += tm.xD; total.sD += tm.sD;
+      total.flank_bytes += tm.flank_bytes; total.fill_bytes += tm.fill_bytes; total.launches_left_dp += tm.launches_left_dp;
+      total.retried_gaps += tm.retried_gaps; total.x_fill_lds += tm.x_fill_lds; total.s_fill_lds += tm.s_fill_lds;
+      total.lds_tier_gaps += tm.lds_tier_gaps; total.lds_launches += tm.lds_launches; total.log_pool_gaps += tm.log_pool_gaps;
+      total.rs_pool_gaps += tm.rs_pool_gaps; total.ms_fill_seg += tm.ms_fill_seg; total.seg_tier_gaps += tm.seg_tier_gaps;
+      total.seg_launches += tm.seg_launches; total.seg_segments += tm.seg_segments; total.ms_fill_segx += tm.ms_fill_segx;
+      total.segx_tier_gaps += tm.segx_tier_gaps; total.segx_launches += tm.segx_launches; total.watchdog_gaps += tm.watchdog_gaps;
+      total.seg2_launches += tm.seg2_launches; total.resident_launches += tm.resident_launches;
+      total.resident_fallbacks += tm.resident_fallbacks; total.draw_dependent_gaps += tm.draw_dependent_gaps;
+      total.d3_table_entries += tm.d3_table_entries; total.host_finished_gaps += tm.host_finished_gaps;
+      total.team_groups += tm.team_groups; total.team_sessions = tm.team_sessions;
+      for (int q = 0; q < 16; q++) total.team_groups_by_session[q] += tm.team_groups_by_session[q];
+      lo = hi;
+      abase += abytes;
+    }
+    total.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    if (timing_out) *timing_out = total;
+    sessions[0]->last_timing = total;
+    return G2S_OK;
+  }
+  {
     const int rr = team_resident(sessions, nsessions, gaps, n, group_size, results, arena, timing_out);  // (the host path below when it declines)
     if (rr == G2S_OK) return G2S_OK;
     if (rr < 0) return rr;

@@ -162,3 +162,39 @@ def test_team_on_the_devices_equals_one_session(product, monkeypatch, nsess, gro
         for s in team:
             s.destroy()
         pg.free()
+
+
+def test_long_lists_go_slice_by_slice(product, monkeypatch):
+    """A list beyond 20 480 gaps is filled in slices of about 16 384 (the draw-count tables of phase D3 grow with the
+    square of the gaps they chain through); the rand() stream runs on from slice to slice, a slice ends where a
+    record ends.  36 000 gaps through g2s_fill_batch, and through a team of two sessions, against the host path."""
+    reads = product.G2S.synth_genome(400000, 3, 20240101)
+    seqs = [ln for ln in reads.splitlines() if not ln.startswith(">")]
+    gl = _parse_scaffolds(product.G2S.synth_gaps(reads, 31, 10, 36000, 60, 400, 20240103))
+    gaps = _gaps(product, gl)
+    for i in range(1, len(gaps), 3):  # records of three gaps: the second and third carry a skip rule
+        gaps[i].skip_dep = 5
+        if i + 1 < len(gaps):
+            gaps[i + 1].skip_dep = 0
+    pg = product.Graph.from_seqs(seqs, 31, 1)
+    try:
+        monkeypatch.setenv("G2S_RESIDENT", "0")
+        s0 = product.Session(pg, 0, d_err=300, randseed=4)
+        want = [_key(r) for r in s0.fill_batch_onecall(gaps)]
+        s0.destroy()
+        monkeypatch.delenv("G2S_RESIDENT")
+        s1 = product.Session(pg, 0, d_err=300, randseed=4)
+        got = [_key(r) for r in s1.fill_batch_onecall(gaps)]
+        tm = product.g2s_timing()
+        product._check(product.load_library().g2s_session_last_timing(s1.h, tm))
+        s1.destroy()
+        assert got == want
+        assert tm.resident_launches == 2 and tm.resident_fallbacks == 0 and tm.seg_tier_gaps == len(gaps)
+        team = [product.Session(pg, 0, d_err=300, randseed=4) for _ in range(2)]
+        got2, tm2 = product.team_fill(team, gaps, group_size=18000, want_timing=True)
+        for s in team:
+            s.destroy()
+        assert [_key(r) for r in got2] == want and tm2.resident_launches == 2 and tm2.team_groups == 4
+        assert sum(1 for r in want if r[3] & product.G2S_GAP_SKIPPED) >= 1  # (a right fuz beyond 0 is rare on this genome)
+    finally:
+        pg.free()
