@@ -223,14 +223,30 @@ __device__ __forceinline__ void d3_scan_body(const D3Params& P, const D3Work& W,
     __threadfence_block();
     __syncthreads();
   }
-  // ---- prefix sums in list order: draws, draw-dependent gaps, spreads
+  // ---- prefix sums in list order: draws, draw-dependent gaps, spreads.  A thread's range is read eight gaps at a
+  // time with all 24 loads in flight (one gap per iteration, load then use, made every pass a chain of memory round
+  // trips: the scan took 26 us of a 10 000-gap list's 1 ms).
+  auto load8 = [&](uint32_t i0, uint32_t* g8, uint32_t* m8, uint32_t* s8) {
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const uint32_t i = i0 + (uint32_t)q;
+      const bool have = i < hi;
+      g8[q] = have ? W.ginfo[i] : GI_SKIPPED;  // (beyond the range: reads as a gap that contributes nothing)
+      m8[q] = have ? W.dmin[i] : 0u;
+      s8[q] = have ? W.dspread[i] : 0u;
+    }
+  };
   uint64_t sd = 0, ss = 0;
   uint32_t nv = 0;
-  for (uint32_t i = lo; i < hi; i++) {
-    const uint32_t gi = W.ginfo[i];
-    if (gi & GI_SKIPPED) continue;
-    sd += W.dmin[i];
-    if (GI_CLASS(gi) == 2u) { nv++; ss += W.dspread[i]; }
+  for (uint32_t i0 = lo; i0 < hi; i0 += 8u) {
+    uint32_t g8[8], m8[8], s8[8];
+    load8(i0, g8, m8, s8);
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      if (g8[q] & GI_SKIPPED) continue;
+      sd += m8[q];
+      if (GI_CLASS(g8[q]) == 2u) { nv++; ss += s8[q]; }
+    }
   }
   uint64_t tot_d, tot_s;
   uint32_t V;
@@ -241,20 +257,26 @@ __device__ __forceinline__ void d3_scan_body(const D3Params& P, const D3Work& W,
   {
     uint64_t d = sd, r = ss;
     uint32_t v = nv;
-    for (uint32_t i = lo; i < hi; i++) {
-      const uint32_t gi = W.ginfo[i];
-      W.base[i] = (uint32_t)d;
-      W.vrank[i] = v;
-      if (gi & GI_SKIPPED) continue;
-      d += W.dmin[i];
-      if (GI_CLASS(gi) == 2u) {
-        W.var_gap[v] = i;
-        W.var_R[v] = (uint32_t)r;
-        my_tab += r + 1u;
-        my_tiles += (uint32_t)((r + D3_TILE) / D3_TILE);
-        if (v % G2S_D3_BLOCK_VARS == 0u) my_blk += r + 1u;
-        v++;
-        r += W.dspread[i];
+    for (uint32_t i0 = lo; i0 < hi; i0 += 8u) {
+      uint32_t g8[8], m8[8], s8[8];
+      load8(i0, g8, m8, s8);
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const uint32_t i = i0 + (uint32_t)q;
+        if (i >= hi) break;
+        W.base[i] = (uint32_t)d;
+        W.vrank[i] = v;
+        if (g8[q] & GI_SKIPPED) continue;
+        d += m8[q];
+        if (GI_CLASS(g8[q]) == 2u) {
+          W.var_gap[v] = i;
+          W.var_R[v] = (uint32_t)r;
+          my_tab += r + 1u;
+          my_tiles += (uint32_t)((r + D3_TILE) / D3_TILE);
+          if (v % G2S_D3_BLOCK_VARS == 0u) my_blk += r + 1u;
+          v++;
+          r += s8[q];
+        }
       }
     }
     if (t == 1023u) W.var_R[V] = (uint32_t)tot_s;
@@ -267,16 +289,20 @@ __device__ __forceinline__ void d3_scan_body(const D3Params& P, const D3Work& W,
   if (!over) {
     uint64_t r = ss;
     uint32_t v = nv;
-    for (uint32_t i = lo; i < hi; i++) {
-      const uint32_t gi = W.ginfo[i];
-      if ((gi & GI_SKIPPED) || GI_CLASS(gi) != 2u) continue;
-      W.var_toff[v] = (uint32_t)to;
-      W.var_tile[v] = tl;
-      tl += (uint32_t)((r + D3_TILE) / D3_TILE);
-      to += r + 1u;
-      if (v % G2S_D3_BLOCK_VARS == 0u) { W.blk_toff[v / G2S_D3_BLOCK_VARS] = (uint32_t)bo; bo += r + 1u; }
-      v++;
-      r += W.dspread[i];
+    for (uint32_t i0 = lo; i0 < hi; i0 += 8u) {
+      uint32_t g8[8], m8[8], s8[8];
+      load8(i0, g8, m8, s8);
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        if ((g8[q] & GI_SKIPPED) || GI_CLASS(g8[q]) != 2u) continue;
+        W.var_toff[v] = (uint32_t)to;
+        W.var_tile[v] = tl;
+        tl += (uint32_t)((r + D3_TILE) / D3_TILE);
+        to += r + 1u;
+        if (v % G2S_D3_BLOCK_VARS == 0u) { W.blk_toff[v / G2S_D3_BLOCK_VARS] = (uint32_t)bo; bo += r + 1u; }
+        v++;
+        r += s8[q];
+      }
     }
     if (t == 1023u) { W.var_toff[V] = (uint32_t)T; W.var_tile[V] = tiles; W.blk_toff[(V + G2S_D3_BLOCK_VARS - 1u) / G2S_D3_BLOCK_VARS] = (uint32_t)TB; }
   }

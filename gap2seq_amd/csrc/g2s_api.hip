@@ -758,6 +758,7 @@ extern "C" int g2s_batch_prepare(g2s_session* s, const g2s_gap* gaps, size_t n, 
   if (!s || (!gaps && n) || !out) return fail(G2S_ERR_ARG, "g2s_batch_prepare: bad argument");
   const Graph& g = *s->graph->g;
   const int k = g.k;
+  const auto tp0 = std::chrono::steady_clock::now();
   g2s_batch* b = new g2s_batch();
   b->s = s;
   memset(&b->timing, 0, sizeof b->timing);
@@ -804,6 +805,7 @@ extern "C" int g2s_batch_prepare(g2s_session* s, const g2s_gap* gaps, size_t n, 
     b->arena_bytes += j.buf_bytes(k, d_err);
   }
   b->n_valid = n_desc;
+  const auto tp1 = std::chrono::steady_clock::now();
   if (hipSetDevice(s->device) != hipSuccess) { delete b; return fail(G2S_ERR_NO_DEVICE, "cannot select device"); }
   // resident mode is likely to take this list: its descriptors are filled by the pass below as well
   GapDev* fast_gd = nullptr;
@@ -881,8 +883,13 @@ extern "C" int g2s_batch_prepare(g2s_session* s, const g2s_gap* gaps, size_t n, 
     if (ntasks > 4) s->pool->run(ntasks, do_range);
     else for (size_t t = 0; t < ntasks; t++) do_range(t);
   }
+  const auto tp2 = std::chrono::steady_clock::now();
   const int rc = b->upload_flanks();
   if (rc != G2S_OK) { delete b; return rc; }
+  if (n >= 1024 && getenv("G2S_DEBUG"))
+    fprintf(stderr, "[g2s] prepare: sizes %.3f ms, text + descriptors %.3f ms, look-up launch %.3f ms\n",
+            std::chrono::duration<double, std::milli>(tp1 - tp0).count(), std::chrono::duration<double, std::milli>(tp2 - tp1).count(),
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp2).count());
   *out = b;
   return G2S_OK;
 }
