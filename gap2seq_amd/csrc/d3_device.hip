@@ -558,27 +558,18 @@ __global__ __launch_bounds__(1024) void g2s_d3_front(const D3Params P, const D3W
   __syncthreads();
   d3_scan_body(P, W, dgaps, sh64, sh32, sh_f);
 }
-__global__ __launch_bounds__(1024) void g2s_d3_back(const D3Work W, const uint32_t* __restrict__ Wd) {
-  __shared__ uint32_t total_dev;
-  if (W.sum->status) return;
-  d3_blocks_body(W, threadIdx.x, 1024u);
-  __threadfence();
-  __syncthreads();
-  d3_chain_body(W, Wd, &total_dev);
-}
 
 // ---------------------------------------------------------------------------------------------------------
 // hand-off: the gaps whose closure the host analyses (GI_HOST) get their record, closure segments and the rand()
 // values of their traceback copied into pinned memory — in front of the trace kernel, so that the host
 // finishes them while that kernel runs.  One wave per 64 gaps of the list.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void g2s_d3_handoff(const D3Params P, const D3Work W, const GapOut* __restrict__ outs,
-                                                     const SubRec* __restrict__ sub, const uint32_t* __restrict__ rnd,
-                                                     uint64_t capacity, const g2s::D3Side side) {
+// (the body: one wave, the 64 gaps from i0 on; true when it handed something over)
+__device__ __forceinline__ bool d3_handoff_body(const D3Params& P, const D3Work& W, const GapOut* __restrict__ outs,
+                                                const SubRec* __restrict__ sub, const uint32_t* __restrict__ rnd, uint64_t capacity,
+                                                const g2s::D3Side& side, uint32_t i0) {
   D3Summary* S = W.sum;
-  if (S->status) return;
-  const int lane = (int)threadIdx.x;
-  const uint32_t i0 = blockIdx.x * 64u;
+  const int lane = (int)(threadIdx.x & 63u);
   const uint32_t mine = i0 + (uint32_t)lane;
   const bool host = mine < P.n && (W.ginfo[mine] & GI_HOST) != 0u;
   for (uint64_t m = __ballot(host); m; m &= m - 1) {
@@ -611,14 +602,42 @@ __global__ __launch_bounds__(64) void g2s_d3_handoff(const D3Params P, const D3W
       side.items[it] = h;
     }
   }
+  return __ballot(host) != 0ull;
+}
+__global__ __launch_bounds__(64) void g2s_d3_handoff(const D3Params P, const D3Work W, const GapOut* __restrict__ outs,
+                                                     const SubRec* __restrict__ sub, const uint32_t* __restrict__ rnd,
+                                                     uint64_t capacity, const g2s::D3Side side) {
+  D3Summary* S = W.sum;
+  if (S->status) return;
   // the number of items, where the host reads it once this kernel's event has fired
-  if (__ballot(host)) __threadfence_system();
-  if (lane == 0) {
+  if (d3_handoff_body(P, W, outs, sub, rnd, capacity, side, blockIdx.x * 64u)) __threadfence_system();
+  if ((threadIdx.x & 63u) == 0u) {
     const unsigned int done = atomicAdd(&S->handoff_waves, 1u) + 1u;
     if (done == gridDim.x) {
       __threadfence_system();
       *side.count = (unsigned long long)S->host_items | ((unsigned long long)(S->anomalies ? 1u : 0u) << 63);
     }
+  }
+}
+// (short lists: blocks, chain and the hand-off in one launch of one workgroup)
+__global__ __launch_bounds__(1024) void g2s_d3_back(const D3Params P, const D3Work W, const GapOut* __restrict__ outs,
+                                                    const SubRec* __restrict__ sub, const uint32_t* __restrict__ Wd, uint64_t capacity,
+                                                    const g2s::D3Side side) {
+  __shared__ uint32_t total_dev;
+  if (W.sum->status) return;
+  d3_blocks_body(W, threadIdx.x, 1024u);
+  __threadfence();
+  __syncthreads();
+  d3_chain_body(W, Wd, &total_dev);
+  __threadfence();
+  __syncthreads();
+  bool any = false;
+  for (uint32_t i0 = (threadIdx.x >> 6) * 64u; i0 < P.n; i0 += 1024u) any |= d3_handoff_body(P, W, outs, sub, Wd + 31, capacity, side, i0);
+  if (any) __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence_system();
+    *side.count = (unsigned long long)W.sum->host_items | ((unsigned long long)(W.sum->anomalies ? 1u : 0u) << 63);
   }
 }
 
@@ -918,13 +937,15 @@ hipError_t launch_d3(hipStream_t st, const D3Params& P, const D3Work& W, const G
     hipLaunchKernelGGL(g2s_d3_classify, dim3((P.n + 255u) / 256u), dim3(256), 0, st, P, W, outs, dgaps);
     hipLaunchKernelGGL(g2s_d3_scan, dim3(1), dim3(1024), 0, st, P, W, dgaps);
   }
-  hipLaunchKernelGGL(g2s_d3_tables, dim3(8192), dim3(256), 0, st, P, W, outs, sub, rnd_all + 31, rnd_capacity);
-  if (short_list) hipLaunchKernelGGL(g2s_d3_back, dim3(1), dim3(1024), 0, st, W, rnd_all);
+  // (a tile of 256 deviations per workgroup, grid-stride: a short list has a few dozen tiles)
+  const uint32_t tgrid = std::min(8192u, std::max(128u, P.n / 2u));
+  hipLaunchKernelGGL(g2s_d3_tables, dim3(tgrid), dim3(256), 0, st, P, W, outs, sub, rnd_all + 31, rnd_capacity);
+  if (short_list) hipLaunchKernelGGL(g2s_d3_back, dim3(1), dim3(1024), 0, st, P, W, outs, sub, rnd_all, rnd_capacity, side);
   else {
     hipLaunchKernelGGL(g2s_d3_blocks, dim3(256), dim3(256), 0, st, W);
     hipLaunchKernelGGL(g2s_d3_chain, dim3(1), dim3(1024), 0, st, W, rnd_all);
+    hipLaunchKernelGGL(g2s_d3_handoff, dim3((P.n + 63u) / 64u), dim3(64), 0, st, P, W, outs, sub, rnd_all + 31, rnd_capacity, side);
   }
-  hipLaunchKernelGGL(g2s_d3_handoff, dim3((P.n + 63u) / 64u), dim3(64), 0, st, P, W, outs, sub, rnd_all + 31, rnd_capacity, side);
   if (handed_over) {
     e = hipEventRecord(handed_over, st);
     if (e != hipSuccess) return e;
