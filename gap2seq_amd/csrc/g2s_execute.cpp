@@ -203,12 +203,26 @@ extern "C" int g2s_execute_scaffolds_stream(g2s_session* s, const g2s_run_opts* 
     }
 
     // ---- the hot path: one batch on the GPU -----------------------------------
-    std::vector<g2s_result> results(jobs.size());
-    std::vector<char> arena;
+    // (result records and fill arena in page-locked memory: a list finished on the device is written there by the
+    // kernels themselves; ordinary memory when that cannot be had)
+    struct HostBuf {
+      void* p = nullptr;
+      bool pinned = false;
+      std::vector<char> plain;
+      void* get(size_t bytes) {
+        p = g2s_host_alloc(bytes);
+        pinned = p != nullptr;
+        if (!p) { plain.resize(bytes); p = plain.data(); }
+        return p;
+      }
+      ~HostBuf() { if (pinned) g2s_host_free(p); }
+    } res_buf, arena_buf;
+    g2s_result* results = (g2s_result*)res_buf.get(std::max<size_t>(1, jobs.size()) * sizeof(g2s_result));
+    const size_t arena_bytes = jobs.empty() ? 0 : g2s_team_arena_bytes(s, jobs.data(), jobs.size());
+    char* arena = (char*)arena_buf.get(std::max<size_t>(1, arena_bytes));
     if (!jobs.empty()) {
       // g2s_fill_batch spreads long lists over the session's team (g2s_session_set_team)
-      arena.resize(g2s_team_arena_bytes(s, jobs.data(), jobs.size()));
-      int rc = g2s_fill_batch(s, jobs.data(), jobs.size(), results.data(), arena.data(), arena.size());
+      int rc = g2s_fill_batch(s, jobs.data(), jobs.size(), results, arena, arena_bytes);
       if (rc != G2S_OK) return rc;
     }
 
@@ -233,7 +247,7 @@ extern "C" int g2s_execute_scaffolds_stream(g2s_session* s, const g2s_run_opts* 
       if (eligible) {
         const g2s_result& r = results[(size_t)ev.job];
         const int sres = r.count;
-        const char* tail = arena.data() + r.fill_off;
+        const char* tail = arena + r.fill_off;
         if (r.flags & G2S_GAP_BACKTRACE_FAIL) os << r.backtrace_msg << "\n";
         const int filledStart = (int)filledSeq.length() + kmer_start + k + lmf - r.left_fuz - prevGapEnd;
         const int gapStart = kmer_start + k + lmf;
