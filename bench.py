@@ -252,6 +252,10 @@ def main():
                   args.fuz != 10])
     steps = args.steps or {"C2": 200, "C3": 30, "C4": 30, "C5": 3}[cfg_name]
     warmup = args.warmup if args.warmup >= 0 else (10 if steps >= 100 else 3 if steps >= 10 else 1)
+    # Resident mode brackets one fill-kernel launch in eight with HIP events (the events cost the stream ~10 us per
+    # list): enough for an average over 100 steps and more; a shorter run times every launch.
+    if steps < 100 and "G2S_KERNEL_TIMING" not in os.environ:
+        os.environ["G2S_KERNEL_TIMING"] = "all"
 
     # ---- workload (untimed) -------------------------------------------------------
     t0 = time.time()
@@ -293,7 +297,7 @@ def main():
         run.step()
     acc = dict(ms_right_bfs=0.0, ms_left_dp=0.0, ms_extract=0.0, ms_fill_lds=0.0, ms_extract_lds=0.0, ms_d2h=0.0,
                ms_host_post=0.0, ms_prepare=0.0, ms_total=0.0, ms_fill_seg=0.0, ms_fill_segx=0.0, ms_d3=0.0, launches=0,
-               lds_launches=0, seg_launches=0, segx_launches=0)
+               lds_launches=0, seg_launches=0, segx_launches=0, seg_timed=0, d3_timed_steps=0)
     in_call = 0.0
     barrier()
     t_begin = time.perf_counter()
@@ -306,6 +310,8 @@ def main():
         acc["launches"] += tm.launches_left_dp
         acc["lds_launches"] += tm.lds_launches
         acc["seg_launches"] += tm.seg_launches
+        acc["seg_timed"] += tm.seg_timed_launches  # resident mode brackets one launch in eight with HIP events
+        acc["d3_timed_steps"] += 1 if tm.ms_d3 > 0 else 0
         acc["segx_launches"] += tm.segx_launches
     elapsed = time.perf_counter() - t_begin
     barrier()
@@ -341,19 +347,27 @@ def main():
         r3 = Runner(P, sessions[:1], g3, 0, not args.pageable_buffers)
         for _ in range(2):
             r3.step()
-        n3, t3, k3 = 10, 0.0, 0.0
+        n3, t3, k3, timed3 = 10, 0.0, 0.0, 0
+        keep_mode = os.environ.get("G2S_KERNEL_TIMING")
+        os.environ["G2S_KERNEL_TIMING"] = "all"  # (ten steps: every launch timed)
         for _ in range(n3):
             t3 += r3.step()
-            k3 += r3.timing().ms_fill_seg if r3.timing().seg_tier_gaps else r3.timing().ms_fill_lds
+            t = r3.timing()
+            k3 += t.ms_fill_seg if t.seg_tier_gaps else t.ms_fill_lds
+            timed3 += t.seg_timed_launches if t.seg_tier_gaps else t.lds_launches
+        if keep_mode is None:
+            del os.environ["G2S_KERNEL_TIMING"]
+        else:
+            os.environ["G2S_KERNEL_TIMING"] = keep_mode
         tm3 = r3.timing()
         nl3 = max(1, tm3.seg_launches if tm3.seg_tier_gaps else tm3.lds_launches)
         x3, s3, by3 = oracle_units(units_key(genome_bp, args.variant, k, 10000, min_len, max_len, args.fuz, d_err))
-        kms3 = k3 / n3 / nl3
+        kms3 = k3 / max(1, timed3)  # average duration of the launches that were timed
         ab3 = algorithmic_bytes(x3, s3, tm3.flank_bytes + tm3.fill_bytes) / nl3 if x3 is not None else None
         c3_beside = dict(workload=CONFIGS["C3"][6], value=round(10000 * n3 / t3, 2), unit="gaps/s", steps=n3,
                          ms_per_step=round(t3 / n3 * 1e3, 4),
                          kernel=("g2s_fill_seg2" if tm3.seg2_launches else "g2s_fill_seg") if tm3.seg_tier_gaps else "g2s_fill_lds",
-                         kernel_ms_per_launch=round(kms3, 4), gaps_left_to_other_kernels=10000 - max(tm3.seg_tier_gaps, tm3.lds_tier_gaps),
+                         kernel_ms_per_launch=round(kms3, 4), kernel_launches_timed="%d of %d" % (timed3, n3 * nl3), gaps_left_to_other_kernels=10000 - max(tm3.seg_tier_gaps, tm3.lds_tier_gaps),
                          launches_per_step=nl3, algorithmic_bytes_per_launch=ab3, expansions=x3, states=s3,
                          units_counted_by=by3,
                          roofline_frac=round(ab3 / (kms3 / 1e3) / 1e9 / HBM_PEAK_GBS, 6) if ab3 is not None else None,
@@ -411,11 +425,14 @@ def main():
         # (short lists run two waves per gap: the same code as g2s_fill_seg, phase A on the second wave)
         kname = "g2s_fill_seg2" if tm.seg2_launches else "g2s_fill_seg"
         launches = acc["seg_launches"] / float(steps)
-        kern_ms = acc["ms_fill_seg"] / max(1, acc["seg_launches"])  # average launch duration
+        # average duration of the launches bracketed with HIP events inside the timed steps: every launch on the host
+        # path, one in eight in resident mode (an event between two kernels costs the stream 4-5 us;
+        # G2S_KERNEL_TIMING=all brackets every launch)
+        kern_ms = acc["ms_fill_seg"] / max(1, acc["seg_timed"])
         if tm.segx_tier_gaps > 0:
             # deep gaps took the tier's large variant as well: the two kernels' launches of a step as one unit
             kname = kname + " + g2s_fill_segx"
-            kern_ms = (acc["ms_fill_seg"] + acc["ms_fill_segx"]) / max(1, acc["seg_launches"])
+            kern_ms = (acc["ms_fill_seg"] + acc["ms_fill_segx"]) / max(1, acc["seg_timed"])
     elif tm.lds_tier_gaps > 0:
         kname = "g2s_fill_lds"
         launches = acc["lds_launches"] / float(steps)
@@ -451,7 +468,10 @@ def main():
                     measured_traffic_GBps=round(traffic / (kern_ms / 1e3) / 1e9, 3) if traffic and kern_ms > 0 else None,
                     algorithmic_bytes_per_launch=alg_bytes, expansions=x_units, states=s_units,
                     units_counted_by=counted_by, kernel_ms_per_launch=round(kern_ms, 4),
-                    launches_per_step=round(launches, 3), seg_tier_gaps=tm.seg_tier_gaps, segx_tier_gaps=tm.segx_tier_gaps, lds_tier_gaps=tm.lds_tier_gaps,
+                    launches_per_step=round(launches, 3),
+                    launches_timed_with_hip_events=(acc["seg_timed"] if kname.startswith("g2s_fill_seg") else None),
+                    launches_in_the_timed_steps=(acc["seg_launches"] if kname.startswith("g2s_fill_seg") else None),
+                    seg_tier_gaps=tm.seg_tier_gaps, segx_tier_gaps=tm.segx_tier_gaps, lds_tier_gaps=tm.lds_tier_gaps,
                     segments=tm.seg_segments)
     workload = "BASELINE %s%s: %d bp genome V%d, k=%d, %d gaps len %d-%d, fuz %d, dist-error %d" % (
         cfg_text if not custom else "custom (based on %s)" % cfg_name, "", genome_bp, args.variant, k, len(gaps), min_len,
@@ -494,9 +514,9 @@ def main():
                      "buffers": "pageable" if args.pageable_buffers else "page-locked (g2s_host_alloc)"},
         "breakdown_ms_per_step": {"wall_inside_the_abi_call": round(in_call / steps * 1e3, 4),
                                   "prepare_flank_lookup_and_upload": per_step("ms_prepare"),
-                                  "fill_seg_kernel": per_step("ms_fill_seg"),
+                                  "fill_seg_kernel": round(acc["ms_fill_seg"] / max(1, acc["seg_timed"]) * acc["seg_launches"] / steps, 4),
                                   "fill_segx_kernel": per_step("ms_fill_segx"),
-                                  "phase_d3_kernels": per_step("ms_d3"),
+                                  "phase_d3_kernels": round(acc["ms_d3"] / max(1, acc["d3_timed_steps"]), 4),
                                   "fill_lds_kernel": per_step("ms_fill_lds"),
                                   "extract_lds_kernel": per_step("ms_extract_lds"),
                                   "hbm_tier_kernels": round((acc["ms_right_bfs"] + acc["ms_left_dp"] +

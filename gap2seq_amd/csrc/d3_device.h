@@ -48,17 +48,37 @@ struct D3Side {  // pinned host memory, written by g2s_d3_trace
   unsigned long long* count = nullptr;  // items handed over (bit 63: something did not fit), written by g2s_d3_handoff's last wave
 };
 
-// what the host reads back after the last kernel
+// What g2s_d3_tables needs of the v-th draw-dependent gap, and what g2s_d3_trace needs of gap i besides its GapOut
+// record: one record each, written by the kernels in front (a wave that gathers them from six arrays spends
+// its time in a chain of memory round trips — on a 500-gap list those chains were the kernels).
+struct alignas(16) D3Var {
+  uint32_t gap, R, toff, tile0;   // the gap; deviations in front of it; where its table starts; tiles in front of its
+  uint32_t base, dmin, dspread, ns;  // first draw at deviation 0; fewest draws; most - fewest; closure segments
+  uint64_t sub_at;                // its closure, in 16-byte units from the list's first closure record
+  uint32_t start_seg, start_t;
+  int32_t len0, len1, n_len;
+  uint32_t pad;
+};
+struct alignas(16) D3Trace {
+  uint64_t arena_off;  // of the gap's fill buffer in the arena
+  uint64_t sub_at;     // its closure (as D3Var.sub_at)
+  uint32_t gi;         // ginfo
+  uint32_t off, want;  // first draw, draws
+  uint16_t lmf, nsegs;
+};
+static_assert(sizeof(D3Var) == 64 && sizeof(D3Trace) == 32, "record layouts");
+
+// what the host reads after the last kernel (g2s_d3_trace's last wave copies it into pinned memory)
 struct D3Summary {
   uint32_t status, unhandled, n_var, anomalies;
   unsigned long long host_items, host_segs, host_rnd;  // cursors of D3Side
-  uint32_t handoff_waves, pad2;
+  uint32_t handoff_waves, tiles;  // tiles: of 256 table entries, all gaps
   uint64_t table_entries, block_entries;
   uint64_t draws_min, draws_spread, draws_total;
   uint64_t xA, sA, xB, sB, xD, sD, segs, fill_bytes;
   uint32_t seg_gaps, filled;
   uint32_t rand_state[31];  // the 31 words in front of the first value the list did not consume
-  uint32_t pad;
+  uint32_t trace_waves;     // waves of g2s_d3_trace that are through
 };
 
 // the jump tables of the generator (seed independent): x^(2^20 a), x^(4096 b), x^(64 l) modulo the
@@ -84,6 +104,10 @@ struct D3Work {
   uint32_t* blk_toff = nullptr; // [n / BLOCK_VARS + 2]
   uint32_t* blk_in = nullptr;   // [n / BLOCK_VARS + 2] deviation in front of the block
   uint32_t* dvar = nullptr;     // [n + 1] deviation in front of the i-th draw-dependent gap (last: of the whole list)
+  int32_t* skip = nullptr;      // [n] skip_if_prev_right_fuz_gt (-1: never skipped)
+  uint32_t* tile_var = nullptr; // [n + G2S_D3_TABLE_BUDGET / 256 + 2] the draw-dependent gap a tile belongs to
+  D3Var* vdesc = nullptr;       // [n + 1]
+  D3Trace* tdesc = nullptr;     // [n]
   uint16_t* tab = nullptr;      // [G2S_D3_TABLE_BUDGET] draws - dmin by (gap, deviation)
   uint32_t* btab = nullptr;     // [G2S_D3_TABLE_BUDGET / 4] deviation behind a block by deviation in front of it
   D3Summary* sum = nullptr;
@@ -102,6 +126,8 @@ struct D3Params {
   uint32_t map_cap;    // fill-buffer positions it can map there: the longest path of the list + 2
   uint32_t group_size; // gaps per group of the list (a list filled by several sessions: one region of closure records
   uint64_t sub_region; // per group, sub_region 16-byte units apart); one group: group_size >= n
+  uint32_t laps;       // G2S_DEBUG: the trace kernel's waves record their laps (atomics on a few words)
+  uint32_t pad;
 };
 
 // the stream: values [0, capacity) into rnd_all[31 ..] (sum_dev = nullptr; independent of the list's kernels, so
@@ -114,13 +140,15 @@ hipError_t launch_rand_fill(hipStream_t st, uint32_t* rnd_all, const RandTables&
 //   (g2s_rand_fill has filled rnd_all by then: launch_rand_fill, on another stream)
 //   g2s_d3_tables  draws of every draw-dependent gap for every offset it can start at
 //   g2s_d3_blocks / g2s_d3_chain  the chain of deviations through those tables, block-wise
-//   g2s_d3_handoff what the host needs to finish the gaps whose closure it analyses, into pinned memory
-//   g2s_d3_trace   one wave per gap: the traceback, fill text and result record
+//   g2s_d3_handoff every gap's first draw and draw count; what the host needs to finish the gaps whose closure it
+//                  analyses, into pinned memory (*side.count says when: the host polls it)
+//   g2s_d3_trace   one wave per gap: the traceback, fill text and result record; the last wave copies the summary
 hipError_t launch_d3(hipStream_t st, const D3Params& P, const D3Work& W, const GapDev* gaps, const GapOut* outs,
                      const D3Gap* dgaps, const SubRec* sub, const char* lastch_up, const char* lastch_dn,
                      const RandTables& rt, uint32_t* rnd_all /* [31 + capacity]: first G2S_RAND_WINDOW words set */,
                      uint64_t rnd_capacity, void* results /* g2s_result[n], device-writable */,
-                     char* arena /* device-writable */, const D3Side& side,
-                     hipEvent_t handed_over /* recorded behind g2s_d3_handoff, in front of g2s_d3_trace; may be null */);
+                     char* arena /* device-writable */, const D3Side& side /* *side.count: ~0 until the hand-over is complete */,
+                     void* summary_host /* device-visible pinned memory: D3Summary in 1024 bytes, then the 64 fill-byte counters */,
+                     bool summary_is_clean /* the summary and the counters are zero already */);
 
 }  // namespace g2s

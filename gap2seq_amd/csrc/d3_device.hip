@@ -54,6 +54,12 @@ __device__ __forceinline__ uint32_t uni(uint32_t x) { return (uint32_t)__builtin
 #define D3_TILE 256u   /* deviations of one gap a workgroup of g2s_d3_tables takes */
 #define GI_HOST 0x80u  /* the host finishes this gap: its closure was not analysed by the fill kernel */
 
+// lap stamps (100 MHz clock) of the first workgroup of every kernel, in the second half of the summary's 1024 bytes:
+// what G2S_DEBUG prints (g2s_api.hip) — how the time of the short kernels of a short list is spent
+__device__ __forceinline__ void stamp(const D3Work& W, int slot) {
+  ((unsigned long long*)((char*)W.sum + 512))[slot] = wall_clock64();
+}
+
 // the closure records of gap i's group (a list filled by several sessions arrives as one region per group)
 __device__ __forceinline__ const SubRec* sub_of(const D3Params& P, const SubRec* sub, uint32_t i) {
   return sub + (uint64_t)(i / P.group_size) * P.sub_region;
@@ -74,41 +80,51 @@ __device__ __forceinline__ unsigned long long wave_add64(unsigned long long v) {
   return v;
 }
 
-__device__ __forceinline__ void d3_classify_body(const D3Params& P, const D3Work& W, const GapOut* __restrict__ outs,
-                                                 const D3Gap* __restrict__ dgaps, uint32_t first, uint32_t stride) {
+// (l_gi, l_dm, l_ds, l_sk: copies of the per-gap words in LDS when one workgroup does the scan as well, else null.
+// red: [16][8] sums per wave.  Returns, in every thread, the number of gaps the segment tier did not finish.)
+__device__ __forceinline__ uint32_t d3_classify_body(const D3Params& P, const D3Work& W, const GapOut* __restrict__ outs,
+                                                     const D3Gap* __restrict__ dgaps, uint32_t first, uint32_t stride,
+                                                     uint32_t* l_gi, uint32_t* l_dm, uint32_t* l_ds, int32_t* l_sk,
+                                                     unsigned long long* red, bool one_wg) {
   const uint32_t n = P.n;
   unsigned long long xA = 0, sA = 0, xB = 0, sB = 0, xD = 0, sD = 0, segs = 0;
   uint32_t unhandled = 0, seg_gaps = 0;
   for (uint32_t i = first; i < n; i += stride) {
+    // (the descriptor comes over the link on a short list, the record from device memory: asked for together)
     const D3Gap dg = dgaps[i];
+    const GapOut& go = outs[i];
+    const uint32_t flags = go.flags, n_states = go.n_states, n_right = go.n_right, x_right = go.x_right, x_left = go.x_left;
+    const uint32_t x_sub = go.x_sub, n_sub = go.n_sub, nseg_b = go.stat[3], dflags = go.dflags, stop0 = go.stop[0], stop1 = go.stop[1];
+    const int c_count = go.c_count, n_len = go.n_len, len0 = go.len[0], len1 = go.len[1], reached_j = go.reached_j, count_s = go.count_s;
+    const uint32_t n_xl = go.n_xl;
+    const uint64_t sub_off = go.sub_off;
     uint32_t gi = 0, dmin = 0, spread = 0;
     if (dg.kind != 0) gi = GI_BAD;
     else {
-      const GapOut& go = outs[i];
-      if (go.flags & (G2S_DEV_OVERFLOW_A | G2S_DEV_OVERFLOW_B)) unhandled++;
-      else if ((uint64_t)go.n_states > P.max_states || (uint64_t)go.n_right > P.max_states) gi = GI_MEM;
+      if (flags & (G2S_DEV_OVERFLOW_A | G2S_DEV_OVERFLOW_B)) unhandled++;
+      else if ((uint64_t)n_states > P.max_states || (uint64_t)n_right > P.max_states) gi = GI_MEM;
       else {
-        xA += go.x_right; sA += go.n_right; xB += go.x_left; sB += go.n_states; xD += go.x_sub; sD += go.n_sub;
-        segs += go.stat[3];
+        xA += x_right; sA += n_right; xB += x_left; sB += n_states; xD += x_sub; sD += n_sub;
+        segs += nseg_b;
         seg_gaps++;
-        const bool phase_d = go.c_count > 0 && go.n_len > 0;  // :1169
-        const bool by_host = phase_d && !(go.dflags & G2S_DEVA_ANALYSED);
+        const bool phase_d = c_count > 0 && n_len > 0;  // :1169
+        const bool by_host = phase_d && !(dflags & G2S_DEVA_ANALYSED);
         // (the all-paths recount — the sum of the counts of the sink states — is the kernel's for every closure,
         // also for those the host analyses: whether a gap counts as filled decides the skip rule of the next)
-        const int cnt = gap_count(go, P, phase_d);
+        const int cnt = (phase_d && !P.skip_confident && P.all_paths) ? count_s : c_count;
         if (cnt > 0 && (!P.unique_paths || cnt == 1)) gi |= GI_FILLED;
-        if (go.n_len > 0) gi |= ((uint32_t)go.reached_j & 0xFFu) << 8;
+        if (n_len > 0) gi |= ((uint32_t)reached_j & 0xFFu) << 8;
         if (phase_d) {
           gi |= GI_PHASE_D;
           if (by_host) gi |= GI_HOST;
           int lo_d = 0x7FFFFFFF, hi_d = 0;
 #pragma unroll
           for (int q = 0; q < 2; q++) {
-            if (q >= go.n_len) continue;
+            if (q >= n_len) continue;
             // stop depths behind traceback start q: lowest | highest << 16 (fill_seg.hip); a traceback stops at a
             // left-flank k-mer, i.e. at a depth in [0, lmf]
-            const uint32_t sw = q ? go.stop[1] : go.stop[0];
-            const int lq = q ? go.len[1] : go.len[0];
+            const uint32_t sw = q ? stop1 : stop0;
+            const int lq = q ? len1 : len0;
             int lo = (int)(sw & 0xFFFFu), hi = (int)(sw >> 16);
             if (lo > hi || hi > (int)dg.lmf) { lo = 0; hi = (int)dg.lmf; }
             lo_d = min(lo_d, 1 + lq - hi);
@@ -122,35 +138,62 @@ __device__ __forceinline__ void d3_classify_body(const D3Params& P, const D3Work
         }
       }
     }
+    gi |= (uint32_t)dg.lmf << 16;
     W.ginfo[i] = gi;
     W.dmin[i] = dmin;
     W.dspread[i] = spread;
+    W.skip[i] = dg.skip_thr;
+    if (l_gi) { l_gi[i] = gi; l_dm[i] = dmin; l_ds[i] = spread; l_sk[i] = dg.skip_thr; }
+    // the half of the trace kernel's record that does not depend on the offsets
+    uint4 h0;
+    const uint64_t ao = P.arena_base + dg.arena_off, sa = (uint64_t)(i / P.group_size) * P.sub_region + sub_off;
+    h0.x = (uint32_t)ao; h0.y = (uint32_t)(ao >> 32); h0.z = (uint32_t)sa; h0.w = (uint32_t)(sa >> 32);
+    ((uint4*)&W.tdesc[i])[0] = h0;
+    (void)n_xl;
   }
+  // ---- the list's counters: per wave, per workgroup through LDS, then one addition per workgroup (a short
+  // list's single workgroup stores them: 144 atomics on two lines were most of its 10 us)
   xA = wave_add64(xA); sA = wave_add64(sA); xB = wave_add64(xB); sB = wave_add64(sB); xD = wave_add64(xD); sD = wave_add64(sD);
   segs = wave_add64(segs);
   const unsigned long long cnts = wave_add64(((unsigned long long)unhandled << 32) | seg_gaps);
+  const uint32_t wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   if ((threadIdx.x & 63u) == 0u) {
-    D3Summary* S = W.sum;
-    atomicAdd((unsigned long long*)&S->xA, xA); atomicAdd((unsigned long long*)&S->sA, sA);
-    atomicAdd((unsigned long long*)&S->xB, xB); atomicAdd((unsigned long long*)&S->sB, sB);
-    atomicAdd((unsigned long long*)&S->xD, xD); atomicAdd((unsigned long long*)&S->sD, sD);
-    atomicAdd((unsigned long long*)&S->segs, segs);
-    if (cnts >> 32) atomicAdd(&S->unhandled, (uint32_t)(cnts >> 32));
-    if (cnts & 0xFFFFFFFFull) atomicAdd(&S->seg_gaps, (uint32_t)cnts);
+    unsigned long long* r = red + wave * 8u;
+    r[0] = xA; r[1] = sA; r[2] = xB; r[3] = sB; r[4] = xD; r[5] = sD; r[6] = segs; r[7] = cnts;
   }
+  __syncthreads();
+  unsigned long long tot = 0;
+  if (threadIdx.x < 8u) for (uint32_t w = 0; w < nwaves; w++) tot += red[w * 8u + threadIdx.x];
+  unsigned long long all_cnts = 0;
+  for (uint32_t w = 0; w < nwaves; w++) all_cnts += red[w * 8u + 7u];
+  D3Summary* S = W.sum;
+  if (threadIdx.x < 7u) {
+    unsigned long long* dst = (unsigned long long*)&S->xA + threadIdx.x;  // xA sA xB sB xD sD segs are consecutive
+    if (one_wg) *dst = tot; else if (tot) atomicAdd(dst, tot);
+  } else if (threadIdx.x == 7u) {
+    if (one_wg) { S->unhandled = (uint32_t)(tot >> 32); S->seg_gaps = (uint32_t)tot; }
+    else {
+      if (tot >> 32) atomicAdd(&S->unhandled, (uint32_t)(tot >> 32));
+      if (tot & 0xFFFFFFFFull) atomicAdd(&S->seg_gaps, (uint32_t)tot);
+    }
+  }
+  return (uint32_t)(all_cnts >> 32);
 }
 __global__ __launch_bounds__(256) void g2s_d3_classify(const D3Params P, const D3Work W, const GapOut* __restrict__ outs,
                                                        const D3Gap* __restrict__ dgaps) {
-  d3_classify_body(P, W, outs, dgaps, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+  __shared__ unsigned long long red[4 * 8];
+  (void)d3_classify_body(P, W, outs, dgaps, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x, nullptr, nullptr, nullptr, nullptr, red, false);
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // scan: the skip rule, prefix sums in list order, table layout.  One workgroup of 1024 threads over the compact
 // per-gap arrays; thread t owns the contiguous range [t * per, (t + 1) * per) of the list.
 // ---------------------------------------------------------------------------------------------------------
-// exclusive prefix sums of (a, b, c) over the 1024 threads of the workgroup; totals in tot[]
-__device__ __forceinline__ void block_scan3(uint64_t& a, uint64_t& b, uint32_t& c, uint64_t* sh64 /* [34] */, uint32_t* sh32 /* [17] */,
-                                            uint64_t* tot_a, uint64_t* tot_b, uint32_t* tot_c) {
+// exclusive prefix sums of (a, b, c) over the 1024 threads of the workgroup; totals in tot[].  One barrier: every
+// wave scans the 16 wave totals itself.  sh: [16][3] 64-bit words, not in use by a previous call still being read
+// (the callers alternate between two).
+__device__ __forceinline__ void block_scan3(uint64_t& a, uint64_t& b, uint32_t& c, uint64_t* sh /* [48] */, uint64_t* tot_a, uint64_t* tot_b,
+                                            uint32_t* tot_c) {
   const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
   uint64_t ia = a, ib = b;
   uint32_t ic = c;
@@ -159,29 +202,24 @@ __device__ __forceinline__ void block_scan3(uint64_t& a, uint64_t& b, uint32_t& 
     const uint32_t yc = __shfl_up(ic, o);
     if (lane >= o) { ia += ya; ib += yb; ic += yc; }
   }
-  if (lane == 63) { sh64[wave] = ia; sh64[17 + wave] = ib; sh32[wave] = ic; }
+  if (lane == 63) { sh[wave * 3] = ia; sh[wave * 3 + 1] = ib; sh[wave * 3 + 2] = ic; }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    uint64_t xa = 0, xb = 0;
-    uint32_t xc = 0;
-    for (int w = 0; w < 16; w++) {
-      const uint64_t ta = sh64[w], tb = sh64[17 + w];
-      const uint32_t tc = sh32[w];
-      sh64[w] = xa; sh64[17 + w] = xb; sh32[w] = xc;
-      xa += ta; xb += tb; xc += tc;
-    }
-    sh64[16] = xa; sh64[33] = xb; sh32[16] = xc;
+  uint64_t wa = lane < 16 ? sh[lane * 3] : 0, wb = lane < 16 ? sh[lane * 3 + 1] : 0, wc = lane < 16 ? sh[lane * 3 + 2] : 0;
+  for (int o = 1; o < 16; o <<= 1) {
+    const uint64_t ya = __shfl_up(wa, o), yb = __shfl_up(wb, o), yc = __shfl_up(wc, o);
+    if (lane >= o) { wa += ya; wb += yb; wc += yc; }
   }
-  __syncthreads();
-  const uint64_t wa = sh64[wave], wb = sh64[17 + wave];
-  const uint32_t wc = sh32[wave];
-  *tot_a = sh64[16]; *tot_b = sh64[33]; *tot_c = sh32[16];
-  a = wa + ia - a; b = wb + ib - b; c = wc + ic - c;
-  __syncthreads();
+  *tot_a = __shfl(wa, 15); *tot_b = __shfl(wb, 15); *tot_c = (uint32_t)__shfl(wc, 15);
+  const uint64_t oa = wave ? __shfl(wa, wave - 1) : 0, ob = wave ? __shfl(wb, wave - 1) : 0, oc = wave ? __shfl(wc, wave - 1) : 0;
+  a = oa + ia - a; b = ob + ib - b; c = (uint32_t)oc + ic - c;
 }
 
-__device__ __forceinline__ void d3_scan_body(const D3Params& P, const D3Work& W, const D3Gap* __restrict__ dgaps, uint64_t* sh64 /* [34] */,
-                                             uint32_t* sh32 /* [17] */, uint32_t* sh_f /* [1024] */) {
+// (gi_a, dm_a, ds_a, sk_a: the per-gap words — W's arrays, or their copies in LDS when this workgroup classified
+// the gaps itself (`dual`: what the skip rule changes is then written to both).  unhandled: gaps the segment tier
+// did not finish.)
+__device__ __forceinline__ void d3_scan_body(const D3Params& P, const D3Work& W, const GapOut* __restrict__ outs, uint32_t* gi_a,
+                                             uint32_t* dm_a, uint32_t* ds_a, const int32_t* sk_a, bool dual, uint32_t unhandled,
+                                             uint64_t* sh /* [96] */, uint32_t* sh_f /* [1024] */) {
   const uint32_t t = threadIdx.x, n = P.n;
   const uint32_t per = (n + 1023u) / 1024u;
   const uint32_t lo = min(n, t * per), hi = min(n, lo + per);
@@ -190,9 +228,9 @@ __device__ __forceinline__ void d3_scan_body(const D3Params& P, const D3Work& W,
   if (P.has_skip) {
     auto s_of = [&](uint32_t i) -> bool {
       if (i == 0) return false;
-      const int thr = dgaps[i].skip_thr;
+      const int thr = sk_a[i];
       if (thr < 0) return false;
-      const uint32_t pg = W.ginfo[i - 1];
+      const uint32_t pg = gi_a[i - 1];
       return (pg & GI_FILLED) && !(pg & (GI_BAD | GI_MEM)) && (int)((pg >> 8) & 0xFFu) > thr;
     };
     // the range as a function of "the gap in front of it was skipped": results for both inputs
@@ -216,9 +254,15 @@ __device__ __forceinline__ void d3_scan_body(const D3Params& P, const D3Work& W,
     }
     __syncthreads();
     bool sk = sh_f[t] != 0;
+    // (a thread's verdicts read the gap in front of its range, which its neighbour may be rewriting: the class bits
+    // only, which s_of does not look at)
     for (uint32_t i = lo; i < hi; i++) {
       sk = s_of(i) && !sk;
-      if (sk) { W.ginfo[i] = (W.ginfo[i] & ~3u) | GI_SKIPPED; W.dmin[i] = 0; W.dspread[i] = 0; }
+      if (sk) {
+        const uint32_t g = (gi_a[i] & ~3u) | GI_SKIPPED;
+        gi_a[i] = g; dm_a[i] = 0; ds_a[i] = 0;
+        if (dual) { W.ginfo[i] = g; W.dmin[i] = 0; W.dspread[i] = 0; }
+      }
     }
     __threadfence_block();
     __syncthreads();
@@ -231,9 +275,9 @@ __device__ __forceinline__ void d3_scan_body(const D3Params& P, const D3Work& W,
     for (int q = 0; q < 8; q++) {
       const uint32_t i = i0 + (uint32_t)q;
       const bool have = i < hi;
-      g8[q] = have ? W.ginfo[i] : GI_SKIPPED;  // (beyond the range: reads as a gap that contributes nothing)
-      m8[q] = have ? W.dmin[i] : 0u;
-      s8[q] = have ? W.dspread[i] : 0u;
+      g8[q] = have ? gi_a[i] : GI_SKIPPED;  // (beyond the range: reads as a gap that contributes nothing)
+      m8[q] = have ? dm_a[i] : 0u;
+      s8[q] = have ? ds_a[i] : 0u;
     }
   };
   uint64_t sd = 0, ss = 0;
@@ -250,7 +294,7 @@ __device__ __forceinline__ void d3_scan_body(const D3Params& P, const D3Work& W,
   }
   uint64_t tot_d, tot_s;
   uint32_t V;
-  block_scan3(sd, ss, nv, sh64, sh32, &tot_d, &tot_s, &V);
+  block_scan3(sd, ss, nv, sh, &tot_d, &tot_s, &V);
   const bool too_wide = tot_d + tot_s >= 0xFFFF0000ull || tot_s >= (uint64_t)G2S_D3_TABLE_BUDGET;
   uint64_t my_tab = 0, my_blk = 0;
   uint32_t my_tiles = 0;
@@ -284,19 +328,35 @@ __device__ __forceinline__ void d3_scan_body(const D3Params& P, const D3Work& W,
   // ---- where every table starts
   uint64_t to = my_tab, bo = my_blk, T, TB;
   uint32_t tl = my_tiles, tiles;
-  block_scan3(to, bo, tl, sh64, sh32, &T, &TB, &tiles);
+  block_scan3(to, bo, tl, sh + 48, &T, &TB, &tiles);
   const bool over = too_wide || T > (uint64_t)G2S_D3_TABLE_BUDGET || TB > (uint64_t)(G2S_D3_TABLE_BUDGET / 4u);
   if (!over) {
-    uint64_t r = ss;
+    uint64_t d = sd, r = ss;
     uint32_t v = nv;
     for (uint32_t i0 = lo; i0 < hi; i0 += 8u) {
       uint32_t g8[8], m8[8], s8[8];
       load8(i0, g8, m8, s8);
 #pragma unroll
       for (int q = 0; q < 8; q++) {
-        if ((g8[q] & GI_SKIPPED) || GI_CLASS(g8[q]) != 2u) continue;
+        if (g8[q] & GI_SKIPPED) continue;
+        const uint32_t base_i = (uint32_t)d;
+        d += m8[q];
+        if (GI_CLASS(g8[q]) != 2u) continue;
         W.var_toff[v] = (uint32_t)to;
         W.var_tile[v] = tl;
+        {  // everything g2s_d3_tables wants to know about this gap, in one record; the gap of each of its tiles
+          const uint32_t i = i0 + (uint32_t)q;
+          const GapOut& go = outs[i];
+          g2s::D3Var vd;
+          vd.gap = i; vd.R = (uint32_t)r; vd.toff = (uint32_t)to; vd.tile0 = tl;
+          vd.base = base_i; vd.dmin = m8[q]; vd.dspread = s8[q]; vd.ns = go.n_xl;
+          vd.sub_at = (uint64_t)(i / P.group_size) * P.sub_region + go.sub_off;
+          vd.start_seg = go.start_seg; vd.start_t = go.start_t;
+          vd.len0 = go.len[0]; vd.len1 = go.len[1]; vd.n_len = go.n_len; vd.pad = 0;
+          W.vdesc[v] = vd;
+          const uint32_t nt = (uint32_t)((r + D3_TILE) / D3_TILE);
+          for (uint32_t x = 0; x < nt; x++) W.tile_var[tl + x] = v;
+        }
         tl += (uint32_t)((r + D3_TILE) / D3_TILE);
         to += r + 1u;
         if (v % G2S_D3_BLOCK_VARS == 0u) { W.blk_toff[v / G2S_D3_BLOCK_VARS] = (uint32_t)bo; bo += r + 1u; }
@@ -308,19 +368,19 @@ __device__ __forceinline__ void d3_scan_body(const D3Params& P, const D3Work& W,
   }
   if (t == 0) {
     D3Summary* S = W.sum;
-    S->status = (S->unhandled ? G2S_D3_UNHANDLED : 0u) | (over ? G2S_D3_BUDGET : 0u);
+    S->status = (unhandled ? G2S_D3_UNHANDLED : 0u) | (over ? G2S_D3_BUDGET : 0u);
     S->n_var = V;
+    S->tiles = over ? 0u : tiles;
     S->table_entries = T;
     S->block_entries = TB;
     S->draws_min = tot_d;
     S->draws_spread = tot_s;
   }
 }
-__global__ __launch_bounds__(1024) void g2s_d3_scan(const D3Params P, const D3Work W, const D3Gap* __restrict__ dgaps) {
-  __shared__ uint64_t sh64[34];
-  __shared__ uint32_t sh32[17];
+__global__ __launch_bounds__(1024) void g2s_d3_scan(const D3Params P, const D3Work W, const GapOut* __restrict__ outs) {
+  __shared__ uint64_t sh[96];
   __shared__ uint32_t sh_f[1024];
-  d3_scan_body(P, W, dgaps, sh64, sh32, sh_f);
+  d3_scan_body(P, W, outs, W.ginfo, W.dmin, W.dspread, W.skip, false, W.sum->unhandled, sh, sh_f);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -402,16 +462,20 @@ __device__ __forceinline__ uint32_t seg_parent(uint32_t p01, uint32_t p23, int s
   return chosen;
 }
 
+// rand() % nb for the 2 to 4 parents a segment can have (a division by a variable is ~40 instructions)
+__device__ __forceinline__ int pick_parent(uint32_t rv, int nb) { return nb == 2 ? (int)(rv & 1u) : nb == 3 ? (int)(rv % 3u) : (int)(rv & 3u); }
+
 // What a walk needs of a closure segment: entry depth | length << 16, the parents, the flags.
 struct SegLite { uint32_t depth_len, par01, par23, flags; };
 
 // rand() draws of the traceback of one gap whose draws start at rnd[0]; *bad: something the host must look at
 __device__ int d3_walk_count(int n_len, int len0, int len1, uint32_t start_seg, uint32_t start_t, int nsegs,
-                             const SegLite* __restrict__ segs, const uint32_t* __restrict__ rnd,
-                             uint64_t avail /* values that exist from rnd[0] on */, bool* bad) {
+                             const SegLite* __restrict__ segs, const uint32_t* lwin /* LDS: the values from the first draw on */,
+                             uint32_t nwin /* how many of them are there */, uint64_t avail /* values that exist from the first on */,
+                             bool* bad) {
   int draws = 1;
-  if (avail < 1) { *bad = true; return draws; }
-  const int pick = n_len > 1 ? (int)((rnd[0] >> 1) % (uint32_t)n_len) : 0;  // :1440
+  if (avail < 1 || nwin < 1) { *bad = true; return draws; }
+  const int pick = n_len > 1 ? (int)((lwin[0] >> 1) & 1u) : 0;  // :1440 (n_len <= 2)
   int d2 = pick ? len1 : len0;
   const uint32_t sg = (start_seg >> (16 * pick)) & 0xFFFFu;
   int i = sg == 0xFFFFu ? -1 : (int)sg;
@@ -425,10 +489,10 @@ __device__ int d3_walk_count(int n_len, int len0, int len1, uint32_t start_seg, 
     if (d2 > 0) {
       if (t > 0) { const int run = min(t, d2); draws += run; d2 -= run; t -= run; continue; }
       const int nb = seg_nparents(s.par01, s.par23);
-      if (nb == 0 || (nb > 1 && !(s.flags & G2S_SEG_ORDERED)) || (uint64_t)draws >= avail) { *bad = true; break; }
-      const uint32_t rv = nb > 1 ? rnd[draws] >> 1 : 0u;  // (rand() % 1: the value does not matter)
+      if (nb == 0 || (nb > 1 && !(s.flags & G2S_SEG_ORDERED)) || (uint64_t)draws >= avail || (uint32_t)draws >= nwin) { *bad = true; break; }
+      const uint32_t rv = nb > 1 ? lwin[draws] >> 1 : 0u;  // (rand() % 1: the value does not matter)
       draws++;
-      i = (int)seg_parent(s.par01, s.par23, nb == 1 ? 0 : (int)(rv % (uint32_t)nb));  // :1513, GATB predecessor order
+      i = (int)seg_parent(s.par01, s.par23, nb == 1 ? 0 : pick_parent(rv, nb));  // :1513, GATB predecessor order
       if (i >= nsegs) { *bad = true; break; }
       s = segs[i];
       t = (int)(s.depth_len >> 16) - 1;
@@ -440,61 +504,60 @@ __device__ int d3_walk_count(int n_len, int len0, int len1, uint32_t start_seg, 
 }
 
 // draws of draw-dependent gap v when its draws start at base + d, for every d it can meet: a workgroup takes 256
-// consecutive deviations of one gap: the closure's links in LDS, one walk per thread
+// consecutive deviations of one gap: the closure's links in LDS, one walk per thread.  What it needs to know comes
+// in three round trips: the tile's gap (tile_var), that gap's record (D3Var), then the closure's links and the
+// rand() values the tile's walks can read — both into LDS: a walk asks for a value at every choice between
+// parents, and a round trip to memory per choice was the kernel's time (20 us for a 30-segment path).
+// (the window: map_cap + 256 words of dynamic LDS — the longest path of the list, 256 starts)
 #define D3_TAB_SEGS 512u
-// (the body: sub-block `sb` of `nsb` sub-blocks of 256 threads takes tiles sb, sb + nsb, ...; every thread of the
-// workgroup passes the same number of barriers)
-__device__ __forceinline__ void d3_tables_body(const D3Params& P, const D3Work& W, const GapOut* __restrict__ outs,
-                                               const SubRec* __restrict__ sub, const uint32_t* __restrict__ rnd, uint64_t capacity,
-                                               SegLite* lseg /* this sub-block's [D3_TAB_SEGS] */, uint32_t sb, uint32_t nsb, uint32_t tid /* 0 .. 255 */) {
+__global__ __launch_bounds__(256) void g2s_d3_tables(const D3Params P, const D3Work W, const SubRec* __restrict__ sub,
+                                                     const uint32_t* __restrict__ rnd /* first upcoming value */, uint64_t capacity) {
+  __shared__ SegLite lseg[D3_TAB_SEGS];
+  extern __shared__ __attribute__((aligned(16))) uint32_t lwin[];
+  const uint32_t win_cap = P.map_cap + D3_TILE;
   const D3Summary* S = W.sum;
-  const uint32_t V = S->n_var;
-  const uint32_t tiles = V ? W.var_tile[V] : 0u;
+  const bool st0 = blockIdx.x == 0 && threadIdx.x == 0;
+  if (st0) stamp(W, 3);
+  const uint32_t status = S->status, tiles = S->tiles;
+  const uint32_t tid = threadIdx.x;
+  if (status) return;
+  if (st0) stamp(W, 4);
   bool bad_any = false;
-  for (uint32_t t0 = 0; t0 < tiles; t0 += nsb) {
-    const uint32_t tile = t0 + sb;
-    const bool have = tile < tiles;
-    uint32_t v = 0, i = 0, ns = 0;
-    if (have) {
-      uint32_t lo = 0, hi = V;  // last v with var_tile[v] <= tile
-      while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (W.var_tile[mid] <= tile) lo = mid; else hi = mid; }
-      v = lo;
-      i = W.var_gap[v];
-      ns = outs[i].n_xl;
-    }
-    __syncthreads();
-    if (have) {
-      const SegW* gs = (const SegW*)(sub_of(P, sub, i) + outs[i].sub_off);
+  for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const uint32_t v = W.tile_var[tile];
+    const g2s::D3Var vd = W.vdesc[v];
+    const uint32_t ns = vd.ns;
+    const uint32_t d0 = (tile - vd.tile0) * D3_TILE, d = d0 + tid;
+    const uint64_t at0 = (uint64_t)vd.base + d0;  // the tile's first value; thread tid starts tid values further on
+    const bool mine = d <= vd.R;
+    // a walk from deviation d reads values [d, d + dmin + dspread) of the tile's window
+    const uint32_t want = min(win_cap, min(vd.R - d0, D3_TILE - 1u) + vd.dmin + vd.dspread + 1u);
+    if (st0) stamp(W, 5);
+    __syncthreads();  // (the previous tile's walks are over)
+    {
+      const SegW* gs = (const SegW*)(sub + vd.sub_at);
       for (uint32_t q = tid; q < ns && q < D3_TAB_SEGS; q += 256u) {
         SegLite l;
         l.depth_len = gs[q].depth_len; l.par01 = gs[q].par01; l.par23 = gs[q].par23; l.flags = gs[q].flags;
         lseg[q] = l;
       }
+      for (uint32_t x = tid; x < want; x += 256u) lwin[x] = at0 + x < capacity ? rnd[at0 + x] : 0u;
     }
     __syncthreads();
-    if (!have) continue;
-    const GapOut& go = outs[i];
-    const uint32_t R = W.var_R[v];
-    const uint32_t d = (tile - W.var_tile[v]) * D3_TILE + tid;
-    if (d <= R) {
+    if (st0) stamp(W, 6);
+    if (mine) {
       bool bad = ns > D3_TAB_SEGS;
-      const uint64_t at = (uint64_t)W.base[i] + d;
-      const int draws = bad ? 0 : d3_walk_count(go.n_len, go.len[0], go.len[1], go.start_seg, go.start_t, (int)ns, lseg, rnd + at,
-                                                capacity > at ? capacity - at : 0ull, &bad);
-      const int dev = draws - (int)W.dmin[i];
-      if (dev < 0 || dev > (int)W.dspread[i]) bad = true;
-      W.tab[(uint64_t)W.var_toff[v] + d] = bad ? (uint16_t)0 : (uint16_t)dev;
+      const uint64_t at = at0 + tid;
+      const int draws = bad ? 0 : d3_walk_count(vd.n_len, vd.len0, vd.len1, vd.start_seg, vd.start_t, (int)ns, lseg, lwin + tid,
+                                                want > tid ? want - tid : 0u, capacity > at ? capacity - at : 0ull, &bad);
+      const int dev = draws - (int)vd.dmin;
+      if (dev < 0 || dev > (int)vd.dspread) bad = true;
+      W.tab[(uint64_t)vd.toff + d] = bad ? (uint16_t)0 : (uint16_t)dev;
       bad_any |= bad;
     }
   }
   if (bad_any) atomicAdd(&W.sum->anomalies, 1u);
-}
-__global__ __launch_bounds__(256) void g2s_d3_tables(const D3Params P, const D3Work W, const GapOut* __restrict__ outs,
-                                                     const SubRec* __restrict__ sub,
-                                                     const uint32_t* __restrict__ rnd /* first upcoming value */, uint64_t capacity) {
-  __shared__ SegLite lseg[D3_TAB_SEGS];
-  if (W.sum->status) return;
-  d3_tables_body(P, W, outs, sub, rnd, capacity, lseg, blockIdx.x, gridDim.x, threadIdx.x);
+  if (st0) stamp(W, 7);
 }
 
 // deviation behind block b for every deviation in front of it
@@ -547,44 +610,73 @@ __global__ __launch_bounds__(1024) void g2s_d3_chain(const D3Work W, const uint3
 }
 
 // Short lists: five launches cost a 2 000-gap list more than the work in them — classes and scan in one launch
-// of one workgroup, blocks and chain in another; the tables keep their own (they want the whole chip).
+// of one workgroup (the per-gap words stay in LDS between the two), blocks and chain in another; the tables keep
+// their own (they want the whole chip).
+#define D3_FRONT_GAPS 3072u
 __global__ __launch_bounds__(1024) void g2s_d3_front(const D3Params P, const D3Work W, const GapOut* __restrict__ outs,
                                                      const D3Gap* __restrict__ dgaps) {
-  __shared__ uint64_t sh64[34];
-  __shared__ uint32_t sh32[17];
+  __shared__ uint64_t sh[96];
+  __shared__ unsigned long long red[16 * 8];
   __shared__ uint32_t sh_f[1024];
-  d3_classify_body(P, W, outs, dgaps, threadIdx.x, 1024u);
-  __threadfence();
+  __shared__ uint32_t l_gi[D3_FRONT_GAPS], l_dm[D3_FRONT_GAPS], l_ds[D3_FRONT_GAPS];
+  __shared__ int32_t l_sk[D3_FRONT_GAPS];
+  if (threadIdx.x == 0) stamp(W, 0);
+  const uint32_t unhandled = d3_classify_body(P, W, outs, dgaps, threadIdx.x, 1024u, l_gi, l_dm, l_ds, l_sk, red, true);
   __syncthreads();
-  d3_scan_body(P, W, dgaps, sh64, sh32, sh_f);
+  if (threadIdx.x == 0) stamp(W, 1);
+  d3_scan_body(P, W, outs, l_gi, l_dm, l_ds, l_sk, true, unhandled, sh, sh_f);
+  if (threadIdx.x == 0) stamp(W, 2);
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// hand-off: the gaps whose closure the host analyses (GI_HOST) get their record, closure segments and the rand()
-// values of their traceback copied into pinned memory — in front of the trace kernel, so that the host
-// finishes them while that kernel runs.  One wave per 64 gaps of the list.
+// hand-off: every gap's first draw and draw count, with what else the trace kernel needs of it, in one record
+// (D3Trace); the gaps whose closure the host analyses (GI_HOST) get their record, closure segments and the rand()
+// values of their traceback copied into pinned memory — in front of the trace kernel, so that the host finishes
+// them while that kernel runs.  One wave per 64 gaps of the list.
 // ---------------------------------------------------------------------------------------------------------
-// (the body: one wave, the 64 gaps from i0 on; true when it handed something over)
+// (the body: one wave, the 64 gaps from i0 on; true when it handed something over.  ldvar/ltab/ltoff: the
+// deviations, tables and table offsets in LDS when the caller holds them there, else null; lcur: the three cursors
+// of the side buffers in LDS when one workgroup hands the whole list over, else null — the summary's are used)
 __device__ __forceinline__ bool d3_handoff_body(const D3Params& P, const D3Work& W, const GapOut* __restrict__ outs,
                                                 const SubRec* __restrict__ sub, const uint32_t* __restrict__ rnd, uint64_t capacity,
-                                                const g2s::D3Side& side, uint32_t i0) {
+                                                const g2s::D3Side& side, uint32_t i0, const uint32_t* ldvar, const uint16_t* ltab,
+                                                const uint32_t* ltoff, unsigned long long* lcur) {
   D3Summary* S = W.sum;
   const int lane = (int)(threadIdx.x & 63u);
   const uint32_t mine = i0 + (uint32_t)lane;
-  const bool host = mine < P.n && (W.ginfo[mine] & GI_HOST) != 0u;
-  for (uint64_t m = __ballot(host); m; m &= m - 1) {
-    const uint32_t i = i0 + (uint32_t)__builtin_ctzll(m);
-    const uint32_t gi = W.ginfo[i];
+  const bool have = mine < P.n;
+  uint32_t gi = 0, my_off = 0, my_want = 0, my_ns = 0;
+  uint64_t my_sub = 0;
+  if (have) {
+    gi = W.ginfo[mine];
+    const uint32_t vr = W.vrank[mine], base = W.base[mine], dmin = W.dmin[mine];
+    const GapOut& go = outs[mine];
+    my_ns = go.n_xl;
+    my_sub = (uint64_t)(mine / P.group_size) * P.sub_region + go.sub_off;
+    const uint32_t dv = ldvar ? ldvar[vr] : W.dvar[vr];
+    my_off = base + dv;
+    my_want = dmin;
+    if (GI_CLASS(gi) == 2u) my_want += ltab ? (uint32_t)ltab[ltoff[vr] + dv] : (uint32_t)W.tab[(uint64_t)W.var_toff[vr] + dv];
+    // the half of the trace kernel's record that depends on the offsets (the classes wrote the other)
+    ((uint4*)&W.tdesc[mine])[1] = make_uint4(gi, my_off, my_want, (gi >> 16) | (min(my_ns, 0xFFFFu) << 16));
+  }
+  const bool host = have && (gi & GI_HOST) != 0u;
+  const uint64_t hm = __ballot(host);
+  for (uint64_t m = hm; m; m &= m - 1) {
+    const int l = __builtin_ctzll(m);
+    const uint32_t i = i0 + (uint32_t)l;
     const GapOut& go = outs[i];
-    const uint32_t vr = W.vrank[i];
-    const uint32_t off = W.base[i] + W.dvar[vr];
-    const uint32_t want = W.dmin[i] + (GI_CLASS(gi) == 2u ? (uint32_t)W.tab[(uint64_t)W.var_toff[vr] + W.dvar[vr]] : 0u);
-    const uint32_t ns = go.n_xl;
+    const uint32_t off = (uint32_t)__shfl((int)my_off, l), want = (uint32_t)__shfl((int)my_want, l), ns = (uint32_t)__shfl((int)my_ns, l);
+    const uint64_t sub_at = ((uint64_t)(uint32_t)__shfl((int)(my_sub >> 32), l) << 32) | (uint32_t)__shfl((int)(uint32_t)my_sub, l);
     unsigned long long it = 0, so = 0, ro = 0;
     if (lane == 0) {
-      it = atomicAdd(&S->host_items, 1ull);
-      so = atomicAdd(&S->host_segs, (unsigned long long)ns);
-      ro = atomicAdd(&S->host_rnd, (unsigned long long)want + 1ull);
+      if (lcur) {
+        it = atomicAdd(&lcur[0], 1ull); so = atomicAdd(&lcur[1], (unsigned long long)ns); ro = atomicAdd(&lcur[2], (unsigned long long)want + 1ull);
+      } else {
+        it = atomicAdd(&S->host_items, 1ull);
+        so = atomicAdd(&S->host_segs, (unsigned long long)ns);
+        ro = atomicAdd(&S->host_rnd, (unsigned long long)want + 1ull);
+      }
     }
     it = __shfl(it, 0); so = __shfl(so, 0); ro = __shfl(ro, 0);
     if (it >= side.cap_items || so + ns > side.cap_segs || ro + want + 1ull > side.cap_rnd || (uint64_t)off + want + 1ull > capacity) {
@@ -592,7 +684,7 @@ __device__ __forceinline__ bool d3_handoff_body(const D3Params& P, const D3Work&
       continue;
     }
     if ((uint32_t)lane < sizeof(GapOut) / 4u) ((uint32_t*)&side.outs[it])[lane] = ((const uint32_t*)&go)[lane];
-    const uint4* src = (const uint4*)(sub_of(P, sub, i) + go.sub_off);
+    const uint4* src = (const uint4*)(sub + sub_at);
     uint4* dst = (uint4*)(side.segs + so);
     for (uint32_t w = (uint32_t)lane; w < 2u * ns; w += 64u) dst[w] = src[w];
     for (uint32_t w = (uint32_t)lane; w < want + 1u; w += 64u) side.rnd[ro + w] = rnd[off + w];
@@ -602,67 +694,162 @@ __device__ __forceinline__ bool d3_handoff_body(const D3Params& P, const D3Work&
       side.items[it] = h;
     }
   }
-  return __ballot(host) != 0ull;
+  return hm != 0ull;
 }
+// (*side.count is ~0 until the hand-over is complete: the host polls it.  Bit 63: something did not fit, or the
+// list is not finished on the device at all.)
 __global__ __launch_bounds__(64) void g2s_d3_handoff(const D3Params P, const D3Work W, const GapOut* __restrict__ outs,
-                                                     const SubRec* __restrict__ sub, const uint32_t* __restrict__ rnd,
-                                                     uint64_t capacity, const g2s::D3Side side) {
+                                                     const SubRec* __restrict__ sub, const uint32_t* __restrict__ rnd, uint64_t capacity,
+                                                     const g2s::D3Side side) {
   D3Summary* S = W.sum;
-  if (S->status) return;
-  // the number of items, where the host reads it once this kernel's event has fired
-  if (d3_handoff_body(P, W, outs, sub, rnd, capacity, side, blockIdx.x * 64u)) __threadfence_system();
+  const bool dead = S->status != 0u;
+  if (!dead && d3_handoff_body(P, W, outs, sub, rnd, capacity, side, blockIdx.x * 64u, nullptr, nullptr, nullptr, nullptr)) __threadfence_system();
   if ((threadIdx.x & 63u) == 0u) {
     const unsigned int done = atomicAdd(&S->handoff_waves, 1u) + 1u;
     if (done == gridDim.x) {
       __threadfence_system();
-      *side.count = (unsigned long long)S->host_items | ((unsigned long long)(S->anomalies ? 1u : 0u) << 63);
+      const unsigned long long items = atomicAdd(&S->host_items, 0ull);
+      const uint32_t anomalies = atomicAdd(&S->anomalies, 0u);
+      __hip_atomic_store(side.count, (items & 0x7FFFFFFFFFFFFFFFull) | ((unsigned long long)((anomalies || dead) ? 1u : 0u) << 63),
+                         __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 }
-// (short lists: blocks, chain and the hand-off in one launch of one workgroup)
+// Short lists: blocks, chain and the hand-off in one launch of one workgroup.  When the tables are small (a 500-gap
+// list: a thousand entries) they come into LDS in one pass and one lane walks the chain there — a chain of loads
+// from LDS instead of two passes of 16 dependent loads from memory.
+#define D3_BACK_TAB 24576u
 __global__ __launch_bounds__(1024) void g2s_d3_back(const D3Params P, const D3Work W, const GapOut* __restrict__ outs,
                                                     const SubRec* __restrict__ sub, const uint32_t* __restrict__ Wd, uint64_t capacity,
                                                     const g2s::D3Side side) {
   __shared__ uint32_t total_dev;
-  if (W.sum->status) return;
-  d3_blocks_body(W, threadIdx.x, 1024u);
-  __threadfence();
-  __syncthreads();
-  d3_chain_body(W, Wd, &total_dev);
-  __threadfence();
-  __syncthreads();
+  __shared__ unsigned long long lcur[3];
+  if (threadIdx.x < 3u) lcur[threadIdx.x] = 0ull;
+  __shared__ uint16_t ltab[D3_BACK_TAB];
+  __shared__ uint32_t ltoff[1025], ldvar[1025];
+  D3Summary* S = W.sum;
+  if (threadIdx.x == 0) stamp(W, 8);
+  const uint32_t status = S->status, V = S->n_var;
+  const uint64_t T = S->table_entries;
+  if (status) {
+    if (threadIdx.x == 0) __hip_atomic_store(side.count, 1ull << 63, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    return;
+  }
+  const bool in_lds = T <= (uint64_t)D3_BACK_TAB && V <= 1024u;
+  if (in_lds) {
+    for (uint32_t e = threadIdx.x; e < (uint32_t)T; e += 1024u) ltab[e] = W.tab[e];
+    if (threadIdx.x <= V) ltoff[threadIdx.x] = W.var_toff[threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      stamp(W, 9);
+      uint32_t d = 0;
+      for (uint32_t v = 0; v < V; v++) { ldvar[v] = d; d += ltab[ltoff[v] + d]; }
+      ldvar[V] = d;
+      total_dev = d;
+    }
+    __syncthreads();
+    if (threadIdx.x <= V) W.dvar[threadIdx.x] = ldvar[threadIdx.x];
+    const uint64_t total = S->draws_min + total_dev;
+    if (threadIdx.x == 0) S->draws_total = total;
+    if (threadIdx.x < 31u) S->rand_state[threadIdx.x] = Wd[total + threadIdx.x];
+  } else {
+    d3_blocks_body(W, threadIdx.x, 1024u);
+    __threadfence();
+    __syncthreads();
+    d3_chain_body(W, Wd, &total_dev);
+    __threadfence();
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) stamp(W, 10);
   bool any = false;
-  for (uint32_t i0 = (threadIdx.x >> 6) * 64u; i0 < P.n; i0 += 1024u) any |= d3_handoff_body(P, W, outs, sub, Wd + 31, capacity, side, i0);
+  for (uint32_t i0 = (threadIdx.x >> 6) * 64u; i0 < P.n; i0 += 1024u)
+    any |= d3_handoff_body(P, W, outs, sub, Wd + 31, capacity, side, i0, in_lds ? ldvar : nullptr, in_lds ? ltab : nullptr,
+                           in_lds ? ltoff : nullptr, lcur);
   if (any) __threadfence_system();
   __syncthreads();
   if (threadIdx.x == 0) {
+    stamp(W, 11);
     __threadfence_system();
-    *side.count = (unsigned long long)W.sum->host_items | ((unsigned long long)(W.sum->anomalies ? 1u : 0u) << 63);
+    const unsigned long long items = lcur[0];
+    S->host_items = items; S->host_segs = lcur[1]; S->host_rnd = lcur[2];
+    const uint32_t anomalies = atomicAdd(&S->anomalies, 0u);
+    __hip_atomic_store(side.count, (items & 0x7FFFFFFFFFFFFFFFull) | ((unsigned long long)(anomalies ? 1u : 0u) << 63), __ATOMIC_RELEASE,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+    stamp(W, 12);
   }
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // the tracebacks: one wave per gap.  Writes g2s_result[i] in full and the gap's fill text.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void g2s_d3_trace(const D3Params P, const D3Work W, const GapDev* __restrict__ gaps,
-                                                   const GapOut* __restrict__ outs, const D3Gap* __restrict__ dgaps,
+// (its first loads — the gap's D3Trace record, its GapOut record, the list's status — do not depend on each other;
+// the closure and the first rand() value follow from the D3Trace record: two round trips in front of the walk)
+__global__ __launch_bounds__(64) void g2s_d3_trace(const D3Params P, const D3Work W, const GapOut* __restrict__ outs,
                                                    const SubRec* __restrict__ sub, const char* __restrict__ chu,
                                                    const char* __restrict__ chd, const uint32_t* __restrict__ rnd,
                                                    uint64_t capacity, g2s_result* __restrict__ results,
-                                                   char* __restrict__ arena) {
+                                                   char* __restrict__ arena, uint32_t* __restrict__ summary_host) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   D3Summary* S = W.sum;
-  if (S->status) return;
   const uint32_t i = blockIdx.x;
   const int lane = (int)threadIdx.x;
   SegW* segs = (SegW*)lds;  // the gap's closure segments
   static_assert(sizeof(g2s_result) == 192, "g2s_result layout");
-  const D3Gap dg = dgaps[i];
-  const uint32_t gi = W.ginfo[i];
-  const uint64_t abs_off = P.arena_base + dg.arena_off;
+  unsigned long long* laps = (unsigned long long*)((char*)W.sum + 512);
+  const unsigned long long tk0 = P.laps ? wall_clock64() : 0ull;
+  unsigned long long tk1 = 0, tk2 = 0, tk3 = 0, hops = 0, tkm = 0;
+  if (P.laps && i == 0 && lane == 0) laps[13] = tk0;
+  const uint32_t status = uni(S->status);
+  // (every lane loads the same words: handed to the scalar unit, so that the walk below is scalar code)
+  g2s::D3Trace td;
+  {
+    const uint4 h0 = ((const uint4*)&W.tdesc[i])[0], h1 = ((const uint4*)&W.tdesc[i])[1];
+    td.arena_off = (uint64_t)uni(h0.x) | ((uint64_t)uni(h0.y) << 32);
+    td.sub_at = (uint64_t)uni(h0.z) | ((uint64_t)uni(h0.w) << 32);
+    td.gi = uni(h1.x); td.off = uni(h1.y); td.want = uni(h1.z);
+    td.lmf = (uint16_t)(uni(h1.w) & 0xFFFFu); td.nsegs = (uint16_t)(uni(h1.w) >> 16);
+  }
+  struct {
+    uint32_t flags, dflags, start_seg, start_t, sub_vertices, sub_edges;
+    int32_t c_count, n_len, len[2], reached_j, count_s;
+  } go;
+  {
+    const GapOut& g = outs[i];
+    go.flags = uni(g.flags); go.dflags = uni(g.dflags); go.start_seg = uni(g.start_seg); go.start_t = uni(g.start_t);
+    go.sub_vertices = uni(g.sub_vertices); go.sub_edges = uni(g.sub_edges);
+    go.c_count = (int32_t)uni((uint32_t)g.c_count); go.n_len = (int32_t)uni((uint32_t)g.n_len);
+    go.len[0] = (int32_t)uni((uint32_t)g.len[0]); go.len[1] = (int32_t)uni((uint32_t)g.len[1]);
+    go.reached_j = (int32_t)uni((uint32_t)g.reached_j); go.count_s = (int32_t)uni((uint32_t)g.count_s);
+  }
+  // The wave that is through last copies the summary and the fill-byte counters to the host's pinned memory (a copy
+  // command behind the kernel costs the stream a barrier).  Who is last: the fill-byte counter of the wave's residue
+  // modulo 64 also counts its waves (bits 40 and up — one addition for both; one counter for all waves would have
+  // 10 000 of them queue at one address), the wave that completes a residue adds to the summary's counter, the one
+  // that completes that copies.  Counters other waves add to are read at the L2.
+  auto leave = [&](uint32_t fill_len) {
+    uint32_t last = 0;
+    if (lane == 0) {
+      if (P.laps) {  // (the longest wave's laps: entry to closure in LDS, the walk, the bases, all of it; the latest end)
+        const unsigned long long tk4 = wall_clock64();
+        atomicMax(&laps[14], tk1 ? tk1 - tk0 : 0ull); atomicMax(&laps[15], tk2 ? tk2 - tk1 : 0ull);
+        atomicMax(&laps[16], tk3 ? tk3 - tk2 : 0ull); atomicMax(&laps[17], tk4 - tk0); atomicMax(&laps[18], tk4);
+        atomicMax(&laps[19], ((tk2 ? tk2 - tk1 : 0ull) << 32) | (hops << 16) | (tkm ? tkm - tk1 : 0ull));
+      }
+      const uint32_t c = i & 63u, n = gridDim.x;
+      const unsigned long long before = atomicAdd(&W.fill_bytes[c * 16u], (unsigned long long)fill_len | (1ull << 40));
+      if ((uint32_t)(before >> 40) + 1u == (n + 63u - c) / 64u) last = atomicAdd(&S->trace_waves, 1u) + 1u == min(n, 64u) ? 1u : 0u;
+    }
+    if (!uni(last)) return;
+    uint32_t* src = (uint32_t*)S;
+    for (uint32_t w = (uint32_t)lane; w < (1024u + 64u * 128u) / 4u; w += 64u)
+      summary_host[w] = __hip_atomic_load(src + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  if (status) { leave(0u); return; }  // (the records in front of this kernel were not written: nothing below may run)
+  const uint32_t gi = td.gi;
+  struct { uint16_t lmf; } dg = {td.lmf};
+  const uint64_t abs_off = td.arena_off;
   char* buf = arena + abs_off;
   const int k = P.k;
-  (void)gaps;
   // the record, words 0-23 of g2s_result (count, left_fuz, right_fuz, flags, fill_off, fill_len, draws, six 64-bit
   // subgraph statistics, phaseC_count, n_lengths, lengths[2]); backtrace_msg (words 24-47) becomes the empty string
   uint32_t rw[24];
@@ -686,16 +873,16 @@ __global__ __launch_bounds__(64) void g2s_d3_trace(const D3Params P, const D3Wor
     if (gi & GI_MEM) rw[0] = (uint32_t)-1;
     if (lane == 0) buf[dg.lmf] = '\0';
     finish(0u);
+    leave(0u);
     return;
   }
-  const GapOut& go = outs[i];
   const bool phase_d = (gi & GI_PHASE_D) != 0;
   rw[20] = (uint32_t)go.c_count;
   rw[21] = (uint32_t)go.n_len;
   rw[22] = (uint32_t)go.len[0];
   rw[23] = (uint32_t)go.len[1];
   rw[3] = (go.flags & (G2S_DEV_Q7_A | G2S_DEV_Q7_B | G2S_DEV_Q7_D)) ? G2S_GAP_Q7 : 0u;
-  rw[0] = (uint32_t)gap_count(go, P, phase_d);
+  rw[0] = (uint32_t)((phase_d && !P.skip_confident && P.all_paths) ? go.count_s : go.c_count);  // pp.count of the host analysis
   if (phase_d && !P.skip_confident) {
     rw[8] = go.sub_vertices; rw[10] = go.sub_edges;    // vertices, edges (nothing contracted: no non-trivial component)
     rw[16] = go.sub_vertices; rw[18] = go.sub_edges;   // vertices_final, edges_final
@@ -703,155 +890,194 @@ __global__ __launch_bounds__(64) void g2s_d3_trace(const D3Params P, const D3Wor
   if (!phase_d) {
     if (lane == 0) buf[dg.lmf] = '\0';
     finish(0u);
+    leave(0u);
     return;
   }
-  if (gi & GI_HOST) return;  // (g2s_d3_handoff gave it to the host, which writes its record and text)
+  if (gi & GI_HOST) { leave(0u); return; }  // (g2s_d3_handoff gave it to the host, which writes its record and text)
   // ---- the closure into LDS
-  const uint32_t nsegs = go.n_xl;
-  const bool in_lds = nsegs <= P.seg_cap;
-  const SegW* gsegs = (const SegW*)(sub_of(P, sub, i) + go.sub_off);
+  // (closures the device analysed have at most seg_cap segments; a longer one would be the host path's business)
+  const uint32_t nsegs = min((uint32_t)td.nsegs, P.seg_cap);
+  const SegW* gsegs = (const SegW*)(sub + td.sub_at);
   uint32_t* cmap = lds + (size_t)P.seg_cap * 8u;  // by fill-buffer index: k-mer index | orientation << 30 | lower case << 31
-  if (in_lds) {
+  // the rand() values of this traceback, into LDS together with the closure: the walk asks for one at every choice
+  // between parents, and each was a round trip to memory in the middle of it (30 us for the longest of 500 walks)
+  uint32_t* lwin = cmap + P.map_cap;
+  const uint32_t nwin = min(td.want, P.map_cap);
+  for (uint32_t x = (uint32_t)lane; x < nwin; x += 64u) lwin[x] = (uint64_t)td.off + x < capacity ? rnd[td.off + x] : 0u;
+  {
     const uint4* src = (const uint4*)gsegs;
     uint4* dst = (uint4*)segs;
     for (uint32_t w = (uint32_t)lane; w < 2u * nsegs; w += 64u) dst[w] = src[w];
   }
   __syncthreads();
-  auto seg_at = [&](uint32_t q) -> SegW { return in_lds ? segs[q] : gsegs[q]; };
-  auto seg_uni = [&](uint32_t q) -> SegW {  // (the walk is the same in every lane: scalar registers)
-    const SegW x = seg_at(q);
-    SegW u;
-    u.node = uni(x.node); u.depth_len = uni(x.depth_len); u.cnt = 0u; u.ts_tt = uni(x.ts_tt);
-    u.par01 = uni(x.par01); u.par23 = uni(x.par23); u.flags = uni(x.flags); u.pad = uni(x.pad);
-    return u;
-  };
+  if (P.laps) tk1 = wall_clock64();
   // the branch rule's verdict for a k-mer that is not in the subgraph at this depth: at another depth, or the
-  // sink's (Q5) — post.cpp: seg_safe
+  // sink's (Q5) — post.cpp: seg_safe.  (Asked by single lanes, for the few states of a traceback closure that are
+  // on no path to a sink: the first segment in emission order that holds the k-mer decides.)
   const bool sink_safe = (go.dflags & G2S_DEVA_SINK_SAFE) != 0;
   auto outside_safe = [&](uint32_t x) -> bool {
-    for (uint32_t q0 = 0; q0 < nsegs; q0 += 64u) {
-      const uint32_t q = q0 + (uint32_t)lane;
-      bool hit = false, verdict = false;
-      if (q < nsegs) {
-        const SegW o = seg_at(q);
-        const int ts = (o.ts_tt & 0x7FFFu) == 0x7FFFu ? -1 : (int)(o.ts_tt & 0x7FFFu);
-        const uint32_t oidx = o.node >> 1;
-        const int tq = (o.node & 1u) ? (int)oidx - (int)x : (int)x - (int)oidx;
-        hit = tq >= 0 && tq <= ts;
-        verdict = tq <= (int)o.pad ? (o.ts_tt & 0x8000u) != 0 : (o.ts_tt & 0x80000000u) != 0;
-      }
-      const uint64_t hm = __ballot(hit);
-      if (hm) return ((__ballot(hit && verdict) >> __builtin_ctzll(hm)) & 1ull) != 0;
+    for (uint32_t q = 0; q < nsegs; q++) {
+      const uint32_t onode = segs[q].node, ots = segs[q].ts_tt;
+      const int ts = (ots & 0x7FFFu) == 0x7FFFu ? -1 : (int)(ots & 0x7FFFu);
+      const uint32_t oidx = onode >> 1;
+      const int tq = (onode & 1u) ? (int)oidx - (int)x : (int)x - (int)oidx;
+      if (tq >= 0 && tq <= ts) return tq <= (int)segs[q].pad ? (ots & 0x8000u) != 0 : (ots & 0x80000000u) != 0;
     }
     return sink_safe;
   };
-  // ---- the walk (wave-uniform).  It touches LDS only (and the rand() values at the choices): where every base of
-  // the fill comes from — k-mer index, orientation, case — goes into cmap; the bases themselves are fetched
-  // afterwards, all lanes at once and several loads in flight (a load and a dependent store per run of bases
-  // inside the walk made the wave wait a memory round trip per segment).
-  const uint32_t vr = W.vrank[i];
-  const uint32_t off = W.base[i] + W.dvar[vr];
-  const uint32_t* rd = rnd + off;
-  const uint64_t avail = capacity > off ? capacity - off : 0ull;
-  const int want = (int)W.dmin[i] + (GI_CLASS(gi) == 2u ? (int)W.tab[(uint64_t)W.var_toff[vr] + W.dvar[vr]] : 0);
+  // ---- the walk, in two parts.  (i) Wave-uniform and as short as it can be: which segments the traceback enters,
+  // and at which state — per segment one read of its links from LDS and, where it has several parents, of a rand()
+  // value.  (ii) All lanes: where every base of the fill comes from — k-mer index, orientation, safe bit — into
+  // cmap, a lane per stretch of consecutive depths; then upper or lower case (:1466-1468: lower case = not safe
+  // and k or more below the nearest safe base above) as a scan over the safe bits.  (One pass that did both per
+  // segment took the longest of 500 walks 25 us — 38 segments at 1 500 cycles of dependent scalar work each;
+  // the bases themselves are fetched afterwards, all lanes at once and several loads in flight.)
+  const uint32_t off = td.off;
+  const uint64_t avail = min((uint64_t)nwin, capacity > off ? capacity - off : 0ull);  // (values the walk can read: in LDS)
+  const int want = (int)td.want;
   const int n_len = go.n_len, len0 = go.len[0], len1 = go.len[1];
   int draws = 1;
-  const int pick = (n_len > 1 && avail > 0) ? (int)((uni(rd[0]) >> 1) % (uint32_t)n_len) : 0;  // :1440
+  auto value = [&](uint32_t x) -> uint32_t { return uni(lwin[x]); };
+  const int pick = (n_len > 1 && avail > 0) ? (int)((value(0) >> 1) & 1u) : 0;  // :1440 (n_len <= 2)
   int d2 = pick ? len1 : len0;
   const int len = d2;
-  int last_solid = d2;
   bool bad = false, ended = false;
-  if ((uint32_t)len + 1u > P.map_cap) bad = true;
+  if ((uint32_t)len + 1u > P.map_cap || (uint32_t)td.nsegs > P.seg_cap || td.want > P.map_cap) bad = true;
+  uint32_t* hop_top = lwin + P.map_cap;     // by hop: the depth at which the walk enters the segment (descending)
+  uint32_t* hop_rec = hop_top + P.seg_cap;  // the segment | its entry state << 16
+  uint32_t* nxt = hop_rec + P.seg_cap;      // by segment: the parent a traceback goes on to from its first state
+  // (Every traced base draws one value — :1513 draws for a single parent too — so the draw made at depth d is the
+  // (1 + len - d)-th of the gap whatever the path: the parent a traceback takes from a segment's first state is a
+  // property of the segment.  All lanes work those out; the walk itself then reads three words per segment.)
+  for (uint32_t q = (uint32_t)lane; q < nsegs; q += 64u) {
+    const uint32_t dl = segs[q].depth_len, p01 = segs[q].par01, p23 = segs[q].par23, fl = segs[q].flags;
+    const int d0 = (int)(dl & 0xFFFFu);
+    const int nb = seg_nparents(p01, p23);
+    const int64_t at = 1 + (int64_t)len - d0;  // draws in front of the one made at this segment's first state
+    uint32_t w;
+    if (nb == 0 || (nb > 1 && !(fl & G2S_SEG_ORDERED)) || at < 1 || (uint64_t)at >= avail) w = 0x80000000u;  // (:1493-1510: the host path's business)
+    else {
+      const uint32_t rv = nb > 1 ? lwin[at] >> 1 : 0u;  // (rand() % 1: the value does not matter)
+      w = seg_parent(p01, p23, nb == 1 ? 0 : pick_parent(rv, nb));  // :1513
+      if (w >= nsegs) w = 0x80000000u;
+    }
+    nxt[q] = w;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  int nh = 0;
   {
     const uint32_t sg = (go.start_seg >> (16 * pick)) & 0xFFFFu;
     int si = sg == 0xFFFFu ? -1 : (int)sg;
     int t = (int)((go.start_t >> (16 * pick)) & 0xFFFFu);
     if (si < 0 || si >= (int)nsegs || avail < 1) bad = true;
     for (int guard = 0; !bad && d2 >= 0; guard++) {
-      if (guard > 70000) { bad = true; break; }
-      const SegW s = seg_uni((uint32_t)si);
-      const int d0 = (int)(s.depth_len & 0xFFFFu);
-      const uint32_t idx0 = s.node >> 1;
-      const bool up = (s.node & 1u) == 0u;
-      const uint32_t obit = up ? 0u : 0x40000000u;
-      if (d0 + t != d2) { bad = true; break; }  // (state t of a segment that begins at depth d0 sits at depth d0 + t)
-      if (t > 0) {
-        // the states t, t-1, ..., 1 of this segment, in runs that share their safe bit (:1466-1468)
-        const int ts = (s.ts_tt & 0x7FFFu) == 0x7FFFu ? -1 : (int)(s.ts_tt & 0x7FFFu);
-        const int split = P.skip_confident ? t : (int)s.pad;
-        const bool sfa = (s.ts_tt & 0x8000u) != 0, sfb = (s.ts_tt & 0x80000000u) != 0;
-        int pos = t;
-        while (pos > 0) {
-          int lo_run;
-          bool sf;
-          if (P.skip_confident) { lo_run = 1; sf = true; }
-          else if (pos > ts) { lo_run = pos; sf = outside_safe(up ? idx0 + (uint32_t)pos : idx0 - (uint32_t)pos); }
-          else if (pos > split) { lo_run = max(1, split + 1); sf = sfb; }
-          else { lo_run = 1; sf = sfa; }
-          const int cnt = pos - lo_run + 1;
-          const int qmax = sf ? -1 : min(pos, last_solid - k - d0);  // lower case unless within k of the last safe base
-          for (int c = lane; c < cnt; c += 64) {
-            const int q = lo_run + c;
-            cmap[d0 + q - 1] = (up ? idx0 + (uint32_t)q : idx0 - (uint32_t)q) | obit | (q <= qmax ? 0x80000000u : 0u);
-          }
-          if (sf) last_solid = d0 + lo_run;
-          pos = lo_run - 1;
-        }
-        draws += t;
-        d2 -= t;
-        t = 0;
-      }
-      if (s.flags & G2S_SUB_SOURCE) { left_fuz = (int)dg.lmf - d2; ended = true; break; }  // :1455-1462
+      if (P.laps) hops++;
+      const uint32_t dl = uni(segs[si].depth_len), fl = uni(segs[si].flags), nx = uni(nxt[si]);
+      const int d0 = (int)(dl & 0xFFFFu);
+      if (guard > 0) t = (int)(dl >> 16) - 1;  // (a child in the closure puts the whole parent there)
+      if (d0 + t != d2 || nh >= (int)P.seg_cap) { bad = true; break; }  // (state t of a segment that begins at depth d0 sits at depth d0 + t)
+      if (lane == 0) { hop_top[nh] = (uint32_t)d2; hop_rec[nh] = (uint32_t)si | ((uint32_t)t << 16); }
+      nh++;
+      draws += t;
+      d2 -= t;
+      if (fl & G2S_SUB_SOURCE) { left_fuz = (int)dg.lmf - d2; ended = true; break; }  // :1455-1462
       if (d2 > 0) {
-        bool safe0;
-        if (P.skip_confident) safe0 = true;
-        else if ((s.ts_tt & 0x7FFFu) != 0x7FFFu) safe0 = (s.ts_tt & 0x8000u) != 0;  // state 0 of an S segment: safe bit a
-        else safe0 = outside_safe(idx0);
-        if (safe0) last_solid = d2;
-        if (lane == 0) cmap[d2 - 1] = idx0 | obit | (d2 > last_solid - k ? 0u : 0x80000000u);
-        const int nb = seg_nparents(s.par01, s.par23);
-        if (nb == 0 || (nb > 1 && !(s.flags & G2S_SEG_ORDERED)) || (uint64_t)draws >= avail) { bad = true; break; }  // (:1493-1510: the host path's business)
-        const uint32_t rv = nb > 1 ? uni(rd[draws]) >> 1 : 0u;  // (rand() % 1: the value does not matter)
+        if (nx & 0x80000000u) { bad = true; break; }
         draws++;
-        si = (int)seg_parent(s.par01, s.par23, nb == 1 ? 0 : (int)(rv % (uint32_t)nb));  // :1513
-        if (si >= (int)nsegs) { bad = true; break; }
-        t = (int)(uni(seg_at((uint32_t)si).depth_len) >> 16) - 1;  // a child in the closure puts the whole parent there
+        si = (int)nx;
       }
       d2--;
     }
   }
   if (!ended || draws != want) bad = true;
-  if (bad) { if (lane == 0) atomicAdd(&S->anomalies, 1u); }
+  if (P.laps) tkm = wall_clock64();
+  if (!bad) {
+    const int stop0 = (int)dg.lmf - left_fuz;  // the fill takes depths stop0 + 1 .. len (cmap index = depth - 1)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    const int npos = max(0, len - stop0), per = (npos + 63) / 64;
+    // lane l: depths (hi_d - cnt, hi_d], from the top of the fill downwards in lane order
+    const int hi_d = len - lane * per, cnt = max(0, min(per, hi_d - stop0));
+    int lowest_safe = 0x7FFFFFFF;
+    if (cnt > 0) {
+      int lo = 0, hi = nh;  // the last hop entered at or above hi_d
+      while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int)hop_top[mid] >= hi_d) lo = mid; else hi = mid; }
+      int h = lo;
+      uint32_t rec = hop_rec[h];
+      int top = (int)hop_top[h], d0 = top - (int)(rec >> 16);
+      SegW sg = segs[rec & 0xFFFFu];
+      for (int c = 0; c < cnt; c++) {
+        const int p = hi_d - c;
+        if (p < d0) {  // the next hop begins right below
+          h++;
+          rec = hop_rec[h];
+          top = (int)hop_top[h]; d0 = top - (int)(rec >> 16);
+          sg = segs[rec & 0xFFFFu];
+        }
+        const int q = p - d0;
+        const uint32_t idx0 = sg.node >> 1;
+        const bool up = (sg.node & 1u) == 0u;
+        const uint32_t x = up ? idx0 + (uint32_t)q : idx0 - (uint32_t)q;
+        const int ts = (sg.ts_tt & 0x7FFFu) == 0x7FFFu ? -1 : (int)(sg.ts_tt & 0x7FFFu);
+        bool sf;
+        if (P.skip_confident) sf = true;
+        else if (q > ts) sf = outside_safe(x);
+        else if (q > (int)sg.pad) sf = (sg.ts_tt & 0x80000000u) != 0;  // beyond the split: safe bit b
+        else sf = (sg.ts_tt & 0x8000u) != 0;
+        if (sf) lowest_safe = p;
+        cmap[p - 1] = x | (up ? 0u : 0x40000000u) | (sf ? 0x20000000u : 0u);
+      }
+    }
+    // the nearest safe depth above each lane's stretch (the walk begins with the top of the fill counting as safe)
+    int above = lowest_safe;
+    for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(above, o); if (lane >= o) above = min(above, y); }
+    above = __shfl_up(above, 1);
+    if (lane == 0) above = 0x7FFFFFFF;
+    int last_solid = min(above, len);
+    for (int c = 0; c < cnt; c++) {
+      const int p = hi_d - c;
+      const uint32_t e = cmap[p - 1];
+      if (e & 0x20000000u) last_solid = p;
+      else if (p <= last_solid - k) cmap[p - 1] = e | 0x80000000u;
+    }
+  }
+  if (P.laps) tk2 = wall_clock64();
+  if (bad) {  // (acknowledged before this wave is counted as through)
+    if (lane == 0) atomicAdd(&S->anomalies, 1u);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
   const int stop = (int)dg.lmf - left_fuz;  // the fill begins at this index of the buffer
   const uint32_t fill_len = (!bad && len >= stop && stop >= 0) ? (uint32_t)(len - stop) : 0u;
   if (!bad) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    // ---- the bases: four loads in flight per lane
-    for (int p0 = stop; p0 < len; p0 += 256) {
-      uint32_t e[4];
-      char c[4];
+    // ---- the bases: eight loads in flight per lane (a 1 000-base fill: two round trips)
+    for (int p0 = stop; p0 < len; p0 += 512) {
+      uint32_t e[8];
+      char c[8];
 #pragma unroll
-      for (int u = 0; u < 4; u++) { const int p = p0 + 64 * u + lane; e[u] = p < len ? cmap[p] : 0u; }
+      for (int u = 0; u < 8; u++) { const int p = p0 + 64 * u + lane; e[u] = p < len ? cmap[p] : 0u; }
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
+      for (int u = 0; u < 8; u++) {
         const uint32_t x = e[u] & 0x0FFFFFFFu;
         c[u] = (e[u] & 0x40000000u) ? chd[x] : chu[x];
       }
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
+      for (int u = 0; u < 8; u++) {
         const int p = p0 + 64 * u + lane;
         if (p < len) buf[p] = (e[u] >> 31) ? (char)(c[u] | 0x20) : c[u];
       }
     }
     if (lane == 0) buf[len] = '\0';
   } else if (lane == 0) buf[dg.lmf] = '\0';
+  if (P.laps) tk3 = wall_clock64();
   rw[2] = (uint32_t)go.reached_j;  // :1171
   rw[3] |= G2S_GAP_PHASE_D;
   rw[7] = (uint32_t)draws;
   // (one counter for the whole list made 10 000 waves queue at one address of the L2: 64 counters, a cache line each)
-  if (lane == 0 && fill_len) atomicAdd((unsigned long long*)&W.fill_bytes[(i & 63u) * 16u], (unsigned long long)fill_len);
   finish(fill_len);
+  leave(fill_len);
 }
 
 }  // namespace
@@ -891,13 +1117,14 @@ void rand_tables_host(uint32_t* hi, uint32_t* mid, uint32_t* lane) {
 }
 
 size_t d3_work_bytes(uint32_t n) {
-  const size_t per = ((size_t)n + 64) * 4;
-  return 12 * per + 64 * 128 + (size_t)G2S_D3_TABLE_BUDGET * 2 + (size_t)(G2S_D3_TABLE_BUDGET / 4u) * 4 + 4096;
+  const size_t per = (((size_t)n + 64) * 4 + 63) & ~(size_t)63;
+  return 13 * per + 64 * 128 + (size_t)G2S_D3_TABLE_BUDGET * 2 + (size_t)(G2S_D3_TABLE_BUDGET / 4u) * 4 + 4096 +
+         ((size_t)n + 64) * (sizeof(D3Var) + sizeof(D3Trace)) + ((size_t)n + G2S_D3_TABLE_BUDGET / 256u + 64) * 4;
 }
 
 void d3_work_carve(void* p, uint32_t n, D3Work* w) {
   char* c = (char*)p;
-  const size_t per = ((size_t)n + 64) * 4;
+  const size_t per = (((size_t)n + 64) * 4 + 63) & ~(size_t)63;
   w->sum = (D3Summary*)c; c += 1024;
   w->fill_bytes = (unsigned long long*)c; c += 64 * 128;
   w->ginfo = (uint32_t*)c; c += per;
@@ -912,6 +1139,10 @@ void d3_work_carve(void* p, uint32_t n, D3Work* w) {
   w->blk_toff = (uint32_t*)c; c += per;
   w->blk_in = (uint32_t*)c; c += per;
   w->dvar = (uint32_t*)c; c += per;
+  w->skip = (int32_t*)c; c += per;
+  w->vdesc = (D3Var*)c; c += ((size_t)n + 64) * sizeof(D3Var);     // (c is a multiple of 64 here)
+  w->tdesc = (D3Trace*)c; c += ((size_t)n + 64) * sizeof(D3Trace);
+  w->tile_var = (uint32_t*)c; c += ((size_t)n + G2S_D3_TABLE_BUDGET / 256u + 64) * 4;
   w->btab = (uint32_t*)c; c += (size_t)(G2S_D3_TABLE_BUDGET / 4u) * 4;
   w->tab = (uint16_t*)c;
 }
@@ -925,36 +1156,38 @@ hipError_t launch_rand_fill(hipStream_t st, uint32_t* rnd_all, const RandTables&
 hipError_t launch_d3(hipStream_t st, const D3Params& P, const D3Work& W, const GapDev* gaps, const GapOut* outs,
                      const D3Gap* dgaps, const SubRec* sub, const char* lastch_up, const char* lastch_dn,
                      const RandTables& rt, uint32_t* rnd_all, uint64_t rnd_capacity, void* results, char* arena,
-                     const D3Side& side, hipEvent_t handed_over) {
+                     const D3Side& side, void* summary_host, bool summary_is_clean) {
   if (P.n == 0) return hipSuccess;
+  (void)gaps;
+  (void)rt;
   static_assert(sizeof(D3Summary) <= 1024, "summary slot");
-  // (the summary and, behind it, the 64 fill-byte counters of the trace kernel)
-  hipError_t e = hipMemsetAsync(W.sum, 0, 1024 + 64 * 128, st);
+  // (the summary and, behind it, the 64 fill-byte counters of the trace kernel: the caller zeroes them behind the
+  // previous list, off this one's critical path — a memset in front of the first kernel costs the stream 10-15 us)
+  hipError_t e = summary_is_clean ? hipSuccess : hipMemsetAsync(W.sum, 0, 1024 + 64 * 128, st);
   if (e != hipSuccess) return e;
-  const bool short_list = P.n <= 3072u;
+  const bool short_list = P.n <= D3_FRONT_GAPS;
   if (short_list) hipLaunchKernelGGL(g2s_d3_front, dim3(1), dim3(1024), 0, st, P, W, outs, dgaps);
   else {
     hipLaunchKernelGGL(g2s_d3_classify, dim3((P.n + 255u) / 256u), dim3(256), 0, st, P, W, outs, dgaps);
-    hipLaunchKernelGGL(g2s_d3_scan, dim3(1), dim3(1024), 0, st, P, W, dgaps);
+    hipLaunchKernelGGL(g2s_d3_scan, dim3(1), dim3(1024), 0, st, P, W, outs);
   }
   // (a tile of 256 deviations per workgroup, grid-stride: a short list has a few dozen tiles)
   const uint32_t tgrid = std::min(8192u, std::max(128u, P.n / 2u));
-  hipLaunchKernelGGL(g2s_d3_tables, dim3(tgrid), dim3(256), 0, st, P, W, outs, sub, rnd_all + 31, rnd_capacity);
+  const size_t win = ((size_t)P.map_cap + 256) * 4;
+  e = hipFuncSetAttribute((const void*)g2s_d3_tables, hipFuncAttributeMaxDynamicSharedMemorySize, (int)win);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(g2s_d3_tables, dim3(tgrid), dim3(256), win, st, P, W, sub, rnd_all + 31, rnd_capacity);
   if (short_list) hipLaunchKernelGGL(g2s_d3_back, dim3(1), dim3(1024), 0, st, P, W, outs, sub, rnd_all, rnd_capacity, side);
   else {
     hipLaunchKernelGGL(g2s_d3_blocks, dim3(256), dim3(256), 0, st, W);
     hipLaunchKernelGGL(g2s_d3_chain, dim3(1), dim3(1024), 0, st, W, rnd_all);
     hipLaunchKernelGGL(g2s_d3_handoff, dim3((P.n + 63u) / 64u), dim3(64), 0, st, P, W, outs, sub, rnd_all + 31, rnd_capacity, side);
   }
-  if (handed_over) {
-    e = hipEventRecord(handed_over, st);
-    if (e != hipSuccess) return e;
-  }
-  const size_t lds = (size_t)P.seg_cap * sizeof(SegRec) + (size_t)P.map_cap * 4 + 16;
+  const size_t lds = (size_t)P.seg_cap * (sizeof(SegRec) + 12) + (size_t)P.map_cap * 8 + 16;  // closure, base map, rand() values, the walk's segments
   e = hipFuncSetAttribute((const void*)g2s_d3_trace, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(g2s_d3_trace, dim3(P.n), dim3(64), lds, st, P, W, gaps, outs, dgaps, sub, lastch_up, lastch_dn,
-                     rnd_all + 31, rnd_capacity, (g2s_result*)results, arena);
+  hipLaunchKernelGGL(g2s_d3_trace, dim3(P.n), dim3(64), lds, st, P, W, outs, sub, lastch_up, lastch_dn, rnd_all + 31, rnd_capacity,
+                     (g2s_result*)results, arena, (uint32_t*)summary_host);
   return hipGetLastError();
 }
 

@@ -224,6 +224,8 @@ extern "C" uint64_t g2s_graph_device_bytes(const g2s_graph* g, int device) {
 // ---------------------------------------------------------------------------
 namespace {
 
+static inline void cpu_relax() { __builtin_ia32_pause(); }
+
 struct DevBuf {  // grow-only device allocation
   void* p = nullptr;
   size_t cap = 0;
@@ -544,7 +546,7 @@ struct g2s_session {
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   g2s_timing last_timing;        // of the last g2s_fill_batch / g2s_batch_run (g2s_session_last_timing)
   // resident mode (run_resident): closures, phase D3 work areas and the rand() stream stay on the device
-  DevBuf d_sub, d_d3, d_rnd, d_lastch, d_rtab, d_resout, d_textout;
+  DevBuf d_sub, d_d3, d_rnd, d_lastch, d_rtab, d_resout, d_textout, d_dgap;
   DevBuf d_outs_all, d_sub_all;  // lead of a team: the groups' records and closure records, gathered for phase D3
   PinBuf h_d3all;                // and the list's D3Gap array, summary and stream window
   PinBuf h_d3;                   // D3Gap per gap | summary | stream window; staging of results / text when the caller's are not pinned
@@ -553,6 +555,7 @@ struct g2s_session {
   std::vector<uint32_t> res_ids, res_at;  // launch order of a resident list and its counting sort, kept between lists
   bool in_team_list = false;     // the session is filling a group of a team's list (team_resident)
   bool team_shares_device = false;  // ... and another session of the team sits on the same device
+  uint32_t timed_seq = 0;        // resident launches so far (one in eight is bracketed with HIP events)
   int resident_strikes = 0;      // lists that had to be run again on the host path; three in a row switch the mode off
   bool resident_off = false;
 };
@@ -649,7 +652,7 @@ extern "C" void g2s_session_destroy(g2s_session* s) {
   s->h_gaps.release();
   for (int i = 0; i < 5; i++) if (s->ev[i]) (void)hipEventDestroy(s->ev[i]);
   s->d_outs_all.release(); s->d_sub_all.release(); s->h_d3all.release();
-  s->d_resout.release(); s->d_textout.release(); s->d_sub.release(); s->d_d3.release(); s->d_rnd.release(); s->d_lastch.release(); s->d_rtab.release();
+  s->d_resout.release(); s->d_textout.release(); s->d_dgap.release(); s->d_sub.release(); s->d_d3.release(); s->d_rnd.release(); s->d_lastch.release(); s->d_rtab.release();
   s->h_d3.release(); s->h_res.release(); s->h_text.release(); s->h_side.release();
   if (s->ev_rand) (void)hipEventDestroy(s->ev_rand);
   if (s->stream2) (void)hipStreamDestroy(s->stream2);
@@ -1337,6 +1340,7 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
     HIP_TRY(hipEventElapsedTime(&ms, s->ev[1], s->ev[2]));
     b->timing.ms_fill_seg += ms;
     b->timing.seg_launches++;
+    b->timing.seg_timed_launches++;
   } else if (lds) {
     HIP_TRY(hipEventElapsedTime(&ms, s->ev[1], s->ev[2]));
     b->timing.ms_fill_lds += ms;
@@ -2388,8 +2392,19 @@ static bool finish_gap_on_host(const Graph& g, const FillParams& fp, const GapJo
 struct ResidentLaunch {
   uint64_t units = 0;
   bool two_waves = false;
+  bool timed = false;  // HIP events around the fill kernel
   size_t launched = 0;
 };
+// Resident mode brackets its kernels with HIP events on one launch in eight (the session's first included): an
+// event between two kernels costs the stream 4-5 us, three of them 4 % of a 500-gap list's step, and the product
+// has no use for the durations — bench.py and the tests read them.  G2S_KERNEL_TIMING=all|off overrides.
+static bool kernel_events_on(g2s_session* s) {
+  const char* m = getenv("G2S_KERNEL_TIMING");
+  const uint32_t seq = s->timed_seq++;
+  if (m && !strcmp(m, "all")) return true;
+  if (m && !strcmp(m, "off")) return false;
+  return seq % 8u == 0u;
+}
 static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl) {
   g2s_session* s = b->s;
   const size_t n = b->jobs.size();
@@ -2476,12 +2491,13 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl) {
   // (two waves per gap when the launch is short enough to end with its slowest gap — unless the sessions of a team
   // share this device: the chip is then as full as one long launch makes it)
   const bool two_waves = getenv("G2S_SEG_WAVES") ? atoi(getenv("G2S_SEG_WAVES")) == 2 : (ids.size() <= 2048 && !s->team_shares_device);
-  HIP_TRY(hipEventRecord(s->ev[1], st));
+  rl->timed = kernel_events_on(s);
+  if (rl->timed) HIP_TRY(hipEventRecord(s->ev[1], st));
   HIP_TRY(launch_fill_seg(st, (uint32_t)ids.size(), dg.succ, dg.urec, gaps_dev, ids_dev, (const uint32_t*)s->d_flank.p,
                           (SubRec*)s->d_sub.p, (unsigned long long)out_states, (unsigned long long*)s->d_counter.p,
                           (GapOut*)s->d_outs.p, nullptr, nullptr, s->params.skip_confident ? 1 : 0, nullptr, two_waves,
                           nullptr, nullptr, 0u, 1u, true));
-  HIP_TRY(hipEventRecord(s->ev[2], st));
+  if (rl->timed) HIP_TRY(hipEventRecord(s->ev[2], st));
   rl->units = out_states;
   rl->two_waves = two_waves;
   rl->launched = ids.size();
@@ -2514,8 +2530,24 @@ struct ResidentList {
   const GapDev* gaps_dev = nullptr;
   hipEvent_t ready = nullptr;          // (optional) the lead's stream waits for it in front of phase D3
 };
-static int resident_d3(g2s_session* s, const ResidentList& L, g2s_result* results, char* arena, g2s_timing* tm_out,
-                       double* ms_d3_out, bool* fell_back) {
+// the rand() values a list can draw, generated on a stream of their own: window of the generator's state from the
+// host, then g2s_rand_fill.  Called in front of the fill kernel's launch when the list is one batch (the stream then
+// fills while the look-ups run and the host prepares the launch: beside the fill kernel it cost that kernel 4 %).
+static size_t rand_capacity(size_t list_cap) { return (list_cap + 2 * G2S_RAND_BLOCK) & ~(size_t)(G2S_RAND_BLOCK - 1); }
+static int resident_rand(g2s_session* s, PinBuf* pin, size_t n, size_t list_cap) {
+  if (hipSetDevice(s->device) != hipSuccess) return fail(G2S_ERR_NO_DEVICE, "cannot select device");
+  const size_t rnd_cap = rand_capacity(list_cap);
+  char* hsum = (char*)pin->p + n * sizeof(D3Gap) + 16 - (n * sizeof(D3Gap)) % 16;
+  uint32_t* hwin = (uint32_t*)(hsum + 1024 + 64 * 128);  // (summary, the trace kernel's 64 fill-byte counters, the window)
+  HIP_TRY(s->d_rnd.ensure((31 + rnd_cap + 64) * 4));
+  memcpy(hwin, s->rcache.window(G2S_RAND_WINDOW), G2S_RAND_WINDOW * 4);
+  HIP_TRY(hipMemcpyAsync(s->d_rnd.p, hwin, G2S_RAND_WINDOW * 4, hipMemcpyHostToDevice, s->stream2));
+  HIP_TRY(launch_rand_fill(s->stream2, (uint32_t*)s->d_rnd.p, s->rtab, nullptr, (uint64_t)rnd_cap));
+  return G2S_OK;
+}
+
+static int resident_d3(g2s_session* s, const ResidentList& L, bool timed, bool rand_launched, g2s_result* results, char* arena,
+                       g2s_timing* tm_out, double* ms_d3_out, bool* fell_back) {
   const size_t n = L.n;
   const Graph& g = *s->graph->g;
   const FillParams fp = fill_params_of(s);
@@ -2523,10 +2555,8 @@ static int resident_d3(g2s_session* s, const ResidentList& L, g2s_result* result
   *fell_back = false;
   if (hipSetDevice(s->device) != hipSuccess) return fail(G2S_ERR_NO_DEVICE, "cannot select device");
   D3Summary* hsum = (D3Summary*)((char*)L.pin->p + n * sizeof(D3Gap) + 16 - (n * sizeof(D3Gap)) % 16);
-  uint32_t* hwin = (uint32_t*)((char*)hsum + 1024 + 64 * 128);  // (summary, the trace kernel's 64 fill-byte counters, the window)
-  size_t rnd_cap = (L.rnd_cap + 2 * G2S_RAND_BLOCK) & ~(size_t)(G2S_RAND_BLOCK - 1);
+  const size_t rnd_cap = rand_capacity(L.rnd_cap);
   HIP_TRY(s->d_d3.ensure(d3_work_bytes((uint32_t)n)));
-  HIP_TRY(s->d_rnd.ensure((31 + rnd_cap + 64) * 4));
   // what the hand-off kernel gives the host for the gaps whose closure the host analyses (a fraction of a per cent of a list)
   D3Side side, side_h;
   {
@@ -2540,7 +2570,7 @@ static int resident_d3(g2s_session* s, const ResidentList& L, g2s_result* result
     side_h.items = (D3HostItem*)hp; side_h.outs = (GapOut*)(hp + b_items); side_h.segs = (SegRec*)(hp + b_items + b_outs);
     side_h.rnd = (uint32_t*)(hp + b_items + b_outs + b_segs);
     side_h.count = (unsigned long long*)(hp + b_items + b_outs + b_segs + ((side_h.cap_rnd * 4 + 63) & ~(size_t)63));
-    *side_h.count = 0;
+    *(volatile unsigned long long*)side_h.count = ~0ull;  // (until the hand-over is complete)
     void* dp = nullptr;
     HIP_TRY(hipHostGetDevicePointer(&dp, s->h_side.p, 0));
     side = side_h;
@@ -2574,14 +2604,25 @@ static int resident_d3(g2s_session* s, const ResidentList& L, g2s_result* result
   hipStream_t st = s->stream;
   void* d_dgaps = nullptr;
   HIP_TRY(hipHostGetDevicePointer(&d_dgaps, L.pin->p, 0));
-  // the rand() values the list can draw, generated beside the look-up and fill kernels on a stream of their own
-  memcpy(hwin, s->rcache.window(G2S_RAND_WINDOW), G2S_RAND_WINDOW * 4);
-  HIP_TRY(hipMemcpyAsync(s->d_rnd.p, hwin, G2S_RAND_WINDOW * 4, hipMemcpyHostToDevice, s->stream2));
-  HIP_TRY(launch_rand_fill(s->stream2, (uint32_t*)s->d_rnd.p, s->rtab, nullptr, (uint64_t)rnd_cap));
+  // the rand() values the list can draw (a team's list: generated here, beside the copies of the groups' records)
+  if (!rand_launched) { const int rc = resident_rand(s, L.pin, n, L.rnd_cap); if (rc != G2S_OK) return rc; }
+  // (the per-gap descriptors of phase D3 of a short list go to device memory behind it: read over the link by the
+  // list's single classify workgroup they were 3 us of its 8; a long list's are read by 40 workgroups at once, and a
+  // 160 KB copy beside the fill kernel cost that kernel 4 %)
+  const bool dgap_on_device = n <= 3072;
+  if (dgap_on_device) {
+    HIP_TRY(s->d_dgap.ensure(n * sizeof(D3Gap) + 16));
+    HIP_TRY(hipMemcpyAsync(s->d_dgap.p, L.pin->p, n * sizeof(D3Gap), hipMemcpyHostToDevice, s->stream2));
+  }
   HIP_TRY(hipEventRecord(s->ev_rand, s->stream2));
   HIP_TRY(hipStreamWaitEvent(st, s->ev_rand, 0));
+  // (the time of phase D3's kernels: from the end of this session's fill kernel, or — a team's list — from here)
+  hipEvent_t d3_begin = s->ev[2];
   if (L.ready) HIP_TRY(hipStreamWaitEvent(st, L.ready, 0));
-  HIP_TRY(hipEventRecord(s->ev[0], st));
+  if (timed && (L.ready || L.groups.size() > 1)) {
+    HIP_TRY(hipEventRecord(s->ev[0], st));
+    d3_begin = s->ev[0];
+  }
   D3Params P;
   P.k = fp.k; P.skip_confident = fp.skip_confident ? 1 : 0; P.all_paths = fp.all_paths ? 1 : 0; P.unique_paths = fp.unique_paths ? 1 : 0;
   P.max_states = (uint64_t)std::max<int64_t>(s->params.max_mem, 1 << 16) / 64;
@@ -2590,28 +2631,43 @@ static int resident_d3(g2s_session* s, const ResidentList& L, g2s_result* result
   P.arena_base = 0;
   P.group_size = (uint32_t)std::max<size_t>(L.group_size, 1);
   P.sub_region = L.sub_region;
+  P.laps = getenv("G2S_DEBUG") ? 1u : 0u;
+  P.pad = 0;
   P.seg_cap = fp.skip_confident ? G2S_SEG_CAP : 192u;
   P.map_cap = ((uint32_t)L.dmax + 2u + 3u) & ~3u;
-  HIP_TRY(launch_d3(st, P, W, L.gaps_dev, L.outs_dev, (const D3Gap*)d_dgaps, L.sub_dev,
+  HIP_TRY(launch_d3(st, P, W, L.gaps_dev, L.outs_dev, dgap_on_device ? (const D3Gap*)s->d_dgap.p : (const D3Gap*)d_dgaps, L.sub_dev,
                     (const char*)s->d_lastch.p, (const char*)s->d_lastch.p + g.n, s->rtab, (uint32_t*)s->d_rnd.p,
-                    (uint64_t)rnd_cap, res_dev, (char*)arena_dev, side, s->ev[4]));
-  HIP_TRY(hipEventRecord(s->ev[3], st));
+                    (uint64_t)rnd_cap, res_dev, (char*)arena_dev, side, (char*)d_dgaps + ((char*)hsum - (char*)L.pin->p),
+                    s->d_d3.clean >= 1024 + 64 * 128));
+  s->d_d3.clean = 0;
+  if (timed) HIP_TRY(hipEventRecord(s->ev[3], st));
   if (stage_dev) {
     HIP_TRY(hipMemcpyAsync(results, s->d_resout.p, n * sizeof(g2s_result), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(arena, s->d_textout.p, L.arena_bytes, hipMemcpyDeviceToHost, st));
   }
-  HIP_TRY(hipMemcpyAsync(hsum, W.sum, 1024 + 64 * 128, hipMemcpyDeviceToHost, st));
   const auto t_launched = std::chrono::steady_clock::now();
   // ---- gaps the device leaves to the host (their closure holds a k-mer at two depths: post.cpp analyses those):
   // handed over in front of the trace kernel, finished here while it runs — analysis of the closure, traceback,
   // record, written where the kernels write the others' (the caller's buffers or the staging)
-  HIP_TRY(hipEventSynchronize(s->ev[4]));
+  // (the hand-off kernel says so in pinned memory; an event between it and the trace kernel cost the stream 9 us.
+  // Should the kernels end without saying so — never expected — the stream's end is noticed instead.)
+  unsigned long long handed = ~0ull;
+  for (unsigned spins = 0;; spins++) {
+    handed = __atomic_load_n(side_h.count, __ATOMIC_ACQUIRE);
+    if (handed != ~0ull) break;
+    if ((spins & 1023u) == 1023u && hipStreamQuery(st) != hipErrorNotReady) {
+      handed = __atomic_load_n(side_h.count, __ATOMIC_ACQUIRE);
+      if (handed == ~0ull) handed = 1ull << 63;
+      break;
+    }
+    cpu_relax();
+  }
   const auto t_handed = std::chrono::steady_clock::now();
   std::atomic<int> host_bad(0);
-  const size_t ni = (size_t)(*side_h.count & 0x7FFFFFFFFFFFFFFFull);
+  const size_t ni = (size_t)(handed & 0x7FFFFFFFFFFFFFFFull);
   g2s_result* rs_host = res_direct && !stage_dev ? results : (g2s_result*)s->h_res.p;
   uint64_t host_fill_bytes = 0;
-  if (ni && !(*side_h.count >> 63) && !stage_dev) {
+  if (ni && !(handed >> 63) && !stage_dev) {
     char* text = arena_direct ? arena : (char*)s->h_text.p;
     auto one = [&](size_t x) {
       const D3HostItem& h = side_h.items[x];
@@ -2629,9 +2685,22 @@ static int resident_d3(g2s_session* s, const ResidentList& L, g2s_result* result
   HIP_TRY(hipStreamSynchronize(st));
   const auto t_synced = std::chrono::steady_clock::now();
   float ms_d3 = 0;
-  HIP_TRY(hipEventElapsedTime(&ms_d3, s->ev[0], s->ev[3]));
+  if (timed) HIP_TRY(hipEventElapsedTime(&ms_d3, d3_begin, s->ev[3]));
   *ms_d3_out = ms_d3;
-  for (int q = 0; q < 64; q++) hsum->fill_bytes += ((const unsigned long long*)((const char*)hsum + 1024))[q * 16];
+  if (getenv("G2S_DEBUG")) {  // the kernels' lap stamps (d3_device.hip: stamp), 100 MHz
+    unsigned long long lp[24];
+    HIP_TRY(hipMemcpy(lp, (char*)W.sum + 512, sizeof lp, hipMemcpyDeviceToHost));
+    auto us = [&](int a, int b) { return lp[a] && lp[b] ? ((double)lp[b] - (double)lp[a]) / 100.0 : -1.0; };
+    fprintf(stderr, "[g2s] phase D3 laps (us): front classify %.1f scan %.1f | to tables %.1f: status %.1f records %.1f closure %.1f walks %.1f | to back %.1f: tables into LDS %.1f chain %.1f hand-off %.1f fence %.1f | to trace %.1f, longest wave: to closure %.1f walk %.1f bases %.1f all %.1f, first entry to last end %.1f\n",
+            us(0, 1), us(1, 2), us(2, 3), us(3, 4), us(4, 5), us(5, 6), us(6, 7), us(7, 8), us(8, 9), us(9, 10), us(10, 11), us(11, 12), us(12, 13),
+            lp[14] / 100.0, lp[15] / 100.0, lp[16] / 100.0, lp[17] / 100.0, us(13, 18));
+    fprintf(stderr, "[g2s] the wave with the longest walk: %.1f us, %llu segments entered in %.1f us\n", (double)(lp[19] >> 32) / 100.0, (lp[19] >> 16) & 0xFFFF, (double)(lp[19] & 0xFFFF) / 100.0);
+  }
+  // (the summary is zeroed for the next list now, off its critical path)
+  HIP_TRY(hipMemsetAsync(W.sum, 0, 1024 + 64 * 128, st));
+  s->d_d3.clean = 1024 + 64 * 128;
+  for (int q = 0; q < 64; q++)  // (bits 40 and up count the trace kernel's waves: d3_device.hip)
+    hsum->fill_bytes += ((const unsigned long long*)((const char*)hsum + 1024))[q * 16] & ((1ull << 40) - 1);
   hsum->fill_bytes += host_fill_bytes;
   const bool test_fallback = getenv("G2S_RESIDENT_TEST_FALLBACK") != nullptr;  // (tests: the attempt is discarded)
   if (stage_dev && hsum->host_items) hsum->anomalies++;  // (the measurement switch has no path for host-finished gaps)
@@ -2686,7 +2755,22 @@ int run_resident(g2s_batch* b, g2s_result* results, char* arena) {
   const size_t n = b->jobs.size();
   const auto t_enter = std::chrono::steady_clock::now();
   ResidentLaunch rl;
-  { const int rc = resident_launch_fill(b, &rl); if (rc != G2S_OK) return rc; }
+  // (the stream of rand() values first: it does not depend on the list's kernels — if the list turns out not to be
+  // for this mode, a few microseconds of one kernel were for nothing)
+  bool rand_launched = false;
+  if (resident_applicable(s, n) && b->seg_tier_all && !b->host_lookup && b->rnd_cap < (1ull << 31) &&
+      s->h_d3.cap >= n * sizeof(D3Gap) + 2048 + 64 * 128 + G2S_RAND_WINDOW * 4) {  // (pinned window in place: the launch below will not move it)
+    const int rc = resident_rand(s, &s->h_d3, n, b->rnd_cap);
+    if (rc != G2S_OK) return rc;
+    rand_launched = true;
+  }
+  {
+    const int rc = resident_launch_fill(b, &rl);
+    if (rc != G2S_OK) {
+      if (rand_launched) (void)hipStreamSynchronize(s->stream2);  // (its copy reads the pinned window)
+      return rc;
+    }
+  }
   ResidentList L;
   L.groups.push_back(b);
   L.n = n; L.group_size = std::max<size_t>(n, 1);
@@ -2705,15 +2789,16 @@ int run_resident(g2s_batch* b, g2s_result* results, char* arena) {
   }
   double ms_d3 = 0;
   bool fell_back = false;
-  const int rc = resident_d3(s, L, results, arena, &b->timing, &ms_d3, &fell_back);
+  const int rc = resident_d3(s, L, rl.timed, rand_launched, results, arena, &b->timing, &ms_d3, &fell_back);
   if (rc != G2S_OK) return rc;
   { const int r2 = resident_reset_fill(s, n); if (r2 != G2S_OK) return r2; }
   if (fell_back) { b->timing.resident_fallbacks++; return 1; }
   float ms_fill = 0;
-  HIP_TRY(hipEventElapsedTime(&ms_fill, s->ev[1], s->ev[2]));
+  if (rl.timed) HIP_TRY(hipEventElapsedTime(&ms_fill, s->ev[1], s->ev[2]));
   g2s_timing& tm = b->timing;
   tm.ms_fill_seg += ms_fill;
   tm.seg_launches++;
+  if (rl.timed) tm.seg_timed_launches++;
   if (rl.two_waves) tm.seg2_launches++;
   tm.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enter).count();
   if (getenv("G2S_DEBUG")) fprintf(stderr, "[g2s] resident mode: %zu gaps in %.3f ms (fill kernel %.3f ms)\n", n, tm.ms_total, ms_fill);
@@ -2818,7 +2903,7 @@ static int team_resident(g2s_session* const* sessions, int nsessions, const g2s_
   std::vector<g2s_batch*> subs(ngroups, nullptr);
   std::vector<int> owner(ngroups, -1);
   std::vector<float> fill_ms(ngroups, 0.f);
-  std::vector<char> two(ngroups, 0);
+  std::vector<char> two(ngroups, 0), timed_g(ngroups, 0);
   std::vector<size_t> group_arena(ngroups + 1, 0);
   for (size_t gi = 0; gi < ngroups; gi++) {
     const size_t off = gi * group_size, cnt = std::min(group_size, n - off);
@@ -2852,6 +2937,7 @@ static int team_resident(g2s_session* const* sessions, int nsessions, const g2s_
         if (rc == 1) { not_for_us.fetch_add(1); queue.abort(); break; }
         if (rc == G2S_OK) {
           two[gi] = rl.two_waves ? 1 : 0;
+          timed_g[gi] = rl.timed ? 1 : 0;
           // the group's share of the list's D3Gap array (offsets into the whole arena)
           const D3Gap* mine = (const D3Gap*)s->h_d3.p;
           for (size_t i = 0; i < cnt; i++) { dg_all[off + i] = mine[i]; dg_all[off + i].arena_off += (uint64_t)group_arena[gi]; }
@@ -2868,7 +2954,7 @@ static int team_resident(g2s_session* const* sessions, int nsessions, const g2s_
             if (e == hipSuccess) e = hipMemcpyPeerAsync(dst_s, lead->device, s->d_sub.p, s->device, sub_bytes, s->stream);
           }
           if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
-          if (e == hipSuccess) e = hipEventElapsedTime(&fill_ms[gi], s->ev[1], s->ev[2]);
+          if (e == hipSuccess && rl.timed) e = hipEventElapsedTime(&fill_ms[gi], s->ev[1], s->ev[2]);
           if (e != hipSuccess) rc = fail(G2S_ERR_HIP, std::string("team, group to the lead's device: ") + hipGetErrorString(e));
           else rc = resident_reset_fill(s, cnt);
           s->desc_owner = nullptr;  // (h_d3 of this session is rewritten by its next group)
@@ -2902,7 +2988,7 @@ static int team_resident(g2s_session* const* sessions, int nsessions, const g2s_
     L.gaps_dev = nullptr;
     for (g2s_batch* b : subs) { L.rnd_cap += b->rnd_cap; L.dmax = std::max(L.dmax, b->dmax); L.has_skip = L.has_skip || b->has_skip; }
     double ms_d3 = 0;
-    rc = resident_d3(lead, L, results, arena, &total, &ms_d3, &fell_back);
+    rc = resident_d3(lead, L, timed_g[0] != 0, false, results, arena, &total, &ms_d3, &fell_back);
   }
   if (rc == G2S_OK && !fell_back) {
     total.team_groups = (uint32_t)ngroups;
@@ -2913,6 +2999,7 @@ static int team_resident(g2s_session* const* sessions, int nsessions, const g2s_
       total.ms_prepare += t.ms_prepare;
       total.ms_fill_seg += fill_ms[gi];
       total.seg_launches++;
+      total.seg_timed_launches += timed_g[gi];
       total.seg2_launches += two[gi];
       if (owner[gi] >= 0 && owner[gi] < 16) total.team_groups_by_session[owner[gi]]++;
     }
@@ -2978,7 +3065,7 @@ extern "C" int g2s_team_fill(g2s_session* const* sessions, int nsessions, const 
       total.retried_gaps += tm.retried_gaps; total.x_fill_lds += tm.x_fill_lds; total.s_fill_lds += tm.s_fill_lds;
       total.lds_tier_gaps += tm.lds_tier_gaps; total.lds_launches += tm.lds_launches; total.log_pool_gaps += tm.log_pool_gaps;
       total.rs_pool_gaps += tm.rs_pool_gaps; total.ms_fill_seg += tm.ms_fill_seg; total.seg_tier_gaps += tm.seg_tier_gaps;
-      total.seg_launches += tm.seg_launches; total.seg_segments += tm.seg_segments; total.ms_fill_segx += tm.ms_fill_segx;
+      total.seg_launches += tm.seg_launches; total.seg_timed_launches += tm.seg_timed_launches; total.seg_segments += tm.seg_segments; total.ms_fill_segx += tm.ms_fill_segx;
       total.segx_tier_gaps += tm.segx_tier_gaps; total.segx_launches += tm.segx_launches; total.watchdog_gaps += tm.watchdog_gaps;
       total.seg2_launches += tm.seg2_launches; total.resident_launches += tm.resident_launches;
       total.resident_fallbacks += tm.resident_fallbacks; total.draw_dependent_gaps += tm.draw_dependent_gaps;
@@ -3070,7 +3157,7 @@ extern "C" int g2s_team_fill(g2s_session* const* sessions, int nsessions, const 
         total.lds_tier_gaps += t.lds_tier_gaps; total.lds_launches += t.lds_launches;
         total.log_pool_gaps += t.log_pool_gaps; total.rs_pool_gaps += t.rs_pool_gaps;
         total.ms_prepare += t.ms_prepare;
-        total.ms_fill_seg += t.ms_fill_seg; total.seg_tier_gaps += t.seg_tier_gaps; total.seg_launches += t.seg_launches;
+        total.ms_fill_seg += t.ms_fill_seg; total.seg_tier_gaps += t.seg_tier_gaps; total.seg_launches += t.seg_launches; total.seg_timed_launches += t.seg_timed_launches;
         total.seg_segments += t.seg_segments;
         total.ms_fill_segx += t.ms_fill_segx; total.segx_tier_gaps += t.segx_tier_gaps; total.segx_launches += t.segx_launches;
         total.watchdog_gaps += t.watchdog_gaps; total.seg2_launches += t.seg2_launches;

@@ -64,7 +64,7 @@ class g2s_timing(C.Structure):
                 ("ms_d3", C.c_double), ("resident_launches", C.c_uint32), ("resident_fallbacks", C.c_uint32),
                 ("draw_dependent_gaps", C.c_uint64), ("d3_table_entries", C.c_uint64),
                 ("host_finished_gaps", C.c_uint32), ("team_groups", C.c_uint32), ("team_sessions", C.c_uint32),
-                ("team_groups_by_session", C.c_uint32 * 16), ("pad_", C.c_uint32)]
+                ("team_groups_by_session", C.c_uint32 * 16), ("seg_timed_launches", C.c_uint32)]
 
 
 class g2s_run_opts(C.Structure):

@@ -179,7 +179,9 @@ typedef struct g2s_timing {
   double ms_prepare;         /* g2s_fill_batch / g2s_team_fill: flank k-mer -> node resolution + descriptor upload
                                 (g2s_batch_prepare), inside ms_total; summed over sessions for a team */
   /* segment tier (kernel g2s_fill_seg = phases A-D1 over unitig segments, fill_seg.hip) */
-  double ms_fill_seg;        /* HIP events on the session stream, summed over launches */
+  double ms_fill_seg;        /* HIP events on the session stream, summed over the launches that were bracketed with
+                                events: all on the host path, one in eight in resident mode (seg_timed_launches;
+                                G2S_KERNEL_TIMING=all times every launch) */
   uint32_t seg_tier_gaps;    /* gaps that completed in the segment tier */
   uint32_t seg_launches;
   uint64_t seg_segments;     /* segments those gaps took (a config-2 gap: ~25 for ~1000 DP states) */
@@ -198,7 +200,7 @@ typedef struct g2s_timing {
   /* g2s_team_fill: the dispatcher's groups and which session took how many (sessions beyond the 16th are not listed) */
   uint32_t team_groups, team_sessions;
   uint32_t team_groups_by_session[16];
-  uint32_t pad_;
+  uint32_t seg_timed_launches;  /* segment-tier launches whose duration is in ms_fill_seg (and, resident mode, in ms_d3) */
 } g2s_timing;
 
 /* ---------------------------------------------------------------------------
