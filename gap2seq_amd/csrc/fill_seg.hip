@@ -1501,63 +1501,76 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
   const bool t_is_s = want_s && !gd.all_paths;  // -best-only: the traceback starts are the sinks (:1245-1259)
   uint32_t start_b0 = SEG_NOPAR, start_b1 = SEG_NOPAR, start_t0 = 0, start_t1 = 0;  // segments and positions of the traceback starts
   bool choice = false;  // some entry of the traceback closure has more than one parent
+  // What a segment holds by itself — a sink, a traceback start, a left-flank k-mer at its first state — does not
+  // depend on its children: all segments at once, in front of the sweep (inside it, each of the sweep's ~80
+  // dependent steps carried these comparisons: phase D1 was half of the tail of a config-2 gap).  s_t: ts | source
+  // << 15 | tt << 16, rewritten by the sweep.
+  for (uint32_t b0 = 0; b0 < nseg; b0 += 64u) {
+    const uint32_t b = b0 + (uint32_t)lane;
+    const bool hb = b < nseg;
+    const uint32_t v0 = hb ? s_node[b] : 0u, dl = hb ? s_dl[b] : 0u;
+    const int d0 = (int)(dl & 0xFFFFu);
+    const int len = max(0, min((int)(dl >> 16), d_last - d0 + 1));
+    int ts = -1, tt = -1, pstart = -1, jstart = 0;
+    if (hb && len > 0) {
+      const int ps = seg_pos(v0, (uint32_t)len, sinknode);
+      if (ps >= 0 && d0 + ps >= lo_sink) ts = ps;
+      const int pt = seg_pos(v0, (uint32_t)len, reached);
+      if (pt >= 0 && (d0 + pt == len0 || (n_len > 1 && d0 + pt == len1))) {
+        tt = pt;
+        if (t_is_s) ts = max(ts, pt);
+        pstart = pt;
+        jstart = d0 + pt == len0 ? 0 : 1;
+      }
+    }
+    const uint32_t ls = (hb && d0 <= lmf) ? l_seed[d0] : G2S_DEV_INVALID;
+    const bool source = ls != G2S_DEV_INVALID && (v0 >> 1) == (ls >> 1);  // :1270, k-mer comparison only
+    if (hb) s_t[b] = enc15(ts) | (source ? 0x8000u : 0u) | (enc15(tt) << 16);
+    for (uint64_t sm = __ballot(pstart >= 0); sm; sm &= sm - 1) {  // (state (reached, len_j) is unique)
+      const int l = __builtin_ctzll(sm);
+      if (rl((uint32_t)jstart, l) == 0u) { start_b0 = b0 + (uint32_t)l; start_t0 = rl((uint32_t)pstart, l); }
+      else { start_b1 = b0 + (uint32_t)l; start_t1 = rl((uint32_t)pstart, l); }
+    }
+  }
+  lds_sync();
   {
+    // the sweep: generation by generation in reverse; a segment in the closure tells its parents — one addition
+    // per parent: children on paths to a sink in bits 20..22 of the parent's word (the out-degree of its last state
+    // in the subgraph, for the branch rule below), children in the traceback closure in bits 24..26 (a state has at
+    // most four successors); a parent with either count above zero is in that closure whole
     uint32_t hi = nseg;
     while (hi > 0) {
       const uint32_t lo = hi > 64u ? hi - 64u : 0u;
       const uint32_t b = lo + (uint32_t)lane;
       const bool hb = b < hi;
-      // (everything a segment's step reads is asked for at once: one LDS round trip instead of three)
+      // (everything a segment's step reads is asked for at once: one LDS round trip)
       const uint32_t aux = hb ? s_aux[b] : 0u;
-      const uint32_t v0 = hb ? s_node[b] : 0u, dl = hb ? s_dl[b] : 0u;
+      const uint32_t pre = hb ? s_t[b] : 0x7FFF7FFFu, dl = hb ? s_dl[b] : 0u;
       const uint32_t p01 = hb ? s_p01[b] : 0xFFFFFFFFu, p23 = hb ? s_p23[b] : 0xFFFFFFFFu;
       const uint32_t gtop = rl(aux & 0xFFFFu, (int)(hi - 1u - lo));
       const uint64_t gm = __ballot(hb && (aux & 0xFFFFu) == gtop);  // segments of one generation are contiguous
       const int first = __builtin_ctzll(gm);
       const bool act = hb && lane >= first;
-      int pstart = -1, jstart = 0;
       bool multi = false;
       if (act) {
         const int d0 = (int)(dl & 0xFFFFu);
         const int len = max(0, min((int)(dl >> 16), d_last - d0 + 1));
-        int ts = -1, tt = -1;
+        int ts = dec15(pre), tt = dec15(pre >> 16);
         if (len > 0) {
-          const int ps = seg_pos(v0, (uint32_t)len, sinknode);
-          if (ps >= 0 && d0 + ps >= lo_sink) ts = ps;
-          const int pt = seg_pos(v0, (uint32_t)len, reached);
-          if (pt >= 0 && (d0 + pt == len0 || (n_len > 1 && d0 + pt == len1))) {
-            tt = pt;
-            if (t_is_s) ts = max(ts, pt);
-            pstart = pt;
-            jstart = d0 + pt == len0 ? 0 : 1;
-          }
-          if (aux & (G2S_SUB_IN_S << 16)) ts = len - 1;
-          if (aux & (G2S_SUB_IN_T << 16)) tt = len - 1;
+          if (aux & (7u << 20)) ts = len - 1;
+          if (aux & (7u << 24)) tt = len - 1;
         }
         s_t[b] = enc15(ts) | (enc15(tt) << 16);
-        // marks for the parents; a parent also counts its children on paths to a sink (bits 20..22: the
-        // out-degree of its last state in the subgraph, for the branch rule below)
-        const uint32_t mk = (((ts >= 0 ? G2S_SUB_IN_S : 0u) | (tt >= 0 ? G2S_SUB_IN_T : 0u)) << 16) | (ts >= 0 ? (1u << 20) : 0u);
-        if ((mk & 0x30000u) && d0 > 0) {
-          const uint32_t ls = d0 <= lmf ? l_seed[d0] : G2S_DEV_INVALID;
-          const bool source = ls != G2S_DEV_INVALID && (v0 >> 1) == (ls >> 1);  // :1270, k-mer comparison only
-          if (!source) {
-            // (the S-children count sits above the two mark bits and those are only ever set: one add of
-            // mark bits that are still clear would do, but two children may carry the same mark: add, then or)
-            if ((p01 & 0xFFFFu) != SEG_NOPAR) atomicAdd(&s_aux[p01 & 0xFFFFu], mk & ~0x30000u), atomicOr(&s_aux[p01 & 0xFFFFu], mk & 0x30000u);
-            if ((p01 >> 16) != SEG_NOPAR) atomicAdd(&s_aux[p01 >> 16], mk & ~0x30000u), atomicOr(&s_aux[p01 >> 16], mk & 0x30000u);
-            if ((p23 & 0xFFFFu) != SEG_NOPAR) atomicAdd(&s_aux[p23 & 0xFFFFu], mk & ~0x30000u), atomicOr(&s_aux[p23 & 0xFFFFu], mk & 0x30000u);
-            if ((p23 >> 16) != SEG_NOPAR) atomicAdd(&s_aux[p23 >> 16], mk & ~0x30000u), atomicOr(&s_aux[p23 >> 16], mk & 0x30000u);
-            multi = tt >= 0 && (p01 >> 16) != SEG_NOPAR;
-          }
+        const uint32_t mk = (ts >= 0 ? (1u << 20) : 0u) | (tt >= 0 ? (1u << 24) : 0u);
+        if (mk && d0 > 0 && !(pre & 0x8000u)) {
+          if ((p01 & 0xFFFFu) != SEG_NOPAR) atomicAdd(&s_aux[p01 & 0xFFFFu], mk);
+          if ((p01 >> 16) != SEG_NOPAR) atomicAdd(&s_aux[p01 >> 16], mk);
+          if ((p23 & 0xFFFFu) != SEG_NOPAR) atomicAdd(&s_aux[p23 & 0xFFFFu], mk);
+          if ((p23 >> 16) != SEG_NOPAR) atomicAdd(&s_aux[p23 >> 16], mk);
+          multi = tt >= 0 && (p01 >> 16) != SEG_NOPAR;
         }
       }
       if (__ballot(multi)) choice = true;
-      for (uint64_t sm = __ballot(pstart >= 0); sm; sm &= sm - 1) {  // (state (reached, len_j) is unique)
-        const int l = __builtin_ctzll(sm);
-        if (rl((uint32_t)jstart, l) == 0u) { start_b0 = lo + (uint32_t)l; start_t0 = rl((uint32_t)pstart, l); }
-        else { start_b1 = lo + (uint32_t)l; start_t1 = rl((uint32_t)pstart, l); }
-      }
       lds_sync();
       hi = lo + (uint32_t)first;
     }

@@ -2758,7 +2758,9 @@ int run_resident(g2s_batch* b, g2s_result* results, char* arena) {
   // (the stream of rand() values first: it does not depend on the list's kernels — if the list turns out not to be
   // for this mode, a few microseconds of one kernel were for nothing)
   bool rand_launched = false;
-  if (resident_applicable(s, n) && b->seg_tier_all && !b->host_lookup && b->rnd_cap < (1ull << 31) &&
+  // (a long list only: its look-up kernel and launch preparation leave the stream 50 us to fill in; on a short
+  // list the two launches would delay the fill kernel's by 10 us, and its stream is short enough to fill beside it)
+  if (n > 3072 && resident_applicable(s, n) && b->seg_tier_all && !b->host_lookup && b->rnd_cap < (1ull << 31) &&
       s->h_d3.cap >= n * sizeof(D3Gap) + 2048 + 64 * 128 + G2S_RAND_WINDOW * 4) {  // (pinned window in place: the launch below will not move it)
     const int rc = resident_rand(s, &s->h_d3, n, b->rnd_cap);
     if (rc != G2S_OK) return rc;
