@@ -2615,7 +2615,17 @@ static int resident_d3(g2s_session* s, const ResidentList& L, bool timed, bool r
     HIP_TRY(hipMemcpyAsync(s->d_dgap.p, L.pin->p, n * sizeof(D3Gap), hipMemcpyHostToDevice, s->stream2));
   }
   HIP_TRY(hipEventRecord(s->ev_rand, s->stream2));
-  HIP_TRY(hipStreamWaitEvent(st, s->ev_rand, 0));
+  // (The fill kernel runs for hundreds of microseconds, the stream's work for tens: this thread waits for the
+  // latter here instead of putting a wait for it into the main stream — that packet, between the fill kernel and
+  // the first kernel of phase D3, cost the list 5 us.  Only if the other stream is late does the main one wait.)
+  {
+    const auto t_w = std::chrono::steady_clock::now();
+    hipError_t q = hipErrorNotReady;
+    while ((q = hipEventQuery(s->ev_rand)) == hipErrorNotReady &&
+           std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_w).count() < 200.0)
+      cpu_relax();
+    if (q != hipSuccess) HIP_TRY(hipStreamWaitEvent(st, s->ev_rand, 0));
+  }
   // (the time of phase D3's kernels: from the end of this session's fill kernel, or — a team's list — from here)
   hipEvent_t d3_begin = s->ev[2];
   if (L.ready) HIP_TRY(hipStreamWaitEvent(st, L.ready, 0));
