@@ -37,7 +37,7 @@ struct D3HostItem {
   uint64_t seg_off;   // into D3Side.segs
   uint64_t rnd_off;   // into D3Side.rnd: the raw words of the gap's draws
   uint32_t draws;     // it will consume
-  uint32_t pad;
+  uint32_t pad;       // D3Side.items: 1 once everything of the item is in host memory (the host polls it, and zeroes it)
 };
 struct D3Side {  // pinned host memory, written by g2s_d3_trace
   D3HostItem* items = nullptr;
@@ -45,7 +45,7 @@ struct D3Side {  // pinned host memory, written by g2s_d3_trace
   SegRec* segs = nullptr;
   uint32_t* rnd = nullptr;
   uint64_t cap_items = 0, cap_segs = 0, cap_rnd = 0;
-  unsigned long long* count = nullptr;  // items handed over (bit 63: something did not fit), written by g2s_d3_handoff's last wave
+  unsigned long long* count = nullptr;  // items to expect (bit 63: something did not fit; ~0: not known yet), written behind the offsets' chain
 };
 
 // What g2s_d3_tables needs of the v-th draw-dependent gap, and what g2s_d3_trace needs of gap i besides its GapOut
@@ -108,6 +108,8 @@ struct D3Work {
   uint32_t* tile_var = nullptr; // [n + G2S_D3_TABLE_BUDGET / 256 + 2] the draw-dependent gap a tile belongs to
   D3Var* vdesc = nullptr;       // [n + 1]
   D3Trace* tdesc = nullptr;     // [n]
+  uint32_t* host_slot = nullptr;  // [n] host-finished gaps: the gap's item of D3Side (~0: it did not fit)
+  D3HostItem* hitems = nullptr;   // [n] by item: where the gap's wave of the trace kernel puts what the host needs
   uint16_t* tab = nullptr;      // [G2S_D3_TABLE_BUDGET] draws - dmin by (gap, deviation)
   uint32_t* btab = nullptr;     // [G2S_D3_TABLE_BUDGET / 4] deviation behind a block by deviation in front of it
   D3Summary* sum = nullptr;

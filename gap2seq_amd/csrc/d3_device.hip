@@ -75,9 +75,32 @@ __device__ __forceinline__ int gap_count(const GapOut& go, const D3Params& P, bo
 // classify: every gap by itself — class, (fewest) draws, spread; the list's counters into the summary (zeroed
 // by the launcher).  One thread per gap.
 // ---------------------------------------------------------------------------------------------------------
+// sums and scans over the lanes as row shifts and row broadcasts inside the vector ALU (a shuffle through the LDS
+// crossbar per step costs ten times as much: 96 of them were 2 us of a 500-gap list's classify)
+__device__ __forceinline__ uint32_t dpp_scan_add(uint32_t x) {  // inclusive prefix sum
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, false);  // row_shr:1
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, false);  // row_shr:2
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, false);  // row_shr:4
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, false);  // row_shr:8
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1 and 3
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);  // row_bcast:31 into rows 2 and 3
+  return x;
+}
+__device__ __forceinline__ uint32_t sat_add(uint32_t a, uint32_t b) { const uint32_t t = a + b; return t < a ? 0xFFFFFFFFu : t; }
+__device__ __forceinline__ uint32_t dpp_scan_sat(uint32_t x) {  // the same with saturating additions (associative too)
+  x = sat_add(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, false));
+  x = sat_add(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, false));
+  x = sat_add(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, false));
+  x = sat_add(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, false));
+  x = sat_add(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false));
+  x = sat_add(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false));
+  return x;
+}
+__device__ __forceinline__ uint32_t dpp_sum(uint32_t x) { return (uint32_t)__builtin_amdgcn_readlane((int)dpp_scan_add(x), 63); }
+// (64-bit values in three limbs of 24, 24 and 16 bits: no limb's sum over 64 lanes carries)
 __device__ __forceinline__ unsigned long long wave_add64(unsigned long long v) {
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+  const unsigned long long lo = dpp_sum((uint32_t)v & 0xFFFFFFu), mid = dpp_sum((uint32_t)(v >> 24) & 0xFFFFFFu), hi = dpp_sum((uint32_t)(v >> 48));
+  return lo + (mid << 24) + (hi << 48);
 }
 
 // (l_gi, l_dm, l_ds, l_sk: copies of the per-gap words in LDS when one workgroup does the scan as well, else null.
@@ -214,12 +237,33 @@ __device__ __forceinline__ void block_scan3(uint64_t& a, uint64_t& b, uint32_t& 
   a = oa + ia - a; b = ob + ib - b; c = (uint32_t)oc + ic - c;
 }
 
+// the same for a short list's sums, which fit 32 bits (a and b cannot reach 2^32 with 3 072 gaps; c — table
+// entries — can: it saturates, and a saturated total is over every budget)
+__device__ __forceinline__ void block_scan3_short(uint32_t& a, uint32_t& b, uint32_t& c, uint32_t* sh /* [48] */, uint32_t* tot_a, uint32_t* tot_b,
+                                                  uint32_t* tot_c) {
+  const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
+  const uint32_t ia = dpp_scan_add(a), ib = dpp_scan_add(b), ic = dpp_scan_sat(c);
+  if (lane == 63) { sh[wave * 3] = ia; sh[wave * 3 + 1] = ib; sh[wave * 3 + 2] = ic; }
+  __syncthreads();
+  uint32_t wa = lane < 16 ? sh[lane * 3] : 0u, wb = lane < 16 ? sh[lane * 3 + 1] : 0u, wc = lane < 16 ? sh[lane * 3 + 2] : 0u;
+  wa = dpp_scan_add(wa); wb = dpp_scan_add(wb); wc = dpp_scan_sat(wc);  // (lanes 16 and up hold the total)
+  *tot_a = (uint32_t)__builtin_amdgcn_readlane((int)wa, 15); *tot_b = (uint32_t)__builtin_amdgcn_readlane((int)wb, 15);
+  *tot_c = (uint32_t)__builtin_amdgcn_readlane((int)wc, 15);
+  const int wp = (int)uni((uint32_t)max(wave - 1, 0));
+  const uint32_t oa = wave ? (uint32_t)__builtin_amdgcn_readlane((int)wa, wp) : 0u, ob = wave ? (uint32_t)__builtin_amdgcn_readlane((int)wb, wp) : 0u;
+  const uint32_t oc = wave ? (uint32_t)__builtin_amdgcn_readlane((int)wc, wp) : 0u;
+  a = oa + ia - a; b = ob + ib - b;
+  // (exclusive value of a saturating scan: the inclusive one without this thread's share, unless it saturated)
+  const uint32_t incl_c = sat_add(oc, ic);
+  c = incl_c == 0xFFFFFFFFu ? 0xFFFFFFFFu : incl_c - c;
+}
+
 // (gi_a, dm_a, ds_a, sk_a: the per-gap words — W's arrays, or their copies in LDS when this workgroup classified
 // the gaps itself (`dual`: what the skip rule changes is then written to both).  unhandled: gaps the segment tier
 // did not finish.)
 __device__ __forceinline__ void d3_scan_body(const D3Params& P, const D3Work& W, const GapOut* __restrict__ outs, uint32_t* gi_a,
                                              uint32_t* dm_a, uint32_t* ds_a, const int32_t* sk_a, bool dual, uint32_t unhandled,
-                                             uint64_t* sh /* [96] */, uint32_t* sh_f /* [1024] */) {
+                                             uint64_t* sh /* [96] */, uint32_t* sh_f /* [1024] */, bool short_list /* <= 3 072 gaps */) {
   const uint32_t t = threadIdx.x, n = P.n;
   const uint32_t per = (n + 1023u) / 1024u;
   const uint32_t lo = min(n, t * per), hi = min(n, lo + per);
@@ -294,7 +338,11 @@ __device__ __forceinline__ void d3_scan_body(const D3Params& P, const D3Work& W,
   }
   uint64_t tot_d, tot_s;
   uint32_t V;
-  block_scan3(sd, ss, nv, sh, &tot_d, &tot_s, &V);
+  if (short_list) {
+    uint32_t a = (uint32_t)sd, b = (uint32_t)ss, ta, tb;
+    block_scan3_short(a, b, nv, (uint32_t*)sh, &ta, &tb, &V);
+    sd = a; ss = b; tot_d = ta; tot_s = tb;
+  } else block_scan3(sd, ss, nv, sh, &tot_d, &tot_s, &V);
   const bool too_wide = tot_d + tot_s >= 0xFFFF0000ull || tot_s >= (uint64_t)G2S_D3_TABLE_BUDGET;
   uint64_t my_tab = 0, my_blk = 0;
   uint32_t my_tiles = 0;
@@ -328,7 +376,11 @@ __device__ __forceinline__ void d3_scan_body(const D3Params& P, const D3Work& W,
   // ---- where every table starts
   uint64_t to = my_tab, bo = my_blk, T, TB;
   uint32_t tl = my_tiles, tiles;
-  block_scan3(to, bo, tl, sh + 48, &T, &TB, &tiles);
+  if (short_list) {
+    uint32_t b = (uint32_t)std::min<uint64_t>(bo, 0xFFFFFFFFull), c = (uint32_t)std::min<uint64_t>(to, 0xFFFFFFFFull), tb, tc;
+    block_scan3_short(tl, b, c, (uint32_t*)(sh + 48), &tiles, &tb, &tc);
+    bo = b; to = c; TB = tb; T = tc == 0xFFFFFFFFu ? ~0ull : tc;
+  } else block_scan3(to, bo, tl, sh + 48, &T, &TB, &tiles);
   const bool over = too_wide || T > (uint64_t)G2S_D3_TABLE_BUDGET || TB > (uint64_t)(G2S_D3_TABLE_BUDGET / 4u);
   if (!over) {
     uint64_t d = sd, r = ss;
@@ -380,7 +432,7 @@ __device__ __forceinline__ void d3_scan_body(const D3Params& P, const D3Work& W,
 __global__ __launch_bounds__(1024) void g2s_d3_scan(const D3Params P, const D3Work W, const GapOut* __restrict__ outs) {
   __shared__ uint64_t sh[96];
   __shared__ uint32_t sh_f[1024];
-  d3_scan_body(P, W, outs, W.ginfo, W.dmin, W.dspread, W.skip, false, W.sum->unhandled, sh, sh_f);
+  d3_scan_body(P, W, outs, W.ginfo, W.dmin, W.dspread, W.skip, false, W.sum->unhandled, sh, sh_f, false);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -485,9 +537,10 @@ __device__ int d3_walk_count(int n_len, int len0, int len1, uint32_t start_seg, 
   bool ended = false;
   for (int guard = 0; d2 >= 0; guard++) {
     if (guard > 70000) { *bad = true; break; }
+    const int run = min(t, d2);  // the states t .. 1 of this segment: a draw each
+    draws += run; d2 -= run; t -= run;
     if (t == 0 && (s.flags & G2S_SUB_SOURCE)) { ended = true; break; }  // :1455-1462
-    if (d2 > 0) {
-      if (t > 0) { const int run = min(t, d2); draws += run; d2 -= run; t -= run; continue; }
+    if (d2 > 0) {  // (then t == 0: the segment's first state, on to a parent)
       const int nb = seg_nparents(s.par01, s.par23);
       if (nb == 0 || (nb > 1 && !(s.flags & G2S_SEG_ORDERED)) || (uint64_t)draws >= avail || (uint32_t)draws >= nwin) { *bad = true; break; }
       const uint32_t rv = nb > 1 ? lwin[draws] >> 1 : 0u;  // (rand() % 1: the value does not matter)
@@ -624,7 +677,7 @@ __global__ __launch_bounds__(1024) void g2s_d3_front(const D3Params P, const D3W
   const uint32_t unhandled = d3_classify_body(P, W, outs, dgaps, threadIdx.x, 1024u, l_gi, l_dm, l_ds, l_sk, red, true);
   __syncthreads();
   if (threadIdx.x == 0) stamp(W, 1);
-  d3_scan_body(P, W, outs, l_gi, l_dm, l_ds, l_sk, true, unhandled, sh, sh_f);
+  d3_scan_body(P, W, outs, l_gi, l_dm, l_ds, l_sk, true, unhandled, sh, sh_f, true);
   if (threadIdx.x == 0) stamp(W, 2);
 }
 
@@ -646,13 +699,11 @@ __device__ __forceinline__ bool d3_handoff_body(const D3Params& P, const D3Work&
   const uint32_t mine = i0 + (uint32_t)lane;
   const bool have = mine < P.n;
   uint32_t gi = 0, my_off = 0, my_want = 0, my_ns = 0;
-  uint64_t my_sub = 0;
   if (have) {
     gi = W.ginfo[mine];
     const uint32_t vr = W.vrank[mine], base = W.base[mine], dmin = W.dmin[mine];
     const GapOut& go = outs[mine];
     my_ns = go.n_xl;
-    my_sub = (uint64_t)(mine / P.group_size) * P.sub_region + go.sub_off;
     const uint32_t dv = ldvar ? ldvar[vr] : W.dvar[vr];
     my_off = base + dv;
     my_want = dmin;
@@ -665,9 +716,7 @@ __device__ __forceinline__ bool d3_handoff_body(const D3Params& P, const D3Work&
   for (uint64_t m = hm; m; m &= m - 1) {
     const int l = __builtin_ctzll(m);
     const uint32_t i = i0 + (uint32_t)l;
-    const GapOut& go = outs[i];
     const uint32_t off = (uint32_t)__shfl((int)my_off, l), want = (uint32_t)__shfl((int)my_want, l), ns = (uint32_t)__shfl((int)my_ns, l);
-    const uint64_t sub_at = ((uint64_t)(uint32_t)__shfl((int)(my_sub >> 32), l) << 32) | (uint32_t)__shfl((int)(uint32_t)my_sub, l);
     unsigned long long it = 0, so = 0, ro = 0;
     if (lane == 0) {
       if (lcur) {
@@ -680,20 +729,19 @@ __device__ __forceinline__ bool d3_handoff_body(const D3Params& P, const D3Work&
     }
     it = __shfl(it, 0); so = __shfl(so, 0); ro = __shfl(ro, 0);
     if (it >= side.cap_items || so + ns > side.cap_segs || ro + want + 1ull > side.cap_rnd || (uint64_t)off + want + 1ull > capacity) {
-      if (lane == 0) atomicAdd(&S->anomalies, 1u);
+      if (lane == 0) { atomicAdd(&S->anomalies, 1u); W.host_slot[i] = 0xFFFFFFFFu; }
       continue;
     }
-    if ((uint32_t)lane < sizeof(GapOut) / 4u) ((uint32_t*)&side.outs[it])[lane] = ((const uint32_t*)&go)[lane];
-    const uint4* src = (const uint4*)(sub + sub_at);
-    uint4* dst = (uint4*)(side.segs + so);
-    for (uint32_t w = (uint32_t)lane; w < 2u * ns; w += 64u) dst[w] = src[w];
-    for (uint32_t w = (uint32_t)lane; w < want + 1u; w += 64u) side.rnd[ro + w] = rnd[off + w];
+    // (where the gap's wave of the trace kernel will put its record, closure and rand() values: it does the
+    // copying — beside the other gaps' tracebacks instead of in front of them)
     if (lane == 0) {
       g2s::D3HostItem h;
       h.gap = i; h.n_segs = ns; h.seg_off = so; h.rnd_off = ro; h.draws = want; h.pad = 0;
-      side.items[it] = h;
+      W.hitems[it] = h;
+      W.host_slot[i] = (uint32_t)it;
     }
   }
+  (void)sub; (void)rnd; (void)outs;
   return hm != 0ull;
 }
 // (*side.count is ~0 until the hand-over is complete: the host polls it.  Bit 63: something did not fit, or the
@@ -703,11 +751,11 @@ __global__ __launch_bounds__(64) void g2s_d3_handoff(const D3Params P, const D3W
                                                      const g2s::D3Side side) {
   D3Summary* S = W.sum;
   const bool dead = S->status != 0u;
-  if (!dead && d3_handoff_body(P, W, outs, sub, rnd, capacity, side, blockIdx.x * 64u, nullptr, nullptr, nullptr, nullptr)) __threadfence_system();
+  if (!dead) (void)d3_handoff_body(P, W, outs, sub, rnd, capacity, side, blockIdx.x * 64u, nullptr, nullptr, nullptr, nullptr);
   if ((threadIdx.x & 63u) == 0u) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (this wave's additions to the cursors have been acknowledged)
     const unsigned int done = atomicAdd(&S->handoff_waves, 1u) + 1u;
     if (done == gridDim.x) {
-      __threadfence_system();
       const unsigned long long items = atomicAdd(&S->host_items, 0ull);
       const uint32_t anomalies = atomicAdd(&S->anomalies, 0u);
       __hip_atomic_store(side.count, (items & 0x7FFFFFFFFFFFFFFFull) | ((unsigned long long)((anomalies || dead) ? 1u : 0u) << 63),
@@ -761,15 +809,12 @@ __global__ __launch_bounds__(1024) void g2s_d3_back(const D3Params P, const D3Wo
     __syncthreads();
   }
   if (threadIdx.x == 0) stamp(W, 10);
-  bool any = false;
   for (uint32_t i0 = (threadIdx.x >> 6) * 64u; i0 < P.n; i0 += 1024u)
-    any |= d3_handoff_body(P, W, outs, sub, Wd + 31, capacity, side, i0, in_lds ? ldvar : nullptr, in_lds ? ltab : nullptr,
-                           in_lds ? ltoff : nullptr, lcur);
-  if (any) __threadfence_system();
+    (void)d3_handoff_body(P, W, outs, sub, Wd + 31, capacity, side, i0, in_lds ? ldvar : nullptr, in_lds ? ltab : nullptr,
+                          in_lds ? ltoff : nullptr, lcur);
   __syncthreads();
   if (threadIdx.x == 0) {
     stamp(W, 11);
-    __threadfence_system();
     const unsigned long long items = lcur[0];
     S->host_items = items; S->host_segs = lcur[1]; S->host_rnd = lcur[2];
     const uint32_t anomalies = atomicAdd(&S->anomalies, 0u);
@@ -788,7 +833,8 @@ __global__ __launch_bounds__(64) void g2s_d3_trace(const D3Params P, const D3Wor
                                                    const SubRec* __restrict__ sub, const char* __restrict__ chu,
                                                    const char* __restrict__ chd, const uint32_t* __restrict__ rnd,
                                                    uint64_t capacity, g2s_result* __restrict__ results,
-                                                   char* __restrict__ arena, uint32_t* __restrict__ summary_host) {
+                                                   char* __restrict__ arena, uint32_t* __restrict__ summary_host,
+                                                   const g2s::D3Side side) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   D3Summary* S = W.sum;
   const uint32_t i = blockIdx.x;
@@ -893,7 +939,33 @@ __global__ __launch_bounds__(64) void g2s_d3_trace(const D3Params P, const D3Wor
     leave(0u);
     return;
   }
-  if (gi & GI_HOST) { leave(0u); return; }  // (g2s_d3_handoff gave it to the host, which writes its record and text)
+  if (gi & GI_HOST) {
+    // The host analyses this gap's closure (a k-mer at two depths) and traces it, while the other gaps' waves work:
+    // its record, closure segments and the rand() values of its traceback go to pinned memory, then the item's
+    // ready word (the host polls it; it knows from *side.count how many items to expect).
+    const uint32_t it = uni(W.host_slot[i]);
+    if (it != 0xFFFFFFFFu) {
+      const g2s::D3HostItem* hp = &W.hitems[it];
+      const uint64_t so = (uint64_t)uni((uint32_t)hp->seg_off) | ((uint64_t)uni((uint32_t)(hp->seg_off >> 32)) << 32);
+      const uint64_t ro = (uint64_t)uni((uint32_t)hp->rnd_off) | ((uint64_t)uni((uint32_t)(hp->rnd_off >> 32)) << 32);
+      const uint32_t ns = uni(hp->n_segs), want = uni(hp->draws);
+      const GapOut& g = outs[i];
+      if ((uint32_t)lane < sizeof(GapOut) / 4u) ((uint32_t*)&side.outs[it])[lane] = ((const uint32_t*)&g)[lane];
+      const uint4* src = (const uint4*)(sub + td.sub_at);
+      uint4* dst = (uint4*)(side.segs + so);
+      for (uint32_t w = (uint32_t)lane; w < 2u * ns; w += 64u) dst[w] = src[w];
+      for (uint32_t w = (uint32_t)lane; w < want + 1u; w += 64u) side.rnd[ro + w] = rnd[td.off + w];
+      __threadfence_system();  // (the whole wave's stores are in host memory before the item says so)
+      if (lane == 0) {
+        g2s::D3HostItem h;
+        h.gap = i; h.n_segs = ns; h.seg_off = so; h.rnd_off = ro; h.draws = want; h.pad = 0;
+        side.items[it] = h;
+        __hip_atomic_store(&side.items[it].pad, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+    leave(0u);
+    return;
+  }
   // ---- the closure into LDS
   // (closures the device analysed have at most seg_cap segments; a longer one would be the host path's business)
   const uint32_t nsegs = min((uint32_t)td.nsegs, P.seg_cap);
@@ -1118,8 +1190,8 @@ void rand_tables_host(uint32_t* hi, uint32_t* mid, uint32_t* lane) {
 
 size_t d3_work_bytes(uint32_t n) {
   const size_t per = (((size_t)n + 64) * 4 + 63) & ~(size_t)63;
-  return 13 * per + 64 * 128 + (size_t)G2S_D3_TABLE_BUDGET * 2 + (size_t)(G2S_D3_TABLE_BUDGET / 4u) * 4 + 4096 +
-         ((size_t)n + 64) * (sizeof(D3Var) + sizeof(D3Trace)) + ((size_t)n + G2S_D3_TABLE_BUDGET / 256u + 64) * 4;
+  return 14 * per + 64 * 128 + (size_t)G2S_D3_TABLE_BUDGET * 2 + (size_t)(G2S_D3_TABLE_BUDGET / 4u) * 4 + 4096 +
+         ((size_t)n + 64) * (sizeof(D3Var) + sizeof(D3Trace) + sizeof(D3HostItem)) + ((size_t)n + G2S_D3_TABLE_BUDGET / 256u + 64) * 4;
 }
 
 void d3_work_carve(void* p, uint32_t n, D3Work* w) {
@@ -1140,8 +1212,10 @@ void d3_work_carve(void* p, uint32_t n, D3Work* w) {
   w->blk_in = (uint32_t*)c; c += per;
   w->dvar = (uint32_t*)c; c += per;
   w->skip = (int32_t*)c; c += per;
+  w->host_slot = (uint32_t*)c; c += per;
   w->vdesc = (D3Var*)c; c += ((size_t)n + 64) * sizeof(D3Var);     // (c is a multiple of 64 here)
   w->tdesc = (D3Trace*)c; c += ((size_t)n + 64) * sizeof(D3Trace);
+  w->hitems = (D3HostItem*)c; c += ((size_t)n + 64) * sizeof(D3HostItem);
   w->tile_var = (uint32_t*)c; c += ((size_t)n + G2S_D3_TABLE_BUDGET / 256u + 64) * 4;
   w->btab = (uint32_t*)c; c += (size_t)(G2S_D3_TABLE_BUDGET / 4u) * 4;
   w->tab = (uint16_t*)c;
@@ -1187,7 +1261,7 @@ hipError_t launch_d3(hipStream_t st, const D3Params& P, const D3Work& W, const G
   e = hipFuncSetAttribute((const void*)g2s_d3_trace, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(g2s_d3_trace, dim3(P.n), dim3(64), lds, st, P, W, outs, sub, lastch_up, lastch_dn, rnd_all + 31, rnd_capacity,
-                     (g2s_result*)results, arena, (uint32_t*)summary_host);
+                     (g2s_result*)results, arena, (uint32_t*)summary_host, side);
   return hipGetLastError();
 }
 

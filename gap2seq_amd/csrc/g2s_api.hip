@@ -555,6 +555,7 @@ struct g2s_session {
   std::vector<uint32_t> res_ids, res_at;  // launch order of a resident list and its counting sort, kept between lists
   bool in_team_list = false;     // the session is filling a group of a team's list (team_resident)
   bool team_shares_device = false;  // ... and another session of the team sits on the same device
+  size_t side_dirty = SIZE_MAX;  // items of h_side whose ready word may be set (resident mode's hand-over)
   uint32_t timed_seq = 0;        // resident launches so far (one in eight is bracketed with HIP events)
   int resident_strikes = 0;      // lists that had to be run again on the host path; three in a row switch the mode off
   bool resident_off = false;
@@ -2565,12 +2566,16 @@ static int resident_d3(g2s_session* s, const ResidentList& L, bool timed, bool r
     side_h.cap_rnd = rnd_cap / 8 + 65536u;
     const size_t b_items = (n * sizeof(D3HostItem) + 63) & ~(size_t)63, b_outs = (n * sizeof(GapOut) + 63) & ~(size_t)63;
     const size_t b_segs = side_h.cap_segs * sizeof(SegRec);
+    const void* side_was = s->h_side.p;
     HIP_TRY(s->h_side.ensure(b_items + b_outs + b_segs + side_h.cap_rnd * 4 + 128));
+    if (s->h_side.p != side_was) s->side_dirty = SIZE_MAX;  // (fresh memory: every ready word is to be zeroed)
     char* hp = (char*)s->h_side.p;
     side_h.items = (D3HostItem*)hp; side_h.outs = (GapOut*)(hp + b_items); side_h.segs = (SegRec*)(hp + b_items + b_outs);
     side_h.rnd = (uint32_t*)(hp + b_items + b_outs + b_segs);
     side_h.count = (unsigned long long*)(hp + b_items + b_outs + b_segs + ((side_h.cap_rnd * 4 + 63) & ~(size_t)63));
-    *(volatile unsigned long long*)side_h.count = ~0ull;  // (until the hand-over is complete)
+    *(volatile unsigned long long*)side_h.count = ~0ull;  // (until the number of items is known)
+    for (size_t x = 0, z = std::min(s->side_dirty, n); x < z; x++) side_h.items[x].pad = 0;  // the items' ready words
+    s->side_dirty = n;  // (until this list is through: any of them may be written)
     void* dp = nullptr;
     HIP_TRY(hipHostGetDevicePointer(&dp, s->h_side.p, 0));
     side = side_h;
@@ -2680,6 +2685,12 @@ static int resident_d3(g2s_session* s, const ResidentList& L, bool timed, bool r
   if (ni && !(handed >> 63) && !stage_dev) {
     char* text = arena_direct ? arena : (char*)s->h_text.p;
     auto one = [&](size_t x) {
+      // (the gap's wave of the trace kernel says when the item is complete)
+      for (unsigned spins = 0; __atomic_load_n(&side_h.items[x].pad, __ATOMIC_ACQUIRE) == 0u; spins++) {
+        if ((spins & 4095u) == 4095u && hipStreamQuery(st) != hipErrorNotReady &&
+            __atomic_load_n(&side_h.items[x].pad, __ATOMIC_ACQUIRE) == 0u) { host_bad.fetch_add(1); return; }
+        cpu_relax();
+      }
       const D3HostItem& h = side_h.items[x];
       const size_t q = h.gap / L.group_size, loc = h.gap % L.group_size;
       const g2s_batch* gb = L.groups[q];
@@ -2723,6 +2734,7 @@ static int resident_d3(g2s_session* s, const ResidentList& L, bool timed, bool r
     return G2S_OK;
   }
   s->resident_strikes = 0;
+  s->side_dirty = ni;  // (the ready words this list set)
   // ---- results that went through staging
   if (!res_direct || !arena_direct) {
     const g2s_result* rs = res_direct ? results : (const g2s_result*)s->h_res.p;
