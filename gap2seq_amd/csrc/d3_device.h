@@ -129,7 +129,7 @@ struct D3Params {
   uint32_t group_size; // gaps per group of the list (a list filled by several sessions: one region of closure records
   uint64_t sub_region; // per group, sub_region 16-byte units apart); one group: group_size >= n
   uint32_t laps;       // G2S_DEBUG: the trace kernel's waves record their laps (atomics on a few words)
-  uint32_t pad;
+  uint32_t self_clean; // the trace kernel zeroes the gaps' records, the summary and the counters behind itself
 };
 
 // the stream: values [0, capacity) into rnd_all[31 ..] (sum_dev = nullptr; independent of the list's kernels, so
@@ -151,6 +151,7 @@ hipError_t launch_d3(hipStream_t st, const D3Params& P, const D3Work& W, const G
                      uint64_t rnd_capacity, void* results /* g2s_result[n], device-writable */,
                      char* arena /* device-writable */, const D3Side& side /* *side.count: ~0 until the hand-over is complete */,
                      void* summary_host /* device-visible pinned memory: D3Summary in 1024 bytes, then the 64 fill-byte counters */,
-                     bool summary_is_clean /* the summary and the counters are zero already */);
+                     bool summary_is_clean /* the summary and the counters are zero already */,
+                     uint32_t* clean_words /* with P.self_clean: eight words the last wave zeroes (the fill kernel's cursors); may be null */);
 
 }  // namespace g2s

@@ -829,12 +829,12 @@ __global__ __launch_bounds__(1024) void g2s_d3_back(const D3Params P, const D3Wo
 // ---------------------------------------------------------------------------------------------------------
 // (its first loads — the gap's D3Trace record, its GapOut record, the list's status — do not depend on each other;
 // the closure and the first rand() value follow from the D3Trace record: two round trips in front of the walk)
-__global__ __launch_bounds__(64) void g2s_d3_trace(const D3Params P, const D3Work W, const GapOut* __restrict__ outs,
+__global__ __launch_bounds__(64) void g2s_d3_trace(const D3Params P, const D3Work W, GapOut* __restrict__ outs,
                                                    const SubRec* __restrict__ sub, const char* __restrict__ chu,
                                                    const char* __restrict__ chd, const uint32_t* __restrict__ rnd,
                                                    uint64_t capacity, g2s_result* __restrict__ results,
                                                    char* __restrict__ arena, uint32_t* __restrict__ summary_host,
-                                                   const g2s::D3Side side) {
+                                                   const g2s::D3Side side, uint32_t* __restrict__ clean_words /* or null */) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   D3Summary* S = W.sum;
   const uint32_t i = blockIdx.x;
@@ -885,10 +885,17 @@ __global__ __launch_bounds__(64) void g2s_d3_trace(const D3Params P, const D3Wor
       const unsigned long long before = atomicAdd(&W.fill_bytes[c * 16u], (unsigned long long)fill_len | (1ull << 40));
       if ((uint32_t)(before >> 40) + 1u == (n + 63u - c) / 64u) last = atomicAdd(&S->trace_waves, 1u) + 1u == min(n, 64u) ? 1u : 0u;
     }
+    // (self_clean — a list that is one batch on one session: what the next list's kernels expect to find zero is
+    // zeroed here instead of by three memsets behind the kernel, which cost the host 10 us between two lists: this
+    // gap's record, and by the last wave the summary, the counters and the fill kernel's cursors)
+    if (P.self_clean && (uint32_t)lane < sizeof(GapOut) / 4u) ((uint32_t*)&outs[i])[lane] = 0u;
     if (!uni(last)) return;
     uint32_t* src = (uint32_t*)S;
-    for (uint32_t w = (uint32_t)lane; w < (1024u + 64u * 128u) / 4u; w += 64u)
+    for (uint32_t w = (uint32_t)lane; w < (1024u + 64u * 128u) / 4u; w += 64u) {
       summary_host[w] = __hip_atomic_load(src + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (P.self_clean) src[w] = 0u;
+    }
+    if (P.self_clean && clean_words && lane < 8) clean_words[lane] = 0u;
   };
   if (status) { leave(0u); return; }  // (the records in front of this kernel were not written: nothing below may run)
   const uint32_t gi = td.gi;
@@ -1230,7 +1237,7 @@ hipError_t launch_rand_fill(hipStream_t st, uint32_t* rnd_all, const RandTables&
 hipError_t launch_d3(hipStream_t st, const D3Params& P, const D3Work& W, const GapDev* gaps, const GapOut* outs,
                      const D3Gap* dgaps, const SubRec* sub, const char* lastch_up, const char* lastch_dn,
                      const RandTables& rt, uint32_t* rnd_all, uint64_t rnd_capacity, void* results, char* arena,
-                     const D3Side& side, void* summary_host, bool summary_is_clean) {
+                     const D3Side& side, void* summary_host, bool summary_is_clean, uint32_t* clean_words) {
   if (P.n == 0) return hipSuccess;
   (void)gaps;
   (void)rt;
@@ -1260,8 +1267,8 @@ hipError_t launch_d3(hipStream_t st, const D3Params& P, const D3Work& W, const G
   const size_t lds = (size_t)P.seg_cap * (sizeof(SegRec) + 12) + (size_t)P.map_cap * 8 + 16;  // closure, base map, rand() values, the walk's segments
   e = hipFuncSetAttribute((const void*)g2s_d3_trace, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(g2s_d3_trace, dim3(P.n), dim3(64), lds, st, P, W, outs, sub, lastch_up, lastch_dn, rnd_all + 31, rnd_capacity,
-                     (g2s_result*)results, arena, (uint32_t*)summary_host, side);
+  hipLaunchKernelGGL(g2s_d3_trace, dim3(P.n), dim3(64), lds, st, P, W, const_cast<GapOut*>(outs), sub, lastch_up, lastch_dn, rnd_all + 31, rnd_capacity,
+                     (g2s_result*)results, arena, (uint32_t*)summary_host, side, clean_words);
   return hipGetLastError();
 }
 

@@ -520,6 +520,7 @@ struct g2s_session {
   RandCache rcache;
   BgWorker bg;
   WorkerPool* pool = nullptr;
+  WorkerPool* team_pool = nullptr;  // (a lead session's) one thread per other session of a team
   bool no_lds_tier = false;  // G2S_NO_LDS_TIER=1: force the general HBM tier (tests, A/B timing)
   size_t mem_budget = 0;  // bytes of HBM this session may use for work areas
   DevBuf d_gaps, d_ids, d_flank, d_outs, d_rs, d_rlog, d_keys, d_cnt, d_mark, d_slog, d_subscr, d_subout, d_counter;
@@ -555,6 +556,7 @@ struct g2s_session {
   std::vector<uint32_t> res_ids, res_at;  // launch order of a resident list and its counting sort, kept between lists
   bool in_team_list = false;     // the session is filling a group of a team's list (team_resident)
   bool team_shares_device = false;  // ... and another session of the team sits on the same device
+  bool self_cleaned = false;     // the last list's trace kernel zeroed records, summary and cursors behind itself
   size_t side_dirty = SIZE_MAX;  // items of h_side whose ready word may be set (resident mode's hand-over)
   uint32_t timed_seq = 0;        // resident launches so far (one in eight is bracketed with HIP events)
   int resident_strikes = 0;      // lists that had to be run again on the host path; three in a row switch the mode off
@@ -647,6 +649,7 @@ extern "C" void g2s_session_destroy(g2s_session* s) {
                     &s->d_log, &s->d_lvl, &s->d_plk, &s->d_xl, &s->d_xo, &s->d_rspool, &s->d_logpool, &s->d_segx};
   for (DevBuf* b : bufs) b->release();
   delete s->pool;
+  delete s->team_pool;
   for (PinBuf* pb : s->pin_free) { pb->release(); delete pb; }
   s->d_lk_kmers.release(); s->d_lk_bucket.release(); s->d_lk_rank2id.release(); s->d_lk_flip.release();
   for (void* v : s->tier_pool) { TierData* t = (TierData*)v; t->outs.release(); t->subs.release(); t->done.release(); delete t; }
@@ -2632,9 +2635,11 @@ static int resident_d3(g2s_session* s, const ResidentList& L, bool timed, bool r
     if (q != hipSuccess) HIP_TRY(hipStreamWaitEvent(st, s->ev_rand, 0));
   }
   // (the time of phase D3's kernels: from the end of this session's fill kernel, or — a team's list — from here)
+  // (one batch on this session: the event behind its fill kernel; a team's list: an event of its own — the lead
+  // may not have launched a fill kernel at all)
   hipEvent_t d3_begin = s->ev[2];
   if (L.ready) HIP_TRY(hipStreamWaitEvent(st, L.ready, 0));
-  if (timed && (L.ready || L.groups.size() > 1)) {
+  if (timed && !(L.groups.size() == 1 && L.outs_dev == (const GapOut*)s->d_outs.p)) {
     HIP_TRY(hipEventRecord(s->ev[0], st));
     d3_begin = s->ev[0];
   }
@@ -2647,13 +2652,16 @@ static int resident_d3(g2s_session* s, const ResidentList& L, bool timed, bool r
   P.group_size = (uint32_t)std::max<size_t>(L.group_size, 1);
   P.sub_region = L.sub_region;
   P.laps = getenv("G2S_DEBUG") ? 1u : 0u;
-  P.pad = 0;
+  // (one batch on this session: the kernels read this session's own records and cursors, and clean up behind
+  // themselves; not while the lap stamps are wanted — they live in the summary's slot)
+  const bool self_clean = L.groups.size() == 1 && L.outs_dev == (const GapOut*)s->d_outs.p && !P.laps;
+  P.self_clean = self_clean ? 1u : 0u;
   P.seg_cap = fp.skip_confident ? G2S_SEG_CAP : 192u;
   P.map_cap = ((uint32_t)L.dmax + 2u + 3u) & ~3u;
   HIP_TRY(launch_d3(st, P, W, L.gaps_dev, L.outs_dev, dgap_on_device ? (const D3Gap*)s->d_dgap.p : (const D3Gap*)d_dgaps, L.sub_dev,
                     (const char*)s->d_lastch.p, (const char*)s->d_lastch.p + g.n, s->rtab, (uint32_t*)s->d_rnd.p,
                     (uint64_t)rnd_cap, res_dev, (char*)arena_dev, side, (char*)d_dgaps + ((char*)hsum - (char*)L.pin->p),
-                    s->d_d3.clean >= 1024 + 64 * 128));
+                    s->d_d3.clean >= 1024 + 64 * 128, self_clean ? (uint32_t*)s->d_counter.p : nullptr));
   s->d_d3.clean = 0;
   if (timed) HIP_TRY(hipEventRecord(s->ev[3], st));
   if (stage_dev) {
@@ -2717,9 +2725,10 @@ static int resident_d3(g2s_session* s, const ResidentList& L, bool timed, bool r
             lp[14] / 100.0, lp[15] / 100.0, lp[16] / 100.0, lp[17] / 100.0, us(13, 18));
     fprintf(stderr, "[g2s] the wave with the longest walk: %.1f us, %llu segments entered in %.1f us\n", (double)(lp[19] >> 32) / 100.0, (lp[19] >> 16) & 0xFFFF, (double)(lp[19] & 0xFFFF) / 100.0);
   }
-  // (the summary is zeroed for the next list now, off its critical path)
-  HIP_TRY(hipMemsetAsync(W.sum, 0, 1024 + 64 * 128, st));
+  // (the summary is zero again for the next list: the trace kernel did it, or a memset now, off the critical path)
+  if (!self_clean) HIP_TRY(hipMemsetAsync(W.sum, 0, 1024 + 64 * 128, st));
   s->d_d3.clean = 1024 + 64 * 128;
+  s->self_cleaned = self_clean && hsum->status == 0;  // (a list the kernels gave up on: its waves left early)
   for (int q = 0; q < 64; q++)  // (bits 40 and up count the trace kernel's waves: d3_device.hip)
     hsum->fill_bytes += ((const unsigned long long*)((const char*)hsum + 1024))[q * 16] & ((1ull << 40) - 1);
   hsum->fill_bytes += host_fill_bytes;
@@ -2815,7 +2824,9 @@ int run_resident(g2s_batch* b, g2s_result* results, char* arena) {
   bool fell_back = false;
   const int rc = resident_d3(s, L, rl.timed, rand_launched, results, arena, &b->timing, &ms_d3, &fell_back);
   if (rc != G2S_OK) return rc;
-  { const int r2 = resident_reset_fill(s, n); if (r2 != G2S_OK) return r2; }
+  if (s->self_cleaned) { s->d_outs.clean = n * sizeof(GapOut); s->d_counter.clean = 32; }
+  else { const int r2 = resident_reset_fill(s, n); if (r2 != G2S_OK) return r2; }
+  s->self_cleaned = false;
   if (fell_back) { b->timing.resident_fallbacks++; return 1; }
   float ms_fill = 0;
   if (rl.timed) HIP_TRY(hipEventElapsedTime(&ms_fill, s->ev[1], s->ev[2]));
@@ -2988,10 +2999,15 @@ static int team_resident(g2s_session* const* sessions, int nsessions, const g2s_
     }
   };
   {
-    std::vector<std::thread> th;
-    for (int t = 1; t < nsessions; t++) th.emplace_back(worker, t);
-    worker(0);
-    for (auto& x : th) x.join();
+    // one host thread per session, from the lead's team pool (persistent: creating and joining a thread per
+    // session and list cost a 10 000-gap list on eight sessions 0.2 ms)
+    if (nsessions > 1 && (!lead->team_pool || lead->team_pool->size() < nsessions - 1)) {
+      delete lead->team_pool;
+      lead->team_pool = new WorkerPool(nsessions - 1);
+    }
+    const std::function<void(size_t)> job = [&](size_t t) { worker((int)t); };
+    if (nsessions > 1) lead->team_pool->run((size_t)nsessions, job);
+    else worker(0);
   }
   int rc = G2S_OK;
   for (int t = 0; t < nsessions; t++) if (rcs[(size_t)t] != G2S_OK) { rc = rcs[(size_t)t]; tl_error = errs[(size_t)t]; }
@@ -3158,10 +3174,15 @@ extern "C" int g2s_team_fill(g2s_session* const* sessions, int nsessions, const 
     }
   };
   {
-    std::vector<std::thread> th;
-    for (int t = 1; t < nsessions; t++) th.emplace_back(worker, t);
-    worker(0);
-    for (auto& x : th) x.join();
+    // one host thread per session, from the lead's team pool (persistent: creating and joining a thread per
+    // session and list cost a 10 000-gap list on eight sessions 0.2 ms)
+    if (nsessions > 1 && (!lead->team_pool || lead->team_pool->size() < nsessions - 1)) {
+      delete lead->team_pool;
+      lead->team_pool = new WorkerPool(nsessions - 1);
+    }
+    const std::function<void(size_t)> job = [&](size_t t) { worker((int)t); };
+    if (nsessions > 1) lead->team_pool->run((size_t)nsessions, job);
+    else worker(0);
   }
   lead->bg.wait();
   int rc = G2S_OK;

@@ -130,8 +130,8 @@ def test_resident_mode_scaffold_records_and_the_skip_rule(product, oracle, monke
     assert out["1"][0] == ofa and out["1"][1] == olog
 
 
-@pytest.mark.parametrize("nsess,group", [(1, 400), (2, 700), (3, 300), (4, 97)])
-def test_team_on_the_devices_equals_one_session(product, monkeypatch, nsess, group):
+@pytest.mark.parametrize("nsess,group,timing", [(1, 400, None), (2, 700, "all"), (3, 300, "off"), (4, 97, None), (4, 5000, "all")])
+def test_team_on_the_devices_equals_one_session(product, monkeypatch, nsess, group, timing):
     """g2s_team_fill with the list finished on the devices: every session runs the fill kernel of the groups it
     pulls, the groups' records and closures are gathered on the lead's device and phase D3 runs once over the
     whole list (the stream offsets chain through the groups).  Same results as one session on the host path,
@@ -147,11 +147,15 @@ def test_team_on_the_devices_equals_one_session(product, monkeypatch, nsess, gro
     want2 = [_key(r) for r in solo.fill_batch(gaps[:200])]
     solo.destroy()
     monkeypatch.delenv("G2S_RESIDENT")
+    if timing:  # HIP events around every resident launch, or none (default: one launch in eight); one group of
+        monkeypatch.setenv("G2S_KERNEL_TIMING", timing)  # four sessions: the lead may not launch a fill kernel at all
     team = [product.Session(pg, 0, d_err=500, randseed=9) for _ in range(nsess)]
     try:
         got, tm = product.team_fill(team, gaps, group_size=group, want_timing=True)
         assert [_key(r) for r in got] == want
         assert tm.resident_launches == 1 and tm.resident_fallbacks == 0
+        assert tm.seg_timed_launches == (0 if timing == "off" else tm.seg_launches if timing == "all" else tm.seg_timed_launches)
+        assert (tm.ms_fill_seg > 0) == (tm.seg_timed_launches > 0)
         ngroups = -(-len(gaps) // group)
         assert tm.team_groups == ngroups and tm.team_sessions == nsess and tm.seg_launches == ngroups
         assert sum(tm.team_groups_by_session[i] for i in range(16)) == ngroups
