@@ -324,6 +324,7 @@ __device__ __forceinline__ void d3_scan_body(const D3Params& P, const D3Work& W,
       s8[q] = have ? ds_a[i] : 0u;
     }
   };
+  if (t == 0) stamp(W, 20);
   uint64_t sd = 0, ss = 0;
   uint32_t nv = 0;
   for (uint32_t i0 = lo; i0 < hi; i0 += 8u) {
@@ -343,6 +344,7 @@ __device__ __forceinline__ void d3_scan_body(const D3Params& P, const D3Work& W,
     block_scan3_short(a, b, nv, (uint32_t*)sh, &ta, &tb, &V);
     sd = a; ss = b; tot_d = ta; tot_s = tb;
   } else block_scan3(sd, ss, nv, sh, &tot_d, &tot_s, &V);
+  if (t == 0) stamp(W, 21);
   const bool too_wide = tot_d + tot_s >= 0xFFFF0000ull || tot_s >= (uint64_t)G2S_D3_TABLE_BUDGET;
   uint64_t my_tab = 0, my_blk = 0;
   uint32_t my_tiles = 0;
@@ -374,6 +376,7 @@ __device__ __forceinline__ void d3_scan_body(const D3Params& P, const D3Work& W,
     if (t == 1023u) W.var_R[V] = (uint32_t)tot_s;
   }
   // ---- where every table starts
+  if (t == 0) stamp(W, 22);
   uint64_t to = my_tab, bo = my_blk, T, TB;
   uint32_t tl = my_tiles, tiles;
   if (short_list) {
@@ -419,6 +422,7 @@ __device__ __forceinline__ void d3_scan_body(const D3Params& P, const D3Work& W,
     if (t == 1023u) { W.var_toff[V] = (uint32_t)T; W.var_tile[V] = tiles; W.blk_toff[(V + G2S_D3_BLOCK_VARS - 1u) / G2S_D3_BLOCK_VARS] = (uint32_t)TB; }
   }
   if (t == 0) {
+    stamp(W, 23);
     D3Summary* S = W.sum;
     S->status = (unhandled ? G2S_D3_UNHANDLED : 0u) | (over ? G2S_D3_BUDGET : 0u);
     S->n_var = V;
@@ -432,7 +436,8 @@ __device__ __forceinline__ void d3_scan_body(const D3Params& P, const D3Work& W,
 __global__ __launch_bounds__(1024) void g2s_d3_scan(const D3Params P, const D3Work W, const GapOut* __restrict__ outs) {
   __shared__ uint64_t sh[96];
   __shared__ uint32_t sh_f[1024];
-  d3_scan_body(P, W, outs, W.ginfo, W.dmin, W.dspread, W.skip, false, W.sum->unhandled, sh, sh_f, false);
+  // (the 32-bit block scans: a list in this mode has at most 20 480 gaps of at most 12 000 draws each)
+  d3_scan_body(P, W, outs, W.ginfo, W.dmin, W.dspread, W.skip, false, W.sum->unhandled, sh, sh_f, P.n <= 262144u);
 }
 
 // ---------------------------------------------------------------------------------------------------------
