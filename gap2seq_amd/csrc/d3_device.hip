@@ -1027,9 +1027,8 @@ __global__ __launch_bounds__(64) void g2s_d3_trace(const D3Params P, const D3Wor
   const int len = d2;
   bool bad = false, ended = false;
   if ((uint32_t)len + 1u > P.map_cap || (uint32_t)td.nsegs > P.seg_cap || td.want > P.map_cap) bad = true;
-  uint32_t* hop_top = lwin + P.map_cap;     // by hop: the depth at which the walk enters the segment (descending)
-  uint32_t* hop_rec = hop_top + P.seg_cap;  // the segment | its entry state << 16
-  uint32_t* nxt = hop_rec + P.seg_cap;      // by segment: the parent a traceback goes on to from its first state
+  uint2* hop = (uint2*)(lwin + P.map_cap);  // by hop: the depth at which the walk enters the segment (descending), the segment | its entry state << 16
+  uint2* pk = hop + P.seg_cap;              // by segment: depth | length << 16, the parent a traceback goes on to from its first state | source << 30 | no way on << 31
   // (Every traced base draws one value — :1513 draws for a single parent too — so the draw made at depth d is the
   // (1 + len - d)-th of the gap whatever the path: the parent a traceback takes from a segment's first state is a
   // property of the segment.  All lanes work those out; the walk itself then reads three words per segment.)
@@ -1045,7 +1044,7 @@ __global__ __launch_bounds__(64) void g2s_d3_trace(const D3Params P, const D3Wor
       w = seg_parent(p01, p23, nb == 1 ? 0 : pick_parent(rv, nb));  // :1513
       if (w >= nsegs) w = 0x80000000u;
     }
-    nxt[q] = w;
+    pk[q] = make_uint2(dl, w | ((fl & G2S_SUB_SOURCE) ? 0x40000000u : 0u));
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_wave_barrier();
@@ -1057,19 +1056,20 @@ __global__ __launch_bounds__(64) void g2s_d3_trace(const D3Params P, const D3Wor
     if (si < 0 || si >= (int)nsegs || avail < 1) bad = true;
     for (int guard = 0; !bad && d2 >= 0; guard++) {
       if (P.laps) hops++;
-      const uint32_t dl = uni(segs[si].depth_len), fl = uni(segs[si].flags), nx = uni(nxt[si]);
+      const uint2 w2 = pk[si];  // (one LDS read per segment entered)
+      const uint32_t dl = uni(w2.x), nx = uni(w2.y);
       const int d0 = (int)(dl & 0xFFFFu);
       if (guard > 0) t = (int)(dl >> 16) - 1;  // (a child in the closure puts the whole parent there)
       if (d0 + t != d2 || nh >= (int)P.seg_cap) { bad = true; break; }  // (state t of a segment that begins at depth d0 sits at depth d0 + t)
-      if (lane == 0) { hop_top[nh] = (uint32_t)d2; hop_rec[nh] = (uint32_t)si | ((uint32_t)t << 16); }
+      if (lane == 0) hop[nh] = make_uint2((uint32_t)d2, (uint32_t)si | ((uint32_t)t << 16));
       nh++;
       draws += t;
       d2 -= t;
-      if (fl & G2S_SUB_SOURCE) { left_fuz = (int)dg.lmf - d2; ended = true; break; }  // :1455-1462
+      if (nx & 0x40000000u) { left_fuz = (int)dg.lmf - d2; ended = true; break; }  // :1455-1462
       if (d2 > 0) {
         if (nx & 0x80000000u) { bad = true; break; }
         draws++;
-        si = (int)nx;
+        si = (int)(nx & 0xFFFFu);
       }
       d2--;
     }
@@ -1086,17 +1086,19 @@ __global__ __launch_bounds__(64) void g2s_d3_trace(const D3Params P, const D3Wor
     int lowest_safe = 0x7FFFFFFF;
     if (cnt > 0) {
       int lo = 0, hi = nh;  // the last hop entered at or above hi_d
-      while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int)hop_top[mid] >= hi_d) lo = mid; else hi = mid; }
+      while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int)hop[mid].x >= hi_d) lo = mid; else hi = mid; }
       int h = lo;
-      uint32_t rec = hop_rec[h];
-      int top = (int)hop_top[h], d0 = top - (int)(rec >> 16);
+      uint2 hr = hop[h];
+      uint32_t rec = hr.y;
+      int top = (int)hr.x, d0 = top - (int)(rec >> 16);
       SegW sg = segs[rec & 0xFFFFu];
       for (int c = 0; c < cnt; c++) {
         const int p = hi_d - c;
         if (p < d0) {  // the next hop begins right below
           h++;
-          rec = hop_rec[h];
-          top = (int)hop_top[h]; d0 = top - (int)(rec >> 16);
+          hr = hop[h];
+          rec = hr.y;
+          top = (int)hr.x; d0 = top - (int)(rec >> 16);
           sg = segs[rec & 0xFFFFu];
         }
         const int q = p - d0;
@@ -1269,7 +1271,7 @@ hipError_t launch_d3(hipStream_t st, const D3Params& P, const D3Work& W, const G
     hipLaunchKernelGGL(g2s_d3_chain, dim3(1), dim3(1024), 0, st, W, rnd_all);
     hipLaunchKernelGGL(g2s_d3_handoff, dim3((P.n + 63u) / 64u), dim3(64), 0, st, P, W, outs, sub, rnd_all + 31, rnd_capacity, side);
   }
-  const size_t lds = (size_t)P.seg_cap * (sizeof(SegRec) + 12) + (size_t)P.map_cap * 8 + 16;  // closure, base map, rand() values, the walk's segments
+  const size_t lds = (size_t)P.seg_cap * (sizeof(SegRec) + 16) + (size_t)P.map_cap * 8 + 16;  // closure, base map, rand() values, the walk's segments
   e = hipFuncSetAttribute((const void*)g2s_d3_trace, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(g2s_d3_trace, dim3(P.n), dim3(64), lds, st, P, W, const_cast<GapOut*>(outs), sub, lastch_up, lastch_dn, rnd_all + 31, rnd_capacity,

@@ -844,12 +844,13 @@ extern "C" int g2s_batch_prepare(g2s_session* s, const g2s_gap* gaps, size_t n, 
     uint32_t q = 0;
     for (size_t i = 0; i < n; i++) didx[i] = b->jobs[i].bad_flank ? 0xFFFFFFFFu : q++;
     const size_t per_task = std::max<size_t>(256, (n + 15) / 16);  // (at most 16 tasks: every task wakes a thread)
-    auto do_range = [&](size_t t) {
+    // (what: 1 = flank text and look-up descriptors, 2 = the fill kernel's and phase D3's descriptors, 3 = both)
+    auto do_range = [&](size_t t, int what) {
       const size_t lo = t * per_task, hi = std::min(n, lo + per_task);
       for (size_t i = lo; i < hi; i++) {
         GapJob& j = b->jobs[i];
         j.nodes = b->nodes + b->flank_off[i];
-        if (fast_gd) {
+        if (fast_gd && (what & 2)) {
           GapDev& d = fast_gd[i];
           memset(&d, 0, sizeof d);
           D3Gap& q = fast_dg[i];
@@ -867,7 +868,7 @@ extern "C" int g2s_batch_prepare(g2s_session* s, const g2s_gap* gaps, size_t n, 
             d.flank_off = b->flank_off[i];
           }
         }
-        if (j.bad_flank) continue;
+        if (j.bad_flank || !(what & 1)) continue;
         const g2s_gap& in = gaps[i];
         char* t = b->text + text_off[i];
         const size_t ll = (size_t)(k + j.lmf), rl2 = (size_t)(k + j.rmf);
@@ -888,8 +889,15 @@ extern "C" int g2s_batch_prepare(g2s_session* s, const g2s_gap* gaps, size_t n, 
       }
     };
     const size_t ntasks = (n + per_task - 1) / per_task;
-    if (ntasks > 4) s->pool->run(ntasks, do_range);
-    else for (size_t t = 0; t < ntasks; t++) do_range(t);
+    if (ntasks > 4) s->pool->run(ntasks, [&](size_t t) { do_range(t, 3); });
+    else if (fast_gd) {
+      // a short list on this thread: the look-up kernel is launched as soon as its input is there, the other
+      // descriptors are written while it runs
+      for (size_t t = 0; t < ntasks; t++) do_range(t, 1);
+      const int rc0 = b->upload_flanks();
+      if (rc0 != G2S_OK) { delete b; return rc0; }
+      for (size_t t = 0; t < ntasks; t++) do_range(t, 2);
+    } else for (size_t t = 0; t < ntasks; t++) do_range(t, 3);
   }
   const auto tp2 = std::chrono::steady_clock::now();
   const int rc = b->upload_flanks();
