@@ -277,6 +277,14 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
   // before they took their tickets — and enters the whole batch in done_list.  The XCD is read from the hardware
   // register, not inferred from the block index.  Gaps of a batch that never completes are not announced: the
   // host takes them at the end of the launch, which flushes everything.
+  // MEMORY-MODEL ASSUMPTION of the batches (not something the HIP memory model promises; checked on gfx950 by
+  // the parity suite and the fuzz campaigns on the host path, where every announced gap is compared with the oracle):
+  // plain stores of wave A to fine-grained host memory that A has waited for ("s_waitcnt vmcnt(0)") sit in the L2 of
+  // A's XCD, and a later "buffer_wbl2 sc0 sc1" by ANOTHER wave B of the same XCD writes them back with B's own.
+  // The ticket (an agent-scope atomic A performs after its wait) is what orders A's stores before B's write-back.
+  // Since round 3 this path only serves the host path of lists beyond 2 048 gaps (G2S_RESIDENT=0, or a list the
+  // device gave back): resident mode announces nothing.  A batch whose closing wave gives up waiting (2^18 looks:
+  // never seen) or that never fills is not lost — the host takes every gap not announced when the launch has ended.
   // The large variant's workgroups publish what several waves stored: it keeps the fences.
   auto publish = [&]() {
     if (A.resident) return;
@@ -389,6 +397,9 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
     }
   };
   unsigned long long cyc_a_end = cyc0;
+#ifdef G2S_SEG_PROFILE
+  uint32_t prof_a[4] = {0, 0, 0, 0};  // phase A (one wave per gap): records wait | probes + atomics | results, slow path, queue | rest of the round
+#endif
   if constexpr (!BIG) {
    if (!TWO || wave == 1) {
     for (uint32_t i = (uint32_t)lane; i < ALAB; i += 64u) lab[i] = G2S_DEV_EMPTY64;
@@ -439,76 +450,78 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
         uint32_t* qn = aq0 + (cur ^ 1u) * ACAP;
         uint32_t* qns = aqs + (cur ^ 1u) * ACAP;
         uint32_t nn = 0;
-        for (uint32_t e0 = 0; e0 < ne && !overflow; e0 += 64u) {
-          const bool mine = e0 + (uint32_t)lane < ne;
-          const uint32_t v = mine ? qc[e0 + (uint32_t)lane] : 0u;
-          const uint32_t slot = mine ? qcs[e0 + (uint32_t)lane] : 0u;
+#ifdef G2S_SEG_PROFILE
+        unsigned long long pa_round = __builtin_amdgcn_s_memtime(), pa_in = 0;
+#endif
+        // Lane = (entry, predecessor slot): sixteen entries and their four proposals each per pass.  (Lane = entry
+        // with a loop over the four slots spent 70 % of a round's 3.7-4.4 k cycles in four rounds of hashing,
+        // probing, ballots and queue appends for the 3-4 entries a round has on average.)
+        for (uint32_t e0 = 0; e0 < ne && !overflow; e0 += 16u) {
+#ifdef G2S_SEG_PROFILE
+          const unsigned long long pa0 = __builtin_amdgcn_s_memtime();
+#endif
+          const uint32_t eidx = e0 + ((uint32_t)lane >> 2), q = (uint32_t)lane & 3u;
+          const bool mine = eidx < ne;
+          const uint32_t v = mine ? qc[eidx] : 0u;
+          const uint32_t slot = mine ? qcs[eidx] : 0u;
           // walking back from v = walking on from v^1: steps left in the unitig and the successor record
           // of the walk's last node (graph.predecessors(last)[i] = succ(last^1)[i] ^ 1) in one record,
           // asked for before the entry's label is read (the label comes from LDS while the record travels)
-          uint4 rec = make_uint4(G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID);
-          uint32_t r = 0;
+          uint32_t w = G2S_DEV_INVALID, r = 0;
           if (mine) {
-            const uint4* u = (const uint4*)(urec + (size_t)(v ^ 1u) * 8);
-            rec = u[0];
-            r = u[1].x;
+            const uint32_t* u = urec + (size_t)(v ^ 1u) * 8;
+            w = u[q];
+            r = u[4];
           }
+#ifdef G2S_SEG_PROFILE
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          const unsigned long long pa1 = __builtin_amdgcn_s_memtime();
+#endif
           const uint32_t d = mine ? (uint32_t)lab[slot] : 0u;  // the entry's current label
-          if (mine) labrem[slot] = r;
+          if (mine && q == 0u) labrem[slot] = r;
           const uint32_t steps = min(r, (uint32_t)gd.right_half - d);
           const bool live = mine && d + steps < (uint32_t)gd.right_half;  // (then steps == r: the record is the last node's)
           const uint32_t dchild = d + steps + 1u;
-          // the four proposals of every entry: first probes side by side (four reads, then four atomics in
-          // flight: one after the other they were eight dependent LDS round trips per round), the rare
-          // collision takes the general loop
-          const uint32_t wq[4] = {rec.x, rec.y, rec.z, rec.w};
-          uint32_t hq[4];
-          uint64_t cq[4], oldmin[4], oldcas[4];  // (one result register pair per atomic: none waits for another)
-          bool aq[4];
-#pragma unroll
-          for (int q = 0; q < 4; q++) {
-            aq[q] = live && wq[q] != G2S_DEV_INVALID;
-            hq[q] = a_hash(wq[q] ^ 1u);
+          // the proposal of this lane: first probe, then the atomic that fits what the probe saw; the rare collision
+          // takes the general loop
+          const bool act = live && w != G2S_DEV_INVALID;
+          const uint32_t pnode = w ^ 1u;
+          const uint64_t key = ((uint64_t)pnode << 32) | dchild;
+          const uint32_t hq = a_hash(pnode);
+          const uint64_t cq = act ? lab[hq] : 0ull;
+          uint64_t oldmin = 0ull, oldcas = 0ull;
+          const bool hit = act && (uint32_t)(cq >> 32) == pnode;
+          if (hit) oldmin = atomicMin((unsigned long long*)&lab[hq], (unsigned long long)key);
+          if (act && cq == G2S_DEV_EMPTY64)
+            oldcas = atomicCAS((unsigned long long*)&lab[hq], (unsigned long long)G2S_DEV_EMPTY64, (unsigned long long)key);
+#ifdef G2S_SEG_PROFILE
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          const unsigned long long pa2 = __builtin_amdgcn_s_memtime();
+#endif
+          const bool claimed = act && cq == G2S_DEV_EMPTY64 && oldcas == G2S_DEV_EMPTY64;
+          bool imp = (hit && oldmin > key) || claimed;
+          nA += (uint32_t)__popcll(__ballot(claimed));
+          uint32_t at = hq;
+          const bool slow = act && !hit && !claimed;  // another node there, or the slot was taken meanwhile
+          if (__ballot(slow)) { if (relabel(slow, pnode, dchild, hq, &at)) imp = true; }
+          const uint64_t m = __ballot(imp);
+          if (imp) {
+            const uint32_t pos = nn + (uint32_t)__popcll(m & below(lane));
+            if (pos < ACAP) { qn[pos] = pnode; qns[pos] = at; }
           }
-#pragma unroll
-          for (int q = 0; q < 4; q++) cq[q] = aq[q] ? lab[hq[q]] : 0ull;
-#pragma unroll
-          for (int q = 0; q < 4; q++) {
-            const uint32_t pnode = wq[q] ^ 1u;
-            const uint64_t key = ((uint64_t)pnode << 32) | dchild;
-            oldmin[q] = 0ull;
-            oldcas[q] = 0ull;
-            if (aq[q] && (uint32_t)(cq[q] >> 32) == pnode) oldmin[q] = atomicMin((unsigned long long*)&lab[hq[q]], (unsigned long long)key);
-            if (aq[q] && cq[q] == G2S_DEV_EMPTY64)
-              oldcas[q] = atomicCAS((unsigned long long*)&lab[hq[q]], (unsigned long long)G2S_DEV_EMPTY64, (unsigned long long)key);
-          }
-          // (all eight in flight before the first result is looked at: the empty statements keep the compiler
-          // from moving the tests of the results up into the branches above)
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int q = 0; q < 4; q++) asm volatile("" : "+v"(oldmin[q]), "+v"(oldcas[q]));
-#pragma unroll
-          for (int q = 0; q < 4; q++) {
-            const uint32_t pnode = wq[q] ^ 1u;
-            const uint64_t key = ((uint64_t)pnode << 32) | dchild;
-            const bool hit = aq[q] && (uint32_t)(cq[q] >> 32) == pnode;
-            const bool claimed = aq[q] && cq[q] == G2S_DEV_EMPTY64 && oldcas[q] == G2S_DEV_EMPTY64;
-            bool imp = (hit && oldmin[q] > key) || claimed;
-            nA += (uint32_t)__popcll(__ballot(claimed));
-            uint32_t at = hq[q];
-            const bool slow = aq[q] && !hit && !claimed;  // another node there, or the slot was taken meanwhile
-            if (__ballot(slow)) { if (relabel(slow, pnode, dchild, hq[q], &at)) imp = true; }
-            const uint64_t m = __ballot(imp);
-            if (imp) {
-              const uint32_t pos = nn + (uint32_t)__popcll(m & below(lane));
-              if (pos < ACAP) { qn[pos] = pnode; qns[pos] = at; }
-            }
-            nn += (uint32_t)__popcll(m);
-            // (the table has 2 ACAP slots: at most ACAP + 64 are ever taken, so every probe ends)
-            if (nn > ACAP || nA > ACAP) { overflow = true; flags |= G2S_DEV_OVERFLOW_A | G2S_DEV_WHY_RS; }
-          }
+          nn += (uint32_t)__popcll(m);
+          // (the table has 2 ACAP slots: at most ACAP + 64 are ever taken, so every probe ends)
+          if (nn > ACAP || nA > ACAP) { overflow = true; flags |= G2S_DEV_OVERFLOW_A | G2S_DEV_WHY_RS; }
+#ifdef G2S_SEG_PROFILE
+          const unsigned long long pa3 = __builtin_amdgcn_s_memtime();
+          prof_a[0] += (uint32_t)(pa1 - pa0); prof_a[1] += (uint32_t)(pa2 - pa1); prof_a[2] += (uint32_t)(pa3 - pa2);
+          pa_in += pa3 - pa0;
+#endif
         }
         lds_sync();
+#ifdef G2S_SEG_PROFILE
+        prof_a[3] += (uint32_t)(__builtin_amdgcn_s_memtime() - pa_round - pa_in);
+#endif
         cur ^= 1u;
         ne = nn;
       }
@@ -1451,6 +1464,7 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
     if (lane == 0) { o[0] = gi; o[1] = nA; o[2] = nseg; o[3] = flags; o[4] = roundsA; o[5] = gen; o[6] = (uint32_t)c_count; o[7] = best; }
 #ifdef G2S_SEG_PROFILE
     if (lane == 0) for (int pi = 0; pi < 4; pi++) o[dbg_words - 4u + pi] = prof_acc[pi];
+    if (lane == 0 && !TWO) for (int pi = 0; pi < 4; pi++) o[dbg_words - 14u + pi] = prof_a[pi];
 #endif
     if constexpr (!BIG) {  // (BIG: written while the entries were turned into intervals)
 #pragma unroll
@@ -1864,10 +1878,10 @@ namespace g2s {
 
 size_t fill_seg_lds_bytes() { return 4u * (7u * G2S_SEG_CAP + 32u); }
 size_t fill_seg2_lds_bytes() { return 4u * (7u * G2S_SEG_CAP + 32u + 2u * 128u * G2S_SEG_ASETS + 128u * G2S_SEG_ASETS + 4u * 64u * G2S_SEG_ASETS + 8u); }
-uint32_t fill_seg_dbg_words() { return 8u + 2u * 64u * G2S_SEG_ASETS + 6u * G2S_SEG_CAP + 10u; }  // (+10: profile words)
+uint32_t fill_seg_dbg_words() { return 8u + 2u * 64u * G2S_SEG_ASETS + 6u * G2S_SEG_CAP + 14u; }  // (+14: profile words)
 size_t fill_segx_lds_bytes() { return 4u * SEGX_LDS_WORDS; }
 size_t fill_segx_scratch_bytes(uint32_t workgroups) { return (size_t)workgroups * SEGX_SCR_WORDS * 4u; }
-uint32_t fill_segx_dbg_words() { return 8u + 2u * G2S_SEGX_EA + 6u * G2S_SEGX_CAP + 10u; }
+uint32_t fill_segx_dbg_words() { return 8u + 2u * G2S_SEGX_EA + 6u * G2S_SEGX_CAP + 14u; }
 
 hipError_t launch_fill_seg(hipStream_t st, uint32_t ngaps, const uint32_t* succ, const uint32_t* urec, const GapDev* gaps,
                            const uint32_t* gap_ids, const uint32_t* flank_nodes, SubRec* sub_out,

@@ -1300,6 +1300,8 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
           if (o[W - 4] | o[W - 3] | o[W - 2] | o[W - 1])  // (-DG2S_SEG_PROFILE builds) cycles of phase B's sections
             fprintf(f, "P %u %u %u %u %u %u %u %u %u %u\n", o[W - 4], o[W - 3], o[W - 2], o[W - 1], o[W - 8], o[W - 7], o[W - 6], o[W - 5],
                     o[W - 10], o[W - 9]);
+          if (o[W - 14] | o[W - 13] | o[W - 12] | o[W - 11])  // (the same builds, one wave per gap) cycles of phase A's sections
+            fprintf(f, "PA %u %u %u %u\n", o[W - 14], o[W - 13], o[W - 12], o[W - 11]);
           for (uint32_t e = 0; e < o[1] && e < ecap; e++) fprintf(f, "A %u %u\n", o[8 + 2 * e], o[9 + 2 * e]);
           for (uint32_t q = 0; q < o[2] && q < scap; q++)
             fprintf(f, "S %u %u %u %u %#x %#x %u\n", o[sb0 + 6 * q], o[sb0 + 6 * q + 1] & 0xFFFF, o[sb0 + 6 * q + 1] >> 16,

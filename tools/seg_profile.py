@@ -29,8 +29,10 @@ cur = None
 for ln in open(dump):
     p = ln.split()
     if p[0] == "gap":
-        cur = dict(gap=int(p[1]), nseg=int(p[5]), rounds=int(p[11]), prof=None)
+        cur = dict(gap=int(p[1]), nseg=int(p[5]), rounds=int(p[11]), rounds_a=int(p[9]), entries=int(p[3]), prof=None)
         rows.append(cur)
+    elif p[0] == "PA":
+        cur["pa"] = [int(x) for x in p[1:5]]
     elif p[0] == "P":
         cur["prof"] = [int(x) for x in p[1:5]]
         cur["tail"] = [int(x) for x in p[5:9]]
@@ -54,3 +56,12 @@ ws = sum(r["sync"][0] for r in rows); ls = sum(r["sync"][1] for r in rows)
 print("two waves: cycles waiting at the barrier for phase A %d, loading the right set behind it %d (all gaps)" % (ws, ls))
 for r in sorted(rows, key=lambda r: -(sum(r["prof"]) + sum(r["tail"]) + sum(r["sync"])))[:6]:
     print("gap %d: B rounds %d, wait for A %d, load %d, tail %d" % (r["gap"], sum(r["prof"]), r["sync"][0], r["sync"][1], sum(r["tail"])))
+
+pa = [r for r in rows if r.get("pa")]
+if pa:  # (one wave per gap: G2S_SEG_WAVES=1)
+    ta = [sum(r["pa"][i] for r in pa) for i in range(4)]
+    ra = sum(r["rounds_a"] for r in pa)
+    print("phase A: %d rounds, %d entries | cycles per round %.0f: records wait %.1f%% probes + atomics %.1f%% results, slow path, queue %.1f%% rest of the round %.1f%%" % (
+        ra, sum(r["entries"] for r in pa), sum(ta) / max(1, ra), *[100.0 * x / max(1, sum(ta)) for x in ta]))
+    for r in sorted(pa, key=lambda r: -sum(r["pa"]))[:6]:
+        print("gap %d: A rounds %d entries %d cycles %d: wait %d probes %d results %d rest %d" % (r["gap"], r["rounds_a"], r["entries"], sum(r["pa"]), *r["pa"]))
