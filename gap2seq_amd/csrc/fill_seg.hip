@@ -881,19 +881,6 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
     }
     ev |= 1ull << l;
   };
-  // phase C: target k-mer j at position t of a segment is a hit at depth + t (lane j holds target j)
-  auto note_hits = [&](uint32_t node, uint32_t L, int depth, uint32_t c, uint32_t st) {
-    const int t = seg_pos(node, L, tg);
-    for (uint64_t hm = __ballot(t >= 0); hm; hm &= hm - 1) {
-      const int j = __builtin_ctzll(hm);
-      const int td = depth + (int)rl((uint32_t)t, j), base = gd.g + lmf + j;
-      const int err = td >= base ? td - base : base - td;
-      if (err > gd.e) continue;
-      const uint32_t key = ((uint32_t)(err + gd.g + lmf + rmf) << 6) | (uint32_t)j;
-      if (key < best) { best = key; c1 = 0; c2 = 0; }
-      if (key == best) { if (td >= base) { c1 = c; s1 = st; } else { c2 = c; s2 = st; } }
-    }
-  };
   if constexpr (!BIG) {
     if (!overflow) {
       // left seeds: left.substr(d, k) enters at depth d with the value 1 ASSIGNED (:995-1015, :1082-1105)
@@ -911,6 +898,7 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
       if (chain) {
         if (lane == 0) {
           s_node[0] = s0; s_dl[0] = (uint32_t)lmf << 16; s_cnt[0] = 1u; s_p01[0] = s_p23[0] = 0xFFFFFFFFu; s_aux[0] = 0u;
+          s_t[0] = 0x7FFFu;  // (holds no target k-mer: checked above)
         }
         nseg = 1; gen = 1;
         sb += (uint32_t)lmf;
@@ -963,7 +951,7 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
         }
         sb += L;
         xb += min(L, (uint32_t)(D - depth));
-        note_hits(node, L, depth, c, stl);
+        (void)c; (void)stl;  // (the target hits of the segments are looked for behind the search, all segments at once)
       }
       if (mine) {
         s_node[esid] = en;
@@ -972,6 +960,7 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
         s_p01[esid] = ep01;
         s_p23[esid] = ep23;
         s_aux[esid] = gen;
+        s_t[esid] = est;  // (stop depths of the entry, until the hits have been looked for: phase D1 fills s_t later)
       }
       nseg += nsel;
       SEG_PROF_T(3);
@@ -997,6 +986,37 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
       SEG_PROF_T(4);
       SEG_PROF_ACC();
       gen++;
+    }
+    // ---- phase C's hits (:1107-1159): target k-mer j at position t of a segment is a hit at depth + t.  Behind the
+    // search, lane = segment and a loop over the <= 32 targets: inside the rounds the same look — one selected event
+    // at a time, wave-uniform — was a tenth of a round.  A hit (error, j) exists at most once above and once below its
+    // base depth (a DP state is in one segment), so the smallest key and its two counts are a reduction.
+    if (!overflow) {
+      lds_sync();
+      uint32_t mybest = SEG_INF, myc1 = 0, myc2 = 0, mys1 = 0x7FFFu, mys2 = 0x7FFFu;
+      for (uint32_t b0 = 0; b0 < nseg; b0 += 64u) {
+        const uint32_t b = b0 + (uint32_t)lane;
+        const bool hb = b < nseg;
+        const uint32_t node = hb ? s_node[b] : 0u, dl = hb ? s_dl[b] : 0u, c = hb ? s_cnt[b] : 0u, st = hb ? s_t[b] : 0x7FFFu;
+        const uint32_t L = dl >> 16;
+        const int depth = (int)(dl & 0xFFFFu);
+        for (int j = 0; j <= rmf && j < 32; j++) {
+          const int t = hb ? seg_pos(node, L, rl(tg, j)) : -1;
+          if (t < 0) continue;
+          const int td = depth + t, base = gd.g + lmf + j;
+          const int err = td >= base ? td - base : base - td;
+          if (err > gd.e) continue;
+          const uint32_t key = ((uint32_t)(err + gd.g + lmf + rmf) << 6) | (uint32_t)j;
+          if (key < mybest) { mybest = key; myc1 = 0; myc2 = 0; }
+          if (key == mybest) { if (td >= base) { myc1 = c; mys1 = st; } else { myc2 = c; mys2 = st; } }
+        }
+      }
+      best = wave_min(mybest);
+      if (best != SEG_INF) {
+        const uint64_t m1 = __ballot(mybest == best && myc1 != 0u), m2 = __ballot(mybest == best && myc2 != 0u);
+        if (m1) { c1 = rl(myc1, __builtin_ctzll(m1)); s1 = rl(mys1, __builtin_ctzll(m1)); }
+        if (m2) { c2 = rl(myc2, __builtin_ctzll(m2)); s2 = rl(mys2, __builtin_ctzll(m2)); }
+      }
     }
   } else {
     // ---- (BIG) the same search with the pending events in LDS.  Lane = event only while a chunk of them is
