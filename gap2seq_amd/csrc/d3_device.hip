@@ -7,23 +7,33 @@
 // thread pool — 1.8 ms of host work beside a 0.48 ms kernel on a 10 000-gap list, and not divided by the
 // number of GPUs.  Here the whole of it runs behind the fill kernel on its stream, with no host round trip:
 //
-//   g2s_d3_scan    one workgroup: every gap's class (no phase D / fixed draw count / draw-dependent), its
-//                  (fewest) draws and their spread, the skip rule of consecutive gaps of a record (:369,402),
-//                  the prefix sums over the list and the layout of the tables below.
+//   g2s_d3_classify / g2s_d3_scan (one launch g2s_d3_front for lists of up to 3 072 gaps: the per-gap words stay in
+//                  LDS between the two)  every gap's class (no phase D / fixed draw count / draw-dependent), its
+//                  (fewest) draws and their spread, the skip rule of consecutive gaps of a record (:369,402), the
+//                  prefix sums over the list and the layout of the tables below; one record per draw-dependent gap
+//                  (D3Var) and the first half of one per gap (D3Trace) for the kernels behind.
 //   g2s_rand_fill  the glibc TYPE_3 stream (x[n] = x[n-31] + x[n-3], the linear recurrence behind rand())
 //                  materialised from the session's position on: a wave computes the state in front of its
 //                  4096 values from the state the host hands over with three jump polynomials
 //                  (x^(2^20 a) x^(4096 b) x^(64 l) modulo x^31 - x^28 - 1 over Z/2^32, seed independent
-//                  tables), then every lane runs the recurrence for its 64 values.
+//                  tables), then every lane runs the recurrence for its 64 values.  On a stream of its own.
 //   g2s_d3_tables  A draw-dependent gap v can only start at base_v + d, d in [0, R_v], R_v = the summed spreads of
-//                  the draw-dependent gaps before it: its draw count for EVERY such start, one lane per (v, d) —
-//                  the serial chain "offset of v+1 = offset of v + draws of v" becomes table look-ups.
+//                  the draw-dependent gaps before it: its draw count for EVERY such start, one lane per (v, d), the
+//                  closure's links and the tile's window of the stream in LDS — the serial chain "offset of v+1 =
+//                  offset of v + draws of v" becomes table look-ups.
 //   g2s_d3_blocks  the chain through 16 consecutive tables for every deviation a block can start with;
 //   g2s_d3_chain   the chain over blocks (one lane), then back into the blocks: the deviation in front of
-//                  every draw-dependent gap, hence every gap's offset.
+//                  every draw-dependent gap;
+//   g2s_d3_handoff every gap's first draw and draw count (second half of D3Trace), a slot in pinned memory for the
+//                  gaps whose closure the host analyses.  (Short lists: one launch g2s_d3_back for the three, the
+//                  tables and the chain in LDS.)
 //   g2s_d3_trace   one wave per gap: the traceback over the closure segments (post.cpp: seg_traceback is
-//                  the host version and the reference for every branch here), fill text and result record
-//                  written where the caller wants them (pinned host memory, or a staging buffer).
+//                  the host version and the reference for every branch here) as a per-segment choice of parent
+//                  (all lanes: the draw made at a depth does not depend on the path), a chase through those, and a
+//                  lane-parallel pass for base sources, safe bits and case; fill text and result record
+//                  written where the caller wants them (pinned host memory, or a staging buffer); host-finished
+//                  gaps handed over by their own waves; the last wave copies the summary to the host and, for a
+//                  list of one session, zeroes what the next list expects to find zero.
 //
 // Anything out of the ordinary (a gap the segment tier could not finish or analyse, tables beyond the
 // budget, a walk that does not end in a left-flank k-mer) is only COUNTED here: the host then discards the
