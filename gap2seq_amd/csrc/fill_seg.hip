@@ -208,6 +208,104 @@ struct SegArgs {
 #define SEGX_EMPTY64 0xFFFFFFFFFFFFFFFFull
 #define SEGX_TOMB64 0xFFFFFFFFFFFFFFFEull
 
+// Q7 between segments, the sorted way (see seg_fill_one): true/false in *found; returns false when there are more upward
+// segments than sbuf holds (nothing decided)
+__device__ __forceinline__ bool seg_q7_sorted(const uint32_t* s_node, const uint32_t* s_dl, uint32_t nseg, uint64_t* sbuf, uint32_t cap, int lane,
+                                              bool* found) {
+    uint32_t nu = 0;
+    bool anydn = false;
+    for (uint32_t b0 = 0; b0 < nseg; b0 += 64u) {
+      const uint32_t b = b0 + (uint32_t)lane;
+      const bool hb = b < nseg;
+      const uint32_t nb_ = hb ? s_node[b] : 0u, lb = hb ? s_dl[b] >> 16 : 0u;
+      const bool up = hb && !(nb_ & 1u) && lb > 0u;
+      const uint64_t m = __ballot(up);
+      if (nu + (uint32_t)__popcll(m) > cap) return false;
+      if (up) sbuf[nu + (uint32_t)__popcll(m & below(lane))] = ((uint64_t)(nb_ >> 1) << 32) | (uint64_t)((nb_ >> 1) + lb - 1u);
+      nu += (uint32_t)__popcll(m);
+      if (__ballot(hb && (nb_ & 1u) && lb > 0u)) anydn = true;
+    }
+    lds_sync();
+    if (nu > 0u && anydn) {
+      uint32_t n2 = 2;
+      while (n2 < nu) n2 <<= 1;
+      for (uint32_t i = nu + (uint32_t)lane; i < n2; i += 64u) sbuf[i] = SEGX_EMPTY64;
+      lds_sync();
+      lds_sort64(sbuf, n2, lane);
+      bool unused = false;
+      const uint32_t Mu = lds_merge_intervals(sbuf, nu, lane, &unused);
+      const uint32_t Pu = 1u << (31 - __builtin_clz(Mu));
+      const uint32_t* uw = (const uint32_t*)sbuf;
+      for (uint32_t b0 = 0; b0 < nseg && !*found; b0 += 64u) {
+        const uint32_t b = b0 + (uint32_t)lane;
+        const bool hb = b < nseg;
+        const uint32_t nb_ = hb ? s_node[b] : 0u, dlb = hb ? s_dl[b] : 0u;
+        const int ib = (int)(nb_ >> 1), db = (int)(dlb & 0xFFFFu), lb = (int)(dlb >> 16);
+        const bool down = hb && (nb_ & 1u) && lb > 0;
+        uint32_t pos = 0;
+        for (uint32_t st = Pu; st; st >>= 1) {
+          const uint32_t pp = pos + st;
+          if (pp <= Mu && uw[2u * (pp - 1u) + 1u] <= (uint32_t)ib) pos = pp;
+        }
+        const bool cand = down && pos > 0u && (int)uw[2u * (pos - 1u)] >= ib - lb + 1;
+        for (uint64_t cm = __ballot(cand); cm && !*found; cm &= cm - 1) {
+          const int l = __builtin_ctzll(cm);
+          const int ibl = (int)rl((uint32_t)ib, l), dbl = (int)rl((uint32_t)db, l), lbl = (int)rl((uint32_t)lb, l);
+          for (uint32_t a0 = 0; a0 < nseg; a0 += 64u) {
+            const uint32_t a = a0 + (uint32_t)lane;
+            const bool ha = a < nseg;
+            const uint32_t na = ha ? s_node[a] : 1u, dla = ha ? s_dl[a] : 0u;
+            const int ia = (int)(na >> 1), da = (int)(dla & 0xFFFFu), la = (int)(dla >> 16);
+            const int sdiff = ibl - ia, ddiff = dbl - da;
+            const int t1 = (sdiff + ddiff) >> 1, t2 = (sdiff - ddiff) >> 1;
+            if (__ballot(ha && !(na & 1u) && !((sdiff + ddiff) & 1) && t1 >= 0 && t1 < la && t2 >= 0 && t2 < lbl)) { *found = true; break; }
+          }
+        }
+      }
+    }
+    lds_sync();
+    return true;
+  }
+// every downward segment against every upward one, both sides a chunk at a time in registers
+__device__ __forceinline__ bool seg_q7_all_pairs(const uint32_t* s_node, const uint32_t* s_dl, uint32_t nseg, int lane) {
+  uint64_t anyup = 0, anydn = 0;
+  for (uint32_t b0 = 0; b0 < nseg; b0 += 64u) {
+    const uint32_t b = b0 + (uint32_t)lane;
+    anyup |= __ballot(b < nseg && !(s_node[b < nseg ? b : 0] & 1u));
+    anydn |= __ballot(b < nseg && (s_node[b < nseg ? b : 0] & 1u));
+  }
+  if (!(anyup && anydn)) return false;
+  for (uint32_t b0 = 0; b0 < nseg; b0 += 64u) {
+    const uint32_t b = b0 + (uint32_t)lane;
+    const bool hb = b < nseg;
+    const uint32_t nb_ = hb ? s_node[b] : 0u, dlb = hb ? s_dl[b] : 0u;
+    const int ib = (int)(nb_ >> 1), db = (int)(dlb & 0xFFFFu), lb = (int)(dlb >> 16);
+    const uint64_t dm0 = __ballot(hb && (nb_ & 1u));
+    if (!dm0) continue;
+    for (uint32_t a0 = 0; a0 < nseg; a0 += 64u) {
+      const uint32_t a = a0 + (uint32_t)lane;
+      const bool ha = a < nseg;
+      const uint32_t na = ha ? s_node[a] : 1u, dla = ha ? s_dl[a] : 0u;
+      const bool upa = ha && !(na & 1u);
+      if (!__ballot(upa)) continue;
+      const int ia = (int)(na >> 1), da = (int)(dla & 0xFFFFu), la = (int)(dla >> 16);
+      for (uint64_t dm = dm0; dm; dm &= dm - 1) {
+        const int l = __builtin_ctzll(dm);
+        const int sdiff = (int)rl((uint32_t)ib, l) - ia, ddiff = (int)rl((uint32_t)db, l) - da;
+        const int t1 = (sdiff + ddiff) >> 1, t2 = (sdiff - ddiff) >> 1;
+        if (__ballot(upa && !((sdiff + ddiff) & 1) && t1 >= 0 && t1 < la && t2 >= 0 && t2 < (int)rl((uint32_t)lb, l))) return true;
+      }
+    }
+  }
+  return false;
+}
+// (regular tier) the whole check: direct for a few dozen segments, sorted beyond
+__device__ __forceinline__ bool seg_q7_between(const uint32_t* s_node, const uint32_t* s_dl, uint32_t nseg, uint64_t* sbuf, uint32_t cap, int lane) {
+  bool found = false;
+  if (nseg <= 64u || !seg_q7_sorted(s_node, s_dl, nseg, sbuf, cap, lane, &found)) found = seg_q7_all_pairs(s_node, s_dl, nseg, lane);
+  return found;
+}
+
 // One gap, one wave.  BIG = false: the tier proper (segments in LDS, pending events and the right set in
 // registers).  BIG = true: the same search for the gaps that outgrow those capacities (-dist-error 2000:
 // thousands of segments, hundreds of pending events, thousands of right-set entries): segments in the
@@ -607,6 +705,14 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
         ash[0] = nA; ash[1] = roundsA; ash[2] = flags; ash[3] = overflow ? 1u : 0u;
         ash[4] = (uint32_t)((cyc_a_end - cyc0) >> 8);
       }
+      __syncthreads();
+      // ...and stays for one more job: the Q7 check between the segments, when wave 0 is through phase B (second
+      // barrier), in this wave's own LDS region (the table is free: the right set went into wave 0's registers); the
+      // verdict waits for wave 0 behind a third barrier
+      __syncthreads();
+      bool f7 = false;
+      if (ash[7]) f7 = seg_q7_between(s_node, s_dl, ash[6], (uint64_t*)lab, CAP / 2u, lane);
+      if (lane == 0) ash[5] = f7 ? 1u : 0u;
       __syncthreads();
       return;
     }
@@ -1359,100 +1465,33 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
   // phase D1 fills later; the large variant: the start of its LDS), a downward segment that touches none of them
   // (the usual case) is done after one binary search, and only the few others are checked against every upward
   // segment.  Lists of a few dozen segments keep the direct all-pairs pass.
-  auto q7_sorted = [&](uint64_t* sbuf, uint32_t cap) -> bool {  // false: more upward segments than sbuf holds
-    uint32_t nu = 0;
-    bool anydn = false;
-    for (uint32_t b0 = 0; b0 < nseg; b0 += 64u) {
-      const uint32_t b = b0 + (uint32_t)lane;
-      const bool hb = b < nseg;
-      const uint32_t nb_ = hb ? s_node[b] : 0u, lb = hb ? s_dl[b] >> 16 : 0u;
-      const bool up = hb && !(nb_ & 1u) && lb > 0u;
-      const uint64_t m = __ballot(up);
-      if (nu + (uint32_t)__popcll(m) > cap) return false;
-      if (up) sbuf[nu + (uint32_t)__popcll(m & below(lane))] = ((uint64_t)(nb_ >> 1) << 32) | (uint64_t)((nb_ >> 1) + lb - 1u);
-      nu += (uint32_t)__popcll(m);
-      if (__ballot(hb && (nb_ & 1u) && lb > 0u)) anydn = true;
-    }
-    lds_sync();
-    if (nu > 0u && anydn) {
-      uint32_t n2 = 2;
-      while (n2 < nu) n2 <<= 1;
-      for (uint32_t i = nu + (uint32_t)lane; i < n2; i += 64u) sbuf[i] = SEGX_EMPTY64;
-      lds_sync();
-      lds_sort64(sbuf, n2, lane);
-      bool unused = false;
-      const uint32_t Mu = lds_merge_intervals(sbuf, nu, lane, &unused);
-      const uint32_t Pu = 1u << (31 - __builtin_clz(Mu));
-      const uint32_t* uw = (const uint32_t*)sbuf;
-      for (uint32_t b0 = 0; b0 < nseg && !(flags & G2S_DEV_Q7_B); b0 += 64u) {
-        const uint32_t b = b0 + (uint32_t)lane;
-        const bool hb = b < nseg;
-        const uint32_t nb_ = hb ? s_node[b] : 0u, dlb = hb ? s_dl[b] : 0u;
-        const int ib = (int)(nb_ >> 1), db = (int)(dlb & 0xFFFFu), lb = (int)(dlb >> 16);
-        const bool down = hb && (nb_ & 1u) && lb > 0;
-        uint32_t pos = 0;
-        for (uint32_t st = Pu; st; st >>= 1) {
-          const uint32_t pp = pos + st;
-          if (pp <= Mu && uw[2u * (pp - 1u) + 1u] <= (uint32_t)ib) pos = pp;
-        }
-        const bool cand = down && pos > 0u && (int)uw[2u * (pos - 1u)] >= ib - lb + 1;
-        for (uint64_t cm = __ballot(cand); cm && !(flags & G2S_DEV_Q7_B); cm &= cm - 1) {
-          const int l = __builtin_ctzll(cm);
-          const int ibl = (int)rl((uint32_t)ib, l), dbl = (int)rl((uint32_t)db, l), lbl = (int)rl((uint32_t)lb, l);
-          for (uint32_t a0 = 0; a0 < nseg; a0 += 64u) {
-            const uint32_t a = a0 + (uint32_t)lane;
-            const bool ha = a < nseg;
-            const uint32_t na = ha ? s_node[a] : 1u, dla = ha ? s_dl[a] : 0u;
-            const int ia = (int)(na >> 1), da = (int)(dla & 0xFFFFu), la = (int)(dla >> 16);
-            const int sdiff = ibl - ia, ddiff = dbl - da;
-            const int t1 = (sdiff + ddiff) >> 1, t2 = (sdiff - ddiff) >> 1;
-            if (__ballot(ha && !(na & 1u) && !((sdiff + ddiff) & 1) && t1 >= 0 && t1 < la && t2 >= 0 && t2 < lbl)) { flags |= G2S_DEV_Q7_B; break; }
-          }
-        }
-      }
-    }
-    lds_sync();
-    return true;
-  };
   if constexpr (BIG) {
-    if (!overflow && !(flags & G2S_DEV_Q7_B) && nseg > 1) (void)q7_sorted((uint64_t*)lds, G2S_SEGX_CAP);
-  } else {
     if (!overflow && !(flags & G2S_DEV_Q7_B) && nseg > 1) {
-      if (nseg <= 64u || !q7_sorted((uint64_t*)s_t, CAP / 2u)) {
-        uint64_t anyup = 0, anydn = 0;
-        for (uint32_t b0 = 0; b0 < nseg; b0 += 64u) {
-          const uint32_t b = b0 + (uint32_t)lane;
-          anyup |= __ballot(b < nseg && !(s_node[b < nseg ? b : 0] & 1u));
-          anydn |= __ballot(b < nseg && (s_node[b < nseg ? b : 0] & 1u));
-        }
-        if (anyup && anydn) {
-          // every downward segment against every upward one, both sides a chunk at a time in registers
-          for (uint32_t b0 = 0; b0 < nseg && !(flags & G2S_DEV_Q7_B); b0 += 64u) {
-            const uint32_t b = b0 + (uint32_t)lane;
-            const bool hb = b < nseg;
-            const uint32_t nb_ = hb ? s_node[b] : 0u, dlb = hb ? s_dl[b] : 0u;
-            const int ib = (int)(nb_ >> 1), db = (int)(dlb & 0xFFFFu), lb = (int)(dlb >> 16);
-            const uint64_t dm0 = __ballot(hb && (nb_ & 1u));
-            if (!dm0) continue;
-            for (uint32_t a0 = 0; a0 < nseg && !(flags & G2S_DEV_Q7_B); a0 += 64u) {
-              const uint32_t a = a0 + (uint32_t)lane;
-              const bool ha = a < nseg;
-              const uint32_t na = ha ? s_node[a] : 1u, dla = ha ? s_dl[a] : 0u;
-              const bool upa = ha && !(na & 1u);
-              if (!__ballot(upa)) continue;
-              const int ia = (int)(na >> 1), da = (int)(dla & 0xFFFFu), la = (int)(dla >> 16);
-              for (uint64_t dm = dm0; dm; dm &= dm - 1) {
-                const int l = __builtin_ctzll(dm);
-                const int sdiff = (int)rl((uint32_t)ib, l) - ia, ddiff = (int)rl((uint32_t)db, l) - da;
-                const int t1 = (sdiff + ddiff) >> 1, t2 = (sdiff - ddiff) >> 1;
-                if (__ballot(upa && !((sdiff + ddiff) & 1) && t1 >= 0 && t1 < la && t2 >= 0 && t2 < (int)rl((uint32_t)lb, l))) { flags |= G2S_DEV_Q7_B; break; }
-              }
-            }
-          }
+      bool f7 = false;
+      (void)seg_q7_sorted(s_node, s_dl, nseg, (uint64_t*)lds, G2S_SEGX_CAP, lane, &f7);
+      if (f7) flags |= G2S_DEV_Q7_B;
+    }
+  } else if constexpr (TWO) {
+    // two waves: wave 1, idle since phase A, makes this check (in its own LDS region: the right set is in wave 0's
+    // registers by now) while this wave goes on with phases C, D1 and D2; its verdict is collected where the gap's
+    // flags are written for the last time (q7_collect)
+    if (lane == 0) { ash[6] = nseg; ash[7] = (!overflow && !(flags & G2S_DEV_Q7_B) && nseg > 1) ? 1u : 0u; }
+    __syncthreads();
+  } else {
+    if (!overflow && !(flags & G2S_DEV_Q7_B) && nseg > 1 && seg_q7_between(s_node, s_dl, nseg, (uint64_t*)s_t, CAP / 2u, lane)) flags |= G2S_DEV_Q7_B;
+  }
+  auto q7_collect = [&]() {  // (two waves) wave 1's verdict into the flags, the record and the diagnostics
+    if constexpr (TWO) {
+      __syncthreads();
+      if (ash[5]) {
+        flags |= G2S_DEV_Q7_B;
+        if (lane == 0) {
+          go->flags |= G2S_DEV_Q7_B;
+          if (dbg) dbg[(size_t)x * dbg_words + 3] |= G2S_DEV_Q7_B;
         }
       }
     }
-  }
+  };
 
   // ---------------- phase C in closed form (:1107-1159) ------------------------------------------
   const bool found = best != SEG_INF;
@@ -1518,6 +1557,7 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
     go->stat[4] = cyc_a_kc; go->stat[5] = (uint32_t)((cyc2 - cyc1) >> 8);
   }
   if (overflow || !(c_count > 0 && n_len > 0)) {  // :1169
+    q7_collect();
     publish();
     return;
   }
@@ -1759,6 +1799,7 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
   hbase = __shfl(hbase, 0);
   if (hbase + nres > out_cap) {  // the host buffer is full: the gap runs again in the LDS tier
     if (lane == 0) go->flags = flags | G2S_DEV_OVERFLOW_B | G2S_DEV_WHY_LOG;
+    q7_collect();
     publish();
     return;
   }
@@ -1860,6 +1901,7 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
     o[dbg_words - 9u] = prof_load;
   }
 #endif
+  q7_collect();
   publish();
 }
 

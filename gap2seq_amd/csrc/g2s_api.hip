@@ -556,6 +556,7 @@ struct g2s_session {
   std::vector<uint32_t> res_ids, res_at;  // launch order of a resident list and its counting sort, kept between lists
   bool in_team_list = false;     // the session is filling a group of a team's list (team_resident)
   bool team_shares_device = false;  // ... and another session of the team sits on the same device
+  int peer_asked_for = -1;       // the lead device this session asked direct access to (team lists)
   bool self_cleaned = false;     // the last list's trace kernel zeroed records, summary and cursors behind itself
   size_t side_dirty = SIZE_MAX;  // items of h_side whose ready word may be set (resident mode's hand-over)
   uint32_t timed_seq = 0;        // resident launches so far (one in eight is bracketed with HIP events)
@@ -2962,6 +2963,21 @@ static int team_resident(g2s_session* const* sessions, int nsessions, const g2s_
   HIP_TRY(lead->d_sub_all.ensure(ngroups * region * sizeof(SubRec)));
   HIP_TRY(lead->h_d3all.ensure(n * sizeof(D3Gap) + 2048 + 64 * 128 + G2S_RAND_WINDOW * 4));
   D3Gap* dg_all = (D3Gap*)lead->h_d3all.p;
+  // sessions on other devices push their groups' records into the lead's memory: direct access over xGMI where the
+  // devices allow it (asked for once per session; without it the runtime stages the copy through the host)
+  for (int t = 0; t < nsessions; t++) {
+    g2s_session* o = sessions[t];
+    if (o->device == lead->device || o->peer_asked_for == lead->device) continue;
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, o->device, lead->device) == hipSuccess && can && hipSetDevice(o->device) == hipSuccess) {
+      const hipError_t pe = hipDeviceEnablePeerAccess(lead->device, 0);
+      if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled && getenv("G2S_DEBUG"))
+        fprintf(stderr, "[g2s] team: device %d cannot open device %d's memory (%s): copies go through the host\n", o->device, lead->device, hipGetErrorString(pe));
+    }
+    (void)hipGetLastError();
+    o->peer_asked_for = lead->device;
+  }
+  if (hipSetDevice(lead->device) != hipSuccess) return fail(G2S_ERR_NO_DEVICE, "cannot select device");
   std::vector<int> rcs((size_t)nsessions, G2S_OK);
   std::vector<std::string> errs((size_t)nsessions);
   std::atomic<int> not_for_us(0);
