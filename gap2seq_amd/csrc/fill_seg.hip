@@ -299,6 +299,36 @@ __device__ __forceinline__ bool seg_q7_all_pairs(const uint32_t* s_node, const u
   }
   return false;
 }
+// Do two segments share a k-mer (as index intervals, whatever their depths)?  When none do, no closure holds a k-mer at
+// two depths either: phase D2 can skip its own test over the closure's extents.  Every chunk against itself and
+// the chunks before it, both sides in registers.
+__device__ __forceinline__ bool seg_extents_overlap(const uint32_t* s_node, const uint32_t* s_dl, uint32_t nseg, int lane) {
+  for (uint32_t b0 = 0; b0 < nseg; b0 += 64u) {
+    const uint32_t b = b0 + (uint32_t)lane;
+    const bool hb = b < nseg;
+    const uint32_t v0 = hb ? s_node[b] : 0u, lb = hb ? s_dl[b] >> 16 : 0u;
+    const bool in = hb && lb > 0u;
+    const uint32_t idx = v0 >> 1;
+    const uint32_t ilo = (v0 & 1u) ? idx - (lb - 1u) : idx, ihi = (v0 & 1u) ? idx : idx + (lb - 1u);
+    for (uint32_t a0 = 0; a0 <= b0; a0 += 64u) {
+      uint32_t alo_ = ilo, ahi_ = ihi;
+      bool a_in = in;
+      if (a0 != b0) {
+        const uint32_t a = a0 + (uint32_t)lane;  // (a < nseg: an earlier chunk is full)
+        const uint32_t va = s_node[a], la = s_dl[a] >> 16, ia = va >> 1;
+        a_in = la > 0u;
+        alo_ = (va & 1u) ? ia - (la - 1u) : ia;
+        ahi_ = (va & 1u) ? ia : ia + (la - 1u);
+      }
+      for (uint64_t am = __ballot(a_in); am; am &= am - 1) {
+        const int al = __builtin_ctzll(am);
+        const uint32_t lo_a = rl(alo_, al), hi_a = rl(ahi_, al);
+        if (__ballot(in && b > a0 + (uint32_t)al && ilo <= hi_a && lo_a <= ihi)) return true;
+      }
+    }
+  }
+  return false;
+}
 // (regular tier) the whole check: direct for a few dozen segments, sorted beyond
 __device__ __forceinline__ bool seg_q7_between(const uint32_t* s_node, const uint32_t* s_dl, uint32_t nseg, uint64_t* sbuf, uint32_t cap, int lane) {
   bool found = false;
@@ -458,7 +488,7 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
   // keyed by node with 64-bit atomic min on (node << 32 | label) — a per-proposal compare against
   // register-resident entries costs ~1.5 k cycles of scalar/vector ping-pong each (measured).
   // LDS (one wave: aliasing the segment arrays, which phase B fills later; two waves: behind them):
-  //   lab[ALAB] u64 | labrem[ALAB] u32 | q[2][ACAP] u32 nodes | q[2][ACAP] u32 table positions | 8 words
+  //   lab[ALAB] u64 | labrem[ALAB] u32 | q[2][ACAP] u32 nodes | q[2][ACAP] u32 table positions | 16 words
   constexpr uint32_t ACAP = 64u * G2S_SEG_ASETS, ALAB = 2u * ACAP;
   uint64_t* lab = (uint64_t*)(TWO ? lds + (7u * G2S_SEG_CAP + 32u) : lds);
   uint32_t* labrem = (uint32_t*)(lab + ALAB);
@@ -712,7 +742,10 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
       __syncthreads();
       bool f7 = false;
       if (ash[7]) f7 = seg_q7_between(s_node, s_dl, ash[6], (uint64_t*)lab, CAP / 2u, lane);
-      if (lane == 0) ash[5] = f7 ? 1u : 0u;
+      // (and, while wave 0 sweeps the closure: do two segments share a k-mer at all? — if not, phase D2 skips its
+      // pairwise test of the closure's extents)
+      const bool apart = ash[7] && ash[6] <= 192u && !seg_extents_overlap(s_node, s_dl, ash[6], lane);
+      if (lane == 0) { ash[5] = f7 ? 1u : 0u; ash[8] = apart ? 1u : 0u; }
       __syncthreads();
       return;
     }
@@ -1480,9 +1513,13 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
   } else {
     if (!overflow && !(flags & G2S_DEV_Q7_B) && nseg > 1 && seg_q7_between(s_node, s_dl, nseg, (uint64_t*)s_t, CAP / 2u, lane)) flags |= G2S_DEV_Q7_B;
   }
-  auto q7_collect = [&]() {  // (two waves) wave 1's verdict into the flags, the record and the diagnostics
+  bool collected = false, segs_apart = false;  // (two waves) no two segments share a k-mer (wave 1 looked)
+  auto q7_collect = [&]() {  // (two waves) wave 1's verdicts: Q7 into the flags, the record and the diagnostics
     if constexpr (TWO) {
+      if (collected) return;
+      collected = true;
       __syncthreads();
+      segs_apart = ash[8] != 0u;
       if (ash[5]) {
         flags |= G2S_DEV_Q7_B;
         if (lane == 0) {
@@ -1664,6 +1701,7 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
   if (want_s && nseg <= 192u) {
     uint32_t n_s = 0, edges = 0, src_out = 0, sink_in = 0;
     bool dag = true;
+    q7_collect();  // (two waves: the second wave may have found that no two segments share a k-mer at all)
     for (uint32_t b0 = 0; b0 < nseg; b0 += 64u) {  // totals, and no two S intervals may overlap
       const uint32_t b = b0 + (uint32_t)lane;
       const bool hb = b < nseg;
@@ -1694,7 +1732,7 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
       // in registers (a pass over LDS per pair of segments was 15 % of the kernel)
       const uint32_t idx = v0 >> 1;
       const uint32_t ilo = (v0 & 1u) ? idx - (uint32_t)max(ts, 0) : idx, ihi = (v0 & 1u) ? idx : idx + (uint32_t)max(ts, 0);
-      for (uint32_t a0 = 0; a0 <= b0 && dag; a0 += 64u) {
+      for (uint32_t a0 = 0; a0 <= b0 && dag && !segs_apart; a0 += 64u) {
         uint32_t alo_ = ilo, ahi_ = ihi;
         bool a_in = in_s;
         if (a0 != b0) {
@@ -1939,7 +1977,7 @@ __global__ __launch_bounds__(64) void g2s_fill_segx(const SegArgs A, uint32_t* s
 namespace g2s {
 
 size_t fill_seg_lds_bytes() { return 4u * (7u * G2S_SEG_CAP + 32u); }
-size_t fill_seg2_lds_bytes() { return 4u * (7u * G2S_SEG_CAP + 32u + 2u * 128u * G2S_SEG_ASETS + 128u * G2S_SEG_ASETS + 4u * 64u * G2S_SEG_ASETS + 8u); }
+size_t fill_seg2_lds_bytes() { return 4u * (7u * G2S_SEG_CAP + 32u + 2u * 128u * G2S_SEG_ASETS + 128u * G2S_SEG_ASETS + 4u * 64u * G2S_SEG_ASETS + 16u); }
 uint32_t fill_seg_dbg_words() { return 8u + 2u * 64u * G2S_SEG_ASETS + 6u * G2S_SEG_CAP + 14u; }  // (+14: profile words)
 size_t fill_segx_lds_bytes() { return 4u * SEGX_LDS_WORDS; }
 size_t fill_segx_scratch_bytes(uint32_t workgroups) { return (size_t)workgroups * SEGX_SCR_WORDS * 4u; }
