@@ -135,11 +135,11 @@ __device__ __forceinline__ void lds_sort64(uint64_t* a, uint32_t n2, int lane) {
 }
 // a[0 .. n): keys (first index << 32 | orientation << 31 | last index), sorted.  Merges overlapping and
 // adjacent intervals in place: a[g] = first << 32 | last for g < M (returned), sorted and disjoint with a
-// hole between any two.  *cross: an interval of each orientation overlap.
-__device__ __forceinline__ uint32_t lds_merge_intervals(uint64_t* a, uint32_t n, int lane, bool* cross) {
+// hole between any two.  *cross: an interval of each orientation overlap; *overlap (optional): any two overlap.
+__device__ __forceinline__ uint32_t lds_merge_intervals(uint64_t* a, uint32_t n, int lane, bool* cross, bool* overlap = nullptr) {
   uint32_t* w = (uint32_t*)a;
   uint32_t M = 0, pm = 0, pm_e = 0, pm_o = 0;  // highest (last index + 1) so far: all, even, odd entries
-  bool cr = false;
+  bool cr = false, ov = false;
   for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
     const uint32_t i = i0 + (uint32_t)lane;
     const bool h = i < n;
@@ -154,6 +154,7 @@ __device__ __forceinline__ uint32_t lds_merge_intervals(uint64_t* a, uint32_t n,
     if (lane == 0) { xa = 0u; xe = 0u; xo = 0u; }
     xa = max(xa, pm); xe = max(xe, pm_e); xo = max(xo, pm_o);   // over everything before element i
     if (__ballot(h && (odd ? xe : xo) > lo)) cr = true;          // an earlier interval of the other orientation ends at or after lo
+    if (__ballot(h && xa > lo)) ov = true;                       // an earlier interval ends at or after lo
     const bool start = h && (xa == 0u || lo > xa);               // a hole in front of this element
     const uint64_t sm = __ballot(start);
     const uint32_t g = M + (uint32_t)__popcll(sm & below(lane));
@@ -169,6 +170,7 @@ __device__ __forceinline__ uint32_t lds_merge_intervals(uint64_t* a, uint32_t n,
   if (M > 0u && lane == 0) w[2u * (M - 1u)] = pm - 1u;
   lds_sync();
   *cross = cr;
+  if (overlap) *overlap = ov;
   return M;
 }
 
@@ -328,6 +330,49 @@ __device__ __forceinline__ bool seg_extents_overlap(const uint32_t* s_node, cons
     }
   }
   return false;
+}
+// (regular tier) Q7 between the segments and "no two segments share a k-mer" in one go.  A few dozen segments: both
+// directly.  Beyond: ALL segments' index intervals sorted and merged once — no overlap at all settles both (no pair
+// can meet without overlapping), an overlap only within one orientation still settles Q7; only when an upward and a
+// downward segment overlap does the detailed check run.
+__device__ __forceinline__ bool seg_q7_between(const uint32_t* s_node, const uint32_t* s_dl, uint32_t nseg, uint64_t* sbuf, uint32_t cap, int lane);
+__device__ __forceinline__ bool seg_extents_overlap(const uint32_t* s_node, const uint32_t* s_dl, uint32_t nseg, int lane);
+// (want_apart: the second verdict is of use — phase D2 runs on the device for this gap, and somebody has the time)
+__device__ __forceinline__ void seg_cross_check(const uint32_t* s_node, const uint32_t* s_dl, uint32_t nseg, uint64_t* sbuf, uint32_t cap, int lane,
+                                                bool want_apart, bool* q7, bool* apart) {
+  *q7 = false;
+  *apart = false;
+  if (nseg <= 64u || !want_apart) {
+    *q7 = seg_q7_between(s_node, s_dl, nseg, sbuf, cap, lane);
+    if (want_apart) *apart = !seg_extents_overlap(s_node, s_dl, nseg, lane);
+    return;
+  }
+  uint32_t nk = 0;
+  bool fits = true;
+  for (uint32_t b0 = 0; b0 < nseg; b0 += 64u) {
+    const uint32_t b = b0 + (uint32_t)lane;
+    const bool hb = b < nseg;
+    const uint32_t v0 = hb ? s_node[b] : 0u, lb = hb ? s_dl[b] >> 16 : 0u;
+    const bool in = hb && lb > 0u;
+    const uint64_t m = __ballot(in);
+    if (nk + (uint32_t)__popcll(m) > cap) { fits = false; break; }
+    const uint32_t idx = v0 >> 1;
+    const uint32_t lo = (v0 & 1u) ? idx - (lb - 1u) : idx, hi = (v0 & 1u) ? idx : idx + (lb - 1u);
+    if (in) sbuf[nk + (uint32_t)__popcll(m & below(lane))] = ((uint64_t)lo << 32) | ((uint64_t)(v0 & 1u) << 31) | (uint64_t)hi;
+    nk += (uint32_t)__popcll(m);
+  }
+  lds_sync();
+  if (!fits) { *q7 = seg_q7_between(s_node, s_dl, nseg, sbuf, cap, lane); return; }
+  if (nk < 2u) { *apart = true; return; }
+  uint32_t n2 = 2;
+  while (n2 < nk) n2 <<= 1;
+  for (uint32_t i = nk + (uint32_t)lane; i < n2; i += 64u) sbuf[i] = SEGX_EMPTY64;
+  lds_sync();
+  lds_sort64(sbuf, n2, lane);
+  bool cross = false, overlap = false;
+  (void)lds_merge_intervals(sbuf, nk, lane, &cross, &overlap);
+  *apart = !overlap;
+  if (cross) *q7 = seg_q7_between(s_node, s_dl, nseg, sbuf, cap, lane);
 }
 // (regular tier) the whole check: direct for a few dozen segments, sorted beyond
 __device__ __forceinline__ bool seg_q7_between(const uint32_t* s_node, const uint32_t* s_dl, uint32_t nseg, uint64_t* sbuf, uint32_t cap, int lane) {
@@ -740,11 +785,10 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
       // barrier), in this wave's own LDS region (the table is free: the right set went into wave 0's registers); the
       // verdict waits for wave 0 behind a third barrier
       __syncthreads();
-      bool f7 = false;
-      if (ash[7]) f7 = seg_q7_between(s_node, s_dl, ash[6], (uint64_t*)lab, CAP / 2u, lane);
       // (and, while wave 0 sweeps the closure: do two segments share a k-mer at all? — if not, phase D2 skips its
       // pairwise test of the closure's extents)
-      const bool apart = ash[7] && ash[6] <= 192u && !seg_extents_overlap(s_node, s_dl, ash[6], lane);
+      bool f7 = false, apart = false;
+      if (ash[7]) seg_cross_check(s_node, s_dl, ash[6], (uint64_t*)lab, CAP / 2u, lane, !A.skip_confident && ash[6] <= 192u, &f7, &apart);
       if (lane == 0) { ash[5] = f7 ? 1u : 0u; ash[8] = apart ? 1u : 0u; }
       __syncthreads();
       return;
@@ -1510,10 +1554,17 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
     // flags are written for the last time (q7_collect)
     if (lane == 0) { ash[6] = nseg; ash[7] = (!overflow && !(flags & G2S_DEV_Q7_B) && nseg > 1) ? 1u : 0u; }
     __syncthreads();
-  } else {
-    if (!overflow && !(flags & G2S_DEV_Q7_B) && nseg > 1 && seg_q7_between(s_node, s_dl, nseg, (uint64_t*)s_t, CAP / 2u, lane)) flags |= G2S_DEV_Q7_B;
   }
-  bool collected = false, segs_apart = false;  // (two waves) no two segments share a k-mer (wave 1 looked)
+  bool collected = false, segs_apart = false;  // no two segments share a k-mer
+  if constexpr (!BIG && !TWO) {
+    if (!overflow && !(flags & G2S_DEV_Q7_B) && nseg > 1) {
+      bool f7 = false;
+      // (one wave: the second verdict costs this wave what it saves on a few dozen segments; beyond, the sorted pass
+      // gives it for the price of sorting the other half of the segments as well)
+      seg_cross_check(s_node, s_dl, nseg, (uint64_t*)s_t, CAP / 2u, lane, !skip_confident && nseg > 64u && nseg <= 192u, &f7, &segs_apart);
+      if (f7) flags |= G2S_DEV_Q7_B;
+    }
+  }
   auto q7_collect = [&]() {  // (two waves) wave 1's verdicts: Q7 into the flags, the record and the diagnostics
     if constexpr (TWO) {
       if (collected) return;
