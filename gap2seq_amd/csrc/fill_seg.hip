@@ -451,7 +451,7 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
   // register, not inferred from the block index.  Gaps of a batch that never completes are not announced: the
   // host takes them at the end of the launch, which flushes everything.
   // MEMORY-MODEL ASSUMPTION of the batches (not something the HIP memory model promises; checked on gfx950 by
-  // the parity suite and the fuzz campaigns on the host path, where every announced gap is compared with the oracle):
+  // the parity suite and the differential campaigns on the host path, which compare every announced gap field by field):
   // plain stores of wave A to fine-grained host memory that A has waited for ("s_waitcnt vmcnt(0)") sit in the L2 of
   // A's XCD, and a later "buffer_wbl2 sc0 sc1" by ANOTHER wave B of the same XCD writes them back with B's own.
   // The ticket (an agent-scope atomic A performs after its wait) is what orders A's stores before B's write-back.
