@@ -424,6 +424,9 @@ class WorkerPool {
       uint64_t g;
       size_t n;
       const std::function<void(size_t)>* f;
+      // a short look for the next job before going to sleep: the jobs of one list follow each other within
+      // microseconds (sizes, flank text, host-finished gaps), and waking a sleeping thread costs tens of them
+      for (int spin = 0; spin < 1500 && gen_.load(std::memory_order_acquire) == seen; spin++) __builtin_ia32_pause();
       {
         std::unique_lock<std::mutex> lk(mu_);
         cv_.wait(lk, [&]() { return gen_.load() != seen; });
@@ -528,6 +531,9 @@ struct g2s_session {
   // the two largest per-gap arrays of a batch, kept from one batch to the next: allocated afresh they are new
   // pages every time (3 MB per 10 000 gaps: 0.2-0.3 ms of page faults per call)
   std::vector<SubView> spare_views;
+  std::vector<GapJob> spare_jobs;            // per-gap arrays of the last batch that was freed (taken by the next one)
+  std::vector<uint32_t> spare_u32[3];
+  std::vector<size_t> spare_sz;
   std::vector<SubPrep> spare_prep;
   DevBuf d_log, d_lvl, d_plk, d_xl, d_xo;  // LDS tier: state log, level offsets, parent links, closure side lists
   DevBuf d_segx;  // large variant of the segment tier: segment arrays and queues of its persistent workgroups
@@ -728,6 +734,9 @@ struct g2s_batch {
       if (s->desc_owner == this) s->desc_owner = nullptr;
       if (pin) s->pin_free.push_back(pin);
       if (views.capacity() > s->spare_views.capacity()) { views.clear(); s->spare_views.swap(views); }
+      if (jobs.capacity() > s->spare_jobs.capacity()) s->spare_jobs.swap(jobs);
+      if (flank_off.capacity() > s->spare_u32[0].capacity()) s->spare_u32[0].swap(flank_off);
+      if (arena_off.capacity() > s->spare_sz.capacity()) s->spare_sz.swap(arena_off);
       if (prep.capacity() > s->spare_prep.capacity()) s->spare_prep.swap(prep);  // (elements kept: analyze_gap resets what it uses)
     }
   }
@@ -771,47 +780,87 @@ extern "C" int g2s_batch_prepare(g2s_session* s, const g2s_gap* gaps, size_t n, 
   g2s_batch* b = new g2s_batch();
   b->s = s;
   memset(&b->timing, 0, sizeof b->timing);
+  // (the per-gap arrays of a batch come from the session and go back to it: 0.5 MB of fresh pages per 10 000-gap
+  // list cost more than filling them)
+  b->jobs.swap(s->spare_jobs);
+  b->flank_off.swap(s->spare_u32[0]);
+  b->arena_off.swap(s->spare_sz);
   b->jobs.resize(n);
   b->flank_off.resize(n);
   b->arena_off.resize(n);
   const int d_err = s->params.d_err;
   // ---- sizes: what fill_gap reads of the flanks is the first k+lmf characters of the left one and the
   // first and last k+rmf of the right one; the k-mer -> node look-ups run on the device (flank_lookup.hip)
+  // (a long list: in parallel — every task its stretch of the list with offsets from the stretch's start, the
+  // stretches' bases from a pass over the <= 16 tasks, added where the second pass below visits the gap.  One
+  // thread took 56 us for 10 000 gaps, in front of everything else the list needs.)
   size_t text_bytes = 0, n_nodes = 0, n_desc = 0;
-  std::vector<uint32_t> text_off(n);
+  std::vector<uint32_t>& text_off = s->spare_u32[1];
+  std::vector<uint32_t>& didx = s->spare_u32[2];  // (didx: descriptor index of every valid gap)
+  text_off.resize(n);
+  didx.resize(n);
   const bool force_host_lookup = getenv("G2S_HOST_LOOKUP") != nullptr;
-  for (size_t i = 0; i < n; i++) {
-    GapJob& j = b->jobs[i];
-    const g2s_gap& in = gaps[i];
-    j.g = in.gap_len;
-    j.lmf = in.lmf;
-    j.rmf = in.rmf;
-    j.skip_if_prev_right_fuz_gt = in.skip_if_prev_right_fuz_gt;
-    // D2: flanks too short would make the reference throw from substr
-    j.bad_flank = !in.left || !in.right || in.lmf < 0 || in.rmf < 0 || in.gap_len < 0 ||
-                  in.left_len < k + in.lmf || in.right_len < k + in.rmf;
-    b->flank_off[i] = (uint32_t)n_nodes;
-    if (!j.bad_flank) {
-      const size_t tb = (size_t)(k + j.lmf) + 2 * (size_t)(k + j.rmf);
-      if (tb > G2S_FLANK_TEXT_MAX || j.lmf > 65535 || j.rmf > 65535 || force_host_lookup) b->host_lookup = true;
-      text_off[i] = (uint32_t)text_bytes;
-      text_bytes += (tb + 3) & ~(size_t)3;
-      n_nodes += (size_t)(j.lmf + 1) + 2 * (size_t)(j.rmf + 1);
-      n_desc++;
-      b->timing.flank_bytes += (uint64_t)in.left_len + (uint64_t)in.right_len;
-      const int dd = j.lmf + j.rmf + j.g + d_err;
-      if (j.rmf > 31 || j.lmf > 31 || dd >= 32767) b->seg_tier_all = false;
-      b->gmax = std::max(b->gmax, j.g);
-      b->dmax = std::max(b->dmax, dd);
-      b->rnd_cap += (size_t)(dd + 2);
-    } else {
-      j.lmf = std::max(0, j.lmf);
-      j.rmf = std::max(0, j.rmf);
-      j.g = std::max(0, j.g);
+  const size_t per_task = std::max<size_t>(256, (n + 15) / 16);  // (at most 16 tasks: every task wakes a thread)
+  const size_t ntasks = (n + per_task - 1) / per_task;
+  struct Part {
+    size_t n_nodes = 0, text_bytes = 0, n_desc = 0, arena_bytes = 0, rnd_cap = 0;
+    uint64_t flank_bytes = 0;
+    int gmax = 0, dmax = 0;
+    bool seg_all = true, host_lookup = false, has_skip = false;
+  };
+  std::vector<Part> parts(std::max<size_t>(ntasks, 1));
+  auto size_range = [&](size_t t) {
+    Part& P = parts[t];
+    const size_t lo = t * per_task, hi = std::min(n, lo + per_task);
+    for (size_t i = lo; i < hi; i++) {
+      GapJob& j = b->jobs[i];
+      const g2s_gap& in = gaps[i];
+      j.g = in.gap_len;
+      j.lmf = in.lmf;
+      j.rmf = in.rmf;
+      j.skip_if_prev_right_fuz_gt = in.skip_if_prev_right_fuz_gt;
+      // D2: flanks too short would make the reference throw from substr
+      j.bad_flank = !in.left || !in.right || in.lmf < 0 || in.rmf < 0 || in.gap_len < 0 ||
+                    in.left_len < k + in.lmf || in.right_len < k + in.rmf;
+      b->flank_off[i] = (uint32_t)P.n_nodes;
+      didx[i] = 0xFFFFFFFFu;
+      if (!j.bad_flank) {
+        const size_t tb = (size_t)(k + j.lmf) + 2 * (size_t)(k + j.rmf);
+        if (tb > G2S_FLANK_TEXT_MAX || j.lmf > 65535 || j.rmf > 65535 || force_host_lookup) P.host_lookup = true;
+        text_off[i] = (uint32_t)P.text_bytes;
+        P.text_bytes += (tb + 3) & ~(size_t)3;
+        P.n_nodes += (size_t)(j.lmf + 1) + 2 * (size_t)(j.rmf + 1);
+        didx[i] = (uint32_t)P.n_desc++;
+        P.flank_bytes += (uint64_t)in.left_len + (uint64_t)in.right_len;
+        const int dd = j.lmf + j.rmf + j.g + d_err;
+        if (j.rmf > 31 || j.lmf > 31 || dd >= 32767) P.seg_all = false;
+        P.gmax = std::max(P.gmax, j.g);
+        P.dmax = std::max(P.dmax, dd);
+        P.rnd_cap += (size_t)(dd + 2);
+      } else {
+        j.lmf = std::max(0, j.lmf);
+        j.rmf = std::max(0, j.rmf);
+        j.g = std::max(0, j.g);
+      }
+      if (j.skip_if_prev_right_fuz_gt >= 0) P.has_skip = true;
+      b->arena_off[i] = P.arena_bytes;
+      P.arena_bytes += j.buf_bytes(k, d_err);
     }
-    if (j.skip_if_prev_right_fuz_gt >= 0) b->has_skip = true;
-    b->arena_off[i] = b->arena_bytes;
-    b->arena_bytes += j.buf_bytes(k, d_err);
+  };
+  if (ntasks > 4) s->pool->run(ntasks, size_range);
+  else for (size_t t = 0; t < ntasks; t++) size_range(t);
+  std::vector<size_t> base_nodes(ntasks + 1), base_text(ntasks + 1), base_desc(ntasks + 1), base_arena(ntasks + 1);
+  for (size_t t = 0; t < ntasks; t++) {
+    const Part& P = parts[t];
+    base_nodes[t] = n_nodes; base_text[t] = text_bytes; base_desc[t] = n_desc; base_arena[t] = b->arena_bytes;
+    n_nodes += P.n_nodes; text_bytes += P.text_bytes; n_desc += P.n_desc; b->arena_bytes += P.arena_bytes;
+    b->rnd_cap += P.rnd_cap;
+    b->timing.flank_bytes += P.flank_bytes;
+    b->gmax = std::max(b->gmax, P.gmax);
+    b->dmax = std::max(b->dmax, P.dmax);
+    if (!P.seg_all) b->seg_tier_all = false;
+    if (P.host_lookup) b->host_lookup = true;
+    if (P.has_skip) b->has_skip = true;
   }
   b->n_valid = n_desc;
   const auto tp1 = std::chrono::steady_clock::now();
@@ -841,15 +890,16 @@ extern "C" int g2s_batch_prepare(g2s_session* s, const g2s_gap* gaps, size_t n, 
   b->n_nodes = n_nodes;
   // ---- flank text and descriptors into the pinned buffer (long lists: on the pool)
   {
-    std::vector<uint32_t> didx(n);  // descriptor index of every valid gap
-    uint32_t q = 0;
-    for (size_t i = 0; i < n; i++) didx[i] = b->jobs[i].bad_flank ? 0xFFFFFFFFu : q++;
-    const size_t per_task = std::max<size_t>(256, (n + 15) / 16);  // (at most 16 tasks: every task wakes a thread)
     // (what: 1 = flank text and look-up descriptors, 2 = the fill kernel's and phase D3's descriptors, 3 = both)
     auto do_range = [&](size_t t, int what) {
       const size_t lo = t * per_task, hi = std::min(n, lo + per_task);
       for (size_t i = lo; i < hi; i++) {
         GapJob& j = b->jobs[i];
+        if (what & 1) {  // (the first visit: the offsets within the task's stretch become offsets within the list)
+          b->flank_off[i] += (uint32_t)base_nodes[t];
+          b->arena_off[i] += base_arena[t];
+          if (!j.bad_flank) { text_off[i] += (uint32_t)base_text[t]; didx[i] += (uint32_t)base_desc[t]; }
+        }
         j.nodes = b->nodes + b->flank_off[i];
         if (fast_gd && (what & 2)) {
           GapDev& d = fast_gd[i];
@@ -889,7 +939,6 @@ extern "C" int g2s_batch_prepare(g2s_session* s, const g2s_gap* gaps, size_t n, 
         }
       }
     };
-    const size_t ntasks = (n + per_task - 1) / per_task;
     if (ntasks > 4) s->pool->run(ntasks, [&](size_t t) { do_range(t, 3); });
     else if (fast_gd) {
       // a short list on this thread: the look-up kernel is launched as soon as its input is there, the other
