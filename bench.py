@@ -253,9 +253,10 @@ def main():
     steps = args.steps or {"C2": 200, "C3": 30, "C4": 30, "C5": 3}[cfg_name]
     warmup = args.warmup if args.warmup >= 0 else (10 if steps >= 100 else 3 if steps >= 10 else 1)
     # Resident mode brackets one fill-kernel launch in eight with HIP events (the events cost the stream ~10 us per
-    # list): enough for an average over 100 steps and more; a shorter run times every launch.
+    # list): enough for an average over 100 steps and more; a shorter run brackets more of its launches.
     if steps < 100 and "G2S_KERNEL_TIMING" not in os.environ:
-        os.environ["G2S_KERNEL_TIMING"] = "all"
+        # (at least three bracketed launches inside the timed steps, however few those are)
+        os.environ["G2S_KERNEL_TIMING"] = "sample:%d" % max(1, min(8, steps // 3))
 
     # ---- workload (untimed) -------------------------------------------------------
     t0 = time.time()

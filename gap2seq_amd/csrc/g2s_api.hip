@@ -2461,13 +2461,15 @@ struct ResidentLaunch {
 };
 // Resident mode brackets its kernels with HIP events on one launch in eight (the session's first included): an
 // event between two kernels costs the stream 4-5 us, three of them 4 % of a 500-gap list's step, and the product
-// has no use for the durations — bench.py and the tests read them.  G2S_KERNEL_TIMING=all|off overrides.
+// has no use for the durations — bench.py and the tests read them.  G2S_KERNEL_TIMING=all|off|sample:N overrides.
 static bool kernel_events_on(g2s_session* s) {
   const char* m = getenv("G2S_KERNEL_TIMING");
   const uint32_t seq = s->timed_seq++;
   if (m && !strcmp(m, "all")) return true;
   if (m && !strcmp(m, "off")) return false;
-  return seq % 8u == 0u;
+  uint32_t period = 8u;
+  if (m && !strncmp(m, "sample:", 7)) period = (uint32_t)std::max(1, atoi(m + 7));  // (one launch in N)
+  return seq % period == 0u;
 }
 static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl) {
   g2s_session* s = b->s;
