@@ -130,6 +130,36 @@ def test_resident_mode_scaffold_records_and_the_skip_rule(product, oracle, monke
     assert out["1"][0] == ofa and out["1"][1] == olog
 
 
+def test_kernel_timing_is_sampled(product, monkeypatch):
+    """Resident mode brackets one launch in N with HIP events (default eight; G2S_KERNEL_TIMING=all|off|sample:N):
+    g2s_timing says which launches carry a duration; the results never depend on it."""
+    reads = product.G2S.synth_genome(120000, 3, 20240101)
+    seqs = [ln for ln in reads.splitlines() if not ln.startswith(">")]
+    gaps = _gaps(product, _parse_scaffolds(product.G2S.synth_gaps(reads, 31, 10, 300, 100, 600, 20240103)))
+    pg = product.Graph.from_seqs(seqs, 31, 1)
+    try:
+        seen = {}
+        for mode, want in (("sample:2", [1, 0, 1, 0]), ("all", [1, 1, 1, 1]), ("off", [0, 0, 0, 0]), (None, [1, 0, 0, 0])):
+            if mode is None:
+                monkeypatch.delenv("G2S_KERNEL_TIMING", raising=False)
+            else:
+                monkeypatch.setenv("G2S_KERNEL_TIMING", mode)
+            s = product.Session(pg, 0, d_err=500, randseed=3)
+            got = []
+            for _ in range(4):
+                s.srand(3)
+                res, tm = s.fill_batch(gaps, True)
+                assert tm.resident_launches == 1 and tm.seg_launches == 1
+                assert (tm.ms_fill_seg > 0) == (tm.seg_timed_launches == 1) and (tm.ms_d3 > 0) == (tm.seg_timed_launches == 1)
+                got.append(tm.seg_timed_launches)
+                seen.setdefault("res", [_key(r) for r in res])
+                assert [_key(r) for r in res] == seen["res"]
+            assert got == want, (mode, got)
+            s.destroy()
+    finally:
+        pg.free()
+
+
 @pytest.mark.parametrize("nsess,group,timing", [(1, 400, None), (2, 700, "all"), (3, 300, "off"), (4, 97, None), (4, 5000, "all")])
 def test_team_on_the_devices_equals_one_session(product, monkeypatch, nsess, group, timing):
     """g2s_team_fill with the list finished on the devices: every session runs the fill kernel of the groups it
