@@ -64,6 +64,42 @@ def test_resident_mode_equals_the_host_path(product, monkeypatch, mode, pinned):
     assert sum(1 for r in d1 if r[0] > 0) > 600
 
 
+def test_list_sizes_around_the_switch_points(product, monkeypatch):
+    """The default choice of path by list size: below 256 gaps the host path; from 256 on the device, with the
+    single-workgroup kernels of short lists up to 3 072 gaps and the multi-workgroup ones beyond.  Lists of 255, 256,
+    3 072 and 3 073 gaps (prefixes of one list) against the host path, one session each so that every list starts
+    at the same place in the stream; then the four in a row on one session (what one list cleans up behind itself is
+    what the next one finds)."""
+    reads = product.G2S.synth_genome(300000, 3, 20240101)
+    seqs = [ln for ln in reads.splitlines() if not ln.startswith(">")]
+    allg = _gaps(product, _parse_scaffolds(product.G2S.synth_gaps(reads, 31, 10, 3073, 60, 300, 20240103)))
+    pg = product.Graph.from_seqs(seqs, 31, 1)
+    sizes = (255, 256, 3072, 3073)
+    try:
+        want = {}
+        monkeypatch.setenv("G2S_RESIDENT", "0")
+        for n in sizes:
+            s = product.Session(pg, 0, d_err=300, randseed=5)
+            want[n] = [_key(r) for r in s.fill_batch(allg[:n])]
+            s.destroy()
+        chain = product.Session(pg, 0, d_err=300, randseed=5)
+        want_chain = [[_key(r) for r in chain.fill_batch(allg[:n])] for n in sizes + (256,)]
+        chain.destroy()
+        monkeypatch.delenv("G2S_RESIDENT")
+        for n in sizes:
+            s = product.Session(pg, 0, d_err=300, randseed=5)
+            res, tm = s.fill_batch(allg[:n], True, pinned=True)
+            assert [_key(r) for r in res] == want[n], n
+            assert tm.resident_launches == (1 if n >= 256 else 0) and tm.resident_fallbacks == 0, n
+            s.destroy()
+        chain = product.Session(pg, 0, d_err=300, randseed=5)
+        got_chain = [[_key(r) for r in chain.fill_batch(allg[:n], pinned=True)] for n in sizes + (256,)]
+        chain.destroy()
+        assert got_chain == want_chain
+    finally:
+        pg.free()
+
+
 def test_resident_mode_vs_oracle_on_the_bench_workload(product, oracle, monkeypatch):
     """BASELINE config 2's list (500 gaps) forced through resident mode, gap by gap against the oracle."""
     monkeypatch.setenv("G2S_RESIDENT", "1")
