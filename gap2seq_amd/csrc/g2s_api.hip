@@ -2544,7 +2544,10 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl) {
   HIP_TRY(hipHostGetDevicePointer(&d_gaps_host, s->h_gaps.p, 0));
   const GapDev* gaps_dev = (const GapDev*)d_gaps_host;
   const uint32_t* ids_dev = (const uint32_t*)(gaps_dev + n);
-  if (ids.size() > 2048) {  // (long lists: the descriptors are read by several kernels; short ones read them once, over the link)
+  // (The fill kernel reads a gap's descriptor and its place in the launch order once, over the link, when the
+  // gap's wave starts.  G2S_EXP_COPY_DESC=1, measurements: two copies into device memory in front of the kernel, as
+  // long lists had them until the copies were found to sit between the look-up kernel and the fill kernel.)
+  if (ids.size() > 2048 && getenv("G2S_EXP_COPY_DESC")) {
     HIP_TRY(hipMemcpyAsync(s->d_gaps.p, gd, n * sizeof(GapDev), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(s->d_ids.p, ids_pinned, ids.size() * 4, hipMemcpyHostToDevice, st));
     gaps_dev = (const GapDev*)s->d_gaps.p;
