@@ -47,4 +47,14 @@ hipError_t launch_fill_segx(hipStream_t st, uint32_t ngaps, uint32_t workgroups,
                             uint32_t* done_list, int skip_confident, uint32_t* dbg, uint32_t* scratch,
                             unsigned long long* next_gap);
 
+// The large variant on a workgroup of eight waves per gap (fill_segw.hip): same arguments; the workgroups take all of a
+// compute unit's LDS, scratch: fill_segw_scratch_bytes().  resident: closures and records stay in device memory.
+size_t fill_segw_lds_bytes();
+size_t fill_segw_scratch_bytes(uint32_t workgroups);
+hipError_t launch_fill_segw(hipStream_t st, uint32_t ngaps, uint32_t workgroups, const uint32_t* succ, const uint32_t* urec,
+                            const GapDev* gaps, const uint32_t* gap_ids, const uint32_t* flank_nodes, SubRec* sub_out,
+                            unsigned long long out_cap, unsigned long long* out_counter, GapOut* outs, GapOut* outs_host,
+                            uint32_t* done_list, int skip_confident, uint32_t* dbg, uint32_t* scratch,
+                            unsigned long long* next_gap, bool resident = false);
+
 }  // namespace g2s

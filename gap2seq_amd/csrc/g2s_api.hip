@@ -1201,7 +1201,16 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
     if (seg == 2) {
       // one persistent workgroup per compute unit (the variant takes nearly all of a CU's LDS)
       const uint32_t wgs = (uint32_t)std::min<size_t>(ids.size(), (size_t)std::max(1, s->num_cus));
-      HIP_TRY(s->d_segx.ensure(fill_segx_scratch_bytes(wgs)));
+      // (G2S_SEGX_ONE_WAVE=1: round 3's kernel, one wave per compute unit — measurements only)
+      static const bool one_wave = getenv("G2S_SEGX_ONE_WAVE") != nullptr;
+      HIP_TRY(s->d_segx.ensure(std::max(fill_segx_scratch_bytes(wgs), fill_segw_scratch_bytes(wgs))));
+      if (!one_wave)
+        HIP_TRY(launch_fill_segw(st, (uint32_t)ids.size(), wgs, dg.succ, dg.urec, gaps_dev, ids_dev, (const uint32_t*)s->d_flank.p,
+                                 (SubRec*)d_subs_host, (unsigned long long)out_states, (unsigned long long*)s->d_counter.p,
+                                 (GapOut*)s->d_outs.p, (GapOut*)d_outs_host, (uint32_t*)d_done_host,
+                                 s->params.skip_confident ? 1 : 0, seg_dbg, (uint32_t*)s->d_segx.p,
+                                 (unsigned long long*)s->d_counter.p + 2));
+      else
       HIP_TRY(launch_fill_segx(st, (uint32_t)ids.size(), wgs, dg.succ, dg.urec, gaps_dev, ids_dev, (const uint32_t*)s->d_flank.p,
                                (SubRec*)d_subs_host, (unsigned long long)out_states, (unsigned long long*)s->d_counter.p,
                                (GapOut*)s->d_outs.p, (GapOut*)d_outs_host, (uint32_t*)d_done_host,
@@ -1352,6 +1361,7 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
                     o[W - 10], o[W - 9]);
           if (o[W - 14] | o[W - 13] | o[W - 12] | o[W - 11])  // (the same builds, one wave per gap) cycles of phase A's sections
             fprintf(f, "PA %u %u %u %u\n", o[W - 14], o[W - 13], o[W - 12], o[W - 11]);
+          if (getenv("G2S_SEG_DUMP_BRIEF")) continue;  // (profiles: no entries, no segments)
           for (uint32_t e = 0; e < o[1] && e < ecap; e++) fprintf(f, "A %u %u\n", o[8 + 2 * e], o[9 + 2 * e]);
           for (uint32_t q = 0; q < o[2] && q < scap; q++)
             fprintf(f, "S %u %u %u %u %#x %#x %u\n", o[sb0 + 6 * q], o[sb0 + 6 * q + 1] & 0xFFFF, o[sb0 + 6 * q + 1] >> 16,

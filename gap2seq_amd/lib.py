@@ -167,7 +167,8 @@ _SIGS = {
 
 
 def library_path():
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "libg2s_hip.so")
+    # (G2S_LIBRARY: an instrumented build of the same sources, tools/ only — the product library stays where it is)
+    return os.environ.get("G2S_LIBRARY") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libg2s_hip.so")
 
 
 _LIB = None
