@@ -79,7 +79,9 @@ struct D3Summary {
   uint32_t seg_gaps, filled;
   uint32_t rand_state[31];  // the 31 words in front of the first value the list did not consume
   uint32_t trace_waves;     // waves of g2s_d3_trace that are through
+  uint32_t big_gaps;        // gaps that ran in the large variant of the segment tier (G2S_DEV_BIG)
 };
+static_assert(sizeof(D3Summary) <= 512, "the lap stamps live at byte 512 of the summary's slot");
 
 // the jump tables of the generator (seed independent): x^(2^20 a), x^(4096 b), x^(64 l) modulo the
 // recurrence's polynomial, 31 coefficients each

@@ -121,7 +121,7 @@ __device__ __forceinline__ uint32_t d3_classify_body(const D3Params& P, const D3
                                                      unsigned long long* red, bool one_wg) {
   const uint32_t n = P.n;
   unsigned long long xA = 0, sA = 0, xB = 0, sB = 0, xD = 0, sD = 0, segs = 0;
-  uint32_t unhandled = 0, seg_gaps = 0;
+  uint32_t unhandled = 0, seg_gaps = 0, big = 0;
   for (uint32_t i = first; i < n; i += stride) {
     // (the descriptor comes over the link on a short list, the record from device memory: asked for together)
     const D3Gap dg = dgaps[i];
@@ -140,6 +140,7 @@ __device__ __forceinline__ uint32_t d3_classify_body(const D3Params& P, const D3
         xA += x_right; sA += n_right; xB += x_left; sB += n_states; xD += x_sub; sD += n_sub;
         segs += nseg_b;
         seg_gaps++;
+        if (flags & G2S_DEV_BIG) big++;
         const bool phase_d = c_count > 0 && n_len > 0;  // :1169
         const bool by_host = phase_d && !(dflags & G2S_DEVA_ANALYSED);
         // (the all-paths recount — the sum of the counts of the sink states — is the kernel's for every closure,
@@ -189,6 +190,8 @@ __device__ __forceinline__ uint32_t d3_classify_body(const D3Params& P, const D3
   xA = wave_add64(xA); sA = wave_add64(sA); xB = wave_add64(xB); sB = wave_add64(sB); xD = wave_add64(xD); sD = wave_add64(sD);
   segs = wave_add64(segs);
   const unsigned long long cnts = wave_add64(((unsigned long long)unhandled << 32) | seg_gaps);
+  big = dpp_sum(big);
+  if ((threadIdx.x & 63u) == 0u && big) atomicAdd(&W.sum->big_gaps, big);
   const uint32_t wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   if ((threadIdx.x & 63u) == 0u) {
     unsigned long long* r = red + wave * 8u;
@@ -535,9 +538,16 @@ __device__ __forceinline__ int pick_parent(uint32_t rv, int nb) { return nb == 2
 // What a walk needs of a closure segment: entry depth | length << 16, the parents, the flags.
 struct SegLite { uint32_t depth_len, par01, par23, flags; };
 
+__device__ __forceinline__ SegLite seg_lite(const SegLite* p, int i) { return p[i]; }
+__device__ __forceinline__ SegLite seg_lite(const SegW* p, int i) {  // (a closure too large for LDS: from the records themselves)
+  SegLite l;
+  l.depth_len = p[i].depth_len; l.par01 = p[i].par01; l.par23 = p[i].par23; l.flags = p[i].flags;
+  return l;
+}
 // rand() draws of the traceback of one gap whose draws start at rnd[0]; *bad: something the host must look at
+template <typename SegT>
 __device__ int d3_walk_count(int n_len, int len0, int len1, uint32_t start_seg, uint32_t start_t, int nsegs,
-                             const SegLite* __restrict__ segs, const uint32_t* lwin /* LDS: the values from the first draw on */,
+                             const SegT* __restrict__ segs, const uint32_t* lwin /* LDS: the values from the first draw on */,
                              uint32_t nwin /* how many of them are there */, uint64_t avail /* values that exist from the first on */,
                              bool* bad) {
   int draws = 1;
@@ -548,7 +558,7 @@ __device__ int d3_walk_count(int n_len, int len0, int len1, uint32_t start_seg, 
   int i = sg == 0xFFFFu ? -1 : (int)sg;
   int t = (int)((start_t >> (16 * pick)) & 0xFFFFu);
   if (i < 0 || i >= nsegs) { *bad = true; return draws; }
-  SegLite s = segs[i];
+  SegLite s = seg_lite(segs, i);
   bool ended = false;
   for (int guard = 0; d2 >= 0; guard++) {
     if (guard > 70000) { *bad = true; break; }
@@ -562,7 +572,7 @@ __device__ int d3_walk_count(int n_len, int len0, int len1, uint32_t start_seg, 
       draws++;
       i = (int)seg_parent(s.par01, s.par23, nb == 1 ? 0 : pick_parent(rv, nb));  // :1513, GATB predecessor order
       if (i >= nsegs) { *bad = true; break; }
-      s = segs[i];
+      s = seg_lite(segs, i);
       t = (int)(s.depth_len >> 16) - 1;
     }
     d2--;
@@ -614,10 +624,14 @@ __global__ __launch_bounds__(256) void g2s_d3_tables(const D3Params P, const D3W
     __syncthreads();
     if (st0) stamp(W, 6);
     if (mine) {
-      bool bad = ns > D3_TAB_SEGS;
+      // (the closures of deep searches — thousands of segments, the large variant's — are walked where they lie)
+      bool bad = false;
       const uint64_t at = at0 + tid;
-      const int draws = bad ? 0 : d3_walk_count(vd.n_len, vd.len0, vd.len1, vd.start_seg, vd.start_t, (int)ns, lseg, lwin + tid,
-                                                want > tid ? want - tid : 0u, capacity > at ? capacity - at : 0ull, &bad);
+      const uint32_t nw = want > tid ? want - tid : 0u;
+      const uint64_t av = capacity > at ? capacity - at : 0ull;
+      const int draws = ns > D3_TAB_SEGS
+                            ? d3_walk_count(vd.n_len, vd.len0, vd.len1, vd.start_seg, vd.start_t, (int)ns, (const SegW*)(sub + vd.sub_at), lwin + tid, nw, av, &bad)
+                            : d3_walk_count(vd.n_len, vd.len0, vd.len1, vd.start_seg, vd.start_t, (int)ns, lseg, lwin + tid, nw, av, &bad);
       const int dev = draws - (int)vd.dmin;
       if (dev < 0 || dev > (int)vd.dspread) bad = true;
       W.tab[(uint64_t)vd.toff + d] = bad ? (uint16_t)0 : (uint16_t)dev;
@@ -855,7 +869,7 @@ __global__ __launch_bounds__(64) void g2s_d3_trace(const D3Params P, const D3Wor
   const uint32_t i = blockIdx.x;
   const int lane = (int)threadIdx.x;
   SegW* segs = (SegW*)lds;  // the gap's closure segments
-  static_assert(sizeof(g2s_result) == 192, "g2s_result layout");
+  static_assert(sizeof(g2s_result) == 112, "g2s_result layout");
   unsigned long long* laps = (unsigned long long*)((char*)W.sum + 512);
   const unsigned long long tk0 = P.laps ? wall_clock64() : 0ull;
   unsigned long long tk1 = 0, tk2 = 0, tk3 = 0, hops = 0, tkm = 0;
@@ -919,7 +933,7 @@ __global__ __launch_bounds__(64) void g2s_d3_trace(const D3Params P, const D3Wor
   char* buf = arena + abs_off;
   const int k = P.k;
   // the record, words 0-23 of g2s_result (count, left_fuz, right_fuz, flags, fill_off, fill_len, draws, six 64-bit
-  // subgraph statistics, phaseC_count, n_lengths, lengths[2]); backtrace_msg (words 24-47) becomes the empty string
+  // subgraph statistics, phaseC_count, n_lengths, lengths[2]); words 24-27 (the "Unable to backtrace!" numbers) are zero
   uint32_t rw[24];
 #pragma unroll
   for (int q = 0; q < 24; q++) rw[q] = 0u;
@@ -933,7 +947,7 @@ __global__ __launch_bounds__(64) void g2s_d3_trace(const D3Params P, const D3Wor
       uint4* dst = (uint4*)&results[i];
 #pragma unroll
       for (int q = 0; q < 6; q++) dst[q] = make_uint4(rw[4 * q], rw[4 * q + 1], rw[4 * q + 2], rw[4 * q + 3]);
-      dst[6] = make_uint4(0u, 0u, 0u, 0u);  // backtrace_msg = "" (the rest of its 96 bytes is not touched)
+      dst[6] = make_uint4(0u, 0u, 0u, 0u);  // (backtrace_depth, backtrace_final_d: a traceback that fails is the host path's)
     }
   };
   if (gi & (GI_BAD | GI_SKIPPED | GI_MEM)) {

@@ -30,6 +30,8 @@
 /* (with an OVERFLOW bit) a probe loop of the segment tier's large variant ran past its bound: a defect, never
    expected; the gap runs again in the LDS tier instead of holding the GPU */
 #define G2S_DEV_WATCHDOG 0x8000u
+/* the gap ran in the large variant of the segment tier (fill_segw.hip) */
+#define G2S_DEV_BIG 0x10000u
 /* LDS tier, lvl[]: bit 31 of the END offset of level L = L was produced by a bulk step
  * (same width as level L-1, state r has the single parent r of level L-1) */
 #define G2S_LVL_UNIFORM 0x80000000u

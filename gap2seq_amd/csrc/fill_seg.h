@@ -33,8 +33,10 @@ hipError_t launch_fill_seg(hipStream_t st, uint32_t ngaps, const uint32_t* succ,
                            // counters, 8 lists of xcd_stride >= ngaps entries set to 0xFFFFFFFF; pub_batch 1 = per gap
                            unsigned long long* xcd_tickets, uint32_t* xcd_list, uint32_t xcd_stride, uint32_t pub_batch,
                            // results stay on the device (sub_out, outs: device memory; outs_host, done_list unused):
-                           // phase D3 follows on the stream (d3_device.hip)
-                           bool resident = false);
+                           // phase D3 follows on the stream (d3_device.hip); ovf_list (optional, device memory, ngaps
+                           // words): the gaps that outgrew the tier's capacities, counted in out_counter[1], for
+                           // launch_fill_segw(..., ngaps_dev = out_counter + 1) behind this launch
+                           bool resident = false, uint32_t* ovf_list = nullptr);
 
 // The large variant: `workgroups` persistent workgroups (one per compute unit) take the listed gaps
 // in order from the counter *next_gap (zero before the launch); scratch: fill_segx_scratch_bytes().
@@ -55,6 +57,10 @@ hipError_t launch_fill_segw(hipStream_t st, uint32_t ngaps, uint32_t workgroups,
                             const GapDev* gaps, const uint32_t* gap_ids, const uint32_t* flank_nodes, SubRec* sub_out,
                             unsigned long long out_cap, unsigned long long* out_counter, GapOut* outs, GapOut* outs_host,
                             uint32_t* done_list, int skip_confident, uint32_t* dbg, uint32_t* scratch,
-                            unsigned long long* next_gap, bool resident = false);
+                            unsigned long long* next_gap, bool resident = false,
+                            // the number of listed gaps is read from device memory when the kernel starts (the list
+                            // was written by the launch in front: launch_fill_seg's ovf_list); ngaps is then the most
+                            // there can be
+                            const unsigned long long* ngaps_dev = nullptr);
 
 }  // namespace g2s

@@ -304,7 +304,11 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
   // never seen) or that never fills is not lost — the host takes every gap not announced when the launch has ended.
   // The large variant's workgroups publish what several waves stored: it keeps the fences.
   auto publish = [&]() {
-    if (A.resident) return;
+    if (A.resident) {
+      if (A.ovf_list && lane == 0 && (flags & (G2S_DEV_OVERFLOW_A | G2S_DEV_OVERFLOW_B)) && !(flags & G2S_DEV_WATCHDOG))
+        A.ovf_list[atomicAdd(out_counter + 1, 1ull)] = gi;
+      return;
+    }
     if constexpr (BIG) __threadfence();
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if ((uint32_t)lane < sizeof(GapOut) / 4u)
@@ -1882,7 +1886,7 @@ hipError_t launch_fill_seg(hipStream_t st, uint32_t ngaps, const uint32_t* succ,
                            const uint32_t* gap_ids, const uint32_t* flank_nodes, SubRec* sub_out,
                            unsigned long long out_cap, unsigned long long* out_counter, GapOut* outs, GapOut* outs_host,
                            uint32_t* done_list, int skip_confident, uint32_t* dbg, bool two_waves, unsigned long long* xcd_tickets,
-                           uint32_t* xcd_list, uint32_t xcd_stride, uint32_t pub_batch, bool resident) {
+                           uint32_t* xcd_list, uint32_t xcd_stride, uint32_t pub_batch, bool resident, uint32_t* ovf_list) {
   if (ngaps == 0) return hipSuccess;
   size_t bytes = two_waves ? fill_seg2_lds_bytes() : fill_seg_lds_bytes();
   // (G2S_SEG_LDS_PAD=BYTES, measurements only: a larger LDS request per gap = fewer gaps resident per compute unit)
@@ -1892,7 +1896,8 @@ hipError_t launch_fill_seg(hipStream_t st, uint32_t ngaps, const uint32_t* succ,
   if (e != hipSuccess) return e;
   if (!xcd_tickets || !xcd_list || pub_batch < 2u || pub_batch > 64u || (pub_batch & (pub_batch - 1u))) pub_batch = 1u;
   const SegArgs A = {succ, urec, gaps, gap_ids, flank_nodes, sub_out, out_cap, out_counter, outs, outs_host, done_list,
-                     skip_confident, dbg, fill_seg_dbg_words(), xcd_tickets, xcd_list, xcd_stride, pub_batch, resident ? 1u : 0u};
+                     skip_confident, dbg, fill_seg_dbg_words(), xcd_tickets, xcd_list, xcd_stride, pub_batch, resident ? 1u : 0u,
+                     0u, resident ? ovf_list : nullptr};
   if (two_waves) hipLaunchKernelGGL(g2s_fill_seg2, dim3(ngaps), dim3(128), bytes, st, A);
   else hipLaunchKernelGGL(g2s_fill_seg, dim3(ngaps), dim3(64), bytes, st, A);
   return hipGetLastError();
@@ -1908,7 +1913,7 @@ hipError_t launch_fill_segx(hipStream_t st, uint32_t ngaps, uint32_t workgroups,
   hipError_t e = hipFuncSetAttribute((const void*)g2s_fill_segx, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   if (e != hipSuccess) return e;
   const SegArgs A = {succ, urec, gaps, gap_ids, flank_nodes, sub_out, out_cap, out_counter, outs, outs_host, done_list,
-                     skip_confident, dbg, fill_segx_dbg_words(), nullptr, nullptr, 0u, 1u, 0u};
+                     skip_confident, dbg, fill_segx_dbg_words(), nullptr, nullptr, 0u, 1u, 0u, 0u, nullptr};
   hipLaunchKernelGGL(g2s_fill_segx, dim3(workgroups), dim3(64), bytes, st, A, scratch, ngaps, next_gap);
   return hipGetLastError();
 }

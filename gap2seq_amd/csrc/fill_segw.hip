@@ -392,8 +392,9 @@ __device__ __forceinline__ void segw_fill_one(uint32_t* lds, const SegArgs& A, c
   };
   uint32_t acc_sb = 0, acc_xb = 0;
   uint32_t gen = 0;
+  // (both strands of a k-mer at one depth share a probe sequence: the walk that inserts one passes the other — Q7)
   auto e_hash = [&](uint32_t w, uint32_t dw) -> uint32_t {
-    uint32_t h = w * 0x9E3779B1u ^ dw * 0x85EBCA6Bu;
+    uint32_t h = (w >> 1) * 0x9E3779B1u ^ dw * 0x85EBCA6Bu;
     h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
     return h & (HS - 1u);
   };
@@ -436,6 +437,7 @@ __device__ __forceinline__ void segw_fill_one(uint32_t* lds, const SegArgs& A, c
     // the horizon their events were selected under — so a key sits at or before the first empty position of its
     // probe sequence, and two lanes with one key meet at that position)
     uint32_t st = act ? 0u : 3u, mslot = 0, pos = e_hash(w, dw);
+    bool q7 = false;
 #pragma nounroll
     for (uint32_t guard = 0; guard < 2u * HS; guard++) {
       uint2 cc = *(const uint2*)&ht[pos];  // (.x: depth << 16 | slot, .y: node)
@@ -445,7 +447,12 @@ __device__ __forceinline__ void segw_fill_one(uint32_t* lds, const SegArgs& A, c
         cc.x = (uint32_t)prev; cc.y = (uint32_t)(prev >> 32);  // (taken meanwhile: what the other lane put there is looked at now)
         if (prev == SEGX_EMPTY64) st = 1u;
       }
-      const bool hit = st == 0u && cc.y == w && (cc.x & 0xFFFF0000u) == klo;
+      const bool samed = (cc.x & 0xFFFF0000u) == klo;
+      const bool hit = st == 0u && cc.y == w && samed;
+      // Q7: the other strand pending at this depth.  A new event's walk passes every entry of the sequence up to the
+      // first empty position, so of two lanes that insert the two strands the one that comes second sees the other
+      // (its own claim included: a lost compare-and-swap returns what the winner put there).
+      q7 |= cc.y == (w ^ 1u) && samed;
       mslot = hit ? (cc.x & 0xFFFFu) : mslot;
       st = hit ? 2u : st;
       pos = st == 0u ? ((pos + 1u) & (HS - 1u)) : pos;
@@ -482,19 +489,7 @@ __device__ __forceinline__ void segw_fill_one(uint32_t* lds, const SegArgs& A, c
       else { const uint4* u = (const uint4*)(urec + (size_t)w * 8); nrec = u[0]; nes = u[1].x; }
     }
     WFINE(6);
-    // Q7: the other strand pending at this depth.  Looked up behind this lane's own insertion: of two lanes that
-    // insert the two strands in one round, the one whose insertion comes second in the LDS's order sees the other.
-    {
-      uint32_t p2 = e_hash(w ^ 1u, dw), look = st == 1u ? 1u : 0u;
-#pragma nounroll
-      for (uint32_t g2 = 0; g2 < 2u * HS; g2++) {
-        const uint2 cc = *(const uint2*)&ht[p2];
-        if ((cc.x & cc.y) == 0xFFFFFFFFu) look = 0u;
-        if (look && cc.y == (w ^ 1u) && (cc.x & 0xFFFF0000u) == klo) { lflags |= G2S_DEV_Q7_B; look = 0u; }
-        p2 = (p2 + 1u) & (HS - 1u);
-        if (!__ballot(look != 0u)) break;
-      }
-    }
+    if (q7 && st == 1u) lflags |= G2S_DEV_Q7_B;
     if (st == 1u) {
       e_rec[slot] = nrec;
       e_de[slot] = dw | (fixed ? 0x8000u : 0u) | (((int)dw < lmf ? 1u : min(nes + 1u, 0x7FFFu)) << 16);
@@ -724,7 +719,7 @@ __device__ __forceinline__ void segw_fill_one(uint32_t* lds, const SegArgs& A, c
   }
   __syncthreads();
   overflow = overflow0 || sh[SH_OVF] != 0u;
-  uint32_t flags = sh[SH_FLAGS];
+  uint32_t flags = sh[SH_FLAGS] | G2S_DEV_BIG;
   if (overflow && !(flags & G2S_DEV_OVERFLOW_A)) flags |= G2S_DEV_OVERFLOW_B;
   const uint32_t nseg = min(sh[SH_NSEG], CAP);
   uint32_t sb = sh[SH_SB] + sh[SH_CHAIN], xb = sh[SH_XB] + sh[SH_CHAIN];
@@ -1276,9 +1271,10 @@ __device__ __forceinline__ void segw_fill_one(uint32_t* lds, const SegArgs& A, c
 
 // The large variant: one workgroup of eight waves per compute unit (it takes all of the LDS), each working through
 // the list by an atomic counter so that the longest searches (the list is sorted) start first.
-__global__ __launch_bounds__(SEGW_NT) void g2s_fill_segw(const SegArgs A, uint32_t* scratch, uint32_t ngaps,
-                                                          unsigned long long* next_gap) {
+__global__ __launch_bounds__(SEGW_NT) void g2s_fill_segw(const SegArgs A, uint32_t* scratch, uint32_t ngaps_max,
+                                                          unsigned long long* next_gap, const unsigned long long* ngaps_dev) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  const uint32_t ngaps = ngaps_dev ? min((uint32_t)*ngaps_dev, ngaps_max) : ngaps_max;
   uint32_t* scr = scratch + (size_t)blockIdx.x * SEGW_SCR_WORDS;
   uint32_t* sh = lds + (SEGW_LDS_WORDS - SH_WORDS);
   while (true) {
@@ -1301,14 +1297,14 @@ hipError_t launch_fill_segw(hipStream_t st, uint32_t ngaps, uint32_t workgroups,
                             const GapDev* gaps, const uint32_t* gap_ids, const uint32_t* flank_nodes, SubRec* sub_out,
                             unsigned long long out_cap, unsigned long long* out_counter, GapOut* outs, GapOut* outs_host,
                             uint32_t* done_list, int skip_confident, uint32_t* dbg, uint32_t* scratch,
-                            unsigned long long* next_gap, bool resident) {
+                            unsigned long long* next_gap, bool resident, const unsigned long long* ngaps_dev) {
   if (ngaps == 0) return hipSuccess;
   const size_t bytes = fill_segw_lds_bytes();
   hipError_t e = hipFuncSetAttribute((const void*)g2s_fill_segw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   if (e != hipSuccess) return e;
   SegArgs A = {succ, urec, gaps, gap_ids, flank_nodes, sub_out, out_cap, out_counter, outs, outs_host, done_list,
-               skip_confident, dbg, fill_segx_dbg_words(), nullptr, nullptr, 0u, 1u, resident ? 1u : 0u};
-  hipLaunchKernelGGL(g2s_fill_segw, dim3(workgroups), dim3(SEGW_NT), bytes, st, A, scratch, ngaps, next_gap);
+               skip_confident, dbg, fill_segx_dbg_words(), nullptr, nullptr, 0u, 1u, resident ? 1u : 0u, 0u, nullptr};
+  hipLaunchKernelGGL(g2s_fill_segw, dim3(workgroups), dim3(SEGW_NT), bytes, st, A, scratch, ngaps, next_gap, ngaps_dev);
   return hipGetLastError();
 }
 

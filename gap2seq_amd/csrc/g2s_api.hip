@@ -52,6 +52,14 @@ static int fail(int code, const std::string& msg) { tl_error = msg; return code;
   } while (0)
 
 extern "C" int g2s_abi_version(void) { return G2S_ABI_VERSION; }
+extern "C" size_t g2s_backtrace_text(const g2s_gap* gap, const g2s_result* r, int k, char* out, size_t cap) {
+  if (!gap || !r || !out || cap == 0 || !(r->flags & G2S_GAP_BACKTRACE_FAIL)) return 0;
+  std::string kmer;
+  if (r->right_fuz >= 0 && gap->right && (int64_t)r->right_fuz + k <= (int64_t)gap->right_len)
+    for (int x = 0; x < k; x++) kmer.push_back((char)toupper((unsigned char)gap->right[r->right_fuz + x]));
+  const int len = snprintf(out, cap, "Unable to backtrace! %d %d %s", r->backtrace_depth, r->backtrace_final_d, kmer.c_str());
+  return len < 0 ? 0 : std::min<size_t>((size_t)len, cap - 1);
+}
 extern "C" const char* g2s_last_error(void) { return tl_error.c_str(); }
 extern "C" void g2s_free(void* p) { free(p); }
 extern "C" void* g2s_host_alloc(size_t bytes) {
@@ -537,6 +545,7 @@ struct g2s_session {
   std::vector<SubPrep> spare_prep;
   DevBuf d_log, d_lvl, d_plk, d_xl, d_xo;  // LDS tier: state log, level offsets, parent links, closure side lists
   DevBuf d_segx;  // large variant of the segment tier: segment arrays and queues of its persistent workgroups
+  DevBuf d_ovf;   // resident mode: the gaps of a launch that outgrew the regular tier (the large variant's list)
   int num_cus = 256;
   DevBuf d_rspool;
   DevBuf d_logpool;  // chunks for state logs that outgrow their slice of d_log (LDS tier)                          // LDS tier: spill pool for right sets
@@ -564,9 +573,16 @@ struct g2s_session {
   bool team_shares_device = false;  // ... and another session of the team sits on the same device
   int peer_asked_for = -1;       // the lead device this session asked direct access to (team lists)
   bool self_cleaned = false;     // the last list's trace kernel zeroed records, summary and cursors behind itself
-  size_t side_dirty = SIZE_MAX;  // items of h_side whose ready word may be set (resident mode's hand-over)
+  size_t side_dirty = SIZE_MAX;  // items of h_side whose ready word may be set (resident mode's hand-over)...
+  size_t side_layout_n = 0;      // ...under the layout of a list of this many gaps (the arrays behind the items move with it)
   uint32_t timed_seq = 0;        // resident launches so far (one in eight is bracketed with HIP events)
   int resident_strikes = 0;      // lists that had to be run again on the host path; three in a row switch the mode off
+  // The large variant behind the fill kernel of a resident launch (for the gaps that outgrow the regular tier) is an
+  // empty launch on most lists, and an empty launch costs a 500-gap list 5 us of its 210: after eight lists in a row
+  // without such a gap it is left out, until a list has one (that list takes the host path once) or is deep by its
+  // parameters.
+  int segw_quiet = 0;
+  hipEvent_t ev_segw = nullptr;  // behind the large variant's launch (timed launches)
   bool resident_off = false;
 };
 
@@ -632,6 +648,7 @@ extern "C" int g2s_session_create(g2s_graph* g, int device, const g2s_params* p,
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_rand, hipEventDisableTiming);
   for (int i = 0; i < 5 && e == hipSuccess; i++) e = hipEventCreate(&s->ev[i]);
+  if (e == hipSuccess) e = hipEventCreate(&s->ev_segw);
   size_t free_b = 0, total_b = 0;
   if (e == hipSuccess) e = hipMemGetInfo(&free_b, &total_b);
   if (e != hipSuccess) { delete s; return fail(G2S_ERR_HIP, std::string("session setup: ") + hipGetErrorString(e)); }
@@ -653,7 +670,7 @@ extern "C" void g2s_session_destroy(g2s_session* s) {
   (void)hipSetDevice(s->device);
   DevBuf* bufs[] = {&s->d_gaps, &s->d_ids, &s->d_flank, &s->d_outs, &s->d_rs, &s->d_rlog, &s->d_keys,
                     &s->d_cnt, &s->d_mark, &s->d_slog, &s->d_subscr, &s->d_subout, &s->d_counter, &s->d_xcd,
-                    &s->d_log, &s->d_lvl, &s->d_plk, &s->d_xl, &s->d_xo, &s->d_rspool, &s->d_logpool, &s->d_segx};
+                    &s->d_log, &s->d_lvl, &s->d_plk, &s->d_xl, &s->d_xo, &s->d_rspool, &s->d_logpool, &s->d_segx, &s->d_ovf};
   for (DevBuf* b : bufs) b->release();
   delete s->pool;
   delete s->team_pool;
@@ -666,6 +683,7 @@ extern "C" void g2s_session_destroy(g2s_session* s) {
   s->d_resout.release(); s->d_textout.release(); s->d_dgap.release(); s->d_sub.release(); s->d_d3.release(); s->d_rnd.release(); s->d_lastch.release(); s->d_rtab.release();
   s->h_d3.release(); s->h_res.release(); s->h_text.release(); s->h_side.release();
   if (s->ev_rand) (void)hipEventDestroy(s->ev_rand);
+  if (s->ev_segw) (void)hipEventDestroy(s->ev_segw);
   if (s->stream2) (void)hipStreamDestroy(s->stream2);
   if (s->stream) (void)hipStreamDestroy(s->stream);
   delete s;
@@ -2467,6 +2485,7 @@ struct ResidentLaunch {
   uint64_t units = 0;
   bool two_waves = false;
   bool timed = false;  // HIP events around the fill kernel
+  bool segw = false;   // the large variant was launched behind it
   size_t launched = 0;
 };
 // Resident mode brackets its kernels with HIP events on one launch in eight (the session's first included): an
@@ -2543,12 +2562,23 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl) {
     b->fast_desc = true;
   }
   // ---- device buffers
-  const uint64_t out_states = (uint64_t)ids.size() * 128u + 2u * G2S_SEG_CAP;  // 16-byte units: two per closure segment
+  // A gap that outgrows the regular tier's capacities runs again in the large variant, behind the fill kernel on
+  // the stream, and stays on the device like the others (one such gap used to send the whole list to the host
+  // path).  Not in a team's groups yet: their closure records are copied to the lead's device by size.
+  const bool rerun = !s->in_team_list && !getenv("G2S_NO_SEGX_TIER") && (s->segw_quiet < 8 || b->dmax >= 2500);
+  rl->segw = rerun;
+  // 16-byte units: two per closure segment (the large variant's closures: thousands of segments)
+  const uint64_t out_states = (uint64_t)ids.size() * 128u + 2u * G2S_SEG_CAP + (rerun ? std::min<uint64_t>((uint64_t)ids.size() * 8192u, 4ull << 20) + 2u * G2S_SEGX_CAP : 0u);
   HIP_TRY(s->d_gaps.ensure(n * sizeof(GapDev)));
   HIP_TRY(s->d_ids.ensure(std::max<size_t>(ids.size() * 4, 16)));
   HIP_TRY(s->d_outs.ensure(n * sizeof(GapOut)));
   HIP_TRY(s->d_counter.ensure(32));
   HIP_TRY(s->d_sub.ensure(out_states * sizeof(SubRec)));
+  const uint32_t segw_wgs = (uint32_t)std::min<size_t>(ids.size(), (size_t)std::max(1, s->num_cus));
+  if (rerun) {
+    HIP_TRY(s->d_ovf.ensure(std::max<size_t>(ids.size() * 4, 16)));
+    HIP_TRY(s->d_segx.ensure(fill_segw_scratch_bytes(segw_wgs)));
+  }
   hipStream_t st = s->stream;
   void* d_gaps_host = nullptr;
   HIP_TRY(hipHostGetDevicePointer(&d_gaps_host, s->h_gaps.p, 0));
@@ -2574,8 +2604,17 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl) {
   HIP_TRY(launch_fill_seg(st, (uint32_t)ids.size(), dg.succ, dg.urec, gaps_dev, ids_dev, (const uint32_t*)s->d_flank.p,
                           (SubRec*)s->d_sub.p, (unsigned long long)out_states, (unsigned long long*)s->d_counter.p,
                           (GapOut*)s->d_outs.p, nullptr, nullptr, s->params.skip_confident ? 1 : 0, nullptr, two_waves,
-                          nullptr, nullptr, 0u, 1u, true));
+                          nullptr, nullptr, 0u, 1u, true, rerun ? (uint32_t*)s->d_ovf.p : nullptr));
   if (rl->timed) HIP_TRY(hipEventRecord(s->ev[2], st));
+  // (the large variant for what the launch above listed: its workgroups read the list's length from device memory and
+  // leave at once when it is empty — the usual case)
+  if (rerun)
+    HIP_TRY(launch_fill_segw(st, (uint32_t)ids.size(), segw_wgs, dg.succ, dg.urec, gaps_dev, (const uint32_t*)s->d_ovf.p,
+                             (const uint32_t*)s->d_flank.p, (SubRec*)s->d_sub.p, (unsigned long long)out_states,
+                             (unsigned long long*)s->d_counter.p, (GapOut*)s->d_outs.p, nullptr, nullptr,
+                             s->params.skip_confident ? 1 : 0, nullptr, (uint32_t*)s->d_segx.p,
+                             (unsigned long long*)s->d_counter.p + 2, true, (const unsigned long long*)s->d_counter.p + 1));
+  if (rerun && rl->timed) HIP_TRY(hipEventRecord(s->ev_segw, st));
   rl->units = out_states;
   rl->two_waves = two_waves;
   rl->launched = ids.size();
@@ -2639,8 +2678,10 @@ static int resident_d3(g2s_session* s, const ResidentList& L, bool timed, bool r
   D3Side side, side_h;
   {
     side_h.cap_items = n;
-    side_h.cap_segs = std::max<uint64_t>((uint64_t)n * 16u, 65536u);
-    side_h.cap_rnd = rnd_cap / 8 + 65536u;
+    // (deep searches — -dist-error in the thousands — leave closures of thousands of segments to the host's analysis)
+    const bool deep = L.dmax >= 2500;
+    side_h.cap_segs = deep ? std::min<uint64_t>((uint64_t)n * 4096u, 4ull << 20) + 65536u : std::max<uint64_t>((uint64_t)n * 16u, 65536u);
+    side_h.cap_rnd = deep ? rnd_cap + 65536u : rnd_cap / 8 + 65536u;
     const size_t b_items = (n * sizeof(D3HostItem) + 63) & ~(size_t)63, b_outs = (n * sizeof(GapOut) + 63) & ~(size_t)63;
     const size_t b_segs = side_h.cap_segs * sizeof(SegRec);
     const void* side_was = s->h_side.p;
@@ -2651,7 +2692,14 @@ static int resident_d3(g2s_session* s, const ResidentList& L, bool timed, bool r
     side_h.rnd = (uint32_t*)(hp + b_items + b_outs + b_segs);
     side_h.count = (unsigned long long*)(hp + b_items + b_outs + b_segs + ((side_h.cap_rnd * 4 + 63) & ~(size_t)63));
     *(volatile unsigned long long*)side_h.count = ~0ull;  // (until the number of items is known)
-    for (size_t x = 0, z = std::min(s->side_dirty, n); x < z; x++) side_h.items[x].pad = 0;  // the items' ready words
+    // the items' ready words.  The arrays behind the items begin where a list of n gaps puts them: a list of another
+    // length wrote its records, segments and values over what is item space now — every word is zeroed then; lists of
+    // one length in a row (the usual case) only left the words of their own items set.
+    {
+      const size_t z = (s->side_layout_n == n) ? std::min(s->side_dirty, n) : n;
+      for (size_t x = 0; x < z; x++) side_h.items[x].pad = 0;
+    }
+    s->side_layout_n = n;
     s->side_dirty = n;  // (until this list is through: any of them may be written)
     void* dp = nullptr;
     HIP_TRY(hipHostGetDevicePointer(&dp, s->h_side.p, 0));
@@ -2813,11 +2861,17 @@ static int resident_d3(g2s_session* s, const ResidentList& L, bool timed, bool r
     if (getenv("G2S_DEBUG"))
       fprintf(stderr, "[g2s] resident mode: list of %zu gaps goes to the host path (status %#x, %u gaps not finished on the device, %u anomalies, %llu table entries, %d host-finished gaps disagree)\n",
               n, hsum->status, hsum->unhandled, hsum->anomalies, (unsigned long long)hsum->table_entries, host_bad.load());
-    if (!test_fallback && ++s->resident_strikes >= 3) s->resident_off = true;
+    // (only what points at a defect counts towards switching the mode off for the session: a walk that met something
+    // unexpected, a host-finished gap that disagrees.  A gap beyond every tier's capacity, tables beyond the budget,
+    // a side buffer that was too small are properties of that list.)
+    const bool defect = hsum->anomalies != 0 || host_bad.load();
+    if (hsum->unhandled) s->segw_quiet = 0;  // (a gap outgrew the regular tier: the large variant follows the next lists' kernels again)
+    if (!test_fallback && defect && ++s->resident_strikes >= 3) s->resident_off = true;
     *fell_back = true;
     return G2S_OK;
   }
   s->resident_strikes = 0;
+  s->segw_quiet = hsum->big_gaps ? 0 : std::min(s->segw_quiet + 1, 1 << 20);
   s->side_dirty = ni;  // (the ready words this list set)
   // ---- results that went through staging
   if (!res_direct || !arena_direct) {
@@ -2837,7 +2891,8 @@ static int resident_d3(g2s_session* s, const ResidentList& L, bool timed, bool r
   g2s_timing& tm = *tm_out;
   tm.xA += hsum->xA; tm.sA += hsum->sA; tm.xB += hsum->xB; tm.sB += hsum->sB; tm.xD += hsum->xD; tm.sD += hsum->sD;
   tm.seg_segments += hsum->segs;
-  tm.seg_tier_gaps += hsum->seg_gaps;
+  tm.seg_tier_gaps += hsum->seg_gaps - hsum->big_gaps;
+  tm.segx_tier_gaps += hsum->big_gaps;
   tm.fill_bytes += hsum->fill_bytes;
   tm.ms_d3 += ms_d3;
   tm.resident_launches++;
@@ -2903,9 +2958,11 @@ int run_resident(g2s_batch* b, g2s_result* results, char* arena) {
   else { const int r2 = resident_reset_fill(s, n); if (r2 != G2S_OK) return r2; }
   s->self_cleaned = false;
   if (fell_back) { b->timing.resident_fallbacks++; return 1; }
-  float ms_fill = 0;
+  float ms_fill = 0, ms_segw = 0;
   if (rl.timed) HIP_TRY(hipEventElapsedTime(&ms_fill, s->ev[1], s->ev[2]));
+  if (rl.timed && rl.segw) HIP_TRY(hipEventElapsedTime(&ms_segw, s->ev[2], s->ev_segw));
   g2s_timing& tm = b->timing;
+  if (rl.segw) { tm.ms_fill_segx += ms_segw; tm.segx_launches++; tm.ms_d3 -= std::min<double>(tm.ms_d3, ms_segw); }
   tm.ms_fill_seg += ms_fill;
   tm.seg_launches++;
   if (rl.timed) tm.seg_timed_launches++;

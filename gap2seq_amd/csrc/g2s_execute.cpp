@@ -248,7 +248,10 @@ extern "C" int g2s_execute_scaffolds_stream(g2s_session* s, const g2s_run_opts* 
         const g2s_result& r = results[(size_t)ev.job];
         const int sres = r.count;
         const char* tail = arena + r.fill_off;
-        if (r.flags & G2S_GAP_BACKTRACE_FAIL) os << r.backtrace_msg << "\n";
+        if (r.flags & G2S_GAP_BACKTRACE_FAIL) {
+          char msg[192];
+          if (g2s_backtrace_text(&jobs[(size_t)ev.job], &r, k, msg, sizeof msg)) os << msg << "\n";
+        }
         const int filledStart = (int)filledSeq.length() + kmer_start + k + lmf - r.left_fuz - prevGapEnd;
         const int gapStart = kmer_start + k + lmf;
         stats_line(os, filledStart, gapStart, (int)i, sres, tail, k, lmf, rmf, r.left_fuz, r.right_fuz,
@@ -351,7 +354,10 @@ extern "C" int g2s_execute_single(g2s_session* s, const g2s_run_opts* o, const c
   std::vector<char> arena((size_t)(length + k + p.d_err + lmf + rmf + 3));
   int rc = g2s_fill_batch(s, &gj, 1, &r, arena.data(), arena.size());
   if (rc != G2S_OK) return rc;
-  if (r.flags & G2S_GAP_BACKTRACE_FAIL) os << r.backtrace_msg << "\n";
+  if (r.flags & G2S_GAP_BACKTRACE_FAIL) {
+    char msg[192];
+    if (g2s_backtrace_text(&gj, &r, k, msg, sizeof msg)) os << msg << "\n";
+  }
   const char* tail = arena.data() + r.fill_off;
   const int filledStart = (int)left_flank.length() - lmf - r.left_fuz;  // :257
   stats_line(os, filledStart, (int)left_flank.length(), (int)left_flank.length() + length, r.count, tail, k, lmf, rmf,

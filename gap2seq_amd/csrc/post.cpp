@@ -400,8 +400,8 @@ void sub_traceback(const Graph& g, const FillParams& p, const GapJob& job, const
         for (int nt = 0; nt < 4; nt++) if (by_slot[nt] >= 0) back[w++] = by_slot[nt];
       }
       if (nb == 0) {  // :1493-1510
-        snprintf(res->backtrace_msg, sizeof res->backtrace_msg, "Unable to backtrace! %d %d %s", d2, go.final_d,
-                 g.node_string(job.targets()[go.reached_j]).c_str());
+        res->backtrace_depth = d2;  // :1494 (the line itself: g2s_backtrace_text)
+        res->backtrace_final_d = go.final_d;
         res->flags |= G2S_GAP_BACKTRACE_FAIL;
         res->count = 0;
         buf[lmf] = '\0';  // no fill: the caller's view of the buffer starts here (left_fuz stays 0)
@@ -1039,8 +1039,8 @@ void seg_traceback(const Graph& g, const FillParams& p, const GapJob& job, const
         for (int nt = 0; nt < 4; nt++) if (by_slot[nt] >= 0) back[w++] = (uint32_t)by_slot[nt];
       }
       if (nb == 0) {  // :1493-1510
-        snprintf(res->backtrace_msg, sizeof res->backtrace_msg, "Unable to backtrace! %d %d %s", d2, go.final_d,
-                 g.node_string(job.targets()[go.reached_j]).c_str());
+        res->backtrace_depth = d2;  // :1494 (the line itself: g2s_backtrace_text)
+        res->backtrace_final_d = go.final_d;
         res->flags |= G2S_GAP_BACKTRACE_FAIL;
         res->count = 0;
         buf[lmf] = '\0';

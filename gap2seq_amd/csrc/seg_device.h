@@ -157,7 +157,10 @@ struct SegArgs {
   // the results stay on the device (sub_out and outs are device memory, phase D3 follows on the stream:
   // d3_device.hip): nothing is announced to the host, no write-back of the L2 per gap
   uint32_t resident;
-  uint32_t dbg_flags;  // (tests) bit 0: the large variant deals no children to lanes (successor slot by slot)
+  uint32_t dbg_flags;  // (unused)
+  // resident mode: a gap that outgrows the regular tier's capacities enters itself here (count: out_counter[1]); the
+  // large variant follows on the stream and takes the list (fill_segw.hip) — the gap's results stay on the device too
+  uint32_t* ovf_list;
 };
 
 // LDS of the large variant (words): see the layout notes at each phase

@@ -46,7 +46,8 @@ class g2s_result(C.Structure):
                 ("vertices", C.c_uint64), ("edges", C.c_uint64), ("nontrivial_components", C.c_uint64),
                 ("size_nontrivial_components", C.c_uint64), ("vertices_final", C.c_uint64),
                 ("edges_final", C.c_uint64), ("phaseC_count", C.c_int32), ("n_lengths", C.c_int32),
-                ("lengths", C.c_int32 * 2), ("backtrace_msg", C.c_char * 96)]
+                ("lengths", C.c_int32 * 2), ("backtrace_depth", C.c_int32), ("backtrace_final_d", C.c_int32),
+                ("reserved", C.c_int32 * 2)]
 
 
 class g2s_timing(C.Structure):
@@ -83,6 +84,7 @@ _VP = C.c_void_p
 TEXT_FN = C.CFUNCTYPE(None, C.POINTER(C.c_char), C.c_size_t, C.c_void_p)  # g2s_text_fn
 _SIGS = {
     "g2s_abi_version": (C.c_int, []),
+    "g2s_backtrace_text": (C.c_size_t, [C.POINTER(g2s_gap), C.POINTER(g2s_result), C.c_int, C.c_char_p, C.c_size_t]),
     "g2s_last_error": (C.c_char_p, []),
     "g2s_graph_build_files": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(_VP)]),
     "g2s_graph_build_seqs": (C.c_int, [C.POINTER(C.c_char_p), C.POINTER(C.c_uint64), C.c_int, C.c_int, C.c_int,
@@ -372,10 +374,11 @@ class FillResult:
 
     def __init__(self, r, arena):
         for name, _ in g2s_result._fields_:
-            if name not in ("lengths", "backtrace_msg"):
+            if name not in ("lengths", "reserved"):
                 setattr(self, name, getattr(r, name))
         self.lengths = [r.lengths[i] for i in range(r.n_lengths)]
-        self.backtrace_msg = r.backtrace_msg.decode("ascii", "replace")
+        # (the reference's "Unable to backtrace!" line minus the k-mer, which g2s_backtrace_text reads from the gap)
+        self.backtrace_msg = ("Unable to backtrace! %d %d" % (r.backtrace_depth, r.backtrace_final_d)) if r.flags & G2S_GAP_BACKTRACE_FAIL else ""
         self.fill = arena[r.fill_off:r.fill_off + r.fill_len].decode("ascii") if r.fill_len > 0 else ""
         self.substats = [r.vertices, r.edges, r.nontrivial_components, r.size_nontrivial_components,
                          r.vertices_final, r.edges_final]

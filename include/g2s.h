@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define G2S_ABI_VERSION 3
+#define G2S_ABI_VERSION 4
 
 /* status codes */
 #define G2S_OK 0
@@ -151,8 +151,17 @@ typedef struct g2s_result {
   int32_t phaseC_count;
   int32_t n_lengths;
   int32_t lengths[2];
-  char backtrace_msg[96]; /* text of the "Unable to backtrace!" line, else "" */
+  /* G2S_GAP_BACKTRACE_FAIL: the two numbers of the reference's "Unable to backtrace!" line (Gap2Seq.cpp:1494:
+   * currentD2, currentD); g2s_backtrace_text() makes the line.  (ABI 3 carried the 96-byte text in every record:
+   * 1.9 MB of a 10 000-gap list's 7.7 MB over the link, for a line no gap of the test lists ever printed.) */
+  int32_t backtrace_depth, backtrace_final_d;
+  int32_t reserved[2];    /* the record is 112 bytes: seven 16-byte stores of the trace kernel */
 } g2s_result;
+
+/* The reference's line for a gap flagged G2S_GAP_BACKTRACE_FAIL (Gap2Seq.cpp:1494): "Unable to backtrace! <currentD2>
+ * <currentD> <toString(reachedTarget)>", without the newline; the k-mer is right[right_fuz .. right_fuz + k) in upper
+ * case (the node was built from that text, Gap2Seq.cpp:1113).  Returns the length, or 0 when the gap is not flagged. */
+size_t g2s_backtrace_text(const g2s_gap* gap, const g2s_result* r, int k, char* out, size_t cap);
 
 /* Per-batch measurements (bench.py). */
 typedef struct g2s_timing {

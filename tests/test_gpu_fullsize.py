@@ -103,6 +103,22 @@ def test_c5_full_size_vs_oracle(product, oracle):
     # the segment tier holds the whole list: ~58 % in the tier proper, the deep ones in its large variant
     assert tm.seg_tier_gaps >= 500 and tm.seg_tier_gaps + tm.segx_tier_gaps == 1000
     assert tm.lds_tier_gaps == 0 and tm.retried_gaps == 0 and tm.watchdog_gaps == 0
+    # ...and the list stays on the device (resident mode per gap): the gaps that outgrow the regular tier run again in
+    # the large variant behind it on the stream, closures the device does not analyse are finished by the host under
+    # the trace kernel — nothing is given back to the host path
+    assert tm.resident_launches == 1 and tm.resident_fallbacks == 0 and tm.segx_tier_gaps >= 300
+
+
+def test_c5_on_the_host_path_vs_oracle(product, oracle, monkeypatch):
+    """The same list with resident mode off (G2S_RESIDENT=0): the host path of round 2 — closures into pinned host
+    memory, analysis while the kernels run, in-order offsets, tracebacks on the pool — stays the fallback."""
+    monkeypatch.setenv("G2S_RESIDENT", "0")
+    reads = product.G2S.synth_genome(3000000, 3, 20240101)
+    seqs = _seqs(reads)
+    gaps = _parse_scaffolds(product.G2S.synth_gaps(reads, 31, 10, 1000, 2000, 5000, 20240103))[:400]
+    c, f, tm, xb, sb = _check_batch(product, oracle, seqs, 31, gaps, 2000, seed=1)
+    assert c >= 398 and (tm.xB, tm.sB) == (xb, sb)
+    assert tm.resident_launches == 0 and tm.segx_tier_gaps >= 100 and tm.watchdog_gaps == 0
 
 
 def _simulated_scaffolds(genome, k, fuz, seed, nrec, rec_len):

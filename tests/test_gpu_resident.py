@@ -111,6 +111,52 @@ def test_resident_mode_vs_oracle_on_the_bench_workload(product, oracle, monkeypa
     assert tm.resident_launches == 1 and tm.resident_fallbacks == 0 and tm.seg_tier_gaps == 500
 
 
+def test_one_deep_gap_does_not_send_a_list_to_the_host_path(product, oracle, monkeypatch):
+    """A C2-shaped list of 2 000 gaps with ONE gap planted in its middle that outgrows the regular tier's capacities
+    (6 kbp: more than 512 segments): the gap runs again in the large variant behind the fill kernel on the stream and
+    rejoins the list's phase D3 — the list is finished on the device, nothing is given back, and every gap is the
+    oracle's.  (Until round 3 one such gap discarded the whole attempt.)"""
+    monkeypatch.delenv("G2S_RESIDENT", raising=False)
+    reads = product.G2S.synth_genome(1000000, 3, 20240101)
+    seqs = [ln for ln in reads.splitlines() if not ln.startswith(">")]
+    gaps = _parse_scaffolds(product.G2S.synth_gaps(reads, 31, 10, 2000, 200, 1000, 20240103))
+    deep = _parse_scaffolds(product.G2S.synth_gaps(reads, 31, 10, 3, 6000, 6000, 77))
+    gaps = gaps[:1000] + deep[:1] + gaps[1000:1999]
+    c, f, tm, xb, sb = _check_batch(product, oracle, seqs, 31, gaps, 500, seed=1)
+    assert c >= 1995 and f >= 1900 and (tm.xB, tm.sB) == (xb, sb)
+    assert tm.resident_launches == 1 and tm.resident_fallbacks == 0
+    assert tm.segx_tier_gaps >= 1 and tm.seg_tier_gaps + tm.segx_tier_gaps == 2000 and tm.watchdog_gaps == 0
+
+
+def test_lists_on_one_session_long_short_long(product, monkeypatch):
+    """The ready words of the host-finished gaps across lists of different length on ONE session: a long
+    list sizes the side buffer, a short list runs, then a long list with more host-finished gaps than the short one
+    has gaps — every list against the host path."""
+    reads = product.G2S.synth_genome(200000, 3, 20240101)
+    seqs = [ln for ln in reads.splitlines() if not ln.startswith(">")]
+    allg = _gaps(product, _parse_scaffolds(product.G2S.synth_gaps(reads, 31, 10, 3000, 100, 900, 20240103)))
+    pg = product.Graph.from_seqs(seqs, 31, 1)
+    lists = [allg, allg[:5], allg, allg[:300], allg]
+    try:
+        monkeypatch.setenv("G2S_RESIDENT", "0")
+        s = product.Session(pg, 0, d_err=500, randseed=9)
+        want = [[_key(r) for r in s.fill_batch(L)] for L in lists]
+        s.destroy()
+        monkeypatch.setenv("G2S_RESIDENT", "1")
+        s = product.Session(pg, 0, d_err=500, randseed=9)
+        got, hosts = [], []
+        for L in lists:
+            res, tm = s.fill_batch(L, True, pinned=True)
+            got.append([_key(r) for r in res])
+            hosts.append(tm.host_finished_gaps)
+            assert tm.resident_launches == 1 and tm.resident_fallbacks == 0
+        s.destroy()
+        assert got == want
+        assert hosts[0] > 5  # (more host-finished gaps in the long list than the short list has gaps)
+    finally:
+        pg.free()
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_resident_mode_on_toy_graphs(product, oracle, monkeypatch, seed):
     """Small k, tandem repeats, inverted repeats: most lists hold a closure the device leaves to the host's
