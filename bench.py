@@ -157,6 +157,62 @@ class Runner:
         self._bufs = []
 
 
+class StreamRunner:
+    """K consecutive lists on one session, two in flight (g2s_fill_begin / g2s_fill_end): list i+1 is begun — its
+    look-ups and fill kernel queued — before list i is ended, so they run while list i's phase D3 writes its results
+    through the link.  The product's steady state (Gap2Seq-core -stream-gaps) is such a sequence of lists."""
+
+    def __init__(self, P, session, gaps, nlists, pinned=True):
+        self.P, self.lib, self.s, self.k = P, P.load_library(), session, nlists
+        self.n = len(gaps)
+        self.arr, self._keep = P._gap_array([P.Gap(g["left"], g["right"], g["gap_len"], g["lmf"], g["rmf"]) for g in gaps])
+        self.nbytes = self.lib.g2s_team_arena_bytes(session.h, self.arr, self.n)
+        self.sets = []
+        for _ in range(2):  # (a list's buffers are free again when the list after the next begins)
+            if pinned:
+                a, r = P.HostBuffer(max(1, self.nbytes)), P.HostBuffer(C.sizeof(P.g2s_result) * max(1, self.n))
+                self.sets.append((a, r, C.cast(a.p, C.c_void_p), r.array(P.g2s_result, max(1, self.n))))
+            else:
+                a = C.create_string_buffer(max(1, self.nbytes))
+                self.sets.append((a, None, C.cast(a, C.c_void_p), (P.g2s_result * max(1, self.n))()))
+
+    def _keys(self, q):
+        a, _, _, res = self.sets[q]
+        raw = a.raw
+        return [result_key(self.P.FillResult(res[i], raw)) for i in range(self.n)]
+
+    def run(self, overlapped, keep=False):
+        """srand(1), then the K lists; returns (seconds, per-list result keys when keep)."""
+        self.s.srand(1)
+        out = []
+        t0 = time.perf_counter()
+        if overlapped:
+            for i in range(self.k):
+                _, _, ap, res = self.sets[i & 1]
+                self.P._check(self.lib.g2s_fill_begin(self.s.h, self.arr, self.n, res, ap, self.nbytes))
+                if i >= 1:
+                    self.P._check(self.lib.g2s_fill_end(self.s.h))
+                    if keep:
+                        out.append(self._keys((i - 1) & 1))
+            self.P._check(self.lib.g2s_fill_end(self.s.h))
+            if keep:
+                out.append(self._keys((self.k - 1) & 1))
+        else:
+            for i in range(self.k):
+                _, _, ap, res = self.sets[i & 1]
+                self.P._check(self.lib.g2s_fill_batch(self.s.h, self.arr, self.n, res, C.cast(ap, C.c_char_p), self.nbytes))
+                if keep:
+                    out.append(self._keys(i & 1))
+        return time.perf_counter() - t0, out
+
+    def free(self):
+        for a, r, _, _ in self.sets:
+            if r is not None:
+                a.free()
+                r.free()
+        self.sets = []
+
+
 def result_key(r):
     return (r.count, r.left_fuz, r.right_fuz, r.flags, r.draws, r.fill, tuple(r.substats), r.phaseC_count, tuple(r.lengths))
 
@@ -191,6 +247,9 @@ def main():
                     help="results and fill arena in ordinary memory instead of g2s_host_alloc's page-locked memory")
     ap.add_argument("--backend", default="gloo", help="torch.distributed backend for the barriers under torchrun")
     ap.add_argument("--share-device", action="store_true", help="testing only: all N sessions on HIP device 0")
+    ap.add_argument("--stream-lists", type=int, default=0,
+                    help="N=1: also measure K consecutive lists of the workload with two in flight (g2s_fill_begin / "
+                         "g2s_fill_end) against the same K lists one at a time; reported as `stream_lists`")
     ap.add_argument("--dry-run", action="store_true",
                     help="testing only (CPU): the launch protocol — rendezvous, barriers, timing reduction, one JSON "
                          "line from rank 0 — without touching a device or measuring anything")
@@ -374,6 +433,29 @@ def main():
                          roofline_frac=round(ab3 / (kms3 / 1e3) / 1e9 / HBM_PEAK_GBS, 6) if ab3 is not None else None,
                          filled=sum(1 for r in r3.results() if r.count > 0))
 
+    # ---- N=1: K consecutive lists, two in flight, against the same lists one at a time ---------------
+    stream_lists = None
+    if ngpu == 1 and len(sessions) == 1 and args.stream_lists >= 2:
+        sr = StreamRunner(P, sessions[0], gaps, args.stream_lists, not args.pageable_buffers)
+        _, want = sr.run(False, keep=True)
+        _, got = sr.run(True, keep=True)
+        if got != want:
+            raise SystemExit("bench.py: %d lists with two in flight differ from the lists one at a time" % args.stream_lists)
+        reps = max(3, min(steps, 10))
+        for _ in range(2):
+            sr.run(True)
+        t_ov = sum(sr.run(True)[0] for _ in range(reps))
+        for _ in range(2):
+            sr.run(False)
+        t_seq = sum(sr.run(False)[0] for _ in range(reps))
+        tot = float(len(gaps) * args.stream_lists * reps)
+        stream_lists = dict(lists=args.stream_lists, gaps_per_list=len(gaps), repetitions=reps,
+                            value=round(tot / t_ov, 2), unit="gaps/s", ms_per_list=round(t_ov / (args.stream_lists * reps) * 1e3, 4),
+                            one_list_at_a_time=round(tot / t_seq, 2), ms_per_list_one_at_a_time=round(t_seq / (args.stream_lists * reps) * 1e3, 4),
+                            results="identical to the lists one at a time, list by list (checked in this run)",
+                            how="g2s_fill_begin(list i+1) before g2s_fill_end(list i): look-ups and fill kernel of the next list run while this one's phase D3 writes through the link")
+        sr.free()
+
     # ---- CPU baseline: the oracle (port of the reference algorithm) on the GPU box's host cores,
     # N=1 only, on a bounded sample of the same gaps
     cpu = None
@@ -534,6 +616,8 @@ def main():
         out["equals_one_gpu_result"] = True
     if c3_beside is not None:
         out["c3_on_one_gpu"] = c3_beside
+    if stream_lists is not None:
+        out["stream_lists"] = stream_lists
     print(json.dumps(out))
     for s in sessions:
         s.destroy()

@@ -473,6 +473,7 @@ struct RandCache {
   int32_t at_const(size_t off) const { return st.value(off); }  // already materialised
   bool would_grow(size_t n) const { return st.would_grow(n); }  // ensure(n) would move the buffer
   void consume(size_t n) { st.consume(n); }
+  void swap(RandCache& o) { st.swap(o.st); }
 };
 
 // One helper thread per session for the work that runs beside a batch (materialising rand() values):
@@ -583,6 +584,17 @@ struct g2s_session {
   // parameters.
   int segw_quiet = 0;
   hipEvent_t ev_segw = nullptr;  // behind the large variant's launch (timed launches)
+  // g2s_fill_begin / g2s_fill_end: up to two lists in flight, alternating between this session and a twin on the same
+  // device (own stream and buffers; created on first use).  The rand() stream is this session's: a list that ends on
+  // the twin borrows it.
+  g2s_session* twin = nullptr;
+  void* d3_pending = nullptr;  // (D3Pending) phase D3 of a list queued on this session's stream and not waited for yet
+  struct InFlight { g2s_batch* b = nullptr; g2s_session* on = nullptr; g2s_result* results = nullptr; char* arena = nullptr; size_t cap = 0;
+                    const g2s_gap* gaps = nullptr; size_t n = 0; double ms_prepare = 0;
+                    bool d3_queued = false; };
+  InFlight inflight[2];
+  int n_inflight = 0;
+  uint64_t begun = 0;
   bool resident_off = false;
 };
 
@@ -667,6 +679,12 @@ extern "C" int g2s_session_create(g2s_graph* g, int device, const g2s_params* p,
 
 extern "C" void g2s_session_destroy(g2s_session* s) {
   if (!s) return;
+  for (int q = 0; q < s->n_inflight; q++) {  // (lists begun and never ended: their kernels first)
+    if (s->inflight[q].on) { (void)hipSetDevice(s->inflight[q].on->device); (void)hipStreamSynchronize(s->inflight[q].on->stream); }
+    g2s_batch_free(s->inflight[q].b);
+  }
+  s->n_inflight = 0;
+  if (s->twin) { g2s_session_destroy(s->twin); s->twin = nullptr; }
   (void)hipSetDevice(s->device);
   DevBuf* bufs[] = {&s->d_gaps, &s->d_ids, &s->d_flank, &s->d_outs, &s->d_rs, &s->d_rlog, &s->d_keys,
                     &s->d_cnt, &s->d_mark, &s->d_slog, &s->d_subscr, &s->d_subout, &s->d_counter, &s->d_xcd,
@@ -720,6 +738,11 @@ struct g2s_batch {
   int gmax = 0, dmax = 0;                       // longest gap, deepest search
   size_t rnd_cap = 0, n_valid = 0;              // rand() values the list can draw at most; gaps with complete flanks
   bool fast_desc = false;                       // GapDev / D3Gap of every gap are in the session's pinned buffers (desc_owner)
+  // g2s_fill_begin: the fill kernel of this list has been queued already (resident_launch_fill); g2s_batch_run goes on
+  // with phase D3
+  bool pre_launched = false, pre_two = false, pre_timed = false, pre_segw = false;
+  bool d3_queued = false;  // ...and its phase D3 too (resident_queue_d3): g2s_batch_run only waits
+  uint64_t pre_units = 0;
   int upload_flanks();
   size_t arena_bytes = 0;
   std::vector<size_t> arena_off;  // of each gap's fill buffer within the batch's share of the arena
@@ -2663,13 +2686,26 @@ static int resident_rand(g2s_session* s, PinBuf* pin, size_t n, size_t list_cap)
   return G2S_OK;
 }
 
-static int resident_d3(g2s_session* s, const ResidentList& L, bool timed, bool rand_launched, g2s_result* results, char* arena,
-                       g2s_timing* tm_out, double* ms_d3_out, bool* fell_back) {
+// (what the second half — waiting, the host-finished gaps, the summary — needs of the first: queueing the kernels)
+struct D3Pending {
+  ResidentList L;
+  bool timed = false, res_direct = false, arena_direct = false, stage_dev = false, self_clean = false;
+  D3Side side_h;
+  D3Work W;
+  D3Summary* hsum = nullptr;
+  hipEvent_t d3_begin = nullptr;
+  g2s_result* results = nullptr;
+  char* arena = nullptr;
+  std::chrono::steady_clock::time_point t_enter, t_launched;
+};
+// first half: everything of phase D3 queued on the session's stream(s), nothing waited for (no_spin: not even the
+// few microseconds for the rand() stream's kernel — the main stream waits for its event instead)
+static int resident_d3_launch(g2s_session* s, const ResidentList& L, bool timed, bool rand_launched, g2s_result* results, char* arena,
+                              bool no_spin) {
   const size_t n = L.n;
   const Graph& g = *s->graph->g;
   const FillParams fp = fill_params_of(s);
   const auto t_enter = std::chrono::steady_clock::now();
-  *fell_back = false;
   if (hipSetDevice(s->device) != hipSuccess) return fail(G2S_ERR_NO_DEVICE, "cannot select device");
   D3Summary* hsum = (D3Summary*)((char*)L.pin->p + n * sizeof(D3Gap) + 16 - (n * sizeof(D3Gap)) % 16);
   const size_t rnd_cap = rand_capacity(L.rnd_cap);
@@ -2751,7 +2787,7 @@ static int resident_d3(g2s_session* s, const ResidentList& L, bool timed, bool r
   {
     const auto t_w = std::chrono::steady_clock::now();
     hipError_t q = hipErrorNotReady;
-    while ((q = hipEventQuery(s->ev_rand)) == hipErrorNotReady &&
+    while (!no_spin && (q = hipEventQuery(s->ev_rand)) == hipErrorNotReady &&
            std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_w).count() < 200.0)
       cpu_relax();
     if (q != hipSuccess) HIP_TRY(hipStreamWaitEvent(st, s->ev_rand, 0));
@@ -2790,7 +2826,37 @@ static int resident_d3(g2s_session* s, const ResidentList& L, bool timed, bool r
     HIP_TRY(hipMemcpyAsync(results, s->d_resout.p, n * sizeof(g2s_result), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(arena, s->d_textout.p, L.arena_bytes, hipMemcpyDeviceToHost, st));
   }
-  const auto t_launched = std::chrono::steady_clock::now();
+  {
+    D3Pending* dp = new D3Pending;
+    dp->L = L; dp->timed = timed; dp->res_direct = res_direct; dp->arena_direct = arena_direct; dp->stage_dev = stage_dev;
+    dp->self_clean = self_clean; dp->side_h = side_h; dp->W = W; dp->hsum = hsum; dp->d3_begin = d3_begin; dp->results = results;
+    dp->arena = arena; dp->t_enter = t_enter; dp->t_launched = std::chrono::steady_clock::now();
+    delete (D3Pending*)s->d3_pending;
+    s->d3_pending = dp;
+  }
+  return G2S_OK;
+}
+// second half: the hand-over, the gaps the host finishes, the end of the stream's work, the summary
+static int resident_d3_wait(g2s_session* s, g2s_timing* tm_out, double* ms_d3_out, bool* fell_back) {
+  *fell_back = false;
+  std::unique_ptr<D3Pending> dpp((D3Pending*)s->d3_pending);
+  s->d3_pending = nullptr;
+  if (!dpp) return fail(G2S_ERR_ARG, "resident mode: no phase D3 queued");
+  const ResidentList& L = dpp->L;
+  const size_t n = L.n;
+  const Graph& g = *s->graph->g;
+  const FillParams fp = fill_params_of(s);
+  const bool timed = dpp->timed, res_direct = dpp->res_direct, arena_direct = dpp->arena_direct, stage_dev = dpp->stage_dev;
+  const bool self_clean = dpp->self_clean;
+  const D3Side& side_h = dpp->side_h;
+  const D3Work& W = dpp->W;
+  D3Summary* hsum = dpp->hsum;
+  hipEvent_t d3_begin = dpp->d3_begin;
+  g2s_result* results = dpp->results;
+  char* arena = dpp->arena;
+  const auto t_enter = dpp->t_enter, t_launched = dpp->t_launched;
+  if (hipSetDevice(s->device) != hipSuccess) return fail(G2S_ERR_NO_DEVICE, "cannot select device");
+  hipStream_t st = s->stream;
   // ---- gaps the device leaves to the host (their closure holds a k-mer at two depths: post.cpp analyses those):
   // handed over in front of the trace kernel, finished here while it runs — analysis of the closure, traceback,
   // record, written where the kernels write the others' (the caller's buffers or the staging)
@@ -2910,24 +2976,36 @@ static int resident_d3(g2s_session* s, const ResidentList& L, bool timed, bool r
   return G2S_OK;
 }
 
+static int resident_d3(g2s_session* s, const ResidentList& L, bool timed, bool rand_launched, g2s_result* results, char* arena,
+                       g2s_timing* tm_out, double* ms_d3_out, bool* fell_back) {
+  *fell_back = false;
+  const int rc = resident_d3_launch(s, L, timed, rand_launched, results, arena, false);
+  if (rc != G2S_OK) return rc;
+  return resident_d3_wait(s, tm_out, ms_d3_out, fell_back);
+}
+
 // One batch on one session.  Returns G2S_OK (done), 1 (not applicable / fall back to the host path), or an error.
-int run_resident(g2s_batch* b, g2s_result* results, char* arena) {
+// (in two halves for lists in flight — g2s_fill_begin / g2s_fill_end: `queue` puts the list's kernels on the stream,
+// phase D3 included, without waiting for anything; `finish` waits and reads the summary)
+static int run_resident_queue(g2s_batch* b, g2s_result* results, char* arena, bool no_spin, ResidentLaunch* rl_out) {
   g2s_session* s = b->s;
   const size_t n = b->jobs.size();
-  const auto t_enter = std::chrono::steady_clock::now();
-  ResidentLaunch rl;
+  ResidentLaunch& rl = *rl_out;
   // (the stream of rand() values first: it does not depend on the list's kernels — if the list turns out not to be
   // for this mode, a few microseconds of one kernel were for nothing)
   bool rand_launched = false;
   // (a long list only: its look-up kernel and launch preparation leave the stream 50 us to fill in; on a short
   // list the two launches would delay the fill kernel's by 10 us, and its stream is short enough to fill beside it)
-  if (n > 3072 && resident_applicable(s, n) && b->seg_tier_all && !b->host_lookup && b->rnd_cap < (1ull << 31) &&
+  if (!b->pre_launched && n > 3072 && resident_applicable(s, n) && b->seg_tier_all && !b->host_lookup && b->rnd_cap < (1ull << 31) &&
       s->h_d3.cap >= n * sizeof(D3Gap) + 2048 + 64 * 128 + G2S_RAND_WINDOW * 4) {  // (pinned window in place: the launch below will not move it)
     const int rc = resident_rand(s, &s->h_d3, n, b->rnd_cap);
     if (rc != G2S_OK) return rc;
     rand_launched = true;
   }
-  {
+  if (b->pre_launched) {  // (g2s_fill_begin queued the fill kernel when the list was handed over)
+    rl.units = b->pre_units; rl.two_waves = b->pre_two; rl.timed = b->pre_timed; rl.segw = b->pre_segw; rl.launched = b->n_valid;
+    b->pre_launched = false;
+  } else {
     const int rc = resident_launch_fill(b, &rl);
     if (rc != G2S_OK) {
       if (rand_launched) (void)hipStreamSynchronize(s->stream2);  // (its copy reads the pinned window)
@@ -2950,9 +3028,14 @@ int run_resident(g2s_batch* b, g2s_result* results, char* arena) {
     for (size_t i = 0; i < n; i++) dq[i].arena_off += (uint64_t)b->arena_base;
     s->desc_owner = nullptr;
   }
+  return resident_d3_launch(s, L, rl.timed, rand_launched, results, arena, no_spin);
+}
+static int run_resident_finish(g2s_batch* b, const ResidentLaunch& rl, std::chrono::steady_clock::time_point t_enter) {
+  g2s_session* s = b->s;
+  const size_t n = b->jobs.size();
   double ms_d3 = 0;
   bool fell_back = false;
-  const int rc = resident_d3(s, L, rl.timed, rand_launched, results, arena, &b->timing, &ms_d3, &fell_back);
+  const int rc = resident_d3_wait(s, &b->timing, &ms_d3, &fell_back);
   if (rc != G2S_OK) return rc;
   if (s->self_cleaned) { s->d_outs.clean = n * sizeof(GapOut); s->d_counter.clean = 32; }
   else { const int r2 = resident_reset_fill(s, n); if (r2 != G2S_OK) return r2; }
@@ -2970,6 +3053,18 @@ int run_resident(g2s_batch* b, g2s_result* results, char* arena) {
   tm.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enter).count();
   if (getenv("G2S_DEBUG")) fprintf(stderr, "[g2s] resident mode: %zu gaps in %.3f ms (fill kernel %.3f ms)\n", n, tm.ms_total, ms_fill);
   return G2S_OK;
+}
+int run_resident(g2s_batch* b, g2s_result* results, char* arena) {
+  const auto t_enter = std::chrono::steady_clock::now();
+  ResidentLaunch rl;
+  if (b->d3_queued) {  // (g2s_fill_begin queued everything already)
+    b->d3_queued = false;
+    rl.units = b->pre_units; rl.two_waves = b->pre_two; rl.timed = b->pre_timed; rl.segw = b->pre_segw; rl.launched = b->n_valid;
+    return run_resident_finish(b, rl, t_enter);
+  }
+  const int rc = run_resident_queue(b, results, arena, false, &rl);
+  if (rc != G2S_OK) return rc;
+  return run_resident_finish(b, rl, t_enter);
 }
 
 }  // namespace
@@ -3401,6 +3496,78 @@ extern "C" int g2s_fill_batch(g2s_session* s, const g2s_gap* gaps, size_t n, g2s
   s->last_timing.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
   return rc;
 }
+
+// ---- two lists in flight (Gap2Seq-core -stream-gaps, bench.py --stream-lists): the product's steady state is a
+// SEQUENCE of lists, and a list's step is a chain — preparation, look-ups, fill kernel, phase D3, of which the last
+// writes the results through the link.  g2s_fill_begin queues everything up to the fill kernel and returns;
+// g2s_fill_end finishes the oldest list begun.  With a second list begun before the first is ended, its look-ups and
+// fill kernel run on the device while the first one's phase D3 writes through the link.  The lists alternate
+// between the session and a twin of it on the same device; the rand() stream is the session's, handed to
+// whichever of the two ends a list, so the results are those of g2s_fill_batch called list by list.
+extern "C" int g2s_fill_begin(g2s_session* s, const g2s_gap* gaps, size_t n, g2s_result* results, char* fill_arena, size_t arena_cap) {
+  if (!s || (!gaps && n) || (!results && n)) return fail(G2S_ERR_ARG, "g2s_fill_begin: bad argument");
+  if (s->n_inflight >= 2) return fail(G2S_ERR_ARG, "g2s_fill_begin: two lists are in flight already (g2s_fill_end first)");
+  // The list in flight (begun before this one, all lists before it ended: the rand() stream stands where it starts)
+  // gets its phase D3 queued now, behind its fill kernel: it then runs while this call prepares the new list, whose
+  // look-ups and fill kernel in turn run while that phase D3 writes through the link.
+  if (s->n_inflight == 1 && s->inflight[0].b && s->inflight[0].b->pre_launched && !s->inflight[0].b->d3_queued) {
+    g2s_session::InFlight& o = s->inflight[0];
+    g2s_session* on = o.on;
+    if (on != s) on->rcache.swap(s->rcache);
+    ResidentLaunch rl;
+    const int rc = run_resident_queue(o.b, o.results, o.arena, true, &rl);
+    if (on != s) on->rcache.swap(s->rcache);
+    if (rc < 0) return rc;
+    if (rc == G2S_OK) { o.b->d3_queued = true; o.b->pre_units = rl.units; o.b->pre_two = rl.two_waves; o.b->pre_timed = rl.timed; o.b->pre_segw = rl.segw; }
+  }
+  g2s_session::InFlight f;
+  f.results = results; f.arena = fill_arena; f.cap = arena_cap; f.gaps = gaps; f.n = n;
+  const size_t group = s->team_group ? s->team_group : (s->helpers.empty() ? (size_t)16384 : (size_t)2048);
+  if (n <= group && n > 0) {
+    g2s_session* on = s;
+    if (s->begun & 1u) {
+      if (!s->twin) {
+        const int rc = g2s_session_create(s->graph, s->device, &s->params, &s->twin);
+        if (rc != G2S_OK) return rc;
+      }
+      on = s->twin;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    int rc = g2s_batch_prepare(on, gaps, n, &f.b);
+    if (rc != G2S_OK) return rc;
+    f.ms_prepare = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (arena_cap < f.b->arena_bytes) { g2s_batch_free(f.b); return fail(G2S_ERR_ARG, "g2s_fill_begin: fill arena too small"); }
+    f.on = on;
+    f.b->arena = fill_arena;
+    f.b->arena_base = 0;
+    ResidentLaunch rl;
+    rc = resident_launch_fill(f.b, &rl);  // (1: not a list for resident mode — g2s_fill_end runs it on the host path)
+    if (rc < 0) { g2s_batch_free(f.b); return rc; }
+    if (rc == G2S_OK) {
+      f.b->pre_launched = true; f.b->pre_units = rl.units; f.b->pre_two = rl.two_waves; f.b->pre_timed = rl.timed; f.b->pre_segw = rl.segw;
+    }
+  }  // (a list for the team pipeline, or an empty one: g2s_fill_end calls g2s_fill_batch)
+  s->inflight[s->n_inflight++] = f;
+  s->begun++;
+  return G2S_OK;
+}
+extern "C" int g2s_fill_end(g2s_session* s) {
+  if (!s || s->n_inflight < 1) return fail(G2S_ERR_ARG, "g2s_fill_end: no list in flight");
+  g2s_session::InFlight f = s->inflight[0];
+  s->inflight[0] = s->inflight[1];
+  s->inflight[1] = g2s_session::InFlight();
+  s->n_inflight--;
+  if (!f.b) return g2s_fill_batch(s, f.gaps, f.n, f.results, f.arena, f.cap);
+  g2s_session* on = f.on;
+  if (on != s) on->rcache.swap(s->rcache);  // the one rand() stream (:178), wherever the list ends
+  const int rc = g2s_batch_run(f.b, f.results, f.arena, f.cap);
+  if (on != s) on->rcache.swap(s->rcache);
+  g2s_batch_free(f.b);
+  s->last_timing = on->last_timing;
+  s->last_timing.ms_prepare = f.ms_prepare;
+  return rc;
+}
+extern "C" int g2s_fill_in_flight(const g2s_session* s) { return s ? s->n_inflight : 0; }
 
 extern "C" int g2s_session_set_team(g2s_session* lead, g2s_session* const* helpers, int nhelpers, size_t group_size) {
   if (!lead || nhelpers < 0 || (nhelpers && !helpers)) return fail(G2S_ERR_ARG, "g2s_session_set_team: bad argument");

@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <memory>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -132,13 +133,50 @@ extern "C" int g2s_execute_scaffolds_stream(g2s_session* s, const g2s_run_opts* 
   std::string filledSeq;
   bool done = recs.empty();
 
-  while (!done) {
-    // ---- static scan: collect gaps until the input ends or a barrier is hit ----
+  // A batch of gaps from scan to replay.  Two may be in flight (g2s_fill_begin / g2s_fill_end): behind a cut at a
+  // record boundary the next batch's scan does not depend on this one's results, so it is scanned and begun — its
+  // look-ups and fill kernel queued — before this one is ended and replayed; behind a barrier (a gap whose
+  // left_max_fuz depends on the previous gap's right_fuz) the next scan waits for the replay.
+  struct Chunk {
     std::vector<GapEvent> events;
     std::vector<g2s_gap> jobs;
-    std::vector<std::string> flanks;  // keeps left/right strings alive
-    size_t sr = cur_rec, si = i_exact;
-    int sprev = prevGapEnd;
+    std::vector<std::string> flanks;
+    size_t sr = 0, si = 0;
+    bool barrier = false, soft = false;
+    g2s_result* results = nullptr;
+    char* arena = nullptr;
+    size_t arena_bytes = 0;
+    bool begun = false;
+  };
+  // (result records and fill arena in page-locked memory — a list finished on the device is written there by the
+  // kernels themselves; ordinary memory when that cannot be had — two pairs, grow-only, kept across the batches)
+  struct HostBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    bool pinned = false;
+    std::vector<char> plain;
+    void* get(size_t bytes) {
+      if (bytes <= cap && p) return p;
+      if (pinned) g2s_host_free(p);
+      const size_t want = bytes + bytes / 4 + 4096;
+      p = g2s_host_alloc(want);
+      pinned = p != nullptr;
+      if (!p) { plain.resize(want); p = plain.data(); }
+      cap = want;
+      return p;
+    }
+    ~HostBuf() { if (pinned) g2s_host_free(p); }
+  } res_buf[2], arena_buf[2];
+  size_t nchunks = 0;
+
+  // ---- static scan: collect gaps until the input ends, a barrier is hit or the batch is full ----
+  auto scan = [&](size_t start_rec, size_t start_i, int start_prev) -> Chunk* {
+    Chunk* c = new Chunk;
+    std::vector<GapEvent>& events = c->events;
+    std::vector<g2s_gap>& jobs = c->jobs;
+    std::vector<std::string>& flanks = c->flanks;  // keeps left/right strings alive
+    size_t sr = start_rec, si = start_i;
+    int sprev = start_prev;
     bool prev_attempted = false;  // previous gap of this record is in this batch and eligible
     int prev_rmf = 0;
     bool barrier = false, soft = false;
@@ -202,30 +240,32 @@ extern "C" int g2s_execute_scaffolds_stream(g2s_session* s, const g2s_run_opts* 
       jobs[j].right = flanks[flank_idx[j].second].c_str();
     }
 
-    // ---- the hot path: one batch on the GPU -----------------------------------
-    // (result records and fill arena in page-locked memory: a list finished on the device is written there by the
-    // kernels themselves; ordinary memory when that cannot be had)
-    struct HostBuf {
-      void* p = nullptr;
-      bool pinned = false;
-      std::vector<char> plain;
-      void* get(size_t bytes) {
-        p = g2s_host_alloc(bytes);
-        pinned = p != nullptr;
-        if (!p) { plain.resize(bytes); p = plain.data(); }
-        return p;
-      }
-      ~HostBuf() { if (pinned) g2s_host_free(p); }
-    } res_buf, arena_buf;
-    g2s_result* results = (g2s_result*)res_buf.get(std::max<size_t>(1, jobs.size()) * sizeof(g2s_result));
-    const size_t arena_bytes = jobs.empty() ? 0 : g2s_team_arena_bytes(s, jobs.data(), jobs.size());
-    char* arena = (char*)arena_buf.get(std::max<size_t>(1, arena_bytes));
-    if (!jobs.empty()) {
-      // g2s_fill_batch spreads long lists over the session's team (g2s_session_set_team)
-      int rc = g2s_fill_batch(s, jobs.data(), jobs.size(), results, arena, arena_bytes);
+    c->sr = sr; c->si = si; c->barrier = barrier; c->soft = soft;
+    return c;
+  };
+  // ---- the hot path: the batch's look-ups and fill kernel queued on the GPU -----------------------------------
+  auto begin = [&](Chunk* c) -> int {
+    const size_t q = nchunks++ & 1u;
+    c->results = (g2s_result*)res_buf[q].get(std::max<size_t>(1, c->jobs.size()) * sizeof(g2s_result));
+    c->arena_bytes = c->jobs.empty() ? 0 : g2s_team_arena_bytes(s, c->jobs.data(), c->jobs.size());
+    c->arena = (char*)arena_buf[q].get(std::max<size_t>(1, c->arena_bytes));
+    if (c->jobs.empty()) return G2S_OK;
+    // (long lists go through the session's team in g2s_fill_end: g2s_session_set_team)
+    const int rc = g2s_fill_begin(s, c->jobs.data(), c->jobs.size(), c->results, c->arena, c->arena_bytes);
+    c->begun = rc == G2S_OK;
+    return rc;
+  };
+  auto finish = [&](Chunk* c) -> int {
+    if (c->begun) {
+      const int rc = g2s_fill_end(s);
       if (rc != G2S_OK) return rc;
     }
-
+    const std::vector<GapEvent>& events = c->events;
+    const std::vector<g2s_gap>& jobs = c->jobs;
+    const g2s_result* results = c->results;
+    const char* arena = c->arena;
+    const size_t sr = c->sr, si = c->si;
+    const bool barrier = c->barrier, soft = c->soft;
     // ---- exact replay of the reference's splice logic (:340-423) ---------------
     auto finish_record = [&]() {
       const std::string& seq = recs[cur_rec].seq;
@@ -291,6 +331,27 @@ extern "C" int g2s_execute_scaffolds_stream(g2s_session* s, const g2s_run_opts* 
       if (on_fasta && !fasta.empty()) on_fasta(fasta.data(), fasta.size(), user);
       fasta.clear();
     }
+    return G2S_OK;
+  };
+  std::unique_ptr<Chunk> cur(done ? nullptr : scan(cur_rec, i_exact, prevGapEnd));
+  if (cur) { const int rc = begin(cur.get()); if (rc != G2S_OK) return rc; }
+  while (cur) {
+    std::unique_ptr<Chunk> nxt;
+    if (cur->soft) {  // (record cur->sr starts the next batch, whatever this one's results are)
+      nxt.reset(scan(cur->sr, 0, 0));
+      const int rc = begin(nxt.get());
+      if (rc != G2S_OK) { if (cur->begun) (void)g2s_fill_end(s); return rc; }
+    }
+    {
+      const int rc = finish(cur.get());
+      if (rc != G2S_OK) { if (nxt && nxt->begun) (void)g2s_fill_end(s); return rc; }
+    }
+    if (!nxt && !done) {  // behind a barrier: the scan resumes where the replay stands
+      nxt.reset(scan(cur_rec, i_exact, prevGapEnd));
+      const int rc = begin(nxt.get());
+      if (rc != G2S_OK) return rc;
+    }
+    cur = std::move(nxt);
   }
   if (recs.empty()) {
     os << "Filled " << filledgapcount << " gaps out of " << gapcount << "\n";

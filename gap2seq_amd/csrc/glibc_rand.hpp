@@ -53,6 +53,7 @@ class GlibcRandStream {
   ~GlibcRandStream() { free(e_); }
   GlibcRandStream(const GlibcRandStream&) = delete;
   GlibcRandStream& operator=(const GlibcRandStream&) = delete;
+  void swap(GlibcRandStream& o) { std::swap(e_, o.e_); std::swap(size_, o.size_); std::swap(cap_, o.cap_); std::swap(first_, o.first_); }
   void seed(uint32_t s) {
     if (s == 0) s = 1;
     uint32_t r[31];

@@ -84,6 +84,9 @@ _VP = C.c_void_p
 TEXT_FN = C.CFUNCTYPE(None, C.POINTER(C.c_char), C.c_size_t, C.c_void_p)  # g2s_text_fn
 _SIGS = {
     "g2s_abi_version": (C.c_int, []),
+    "g2s_fill_begin": (C.c_int, [_VP, C.POINTER(g2s_gap), C.c_size_t, C.POINTER(g2s_result), C.c_void_p, C.c_size_t]),
+    "g2s_fill_end": (C.c_int, [_VP]),
+    "g2s_fill_in_flight": (C.c_int, [_VP]),
     "g2s_backtrace_text": (C.c_size_t, [C.POINTER(g2s_gap), C.POINTER(g2s_result), C.c_int, C.c_char_p, C.c_size_t]),
     "g2s_last_error": (C.c_char_p, []),
     "g2s_graph_build_files": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(_VP)]),
@@ -449,6 +452,43 @@ class Session:
             for hb in bufs:
                 hb.free()
         return (out, t) if want_timing else out
+
+    def fill_lists_overlapped(self, lists, pinned=True):
+        """g2s_fill_begin / g2s_fill_end over consecutive lists, two in flight: list i+1 is begun before list i is
+        ended.  Returns the lists' results in order (and the timing of the last list ended)."""
+        lib = load_library()
+        ctx = []
+        for gaps in lists:
+            arr, keep = _gap_array(gaps)
+            nbytes = lib.g2s_team_arena_bytes(self.h, arr, len(gaps))
+            if pinned:
+                arena = HostBuffer(max(1, nbytes))
+                rbuf = HostBuffer(C.sizeof(g2s_result) * max(1, len(gaps)))
+                res = rbuf.array(g2s_result, max(1, len(gaps)))
+                ctx.append(dict(arr=arr, keep=keep, n=len(gaps), nbytes=nbytes, arena=arena, rbuf=rbuf, res=res, ap=C.cast(arena.p, C.c_void_p)))
+            else:
+                arena = C.create_string_buffer(max(1, nbytes))
+                res = (g2s_result * max(1, len(gaps)))()
+                ctx.append(dict(arr=arr, keep=keep, n=len(gaps), nbytes=nbytes, arena=arena, rbuf=None, res=res, ap=C.cast(arena, C.c_void_p)))
+        out = []
+        t = g2s_timing()
+        try:
+            for i, c in enumerate(ctx):
+                _check(lib.g2s_fill_begin(self.h, c["arr"], c["n"], c["res"], c["ap"], c["nbytes"]))
+                if i >= 1:
+                    _check(lib.g2s_fill_end(self.h))
+            while lib.g2s_fill_in_flight(self.h) > 0:
+                _check(lib.g2s_fill_end(self.h))
+            _check(lib.g2s_session_last_timing(self.h, C.byref(t)))
+            for c in ctx:
+                raw = c["arena"].raw
+                out.append([FillResult(c["res"][i], raw) for i in range(c["n"])])
+        finally:
+            for c in ctx:
+                if c["rbuf"] is not None:
+                    c["rbuf"].free()
+                    c["arena"].free()
+        return out, t
 
     def fill_batch_onecall(self, gaps):
         """g2s_fill_batch (prepare + run + free in one ABI call; lists longer than the group size

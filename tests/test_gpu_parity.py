@@ -541,6 +541,31 @@ def test_execute_stream_is_the_one_batch_text_for_every_chunk_size(product):
         pg.free()
 
 
+def test_execute_stream_with_lists_in_flight(product):
+    """The same with batches long enough to be finished on the device (resident mode) and, behind every cut at a
+    record boundary, TWO of them in flight (g2s_fill_begin / g2s_fill_end: the next batch is scanned and begun before
+    this one is ended and replayed): the concatenated text is the one-batch text for every batch size."""
+    import test_gpu_fullsize
+    k = 31
+    reads = product.G2S.synth_genome(1300000, 3, 20240101)
+    seqs = [ln for ln in reads.splitlines() if not ln.startswith(">")]
+    text = test_gpu_fullsize._simulated_scaffolds(seqs[0], k, 10, 5, 840, 1500)
+    pg = product.Graph.from_seqs(seqs, k, 1)
+    try:
+        sess = product.Session(pg, 0, d_err=500, randseed=4)
+        want = sess.execute_scaffolds(text, k, solid=1)
+        sess.destroy()
+        assert want[2] >= 1200 and want[3] >= 700
+        for chunk in (260, 300, 700):
+            sess = product.Session(pg, 0, d_err=500, randseed=4)
+            fas, lgs, ngaps, nfilled = sess.execute_scaffolds_stream(text, k, chunk, solid=1)
+            sess.destroy()
+            assert ("".join(fas), "".join(lgs), ngaps, nfilled) == want, chunk
+            assert len(lgs) >= 2
+    finally:
+        pg.free()
+
+
 def _stream_scaffolds(genome, k):
     """multi-gap scaffold records over a toy genome (the generator of the full-size C1 stand-in)"""
     import test_gpu_fullsize

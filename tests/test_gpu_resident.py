@@ -128,6 +128,37 @@ def test_one_deep_gap_does_not_send_a_list_to_the_host_path(product, oracle, mon
     assert tm.segx_tier_gaps >= 1 and tm.seg_tier_gaps + tm.segx_tier_gaps == 2000 and tm.watchdog_gaps == 0
 
 
+def test_two_lists_in_flight_equal_list_by_list(product, monkeypatch):
+    """g2s_fill_begin / g2s_fill_end: seven lists of different lengths (resident and not, one empty), the next one begun
+    before the last one is ended — its look-ups and fill kernel run while the other's results cross the link, on a twin
+    of the session — against g2s_fill_batch list by list: every field, the fill text, and the one rand() stream."""
+    reads = product.G2S.synth_genome(300000, 3, 20240101)
+    seqs = [ln for ln in reads.splitlines() if not ln.startswith(">")]
+    allg = _gaps(product, _parse_scaffolds(product.G2S.synth_gaps(reads, 31, 10, 4000, 100, 900, 20240103)))
+    lists = [allg[:1500], allg[1500:1800], allg[1800:1810], [], allg[1810:3500], allg[3500:], allg[:700]]
+    pg = product.Graph.from_seqs(seqs, 31, 1)
+    try:
+        monkeypatch.delenv("G2S_RESIDENT", raising=False)
+        s = product.Session(pg, 0, d_err=500, randseed=11)
+        want = [[_key(r) for r in s.fill_batch(L, pinned=True)] if L else [] for L in lists]
+        s.destroy()
+        for pinned in (True, False):
+            s = product.Session(pg, 0, d_err=500, randseed=11)
+            got, tm = s.fill_lists_overlapped(lists, pinned=pinned)
+            tail = [_key(r) for r in s.fill_batch(allg[:300], pinned=True)]  # (the session itself goes on behind them)
+            s.destroy()
+            assert [[_key(r) for r in L] for L in got] == want
+            assert tm.resident_launches == 1 and tm.resident_fallbacks == 0
+        s = product.Session(pg, 0, d_err=500, randseed=11)
+        for L in lists:
+            if L:
+                s.fill_batch(L, pinned=True)
+        assert [_key(r) for r in s.fill_batch(allg[:300], pinned=True)] == tail
+        s.destroy()
+    finally:
+        pg.free()
+
+
 def test_lists_on_one_session_long_short_long(product, monkeypatch):
     """The ready words of the host-finished gaps across lists of different length on ONE session: a long
     list sizes the side buffer, a short list runs, then a long list with more host-finished gaps than the short one
