@@ -132,6 +132,10 @@ struct D3Params {
   uint64_t sub_region; // per group, sub_region 16-byte units apart); one group: group_size >= n
   uint32_t laps;       // G2S_DEBUG: the trace kernel's waves record their laps (atomics on a few words)
   uint32_t self_clean; // the trace kernel zeroes the gaps' records, the summary and the counters behind itself
+  // A list sharded over the sessions of a team, one group each (launch_d3_sharded_*): this group's place in the list's
+  // one rand() stream.  base0: fewest draws of all groups in front; R0: their summed spreads (the deviations this
+  // group's first draw-dependent gap can start with: 0 .. R0); d_in: the deviation it does start with.
+  uint32_t base0, R0, d_in;
 };
 
 // the stream: values [0, capacity) into rnd_all[31 ..] (sum_dev = nullptr; independent of the list's kernels, so
@@ -147,6 +151,24 @@ hipError_t launch_rand_fill(hipStream_t st, uint32_t* rnd_all, const RandTables&
 //   g2s_d3_handoff every gap's first draw and draw count; what the host needs to finish the gaps whose closure it
 //                  analyses, into pinned memory (*side.count says when: the host polls it)
 //   g2s_d3_trace   one wave per gap: the traceback, fill text and result record; the last wave copies the summary
+// The same in three steps, for a list whose groups stay on the GPUs that filled them (one session per GPU, every one
+// tracing its own gaps and writing its own results through its own link).  Between the steps the host exchanges a
+// few words per group:
+//   classes  classify + scan with offsets 0: the group's totals (D3Summary.draws_min, .draws_spread, .status)
+//            -> host: base0, R0 of every group = prefix sums over the groups in front
+//   tables   scan again with (P.base0, P.R0), tables, blocks, then the GROUP FUNCTION: the deviation behind the
+//            group for every deviation 0 .. R0 in front of it, into group_fn[] (pinned)
+//            -> host: d_in of group q+1 = group_fn_q[d_in of group q], d_in of group 0 = 0
+//   trace    chain from P.d_in, hand-off, trace kernel (results and text of this group's gaps)
+// rnd_all holds the list's stream from its first value (every session generates what its group can reach).
+hipError_t launch_d3_sharded_classes(hipStream_t st, const D3Params& P, const D3Work& W, const GapOut* outs, const D3Gap* dgaps,
+                                     bool summary_is_clean);
+hipError_t launch_d3_sharded_tables(hipStream_t st, const D3Params& P, const D3Work& W, const GapOut* outs, const SubRec* sub,
+                                    uint32_t* rnd_all, uint64_t rnd_capacity, uint32_t* group_fn /* [P.R0 + 1], device-writable */);
+hipError_t launch_d3_sharded_trace(hipStream_t st, const D3Params& P, const D3Work& W, const GapOut* outs, const SubRec* sub,
+                                   const char* lastch_up, const char* lastch_dn, uint32_t* rnd_all, uint64_t rnd_capacity,
+                                   void* results, char* arena, const D3Side& side, void* summary_host);
+
 hipError_t launch_d3(hipStream_t st, const D3Params& P, const D3Work& W, const GapDev* gaps, const GapOut* outs,
                      const D3Gap* dgaps, const SubRec* sub, const char* lastch_up, const char* lastch_dn,
                      const RandTables& rt, uint32_t* rnd_all /* [31 + capacity]: first G2S_RAND_WINDOW words set */,

@@ -358,11 +358,11 @@ __device__ __forceinline__ void d3_scan_body(const D3Params& P, const D3Work& W,
     sd = a; ss = b; tot_d = ta; tot_s = tb;
   } else block_scan3(sd, ss, nv, sh, &tot_d, &tot_s, &V);
   if (t == 0) stamp(W, 21);
-  const bool too_wide = tot_d + tot_s >= 0xFFFF0000ull || tot_s >= (uint64_t)G2S_D3_TABLE_BUDGET;
+  const bool too_wide = tot_d + tot_s + P.base0 + P.R0 >= 0xFFFF0000ull || tot_s + P.R0 >= (uint64_t)G2S_D3_TABLE_BUDGET;
   uint64_t my_tab = 0, my_blk = 0;
   uint32_t my_tiles = 0;
   {
-    uint64_t d = sd, r = ss;
+    uint64_t d = sd + P.base0, r = ss + P.R0;  // (a group of a sharded list: behind the groups in front of it)
     uint32_t v = nv;
     for (uint32_t i0 = lo; i0 < hi; i0 += 8u) {
       uint32_t g8[8], m8[8], s8[8];
@@ -386,7 +386,7 @@ __device__ __forceinline__ void d3_scan_body(const D3Params& P, const D3Work& W,
         }
       }
     }
-    if (t == 1023u) W.var_R[V] = (uint32_t)tot_s;
+    if (t == 1023u) W.var_R[V] = (uint32_t)tot_s + P.R0;
   }
   // ---- where every table starts
   if (t == 0) stamp(W, 22);
@@ -399,7 +399,7 @@ __device__ __forceinline__ void d3_scan_body(const D3Params& P, const D3Work& W,
   } else block_scan3(to, bo, tl, sh + 48, &T, &TB, &tiles);
   const bool over = too_wide || T > (uint64_t)G2S_D3_TABLE_BUDGET || TB > (uint64_t)(G2S_D3_TABLE_BUDGET / 4u);
   if (!over) {
-    uint64_t d = sd, r = ss;
+    uint64_t d = sd + P.base0, r = ss + P.R0;
     uint32_t v = nv;
     for (uint32_t i0 = lo; i0 < hi; i0 += 8u) {
       uint32_t g8[8], m8[8], s8[8];
@@ -664,12 +664,13 @@ __global__ __launch_bounds__(256) void g2s_d3_blocks(const D3Work W) {
 }
 
 // the chain over blocks, then inside every block; the list's total and the generator's state behind it
-__device__ __forceinline__ void d3_chain_body(const D3Work& W, const uint32_t* __restrict__ Wd, uint32_t* total_dev /* shared */) {
+__device__ __forceinline__ void d3_chain_body(const D3Work& W, const uint32_t* __restrict__ Wd, uint32_t* total_dev /* shared */,
+                                              uint32_t base0 = 0u, uint32_t d_in = 0u) {
   D3Summary* S = W.sum;
   const uint32_t V = S->n_var;
   const uint32_t NB = (V + G2S_D3_BLOCK_VARS - 1u) / G2S_D3_BLOCK_VARS;
   if (threadIdx.x == 0) {
-    uint32_t d = 0;
+    uint32_t d = d_in;
     for (uint32_t b = 0; b < NB; b++) { W.blk_in[b] = d; d = W.btab[(uint64_t)W.blk_toff[b] + d]; }
     W.dvar[V] = d;
     *total_dev = d;
@@ -681,14 +682,27 @@ __device__ __forceinline__ void d3_chain_body(const D3Work& W, const uint32_t* _
     const uint32_t v1 = min(V, (b + 1u) * G2S_D3_BLOCK_VARS);
     for (uint32_t v = b * G2S_D3_BLOCK_VARS; v < v1; v++) { W.dvar[v] = d; d += W.tab[(uint64_t)W.var_toff[v] + d]; }
   }
-  const uint64_t total = S->draws_min + *total_dev;
+  const uint64_t total = (uint64_t)base0 + S->draws_min + *total_dev;  // (draws of the list up to the end of this group)
   if (threadIdx.x == 0) S->draws_total = total;
   if (threadIdx.x < 31u) S->rand_state[threadIdx.x] = Wd[total + threadIdx.x];
 }
-__global__ __launch_bounds__(1024) void g2s_d3_chain(const D3Work W, const uint32_t* __restrict__ Wd) {
+__global__ __launch_bounds__(1024) void g2s_d3_chain(const D3Work W, const uint32_t* __restrict__ Wd, uint32_t base0, uint32_t d_in) {
   __shared__ uint32_t total_dev;
   if (W.sum->status) return;
-  d3_chain_body(W, Wd, &total_dev);
+  d3_chain_body(W, Wd, &total_dev, base0, d_in);
+}
+// (sharded lists) the deviation behind this group for every deviation d = 0 .. R0 in front of it: a walk through the
+// blocks' tables per d.  fn[] is pinned host memory; fn[R0 + 1] = 1 says it is complete (the stream's end does too).
+__global__ __launch_bounds__(256) void g2s_d3_groupfn(const D3Work W, uint32_t R0, uint32_t* __restrict__ fn) {
+  const D3Summary* S = W.sum;
+  if (S->status) return;
+  const uint32_t V = S->n_var;
+  const uint32_t NB = (V + G2S_D3_BLOCK_VARS - 1u) / G2S_D3_BLOCK_VARS;
+  for (uint32_t d0 = blockIdx.x * blockDim.x + threadIdx.x; d0 <= R0; d0 += gridDim.x * blockDim.x) {
+    uint32_t d = d0;
+    for (uint32_t b = 0; b < NB; b++) d = W.btab[(uint64_t)W.blk_toff[b] + d];
+    fn[d0] = d;
+  }
 }
 
 // Short lists: five launches cost a 2 000-gap list more than the work in them — classes and scan in one launch
@@ -1265,6 +1279,42 @@ hipError_t launch_rand_fill(hipStream_t st, uint32_t* rnd_all, const RandTables&
   return hipGetLastError();
 }
 
+hipError_t launch_d3_sharded_classes(hipStream_t st, const D3Params& P, const D3Work& W, const GapOut* outs, const D3Gap* dgaps,
+                                     bool summary_is_clean) {
+  if (P.n == 0) return hipSuccess;
+  hipError_t e = summary_is_clean ? hipSuccess : hipMemsetAsync(W.sum, 0, 1024 + 64 * 128, st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(g2s_d3_classify, dim3((P.n + 255u) / 256u), dim3(256), 0, st, P, W, outs, dgaps);
+  hipLaunchKernelGGL(g2s_d3_scan, dim3(1), dim3(1024), 0, st, P, W, outs);  // (P.base0 = P.R0 = 0: the group's totals)
+  return hipGetLastError();
+}
+hipError_t launch_d3_sharded_tables(hipStream_t st, const D3Params& P, const D3Work& W, const GapOut* outs, const SubRec* sub,
+                                    uint32_t* rnd_all, uint64_t rnd_capacity, uint32_t* group_fn) {
+  if (P.n == 0) return hipSuccess;
+  hipLaunchKernelGGL(g2s_d3_scan, dim3(1), dim3(1024), 0, st, P, W, outs);  // (the layout again, behind the groups in front)
+  const uint32_t tgrid = std::min(8192u, std::max(128u, P.n / 2u));
+  const size_t win = ((size_t)P.map_cap + 256) * 4;
+  hipError_t e = hipFuncSetAttribute((const void*)g2s_d3_tables, hipFuncAttributeMaxDynamicSharedMemorySize, (int)win);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(g2s_d3_tables, dim3(tgrid), dim3(256), win, st, P, W, sub, rnd_all + 31, rnd_capacity);
+  hipLaunchKernelGGL(g2s_d3_blocks, dim3(256), dim3(256), 0, st, W);
+  hipLaunchKernelGGL(g2s_d3_groupfn, dim3(std::min(256u, (P.R0 + 256u) / 256u)), dim3(256), 0, st, W, P.R0, group_fn);
+  return hipGetLastError();
+}
+hipError_t launch_d3_sharded_trace(hipStream_t st, const D3Params& P, const D3Work& W, const GapOut* outs, const SubRec* sub,
+                                   const char* lastch_up, const char* lastch_dn, uint32_t* rnd_all, uint64_t rnd_capacity,
+                                   void* results, char* arena, const D3Side& side, void* summary_host) {
+  if (P.n == 0) return hipSuccess;
+  hipLaunchKernelGGL(g2s_d3_chain, dim3(1), dim3(1024), 0, st, W, rnd_all, P.base0, P.d_in);
+  hipLaunchKernelGGL(g2s_d3_handoff, dim3((P.n + 63u) / 64u), dim3(64), 0, st, P, W, outs, sub, rnd_all + 31, rnd_capacity, side);
+  const size_t lds = (size_t)P.seg_cap * (sizeof(SegRec) + 16) + (size_t)P.map_cap * 8 + 16;
+  hipError_t e = hipFuncSetAttribute((const void*)g2s_d3_trace, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(g2s_d3_trace, dim3(P.n), dim3(64), lds, st, P, W, const_cast<GapOut*>(outs), sub, lastch_up, lastch_dn, rnd_all + 31, rnd_capacity,
+                     (g2s_result*)results, arena, (uint32_t*)summary_host, side, (uint32_t*)nullptr);
+  return hipGetLastError();
+}
+
 hipError_t launch_d3(hipStream_t st, const D3Params& P, const D3Work& W, const GapDev* gaps, const GapOut* outs,
                      const D3Gap* dgaps, const SubRec* sub, const char* lastch_up, const char* lastch_dn,
                      const RandTables& rt, uint32_t* rnd_all, uint64_t rnd_capacity, void* results, char* arena,
@@ -1292,7 +1342,7 @@ hipError_t launch_d3(hipStream_t st, const D3Params& P, const D3Work& W, const G
   if (short_list) hipLaunchKernelGGL(g2s_d3_back, dim3(1), dim3(1024), 0, st, P, W, outs, sub, rnd_all, rnd_capacity, side);
   else {
     hipLaunchKernelGGL(g2s_d3_blocks, dim3(256), dim3(256), 0, st, W);
-    hipLaunchKernelGGL(g2s_d3_chain, dim3(1), dim3(1024), 0, st, W, rnd_all);
+    hipLaunchKernelGGL(g2s_d3_chain, dim3(1), dim3(1024), 0, st, W, rnd_all, 0u, 0u);
     hipLaunchKernelGGL(g2s_d3_handoff, dim3((P.n + 63u) / 64u), dim3(64), 0, st, P, W, outs, sub, rnd_all + 31, rnd_capacity, side);
   }
   const size_t lds = (size_t)P.seg_cap * (sizeof(SegRec) + 16) + (size_t)P.map_cap * 8 + 16;  // closure, base map, rand() values, the walk's segments

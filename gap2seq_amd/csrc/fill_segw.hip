@@ -725,6 +725,94 @@ __device__ __forceinline__ void segw_fill_one(uint32_t* lds, const SegArgs& A, c
   uint32_t sb = sh[SH_SB] + sh[SH_CHAIN], xb = sh[SH_XB] + sh[SH_CHAIN];
   const unsigned long long cyc2 = __builtin_amdgcn_s_memtime();
 
+  // ---------------- Q7: an upward and a downward segment of one unitig meeting on a k-mer ------
+  // The upward segments' index intervals sorted and merged in LDS; a downward segment that touches none of them (the
+  // usual case) is done after one binary search; the few others are checked against every upward segment.
+  // (for every gap the search finished, filled or not: the reference's outcome is in doubt either way)
+  if (!overflow && !(flags & G2S_DEV_Q7_B) && nseg > 1u) {
+    uint64_t* sbuf = (uint64_t*)lds;
+    uint32_t* clist = lds + 2u * CAP;
+    for (uint32_t b0 = 0; b0 < nseg; b0 += NT) {
+      const uint32_t b = b0 + tid;
+      const bool hb = b < nseg;
+      const uint32_t nb_ = hb ? s_node[b] : 0u, lb = hb ? s_dl[b] >> 16 : 0u;
+      const bool up = hb && !(nb_ & 1u) && lb > 0u;
+      const uint32_t pos = wave_reserve(up, &sh[SH_NU], lane);
+      if (up) sbuf[pos] = ((uint64_t)(nb_ >> 1) << 32) | (uint64_t)((nb_ >> 1) + lb - 1u);
+      if (__ballot(hb && (nb_ & 1u) && lb > 0u) && lane == 0) sh[SH_ANYDN] = 1u;
+    }
+    __syncthreads();
+    const uint32_t nu = sh[SH_NU];
+    const bool anydn = sh[SH_ANYDN] != 0u;
+    if (nu > 0u && anydn) {
+      uint32_t n2 = 2;
+      while (n2 < nu) n2 <<= 1;
+      for (uint32_t i = nu + tid; i < n2; i += NT) sbuf[i] = SEGX_EMPTY64;
+      __syncthreads();
+      block_sort64(sbuf, n2, tid);
+      // sorted by first index; the last indices become their running maximum: a downward segment [ib - lb + 1, ib]
+      // touches an upward one iff the maximum over the intervals that begin at or before ib reaches ib - lb + 1
+      uint32_t* uw = (uint32_t*)sbuf;  // uw[2 i] = last index (then: running maximum), uw[2 i + 1] = first index
+      {
+        uint32_t* wtot = lds + 2u * CAP + SEGW_CL_CAP;  // [SEGW_NW]
+        const uint32_t K = (nu + NT - 1u) / NT;
+        const uint32_t i_lo = min(nu, tid * K), i_hi = min(nu, (tid + 1u) * K);
+        uint32_t run = 0;
+        for (uint32_t i = i_lo; i < i_hi; i++) run = max(run, uw[2u * i]);
+        uint32_t inc = run;
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)inc, o); if (lane >= o) inc = max(inc, y); }
+        if (lane == 63) wtot[wave] = inc;
+        uint32_t excl = (uint32_t)__shfl_up((int)inc, 1);
+        if (lane == 0) excl = 0u;
+        __syncthreads();
+        for (uint32_t w2 = 0; w2 < wave; w2++) excl = max(excl, wtot[w2]);
+        run = excl;
+        for (uint32_t i = i_lo; i < i_hi; i++) { run = max(run, uw[2u * i]); uw[2u * i] = run; }
+      }
+      __syncthreads();
+      const uint32_t Mu = nu;
+      const uint32_t Pu = 1u << (31 - __builtin_clz(Mu));
+      for (uint32_t b0 = 0; b0 < nseg; b0 += NT) {
+        const uint32_t b = b0 + tid;
+        const bool hb = b < nseg;
+        const uint32_t nb_ = hb ? s_node[b] : 0u, dlb = hb ? s_dl[b] : 0u;
+        const int ib = (int)(nb_ >> 1), lb = (int)(dlb >> 16);
+        const bool down = hb && (nb_ & 1u) && lb > 0;
+        uint32_t pos = 0;
+        for (uint32_t st = Pu; st; st >>= 1) {
+          const uint32_t pp = pos + st;
+          if (pp <= Mu && uw[2u * (pp - 1u) + 1u] <= (uint32_t)ib) pos = pp;
+        }
+        const bool cand = down && pos > 0u && (int)uw[2u * (pos - 1u)] >= ib - lb + 1;
+        const uint32_t at = wave_reserve(cand, &sh[SH_NC], lane);
+        if (cand && at < SEGW_CL_CAP) clist[at] = b;
+      }
+      __syncthreads();
+      const uint32_t nc = sh[SH_NC];
+      if (nc > SEGW_CL_CAP) {  // (never seen: the gap runs in the LDS tier)
+        flags |= G2S_DEV_OVERFLOW_B | G2S_DEV_WHY_LOG;
+        overflow = true;
+      }
+      bool hit = false;
+      for (uint32_t c = 0; c < min(nc, SEGW_CL_CAP) && !hit; c++) {
+        const uint32_t b = clist[c];
+        const uint32_t nb_ = s_node[b], dlb = s_dl[b];
+        const int ibl = (int)(nb_ >> 1), dbl = (int)(dlb & 0xFFFFu), lbl = (int)(dlb >> 16);
+        for (uint32_t a = tid; a < nseg; a += NT) {
+          const uint32_t na = s_node[a], dla = s_dl[a];
+          const int ia = (int)(na >> 1), da = (int)(dla & 0xFFFFu), la = (int)(dla >> 16);
+          const int sdiff = ibl - ia, ddiff = dbl - da;
+          const int t1 = (sdiff + ddiff) >> 1, t2 = (sdiff - ddiff) >> 1;
+          if (!(na & 1u) && !((sdiff + ddiff) & 1) && t1 >= 0 && t1 < la && t2 >= 0 && t2 < lbl) { hit = true; break; }
+        }
+      }
+      if (__ballot(hit) && lane == 0) atomicOr(&sh[SH_FLAGS], G2S_DEV_Q7_B);
+      __syncthreads();
+      flags |= sh[SH_FLAGS] & G2S_DEV_Q7_B;
+    }
+    __syncthreads();
+  }
+
   WPROF(8);
   // ---------------- phase C's hits (:1107-1159): target k-mer j at position t of a segment is a hit at depth + t --------
   // Behind the search, thread = segment and a loop over the <= 32 targets.  A hit (error, j) exists at most once
@@ -821,96 +909,6 @@ __device__ __forceinline__ void segw_fill_one(uint32_t* lds, const SegArgs& A, c
   if (overflow || !(c_count > 0 && n_len > 0)) {  // :1169
     publish();
     return;
-  }
-
-  // ---------------- Q7: an upward and a downward segment of one unitig meeting on a k-mer ------
-  // The upward segments' index intervals sorted and merged in LDS; a downward segment that touches none of them (the
-  // usual case) is done after one binary search; the few others are checked against every upward segment.
-  if (!(flags & G2S_DEV_Q7_B) && nseg > 1u) {
-    uint64_t* sbuf = (uint64_t*)lds;
-    uint32_t* clist = lds + 2u * CAP;
-    for (uint32_t b0 = 0; b0 < nseg; b0 += NT) {
-      const uint32_t b = b0 + tid;
-      const bool hb = b < nseg;
-      const uint32_t nb_ = hb ? s_node[b] : 0u, lb = hb ? s_dl[b] >> 16 : 0u;
-      const bool up = hb && !(nb_ & 1u) && lb > 0u;
-      const uint32_t pos = wave_reserve(up, &sh[SH_NU], lane);
-      if (up) sbuf[pos] = ((uint64_t)(nb_ >> 1) << 32) | (uint64_t)((nb_ >> 1) + lb - 1u);
-      if (__ballot(hb && (nb_ & 1u) && lb > 0u) && lane == 0) sh[SH_ANYDN] = 1u;
-    }
-    __syncthreads();
-    const uint32_t nu = sh[SH_NU];
-    const bool anydn = sh[SH_ANYDN] != 0u;
-    if (nu > 0u && anydn) {
-      uint32_t n2 = 2;
-      while (n2 < nu) n2 <<= 1;
-      for (uint32_t i = nu + tid; i < n2; i += NT) sbuf[i] = SEGX_EMPTY64;
-      __syncthreads();
-      block_sort64(sbuf, n2, tid);
-      // sorted by first index; the last indices become their running maximum: a downward segment [ib - lb + 1, ib]
-      // touches an upward one iff the maximum over the intervals that begin at or before ib reaches ib - lb + 1
-      uint32_t* uw = (uint32_t*)sbuf;  // uw[2 i] = last index (then: running maximum), uw[2 i + 1] = first index
-      {
-        uint32_t* wtot = lds + 2u * CAP + SEGW_CL_CAP;  // [SEGW_NW]
-        const uint32_t K = (nu + NT - 1u) / NT;
-        const uint32_t i_lo = min(nu, tid * K), i_hi = min(nu, (tid + 1u) * K);
-        uint32_t run = 0;
-        for (uint32_t i = i_lo; i < i_hi; i++) run = max(run, uw[2u * i]);
-        uint32_t inc = run;
-        for (int o = 1; o < 64; o <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)inc, o); if (lane >= o) inc = max(inc, y); }
-        if (lane == 63) wtot[wave] = inc;
-        uint32_t excl = (uint32_t)__shfl_up((int)inc, 1);
-        if (lane == 0) excl = 0u;
-        __syncthreads();
-        for (uint32_t w2 = 0; w2 < wave; w2++) excl = max(excl, wtot[w2]);
-        run = excl;
-        for (uint32_t i = i_lo; i < i_hi; i++) { run = max(run, uw[2u * i]); uw[2u * i] = run; }
-      }
-      __syncthreads();
-      const uint32_t Mu = nu;
-      const uint32_t Pu = 1u << (31 - __builtin_clz(Mu));
-      for (uint32_t b0 = 0; b0 < nseg; b0 += NT) {
-        const uint32_t b = b0 + tid;
-        const bool hb = b < nseg;
-        const uint32_t nb_ = hb ? s_node[b] : 0u, dlb = hb ? s_dl[b] : 0u;
-        const int ib = (int)(nb_ >> 1), lb = (int)(dlb >> 16);
-        const bool down = hb && (nb_ & 1u) && lb > 0;
-        uint32_t pos = 0;
-        for (uint32_t st = Pu; st; st >>= 1) {
-          const uint32_t pp = pos + st;
-          if (pp <= Mu && uw[2u * (pp - 1u) + 1u] <= (uint32_t)ib) pos = pp;
-        }
-        const bool cand = down && pos > 0u && (int)uw[2u * (pos - 1u)] >= ib - lb + 1;
-        const uint32_t at = wave_reserve(cand, &sh[SH_NC], lane);
-        if (cand && at < SEGW_CL_CAP) clist[at] = b;
-      }
-      __syncthreads();
-      const uint32_t nc = sh[SH_NC];
-      if (nc > SEGW_CL_CAP) {  // (never seen: the gap runs in the LDS tier)
-        flags |= G2S_DEV_OVERFLOW_B | G2S_DEV_WHY_LOG;
-        if (tid == 0) go->flags = flags;
-        publish();
-        return;
-      }
-      bool hit = false;
-      for (uint32_t c = 0; c < nc && !hit; c++) {
-        const uint32_t b = clist[c];
-        const uint32_t nb_ = s_node[b], dlb = s_dl[b];
-        const int ibl = (int)(nb_ >> 1), dbl = (int)(dlb & 0xFFFFu), lbl = (int)(dlb >> 16);
-        for (uint32_t a = tid; a < nseg; a += NT) {
-          const uint32_t na = s_node[a], dla = s_dl[a];
-          const int ia = (int)(na >> 1), da = (int)(dla & 0xFFFFu), la = (int)(dla >> 16);
-          const int sdiff = ibl - ia, ddiff = dbl - da;
-          const int t1 = (sdiff + ddiff) >> 1, t2 = (sdiff - ddiff) >> 1;
-          if (!(na & 1u) && !((sdiff + ddiff) & 1) && t1 >= 0 && t1 < la && t2 >= 0 && t2 < lbl) { hit = true; break; }
-        }
-      }
-      if (__ballot(hit) && lane == 0) atomicOr(&sh[SH_FLAGS], G2S_DEV_Q7_B);
-      __syncthreads();
-      flags |= sh[SH_FLAGS] & G2S_DEV_Q7_B;
-      if (tid == 0) go->flags = flags;
-    }
-    __syncthreads();
   }
 
   WPROF(9);

@@ -2802,6 +2802,7 @@ static int resident_d3_launch(g2s_session* s, const ResidentList& L, bool timed,
     d3_begin = s->ev[0];
   }
   D3Params P;
+  memset(&P, 0, sizeof P);
   P.k = fp.k; P.skip_confident = fp.skip_confident ? 1 : 0; P.all_paths = fp.all_paths ? 1 : 0; P.unique_paths = fp.unique_paths ? 1 : 0;
   P.max_states = (uint64_t)std::max<int64_t>(s->params.max_mem, 1 << 16) / 64;
   P.n = (uint32_t)n;

@@ -88,8 +88,10 @@ Region make_region(int tid, int64_t beg, int64_t end, std::string* warn) {
   }
   return q;
 }
+// (an empty region [x, x) yields nothing and no warning: htslib's reg2bins returns no bin for beg >= end, so the
+// iterator exists and ends at once — it is not a point query)
 inline bool overlaps(const g2s::BamRec& r, const Region& q) {
-  return q.valid && r.ref_id == q.tid && (int64_t)r.pos < q.end && r.end_pos() > q.beg;
+  return q.valid && q.beg < q.end && r.ref_id == q.tid && (int64_t)r.pos < q.end && r.end_pos() > q.beg;
 }
 
 char* dup_text(const std::string& s) {
@@ -180,6 +182,13 @@ int run_filter(g2s::BamFile& bam, const g2s_filter_opts* o, char** fasta_out, ch
   if (fasta_out) *fasta_out = dup_text(fasta);
   if (log_out) *log_out = dup_text(log);
   if (warn_out) *warn_out = dup_text(warn);
+  if ((fasta_out && !*fasta_out) || (log_out && !*log_out) || (warn_out && !*warn_out)) {  // (out of memory)
+    if (fasta_out) { free(*fasta_out); *fasta_out = nullptr; }
+    if (log_out) { free(*log_out); *log_out = nullptr; }
+    if (warn_out) { free(*warn_out); *warn_out = nullptr; }
+    rf_error = "out of memory";
+    return G2S_ERR_NOMEM;
+  }
   if (extracted_out) *extracted_out = extracted;
   if (total_out) *total_out = (int64_t)total;
   return G2S_OK;

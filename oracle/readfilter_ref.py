@@ -131,6 +131,8 @@ def _query(recs, tid, beg, end, warn):  # sam_iterator(io, tid, start, end) (:18
     if tid < 0 or end < beg:
         warn.append("WARNING: SAM iterator is NULL!\n")
         return []
+    if beg >= end:  # (reg2bins finds no bin for an empty region: the iterator exists and ends at once)
+        return []
     return [r for r in recs if r.tid == tid and r.pos < end and r.end_pos() > beg]
 
 

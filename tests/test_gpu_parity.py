@@ -49,6 +49,44 @@ def _assert_gap_equal(product, r, o, skip, what=""):
             assert r.substats == o.substats, what
 
 
+def _compare_with_oracle_in_parallel(product, oracle, og, gaps, res, e, seed, skip=False, allp=True, threads=0):
+    """Every gap of a finished list against the oracle, on all host cores: gap i's oracle run starts its own rand()
+    stream at the product's cumulative draw count in front of gap i (what the sequential harness re-synchronises to
+    anyway), so the gaps are independent.  Returns (compared, oracle_q7); the oracle's calls release the GIL."""
+    import concurrent.futures
+    import threading
+    offs, used = [], 0
+    for r in res:
+        offs.append(used)
+        used += r.draws
+    lock = threading.Lock()
+    tally = dict(compared=0, q7=0)
+
+    def one(i):
+        g, r = gaps[i], res[i]
+        rng = oracle.OracleRng(seed, offs[i])
+        try:
+            o = oracle.fill_gap(og, rng, g["left"], g["right"], g["gap_len"], e, g["lmf"], g["rmf"], skip, allp)
+        finally:
+            rng.free()
+        if o.info.q7:
+            assert r.flags & product.G2S_GAP_Q7, "oracle saw a Q7 collision the GPU path did not flag (gap %d)" % i
+            with lock:
+                tally["q7"] += 1
+            return
+        if r.count == -1:
+            return
+        _assert_gap_equal(product, r, o, skip, "gap %d" % i)
+        with lock:
+            tally["compared"] += 1
+
+    nthreads = threads or min(64, os.cpu_count() or 1)
+    with concurrent.futures.ThreadPoolExecutor(nthreads) as ex:
+        for f in [ex.submit(one, i) for i in range(len(gaps))]:
+            f.result()  # (raises the first failed comparison)
+    return tally["compared"], tally["q7"]
+
+
 def _check_batch(product, oracle, seqs, k, gaps, e, skip=False, allp=True, seed=5, max_mem=20 << 30):
     """The product's batch against the oracle gap by gap.  Only gaps on which the ORACLE
     sees a Q7 collision (both strands of a k-mer in one border: the reference's outcome then
@@ -859,6 +897,9 @@ def test_fuzz_regressions(product, oracle, idx, monkeypatch):
                           max_len=cfg["max_len"], d_err=cfg["d_err"])
     if cfg["hbm_tier"]:
         monkeypatch.setenv("G2S_NO_LDS_TIER", "1")
+    if cfg.get("force_segx"):  # (every gap through the large variant of the segment tier, on the host path)
+        monkeypatch.setenv("G2S_FORCE_SEGX", "1")
+        monkeypatch.setenv("G2S_RESIDENT", "0")
     c, f, _, _, _ = _check_batch(product, oracle, seqs, k, gaps, cfg["d_err"], cfg["skip"], cfg["allp"],
                                  seed=cfg["randseed"])
     assert c > 0 and f > 0

@@ -188,11 +188,12 @@ def test_lists_on_one_session_long_short_long(product, monkeypatch):
         pg.free()
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(12))
 def test_resident_mode_on_toy_graphs(product, oracle, monkeypatch, seed):
-    """Small k, tandem repeats, inverted repeats: most lists hold a closure the device leaves to the host's
-    analysis (a k-mer at two depths) or a gap with both strands of a k-mer — the attempt is then discarded and
-    the host path runs; either way the results are the oracle's."""
+    """Small k, tandem repeats, inverted repeats: most lists hold closures the device leaves to the host's analysis
+    (a k-mer at two depths: finished by the host under the trace kernel), gaps with both strands of a k-mer, gaps
+    that outgrow the regular tier (they rerun in the large variant on the stream) — and every list is FINISHED ON THE
+    DEVICE all the same (until round 3 most of these attempts were discarded); the results are the oracle's."""
     monkeypatch.setenv("G2S_RESIDENT", "1")
     k = [9, 11, 13, 15, 17, 21][seed % 6]
     seqs = cases.toy_genome(seed, 1500, k, repeats=seed % 3, tandem=seed % 2, inverted=int(seed % 4 == 0), snp_every=(0 if seed % 2 else 97))
@@ -200,7 +201,7 @@ def test_resident_mode_on_toy_graphs(product, oracle, monkeypatch, seed):
     gaps = cases.cut_gaps(seed, seqs[0], k, fuz=seed % 5 + 1, ngaps=60, min_len=1, max_len=80, d_err=e)
     for skip, allp in ((False, True), (False, False), (True, True)):
         c, f, tm, _, _ = _check_batch(product, oracle, seqs, k, gaps, e, skip, allp)
-        assert tm.resident_launches + tm.resident_fallbacks == 1
+        assert tm.resident_launches == 1 and tm.resident_fallbacks == 0
 
 
 def test_resident_mode_gives_a_list_back(product, monkeypatch):
