@@ -247,6 +247,9 @@ def main():
                     help="results and fill arena in ordinary memory instead of g2s_host_alloc's page-locked memory")
     ap.add_argument("--backend", default="gloo", help="torch.distributed backend for the barriers under torchrun")
     ap.add_argument("--share-device", action="store_true", help="testing only: all N sessions on HIP device 0")
+    ap.add_argument("--weak", action="store_true",
+                    help="N>1: weak scaling — the workload's gap count PER GPU (config 3: 10 000 each) instead of one list "
+                         "for all of them")
     ap.add_argument("--stream-lists", type=int, default=0,
                     help="N=1: also measure K consecutive lists of the workload with two in flight (g2s_fill_begin / "
                          "g2s_fill_end) against the same K lists one at a time; reported as `stream_lists`")
@@ -304,6 +307,8 @@ def main():
     genome_bp = args.genome or genome_bp
     k = args.k or k
     ngaps = args.gaps or ngaps
+    if args.weak and ngpu > 1:
+        ngaps *= ngpu
     min_len = args.min_len or min_len
     max_len = args.max_len or max_len
     d_err = args.dist_error or d_err
@@ -341,7 +346,9 @@ def main():
     if group < 0:
         # groups are cut for DEVICES: sessions that share a device (--share-device, --sessions) pull from the same
         # counter, and a device gains nothing from two launches where one would do
-        group = 0 if len(sessions) == 1 else shard.group_size(len(gaps), len(set(devices)), per_session=args.groups_per_session)
+        # (--share-device: one group per SESSION, as N GPUs would get them — the sharded phase D3 is what is being tested)
+        group = 0 if len(sessions) == 1 else shard.group_size(len(gaps), len(sessions) if args.share_device else len(set(devices)),
+                                                                per_session=args.groups_per_session)
     run = Runner(P, sessions, gaps, group, not args.pageable_buffers)
 
     # what a one-shot run pays: the first call on a fresh session (buffers are allocated and page-locked in it,
@@ -569,7 +576,7 @@ def main():
         "warmup": warmup,
         "ms_per_step": round(elapsed / steps * 1e3, 4),
         "higher_is_better": True,
-        "scaling": "strong" if ngpu > 1 else "weak",
+        "scaling": "weak" if (ngpu == 1 or args.weak) else "strong",
         "vs_baseline": None,
         "dtype": "u32",
         "data": "synthetic",
@@ -594,6 +601,12 @@ def main():
                      "gaps_finished_by_the_host": tm.host_finished_gaps,
                      "team_groups": tm.team_groups,
                      "team_groups_by_session": [tm.team_groups_by_session[i] for i in range(min(16, max(1, len(sessions))))],
+                     "team_phase_d3": ("sharded: every session traces its own group and writes its own results" if tm.team_d3_sharded
+                                       else "on the lead's device (groups gathered)") if len(sessions) > 1 else None,
+                     "team_ms_by_session": {"fill_kernel": [round(tm.team_ms_fill[i], 4) for i in range(min(16, len(sessions)))],
+                                            "phase_d3_kernels": [round(tm.team_ms_d3[i], 4) for i in range(min(16, len(sessions)))],
+                                            "thread_wall": [round(tm.team_ms_wall[i], 4) for i in range(min(16, len(sessions)))],
+                                            "of": "the last timed step"} if len(sessions) > 1 else None,
                      "buffers": "pageable" if args.pageable_buffers else "page-locked (g2s_host_alloc)"},
         "breakdown_ms_per_step": {"wall_inside_the_abi_call": round(in_call / steps * 1e3, 4),
                                   "prepare_flank_lookup_and_upload": per_step("ms_prepare"),

@@ -141,7 +141,10 @@ struct D3Params {
 // the stream: values [0, capacity) into rnd_all[31 ..] (sum_dev = nullptr; independent of the list's kernels, so
 // it runs beside the fill kernel on a stream of its own), or only as far as the summary at sum_dev says the list
 // can draw.  rnd_all[0 .. G2S_RAND_WINDOW) come from the host.
-hipError_t launch_rand_fill(hipStream_t st, uint32_t* rnd_all, const RandTables& rt, const D3Summary* sum_dev, uint64_t capacity);
+// first_value: values in front of its block of 4 096 are not generated (a group of a sharded list: nothing of the
+// list draws them on this device)
+hipError_t launch_rand_fill(hipStream_t st, uint32_t* rnd_all, const RandTables& rt, const D3Summary* sum_dev, uint64_t capacity,
+                            uint64_t first_value = 0);
 
 // all of phase D3 behind the fill kernel, on its stream, without a host round trip:
 //   g2s_d3_classify / g2s_d3_scan   classes, draw counts, the skip rule (:369), prefix sums, table layout

@@ -458,7 +458,7 @@ __global__ __launch_bounds__(1024) void g2s_d3_scan(const D3Params P, const D3Wo
 // the session will draw (raw words: rand() returns word >> 1).  The host hands over W[0 .. G2S_RAND_WINDOW).
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void g2s_rand_fill(uint32_t* __restrict__ Wd, const g2s::RandTables rt, const D3Summary* sum,
-                                                    uint64_t capacity) {
+                                                    uint64_t capacity, uint64_t first_block) {
   __shared__ uint32_t base[G2S_RAND_WINDOW], s1[96], s2[64];
   // (sum: only as far as the list can draw, known once its scan has run; nullptr: the whole capacity, for a launch
   // beside the fill kernel)
@@ -468,7 +468,8 @@ __global__ __launch_bounds__(64) void g2s_rand_fill(uint32_t* __restrict__ Wd, c
   for (uint32_t i = lane; i < G2S_RAND_WINDOW; i += 64u) base[i] = Wd[i];
   __syncthreads();
   const uint64_t nblocks = (need + G2S_RAND_BLOCK - 1u) / G2S_RAND_BLOCK;
-  for (uint64_t B = blockIdx.x; B < nblocks; B += gridDim.x) {
+  // (first_block: a group of a sharded list generates the stream from where its own gaps can first draw)
+  for (uint64_t B = first_block + blockIdx.x; B < nblocks; B += gridDim.x) {
     const uint32_t* ph = rt.hi + (size_t)((B >> 8) & 127u) * 31u;
     const uint32_t* pm = rt.mid + (size_t)(B & 255u) * 31u;
     const uint32_t* pl = rt.lane + (size_t)lane * 31u;
@@ -1273,9 +1274,12 @@ void d3_work_carve(void* p, uint32_t n, D3Work* w) {
   w->tab = (uint16_t*)c;
 }
 
-hipError_t launch_rand_fill(hipStream_t st, uint32_t* rnd_all, const RandTables& rt, const D3Summary* sum_dev, uint64_t capacity) {
-  const uint32_t rblocks = (uint32_t)std::min<uint64_t>((capacity + G2S_RAND_BLOCK - 1) / G2S_RAND_BLOCK, 4096);
-  hipLaunchKernelGGL(g2s_rand_fill, dim3(std::max(1u, rblocks)), dim3(64), 0, st, rnd_all, rt, sum_dev, capacity);
+hipError_t launch_rand_fill(hipStream_t st, uint32_t* rnd_all, const RandTables& rt, const D3Summary* sum_dev, uint64_t capacity,
+                            uint64_t first_value) {
+  const uint64_t first_block = first_value / G2S_RAND_BLOCK;
+  const uint64_t all = (capacity + G2S_RAND_BLOCK - 1) / G2S_RAND_BLOCK;
+  const uint32_t rblocks = (uint32_t)std::min<uint64_t>(all > first_block ? all - first_block : 1, 4096);
+  hipLaunchKernelGGL(g2s_rand_fill, dim3(std::max(1u, rblocks)), dim3(64), 0, st, rnd_all, rt, sum_dev, capacity, first_block);
   return hipGetLastError();
 }
 

@@ -566,6 +566,8 @@ struct g2s_session {
   DevBuf d_sub, d_d3, d_rnd, d_lastch, d_rtab, d_resout, d_textout, d_dgap;
   DevBuf d_outs_all, d_sub_all;  // lead of a team: the groups' records and closure records, gathered for phase D3
   PinBuf h_d3all;                // and the list's D3Gap array, summary and stream window
+  PinBuf h_gfn;                  // a group of a sharded list: its group function (deviation behind it by deviation in front)
+  bool team_sharded = false;     // this session's group of a team's list stays on its device through phase D3
   PinBuf h_d3;                   // D3Gap per gap | summary | stream window; staging of results / text when the caller's are not pinned
   PinBuf h_res, h_text, h_side;
   RandTables rtab;
@@ -699,7 +701,7 @@ extern "C" void g2s_session_destroy(g2s_session* s) {
   for (int i = 0; i < 5; i++) if (s->ev[i]) (void)hipEventDestroy(s->ev[i]);
   s->d_outs_all.release(); s->d_sub_all.release(); s->h_d3all.release();
   s->d_resout.release(); s->d_textout.release(); s->d_dgap.release(); s->d_sub.release(); s->d_d3.release(); s->d_rnd.release(); s->d_lastch.release(); s->d_rtab.release();
-  s->h_d3.release(); s->h_res.release(); s->h_text.release(); s->h_side.release();
+  s->h_d3.release(); s->h_res.release(); s->h_text.release(); s->h_side.release(); s->h_gfn.release();
   if (s->ev_rand) (void)hipEventDestroy(s->ev_rand);
   if (s->ev_segw) (void)hipEventDestroy(s->ev_segw);
   if (s->stream2) (void)hipStreamDestroy(s->stream2);
@@ -2588,7 +2590,7 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl) {
   // A gap that outgrows the regular tier's capacities runs again in the large variant, behind the fill kernel on
   // the stream, and stays on the device like the others (one such gap used to send the whole list to the host
   // path).  Not in a team's groups yet: their closure records are copied to the lead's device by size.
-  const bool rerun = !s->in_team_list && !getenv("G2S_NO_SEGX_TIER") && (s->segw_quiet < 8 || b->dmax >= 2500);
+  const bool rerun = (!s->in_team_list || s->team_sharded) && !getenv("G2S_NO_SEGX_TIER") && (s->segw_quiet < 8 || b->dmax >= 2500);
   rl->segw = rerun;
   // 16-byte units: two per closure segment (the large variant's closures: thousands of segments)
   const uint64_t out_states = (uint64_t)ids.size() * 128u + 2u * G2S_SEG_CAP + (rerun ? std::min<uint64_t>((uint64_t)ids.size() * 8192u, 4ull << 20) + 2u * G2S_SEGX_CAP : 0u);
@@ -2697,11 +2699,22 @@ struct D3Pending {
   g2s_result* results = nullptr;
   char* arena = nullptr;
   std::chrono::steady_clock::time_point t_enter, t_launched;
+  // a group of a sharded list (team_resident_sharded): what the second and third step launch with
+  bool sharded = false;
+  D3Params P;
+  D3Side side_dev;
+  void* res_dev = nullptr;
+  char* arena_dev = nullptr;
+  const D3Gap* dgaps_dev = nullptr;
+  void* summary_dev = nullptr;   // the pinned summary slot as the device sees it
+  uint32_t* group_fn = nullptr;  // pinned: the group function (host pointer; device pointer below)
+  uint32_t* group_fn_dev = nullptr;
+  size_t rnd_cap = 0;
 };
 // first half: everything of phase D3 queued on the session's stream(s), nothing waited for (no_spin: not even the
 // few microseconds for the rand() stream's kernel — the main stream waits for its event instead)
 static int resident_d3_launch(g2s_session* s, const ResidentList& L, bool timed, bool rand_launched, g2s_result* results, char* arena,
-                              bool no_spin) {
+                              bool no_spin, bool sharded = false /* the first step only: classes and the group's totals */) {
   const size_t n = L.n;
   const Graph& g = *s->graph->g;
   const FillParams fp = fill_params_of(s);
@@ -2770,27 +2783,28 @@ static int resident_d3_launch(g2s_session* s, const ResidentList& L, bool timed,
   hipStream_t st = s->stream;
   void* d_dgaps = nullptr;
   HIP_TRY(hipHostGetDevicePointer(&d_dgaps, L.pin->p, 0));
-  // the rand() values the list can draw (a team's list: generated here, beside the copies of the groups' records)
-  if (!rand_launched) { const int rc = resident_rand(s, L.pin, n, L.rnd_cap); if (rc != G2S_OK) return rc; }
+  // the rand() values the list can draw (a team's list: generated here, beside the copies of the groups' records;
+  // a group of a sharded list: in its second step, when its place in the stream is known)
+  if (!rand_launched && !sharded) { const int rc = resident_rand(s, L.pin, n, L.rnd_cap); if (rc != G2S_OK) return rc; }
   // (the per-gap descriptors of phase D3 of a short list go to device memory behind it: read over the link by the
   // list's single classify workgroup they were 3 us of its 8; a long list's are read by 40 workgroups at once, and a
   // 160 KB copy beside the fill kernel cost that kernel 4 %)
-  const bool dgap_on_device = n <= 3072;
+  const bool dgap_on_device = n <= 3072 && !sharded;
   if (dgap_on_device) {
     HIP_TRY(s->d_dgap.ensure(n * sizeof(D3Gap) + 16));
     HIP_TRY(hipMemcpyAsync(s->d_dgap.p, L.pin->p, n * sizeof(D3Gap), hipMemcpyHostToDevice, s->stream2));
   }
-  HIP_TRY(hipEventRecord(s->ev_rand, s->stream2));
+  if (!sharded) HIP_TRY(hipEventRecord(s->ev_rand, s->stream2));
   // (The fill kernel runs for hundreds of microseconds, the stream's work for tens: this thread waits for the
   // latter here instead of putting a wait for it into the main stream — that packet, between the fill kernel and
   // the first kernel of phase D3, cost the list 5 us.  Only if the other stream is late does the main one wait.)
   {
     const auto t_w = std::chrono::steady_clock::now();
     hipError_t q = hipErrorNotReady;
-    while (!no_spin && (q = hipEventQuery(s->ev_rand)) == hipErrorNotReady &&
+    while (!no_spin && !sharded && (q = hipEventQuery(s->ev_rand)) == hipErrorNotReady &&
            std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_w).count() < 200.0)
       cpu_relax();
-    if (q != hipSuccess) HIP_TRY(hipStreamWaitEvent(st, s->ev_rand, 0));
+    if (q != hipSuccess && !sharded) HIP_TRY(hipStreamWaitEvent(st, s->ev_rand, 0));
   }
   // (the time of phase D3's kernels: from the end of this session's fill kernel, or — a team's list — from here)
   // (one batch on this session: the event behind its fill kernel; a team's list: an event of its own — the lead
@@ -2813,17 +2827,21 @@ static int resident_d3_launch(g2s_session* s, const ResidentList& L, bool timed,
   P.laps = getenv("G2S_DEBUG") ? 1u : 0u;
   // (one batch on this session: the kernels read this session's own records and cursors, and clean up behind
   // themselves; not while the lap stamps are wanted — they live in the summary's slot)
-  const bool self_clean = L.groups.size() == 1 && L.outs_dev == (const GapOut*)s->d_outs.p && !P.laps;
+  const bool self_clean = L.groups.size() == 1 && L.outs_dev == (const GapOut*)s->d_outs.p && !P.laps && !sharded;
   P.self_clean = self_clean ? 1u : 0u;
   P.seg_cap = fp.skip_confident ? G2S_SEG_CAP : 192u;
   P.map_cap = ((uint32_t)L.dmax + 2u + 3u) & ~3u;
+  if (sharded) {
+    HIP_TRY(launch_d3_sharded_classes(st, P, W, L.outs_dev, (const D3Gap*)d_dgaps, s->d_d3.clean >= 1024 + 64 * 128));
+    HIP_TRY(hipMemcpyAsync(hsum, W.sum, sizeof(D3Summary), hipMemcpyDeviceToHost, st));  // (the group's totals)
+  } else
   HIP_TRY(launch_d3(st, P, W, L.gaps_dev, L.outs_dev, dgap_on_device ? (const D3Gap*)s->d_dgap.p : (const D3Gap*)d_dgaps, L.sub_dev,
                     (const char*)s->d_lastch.p, (const char*)s->d_lastch.p + g.n, s->rtab, (uint32_t*)s->d_rnd.p,
                     (uint64_t)rnd_cap, res_dev, (char*)arena_dev, side, (char*)d_dgaps + ((char*)hsum - (char*)L.pin->p),
                     s->d_d3.clean >= 1024 + 64 * 128, self_clean ? (uint32_t*)s->d_counter.p : nullptr));
   s->d_d3.clean = 0;
-  if (timed) HIP_TRY(hipEventRecord(s->ev[3], st));
-  if (stage_dev) {
+  if (timed && !sharded) HIP_TRY(hipEventRecord(s->ev[3], st));
+  if (stage_dev && !sharded) {
     HIP_TRY(hipMemcpyAsync(results, s->d_resout.p, n * sizeof(g2s_result), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(arena, s->d_textout.p, L.arena_bytes, hipMemcpyDeviceToHost, st));
   }
@@ -2832,9 +2850,58 @@ static int resident_d3_launch(g2s_session* s, const ResidentList& L, bool timed,
     dp->L = L; dp->timed = timed; dp->res_direct = res_direct; dp->arena_direct = arena_direct; dp->stage_dev = stage_dev;
     dp->self_clean = self_clean; dp->side_h = side_h; dp->W = W; dp->hsum = hsum; dp->d3_begin = d3_begin; dp->results = results;
     dp->arena = arena; dp->t_enter = t_enter; dp->t_launched = std::chrono::steady_clock::now();
+    dp->sharded = sharded; dp->P = P; dp->side_dev = side; dp->res_dev = res_dev; dp->arena_dev = (char*)arena_dev;
+    dp->dgaps_dev = (const D3Gap*)d_dgaps; dp->summary_dev = (char*)d_dgaps + ((char*)hsum - (char*)L.pin->p);
     delete (D3Pending*)s->d3_pending;
     s->d3_pending = dp;
   }
+  return G2S_OK;
+}
+// A group of a sharded list, second step: its place in the list's rand() stream is known — (base0, R0): the stream
+// from the list's first value as far as this group can reach (win: the generator's window at the list's start), the
+// layout again, the tables, the blocks, the group function into pinned memory.
+static int resident_d3_sharded_tables(g2s_session* s, uint32_t base0, uint32_t R0, const uint32_t* win) {
+  D3Pending* dp = (D3Pending*)s->d3_pending;
+  if (!dp || !dp->sharded) return fail(G2S_ERR_ARG, "sharded list: no group pending");
+  if (hipSetDevice(s->device) != hipSuccess) return fail(G2S_ERR_NO_DEVICE, "cannot select device");
+  const size_t n = dp->L.n;
+  const size_t rnd_cap = rand_capacity((size_t)base0 + (size_t)R0 + dp->L.rnd_cap);
+  dp->rnd_cap = rnd_cap;
+  {  // the stream: window from the lead's generator, then g2s_rand_fill on the second stream; the main one waits for it
+    char* hsum_c = (char*)dp->hsum;
+    uint32_t* hwin = (uint32_t*)(hsum_c + 1024 + 64 * 128);
+    HIP_TRY(s->d_rnd.ensure((31 + rnd_cap + 64) * 4));
+    memcpy(hwin, win, G2S_RAND_WINDOW * 4);
+    HIP_TRY(hipMemcpyAsync(s->d_rnd.p, hwin, G2S_RAND_WINDOW * 4, hipMemcpyHostToDevice, s->stream2));
+    HIP_TRY(launch_rand_fill(s->stream2, (uint32_t*)s->d_rnd.p, s->rtab, nullptr, (uint64_t)rnd_cap, (uint64_t)base0));
+    HIP_TRY(hipEventRecord(s->ev_rand, s->stream2));
+    HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_rand, 0));
+  }
+  HIP_TRY(s->h_gfn.ensure(((size_t)R0 + 64) * 4));
+  dp->group_fn = (uint32_t*)s->h_gfn.p;
+  void* gd = nullptr;
+  HIP_TRY(hipHostGetDevicePointer(&gd, s->h_gfn.p, 0));
+  dp->group_fn_dev = (uint32_t*)gd;
+  dp->P.base0 = base0; dp->P.R0 = R0;
+  HIP_TRY(launch_d3_sharded_tables(s->stream, dp->P, dp->W, dp->L.outs_dev, dp->L.sub_dev, (uint32_t*)s->d_rnd.p, (uint64_t)rnd_cap,
+                                   dp->group_fn_dev));
+  HIP_TRY(hipMemcpyAsync(dp->hsum, dp->W.sum, sizeof(D3Summary), hipMemcpyDeviceToHost, s->stream));  // (the status behind the offsets)
+  (void)n;
+  return G2S_OK;
+}
+// third step: the deviation the group starts with is known: chain, hand-off, trace kernel (resident_d3_wait follows)
+static int resident_d3_sharded_trace(g2s_session* s, uint32_t d_in) {
+  D3Pending* dp = (D3Pending*)s->d3_pending;
+  if (!dp || !dp->sharded) return fail(G2S_ERR_ARG, "sharded list: no group pending");
+  if (hipSetDevice(s->device) != hipSuccess) return fail(G2S_ERR_NO_DEVICE, "cannot select device");
+  const Graph& g = *s->graph->g;
+  dp->P.d_in = d_in;
+  *(volatile unsigned long long*)dp->side_h.count = ~0ull;
+  HIP_TRY(launch_d3_sharded_trace(s->stream, dp->P, dp->W, dp->L.outs_dev, dp->L.sub_dev, (const char*)s->d_lastch.p,
+                                  (const char*)s->d_lastch.p + g.n, (uint32_t*)s->d_rnd.p, (uint64_t)dp->rnd_cap, dp->res_dev,
+                                  dp->arena_dev, dp->side_dev, dp->summary_dev));
+  if (dp->timed) HIP_TRY(hipEventRecord(s->ev[3], s->stream));
+  dp->t_launched = std::chrono::steady_clock::now();
   return G2S_OK;
 }
 // second half: the hand-over, the gaps the host finishes, the end of the stream's work, the summary
@@ -2954,7 +3021,7 @@ static int resident_d3_wait(g2s_session* s, g2s_timing* tm_out, double* ms_d3_ou
     if (ntasks > 2) s->pool->run(ntasks, copy_range);
     else for (size_t t = 0; t < ntasks; t++) copy_range(t);
   }
-  s->rcache.jump((size_t)hsum->draws_total, hsum->rand_state);
+  if (!dpp->sharded) s->rcache.jump((size_t)hsum->draws_total, hsum->rand_state);  // (a sharded list: the team's lead, once)
   g2s_timing& tm = *tm_out;
   tm.xA += hsum->xA; tm.sA += hsum->sA; tm.xB += hsum->xB; tm.sB += hsum->sB; tm.xD += hsum->xD; tm.sD += hsum->sD;
   tm.seg_segments += hsum->segs;
@@ -3145,8 +3212,218 @@ struct GroupQueue {
 // (resident_d3) — the stream offsets chain through all groups, and the kernels write results and text straight into
 // the caller's buffers.  No collective; the graph is replicated.  Returns G2S_OK (done), 1 (the host path takes the
 // list) or an error.
+// ---- A team's list with phase D3 SHARDED: one group per session, and every group stays on the GPU that filled it —
+// that GPU classifies, builds the draw-count tables of, traces and writes the results of its own gaps, through its
+// own PCIe link (gathering all groups on the lead's device made the lead trace 10 000 gaps and write 7.7 MB while
+// seven GPUs waited: DESIGN §7).  What couples the groups is the one rand() stream (:178): gap i's first draw is the
+// sum of the draws of all gaps before it.  Three steps, the sessions' threads meeting twice:
+//   1. every GPU: fill kernel, classes, totals of its group (fewest draws, spread)        -> prefix sums over the groups
+//   2. every GPU: the stream as far as its group reaches, its tables for every deviation its gaps can start with, and
+//      the GROUP FUNCTION (deviation behind the group by deviation in front)               -> composed in group order
+//   3. every GPU: chain from its deviation, hand-off, trace kernel; the gaps the host finishes, per session
+// Results are those of one session filling the whole list (asserted by bench.py and tests/test_gpu_resident.py).
+// Returns 1 when the list is not one for this form (the gather form or the host path take it).
+namespace {
+struct TeamBarrier {
+  std::mutex mu;
+  std::condition_variable cv;
+  int n, waiting = 0;
+  uint64_t gen = 0;
+  explicit TeamBarrier(int n_) : n(n_) {}
+  void wait() {
+    std::unique_lock<std::mutex> lk(mu);
+    const uint64_t g = gen;
+    if (++waiting == n) { waiting = 0; gen++; cv.notify_all(); return; }
+    cv.wait(lk, [&] { return gen != g; });
+  }
+};
+}  // namespace
+static int team_resident_sharded(g2s_session* const* sessions, int nsessions, const g2s_gap* gaps, size_t n, size_t group_size,
+                                 g2s_result* results, char* arena, g2s_timing* timing_out) {
+  g2s_session* lead = sessions[0];
+  if (getenv("G2S_TEAM_GATHER")) return 1;  // (measurements: the gather form)
+  const size_t ngroups = (n + group_size - 1) / group_size;
+  if (nsessions < 2 || ngroups != (size_t)nsessions || nsessions > 16) return 1;
+  for (int t = 0; t < nsessions; t++) if (!resident_applicable(sessions[t], n) || sessions[t]->d3_pending) return 1;
+  for (size_t q = 1; q < ngroups; q++) if (gaps[q * group_size].skip_if_prev_right_fuz_gt >= 0) return 1;  // a record cut by a group boundary
+  {  // the kernels write the caller's buffers from every device: page-locked through the ABI (g2s_host_alloc), or not this form
+    void* d = nullptr;
+    if (!device_pointer_of(results, &d) || !device_pointer_of(arena, &d)) return 1;
+  }
+  struct InTeam {
+    g2s_session* const* ss; int ns;
+    InTeam(g2s_session* const* a, int b_) : ss(a), ns(b_) {
+      for (int t = 0; t < ns; t++) {
+        ss[t]->in_team_list = true; ss[t]->team_sharded = true;
+        for (int u = 0; u < ns; u++) if (u != t && ss[u]->device == ss[t]->device) ss[t]->team_shares_device = true;
+      }
+    }
+    ~InTeam() { for (int t = 0; t < ns; t++) { ss[t]->in_team_list = false; ss[t]->team_sharded = false; ss[t]->team_shares_device = false; } }
+  } in_team(sessions, nsessions);
+  const auto t_begin = std::chrono::steady_clock::now();
+  std::vector<size_t> group_arena(ngroups + 1, 0);
+  for (size_t gi = 0; gi < ngroups; gi++) {
+    const size_t off = gi * group_size, cnt = std::min(group_size, n - off);
+    group_arena[gi + 1] = group_arena[gi] + g2s_team_arena_bytes(lead, gaps + off, cnt);
+  }
+  std::vector<g2s_batch*> subs(ngroups, nullptr);
+  std::vector<ResidentLaunch> rls(ngroups);
+  std::vector<int> rcs((size_t)nsessions, G2S_OK);
+  std::vector<std::string> errs((size_t)nsessions);
+  std::vector<uint64_t> tot_min(ngroups, 0), tot_spread(ngroups, 0);
+  std::vector<uint32_t> base0(ngroups, 0), R0(ngroups, 0), d_in(ngroups, 0);
+  std::vector<const uint32_t*> gfn(ngroups, nullptr);  // the groups' functions (pinned memory of their sessions)
+  std::vector<char> fell(ngroups, 0);
+  std::vector<double> ms_d3(ngroups, 0.0), ms_wall(ngroups, 0.0);
+  std::atomic<int> give_up(0);  // 1: not a list for this form (decided in front of the results: the caller goes on), 2: error
+  uint32_t win[G2S_RAND_WINDOW];
+  memcpy(win, lead->rcache.window(G2S_RAND_WINDOW), sizeof win);  // the generator where the list starts
+  TeamBarrier bar(nsessions);
+  auto worker = [&](int t) {
+    g2s_session* s = sessions[t];
+    const size_t off = (size_t)t * group_size, cnt = std::min(group_size, n - off);
+    auto failed = [&](int rc) { rcs[(size_t)t] = rc; errs[(size_t)t] = tl_error; give_up.store(2); };
+    // ---- step 1: fill kernel, classes, totals
+    bool mine_ok = false;
+    {
+      g2s_batch* b = nullptr;
+      const auto t0 = std::chrono::steady_clock::now();
+      int rc = g2s_batch_prepare(s, gaps + off, cnt, &b);
+      if (rc == G2S_OK) {
+        subs[(size_t)t] = b;
+        b->timing.ms_prepare = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        b->arena = arena + group_arena[(size_t)t];
+        b->arena_base = group_arena[(size_t)t];
+        rc = resident_launch_fill(b, &rls[(size_t)t]);
+        if (rc == 1) give_up.store(1);
+        else if (rc == G2S_OK) {
+          ResidentList L;
+          L.groups.push_back(b);
+          L.n = cnt; L.group_size = std::max<size_t>(cnt, 1);
+          L.group_arena.push_back(group_arena[(size_t)t]);
+          L.arena_bytes = group_arena[ngroups];
+          L.outs_dev = (const GapOut*)s->d_outs.p;
+          L.sub_dev = (const SubRec*)s->d_sub.p;
+          L.sub_region = 0;
+          L.pin = &s->h_d3;
+          L.rnd_cap = b->rnd_cap; L.dmax = b->dmax; L.has_skip = b->has_skip;
+          L.gaps_dev = (const GapDev*)s->d_gaps.p;
+          {  // (the D3Gap offsets are within the group's share: make them offsets into the arena)
+            D3Gap* dq = (D3Gap*)s->h_d3.p;
+            for (size_t i = 0; i < cnt; i++) dq[i].arena_off += (uint64_t)group_arena[(size_t)t];
+            s->desc_owner = nullptr;
+          }
+          rc = resident_d3_launch(s, L, rls[(size_t)t].timed, false, results + off, arena, true, true);
+          if (rc == G2S_OK && hipStreamSynchronize(s->stream) != hipSuccess) rc = fail(G2S_ERR_HIP, "sharded list, step 1");
+          if (rc == G2S_OK) {
+            const D3Summary* hs = ((D3Pending*)s->d3_pending)->hsum;
+            if (hs->status != 0) give_up.store(1);  // (a gap beyond every tier, tables beyond the budget: the host path's business)
+            tot_min[(size_t)t] = hs->draws_min; tot_spread[(size_t)t] = hs->draws_spread;
+            mine_ok = true;
+          }
+        }
+      }
+      if (rc < 0) failed(rc);
+    }
+    bar.wait();
+    // ---- the groups' places in the stream (every thread computes the same few sums)
+    uint64_t b0 = 0, r0 = 0;
+    for (int q = 0; q < t; q++) { b0 += tot_min[(size_t)q]; r0 += tot_spread[(size_t)q]; }
+    if (b0 + r0 >= 0xF0000000ull) give_up.store(1);
+    const bool go2 = give_up.load() == 0 && mine_ok;
+    // ---- step 2: the stream, the tables, the group function
+    if (go2) {
+      base0[(size_t)t] = (uint32_t)b0; R0[(size_t)t] = (uint32_t)r0;
+      int rc = resident_d3_sharded_tables(s, (uint32_t)b0, (uint32_t)r0, win);
+      if (rc == G2S_OK && hipStreamSynchronize(s->stream) != hipSuccess) rc = fail(G2S_ERR_HIP, "sharded list, step 2");
+      if (rc == G2S_OK && ((D3Pending*)s->d3_pending)->hsum->status != 0) give_up.store(1);
+      if (rc == G2S_OK) gfn[(size_t)t] = ((D3Pending*)s->d3_pending)->group_fn;
+      if (rc < 0) failed(rc);
+    }
+    bar.wait();
+    // ---- the deviation every group starts with: the group functions composed in group order
+    const bool go3 = give_up.load() == 0 && mine_ok;
+    if (go3) {
+      uint32_t d = 0;
+      for (int q = 0; q < t; q++) d = gfn[(size_t)q][std::min(d, R0[(size_t)q])];
+      d_in[(size_t)t] = d;
+      // ---- step 3: chain, hand-off, trace; the gaps the host finishes; the summary
+      int rc = resident_d3_sharded_trace(s, d);
+      bool fb = false;
+      if (rc == G2S_OK) rc = resident_d3_wait(s, &subs[(size_t)t]->timing, &ms_d3[(size_t)t], &fb);
+      if (rc == G2S_OK) rc = resident_reset_fill(s, cnt);
+      fell[(size_t)t] = fb ? 1 : 0;
+      ms_wall[(size_t)t] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+      if (rc < 0) failed(rc);
+    } else if (s->d3_pending) {  // (the list goes another way: what this session queued is waited for and dropped)
+      (void)hipSetDevice(s->device);
+      (void)hipStreamSynchronize(s->stream);
+      (void)hipStreamSynchronize(s->stream2);
+      delete (D3Pending*)s->d3_pending;
+      s->d3_pending = nullptr;
+      s->d_d3.clean = 0;
+      (void)resident_reset_fill(s, cnt);
+    }
+  };
+  {
+    if (!lead->team_pool || lead->team_pool->size() < nsessions - 1) {
+      delete lead->team_pool;
+      lead->team_pool = new WorkerPool(nsessions - 1);
+    }
+    const std::function<void(size_t)> job = [&](size_t t) { worker((int)t); };
+    lead->team_pool->run((size_t)nsessions, job);
+  }
+  int rc = G2S_OK;
+  for (int t = 0; t < nsessions; t++) if (rcs[(size_t)t] != G2S_OK) { rc = rcs[(size_t)t]; tl_error = errs[(size_t)t]; }
+  bool fell_back = give_up.load() == 1;
+  for (size_t q = 0; q < ngroups; q++) fell_back = fell_back || fell[q] != 0 || !subs[q];
+  g2s_timing total;
+  memset(&total, 0, sizeof total);
+  if (rc == G2S_OK && !fell_back) {
+    // the one stream goes on behind the list: the last group's summary knows where and in which state
+    const D3Summary* last = (const D3Summary*)((char*)sessions[nsessions - 1]->h_d3.p +
+        (n - (size_t)(nsessions - 1) * group_size) * sizeof(D3Gap) + 16 - ((n - (size_t)(nsessions - 1) * group_size) * sizeof(D3Gap)) % 16);
+    lead->rcache.jump((size_t)last->draws_total, last->rand_state);
+    total.team_groups = (uint32_t)ngroups;
+    total.team_sessions = (uint32_t)nsessions;
+    for (size_t gi = 0; gi < ngroups; gi++) {
+      const g2s_timing& t = subs[gi]->timing;
+      g2s_session* s = sessions[gi];
+      total.flank_bytes += t.flank_bytes; total.ms_prepare += t.ms_prepare;
+      total.xA += t.xA; total.sA += t.sA; total.xB += t.xB; total.sB += t.sB; total.xD += t.xD; total.sD += t.sD;
+      total.seg_segments += t.seg_segments; total.seg_tier_gaps += t.seg_tier_gaps; total.segx_tier_gaps += t.segx_tier_gaps;
+      total.fill_bytes += t.fill_bytes; total.ms_d3 += t.ms_d3;
+      total.draw_dependent_gaps += t.draw_dependent_gaps; total.host_finished_gaps += t.host_finished_gaps;
+      total.d3_table_entries += t.d3_table_entries;
+      float ms_fill = 0;
+      if (rls[gi].timed && hipSetDevice(s->device) == hipSuccess && hipEventElapsedTime(&ms_fill, s->ev[1], s->ev[2]) == hipSuccess) {
+        total.ms_fill_seg += ms_fill; total.seg_timed_launches++;
+        if (gi < 16) total.team_ms_fill[gi] = ms_fill;
+      }
+      if (gi < 16) { total.team_ms_d3[gi] = ms_d3[gi]; total.team_ms_wall[gi] = ms_wall[gi]; }
+      (void)hipGetLastError();
+      total.seg_launches++;
+      total.seg2_launches += rls[gi].two_waves ? 1u : 0u;
+      if (gi < 16) total.team_groups_by_session[gi]++;
+    }
+    total.team_d3_sharded = 1;
+    total.resident_launches = 1;  // (one list, finished on the devices)
+  }
+  for (g2s_batch* b : subs) if (b) g2s_batch_free(b);
+  if (rc != G2S_OK) return rc;
+  if (fell_back) return 1;
+  total.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+  if (timing_out) *timing_out = total;
+  lead->last_timing = total;
+  return G2S_OK;
+}
+
 static int team_resident(g2s_session* const* sessions, int nsessions, const g2s_gap* gaps, size_t n, size_t group_size,
                          g2s_result* results, char* arena, g2s_timing* timing_out) {
+  {  // one group per session: the groups stay where they were filled (phase D3 sharded)
+    const int rs = team_resident_sharded(sessions, nsessions, gaps, n, group_size, results, arena, timing_out);
+    if (rs != 1) return rs;
+  }
   g2s_session* lead = sessions[0];
   if (!resident_applicable(lead, n)) return 1;
   for (int t = 1; t < nsessions; t++) if (!resident_applicable(sessions[t], n)) return 1;
@@ -3354,7 +3631,11 @@ extern "C" int g2s_team_fill(g2s_session* const* sessions, int nsessions, const 
       total.resident_fallbacks += tm.resident_fallbacks; total.draw_dependent_gaps += tm.draw_dependent_gaps;
       total.d3_table_entries += tm.d3_table_entries; total.host_finished_gaps += tm.host_finished_gaps;
       total.team_groups += tm.team_groups; total.team_sessions = tm.team_sessions;
-      for (int q = 0; q < 16; q++) total.team_groups_by_session[q] += tm.team_groups_by_session[q];
+      for (int q = 0; q < 16; q++) {
+        total.team_groups_by_session[q] += tm.team_groups_by_session[q];
+        total.team_ms_fill[q] += tm.team_ms_fill[q]; total.team_ms_d3[q] += tm.team_ms_d3[q]; total.team_ms_wall[q] += tm.team_ms_wall[q];
+      }
+      total.team_d3_sharded = (lo == 0 ? 1u : total.team_d3_sharded) & tm.team_d3_sharded;  // (every slice)
       lo = hi;
       abase += abytes;
     }

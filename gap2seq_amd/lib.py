@@ -65,7 +65,8 @@ class g2s_timing(C.Structure):
                 ("ms_d3", C.c_double), ("resident_launches", C.c_uint32), ("resident_fallbacks", C.c_uint32),
                 ("draw_dependent_gaps", C.c_uint64), ("d3_table_entries", C.c_uint64),
                 ("host_finished_gaps", C.c_uint32), ("team_groups", C.c_uint32), ("team_sessions", C.c_uint32),
-                ("team_groups_by_session", C.c_uint32 * 16), ("seg_timed_launches", C.c_uint32)]
+                ("team_groups_by_session", C.c_uint32 * 16), ("seg_timed_launches", C.c_uint32), ("team_d3_sharded", C.c_uint32), ("reserved0", C.c_uint32),
+                ("team_ms_fill", C.c_double * 16), ("team_ms_d3", C.c_double * 16), ("team_ms_wall", C.c_double * 16)]
 
 
 class g2s_run_opts(C.Structure):
@@ -552,14 +553,29 @@ class Session:
             self.h = None
 
 
-def team_fill(sessions, gaps, group_size=0, want_timing=False, prepared=None):
+def team_fill(sessions, gaps, group_size=0, want_timing=False, prepared=None, pinned=False):
     """g2s_team_fill: the sessions (one or more per device) share one gap list; results equal
     sessions[0].fill_batch(gaps).  `prepared` = (arr, keep, arena, res) from a previous call to
-    skip the marshalling (bench)."""
+    skip the marshalling (bench).  pinned: results and arena in g2s_host_alloc memory (every session's kernels then
+    write its own group's results there: phase D3 sharded over the team); the buffers are not freed (tests)."""
     lib = load_library()
     if prepared is None:
         arr, keep = _gap_array(gaps)
         nbytes = lib.g2s_team_arena_bytes(sessions[0].h, arr, len(gaps))
+        if pinned:
+            arena = HostBuffer(max(1, nbytes))
+            rbuf = HostBuffer(C.sizeof(g2s_result) * max(1, len(gaps)))
+            res = rbuf.array(g2s_result, max(1, len(gaps)))
+            hs = (_VP * len(sessions))(*[s.h for s in sessions])
+            t = g2s_timing()
+            try:
+                _check(lib.g2s_team_fill(hs, len(sessions), arr, len(gaps), group_size, res, C.cast(arena.p, C.c_char_p), nbytes, C.byref(t)))
+                raw = arena.raw
+                out = [FillResult(res[i], raw) for i in range(len(gaps))]
+            finally:
+                arena.free()
+                rbuf.free()
+            return (out, t) if want_timing else out
         arena = C.create_string_buffer(max(1, nbytes))
         res = (g2s_result * max(1, len(gaps)))()
         prepared = (arr, keep, arena, res, nbytes)

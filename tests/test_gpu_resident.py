@@ -312,6 +312,46 @@ def test_team_on_the_devices_equals_one_session(product, monkeypatch, nsess, gro
         pg.free()
 
 
+@pytest.mark.parametrize("nsess", [2, 3, 4, 8])
+def test_team_with_phase_d3_sharded_equals_one_session(product, monkeypatch, nsess):
+    """g2s_team_fill, one group per session, the caller's buffers page-locked: every group stays on the device that
+    filled it — its session classifies, builds the tables of, traces and writes the results of its own gaps; the
+    sessions meet twice to place the groups in the one rand() stream (totals, then the composed group functions).
+    Same results as one session on the host path, same stream position afterwards.  (The sessions share device 0 here:
+    the logic is the one of N GPUs, the timing is not.)"""
+    reads = product.G2S.synth_genome(200000, 3, 20240101)
+    seqs = [ln for ln in reads.splitlines() if not ln.startswith(">")]
+    gl = _parse_scaffolds(product.G2S.synth_gaps(reads, 31, 10, 1400, 100, 900, 20240103))
+    deep = _parse_scaffolds(product.G2S.synth_gaps(reads, 31, 10, 2, 6000, 6000, 77))
+    gl = gl[:500] + deep[:1] + gl[500:1399]  # (one long gap among them)
+    gaps = _gaps(product, gl)
+    monkeypatch.setenv("G2S_RESIDENT", "0")
+    pg = product.Graph.from_seqs(seqs, 31, 1)
+    solo = product.Session(pg, 0, d_err=500, randseed=9)
+    want = [_key(r) for r in solo.fill_batch(gaps)]
+    want2 = [_key(r) for r in solo.fill_batch(gaps[:200])]
+    solo.destroy()
+    monkeypatch.delenv("G2S_RESIDENT")
+    team = [product.Session(pg, 0, d_err=500, randseed=9) for _ in range(nsess)]
+    try:
+        group = -(-len(gaps) // nsess)
+        got, tm = product.team_fill(team, gaps, group_size=group, want_timing=True, pinned=True)
+        assert [_key(r) for r in got] == want
+        assert tm.team_d3_sharded == 1 and tm.resident_launches == 1 and tm.resident_fallbacks == 0
+        assert tm.team_groups == nsess and tm.team_sessions == nsess
+        assert tm.seg_tier_gaps + tm.segx_tier_gaps == len(gaps)
+        got2 = product.team_fill(team, gaps[:200], group_size=group)  # (short list: the host path; the stream goes on)
+        assert [_key(r) for r in got2] == want2
+        # the same list with the groups gathered on the lead's device (pageable buffers): the other form, same results
+        team[0].srand(9)
+        got3, tm3 = product.team_fill(team, gaps, group_size=group, want_timing=True)
+        assert [_key(r) for r in got3] == want and tm3.team_d3_sharded == 0
+    finally:
+        for s in team:
+            s.destroy()
+        pg.free()
+
+
 def test_long_lists_go_slice_by_slice(product, monkeypatch):
     """A list beyond 20 480 gaps is filled in slices of about 16 384 (the draw-count tables of phase D3 grow with the
     square of the gaps they chain through); the rand() stream runs on from slice to slice, a slice ends where a
