@@ -521,7 +521,7 @@ def main():
         kern_ms = acc["ms_fill_seg"] / max(1, acc["seg_timed"])
         if tm.segx_tier_gaps > 0:
             # deep gaps took the tier's large variant as well: the two kernels' launches of a step as one unit
-            kname = kname + " + g2s_fill_segx"
+            kname = kname + " + g2s_fill_segw"
             kern_ms = (acc["ms_fill_seg"] + acc["ms_fill_segx"]) / max(1, acc["seg_timed"])
     elif tm.lds_tier_gaps > 0:
         kname = "g2s_fill_lds"
@@ -539,7 +539,9 @@ def main():
     traffic, traffic_src = None, None
     # HBM bytes per launch of that kernel from the committed counter passes of this workload (rocprofv3 --pmc
     # FETCH_SIZE / WRITE_SIZE in passes of their own, gfx950 read-side correction: tools/pmc_summary.py)
-    pmc = os.path.join(ROOT, "profiles", "r03_pmc_%s.json" % cfg_name.lower())
+    pmc = os.path.join(ROOT, "profiles", "r04_pmc_%s.json" % cfg_name.lower())
+    if not os.path.exists(pmc):
+        pmc = os.path.join(ROOT, "profiles", "r03_pmc_%s.json" % cfg_name.lower())
     if os.path.exists(pmc) and not custom and ngpu == 1:
         try:
             pj = json.load(open(pmc))
