@@ -783,8 +783,12 @@ __device__ __forceinline__ bool d3_handoff_body(const D3Params& P, const D3Work&
       h.gap = i; h.n_segs = ns; h.seg_off = so; h.rnd_off = ro; h.draws = want; h.pad = 0;
       W.hitems[it] = h;
       W.host_slot[i] = (uint32_t)it;
+      // (the host as well, without the ready word: it takes the items largest closure first)
+      uint32_t* hi = (uint32_t*)&side.items[it];
+      hi[0] = i; hi[1] = ns; hi[2] = (uint32_t)so; hi[3] = (uint32_t)(so >> 32); hi[4] = (uint32_t)ro; hi[5] = (uint32_t)(ro >> 32); hi[6] = want;
     }
   }
+  if (hm != 0ull) __threadfence_system();  // (the items are in host memory before the count that announces them)
   (void)sub; (void)rnd; (void)outs;
   return hm != 0ull;
 }
@@ -1008,9 +1012,7 @@ __global__ __launch_bounds__(64) void g2s_d3_trace(const D3Params P, const D3Wor
       for (uint32_t w = (uint32_t)lane; w < want + 1u; w += 64u) side.rnd[ro + w] = rnd[td.off + w];
       __threadfence_system();  // (the whole wave's stores are in host memory before the item says so)
       if (lane == 0) {
-        g2s::D3HostItem h;
-        h.gap = i; h.n_segs = ns; h.seg_off = so; h.rnd_off = ro; h.draws = want; h.pad = 0;
-        side.items[it] = h;
+        // (the item's other words: the hand-off wrote them)
         __hip_atomic_store(&side.items[it].pad, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
       }
     }

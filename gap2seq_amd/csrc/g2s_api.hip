@@ -576,6 +576,7 @@ struct g2s_session {
   bool team_shares_device = false;  // ... and another session of the team sits on the same device
   int peer_asked_for = -1;       // the lead device this session asked direct access to (team lists)
   bool self_cleaned = false;     // the last list's trace kernel zeroed records, summary and cursors behind itself
+  std::vector<uint32_t> host_order;  // resident mode: the handed-over items, largest closure first
   size_t side_dirty = SIZE_MAX;  // items of h_side whose ready word may be set (resident mode's hand-over)...
   size_t side_layout_n = 0;      // ...under the layout of a list of this many gaps (the arrays behind the items move with it)
   uint32_t timed_seq = 0;        // resident launches so far (one in eight is bracketed with HIP events)
@@ -2471,12 +2472,17 @@ static bool finish_gap_on_host(const Graph& g, const FillParams& fp, const GapJo
                                uint32_t n_segs, const uint32_t* rands, uint32_t expect_draws, uint64_t arena_off, char* arena,
                                g2s_result* r) {
   memset(r, 0, sizeof *r);
+  const auto t_fin0 = std::chrono::steady_clock::now();
   SubView v;
   v.out = &go; v.segs = segs; v.n_segs = n_segs;
-  SubPrep pp;
+  static thread_local SubPrep pp_store;  // (its vectors keep their storage from gap to gap)
+  static thread_local std::vector<uint64_t> scratch;
+  SubPrep& pp = pp_store;
+  pp.reset();
+  if (scratch.size() < 3 * (size_t)n_segs + 1) scratch.resize(3 * (size_t)n_segs + 1);
   std::vector<SubRec> own;
-  if (!seg_analyze(fp, j, v, &pp, nullptr)) {  // (G2S_STATE_D2: per-state records)
-    pp = SubPrep();
+  if (!seg_analyze(fp, j, v, &pp, scratch.data())) {  // (G2S_STATE_D2: per-state records)
+    pp.reset();
     own.resize((size_t)go.n_sub + ((size_t)go.n_xp + 1) / 2 + 1);
     uint64_t* xp = (uint64_t*)(own.data() + go.n_sub);
     seg_expand(fp, j, go, segs, n_segs, own.data(), xp);
@@ -2495,8 +2501,18 @@ static bool finish_gap_on_host(const Graph& g, const FillParams& fp, const GapJo
   if (!pp.phase_d) return false;
   r->vertices = pp.sub[0]; r->edges = pp.sub[1]; r->nontrivial_components = pp.sub[2];
   r->size_nontrivial_components = pp.sub[3]; r->vertices_final = pp.sub[4]; r->edges_final = pp.sub[5];
+  const auto t_an = std::chrono::steady_clock::now();
   if (pp.seg_mode) seg_traceback(g, fp, j, v, pp, rands, arena + arena_off, r);
   else sub_traceback(g, fp, j, v, pp, rands, arena + arena_off, r);
+  if (dbg_analysis_stats && n_segs >= 2000 && pp.run_mode) {
+    const double* l = g2s_post_laps;
+    fprintf(stderr, "[g2s] run analysis laps (us): front %.0f | collect %.0f merge+sort %.0f runs %.0f edges %.0f csr %.0f tarjan %.0f rest %.0f\n",
+            l[0] - std::chrono::duration<double, std::micro>(t_fin0.time_since_epoch()).count(), l[1] - l[0], l[2] - l[1], l[3] - l[2], l[4] - l[3], l[5] - l[4], l[6] - l[5], l[7] - l[6]);
+  }
+  if (dbg_analysis_stats && n_segs >= 2000)
+    fprintf(stderr, "[g2s] host-finished gap of %u segments: analysis %.3f ms (%s, %zu runs), traceback %.3f ms\n", n_segs,
+            std::chrono::duration<double, std::milli>(t_an - t_fin0).count(), pp.run_mode ? "runs" : pp.seg_mode ? "segments" : "states", pp.runs.size(),
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_an).count());
   if ((uint32_t)r->draws != expect_draws || (r->flags & G2S_GAP_BACKTRACE_FAIL)) return false;
   r->fill_off = arena_off + (uint64_t)(j.lmf - r->left_fuz);
   r->fill_len = (int32_t)strlen(arena + r->fill_off);
@@ -2958,13 +2974,40 @@ static int resident_d3_wait(g2s_session* s, g2s_timing* tm_out, double* ms_d3_ou
       const D3HostItem& h = side_h.items[x];
       const size_t q = h.gap / L.group_size, loc = h.gap % L.group_size;
       const g2s_batch* gb = L.groups[q];
+      const auto t_one = std::chrono::steady_clock::now();
+      struct Lap { const std::chrono::steady_clock::time_point t0, th; const D3HostItem& h; size_t x; bool on;
+                   ~Lap() { if (on && h.n_segs >= 2000) fprintf(stderr, "[g2s] host-finished item %zu (gap %u): %u segments, %u draws: picked up %.3f ms after the hand-over, %.3f ms\n", x, h.gap, h.n_segs, h.draws,
+                                                              std::chrono::duration<double, std::milli>(t0 - th).count(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); } }
+          lap{t_one, t_handed, h, x, dbg_analysis_stats};
       if (!finish_gap_on_host(g, fp, gb->jobs[loc], side_h.outs[x], side_h.segs + h.seg_off, h.n_segs, side_h.rnd + h.rnd_off, h.draws,
                               (uint64_t)(L.group_arena[q] + gb->arena_off[loc]), text, &rs_host[h.gap]))
         host_bad.fetch_add(1);
     };
-    if (ni > 2) s->pool->run(ni, one);
-    else for (size_t x = 0; x < ni; x++) one(x);
+    // (largest closures first: the hand-off kernel wrote every item's size before it said how many there are;
+    // the last of a -dist-error 2000 list's 400 items to be picked up was its largest, a third of the wait)
+    std::vector<uint32_t>& lpt = s->host_order;
+    lpt.resize(ni);
+    for (size_t x = 0; x < ni; x++) lpt[x] = (uint32_t)x;
+    if (ni > 2) {
+      std::sort(lpt.begin(), lpt.end(), [&](uint32_t a, uint32_t b) {
+        const uint32_t na = side_h.items[a].n_segs, nb = side_h.items[b].n_segs;
+        return na != nb ? na > nb : a < b;
+      });
+      s->pool->run(ni, [&](size_t x) { one((size_t)lpt[x]); });
+    } else for (size_t x = 0; x < ni; x++) one(x);
     for (size_t x = 0; x < ni; x++) host_fill_bytes += (uint64_t)rs_host[side_h.items[x].gap].fill_len;
+    if (const char* path = getenv("G2S_HOST_ITEMS_DUMP")) {  // (tools/host_items_replay.py: the host's share of a list, replayed without a GPU)
+      if (FILE* f = fopen(path, "wb")) {
+        for (size_t x = 0; x < ni; x++) {
+          const D3HostItem& h = side_h.items[x];
+          const GapOut& go = side_h.outs[x];
+          const int32_t hd[8] = {(int32_t)h.gap, (int32_t)h.n_segs, go.c_count, go.n_len, go.len[0], go.len[1], go.reached_j, go.final_d};
+          fwrite(hd, sizeof hd, 1, f);
+          fwrite(side_h.segs + h.seg_off, sizeof(SegRec), h.n_segs, f);
+        }
+        fclose(f);
+      }
+    }
   }
   const auto t_finished = std::chrono::steady_clock::now();
   HIP_TRY(hipStreamSynchronize(st));
@@ -4023,8 +4066,16 @@ extern "C" int g2s_test_post_segments(const g2s_graph* gh, const g2s_params* p, 
   SubView v;
   v.out = &go; v.segs = (const SegRec*)segs; v.n_segs = n_segs;
   SubPrep prep;
+  const auto t_an0 = std::chrono::steady_clock::now();
   const bool ok = seg_analyze(fp, j, v, &prep);
   if (on_segments) *on_segments = ok ? 1 : 0;
+  if (n_segs >= 2000 && prep.run_mode && getenv("G2S_POST_LAPS")) {  // (tools/host_items_replay.py)
+    const double* l = g2s_post_laps;
+    const double t1 = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    fprintf(stderr, "[g2s] %u segments, run analysis laps (us): front %.0f | collect %.0f merge+sort %.0f runs %.0f edges %.0f csr %.0f tarjan %.0f rest %.0f | all %.0f\n", n_segs,
+            l[0] - std::chrono::duration<double, std::micro>(t_an0.time_since_epoch()).count(), l[1] - l[0], l[2] - l[1], l[3] - l[2], l[4] - l[3], l[5] - l[4], l[6] - l[5], l[7] - l[6],
+            t1 - std::chrono::duration<double, std::micro>(t_an0.time_since_epoch()).count());
+  }
   memset(res, 0, sizeof *res);
   memset(buf, 0, j.buf_bytes(k, fp.d_err));
   if (!ok) return G2S_OK;  // a k-mer at two depths: the caller takes g2s_test_seg_expand + g2s_test_post_closure

@@ -2,6 +2,7 @@
 #include "post.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cctype>
 #include <cstdio>
 #include <cstdlib>
@@ -42,6 +43,9 @@ struct VertexMap {
   }
 };
 
+}  // namespace
+thread_local double g2s_post_laps[12];
+namespace {
 // Tarjan over a CSR adjacency; component ids are arbitrary.
 int strong_components(int nv, const std::vector<int>& off, const std::vector<int>& adj, std::vector<int>* comp) {
   static thread_local std::vector<int> index, low, it, stack, call;
@@ -590,21 +594,69 @@ inline bool seg_safe(const SubView& v, const SubPrep& prep, uint32_t i, int t) {
 
 namespace {
 
-// sorted, disjoint intervals from a list of (first, last) pairs; overlapping and adjacent ones merge
-void merge_intervals(std::vector<std::pair<uint32_t, uint32_t>>* a) {
-  std::sort(a->begin(), a->end());
+// Stable LSD radix sort of unsigned keys on the bits of `bits` (one contiguous field); only the digits in which the
+// keys differ take a pass.  (The analysis below sorts some twenty thousand k-mer indices and edges for a closure of four thousand
+// segments: with std::sort that was 60 % of its time.)
+template <class T>
+void radix_sort(T* a, size_t n, T bits) {
+  static thread_local std::vector<T> tmp;
+  if (n < 2) return;
+  if (n <= 24) {
+    for (size_t i = 1; i < n; i++) {
+      const T x = a[i];
+      size_t j = i;
+      while (j > 0 && (a[j - 1] & bits) > (x & bits)) { a[j] = a[j - 1]; j--; }
+      a[j] = x;
+    }
+    return;
+  }
+  T diff = 0;
+  for (size_t i = 1; i < n; i++) diff |= a[i] ^ a[0];
+  diff &= bits;
+  if (tmp.size() < n) tmp.resize(n);
+  T* src = a;
+  T* dst = tmp.data();
+  constexpr unsigned kDigit = 11u;  // (20-odd bits of k-mer index: two passes)
+  unsigned b = 0;
+  while (b < sizeof(T) * 8u && !((bits >> b) & (T)1)) b++;
+  for (; b < sizeof(T) * 8u; b += kDigit) {
+    const T dm = (bits >> b) & (T)((1u << kDigit) - 1u);
+    if (!((diff >> b) & dm)) continue;
+    uint32_t cnt[1u << kDigit];
+    memset(cnt, 0, sizeof cnt);
+    for (size_t i = 0; i < n; i++) cnt[(size_t)((src[i] >> b) & dm)]++;
+    uint32_t sum = 0;
+    for (unsigned q = 0; q < (1u << kDigit); q++) { const uint32_t c = cnt[q]; cnt[q] = sum; sum += c; }
+    for (size_t i = 0; i < n; i++) dst[cnt[(size_t)((src[i] >> b) & dm)]++] = src[i];
+    std::swap(src, dst);
+  }
+  if (src != a) memcpy(a, src, n * sizeof(T));
+}
+constexpr uint64_t kHi32 = 0xFFFFFFFF00000000ull, kLo32 = 0x00000000FFFFFFFFull;
+
+// intervals as first << 32 | last: sorted and disjoint afterwards; overlapping ones merge, adjacent ones when asked
+void merge_intervals(std::vector<uint64_t>* a, bool adjacent) {
+  radix_sort(a->data(), a->size(), kHi32);
   size_t w = 0;
   for (size_t i = 0; i < a->size(); i++) {
-    if (w > 0 && (*a)[i].first <= (*a)[w - 1].second + 1u) (*a)[w - 1].second = std::max((*a)[w - 1].second, (*a)[i].second);
-    else (*a)[w++] = (*a)[i];
+    const uint64_t x = (*a)[i];
+    const uint32_t lo = (uint32_t)(x >> 32), hi = (uint32_t)x;
+    if (w > 0 && (uint64_t)lo <= (uint64_t)(uint32_t)(*a)[w - 1] + (adjacent ? 1u : 0u)) {
+      if (hi > (uint32_t)(*a)[w - 1]) (*a)[w - 1] = ((*a)[w - 1] & kHi32) | hi;
+    } else (*a)[w++] = x;
   }
   a->resize(w);
 }
-inline bool in_intervals(const std::vector<std::pair<uint32_t, uint32_t>>& a, uint32_t x) {
-  size_t lo = 0, hi = a.size();
-  while (lo < hi) { const size_t mid = (lo + hi) >> 1; if (a[mid].first <= x) lo = mid + 1; else hi = mid; }
-  return lo > 0 && x <= a[lo - 1].second;
-}
+// membership in such a list for queries that never decrease
+struct IntervalSweep {
+  const std::vector<uint64_t>& a;
+  size_t p = 0;
+  explicit IntervalSweep(const std::vector<uint64_t>& v) : a(v) {}
+  bool has(uint32_t x) {
+    while (p < a.size() && (uint32_t)a[p] < x) p++;
+    return p < a.size() && (uint32_t)(a[p] >> 32) <= x;
+  }
+};
 
 // :1314-1435 on a closure in which k-mers occur at several depths.  The reference's vertices are k-mers
 // (node2boost), its edges the deduplicated (boost::edge(u, v).second) state transitions.  Inside a unitig the
@@ -615,19 +667,24 @@ inline bool in_intervals(const std::vector<std::pair<uint32_t, uint32_t>>& a, ui
 // contraction and the branch rule run on runs; a run that is not in a component of several vertices stands
 // for a row of trivial vertices with one edge in and one out each, along which the running count of the
 // branch rule cannot change.  sinkpos: position of the sink state inside each segment or -1.
+// (Everything in front of the strong components is radix sorts and sweeps over sorted lists: the closures of
+// a -dist-error 2000 list have thousands of segments each, and a list waits for the slowest of them.)
 void seg_analyze_runs(const FillParams& p, const SubView& v, SubPrep* out, const std::vector<int>& sinkpos) {
-  typedef std::pair<uint32_t, uint32_t> IV;
   const uint32_t n = v.n_segs;
   const SegRec* sg = v.segs;
-  constexpr uint32_t VSINK = 0xFFFFFFFEu, VSRC = 0xFFFFFFFFu;
-  static thread_local std::vector<IV> viv, uiv, div;
-  static thread_local std::vector<uint64_t> sp;
-  static thread_local std::vector<uint32_t> bp;
+  static thread_local std::vector<uint64_t> viv, uiv, div, sp;  // intervals first << 32 | last; edges from << 32 | to
+  static thread_local std::vector<uint32_t> bp, srcs, sinks, loopk;
+  static thread_local std::vector<int> bp_run;
+  static thread_local std::vector<uint8_t> is_par;
   static thread_local std::vector<std::pair<int, int>> ce;
-  static thread_local std::vector<int> off, adj, comp, cnodes, cweight, din, dout, foff, fadj, indeg, order, fbranch, internal, loops;
+  static thread_local std::vector<int> off, adj, comp, cnodes, cweight, din, dout, foff, fadj, indeg, order, fbranch, internal, loops, pos;
   static thread_local std::vector<char> cyc, nontriv;
-  viv.clear(); uiv.clear(); div.clear(); sp.clear(); bp.clear(); ce.clear(); loops.clear();
+  viv.clear(); uiv.clear(); div.clear(); sp.clear(); bp.clear(); srcs.clear(); sinks.clear(); loopk.clear(); ce.clear(); loops.clear();
+  is_par.assign(n, 0);
   int count = 0;
+  int lapi = 0;
+  auto lap = [&]() { if (lapi < 12) g2s_post_laps[lapi++] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  lap();
   for (uint32_t i = 0; i < n; i++) {
     const SegRec& s = sg[i];
     const int ts = seg_ts(s);
@@ -635,11 +692,11 @@ void seg_analyze_runs(const FillParams& p, const SubView& v, SubPrep* out, const
     const uint32_t idx = s.node >> 1;
     const bool up = (s.node & 1u) == 0;
     const uint32_t lo = up ? idx : idx - (uint32_t)ts, hi = up ? idx + (uint32_t)ts : idx;
-    viv.emplace_back(lo, hi);
+    viv.push_back(((uint64_t)lo << 32) | hi);
     bp.push_back(lo);
     bp.push_back(hi);
-    if (ts > 0) (up ? uiv : div).emplace_back(lo, hi - 1u);  // chain edges by the lower index of their two k-mers
-    if (s.flags & G2S_SUB_SOURCE) sp.push_back(((uint64_t)VSRC << 32) | idx);                    // :1303-1305
+    if (ts > 0) (up ? uiv : div).push_back(((uint64_t)lo << 32) | (hi - 1u));  // chain edges by the lower index of their two k-mers
+    if (s.flags & G2S_SUB_SOURCE) srcs.push_back(idx);                                            // :1303-1305
     else {
       uint32_t ps[4];
       const int np = seg_parents(s, ps);
@@ -647,104 +704,135 @@ void seg_analyze_runs(const FillParams& p, const SubView& v, SubPrep* out, const
         const SegRec& q = sg[ps[x]];
         const uint32_t last = seg_state(q, (int)(q.depth_len >> 16) - 1) >> 1;
         sp.push_back(((uint64_t)last << 32) | idx);
-        bp.push_back(last);
+        if (!is_par[ps[x]]) { is_par[ps[x]] = 1; bp.push_back(last); }
       }
     }
     if (sinkpos[i] >= 0 && sinkpos[i] <= ts) {                                                    // :1216-1226 / :1248-1256
       const uint32_t x = seg_state(s, sinkpos[i]) >> 1;
-      sp.push_back(((uint64_t)x << 32) | VSINK);
+      sinks.push_back(x);
       bp.push_back(x);
       count = sat_add(count, (int)s.cnt);
     }
   }
+  lap();
   if (p.all_paths) out->count = count;  // recount (:1189-1191); -best-only keeps the phase C count
-  merge_intervals(&uiv);
-  merge_intervals(&div);
-  {  // vertices: overlapping intervals merge (adjacent ones may: whether an edge joins them is looked up)
-    std::sort(viv.begin(), viv.end());
-    size_t w = 0;
-    for (size_t i = 0; i < viv.size(); i++) {
-      if (w > 0 && viv[i].first <= viv[w - 1].second) viv[w - 1].second = std::max(viv[w - 1].second, viv[i].second);
-      else viv[w++] = viv[i];
-    }
-    viv.resize(w);
-  }
+  merge_intervals(&uiv, true);
+  merge_intervals(&div, true);
+  merge_intervals(&viv, false);  // vertices: overlapping intervals merge (adjacent ones may: whether an edge joins them is looked up)
   uint64_t V = 2;
-  for (const IV& a : viv) V += (uint64_t)(a.second - a.first) + 1u;
-  std::sort(bp.begin(), bp.end());
+  for (const uint64_t a : viv) V += (uint64_t)((uint32_t)a - (uint32_t)(a >> 32)) + 1u;
+  radix_sort(bp.data(), bp.size(), 0xFFFFFFFFu);
   bp.erase(std::unique(bp.begin(), bp.end()), bp.end());
-  std::sort(sp.begin(), sp.end());
-  sp.erase(std::unique(sp.begin(), sp.end()), sp.end());  // boost::edge(u, v).second de-duplication ...
-  {                                                       // ... also against the chains' own edges
-    size_t w = 0;
-    for (uint64_t e : sp) {
-      const uint32_t a = (uint32_t)(e >> 32), b = (uint32_t)e;
-      if (a < VSINK && b < VSINK) {
-        if (b == a + 1u && in_intervals(uiv, a)) continue;
-        if (a == b + 1u && in_intervals(div, b)) continue;
-      }
-      sp[w++] = e;
-    }
-    sp.resize(w);
-  }
+  radix_sort(srcs.data(), srcs.size(), 0xFFFFFFFFu);
+  srcs.erase(std::unique(srcs.begin(), srcs.end()), srcs.end());  // boost::edge(u, v).second de-duplication ...
+  radix_sort(sinks.data(), sinks.size(), 0xFFFFFFFFu);
+  sinks.erase(std::unique(sinks.begin(), sinks.end()), sinks.end());
+  lap();
   // ---- runs: every cut k-mer alone, and what lies between two cuts
   std::vector<SegRun>& runs = out->runs;
   runs.clear();
+  runs.reserve(2 * bp.size() + 2);
+  bp_run.assign(bp.size(), -1);
   {
     size_t b = 0;
-    for (const IV& a : viv) {
-      uint32_t next = a.first;  // first k-mer not yet in a run
-      while (b < bp.size() && bp[b] < a.first) b++;
-      for (; b < bp.size() && bp[b] <= a.second; b++) {
+    for (const uint64_t a : viv) {
+      const uint32_t a_lo = (uint32_t)(a >> 32), a_hi = (uint32_t)a;
+      uint32_t next = a_lo;  // first k-mer not yet in a run
+      while (b < bp.size() && bp[b] < a_lo) b++;
+      for (; b < bp.size() && bp[b] <= a_hi; b++) {
         if (bp[b] > next) runs.push_back(SegRun{next, bp[b] - 1u, 0});
+        bp_run[b] = (int)runs.size();
         runs.push_back(SegRun{bp[b], bp[b], 0});
         next = bp[b] + 1u;
       }
-      if (next <= a.second) runs.push_back(SegRun{next, a.second, 0});  // (cannot happen: interval ends are cuts)
+      if (next <= a_hi) runs.push_back(SegRun{next, a_hi, 0});  // (cannot happen: interval ends are cuts)
     }
   }
   const int R = (int)runs.size(), NV = R + 2;  // node 0 = sink, 1 = source, 2 + r = run r
-  auto node_of = [&](uint32_t x) -> int {
-    if (x == VSINK) return 0;
-    if (x == VSRC) return 1;
+  auto node_search = [&](uint32_t x) -> int {
     size_t lo = 0, hi = runs.size();
     while (lo < hi) { const size_t mid = (lo + hi) >> 1; if (runs[mid].lo <= x) lo = mid + 1; else hi = mid; }
     return 2 + (int)(lo - 1);
   };
+  // the node of k-mer x, for queries that never decrease (every end of an edge is a cut: a run of its own)
+  struct CutSweep {
+    const std::vector<uint32_t>& bp; const std::vector<int>& bp_run; size_t p = 0;
+    int at(uint32_t x) { while (p < bp.size() && bp[p] < x) p++; return (p < bp.size() && bp[p] == x) ? bp_run[p] : -1; }
+  };
+  lap();
   // ---- edges between nodes, one per distinct edge of the reference's graph; edges inside a run are counted
   internal.assign((size_t)NV, 0);
   cyc.assign((size_t)NV, 0);
   uint64_t e_all = 0;
-  for (int r = 0; r < R; r++) {
-    const uint32_t L = runs[(size_t)r].hi - runs[(size_t)r].lo + 1u;
-    if (L > 1u) {
-      const bool u = in_intervals(uiv, runs[(size_t)r].lo), d = in_intervals(div, runs[(size_t)r].lo);
-      internal[(size_t)(2 + r)] = (int)((u ? L - 1u : 0u) + (d ? L - 1u : 0u));
-      cyc[(size_t)(2 + r)] = u && d;  // covered in both directions: its k-mers are one strong component
-      e_all += (uint64_t)internal[(size_t)(2 + r)];
-    }
-    if (r + 1 < R && runs[(size_t)r].hi + 1u == runs[(size_t)r + 1].lo) {  // the chain edge(s) into the next run
-      const uint32_t x = runs[(size_t)r].hi;
-      if (in_intervals(uiv, x)) ce.emplace_back(2 + r, 2 + r + 1);
-      if (in_intervals(div, x)) ce.emplace_back(2 + r + 1, 2 + r);
+  {
+    IntervalSweep su(uiv), sd(div);
+    for (int r = 0; r < R; r++) {
+      const uint32_t L = runs[(size_t)r].hi - runs[(size_t)r].lo + 1u;
+      if (L > 1u) {
+        const bool u = su.has(runs[(size_t)r].lo), d = sd.has(runs[(size_t)r].lo);
+        internal[(size_t)(2 + r)] = (int)((u ? L - 1u : 0u) + (d ? L - 1u : 0u));
+        cyc[(size_t)(2 + r)] = u && d;  // covered in both directions: its k-mers are one strong component
+        e_all += (uint64_t)internal[(size_t)(2 + r)];
+      }
+      if (r + 1 < R && runs[(size_t)r].hi + 1u == runs[(size_t)r + 1].lo) {  // the chain edge(s) into the next run
+        const uint32_t x = runs[(size_t)r].hi;
+        if (su.has(x)) ce.emplace_back(2 + r, 2 + r + 1);
+        if (sd.has(x)) ce.emplace_back(2 + r + 1, 2 + r);
+      }
     }
   }
-  for (uint64_t e : sp) {
-    const uint32_t a = (uint32_t)(e >> 32), b = (uint32_t)e;
-    if (a == b) { loops.push_back(node_of(a)); continue; }  // self loop (a homopolymer k-mer): never between components
-    ce.emplace_back(node_of(a), node_of(b));
+  {
+    // the other edges, in the order of their heads first: those that double a chain's own edge go (the
+    // de-duplication again), self loops (a homopolymer k-mer: never between components) are set aside, the
+    // head becomes its node; then in the order of their tails (stable: equal edges are neighbours), the tail likewise
+    radix_sort(sp.data(), sp.size(), kLo32);
+    IntervalSweep su(uiv), sd(div);
+    CutSweep cb{bp, bp_run};
+    size_t w = 0;
+    for (const uint64_t e : sp) {
+      const uint32_t a = (uint32_t)(e >> 32), b = (uint32_t)e;
+      if (b == a + 1u && su.has(a)) continue;
+      if (a == b + 1u && sd.has(b)) continue;
+      if (a == b) { loopk.push_back(a); continue; }
+      int rb = cb.at(b);
+      if (rb < 0) rb = node_search(b) - 2;
+      sp[w++] = ((uint64_t)a << 32) | (uint32_t)rb;
+    }
+    sp.resize(w);
+    radix_sort(sp.data(), sp.size(), kHi32);
+    CutSweep ca{bp, bp_run};
+    uint64_t prev = ~0ull;
+    for (const uint64_t e : sp) {
+      if (e == prev) continue;
+      prev = e;
+      const uint32_t a = (uint32_t)(e >> 32);
+      int ra = ca.at(a);
+      if (ra < 0) ra = node_search(a) - 2;
+      ce.emplace_back(2 + ra, 2 + (int)(uint32_t)e);
+    }
+    radix_sort(loopk.data(), loopk.size(), 0xFFFFFFFFu);
+    loopk.erase(std::unique(loopk.begin(), loopk.end()), loopk.end());
+    CutSweep cl{bp, bp_run};
+    for (const uint32_t x : loopk) { const int r = cl.at(x); loops.push_back(r < 0 ? node_search(x) : 2 + r); }
+    CutSweep cs{bp, bp_run};
+    for (const uint32_t x : srcs) { const int r = cs.at(x); ce.emplace_back(1, r < 0 ? node_search(x) : 2 + r); }
+    CutSweep ck{bp, bp_run};
+    for (const uint32_t x : sinks) { const int r = ck.at(x); ce.emplace_back(r < 0 ? node_search(x) : 2 + r, 0); }
   }
   e_all += (uint64_t)ce.size() + (uint64_t)loops.size();
+  lap();
   // ---- strong components of the node graph
   off.assign((size_t)NV + 1, 0);
   adj.resize(ce.size());
   for (auto& ed : ce) off[(size_t)ed.first + 1]++;
   for (int i = 0; i < NV; i++) off[(size_t)i + 1] += off[(size_t)i];
   {
-    std::vector<int> pos(off.begin(), off.end() - 1);
+    pos.assign(off.begin(), off.end() - 1);
     for (auto& ed : ce) adj[(size_t)pos[(size_t)ed.first]++] = ed.second;
   }
+  lap();
   const int nc = strong_components(NV, off, adj, &comp);
+  lap();
   cnodes.assign((size_t)nc, 0);
   cweight.assign((size_t)nc, 0);
   nontriv.assign((size_t)nc, 0);
@@ -788,7 +876,7 @@ void seg_analyze_runs(const FillParams& p, const SubView& v, SubPrep* out, const
   for (int c = 0; c < nc; c++) foff[(size_t)c + 1] += foff[(size_t)c];
   fadj.resize(foff[(size_t)nc]);
   {
-    std::vector<int> pos(foff.begin(), foff.end() - 1);
+    pos.assign(foff.begin(), foff.end() - 1);
     for (auto& ed : ce) {
       const int a = comp[(size_t)ed.first], b = comp[(size_t)ed.second];
       if (a != b) fadj[(size_t)pos[(size_t)a]++] = b;
@@ -817,6 +905,7 @@ void seg_analyze_runs(const FillParams& p, const SubView& v, SubPrep* out, const
   }
   out->sink_safe = !nontriv[(size_t)comp[0]] && fbranch[(size_t)comp[0]] == 1;
   out->run_mode = true;
+  lap();
 }
 
 }  // namespace
@@ -912,7 +1001,8 @@ bool seg_analyze(const FillParams& p, const GapJob& job, const SubView& v, SubPr
     if (sinkpos[i] >= 0 && sinkpos[i] <= ts) { sink_in++; edges++; count_s = sat_add(count_s, (int)s.cnt); }
   }
   out->n_iv = niv;
-  std::sort(iv, iv + niv);
+  static_assert(sizeof(iv[0]) == 8, "interval records are (first index, segment) words");
+  radix_sort((uint64_t*)iv, (size_t)niv, kLo32);  // by first index (the low word); equal ones stay in segment order
   for (size_t x = 1; x < niv; x++) {
     const SegRec& a = sg[iv[x - 1].second];
     const uint32_t a_hi = iv[x - 1].first + (uint32_t)seg_ts(a);

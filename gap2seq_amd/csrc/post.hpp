@@ -186,4 +186,7 @@ struct HostTable {
 void host_closure(const Graph& g, const FillParams& p, const GapJob& job, const HostTable& t, const GapOut& go,
                   std::vector<SubState>* out, uint32_t* q7);
 
+// (G2S_DEBUG) time stamps of the last seg_analyze_runs on this thread, microseconds
+extern thread_local double g2s_post_laps[12];
+
 }  // namespace g2s
