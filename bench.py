@@ -158,17 +158,19 @@ class Runner:
 
 
 class StreamRunner:
-    """K consecutive lists on one session, two in flight (g2s_fill_begin / g2s_fill_end): list i+1 is begun — its
-    look-ups and fill kernel queued — before list i is ended, so they run while list i's phase D3 writes its results
-    through the link.  The product's steady state (Gap2Seq-core -stream-gaps) is such a sequence of lists."""
+    """K consecutive lists on one session, `depth` in flight (g2s_fill_begin / g2s_fill_end): list i+depth-1 is begun —
+    its kernels queued — before list i is ended, so they run while list i's phase D3 writes its results through the
+    link and the host prepares the next list.  The product's steady state (Gap2Seq-core -stream-gaps) is such a
+    sequence of lists."""
 
-    def __init__(self, P, session, gaps, nlists, pinned=True):
+    def __init__(self, P, session, gaps, nlists, pinned=True, depth=3):
         self.P, self.lib, self.s, self.k = P, P.load_library(), session, nlists
+        self.depth = max(2, min(depth, P.G2S_MAX_IN_FLIGHT))
         self.n = len(gaps)
         self.arr, self._keep = P._gap_array([P.Gap(g["left"], g["right"], g["gap_len"], g["lmf"], g["rmf"]) for g in gaps])
         self.nbytes = self.lib.g2s_team_arena_bytes(session.h, self.arr, self.n)
         self.sets = []
-        for _ in range(2):  # (a list's buffers are free again when the list after the next begins)
+        for _ in range(self.depth):  # (a list's buffers are free again once it has ended)
             if pinned:
                 a, r = P.HostBuffer(max(1, self.nbytes)), P.HostBuffer(C.sizeof(P.g2s_result) * max(1, self.n))
                 self.sets.append((a, r, C.cast(a.p, C.c_void_p), r.array(P.g2s_result, max(1, self.n))))
@@ -187,22 +189,26 @@ class StreamRunner:
         out = []
         t0 = time.perf_counter()
         if overlapped:
+            D, ended = self.depth, 0
             for i in range(self.k):
-                _, _, ap, res = self.sets[i & 1]
+                _, _, ap, res = self.sets[i % D]
                 self.P._check(self.lib.g2s_fill_begin(self.s.h, self.arr, self.n, res, ap, self.nbytes))
-                if i >= 1:
+                if i >= D - 1:
                     self.P._check(self.lib.g2s_fill_end(self.s.h))
                     if keep:
-                        out.append(self._keys((i - 1) & 1))
-            self.P._check(self.lib.g2s_fill_end(self.s.h))
-            if keep:
-                out.append(self._keys((self.k - 1) & 1))
+                        out.append(self._keys(ended % D))
+                    ended += 1
+            while ended < self.k:
+                self.P._check(self.lib.g2s_fill_end(self.s.h))
+                if keep:
+                    out.append(self._keys(ended % D))
+                ended += 1
         else:
             for i in range(self.k):
-                _, _, ap, res = self.sets[i & 1]
+                _, _, ap, res = self.sets[i % self.depth]
                 self.P._check(self.lib.g2s_fill_batch(self.s.h, self.arr, self.n, res, C.cast(ap, C.c_char_p), self.nbytes))
                 if keep:
-                    out.append(self._keys(i & 1))
+                    out.append(self._keys(i % self.depth))
         return time.perf_counter() - t0, out
 
     def free(self):
@@ -250,6 +256,7 @@ def main():
     ap.add_argument("--weak", action="store_true",
                     help="N>1: weak scaling — the workload's gap count PER GPU (config 3: 10 000 each) instead of one list "
                          "for all of them")
+    ap.add_argument("--in-flight", type=int, default=3, help="--stream-lists: lists begun and not ended (2 or 3)")
     ap.add_argument("--stream-lists", type=int, default=0,
                     help="N=1: also measure K consecutive lists of the workload with two in flight (g2s_fill_begin / "
                          "g2s_fill_end) against the same K lists one at a time; reported as `stream_lists`")
@@ -443,7 +450,7 @@ def main():
     # ---- N=1: K consecutive lists, two in flight, against the same lists one at a time ---------------
     stream_lists = None
     if ngpu == 1 and len(sessions) == 1 and args.stream_lists >= 2:
-        sr = StreamRunner(P, sessions[0], gaps, args.stream_lists, not args.pageable_buffers)
+        sr = StreamRunner(P, sessions[0], gaps, args.stream_lists, not args.pageable_buffers, args.in_flight)
         _, want = sr.run(False, keep=True)
         _, got = sr.run(True, keep=True)
         if got != want:
@@ -456,7 +463,7 @@ def main():
             sr.run(False)
         t_seq = sum(sr.run(False)[0] for _ in range(reps))
         tot = float(len(gaps) * args.stream_lists * reps)
-        stream_lists = dict(lists=args.stream_lists, gaps_per_list=len(gaps), repetitions=reps,
+        stream_lists = dict(lists=args.stream_lists, in_flight=sr.depth, gaps_per_list=len(gaps), repetitions=reps,
                             value=round(tot / t_ov, 2), unit="gaps/s", ms_per_list=round(t_ov / (args.stream_lists * reps) * 1e3, 4),
                             one_list_at_a_time=round(tot / t_seq, 2), ms_per_list_one_at_a_time=round(t_seq / (args.stream_lists * reps) * 1e3, 4),
                             results="identical to the lists one at a time, list by list (checked in this run)",

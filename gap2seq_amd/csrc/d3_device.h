@@ -116,6 +116,9 @@ struct D3Work {
   uint32_t* btab = nullptr;     // [G2S_D3_TABLE_BUDGET / 4] deviation behind a block by deviation in front of it
   D3Summary* sum = nullptr;
   unsigned long long* fill_bytes = nullptr;  // 64 counters, 16 words apart, right behind the summary's 1024 bytes
+  // (not carved: the caller's) 32 words that outlive the list's summary: the generator's state behind the list's last
+  // draw, for the next list's stream when that list is queued before this one has ended (g2s_fill_begin); may be null
+  uint32_t* link = nullptr;
 };
 size_t d3_work_bytes(uint32_t n);
 void d3_work_carve(void* p, uint32_t n, D3Work* w);
@@ -172,6 +175,9 @@ hipError_t launch_d3_sharded_trace(hipStream_t st, const D3Params& P, const D3Wo
                                    const char* lastch_up, const char* lastch_dn, uint32_t* rnd_all, uint64_t rnd_capacity,
                                    void* results, char* arena, const D3Side& side, void* summary_host);
 
+// the first G2S_RAND_WINDOW words of a stream from the 31 words of state another list's kernels left (D3Work.link)
+hipError_t launch_rand_window(hipStream_t st, uint32_t* rnd_all, const uint32_t* link);
+
 hipError_t launch_d3(hipStream_t st, const D3Params& P, const D3Work& W, const GapDev* gaps, const GapOut* outs,
                      const D3Gap* dgaps, const SubRec* sub, const char* lastch_up, const char* lastch_dn,
                      const RandTables& rt, uint32_t* rnd_all /* [31 + capacity]: first G2S_RAND_WINDOW words set */,
@@ -179,6 +185,7 @@ hipError_t launch_d3(hipStream_t st, const D3Params& P, const D3Work& W, const G
                      char* arena /* device-writable */, const D3Side& side /* *side.count: ~0 until the hand-over is complete */,
                      void* summary_host /* device-visible pinned memory: D3Summary in 1024 bytes, then the 64 fill-byte counters */,
                      bool summary_is_clean /* the summary and the counters are zero already */,
-                     uint32_t* clean_words /* with P.self_clean: eight words the last wave zeroes (the fill kernel's cursors); may be null */);
+                     uint32_t* clean_words /* with P.self_clean: eight words the last wave zeroes (the fill kernel's cursors); may be null */,
+                     hipEvent_t ev_chain = nullptr /* recorded behind the kernel that knows the list's draws (W.link is written) */);
 
 }  // namespace g2s

@@ -457,6 +457,19 @@ __global__ __launch_bounds__(1024) void g2s_d3_scan(const D3Params P, const D3Wo
 // the rand() stream.  W[0 .. 31) is the generator's state in front of the next value, W[31 + k] the k-th value
 // the session will draw (raw words: rand() returns word >> 1).  The host hands over W[0 .. G2S_RAND_WINDOW).
 // ---------------------------------------------------------------------------------------------------------
+// The window of a stream that continues another list's: W[0 .. 31) = the state that list's kernels left behind its
+// last draw, W[31 + i] = W[i] + W[28 + i] (glibc TYPE_3: r[i] = r[i-31] + r[i-3]) — three values a step.
+__global__ __launch_bounds__(64) void g2s_rand_window(uint32_t* __restrict__ Wd, const uint32_t* __restrict__ link) {
+  __shared__ uint32_t w[G2S_RAND_WINDOW + 2];
+  const uint32_t lane = threadIdx.x;
+  if (lane < 31u) w[lane] = link[lane];
+  __syncthreads();
+  for (uint32_t i = 31u; i < G2S_RAND_WINDOW; i += 3u) {
+    if (lane < 3u) w[i + lane] = w[i + lane - 31u] + w[i + lane - 3u];
+    __syncthreads();
+  }
+  for (uint32_t i = lane; i < G2S_RAND_WINDOW; i += 64u) Wd[i] = w[i];
+}
 __global__ __launch_bounds__(64) void g2s_rand_fill(uint32_t* __restrict__ Wd, const g2s::RandTables rt, const D3Summary* sum,
                                                     uint64_t capacity, uint64_t first_block) {
   __shared__ uint32_t base[G2S_RAND_WINDOW], s1[96], s2[64];
@@ -685,7 +698,11 @@ __device__ __forceinline__ void d3_chain_body(const D3Work& W, const uint32_t* _
   }
   const uint64_t total = (uint64_t)base0 + S->draws_min + *total_dev;  // (draws of the list up to the end of this group)
   if (threadIdx.x == 0) S->draws_total = total;
-  if (threadIdx.x < 31u) S->rand_state[threadIdx.x] = Wd[total + threadIdx.x];
+  if (threadIdx.x < 31u) {
+    const uint32_t w = Wd[total + threadIdx.x];
+    S->rand_state[threadIdx.x] = w;
+    if (W.link) W.link[threadIdx.x] = w;
+  }
 }
 __global__ __launch_bounds__(1024) void g2s_d3_chain(const D3Work W, const uint32_t* __restrict__ Wd, uint32_t base0, uint32_t d_in) {
   __shared__ uint32_t total_dev;
@@ -847,7 +864,11 @@ __global__ __launch_bounds__(1024) void g2s_d3_back(const D3Params P, const D3Wo
     if (threadIdx.x <= V) W.dvar[threadIdx.x] = ldvar[threadIdx.x];
     const uint64_t total = S->draws_min + total_dev;
     if (threadIdx.x == 0) S->draws_total = total;
-    if (threadIdx.x < 31u) S->rand_state[threadIdx.x] = Wd[total + threadIdx.x];
+    if (threadIdx.x < 31u) {
+      const uint32_t w = Wd[total + threadIdx.x];
+      S->rand_state[threadIdx.x] = w;
+      if (W.link) W.link[threadIdx.x] = w;
+    }
   } else {
     d3_blocks_body(W, threadIdx.x, 1024u);
     __threadfence();
@@ -1285,6 +1306,11 @@ hipError_t launch_rand_fill(hipStream_t st, uint32_t* rnd_all, const RandTables&
   return hipGetLastError();
 }
 
+hipError_t launch_rand_window(hipStream_t st, uint32_t* rnd_all, const uint32_t* link) {
+  hipLaunchKernelGGL(g2s_rand_window, dim3(1), dim3(64), 0, st, rnd_all, link);
+  return hipGetLastError();
+}
+
 hipError_t launch_d3_sharded_classes(hipStream_t st, const D3Params& P, const D3Work& W, const GapOut* outs, const D3Gap* dgaps,
                                      bool summary_is_clean) {
   if (P.n == 0) return hipSuccess;
@@ -1324,7 +1350,7 @@ hipError_t launch_d3_sharded_trace(hipStream_t st, const D3Params& P, const D3Wo
 hipError_t launch_d3(hipStream_t st, const D3Params& P, const D3Work& W, const GapDev* gaps, const GapOut* outs,
                      const D3Gap* dgaps, const SubRec* sub, const char* lastch_up, const char* lastch_dn,
                      const RandTables& rt, uint32_t* rnd_all, uint64_t rnd_capacity, void* results, char* arena,
-                     const D3Side& side, void* summary_host, bool summary_is_clean, uint32_t* clean_words) {
+                     const D3Side& side, void* summary_host, bool summary_is_clean, uint32_t* clean_words, hipEvent_t ev_chain) {
   if (P.n == 0) return hipSuccess;
   (void)gaps;
   (void)rt;
@@ -1345,10 +1371,13 @@ hipError_t launch_d3(hipStream_t st, const D3Params& P, const D3Work& W, const G
   e = hipFuncSetAttribute((const void*)g2s_d3_tables, hipFuncAttributeMaxDynamicSharedMemorySize, (int)win);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(g2s_d3_tables, dim3(tgrid), dim3(256), win, st, P, W, sub, rnd_all + 31, rnd_capacity);
-  if (short_list) hipLaunchKernelGGL(g2s_d3_back, dim3(1), dim3(1024), 0, st, P, W, outs, sub, rnd_all, rnd_capacity, side);
-  else {
+  if (short_list) {
+    hipLaunchKernelGGL(g2s_d3_back, dim3(1), dim3(1024), 0, st, P, W, outs, sub, rnd_all, rnd_capacity, side);
+    if (ev_chain) { e = hipEventRecord(ev_chain, st); if (e != hipSuccess) return e; }
+  } else {
     hipLaunchKernelGGL(g2s_d3_blocks, dim3(256), dim3(256), 0, st, W);
     hipLaunchKernelGGL(g2s_d3_chain, dim3(1), dim3(1024), 0, st, W, rnd_all, 0u, 0u);
+    if (ev_chain) { e = hipEventRecord(ev_chain, st); if (e != hipSuccess) return e; }
     hipLaunchKernelGGL(g2s_d3_handoff, dim3((P.n + 63u) / 64u), dim3(64), 0, st, P, W, outs, sub, rnd_all + 31, rnd_capacity, side);
   }
   const size_t lds = (size_t)P.seg_cap * (sizeof(SegRec) + 16) + (size_t)P.map_cap * 8 + 16;  // closure, base map, rand() values, the walk's segments

@@ -587,15 +587,21 @@ struct g2s_session {
   // parameters.
   int segw_quiet = 0;
   hipEvent_t ev_segw = nullptr;  // behind the large variant's launch (timed launches)
-  // g2s_fill_begin / g2s_fill_end: up to two lists in flight, alternating between this session and a twin on the same
-  // device (own stream and buffers; created on first use).  The rand() stream is this session's: a list that ends on
-  // the twin borrows it.
-  g2s_session* twin = nullptr;
+  // g2s_fill_begin / g2s_fill_end: up to G2S_MAX_IN_FLIGHT lists in flight, each on this session or a twin of it on the
+  // same device (own streams and buffers; created on first use).  The rand() stream is this session's: a list that
+  // ends on a twin borrows it.
+  g2s_session* twins[G2S_MAX_IN_FLIGHT - 1] = {};
+  // (lists in flight) the generator's state behind the last draw of the list whose phase D3 ran here last, in device
+  // memory (D3Work.link), and the event behind the kernel that writes it: the next list's stream starts from it
+  // without the host in between
+  DevBuf d_link;
+  hipEvent_t ev_chain = nullptr;
   void* d3_pending = nullptr;  // (D3Pending) phase D3 of a list queued on this session's stream and not waited for yet
   struct InFlight { g2s_batch* b = nullptr; g2s_session* on = nullptr; g2s_result* results = nullptr; char* arena = nullptr; size_t cap = 0;
                     const g2s_gap* gaps = nullptr; size_t n = 0; double ms_prepare = 0;
-                    bool d3_queued = false; };
-  InFlight inflight[2];
+                    bool d3_queued = false;
+                    bool chained = false; };  // its rand() stream continues the older list's on the device
+  InFlight inflight[G2S_MAX_IN_FLIGHT];
   int n_inflight = 0;
   uint64_t begun = 0;
   bool resident_off = false;
@@ -664,6 +670,8 @@ extern "C" int g2s_session_create(g2s_graph* g, int device, const g2s_params* p,
   if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_rand, hipEventDisableTiming);
   for (int i = 0; i < 5 && e == hipSuccess; i++) e = hipEventCreate(&s->ev[i]);
   if (e == hipSuccess) e = hipEventCreate(&s->ev_segw);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_chain, hipEventDisableTiming);
+  if (e == hipSuccess) e = s->d_link.ensure(32 * 4);
   size_t free_b = 0, total_b = 0;
   if (e == hipSuccess) e = hipMemGetInfo(&free_b, &total_b);
   if (e != hipSuccess) { delete s; return fail(G2S_ERR_HIP, std::string("session setup: ") + hipGetErrorString(e)); }
@@ -687,7 +695,7 @@ extern "C" void g2s_session_destroy(g2s_session* s) {
     g2s_batch_free(s->inflight[q].b);
   }
   s->n_inflight = 0;
-  if (s->twin) { g2s_session_destroy(s->twin); s->twin = nullptr; }
+  for (g2s_session*& t : s->twins) if (t) { g2s_session_destroy(t); t = nullptr; }
   (void)hipSetDevice(s->device);
   DevBuf* bufs[] = {&s->d_gaps, &s->d_ids, &s->d_flank, &s->d_outs, &s->d_rs, &s->d_rlog, &s->d_keys,
                     &s->d_cnt, &s->d_mark, &s->d_slog, &s->d_subscr, &s->d_subout, &s->d_counter, &s->d_xcd,
@@ -705,6 +713,8 @@ extern "C" void g2s_session_destroy(g2s_session* s) {
   s->h_d3.release(); s->h_res.release(); s->h_text.release(); s->h_side.release(); s->h_gfn.release();
   if (s->ev_rand) (void)hipEventDestroy(s->ev_rand);
   if (s->ev_segw) (void)hipEventDestroy(s->ev_segw);
+  if (s->ev_chain) (void)hipEventDestroy(s->ev_chain);
+  s->d_link.release();
   if (s->stream2) (void)hipStreamDestroy(s->stream2);
   if (s->stream) (void)hipStreamDestroy(s->stream);
   delete s;
@@ -745,6 +755,7 @@ struct g2s_batch {
   // with phase D3
   bool pre_launched = false, pre_two = false, pre_timed = false, pre_segw = false;
   bool d3_queued = false;  // ...and its phase D3 too (resident_queue_d3): g2s_batch_run only waits
+  bool chain_broken = false;  // ...from the device state of a list in front of it which then did not end on the device
   uint64_t pre_units = 0;
   int upload_flanks();
   size_t arena_bytes = 0;
@@ -2692,12 +2703,21 @@ struct ResidentList {
 // host, then g2s_rand_fill.  Called in front of the fill kernel's launch when the list is one batch (the stream then
 // fills while the look-ups run and the host prepares the launch: beside the fill kernel it cost that kernel 4 %).
 static size_t rand_capacity(size_t list_cap) { return (list_cap + 2 * G2S_RAND_BLOCK) & ~(size_t)(G2S_RAND_BLOCK - 1); }
-static int resident_rand(g2s_session* s, PinBuf* pin, size_t n, size_t list_cap) {
+// (chain_from: the session on which the list in front of this one has its phase D3 queued — the stream continues
+// from the state that list's kernels leave in device memory, behind the event that says it is there; null: from
+// the host's generator, which stands at this list's first draw when every list in front of it has ended)
+static int resident_rand(g2s_session* s, PinBuf* pin, size_t n, size_t list_cap, g2s_session* chain_from = nullptr) {
   if (hipSetDevice(s->device) != hipSuccess) return fail(G2S_ERR_NO_DEVICE, "cannot select device");
   const size_t rnd_cap = rand_capacity(list_cap);
   char* hsum = (char*)pin->p + n * sizeof(D3Gap) + 16 - (n * sizeof(D3Gap)) % 16;
   uint32_t* hwin = (uint32_t*)(hsum + 1024 + 64 * 128);  // (summary, the trace kernel's 64 fill-byte counters, the window)
   HIP_TRY(s->d_rnd.ensure((31 + rnd_cap + 64) * 4));
+  if (chain_from) {
+    HIP_TRY(hipStreamWaitEvent(s->stream2, chain_from->ev_chain, 0));
+    HIP_TRY(launch_rand_window(s->stream2, (uint32_t*)s->d_rnd.p, (const uint32_t*)chain_from->d_link.p));
+    HIP_TRY(launch_rand_fill(s->stream2, (uint32_t*)s->d_rnd.p, s->rtab, nullptr, (uint64_t)rnd_cap));
+    return G2S_OK;
+  }
   memcpy(hwin, s->rcache.window(G2S_RAND_WINDOW), G2S_RAND_WINDOW * 4);
   HIP_TRY(hipMemcpyAsync(s->d_rnd.p, hwin, G2S_RAND_WINDOW * 4, hipMemcpyHostToDevice, s->stream2));
   HIP_TRY(launch_rand_fill(s->stream2, (uint32_t*)s->d_rnd.p, s->rtab, nullptr, (uint64_t)rnd_cap));
@@ -2708,6 +2728,7 @@ static int resident_rand(g2s_session* s, PinBuf* pin, size_t n, size_t list_cap)
 struct D3Pending {
   ResidentList L;
   bool timed = false, res_direct = false, arena_direct = false, stage_dev = false, self_clean = false;
+  bool discard = false;  // (its stream continued a list that did not end on the device: nothing of it counts)
   D3Side side_h;
   D3Work W;
   D3Summary* hsum = nullptr;
@@ -2730,7 +2751,8 @@ struct D3Pending {
 // first half: everything of phase D3 queued on the session's stream(s), nothing waited for (no_spin: not even the
 // few microseconds for the rand() stream's kernel — the main stream waits for its event instead)
 static int resident_d3_launch(g2s_session* s, const ResidentList& L, bool timed, bool rand_launched, g2s_result* results, char* arena,
-                              bool no_spin, bool sharded = false /* the first step only: classes and the group's totals */) {
+                              bool no_spin, bool sharded = false /* the first step only: classes and the group's totals */,
+                              g2s_session* chain_from = nullptr /* resident_rand */) {
   const size_t n = L.n;
   const Graph& g = *s->graph->g;
   const FillParams fp = fill_params_of(s);
@@ -2775,6 +2797,7 @@ static int resident_d3_launch(g2s_session* s, const ResidentList& L, bool timed,
   }
   D3Work W;
   d3_work_carve(s->d_d3.p, (uint32_t)n, &W);
+  W.link = sharded ? nullptr : (uint32_t*)s->d_link.p;
   // where the kernels write results and text: the caller's buffers when those are pinned, staging otherwise
   void *res_dev = nullptr, *arena_dev = nullptr;
   // (G2S_D3_STAGE=device, measurements only: the kernels write device memory, two copies bring it to the caller)
@@ -2801,7 +2824,7 @@ static int resident_d3_launch(g2s_session* s, const ResidentList& L, bool timed,
   HIP_TRY(hipHostGetDevicePointer(&d_dgaps, L.pin->p, 0));
   // the rand() values the list can draw (a team's list: generated here, beside the copies of the groups' records;
   // a group of a sharded list: in its second step, when its place in the stream is known)
-  if (!rand_launched && !sharded) { const int rc = resident_rand(s, L.pin, n, L.rnd_cap); if (rc != G2S_OK) return rc; }
+  if (!rand_launched && !sharded) { const int rc = resident_rand(s, L.pin, n, L.rnd_cap, chain_from); if (rc != G2S_OK) return rc; }
   // (the per-gap descriptors of phase D3 of a short list go to device memory behind it: read over the link by the
   // list's single classify workgroup they were 3 us of its 8; a long list's are read by 40 workgroups at once, and a
   // 160 KB copy beside the fill kernel cost that kernel 4 %)
@@ -2854,7 +2877,8 @@ static int resident_d3_launch(g2s_session* s, const ResidentList& L, bool timed,
   HIP_TRY(launch_d3(st, P, W, L.gaps_dev, L.outs_dev, dgap_on_device ? (const D3Gap*)s->d_dgap.p : (const D3Gap*)d_dgaps, L.sub_dev,
                     (const char*)s->d_lastch.p, (const char*)s->d_lastch.p + g.n, s->rtab, (uint32_t*)s->d_rnd.p,
                     (uint64_t)rnd_cap, res_dev, (char*)arena_dev, side, (char*)d_dgaps + ((char*)hsum - (char*)L.pin->p),
-                    s->d_d3.clean >= 1024 + 64 * 128, self_clean ? (uint32_t*)s->d_counter.p : nullptr));
+                    s->d_d3.clean >= 1024 + 64 * 128, self_clean ? (uint32_t*)s->d_counter.p : nullptr,
+                    no_spin ? s->ev_chain : nullptr /* (lists in flight: the next one's stream may wait for it) */));
   s->d_d3.clean = 0;
   if (timed && !sharded) HIP_TRY(hipEventRecord(s->ev[3], st));
   if (stage_dev && !sharded) {
@@ -2947,6 +2971,16 @@ static int resident_d3_wait(g2s_session* s, g2s_timing* tm_out, double* ms_d3_ou
   // (the hand-off kernel says so in pinned memory; an event between it and the trace kernel cost the stream 9 us.
   // Should the kernels end without saying so — never expected — the stream's end is noticed instead.)
   unsigned long long handed = ~0ull;
+  if (dpp->discard) {  // (nothing of this attempt counts: its kernels drew from a stream that was not the list's)
+    HIP_TRY(hipStreamSynchronize(st));
+    if (!self_clean) HIP_TRY(hipMemsetAsync(W.sum, 0, 1024 + 64 * 128, st));
+    s->d_d3.clean = 1024 + 64 * 128;
+    s->self_cleaned = self_clean && hsum->status == 0;
+    s->side_dirty = SIZE_MAX;
+    *ms_d3_out = 0;
+    *fell_back = true;
+    return G2S_OK;
+  }
   for (unsigned spins = 0;; spins++) {
     handed = __atomic_load_n(side_h.count, __ATOMIC_ACQUIRE);
     if (handed != ~0ull) break;
@@ -3032,7 +3066,17 @@ static int resident_d3_wait(g2s_session* s, g2s_timing* tm_out, double* ms_d3_ou
   for (int q = 0; q < 64; q++)  // (bits 40 and up count the trace kernel's waves: d3_device.hip)
     hsum->fill_bytes += ((const unsigned long long*)((const char*)hsum + 1024))[q * 16] & ((1ull << 40) - 1);
   hsum->fill_bytes += host_fill_bytes;
-  const bool test_fallback = getenv("G2S_RESIDENT_TEST_FALLBACK") != nullptr;  // (tests: the attempt is discarded)
+  // (tests: the attempt is discarded — every one, or with "rel:K" only the K-th wait since that value was first seen)
+  bool test_fallback = false;
+  if (const char* tf = getenv("G2S_RESIDENT_TEST_FALLBACK")) {
+    static std::mutex mu;
+    static std::string seen;
+    static int waits = 0;
+    std::lock_guard<std::mutex> lk(mu);
+    if (seen != tf) { seen = tf; waits = 0; }
+    const int mine = waits++;
+    test_fallback = strncmp(tf, "rel:", 4) != 0 || mine == atoi(tf + 4);
+  }
   if (stage_dev && hsum->host_items) hsum->anomalies++;  // (the measurement switch has no path for host-finished gaps)
   if (hsum->status != 0 || hsum->anomalies != 0 || test_fallback || host_bad.load() || hsum->host_items != ni) {
     if (getenv("G2S_DEBUG"))
@@ -3098,7 +3142,8 @@ static int resident_d3(g2s_session* s, const ResidentList& L, bool timed, bool r
 // One batch on one session.  Returns G2S_OK (done), 1 (not applicable / fall back to the host path), or an error.
 // (in two halves for lists in flight — g2s_fill_begin / g2s_fill_end: `queue` puts the list's kernels on the stream,
 // phase D3 included, without waiting for anything; `finish` waits and reads the summary)
-static int run_resident_queue(g2s_batch* b, g2s_result* results, char* arena, bool no_spin, ResidentLaunch* rl_out) {
+static int run_resident_queue(g2s_batch* b, g2s_result* results, char* arena, bool no_spin, ResidentLaunch* rl_out,
+                              g2s_session* chain_from = nullptr) {
   g2s_session* s = b->s;
   const size_t n = b->jobs.size();
   ResidentLaunch& rl = *rl_out;
@@ -3139,7 +3184,7 @@ static int run_resident_queue(g2s_batch* b, g2s_result* results, char* arena, bo
     for (size_t i = 0; i < n; i++) dq[i].arena_off += (uint64_t)b->arena_base;
     s->desc_owner = nullptr;
   }
-  return resident_d3_launch(s, L, rl.timed, rand_launched, results, arena, no_spin);
+  return resident_d3_launch(s, L, rl.timed, rand_launched, results, arena, no_spin, false, chain_from);
 }
 static int run_resident_finish(g2s_batch* b, const ResidentLaunch& rl, std::chrono::steady_clock::time_point t_enter) {
   g2s_session* s = b->s;
@@ -3171,7 +3216,14 @@ int run_resident(g2s_batch* b, g2s_result* results, char* arena) {
   if (b->d3_queued) {  // (g2s_fill_begin queued everything already)
     b->d3_queued = false;
     rl.units = b->pre_units; rl.two_waves = b->pre_two; rl.timed = b->pre_timed; rl.segw = b->pre_segw; rl.launched = b->n_valid;
-    return run_resident_finish(b, rl, t_enter);
+    if (!b->chain_broken) return run_resident_finish(b, rl, t_enter);
+    // Its rand() stream was to continue, on the device, that of a list which then did not end there: the kernels
+    // are waited for, what they wrote is dropped, and the list runs again from the host's generator.
+    b->chain_broken = false;
+    if (b->s->d3_pending) ((D3Pending*)b->s->d3_pending)->discard = true;
+    const int rc = run_resident_finish(b, rl, t_enter);
+    if (rc < 0) return rc;
+    b->timing.resident_fallbacks = 0;  // (not a list the mode gave up on)
   }
   const int rc = run_resident_queue(b, results, arena, false, &rl);
   if (rc != G2S_OK) return rc;
@@ -3822,41 +3874,69 @@ extern "C" int g2s_fill_batch(g2s_session* s, const g2s_gap* gaps, size_t n, g2s
   return rc;
 }
 
-// ---- two lists in flight (Gap2Seq-core -stream-gaps, bench.py --stream-lists): the product's steady state is a
+// ---- lists in flight (Gap2Seq-core -stream-gaps, bench.py --stream-lists): the product's steady state is a
 // SEQUENCE of lists, and a list's step is a chain — preparation, look-ups, fill kernel, phase D3, of which the last
-// writes the results through the link.  g2s_fill_begin queues everything up to the fill kernel and returns;
-// g2s_fill_end finishes the oldest list begun.  With a second list begun before the first is ended, its look-ups and
-// fill kernel run on the device while the first one's phase D3 writes through the link.  The lists alternate
-// between the session and a twin of it on the same device; the rand() stream is the session's, handed to
-// whichever of the two ends a list, so the results are those of g2s_fill_batch called list by list.
-extern "C" int g2s_fill_begin(g2s_session* s, const g2s_gap* gaps, size_t n, g2s_result* results, char* fill_arena, size_t arena_cap) {
-  if (!s || (!gaps && n) || (!results && n)) return fail(G2S_ERR_ARG, "g2s_fill_begin: bad argument");
-  if (s->n_inflight >= 2) return fail(G2S_ERR_ARG, "g2s_fill_begin: two lists are in flight already (g2s_fill_end first)");
-  // The list in flight (begun before this one, all lists before it ended: the rand() stream stands where it starts)
-  // gets its phase D3 queued now, behind its fill kernel: it then runs while this call prepares the new list, whose
-  // look-ups and fill kernel in turn run while that phase D3 writes through the link.
-  if (s->n_inflight == 1 && s->inflight[0].b && s->inflight[0].b->pre_launched && !s->inflight[0].b->d3_queued) {
-    g2s_session::InFlight& o = s->inflight[0];
-    g2s_session* on = o.on;
+// writes the results through the link.  g2s_fill_begin queues all of it and returns; g2s_fill_end finishes the oldest
+// list begun.  With further lists begun before the first is ended, their look-ups and fill kernels run on the device
+// while the older ones' phase D3 writes through the link, and the host prepares the next list meanwhile.  The lists
+// take turns on the session and two twins of it on the same device (own streams and buffers); the rand() stream is the
+// session's: on the host it is handed to whichever session ends a list; on the device a list's stream is generated
+// from the state the list in front of it leaves in device memory (D3Work.link), so that the host is not in the chain
+// from one list's draws to the next one's.  The results are those of g2s_fill_batch called list by list.
+namespace {
+// Phase D3 of every list in flight that can have it now, oldest first.  The oldest list's stream starts where the
+// host's generator stands (every list in front of it has ended); a list behind one whose phase D3 is queued
+// continues that one's stream on the device.  A list behind one that is to run again, or that is not on the device
+// at all, waits for it to end.
+int inflight_settle(g2s_session* s) {
+  static const bool no_chain = getenv("G2S_NO_DEVICE_CHAIN") != nullptr;
+  for (int i = 0; i < s->n_inflight; i++) {
+    g2s_session::InFlight& f = s->inflight[i];
+    if (!f.b) break;  // (a list for g2s_fill_batch: it draws on the host, when it is ended)
+    if (f.b->d3_queued) continue;
+    if (!f.b->pre_launched) break;  // (not a list for resident mode: the host path, when it is ended)
+    g2s_session* chain_from = nullptr;
+    if (i > 0) {
+      const g2s_session::InFlight& o = s->inflight[i - 1];
+      if (no_chain || !o.b || !o.b->d3_queued || o.b->chain_broken) break;
+      chain_from = o.on;
+    }
+    g2s_session* on = f.on;
     if (on != s) on->rcache.swap(s->rcache);
     ResidentLaunch rl;
-    const int rc = run_resident_queue(o.b, o.results, o.arena, true, &rl);
+    const int rc = run_resident_queue(f.b, f.results, f.arena, true, &rl, chain_from);
     if (on != s) on->rcache.swap(s->rcache);
     if (rc < 0) return rc;
-    if (rc == G2S_OK) { o.b->d3_queued = true; o.b->pre_units = rl.units; o.b->pre_two = rl.two_waves; o.b->pre_timed = rl.timed; o.b->pre_segw = rl.segw; }
+    if (rc != G2S_OK) break;  // (its fill kernel ran for nothing: the host path when it is ended)
+    f.b->d3_queued = true; f.b->pre_units = rl.units; f.b->pre_two = rl.two_waves; f.b->pre_timed = rl.timed; f.b->pre_segw = rl.segw;
+    f.chained = chain_from != nullptr;
   }
+  return G2S_OK;
+}
+}  // namespace
+
+extern "C" int g2s_fill_begin(g2s_session* s, const g2s_gap* gaps, size_t n, g2s_result* results, char* fill_arena, size_t arena_cap) {
+  if (!s || (!gaps && n) || (!results && n)) return fail(G2S_ERR_ARG, "g2s_fill_begin: bad argument");
+  if (s->n_inflight >= G2S_MAX_IN_FLIGHT) return fail(G2S_ERR_ARG, "g2s_fill_begin: G2S_MAX_IN_FLIGHT lists are in flight already (g2s_fill_end first)");
   g2s_session::InFlight f;
   f.results = results; f.arena = fill_arena; f.cap = arena_cap; f.gaps = gaps; f.n = n;
   const size_t group = s->team_group ? s->team_group : (s->helpers.empty() ? (size_t)16384 : (size_t)2048);
   if (n <= group && n > 0) {
-    g2s_session* on = s;
-    if (s->begun & 1u) {
-      if (!s->twin) {
-        const int rc = g2s_session_create(s->graph, s->device, &s->params, &s->twin);
+    // the session, or a twin of it, that no list in flight is on (a list for g2s_fill_batch will run on the session itself)
+    g2s_session* on = nullptr;
+    for (int c = 0; c < G2S_MAX_IN_FLIGHT && !on; c++) {
+      g2s_session* cand = c == 0 ? s : s->twins[c - 1];
+      bool busy = false;
+      for (int i = 0; i < s->n_inflight; i++) busy = busy || (s->inflight[i].b ? s->inflight[i].on == cand && cand != nullptr : c == 0);
+      if (busy) continue;
+      if (!cand) {
+        const int rc = g2s_session_create(s->graph, s->device, &s->params, &s->twins[c - 1]);
         if (rc != G2S_OK) return rc;
+        cand = s->twins[c - 1];
       }
-      on = s->twin;
+      on = cand;
     }
+    if (!on) return fail(G2S_ERR_STATE, "g2s_fill_begin: no session free");
     const auto t0 = std::chrono::steady_clock::now();
     int rc = g2s_batch_prepare(on, gaps, n, &f.b);
     if (rc != G2S_OK) return rc;
@@ -3874,22 +3954,45 @@ extern "C" int g2s_fill_begin(g2s_session* s, const g2s_gap* gaps, size_t n, g2s
   }  // (a list for the team pipeline, or an empty one: g2s_fill_end calls g2s_fill_batch)
   s->inflight[s->n_inflight++] = f;
   s->begun++;
+  const int rs = inflight_settle(s);  // (phase D3 behind the fill kernel at once, where that can be)
+  if (rs < 0) {  // (the list is not in flight then)
+    s->n_inflight--;
+    if (f.b) { if (f.on->d3_pending && f.b->d3_queued) ((D3Pending*)f.on->d3_pending)->discard = true; g2s_batch_free(f.b); }
+    s->inflight[s->n_inflight] = g2s_session::InFlight();
+    return rs;
+  }
   return G2S_OK;
 }
 extern "C" int g2s_fill_end(g2s_session* s) {
   if (!s || s->n_inflight < 1) return fail(G2S_ERR_ARG, "g2s_fill_end: no list in flight");
   g2s_session::InFlight f = s->inflight[0];
-  s->inflight[0] = s->inflight[1];
-  s->inflight[1] = g2s_session::InFlight();
+  for (int i = 1; i < G2S_MAX_IN_FLIGHT; i++) s->inflight[i - 1] = s->inflight[i];
+  s->inflight[G2S_MAX_IN_FLIGHT - 1] = g2s_session::InFlight();
   s->n_inflight--;
-  if (!f.b) return g2s_fill_batch(s, f.gaps, f.n, f.results, f.arena, f.cap);
-  g2s_session* on = f.on;
-  if (on != s) on->rcache.swap(s->rcache);  // the one rand() stream (:178), wherever the list ends
-  const int rc = g2s_batch_run(f.b, f.results, f.arena, f.cap);
-  if (on != s) on->rcache.swap(s->rcache);
-  g2s_batch_free(f.b);
-  s->last_timing = on->last_timing;
-  s->last_timing.ms_prepare = f.ms_prepare;
+  int rc;
+  bool on_device = false;
+  if (!f.b) rc = g2s_fill_batch(s, f.gaps, f.n, f.results, f.arena, f.cap);
+  else {
+    g2s_session* on = f.on;
+    if (on != s) on->rcache.swap(s->rcache);  // the one rand() stream (:178), wherever the list ends
+    rc = g2s_batch_run(f.b, f.results, f.arena, f.cap);
+    if (on != s) on->rcache.swap(s->rcache);
+    on_device = rc == G2S_OK && f.b->timing.resident_launches > 0 && f.b->timing.resident_fallbacks == 0;
+    g2s_batch_free(f.b);
+    s->last_timing = on->last_timing;
+    s->last_timing.ms_prepare = f.ms_prepare;
+  }
+  // The lists behind it that continued its stream on the device, and those that continued theirs: only good when
+  // this one ended on the device.  Otherwise what their kernels wrote is dropped and they run again when they are ended
+  // (g2s_batch_run: chain_broken), each from the host's generator, which then stands where it starts.
+  if (!on_device)
+    for (int i = 0; i < s->n_inflight; i++) {
+      g2s_session::InFlight& y = s->inflight[i];
+      if (!y.b || !y.chained || !y.b->d3_queued) break;
+      y.b->chain_broken = true;
+    }
+  if (s->n_inflight >= 1) s->inflight[0].chained = false;
+  if (rc >= 0) { const int rs = inflight_settle(s); if (rs < 0) return rs; }
   return rc;
 }
 extern "C" int g2s_fill_in_flight(const g2s_session* s) { return s ? s->n_inflight : 0; }

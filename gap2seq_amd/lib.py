@@ -14,6 +14,7 @@ G2S_ERR_IO = -2
 G2S_ERR_NO_DEVICE = -3
 G2S_INVALID_NODE = 0xFFFFFFFF
 G2S_MAX_PATHS = 2147483647 // 2 - 1
+G2S_MAX_IN_FLIGHT = 3  # include/g2s.h: lists begun and not ended on one session
 G2S_GAP_SKIPPED = 0x1
 G2S_GAP_Q7 = 0x2
 G2S_GAP_MEM_EXCEEDED = 0x4
@@ -454,9 +455,9 @@ class Session:
                 hb.free()
         return (out, t) if want_timing else out
 
-    def fill_lists_overlapped(self, lists, pinned=True):
-        """g2s_fill_begin / g2s_fill_end over consecutive lists, two in flight: list i+1 is begun before list i is
-        ended.  Returns the lists' results in order (and the timing of the last list ended)."""
+    def fill_lists_overlapped(self, lists, pinned=True, depth=G2S_MAX_IN_FLIGHT):
+        """g2s_fill_begin / g2s_fill_end over consecutive lists, `depth` in flight: list i+depth-1 is begun before
+        list i is ended.  Returns the lists' results in order (and the timing of the last list ended)."""
         lib = load_library()
         ctx = []
         for gaps in lists:
@@ -476,7 +477,7 @@ class Session:
         try:
             for i, c in enumerate(ctx):
                 _check(lib.g2s_fill_begin(self.h, c["arr"], c["n"], c["res"], c["ap"], c["nbytes"]))
-                if i >= 1:
+                if i >= depth - 1:
                     _check(lib.g2s_fill_end(self.h))
             while lib.g2s_fill_in_flight(self.h) > 0:
                 _check(lib.g2s_fill_end(self.h))

@@ -158,13 +158,14 @@ typedef struct g2s_result {
   int32_t reserved[2];    /* the record is 112 bytes: seven 16-byte stores of the trace kernel */
 } g2s_result;
 
-/* Two lists in flight on one GPU, for a caller that streams lists (Gap2Seq-core -stream-gaps; the reference prints
- * a gap when it is done and goes on, Gap2Seq.cpp:385,426-431).  g2s_fill_begin() takes a list as g2s_fill_batch()
- * does, queues its look-ups and its fill kernel and returns; g2s_fill_end() finishes the OLDEST list begun (phase D3,
- * results and fill text in that list's buffers, which must stay valid until then) and returns what g2s_fill_batch()
- * would.  At most two lists may be begun and not ended: the second one's kernels then run while the first one's
- * results cross the link.  Lists end in the order they were begun and draw from the session's one rand() stream in
+/* Lists in flight on one GPU, for a caller that streams lists (Gap2Seq-core -stream-gaps; the reference prints a gap
+ * when it is done and goes on, Gap2Seq.cpp:385,426-431).  g2s_fill_begin() takes a list as g2s_fill_batch() does,
+ * queues its kernels and returns; g2s_fill_end() finishes the OLDEST list begun (results and fill text in that list's
+ * buffers, which must stay valid until then) and returns what g2s_fill_batch() would.  At most G2S_MAX_IN_FLIGHT lists
+ * may be begun and not ended: the younger ones' kernels then run while the oldest one's results cross the link and the
+ * host prepares the next.  Lists end in the order they were begun and draw from the session's one rand() stream in
  * that order: results are identical to g2s_fill_batch() list by list.  g2s_fill_in_flight(): lists begun, not ended. */
+#define G2S_MAX_IN_FLIGHT 3
 int g2s_fill_begin(g2s_session* s, const g2s_gap* gaps, size_t n, g2s_result* results, char* fill_arena, size_t arena_cap);
 int g2s_fill_end(g2s_session* s);
 int g2s_fill_in_flight(const g2s_session* s);

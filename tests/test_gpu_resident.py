@@ -129,9 +129,10 @@ def test_one_deep_gap_does_not_send_a_list_to_the_host_path(product, oracle, mon
 
 
 def test_two_lists_in_flight_equal_list_by_list(product, monkeypatch):
-    """g2s_fill_begin / g2s_fill_end: seven lists of different lengths (resident and not, one empty), the next one begun
-    before the last one is ended — its look-ups and fill kernel run while the other's results cross the link, on a twin
-    of the session — against g2s_fill_batch list by list: every field, the fill text, and the one rand() stream."""
+    """g2s_fill_begin / g2s_fill_end: seven lists of different lengths (resident and not, one empty), three (and two) in
+    flight — the younger ones' kernels run while the oldest one's results cross the link, on twins of the session, their
+    rand() streams continued from list to list on the device — against g2s_fill_batch list by list: every field, the
+    fill text, and the one rand() stream."""
     reads = product.G2S.synth_genome(300000, 3, 20240101)
     seqs = [ln for ln in reads.splitlines() if not ln.startswith(">")]
     allg = _gaps(product, _parse_scaffolds(product.G2S.synth_gaps(reads, 31, 10, 4000, 100, 900, 20240103)))
@@ -142,9 +143,9 @@ def test_two_lists_in_flight_equal_list_by_list(product, monkeypatch):
         s = product.Session(pg, 0, d_err=500, randseed=11)
         want = [[_key(r) for r in s.fill_batch(L, pinned=True)] if L else [] for L in lists]
         s.destroy()
-        for pinned in (True, False):
+        for pinned, depth in ((True, 3), (False, 3), (True, 2)):
             s = product.Session(pg, 0, d_err=500, randseed=11)
-            got, tm = s.fill_lists_overlapped(lists, pinned=pinned)
+            got, tm = s.fill_lists_overlapped(lists, pinned=pinned, depth=depth)
             tail = [_key(r) for r in s.fill_batch(allg[:300], pinned=True)]  # (the session itself goes on behind them)
             s.destroy()
             assert [[_key(r) for r in L] for L in got] == want
@@ -155,6 +156,45 @@ def test_two_lists_in_flight_equal_list_by_list(product, monkeypatch):
                 s.fill_batch(L, pinned=True)
         assert [_key(r) for r in s.fill_batch(allg[:300], pinned=True)] == tail
         s.destroy()
+    finally:
+        pg.free()
+
+
+def test_lists_in_flight_when_one_does_not_end_on_the_device(product, monkeypatch):
+    """Lists in flight draw from ONE rand() stream, and the list behind another has its phase D3 queued before the one
+    in front has ended: its stream is generated on the device from the state the older list's kernels leave there.
+    When the older list then does not end on the device (here: the K-th wait of the process is told to give up,
+    G2S_RESIDENT_TEST_FALLBACK=nth:K, and the list takes the host path), what the younger one's kernels wrote is
+    dropped and it runs again from the host's generator — every list as g2s_fill_batch list by list gives it, for
+    every position of the failure; and the same with the device chain switched off."""
+    reads = product.G2S.synth_genome(200000, 3, 20240101)
+    seqs = [ln for ln in reads.splitlines() if not ln.startswith(">")]
+    allg = _gaps(product, _parse_scaffolds(product.G2S.synth_gaps(reads, 31, 10, 2400, 100, 900, 20240103)))
+    lists = [allg[:600], allg[600:1100], allg[1100:1500], allg[1500:2100], allg[2100:], allg[:400]]
+    pg = product.Graph.from_seqs(seqs, 31, 1)
+    try:
+        monkeypatch.delenv("G2S_RESIDENT", raising=False)
+        s = product.Session(pg, 0, d_err=500, randseed=5)
+        want = [[_key(r) for r in s.fill_batch(L, pinned=True)] for L in lists]
+        tail = [_key(r) for r in s.fill_batch(allg[:200], pinned=True)]
+        s.destroy()
+        for env in ({}, {"G2S_NO_DEVICE_CHAIN": "1"}, {"G2S_RESIDENT_TEST_FALLBACK": "nth"}):
+            # (the wait counter is the process's: the K-th wait from here on = K + the waits done so far; "nth" alone
+            # is filled in per position below)
+            positions = range(len(lists) + 1) if "G2S_RESIDENT_TEST_FALLBACK" in env else [None]
+            for pos in positions:
+                for k, v in env.items():
+                    monkeypatch.setenv(k, v)
+                if pos is not None:
+                    monkeypatch.setenv("G2S_RESIDENT_TEST_FALLBACK", "rel:%d" % pos)
+                s = product.Session(pg, 0, d_err=500, randseed=5)
+                got, tm = s.fill_lists_overlapped(lists, pinned=True)
+                monkeypatch.delenv("G2S_RESIDENT_TEST_FALLBACK", raising=False)
+                assert [_key(r) for r in s.fill_batch(allg[:200], pinned=True)] == tail, (env, pos)
+                s.destroy()
+                for k in env:
+                    monkeypatch.delenv(k, raising=False)
+                assert [[_key(r) for r in L] for L in got] == want, (env, pos)
     finally:
         pg.free()
 
