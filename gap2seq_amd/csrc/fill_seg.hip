@@ -38,7 +38,7 @@
 //            level |depth - (g+lmf+j)| + g+lmf+rmf; smallest level, then smallest j.
 //   Q7       both strands of a k-mer at one depth: among pending events (compare + ballot) and where an
 //            upward and a downward segment of one unitig cross (arithmetic).
-//   phase D1 (:1169-1312) backward closure over the segments, generation by generation in reverse (children
+//   phase D1 (:1169-1312) backward closure over the segments, chunks of 64 in reverse (children
 //            were created after their parent was expanded).
 //   phase D2 (:1314-1435) when no k-mer repeats in the closure: the branch rule as a prefix sum over segments.
 //   output   the closure as 32-byte segment records (SegRec), children before parents, parents in GATB's
@@ -1544,45 +1544,53 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
   }
   lds_sync();
   {
-    // the sweep: generation by generation in reverse; a segment in the closure tells its parents — one addition
-    // per parent: children on paths to a sink in bits 20..22 of the parent's word (the out-degree of its last state
-    // in the subgraph, for the branch rule below), children in the traceback closure in bits 24..26 (a state has at
-    // most four successors); a parent with either count above zero is in that closure whole
+    // the sweep, in reverse: a segment in the closure tells its parents — one addition per parent and mark:
+    // children on paths to a sink in bits 20..22 of the parent's word (the out-degree of its last state in the
+    // subgraph, for the branch rule below), children in the traceback closure in bits 24..26 (a state has at most
+    // four successors); a parent with either count above zero is in that closure whole.  A parent has a lower id
+    // than its children, so by the time a chunk of 64 segments is reached every child outside it has spoken; a pass
+    // over the chunk is final unless a segment that spoke in it has a parent INSIDE the chunk — then another pass.
+    // (The sweep used to take the generations — rounds of phase B — one by one: 80 dependent steps on a config-2 gap;
+    // a parent is mostly many rounds older than its child, and most chunks are done in one pass.)
     uint32_t hi = nseg;
     while (hi > 0) {
       const uint32_t lo = hi > 64u ? hi - 64u : 0u;
       const uint32_t b = lo + (uint32_t)lane;
       const bool hb = b < hi;
-      // (everything a segment's step reads is asked for at once: one LDS round trip)
-      const uint32_t aux = hb ? s_aux[b] : 0u;
       const uint32_t pre = hb ? s_t[b] : 0x7FFF7FFFu, dl = hb ? s_dl[b] : 0u;
       const uint32_t p01 = hb ? s_p01[b] : 0xFFFFFFFFu, p23 = hb ? s_p23[b] : 0xFFFFFFFFu;
-      const uint32_t gtop = rl(aux & 0xFFFFu, (int)(hi - 1u - lo));
-      const uint64_t gm = __ballot(hb && (aux & 0xFFFFu) == gtop);  // segments of one generation are contiguous
-      const int first = __builtin_ctzll(gm);
-      const bool act = hb && lane >= first;
-      bool multi = false;
-      if (act) {
-        const int d0 = (int)(dl & 0xFFFFu);
-        const int len = max(0, min((int)(dl >> 16), d_last - d0 + 1));
-        int ts = dec15(pre), tt = dec15(pre >> 16);
+      const int d0 = (int)(dl & 0xFFFFu);
+      const int len = max(0, min((int)(dl >> 16), d_last - d0 + 1));
+      const uint32_t q0 = p01 & 0xFFFFu, q1 = p01 >> 16, q2 = p23 & 0xFFFFu, q3 = p23 >> 16;
+      const bool speaks = hb && d0 > 0 && !(pre & 0x8000u);
+      const bool inside = (q0 != SEG_NOPAR && q0 >= lo) || (q1 != SEG_NOPAR && q1 >= lo) || (q2 != SEG_NOPAR && q2 >= lo) ||
+                          (q3 != SEG_NOPAR && q3 >= lo);
+      uint32_t sent = 0u;  // marks this segment has passed on: bit 0 to a sink, bit 1 traceback closure
+      int ts = -1, tt = -1;
+#pragma nounroll
+      while (true) {
+        const uint32_t aux = hb ? s_aux[b] : 0u;
+        ts = dec15(pre); tt = dec15(pre >> 16);
         if (len > 0) {
           if (aux & (7u << 20)) ts = len - 1;
           if (aux & (7u << 24)) tt = len - 1;
         }
-        s_t[b] = enc15(ts) | (enc15(tt) << 16);
-        const uint32_t mk = (ts >= 0 ? (1u << 20) : 0u) | (tt >= 0 ? (1u << 24) : 0u);
-        if (mk && d0 > 0 && !(pre & 0x8000u)) {
-          if ((p01 & 0xFFFFu) != SEG_NOPAR) atomicAdd(&s_aux[p01 & 0xFFFFu], mk);
-          if ((p01 >> 16) != SEG_NOPAR) atomicAdd(&s_aux[p01 >> 16], mk);
-          if ((p23 & 0xFFFFu) != SEG_NOPAR) atomicAdd(&s_aux[p23 & 0xFFFFu], mk);
-          if ((p23 >> 16) != SEG_NOPAR) atomicAdd(&s_aux[p23 >> 16], mk);
-          multi = tt >= 0 && (p01 >> 16) != SEG_NOPAR;
+        const uint32_t want = speaks ? ((ts >= 0 ? 1u : 0u) | (tt >= 0 ? 2u : 0u)) & ~sent : 0u;
+        const uint32_t mk = ((want & 1u) << 20) | ((want & 2u) << 23);
+        if (mk) {
+          if (q0 != SEG_NOPAR) atomicAdd(&s_aux[q0], mk);
+          if (q1 != SEG_NOPAR) atomicAdd(&s_aux[q1], mk);
+          if (q2 != SEG_NOPAR) atomicAdd(&s_aux[q2], mk);
+          if (q3 != SEG_NOPAR) atomicAdd(&s_aux[q3], mk);
         }
+        sent |= want;
+        const bool again = __ballot(mk != 0u && inside) != 0ull;
+        lds_sync();
+        if (!again) break;
       }
-      if (__ballot(multi)) choice = true;
-      lds_sync();
-      hi = lo + (uint32_t)first;
+      if (hb) s_t[b] = enc15(ts) | (enc15(tt) << 16);
+      if (__ballot(speaks && tt >= 0 && q1 != SEG_NOPAR)) choice = true;
+      hi = lo;
     }
   }
   SEG_PROF_TAIL(2);

@@ -944,51 +944,53 @@ __device__ __forceinline__ void segw_fill_one(uint32_t* lds, const SegArgs& A, c
   }
   __syncthreads();
   if (wave == 0u) {
-    // the sweep (wave 0): generation by generation in reverse; a segment in the closure tells its parents — one
-    // addition per parent: children on paths to a sink in bits 20..22 of the parent's word, children in the
-    // traceback closure in bits 24..26 (see fill_seg.hip)
+    // the sweep (wave 0), in reverse: a segment in the closure tells its parents — one addition per parent and
+    // mark: children on paths to a sink in bits 20..22 of the parent's word, children in the traceback closure in
+    // bits 24..26 (see fill_seg.hip).  A parent has a lower id than its children, so by the time a chunk of 64
+    // segments is reached every child outside it has spoken; a pass over the chunk is final unless a segment that
+    // spoke in it has a parent INSIDE the chunk — then another pass (a parent is mostly many rounds older than its
+    // child: one pass for most chunks, where the sweep used to take one per generation, five or six a chunk).
     bool choice = false;
     uint32_t hi = nseg;
     while (hi > 0) {
-      // (the words of a chunk of 64 segments come from the scratch once; the generations inside the chunk — half a
-      // dozen on a deep gap — then only read the marks their children left in LDS)
       const uint32_t lo = hi > 64u ? hi - 64u : 0u;
       const uint32_t b = lo + (uint32_t)lane;
-      const bool hb0 = b < hi;
-      const uint32_t dl = hb0 ? s_dl[b] : 0u;
-      const uint32_t p01 = hb0 ? s_p01[b] : 0xFFFFFFFFu, p23 = hb0 ? s_p23[b] : 0xFFFFFFFFu;
+      const bool hb = b < hi;
+      const uint32_t dl = hb ? s_dl[b] : 0u;
+      const uint32_t p01 = hb ? s_p01[b] : 0xFFFFFFFFu, p23 = hb ? s_p23[b] : 0xFFFFFFFFu;
+      const uint32_t pre = hb ? s_t[b] : 0x7FFF7FFFu;
+      const int d0 = (int)(dl & 0xFFFFu);
+      const int len = max(0, min((int)(dl >> 16), d_last - d0 + 1));
+      const uint32_t q0 = p01 & 0xFFFFu, q1 = p01 >> 16, q2 = p23 & 0xFFFFu, q3 = p23 >> 16;
+      const bool speaks = hb && d0 > 0 && !(pre & 0x8000u);
+      const bool inside = (q0 != SEG_NOPAR && q0 >= lo) || (q1 != SEG_NOPAR && q1 >= lo) || (q2 != SEG_NOPAR && q2 >= lo) ||
+                          (q3 != SEG_NOPAR && q3 >= lo);
+      uint32_t sent = 0u;  // marks this segment has passed on: bit 0 to a sink, bit 1 traceback closure
+      int ts = -1, tt = -1;
+#pragma nounroll
       while (true) {
-        const bool hb = b < hi;
         const uint32_t aux = hb ? s_aux[b] : 0u;
-        const uint32_t pre = hb ? s_t[b] : 0x7FFF7FFFu;
-        const uint32_t gtop = rl(aux & 0xFFFFu, (int)(hi - 1u - lo));
-        const uint64_t gm = __ballot(hb && (aux & 0xFFFFu) == gtop);  // segments of one generation are contiguous
-        const int first = __builtin_ctzll(gm);
-        const bool act = hb && lane >= first;
-        bool multi = false;
-        if (act) {
-          const int d0 = (int)(dl & 0xFFFFu);
-          const int len = max(0, min((int)(dl >> 16), d_last - d0 + 1));
-          int ts = dec15(pre), tt = dec15(pre >> 16);
-          if (len > 0) {
-            if (aux & (7u << 20)) ts = len - 1;
-            if (aux & (7u << 24)) tt = len - 1;
-          }
-          s_t[b] = enc15(ts) | (enc15(tt) << 16);
-          const uint32_t mk = (ts >= 0 ? (1u << 20) : 0u) | (tt >= 0 ? (1u << 24) : 0u);
-          if (mk && d0 > 0 && !(pre & 0x8000u)) {
-            if ((p01 & 0xFFFFu) != SEG_NOPAR) atomicAdd(&s_aux[p01 & 0xFFFFu], mk);
-            if ((p01 >> 16) != SEG_NOPAR) atomicAdd(&s_aux[p01 >> 16], mk);
-            if ((p23 & 0xFFFFu) != SEG_NOPAR) atomicAdd(&s_aux[p23 & 0xFFFFu], mk);
-            if ((p23 >> 16) != SEG_NOPAR) atomicAdd(&s_aux[p23 >> 16], mk);
-            multi = tt >= 0 && (p01 >> 16) != SEG_NOPAR;
-          }
+        ts = dec15(pre); tt = dec15(pre >> 16);
+        if (len > 0) {
+          if (aux & (7u << 20)) ts = len - 1;
+          if (aux & (7u << 24)) tt = len - 1;
         }
-        if (__ballot(multi)) choice = true;
+        const uint32_t want = speaks ? ((ts >= 0 ? 1u : 0u) | (tt >= 0 ? 2u : 0u)) & ~sent : 0u;
+        const uint32_t mk = ((want & 1u) << 20) | ((want & 2u) << 23);
+        if (mk) {
+          if (q0 != SEG_NOPAR) atomicAdd(&s_aux[q0], mk);
+          if (q1 != SEG_NOPAR) atomicAdd(&s_aux[q1], mk);
+          if (q2 != SEG_NOPAR) atomicAdd(&s_aux[q2], mk);
+          if (q3 != SEG_NOPAR) atomicAdd(&s_aux[q3], mk);
+        }
+        sent |= want;
+        const bool again = __ballot(mk != 0u && inside) != 0ull;
         lds_sync();
-        hi = lo + (uint32_t)first;
-        if (first == 0) break;
+        if (!again) break;
       }
+      if (hb) s_t[b] = enc15(ts) | (enc15(tt) << 16);
+      if (__ballot(speaks && tt >= 0 && q1 != SEG_NOPAR)) choice = true;
+      hi = lo;
     }
     if (lane == 0 && choice) sh[SH_CHOICE] = 1u;
   }
