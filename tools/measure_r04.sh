@@ -33,8 +33,14 @@ timeout 400 python bench.py --no-cpu-baseline --config C4 | tee -a $O/other.json
 for r in 1 2; do timeout 400 python bench.py --no-cpu-baseline --config C5 --steps 5 | tee -a $O/other.jsonl | python tools/bsum.py C5; done
 G2S_RESIDENT=0 timeout 400 python bench.py --no-cpu-baseline --config C5 --steps 5 | tee -a $O/other.jsonl | python tools/bsum.py C5-host-path
 G2S_RESIDENT=0 G2S_SEGX_ONE_WAVE=1 timeout 400 python bench.py --no-cpu-baseline --config C5 --steps 3 | tee -a $O/other.jsonl | python tools/bsum.py C5-host-path-round3-kernel
-for r in 1 2; do timeout 400 python bench.py --config C3 --no-cpu-baseline --stream-lists 10 --steps 10 | tee -a $O/stream.jsonl | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('C3 stream', d['stream_lists'])"; done
+for r in 1 2; do timeout 400 python bench.py --config C3 --no-cpu-baseline --stream-lists 12 --steps 10 | tee -a $O/stream.jsonl | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('C3 stream', d['stream_lists'])"; done
 timeout 400 python bench.py --no-cpu-baseline --no-c3-beside --stream-lists 10 --steps 50 | tee -a $O/stream.jsonl | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('C2 stream', d['stream_lists'])"
+timeout 400 python bench.py --config C3 --no-cpu-baseline --stream-lists 12 --in-flight 2 --steps 10 | tee -a $O/stream.jsonl | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('C3 stream, two in flight', d['stream_lists'])"
+G2S_NO_DEVICE_CHAIN=1 timeout 400 python bench.py --config C3 --no-cpu-baseline --stream-lists 12 --steps 10 | tee -a $O/stream.jsonl | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('C3 stream, rand() stream through the host', d['stream_lists'])"
+timeout 400 python bench.py --config C5 --no-cpu-baseline --stream-lists 6 --steps 3 | tee -a $O/stream.jsonl | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('C5 stream', d['stream_lists'])"
 timeout 200 python bench.py --no-cpu-baseline --no-c3-beside --prime-seconds 0 --warmup 0 --steps 20 | tee $O/cold.json | python tools/bsum.py C2-unprimed
 timeout 600 python tools/segw_profile.py C5 2>&1 | tail -12 | tee $O/segw_profile_c5.txt
+G2S_LIBRARY=$PWD/gap2seq_amd/_prof/libg2s_hip.so timeout 600 python tools/seg_profile.py C2 2>&1 | tail -24 > $O/segprof_c2.txt
+G2S_LIBRARY=$PWD/gap2seq_amd/_prof/libg2s_hip.so G2S_SEG_WAVES=1 timeout 600 python tools/seg_profile.py C3 2>&1 | tail -24 > $O/segprof_c3.txt
+G2S_HOST_ITEMS_DUMP=$O/items_c5.bin G2S_DEBUG=1 timeout 600 python bench.py --config C5 --steps 3 --warmup 1 --prime-seconds 1 --no-cpu-baseline 2> $O/c5_debug.txt > /dev/null; grep -E "host-finished|run analysis|resident mode, phase D3" $O/c5_debug.txt | tail -12 | cut -c1-700 > $O/c5_host_share.txt; rm -f $O/items_c5.bin $O/c5_debug.txt
 bash tools/r04_scale_shared.sh < /dev/null 2>&1 | cut -c1-700 | tee $O/shared.txt
