@@ -790,7 +790,7 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
     uint64_t m = 0;
 #pragma unroll
     for (int s = 0; s < G2S_SEG_ASETS; s++)
-      if ((uint32_t)s * 64u < nA) m |= __ballot(alo[s] <= x && x <= ahi[s]);
+      if ((uint32_t)s * 64u < nA) m |= __ballot(alo[s] <= x) & __ballot(x <= ahi[s]);
     return m != 0;
   };
   // largest y <= xmax with [x0, y] inside the right set (x0 - 1 when x0 is not in it)
@@ -866,7 +866,8 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
   // ---------------- phase B: entry events in registers, segments into LDS ----------------------
   uint32_t en = G2S_DEV_INVALID, ec = 0, es = 1, ep01 = 0xFFFFFFFFu, ep23 = 0xFFFFFFFFu;
   uint4 erec = make_uint4(G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID);  // where the event's segment leaves
-  int ed = 0;
+  constexpr int SEG_NOEV = 0x3FFFFFFF;  // depth of a lane without an event
+  int ed = SEG_NOEV;
   uint64_t ev = 0, efx = 0;  // pending events, and which of them have an assigned count (left seeds)
   uint32_t nseg = 0, gen = 0, xb = 0, sb = 0;
 #ifdef G2S_SEG_PROFILE
@@ -886,30 +887,40 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
     const uint32_t ls = uni(l_seed[dw]);
     return ls != G2S_DEV_INVALID && (w >> 1) == (ls >> 1);
   };
+  // One child (w, dw) with count c from segment par: merged into the pending event of its state, or a new event in a
+  // free lane.  Which of the two it is, and which lane changes, are wave-uniform: two scalar branches, and inside them
+  // every register of the event takes its new value through a select (the version with `if (lane == l) { ... }`
+  // around the updates saved and restored the execution mask around three levels of cases and copied every event
+  // register at every join).  A ballot is taken of ONE comparison at a time and the masks are combined as scalars: a
+  // ballot of a conjunction goes through a vector register (0 / 1, compared again).  (A lane without an event carries
+  // depth SEG_NOEV: it matches no child.)
   auto add_event = [&](uint32_t w, int dw, uint32_t c, uint32_t par, uint32_t pstop) {
-    const bool valid = (ev >> lane) & 1ull;
-    const uint64_t m = __ballot(valid && en == w && ed == dw);
+    const uint64_t md = __ballot(ed == dw);
+    const uint64_t m = md & __ballot(en == w);
     const bool src = is_source(w, dw);
     if (m) {
-      const int l = __builtin_ctzll(m);
-      if (lane == l) {
-        if (!src) est = stop_join(est, pstop);
-        ec = min(ec + c, (uint32_t)G2S_DEV_MAX_PATHS);  // saturating add is associative (:1058-1060)
-        if ((ep01 >> 16) == SEG_NOPAR) ep01 = (ep01 & 0xFFFFu) | (par << 16);
-        else if ((ep23 & 0xFFFFu) == SEG_NOPAR) ep23 = (ep23 & 0xFFFF0000u) | par;
-        else ep23 = (ep23 & 0xFFFFu) | (par << 16);
-      }
+      const bool me = lane == __builtin_ctzll(m);
+      if (!src) est = me ? stop_join(est, pstop) : est;
+      ec = me ? min(ec + c, (uint32_t)G2S_DEV_MAX_PATHS) : ec;  // saturating add is associative (:1058-1060)
+      const bool free1 = (ep01 >> 16) == SEG_NOPAR, free2 = (ep23 & 0xFFFFu) == SEG_NOPAR;
+      const uint32_t a01 = (ep01 & 0xFFFFu) | (par << 16);
+      const uint32_t a23 = free2 ? ((ep23 & 0xFFFF0000u) | par) : ((ep23 & 0xFFFFu) | (par << 16));
+      ep01 = (me && free1) ? a01 : ep01;
+      ep23 = (me && !free1) ? a23 : ep23;
       return;
     }
-    if (__ballot(valid && en == (w ^ 1u) && ed == dw)) flags |= G2S_DEV_Q7_B;  // the other strand at this depth
+    if (md & __ballot(en == (w ^ 1u))) flags |= G2S_DEV_Q7_B;  // the other strand at this depth
     const uint64_t fr = ~ev;
     if (!fr) { overflow = true; flags |= G2S_DEV_OVERFLOW_B | G2S_DEV_WHY_FRONTIER; return; }
     const int l = __builtin_ctzll(fr);
-    if (lane == l) {
-      en = w; ed = dw; ec = c; ep01 = 0xFFFF0000u | par; ep23 = 0xFFFFFFFFu;
-      es = 0u;  // states up to the end of the unitig: loaded with the exit record for all new events at once
-      est = src ? ((uint32_t)dw | ((uint32_t)dw << 16)) : pstop;
-    }
+    const bool me = lane == l;
+    en = me ? w : en;
+    ed = me ? dw : ed;
+    ec = me ? c : ec;
+    ep01 = me ? (0xFFFF0000u | par) : ep01;
+    ep23 = me ? 0xFFFFFFFFu : ep23;
+    es = me ? 0u : es;  // states up to the end of the unitig: loaded with the exit record for all new events at once
+    est = me ? (src ? ((uint32_t)dw | ((uint32_t)dw << 16)) : pstop) : est;
     ev |= 1ull << l;
   };
   if constexpr (!BIG) {
@@ -1002,6 +1013,7 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
       const uint32_t est_sel = est;             // (add_event below may reuse a selected lane for a new event)
       ev &= ~sel;
       efx &= ~sel;
+      ed = mine ? SEG_NOEV : ed;  // (the selected events' lanes are free: they match no child)
       // (successor slot by successor slot, only the lanes whose slot holds a node: the order in which the
       // children arrive does not matter — counts add up, the host puts parents into GATB order)
 #pragma unroll

@@ -7,6 +7,12 @@
 #include "fill_device.h"
 #include "fill_seg.h"
 
+// The HIP headers' __ballot(p) compares an int with zero: a predicate is first turned into 0 / 1 in a vector register
+// and then compared again — three instructions where the compare that made the predicate had already left the mask in
+// a scalar register pair.  The segment kernels hold hundreds of ballots in their inner loops.
+__device__ __forceinline__ unsigned long long g2s_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+#define __ballot(p) g2s_ballot(p)
+
 #define SEG_INF 0x7FFFFFFFu
 // -DG2S_SEG_PROFILE: cycles of the sections of a phase B round, summed per gap into the last words of the
 // gap's diagnostics row (G2S_SEG_DUMP; tools only)
