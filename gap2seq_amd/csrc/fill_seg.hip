@@ -802,7 +802,7 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
 #pragma unroll
       for (int s = 0; s < G2S_SEG_ASETS; s++) {
         if ((uint32_t)s * 64u < nA) {
-          for (uint64_t m = __ballot(alo[s] <= cur && cur <= ahi[s]); m; m &= m - 1) {
+          for (uint64_t m = ballot_and(alo[s] <= cur, cur <= ahi[s]); m; m &= m - 1) {
             const uint32_t h = rl(ahi[s], __builtin_ctzll(m));
             best = hit ? max(best, h) : h;
             hit = true;
@@ -823,7 +823,7 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
 #pragma unroll
       for (int s = 0; s < G2S_SEG_ASETS; s++) {
         if ((uint32_t)s * 64u < nA) {
-          for (uint64_t m = __ballot(alo[s] <= cur && cur <= ahi[s]); m; m &= m - 1) {
+          for (uint64_t m = ballot_and(alo[s] <= cur, cur <= ahi[s]); m; m &= m - 1) {
             const uint32_t lo_ = rl(alo[s], __builtin_ctzll(m));
             best = hit ? min(best, lo_) : lo_;
             hit = true;
@@ -963,7 +963,7 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
       // ---- which events are final: depth below the horizon
       const bool valid = (ev >> lane) & 1ull;
       const uint32_t H = wave_min(valid ? (uint32_t)ed + es : SEG_INF);
-      const uint64_t sel = __ballot(valid && (uint32_t)ed < H);
+      const uint64_t sel = ev & __ballot((uint32_t)ed < H);
       const uint32_t nsel = (uint32_t)__popcll(sel);
       if (nseg + nsel > G2S_SEG_CAP) { overflow = true; flags |= G2S_DEV_OVERFLOW_B | G2S_DEV_WHY_LOG; break; }
       const bool mine = (sel >> lane) & 1ull;
@@ -972,7 +972,7 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
       uint32_t elen = lcap;
       const uint32_t esid = nseg + (uint32_t)__popcll(sel & below(lane));
       if constexpr (TWO) {  // a state or a child at or beyond the depth the pruning rule starts at: the right set now
-        if (!have_rs && __ballot(mine && ed + (int)lcap >= gd.prune_from)) {
+        if (!have_rs && (sel & __ballot(ed + (int)lcap >= gd.prune_from))) {
           take_right_set();
           if (overflow) break;
         }
@@ -1007,7 +1007,7 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
       nseg += nsel;
       SEG_PROF_T(3);
       // ---- segments that reached the end of their stretch leave through the successor table
-      const bool exits = mine && elen == es && ed + (int)elen - 1 < D;
+      const uint64_t exits_m = sel & ballot_and(elen == es, ed + (int)elen - 1 < D);
       const uint4 rec = erec;  // elen == lcap == es: the walk reached the node the record belongs to
       const uint32_t xd = (uint32_t)ed + elen;  // depth of the children
       const uint32_t est_sel = est;             // (add_event below may reuse a selected lane for a new event)
@@ -1019,7 +1019,7 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         const uint32_t wv = q == 0 ? rec.x : q == 1 ? rec.y : q == 2 ? rec.z : rec.w;
-        for (uint64_t m = __ballot(exits && wv != G2S_DEV_INVALID); m && !overflow; m &= m - 1) {
+        for (uint64_t m = exits_m & __ballot(wv != G2S_DEV_INVALID); m && !overflow; m &= m - 1) {
           const int l = __builtin_ctzll(m);
           const uint32_t w = rl(wv, l);
           const int dw = (int)rl(xd, l);
@@ -1575,8 +1575,9 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
       const int len = max(0, min((int)(dl >> 16), d_last - d0 + 1));
       const uint32_t q0 = p01 & 0xFFFFu, q1 = p01 >> 16, q2 = p23 & 0xFFFFu, q3 = p23 >> 16;
       const bool speaks = hb && d0 > 0 && !(pre & 0x8000u);
-      const bool inside = (q0 != SEG_NOPAR && q0 >= lo) || (q1 != SEG_NOPAR && q1 >= lo) || (q2 != SEG_NOPAR && q2 >= lo) ||
-                          (q3 != SEG_NOPAR && q3 >= lo);
+      // (a parent's id is below the segment's own: inside the chunk = at or above its first id; SEG_NOPAR is above all)
+      const uint64_t inside_m = (ballot_and(q0 >= lo, q0 != SEG_NOPAR) | ballot_and(q1 >= lo, q1 != SEG_NOPAR) |
+                                 ballot_and(q2 >= lo, q2 != SEG_NOPAR) | ballot_and(q3 >= lo, q3 != SEG_NOPAR));
       uint32_t sent = 0u;  // marks this segment has passed on: bit 0 to a sink, bit 1 traceback closure
       int ts = -1, tt = -1;
 #pragma nounroll
@@ -1596,7 +1597,7 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
           if (q3 != SEG_NOPAR) atomicAdd(&s_aux[q3], mk);
         }
         sent |= want;
-        const bool again = __ballot(mk != 0u && inside) != 0ull;
+        const bool again = (__ballot(mk != 0u) & inside_m) != 0ull;
         lds_sync();
         if (!again) break;
       }
@@ -1665,7 +1666,7 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
         for (uint64_t am = __ballot(a_in); am && dag; am &= am - 1) {
           const int al = __builtin_ctzll(am);
           const uint32_t lo_a = rl(alo_, al), hi_a = rl(ahi_, al);
-          if (__ballot(in_s && b > a0 + (uint32_t)al && ilo <= hi_a && lo_a <= ihi)) dag = false;
+          if (ballot_and(in_s, b > a0 + (uint32_t)al, ilo <= hi_a, lo_a <= ihi)) dag = false;
         }
       }
     }

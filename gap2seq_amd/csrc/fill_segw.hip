@@ -406,13 +406,13 @@ __device__ __forceinline__ void segw_fill_one(uint32_t* lds, const SegArgs& A, c
   // with a per-lane STATE word (0 pending, 1 new event, 2 merged), the rare cases behind wave-uniform branches.
   auto ev_insert = [&](bool act, uint32_t w, uint32_t dw, uint32_t c, uint32_t par, uint32_t pslo, uint32_t pshi, bool fixed,
                        uint32_t clo, uint32_t chi, uint32_t at) {
-    if (__ballot(act && (int32_t)(tail_snap - at) <= 0)) {  // the ring has nothing left from before this round
+    if (ballot_and(act, (int32_t)(tail_snap - at) <= 0)) {  // the ring has nothing left from before this round
       if (act && (int32_t)(tail_snap - at) <= 0) { act = false; lflags |= G2S_DEV_OVERFLOW_B | G2S_DEV_WHY_FRONTIER; sh[SH_OVF] = 1u; }
     }
     const uint32_t slot = fq[at & (PE - 1u)];
     uint32_t slo = pslo, shi = pshi;
     bool src = false;
-    if (__ballot(act && dw <= (uint32_t)lmf)) {  // :1270 (the first rounds only)
+    if (ballot_and(act, dw <= (uint32_t)lmf)) {  // :1270 (the first rounds only)
       const uint32_t ls = (act && dw <= (uint32_t)lmf) ? l_seed[dw] : G2S_DEV_INVALID;
       src = ls != G2S_DEV_INVALID && (w >> 1) == (ls >> 1);
       if (src) { slo = dw; shi = dw; }
@@ -636,7 +636,7 @@ __device__ __forceinline__ void segw_fill_one(uint32_t* lds, const SegArgs& A, c
         const uint32_t l_up = (idx0 + 1u <= chi ? min(chi, idx0 + lcap - 1u) : idx0) - idx0 + 1u;
         const uint32_t l_dn = idx0 - ((idx0 >= 1u && idx0 - 1u >= clo) ? max(clo, idx0 - (lcap - 1u)) : idx0) + 1u;
         uint32_t L = (pr && clo != 0xFFFFFFFFu) ? ((en & 1u) ? l_dn : l_up) : lcap;  // (known interval: ed >= prune_from, the rule holds from the second state on)
-        if (__ballot(mine && pr && clo == 0xFFFFFFFFu)) {
+        if (ballot_and(mine, pr, clo == 0xFFFFFFFFu)) {
           const uint32_t t1 = (uint32_t)max(1, gd.prune_from - ed);
           const uint32_t q0 = (en & 1u) ? idx0 - t1 : idx0 + t1;  // first state entered under the rule
           const uint32_t r = iv_rank(q0);
@@ -654,7 +654,7 @@ __device__ __forceinline__ void segw_fill_one(uint32_t* lds, const SegArgs& A, c
         const uint32_t xd = (uint32_t)ed + L;  // depth of the children
         bool cact = exits && w != G2S_DEV_INVALID;
         uint32_t cclo = 0xFFFFFFFFu, cchi = 0u;
-        if (__ballot(cact && (int)xd >= gd.prune_from)) {
+        if (ballot_and(cact, (int)xd >= gd.prune_from)) {
           const bool cm = cact && (int)xd >= gd.prune_from;
           const uint32_t r = iv_rank(w >> 1);
           const uint32_t r1 = r > 0u ? r - 1u : 0u;
@@ -674,7 +674,7 @@ __device__ __forceinline__ void segw_fill_one(uint32_t* lds, const SegArgs& A, c
         const uint32_t esid = rl(rsv, 0) + ((uint32_t)lane >> 2);
         const uint32_t back = rl(rsv, 1) + ((uint32_t)lane >> 2);
         const uint32_t at = rl(rsv, 2) + (uint32_t)__popcll(cmk & below(lane));
-        if (__ballot(mine && esid >= CAP)) {  // (the gap then runs in the LDS tier)
+        if (ballot_and(mine, esid >= CAP)) {  // (the gap then runs in the LDS tier)
           if (mine && esid >= CAP) { cact = false; lflags |= G2S_DEV_OVERFLOW_B | G2S_DEV_WHY_LOG; sh[SH_OVF] = 1u; }
         }
         if (lead) {
@@ -963,8 +963,8 @@ __device__ __forceinline__ void segw_fill_one(uint32_t* lds, const SegArgs& A, c
       const int len = max(0, min((int)(dl >> 16), d_last - d0 + 1));
       const uint32_t q0 = p01 & 0xFFFFu, q1 = p01 >> 16, q2 = p23 & 0xFFFFu, q3 = p23 >> 16;
       const bool speaks = hb && d0 > 0 && !(pre & 0x8000u);
-      const bool inside = (q0 != SEG_NOPAR && q0 >= lo) || (q1 != SEG_NOPAR && q1 >= lo) || (q2 != SEG_NOPAR && q2 >= lo) ||
-                          (q3 != SEG_NOPAR && q3 >= lo);
+      const uint64_t inside_m = (ballot_and(q0 >= lo, q0 != SEG_NOPAR) | ballot_and(q1 >= lo, q1 != SEG_NOPAR) |
+                                 ballot_and(q2 >= lo, q2 != SEG_NOPAR) | ballot_and(q3 >= lo, q3 != SEG_NOPAR));
       uint32_t sent = 0u;  // marks this segment has passed on: bit 0 to a sink, bit 1 traceback closure
       int ts = -1, tt = -1;
 #pragma nounroll
@@ -984,7 +984,7 @@ __device__ __forceinline__ void segw_fill_one(uint32_t* lds, const SegArgs& A, c
           if (q3 != SEG_NOPAR) atomicAdd(&s_aux[q3], mk);
         }
         sent |= want;
-        const bool again = __ballot(mk != 0u && inside) != 0ull;
+        const bool again = (__ballot(mk != 0u) & inside_m) != 0ull;
         lds_sync();
         if (!again) break;
       }
@@ -1053,7 +1053,7 @@ __device__ __forceinline__ void segw_fill_one(uint32_t* lds, const SegArgs& A, c
           for (uint64_t am = __ballot(a_in); am && dag; am &= am - 1) {
             const int al = __builtin_ctzll(am);
             const uint32_t lo_a = rl(alo_, al), hi_a = rl(ahi_, al);
-            if (__ballot(in_s && b > a0 + (uint32_t)al && ilo <= hi_a && lo_a <= ihi)) dag = false;
+            if (ballot_and(in_s, b > a0 + (uint32_t)al, ilo <= hi_a, lo_a <= ihi)) dag = false;
           }
         }
       }

@@ -12,6 +12,10 @@
 // a scalar register pair.  The segment kernels hold hundreds of ballots in their inner loops.
 __device__ __forceinline__ unsigned long long g2s_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 #define __ballot(p) g2s_ballot(p)
+// the lanes in which every one of the conditions holds: a ballot of each (one comparison = one instruction that leaves
+// the mask in scalar registers), combined as scalars — a ballot of the conjunction goes through a vector register
+template <class... B>
+__device__ __forceinline__ unsigned long long ballot_and(bool a, B... b) { return (g2s_ballot(a) & ... & g2s_ballot(b)); }
 
 #define SEG_INF 0x7FFFFFFFu
 // -DG2S_SEG_PROFILE: cycles of the sections of a phase B round, summed per gap into the last words of the
