@@ -364,6 +364,7 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
   if (lane < 32 && wave == 0) l_seed[lane] = lane <= lmf ? lseeds[lane] : G2S_DEV_INVALID;
 
   uint32_t nA = 0, roundsA = 0, nvis = 0, xa = 0;
+  uint32_t nM = 0;  // (regular tier) the right set's entries as merged k-mer index intervals: how many
   // (!BIG) the right-set entries in registers: lane l of set s holds entry 64 s + l, as a k-mer index interval
   uint32_t an[G2S_SEG_ASETS], al[G2S_SEG_ASETS], ar[G2S_SEG_ASETS], alo[G2S_SEG_ASETS], ahi[G2S_SEG_ASETS];
 #pragma unroll
@@ -402,19 +403,26 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
         }
         lds_sync();
       }
-      // the entries as k-mer index intervals [alo, ahi]; lanes without an entry hold an empty interval
+      // the set's size (intervals of one unitig may overlap: an upper bound) and the expansions of the search
 #pragma unroll
       for (int s = 0; s < G2S_SEG_ASETS; s++) {
         const bool have = (uint32_t)s * 64u + (uint32_t)lane < nA;
         const uint32_t steps = have ? min(ar[s], (uint32_t)gd.right_half - al[s]) : 0u;
-        const uint32_t w0 = an[s] ^ 1u, idx = w0 >> 1;
-        alo[s] = have ? ((w0 & 1u) ? idx - steps : idx) : 1u;
-        ahi[s] = have ? ((w0 & 1u) ? idx : idx + steps) : 0u;
         if ((uint32_t)s * 64u < nA) {
-          nvis += wave_sum(have ? steps + 1u : 0u);  // (intervals of one unitig may overlap: an upper bound of the set's size)
+          nvis += wave_sum(have ? steps + 1u : 0u);
           xa += wave_sum(have ? min(steps + 1u, (uint32_t)gd.right_half - al[s]) : 0u);
         }
       }
+      // the merged intervals [alo, ahi]: lane l of set s holds the (64 s + l)-th; lanes without one an empty interval
+      const uint64_t* ivl = (const uint64_t*)(aq0 + 2u * ACAP);
+#pragma unroll
+      for (int s = 0; s < G2S_SEG_ASETS; s++) {
+        const uint32_t e = (uint32_t)s * 64u + (uint32_t)lane;
+        const uint64_t x = (!overflow && e < nM) ? ivl[e] : 1ull << 32;
+        alo[s] = (uint32_t)(x >> 32);
+        ahi[s] = (uint32_t)x;
+      }
+      lds_sync();
     }
   };
   unsigned long long cyc_a_end = cyc0;
@@ -569,63 +577,40 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
         if (keep_at[c] != G2S_DEV_INVALID) { cnode[keep_at[c]] = keep_n[c]; clab[keep_at[c]] = keep_l[c]; crem[keep_at[c]] = keep_r[c]; }
       lds_sync();
     }
-    // Q7 in the right set, conservatively as in the LDS tier: both strands of some k-mer are in it = an entry of
-    // each orientation with overlapping intervals.  Every lane keeps its (up to four) entries in registers and
-    // all lanes walk the list of intervals together (uniform LDS reads): a loop over the entries with a
-    // broadcast per entry from registers cost 350 cycles per entry, up to 50 k cycles of a 450 k-cycle gap.
-    if (!overflow && nA > 1u) {
+    // The entries as k-mer index intervals, sorted and merged in LDS (holes between any two): phase B's pruning test
+    // and the lengths of its runs then take ONE look at the list instead of following chains of overlapping entries,
+    // and the list is shorter (fewer 64-entry sets to ballot over per child).  Q7 in the right set, conservatively as
+    // in the LDS tier — both strands of some k-mer are in it = an entry of each orientation with overlapping
+    // intervals — falls out of the merge.
+    if (!overflow && nA > 0u) {
       const uint32_t* cnode = aq0;
       const uint32_t* clab = aq0 + ACAP;
       const uint32_t* crem = (const uint32_t*)lab;
-      uint64_t* ivl = (uint64_t*)(aq0 + 2u * ACAP);  // (the table-position queues are idle): first | last << 32
-      uint32_t mlo[G2S_SEG_ASETS], mhi[G2S_SEG_ASETS];
-      uint32_t n_odd = 0, n_even = 0;
-#pragma unroll
-      for (int q = 0; q < G2S_SEG_ASETS; q++) {
-        const uint32_t e = (uint32_t)q * 64u + (uint32_t)lane;
-        mlo[q] = 0xFFFFFFFFu; mhi[q] = 0u;  // (no entry: starts behind every interval)
+      uint64_t* ivl = (uint64_t*)(aq0 + 2u * ACAP);  // (the table-position queues are idle)
+      uint32_t n2 = 2u;
+      while (n2 < nA) n2 <<= 1;
+      for (uint32_t e = (uint32_t)lane; e < n2; e += 64u) {
+        uint64_t key = ~0ull;
         if (e < nA) {
           const uint32_t v = cnode[e];
           const uint32_t steps = min(crem[e], (uint32_t)gd.right_half - clab[e]);
           const uint32_t w0 = v ^ 1u, idx = w0 >> 1;
-          mlo[q] = (w0 & 1u) ? idx - steps : idx;
-          mhi[q] = ((w0 & 1u) ? idx : idx + steps) | ((v & 1u) << 31);
+          const uint32_t lo = (w0 & 1u) ? idx - steps : idx, hi = (w0 & 1u) ? idx : idx + steps;
+          key = ((uint64_t)lo << 32) | ((uint64_t)(v & 1u) << 31) | hi;
         }
-        n_odd += (uint32_t)__popcll(__ballot(e < nA && (mhi[q] >> 31)));
-        n_even += (uint32_t)__popcll(__ballot(e < nA && !(mhi[q] >> 31)));
+        ivl[e] = key;
       }
-      if (n_odd && n_even) {
-        // the intervals of the rarer orientation as a list; every lane tests its entries of the other one
-        const uint32_t minor = n_odd <= n_even ? 1u : 0u;
-        uint32_t m = 0;
-#pragma unroll
-        for (int q = 0; q < G2S_SEG_ASETS; q++) {
-          const uint32_t e = (uint32_t)q * 64u + (uint32_t)lane;
-          const bool put = e < nA && (mhi[q] >> 31) == minor;
-          const uint64_t pm = __ballot(put);
-          if (put) ivl[m + (uint32_t)__popcll(pm & below(lane))] = (uint64_t)mlo[q] | ((uint64_t)(mhi[q] & 0x7FFFFFFFu) << 32);
-          m += (uint32_t)__popcll(pm);
-          if (put || e >= nA) mlo[q] = 0xFFFFFFFFu;  // (only entries of the other orientation are tested below)
-          mhi[q] &= 0x7FFFFFFFu;
-        }
-        lds_sync();
-        bool hit = false;
-#pragma unroll 4
-        for (uint32_t e = 0; e < m; e++) {
-          const uint64_t x = ivl[e];
-          const uint32_t lo_e = (uint32_t)x, hi_e = (uint32_t)(x >> 32);
-#pragma unroll
-          for (int q = 0; q < G2S_SEG_ASETS; q++)
-            if ((uint32_t)q * 64u < nA) hit |= mlo[q] <= hi_e && lo_e <= mhi[q];
-        }
-        if (__ballot(hit)) flags |= G2S_DEV_Q7_A;
-      }
+      lds_sync();
+      lds_sort64(ivl, n2, lane);
+      bool cross = false;
+      nM = lds_merge_intervals(ivl, nA, lane, &cross);
+      if (cross) flags |= G2S_DEV_Q7_A;
       lds_sync();
     }
     cyc_a_end = __builtin_amdgcn_s_memtime();
     if constexpr (TWO) {  // wave 1 is done: what wave 0 needs to know, then the barrier it waits at
       if (lane == 0) {
-        ash[0] = nA; ash[1] = roundsA; ash[2] = flags; ash[3] = overflow ? 1u : 0u;
+        ash[0] = nA; ash[1] = roundsA; ash[2] = flags; ash[3] = overflow ? 1u : 0u; ash[9] = nM;
         ash[4] = (uint32_t)((cyc_a_end - cyc0) >> 8);
       }
       __syncthreads();
@@ -785,55 +770,40 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
       ivP = M ? 1u << (31 - __builtin_clz(M)) : 0u;
     }
   }
-  // k-mer index x in the right set?  (wave-uniform)
+  // k-mer index x in the right set?  (wave-uniform; BIG: iv_find below)
   auto contains = [&](uint32_t x) -> bool {
     uint64_t m = 0;
 #pragma unroll
     for (int s = 0; s < G2S_SEG_ASETS; s++)
-      if ((uint32_t)s * 64u < nA) m |= __ballot(alo[s] <= x) & __ballot(x <= ahi[s]);
+      if ((uint32_t)s * 64u < nM) m |= __ballot(alo[s] <= x) & __ballot(x <= ahi[s]);
     return m != 0;
   };
-  // largest y <= xmax with [x0, y] inside the right set (x0 - 1 when x0 is not in it)
+  // largest y <= xmax with [x0, y] inside the right set (x0 - 1 when x0 is not in it): the merged interval that holds
+  // x0 ends where the set's coverage ends
   auto covered_up = [&](uint32_t x0, uint32_t xmax) -> uint32_t {
-    uint32_t cur = x0;
-    while (cur <= xmax) {
-      uint32_t best = 0;
-      bool hit = false;
+    uint32_t h = 0;
+    bool hit = false;
 #pragma unroll
-      for (int s = 0; s < G2S_SEG_ASETS; s++) {
-        if ((uint32_t)s * 64u < nA) {
-          for (uint64_t m = ballot_and(alo[s] <= cur, cur <= ahi[s]); m; m &= m - 1) {
-            const uint32_t h = rl(ahi[s], __builtin_ctzll(m));
-            best = hit ? max(best, h) : h;
-            hit = true;
-          }
-        }
+    for (int s = 0; s < G2S_SEG_ASETS; s++) {
+      if ((uint32_t)s * 64u < nM) {
+        const uint64_t m = __ballot(alo[s] <= x0) & __ballot(x0 <= ahi[s]);
+        if (m) { h = rl(ahi[s], __builtin_ctzll(m)); hit = true; }
       }
-      if (!hit) break;
-      cur = best + 1u;
     }
-    return min(cur - 1u, xmax);
+    return hit ? min(h, xmax) : x0 - 1u;
   };
   // smallest y >= xmin with [y, x0] inside the right set (x0 + 1 when x0 is not in it)
   auto covered_down = [&](uint32_t x0, uint32_t xmin) -> uint32_t {
-    uint32_t cur = x0;
-    while (true) {
-      uint32_t best = 0;
-      bool hit = false;
+    uint32_t l = 0;
+    bool hit = false;
 #pragma unroll
-      for (int s = 0; s < G2S_SEG_ASETS; s++) {
-        if ((uint32_t)s * 64u < nA) {
-          for (uint64_t m = ballot_and(alo[s] <= cur, cur <= ahi[s]); m; m &= m - 1) {
-            const uint32_t lo_ = rl(alo[s], __builtin_ctzll(m));
-            best = hit ? min(best, lo_) : lo_;
-            hit = true;
-          }
-        }
+    for (int s = 0; s < G2S_SEG_ASETS; s++) {
+      if ((uint32_t)s * 64u < nM) {
+        const uint64_t m = __ballot(alo[s] <= x0) & __ballot(x0 <= ahi[s]);
+        if (m) { l = rl(alo[s], __builtin_ctzll(m)); hit = true; }
       }
-      if (!hit) return cur + 1u;
-      if (best <= xmin) return xmin;
-      cur = best - 1u;
     }
+    return hit ? max(l, xmin) : x0 + 1u;
   };
   const unsigned long long cyc1 = TWO ? cyc0 : __builtin_amdgcn_s_memtime();
   uint32_t cyc_a_kc = (uint32_t)((cyc_a_end - cyc0) >> 8);
@@ -851,7 +821,7 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
 #ifdef G2S_SEG_PROFILE
       const unsigned long long tw1 = __builtin_amdgcn_s_memtime();
 #endif
-      nA = ash[0]; roundsA = ash[1]; flags |= ash[2];
+      nA = ash[0]; roundsA = ash[1]; flags |= ash[2]; nM = ash[9];
       if (ash[3]) overflow = true;
       cyc_a_kc = ash[4];
       load_right_set();
