@@ -85,6 +85,19 @@ __device__ __forceinline__ uint32_t wave_scan(uint32_t x, int lane) {
   return x;
 }
 
+// inclusive prefix maximum over the lanes (unsigned values; the same six steps)
+__device__ __forceinline__ uint32_t wave_scan_max(uint32_t x) {
+  x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, false));
+  x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, false));
+  x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, false));
+  x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, false));
+  x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false));
+  x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false));
+  return x;
+}
+// the value of the lane below (lane 0: zero) — wave_shr:1
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138, 0xF, 0xF, false); }
+
 // ascending bitonic sort of n2 (a power of two >= 2) 64-bit keys in LDS by one wave
 __device__ __forceinline__ void lds_sort64(uint64_t* a, uint32_t n2, int lane) {
   for (uint32_t k = 2; k <= n2; k <<= 1)
@@ -111,13 +124,11 @@ __device__ __forceinline__ uint32_t lds_merge_intervals(uint64_t* a, uint32_t n,
     const bool h = i < n;
     const uint64_t key = h ? a[i] : 0ull;
     const uint32_t lo = (uint32_t)(key >> 32), hi = (uint32_t)key & 0x7FFFFFFFu, odd = ((uint32_t)key >> 31) & 1u;
-    uint32_t sa = h ? hi + 1u : 0u, se = (h && !odd) ? hi + 1u : 0u, so = (h && odd) ? hi + 1u : 0u;
-    for (int o = 1; o < 64; o <<= 1) {  // inclusive prefix maxima
-      const uint32_t ya = (uint32_t)__shfl_up((int)sa, o), ye = (uint32_t)__shfl_up((int)se, o), yo = (uint32_t)__shfl_up((int)so, o);
-      if (lane >= o) { sa = max(sa, ya); se = max(se, ye); so = max(so, yo); }
-    }
-    uint32_t xa = (uint32_t)__shfl_up((int)sa, 1), xe = (uint32_t)__shfl_up((int)se, 1), xo = (uint32_t)__shfl_up((int)so, 1);
-    if (lane == 0) { xa = 0u; xe = 0u; xo = 0u; }
+    // inclusive prefix maxima (inside the vector ALU: a shuffle through the LDS crossbar per step and value was most
+    // of this function), then the value of the lane below
+    const uint32_t sa = wave_scan_max(h ? hi + 1u : 0u), se = wave_scan_max((h && !odd) ? hi + 1u : 0u),
+                   so = wave_scan_max((h && odd) ? hi + 1u : 0u);
+    uint32_t xa = wave_shr1(sa), xe = wave_shr1(se), xo = wave_shr1(so);
     xa = max(xa, pm); xe = max(xe, pm_e); xo = max(xo, pm_o);   // over everything before element i
     if (__ballot(h && (odd ? xe : xo) > lo)) cr = true;          // an earlier interval of the other orientation ends at or after lo
     if (__ballot(h && xa > lo)) ov = true;                       // an earlier interval ends at or after lo
