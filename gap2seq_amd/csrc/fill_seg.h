@@ -51,6 +51,15 @@ hipError_t launch_fill_segx(hipStream_t st, uint32_t ngaps, uint32_t workgroups,
 
 // The large variant on a workgroup of eight waves per gap (fill_segw.hip): same arguments; the workgroups take all of a
 // compute unit's LDS, scratch: fill_segw_scratch_bytes().  resident: closures and records stay in device memory.
+// resident mode, deep lists: where g2s_fill_segw puts the closures the host will analyse the moment their gaps end
+// (SegArgs.early_*: device-visible pinned memory, the counters in device memory)
+struct SegEarly {
+  SegRec* segs = nullptr;
+  uint32_t* items = nullptr;  // eight words per item: {gap, segments (0: no room), offset, -, ready, -, -, -}
+  GapOut* outs = nullptr;
+  unsigned long long* ctr = nullptr;
+  uint32_t cap_items = 0, cap_segs = 0;
+};
 size_t fill_segw_lds_bytes();
 size_t fill_segw_scratch_bytes(uint32_t workgroups);
 hipError_t launch_fill_segw(hipStream_t st, uint32_t ngaps, uint32_t workgroups, const uint32_t* succ, const uint32_t* urec,
@@ -61,6 +70,6 @@ hipError_t launch_fill_segw(hipStream_t st, uint32_t ngaps, uint32_t workgroups,
                             // the number of listed gaps is read from device memory when the kernel starts (the list
                             // was written by the launch in front: launch_fill_seg's ovf_list); ngaps is then the most
                             // there can be
-                            const unsigned long long* ngaps_dev = nullptr);
+                            const unsigned long long* ngaps_dev = nullptr, const SegEarly* early = nullptr);
 
 }  // namespace g2s

@@ -67,6 +67,7 @@ enum {
   SH_PK, SH_BO_SB, SH_BO_XB, SH_NU, SH_ANYDN, SH_MU, SH_NC, SH_D2F, SH_D2V, SH_D2E,                             // 26-35
   SH_START0, SH_START1, SH_ST0, SH_ST1, SH_CHOICE, SH_NREC, SH_NSUB, SH_NXP, SH_HBASE_LO, SH_HBASE_HI,          // 36-45
   SH_NSEL, SH_NSEL1,                                                                                            // 46-47
+  SH_ESLOT, SH_EOFF,                                                                                            // 48-49 (the gap's item of the early hand-over, its segments' offset)
   SH_WORDS = 64
 };
 static_assert(SH_CS_LO % 2 == 0, "the 64-bit sum is 8-byte aligned");
@@ -1157,11 +1158,24 @@ __device__ __forceinline__ void segw_fill_one(uint32_t* lds, const SegArgs& A, c
   const uint32_t nrec = sh[SH_NREC], nsub = sh[SH_NSUB];
   const int count_s = (int)min(*(unsigned long long*)&sh[SH_CS_LO], (unsigned long long)G2S_DEV_MAX_PATHS);
   const uint32_t nres = 2u * nrec;  // in 16-byte units of the output buffer
+  // (a closure the host will analyse goes to pinned memory as well, now: see SegArgs.early_*)
+  const bool early = A.early_items != nullptr && want_s && !analysed && nrec > 0u;
   if (tid == 0) {
     const unsigned long long hb_ = atomicAdd(out_counter, (unsigned long long)nres);
     sh[SH_HBASE_LO] = (uint32_t)hb_; sh[SH_HBASE_HI] = (uint32_t)(hb_ >> 32);
+    sh[SH_ESLOT] = 0xFFFFFFFFu;
+    if (early) {
+      const unsigned long long slot = atomicAdd(&A.early_ctr[0], 1ull);
+      if (slot < (unsigned long long)A.early_cap_items) {
+        const unsigned long long so = atomicAdd(&A.early_ctr[1], (unsigned long long)nrec);
+        sh[SH_ESLOT] = (uint32_t)slot;
+        sh[SH_EOFF] = so + nrec <= (unsigned long long)A.early_cap_segs ? (uint32_t)so : 0xFFFFFFFFu;  // (no room: the item says so)
+      }
+    }
   }
   __syncthreads();
+  const uint32_t eslot = sh[SH_ESLOT], eoff = sh[SH_EOFF];
+  SegRec* edst = (eslot != 0xFFFFFFFFu && eoff != 0xFFFFFFFFu) ? A.early_segs + eoff : nullptr;
   const unsigned long long hbase = (unsigned long long)sh[SH_HBASE_LO] | ((unsigned long long)sh[SH_HBASE_HI] << 32);
   if (hbase + nres > out_cap) {  // the output buffer is full: the gap runs again in the LDS tier
     if (tid == 0) go->flags = flags | G2S_DEV_OVERFLOW_B | G2S_DEV_WHY_LOG;
@@ -1224,7 +1238,9 @@ __device__ __forceinline__ void segw_fill_one(uint32_t* lds, const SegArgs& A, c
         nxp += k > 1u ? k - 1u : 0u;
       }
       dst[s_aux[b]] = r;
+      if (edst) edst[s_aux[b]] = r;
     }
+    if (edst) __threadfence_system();  // (this thread's records are in host memory before the item says so)
     nxp = wave_sum(nxp);
     if (lane == 0 && nxp) atomicAdd(&sh[SH_NXP], nxp);
   }
@@ -1251,6 +1267,19 @@ __device__ __forceinline__ void segw_fill_one(uint32_t* lds, const SegArgs& A, c
     go->x_sub = nsub;
     go->stat[6] = gen;
     go->stat[7] = (uint32_t)((__builtin_amdgcn_s_memtime() - cyc2) >> 8);
+    if (eslot != 0xFFFFFFFFu) {  // the item: the gap's record, then what says it is complete
+      if (edst) {
+        static_assert(sizeof(GapOut) % 16 == 0, "GapOut is copied in 16-byte words");
+        __threadfence();  // (the record's words above: read back below)
+        const uint4* gs = (const uint4*)go;
+        uint4* gd4 = (uint4*)&A.early_outs[eslot];
+        for (uint32_t q = 0; q < sizeof(GapOut) / 16u; q++) gd4[q] = gs[q];
+      }
+      uint32_t* it = A.early_items + 8u * (size_t)eslot;
+      it[0] = gi; it[1] = edst ? nrec : 0u; it[2] = eoff; it[3] = 0u;
+      __threadfence_system();
+      __hip_atomic_store(&it[4], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 #ifdef G2S_SEGW_PROFILE
   if (dbg && tid == 0) {
@@ -1297,13 +1326,15 @@ hipError_t launch_fill_segw(hipStream_t st, uint32_t ngaps, uint32_t workgroups,
                             const GapDev* gaps, const uint32_t* gap_ids, const uint32_t* flank_nodes, SubRec* sub_out,
                             unsigned long long out_cap, unsigned long long* out_counter, GapOut* outs, GapOut* outs_host,
                             uint32_t* done_list, int skip_confident, uint32_t* dbg, uint32_t* scratch,
-                            unsigned long long* next_gap, bool resident, const unsigned long long* ngaps_dev) {
+                            unsigned long long* next_gap, bool resident, const unsigned long long* ngaps_dev, const SegEarly* early) {
   if (ngaps == 0) return hipSuccess;
   const size_t bytes = fill_segw_lds_bytes();
   hipError_t e = hipFuncSetAttribute((const void*)g2s_fill_segw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   if (e != hipSuccess) return e;
   SegArgs A = {succ, urec, gaps, gap_ids, flank_nodes, sub_out, out_cap, out_counter, outs, outs_host, done_list,
-               skip_confident, dbg, fill_segx_dbg_words(), nullptr, nullptr, 0u, 1u, resident ? 1u : 0u, 0u, nullptr};
+               skip_confident, dbg, fill_segx_dbg_words(), nullptr, nullptr, 0u, 1u, resident ? 1u : 0u, 0u, nullptr,
+               early ? early->segs : nullptr, early ? early->items : nullptr, early ? early->outs : nullptr,
+               early ? early->ctr : nullptr, early ? early->cap_items : 0u, early ? early->cap_segs : 0u};
   hipLaunchKernelGGL(g2s_fill_segw, dim3(workgroups), dim3(SEGW_NT), bytes, st, A, scratch, ngaps, next_gap, ngaps_dev);
   return hipGetLastError();
 }

@@ -570,6 +570,15 @@ struct g2s_session {
   bool team_sharded = false;     // this session's group of a team's list stays on its device through phase D3
   PinBuf h_d3;                   // D3Gap per gap | summary | stream window; staging of results / text when the caller's are not pinned
   PinBuf h_res, h_text, h_side;
+  // resident mode, deep lists: the closures the host analyses arrive while the large variant still runs (SegEarly):
+  // pinned items | GapOut copies | segments, the device's two counters, and what the analysis of an item leaves for
+  // its traceback behind phase D3's hand-over
+  PinBuf h_early;
+  DevBuf d_early_ctr;
+  SegEarly early_host;             // host pointers into h_early (cap_items 0: not in use for the list in flight)
+  std::vector<SubPrep> early_prep;
+  std::vector<std::vector<uint64_t>> early_scratch;
+  std::vector<int32_t> early_of_gap;  // by gap: its early item, or -1
   RandTables rtab;
   std::vector<uint32_t> res_ids, res_at;  // launch order of a resident list and its counting sort, kept between lists
   bool in_team_list = false;     // the session is filling a group of a team's list (team_resident)
@@ -711,6 +720,7 @@ extern "C" void g2s_session_destroy(g2s_session* s) {
   s->d_outs_all.release(); s->d_sub_all.release(); s->h_d3all.release();
   s->d_resout.release(); s->d_textout.release(); s->d_dgap.release(); s->d_sub.release(); s->d_d3.release(); s->d_rnd.release(); s->d_lastch.release(); s->d_rtab.release();
   s->h_d3.release(); s->h_res.release(); s->h_text.release(); s->h_side.release(); s->h_gfn.release();
+  s->h_early.release(); s->d_early_ctr.release();
   if (s->ev_rand) (void)hipEventDestroy(s->ev_rand);
   if (s->ev_segw) (void)hipEventDestroy(s->ev_segw);
   if (s->ev_chain) (void)hipEventDestroy(s->ev_chain);
@@ -2479,20 +2489,21 @@ static bool device_pointer_of(void* host, void** dev) {
 // One gap the device left to the host (D3HostItem): phase D2 on its closure segments (post.cpp), then its traceback
 // over the rand() values the device copied out for it.  False when the traceback did not draw what the device's
 // walk over the same closure counted (never expected: the list then takes the host path).
+// (pre: the closure was analysed when it arrived — SegEarly, over the same segments: only the traceback is left)
 static bool finish_gap_on_host(const Graph& g, const FillParams& fp, const GapJob& j, const GapOut& go, const SegRec* segs,
                                uint32_t n_segs, const uint32_t* rands, uint32_t expect_draws, uint64_t arena_off, char* arena,
-                               g2s_result* r) {
+                               g2s_result* r, const SubPrep* pre = nullptr) {
   memset(r, 0, sizeof *r);
   const auto t_fin0 = std::chrono::steady_clock::now();
   SubView v;
   v.out = &go; v.segs = segs; v.n_segs = n_segs;
   static thread_local SubPrep pp_store;  // (its vectors keep their storage from gap to gap)
   static thread_local std::vector<uint64_t> scratch;
-  SubPrep& pp = pp_store;
-  pp.reset();
-  if (scratch.size() < 3 * (size_t)n_segs + 1) scratch.resize(3 * (size_t)n_segs + 1);
+  SubPrep& pp = pre ? const_cast<SubPrep&>(*pre) : pp_store;
+  if (!pre) pp.reset();
+  if (!pre && scratch.size() < 3 * (size_t)n_segs + 1) scratch.resize(3 * (size_t)n_segs + 1);
   std::vector<SubRec> own;
-  if (!seg_analyze(fp, j, v, &pp, scratch.data())) {  // (G2S_STATE_D2: per-state records)
+  if (!pre && !seg_analyze(fp, j, v, &pp, scratch.data())) {  // (G2S_STATE_D2: per-state records)
     pp.reset();
     own.resize((size_t)go.n_sub + ((size_t)go.n_xp + 1) / 2 + 1);
     uint64_t* xp = (uint64_t*)(own.data() + go.n_sub);
@@ -2660,12 +2671,33 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl) {
   if (rl->timed) HIP_TRY(hipEventRecord(s->ev[2], st));
   // (the large variant for what the launch above listed: its workgroups read the list's length from device memory and
   // leave at once when it is empty — the usual case)
+  // (a deep list: the closures the host will analyse leave the large variant's gaps one by one, into pinned memory)
+  SegEarly early_dev;
+  s->early_host = SegEarly();
+  if (rerun && b->dmax >= 2500 && !s->in_team_list && !getenv("G2S_NO_EARLY_HANDOVER")) {
+    const size_t cap_items = n, cap_segs = (size_t)std::min<uint64_t>((uint64_t)n * 1024u, 2ull << 20) + 65536u;
+    const size_t b_items = (cap_items * 32 + 63) & ~(size_t)63, b_outs = (cap_items * sizeof(GapOut) + 63) & ~(size_t)63;
+    HIP_TRY(s->h_early.ensure(b_items + b_outs + cap_segs * sizeof(SegRec)));
+    HIP_TRY(s->d_early_ctr.ensure(16));
+    char* hp = (char*)s->h_early.p;
+    memset(hp, 0, b_items);  // (the ready words)
+    void* dp = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(&dp, hp, 0));
+    SegEarly& eh = s->early_host;
+    eh.items = (uint32_t*)hp; eh.outs = (GapOut*)(hp + b_items); eh.segs = (SegRec*)(hp + b_items + b_outs);
+    eh.cap_items = (uint32_t)cap_items; eh.cap_segs = (uint32_t)cap_segs;
+    early_dev = eh;
+    early_dev.items = (uint32_t*)dp; early_dev.outs = (GapOut*)((char*)dp + b_items); early_dev.segs = (SegRec*)((char*)dp + b_items + b_outs);
+    early_dev.ctr = (unsigned long long*)s->d_early_ctr.p;
+    HIP_TRY(hipMemsetAsync(s->d_early_ctr.p, 0, 16, st));
+  }
   if (rerun)
     HIP_TRY(launch_fill_segw(st, (uint32_t)ids.size(), segw_wgs, dg.succ, dg.urec, gaps_dev, (const uint32_t*)s->d_ovf.p,
                              (const uint32_t*)s->d_flank.p, (SubRec*)s->d_sub.p, (unsigned long long)out_states,
                              (unsigned long long*)s->d_counter.p, (GapOut*)s->d_outs.p, nullptr, nullptr,
                              s->params.skip_confident ? 1 : 0, nullptr, (uint32_t*)s->d_segx.p,
-                             (unsigned long long*)s->d_counter.p + 2, true, (const unsigned long long*)s->d_counter.p + 1));
+                             (unsigned long long*)s->d_counter.p + 2, true, (const unsigned long long*)s->d_counter.p + 1,
+                             early_dev.items ? &early_dev : nullptr));
   if (rerun && rl->timed) HIP_TRY(hipEventRecord(s->ev_segw, st));
   rl->units = out_states;
   rl->two_waves = two_waves;
@@ -2981,6 +3013,49 @@ static int resident_d3_wait(g2s_session* s, g2s_timing* tm_out, double* ms_d3_ou
     *fell_back = true;
     return G2S_OK;
   }
+  // ---- (a deep list) the closures that leave the large variant's gaps one by one (SegEarly): analysed as they come,
+  // by the pool, while this thread waits for the hand-over — the list's deepest closure, four thousand segments, is
+  // 0.4 ms of analysis that used to begin behind phase D3's front kernels
+  const SegEarly eh = s->early_host;
+  std::atomic<uint32_t> early_next(0);
+  std::atomic<int> early_done(0);
+  std::function<void(size_t)> early_worker;
+  bool early_posted = false;
+  // (not when the hand-over is there already — a list in flight that is ended late: every closure has arrived, and
+  // the whole pool takes them largest first below)
+  if (eh.cap_items && !stage_dev && L.groups.size() == 1 && s->pool->size() > 0 &&
+      __atomic_load_n(side_h.count, __ATOMIC_ACQUIRE) == ~0ull) {
+    s->early_of_gap.assign(n, -1);
+    if (s->early_prep.size() < eh.cap_items) { s->early_prep.resize(eh.cap_items); s->early_scratch.resize(eh.cap_items); }
+    early_worker = [&](size_t) {
+      for (;;) {
+        uint32_t idx = early_next.load(std::memory_order_acquire);
+        const bool ready = idx < eh.cap_items && __atomic_load_n(&eh.items[8 * (size_t)idx + 4], __ATOMIC_ACQUIRE) != 0u;
+        if (ready) {
+          if (!early_next.compare_exchange_weak(idx, idx + 1u)) continue;
+          const uint32_t gap = eh.items[8 * (size_t)idx], ns = eh.items[8 * (size_t)idx + 1], so = eh.items[8 * (size_t)idx + 2];
+          if (ns == 0u || gap >= n) continue;  // (no room for its segments: the hand-over brings them)
+          SubPrep& pp = s->early_prep[idx];
+          pp.reset();
+          std::vector<uint64_t>& sc = s->early_scratch[idx];
+          if (sc.size() < 3 * (size_t)ns + 1) sc.resize(3 * (size_t)ns + 1);
+          SubView v;
+          v.out = &eh.outs[idx]; v.segs = eh.segs + so; v.n_segs = ns;
+          if (seg_analyze(fp, L.groups[0]->jobs[gap], v, &pp, sc.data())) s->early_of_gap[gap] = (int32_t)idx;
+          continue;
+        }
+        if (early_done.load(std::memory_order_acquire)) {
+          // (the kernels are through: an item that is not complete now never will be)
+          idx = early_next.load(std::memory_order_acquire);
+          if (idx < eh.cap_items && __atomic_load_n(&eh.items[8 * (size_t)idx + 4], __ATOMIC_ACQUIRE) != 0u) continue;
+          return;
+        }
+        cpu_relax();
+      }
+    };
+    s->pool->post((size_t)std::min(s->pool->size(), 15), early_worker);
+    early_posted = true;
+  }
   for (unsigned spins = 0;; spins++) {
     handed = __atomic_load_n(side_h.count, __ATOMIC_ACQUIRE);
     if (handed != ~0ull) break;
@@ -2991,6 +3066,7 @@ static int resident_d3_wait(g2s_session* s, g2s_timing* tm_out, double* ms_d3_ou
     }
     cpu_relax();
   }
+  if (early_posted) { early_done.store(1, std::memory_order_release); s->pool->finish(); }
   const auto t_handed = std::chrono::steady_clock::now();
   std::atomic<int> host_bad(0);
   const size_t ni = (size_t)(handed & 0x7FFFFFFFFFFFFFFFull);
@@ -3013,9 +3089,13 @@ static int resident_d3_wait(g2s_session* s, g2s_timing* tm_out, double* ms_d3_ou
                    ~Lap() { if (on && h.n_segs >= 2000) fprintf(stderr, "[g2s] host-finished item %zu (gap %u): %u segments, %u draws: picked up %.3f ms after the hand-over, %.3f ms\n", x, h.gap, h.n_segs, h.draws,
                                                               std::chrono::duration<double, std::milli>(t0 - th).count(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); } }
           lap{t_one, t_handed, h, x, dbg_analysis_stats};
-      if (!finish_gap_on_host(g, fp, gb->jobs[loc], side_h.outs[x], side_h.segs + h.seg_off, h.n_segs, side_h.rnd + h.rnd_off, h.draws,
-                              (uint64_t)(L.group_arena[q] + gb->arena_off[loc]), text, &rs_host[h.gap]))
-        host_bad.fetch_add(1);
+      const int32_t ei = early_posted ? s->early_of_gap[h.gap] : -1;  // (analysed when it arrived: the traceback is left)
+      const bool ok = ei >= 0 && eh.items[8 * (size_t)ei + 1] == h.n_segs
+          ? finish_gap_on_host(g, fp, gb->jobs[loc], eh.outs[ei], eh.segs + eh.items[8 * (size_t)ei + 2], h.n_segs, side_h.rnd + h.rnd_off,
+                               h.draws, (uint64_t)(L.group_arena[q] + gb->arena_off[loc]), text, &rs_host[h.gap], &s->early_prep[(size_t)ei])
+          : finish_gap_on_host(g, fp, gb->jobs[loc], side_h.outs[x], side_h.segs + h.seg_off, h.n_segs, side_h.rnd + h.rnd_off, h.draws,
+                               (uint64_t)(L.group_arena[q] + gb->arena_off[loc]), text, &rs_host[h.gap]);
+      if (!ok) host_bad.fetch_add(1);
     };
     // (largest closures first: the hand-off kernel wrote every item's size before it said how many there are;
     // the last of a -dist-error 2000 list's 400 items to be picked up was its largest, a third of the wait)

@@ -182,6 +182,16 @@ struct SegArgs {
   // resident mode: a gap that outgrows the regular tier's capacities enters itself here (count: out_counter[1]); the
   // large variant follows on the stream and takes the list (fill_segw.hip) — the gap's results stay on the device too
   uint32_t* ovf_list;
+  // resident mode, deep lists (g2s_fill_segw): a closure the host will analyse (more than 192 segments, or a k-mer at
+  // two depths) also goes to pinned host memory the moment its gap ends — the host analyses it under the rest of the
+  // launch instead of behind phase D3's hand-over.  early_items: eight words per item {gap, segments, offset (two
+  // words), ready, -, -, -}, zero before the launch; early_ctr (device memory, zero before the launch): items and
+  // segments handed out.  All null: no early hand-over.
+  SegRec* early_segs;
+  uint32_t* early_items;
+  GapOut* early_outs;
+  unsigned long long* early_ctr;
+  uint32_t early_cap_items, early_cap_segs;
 };
 
 // LDS of the large variant (words): see the layout notes at each phase
