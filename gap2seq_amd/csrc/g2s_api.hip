@@ -564,6 +564,7 @@ struct g2s_session {
   g2s_timing last_timing;        // of the last g2s_fill_batch / g2s_batch_run (g2s_session_last_timing)
   // resident mode (run_resident): closures, phase D3 work areas and the rand() stream stay on the device
   DevBuf d_sub, d_d3, d_rnd, d_lastch, d_rtab, d_resout, d_textout, d_dgap;
+  DevBuf d_fstage;  // a long list's look-up descriptors and flank text, copied in front of the look-up kernel
   DevBuf d_outs_all, d_sub_all;  // lead of a team: the groups' records and closure records, gathered for phase D3
   PinBuf h_d3all;                // and the list's D3Gap array, summary and stream window
   PinBuf h_gfn;                  // a group of a sharded list: its group function (deviation behind it by deviation in front)
@@ -720,7 +721,7 @@ extern "C" void g2s_session_destroy(g2s_session* s) {
   s->d_outs_all.release(); s->d_sub_all.release(); s->h_d3all.release();
   s->d_resout.release(); s->d_textout.release(); s->d_dgap.release(); s->d_sub.release(); s->d_d3.release(); s->d_rnd.release(); s->d_lastch.release(); s->d_rtab.release();
   s->h_d3.release(); s->h_res.release(); s->h_text.release(); s->h_side.release(); s->h_gfn.release();
-  s->h_early.release(); s->d_early_ctr.release();
+  s->h_early.release(); s->d_early_ctr.release(); s->d_fstage.release();
   if (s->ev_rand) (void)hipEventDestroy(s->ev_rand);
   if (s->ev_segw) (void)hipEventDestroy(s->ev_segw);
   if (s->ev_chain) (void)hipEventDestroy(s->ev_chain);
@@ -1041,6 +1042,16 @@ int g2s_batch::upload_flanks() {
       e = hipHostGetDevicePointer(&d_desc, desc, 0);
       if (e == hipSuccess) e = hipHostGetDevicePointer(&d_text, text, 0);
       if (e == hipSuccess) e = hipHostGetDevicePointer(&d_nodes, nodes, 0);
+      // (a long list: descriptors and flank text go to device memory in one copy in front of the kernel — 10 000
+      // workgroups that each read their descriptor and then their text over the link are two round trips of the link
+      // each: 0.10 ms for config 3's list, against a 1.5 MB copy and a kernel that reads device memory)
+      if (e == hipSuccess && n_desc > 2048 && !getenv("G2S_FLANKS_OVER_THE_LINK")) {
+        const size_t bytes = (size_t)((const char*)nodes - (const char*)desc);  // [descriptors][text], contiguous
+        e = s->d_fstage.ensure(bytes);
+        if (e == hipSuccess) e = hipMemcpyAsync(s->d_fstage.p, desc, bytes, hipMemcpyHostToDevice, s->stream);
+        d_desc = s->d_fstage.p;
+        d_text = (char*)s->d_fstage.p + ((const char*)text - (const char*)desc);
+      }
       if (e == hipSuccess)
         e = launch_resolve_flanks(s->stream, s->lookup, (uint32_t)n_desc, (const FlankDesc*)d_desc, (const char*)d_text,
                                   (uint32_t*)s->d_flank.p, (uint32_t*)d_nodes);
