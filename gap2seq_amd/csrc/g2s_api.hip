@@ -50,6 +50,17 @@ static int fail(int code, const std::string& msg) { tl_error = msg; return code;
     if (e_ != hipSuccess)                                                                     \
       return fail(G2S_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));            \
   } while (0)
+// (resident mode: kernels of the list may be in flight on the session's streams and write the caller's pinned buffers
+// — an error return waits for them first)
+#define HIP_TRY_S(expr)                                                                       \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess) {                                                                   \
+      (void)hipStreamSynchronize(s->stream);                                                  \
+      (void)hipStreamSynchronize(s->stream2);                                                 \
+      return fail(G2S_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));            \
+    }                                                                                         \
+  } while (0)
 
 extern "C" int g2s_abi_version(void) { return G2S_ABI_VERSION; }
 extern "C" size_t g2s_backtrace_text(const g2s_gap* gap, const g2s_result* r, int k, char* out, size_t cap) {
@@ -2599,8 +2610,8 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl) {
   } else {
     for (size_t i = 0; i < n; i++) if (!b->jobs[i].bad_flank) ids.push_back((uint32_t)i);
   }
-  HIP_TRY(s->h_gaps.ensure(n * sizeof(GapDev) + n * 4 + 16));
-  HIP_TRY(s->h_d3.ensure(n * sizeof(D3Gap) + 2048 + 64 * 128 + G2S_RAND_WINDOW * 4));
+  HIP_TRY_S(s->h_gaps.ensure(n * sizeof(GapDev) + n * 4 + 16));
+  HIP_TRY_S(s->h_d3.ensure(n * sizeof(D3Gap) + 2048 + 64 * 128 + G2S_RAND_WINDOW * 4));
   GapDev* gd = (GapDev*)s->h_gaps.p;
   uint32_t* ids_pinned = (uint32_t*)(gd + n);
   if (!ids.empty()) memcpy(ids_pinned, ids.data(), ids.size() * 4);
@@ -2643,43 +2654,43 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl) {
   rl->segw = rerun;
   // 16-byte units: two per closure segment (the large variant's closures: thousands of segments)
   const uint64_t out_states = (uint64_t)ids.size() * 128u + 2u * G2S_SEG_CAP + (rerun ? std::min<uint64_t>((uint64_t)ids.size() * 8192u, 4ull << 20) + 2u * G2S_SEGX_CAP : 0u);
-  HIP_TRY(s->d_gaps.ensure(n * sizeof(GapDev)));
-  HIP_TRY(s->d_ids.ensure(std::max<size_t>(ids.size() * 4, 16)));
-  HIP_TRY(s->d_outs.ensure(n * sizeof(GapOut)));
-  HIP_TRY(s->d_counter.ensure(32));
-  HIP_TRY(s->d_sub.ensure(out_states * sizeof(SubRec)));
+  HIP_TRY_S(s->d_gaps.ensure(n * sizeof(GapDev)));
+  HIP_TRY_S(s->d_ids.ensure(std::max<size_t>(ids.size() * 4, 16)));
+  HIP_TRY_S(s->d_outs.ensure(n * sizeof(GapOut)));
+  HIP_TRY_S(s->d_counter.ensure(32));
+  HIP_TRY_S(s->d_sub.ensure(out_states * sizeof(SubRec)));
   const uint32_t segw_wgs = (uint32_t)std::min<size_t>(ids.size(), (size_t)std::max(1, s->num_cus));
   if (rerun) {
-    HIP_TRY(s->d_ovf.ensure(std::max<size_t>(ids.size() * 4, 16)));
-    HIP_TRY(s->d_segx.ensure(fill_segw_scratch_bytes(segw_wgs)));
+    HIP_TRY_S(s->d_ovf.ensure(std::max<size_t>(ids.size() * 4, 16)));
+    HIP_TRY_S(s->d_segx.ensure(fill_segw_scratch_bytes(segw_wgs)));
   }
   hipStream_t st = s->stream;
   void* d_gaps_host = nullptr;
-  HIP_TRY(hipHostGetDevicePointer(&d_gaps_host, s->h_gaps.p, 0));
+  HIP_TRY_S(hipHostGetDevicePointer(&d_gaps_host, s->h_gaps.p, 0));
   const GapDev* gaps_dev = (const GapDev*)d_gaps_host;
   const uint32_t* ids_dev = (const uint32_t*)(gaps_dev + n);
   // (long lists: descriptors and launch order go to device memory in front of the kernel — read over the link by
   // 10 000 starting waves they cost config 3's launch 0.04 ms: 0.365 against 0.324 ms; short lists read them over the link)
   if (ids.size() > 2048) {
-    HIP_TRY(hipMemcpyAsync(s->d_gaps.p, gd, n * sizeof(GapDev), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(s->d_ids.p, ids_pinned, ids.size() * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY_S(hipMemcpyAsync(s->d_gaps.p, gd, n * sizeof(GapDev), hipMemcpyHostToDevice, st));
+    HIP_TRY_S(hipMemcpyAsync(s->d_ids.p, ids_pinned, ids.size() * 4, hipMemcpyHostToDevice, st));
     gaps_dev = (const GapDev*)s->d_gaps.p;
     ids_dev = (const uint32_t*)s->d_ids.p;
   }
-  if (s->d_outs.clean < n * sizeof(GapOut)) HIP_TRY(hipMemsetAsync(s->d_outs.p, 0, n * sizeof(GapOut), st));
-  if (s->d_counter.clean < 32) HIP_TRY(hipMemsetAsync(s->d_counter.p, 0, 32, st));
+  if (s->d_outs.clean < n * sizeof(GapOut)) HIP_TRY_S(hipMemsetAsync(s->d_outs.p, 0, n * sizeof(GapOut), st));
+  if (s->d_counter.clean < 32) HIP_TRY_S(hipMemsetAsync(s->d_counter.p, 0, 32, st));
   s->d_outs.clean = 0;
   s->d_counter.clean = 0;
   // (two waves per gap when the launch is short enough to end with its slowest gap — unless the sessions of a team
   // share this device: the chip is then as full as one long launch makes it)
   const bool two_waves = getenv("G2S_SEG_WAVES") ? atoi(getenv("G2S_SEG_WAVES")) == 2 : (ids.size() <= 2048 && !s->team_shares_device);
   rl->timed = kernel_events_on(s);
-  if (rl->timed) HIP_TRY(hipEventRecord(s->ev[1], st));
-  HIP_TRY(launch_fill_seg(st, (uint32_t)ids.size(), dg.succ, dg.urec, gaps_dev, ids_dev, (const uint32_t*)s->d_flank.p,
+  if (rl->timed) HIP_TRY_S(hipEventRecord(s->ev[1], st));
+  HIP_TRY_S(launch_fill_seg(st, (uint32_t)ids.size(), dg.succ, dg.urec, gaps_dev, ids_dev, (const uint32_t*)s->d_flank.p,
                           (SubRec*)s->d_sub.p, (unsigned long long)out_states, (unsigned long long*)s->d_counter.p,
                           (GapOut*)s->d_outs.p, nullptr, nullptr, s->params.skip_confident ? 1 : 0, nullptr, two_waves,
                           nullptr, nullptr, 0u, 1u, true, rerun ? (uint32_t*)s->d_ovf.p : nullptr));
-  if (rl->timed) HIP_TRY(hipEventRecord(s->ev[2], st));
+  if (rl->timed) HIP_TRY_S(hipEventRecord(s->ev[2], st));
   // (the large variant for what the launch above listed: its workgroups read the list's length from device memory and
   // leave at once when it is empty — the usual case)
   // (a deep list: the closures the host will analyse leave the large variant's gaps one by one, into pinned memory)
@@ -2688,28 +2699,28 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl) {
   if (rerun && b->dmax >= 2500 && !s->in_team_list && !getenv("G2S_NO_EARLY_HANDOVER")) {
     const size_t cap_items = n, cap_segs = (size_t)std::min<uint64_t>((uint64_t)n * 1024u, 2ull << 20) + 65536u;
     const size_t b_items = (cap_items * 32 + 63) & ~(size_t)63, b_outs = (cap_items * sizeof(GapOut) + 63) & ~(size_t)63;
-    HIP_TRY(s->h_early.ensure(b_items + b_outs + cap_segs * sizeof(SegRec)));
-    HIP_TRY(s->d_early_ctr.ensure(16));
+    HIP_TRY_S(s->h_early.ensure(b_items + b_outs + cap_segs * sizeof(SegRec)));
+    HIP_TRY_S(s->d_early_ctr.ensure(16));
     char* hp = (char*)s->h_early.p;
     memset(hp, 0, b_items);  // (the ready words)
     void* dp = nullptr;
-    HIP_TRY(hipHostGetDevicePointer(&dp, hp, 0));
+    HIP_TRY_S(hipHostGetDevicePointer(&dp, hp, 0));
     SegEarly& eh = s->early_host;
     eh.items = (uint32_t*)hp; eh.outs = (GapOut*)(hp + b_items); eh.segs = (SegRec*)(hp + b_items + b_outs);
     eh.cap_items = (uint32_t)cap_items; eh.cap_segs = (uint32_t)cap_segs;
     early_dev = eh;
     early_dev.items = (uint32_t*)dp; early_dev.outs = (GapOut*)((char*)dp + b_items); early_dev.segs = (SegRec*)((char*)dp + b_items + b_outs);
     early_dev.ctr = (unsigned long long*)s->d_early_ctr.p;
-    HIP_TRY(hipMemsetAsync(s->d_early_ctr.p, 0, 16, st));
+    HIP_TRY_S(hipMemsetAsync(s->d_early_ctr.p, 0, 16, st));
   }
   if (rerun)
-    HIP_TRY(launch_fill_segw(st, (uint32_t)ids.size(), segw_wgs, dg.succ, dg.urec, gaps_dev, (const uint32_t*)s->d_ovf.p,
+    HIP_TRY_S(launch_fill_segw(st, (uint32_t)ids.size(), segw_wgs, dg.succ, dg.urec, gaps_dev, (const uint32_t*)s->d_ovf.p,
                              (const uint32_t*)s->d_flank.p, (SubRec*)s->d_sub.p, (unsigned long long)out_states,
                              (unsigned long long*)s->d_counter.p, (GapOut*)s->d_outs.p, nullptr, nullptr,
                              s->params.skip_confident ? 1 : 0, nullptr, (uint32_t*)s->d_segx.p,
                              (unsigned long long*)s->d_counter.p + 2, true, (const unsigned long long*)s->d_counter.p + 1,
                              early_dev.items ? &early_dev : nullptr));
-  if (rerun && rl->timed) HIP_TRY(hipEventRecord(s->ev_segw, st));
+  if (rerun && rl->timed) HIP_TRY_S(hipEventRecord(s->ev_segw, st));
   rl->units = out_states;
   rl->two_waves = two_waves;
   rl->launched = ids.size();
@@ -2800,10 +2811,14 @@ static int resident_d3_launch(g2s_session* s, const ResidentList& L, bool timed,
   const Graph& g = *s->graph->g;
   const FillParams fp = fill_params_of(s);
   const auto t_enter = std::chrono::steady_clock::now();
+  // What phase D3's kernels are built for, checked for the LIST (a team's list is the sum of its groups, and a slice
+  // grows beyond its size while a skip rule chains its gaps): 32-bit prefix sums over at most 20 480 gaps of at most
+  // 12 000 draws each, the stream below 2^31 values.  Anything else is the host path's.
+  if (n > 20480 || L.dmax > 12000 || rand_capacity(L.rnd_cap) >= (1ull << 31)) return 1;
   if (hipSetDevice(s->device) != hipSuccess) return fail(G2S_ERR_NO_DEVICE, "cannot select device");
   D3Summary* hsum = (D3Summary*)((char*)L.pin->p + n * sizeof(D3Gap) + 16 - (n * sizeof(D3Gap)) % 16);
   const size_t rnd_cap = rand_capacity(L.rnd_cap);
-  HIP_TRY(s->d_d3.ensure(d3_work_bytes((uint32_t)n)));
+  HIP_TRY_S(s->d_d3.ensure(d3_work_bytes((uint32_t)n)));
   // what the hand-off kernel gives the host for the gaps whose closure the host analyses (a fraction of a per cent of a list)
   D3Side side, side_h;
   {
@@ -2815,7 +2830,7 @@ static int resident_d3_launch(g2s_session* s, const ResidentList& L, bool timed,
     const size_t b_items = (n * sizeof(D3HostItem) + 63) & ~(size_t)63, b_outs = (n * sizeof(GapOut) + 63) & ~(size_t)63;
     const size_t b_segs = side_h.cap_segs * sizeof(SegRec);
     const void* side_was = s->h_side.p;
-    HIP_TRY(s->h_side.ensure(b_items + b_outs + b_segs + side_h.cap_rnd * 4 + 128));
+    HIP_TRY_S(s->h_side.ensure(b_items + b_outs + b_segs + side_h.cap_rnd * 4 + 128));
     if (s->h_side.p != side_was) s->side_dirty = SIZE_MAX;  // (fresh memory: every ready word is to be zeroed)
     char* hp = (char*)s->h_side.p;
     side_h.items = (D3HostItem*)hp; side_h.outs = (GapOut*)(hp + b_items); side_h.segs = (SegRec*)(hp + b_items + b_outs);
@@ -2832,7 +2847,7 @@ static int resident_d3_launch(g2s_session* s, const ResidentList& L, bool timed,
     s->side_layout_n = n;
     s->side_dirty = n;  // (until this list is through: any of them may be written)
     void* dp = nullptr;
-    HIP_TRY(hipHostGetDevicePointer(&dp, s->h_side.p, 0));
+    HIP_TRY_S(hipHostGetDevicePointer(&dp, s->h_side.p, 0));
     side = side_h;
     side.items = (D3HostItem*)dp; side.outs = (GapOut*)((char*)dp + b_items); side.segs = (SegRec*)((char*)dp + b_items + b_outs);
     side.rnd = (uint32_t*)((char*)dp + b_items + b_outs + b_segs);
@@ -2848,23 +2863,23 @@ static int resident_d3_launch(g2s_session* s, const ResidentList& L, bool timed,
   bool res_direct = !stage_dev && device_pointer_of(results, &res_dev);
   bool arena_direct = !stage_dev && (L.arena_bytes == 0 || device_pointer_of(arena, &arena_dev));
   if (stage_dev) {
-    HIP_TRY(s->d_resout.ensure(n * sizeof(g2s_result)));
-    HIP_TRY(s->d_textout.ensure(L.arena_bytes + 16));
+    HIP_TRY_S(s->d_resout.ensure(n * sizeof(g2s_result)));
+    HIP_TRY_S(s->d_textout.ensure(L.arena_bytes + 16));
     res_dev = s->d_resout.p;
     arena_dev = s->d_textout.p;
     res_direct = arena_direct = true;
   }
   if (!res_direct && !stage_dev) {
-    HIP_TRY(s->h_res.ensure(n * sizeof(g2s_result)));
-    HIP_TRY(hipHostGetDevicePointer(&res_dev, s->h_res.p, 0));
+    HIP_TRY_S(s->h_res.ensure(n * sizeof(g2s_result)));
+    HIP_TRY_S(hipHostGetDevicePointer(&res_dev, s->h_res.p, 0));
   }
   if (!arena_direct && !stage_dev) {
-    HIP_TRY(s->h_text.ensure(L.arena_bytes + 16));
-    HIP_TRY(hipHostGetDevicePointer(&arena_dev, s->h_text.p, 0));
+    HIP_TRY_S(s->h_text.ensure(L.arena_bytes + 16));
+    HIP_TRY_S(hipHostGetDevicePointer(&arena_dev, s->h_text.p, 0));
   }
   hipStream_t st = s->stream;
   void* d_dgaps = nullptr;
-  HIP_TRY(hipHostGetDevicePointer(&d_dgaps, L.pin->p, 0));
+  HIP_TRY_S(hipHostGetDevicePointer(&d_dgaps, L.pin->p, 0));
   // the rand() values the list can draw (a team's list: generated here, beside the copies of the groups' records;
   // a group of a sharded list: in its second step, when its place in the stream is known)
   if (!rand_launched && !sharded) { const int rc = resident_rand(s, L.pin, n, L.rnd_cap, chain_from); if (rc != G2S_OK) return rc; }
@@ -2873,10 +2888,10 @@ static int resident_d3_launch(g2s_session* s, const ResidentList& L, bool timed,
   // 160 KB copy beside the fill kernel cost that kernel 4 %)
   const bool dgap_on_device = n <= 3072 && !sharded;
   if (dgap_on_device) {
-    HIP_TRY(s->d_dgap.ensure(n * sizeof(D3Gap) + 16));
-    HIP_TRY(hipMemcpyAsync(s->d_dgap.p, L.pin->p, n * sizeof(D3Gap), hipMemcpyHostToDevice, s->stream2));
+    HIP_TRY_S(s->d_dgap.ensure(n * sizeof(D3Gap) + 16));
+    HIP_TRY_S(hipMemcpyAsync(s->d_dgap.p, L.pin->p, n * sizeof(D3Gap), hipMemcpyHostToDevice, s->stream2));
   }
-  if (!sharded) HIP_TRY(hipEventRecord(s->ev_rand, s->stream2));
+  if (!sharded) HIP_TRY_S(hipEventRecord(s->ev_rand, s->stream2));
   // (The fill kernel runs for hundreds of microseconds, the stream's work for tens: this thread waits for the
   // latter here instead of putting a wait for it into the main stream — that packet, between the fill kernel and
   // the first kernel of phase D3, cost the list 5 us.  Only if the other stream is late does the main one wait.)
@@ -2886,15 +2901,15 @@ static int resident_d3_launch(g2s_session* s, const ResidentList& L, bool timed,
     while (!no_spin && !sharded && (q = hipEventQuery(s->ev_rand)) == hipErrorNotReady &&
            std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_w).count() < 200.0)
       cpu_relax();
-    if (q != hipSuccess && !sharded) HIP_TRY(hipStreamWaitEvent(st, s->ev_rand, 0));
+    if (q != hipSuccess && !sharded) HIP_TRY_S(hipStreamWaitEvent(st, s->ev_rand, 0));
   }
   // (the time of phase D3's kernels: from the end of this session's fill kernel, or — a team's list — from here)
   // (one batch on this session: the event behind its fill kernel; a team's list: an event of its own — the lead
   // may not have launched a fill kernel at all)
   hipEvent_t d3_begin = s->ev[2];
-  if (L.ready) HIP_TRY(hipStreamWaitEvent(st, L.ready, 0));
+  if (L.ready) HIP_TRY_S(hipStreamWaitEvent(st, L.ready, 0));
   if (timed && !(L.groups.size() == 1 && L.outs_dev == (const GapOut*)s->d_outs.p)) {
-    HIP_TRY(hipEventRecord(s->ev[0], st));
+    HIP_TRY_S(hipEventRecord(s->ev[0], st));
     d3_begin = s->ev[0];
   }
   D3Params P;
@@ -2914,19 +2929,19 @@ static int resident_d3_launch(g2s_session* s, const ResidentList& L, bool timed,
   P.seg_cap = fp.skip_confident ? G2S_SEG_CAP : 192u;
   P.map_cap = ((uint32_t)L.dmax + 2u + 3u) & ~3u;
   if (sharded) {
-    HIP_TRY(launch_d3_sharded_classes(st, P, W, L.outs_dev, (const D3Gap*)d_dgaps, s->d_d3.clean >= 1024 + 64 * 128));
-    HIP_TRY(hipMemcpyAsync(hsum, W.sum, sizeof(D3Summary), hipMemcpyDeviceToHost, st));  // (the group's totals)
+    HIP_TRY_S(launch_d3_sharded_classes(st, P, W, L.outs_dev, (const D3Gap*)d_dgaps, s->d_d3.clean >= 1024 + 64 * 128));
+    HIP_TRY_S(hipMemcpyAsync(hsum, W.sum, sizeof(D3Summary), hipMemcpyDeviceToHost, st));  // (the group's totals)
   } else
-  HIP_TRY(launch_d3(st, P, W, L.gaps_dev, L.outs_dev, dgap_on_device ? (const D3Gap*)s->d_dgap.p : (const D3Gap*)d_dgaps, L.sub_dev,
+  HIP_TRY_S(launch_d3(st, P, W, L.gaps_dev, L.outs_dev, dgap_on_device ? (const D3Gap*)s->d_dgap.p : (const D3Gap*)d_dgaps, L.sub_dev,
                     (const char*)s->d_lastch.p, (const char*)s->d_lastch.p + g.n, s->rtab, (uint32_t*)s->d_rnd.p,
                     (uint64_t)rnd_cap, res_dev, (char*)arena_dev, side, (char*)d_dgaps + ((char*)hsum - (char*)L.pin->p),
                     s->d_d3.clean >= 1024 + 64 * 128, self_clean ? (uint32_t*)s->d_counter.p : nullptr,
                     no_spin ? s->ev_chain : nullptr /* (lists in flight: the next one's stream may wait for it) */));
   s->d_d3.clean = 0;
-  if (timed && !sharded) HIP_TRY(hipEventRecord(s->ev[3], st));
+  if (timed && !sharded) HIP_TRY_S(hipEventRecord(s->ev[3], st));
   if (stage_dev && !sharded) {
-    HIP_TRY(hipMemcpyAsync(results, s->d_resout.p, n * sizeof(g2s_result), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(arena, s->d_textout.p, L.arena_bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY_S(hipMemcpyAsync(results, s->d_resout.p, n * sizeof(g2s_result), hipMemcpyDeviceToHost, st));
+    HIP_TRY_S(hipMemcpyAsync(arena, s->d_textout.p, L.arena_bytes, hipMemcpyDeviceToHost, st));
   }
   {
     D3Pending* dp = new D3Pending;
@@ -2953,22 +2968,22 @@ static int resident_d3_sharded_tables(g2s_session* s, uint32_t base0, uint32_t R
   {  // the stream: window from the lead's generator, then g2s_rand_fill on the second stream; the main one waits for it
     char* hsum_c = (char*)dp->hsum;
     uint32_t* hwin = (uint32_t*)(hsum_c + 1024 + 64 * 128);
-    HIP_TRY(s->d_rnd.ensure((31 + rnd_cap + 64) * 4));
+    HIP_TRY_S(s->d_rnd.ensure((31 + rnd_cap + 64) * 4));
     memcpy(hwin, win, G2S_RAND_WINDOW * 4);
-    HIP_TRY(hipMemcpyAsync(s->d_rnd.p, hwin, G2S_RAND_WINDOW * 4, hipMemcpyHostToDevice, s->stream2));
-    HIP_TRY(launch_rand_fill(s->stream2, (uint32_t*)s->d_rnd.p, s->rtab, nullptr, (uint64_t)rnd_cap, (uint64_t)base0));
-    HIP_TRY(hipEventRecord(s->ev_rand, s->stream2));
-    HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_rand, 0));
+    HIP_TRY_S(hipMemcpyAsync(s->d_rnd.p, hwin, G2S_RAND_WINDOW * 4, hipMemcpyHostToDevice, s->stream2));
+    HIP_TRY_S(launch_rand_fill(s->stream2, (uint32_t*)s->d_rnd.p, s->rtab, nullptr, (uint64_t)rnd_cap, (uint64_t)base0));
+    HIP_TRY_S(hipEventRecord(s->ev_rand, s->stream2));
+    HIP_TRY_S(hipStreamWaitEvent(s->stream, s->ev_rand, 0));
   }
-  HIP_TRY(s->h_gfn.ensure(((size_t)R0 + 64) * 4));
+  HIP_TRY_S(s->h_gfn.ensure(((size_t)R0 + 64) * 4));
   dp->group_fn = (uint32_t*)s->h_gfn.p;
   void* gd = nullptr;
-  HIP_TRY(hipHostGetDevicePointer(&gd, s->h_gfn.p, 0));
+  HIP_TRY_S(hipHostGetDevicePointer(&gd, s->h_gfn.p, 0));
   dp->group_fn_dev = (uint32_t*)gd;
   dp->P.base0 = base0; dp->P.R0 = R0;
-  HIP_TRY(launch_d3_sharded_tables(s->stream, dp->P, dp->W, dp->L.outs_dev, dp->L.sub_dev, (uint32_t*)s->d_rnd.p, (uint64_t)rnd_cap,
+  HIP_TRY_S(launch_d3_sharded_tables(s->stream, dp->P, dp->W, dp->L.outs_dev, dp->L.sub_dev, (uint32_t*)s->d_rnd.p, (uint64_t)rnd_cap,
                                    dp->group_fn_dev));
-  HIP_TRY(hipMemcpyAsync(dp->hsum, dp->W.sum, sizeof(D3Summary), hipMemcpyDeviceToHost, s->stream));  // (the status behind the offsets)
+  HIP_TRY_S(hipMemcpyAsync(dp->hsum, dp->W.sum, sizeof(D3Summary), hipMemcpyDeviceToHost, s->stream));  // (the status behind the offsets)
   (void)n;
   return G2S_OK;
 }
@@ -2980,10 +2995,10 @@ static int resident_d3_sharded_trace(g2s_session* s, uint32_t d_in) {
   const Graph& g = *s->graph->g;
   dp->P.d_in = d_in;
   *(volatile unsigned long long*)dp->side_h.count = ~0ull;
-  HIP_TRY(launch_d3_sharded_trace(s->stream, dp->P, dp->W, dp->L.outs_dev, dp->L.sub_dev, (const char*)s->d_lastch.p,
+  HIP_TRY_S(launch_d3_sharded_trace(s->stream, dp->P, dp->W, dp->L.outs_dev, dp->L.sub_dev, (const char*)s->d_lastch.p,
                                   (const char*)s->d_lastch.p + g.n, (uint32_t*)s->d_rnd.p, (uint64_t)dp->rnd_cap, dp->res_dev,
                                   dp->arena_dev, dp->side_dev, dp->summary_dev));
-  if (dp->timed) HIP_TRY(hipEventRecord(s->ev[3], s->stream));
+  if (dp->timed) HIP_TRY_S(hipEventRecord(s->ev[3], s->stream));
   dp->t_launched = std::chrono::steady_clock::now();
   return G2S_OK;
 }
@@ -3015,8 +3030,8 @@ static int resident_d3_wait(g2s_session* s, g2s_timing* tm_out, double* ms_d3_ou
   // Should the kernels end without saying so — never expected — the stream's end is noticed instead.)
   unsigned long long handed = ~0ull;
   if (dpp->discard) {  // (nothing of this attempt counts: its kernels drew from a stream that was not the list's)
-    HIP_TRY(hipStreamSynchronize(st));
-    if (!self_clean) HIP_TRY(hipMemsetAsync(W.sum, 0, 1024 + 64 * 128, st));
+    HIP_TRY_S(hipStreamSynchronize(st));
+    if (!self_clean) HIP_TRY_S(hipMemsetAsync(W.sum, 0, 1024 + 64 * 128, st));
     s->d_d3.clean = 1024 + 64 * 128;
     s->self_cleaned = self_clean && hsum->status == 0;
     s->side_dirty = SIZE_MAX;
@@ -3135,14 +3150,14 @@ static int resident_d3_wait(g2s_session* s, g2s_timing* tm_out, double* ms_d3_ou
     }
   }
   const auto t_finished = std::chrono::steady_clock::now();
-  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY_S(hipStreamSynchronize(st));
   const auto t_synced = std::chrono::steady_clock::now();
   float ms_d3 = 0;
-  if (timed) HIP_TRY(hipEventElapsedTime(&ms_d3, d3_begin, s->ev[3]));
+  if (timed) HIP_TRY_S(hipEventElapsedTime(&ms_d3, d3_begin, s->ev[3]));
   *ms_d3_out = ms_d3;
   if (getenv("G2S_DEBUG")) {  // the kernels' lap stamps (d3_device.hip: stamp), 100 MHz
     unsigned long long lp[24];
-    HIP_TRY(hipMemcpy(lp, (char*)W.sum + 512, sizeof lp, hipMemcpyDeviceToHost));
+    HIP_TRY_S(hipMemcpy(lp, (char*)W.sum + 512, sizeof lp, hipMemcpyDeviceToHost));
     auto us = [&](int a, int b) { return lp[a] && lp[b] ? ((double)lp[b] - (double)lp[a]) / 100.0 : -1.0; };
     fprintf(stderr, "[g2s] phase D3 laps (us): front classify %.1f scan %.1f | to tables %.1f: status %.1f records %.1f closure %.1f walks %.1f | to back %.1f: tables into LDS %.1f chain %.1f hand-off %.1f fence %.1f | to trace %.1f, longest wave: to closure %.1f walk %.1f bases %.1f all %.1f, first entry to last end %.1f\n",
             us(0, 1), us(1, 2), us(2, 3), us(3, 4), us(4, 5), us(5, 6), us(6, 7), us(7, 8), us(8, 9), us(9, 10), us(10, 11), us(11, 12), us(12, 13),
@@ -3151,7 +3166,7 @@ static int resident_d3_wait(g2s_session* s, g2s_timing* tm_out, double* ms_d3_ou
     fprintf(stderr, "[g2s] the wave with the longest walk: %.1f us, %llu segments entered in %.1f us\n", (double)(lp[19] >> 32) / 100.0, (lp[19] >> 16) & 0xFFFF, (double)(lp[19] & 0xFFFF) / 100.0);
   }
   // (the summary is zero again for the next list: the trace kernel did it, or a memset now, off the critical path)
-  if (!self_clean) HIP_TRY(hipMemsetAsync(W.sum, 0, 1024 + 64 * 128, st));
+  if (!self_clean) HIP_TRY_S(hipMemsetAsync(W.sum, 0, 1024 + 64 * 128, st));
   s->d_d3.clean = 1024 + 64 * 128;
   s->self_cleaned = self_clean && hsum->status == 0;  // (a list the kernels gave up on: its waves left early)
   for (int q = 0; q < 64; q++)  // (bits 40 and up count the trace kernel's waves: d3_device.hip)
