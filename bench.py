@@ -258,7 +258,7 @@ def main():
                          "for all of them")
     ap.add_argument("--in-flight", type=int, default=3, help="--stream-lists: lists begun and not ended (2 or 3)")
     ap.add_argument("--stream-lists", type=int, default=0,
-                    help="N=1: also measure K consecutive lists of the workload with two in flight (g2s_fill_begin / "
+                    help="N=1: also measure K consecutive lists of the workload with --in-flight of them in flight (g2s_fill_begin / "
                          "g2s_fill_end) against the same K lists one at a time; reported as `stream_lists`")
     ap.add_argument("--dry-run", action="store_true",
                     help="testing only (CPU): the launch protocol — rendezvous, barriers, timing reduction, one JSON "
@@ -447,14 +447,14 @@ def main():
                          roofline_frac=round(ab3 / (kms3 / 1e3) / 1e9 / HBM_PEAK_GBS, 6) if ab3 is not None else None,
                          filled=sum(1 for r in r3.results() if r.count > 0))
 
-    # ---- N=1: K consecutive lists, two in flight, against the same lists one at a time ---------------
+    # ---- N=1: K consecutive lists, --in-flight of them in flight, against the same lists one at a time ---------------
     stream_lists = None
     if ngpu == 1 and len(sessions) == 1 and args.stream_lists >= 2:
         sr = StreamRunner(P, sessions[0], gaps, args.stream_lists, not args.pageable_buffers, args.in_flight)
         _, want = sr.run(False, keep=True)
         _, got = sr.run(True, keep=True)
         if got != want:
-            raise SystemExit("bench.py: %d lists with two in flight differ from the lists one at a time" % args.stream_lists)
+            raise SystemExit("bench.py: %d lists in flight differ from the lists one at a time" % args.stream_lists)
         reps = max(3, min(steps, 10))
         for _ in range(2):
             sr.run(True)
@@ -467,7 +467,7 @@ def main():
                             value=round(tot / t_ov, 2), unit="gaps/s", ms_per_list=round(t_ov / (args.stream_lists * reps) * 1e3, 4),
                             one_list_at_a_time=round(tot / t_seq, 2), ms_per_list_one_at_a_time=round(t_seq / (args.stream_lists * reps) * 1e3, 4),
                             results="identical to the lists one at a time, list by list (checked in this run)",
-                            how="g2s_fill_begin(list i+1) before g2s_fill_end(list i): look-ups and fill kernel of the next list run while this one's phase D3 writes through the link")
+                            how="g2s_fill_begin(list i+D-1) before g2s_fill_end(list i), D = in_flight: the younger lists' kernels run while the oldest one's results cross the link; the rand() stream continues from list to list on the device")
         sr.free()
 
     # ---- CPU baseline: the oracle (port of the reference algorithm) on the GPU box's host cores,
