@@ -3995,7 +3995,7 @@ namespace {
 // continues that one's stream on the device.  A list behind one that is to run again, or that is not on the device
 // at all, waits for it to end.
 int inflight_settle(g2s_session* s) {
-  static const bool no_chain = getenv("G2S_NO_DEVICE_CHAIN") != nullptr;
+  const bool no_chain = getenv("G2S_NO_DEVICE_CHAIN") != nullptr;  // (read per call: the tests switch it)
   for (int i = 0; i < s->n_inflight; i++) {
     g2s_session::InFlight& f = s->inflight[i];
     if (!f.b) break;  // (a list for g2s_fill_batch: it draws on the host, when it is ended)
