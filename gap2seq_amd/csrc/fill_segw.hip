@@ -364,26 +364,31 @@ __device__ __forceinline__ void segw_fill_one(uint32_t* lds, const SegArgs& A, c
     uint32_t* tmp = lds + 16384u;  // (free: the sort used the first 16 384 words at most)
     for (uint32_t i = tid; i < M; i += NT) { tmp[i] = ivw[2u * i + 1u]; tmp[8192u + i] = ivw[2u * i]; }
     __syncthreads();
-    for (uint32_t i = tid; i < EA + 16u; i += NT) ivF[i] = i < M ? tmp[i] : 0xFFFFFFFFu;
+    for (uint32_t i = tid; i < EA + 16u; i += NT) ivF[i] = i < M ? tmp[i] : 0x7FFFFFFFu;
     for (uint32_t i = tid; i < M; i += NT) ivL[i] = tmp[8192u + i];
     __syncthreads();
-    for (uint32_t i = tid; i < 784u; i += NT) lds[LV1 + i] = 8u * i + 7u < EA + 16u ? ivF[8u * i + 7u] : 0xFFFFFFFFu;
+    for (uint32_t i = tid; i < 784u; i += NT) lds[LV1 + i] = 8u * i + 7u < EA + 16u ? ivF[8u * i + 7u] : 0x7FFFFFFFu;
     __syncthreads();
-    for (uint32_t i = tid; i < 112u; i += NT) lds[LV2 + i] = 8u * i + 7u < 784u ? lds[LV1 + 8u * i + 7u] : 0xFFFFFFFFu;
+    for (uint32_t i = tid; i < 112u; i += NT) lds[LV2 + i] = 8u * i + 7u < 784u ? lds[LV1 + 8u * i + 7u] : 0x7FFFFFFFu;
     __syncthreads();
-    if (tid < 32u) lds[LV3 + tid] = 8u * tid + 7u < 112u ? lds[LV2 + 8u * tid + 7u] : 0xFFFFFFFFu;
+    if (tid < 32u) lds[LV3 + tid] = 8u * tid + 7u < 112u ? lds[LV2 + 8u * tid + 7u] : 0x7FFFFFFFu;
     __syncthreads();
-    if (tid < 16u) lds[LV4 + tid] = 8u * tid + 7u < 32u ? lds[LV3 + 8u * tid + 7u] : 0xFFFFFFFFu;
+    if (tid < 16u) lds[LV4 + tid] = 8u * tid + 7u < 32u ? lds[LV3 + 8u * tid + 7u] : 0x7FFFFFFFu;
     __syncthreads();
   }
-  // number of firsts at or below q among the eight at p (16-byte aligned)
+  // number of firsts at or below q among the eight at p (16-byte aligned).  k-mer indices and the padding
+  // (0x7FFFFFFF) are below 2^31, so a first above q leaves the sign bit of (q - first) set: a subtraction and a
+  // shift per sample, the sums as three-operand adds — a comparison per sample was three instructions (the compare,
+  // a wait state for its mask, the add with carry).
   auto cnt8 = [&](const uint32_t* p, uint32_t q) -> uint32_t {
     const uint4 a = ((const uint4*)p)[0], b = ((const uint4*)p)[1];
-    return (uint32_t)(a.x <= q) + (uint32_t)(a.y <= q) + (uint32_t)(a.z <= q) + (uint32_t)(a.w <= q) +
-           (uint32_t)(b.x <= q) + (uint32_t)(b.y <= q) + (uint32_t)(b.z <= q) + (uint32_t)(b.w <= q);
+    const uint32_t above = ((q - a.x) >> 31) + ((q - a.y) >> 31) + ((q - a.z) >> 31) + ((q - a.w) >> 31) +
+                           ((q - b.x) >> 31) + ((q - b.y) >> 31) + ((q - b.z) >> 31) + ((q - b.w) >> 31);
+    return 8u - above;
   };
   // number of intervals that begin at or before k-mer index q, per lane (wave-uniform control flow: M is uniform)
   auto iv_rank = [&](uint32_t q) -> uint32_t {
+    q = min(q, 0x7FFFFFFEu);  // (cnt8 wants keys below the padding)
     uint32_t blk = 0;
     if (M > 4096u) blk = cnt8(lds + LV4, q);
     if (M > 512u) blk = 8u * blk + cnt8(lds + LV3 + 8u * blk, q);
