@@ -424,6 +424,16 @@ __device__ __forceinline__ void segw_fill_one(uint32_t* lds, const SegArgs& A, c
       if (src) { slo = dw; shi = dw; }
     }
     const uint32_t klo = dw << 16;  // the key: node in the high word, depth in the upper half of the low word (the slot below)
+    // The exit record of the event this child may become (states to the end of its unitig, where the segment leaves)
+    // is asked for NOW — before the walk along the table tells whether the child is a new event or merges into a
+    // pending one: the record travels while the walk's LDS round trips go on, and lands in the slot at the end of this
+    // call (the next round's scan finds it there instead of waiting for memory).  A merged child's record is dropped.
+    uint4 nrec = make_uint4(G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID);
+    uint32_t nes = 1u;
+    if (act) {
+      if ((int)dw < lmf) nrec = *(const uint4*)(succ + (size_t)w * 4);  // above the flank: one state
+      else { const uint4* u = (const uint4*)(urec + (size_t)w * 8); nrec = u[0]; nes = u[1].x; }
+    }
     if (act) {
       // (the node last: the slot's owner may be looking at it right now, and a slot whose node it can see must show the
       // new depth — at or above the horizon — whichever of the two words it reads first: freed slots keep depth 0x7FFF)
@@ -486,14 +496,9 @@ __device__ __forceinline__ void segw_fill_one(uint32_t* lds, const SegArgs& A, c
     }
     const uint64_t fm = __ballot(st == 1u);
     if (fm && lane == 0) atomicAdd(&sh[SH_NPEND], (uint32_t)__popcll(fm));
-    // a new event's exit record (states to the end of its unitig, where the segment leaves) is asked for now and lands
-    // in the slot at the end of this call: the next round's scan finds it there instead of waiting for memory
-    uint4 nrec = make_uint4(G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID);
-    uint32_t nes = 1u;
-    if (st == 1u) {
-      if ((int)dw < lmf) nrec = *(const uint4*)(succ + (size_t)w * 4);  // above the flank: one state
-      else { const uint4* u = (const uint4*)(urec + (size_t)w * 8); nrec = u[0]; nes = u[1].x; }
-    }
+    // (nothing is computed on the record before this point: a use further up makes the wave wait for the load where it
+    // was asked for)
+    asm volatile("" : "+v"(nes) : : "memory");
     WFINE(6);
     if (q7 && st == 1u) lflags |= G2S_DEV_Q7_B;
     if (st == 1u) {
