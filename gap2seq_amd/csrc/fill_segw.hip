@@ -386,15 +386,24 @@ __device__ __forceinline__ void segw_fill_one(uint32_t* lds, const SegArgs& A, c
                            ((q - b.x) >> 31) + ((q - b.y) >> 31) + ((q - b.z) >> 31) + ((q - b.w) >> 31);
     return 8u - above;
   };
+  // The first level a search reads is one block of eight, the same for every key: kept in registers for the gap
+  // (one LDS round trip less per search: a round is a chain of them).
+  uint4 top_a = make_uint4(0x7FFFFFFFu, 0x7FFFFFFFu, 0x7FFFFFFFu, 0x7FFFFFFFu), top_b = top_a;
+  if (!overflow) {
+    const uint32_t* tp = M > 4096u ? lds + LV4 : M > 512u ? lds + LV3 : M > 64u ? lds + LV2 : M > 8u ? lds + LV1 : ivF;
+    top_a = ((const uint4*)tp)[0];
+    top_b = ((const uint4*)tp)[1];
+  }
   // number of intervals that begin at or before k-mer index q, per lane (wave-uniform control flow: M is uniform)
   auto iv_rank = [&](uint32_t q) -> uint32_t {
     q = min(q, 0x7FFFFFFEu);  // (cnt8 wants keys below the padding)
-    uint32_t blk = 0;
-    if (M > 4096u) blk = cnt8(lds + LV4, q);
-    if (M > 512u) blk = 8u * blk + cnt8(lds + LV3 + 8u * blk, q);
-    if (M > 64u) blk = 8u * blk + cnt8(lds + LV2 + 8u * blk, q);
-    if (M > 8u) blk = 8u * blk + cnt8(lds + LV1 + 8u * blk, q);
-    return 8u * blk + cnt8(ivF + 8u * blk, q);
+    uint32_t blk = 8u - (((q - top_a.x) >> 31) + ((q - top_a.y) >> 31) + ((q - top_a.z) >> 31) + ((q - top_a.w) >> 31) +
+                         ((q - top_b.x) >> 31) + ((q - top_b.y) >> 31) + ((q - top_b.z) >> 31) + ((q - top_b.w) >> 31));
+    if (M > 4096u) blk = 8u * blk + cnt8(lds + LV3 + 8u * blk, q);
+    if (M > 512u) blk = 8u * blk + cnt8(lds + LV2 + 8u * blk, q);
+    if (M > 64u) blk = 8u * blk + cnt8(lds + LV1 + 8u * blk, q);
+    if (M > 8u) blk = 8u * blk + cnt8(ivF + 8u * blk, q);
+    return blk;
   };
   uint32_t acc_sb = 0, acc_xb = 0;
   uint32_t gen = 0;
