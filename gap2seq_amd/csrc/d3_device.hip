@@ -781,15 +781,15 @@ __device__ __forceinline__ bool d3_handoff_body(const D3Params& P, const D3Work&
     unsigned long long it = 0, so = 0, ro = 0;
     if (lane == 0) {
       if (lcur) {
-        it = atomicAdd(&lcur[0], 1ull); so = atomicAdd(&lcur[1], (unsigned long long)ns); ro = atomicAdd(&lcur[2], (unsigned long long)want + 1ull);
+        it = atomicAdd(&lcur[0], 1ull); so = atomicAdd(&lcur[1], (unsigned long long)ns); ro = atomicAdd(&lcur[2], ((unsigned long long)want + 8ull) / 8ull);
       } else {
         it = atomicAdd(&S->host_items, 1ull);
         so = atomicAdd(&S->host_segs, (unsigned long long)ns);
-        ro = atomicAdd(&S->host_rnd, (unsigned long long)want + 1ull);
+        ro = atomicAdd(&S->host_rnd, ((unsigned long long)want + 8ull) / 8ull);  // (its draws go to the host four bits each: below)
       }
     }
     it = __shfl(it, 0); so = __shfl(so, 0); ro = __shfl(ro, 0);
-    if (it >= side.cap_items || so + ns > side.cap_segs || ro + want + 1ull > side.cap_rnd || (uint64_t)off + want + 1ull > capacity) {
+    if (it >= side.cap_items || so + ns > side.cap_segs || ro + (want + 8ull) / 8ull > side.cap_rnd || (uint64_t)off + want + 1ull > capacity) {
       if (lane == 0) { atomicAdd(&S->anomalies, 1u); W.host_slot[i] = 0xFFFFFFFFu; }
       continue;
     }
@@ -1030,7 +1030,18 @@ __global__ __launch_bounds__(64) void g2s_d3_trace(const D3Params P, const D3Wor
       const uint4* src = (const uint4*)(sub + td.sub_at);
       uint4* dst = (uint4*)(side.segs + so);
       for (uint32_t w = (uint32_t)lane; w < 2u * ns; w += 64u) dst[w] = src[w];
-      for (uint32_t w = (uint32_t)lane; w < want + 1u; w += 64u) side.rnd[ro + w] = rnd[td.off + w];
+      // (the rand() values of its traceback as their remainders by 12, four bits each: all a traceback asks of a value is
+      // its remainder by the number of lengths or of parents — 1 .. 4; config 5's 412 host-finished gaps: 7 MB of raw
+      // words through the link, half of what the kernel wrote)
+      for (uint32_t w = (uint32_t)lane; w < (want + 8u) / 8u; w += 64u) {
+        uint32_t pk8 = 0u;
+#pragma unroll
+        for (uint32_t x = 0; x < 8u; x++) {
+          const uint32_t at = 8u * w + x;
+          if (at <= want) pk8 |= ((rnd[td.off + at] >> 1) % 12u) << (4u * x);
+        }
+        side.rnd[ro + w] = pk8;
+      }
       __threadfence_system();  // (the whole wave's stores are in host memory before the item says so)
       if (lane == 0) {
         // (the item's other words: the hand-off wrote them)

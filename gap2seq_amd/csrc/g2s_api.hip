@@ -2514,7 +2514,7 @@ static bool device_pointer_of(void* host, void** dev) {
 // (pre: the closure was analysed when it arrived — SegEarly, over the same segments: only the traceback is left)
 static bool finish_gap_on_host(const Graph& g, const FillParams& fp, const GapJob& j, const GapOut& go, const SegRec* segs,
                                uint32_t n_segs, const uint32_t* rands, uint32_t expect_draws, uint64_t arena_off, char* arena,
-                               g2s_result* r, const SubPrep* pre = nullptr) {
+                               g2s_result* r, const SubPrep* pre = nullptr, bool rands_packed12 = false) {
   memset(r, 0, sizeof *r);
   const auto t_fin0 = std::chrono::steady_clock::now();
   SubView v;
@@ -2546,8 +2546,13 @@ static bool finish_gap_on_host(const Graph& g, const FillParams& fp, const GapJo
   r->vertices = pp.sub[0]; r->edges = pp.sub[1]; r->nontrivial_components = pp.sub[2];
   r->size_nontrivial_components = pp.sub[3]; r->vertices_final = pp.sub[4]; r->edges_final = pp.sub[5];
   const auto t_an = std::chrono::steady_clock::now();
-  if (pp.seg_mode) seg_traceback(g, fp, j, v, pp, rands, arena + arena_off, r);
-  else sub_traceback(g, fp, j, v, pp, rands, arena + arena_off, r);
+  if (pp.seg_mode) seg_traceback(g, fp, j, v, pp, rands, arena + arena_off, r, rands_packed12);
+  else if (!rands_packed12) sub_traceback(g, fp, j, v, pp, rands, arena + arena_off, r);
+  else {  // (G2S_STATE_D2, tests: the per-state traceback reads raw words)
+    std::vector<uint32_t> raw((size_t)expect_draws + 2);
+    for (size_t x = 0; x < raw.size(); x++) raw[x] = ((rands[x >> 3] >> (4 * (x & 7))) & 15u) << 1;
+    sub_traceback(g, fp, j, v, pp, raw.data(), arena + arena_off, r);
+  }
   if (dbg_analysis_stats && n_segs >= 2000 && pp.run_mode) {
     const double* l = g2s_post_laps;
     fprintf(stderr, "[g2s] run analysis laps (us): front %.0f | collect %.0f merge+sort %.0f runs %.0f edges %.0f csr %.0f tarjan %.0f rest %.0f\n",
@@ -3118,9 +3123,9 @@ static int resident_d3_wait(g2s_session* s, g2s_timing* tm_out, double* ms_d3_ou
       const int32_t ei = early_posted ? s->early_of_gap[h.gap] : -1;  // (analysed when it arrived: the traceback is left)
       const bool ok = ei >= 0 && eh.items[8 * (size_t)ei + 1] == h.n_segs
           ? finish_gap_on_host(g, fp, gb->jobs[loc], eh.outs[ei], eh.segs + eh.items[8 * (size_t)ei + 2], h.n_segs, side_h.rnd + h.rnd_off,
-                               h.draws, (uint64_t)(L.group_arena[q] + gb->arena_off[loc]), text, &rs_host[h.gap], &s->early_prep[(size_t)ei])
+                               h.draws, (uint64_t)(L.group_arena[q] + gb->arena_off[loc]), text, &rs_host[h.gap], &s->early_prep[(size_t)ei], true)
           : finish_gap_on_host(g, fp, gb->jobs[loc], side_h.outs[x], side_h.segs + h.seg_off, h.n_segs, side_h.rnd + h.rnd_off, h.draws,
-                               (uint64_t)(L.group_arena[q] + gb->arena_off[loc]), text, &rs_host[h.gap]);
+                               (uint64_t)(L.group_arena[q] + gb->arena_off[loc]), text, &rs_host[h.gap], nullptr, true);
       if (!ok) host_bad.fetch_add(1);
     };
     // (largest closures first: the hand-off kernel wrote every item's size before it said how many there are;

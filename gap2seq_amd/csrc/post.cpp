@@ -1041,14 +1041,20 @@ bool seg_analyze(const FillParams& p, const GapJob& job, const SubView& v, SubPr
 }
 
 void seg_traceback(const Graph& g, const FillParams& p, const GapJob& job, const SubView& v, const SubPrep& prep,
-                   const uint32_t* rands, char* buf, g2s_result* res) {
+                   const uint32_t* rands, char* buf, g2s_result* res, bool packed12) {
   static const char kUp[4] = {'A', 'C', 'T', 'G'}, kLow[4] = {'a', 'c', 't', 'g'};  // GATB codes (kmer.hpp)
   const GapOut& go = *v.out;
   const int lmf = job.lmf, k = p.k;
   res->right_fuz = go.reached_j;  // :1171
   res->flags |= G2S_GAP_PHASE_D;
   int draws = 0;
-  auto draw = [&]() -> uint32_t { const uint32_t r = rands ? rands[draws] : 0u; draws++; return r; };
+  // (raw words: the value is word >> 1; packed: the value's remainder by 12 stands for it)
+  auto draw = [&]() -> uint32_t {
+    uint32_t r = 0u;
+    if (rands) r = packed12 ? ((rands[(size_t)draws >> 3] >> (4 * (draws & 7))) & 15u) << 1 : rands[draws];
+    draws++;
+    return r;
+  };
   const int pick = (int)((draw() >> 1) % (uint32_t)go.n_len);  // :1440
   int d2 = go.len[pick];
   int last_solid = d2;

@@ -160,8 +160,11 @@ inline int sub_fixed_draws(const SubView& v, const SubPrep& prep, int pick) {
 // segments.
 // `scratch`: 24 bytes per segment, 8-byte aligned, alive as long as *out is used (nullptr: *out allocates).
 bool seg_analyze(const FillParams& p, const GapJob& job, const SubView& v, SubPrep* out, void* scratch = nullptr);
+// (packed12: `rands` holds (value % 12) in four bits per draw, eight draws a word — all a traceback asks of a value is
+// its remainder by the number of lengths (<= 2) or of parents (<= 4): what the device hands the host for the gaps it
+// finishes, an eighth of the words over the link)
 void seg_traceback(const Graph& g, const FillParams& p, const GapJob& job, const SubView& v, const SubPrep& prep,
-                   const uint32_t* rands, char* buf, g2s_result* res);
+                   const uint32_t* rands, char* buf, g2s_result* res, bool packed12 = false);
 int seg_count_draws(const Graph& g, const SubView& v, const SubPrep& prep, const uint32_t* rands);
 // (lowest, highest) depth at which a traceback that passes through the entry of each closure segment stops
 // (:1455-1462), (-1, 1 << 30) where that is not fixed by the subgraph; out: two values per segment
