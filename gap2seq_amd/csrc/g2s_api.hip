@@ -538,6 +538,9 @@ struct g2s_session {
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;  // resident mode: the rand() stream is generated beside the fill kernel
+  hipStream_t stream3 = nullptr;  // resident mode, deep lists: the large variant's early launch (resident_launch_fill)
+  hipEvent_t ev_pre = nullptr, ev_early = nullptr;  // in front of the fill kernel; behind the early launch
+  DevBuf d_segx1;                 // the early launch's scratch
   hipEvent_t ev_rand = nullptr;
   g2s_params params;
   RandCache rcache;
@@ -692,6 +695,9 @@ extern "C" int g2s_session_create(g2s_graph* g, int device, const g2s_params* p,
   for (int i = 0; i < 5 && e == hipSuccess; i++) e = hipEventCreate(&s->ev[i]);
   if (e == hipSuccess) e = hipEventCreate(&s->ev_segw);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_chain, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->stream3, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_pre, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_early, hipEventDisableTiming);
   if (e == hipSuccess) e = s->d_link.ensure(32 * 4);
   size_t free_b = 0, total_b = 0;
   if (e == hipSuccess) e = hipMemGetInfo(&free_b, &total_b);
@@ -736,6 +742,10 @@ extern "C" void g2s_session_destroy(g2s_session* s) {
   if (s->ev_rand) (void)hipEventDestroy(s->ev_rand);
   if (s->ev_segw) (void)hipEventDestroy(s->ev_segw);
   if (s->ev_chain) (void)hipEventDestroy(s->ev_chain);
+  if (s->ev_pre) (void)hipEventDestroy(s->ev_pre);
+  if (s->ev_early) (void)hipEventDestroy(s->ev_early);
+  if (s->stream3) (void)hipStreamDestroy(s->stream3);
+  s->d_segx1.release();
   s->d_link.release();
   if (s->stream2) (void)hipStreamDestroy(s->stream2);
   if (s->stream) (void)hipStreamDestroy(s->stream);
@@ -778,6 +788,7 @@ struct g2s_batch {
   bool pre_launched = false, pre_two = false, pre_timed = false, pre_segw = false;
   bool d3_queued = false;  // ...and its phase D3 too (resident_queue_d3): g2s_batch_run only waits
   bool chain_broken = false;  // ...from the device state of a list in front of it which then did not end on the device
+  bool others_in_flight = false;  // begun while another list was in flight: the device is shared (resident_launch_fill)
   uint64_t pre_units = 0;
   int upload_flanks();
   size_t arena_bytes = 0;
@@ -2615,6 +2626,33 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl) {
   } else {
     for (size_t i = 0; i < n; i++) if (!b->jobs[i].bad_flank) ids.push_back((uint32_t)i);
   }
+  // A deep list (-dist-error in the thousands): the launch of the large variant is as long as its slowest gap, and
+  // that gap is one of the list's longest — which would only enter the large variant when the regular tier's whole
+  // launch is through (0.54 of config 5's 4.1 ms).  The gaps in the upper part of the list's length range go to
+  // the large variant at once, on a stream of its own beside the regular tier's kernel (half of them would have
+  // outgrown the regular tier anyway; the others cost the large variant's idle workgroups some work); the rest as
+  // before.  ids: [the regular tier's gaps][the early launch's gaps].
+  size_t n_early = 0;
+  const bool deep_list = b->dmax >= 2500 && !s->in_team_list && !getenv("G2S_NO_SEGX_TIER");
+  // (not beside other lists in flight: there the device is full, and the gaps the regular tier would have finished
+  // cost the large variant more than an earlier start gains — 485 k against 343 k gaps/s with three lists in flight)
+  if (deep_list && ids.size() >= 256 && !b->others_in_flight && !getenv("G2S_NO_EARLY_SEGW")) {
+    int gmin = gmax;
+    for (uint32_t i : ids) gmin = std::min(gmin, b->jobs[i].g);
+    const int gcut = gmin + (int)(0.55 * (double)(gmax - gmin));
+    std::vector<uint32_t>& tmp = s->res_at;
+    tmp.clear();
+    size_t w = 0;
+    for (size_t x = 0; x < ids.size(); x++) {
+      if (b->jobs[ids[x]].g >= gcut && gmax > gmin) tmp.push_back(ids[x]);
+      else ids[w++] = ids[x];
+    }
+    n_early = tmp.size();
+    for (size_t x = 0; x < n_early; x++) ids[w + x] = tmp[x];
+    // (longest first among the early ones: the slowest start first)
+    std::stable_sort(ids.begin() + (ptrdiff_t)w, ids.end(), [&](uint32_t a2, uint32_t b2) { return b->jobs[a2].g > b->jobs[b2].g; });
+  }
+  const size_t n_reg = ids.size() - n_early;
   HIP_TRY_S(s->h_gaps.ensure(n * sizeof(GapDev) + n * 4 + 16));
   HIP_TRY_S(s->h_d3.ensure(n * sizeof(D3Gap) + 2048 + 64 * 128 + G2S_RAND_WINDOW * 4));
   GapDev* gd = (GapDev*)s->h_gaps.p;
@@ -2686,18 +2724,6 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl) {
   if (s->d_counter.clean < 32) HIP_TRY_S(hipMemsetAsync(s->d_counter.p, 0, 32, st));
   s->d_outs.clean = 0;
   s->d_counter.clean = 0;
-  // (two waves per gap when the launch is short enough to end with its slowest gap — unless the sessions of a team
-  // share this device: the chip is then as full as one long launch makes it)
-  const bool two_waves = getenv("G2S_SEG_WAVES") ? atoi(getenv("G2S_SEG_WAVES")) == 2 : (ids.size() <= 2048 && !s->team_shares_device);
-  rl->timed = kernel_events_on(s);
-  if (rl->timed) HIP_TRY_S(hipEventRecord(s->ev[1], st));
-  HIP_TRY_S(launch_fill_seg(st, (uint32_t)ids.size(), dg.succ, dg.urec, gaps_dev, ids_dev, (const uint32_t*)s->d_flank.p,
-                          (SubRec*)s->d_sub.p, (unsigned long long)out_states, (unsigned long long*)s->d_counter.p,
-                          (GapOut*)s->d_outs.p, nullptr, nullptr, s->params.skip_confident ? 1 : 0, nullptr, two_waves,
-                          nullptr, nullptr, 0u, 1u, true, rerun ? (uint32_t*)s->d_ovf.p : nullptr));
-  if (rl->timed) HIP_TRY_S(hipEventRecord(s->ev[2], st));
-  // (the large variant for what the launch above listed: its workgroups read the list's length from device memory and
-  // leave at once when it is empty — the usual case)
   // (a deep list: the closures the host will analyse leave the large variant's gaps one by one, into pinned memory)
   SegEarly early_dev;
   s->early_host = SegEarly();
@@ -2718,13 +2744,44 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl) {
     early_dev.ctr = (unsigned long long*)s->d_early_ctr.p;
     HIP_TRY_S(hipMemsetAsync(s->d_early_ctr.p, 0, 16, st));
   }
+  // (two waves per gap when the launch is short enough to end with its slowest gap — unless the sessions of a team
+  // share this device: the chip is then as full as one long launch makes it)
+  const bool two_waves = getenv("G2S_SEG_WAVES") ? atoi(getenv("G2S_SEG_WAVES")) == 2 : (n_reg <= 2048 && !s->team_shares_device);
+  // (the early launch of the large variant — see n_early above: behind everything the stream has prepared, beside the
+  // regular tier's kernel; its gaps' records and closures go where the others' do, through the same cursors)
+  if (n_early && rerun) HIP_TRY_S(hipEventRecord(s->ev_pre, st));  // (what the early launch waits for: not the regular tier's kernel)
+  rl->timed = kernel_events_on(s);
+  if (rl->timed) HIP_TRY_S(hipEventRecord(s->ev[1], st));
+  HIP_TRY_S(launch_fill_seg(st, (uint32_t)n_reg, dg.succ, dg.urec, gaps_dev, ids_dev, (const uint32_t*)s->d_flank.p,
+                          (SubRec*)s->d_sub.p, (unsigned long long)out_states, (unsigned long long*)s->d_counter.p,
+                          (GapOut*)s->d_outs.p, nullptr, nullptr, s->params.skip_confident ? 1 : 0, nullptr, two_waves,
+                          nullptr, nullptr, 0u, 1u, true, rerun ? (uint32_t*)s->d_ovf.p : nullptr));
+  if (rl->timed) HIP_TRY_S(hipEventRecord(s->ev[2], st));
+  // (queued BEHIND the regular tier's kernel, which takes the compute units first — a workgroup of the large variant
+  // needs a whole unit's LDS and stays for the launch: started first, 256 of them leave the regular tier no unit until
+  // the early list runs dry (4.4 instead of 3.65 ms, when the hardware happened to order them so); its workgroups
+  // begin as units run out of regular-tier gaps, a tenth of a millisecond in)
+  if (n_early && rerun) {
+    const uint32_t wgs1 = (uint32_t)std::min<size_t>(n_early, (size_t)std::max(1, s->num_cus));
+    HIP_TRY_S(s->d_segx1.ensure(fill_segw_scratch_bytes(wgs1)));
+    HIP_TRY_S(hipStreamWaitEvent(s->stream3, s->ev_pre, 0));
+    HIP_TRY_S(launch_fill_segw(s->stream3, (uint32_t)n_early, wgs1, dg.succ, dg.urec, gaps_dev, ids_dev + n_reg,
+                               (const uint32_t*)s->d_flank.p, (SubRec*)s->d_sub.p, (unsigned long long)out_states,
+                               (unsigned long long*)s->d_counter.p, (GapOut*)s->d_outs.p, nullptr, nullptr,
+                               s->params.skip_confident ? 1 : 0, nullptr, (uint32_t*)s->d_segx1.p,
+                               (unsigned long long*)s->d_counter.p + 3, true, nullptr, early_dev.items ? &early_dev : nullptr));
+    HIP_TRY_S(hipEventRecord(s->ev_early, s->stream3));
+  }
+  // (the large variant for what the launch above listed: its workgroups read the list's length from device memory and
+  // leave at once when it is empty — the usual case)
   if (rerun)
-    HIP_TRY_S(launch_fill_segw(st, (uint32_t)ids.size(), segw_wgs, dg.succ, dg.urec, gaps_dev, (const uint32_t*)s->d_ovf.p,
+    HIP_TRY_S(launch_fill_segw(st, (uint32_t)std::max<size_t>(n_reg, 1), segw_wgs, dg.succ, dg.urec, gaps_dev, (const uint32_t*)s->d_ovf.p,
                              (const uint32_t*)s->d_flank.p, (SubRec*)s->d_sub.p, (unsigned long long)out_states,
                              (unsigned long long*)s->d_counter.p, (GapOut*)s->d_outs.p, nullptr, nullptr,
                              s->params.skip_confident ? 1 : 0, nullptr, (uint32_t*)s->d_segx.p,
                              (unsigned long long*)s->d_counter.p + 2, true, (const unsigned long long*)s->d_counter.p + 1,
                              early_dev.items ? &early_dev : nullptr));
+  if (n_early && rerun) HIP_TRY_S(hipStreamWaitEvent(st, s->ev_early, 0));  // (phase D3 follows on this stream: behind both)
   if (rerun && rl->timed) HIP_TRY_S(hipEventRecord(s->ev_segw, st));
   rl->units = out_states;
   rl->two_waves = two_waves;
@@ -4056,6 +4113,7 @@ extern "C" int g2s_fill_begin(g2s_session* s, const g2s_gap* gaps, size_t n, g2s
     f.on = on;
     f.b->arena = fill_arena;
     f.b->arena_base = 0;
+    f.b->others_in_flight = s->n_inflight > 0;
     ResidentLaunch rl;
     rc = resident_launch_fill(f.b, &rl);  // (1: not a list for resident mode — g2s_fill_end runs it on the host path)
     if (rc < 0) { g2s_batch_free(f.b); return rc; }

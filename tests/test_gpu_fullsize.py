@@ -89,8 +89,9 @@ def test_c5_full_size_vs_oracle(product, oracle):
     c, f, tm, xb, sb = _check_batch(product, oracle, seqs, 31, gaps, 2000, seed=1)
     assert c >= 995 and f >= 990
     assert (tm.xB, tm.sB) == (xb, sb)
-    # the segment tier holds the whole list: ~58 % in the tier proper, the deep ones in its large variant
-    assert tm.seg_tier_gaps >= 500 and tm.seg_tier_gaps + tm.segx_tier_gaps == 1000
+    # the segment tier holds the whole list: the regular tier finishes 58 % of the gaps it is given — the longest 45 %
+    # of a deep list go to the large variant at once (resident mode), the rest of what outgrows the tier behind it
+    assert tm.seg_tier_gaps >= 300 and tm.seg_tier_gaps + tm.segx_tier_gaps == 1000
     assert tm.lds_tier_gaps == 0 and tm.retried_gaps == 0 and tm.watchdog_gaps == 0
     # ...and the list stays on the device (resident mode per gap): the gaps that outgrow the regular tier run again in
     # the large variant behind it on the stream, closures the device does not analyse are finished by the host under
