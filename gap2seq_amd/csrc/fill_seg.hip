@@ -388,6 +388,12 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
   uint32_t* labrem = (uint32_t*)(lab + ALAB);
   uint32_t* aq0 = labrem + ALAB;
   uint32_t* ash = aq0 + 4u * ACAP;  // (two waves) what wave 1 hands over: entries, rounds, flags, overflow, cycles
+  // (two waves) the records of the entries queued for the next round, asked for when they are PROPOSED — before the
+  // probe of the table and its atomic tell whether the proposal improves anything — and parked here by queue position:
+  // the next round reads LDS where it waited a thousand cycles for memory (40 % of a round of the search, and the
+  // gaps that end a short list's launch wait for this wave)
+  uint4* qrec = (uint4*)(ash + 16u);               // [2][ACAP] the unitig's exit
+  uint32_t* qrem = (uint32_t*)(qrec + 2u * ACAP);  // [2][ACAP] steps to its end
   // the table's entries, packed (the queues are idle by then), and from there into registers: lane l of set s
   // holds entry 64 s + l as a k-mer index interval; then Q7 in the right set
   auto load_right_set = [&]() {
@@ -469,6 +475,13 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
         const bool imp = relabel(sd != G2S_DEV_INVALID && lane <= gd.right_half, sd, (uint32_t)lane, a_hash(sd), &at);
         const uint64_t m = __ballot(imp);
         if (imp) { aq0[(uint32_t)__popcll(m & below(lane))] = sd; aqs[(uint32_t)__popcll(m & below(lane))] = at; }
+        if constexpr (TWO) {
+          if (imp) {
+            const uint4* u = (const uint4*)(urec + (size_t)(sd ^ 1u) * 8);
+            qrec[(uint32_t)__popcll(m & below(lane))] = u[0];
+            qrem[(uint32_t)__popcll(m & below(lane))] = u[1].x;
+          }
+        }
         ne = (uint32_t)__popcll(m);
         lds_sync();
       }
@@ -478,6 +491,10 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
         const uint32_t* qcs = aqs + cur * ACAP;
         uint32_t* qn = aq0 + (cur ^ 1u) * ACAP;
         uint32_t* qns = aqs + (cur ^ 1u) * ACAP;
+        const uint4* qcr = qrec + cur * ACAP;
+        const uint32_t* qcm = qrem + cur * ACAP;
+        uint4* qnr = qrec + (cur ^ 1u) * ACAP;
+        uint32_t* qnm = qrem + (cur ^ 1u) * ACAP;
         uint32_t nn = 0;
 #ifdef G2S_SEG_PROFILE
         unsigned long long pa_round = __builtin_amdgcn_s_memtime(), pa_in = 0;
@@ -498,9 +515,14 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
           // asked for before the entry's label is read (the label comes from LDS while the record travels)
           uint32_t w = G2S_DEV_INVALID, r = 0;
           if (mine) {
-            const uint32_t* u = urec + (size_t)(v ^ 1u) * 8;
-            w = u[q];
-            r = u[4];
+            if constexpr (TWO) {
+              w = ((const uint32_t*)(qcr + eidx))[q];
+              r = qcm[eidx];
+            } else {
+              const uint32_t* u = urec + (size_t)(v ^ 1u) * 8;
+              w = u[q];
+              r = u[4];
+            }
           }
 #ifdef G2S_SEG_PROFILE
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -515,6 +537,16 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
           // takes the general loop
           const bool act = live && w != G2S_DEV_INVALID;
           const uint32_t pnode = w ^ 1u;
+          // (two waves: the proposed node's own record, for the round in which it would be an entry — see qrec)
+          uint4 prec = make_uint4(G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID, G2S_DEV_INVALID);
+          uint32_t prem = 0u;
+          if constexpr (TWO) {
+            if (act) {
+              const uint4* u = (const uint4*)(urec + (size_t)w * 8);  // (pnode ^ 1 = w)
+              prec = u[0];
+              prem = u[1].x;
+            }
+          }
           const uint64_t key = ((uint64_t)pnode << 32) | dchild;
           const uint32_t hq = a_hash(pnode);
           const uint64_t cq = act ? lab[hq] : 0ull;
@@ -536,7 +568,10 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
           const uint64_t m = __ballot(imp);
           if (imp) {
             const uint32_t pos = nn + (uint32_t)__popcll(m & below(lane));
-            if (pos < ACAP) { qn[pos] = pnode; qns[pos] = at; }
+            if (pos < ACAP) {
+              qn[pos] = pnode; qns[pos] = at;
+              if constexpr (TWO) { qnr[pos] = prec; qnm[pos] = prem; }
+            }
           }
           nn += (uint32_t)__popcll(m);
           // (the table has 2 ACAP slots: at most ACAP + 64 are ever taken, so every probe ends)
@@ -1867,7 +1902,9 @@ __global__ __launch_bounds__(64) void g2s_fill_segx(const SegArgs A, uint32_t* s
 namespace g2s {
 
 size_t fill_seg_lds_bytes() { return 4u * (7u * G2S_SEG_CAP + 32u); }
-size_t fill_seg2_lds_bytes() { return 4u * (7u * G2S_SEG_CAP + 32u + 2u * 128u * G2S_SEG_ASETS + 128u * G2S_SEG_ASETS + 4u * 64u * G2S_SEG_ASETS + 16u); }
+size_t fill_seg2_lds_bytes() {  // (... + the next round's records: 2 x 64 x sets x (16 + 4) bytes)
+  return 4u * (7u * G2S_SEG_CAP + 32u + 2u * 128u * G2S_SEG_ASETS + 128u * G2S_SEG_ASETS + 4u * 64u * G2S_SEG_ASETS + 16u + 2u * 64u * G2S_SEG_ASETS * 5u);
+}
 uint32_t fill_seg_dbg_words() { return 8u + 2u * 64u * G2S_SEG_ASETS + 6u * G2S_SEG_CAP + 14u; }  // (+14: profile words)
 size_t fill_segx_lds_bytes() { return 4u * SEGX_LDS_WORDS; }
 size_t fill_segx_scratch_bytes(uint32_t workgroups) { return (size_t)workgroups * SEGX_SCR_WORDS * 4u; }
