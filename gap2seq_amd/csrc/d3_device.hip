@@ -1123,28 +1123,56 @@ __global__ __launch_bounds__(64) void g2s_d3_trace(const D3Params P, const D3Wor
   __builtin_amdgcn_wave_barrier();
   int nh = 0;
   {
+    // (i) The chain of segments: from the start along the parents chosen above until a source or a segment without a
+    // way on — ONE LDS word and a dozen scalar instructions per segment entered (the walk that also carried depths and
+    // checked them was 80 instructions and 500 cycles a segment: 8 of the 27 us of config 2's longest wave).
+    // A traceback descends: it enters a segment once, so a chain of more than nsegs segments is not one.
     const uint32_t sg = (go.start_seg >> (16 * pick)) & 0xFFFFu;
     int si = sg == 0xFFFFu ? -1 : (int)sg;
-    int t = (int)((go.start_t >> (16 * pick)) & 0xFFFFu);
+    const int t0 = (int)((go.start_t >> (16 * pick)) & 0xFFFFu);
     if (si < 0 || si >= (int)nsegs || avail < 1) bad = true;
-    for (int guard = 0; !bad && d2 >= 0; guard++) {
-      if (P.laps) hops++;
-      const uint2 w2 = pk[si];  // (one LDS read per segment entered)
-      const uint32_t dl = uni(w2.x), nx = uni(w2.y);
-      const int d0 = (int)(dl & 0xFFFFu);
-      if (guard > 0) t = (int)(dl >> 16) - 1;  // (a child in the closure puts the whole parent there)
-      if (d0 + t != d2 || nh >= (int)P.seg_cap) { bad = true; break; }  // (state t of a segment that begins at depth d0 sits at depth d0 + t)
-      if (lane == 0) hop[nh] = make_uint2((uint32_t)d2, (uint32_t)si | ((uint32_t)t << 16));
-      nh++;
-      draws += t;
-      d2 -= t;
-      if (nx & 0x40000000u) { left_fuz = (int)dg.lmf - d2; ended = true; break; }  // :1455-1462
-      if (d2 > 0) {
-        if (nx & 0x80000000u) { bad = true; break; }
-        draws++;
-        si = (int)(nx & 0xFFFFu);
+    uint32_t last = 0x80000000u;
+    const int hop_cap = (int)min(nsegs, P.seg_cap);
+    if (!bad) {
+      for (;;) {
+        if (nh >= hop_cap) { bad = true; break; }
+        if (P.laps) hops++;
+        last = uni(pk[si].y);
+        if (lane == 0) hop[nh].y = (uint32_t)si;
+        nh++;
+        if (last & 0xC0000000u) break;
+        si = (int)(last & 0xFFFFu);
       }
-      d2--;
+    }
+    if (!(last & 0x40000000u)) bad = true;  // (ended without a way on — :1493-1510 — or past the depth of a source)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    // (ii) All lanes, a hop each: state t of a segment that begins at depth d0 sits at depth d0 + t; the walk enters
+    // the first segment at state start_t and every other at its last state, and steps from a segment's first state
+    // to the depth below it: the depth at which hop h is entered is len less the states passed before it — a scan —
+    // and has to be d0 + t there.  Every state passed draws once (:1513), so the walk draws 1 + len - (the depth at
+    // which it ends) times.
+    int carry = 0, d_end = 0;
+    for (int h0 = 0; !bad && h0 < nh; h0 += 64) {
+      const int h = h0 + lane;
+      const bool in = h < nh;
+      const uint32_t sq = in ? hop[h].y : 0u;
+      const uint32_t dl = in ? pk[sq].x : 0u;
+      const int d0 = (int)(dl & 0xFFFFu), t = h == 0 ? t0 : (int)(dl >> 16) - 1;  // (a child in the closure puts the whole parent there)
+      int inc = in ? t + 1 : 0;
+      for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(inc, o); if (lane >= o) inc += y; }
+      const int at = len - carry - (inc - (in ? t + 1 : 0));  // the depth at which this hop is entered
+      // (a hop that is not the last leaves its segment above depth 0: the step down exists)
+      if (__ballot(in && (d0 + t != at || t < 0 || (h + 1 < nh && d0 < 1))) != 0ull) { bad = true; break; }
+      if (in) hop[h] = make_uint2((uint32_t)at, sq | ((uint32_t)t << 16));
+      if (h + 1 == nh) d_end = d0;
+      carry += __shfl(inc, 63);
+    }
+    if (!bad) {
+      d2 = uni((uint32_t)__shfl(d_end, (nh - 1) & 63));
+      draws = 1 + len - d2;
+      left_fuz = (int)dg.lmf - d2;  // :1455-1462
+      ended = true;
     }
   }
   if (!ended || draws != want) bad = true;
