@@ -104,7 +104,7 @@ __device__ __forceinline__ bool seg_q7_sorted(const uint32_t* s_node, const uint
             const int ia = (int)(na >> 1), da = (int)(dla & 0xFFFFu), la = (int)(dla >> 16);
             const int sdiff = ibl - ia, ddiff = dbl - da;
             const int t1 = (sdiff + ddiff) >> 1, t2 = (sdiff - ddiff) >> 1;
-            if (__ballot(ha && !(na & 1u) && !((sdiff + ddiff) & 1) && t1 >= 0 && t1 < la && t2 >= 0 && t2 < lbl)) { *found = true; break; }
+            if (ballot_and(ha, !(na & 1u), !((sdiff + ddiff) & 1), t1 >= 0, t1 < la, t2 >= 0, t2 < lbl)) { *found = true; break; }
           }
         }
       }
@@ -135,11 +135,16 @@ __device__ __forceinline__ bool seg_q7_all_pairs(const uint32_t* s_node, const u
       const bool upa = ha && !(na & 1u);
       if (!__ballot(upa)) continue;
       const int ia = (int)(na >> 1), da = (int)(dla & 0xFFFFu), la = (int)(dla >> 16);
+      const uint64_t upm = __ballot(upa && la > 0);
       for (uint64_t dm = dm0; dm; dm &= dm - 1) {
         const int l = __builtin_ctzll(dm);
-        const int sdiff = (int)rl((uint32_t)ib, l) - ia, ddiff = (int)rl((uint32_t)db, l) - da;
+        const int ibl = (int)rl((uint32_t)ib, l), lbl = (int)rl((uint32_t)lb, l);
+        // (two segments can only meet on a k-mer both hold: the downward one's indices ibl - lbl + 1 .. ibl against the
+        // upward ones' ia .. ia + la - 1 — nearly every pair is settled by these two comparisons)
+        if (!(upm & __ballot(ia <= ibl) & __ballot(ibl - lbl < ia + la))) continue;
+        const int sdiff = ibl - ia, ddiff = (int)rl((uint32_t)db, l) - da;
         const int t1 = (sdiff + ddiff) >> 1, t2 = (sdiff - ddiff) >> 1;
-        if (__ballot(upa && !((sdiff + ddiff) & 1) && t1 >= 0 && t1 < la && t2 >= 0 && t2 < (int)rl((uint32_t)lb, l))) return true;
+        if (upm & ballot_and(!((sdiff + ddiff) & 1), t1 >= 0, t1 < la, t2 >= 0, t2 < lbl)) return true;
       }
     }
   }
@@ -169,7 +174,7 @@ __device__ __forceinline__ bool seg_extents_overlap(const uint32_t* s_node, cons
       for (uint64_t am = __ballot(a_in); am; am &= am - 1) {
         const int al = __builtin_ctzll(am);
         const uint32_t lo_a = rl(alo_, al), hi_a = rl(ahi_, al);
-        if (__ballot(in && b > a0 + (uint32_t)al && ilo <= hi_a && lo_a <= ihi)) return true;
+        if (ballot_and(in, b > a0 + (uint32_t)al, ilo <= hi_a, lo_a <= ihi)) return true;
       }
     }
   }
