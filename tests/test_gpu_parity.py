@@ -87,7 +87,7 @@ def _compare_with_oracle_in_parallel(product, oracle, og, gaps, res, e, seed, sk
     return tally["compared"], tally["q7"]
 
 
-def _check_batch(product, oracle, seqs, k, gaps, e, skip=False, allp=True, seed=5, max_mem=20 << 30):
+def _check_batch(product, oracle, seqs, k, gaps, e, skip=False, allp=True, seed=5, max_mem=20 << 30, run_product=None):
     """The product's batch against the oracle gap by gap.  Only gaps on which the ORACLE
     sees a Q7 collision (both strands of a k-mer in one border: the reference's outcome then
     depends on libstdc++'s hash-set order) are outside the bit-exact claim; they must carry
@@ -95,11 +95,12 @@ def _check_batch(product, oracle, seqs, k, gaps, e, skip=False, allp=True, seed=
     collision is compared like any other.  The oracle's rand() stream is re-synchronised
     with the product's after every gap whose draw counts differ (possible for oracle-Q7 gaps
     only), so every later gap is still compared.  Returns (compared, filled, timing, xB, sB)
-    with compared == len(gaps) - oracle_q7 asserted."""
+    with compared == len(gaps) - oracle_q7 asserted.  run_product(sess, gap structs) -> (results, timing) replaces the
+    one g2s_fill_batch call (tools/fuzz_parity.py: the same gaps as several lists in flight)."""
     og = oracle.OracleGraph(seqs, k, 1)
     pg = product.Graph.from_seqs(seqs, k, 1)
     sess = product.Session(pg, 0, d_err=e, skip_confident=skip, all_paths=allp, randseed=seed, max_mem=max_mem)
-    res, tm = sess.fill_batch(_gaps(product, gaps), True)
+    res, tm = run_product(sess, _gaps(product, gaps)) if run_product else sess.fill_batch(_gaps(product, gaps), True)
     assert tm.watchdog_gaps == 0  # (a probe loop of the large variant ran past its bound: a defect)
     rng = oracle.OracleRng(seed)
     compared = filled = oracle_q7 = 0

@@ -26,6 +26,8 @@ import oracle_lib  # noqa: E402
 import test_gpu_parity as tp  # noqa: E402
 from gap2seq_amd import lib as product  # noqa: E402
 
+IN_FLIGHT = False  # (--in-flight)
+
 
 def draw_big(rng):
     """Long gap lists and deep gaps: small LDS shares, the right-set spill pool, passes 1 and 2,
@@ -91,7 +93,23 @@ def run(cfg):
     else:
         os.environ.pop("G2S_NO_LDS_TIER", None)
     return tp._check_batch(product, oracle_lib, seqs, k, gaps, cfg["d_err"], cfg["skip"], cfg["allp"],
-                           seed=cfg["randseed"])
+                           seed=cfg["randseed"], run_product=in_flight_runner(cfg) if IN_FLIGHT else None)
+
+
+def in_flight_runner(cfg):
+    """--in-flight: the configuration's gaps as three to six consecutive lists through g2s_fill_begin / g2s_fill_end, up
+    to three of them in flight (one rand() stream from list to list — on the device when a list ends there, through
+    the host when one falls back, which makes the lists behind it run again): the results in order are those of one
+    list, which is what _check_batch compares with the oracle."""
+    def runner(sess, gap_structs):
+        rng = cases.SplitMix(cfg["cseed"] ^ 0x5EED)
+        n = len(gap_structs)
+        parts = min(n, rng.randint(3, 6))
+        cuts = sorted({0, n} | {rng.randint(1, max(1, n - 1)) for _ in range(parts - 1)})
+        lists = [gap_structs[a:b] for a, b in zip(cuts, cuts[1:]) if b > a]
+        outs, tm = sess.fill_lists_overlapped(lists, pinned=rng.random() < 0.7, depth=rng.randint(2, 3))
+        return [r for part in outs for r in part], tm
+    return runner
 
 
 def draw_scaffold(rng):
@@ -212,7 +230,10 @@ def main():
     ap.add_argument("--big", type=float, default=0.08, help="share of long-list / deep-gap configurations")
     ap.add_argument("--scaffold", type=float, default=0.1, help="share of whole-scaffold (execute) configurations")
     ap.add_argument("--replay", default=None)
+    ap.add_argument("--in-flight", action="store_true", help="every configuration's gaps as several lists in flight")
     a = ap.parse_args()
+    global IN_FLIGHT
+    IN_FLIGHT = a.in_flight
     oracle_lib.lib()
     product.load_library()
     if a.replay:
