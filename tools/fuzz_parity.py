@@ -165,7 +165,12 @@ def run_scaffold(cfg):
             return 0, 0
         sess = product.Session(pg, 0, d_err=e, randseed=cfg["randseed"], **kw)
         try:
-            fa, lg, gaps, filled = sess.execute_scaffolds(text, k, solid=1, max_fuz=fuz)
+            if IN_FLIGHT:  # (the same records batch by batch, batches in flight where they are long enough)
+                chunk = cases.SplitMix(cfg["cseed"] ^ 0xC4).choice([1, 3, 10, 40, 300])
+                fas, lgs, gaps, filled = sess.execute_scaffolds_stream(text, k, chunk, solid=1, max_fuz=fuz)
+                fa, lg = "".join(fas), "".join(lgs)
+            else:
+                fa, lg, gaps, filled = sess.execute_scaffolds(text, k, solid=1, max_fuz=fuz)
         finally:
             sess.destroy()
         assert fa == ofa, "FASTA differs"
