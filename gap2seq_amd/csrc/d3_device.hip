@@ -595,6 +595,37 @@ __device__ int d3_walk_count(int n_len, int len0, int len1, uint32_t start_seg, 
   return draws;
 }
 
+// The same count for a closure whose links are in LDS, as the trace kernel's walk goes (see there): every state passed
+// draws once, so the draw made at a segment's first state, at depth d0, is the (1 + len - d0)-th of the gap whatever
+// the path, and a walk that ends at a source at depth d0 has drawn 1 + len - d0 times — one record and one rand()
+// value per segment entered, no counters carried along.  (The depths are the records': a closure whose segments do
+// not follow each other as their depths say is the trace kernel's to find — it checks every hop of the walk that is
+// taken — and the host's to decide.)
+__device__ int d3_walk_count_lite(int n_len, int len0, int len1, uint32_t start_seg, int nsegs, const SegLite* __restrict__ segs,
+                                  const uint32_t* lwin, uint32_t nwin, uint64_t avail, bool* bad) {
+  if (avail < 1 || nwin < 1) { *bad = true; return 1; }
+  const int pick = n_len > 1 ? (int)((lwin[0] >> 1) & 1u) : 0;  // :1440 (n_len <= 2)
+  const int len = pick ? len1 : len0;
+  const uint32_t sg = (start_seg >> (16 * pick)) & 0xFFFFu;
+  int i = sg == 0xFFFFu ? -1 : (int)sg;
+  if (i < 0 || i >= nsegs || len < 0) { *bad = true; return 1; }
+  for (int hop = 0; hop <= nsegs; hop++) {  // (a traceback descends: it enters a segment once)
+    const SegLite s = segs[i];
+    const int d0 = (int)(s.depth_len & 0xFFFFu);
+    if (d0 > len) break;
+    if (s.flags & G2S_SUB_SOURCE) return 1 + len - d0;  // :1455-1462
+    if (d0 == 0) break;  // (no depth below: the walk ends without a source, :1493-1510)
+    const int nb = seg_nparents(s.par01, s.par23);
+    const uint32_t at = (uint32_t)(1 + len - d0);
+    if (nb == 0 || (nb > 1 && !(s.flags & G2S_SEG_ORDERED)) || (uint64_t)at >= avail || at >= nwin) break;
+    const uint32_t rv = nb > 1 ? lwin[at] >> 1 : 0u;  // (rand() % 1: the value does not matter)
+    i = (int)seg_parent(s.par01, s.par23, nb == 1 ? 0 : pick_parent(rv, nb));  // :1513, GATB predecessor order
+    if (i >= nsegs) break;
+  }
+  *bad = true;
+  return 1;
+}
+
 // draws of draw-dependent gap v when its draws start at base + d, for every d it can meet: a workgroup takes 256
 // consecutive deviations of one gap: the closure's links in LDS, one walk per thread.  What it needs to know comes
 // in three round trips: the tile's gap (tile_var), that gap's record (D3Var), then the closure's links and the
@@ -645,7 +676,7 @@ __global__ __launch_bounds__(256) void g2s_d3_tables(const D3Params P, const D3W
       const uint64_t av = capacity > at ? capacity - at : 0ull;
       const int draws = ns > D3_TAB_SEGS
                             ? d3_walk_count(vd.n_len, vd.len0, vd.len1, vd.start_seg, vd.start_t, (int)ns, (const SegW*)(sub + vd.sub_at), lwin + tid, nw, av, &bad)
-                            : d3_walk_count(vd.n_len, vd.len0, vd.len1, vd.start_seg, vd.start_t, (int)ns, lseg, lwin + tid, nw, av, &bad);
+                            : d3_walk_count_lite(vd.n_len, vd.len0, vd.len1, vd.start_seg, (int)ns, lseg, lwin + tid, nw, av, &bad);
       const int dev = draws - (int)vd.dmin;
       if (dev < 0 || dev > (int)vd.dspread) bad = true;
       W.tab[(uint64_t)vd.toff + d] = bad ? (uint16_t)0 : (uint16_t)dev;
