@@ -244,6 +244,30 @@ def test_resident_mode_on_toy_graphs(product, oracle, monkeypatch, seed):
         assert tm.resident_launches == 1 and tm.resident_fallbacks == 0
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_lists_in_flight_on_toy_graphs_vs_oracle(product, oracle, monkeypatch, seed):
+    """The same kind of lists cut into three to five consecutive lists that are in flight together (g2s_fill_begin /
+    g2s_fill_end, pinned and pageable buffers): the results in order are the oracle's for the one list — the rand()
+    stream goes from list to list, on the device or through the host, whatever each list's way to its end was
+    (tools/fuzz_parity.py --in-flight runs this comparison over random configurations)."""
+    monkeypatch.setenv("G2S_RESIDENT", "1")
+    k = [11, 15, 21, 31, 13, 17][seed]
+    seqs = cases.toy_genome(100 + seed, 4000, k, repeats=seed % 3, tandem=seed % 2, inverted=int(seed % 3 == 0), snp_every=(0 if seed % 2 else 97))
+    e = [20, 40, 9][seed % 3] + k
+    gaps = cases.cut_gaps(100 + seed, seqs[0], k, fuz=seed % 5 + 1, ngaps=150, min_len=1, max_len=120, d_err=e)
+
+    def in_flight(sess, structs):
+        rng = cases.SplitMix(seed)
+        n = len(structs)
+        cuts = sorted({0, n} | {rng.randint(1, n - 1) for _ in range(2 + seed % 3)})
+        lists = [structs[a:b] for a, b in zip(cuts, cuts[1:])]
+        outs, tm = sess.fill_lists_overlapped(lists, pinned=seed % 2 == 0, depth=2 + seed % 2)
+        return [r for part in outs for r in part], tm
+
+    c, f, _, _, _ = _check_batch(product, oracle, seqs, k, gaps, e, False, True, run_product=in_flight)
+    assert c > 100 and f > 20
+
+
 def test_resident_mode_gives_a_list_back(product, monkeypatch):
     """G2S_RESIDENT_TEST_FALLBACK: the device's attempt is discarded after it ran; the host path must then
     produce the same results from the same stream position (nothing of the attempt may have stuck)."""
