@@ -19,6 +19,10 @@ seqs = [ln for ln in reads.splitlines() if not ln.startswith(">")]
 gaps = bench.parse_gaps(P.G2S.synth_gaps(reads, k, 10, ngaps, min_len, max_len, 20240103), 10)
 if ngaps_override:
     gaps = gaps[:ngaps_override]
+if os.environ.get("G2S_PROFILE_ONLY"):  # these gaps alone (ids of the full list): each has a compute unit to itself
+    only = [int(x) for x in os.environ["G2S_PROFILE_ONLY"].split(",")]
+    gaps = [gaps[i] for i in only]
+    print("gaps", only, "alone: gap i below is the i-th of these")
 dump = tempfile.mktemp()
 os.environ["G2S_SEG_DUMP"] = dump
 pg = P.Graph.from_seqs(seqs, k, 1)
