@@ -8,11 +8,12 @@
 //   g2s_merge_scaffolds = what GapMerger reads back (/root/reference/src/GapMerger.cpp:142-235):
 //                         contigs in order, each followed by its (filled) gap record(s), the
 //                         markers stripped from the comment.
-// Pure host string work: nothing here touches the GPU.  g2s_cut_scaffolds follows the reference's scan
-// (GapCutter.cpp:160-319) case for case: its chain of distances from the current position (bases, N run,
-// bases, N run, bases) is the same chain here under other names, because the three cases and every offset
-// in them ARE the file format the wrapper and GapMerger depend on.  g2s_merge_scaffolds is arranged
-// differently (an index over the gap records instead of the reference's rescan per contig).
+// Pure host string work: nothing here touches the GPU.  g2s_cut_scaffolds tokenises a record ONCE into
+// runs (bases / N's) and walks the runs with a cursor (ScaffoldRuns below): what a cut emits is decided by
+// the lengths of the runs ahead of the cursor, classified into one of five outcomes (Cut) and emitted by
+// outcome.  The outcomes and every offset in them are the file format the wrapper and GapMerger depend on;
+// tests/test_gapio.py holds them against an independent restatement (oracle/gapio_ref.py).
+// g2s_merge_scaffolds keeps an index over the gap records instead of the reference's rescan per contig.
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -35,12 +36,45 @@ char* dup_text(const std::string& s) {
 
 inline bool is_gap_char(char c) { return c == 'N' || c == 'n'; }
 
-// length of the stretch of bases (gap = false) or of N/n (gap = true) that starts at `from`
-size_t stretch(const std::string& s, size_t from, bool gap) {
-  size_t e = from;
-  while (e < s.size() && is_gap_char(s[e]) == gap) e++;
-  return e - from;
-}
+// A scaffold record as alternating runs of bases and of N/n, with a cursor.  The cursor may stand inside a
+// run of bases (behind a right flank that became part of a gap record); it never stands inside a run of N's.
+struct ScaffoldRuns {
+  struct Run { size_t start, len; bool gap; };
+  std::vector<Run> runs;
+  size_t cur = 0;      // run the cursor stands in
+  size_t at = 0;       // the cursor's position in the record
+  size_t size = 0;
+
+  explicit ScaffoldRuns(const std::string& s) : size(s.size()) {
+    for (size_t i = 0; i < s.size();) {
+      size_t e = i;
+      const bool gap = is_gap_char(s[i]);
+      while (e < s.size() && is_gap_char(s[e]) == gap) e++;
+      runs.push_back({i, e - i, gap});
+      i = e;
+    }
+  }
+  bool done() const { return at >= size; }
+  // index of the first run of N's at or behind the cursor
+  size_t gap_run() const { return cur < runs.size() && runs[cur].gap ? cur : cur + 1; }
+  // bases between the cursor and that run
+  size_t bases_ahead() const { return cur < runs.size() && !runs[cur].gap ? runs[cur].start + runs[cur].len - at : 0; }
+  size_t len(size_t r) const { return r < runs.size() ? runs[r].len : 0; }
+  size_t start(size_t r) const { return r < runs.size() ? runs[r].start : size; }
+  void move_to(size_t pos) {
+    at = pos;
+    while (cur < runs.size() && runs[cur].start + runs[cur].len <= at) cur++;
+  }
+};
+
+// what the runs ahead of the cursor amount to
+enum class Cut {
+  kTail,        // no N's ahead: the rest of the record is a contig (GapCutter.cpp:189-195)
+  kNoLeftFlank, // fewer than k bases in front of the N's: contig up to their end (:198-204)
+  kPlain,       // a gap with a flank of its own on either side (:212-233, and :236-277 when not split)
+  kSplit,       // two gaps that share the bases between them as flank (:236-277)
+  kCluster,     // N runs around stretches too short to be flanks (:279-319)
+};
 
 const char* kScaffold = " scaffold ";
 const char* kContig = " contig ";
@@ -85,86 +119,82 @@ extern "C" int g2s_cut_scaffolds(const char* scaffolds_text, int k_, int fuz_, i
     // BED lines carry the record's name = the comment up to its first blank (:173-175; the reference
     // asserts that there is one, here a comment without a blank is its own name)
     const std::string name = rec.comment.substr(0, rec.comment.find(' '));
-    size_t at = 0;
-    while (at < s.size()) {
-      const std::string piece = rec.comment + kScaffold + std::to_string(n_scaffold) + kContig + std::to_string(n_contig);
+    const std::string tag = rec.comment + kScaffold + std::to_string(n_scaffold) + kContig;
+    ScaffoldRuns sc(s);
+    auto contig = [&](const std::string& comment, size_t from, size_t to) {
+      append_fasta(&contigs, comment, s.substr(from, to - from));
+      n_contig++;
+    };
+    auto bed_line = [&](size_t from, size_t to) { bed << name << "\t" << from << "\t" << to << "\n"; };
+    while (!sc.done()) {
+      const std::string piece = tag + std::to_string(n_contig);
       const std::string gap_piece = piece + kGap + std::to_string(n_gap);
-      const size_t left = stretch(s, at, false);          // bases before the next gap
-      const size_t hole = stretch(s, at + left, true);    // that gap
-      if (left > 0 && hole == 0) {                        // no gap left: the rest is a contig (:189-195)
-        append_fasta(&contigs, piece, s.substr(at));
-        n_contig++;
-        break;
+      const size_t g = sc.gap_run();              // the N's ahead, then: g+1 bases, g+2 N's, g+3 bases ...
+      const size_t left = sc.bases_ahead();
+      const size_t mid = sc.len(g + 1), after = sc.len(g + 3);
+      // ---- classify
+      Cut what;
+      size_t far = g + 3;                          // kCluster: the first later run of bases that can be a flank
+      if (g >= sc.runs.size()) what = Cut::kTail;
+      else if (left < k) what = Cut::kNoLeftFlank;
+      else if (mid >= 2 * k || (mid >= k && after == 0)) what = Cut::kPlain;
+      else if (mid >= k) what = (!no_split && after >= k) ? Cut::kSplit : Cut::kPlain;
+      else {
+        what = Cut::kCluster;
+        while (far < sc.runs.size() && sc.len(far) < k) far += 2;
+        if (far >= sc.runs.size()) what = Cut::kTail;   // no flank anywhere behind: everything left is a contig
       }
-      if (left < k) {                                     // no room for a left flank: contig up to the gap's end (:198-204)
-        append_fasta(&contigs, piece, s.substr(at, left + hole));
-        n_contig++;
-        at += left + hole;
-        continue;
-      }
+      // ---- emit
+      const size_t gap_at = sc.start(g), gap_end = gap_at + sc.len(g);
       const size_t lflank = std::min(left, reach);
-      const size_t gap_at = at + left;                    // first N of the gap
-      const size_t mid = stretch(s, gap_at + hole, false);               // bases between this gap and the next
-      const size_t hole2 = stretch(s, gap_at + hole + mid, true);        // the next gap
-      const size_t after = stretch(s, gap_at + hole + mid + hole2, false);  // bases after the next gap
-      // ---- case 1: enough sequence on both sides (:212-233)
-      if (mid >= 2 * k || (mid >= k && after == 0)) {
-        const size_t rflank = mid >= 2 * k ? std::min(mid, reach) : mid;  // the last gap takes the rest of the scaffold
-        append_fasta(&gaps, gap_piece, s.substr(gap_at - lflank, lflank + hole + rflank));
-        append_fasta(&contigs, gap_piece, s.substr(at, left - lflank));
-        bed << name << "\t" << gap_at - lflank << "\t" << gap_at + hole + rflank << "\n";
-        n_gap++;
-        n_contig++;
-        at = gap_at + hole + rflank;
-        continue;
-      }
-      // ---- case 2: two gaps share the sequence between them as flank (:236-277)
-      if (mid >= k) {
-        if (!no_split && after >= k) {
-          const size_t flank3 = std::min(after, reach);
-          // the first gap gets the whole middle as right flank, the second only its last k bases as left flank
-          append_fasta(&gaps, gap_piece + kSplit + "1", s.substr(gap_at - lflank, lflank + hole + mid));
-          append_fasta(&gaps, gap_piece + kSplit + "2 " + std::to_string(k), s.substr(gap_at + hole + mid - k, k + hole2 + flank3));
-          append_fasta(&contigs, gap_piece, s.substr(at, left - lflank));
-          bed << name << "\t" << gap_at - lflank << "\t" << gap_at + hole + mid << "\n";
-          bed << name << "\t" << gap_at + hole << "\t" << gap_at + hole + mid + hole2 + flank3 << "\n";
+      switch (what) {
+        case Cut::kTail:
+          contig(piece, sc.at, sc.size);
+          sc.move_to(sc.size);
+          break;
+        case Cut::kNoLeftFlank:
+          contig(piece, sc.at, gap_end);
+          sc.move_to(gap_end);
+          break;
+        case Cut::kPlain: {
+          // the scaffold's last gap takes whatever follows it; otherwise at most k + fuz bases
+          const size_t rflank = (mid < 2 * k && after == 0) ? mid : std::min(mid, reach);
+          append_fasta(&gaps, gap_piece, s.substr(gap_at - lflank, lflank + (gap_end - gap_at) + rflank));
+          bed_line(gap_at - lflank, gap_end + rflank);
+          contig(gap_piece, sc.at, gap_at - lflank);
           n_gap++;
-          n_contig++;
-          at = gap_at + hole + mid + hole2 + flank3;
-        } else {
-          const size_t rflank = std::min(mid, reach);
-          append_fasta(&gaps, gap_piece, s.substr(gap_at - lflank, lflank + hole + rflank));
-          append_fasta(&contigs, gap_piece, s.substr(at, left - lflank));
-          bed << name << "\t" << gap_at - lflank << "\t" << gap_at + hole + rflank << "\n";
-          n_gap++;
-          n_contig++;
-          at = gap_at + hole + rflank;
+          sc.move_to(gap_end + rflank);
+          break;
         }
-        continue;
-      }
-      // ---- case 3: gaps around sequence too short to be a flank: look for the next usable flank (:279-319)
-      size_t span = hole + mid + hole2, next = after;
-      while (next > 0 && next < k) {
-        span += next + stretch(s, gap_at + span + next, true);
-        next = stretch(s, gap_at + span, false);
-      }
-      if (next < k) {  // the last stretch is too short as well: everything left is a contig
-        append_fasta(&contigs, piece, s.substr(at));
-        n_contig++;
-        break;
-      }
-      if (mask) {      // everything between the two flanks becomes one gap of n's
-        const size_t rflank = std::min(next, reach);
-        append_fasta(&gaps, gap_piece, s.substr(gap_at - lflank, lflank) + std::string(span, 'n') + s.substr(gap_at + span, rflank));
-        append_fasta(&contigs, gap_piece, s.substr(at, left - lflank));
-        bed << name << "\t" << gap_at - lflank << "\t" << gap_at + span + rflank << "\n";
-        n_gap++;
-        n_contig++;
-        at = gap_at + span + rflank;
-      } else {
-        append_fasta(&contigs, piece, s.substr(at, left + span));
-        n_contig++;
-        at = gap_at + span;
+        case Cut::kSplit: {
+          // the first half gets the whole middle as right flank, the second its last k bases as left flank
+          const size_t gap2_at = sc.start(g + 2), gap2_end = gap2_at + sc.len(g + 2);
+          const size_t flank3 = std::min(after, reach);
+          append_fasta(&gaps, gap_piece + kSplit + "1", s.substr(gap_at - lflank, gap2_at - (gap_at - lflank)));
+          append_fasta(&gaps, gap_piece + kSplit + "2 " + std::to_string(k), s.substr(gap2_at - k, gap2_end + flank3 - (gap2_at - k)));
+          bed_line(gap_at - lflank, gap2_at);
+          bed_line(gap_end, gap2_end + flank3);
+          contig(gap_piece, sc.at, gap_at - lflank);
+          n_gap++;
+          sc.move_to(gap2_end + flank3);
+          break;
+        }
+        case Cut::kCluster: {
+          const size_t far_at = sc.start(far);      // everything in [gap_at, far_at) lies between two flanks
+          if (mask) {                               // and becomes one gap of n's
+            const size_t rflank = std::min(sc.len(far), reach);
+            append_fasta(&gaps, gap_piece,
+                         s.substr(gap_at - lflank, lflank) + std::string(far_at - gap_at, 'n') + s.substr(far_at, rflank));
+            bed_line(gap_at - lflank, far_at + rflank);
+            contig(gap_piece, sc.at, gap_at - lflank);
+            n_gap++;
+            sc.move_to(far_at + rflank);
+          } else {                                  // or stays inside a contig
+            contig(piece, sc.at, far_at);
+            sc.move_to(far_at);
+          }
+          break;
+        }
       }
     }
     n_scaffold++;
