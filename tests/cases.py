@@ -64,6 +64,15 @@ def toy_genome(seed, length, k, repeats=0, tandem=0, inverted=0, snp_every=0):
     return seqs
 
 
+def one_strand_genome(seed, length, alphabet="AC"):
+    """A genome over A and C only: the reverse complement of every k-mer is made of T and G, so no k-mer ever
+    meets its own reverse strand and NO gap is a Q7 case — at k = 5 or 7 the toy genomes of
+    toy_genome() make nearly every gap one, and Q7 gaps are outside the bit-exact comparison.  With 2^k
+    possible k-mers the graph is dense: dozens of cycles per closure, path counts that saturate at MAX_PATHS."""
+    rng = SplitMix(seed * 7919 + 13)
+    return "".join(alphabet[rng.randint(0, len(alphabet) - 1)] for _ in range(length))
+
+
 def cut_gaps(seed, genome, k, fuz, ngaps, min_len, max_len, d_err, vary_fuz=True, claim_noise=True):
     """List of dicts(left,right,gap_len,lmf,rmf,true_len).  The claimed gap length is
     chosen so that most gaps are fillable: the DP accepts path lengths

@@ -22,9 +22,9 @@ import oracle_lib as O  # noqa: E402
 import pyref  # noqa: E402
 
 
-def one_set(name, seed, k, length, e, fuz, ngaps, skip, allp, **gk):
+def one_set(name, seed, k, length, e, fuz, ngaps, skip, allp, min_len=1, max_len=80, **gk):
     seqs = cases.toy_genome(seed, length, k, **gk)
-    gaps = cases.cut_gaps(seed, seqs[0], k, fuz, ngaps, 1, 80, e)
+    gaps = cases.cut_gaps(seed, seqs[0], k, fuz, ngaps, min_len, max_len, e)
     og = O.OracleGraph(seqs, k, 1)
     pg = pyref.Graph(seqs, k, 1)
     rng, prng = O.OracleRng(11), pyref.GlibcRand(11)
@@ -93,6 +93,11 @@ def main():
         one_set("inverted_k15", 7, 15, 900, 15 + 12, 3, 12, False, True, inverted=3, repeats=1),
         one_set("even_k12", 8, 12, 900, 12 + 15, 3, 12, False, True, repeats=2, snp_every=89),
         one_set("wide_k33", 9, 33, 1600, 33 + 40, 6, 8, False, True, repeats=1, snp_every=150),
+        # SURVEY 8(c) pin (5): the 128-bit k-mer codec (k = 63 is BASELINE config 4's)
+        one_set("wide_k63", 10, 63, 2600, 63 + 60, 8, 8, False, True, repeats=1, snp_every=210),
+        # -dist-error 2000 (BASELINE config 5's): thousands of DP levels, a tandem repeat and bubbles inside them
+        one_set("deep_e2000", 13, 21, 9000, 2000, 10, 3, False, True, min_len=600, max_len=1500, repeats=2, tandem=2,
+                snp_every=260),
     ]
     with open(os.path.join(HERE, "fill_gap_cases.json"), "w") as f:
         json.dump(sets, f, indent=0, sort_keys=True)

@@ -168,8 +168,28 @@ def test_toy_graphs_all_modes(product, oracle, seed, tier):
     for skip, allp in ((False, True), (False, False), (True, True)):
         c, f, _, _, _ = _check_batch(product, oracle, seqs, k, gaps, e, skip, allp)  # asserts c == gaps - oracle Q7
         total += c
-    # (k = 5, 7: nearly every gap of a 900 bp genome meets both strands of some k-mer)
+    # (k = 5, 7: nearly every gap of a 900 bp genome meets both strands of some k-mer: _check_batch has
+    # asserted that each of those carries the product's Q7 flag and that every other gap is equal;
+    # test_small_k_without_strand_collisions is where gaps at these k are compared bit for bit)
     assert total >= (90 if k >= 11 else 30 if k >= 9 else 0)
+
+
+@pytest.mark.parametrize("k,length", [(5, 60), (5, 100), (7, 200)])
+def test_small_k_without_strand_collisions(product, oracle, k, length, tier):
+    """k = 5 and 7 on genomes over {A, C} (cases.one_strand_genome): no k-mer meets its reverse strand, so the
+    oracle sees no Q7 case and EVERY gap is compared bit for bit — dense graphs, closures made of cycles,
+    counts that saturate (on the toy graphs above nearly every gap at these k is a Q7 case and only its flag
+    is checked)."""
+    for seed in range(4):
+        seqs = [cases.one_strand_genome(seed, length)]
+        e = [0, 4, 9, 20, 31][seed % 5] + k
+        gaps = cases.cut_gaps(seed, seqs[0], k, fuz=seed % 3 + 1, ngaps=40, min_len=1, max_len=length // 4, d_err=e)
+        filled = 0
+        for skip, allp in ((False, True), (False, False), (True, True)):
+            c, f, _, _, _ = _check_batch(product, oracle, seqs, k, gaps, e, skip, allp)
+            assert c == len(gaps)
+            filled += f
+        assert filled >= 100
 
 
 def test_golden_vectors_on_gpu(product):

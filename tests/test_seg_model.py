@@ -138,3 +138,16 @@ def test_model_tandem_flanks_and_fuz_extremes(product, oracle):
         gaps = cases.cut_gaps(3 + fuz, seqs[0], k, fuz=fuz, ngaps=40, min_len=1, max_len=80, d_err=30)
         c, q = check_config(product, oracle, seqs, k, gaps, 30)
         assert c + q == 40 and c >= 20
+
+
+@pytest.mark.parametrize("k,length", [(5, 60), (5, 100), (7, 200)])
+def test_model_small_k_without_strand_collisions(product, oracle, k, length):
+    """k = 5 and 7 on genomes over {A, C}: no gap is a Q7 case, so every one is compared — dense graphs,
+    closures full of cycles, saturating counts (the toy graphs above leave almost nothing to compare at these k)."""
+    for seed in range(3):
+        seqs = [cases.one_strand_genome(seed, length)]
+        e = [0, 4, 9, 20, 31][seed % 5] + k
+        gaps = cases.cut_gaps(seed, seqs[0], k, fuz=seed % 3 + 1, ngaps=16, min_len=1, max_len=length // 4, d_err=e)
+        for skip, allp in ((False, True), (False, False), (True, True)):
+            c, q = check_config(product, oracle, seqs, k, gaps, e, allp, skip)
+            assert (c, q) == (len(gaps), 0)
