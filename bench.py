@@ -212,6 +212,9 @@ class StreamRunner:
         return time.perf_counter() - t0, out
 
     def free(self):
+        # (after an error between begin and end the lists still in flight write into these buffers: end them first)
+        while self.lib.g2s_fill_in_flight(self.s.h) > 0:
+            self.lib.g2s_fill_end(self.s.h)
         for a, r, _, _ in self.sets:
             if r is not None:
                 a.free()

@@ -84,8 +84,13 @@ int main(int argc, char** argv) {
   // (GATB: all cores) the reference's per-gap budget depends on the host's CPU count, which says nothing about
   // what a GPU can hold; the whole budget then applies per gap (the device-budget analogue D3)
   const int mem_div = std::max(1, o.nb_cores);
-  if (o.nb_cores <= 0) o.nb_cores = (int)std::max(1u, std::thread::hardware_concurrency());
+  const bool cores_given = o.nb_cores > 0;
+  if (!cores_given) o.nb_cores = (int)std::max(1u, std::thread::hardware_concurrency());
   p.max_mem = (int64_t)(o.max_mem_gb * 1024 * 1024 * 1024) / mem_div;
+  if (!cores_given)  // (the "Max mem:" line of the log keeps the reference's formula, :302-303; this is what applies)
+    std::cerr << "[g2s] -nb-cores not given: the whole -max-mem (" << (long long)p.max_mem
+              << " bytes) is the per-gap device budget; the log's \"Max mem:\" line is -max-mem / " << o.nb_cores
+              << " host CPUs as the reference prints it" << std::endl;
   // the session seeds with time(NULL) when this is 0 (:178); the echo prints the user's value (:191)
   p.randseed = randseed > 0 ? (uint32_t)randseed : 0u;
   p.host_threads = 0;

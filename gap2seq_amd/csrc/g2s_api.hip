@@ -58,6 +58,7 @@ static int fail(int code, const std::string& msg) { tl_error = msg; return code;
     if (e_ != hipSuccess) {                                                                   \
       (void)hipStreamSynchronize(s->stream);                                                  \
       (void)hipStreamSynchronize(s->stream2);                                                 \
+      if (s->stream3) (void)hipStreamSynchronize(s->stream3);                                 \
       return fail(G2S_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));            \
     }                                                                                         \
   } while (0)
@@ -627,9 +628,26 @@ struct g2s_session {
                     bool chained = false; };  // its rand() stream continues the older list's on the device
   InFlight inflight[G2S_MAX_IN_FLIGHT];
   int n_inflight = 0;
+  // g2s_fill_begin / g2s_fill_end calling the other entry points for a list of their own: those refuse callers
+  // while lists are in flight (the lists' kernels still read and write this session's buffers)
+  int internal_calls = 0;
   uint64_t begun = 0;
   bool resident_off = false;
 };
+
+static void d3_pending_drop(g2s_session* s);  // (D3Pending is defined with phase D3's launch code below)
+namespace {
+// Between g2s_fill_begin and the matching g2s_fill_end the session's pinned and device buffers belong to the lists in
+// flight: every other entry point that would queue work on the session, or move its rand() stream, refuses.
+inline bool lists_in_flight(const g2s_session* s) { return s && s->n_inflight > 0 && s->internal_calls == 0; }
+struct InternalCall {
+  g2s_session* s;
+  explicit InternalCall(g2s_session* s_) : s(s_) { s->internal_calls++; }
+  ~InternalCall() { s->internal_calls--; }
+};
+#define REFUSE_IN_FLIGHT(s, who) \
+  do { if (lists_in_flight(s)) return fail(G2S_ERR_STATE, who ": lists are in flight on this session (g2s_fill_end them first)"); } while (0)
+}  // namespace
 
 extern "C" int g2s_session_create(g2s_graph* g, int device, const g2s_params* p, g2s_session** out) {
   if (!g || !p || !out) return fail(G2S_ERR_ARG, "g2s_session_create: bad argument");
@@ -717,13 +735,21 @@ extern "C" int g2s_session_create(g2s_graph* g, int device, const g2s_params* p,
 
 extern "C" void g2s_session_destroy(g2s_session* s) {
   if (!s) return;
-  for (int q = 0; q < s->n_inflight; q++) {  // (lists begun and never ended: their kernels first)
-    if (s->inflight[q].on) { (void)hipSetDevice(s->inflight[q].on->device); (void)hipStreamSynchronize(s->inflight[q].on->stream); }
-    g2s_batch_free(s->inflight[q].b);
-  }
+  // lists begun and never ended: their kernels first — on all three streams of every session that carries one (the
+  // rand() stream and the descriptors run on the second, the large variant's early launch on the third) — and what
+  // was queued for their phase D3 (it points into the batches freed below)
+  for (int q = 0; q < s->n_inflight; q++)
+    if (g2s_session* on = s->inflight[q].on) {
+      (void)hipSetDevice(on->device);
+      for (hipStream_t st : {on->stream, on->stream2, on->stream3}) if (st) (void)hipStreamSynchronize(st);
+    }
+  d3_pending_drop(s);
+  for (g2s_session* t : s->twins) if (t) d3_pending_drop(t);
+  for (int q = 0; q < s->n_inflight; q++) g2s_batch_free(s->inflight[q].b);
   s->n_inflight = 0;
   for (g2s_session*& t : s->twins) if (t) { g2s_session_destroy(t); t = nullptr; }
   (void)hipSetDevice(s->device);
+  for (hipStream_t st : {s->stream, s->stream2, s->stream3}) if (st) (void)hipStreamSynchronize(st);
   DevBuf* bufs[] = {&s->d_gaps, &s->d_ids, &s->d_flank, &s->d_outs, &s->d_rs, &s->d_rlog, &s->d_keys,
                     &s->d_cnt, &s->d_mark, &s->d_slog, &s->d_subscr, &s->d_subout, &s->d_counter, &s->d_xcd,
                     &s->d_log, &s->d_lvl, &s->d_plk, &s->d_xl, &s->d_xo, &s->d_rspool, &s->d_logpool, &s->d_segx, &s->d_ovf};
@@ -752,15 +778,23 @@ extern "C" void g2s_session_destroy(g2s_session* s) {
   delete s;
 }
 
-extern "C" void g2s_session_srand(g2s_session* s, uint32_t seed) { if (s) s->rcache.seed(seed); }
-extern "C" void g2s_session_skip_draws(g2s_session* s, uint64_t n) {
-  if (!s) return;
+extern "C" int g2s_session_srand(g2s_session* s, uint32_t seed) {
+  if (!s) return fail(G2S_ERR_ARG, "g2s_session_srand: bad argument");
+  // (a list in flight that continues an older one's stream on the device would not see the new seed)
+  REFUSE_IN_FLIGHT(s, "g2s_session_srand");
+  s->rcache.seed(seed);
+  return G2S_OK;
+}
+extern "C" int g2s_session_skip_draws(g2s_session* s, uint64_t n) {
+  if (!s) return fail(G2S_ERR_ARG, "g2s_session_skip_draws: bad argument");
+  REFUSE_IN_FLIGHT(s, "g2s_session_skip_draws");
   while (n) {  // in pieces: the stream is materialised before it is consumed
     const size_t c = (size_t)std::min<uint64_t>(n, 1u << 20);
     s->rcache.ensure(c);
     s->rcache.consume(c);
     n -= c;
   }
+  return G2S_OK;
 }
 
 // ---------------------------------------------------------------------------
@@ -862,6 +896,7 @@ static bool resident_applicable(const g2s_session* s, size_t n) {
 
 extern "C" int g2s_batch_prepare(g2s_session* s, const g2s_gap* gaps, size_t n, g2s_batch** out) {
   if (!s || (!gaps && n) || !out) return fail(G2S_ERR_ARG, "g2s_batch_prepare: bad argument");
+  REFUSE_IN_FLIGHT(s, "g2s_batch_prepare");
   const Graph& g = *s->graph->g;
   const int k = g.k;
   const auto tp0 = std::chrono::steady_clock::now();
@@ -3400,10 +3435,13 @@ int run_resident(g2s_batch* b, g2s_result* results, char* arena) {
 
 }  // namespace
 
+static void d3_pending_drop(g2s_session* s) { delete (D3Pending*)s->d3_pending; s->d3_pending = nullptr; }
+
 extern "C" int g2s_batch_run(g2s_batch* b, g2s_result* results, char* arena, size_t arena_cap) {
   if (!b || !results || (!arena && b->arena_bytes)) return fail(G2S_ERR_ARG, "g2s_batch_run: bad argument");
   if (arena_cap < b->arena_bytes) return fail(G2S_ERR_ARG, "g2s_batch_run: fill arena too small");
   g2s_session* s = b->s;
+  REFUSE_IN_FLIGHT(s, "g2s_batch_run");
   const size_t n = b->jobs.size();
   const auto t_run0 = std::chrono::steady_clock::now();
   {  // the whole list on the device when that applies (run_resident); otherwise, or when it gives up, the host path
@@ -3849,6 +3887,7 @@ extern "C" int g2s_team_fill(g2s_session* const* sessions, int nsessions, const 
   for (int t = 0; t < nsessions; t++)
     if (!sessions[t] || sessions[t]->graph != sessions[0]->graph)
       return fail(G2S_ERR_ARG, "g2s_team_fill: sessions must share one graph");
+  for (int t = 0; t < nsessions; t++) REFUSE_IN_FLIGHT(sessions[t], "g2s_team_fill");
   if (group_size == 0) group_size = 2048;
   {
     const size_t need = g2s_team_arena_bytes(sessions[0], gaps, n);
@@ -4018,6 +4057,7 @@ extern "C" size_t g2s_team_arena_bytes(const g2s_session* s, const g2s_gap* gaps
 extern "C" int g2s_fill_batch(g2s_session* s, const g2s_gap* gaps, size_t n, g2s_result* results, char* fill_arena,
                               size_t arena_cap) {
   if (!s) return fail(G2S_ERR_ARG, "g2s_fill_batch: bad argument");
+  REFUSE_IN_FLIGHT(s, "g2s_fill_batch");
   // long lists go through the group pipeline: with helpers to use every session, without
   // them to bound the HBM the state logs of one launch take
   const size_t group = s->team_group ? s->team_group : (s->helpers.empty() ? (size_t)16384 : (size_t)2048);
@@ -4086,6 +4126,7 @@ int inflight_settle(g2s_session* s) {
 extern "C" int g2s_fill_begin(g2s_session* s, const g2s_gap* gaps, size_t n, g2s_result* results, char* fill_arena, size_t arena_cap) {
   if (!s || (!gaps && n) || (!results && n)) return fail(G2S_ERR_ARG, "g2s_fill_begin: bad argument");
   if (s->n_inflight >= G2S_MAX_IN_FLIGHT) return fail(G2S_ERR_ARG, "g2s_fill_begin: G2S_MAX_IN_FLIGHT lists are in flight already (g2s_fill_end first)");
+  InternalCall own(s);
   g2s_session::InFlight f;
   f.results = results; f.arena = fill_arena; f.cap = arena_cap; f.gaps = gaps; f.n = n;
   const size_t group = s->team_group ? s->team_group : (s->helpers.empty() ? (size_t)16384 : (size_t)2048);
@@ -4134,6 +4175,7 @@ extern "C" int g2s_fill_begin(g2s_session* s, const g2s_gap* gaps, size_t n, g2s
 }
 extern "C" int g2s_fill_end(g2s_session* s) {
   if (!s || s->n_inflight < 1) return fail(G2S_ERR_ARG, "g2s_fill_end: no list in flight");
+  InternalCall own(s);
   g2s_session::InFlight f = s->inflight[0];
   for (int i = 1; i < G2S_MAX_IN_FLIGHT; i++) s->inflight[i - 1] = s->inflight[i];
   s->inflight[G2S_MAX_IN_FLIGHT - 1] = g2s_session::InFlight();
@@ -4171,6 +4213,7 @@ extern "C" int g2s_session_set_team(g2s_session* lead, g2s_session* const* helpe
   for (int i = 0; i < nhelpers; i++)
     if (!helpers[i] || helpers[i] == lead || helpers[i]->graph != lead->graph)
       return fail(G2S_ERR_ARG, "g2s_session_set_team: helpers must be other sessions on the same graph");
+  REFUSE_IN_FLIGHT(lead, "g2s_session_set_team");
   lead->helpers.assign(helpers, helpers + nhelpers);
   lead->team_group = group_size;
   return G2S_OK;

@@ -120,10 +120,10 @@ extern "C" int g2s_execute_scaffolds_stream(g2s_session* s, const g2s_run_opts* 
   std::string fasta;
   const long long max_mem_total = (long long)(o->max_mem_gb * 1024 * 1024 * 1024);  // :170
   echo_params(os, *o, p, reads_label, filled_label, max_mem_total);
-  // :302-303 prints the per-gap budget, total / threads.  Here: the budget the session applies (g2s_params.max_mem) —
-  // the same number whenever -nb-cores is given; with the option omitted Gap2Seq-core applies the whole -max-mem per
-  // gap (core_main.cpp: a host's CPU count says nothing about what a GPU can hold) and says so here.
-  os << "Max mem: " << (p.max_mem > 0 ? (long long)p.max_mem : max_mem_total / std::max(1, o->nb_cores)) << "\n";
+  // :302-303: the reference's own line, total / execution units (Gap2Seq-core hands over the host's CPU count when
+  // -nb-cores is omitted, as GATB's dispatcher does).  The budget the session APPLIES is g2s_params.max_mem — the same
+  // number whenever -nb-cores is given; when it is omitted the command line says on stderr what applies instead.
+  os << "Max mem: " << max_mem_total / std::max(1, o->nb_cores) << "\n";
 
   std::vector<FastxRecord> recs;
   parse_fastx(std::string(scaffolds_text), &recs);

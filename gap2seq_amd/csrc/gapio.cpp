@@ -12,7 +12,7 @@
 // runs (bases / N's) and walks the runs with a cursor (ScaffoldRuns below): what a cut emits is decided by
 // the lengths of the runs ahead of the cursor, classified into one of five outcomes (Cut) and emitted by
 // outcome.  The outcomes and every offset in them are the file format the wrapper and GapMerger depend on;
-// tests/test_gapio.py holds them against an independent restatement (oracle/gapio_ref.py).
+// tests/test_gapio.py holds them against an independent Python restatement.
 // g2s_merge_scaffolds keeps an index over the gap records instead of the reference's rescan per contig.
 #include <cstdlib>
 #include <cstring>

@@ -12,6 +12,7 @@ import os
 G2S_OK = 0
 G2S_ERR_IO = -2
 G2S_ERR_NO_DEVICE = -3
+G2S_ERR_STATE = -6
 G2S_INVALID_NODE = 0xFFFFFFFF
 G2S_MAX_PATHS = 2147483647 // 2 - 1
 G2S_MAX_IN_FLIGHT = 3  # include/g2s.h: lists begun and not ended on one session
@@ -109,8 +110,8 @@ _SIGS = {
     "g2s_graph_device_bytes": (C.c_uint64, [_VP, C.c_int]),
     "g2s_session_create": (C.c_int, [_VP, C.c_int, C.POINTER(g2s_params), C.POINTER(_VP)]),
     "g2s_session_destroy": (None, [_VP]),
-    "g2s_session_srand": (None, [_VP, C.c_uint32]),
-    "g2s_session_skip_draws": (None, [_VP, C.c_uint64]),
+    "g2s_session_srand": (C.c_int, [_VP, C.c_uint32]),
+    "g2s_session_skip_draws": (C.c_int, [_VP, C.c_uint64]),
     "g2s_session_graph": (_VP, [_VP]),
     "g2s_session_get_params": (C.c_int, [_VP, C.POINTER(g2s_params)]),
     "g2s_batch_prepare": (C.c_int, [_VP, C.POINTER(g2s_gap), C.c_size_t, C.POINTER(_VP)]),
@@ -422,9 +423,9 @@ class Session:
         self.h = h
 
     def srand(self, seed, skip=0):
-        load_library().g2s_session_srand(self.h, seed)
+        _check(load_library().g2s_session_srand(self.h, seed))
         if skip:
-            load_library().g2s_session_skip_draws(self.h, skip)
+            _check(load_library().g2s_session_skip_draws(self.h, skip))
 
     def fill_batch(self, gaps, want_timing=False, pinned=False):
         """prepare + run; returns list of FillResult (and g2s_timing).  pinned: results and arena in
@@ -486,6 +487,10 @@ class Session:
                 raw = c["arena"].raw
                 out.append([FillResult(c["res"][i], raw) for i in range(c["n"])])
         finally:
+            # (an error between begin and end: the lists still in flight write into these buffers — end them,
+            # whatever they return, before the buffers go)
+            while lib.g2s_fill_in_flight(self.h) > 0:
+                lib.g2s_fill_end(self.h)
             for c in ctx:
                 if c["rbuf"] is not None:
                     c["rbuf"].free()

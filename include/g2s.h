@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define G2S_ABI_VERSION 4
+#define G2S_ABI_VERSION 5
 
 /* status codes */
 #define G2S_OK 0
@@ -164,7 +164,11 @@ typedef struct g2s_result {
  * buffers, which must stay valid until then) and returns what g2s_fill_batch() would.  At most G2S_MAX_IN_FLIGHT lists
  * may be begun and not ended: the younger ones' kernels then run while the oldest one's results cross the link and the
  * host prepares the next.  Lists end in the order they were begun and draw from the session's one rand() stream in
- * that order: results are identical to g2s_fill_batch() list by list.  g2s_fill_in_flight(): lists begun, not ended. */
+ * that order: results are identical to g2s_fill_batch() list by list.  g2s_fill_in_flight(): lists begun, not ended.
+ * While lists are in flight the session's buffers and its rand() stream belong to them: g2s_fill_batch,
+ * g2s_batch_prepare, g2s_batch_run, g2s_team_fill (with this session in the team), g2s_session_set_team,
+ * g2s_session_srand and g2s_session_skip_draws return G2S_ERR_STATE and do nothing until every list has been ended
+ * (ABI 5; g2s_session_destroy may be called at any time: it waits for the lists' kernels and drops them). */
 #define G2S_MAX_IN_FLIGHT 3
 int g2s_fill_begin(g2s_session* s, const g2s_gap* gaps, size_t n, g2s_result* results, char* fill_arena, size_t arena_cap);
 int g2s_fill_end(g2s_session* s);
@@ -235,11 +239,11 @@ typedef struct g2s_timing {
  * ------------------------------------------------------------------------ */
 int g2s_session_create(g2s_graph* g, int device, const g2s_params* p, g2s_session** out);
 void g2s_session_destroy(g2s_session* s);
-/* srand(seed) (Gap2Seq.cpp:178). */
-void g2s_session_srand(g2s_session* s, uint32_t seed);
+/* srand(seed) (Gap2Seq.cpp:178).  G2S_OK, or G2S_ERR_STATE with lists in flight (ABI 5: void before). */
+int g2s_session_srand(g2s_session* s, uint32_t seed);
 /* Discard the next n values of the session's rand() stream: what n calls of rand() by the
- * caller between two fill_gap calls would do to the reference's libc stream. */
-void g2s_session_skip_draws(g2s_session* s, uint64_t n);
+ * caller between two fill_gap calls would do to the reference's libc stream.  Returns as g2s_session_srand. */
+int g2s_session_skip_draws(g2s_session* s, uint64_t n);
 
 /* Resolve flank k-mers to node ids on the host and upload the gap descriptors
  * to HBM.  Replaces the argument marshalling of Gap2Seq.cpp:380-383. */

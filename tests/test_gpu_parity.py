@@ -417,6 +417,28 @@ def test_bench_workload_c2_vs_oracle(product, oracle):
     pg.free()
 
 
+def test_log_keeps_the_references_max_mem_line_whatever_budget_applies(product, oracle):
+    """`Max mem:` is -max-mem / execution units in the reference (Gap2Seq.cpp:302-303).  The session applies its own
+    per-gap budget (g2s_params.max_mem: the whole -max-mem when -nb-cores is omitted on the command line); the log
+    line keeps the reference's formula either way."""
+    reads = product.G2S.synth_genome(60000, 3, 20240101)
+    seqs = [ln for ln in reads.splitlines() if not ln.startswith(">")]
+    scaf = product.G2S.synth_gaps(reads, 31, 10, 20, 100, 400, 20240103)
+    og = oracle.OracleGraph(seqs, 31, 1)
+    pg = product.Graph.from_seqs(seqs, 31, 1)
+    try:
+        for cores in (1, 7, 64):
+            ofa, olog, sm = oracle.execute_scaffolds(og, scaf, 31, solid=1, d_err=500, max_fuz=10, randseed=1, nb_cores=cores)
+            sess = product.Session(pg, 0, d_err=500, randseed=1)  # (budget: the whole 20 GB per gap, not divided)
+            fa, lg, ngaps, nfilled = sess.execute_scaffolds(scaf, 31, solid=1, max_fuz=10, nb_cores=cores)
+            sess.destroy()
+            assert "Max mem: %d\n" % ((20 << 30) // cores) in lg
+            assert fa == ofa and lg == olog
+    finally:
+        og.free()
+        pg.free()
+
+
 @pytest.mark.parametrize("which", ["res", "seg", "lds"])
 def test_c3_gap_list_on_the_branching_genome_vs_oracle(product, oracle, which, monkeypatch):
     """BASELINE config 3's list length (10 000 gaps, 3 Mbp, k=31, -fuz 10, -dist-error 500) on

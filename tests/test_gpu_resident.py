@@ -160,6 +160,66 @@ def test_two_lists_in_flight_equal_list_by_list(product, monkeypatch):
         pg.free()
 
 
+def test_other_entry_points_refuse_while_lists_are_in_flight(product, monkeypatch):
+    """Between g2s_fill_begin and the matching g2s_fill_end the session's buffers and rand() stream belong to the lists in
+    flight (include/g2s.h, ABI 5): every other entry point that would queue work on the session or move its stream
+    returns G2S_ERR_STATE and changes nothing — the lists then end with the results of g2s_fill_batch list by list; and a
+    session destroyed with lists begun and never ended waits for their kernels."""
+    import ctypes as C
+    reads = product.G2S.synth_genome(200000, 3, 20240101)
+    seqs = [ln for ln in reads.splitlines() if not ln.startswith(">")]
+    allg = _gaps(product, _parse_scaffolds(product.G2S.synth_gaps(reads, 31, 10, 1200, 100, 900, 20240103)))
+    lists = [allg[:500], allg[500:900], allg[900:]]
+    lib = product.load_library()
+    pg = product.Graph.from_seqs(seqs, 31, 1)
+    try:
+        monkeypatch.delenv("G2S_RESIDENT", raising=False)
+        s = product.Session(pg, 0, d_err=500, randseed=7)
+        want = [[_key(r) for r in s.fill_batch(L, pinned=True)] for L in lists]
+        s.destroy()
+        s = product.Session(pg, 0, d_err=500, randseed=7)
+        helper = product.Session(pg, 0, d_err=500, randseed=7)
+        ctx = []
+        for L in lists:
+            arr, keep = product._gap_array(L)
+            nbytes = lib.g2s_team_arena_bytes(s.h, arr, len(L))
+            arena, rbuf = product.HostBuffer(max(1, nbytes)), product.HostBuffer(C.sizeof(product.g2s_result) * len(L))
+            ctx.append((arr, keep, nbytes, arena, rbuf, rbuf.array(product.g2s_result, len(L))))
+        for arr, keep, nbytes, arena, rbuf, res in ctx[:2]:
+            product._check(lib.g2s_fill_begin(s.h, arr, len(res), res, C.cast(arena.p, C.c_void_p), nbytes))
+        arr, keep, nbytes, arena, rbuf, res = ctx[2]
+        ap = C.cast(arena.p, C.c_char_p)
+        b = product._VP()
+        team = (product._VP * 2)(s.h, helper.h)
+        refused = [
+            lib.g2s_fill_batch(s.h, arr, len(res), res, ap, nbytes),
+            lib.g2s_batch_prepare(s.h, arr, len(res), C.byref(b)),
+            lib.g2s_team_fill(team, 2, arr, len(res), 0, res, ap, nbytes, None),
+            lib.g2s_session_set_team(s.h, (product._VP * 1)(helper.h), 1, 0),
+            lib.g2s_session_srand(s.h, 99),
+            lib.g2s_session_skip_draws(s.h, 5),
+        ]
+        assert refused == [product.G2S_ERR_STATE] * len(refused)
+        assert b"in flight" in lib.g2s_last_error()
+        assert lib.g2s_fill_in_flight(s.h) == 2
+        product._check(lib.g2s_fill_begin(s.h, arr, len(res), res, C.cast(arena.p, C.c_void_p), nbytes))
+        while lib.g2s_fill_in_flight(s.h) > 0:
+            product._check(lib.g2s_fill_end(s.h))
+        got = [[_key(product.FillResult(c[5][i], c[3].raw)) for i in range(len(c[5]))] for c in ctx]
+        assert got == want
+        s.srand(7)  # (no list in flight any more)
+        # a session destroyed with lists begun and never ended: their kernels are waited for, the buffers go afterwards
+        for arr, keep, nbytes, arena, rbuf, res in ctx[:2]:
+            product._check(lib.g2s_fill_begin(s.h, arr, len(res), res, C.cast(arena.p, C.c_void_p), nbytes))
+        s.destroy()
+        helper.destroy()
+        for c in ctx:
+            c[3].free()
+            c[4].free()
+    finally:
+        pg.free()
+
+
 def test_lists_in_flight_when_one_does_not_end_on_the_device(product, monkeypatch):
     """Lists in flight draw from ONE rand() stream, and the list behind another has its phase D3 queued before the one
     in front has ended: its stream is generated on the device from the state the older list's kernels leave there.
