@@ -1,0 +1,893 @@
+// gap2seq_amd/csrc/d2_device.hip — phase D2 of fill_gap (/root/reference/src/Gap2Seq.cpp:1314-1435: strong
+// components, contraction, topological sweep with the branch counter, branch[v] == 1) on the device, for the closures
+// the fill kernels leave unanalysed: more than 192 segments, or a k-mer at several depths.  One wave per gap, the
+// gap's graph in LDS; post.cpp (seg_analyze, seg_analyze_runs) is the host version and the reference for every step.
+//
+// A closure arrives as SegRec records (fill_device.h): unitig segments whose states t <= ts lie on a path to a sink.
+//  * Every k-mer at one depth (the segments' index intervals are disjoint: a sort tells): the subgraph is a DAG whose
+//    vertices are the states, and the branch rule is a prefix sum over the segments in creation order (fill_seg.hip
+//    does the same for closures of up to 192 segments, with a pairwise test in place of the sort).
+//  * Otherwise the reference's vertices are K-MERS (node2boost) and its edges the de-duplicated state transitions.
+//    Inside a unitig those are index +-1 steps: cut the closure's index intervals at every segment end and at every
+//    k-mer that carries another edge (a parent's last k-mer, an entry, a sink position); between two cuts lies a RUN
+//    of k-mers whose only edges are the chain's own.  The run graph (a few hundred to a few thousand nodes) goes
+//    into LDS as two adjacency tables.  Strong components: nodes without a live edge in or out are peeled off round
+//    by round (each its own component), what is left is cycles and the paths between them — a forward and a backward
+//    search from a pivot give one component, and the peeling goes on.  Then the components in topological order
+//    (Kahn, by rounds; any topological order gives the same verdicts), the branch counter as a prefix
+//    sum over that order, and the verdict of every run.
+// What leaves: per gap the subgraph statistics and a sorted list of runs {first index, last index | safe << 31};
+// g2s_d3_trace looks the safe bit of a traced base up there (a k-mer in no run reads branch[sink], Q5).
+// A closure beyond an instantiation's capacities is passed on (small -> large) or left to the host (post.cpp).
+#include <hip/hip_runtime.h>
+
+#include "d2_device.h"
+#include "seg_device.h"
+
+namespace {
+
+using g2s::D2Args;
+using g2s::D2Out;
+
+template <uint32_t NS_, uint32_t NREC_, uint32_t BP_, uint32_t NV_, uint32_t E_>
+struct D2Caps {
+  static constexpr uint32_t NS = NS_, NREC = NREC_, BP = BP_, NV = NV_, E = E_;
+  // LDS, bytes: the sort buffer (and, DAG closures, the per-segment words behind its first NS keys) ...
+  static constexpr uint32_t K_BYTES = BP * 8u;
+  // ... or the graph: offsets and adjacency in both directions (u16), live degrees (u16, packed), component / state
+  // (u32), two work lists (u16)
+  static constexpr uint32_t OFF_BYTES = ((NV + 2u) * 2u + 15u) & ~15u;
+  static constexpr uint32_t G_BYTES = 2u * OFF_BYTES + 2u * E * 2u + 2u * NV * 2u + NV * 4u + 2u * NV * 2u;
+  static constexpr uint32_t LDS_BYTES = (K_BYTES > G_BYTES ? K_BYTES : G_BYTES) + 64u;
+  // global scratch of a workgroup, words
+  static constexpr uint32_t SCR_WORDS = 9u * NS + 2u * BP + 4u * NV + E + 64u;
+};
+using D2Small = D2Caps<G2S_D2_SMALL_NS, G2S_D2_SMALL_NREC, G2S_D2_SMALL_BP, G2S_D2_SMALL_NV, G2S_D2_SMALL_E>;
+using D2Big = D2Caps<G2S_D2_BIG_NS, G2S_D2_BIG_NREC, G2S_D2_BIG_BP, G2S_D2_BIG_NV, G2S_D2_BIG_E>;
+
+#define D2_ALIVE 0xFFFFFFFFu
+#define D2_QUEUED 0xFFFFFFFEu
+#define D2_FW 0xFFFFFFFDu
+#define D2_FWBW 0xFFFFFFFCu
+
+// what the wave wrote to global scratch is read back by other lanes
+__device__ __forceinline__ void gsync() {
+  __threadfence_block();
+  __builtin_amdgcn_wave_barrier();
+}
+// 16-bit counters, two a word: atomics on the word (a counter never leaves 0 .. 65535)
+__device__ __forceinline__ uint32_t pk_get(const uint32_t* a, uint32_t i) { return (a[i >> 1] >> (16u * (i & 1u))) & 0xFFFFu; }
+__device__ __forceinline__ uint32_t pk_add(uint32_t* a, uint32_t i, uint32_t d) {
+  const uint32_t sh = 16u * (i & 1u);
+  return (atomicAdd(&a[i >> 1], d << sh) >> sh) & 0xFFFFu;
+}
+__device__ __forceinline__ uint32_t pk_sub(uint32_t* a, uint32_t i, uint32_t d) {
+  const uint32_t sh = 16u * (i & 1u);
+  return (atomicSub(&a[i >> 1], d << sh) >> sh) & 0xFFFFu;
+}
+__device__ __forceinline__ uint32_t pow2_at_least(uint32_t n) {
+  uint32_t p = 2u;
+  while (p < n) p <<= 1;
+  return p;
+}
+// intervals {first, last} sorted by first, disjoint: is x in one of them?  *hi_out: the last index of that one
+__device__ __forceinline__ bool iv_has(const uint32_t* iv, uint32_t m, uint32_t x, uint32_t* hi_out = nullptr) {
+  uint32_t lo = 0, hi = m;
+  while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (iv[2u * mid] <= x) lo = mid + 1u; else hi = mid; }
+  if (lo == 0u) return false;
+  const uint32_t h = iv[2u * (lo - 1u) + 1u];
+  if (hi_out) *hi_out = h;
+  return x <= h;
+}
+// position of x in a sorted list of distinct values (x is in it)
+__device__ __forceinline__ uint32_t cut_index(const uint32_t* cut, uint32_t n, uint32_t x) {
+  uint32_t lo = 0, hi = n;
+  while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (cut[mid] < x) lo = mid + 1u; else hi = mid; }
+  return lo < n ? lo : n - 1u;
+}
+
+struct SegD {  // a closure segment as this kernel reads it
+  uint32_t node, dl, ts_tt, p01, p23, flags;
+  __device__ __forceinline__ int ts() const { return dec15(ts_tt); }
+  __device__ __forceinline__ int len() const { return (int)(dl >> 16); }
+  __device__ __forceinline__ int d0() const { return (int)(dl & 0xFFFFu); }
+  __device__ __forceinline__ bool up() const { return (node & 1u) == 0u; }
+  __device__ __forceinline__ bool source() const { return (flags & G2S_SUB_SOURCE) != 0u; }
+  __device__ __forceinline__ uint32_t idx(int t) const { return up() ? (node >> 1) + (uint32_t)t : (node >> 1) - (uint32_t)t; }
+  __device__ __forceinline__ uint32_t par(int q) const { return q == 0 ? (p01 & 0xFFFFu) : q == 1 ? (p01 >> 16) : q == 2 ? (p23 & 0xFFFFu) : (p23 >> 16); }
+  __device__ __forceinline__ int npar() const {
+    if (source()) return 0;  // (post.cpp: seg_parents)
+    return (int)(((p01 & 0xFFFFu) != 0xFFFFu) + ((p01 >> 16) != 0xFFFFu) + ((p23 & 0xFFFFu) != 0xFFFFu) + ((p23 >> 16) != 0xFFFFu));
+  }
+};
+__device__ __forceinline__ SegD seg_load(const SegRec* segs, uint32_t q) {
+  const uint4 a = ((const uint4*)(segs + q))[0];
+  const uint2 b = ((const uint2*)(segs + q))[2];
+  SegD s;
+  s.node = a.x; s.dl = a.y; s.ts_tt = a.w; s.p01 = b.x; s.p23 = b.y;
+  s.flags = ((const uint32_t*)(segs + q))[6];
+  return s;
+}
+
+// K[0 .. n): sorted keys.  PACKED: first << 32 | up << 31 | length - 1 << 16 | segment (the vertex intervals); else
+// first << 32 | last.  Writes the merged intervals {first, last} to out and returns how many; merges overlapping
+// intervals, and adjacent ones when asked.  *overlap: two of them overlap.
+template <bool PACKED>
+__device__ __forceinline__ uint32_t merge_sorted(const uint64_t* K, uint32_t n, bool adjacent, uint32_t* out, int lane, bool* overlap) {
+  uint32_t M = 0, pm = 0;  // highest (last + 1) so far
+  bool ov = false;
+  for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
+    const uint32_t i = i0 + (uint32_t)lane;
+    const bool h = i < n;
+    const uint64_t key = h ? K[i] : 0ull;
+    const uint32_t lo = (uint32_t)(key >> 32);
+    const uint32_t hi = PACKED ? lo + (((uint32_t)key >> 16) & 0x7FFFu) : (uint32_t)key;
+    const uint32_t sa = wave_scan_max(h ? hi + 1u : 0u);
+    uint32_t xa = wave_shr1(sa);
+    xa = max(xa, pm);  // over everything in front of element i
+    if (__ballot(h && xa > lo)) ov = true;
+    const bool start = h && (xa == 0u || (adjacent ? lo > xa : lo >= xa));
+    const uint64_t sm = __ballot(start);
+    const uint32_t g = M + (uint32_t)__popcll(sm & below(lane));
+    if (start) {
+      out[2u * g] = lo;
+      if (g > 0u) out[2u * (g - 1u) + 1u] = xa - 1u;
+    }
+    M += (uint32_t)__popcll(sm);
+    pm = max(pm, rl(sa, 63));
+  }
+  if (M > 0u && lane == 0) out[2u * (M - 1u) + 1u] = pm - 1u;
+  gsync();
+  *overlap = ov;
+  return M;
+}
+
+// sorts K[0 .. n) (padding with the largest key), then drops repeated keys in place; returns how many are left
+__device__ __forceinline__ uint32_t sort_unique(uint64_t* K, uint32_t n, int lane) {
+  if (n == 0u) return 0u;
+  const uint32_t n2 = pow2_at_least(n);
+  for (uint32_t i = n + (uint32_t)lane; i < n2; i += 64u) K[i] = ~0ull;
+  lds_sync();
+  lds_sort64(K, n2, lane);
+  uint32_t w = 0;
+  for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
+    const uint32_t i = i0 + (uint32_t)lane;
+    const bool h = i < n;
+    const uint64_t key = h ? K[i] : 0ull;
+    const bool keep = h && (i == 0u || K[i - 1u] != key);
+    const uint64_t m = __ballot(keep);
+    lds_sync();  // (every lane has read its element and the one in front: the writes land at or in front of the chunk)
+    if (keep) K[w + (uint32_t)__popcll(m & below(lane))] = key;
+    w += (uint32_t)__popcll(m);
+    lds_sync();
+  }
+  return w;
+}
+
+#define D2_LAP(i) do { if (A.prof) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) atomicAdd(A.prof + (i), t_ - t_lap); t_lap = t_; } } while (0)
+// returns 0: analysed; 1: beyond this instantiation's capacities; 2: no room for the runs
+template <class C>
+__device__ int d2_one(uint32_t* lds, const D2Args& A, uint32_t gap, uint32_t* scr) {
+  const int lane = (int)threadIdx.x;
+  unsigned long long t_lap = A.prof ? __builtin_amdgcn_s_memtime() : 0ull;
+  GapOut* go = A.outs + gap;
+  const uint32_t nrec = uni(go->n_xl);
+  const SegRec* segs = (const SegRec*)(A.sub + uni((uint32_t)go->sub_off) + ((uint64_t)uni((uint32_t)(go->sub_off >> 32)) << 32));
+  SegRec* segs_w = const_cast<SegRec*>(segs);
+  const GapDev gd = A.gaps[gap];
+  const int lmf = (int)uni((uint32_t)gd.lmf), rmf = (int)uni((uint32_t)gd.rmf);
+  const uint32_t* targets = A.flank_nodes + uni(gd.flank_off) + (uint32_t)(lmf + 1) + (uint32_t)(rmf + 1);
+  const bool all_paths = A.all_paths != 0;
+  const uint32_t sinknode = (all_paths && rmf >= 1) ? uni(targets[rmf - 1]) : G2S_DEV_INVALID;  // Q3 / Q4
+  const int lo_sink = max(0, lmf + (int)uni((uint32_t)gd.g) - (int)uni((uint32_t)gd.e));         // :1196
+  const uint32_t reached = uni(targets[uni((uint32_t)go->reached_j)]);
+  const bool t_is_s = !all_paths;  // -best-only: the traceback starts are the sinks (:1245-1259)
+  const int n_len = (int)uni((uint32_t)go->n_len), len0 = (int)uni((uint32_t)go->len[0]), len1 = (int)uni((uint32_t)go->len[1]);
+  if (nrec == 0u || nrec > C::NREC) return 1;
+  // position of the sink state inside a segment of the S closure, or -1 (post.cpp: sinkpos)
+  auto sink_pos = [&](const SegD& s) -> int {
+    const int ts = s.ts();
+    if (ts < 0) return -1;
+    int sp = -1;
+    const int pk = seg_pos(s.node, (uint32_t)s.len(), sinknode);
+    if (pk >= 0 && s.d0() + pk >= lo_sink) sp = pk;
+    if (t_is_s) {
+      const int pt = seg_pos(s.node, (uint32_t)s.len(), reached);
+      if (pt >= 0 && (s.d0() + pt == len0 || (n_len > 1 && s.d0() + pt == len1))) sp = pt;
+    }
+    return sp > ts ? -1 : sp;
+  };
+  uint64_t* K = (uint64_t*)lds;
+  uint32_t* hdr = lds + (C::LDS_BYTES - 64u) / 4u;  // a few counters
+  // scratch
+  uint32_t* VM = scr;                      // merged vertex intervals
+  uint32_t* UI = VM + 2u * C::NS;          // chain edges of upward segments, by the lower of their two k-mers
+  uint32_t* DI = UI + 2u * C::NS;          // ... of downward segments
+  uint32_t* SRCS = DI + 2u * C::NS;
+  uint32_t* SINKS = SRCS + C::NS;
+  uint32_t* LOOPS = SINKS + C::NS;
+  uint32_t* CUT = LOOPS + C::NS;
+  uint32_t* RC = CUT + C::BP;              // run of cut j
+  uint32_t* RLO = RC + C::BP;              // by node
+  uint32_t* RHI = RLO + C::NV;
+  uint32_t* NW = RHI + C::NV;              // k-mers of the node | covered upwards << 30 | downwards << 31
+  uint32_t* ORDER = NW + C::NV;
+  uint32_t* EDGE = ORDER + C::NV;          // from << 16 | to
+
+  // ---- the S closure's index intervals, sorted
+  uint32_t ns = 0;
+  for (uint32_t q0 = 0; q0 < nrec; q0 += 64u) {
+    const uint32_t q = q0 + (uint32_t)lane;
+    const bool h = q < nrec;
+    SegD s;
+    if (h) s = seg_load(segs, q);
+    const int ts = h ? s.ts() : -1;
+    const bool in_s = ts >= 0;
+    const uint64_t m = __ballot(in_s);
+    const uint32_t pos = ns + (uint32_t)__popcll(m & below(lane));
+    if (in_s && pos < C::NS) {
+      const uint32_t lo = s.up() ? (s.node >> 1) : (s.node >> 1) - (uint32_t)ts;
+      K[pos] = ((uint64_t)lo << 32) | (s.up() ? 0x80000000u : 0u) | ((uint32_t)ts << 16) | q;
+    }
+    ns += (uint32_t)__popcll(m);
+  }
+  if (ns > C::NS) return 1;
+  if (ns == 0u) {  // (phase D ran without a sink state: nothing to analyse; the recount is the fill kernel's)
+    if (lane == 0) {
+      D2Out o; o.run_off = 0; o.n_runs = 0; o.sub[0] = 2; o.sub[1] = 0; o.sub[2] = 0; o.sub[3] = 0; o.sub[4] = 2; o.sub[5] = 0;
+      A.d2out[gap] = o;
+      go->dflags = (go->dflags & ~G2S_DEVA_SINK_SAFE) | G2S_DEVA_ANALYSED | G2S_DEVA_RUNS;
+      go->sub_vertices = 2; go->sub_edges = 0;
+    }
+    return 0;
+  }
+  {
+    const uint32_t n2 = pow2_at_least(ns);
+    for (uint32_t i = ns + (uint32_t)lane; i < n2; i += 64u) K[i] = ~0ull;
+    lds_sync();
+    lds_sort64(K, n2, lane);
+  }
+  bool overlap = false;
+  const uint32_t MV = merge_sorted<true>(K, ns, false, VM, lane, &overlap);
+  uint32_t V = 2u;
+  for (uint32_t i0 = 0; i0 < MV; i0 += 64u) {
+    const uint32_t i = i0 + (uint32_t)lane;
+    V += wave_sum(i < MV ? VM[2u * i + 1u] - VM[2u * i] + 1u : 0u);
+  }
+
+  D2_LAP(0);
+  if (!overlap) {
+    // ================= every k-mer at one depth: the branch rule as a prefix sum (post.cpp: seg_analyze) ==========
+    // by segment, behind the keys: safe_a | safe_b << 1 | split << 2 | children on paths to a sink << 24
+    uint32_t* sv = lds + 2u * C::NS;
+    static_assert(2u * C::NS + C::NREC <= C::K_BYTES / 4u, "the per-segment words fit behind the keys");
+    for (uint32_t q = (uint32_t)lane; q < nrec; q += 64u) sv[q] = 0u;
+    lds_sync();
+    uint32_t n_s = 0, edges = 0, src_out = 0, sink_in = 0;
+    for (uint32_t q0 = 0; q0 < nrec; q0 += 64u) {
+      const uint32_t q = q0 + (uint32_t)lane;
+      const bool h = q < nrec;
+      SegD s;
+      if (h) s = seg_load(segs, q);
+      const int ts = h ? s.ts() : -1;
+      const bool in_s = ts >= 0;
+      const int np = in_s ? s.npar() : 0;
+      const int sp = in_s ? sink_pos(s) : -1;
+      const bool src = in_s && s.source();
+      n_s += wave_sum(in_s ? (uint32_t)ts + 1u : 0u);
+      edges += wave_sum(in_s ? (uint32_t)ts + (src ? 1u : (uint32_t)np) + (sp >= 0 ? 1u : 0u) : 0u);
+      src_out += (uint32_t)__popcll(__ballot(src));
+      sink_in += (uint32_t)__popcll(__ballot(sp >= 0));
+      if (in_s && !src)
+        for (int x = 0; x < 4; x++) { const uint32_t p = s.par(x); if (p != 0xFFFFu && p < nrec) atomicAdd(&sv[p], 1u << 24); }
+    }
+    lds_sync();
+    int bc = 1 + (src_out > 1u ? (int)src_out - 1 : 0);  // the source pseudo-vertex comes first
+    for (uint32_t i0 = 0; i0 < nrec; i0 += 64u) {         // parents first = descending record index
+      const uint32_t i = i0 + (uint32_t)lane;
+      const bool h = i < nrec;
+      const uint32_t q = h ? nrec - 1u - i : 0u;
+      SegD s;
+      if (h) s = seg_load(segs, q);
+      const int ts = h ? s.ts() : -1;
+      const bool in_s = ts >= 0;
+      const int sp = in_s ? sink_pos(s) : -1;
+      const int din = in_s ? (s.source() ? 1 : s.npar()) : 0;
+      const int outs = in_s ? (int)(sv[q] >> 24) : 0;
+      const int d_in = (in_s && din > 1) ? -(din - 1) : 0;
+      const int d_mid = (in_s && sp >= 0 && sp < ts) ? 1 : 0;  // out-degree 2: the next state and the sink
+      const int dout = in_s ? (ts == s.len() - 1 ? outs : 0) + (sp == ts ? 1 : 0) : 0;
+      const int d_out = dout > 1 ? dout - 1 : 0;
+      const int total = d_in + d_mid + d_out;
+      const int incl = (int)wave_scan((uint32_t)total, lane);
+      const int at_entry = bc + incl - total + d_in;
+      if (in_s) {
+        const bool sa = at_entry == 1, sb = at_entry + d_mid == 1;
+        const int split = d_mid ? sp : ts;
+        sv[q] = (sv[q] & 0xFF000000u) | (sa ? 1u : 0u) | (sb ? 2u : 0u) | ((uint32_t)split << 2);
+        // (the records carry the verdicts as the fill kernel's own analysis leaves them)
+        segs_w[q].ts_tt = (s.ts_tt & 0x7FFF7FFFu) | (sa ? 0x8000u : 0u) | (sb ? 0x80000000u : 0u);
+        segs_w[q].pad = (uint32_t)split;
+      }
+      bc += (int)rl((uint32_t)incl, 63);
+    }
+    bool sink_safe = false;
+    if (sink_in >= 1u) { if (sink_in > 1u) bc -= (int)sink_in - 1; sink_safe = bc == 1; }
+    lds_sync();
+    // runs, in the order of the sorted intervals: one per segment, two where a sink splits it
+    uint32_t total_runs = 0;
+    for (uint32_t j0 = 0; j0 < ns; j0 += 64u) {
+      const uint32_t j = j0 + (uint32_t)lane;
+      const bool h = j < ns;
+      const uint32_t low = h ? (uint32_t)K[j] : 0u;
+      const uint32_t ts = (low >> 16) & 0x7FFFu, q = low & 0xFFFFu;
+      total_runs += wave_sum(h ? (((sv[q] >> 2) & 0x7FFFu) < ts ? 2u : 1u) : 0u);
+    }
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(A.run_cursor, (unsigned long long)total_runs);
+    base = ((unsigned long long)uni((uint32_t)(base >> 32)) << 32) | uni((uint32_t)base);
+    if (base + total_runs > A.run_cap) return 2;
+    uint32_t* runs = A.runs + 2ull * base;
+    uint32_t w = 0;
+    for (uint32_t j0 = 0; j0 < ns; j0 += 64u) {
+      const uint32_t j = j0 + (uint32_t)lane;
+      const bool h = j < ns;
+      const uint64_t key = h ? K[j] : 0ull;
+      const uint32_t low = (uint32_t)key, lo = (uint32_t)(key >> 32);
+      const uint32_t ts = (low >> 16) & 0x7FFFu, q = low & 0xFFFFu;
+      const bool up = (low & 0x80000000u) != 0u;
+      const uint32_t v = h ? sv[q] : 0u;
+      const uint32_t split = (v >> 2) & 0x7FFFu;
+      const uint32_t sa = v & 1u, sb = (v >> 1) & 1u;
+      const uint32_t mine = h ? (split < ts ? 2u : 1u) : 0u;
+      const uint32_t incl = wave_scan(mine, lane);
+      const uint32_t at = w + incl - mine;
+      if (h) {
+        const uint32_t hi = lo + ts;
+        if (mine == 1u) { runs[2u * at] = lo; runs[2u * at + 1u] = hi | (sa << 31); }
+        else if (up) {  // states 0 .. split, then the rest
+          runs[2u * at] = lo; runs[2u * at + 1u] = (lo + split) | (sa << 31);
+          runs[2u * at + 2u] = lo + split + 1u; runs[2u * at + 3u] = hi | (sb << 31);
+        } else {        // (a downward segment: state t is k-mer hi - t)
+          runs[2u * at] = lo; runs[2u * at + 1u] = (hi - split - 1u) | (sb << 31);
+          runs[2u * at + 2u] = hi - split; runs[2u * at + 3u] = hi | (sa << 31);
+        }
+      }
+      w += rl(incl, 63);
+    }
+    if (lane == 0) {
+      D2Out o;
+      o.run_off = (uint32_t)base; o.n_runs = total_runs;
+      o.sub[0] = n_s + 2u; o.sub[1] = edges; o.sub[2] = 0u; o.sub[3] = 0u; o.sub[4] = n_s + 2u; o.sub[5] = edges;
+      A.d2out[gap] = o;
+      go->sub_vertices = n_s + 2u; go->sub_edges = edges;
+      go->dflags = (go->dflags & ~G2S_DEVA_SINK_SAFE) | G2S_DEVA_ANALYSED | G2S_DEVA_RUNS | (sink_safe ? G2S_DEVA_SINK_SAFE : 0u);
+    }
+    D2_LAP(1);
+    return 0;
+  }
+
+  // ================= a k-mer at several depths: the graph of runs (post.cpp: seg_analyze_runs) ======================
+  // ---- chain edges of the upward and of the downward segments as merged intervals (adjacent ones merge)
+  uint32_t MU = 0, MD = 0;
+  for (int dir = 0; dir < 2; dir++) {
+    uint32_t n = 0;
+    for (uint32_t q0 = 0; q0 < nrec; q0 += 64u) {
+      const uint32_t q = q0 + (uint32_t)lane;
+      const bool h = q < nrec;
+      SegD s;
+      if (h) s = seg_load(segs, q);
+      const int ts = h ? s.ts() : -1;
+      const bool take = ts > 0 && (s.up() ? dir == 0 : dir == 1);
+      const uint64_t m = __ballot(take);
+      if (take) {
+        const uint32_t lo = s.up() ? (s.node >> 1) : (s.node >> 1) - (uint32_t)ts;
+        K[n + (uint32_t)__popcll(m & below(lane))] = ((uint64_t)lo << 32) | (lo + (uint32_t)ts - 1u);
+      }
+      n += (uint32_t)__popcll(m);
+    }
+    lds_sync();
+    uint32_t M = 0;
+    if (n > 0u) {
+      const uint32_t n2 = pow2_at_least(n);
+      for (uint32_t i = n + (uint32_t)lane; i < n2; i += 64u) K[i] = ~0ull;
+      lds_sync();
+      lds_sort64(K, n2, lane);
+      bool ov;
+      M = merge_sorted<false>(K, n, true, dir == 0 ? UI : DI, lane, &ov);
+    }
+    if (dir == 0) MU = M; else MD = M;
+    lds_sync();
+  }
+  D2_LAP(2);
+  // ---- the cuts: ends of every interval, a parent's last k-mer, sink positions; the sources; the sinks
+  uint32_t nb = 0, nsrc = 0, nsink = 0, npairs = 0;
+  for (int pass = 0; pass < 3; pass++) {  // 0: cuts, 1: sources, 2: sinks (each through the sort buffer)
+    uint32_t n = 0;
+    bool full = false;
+    for (uint32_t q0 = 0; q0 < nrec && !full; q0 += 64u) {
+      const uint32_t q = q0 + (uint32_t)lane;
+      const bool h = q < nrec;
+      SegD s;
+      if (h) s = seg_load(segs, q);
+      const int ts = h ? s.ts() : -1;
+      const bool in_s = ts >= 0;
+      const int sp = in_s ? sink_pos(s) : -1;
+      uint32_t vals[7];
+      uint32_t k = 0;
+      if (in_s && pass == 0) {
+        vals[k++] = s.idx(0);
+        vals[k++] = s.idx(ts);
+        if (!s.source())
+          for (int x = 0; x < 4; x++) {
+            const uint32_t p = s.par(x);
+            if (p == 0xFFFFu || p >= nrec) continue;
+            const SegD ps = seg_load(segs, p);
+            vals[k++] = ps.idx(ps.len() - 1);
+          }
+        if (sp >= 0) vals[k++] = s.idx(sp);
+      } else if (in_s && pass == 1) { if (s.source()) vals[k++] = s.idx(0); }
+      else if (in_s && pass == 2) { if (sp >= 0) vals[k++] = s.idx(sp); }
+      if (pass == 0) npairs += wave_sum((in_s && !s.source()) ? (uint32_t)s.npar() : 0u);
+      const uint32_t incl = wave_scan(k, lane);
+      const uint32_t tot = rl(incl, 63);
+      if (n + tot > C::BP) { full = true; break; }
+      const uint32_t at = n + incl - k;
+      for (uint32_t x = 0; x < k; x++) K[at + x] = (uint64_t)vals[x];
+      n += tot;
+    }
+    if (full) return 1;
+    lds_sync();
+    const uint32_t u = sort_unique(K, n, lane);
+    uint32_t* dst = pass == 0 ? CUT : pass == 1 ? SRCS : SINKS;
+    if (pass != 0 && u > C::NS) return 1;
+    for (uint32_t i = (uint32_t)lane; i < u; i += 64u) dst[i] = (uint32_t)K[i];
+    if (pass == 0) nb = u; else if (pass == 1) nsrc = u; else nsink = u;
+    gsync();
+    lds_sync();
+  }
+  if (npairs > C::BP) return 1;
+  D2_LAP(3);
+  // ---- runs: every cut k-mer alone, and what lies between two cuts of one vertex interval
+  uint32_t R = 0;
+  unsigned long long e_internal = 0;
+  {
+    uint32_t gaps_before = 0;
+    for (uint32_t j0 = 0; j0 < nb; j0 += 64u) {
+      const uint32_t j = j0 + (uint32_t)lane;
+      const bool h = j < nb;
+      const uint32_t c = h ? CUT[j] : 0u, cn = (h && j + 1u < nb) ? CUT[j + 1u] : 0u;
+      uint32_t hi_v = 0;
+      const bool inside = h && iv_has(VM, MV, c, &hi_v);
+      const bool gp = inside && j + 1u < nb && cn <= hi_v && cn > c + 1u;
+      const uint64_t m = __ballot(gp);
+      const uint32_t r = j + gaps_before + (uint32_t)__popcll(m & below(lane));
+      uint32_t internal = 0;
+      if (h && r + 3u < C::NV) {
+        RC[j] = r;
+        RLO[2u + r] = c; RHI[2u + r] = c; NW[2u + r] = 1u;
+        if (gp) {
+          const uint32_t L = cn - c - 1u;
+          uint32_t cover = 0u;
+          if (L > 1u) {
+            const bool u = iv_has(UI, MU, c + 1u), d = iv_has(DI, MD, c + 1u);
+            cover = (u ? 0x40000000u : 0u) | (d ? 0x80000000u : 0u);
+            internal = ((u ? 1u : 0u) + (d ? 1u : 0u)) * (L - 1u);
+          }
+          RLO[3u + r] = c + 1u; RHI[3u + r] = cn - 1u; NW[3u + r] = L | cover;
+        }
+      }
+      e_internal += wave_sum(internal);
+      gaps_before += (uint32_t)__popcll(m);
+    }
+    R = nb + gaps_before;
+  }
+  const uint32_t NV = R + 2u;
+  if (NV > C::NV) return 1;
+  if (lane == 0) { RLO[0] = RHI[0] = 0u; NW[0] = 1u; RLO[1] = RHI[1] = 0u; NW[1] = 1u; }  // 0: sink, 1: source
+  gsync();
+  D2_LAP(4);
+  auto node_of = [&](uint32_t x) -> uint32_t { return 2u + RC[cut_index(CUT, nb, x)]; };  // (every end of an edge is a cut)
+  // ---- edges between nodes, one per distinct edge of the reference's graph
+  uint32_t ne = 0, nloops = 0;
+  bool e_full = false;
+  auto emit = [&](bool take, uint32_t from, uint32_t to) {
+    const uint64_t m = __ballot(take);
+    const uint32_t at = ne + (uint32_t)__popcll(m & below(lane));
+    if (take && at < C::E) EDGE[at] = (from << 16) | to;
+    ne += (uint32_t)__popcll(m);
+    if (ne > C::E) e_full = true;
+  };
+  for (uint32_t r0 = 0; r0 + 1u < R; r0 += 64u) {  // the chain's own edges into the next run
+    const uint32_t r = r0 + (uint32_t)lane;
+    const bool h = r + 1u < R;
+    const uint32_t x = h ? RHI[2u + r] : 0u;
+    const bool adj = h && x + 1u == RLO[3u + r];
+    const bool u = adj && iv_has(UI, MU, x), d = adj && iv_has(DI, MD, x);
+    emit(u, 2u + r, 3u + r);
+    emit(d, 3u + r, 2u + r);
+  }
+  {  // the edges from a parent's last k-mer to an entry: sorted, those that double a chain edge go, self loops aside
+    uint32_t n = 0;
+    for (uint32_t q0 = 0; q0 < nrec; q0 += 64u) {
+      const uint32_t q = q0 + (uint32_t)lane;
+      const bool h = q < nrec;
+      SegD s;
+      if (h) s = seg_load(segs, q);
+      const bool in_s = h && s.ts() >= 0 && !s.source();
+      uint64_t vals[4];
+      uint32_t k = 0;
+      if (in_s)
+        for (int x = 0; x < 4; x++) {
+          const uint32_t p = s.par(x);
+          if (p == 0xFFFFu || p >= nrec) continue;
+          const SegD ps = seg_load(segs, p);
+          vals[k++] = ((uint64_t)ps.idx(ps.len() - 1) << 32) | s.idx(0);
+        }
+      const uint32_t incl = wave_scan(k, lane);
+      const uint32_t at = n + incl - k;
+      for (uint32_t x = 0; x < k; x++) K[at + x] = vals[x];  // (n + total <= npairs <= BP: counted above)
+      n += rl(incl, 63);
+    }
+    lds_sync();
+    const uint32_t u = sort_unique(K, n, lane);
+    for (uint32_t i0 = 0; i0 < u; i0 += 64u) {
+      const uint32_t i = i0 + (uint32_t)lane;
+      const bool h = i < u;
+      const uint64_t e = h ? K[i] : 0ull;
+      const uint32_t a = (uint32_t)(e >> 32), b = (uint32_t)e;
+      bool keep = h;
+      if (keep && b == a + 1u && iv_has(UI, MU, a)) keep = false;
+      if (keep && a == b + 1u && iv_has(DI, MD, b)) keep = false;
+      const bool loop = keep && a == b;
+      const uint64_t lm = __ballot(loop);
+      if (loop) { const uint32_t at = nloops + (uint32_t)__popcll(lm & below(lane)); if (at < C::NS) LOOPS[at] = node_of(a); }
+      nloops += (uint32_t)__popcll(lm);
+      const bool edge = keep && !loop;
+      emit(edge, edge ? node_of(a) : 0u, edge ? node_of(b) : 0u);
+    }
+    lds_sync();
+  }
+  if (nloops > C::NS) return 1;
+  for (uint32_t i0 = 0; i0 < nsrc; i0 += 64u) { const uint32_t i = i0 + (uint32_t)lane; const bool h = i < nsrc; emit(h, 1u, h ? node_of(SRCS[i]) : 0u); }      // :1303-1305
+  for (uint32_t i0 = 0; i0 < nsink; i0 += 64u) { const uint32_t i = i0 + (uint32_t)lane; const bool h = i < nsink; emit(h, h ? node_of(SINKS[i]) : 0u, 0u); }  // :1216-1226
+  if (e_full || ne > C::E) return 1;
+  const unsigned long long e_all = e_internal + ne + nloops;
+  gsync();
+  D2_LAP(5);
+
+  // ---- the graph into LDS: offsets and adjacency both ways, live degrees
+  uint16_t* off_f = (uint16_t*)lds;
+  uint16_t* off_r = (uint16_t*)((char*)off_f + C::OFF_BYTES);
+  uint16_t* adj_f = (uint16_t*)((char*)off_r + C::OFF_BYTES);
+  uint16_t* adj_r = adj_f + C::E;
+  uint32_t* degi = (uint32_t*)(adj_r + C::E);   // packed, NV / 2 words
+  uint32_t* dego = degi + C::NV / 2u;
+  uint32_t* comp = dego + C::NV / 2u;
+  uint16_t* wl0 = (uint16_t*)(comp + C::NV);
+  uint16_t* wl1 = wl0 + C::NV;
+  for (uint32_t i = (uint32_t)lane; i < C::NV / 2u; i += 64u) { degi[i] = 0u; dego[i] = 0u; ((uint32_t*)wl0)[i] = 0u; ((uint32_t*)wl1)[i] = 0u; }
+  for (uint32_t v = (uint32_t)lane; v < NV; v += 64u) comp[v] = D2_ALIVE;
+  lds_sync();
+  for (uint32_t i = (uint32_t)lane; i < ne; i += 64u) {
+    const uint32_t e = EDGE[i];
+    pk_add(dego, e >> 16, 1u);
+    pk_add(degi, e & 0xFFFFu, 1u);
+  }
+  lds_sync();
+  {
+    uint32_t run_f = 0, run_r = 0;
+    for (uint32_t v0 = 0; v0 < NV; v0 += 64u) {
+      const uint32_t v = v0 + (uint32_t)lane;
+      const bool h = v < NV;
+      const uint32_t df = h ? pk_get(dego, v) : 0u, dr = h ? pk_get(degi, v) : 0u;
+      const uint32_t sf = wave_scan(df, lane), sr = wave_scan(dr, lane);
+      if (h) { off_f[v] = (uint16_t)(run_f + sf - df); off_r[v] = (uint16_t)(run_r + sr - dr); }
+      run_f += rl(sf, 63); run_r += rl(sr, 63);
+    }
+    if (lane == 0) { off_f[NV] = (uint16_t)run_f; off_r[NV] = (uint16_t)run_r; }
+  }
+  lds_sync();
+  {  // (the two work lists serve as fill cursors first)
+    uint32_t* cur_f = (uint32_t*)wl0;
+    uint32_t* cur_r = (uint32_t*)wl1;
+    for (uint32_t i = (uint32_t)lane; i < ne; i += 64u) {
+      const uint32_t e = EDGE[i];
+      const uint32_t a = e >> 16, b = e & 0xFFFFu;
+      adj_f[(uint32_t)off_f[a] + pk_add(cur_f, a, 1u)] = (uint16_t)b;
+      adj_r[(uint32_t)off_r[b] + pk_add(cur_r, b, 1u)] = (uint16_t)a;
+    }
+  }
+  lds_sync();
+
+  D2_LAP(6);
+  // ---- strong components
+  // remove(u): u leaves the live graph — its neighbours lose an edge, and those left without a live edge in, or
+  // without one out, are queued (once: the state word decides)
+  uint32_t* n_next = hdr;
+  uint16_t* cur = wl0;
+  uint16_t* nxt = wl1;
+  auto push = [&](uint32_t v) {
+    if (atomicCAS(&comp[v], D2_ALIVE, D2_QUEUED) == D2_ALIVE) nxt[atomicAdd(n_next, 1u)] = (uint16_t)v;
+  };
+  auto drop_edges = [&](uint32_t u) {
+    for (uint32_t e = off_f[u]; e < (uint32_t)off_f[u + 1u]; e++) { const uint32_t w = adj_f[e]; if (pk_sub(degi, w, 1u) == 1u) push(w); }
+    for (uint32_t e = off_r[u]; e < (uint32_t)off_r[u + 1u]; e++) { const uint32_t p = adj_r[e]; if (pk_sub(dego, p, 1u) == 1u) push(p); }
+  };
+  if (lane == 0) *n_next = 0u;
+  lds_sync();
+  for (uint32_t v = (uint32_t)lane; v < NV; v += 64u)
+    if (pk_get(degi, v) == 0u || pk_get(dego, v) == 0u) push(v);
+  lds_sync();
+  uint32_t ncur = 0;
+  uint32_t guard = 0;  // (every loop below ends after at most NV rounds by construction; a defect must not hold the GPU)
+  const uint32_t guard_max = 8u * NV + 64u;
+  for (;;) {
+    // peel: nodes without a live edge in or out are components of their own
+    for (;;) {
+      lds_sync();
+      ncur = uni(*n_next);
+      if (ncur == 0u || ++guard > guard_max) break;
+      { uint16_t* t = cur; cur = nxt; nxt = t; }
+      if (lane == 0) *n_next = 0u;
+      lds_sync();
+      for (uint32_t i = (uint32_t)lane; i < ncur; i += 64u) comp[cur[i]] = cur[i];
+      lds_sync();
+      for (uint32_t i = (uint32_t)lane; i < ncur; i += 64u) drop_edges(cur[i]);
+    }
+    // what is left lies on cycles or between them: the component of the lowest live node
+    uint32_t pivot = 0xFFFFFFFFu;
+    for (uint32_t v0 = 0; v0 < NV; v0 += 64u) {
+      const uint32_t v = v0 + (uint32_t)lane;
+      pivot = min(pivot, wave_min((v < NV && comp[v] == D2_ALIVE) ? v : 0xFFFFFFFFu));
+    }
+    if (pivot == 0xFFFFFFFFu || guard > guard_max) break;
+    // forward from the pivot over live nodes ...
+    if (lane == 0) { comp[pivot] = D2_FW; cur[0] = (uint16_t)pivot; *n_next = 0u; }
+    ncur = 1u;
+    lds_sync();
+    while (ncur && ++guard <= guard_max) {
+      for (uint32_t i = (uint32_t)lane; i < ncur; i += 64u) {
+        const uint32_t u = cur[i];
+        for (uint32_t e = off_f[u]; e < (uint32_t)off_f[u + 1u]; e++) {
+          const uint32_t w = adj_f[e];
+          if (atomicCAS(&comp[w], D2_ALIVE, D2_FW) == D2_ALIVE) nxt[atomicAdd(n_next, 1u)] = (uint16_t)w;
+        }
+      }
+      lds_sync();
+      ncur = uni(*n_next);
+      { uint16_t* t = cur; cur = nxt; nxt = t; }
+      if (lane == 0) *n_next = 0u;
+      lds_sync();
+    }
+    // ... and backward from it over what the forward search reached: the intersection is the component
+    if (lane == 0) { comp[pivot] = D2_FWBW; cur[0] = (uint16_t)pivot; }
+    ncur = 1u;
+    lds_sync();
+    while (ncur && ++guard <= guard_max) {
+      for (uint32_t i = (uint32_t)lane; i < ncur; i += 64u) {
+        const uint32_t u = cur[i];
+        for (uint32_t e = off_r[u]; e < (uint32_t)off_r[u + 1u]; e++) {
+          const uint32_t p = adj_r[e];
+          if (atomicCAS(&comp[p], D2_FW, D2_FWBW) == D2_FW) nxt[atomicAdd(n_next, 1u)] = (uint16_t)p;
+        }
+      }
+      lds_sync();
+      ncur = uni(*n_next);
+      { uint16_t* t = cur; cur = nxt; nxt = t; }
+      if (lane == 0) *n_next = 0u;
+      lds_sync();
+    }
+    // the component's nodes leave the live graph together; the others the forward search marked are live again
+    uint32_t nmem = 0;
+    for (uint32_t v0 = 0; v0 < NV; v0 += 64u) {
+      const uint32_t v = v0 + (uint32_t)lane;
+      const uint32_t st = v < NV ? comp[v] : 0u;
+      if (st == D2_FW) comp[v] = D2_ALIVE;
+      const bool mem = st == D2_FWBW;
+      const uint64_t m = __ballot(mem);
+      if (mem) { comp[v] = pivot; cur[nmem + (uint32_t)__popcll(m & below(lane))] = (uint16_t)v; }
+      nmem += (uint32_t)__popcll(m);
+    }
+    lds_sync();
+    for (uint32_t i = (uint32_t)lane; i < nmem; i += 64u) drop_edges(cur[i]);
+    lds_sync();
+  }
+  lds_sync();
+  if (guard > guard_max) return 2;
+  D2_LAP(7);
+
+  // ---- the components: size, which are non-trivial (several nodes, or a run covered in both directions), the
+  // contracted multigraph's degrees (:1342-1378); then the statistics (:1404-1409)
+  uint32_t* csize = degi;                         // [NV] words (the two degree tables are through)
+  uint32_t* cdeg_in = (uint32_t*)adj_r;           // packed: edges into the component from others ...
+  uint32_t* cdeg_out = cdeg_in + C::NV / 2u;      // ... and out of it (E * 2 bytes >= NV * 2 bytes: E >= 2 NV)
+  uint32_t* cwork = (uint32_t*)off_r;             // packed: edges in not yet accounted for (Kahn)
+  static_assert(C::E >= 2u * C::NV, "the reverse adjacency's space holds two packed degree tables");
+  for (uint32_t v = (uint32_t)lane; v < C::NV; v += 64u) csize[v] = 0u;
+  for (uint32_t i = (uint32_t)lane; i < C::NV / 2u; i += 64u) { cdeg_in[i] = 0u; cdeg_out[i] = 0u; }
+  for (uint32_t i = (uint32_t)lane; i < (C::NV + 2u) / 2u; i += 64u) cwork[i] = 0u;
+  lds_sync();
+  for (uint32_t v = (uint32_t)lane; v < NV; v += 64u) atomicAdd(&csize[comp[v]], 1u);
+  lds_sync();
+  auto nontriv = [&](uint32_t c) -> bool { return (csize[c] & 0x7FFFFFFFu) > 1u || (NW[c] & 0xC0000000u) == 0xC0000000u; };
+  unsigned long long fe = 0;
+  for (uint32_t i0 = 0; i0 < ne; i0 += 64u) {
+    const uint32_t i = i0 + (uint32_t)lane;
+    const bool h = i < ne;
+    const uint32_t e = h ? EDGE[i] : 0u;
+    const uint32_t a = h ? comp[e >> 16] : 0u, b = h ? comp[e & 0xFFFFu] : 0u;
+    const bool cross = h && a != b;
+    if (cross) { pk_add(cdeg_out, a, 1u); pk_add(cdeg_in, b, 1u); pk_add(cwork, b, 1u); }
+    fe += (unsigned long long)__popcll(__ballot(cross));
+  }
+  uint32_t nontrivial = 0;
+  unsigned long long size_nontrivial = 0;
+  for (uint32_t v0 = 0; v0 < NV; v0 += 64u) {
+    const uint32_t v = v0 + (uint32_t)lane;
+    const bool h = v < NV;
+    const uint32_t c = h ? comp[v] : 0u;
+    const bool nt = h && nontriv(c);
+    const uint32_t wgt = h ? (NW[v] & 0x3FFFFFFFu) : 0u, cov = h ? NW[v] >> 30 : 0u;
+    nontrivial += (uint32_t)__popcll(__ballot(nt && c == v));
+    size_nontrivial += wave_sum(nt ? wgt : 0u);
+    // (a run outside the non-trivial components keeps its own edges in the contracted graph)
+    fe += wave_sum((h && !nt && wgt > 1u) ? ((cov & 1u) + (cov >> 1)) * (wgt - 1u) : 0u);
+  }
+  uint32_t loops_trivial = 0;
+  for (uint32_t i0 = 0; i0 < nloops; i0 += 64u) {
+    const uint32_t i = i0 + (uint32_t)lane;
+    loops_trivial += (uint32_t)__popcll(__ballot(i < nloops && !nontriv(comp[LOOPS[i]])));  // :1385-1402
+  }
+  lds_sync();
+
+  D2_LAP(8);
+  // ---- the components in topological order (Kahn, round by round), into ORDER
+  uint32_t n_order = 0;
+  cur = wl0; nxt = wl1;
+  if (lane == 0) *n_next = 0u;
+  lds_sync();
+  for (uint32_t v = (uint32_t)lane; v < NV; v += 64u)
+    if (comp[v] == v && pk_get(cwork, v) == 0u) nxt[atomicAdd(n_next, 1u)] = (uint16_t)v;
+  for (;;) {
+    lds_sync();
+    ncur = uni(*n_next);
+    if (ncur == 0u || n_order + ncur > NV) break;
+    { uint16_t* t = cur; cur = nxt; nxt = t; }
+    if (lane == 0) *n_next = 0u;
+    lds_sync();
+    for (uint32_t i0 = 0; i0 < ncur; i0 += 64u) {
+      const uint32_t i = i0 + (uint32_t)lane;
+      const bool h = i < ncur;
+      const uint32_t c = h ? cur[i] : 0u;
+      if (h) ORDER[n_order + i] = c;
+      const bool big = h && (csize[c] & 0x7FFFFFFFu) > 1u;
+      if (h && !big)
+        for (uint32_t e = off_f[c]; e < (uint32_t)off_f[c + 1u]; e++) {
+          const uint32_t b = comp[adj_f[e]];
+          if (b != c && pk_sub(cwork, b, 1u) == 1u) nxt[atomicAdd(n_next, 1u)] = (uint16_t)b;
+        }
+      for (uint64_t bm = __ballot(big); bm; bm &= bm - 1) {  // a component of several nodes: all of them (there are few)
+        const uint32_t cc = rl(c, __builtin_ctzll(bm));
+        for (uint32_t v = (uint32_t)lane; v < NV; v += 64u) {
+          if (comp[v] != cc) continue;
+          for (uint32_t e = off_f[v]; e < (uint32_t)off_f[v + 1u]; e++) {
+            const uint32_t b = comp[adj_f[e]];
+            if (b != cc && pk_sub(cwork, b, 1u) == 1u) nxt[atomicAdd(n_next, 1u)] = (uint16_t)b;
+          }
+        }
+      }
+    }
+    n_order += ncur;
+  }
+  gsync();
+  D2_LAP(9);
+  // ---- the branch rule over that order (:1411-1434): -(in - 1) in front of a vertex, +(out - 1) behind it
+  {
+    int bc = 1;
+    for (uint32_t p0 = 0; p0 < n_order; p0 += 64u) {
+      const uint32_t p = p0 + (uint32_t)lane;
+      const bool h = p < n_order;
+      const uint32_t c = h ? ORDER[p] : 0u;
+      const int din = h ? (int)pk_get(cdeg_in, c) : 0, dout = h ? (int)pk_get(cdeg_out, c) : 0;
+      const bool act = din >= 1 || dout >= 1;
+      const int pre = (act && din > 1) ? -(din - 1) : 0, post = (act && dout > 1) ? dout - 1 : 0;
+      const int incl = (int)wave_scan((uint32_t)(pre + post), lane);
+      const int at = bc + incl - (pre + post) + pre;
+      if (h && act && at == 1 && !nontriv(c)) csize[c] |= 0x80000000u;  // the verdict: branch[c] == 1
+      bc += (int)rl((uint32_t)incl, 63);
+    }
+  }
+  lds_sync();
+  const bool sink_safe = (csize[comp[0]] & 0x80000000u) != 0u;
+  // ---- what leaves: the runs with their verdicts, the statistics
+  unsigned long long base = 0;
+  if (lane == 0) base = atomicAdd(A.run_cursor, (unsigned long long)R);
+  base = ((unsigned long long)uni((uint32_t)(base >> 32)) << 32) | uni((uint32_t)base);
+  if (base + R > A.run_cap || n_order == 0u) return 2;
+  uint32_t* runs = A.runs + 2ull * base;
+  for (uint32_t r = (uint32_t)lane; r < R; r += 64u) {
+    const uint32_t safe = csize[comp[2u + r]] >> 31;
+    runs[2u * r] = RLO[2u + r];
+    runs[2u * r + 1u] = RHI[2u + r] | (safe << 31);
+  }
+  if (lane == 0) {
+    D2Out o;
+    o.run_off = (uint32_t)base; o.n_runs = R;
+    o.sub[0] = V;
+    o.sub[1] = (uint32_t)(e_all - loops_trivial);
+    o.sub[2] = nontrivial;
+    o.sub[3] = (uint32_t)size_nontrivial;
+    o.sub[4] = (uint32_t)((unsigned long long)V + nontrivial - size_nontrivial);
+    o.sub[5] = (uint32_t)fe;
+    A.d2out[gap] = o;
+    go->sub_vertices = V; go->sub_edges = o.sub[1];
+    go->dflags = (go->dflags & ~G2S_DEVA_SINK_SAFE) | G2S_DEVA_ANALYSED | G2S_DEVA_RUNS | (sink_safe ? G2S_DEVA_SINK_SAFE : 0u);
+  }
+  D2_LAP(10);
+  if (A.prof && lane == 0) { atomicAdd(A.prof + 11, 1ull); atomicAdd(A.prof + 12, (unsigned long long)NV); atomicAdd(A.prof + 13, (unsigned long long)guard); }
+  return 0;
+}
+
+template <class C>
+__device__ __forceinline__ void d2_loop(uint32_t* lds, const D2Args& A) {
+  uint32_t* scr = A.scratch + (size_t)blockIdx.x * C::SCR_WORDS;
+  const unsigned long long n = *A.count;
+  for (;;) {
+    unsigned long long x = 0;
+    if (threadIdx.x == 0) x = atomicAdd(A.next, 1ull);
+    x = ((unsigned long long)uni((uint32_t)(x >> 32)) << 32) | uni((uint32_t)x);
+    if (x >= n || x >= (unsigned long long)A.list_cap) break;
+    const uint32_t gap = uni(A.list[x]);
+    const int rc = (A.pass_all && A.list_next) ? 1 : d2_one<C>(lds, A, gap, scr);
+    if (rc == 1 && A.list_next && threadIdx.x == 0) {  // beyond these capacities: the larger instantiation's
+      const unsigned long long at = atomicAdd(A.count_next, 1ull);
+      if (at < (unsigned long long)A.list_cap) A.list_next[at] = gap;
+    }
+    // (rc == 2, or 1 in the large instantiation: the gap stays without G2S_DEVA_ANALYSED — the host's, post.cpp)
+    lds_sync();
+    gsync();
+  }
+}
+
+__global__ __launch_bounds__(64) void g2s_d2_small(const D2Args A) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  d2_loop<D2Small>(lds, A);
+}
+__global__ __launch_bounds__(64) void g2s_d2_big(const D2Args A) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  d2_loop<D2Big>(lds, A);
+}
+
+}  // namespace
+
+namespace g2s {
+
+size_t d2_scratch_bytes(bool big, uint32_t workgroups) {
+  return (size_t)workgroups * (big ? D2Big::SCR_WORDS : D2Small::SCR_WORDS) * 4u;
+}
+
+hipError_t launch_d2(hipStream_t st, const D2Args& A0, uint32_t small_wgs, uint32_t big_wgs, uint32_t* scratch_small,
+                     uint32_t* scratch_big, uint32_t* list_big, unsigned long long* count_big, unsigned long long* next_big) {
+  hipError_t e = hipFuncSetAttribute((const void*)g2s_d2_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)D2Small::LDS_BYTES);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void*)g2s_d2_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)D2Big::LDS_BYTES);
+  if (e != hipSuccess) return e;
+  D2Args A = A0;
+  A.scratch = scratch_small;
+  A.list_next = big_wgs ? list_big : nullptr;
+  A.count_next = count_big;
+  hipLaunchKernelGGL(g2s_d2_small, dim3(std::max(1u, small_wgs)), dim3(64), D2Small::LDS_BYTES, st, A);
+  if (big_wgs == 0u) return hipGetLastError();  // (a list without deep searches: what the small one cannot take is the host's)
+  D2Args B = A0;
+  B.list = list_big;
+  B.count = count_big;
+  B.next = next_big;
+  B.scratch = scratch_big;
+  B.list_next = nullptr;
+  B.count_next = nullptr;
+  hipLaunchKernelGGL(g2s_d2_big, dim3(std::max(1u, big_wgs)), dim3(64), D2Big::LDS_BYTES, st, B);
+  return hipGetLastError();
+}
+
+}  // namespace g2s

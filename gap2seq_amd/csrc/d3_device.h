@@ -5,6 +5,7 @@
 #include <hip/hip_runtime_api.h>
 #include <stdint.h>
 
+#include "d2_device.h"
 #include "fill_device.h"
 
 #define G2S_D3_BLOCK_VARS 16u            /* draw-dependent gaps per block of the offset chain */
@@ -119,6 +120,13 @@ struct D3Work {
   // (not carved: the caller's) 32 words that outlive the list's summary: the generator's state behind the list's last
   // draw, for the next list's stream when that list is queued before this one has ended (g2s_fill_begin); may be null
   uint32_t* link = nullptr;
+  // (not carved: the caller's) what g2s_d2_* left for the gaps it analysed (GapOut.dflags & G2S_DEVA_RUNS): per-gap
+  // statistics and runs (d2_device.h); hops: where the trace kernel lists the segments a traceback enters when the
+  // closure is too large for its LDS — an entry per closure segment, at the closure's own offset.  All null: no gap
+  // carries G2S_DEVA_RUNS and every closure the trace kernel meets fits its LDS.
+  const D2Out* d2out = nullptr;
+  const uint32_t* d2runs = nullptr;
+  uint64_t* hops = nullptr;  // (depth at which the hop is entered | (segment | entry state << 16) << 32)
 };
 size_t d3_work_bytes(uint32_t n);
 void d3_work_carve(void* p, uint32_t n, D3Work* w);

@@ -995,7 +995,7 @@ __global__ __launch_bounds__(64) void g2s_d3_trace(const D3Params P, const D3Wor
       summary_host[w] = __hip_atomic_load(src + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (P.self_clean) src[w] = 0u;
     }
-    if (P.self_clean && clean_words && lane < 8) clean_words[lane] = 0u;
+    if (P.self_clean && clean_words && lane < 32) clean_words[lane] = 0u;  // (the fill kernels' and g2s_d2_*'s cursors: 16 counters)
   };
   if (status) { leave(0u); return; }  // (the records in front of this kernel were not written: nothing below may run)
   const uint32_t gi = td.gi;
@@ -1036,9 +1036,20 @@ __global__ __launch_bounds__(64) void g2s_d3_trace(const D3Params P, const D3Wor
   rw[23] = (uint32_t)go.len[1];
   rw[3] = (go.flags & (G2S_DEV_Q7_A | G2S_DEV_Q7_B | G2S_DEV_Q7_D)) ? G2S_GAP_Q7 : 0u;
   rw[0] = (uint32_t)((phase_d && !P.skip_confident && P.all_paths) ? go.count_s : go.c_count);  // pp.count of the host analysis
+  // (the gap's closure was analysed by g2s_d2_* — d2_device.hip: more than 192 segments, or a k-mer at several depths:
+  // the statistics and the verdicts are in its record and its runs)
+  const bool by_runs = phase_d && !P.skip_confident && (go.dflags & G2S_DEVA_RUNS) != 0u && W.d2out != nullptr;
+  uint32_t n_runs = 0;
+  const uint32_t* runs = nullptr;
   if (phase_d && !P.skip_confident) {
     rw[8] = go.sub_vertices; rw[10] = go.sub_edges;    // vertices, edges (nothing contracted: no non-trivial component)
     rw[16] = go.sub_vertices; rw[18] = go.sub_edges;   // vertices_final, edges_final
+    if (by_runs) {
+      const uint4 o0 = ((const uint4*)&W.d2out[i])[0], o1 = ((const uint4*)&W.d2out[i])[1];
+      runs = W.d2runs + 2ull * uni(o0.x);
+      n_runs = uni(o0.y);
+      rw[8] = uni(o0.z); rw[10] = uni(o0.w); rw[12] = uni(o1.x); rw[14] = uni(o1.y); rw[16] = uni(o1.z); rw[18] = uni(o1.w);
+    }
   }
   if (!phase_d) {
     if (lane == 0) buf[dg.lmf] = '\0';
@@ -1083,16 +1094,19 @@ __global__ __launch_bounds__(64) void g2s_d3_trace(const D3Params P, const D3Wor
     return;
   }
   // ---- the closure into LDS
-  // (closures the device analysed have at most seg_cap segments; a longer one would be the host path's business)
-  const uint32_t nsegs = min((uint32_t)td.nsegs, P.seg_cap);
+  // (closures the fill kernel analysed have at most seg_cap segments; a longer one — analysed by g2s_d2_* — is walked
+  // where it lies, the segments its traceback enters listed in device memory: `big`)
+  const bool big = (uint32_t)td.nsegs > P.seg_cap && by_runs && W.hops != nullptr;
+  const uint32_t nsegs = big ? (uint32_t)td.nsegs : min((uint32_t)td.nsegs, P.seg_cap);
   const SegW* gsegs = (const SegW*)(sub + td.sub_at);
+  uint64_t* ghop = big ? W.hops + td.sub_at / 2u : nullptr;
   uint32_t* cmap = lds + (size_t)P.seg_cap * 8u;  // by fill-buffer index: k-mer index | orientation << 30 | lower case << 31
   // the rand() values of this traceback, into LDS together with the closure: the walk asks for one at every choice
   // between parents, and each was a round trip to memory in the middle of it (30 us for the longest of 500 walks)
   uint32_t* lwin = cmap + P.map_cap;
   const uint32_t nwin = min(td.want, P.map_cap);
   for (uint32_t x = (uint32_t)lane; x < nwin; x += 64u) lwin[x] = (uint64_t)td.off + x < capacity ? rnd[td.off + x] : 0u;
-  {
+  if (!big) {
     const uint4* src = (const uint4*)gsegs;
     uint4* dst = (uint4*)segs;
     for (uint32_t w = (uint32_t)lane; w < 2u * nsegs; w += 64u) dst[w] = src[w];
@@ -1113,6 +1127,18 @@ __global__ __launch_bounds__(64) void g2s_d3_trace(const D3Params P, const D3Wor
     }
     return sink_safe;
   };
+  // the verdict of k-mer x from the gap's runs (sorted, disjoint); *rlo, *rhi: the run's ends, or x itself when it is
+  // in no run (a k-mer outside the subgraph reads branch[sink], Q5)
+  auto run_verdict = [&](uint32_t x, uint32_t* rlo, uint32_t* rhi) -> bool {
+    uint32_t lo = 0, hi = n_runs;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (runs[2u * mid] <= x) lo = mid + 1u; else hi = mid; }
+    if (lo > 0u) {
+      const uint32_t f = runs[2u * (lo - 1u)], l = runs[2u * (lo - 1u) + 1u];
+      if (x <= (l & 0x7FFFFFFFu)) { *rlo = f; *rhi = l & 0x7FFFFFFFu; return (l >> 31) != 0u; }
+    }
+    *rlo = x; *rhi = x;
+    return sink_safe;
+  };
   // ---- the walk, in two parts.  (i) Wave-uniform and as short as it can be: which segments the traceback enters,
   // and at which state — per segment one read of its links from LDS and, where it has several parents, of a rand()
   // value.  (ii) All lanes: where every base of the fill comes from — k-mer index, orientation, safe bit — into
@@ -1130,13 +1156,13 @@ __global__ __launch_bounds__(64) void g2s_d3_trace(const D3Params P, const D3Wor
   int d2 = pick ? len1 : len0;
   const int len = d2;
   bool bad = false, ended = false;
-  if ((uint32_t)len + 1u > P.map_cap || (uint32_t)td.nsegs > P.seg_cap || td.want > P.map_cap) bad = true;
+  if ((uint32_t)len + 1u > P.map_cap || (!big && (uint32_t)td.nsegs > P.seg_cap) || td.want > P.map_cap) bad = true;
   uint2* hop = (uint2*)(lwin + P.map_cap);  // by hop: the depth at which the walk enters the segment (descending), the segment | its entry state << 16
   uint2* pk = hop + P.seg_cap;              // by segment: depth | length << 16, the parent a traceback goes on to from its first state | source << 30 | no way on << 31
   // (Every traced base draws one value — :1513 draws for a single parent too — so the draw made at depth d is the
   // (1 + len - d)-th of the gap whatever the path: the parent a traceback takes from a segment's first state is a
   // property of the segment.  All lanes work those out; the walk itself then reads three words per segment.)
-  for (uint32_t q = (uint32_t)lane; q < nsegs; q += 64u) {
+  for (uint32_t q = (uint32_t)lane; q < nsegs && !big; q += 64u) {
     const uint32_t dl = segs[q].depth_len, p01 = segs[q].par01, p23 = segs[q].par23, fl = segs[q].flags;
     const int d0 = (int)(dl & 0xFFFFu);
     const int nb = seg_nparents(p01, p23);
@@ -1163,8 +1189,8 @@ __global__ __launch_bounds__(64) void g2s_d3_trace(const D3Params P, const D3Wor
     const int t0 = (int)((go.start_t >> (16 * pick)) & 0xFFFFu);
     if (si < 0 || si >= (int)nsegs || avail < 1) bad = true;
     uint32_t last = 0x80000000u;
-    const int hop_cap = (int)min(nsegs, P.seg_cap);
-    if (!bad) {
+    const int hop_cap = (int)(big ? nsegs : min(nsegs, P.seg_cap));
+    if (!bad && !big) {
       for (;;) {
         if (nh >= hop_cap) { bad = true; break; }
         if (P.laps) hops++;
@@ -1174,6 +1200,29 @@ __global__ __launch_bounds__(64) void g2s_d3_trace(const D3Params P, const D3Wor
         if (last & 0xC0000000u) break;
         si = (int)(last & 0xFFFFu);
       }
+    }
+    if (!bad && big) {  // (the same chain over the records in device memory: a round trip per segment entered)
+      for (;;) {
+        if (nh >= hop_cap) { bad = true; break; }
+        if (P.laps) hops++;
+        const uint32_t dl = uni(gsegs[si].depth_len), p01 = uni(gsegs[si].par01), p23 = uni(gsegs[si].par23), fl = uni(gsegs[si].flags);
+        const int d0 = (int)(dl & 0xFFFFu);
+        const int nb = seg_nparents(p01, p23);
+        const int64_t at = 1 + (int64_t)len - d0;
+        uint32_t w;
+        if (nb == 0 || (nb > 1 && !(fl & G2S_SEG_ORDERED)) || at < 1 || (uint64_t)at >= avail) w = 0x80000000u;
+        else {
+          const uint32_t rv = nb > 1 ? value((uint32_t)at) >> 1 : 0u;
+          w = seg_parent(p01, p23, nb == 1 ? 0 : pick_parent(rv, nb));  // :1513
+          if (w >= nsegs) w = 0x80000000u;
+        }
+        last = w | ((fl & G2S_SUB_SOURCE) ? 0x40000000u : 0u);
+        if (lane == 0) ghop[nh] = (uint64_t)(uint32_t)si << 32;
+        nh++;
+        if (last & 0xC0000000u) break;
+        si = (int)(last & 0xFFFFu);
+      }
+      __threadfence_block();
     }
     if (!(last & 0x40000000u)) bad = true;  // (ended without a way on — :1493-1510 — or past the depth of a source)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1187,15 +1236,15 @@ __global__ __launch_bounds__(64) void g2s_d3_trace(const D3Params P, const D3Wor
     for (int h0 = 0; !bad && h0 < nh; h0 += 64) {
       const int h = h0 + lane;
       const bool in = h < nh;
-      const uint32_t sq = in ? hop[h].y : 0u;
-      const uint32_t dl = in ? pk[sq].x : 0u;
+      const uint32_t sq = in ? (big ? (uint32_t)(ghop[h] >> 32) : hop[h].y) : 0u;
+      const uint32_t dl = in ? (big ? gsegs[sq].depth_len : pk[sq].x) : 0u;
       const int d0 = (int)(dl & 0xFFFFu), t = h == 0 ? t0 : (int)(dl >> 16) - 1;  // (a child in the closure puts the whole parent there)
       int inc = in ? t + 1 : 0;
       for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(inc, o); if (lane >= o) inc += y; }
       const int at = len - carry - (inc - (in ? t + 1 : 0));  // the depth at which this hop is entered
       // (a hop that is not the last leaves its segment above depth 0: the step down exists)
       if (__ballot(in && (d0 + t != at || t < 0 || (h + 1 < nh && d0 < 1))) != 0ull) { bad = true; break; }
-      if (in) hop[h] = make_uint2((uint32_t)at, sq | ((uint32_t)t << 16));
+      if (in) { if (big) ghop[h] = (uint64_t)(uint32_t)at | ((uint64_t)(sq | ((uint32_t)t << 16)) << 32); else hop[h] = make_uint2((uint32_t)at, sq | ((uint32_t)t << 16)); }
       if (h + 1 == nh) d_end = d0;
       carry += __shfl(inc, 63);
     }
@@ -1217,21 +1266,31 @@ __global__ __launch_bounds__(64) void g2s_d3_trace(const D3Params P, const D3Wor
     const int hi_d = len - lane * per, cnt = max(0, min(per, hi_d - stop0));
     int lowest_safe = 0x7FFFFFFF;
     if (cnt > 0) {
+      // (hop h: the depth at which it is entered, the segment | its entry state << 16 — from LDS, or, a closure too
+      // large for it, from where the chain above listed them)
+      auto hop_at = [&](int h) -> uint2 {
+        if (!big) return hop[h];
+        const uint64_t w = ghop[h];
+        return make_uint2((uint32_t)w, (uint32_t)(w >> 32));
+      };
+      auto seg_at = [&](uint32_t q) -> SegW { return big ? gsegs[q] : segs[q]; };
       int lo = 0, hi = nh;  // the last hop entered at or above hi_d
-      while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int)hop[mid].x >= hi_d) lo = mid; else hi = mid; }
+      while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int)hop_at(mid).x >= hi_d) lo = mid; else hi = mid; }
       int h = lo;
-      uint2 hr = hop[h];
+      uint2 hr = hop_at(h);
       uint32_t rec = hr.y;
       int top = (int)hr.x, d0 = top - (int)(rec >> 16);
-      SegW sg = segs[rec & 0xFFFFu];
+      SegW sg = seg_at(rec & 0xFFFFu);
+      uint32_t rlo = 1u, rhi = 0u;  // the run the last k-mer lay in (none yet)
+      bool rsafe = false;
       for (int c = 0; c < cnt; c++) {
         const int p = hi_d - c;
         if (p < d0) {  // the next hop begins right below
           h++;
-          hr = hop[h];
+          hr = hop_at(h);
           rec = hr.y;
           top = (int)hr.x; d0 = top - (int)(rec >> 16);
-          sg = segs[rec & 0xFFFFu];
+          sg = seg_at(rec & 0xFFFFu);
         }
         const int q = p - d0;
         const uint32_t idx0 = sg.node >> 1;
@@ -1240,6 +1299,10 @@ __global__ __launch_bounds__(64) void g2s_d3_trace(const D3Params P, const D3Wor
         const int ts = (sg.ts_tt & 0x7FFFu) == 0x7FFFu ? -1 : (int)(sg.ts_tt & 0x7FFFu);
         bool sf;
         if (P.skip_confident) sf = true;
+        else if (by_runs) {  // (consecutive bases are consecutive k-mers: a search only where a run ends)
+          if (x < rlo || x > rhi) rsafe = run_verdict(x, &rlo, &rhi);
+          sf = rsafe;
+        }
         else if (q > ts) sf = outside_safe(x);
         else if (q > (int)sg.pad) sf = (sg.ts_tt & 0x80000000u) != 0;  // beyond the split: safe bit b
         else sf = (sg.ts_tt & 0x8000u) != 0;

@@ -36,7 +36,10 @@ hipError_t launch_fill_seg(hipStream_t st, uint32_t ngaps, const uint32_t* succ,
                            // phase D3 follows on the stream (d3_device.hip); ovf_list (optional, device memory, ngaps
                            // words): the gaps that outgrew the tier's capacities, counted in out_counter[1], for
                            // launch_fill_segw(..., ngaps_dev = out_counter + 1) behind this launch
-                           bool resident = false, uint32_t* ovf_list = nullptr);
+                           bool resident = false, uint32_t* ovf_list = nullptr,
+                           // (resident) the gaps whose closure the kernel leaves unanalysed, counted in out_counter[4]:
+                           // g2s_d2_* (d2_device.hip) behind the fill kernels; null: the host analyses them
+                           uint32_t* d2_list = nullptr);
 
 // The large variant: `workgroups` persistent workgroups (one per compute unit) take the listed gaps
 // in order from the counter *next_gap (zero before the launch); scratch: fill_segx_scratch_bytes().
@@ -70,6 +73,7 @@ hipError_t launch_fill_segw(hipStream_t st, uint32_t ngaps, uint32_t workgroups,
                             // the number of listed gaps is read from device memory when the kernel starts (the list
                             // was written by the launch in front: launch_fill_seg's ovf_list); ngaps is then the most
                             // there can be
-                            const unsigned long long* ngaps_dev = nullptr, const SegEarly* early = nullptr);
+                            const unsigned long long* ngaps_dev = nullptr, const SegEarly* early = nullptr,
+                            uint32_t* d2_list = nullptr /* as launch_fill_seg */);
 
 }  // namespace g2s

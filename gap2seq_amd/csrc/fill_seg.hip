@@ -1851,6 +1851,7 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
     go->sub_edges = sub_edges;
     go->count_s = count_s;
     go->dflags = (analysed || !want_s ? G2S_DEVA_ANALYSED : 0u) | (choice ? G2S_DEVA_CHOICE : 0u) | (sink_safe ? G2S_DEVA_SINK_SAFE : 0u);
+    if (A.d2_list && want_s && !analysed) A.d2_list[atomicAdd(out_counter + 4, 1ull)] = gi;  // (d2_device.hip takes it)
     go->flags = flags | G2S_DEV_COMPACT;
     go->n_sub = nsub;
     go->n_xp = nxp;
@@ -1919,7 +1920,8 @@ hipError_t launch_fill_seg(hipStream_t st, uint32_t ngaps, const uint32_t* succ,
                            const uint32_t* gap_ids, const uint32_t* flank_nodes, SubRec* sub_out,
                            unsigned long long out_cap, unsigned long long* out_counter, GapOut* outs, GapOut* outs_host,
                            uint32_t* done_list, int skip_confident, uint32_t* dbg, bool two_waves, unsigned long long* xcd_tickets,
-                           uint32_t* xcd_list, uint32_t xcd_stride, uint32_t pub_batch, bool resident, uint32_t* ovf_list) {
+                           uint32_t* xcd_list, uint32_t xcd_stride, uint32_t pub_batch, bool resident, uint32_t* ovf_list,
+                           uint32_t* d2_list) {
   if (ngaps == 0) return hipSuccess;
   size_t bytes = two_waves ? fill_seg2_lds_bytes() : fill_seg_lds_bytes();
   // (G2S_SEG_LDS_PAD=BYTES, measurements only: a larger LDS request per gap = fewer gaps resident per compute unit)
@@ -1930,7 +1932,7 @@ hipError_t launch_fill_seg(hipStream_t st, uint32_t ngaps, const uint32_t* succ,
   if (!xcd_tickets || !xcd_list || pub_batch < 2u || pub_batch > 64u || (pub_batch & (pub_batch - 1u))) pub_batch = 1u;
   const SegArgs A = {succ, urec, gaps, gap_ids, flank_nodes, sub_out, out_cap, out_counter, outs, outs_host, done_list,
                      skip_confident, dbg, fill_seg_dbg_words(), xcd_tickets, xcd_list, xcd_stride, pub_batch, resident ? 1u : 0u,
-                     0u, resident ? ovf_list : nullptr};
+                     0u, resident ? ovf_list : nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0u, resident ? d2_list : nullptr};
   if (two_waves) hipLaunchKernelGGL(g2s_fill_seg2, dim3(ngaps), dim3(128), bytes, st, A);
   else hipLaunchKernelGGL(g2s_fill_seg, dim3(ngaps), dim3(64), bytes, st, A);
   return hipGetLastError();

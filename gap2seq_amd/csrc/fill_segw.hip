@@ -1278,6 +1278,7 @@ __device__ __forceinline__ void segw_fill_one(uint32_t* lds, const SegArgs& A, c
     go->sub_edges = sub_edges;
     go->count_s = count_s;
     go->dflags = (analysed || !want_s ? G2S_DEVA_ANALYSED : 0u) | (choice ? G2S_DEVA_CHOICE : 0u) | (sink_safe ? G2S_DEVA_SINK_SAFE : 0u);
+    if (A.d2_list && want_s && !analysed) A.d2_list[atomicAdd(out_counter + 4, 1ull)] = gi;  // (d2_device.hip takes it)
     go->flags = flags | G2S_DEV_COMPACT;
     go->n_sub = nsub;
     go->n_xp = sh[SH_NXP];
@@ -1345,7 +1346,8 @@ hipError_t launch_fill_segw(hipStream_t st, uint32_t ngaps, uint32_t workgroups,
                             const GapDev* gaps, const uint32_t* gap_ids, const uint32_t* flank_nodes, SubRec* sub_out,
                             unsigned long long out_cap, unsigned long long* out_counter, GapOut* outs, GapOut* outs_host,
                             uint32_t* done_list, int skip_confident, uint32_t* dbg, uint32_t* scratch,
-                            unsigned long long* next_gap, bool resident, const unsigned long long* ngaps_dev, const SegEarly* early) {
+                            unsigned long long* next_gap, bool resident, const unsigned long long* ngaps_dev, const SegEarly* early,
+                            uint32_t* d2_list) {
   if (ngaps == 0) return hipSuccess;
   const size_t bytes = fill_segw_lds_bytes();
   hipError_t e = hipFuncSetAttribute((const void*)g2s_fill_segw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
@@ -1353,7 +1355,7 @@ hipError_t launch_fill_segw(hipStream_t st, uint32_t ngaps, uint32_t workgroups,
   SegArgs A = {succ, urec, gaps, gap_ids, flank_nodes, sub_out, out_cap, out_counter, outs, outs_host, done_list,
                skip_confident, dbg, fill_segx_dbg_words(), nullptr, nullptr, 0u, 1u, resident ? 1u : 0u, 0u, nullptr,
                early ? early->segs : nullptr, early ? early->items : nullptr, early ? early->outs : nullptr,
-               early ? early->ctr : nullptr, early ? early->cap_items : 0u, early ? early->cap_segs : 0u};
+               early ? early->ctr : nullptr, early ? early->cap_items : 0u, early ? early->cap_segs : 0u, resident ? d2_list : nullptr};
   hipLaunchKernelGGL(g2s_fill_segw, dim3(workgroups), dim3(SEGW_NT), bytes, st, A, scratch, ngaps, next_gap, ngaps_dev);
   return hipGetLastError();
 }

@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "../../include/g2s.h"
+#include "d2_device.h"
 #include "d3_device.h"
 #include "dbg.hpp"
 #include "fastx.hpp"
@@ -562,6 +563,13 @@ struct g2s_session {
   DevBuf d_log, d_lvl, d_plk, d_xl, d_xo;  // LDS tier: state log, level offsets, parent links, closure side lists
   DevBuf d_segx;  // large variant of the segment tier: segment arrays and queues of its persistent workgroups
   DevBuf d_ovf;   // resident mode: the gaps of a launch that outgrew the regular tier (the large variant's list)
+  // resident mode, phase D2 on the device for the closures the fill kernels leave (d2_device.hip): the gaps they list
+  // (two lists of n: the small instantiation's, then what it passes on), the per-gap results, the runs, the kernels'
+  // scratch; d_hops: where the trace kernel keeps the segments a traceback enters when the closure is too large for
+  // its LDS (a traceback enters a segment once: as many entries as the closure has segments, at the closure's offset)
+  DevBuf d_d2list, d_d2out, d_d2runs, d_d2scr_small, d_d2scr_big, d_hops;
+  bool d2_launched = false;  // the last fill launch had g2s_d2_* behind it
+  bool d2_prof_on = false;   // (G2S_D2_PROF) the section counters behind the cursors have been zeroed
   int num_cus = 256;
   DevBuf d_rspool;
   DevBuf d_logpool;  // chunks for state logs that outgrow their slice of d_log (LDS tier)                          // LDS tier: spill pool for right sets
@@ -735,6 +743,18 @@ extern "C" int g2s_session_create(g2s_graph* g, int device, const g2s_params* p,
 
 extern "C" void g2s_session_destroy(g2s_session* s) {
   if (!s) return;
+  if (s->d2_prof_on && s->d_counter.p) {  // (G2S_D2_PROF: what g2s_d2_* spent where, over the session's lists)
+    unsigned long long pr[16] = {0};
+    (void)hipSetDevice(s->device);
+    (void)hipDeviceSynchronize();
+    if (hipMemcpy(pr, (char*)s->d_counter.p + 128, 128, hipMemcpyDeviceToHost) == hipSuccess) {
+      static const char* names[11] = {"load+sort", "dag", "chain intervals", "cuts", "runs", "edges", "csr", "components", "statistics", "order", "verdicts"};
+      fprintf(stderr, "[g2s] g2s_d2_*: %llu closures on runs, %.0f nodes and %.0f rounds each; cycles (100 MHz clock) per closure:", pr[11],
+              pr[11] ? (double)pr[12] / (double)pr[11] : 0.0, pr[11] ? (double)pr[13] / (double)pr[11] : 0.0);
+      for (int q = 0; q < 11; q++) fprintf(stderr, " %s %.0f", names[q], pr[11] ? (double)pr[q] / (double)pr[11] : (double)pr[q]);
+      fprintf(stderr, "\n");
+    }
+  }
   // lists begun and never ended: their kernels first — on all three streams of every session that carries one (the
   // rand() stream and the descriptors run on the second, the large variant's early launch on the third) — and what
   // was queued for their phase D3 (it points into the batches freed below)
@@ -772,6 +792,7 @@ extern "C" void g2s_session_destroy(g2s_session* s) {
   if (s->ev_early) (void)hipEventDestroy(s->ev_early);
   if (s->stream3) (void)hipStreamDestroy(s->stream3);
   s->d_segx1.release();
+  s->d_d2list.release(); s->d_d2out.release(); s->d_d2runs.release(); s->d_d2scr_small.release(); s->d_d2scr_big.release(); s->d_hops.release();
   s->d_link.release();
   if (s->stream2) (void)hipStreamDestroy(s->stream2);
   if (s->stream) (void)hipStreamDestroy(s->stream);
@@ -2735,9 +2756,30 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl) {
   HIP_TRY_S(s->d_gaps.ensure(n * sizeof(GapDev)));
   HIP_TRY_S(s->d_ids.ensure(std::max<size_t>(ids.size() * 4, 16)));
   HIP_TRY_S(s->d_outs.ensure(n * sizeof(GapOut)));
-  HIP_TRY_S(s->d_counter.ensure(32));
+  // ([0] closure cursor, [1] overflow list, [2] [3] work counters of the large variant's two launches; d2_device.hip:
+  // [4] gaps listed, [5] small instantiation's work counter, [6] gaps passed on, [7] large one's work counter, [8] runs)
+  HIP_TRY_S(s->d_counter.ensure(256));  // ([16 .. 31]: G2S_D2_PROF, never zeroed by the kernels)
   HIP_TRY_S(s->d_sub.ensure(out_states * sizeof(SubRec)));
   const uint32_t segw_wgs = (uint32_t)std::min<size_t>(ids.size(), (size_t)std::max(1, s->num_cus));
+  // Phase D2 on the device for the closures the fill kernels do not analyse themselves (d2_device.hip: more than 192
+  // segments, a k-mer at several depths): g2s_d2_small / g2s_d2_big behind the fill kernels, in front of phase D3.
+  // Not for a team's groups that are gathered on the lead's device (their results would have to travel too), not with
+  // -all-upper (no phase D2 at all).  G2S_DEVICE_D2=0: those closures are the host's, as until round 4 (post.cpp).
+  bool dev_d2 = (!s->in_team_list || s->team_sharded) && !s->params.skip_confident && !ids.empty();
+  if (const char* env = getenv("G2S_DEVICE_D2")) dev_d2 = dev_d2 && atoi(env) != 0;
+  const bool d2_big = dev_d2 && (b->dmax >= 2500 || getenv("G2S_D2_BIG") != nullptr);  // (a deep list: closures of thousands of segments)
+  const uint32_t d2_small_wgs = (uint32_t)std::min<size_t>(ids.size(), (size_t)std::max(1, s->num_cus) * 4u);
+  const uint32_t d2_big_wgs = (uint32_t)std::min<size_t>(ids.size(), (size_t)std::max(1, s->num_cus));
+  const uint64_t d2_run_cap = out_states + 65536u;
+  if (dev_d2) {
+    HIP_TRY_S(s->d_d2list.ensure(std::max<size_t>(2 * n * 4, 16)));
+    HIP_TRY_S(s->d_d2out.ensure(std::max<size_t>(n * sizeof(D2Out), 32)));
+    HIP_TRY_S(s->d_d2runs.ensure((size_t)d2_run_cap * 8));
+    HIP_TRY_S(s->d_d2scr_small.ensure(d2_scratch_bytes(false, d2_small_wgs)));
+    if (d2_big) HIP_TRY_S(s->d_d2scr_big.ensure(d2_scratch_bytes(true, d2_big_wgs)));
+    HIP_TRY_S(s->d_hops.ensure((size_t)(out_states / 2 + 64) * 8));
+  }
+  s->d2_launched = dev_d2;
   if (rerun) {
     HIP_TRY_S(s->d_ovf.ensure(std::max<size_t>(ids.size() * 4, 16)));
     HIP_TRY_S(s->d_segx.ensure(fill_segw_scratch_bytes(segw_wgs)));
@@ -2756,13 +2798,14 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl) {
     ids_dev = (const uint32_t*)s->d_ids.p;
   }
   if (s->d_outs.clean < n * sizeof(GapOut)) HIP_TRY_S(hipMemsetAsync(s->d_outs.p, 0, n * sizeof(GapOut), st));
-  if (s->d_counter.clean < 32) HIP_TRY_S(hipMemsetAsync(s->d_counter.p, 0, 32, st));
+  if (s->d_counter.clean < 128) HIP_TRY_S(hipMemsetAsync(s->d_counter.p, 0, 128, st));
   s->d_outs.clean = 0;
   s->d_counter.clean = 0;
   // (a deep list: the closures the host will analyse leave the large variant's gaps one by one, into pinned memory)
   SegEarly early_dev;
   s->early_host = SegEarly();
-  if (rerun && b->dmax >= 2500 && !s->in_team_list && !getenv("G2S_NO_EARLY_HANDOVER")) {
+  // (with phase D2 on the device — below — there is nothing to hand over early)
+  if (rerun && b->dmax >= 2500 && !s->in_team_list && !getenv("G2S_NO_EARLY_HANDOVER") && !dev_d2) {
     const size_t cap_items = n, cap_segs = (size_t)std::min<uint64_t>((uint64_t)n * 1024u, 2ull << 20) + 65536u;
     const size_t b_items = (cap_items * 32 + 63) & ~(size_t)63, b_outs = (cap_items * sizeof(GapOut) + 63) & ~(size_t)63;
     HIP_TRY_S(s->h_early.ensure(b_items + b_outs + cap_segs * sizeof(SegRec)));
@@ -2790,7 +2833,8 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl) {
   HIP_TRY_S(launch_fill_seg(st, (uint32_t)n_reg, dg.succ, dg.urec, gaps_dev, ids_dev, (const uint32_t*)s->d_flank.p,
                           (SubRec*)s->d_sub.p, (unsigned long long)out_states, (unsigned long long*)s->d_counter.p,
                           (GapOut*)s->d_outs.p, nullptr, nullptr, s->params.skip_confident ? 1 : 0, nullptr, two_waves,
-                          nullptr, nullptr, 0u, 1u, true, rerun ? (uint32_t*)s->d_ovf.p : nullptr));
+                          nullptr, nullptr, 0u, 1u, true, rerun ? (uint32_t*)s->d_ovf.p : nullptr,
+                          dev_d2 ? (uint32_t*)s->d_d2list.p : nullptr));
   if (rl->timed) HIP_TRY_S(hipEventRecord(s->ev[2], st));
   // (queued BEHIND the regular tier's kernel, which takes the compute units first — a workgroup of the large variant
   // needs a whole unit's LDS and stays for the launch: started first, 256 of them leave the regular tier no unit until
@@ -2804,7 +2848,8 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl) {
                                (const uint32_t*)s->d_flank.p, (SubRec*)s->d_sub.p, (unsigned long long)out_states,
                                (unsigned long long*)s->d_counter.p, (GapOut*)s->d_outs.p, nullptr, nullptr,
                                s->params.skip_confident ? 1 : 0, nullptr, (uint32_t*)s->d_segx1.p,
-                               (unsigned long long*)s->d_counter.p + 3, true, nullptr, early_dev.items ? &early_dev : nullptr));
+                               (unsigned long long*)s->d_counter.p + 3, true, nullptr, early_dev.items ? &early_dev : nullptr,
+                               dev_d2 ? (uint32_t*)s->d_d2list.p : nullptr));
     HIP_TRY_S(hipEventRecord(s->ev_early, s->stream3));
   }
   // (the large variant for what the launch above listed: its workgroups read the list's length from device memory and
@@ -2815,8 +2860,25 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl) {
                              (unsigned long long*)s->d_counter.p, (GapOut*)s->d_outs.p, nullptr, nullptr,
                              s->params.skip_confident ? 1 : 0, nullptr, (uint32_t*)s->d_segx.p,
                              (unsigned long long*)s->d_counter.p + 2, true, (const unsigned long long*)s->d_counter.p + 1,
-                             early_dev.items ? &early_dev : nullptr));
+                             early_dev.items ? &early_dev : nullptr, dev_d2 ? (uint32_t*)s->d_d2list.p : nullptr));
   if (n_early && rerun) HIP_TRY_S(hipStreamWaitEvent(st, s->ev_early, 0));  // (phase D3 follows on this stream: behind both)
+  if (dev_d2) {  // (its workgroups read the list's length from device memory and leave at once when it is empty)
+    D2Args DA;
+    memset(&DA, 0, sizeof DA);
+    unsigned long long* ctr = (unsigned long long*)s->d_counter.p;
+    DA.gaps = gaps_dev; DA.flank_nodes = (const uint32_t*)s->d_flank.p; DA.outs = (GapOut*)s->d_outs.p; DA.sub = (SubRec*)s->d_sub.p;
+    DA.list = (const uint32_t*)s->d_d2list.p; DA.count = ctr + 4; DA.next = ctr + 5;
+    DA.d2out = (D2Out*)s->d_d2out.p; DA.runs = (uint32_t*)s->d_d2runs.p; DA.run_cursor = ctr + 8; DA.run_cap = d2_run_cap;
+    DA.all_paths = s->params.all_paths ? 1 : 0; DA.list_cap = (uint32_t)n;
+    static const bool d2_prof = getenv("G2S_D2_PROF") != nullptr;
+    if (d2_prof) {
+      if (!s->d2_prof_on) { HIP_TRY_S(hipMemsetAsync((char*)s->d_counter.p + 128, 0, 128, st)); s->d2_prof_on = true; }
+      DA.prof = ctr + 16;
+    }
+    DA.pass_all = (d2_big && getenv("G2S_D2_BIG") && atoi(getenv("G2S_D2_BIG")) == 2) ? 1u : 0u;  // (tests: every closure through the large instantiation)
+    HIP_TRY_S(launch_d2(st, DA, d2_small_wgs, d2_big ? d2_big_wgs : 0u, (uint32_t*)s->d_d2scr_small.p, (uint32_t*)s->d_d2scr_big.p,
+                        (uint32_t*)s->d_d2list.p + n, ctr + 6, ctr + 7));
+  }
   if (rerun && rl->timed) HIP_TRY_S(hipEventRecord(s->ev_segw, st));
   rl->units = out_states;
   rl->two_waves = two_waves;
@@ -2827,8 +2889,8 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl) {
 static int resident_reset_fill(g2s_session* s, size_t n) {
   HIP_TRY(hipMemsetAsync(s->d_outs.p, 0, n * sizeof(GapOut), s->stream));
   s->d_outs.clean = n * sizeof(GapOut);
-  HIP_TRY(hipMemsetAsync(s->d_counter.p, 0, 32, s->stream));
-  s->d_counter.clean = 32;
+  HIP_TRY(hipMemsetAsync(s->d_counter.p, 0, 128, s->stream));
+  s->d_counter.clean = 128;
   return G2S_OK;
 }
 
@@ -2953,6 +3015,9 @@ static int resident_d3_launch(g2s_session* s, const ResidentList& L, bool timed,
   D3Work W;
   d3_work_carve(s->d_d3.p, (uint32_t)n, &W);
   W.link = sharded ? nullptr : (uint32_t*)s->d_link.p;
+  if (s->d2_launched && L.outs_dev == (const GapOut*)s->d_outs.p) {  // (this session's own fill launch: g2s_d2_* ran behind it)
+    W.d2out = (const D2Out*)s->d_d2out.p; W.d2runs = (const uint32_t*)s->d_d2runs.p; W.hops = (uint64_t*)s->d_hops.p;
+  }
   // where the kernels write results and text: the caller's buffers when those are pinned, staging otherwise
   void *res_dev = nullptr, *arena_dev = nullptr;
   // (G2S_D3_STAGE=device, measurements only: the kernels write device memory, two copies bring it to the caller)
@@ -3396,7 +3461,7 @@ static int run_resident_finish(g2s_batch* b, const ResidentLaunch& rl, std::chro
   bool fell_back = false;
   const int rc = resident_d3_wait(s, &b->timing, &ms_d3, &fell_back);
   if (rc != G2S_OK) return rc;
-  if (s->self_cleaned) { s->d_outs.clean = n * sizeof(GapOut); s->d_counter.clean = 32; }
+  if (s->self_cleaned) { s->d_outs.clean = n * sizeof(GapOut); s->d_counter.clean = 128; }
   else { const int r2 = resident_reset_fill(s, n); if (r2 != G2S_OK) return r2; }
   s->self_cleaned = false;
   if (fell_back) { b->timing.resident_fallbacks++; return 1; }

@@ -1,5 +1,6 @@
 // gap2seq_amd/csrc/post.cpp — see post.hpp.
 #include "post.hpp"
+#include <mutex>
 
 #include <algorithm>
 #include <chrono>
@@ -906,6 +907,30 @@ void seg_analyze_runs(const FillParams& p, const SubView& v, SubPrep* out, const
   out->sink_safe = !nontriv[(size_t)comp[0]] && fbranch[(size_t)comp[0]] == 1;
   out->run_mode = true;
   lap();
+  if (const char* path = getenv("G2S_D2_STATS")) {  // (tools: the shape of the graphs phase D2 works on, a line per closure)
+    // longest path of the condensation in components, and counting only components that branch (in or out degree
+    // other than one): what a level-synchronous sweep on the device would take
+    std::vector<int> lvl((size_t)nc, 0), blvl((size_t)nc, 0);
+    int deep = 0, bdeep = 0, nbranch = 0;
+    for (int u : order) {
+      const bool br = din[(size_t)u] != 1 || dout[(size_t)u] != 1;
+      nbranch += br;
+      const int mine = lvl[(size_t)u] + 1, bmine = blvl[(size_t)u] + (br ? 1 : 0);
+      deep = std::max(deep, mine); bdeep = std::max(bdeep, bmine);
+      for (int x = foff[(size_t)u]; x < foff[(size_t)u + 1]; x++) {
+        const int w = fadj[(size_t)x];
+        lvl[(size_t)w] = std::max(lvl[(size_t)w], mine);
+        blvl[(size_t)w] = std::max(blvl[(size_t)w], bmine);
+      }
+    }
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    if (FILE* f = fopen(path, "a")) {
+      fprintf(f, "segs %u runs %d edges %zu loops %zu comps %d nontrivial %d size_nontrivial %llu levels %d branch_comps %d branch_levels %d\n",
+              n, R, ce.size(), loops.size(), nc, nontrivial, (unsigned long long)size_nontrivial, deep, nbranch, bdeep);
+      fclose(f);
+    }
+  }
 }
 
 }  // namespace

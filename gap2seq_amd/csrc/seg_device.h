@@ -192,6 +192,10 @@ struct SegArgs {
   GapOut* early_outs;
   unsigned long long* early_ctr;
   uint32_t early_cap_items, early_cap_segs;
+  // resident mode: a gap whose closure this kernel leaves unanalysed (more than 192 segments, a k-mer at several
+  // depths) enters itself here, counted in out_counter[4]: g2s_d2_* (d2_device.hip) follows on the stream.  Null: such
+  // gaps are the host's (post.cpp).
+  uint32_t* d2_list;
 };
 
 // LDS of the large variant (words): see the layout notes at each phase

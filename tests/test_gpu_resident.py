@@ -58,10 +58,33 @@ def test_resident_mode_equals_the_host_path(product, monkeypatch, mode, pinned):
     assert d2 == h2  # (the second list began at the right place in the stream)
     assert (td.xB, td.sB, td.seg_tier_gaps, td.seg_segments, td.fill_bytes) == (th.xB, th.sB, th.seg_tier_gaps, th.seg_segments, th.fill_bytes)
     assert td.draw_dependent_gaps > 0 and td.d3_table_entries >= td.draw_dependent_gaps
-    # a few closures per thousand hold a k-mer at two depths: the host analyses and traces those (with -all-upper
-    # nothing is analysed at all)
-    assert (td.host_finished_gaps > 0) == (mode != "all_upper")
+    # a few closures per thousand hold a k-mer at two depths: g2s_d2_* analyses those behind the fill kernel
+    # (d2_device.hip; until round 4 they were handed to the host) — nothing is left to the host's threads
+    assert td.host_finished_gaps == 0
     assert sum(1 for r in d1 if r[0] > 0) > 600
+
+
+@pytest.mark.parametrize("how", ["host", "small", "large"])
+def test_phase_d2_on_the_device_equals_the_hosts(product, monkeypatch, how):
+    """The closures the fill kernels do not analyse themselves (a k-mer at several depths, more than 192 segments):
+    analysed by g2s_d2_small / g2s_d2_big and traced by the trace kernel from their runs (the default; "large": every
+    one of them through the large instantiation, G2S_D2_BIG=2), or handed to the host's threads (G2S_DEVICE_D2=0: round
+    4's way, post.cpp) — every field of every result and the subgraph statistics equal the host path's either way."""
+    reads = product.G2S.synth_genome(200000, 3, 20240101)
+    seqs = [ln for ln in reads.splitlines() if not ln.startswith(">")]
+    gaps = _parse_scaffolds(product.G2S.synth_gaps(reads, 31, 10, 3000, 100, 900, 20240103))
+    for mode_kw in ({}, dict(all_paths=False)):
+        monkeypatch.delenv("G2S_DEVICE_D2", raising=False)
+        monkeypatch.delenv("G2S_D2_BIG", raising=False)
+        h1, h2, th, _ = _run(product, monkeypatch, False, seqs, 31, gaps, 500, **mode_kw)
+        if how == "host":
+            monkeypatch.setenv("G2S_DEVICE_D2", "0")
+        elif how == "large":
+            monkeypatch.setenv("G2S_D2_BIG", "2")
+        d1, d2, td, td2 = _run(product, monkeypatch, True, seqs, 31, gaps, 500, pinned=True, **mode_kw)
+        assert td.resident_launches == 1 and td.resident_fallbacks == 0
+        assert d1 == h1 and d2 == h2
+        assert (td.host_finished_gaps > 5) if how == "host" else (td.host_finished_gaps == 0)
 
 
 def test_list_sizes_around_the_switch_points(product, monkeypatch):
@@ -274,6 +297,7 @@ def test_lists_on_one_session_long_short_long(product, monkeypatch):
         want = [[_key(r) for r in s.fill_batch(L)] for L in lists]
         s.destroy()
         monkeypatch.setenv("G2S_RESIDENT", "1")
+        monkeypatch.setenv("G2S_DEVICE_D2", "0")  # (the hand-over to the host's threads is what this test is about)
         s = product.Session(pg, 0, d_err=500, randseed=9)
         got, hosts = [], []
         for L in lists:
@@ -302,6 +326,8 @@ def test_resident_mode_on_toy_graphs(product, oracle, monkeypatch, seed):
     for skip, allp in ((False, True), (False, False), (True, True)):
         c, f, tm, _, _ = _check_batch(product, oracle, seqs, k, gaps, e, skip, allp)
         assert tm.resident_launches == 1 and tm.resident_fallbacks == 0
+        # (cyclic closures — tandem repeats — included: strong components and the safe-vertex rule ran on the device)
+        assert tm.host_finished_gaps == 0
 
 
 @pytest.mark.parametrize("seed", range(6))
