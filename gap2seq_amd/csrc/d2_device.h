@@ -23,11 +23,11 @@ static_assert(sizeof(D2Out) == 32, "D2Out layout");
 // capacities of the two instantiations (closure segments on paths to a sink, closure segments in all, cut points,
 // nodes of the run graph, its edges): a gap that does not fit the small one is passed on to the large one, a gap that
 // does not fit that stays the host's (post.cpp)
-#define G2S_D2_SMALL_NS 512u
-#define G2S_D2_SMALL_NREC 1024u
-#define G2S_D2_SMALL_BP 2048u
-#define G2S_D2_SMALL_NV 1024u
-#define G2S_D2_SMALL_E 2048u
+#define G2S_D2_SMALL_NS 256u
+#define G2S_D2_SMALL_NREC 512u
+#define G2S_D2_SMALL_BP 1024u
+#define G2S_D2_SMALL_NV 512u
+#define G2S_D2_SMALL_E 1024u
 #define G2S_D2_BIG_NS 4096u
 #define G2S_D2_BIG_NREC 16384u
 #define G2S_D2_BIG_BP 16384u
@@ -51,7 +51,7 @@ struct D2Args {
   uint32_t* scratch;                    // d2_scratch_words() words per workgroup
   int32_t all_paths;
   uint32_t list_cap;                    // most gaps the list can hold (the grid is sized by it)
-  uint32_t pass_all;                    // (tests) the small instantiation passes every gap on to the large one
+  uint32_t pass_all;                    // (tests) bit 0: the small instantiation passes every gap on to the large one; bit 1: no chains are contracted
   unsigned long long* prof;             // (tools, may be null) 16 counters: cycles per section of the analysis, summed over gaps
 };
 

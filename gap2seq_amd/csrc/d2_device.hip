@@ -38,17 +38,26 @@ struct D2Caps {
   // (u32), two work lists (u16)
   static constexpr uint32_t OFF_BYTES = ((NV + 2u) * 2u + 15u) & ~15u;
   static constexpr uint32_t G_BYTES = 2u * OFF_BYTES + 2u * E * 2u + 2u * NV * 2u + NV * 4u + 2u * NV * 2u;
-  static constexpr uint32_t LDS_BYTES = (K_BYTES > G_BYTES ? K_BYTES : G_BYTES) + 64u;
+  static constexpr uint32_t MAIN_BYTES = K_BYTES > G_BYTES ? K_BYTES : G_BYTES;
+  // ... and behind either: per 64 cuts a mask and a count of the runs between cuts, a bit per node (pass-through), counters
+  static constexpr uint32_t AUX_BYTES = (BP / 64u) * 12u + (NV / 32u) * 4u + 64u;
+  static constexpr uint32_t LDS_BYTES = MAIN_BYTES + AUX_BYTES;
   // global scratch of a workgroup, words
-  static constexpr uint32_t SCR_WORDS = 9u * NS + 2u * BP + 4u * NV + E + 64u;
+  static constexpr uint32_t SCR_WORDS = 9u * NS + 3u * BP + 5u * NV + E + 64u;
+  static_assert(BP >= 4u * NS, "the sort buffer holds the look-up tables: cuts, vertex intervals, chain intervals");
 };
 using D2Small = D2Caps<G2S_D2_SMALL_NS, G2S_D2_SMALL_NREC, G2S_D2_SMALL_BP, G2S_D2_SMALL_NV, G2S_D2_SMALL_E>;
 using D2Big = D2Caps<G2S_D2_BIG_NS, G2S_D2_BIG_NREC, G2S_D2_BIG_BP, G2S_D2_BIG_NV, G2S_D2_BIG_E>;
 
+// state of a node while the strong components are found; afterwards: its component (the id of one of its nodes)
 #define D2_ALIVE 0xFFFFFFFFu
-#define D2_QUEUED 0xFFFFFFFEu
 #define D2_FW 0xFFFFFFFDu
 #define D2_FWBW 0xFFFFFFFCu
+// a pass-through node (one edge in, one out, not covered in both directions): 0x80000000 | edge slot << 16 | the node
+// its chain leaves, D2_PASS until the chain has been walked
+#define D2_PASS 0xFFFFFF00u
+__device__ __forceinline__ bool d2_is_pass(uint32_t st) { return st >= 0x80000000u && st <= D2_PASS; }
+#define D2_NONE 0xFFFFFFFFu
 
 // what the wave wrote to global scratch is read back by other lanes
 __device__ __forceinline__ void gsync() {
@@ -198,7 +207,10 @@ __device__ int d2_one(uint32_t* lds, const D2Args& A, uint32_t gap, uint32_t* sc
     return sp > ts ? -1 : sp;
   };
   uint64_t* K = (uint64_t*)lds;
-  uint32_t* hdr = lds + (C::LDS_BYTES - 64u) / 4u;  // a few counters
+  uint64_t* GM = (uint64_t*)(lds + C::MAIN_BYTES / 4u);   // per 64 cuts: which of them have a run behind them ...
+  uint32_t* GP = (uint32_t*)(GM + C::BP / 64u);           // ... and how many such runs lie in front of the 64
+  uint32_t* PM = GP + C::BP / 64u;                        // a bit per node: pass-through
+  uint32_t* hdr = PM + C::NV / 32u;                       // a few counters
   // scratch
   uint32_t* VM = scr;                      // merged vertex intervals
   uint32_t* UI = VM + 2u * C::NS;          // chain edges of upward segments, by the lower of their two k-mers
@@ -207,11 +219,12 @@ __device__ int d2_one(uint32_t* lds, const D2Args& A, uint32_t gap, uint32_t* sc
   uint32_t* SINKS = SRCS + C::NS;
   uint32_t* LOOPS = SINKS + C::NS;
   uint32_t* CUT = LOOPS + C::NS;
-  uint32_t* RC = CUT + C::BP;              // run of cut j
-  uint32_t* RLO = RC + C::BP;              // by node
+  uint64_t* SP = (uint64_t*)(CUT + C::BP); // the distinct (parent's last k-mer, entry) pairs, sorted
+  uint32_t* RLO = (uint32_t*)(SP + C::BP); // by node
   uint32_t* RHI = RLO + C::NV;
   uint32_t* NW = RHI + C::NV;              // k-mers of the node | covered upwards << 30 | downwards << 31
-  uint32_t* ORDER = NW + C::NV;
+  uint32_t* HEAD = NW + C::NV;             // pass-through nodes outside the components: the component their chain leaves
+  uint32_t* ORDER = HEAD + C::NV;
   uint32_t* EDGE = ORDER + C::NV;          // from << 16 | to
 
   // ---- the S closure's index intervals, sorted
@@ -368,6 +381,7 @@ __device__ int d2_one(uint32_t* lds, const D2Args& A, uint32_t gap, uint32_t* sc
   }
 
   // ================= a k-mer at several depths: the graph of runs (post.cpp: seg_analyze_runs) ======================
+  // (all the sorting first; the sort buffer then holds the tables the rest looks things up in)
   // ---- chain edges of the upward and of the downward segments as merged intervals (adjacent ones merge)
   uint32_t MU = 0, MD = 0;
   for (int dir = 0; dir < 2; dir++) {
@@ -443,71 +457,12 @@ __device__ int d2_one(uint32_t* lds, const D2Args& A, uint32_t gap, uint32_t* sc
     if (pass != 0 && u > C::NS) return 1;
     for (uint32_t i = (uint32_t)lane; i < u; i += 64u) dst[i] = (uint32_t)K[i];
     if (pass == 0) nb = u; else if (pass == 1) nsrc = u; else nsink = u;
-    gsync();
     lds_sync();
   }
   if (npairs > C::BP) return 1;
-  D2_LAP(3);
-  // ---- runs: every cut k-mer alone, and what lies between two cuts of one vertex interval
-  uint32_t R = 0;
-  unsigned long long e_internal = 0;
+  // ---- the edges from a parent's last k-mer to an entry, sorted, each once (boost::edge(u, v).second)
+  uint32_t nsp = 0;
   {
-    uint32_t gaps_before = 0;
-    for (uint32_t j0 = 0; j0 < nb; j0 += 64u) {
-      const uint32_t j = j0 + (uint32_t)lane;
-      const bool h = j < nb;
-      const uint32_t c = h ? CUT[j] : 0u, cn = (h && j + 1u < nb) ? CUT[j + 1u] : 0u;
-      uint32_t hi_v = 0;
-      const bool inside = h && iv_has(VM, MV, c, &hi_v);
-      const bool gp = inside && j + 1u < nb && cn <= hi_v && cn > c + 1u;
-      const uint64_t m = __ballot(gp);
-      const uint32_t r = j + gaps_before + (uint32_t)__popcll(m & below(lane));
-      uint32_t internal = 0;
-      if (h && r + 3u < C::NV) {
-        RC[j] = r;
-        RLO[2u + r] = c; RHI[2u + r] = c; NW[2u + r] = 1u;
-        if (gp) {
-          const uint32_t L = cn - c - 1u;
-          uint32_t cover = 0u;
-          if (L > 1u) {
-            const bool u = iv_has(UI, MU, c + 1u), d = iv_has(DI, MD, c + 1u);
-            cover = (u ? 0x40000000u : 0u) | (d ? 0x80000000u : 0u);
-            internal = ((u ? 1u : 0u) + (d ? 1u : 0u)) * (L - 1u);
-          }
-          RLO[3u + r] = c + 1u; RHI[3u + r] = cn - 1u; NW[3u + r] = L | cover;
-        }
-      }
-      e_internal += wave_sum(internal);
-      gaps_before += (uint32_t)__popcll(m);
-    }
-    R = nb + gaps_before;
-  }
-  const uint32_t NV = R + 2u;
-  if (NV > C::NV) return 1;
-  if (lane == 0) { RLO[0] = RHI[0] = 0u; NW[0] = 1u; RLO[1] = RHI[1] = 0u; NW[1] = 1u; }  // 0: sink, 1: source
-  gsync();
-  D2_LAP(4);
-  auto node_of = [&](uint32_t x) -> uint32_t { return 2u + RC[cut_index(CUT, nb, x)]; };  // (every end of an edge is a cut)
-  // ---- edges between nodes, one per distinct edge of the reference's graph
-  uint32_t ne = 0, nloops = 0;
-  bool e_full = false;
-  auto emit = [&](bool take, uint32_t from, uint32_t to) {
-    const uint64_t m = __ballot(take);
-    const uint32_t at = ne + (uint32_t)__popcll(m & below(lane));
-    if (take && at < C::E) EDGE[at] = (from << 16) | to;
-    ne += (uint32_t)__popcll(m);
-    if (ne > C::E) e_full = true;
-  };
-  for (uint32_t r0 = 0; r0 + 1u < R; r0 += 64u) {  // the chain's own edges into the next run
-    const uint32_t r = r0 + (uint32_t)lane;
-    const bool h = r + 1u < R;
-    const uint32_t x = h ? RHI[2u + r] : 0u;
-    const bool adj = h && x + 1u == RLO[3u + r];
-    const bool u = adj && iv_has(UI, MU, x), d = adj && iv_has(DI, MD, x);
-    emit(u, 2u + r, 3u + r);
-    emit(d, 3u + r, 2u + r);
-  }
-  {  // the edges from a parent's last k-mer to an entry: sorted, those that double a chain edge go, self loops aside
     uint32_t n = 0;
     for (uint32_t q0 = 0; q0 < nrec; q0 += 64u) {
       const uint32_t q = q0 + (uint32_t)lane;
@@ -530,23 +485,102 @@ __device__ int d2_one(uint32_t* lds, const D2Args& A, uint32_t gap, uint32_t* sc
       n += rl(incl, 63);
     }
     lds_sync();
-    const uint32_t u = sort_unique(K, n, lane);
-    for (uint32_t i0 = 0; i0 < u; i0 += 64u) {
-      const uint32_t i = i0 + (uint32_t)lane;
-      const bool h = i < u;
-      const uint64_t e = h ? K[i] : 0ull;
-      const uint32_t a = (uint32_t)(e >> 32), b = (uint32_t)e;
-      bool keep = h;
-      if (keep && b == a + 1u && iv_has(UI, MU, a)) keep = false;
-      if (keep && a == b + 1u && iv_has(DI, MD, b)) keep = false;
-      const bool loop = keep && a == b;
-      const uint64_t lm = __ballot(loop);
-      if (loop) { const uint32_t at = nloops + (uint32_t)__popcll(lm & below(lane)); if (at < C::NS) LOOPS[at] = node_of(a); }
-      nloops += (uint32_t)__popcll(lm);
-      const bool edge = keep && !loop;
-      emit(edge, edge ? node_of(a) : 0u, edge ? node_of(b) : 0u);
-    }
+    nsp = sort_unique(K, n, lane);
+    for (uint32_t i = (uint32_t)lane; i < nsp; i += 64u) SP[i] = K[i];
     lds_sync();
+  }
+  gsync();
+  D2_LAP(3);
+  // ---- the sort buffer becomes the tables: cuts, vertex intervals, chain intervals of either direction
+  uint32_t* CUTL = lds;
+  uint32_t* VML = lds + C::BP;
+  uint32_t* UL = VML + 2u * C::NS;
+  uint32_t* DL = UL + 2u * MU;
+  for (uint32_t i = (uint32_t)lane; i < nb; i += 64u) CUTL[i] = CUT[i];
+  for (uint32_t i = (uint32_t)lane; i < 2u * MV; i += 64u) VML[i] = VM[i];
+  for (uint32_t i = (uint32_t)lane; i < 2u * MU; i += 64u) UL[i] = UI[i];
+  for (uint32_t i = (uint32_t)lane; i < 2u * MD; i += 64u) DL[i] = DI[i];
+  lds_sync();
+  // ---- runs: every cut k-mer alone, and what lies between two cuts of one vertex interval; the chain's own edges
+  // between neighbouring runs on the way
+  uint32_t R = 0, ne = 0, nloops = 0;
+  bool e_full = false;
+  unsigned long long e_internal = 0;
+  auto emit = [&](bool take, uint32_t from, uint32_t to) {
+    const uint64_t m = __ballot(take);
+    const uint32_t at = ne + (uint32_t)__popcll(m & below(lane));
+    if (take && at < C::E) EDGE[at] = (from << 16) | to;
+    ne += (uint32_t)__popcll(m);
+    if (ne > C::E) e_full = true;
+  };
+  {
+    uint32_t gaps_before = 0;
+    for (uint32_t j0 = 0; j0 < nb; j0 += 64u) {
+      const uint32_t j = j0 + (uint32_t)lane;
+      const bool h = j < nb;
+      const uint32_t c = h ? CUTL[j] : 0u, cn = (h && j + 1u < nb) ? CUTL[j + 1u] : 0u;
+      const bool more = h && j + 1u < nb;
+      uint32_t hi_v = 0;
+      const bool inside = h && iv_has(VML, MV, c, &hi_v);
+      const bool gp = inside && more && cn <= hi_v && cn > c + 1u;
+      const uint64_t m = __ballot(gp);
+      const uint32_t r = j + gaps_before + (uint32_t)__popcll(m & below(lane));
+      if (lane == 0) { GM[j0 >> 6] = m; GP[j0 >> 6] = gaps_before; }
+      uint32_t internal = 0;
+      const bool fits = h && r + 5u < C::NV + 3u;  // (nodes 2 + r .. 4 + r)
+      // chain edges leave the cut k-mer towards the next run (c -> c + 1 upwards, c + 1 -> c downwards) and, where
+      // a run lies between, that run towards the next cut
+      const bool next_to = more && (gp || cn == c + 1u);
+      const bool u0 = next_to && iv_has(UL, MU, c), d0 = next_to && iv_has(DL, MD, c);
+      const bool u1 = gp && iv_has(UL, MU, cn - 1u), d1 = gp && iv_has(DL, MD, cn - 1u);
+      if (fits) {
+        RLO[2u + r] = c; RHI[2u + r] = c; NW[2u + r] = 1u;
+        if (gp) {
+          const uint32_t L = cn - c - 1u;
+          uint32_t cover = 0u;
+          if (L > 1u) {
+            const bool u = iv_has(UL, MU, c + 1u), d = iv_has(DL, MD, c + 1u);
+            cover = (u ? 0x40000000u : 0u) | (d ? 0x80000000u : 0u);
+            internal = ((u ? 1u : 0u) + (d ? 1u : 0u)) * (L - 1u);
+          }
+          RLO[3u + r] = c + 1u; RHI[3u + r] = cn - 1u; NW[3u + r] = L | cover;
+        }
+      }
+      e_internal += wave_sum(internal);
+      emit(fits && u0, 2u + r, 3u + r);
+      emit(fits && d0, 3u + r, 2u + r);
+      emit(fits && u1, 3u + r, 4u + r);
+      emit(fits && d1, 4u + r, 3u + r);
+      gaps_before += (uint32_t)__popcll(m);
+    }
+    R = nb + gaps_before;
+  }
+  const uint32_t NV = R + 2u;
+  if (NV > C::NV) return 1;
+  if (lane == 0) { RLO[0] = RHI[0] = 0u; NW[0] = 1u; RLO[1] = RHI[1] = 0u; NW[1] = 1u; }  // 0: sink, 1: source
+  lds_sync();
+  D2_LAP(4);
+  // the node of k-mer x (every end of an edge is a cut: a run of its own)
+  auto node_of = [&](uint32_t x) -> uint32_t {
+    const uint32_t j = cut_index(CUTL, nb, x);
+    return 2u + j + GP[j >> 6] + (uint32_t)__popcll(GM[j >> 6] & ((1ull << (j & 63u)) - 1ull));
+  };
+  // ---- the other edges, one per distinct edge of the reference's graph: those that double a chain edge go, self
+  // loops (a homopolymer k-mer: never between components) are set aside
+  for (uint32_t i0 = 0; i0 < nsp; i0 += 64u) {
+    const uint32_t i = i0 + (uint32_t)lane;
+    const bool h = i < nsp;
+    const uint64_t e = h ? SP[i] : 0ull;
+    const uint32_t a = (uint32_t)(e >> 32), b = (uint32_t)e;
+    bool keep = h;
+    if (keep && b == a + 1u && iv_has(UL, MU, a)) keep = false;
+    if (keep && a == b + 1u && iv_has(DL, MD, b)) keep = false;
+    const bool loop = keep && a == b;
+    const uint64_t lm = __ballot(loop);
+    if (loop) { const uint32_t at = nloops + (uint32_t)__popcll(lm & below(lane)); if (at < C::NS) LOOPS[at] = node_of(a); }
+    nloops += (uint32_t)__popcll(lm);
+    const bool edge = keep && !loop;
+    emit(edge, edge ? node_of(a) : 0u, edge ? node_of(b) : 0u);
   }
   if (nloops > C::NS) return 1;
   for (uint32_t i0 = 0; i0 < nsrc; i0 += 64u) { const uint32_t i = i0 + (uint32_t)lane; const bool h = i < nsrc; emit(h, 1u, h ? node_of(SRCS[i]) : 0u); }      // :1303-1305
@@ -554,9 +588,10 @@ __device__ int d2_one(uint32_t* lds, const D2Args& A, uint32_t gap, uint32_t* sc
   if (e_full || ne > C::E) return 1;
   const unsigned long long e_all = e_internal + ne + nloops;
   gsync();
+  lds_sync();
   D2_LAP(5);
 
-  // ---- the graph into LDS: offsets and adjacency both ways, live degrees
+  // ---- the graph into LDS (over the tables): offsets and adjacency both ways, live degrees
   uint16_t* off_f = (uint16_t*)lds;
   uint16_t* off_r = (uint16_t*)((char*)off_f + C::OFF_BYTES);
   uint16_t* adj_f = (uint16_t*)((char*)off_r + C::OFF_BYTES);
@@ -567,6 +602,7 @@ __device__ int d2_one(uint32_t* lds, const D2Args& A, uint32_t gap, uint32_t* sc
   uint16_t* wl0 = (uint16_t*)(comp + C::NV);
   uint16_t* wl1 = wl0 + C::NV;
   for (uint32_t i = (uint32_t)lane; i < C::NV / 2u; i += 64u) { degi[i] = 0u; dego[i] = 0u; ((uint32_t*)wl0)[i] = 0u; ((uint32_t*)wl1)[i] = 0u; }
+  for (uint32_t i = (uint32_t)lane; i < C::NV / 32u; i += 64u) PM[i] = 0u;
   for (uint32_t v = (uint32_t)lane; v < NV; v += 64u) comp[v] = D2_ALIVE;
   lds_sync();
   for (uint32_t i = (uint32_t)lane; i < ne; i += 64u) {
@@ -599,41 +635,81 @@ __device__ int d2_one(uint32_t* lds, const D2Args& A, uint32_t gap, uint32_t* sc
     }
   }
   lds_sync();
-
   D2_LAP(6);
-  // ---- strong components
-  // remove(u): u leaves the live graph — its neighbours lose an edge, and those left without a live edge in, or
-  // without one out, are queued (once: the state word decides)
+
+  // ---- pass-through nodes leave the graph: a run with one edge in and one out (and not covered in both directions)
+  // only hands on what reaches it.  Every other node's edges skip them — the adjacency entry becomes the node at the
+  // chain's end — and a pass-through node remembers which edge of which node its chain is.  What is left has as many
+  // levels as the paths have BRANCHINGS, not runs (a tenth to a third).
+  for (uint32_t v0 = 0; v0 < NV; v0 += 64u) {
+    const uint32_t v = v0 + (uint32_t)lane;
+    const bool pass = !(A.pass_all & 2u) && v >= 2u && v < NV && pk_get(degi, v) == 1u && pk_get(dego, v) == 1u && (NW[v] & 0xC0000000u) != 0xC0000000u;
+    if (pass) comp[v] = D2_PASS;
+    const uint64_t m = __ballot(pass);
+    if (lane == 0) { PM[v0 >> 5] = (uint32_t)m; if ((v0 >> 5) + 1u < C::NV / 32u) PM[(v0 >> 5) + 1u] = (uint32_t)(m >> 32); }
+  }
+  lds_sync();
+  for (uint32_t u = (uint32_t)lane; u < NV; u += 64u) {
+    if (comp[u] != D2_ALIVE) continue;
+    uint32_t k = 0;
+    for (uint32_t e = off_f[u]; e < (uint32_t)off_f[u + 1u]; e++, k++) {
+      uint32_t w = adj_f[e];
+      for (uint32_t steps = 0; d2_is_pass(comp[w]) && steps <= NV; steps++) {
+        comp[w] = 0x80000000u | (min(k, 15u) << 16) | u;
+        w = adj_f[off_f[w]];
+      }
+      adj_f[e] = (uint16_t)w;
+    }
+    for (uint32_t e = off_r[u]; e < (uint32_t)off_r[u + 1u]; e++) {
+      uint32_t p = adj_r[e];
+      for (uint32_t steps = 0; d2_is_pass(comp[p]) && steps <= NV; steps++) p = adj_r[off_r[p]];
+      adj_r[e] = (uint16_t)p;
+    }
+  }
+  lds_sync();
+
+  // ---- strong components of what is left.  A node without a live edge in, or without one out, is a component of
+  // its own: taken (its state becomes its own id) by whoever sees its last such edge go, and its edges dropped by the
+  // same lane at once — a lane follows a chain of such nodes without a round trip through the work list, which only
+  // takes the second and further nodes a step frees.
   uint32_t* n_next = hdr;
   uint16_t* cur = wl0;
   uint16_t* nxt = wl1;
-  auto push = [&](uint32_t v) {
-    if (atomicCAS(&comp[v], D2_ALIVE, D2_QUEUED) == D2_ALIVE) nxt[atomicAdd(n_next, 1u)] = (uint16_t)v;
-  };
-  auto drop_edges = [&](uint32_t u) {
-    for (uint32_t e = off_f[u]; e < (uint32_t)off_f[u + 1u]; e++) { const uint32_t w = adj_f[e]; if (pk_sub(degi, w, 1u) == 1u) push(w); }
-    for (uint32_t e = off_r[u]; e < (uint32_t)off_r[u + 1u]; e++) { const uint32_t p = adj_r[e]; if (pk_sub(dego, p, 1u) == 1u) push(p); }
+  auto take = [&](uint32_t v) -> bool { return atomicCAS(&comp[v], D2_ALIVE, v) == D2_ALIVE; };
+  auto spill = [&](uint32_t v) { nxt[atomicAdd(n_next, 1u)] = (uint16_t)v; };
+  // drops the edges of u (which has left the live graph) and of every node that frees along the way
+  auto peel_from = [&](uint32_t u, bool first_only_drop) {
+    for (uint32_t steps = 0; steps <= NV; steps++) {
+      uint32_t next = D2_NONE;
+      for (uint32_t e = off_f[u]; e < (uint32_t)off_f[u + 1u]; e++) {
+        const uint32_t w = adj_f[e];
+        if (pk_sub(degi, w, 1u) == 1u && take(w)) { if (next == D2_NONE) next = w; else spill(w); }
+      }
+      for (uint32_t e = off_r[u]; e < (uint32_t)off_r[u + 1u]; e++) {
+        const uint32_t p = adj_r[e];
+        if (pk_sub(dego, p, 1u) == 1u && take(p)) { if (next == D2_NONE) next = p; else spill(p); }
+      }
+      if (next == D2_NONE) break;
+      u = next;
+    }
+    (void)first_only_drop;
   };
   if (lane == 0) *n_next = 0u;
   lds_sync();
   for (uint32_t v = (uint32_t)lane; v < NV; v += 64u)
-    if (pk_get(degi, v) == 0u || pk_get(dego, v) == 0u) push(v);
-  lds_sync();
+    if (comp[v] == D2_ALIVE && (pk_get(degi, v) == 0u || pk_get(dego, v) == 0u) && take(v)) peel_from(v, false);
   uint32_t ncur = 0;
   uint32_t guard = 0;  // (every loop below ends after at most NV rounds by construction; a defect must not hold the GPU)
   const uint32_t guard_max = 8u * NV + 64u;
   for (;;) {
-    // peel: nodes without a live edge in or out are components of their own
-    for (;;) {
+    for (;;) {  // what the lanes above could not follow themselves
       lds_sync();
       ncur = uni(*n_next);
       if (ncur == 0u || ++guard > guard_max) break;
       { uint16_t* t = cur; cur = nxt; nxt = t; }
       if (lane == 0) *n_next = 0u;
       lds_sync();
-      for (uint32_t i = (uint32_t)lane; i < ncur; i += 64u) comp[cur[i]] = cur[i];
-      lds_sync();
-      for (uint32_t i = (uint32_t)lane; i < ncur; i += 64u) drop_edges(cur[i]);
+      for (uint32_t i = (uint32_t)lane; i < ncur; i += 64u) peel_from(cur[i], false);
     }
     // what is left lies on cycles or between them: the component of the lowest live node
     uint32_t pivot = 0xFFFFFFFFu;
@@ -690,11 +766,27 @@ __device__ int d2_one(uint32_t* lds, const D2Args& A, uint32_t gap, uint32_t* sc
       nmem += (uint32_t)__popcll(m);
     }
     lds_sync();
-    for (uint32_t i = (uint32_t)lane; i < nmem; i += 64u) drop_edges(cur[i]);
+    for (uint32_t i = (uint32_t)lane; i < nmem; i += 64u) peel_from(cur[i], false);
     lds_sync();
   }
   lds_sync();
   if (guard > guard_max) return 2;
+  // a pass-through node belongs to the component both ends of its chain are in (the chain then lies on a cycle), and is
+  // a component of its own otherwise — HEAD: the component its chain leaves
+  for (uint32_t v = (uint32_t)lane; v < NV; v += 64u) {
+    const uint32_t st = comp[v];
+    if (!d2_is_pass(st)) continue;
+    uint32_t c = v, head = v;
+    if (st != D2_PASS) {  // (D2_PASS: a chain no node leads into — cannot be: every node is reached from the source)
+      const uint32_t u = st & 0xFFFFu, k = (st >> 16) & 15u;
+      const uint32_t w = adj_f[(uint32_t)off_f[u] + k];
+      head = comp[u];  // (u is not a pass-through node: its state is final)
+      if (head == comp[w]) c = head;
+    }
+    HEAD[v] = head;
+    comp[v] = c;
+  }
+  lds_sync();
   D2_LAP(7);
 
   // ---- the components: size, which are non-trivial (several nodes, or a run covered in both directions), the
@@ -710,7 +802,8 @@ __device__ int d2_one(uint32_t* lds, const D2Args& A, uint32_t gap, uint32_t* sc
   lds_sync();
   for (uint32_t v = (uint32_t)lane; v < NV; v += 64u) atomicAdd(&csize[comp[v]], 1u);
   lds_sync();
-  auto nontriv = [&](uint32_t c) -> bool { return (csize[c] & 0x7FFFFFFFu) > 1u || (NW[c] & 0xC0000000u) == 0xC0000000u; };
+  auto is_pass_node = [&](uint32_t v) -> bool { return (PM[v >> 5] >> (v & 31u)) & 1u; };
+  auto nontriv = [&](uint32_t c) -> bool { return (csize[c] & 0x3FFFFFFFu) > 1u || (NW[c] & 0xC0000000u) == 0xC0000000u; };
   unsigned long long fe = 0;
   for (uint32_t i0 = 0; i0 < ne; i0 += 64u) {
     const uint32_t i = i0 + (uint32_t)lane;
@@ -718,8 +811,14 @@ __device__ int d2_one(uint32_t* lds, const D2Args& A, uint32_t gap, uint32_t* sc
     const uint32_t e = h ? EDGE[i] : 0u;
     const uint32_t a = h ? comp[e >> 16] : 0u, b = h ? comp[e & 0xFFFFu] : 0u;
     const bool cross = h && a != b;
-    if (cross) { pk_add(cdeg_out, a, 1u); pk_add(cdeg_in, b, 1u); pk_add(cwork, b, 1u); }
+    if (cross) { pk_add(cdeg_out, a, 1u); pk_add(cdeg_in, b, 1u); }
     fe += (unsigned long long)__popcll(__ballot(cross));
+  }
+  // (what Kahn counts down: the edges into a component from other components with the chains skipped)
+  for (uint32_t u = (uint32_t)lane; u < NV; u += 64u) {
+    if (is_pass_node(u)) continue;
+    const uint32_t a = comp[u];
+    for (uint32_t e = off_f[u]; e < (uint32_t)off_f[u + 1u]; e++) { const uint32_t b = comp[adj_f[e]]; if (b != a) pk_add(cwork, b, 1u); }
   }
   uint32_t nontrivial = 0;
   unsigned long long size_nontrivial = 0;
@@ -740,76 +839,113 @@ __device__ int d2_one(uint32_t* lds, const D2Args& A, uint32_t gap, uint32_t* sc
     loops_trivial += (uint32_t)__popcll(__ballot(i < nloops && !nontriv(comp[LOOPS[i]])));  // :1385-1402
   }
   lds_sync();
-
   D2_LAP(8);
-  // ---- the components in topological order (Kahn, round by round), into ORDER
-  uint32_t n_order = 0;
-  cur = wl0; nxt = wl1;
-  if (lane == 0) *n_next = 0u;
+
+  // ---- the components (chains skipped) in a topological order: a component whose last edge in has been accounted
+  // for takes the next place — the lane that accounted for it goes on with it at once; components of several nodes
+  // wait for a pass of all lanes over their nodes
+  uint32_t* n_order = hdr + 1;
+  uint32_t* n_bigs = hdr + 2;
+  uint16_t* bigs = (uint16_t*)(hdr + 4);  // (a handful: 24 entries)
+  if (lane == 0) { *n_next = 0u; *n_order = 0u; *n_bigs = 0u; }
   lds_sync();
+  auto ready = [&](uint32_t b, uint32_t* next) {  // component b has no edge in left
+    if ((csize[b] & 0x3FFFFFFFu) > 1u && !is_pass_node(b)) { const uint32_t at = atomicAdd(n_bigs, 1u); if (at < 24u) bigs[at] = (uint16_t)b; else spill(b); }
+    else if (*next == D2_NONE) *next = b;
+    else spill(b);
+  };
+  auto order_from = [&](uint32_t c) {  // c: a component of one node whose turn it is
+    for (uint32_t steps = 0; steps <= NV; steps++) {
+      ORDER[atomicAdd(n_order, 1u)] = c;
+      uint32_t next = D2_NONE;
+      for (uint32_t e = off_f[c]; e < (uint32_t)off_f[c + 1u]; e++) {
+        const uint32_t b = comp[adj_f[e]];
+        if (b != c && pk_sub(cwork, b, 1u) == 1u) ready(b, &next);
+      }
+      if (next == D2_NONE) break;
+      c = next;
+    }
+  };
+  // (the components without an edge in — the source's — go through the list: looked for before anything is counted down)
   for (uint32_t v = (uint32_t)lane; v < NV; v += 64u)
-    if (comp[v] == v && pk_get(cwork, v) == 0u) nxt[atomicAdd(n_next, 1u)] = (uint16_t)v;
-  for (;;) {
+    if (comp[v] == v && !is_pass_node(v) && pk_get(cwork, v) == 0u) spill(v);
+  for (guard = 0; guard <= guard_max; guard++) {
     lds_sync();
+    const uint32_t nbig = min(uni(*n_bigs), 24u);
     ncur = uni(*n_next);
-    if (ncur == 0u || n_order + ncur > NV) break;
+    if (nbig == 0u && ncur == 0u) break;
     { uint16_t* t = cur; cur = nxt; nxt = t; }
-    if (lane == 0) *n_next = 0u;
+    uint32_t big_c[24];
+    for (uint32_t x = 0; x < nbig; x++) big_c[x] = uni((uint32_t)bigs[x]);
     lds_sync();
-    for (uint32_t i0 = 0; i0 < ncur; i0 += 64u) {
-      const uint32_t i = i0 + (uint32_t)lane;
-      const bool h = i < ncur;
-      const uint32_t c = h ? cur[i] : 0u;
-      if (h) ORDER[n_order + i] = c;
-      const bool big = h && (csize[c] & 0x7FFFFFFFu) > 1u;
-      if (h && !big)
-        for (uint32_t e = off_f[c]; e < (uint32_t)off_f[c + 1u]; e++) {
+    if (lane == 0) { *n_next = 0u; *n_bigs = 0u; }
+    lds_sync();
+    for (uint32_t x = 0; x < nbig; x++) {  // a component of several nodes: all lanes over the nodes
+      const uint32_t cc = big_c[x];
+      if (lane == 0) ORDER[atomicAdd(n_order, 1u)] = cc;
+      for (uint32_t v = (uint32_t)lane; v < NV; v += 64u) {
+        if (comp[v] != cc || is_pass_node(v)) continue;
+        uint32_t next = D2_NONE;
+        for (uint32_t e = off_f[v]; e < (uint32_t)off_f[v + 1u]; e++) {
           const uint32_t b = comp[adj_f[e]];
-          if (b != c && pk_sub(cwork, b, 1u) == 1u) nxt[atomicAdd(n_next, 1u)] = (uint16_t)b;
+          if (b != cc && pk_sub(cwork, b, 1u) == 1u) ready(b, &next);
         }
-      for (uint64_t bm = __ballot(big); bm; bm &= bm - 1) {  // a component of several nodes: all of them (there are few)
-        const uint32_t cc = rl(c, __builtin_ctzll(bm));
-        for (uint32_t v = (uint32_t)lane; v < NV; v += 64u) {
-          if (comp[v] != cc) continue;
-          for (uint32_t e = off_f[v]; e < (uint32_t)off_f[v + 1u]; e++) {
-            const uint32_t b = comp[adj_f[e]];
-            if (b != cc && pk_sub(cwork, b, 1u) == 1u) nxt[atomicAdd(n_next, 1u)] = (uint16_t)b;
-          }
-        }
+        if (next != D2_NONE) order_from(next);
       }
     }
-    n_order += ncur;
+    for (uint32_t i = (uint32_t)lane; i < ncur; i += 64u) {
+      const uint32_t c = cur[i];
+      if ((csize[c] & 0x3FFFFFFFu) > 1u && !is_pass_node(c)) { const uint32_t at = atomicAdd(n_bigs, 1u); if (at < 24u) bigs[at] = (uint16_t)c; else spill(c); }
+      else order_from(c);
+    }
+  }
+  lds_sync();
+  const uint32_t n_ord = uni(*n_order);
+  {  // (every component outside the chains has its place: anything else is a defect — the gap is left to the host)
+    uint32_t n_branch = 0;
+    for (uint32_t v0 = 0; v0 < NV; v0 += 64u) {
+      const uint32_t v = v0 + (uint32_t)lane;
+      n_branch += (uint32_t)__popcll(__ballot(v < NV && comp[v] == v && !is_pass_node(v)));
+    }
+    if (n_branch != n_ord) { if (A.prof && lane == 0) atomicAdd(A.prof + 10, 1000000ull); return 2; }
   }
   gsync();
   D2_LAP(9);
-  // ---- the branch rule over that order (:1411-1434): -(in - 1) in front of a vertex, +(out - 1) behind it
+  // ---- the branch rule over that order (:1411-1434): -(in - 1) in front of a vertex, +(out - 1) behind it.  Bit 31
+  // of a component's word: the count is 1 at it; bit 30: the count is 1 behind it (what the nodes of a chain that
+  // leaves it see: one edge in, one out each, the count does not move along them)
   {
     int bc = 1;
-    for (uint32_t p0 = 0; p0 < n_order; p0 += 64u) {
+    for (uint32_t p0 = 0; p0 < n_ord; p0 += 64u) {
       const uint32_t p = p0 + (uint32_t)lane;
-      const bool h = p < n_order;
+      const bool h = p < n_ord;
       const uint32_t c = h ? ORDER[p] : 0u;
       const int din = h ? (int)pk_get(cdeg_in, c) : 0, dout = h ? (int)pk_get(cdeg_out, c) : 0;
       const bool act = din >= 1 || dout >= 1;
       const int pre = (act && din > 1) ? -(din - 1) : 0, post = (act && dout > 1) ? dout - 1 : 0;
       const int incl = (int)wave_scan((uint32_t)(pre + post), lane);
       const int at = bc + incl - (pre + post) + pre;
-      if (h && act && at == 1 && !nontriv(c)) csize[c] |= 0x80000000u;  // the verdict: branch[c] == 1
+      if (h) csize[c] |= ((act && at == 1) ? 0x80000000u : 0u) | ((at + post == 1) ? 0x40000000u : 0u);
       bc += (int)rl((uint32_t)incl, 63);
     }
   }
   lds_sync();
-  const bool sink_safe = (csize[comp[0]] & 0x80000000u) != 0u;
+  auto verdict = [&](uint32_t v) -> uint32_t {  // branch[v] == 1, v outside the non-trivial components
+    const uint32_t c = comp[v];
+    if (nontriv(c)) return 0u;
+    if (is_pass_node(v)) return (csize[HEAD[v]] >> 30) & 1u;
+    return csize[c] >> 31;
+  };
+  const bool sink_safe = verdict(0u) != 0u;
   // ---- what leaves: the runs with their verdicts, the statistics
   unsigned long long base = 0;
   if (lane == 0) base = atomicAdd(A.run_cursor, (unsigned long long)R);
   base = ((unsigned long long)uni((uint32_t)(base >> 32)) << 32) | uni((uint32_t)base);
-  if (base + R > A.run_cap || n_order == 0u) return 2;
+  if (base + R > A.run_cap || n_ord == 0u) return 2;
   uint32_t* runs = A.runs + 2ull * base;
   for (uint32_t r = (uint32_t)lane; r < R; r += 64u) {
-    const uint32_t safe = csize[comp[2u + r]] >> 31;
     runs[2u * r] = RLO[2u + r];
-    runs[2u * r + 1u] = RHI[2u + r] | (safe << 31);
+    runs[2u * r + 1u] = RHI[2u + r] | (verdict(2u + r) << 31);
   }
   if (lane == 0) {
     D2Out o;
@@ -839,7 +975,8 @@ __device__ __forceinline__ void d2_loop(uint32_t* lds, const D2Args& A) {
     x = ((unsigned long long)uni((uint32_t)(x >> 32)) << 32) | uni((uint32_t)x);
     if (x >= n || x >= (unsigned long long)A.list_cap) break;
     const uint32_t gap = uni(A.list[x]);
-    const int rc = (A.pass_all && A.list_next) ? 1 : d2_one<C>(lds, A, gap, scr);
+    const int rc = ((A.pass_all & 1u) && A.list_next) ? 1 : d2_one<C>(lds, A, gap, scr);
+    if (A.prof && rc != 0 && threadIdx.x == 0) atomicAdd(A.prof + 13 + rc, 1ull);  // (14: beyond the capacities, 15: given up)
     if (rc == 1 && A.list_next && threadIdx.x == 0) {  // beyond these capacities: the larger instantiation's
       const unsigned long long at = atomicAdd(A.count_next, 1ull);
       if (at < (unsigned long long)A.list_cap) A.list_next[at] = gap;

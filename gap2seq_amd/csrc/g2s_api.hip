@@ -752,7 +752,7 @@ extern "C" void g2s_session_destroy(g2s_session* s) {
       fprintf(stderr, "[g2s] g2s_d2_*: %llu closures on runs, %.0f nodes and %.0f rounds each; cycles (100 MHz clock) per closure:", pr[11],
               pr[11] ? (double)pr[12] / (double)pr[11] : 0.0, pr[11] ? (double)pr[13] / (double)pr[11] : 0.0);
       for (int q = 0; q < 11; q++) fprintf(stderr, " %s %.0f", names[q], pr[11] ? (double)pr[q] / (double)pr[11] : (double)pr[q]);
-      fprintf(stderr, "\n");
+      fprintf(stderr, " | beyond the capacities %llu, given up %llu\n", pr[14], pr[15]);
     }
   }
   // lists begun and never ended: their kernels first — on all three streams of every session that carries one (the
@@ -2876,6 +2876,7 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl) {
       DA.prof = ctr + 16;
     }
     DA.pass_all = (d2_big && getenv("G2S_D2_BIG") && atoi(getenv("G2S_D2_BIG")) == 2) ? 1u : 0u;  // (tests: every closure through the large instantiation)
+    if (getenv("G2S_D2_NO_CHAINS")) DA.pass_all |= 2u;  // (tests: no node counts as pass-through — the whole graph of runs goes through the component search)
     HIP_TRY_S(launch_d2(st, DA, d2_small_wgs, d2_big ? d2_big_wgs : 0u, (uint32_t*)s->d_d2scr_small.p, (uint32_t*)s->d_d2scr_big.p,
                         (uint32_t*)s->d_d2list.p + n, ctr + 6, ctr + 7));
   }
