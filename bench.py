@@ -309,6 +309,12 @@ def main():
     if ndev < 1:
         raise SystemExit("bench.py: no gfx950 device; the fill path has no CPU fallback")
     if ndev < ngpu and not args.share_device:
+        # ONE line that names what usually hides the devices from this rank (a launcher that pins a device per rank)
+        vis = {v: os.environ.get(v) for v in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES") if os.environ.get(v) is not None}
+        sys.stderr.write("bench.py: rank %d sees %d gfx950 device(s) but --gpus %d needs %d in THIS process (one process drives all GPUs; the "
+                         "other ranks only join the barriers): %s\n"
+                         % (rank, ndev, ngpu, ngpu, ("unset " + ", ".join("%s=%s" % kv for kv in vis.items()) + " for rank 0") if vis else
+                            "HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES are not set here - the node has fewer devices, or the container hides them"))
         raise SystemExit("bench.py: --gpus %d but only %d gfx950 device(s) are usable" % (ngpu, ndev))
     devices = [0] * ngpu if args.share_device else list(range(ngpu))
 
@@ -328,6 +334,10 @@ def main():
     warmup = args.warmup if args.warmup >= 0 else (10 if steps >= 100 else 3 if steps >= 10 else 1)
     # Resident mode brackets one fill-kernel launch in eight with HIP events (the events cost the stream ~10 us per
     # list): enough for an average over 100 steps and more; a shorter run brackets more of its launches.
+    if ngpu > 1 and "G2S_KERNEL_TIMING" not in os.environ:
+        # (a team's per-session times — resident.team_ms_by_session — are the LAST step's: every launch bracketed, so that
+        # the line of a multi-GPU run explains itself; ~10 us per list and session)
+        os.environ["G2S_KERNEL_TIMING"] = "all"
     if steps < 100 and "G2S_KERNEL_TIMING" not in os.environ:
         # (at least three bracketed launches inside the timed steps, however few those are)
         os.environ["G2S_KERNEL_TIMING"] = "sample:%d" % max(1, min(8, steps // 3))

@@ -40,7 +40,7 @@ struct D2Caps {
   static constexpr uint32_t G_BYTES = 2u * OFF_BYTES + 2u * E * 2u + 2u * NV * 2u + NV * 4u + 2u * NV * 2u;
   static constexpr uint32_t MAIN_BYTES = K_BYTES > G_BYTES ? K_BYTES : G_BYTES;
   // ... and behind either: per 64 cuts a mask and a count of the runs between cuts, a bit per node (pass-through), counters
-  static constexpr uint32_t AUX_BYTES = (BP / 64u) * 12u + (NV / 32u) * 4u + 64u;
+  static constexpr uint32_t AUX_BYTES = (BP / 64u) * 12u + 2u * (NV / 32u) * 4u + 64u;
   static constexpr uint32_t LDS_BYTES = MAIN_BYTES + AUX_BYTES;
   // global scratch of a workgroup, words
   static constexpr uint32_t SCR_WORDS = 9u * NS + 3u * BP + 5u * NV + E + 64u;
@@ -129,7 +129,7 @@ __device__ __forceinline__ uint32_t merge_sorted(const uint64_t* K, uint32_t n, 
     const uint32_t i = i0 + (uint32_t)lane;
     const bool h = i < n;
     const uint64_t key = h ? K[i] : 0ull;
-    const uint32_t lo = (uint32_t)(key >> 32);
+    const uint32_t lo = (uint32_t)(key >> 32) & 0x7FFFFFFFu;  // (bit 63: a direction some callers sort by)
     const uint32_t hi = PACKED ? lo + (((uint32_t)key >> 16) & 0x7FFFu) : (uint32_t)key;
     const uint32_t sa = wave_scan_max(h ? hi + 1u : 0u);
     uint32_t xa = wave_shr1(sa);
@@ -382,41 +382,42 @@ __device__ int d2_one(uint32_t* lds, const D2Args& A, uint32_t gap, uint32_t* sc
 
   // ================= a k-mer at several depths: the graph of runs (post.cpp: seg_analyze_runs) ======================
   // (all the sorting first; the sort buffer then holds the tables the rest looks things up in)
-  // ---- chain edges of the upward and of the downward segments as merged intervals (adjacent ones merge)
+  // ---- chain edges of the upward and of the downward segments as merged intervals (adjacent ones merge): one pass
+  // over the segments, one sort (the direction is the key's top bit)
   uint32_t MU = 0, MD = 0;
-  for (int dir = 0; dir < 2; dir++) {
-    uint32_t n = 0;
+  {
+    uint32_t n = 0, n_up = 0;
     for (uint32_t q0 = 0; q0 < nrec; q0 += 64u) {
       const uint32_t q = q0 + (uint32_t)lane;
       const bool h = q < nrec;
       SegD s;
       if (h) s = seg_load(segs, q);
       const int ts = h ? s.ts() : -1;
-      const bool take = ts > 0 && (s.up() ? dir == 0 : dir == 1);
+      const bool take = ts > 0;
       const uint64_t m = __ballot(take);
       if (take) {
         const uint32_t lo = s.up() ? (s.node >> 1) : (s.node >> 1) - (uint32_t)ts;
-        K[n + (uint32_t)__popcll(m & below(lane))] = ((uint64_t)lo << 32) | (lo + (uint32_t)ts - 1u);
+        K[n + (uint32_t)__popcll(m & below(lane))] = (s.up() ? 0ull : 1ull << 63) | ((uint64_t)lo << 32) | (lo + (uint32_t)ts - 1u);
       }
       n += (uint32_t)__popcll(m);
+      n_up += (uint32_t)__popcll(__ballot(take && s.up()));
     }
     lds_sync();
-    uint32_t M = 0;
     if (n > 0u) {
       const uint32_t n2 = pow2_at_least(n);
       for (uint32_t i = n + (uint32_t)lane; i < n2; i += 64u) K[i] = ~0ull;
       lds_sync();
       lds_sort64(K, n2, lane);
       bool ov;
-      M = merge_sorted<false>(K, n, true, dir == 0 ? UI : DI, lane, &ov);
+      if (n_up > 0u) MU = merge_sorted<false>(K, n_up, true, UI, lane, &ov);
+      if (n > n_up) MD = merge_sorted<false>(K + n_up, n - n_up, true, DI, lane, &ov);
     }
-    if (dir == 0) MU = M; else MD = M;
     lds_sync();
   }
   D2_LAP(2);
-  // ---- the cuts: ends of every interval, a parent's last k-mer, sink positions; the sources; the sinks
-  uint32_t nb = 0, nsrc = 0, nsink = 0, npairs = 0;
-  for (int pass = 0; pass < 3; pass++) {  // 0: cuts, 1: sources, 2: sinks (each through the sort buffer)
+  // ---- the cuts: ends of every interval, a parent's last k-mer, sink positions
+  uint32_t nb = 0, npairs = 0;
+  {
     uint32_t n = 0;
     bool full = false;
     for (uint32_t q0 = 0; q0 < nrec && !full; q0 += 64u) {
@@ -427,36 +428,31 @@ __device__ int d2_one(uint32_t* lds, const D2Args& A, uint32_t gap, uint32_t* sc
       const int ts = h ? s.ts() : -1;
       const bool in_s = ts >= 0;
       const int sp = in_s ? sink_pos(s) : -1;
-      uint32_t vals[7];
-      uint32_t k = 0;
-      if (in_s && pass == 0) {
-        vals[k++] = s.idx(0);
-        vals[k++] = s.idx(ts);
-        if (!s.source())
+      const uint32_t np = (in_s && !s.source()) ? (uint32_t)s.npar() : 0u;
+      const uint32_t k = in_s ? 2u + np + (sp >= 0 ? 1u : 0u) : 0u;
+      npairs += wave_sum(np);
+      const uint32_t incl = wave_scan(k, lane);
+      const uint32_t tot = rl(incl, 63);
+      if (n + tot > C::BP) { full = true; break; }
+      uint32_t w = n + incl - k;
+      if (in_s) {
+        K[w++] = (uint64_t)s.idx(0);
+        K[w++] = (uint64_t)s.idx(ts);
+        if (np)
           for (int x = 0; x < 4; x++) {
             const uint32_t p = s.par(x);
             if (p == 0xFFFFu || p >= nrec) continue;
             const SegD ps = seg_load(segs, p);
-            vals[k++] = ps.idx(ps.len() - 1);
+            K[w++] = (uint64_t)ps.idx(ps.len() - 1);
           }
-        if (sp >= 0) vals[k++] = s.idx(sp);
-      } else if (in_s && pass == 1) { if (s.source()) vals[k++] = s.idx(0); }
-      else if (in_s && pass == 2) { if (sp >= 0) vals[k++] = s.idx(sp); }
-      if (pass == 0) npairs += wave_sum((in_s && !s.source()) ? (uint32_t)s.npar() : 0u);
-      const uint32_t incl = wave_scan(k, lane);
-      const uint32_t tot = rl(incl, 63);
-      if (n + tot > C::BP) { full = true; break; }
-      const uint32_t at = n + incl - k;
-      for (uint32_t x = 0; x < k; x++) K[at + x] = (uint64_t)vals[x];
+        if (sp >= 0) K[w++] = (uint64_t)s.idx(sp);
+      }
       n += tot;
     }
     if (full) return 1;
     lds_sync();
-    const uint32_t u = sort_unique(K, n, lane);
-    uint32_t* dst = pass == 0 ? CUT : pass == 1 ? SRCS : SINKS;
-    if (pass != 0 && u > C::NS) return 1;
-    for (uint32_t i = (uint32_t)lane; i < u; i += 64u) dst[i] = (uint32_t)K[i];
-    if (pass == 0) nb = u; else if (pass == 1) nsrc = u; else nsink = u;
+    nb = sort_unique(K, n, lane);
+    for (uint32_t i = (uint32_t)lane; i < nb; i += 64u) CUT[i] = (uint32_t)K[i];
     lds_sync();
   }
   if (npairs > C::BP) return 1;
@@ -470,18 +466,16 @@ __device__ int d2_one(uint32_t* lds, const D2Args& A, uint32_t gap, uint32_t* sc
       SegD s;
       if (h) s = seg_load(segs, q);
       const bool in_s = h && s.ts() >= 0 && !s.source();
-      uint64_t vals[4];
-      uint32_t k = 0;
-      if (in_s)
+      const uint32_t k = in_s ? (uint32_t)s.npar() : 0u;
+      const uint32_t incl = wave_scan(k, lane);
+      uint32_t w = n + incl - k;  // (n + total <= npairs <= BP: counted above)
+      if (k)
         for (int x = 0; x < 4; x++) {
           const uint32_t p = s.par(x);
           if (p == 0xFFFFu || p >= nrec) continue;
           const SegD ps = seg_load(segs, p);
-          vals[k++] = ((uint64_t)ps.idx(ps.len() - 1) << 32) | s.idx(0);
+          K[w++] = ((uint64_t)ps.idx(ps.len() - 1) << 32) | s.idx(0);
         }
-      const uint32_t incl = wave_scan(k, lane);
-      const uint32_t at = n + incl - k;
-      for (uint32_t x = 0; x < k; x++) K[at + x] = vals[x];  // (n + total <= npairs <= BP: counted above)
       n += rl(incl, 63);
     }
     lds_sync();
@@ -583,8 +577,31 @@ __device__ int d2_one(uint32_t* lds, const D2Args& A, uint32_t gap, uint32_t* sc
     emit(edge, edge ? node_of(a) : 0u, edge ? node_of(b) : 0u);
   }
   if (nloops > C::NS) return 1;
-  for (uint32_t i0 = 0; i0 < nsrc; i0 += 64u) { const uint32_t i = i0 + (uint32_t)lane; const bool h = i < nsrc; emit(h, 1u, h ? node_of(SRCS[i]) : 0u); }      // :1303-1305
-  for (uint32_t i0 = 0; i0 < nsink; i0 += 64u) { const uint32_t i = i0 + (uint32_t)lane; const bool h = i < nsink; emit(h, h ? node_of(SINKS[i]) : 0u, 0u); }  // :1216-1226
+  // the source's edges to the entries that are left-flank k-mers (:1303-1305) and the sink positions' edges to the sink
+  // (:1216-1226), one per k-mer: a bit per node, then one edge per bit
+  {
+    uint32_t* SM = PM;                    // (the pass-through bits come later)
+    uint32_t* KM = hdr + 16;              // [NV / 32]
+    for (uint32_t i = (uint32_t)lane; i < C::NV / 32u; i += 64u) { SM[i] = 0u; KM[i] = 0u; }
+    lds_sync();
+    for (uint32_t q0 = 0; q0 < nrec; q0 += 64u) {
+      const uint32_t q = q0 + (uint32_t)lane;
+      if (q >= nrec) continue;
+      const SegD s = seg_load(segs, q);
+      if (s.ts() < 0) continue;
+      if (s.source()) { const uint32_t v = node_of(s.idx(0)); atomicOr(&SM[v >> 5], 1u << (v & 31u)); }
+      const int sp = sink_pos(s);
+      if (sp >= 0) { const uint32_t v = node_of(s.idx(sp)); atomicOr(&KM[v >> 5], 1u << (v & 31u)); }
+    }
+    lds_sync();
+    for (uint32_t v0 = 0; v0 < NV; v0 += 64u) {
+      const uint32_t v = v0 + (uint32_t)lane;
+      const bool h = v < NV;
+      emit(h && ((SM[v >> 5] >> (v & 31u)) & 1u), 1u, v);
+      emit(h && ((KM[v >> 5] >> (v & 31u)) & 1u), v, 0u);
+    }
+    lds_sync();
+  }
   if (e_full || ne > C::E) return 1;
   const unsigned long long e_all = e_internal + ne + nloops;
   gsync();
@@ -846,11 +863,13 @@ __device__ int d2_one(uint32_t* lds, const D2Args& A, uint32_t gap, uint32_t* sc
   // wait for a pass of all lanes over their nodes
   uint32_t* n_order = hdr + 1;
   uint32_t* n_bigs = hdr + 2;
-  uint16_t* bigs = (uint16_t*)(hdr + 4);  // (a handful: 24 entries)
+  uint16_t* bigs_a = (uint16_t*)(hdr + 4);  // (a handful: two lists of 12 entries that take turns)
+  uint16_t* bigs_b = bigs_a + 12;
+  uint16_t* bigs = bigs_a;
   if (lane == 0) { *n_next = 0u; *n_order = 0u; *n_bigs = 0u; }
   lds_sync();
   auto ready = [&](uint32_t b, uint32_t* next) {  // component b has no edge in left
-    if ((csize[b] & 0x3FFFFFFFu) > 1u && !is_pass_node(b)) { const uint32_t at = atomicAdd(n_bigs, 1u); if (at < 24u) bigs[at] = (uint16_t)b; else spill(b); }
+    if ((csize[b] & 0x3FFFFFFFu) > 1u && !is_pass_node(b)) { const uint32_t at = atomicAdd(n_bigs, 1u); if (at < 12u) bigs[at] = (uint16_t)b; else spill(b); }
     else if (*next == D2_NONE) *next = b;
     else spill(b);
   };
@@ -871,17 +890,16 @@ __device__ int d2_one(uint32_t* lds, const D2Args& A, uint32_t gap, uint32_t* sc
     if (comp[v] == v && !is_pass_node(v) && pk_get(cwork, v) == 0u) spill(v);
   for (guard = 0; guard <= guard_max; guard++) {
     lds_sync();
-    const uint32_t nbig = min(uni(*n_bigs), 24u);
+    const uint32_t nbig = min(uni(*n_bigs), 12u);
     ncur = uni(*n_next);
     if (nbig == 0u && ncur == 0u) break;
     { uint16_t* t = cur; cur = nxt; nxt = t; }
-    uint32_t big_c[24];
-    for (uint32_t x = 0; x < nbig; x++) big_c[x] = uni((uint32_t)bigs[x]);
-    lds_sync();
+    const uint16_t* bigs_now = bigs;
+    bigs = bigs == bigs_a ? bigs_b : bigs_a;  // (what becomes ready meanwhile is listed in the other half)
     if (lane == 0) { *n_next = 0u; *n_bigs = 0u; }
     lds_sync();
     for (uint32_t x = 0; x < nbig; x++) {  // a component of several nodes: all lanes over the nodes
-      const uint32_t cc = big_c[x];
+      const uint32_t cc = uni((uint32_t)bigs_now[x]);
       if (lane == 0) ORDER[atomicAdd(n_order, 1u)] = cc;
       for (uint32_t v = (uint32_t)lane; v < NV; v += 64u) {
         if (comp[v] != cc || is_pass_node(v)) continue;
@@ -895,7 +913,7 @@ __device__ int d2_one(uint32_t* lds, const D2Args& A, uint32_t gap, uint32_t* sc
     }
     for (uint32_t i = (uint32_t)lane; i < ncur; i += 64u) {
       const uint32_t c = cur[i];
-      if ((csize[c] & 0x3FFFFFFFu) > 1u && !is_pass_node(c)) { const uint32_t at = atomicAdd(n_bigs, 1u); if (at < 24u) bigs[at] = (uint16_t)c; else spill(c); }
+      if ((csize[c] & 0x3FFFFFFFu) > 1u && !is_pass_node(c)) { const uint32_t at = atomicAdd(n_bigs, 1u); if (at < 12u) bigs[at] = (uint16_t)c; else spill(c); }
       else order_from(c);
     }
   }

@@ -181,7 +181,8 @@ hipError_t launch_d3_sharded_tables(hipStream_t st, const D3Params& P, const D3W
                                     uint32_t* rnd_all, uint64_t rnd_capacity, uint32_t* group_fn /* [P.R0 + 1], device-writable */);
 hipError_t launch_d3_sharded_trace(hipStream_t st, const D3Params& P, const D3Work& W, const GapOut* outs, const SubRec* sub,
                                    const char* lastch_up, const char* lastch_dn, uint32_t* rnd_all, uint64_t rnd_capacity,
-                                   void* results, char* arena, const D3Side& side, void* summary_host);
+                                   void* results, char* arena, const D3Side& side, void* summary_host,
+                                   hipEvent_t ev_d2 = nullptr /* as launch_d3 */);
 
 // the first G2S_RAND_WINDOW words of a stream from the 31 words of state another list's kernels left (D3Work.link)
 hipError_t launch_rand_window(hipStream_t st, uint32_t* rnd_all, const uint32_t* link);
@@ -194,6 +195,7 @@ hipError_t launch_d3(hipStream_t st, const D3Params& P, const D3Work& W, const G
                      void* summary_host /* device-visible pinned memory: D3Summary in 1024 bytes, then the 64 fill-byte counters */,
                      bool summary_is_clean /* the summary and the counters are zero already */,
                      uint32_t* clean_words /* with P.self_clean: eight words the last wave zeroes (the fill kernel's cursors); may be null */,
-                     hipEvent_t ev_chain = nullptr /* recorded behind the kernel that knows the list's draws (W.link is written) */);
+                     hipEvent_t ev_chain = nullptr /* recorded behind the kernel that knows the list's draws (W.link is written) */,
+                     hipEvent_t ev_d2 = nullptr /* behind g2s_d2_* on its own stream: the hand-off waits for it (null: nothing to wait for) */);
 
 }  // namespace g2s

@@ -142,7 +142,8 @@ __device__ __forceinline__ uint32_t d3_classify_body(const D3Params& P, const D3
         seg_gaps++;
         if (flags & G2S_DEV_BIG) big++;
         const bool phase_d = c_count > 0 && n_len > 0;  // :1169
-        const bool by_host = phase_d && !(dflags & G2S_DEVA_ANALYSED);
+        // (a gap listed for g2s_d2_* is not the host's yet: that kernel may still be running — the hand-off decides)
+        const bool by_host = phase_d && !(dflags & (G2S_DEVA_ANALYSED | G2S_DEVA_D2_PENDING));
         // (the all-paths recount — the sum of the counts of the sink states — is the kernel's for every closure,
         // also for those the host analyses: whether a gap counts as filled decides the skip rule of the next)
         const int cnt = (phase_d && !P.skip_confident && P.all_paths) ? count_s : c_count;
@@ -796,6 +797,11 @@ __device__ __forceinline__ bool d3_handoff_body(const D3Params& P, const D3Work&
     const uint32_t vr = W.vrank[mine], base = W.base[mine], dmin = W.dmin[mine];
     const GapOut& go = outs[mine];
     my_ns = go.n_xl;
+    // (g2s_d2_* has run by now: a gap it was to analyse and could not — beyond its capacities — is the host's after all)
+    if ((gi & GI_PHASE_D) && !P.skip_confident) {
+      const uint32_t dfl = go.dflags;
+      if ((dfl & G2S_DEVA_D2_PENDING) && !(dfl & G2S_DEVA_RUNS)) gi |= GI_HOST;
+    }
     const uint32_t dv = ldvar ? ldvar[vr] : W.dvar[vr];
     my_off = base + dv;
     my_want = dmin;
@@ -1468,9 +1474,10 @@ hipError_t launch_d3_sharded_tables(hipStream_t st, const D3Params& P, const D3W
 }
 hipError_t launch_d3_sharded_trace(hipStream_t st, const D3Params& P, const D3Work& W, const GapOut* outs, const SubRec* sub,
                                    const char* lastch_up, const char* lastch_dn, uint32_t* rnd_all, uint64_t rnd_capacity,
-                                   void* results, char* arena, const D3Side& side, void* summary_host) {
+                                   void* results, char* arena, const D3Side& side, void* summary_host, hipEvent_t ev_d2) {
   if (P.n == 0) return hipSuccess;
   hipLaunchKernelGGL(g2s_d3_chain, dim3(1), dim3(1024), 0, st, W, rnd_all, P.base0, P.d_in);
+  if (ev_d2) { const hipError_t e2 = hipStreamWaitEvent(st, ev_d2, 0); if (e2 != hipSuccess) return e2; }
   hipLaunchKernelGGL(g2s_d3_handoff, dim3((P.n + 63u) / 64u), dim3(64), 0, st, P, W, outs, sub, rnd_all + 31, rnd_capacity, side);
   const size_t lds = (size_t)P.seg_cap * (sizeof(SegRec) + 16) + (size_t)P.map_cap * 8 + 16;
   hipError_t e = hipFuncSetAttribute((const void*)g2s_d3_trace, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1483,7 +1490,8 @@ hipError_t launch_d3_sharded_trace(hipStream_t st, const D3Params& P, const D3Wo
 hipError_t launch_d3(hipStream_t st, const D3Params& P, const D3Work& W, const GapDev* gaps, const GapOut* outs,
                      const D3Gap* dgaps, const SubRec* sub, const char* lastch_up, const char* lastch_dn,
                      const RandTables& rt, uint32_t* rnd_all, uint64_t rnd_capacity, void* results, char* arena,
-                     const D3Side& side, void* summary_host, bool summary_is_clean, uint32_t* clean_words, hipEvent_t ev_chain) {
+                     const D3Side& side, void* summary_host, bool summary_is_clean, uint32_t* clean_words, hipEvent_t ev_chain,
+                     hipEvent_t ev_d2) {
   if (P.n == 0) return hipSuccess;
   (void)gaps;
   (void)rt;
@@ -1504,6 +1512,8 @@ hipError_t launch_d3(hipStream_t st, const D3Params& P, const D3Work& W, const G
   e = hipFuncSetAttribute((const void*)g2s_d3_tables, hipFuncAttributeMaxDynamicSharedMemorySize, (int)win);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(g2s_d3_tables, dim3(tgrid), dim3(256), win, st, P, W, sub, rnd_all + 31, rnd_capacity);
+  // (g2s_d2_* runs on a stream of its own beside the kernels above; the hand-off reads what it decided)
+  if (ev_d2 && short_list) { e = hipStreamWaitEvent(st, ev_d2, 0); if (e != hipSuccess) return e; }
   if (short_list) {
     hipLaunchKernelGGL(g2s_d3_back, dim3(1), dim3(1024), 0, st, P, W, outs, sub, rnd_all, rnd_capacity, side);
     if (ev_chain) { e = hipEventRecord(ev_chain, st); if (e != hipSuccess) return e; }
@@ -1511,6 +1521,7 @@ hipError_t launch_d3(hipStream_t st, const D3Params& P, const D3Work& W, const G
     hipLaunchKernelGGL(g2s_d3_blocks, dim3(256), dim3(256), 0, st, W);
     hipLaunchKernelGGL(g2s_d3_chain, dim3(1), dim3(1024), 0, st, W, rnd_all, 0u, 0u);
     if (ev_chain) { e = hipEventRecord(ev_chain, st); if (e != hipSuccess) return e; }
+    if (ev_d2) { e = hipStreamWaitEvent(st, ev_d2, 0); if (e != hipSuccess) return e; }
     hipLaunchKernelGGL(g2s_d3_handoff, dim3((P.n + 63u) / 64u), dim3(64), 0, st, P, W, outs, sub, rnd_all + 31, rnd_capacity, side);
   }
   const size_t lds = (size_t)P.seg_cap * (sizeof(SegRec) + 16) + (size_t)P.map_cap * 8 + 16;  // closure, base map, rand() values, the walk's segments

@@ -1277,8 +1277,10 @@ __device__ __forceinline__ void segw_fill_one(uint32_t* lds, const SegArgs& A, c
     go->sub_vertices = sub_vertices;
     go->sub_edges = sub_edges;
     go->count_s = count_s;
-    go->dflags = (analysed || !want_s ? G2S_DEVA_ANALYSED : 0u) | (choice ? G2S_DEVA_CHOICE : 0u) | (sink_safe ? G2S_DEVA_SINK_SAFE : 0u);
-    if (A.d2_list && want_s && !analysed) A.d2_list[atomicAdd(out_counter + 4, 1ull)] = gi;  // (d2_device.hip takes it)
+    const bool to_d2 = A.d2_list && want_s && !analysed;  // (d2_device.hip takes it)
+    go->dflags = (analysed || !want_s ? G2S_DEVA_ANALYSED : 0u) | (choice ? G2S_DEVA_CHOICE : 0u) | (sink_safe ? G2S_DEVA_SINK_SAFE : 0u) |
+                 (to_d2 ? G2S_DEVA_D2_PENDING : 0u);
+    if (to_d2) A.d2_list[atomicAdd(out_counter + 4, 1ull)] = gi;
     go->flags = flags | G2S_DEV_COMPACT;
     go->n_sub = nsub;
     go->n_xp = sh[SH_NXP];

@@ -542,6 +542,7 @@ struct g2s_session {
   hipStream_t stream2 = nullptr;  // resident mode: the rand() stream is generated beside the fill kernel
   hipStream_t stream3 = nullptr;  // resident mode, deep lists: the large variant's early launch (resident_launch_fill)
   hipEvent_t ev_pre = nullptr, ev_early = nullptr;  // in front of the fill kernel; behind the early launch
+  hipEvent_t ev_fill = nullptr, ev_d2 = nullptr;    // behind the fill kernels (what g2s_d2_* waits for on its stream); behind g2s_d2_*
   DevBuf d_segx1;                 // the early launch's scratch
   hipEvent_t ev_rand = nullptr;
   g2s_params params;
@@ -724,6 +725,8 @@ extern "C" int g2s_session_create(g2s_graph* g, int device, const g2s_params* p,
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->stream3, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_pre, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_early, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_fill, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_d2, hipEventDisableTiming);
   if (e == hipSuccess) e = s->d_link.ensure(32 * 4);
   size_t free_b = 0, total_b = 0;
   if (e == hipSuccess) e = hipMemGetInfo(&free_b, &total_b);
@@ -790,6 +793,8 @@ extern "C" void g2s_session_destroy(g2s_session* s) {
   if (s->ev_chain) (void)hipEventDestroy(s->ev_chain);
   if (s->ev_pre) (void)hipEventDestroy(s->ev_pre);
   if (s->ev_early) (void)hipEventDestroy(s->ev_early);
+  if (s->ev_fill) (void)hipEventDestroy(s->ev_fill);
+  if (s->ev_d2) (void)hipEventDestroy(s->ev_d2);
   if (s->stream3) (void)hipStreamDestroy(s->stream3);
   s->d_segx1.release();
   s->d_d2list.release(); s->d_d2out.release(); s->d_d2runs.release(); s->d_d2scr_small.release(); s->d_d2scr_big.release(); s->d_hops.release();
@@ -2765,8 +2770,13 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl) {
   // segments, a k-mer at several depths): g2s_d2_small / g2s_d2_big behind the fill kernels, in front of phase D3.
   // Not for a team's groups that are gathered on the lead's device (their results would have to travel too), not with
   // -all-upper (no phase D2 at all).  G2S_DEVICE_D2=0: those closures are the host's, as until round 4 (post.cpp).
+  // By default for the lists that fill the chip (from 3 072 gaps: the multi-workgroup kernels of phase D3, under whose
+  // first ones g2s_d2_* runs on its own stream) and for deep lists; a short list keeps handing its two or three such
+  // closures to the host's threads, which finish them under the trace kernel — there the launch is the step's
+  // critical path and the threads are idle.  G2S_DEVICE_D2=1 / 0: always / never.
   bool dev_d2 = (!s->in_team_list || s->team_sharded) && !s->params.skip_confident && !ids.empty();
   if (const char* env = getenv("G2S_DEVICE_D2")) dev_d2 = dev_d2 && atoi(env) != 0;
+  else dev_d2 = dev_d2 && (ids.size() >= 3072 || b->dmax >= 2500);
   const bool d2_big = dev_d2 && (b->dmax >= 2500 || getenv("G2S_D2_BIG") != nullptr);  // (a deep list: closures of thousands of segments)
   const uint32_t d2_small_wgs = (uint32_t)std::min<size_t>(ids.size(), (size_t)std::max(1, s->num_cus) * 4u);
   const uint32_t d2_big_wgs = (uint32_t)std::min<size_t>(ids.size(), (size_t)std::max(1, s->num_cus));
@@ -2877,8 +2887,12 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl) {
     }
     DA.pass_all = (d2_big && getenv("G2S_D2_BIG") && atoi(getenv("G2S_D2_BIG")) == 2) ? 1u : 0u;  // (tests: every closure through the large instantiation)
     if (getenv("G2S_D2_NO_CHAINS")) DA.pass_all |= 2u;  // (tests: no node counts as pass-through — the whole graph of runs goes through the component search)
-    HIP_TRY_S(launch_d2(st, DA, d2_small_wgs, d2_big ? d2_big_wgs : 0u, (uint32_t*)s->d_d2scr_small.p, (uint32_t*)s->d_d2scr_big.p,
+    // (on the third stream, behind the fill kernels: phase D3's first kernels do not wait for it — launch_d3)
+    HIP_TRY_S(hipEventRecord(s->ev_fill, st));
+    HIP_TRY_S(hipStreamWaitEvent(s->stream3, s->ev_fill, 0));
+    HIP_TRY_S(launch_d2(s->stream3, DA, d2_small_wgs, d2_big ? d2_big_wgs : 0u, (uint32_t*)s->d_d2scr_small.p, (uint32_t*)s->d_d2scr_big.p,
                         (uint32_t*)s->d_d2list.p + n, ctr + 6, ctr + 7));
+    HIP_TRY_S(hipEventRecord(s->ev_d2, s->stream3));
   }
   if (rerun && rl->timed) HIP_TRY_S(hipEventRecord(s->ev_segw, st));
   rl->units = out_states;
@@ -3099,7 +3113,8 @@ static int resident_d3_launch(g2s_session* s, const ResidentList& L, bool timed,
                     (const char*)s->d_lastch.p, (const char*)s->d_lastch.p + g.n, s->rtab, (uint32_t*)s->d_rnd.p,
                     (uint64_t)rnd_cap, res_dev, (char*)arena_dev, side, (char*)d_dgaps + ((char*)hsum - (char*)L.pin->p),
                     s->d_d3.clean >= 1024 + 64 * 128, self_clean ? (uint32_t*)s->d_counter.p : nullptr,
-                    no_spin ? s->ev_chain : nullptr /* (lists in flight: the next one's stream may wait for it) */));
+                    no_spin ? s->ev_chain : nullptr /* (lists in flight: the next one's stream may wait for it) */,
+                    W.d2out ? s->ev_d2 : nullptr));
   s->d_d3.clean = 0;
   if (timed && !sharded) HIP_TRY_S(hipEventRecord(s->ev[3], st));
   if (stage_dev && !sharded) {
@@ -3160,7 +3175,7 @@ static int resident_d3_sharded_trace(g2s_session* s, uint32_t d_in) {
   *(volatile unsigned long long*)dp->side_h.count = ~0ull;
   HIP_TRY_S(launch_d3_sharded_trace(s->stream, dp->P, dp->W, dp->L.outs_dev, dp->L.sub_dev, (const char*)s->d_lastch.p,
                                   (const char*)s->d_lastch.p + g.n, (uint32_t*)s->d_rnd.p, (uint64_t)dp->rnd_cap, dp->res_dev,
-                                  dp->arena_dev, dp->side_dev, dp->summary_dev));
+                                  dp->arena_dev, dp->side_dev, dp->summary_dev, dp->W.d2out ? s->ev_d2 : nullptr));
   if (dp->timed) HIP_TRY_S(hipEventRecord(s->ev[3], s->stream));
   dp->t_launched = std::chrono::steady_clock::now();
   return G2S_OK;

@@ -58,29 +58,36 @@ def test_resident_mode_equals_the_host_path(product, monkeypatch, mode, pinned):
     assert d2 == h2  # (the second list began at the right place in the stream)
     assert (td.xB, td.sB, td.seg_tier_gaps, td.seg_segments, td.fill_bytes) == (th.xB, th.sB, th.seg_tier_gaps, th.seg_segments, th.fill_bytes)
     assert td.draw_dependent_gaps > 0 and td.d3_table_entries >= td.draw_dependent_gaps
-    # a few closures per thousand hold a k-mer at two depths: g2s_d2_* analyses those behind the fill kernel
-    # (d2_device.hip; until round 4 they were handed to the host) — nothing is left to the host's threads
-    assert td.host_finished_gaps == 0
+    # a few closures per thousand hold a k-mer at two depths: on a list this short the host's threads finish those under
+    # the trace kernel (lists that fill the chip, and deep ones, have them analysed by g2s_d2_*: the next test); with
+    # -all-upper nothing is analysed at all
+    assert (td.host_finished_gaps > 0) == (mode != "all_upper")
     assert sum(1 for r in d1 if r[0] > 0) > 600
 
 
-@pytest.mark.parametrize("how", ["host", "small", "large"])
+@pytest.mark.parametrize("how", ["default", "host", "small", "large", "no_chains"])
 def test_phase_d2_on_the_device_equals_the_hosts(product, monkeypatch, how):
     """The closures the fill kernels do not analyse themselves (a k-mer at several depths, more than 192 segments):
-    analysed by g2s_d2_small / g2s_d2_big and traced by the trace kernel from their runs (the default; "large": every
-    one of them through the large instantiation, G2S_D2_BIG=2), or handed to the host's threads (G2S_DEVICE_D2=0: round
-    4's way, post.cpp) — every field of every result and the subgraph statistics equal the host path's either way."""
+    analysed by g2s_d2_small / g2s_d2_big on a stream of their own and traced by the trace kernel from their runs (the
+    default from 3 072 gaps on; "small": forced on a shorter list; "large": every one of them through the large
+    instantiation, G2S_D2_BIG=2; "no_chains": the whole graph of runs through the component search), or handed to the
+    host's threads (G2S_DEVICE_D2=0: round 4's way, post.cpp) — every field of every result and the subgraph statistics
+    equal the host path's either way."""
     reads = product.G2S.synth_genome(200000, 3, 20240101)
     seqs = [ln for ln in reads.splitlines() if not ln.startswith(">")]
-    gaps = _parse_scaffolds(product.G2S.synth_gaps(reads, 31, 10, 3000, 100, 900, 20240103))
+    gaps = _parse_scaffolds(product.G2S.synth_gaps(reads, 31, 10, 3300 if how in ("default", "host") else 1500, 100, 900, 20240103))
+    for k in ("G2S_DEVICE_D2", "G2S_D2_BIG", "G2S_D2_NO_CHAINS"):
+        monkeypatch.delenv(k, raising=False)
     for mode_kw in ({}, dict(all_paths=False)):
-        monkeypatch.delenv("G2S_DEVICE_D2", raising=False)
-        monkeypatch.delenv("G2S_D2_BIG", raising=False)
         h1, h2, th, _ = _run(product, monkeypatch, False, seqs, 31, gaps, 500, **mode_kw)
         if how == "host":
             monkeypatch.setenv("G2S_DEVICE_D2", "0")
-        elif how == "large":
+        elif how != "default":
+            monkeypatch.setenv("G2S_DEVICE_D2", "1")
+        if how == "large":
             monkeypatch.setenv("G2S_D2_BIG", "2")
+        if how == "no_chains":
+            monkeypatch.setenv("G2S_D2_NO_CHAINS", "1")
         d1, d2, td, td2 = _run(product, monkeypatch, True, seqs, 31, gaps, 500, pinned=True, **mode_kw)
         assert td.resident_launches == 1 and td.resident_fallbacks == 0
         assert d1 == h1 and d2 == h2
@@ -319,6 +326,7 @@ def test_resident_mode_on_toy_graphs(product, oracle, monkeypatch, seed):
     that outgrow the regular tier (they rerun in the large variant on the stream) — and every list is FINISHED ON THE
     DEVICE all the same (until round 3 most of these attempts were discarded); the results are the oracle's."""
     monkeypatch.setenv("G2S_RESIDENT", "1")
+    monkeypatch.setenv("G2S_DEVICE_D2", "1")  # (short lists: by default their few such closures are the host threads')
     k = [9, 11, 13, 15, 17, 21][seed % 6]
     seqs = cases.toy_genome(seed, 1500, k, repeats=seed % 3, tandem=seed % 2, inverted=int(seed % 4 == 0), snp_every=(0 if seed % 2 else 97))
     e = [0, 9, 20, 31][seed % 4] + k
