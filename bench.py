@@ -142,6 +142,23 @@ class Runner:
         self.P._check(rc)
         return dt
 
+    def stream(self, k, keep=False):
+        """srand(1) once, then K consecutive calls on the same list: the rand() stream goes on from call to call (the
+        reference's one stream over the whole run, Gap2Seq.cpp:178).  Returns (seconds, per-call result keys when keep)."""
+        self.sessions[0].srand(1)
+        out = []
+        t0 = time.perf_counter()
+        for _ in range(k):
+            if len(self.sessions) == 1 and self.group == 0:
+                rc = self.lib.g2s_fill_batch(self.sessions[0].h, self.arr, self.n, self.res, self.arena, self.nbytes)
+            else:
+                rc = self.lib.g2s_team_fill(self.hs, len(self.sessions), self.arr, self.n, self.group, self.res, self.arena,
+                                            self.nbytes, C.byref(self.tm))
+            self.P._check(rc)
+            if keep:
+                out.append([result_key(r) for r in self.results()])
+        return time.perf_counter() - t0, out
+
     def timing(self):
         if len(self.sessions) == 1 and self.group == 0:
             self.P._check(self.lib.g2s_session_last_timing(self.sessions[0].h, C.byref(self.tm)))
@@ -482,6 +499,32 @@ def main():
                             results="identical to the lists one at a time, list by list (checked in this run)",
                             how="g2s_fill_begin(list i+D-1) before g2s_fill_end(list i), D = in_flight: the younger lists' kernels run while the oldest one's results cross the link; the rand() stream continues from list to list on the device")
         sr.free()
+
+    # ---- N>1: a STREAM of lists over the team — every call hands each GPU a whole share of the list (one group per
+    # session: each GPU fills, traces and writes its own share, the rand() stream chained from share to share and from
+    # list to list), K calls in a row without reseeding; against the same K lists on one session, list by list
+    if len(sessions) > 1 and args.stream_lists >= 2:
+        solo = make_sessions(devices[:1], 1)
+        r1 = Runner(P, solo, gaps, 0, not args.pageable_buffers)
+        _, want = r1.stream(args.stream_lists, keep=True)
+        _, got = run.stream(args.stream_lists, keep=True)
+        if got != want:
+            raise SystemExit("bench.py: a stream of %d lists on %d sessions differs from the same lists on one session" % (args.stream_lists, len(sessions)))
+        reps = max(3, min(steps, 10))
+        run.stream(args.stream_lists)
+        t_team = sum(run.stream(args.stream_lists)[0] for _ in range(reps))
+        r1.stream(args.stream_lists)
+        t_one = sum(r1.stream(args.stream_lists)[0] for _ in range(reps))
+        tot = float(len(gaps) * args.stream_lists * reps)
+        stream_lists = dict(lists=args.stream_lists, sessions=len(sessions), gaps_per_list=len(gaps), gaps_per_session_and_list=group or len(gaps),
+                            repetitions=reps, value=round(tot / t_team, 2), unit="gaps/s",
+                            ms_per_list=round(t_team / (args.stream_lists * reps) * 1e3, 4),
+                            one_session=round(tot / t_one, 2), ms_per_list_one_session=round(t_one / (args.stream_lists * reps) * 1e3, 4),
+                            results="identical to the same lists on one session, list by list (checked in this run)",
+                            how="g2s_team_fill per list, one group per session (phase D3 sharded); the rand() stream runs on from list to list; one list at a time (lists in flight are a one-session feature so far)")
+        r1.free()
+        for s_ in solo:
+            s_.destroy()
 
     # ---- CPU baseline: the oracle (port of the reference algorithm) on the GPU box's host cores,
     # N=1 only, on a bounded sample of the same gaps

@@ -31,6 +31,7 @@ int main(int argc, char** argv) {
   memset(&p, 0, sizeof p);
   p.d_err = 500; p.all_paths = 1;
   int randseed = 0, device = 0, streams = 2, stream_gaps = 8192;
+  bool streams_given = false;
   static int fasta_width = 0;  // (static: read by the output callback)
   std::string devices;  // "0,1,2": GPUs sharing the gap list (the graph is replicated)
   std::string reads, scaffolds, filled, left, right;
@@ -61,7 +62,7 @@ int main(int argc, char** argv) {
     else if (a == "-version") { std::cout << "Gap2Seq-core (MI355X) ABI " << G2S_ABI_VERSION << std::endl; return EXIT_SUCCESS; }
     else if (a == "-device") device = atoi(val());
     else if (a == "-devices") devices = val();
-    else if (a == "-streams") streams = atoi(val());
+    else if (a == "-streams") { streams = atoi(val()); streams_given = true; }
     else if (a == "-stream-gaps") stream_gaps = atoi(val());
     else if (a == "-fasta-width") fasta_width = atoi(val());
     else if (a == "-help" || a == "-h") {
@@ -143,6 +144,11 @@ int main(int argc, char** argv) {
     rc = g2s_session_create(g, devs[0], &p, &s);
     if (rc != G2S_OK) { std::cout << "EXCEPTION: " << g2s_last_error() << std::endl; return EXIT_FAILURE; }
   }
+  // Several GPUs: one session per GPU, and every batch of the stream is -stream-gaps gaps PER GPU, cut into one share
+  // per GPU — each GPU fills, traces and writes a whole share, the rand() stream chained from share to share (phase D3
+  // sharded) — unless -streams asks for the round-2 dispatcher (several sessions a GPU pulling small groups).
+  const bool per_gpu_shares = devs.size() > 1 && !streams_given;
+  if (per_gpu_shares) streams = 1;
   std::vector<g2s_session*> helpers;
   for (size_t d = 0; d < devs.size(); d++)
     for (int t = (d == 0 ? 1 : 0); t < std::max(1, streams); t++) {
@@ -151,7 +157,8 @@ int main(int argc, char** argv) {
       if (rc != G2S_OK) { std::cout << "EXCEPTION: " << g2s_last_error() << std::endl; return EXIT_FAILURE; }
       helpers.push_back(h);
     }
-  if (!helpers.empty()) g2s_session_set_team(s, helpers.data(), (int)helpers.size(), 0);
+  if (!helpers.empty()) g2s_session_set_team(s, helpers.data(), (int)helpers.size(), per_gpu_shares ? G2S_GROUP_PER_SESSION : 0);
+  if (per_gpu_shares) stream_gaps = (int)std::min<long long>((long long)std::max(0, stream_gaps) * (long long)devs.size(), 1 << 24);
   char *fasta = nullptr, *log = nullptr;
   if (saw_left && saw_right && saw_len) {
     rc = g2s_execute_single(s, &o, reads.c_str(), filled.c_str(), left.c_str(), right.c_str(), length, &fasta, &log);

@@ -53,6 +53,7 @@ struct D2Args {
   uint32_t list_cap;                    // most gaps the list can hold (the grid is sized by it)
   uint32_t pass_all;                    // (tests) bit 0: the small instantiation passes every gap on to the large one; bit 1: no chains are contracted
   unsigned long long* prof;             // (tools, may be null) 16 counters: cycles per section of the analysis, summed over gaps
+  unsigned long long* wgs_done;         // workgroups of g2s_d2_* that are through (the trace kernel's last wave waits for all of them)
 };
 
 size_t d2_scratch_bytes(bool big, uint32_t workgroups);

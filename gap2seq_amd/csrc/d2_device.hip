@@ -174,6 +174,12 @@ __device__ __forceinline__ uint32_t sort_unique(uint64_t* K, uint32_t n, int lan
 }
 
 #define D2_LAP(i) do { if (A.prof) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) atomicAdd(A.prof + (i), t_ - t_lap); t_lap = t_; } } while (0)
+// the gap's verdict word, behind everything the wave wrote for the gap: its trace wave (g2s_d3_trace) may be waiting for it
+__device__ __forceinline__ void d2_publish(GapOut* go, uint32_t dflags, int lane) {
+  __threadfence();
+  __builtin_amdgcn_wave_barrier();
+  if (lane == 0) __hip_atomic_store(&go->dflags, dflags, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
 // returns 0: analysed; 1: beyond this instantiation's capacities; 2: no room for the runs
 template <class C>
 __device__ int d2_one(uint32_t* lds, const D2Args& A, uint32_t gap, uint32_t* scr) {
@@ -249,9 +255,9 @@ __device__ int d2_one(uint32_t* lds, const D2Args& A, uint32_t gap, uint32_t* sc
     if (lane == 0) {
       D2Out o; o.run_off = 0; o.n_runs = 0; o.sub[0] = 2; o.sub[1] = 0; o.sub[2] = 0; o.sub[3] = 0; o.sub[4] = 2; o.sub[5] = 0;
       A.d2out[gap] = o;
-      go->dflags = (go->dflags & ~G2S_DEVA_SINK_SAFE) | G2S_DEVA_ANALYSED | G2S_DEVA_RUNS;
       go->sub_vertices = 2; go->sub_edges = 0;
     }
+    d2_publish(go, (uni(go->dflags) & ~G2S_DEVA_SINK_SAFE) | G2S_DEVA_ANALYSED | G2S_DEVA_RUNS, lane);
     return 0;
   }
   {
@@ -374,8 +380,8 @@ __device__ int d2_one(uint32_t* lds, const D2Args& A, uint32_t gap, uint32_t* sc
       o.sub[0] = n_s + 2u; o.sub[1] = edges; o.sub[2] = 0u; o.sub[3] = 0u; o.sub[4] = n_s + 2u; o.sub[5] = edges;
       A.d2out[gap] = o;
       go->sub_vertices = n_s + 2u; go->sub_edges = edges;
-      go->dflags = (go->dflags & ~G2S_DEVA_SINK_SAFE) | G2S_DEVA_ANALYSED | G2S_DEVA_RUNS | (sink_safe ? G2S_DEVA_SINK_SAFE : 0u);
     }
+    d2_publish(go, (uni(go->dflags) & ~G2S_DEVA_SINK_SAFE) | G2S_DEVA_ANALYSED | G2S_DEVA_RUNS | (sink_safe ? G2S_DEVA_SINK_SAFE : 0u), lane);
     D2_LAP(1);
     return 0;
   }
@@ -976,8 +982,8 @@ __device__ int d2_one(uint32_t* lds, const D2Args& A, uint32_t gap, uint32_t* sc
     o.sub[5] = (uint32_t)fe;
     A.d2out[gap] = o;
     go->sub_vertices = V; go->sub_edges = o.sub[1];
-    go->dflags = (go->dflags & ~G2S_DEVA_SINK_SAFE) | G2S_DEVA_ANALYSED | G2S_DEVA_RUNS | (sink_safe ? G2S_DEVA_SINK_SAFE : 0u);
   }
+  d2_publish(go, (uni(go->dflags) & ~G2S_DEVA_SINK_SAFE) | G2S_DEVA_ANALYSED | G2S_DEVA_RUNS | (sink_safe ? G2S_DEVA_SINK_SAFE : 0u), lane);
   D2_LAP(10);
   if (A.prof && lane == 0) { atomicAdd(A.prof + 11, 1ull); atomicAdd(A.prof + 12, (unsigned long long)NV); atomicAdd(A.prof + 13, (unsigned long long)guard); }
   return 0;
@@ -999,10 +1005,12 @@ __device__ __forceinline__ void d2_loop(uint32_t* lds, const D2Args& A) {
       const unsigned long long at = atomicAdd(A.count_next, 1ull);
       if (at < (unsigned long long)A.list_cap) A.list_next[at] = gap;
     }
-    // (rc == 2, or 1 in the large instantiation: the gap stays without G2S_DEVA_ANALYSED — the host's, post.cpp)
+    // (rc == 2, or 1 where nobody takes the gap over: it stays without G2S_DEVA_ANALYSED — the host's, post.cpp — and says so)
+    if (rc != 0 && !(rc == 1 && A.list_next)) d2_publish(A.outs + gap, uni(A.outs[gap].dflags) | G2S_DEVA_D2_FAILED, (int)threadIdx.x);
     lds_sync();
     gsync();
   }
+  if (A.wgs_done && threadIdx.x == 0) { __threadfence(); atomicAdd(A.wgs_done, 1ull); }
 }
 
 __global__ __launch_bounds__(64) void g2s_d2_small(const D2Args A) {

@@ -147,6 +147,11 @@ struct D3Params {
   // one rand() stream.  base0: fewest draws of all groups in front; R0: their summed spreads (the deviations this
   // group's first draw-dependent gap can start with: 0 .. R0); d_in: the deviation it does start with.
   uint32_t base0, R0, d_in;
+  // g2s_d2_* runs on a stream of its own beside this list's phase D3: the trace waves of the gaps it analyses wait for
+  // their gap's verdict word, and the wave that cleans up behind the list waits until d2_wgs workgroups of it have
+  // left (*d2_done counts them; null: nothing of the kind is running)
+  const unsigned long long* d2_done;
+  uint32_t d2_wgs, pad1;
 };
 
 // the stream: values [0, capacity) into rnd_all[31 ..] (sum_dev = nullptr; independent of the list's kernels, so

@@ -797,10 +797,11 @@ __device__ __forceinline__ bool d3_handoff_body(const D3Params& P, const D3Work&
     const uint32_t vr = W.vrank[mine], base = W.base[mine], dmin = W.dmin[mine];
     const GapOut& go = outs[mine];
     my_ns = go.n_xl;
-    // (g2s_d2_* has run by now: a gap it was to analyse and could not — beyond its capacities — is the host's after all)
+    // (g2s_d2_* runs beside these kernels: a gap it was to analyse and has given up on — beyond its capacities — is the
+    // host's after all; one it has not got to yet is waited for by the gap's trace wave)
     if ((gi & GI_PHASE_D) && !P.skip_confident) {
       const uint32_t dfl = go.dflags;
-      if ((dfl & G2S_DEVA_D2_PENDING) && !(dfl & G2S_DEVA_RUNS)) gi |= GI_HOST;
+      if ((dfl & G2S_DEVA_D2_PENDING) && (dfl & G2S_DEVA_D2_FAILED)) gi |= GI_HOST;
     }
     const uint32_t dv = ldvar ? ldvar[vr] : W.dvar[vr];
     my_off = base + dv;
@@ -973,6 +974,23 @@ __global__ __launch_bounds__(64) void g2s_d3_trace(const D3Params P, const D3Wor
     go.len[0] = (int32_t)uni((uint32_t)g.len[0]); go.len[1] = (int32_t)uni((uint32_t)g.len[1]);
     go.reached_j = (int32_t)uni((uint32_t)g.reached_j); go.count_s = (int32_t)uni((uint32_t)g.count_s);
   }
+  // (the gap's closure is g2s_d2_*'s to analyse, on its own stream: until its verdict word says it has — or has given
+  // up —, this wave waits; then the words that kernel wrote are read again)
+  bool d2_lost = false;
+  if ((go.dflags & G2S_DEVA_D2_PENDING) && !(go.dflags & (G2S_DEVA_RUNS | G2S_DEVA_D2_FAILED)) && !P.skip_confident) {
+    uint32_t v = go.dflags;
+    for (uint32_t spin = 0; spin < (1u << 22) && !(v & (G2S_DEVA_RUNS | G2S_DEVA_D2_FAILED)); spin++) {
+      __builtin_amdgcn_s_sleep(8);
+      v = uni(__hip_atomic_load(&outs[i].dflags, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    go.dflags = v;
+    go.sub_vertices = uni(__hip_atomic_load(&outs[i].sub_vertices, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    go.sub_edges = uni(__hip_atomic_load(&outs[i].sub_edges, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    if (!(v & (G2S_DEVA_RUNS | G2S_DEVA_D2_FAILED))) d2_lost = true;  // (never expected: the list goes to the host path)
+  }
+  // (given up after the hand-off looked: too late for a slot in the host's side buffers — counted, the host path's)
+  if ((go.dflags & G2S_DEVA_D2_PENDING) && (go.dflags & G2S_DEVA_D2_FAILED) && !(td.gi & GI_HOST) && (td.gi & GI_PHASE_D)) d2_lost = true;
   // The wave that is through last copies the summary and the fill-byte counters to the host's pinned memory (a copy
   // command behind the kernel costs the stream a barrier).  Who is last: the fill-byte counter of the wave's residue
   // modulo 64 also counts its waves (bits 40 and up — one addition for both; one counter for all waves would have
@@ -996,6 +1014,10 @@ __global__ __launch_bounds__(64) void g2s_d3_trace(const D3Params P, const D3Wor
     // gap's record, and by the last wave the summary, the counters and the fill kernel's cursors)
     if (P.self_clean && (uint32_t)lane < sizeof(GapOut) / 4u) ((uint32_t*)&outs[i])[lane] = 0u;
     if (!uni(last)) return;
+    // (g2s_d2_*'s workgroups have all left before the cursors they read are zeroed)
+    if (P.d2_done && lane == 0)
+      for (uint32_t spin = 0; spin < (1u << 22) && __hip_atomic_load(P.d2_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned long long)P.d2_wgs; spin++)
+        __builtin_amdgcn_s_sleep(8);
     uint32_t* src = (uint32_t*)S;
     for (uint32_t w = (uint32_t)lane; w < (1024u + 64u * 128u) / 4u; w += 64u) {
       summary_host[w] = __hip_atomic_load(src + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1004,6 +1026,12 @@ __global__ __launch_bounds__(64) void g2s_d3_trace(const D3Params P, const D3Wor
     if (P.self_clean && clean_words && lane < 32) clean_words[lane] = 0u;  // (the fill kernels' and g2s_d2_*'s cursors: 16 counters)
   };
   if (status) { leave(0u); return; }  // (the records in front of this kernel were not written: nothing below may run)
+  if (d2_lost) {
+    if (lane == 0) { atomicAdd(&S->anomalies, 1u); arena[td.arena_off + td.lmf] = '\0'; }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    leave(0u);
+    return;
+  }
   const uint32_t gi = td.gi;
   struct { uint16_t lmf; } dg = {td.lmf};
   const uint64_t abs_off = td.arena_off;

@@ -146,5 +146,6 @@ struct GapOut {
 #define G2S_DEVA_SINK_SAFE 0x4u  /* branch[sink] == 1 (Q5: what k-mers outside the subgraph read) */
 #define G2S_DEVA_D2_PENDING 0x10u /* the fill kernel listed the gap for g2s_d2_* (which runs beside phase D3's first kernels: the
                                     hand-off looks whether G2S_DEVA_RUNS has joined it; if not, the closure is the host's) */
+#define G2S_DEVA_D2_FAILED 0x20u  /* g2s_d2_* could not analyse the closure (beyond its capacities): the host's after all */
 #define G2S_DEVA_RUNS 0x8u       /* (with ANALYSED) analysed by g2s_d2_* (d2_device.hip): the verdicts are the gap's runs (D2Out),
                                     the subgraph statistics D2Out.sub */

@@ -570,6 +570,9 @@ struct g2s_session {
   // its LDS (a traceback enters a segment once: as many entries as the closure has segments, at the closure's offset)
   DevBuf d_d2list, d_d2out, d_d2runs, d_d2scr_small, d_d2scr_big, d_hops;
   bool d2_launched = false;  // the last fill launch had g2s_d2_* behind it
+  bool d2_wait = false;      // ... and phase D3's hand-off waits for it (deep lists: their trace waves would keep its
+                             // large instantiation off the compute units); else the trace waves of its gaps do
+  uint32_t d2_wgs = 0;       // workgroups of g2s_d2_* behind the last fill launch
   bool d2_prof_on = false;   // (G2S_D2_PROF) the section counters behind the cursors have been zeroed
   int num_cus = 256;
   DevBuf d_rspool;
@@ -2770,14 +2773,20 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl) {
   // segments, a k-mer at several depths): g2s_d2_small / g2s_d2_big behind the fill kernels, in front of phase D3.
   // Not for a team's groups that are gathered on the lead's device (their results would have to travel too), not with
   // -all-upper (no phase D2 at all).  G2S_DEVICE_D2=0: those closures are the host's, as until round 4 (post.cpp).
-  // By default for the lists that fill the chip (from 3 072 gaps: the multi-workgroup kernels of phase D3, under whose
-  // first ones g2s_d2_* runs on its own stream) and for deep lists; a short list keeps handing its two or three such
-  // closures to the host's threads, which finish them under the trace kernel — there the launch is the step's
-  // critical path and the threads are idle.  G2S_DEVICE_D2=1 / 0: always / never.
+  // By default for the lists that fill the chip (from 3 072 gaps) when they are not deep: g2s_d2_* runs on the third
+  // stream beside phase D3's kernels, and the trace waves of its gaps wait for their gap's verdict word (config 3's list:
+  // no gap left to the host's threads, the step 7 % longer — the kernel works a wave per closure, 0.2-0.3 ms for the 70
+  // closures against 0.1 ms of cover).  A short list keeps handing its two or three such closures to the host's threads,
+  // which finish them under the trace kernel: there the launch is the step's critical path and the threads are idle.
+  // A deep list (-dist-error in the thousands: closures of thousands of segments, 412 of config 5's 1 000) keeps the
+  // host's threads with the early hand-over too: one wave per closure takes 4 ms where the host's pool takes 0.6 under
+  // the launch.  G2S_DEVICE_D2=1 / 0: always / never.
   bool dev_d2 = (!s->in_team_list || s->team_sharded) && !s->params.skip_confident && !ids.empty();
   if (const char* env = getenv("G2S_DEVICE_D2")) dev_d2 = dev_d2 && atoi(env) != 0;
-  else dev_d2 = dev_d2 && (ids.size() >= 3072 || b->dmax >= 2500);
-  const bool d2_big = dev_d2 && (b->dmax >= 2500 || getenv("G2S_D2_BIG") != nullptr);  // (a deep list: closures of thousands of segments)
+  else dev_d2 = dev_d2 && ids.size() >= 3072 && b->dmax < 2500;
+  // (the large instantiation always rides along on that stream: what the small one cannot take is passed on, not lost)
+  const bool d2_big = dev_d2;
+  const bool d2_deep = dev_d2 && b->dmax >= 2500;
   const uint32_t d2_small_wgs = (uint32_t)std::min<size_t>(ids.size(), (size_t)std::max(1, s->num_cus) * 4u);
   const uint32_t d2_big_wgs = (uint32_t)std::min<size_t>(ids.size(), (size_t)std::max(1, s->num_cus));
   const uint64_t d2_run_cap = out_states + 65536u;
@@ -2790,6 +2799,8 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl) {
     HIP_TRY_S(s->d_hops.ensure((size_t)(out_states / 2 + 64) * 8));
   }
   s->d2_launched = dev_d2;
+  s->d2_wait = d2_deep;  // (the trace waves of a deep list hold so much LDS that the large instantiation might find no unit)
+  s->d2_wgs = dev_d2 ? d2_small_wgs + (d2_big ? d2_big_wgs : 0u) : 0u;
   if (rerun) {
     HIP_TRY_S(s->d_ovf.ensure(std::max<size_t>(ids.size() * 4, 16)));
     HIP_TRY_S(s->d_segx.ensure(fill_segw_scratch_bytes(segw_wgs)));
@@ -2880,12 +2891,13 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl) {
     DA.list = (const uint32_t*)s->d_d2list.p; DA.count = ctr + 4; DA.next = ctr + 5;
     DA.d2out = (D2Out*)s->d_d2out.p; DA.runs = (uint32_t*)s->d_d2runs.p; DA.run_cursor = ctr + 8; DA.run_cap = d2_run_cap;
     DA.all_paths = s->params.all_paths ? 1 : 0; DA.list_cap = (uint32_t)n;
+    DA.wgs_done = ctr + 9;
     static const bool d2_prof = getenv("G2S_D2_PROF") != nullptr;
     if (d2_prof) {
       if (!s->d2_prof_on) { HIP_TRY_S(hipMemsetAsync((char*)s->d_counter.p + 128, 0, 128, st)); s->d2_prof_on = true; }
       DA.prof = ctr + 16;
     }
-    DA.pass_all = (d2_big && getenv("G2S_D2_BIG") && atoi(getenv("G2S_D2_BIG")) == 2) ? 1u : 0u;  // (tests: every closure through the large instantiation)
+    DA.pass_all = (getenv("G2S_D2_BIG") && atoi(getenv("G2S_D2_BIG")) == 2) ? 1u : 0u;  // (tests: every closure through the large instantiation)
     if (getenv("G2S_D2_NO_CHAINS")) DA.pass_all |= 2u;  // (tests: no node counts as pass-through — the whole graph of runs goes through the component search)
     // (on the third stream, behind the fill kernels: phase D3's first kernels do not wait for it — launch_d3)
     HIP_TRY_S(hipEventRecord(s->ev_fill, st));
@@ -3103,6 +3115,7 @@ static int resident_d3_launch(g2s_session* s, const ResidentList& L, bool timed,
   // themselves; not while the lap stamps are wanted — they live in the summary's slot)
   const bool self_clean = L.groups.size() == 1 && L.outs_dev == (const GapOut*)s->d_outs.p && !P.laps && !sharded;
   P.self_clean = self_clean ? 1u : 0u;
+  if (W.d2out) { P.d2_done = (const unsigned long long*)s->d_counter.p + 9; P.d2_wgs = s->d2_wgs; }
   P.seg_cap = fp.skip_confident ? G2S_SEG_CAP : 192u;
   P.map_cap = ((uint32_t)L.dmax + 2u + 3u) & ~3u;
   if (sharded) {
@@ -3114,7 +3127,7 @@ static int resident_d3_launch(g2s_session* s, const ResidentList& L, bool timed,
                     (uint64_t)rnd_cap, res_dev, (char*)arena_dev, side, (char*)d_dgaps + ((char*)hsum - (char*)L.pin->p),
                     s->d_d3.clean >= 1024 + 64 * 128, self_clean ? (uint32_t*)s->d_counter.p : nullptr,
                     no_spin ? s->ev_chain : nullptr /* (lists in flight: the next one's stream may wait for it) */,
-                    W.d2out ? s->ev_d2 : nullptr));
+                    (W.d2out && s->d2_wait) ? s->ev_d2 : nullptr));
   s->d_d3.clean = 0;
   if (timed && !sharded) HIP_TRY_S(hipEventRecord(s->ev[3], st));
   if (stage_dev && !sharded) {
@@ -3175,7 +3188,7 @@ static int resident_d3_sharded_trace(g2s_session* s, uint32_t d_in) {
   *(volatile unsigned long long*)dp->side_h.count = ~0ull;
   HIP_TRY_S(launch_d3_sharded_trace(s->stream, dp->P, dp->W, dp->L.outs_dev, dp->L.sub_dev, (const char*)s->d_lastch.p,
                                   (const char*)s->d_lastch.p + g.n, (uint32_t*)s->d_rnd.p, (uint64_t)dp->rnd_cap, dp->res_dev,
-                                  dp->arena_dev, dp->side_dev, dp->summary_dev, dp->W.d2out ? s->ev_d2 : nullptr));
+                                  dp->arena_dev, dp->side_dev, dp->summary_dev, (dp->W.d2out && s->d2_wait) ? s->ev_d2 : nullptr));
   if (dp->timed) HIP_TRY_S(hipEventRecord(s->ev[3], s->stream));
   dp->t_launched = std::chrono::steady_clock::now();
   return G2S_OK;
@@ -4135,13 +4148,24 @@ extern "C" size_t g2s_team_arena_bytes(const g2s_session* s, const g2s_gap* gaps
   return need;
 }
 
+// the group size a list of n gaps is cut with on this session (a list of up to that many gaps runs on the session alone)
+static size_t team_group_for(const g2s_session* s, size_t n) {
+  if (s->team_group == G2S_GROUP_PER_SESSION && !s->helpers.empty()) {
+    const size_t ns = s->helpers.size() + 1;
+    if (n < 512 * ns) return n;  // (too short to be worth the team)
+    return (n + ns - 1) / ns;    // one group per session: phase D3 sharded (team_resident_sharded)
+  }
+  if (s->team_group && s->team_group != G2S_GROUP_PER_SESSION) return s->team_group;
+  return s->helpers.empty() ? (size_t)16384 : (size_t)2048;
+}
+
 extern "C" int g2s_fill_batch(g2s_session* s, const g2s_gap* gaps, size_t n, g2s_result* results, char* fill_arena,
                               size_t arena_cap) {
   if (!s) return fail(G2S_ERR_ARG, "g2s_fill_batch: bad argument");
   REFUSE_IN_FLIGHT(s, "g2s_fill_batch");
   // long lists go through the group pipeline: with helpers to use every session, without
   // them to bound the HBM the state logs of one launch take
-  const size_t group = s->team_group ? s->team_group : (s->helpers.empty() ? (size_t)16384 : (size_t)2048);
+  const size_t group = team_group_for(s, n);
   if (n > group) {
     std::vector<g2s_session*> team{s};
     team.insert(team.end(), s->helpers.begin(), s->helpers.end());
@@ -4210,7 +4234,7 @@ extern "C" int g2s_fill_begin(g2s_session* s, const g2s_gap* gaps, size_t n, g2s
   InternalCall own(s);
   g2s_session::InFlight f;
   f.results = results; f.arena = fill_arena; f.cap = arena_cap; f.gaps = gaps; f.n = n;
-  const size_t group = s->team_group ? s->team_group : (s->helpers.empty() ? (size_t)16384 : (size_t)2048);
+  const size_t group = team_group_for(s, n);
   if (n <= group && n > 0) {
     // the session, or a twin of it, that no list in flight is on (a list for g2s_fill_batch will run on the session itself)
     g2s_session* on = nullptr;

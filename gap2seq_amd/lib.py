@@ -16,6 +16,7 @@ G2S_ERR_STATE = -6
 G2S_INVALID_NODE = 0xFFFFFFFF
 G2S_MAX_PATHS = 2147483647 // 2 - 1
 G2S_MAX_IN_FLIGHT = 3  # include/g2s.h: lists begun and not ended on one session
+G2S_GROUP_PER_SESSION = (1 << 64) - 1  # include/g2s.h: g2s_session_set_team cuts every long list into one group per session
 G2S_GAP_SKIPPED = 0x1
 G2S_GAP_Q7 = 0x2
 G2S_GAP_MEM_EXCEEDED = 0x4
@@ -497,17 +498,32 @@ class Session:
                     c["arena"].free()
         return out, t
 
-    def fill_batch_onecall(self, gaps):
+    def fill_batch_onecall(self, gaps, pinned=False, want_timing=False):
         """g2s_fill_batch (prepare + run + free in one ABI call; lists longer than the group size
         go through the group pipeline, with the session's team when it has one)."""
         lib = load_library()
         arr, keep = _gap_array(gaps)
         nbytes = lib.g2s_team_arena_bytes(self.h, arr, len(gaps))
-        arena = C.create_string_buffer(max(1, nbytes))
-        res = (g2s_result * max(1, len(gaps)))()
-        _check(lib.g2s_fill_batch(self.h, arr, len(gaps), res, arena, nbytes))
-        raw = arena.raw
-        return [FillResult(res[i], raw) for i in range(len(gaps))]
+        bufs = []
+        try:
+            if pinned:
+                bufs = [HostBuffer(max(1, nbytes)), HostBuffer(C.sizeof(g2s_result) * max(1, len(gaps)))]
+                arena, res = bufs[0], bufs[1].array(g2s_result, max(1, len(gaps)))
+                _check(lib.g2s_fill_batch(self.h, arr, len(gaps), res, C.cast(arena.p, C.c_char_p), nbytes))
+            else:
+                arena = C.create_string_buffer(max(1, nbytes))
+                res = (g2s_result * max(1, len(gaps)))()
+                _check(lib.g2s_fill_batch(self.h, arr, len(gaps), res, arena, nbytes))
+            raw = arena.raw
+            out = [FillResult(res[i], raw) for i in range(len(gaps))]
+        finally:
+            for hb in bufs:
+                hb.free()
+        if want_timing:
+            t = g2s_timing()
+            _check(lib.g2s_session_last_timing(self.h, C.byref(t)))
+            return out, t
+        return out
 
     def set_team(self, helpers, group_size=0):
         """g2s_session_set_team: fill_batch / execute_* on this session use self + helpers."""

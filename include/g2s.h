@@ -283,6 +283,10 @@ int g2s_team_fill(g2s_session* const* sessions, int nsessions, const g2s_gap* ga
                   g2s_result* results, char* fill_arena, size_t arena_cap, g2s_timing* timing);
 size_t g2s_team_arena_bytes(const g2s_session* s, const g2s_gap* gaps, size_t n);
 int g2s_session_set_team(g2s_session* lead, g2s_session* const* helpers, int nhelpers, size_t group_size);
+/* group_size for g2s_session_set_team: every list of at least 512 gaps per session is cut into ONE group per session
+ * (a whole share of the list per GPU: each GPU fills, traces and writes its own share, the rand() stream chained from
+ * share to share by draw totals — what a caller that streams long lists over several GPUs wants; Gap2Seq-core -devices) */
+#define G2S_GROUP_PER_SESSION ((size_t)-1)
 
 /* ---------------------------------------------------------------------------
  *  Gap2Seq::execute() after the graph exists (Gap2Seq.cpp:224-438): scaffold

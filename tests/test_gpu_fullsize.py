@@ -99,6 +99,23 @@ def test_c5_full_size_vs_oracle(product, oracle):
     assert tm.resident_launches == 1 and tm.resident_fallbacks == 0 and tm.segx_tier_gaps >= 300
 
 
+def test_c5_full_size_with_phase_d2_on_the_device_vs_oracle(product, oracle, monkeypatch):
+    """The same list with the closures the fill kernels do not analyse (412 of the 1 000: more than 192 segments, a k-mer
+    at several depths) analysed by g2s_d2_small / g2s_d2_big instead of the host's threads (G2S_DEVICE_D2=1; not the
+    default for deep lists: DESIGN 3.6 says what it costs) and traced by the trace kernel from their runs, closures of
+    thousands of segments walked where they lie: every gap against the oracle, at most a handful left to the host
+    (closures beyond the large instantiation's capacities)."""
+    monkeypatch.setenv("G2S_DEVICE_D2", "1")
+    reads = product.G2S.synth_genome(3000000, 3, 20240101)
+    seqs = _seqs(reads)
+    gaps = _parse_scaffolds(product.G2S.synth_gaps(reads, 31, 10, 1000, 2000, 5000, 20240103))
+    c, f, tm, xb, sb = _check_batch(product, oracle, seqs, 31, gaps, 2000, seed=1)
+    assert c >= 995 and f >= 990
+    assert (tm.xB, tm.sB) == (xb, sb)
+    assert tm.resident_launches == 1 and tm.resident_fallbacks == 0 and tm.watchdog_gaps == 0
+    assert tm.host_finished_gaps <= 10
+
+
 def test_c5_on_the_host_path_vs_oracle(product, oracle, monkeypatch):
     """The same list with resident mode off (G2S_RESIDENT=0): the host path of round 2 — closures into pinned host
     memory, analysis while the kernels run, in-order offsets, tracebacks on the pool — stays the fallback."""

@@ -459,6 +459,9 @@ def test_c3_gap_list_on_the_branching_genome_vs_oracle(product, oracle, which, m
     assert c > 9900 and f > 9900
     if which == "res":  # the whole list on the device: fill kernel + phase D3, nothing left for the host path
         assert tm.resident_launches == 1 and tm.resident_fallbacks == 0 and tm.seg_tier_gaps == 10000
+        # (the 70 closures with a k-mer at several depths: analysed by g2s_d2_* on its own stream — d2_device.hip —, none
+        # left to the host's threads)
+        assert tm.host_finished_gaps <= 5
         assert tm.draw_dependent_gaps > 100
     if which in ("seg", "res"):
         assert tm.seg_tier_gaps == 10000 and tm.seg_launches == 1 and tm.lds_launches == 0

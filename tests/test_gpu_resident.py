@@ -510,6 +510,39 @@ def test_team_with_phase_d3_sharded_equals_one_session(product, monkeypatch, nse
         pg.free()
 
 
+@pytest.mark.parametrize("nsess", [2, 4])
+def test_stream_of_lists_over_a_team_equals_one_session(product, monkeypatch, nsess):
+    """A caller that streams lists over several GPUs (Gap2Seq-core -devices, bench.py --gpus N --stream-lists K):
+    g2s_session_set_team(lead, helpers, G2S_GROUP_PER_SESSION) and then g2s_fill_batch list after list — every list of at
+    least 512 gaps per session is cut into ONE share per session (each GPU fills, traces and writes a whole share;
+    phase D3 sharded), shorter ones run on the lead alone, and the one rand() stream runs on from share to share and
+    from list to list: the results are those of one session, list by list.  (The sessions share device 0 here.)"""
+    reads = product.G2S.synth_genome(200000, 3, 20240101)
+    seqs = [ln for ln in reads.splitlines() if not ln.startswith(">")]
+    allg = _gaps(product, _parse_scaffolds(product.G2S.synth_gaps(reads, 31, 10, 4200, 100, 900, 20240103)))
+    lists = [allg[:2100], allg[2100:4200], allg[:300], allg[1000:3300]]
+    monkeypatch.delenv("G2S_RESIDENT", raising=False)
+    pg = product.Graph.from_seqs(seqs, 31, 1)
+    solo = product.Session(pg, 0, d_err=500, randseed=13)
+    want = [[_key(r) for r in solo.fill_batch_onecall(L, pinned=True)] for L in lists]
+    solo.destroy()
+    team = [product.Session(pg, 0, d_err=500, randseed=13) for _ in range(nsess)]
+    try:
+        team[0].set_team(team[1:], product.G2S_GROUP_PER_SESSION)
+        for L, w in zip(lists, want):
+            got, tm = team[0].fill_batch_onecall(L, pinned=True, want_timing=True)
+            assert [_key(r) for r in got] == w
+            if len(L) >= 512 * nsess:
+                assert tm.team_d3_sharded == 1 and tm.team_groups == nsess and tm.resident_fallbacks == 0
+            else:
+                assert tm.team_groups == 0  # (too short for the team: the lead alone)
+        team[0].set_team([], 0)
+    finally:
+        for s in team:
+            s.destroy()
+        pg.free()
+
+
 def test_long_lists_go_slice_by_slice(product, monkeypatch):
     """A list beyond 20 480 gaps is filled in slices of about 16 384 (the draw-count tables of phase D3 grow with the
     square of the gaps they chain through); the rand() stream runs on from slice to slice, a slice ends where a
