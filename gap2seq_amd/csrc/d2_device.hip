@@ -151,13 +151,44 @@ __device__ __forceinline__ uint32_t merge_sorted(const uint64_t* K, uint32_t n, 
   return M;
 }
 
+// ascending bitonic sort of n2 (a power of two >= 2) 64-bit keys in LDS by one wave: lds_sort64 with four independent
+// compare-exchanges of a stage in flight per lane (the pairs of a stage are disjoint; one at a time the loop waits out an
+// LDS round trip per pair — the sorts were the kernel's largest share on closures of thousands of segments)
+__device__ __forceinline__ void d2_sort64(uint64_t* a, uint32_t n2, int lane) {
+  const uint32_t half = n2 >> 1;
+  for (uint32_t k = 2; k <= n2; k <<= 1)
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      uint32_t t = (uint32_t)lane;
+      for (; t + 192u < half; t += 256u) {
+        uint32_t i[4], l[4];
+        uint64_t p[4], q[4];
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+          const uint32_t tx = t + 64u * (uint32_t)x;
+          i[x] = ((tx & ~(j - 1u)) << 1) | (tx & (j - 1u));
+          l[x] = i[x] | j;
+          p[x] = a[i[x]]; q[x] = a[l[x]];
+        }
+#pragma unroll
+        for (int x = 0; x < 4; x++)
+          if ((p[x] > q[x]) == ((i[x] & k) == 0u)) { a[i[x]] = q[x]; a[l[x]] = p[x]; }
+      }
+      for (; t < half; t += 64u) {
+        const uint32_t i = ((t & ~(j - 1u)) << 1) | (t & (j - 1u));
+        const uint32_t l = i | j;
+        const uint64_t p = a[i], q = a[l];
+        if ((p > q) == ((i & k) == 0u)) { a[i] = q; a[l] = p; }
+      }
+      lds_sync();
+    }
+}
 // sorts K[0 .. n) (padding with the largest key), then drops repeated keys in place; returns how many are left
 __device__ __forceinline__ uint32_t sort_unique(uint64_t* K, uint32_t n, int lane) {
   if (n == 0u) return 0u;
   const uint32_t n2 = pow2_at_least(n);
   for (uint32_t i = n + (uint32_t)lane; i < n2; i += 64u) K[i] = ~0ull;
   lds_sync();
-  lds_sort64(K, n2, lane);
+  d2_sort64(K, n2, lane);
   uint32_t w = 0;
   for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
     const uint32_t i = i0 + (uint32_t)lane;
@@ -264,7 +295,7 @@ __device__ int d2_one(uint32_t* lds, const D2Args& A, uint32_t gap, uint32_t* sc
     const uint32_t n2 = pow2_at_least(ns);
     for (uint32_t i = ns + (uint32_t)lane; i < n2; i += 64u) K[i] = ~0ull;
     lds_sync();
-    lds_sort64(K, n2, lane);
+    d2_sort64(K, n2, lane);
   }
   bool overlap = false;
   const uint32_t MV = merge_sorted<true>(K, ns, false, VM, lane, &overlap);
@@ -413,7 +444,7 @@ __device__ int d2_one(uint32_t* lds, const D2Args& A, uint32_t gap, uint32_t* sc
       const uint32_t n2 = pow2_at_least(n);
       for (uint32_t i = n + (uint32_t)lane; i < n2; i += 64u) K[i] = ~0ull;
       lds_sync();
-      lds_sort64(K, n2, lane);
+      d2_sort64(K, n2, lane);
       bool ov;
       if (n_up > 0u) MU = merge_sorted<false>(K, n_up, true, UI, lane, &ov);
       if (n > n_up) MD = merge_sorted<false>(K + n_up, n - n_up, true, DI, lane, &ov);
@@ -421,7 +452,7 @@ __device__ int d2_one(uint32_t* lds, const D2Args& A, uint32_t gap, uint32_t* sc
     lds_sync();
   }
   D2_LAP(2);
-  // ---- the cuts: ends of every interval, a parent's last k-mer, sink positions
+  // ---- the cuts: ends of every interval, sink positions
   uint32_t nb = 0, npairs = 0;
   {
     uint32_t n = 0;
@@ -434,8 +465,10 @@ __device__ int d2_one(uint32_t* lds, const D2Args& A, uint32_t gap, uint32_t* sc
       const int ts = h ? s.ts() : -1;
       const bool in_s = ts >= 0;
       const int sp = in_s ? sink_pos(s) : -1;
+      // (a parent's last k-mer — post.cpp pushes it as a cut — is an end of the parent's own interval: a segment with a
+      // child on a path to a sink lies on such paths whole)
       const uint32_t np = (in_s && !s.source()) ? (uint32_t)s.npar() : 0u;
-      const uint32_t k = in_s ? 2u + np + (sp >= 0 ? 1u : 0u) : 0u;
+      const uint32_t k = in_s ? 2u + (sp >= 0 ? 1u : 0u) : 0u;
       npairs += wave_sum(np);
       const uint32_t incl = wave_scan(k, lane);
       const uint32_t tot = rl(incl, 63);
@@ -444,13 +477,6 @@ __device__ int d2_one(uint32_t* lds, const D2Args& A, uint32_t gap, uint32_t* sc
       if (in_s) {
         K[w++] = (uint64_t)s.idx(0);
         K[w++] = (uint64_t)s.idx(ts);
-        if (np)
-          for (int x = 0; x < 4; x++) {
-            const uint32_t p = s.par(x);
-            if (p == 0xFFFFu || p >= nrec) continue;
-            const SegD ps = seg_load(segs, p);
-            K[w++] = (uint64_t)ps.idx(ps.len() - 1);
-          }
         if (sp >= 0) K[w++] = (uint64_t)s.idx(sp);
       }
       n += tot;

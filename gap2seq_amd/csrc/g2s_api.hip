@@ -2785,9 +2785,9 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl) {
   if (const char* env = getenv("G2S_DEVICE_D2")) dev_d2 = dev_d2 && atoi(env) != 0;
   else dev_d2 = dev_d2 && ids.size() >= 3072 && b->dmax < 2500;
   // (the large instantiation always rides along on that stream: what the small one cannot take is passed on, not lost)
-  const bool d2_big = dev_d2;
+  const bool d2_big = dev_d2 && !(getenv("G2S_D2_BIG") && atoi(getenv("G2S_D2_BIG")) == 0);  // (=0: measurements)
   const bool d2_deep = dev_d2 && b->dmax >= 2500;
-  const uint32_t d2_small_wgs = (uint32_t)std::min<size_t>(ids.size(), (size_t)std::max(1, s->num_cus) * 4u);
+  const uint32_t d2_small_wgs = (uint32_t)std::min<size_t>(ids.size(), (size_t)std::max(1, s->num_cus) * 2u);
   const uint32_t d2_big_wgs = (uint32_t)std::min<size_t>(ids.size(), (size_t)std::max(1, s->num_cus));
   const uint64_t d2_run_cap = out_states + 65536u;
   if (dev_d2) {
