@@ -39,8 +39,8 @@ struct D2Args {
   const uint32_t* flank_nodes;
   GapOut* outs;
   SubRec* sub;                          // the closures (SegRec), where the fill kernels left them
-  const uint32_t* list;                 // the gaps to analyse ...
-  const unsigned long long* count;      // ... how many (device memory: the fill kernels counted them)
+  uint32_t* list;                       // the gaps to analyse (| tag, when the fill kernels tag their entries) ...
+  const unsigned long long* count;      // ... how many (device memory: the fill kernels count them)
   unsigned long long* next;             // work counter of this launch (zero before it)
   uint32_t* list_next;                  // small instantiation: the gaps it passes on, counted in *count_next
   unsigned long long* count_next;
@@ -54,11 +54,21 @@ struct D2Args {
   uint32_t pass_all;                    // (tests) bit 0: the small instantiation passes every gap on to the large one; bit 1: no chains are contracted
   unsigned long long* prof;             // (tools, may be null) 16 counters: cycles per section of the analysis, summed over gaps
   unsigned long long* wgs_done;         // workgroups of g2s_d2_* that are through (the trace kernel's last wave waits for all of them)
+  // entries carry this tag in bits 24-31 (0: plain gap numbers); poll: the launch runs BESIDE the fill kernel and takes
+  // entries as they appear, until the 64 counters at `done` add up to `expected` (every gap of the fill launch is
+  // through) and the list is empty
+  uint32_t tag, poll;
+  const unsigned long long* done;
+  unsigned long long expected;
 };
 
 size_t d2_scratch_bytes(bool big, uint32_t workgroups);
 // both instantiations behind each other on the stream: small (many workgroups a compute unit), then large (one)
 hipError_t launch_d2(hipStream_t st, const D2Args& A, uint32_t small_wgs, uint32_t big_wgs, uint32_t* scratch_small,
                      uint32_t* scratch_big, uint32_t* list_big, unsigned long long* count_big, unsigned long long* next_big);
+// the small instantiation beside the fill kernel (A.poll, A.done, A.expected, A.tag set): a few workgroups that take
+// the closures as their gaps end; launch_d2 follows behind the fill kernels for what is left
+hipError_t launch_d2_poll(hipStream_t st, const D2Args& A, uint32_t wgs, uint32_t* scratch_small, uint32_t* list_big,
+                          unsigned long long* count_big);
 
 }  // namespace g2s

@@ -1015,16 +1015,58 @@ __device__ int d2_one(uint32_t* lds, const D2Args& A, uint32_t gap, uint32_t* sc
   return 0;
 }
 
+// the next gap of the list for this workgroup, or D2_NONE when there is none (and, polling, none can come any more)
+__device__ __forceinline__ uint32_t d2_claim(const D2Args& A) {
+  uint32_t gap = D2_NONE;
+  if (threadIdx.x == 0) {
+    for (uint32_t spins = 0;;) {
+      const unsigned long long cur = __hip_atomic_load(A.next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long cnt = __hip_atomic_load(A.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (cur < cnt && cur < (unsigned long long)A.list_cap) {
+        if (atomicCAS(A.next, cur, cur + 1ull) != cur) continue;  // (another workgroup took it)
+        uint32_t e = 0;
+        if (A.tag) {  // (the entry follows its counter: wait for this list's tag, then leave the place clean)
+          for (uint32_t w = 0; w < (1u << 24); w++) {
+            e = __hip_atomic_load(&A.list[cur], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((e & 0xFF000000u) == A.tag) break;
+            __builtin_amdgcn_s_sleep(4);
+          }
+          if ((e & 0xFF000000u) != A.tag) continue;  // (never expected: the gap stays pending and the list goes to the host path)
+          __hip_atomic_store(&A.list[cur], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          e &= 0x00FFFFFFu;
+        } else e = A.list[cur];
+        gap = e;
+        break;
+      }
+      if (!A.poll) break;
+      // (a look at the list every few microseconds; at the 64 counters that say whether anything can still come only
+      // every eighth time: 64 loads from the L2 that the fill kernel's own atomics go through)
+      if ((spins & 7u) == 7u) {
+        unsigned long long through = 0;
+        for (int q = 0; q < 64; q++) through += __hip_atomic_load(A.done + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (through >= A.expected) {  // every gap of the fill launch is through: what is listed now is all there will be
+          if (__hip_atomic_load(A.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >
+              __hip_atomic_load(A.next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) continue;
+          break;
+        }
+      }
+      if (++spins > (1u << 17)) break;  // (half a second: a defect must not hold the GPU; what is left is taken by the launch behind the fill kernels)
+      __builtin_amdgcn_s_sleep(127);
+      __builtin_amdgcn_s_sleep(127);
+    }
+  }
+  return uni(gap);
+}
+
 template <class C>
 __device__ __forceinline__ void d2_loop(uint32_t* lds, const D2Args& A) {
   uint32_t* scr = A.scratch + (size_t)blockIdx.x * C::SCR_WORDS;
-  const unsigned long long n = *A.count;
   for (;;) {
-    unsigned long long x = 0;
-    if (threadIdx.x == 0) x = atomicAdd(A.next, 1ull);
-    x = ((unsigned long long)uni((uint32_t)(x >> 32)) << 32) | uni((uint32_t)x);
-    if (x >= n || x >= (unsigned long long)A.list_cap) break;
-    const uint32_t gap = uni(A.list[x]);
+    const uint32_t gap = d2_claim(A);
+    if (gap == D2_NONE) break;
+    // (an entry taken while the fill kernel runs: with the fill wave's fence in front of it, record and closure are here;
+    // a launch behind the fill kernels sees everything anyway)
+    if (A.tag) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     const int rc = ((A.pass_all & 1u) && A.list_next) ? 1 : d2_one<C>(lds, A, gap, scr);
     if (A.prof && rc != 0 && threadIdx.x == 0) atomicAdd(A.prof + 13 + rc, 1ull);  // (14: beyond the capacities, 15: given up)
     if (rc == 1 && A.list_next && threadIdx.x == 0) {  // beyond these capacities: the larger instantiation's
@@ -1063,12 +1105,14 @@ hipError_t launch_d2(hipStream_t st, const D2Args& A0, uint32_t small_wgs, uint3
   e = hipFuncSetAttribute((const void*)g2s_d2_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)D2Big::LDS_BYTES);
   if (e != hipSuccess) return e;
   D2Args A = A0;
+  A.poll = 0u;
   A.scratch = scratch_small;
   A.list_next = big_wgs ? list_big : nullptr;
   A.count_next = count_big;
   hipLaunchKernelGGL(g2s_d2_small, dim3(std::max(1u, small_wgs)), dim3(64), D2Small::LDS_BYTES, st, A);
   if (big_wgs == 0u) return hipGetLastError();  // (a list without deep searches: what the small one cannot take is the host's)
   D2Args B = A0;
+  B.tag = 0u; B.poll = 0u;  // (the entries the small instantiation passes on are plain)
   B.list = list_big;
   B.count = count_big;
   B.next = next_big;
@@ -1076,6 +1120,18 @@ hipError_t launch_d2(hipStream_t st, const D2Args& A0, uint32_t small_wgs, uint3
   B.list_next = nullptr;
   B.count_next = nullptr;
   hipLaunchKernelGGL(g2s_d2_big, dim3(std::max(1u, big_wgs)), dim3(64), D2Big::LDS_BYTES, st, B);
+  return hipGetLastError();
+}
+
+hipError_t launch_d2_poll(hipStream_t st, const D2Args& A0, uint32_t wgs, uint32_t* scratch_small, uint32_t* list_big,
+                          unsigned long long* count_big) {
+  hipError_t e = hipFuncSetAttribute((const void*)g2s_d2_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)D2Small::LDS_BYTES);
+  if (e != hipSuccess) return e;
+  D2Args A = A0;
+  A.scratch = scratch_small;
+  A.list_next = list_big;
+  A.count_next = count_big;
+  hipLaunchKernelGGL(g2s_d2_small, dim3(std::max(1u, wgs)), dim3(64), D2Small::LDS_BYTES, st, A);
   return hipGetLastError();
 }
 

@@ -39,7 +39,7 @@ hipError_t launch_fill_seg(hipStream_t st, uint32_t ngaps, const uint32_t* succ,
                            bool resident = false, uint32_t* ovf_list = nullptr,
                            // (resident) the gaps whose closure the kernel leaves unanalysed, counted in out_counter[4]:
                            // g2s_d2_* (d2_device.hip) behind the fill kernels; null: the host analyses them
-                           uint32_t* d2_list = nullptr);
+                           uint32_t* d2_list = nullptr, uint32_t d2_tag = 0u /* SegArgs.d2_tag */);
 
 // The large variant: `workgroups` persistent workgroups (one per compute unit) take the listed gaps
 // in order from the counter *next_gap (zero before the launch); scratch: fill_segx_scratch_bytes().
@@ -74,6 +74,6 @@ hipError_t launch_fill_segw(hipStream_t st, uint32_t ngaps, uint32_t workgroups,
                             // was written by the launch in front: launch_fill_seg's ovf_list); ngaps is then the most
                             // there can be
                             const unsigned long long* ngaps_dev = nullptr, const SegEarly* early = nullptr,
-                            uint32_t* d2_list = nullptr /* as launch_fill_seg */);
+                            uint32_t* d2_list = nullptr, uint32_t d2_tag = 0u /* as launch_fill_seg */);
 
 }  // namespace g2s

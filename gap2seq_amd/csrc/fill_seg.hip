@@ -312,6 +312,9 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
     if (A.resident) {
       if (A.ovf_list && lane == 0 && (flags & (G2S_DEV_OVERFLOW_A | G2S_DEV_OVERFLOW_B)) && !(flags & G2S_DEV_WATCHDOG))
         A.ovf_list[atomicAdd(out_counter + 1, 1ull)] = gi;
+      // (this gap is through: what a polling g2s_d2_small counts to know that no entry can come any more — behind the
+      // gap's own entry, whose counter this wave has waited for; 64 counters, the result not asked for)
+      if (A.d2_list && A.d2_tag && lane == 0) (void)atomicAdd(out_counter + 32 + (gi & 63u), 1ull);
       return;
     }
     if constexpr (BIG) __threadfence();
@@ -1853,7 +1856,6 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
     const bool to_d2 = A.d2_list && want_s && !analysed;  // (d2_device.hip takes it)
     go->dflags = (analysed || !want_s ? G2S_DEVA_ANALYSED : 0u) | (choice ? G2S_DEVA_CHOICE : 0u) | (sink_safe ? G2S_DEVA_SINK_SAFE : 0u) |
                  (to_d2 ? G2S_DEVA_D2_PENDING : 0u);
-    if (to_d2) A.d2_list[atomicAdd(out_counter + 4, 1ull)] = gi;
     go->flags = flags | G2S_DEV_COMPACT;
     go->n_sub = nsub;
     go->n_xp = nxp;
@@ -1862,6 +1864,11 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
     go->x_sub = nsub;
     go->stat[6] = gen;
     go->stat[7] = (uint32_t)((__builtin_amdgcn_s_memtime() - cyc2) >> 8);
+    if (to_d2) {  // (record and closure are in device memory in front of the entry: g2s_d2_small may be polling the list)
+      __threadfence();
+      const unsigned long long at = atomicAdd(out_counter + 4, 1ull);
+      __hip_atomic_store(&A.d2_list[at], gi | A.d2_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 #ifdef G2S_SEG_PROFILE
   SEG_PROF_TAIL(4);
@@ -1923,7 +1930,7 @@ hipError_t launch_fill_seg(hipStream_t st, uint32_t ngaps, const uint32_t* succ,
                            unsigned long long out_cap, unsigned long long* out_counter, GapOut* outs, GapOut* outs_host,
                            uint32_t* done_list, int skip_confident, uint32_t* dbg, bool two_waves, unsigned long long* xcd_tickets,
                            uint32_t* xcd_list, uint32_t xcd_stride, uint32_t pub_batch, bool resident, uint32_t* ovf_list,
-                           uint32_t* d2_list) {
+                           uint32_t* d2_list, uint32_t d2_tag) {
   if (ngaps == 0) return hipSuccess;
   size_t bytes = two_waves ? fill_seg2_lds_bytes() : fill_seg_lds_bytes();
   // (G2S_SEG_LDS_PAD=BYTES, measurements only: a larger LDS request per gap = fewer gaps resident per compute unit)
@@ -1934,7 +1941,8 @@ hipError_t launch_fill_seg(hipStream_t st, uint32_t ngaps, const uint32_t* succ,
   if (!xcd_tickets || !xcd_list || pub_batch < 2u || pub_batch > 64u || (pub_batch & (pub_batch - 1u))) pub_batch = 1u;
   const SegArgs A = {succ, urec, gaps, gap_ids, flank_nodes, sub_out, out_cap, out_counter, outs, outs_host, done_list,
                      skip_confident, dbg, fill_seg_dbg_words(), xcd_tickets, xcd_list, xcd_stride, pub_batch, resident ? 1u : 0u,
-                     0u, resident ? ovf_list : nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0u, resident ? d2_list : nullptr};
+                     0u, resident ? ovf_list : nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0u, resident ? d2_list : nullptr,
+                     resident ? d2_tag : 0u};
   if (two_waves) hipLaunchKernelGGL(g2s_fill_seg2, dim3(ngaps), dim3(128), bytes, st, A);
   else hipLaunchKernelGGL(g2s_fill_seg, dim3(ngaps), dim3(64), bytes, st, A);
   return hipGetLastError();

@@ -1280,7 +1280,6 @@ __device__ __forceinline__ void segw_fill_one(uint32_t* lds, const SegArgs& A, c
     const bool to_d2 = A.d2_list && want_s && !analysed;  // (d2_device.hip takes it)
     go->dflags = (analysed || !want_s ? G2S_DEVA_ANALYSED : 0u) | (choice ? G2S_DEVA_CHOICE : 0u) | (sink_safe ? G2S_DEVA_SINK_SAFE : 0u) |
                  (to_d2 ? G2S_DEVA_D2_PENDING : 0u);
-    if (to_d2) A.d2_list[atomicAdd(out_counter + 4, 1ull)] = gi;
     go->flags = flags | G2S_DEV_COMPACT;
     go->n_sub = nsub;
     go->n_xp = sh[SH_NXP];
@@ -1289,6 +1288,11 @@ __device__ __forceinline__ void segw_fill_one(uint32_t* lds, const SegArgs& A, c
     go->x_sub = nsub;
     go->stat[6] = gen;
     go->stat[7] = (uint32_t)((__builtin_amdgcn_s_memtime() - cyc2) >> 8);
+    if (to_d2) {  // (as in fill_seg.hip: the entry carries the list's tag)
+      __threadfence();
+      const unsigned long long at = atomicAdd(out_counter + 4, 1ull);
+      __hip_atomic_store(&A.d2_list[at], gi | A.d2_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (eslot != 0xFFFFFFFFu) {  // the item: the gap's record, then what says it is complete
       if (edst) {
         static_assert(sizeof(GapOut) % 16 == 0, "GapOut is copied in 16-byte words");
@@ -1349,7 +1353,7 @@ hipError_t launch_fill_segw(hipStream_t st, uint32_t ngaps, uint32_t workgroups,
                             unsigned long long out_cap, unsigned long long* out_counter, GapOut* outs, GapOut* outs_host,
                             uint32_t* done_list, int skip_confident, uint32_t* dbg, uint32_t* scratch,
                             unsigned long long* next_gap, bool resident, const unsigned long long* ngaps_dev, const SegEarly* early,
-                            uint32_t* d2_list) {
+                            uint32_t* d2_list, uint32_t d2_tag) {
   if (ngaps == 0) return hipSuccess;
   const size_t bytes = fill_segw_lds_bytes();
   hipError_t e = hipFuncSetAttribute((const void*)g2s_fill_segw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
@@ -1357,7 +1361,7 @@ hipError_t launch_fill_segw(hipStream_t st, uint32_t ngaps, uint32_t workgroups,
   SegArgs A = {succ, urec, gaps, gap_ids, flank_nodes, sub_out, out_cap, out_counter, outs, outs_host, done_list,
                skip_confident, dbg, fill_segx_dbg_words(), nullptr, nullptr, 0u, 1u, resident ? 1u : 0u, 0u, nullptr,
                early ? early->segs : nullptr, early ? early->items : nullptr, early ? early->outs : nullptr,
-               early ? early->ctr : nullptr, early ? early->cap_items : 0u, early ? early->cap_segs : 0u, resident ? d2_list : nullptr};
+               early ? early->ctr : nullptr, early ? early->cap_items : 0u, early ? early->cap_segs : 0u, resident ? d2_list : nullptr, resident ? d2_tag : 0u};
   hipLaunchKernelGGL(g2s_fill_segw, dim3(workgroups), dim3(SEGW_NT), bytes, st, A, scratch, ngaps, next_gap, ngaps_dev);
   return hipGetLastError();
 }

@@ -573,6 +573,9 @@ struct g2s_session {
   bool d2_wait = false;      // ... and phase D3's hand-off waits for it (deep lists: their trace waves would keep its
                              // large instantiation off the compute units); else the trace waves of its gaps do
   uint32_t d2_wgs = 0;       // workgroups of g2s_d2_* behind the last fill launch
+  uint32_t d2_lists = 0;     // lists whose fill kernels tagged their entries for a polling g2s_d2_small (the tag's low bits)
+  unsigned long long d2_done_total = 0;  // gaps those fill launches counted as through, all lists (the counters only grow)
+  const void* d2_ctr_seen = nullptr;     // the counter buffer those counts live in
   bool d2_prof_on = false;   // (G2S_D2_PROF) the section counters behind the cursors have been zeroed
   int num_cus = 256;
   DevBuf d_rspool;
@@ -2766,7 +2769,11 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl) {
   HIP_TRY_S(s->d_outs.ensure(n * sizeof(GapOut)));
   // ([0] closure cursor, [1] overflow list, [2] [3] work counters of the large variant's two launches; d2_device.hip:
   // [4] gaps listed, [5] small instantiation's work counter, [6] gaps passed on, [7] large one's work counter, [8] runs)
-  HIP_TRY_S(s->d_counter.ensure(256));  // ([16 .. 31]: G2S_D2_PROF, never zeroed by the kernels)
+  HIP_TRY_S(s->d_counter.ensure(1024));  // ([16 .. 31]: G2S_D2_PROF; [32 .. 95]: gaps through, for a polling g2s_d2_small — neither zeroed by the kernels)
+  if (s->d_counter.p != s->d2_ctr_seen) {  // (a fresh buffer: the counters that only grow start at zero)
+    HIP_TRY_S(hipMemset((char*)s->d_counter.p + 128, 0, 1024 - 128));
+    s->d2_ctr_seen = s->d_counter.p; s->d2_done_total = 0; s->d2_prof_on = false;
+  }
   HIP_TRY_S(s->d_sub.ensure(out_states * sizeof(SubRec)));
   const uint32_t segw_wgs = (uint32_t)std::min<size_t>(ids.size(), (size_t)std::max(1, s->num_cus));
   // Phase D2 on the device for the closures the fill kernels do not analyse themselves (d2_device.hip: more than 192
@@ -2787,8 +2794,24 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl) {
   // (the large instantiation always rides along on that stream: what the small one cannot take is passed on, not lost)
   const bool d2_big = dev_d2 && !(getenv("G2S_D2_BIG") && atoi(getenv("G2S_D2_BIG")) == 0);  // (=0: measurements)
   const bool d2_deep = dev_d2 && b->dmax >= 2500;
-  const uint32_t d2_small_wgs = (uint32_t)std::min<size_t>(ids.size(), (size_t)std::max(1, s->num_cus) * 2u);
-  const uint32_t d2_big_wgs = (uint32_t)std::min<size_t>(ids.size(), (size_t)std::max(1, s->num_cus));
+  // G2S_D2_POLL=1 (measurements): a few workgroups of the small instantiation run BESIDE the fill kernel and take the
+  // closures as their gaps end (the fill launch ends with its slowest gaps: most of its wave slots are empty for its
+  // last third) — what is listed late is taken by the launch behind the fill kernels.  Not on deep lists (the large
+  // variant holds the compute units' LDS).  It relies on the third stream's kernels not sharing a hardware queue with
+  // the fill kernel's stream (a polling kernel in front of the fill kernel in one queue would wait out its bound).
+  // (measured, config 3: 0.93-0.96 ms per step against 0.89-0.92 with everything behind the fill kernel — the polling waves
+  // cost the fill kernel 5 % — so: only with G2S_D2_POLL=1)
+  const bool d2_poll = dev_d2 && !d2_deep && getenv("G2S_D2_POLL") && atoi(getenv("G2S_D2_POLL")) == 1;
+  const uint32_t d2_poll_wgs = d2_poll ? (uint32_t)std::min<size_t>(ids.size(), (size_t)std::max(1, atoi(getenv("G2S_D2_POLL_WGS") ? getenv("G2S_D2_POLL_WGS") : "16"))) : 0u;
+  const uint32_t d2_tag = d2_poll ? (0x80000000u | ((++s->d2_lists & 0x7Fu) << 24)) : 0u;
+  // (how many workgroups: the trace kernel's last wave waits until every one of them has left, and they are dispatched
+  // beside that kernel's 10 000 waves — config 3's list, 70 closures: 0.89 ms per step with 128 workgroups, 1.2 with 512,
+  // 1.6 with 1 024, profiles/r05_d2_workgroups_c3.txt; a deep list has hundreds of closures and waits for the kernel anyway)
+  const uint32_t d2_small_wgs = (uint32_t)std::min<size_t>(ids.size(), getenv("G2S_D2_SMALL_WGS") ? (size_t)std::max(1, atoi(getenv("G2S_D2_SMALL_WGS")))
+                                                                                   : (b->dmax >= 2500 ? (size_t)std::max(1, s->num_cus) * 2u : (size_t)128));
+  // (the large instantiation's workgroups need a whole compute unit's LDS each: on a list that is not deep only a few
+  // are launched — what the small one passes on there is rare —, so that they find their units beside the trace kernel)
+  const uint32_t d2_big_wgs = (uint32_t)std::min<size_t>(ids.size(), b->dmax >= 2500 ? (size_t)std::max(1, s->num_cus) : (size_t)8);
   const uint64_t d2_run_cap = out_states + 65536u;
   if (dev_d2) {
     HIP_TRY_S(s->d_d2list.ensure(std::max<size_t>(2 * n * 4, 16)));
@@ -2800,7 +2823,7 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl) {
   }
   s->d2_launched = dev_d2;
   s->d2_wait = d2_deep;  // (the trace waves of a deep list hold so much LDS that the large instantiation might find no unit)
-  s->d2_wgs = dev_d2 ? d2_small_wgs + (d2_big ? d2_big_wgs : 0u) : 0u;
+  s->d2_wgs = dev_d2 ? d2_poll_wgs + d2_small_wgs + (d2_big ? d2_big_wgs : 0u) : 0u;
   if (rerun) {
     HIP_TRY_S(s->d_ovf.ensure(std::max<size_t>(ids.size() * 4, 16)));
     HIP_TRY_S(s->d_segx.ensure(fill_segw_scratch_bytes(segw_wgs)));
@@ -2849,13 +2872,37 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl) {
   // (the early launch of the large variant — see n_early above: behind everything the stream has prepared, beside the
   // regular tier's kernel; its gaps' records and closures go where the others' do, through the same cursors)
   if (n_early && rerun) HIP_TRY_S(hipEventRecord(s->ev_pre, st));  // (what the early launch waits for: not the regular tier's kernel)
+  D2Args DA;
+  memset(&DA, 0, sizeof DA);
+  if (dev_d2) {
+    unsigned long long* ctr = (unsigned long long*)s->d_counter.p;
+    DA.gaps = gaps_dev; DA.flank_nodes = (const uint32_t*)s->d_flank.p; DA.outs = (GapOut*)s->d_outs.p; DA.sub = (SubRec*)s->d_sub.p;
+    DA.list = (uint32_t*)s->d_d2list.p; DA.count = ctr + 4; DA.next = ctr + 5;
+    DA.d2out = (D2Out*)s->d_d2out.p; DA.runs = (uint32_t*)s->d_d2runs.p; DA.run_cursor = ctr + 8; DA.run_cap = d2_run_cap;
+    DA.all_paths = s->params.all_paths ? 1 : 0; DA.list_cap = (uint32_t)n;
+    DA.wgs_done = ctr + 9;
+    DA.tag = d2_tag;
+    static const bool d2_prof = getenv("G2S_D2_PROF") != nullptr;
+    if (d2_prof) { s->d2_prof_on = true; DA.prof = ctr + 16; }
+    DA.pass_all = (getenv("G2S_D2_BIG") && atoi(getenv("G2S_D2_BIG")) == 2) ? 1u : 0u;  // (tests: every closure through the large instantiation)
+    if (getenv("G2S_D2_NO_CHAINS")) DA.pass_all |= 2u;  // (tests: no node counts as pass-through — the whole graph of runs goes through the component search)
+  }
+  if (d2_poll) {  // (beside the fill kernel: behind everything the stream has prepared for it)
+    s->d2_done_total += n_reg;
+    D2Args DP = DA;
+    DP.poll = 1u; DP.done = (const unsigned long long*)s->d_counter.p + 32; DP.expected = s->d2_done_total;
+    if (!(n_early && rerun)) HIP_TRY_S(hipEventRecord(s->ev_pre, st));
+    HIP_TRY_S(hipStreamWaitEvent(s->stream3, s->ev_pre, 0));
+    HIP_TRY_S(launch_d2_poll(s->stream3, DP, d2_poll_wgs, (uint32_t*)s->d_d2scr_small.p, (uint32_t*)s->d_d2list.p + n,
+                             (unsigned long long*)s->d_counter.p + 6));
+  }
   rl->timed = kernel_events_on(s);
   if (rl->timed) HIP_TRY_S(hipEventRecord(s->ev[1], st));
   HIP_TRY_S(launch_fill_seg(st, (uint32_t)n_reg, dg.succ, dg.urec, gaps_dev, ids_dev, (const uint32_t*)s->d_flank.p,
                           (SubRec*)s->d_sub.p, (unsigned long long)out_states, (unsigned long long*)s->d_counter.p,
                           (GapOut*)s->d_outs.p, nullptr, nullptr, s->params.skip_confident ? 1 : 0, nullptr, two_waves,
                           nullptr, nullptr, 0u, 1u, true, rerun ? (uint32_t*)s->d_ovf.p : nullptr,
-                          dev_d2 ? (uint32_t*)s->d_d2list.p : nullptr));
+                          dev_d2 ? (uint32_t*)s->d_d2list.p : nullptr, d2_tag));
   if (rl->timed) HIP_TRY_S(hipEventRecord(s->ev[2], st));
   // (queued BEHIND the regular tier's kernel, which takes the compute units first — a workgroup of the large variant
   // needs a whole unit's LDS and stays for the launch: started first, 256 of them leave the regular tier no unit until
@@ -2870,7 +2917,7 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl) {
                                (unsigned long long*)s->d_counter.p, (GapOut*)s->d_outs.p, nullptr, nullptr,
                                s->params.skip_confident ? 1 : 0, nullptr, (uint32_t*)s->d_segx1.p,
                                (unsigned long long*)s->d_counter.p + 3, true, nullptr, early_dev.items ? &early_dev : nullptr,
-                               dev_d2 ? (uint32_t*)s->d_d2list.p : nullptr));
+                               dev_d2 ? (uint32_t*)s->d_d2list.p : nullptr, d2_tag));
     HIP_TRY_S(hipEventRecord(s->ev_early, s->stream3));
   }
   // (the large variant for what the launch above listed: its workgroups read the list's length from device memory and
@@ -2881,29 +2928,14 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl) {
                              (unsigned long long*)s->d_counter.p, (GapOut*)s->d_outs.p, nullptr, nullptr,
                              s->params.skip_confident ? 1 : 0, nullptr, (uint32_t*)s->d_segx.p,
                              (unsigned long long*)s->d_counter.p + 2, true, (const unsigned long long*)s->d_counter.p + 1,
-                             early_dev.items ? &early_dev : nullptr, dev_d2 ? (uint32_t*)s->d_d2list.p : nullptr));
+                             early_dev.items ? &early_dev : nullptr, dev_d2 ? (uint32_t*)s->d_d2list.p : nullptr, d2_tag));
   if (n_early && rerun) HIP_TRY_S(hipStreamWaitEvent(st, s->ev_early, 0));  // (phase D3 follows on this stream: behind both)
   if (dev_d2) {  // (its workgroups read the list's length from device memory and leave at once when it is empty)
-    D2Args DA;
-    memset(&DA, 0, sizeof DA);
-    unsigned long long* ctr = (unsigned long long*)s->d_counter.p;
-    DA.gaps = gaps_dev; DA.flank_nodes = (const uint32_t*)s->d_flank.p; DA.outs = (GapOut*)s->d_outs.p; DA.sub = (SubRec*)s->d_sub.p;
-    DA.list = (const uint32_t*)s->d_d2list.p; DA.count = ctr + 4; DA.next = ctr + 5;
-    DA.d2out = (D2Out*)s->d_d2out.p; DA.runs = (uint32_t*)s->d_d2runs.p; DA.run_cursor = ctr + 8; DA.run_cap = d2_run_cap;
-    DA.all_paths = s->params.all_paths ? 1 : 0; DA.list_cap = (uint32_t)n;
-    DA.wgs_done = ctr + 9;
-    static const bool d2_prof = getenv("G2S_D2_PROF") != nullptr;
-    if (d2_prof) {
-      if (!s->d2_prof_on) { HIP_TRY_S(hipMemsetAsync((char*)s->d_counter.p + 128, 0, 128, st)); s->d2_prof_on = true; }
-      DA.prof = ctr + 16;
-    }
-    DA.pass_all = (getenv("G2S_D2_BIG") && atoi(getenv("G2S_D2_BIG")) == 2) ? 1u : 0u;  // (tests: every closure through the large instantiation)
-    if (getenv("G2S_D2_NO_CHAINS")) DA.pass_all |= 2u;  // (tests: no node counts as pass-through — the whole graph of runs goes through the component search)
     // (on the third stream, behind the fill kernels: phase D3's first kernels do not wait for it — launch_d3)
     HIP_TRY_S(hipEventRecord(s->ev_fill, st));
     HIP_TRY_S(hipStreamWaitEvent(s->stream3, s->ev_fill, 0));
     HIP_TRY_S(launch_d2(s->stream3, DA, d2_small_wgs, d2_big ? d2_big_wgs : 0u, (uint32_t*)s->d_d2scr_small.p, (uint32_t*)s->d_d2scr_big.p,
-                        (uint32_t*)s->d_d2list.p + n, ctr + 6, ctr + 7));
+                        (uint32_t*)s->d_d2list.p + n, (unsigned long long*)s->d_counter.p + 6, (unsigned long long*)s->d_counter.p + 7));
     HIP_TRY_S(hipEventRecord(s->ev_d2, s->stream3));
   }
   if (rerun && rl->timed) HIP_TRY_S(hipEventRecord(s->ev_segw, st));

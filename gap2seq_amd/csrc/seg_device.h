@@ -196,6 +196,10 @@ struct SegArgs {
   // depths) enters itself here, counted in out_counter[4]: g2s_d2_* (d2_device.hip) follows on the stream.  Null: such
   // gaps are the host's (post.cpp).
   uint32_t* d2_list;
+  // ... as gap | d2_tag (0x80 | the list's number mod 128, in bits 24-31): g2s_d2_small may be polling the list while
+  // this kernel runs, and takes an entry only when it carries this list's tag (the gap's record and closure are
+  // written, and fenced, in front of it).  out_counter[32 + (gap & 63)] counts the gaps that are through.
+  uint32_t d2_tag;
 };
 
 // LDS of the large variant (words): see the layout notes at each phase

@@ -65,18 +65,19 @@ def test_resident_mode_equals_the_host_path(product, monkeypatch, mode, pinned):
     assert sum(1 for r in d1 if r[0] > 0) > 600
 
 
-@pytest.mark.parametrize("how", ["default", "host", "small", "large", "no_chains"])
+@pytest.mark.parametrize("how", ["default", "host", "small", "large", "no_chains", "beside"])
 def test_phase_d2_on_the_device_equals_the_hosts(product, monkeypatch, how):
     """The closures the fill kernels do not analyse themselves (a k-mer at several depths, more than 192 segments):
     analysed by g2s_d2_small / g2s_d2_big on a stream of their own and traced by the trace kernel from their runs (the
     default from 3 072 gaps on; "small": forced on a shorter list; "large": every one of them through the large
-    instantiation, G2S_D2_BIG=2; "no_chains": the whole graph of runs through the component search), or handed to the
+    instantiation, G2S_D2_BIG=2; "no_chains": the whole graph of runs through the component search; "beside": part of
+    them taken by workgroups that poll the list while the fill kernel runs), or handed to the
     host's threads (G2S_DEVICE_D2=0: round 4's way, post.cpp) — every field of every result and the subgraph statistics
     equal the host path's either way."""
     reads = product.G2S.synth_genome(200000, 3, 20240101)
     seqs = [ln for ln in reads.splitlines() if not ln.startswith(">")]
     gaps = _parse_scaffolds(product.G2S.synth_gaps(reads, 31, 10, 3300 if how in ("default", "host") else 1500, 100, 900, 20240103))
-    for k in ("G2S_DEVICE_D2", "G2S_D2_BIG", "G2S_D2_NO_CHAINS"):
+    for k in ("G2S_DEVICE_D2", "G2S_D2_BIG", "G2S_D2_NO_CHAINS", "G2S_D2_POLL"):
         monkeypatch.delenv(k, raising=False)
     for mode_kw in ({}, dict(all_paths=False)):
         h1, h2, th, _ = _run(product, monkeypatch, False, seqs, 31, gaps, 500, **mode_kw)
@@ -88,6 +89,8 @@ def test_phase_d2_on_the_device_equals_the_hosts(product, monkeypatch, how):
             monkeypatch.setenv("G2S_D2_BIG", "2")
         if how == "no_chains":
             monkeypatch.setenv("G2S_D2_NO_CHAINS", "1")
+        if how == "beside":  # (a few workgroups of g2s_d2_small beside the fill kernel, polling the list: G2S_D2_POLL=1)
+            monkeypatch.setenv("G2S_D2_POLL", "1")
         d1, d2, td, td2 = _run(product, monkeypatch, True, seqs, 31, gaps, 500, pinned=True, **mode_kw)
         assert td.resident_launches == 1 and td.resident_fallbacks == 0
         assert d1 == h1 and d2 == h2
