@@ -2808,7 +2808,7 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl) {
   // beside that kernel's 10 000 waves — config 3's list, 70 closures: 0.89 ms per step with 128 workgroups, 1.2 with 512,
   // 1.6 with 1 024, profiles/r05_d2_workgroups_c3.txt; a deep list has hundreds of closures and waits for the kernel anyway)
   const uint32_t d2_small_wgs = (uint32_t)std::min<size_t>(ids.size(), getenv("G2S_D2_SMALL_WGS") ? (size_t)std::max(1, atoi(getenv("G2S_D2_SMALL_WGS")))
-                                                                                   : (b->dmax >= 2500 ? (size_t)std::max(1, s->num_cus) * 2u : (size_t)128));
+                                                                                   : (b->dmax >= 2500 ? (size_t)std::max(1, s->num_cus) * 4u : (size_t)128));
   // (the large instantiation's workgroups need a whole compute unit's LDS each: on a list that is not deep only a few
   // are launched — what the small one passes on there is rare —, so that they find their units beside the trace kernel)
   const uint32_t d2_big_wgs = (uint32_t)std::min<size_t>(ids.size(), b->dmax >= 2500 ? (size_t)std::max(1, s->num_cus) : (size_t)8);
