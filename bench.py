@@ -605,9 +605,11 @@ def main():
     traffic, traffic_src = None, None
     # HBM bytes per launch of that kernel from the committed counter passes of this workload (rocprofv3 --pmc
     # FETCH_SIZE / WRITE_SIZE in passes of their own, gfx950 read-side correction: tools/pmc_summary.py)
-    pmc = os.path.join(ROOT, "profiles", "r04_pmc_%s.json" % cfg_name.lower())
-    if not os.path.exists(pmc):
-        pmc = os.path.join(ROOT, "profiles", "r03_pmc_%s.json" % cfg_name.lower())
+    pmc = None
+    for rnd in ("r05", "r04", "r03"):  # (the latest round that holds counter passes of this workload)
+        pmc = os.path.join(ROOT, "profiles", "%s_pmc_%s.json" % (rnd, cfg_name.lower()))
+        if os.path.exists(pmc):
+            break
     if os.path.exists(pmc) and not custom and ngpu == 1:
         try:
             pj = json.load(open(pmc))
