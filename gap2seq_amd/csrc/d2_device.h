@@ -28,6 +28,9 @@ static_assert(sizeof(D2Out) == 32, "D2Out layout");
 #define G2S_D2_SMALL_BP 1024u
 #define G2S_D2_SMALL_NV 512u
 #define G2S_D2_SMALL_E 1024u
+#ifndef G2S_D2_BIG_NT
+#define G2S_D2_BIG_NT 1024u  // threads of a workgroup of the large instantiation
+#endif
 #define G2S_D2_BIG_NS 4096u
 #define G2S_D2_BIG_NREC 16384u
 #define G2S_D2_BIG_BP 16384u
@@ -52,7 +55,10 @@ struct D2Args {
   int32_t all_paths;
   uint32_t list_cap;                    // most gaps the list can hold (the grid is sized by it)
   uint32_t pass_all;                    // (tests) bit 0: the small instantiation passes every gap on to the large one; bit 1: no chains are contracted
-  unsigned long long* prof;             // (tools, may be null) 16 counters: cycles per section of the analysis, summed over gaps
+  unsigned long long* prof;             // (tools, may be null) 2 x 32 counters (small, large): ticks per section of the analysis, summed over gaps; counts
+  unsigned long long* log;              // (tools, may be null) 16 words per closure taken: see tools/d2_log.py; the first half is the small instantiation's
+  uint32_t log_cap;
+  uint32_t behind;                      // the gaps' results are read only behind the launch (an event): no release per closure
   unsigned long long* wgs_done;         // workgroups of g2s_d2_* that are through (the trace kernel's last wave waits for all of them)
   // entries carry this tag in bits 24-31 (0: plain gap numbers); poll: the launch runs BESIDE the fill kernel and takes
   // entries as they appear, until the 64 counters at `done` add up to `expected` (every gap of the fill launch is

@@ -1,7 +1,8 @@
 // gap2seq_amd/csrc/d2_device.hip — phase D2 of fill_gap (/root/reference/src/Gap2Seq.cpp:1314-1435: strong
 // components, contraction, topological sweep with the branch counter, branch[v] == 1) on the device, for the closures
-// the fill kernels leave unanalysed: more than 192 segments, or a k-mer at several depths.  One wave per gap, the
-// gap's graph in LDS; post.cpp (seg_analyze, seg_analyze_runs) is the host version and the reference for every step.
+// the fill kernels leave unanalysed: more than 192 segments, or a k-mer at several depths.  One workgroup per gap — one
+// wave for closures of up to 256 segments (g2s_d2_small), sixteen for the rest (g2s_d2_big) —, the gap's graph in LDS;
+// post.cpp (seg_analyze, seg_analyze_runs) is the host version and the reference for every step.
 //
 // A closure arrives as SegRec records (fill_device.h): unitig segments whose states t <= ts lie on a path to a sink.
 //  * Every k-mer at one depth (the segments' index intervals are disjoint: a sort tells): the subgraph is a DAG whose
@@ -11,14 +12,19 @@
 //    Inside a unitig those are index +-1 steps: cut the closure's index intervals at every segment end and at every
 //    k-mer that carries another edge (a parent's last k-mer, an entry, a sink position); between two cuts lies a RUN
 //    of k-mers whose only edges are the chain's own.  The run graph (a few hundred to a few thousand nodes) goes
-//    into LDS as two adjacency tables.  Strong components: nodes without a live edge in or out are peeled off round
-//    by round (each its own component), what is left is cycles and the paths between them — a forward and a backward
-//    search from a pivot give one component, and the peeling goes on.  Then the components in topological order
-//    (Kahn, by rounds; any topological order gives the same verdicts), the branch counter as a prefix
-//    sum over that order, and the verdict of every run.
+//    into LDS as two adjacency tables.  Runs with one edge in and one out are contracted out of it.  Strong
+//    components: nodes without a live edge in or out are peeled off (each its own component; a lane follows a chain
+//    of freed nodes itself), what is left is cycles and the paths between them — a forward and a backward search
+//    from a pivot give one component, and the peeling goes on.  Then the components in a topological order (Kahn;
+//    any topological order gives the same verdicts), the branch counter as a prefix sum over that order,
+//    and the verdict of every run.
 // What leaves: per gap the subgraph statistics and a sorted list of runs {first index, last index | safe << 31};
 // g2s_d3_trace looks the safe bit of a traced base up there (a k-mer in no run reads branch[sink], Q5).
 // A closure beyond an instantiation's capacities is passed on (small -> large) or left to the host (post.cpp).
+//
+// Several waves: the passes over the segments, the sorts, the runs, the edges, the adjacency, the chains, the peeling
+// and the searches are shared by all threads (positions by atomic counters where the order does not matter, two-level
+// prefix sums where it does); merging sorted intervals and the scans over per-chunk totals stay on the first wave.
 #include <hip/hip_runtime.h>
 
 #include "d2_device.h"
@@ -29,9 +35,9 @@ namespace {
 using g2s::D2Args;
 using g2s::D2Out;
 
-template <uint32_t NS_, uint32_t NREC_, uint32_t BP_, uint32_t NV_, uint32_t E_>
+template <uint32_t NT_, uint32_t NS_, uint32_t NREC_, uint32_t BP_, uint32_t NV_, uint32_t E_>
 struct D2Caps {
-  static constexpr uint32_t NS = NS_, NREC = NREC_, BP = BP_, NV = NV_, E = E_;
+  static constexpr uint32_t NT = NT_, NS = NS_, NREC = NREC_, BP = BP_, NV = NV_, E = E_;
   // LDS, bytes: the sort buffer (and, DAG closures, the per-segment words behind its first NS keys) ...
   static constexpr uint32_t K_BYTES = BP * 8u;
   // ... or the graph: offsets and adjacency in both directions (u16), live degrees (u16, packed), component / state
@@ -39,15 +45,20 @@ struct D2Caps {
   static constexpr uint32_t OFF_BYTES = ((NV + 2u) * 2u + 15u) & ~15u;
   static constexpr uint32_t G_BYTES = 2u * OFF_BYTES + 2u * E * 2u + 2u * NV * 2u + NV * 4u + 2u * NV * 2u;
   static constexpr uint32_t MAIN_BYTES = K_BYTES > G_BYTES ? K_BYTES : G_BYTES;
-  // ... and behind either: per 64 cuts a mask and a count of the runs between cuts, a bit per node (pass-through), counters
-  static constexpr uint32_t AUX_BYTES = (BP / 64u) * 12u + 2u * (NV / 32u) * 4u + 64u;
+  // ... and behind either: per 64 cuts a mask and a count of the runs between cuts (or: per 64 segments a total), two
+  // bits per node (pass-through; sink position), counters
+  static constexpr uint32_t CHUNKS = (BP > NREC ? BP : NREC) / 64u;
+  static constexpr uint32_t HDR_WORDS = 64u;
+  static constexpr uint32_t AUX_BYTES = CHUNKS * 12u + 2u * (NV / 32u) * 4u + HDR_WORDS * 4u;
   static constexpr uint32_t LDS_BYTES = MAIN_BYTES + AUX_BYTES;
   // global scratch of a workgroup, words
-  static constexpr uint32_t SCR_WORDS = 9u * NS + 3u * BP + 5u * NV + E + 64u;
+  static constexpr uint32_t SCR_WORDS = 7u * NS + 3u * BP + 5u * NV + E + 64u;
   static_assert(BP >= 4u * NS, "the sort buffer holds the look-up tables: cuts, vertex intervals, chain intervals");
+  static_assert(2u * NS + NREC <= K_BYTES / 4u, "the per-segment words fit behind the keys");
+  static_assert(E >= 2u * NV, "the reverse adjacency's space holds two packed degree tables");
 };
-using D2Small = D2Caps<G2S_D2_SMALL_NS, G2S_D2_SMALL_NREC, G2S_D2_SMALL_BP, G2S_D2_SMALL_NV, G2S_D2_SMALL_E>;
-using D2Big = D2Caps<G2S_D2_BIG_NS, G2S_D2_BIG_NREC, G2S_D2_BIG_BP, G2S_D2_BIG_NV, G2S_D2_BIG_E>;
+using D2Small = D2Caps<64u, G2S_D2_SMALL_NS, G2S_D2_SMALL_NREC, G2S_D2_SMALL_BP, G2S_D2_SMALL_NV, G2S_D2_SMALL_E>;
+using D2Big = D2Caps<G2S_D2_BIG_NT, G2S_D2_BIG_NS, G2S_D2_BIG_NREC, G2S_D2_BIG_BP, G2S_D2_BIG_NV, G2S_D2_BIG_E>;
 
 // state of a node while the strong components are found; afterwards: its component (the id of one of its nodes)
 #define D2_ALIVE 0xFFFFFFFFu
@@ -59,10 +70,22 @@ using D2Big = D2Caps<G2S_D2_BIG_NS, G2S_D2_BIG_NREC, G2S_D2_BIG_BP, G2S_D2_BIG_N
 __device__ __forceinline__ bool d2_is_pass(uint32_t st) { return st >= 0x80000000u && st <= D2_PASS; }
 #define D2_NONE 0xFFFFFFFFu
 
-// what the wave wrote to global scratch is read back by other lanes
+// header words (LDS)
+enum {
+  H_NEXT = 0, H_ORDER, H_BIGS, H_N0, H_N1, H_N2, H_FLAG, H_PIVOT, H_R0, H_R1, H_R2, H_R3, H_M0, H_M1, H_M2, H_BASE_LO, H_BASE_HI,
+  H_A64 = 18 /* three 64-bit accumulators: words 18-23 */, H_BIGS_A = 24 /* 12 u16 */, H_BIGS_B = 30 /* 12 u16 */, H_GAP = 36, H_SLOT = 37
+};
+
+// all threads of the workgroup (one wave: nothing but the LDS queue to wait for)
+template <uint32_t NT>
+__device__ __forceinline__ void bsync() {
+  if constexpr (NT == 64u) lds_sync(); else __syncthreads();
+}
+// what the workgroup wrote to global scratch is read back by other threads of it
+template <uint32_t NT>
 __device__ __forceinline__ void gsync() {
   __threadfence_block();
-  __builtin_amdgcn_wave_barrier();
+  if constexpr (NT == 64u) __builtin_amdgcn_wave_barrier(); else __syncthreads();
 }
 // 16-bit counters, two a word: atomics on the word (a counter never leaves 0 .. 65535)
 __device__ __forceinline__ uint32_t pk_get(const uint32_t* a, uint32_t i) { return (a[i >> 1] >> (16u * (i & 1u))) & 0xFFFFu; }
@@ -94,6 +117,12 @@ __device__ __forceinline__ uint32_t cut_index(const uint32_t* cut, uint32_t n, u
   while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (cut[mid] < x) lo = mid + 1u; else hi = mid; }
   return lo < n ? lo : n - 1u;
 }
+// places behind *ctr for the lanes of this wave that ask (m: their ballot): the lane's own place
+__device__ __forceinline__ uint32_t wave_reserve(uint32_t* ctr, uint64_t m, int lane) {
+  uint32_t base = 0;
+  if (lane == 0 && m) base = atomicAdd(ctr, (uint32_t)__popcll(m));
+  return rl(base, 0) + (uint32_t)__popcll(m & below(lane));
+}
 
 struct SegD {  // a closure segment as this kernel reads it
   uint32_t node, dl, ts_tt, p01, p23, flags;
@@ -118,9 +147,9 @@ __device__ __forceinline__ SegD seg_load(const SegRec* segs, uint32_t q) {
   return s;
 }
 
-// K[0 .. n): sorted keys.  PACKED: first << 32 | up << 31 | length - 1 << 16 | segment (the vertex intervals); else
-// first << 32 | last.  Writes the merged intervals {first, last} to out and returns how many; merges overlapping
-// intervals, and adjacent ones when asked.  *overlap: two of them overlap.
+// (FIRST WAVE) K[0 .. n): sorted keys.  PACKED: first << 32 | up << 31 | length - 1 << 16 | segment (the vertex
+// intervals); else first << 32 | last (bit 63: a direction some callers sort by).  Writes the merged intervals {first,
+// last} to out and returns how many; merges overlapping intervals, and adjacent ones when asked.  *overlap: two overlap.
 template <bool PACKED>
 __device__ __forceinline__ uint32_t merge_sorted(const uint64_t* K, uint32_t n, bool adjacent, uint32_t* out, int lane, bool* overlap) {
   uint32_t M = 0, pm = 0;  // highest (last + 1) so far
@@ -129,7 +158,7 @@ __device__ __forceinline__ uint32_t merge_sorted(const uint64_t* K, uint32_t n, 
     const uint32_t i = i0 + (uint32_t)lane;
     const bool h = i < n;
     const uint64_t key = h ? K[i] : 0ull;
-    const uint32_t lo = (uint32_t)(key >> 32) & 0x7FFFFFFFu;  // (bit 63: a direction some callers sort by)
+    const uint32_t lo = (uint32_t)(key >> 32) & 0x7FFFFFFFu;
     const uint32_t hi = PACKED ? lo + (((uint32_t)key >> 16) & 0x7FFFu) : (uint32_t)key;
     const uint32_t sa = wave_scan_max(h ? hi + 1u : 0u);
     uint32_t xa = wave_shr1(sa);
@@ -146,25 +175,25 @@ __device__ __forceinline__ uint32_t merge_sorted(const uint64_t* K, uint32_t n, 
     pm = max(pm, rl(sa, 63));
   }
   if (M > 0u && lane == 0) out[2u * (M - 1u) + 1u] = pm - 1u;
-  gsync();
   *overlap = ov;
   return M;
 }
 
-// ascending bitonic sort of n2 (a power of two >= 2) 64-bit keys in LDS by one wave: lds_sort64 with four independent
-// compare-exchanges of a stage in flight per lane (the pairs of a stage are disjoint; one at a time the loop waits out an
-// LDS round trip per pair — the sorts were the kernel's largest share on closures of thousands of segments)
-__device__ __forceinline__ void d2_sort64(uint64_t* a, uint32_t n2, int lane) {
+// ascending bitonic sort of n2 (a power of two >= 2) 64-bit keys in LDS by the workgroup: four independent
+// compare-exchanges of a stage in flight per thread (the pairs of a stage are disjoint; one at a time the loop waits out
+// an LDS round trip per pair)
+template <uint32_t NT>
+__device__ __forceinline__ void blk_sort64(uint64_t* a, uint32_t n2, uint32_t tid) {
   const uint32_t half = n2 >> 1;
   for (uint32_t k = 2; k <= n2; k <<= 1)
     for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-      uint32_t t = (uint32_t)lane;
-      for (; t + 192u < half; t += 256u) {
+      uint32_t t = tid;
+      for (; t + 3u * NT < half; t += 4u * NT) {
         uint32_t i[4], l[4];
         uint64_t p[4], q[4];
 #pragma unroll
         for (int x = 0; x < 4; x++) {
-          const uint32_t tx = t + 64u * (uint32_t)x;
+          const uint32_t tx = t + NT * (uint32_t)x;
           i[x] = ((tx & ~(j - 1u)) << 1) | (tx & (j - 1u));
           l[x] = i[x] | j;
           p[x] = a[i[x]]; q[x] = a[l[x]];
@@ -173,22 +202,26 @@ __device__ __forceinline__ void d2_sort64(uint64_t* a, uint32_t n2, int lane) {
         for (int x = 0; x < 4; x++)
           if ((p[x] > q[x]) == ((i[x] & k) == 0u)) { a[i[x]] = q[x]; a[l[x]] = p[x]; }
       }
-      for (; t < half; t += 64u) {
+      for (; t < half; t += NT) {
         const uint32_t i = ((t & ~(j - 1u)) << 1) | (t & (j - 1u));
         const uint32_t l = i | j;
         const uint64_t p = a[i], q = a[l];
         if ((p > q) == ((i & k) == 0u)) { a[i] = q; a[l] = p; }
       }
-      lds_sync();
+      bsync<NT>();
     }
 }
-// sorts K[0 .. n) (padding with the largest key), then drops repeated keys in place; returns how many are left
-__device__ __forceinline__ uint32_t sort_unique(uint64_t* K, uint32_t n, int lane) {
-  if (n == 0u) return 0u;
+// K[0 .. n) padded with the largest key to a power of two and sorted (all threads)
+template <uint32_t NT>
+__device__ __forceinline__ void blk_sort_padded(uint64_t* K, uint32_t n, uint32_t tid) {
+  if (n < 2u) return;
   const uint32_t n2 = pow2_at_least(n);
-  for (uint32_t i = n + (uint32_t)lane; i < n2; i += 64u) K[i] = ~0ull;
-  lds_sync();
-  d2_sort64(K, n2, lane);
+  for (uint32_t i = n + tid; i < n2; i += NT) K[i] = ~0ull;
+  bsync<NT>();
+  blk_sort64<NT>(K, n2, tid);
+}
+// (FIRST WAVE) drops repeated keys of the sorted K[0 .. n) in place; returns how many are left
+__device__ __forceinline__ uint32_t wave_unique(uint64_t* K, uint32_t n, int lane) {
   uint32_t w = 0;
   for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
     const uint32_t i = i0 + (uint32_t)lane;
@@ -204,18 +237,28 @@ __device__ __forceinline__ uint32_t sort_unique(uint64_t* K, uint32_t n, int lan
   return w;
 }
 
-#define D2_LAP(i) do { if (A.prof) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) atomicAdd(A.prof + (i), t_ - t_lap); t_lap = t_; } } while (0)
-// the gap's verdict word, behind everything the wave wrote for the gap: its trace wave (g2s_d3_trace) may be waiting for it
-__device__ __forceinline__ void d2_publish(GapOut* go, uint32_t dflags, int lane) {
+#define D2_LAP(i) do { if (A.prof) { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); if (tid == 0u) { atomicAdd(A.prof + (i), t_ - t_lap); if (plog) plog[3 + (i)] = t_ - t_lap; } t_lap = t_; } } while (0)
+// the gap's verdict word, behind everything the workgroup wrote for the gap: its trace wave (g2s_d3_trace) may be waiting
+template <uint32_t NT>
+__device__ __forceinline__ void d2_publish(GapOut* go, uint32_t dflags, bool behind_the_launch) {
+  if (behind_the_launch) {  // (nobody reads the gap's results before the launch has ended: no release per closure — on this
+    // chip a release at device scope writes the workgroup's whole L2 back, and an acquire empties it for everybody)
+    if (threadIdx.x == 0) go->dflags = dflags;
+    return;
+  }
   __threadfence();
-  __builtin_amdgcn_wave_barrier();
-  if (lane == 0) __hip_atomic_store(&go->dflags, dflags, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  bsync<NT>();
+  if (threadIdx.x == 0) __hip_atomic_store(&go->dflags, dflags, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
-// returns 0: analysed; 1: beyond this instantiation's capacities; 2: no room for the runs
+
+// returns 0: analysed; 1: beyond this instantiation's capacities; 2: no room for the runs / given up
 template <class C>
 __device__ int d2_one(uint32_t* lds, const D2Args& A, uint32_t gap, uint32_t* scr) {
-  const int lane = (int)threadIdx.x;
-  unsigned long long t_lap = A.prof ? __builtin_amdgcn_s_memtime() : 0ull;
+  constexpr uint32_t NT = C::NT;
+  const uint32_t tid = threadIdx.x;
+  const int lane = (int)(tid & 63u);
+  const uint32_t wave = tid >> 6;
+  unsigned long long t_lap = A.prof ? __builtin_amdgcn_s_memrealtime() : 0ull;
   GapOut* go = A.outs + gap;
   const uint32_t nrec = uni(go->n_xl);
   const SegRec* segs = (const SegRec*)(A.sub + uni((uint32_t)go->sub_off) + ((uint64_t)uni((uint32_t)(go->sub_off >> 32)) << 32));
@@ -229,6 +272,7 @@ __device__ int d2_one(uint32_t* lds, const D2Args& A, uint32_t gap, uint32_t* sc
   const uint32_t reached = uni(targets[uni((uint32_t)go->reached_j)]);
   const bool t_is_s = !all_paths;  // -best-only: the traceback starts are the sinks (:1245-1259)
   const int n_len = (int)uni((uint32_t)go->n_len), len0 = (int)uni((uint32_t)go->len[0]), len1 = (int)uni((uint32_t)go->len[1]);
+  const uint32_t dflags0 = uni(go->dflags);
   if (nrec == 0u || nrec > C::NREC) return 1;
   // position of the sink state inside a segment of the S closure, or -1 (post.cpp: sinkpos)
   auto sink_pos = [&](const SegD& s) -> int {
@@ -245,16 +289,16 @@ __device__ int d2_one(uint32_t* lds, const D2Args& A, uint32_t gap, uint32_t* sc
   };
   uint64_t* K = (uint64_t*)lds;
   uint64_t* GM = (uint64_t*)(lds + C::MAIN_BYTES / 4u);   // per 64 cuts: which of them have a run behind them ...
-  uint32_t* GP = (uint32_t*)(GM + C::BP / 64u);           // ... and how many such runs lie in front of the 64
-  uint32_t* PM = GP + C::BP / 64u;                        // a bit per node: pass-through
-  uint32_t* hdr = PM + C::NV / 32u;                       // a few counters
+  uint32_t* GP = (uint32_t*)(GM + C::CHUNKS);             // ... and how many such runs lie in front of the 64 (or: chunk totals)
+  uint32_t* PM = GP + C::CHUNKS;                          // a bit per node: pass-through (before that: a source's entry)
+  uint32_t* KM = PM + C::NV / 32u;                        // a bit per node: a sink position
+  uint32_t* hdr = KM + C::NV / 32u;                       // counters
+  unsigned long long* acc64 = (unsigned long long*)(hdr + H_A64);
   // scratch
   uint32_t* VM = scr;                      // merged vertex intervals
   uint32_t* UI = VM + 2u * C::NS;          // chain edges of upward segments, by the lower of their two k-mers
   uint32_t* DI = UI + 2u * C::NS;          // ... of downward segments
-  uint32_t* SRCS = DI + 2u * C::NS;
-  uint32_t* SINKS = SRCS + C::NS;
-  uint32_t* LOOPS = SINKS + C::NS;
+  uint32_t* LOOPS = DI + 2u * C::NS;
   uint32_t* CUT = LOOPS + C::NS;
   uint64_t* SP = (uint64_t*)(CUT + C::BP); // the distinct (parent's last k-mer, entry) pairs, sorted
   uint32_t* RLO = (uint32_t*)(SP + C::BP); // by node
@@ -264,9 +308,12 @@ __device__ int d2_one(uint32_t* lds, const D2Args& A, uint32_t gap, uint32_t* sc
   uint32_t* ORDER = HEAD + C::NV;
   uint32_t* EDGE = ORDER + C::NV;          // from << 16 | to
 
+  unsigned long long* plog = (A.prof && A.log && hdr[H_SLOT] < A.log_cap) ? A.log + 16ull * hdr[H_SLOT] : nullptr;
+  bsync<NT>();
+  for (uint32_t i = tid; i < C::HDR_WORDS; i += NT) if (i != (uint32_t)H_GAP && i != (uint32_t)H_SLOT) hdr[i] = 0u;
+  bsync<NT>();
   // ---- the S closure's index intervals, sorted
-  uint32_t ns = 0;
-  for (uint32_t q0 = 0; q0 < nrec; q0 += 64u) {
+  for (uint32_t q0 = wave * 64u; q0 < nrec; q0 += NT) {
     const uint32_t q = q0 + (uint32_t)lane;
     const bool h = q < nrec;
     SegD s;
@@ -274,47 +321,54 @@ __device__ int d2_one(uint32_t* lds, const D2Args& A, uint32_t gap, uint32_t* sc
     const int ts = h ? s.ts() : -1;
     const bool in_s = ts >= 0;
     const uint64_t m = __ballot(in_s);
-    const uint32_t pos = ns + (uint32_t)__popcll(m & below(lane));
+    const uint32_t pos = wave_reserve(&hdr[H_N0], m, lane);
     if (in_s && pos < C::NS) {
       const uint32_t lo = s.up() ? (s.node >> 1) : (s.node >> 1) - (uint32_t)ts;
       K[pos] = ((uint64_t)lo << 32) | (s.up() ? 0x80000000u : 0u) | ((uint32_t)ts << 16) | q;
     }
-    ns += (uint32_t)__popcll(m);
   }
+  bsync<NT>();
+  const uint32_t ns = hdr[H_N0];
   if (ns > C::NS) return 1;
   if (ns == 0u) {  // (phase D ran without a sink state: nothing to analyse; the recount is the fill kernel's)
-    if (lane == 0) {
+    if (tid == 0u) {
       D2Out o; o.run_off = 0; o.n_runs = 0; o.sub[0] = 2; o.sub[1] = 0; o.sub[2] = 0; o.sub[3] = 0; o.sub[4] = 2; o.sub[5] = 0;
       A.d2out[gap] = o;
       go->sub_vertices = 2; go->sub_edges = 0;
     }
-    d2_publish(go, (uni(go->dflags) & ~G2S_DEVA_SINK_SAFE) | G2S_DEVA_ANALYSED | G2S_DEVA_RUNS, lane);
+    d2_publish<NT>(go, (dflags0 & ~G2S_DEVA_SINK_SAFE) | G2S_DEVA_ANALYSED | G2S_DEVA_RUNS, A.behind != 0u);
     return 0;
   }
-  {
-    const uint32_t n2 = pow2_at_least(ns);
-    for (uint32_t i = ns + (uint32_t)lane; i < n2; i += 64u) K[i] = ~0ull;
-    lds_sync();
-    d2_sort64(K, n2, lane);
+  blk_sort_padded<NT>(K, ns, tid);
+  bsync<NT>();
+  if (wave == 0u) {
+    bool ov = false;
+    const uint32_t mv = merge_sorted<true>(K, ns, false, VM, lane, &ov);
+    if (lane == 0) { hdr[H_M0] = mv; hdr[H_FLAG] = ov ? 1u : 0u; }
   }
-  bool overlap = false;
-  const uint32_t MV = merge_sorted<true>(K, ns, false, VM, lane, &overlap);
-  uint32_t V = 2u;
-  for (uint32_t i0 = 0; i0 < MV; i0 += 64u) {
+  gsync<NT>();
+  const uint32_t MV = hdr[H_M0];
+  const bool overlap = hdr[H_FLAG] != 0u;
+  for (uint32_t i0 = wave * 64u; i0 < MV; i0 += NT) {
     const uint32_t i = i0 + (uint32_t)lane;
-    V += wave_sum(i < MV ? VM[2u * i + 1u] - VM[2u * i] + 1u : 0u);
+    const uint32_t len = wave_sum(i < MV ? VM[2u * i + 1u] - VM[2u * i] + 1u : 0u);
+    if (lane == 0) atomicAdd(&hdr[H_R0], len);
   }
-
+  bsync<NT>();
+  const uint32_t V = 2u + hdr[H_R0];
+  bsync<NT>();
   D2_LAP(0);
+
   if (!overlap) {
     // ================= every k-mer at one depth: the branch rule as a prefix sum (post.cpp: seg_analyze) ==========
     // by segment, behind the keys: safe_a | safe_b << 1 | split << 2 | children on paths to a sink << 24
     uint32_t* sv = lds + 2u * C::NS;
-    static_assert(2u * C::NS + C::NREC <= C::K_BYTES / 4u, "the per-segment words fit behind the keys");
-    for (uint32_t q = (uint32_t)lane; q < nrec; q += 64u) sv[q] = 0u;
-    lds_sync();
-    uint32_t n_s = 0, edges = 0, src_out = 0, sink_in = 0;
-    for (uint32_t q0 = 0; q0 < nrec; q0 += 64u) {
+    int* T = (int*)GP;  // per 64 segments (in the order of the sweep): the counter's change, then the counter in front
+    for (uint32_t q = tid; q < nrec; q += NT) sv[q] = 0u;
+    // totals; children per parent.  H_R0: states, H_R1: edges, H_R2: segments the source leads into, H_R3: sink states
+    if (tid == 0u) { hdr[H_R0] = 0u; hdr[H_R1] = 0u; hdr[H_R2] = 0u; hdr[H_R3] = 0u; }
+    bsync<NT>();
+    for (uint32_t q0 = wave * 64u; q0 < nrec; q0 += NT) {
       const uint32_t q = q0 + (uint32_t)lane;
       const bool h = q < nrec;
       SegD s;
@@ -324,21 +378,23 @@ __device__ int d2_one(uint32_t* lds, const D2Args& A, uint32_t gap, uint32_t* sc
       const int np = in_s ? s.npar() : 0;
       const int sp = in_s ? sink_pos(s) : -1;
       const bool src = in_s && s.source();
-      n_s += wave_sum(in_s ? (uint32_t)ts + 1u : 0u);
-      edges += wave_sum(in_s ? (uint32_t)ts + (src ? 1u : (uint32_t)np) + (sp >= 0 ? 1u : 0u) : 0u);
-      src_out += (uint32_t)__popcll(__ballot(src));
-      sink_in += (uint32_t)__popcll(__ballot(sp >= 0));
+      const uint32_t a0 = wave_sum(in_s ? (uint32_t)ts + 1u : 0u);
+      const uint32_t a1 = wave_sum(in_s ? (uint32_t)ts + (src ? 1u : (uint32_t)np) + (sp >= 0 ? 1u : 0u) : 0u);
+      const uint32_t a2 = (uint32_t)__popcll(__ballot(src)), a3 = (uint32_t)__popcll(__ballot(sp >= 0));
+      if (lane == 0) { atomicAdd(&hdr[H_R0], a0); atomicAdd(&hdr[H_R1], a1); atomicAdd(&hdr[H_R2], a2); atomicAdd(&hdr[H_R3], a3); }
       if (in_s && !src)
         for (int x = 0; x < 4; x++) { const uint32_t p = s.par(x); if (p != 0xFFFFu && p < nrec) atomicAdd(&sv[p], 1u << 24); }
     }
-    lds_sync();
-    int bc = 1 + (src_out > 1u ? (int)src_out - 1 : 0);  // the source pseudo-vertex comes first
-    for (uint32_t i0 = 0; i0 < nrec; i0 += 64u) {         // parents first = descending record index
-      const uint32_t i = i0 + (uint32_t)lane;
+    bsync<NT>();
+    const uint32_t n_s = hdr[H_R0], edges = hdr[H_R1], src_out = hdr[H_R2], sink_in = hdr[H_R3];
+    bsync<NT>();
+    // what a segment does to the counter (parents first = descending record index): -(in - 1) at its entry, +1 at a
+    // sink inside it, +(out - 1) behind its last state
+    auto seg_delta = [&](uint32_t i, SegD* s_out, int* ts_out, int* sp_out, int* d_in_out, int* d_mid_out) -> int {
       const bool h = i < nrec;
       const uint32_t q = h ? nrec - 1u - i : 0u;
       SegD s;
-      if (h) s = seg_load(segs, q);
+      if (h) s = seg_load(segs, q); else { s.node = 0; s.dl = 0; s.ts_tt = 0x7FFF7FFFu; s.p01 = s.p23 = 0xFFFFFFFFu; s.flags = 0; }
       const int ts = h ? s.ts() : -1;
       const bool in_s = ts >= 0;
       const int sp = in_s ? sink_pos(s) : -1;
@@ -348,10 +404,38 @@ __device__ int d2_one(uint32_t* lds, const D2Args& A, uint32_t gap, uint32_t* sc
       const int d_mid = (in_s && sp >= 0 && sp < ts) ? 1 : 0;  // out-degree 2: the next state and the sink
       const int dout = in_s ? (ts == s.len() - 1 ? outs : 0) + (sp == ts ? 1 : 0) : 0;
       const int d_out = dout > 1 ? dout - 1 : 0;
-      const int total = d_in + d_mid + d_out;
+      *s_out = s; *ts_out = ts; *sp_out = sp; *d_in_out = d_in; *d_mid_out = d_mid;
+      return d_in + d_mid + d_out;
+    };
+    const uint32_t nchunks = (nrec + 63u) / 64u;
+    for (uint32_t c = wave; c < nchunks; c += NT / 64u) {
+      SegD s; int ts, sp, d_in, d_mid;
+      const int total = seg_delta(c * 64u + (uint32_t)lane, &s, &ts, &sp, &d_in, &d_mid);
+      const int sum = (int)wave_sum((uint32_t)total);
+      if (lane == 0) T[c] = sum;
+    }
+    bsync<NT>();
+    if (wave == 0u) {  // the counter in front of every chunk
+      int bc = 1 + (src_out > 1u ? (int)src_out - 1 : 0);  // the source pseudo-vertex comes first
+      for (uint32_t c0 = 0; c0 < nchunks; c0 += 64u) {
+        const uint32_t c = c0 + (uint32_t)lane;
+        const int mine = c < nchunks ? T[c] : 0;
+        const int incl = (int)wave_scan((uint32_t)mine, lane);
+        lds_sync();
+        if (c < nchunks) T[c] = bc + incl - mine;
+        bc += (int)rl((uint32_t)incl, 63);
+      }
+      if (lane == 0) hdr[H_R0] = (uint32_t)bc;  // (behind the last segment)
+    }
+    bsync<NT>();
+    for (uint32_t c = wave; c < nchunks; c += NT / 64u) {
+      SegD s; int ts, sp, d_in, d_mid;
+      const uint32_t i = c * 64u + (uint32_t)lane;
+      const int total = seg_delta(i, &s, &ts, &sp, &d_in, &d_mid);
       const int incl = (int)wave_scan((uint32_t)total, lane);
-      const int at_entry = bc + incl - total + d_in;
-      if (in_s) {
+      const int at_entry = T[c] + incl - total + d_in;
+      if (ts >= 0) {
+        const uint32_t q = nrec - 1u - i;
         const bool sa = at_entry == 1, sb = at_entry + d_mid == 1;
         const int split = d_mid ? sp : ts;
         sv[q] = (sv[q] & 0xFF000000u) | (sa ? 1u : 0u) | (sb ? 2u : 0u) | ((uint32_t)split << 2);
@@ -359,28 +443,43 @@ __device__ int d2_one(uint32_t* lds, const D2Args& A, uint32_t gap, uint32_t* sc
         segs_w[q].ts_tt = (s.ts_tt & 0x7FFF7FFFu) | (sa ? 0x8000u : 0u) | (sb ? 0x80000000u : 0u);
         segs_w[q].pad = (uint32_t)split;
       }
-      bc += (int)rl((uint32_t)incl, 63);
     }
+    bsync<NT>();
     bool sink_safe = false;
-    if (sink_in >= 1u) { if (sink_in > 1u) bc -= (int)sink_in - 1; sink_safe = bc == 1; }
-    lds_sync();
+    { int bc = (int)hdr[H_R0]; if (sink_in >= 1u) { if (sink_in > 1u) bc -= (int)sink_in - 1; sink_safe = bc == 1; } }
     // runs, in the order of the sorted intervals: one per segment, two where a sink splits it
-    uint32_t total_runs = 0;
-    for (uint32_t j0 = 0; j0 < ns; j0 += 64u) {
-      const uint32_t j = j0 + (uint32_t)lane;
+    const uint32_t schunks = (ns + 63u) / 64u;
+    for (uint32_t c = wave; c < schunks; c += NT / 64u) {
+      const uint32_t j = c * 64u + (uint32_t)lane;
       const bool h = j < ns;
       const uint32_t low = h ? (uint32_t)K[j] : 0u;
       const uint32_t ts = (low >> 16) & 0x7FFFu, q = low & 0xFFFFu;
-      total_runs += wave_sum(h ? (((sv[q] >> 2) & 0x7FFFu) < ts ? 2u : 1u) : 0u);
+      const uint32_t cnt = wave_sum(h ? (((sv[q] >> 2) & 0x7FFFu) < ts ? 2u : 1u) : 0u);
+      if (lane == 0) GP[c] = cnt;
     }
-    unsigned long long base = 0;
-    if (lane == 0) base = atomicAdd(A.run_cursor, (unsigned long long)total_runs);
-    base = ((unsigned long long)uni((uint32_t)(base >> 32)) << 32) | uni((uint32_t)base);
+    bsync<NT>();
+    if (wave == 0u) {
+      uint32_t run = 0;
+      for (uint32_t c0 = 0; c0 < schunks; c0 += 64u) {
+        const uint32_t c = c0 + (uint32_t)lane;
+        const uint32_t mine = c < schunks ? GP[c] : 0u;
+        const uint32_t incl = wave_scan(mine, lane);
+        lds_sync();
+        if (c < schunks) GP[c] = run + incl - mine;
+        run += rl(incl, 63);
+      }
+      if (lane == 0) {
+        const unsigned long long base = atomicAdd(A.run_cursor, (unsigned long long)run);
+        hdr[H_R1] = run; hdr[H_BASE_LO] = (uint32_t)base; hdr[H_BASE_HI] = (uint32_t)(base >> 32);
+      }
+    }
+    bsync<NT>();
+    const uint32_t total_runs = hdr[H_R1];
+    const unsigned long long base = ((unsigned long long)hdr[H_BASE_HI] << 32) | hdr[H_BASE_LO];
     if (base + total_runs > A.run_cap) return 2;
     uint32_t* runs = A.runs + 2ull * base;
-    uint32_t w = 0;
-    for (uint32_t j0 = 0; j0 < ns; j0 += 64u) {
-      const uint32_t j = j0 + (uint32_t)lane;
+    for (uint32_t c = wave; c < schunks; c += NT / 64u) {
+      const uint32_t j = c * 64u + (uint32_t)lane;
       const bool h = j < ns;
       const uint64_t key = h ? K[j] : 0ull;
       const uint32_t low = (uint32_t)key, lo = (uint32_t)(key >> 32);
@@ -391,7 +490,7 @@ __device__ int d2_one(uint32_t* lds, const D2Args& A, uint32_t gap, uint32_t* sc
       const uint32_t sa = v & 1u, sb = (v >> 1) & 1u;
       const uint32_t mine = h ? (split < ts ? 2u : 1u) : 0u;
       const uint32_t incl = wave_scan(mine, lane);
-      const uint32_t at = w + incl - mine;
+      const uint32_t at = GP[c] + incl - mine;
       if (h) {
         const uint32_t hi = lo + ts;
         if (mine == 1u) { runs[2u * at] = lo; runs[2u * at + 1u] = hi | (sa << 31); }
@@ -403,17 +502,17 @@ __device__ int d2_one(uint32_t* lds, const D2Args& A, uint32_t gap, uint32_t* sc
           runs[2u * at + 2u] = hi - split; runs[2u * at + 3u] = hi | (sa << 31);
         }
       }
-      w += rl(incl, 63);
     }
-    if (lane == 0) {
+    if (tid == 0u) {
       D2Out o;
       o.run_off = (uint32_t)base; o.n_runs = total_runs;
       o.sub[0] = n_s + 2u; o.sub[1] = edges; o.sub[2] = 0u; o.sub[3] = 0u; o.sub[4] = n_s + 2u; o.sub[5] = edges;
       A.d2out[gap] = o;
       go->sub_vertices = n_s + 2u; go->sub_edges = edges;
     }
-    d2_publish(go, (uni(go->dflags) & ~G2S_DEVA_SINK_SAFE) | G2S_DEVA_ANALYSED | G2S_DEVA_RUNS | (sink_safe ? G2S_DEVA_SINK_SAFE : 0u), lane);
+    d2_publish<NT>(go, (dflags0 & ~G2S_DEVA_SINK_SAFE) | G2S_DEVA_ANALYSED | G2S_DEVA_RUNS | (sink_safe ? G2S_DEVA_SINK_SAFE : 0u), A.behind != 0u);
     D2_LAP(1);
+    if (A.prof && tid == 0u) atomicAdd(A.prof + 19, 1ull);
     return 0;
   }
 
@@ -421,170 +520,199 @@ __device__ int d2_one(uint32_t* lds, const D2Args& A, uint32_t gap, uint32_t* sc
   // (all the sorting first; the sort buffer then holds the tables the rest looks things up in)
   // ---- chain edges of the upward and of the downward segments as merged intervals (adjacent ones merge): one pass
   // over the segments, one sort (the direction is the key's top bit)
-  uint32_t MU = 0, MD = 0;
-  {
-    uint32_t n = 0, n_up = 0;
-    for (uint32_t q0 = 0; q0 < nrec; q0 += 64u) {
-      const uint32_t q = q0 + (uint32_t)lane;
-      const bool h = q < nrec;
-      SegD s;
-      if (h) s = seg_load(segs, q);
-      const int ts = h ? s.ts() : -1;
-      const bool take = ts > 0;
-      const uint64_t m = __ballot(take);
-      if (take) {
-        const uint32_t lo = s.up() ? (s.node >> 1) : (s.node >> 1) - (uint32_t)ts;
-        K[n + (uint32_t)__popcll(m & below(lane))] = (s.up() ? 0ull : 1ull << 63) | ((uint64_t)lo << 32) | (lo + (uint32_t)ts - 1u);
-      }
-      n += (uint32_t)__popcll(m);
-      n_up += (uint32_t)__popcll(__ballot(take && s.up()));
+  if (tid == 0u) { hdr[H_N0] = 0u; hdr[H_N1] = 0u; hdr[H_N2] = 0u; hdr[H_M1] = 0u; hdr[H_M2] = 0u; }
+  bsync<NT>();
+  for (uint32_t q0 = wave * 64u; q0 < nrec; q0 += NT) {
+    const uint32_t q = q0 + (uint32_t)lane;
+    const bool h = q < nrec;
+    SegD s;
+    if (h) s = seg_load(segs, q); else s.node = 0;
+    const int ts = h ? s.ts() : -1;
+    const bool take = ts > 0;
+    const uint64_t m = __ballot(take);
+    const uint32_t pos = wave_reserve(&hdr[H_N0], m, lane);
+    if (take && pos < C::NS) {
+      const uint32_t lo = s.up() ? (s.node >> 1) : (s.node >> 1) - (uint32_t)ts;
+      K[pos] = (s.up() ? 0ull : 1ull << 63) | ((uint64_t)lo << 32) | (lo + (uint32_t)ts - 1u);
     }
-    lds_sync();
-    if (n > 0u) {
-      const uint32_t n2 = pow2_at_least(n);
-      for (uint32_t i = n + (uint32_t)lane; i < n2; i += 64u) K[i] = ~0ull;
-      lds_sync();
-      d2_sort64(K, n2, lane);
+    const uint32_t ups = (uint32_t)__popcll(__ballot(take && s.up()));
+    if (lane == 0 && ups) atomicAdd(&hdr[H_N1], ups);
+  }
+  bsync<NT>();
+  {
+    const uint32_t n = hdr[H_N0], n_up = hdr[H_N1];  // (n <= ns <= NS)
+    blk_sort_padded<NT>(K, n, tid);
+    bsync<NT>();
+    if (wave == 0u) {
       bool ov;
-      if (n_up > 0u) MU = merge_sorted<false>(K, n_up, true, UI, lane, &ov);
-      if (n > n_up) MD = merge_sorted<false>(K + n_up, n - n_up, true, DI, lane, &ov);
+      uint32_t mu = 0, md = 0;
+      if (n_up > 0u) mu = merge_sorted<false>(K, n_up, true, UI, lane, &ov);
+      if (n > n_up) md = merge_sorted<false>(K + n_up, n - n_up, true, DI, lane, &ov);
+      if (lane == 0) { hdr[H_M1] = mu; hdr[H_M2] = md; }
     }
-    lds_sync();
+    gsync<NT>();
   }
+  const uint32_t MU = hdr[H_M1], MD = hdr[H_M2];
   D2_LAP(2);
-  // ---- the cuts: ends of every interval, sink positions
-  uint32_t nb = 0, npairs = 0;
-  {
-    uint32_t n = 0;
-    bool full = false;
-    for (uint32_t q0 = 0; q0 < nrec && !full; q0 += 64u) {
-      const uint32_t q = q0 + (uint32_t)lane;
-      const bool h = q < nrec;
-      SegD s;
-      if (h) s = seg_load(segs, q);
-      const int ts = h ? s.ts() : -1;
-      const bool in_s = ts >= 0;
-      const int sp = in_s ? sink_pos(s) : -1;
-      // (a parent's last k-mer — post.cpp pushes it as a cut — is an end of the parent's own interval: a segment with a
-      // child on a path to a sink lies on such paths whole)
-      const uint32_t np = (in_s && !s.source()) ? (uint32_t)s.npar() : 0u;
-      const uint32_t k = in_s ? 2u + (sp >= 0 ? 1u : 0u) : 0u;
-      npairs += wave_sum(np);
-      const uint32_t incl = wave_scan(k, lane);
-      const uint32_t tot = rl(incl, 63);
-      if (n + tot > C::BP) { full = true; break; }
-      uint32_t w = n + incl - k;
-      if (in_s) {
-        K[w++] = (uint64_t)s.idx(0);
-        K[w++] = (uint64_t)s.idx(ts);
-        if (sp >= 0) K[w++] = (uint64_t)s.idx(sp);
-      }
-      n += tot;
+  // ---- the cuts: ends of every interval, sink positions; and how many parent -> entry pairs there are
+  if (tid == 0u) { hdr[H_N0] = 0u; hdr[H_N1] = 0u; }
+  bsync<NT>();
+  for (uint32_t q0 = wave * 64u; q0 < nrec; q0 += NT) {
+    const uint32_t q = q0 + (uint32_t)lane;
+    const bool h = q < nrec;
+    SegD s;
+    if (h) s = seg_load(segs, q); else { s.node = 0; s.flags = 0; s.p01 = s.p23 = 0xFFFFFFFFu; }
+    const int ts = h ? s.ts() : -1;
+    const bool in_s = ts >= 0;
+    const int sp = in_s ? sink_pos(s) : -1;
+    // (a parent's last k-mer — post.cpp pushes it as a cut — is an end of the parent's own interval: a segment with a
+    // child on a path to a sink lies on such paths whole)
+    const uint32_t np = (in_s && !s.source()) ? (uint32_t)s.npar() : 0u;
+    const uint32_t k = in_s ? 2u + (sp >= 0 ? 1u : 0u) : 0u;
+    const uint32_t incl = wave_scan(k, lane);
+    const uint32_t tot = rl(incl, 63), nps = wave_sum(np);
+    uint32_t base = 0;
+    if (lane == 0) { base = atomicAdd(&hdr[H_N0], tot); atomicAdd(&hdr[H_N1], nps); }
+    uint32_t w = rl(base, 0) + incl - k;
+    if (in_s && w + k <= C::BP) {
+      K[w++] = (uint64_t)s.idx(0);
+      K[w++] = (uint64_t)s.idx(ts);
+      if (sp >= 0) K[w++] = (uint64_t)s.idx(sp);
     }
-    if (full) return 1;
-    lds_sync();
-    nb = sort_unique(K, n, lane);
-    for (uint32_t i = (uint32_t)lane; i < nb; i += 64u) CUT[i] = (uint32_t)K[i];
-    lds_sync();
   }
-  if (npairs > C::BP) return 1;
+  bsync<NT>();
+  {
+    const uint32_t n = hdr[H_N0];
+    if (n > C::BP || hdr[H_N1] > C::BP) return 1;
+    blk_sort_padded<NT>(K, n, tid);
+    bsync<NT>();
+    if (wave == 0u) { const uint32_t u = wave_unique(K, n, lane); if (lane == 0) hdr[H_M0] = u; }
+    bsync<NT>();
+  }
+  const uint32_t nb = hdr[H_M0];
+  for (uint32_t i = tid; i < nb; i += NT) CUT[i] = (uint32_t)K[i];
+  bsync<NT>();
+  if (tid == 0u) hdr[H_N0] = 0u;
+  bsync<NT>();
   // ---- the edges from a parent's last k-mer to an entry, sorted, each once (boost::edge(u, v).second)
-  uint32_t nsp = 0;
-  {
-    uint32_t n = 0;
-    for (uint32_t q0 = 0; q0 < nrec; q0 += 64u) {
-      const uint32_t q = q0 + (uint32_t)lane;
-      const bool h = q < nrec;
-      SegD s;
-      if (h) s = seg_load(segs, q);
-      const bool in_s = h && s.ts() >= 0 && !s.source();
-      const uint32_t k = in_s ? (uint32_t)s.npar() : 0u;
-      const uint32_t incl = wave_scan(k, lane);
-      uint32_t w = n + incl - k;  // (n + total <= npairs <= BP: counted above)
-      if (k)
-        for (int x = 0; x < 4; x++) {
-          const uint32_t p = s.par(x);
-          if (p == 0xFFFFu || p >= nrec) continue;
-          const SegD ps = seg_load(segs, p);
-          K[w++] = ((uint64_t)ps.idx(ps.len() - 1) << 32) | s.idx(0);
-        }
-      n += rl(incl, 63);
-    }
-    lds_sync();
-    nsp = sort_unique(K, n, lane);
-    for (uint32_t i = (uint32_t)lane; i < nsp; i += 64u) SP[i] = K[i];
-    lds_sync();
+  for (uint32_t q0 = wave * 64u; q0 < nrec; q0 += NT) {
+    const uint32_t q = q0 + (uint32_t)lane;
+    const bool h = q < nrec;
+    SegD s;
+    if (h) s = seg_load(segs, q); else { s.node = 0; s.flags = 0; s.p01 = s.p23 = 0xFFFFFFFFu; s.ts_tt = 0x7FFF7FFFu; }
+    const bool in_s = h && s.ts() >= 0 && !s.source();
+    const uint32_t k = in_s ? (uint32_t)s.npar() : 0u;
+    const uint32_t incl = wave_scan(k, lane);
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&hdr[H_N0], rl(incl, 63));
+    uint32_t w = rl(base, 0) + incl - k;  // (the total is what was counted above: <= BP)
+    if (k)
+      for (int x = 0; x < 4; x++) {
+        const uint32_t p = s.par(x);
+        if (p == 0xFFFFu || p >= nrec) continue;
+        const SegD ps = seg_load(segs, p);
+        if (w < C::BP) K[w++] = ((uint64_t)ps.idx(ps.len() - 1) << 32) | s.idx(0);
+      }
   }
-  gsync();
+  bsync<NT>();
+  {
+    const uint32_t n = min(hdr[H_N0], C::BP);
+    bsync<NT>();
+    blk_sort_padded<NT>(K, n, tid);
+    bsync<NT>();
+    if (wave == 0u) { const uint32_t u = wave_unique(K, n, lane); if (lane == 0) hdr[H_M0] = u; }
+    bsync<NT>();
+  }
+  const uint32_t nsp = hdr[H_M0];
+  for (uint32_t i = tid; i < nsp; i += NT) SP[i] = K[i];
+  gsync<NT>();
   D2_LAP(3);
   // ---- the sort buffer becomes the tables: cuts, vertex intervals, chain intervals of either direction
   uint32_t* CUTL = lds;
   uint32_t* VML = lds + C::BP;
   uint32_t* UL = VML + 2u * C::NS;
   uint32_t* DL = UL + 2u * MU;
-  for (uint32_t i = (uint32_t)lane; i < nb; i += 64u) CUTL[i] = CUT[i];
-  for (uint32_t i = (uint32_t)lane; i < 2u * MV; i += 64u) VML[i] = VM[i];
-  for (uint32_t i = (uint32_t)lane; i < 2u * MU; i += 64u) UL[i] = UI[i];
-  for (uint32_t i = (uint32_t)lane; i < 2u * MD; i += 64u) DL[i] = DI[i];
-  lds_sync();
-  // ---- runs: every cut k-mer alone, and what lies between two cuts of one vertex interval; the chain's own edges
-  // between neighbouring runs on the way
-  uint32_t R = 0, ne = 0, nloops = 0;
-  bool e_full = false;
-  unsigned long long e_internal = 0;
-  auto emit = [&](bool take, uint32_t from, uint32_t to) {
-    const uint64_t m = __ballot(take);
-    const uint32_t at = ne + (uint32_t)__popcll(m & below(lane));
-    if (take && at < C::E) EDGE[at] = (from << 16) | to;
-    ne += (uint32_t)__popcll(m);
-    if (ne > C::E) e_full = true;
+  for (uint32_t i = tid; i < nb; i += NT) CUTL[i] = CUT[i];
+  for (uint32_t i = tid; i < 2u * MV; i += NT) VML[i] = VM[i];
+  for (uint32_t i = tid; i < 2u * MU; i += NT) UL[i] = UI[i];
+  for (uint32_t i = tid; i < 2u * MD; i += NT) DL[i] = DI[i];
+  if (tid == 0u) { hdr[H_N0] = 0u; hdr[H_N1] = 0u; hdr[H_N2] = 0u; hdr[H_R0] = 0u; acc64[0] = 0ull; acc64[1] = 0ull; acc64[2] = 0ull; }
+  bsync<NT>();
+  // ---- runs: every cut k-mer alone, and what lies between two cuts of one vertex interval.  First which cuts have a
+  // run behind them (a mask per 64 cuts) and how many such runs lie in front of every 64; then the runs and the chain's
+  // own edges between neighbouring runs
+  const uint32_t cchunks = (nb + 63u) / 64u;
+  auto cut_gap = [&](uint32_t j, uint32_t* c_out, uint32_t* cn_out, bool* more_out) -> bool {
+    const bool h = j < nb;
+    const uint32_t c = h ? CUTL[j] : 0u, cn = (h && j + 1u < nb) ? CUTL[j + 1u] : 0u;
+    const bool more = h && j + 1u < nb;
+    uint32_t hi_v = 0;
+    const bool inside = h && iv_has(VML, MV, c, &hi_v);
+    *c_out = c; *cn_out = cn; *more_out = more;
+    return inside && more && cn <= hi_v && cn > c + 1u;
   };
-  {
-    uint32_t gaps_before = 0;
-    for (uint32_t j0 = 0; j0 < nb; j0 += 64u) {
-      const uint32_t j = j0 + (uint32_t)lane;
-      const bool h = j < nb;
-      const uint32_t c = h ? CUTL[j] : 0u, cn = (h && j + 1u < nb) ? CUTL[j + 1u] : 0u;
-      const bool more = h && j + 1u < nb;
-      uint32_t hi_v = 0;
-      const bool inside = h && iv_has(VML, MV, c, &hi_v);
-      const bool gp = inside && more && cn <= hi_v && cn > c + 1u;
-      const uint64_t m = __ballot(gp);
-      const uint32_t r = j + gaps_before + (uint32_t)__popcll(m & below(lane));
-      if (lane == 0) { GM[j0 >> 6] = m; GP[j0 >> 6] = gaps_before; }
-      uint32_t internal = 0;
-      const bool fits = h && r + 5u < C::NV + 3u;  // (nodes 2 + r .. 4 + r)
-      // chain edges leave the cut k-mer towards the next run (c -> c + 1 upwards, c + 1 -> c downwards) and, where
-      // a run lies between, that run towards the next cut
-      const bool next_to = more && (gp || cn == c + 1u);
-      const bool u0 = next_to && iv_has(UL, MU, c), d0 = next_to && iv_has(DL, MD, c);
-      const bool u1 = gp && iv_has(UL, MU, cn - 1u), d1 = gp && iv_has(DL, MD, cn - 1u);
-      if (fits) {
-        RLO[2u + r] = c; RHI[2u + r] = c; NW[2u + r] = 1u;
-        if (gp) {
-          const uint32_t L = cn - c - 1u;
-          uint32_t cover = 0u;
-          if (L > 1u) {
-            const bool u = iv_has(UL, MU, c + 1u), d = iv_has(DL, MD, c + 1u);
-            cover = (u ? 0x40000000u : 0u) | (d ? 0x80000000u : 0u);
-            internal = ((u ? 1u : 0u) + (d ? 1u : 0u)) * (L - 1u);
-          }
-          RLO[3u + r] = c + 1u; RHI[3u + r] = cn - 1u; NW[3u + r] = L | cover;
-        }
-      }
-      e_internal += wave_sum(internal);
-      emit(fits && u0, 2u + r, 3u + r);
-      emit(fits && d0, 3u + r, 2u + r);
-      emit(fits && u1, 3u + r, 4u + r);
-      emit(fits && d1, 4u + r, 3u + r);
-      gaps_before += (uint32_t)__popcll(m);
-    }
-    R = nb + gaps_before;
+  for (uint32_t ch = wave; ch < cchunks; ch += NT / 64u) {
+    uint32_t c, cn; bool more;
+    const uint64_t m = __ballot(cut_gap(ch * 64u + (uint32_t)lane, &c, &cn, &more));
+    if (lane == 0) { GM[ch] = m; GP[ch] = (uint32_t)__popcll(m); }
   }
+  bsync<NT>();
+  if (wave == 0u) {
+    uint32_t run = 0;
+    for (uint32_t c0 = 0; c0 < cchunks; c0 += 64u) {
+      const uint32_t c = c0 + (uint32_t)lane;
+      const uint32_t mine = c < cchunks ? GP[c] : 0u;
+      const uint32_t incl = wave_scan(mine, lane);
+      lds_sync();
+      if (c < cchunks) GP[c] = run + incl - mine;
+      run += rl(incl, 63);
+    }
+    if (lane == 0) hdr[H_R0] = run;
+  }
+  bsync<NT>();
+  const uint32_t R = nb + hdr[H_R0];
   const uint32_t NV = R + 2u;
   if (NV > C::NV) return 1;
-  if (lane == 0) { RLO[0] = RHI[0] = 0u; NW[0] = 1u; RLO[1] = RHI[1] = 0u; NW[1] = 1u; }  // 0: sink, 1: source
-  lds_sync();
+  uint32_t* n_edges = &hdr[H_N0];
+  auto emit = [&](bool take, uint32_t from, uint32_t to) {  // (order does not matter: a place by an atomic counter)
+    const uint64_t m = __ballot(take);
+    const uint32_t at = wave_reserve(n_edges, m, lane);
+    if (take && at < C::E) EDGE[at] = (from << 16) | to;
+  };
+  for (uint32_t ch = wave; ch < cchunks; ch += NT / 64u) {
+    const uint32_t j = ch * 64u + (uint32_t)lane;
+    uint32_t c, cn; bool more;
+    const bool gp = cut_gap(j, &c, &cn, &more);
+    const bool h = j < nb;
+    const uint32_t r = j + GP[ch] + (uint32_t)__popcll(GM[ch] & below(lane));
+    uint32_t internal = 0;
+    // chain edges leave the cut k-mer towards the next run (c -> c + 1 upwards, c + 1 -> c downwards) and, where
+    // a run lies between, that run towards the next cut
+    const bool next_to = more && (gp || cn == c + 1u);
+    const bool u0 = next_to && iv_has(UL, MU, c), d0 = next_to && iv_has(DL, MD, c);
+    const bool u1 = gp && iv_has(UL, MU, cn - 1u), d1 = gp && iv_has(DL, MD, cn - 1u);
+    if (h) {
+      RLO[2u + r] = c; RHI[2u + r] = c; NW[2u + r] = 1u;
+      if (gp) {
+        const uint32_t L = cn - c - 1u;
+        uint32_t cover = 0u;
+        if (L > 1u) {
+          const bool u = iv_has(UL, MU, c + 1u), d = iv_has(DL, MD, c + 1u);
+          cover = (u ? 0x40000000u : 0u) | (d ? 0x80000000u : 0u);
+          internal = ((u ? 1u : 0u) + (d ? 1u : 0u)) * (L - 1u);
+        }
+        RLO[3u + r] = c + 1u; RHI[3u + r] = cn - 1u; NW[3u + r] = L | cover;
+      }
+    }
+    const uint32_t isum = wave_sum(internal);
+    if (lane == 0 && isum) atomicAdd(&acc64[0], (unsigned long long)isum);
+    emit(h && u0, 2u + r, 3u + r);
+    emit(h && d0, 3u + r, 2u + r);
+    emit(h && u1, 3u + r, 4u + r);
+    emit(h && d1, 4u + r, 3u + r);
+  }
+  if (tid == 0u) { RLO[0] = RHI[0] = 0u; NW[0] = 1u; RLO[1] = RHI[1] = 0u; NW[1] = 1u; }  // 0: sink, 1: source
+  bsync<NT>();
   D2_LAP(4);
   // the node of k-mer x (every end of an edge is a cut: a run of its own)
   auto node_of = [&](uint32_t x) -> uint32_t {
@@ -593,7 +721,7 @@ __device__ int d2_one(uint32_t* lds, const D2Args& A, uint32_t gap, uint32_t* sc
   };
   // ---- the other edges, one per distinct edge of the reference's graph: those that double a chain edge go, self
   // loops (a homopolymer k-mer: never between components) are set aside
-  for (uint32_t i0 = 0; i0 < nsp; i0 += 64u) {
+  for (uint32_t i0 = wave * 64u; i0 < nsp; i0 += NT) {
     const uint32_t i = i0 + (uint32_t)lane;
     const bool h = i < nsp;
     const uint64_t e = h ? SP[i] : 0ull;
@@ -603,41 +731,38 @@ __device__ int d2_one(uint32_t* lds, const D2Args& A, uint32_t gap, uint32_t* sc
     if (keep && a == b + 1u && iv_has(DL, MD, b)) keep = false;
     const bool loop = keep && a == b;
     const uint64_t lm = __ballot(loop);
-    if (loop) { const uint32_t at = nloops + (uint32_t)__popcll(lm & below(lane)); if (at < C::NS) LOOPS[at] = node_of(a); }
-    nloops += (uint32_t)__popcll(lm);
+    const uint32_t lat = wave_reserve(&hdr[H_N1], lm, lane);
+    if (loop && lat < C::NS) LOOPS[lat] = node_of(a);
     const bool edge = keep && !loop;
     emit(edge, edge ? node_of(a) : 0u, edge ? node_of(b) : 0u);
   }
-  if (nloops > C::NS) return 1;
   // the source's edges to the entries that are left-flank k-mers (:1303-1305) and the sink positions' edges to the sink
   // (:1216-1226), one per k-mer: a bit per node, then one edge per bit
   {
-    uint32_t* SM = PM;                    // (the pass-through bits come later)
-    uint32_t* KM = hdr + 16;              // [NV / 32]
-    for (uint32_t i = (uint32_t)lane; i < C::NV / 32u; i += 64u) { SM[i] = 0u; KM[i] = 0u; }
-    lds_sync();
-    for (uint32_t q0 = 0; q0 < nrec; q0 += 64u) {
-      const uint32_t q = q0 + (uint32_t)lane;
-      if (q >= nrec) continue;
+    uint32_t* SM = PM;  // (the pass-through bits come later)
+    for (uint32_t i = tid; i < C::NV / 32u; i += NT) { SM[i] = 0u; KM[i] = 0u; }
+    bsync<NT>();
+    for (uint32_t q = tid; q < nrec; q += NT) {
       const SegD s = seg_load(segs, q);
       if (s.ts() < 0) continue;
       if (s.source()) { const uint32_t v = node_of(s.idx(0)); atomicOr(&SM[v >> 5], 1u << (v & 31u)); }
       const int sp = sink_pos(s);
       if (sp >= 0) { const uint32_t v = node_of(s.idx(sp)); atomicOr(&KM[v >> 5], 1u << (v & 31u)); }
     }
-    lds_sync();
-    for (uint32_t v0 = 0; v0 < NV; v0 += 64u) {
+    bsync<NT>();
+    for (uint32_t v0 = wave * 64u; v0 < NV; v0 += NT) {
       const uint32_t v = v0 + (uint32_t)lane;
       const bool h = v < NV;
       emit(h && ((SM[v >> 5] >> (v & 31u)) & 1u), 1u, v);
       emit(h && ((KM[v >> 5] >> (v & 31u)) & 1u), v, 0u);
     }
-    lds_sync();
   }
-  if (e_full || ne > C::E) return 1;
-  const unsigned long long e_all = e_internal + ne + nloops;
-  gsync();
-  lds_sync();
+  gsync<NT>();
+  const uint32_t ne = hdr[H_N0], nloops = hdr[H_N1];
+  if (plog && tid == 0u) { plog[1] = ns | ((unsigned long long)NV << 32); plog[2] = ne; }
+  if (ne > C::E || nloops > C::NS) return 1;
+  const unsigned long long e_all = acc64[0] + ne + nloops;
+  bsync<NT>();
   D2_LAP(5);
 
   // ---- the graph into LDS (over the tables): offsets and adjacency both ways, live degrees
@@ -650,17 +775,18 @@ __device__ int d2_one(uint32_t* lds, const D2Args& A, uint32_t gap, uint32_t* sc
   uint32_t* comp = dego + C::NV / 2u;
   uint16_t* wl0 = (uint16_t*)(comp + C::NV);
   uint16_t* wl1 = wl0 + C::NV;
-  for (uint32_t i = (uint32_t)lane; i < C::NV / 2u; i += 64u) { degi[i] = 0u; dego[i] = 0u; ((uint32_t*)wl0)[i] = 0u; ((uint32_t*)wl1)[i] = 0u; }
-  for (uint32_t i = (uint32_t)lane; i < C::NV / 32u; i += 64u) PM[i] = 0u;
-  for (uint32_t v = (uint32_t)lane; v < NV; v += 64u) comp[v] = D2_ALIVE;
-  lds_sync();
-  for (uint32_t i = (uint32_t)lane; i < ne; i += 64u) {
+  for (uint32_t i = tid; i < C::NV / 2u; i += NT) { degi[i] = 0u; dego[i] = 0u; ((uint32_t*)wl0)[i] = 0u; ((uint32_t*)wl1)[i] = 0u; }
+  for (uint32_t i = tid; i < C::NV / 32u; i += NT) PM[i] = 0u;
+  for (uint32_t v = tid; v < NV; v += NT) comp[v] = D2_ALIVE;
+  if (tid == 0u) { hdr[H_NEXT] = 0u; hdr[H_ORDER] = 0u; hdr[H_BIGS] = 0u; hdr[H_N0] = 0u; hdr[H_N1] = 0u; hdr[H_N2] = 0u; acc64[0] = 0ull; }
+  bsync<NT>();
+  for (uint32_t i = tid; i < ne; i += NT) {
     const uint32_t e = EDGE[i];
     pk_add(dego, e >> 16, 1u);
     pk_add(degi, e & 0xFFFFu, 1u);
   }
-  lds_sync();
-  {
+  bsync<NT>();
+  if (wave == 0u) {
     uint32_t run_f = 0, run_r = 0;
     for (uint32_t v0 = 0; v0 < NV; v0 += 64u) {
       const uint32_t v = v0 + (uint32_t)lane;
@@ -672,33 +798,33 @@ __device__ int d2_one(uint32_t* lds, const D2Args& A, uint32_t gap, uint32_t* sc
     }
     if (lane == 0) { off_f[NV] = (uint16_t)run_f; off_r[NV] = (uint16_t)run_r; }
   }
-  lds_sync();
+  bsync<NT>();
   {  // (the two work lists serve as fill cursors first)
     uint32_t* cur_f = (uint32_t*)wl0;
     uint32_t* cur_r = (uint32_t*)wl1;
-    for (uint32_t i = (uint32_t)lane; i < ne; i += 64u) {
+    for (uint32_t i = tid; i < ne; i += NT) {
       const uint32_t e = EDGE[i];
       const uint32_t a = e >> 16, b = e & 0xFFFFu;
       adj_f[(uint32_t)off_f[a] + pk_add(cur_f, a, 1u)] = (uint16_t)b;
       adj_r[(uint32_t)off_r[b] + pk_add(cur_r, b, 1u)] = (uint16_t)a;
     }
   }
-  lds_sync();
+  bsync<NT>();
   D2_LAP(6);
 
   // ---- pass-through nodes leave the graph: a run with one edge in and one out (and not covered in both directions)
   // only hands on what reaches it.  Every other node's edges skip them — the adjacency entry becomes the node at the
   // chain's end — and a pass-through node remembers which edge of which node its chain is.  What is left has as many
   // levels as the paths have BRANCHINGS, not runs (a tenth to a third).
-  for (uint32_t v0 = 0; v0 < NV; v0 += 64u) {
+  for (uint32_t v0 = wave * 64u; v0 < NV; v0 += NT) {
     const uint32_t v = v0 + (uint32_t)lane;
     const bool pass = !(A.pass_all & 2u) && v >= 2u && v < NV && pk_get(degi, v) == 1u && pk_get(dego, v) == 1u && (NW[v] & 0xC0000000u) != 0xC0000000u;
     if (pass) comp[v] = D2_PASS;
     const uint64_t m = __ballot(pass);
     if (lane == 0) { PM[v0 >> 5] = (uint32_t)m; if ((v0 >> 5) + 1u < C::NV / 32u) PM[(v0 >> 5) + 1u] = (uint32_t)(m >> 32); }
   }
-  lds_sync();
-  for (uint32_t u = (uint32_t)lane; u < NV; u += 64u) {
+  bsync<NT>();
+  for (uint32_t u = tid; u < NV; u += NT) {
     if (comp[u] != D2_ALIVE) continue;
     uint32_t k = 0;
     for (uint32_t e = off_f[u]; e < (uint32_t)off_f[u + 1u]; e++, k++) {
@@ -715,19 +841,19 @@ __device__ int d2_one(uint32_t* lds, const D2Args& A, uint32_t gap, uint32_t* sc
       adj_r[e] = (uint16_t)p;
     }
   }
-  lds_sync();
+  bsync<NT>();
 
   // ---- strong components of what is left.  A node without a live edge in, or without one out, is a component of
   // its own: taken (its state becomes its own id) by whoever sees its last such edge go, and its edges dropped by the
   // same lane at once — a lane follows a chain of such nodes without a round trip through the work list, which only
   // takes the second and further nodes a step frees.
-  uint32_t* n_next = hdr;
+  uint32_t* n_next = &hdr[H_NEXT];
   uint16_t* cur = wl0;
   uint16_t* nxt = wl1;
   auto take = [&](uint32_t v) -> bool { return atomicCAS(&comp[v], D2_ALIVE, v) == D2_ALIVE; };
   auto spill = [&](uint32_t v) { nxt[atomicAdd(n_next, 1u)] = (uint16_t)v; };
   // drops the edges of u (which has left the live graph) and of every node that frees along the way
-  auto peel_from = [&](uint32_t u, bool first_only_drop) {
+  auto peel_from = [&](uint32_t u) {
     for (uint32_t steps = 0; steps <= NV; steps++) {
       uint32_t next = D2_NONE;
       for (uint32_t e = off_f[u]; e < (uint32_t)off_f[u + 1u]; e++) {
@@ -741,88 +867,95 @@ __device__ int d2_one(uint32_t* lds, const D2Args& A, uint32_t gap, uint32_t* sc
       if (next == D2_NONE) break;
       u = next;
     }
-    (void)first_only_drop;
   };
-  if (lane == 0) *n_next = 0u;
-  lds_sync();
-  for (uint32_t v = (uint32_t)lane; v < NV; v += 64u)
-    if (comp[v] == D2_ALIVE && (pk_get(degi, v) == 0u || pk_get(dego, v) == 0u) && take(v)) peel_from(v, false);
+  for (uint32_t v = tid; v < NV; v += NT)
+    if (comp[v] == D2_ALIVE && (pk_get(degi, v) == 0u || pk_get(dego, v) == 0u) && take(v)) peel_from(v);
   uint32_t ncur = 0;
   uint32_t guard = 0;  // (every loop below ends after at most NV rounds by construction; a defect must not hold the GPU)
   const uint32_t guard_max = 8u * NV + 64u;
   for (;;) {
     for (;;) {  // what the lanes above could not follow themselves
-      lds_sync();
-      ncur = uni(*n_next);
+      bsync<NT>();
+      ncur = hdr[H_NEXT];
+      bsync<NT>();
       if (ncur == 0u || ++guard > guard_max) break;
       { uint16_t* t = cur; cur = nxt; nxt = t; }
-      if (lane == 0) *n_next = 0u;
-      lds_sync();
-      for (uint32_t i = (uint32_t)lane; i < ncur; i += 64u) peel_from(cur[i], false);
+      if (tid == 0u) *n_next = 0u;
+      bsync<NT>();
+      for (uint32_t i = tid; i < ncur; i += NT) peel_from(cur[i]);
     }
     // what is left lies on cycles or between them: the component of the lowest live node
-    uint32_t pivot = 0xFFFFFFFFu;
-    for (uint32_t v0 = 0; v0 < NV; v0 += 64u) {
+    if (tid == 0u) hdr[H_PIVOT] = 0xFFFFFFFFu;
+    bsync<NT>();
+    for (uint32_t v0 = wave * 64u; v0 < NV; v0 += NT) {
       const uint32_t v = v0 + (uint32_t)lane;
-      pivot = min(pivot, wave_min((v < NV && comp[v] == D2_ALIVE) ? v : 0xFFFFFFFFu));
+      const uint32_t mn = wave_min((v < NV && comp[v] == D2_ALIVE) ? v : 0xFFFFFFFFu);
+      if (lane == 0 && mn != 0xFFFFFFFFu) atomicMin(&hdr[H_PIVOT], mn);
     }
+    bsync<NT>();
+    const uint32_t pivot = hdr[H_PIVOT];
+    bsync<NT>();
     if (pivot == 0xFFFFFFFFu || guard > guard_max) break;
     // forward from the pivot over live nodes ...
-    if (lane == 0) { comp[pivot] = D2_FW; cur[0] = (uint16_t)pivot; *n_next = 0u; }
+    if (tid == 0u) { comp[pivot] = D2_FW; cur[0] = (uint16_t)pivot; *n_next = 0u; }
     ncur = 1u;
-    lds_sync();
+    bsync<NT>();
     while (ncur && ++guard <= guard_max) {
-      for (uint32_t i = (uint32_t)lane; i < ncur; i += 64u) {
+      for (uint32_t i = tid; i < ncur; i += NT) {
         const uint32_t u = cur[i];
         for (uint32_t e = off_f[u]; e < (uint32_t)off_f[u + 1u]; e++) {
           const uint32_t w = adj_f[e];
           if (atomicCAS(&comp[w], D2_ALIVE, D2_FW) == D2_ALIVE) nxt[atomicAdd(n_next, 1u)] = (uint16_t)w;
         }
       }
-      lds_sync();
-      ncur = uni(*n_next);
+      bsync<NT>();
+      ncur = hdr[H_NEXT];
+      bsync<NT>();
       { uint16_t* t = cur; cur = nxt; nxt = t; }
-      if (lane == 0) *n_next = 0u;
-      lds_sync();
+      if (tid == 0u) *n_next = 0u;
+      bsync<NT>();
     }
     // ... and backward from it over what the forward search reached: the intersection is the component
-    if (lane == 0) { comp[pivot] = D2_FWBW; cur[0] = (uint16_t)pivot; }
+    if (tid == 0u) { comp[pivot] = D2_FWBW; cur[0] = (uint16_t)pivot; }
     ncur = 1u;
-    lds_sync();
+    bsync<NT>();
     while (ncur && ++guard <= guard_max) {
-      for (uint32_t i = (uint32_t)lane; i < ncur; i += 64u) {
+      for (uint32_t i = tid; i < ncur; i += NT) {
         const uint32_t u = cur[i];
         for (uint32_t e = off_r[u]; e < (uint32_t)off_r[u + 1u]; e++) {
           const uint32_t p = adj_r[e];
           if (atomicCAS(&comp[p], D2_FW, D2_FWBW) == D2_FW) nxt[atomicAdd(n_next, 1u)] = (uint16_t)p;
         }
       }
-      lds_sync();
-      ncur = uni(*n_next);
+      bsync<NT>();
+      ncur = hdr[H_NEXT];
+      bsync<NT>();
       { uint16_t* t = cur; cur = nxt; nxt = t; }
-      if (lane == 0) *n_next = 0u;
-      lds_sync();
+      if (tid == 0u) *n_next = 0u;
+      bsync<NT>();
     }
     // the component's nodes leave the live graph together; the others the forward search marked are live again
-    uint32_t nmem = 0;
-    for (uint32_t v0 = 0; v0 < NV; v0 += 64u) {
+    if (tid == 0u) hdr[H_N2] = 0u;
+    bsync<NT>();
+    for (uint32_t v0 = wave * 64u; v0 < NV; v0 += NT) {
       const uint32_t v = v0 + (uint32_t)lane;
       const uint32_t st = v < NV ? comp[v] : 0u;
       if (st == D2_FW) comp[v] = D2_ALIVE;
       const bool mem = st == D2_FWBW;
       const uint64_t m = __ballot(mem);
-      if (mem) { comp[v] = pivot; cur[nmem + (uint32_t)__popcll(m & below(lane))] = (uint16_t)v; }
-      nmem += (uint32_t)__popcll(m);
+      const uint32_t at = wave_reserve(&hdr[H_N2], m, lane);
+      if (mem) { comp[v] = pivot; cur[at] = (uint16_t)v; }
     }
-    lds_sync();
-    for (uint32_t i = (uint32_t)lane; i < nmem; i += 64u) peel_from(cur[i], false);
-    lds_sync();
+    bsync<NT>();
+    const uint32_t nmem = hdr[H_N2];
+    for (uint32_t i = tid; i < nmem; i += NT) peel_from(cur[i]);
   }
-  lds_sync();
+  bsync<NT>();
   if (guard > guard_max) return 2;
+  if (plog && tid == 0u) plog[1] |= (unsigned long long)min(guard, 0xFFFFu) << 48;
   // a pass-through node belongs to the component both ends of its chain are in (the chain then lies on a cycle), and is
   // a component of its own otherwise — HEAD: the component its chain leaves
-  for (uint32_t v = (uint32_t)lane; v < NV; v += 64u) {
+  for (uint32_t v = tid; v < NV; v += NT) {
     const uint32_t st = comp[v];
     if (!d2_is_pass(st)) continue;
     uint32_t c = v, head = v;
@@ -835,7 +968,7 @@ __device__ int d2_one(uint32_t* lds, const D2Args& A, uint32_t gap, uint32_t* sc
     HEAD[v] = head;
     comp[v] = c;
   }
-  lds_sync();
+  bsync<NT>();
   D2_LAP(7);
 
   // ---- the components: size, which are non-trivial (several nodes, or a run covered in both directions), the
@@ -844,62 +977,71 @@ __device__ int d2_one(uint32_t* lds, const D2Args& A, uint32_t gap, uint32_t* sc
   uint32_t* cdeg_in = (uint32_t*)adj_r;           // packed: edges into the component from others ...
   uint32_t* cdeg_out = cdeg_in + C::NV / 2u;      // ... and out of it (E * 2 bytes >= NV * 2 bytes: E >= 2 NV)
   uint32_t* cwork = (uint32_t*)off_r;             // packed: edges in not yet accounted for (Kahn)
-  static_assert(C::E >= 2u * C::NV, "the reverse adjacency's space holds two packed degree tables");
-  for (uint32_t v = (uint32_t)lane; v < C::NV; v += 64u) csize[v] = 0u;
-  for (uint32_t i = (uint32_t)lane; i < C::NV / 2u; i += 64u) { cdeg_in[i] = 0u; cdeg_out[i] = 0u; }
-  for (uint32_t i = (uint32_t)lane; i < (C::NV + 2u) / 2u; i += 64u) cwork[i] = 0u;
-  lds_sync();
-  for (uint32_t v = (uint32_t)lane; v < NV; v += 64u) atomicAdd(&csize[comp[v]], 1u);
-  lds_sync();
+  for (uint32_t v = tid; v < C::NV; v += NT) csize[v] = 0u;
+  for (uint32_t i = tid; i < C::NV / 2u; i += NT) { cdeg_in[i] = 0u; cdeg_out[i] = 0u; }
+  for (uint32_t i = tid; i < (C::NV + 2u) / 2u; i += NT) cwork[i] = 0u;
+  if (tid == 0u) { hdr[H_R0] = 0u; hdr[H_R1] = 0u; acc64[0] = 0ull; acc64[1] = 0ull; }
+  bsync<NT>();
+  for (uint32_t v = tid; v < NV; v += NT) atomicAdd(&csize[comp[v]], 1u);
+  bsync<NT>();
   auto is_pass_node = [&](uint32_t v) -> bool { return (PM[v >> 5] >> (v & 31u)) & 1u; };
   auto nontriv = [&](uint32_t c) -> bool { return (csize[c] & 0x3FFFFFFFu) > 1u || (NW[c] & 0xC0000000u) == 0xC0000000u; };
-  unsigned long long fe = 0;
-  for (uint32_t i0 = 0; i0 < ne; i0 += 64u) {
+  // acc64[0]: edges of the contracted graph, acc64[1]: k-mers in non-trivial components; H_R0: non-trivial components,
+  // H_R1: self loops outside them
+  for (uint32_t i0 = wave * 64u; i0 < ne; i0 += NT) {
     const uint32_t i = i0 + (uint32_t)lane;
     const bool h = i < ne;
     const uint32_t e = h ? EDGE[i] : 0u;
     const uint32_t a = h ? comp[e >> 16] : 0u, b = h ? comp[e & 0xFFFFu] : 0u;
     const bool cross = h && a != b;
     if (cross) { pk_add(cdeg_out, a, 1u); pk_add(cdeg_in, b, 1u); }
-    fe += (unsigned long long)__popcll(__ballot(cross));
+    const uint32_t nc = (uint32_t)__popcll(__ballot(cross));
+    if (lane == 0 && nc) atomicAdd(&acc64[0], (unsigned long long)nc);
   }
   // (what Kahn counts down: the edges into a component from other components with the chains skipped)
-  for (uint32_t u = (uint32_t)lane; u < NV; u += 64u) {
+  for (uint32_t u = tid; u < NV; u += NT) {
     if (is_pass_node(u)) continue;
     const uint32_t a = comp[u];
     for (uint32_t e = off_f[u]; e < (uint32_t)off_f[u + 1u]; e++) { const uint32_t b = comp[adj_f[e]]; if (b != a) pk_add(cwork, b, 1u); }
   }
-  uint32_t nontrivial = 0;
-  unsigned long long size_nontrivial = 0;
-  for (uint32_t v0 = 0; v0 < NV; v0 += 64u) {
+  for (uint32_t v0 = wave * 64u; v0 < NV; v0 += NT) {
     const uint32_t v = v0 + (uint32_t)lane;
     const bool h = v < NV;
     const uint32_t c = h ? comp[v] : 0u;
     const bool nt = h && nontriv(c);
     const uint32_t wgt = h ? (NW[v] & 0x3FFFFFFFu) : 0u, cov = h ? NW[v] >> 30 : 0u;
-    nontrivial += (uint32_t)__popcll(__ballot(nt && c == v));
-    size_nontrivial += wave_sum(nt ? wgt : 0u);
+    const uint32_t n_nt = (uint32_t)__popcll(__ballot(nt && c == v));
+    const uint32_t s_nt = wave_sum(nt ? wgt : 0u);
     // (a run outside the non-trivial components keeps its own edges in the contracted graph)
-    fe += wave_sum((h && !nt && wgt > 1u) ? ((cov & 1u) + (cov >> 1)) * (wgt - 1u) : 0u);
+    const uint32_t own = wave_sum((h && !nt && wgt > 1u) ? ((cov & 1u) + (cov >> 1)) * (wgt - 1u) : 0u);
+    if (lane == 0) {
+      if (n_nt) atomicAdd(&hdr[H_R0], n_nt);
+      if (s_nt) atomicAdd(&acc64[1], (unsigned long long)s_nt);
+      if (own) atomicAdd(&acc64[0], (unsigned long long)own);
+    }
   }
-  uint32_t loops_trivial = 0;
-  for (uint32_t i0 = 0; i0 < nloops; i0 += 64u) {
+  for (uint32_t i0 = wave * 64u; i0 < nloops; i0 += NT) {
     const uint32_t i = i0 + (uint32_t)lane;
-    loops_trivial += (uint32_t)__popcll(__ballot(i < nloops && !nontriv(comp[LOOPS[i]])));  // :1385-1402
+    const uint32_t lt = (uint32_t)__popcll(__ballot(i < nloops && !nontriv(comp[LOOPS[i]])));  // :1385-1402
+    if (lane == 0 && lt) atomicAdd(&hdr[H_R1], lt);
   }
-  lds_sync();
+  bsync<NT>();
+  const unsigned long long fe = acc64[0], size_nontrivial = acc64[1];
+  const uint32_t nontrivial = hdr[H_R0], loops_trivial = hdr[H_R1];
+  bsync<NT>();
   D2_LAP(8);
 
   // ---- the components (chains skipped) in a topological order: a component whose last edge in has been accounted
   // for takes the next place — the lane that accounted for it goes on with it at once; components of several nodes
-  // wait for a pass of all lanes over their nodes
-  uint32_t* n_order = hdr + 1;
-  uint32_t* n_bigs = hdr + 2;
-  uint16_t* bigs_a = (uint16_t*)(hdr + 4);  // (a handful: two lists of 12 entries that take turns)
-  uint16_t* bigs_b = bigs_a + 12;
+  // wait for a pass of all threads over their nodes
+  uint32_t* n_order = &hdr[H_ORDER];
+  uint32_t* n_bigs = &hdr[H_BIGS];
+  uint16_t* bigs_a = (uint16_t*)(hdr + H_BIGS_A);  // (a handful: two lists of 12 entries that take turns)
+  uint16_t* bigs_b = (uint16_t*)(hdr + H_BIGS_B);
   uint16_t* bigs = bigs_a;
-  if (lane == 0) { *n_next = 0u; *n_order = 0u; *n_bigs = 0u; }
-  lds_sync();
+  cur = wl0; nxt = wl1;
+  if (tid == 0u) { *n_next = 0u; *n_order = 0u; *n_bigs = 0u; }
+  bsync<NT>();
   auto ready = [&](uint32_t b, uint32_t* next) {  // component b has no edge in left
     if ((csize[b] & 0x3FFFFFFFu) > 1u && !is_pass_node(b)) { const uint32_t at = atomicAdd(n_bigs, 1u); if (at < 12u) bigs[at] = (uint16_t)b; else spill(b); }
     else if (*next == D2_NONE) *next = b;
@@ -918,22 +1060,23 @@ __device__ int d2_one(uint32_t* lds, const D2Args& A, uint32_t gap, uint32_t* sc
     }
   };
   // (the components without an edge in — the source's — go through the list: looked for before anything is counted down)
-  for (uint32_t v = (uint32_t)lane; v < NV; v += 64u)
+  for (uint32_t v = tid; v < NV; v += NT)
     if (comp[v] == v && !is_pass_node(v) && pk_get(cwork, v) == 0u) spill(v);
   for (guard = 0; guard <= guard_max; guard++) {
-    lds_sync();
-    const uint32_t nbig = min(uni(*n_bigs), 12u);
-    ncur = uni(*n_next);
+    bsync<NT>();
+    const uint32_t nbig = min(hdr[H_BIGS], 12u);
+    ncur = hdr[H_NEXT];
+    bsync<NT>();
     if (nbig == 0u && ncur == 0u) break;
     { uint16_t* t = cur; cur = nxt; nxt = t; }
     const uint16_t* bigs_now = bigs;
     bigs = bigs == bigs_a ? bigs_b : bigs_a;  // (what becomes ready meanwhile is listed in the other half)
-    if (lane == 0) { *n_next = 0u; *n_bigs = 0u; }
-    lds_sync();
-    for (uint32_t x = 0; x < nbig; x++) {  // a component of several nodes: all lanes over the nodes
-      const uint32_t cc = uni((uint32_t)bigs_now[x]);
-      if (lane == 0) ORDER[atomicAdd(n_order, 1u)] = cc;
-      for (uint32_t v = (uint32_t)lane; v < NV; v += 64u) {
+    if (tid == 0u) { *n_next = 0u; *n_bigs = 0u; }
+    bsync<NT>();
+    for (uint32_t x = 0; x < nbig; x++) {  // a component of several nodes: all threads over the nodes
+      const uint32_t cc = bigs_now[x];
+      if (tid == 0u) ORDER[atomicAdd(n_order, 1u)] = cc;
+      for (uint32_t v = tid; v < NV; v += NT) {
         if (comp[v] != cc || is_pass_node(v)) continue;
         uint32_t next = D2_NONE;
         for (uint32_t e = off_f[v]; e < (uint32_t)off_f[v + 1u]; e++) {
@@ -943,28 +1086,32 @@ __device__ int d2_one(uint32_t* lds, const D2Args& A, uint32_t gap, uint32_t* sc
         if (next != D2_NONE) order_from(next);
       }
     }
-    for (uint32_t i = (uint32_t)lane; i < ncur; i += 64u) {
+    for (uint32_t i = tid; i < ncur; i += NT) {
       const uint32_t c = cur[i];
       if ((csize[c] & 0x3FFFFFFFu) > 1u && !is_pass_node(c)) { const uint32_t at = atomicAdd(n_bigs, 1u); if (at < 12u) bigs[at] = (uint16_t)c; else spill(c); }
       else order_from(c);
     }
   }
-  lds_sync();
-  const uint32_t n_ord = uni(*n_order);
+  bsync<NT>();
+  const uint32_t n_ord = hdr[H_ORDER];
+  if (plog && tid == 0u) plog[2] |= (unsigned long long)min(guard, 0xFFFFu) << 48;
   {  // (every component outside the chains has its place: anything else is a defect — the gap is left to the host)
-    uint32_t n_branch = 0;
-    for (uint32_t v0 = 0; v0 < NV; v0 += 64u) {
+    if (tid == 0u) hdr[H_N2] = 0u;
+    bsync<NT>();
+    for (uint32_t v0 = wave * 64u; v0 < NV; v0 += NT) {
       const uint32_t v = v0 + (uint32_t)lane;
-      n_branch += (uint32_t)__popcll(__ballot(v < NV && comp[v] == v && !is_pass_node(v)));
+      const uint32_t nbr = (uint32_t)__popcll(__ballot(v < NV && comp[v] == v && !is_pass_node(v)));
+      if (lane == 0 && nbr) atomicAdd(&hdr[H_N2], nbr);
     }
-    if (n_branch != n_ord) { if (A.prof && lane == 0) atomicAdd(A.prof + 10, 1000000ull); return 2; }
+    bsync<NT>();
+    if (hdr[H_N2] != n_ord || n_ord == 0u) { if (A.prof && tid == 0u) atomicAdd(A.prof + 10, 1000000ull); return 2; }
   }
-  gsync();
+  gsync<NT>();
   D2_LAP(9);
   // ---- the branch rule over that order (:1411-1434): -(in - 1) in front of a vertex, +(out - 1) behind it.  Bit 31
   // of a component's word: the count is 1 at it; bit 30: the count is 1 behind it (what the nodes of a chain that
   // leaves it see: one edge in, one out each, the count does not move along them)
-  {
+  if (wave == 0u) {
     int bc = 1;
     for (uint32_t p0 = 0; p0 < n_ord; p0 += 64u) {
       const uint32_t p = p0 + (uint32_t)lane;
@@ -979,7 +1126,7 @@ __device__ int d2_one(uint32_t* lds, const D2Args& A, uint32_t gap, uint32_t* sc
       bc += (int)rl((uint32_t)incl, 63);
     }
   }
-  lds_sync();
+  bsync<NT>();
   auto verdict = [&](uint32_t v) -> uint32_t {  // branch[v] == 1, v outside the non-trivial components
     const uint32_t c = comp[v];
     if (nontriv(c)) return 0u;
@@ -988,16 +1135,19 @@ __device__ int d2_one(uint32_t* lds, const D2Args& A, uint32_t gap, uint32_t* sc
   };
   const bool sink_safe = verdict(0u) != 0u;
   // ---- what leaves: the runs with their verdicts, the statistics
-  unsigned long long base = 0;
-  if (lane == 0) base = atomicAdd(A.run_cursor, (unsigned long long)R);
-  base = ((unsigned long long)uni((uint32_t)(base >> 32)) << 32) | uni((uint32_t)base);
-  if (base + R > A.run_cap || n_ord == 0u) return 2;
+  if (tid == 0u) {
+    const unsigned long long b0 = atomicAdd(A.run_cursor, (unsigned long long)R);
+    hdr[H_BASE_LO] = (uint32_t)b0; hdr[H_BASE_HI] = (uint32_t)(b0 >> 32);
+  }
+  bsync<NT>();
+  const unsigned long long base = ((unsigned long long)hdr[H_BASE_HI] << 32) | hdr[H_BASE_LO];
+  if (base + R > A.run_cap) return 2;
   uint32_t* runs = A.runs + 2ull * base;
-  for (uint32_t r = (uint32_t)lane; r < R; r += 64u) {
+  for (uint32_t r = tid; r < R; r += NT) {
     runs[2u * r] = RLO[2u + r];
     runs[2u * r + 1u] = RHI[2u + r] | (verdict(2u + r) << 31);
   }
-  if (lane == 0) {
+  if (tid == 0u) {
     D2Out o;
     o.run_off = (uint32_t)base; o.n_runs = R;
     o.sub[0] = V;
@@ -1009,74 +1159,104 @@ __device__ int d2_one(uint32_t* lds, const D2Args& A, uint32_t gap, uint32_t* sc
     A.d2out[gap] = o;
     go->sub_vertices = V; go->sub_edges = o.sub[1];
   }
-  d2_publish(go, (uni(go->dflags) & ~G2S_DEVA_SINK_SAFE) | G2S_DEVA_ANALYSED | G2S_DEVA_RUNS | (sink_safe ? G2S_DEVA_SINK_SAFE : 0u), lane);
+  d2_publish<NT>(go, (dflags0 & ~G2S_DEVA_SINK_SAFE) | G2S_DEVA_ANALYSED | G2S_DEVA_RUNS | (sink_safe ? G2S_DEVA_SINK_SAFE : 0u), A.behind != 0u);
   D2_LAP(10);
-  if (A.prof && lane == 0) { atomicAdd(A.prof + 11, 1ull); atomicAdd(A.prof + 12, (unsigned long long)NV); atomicAdd(A.prof + 13, (unsigned long long)guard); }
+  if (A.prof && tid == 0u) { atomicAdd(A.prof + 11, 1ull); atomicAdd(A.prof + 12, (unsigned long long)NV); atomicAdd(A.prof + 13, (unsigned long long)guard); }
   return 0;
 }
 
 // the next gap of the list for this workgroup, or D2_NONE when there is none (and, polling, none can come any more)
 __device__ __forceinline__ uint32_t d2_claim(const D2Args& A) {
   uint32_t gap = D2_NONE;
-  if (threadIdx.x == 0) {
-    for (uint32_t spins = 0;;) {
-      const unsigned long long cur = __hip_atomic_load(A.next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned long long cnt = __hip_atomic_load(A.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (cur < cnt && cur < (unsigned long long)A.list_cap) {
-        if (atomicCAS(A.next, cur, cur + 1ull) != cur) continue;  // (another workgroup took it)
-        uint32_t e = 0;
-        if (A.tag) {  // (the entry follows its counter: wait for this list's tag, then leave the place clean)
-          for (uint32_t w = 0; w < (1u << 24); w++) {
-            e = __hip_atomic_load(&A.list[cur], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((e & 0xFF000000u) == A.tag) break;
-            __builtin_amdgcn_s_sleep(4);
-          }
-          if ((e & 0xFF000000u) != A.tag) continue;  // (never expected: the gap stays pending and the list goes to the host path)
-          __hip_atomic_store(&A.list[cur], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          e &= 0x00FFFFFFu;
-        } else e = A.list[cur];
-        gap = e;
+  if (!A.poll) {
+    // (behind the fill kernels the list is complete: a ticket.  Not a compare-and-swap loop — a thousand workgroups that
+    // start together retry half a million times on one word, and for milliseconds everything that touches the counters'
+    // cache line waits behind them: tools/r05_c5_wgs.sh, LAB_NOTES)
+    const unsigned long long cnt = __hip_atomic_load(A.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (__hip_atomic_load(A.next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= cnt) return D2_NONE;
+    const unsigned long long at = atomicAdd(A.next, 1ull);
+    if (at >= cnt || at >= (unsigned long long)A.list_cap) return D2_NONE;
+    const uint32_t e = A.list[at];
+    if (A.tag) A.list[at] = 0u;  // (tagged entries: the place is left clean for a polling launch of a later list)
+    return A.tag ? (e & 0x00FFFFFFu) : e;
+  }
+  for (uint32_t spins = 0;;) {
+    const unsigned long long cur = __hip_atomic_load(A.next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long cnt = __hip_atomic_load(A.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cur < cnt && cur < (unsigned long long)A.list_cap) {
+      if (atomicCAS(A.next, cur, cur + 1ull) != cur) continue;  // (another workgroup took it)
+      uint32_t e = 0;
+      if (A.tag) {  // (the entry follows its counter: wait for this list's tag, then leave the place clean)
+        for (uint32_t w = 0; w < (1u << 24); w++) {
+          e = __hip_atomic_load(&A.list[cur], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((e & 0xFF000000u) == A.tag) break;
+          __builtin_amdgcn_s_sleep(4);
+        }
+        if ((e & 0xFF000000u) != A.tag) continue;  // (never expected: the gap stays pending and the list goes to the host path)
+        __hip_atomic_store(&A.list[cur], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        e &= 0x00FFFFFFu;
+      } else e = A.list[cur];
+      gap = e;
+      break;
+    }
+    if (!A.poll) break;
+    // (a look at the list every few microseconds; at the 64 counters that say whether anything can still come only
+    // every eighth time: 64 loads from the L2 that the fill kernel's own atomics go through)
+    if ((spins & 7u) == 7u) {
+      unsigned long long through = 0;
+      for (int q = 0; q < 64; q++) through += __hip_atomic_load(A.done + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (through >= A.expected) {  // every gap of the fill launch is through: what is listed now is all there will be
+        if (__hip_atomic_load(A.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >
+            __hip_atomic_load(A.next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) continue;
         break;
       }
-      if (!A.poll) break;
-      // (a look at the list every few microseconds; at the 64 counters that say whether anything can still come only
-      // every eighth time: 64 loads from the L2 that the fill kernel's own atomics go through)
-      if ((spins & 7u) == 7u) {
-        unsigned long long through = 0;
-        for (int q = 0; q < 64; q++) through += __hip_atomic_load(A.done + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (through >= A.expected) {  // every gap of the fill launch is through: what is listed now is all there will be
-          if (__hip_atomic_load(A.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >
-              __hip_atomic_load(A.next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) continue;
-          break;
-        }
-      }
-      if (++spins > (1u << 17)) break;  // (half a second: a defect must not hold the GPU; what is left is taken by the launch behind the fill kernels)
-      __builtin_amdgcn_s_sleep(127);
-      __builtin_amdgcn_s_sleep(127);
     }
+    if (++spins > (1u << 17)) break;  // (half a second: a defect must not hold the GPU; what is left is taken by the launch behind the fill kernels)
+    __builtin_amdgcn_s_sleep(127);
+    __builtin_amdgcn_s_sleep(127);
   }
-  return uni(gap);
+  return gap;
 }
 
 template <class C>
 __device__ __forceinline__ void d2_loop(uint32_t* lds, const D2Args& A) {
+  constexpr uint32_t NT = C::NT;
   uint32_t* scr = A.scratch + (size_t)blockIdx.x * C::SCR_WORDS;
+  uint32_t* hdr_gap = lds + (C::LDS_BYTES - C::HDR_WORDS * 4u) / 4u + H_GAP;
   for (;;) {
-    const uint32_t gap = d2_claim(A);
+    if (threadIdx.x == 0) *hdr_gap = d2_claim(A);
+    bsync<NT>();
+    const uint32_t gap = uni(*hdr_gap);
+    bsync<NT>();
     if (gap == D2_NONE) break;
     // (an entry taken while the fill kernel runs: with the fill wave's fence in front of it, record and closure are here;
     // a launch behind the fill kernels sees everything anyway)
     if (A.tag) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const unsigned long long t_in = A.prof ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    if (A.prof && A.log) {
+      if (threadIdx.x == 0) {
+        const uint32_t slot = (uint32_t)atomicAdd(A.prof + 21, 1ull);
+        hdr_gap[H_SLOT - H_GAP] = slot;
+        if (slot < A.log_cap) { unsigned long long* e = A.log + 16ull * slot; for (int q = 0; q < 16; q++) e[q] = 0ull; e[0] = gap | ((unsigned long long)A.outs[gap].n_xl << 32); e[15] = (C::NT == 64u ? 0ull : 1ull) | ((unsigned long long)(blockIdx.x & 0x7FFFu) << 1) | (t_in << 16); }
+      }
+      bsync<NT>();
+    }
     const int rc = ((A.pass_all & 1u) && A.list_next) ? 1 : d2_one<C>(lds, A, gap, scr);
-    if (A.prof && rc != 0 && threadIdx.x == 0) atomicAdd(A.prof + 13 + rc, 1ull);  // (14: beyond the capacities, 15: given up)
+    bsync<NT>();
+    if (A.prof && threadIdx.x == 0) {
+      if (rc != 0) atomicAdd(A.prof + 13 + rc, 1ull);  // (14: beyond the capacities, 15: given up)
+      const unsigned long long dt = __builtin_amdgcn_s_memrealtime() - t_in;
+      atomicAdd(A.prof + 17, 1ull); atomicAdd(A.prof + 18, dt);
+      if (atomicMax(A.prof + 16, dt) < dt) A.prof[20] = A.outs[gap].n_xl;
+      if (A.log && hdr_gap[H_SLOT - H_GAP] < A.log_cap) { unsigned long long* e = A.log + 16ull * hdr_gap[H_SLOT - H_GAP]; e[2] |= (unsigned long long)(rc & 0xFFFF) << 32; e[14] = dt; }
+    }
     if (rc == 1 && A.list_next && threadIdx.x == 0) {  // beyond these capacities: the larger instantiation's
       const unsigned long long at = atomicAdd(A.count_next, 1ull);
       if (at < (unsigned long long)A.list_cap) A.list_next[at] = gap;
     }
     // (rc == 2, or 1 where nobody takes the gap over: it stays without G2S_DEVA_ANALYSED — the host's, post.cpp — and says so)
-    if (rc != 0 && !(rc == 1 && A.list_next)) d2_publish(A.outs + gap, uni(A.outs[gap].dflags) | G2S_DEVA_D2_FAILED, (int)threadIdx.x);
-    lds_sync();
-    gsync();
+    if (rc != 0 && !(rc == 1 && A.list_next)) d2_publish<NT>(A.outs + gap, uni(A.outs[gap].dflags) | G2S_DEVA_D2_FAILED, A.behind != 0u);
+    gsync<NT>();
   }
   if (A.wgs_done && threadIdx.x == 0) { __threadfence(); atomicAdd(A.wgs_done, 1ull); }
 }
@@ -1085,7 +1265,7 @@ __global__ __launch_bounds__(64) void g2s_d2_small(const D2Args A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   d2_loop<D2Small>(lds, A);
 }
-__global__ __launch_bounds__(64) void g2s_d2_big(const D2Args A) {
+__global__ __launch_bounds__(G2S_D2_BIG_NT) void g2s_d2_big(const D2Args A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   d2_loop<D2Big>(lds, A);
 }
@@ -1106,12 +1286,15 @@ hipError_t launch_d2(hipStream_t st, const D2Args& A0, uint32_t small_wgs, uint3
   if (e != hipSuccess) return e;
   D2Args A = A0;
   A.poll = 0u;
+  if (A.prof && A.log) A.log_cap /= 2u;
   A.scratch = scratch_small;
   A.list_next = big_wgs ? list_big : nullptr;
   A.count_next = count_big;
-  hipLaunchKernelGGL(g2s_d2_small, dim3(std::max(1u, small_wgs)), dim3(64), D2Small::LDS_BYTES, st, A);
-  if (big_wgs == 0u) return hipGetLastError();  // (a list without deep searches: what the small one cannot take is the host's)
+  hipLaunchKernelGGL(g2s_d2_small, dim3(std::max(1u, small_wgs)), dim3(D2Small::NT), D2Small::LDS_BYTES, st, A);
+  if (big_wgs == 0u) return hipGetLastError();  // (what the small one cannot take is then the host's)
   D2Args B = A0;
+  if (B.prof) B.prof += 32;  // (the log's cursor is each block's word 21: the large instantiation's entries lie behind the small one's capacity)
+  if (B.prof && B.log) { B.log += 16ull * (B.log_cap / 2u); B.log_cap /= 2u; }
   B.tag = 0u; B.poll = 0u;  // (the entries the small instantiation passes on are plain)
   B.list = list_big;
   B.count = count_big;
@@ -1119,7 +1302,7 @@ hipError_t launch_d2(hipStream_t st, const D2Args& A0, uint32_t small_wgs, uint3
   B.scratch = scratch_big;
   B.list_next = nullptr;
   B.count_next = nullptr;
-  hipLaunchKernelGGL(g2s_d2_big, dim3(std::max(1u, big_wgs)), dim3(64), D2Big::LDS_BYTES, st, B);
+  hipLaunchKernelGGL(g2s_d2_big, dim3(std::max(1u, big_wgs)), dim3(D2Big::NT), D2Big::LDS_BYTES, st, B);
   return hipGetLastError();
 }
 
@@ -1131,7 +1314,7 @@ hipError_t launch_d2_poll(hipStream_t st, const D2Args& A0, uint32_t wgs, uint32
   A.scratch = scratch_small;
   A.list_next = list_big;
   A.count_next = count_big;
-  hipLaunchKernelGGL(g2s_d2_small, dim3(std::max(1u, wgs)), dim3(64), D2Small::LDS_BYTES, st, A);
+  hipLaunchKernelGGL(g2s_d2_small, dim3(std::max(1u, wgs)), dim3(D2Small::NT), D2Small::LDS_BYTES, st, A);
   return hipGetLastError();
 }
 

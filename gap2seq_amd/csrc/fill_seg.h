@@ -18,6 +18,9 @@
 
 namespace g2s {
 
+// (tools, G2S_D2_LOG) where in d2_list the fill kernels note when a gap's closure was listed; 0: nowhere
+extern uint32_t d2_ticks_offset;
+
 size_t fill_seg_lds_bytes();
 uint32_t fill_seg_dbg_words();  // words per gap of the optional diagnostics buffer
 // phases A-D1 of every listed gap in one launch; results land in pinned host memory exactly as

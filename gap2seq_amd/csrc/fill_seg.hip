@@ -1865,9 +1865,10 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
     go->stat[6] = gen;
     go->stat[7] = (uint32_t)((__builtin_amdgcn_s_memtime() - cyc2) >> 8);
     if (to_d2) {  // (record and closure are in device memory in front of the entry: g2s_d2_small may be polling the list)
-      __threadfence();
+      if (A.d2_tag) __threadfence();  // (a polling launch reads them while this kernel runs; a launch behind it needs no fence)
       const unsigned long long at = atomicAdd(out_counter + 4, 1ull);
       __hip_atomic_store(&A.d2_list[at], gi | A.d2_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (A.d2_ticks) A.d2_list[A.d2_ticks + gi] = (uint32_t)__builtin_amdgcn_s_memrealtime();  // (tools: when the closure was listed)
     }
   }
 #ifdef G2S_SEG_PROFILE
@@ -1916,6 +1917,9 @@ __global__ __launch_bounds__(64) void g2s_fill_segx(const SegArgs A, uint32_t* s
 
 namespace g2s {
 
+uint32_t d2_ticks_offset = 0u;
+
+
 size_t fill_seg_lds_bytes() { return 4u * (7u * G2S_SEG_CAP + 32u); }
 size_t fill_seg2_lds_bytes() {  // (... + the next round's records: 2 x 64 x sets x (16 + 4) bytes)
   return 4u * (7u * G2S_SEG_CAP + 32u + 2u * 128u * G2S_SEG_ASETS + 128u * G2S_SEG_ASETS + 4u * 64u * G2S_SEG_ASETS + 16u + 2u * 64u * G2S_SEG_ASETS * 5u);
@@ -1941,8 +1945,8 @@ hipError_t launch_fill_seg(hipStream_t st, uint32_t ngaps, const uint32_t* succ,
   if (!xcd_tickets || !xcd_list || pub_batch < 2u || pub_batch > 64u || (pub_batch & (pub_batch - 1u))) pub_batch = 1u;
   const SegArgs A = {succ, urec, gaps, gap_ids, flank_nodes, sub_out, out_cap, out_counter, outs, outs_host, done_list,
                      skip_confident, dbg, fill_seg_dbg_words(), xcd_tickets, xcd_list, xcd_stride, pub_batch, resident ? 1u : 0u,
-                     0u, resident ? ovf_list : nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0u, resident ? d2_list : nullptr,
-                     resident ? d2_tag : 0u};
+                     (resident && d2_list) ? g2s::d2_ticks_offset : 0u, resident ? ovf_list : nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0u,
+                     resident ? d2_list : nullptr, resident ? d2_tag : 0u};
   if (two_waves) hipLaunchKernelGGL(g2s_fill_seg2, dim3(ngaps), dim3(128), bytes, st, A);
   else hipLaunchKernelGGL(g2s_fill_seg, dim3(ngaps), dim3(64), bytes, st, A);
   return hipGetLastError();

@@ -1289,9 +1289,10 @@ __device__ __forceinline__ void segw_fill_one(uint32_t* lds, const SegArgs& A, c
     go->stat[6] = gen;
     go->stat[7] = (uint32_t)((__builtin_amdgcn_s_memtime() - cyc2) >> 8);
     if (to_d2) {  // (as in fill_seg.hip: the entry carries the list's tag)
-      __threadfence();
+      if (A.d2_tag) __threadfence();  // (a polling launch reads them while this kernel runs; a launch behind it needs no fence)
       const unsigned long long at = atomicAdd(out_counter + 4, 1ull);
       __hip_atomic_store(&A.d2_list[at], gi | A.d2_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (A.d2_ticks) A.d2_list[A.d2_ticks + gi] = (uint32_t)__builtin_amdgcn_s_memrealtime();  // (tools: when the closure was listed)
     }
     if (eslot != 0xFFFFFFFFu) {  // the item: the gap's record, then what says it is complete
       if (edst) {
@@ -1359,8 +1360,8 @@ hipError_t launch_fill_segw(hipStream_t st, uint32_t ngaps, uint32_t workgroups,
   hipError_t e = hipFuncSetAttribute((const void*)g2s_fill_segw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   if (e != hipSuccess) return e;
   SegArgs A = {succ, urec, gaps, gap_ids, flank_nodes, sub_out, out_cap, out_counter, outs, outs_host, done_list,
-               skip_confident, dbg, fill_segx_dbg_words(), nullptr, nullptr, 0u, 1u, resident ? 1u : 0u, 0u, nullptr,
-               early ? early->segs : nullptr, early ? early->items : nullptr, early ? early->outs : nullptr,
+               skip_confident, dbg, fill_segx_dbg_words(), nullptr, nullptr, 0u, 1u, resident ? 1u : 0u,
+               (resident && d2_list) ? d2_ticks_offset : 0u, nullptr, early ? early->segs : nullptr, early ? early->items : nullptr, early ? early->outs : nullptr,
                early ? early->ctr : nullptr, early ? early->cap_items : 0u, early ? early->cap_segs : 0u, resident ? d2_list : nullptr, resident ? d2_tag : 0u};
   hipLaunchKernelGGL(g2s_fill_segw, dim3(workgroups), dim3(SEGW_NT), bytes, st, A, scratch, ngaps, next_gap, ngaps_dev);
   return hipGetLastError();

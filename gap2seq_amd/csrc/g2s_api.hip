@@ -576,6 +576,7 @@ struct g2s_session {
   uint32_t d2_lists = 0;     // lists whose fill kernels tagged their entries for a polling g2s_d2_small (the tag's low bits)
   unsigned long long d2_done_total = 0;  // gaps those fill launches counted as through, all lists (the counters only grow)
   const void* d2_ctr_seen = nullptr;     // the counter buffer those counts live in
+  size_t d2_ticks_n = 0;     // (G2S_D2_LOG) gaps of the last list whose listing times are in d_d2list
   bool d2_prof_on = false;   // (G2S_D2_PROF) the section counters behind the cursors have been zeroed
   int num_cus = 256;
   DevBuf d_rspool;
@@ -593,7 +594,7 @@ struct g2s_session {
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   g2s_timing last_timing;        // of the last g2s_fill_batch / g2s_batch_run (g2s_session_last_timing)
   // resident mode (run_resident): closures, phase D3 work areas and the rand() stream stay on the device
-  DevBuf d_sub, d_d3, d_rnd, d_lastch, d_rtab, d_resout, d_textout, d_dgap;
+  DevBuf d_d2log, d_sub, d_d3, d_rnd, d_lastch, d_rtab, d_resout, d_textout, d_dgap;
   DevBuf d_fstage;  // a long list's look-up descriptors and flank text, copied in front of the look-up kernel
   DevBuf d_outs_all, d_sub_all;  // lead of a team: the groups' records and closure records, gathered for phase D3
   PinBuf h_d3all;                // and the list's D3Gap array, summary and stream window
@@ -753,16 +754,35 @@ extern "C" int g2s_session_create(g2s_graph* g, int device, const g2s_params* p,
 extern "C" void g2s_session_destroy(g2s_session* s) {
   if (!s) return;
   if (s->d2_prof_on && s->d_counter.p) {  // (G2S_D2_PROF: what g2s_d2_* spent where, over the session's lists)
-    unsigned long long pr[16] = {0};
+    unsigned long long both[64] = {0};
     (void)hipSetDevice(s->device);
     (void)hipDeviceSynchronize();
-    if (hipMemcpy(pr, (char*)s->d_counter.p + 128, 128, hipMemcpyDeviceToHost) == hipSuccess) {
-      static const char* names[11] = {"load+sort", "dag", "chain intervals", "cuts", "runs", "edges", "csr", "components", "statistics", "order", "verdicts"};
-      fprintf(stderr, "[g2s] g2s_d2_*: %llu closures on runs, %.0f nodes and %.0f rounds each; cycles (100 MHz clock) per closure:", pr[11],
-              pr[11] ? (double)pr[12] / (double)pr[11] : 0.0, pr[11] ? (double)pr[13] / (double)pr[11] : 0.0);
-      for (int q = 0; q < 11; q++) fprintf(stderr, " %s %.0f", names[q], pr[11] ? (double)pr[q] / (double)pr[11] : (double)pr[q]);
-      fprintf(stderr, " | beyond the capacities %llu, given up %llu\n", pr[14], pr[15]);
-    }
+    if (hipMemcpy(both, (char*)s->d_counter.p + 1024, 512, hipMemcpyDeviceToHost) == hipSuccess)
+      for (int k = 0; k < 2; k++) {  // ([0 .. 31]: g2s_d2_small, [32 .. 63]: g2s_d2_big; s_memrealtime ticks of 10 ns)
+        const unsigned long long* pr = both + 32 * k;
+        static const char* names[11] = {"load+sort", "dag", "chain intervals", "cuts", "runs", "edges", "csr", "components", "statistics", "order", "verdicts"};
+        fprintf(stderr, "[g2s] %s: %llu closures taken, %llu through on runs (%.0f nodes, %.0f rounds each), %llu as a DAG; ticks per closure taken %.0f, the longest %llu (%llu records); by section, summed:",
+                k ? "g2s_d2_big" : "g2s_d2_small", pr[17], pr[11], pr[11] ? (double)pr[12] / (double)pr[11] : 0.0,
+                pr[11] ? (double)pr[13] / (double)pr[11] : 0.0, pr[19], pr[17] ? (double)pr[18] / (double)pr[17] : 0.0, pr[16], pr[20]);
+        for (int q = 0; q < 11; q++) fprintf(stderr, " %s %llu", names[q], pr[q]);
+        fprintf(stderr, " | beyond the capacities %llu, given up %llu\n", pr[14], pr[15]);
+      }
+    if (const char* path = getenv("G2S_D2_LOG"))  // (one line per closure taken: tools/d2_log.py)
+      if (s->d_d2log.p) {
+        std::vector<unsigned long long> lg(16u * 8192u);
+        if (hipMemcpy(lg.data(), s->d_d2log.p, lg.size() * 8, hipMemcpyDeviceToHost) == hipSuccess)
+          if (FILE* f = fopen(path, "w")) {
+            for (int k = 0; k < 2; k++)
+              for (unsigned long long q = 0; q < std::min<unsigned long long>(both[32 * k + 21], 4096ull); q++) {
+                const unsigned long long* e = lg.data() + 16ull * (4096ull * k + q);
+                for (int w = 0; w < 16; w++) fprintf(f, "%llu%c", e[w], w == 15 ? '\n' : ' ');
+              }
+            std::vector<uint32_t> tk(s->d2_ticks_n);  // (the last list's: "T gap tick" — s_memrealtime, 10 ns)
+            if (s->d2_ticks_n && s->d_d2list.p && hipMemcpy(tk.data(), (uint32_t*)s->d_d2list.p + 2 * s->d2_ticks_n, tk.size() * 4, hipMemcpyDeviceToHost) == hipSuccess)
+              for (size_t q = 0; q < tk.size(); q++) if (tk[q]) fprintf(f, "T %zu %u\n", q, tk[q]);
+            fclose(f);
+          }
+      }
   }
   // lists begun and never ended: their kernels first — on all three streams of every session that carries one (the
   // rand() stream and the descriptors run on the second, the large variant's early launch on the third) — and what
@@ -791,7 +811,7 @@ extern "C" void g2s_session_destroy(g2s_session* s) {
   s->h_gaps.release();
   for (int i = 0; i < 5; i++) if (s->ev[i]) (void)hipEventDestroy(s->ev[i]);
   s->d_outs_all.release(); s->d_sub_all.release(); s->h_d3all.release();
-  s->d_resout.release(); s->d_textout.release(); s->d_dgap.release(); s->d_sub.release(); s->d_d3.release(); s->d_rnd.release(); s->d_lastch.release(); s->d_rtab.release();
+  s->d_resout.release(); s->d_textout.release(); s->d_dgap.release(); s->d_d2log.release(); s->d_sub.release(); s->d_d3.release(); s->d_rnd.release(); s->d_lastch.release(); s->d_rtab.release();
   s->h_d3.release(); s->h_res.release(); s->h_text.release(); s->h_side.release(); s->h_gfn.release();
   s->h_early.release(); s->d_early_ctr.release(); s->d_fstage.release();
   if (s->ev_rand) (void)hipEventDestroy(s->ev_rand);
@@ -2769,9 +2789,9 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl) {
   HIP_TRY_S(s->d_outs.ensure(n * sizeof(GapOut)));
   // ([0] closure cursor, [1] overflow list, [2] [3] work counters of the large variant's two launches; d2_device.hip:
   // [4] gaps listed, [5] small instantiation's work counter, [6] gaps passed on, [7] large one's work counter, [8] runs)
-  HIP_TRY_S(s->d_counter.ensure(1024));  // ([16 .. 31]: G2S_D2_PROF; [32 .. 95]: gaps through, for a polling g2s_d2_small — neither zeroed by the kernels)
+  HIP_TRY_S(s->d_counter.ensure(1536));  // ([32 .. 95]: gaps through, for a polling g2s_d2_small; [128 .. 191]: G2S_D2_PROF — neither zeroed by the kernels)
   if (s->d_counter.p != s->d2_ctr_seen) {  // (a fresh buffer: the counters that only grow start at zero)
-    HIP_TRY_S(hipMemset((char*)s->d_counter.p + 128, 0, 1024 - 128));
+    HIP_TRY_S(hipMemset((char*)s->d_counter.p + 128, 0, 1536 - 128));
     s->d2_ctr_seen = s->d_counter.p; s->d2_done_total = 0; s->d2_prof_on = false;
   }
   HIP_TRY_S(s->d_sub.ensure(out_states * sizeof(SubRec)));
@@ -2814,7 +2834,7 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl) {
   const uint32_t d2_big_wgs = (uint32_t)std::min<size_t>(ids.size(), b->dmax >= 2500 ? (size_t)std::max(1, s->num_cus) : (size_t)8);
   const uint64_t d2_run_cap = out_states + 65536u;
   if (dev_d2) {
-    HIP_TRY_S(s->d_d2list.ensure(std::max<size_t>(2 * n * 4, 16)));
+    HIP_TRY_S(s->d_d2list.ensure(std::max<size_t>(3 * n * 4, 16)));  // (list, the large instantiation's list, G2S_D2_LOG: listing times)
     HIP_TRY_S(s->d_d2out.ensure(std::max<size_t>(n * sizeof(D2Out), 32)));
     HIP_TRY_S(s->d_d2runs.ensure((size_t)d2_run_cap * 8));
     HIP_TRY_S(s->d_d2scr_small.ensure(d2_scratch_bytes(false, d2_small_wgs)));
@@ -2881,9 +2901,18 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl) {
     DA.d2out = (D2Out*)s->d_d2out.p; DA.runs = (uint32_t*)s->d_d2runs.p; DA.run_cursor = ctr + 8; DA.run_cap = d2_run_cap;
     DA.all_paths = s->params.all_paths ? 1 : 0; DA.list_cap = (uint32_t)n;
     DA.wgs_done = ctr + 9;
+    DA.behind = (d2_deep && !getenv("G2S_D2_RELEASE")) ? 1u : 0u;  // (a deep list's phase D3 waits for the launch: s->d2_wait)
     DA.tag = d2_tag;
     static const bool d2_prof = getenv("G2S_D2_PROF") != nullptr;
-    if (d2_prof) { s->d2_prof_on = true; DA.prof = ctr + 16; }
+    if (d2_prof) {
+      s->d2_prof_on = true; DA.prof = ctr + 128;
+      if (getenv("G2S_D2_LOG")) {
+        if (!s->d_d2log.p) { HIP_TRY_S(s->d_d2log.ensure(16u * 8192u * 8u)); HIP_TRY_S(hipMemset(s->d_d2log.p, 0, 16u * 8192u * 8u)); }
+        DA.log = (unsigned long long*)s->d_d2log.p; DA.log_cap = 8192u;
+        g2s::d2_ticks_offset = (uint32_t)(2 * n); s->d2_ticks_n = n;
+        HIP_TRY_S(hipMemsetAsync((uint32_t*)s->d_d2list.p + 2 * n, 0, n * 4, st));
+      }
+    }
     DA.pass_all = (getenv("G2S_D2_BIG") && atoi(getenv("G2S_D2_BIG")) == 2) ? 1u : 0u;  // (tests: every closure through the large instantiation)
     if (getenv("G2S_D2_NO_CHAINS")) DA.pass_all |= 2u;  // (tests: no node counts as pass-through — the whole graph of runs goes through the component search)
   }

@@ -178,7 +178,7 @@ struct SegArgs {
   // the results stay on the device (sub_out and outs are device memory, phase D3 follows on the stream:
   // d3_device.hip): nothing is announced to the host, no write-back of the L2 per gap
   uint32_t resident;
-  uint32_t dbg_flags;  // (unused)
+  uint32_t d2_ticks;  // (tools, G2S_D2_LOG) where in d2_list the gaps' listing times go, by gap; 0: nowhere
   // resident mode: a gap that outgrows the regular tier's capacities enters itself here (count: out_counter[1]); the
   // large variant follows on the stream and takes the list (fill_segw.hip) — the gap's results stay on the device too
   uint32_t* ovf_list;
