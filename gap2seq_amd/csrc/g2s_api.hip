@@ -615,6 +615,7 @@ struct g2s_session {
   std::vector<uint32_t> res_ids, res_at;  // launch order of a resident list and its counting sort, kept between lists
   bool in_team_list = false;     // the session is filling a group of a team's list (team_resident)
   bool team_shares_device = false;  // ... and another session of the team sits on the same device
+  int team_sessions = 1;            // ... sessions of that team (they share the host's threads)
   int peer_asked_for = -1;       // the lead device this session asked direct access to (team lists)
   bool self_cleaned = false;     // the last list's trace kernel zeroed records, summary and cursors behind itself
   std::vector<uint32_t> host_order;  // resident mode: the handed-over items, largest closure first
@@ -2810,7 +2811,15 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl) {
   // the launch.  G2S_DEVICE_D2=1 / 0: always / never.
   bool dev_d2 = (!s->in_team_list || s->team_sharded) && !s->params.skip_confident && !ids.empty();
   if (const char* env = getenv("G2S_DEVICE_D2")) dev_d2 = dev_d2 && atoi(env) != 0;
-  else dev_d2 = dev_d2 && ids.size() >= 3072 && b->dmax < 2500;
+  else {
+    // (a deep list all the same when the host cannot give this session the threads: the processes of a launcher — one
+    // rank per GPU — and the sessions of a team share the host's CPUs; below 16 per session the device's 4.9 ms beat
+    // the pool's)
+    static const int cpus = usable_cpus();
+    static const int ranks = getenv("LOCAL_WORLD_SIZE") ? std::max(1, atoi(getenv("LOCAL_WORLD_SIZE"))) : 1;
+    const bool starved = cpus / (ranks * std::max(1, s->team_sessions)) < 16;
+    dev_d2 = dev_d2 && ((ids.size() >= 3072 && b->dmax < 2500) || (b->dmax >= 2500 && ids.size() >= 256 && starved));
+  }
   // (the large instantiation always rides along on that stream: what the small one cannot take is passed on, not lost)
   const bool d2_big = dev_d2 && !(getenv("G2S_D2_BIG") && atoi(getenv("G2S_D2_BIG")) == 0);  // (=0: measurements)
   const bool d2_deep = dev_d2 && b->dmax >= 2500;
@@ -3710,11 +3719,11 @@ static int team_resident_sharded(g2s_session* const* sessions, int nsessions, co
     g2s_session* const* ss; int ns;
     InTeam(g2s_session* const* a, int b_) : ss(a), ns(b_) {
       for (int t = 0; t < ns; t++) {
-        ss[t]->in_team_list = true; ss[t]->team_sharded = true;
+        ss[t]->in_team_list = true; ss[t]->team_sharded = true; ss[t]->team_sessions = ns;
         for (int u = 0; u < ns; u++) if (u != t && ss[u]->device == ss[t]->device) ss[t]->team_shares_device = true;
       }
     }
-    ~InTeam() { for (int t = 0; t < ns; t++) { ss[t]->in_team_list = false; ss[t]->team_sharded = false; ss[t]->team_shares_device = false; } }
+    ~InTeam() { for (int t = 0; t < ns; t++) { ss[t]->in_team_list = false; ss[t]->team_sharded = false; ss[t]->team_shares_device = false; ss[t]->team_sessions = 1; } }
   } in_team(sessions, nsessions);
   const auto t_begin = std::chrono::steady_clock::now();
   std::vector<size_t> group_arena(ngroups + 1, 0);
