@@ -70,7 +70,7 @@ __global__ __launch_bounds__(64) void g2s_resolve_flanks(g2s::FlankLookup lk, co
     uint32_t node = G2S_DEV_INVALID;
     if (lo < end && v[lo] == canon) node = 2u * lk.rank2id[lo] + ((fwd ? 0u : 1u) ^ (uint32_t)lk.flip[lo]);
     nodes_dev[d.flank_off + (uint32_t)i] = node;
-    nodes_host[d.flank_off + (uint32_t)i] = node;
+    if (nodes_host) nodes_host[d.flank_off + (uint32_t)i] = node;
   }
 }
 

@@ -1164,7 +1164,7 @@ int g2s_batch::upload_flanks() {
       }
       if (e == hipSuccess)
         e = launch_resolve_flanks(s->stream, s->lookup, (uint32_t)n_desc, (const FlankDesc*)d_desc, (const char*)d_text,
-                                  (uint32_t*)s->d_flank.p, (uint32_t*)d_nodes);
+                                  (uint32_t*)s->d_flank.p, getenv("G2S_NO_HOST_NODES") ? nullptr : (uint32_t*)d_nodes);
     }
   }
   if (e != hipSuccess) return fail(G2S_ERR_HIP, std::string("batch flank look-up: ") + hipGetErrorString(e));
