@@ -12,6 +12,9 @@
 // fill kernels) and to pinned host memory (for the host half of phase D).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstdlib>
+
 #include "fill_device.h"
 #include "flank_lookup.h"
 #include "kmer.hpp"
@@ -32,45 +35,56 @@ __device__ __forceinline__ u128 d_revcomp(u128 x, int k) {
   return y >> (128 - 2 * k);
 }
 
+// FLANK_WAVES waves a workgroup, a gap per wave at a time (a quarter of the dispatches of one-wave workgroups).  What
+// rocprofv3 shows as this kernel's 75-80 us on a 10 000-gap list is mostly the 1.5 MB copy of descriptors and flank text
+// in front of it (53 us with the look-ups switched off; the look-ups themselves ~22 us)
+#define FLANK_WAVES 4
 template <class KT>
-__global__ __launch_bounds__(64) void g2s_resolve_flanks(g2s::FlankLookup lk, const g2s::FlankDesc* __restrict__ desc,
-                                                         const char* __restrict__ text, uint32_t* __restrict__ nodes_dev,
-                                                         uint32_t* __restrict__ nodes_host) {
+__global__ __launch_bounds__(64 * FLANK_WAVES) void g2s_resolve_flanks(g2s::FlankLookup lk, const g2s::FlankDesc* __restrict__ desc,
+                                                                       const char* __restrict__ text, uint32_t* __restrict__ nodes_dev,
+                                                                       uint32_t* __restrict__ nodes_host, uint32_t ngaps) {
   // the gap's flank text: [left: first k+lmf chars][right: first k+rmf chars][right: last k+rmf chars]
-  __shared__ __attribute__((aligned(16))) uint32_t tw[G2S_FLANK_TEXT_MAX / 4];
-  const g2s::FlankDesc d = desc[blockIdx.x];
-  const int lane = threadIdx.x;
+  __shared__ __attribute__((aligned(16))) uint32_t tws[FLANK_WAVES][G2S_FLANK_TEXT_MAX / 4];
+  const int lane = (int)(threadIdx.x & 63u);
+  const uint32_t wave = threadIdx.x >> 6;
+  uint32_t* tw = tws[wave];
   const int k = lk.k;
-  const int nl = (int)d.lmf + 1, nr = (int)d.rmf + 1;
-  const int llen = k + (int)d.lmf, rlen = k + (int)d.rmf;
-  const uint32_t words = (uint32_t)(llen + 2 * rlen + 3) / 4u;
-  for (uint32_t w = (uint32_t)lane; w < words; w += 64u) tw[w] = ((const uint32_t*)(text + d.text_off))[w];  // (4-byte aligned, padded)
-  __syncthreads();
-  const char* t = (const char*)tw;
   const KT* v = (const KT*)lk.kmers;
   const int shift = 2 * k - lk.bucket_bits;
-  for (int i = lane; i < nl + 2 * nr; i += 64) {
-    int off;
-    if (i < nl) off = i;                                     // left.substr(d, k)          :995,1083
-    else if (i < nl + nr) off = llen + rlen + (rlen - k - (i - nl));  // right.substr(len-k-j, k)    :878,954
-    else off = llen + (i - nl - nr);                        // right.substr(j, k)         :1113
-    KT f = 0;
-    for (int c = 0; c < k; c++) f = (f << 2) | (KT)((t[off + c] >> 1) & 3);  // GATB codec: A0 C1 T2 G3, any byte maps to a base
-    const KT r = d_revcomp(f, k);
-    const bool fwd = f < r;
-    const KT canon = fwd ? f : r;
-    // sorted rank through the prefix index (dbg.cpp: rank_of)
-    const size_t b = (size_t)(canon >> shift);
-    uint32_t lo = lk.bucket[b], hi = lk.bucket[b + 1];
-    const uint32_t end = hi;
-    while (lo < hi) {
-      const uint32_t mid = (lo + hi) >> 1;
-      if (v[mid] < canon) lo = mid + 1; else hi = mid;
+  for (uint32_t gap = blockIdx.x * FLANK_WAVES + wave; gap < ngaps; gap += gridDim.x * FLANK_WAVES) {
+    const g2s::FlankDesc d = desc[gap];
+    const int nl = (int)d.lmf + 1, nr = (int)d.rmf + 1;
+    const int llen = k + (int)d.lmf, rlen = k + (int)d.rmf;
+    const uint32_t words = (uint32_t)(llen + 2 * rlen + 3) / 4u;
+    for (uint32_t w = (uint32_t)lane; w < words; w += 64u) tw[w] = ((const uint32_t*)(text + d.text_off))[w];  // (4-byte aligned, padded)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // (the wave's own words: no other wave reads them)
+    __builtin_amdgcn_wave_barrier();
+    const char* t = (const char*)tw;
+    for (int i = lane; i < nl + 2 * nr; i += 64) {
+      int off;
+      if (i < nl) off = i;                                     // left.substr(d, k)          :995,1083
+      else if (i < nl + nr) off = llen + rlen + (rlen - k - (i - nl));  // right.substr(len-k-j, k)    :878,954
+      else off = llen + (i - nl - nr);                        // right.substr(j, k)         :1113
+      KT f = 0;
+      for (int c = 0; c < k; c++) f = (f << 2) | (KT)((t[off + c] >> 1) & 3);  // GATB codec: A0 C1 T2 G3, any byte maps to a base
+      const KT r = d_revcomp(f, k);
+      const bool fwd = f < r;
+      const KT canon = fwd ? f : r;
+      // sorted rank through the prefix index (dbg.cpp: rank_of)
+      const size_t b = (size_t)(canon >> shift);
+      uint32_t lo = lk.bucket[b], hi = lk.bucket[b + 1];
+      const uint32_t end = hi;
+      while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (v[mid] < canon) lo = mid + 1; else hi = mid;
+      }
+      uint32_t node = G2S_DEV_INVALID;
+      if (lo < end && v[lo] == canon) node = 2u * lk.rank2id[lo] + ((fwd ? 0u : 1u) ^ (uint32_t)lk.flip[lo]);
+      nodes_dev[d.flank_off + (uint32_t)i] = node;
+      nodes_host[d.flank_off + (uint32_t)i] = node;
     }
-    uint32_t node = G2S_DEV_INVALID;
-    if (lo < end && v[lo] == canon) node = 2u * lk.rank2id[lo] + ((fwd ? 0u : 1u) ^ (uint32_t)lk.flip[lo]);
-    nodes_dev[d.flank_off + (uint32_t)i] = node;
-    if (nodes_host) nodes_host[d.flank_off + (uint32_t)i] = node;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the text has been read before the next gap's overwrites it)
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -81,10 +95,11 @@ namespace g2s {
 hipError_t launch_resolve_flanks(hipStream_t st, const FlankLookup& lk, uint32_t ngaps, const FlankDesc* desc, const char* text,
                                  uint32_t* nodes_dev, uint32_t* nodes_host) {
   if (ngaps == 0) return hipSuccess;
+  const uint32_t wgs = std::min<uint32_t>((ngaps + FLANK_WAVES - 1u) / FLANK_WAVES, 4096u);
   if (lk.wide)
-    hipLaunchKernelGGL(g2s_resolve_flanks<u128>, dim3(ngaps), dim3(64), 0, st, lk, desc, text, nodes_dev, nodes_host);
+    hipLaunchKernelGGL(g2s_resolve_flanks<u128>, dim3(wgs), dim3(64 * FLANK_WAVES), 0, st, lk, desc, text, nodes_dev, nodes_host, ngaps);
   else
-    hipLaunchKernelGGL(g2s_resolve_flanks<uint64_t>, dim3(ngaps), dim3(64), 0, st, lk, desc, text, nodes_dev, nodes_host);
+    hipLaunchKernelGGL(g2s_resolve_flanks<uint64_t>, dim3(wgs), dim3(64 * FLANK_WAVES), 0, st, lk, desc, text, nodes_dev, nodes_host, ngaps);
   return hipGetLastError();
 }
 

@@ -541,6 +541,7 @@ struct g2s_session {
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;  // resident mode: the rand() stream is generated beside the fill kernel
   hipStream_t stream3 = nullptr;  // resident mode, deep lists: the large variant's early launch (resident_launch_fill)
+  hipEvent_t ev_desc = nullptr;  // the fill kernel's descriptors and launch order are in device memory (copied on the third stream)
   hipEvent_t ev_pre = nullptr, ev_early = nullptr;  // in front of the fill kernel; behind the early launch
   hipEvent_t ev_fill = nullptr, ev_d2 = nullptr;    // behind the fill kernels (what g2s_d2_* waits for on its stream); behind g2s_d2_*
   DevBuf d_segx1;                 // the early launch's scratch
@@ -732,6 +733,7 @@ extern "C" int g2s_session_create(g2s_graph* g, int device, const g2s_params* p,
   if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_chain, hipEventDisableTiming);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->stream3, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_pre, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_desc, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_early, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_fill, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_d2, hipEventDisableTiming);
@@ -819,6 +821,7 @@ extern "C" void g2s_session_destroy(g2s_session* s) {
   if (s->ev_segw) (void)hipEventDestroy(s->ev_segw);
   if (s->ev_chain) (void)hipEventDestroy(s->ev_chain);
   if (s->ev_pre) (void)hipEventDestroy(s->ev_pre);
+  if (s->ev_desc) (void)hipEventDestroy(s->ev_desc);
   if (s->ev_early) (void)hipEventDestroy(s->ev_early);
   if (s->ev_fill) (void)hipEventDestroy(s->ev_fill);
   if (s->ev_d2) (void)hipEventDestroy(s->ev_d2);
@@ -1164,7 +1167,7 @@ int g2s_batch::upload_flanks() {
       }
       if (e == hipSuccess)
         e = launch_resolve_flanks(s->stream, s->lookup, (uint32_t)n_desc, (const FlankDesc*)d_desc, (const char*)d_text,
-                                  (uint32_t*)s->d_flank.p, getenv("G2S_NO_HOST_NODES") ? nullptr : (uint32_t*)d_nodes);
+                                  (uint32_t*)s->d_flank.p, (uint32_t*)d_nodes);
     }
   }
   if (e != hipSuccess) return fail(G2S_ERR_HIP, std::string("batch flank look-up: ") + hipGetErrorString(e));
@@ -2865,8 +2868,14 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl) {
   // (long lists: descriptors and launch order go to device memory in front of the kernel — read over the link by
   // 10 000 starting waves they cost config 3's launch 0.04 ms: 0.365 against 0.324 ms; short lists read them over the link)
   if (ids.size() > 2048) {
-    HIP_TRY_S(hipMemcpyAsync(s->d_gaps.p, gd, n * sizeof(GapDev), hipMemcpyHostToDevice, st));
-    HIP_TRY_S(hipMemcpyAsync(s->d_ids.p, ids_pinned, ids.size() * 4, hipMemcpyHostToDevice, st));
+    // (on the third stream, beside the look-up kernel the stream still holds — behind it the two copies were 0.04 ms
+    // between that kernel and the fill kernel; the fill kernel waits for the event.  The stream's earlier work — the
+    // previous list's phase D2 — read the same buffers: stream order keeps the copies behind it)
+    static const bool beside = !getenv("G2S_DESC_ON_STREAM");
+    hipStream_t cs = beside ? s->stream3 : st;
+    HIP_TRY_S(hipMemcpyAsync(s->d_gaps.p, gd, n * sizeof(GapDev), hipMemcpyHostToDevice, cs));
+    HIP_TRY_S(hipMemcpyAsync(s->d_ids.p, ids_pinned, ids.size() * 4, hipMemcpyHostToDevice, cs));
+    if (beside) { HIP_TRY_S(hipEventRecord(s->ev_desc, cs)); HIP_TRY_S(hipStreamWaitEvent(st, s->ev_desc, 0)); }
     gaps_dev = (const GapDev*)s->d_gaps.p;
     ids_dev = (const uint32_t*)s->d_ids.p;
   }

@@ -31,7 +31,8 @@ B="python3 bench.py --config C5 --steps 4 --warmup 2 --no-cpu-baseline --no-c3-b
 G2S_DEVICE_D2=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c5d2 -- $B > $O/bench_c5_device_d2_under_rocprof.json 2> $O/rp_c5d2.err
 cp $O/stats_c5d2/*/*_kernel_stats.csv $O/c5_device_d2_kernel_stats.csv; rm -rf $O/stats_c5d2
 python3 tools/kstats.py $O/c5_device_d2_kernel_stats.csv | head -8
-for C in C3 C5; do G2S_DEVICE_D2=1 G2S_D2_PROF=1 timeout 600 python bench.py --config $C --no-cpu-baseline --steps 4 --warmup 1 --prime-seconds 0 2>&1 > /dev/null | grep "g2s_d2" | tail -1 | sed "s/^/$C: /" | tee -a $O/d2_sections.txt; done
+for C in C3 C5; do G2S_DEVICE_D2=1 G2S_D2_PROF=1 G2S_D2_LOG=$O/d2log_$C.txt timeout 600 python bench.py --config $C --no-cpu-baseline --no-c3-beside --steps 4 --warmup 1 --prime-seconds 0 2>&1 > /dev/null | grep "g2s_d2" | tail -2 | sed "s/^/$C: /" | tee -a $O/d2_sections.txt; done
+{ echo "# config 3"; python tools/d2_log.py $O/d2log_C3.txt --top 3; echo "# config 5"; python tools/d2_log.py $O/d2log_C5.txt --top 6 --poll-model 32 16; } > $O/d2_closures.txt; grep "closures;\|the last" $O/d2_closures.txt
 for v in 0 1 2; do timeout 100 python bench.py --no-cpu-baseline --no-c3-beside --variant $v | tee -a $O/other.jsonl | python tools/bsum.py V$v; done
 timeout 100 python bench.py --no-cpu-baseline --config C3 --gaps 1250 --steps 100 | tee -a $O/other.jsonl | python tools/bsum.py C3-1250
 for r in 1 2 3; do
