@@ -41,6 +41,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "../../include/g2s.h"
 #include "d3_device.h"
@@ -936,7 +937,11 @@ __global__ __launch_bounds__(1024) void g2s_d3_back(const D3Params P, const D3Wo
 // ---------------------------------------------------------------------------------------------------------
 // (its first loads — the gap's D3Trace record, its GapOut record, the list's status — do not depend on each other;
 // the closure and the first rand() value follow from the D3Trace record: two round trips in front of the walk)
-__global__ __launch_bounds__(64) void g2s_d3_trace(const D3Params P, const D3Work W, GapOut* __restrict__ outs,
+// NW waves per gap: one on a list that fills the chip; four on a short list, whose trace kernel is its slowest gap —
+// the passes over the closure, over the stretches of the fill and over its bases are shared by the workgroup's threads,
+// the chain of segments is walked by every wave for itself (LDS reads; the same words written by all)
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void g2s_d3_trace(const D3Params P, const D3Work W, GapOut* __restrict__ outs,
                                                    const SubRec* __restrict__ sub, const char* __restrict__ chu,
                                                    const char* __restrict__ chd, const uint32_t* __restrict__ rnd,
                                                    uint64_t capacity, g2s_result* __restrict__ results,
@@ -945,13 +950,16 @@ __global__ __launch_bounds__(64) void g2s_d3_trace(const D3Params P, const D3Wor
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   D3Summary* S = W.sum;
   const uint32_t i = blockIdx.x;
-  const int lane = (int)threadIdx.x;
+  constexpr int NT = 64 * NW;
+  const int tid = (int)threadIdx.x, lane = tid & 63;
+  const bool w0 = tid < 64;  // (the first wave: what one wave does for the gap — counters, the hand to the host, the clean-up)
+  auto wg_sync = [&]() { if constexpr (NW > 1) __syncthreads(); else { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } };
   SegW* segs = (SegW*)lds;  // the gap's closure segments
   static_assert(sizeof(g2s_result) == 112, "g2s_result layout");
   unsigned long long* laps = (unsigned long long*)((char*)W.sum + 512);
   const unsigned long long tk0 = P.laps ? wall_clock64() : 0ull;
   unsigned long long tk1 = 0, tk2 = 0, tk3 = 0, hops = 0, tkm = 0;
-  if (P.laps && i == 0 && lane == 0) laps[13] = tk0;
+  if (P.laps && i == 0 && tid == 0) laps[13] = tk0;
   const uint32_t status = uni(S->status);
   // (every lane loads the same words: handed to the scalar unit, so that the walk below is scalar code)
   g2s::D3Trace td;
@@ -997,12 +1005,13 @@ __global__ __launch_bounds__(64) void g2s_d3_trace(const D3Params P, const D3Wor
   // 10 000 of them queue at one address), the wave that completes a residue adds to the summary's counter, the one
   // that completes that copies.  Counters other waves add to are read at the L2.
   auto leave = [&](uint32_t fill_len) {
+    if (!w0) return;
     uint32_t last = 0;
     if (lane == 0) {
       if (P.laps) {  // (the longest wave's laps: entry to closure in LDS, the walk, the bases, all of it; the latest end)
         const unsigned long long tk4 = wall_clock64();
         atomicMax(&laps[14], tk1 ? tk1 - tk0 : 0ull); atomicMax(&laps[15], tk2 ? tk2 - tk1 : 0ull);
-        atomicMax(&laps[16], tk3 ? tk3 - tk2 : 0ull); atomicMax(&laps[17], tk4 - tk0); atomicMax(&laps[18], tk4);
+        atomicMax(&laps[16], tk3 ? tk3 - tk2 : 0ull); atomicMax(&laps[17], ((tk4 - tk0) << 24) | ((td.gi & GI_HOST) ? 1ull << 23 : 0ull) | (unsigned long long)(i & 0x7FFFFFu)); atomicMax(&laps[18], tk4);
         atomicMax(&laps[19], ((tk2 ? tk2 - tk1 : 0ull) << 32) | (hops << 16) | (tkm ? tkm - tk1 : 0ull));
       }
       const uint32_t c = i & 63u, n = gridDim.x;
@@ -1027,7 +1036,7 @@ __global__ __launch_bounds__(64) void g2s_d3_trace(const D3Params P, const D3Wor
   };
   if (status) { leave(0u); return; }  // (the records in front of this kernel were not written: nothing below may run)
   if (d2_lost) {
-    if (lane == 0) { atomicAdd(&S->anomalies, 1u); arena[td.arena_off + td.lmf] = '\0'; }
+    if (tid == 0) { atomicAdd(&S->anomalies, 1u); arena[td.arena_off + td.lmf] = '\0'; }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     leave(0u);
     return;
@@ -1043,22 +1052,23 @@ __global__ __launch_bounds__(64) void g2s_d3_trace(const D3Params P, const D3Wor
 #pragma unroll
   for (int q = 0; q < 24; q++) rw[q] = 0u;
   int left_fuz = 0;
+  // (the first wave writes it, a word a lane: 112 contiguous bytes in one instruction — seven 16-byte stores of one lane
+  // were seven packets of the link; the words are the same in every lane)
   auto finish = [&](uint32_t fill_len) {
-    if (lane == 0) {
-      const uint64_t fo = abs_off + (uint64_t)((int)dg.lmf - left_fuz);
-      rw[1] = (uint32_t)left_fuz;
-      rw[4] = (uint32_t)fo; rw[5] = (uint32_t)(fo >> 32);
-      rw[6] = fill_len;
-      uint4* dst = (uint4*)&results[i];
+    if (!w0) return;
+    const uint64_t fo = abs_off + (uint64_t)((int)dg.lmf - left_fuz);
+    rw[1] = (uint32_t)left_fuz;
+    rw[4] = (uint32_t)fo; rw[5] = (uint32_t)(fo >> 32);
+    rw[6] = fill_len;
+    uint32_t mine = 0u;  // (words 24-27 — backtrace_depth, backtrace_final_d: a traceback that fails is the host path's)
 #pragma unroll
-      for (int q = 0; q < 6; q++) dst[q] = make_uint4(rw[4 * q], rw[4 * q + 1], rw[4 * q + 2], rw[4 * q + 3]);
-      dst[6] = make_uint4(0u, 0u, 0u, 0u);  // (backtrace_depth, backtrace_final_d: a traceback that fails is the host path's)
-    }
+    for (int q = 0; q < 24; q++) mine = lane == q ? rw[q] : mine;
+    if (lane < 28) ((uint32_t*)&results[i])[lane] = mine;
   };
   if (gi & (GI_BAD | GI_SKIPPED | GI_MEM)) {
     rw[3] = (gi & GI_BAD) ? G2S_GAP_BAD_FLANK : (gi & GI_SKIPPED) ? G2S_GAP_SKIPPED : G2S_GAP_MEM_EXCEEDED;
     if (gi & GI_MEM) rw[0] = (uint32_t)-1;
-    if (lane == 0) buf[dg.lmf] = '\0';
+    if (tid == 0) buf[dg.lmf] = '\0';
     finish(0u);
     leave(0u);
     return;
@@ -1086,7 +1096,7 @@ __global__ __launch_bounds__(64) void g2s_d3_trace(const D3Params P, const D3Wor
     }
   }
   if (!phase_d) {
-    if (lane == 0) buf[dg.lmf] = '\0';
+    if (tid == 0) buf[dg.lmf] = '\0';
     finish(0u);
     leave(0u);
     return;
@@ -1102,14 +1112,14 @@ __global__ __launch_bounds__(64) void g2s_d3_trace(const D3Params P, const D3Wor
       const uint64_t ro = (uint64_t)uni((uint32_t)hp->rnd_off) | ((uint64_t)uni((uint32_t)(hp->rnd_off >> 32)) << 32);
       const uint32_t ns = uni(hp->n_segs), want = uni(hp->draws);
       const GapOut& g = outs[i];
-      if ((uint32_t)lane < sizeof(GapOut) / 4u) ((uint32_t*)&side.outs[it])[lane] = ((const uint32_t*)&g)[lane];
+      if ((uint32_t)tid < sizeof(GapOut) / 4u) ((uint32_t*)&side.outs[it])[tid] = ((const uint32_t*)&g)[tid];
       const uint4* src = (const uint4*)(sub + td.sub_at);
       uint4* dst = (uint4*)(side.segs + so);
-      for (uint32_t w = (uint32_t)lane; w < 2u * ns; w += 64u) dst[w] = src[w];
+      for (uint32_t w = (uint32_t)tid; w < 2u * ns; w += (uint32_t)NT) dst[w] = src[w];
       // (the rand() values of its traceback as their remainders by 12, four bits each: all a traceback asks of a value is
       // its remainder by the number of lengths or of parents — 1 .. 4; config 5's 412 host-finished gaps: 7 MB of raw
       // words through the link, half of what the kernel wrote)
-      for (uint32_t w = (uint32_t)lane; w < (want + 8u) / 8u; w += 64u) {
+      for (uint32_t w = (uint32_t)tid; w < (want + 8u) / 8u; w += (uint32_t)NT) {
         uint32_t pk8 = 0u;
 #pragma unroll
         for (uint32_t x = 0; x < 8u; x++) {
@@ -1118,8 +1128,9 @@ __global__ __launch_bounds__(64) void g2s_d3_trace(const D3Params P, const D3Wor
         }
         side.rnd[ro + w] = pk8;
       }
-      __threadfence_system();  // (the whole wave's stores are in host memory before the item says so)
-      if (lane == 0) {
+      __threadfence_system();  // (the whole workgroup's stores are in host memory before the item says so)
+      if constexpr (NW > 1) __syncthreads();
+      if (tid == 0) {
         // (the item's other words: the hand-off wrote them)
         __hip_atomic_store(&side.items[it].pad, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
       }
@@ -1139,11 +1150,11 @@ __global__ __launch_bounds__(64) void g2s_d3_trace(const D3Params P, const D3Wor
   // between parents, and each was a round trip to memory in the middle of it (30 us for the longest of 500 walks)
   uint32_t* lwin = cmap + P.map_cap;
   const uint32_t nwin = min(td.want, P.map_cap);
-  for (uint32_t x = (uint32_t)lane; x < nwin; x += 64u) lwin[x] = (uint64_t)td.off + x < capacity ? rnd[td.off + x] : 0u;
+  for (uint32_t x = (uint32_t)tid; x < nwin; x += (uint32_t)NT) lwin[x] = (uint64_t)td.off + x < capacity ? rnd[td.off + x] : 0u;
   if (!big) {
     const uint4* src = (const uint4*)gsegs;
     uint4* dst = (uint4*)segs;
-    for (uint32_t w = (uint32_t)lane; w < 2u * nsegs; w += 64u) dst[w] = src[w];
+    for (uint32_t w = (uint32_t)tid; w < 2u * nsegs; w += (uint32_t)NT) dst[w] = src[w];
   }
   __syncthreads();
   if (P.laps) tk1 = wall_clock64();
@@ -1196,7 +1207,7 @@ __global__ __launch_bounds__(64) void g2s_d3_trace(const D3Params P, const D3Wor
   // (Every traced base draws one value — :1513 draws for a single parent too — so the draw made at depth d is the
   // (1 + len - d)-th of the gap whatever the path: the parent a traceback takes from a segment's first state is a
   // property of the segment.  All lanes work those out; the walk itself then reads three words per segment.)
-  for (uint32_t q = (uint32_t)lane; q < nsegs && !big; q += 64u) {
+  for (uint32_t q = (uint32_t)tid; q < nsegs && !big; q += (uint32_t)NT) {
     const uint32_t dl = segs[q].depth_len, p01 = segs[q].par01, p23 = segs[q].par23, fl = segs[q].flags;
     const int d0 = (int)(dl & 0xFFFFu);
     const int nb = seg_nparents(p01, p23);
@@ -1210,8 +1221,7 @@ __global__ __launch_bounds__(64) void g2s_d3_trace(const D3Params P, const D3Wor
     }
     pk[q] = make_uint2(dl, w | ((fl & G2S_SUB_SOURCE) ? 0x40000000u : 0u));
   }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_wave_barrier();
+  wg_sync();
   int nh = 0;
   {
     // (i) The chain of segments: from the start along the parents chosen above until a source or a segment without a
@@ -1259,8 +1269,7 @@ __global__ __launch_bounds__(64) void g2s_d3_trace(const D3Params P, const D3Wor
       __threadfence_block();
     }
     if (!(last & 0x40000000u)) bad = true;  // (ended without a way on — :1493-1510 — or past the depth of a source)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
+    wg_sync();  // (every wave has listed the chain — the same words — before any of them rewrites an entry below)
     // (ii) All lanes, a hop each: state t of a segment that begins at depth d0 sits at depth d0 + t; the walk enters
     // the first segment at state start_t and every other at its last state, and steps from a segment's first state
     // to the depth below it: the depth at which hop h is entered is len less the states passed before it — a scan —
@@ -1270,7 +1279,7 @@ __global__ __launch_bounds__(64) void g2s_d3_trace(const D3Params P, const D3Wor
     for (int h0 = 0; !bad && h0 < nh; h0 += 64) {
       const int h = h0 + lane;
       const bool in = h < nh;
-      const uint32_t sq = in ? (big ? (uint32_t)(ghop[h] >> 32) : hop[h].y) : 0u;
+      const uint32_t sq = in ? ((big ? (uint32_t)(ghop[h] >> 32) : hop[h].y) & 0xFFFFu) : 0u;  // (another wave may have completed the entry already)
       const uint32_t dl = in ? (big ? gsegs[sq].depth_len : pk[sq].x) : 0u;
       const int d0 = (int)(dl & 0xFFFFu), t = h == 0 ? t0 : (int)(dl >> 16) - 1;  // (a child in the closure puts the whole parent there)
       int inc = in ? t + 1 : 0;
@@ -1293,11 +1302,10 @@ __global__ __launch_bounds__(64) void g2s_d3_trace(const D3Params P, const D3Wor
   if (P.laps) tkm = wall_clock64();
   if (!bad) {
     const int stop0 = (int)dg.lmf - left_fuz;  // the fill takes depths stop0 + 1 .. len (cmap index = depth - 1)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-    const int npos = max(0, len - stop0), per = (npos + 63) / 64;
-    // lane l: depths (hi_d - cnt, hi_d], from the top of the fill downwards in lane order
-    const int hi_d = len - lane * per, cnt = max(0, min(per, hi_d - stop0));
+    wg_sync();
+    const int npos = max(0, len - stop0), per = (npos + NT - 1) / NT;
+    // thread t: depths (hi_d - cnt, hi_d], from the top of the fill downwards in thread order
+    const int hi_d = len - tid * per, cnt = max(0, min(per, hi_d - stop0));
     int lowest_safe = 0x7FFFFFFF;
     if (cnt > 0) {
       // (hop h: the depth at which it is entered, the segment | its entry state << 16 — from LDS, or, a closure too
@@ -1347,8 +1355,16 @@ __global__ __launch_bounds__(64) void g2s_d3_trace(const D3Params P, const D3Wor
     // the nearest safe depth above each lane's stretch (the walk begins with the top of the fill counting as safe)
     int above = lowest_safe;
     for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(above, o); if (lane >= o) above = min(above, y); }
+    int waves_above = 0x7FFFFFFF;  // (the stretches of the waves in front of this one)
+    if constexpr (NW > 1) {
+      int* xw = (int*)(lds + (size_t)P.seg_cap * 12u + (size_t)P.map_cap * 2u);  // (the four spare words behind everything)
+      if (lane == 63) xw[tid >> 6] = above;
+      __syncthreads();
+      for (int w = 0; w < (tid >> 6); w++) waves_above = min(waves_above, xw[w]);
+    }
     above = __shfl_up(above, 1);
     if (lane == 0) above = 0x7FFFFFFF;
+    above = min(above, waves_above);
     int last_solid = min(above, len);
     for (int c = 0; c < cnt; c++) {
       const int p = hi_d - c;
@@ -1359,33 +1375,45 @@ __global__ __launch_bounds__(64) void g2s_d3_trace(const D3Params P, const D3Wor
   }
   if (P.laps) tk2 = wall_clock64();
   if (bad) {  // (acknowledged before this wave is counted as through)
-    if (lane == 0) atomicAdd(&S->anomalies, 1u);
+    if (tid == 0) atomicAdd(&S->anomalies, 1u);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   const int stop = (int)dg.lmf - left_fuz;  // the fill begins at this index of the buffer
   const uint32_t fill_len = (!bad && len >= stop && stop >= 0) ? (uint32_t)(len - stop) : 0u;
   if (!bad) {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-    // ---- the bases: eight loads in flight per lane (a 1 000-base fill: two round trips)
-    for (int p0 = stop; p0 < len; p0 += 512) {
+    wg_sync();
+    // ---- the bases: eight loads in flight per lane (a 1 000-base fill: two round trips on one wave); the text leaves
+    // in 4-byte words — 256 bytes an instruction, whole cache lines for the link's packets instead of halves — with
+    // single bytes up to the first aligned address and behind the last whole word
+    auto base_at = [&](uint32_t e, char c) -> uint32_t { return (uint32_t)(uint8_t)((e >> 31) ? (char)(c | 0x20) : c); };
+    const int head = min(len - stop, (int)((4u - ((uint32_t)(uintptr_t)(buf + stop) & 3u)) & 3u));
+    if (tid < head) {
+      const uint32_t e = cmap[stop + tid];
+      const uint32_t x = e & 0x0FFFFFFFu;
+      buf[stop + tid] = (char)base_at(e, (e & 0x40000000u) ? chd[x] : chu[x]);
+    }
+    for (int p0 = stop + head; p0 < len; p0 += 8 * NT) {
       uint32_t e[8];
       char c[8];
 #pragma unroll
-      for (int u = 0; u < 8; u++) { const int p = p0 + 64 * u + lane; e[u] = p < len ? cmap[p] : 0u; }
+      for (int u = 0; u < 8; u++) { const int p = p0 + 4 * (NT * (u >> 2) + tid) + (u & 3); e[u] = p < len ? cmap[p] : 0u; }
 #pragma unroll
       for (int u = 0; u < 8; u++) {
         const uint32_t x = e[u] & 0x0FFFFFFFu;
         c[u] = (e[u] & 0x40000000u) ? chd[x] : chu[x];
       }
 #pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const int p = p0 + 64 * u + lane;
-        if (p < len) buf[p] = (e[u] >> 31) ? (char)(c[u] | 0x20) : c[u];
+      for (int u = 0; u < 2; u++) {
+        const int pb = p0 + 4 * (NT * u + tid);
+        if (pb + 3 < len)
+          *(uint32_t*)(buf + pb) = base_at(e[4 * u], c[4 * u]) | (base_at(e[4 * u + 1], c[4 * u + 1]) << 8) |
+                                   (base_at(e[4 * u + 2], c[4 * u + 2]) << 16) | (base_at(e[4 * u + 3], c[4 * u + 3]) << 24);
+        else
+          for (int j = 0; j < 4; j++) if (pb + j < len) buf[pb + j] = (char)base_at(e[4 * u + j], c[4 * u + j]);
       }
     }
-    if (lane == 0) buf[len] = '\0';
-  } else if (lane == 0) buf[dg.lmf] = '\0';
+    if (tid == 0) buf[len] = '\0';
+  } else if (tid == 0) buf[dg.lmf] = '\0';
   if (P.laps) tk3 = wall_clock64();
   rw[2] = (uint32_t)go.reached_j;  // :1171
   rw[3] |= G2S_GAP_PHASE_D;
@@ -1508,9 +1536,9 @@ hipError_t launch_d3_sharded_trace(hipStream_t st, const D3Params& P, const D3Wo
   if (ev_d2) { const hipError_t e2 = hipStreamWaitEvent(st, ev_d2, 0); if (e2 != hipSuccess) return e2; }
   hipLaunchKernelGGL(g2s_d3_handoff, dim3((P.n + 63u) / 64u), dim3(64), 0, st, P, W, outs, sub, rnd_all + 31, rnd_capacity, side);
   const size_t lds = (size_t)P.seg_cap * (sizeof(SegRec) + 16) + (size_t)P.map_cap * 8 + 16;
-  hipError_t e = hipFuncSetAttribute((const void*)g2s_d3_trace, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipError_t e = hipFuncSetAttribute((const void*)g2s_d3_trace<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(g2s_d3_trace, dim3(P.n), dim3(64), lds, st, P, W, const_cast<GapOut*>(outs), sub, lastch_up, lastch_dn, rnd_all + 31, rnd_capacity,
+  hipLaunchKernelGGL(g2s_d3_trace<1>, dim3(P.n), dim3(64), lds, st, P, W, const_cast<GapOut*>(outs), sub, lastch_up, lastch_dn, rnd_all + 31, rnd_capacity,
                      (g2s_result*)results, arena, (uint32_t*)summary_host, side, (uint32_t*)nullptr);
   return hipGetLastError();
 }
@@ -1553,10 +1581,17 @@ hipError_t launch_d3(hipStream_t st, const D3Params& P, const D3Work& W, const G
     hipLaunchKernelGGL(g2s_d3_handoff, dim3((P.n + 63u) / 64u), dim3(64), 0, st, P, W, outs, sub, rnd_all + 31, rnd_capacity, side);
   }
   const size_t lds = (size_t)P.seg_cap * (sizeof(SegRec) + 16) + (size_t)P.map_cap * 8 + 16;  // closure, base map, rand() values, the walk's segments
-  e = hipFuncSetAttribute((const void*)g2s_d3_trace, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  // (a short list: four waves per gap — the kernel is its slowest gap, and the chip has the wave slots)
+  static const int waves_env = getenv("G2S_TRACE_WAVES") ? atoi(getenv("G2S_TRACE_WAVES")) : 0;
+  const bool four = waves_env ? waves_env == 4 : P.n <= 2048u;
+  e = hipFuncSetAttribute(four ? (const void*)g2s_d3_trace<4> : (const void*)g2s_d3_trace<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(g2s_d3_trace, dim3(P.n), dim3(64), lds, st, P, W, const_cast<GapOut*>(outs), sub, lastch_up, lastch_dn, rnd_all + 31, rnd_capacity,
-                     (g2s_result*)results, arena, (uint32_t*)summary_host, side, clean_words);
+  if (four)
+    hipLaunchKernelGGL(g2s_d3_trace<4>, dim3(P.n), dim3(256), lds, st, P, W, const_cast<GapOut*>(outs), sub, lastch_up, lastch_dn, rnd_all + 31, rnd_capacity,
+                       (g2s_result*)results, arena, (uint32_t*)summary_host, side, clean_words);
+  else
+    hipLaunchKernelGGL(g2s_d3_trace<1>, dim3(P.n), dim3(64), lds, st, P, W, const_cast<GapOut*>(outs), sub, lastch_up, lastch_dn, rnd_all + 31, rnd_capacity,
+                       (g2s_result*)results, arena, (uint32_t*)summary_host, side, clean_words);
   return hipGetLastError();
 }
 

@@ -3431,7 +3431,8 @@ static int resident_d3_wait(g2s_session* s, g2s_timing* tm_out, double* ms_d3_ou
     auto us = [&](int a, int b) { return lp[a] && lp[b] ? ((double)lp[b] - (double)lp[a]) / 100.0 : -1.0; };
     fprintf(stderr, "[g2s] phase D3 laps (us): front classify %.1f scan %.1f | to tables %.1f: status %.1f records %.1f closure %.1f walks %.1f | to back %.1f: tables into LDS %.1f chain %.1f hand-off %.1f fence %.1f | to trace %.1f, longest wave: to closure %.1f walk %.1f bases %.1f all %.1f, first entry to last end %.1f\n",
             us(0, 1), us(1, 2), us(2, 3), us(3, 4), us(4, 5), us(5, 6), us(6, 7), us(7, 8), us(8, 9), us(9, 10), us(10, 11), us(11, 12), us(12, 13),
-            lp[14] / 100.0, lp[15] / 100.0, lp[16] / 100.0, lp[17] / 100.0, us(13, 18));
+            lp[14] / 100.0, lp[15] / 100.0, lp[16] / 100.0, (double)(lp[17] >> 24) / 100.0, us(13, 18));
+    fprintf(stderr, "[g2s] the longest wave of the trace kernel: gap %llu%s\n", lp[17] & 0x7FFFFFull, (lp[17] >> 23) & 1ull ? " (handed to the host)" : "");
     fprintf(stderr, "[g2s] scan (us): sums %.1f, base + layout pass %.1f, table offsets + records %.1f\n", us(20, 21), us(21, 22), us(22, 23));
     fprintf(stderr, "[g2s] the wave with the longest walk: %.1f us, %llu segments entered in %.1f us\n", (double)(lp[19] >> 32) / 100.0, (lp[19] >> 16) & 0xFFFF, (double)(lp[19] & 0xFFFF) / 100.0);
   }
