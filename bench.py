@@ -547,11 +547,20 @@ def main():
             s1, ofilled, octr = O.time_fill_batch(og, sample, d_err, 1)
             secs1 += s1
         ncpu = os.cpu_count() or 1
+        # (what the box lets this process use: a container's CPU quota is an average over 100 ms — 16 CPUs' worth on the
+        # pool's boxes of 256 logical CPUs; reported beside the thread count, which stays the number of threads started)
+        quota = None
+        try:
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            if q != "max":
+                quota = round(int(q) / int(per), 2)
+        except (OSError, ValueError):
+            pass
         sN, _, _ = O.time_fill_batch(og, sample, d_err, ncpu)
         cpu = dict(value=round(len(sample) * passes / secs1, 2), unit="gaps/s", cores=1, kind="port",
                    sample="%s %d gaps of the bench list, %d pass(es), oracle fill_gap only (graph build excluded)"
                           % ("all" if len(sample) == len(gaps) else "the first", len(sample), passes),
-                   value_all_cores=round(len(sample) / sN, 2), cores_all=ncpu, filled=ofilled,
+                   value_all_cores=round(len(sample) / sN, 2), cores_all=ncpu, cpu_quota_cgroup=quota, filled=ofilled,
                    oracle_expansions_A_B_D1=[octr[0], octr[2], octr[4]],
                    oracle_states_A_B_D1=[octr[1], octr[3], octr[5]])
         if len(sample) != len(gaps):

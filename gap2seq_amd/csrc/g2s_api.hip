@@ -2816,11 +2816,12 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl) {
   if (const char* env = getenv("G2S_DEVICE_D2")) dev_d2 = dev_d2 && atoi(env) != 0;
   else {
     // (a deep list all the same when the host cannot give this session the threads: the processes of a launcher — one
-    // rank per GPU — and the sessions of a team share the host's CPUs; below 16 per session the device's 4.9 ms beat
-    // the pool's)
+    // rank per GPU — and the sessions of a team share the host's CPUs.  Config 5, profiles/r05_c5_host_threads.txt: the
+    // device's 4.87 ms per step whatever the threads; the host's pool 14.1 / 6.1 / 4.4 / 3.8 ms with 2 / 4 / 8 / 16)
     static const int cpus = usable_cpus();
     static const int ranks = getenv("LOCAL_WORLD_SIZE") ? std::max(1, atoi(getenv("LOCAL_WORLD_SIZE"))) : 1;
-    const bool starved = cpus / (ranks * std::max(1, s->team_sessions)) < 16;
+    const int threads = std::min(s->pool->size() + 1, std::max(1, cpus / (ranks * std::max(1, s->team_sessions))));
+    const bool starved = threads < 6;
     dev_d2 = dev_d2 && ((ids.size() >= 3072 && b->dmax < 2500) || (b->dmax >= 2500 && ids.size() >= 256 && starved));
   }
   // (the large instantiation always rides along on that stream: what the small one cannot take is passed on, not lost)
