@@ -116,6 +116,24 @@ def test_c5_full_size_with_phase_d2_on_the_device_vs_oracle(product, oracle, mon
     assert tm.host_finished_gaps <= 10
 
 
+def test_deep_list_on_a_host_short_of_threads_takes_phase_d2_to_the_device(product, oracle, monkeypatch):
+    """The library's own choice (G2S_DEVICE_D2 unset) for a deep list: the host's pool with its default threads, the
+    device when the session has fewer than 6 (g2s_params.host_threads = 2 here; the ranks of a launcher and the sessions of
+    a team divide the host's CPUs the same way) — profiles/r05_c5_host_threads.txt is the measurement behind the threshold.
+    The first 400 gaps of config 5's list, every gap against the oracle both ways."""
+    monkeypatch.delenv("G2S_DEVICE_D2", raising=False)
+    monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
+    reads = product.G2S.synth_genome(3000000, 3, 20240101)
+    seqs = _seqs(reads)
+    gaps = _parse_scaffolds(product.G2S.synth_gaps(reads, 31, 10, 1000, 2000, 5000, 20240103))[:400]
+    c, f, tm, xb, sb = _check_batch(product, oracle, seqs, 31, gaps, 2000, seed=1, host_threads=2)
+    assert c >= 398 and (tm.xB, tm.sB) == (xb, sb)
+    assert tm.resident_launches == 1 and tm.resident_fallbacks == 0 and tm.host_finished_gaps <= 5
+    c2, f2, tm2, xb2, sb2 = _check_batch(product, oracle, seqs, 31, gaps, 2000, seed=1)
+    assert (c2, f2, xb2, sb2) == (c, f, xb, sb)
+    assert tm2.resident_launches == 1 and tm2.host_finished_gaps >= 50
+
+
 def test_c5_on_the_host_path_vs_oracle(product, oracle, monkeypatch):
     """The same list with resident mode off (G2S_RESIDENT=0): the host path of round 2 — closures into pinned host
     memory, analysis while the kernels run, in-order offsets, tracebacks on the pool — stays the fallback."""

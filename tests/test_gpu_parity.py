@@ -87,7 +87,7 @@ def _compare_with_oracle_in_parallel(product, oracle, og, gaps, res, e, seed, sk
     return tally["compared"], tally["q7"]
 
 
-def _check_batch(product, oracle, seqs, k, gaps, e, skip=False, allp=True, seed=5, max_mem=20 << 30, run_product=None):
+def _check_batch(product, oracle, seqs, k, gaps, e, skip=False, allp=True, seed=5, max_mem=20 << 30, run_product=None, host_threads=0):
     """The product's batch against the oracle gap by gap.  Only gaps on which the ORACLE
     sees a Q7 collision (both strands of a k-mer in one border: the reference's outcome then
     depends on libstdc++'s hash-set order) are outside the bit-exact claim; they must carry
@@ -99,7 +99,7 @@ def _check_batch(product, oracle, seqs, k, gaps, e, skip=False, allp=True, seed=
     one g2s_fill_batch call (tools/fuzz_parity.py: the same gaps as several lists in flight)."""
     og = oracle.OracleGraph(seqs, k, 1)
     pg = product.Graph.from_seqs(seqs, k, 1)
-    sess = product.Session(pg, 0, d_err=e, skip_confident=skip, all_paths=allp, randseed=seed, max_mem=max_mem)
+    sess = product.Session(pg, 0, d_err=e, skip_confident=skip, all_paths=allp, randseed=seed, max_mem=max_mem, host_threads=host_threads)
     res, tm = run_product(sess, _gaps(product, gaps)) if run_product else sess.fill_batch(_gaps(product, gaps), True)
     assert tm.watchdog_gaps == 0  # (a probe loop of the large variant ran past its bound: a defect)
     rng = oracle.OracleRng(seed)
