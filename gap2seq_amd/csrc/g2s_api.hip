@@ -2822,7 +2822,10 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl) {
     static const int ranks = getenv("LOCAL_WORLD_SIZE") ? std::max(1, atoi(getenv("LOCAL_WORLD_SIZE"))) : 1;
     const int threads = std::min(s->pool->size() + 1, std::max(1, cpus / (ranks * std::max(1, s->team_sessions))));
     const bool starved = threads < 6;
-    dev_d2 = dev_d2 && ((ids.size() >= 3072 && b->dmax < 2500) || (b->dmax >= 2500 && ids.size() >= 256 && starved));
+    // (a list begun while others are in flight keeps the host's threads too: its closures are analysed under the other
+    // lists' kernels, where g2s_d2_* would compete with them — twelve config-3 lists, three in flight: 17.5 M gaps/s
+    // against 15.2-16.4 M)
+    dev_d2 = dev_d2 && ((ids.size() >= 3072 && b->dmax < 2500 && (!b->others_in_flight || starved)) || (b->dmax >= 2500 && ids.size() >= 256 && starved));
   }
   // (the large instantiation always rides along on that stream: what the small one cannot take is passed on, not lost)
   const bool d2_big = dev_d2 && !(getenv("G2S_D2_BIG") && atoi(getenv("G2S_D2_BIG")) == 0);  // (=0: measurements)
