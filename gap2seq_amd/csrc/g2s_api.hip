@@ -879,6 +879,7 @@ struct g2s_batch {
   bool d3_queued = false;  // ...and its phase D3 too (resident_queue_d3): g2s_batch_run only waits
   bool chain_broken = false;  // ...from the device state of a list in front of it which then did not end on the device
   bool others_in_flight = false;  // begun while another list was in flight: the device is shared (resident_launch_fill)
+  bool through_begin = false;     // handed over by g2s_fill_begin: other lists' kernels will run beside this one's
   uint64_t pre_units = 0;
   int upload_flanks();
   size_t arena_bytes = 0;
@@ -2822,10 +2823,10 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl) {
     static const int ranks = getenv("LOCAL_WORLD_SIZE") ? std::max(1, atoi(getenv("LOCAL_WORLD_SIZE"))) : 1;
     const int threads = std::min(s->pool->size() + 1, std::max(1, cpus / (ranks * std::max(1, s->team_sessions))));
     const bool starved = threads < 6;
-    // (a list begun while others are in flight keeps the host's threads too: its closures are analysed under the other
-    // lists' kernels, where g2s_d2_* would compete with them — twelve config-3 lists, three in flight: 17.5 M gaps/s
-    // against 15.2-16.4 M)
-    dev_d2 = dev_d2 && ((ids.size() >= 3072 && b->dmax < 2500 && (!b->others_in_flight || starved)) || (b->dmax >= 2500 && ids.size() >= 256 && starved));
+    // (a list of a stream with lists in flight — g2s_fill_begin — keeps the host's threads too: its closures are analysed
+    // under the other lists' kernels, where g2s_d2_* would compete with them: twelve config-3 lists, three in flight,
+    // 21.2 M gaps/s against 19.7 M)
+    dev_d2 = dev_d2 && ((ids.size() >= 3072 && b->dmax < 2500 && (!b->through_begin || starved)) || (b->dmax >= 2500 && ids.size() >= 256 && starved));
   }
   // (the large instantiation always rides along on that stream: what the small one cannot take is passed on, not lost)
   const bool d2_big = dev_d2 && !(getenv("G2S_D2_BIG") && atoi(getenv("G2S_D2_BIG")) == 0);  // (=0: measurements)
@@ -2875,7 +2876,10 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl) {
     // (on the third stream, beside the look-up kernel the stream still holds — behind it the two copies were 0.04 ms
     // between that kernel and the fill kernel; the fill kernel waits for the event.  The stream's earlier work — the
     // previous list's phase D2 — read the same buffers: stream order keeps the copies behind it)
-    static const bool beside = !getenv("G2S_DESC_ON_STREAM");
+    // (not for a stream of lists in flight: nine streams of three sessions share the hardware queues, and the copies
+    // on one more of them cost twelve config-3 lists 17.5 instead of 21.2 M gaps/s)
+    static const bool beside_ok = !getenv("G2S_DESC_ON_STREAM");
+    const bool beside = beside_ok && !b->through_begin;
     hipStream_t cs = beside ? s->stream3 : st;
     HIP_TRY_S(hipMemcpyAsync(s->d_gaps.p, gd, n * sizeof(GapDev), hipMemcpyHostToDevice, cs));
     HIP_TRY_S(hipMemcpyAsync(s->d_ids.p, ids_pinned, ids.size() * 4, hipMemcpyHostToDevice, cs));
@@ -4344,6 +4348,7 @@ extern "C" int g2s_fill_begin(g2s_session* s, const g2s_gap* gaps, size_t n, g2s
     f.b->arena = fill_arena;
     f.b->arena_base = 0;
     f.b->others_in_flight = s->n_inflight > 0;
+    f.b->through_begin = true;
     ResidentLaunch rl;
     rc = resident_launch_fill(f.b, &rl);  // (1: not a list for resident mode — g2s_fill_end runs it on the host path)
     if (rc < 0) { g2s_batch_free(f.b); return rc; }
