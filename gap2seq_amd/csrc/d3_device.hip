@@ -1382,34 +1382,23 @@ __global__ __launch_bounds__(64 * NW) void g2s_d3_trace(const D3Params P, const 
   const uint32_t fill_len = (!bad && len >= stop && stop >= 0) ? (uint32_t)(len - stop) : 0u;
   if (!bad) {
     wg_sync();
-    // ---- the bases: eight loads in flight per lane (a 1 000-base fill: two round trips on one wave); the text leaves
-    // in 4-byte words — 256 bytes an instruction, whole cache lines for the link's packets instead of halves — with
-    // single bytes up to the first aligned address and behind the last whole word
-    auto base_at = [&](uint32_t e, char c) -> uint32_t { return (uint32_t)(uint8_t)((e >> 31) ? (char)(c | 0x20) : c); };
-    const int head = min(len - stop, (int)((4u - ((uint32_t)(uintptr_t)(buf + stop) & 3u)) & 3u));
-    if (tid < head) {
-      const uint32_t e = cmap[stop + tid];
-      const uint32_t x = e & 0x0FFFFFFFu;
-      buf[stop + tid] = (char)base_at(e, (e & 0x40000000u) ? chd[x] : chu[x]);
-    }
-    for (int p0 = stop + head; p0 < len; p0 += 8 * NT) {
+    // ---- the bases: eight loads in flight per lane (a 1 000-base fill: two round trips on one wave).  (Measured and
+    // not kept: the text in 4-byte words, 256 bytes an instruction — config 3's kernel 207 us against 205 with a byte a
+    // lane, config 4's 57 against 54: the link takes what the kernel writes at ~38 GB/s either way.)
+    for (int p0 = stop; p0 < len; p0 += 8 * NT) {
       uint32_t e[8];
       char c[8];
 #pragma unroll
-      for (int u = 0; u < 8; u++) { const int p = p0 + 4 * (NT * (u >> 2) + tid) + (u & 3); e[u] = p < len ? cmap[p] : 0u; }
+      for (int u = 0; u < 8; u++) { const int p = p0 + NT * u + tid; e[u] = p < len ? cmap[p] : 0u; }
 #pragma unroll
       for (int u = 0; u < 8; u++) {
         const uint32_t x = e[u] & 0x0FFFFFFFu;
         c[u] = (e[u] & 0x40000000u) ? chd[x] : chu[x];
       }
 #pragma unroll
-      for (int u = 0; u < 2; u++) {
-        const int pb = p0 + 4 * (NT * u + tid);
-        if (pb + 3 < len)
-          *(uint32_t*)(buf + pb) = base_at(e[4 * u], c[4 * u]) | (base_at(e[4 * u + 1], c[4 * u + 1]) << 8) |
-                                   (base_at(e[4 * u + 2], c[4 * u + 2]) << 16) | (base_at(e[4 * u + 3], c[4 * u + 3]) << 24);
-        else
-          for (int j = 0; j < 4; j++) if (pb + j < len) buf[pb + j] = (char)base_at(e[4 * u + j], c[4 * u + j]);
+      for (int u = 0; u < 8; u++) {
+        const int p = p0 + NT * u + tid;
+        if (p < len) buf[p] = (e[u] >> 31) ? (char)(c[u] | 0x20) : c[u];
       }
     }
     if (tid == 0) buf[len] = '\0';
@@ -1583,7 +1572,7 @@ hipError_t launch_d3(hipStream_t st, const D3Params& P, const D3Work& W, const G
   const size_t lds = (size_t)P.seg_cap * (sizeof(SegRec) + 16) + (size_t)P.map_cap * 8 + 16;  // closure, base map, rand() values, the walk's segments
   // (a short list: four waves per gap — the kernel is its slowest gap, and the chip has the wave slots)
   static const int waves_env = getenv("G2S_TRACE_WAVES") ? atoi(getenv("G2S_TRACE_WAVES")) : 0;
-  const bool four = waves_env ? waves_env == 4 : P.n <= 2048u;
+  const bool four = waves_env ? waves_env == 4 : P.n <= 768u;  // (2 000 gaps on four waves each: 1-2 % slower than on one)
   e = hipFuncSetAttribute(four ? (const void*)g2s_d3_trace<4> : (const void*)g2s_d3_trace<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   if (four)
