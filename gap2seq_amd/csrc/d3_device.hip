@@ -987,9 +987,11 @@ __global__ __launch_bounds__(64 * NW) void g2s_d3_trace(const D3Params P, const 
   bool d2_lost = false;
   if ((go.dflags & G2S_DEVA_D2_PENDING) && !(go.dflags & (G2S_DEVA_RUNS | G2S_DEVA_D2_FAILED)) && !P.skip_confident) {
     uint32_t v = go.dflags;
+    // (relaxed looks, one acquire behind the loop: an acquire at device scope empties this compute unit's view of the
+    // L2 for every wave on it — seventy waves doing that every few hundred cycles for 0.1 ms slowed the whole kernel)
     for (uint32_t spin = 0; spin < (1u << 22) && !(v & (G2S_DEVA_RUNS | G2S_DEVA_D2_FAILED)); spin++) {
-      __builtin_amdgcn_s_sleep(8);
-      v = uni(__hip_atomic_load(&outs[i].dflags, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT));
+      __builtin_amdgcn_s_sleep(32);
+      v = uni(__hip_atomic_load(&outs[i].dflags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     go.dflags = v;
@@ -1174,11 +1176,13 @@ __global__ __launch_bounds__(64 * NW) void g2s_d3_trace(const D3Params P, const 
   };
   // the verdict of k-mer x from the gap's runs (sorted, disjoint); *rlo, *rhi: the run's ends, or x itself when it is
   // in no run (a k-mer outside the subgraph reads branch[sink], Q5)
+  const uint32_t* lruns = nullptr;  // (the gap's runs in LDS, once the walk has no more use for the rand() values there)
   auto run_verdict = [&](uint32_t x, uint32_t* rlo, uint32_t* rhi) -> bool {
+    const uint32_t* rr = lruns ? lruns : runs;
     uint32_t lo = 0, hi = n_runs;
-    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (runs[2u * mid] <= x) lo = mid + 1u; else hi = mid; }
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (rr[2u * mid] <= x) lo = mid + 1u; else hi = mid; }
     if (lo > 0u) {
-      const uint32_t f = runs[2u * (lo - 1u)], l = runs[2u * (lo - 1u) + 1u];
+      const uint32_t f = rr[2u * (lo - 1u)], l = rr[2u * (lo - 1u) + 1u];
       if (x <= (l & 0x7FFFFFFFu)) { *rlo = f; *rhi = l & 0x7FFFFFFFu; return (l >> 31) != 0u; }
     }
     *rlo = x; *rhi = x;
@@ -1303,6 +1307,14 @@ __global__ __launch_bounds__(64 * NW) void g2s_d3_trace(const D3Params P, const 
   if (!bad) {
     const int stop0 = (int)dg.lmf - left_fuz;  // the fill takes depths stop0 + 1 .. len (cmap index = depth - 1)
     wg_sync();
+    // (a closure g2s_d2_* analysed: its runs — a binary search wherever the fill leaves one — come into LDS over the
+    // rand() values, which the chain above was the last to read: eight dependent reads of device memory per search
+    // made these gaps' waves the kernel's last, config 3: 213 instead of 196 us)
+    if (by_runs && 2u * n_runs <= P.map_cap) {
+      for (uint32_t w = (uint32_t)tid; w < 2u * n_runs; w += (uint32_t)NT) lwin[w] = runs[w];
+      wg_sync();
+      lruns = lwin;
+    }
     const int npos = max(0, len - stop0), per = (npos + NT - 1) / NT;
     // thread t: depths (hi_d - cnt, hi_d], from the top of the fill downwards in thread order
     const int hi_d = len - tid * per, cnt = max(0, min(per, hi_d - stop0));

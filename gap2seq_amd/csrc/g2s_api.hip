@@ -2828,9 +2828,13 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl) {
     // 21.2 M gaps/s against 19.7 M)
     dev_d2 = dev_d2 && ((ids.size() >= 3072 && b->dmax < 2500 && (!b->through_begin || starved)) || (b->dmax >= 2500 && ids.size() >= 256 && starved));
   }
-  // (the large instantiation always rides along on that stream: what the small one cannot take is passed on, not lost)
-  const bool d2_big = dev_d2 && !(getenv("G2S_D2_BIG") && atoi(getenv("G2S_D2_BIG")) == 0);  // (=0: measurements)
   const bool d2_deep = dev_d2 && b->dmax >= 2500;
+  // (the large instantiation follows on that stream on deep lists, where the small one passes a quarter of the closures on.
+  // On other lists what the small one cannot take — none of config 3's 70 — is left to the host's threads: the large one's
+  // workgroups want a whole compute unit's LDS each, find it only when the trace kernel's 10 000 workgroups have all but
+  // left, and that kernel's last wave waits for them: 205 instead of 196 us.  G2S_D2_BIG=1 / 2: always / every closure
+  // through it (tests); =0: never.)
+  const bool d2_big = dev_d2 && (getenv("G2S_D2_BIG") ? atoi(getenv("G2S_D2_BIG")) != 0 : d2_deep);
   // G2S_D2_POLL=1 (measurements): a few workgroups of the small instantiation run BESIDE the fill kernel and take the
   // closures as their gaps end (the fill launch ends with its slowest gaps: most of its wave slots are empty for its
   // last third) — what is listed late is taken by the launch behind the fill kernels.  Not on deep lists (the large
