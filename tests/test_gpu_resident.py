@@ -97,6 +97,25 @@ def test_phase_d2_on_the_device_equals_the_hosts(product, monkeypatch, how):
         assert (td.host_finished_gaps > 5) if how == "host" else (td.host_finished_gaps == 0)
 
 
+@pytest.mark.parametrize("waves,ngaps", [("1", 600), ("4", 600), ("1", 1500), ("4", 1500)])
+def test_trace_kernel_on_one_and_on_four_waves_per_gap(product, monkeypatch, waves, ngaps):
+    """g2s_d3_trace gives a gap one wave or four (by default four on lists of up to 768 gaps: the kernel of a short list is
+    its slowest gap): both instantiations on both sides of that limit (G2S_TRACE_WAVES), closures of the host's threads
+    and of g2s_d2_* among them, every field of every result equal to the host path's."""
+    reads = product.G2S.synth_genome(200000, 3, 20240101)
+    seqs = [ln for ln in reads.splitlines() if not ln.startswith(">")]
+    gaps = _parse_scaffolds(product.G2S.synth_gaps(reads, 31, 10, ngaps, 100, 900, 20240103))
+    for k in ("G2S_DEVICE_D2", "G2S_TRACE_WAVES"):
+        monkeypatch.delenv(k, raising=False)
+    h1, h2, th, _ = _run(product, monkeypatch, False, seqs, 31, gaps, 500)
+    monkeypatch.setenv("G2S_TRACE_WAVES", waves)
+    for d2 in ("0", "1"):
+        monkeypatch.setenv("G2S_DEVICE_D2", d2)
+        d1, d2r, td, _ = _run(product, monkeypatch, True, seqs, 31, gaps, 500, pinned=True)
+        assert td.resident_launches == 1 and td.resident_fallbacks == 0
+        assert d1 == h1 and d2r == h2
+
+
 def test_list_sizes_around_the_switch_points(product, monkeypatch):
     """The default choice of path by list size: below 256 gaps the host path; from 256 on the device, with the
     single-workgroup kernels of short lists up to 3 072 gaps and the multi-workgroup ones beyond.  Lists of 255, 256,
