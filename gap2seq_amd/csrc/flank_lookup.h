@@ -10,8 +10,7 @@ namespace g2s {
 struct FlankLookup {
   const void* kmers = nullptr;      // uint64_t[n] (k <= 31) or unsigned __int128[n]
   const uint32_t* bucket = nullptr; // [(1 << bucket_bits) + 1]
-  const uint32_t* rank2id = nullptr;
-  const uint8_t* flip = nullptr;
+  const uint32_t* rank2node = nullptr;  // by sorted rank: 2 * node id | strand flip of the canonical k-mer
   int32_t k = 0, bucket_bits = 0, wide = 0, pad = 0;
 };
 
@@ -21,8 +20,9 @@ struct FlankLookup {
 struct FlankDesc {
   uint32_t text_off;
   uint32_t flank_off;
-  uint16_t lmf, rmf;
+  uint16_t lmf, rmf;  // rmf: bit 15 = the right flank is exactly k + rmf characters and stands in the text once
 };
+#define G2S_FLANK_RIGHT_ONCE 0x8000u
 #define G2S_FLANK_TEXT_MAX 2048 /* bytes of flank text per gap the kernel stages in LDS */
 
 hipError_t launch_resolve_flanks(hipStream_t st, const FlankLookup& lk, uint32_t ngaps, const FlankDesc* desc /* device-readable */,

@@ -43,7 +43,8 @@ template <class KT>
 __global__ __launch_bounds__(64 * FLANK_WAVES) void g2s_resolve_flanks(g2s::FlankLookup lk, const g2s::FlankDesc* __restrict__ desc,
                                                                        const char* __restrict__ text, uint32_t* __restrict__ nodes_dev,
                                                                        uint32_t* __restrict__ nodes_host, uint32_t ngaps) {
-  // the gap's flank text: [left: first k+lmf chars][right: first k+rmf chars][right: last k+rmf chars]
+  // the gap's flank text: [left: first k+lmf chars][right: first k+rmf chars][right: last k+rmf chars] — the last part
+  // left out when it is the second (a flank of exactly k+rmf characters: what GapCutter writes)
   __shared__ __attribute__((aligned(16))) uint32_t tws[FLANK_WAVES][G2S_FLANK_TEXT_MAX / 4];
   const int lane = (int)(threadIdx.x & 63u);
   const uint32_t wave = threadIdx.x >> 6;
@@ -53,9 +54,12 @@ __global__ __launch_bounds__(64 * FLANK_WAVES) void g2s_resolve_flanks(g2s::Flan
   const int shift = 2 * k - lk.bucket_bits;
   for (uint32_t gap = blockIdx.x * FLANK_WAVES + wave; gap < ngaps; gap += gridDim.x * FLANK_WAVES) {
     const g2s::FlankDesc d = desc[gap];
-    const int nl = (int)d.lmf + 1, nr = (int)d.rmf + 1;
-    const int llen = k + (int)d.lmf, rlen = k + (int)d.rmf;
-    const uint32_t words = (uint32_t)(llen + 2 * rlen + 3) / 4u;
+    const bool once = (d.rmf & G2S_FLANK_RIGHT_ONCE) != 0u;
+    const int rmf = (int)(d.rmf & 0x7FFFu);
+    const int nl = (int)d.lmf + 1, nr = rmf + 1;
+    const int llen = k + (int)d.lmf, rlen = k + rmf;
+    const int tail = once ? llen : llen + rlen;  // where the right flank's last k+rmf characters begin
+    const uint32_t words = (uint32_t)(tail + rlen + 3) / 4u;
     for (uint32_t w = (uint32_t)lane; w < words; w += 64u) tw[w] = ((const uint32_t*)(text + d.text_off))[w];  // (4-byte aligned, padded)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // (the wave's own words: no other wave reads them)
     __builtin_amdgcn_wave_barrier();
@@ -63,7 +67,7 @@ __global__ __launch_bounds__(64 * FLANK_WAVES) void g2s_resolve_flanks(g2s::Flan
     for (int i = lane; i < nl + 2 * nr; i += 64) {
       int off;
       if (i < nl) off = i;                                     // left.substr(d, k)          :995,1083
-      else if (i < nl + nr) off = llen + rlen + (rlen - k - (i - nl));  // right.substr(len-k-j, k)    :878,954
+      else if (i < nl + nr) off = tail + (rlen - k - (i - nl));  // right.substr(len-k-j, k)    :878,954
       else off = llen + (i - nl - nr);                        // right.substr(j, k)         :1113
       KT f = 0;
       for (int c = 0; c < k; c++) f = (f << 2) | (KT)((t[off + c] >> 1) & 3);  // GATB codec: A0 C1 T2 G3, any byte maps to a base
@@ -79,7 +83,7 @@ __global__ __launch_bounds__(64 * FLANK_WAVES) void g2s_resolve_flanks(g2s::Flan
         if (v[mid] < canon) lo = mid + 1; else hi = mid;
       }
       uint32_t node = G2S_DEV_INVALID;
-      if (lo < end && v[lo] == canon) node = 2u * lk.rank2id[lo] + ((fwd ? 0u : 1u) ^ (uint32_t)lk.flip[lo]);
+      if (lo < end && v[lo] == canon) node = lk.rank2node[lo] ^ (fwd ? 0u : 1u);
       nodes_dev[d.flank_off + (uint32_t)i] = node;
       nodes_host[d.flank_off + (uint32_t)i] = node;
     }

@@ -692,13 +692,17 @@ extern "C" int g2s_session_create(g2s_graph* g, int device, const g2s_params* p,
     if (e == hipSuccess && kb) e = hipMemcpy(s->d_lk_kmers.p, gr.wide ? (const void*)gr.kmers128.data() : (const void*)gr.kmers64.data(), kb, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = s->d_lk_bucket.ensure(std::max<size_t>(gr.bucket.size() * 4, 16));
     if (e == hipSuccess && !gr.bucket.empty()) e = hipMemcpy(s->d_lk_bucket.p, gr.bucket.data(), gr.bucket.size() * 4, hipMemcpyHostToDevice);
+    // (rank -> the oriented node of the canonical k-mer, one word: 2 * id | flip — one random access of the look-up
+    // instead of two)
     if (e == hipSuccess) e = s->d_lk_rank2id.ensure(std::max<size_t>(gr.rank2id.size() * 4, 16));
-    if (e == hipSuccess && !gr.rank2id.empty()) e = hipMemcpy(s->d_lk_rank2id.p, gr.rank2id.data(), gr.rank2id.size() * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = s->d_lk_flip.ensure(std::max<size_t>(gr.flip.size(), 16));
-    if (e == hipSuccess && !gr.flip.empty()) e = hipMemcpy(s->d_lk_flip.p, gr.flip.data(), gr.flip.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess && !gr.rank2id.empty()) {
+      std::vector<uint32_t> r2n(gr.rank2id.size());
+      for (size_t q = 0; q < r2n.size(); q++) r2n[q] = 2u * gr.rank2id[q] | (uint32_t)(gr.flip[q] & 1u);
+      e = hipMemcpy(s->d_lk_rank2id.p, r2n.data(), r2n.size() * 4, hipMemcpyHostToDevice);
+    }
     if (e != hipSuccess) { delete s; return fail(G2S_ERR_HIP, std::string("session setup (look-up tables): ") + hipGetErrorString(e)); }
     s->lookup.kmers = s->d_lk_kmers.p; s->lookup.bucket = (const uint32_t*)s->d_lk_bucket.p;
-    s->lookup.rank2id = (const uint32_t*)s->d_lk_rank2id.p; s->lookup.flip = (const uint8_t*)s->d_lk_flip.p;
+    s->lookup.rank2node = (const uint32_t*)s->d_lk_rank2id.p;
     s->lookup.k = gr.k; s->lookup.bucket_bits = gr.bucket_bits; s->lookup.wide = gr.wide ? 1 : 0;
   }
   {  // phase D3 on the device (d3_device.hip): the last base of every oriented k-mer as text, the generator's jump tables
