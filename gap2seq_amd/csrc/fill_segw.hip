@@ -939,6 +939,10 @@ __device__ __forceinline__ void segw_fill_one(uint32_t* lds, const SegArgs& A, c
   const uint32_t reached = uni(targets[reached_j]);
   const bool t_is_s = want_s && !gd.all_paths;  // -best-only: the traceback starts are the sinks (:1245-1259)
   if (tid == 0) { sh[SH_START0] = SEG_NOPAR; sh[SH_START1] = SEG_NOPAR; sh[SH_ST0] = 0u; sh[SH_ST1] = 0u; sh[SH_CHOICE] = 0u; }
+  // (in front of the pass that sets them: without this barrier a wave that found the traceback's start before thread 0
+  // got here had its entry overwritten — once in a hundred lists of a campaign leg a gap lost its start segment and the
+  // host's traceback stopped at its first state: round 5's fuzz campaign, part 4)
+  __syncthreads();
   // what a segment holds by itself — a sink, a traceback start, a left-flank k-mer at its first state: all
   // segments at once, in front of the sweep.  s_t: ts | source << 15 | tt << 16, rewritten by the sweep.
   for (uint32_t b = tid; b < nseg; b += NT) {

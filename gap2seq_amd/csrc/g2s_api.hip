@@ -2557,7 +2557,20 @@ int batches_stage2(const std::vector<g2s_batch*>& bs, g2s_session* lead, g2s_res
           if (b->prep[i].seg_mode) seg_traceback(g, fp, j, b->views[i], b->prep[i], rp, arena + arena_off[gi], &r);
           else sub_traceback(g, fp, j, b->views[i], b->prep[i], rp, arena + arena_off[gi], &r);
           // cannot happen: the draw count was proven fixed, or counted over the same draws
-          if (r.draws != expect_draws[gi]) r.flags |= G2S_GAP_BACKTRACE_FAIL;
+          if (r.draws != expect_draws[gi]) {
+            r.flags |= G2S_GAP_BACKTRACE_FAIL;
+            if (getenv("G2S_DEBUG_DRAWS")) {
+              const SubView& vw = b->views[i];
+              const GapOut& go = *vw.out;
+              fprintf(stderr, "[g2s] gap %zu: traceback drew %d values, %d expected; seg mode %d, n_len %d lens %d %d start_seg %#x start_t %#x fixed %d %d stop %#x %#x n_segs %u n_xl %u flags %#x dflags %#x rand %u %u offset %llu\n",
+                      gi, r.draws, (int)expect_draws[gi], (int)b->prep[i].seg_mode, go.n_len, go.len[0], go.len[1], go.start_seg, go.start_t, go.fixed_draws[0], go.fixed_draws[1],
+                      go.stop[0], go.stop[1], vw.n_segs, go.n_xl, go.flags, go.dflags, rp[0] >> 1, rp[1] >> 1, (unsigned long long)offset_of(gi));
+              for (uint32_t q = 0; q < std::min(vw.n_segs, 3u); q++) {
+                const uint32_t sq = q == 0 ? (go.start_seg & 0xFFFFu) : q == 1 ? (go.start_seg >> 16) : 0u;
+                if (sq < vw.n_segs) fprintf(stderr, "[g2s]    segment %u: node %#x depth_len %#x cnt %u ts_tt %#x par %#x %#x flags %#x\n", sq, vw.segs[sq].node, vw.segs[sq].depth_len, vw.segs[sq].cnt, vw.segs[sq].ts_tt, vw.segs[sq].par01, vw.segs[sq].par23, vw.segs[sq].flags);
+              }
+            }
+          }
         }
         if (r.flags & G2S_GAP_PHASE_D) {
           r.fill_off = (uint64_t)arena_off[gi] + (uint64_t)(j.lmf - r.left_fuz);

@@ -39,14 +39,18 @@ def _parse_scaffolds(text, fuz=10):
 
 def _assert_gap_equal(product, r, o, skip, what=""):
     """One gap of the product against the oracle's fill_gap: every observable field."""
-    assert r.count == o.count, what
-    assert r.phaseC_count == o.info.phaseC_count and r.lengths == o.lengths, what
-    assert r.draws == o.info.draws, what
+    assert r.count == o.count, "%s: count %r, the oracle's %r (flags %#x)" % (what, r.count, o.count, r.flags)
+    assert r.phaseC_count == o.info.phaseC_count and r.lengths == o.lengths, "%s: phase C count %r lengths %r, the oracle's %r %r (flags %#x)" % (
+        what, r.phaseC_count, r.lengths, o.info.phaseC_count, o.lengths, r.flags)
+    assert r.draws == o.info.draws, "%s: %r draws, the oracle's %r (flags %#x)" % (what, r.draws, o.info.draws, r.flags)
     if o.phase_d:
-        assert (r.left_fuz, r.right_fuz) == (o.left_fuz, o.right_fuz), what
-        assert r.fill == o.fill, what  # sequence AND case (safe/unsafe bases)
+        assert (r.left_fuz, r.right_fuz) == (o.left_fuz, o.right_fuz), "%s: fuz %r, the oracle's %r" % (what, (r.left_fuz, r.right_fuz), (o.left_fuz, o.right_fuz))
+        if r.fill != o.fill:  # sequence AND case (safe/unsafe bases)
+            at = next((x for x in range(min(len(r.fill), len(o.fill))) if r.fill[x] != o.fill[x]), min(len(r.fill), len(o.fill)))
+            raise AssertionError("%s: fill text differs at %d of %d / %d (%r against the oracle's %r; case only: %r; flags %#x)" % (
+                what, at, len(r.fill), len(o.fill), r.fill[at:at + 12], o.fill[at:at + 12], r.fill.upper() == o.fill.upper(), r.flags))
         if not skip:
-            assert r.substats == o.substats, what
+            assert r.substats == o.substats, "%s: subgraph statistics %r, the oracle's %r" % (what, r.substats, o.substats)
 
 
 def _compare_with_oracle_in_parallel(product, oracle, og, gaps, res, e, seed, skip=False, allp=True, threads=0):

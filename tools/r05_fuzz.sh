@@ -12,7 +12,9 @@ B=${2:-500}; X=${3:-1}
 leg() {  # title, seconds, seed, extra args, env...
   local title=$1 secs=$2 seed=$3 args=$4; shift 4
   echo "## $title: $* --seconds $secs --seed $seed $args" | tee -a $O/fuzz.txt
-  env "$@" timeout $((secs + 200)) python tools/fuzz_parity.py --seconds $secs --seed $seed $args 2>&1 | tail -3 | tee -a $O/fuzz.txt
+  # (a failing configuration's line — what tools/fuzz_parity.py --replay and tools/hammer_config.py take — is kept)
+  env "$@" timeout $((secs + 200)) python tools/fuzz_parity.py --seconds $secs --seed $seed $args > $O/leg.txt 2>&1
+  { grep -A1 "^FAIL" $O/leg.txt | cut -c1-900; tail -3 $O/leg.txt | grep "^#"; } | tee -a $O/fuzz.txt
 }
 leg "phase D2 on the device" $((200 * X)) $((B + 0)) "--big 0.4 --scaffold 0.2" G2S_RESIDENT=1 G2S_DEVICE_D2=1
 leg "... every closure through the large instantiation" $((150 * X)) $((B + 1)) "--big 0.4 --scaffold 0.2" G2S_RESIDENT=1 G2S_DEVICE_D2=1 G2S_D2_BIG=2
