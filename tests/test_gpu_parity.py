@@ -953,3 +953,17 @@ def test_fuzz_regressions(product, oracle, idx, monkeypatch):
     c, f, _, _, _ = _check_batch(product, oracle, seqs, k, gaps, cfg["d_err"], cfg["skip"], cfg["allp"],
                                  seed=cfg["randseed"])
     assert c > 0 and f > 0
+
+
+def test_large_variant_loses_no_traceback_start_over_many_runs(product, oracle, monkeypatch):
+    """A deep list through g2s_fill_segw (G2S_FORCE_SEGX=1, -dist-error 2000, -all-upper) forty times in one process: the
+    kernel's eight waves share the words that say where a gap's traceback starts — round 5's campaign found thread 0
+    resetting them without a barrier in front of the pass that sets them: one run in a hundred of this very list lost a
+    gap's start and the host's traceback stopped at its first state (draws 1).  Every gap against the oracle, every run."""
+    monkeypatch.setenv("G2S_FORCE_SEGX", "1")
+    k = 21
+    seqs = cases.toy_genome(327597752, 1000000, k, repeats=200, tandem=0, inverted=0, snp_every=500)
+    gaps = cases.cut_gaps(858877549, seqs[0], k, fuz=10, ngaps=200, min_len=1000, max_len=5000, d_err=2000)
+    for _ in range(40):
+        c, f, tm, _, _ = _check_batch(product, oracle, seqs, k, gaps, 2000, skip=True, allp=True, seed=67666)
+        assert c >= 190 and tm.segx_tier_gaps == 200
