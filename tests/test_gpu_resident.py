@@ -116,6 +116,26 @@ def test_trace_kernel_on_one_and_on_four_waves_per_gap(product, monkeypatch, wav
         assert d1 == h1 and d2r == h2
 
 
+def test_the_same_list_a_hundred_times_says_the_same(product, monkeypatch):
+    """One list of 600 gaps a hundred times through one session (srand before every call): every field and the fill text of
+    every gap as in the first call — what a race between the waves of a kernel shows as when it strikes once in many runs
+    (tools/self_consistency.py does this with the bench lists, profiles/r05_self_consistency.txt)."""
+    reads = product.G2S.synth_genome(200000, 3, 20240101)
+    seqs = [ln for ln in reads.splitlines() if not ln.startswith(">")]
+    gaps = _gaps(product, _parse_scaffolds(product.G2S.synth_gaps(reads, 31, 10, 600, 100, 900, 20240103)))
+    pg = product.Graph.from_seqs(seqs, 31, 1)
+    sess = product.Session(pg, 0, d_err=500, randseed=1)
+    first = None
+    for it in range(100):
+        sess.srand(1)
+        res, tm = sess.fill_batch(gaps, True)
+        now = [(r.count, r.left_fuz, r.right_fuz, r.flags, r.draws, r.fill, tuple(r.substats), r.phaseC_count, tuple(r.lengths)) for r in res]
+        if first is None:
+            first = now
+            assert tm.resident_launches == 1 and sum(1 for r in res if r.count > 0) > 400
+        assert now == first, "call %d differs from the first" % it
+
+
 def test_list_sizes_around_the_switch_points(product, monkeypatch):
     """The default choice of path by list size: below 256 gaps the host path; from 256 on the device, with the
     single-workgroup kernels of short lists up to 3 072 gaps and the multi-workgroup ones beyond.  Lists of 255, 256,
