@@ -5,11 +5,17 @@ missing barrier in g2s_fill_segw's tail (round 5) lost a gap's traceback start o
 On a failure: the assertion and the call's timing counters (which path the list took).
 
   G2S_FORCE_SEGX=1 G2S_DEBUG_DRAWS=1 python tools/hammer_config.py FILE N
+  python tools/hammer_config.py draw:SEED:COUNT:BIG N     (COUNT configurations drawn as a campaign with --seed SEED --big BIG would)
 """
 import json, os, sys, traceback
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import fuzz_parity as F
-cfgs = [json.loads(l) for l in open(sys.argv[1]) if l.strip()]
+if sys.argv[1].startswith("draw:"):
+    _, seed, count, big = sys.argv[1].split(":")
+    rng = F.cases.SplitMix(int(seed) * 1000003 + 17)
+    cfgs = [F.draw(rng, float(big)) for _ in range(int(count))]
+else:
+    cfgs = [json.loads(l) for l in open(sys.argv[1]) if l.strip()]
 n = int(sys.argv[2])
 F.oracle_lib.lib(); F.product.load_library()
 last = {}
