@@ -131,7 +131,20 @@ def test_deep_list_on_a_host_short_of_threads_takes_phase_d2_to_the_device(produ
     assert tm.resident_launches == 1 and tm.resident_fallbacks == 0 and tm.host_finished_gaps <= 5
     c2, f2, tm2, xb2, sb2 = _check_batch(product, oracle, seqs, 31, gaps, 2000, seed=1)
     assert (c2, f2, xb2, sb2) == (c, f, xb, sb)
-    assert tm2.resident_launches == 1 and tm2.host_finished_gaps >= 50
+    assert tm2.resident_launches == 1
+    # (the default pool: the CPUs this process may use — affinity mask, container quota —, at most 32; a box that gives
+    # the process fewer than 6 takes the device here too)
+    cpus = len(os.sched_getaffinity(0))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            cpus = min(cpus, max(1, -(-int(q) // int(per))))
+    except (OSError, ValueError):
+        pass
+    if cpus >= 8:
+        assert tm2.host_finished_gaps >= 50
+    elif cpus < 6:
+        assert tm2.host_finished_gaps <= 5
 
 
 def test_c5_on_the_host_path_vs_oracle(product, oracle, monkeypatch):
