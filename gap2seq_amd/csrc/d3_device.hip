@@ -987,11 +987,11 @@ __global__ __launch_bounds__(64 * NW) void g2s_d3_trace(const D3Params P, const 
   bool d2_lost = false;
   if ((go.dflags & G2S_DEVA_D2_PENDING) && !(go.dflags & (G2S_DEVA_RUNS | G2S_DEVA_D2_FAILED)) && !P.skip_confident) {
     uint32_t v = go.dflags;
-    // (relaxed looks, one acquire behind the loop: an acquire at device scope empties this compute unit's view of the
-    // L2 for every wave on it — seventy waves doing that every few hundred cycles for 0.1 ms slowed the whole kernel)
+    // (an acquire with every look: a relaxed look may be answered from this compute unit's view of the L2 for as long
+    // as the line stays there — two of ten config-3 steps took 8 ms that way)
     for (uint32_t spin = 0; spin < (1u << 22) && !(v & (G2S_DEVA_RUNS | G2S_DEVA_D2_FAILED)); spin++) {
-      __builtin_amdgcn_s_sleep(32);
-      v = uni(__hip_atomic_load(&outs[i].dflags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      __builtin_amdgcn_s_sleep(8);
+      v = uni(__hip_atomic_load(&outs[i].dflags, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT));
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     go.dflags = v;
