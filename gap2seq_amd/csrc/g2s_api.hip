@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "../../include/g2s.h"
+#include "../../include/g2s_test.h"
 #include "d2_device.h"
 #include "d3_device.h"
 #include "dbg.hpp"
@@ -4442,7 +4443,7 @@ extern "C" int g2s_session_get_params(const g2s_session* s, g2s_params* out) {
   return G2S_OK;
 }
 
-// TEST HOOK, see include/g2s.h: host half of phase D on a caller-supplied DP table.
+// TEST HOOK, see include/g2s_test.h: host half of phase D on a caller-supplied DP table.
 // The closure the g2s_extract kernel would compute is derived on the host (host_closure).
 extern "C" int g2s_test_post_gap(const g2s_graph* gh, const g2s_params* p, const g2s_gap* gap, int32_t n_states,
                                  const uint32_t* nodes, const int32_t* depths, const uint32_t* counts,

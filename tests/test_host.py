@@ -16,13 +16,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_abi_exports_every_declared_symbol(product):
-    hdr = open(os.path.join(ROOT, "include", "g2s.h")).read()
-    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    names = set(re.findall(r"\b(g2s_[a-z0-9_]+)\s*\(", hdr))
+    names = set()
+    for h in ("g2s.h", "g2s_test.h"):  # the reference-facing interface, and the unit tests' hooks
+        hdr = open(os.path.join(ROOT, "include", h)).read()
+        hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+        found = set(re.findall(r"\b(g2s_[a-z0-9_]+)\s*\(", hdr))
+        assert all(n.startswith("g2s_test_") for n in found) == (h == "g2s_test.h") or h == "g2s.h"
+        if h == "g2s.h":
+            assert not any(n.startswith("g2s_test_") for n in found), "test hooks belong in include/g2s_test.h"
+        names |= found
     assert len(names) >= 30
     so = ctypes.CDLL(product.library_path())
     for n in sorted(names):
-        assert hasattr(so, n), "include/g2s.h declares %s but libg2s_hip.so does not export it" % n
+        assert hasattr(so, n), "include/*.h declares %s but libg2s_hip.so does not export it" % n
     assert set(product._SIGS) == names  # the ctypes binding covers the whole header
     assert so.g2s_abi_version() == 5
 
