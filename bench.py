@@ -403,6 +403,7 @@ def main():
                ms_host_post=0.0, ms_prepare=0.0, ms_total=0.0, ms_fill_seg=0.0, ms_fill_segx=0.0, ms_d3=0.0, launches=0,
                lds_launches=0, seg_launches=0, segx_launches=0, seg_timed=0, d3_timed_steps=0)
     in_call = 0.0
+    host_us = [0.0] * 6
     barrier()
     t_begin = time.perf_counter()
     for _ in range(steps):
@@ -417,6 +418,8 @@ def main():
         acc["seg_timed"] += tm.seg_timed_launches  # resident mode brackets one launch in eight with HIP events
         acc["d3_timed_steps"] += 1 if tm.ms_d3 > 0 else 0
         acc["segx_launches"] += tm.segx_launches
+        for q in range(6):
+            host_us[q] += tm.host_us[q]
     elapsed = time.perf_counter() - t_begin
     barrier()
     elapsed, units = shard.reduce_timing(elapsed, float(len(gaps) * steps), dist)
@@ -710,6 +713,9 @@ def main():
                                   "d2h_closures": per_step("ms_d2h"),
                                   "host_phase_d": per_step("ms_host_post"),
                                   "library_total": per_step("ms_total"),
+                                  "host_us_inside_the_call": dict(zip(
+                                      ("entry_to_fill_kernel_queued", "to_phase_d3_queued", "to_hand_over_seen", "to_host_finished_gaps_done",
+                                       "to_stream_synchronised", "to_return"), [round(x / steps, 2) for x in host_us])),
                                   "note": "kernel and host figures are sums over sessions and overlap at N>1"},
         "setup_s": {"synth": round(t_synth, 3), "graph_build": round(t_build, 3), "graph_upload": round(t_upload, 3)},
         "graph": {"kmers": graph.num_kmers, "unitigs": graph.num_unitigs, "hbm_bytes": graph.device_bytes(devices[0])},

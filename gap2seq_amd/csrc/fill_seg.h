@@ -16,7 +16,18 @@
 #define G2S_SEGX_PE 1024u    /* pending events (LDS slots) */
 #define G2S_SEGX_HS 4096u    /* slots of the event table */
 
+#include "flank_lookup.h"
+
 namespace g2s {
+
+// launch_fill_seg: flank look-ups inside the fill kernel (fill_seg.hip, SegArgs.inl_*)
+struct SegInline {
+  FlankLookup lk;
+  const char* text = nullptr;        // device-readable: the list's flank text (GapDev.rs_mask: the gap's offset)
+  uint32_t* nodes_dev = nullptr;     // the table flank_nodes points at, writable
+  uint32_t* nodes_host = nullptr;    // its pinned copy for the host's half (device-writable)
+  uint32_t text_stride = 0;          // not 0: text of the gap at launch position x at text + x * text_stride (gap_ids null)
+};
 
 // (tools, G2S_D2_LOG) where in d2_list the fill kernels note when a gap's closure was listed; 0: nowhere
 extern uint32_t d2_ticks_offset;
@@ -42,7 +53,10 @@ hipError_t launch_fill_seg(hipStream_t st, uint32_t ngaps, const uint32_t* succ,
                            bool resident = false, uint32_t* ovf_list = nullptr,
                            // (resident) the gaps whose closure the kernel leaves unanalysed, counted in out_counter[4]:
                            // g2s_d2_* (d2_device.hip) behind the fill kernels; null: the host analyses them
-                           uint32_t* d2_list = nullptr, uint32_t d2_tag = 0u /* SegArgs.d2_tag */);
+                           uint32_t* d2_list = nullptr, uint32_t d2_tag = 0u /* SegArgs.d2_tag */,
+                           // (resident) the waves resolve their gap's flank k-mers themselves (SegArgs.inl_*): the flank
+                           // text, where the ids go besides flank_nodes' own table; null: flank_nodes holds them already
+                           const SegInline* inl = nullptr);
 
 // The large variant: `workgroups` persistent workgroups (one per compute unit) take the listed gaps
 // in order from the counter *next_gap (zero before the launch); scratch: fill_segx_scratch_bytes().

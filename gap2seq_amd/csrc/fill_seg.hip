@@ -47,9 +47,13 @@
 // runs again in the next kernel of the chain (g2s_fill_segx, then the LDS tier).  Integer work only: no MFMA.
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#include <mutex>
+#include <set>
+#include <utility>
 
 #include "fill_device.h"
 #include "fill_seg.h"
+#include "flank_device.h"
 
 #include "seg_device.h"
 
@@ -270,7 +274,21 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
 
   const int lane = (int)(threadIdx.x & 63u);
   const int wave = TWO ? (int)(threadIdx.x >> 6) : 0;
-  const uint32_t gi = uni(gap_ids[x]);
+  const uint32_t gi = gap_ids ? uni(gap_ids[x]) : x;  // (no list: the launch takes the gaps in list order)
+  // (look-ups in this kernel, the text at a fixed stride by launch position: asked for beside the gap's descriptor —
+  // on a short list both come over the link, one round trip instead of two)
+  bool inl = false, inl_early = false;
+  uint32_t tw0 = 0u, tw1 = 0u;  // (the text's words lane and lane + 64, in flight while the descriptor travels)
+  if constexpr (!BIG) {
+    inl = A.inl_text != nullptr;
+    if (inl && A.inl_stride) {
+      const uint32_t* src = (const uint32_t*)(A.inl_text + (size_t)x * A.inl_stride);
+      const uint32_t words = A.inl_stride / 4u, w = threadIdx.x & 63u;
+      if (w < words) tw0 = src[w];
+      if (w + 64u < words) tw1 = src[w + 64u];
+      inl_early = true;
+    }
+  }
   const GapDev gd = gaps[gi];
   GapOut* go = &outs[gi];
   const uint32_t* lseeds = flank_nodes + gd.flank_off;
@@ -368,8 +386,55 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
     }
   };
 
-  const uint32_t tg = (lane <= rmf && lane < 32) ? targets[lane] : G2S_DEV_INVALID;  // lane j: target k-mer j
-  if (lane < 32 && wave == 0) l_seed[lane] = lane <= lmf ? lseeds[lane] : G2S_DEV_INVALID;
+  // ---- the gap's flank nodes: lane d holds left seed d (f_l), lane j right seed j (f_r) and target j (tg).  From the
+  // table the look-up kernel wrote (flank_lookup.hip) — or, when the list stays on the device and the launch says so
+  // (SegArgs.inl_text), resolved HERE from the gap's flank text: the look-up kernel in front of this one was a launch,
+  // a dependency and two round trips of the link per gap (10 us of a 500-gap step, 75 us of a 10 000-gap one, most
+  // of it the copy of descriptors and text in front of it); a wave's own look-ups are ~2 us at the head of its gap.
+  // Two waves per gap: wave 1 resolves (and stores) the right seeds, wave 0 the left seeds and the targets.  The
+  // ids also go where the table would hold them (g2s_d2_*, the large variant's reruns and the host read them there).
+  uint32_t f_l = G2S_DEV_INVALID, f_r = G2S_DEV_INVALID, tg = G2S_DEV_INVALID;
+  if (inl) {
+    if constexpr (!BIG) {
+      // LDS of this wave (nothing of the search lives there yet): text [0, 128) words, node ids [128, 224)
+      uint32_t* stage = (TWO && wave == 1) ? lds + (7u * G2S_SEG_CAP + 32u) : lds;
+      const int k = A.lk.k;
+      const int llen = k + lmf, rlen = k + rmf, tail = llen + rlen;
+      const uint32_t words = (uint32_t)(tail + rlen + 3) / 4u;  // (k <= 63, lmf, rmf <= 31: at most 71)
+      if (!inl_early) {
+        const uint32_t* src = (const uint32_t*)(A.inl_text + gd.rs_mask);  // (4-byte aligned, padded: g2s_batch_prepare)
+        if ((uint32_t)lane < words) tw0 = src[lane];
+        if ((uint32_t)lane + 64u < words) tw1 = src[lane + 64];
+      }
+      stage[lane] = tw0;
+      stage[lane + 64] = tw1;
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      const char* t = (const char*)stage;
+      uint32_t* fn = stage + 128;
+      const int nl = lmf + 1, nr = rmf + 1;
+      for (int i = lane; i < nl + 2 * nr; i += 64) {
+        const bool right_seed = i >= nl && i < nl + nr;
+        if (TWO && right_seed != (wave == 1)) continue;
+        const char* at = t + g2s::flank_item_offset(i, k, lmf, rmf, tail);
+        const uint32_t node = A.lk.wide ? g2s::flank_node_of<g2s::u128>(A.lk, at) : g2s::flank_node_of<uint64_t>(A.lk, at);
+        fn[i] = node;
+        A.inl_nodes_dev[gd.flank_off + (uint32_t)i] = node;
+        A.inl_nodes_host[gd.flank_off + (uint32_t)i] = node;
+      }
+      lds_sync();
+      __builtin_amdgcn_wave_barrier();
+      if (lane <= lmf && lane < 32 && (!TWO || wave == 0)) f_l = fn[lane];
+      if (lane <= rmf && lane < 32 && (!TWO || wave == 1)) f_r = fn[nl + lane];
+      if (lane <= rmf && lane < 32 && (!TWO || wave == 0)) tg = fn[nl + nr + lane];
+      lds_sync();
+      __builtin_amdgcn_wave_barrier();
+    }
+  } else {
+    if (lane <= lmf && lane < 32) f_l = lseeds[lane];
+    if (lane <= rmf && lane < 32) { f_r = rseeds[lane]; tg = targets[lane]; }  // lane j: target k-mer j
+  }
+  if (lane < 32 && wave == 0) l_seed[lane] = f_l;
 
   uint32_t nA = 0, roundsA = 0, nvis = 0, xa = 0;
   uint32_t nM = 0;  // (regular tier) the right set's entries as merged k-mer index intervals: how many
@@ -478,7 +543,7 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
     if (!overflow) {
       uint32_t cur = 0, ne = 0;
       {  // seeds: right.substr(len-k-j, k) enters at depth j (:878-884, :953-976)
-        const uint32_t sd = (lane <= rmf && lane < 32) ? rseeds[lane] : G2S_DEV_INVALID;
+        const uint32_t sd = f_r;
         uint32_t at = 0;
         const bool imp = relabel(sd != G2S_DEV_INVALID && lane <= gd.right_half, sd, (uint32_t)lane, a_hash(sd), &at);
         const uint64_t m = __ballot(imp);
@@ -939,7 +1004,7 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
   if constexpr (!BIG) {
     if (!overflow) {
       // left seeds: left.substr(d, k) enters at depth d with the value 1 ASSIGNED (:995-1015, :1082-1105)
-      const uint32_t sd = lane <= lmf ? lseeds[lane] : G2S_DEV_INVALID;
+      const uint32_t sd = f_l;
       const uint32_t s0 = rl(sd, 0);
       // The usual flank is a stretch of ONE unitig: seed d is the d-th node after seed 0 and the walk
       // from seed 0 stays unitig-internal for lmf steps.  Levels 0 .. lmf-1 are then that chain with
@@ -1530,9 +1595,9 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
     lds_sync();
   }
   const bool want_s = !skip_confident;
-  const uint32_t sinknode = (want_s && gd.all_paths && rmf >= 1) ? uni(targets[rmf - 1]) : G2S_DEV_INVALID;  // Q3/Q4
+  const uint32_t sinknode = (want_s && gd.all_paths && rmf >= 1) ? rl(tg, rmf - 1) : G2S_DEV_INVALID;  // Q3/Q4
   const int lo_sink = max(0, lmf + gd.g - gd.e);  // :1196
-  const uint32_t reached = uni(targets[reached_j]);
+  const uint32_t reached = rl(tg, (int)uni((uint32_t)reached_j));
   const bool t_is_s = want_s && !gd.all_paths;  // -best-only: the traceback starts are the sinks (:1245-1259)
   uint32_t start_b0 = SEG_NOPAR, start_b1 = SEG_NOPAR, start_t0 = 0, start_t1 = 0;  // segments and positions of the traceback starts
   bool choice = false;  // some entry of the traceback closure has more than one parent
@@ -1934,19 +1999,31 @@ hipError_t launch_fill_seg(hipStream_t st, uint32_t ngaps, const uint32_t* succ,
                            unsigned long long out_cap, unsigned long long* out_counter, GapOut* outs, GapOut* outs_host,
                            uint32_t* done_list, int skip_confident, uint32_t* dbg, bool two_waves, unsigned long long* xcd_tickets,
                            uint32_t* xcd_list, uint32_t xcd_stride, uint32_t pub_batch, bool resident, uint32_t* ovf_list,
-                           uint32_t* d2_list, uint32_t d2_tag) {
+                           uint32_t* d2_list, uint32_t d2_tag, const SegInline* inl) {
   if (ngaps == 0) return hipSuccess;
   size_t bytes = two_waves ? fill_seg2_lds_bytes() : fill_seg_lds_bytes();
   // (G2S_SEG_LDS_PAD=BYTES, measurements only: a larger LDS request per gap = fewer gaps resident per compute unit)
-  if (const char* pad = getenv("G2S_SEG_LDS_PAD")) bytes += (size_t)atoi(pad);
-  hipError_t e = hipFuncSetAttribute(two_waves ? (const void*)g2s_fill_seg2 : (const void*)g2s_fill_seg,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-  if (e != hipSuccess) return e;
+  static const size_t lds_pad = getenv("G2S_SEG_LDS_PAD") ? (size_t)atoi(getenv("G2S_SEG_LDS_PAD")) : 0;
+  bytes += lds_pad;
+  {  // (the attribute is per device and kernel: set when a device sees a kernel for the first time, not per launch)
+    static std::mutex mu;
+    static std::set<std::pair<int, int>> done;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(mu);
+    if (done.insert(std::make_pair(dev, two_waves ? 1 : 0)).second) {
+      const hipError_t e = hipFuncSetAttribute(two_waves ? (const void*)g2s_fill_seg2 : (const void*)g2s_fill_seg,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+      if (e != hipSuccess) { done.erase(std::make_pair(dev, two_waves ? 1 : 0)); return e; }
+    }
+  }
   if (!xcd_tickets || !xcd_list || pub_batch < 2u || pub_batch > 64u || (pub_batch & (pub_batch - 1u))) pub_batch = 1u;
   const SegArgs A = {succ, urec, gaps, gap_ids, flank_nodes, sub_out, out_cap, out_counter, outs, outs_host, done_list,
                      skip_confident, dbg, fill_seg_dbg_words(), xcd_tickets, xcd_list, xcd_stride, pub_batch, resident ? 1u : 0u,
                      (resident && d2_list) ? g2s::d2_ticks_offset : 0u, resident ? ovf_list : nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0u,
-                     resident ? d2_list : nullptr, resident ? d2_tag : 0u};
+                     resident ? d2_list : nullptr, resident ? d2_tag : 0u,
+                     (resident && inl) ? inl->text : nullptr, inl ? inl->nodes_dev : nullptr, inl ? inl->nodes_host : nullptr,
+                     inl ? inl->text_stride : 0u, inl ? inl->lk : FlankLookup()};
   if (two_waves) hipLaunchKernelGGL(g2s_fill_seg2, dim3(ngaps), dim3(128), bytes, st, A);
   else hipLaunchKernelGGL(g2s_fill_seg, dim3(ngaps), dim3(64), bytes, st, A);
   return hipGetLastError();

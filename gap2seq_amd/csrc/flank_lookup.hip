@@ -16,24 +16,13 @@
 #include <cstdlib>
 
 #include "fill_device.h"
+#include "flank_device.h"
 #include "flank_lookup.h"
 #include "kmer.hpp"
 
 namespace {
 
 using g2s::u128;
-
-__device__ __forceinline__ uint64_t d_revcomp32(uint64_t x) {
-  x = ((x >> 2) & 0x3333333333333333ULL) | ((x & 0x3333333333333333ULL) << 2);
-  x = ((x >> 4) & 0x0F0F0F0F0F0F0F0FULL) | ((x & 0x0F0F0F0F0F0F0F0FULL) << 4);
-  x = __builtin_bswap64(x);
-  return x ^ 0xAAAAAAAAAAAAAAAAULL;
-}
-__device__ __forceinline__ uint64_t d_revcomp(uint64_t x, int k) { return d_revcomp32(x) >> (64 - 2 * k); }
-__device__ __forceinline__ u128 d_revcomp(u128 x, int k) {
-  const u128 y = ((u128)d_revcomp32((uint64_t)x) << 64) | (u128)d_revcomp32((uint64_t)(x >> 64));
-  return y >> (128 - 2 * k);
-}
 
 // FLANK_WAVES waves a workgroup, a gap per wave at a time (a quarter of the dispatches of one-wave workgroups).  What
 // rocprofv3 shows as this kernel's 75-80 us on a 10 000-gap list is mostly the 1.5 MB copy of descriptors and flank text
@@ -50,14 +39,13 @@ __global__ __launch_bounds__(64 * FLANK_WAVES) void g2s_resolve_flanks(g2s::Flan
   const uint32_t wave = threadIdx.x >> 6;
   uint32_t* tw = tws[wave];
   const int k = lk.k;
-  const KT* v = (const KT*)lk.kmers;
-  const int shift = 2 * k - lk.bucket_bits;
   for (uint32_t gap = blockIdx.x * FLANK_WAVES + wave; gap < ngaps; gap += gridDim.x * FLANK_WAVES) {
     const g2s::FlankDesc d = desc[gap];
     const bool once = (d.rmf & G2S_FLANK_RIGHT_ONCE) != 0u;
     const int rmf = (int)(d.rmf & 0x7FFFu);
     const int nl = (int)d.lmf + 1, nr = rmf + 1;
     const int llen = k + (int)d.lmf, rlen = k + rmf;
+    (void)nl; (void)nr;
     const int tail = once ? llen : llen + rlen;  // where the right flank's last k+rmf characters begin
     const uint32_t words = (uint32_t)(tail + rlen + 3) / 4u;
     for (uint32_t w = (uint32_t)lane; w < words; w += 64u) tw[w] = ((const uint32_t*)(text + d.text_off))[w];  // (4-byte aligned, padded)
@@ -65,25 +53,7 @@ __global__ __launch_bounds__(64 * FLANK_WAVES) void g2s_resolve_flanks(g2s::Flan
     __builtin_amdgcn_wave_barrier();
     const char* t = (const char*)tw;
     for (int i = lane; i < nl + 2 * nr; i += 64) {
-      int off;
-      if (i < nl) off = i;                                     // left.substr(d, k)          :995,1083
-      else if (i < nl + nr) off = tail + (rlen - k - (i - nl));  // right.substr(len-k-j, k)    :878,954
-      else off = llen + (i - nl - nr);                        // right.substr(j, k)         :1113
-      KT f = 0;
-      for (int c = 0; c < k; c++) f = (f << 2) | (KT)((t[off + c] >> 1) & 3);  // GATB codec: A0 C1 T2 G3, any byte maps to a base
-      const KT r = d_revcomp(f, k);
-      const bool fwd = f < r;
-      const KT canon = fwd ? f : r;
-      // sorted rank through the prefix index (dbg.cpp: rank_of)
-      const size_t b = (size_t)(canon >> shift);
-      uint32_t lo = lk.bucket[b], hi = lk.bucket[b + 1];
-      const uint32_t end = hi;
-      while (lo < hi) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (v[mid] < canon) lo = mid + 1; else hi = mid;
-      }
-      uint32_t node = G2S_DEV_INVALID;
-      if (lo < end && v[lo] == canon) node = lk.rank2node[lo] ^ (fwd ? 0u : 1u);
+      const uint32_t node = g2s::flank_node_of<KT>(lk, t + g2s::flank_item_offset(i, k, (int)d.lmf, rmf, tail));
       nodes_dev[d.flank_off + (uint32_t)i] = node;
       nodes_host[d.flank_off + (uint32_t)i] = node;
     }

@@ -624,6 +624,9 @@ struct g2s_session {
   size_t side_dirty = SIZE_MAX;  // items of h_side whose ready word may be set (resident mode's hand-over)...
   size_t side_layout_n = 0;      // ...under the layout of a list of this many gaps (the arrays behind the items move with it)
   uint32_t timed_seq = 0;        // resident launches so far (one in eight is bracketed with HIP events)
+  // g2s_timing.host_us: time points of the last resident list on this session (g2s_fill_batch computes the laps)
+  std::chrono::steady_clock::time_point lap_fill_queued, lap_d3_queued, lap_handed, lap_finished, lap_synced, lap_end;
+  bool laps_valid = false;
   int resident_strikes = 0;      // lists that had to be run again on the host path; three in a row switch the mode off
   // The large variant behind the fill kernel of a resident launch (for the gaps that outgrow the regular tier) is an
   // empty launch on most lists, and an empty launch costs a 500-gap list 5 us of its 210: after eight lists in a row
@@ -886,7 +889,14 @@ struct g2s_batch {
   bool others_in_flight = false;  // begun while another list was in flight: the device is shared (resident_launch_fill)
   bool through_begin = false;     // handed over by g2s_fill_begin: other lists' kernels will run beside this one's
   uint64_t pre_units = 0;
-  int upload_flanks();
+  // Flank look-ups: by the look-up kernel in front of the fill kernels (upload_flanks queues it), or — allow_inline, a
+  // list resident mode is about to launch in the regular segment tier — by the fill kernel's own waves (fill_seg.hip):
+  // then only the text is staged and inline_pending says that d_flank does not hold the ids yet.  Whoever needs the ids
+  // in d_flank without that launch (the host path taking over) calls upload_flanks() again: the kernel after all.
+  bool inline_ok = false, inline_pending = false;
+  const char* inline_text_dev = nullptr;  // device-readable flank text of the list (pinned memory, or its copy in d_fstage)
+  uint32_t text_stride = 0;               // not 0: gap i's text at i * text_stride (a list without a bad flank)
+  int upload_flanks(bool allow_inline = false);
   size_t arena_bytes = 0;
   std::vector<size_t> arena_off;  // of each gap's fill buffer within the batch's share of the arena
   char* arena = nullptr;          // the batch's share of the caller's fill arena (stage 1 writes the
@@ -979,7 +989,7 @@ extern "C" int g2s_batch_prepare(g2s_session* s, const g2s_gap* gaps, size_t n, 
   // (a long list: in parallel — every task its stretch of the list with offsets from the stretch's start, the
   // stretches' bases from a pass over the <= 16 tasks, added where the second pass below visits the gap.  One
   // thread took 56 us for 10 000 gaps, in front of everything else the list needs.)
-  size_t text_bytes = 0, n_nodes = 0, n_desc = 0;
+  size_t text_bytes = 0, n_nodes = 0, n_desc = 0, tb_max = 0;
   std::vector<uint32_t>& text_off = s->spare_u32[1];
   std::vector<uint32_t>& didx = s->spare_u32[2];  // (didx: descriptor index of every valid gap)
   text_off.resize(n);
@@ -991,6 +1001,7 @@ extern "C" int g2s_batch_prepare(g2s_session* s, const g2s_gap* gaps, size_t n, 
     size_t n_nodes = 0, text_bytes = 0, n_desc = 0, arena_bytes = 0, rnd_cap = 0;
     uint64_t flank_bytes = 0;
     int gmax = 0, dmax = 0;
+    size_t tb_max = 0;
     bool seg_all = true, host_lookup = false, has_skip = false;
   };
   std::vector<Part> parts(std::max<size_t>(ntasks, 1));
@@ -1014,6 +1025,7 @@ extern "C" int g2s_batch_prepare(g2s_session* s, const g2s_gap* gaps, size_t n, 
         if (tb > G2S_FLANK_TEXT_MAX || j.lmf > 65535 || j.rmf > 65535 || force_host_lookup) P.host_lookup = true;
         text_off[i] = (uint32_t)P.text_bytes;
         P.text_bytes += (tb + 3) & ~(size_t)3;
+        P.tb_max = std::max(P.tb_max, tb);
         P.n_nodes += (size_t)(j.lmf + 1) + 2 * (size_t)(j.rmf + 1);
         didx[i] = (uint32_t)P.n_desc++;
         P.flank_bytes += (uint64_t)in.left_len + (uint64_t)in.right_len;
@@ -1043,6 +1055,7 @@ extern "C" int g2s_batch_prepare(g2s_session* s, const g2s_gap* gaps, size_t n, 
     b->timing.flank_bytes += P.flank_bytes;
     b->gmax = std::max(b->gmax, P.gmax);
     b->dmax = std::max(b->dmax, P.dmax);
+    tb_max = std::max(tb_max, P.tb_max);
     if (!P.seg_all) b->seg_tier_all = false;
     if (P.host_lookup) b->host_lookup = true;
     if (P.has_skip) b->has_skip = true;
@@ -1062,6 +1075,17 @@ extern "C" int g2s_batch_prepare(g2s_session* s, const g2s_gap* gaps, size_t n, 
       b->fast_desc = true;
     }
   }
+  // (the regular segment tier's waves resolve their own flanks when resident mode takes the list — not a deep list,
+  // whose longest gaps start in the large variant; G2S_FLANK_KERNEL=1: the look-up kernel as until round 5.  A list
+  // without a bad flank gets its text at a FIXED STRIDE: when the launch takes the gaps in list order, a wave knows
+  // where its text is before its descriptor has arrived — on a short list both come over the link.)
+  b->inline_ok = fast_gd != nullptr && b->dmax < 2500 && !getenv("G2S_FLANK_KERNEL");
+  uint32_t tstride = 0;
+  if (b->inline_ok && n_desc == n && tb_max <= 508 && !getenv("G2S_NO_TEXT_STRIDE")) {
+    tstride = (uint32_t)((tb_max + 3) & ~(size_t)3);
+    if ((uint64_t)n * tstride < (1ull << 31)) text_bytes = (size_t)n * tstride; else tstride = 0;
+  }
+  b->text_stride = tstride;
   const int all_paths = s->params.all_paths ? 1 : 0;
   if (!s->pin_free.empty()) { b->pin = s->pin_free.back(); s->pin_free.pop_back(); }
   else b->pin = new PinBuf();
@@ -1083,7 +1107,7 @@ extern "C" int g2s_batch_prepare(g2s_session* s, const g2s_gap* gaps, size_t n, 
         if (what & 1) {  // (the first visit: the offsets within the task's stretch become offsets within the list)
           b->flank_off[i] += (uint32_t)base_nodes[t];
           b->arena_off[i] += base_arena[t];
-          if (!j.bad_flank) { text_off[i] += (uint32_t)base_text[t]; didx[i] += (uint32_t)base_desc[t]; }
+          if (!j.bad_flank) { text_off[i] = tstride ? (uint32_t)i * tstride : text_off[i] + (uint32_t)base_text[t]; didx[i] += (uint32_t)base_desc[t]; }
         }
         j.nodes = b->nodes + b->flank_off[i];
         if (fast_gd && (what & 2)) {
@@ -1102,8 +1126,10 @@ extern "C" int g2s_batch_prepare(g2s_session* s, const g2s_gap* gaps, size_t n, 
             d.prune_from = j.g / 2 + d_err / 2 + j.lmf;
             d.all_paths = all_paths;
             d.flank_off = b->flank_off[i];
+            d.rs_mask = text_off[i];  // (the segment tier's kernels: where the gap's flank text starts — look-ups in the kernel)
           }
         }
+        if (!j.bad_flank && (what & 1)) j.text_off = text_off[i];
         if (j.bad_flank || !(what & 1)) continue;
         const g2s_gap& in = gaps[i];
         char* t = b->text + text_off[i];
@@ -1129,13 +1155,13 @@ extern "C" int g2s_batch_prepare(g2s_session* s, const g2s_gap* gaps, size_t n, 
       // a short list on this thread: the look-up kernel is launched as soon as its input is there, the other
       // descriptors are written while it runs
       for (size_t t = 0; t < ntasks; t++) do_range(t, 1);
-      const int rc0 = b->upload_flanks();
+      const int rc0 = b->upload_flanks(true);
       if (rc0 != G2S_OK) { delete b; return rc0; }
       for (size_t t = 0; t < ntasks; t++) do_range(t, 2);
     } else for (size_t t = 0; t < ntasks; t++) do_range(t, 3);
   }
   const auto tp2 = std::chrono::steady_clock::now();
-  const int rc = b->upload_flanks();
+  const int rc = b->upload_flanks(true);
   if (rc != G2S_OK) { delete b; return rc; }
   if (n >= 1024 && getenv("G2S_DEBUG"))
     fprintf(stderr, "[g2s] prepare: sizes %.3f ms, text + descriptors %.3f ms, look-up launch %.3f ms\n",
@@ -1149,10 +1175,28 @@ extern "C" int g2s_batch_prepare(g2s_session* s, const g2s_gap* gaps, size_t n, 
 // computed on the session's stream by the look-up kernel (no host synchronisation: the fill
 // kernels follow on the same stream; the host reads them from pinned memory only after a fill
 // kernel has reported gaps as done).
-int g2s_batch::upload_flanks() {
-  if (s->flank_owner == this) return G2S_OK;
+int g2s_batch::upload_flanks(bool allow_inline) {
+  if (s->flank_owner == this && (!inline_pending || allow_inline)) return G2S_OK;
   if (hipSetDevice(s->device) != hipSuccess) return fail(G2S_ERR_NO_DEVICE, "cannot select device");
   hipError_t e = s->d_flank.ensure(std::max<size_t>(n_nodes * 4, 16));
+  const bool staged = s->flank_owner == this && inline_pending;  // (the text is where the kernel reads it already)
+  inline_pending = false;
+  if (e == hipSuccess && n_nodes && allow_inline && inline_ok && !host_lookup) {
+    // the fill kernel's waves do the look-ups: the text where they can read it (a long list: one copy to device memory)
+    void* d_text = nullptr;
+    e = hipHostGetDevicePointer(&d_text, text, 0);
+    if (e == hipSuccess && n_desc > 2048) {
+      const size_t bytes = (size_t)((const char*)nodes - (const char*)text);
+      e = s->d_fstage.ensure(bytes);
+      if (e == hipSuccess) e = hipMemcpyAsync(s->d_fstage.p, text, bytes, hipMemcpyHostToDevice, s->stream);
+      d_text = s->d_fstage.p;
+    }
+    if (e != hipSuccess) return fail(G2S_ERR_HIP, std::string("batch flank text: ") + hipGetErrorString(e));
+    inline_text_dev = (const char*)d_text;
+    inline_pending = true;
+    s->flank_owner = this;
+    return G2S_OK;
+  }
   if (e == hipSuccess && n_nodes) {
     if (host_lookup) {
       e = hipMemcpyAsync(s->d_flank.p, nodes, n_nodes * 4, hipMemcpyHostToDevice, s->stream);
@@ -1164,7 +1208,7 @@ int g2s_batch::upload_flanks() {
       // (a long list: descriptors and flank text go to device memory in one copy in front of the kernel — 10 000
       // workgroups that each read their descriptor and then their text over the link are two round trips of the link
       // each: 0.10 ms for config 3's list, against a 1.5 MB copy and a kernel that reads device memory)
-      if (e == hipSuccess && n_desc > 2048 && !getenv("G2S_FLANKS_OVER_THE_LINK")) {
+      if (e == hipSuccess && n_desc > 2048 && !getenv("G2S_FLANKS_OVER_THE_LINK") && !staged) {
         const size_t bytes = (size_t)((const char*)nodes - (const char*)desc);  // [descriptors][text], contiguous
         e = s->d_fstage.ensure(bytes);
         if (e == hipSuccess) e = hipMemcpyAsync(s->d_fstage.p, desc, bytes, hipMemcpyHostToDevice, s->stream);
@@ -2719,13 +2763,14 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl) {
   const DeviceGraph& dg = g.dev.at(s->device);
   const int d_err = s->params.d_err;
   if (hipSetDevice(s->device) != hipSuccess) return fail(G2S_ERR_NO_DEVICE, "cannot select device");
-  { const int rc = b->upload_flanks(); if (rc != G2S_OK) return rc; }
-  const int gmax = b->gmax;
   if (b->rnd_cap >= (1ull << 31) || b->dmax > 12000) return 1;  // (the trace kernel maps a whole fill in LDS)
+  { const int rc = b->upload_flanks(true); if (rc != G2S_OK) return rc; }
+  const int gmax = b->gmax;
   // ---- the launch order: longest gaps first (a stable counting sort; the session keeps the vectors)
   std::vector<uint32_t>& ids = s->res_ids;
   ids.clear();
   ids.reserve(n);
+  bool ids_identity = false;  // the launch takes the gaps in list order, all of them
   if (b->n_valid > 1024 && !getenv("G2S_NO_LPT") && (size_t)gmax <= 8 * b->n_valid + 65536) {
     std::vector<uint32_t>& at = s->res_at;
     at.assign((size_t)gmax + 2, 0);
@@ -2735,6 +2780,7 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl) {
     for (size_t i = 0; i < n; i++) if (!b->jobs[i].bad_flank) ids[at[(size_t)(gmax - b->jobs[i].g)]++] = (uint32_t)i;
   } else {
     for (size_t i = 0; i < n; i++) if (!b->jobs[i].bad_flank) ids.push_back((uint32_t)i);
+    ids_identity = ids.size() == n;
   }
   // A deep list (-dist-error in the thousands): the launch of the large variant is as long as its slowest gap, and
   // that gap is one of the list's longest — which would only enter the large variant when the regular tier's whole
@@ -2791,6 +2837,7 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl) {
         d.prune_from = j.g / 2 + d_err / 2 + j.lmf;
         d.all_paths = s->params.all_paths ? 1 : 0;
         d.flank_off = b->flank_off[i];
+        d.rs_mask = j.text_off;
       }
     };
     const size_t per_task = std::max<size_t>(512, (n + 15) / 16), ntasks = (n + per_task - 1) / per_task;
@@ -2975,11 +3022,26 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl) {
   }
   rl->timed = kernel_events_on(s);
   if (rl->timed) HIP_TRY_S(hipEventRecord(s->ev[1], st));
-  HIP_TRY_S(launch_fill_seg(st, (uint32_t)n_reg, dg.succ, dg.urec, gaps_dev, ids_dev, (const uint32_t*)s->d_flank.p,
+  // (the flank look-ups in this kernel's waves: every valid gap of such a list is in this launch — inline_ok excludes
+  // the deep lists, whose longest gaps start in the large variant)
+  SegInline inl;
+  const bool use_inl = b->inline_pending && n_early == 0;
+  if (b->inline_pending && !use_inl) { const int rc = b->upload_flanks(false); if (rc != G2S_OK) return rc; }
+  if (use_inl) {
+    void* d_nodes = nullptr;
+    HIP_TRY_S(hipHostGetDevicePointer(&d_nodes, b->nodes, 0));
+    inl.lk = s->lookup; inl.text = b->inline_text_dev; inl.nodes_dev = (uint32_t*)s->d_flank.p; inl.nodes_host = (uint32_t*)d_nodes;
+    inl.text_stride = (ids_identity && n_reg == n) ? b->text_stride : 0u;
+  }
+  // (in list order: no launch order to read — on a short list one round trip of the link less at the head of every gap)
+  const uint32_t* ids_fill = (use_inl && inl.text_stride) ? nullptr : ids_dev;
+  HIP_TRY_S(launch_fill_seg(st, (uint32_t)n_reg, dg.succ, dg.urec, gaps_dev, ids_fill, (const uint32_t*)s->d_flank.p,
                           (SubRec*)s->d_sub.p, (unsigned long long)out_states, (unsigned long long*)s->d_counter.p,
                           (GapOut*)s->d_outs.p, nullptr, nullptr, s->params.skip_confident ? 1 : 0, nullptr, two_waves,
                           nullptr, nullptr, 0u, 1u, true, rerun ? (uint32_t*)s->d_ovf.p : nullptr,
-                          dev_d2 ? (uint32_t*)s->d_d2list.p : nullptr, d2_tag));
+                          dev_d2 ? (uint32_t*)s->d_d2list.p : nullptr, d2_tag, use_inl ? &inl : nullptr));
+  if (use_inl) b->inline_pending = false;  // (behind this kernel d_flank and the pinned copy hold the ids)
+  s->lap_fill_queued = std::chrono::steady_clock::now();
   if (rl->timed) HIP_TRY_S(hipEventRecord(s->ev[2], st));
   // (queued BEHIND the regular tier's kernel, which takes the compute units first — a workgroup of the large variant
   // needs a whole unit's LDS and stays for the launch: started first, 256 of them leave the regular tier no unit until
@@ -3528,6 +3590,8 @@ static int resident_d3_wait(g2s_session* s, g2s_timing* tm_out, double* ms_d3_ou
   tm.host_finished_gaps += (uint32_t)hsum->host_items;
   tm.d3_table_entries += hsum->table_entries;
   const auto t_end = std::chrono::steady_clock::now();
+  s->lap_d3_queued = t_launched; s->lap_handed = t_handed; s->lap_finished = t_finished; s->lap_synced = t_synced; s->lap_end = t_end;
+  s->laps_valid = true;
   if (getenv("G2S_DEBUG"))
     fprintf(stderr, "[g2s] resident mode, phase D3 of %zu gaps: set-up + launches %.3f ms, wait for the hand-over %.3f ms, %zu gaps finished by the host in %.3f ms, wait for the trace kernel %.3f ms, results %.3f ms (kernels %.3f ms); %u draw-dependent gaps, %llu table entries, %llu draws; results %s, text %s\n",
             n, std::chrono::duration<double, std::milli>(t_launched - t_enter).count(), std::chrono::duration<double, std::milli>(t_handed - t_launched).count(),
@@ -4286,9 +4350,16 @@ extern "C" int g2s_fill_batch(g2s_session* s, const g2s_gap* gaps, size_t n, g2s
   int rc = g2s_batch_prepare(s, gaps, n, &b);
   if (rc != G2S_OK) return rc;
   const double ms_prep = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+  s->laps_valid = false;
   rc = g2s_batch_run(b, results, fill_arena, arena_cap);
   const auto t_free = std::chrono::steady_clock::now();
   g2s_batch_free(b);
+  if (rc == G2S_OK && s->laps_valid && s->last_timing.resident_launches == 1 && s->last_timing.resident_fallbacks == 0) {
+    auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point c) { return std::chrono::duration<double, std::micro>(c - a).count(); };
+    double* h = s->last_timing.host_us;
+    h[0] = us(t_begin, s->lap_fill_queued); h[1] = us(s->lap_fill_queued, s->lap_d3_queued); h[2] = us(s->lap_d3_queued, s->lap_handed);
+    h[3] = us(s->lap_handed, s->lap_finished); h[4] = us(s->lap_finished, s->lap_synced); h[5] = us(s->lap_synced, std::chrono::steady_clock::now());
+  }
   if (getenv("G2S_DEBUG"))
     fprintf(stderr, "[g2s] fill_batch: prepare %.3f ms, free %.3f ms\n", ms_prep,
             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_free).count());

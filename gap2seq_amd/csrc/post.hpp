@@ -24,6 +24,7 @@ struct GapJob {
   int g = 0, lmf = 0, rmf = 0;
   int skip_if_prev_right_fuz_gt = -1;
   bool bad_flank = false;
+  uint32_t text_off = 0;  // (batches) where the gap's flank text starts in the batch's pinned text (flank look-ups on the device)
   // oriented node (or kInvalidNode) of: left.substr(d,k) d=0..lmf | right-BFS
   // seeds right.substr(len-k-j,k) j=0..rmf | targets right.substr(j,k) j=0..rmf.
   // Not owned: the batch's pinned buffer (written by the flank look-up kernel, flank_lookup.hip)

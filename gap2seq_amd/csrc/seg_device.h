@@ -6,6 +6,7 @@
 
 #include "fill_device.h"
 #include "fill_seg.h"
+#include "flank_lookup.h"
 
 // The HIP headers' __ballot(p) compares an int with zero: a predicate is first turned into 0 / 1 in a vector register
 // and then compared again — three instructions where the compare that made the predicate had already left the mask in
@@ -200,6 +201,18 @@ struct SegArgs {
   // this kernel runs, and takes an entry only when it carries this list's tag (the gap's record and closure are
   // written, and fenced, in front of it).  out_counter[32 + (gap & 63)] counts the gaps that are through.
   uint32_t d2_tag;
+  // resident mode, g2s_fill_seg / g2s_fill_seg2: every gap's wave(s) resolve the gap's flank k-mers themselves
+  // (flank_device.h) — no look-up kernel in front.  inl_text: the list's flank text (GapDev.rs_mask = the gap's offset
+  // in it: [left k+lmf][right first k+rmf][right last k+rmf], 4-byte aligned), null: the ids are in flank_nodes.  The
+  // ids are also stored at inl_nodes_dev / inl_nodes_host + GapDev.flank_off (the table the later kernels and the
+  // host's half read).
+  const char* inl_text;
+  uint32_t* inl_nodes_dev;
+  uint32_t* inl_nodes_host;
+  // (not 0: the gap at launch position x has its text at inl_text + x * inl_stride — a list launched in list order,
+  // gap_ids null; a multiple of 4, at most 512)
+  uint32_t inl_stride;
+  g2s::FlankLookup lk;
 };
 
 // LDS of the large variant (words): see the layout notes at each phase

@@ -69,7 +69,8 @@ class g2s_timing(C.Structure):
                 ("draw_dependent_gaps", C.c_uint64), ("d3_table_entries", C.c_uint64),
                 ("host_finished_gaps", C.c_uint32), ("team_groups", C.c_uint32), ("team_sessions", C.c_uint32),
                 ("team_groups_by_session", C.c_uint32 * 16), ("seg_timed_launches", C.c_uint32), ("team_d3_sharded", C.c_uint32), ("reserved0", C.c_uint32),
-                ("team_ms_fill", C.c_double * 16), ("team_ms_d3", C.c_double * 16), ("team_ms_wall", C.c_double * 16)]
+                ("team_ms_fill", C.c_double * 16), ("team_ms_d3", C.c_double * 16), ("team_ms_wall", C.c_double * 16),
+                ("host_us", C.c_double * 8)]
 
 
 class g2s_run_opts(C.Structure):

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define G2S_ABI_VERSION 5
+#define G2S_ABI_VERSION 6
 
 /* status codes */
 #define G2S_OK 0
@@ -231,6 +231,11 @@ typedef struct g2s_timing {
   /* ...and, per session (the first 16), what its group took: fill kernel(s) and phase D3 kernels by HIP events (timed
    * launches only), and the wall time of the session's thread from the call to its last result */
   double team_ms_fill[16], team_ms_d3[16], team_ms_wall[16];
+  /* (ABI 6) g2s_fill_batch on one session, resident mode: where the host's time inside the call goes, in microseconds:
+   * [0] entry -> fill kernel queued (preparation and launch set-up: the device idles until then), [1] -> phase D3
+   * queued, [2] -> the device's hand-over seen (waiting), [3] -> the host-finished gaps done, [4] -> stream
+   * synchronised, [5] -> return.  Zero when the list took another path. */
+  double host_us[8];
 } g2s_timing;
 
 /* ---------------------------------------------------------------------------

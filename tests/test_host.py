@@ -30,7 +30,7 @@ def test_abi_exports_every_declared_symbol(product):
     for n in sorted(names):
         assert hasattr(so, n), "include/*.h declares %s but libg2s_hip.so does not export it" % n
     assert set(product._SIGS) == names  # the ctypes binding covers the whole header
-    assert so.g2s_abi_version() == 5
+    assert so.g2s_abi_version() == 6
 
 
 def test_product_never_touches_the_oracle():

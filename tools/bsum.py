@@ -18,4 +18,4 @@ for ln in lines:
           b["fill_lds_kernel"], "(per launch", r["kernel_ms_per_launch"], "x", r["launches_per_step"], ") hbm-tier",
           b["hbm_tier_kernels"], "host", b["host_phase_d"], "| frac", r["frac"], "| filled", d["filled"],
           "| c3:", (d.get("c3_on_one_gpu") or {}).get("value"), (d.get("c3_on_one_gpu") or {}).get("kernel_ms_per_launch"),
-          (d.get("c3_on_one_gpu") or {}).get("roofline_frac"))
+          (d.get("c3_on_one_gpu") or {}).get("roofline_frac"), "| host us", list((b.get("host_us_inside_the_call") or {}).values()))
