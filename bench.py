@@ -691,6 +691,7 @@ def main():
         "retried_gaps": tm.retried_gaps,
         "resident": {"lists_finished_on_the_device": tm.resident_launches, "lists_given_back_to_the_host_path": tm.resident_fallbacks,
                      "draw_dependent_gaps": tm.draw_dependent_gaps, "draw_count_table_entries": tm.d3_table_entries,
+                     "gaps_traced_by_the_fill_kernel": tm.traced_in_fill_gaps,
                      "gaps_finished_by_the_host": tm.host_finished_gaps,
                      "team_groups": tm.team_groups,
                      "team_groups_by_session": [tm.team_groups_by_session[i] for i in range(min(16, max(1, len(sessions))))],

@@ -39,6 +39,8 @@ static_assert(sizeof(D2Out) == 32, "D2Out layout");
 
 struct D2Args {
   const GapDev* gaps;
+  const GapLite* lite;                  // not null: the descriptors as short records (fill_device.h: GapSrc), `gaps` is not read
+  int32_t lite_e;
   const uint32_t* flank_nodes;
   GapOut* outs;
   SubRec* sub;                          // the closures (SegRec), where the fill kernels left them

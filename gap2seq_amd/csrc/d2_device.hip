@@ -263,7 +263,7 @@ __device__ int d2_one(uint32_t* lds, const D2Args& A, uint32_t gap, uint32_t* sc
   const uint32_t nrec = uni(go->n_xl);
   const SegRec* segs = (const SegRec*)(A.sub + uni((uint32_t)go->sub_off) + ((uint64_t)uni((uint32_t)(go->sub_off >> 32)) << 32));
   SegRec* segs_w = const_cast<SegRec*>(segs);
-  const GapDev gd = A.gaps[gap];
+  const GapDev gd = GapSrc{A.gaps, A.lite, A.lite_e, A.all_paths}.load(gap);
   const int lmf = (int)uni((uint32_t)gd.lmf), rmf = (int)uni((uint32_t)gd.rmf);
   const uint32_t* targets = A.flank_nodes + uni(gd.flank_off) + (uint32_t)(lmf + 1) + (uint32_t)(rmf + 1);
   const bool all_paths = A.all_paths != 0;

@@ -81,6 +81,7 @@ struct D3Summary {
   uint32_t rand_state[31];  // the 31 words in front of the first value the list did not consume
   uint32_t trace_waves;     // waves of g2s_d3_trace that are through
   uint32_t big_gaps;        // gaps that ran in the large variant of the segment tier (G2S_DEV_BIG)
+  uint32_t traced_gaps;     // gaps whose fill kernel's wave wrote text and record itself (G2S_DEVA_TRACED)
 };
 static_assert(sizeof(D3Summary) <= 512, "the lap stamps live at byte 512 of the summary's slot");
 

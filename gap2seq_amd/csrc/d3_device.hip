@@ -122,7 +122,7 @@ __device__ __forceinline__ uint32_t d3_classify_body(const D3Params& P, const D3
                                                      unsigned long long* red, bool one_wg) {
   const uint32_t n = P.n;
   unsigned long long xA = 0, sA = 0, xB = 0, sB = 0, xD = 0, sD = 0, segs = 0;
-  uint32_t unhandled = 0, seg_gaps = 0, big = 0;
+  uint32_t unhandled = 0, seg_gaps = 0, big = 0, traced = 0;
   for (uint32_t i = first; i < n; i += stride) {
     // (the descriptor comes over the link on a short list, the record from device memory: asked for together)
     const D3Gap dg = dgaps[i];
@@ -142,6 +142,7 @@ __device__ __forceinline__ uint32_t d3_classify_body(const D3Params& P, const D3
         segs += nseg_b;
         seg_gaps++;
         if (flags & G2S_DEV_BIG) big++;
+        if (dflags & G2S_DEVA_TRACED) traced++;
         const bool phase_d = c_count > 0 && n_len > 0;  // :1169
         // (a gap listed for g2s_d2_* is not the host's yet: that kernel may still be running — the hand-off decides)
         const bool by_host = phase_d && !(dflags & (G2S_DEVA_ANALYSED | G2S_DEVA_D2_PENDING));
@@ -194,6 +195,8 @@ __device__ __forceinline__ uint32_t d3_classify_body(const D3Params& P, const D3
   const unsigned long long cnts = wave_add64(((unsigned long long)unhandled << 32) | seg_gaps);
   big = dpp_sum(big);
   if ((threadIdx.x & 63u) == 0u && big) atomicAdd(&W.sum->big_gaps, big);
+  traced = dpp_sum(traced);
+  if ((threadIdx.x & 63u) == 0u && traced) atomicAdd(&W.sum->traced_gaps, traced);
   const uint32_t wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   if ((threadIdx.x & 63u) == 0u) {
     unsigned long long* r = red + wave * 8u;
@@ -971,11 +974,12 @@ __global__ __launch_bounds__(64 * NW) void g2s_d3_trace(const D3Params P, const 
     td.lmf = (uint16_t)(uni(h1.w) & 0xFFFFu); td.nsegs = (uint16_t)(uni(h1.w) >> 16);
   }
   struct {
-    uint32_t flags, dflags, start_seg, start_t, sub_vertices, sub_edges;
+    uint32_t flags, dflags, start_seg, start_t, sub_vertices, sub_edges, top_level;
     int32_t c_count, n_len, len[2], reached_j, count_s;
   } go;
   {
     const GapOut& g = outs[i];
+    go.top_level = uni(g.top_level);
     go.flags = uni(g.flags); go.dflags = uni(g.dflags); go.start_seg = uni(g.start_seg); go.start_t = uni(g.start_t);
     go.sub_vertices = uni(g.sub_vertices); go.sub_edges = uni(g.sub_edges);
     go.c_count = (int32_t)uni((uint32_t)g.c_count); go.n_len = (int32_t)uni((uint32_t)g.n_len);
@@ -1044,6 +1048,13 @@ __global__ __launch_bounds__(64 * NW) void g2s_d3_trace(const D3Params P, const 
     return;
   }
   const uint32_t gi = td.gi;
+  // (its fill kernel's wave traced the gap itself — one path, nothing to draw for: text and record are written; a gap the
+  // skip rule or the memory verdict took out after all cannot carry the flag: fill_seg.hip asks for neither)
+  if ((go.dflags & G2S_DEVA_TRACED) && !(gi & (GI_BAD | GI_SKIPPED | GI_MEM | GI_HOST)) && (gi & GI_PHASE_D)) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    leave(go.top_level);
+    return;
+  }
   struct { uint16_t lmf; } dg = {td.lmf};
   const uint64_t abs_off = td.arena_off;
   char* buf = arena + abs_off;

@@ -57,6 +57,40 @@ struct GapDev {
   uint64_t lvl_off;    // LDS tier: D+2 level offsets into the state log
 };
 
+/* Resident mode, segment tier: the 32 bytes of a gap that are not the same for the whole list and cannot be derived —
+ * what the host writes per gap and the link carries (GapDev: 96 bytes, most of them the work-area offsets of the tiers
+ * that keep their search state in device memory).  The kernels expand it (GapSrc::load). */
+struct GapLite {
+  int32_t g;            // gap_len
+  uint16_t lmf, rmf;
+  uint32_t flank_off;   // as GapDev.flank_off
+  uint32_t text_off;    // -> GapDev.rs_mask: the gap's flank text (look-ups in the fill kernel)
+  uint64_t arena_off;   // -> GapDev.rlog_off: the gap's fill buffer in the batch's share of the arena
+  uint32_t has_skip;    // -> GapDev.rlog_cap: a skip rule decides over the gap
+  uint32_t pad;
+};
+#ifdef __HIPCC__
+/* where a kernel of the segment tier reads a gap's descriptor from: the full records, or the short ones + the list's constants */
+struct GapSrc {
+  const GapDev* full;
+  const GapLite* lite;
+  int32_t e, all_paths;
+  __device__ __forceinline__ GapDev load(uint32_t gi) const {
+    if (!lite) return full[gi];
+    const GapLite l = lite[gi];
+    GapDev d;
+    d.g = l.g; d.e = e; d.lmf = (int32_t)l.lmf; d.rmf = (int32_t)l.rmf;
+    d.D = d.lmf + d.rmf + d.g + e;                 // :862-863,1029
+    d.right_half = d.rmf + (d.g + e + 1) / 2;      // :862
+    d.prune_from = d.g / 2 + e / 2 + d.lmf;        // :1050
+    d.all_paths = all_paths;
+    d.flank_off = l.flank_off; d.rs_mask = l.text_off; d.rlog_cap = l.has_skip; d.st_mask = 0u; d.slog_cap = 0u; d.pad0 = 0u;
+    d.rs_off = 0ull; d.rlog_off = l.arena_off; d.st_off = 0ull; d.slog_off = 0ull; d.lvl_off = 0ull;
+    return d;
+  }
+};
+#endif
+
 /* SubState.flags */
 #define G2S_SUB_IN_S 0x1u     /* on a path to a sink of the reference's subgraph (D1/D2)      */
 #define G2S_SUB_IN_T 0x2u     /* reachable backwards from a traceback start (D3)              */
@@ -147,5 +181,7 @@ struct GapOut {
 #define G2S_DEVA_D2_PENDING 0x10u /* the fill kernel listed the gap for g2s_d2_* (which runs beside phase D3's first kernels: the
                                     hand-off looks whether G2S_DEVA_RUNS has joined it; if not, the closure is the host's) */
 #define G2S_DEVA_D2_FAILED 0x20u  /* g2s_d2_* could not analyse the closure (beyond its capacities): the host's after all */
+#define G2S_DEVA_TRACED 0x40u    /* the fill kernel's wave traced the gap itself (one path, nothing to draw for): fill text and result
+                                    record are written, GapOut.top_level = the fill's length; phase D3 counts its draws, the trace kernel skips it */
 #define G2S_DEVA_RUNS 0x8u       /* (with ANALYSED) analysed by g2s_d2_* (d2_device.hip): the verdicts are the gap's runs (D2Out),
                                     the subgraph statistics D2Out.sub */

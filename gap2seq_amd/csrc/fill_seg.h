@@ -20,13 +20,33 @@
 
 namespace g2s {
 
+// resident mode, deep lists: where g2s_fill_segw puts the closures the host will analyse the moment their gaps end
+// (SegArgs.early_*: device-visible pinned memory, the counters in device memory)
+struct SegEarly {
+  SegRec* segs = nullptr;
+  uint32_t* items = nullptr;  // eight words per item: {gap, segments (0: no room), offset, -, ready, -, -, -}
+  GapOut* outs = nullptr;
+  unsigned long long* ctr = nullptr;
+  uint32_t cap_items = 0, cap_segs = 0;
+};
+
 // launch_fill_seg: flank look-ups inside the fill kernel (fill_seg.hip, SegArgs.inl_*)
 struct SegInline {
   FlankLookup lk;
   const char* text = nullptr;        // device-readable: the list's flank text (GapDev.rs_mask: the gap's offset)
   uint32_t* nodes_dev = nullptr;     // the table flank_nodes points at, writable
   uint32_t* nodes_host = nullptr;    // its pinned copy for the host's half (device-writable)
-  uint32_t text_stride = 0;          // not 0: text of the gap at launch position x at text + x * text_stride (gap_ids null)
+  uint32_t text_stride = 0;          // not 0: gap i's text at text + i * text_stride (a list without a bad flank)
+};
+
+// launch_fill_seg: tracebacks that have no choice to make, by the gap's own wave (fill_seg.hip, SegArgs.tr_*)
+struct SegTrace {
+  uint32_t* results = nullptr;  // g2s_result[n], device-writable
+  char* arena = nullptr;        // device-writable
+  unsigned long long arena_base = 0, max_states = 0;
+  const char* chu = nullptr;
+  const char* chd = nullptr;
+  int k = 0;
 };
 
 // (tools, G2S_D2_LOG) where in d2_list the fill kernels note when a gap's closure was listed; 0: nowhere
@@ -56,7 +76,15 @@ hipError_t launch_fill_seg(hipStream_t st, uint32_t ngaps, const uint32_t* succ,
                            uint32_t* d2_list = nullptr, uint32_t d2_tag = 0u /* SegArgs.d2_tag */,
                            // (resident) the waves resolve their gap's flank k-mers themselves (SegArgs.inl_*): the flank
                            // text, where the ids go besides flank_nodes' own table; null: flank_nodes holds them already
-                           const SegInline* inl = nullptr);
+                           const SegInline* inl = nullptr,
+                           // (resident, lists that are not deep) the closures the host will analyse also go to pinned
+                           // memory as their gaps end (SegArgs.early_*); null: behind phase D3's hand-over
+                           const SegEarly* early = nullptr,
+                           // (resident) single-path gaps traced by their own waves (SegArgs.tr_*); null: none
+                           const SegTrace* tr = nullptr,
+                           // (resident) the gaps' descriptors as GapLite records (fill_device.h) + the list's constants:
+                           // `gaps` is not read then
+                           const GapLite* lite = nullptr, int lite_e = 0, int lite_all_paths = 0);
 
 // The large variant: `workgroups` persistent workgroups (one per compute unit) take the listed gaps
 // in order from the counter *next_gap (zero before the launch); scratch: fill_segx_scratch_bytes().
@@ -71,15 +99,6 @@ hipError_t launch_fill_segx(hipStream_t st, uint32_t ngaps, uint32_t workgroups,
 
 // The large variant on a workgroup of eight waves per gap (fill_segw.hip): same arguments; the workgroups take all of a
 // compute unit's LDS, scratch: fill_segw_scratch_bytes().  resident: closures and records stay in device memory.
-// resident mode, deep lists: where g2s_fill_segw puts the closures the host will analyse the moment their gaps end
-// (SegArgs.early_*: device-visible pinned memory, the counters in device memory)
-struct SegEarly {
-  SegRec* segs = nullptr;
-  uint32_t* items = nullptr;  // eight words per item: {gap, segments (0: no room), offset, -, ready, -, -, -}
-  GapOut* outs = nullptr;
-  unsigned long long* ctr = nullptr;
-  uint32_t cap_items = 0, cap_segs = 0;
-};
 size_t fill_segw_lds_bytes();
 size_t fill_segw_scratch_bytes(uint32_t workgroups);
 hipError_t launch_fill_segw(hipStream_t st, uint32_t ngaps, uint32_t workgroups, const uint32_t* succ, const uint32_t* urec,
@@ -91,6 +110,7 @@ hipError_t launch_fill_segw(hipStream_t st, uint32_t ngaps, uint32_t workgroups,
                             // was written by the launch in front: launch_fill_seg's ovf_list); ngaps is then the most
                             // there can be
                             const unsigned long long* ngaps_dev = nullptr, const SegEarly* early = nullptr,
-                            uint32_t* d2_list = nullptr, uint32_t d2_tag = 0u /* as launch_fill_seg */);
+                            uint32_t* d2_list = nullptr, uint32_t d2_tag = 0u /* as launch_fill_seg */,
+                            const GapLite* lite = nullptr, int lite_e = 0, int lite_all_paths = 0 /* as launch_fill_seg */);
 
 }  // namespace g2s

@@ -51,6 +51,7 @@
 #include <set>
 #include <utility>
 
+#include "../../include/g2s.h"
 #include "fill_device.h"
 #include "fill_seg.h"
 #include "flank_device.h"
@@ -248,7 +249,6 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
   static_assert(!(BIG && TWO), "the large variant is one wave per gap");
   const uint32_t* __restrict__ succ = A.succ;
   const uint32_t* __restrict__ urec = A.urec;
-  const GapDev* __restrict__ gaps = A.gaps;
   const uint32_t* __restrict__ gap_ids = A.gap_ids;
   const uint32_t* __restrict__ flank_nodes = A.flank_nodes;
   SubRec* sub_out = A.sub_out;
@@ -275,21 +275,21 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
   const int lane = (int)(threadIdx.x & 63u);
   const int wave = TWO ? (int)(threadIdx.x >> 6) : 0;
   const uint32_t gi = gap_ids ? uni(gap_ids[x]) : x;  // (no list: the launch takes the gaps in list order)
-  // (look-ups in this kernel, the text at a fixed stride by launch position: asked for beside the gap's descriptor —
-  // on a short list both come over the link, one round trip instead of two)
+  // (look-ups in this kernel, the text at a fixed stride by gap: asked for beside the gap's descriptor — one round trip
+  // instead of two; on a short list both come over the link)
   bool inl = false, inl_early = false;
   uint32_t tw0 = 0u, tw1 = 0u;  // (the text's words lane and lane + 64, in flight while the descriptor travels)
   if constexpr (!BIG) {
     inl = A.inl_text != nullptr;
     if (inl && A.inl_stride) {
-      const uint32_t* src = (const uint32_t*)(A.inl_text + (size_t)x * A.inl_stride);
+      const uint32_t* src = (const uint32_t*)(A.inl_text + (size_t)gi * A.inl_stride);
       const uint32_t words = A.inl_stride / 4u, w = threadIdx.x & 63u;
       if (w < words) tw0 = src[w];
       if (w + 64u < words) tw1 = src[w + 64u];
       inl_early = true;
     }
   }
-  const GapDev gd = gaps[gi];
+  const GapDev gd = A.gaps.load(gi);
   GapOut* go = &outs[gi];
   const uint32_t* lseeds = flank_nodes + gd.flank_off;
   const uint32_t* rseeds = lseeds + (uint32_t)(gd.lmf + 1);
@@ -326,8 +326,22 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
   // device gave back): resident mode announces nothing.  A batch whose closing wave gives up waiting (2^18 looks:
   // never seen) or that never fills is not lost — the host takes every gap not announced when the launch has ended.
   // The large variant's workgroups publish what several waves stored: it keeps the fences.
+  // (look-ups in this kernel: the host's copy of the gap's node ids is written only for the gaps the host will look
+  // at — a closure it analyses, a gap that outgrew the tier — : 132 bytes a gap through the link for every gap were
+  // 1.3 MB of a 10 000-gap list, 30 us of its launch)
+  auto nodes_to_host = [&]() {
+    if constexpr (!BIG) {
+      if (A.inl_text != nullptr && A.inl_nodes_host != nullptr) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t nit = (uint32_t)(gd.lmf + 1) + 2u * (uint32_t)(gd.rmf + 1);
+        for (uint32_t q = (uint32_t)(threadIdx.x & 63u); q < nit; q += 64u)
+          A.inl_nodes_host[gd.flank_off + q] = __hip_atomic_load(&A.inl_nodes_dev[gd.flank_off + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  };
   auto publish = [&]() {
     if (A.resident) {
+      if (flags & (G2S_DEV_OVERFLOW_A | G2S_DEV_OVERFLOW_B)) nodes_to_host();
       if (A.ovf_list && lane == 0 && (flags & (G2S_DEV_OVERFLOW_A | G2S_DEV_OVERFLOW_B)) && !(flags & G2S_DEV_WATCHDOG))
         A.ovf_list[atomicAdd(out_counter + 1, 1ull)] = gi;
       // (this gap is through: what a polling g2s_d2_small counts to know that no entry can come any more — behind the
@@ -410,17 +424,15 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
       stage[lane + 64] = tw1;
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_wave_barrier();
-      const char* t = (const char*)stage;
       uint32_t* fn = stage + 128;
       const int nl = lmf + 1, nr = rmf + 1;
       for (int i = lane; i < nl + 2 * nr; i += 64) {
         const bool right_seed = i >= nl && i < nl + nr;
         if (TWO && right_seed != (wave == 1)) continue;
-        const char* at = t + g2s::flank_item_offset(i, k, lmf, rmf, tail);
-        const uint32_t node = A.lk.wide ? g2s::flank_node_of<g2s::u128>(A.lk, at) : g2s::flank_node_of<uint64_t>(A.lk, at);
+        const int at = g2s::flank_item_offset(i, k, lmf, rmf, tail);
+        const uint32_t node = A.lk.wide ? g2s::flank_node_of<g2s::u128>(A.lk, stage, at) : g2s::flank_node_of<uint64_t>(A.lk, stage, at);
         fn[i] = node;
-        A.inl_nodes_dev[gd.flank_off + (uint32_t)i] = node;
-        A.inl_nodes_host[gd.flank_off + (uint32_t)i] = node;
+        A.inl_nodes_dev[gd.flank_off + (uint32_t)i] = node;  // (the pinned copy: only of the gaps the host will look at — publish)
       }
       lds_sync();
       __builtin_amdgcn_wave_barrier();
@@ -997,7 +1009,13 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
     ec = me ? c : ec;
     ep01 = me ? (0xFFFF0000u | par) : ep01;
     ep23 = me ? 0xFFFFFFFFu : ep23;
-    es = me ? 0u : es;  // states up to the end of the unitig: loaded with the exit record for all new events at once
+    // states up to the end of the unitig: loaded with the exit record for all new events at once, at the head of the next
+    // round.  (Round 6, measured and not kept: the record asked for HERE, by the event's lane.  The compiler waits for
+    // it on the spot — the loaded registers are event state that every join of this lambda copies — and the launch got
+    // slower, g2s_fill_seg2 0.102 -> 0.104 ms, g2s_fill_seg on 10 000 gaps 0.281 -> 0.320 ms; and a load the compiler
+    // does not see could only pass under the round's remaining children: the next round begins with the horizon over
+    // this very value.  LAB_NOTES, round 6.)
+    es = me ? 0u : es;
     est = me ? (src ? ((uint32_t)dw | ((uint32_t)dw << 16)) : pstop) : est;
     ev |= 1ull << l;
   };
@@ -1839,6 +1857,27 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
     publish();
     return;
   }
+  // (resident mode, lists that are not deep: a closure the host will analyse — more than 192 segments, a k-mer at two
+  // depths — goes to pinned host memory as well, the moment its gap ends, as the large variant's do on deep lists
+  // (SegArgs.early_*, fill_segw.hip): the thread that waits for the list analyses it under the rest of the launch instead
+  // of behind phase D3's hand-over, where two such closures were 25 us of a 500-gap list's step beside a 24 us kernel)
+  SegRec* edst = nullptr;
+  uint32_t eslot = 0xFFFFFFFFu, eoff = 0xFFFFFFFFu;
+  if (want_s && !analysed) nodes_to_host();  // (in front of the early item's release below, and of everything phase D3 hands over)
+  if constexpr (!BIG) {
+    if (A.early_items != nullptr && want_s && !analysed && nrec > 0u) {
+      unsigned long long slot = 0, so = 0;
+      if (lane == 0) {
+        slot = atomicAdd(&A.early_ctr[0], 1ull);
+        if (slot < (unsigned long long)A.early_cap_items) so = atomicAdd(&A.early_ctr[1], (unsigned long long)nrec);
+      }
+      slot = __shfl(slot, 0); so = __shfl(so, 0);
+      if (slot < (unsigned long long)A.early_cap_items) {
+        eslot = (uint32_t)slot;
+        if (so + nrec <= (unsigned long long)A.early_cap_segs) { eoff = (uint32_t)so; edst = A.early_segs + eoff; }  // (no room: the item says so)
+      }
+    }
+  }
   {
     SegRec* dst = (SegRec*)(sub_out + hbase);
     for (uint32_t b0 = 0; b0 < nseg; b0 += 64u) {
@@ -1902,7 +1941,9 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
         nxp += k > 1u ? k - 1u : 0u;
       }
       dst[s_aux[b]] = r;
+      if (edst) edst[s_aux[b]] = r;
     }
+    if (edst) __threadfence_system();  // (this lane's records are in host memory before the item says so)
     nxp = wave_sum(nxp);
   }
   if (lane == 0) {
@@ -1946,6 +1987,195 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
   }
 #endif
   q7_collect();
+  if constexpr (!BIG) {
+    if (eslot != 0xFFFFFFFFu && lane == 0) {  // the early item: the gap's finished record, then what says it is complete
+      if (edst) {
+        static_assert(sizeof(GapOut) % 16 == 0, "GapOut is copied in 16-byte words");
+        __threadfence();  // (the record's words above: read back below)
+        const uint4* gs = (const uint4*)go;
+        uint4* gd4 = (uint4*)&A.early_outs[eslot];
+        for (uint32_t q = 0; q < sizeof(GapOut) / 16u; q++) gd4[q] = gs[q];
+      }
+      uint32_t* it = A.early_items + 8u * (size_t)eslot;
+      it[0] = gi; it[1] = edst ? nrec : 0u; it[2] = eoff; it[3] = 0u;
+      __threadfence_system();
+      __hip_atomic_store(&it[4], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  // ---------------- the traceback of a gap whose path is its only one, here (round 6) -----------------------------
+  // :1437-1522 draws rand() for the path length and at every traced base, but what a traceback WRITES depends on the
+  // values only where it has a choice: one path length and no entry of the traceback closure with several parents
+  // (most gaps of a list) leave one path, whatever is drawn — its fill text, case, fuz values and number of draws are
+  // known now.  Resident mode's trace kernel (d3_device.hip) waits for every gap of the list — the offsets into the one
+  // rand() stream are prefix sums — and then pushes the whole list's text through the link at once: 214 us for the
+  // 8 MB of a 10 000-gap list, behind everything else.  Such a gap's wave writes text and result record itself, while
+  // the other gaps are still being searched (the link is idle then); phase D3 still counts the gap's draws, its wave
+  // of the trace kernel finds G2S_DEVA_TRACED and leaves.  Everything here follows g2s_d3_trace step by step (the walk
+  // along the parents, the safe bit of every base, lower case = not safe and k or more below the nearest safe base
+  // above, :1466-1468); anything out of the ordinary leaves the gap to that kernel.
+  if constexpr (!BIG) {
+    const bool no_over = sb <= A.tr_max_states && nvis <= A.tr_max_states;  // (else the -max-mem verdict: phase D3's)
+    const uint32_t sa_w = c1 > 0 ? s1 : s2;
+    if (A.tr_results != nullptr && (analysed || !want_s) && !choice && n_len == 1 && start_b0 != SEG_NOPAR && no_over &&
+        gd.rlog_cap == 0u /* no skip rule on this gap */ && len0 >= 1 && len0 <= 4096 && nrec <= 256u &&
+        (sa_w & 0xFFFFu) == (sa_w >> 16)) {
+      const int len = len0, k = A.tr_k;
+      uint2* hop = (uint2*)s_cnt;           // by hop: the depth at which it is entered | the segment | entry state << 16
+      unsigned char* cb = (unsigned char*)s_p23;  // by fill-buffer index: safe bit, then the character (s_p23 and s_aux: 4 096 bytes)
+      lds_sync();
+      // (i) the chain of segments, wave-uniform: from the start along the one parent to a source
+      bool bad = false;
+      int nh = 0, d_end = -1;
+      {
+        uint32_t si = start_b0;
+        int at = len;
+        for (;;) {
+          if (nh >= 256) { bad = true; break; }
+          const uint32_t dl = uni(s_dl[si]), st = uni(s_t[si]), v0 = uni(s_node[si]);
+          const int d0 = (int)(dl & 0xFFFFu);
+          const int t = nh == 0 ? (int)start_t0 : max(dec15(st), dec15(st >> 16));  // (a child in the closure puts the whole parent there)
+          if (t < 0 || d0 + t != at) { bad = true; break; }
+          if (lane == 0) hop[nh] = make_uint2((uint32_t)at, si | ((uint32_t)t << 16));
+          nh++;
+          const uint32_t ls = d0 <= lmf ? uni(l_seed[d0]) : G2S_DEV_INVALID;
+          if (ls != G2S_DEV_INVALID && (v0 >> 1) == (ls >> 1)) { d_end = d0; break; }  // a source: :1455-1462
+          const uint32_t par = uni(s_p01[si]) & 0xFFFFu;
+          if (d0 < 1 || par == SEG_NOPAR || par >= nseg) { bad = true; break; }  // (:1493-1510: the trace kernel's, and the host's)
+          at = d0 - 1;
+          si = par;
+        }
+      }
+      if (!bad && d_end != (int)(sa_w & 0xFFFFu)) bad = true;  // (the stop depth the search itself found)
+      lds_sync();
+      if (!bad) {
+        const int stop0 = d_end, left_fuz = lmf - d_end, draws = 1 + len - d_end;
+        const int npos = len - stop0, per = (npos + 63) / 64;
+        const int hi_d = len - lane * per, cnt = max(0, min(per, hi_d - stop0));  // this lane: depths (hi_d - cnt, hi_d]
+        // the safe bit of the k-mer of state q of segment b (g2s_d3_trace: outside_safe, and the rule in front of it)
+        auto split_of = [&](uint32_t b, int ts) -> int {
+          int split = ts;
+          if (analysed && ts >= 0) {
+            const uint32_t dl = s_dl[b], v0 = s_node[b];
+            const int d0 = (int)(dl & 0xFFFFu);
+            const int ln = max(0, min((int)(dl >> 16), d_last - d0 + 1));
+            int sp = -1;
+            const int pk = seg_pos(v0, (uint32_t)ln, sinknode);
+            if (pk >= 0 && d0 + pk >= lo_sink) sp = pk;
+            if (t_is_s) { const int pt = seg_pos(v0, (uint32_t)ln, reached); if (pt >= 0 && (d0 + pt == len0 || (n_len > 1 && d0 + pt == len1))) sp = pt; }
+            if (sp >= 0 && sp < ts) split = sp;
+          }
+          return max(split, 0);
+        };
+        auto safe_of = [&](uint32_t b, int q) -> bool {
+          if (!want_s) return true;
+          const uint32_t st = s_t[b];
+          const int ts = dec15(st);
+          if (q > ts) {  // in the traceback closure only: the first segment in emission order that holds the k-mer on a path to a sink
+            const uint32_t v0 = s_node[b];
+            const uint32_t x = (v0 & 1u) ? (v0 >> 1) - (uint32_t)q : (v0 >> 1) + (uint32_t)q;
+            for (int o = (int)nseg - 1; o >= 0; o--) {
+              const uint32_t ost = s_t[o];
+              if (max(dec15(ost), dec15(ost >> 16)) < 0) continue;  // (not emitted)
+              const int ots = dec15(ost);
+              const uint32_t on = s_node[o], oidx = on >> 1;
+              const int tq = (on & 1u) ? (int)oidx - (int)x : (int)x - (int)oidx;
+              if (tq >= 0 && tq <= ots) return tq <= split_of((uint32_t)o, ots) ? (ost & 0x8000u) != 0u : (ost & 0x80000000u) != 0u;
+            }
+            return sink_safe;
+          }
+          return q > split_of(b, ts) ? (st & 0x80000000u) != 0u : (st & 0x8000u) != 0u;
+        };
+        auto hop_find = [&](int d) -> int {  // the last hop entered at or above depth d
+          int lo = 0, hi = nh;
+          while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int)hop[mid].x >= d) lo = mid; else hi = mid; }
+          return lo;
+        };
+        // pass 1: the safe bits of this lane's stretch, from the top of the fill downwards
+        int lowest_safe = 0x7FFFFFFF;
+        if (cnt > 0) {
+          int h = hop_find(hi_d);
+          uint2 hr = hop[h];
+          int d0 = (int)hr.x - (int)(hr.y >> 16);
+          for (int c = 0; c < cnt; c++) {
+            const int p = hi_d - c;
+            if (p < d0) { h++; hr = hop[h]; d0 = (int)hr.x - (int)(hr.y >> 16); }
+            const bool sf = safe_of(hr.y & 0xFFFFu, p - d0);
+            if (sf) lowest_safe = p;
+            cb[p - 1] = sf ? 1u : 0u;
+          }
+        }
+        // the nearest safe depth above each lane's stretch (the walk begins with the top of the fill counting as safe)
+        int above = lowest_safe;
+        for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(above, o); if (lane >= o) above = min(above, y); }
+        above = __shfl_up(above, 1);
+        if (lane == 0) above = 0x7FFFFFFF;
+        int last_solid = min(above, len);
+        // pass 2: case, and the characters (the last base of the k-mer, by orientation) — eight loads in flight
+        if (cnt > 0) {
+          int h = hop_find(hi_d);
+          uint2 hr = hop[h];
+          int d0 = (int)hr.x - (int)(hr.y >> 16);
+          uint32_t v0 = s_node[hr.y & 0xFFFFu];
+          for (int c0 = 0; c0 < cnt; c0 += 8) {
+            uint32_t xs[8];
+            bool lowc[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+              const int c = c0 + u;
+              xs[u] = 0u; lowc[u] = false;
+              if (c < cnt) {
+                const int p = hi_d - c;
+                if (p < d0) { h++; hr = hop[h]; d0 = (int)hr.x - (int)(hr.y >> 16); v0 = s_node[hr.y & 0xFFFFu]; }
+                const int q = p - d0;
+                const bool up = (v0 & 1u) == 0u;
+                xs[u] = (up ? (v0 >> 1) + (uint32_t)q : (v0 >> 1) - (uint32_t)q) | (up ? 0u : 0x80000000u);
+                if (cb[p - 1]) last_solid = p;
+                else lowc[u] = p <= last_solid - k;
+              }
+            }
+            char ch[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) ch[u] = (c0 + u < cnt) ? ((xs[u] >> 31) ? A.tr_chd[xs[u] & 0x7FFFFFFFu] : A.tr_chu[xs[u]]) : (char)0;
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+              if (c0 + u < cnt) cb[hi_d - (c0 + u) - 1] = (unsigned char)(lowc[u] ? (ch[u] | 0x20) : ch[u]);
+          }
+        }
+        lds_sync();
+        // the text, 64 consecutive bytes an instruction, and the record, a word a lane (g2s_d3_trace: finish)
+        const uint64_t abs_off = A.tr_arena_base + gd.rlog_off;
+        char* buf = A.tr_arena + abs_off;
+        for (int p = stop0 + lane; p < len; p += 64) buf[p] = (char)cb[p];
+        if (lane == 0) buf[len] = '\0';
+        const uint64_t fo = abs_off + (uint64_t)stop0;
+        const uint32_t rflags = ((flags & (G2S_DEV_Q7_A | G2S_DEV_Q7_B | G2S_DEV_Q7_D)) ? G2S_GAP_Q7 : 0u) | G2S_GAP_PHASE_D;
+        const uint32_t cnt_out = (uint32_t)((want_s && gd.all_paths) ? count_s : c_count);
+        uint32_t w = 0u;
+        switch (lane) {
+          case 0: w = cnt_out; break;
+          case 1: w = (uint32_t)left_fuz; break;
+          case 2: w = (uint32_t)reached_j; break;
+          case 3: w = rflags; break;
+          case 4: w = (uint32_t)fo; break;
+          case 5: w = (uint32_t)(fo >> 32); break;
+          case 6: w = (uint32_t)(len - stop0); break;
+          case 7: w = (uint32_t)draws; break;
+          case 8: case 16: w = want_s ? sub_vertices : 0u; break;
+          case 10: case 18: w = want_s ? sub_edges : 0u; break;
+          case 20: w = (uint32_t)c_count; break;
+          case 21: w = (uint32_t)n_len; break;
+          case 22: w = (uint32_t)len0; break;
+          case 23: w = (uint32_t)len1; break;
+          default: break;
+        }
+        if (lane < 28) A.tr_results[(size_t)gi * 28u + (uint32_t)lane] = w;
+        if (lane == 0) {
+          go->top_level = (uint32_t)(len - stop0);  // (the trace kernel's wave adds it to the list's fill bytes)
+          go->dflags |= G2S_DEVA_TRACED;
+        }
+      }
+    }
+  }
   publish();
 }
 
@@ -1999,7 +2229,8 @@ hipError_t launch_fill_seg(hipStream_t st, uint32_t ngaps, const uint32_t* succ,
                            unsigned long long out_cap, unsigned long long* out_counter, GapOut* outs, GapOut* outs_host,
                            uint32_t* done_list, int skip_confident, uint32_t* dbg, bool two_waves, unsigned long long* xcd_tickets,
                            uint32_t* xcd_list, uint32_t xcd_stride, uint32_t pub_batch, bool resident, uint32_t* ovf_list,
-                           uint32_t* d2_list, uint32_t d2_tag, const SegInline* inl) {
+                           uint32_t* d2_list, uint32_t d2_tag, const SegInline* inl, const SegEarly* early, const SegTrace* tr,
+                           const GapLite* lite, int lite_e, int lite_all_paths) {
   if (ngaps == 0) return hipSuccess;
   size_t bytes = two_waves ? fill_seg2_lds_bytes() : fill_seg_lds_bytes();
   // (G2S_SEG_LDS_PAD=BYTES, measurements only: a larger LDS request per gap = fewer gaps resident per compute unit)
@@ -2018,12 +2249,17 @@ hipError_t launch_fill_seg(hipStream_t st, uint32_t ngaps, const uint32_t* succ,
     }
   }
   if (!xcd_tickets || !xcd_list || pub_batch < 2u || pub_batch > 64u || (pub_batch & (pub_batch - 1u))) pub_batch = 1u;
-  const SegArgs A = {succ, urec, gaps, gap_ids, flank_nodes, sub_out, out_cap, out_counter, outs, outs_host, done_list,
+  const SegArgs A = {succ, urec, GapSrc{gaps, resident ? lite : nullptr, lite_e, lite_all_paths}, gap_ids, flank_nodes, sub_out, out_cap, out_counter, outs, outs_host, done_list,
                      skip_confident, dbg, fill_seg_dbg_words(), xcd_tickets, xcd_list, xcd_stride, pub_batch, resident ? 1u : 0u,
-                     (resident && d2_list) ? g2s::d2_ticks_offset : 0u, resident ? ovf_list : nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0u,
+                     (resident && d2_list) ? g2s::d2_ticks_offset : 0u, resident ? ovf_list : nullptr,
+                     (resident && early) ? early->segs : nullptr, (resident && early) ? early->items : nullptr,
+                     (resident && early) ? early->outs : nullptr, (resident && early) ? early->ctr : nullptr,
+                     (resident && early) ? early->cap_items : 0u, (resident && early) ? early->cap_segs : 0u,
                      resident ? d2_list : nullptr, resident ? d2_tag : 0u,
                      (resident && inl) ? inl->text : nullptr, inl ? inl->nodes_dev : nullptr, inl ? inl->nodes_host : nullptr,
-                     inl ? inl->text_stride : 0u, inl ? inl->lk : FlankLookup()};
+                     inl ? inl->text_stride : 0u, inl ? inl->lk : FlankLookup(),
+                     (resident && tr) ? tr->results : nullptr, tr ? tr->arena : nullptr, tr ? tr->arena_base : 0ull, tr ? tr->chu : nullptr,
+                     tr ? tr->chd : nullptr, tr ? tr->max_states : 0ull, tr ? tr->k : 0};
   if (two_waves) hipLaunchKernelGGL(g2s_fill_seg2, dim3(ngaps), dim3(128), bytes, st, A);
   else hipLaunchKernelGGL(g2s_fill_seg, dim3(ngaps), dim3(64), bytes, st, A);
   return hipGetLastError();
@@ -2038,7 +2274,7 @@ hipError_t launch_fill_segx(hipStream_t st, uint32_t ngaps, uint32_t workgroups,
   const size_t bytes = fill_segx_lds_bytes();
   hipError_t e = hipFuncSetAttribute((const void*)g2s_fill_segx, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   if (e != hipSuccess) return e;
-  const SegArgs A = {succ, urec, gaps, gap_ids, flank_nodes, sub_out, out_cap, out_counter, outs, outs_host, done_list,
+  const SegArgs A = {succ, urec, GapSrc{gaps, nullptr, 0, 0}, gap_ids, flank_nodes, sub_out, out_cap, out_counter, outs, outs_host, done_list,
                      skip_confident, dbg, fill_segx_dbg_words(), nullptr, nullptr, 0u, 1u, 0u, 0u, nullptr};
   hipLaunchKernelGGL(g2s_fill_segx, dim3(workgroups), dim3(64), bytes, st, A, scratch, ngaps, next_gap);
   return hipGetLastError();

@@ -132,7 +132,7 @@ __device__ __forceinline__ void segw_fill_one(uint32_t* lds, const SegArgs& A, c
   const int lane = (int)(tid & 63u);
   const uint32_t wave = tid >> 6;
   const uint32_t gi = uni(A.gap_ids[x]);
-  const GapDev gd = A.gaps[gi];
+  const GapDev gd = A.gaps.load(gi);
   GapOut* go = &A.outs[gi];
   const uint32_t* lseeds = A.flank_nodes + gd.flank_off;
   const uint32_t* rseeds = lseeds + (uint32_t)(gd.lmf + 1);
@@ -1358,12 +1358,12 @@ hipError_t launch_fill_segw(hipStream_t st, uint32_t ngaps, uint32_t workgroups,
                             unsigned long long out_cap, unsigned long long* out_counter, GapOut* outs, GapOut* outs_host,
                             uint32_t* done_list, int skip_confident, uint32_t* dbg, uint32_t* scratch,
                             unsigned long long* next_gap, bool resident, const unsigned long long* ngaps_dev, const SegEarly* early,
-                            uint32_t* d2_list, uint32_t d2_tag) {
+                            uint32_t* d2_list, uint32_t d2_tag, const GapLite* lite, int lite_e, int lite_all_paths) {
   if (ngaps == 0) return hipSuccess;
   const size_t bytes = fill_segw_lds_bytes();
   hipError_t e = hipFuncSetAttribute((const void*)g2s_fill_segw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   if (e != hipSuccess) return e;
-  SegArgs A = {succ, urec, gaps, gap_ids, flank_nodes, sub_out, out_cap, out_counter, outs, outs_host, done_list,
+  SegArgs A = {succ, urec, GapSrc{gaps, resident ? lite : nullptr, lite_e, lite_all_paths}, gap_ids, flank_nodes, sub_out, out_cap, out_counter, outs, outs_host, done_list,
                skip_confident, dbg, fill_segx_dbg_words(), nullptr, nullptr, 0u, 1u, resident ? 1u : 0u,
                (resident && d2_list) ? d2_ticks_offset : 0u, nullptr, early ? early->segs : nullptr, early ? early->items : nullptr, early ? early->outs : nullptr,
                early ? early->ctr : nullptr, early ? early->cap_items : 0u, early ? early->cap_segs : 0u, resident ? d2_list : nullptr, resident ? d2_tag : 0u};

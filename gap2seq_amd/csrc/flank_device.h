@@ -26,30 +26,67 @@ __device__ __forceinline__ u128 d_revcomp(u128 x, int k) {
   return y >> (128 - 2 * k);
 }
 
-// the k characters at t (any memory the lane can read bytes of: the kernels stage the gap's flank text in LDS)
+// The k characters from byte `off` of the text at `tw` (4-byte aligned words, in LDS; sizeof(KT) + 1 words from word
+// off / 4 on are read, whatever they hold) as a k-mer, GATB codec: A0 C1 T2 G3, any byte maps to a base ((c >> 1) & 3),
+// first base most significant.  Four characters a word: the four 2-bit codes of a word gathered into a byte by one
+// multiplication (the codes sit at bits 0, 8, 16, 24; times 2^30 + 2^20 + 2^10 + 1 they meet, in text order, in the top
+// byte — no two partial products overlap), the bytes strung together, the window of 2k bits cut out.  (A byte a step —
+// one LDS read, a wait and three operations per character — was 4 000 cycles of a gap's wave at k = 31.)
 template <class KT>
-__device__ __forceinline__ uint32_t flank_node_of(const FlankLookup& lk, const char* t) {
+__device__ __forceinline__ KT flank_encode(const uint32_t* tw, int off, int k) {
+  constexpr int NB = (int)sizeof(KT);
+  const uint32_t* w = tw + (off >> 2);
+  uint32_t code[NB + 1];
+#pragma unroll
+  for (int j = 0; j <= NB; j++) code[j] = ((((w[j] >> 1) & 0x03030303u) * 0x40100401u) >> 24) & 0xFFu;
+  KT a = 0;
+#pragma unroll
+  for (int j = 0; j < NB; j++) a = (a << 8) | (KT)code[j];
+  const int s0 = 2 * (off & 3);
+  const KT win = s0 ? (KT)((a << s0) | (KT)(code[NB] >> (8 - s0))) : a;
+  return win >> (8 * NB - 2 * k);
+}
+
+// the k characters at byte `off` of the text staged at tw (see flank_encode)
+template <class KT>
+__device__ __forceinline__ uint32_t flank_node_of(const FlankLookup& lk, const uint32_t* tw, int off) {
   const int k = lk.k;
   const KT* v = (const KT*)lk.kmers;
   const int shift = 2 * k - lk.bucket_bits;
-  KT f = 0;
-  for (int c = 0; c < k; c++) f = (f << 2) | (KT)((t[c] >> 1) & 3);  // GATB codec: A0 C1 T2 G3, any byte maps to a base
+  const KT f = flank_encode<KT>(tw, off, k);
   const KT r = d_revcomp(f, k);
   const bool fwd = f < r;
   const KT canon = fwd ? f : r;
-  // sorted rank through the prefix index (dbg.cpp: rank_of)
+  // sorted rank through the prefix index (dbg.cpp: rank_of).  A bucket holds less than one k-mer on average: its first
+  // four and their nodes are asked for at once — two dependent round trips per look-up (the bounds, the candidates)
+  // where a binary search and the final look took four; a fuller bucket is searched.
   const size_t b = (size_t)(canon >> shift);
-  uint32_t lo = lk.bucket[b], hi = lk.bucket[b + 1];
-  const uint32_t end = hi;
-  while (lo < hi) {
-    const uint32_t mid = (lo + hi) >> 1;
-    if (v[mid] < canon) lo = mid + 1; else hi = mid;
+  uint32_t lo = lk.bucket[b];
+  const uint32_t end = lk.bucket[b + 1];
+  if (end - lo > 4u) {
+    uint32_t hi = end;
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (v[mid] < canon) lo = mid + 1; else hi = mid;
+    }
+    if (lo >= end) return G2S_DEV_INVALID;
+    const KT found = v[lo];
+    const uint32_t r2n = lk.rank2node[lo];
+    return found == canon ? (r2n ^ (fwd ? 0u : 1u)) : G2S_DEV_INVALID;
   }
-  // (the k-mer at the rank and the rank's node asked for together: one round trip instead of two)
-  const uint32_t at = lo < end ? lo : (end ? end - 1u : 0u);
-  const KT found = v[at];
-  const uint32_t r2n = lk.rank2node[at];
-  return (lo < end && found == canon) ? (r2n ^ (fwd ? 0u : 1u)) : G2S_DEV_INVALID;
+  KT c4[4];
+  uint32_t n4[4];
+#pragma unroll
+  for (uint32_t q = 0; q < 4u; q++) {
+    const bool in = lo + q < end;
+    c4[q] = in ? v[lo + q] : (KT)0;
+    n4[q] = in ? lk.rank2node[lo + q] : 0u;
+  }
+  uint32_t node = G2S_DEV_INVALID;
+#pragma unroll
+  for (uint32_t q = 0; q < 4u; q++)
+    if (lo + q < end && c4[q] == canon) node = n4[q] ^ (fwd ? 0u : 1u);
+  return node;
 }
 
 // where item i of a gap's (lmf + 1) + 2 (rmf + 1) flank k-mers starts in the gap's flank text

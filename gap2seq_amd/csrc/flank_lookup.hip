@@ -34,7 +34,7 @@ __global__ __launch_bounds__(64 * FLANK_WAVES) void g2s_resolve_flanks(g2s::Flan
                                                                        uint32_t* __restrict__ nodes_host, uint32_t ngaps) {
   // the gap's flank text: [left: first k+lmf chars][right: first k+rmf chars][right: last k+rmf chars] — the last part
   // left out when it is the second (a flank of exactly k+rmf characters: what GapCutter writes)
-  __shared__ __attribute__((aligned(16))) uint32_t tws[FLANK_WAVES][G2S_FLANK_TEXT_MAX / 4];
+  __shared__ __attribute__((aligned(16))) uint32_t tws[FLANK_WAVES][G2S_FLANK_TEXT_MAX / 4 + 20];  // (+20: flank_encode reads sizeof(KT) + 1 words from an item's first)
   const int lane = (int)(threadIdx.x & 63u);
   const uint32_t wave = threadIdx.x >> 6;
   uint32_t* tw = tws[wave];
@@ -51,9 +51,8 @@ __global__ __launch_bounds__(64 * FLANK_WAVES) void g2s_resolve_flanks(g2s::Flan
     for (uint32_t w = (uint32_t)lane; w < words; w += 64u) tw[w] = ((const uint32_t*)(text + d.text_off))[w];  // (4-byte aligned, padded)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // (the wave's own words: no other wave reads them)
     __builtin_amdgcn_wave_barrier();
-    const char* t = (const char*)tw;
     for (int i = lane; i < nl + 2 * nr; i += 64) {
-      const uint32_t node = g2s::flank_node_of<KT>(lk, t + g2s::flank_item_offset(i, k, (int)d.lmf, rmf, tail));
+      const uint32_t node = g2s::flank_node_of<KT>(lk, tw, g2s::flank_item_offset(i, k, (int)d.lmf, rmf, tail));
       nodes_dev[d.flank_off + (uint32_t)i] = node;
       nodes_host[d.flank_off + (uint32_t)i] = node;
     }

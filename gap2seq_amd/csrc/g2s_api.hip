@@ -613,6 +613,7 @@ struct g2s_session {
   std::vector<SubPrep> early_prep;
   std::vector<std::vector<uint64_t>> early_scratch;
   std::vector<int32_t> early_of_gap;  // by gap: its early item, or -1
+  std::vector<std::pair<uint32_t, uint32_t>> early_inline_done;  // (lists that are not deep) the (gap, item) pairs the waiting thread analysed
   RandTables rtab;
   std::vector<uint32_t> res_ids, res_at;  // launch order of a resident list and its counting sort, kept between lists
   bool in_team_list = false;     // the session is filling a group of a team's list (team_resident)
@@ -995,7 +996,8 @@ extern "C" int g2s_batch_prepare(g2s_session* s, const g2s_gap* gaps, size_t n, 
   text_off.resize(n);
   didx.resize(n);
   const bool force_host_lookup = getenv("G2S_HOST_LOOKUP") != nullptr;
-  const size_t per_task = std::max<size_t>(256, (n + 15) / 16);  // (at most 16 tasks: every task wakes a thread)
+  static const size_t max_tasks = getenv("G2S_PREP_TASKS") ? (size_t)std::max(1, atoi(getenv("G2S_PREP_TASKS"))) : 16;
+  const size_t per_task = std::max<size_t>(256, (n + max_tasks - 1) / max_tasks);  // (at most 16 tasks: every task wakes a thread)
   const size_t ntasks = (n + per_task - 1) / per_task;
   struct Part {
     size_t n_nodes = 0, text_bytes = 0, n_desc = 0, arena_bytes = 0, rnd_cap = 0;
@@ -1064,12 +1066,12 @@ extern "C" int g2s_batch_prepare(g2s_session* s, const g2s_gap* gaps, size_t n, 
   const auto tp1 = std::chrono::steady_clock::now();
   if (hipSetDevice(s->device) != hipSuccess) { delete b; return fail(G2S_ERR_NO_DEVICE, "cannot select device"); }
   // resident mode is likely to take this list: its descriptors are filled by the pass below as well
-  GapDev* fast_gd = nullptr;
+  GapLite* fast_gd = nullptr;  // (resident mode's descriptors: 32 bytes a gap — fill_device.h — the kernels expand them)
   D3Gap* fast_dg = nullptr;
   if (resident_applicable(s, n) && b->seg_tier_all && !b->host_lookup) {
     if (s->h_gaps.ensure(n * sizeof(GapDev) + n * 4 + 16) == hipSuccess &&
         s->h_d3.ensure(n * sizeof(D3Gap) + 2048 + 64 * 128 + G2S_RAND_WINDOW * 4) == hipSuccess) {
-      fast_gd = (GapDev*)s->h_gaps.p;
+      fast_gd = (GapLite*)s->h_gaps.p;
       fast_dg = (D3Gap*)s->h_d3.p;
       s->desc_owner = b;
       b->fast_desc = true;
@@ -1086,7 +1088,6 @@ extern "C" int g2s_batch_prepare(g2s_session* s, const g2s_gap* gaps, size_t n, 
     if ((uint64_t)n * tstride < (1ull << 31)) text_bytes = (size_t)n * tstride; else tstride = 0;
   }
   b->text_stride = tstride;
-  const int all_paths = s->params.all_paths ? 1 : 0;
   if (!s->pin_free.empty()) { b->pin = s->pin_free.back(); s->pin_free.pop_back(); }
   else b->pin = new PinBuf();
   const size_t desc_bytes = (n_desc * sizeof(FlankDesc) + 15) & ~(size_t)15;
@@ -1111,23 +1112,19 @@ extern "C" int g2s_batch_prepare(g2s_session* s, const g2s_gap* gaps, size_t n, 
         }
         j.nodes = b->nodes + b->flank_off[i];
         if (fast_gd && (what & 2)) {
-          GapDev& d = fast_gd[i];
-          memset(&d, 0, sizeof d);
+          GapLite& d = fast_gd[i];
           D3Gap& q = fast_dg[i];
           q.arena_off = (uint64_t)b->arena_off[i];  // (within the batch's share of the arena: D3Params.arena_base is added on the device)
           q.skip_thr = std::max(-1, std::min(j.skip_if_prev_right_fuz_gt, 32767));
           q.lmf = (uint16_t)j.lmf;
           q.kind = j.bad_flank ? 1 : 0;
           q.pad = 0;
-          if (!j.bad_flank) {
-            d.g = j.g; d.e = d_err; d.lmf = j.lmf; d.rmf = j.rmf;
-            d.D = j.lmf + j.rmf + j.g + d_err;
-            d.right_half = j.rmf + (j.g + d_err + 1) / 2;
-            d.prune_from = j.g / 2 + d_err / 2 + j.lmf;
-            d.all_paths = all_paths;
-            d.flank_off = b->flank_off[i];
-            d.rs_mask = text_off[i];  // (the segment tier's kernels: where the gap's flank text starts — look-ups in the kernel)
-          }
+          d.g = j.g; d.lmf = (uint16_t)j.lmf; d.rmf = (uint16_t)j.rmf;
+          d.flank_off = b->flank_off[i];
+          d.text_off = j.bad_flank ? 0u : text_off[i];                // (where the gap's flank text starts: look-ups in the kernel)
+          d.arena_off = (uint64_t)b->arena_off[i];                    // (its fill buffer in the batch's share of the arena,
+          d.has_skip = j.skip_if_prev_right_fuz_gt >= 0 ? 1u : 0u;     // and whether a skip rule decides over it: tracebacks in the kernel)
+          d.pad = 0u;
         }
         if (!j.bad_flank && (what & 1)) j.text_off = text_off[i];
         if (j.bad_flank || !(what & 1)) continue;
@@ -2755,7 +2752,26 @@ static bool kernel_events_on(g2s_session* s) {
   if (m && !strncmp(m, "sample:", 7)) period = (uint32_t)std::max(1, atoi(m + 7));  // (one launch in N)
   return seq % period == 0u;
 }
-static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl) {
+// Where a resident list's kernels write results and fill text: the caller's buffers when the device can (page-locked:
+// g2s_host_alloc), else the session's staging buffers (copied to the caller's when the list has ended).  The fill launch
+// (tracebacks in the kernel) and phase D3's launch both ask; the same answer both times.
+static int resident_targets(g2s_session* s, g2s_result* results, char* arena, size_t n, size_t arena_bytes, void** res_dev, void** arena_dev,
+                            bool* res_direct, bool* arena_direct) {
+  *res_dev = nullptr; *arena_dev = nullptr;
+  *res_direct = device_pointer_of(results, res_dev);
+  *arena_direct = arena_bytes == 0 || device_pointer_of(arena, arena_dev);
+  if (!*res_direct) {
+    HIP_TRY_S(s->h_res.ensure(n * sizeof(g2s_result)));
+    HIP_TRY_S(hipHostGetDevicePointer(res_dev, s->h_res.p, 0));
+  }
+  if (!*arena_direct) {
+    HIP_TRY_S(s->h_text.ensure(arena_bytes + 16));
+    HIP_TRY_S(hipHostGetDevicePointer(arena_dev, s->h_text.p, 0));
+  }
+  return G2S_OK;
+}
+// (results / arena: where the list's results go — null: not known here, a team's group: no tracebacks in the fill kernel)
+static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl, g2s_result* results = nullptr, char* arena = nullptr) {
   g2s_session* s = b->s;
   const size_t n = b->jobs.size();
   if (!resident_applicable(s, n) || !b->seg_tier_all || b->host_lookup) return 1;
@@ -2811,7 +2827,7 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl) {
   const size_t n_reg = ids.size() - n_early;
   HIP_TRY_S(s->h_gaps.ensure(n * sizeof(GapDev) + n * 4 + 16));
   HIP_TRY_S(s->h_d3.ensure(n * sizeof(D3Gap) + 2048 + 64 * 128 + G2S_RAND_WINDOW * 4));
-  GapDev* gd = (GapDev*)s->h_gaps.p;
+  GapLite* gd = (GapLite*)s->h_gaps.p;  // (the short records: fill_device.h — the kernels expand them with the list's constants)
   uint32_t* ids_pinned = (uint32_t*)(gd + n);
   if (!ids.empty()) memcpy(ids_pinned, ids.data(), ids.size() * 4);
   D3Gap* dgaps = (D3Gap*)s->h_d3.p;
@@ -2822,22 +2838,19 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl) {
     auto fill_range = [&](size_t lo, size_t hi) {
       for (size_t i = lo; i < hi; i++) {
         const GapJob& j = b->jobs[i];
-        GapDev& d = gd[i];
-        memset(&d, 0, sizeof d);
+        GapLite& d = gd[i];
         D3Gap& q = dgaps[i];
         q.arena_off = (uint64_t)b->arena_off[i];
         q.skip_thr = std::max(-1, std::min(j.skip_if_prev_right_fuz_gt, 32767));
         q.lmf = (uint16_t)j.lmf;
         q.kind = j.bad_flank ? 1 : 0;
         q.pad = 0;
-        if (j.bad_flank) continue;
-        d.g = j.g; d.e = d_err; d.lmf = j.lmf; d.rmf = j.rmf;
-        d.D = j.lmf + j.rmf + j.g + d_err;
-        d.right_half = j.rmf + (j.g + d_err + 1) / 2;
-        d.prune_from = j.g / 2 + d_err / 2 + j.lmf;
-        d.all_paths = s->params.all_paths ? 1 : 0;
+        d.g = j.g; d.lmf = (uint16_t)j.lmf; d.rmf = (uint16_t)j.rmf;
         d.flank_off = b->flank_off[i];
-        d.rs_mask = j.text_off;
+        d.text_off = j.bad_flank ? 0u : j.text_off;
+        d.arena_off = (uint64_t)b->arena_off[i];
+        d.has_skip = j.skip_if_prev_right_fuz_gt >= 0 ? 1u : 0u;
+        d.pad = 0u;
       }
     };
     const size_t per_task = std::max<size_t>(512, (n + 15) / 16), ntasks = (n + per_task - 1) / per_task;
@@ -2937,8 +2950,9 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl) {
   hipStream_t st = s->stream;
   void* d_gaps_host = nullptr;
   HIP_TRY_S(hipHostGetDevicePointer(&d_gaps_host, s->h_gaps.p, 0));
-  const GapDev* gaps_dev = (const GapDev*)d_gaps_host;
+  const GapLite* gaps_dev = (const GapLite*)d_gaps_host;
   const uint32_t* ids_dev = (const uint32_t*)(gaps_dev + n);
+  const int lite_e = d_err, lite_ap = s->params.all_paths ? 1 : 0;
   // (long lists: descriptors and launch order go to device memory in front of the kernel — read over the link by
   // 10 000 starting waves they cost config 3's launch 0.04 ms: 0.365 against 0.324 ms; short lists read them over the link)
   if (ids.size() > 2048) {
@@ -2950,11 +2964,11 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl) {
     static const bool beside_ok = !getenv("G2S_DESC_ON_STREAM");
     const bool beside = beside_ok && !b->through_begin;
     hipStream_t cs = beside ? s->stream3 : st;
-    HIP_TRY_S(hipMemcpyAsync(s->d_gaps.p, gd, n * sizeof(GapDev), hipMemcpyHostToDevice, cs));
-    HIP_TRY_S(hipMemcpyAsync(s->d_ids.p, ids_pinned, ids.size() * 4, hipMemcpyHostToDevice, cs));
+    // (one copy: the short records and, right behind them, the launch order)
+    HIP_TRY_S(hipMemcpyAsync(s->d_gaps.p, gd, n * sizeof(GapLite) + ids.size() * 4, hipMemcpyHostToDevice, cs));
     if (beside) { HIP_TRY_S(hipEventRecord(s->ev_desc, cs)); HIP_TRY_S(hipStreamWaitEvent(st, s->ev_desc, 0)); }
-    gaps_dev = (const GapDev*)s->d_gaps.p;
-    ids_dev = (const uint32_t*)s->d_ids.p;
+    gaps_dev = (const GapLite*)s->d_gaps.p;
+    ids_dev = (const uint32_t*)(gaps_dev + n);
   }
   if (s->d_outs.clean < n * sizeof(GapOut)) HIP_TRY_S(hipMemsetAsync(s->d_outs.p, 0, n * sizeof(GapOut), st));
   if (s->d_counter.clean < 128) HIP_TRY_S(hipMemsetAsync(s->d_counter.p, 0, 128, st));
@@ -2981,6 +2995,26 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl) {
     early_dev.ctr = (unsigned long long*)s->d_early_ctr.p;
     HIP_TRY_S(hipMemsetAsync(s->d_early_ctr.p, 0, 16, st));
   }
+  // (a list that is not deep, its closures left to the host — the short lists: the few closures the regular tier does not
+  // analyse itself leave their gaps' waves the same way, and the thread that waits for the hand-over analyses them
+  // meanwhile: resident_d3_wait.  The two counters live behind the fill kernel's cursors, zeroed with them.)
+  const bool early_reg = b->dmax < 2500 && !s->in_team_list && !dev_d2 && !s->params.skip_confident && !ids.empty() &&
+                         !getenv("G2S_NO_EARLY_HANDOVER");
+  if (early_reg) {
+    const size_t cap_items = n, cap_segs = std::max<size_t>(n * 16, 65536);
+    const size_t b_items = (cap_items * 32 + 63) & ~(size_t)63, b_outs = (cap_items * sizeof(GapOut) + 63) & ~(size_t)63;
+    HIP_TRY_S(s->h_early.ensure(b_items + b_outs + cap_segs * sizeof(SegRec)));
+    char* hp = (char*)s->h_early.p;
+    memset(hp, 0, b_items);  // (the ready words)
+    void* dp = nullptr;
+    HIP_TRY_S(hipHostGetDevicePointer(&dp, hp, 0));
+    SegEarly& eh = s->early_host;
+    eh.items = (uint32_t*)hp; eh.outs = (GapOut*)(hp + b_items); eh.segs = (SegRec*)(hp + b_items + b_outs);
+    eh.cap_items = (uint32_t)cap_items; eh.cap_segs = (uint32_t)cap_segs;
+    early_dev = eh;
+    early_dev.items = (uint32_t*)dp; early_dev.outs = (GapOut*)((char*)dp + b_items); early_dev.segs = (SegRec*)((char*)dp + b_items + b_outs);
+    early_dev.ctr = (unsigned long long*)s->d_counter.p + 10;
+  }
   // (two waves per gap when the launch is short enough to end with its slowest gap — unless the sessions of a team
   // share this device: the chip is then as full as one long launch makes it)
   const bool two_waves = getenv("G2S_SEG_WAVES") ? atoi(getenv("G2S_SEG_WAVES")) == 2 : (n_reg <= 2048 && !s->team_shares_device);
@@ -2991,7 +3025,7 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl) {
   memset(&DA, 0, sizeof DA);
   if (dev_d2) {
     unsigned long long* ctr = (unsigned long long*)s->d_counter.p;
-    DA.gaps = gaps_dev; DA.flank_nodes = (const uint32_t*)s->d_flank.p; DA.outs = (GapOut*)s->d_outs.p; DA.sub = (SubRec*)s->d_sub.p;
+    DA.gaps = nullptr; DA.lite = gaps_dev; DA.lite_e = lite_e; DA.flank_nodes = (const uint32_t*)s->d_flank.p; DA.outs = (GapOut*)s->d_outs.p; DA.sub = (SubRec*)s->d_sub.p;
     DA.list = (uint32_t*)s->d_d2list.p; DA.count = ctr + 4; DA.next = ctr + 5;
     DA.d2out = (D2Out*)s->d_d2out.p; DA.runs = (uint32_t*)s->d_d2runs.p; DA.run_cursor = ctr + 8; DA.run_cap = d2_run_cap;
     DA.all_paths = s->params.all_paths ? 1 : 0; DA.list_cap = (uint32_t)n;
@@ -3031,15 +3065,29 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl) {
     void* d_nodes = nullptr;
     HIP_TRY_S(hipHostGetDevicePointer(&d_nodes, b->nodes, 0));
     inl.lk = s->lookup; inl.text = b->inline_text_dev; inl.nodes_dev = (uint32_t*)s->d_flank.p; inl.nodes_host = (uint32_t*)d_nodes;
-    inl.text_stride = (ids_identity && n_reg == n) ? b->text_stride : 0u;
+    inl.text_stride = b->text_stride;  // (by gap, whatever the launch order)
   }
   // (in list order: no launch order to read — on a short list one round trip of the link less at the head of every gap)
-  const uint32_t* ids_fill = (use_inl && inl.text_stride) ? nullptr : ids_dev;
-  HIP_TRY_S(launch_fill_seg(st, (uint32_t)n_reg, dg.succ, dg.urec, gaps_dev, ids_fill, (const uint32_t*)s->d_flank.p,
+  const uint32_t* ids_fill = (ids_identity && n_reg == n) ? nullptr : ids_dev;
+  // (tracebacks that have no choice to make, by the gaps' own waves: fill_seg.hip.  G2S_TRACE_IN_FILL=0: all by phase D3.)
+  SegTrace tr;
+  const bool use_tr = results != nullptr && !s->in_team_list && !getenv("G2S_D3_STAGE") &&
+                      !(getenv("G2S_TRACE_IN_FILL") && atoi(getenv("G2S_TRACE_IN_FILL")) == 0);
+  if (use_tr) {
+    void *res_dev = nullptr, *arena_dev = nullptr;
+    bool rd = false, ad = false;
+    { const int rc = resident_targets(s, results, arena, n, b->arena_base + b->arena_bytes, &res_dev, &arena_dev, &rd, &ad); if (rc != G2S_OK) return rc; }
+    tr.results = (uint32_t*)res_dev; tr.arena = (char*)arena_dev; tr.arena_base = (unsigned long long)b->arena_base;
+    tr.chu = (const char*)s->d_lastch.p; tr.chd = (const char*)s->d_lastch.p + g.n;
+    tr.max_states = (uint64_t)std::max<int64_t>(s->params.max_mem, 1 << 16) / 64;
+    tr.k = g.k;
+  }
+  HIP_TRY_S(launch_fill_seg(st, (uint32_t)n_reg, dg.succ, dg.urec, nullptr, ids_fill, (const uint32_t*)s->d_flank.p,
                           (SubRec*)s->d_sub.p, (unsigned long long)out_states, (unsigned long long*)s->d_counter.p,
                           (GapOut*)s->d_outs.p, nullptr, nullptr, s->params.skip_confident ? 1 : 0, nullptr, two_waves,
                           nullptr, nullptr, 0u, 1u, true, rerun ? (uint32_t*)s->d_ovf.p : nullptr,
-                          dev_d2 ? (uint32_t*)s->d_d2list.p : nullptr, d2_tag, use_inl ? &inl : nullptr));
+                          dev_d2 ? (uint32_t*)s->d_d2list.p : nullptr, d2_tag, use_inl ? &inl : nullptr,
+                          early_reg ? &early_dev : nullptr, (use_tr && tr.chu) ? &tr : nullptr, gaps_dev, lite_e, lite_ap));
   if (use_inl) b->inline_pending = false;  // (behind this kernel d_flank and the pinned copy hold the ids)
   s->lap_fill_queued = std::chrono::steady_clock::now();
   if (rl->timed) HIP_TRY_S(hipEventRecord(s->ev[2], st));
@@ -3051,23 +3099,24 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl) {
     const uint32_t wgs1 = (uint32_t)std::min<size_t>(n_early, (size_t)std::max(1, s->num_cus));
     HIP_TRY_S(s->d_segx1.ensure(fill_segw_scratch_bytes(wgs1)));
     HIP_TRY_S(hipStreamWaitEvent(s->stream3, s->ev_pre, 0));
-    HIP_TRY_S(launch_fill_segw(s->stream3, (uint32_t)n_early, wgs1, dg.succ, dg.urec, gaps_dev, ids_dev + n_reg,
+    HIP_TRY_S(launch_fill_segw(s->stream3, (uint32_t)n_early, wgs1, dg.succ, dg.urec, nullptr, ids_dev + n_reg,
                                (const uint32_t*)s->d_flank.p, (SubRec*)s->d_sub.p, (unsigned long long)out_states,
                                (unsigned long long*)s->d_counter.p, (GapOut*)s->d_outs.p, nullptr, nullptr,
                                s->params.skip_confident ? 1 : 0, nullptr, (uint32_t*)s->d_segx1.p,
-                               (unsigned long long*)s->d_counter.p + 3, true, nullptr, early_dev.items ? &early_dev : nullptr,
-                               dev_d2 ? (uint32_t*)s->d_d2list.p : nullptr, d2_tag));
+                               (unsigned long long*)s->d_counter.p + 3, true, nullptr, (early_dev.items && !early_reg) ? &early_dev : nullptr,
+                               dev_d2 ? (uint32_t*)s->d_d2list.p : nullptr, d2_tag, gaps_dev, lite_e, lite_ap));
     HIP_TRY_S(hipEventRecord(s->ev_early, s->stream3));
   }
   // (the large variant for what the launch above listed: its workgroups read the list's length from device memory and
   // leave at once when it is empty — the usual case)
   if (rerun)
-    HIP_TRY_S(launch_fill_segw(st, (uint32_t)std::max<size_t>(n_reg, 1), segw_wgs, dg.succ, dg.urec, gaps_dev, (const uint32_t*)s->d_ovf.p,
+    HIP_TRY_S(launch_fill_segw(st, (uint32_t)std::max<size_t>(n_reg, 1), segw_wgs, dg.succ, dg.urec, nullptr, (const uint32_t*)s->d_ovf.p,
                              (const uint32_t*)s->d_flank.p, (SubRec*)s->d_sub.p, (unsigned long long)out_states,
                              (unsigned long long*)s->d_counter.p, (GapOut*)s->d_outs.p, nullptr, nullptr,
                              s->params.skip_confident ? 1 : 0, nullptr, (uint32_t*)s->d_segx.p,
                              (unsigned long long*)s->d_counter.p + 2, true, (const unsigned long long*)s->d_counter.p + 1,
-                             early_dev.items ? &early_dev : nullptr, dev_d2 ? (uint32_t*)s->d_d2list.p : nullptr, d2_tag));
+                             (early_dev.items && !early_reg) ? &early_dev : nullptr, dev_d2 ? (uint32_t*)s->d_d2list.p : nullptr, d2_tag,
+                             gaps_dev, lite_e, lite_ap));
   if (n_early && rerun) HIP_TRY_S(hipStreamWaitEvent(st, s->ev_early, 0));  // (phase D3 follows on this stream: behind both)
   if (dev_d2) {  // (its workgroups read the list's length from device memory and leave at once when it is empty)
     // (on the third stream, behind the fill kernels: phase D3's first kernels do not wait for it — launch_d3)
@@ -3220,22 +3269,14 @@ static int resident_d3_launch(g2s_session* s, const ResidentList& L, bool timed,
   void *res_dev = nullptr, *arena_dev = nullptr;
   // (G2S_D3_STAGE=device, measurements only: the kernels write device memory, two copies bring it to the caller)
   const bool stage_dev = getenv("G2S_D3_STAGE") && !strcmp(getenv("G2S_D3_STAGE"), "device");
-  bool res_direct = !stage_dev && device_pointer_of(results, &res_dev);
-  bool arena_direct = !stage_dev && (L.arena_bytes == 0 || device_pointer_of(arena, &arena_dev));
+  bool res_direct = false, arena_direct = false;
+  if (!stage_dev) { const int rc = resident_targets(s, results, arena, n, L.arena_bytes, &res_dev, &arena_dev, &res_direct, &arena_direct); if (rc != G2S_OK) return rc; }
   if (stage_dev) {
     HIP_TRY_S(s->d_resout.ensure(n * sizeof(g2s_result)));
     HIP_TRY_S(s->d_textout.ensure(L.arena_bytes + 16));
     res_dev = s->d_resout.p;
     arena_dev = s->d_textout.p;
     res_direct = arena_direct = true;
-  }
-  if (!res_direct && !stage_dev) {
-    HIP_TRY_S(s->h_res.ensure(n * sizeof(g2s_result)));
-    HIP_TRY_S(hipHostGetDevicePointer(&res_dev, s->h_res.p, 0));
-  }
-  if (!arena_direct && !stage_dev) {
-    HIP_TRY_S(s->h_text.ensure(L.arena_bytes + 16));
-    HIP_TRY_S(hipHostGetDevicePointer(&arena_dev, s->h_text.p, 0));
   }
   hipStream_t st = s->stream;
   void* d_dgaps = nullptr;
@@ -3411,7 +3452,28 @@ static int resident_d3_wait(g2s_session* s, g2s_timing* tm_out, double* ms_d3_ou
   bool early_posted = false;
   // (not when the hand-over is there already — a list in flight that is ended late: every closure has arrived, and
   // the whole pool takes them largest first below)
-  if (eh.cap_items && !stage_dev && L.groups.size() == 1 && s->pool->size() > 0 &&
+  // (a list that is not deep has a handful of such closures, a few hundred segments each: this thread takes them itself
+  // while it waits — waking the pool costs more than they do)
+  const bool early_inline = eh.cap_items && !stage_dev && L.groups.size() == 1 && L.dmax < 2500;
+  std::vector<std::pair<uint32_t, uint32_t>>& inline_done = s->early_inline_done;  // (gap, item) analysed here
+  inline_done.clear();
+  uint32_t inline_next = 0;
+  auto early_take_ready = [&]() {
+    while (inline_next < eh.cap_items && __atomic_load_n(&eh.items[8 * (size_t)inline_next + 4], __ATOMIC_ACQUIRE) != 0u) {
+      const uint32_t idx = inline_next++;
+      const uint32_t gap = eh.items[8 * (size_t)idx], ns = eh.items[8 * (size_t)idx + 1], so = eh.items[8 * (size_t)idx + 2];
+      if (ns == 0u || gap >= n) continue;  // (no room for its segments: the hand-over brings them)
+      if (s->early_prep.size() <= idx) { s->early_prep.resize((size_t)idx + 8); s->early_scratch.resize((size_t)idx + 8); }
+      SubPrep& pp = s->early_prep[idx];
+      pp.reset();
+      std::vector<uint64_t>& sc = s->early_scratch[idx];
+      if (sc.size() < 3 * (size_t)ns + 1) sc.resize(3 * (size_t)ns + 1);
+      SubView v;
+      v.out = &eh.outs[idx]; v.segs = eh.segs + so; v.n_segs = ns;
+      if (seg_analyze(fp, L.groups[0]->jobs[gap], v, &pp, sc.data())) inline_done.emplace_back(gap, idx);
+    }
+  };
+  if (!early_inline && eh.cap_items && !stage_dev && L.groups.size() == 1 && s->pool->size() > 0 &&
       __atomic_load_n(side_h.count, __ATOMIC_ACQUIRE) == ~0ull) {
     s->early_of_gap.assign(n, -1);
     if (s->early_prep.size() < eh.cap_items) { s->early_prep.resize(eh.cap_items); s->early_scratch.resize(eh.cap_items); }
@@ -3447,6 +3509,7 @@ static int resident_d3_wait(g2s_session* s, g2s_timing* tm_out, double* ms_d3_ou
   for (unsigned spins = 0;; spins++) {
     handed = __atomic_load_n(side_h.count, __ATOMIC_ACQUIRE);
     if (handed != ~0ull) break;
+    if (early_inline) early_take_ready();
     if ((spins & 1023u) == 1023u && hipStreamQuery(st) != hipErrorNotReady) {
       handed = __atomic_load_n(side_h.count, __ATOMIC_ACQUIRE);
       if (handed == ~0ull) handed = 1ull << 63;
@@ -3454,6 +3517,7 @@ static int resident_d3_wait(g2s_session* s, g2s_timing* tm_out, double* ms_d3_ou
     }
     cpu_relax();
   }
+  if (early_inline && handed != ~0ull && !(handed >> 63) && (handed & 0x7FFFFFFFFFFFFFFFull)) early_take_ready();  // (the fill kernels have ended: every item is there)
   if (early_posted) { early_done.store(1, std::memory_order_release); s->pool->finish(); }
   const auto t_handed = std::chrono::steady_clock::now();
   std::atomic<int> host_bad(0);
@@ -3477,7 +3541,8 @@ static int resident_d3_wait(g2s_session* s, g2s_timing* tm_out, double* ms_d3_ou
                    ~Lap() { if (on && h.n_segs >= 2000) fprintf(stderr, "[g2s] host-finished item %zu (gap %u): %u segments, %u draws: picked up %.3f ms after the hand-over, %.3f ms\n", x, h.gap, h.n_segs, h.draws,
                                                               std::chrono::duration<double, std::milli>(t0 - th).count(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); } }
           lap{t_one, t_handed, h, x, dbg_analysis_stats};
-      const int32_t ei = early_posted ? s->early_of_gap[h.gap] : -1;  // (analysed when it arrived: the traceback is left)
+      int32_t ei = early_posted ? s->early_of_gap[h.gap] : -1;  // (analysed when it arrived: the traceback is left)
+      if (early_inline) for (const auto& pr : inline_done) if (pr.first == h.gap) { ei = (int32_t)pr.second; break; }
       const bool ok = ei >= 0 && eh.items[8 * (size_t)ei + 1] == h.n_segs
           ? finish_gap_on_host(g, fp, gb->jobs[loc], eh.outs[ei], eh.segs + eh.items[8 * (size_t)ei + 2], h.n_segs, side_h.rnd + h.rnd_off,
                                h.draws, (uint64_t)(L.group_arena[q] + gb->arena_off[loc]), text, &rs_host[h.gap], &s->early_prep[(size_t)ei], true)
@@ -3588,6 +3653,7 @@ static int resident_d3_wait(g2s_session* s, g2s_timing* tm_out, double* ms_d3_ou
   tm.resident_launches++;
   tm.draw_dependent_gaps += hsum->n_var;
   tm.host_finished_gaps += (uint32_t)hsum->host_items;
+  tm.traced_in_fill_gaps += hsum->traced_gaps;
   tm.d3_table_entries += hsum->table_entries;
   const auto t_end = std::chrono::steady_clock::now();
   s->lap_d3_queued = t_launched; s->lap_handed = t_handed; s->lap_finished = t_finished; s->lap_synced = t_synced; s->lap_end = t_end;
@@ -3633,7 +3699,7 @@ static int run_resident_queue(g2s_batch* b, g2s_result* results, char* arena, bo
     rl.units = b->pre_units; rl.two_waves = b->pre_two; rl.timed = b->pre_timed; rl.segw = b->pre_segw; rl.launched = b->n_valid;
     b->pre_launched = false;
   } else {
-    const int rc = resident_launch_fill(b, &rl);
+    const int rc = resident_launch_fill(b, &rl, results, arena);
     if (rc != G2S_OK) {
       if (rand_launched) (void)hipStreamSynchronize(s->stream2);  // (its copy reads the pinned window)
       return rc;
@@ -4443,7 +4509,7 @@ extern "C" int g2s_fill_begin(g2s_session* s, const g2s_gap* gaps, size_t n, g2s
     f.b->others_in_flight = s->n_inflight > 0;
     f.b->through_begin = true;
     ResidentLaunch rl;
-    rc = resident_launch_fill(f.b, &rl);  // (1: not a list for resident mode — g2s_fill_end runs it on the host path)
+    rc = resident_launch_fill(f.b, &rl, results, fill_arena);  // (1: not a list for resident mode — g2s_fill_end runs it on the host path)
     if (rc < 0) { g2s_batch_free(f.b); return rc; }
     if (rc == G2S_OK) {
       f.b->pre_launched = true; f.b->pre_units = rl.units; f.b->pre_two = rl.two_waves; f.b->pre_timed = rl.timed; f.b->pre_segw = rl.segw;

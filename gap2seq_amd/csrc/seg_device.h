@@ -158,7 +158,7 @@ __device__ __forceinline__ uint32_t lds_merge_intervals(uint64_t* a, uint32_t n,
 struct SegArgs {
   const uint32_t* succ;
   const uint32_t* urec;
-  const GapDev* gaps;
+  GapSrc gaps;
   const uint32_t* gap_ids;
   const uint32_t* flank_nodes;
   SubRec* sub_out;
@@ -209,10 +209,22 @@ struct SegArgs {
   const char* inl_text;
   uint32_t* inl_nodes_dev;
   uint32_t* inl_nodes_host;
-  // (not 0: the gap at launch position x has its text at inl_text + x * inl_stride — a list launched in list order,
-  // gap_ids null; a multiple of 4, at most 512)
+  // (not 0: gap i has its text at inl_text + i * inl_stride — a list without a bad flank; a multiple of 4, at most 512)
   uint32_t inl_stride;
   g2s::FlankLookup lk;
+  // resident mode, g2s_fill_seg / g2s_fill_seg2: a gap whose traceback has no choice to make (one path length, no entry
+  // of the traceback closure with several parents) is traced by its own wave — fill text and g2s_result record written
+  // where phase D3's trace kernel would write them, GapOut.dflags |= G2S_DEVA_TRACED, GapOut.top_level = the fill's
+  // length (fill_seg.hip).  tr_results: g2s_result[n] as 28 words each, device-writable; null: every gap is the trace
+  // kernel's.  GapDev.rlog_off = the gap's offset in the arena behind tr_arena_base; GapDev.rlog_cap != 0: the gap
+  // carries a skip rule (its result depends on the gap in front: not traced here).
+  uint32_t* tr_results;
+  char* tr_arena;
+  unsigned long long tr_arena_base;
+  const char* tr_chu;   // last base of every k-mer by index, walked upwards / downwards (the trace kernel's tables)
+  const char* tr_chd;
+  unsigned long long tr_max_states;  // -max-mem / 64: a gap beyond it gets the memory verdict (phase D3's)
+  int tr_k;
 };
 
 // LDS of the large variant (words): see the layout notes at each phase

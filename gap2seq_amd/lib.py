@@ -68,7 +68,7 @@ class g2s_timing(C.Structure):
                 ("ms_d3", C.c_double), ("resident_launches", C.c_uint32), ("resident_fallbacks", C.c_uint32),
                 ("draw_dependent_gaps", C.c_uint64), ("d3_table_entries", C.c_uint64),
                 ("host_finished_gaps", C.c_uint32), ("team_groups", C.c_uint32), ("team_sessions", C.c_uint32),
-                ("team_groups_by_session", C.c_uint32 * 16), ("seg_timed_launches", C.c_uint32), ("team_d3_sharded", C.c_uint32), ("reserved0", C.c_uint32),
+                ("team_groups_by_session", C.c_uint32 * 16), ("seg_timed_launches", C.c_uint32), ("team_d3_sharded", C.c_uint32), ("traced_in_fill_gaps", C.c_uint32),
                 ("team_ms_fill", C.c_double * 16), ("team_ms_d3", C.c_double * 16), ("team_ms_wall", C.c_double * 16),
                 ("host_us", C.c_double * 8)]
 

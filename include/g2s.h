@@ -227,7 +227,8 @@ typedef struct g2s_timing {
   uint32_t team_groups_by_session[16];
   uint32_t seg_timed_launches;  /* segment-tier launches whose duration is in ms_fill_seg (and, resident mode, in ms_d3) */
   uint32_t team_d3_sharded;     /* g2s_team_fill: every session traced its own group and wrote its own results (phase D3 sharded) */
-  uint32_t reserved0;
+  uint32_t traced_in_fill_gaps; /* (ABI 6) gaps of resident lists whose fill kernel's wave wrote fill text and record itself: a traceback
+                                   with one path length and no choice between parents writes the same whatever rand() returns */
   /* ...and, per session (the first 16), what its group took: fill kernel(s) and phase D3 kernels by HIP events (timed
    * launches only), and the wall time of the session's thread from the call to its last result */
   double team_ms_fill[16], team_ms_d3[16], team_ms_wall[16];
