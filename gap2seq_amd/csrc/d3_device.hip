@@ -42,6 +42,8 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <mutex>
+#include <set>
 
 #include "../../include/g2s.h"
 #include "d3_device.h"
@@ -417,18 +419,13 @@ __device__ __forceinline__ void d3_scan_body(const D3Params& P, const D3Work& W,
         if (GI_CLASS(g8[q]) != 2u) continue;
         W.var_toff[v] = (uint32_t)to;
         W.var_tile[v] = tl;
-        {  // everything g2s_d3_tables wants to know about this gap, in one record; the gap of each of its tiles
+        {  // the half of the gap's record for g2s_d3_tables that this pass knows (the other half: below, a thread a gap)
           const uint32_t i = i0 + (uint32_t)q;
-          const GapOut& go = outs[i];
-          g2s::D3Var vd;
-          vd.gap = i; vd.R = (uint32_t)r; vd.toff = (uint32_t)to; vd.tile0 = tl;
-          vd.base = base_i; vd.dmin = m8[q]; vd.dspread = s8[q]; vd.ns = go.n_xl;
-          vd.sub_at = (uint64_t)(i / P.group_size) * P.sub_region + go.sub_off;
-          vd.start_seg = go.start_seg; vd.start_t = go.start_t;
-          vd.len0 = go.len[0]; vd.len1 = go.len[1]; vd.n_len = go.n_len; vd.pad = 0;
-          W.vdesc[v] = vd;
-          const uint32_t nt = (uint32_t)((r + D3_TILE) / D3_TILE);
-          for (uint32_t x = 0; x < nt; x++) W.tile_var[tl + x] = v;
+          uint4 h0, h1;
+          h0.x = i; h0.y = (uint32_t)r; h0.z = (uint32_t)to; h0.w = tl;
+          h1.x = base_i; h1.y = m8[q]; h1.z = s8[q]; h1.w = 0u;
+          ((uint4*)&W.vdesc[v])[0] = h0;
+          ((uint4*)&W.vdesc[v])[1] = h1;
         }
         tl += (uint32_t)((r + D3_TILE) / D3_TILE);
         to += r + 1u;
@@ -438,6 +435,26 @@ __device__ __forceinline__ void d3_scan_body(const D3Params& P, const D3Work& W,
       }
     }
     if (t == 1023u) { W.var_toff[V] = (uint32_t)T; W.var_tile[V] = tiles; W.blk_toff[(V + G2S_D3_BLOCK_VARS - 1u) / G2S_D3_BLOCK_VARS] = (uint32_t)TB; }
+    // ---- the other half of every draw-dependent gap's record — what its GapOut record holds — and the gap of each of
+    // its tiles: a thread a gap, all their loads in flight at once.  (Inside the pass above, the thread that owns a
+    // range took its gaps one by one, a round trip to memory each: 17 of the 44 us this kernel took on a 10 000-gap list.)
+    __threadfence_block();
+    __syncthreads();
+    for (uint32_t v = t; v < V; v += 1024u) {
+      const uint4 h0 = ((const uint4*)&W.vdesc[v])[0];
+      const uint32_t i = h0.x, r = h0.y, tl0 = h0.w;
+      const GapOut& go = outs[i];
+      uint4 h2, h3;
+      const uint64_t sa = (uint64_t)(i / P.group_size) * P.sub_region + go.sub_off;
+      // (D3Var: gap R toff tile0 | base dmin dspread ns | sub_at start_seg start_t | len0 len1 n_len pad)
+      ((uint32_t*)&W.vdesc[v])[7] = go.n_xl;
+      h2.x = (uint32_t)sa; h2.y = (uint32_t)(sa >> 32); h2.z = go.start_seg; h2.w = go.start_t;
+      h3.x = (uint32_t)go.len[0]; h3.y = (uint32_t)go.len[1]; h3.z = (uint32_t)go.n_len; h3.w = 0u;
+      ((uint4*)&W.vdesc[v])[2] = h2;
+      ((uint4*)&W.vdesc[v])[3] = h3;
+      const uint32_t nt = (r + D3_TILE) / D3_TILE;
+      for (uint32_t x = 0; x < nt; x++) W.tile_var[tl0 + x] = v;
+    }
   }
   if (t == 0) {
     stamp(W, 23);
@@ -451,10 +468,24 @@ __device__ __forceinline__ void d3_scan_body(const D3Params& P, const D3Work& W,
     S->draws_spread = tot_s;
   }
 }
+// (the per-gap words of a list of up to D3_SCAN_LDS_GAPS gaps come into LDS first, 1 024 consecutive words an
+// instruction: the body's three passes give every thread a contiguous range of the list, and read from device memory
+// that way — every lane its own cache lines — each pass was a chain of round trips: 13 of this kernel's 44 us on a
+// 10 000-gap list.  Dynamic LDS: 12 bytes a gap, or none.)
+#define D3_SCAN_LDS_GAPS 12288u
 __global__ __launch_bounds__(1024) void g2s_d3_scan(const D3Params P, const D3Work W, const GapOut* __restrict__ outs) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t dyn[];
   __shared__ uint64_t sh[96];
   __shared__ uint32_t sh_f[1024];
   // (the 32-bit block scans: a list in this mode has at most 20 480 gaps of at most 12 000 draws each)
+  if (P.n <= D3_SCAN_LDS_GAPS) {
+    uint32_t *l_gi = dyn, *l_dm = dyn + P.n, *l_ds = dyn + 2u * P.n;
+    for (uint32_t i = threadIdx.x; i < P.n; i += 1024u) { l_gi[i] = W.ginfo[i]; l_dm[i] = W.dmin[i]; l_ds[i] = W.dspread[i]; }
+    const uint32_t unhandled = W.sum->unhandled;
+    __syncthreads();
+    d3_scan_body(P, W, outs, l_gi, l_dm, l_ds, W.skip, true, unhandled, sh, sh_f, true);
+    return;
+  }
   d3_scan_body(P, W, outs, W.ginfo, W.dmin, W.dspread, W.skip, false, W.sum->unhandled, sh, sh_f, P.n <= 262144u);
 }
 
@@ -1513,6 +1544,21 @@ hipError_t launch_rand_fill(hipStream_t st, uint32_t* rnd_all, const RandTables&
   return hipGetLastError();
 }
 
+// g2s_d3_scan with the per-gap words in (dynamic) LDS when the list fits
+static void launch_scan(hipStream_t st, const D3Params& P, const D3Work& W, const GapOut* outs) {
+  static std::mutex mu;
+  static std::set<int> done;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    if (done.insert(dev).second)
+      (void)hipFuncSetAttribute((const void*)g2s_d3_scan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(12u * D3_SCAN_LDS_GAPS));
+  }
+  const size_t lds = P.n <= D3_SCAN_LDS_GAPS ? 12u * (size_t)P.n : 0u;
+  hipLaunchKernelGGL(g2s_d3_scan, dim3(1), dim3(1024), lds, st, P, W, outs);
+}
+
 hipError_t launch_rand_window(hipStream_t st, uint32_t* rnd_all, const uint32_t* link) {
   hipLaunchKernelGGL(g2s_rand_window, dim3(1), dim3(64), 0, st, rnd_all, link);
   return hipGetLastError();
@@ -1524,13 +1570,13 @@ hipError_t launch_d3_sharded_classes(hipStream_t st, const D3Params& P, const D3
   hipError_t e = summary_is_clean ? hipSuccess : hipMemsetAsync(W.sum, 0, 1024 + 64 * 128, st);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(g2s_d3_classify, dim3((P.n + 255u) / 256u), dim3(256), 0, st, P, W, outs, dgaps);
-  hipLaunchKernelGGL(g2s_d3_scan, dim3(1), dim3(1024), 0, st, P, W, outs);  // (P.base0 = P.R0 = 0: the group's totals)
+  launch_scan(st, P, W, outs);  // (P.base0 = P.R0 = 0: the group's totals)
   return hipGetLastError();
 }
 hipError_t launch_d3_sharded_tables(hipStream_t st, const D3Params& P, const D3Work& W, const GapOut* outs, const SubRec* sub,
                                     uint32_t* rnd_all, uint64_t rnd_capacity, uint32_t* group_fn) {
   if (P.n == 0) return hipSuccess;
-  hipLaunchKernelGGL(g2s_d3_scan, dim3(1), dim3(1024), 0, st, P, W, outs);  // (the layout again, behind the groups in front)
+  launch_scan(st, P, W, outs);  // (the layout again, behind the groups in front)
   const uint32_t tgrid = std::min(8192u, std::max(128u, P.n / 2u));
   const size_t win = ((size_t)P.map_cap + 256) * 4;
   hipError_t e = hipFuncSetAttribute((const void*)g2s_d3_tables, hipFuncAttributeMaxDynamicSharedMemorySize, (int)win);
@@ -1572,7 +1618,7 @@ hipError_t launch_d3(hipStream_t st, const D3Params& P, const D3Work& W, const G
   if (short_list) hipLaunchKernelGGL(g2s_d3_front, dim3(1), dim3(1024), 0, st, P, W, outs, dgaps);
   else {
     hipLaunchKernelGGL(g2s_d3_classify, dim3((P.n + 255u) / 256u), dim3(256), 0, st, P, W, outs, dgaps);
-    hipLaunchKernelGGL(g2s_d3_scan, dim3(1), dim3(1024), 0, st, P, W, outs);
+    launch_scan(st, P, W, outs);
   }
   // (a tile of 256 deviations per workgroup, grid-stride: a short list has a few dozen tiles)
   const uint32_t tgrid = std::min(8192u, std::max(128u, P.n / 2u));
