@@ -3454,7 +3454,8 @@ static int resident_d3_wait(g2s_session* s, g2s_timing* tm_out, double* ms_d3_ou
   // the whole pool takes them largest first below)
   // (a list that is not deep has a handful of such closures, a few hundred segments each: this thread takes them itself
   // while it waits — waking the pool costs more than they do)
-  const bool early_inline = eh.cap_items && !stage_dev && L.groups.size() == 1 && L.dmax < 2500;
+  // (a long list whose closures are the host's — G2S_DEVICE_D2=0 — has dozens: the pool's, as on deep lists)
+  const bool early_inline = eh.cap_items && !stage_dev && L.groups.size() == 1 && L.dmax < 2500 && n < 3072;
   std::vector<std::pair<uint32_t, uint32_t>>& inline_done = s->early_inline_done;  // (gap, item) analysed here
   inline_done.clear();
   uint32_t inline_next = 0;
