@@ -25,6 +25,7 @@
 // Several waves: the passes over the segments, the sorts, the runs, the edges, the adjacency, the chains, the peeling
 // and the searches are shared by all threads (positions by atomic counters where the order does not matter, two-level
 // prefix sums where it does); merging sorted intervals and the scans over per-chunk totals stay on the first wave.
+#include "sync_debug.h"
 #include <hip/hip_runtime.h>
 
 #include "d2_device.h"

@@ -38,6 +38,7 @@
 // Anything out of the ordinary (a gap the segment tier could not finish or analyse, tables beyond the
 // budget, a walk that does not end in a left-flank k-mer) is only COUNTED here: the host then discards the
 // attempt and runs the list through the host path (g2s_api.hip), which remains the authority.
+#include "sync_debug.h"
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -987,7 +988,11 @@ __global__ __launch_bounds__(64 * NW) void g2s_d3_trace(const D3Params P, const 
   constexpr int NT = 64 * NW;
   const int tid = (int)threadIdx.x, lane = tid & 63;
   const bool w0 = tid < 64;  // (the first wave: what one wave does for the gap — counters, the hand to the host, the clean-up)
+#ifdef G2S_SYNC_DEBUG
+  auto wg_sync = [&]() { if constexpr (NW > 1) __syncthreads(); else { g2s_sync_jitter(0xD3u); g2s_wait_all(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } };
+#else
   auto wg_sync = [&]() { if constexpr (NW > 1) __syncthreads(); else { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } };
+#endif
   SegW* segs = (SegW*)lds;  // the gap's closure segments
   static_assert(sizeof(g2s_result) == 112, "g2s_result layout");
   unsigned long long* laps = (unsigned long long*)((char*)W.sum + 512);

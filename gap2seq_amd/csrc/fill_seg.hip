@@ -45,6 +45,7 @@
 //            predecessor order, written straight into pinned host memory; the host walks them (post.cpp).
 // A gap that outgrows a capacity (segments, pending events, right-set entries, host buffer) is flagged and
 // runs again in the next kernel of the chain (g2s_fill_segx, then the LDS tier).  Integer work only: no MFMA.
+#include "sync_debug.h"
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include <mutex>

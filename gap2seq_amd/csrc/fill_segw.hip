@@ -26,6 +26,7 @@
 // Segments within one generation are numbered in the order the waves reserve them: nothing downstream depends on
 // that order (any order is topological; parents leave in GATB's order; tools/seg_check.py compares sets).
 // Integer work only: no MFMA.
+#include "sync_debug.h"
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 

@@ -897,6 +897,10 @@ struct g2s_batch {
   bool inline_ok = false, inline_pending = false;
   const char* inline_text_dev = nullptr;  // device-readable flank text of the list (pinned memory, or its copy in d_fstage)
   uint32_t text_stride = 0;               // not 0: gap i's text at i * text_stride (a list without a bad flank)
+  // the fill kernel resolved the flanks and wrote the pinned copy of the node ids only for the gaps resident mode hands
+  // to the host: whoever reads `nodes` of other gaps — the host path, when the list is given back — fetches the table first
+  bool nodes_dev_only = false;
+  int fetch_nodes();
   int upload_flanks(bool allow_inline = false);
   size_t arena_bytes = 0;
   std::vector<size_t> arena_off;  // of each gap's fill buffer within the batch's share of the arena
@@ -1172,6 +1176,16 @@ extern "C" int g2s_batch_prepare(g2s_session* s, const g2s_gap* gaps, size_t n, 
 // computed on the session's stream by the look-up kernel (no host synchronisation: the fill
 // kernels follow on the same stream; the host reads them from pinned memory only after a fill
 // kernel has reported gaps as done).
+int g2s_batch::fetch_nodes() {
+  if (!nodes_dev_only) return G2S_OK;
+  if (s->flank_owner != this) return fail(G2S_ERR_STATE, "batch flank nodes: the device table belongs to another batch");
+  if (hipSetDevice(s->device) != hipSuccess) return fail(G2S_ERR_NO_DEVICE, "cannot select device");
+  hipError_t e = hipStreamSynchronize(s->stream);
+  if (e == hipSuccess && n_nodes) e = hipMemcpy(nodes, s->d_flank.p, n_nodes * 4, hipMemcpyDeviceToHost);
+  if (e != hipSuccess) return fail(G2S_ERR_HIP, std::string("batch flank nodes: ") + hipGetErrorString(e));
+  nodes_dev_only = false;
+  return G2S_OK;
+}
 int g2s_batch::upload_flanks(bool allow_inline) {
   if (s->flank_owner == this && (!inline_pending || allow_inline)) return G2S_OK;
   if (hipSetDevice(s->device) != hipSuccess) return fail(G2S_ERR_NO_DEVICE, "cannot select device");
@@ -1820,6 +1834,7 @@ int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
     t_lap = now;
   };
   { const int rc = b->upload_flanks(); if (rc != G2S_OK) return rc; }
+  { const int rc = b->fetch_nodes(); if (rc != G2S_OK) return rc; }  // (a list resident mode gave back: the kernel kept most node ids on the device)
   b->drop_tiers();
   b->force_host_d2 = getenv("G2S_HOST_D2") != nullptr;
   if (getenv("G2S_DEBUG")) fprintf(stderr, "[g2s] stage 1 begins\n");
@@ -3088,7 +3103,7 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl, g2s_result* re
                           nullptr, nullptr, 0u, 1u, true, rerun ? (uint32_t*)s->d_ovf.p : nullptr,
                           dev_d2 ? (uint32_t*)s->d_d2list.p : nullptr, d2_tag, use_inl ? &inl : nullptr,
                           early_reg ? &early_dev : nullptr, (use_tr && tr.chu) ? &tr : nullptr, gaps_dev, lite_e, lite_ap));
-  if (use_inl) b->inline_pending = false;  // (behind this kernel d_flank and the pinned copy hold the ids)
+  if (use_inl) { b->inline_pending = false; b->nodes_dev_only = true; }  // (behind this kernel d_flank holds the ids; the pinned copy those of the host's gaps)
   s->lap_fill_queued = std::chrono::steady_clock::now();
   if (rl->timed) HIP_TRY_S(hipEventRecord(s->ev[2], st));
   // (queued BEHIND the regular tier's kernel, which takes the compute units first — a workgroup of the large variant

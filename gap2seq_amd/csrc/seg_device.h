@@ -2,6 +2,7 @@
 // waves per gap; fill_segw.hip: the large variant, a workgroup of several waves per gap): wave reductions and scans
 // inside the vector ALU, segment arithmetic, the bitonic sort and interval merge in LDS, the launch arguments.
 #pragma once
+#include "sync_debug.h"
 #include <hip/hip_runtime.h>
 
 #include "fill_device.h"
@@ -36,7 +37,20 @@ __device__ __forceinline__ unsigned long long ballot_and(bool a, B... b) { retur
 
 namespace {
 
+#ifdef G2S_SYNC_DEBUG  /* sync_debug.h: the race-hunting builds */
+__device__ __forceinline__ void lds_sync_at(uint32_t site) {
+  g2s_sync_jitter(site);
+#ifdef G2S_PARANOID_SYNC
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+#else
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+}
+#define lds_sync() lds_sync_at((uint32_t)__LINE__)
+#else
 __device__ __forceinline__ void lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+#endif
 __device__ __forceinline__ uint32_t rl(uint32_t x, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)x, l); }
 __device__ __forceinline__ uint32_t uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
 __device__ __forceinline__ uint64_t below(int lane) { return (1ull << lane) - 1ull; }

@@ -619,3 +619,69 @@ def test_long_lists_go_slice_by_slice(product, monkeypatch):
         assert sum(1 for r in want if r[3] & product.G2S_GAP_SKIPPED) >= 1  # (a right fuz beyond 0 is rare on this genome)
     finally:
         pg.free()
+
+
+# ---- race hunting (round 6): the kernels' synchronisation is hand-written — wave-local waits, workgroup barriers,
+# spin-waits across streams — and a missing barrier shows only when the waves' timing happens to expose it (round 5's
+# in g2s_fill_segw's tail: once in a hundred runs, green suites for two rounds).  Two instrumented builds of the same
+# sources (csrc/sync_debug.h; built by __graft_entry__.build()) move that timing: a pseudo-random sleep at every
+# synchronisation point, and every wait widened to everything outstanding with every barrier taken twice.  Every
+# kernel path, dozens of calls per build: no call may differ from its run's first, and the three builds must agree.
+def _race_hunt(path, runs, library):
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = os.path.join(root, "gap2seq_amd", library, "libg2s_hip.so") if library else os.path.join(root, "gap2seq_amd", "libg2s_hip.so")
+    if not os.path.exists(so):
+        pytest.fail("%s is missing: __graft_entry__.build() makes it" % so)
+    env = dict(os.environ, G2S_LIBRARY=so)
+    for v in ("G2S_RESIDENT", "G2S_DEVICE_D2", "G2S_FORCE_SEGX", "G2S_NO_SEG_TIER"):
+        env.pop(v, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "race_hunt.py"), path, str(runs)], env=env, capture_output=True,
+                         text=True, timeout=900)
+    rows = [json.loads(ln) for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert rows, "race_hunt.py %s with %s: %s" % (path, library or "the product build", out.stderr[-2000:])
+    return rows[-1]
+
+
+@pytest.mark.parametrize("path,runs", [("seg2", 60), ("seg", 30), ("segw", 50), ("d2", 50)])
+def test_race_hunting_builds_give_the_product_builds_results(path, runs):
+    """tools/race_hunt.py: one list `runs` times on one kernel path (seg2: two waves per gap + four-wave trace kernel +
+    closures handed to the host early; seg: one wave per gap, g2s_d2_small, the long list's phase D3; segw: the
+    eight-wave kernel on a -dist-error 2000 list, closures on the host's threads; d2: the same list through
+    g2s_d2_small / g2s_d2_big) with the product build, the jitter build and the paranoid build."""
+    rows = [_race_hunt(path, runs, lib) for lib in ("", "_jit", "_par")]
+    for r in rows:
+        assert r["differ"] == 0, "%s, %s: %d of %d calls differ from the first" % (path, r["library"], r["differ"], r["runs"])
+        assert r["resident_launches"] == 1 and r["fallbacks"] == 0 and r["filled"] == r["gaps"], r
+    assert len({r["digest"] for r in rows}) == 1, "the builds disagree on %s: %r" % (path, [(r["library"], r["digest"]) for r in rows])
+    if path == "d2":
+        assert rows[0]["host_finished"] <= 1 and rows[0]["segx_tier_gaps"] > 0
+    if path == "segw":
+        assert rows[0]["host_finished"] > 0 and rows[0]["segx_tier_gaps"] > 0
+
+
+@pytest.mark.parametrize("variant,n", [(0, 600), (1, 600), (3, 2500), (0, 3500)])
+def test_single_path_gaps_traced_by_the_fill_kernel(product, monkeypatch, variant, n):
+    """Round 6: a gap whose traceback has no choice to make (one path length, no entry of the traceback closure with
+    several parents) is traced by its fill kernel's own wave — text, case, fuz values, draws — while the rest of the
+    list is still being searched (fill_seg.hip, G2S_DEVA_TRACED); phase D3 only counts its draws.  On a genome without
+    bubbles that is nearly every gap.  Against the same lists with the switch off (every gap through g2s_d3_trace),
+    field by field and in the position the rand() stream is left at; short lists (two waves per gap) and long ones."""
+    reads = product.G2S.synth_genome(300000, variant, 20240101)
+    seqs = [ln for ln in reads.splitlines() if not ln.startswith(">")]
+    gaps = _parse_scaffolds(product.G2S.synth_gaps(reads, 31, 10, n, 100, 900, 20240103))
+    monkeypatch.setenv("G2S_TRACE_IN_FILL", "0")
+    a1, a2, ta, _ = _run(product, monkeypatch, True, seqs, 31, gaps, 500, pinned=True)
+    monkeypatch.setenv("G2S_TRACE_IN_FILL", "1")
+    b1, b2, tb, _ = _run(product, monkeypatch, True, seqs, 31, gaps, 500, pinned=True)
+    c1, c2, tc, _ = _run(product, monkeypatch, True, seqs, 31, gaps, 500, pinned=False)
+    assert ta.resident_launches == 1 and tb.resident_launches == 1 and tb.resident_fallbacks == 0
+    assert ta.traced_in_fill_gaps == 0
+    assert tb.traced_in_fill_gaps > (len(gaps) * 8 // 10 if variant == 0 else 0)
+    assert tc.traced_in_fill_gaps == tb.traced_in_fill_gaps
+    assert b1 == a1 and b2 == a2
+    assert c1 == a1 and c2 == a2
+    assert tb.fill_bytes == ta.fill_bytes
