@@ -243,6 +243,125 @@ def result_key(r):
     return (r.count, r.left_fuz, r.right_fuz, r.flags, r.draws, r.fill, tuple(r.substats), r.phaseC_count, tuple(r.lengths))
 
 
+def run_rank_per_gpu(args, dist, rank, world, seen):
+    """N ranks, one GPU each: rank r fills, traces and writes the r-th contiguous share of the list on the device it
+    sees; the shares are placed in the one rand() stream by two all-gathers of host scalars (shard.fill_share).  The
+    timed region, the barriers and the reduction are the contract's; rank 0 prints the line."""
+    from gap2seq_amd import lib as P
+    from gap2seq_amd import shard
+    cfg_name = args.config or "C3"
+    genome_bp, k, ngaps, min_len, max_len, d_err, cfg_text = CONFIGS[cfg_name]
+    genome_bp = args.genome or genome_bp
+    k = args.k or k
+    ngaps = args.gaps or ngaps
+    if args.weak:
+        ngaps *= world
+    min_len, max_len, d_err = args.min_len or min_len, args.max_len or max_len, args.dist_error or d_err
+    steps = args.steps or {"C2": 200, "C3": 30, "C4": 30, "C5": 3}[cfg_name]
+    warmup = args.warmup if args.warmup >= 0 else (10 if steps >= 100 else 3 if steps >= 10 else 1)
+    os.environ.setdefault("G2S_KERNEL_TIMING", "all")
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    device = 0 if (seen[rank] == 1 or args.share_device) else local % seen[rank]
+    reads = P.G2S.synth_genome(genome_bp, args.variant, GENOME_SEED)
+    seqs = [ln for ln in reads.splitlines() if not ln.startswith(">")]
+    gaps = parse_gaps(P.G2S.synth_gaps(reads, k, args.fuz, ngaps, min_len, max_len, GAP_SEED), args.fuz)
+    os.environ["G2S_DEVICE"] = str(device)
+    t0 = time.time()
+    graph = P.Graph.from_seqs(seqs, k, 1)
+    graph.upload(device)
+    t_graph = time.time() - t0
+    sess = P.Session(graph, device, d_err=d_err, randseed=1, host_threads=args.host_threads)
+    comm = shard.DistComm(dist)
+    lo, hi = shard.share_bounds(len(gaps), world)[rank]
+    lib = P.load_library()
+    arr, _keep = P._gap_array([P.Gap(g["left"], g["right"], g["gap_len"], g["lmf"], g["rmf"]) for g in gaps[lo:hi]])
+    n = hi - lo
+    nbytes = lib.g2s_team_arena_bytes(sess.h, arr, n)
+    abuf, rbuf = P.HostBuffer(max(1, nbytes)), P.HostBuffer(C.sizeof(P.g2s_result) * max(1, n))
+    res = rbuf.array(P.g2s_result, max(1, n))
+    ap_ = C.cast(abuf.p, C.c_void_p)
+
+    def step():
+        sess.srand(1)
+        t = time.perf_counter()
+        draws = shard.fill_share(P, sess, comm, arr, n, res, ap_, nbytes)
+        return time.perf_counter() - t, draws
+
+    # ---- the shares must give the one-GPU result, bit for bit: every rank fills the WHOLE list once on its own GPU
+    # (g2s_fill_batch, untimed) and compares its share with that
+    whole = Runner(P, [sess], gaps, 0, True)
+    whole.step()
+    want = [result_key(r) for r in whole.results()][lo:hi]
+    whole.free()
+    _, draws = step()
+    got = None if draws is None else [result_key(P.FillResult(res[i], abuf.raw)) for i in range(n)]
+    same = comm.all_gather([1 if got == want else 0, 1 if draws is not None else 0])
+    if not all(x[1] for x in same):
+        if rank == 0:
+            sys.stderr.write("bench.py: one rank per GPU: a share could not be taken on its device (shares of %s gaps)\n" % [b - a for a, b in shard.share_bounds(len(gaps), world)])
+        dist.destroy_process_group()
+        return 3
+    if not all(x[0] for x in same):
+        if rank == 0:
+            sys.stderr.write("bench.py: one rank per GPU: the shares differ from the one-GPU results on rank(s) %s\n" % [r for r, x in enumerate(same) if not x[0]])
+        dist.destroy_process_group()
+        return 4
+    for _ in range(warmup):
+        step()
+    kern_ms, timed = 0.0, 0
+    dist.barrier()
+    t_begin = time.perf_counter()
+    for _ in range(steps):
+        step()
+        tm = sess.last_timing()
+        kern_ms += tm.ms_fill_seg
+        timed += tm.seg_timed_launches
+    elapsed = time.perf_counter() - t_begin
+    dist.barrier()
+    elapsed, units = shard.reduce_timing(elapsed, float(n * steps), dist)
+    tm = sess.last_timing()
+    per_rank = comm.all_gather([int(kern_ms * 1e6), timed, n, int(tm.fill_bytes), int(tm.flank_bytes), tm.seg_tier_gaps + tm.segx_tier_gaps,
+                                sum(1 for i in range(n) if res[i].count > 0)])
+    if rank == 0:
+        x_units, s_units, counted_by = oracle_units(units_key(genome_bp, args.variant, k, len(gaps), min_len, max_len, args.fuz, d_err))
+        kms = [p[0] / 1e6 / max(1, p[1]) for p in per_rank]  # average launch duration per rank
+        kern = sum(kms) / len(kms)
+        io = sum(p[3] + p[4] for p in per_rank)
+        alg = algorithmic_bytes(x_units, s_units, io) / world if x_units is not None else None  # per launch: a share each
+        ach = alg / (kern / 1e3) / 1e9 if alg is not None and kern > 0 else None
+        out = {
+            "metric": "gaps filled/sec (whole node), k=%d synthetic %s DBG" % (k, "3 Mbp" if genome_bp == 3000000 else "%d bp" % genome_bp),
+            "value": round(units / elapsed, 2), "unit": "gaps/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": round(elapsed / steps * 1e3, 4), "higher_is_better": True, "scaling": "weak" if args.weak else "strong",
+            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": "BASELINE %s: %d bp genome V%d, k=%d, %d gaps len %d-%d, fuz %d, dist-error %d" % (
+                           cfg_text, genome_bp, args.variant, k, len(gaps), min_len, max_len, args.fuz, d_err),
+                       "config": cfg_name, "gaps": len(gaps), "genome_bp": genome_bp, "variant": args.variant, "k": k,
+                       "timed_region": "per rank: srand(1) + g2s_share_begin / _tables / _trace / _end on its share, with the two all-gathers "
+                                       "of host scalars between them (gap2seq_amd/shard.py: fill_share)",
+                       "parallelism": "%d processes, one GPU and one contiguous share of the list each (%s gaps), graph replicated, the shares "
+                                      "placed in the one rand() stream by two %s all-gathers of draw totals and share functions; no "
+                                      "collective on the data path, results stay with the ranks" % (world, [p[2] for p in per_rank], dist.get_backend()),
+                       "mode": "rank_per_gpu", "devices_seen_by_rank": seen, "ranks_under_torchrun": world},
+            "roofline": dict(bound="hbm", kernel="g2s_fill_seg", achieved=round(ach, 3) if ach is not None else None, peak=HBM_PEAK_GBS, unit="GB/s",
+                             frac=round(ach / HBM_PEAK_GBS, 6) if ach is not None else None, traffic=None,
+                             algorithmic_bytes_per_launch=alg, expansions=x_units, states=s_units, units_counted_by=counted_by,
+                             kernel_ms_per_launch=round(kern, 4), kernel_ms_per_launch_by_rank=[round(x, 4) for x in kms], launches_per_step=float(world)),
+            "cpu_baseline": None,
+            "filled": sum(p[6] for p in per_rank),
+            "equals_one_gpu_result": True,
+            "list_draws": draws,
+            "setup_s": {"graph_build_and_upload_per_rank": round(t_graph, 3)},
+        }
+        print(json.dumps(out))
+        sys.stdout.flush()
+    abuf.free(); rbuf.free()
+    sess.destroy()
+    graph.free()
+    dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -280,6 +399,10 @@ def main():
     ap.add_argument("--stream-lists", type=int, default=0,
                     help="N=1: also measure K consecutive lists of the workload with --in-flight of them in flight (g2s_fill_begin / "
                          "g2s_fill_end) against the same K lists one at a time; reported as `stream_lists`")
+    ap.add_argument("--rank-per-gpu", action="store_true",
+                    help="N>1 under torchrun: every rank drives ONE GPU and fills its share of the list (g2s_share_*, "
+                         "gap2seq_amd/shard.py: fill_share); chosen by itself when rank 0 cannot see N devices (a launcher "
+                         "that pins a device per rank)")
     ap.add_argument("--dry-run", action="store_true",
                     help="testing only (CPU): the launch protocol — rendezvous, barriers, timing reduction, one JSON "
                          "line from rank 0 — without touching a device or measuring anything")
@@ -298,6 +421,22 @@ def main():
             dist.barrier()
 
     from gap2seq_amd import shard
+    # ---- which form a multi-rank launch takes.  One process drives all N GPUs (rank 0; the other ranks only join the
+    # barriers) whenever rank 0 can see N devices.  A launcher that pins a device per rank leaves it one: every rank
+    # then drives the GPU it sees and fills its share of the list (run_rank_per_gpu).  The ranks agree on the form by
+    # one all-gather of what each of them sees (counting devices does not touch them).
+    if world > 1 and not args.dry_run:
+        from gap2seq_amd import lib as P0
+        seen = shard.DistComm(dist).all_gather([P0.G2S.device_count()])
+        per_rank = args.rank_per_gpu or (seen[0][0] < ngpu and not args.share_device)
+        if per_rank:
+            if world != ngpu or min(x[0] for x in seen) < 1:
+                if rank == 0:
+                    sys.stderr.write("bench.py: --gpus %d with %d rank(s) seeing %s gfx950 device(s): neither one process for all "
+                                     "GPUs (rank 0 sees %d) nor one rank per GPU is possible\n" % (ngpu, world, [x[0] for x in seen], seen[0][0]))
+                dist.destroy_process_group()
+                return 2
+            return run_rank_per_gpu(args, dist, rank, world, [x[0] for x in seen])
     if rank != 0:
         # this rank's GPU is driven by a session of rank 0's process (one process, N devices)
         barrier()  # timed region begins
@@ -532,6 +671,47 @@ def main():
         for s_ in solo:
             s_.destroy()
 
+    # ---- N>1, the default line: the driver passes no flags, and the strong headline (config 3's ONE list over N GPUs)
+    # is bound by its 1 250-gap shares at N = 8 — beside it, in the same line: WEAK scaling (the config's gap count per
+    # GPU in one list, each GPU a share of 10 000) and a STREAM of such lists (the rand() stream running on from list
+    # to list), each checked against one session and timed against it
+    weak_beside = None
+    if len(sessions) > 1 and not custom and not args.weak and args.stream_lists < 2 and group != 0:
+        gw = parse_gaps(P.G2S.synth_gaps(reads, k, args.fuz, ngaps * ngpu, min_len, max_len, GAP_SEED), args.fuz)
+        gweak = shard.group_size(len(gw), len(sessions) if args.share_device else len(set(devices)), per_session=args.groups_per_session)
+        rw = Runner(P, sessions, gw, gweak, not args.pageable_buffers)
+        solo = make_sessions(devices[:1], 1)
+        r1 = Runner(P, solo, gw, 0, not args.pageable_buffers)
+        rw.step()
+        r1.step()
+        if [result_key(a) for a in r1.results()] != [result_key(b) for b in rw.results()]:
+            raise SystemExit("bench.py: the weak list (%d gaps) on %d sessions differs from the one-session results" % (len(gw), len(sessions)))
+        nw = max(3, min(steps, 6))
+        rw.step()
+        tw = sum(rw.step() for _ in range(nw))
+        t1w = sum(r1.step() for _ in range(nw))
+        kl = 4
+        _, want = r1.stream(kl, keep=True)
+        _, got = rw.stream(kl, keep=True)
+        if got != want:
+            raise SystemExit("bench.py: a stream of %d weak lists on %d sessions differs from the same lists on one session" % (kl, len(sessions)))
+        rw.stream(kl)
+        ts = sum(rw.stream(kl)[0] for _ in range(3))
+        t1s = sum(r1.stream(kl)[0] for _ in range(3))
+        weak_beside = dict(
+            weak=dict(scaling="weak", gaps=len(gw), gaps_per_session=gweak, steps=nw, value=round(len(gw) * nw / tw, 2), unit="gaps/s",
+                      ms_per_step=round(tw / nw * 1e3, 4), one_session=round(len(gw) * nw / t1w, 2),
+                      ms_per_step_one_session=round(t1w / nw * 1e3, 4), results="identical to one session (checked in this run)"),
+            stream=dict(lists=kl, gaps_per_list=len(gw), gaps_per_session_and_list=gweak, repetitions=3,
+                        value=round(len(gw) * kl * 3 / ts, 2), unit="gaps/s", ms_per_list=round(ts / (kl * 3) * 1e3, 4),
+                        one_session=round(len(gw) * kl * 3 / t1s, 2), ms_per_list_one_session=round(t1s / (kl * 3) * 1e3, 4),
+                        results="identical to the same lists on one session, list by list (checked in this run)"),
+            how="g2s_team_fill, one share of the list per session: every GPU fills, traces and writes its own share, the shares "
+                "placed in the one rand() stream by draw totals and share functions between the sessions' threads; no collective")
+        rw.free(); r1.free()
+        for s_ in solo:
+            s_.destroy()
+
     # ---- CPU baseline: the oracle (port of the reference algorithm) on the GPU box's host cores,
     # N=1 only, on a bounded sample of the same gaps
     cpu = None
@@ -728,6 +908,8 @@ def main():
         out["c3_on_one_gpu"] = c3_beside
     if stream_lists is not None:
         out["stream_lists"] = stream_lists
+    if weak_beside is not None:
+        out["weak_and_stream_beside"] = weak_beside
     print(json.dumps(out))
     for s in sessions:
         s.destroy()

@@ -59,6 +59,10 @@ struct D2Caps {
   static_assert(E >= 2u * NV, "the reverse adjacency's space holds two packed degree tables");
 };
 using D2Small = D2Caps<64u, G2S_D2_SMALL_NS, G2S_D2_SMALL_NREC, G2S_D2_SMALL_BP, G2S_D2_SMALL_NV, G2S_D2_SMALL_E>;
+// (round 6) the small capacities on FOUR waves: a list's launch of g2s_d2_small ends with its largest closure — 240 us on
+// one wave for config 3's, longer than phase D3's front kernels and half the trace kernel that hide the launch on a
+// list of 5 000 gaps — and the passes over segments, cuts, edges and nodes are strided over the workgroup's waves
+using D2Small4 = D2Caps<256u, G2S_D2_SMALL_NS, G2S_D2_SMALL_NREC, G2S_D2_SMALL_BP, G2S_D2_SMALL_NV, G2S_D2_SMALL_E>;
 using D2Big = D2Caps<G2S_D2_BIG_NT, G2S_D2_BIG_NS, G2S_D2_BIG_NREC, G2S_D2_BIG_BP, G2S_D2_BIG_NV, G2S_D2_BIG_E>;
 
 // state of a node while the strong components are found; afterwards: its component (the id of one of its nodes)
@@ -1266,6 +1270,10 @@ __global__ __launch_bounds__(64) void g2s_d2_small(const D2Args A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   d2_loop<D2Small>(lds, A);
 }
+__global__ __launch_bounds__(256) void g2s_d2_small4(const D2Args A) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  d2_loop<D2Small4>(lds, A);
+}
 __global__ __launch_bounds__(G2S_D2_BIG_NT) void g2s_d2_big(const D2Args A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   d2_loop<D2Big>(lds, A);
@@ -1291,6 +1299,13 @@ hipError_t launch_d2(hipStream_t st, const D2Args& A0, uint32_t small_wgs, uint3
   A.scratch = scratch_small;
   A.list_next = big_wgs ? list_big : nullptr;
   A.count_next = count_big;
+  // (four waves a closure — G2S_D2_SMALL_WAVES=1: one, as in round 5)
+  static const bool four = !(getenv("G2S_D2_SMALL_WAVES") && atoi(getenv("G2S_D2_SMALL_WAVES")) == 1);
+  if (four) {
+    e = hipFuncSetAttribute((const void*)g2s_d2_small4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)D2Small4::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(g2s_d2_small4, dim3(std::max(1u, small_wgs)), dim3(D2Small4::NT), D2Small4::LDS_BYTES, st, A);
+  } else
   hipLaunchKernelGGL(g2s_d2_small, dim3(std::max(1u, small_wgs)), dim3(D2Small::NT), D2Small::LDS_BYTES, st, A);
   if (big_wgs == 0u) return hipGetLastError();  // (what the small one cannot take is then the host's)
   D2Args B = A0;

@@ -487,6 +487,7 @@ struct RandCache {
   int32_t at_const(size_t off) const { return st.value(off); }  // already materialised
   bool would_grow(size_t n) const { return st.would_grow(n); }  // ensure(n) would move the buffer
   void consume(size_t n) { st.consume(n); }
+  void skip(uint64_t n) { st.skip(n); }  // n values drawn elsewhere, the state behind them not handed over
   void swap(RandCache& o) { st.swap(o.st); }
 };
 
@@ -655,6 +656,11 @@ struct g2s_session {
   // while lists are in flight (the lists' kernels still read and write this session's buffers)
   int internal_calls = 0;
   uint64_t begun = 0;
+  // g2s_share_*: this rank's share of a list sharded over processes, between g2s_share_begin and g2s_share_end
+  g2s_batch* share_batch = nullptr;
+  int share_step = 0;  // 1 begun, 2 tables, 3 traced
+  bool share_timed = false, share_two = false;
+  uint32_t share_win[G2S_RAND_WINDOW];
   bool resident_off = false;
 };
 
@@ -4577,6 +4583,117 @@ extern "C" int g2s_fill_end(g2s_session* s) {
 }
 extern "C" int g2s_fill_in_flight(const g2s_session* s) { return s ? s->n_inflight : 0; }
 
+// ---- one list over several processes, a GPU and a share each (include/g2s.h): the three steps of team_resident_sharded
+// with the exchanges between them left to the caller (gap2seq_amd/shard.py: gloo all-gathers of host scalars)
+namespace {
+void share_drop(g2s_session* s) {
+  if (s->d3_pending) {
+    (void)hipSetDevice(s->device);
+    (void)hipStreamSynchronize(s->stream);
+    (void)hipStreamSynchronize(s->stream2);
+    delete (D3Pending*)s->d3_pending;
+    s->d3_pending = nullptr;
+    s->d_d3.clean = 0;
+  }
+  if (s->share_batch) { (void)resident_reset_fill(s, s->share_batch->jobs.size()); g2s_batch_free(s->share_batch); s->share_batch = nullptr; }
+  s->share_step = 0;
+  s->in_team_list = false; s->team_sharded = false; s->team_sessions = 1;
+}
+}  // namespace
+extern "C" int g2s_share_begin(g2s_session* s, const g2s_gap* gaps, size_t n, g2s_result* results, char* fill_arena, size_t arena_cap,
+                               uint64_t totals[2]) {
+  if (!s || !gaps || !results || !totals || n == 0) return fail(G2S_ERR_ARG, "g2s_share_begin: bad argument");
+  REFUSE_IN_FLIGHT(s, "g2s_share_begin");
+  if (s->share_step != 0) return fail(G2S_ERR_STATE, "g2s_share_begin: a share is open on this session (g2s_share_end it first)");
+  if (gaps[0].skip_if_prev_right_fuz_gt >= 0) return fail(G2S_ERR_STATE, "g2s_share_begin: the share's first gap carries a skip rule (a record cut by a share boundary)");
+  {
+    void* d = nullptr;
+    if (!device_pointer_of(results, &d) || (arena_cap && !device_pointer_of(fill_arena, &d)))
+      return fail(G2S_ERR_ARG, "g2s_share_begin: results and fill_arena must be g2s_host_alloc memory (the kernels write them)");
+  }
+  s->in_team_list = true; s->team_sharded = true; s->team_sessions = 1;
+  if (!resident_applicable(s, n) || s->d3_pending) { share_drop(s); return fail(G2S_ERR_STATE, "g2s_share_begin: not a list for resident mode on this session"); }
+  memcpy(s->share_win, s->rcache.window(G2S_RAND_WINDOW), sizeof s->share_win);  // the generator where the LIST starts (every rank's is there)
+  g2s_batch* b = nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
+  int rc = g2s_batch_prepare(s, gaps, n, &b);
+  if (rc != G2S_OK) { share_drop(s); return rc; }
+  s->share_batch = b;
+  b->timing.ms_prepare = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  if (arena_cap < b->arena_bytes) { share_drop(s); return fail(G2S_ERR_ARG, "g2s_share_begin: fill arena too small"); }
+  b->arena = fill_arena;
+  b->arena_base = 0;
+  ResidentLaunch rl;
+  rc = resident_launch_fill(b, &rl);
+  if (rc == 1) { share_drop(s); return fail(G2S_ERR_STATE, "g2s_share_begin: not a list for resident mode"); }
+  if (rc != G2S_OK) { share_drop(s); return rc; }
+  s->share_timed = rl.timed; s->share_two = rl.two_waves;
+  ResidentList L;
+  L.groups.push_back(b);
+  L.n = n; L.group_size = std::max<size_t>(n, 1);
+  L.group_arena.push_back(0);
+  L.arena_bytes = b->arena_bytes;
+  L.outs_dev = (const GapOut*)s->d_outs.p;
+  L.sub_dev = (const SubRec*)s->d_sub.p;
+  L.sub_region = 0;
+  L.pin = &s->h_d3;
+  L.rnd_cap = b->rnd_cap; L.dmax = b->dmax; L.has_skip = b->has_skip;
+  L.gaps_dev = (const GapDev*)s->d_gaps.p;
+  rc = resident_d3_launch(s, L, rl.timed, false, results, fill_arena, true, true);
+  if (rc == 1) { share_drop(s); return fail(G2S_ERR_STATE, "g2s_share_begin: not a list for phase D3 on the device"); }
+  if (rc == G2S_OK && hipStreamSynchronize(s->stream) != hipSuccess) rc = fail(G2S_ERR_HIP, "g2s_share_begin: the share's first kernels");
+  if (rc != G2S_OK) { share_drop(s); return rc; }
+  const D3Summary* hs = ((D3Pending*)s->d3_pending)->hsum;
+  if (hs->status != 0) { share_drop(s); return fail(G2S_ERR_STATE, "g2s_share_begin: a gap beyond every tier of the device, or tables beyond the budget"); }
+  totals[0] = hs->draws_min; totals[1] = hs->draws_spread;
+  s->share_step = 1;
+  return G2S_OK;
+}
+extern "C" int g2s_share_tables(g2s_session* s, uint64_t base0, uint64_t R0, const uint32_t** fn) {
+  if (!s || !fn) return fail(G2S_ERR_ARG, "g2s_share_tables: bad argument");
+  if (s->share_step != 1) return fail(G2S_ERR_STATE, "g2s_share_tables: no share begun on this session");
+  if (base0 + R0 >= 0xF0000000ull) { share_drop(s); return fail(G2S_ERR_STATE, "g2s_share_tables: the list draws more than phase D3 on the device counts"); }
+  int rc = resident_d3_sharded_tables(s, (uint32_t)base0, (uint32_t)R0, s->share_win);
+  if (rc == G2S_OK && hipStreamSynchronize(s->stream) != hipSuccess) rc = fail(G2S_ERR_HIP, "g2s_share_tables: the share's tables");
+  if (rc != G2S_OK) { share_drop(s); return rc; }
+  if (((D3Pending*)s->d3_pending)->hsum->status != 0) { share_drop(s); return fail(G2S_ERR_STATE, "g2s_share_tables: tables beyond the budget"); }
+  *fn = ((D3Pending*)s->d3_pending)->group_fn;
+  s->share_step = 2;
+  return G2S_OK;
+}
+extern "C" int g2s_share_trace(g2s_session* s, uint32_t d_in) {
+  if (!s) return fail(G2S_ERR_ARG, "g2s_share_trace: bad argument");
+  if (s->share_step != 2) return fail(G2S_ERR_STATE, "g2s_share_trace: no tables on this session (g2s_share_tables first)");
+  g2s_batch* b = s->share_batch;
+  const size_t n = b->jobs.size();
+  int rc = resident_d3_sharded_trace(s, d_in);
+  bool fb = false;
+  double ms_d3 = 0;
+  if (rc == G2S_OK) rc = resident_d3_wait(s, &b->timing, &ms_d3, &fb);
+  if (rc == G2S_OK) rc = resident_reset_fill(s, n);
+  if (rc != G2S_OK) { share_drop(s); return rc; }
+  if (fb) { share_drop(s); return fail(G2S_ERR_STATE, "g2s_share_trace: the share was not finished on the device"); }
+  float ms_fill = 0;
+  if (s->share_timed && hipEventElapsedTime(&ms_fill, s->ev[1], s->ev[2]) == hipSuccess) { b->timing.ms_fill_seg += ms_fill; b->timing.seg_timed_launches++; }
+  (void)hipGetLastError();
+  b->timing.seg_launches++;
+  if (s->share_two) b->timing.seg2_launches++;
+  b->timing.team_d3_sharded = 1;
+  s->last_timing = b->timing;
+  s->share_step = 3;
+  return G2S_OK;
+}
+extern "C" int g2s_share_end(g2s_session* s, uint64_t list_draws) {
+  if (!s) return fail(G2S_ERR_ARG, "g2s_share_end: bad argument");
+  if (s->share_step != 3) { share_drop(s); return fail(G2S_ERR_STATE, "g2s_share_end: the share was not traced (dropped)"); }
+  g2s_batch_free(s->share_batch);
+  s->share_batch = nullptr;
+  s->share_step = 0;
+  s->in_team_list = false; s->team_sharded = false; s->team_sessions = 1;
+  s->rcache.skip(list_draws);  // (every rank's generator moves past the whole list)
+  return G2S_OK;
+}
+
 extern "C" int g2s_session_set_team(g2s_session* lead, g2s_session* const* helpers, int nhelpers, size_t group_size) {
   if (!lead || nhelpers < 0 || (nhelpers && !helpers)) return fail(G2S_ERR_ARG, "g2s_session_set_team: bad argument");
   for (int i = 0; i < nhelpers; i++)
@@ -4965,6 +5082,17 @@ extern "C" int g2s_test_device_rand(int device, uint32_t seed, uint64_t skip, ui
   return G2S_OK;
 }
 
+// TEST HOOK: the n values behind `skip` values that were drawn elsewhere — GlibcRandStream::skip, the jump by the
+// recurrence's polynomial g2s_share_end moves a rank's generator with — for comparison with g2s_test_rand_stream
+extern "C" int g2s_test_rand_skip(uint32_t seed, uint64_t skip, uint32_t n, int32_t* out) {
+  if (!out) return fail(G2S_ERR_ARG, "g2s_test_rand_skip: bad argument");
+  GlibcRandStream st;
+  st.seed(seed);
+  st.skip(skip);
+  st.ensure(n);
+  for (uint32_t i = 0; i < n; i++) out[i] = st.value(i);
+  return G2S_OK;
+}
 extern "C" int g2s_test_rand_stream(uint32_t seed, uint32_t skip, uint32_t n, int32_t* out) {
   if (!out) return fail(G2S_ERR_ARG, "g2s_test_rand_stream: bad argument");
   GlibcRandStream st;

@@ -89,6 +89,24 @@ class GlibcRandStream {
     size_ = 31;
     first_ = 31;
   }
+  // n values were consumed elsewhere and nobody kept the state behind them: the recurrence is linear, so the state n
+  // values on is a fixed combination (x^n modulo the recurrence's polynomial) of the 61 words from the state here
+  void skip(uint64_t n) {
+    if (first_ + n <= size_) { consume((size_t)n); return; }
+    ensure(31);
+    uint32_t q[31], st[31];
+    jump_poly(n, q);
+    const uint32_t* e = e_ + first_ - 31;
+    for (int j = 0; j < 31; j++) {
+      uint32_t acc = 0;
+      for (int i = 0; i < 31; i++) acc += q[i] * e[j + i];
+      st[j] = acc;
+    }
+    reserve(31 + 4096);
+    memcpy(e_, st, sizeof st);
+    size_ = 31;
+    first_ = 31;
+  }
   // drop the first n values (they were consumed)
   void consume(size_t n) {
     first_ += n;

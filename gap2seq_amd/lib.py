@@ -92,6 +92,11 @@ _SIGS = {
     "g2s_fill_begin": (C.c_int, [_VP, C.POINTER(g2s_gap), C.c_size_t, C.POINTER(g2s_result), C.c_void_p, C.c_size_t]),
     "g2s_fill_end": (C.c_int, [_VP]),
     "g2s_fill_in_flight": (C.c_int, [_VP]),
+    "g2s_share_begin": (C.c_int, [_VP, C.POINTER(g2s_gap), C.c_size_t, C.POINTER(g2s_result), C.c_void_p, C.c_size_t,
+                                  C.POINTER(C.c_uint64)]),
+    "g2s_share_tables": (C.c_int, [_VP, C.c_uint64, C.c_uint64, C.POINTER(C.POINTER(C.c_uint32))]),
+    "g2s_share_trace": (C.c_int, [_VP, C.c_uint32]),
+    "g2s_share_end": (C.c_int, [_VP, C.c_uint64]),
     "g2s_backtrace_text": (C.c_size_t, [C.POINTER(g2s_gap), C.POINTER(g2s_result), C.c_int, C.c_char_p, C.c_size_t]),
     "g2s_last_error": (C.c_char_p, []),
     "g2s_graph_build_files": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(_VP)]),
@@ -151,6 +156,7 @@ _SIGS = {
     "g2s_synth_genome": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint64, C.POINTER(_VP)]),
     "g2s_synth_gaps": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64,
                                  C.POINTER(_VP)]),
+    "g2s_test_rand_skip": (C.c_int, [C.c_uint32, C.c_uint64, C.c_uint32, C.POINTER(C.c_int32)]),
     "g2s_test_rand_stream": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_int32)]),
     "g2s_test_device_rand": (C.c_int, [C.c_int, C.c_uint32, C.c_uint64, C.c_uint32, C.POINTER(C.c_int32)]),
     "g2s_test_post_closure": (C.c_int, [_VP, C.POINTER(g2s_params), C.POINTER(g2s_gap), C.c_uint32,
@@ -423,6 +429,12 @@ class Session:
         h = _VP()
         _check(load_library().g2s_session_create(graph.h, device, C.byref(self.params), C.byref(h)))
         self.h = h
+
+    def last_timing(self):
+        """g2s_session_last_timing: the g2s_timing of the last list this session finished."""
+        t = g2s_timing()
+        _check(load_library().g2s_session_last_timing(self.h, C.byref(t)))
+        return t
 
     def srand(self, seed, skip=0):
         _check(load_library().g2s_session_srand(self.h, seed))
@@ -746,6 +758,13 @@ def test_group_queue_slow(nworkers, n, group_size, slow_worker, slow_us):
     owner = (C.c_int32 * max(1, n))()
     _check(load_library().g2s_test_group_queue_slow(nworkers, n, group_size, slow_worker, slow_us, owner))
     return [owner[i] for i in range(n)]
+
+
+def test_rand_skip(seed, skip, n):
+    """TEST HOOK binding: the same values reached by a jump over `skip` values (g2s_share_end's way)."""
+    out = (C.c_int32 * max(1, n))()
+    _check(load_library().g2s_test_rand_skip(seed, skip, n, out))
+    return [out[i] for i in range(n)]
 
 
 def test_rand_stream(seed, skip, n):

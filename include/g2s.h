@@ -295,6 +295,34 @@ int g2s_session_set_team(g2s_session* lead, g2s_session* const* helpers, int nhe
 #define G2S_GROUP_PER_SESSION ((size_t)-1)
 
 /* ---------------------------------------------------------------------------
+ *  One list over several PROCESSES, one GPU each (ABI 6) — for a launcher that pins a device per rank (torchrun with
+ *  HIP_VISIBLE_DEVICES per rank), where g2s_team_fill's one process cannot see the other GPUs.  The reference's threads
+ *  share one rand() stream (Gap2Seq.cpp:178,296-306, at -nb-cores 1: in input order); here every rank fills,
+ *  classifies, traces and writes ITS contiguous share of the list, and the shares are placed in the one stream by two
+ *  exchanges of host scalars between the ranks (any transport: gloo all-gathers in gap2seq_amd/shard.py — nothing
+ *  crosses between the devices, no RCCL):
+ *
+ *    g2s_share_begin   the share's kernels up to its draw totals: totals[0] = draws if every draw-dependent gap took
+ *                      its fewest, totals[1] = the summed spreads.          --> all ranks learn all totals
+ *    g2s_share_tables  base0 / R0 = the sums of totals[0] / totals[1] over the ranks in front: the tables, and the
+ *                      share's function fn[d] = deviation behind the share for deviation d in front of it, d = 0 .. R0
+ *                      (*fn: valid until g2s_share_end).                    --> all ranks learn all functions
+ *    g2s_share_trace   d_in = the functions of the ranks in front composed from 0: tracebacks, results, fill text.
+ *    g2s_share_end     list_draws = what the whole list drew (the sum of all totals[0] + the last function's value):
+ *                      this rank's generator moves past the list, as every other rank's does.
+ *
+ *  Every rank holds the same session state in front of the list (same seed, same lists before).  results / fill_arena:
+ *  the share's own, g2s_host_alloc memory.  A share of fewer than 256 gaps, a gap with a skip rule at a share's head, a
+ *  list resident mode does not take: G2S_ERR_STATE from g2s_share_begin on that rank (the caller falls back to one rank
+ *  filling the list).  Results are those of g2s_fill_batch on the whole list, bit for bit (tests/test_gpu_resident.py).
+ * ------------------------------------------------------------------------ */
+int g2s_share_begin(g2s_session* s, const g2s_gap* gaps, size_t n, g2s_result* results, char* fill_arena, size_t arena_cap,
+                    uint64_t totals[2]);
+int g2s_share_tables(g2s_session* s, uint64_t base0, uint64_t R0, const uint32_t** fn);
+int g2s_share_trace(g2s_session* s, uint32_t d_in);
+int g2s_share_end(g2s_session* s, uint64_t list_draws);
+
+/* ---------------------------------------------------------------------------
  *  Gap2Seq::execute() after the graph exists (Gap2Seq.cpp:224-438): scaffold
  *  scanner, per-gap statistics text, splice, FASTA text.  Outputs are malloc'ed
  *  strings released with g2s_free.  `reads_label`/`filled_label` only feed the

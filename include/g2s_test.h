@@ -59,6 +59,10 @@ int g2s_test_graph_tables(const g2s_graph* g, uint32_t* succ_out, uint64_t* usta
  * (the flat glibc TYPE_3 generator the tracebacks read), for comparison with libc. */
 int g2s_test_rand_stream(uint32_t seed, uint32_t skip, uint32_t n, int32_t* out);
 
+/* TEST HOOK: the same values reached by a JUMP over the `skip` values in front (the recurrence's polynomial: what
+ * g2s_share_end moves a rank's generator with when the values were drawn on other ranks' devices). */
+int g2s_test_rand_skip(uint32_t seed, uint64_t skip, uint32_t n, int32_t* out);
+
 /* TEST HOOK: the same values from the DEVICE's generator (d3_device.hip: g2s_rand_fill — the state behind `skip`
  * values handed over by the host, every block of 4096 values reached with three jump polynomials). */
 int g2s_test_device_rand(int device, uint32_t seed, uint64_t skip, uint32_t n, int32_t* out);

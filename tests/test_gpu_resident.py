@@ -685,3 +685,108 @@ def test_single_path_gaps_traced_by_the_fill_kernel(product, monkeypatch, varian
     assert b1 == a1 and b2 == a2
     assert c1 == a1 and c2 == a2
     assert tb.fill_bytes == ta.fill_bytes
+
+
+# ---- round 6: one list over several PROCESSES, a GPU and a share each (g2s_share_*, gap2seq_amd/shard.py) -----------
+class _ThreadComm:
+    """shard.fill_share's communicator over the threads of one process (a barrier and a shared table)."""
+
+    def __init__(self, rank, world, table, barrier):
+        self.rank, self.world, self._t, self._b = rank, world, table, barrier
+
+    def all_gather(self, values, maxlen=None):
+        assert maxlen is None or len(values) <= maxlen
+        self._t[self.rank] = list(values)
+        self._b.wait()
+        out = [list(v) for v in self._t]
+        self._b.wait()
+        return out
+
+
+@pytest.mark.parametrize("world,variant", [(2, 3), (3, 3), (4, 1)])
+def test_shares_of_a_list_on_ranks_of_their_own_equal_one_session(product, monkeypatch, world, variant):
+    """Every 'rank' a session of its own (here: threads of one process on one device; bench.py --rank-per-gpu runs the
+    same protocol over gloo) with the same seed: share by share the results of g2s_fill_batch on the whole list, and every
+    rank's generator behind the list where the one session's is — a second list says so."""
+    import ctypes as C
+    import threading
+    from gap2seq_amd import shard
+    monkeypatch.delenv("G2S_RESIDENT", raising=False)
+    reads = product.G2S.synth_genome(300000, variant, 20240101)
+    seqs = [ln for ln in reads.splitlines() if not ln.startswith(">")]
+    gaps = _gaps(product, _parse_scaffolds(product.G2S.synth_gaps(reads, 31, 10, 2400, 100, 900, 20240103)))
+    second = gaps[:900]
+    pg = product.Graph.from_seqs(seqs, 31, 1)
+    solo = product.Session(pg, 0, d_err=500, randseed=5)
+    want1 = [_key(r) for r in solo.fill_batch(gaps, pinned=True)]
+    want2 = [_key(r) for r in solo.fill_batch(second, pinned=True)]
+    solo.destroy()
+    lib = product.load_library()
+    sessions = [product.Session(pg, 0, d_err=500, randseed=5) for _ in range(world)]
+    table, barrier = [None] * world, threading.Barrier(world)
+    out, errs = [None] * world, []
+
+    def rank_main(r):
+        try:
+            comm = _ThreadComm(r, world, table, barrier)
+            got = []
+            for lst in (gaps, second):
+                lo, hi = shard.share_bounds(len(lst), world)[r]
+                arr, keep = product._gap_array(lst[lo:hi])
+                n = hi - lo
+                nbytes = lib.g2s_team_arena_bytes(sessions[r].h, arr, n)
+                abuf, rbuf = product.HostBuffer(max(1, nbytes)), product.HostBuffer(C.sizeof(product.g2s_result) * max(1, n))
+                res = rbuf.array(product.g2s_result, max(1, n))
+                draws = shard.fill_share(product, sessions[r], comm, arr, n, res, C.cast(abuf.p, C.c_void_p), nbytes)
+                assert draws is not None and draws > 0
+                raw = abuf.raw
+                got.append((lo, hi, draws, [_key(product.FillResult(res[i], raw)) for i in range(n)]))
+                abuf.free(); rbuf.free()
+            out[r] = got
+        except BaseException as e:  # noqa: B902 (a failing rank must not leave the others at the barrier)
+            errs.append((r, repr(e)))
+            barrier.abort()
+
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for s_ in sessions:
+        s_.destroy()
+    pg.free()
+    assert not errs, errs
+    for li, want in enumerate((want1, want2)):
+        assert len({out[r][li][2] for r in range(world)}) == 1  # every rank knows what the list drew
+        got = []
+        for r in range(world):
+            got += out[r][li][3]
+        assert got == want, "list %d" % li
+
+
+def test_bench_one_rank_per_gpu_under_torchrun_two_ranks_on_one_device():
+    """The launch the driver makes for N = 2 when the launcher pins a device per rank: two ranks, each seeing ONE GPU
+    (here the same one), bench.py falls back to one rank per GPU by itself, checks the shares against the one-GPU
+    results and prints one line."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="0")
+    for v in ("G2S_RESIDENT", "G2S_DEVICE_D2"):
+        env.pop(v, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--gaps", "3000"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["config"]["mode"] == "rank_per_gpu" and out["n_gpus"] == 2 and out["equals_one_gpu_result"] is True
+    assert out["filled"] == 3000 and out["value"] > 0 and out["scaling"] == "strong"
+    assert out["config"]["devices_seen_by_rank"] == [1, 1]

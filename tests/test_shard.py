@@ -7,6 +7,8 @@ import json
 import os
 import socket
 import subprocess
+
+import pytest
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -79,3 +81,64 @@ def test_bench_refuses_more_gpus_than_there_are():
                          capture_output=True, text=True, timeout=600)
     assert res.returncode != 0
     assert "device" in (res.stdout + res.stderr)
+
+
+# ---- round 6: one rank per GPU (a launcher that pins a device per rank): the shares of a list placed in the one
+# rand() stream by two all-gathers of host scalars (gap2seq_amd/shard.py: place_shares, DistComm, fill_share)
+def test_place_shares_composes_the_share_functions():
+    from gap2seq_amd import shard
+    assert shard.share_bounds(10, 3) == [(0, 3), (3, 6), (6, 10)]
+    assert shard.share_bounds(2, 4) == [(0, 0), (0, 1), (1, 1), (1, 2)]
+    totals = [(100, 3), (50, 0), (70, 2)]
+    base0, R0, d_in, draws = shard.place_shares(totals, None)
+    assert (base0, R0, d_in, draws) == ([0, 100, 150], [0, 3, 3], None, None)
+    # share 0 starts at deviation 0 and leaves 2; share 1 has no draw-dependent gap (identity on 0 .. 3); share 2 maps 2 -> 4
+    fns = [[2], [0, 1, 2, 3], [0, 1, 4, 5]]
+    base0, R0, d_in, draws = shard.place_shares(totals, fns)
+    assert d_in == [0, 2, 2] and draws == 100 + 50 + 70 + 4
+    # a deviation beyond what a function lists reads its last entry (the C side clamps the same way)
+    assert shard.place_shares([(10, 1), (10, 0)], [[5], [7]])[2:] == ([0, 5], 20 + 7)
+    c = shard.LocalComm()
+    assert c.all_gather([1, 2, 3]) == [[1, 2, 3]] and (c.rank, c.world) == (0, 1)
+
+
+@pytest.mark.parametrize("seed,skip", [(1, 0), (1, 1), (42, 30), (7, 31), (1, 4095), (20240101, 5000000), (3, (1 << 33) + 12345)])
+def test_a_jump_over_values_drawn_elsewhere_lands_in_the_same_stream(product, seed, skip):
+    """g2s_share_end moves a rank's generator past the whole list — drawn on other ranks' devices — by the
+    recurrence's jump polynomial; the stream behind it is the one reached by drawing (checked against libc's rand()
+    by test_host.py) wherever materialising that many values is feasible, and consistent with two shorter jumps beyond."""
+    n = 200
+    if skip <= 6000000:
+        assert product.test_rand_skip(seed, skip, n) == product.test_rand_stream(seed, skip, n)
+    else:
+        a = product.test_rand_skip(seed, skip, n)
+        assert a[100:] == product.test_rand_skip(seed, skip + 100, 100)
+        assert a != product.test_rand_skip(seed, skip + 1, n)
+
+
+def test_dist_comm_all_gather_two_ranks_gloo(tmp_path):
+    """The exchange fill_share runs between the steps of a share: lists of integers of different lengths per rank,
+    over gloo, every rank receiving every rank's."""
+    script = tmp_path / "ag.py"
+    script.write_text(
+        "import os, sys, json\n"
+        "sys.path.insert(0, %r)\n"
+        "import torch.distributed as dist\n"
+        "from gap2seq_amd import shard\n"
+        "dist.init_process_group('gloo')\n"
+        "c = shard.DistComm(dist)\n"
+        "mine = [c.rank + 1] * (3 + 4 * c.rank) + [1 << 40]\n"
+        "got = c.all_gather(mine)\n"
+        "empty = c.all_gather([] if c.rank else [9])\n"
+        "fixed = c.all_gather([7, c.rank], 5)\n"
+        "print(json.dumps({'rank': c.rank, 'got': got, 'empty': empty, 'fixed': fixed}))\n"
+        "dist.destroy_process_group()\n" % ROOT)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(script)]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    rows = [json.loads(ln) for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert sorted(r["rank"] for r in rows) == [0, 1]
+    want = [[1, 1, 1, 1 << 40], [2] * 7 + [1 << 40]]
+    for r in rows:
+        assert r["got"] == want and r["empty"] == [[9], []] and r["fixed"] == [[7, 0], [7, 1]]
