@@ -1056,6 +1056,8 @@ extern "C" int g2s_batch_prepare(g2s_session* s, const g2s_gap* gaps, size_t n, 
       P.arena_bytes += j.buf_bytes(k, d_err);
     }
   };
+  // (on the pool although one thread takes this pass in 42 us against 55-67: the pass behind it then finds the workers
+  // awake — on one thread here that pass took 150-370 us instead of 35, LAB_NOTES round 6)
   if (ntasks > 4) s->pool->run(ntasks, size_range);
   else for (size_t t = 0; t < ntasks; t++) size_range(t);
   std::vector<size_t> base_nodes(ntasks + 1), base_text(ntasks + 1), base_desc(ntasks + 1), base_arena(ntasks + 1);
@@ -2795,6 +2797,10 @@ static int resident_targets(g2s_session* s, g2s_result* results, char* arena, si
 static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl, g2s_result* results = nullptr, char* arena = nullptr) {
   g2s_session* s = b->s;
   const size_t n = b->jobs.size();
+  static const bool dbg_laps = getenv("G2S_DEBUG") != nullptr;
+  auto t_lap = std::chrono::steady_clock::now();
+  double laps_us[6] = {0, 0, 0, 0, 0, 0};
+  auto lap = [&](int q) { if (!dbg_laps) return; const auto now = std::chrono::steady_clock::now(); laps_us[q] += std::chrono::duration<double, std::micro>(now - t_lap).count(); t_lap = now; };
   if (!resident_applicable(s, n) || !b->seg_tier_all || b->host_lookup) return 1;
   const Graph& g = *s->graph->g;
   const DeviceGraph& dg = g.dev.at(s->device);
@@ -2846,6 +2852,7 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl, g2s_result* re
     std::stable_sort(ids.begin() + (ptrdiff_t)w, ids.end(), [&](uint32_t a2, uint32_t b2) { return b->jobs[a2].g > b->jobs[b2].g; });
   }
   const size_t n_reg = ids.size() - n_early;
+  lap(0);
   HIP_TRY_S(s->h_gaps.ensure(n * sizeof(GapDev) + n * 4 + 16));
   HIP_TRY_S(s->h_d3.ensure(n * sizeof(D3Gap) + 2048 + 64 * 128 + G2S_RAND_WINDOW * 4));
   GapLite* gd = (GapLite*)s->h_gaps.p;  // (the short records: fill_device.h — the kernels expand them with the list's constants)
@@ -2968,6 +2975,7 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl, g2s_result* re
     HIP_TRY_S(s->d_ovf.ensure(std::max<size_t>(ids.size() * 4, 16)));
     HIP_TRY_S(s->d_segx.ensure(fill_segw_scratch_bytes(segw_wgs)));
   }
+  lap(1);
   hipStream_t st = s->stream;
   void* d_gaps_host = nullptr;
   HIP_TRY_S(hipHostGetDevicePointer(&d_gaps_host, s->h_gaps.p, 0));
@@ -3075,6 +3083,7 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl, g2s_result* re
     HIP_TRY_S(launch_d2_poll(s->stream3, DP, d2_poll_wgs, (uint32_t*)s->d_d2scr_small.p, (uint32_t*)s->d_d2list.p + n,
                              (unsigned long long*)s->d_counter.p + 6));
   }
+  lap(2);
   rl->timed = kernel_events_on(s);
   if (rl->timed) HIP_TRY_S(hipEventRecord(s->ev[1], st));
   // (the flank look-ups in this kernel's waves: every valid gap of such a list is in this launch — inline_ok excludes
@@ -3111,6 +3120,7 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl, g2s_result* re
                           early_reg ? &early_dev : nullptr, (use_tr && tr.chu) ? &tr : nullptr, gaps_dev, lite_e, lite_ap));
   if (use_inl) { b->inline_pending = false; b->nodes_dev_only = true; }  // (behind this kernel d_flank holds the ids; the pinned copy those of the host's gaps)
   s->lap_fill_queued = std::chrono::steady_clock::now();
+  lap(3);
   if (rl->timed) HIP_TRY_S(hipEventRecord(s->ev[2], st));
   // (queued BEHIND the regular tier's kernel, which takes the compute units first — a workgroup of the large variant
   // needs a whole unit's LDS and stays for the launch: started first, 256 of them leave the regular tier no unit until
@@ -3151,6 +3161,10 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl, g2s_result* re
   rl->units = out_states;
   rl->two_waves = two_waves;
   rl->launched = ids.size();
+  lap(4);
+  if (dbg_laps && n >= 1024)
+    fprintf(stderr, "[g2s] fill launch of %zu gaps (us): launch order %.1f, descriptors + buffers %.1f, copies + events %.1f, fill kernel queued %.1f, the kernels behind it %.1f\n",
+            n, laps_us[0], laps_us[1], laps_us[2], laps_us[3], laps_us[4]);
   return G2S_OK;
 }
 // the buffers a fill launch used are reset for the next one, off its critical path
@@ -3709,8 +3723,10 @@ static int run_resident_queue(g2s_batch* b, g2s_result* results, char* arena, bo
   // (the stream of rand() values first: it does not depend on the list's kernels — if the list turns out not to be
   // for this mode, a few microseconds of one kernel were for nothing)
   bool rand_launched = false;
-  // (a long list only: its look-up kernel and launch preparation leave the stream 50 us to fill in; on a short
-  // list the two launches would delay the fill kernel's by 10 us, and its stream is short enough to fill beside it)
+  // (a long list only: its launch preparation leaves the stream 50 us to fill in; on a short list the two launches would
+  // delay the fill kernel's by 10 us, and its stream is short enough to fill beside it.  Round 6, measured: queued BEHIND
+  // the fill kernel's launch instead, the host reaches that launch 8 us earlier and the kernel, with the stream's 2 741
+  // waves beside its first generation, takes 6 us longer — 0.739-0.829 against 0.764-0.820 ms alternating: kept in front)
   if (!b->pre_launched && n > 3072 && resident_applicable(s, n) && b->seg_tier_all && !b->host_lookup && b->rnd_cap < (1ull << 31) &&
       s->h_d3.cap >= n * sizeof(D3Gap) + 2048 + 64 * 128 + G2S_RAND_WINDOW * 4) {  // (pinned window in place: the launch below will not move it)
     const int rc = resident_rand(s, &s->h_d3, n, b->rnd_cap);
