@@ -48,6 +48,7 @@
 
 #include "../../include/g2s.h"
 #include "d3_device.h"
+#include "envcache.hpp"
 
 namespace {
 
@@ -1659,7 +1660,7 @@ hipError_t launch_d3(hipStream_t st, const D3Params& P, const D3Work& W, const G
   }
   const size_t lds = (size_t)P.seg_cap * (sizeof(SegRec) + 16) + (size_t)P.map_cap * 8 + 16;  // closure, base map, rand() values, the walk's segments
   // (a short list: four waves per gap — the kernel is its slowest gap, and the chip has the wave slots)
-  const char* waves_s = getenv("G2S_TRACE_WAVES");  // (read per launch: the tests switch it within a process)
+  const char* waves_s = GENV("G2S_TRACE_WAVES");  // (read per launch: the tests switch it within a process)
   const int waves_env = waves_s ? atoi(waves_s) : 0;
   const bool four = waves_env ? waves_env == 4 : P.n <= 768u;  // (2 000 gaps on four waves each: 1-2 % slower than on one)
   e = hipFuncSetAttribute(four ? (const void*)g2s_d3_trace<4> : (const void*)g2s_d3_trace<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

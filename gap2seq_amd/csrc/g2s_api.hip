@@ -27,6 +27,7 @@
 
 #include "../../include/g2s.h"
 #include "../../include/g2s_test.h"
+#include "envcache.hpp"
 #include "d2_device.h"
 #include "d3_device.h"
 #include "dbg.hpp"
@@ -204,6 +205,7 @@ extern "C" int g2s_graph_node_string(const g2s_graph* g, uint32_t node, char* ou
 }
 
 extern "C" int g2s_graph_upload(g2s_graph* gh, int device) {
+  g2s_env_sync();
   if (!gh) return fail(G2S_ERR_ARG, "g2s_graph_upload: null graph");
   Graph& g = *gh->g;
   if (g.dev.count(device)) return G2S_OK;
@@ -290,7 +292,7 @@ inline uint32_t pow2ceil(uint64_t x) {
 // diagnostics: G2S_PROGRESS_FILE=path appends one line per kernel launch / completion (opened and closed per
 // line, so that the file is complete even when the process has to be abandoned)
 static void progress_note(const char* fmt, ...) {
-  const char* path = getenv("G2S_PROGRESS_FILE");
+  const char* path = GENV("G2S_PROGRESS_FILE");
   if (!path) return;
   if (FILE* f = fopen(path, "a")) {
     va_list ap;
@@ -383,7 +385,7 @@ class WorkerPool {
     // they read were copied into pinned memory of that node, and what they write is read
     // back by that thread
     cpu_set_t node;
-    if (!getenv("G2S_NO_NUMA_BIND") && local_node_cpus(&node))
+    if (!GENV("G2S_NO_NUMA_BIND") && local_node_cpus(&node))
       for (auto& t : th_) pthread_setaffinity_np(t.native_handle(), sizeof node, &node);
   }
   ~WorkerPool() {
@@ -679,6 +681,7 @@ struct InternalCall {
 }  // namespace
 
 extern "C" int g2s_session_create(g2s_graph* g, int device, const g2s_params* p, g2s_session** out) {
+  g2s_env_sync();
   if (!g || !p || !out) return fail(G2S_ERR_ARG, "g2s_session_create: bad argument");
   int rc = g2s_graph_upload(g, device);
   if (rc != G2S_OK) return rc;
@@ -731,7 +734,7 @@ extern "C" int g2s_session_create(g2s_graph* g, int device, const g2s_params* p,
     s->rtab.hi = (const uint32_t*)s->d_rtab.p;
     s->rtab.mid = s->rtab.hi + 128 * 31;
     s->rtab.lane = s->rtab.mid + 256 * 31;
-    if (const char* env = getenv("G2S_RESIDENT")) s->resident_off = atoi(env) == 0;
+    if (const char* env = GENV("G2S_RESIDENT")) s->resident_off = atoi(env) == 0;
   }
   s->graph = g;
   s->device = device;
@@ -739,7 +742,7 @@ extern "C" int g2s_session_create(g2s_graph* g, int device, const g2s_params* p,
   memset(&s->last_timing, 0, sizeof s->last_timing);
   // srand((randseed > 0) ? randseed : time(NULL)) (Gap2Seq.cpp:178); params keep the user's value for the echo (:191)
   s->rcache.seed(p->randseed > 0 ? p->randseed : (uint32_t)time(nullptr));
-  if (const char* env = getenv("G2S_NO_LDS_TIER")) s->no_lds_tier = atoi(env) != 0;
+  if (const char* env = GENV("G2S_NO_LDS_TIER")) s->no_lds_tier = atoi(env) != 0;
   hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_rand, hipEventDisableTiming);
@@ -785,7 +788,7 @@ extern "C" void g2s_session_destroy(g2s_session* s) {
         for (int q = 0; q < 11; q++) fprintf(stderr, " %s %llu", names[q], pr[q]);
         fprintf(stderr, " | beyond the capacities %llu, given up %llu\n", pr[14], pr[15]);
       }
-    if (const char* path = getenv("G2S_D2_LOG"))  // (one line per closure taken: tools/d2_log.py)
+    if (const char* path = GENV("G2S_D2_LOG"))  // (one line per closure taken: tools/d2_log.py)
       if (s->d_d2log.p) {
         std::vector<unsigned long long> lg(16u * 8192u);
         if (hipMemcpy(lg.data(), s->d_d2log.p, lg.size() * 8, hipMemcpyDeviceToHost) == hipSuccess)
@@ -962,13 +965,13 @@ static TierData* take_tier(g2s_session* s, size_t /*unused*/) {
 // Can a list of n gaps be finished on the device (run_resident)?  The checks that do not look at the gaps.
 static bool resident_applicable(const g2s_session* s, size_t n) {
   if (s->resident_off || n == 0) return false;
-  const int forced = getenv("G2S_RESIDENT") ? atoi(getenv("G2S_RESIDENT")) : -1;  // (1: lists of any length; 0: never)
+  const int forced = GENV("G2S_RESIDENT") ? atoi(GENV("G2S_RESIDENT")) : -1;  // (1: lists of any length; 0: never)
   // (lists of a few dozen gaps: the host analyses gaps while the launch's stragglers run and is done before four
   // more launches would be; measured on config 2's 500 gaps: 0.32 ms on the device against 0.35-0.39 ms.  The
   // groups of a team's list may be short: the list is what counts)
   if (forced == 0 || (forced != 1 && !s->in_team_list && n < 256)) return false;
-  if (getenv("G2S_NO_SEG_TIER") || getenv("G2S_FORCE_SEGX") || getenv("G2S_HOST_D2") || getenv("G2S_SEG_DUMP") ||
-      getenv("G2S_DUMP_STATS") || getenv("G2S_NO_LDS_TIER") || getenv("G2S_STATE_D2"))
+  if (GENV("G2S_NO_SEG_TIER") || GENV("G2S_FORCE_SEGX") || GENV("G2S_HOST_D2") || GENV("G2S_SEG_DUMP") ||
+      GENV("G2S_DUMP_STATS") || GENV("G2S_NO_LDS_TIER") || GENV("G2S_STATE_D2"))
     return false;
   const Graph& g = *s->graph->g;
   auto it = g.dev.find(s->device);
@@ -978,6 +981,7 @@ static bool resident_applicable(const g2s_session* s, size_t n) {
 }
 
 extern "C" int g2s_batch_prepare(g2s_session* s, const g2s_gap* gaps, size_t n, g2s_batch** out) {
+  g2s_env_sync();
   if (!s || (!gaps && n) || !out) return fail(G2S_ERR_ARG, "g2s_batch_prepare: bad argument");
   REFUSE_IN_FLIGHT(s, "g2s_batch_prepare");
   const Graph& g = *s->graph->g;
@@ -1005,7 +1009,7 @@ extern "C" int g2s_batch_prepare(g2s_session* s, const g2s_gap* gaps, size_t n, 
   std::vector<uint32_t>& didx = s->spare_u32[2];  // (didx: descriptor index of every valid gap)
   text_off.resize(n);
   didx.resize(n);
-  const bool force_host_lookup = getenv("G2S_HOST_LOOKUP") != nullptr;
+  const bool force_host_lookup = GENV("G2S_HOST_LOOKUP") != nullptr;
   static const size_t max_tasks = getenv("G2S_PREP_TASKS") ? (size_t)std::max(1, atoi(getenv("G2S_PREP_TASKS"))) : 16;
   const size_t per_task = std::max<size_t>(256, (n + max_tasks - 1) / max_tasks);  // (at most 16 tasks: every task wakes a thread)
   const size_t ntasks = (n + per_task - 1) / per_task;
@@ -1093,9 +1097,9 @@ extern "C" int g2s_batch_prepare(g2s_session* s, const g2s_gap* gaps, size_t n, 
   // whose longest gaps start in the large variant; G2S_FLANK_KERNEL=1: the look-up kernel as until round 5.  A list
   // without a bad flank gets its text at a FIXED STRIDE: when the launch takes the gaps in list order, a wave knows
   // where its text is before its descriptor has arrived — on a short list both come over the link.)
-  b->inline_ok = fast_gd != nullptr && b->dmax < 2500 && !getenv("G2S_FLANK_KERNEL");
+  b->inline_ok = fast_gd != nullptr && b->dmax < 2500 && !GENV("G2S_FLANK_KERNEL");
   uint32_t tstride = 0;
-  if (b->inline_ok && n_desc == n && tb_max <= 508 && !getenv("G2S_NO_TEXT_STRIDE")) {
+  if (b->inline_ok && n_desc == n && tb_max <= 508 && !GENV("G2S_NO_TEXT_STRIDE")) {
     tstride = (uint32_t)((tb_max + 3) & ~(size_t)3);
     if ((uint64_t)n * tstride < (1ull << 31)) text_bytes = (size_t)n * tstride; else tstride = 0;
   }
@@ -1172,7 +1176,7 @@ extern "C" int g2s_batch_prepare(g2s_session* s, const g2s_gap* gaps, size_t n, 
   const auto tp2 = std::chrono::steady_clock::now();
   const int rc = b->upload_flanks(true);
   if (rc != G2S_OK) { delete b; return rc; }
-  if (n >= 1024 && getenv("G2S_DEBUG"))
+  if (n >= 1024 && GENV("G2S_DEBUG"))
     fprintf(stderr, "[g2s] prepare: sizes %.3f ms, text + descriptors %.3f ms, look-up launch %.3f ms\n",
             std::chrono::duration<double, std::milli>(tp1 - tp0).count(), std::chrono::duration<double, std::milli>(tp2 - tp1).count(),
             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp2).count());
@@ -1227,7 +1231,7 @@ int g2s_batch::upload_flanks(bool allow_inline) {
       // (a long list: descriptors and flank text go to device memory in one copy in front of the kernel — 10 000
       // workgroups that each read their descriptor and then their text over the link are two round trips of the link
       // each: 0.10 ms for config 3's list, against a 1.5 MB copy and a kernel that reads device memory)
-      if (e == hipSuccess && n_desc > 2048 && !getenv("G2S_FLANKS_OVER_THE_LINK") && !staged) {
+      if (e == hipSuccess && n_desc > 2048 && !GENV("G2S_FLANKS_OVER_THE_LINK") && !staged) {
         const size_t bytes = (size_t)((const char*)nodes - (const char*)desc);  // [descriptors][text], contiguous
         e = s->d_fstage.ensure(bytes);
         if (e == hipSuccess) e = hipMemcpyAsync(s->d_fstage.p, desc, bytes, hipMemcpyHostToDevice, s->stream);
@@ -1430,16 +1434,16 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
       gaps_dev = (const GapDev*)s->d_gaps.p;
       ids_dev = (const uint32_t*)s->d_ids.p;
     }
-    const char* seg_dump = seg ? getenv("G2S_SEG_DUMP") : nullptr;  // diagnostics: phase A entries + segments of every gap
+    const char* seg_dump = seg ? GENV("G2S_SEG_DUMP") : nullptr;  // diagnostics: phase A entries + segments of every gap
     const uint32_t seg_dbg_w = seg == 2 ? fill_segx_dbg_words() : fill_seg_dbg_words();
-    const bool seg_two_waves = getenv("G2S_SEG_WAVES") ? atoi(getenv("G2S_SEG_WAVES")) == 2 : ids.size() <= 2048;
+    const bool seg_two_waves = GENV("G2S_SEG_WAVES") ? atoi(GENV("G2S_SEG_WAVES")) == 2 : ids.size() <= 2048;
     if (seg == 1 && seg_two_waves) b->timing.seg2_launches++;
     // long lists: finished gaps are announced in batches of 16 per XCD (one L2 write-back per batch instead of per
     // gap; fill_seg.hip, `publish`): config 3's launch 0.8 -> 0.48 ms.  Short lists announce every gap by itself:
     // their launch ends with its slowest gap either way (config 2: 0.152 ms with batches of 4, 0.153 without), and
     // the gaps of unfinished batches would be analysed behind the launch's end instead of under it (config 2's
     // step 0.39 ms against 0.37).  G2S_PUBLISH_BATCH=N forces (1 = every gap by itself).
-    uint32_t pub_batch = getenv("G2S_PUBLISH_BATCH") ? (uint32_t)atoi(getenv("G2S_PUBLISH_BATCH")) : (ids.size() <= 2048 ? 1u : 16u);
+    uint32_t pub_batch = GENV("G2S_PUBLISH_BATCH") ? (uint32_t)atoi(GENV("G2S_PUBLISH_BATCH")) : (ids.size() <= 2048 ? 1u : 16u);
     size_t xcd_bytes = 0;
     if (seg == 1 && pub_batch > 1) {
       xcd_bytes = 64 + 8 * ids.size() * 4;
@@ -1597,7 +1601,7 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
         }
       }
       prctl(PR_SET_TIMERSLACK, old_slack > 0 ? (unsigned long)old_slack : 50000UL, 0, 0, 0);
-      if (getenv("G2S_DEBUG"))
+      if (GENV("G2S_DEBUG"))
         fprintf(stderr, "[g2s] run_tier: first gap seen %.3f ms after the launch call, kernel seen finished at %.3f ms\n", dbg_first, dbg_fin);
     }
     const auto t_polled = std::chrono::steady_clock::now();
@@ -1609,7 +1613,7 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
       const uint32_t ecap = seg == 2 ? G2S_SEGX_EA : 64u * G2S_SEG_ASETS, scap = seg == 2 ? G2S_SEGX_CAP : G2S_SEG_CAP;
       std::vector<uint32_t> h((size_t)ids.size() * W);
       HIP_TRY(hipMemcpy(h.data(), seg_dbg, h.size() * 4, hipMemcpyDeviceToHost));
-      if (FILE* f = fopen(getenv("G2S_SEG_DUMP"), "a")) {
+      if (FILE* f = fopen(GENV("G2S_SEG_DUMP"), "a")) {
         const uint32_t sb0 = 8u + 2u * ecap;
         for (size_t x = 0; x < ids.size(); x++) {
           const uint32_t* o = h.data() + x * W;
@@ -1619,7 +1623,7 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
                     o[W - 10], o[W - 9]);
           if (o[W - 14] | o[W - 13] | o[W - 12] | o[W - 11])  // (the same builds, one wave per gap) cycles of phase A's sections
             fprintf(f, "PA %u %u %u %u\n", o[W - 14], o[W - 13], o[W - 12], o[W - 11]);
-          if (getenv("G2S_SEG_DUMP_BRIEF")) continue;  // (profiles: no entries, no segments)
+          if (GENV("G2S_SEG_DUMP_BRIEF")) continue;  // (profiles: no entries, no segments)
           for (uint32_t e = 0; e < o[1] && e < ecap; e++) fprintf(f, "A %u %u\n", o[8 + 2 * e], o[9 + 2 * e]);
           for (uint32_t q = 0; q < o[2] && q < scap; q++)
             fprintf(f, "S %u %u %u %u %#x %#x %u\n", o[sb0 + 6 * q], o[sb0 + 6 * q + 1] & 0xFFFF, o[sb0 + 6 * q + 1] >> 16,
@@ -1643,7 +1647,7 @@ int run_tier(g2s_batch* b, const std::vector<uint32_t>& ids, uint64_t scale, uin
         s->d_rspool.clean = pool_bytes_used;
       }
     }
-    if (getenv("G2S_DEBUG"))
+    if (GENV("G2S_DEBUG"))
       fprintf(stderr, "[g2s] run_tier: plan+upload+launch %.3f ms, polling/analysis %.3f ms, final sync %.3f ms\n",
               std::chrono::duration<double, std::milli>(t_launched - t_enter).count(),
               std::chrono::duration<double, std::milli>(t_polled - t_launched).count(),
@@ -1833,7 +1837,7 @@ int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
   const Graph& g = *s->graph->g;
   const size_t n = b->jobs.size();
   auto t_begin = std::chrono::steady_clock::now();
-  const bool dbg_laps = getenv("G2S_DEBUG") != nullptr;
+  const bool dbg_laps = GENV("G2S_DEBUG") != nullptr;
   auto t_lap = t_begin;
   auto lap = [&](const char* what) {  // (diagnostics) where stage 1 spends its time outside the launches
     if (!dbg_laps) return;
@@ -1844,8 +1848,8 @@ int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
   { const int rc = b->upload_flanks(); if (rc != G2S_OK) return rc; }
   { const int rc = b->fetch_nodes(); if (rc != G2S_OK) return rc; }  // (a list resident mode gave back: the kernel kept most node ids on the device)
   b->drop_tiers();
-  b->force_host_d2 = getenv("G2S_HOST_D2") != nullptr;
-  if (getenv("G2S_DEBUG")) fprintf(stderr, "[g2s] stage 1 begins\n");
+  b->force_host_d2 = GENV("G2S_HOST_D2") != nullptr;
+  if (GENV("G2S_DEBUG")) fprintf(stderr, "[g2s] stage 1 begins\n");
   lap("flank upload");
   g2s_timing keep = b->timing;
   memset(&b->timing, 0, sizeof b->timing);
@@ -2007,7 +2011,7 @@ int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
   // ---- segment tier first (fill_seg.hip): every gap it can hold (odd k, -fuz <= 31, D < 2^15);
   // a gap that outgrows one of its capacities comes back flagged and takes the passes below
   std::vector<char> seg_done(n, 0);
-  const bool seg_ok = lds_ok && s->graph->g->dev.at(s->device).rem != nullptr && !getenv("G2S_NO_SEG_TIER");
+  const bool seg_ok = lds_ok && s->graph->g->dev.at(s->device).rem != nullptr && !GENV("G2S_NO_SEG_TIER");
   if (seg_ok) {
     std::vector<uint32_t> seg_ids;
     for (size_t i = 0; i < n; i++) {
@@ -2019,10 +2023,10 @@ int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
     // mode 1 (-dist-error 2000: thousands of segments and right-set entries); what outgrows that too takes
     // the passes below
     // (tests: G2S_FORCE_SEGX=1 sends every gap to the large variant, G2S_NO_SEGX_TIER=1 none)
-    for (int mode = getenv("G2S_FORCE_SEGX") ? 2 : 1; mode <= 2 && !seg_ids.empty(); mode++) {
-      if (mode == 2 && getenv("G2S_NO_SEGX_TIER")) break;
+    for (int mode = GENV("G2S_FORCE_SEGX") ? 2 : 1; mode <= 2 && !seg_ids.empty(); mode++) {
+      if (mode == 2 && GENV("G2S_NO_SEGX_TIER")) break;
       // longest searches first (see below): always for the large variant, whose workgroups take the list in order
-      if ((seg_ids.size() > 1024 || mode == 2) && !getenv("G2S_NO_LPT")) {
+      if ((seg_ids.size() > 1024 || mode == 2) && !GENV("G2S_NO_LPT")) {
         // (a stable counting sort by gap length, longest first: a comparison sort of 10 000 ids cost 0.3 ms)
         int gmax = 0;
         for (uint32_t i : seg_ids) gmax = std::max(gmax, b->jobs[i].g);
@@ -2065,7 +2069,7 @@ int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
         }
         const GapOut& go = outs[i];
         if (go.flags & (G2S_DEV_OVERFLOW_A | G2S_DEV_OVERFLOW_B)) {
-          if (getenv("G2S_DEBUG"))
+          if (GENV("G2S_DEBUG"))
             fprintf(stderr, "[g2s] gap %u left the segment tier (mode %d): flags 0x%x entries %u segments %u g %d\n", i, mode,
                     go.flags, go.stat[1], go.stat[3], b->jobs[i].g);
           if (go.flags & G2S_DEV_WATCHDOG) {  // a defect, never expected: say so, the gap is filled by the LDS tier
@@ -2092,7 +2096,7 @@ int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
         if (mode == 2) b->timing.segx_tier_gaps++; else b->timing.seg_tier_gaps++;
         b->timing.seg_segments += go.stat[3];
       }
-      if (const char* dump = getenv("G2S_DUMP_STATS")) {
+      if (const char* dump = GENV("G2S_DUMP_STATS")) {
         if (FILE* f = fopen(dump, "a")) {
           fprintf(f, "# segment tier%s: gap g flags A_rounds A_entries B_rounds segments cycA cycB 0 0 cycD n_right x_right n_states x_left n_sub 0\n",
                   mode == 2 ? " (large variant)" : "");
@@ -2105,7 +2109,7 @@ int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
           fclose(f);
         }
       }
-      if (getenv("G2S_DEBUG")) {
+      if (GENV("G2S_DEBUG")) {
         std::vector<uint32_t> ord(seg_ids);
         std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t c) {
           return outs[a].stat[4] + outs[a].stat[5] + outs[a].stat[7] > outs[c].stat[4] + outs[c].stat[5] + outs[c].stat[7]; });
@@ -2148,7 +2152,7 @@ int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
     // Workgroups are dispatched in id order and a launch ends with its slowest gap: start the
     // gaps with the most DP levels first, so that the long ones are not the last to begin
     // (lists longer than the chip holds at once; G2S_NO_LPT=1 keeps the input order).
-    if (cand[pass].size() > 1024 && !getenv("G2S_NO_LPT"))
+    if (cand[pass].size() > 1024 && !GENV("G2S_NO_LPT"))
       std::stable_sort(cand[pass].begin(), cand[pass].end(),
                        [&](uint32_t a, uint32_t c) { return b->jobs[a].g > b->jobs[c].g; });
     const std::vector<uint32_t>& ids = cand[pass];
@@ -2165,7 +2169,7 @@ int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
     for (uint32_t i : ids) {
       const GapOut& go = outs[i];
       if (go.flags & (G2S_DEV_OVERFLOW_A | G2S_DEV_OVERFLOW_B)) {
-        if (getenv("G2S_DEBUG"))
+        if (GENV("G2S_DEBUG"))
           fprintf(stderr, "[g2s] gap %u left LDS pass %d: flags 0x%x n_right %u x_right %u n_states %u x_left %u final_d %d g %d\n",
                   i, pass, go.flags, go.n_right, go.x_right, go.n_states, go.x_left, go.final_d, b->jobs[i].g);
         // a right-set overflow is cured by a larger right set (pass 1 unless pass 0 already
@@ -2196,7 +2200,7 @@ int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
       b->timing.log_pool_gaps += (go.flags & G2S_DEV_LOG_POOL) != 0;
       b->timing.rs_pool_gaps += (go.flags & G2S_DEV_RS_POOL) != 0;
     }
-    if (const char* dump = getenv("G2S_DUMP_STATS")) {  // diagnostics: one line per gap of this pass (appended)
+    if (const char* dump = GENV("G2S_DUMP_STATS")) {  // diagnostics: one line per gap of this pass (appended)
       if (FILE* f = fopen(dump, "a")) {
         fprintf(f, "# pass %d: gap g flags A_steps A_rounds B_slow B_bulk cycA cycB D_slow D_bulk cycD n_right x_right n_states x_left n_sub top_level\n", pass);
         for (uint32_t i : ids) {
@@ -2208,7 +2212,7 @@ int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
         fclose(f);
       }
     }
-    if (getenv("G2S_DEBUG")) {  // the slowest gaps of the LDS tier and why
+    if (GENV("G2S_DEBUG")) {  // the slowest gaps of the LDS tier and why
       std::vector<uint32_t> ord(ids);
       std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t c) {
         return outs[a].stat[4] + outs[a].stat[5] + outs[a].stat[7] > outs[c].stat[4] + outs[c].stat[5] + outs[c].stat[7]; });
@@ -2307,7 +2311,7 @@ int batch_stage1(g2s_batch* b, bool analyze, g2s_result* results) {
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_post).count();
     b->timing.ms_host_post = ms + ms_stream;  // ms_stream overlapped the kernels
     b->timing.ms_total += ms;
-    if (getenv("G2S_DEBUG")) {
+    if (GENV("G2S_DEBUG")) {
       fprintf(stderr, "[g2s] analysis: %.3f ms while the kernels ran, %.3f ms after (%zu gaps)\n", ms_stream, ms, fresh.size());
       fprintf(stderr, "[g2s] analysis on the host: %llu closures on segments %.3f ms; %llu on per-state records (a k-mer at two depths) %.3f ms, %llu states\n",
               (unsigned long long)dbg_n_seg.exchange(0), dbg_ns_seg.exchange(0) / 1e6, (unsigned long long)dbg_n_state.exchange(0),
@@ -2624,7 +2628,7 @@ int batches_stage2(const std::vector<g2s_batch*>& bs, g2s_session* lead, g2s_res
           // cannot happen: the draw count was proven fixed, or counted over the same draws
           if (r.draws != expect_draws[gi]) {
             r.flags |= G2S_GAP_BACKTRACE_FAIL;
-            if (getenv("G2S_DEBUG_DRAWS")) {
+            if (GENV("G2S_DEBUG_DRAWS")) {
               const SubView& vw = b->views[i];
               const GapOut& go = *vw.out;
               fprintf(stderr, "[g2s] gap %zu: traceback drew %d values, %d expected; seg mode %d, n_len %d lens %d %d start_seg %#x start_t %#x fixed %d %d stop %#x %#x n_segs %u n_xl %u flags %#x dflags %#x rand %u %u offset %llu\n",
@@ -2655,7 +2659,7 @@ int batches_stage2(const std::vector<g2s_batch*>& bs, g2s_session* lead, g2s_res
   if (jobs_in_flight) lead->pool->finish();
   lead->rcache.consume(draws_used);
   auto t_end = std::chrono::steady_clock::now();
-  if (getenv("G2S_DEBUG"))
+  if (GENV("G2S_DEBUG"))
     fprintf(stderr, "[g2s] host stage 2 (%s analysis): %.3f ms = setup+analysis %.3f + block pass %.3f + in-order pass %.3f (draw-count walks %.3f; %zu gaps traced inline, %zu with two lengths, %zu not traced by the analysis) + tracebacks\n",
             analyze ? "with" : "after", std::chrono::duration<double, std::milli>(t_end - t_begin).count(), ms_ana, ms_blocks, ms_order,
             ms_walks, n_inline, n_two, n_rest);
@@ -2767,7 +2771,7 @@ struct ResidentLaunch {
 // event between two kernels costs the stream 4-5 us, three of them 4 % of a 500-gap list's step, and the product
 // has no use for the durations — bench.py and the tests read them.  G2S_KERNEL_TIMING=all|off|sample:N overrides.
 static bool kernel_events_on(g2s_session* s) {
-  const char* m = getenv("G2S_KERNEL_TIMING");
+  const char* m = GENV("G2S_KERNEL_TIMING");
   const uint32_t seq = s->timed_seq++;
   if (m && !strcmp(m, "all")) return true;
   if (m && !strcmp(m, "off")) return false;
@@ -2814,7 +2818,7 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl, g2s_result* re
   ids.clear();
   ids.reserve(n);
   bool ids_identity = false;  // the launch takes the gaps in list order, all of them
-  if (b->n_valid > 1024 && !getenv("G2S_NO_LPT") && (size_t)gmax <= 8 * b->n_valid + 65536) {
+  if (b->n_valid > 1024 && !GENV("G2S_NO_LPT") && (size_t)gmax <= 8 * b->n_valid + 65536) {
     std::vector<uint32_t>& at = s->res_at;
     at.assign((size_t)gmax + 2, 0);
     for (size_t i = 0; i < n; i++) if (!b->jobs[i].bad_flank) at[(size_t)(gmax - b->jobs[i].g) + 1]++;
@@ -2832,10 +2836,10 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl, g2s_result* re
   // outgrown the regular tier anyway; the others cost the large variant's idle workgroups some work); the rest as
   // before.  ids: [the regular tier's gaps][the early launch's gaps].
   size_t n_early = 0;
-  const bool deep_list = b->dmax >= 2500 && !s->in_team_list && !getenv("G2S_NO_SEGX_TIER");
+  const bool deep_list = b->dmax >= 2500 && !s->in_team_list && !GENV("G2S_NO_SEGX_TIER");
   // (not beside other lists in flight: there the device is full, and the gaps the regular tier would have finished
   // cost the large variant more than an earlier start gains — 485 k against 343 k gaps/s with three lists in flight)
-  if (deep_list && ids.size() >= 256 && !b->others_in_flight && !getenv("G2S_NO_EARLY_SEGW")) {
+  if (deep_list && ids.size() >= 256 && !b->others_in_flight && !GENV("G2S_NO_EARLY_SEGW")) {
     int gmin = gmax;
     for (uint32_t i : ids) gmin = std::min(gmin, b->jobs[i].g);
     const int gcut = gmin + (int)(0.55 * (double)(gmax - gmin));
@@ -2891,7 +2895,7 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl, g2s_result* re
   // A gap that outgrows the regular tier's capacities runs again in the large variant, behind the fill kernel on
   // the stream, and stays on the device like the others (one such gap used to send the whole list to the host
   // path).  Not in a team's groups yet: their closure records are copied to the lead's device by size.
-  const bool rerun = (!s->in_team_list || s->team_sharded) && !getenv("G2S_NO_SEGX_TIER") && (s->segw_quiet < 8 || b->dmax >= 2500);
+  const bool rerun = (!s->in_team_list || s->team_sharded) && !GENV("G2S_NO_SEGX_TIER") && (s->segw_quiet < 8 || b->dmax >= 2500);
   rl->segw = rerun;
   // 16-byte units: two per closure segment (the large variant's closures: thousands of segments)
   const uint64_t out_states = (uint64_t)ids.size() * 128u + 2u * G2S_SEG_CAP + (rerun ? std::min<uint64_t>((uint64_t)ids.size() * 8192u, 4ull << 20) + 2u * G2S_SEGX_CAP : 0u);
@@ -2920,7 +2924,7 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl, g2s_result* re
   // host's threads with the early hand-over too: one wave per closure takes 4 ms where the host's pool takes 0.6 under
   // the launch.  G2S_DEVICE_D2=1 / 0: always / never.
   bool dev_d2 = (!s->in_team_list || s->team_sharded) && !s->params.skip_confident && !ids.empty();
-  if (const char* env = getenv("G2S_DEVICE_D2")) dev_d2 = dev_d2 && atoi(env) != 0;
+  if (const char* env = GENV("G2S_DEVICE_D2")) dev_d2 = dev_d2 && atoi(env) != 0;
   else {
     // (a deep list all the same when the host cannot give this session the threads: the processes of a launcher — one
     // rank per GPU — and the sessions of a team share the host's CPUs.  Config 5, profiles/r05_c5_host_threads.txt: the
@@ -2940,7 +2944,7 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl, g2s_result* re
   // workgroups want a whole compute unit's LDS each, find it only when the trace kernel's 10 000 workgroups have all but
   // left, and that kernel's last wave waits for them: 205 instead of 196 us.  G2S_D2_BIG=1 / 2: always / every closure
   // through it (tests); =0: never.)
-  const bool d2_big = dev_d2 && (getenv("G2S_D2_BIG") ? atoi(getenv("G2S_D2_BIG")) != 0 : d2_deep);
+  const bool d2_big = dev_d2 && (GENV("G2S_D2_BIG") ? atoi(GENV("G2S_D2_BIG")) != 0 : d2_deep);
   // G2S_D2_POLL=1 (measurements): a few workgroups of the small instantiation run BESIDE the fill kernel and take the
   // closures as their gaps end (the fill launch ends with its slowest gaps: most of its wave slots are empty for its
   // last third) — what is listed late is taken by the launch behind the fill kernels.  Not on deep lists (the large
@@ -2948,13 +2952,13 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl, g2s_result* re
   // the fill kernel's stream (a polling kernel in front of the fill kernel in one queue would wait out its bound).
   // (measured, config 3: 0.93-0.96 ms per step against 0.89-0.92 with everything behind the fill kernel — the polling waves
   // cost the fill kernel 5 % — so: only with G2S_D2_POLL=1)
-  const bool d2_poll = dev_d2 && !d2_deep && getenv("G2S_D2_POLL") && atoi(getenv("G2S_D2_POLL")) == 1;
-  const uint32_t d2_poll_wgs = d2_poll ? (uint32_t)std::min<size_t>(ids.size(), (size_t)std::max(1, atoi(getenv("G2S_D2_POLL_WGS") ? getenv("G2S_D2_POLL_WGS") : "16"))) : 0u;
+  const bool d2_poll = dev_d2 && !d2_deep && GENV("G2S_D2_POLL") && atoi(GENV("G2S_D2_POLL")) == 1;
+  const uint32_t d2_poll_wgs = d2_poll ? (uint32_t)std::min<size_t>(ids.size(), (size_t)std::max(1, atoi(GENV("G2S_D2_POLL_WGS") ? GENV("G2S_D2_POLL_WGS") : "16"))) : 0u;
   const uint32_t d2_tag = d2_poll ? (0x80000000u | ((++s->d2_lists & 0x7Fu) << 24)) : 0u;
   // (how many workgroups: the trace kernel's last wave waits until every one of them has left, and they are dispatched
   // beside that kernel's 10 000 waves — config 3's list, 70 closures: 0.89 ms per step with 128 workgroups, 1.2 with 512,
   // 1.6 with 1 024, profiles/r05_d2_workgroups_c3.txt; a deep list has hundreds of closures and waits for the kernel anyway)
-  const uint32_t d2_small_wgs = (uint32_t)std::min<size_t>(ids.size(), getenv("G2S_D2_SMALL_WGS") ? (size_t)std::max(1, atoi(getenv("G2S_D2_SMALL_WGS")))
+  const uint32_t d2_small_wgs = (uint32_t)std::min<size_t>(ids.size(), GENV("G2S_D2_SMALL_WGS") ? (size_t)std::max(1, atoi(GENV("G2S_D2_SMALL_WGS")))
                                                                                    : (b->dmax >= 2500 ? (size_t)std::max(1, s->num_cus) * 4u : (size_t)128));
   // (the large instantiation's workgroups need a whole compute unit's LDS each: on a list that is not deep only a few
   // are launched — what the small one passes on there is rare —, so that they find their units beside the trace kernel)
@@ -3007,7 +3011,7 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl, g2s_result* re
   SegEarly early_dev;
   s->early_host = SegEarly();
   // (with phase D2 on the device — below — there is nothing to hand over early)
-  if (rerun && b->dmax >= 2500 && !s->in_team_list && !getenv("G2S_NO_EARLY_HANDOVER") && !dev_d2) {
+  if (rerun && b->dmax >= 2500 && !s->in_team_list && !GENV("G2S_NO_EARLY_HANDOVER") && !dev_d2) {
     const size_t cap_items = n, cap_segs = (size_t)std::min<uint64_t>((uint64_t)n * 1024u, 2ull << 20) + 65536u;
     const size_t b_items = (cap_items * 32 + 63) & ~(size_t)63, b_outs = (cap_items * sizeof(GapOut) + 63) & ~(size_t)63;
     HIP_TRY_S(s->h_early.ensure(b_items + b_outs + cap_segs * sizeof(SegRec)));
@@ -3028,7 +3032,7 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl, g2s_result* re
   // analyse itself leave their gaps' waves the same way, and the thread that waits for the hand-over analyses them
   // meanwhile: resident_d3_wait.  The two counters live behind the fill kernel's cursors, zeroed with them.)
   const bool early_reg = b->dmax < 2500 && !s->in_team_list && !dev_d2 && !s->params.skip_confident && !ids.empty() &&
-                         !getenv("G2S_NO_EARLY_HANDOVER");
+                         !GENV("G2S_NO_EARLY_HANDOVER");
   if (early_reg) {
     const size_t cap_items = n, cap_segs = std::max<size_t>(n * 16, 65536);
     const size_t b_items = (cap_items * 32 + 63) & ~(size_t)63, b_outs = (cap_items * sizeof(GapOut) + 63) & ~(size_t)63;
@@ -3046,7 +3050,7 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl, g2s_result* re
   }
   // (two waves per gap when the launch is short enough to end with its slowest gap — unless the sessions of a team
   // share this device: the chip is then as full as one long launch makes it)
-  const bool two_waves = getenv("G2S_SEG_WAVES") ? atoi(getenv("G2S_SEG_WAVES")) == 2 : (n_reg <= 2048 && !s->team_shares_device);
+  const bool two_waves = GENV("G2S_SEG_WAVES") ? atoi(GENV("G2S_SEG_WAVES")) == 2 : (n_reg <= 2048 && !s->team_shares_device);
   // (the early launch of the large variant — see n_early above: behind everything the stream has prepared, beside the
   // regular tier's kernel; its gaps' records and closures go where the others' do, through the same cursors)
   if (n_early && rerun) HIP_TRY_S(hipEventRecord(s->ev_pre, st));  // (what the early launch waits for: not the regular tier's kernel)
@@ -3059,20 +3063,20 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl, g2s_result* re
     DA.d2out = (D2Out*)s->d_d2out.p; DA.runs = (uint32_t*)s->d_d2runs.p; DA.run_cursor = ctr + 8; DA.run_cap = d2_run_cap;
     DA.all_paths = s->params.all_paths ? 1 : 0; DA.list_cap = (uint32_t)n;
     DA.wgs_done = ctr + 9;
-    DA.behind = (d2_deep && !getenv("G2S_D2_RELEASE")) ? 1u : 0u;  // (a deep list's phase D3 waits for the launch: s->d2_wait)
+    DA.behind = (d2_deep && !GENV("G2S_D2_RELEASE")) ? 1u : 0u;  // (a deep list's phase D3 waits for the launch: s->d2_wait)
     DA.tag = d2_tag;
     static const bool d2_prof = getenv("G2S_D2_PROF") != nullptr;
     if (d2_prof) {
       s->d2_prof_on = true; DA.prof = ctr + 128;
-      if (getenv("G2S_D2_LOG")) {
+      if (GENV("G2S_D2_LOG")) {
         if (!s->d_d2log.p) { HIP_TRY_S(s->d_d2log.ensure(16u * 8192u * 8u)); HIP_TRY_S(hipMemset(s->d_d2log.p, 0, 16u * 8192u * 8u)); }
         DA.log = (unsigned long long*)s->d_d2log.p; DA.log_cap = 8192u;
         g2s::d2_ticks_offset = (uint32_t)(2 * n); s->d2_ticks_n = n;
         HIP_TRY_S(hipMemsetAsync((uint32_t*)s->d_d2list.p + 2 * n, 0, n * 4, st));
       }
     }
-    DA.pass_all = (getenv("G2S_D2_BIG") && atoi(getenv("G2S_D2_BIG")) == 2) ? 1u : 0u;  // (tests: every closure through the large instantiation)
-    if (getenv("G2S_D2_NO_CHAINS")) DA.pass_all |= 2u;  // (tests: no node counts as pass-through — the whole graph of runs goes through the component search)
+    DA.pass_all = (GENV("G2S_D2_BIG") && atoi(GENV("G2S_D2_BIG")) == 2) ? 1u : 0u;  // (tests: every closure through the large instantiation)
+    if (GENV("G2S_D2_NO_CHAINS")) DA.pass_all |= 2u;  // (tests: no node counts as pass-through — the whole graph of runs goes through the component search)
   }
   if (d2_poll) {  // (beside the fill kernel: behind everything the stream has prepared for it)
     s->d2_done_total += n_reg;
@@ -3101,8 +3105,8 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl, g2s_result* re
   const uint32_t* ids_fill = (ids_identity && n_reg == n) ? nullptr : ids_dev;
   // (tracebacks that have no choice to make, by the gaps' own waves: fill_seg.hip.  G2S_TRACE_IN_FILL=0: all by phase D3.)
   SegTrace tr;
-  const bool use_tr = results != nullptr && !s->in_team_list && !getenv("G2S_D3_STAGE") &&
-                      !(getenv("G2S_TRACE_IN_FILL") && atoi(getenv("G2S_TRACE_IN_FILL")) == 0);
+  const bool use_tr = results != nullptr && !s->in_team_list && !GENV("G2S_D3_STAGE") &&
+                      !(GENV("G2S_TRACE_IN_FILL") && atoi(GENV("G2S_TRACE_IN_FILL")) == 0);
   if (use_tr) {
     void *res_dev = nullptr, *arena_dev = nullptr;
     bool rd = false, ad = false;
@@ -3303,7 +3307,7 @@ static int resident_d3_launch(g2s_session* s, const ResidentList& L, bool timed,
   // where the kernels write results and text: the caller's buffers when those are pinned, staging otherwise
   void *res_dev = nullptr, *arena_dev = nullptr;
   // (G2S_D3_STAGE=device, measurements only: the kernels write device memory, two copies bring it to the caller)
-  const bool stage_dev = getenv("G2S_D3_STAGE") && !strcmp(getenv("G2S_D3_STAGE"), "device");
+  const bool stage_dev = GENV("G2S_D3_STAGE") && !strcmp(GENV("G2S_D3_STAGE"), "device");
   bool res_direct = false, arena_direct = false;
   if (!stage_dev) { const int rc = resident_targets(s, results, arena, n, L.arena_bytes, &res_dev, &arena_dev, &res_direct, &arena_direct); if (rc != G2S_OK) return rc; }
   if (stage_dev) {
@@ -3357,7 +3361,7 @@ static int resident_d3_launch(g2s_session* s, const ResidentList& L, bool timed,
   P.arena_base = 0;
   P.group_size = (uint32_t)std::max<size_t>(L.group_size, 1);
   P.sub_region = L.sub_region;
-  P.laps = getenv("G2S_DEBUG") ? 1u : 0u;
+  P.laps = GENV("G2S_DEBUG") ? 1u : 0u;
   // (one batch on this session: the kernels read this session's own records and cursors, and clean up behind
   // themselves; not while the lap stamps are wanted — they live in the summary's slot)
   const bool self_clean = L.groups.size() == 1 && L.outs_dev == (const GapOut*)s->d_outs.p && !P.laps && !sharded;
@@ -3599,7 +3603,7 @@ static int resident_d3_wait(g2s_session* s, g2s_timing* tm_out, double* ms_d3_ou
       s->pool->run(ni, [&](size_t x) { one((size_t)lpt[x]); });
     } else for (size_t x = 0; x < ni; x++) one(x);
     for (size_t x = 0; x < ni; x++) host_fill_bytes += (uint64_t)rs_host[side_h.items[x].gap].fill_len;
-    if (const char* path = getenv("G2S_HOST_ITEMS_DUMP")) {  // (tools/host_items_replay.py: the host's share of a list, replayed without a GPU)
+    if (const char* path = GENV("G2S_HOST_ITEMS_DUMP")) {  // (tools/host_items_replay.py: the host's share of a list, replayed without a GPU)
       if (FILE* f = fopen(path, "wb")) {
         for (size_t x = 0; x < ni; x++) {
           const D3HostItem& h = side_h.items[x];
@@ -3618,7 +3622,7 @@ static int resident_d3_wait(g2s_session* s, g2s_timing* tm_out, double* ms_d3_ou
   float ms_d3 = 0;
   if (timed) HIP_TRY_S(hipEventElapsedTime(&ms_d3, d3_begin, s->ev[3]));
   *ms_d3_out = ms_d3;
-  if (getenv("G2S_DEBUG")) {  // the kernels' lap stamps (d3_device.hip: stamp), 100 MHz
+  if (GENV("G2S_DEBUG")) {  // the kernels' lap stamps (d3_device.hip: stamp), 100 MHz
     unsigned long long lp[24];
     HIP_TRY_S(hipMemcpy(lp, (char*)W.sum + 512, sizeof lp, hipMemcpyDeviceToHost));
     auto us = [&](int a, int b) { return lp[a] && lp[b] ? ((double)lp[b] - (double)lp[a]) / 100.0 : -1.0; };
@@ -3638,7 +3642,7 @@ static int resident_d3_wait(g2s_session* s, g2s_timing* tm_out, double* ms_d3_ou
   hsum->fill_bytes += host_fill_bytes;
   // (tests: the attempt is discarded — every one, or with "rel:K" only the K-th wait since that value was first seen)
   bool test_fallback = false;
-  if (const char* tf = getenv("G2S_RESIDENT_TEST_FALLBACK")) {
+  if (const char* tf = GENV("G2S_RESIDENT_TEST_FALLBACK")) {
     static std::mutex mu;
     static std::string seen;
     static int waits = 0;
@@ -3649,7 +3653,7 @@ static int resident_d3_wait(g2s_session* s, g2s_timing* tm_out, double* ms_d3_ou
   }
   if (stage_dev && hsum->host_items) hsum->anomalies++;  // (the measurement switch has no path for host-finished gaps)
   if (hsum->status != 0 || hsum->anomalies != 0 || test_fallback || host_bad.load() || hsum->host_items != ni) {
-    if (getenv("G2S_DEBUG"))
+    if (GENV("G2S_DEBUG"))
       fprintf(stderr, "[g2s] resident mode: list of %zu gaps goes to the host path (status %#x, %u gaps not finished on the device, %u anomalies, %llu table entries, %d host-finished gaps disagree)\n",
               n, hsum->status, hsum->unhandled, hsum->anomalies, (unsigned long long)hsum->table_entries, host_bad.load());
     // (only what points at a defect counts towards switching the mode off for the session: a walk that met something
@@ -3694,7 +3698,7 @@ static int resident_d3_wait(g2s_session* s, g2s_timing* tm_out, double* ms_d3_ou
   const auto t_end = std::chrono::steady_clock::now();
   s->lap_d3_queued = t_launched; s->lap_handed = t_handed; s->lap_finished = t_finished; s->lap_synced = t_synced; s->lap_end = t_end;
   s->laps_valid = true;
-  if (getenv("G2S_DEBUG"))
+  if (GENV("G2S_DEBUG"))
     fprintf(stderr, "[g2s] resident mode, phase D3 of %zu gaps: set-up + launches %.3f ms, wait for the hand-over %.3f ms, %zu gaps finished by the host in %.3f ms, wait for the trace kernel %.3f ms, results %.3f ms (kernels %.3f ms); %u draw-dependent gaps, %llu table entries, %llu draws; results %s, text %s\n",
             n, std::chrono::duration<double, std::milli>(t_launched - t_enter).count(), std::chrono::duration<double, std::milli>(t_handed - t_launched).count(),
             ni, std::chrono::duration<double, std::milli>(t_finished - t_handed).count(), std::chrono::duration<double, std::milli>(t_synced - t_finished).count(),
@@ -3782,7 +3786,7 @@ static int run_resident_finish(g2s_batch* b, const ResidentLaunch& rl, std::chro
   if (rl.timed) tm.seg_timed_launches++;
   if (rl.two_waves) tm.seg2_launches++;
   tm.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enter).count();
-  if (getenv("G2S_DEBUG")) fprintf(stderr, "[g2s] resident mode: %zu gaps in %.3f ms (fill kernel %.3f ms)\n", n, tm.ms_total, ms_fill);
+  if (GENV("G2S_DEBUG")) fprintf(stderr, "[g2s] resident mode: %zu gaps in %.3f ms (fill kernel %.3f ms)\n", n, tm.ms_total, ms_fill);
   return G2S_OK;
 }
 int run_resident(g2s_batch* b, g2s_result* results, char* arena) {
@@ -3810,6 +3814,7 @@ int run_resident(g2s_batch* b, g2s_result* results, char* arena) {
 static void d3_pending_drop(g2s_session* s) { delete (D3Pending*)s->d3_pending; s->d3_pending = nullptr; }
 
 extern "C" int g2s_batch_run(g2s_batch* b, g2s_result* results, char* arena, size_t arena_cap) {
+  g2s_env_sync();
   if (!b || !results || (!arena && b->arena_bytes)) return fail(G2S_ERR_ARG, "g2s_batch_run: bad argument");
   if (arena_cap < b->arena_bytes) return fail(G2S_ERR_ARG, "g2s_batch_run: fill arena too small");
   g2s_session* s = b->s;
@@ -3841,7 +3846,7 @@ extern "C" int g2s_batch_run(g2s_batch* b, g2s_result* results, char* arena, siz
   s->bg.wait();
   const auto t_run2 = std::chrono::steady_clock::now();
   if (rc == G2S_OK) rc = batches_stage2(std::vector<g2s_batch*>{b}, s, results, arena, &b->timing, false);
-  if (getenv("G2S_DEBUG")) {
+  if (GENV("G2S_DEBUG")) {
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point c) { return std::chrono::duration<double, std::milli>(c - a).count(); };
     fprintf(stderr, "[g2s] batch_run: init %.3f ms, stage 1 %.3f ms, wait for rand() values %.3f ms, stage 2 %.3f ms\n",
             ms(t_run0, t_run1), ms(t_run1, t_join), ms(t_join, t_run2), ms(t_run2, std::chrono::steady_clock::now()));
@@ -3914,7 +3919,7 @@ struct TeamBarrier {
 static int team_resident_sharded(g2s_session* const* sessions, int nsessions, const g2s_gap* gaps, size_t n, size_t group_size,
                                  g2s_result* results, char* arena, g2s_timing* timing_out) {
   g2s_session* lead = sessions[0];
-  if (getenv("G2S_TEAM_GATHER")) return 1;  // (measurements: the gather form)
+  if (GENV("G2S_TEAM_GATHER")) return 1;  // (measurements: the gather form)
   const size_t ngroups = (n + group_size - 1) / group_size;
   if (nsessions < 2 || ngroups != (size_t)nsessions || nsessions > 16) return 1;
   for (int t = 0; t < nsessions; t++) if (!resident_applicable(sessions[t], n) || sessions[t]->d3_pending) return 1;
@@ -4137,7 +4142,7 @@ static int team_resident(g2s_session* const* sessions, int nsessions, const g2s_
     int can = 0;
     if (hipDeviceCanAccessPeer(&can, o->device, lead->device) == hipSuccess && can && hipSetDevice(o->device) == hipSuccess) {
       const hipError_t pe = hipDeviceEnablePeerAccess(lead->device, 0);
-      if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled && getenv("G2S_DEBUG"))
+      if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled && GENV("G2S_DEBUG"))
         fprintf(stderr, "[g2s] team: device %d cannot open device %d's memory (%s): copies go through the host\n", o->device, lead->device, hipGetErrorString(pe));
     }
     (void)hipGetLastError();
@@ -4255,6 +4260,7 @@ static int team_resident(g2s_session* const* sessions, int nsessions, const g2s_
 extern "C" int g2s_team_fill(g2s_session* const* sessions, int nsessions, const g2s_gap* gaps, size_t n,
                              size_t group_size, g2s_result* results, char* arena, size_t arena_cap,
                              g2s_timing* timing_out) {
+  g2s_env_sync();
   if (!sessions || nsessions < 1 || (!gaps && n) || !results) return fail(G2S_ERR_ARG, "g2s_team_fill: bad argument");
   for (int t = 0; t < nsessions; t++)
     if (!sessions[t] || sessions[t]->graph != sessions[0]->graph)
@@ -4364,7 +4370,7 @@ extern "C" int g2s_team_fill(g2s_session* const* sessions, int nsessions, const 
         b->arena_base = group_arena[gi];
         rc = batch_stage1(b, true, results + off);
       }
-      if (getenv("G2S_DEBUG"))
+      if (GENV("G2S_DEBUG"))
         fprintf(stderr, "[g2s] team session %d group %zu (%zu gaps): prepare %.3f ms, stage 1 %.3f ms\n", t, gi, cnt,
                 std::chrono::duration<double, std::milli>(t1 - t0).count(),
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
@@ -4439,6 +4445,7 @@ static size_t team_group_for(const g2s_session* s, size_t n) {
 
 extern "C" int g2s_fill_batch(g2s_session* s, const g2s_gap* gaps, size_t n, g2s_result* results, char* fill_arena,
                               size_t arena_cap) {
+  g2s_env_sync();
   if (!s) return fail(G2S_ERR_ARG, "g2s_fill_batch: bad argument");
   REFUSE_IN_FLIGHT(s, "g2s_fill_batch");
   // long lists go through the group pipeline: with helpers to use every session, without
@@ -4464,7 +4471,7 @@ extern "C" int g2s_fill_batch(g2s_session* s, const g2s_gap* gaps, size_t n, g2s
     h[0] = us(t_begin, s->lap_fill_queued); h[1] = us(s->lap_fill_queued, s->lap_d3_queued); h[2] = us(s->lap_d3_queued, s->lap_handed);
     h[3] = us(s->lap_handed, s->lap_finished); h[4] = us(s->lap_finished, s->lap_synced); h[5] = us(s->lap_synced, std::chrono::steady_clock::now());
   }
-  if (getenv("G2S_DEBUG"))
+  if (GENV("G2S_DEBUG"))
     fprintf(stderr, "[g2s] fill_batch: prepare %.3f ms, free %.3f ms\n", ms_prep,
             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_free).count());
   s->last_timing.ms_prepare = ms_prep;
@@ -4487,7 +4494,7 @@ namespace {
 // continues that one's stream on the device.  A list behind one that is to run again, or that is not on the device
 // at all, waits for it to end.
 int inflight_settle(g2s_session* s) {
-  const bool no_chain = getenv("G2S_NO_DEVICE_CHAIN") != nullptr;  // (read per call: the tests switch it)
+  const bool no_chain = GENV("G2S_NO_DEVICE_CHAIN") != nullptr;  // (read per call: the tests switch it)
   for (int i = 0; i < s->n_inflight; i++) {
     g2s_session::InFlight& f = s->inflight[i];
     if (!f.b) break;  // (a list for g2s_fill_batch: it draws on the host, when it is ended)
@@ -4514,6 +4521,7 @@ int inflight_settle(g2s_session* s) {
 }  // namespace
 
 extern "C" int g2s_fill_begin(g2s_session* s, const g2s_gap* gaps, size_t n, g2s_result* results, char* fill_arena, size_t arena_cap) {
+  g2s_env_sync();
   if (!s || (!gaps && n) || (!results && n)) return fail(G2S_ERR_ARG, "g2s_fill_begin: bad argument");
   if (s->n_inflight >= G2S_MAX_IN_FLIGHT) return fail(G2S_ERR_ARG, "g2s_fill_begin: G2S_MAX_IN_FLIGHT lists are in flight already (g2s_fill_end first)");
   InternalCall own(s);
@@ -4565,6 +4573,7 @@ extern "C" int g2s_fill_begin(g2s_session* s, const g2s_gap* gaps, size_t n, g2s
   return G2S_OK;
 }
 extern "C" int g2s_fill_end(g2s_session* s) {
+  g2s_env_sync();
   if (!s || s->n_inflight < 1) return fail(G2S_ERR_ARG, "g2s_fill_end: no list in flight");
   InternalCall own(s);
   g2s_session::InFlight f = s->inflight[0];
@@ -4618,6 +4627,7 @@ void share_drop(g2s_session* s) {
 }  // namespace
 extern "C" int g2s_share_begin(g2s_session* s, const g2s_gap* gaps, size_t n, g2s_result* results, char* fill_arena, size_t arena_cap,
                                uint64_t totals[2]) {
+  g2s_env_sync();
   if (!s || !gaps || !results || !totals || n == 0) return fail(G2S_ERR_ARG, "g2s_share_begin: bad argument");
   REFUSE_IN_FLIGHT(s, "g2s_share_begin");
   if (s->share_step != 0) return fail(G2S_ERR_STATE, "g2s_share_begin: a share is open on this session (g2s_share_end it first)");
@@ -4666,6 +4676,7 @@ extern "C" int g2s_share_begin(g2s_session* s, const g2s_gap* gaps, size_t n, g2
   return G2S_OK;
 }
 extern "C" int g2s_share_tables(g2s_session* s, uint64_t base0, uint64_t R0, const uint32_t** fn) {
+  g2s_env_sync();
   if (!s || !fn) return fail(G2S_ERR_ARG, "g2s_share_tables: bad argument");
   if (s->share_step != 1) return fail(G2S_ERR_STATE, "g2s_share_tables: no share begun on this session");
   if (base0 + R0 >= 0xF0000000ull) { share_drop(s); return fail(G2S_ERR_STATE, "g2s_share_tables: the list draws more than phase D3 on the device counts"); }
@@ -4678,6 +4689,7 @@ extern "C" int g2s_share_tables(g2s_session* s, uint64_t base0, uint64_t R0, con
   return G2S_OK;
 }
 extern "C" int g2s_share_trace(g2s_session* s, uint32_t d_in) {
+  g2s_env_sync();
   if (!s) return fail(G2S_ERR_ARG, "g2s_share_trace: bad argument");
   if (s->share_step != 2) return fail(G2S_ERR_STATE, "g2s_share_trace: no tables on this session (g2s_share_tables first)");
   g2s_batch* b = s->share_batch;
@@ -4711,6 +4723,7 @@ extern "C" int g2s_share_end(g2s_session* s, uint64_t list_draws) {
 }
 
 extern "C" int g2s_session_set_team(g2s_session* lead, g2s_session* const* helpers, int nhelpers, size_t group_size) {
+  g2s_env_sync();
   if (!lead || nhelpers < 0 || (nhelpers && !helpers)) return fail(G2S_ERR_ARG, "g2s_session_set_team: bad argument");
   for (int i = 0; i < nhelpers; i++)
     if (!helpers[i] || helpers[i] == lead || helpers[i]->graph != lead->graph)
@@ -4886,7 +4899,7 @@ extern "C" int g2s_test_post_segments(const g2s_graph* gh, const g2s_params* p, 
   const auto t_an0 = std::chrono::steady_clock::now();
   const bool ok = seg_analyze(fp, j, v, &prep);
   if (on_segments) *on_segments = ok ? 1 : 0;
-  if (n_segs >= 2000 && prep.run_mode && getenv("G2S_POST_LAPS")) {  // (tools/host_items_replay.py)
+  if (n_segs >= 2000 && prep.run_mode && GENV("G2S_POST_LAPS")) {  // (tools/host_items_replay.py)
     const double* l = g2s_post_laps;
     const double t1 = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
     fprintf(stderr, "[g2s] %u segments, run analysis laps (us): front %.0f | collect %.0f merge+sort %.0f runs %.0f edges %.0f csr %.0f tarjan %.0f rest %.0f | all %.0f\n", n_segs,
