@@ -872,6 +872,8 @@ def main():
         "resident": {"lists_finished_on_the_device": tm.resident_launches, "lists_given_back_to_the_host_path": tm.resident_fallbacks,
                      "draw_dependent_gaps": tm.draw_dependent_gaps, "draw_count_table_entries": tm.d3_table_entries,
                      "gaps_traced_by_the_fill_kernel": tm.traced_in_fill_gaps,
+                     "gaps_guessed_by_the_fill_kernel": tm.guessed_in_fill_gaps,
+                     "guessed_text_groups_of_64_bases_compared_and_sent_again": [tm.guessed_groups, tm.guessed_groups_resent],
                      "gaps_finished_by_the_host": tm.host_finished_gaps,
                      "team_groups": tm.team_groups,
                      "team_groups_by_session": [tm.team_groups_by_session[i] for i in range(min(16, max(1, len(sessions))))],

@@ -82,6 +82,8 @@ struct D3Summary {
   uint32_t trace_waves;     // waves of g2s_d3_trace that are through
   uint32_t big_gaps;        // gaps that ran in the large variant of the segment tier (G2S_DEV_BIG)
   uint32_t traced_gaps;     // gaps whose fill kernel's wave wrote text and record itself (G2S_DEVA_TRACED)
+  uint32_t spec_gaps;       // gaps whose fill kernel's wave wrote a guess (G2S_DEVA_SPEC); how much of them the trace kernel sent
+                            // again: word 1 of each of the 64 fill-byte counters' lines (groups of 64 bases compared | sent << 32)
 };
 static_assert(sizeof(D3Summary) <= 512, "the lap stamps live at byte 512 of the summary's slot");
 
@@ -128,6 +130,11 @@ struct D3Work {
   const D2Out* d2out = nullptr;
   const uint32_t* d2runs = nullptr;
   uint64_t* hops = nullptr;  // (depth at which the hop is entered | (segment | entry state << 16) << 32)
+  // (not carved: the caller's) where the fill kernel's waves left their GUESSES of tracebacks that have choices
+  // (G2S_DEVA_SPEC: text at the arena's offsets, records as g2s_result): the trace kernel compares and sends through the
+  // link what differs.  Null: every traced gap is written in full.
+  const char* spec_text = nullptr;
+  const uint32_t* spec_res = nullptr;
 };
 size_t d3_work_bytes(uint32_t n);
 void d3_work_carve(void* p, uint32_t n, D3Work* w);

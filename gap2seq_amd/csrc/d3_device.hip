@@ -126,7 +126,7 @@ __device__ __forceinline__ uint32_t d3_classify_body(const D3Params& P, const D3
                                                      unsigned long long* red, bool one_wg) {
   const uint32_t n = P.n;
   unsigned long long xA = 0, sA = 0, xB = 0, sB = 0, xD = 0, sD = 0, segs = 0;
-  uint32_t unhandled = 0, seg_gaps = 0, big = 0, traced = 0;
+  uint32_t unhandled = 0, seg_gaps = 0, big = 0, traced = 0, spec = 0;
   for (uint32_t i = first; i < n; i += stride) {
     // (the descriptor comes over the link on a short list, the record from device memory: asked for together)
     const D3Gap dg = dgaps[i];
@@ -147,6 +147,7 @@ __device__ __forceinline__ uint32_t d3_classify_body(const D3Params& P, const D3
         seg_gaps++;
         if (flags & G2S_DEV_BIG) big++;
         if (dflags & G2S_DEVA_TRACED) traced++;
+        if (dflags & G2S_DEVA_SPEC) spec++;
         const bool phase_d = c_count > 0 && n_len > 0;  // :1169
         // (a gap listed for g2s_d2_* is not the host's yet: that kernel may still be running — the hand-off decides)
         const bool by_host = phase_d && !(dflags & (G2S_DEVA_ANALYSED | G2S_DEVA_D2_PENDING));
@@ -201,6 +202,8 @@ __device__ __forceinline__ uint32_t d3_classify_body(const D3Params& P, const D3
   if ((threadIdx.x & 63u) == 0u && big) atomicAdd(&W.sum->big_gaps, big);
   traced = dpp_sum(traced);
   if ((threadIdx.x & 63u) == 0u && traced) atomicAdd(&W.sum->traced_gaps, traced);
+  spec = dpp_sum(spec);
+  if ((threadIdx.x & 63u) == 0u && spec) atomicAdd(&W.sum->spec_gaps, spec);
   const uint32_t wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   if ((threadIdx.x & 63u) == 0u) {
     unsigned long long* r = red + wave * 8u;
@@ -1061,6 +1064,7 @@ __global__ __launch_bounds__(64 * NW) void g2s_d3_trace(const D3Params P, const 
   // modulo 64 also counts its waves (bits 40 and up — one addition for both; one counter for all waves would have
   // 10 000 of them queue at one address), the wave that completes a residue adds to the summary's counter, the one
   // that completes that copies.  Counters other waves add to are read at the L2.
+  uint32_t gsp_all = 0, gsp_sent = 0;  // (guessed gaps: groups of 64 bases the first wave compared / sent again — the other waves' are not counted)
   auto leave = [&](uint32_t fill_len) {
     if (!w0) return;
     uint32_t last = 0;
@@ -1073,6 +1077,7 @@ __global__ __launch_bounds__(64 * NW) void g2s_d3_trace(const D3Params P, const 
       }
       const uint32_t c = i & 63u, n = gridDim.x;
       const unsigned long long before = atomicAdd(&W.fill_bytes[c * 16u], (unsigned long long)fill_len | (1ull << 40));
+      if (gsp_all) atomicAdd(&W.fill_bytes[c * 16u + 1u], (unsigned long long)gsp_all | ((unsigned long long)gsp_sent << 32));  // (the same line)
       if ((uint32_t)(before >> 40) + 1u == (n + 63u - c) / 64u) last = atomicAdd(&S->trace_waves, 1u) + 1u == min(n, 64u) ? 1u : 0u;
     }
     // (self_clean — a list that is one batch on one session: what the next list's kernels expect to find zero is
@@ -1103,9 +1108,15 @@ __global__ __launch_bounds__(64 * NW) void g2s_d3_trace(const D3Params P, const 
   // skip rule or the memory verdict took out after all cannot carry the flag: fill_seg.hip asks for neither)
   if ((go.dflags & G2S_DEVA_TRACED) && !(gi & (GI_BAD | GI_SKIPPED | GI_MEM | GI_HOST)) && (gi & GI_PHASE_D)) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    leave(go.top_level);
+    leave((go.top_level >> 16) - (go.top_level & 0xFFFFu));
     return;
   }
+  // (its fill kernel's wave wrote a guess — first length, first parent at every choice — to the caller's buffers and to
+  // device memory: what this wave finds equal there, 64 bases or the whole record at a time, it does not send again)
+  const bool spec = (go.dflags & G2S_DEVA_SPEC) != 0u && W.spec_text != nullptr && !(gi & (GI_BAD | GI_SKIPPED | GI_MEM | GI_HOST)) && (gi & GI_PHASE_D);
+  const int spec_stop = (int)(go.top_level & 0xFFFFu), spec_len = (int)(go.top_level >> 16);
+  // (the chain of segments the guess followed, as a 64-bit hash of their ids in order: fill_seg.hip)
+  const unsigned long long spec_chain = spec ? ((unsigned long long)uni(outs[i].stat[6]) | ((unsigned long long)uni(outs[i].stat[7]) << 32)) : 0ull;
   struct { uint16_t lmf; } dg = {td.lmf};
   const uint64_t abs_off = td.arena_off;
   char* buf = arena + abs_off;
@@ -1116,6 +1127,8 @@ __global__ __launch_bounds__(64 * NW) void g2s_d3_trace(const D3Params P, const 
 #pragma unroll
   for (int q = 0; q < 24; q++) rw[q] = 0u;
   int left_fuz = 0;
+  bool spec_rec = false;  // (set where the gap turns out to be one whose guess stands to be compared)
+  uint32_t g_all = 0, g_sent = 0;  // (a guessed gap: groups of 64 bases this wave looked at / sent through the link again)
   // (the first wave writes it, a word a lane: 112 contiguous bytes in one instruction — seven 16-byte stores of one lane
   // were seven packets of the link; the words are the same in every lane)
   auto finish = [&](uint32_t fill_len) {
@@ -1127,6 +1140,10 @@ __global__ __launch_bounds__(64 * NW) void g2s_d3_trace(const D3Params P, const 
     uint32_t mine = 0u;  // (words 24-27 — backtrace_depth, backtrace_final_d: a traceback that fails is the host path's)
 #pragma unroll
     for (int q = 0; q < 24; q++) mine = lane == q ? rw[q] : mine;
+    if (spec_rec) {  // (the guessed record is there already: the same words are not sent again)
+      const uint32_t was = lane < 28 ? W.spec_res[(size_t)i * 28u + (uint32_t)lane] : 0u;
+      if (__ballot(lane < 28 && was != mine) == 0ull) return;
+    }
     if (lane < 28) ((uint32_t*)&results[i])[lane] = mine;
   };
   if (gi & (GI_BAD | GI_SKIPPED | GI_MEM)) {
@@ -1300,15 +1317,24 @@ __global__ __launch_bounds__(64 * NW) void g2s_d3_trace(const D3Params P, const 
     if (si < 0 || si >= (int)nsegs || avail < 1) bad = true;
     uint32_t last = 0x80000000u;
     const int hop_cap = (int)(big ? nsegs : min(nsegs, P.seg_cap));
+    unsigned long long chain_hash = 14695981039346656037ull;
     if (!bad && !big) {
       for (;;) {
         if (nh >= hop_cap) { bad = true; break; }
         if (P.laps) hops++;
         last = uni(pk[si].y);
+        chain_hash = (chain_hash ^ (unsigned long long)(uint32_t)si) * 1099511628211ull;
         if (lane == 0) hop[nh].y = (uint32_t)si;
         nh++;
         if (last & 0xC0000000u) break;
         si = (int)(last & 0xFFFFu);
+      }
+      // (the fill kernel's wave guessed THIS chain, from this length: text, case, fuz values and draws are the guess's —
+      // they are in the caller's buffers already)
+      if (!bad && spec && pick == 0 && len == spec_len && (last & 0x40000000u) && chain_hash == spec_chain) {
+        gsp_all = 1u;  // (counted as one group compared, none sent)
+        leave((uint32_t)(spec_len - spec_stop));
+        return;
       }
     }
     if (!bad && big) {  // (the same chain over the records in device memory: a round trip per segment entered)
@@ -1459,28 +1485,38 @@ __global__ __launch_bounds__(64 * NW) void g2s_d3_trace(const D3Params P, const 
     // ---- the bases: eight loads in flight per lane (a 1 000-base fill: two round trips on one wave).  (Measured and
     // not kept: the text in 4-byte words, 256 bytes an instruction — config 3's kernel 207 us against 205 with a byte a
     // lane, config 4's 57 against 54: the link takes what the kernel writes at ~38 GB/s either way.)
+    const char* sbuf = spec ? W.spec_text + abs_off : nullptr;
     for (int p0 = stop; p0 < len; p0 += 8 * NT) {
       uint32_t e[8];
-      char c[8];
+      char c[8], was[8];
 #pragma unroll
       for (int u = 0; u < 8; u++) { const int p = p0 + NT * u + tid; e[u] = p < len ? cmap[p] : 0u; }
 #pragma unroll
       for (int u = 0; u < 8; u++) {
         const uint32_t x = e[u] & 0x0FFFFFFFu;
         c[u] = (e[u] & 0x40000000u) ? chd[x] : chu[x];
+        const int p = p0 + NT * u + tid;
+        was[u] = (spec && p >= spec_stop && p < spec_len && p < len) ? sbuf[p] : (char)0;  // (0: no base — nothing was guessed there)
       }
 #pragma unroll
       for (int u = 0; u < 8; u++) {
         const int p = p0 + NT * u + tid;
-        if (p < len) buf[p] = (e[u] >> 31) ? (char)(c[u] | 0x20) : c[u];
+        const char ch = (e[u] >> 31) ? (char)(c[u] | 0x20) : c[u];
+        // (a wave's lanes hold 64 consecutive bases: sent when any of them differs from the guess)
+        const uint64_t diff = __ballot(p < len && was[u] != ch), any = __ballot(p < len);
+        if (any && spec) { g_all++; if (diff) g_sent++; }
+        if (diff != 0ull && p < len) buf[p] = ch;
       }
     }
-    if (tid == 0) buf[len] = '\0';
+    if (tid == 0 && !(spec && spec_len == len)) buf[len] = '\0';
+
   } else if (tid == 0) buf[dg.lmf] = '\0';
   if (P.laps) tk3 = wall_clock64();
   rw[2] = (uint32_t)go.reached_j;  // :1171
   rw[3] |= G2S_GAP_PHASE_D;
   rw[7] = (uint32_t)draws;
+  spec_rec = spec && !bad && W.spec_res != nullptr;
+  gsp_all = g_all; gsp_sent = g_sent;
   // (one counter for the whole list made 10 000 waves queue at one address of the L2: 64 counters, a cache line each)
   finish(fill_len);
   leave(fill_len);

@@ -183,5 +183,8 @@ struct GapOut {
 #define G2S_DEVA_D2_FAILED 0x20u  /* g2s_d2_* could not analyse the closure (beyond its capacities): the host's after all */
 #define G2S_DEVA_TRACED 0x40u    /* the fill kernel's wave traced the gap itself (one path, nothing to draw for): fill text and result
                                     record are written, GapOut.top_level = the fill's length; phase D3 counts its draws, the trace kernel skips it */
+#define G2S_DEVA_SPEC 0x80u      /* the fill kernel's wave wrote a GUESS of the gap's traceback (first path length, first parent at every
+                                    choice): text and record in the caller's buffers and in device memory; GapOut.top_level = where that
+                                    text begins | ends << 16; the trace kernel traces the gap and sends through the link what differs */
 #define G2S_DEVA_RUNS 0x8u       /* (with ANALYSED) analysed by g2s_d2_* (d2_device.hip): the verdicts are the gap's runs (D2Out),
                                     the subgraph statistics D2Out.sub */

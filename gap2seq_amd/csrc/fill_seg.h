@@ -47,6 +47,8 @@ struct SegTrace {
   const char* chu = nullptr;
   const char* chd = nullptr;
   int k = 0;
+  char* spec_text = nullptr;     // device memory, the arena's size: guessed tracebacks (G2S_DEVA_SPEC), or null
+  uint32_t* spec_res = nullptr;  // device memory, g2s_result[n]
 };
 
 // (tools, G2S_D2_LOG) where in d2_list the fill kernels note when a gap's closure was listed; 0: nowhere

@@ -2017,36 +2017,75 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
   if constexpr (!BIG) {
     const bool no_over = sb <= A.tr_max_states && nvis <= A.tr_max_states;  // (else the -max-mem verdict: phase D3's)
     const uint32_t sa_w = c1 > 0 ? s1 : s2;
-    if (A.tr_results != nullptr && (analysed || !want_s) && !choice && n_len == 1 && start_b0 != SEG_NOPAR && no_over &&
-        gd.rlog_cap == 0u /* no skip rule on this gap */ && len0 >= 1 && len0 <= 4096 && nrec <= 256u &&
-        (sa_w & 0xFFFFu) == (sa_w >> 16)) {
+    // (round 6, second step: a traceback that HAS choices is written here too — as a GUESS: the first path length, the
+    // first parent at every choice — with a copy of text and record in device memory.  The bench's genome has a second
+    // haplotype every ~500 bp: nine tracebacks in ten cross a bubble, but the two ways through one differ in a base or
+    // two.  Phase D3's trace kernel still traces such a gap for real, compares 64 bases at a time with what was guessed,
+    // and sends through the link only what differs: G2S_DEVA_SPEC.)
+    const bool sure = !choice && n_len == 1 && (sa_w & 0xFFFFu) == (sa_w >> 16);
+    if (A.tr_results != nullptr && (analysed || !want_s) && (sure || A.tr_spec_text != nullptr) && start_b0 != SEG_NOPAR && no_over &&
+        gd.rlog_cap == 0u /* no skip rule on this gap */ && len0 >= 1 && len0 <= 4096 && nrec <= 256u) {
       const int len = len0, k = A.tr_k;
       uint2* hop = (uint2*)s_cnt;           // by hop: the depth at which it is entered | the segment | entry state << 16
       unsigned char* cb = (unsigned char*)s_p23;  // by fill-buffer index: safe bit, then the character (s_p23 and s_aux: 4 096 bytes)
       lds_sync();
-      // (i) the chain of segments, wave-uniform: from the start along the one parent to a source
+      // (i) the chain of segments: from the start along the (first) parent to a source.  As in g2s_d3_trace: what the
+      // walk needs of a segment — the parent it goes on to, its emitted id (for the chain's hash), whether it is a source
+      // or has no way on — is packed into ONE word per segment by all lanes first, so that the walk itself, a chain of
+      // dependent steps on one wave, reads one LDS word a segment (with five reads and the tests a step it was 400
+      // cycles a segment, 10 k cycles of a guess); then all lanes check that the hops' depths follow each other.
+      uint32_t* pk2 = s_p23;  // parent | emitted id << 16 | source << 30 | no way on << 31   (s_p23: free until the characters go there)
+      for (uint32_t b0 = 0; b0 < nseg; b0 += 64u) {
+        const uint32_t b = b0 + (uint32_t)lane;
+        if (b >= nseg) continue;
+        const uint32_t dl = s_dl[b], v0 = s_node[b], par = s_p01[b] & 0xFFFFu;
+        const int d0 = (int)(dl & 0xFFFFu);
+        const uint32_t ls = d0 <= lmf ? l_seed[d0] : G2S_DEV_INVALID;
+        const bool source = ls != G2S_DEV_INVALID && (v0 >> 1) == (ls >> 1);  // :1455-1462
+        const bool stuck = !source && (d0 < 1 || par == SEG_NOPAR || par >= nseg);  // (:1493-1510: the trace kernel's, and the host's)
+        pk2[b] = (par & 0xFFFFu) | ((s_aux[b] & 0x3FFu) << 16) | (source ? 0x40000000u : 0u) | (stuck ? 0x80000000u : 0u);
+      }
+      lds_sync();
       bool bad = false;
       int nh = 0, d_end = -1;
+      unsigned long long chain_hash = 14695981039346656037ull;  // (of the emitted ids of the segments entered, in order: the trace kernel's walk makes the same)
       {
-        uint32_t si = start_b0;
-        int at = len;
+        uint32_t si = start_b0, w = 0u;
         for (;;) {
           if (nh >= 256) { bad = true; break; }
-          const uint32_t dl = uni(s_dl[si]), st = uni(s_t[si]), v0 = uni(s_node[si]);
-          const int d0 = (int)(dl & 0xFFFFu);
-          const int t = nh == 0 ? (int)start_t0 : max(dec15(st), dec15(st >> 16));  // (a child in the closure puts the whole parent there)
-          if (t < 0 || d0 + t != at) { bad = true; break; }
-          if (lane == 0) hop[nh] = make_uint2((uint32_t)at, si | ((uint32_t)t << 16));
+          w = uni(pk2[si]);
+          chain_hash = (chain_hash ^ (unsigned long long)((w >> 16) & 0x3FFu)) * 1099511628211ull;
+          if (lane == 0) hop[nh].y = si;
           nh++;
-          const uint32_t ls = d0 <= lmf ? uni(l_seed[d0]) : G2S_DEV_INVALID;
-          if (ls != G2S_DEV_INVALID && (v0 >> 1) == (ls >> 1)) { d_end = d0; break; }  // a source: :1455-1462
-          const uint32_t par = uni(s_p01[si]) & 0xFFFFu;
-          if (d0 < 1 || par == SEG_NOPAR || par >= nseg) { bad = true; break; }  // (:1493-1510: the trace kernel's, and the host's)
-          at = d0 - 1;
-          si = par;
+          if (w & 0xC0000000u) break;
+          si = w & 0xFFFFu;
+        }
+        if (!bad && !(w & 0x40000000u)) bad = true;
+      }
+      lds_sync();
+      // (ii) all lanes, a hop each: the walk enters the first segment at the start's state and every other at its last
+      // closure state, and steps from a segment's first state to the depth below: the depth at which hop h is entered is
+      // len less the states passed before it — a scan — and has to be the segment's own depth at that state
+      {
+        int carry = 0;
+        for (int h0 = 0; !bad && h0 < nh; h0 += 64) {
+          const int h = h0 + lane;
+          const bool in = h < nh;
+          const uint32_t sq = in ? hop[h].y : 0u;
+          const uint32_t dl = in ? s_dl[sq] : 0u, st = in ? s_t[sq] : 0x7FFF7FFFu;
+          const int d0 = (int)(dl & 0xFFFFu);
+          const int t = h == 0 ? (int)start_t0 : max(dec15(st), dec15(st >> 16));  // (a child in the closure puts the whole parent there)
+          const int inc = in ? t + 1 : 0;
+          const int incl = (int)wave_scan((uint32_t)inc, lane);
+          const int at = len - carry - (incl - inc);
+          if (__ballot(in && (t < 0 || d0 + t != at)) != 0ull) { bad = true; break; }
+          if (in) hop[h] = make_uint2((uint32_t)at, sq | ((uint32_t)t << 16));
+          if (__ballot(in && h + 1 == nh)) d_end = (int)rl((uint32_t)d0, (nh - 1) & 63);
+          carry += (int)rl((uint32_t)incl, 63);
         }
       }
-      if (!bad && d_end != (int)(sa_w & 0xFFFFu)) bad = true;  // (the stop depth the search itself found)
+      lds_sync();
+      if (!bad && sure && d_end != (int)(sa_w & 0xFFFFu)) bad = true;  // (the stop depth the search itself found)
       lds_sync();
       if (!bad) {
         const int stop0 = d_end, left_fuz = lmf - d_end, draws = 1 + len - d_end;
@@ -2091,16 +2130,30 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
           while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int)hop[mid].x >= d) lo = mid; else hi = mid; }
           return lo;
         };
-        // pass 1: the safe bits of this lane's stretch, from the top of the fill downwards
+        // pass 1: the safe bits of this lane's stretch, from the top of the fill downwards.  What a segment says about
+        // its states — where its part on a path to a sink ends, where the bit changes inside it, the two bits — is
+        // worked out when the stretch enters the segment, not per base (with it per base this pass was most of the
+        // 19 k cycles a guess cost a gap's wave)
         int lowest_safe = 0x7FFFFFFF;
         if (cnt > 0) {
           int h = hop_find(hi_d);
           uint2 hr = hop[h];
           int d0 = (int)hr.x - (int)(hr.y >> 16);
+          int h_ts = -1, h_split = 0;
+          bool h_a = true, h_b = true;
+          auto enter = [&]() {
+            if (!want_s) return;
+            const uint32_t b = hr.y & 0xFFFFu, st = s_t[b];
+            h_ts = dec15(st);
+            h_split = split_of(b, h_ts);
+            h_a = (st & 0x8000u) != 0u; h_b = (st & 0x80000000u) != 0u;
+          };
+          enter();
           for (int c = 0; c < cnt; c++) {
             const int p = hi_d - c;
-            if (p < d0) { h++; hr = hop[h]; d0 = (int)hr.x - (int)(hr.y >> 16); }
-            const bool sf = safe_of(hr.y & 0xFFFFu, p - d0);
+            if (p < d0) { h++; hr = hop[h]; d0 = (int)hr.x - (int)(hr.y >> 16); enter(); }
+            const int q = p - d0;
+            const bool sf = !want_s ? true : q > h_ts ? safe_of(hr.y & 0xFFFFu, q) : (q > h_split ? h_b : h_a);
             if (sf) lowest_safe = p;
             cb[p - 1] = sf ? 1u : 0u;
           }
@@ -2111,17 +2164,18 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
         above = __shfl_up(above, 1);
         if (lane == 0) above = 0x7FFFFFFF;
         int last_solid = min(above, len);
-        // pass 2: case, and the characters (the last base of the k-mer, by orientation) — eight loads in flight
+        // pass 2: case, and the characters (the last base of the k-mer, by orientation) — sixteen loads in flight: a lane's
+        // stretch of a 1 000-base fill in one round trip (with eight, the second round trip was a fifth of a guess's cost)
         if (cnt > 0) {
           int h = hop_find(hi_d);
           uint2 hr = hop[h];
           int d0 = (int)hr.x - (int)(hr.y >> 16);
           uint32_t v0 = s_node[hr.y & 0xFFFFu];
-          for (int c0 = 0; c0 < cnt; c0 += 8) {
-            uint32_t xs[8];
-            bool lowc[8];
+          for (int c0 = 0; c0 < cnt; c0 += 16) {
+            uint32_t xs[16];
+            bool lowc[16];
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
+            for (int u = 0; u < 16; u++) {
               const int c = c0 + u;
               xs[u] = 0u; lowc[u] = false;
               if (c < cnt) {
@@ -2134,11 +2188,11 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
                 else lowc[u] = p <= last_solid - k;
               }
             }
-            char ch[8];
+            char ch[16];
 #pragma unroll
-            for (int u = 0; u < 8; u++) ch[u] = (c0 + u < cnt) ? ((xs[u] >> 31) ? A.tr_chd[xs[u] & 0x7FFFFFFFu] : A.tr_chu[xs[u]]) : (char)0;
+            for (int u = 0; u < 16; u++) ch[u] = (c0 + u < cnt) ? ((xs[u] >> 31) ? A.tr_chd[xs[u] & 0x7FFFFFFFu] : A.tr_chu[xs[u]]) : (char)0;
 #pragma unroll
-            for (int u = 0; u < 8; u++)
+            for (int u = 0; u < 16; u++)
               if (c0 + u < cnt) cb[hi_d - (c0 + u) - 1] = (unsigned char)(lowc[u] ? (ch[u] | 0x20) : ch[u]);
           }
         }
@@ -2148,6 +2202,10 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
         char* buf = A.tr_arena + abs_off;
         for (int p = stop0 + lane; p < len; p += 64) buf[p] = (char)cb[p];
         if (lane == 0) buf[len] = '\0';
+        if (!sure) {  // (the guess, where the trace kernel can compare with it)
+          char* sbuf = A.tr_spec_text + abs_off;
+          for (int p = stop0 + lane; p < len; p += 64) sbuf[p] = (char)cb[p];
+        }
         const uint64_t fo = abs_off + (uint64_t)stop0;
         const uint32_t rflags = ((flags & (G2S_DEV_Q7_A | G2S_DEV_Q7_B | G2S_DEV_Q7_D)) ? G2S_GAP_Q7 : 0u) | G2S_GAP_PHASE_D;
         const uint32_t cnt_out = (uint32_t)((want_s && gd.all_paths) ? count_s : c_count);
@@ -2170,9 +2228,13 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
           default: break;
         }
         if (lane < 28) A.tr_results[(size_t)gi * 28u + (uint32_t)lane] = w;
+        if (!sure && lane < 28) A.tr_spec_res[(size_t)gi * 28u + (uint32_t)lane] = w;
         if (lane == 0) {
-          go->top_level = (uint32_t)(len - stop0);  // (the trace kernel's wave adds it to the list's fill bytes)
-          go->dflags |= G2S_DEVA_TRACED;
+          go->top_level = (uint32_t)stop0 | ((uint32_t)len << 16);  // (where the text written here begins and ends)
+          go->dflags |= sure ? G2S_DEVA_TRACED : G2S_DEVA_SPEC;
+          // (a guess: which chain of segments it followed — the trace kernel's wave that finds its own chain to be the same
+          // one has nothing to compare or send; the two diagnostic words of the record carry it)
+          if (!sure) { go->stat[6] = (uint32_t)chain_hash; go->stat[7] = (uint32_t)(chain_hash >> 32); }
         }
       }
     }
@@ -2260,7 +2322,7 @@ hipError_t launch_fill_seg(hipStream_t st, uint32_t ngaps, const uint32_t* succ,
                      (resident && inl) ? inl->text : nullptr, inl ? inl->nodes_dev : nullptr, inl ? inl->nodes_host : nullptr,
                      inl ? inl->text_stride : 0u, inl ? inl->lk : FlankLookup(),
                      (resident && tr) ? tr->results : nullptr, tr ? tr->arena : nullptr, tr ? tr->arena_base : 0ull, tr ? tr->chu : nullptr,
-                     tr ? tr->chd : nullptr, tr ? tr->max_states : 0ull, tr ? tr->k : 0};
+                     tr ? tr->chd : nullptr, tr ? tr->max_states : 0ull, tr ? tr->k : 0, tr ? tr->spec_text : nullptr, tr ? tr->spec_res : nullptr};
   if (two_waves) hipLaunchKernelGGL(g2s_fill_seg2, dim3(ngaps), dim3(128), bytes, st, A);
   else hipLaunchKernelGGL(g2s_fill_seg, dim3(ngaps), dim3(64), bytes, st, A);
   return hipGetLastError();

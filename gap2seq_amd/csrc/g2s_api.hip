@@ -574,6 +574,7 @@ struct g2s_session {
   // scratch; d_hops: where the trace kernel keeps the segments a traceback enters when the closure is too large for
   // its LDS (a traceback enters a segment once: as many entries as the closure has segments, at the closure's offset)
   DevBuf d_d2list, d_d2out, d_d2runs, d_d2scr_small, d_d2scr_big, d_hops;
+  bool spec_on = false;      // the last fill launch's waves left guessed tracebacks in d_textout / d_resout (G2S_DEVA_SPEC)
   bool d2_launched = false;  // the last fill launch had g2s_d2_* behind it
   bool d2_wait = false;      // ... and phase D3's hand-off waits for it (deep lists: their trace waves would keep its
                              // large instantiation off the compute units); else the trace waves of its gaps do
@@ -3115,7 +3116,19 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl, g2s_result* re
     tr.chu = (const char*)s->d_lastch.p; tr.chd = (const char*)s->d_lastch.p + g.n;
     tr.max_states = (uint64_t)std::max<int64_t>(s->params.max_mem, 1 << 16) / 64;
     tr.k = g.k;
+    // (tracebacks WITH choices as guesses, their text and records also in device memory for the trace kernel to compare
+    // with — G2S_TRACE_GUESS=0: only the tracebacks that have no choice to make)
+    // (lists that fill the chip only — one wave a gap: their trace kernel is the link's 8 MB; a short list's launch ends
+    // with its slowest gap, whose own guess would add its 15-20 us to the step for a trace kernel that is not link-bound:
+    // config 2 0.179 -> 0.194 ms with guesses.  G2S_TRACE_GUESS=1: short lists too.)
+    const bool guess = GENV("G2S_TRACE_GUESS") ? atoi(GENV("G2S_TRACE_GUESS")) != 0 : !two_waves;
+    if (guess) {
+      HIP_TRY_S(s->d_textout.ensure(b->arena_base + b->arena_bytes + 16));
+      HIP_TRY_S(s->d_resout.ensure(n * sizeof(g2s_result)));
+      tr.spec_text = (char*)s->d_textout.p; tr.spec_res = (uint32_t*)s->d_resout.p;
+    }
   }
+  s->spec_on = use_tr && tr.spec_text != nullptr;
   HIP_TRY_S(launch_fill_seg(st, (uint32_t)n_reg, dg.succ, dg.urec, nullptr, ids_fill, (const uint32_t*)s->d_flank.p,
                           (SubRec*)s->d_sub.p, (unsigned long long)out_states, (unsigned long long*)s->d_counter.p,
                           (GapOut*)s->d_outs.p, nullptr, nullptr, s->params.skip_confident ? 1 : 0, nullptr, two_waves,
@@ -3301,6 +3314,9 @@ static int resident_d3_launch(g2s_session* s, const ResidentList& L, bool timed,
   D3Work W;
   d3_work_carve(s->d_d3.p, (uint32_t)n, &W);
   W.link = sharded ? nullptr : (uint32_t*)s->d_link.p;
+  if (s->spec_on && !sharded && L.groups.size() == 1 && L.outs_dev == (const GapOut*)s->d_outs.p) {  // (this session's own fill launch left guesses)
+    W.spec_text = (const char*)s->d_textout.p; W.spec_res = (const uint32_t*)s->d_resout.p;
+  }
   if (s->d2_launched && L.outs_dev == (const GapOut*)s->d_outs.p) {  // (this session's own fill launch: g2s_d2_* ran behind it)
     W.d2out = (const D2Out*)s->d_d2out.p; W.d2runs = (const uint32_t*)s->d_d2runs.p; W.hops = (uint64_t*)s->d_hops.p;
   }
@@ -3637,8 +3653,12 @@ static int resident_d3_wait(g2s_session* s, g2s_timing* tm_out, double* ms_d3_ou
   if (!self_clean) HIP_TRY_S(hipMemsetAsync(W.sum, 0, 1024 + 64 * 128, st));
   s->d_d3.clean = 1024 + 64 * 128;
   s->self_cleaned = self_clean && hsum->status == 0;  // (a list the kernels gave up on: its waves left early)
-  for (int q = 0; q < 64; q++)  // (bits 40 and up count the trace kernel's waves: d3_device.hip)
+  uint64_t spec_groups = 0, spec_sent = 0;
+  for (int q = 0; q < 64; q++) {  // (bits 40 and up count the trace kernel's waves: d3_device.hip)
     hsum->fill_bytes += ((const unsigned long long*)((const char*)hsum + 1024))[q * 16] & ((1ull << 40) - 1);
+    const unsigned long long gw = ((const unsigned long long*)((const char*)hsum + 1024))[q * 16 + 1];  // (guessed gaps: groups compared | sent << 32)
+    spec_groups += gw & 0xFFFFFFFFull; spec_sent += gw >> 32;
+  }
   hsum->fill_bytes += host_fill_bytes;
   // (tests: the attempt is discarded — every one, or with "rel:K" only the K-th wait since that value was first seen)
   bool test_fallback = false;
@@ -3694,6 +3714,8 @@ static int resident_d3_wait(g2s_session* s, g2s_timing* tm_out, double* ms_d3_ou
   tm.draw_dependent_gaps += hsum->n_var;
   tm.host_finished_gaps += (uint32_t)hsum->host_items;
   tm.traced_in_fill_gaps += hsum->traced_gaps;
+  tm.guessed_in_fill_gaps += hsum->spec_gaps;
+  tm.guessed_groups += (uint32_t)spec_groups; tm.guessed_groups_resent += (uint32_t)spec_sent;
   tm.d3_table_entries += hsum->table_entries;
   const auto t_end = std::chrono::steady_clock::now();
   s->lap_d3_queued = t_launched; s->lap_handed = t_handed; s->lap_finished = t_finished; s->lap_synced = t_synced; s->lap_end = t_end;

@@ -239,6 +239,10 @@ struct SegArgs {
   const char* tr_chd;
   unsigned long long tr_max_states;  // -max-mem / 64: a gap beyond it gets the memory verdict (phase D3's)
   int tr_k;
+  // ... and a traceback WITH choices is written as a guess (first length, first parent), text and record also at the same
+  // offsets of these device buffers: GapOut.dflags |= G2S_DEVA_SPEC; the trace kernel sends what differs.  Null: no guesses.
+  char* tr_spec_text;
+  uint32_t* tr_spec_res;
 };
 
 // LDS of the large variant (words): see the layout notes at each phase

@@ -70,7 +70,8 @@ class g2s_timing(C.Structure):
                 ("host_finished_gaps", C.c_uint32), ("team_groups", C.c_uint32), ("team_sessions", C.c_uint32),
                 ("team_groups_by_session", C.c_uint32 * 16), ("seg_timed_launches", C.c_uint32), ("team_d3_sharded", C.c_uint32), ("traced_in_fill_gaps", C.c_uint32),
                 ("team_ms_fill", C.c_double * 16), ("team_ms_d3", C.c_double * 16), ("team_ms_wall", C.c_double * 16),
-                ("host_us", C.c_double * 8)]
+                ("host_us", C.c_double * 8), ("guessed_in_fill_gaps", C.c_uint32), ("guessed_groups", C.c_uint32),
+                ("guessed_groups_resent", C.c_uint32), ("reserved1", C.c_uint32)]
 
 
 class g2s_run_opts(C.Structure):

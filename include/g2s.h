@@ -237,6 +237,10 @@ typedef struct g2s_timing {
    * queued, [2] -> the device's hand-over seen (waiting), [3] -> the host-finished gaps done, [4] -> stream
    * synchronised, [5] -> return.  Zero when the list took another path. */
   double host_us[8];
+  /* (ABI 6) ... and whose fill kernel's wave wrote a GUESS of a traceback that has choices (first path length, first
+   * parent at every choice); of those gaps' text, in groups of 64 bases as the trace kernel's first waves compared them:
+   * all / sent through the link again because the real traceback differs there */
+  uint32_t guessed_in_fill_gaps, guessed_groups, guessed_groups_resent, reserved1;
 } g2s_timing;
 
 /* ---------------------------------------------------------------------------
