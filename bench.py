@@ -809,7 +809,7 @@ def main():
     # HBM bytes per launch of that kernel from the committed counter passes of this workload (rocprofv3 --pmc
     # FETCH_SIZE / WRITE_SIZE in passes of their own, gfx950 read-side correction: tools/pmc_summary.py)
     pmc = None
-    for rnd in ("r05", "r04", "r03"):  # (the latest round that holds counter passes of this workload)
+    for rnd in ("r06", "r05", "r04", "r03"):  # (the latest round that holds counter passes of this workload)
         pmc = os.path.join(ROOT, "profiles", "%s_pmc_%s.json" % (rnd, cfg_name.lower()))
         if os.path.exists(pmc):
             break
