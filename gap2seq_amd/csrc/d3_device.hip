@@ -1074,6 +1074,7 @@ __global__ __launch_bounds__(64 * NW) void g2s_d3_trace(const D3Params P, const 
         atomicMax(&laps[14], tk1 ? tk1 - tk0 : 0ull); atomicMax(&laps[15], tk2 ? tk2 - tk1 : 0ull);
         atomicMax(&laps[16], tk3 ? tk3 - tk2 : 0ull); atomicMax(&laps[17], ((tk4 - tk0) << 24) | ((td.gi & GI_HOST) ? 1ull << 23 : 0ull) | (unsigned long long)(i & 0x7FFFFFu)); atomicMax(&laps[18], tk4);
         atomicMax(&laps[19], ((tk2 ? tk2 - tk1 : 0ull) << 32) | (hops << 16) | (tkm ? tkm - tk1 : 0ull));
+        if ((P.laps >> 4) == i + 1u) { laps[26] = tk0; laps[27] = tk1; laps[28] = tkm; laps[29] = tk2; laps[30] = tk3; laps[31] = tk4; }  // (G2S_DEBUG_GAP: this gap's own)
       }
       const uint32_t c = i & 63u, n = gridDim.x;
       const unsigned long long before = atomicAdd(&W.fill_bytes[c * 16u], (unsigned long long)fill_len | (1ull << 40));
@@ -1090,11 +1091,27 @@ __global__ __launch_bounds__(64 * NW) void g2s_d3_trace(const D3Params P, const 
       for (uint32_t spin = 0; spin < (1u << 22) && __hip_atomic_load(P.d2_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned long long)P.d2_wgs; spin++)
         __builtin_amdgcn_s_sleep(8);
     uint32_t* src = (uint32_t*)S;
-    for (uint32_t w = (uint32_t)lane; w < (1024u + 64u * 128u) / 4u; w += 64u) {
-      summary_host[w] = __hip_atomic_load(src + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (P.self_clean) src[w] = 0u;
+    if (P.laps && lane == 0) laps[24] = wall_clock64();
+    // (what the host reads: the summary's 512 bytes, and of each of the 64 counters' lines its first two words — all
+    // loads first, then the stores: as a loop over the slot's 2 304 words, a load and a store an iteration, every store
+    // waited for the acknowledgement of the one before it over the link — 8-11 us at the end of every list's last kernel)
+    static_assert(sizeof(D3Summary) <= 512, "two words a lane");
+    const uint32_t s0 = __hip_atomic_load(src + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t s1 = __hip_atomic_load(src + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long* cl = (const unsigned long long*)(src + 256 + 32 * lane);  // (counter `lane`: a 128-byte line)
+    const unsigned long long c0 = __hip_atomic_load(cl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long c1 = __hip_atomic_load(cl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    summary_host[lane] = s0;
+    summary_host[64 + lane] = s1;
+    ((unsigned long long*)(summary_host + 256 + 32 * lane))[0] = c0;
+    ((unsigned long long*)(summary_host + 256 + 32 * lane))[1] = c1;
+    if (P.self_clean) {  // (nothing else of the slot is ever written: the lap stamps at byte 512 only without self_clean)
+      src[lane] = 0u; src[64 + lane] = 0u;
+      ((unsigned long long*)(src + 256 + 32 * lane))[0] = 0ull;
+      ((unsigned long long*)(src + 256 + 32 * lane))[1] = 0ull;
     }
     if (P.self_clean && clean_words && lane < 32) clean_words[lane] = 0u;  // (the fill kernels' and g2s_d2_*'s cursors: 16 counters)
+    if (P.laps && lane == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); laps[25] = wall_clock64(); }
   };
   if (status) { leave(0u); return; }  // (the records in front of this kernel were not written: nothing below may run)
   if (d2_lost) {
@@ -1319,16 +1336,33 @@ __global__ __launch_bounds__(64 * NW) void g2s_d3_trace(const D3Params P, const 
     const int hop_cap = (int)(big ? nsegs : min(nsegs, P.seg_cap));
     unsigned long long chain_hash = 14695981039346656037ull;
     if (!bad && !big) {
-      for (;;) {
-        if (nh >= hop_cap) { bad = true; break; }
-        if (P.laps) hops++;
-        last = uni(pk[si].y);
-        chain_hash = (chain_hash ^ (unsigned long long)(uint32_t)si) * 1099511628211ull;
-        if (lane == 0) hop[nh].y = (uint32_t)si;
-        nh++;
-        if (last & 0xC0000000u) break;
-        si = (int)(last & 0xFFFFu);
+      if (spec) {  // (a guessed gap: the chain's hash in the order of the walk)
+        for (;;) {
+          if (nh >= hop_cap) { bad = true; break; }
+          last = uni(pk[si].y);
+          chain_hash = (chain_hash ^ (unsigned long long)(uint32_t)si) * 1099511628211ull;
+          if (lane == 0) hop[nh].y = (uint32_t)si;
+          nh++;
+          if (last & 0xC0000000u) break;
+          si = (int)(last & 0xFFFFu);
+        }
+      } else {
+        // (the same chain with nothing in the step but the read it depends on: the segment entered at hop h stays in
+        // lane h & 63 and goes to LDS 64 hops at a time — with the hash and a masked store a step was 350 cycles, and
+        // the longest of a short list's walks, 38 segments, 6 of its trace wave's 20 us)
+        uint32_t hv = 0u;
+        for (;;) {
+          if (nh >= hop_cap) { bad = true; break; }
+          last = uni(pk[si].y);
+          hv = lane == (nh & 63) ? (uint32_t)si : hv;
+          nh++;
+          if ((nh & 63) == 0) hop[nh - 64 + lane].y = hv;
+          if (last & 0xC0000000u) break;
+          si = (int)(last & 0xFFFFu);
+        }
+        if (!bad && (nh & 63) != 0 && lane < (nh & 63)) hop[(nh & ~63) + lane].y = hv;
       }
+      if (P.laps) hops = (unsigned long long)nh;
       // (the fill kernel's wave guessed THIS chain, from this length: text, case, fuz values and draws are the guess's —
       // they are in the caller's buffers already)
       if (!bad && spec && pick == 0 && len == spec_len && (last & 0x40000000u) && chain_hash == spec_chain) {

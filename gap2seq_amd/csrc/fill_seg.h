@@ -49,6 +49,7 @@ struct SegTrace {
   int k = 0;
   char* spec_text = nullptr;     // device memory, the arena's size: guessed tracebacks (G2S_DEVA_SPEC), or null
   uint32_t* spec_res = nullptr;  // device memory, g2s_result[n]
+  uint32_t guess_until = 0;      // two waves per gap: how many gaps — in the order their searches end — may guess (0: all)
 };
 
 // (tools, G2S_D2_LOG) where in d2_list the fill kernels note when a gap's closure was listed; 0: nowhere

@@ -244,6 +244,8 @@ __device__ __forceinline__ bool seg_q7_between(const uint32_t* s_node, const uin
 // TWO (with BIG = false): the workgroup has two waves — wave 1 runs phase A while wave 0 runs the part of
 // phase B that does not look at the right set yet (:1050 first consults it at depth g/2 + e/2 + lmf), so
 // that phase A leaves the critical path of the slowest gaps; they meet at one barrier.
+#define G2S_GUESS_LATE_CYCLES 100000u /* two waves per gap: a search that ends later than this leaves its traceback to the trace kernel */
+
 template <bool BIG, bool TWO>
 __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, const uint32_t x /* position in the launch */,
                                              uint32_t* scr) {
@@ -1490,6 +1492,15 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
   lds_sync();
   const unsigned long long cyc2 = __builtin_amdgcn_s_memtime();
   SEG_PROF_TAIL(0);
+  // (two waves per gap — a short list, whose launch lasts as long as its slowest gap: a guessed traceback at the end
+  // of this wave — 20-40 k cycles — is worth its while only under the searches still running.  The gaps count themselves
+  // as their searches end, here, where the answer has the whole tail to arrive; a search that took longer than most
+  // searches take altogether does not ask: it is one of those the launch waits for.)
+  uint32_t guess_order = 0xFFFFFFFFu;
+  if constexpr (TWO) {
+    if (A.tr_spec_text != nullptr && A.tr_guess_until != 0u && !overflow && cyc2 - cyc0 < (unsigned long long)G2S_GUESS_LATE_CYCLES && lane == 0)
+      guess_order = (uint32_t)atomicAdd(out_counter + 12, 1ull);
+  }
 
   // ---------------- Q7: an upward and a downward segment of one unitig meeting on a k-mer ------
   // All pairs (every downward segment against every upward one) cost the slowest gaps of a 10 000-gap list a third
@@ -2023,7 +2034,11 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
     // two.  Phase D3's trace kernel still traces such a gap for real, compares 64 bases at a time with what was guessed,
     // and sends through the link only what differs: G2S_DEVA_SPEC.)
     const bool sure = !choice && n_len == 1 && (sa_w & 0xFFFFu) == (sa_w >> 16);
-    if (A.tr_results != nullptr && (analysed || !want_s) && (sure || A.tr_spec_text != nullptr) && start_b0 != SEG_NOPAR && no_over &&
+    bool may_guess = A.tr_spec_text != nullptr;
+    if constexpr (TWO) {
+      if (may_guess && A.tr_guess_until != 0u) may_guess = uni(guess_order) < A.tr_guess_until;  // (asked at the head of the tail)
+    }
+    if (A.tr_results != nullptr && (analysed || !want_s) && (sure || may_guess) && start_b0 != SEG_NOPAR && no_over &&
         gd.rlog_cap == 0u /* no skip rule on this gap */ && len0 >= 1 && len0 <= 4096 && nrec <= 256u) {
       const int len = len0, k = A.tr_k;
       uint2* hop = (uint2*)s_cnt;           // by hop: the depth at which it is entered | the segment | entry state << 16
@@ -2322,7 +2337,8 @@ hipError_t launch_fill_seg(hipStream_t st, uint32_t ngaps, const uint32_t* succ,
                      (resident && inl) ? inl->text : nullptr, inl ? inl->nodes_dev : nullptr, inl ? inl->nodes_host : nullptr,
                      inl ? inl->text_stride : 0u, inl ? inl->lk : FlankLookup(),
                      (resident && tr) ? tr->results : nullptr, tr ? tr->arena : nullptr, tr ? tr->arena_base : 0ull, tr ? tr->chu : nullptr,
-                     tr ? tr->chd : nullptr, tr ? tr->max_states : 0ull, tr ? tr->k : 0, tr ? tr->spec_text : nullptr, tr ? tr->spec_res : nullptr};
+                     tr ? tr->chd : nullptr, tr ? tr->max_states : 0ull, tr ? tr->k : 0, tr ? tr->spec_text : nullptr, tr ? tr->spec_res : nullptr,
+                     (tr && two_waves) ? tr->guess_until : 0u};
   if (two_waves) hipLaunchKernelGGL(g2s_fill_seg2, dim3(ngaps), dim3(128), bytes, st, A);
   else hipLaunchKernelGGL(g2s_fill_seg, dim3(ngaps), dim3(64), bytes, st, A);
   return hipGetLastError();

@@ -3121,8 +3121,15 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl, g2s_result* re
     // (lists that fill the chip only — one wave a gap: their trace kernel is the link's 8 MB; a short list's launch ends
     // with its slowest gap, whose own guess would add its 15-20 us to the step for a trace kernel that is not link-bound:
     // config 2 0.179 -> 0.194 ms with guesses.  G2S_TRACE_GUESS=1: short lists too.)
-    const bool guess = GENV("G2S_TRACE_GUESS") ? atoi(GENV("G2S_TRACE_GUESS")) != 0 : !two_waves;
+    // Round 6, later: short lists guess too, but only the gaps whose searches end while most others still run — the
+    // first seven in eight (G2S_GUESS_PERCENT) in the order they end: the trace kernel then has a fifth of the text left to
+    // send.)
+    const bool guess = GENV("G2S_TRACE_GUESS") ? atoi(GENV("G2S_TRACE_GUESS")) != 0 : true;
     if (guess) {
+      if (two_waves && !GENV("G2S_TRACE_GUESS")) {
+        const int pct = GENV("G2S_GUESS_PERCENT") ? std::min(100, std::max(1, atoi(GENV("G2S_GUESS_PERCENT")))) : 87;
+        tr.guess_until = pct >= 100 ? 0u : (uint32_t)std::max<size_t>(1, n_reg * (size_t)pct / 100);
+      }
       HIP_TRY_S(s->d_textout.ensure(b->arena_base + b->arena_bytes + 16));
       HIP_TRY_S(s->d_resout.ensure(n * sizeof(g2s_result)));
       tr.spec_text = (char*)s->d_textout.p; tr.spec_res = (uint32_t*)s->d_resout.p;
@@ -3377,7 +3384,7 @@ static int resident_d3_launch(g2s_session* s, const ResidentList& L, bool timed,
   P.arena_base = 0;
   P.group_size = (uint32_t)std::max<size_t>(L.group_size, 1);
   P.sub_region = L.sub_region;
-  P.laps = GENV("G2S_DEBUG") ? 1u : 0u;
+  P.laps = GENV("G2S_DEBUG") ? (1u | (GENV("G2S_DEBUG_GAP") ? ((uint32_t)atoi(GENV("G2S_DEBUG_GAP")) + 1u) << 4 : 0u)) : 0u;
   // (one batch on this session: the kernels read this session's own records and cursors, and clean up behind
   // themselves; not while the lap stamps are wanted — they live in the summary's slot)
   const bool self_clean = L.groups.size() == 1 && L.outs_dev == (const GapOut*)s->d_outs.p && !P.laps && !sharded;
@@ -3639,7 +3646,7 @@ static int resident_d3_wait(g2s_session* s, g2s_timing* tm_out, double* ms_d3_ou
   if (timed) HIP_TRY_S(hipEventElapsedTime(&ms_d3, d3_begin, s->ev[3]));
   *ms_d3_out = ms_d3;
   if (GENV("G2S_DEBUG")) {  // the kernels' lap stamps (d3_device.hip: stamp), 100 MHz
-    unsigned long long lp[24];
+    unsigned long long lp[32];
     HIP_TRY_S(hipMemcpy(lp, (char*)W.sum + 512, sizeof lp, hipMemcpyDeviceToHost));
     auto us = [&](int a, int b) { return lp[a] && lp[b] ? ((double)lp[b] - (double)lp[a]) / 100.0 : -1.0; };
     fprintf(stderr, "[g2s] phase D3 laps (us): front classify %.1f scan %.1f | to tables %.1f: status %.1f records %.1f closure %.1f walks %.1f | to back %.1f: tables into LDS %.1f chain %.1f hand-off %.1f fence %.1f | to trace %.1f, longest wave: to closure %.1f walk %.1f bases %.1f all %.1f, first entry to last end %.1f\n",
@@ -3647,6 +3654,10 @@ static int resident_d3_wait(g2s_session* s, g2s_timing* tm_out, double* ms_d3_ou
             lp[14] / 100.0, lp[15] / 100.0, lp[16] / 100.0, (double)(lp[17] >> 24) / 100.0, us(13, 18));
     fprintf(stderr, "[g2s] the longest wave of the trace kernel: gap %llu%s\n", lp[17] & 0x7FFFFFull, (lp[17] >> 23) & 1ull ? " (handed to the host)" : "");
     fprintf(stderr, "[g2s] scan (us): sums %.1f, base + layout pass %.1f, table offsets + records %.1f\n", us(20, 21), us(21, 22), us(22, 23));
+    fprintf(stderr, "[g2s] the last wave of the trace kernel: the summary's copy to the host begins %.1f us after the kernel's first entry and takes %.1f us\n", us(13, 24), us(24, 25));
+    if (GENV("G2S_DEBUG_GAP") && lp[26])
+      fprintf(stderr, "[g2s] gap %s in the trace kernel (us): enters %.1f behind the kernel's first wave | to closure in LDS %.1f | chain %.1f | bases classified %.1f | text %.1f | record %.1f\n",
+              GENV("G2S_DEBUG_GAP"), us(13, 26), us(26, 27), us(27, 28), us(28, 29), us(29, 30), us(30, 31));
     fprintf(stderr, "[g2s] the wave with the longest walk: %.1f us, %llu segments entered in %.1f us\n", (double)(lp[19] >> 32) / 100.0, (lp[19] >> 16) & 0xFFFF, (double)(lp[19] & 0xFFFF) / 100.0);
   }
   // (the summary is zero again for the next list: the trace kernel did it, or a memset now, off the critical path)

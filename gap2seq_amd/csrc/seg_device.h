@@ -243,6 +243,9 @@ struct SegArgs {
   // offsets of these device buffers: GapOut.dflags |= G2S_DEVA_SPEC; the trace kernel sends what differs.  Null: no guesses.
   char* tr_spec_text;
   uint32_t* tr_spec_res;
+  // (two waves per gap — short lists, whose launch ends with its slowest gap) not 0: only the first tr_guess_until gaps
+  // to end their search write a guess; the gaps the launch waits for do not add their guess's cycles to it
+  uint32_t tr_guess_until;
 };
 
 // LDS of the large variant (words): see the layout notes at each phase
