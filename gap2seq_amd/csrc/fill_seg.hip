@@ -244,7 +244,9 @@ __device__ __forceinline__ bool seg_q7_between(const uint32_t* s_node, const uin
 // TWO (with BIG = false): the workgroup has two waves — wave 1 runs phase A while wave 0 runs the part of
 // phase B that does not look at the right set yet (:1050 first consults it at depth g/2 + e/2 + lmf), so
 // that phase A leaves the critical path of the slowest gaps; they meet at one barrier.
+#ifndef G2S_GUESS_LATE_CYCLES
 #define G2S_GUESS_LATE_CYCLES 100000u /* two waves per gap: a search that ends later than this leaves its traceback to the trace kernel */
+#endif
 
 template <bool BIG, bool TWO>
 __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, const uint32_t x /* position in the launch */,
@@ -1051,6 +1053,11 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
         if ((ev >> lane) & 1ull) { en = sd; ed = lane; ec = 1; ep01 = ep23 = 0xFFFFFFFFu; es = 0u; est = (uint32_t)lane | ((uint32_t)lane << 16); }
       }
     }
+    // (two waves: the rounds in two stretches — up to the round that first needs the right set, and from there on — so
+    // that the 21 registers it lives in change between two loops, not inside one: with take_right_set() in the loop the
+    // compiler copied them at the head and at the end of EVERY round, 40-odd moves of a round's ~800 instructions)
+    for (int stretch = 0; stretch < (TWO ? 2 : 1); stretch++) {
+    bool want_rs = false;
     while (ev && !overflow) {
       SEG_PROF_T(0);
       if (((ev >> lane) & 1ull) && es == 0u) {  // one round trip for all events created last round
@@ -1071,10 +1078,8 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
       uint32_t elen = lcap;
       const uint32_t esid = nseg + (uint32_t)__popcll(sel & below(lane));
       if constexpr (TWO) {  // a state or a child at or beyond the depth the pruning rule starts at: the right set now
-        if (!have_rs && (sel & __ballot(ed + (int)lcap >= gd.prune_from))) {
-          take_right_set();
-          if (overflow) break;
-        }
+        // (nothing of this round has been written yet: it starts again behind the barrier)
+        if (!have_rs && (sel & __ballot(ed + (int)lcap >= gd.prune_from))) { want_rs = true; break; }
       }
       SEG_PROF_T(2);
       // ---- their lengths under the pruning rule, their target hits (one segment at a time, wave-uniform)
@@ -1128,6 +1133,9 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
       SEG_PROF_T(4);
       SEG_PROF_ACC();
       gen++;
+    }
+    if (!want_rs) break;
+    take_right_set();
     }
     // ---- phase C's hits (:1107-1159): target k-mer j at position t of a segment is a hit at depth + t.  Behind the
     // search, lane = segment and a loop over the <= 32 targets: inside the rounds the same look — one selected event
