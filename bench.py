@@ -496,7 +496,7 @@ def main():
         os.environ["G2S_KERNEL_TIMING"] = "all"
     if steps < 100 and "G2S_KERNEL_TIMING" not in os.environ:
         # (at least three bracketed launches inside the timed steps, however few those are)
-        os.environ["G2S_KERNEL_TIMING"] = "sample:%d" % max(1, min(8, steps // 3))
+        os.environ["G2S_KERNEL_TIMING"] = "sample:%d" % max(1, min(8, (steps + 2) // 3))
 
     # ---- workload (untimed) -------------------------------------------------------
     t0 = time.time()
@@ -543,11 +543,20 @@ def main():
                lds_launches=0, seg_launches=0, segx_launches=0, seg_timed=0, d3_timed_steps=0)
     in_call = 0.0
     host_us = [0.0] * 6
+    # (inside the timed steps only the call and a copy of its timing record — 0.3 us; the sums over the records are
+    # taken behind the loop: two dozen attribute reads per step were 4-5 us of Python between two 170 us calls)
+    snaps = (P.g2s_timing * steps)()
+    tm_bytes = C.sizeof(P.g2s_timing)
+    step_s = [0.0] * steps
     barrier()
     t_begin = time.perf_counter()
-    for _ in range(steps):
-        in_call += run.step()
-        tm = run.timing()
+    for i in range(steps):
+        step_s[i] = run.step()
+        C.memmove(C.byref(snaps[i]), C.byref(run.timing()), tm_bytes)
+    elapsed = time.perf_counter() - t_begin
+    barrier()
+    in_call = sum(step_s)
+    for tm in snaps:
         for key in ("ms_right_bfs", "ms_left_dp", "ms_extract", "ms_fill_lds", "ms_extract_lds", "ms_d2h",
                     "ms_host_post", "ms_prepare", "ms_total", "ms_fill_seg", "ms_fill_segx", "ms_d3"):
             acc[key] += getattr(tm, key)
@@ -559,8 +568,6 @@ def main():
         acc["segx_launches"] += tm.segx_launches
         for q in range(6):
             host_us[q] += tm.host_us[q]
-    elapsed = time.perf_counter() - t_begin
-    barrier()
     elapsed, units = shard.reduce_timing(elapsed, float(len(gaps) * steps), dist)
 
     tm = run.timing()
@@ -885,6 +892,8 @@ def main():
                                             "of": "the last timed step"} if len(sessions) > 1 else None,
                      "buffers": "pageable" if args.pageable_buffers else "page-locked (g2s_host_alloc)"},
         "breakdown_ms_per_step": {"wall_inside_the_abi_call": round(in_call / steps * 1e3, 4),
+                                  "wall_inside_the_abi_call_min_median_max": [round(x * 1e3, 4) for x in (min(step_s), sorted(step_s)[len(step_s) // 2], max(step_s))],
+                                  "wall_inside_the_abi_call_each": [round(x * 1e3, 4) for x in step_s] if steps <= 40 else None,
                                   "prepare_flank_lookup_and_upload": per_step("ms_prepare"),
                                   "fill_seg_kernel": round(acc["ms_fill_seg"] / max(1, acc["seg_timed"]) * acc["seg_launches"] / steps, 4),
                                   "fill_segx_kernel": per_step("ms_fill_segx"),
