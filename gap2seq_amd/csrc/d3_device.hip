@@ -726,6 +726,11 @@ __global__ __launch_bounds__(256) void g2s_d3_tables(const D3Params P, const D3W
   }
   if (bad_any) atomicAdd(&W.sum->anomalies, 1u);
   if (st0) stamp(W, 7);
+  if (P.laps && tid == 0) {  // (G2S_DEBUG: the first workgroup's entry and the last workgroup's end, any workgroup with a tile)
+    unsigned long long* laps = (unsigned long long*)((char*)W.sum + 512);
+    if (blockIdx.x < tiles) atomicMax(&laps[32], wall_clock64());
+    atomicMax(&laps[33], wall_clock64());
+  }
 }
 
 // deviation behind block b for every deviation in front of it

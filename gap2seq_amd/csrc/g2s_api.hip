@@ -3646,7 +3646,7 @@ static int resident_d3_wait(g2s_session* s, g2s_timing* tm_out, double* ms_d3_ou
   if (timed) HIP_TRY_S(hipEventElapsedTime(&ms_d3, d3_begin, s->ev[3]));
   *ms_d3_out = ms_d3;
   if (GENV("G2S_DEBUG")) {  // the kernels' lap stamps (d3_device.hip: stamp), 100 MHz
-    unsigned long long lp[32];
+    unsigned long long lp[34];
     HIP_TRY_S(hipMemcpy(lp, (char*)W.sum + 512, sizeof lp, hipMemcpyDeviceToHost));
     auto us = [&](int a, int b) { return lp[a] && lp[b] ? ((double)lp[b] - (double)lp[a]) / 100.0 : -1.0; };
     fprintf(stderr, "[g2s] phase D3 laps (us): front classify %.1f scan %.1f | to tables %.1f: status %.1f records %.1f closure %.1f walks %.1f | to back %.1f: tables into LDS %.1f chain %.1f hand-off %.1f fence %.1f | to trace %.1f, longest wave: to closure %.1f walk %.1f bases %.1f all %.1f, first entry to last end %.1f\n",
@@ -3658,6 +3658,7 @@ static int resident_d3_wait(g2s_session* s, g2s_timing* tm_out, double* ms_d3_ou
     if (GENV("G2S_DEBUG_GAP") && lp[26])
       fprintf(stderr, "[g2s] gap %s in the trace kernel (us): enters %.1f behind the kernel's first wave | to closure in LDS %.1f | chain %.1f | bases classified %.1f | text %.1f | record %.1f\n",
               GENV("G2S_DEBUG_GAP"), us(13, 26), us(26, 27), us(27, 28), us(28, 29), us(29, 30), us(30, 31));
+    fprintf(stderr, "[g2s] g2s_d3_tables: the last workgroup with a tile ends %.1f us after the first workgroup's entry, the last workgroup of all %.1f us\n", us(3, 32), us(3, 33));
     fprintf(stderr, "[g2s] the wave with the longest walk: %.1f us, %llu segments entered in %.1f us\n", (double)(lp[19] >> 32) / 100.0, (lp[19] >> 16) & 0xFFFF, (double)(lp[19] & 0xFFFF) / 100.0);
   }
   // (the summary is zero again for the next list: the trace kernel did it, or a memset now, off the critical path)
