@@ -9,6 +9,11 @@ rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 timeout 600 python bench.py > $O/bench.json 2> $O/bench.err < /dev/null
 python tools/bsum.py C2-full < $O/bench.json
+# the driver's own command line, three times (20 timed steps: a noisier line than the default 200)
+for r in 1 2 3; do timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 < /dev/null | tee -a $O/driver_style.jsonl | python tools/bsum.py driver-style; done
+# the slowest gaps of the two lists in the regular tier's kernel (the kernel's own clock reads)
+timeout 300 python tools/slow_gaps.py C2 12 > $O/slowest_gaps_c2.txt 2>&1; head -3 $O/slowest_gaps_c2.txt | cut -c1-200
+timeout 300 python tools/slow_gaps.py C3 25 > $O/slowest_gaps_c3.txt 2>&1; head -3 $O/slowest_gaps_c3.txt | cut -c1-200
 SQ1="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS"
 SQ2="SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU"
 for C in C2 C3 C5; do
