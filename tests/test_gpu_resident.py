@@ -687,6 +687,38 @@ def test_single_path_gaps_traced_by_the_fill_kernel(product, monkeypatch, varian
     assert tb.fill_bytes == ta.fill_bytes
 
 
+@pytest.mark.parametrize("variant,n", [(3, 600), (2, 1500), (3, 2048)])
+def test_short_lists_guess_the_tracebacks_of_their_early_gaps(product, monkeypatch, variant, n):
+    """Round 6: on a short list (two waves per gap: the launch lasts as long as its slowest gap) a traceback WITH choices
+    is guessed by its fill wave — first length, first parent — only when the gap's search ends early: among the first
+    87 % of the list in the order the searches end (G2S_GUESS_PERCENT) and within 100 k cycles; the trace kernel sends
+    what differs.  Which gaps guess depends on the waves' timing, the results must not: against the same list with
+    guesses off, with every gap guessing and with a third of them, three calls each, field by field and in the
+    position the rand() stream is left at."""
+    reads = product.G2S.synth_genome(300000, variant, 20240101)
+    seqs = [ln for ln in reads.splitlines() if not ln.startswith(">")]
+    gaps = _parse_scaffolds(product.G2S.synth_gaps(reads, 31, 10, n, 100, 900, 20240103))
+    monkeypatch.setenv("G2S_TRACE_GUESS", "0")
+    a1, a2, ta, _ = _run(product, monkeypatch, True, seqs, 31, gaps, 500, pinned=True)
+    assert ta.resident_launches == 1 and ta.guessed_in_fill_gaps == 0
+    monkeypatch.delenv("G2S_TRACE_GUESS")
+    guessed = {}
+    for pct in ("", "100", "33"):
+        if pct:
+            monkeypatch.setenv("G2S_GUESS_PERCENT", pct)
+        for rep in range(3):
+            b1, b2, tb, _ = _run(product, monkeypatch, True, seqs, 31, gaps, 500, pinned=True)
+            assert tb.resident_launches == 1 and tb.resident_fallbacks == 0
+            assert b1 == a1 and b2 == a2, "guesses (G2S_GUESS_PERCENT=%s, call %d) changed a result" % (pct or "default", rep)
+            assert tb.fill_bytes == ta.fill_bytes
+            guessed[pct] = tb.guessed_in_fill_gaps
+            assert tb.guessed_groups >= tb.guessed_groups_resent
+    monkeypatch.delenv("G2S_GUESS_PERCENT")
+    assert 0 < guessed[""] <= len(gaps) * 87 // 100 + 1
+    assert guessed["33"] <= len(gaps) * 33 // 100 + 1
+    assert guessed["100"] >= guessed["33"]
+
+
 # ---- round 6: one list over several PROCESSES, a GPU and a share each (g2s_share_*, gap2seq_amd/shard.py) -----------
 class _ThreadComm:
     """shard.fill_share's communicator over the threads of one process (a barrier and a shared table)."""
