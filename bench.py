@@ -603,12 +603,13 @@ def main():
         n3, t3, k3, timed3 = 10, 0.0, 0.0, 0
         keep_mode = os.environ.get("G2S_KERNEL_TIMING")
         os.environ["G2S_KERNEL_TIMING"] = "sample:4"  # (ten steps: three launches bracketed with HIP events, ~10 us each)
-        step_ms3 = []
+        step_ms3, hus3 = [], []
         for _ in range(n3):
             dt3 = r3.step()
             step_ms3.append(round(dt3 * 1e3, 3))
             t3 += dt3
             t = r3.timing()
+            hus3.append([round(t.host_us[q], 1) for q in range(6)])
             k3 += t.ms_fill_seg if t.seg_tier_gaps else t.ms_fill_lds
             timed3 += t.seg_timed_launches if t.seg_tier_gaps else t.lds_launches
         if keep_mode is None:
@@ -622,6 +623,8 @@ def main():
         ab3 = algorithmic_bytes(x3, s3, tm3.flank_bytes + tm3.fill_bytes) / nl3 if x3 is not None else None
         c3_beside = dict(workload=CONFIGS["C3"][6], value=round(10000 * n3 / t3, 2), unit="gaps/s", steps=n3,
                          ms_per_step=round(t3 / n3 * 1e3, 4), step_ms=step_ms3,
+                         value_of_the_median_step=round(10000 / (sorted(step_ms3)[len(step_ms3) // 2] * 1e-3), 2),
+                         slowest_step_host_us_inside_the_call=dict(zip(("entry_to_fill_kernel_queued", "to_phase_d3_queued", "to_hand_over_seen", "to_host_finished_gaps_done", "to_stream_synchronised", "to_return"), hus3[step_ms3.index(max(step_ms3))])),
                          kernel=("g2s_fill_seg2" if tm3.seg2_launches else "g2s_fill_seg") if tm3.seg_tier_gaps else "g2s_fill_lds",
                          kernel_ms_per_launch=round(kms3, 4), kernel_launches_timed="%d of %d" % (timed3, n3 * nl3), gaps_left_to_other_kernels=10000 - max(tm3.seg_tier_gaps, tm3.lds_tier_gaps),
                          launches_per_step=nl3, algorithmic_bytes_per_launch=ab3, expansions=x3, states=s3,
