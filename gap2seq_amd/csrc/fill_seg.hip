@@ -244,6 +244,9 @@ __device__ __forceinline__ bool seg_q7_between(const uint32_t* s_node, const uin
 // TWO (with BIG = false): the workgroup has two waves — wave 1 runs phase A while wave 0 runs the part of
 // phase B that does not look at the right set yet (:1050 first consults it at depth g/2 + e/2 + lmf), so
 // that phase A leaves the critical path of the slowest gaps; they meet at one barrier.
+#ifndef G2S_GUESS_LATE_CYCLES_LONG
+#define G2S_GUESS_LATE_CYCLES_LONG 200000u /* one wave per gap: the same for the gaps a chip-filling list's launch ends with */
+#endif
 #ifndef G2S_GUESS_LATE_CYCLES
 #define G2S_GUESS_LATE_CYCLES 100000u /* two waves per gap: a search that ends later than this leaves its traceback to the trace kernel */
 #endif
@@ -2045,6 +2048,11 @@ __device__ __forceinline__ void seg_fill_one(uint32_t* lds, const SegArgs& A, co
     bool may_guess = A.tr_spec_text != nullptr;
     if constexpr (TWO) {
       if (may_guess && A.tr_guess_until != 0u) may_guess = uni(guess_order) < A.tr_guess_until;  // (asked at the head of the tail)
+    } else {
+      // (a chip-filling list: its launch ends with its slowest gaps too — a few dozen of 10 000, whose searches took several
+      // times the mean: their guesses, 20-40 k cycles each, would be the launch's last; the trace kernel has them.
+      // Config 3: g2s_fill_seg 0.317 -> 0.313 ms)
+      if (may_guess && cyc2 - cyc0 > (unsigned long long)G2S_GUESS_LATE_CYCLES_LONG) may_guess = false;
     }
     if (A.tr_results != nullptr && (analysed || !want_s) && (sure || may_guess) && start_b0 != SEG_NOPAR && no_over &&
         gd.rlog_cap == 0u /* no skip rule on this gap */ && len0 >= 1 && len0 <= 4096 && nrec <= 256u) {
