@@ -209,6 +209,7 @@ hipError_t launch_d3(hipStream_t st, const D3Params& P, const D3Work& W, const G
                      bool summary_is_clean /* the summary and the counters are zero already */,
                      uint32_t* clean_words /* with P.self_clean: eight words the last wave zeroes (the fill kernel's cursors); may be null */,
                      hipEvent_t ev_chain = nullptr /* recorded behind the kernel that knows the list's draws (W.link is written) */,
-                     hipEvent_t ev_d2 = nullptr /* behind g2s_d2_* on its own stream: the hand-off waits for it (null: nothing to wait for) */);
+                     hipEvent_t ev_d2 = nullptr /* behind g2s_d2_* on its own stream: the hand-off waits for it (null: nothing to wait for) */,
+                     hipEvent_t ev_stop = nullptr /* the trace kernel's own stop time (hipExtLaunchKernelGGL): a timed list's last kernel */);
 
 }  // namespace g2s

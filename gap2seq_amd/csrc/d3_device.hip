@@ -40,6 +40,7 @@
 // attempt and runs the list through the host path (g2s_api.hip), which remains the authority.
 #include "sync_debug.h"
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cstdlib>
@@ -1700,7 +1701,7 @@ hipError_t launch_d3(hipStream_t st, const D3Params& P, const D3Work& W, const G
                      const D3Gap* dgaps, const SubRec* sub, const char* lastch_up, const char* lastch_dn,
                      const RandTables& rt, uint32_t* rnd_all, uint64_t rnd_capacity, void* results, char* arena,
                      const D3Side& side, void* summary_host, bool summary_is_clean, uint32_t* clean_words, hipEvent_t ev_chain,
-                     hipEvent_t ev_d2) {
+                     hipEvent_t ev_d2, hipEvent_t ev_stop) {
   if (P.n == 0) return hipSuccess;
   (void)gaps;
   (void)rt;
@@ -1740,6 +1741,15 @@ hipError_t launch_d3(hipStream_t st, const D3Params& P, const D3Work& W, const G
   const bool four = waves_env ? waves_env == 4 : P.n <= 768u;  // (2 000 gaps on four waves each: 1-2 % slower than on one)
   e = hipFuncSetAttribute(four ? (const void*)g2s_d3_trace<4> : (const void*)g2s_d3_trace<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
+  if (ev_stop != nullptr) {  // (a timed list: the dispatch's own stop time — an event recorded behind the kernel is a packet of its own)
+    if (four)
+      hipExtLaunchKernelGGL(g2s_d3_trace<4>, dim3(P.n), dim3(256), (uint32_t)lds, st, nullptr, ev_stop, 0u, P, W, const_cast<GapOut*>(outs), sub, lastch_up, lastch_dn,
+                            rnd_all + 31, rnd_capacity, (g2s_result*)results, arena, (uint32_t*)summary_host, side, clean_words);
+    else
+      hipExtLaunchKernelGGL(g2s_d3_trace<1>, dim3(P.n), dim3(64), (uint32_t)lds, st, nullptr, ev_stop, 0u, P, W, const_cast<GapOut*>(outs), sub, lastch_up, lastch_dn,
+                            rnd_all + 31, rnd_capacity, (g2s_result*)results, arena, (uint32_t*)summary_host, side, clean_words);
+    return hipGetLastError();
+  }
   if (four)
     hipLaunchKernelGGL(g2s_d3_trace<4>, dim3(P.n), dim3(256), lds, st, P, W, const_cast<GapOut*>(outs), sub, lastch_up, lastch_dn, rnd_all + 31, rnd_capacity,
                        (g2s_result*)results, arena, (uint32_t*)summary_host, side, clean_words);

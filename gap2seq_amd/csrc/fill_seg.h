@@ -87,7 +87,11 @@ hipError_t launch_fill_seg(hipStream_t st, uint32_t ngaps, const uint32_t* succ,
                            const SegTrace* tr = nullptr,
                            // (resident) the gaps' descriptors as GapLite records (fill_device.h) + the list's constants:
                            // `gaps` is not read then
-                           const GapLite* lite = nullptr, int lite_e = 0, int lite_all_paths = 0);
+                           const GapLite* lite = nullptr, int lite_e = 0, int lite_all_paths = 0,
+                           // the launch's own start and stop times into these HIP events (hipExtLaunchKernelGGL: no
+                           // packets of their own in front of and behind the kernel, as two hipEventRecord calls cost
+                           // the stream ~10 us a launch); null: not timed
+                           hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 
 // The large variant: `workgroups` persistent workgroups (one per compute unit) take the listed gaps
 // in order from the counter *next_gap (zero before the launch); scratch: fill_segx_scratch_bytes().

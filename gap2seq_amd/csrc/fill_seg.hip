@@ -57,6 +57,8 @@
 #include "fill_seg.h"
 #include "flank_device.h"
 
+#include <hip/hip_ext.h>
+
 #include "seg_device.h"
 
 
@@ -2324,7 +2326,7 @@ hipError_t launch_fill_seg(hipStream_t st, uint32_t ngaps, const uint32_t* succ,
                            uint32_t* done_list, int skip_confident, uint32_t* dbg, bool two_waves, unsigned long long* xcd_tickets,
                            uint32_t* xcd_list, uint32_t xcd_stride, uint32_t pub_batch, bool resident, uint32_t* ovf_list,
                            uint32_t* d2_list, uint32_t d2_tag, const SegInline* inl, const SegEarly* early, const SegTrace* tr,
-                           const GapLite* lite, int lite_e, int lite_all_paths) {
+                           const GapLite* lite, int lite_e, int lite_all_paths, hipEvent_t ev_start, hipEvent_t ev_stop) {
   if (ngaps == 0) return hipSuccess;
   size_t bytes = two_waves ? fill_seg2_lds_bytes() : fill_seg_lds_bytes();
   // (G2S_SEG_LDS_PAD=BYTES, measurements only: a larger LDS request per gap = fewer gaps resident per compute unit)
@@ -2355,6 +2357,11 @@ hipError_t launch_fill_seg(hipStream_t st, uint32_t ngaps, const uint32_t* succ,
                      (resident && tr) ? tr->results : nullptr, tr ? tr->arena : nullptr, tr ? tr->arena_base : 0ull, tr ? tr->chu : nullptr,
                      tr ? tr->chd : nullptr, tr ? tr->max_states : 0ull, tr ? tr->k : 0, tr ? tr->spec_text : nullptr, tr ? tr->spec_res : nullptr,
                      (tr && two_waves) ? tr->guess_until : 0u};
+  if (ev_start != nullptr || ev_stop != nullptr) {  // (a bracketed launch: the dispatch's own times in the two events)
+    if (two_waves) hipExtLaunchKernelGGL(g2s_fill_seg2, dim3(ngaps), dim3(128), (uint32_t)bytes, st, ev_start, ev_stop, 0u, A);
+    else hipExtLaunchKernelGGL(g2s_fill_seg, dim3(ngaps), dim3(64), (uint32_t)bytes, st, ev_start, ev_stop, 0u, A);
+    return hipGetLastError();
+  }
   if (two_waves) hipLaunchKernelGGL(g2s_fill_seg2, dim3(ngaps), dim3(128), bytes, st, A);
   else hipLaunchKernelGGL(g2s_fill_seg, dim3(ngaps), dim3(64), bytes, st, A);
   return hipGetLastError();

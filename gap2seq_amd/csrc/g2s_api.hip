@@ -3090,7 +3090,11 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl, g2s_result* re
   }
   lap(2);
   rl->timed = kernel_events_on(s);
-  if (rl->timed) HIP_TRY_S(hipEventRecord(s->ev[1], st));
+  // (a bracketed launch: the kernel's own start and stop times go into ev[1] / ev[2] with the dispatch — two
+  // hipEventRecord calls around it put packets of their own into the stream, ~10 us of such a step.  G2S_EVENT_RECORD=1:
+  // as until round 6.)
+  const bool ext_events = rl->timed && !GENV("G2S_EVENT_RECORD");
+  if (rl->timed && !ext_events) HIP_TRY_S(hipEventRecord(s->ev[1], st));
   // (the flank look-ups in this kernel's waves: every valid gap of such a list is in this launch — inline_ok excludes
   // the deep lists, whose longest gaps start in the large variant)
   SegInline inl;
@@ -3141,11 +3145,12 @@ static int resident_launch_fill(g2s_batch* b, ResidentLaunch* rl, g2s_result* re
                           (GapOut*)s->d_outs.p, nullptr, nullptr, s->params.skip_confident ? 1 : 0, nullptr, two_waves,
                           nullptr, nullptr, 0u, 1u, true, rerun ? (uint32_t*)s->d_ovf.p : nullptr,
                           dev_d2 ? (uint32_t*)s->d_d2list.p : nullptr, d2_tag, use_inl ? &inl : nullptr,
-                          early_reg ? &early_dev : nullptr, (use_tr && tr.chu) ? &tr : nullptr, gaps_dev, lite_e, lite_ap));
+                          early_reg ? &early_dev : nullptr, (use_tr && tr.chu) ? &tr : nullptr, gaps_dev, lite_e, lite_ap,
+                          ext_events ? s->ev[1] : nullptr, ext_events ? s->ev[2] : nullptr));
   if (use_inl) { b->inline_pending = false; b->nodes_dev_only = true; }  // (behind this kernel d_flank holds the ids; the pinned copy those of the host's gaps)
   s->lap_fill_queued = std::chrono::steady_clock::now();
   lap(3);
-  if (rl->timed) HIP_TRY_S(hipEventRecord(s->ev[2], st));
+  if (rl->timed && !ext_events) HIP_TRY_S(hipEventRecord(s->ev[2], st));
   // (queued BEHIND the regular tier's kernel, which takes the compute units first — a workgroup of the large variant
   // needs a whole unit's LDS and stays for the launch: started first, 256 of them leave the regular tier no unit until
   // the early list runs dry (4.4 instead of 3.65 ms, when the hardware happened to order them so); its workgroups
@@ -3401,9 +3406,10 @@ static int resident_d3_launch(g2s_session* s, const ResidentList& L, bool timed,
                     (uint64_t)rnd_cap, res_dev, (char*)arena_dev, side, (char*)d_dgaps + ((char*)hsum - (char*)L.pin->p),
                     s->d_d3.clean >= 1024 + 64 * 128, self_clean ? (uint32_t*)s->d_counter.p : nullptr,
                     no_spin ? s->ev_chain : nullptr /* (lists in flight: the next one's stream may wait for it) */,
-                    (W.d2out && s->d2_wait) ? s->ev_d2 : nullptr));
+                    (W.d2out && s->d2_wait) ? s->ev_d2 : nullptr,
+                    (timed && !GENV("G2S_EVENT_RECORD")) ? s->ev[3] : nullptr /* (the trace kernel's own stop time) */));
   s->d_d3.clean = 0;
-  if (timed && !sharded) HIP_TRY_S(hipEventRecord(s->ev[3], st));
+  if (timed && !sharded && GENV("G2S_EVENT_RECORD")) HIP_TRY_S(hipEventRecord(s->ev[3], st));
   if (stage_dev && !sharded) {
     HIP_TRY_S(hipMemcpyAsync(results, s->d_resout.p, n * sizeof(g2s_result), hipMemcpyDeviceToHost, st));
     HIP_TRY_S(hipMemcpyAsync(arena, s->d_textout.p, L.arena_bytes, hipMemcpyDeviceToHost, st));
